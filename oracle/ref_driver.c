@@ -1,0 +1,379 @@
+/* oracle/ref_driver.c - TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Plain-C entry points (ctypes-friendly: pointers, ints, doubles, C strings) around the REFERENCE's
+ * own library API, compiled together with the reference sources by oracle/ref_build.py into
+ * oracle/_ref/libgstref.so.  Every function here only marshals arguments into the reference's
+ * types and calls the reference:
+ *   gst_video_converter_new / _frame      (gst-libs/gst/video/video-converter.h:291-316)
+ *   BlendFunction / FillCheckerFunction   (gst/compositor/blend.h:50-52, blend.c:2024)
+ *   gst_audio_resampler_new / _resample   (gst-libs/gst/audio/audio-resampler.h:222-256)
+ */
+#include <gst/gst.h>
+#include <gst/video/video.h>
+#include <gst/audio/audio.h>
+#include <string.h>
+#include "blend.h"
+
+static gsize ref_inited = 0;
+
+int
+ref_init (void)
+{
+  if (g_once_init_enter (&ref_inited)) {
+    gst_init (NULL, NULL);
+    /* make the enum GTypes known to gst_structure_from_string() */
+    g_type_class_ref (gst_video_resampler_method_get_type ());
+    g_type_class_ref (gst_video_dither_method_get_type ());
+    g_type_class_ref (gst_video_chroma_method_get_type ());
+    g_type_class_ref (gst_video_alpha_mode_get_type ());
+    g_type_class_ref (gst_video_chroma_mode_get_type ());
+    g_type_class_ref (gst_video_matrix_mode_get_type ());
+    g_type_class_ref (gst_video_gamma_mode_get_type ());
+    g_type_class_ref (gst_video_primaries_mode_get_type ());
+    g_type_class_ref (gst_audio_resampler_filter_mode_get_type ());
+    g_type_class_ref (gst_audio_resampler_filter_interpolation_get_type ());
+    gst_compositor_init_blend ();
+    g_once_init_leave (&ref_inited, 1);
+  }
+  return 0;
+}
+
+/* Fill a GstVideoInfo.  colorimetry / chroma_site may be NULL or "" (keep the defaults that
+ * gst_video_info_set_format picks, video-info.c:155-225).  stride/offset may be NULL (defaults). */
+static gboolean
+make_info (GstVideoInfo * info, const char *format, int w, int h, const char *colorimetry,
+    const char *chroma_site, const int *stride, const gsize * offset)
+{
+  /* go through caps exactly as the elements do (gst_video_info_from_caps, video-info.c:452-600),
+   * so that absent colorimetry / chroma-site get the reference's negotiated defaults */
+  GstCaps *caps;
+  gboolean ok;
+  int i;
+  if (gst_video_format_from_string (format) == GST_VIDEO_FORMAT_UNKNOWN)
+    return FALSE;
+  caps = gst_caps_new_simple ("video/x-raw", "format", G_TYPE_STRING, format,
+      "width", G_TYPE_INT, w, "height", G_TYPE_INT, h, "framerate", GST_TYPE_FRACTION, 30, 1, NULL);
+  if (colorimetry && *colorimetry)
+    gst_caps_set_simple (caps, "colorimetry", G_TYPE_STRING, colorimetry, NULL);
+  if (chroma_site && *chroma_site)
+    gst_caps_set_simple (caps, "chroma-site", G_TYPE_STRING, chroma_site, NULL);
+  gst_video_info_init (info);
+  ok = gst_video_info_from_caps (info, caps);
+  gst_caps_unref (caps);
+  if (!ok)
+    return FALSE;
+  if (stride && offset) {
+    for (i = 0; i < (int) GST_VIDEO_INFO_N_PLANES (info); i++) {
+      info->stride[i] = stride[i];
+      info->offset[i] = offset[i];
+    }
+  }
+  return TRUE;
+}
+
+/* Query the default layout: returns n_planes, fills stride[4]/offset[4]/size; also reports the
+ * default colorimetry string and chroma-site the reference assigns. */
+int
+ref_video_info (const char *format, int w, int h, int *stride, gsize * offset, gsize * size,
+    char *colorimetry_out, int colorimetry_len, char *chroma_out, int chroma_len)
+{
+  GstVideoInfo info;
+  int i;
+  ref_init ();
+  if (!make_info (&info, format, w, h, NULL, NULL, NULL, NULL))
+    return -1;
+  for (i = 0; i < 4; i++) {
+    stride[i] = i < (int) GST_VIDEO_INFO_N_PLANES (&info) ? info.stride[i] : 0;
+    offset[i] = i < (int) GST_VIDEO_INFO_N_PLANES (&info) ? info.offset[i] : 0;
+  }
+  *size = info.size;
+  if (colorimetry_out) {
+    gchar *c = gst_video_colorimetry_to_string (&info.colorimetry);
+    g_strlcpy (colorimetry_out, c ? c : "", colorimetry_len);
+    g_free (c);
+  }
+  if (chroma_out) {
+    gchar *c = gst_video_chroma_site_to_string (info.chroma_site);
+    g_strlcpy (chroma_out, c ? c : "", chroma_len);
+    g_free (c);
+  }
+  return GST_VIDEO_INFO_N_PLANES (&info);
+}
+
+static GstBuffer *
+wrap_frame (GstVideoInfo * info, guint8 * data, gsize size, gboolean writable)
+{
+  GstBuffer *buf = gst_buffer_new_wrapped_full (writable ? 0 : GST_MEMORY_FLAG_READONLY,
+      data, size, 0, size, NULL, NULL);
+  gst_buffer_add_video_meta_full (buf, GST_VIDEO_FRAME_FLAG_NONE, GST_VIDEO_INFO_FORMAT (info),
+      GST_VIDEO_INFO_WIDTH (info), GST_VIDEO_INFO_HEIGHT (info), GST_VIDEO_INFO_N_PLANES (info),
+      info->offset, info->stride);
+  return buf;
+}
+
+typedef struct
+{
+  GstVideoInfo in_info, out_info;
+  GstVideoConverter *conv;
+} RefConverter;
+
+/* config: serialized GstStructure ("GstVideoConverter, GstVideoConverter.threads=(uint)1, ...")
+ * or NULL for the library defaults (video-converter.c:778-796). */
+void *
+ref_video_converter_new (const char *in_format, int in_w, int in_h, const char *in_colorimetry,
+    const char *in_chroma_site, const int *in_stride, const gsize * in_offset,
+    const char *out_format, int out_w, int out_h, const char *out_colorimetry,
+    const char *out_chroma_site, const int *out_stride, const gsize * out_offset,
+    const char *config)
+{
+  RefConverter *rc;
+  GstStructure *s = NULL;
+  ref_init ();
+  rc = g_new0 (RefConverter, 1);
+  if (!make_info (&rc->in_info, in_format, in_w, in_h, in_colorimetry, in_chroma_site, in_stride,
+          in_offset)
+      || !make_info (&rc->out_info, out_format, out_w, out_h, out_colorimetry, out_chroma_site,
+          out_stride, out_offset)) {
+    g_free (rc);
+    return NULL;
+  }
+  if (config && *config) {
+    s = gst_structure_from_string (config, NULL);
+    if (!s) {
+      g_free (rc);
+      return NULL;
+    }
+  }
+  rc->conv = gst_video_converter_new (&rc->in_info, &rc->out_info, s);
+  if (!rc->conv) {
+    g_free (rc);
+    return NULL;
+  }
+  return rc;
+}
+
+int
+ref_video_converter_frame (void *h, const guint8 * in_data, gsize in_size, guint8 * out_data,
+    gsize out_size)
+{
+  RefConverter *rc = h;
+  GstBuffer *ib = wrap_frame (&rc->in_info, (guint8 *) in_data, in_size, FALSE);
+  GstBuffer *ob = wrap_frame (&rc->out_info, out_data, out_size, TRUE);
+  GstVideoFrame inf, outf;
+  int ret = -1;
+  if (gst_video_frame_map (&inf, &rc->in_info, ib, GST_MAP_READ)) {
+    if (gst_video_frame_map (&outf, &rc->out_info, ob, GST_MAP_WRITE)) {
+      gst_video_converter_frame (rc->conv, &inf, &outf);
+      gst_video_frame_unmap (&outf);
+      ret = 0;
+    }
+    gst_video_frame_unmap (&inf);
+  }
+  gst_buffer_unref (ib);
+  gst_buffer_unref (ob);
+  return ret;
+}
+
+/* times n_frames back-to-back conversions of the same mapped frame; returns seconds */
+double
+ref_video_converter_bench (void *h, const guint8 * in_data, gsize in_size, guint8 * out_data,
+    gsize out_size, int n_frames)
+{
+  RefConverter *rc = h;
+  GstBuffer *ib = wrap_frame (&rc->in_info, (guint8 *) in_data, in_size, FALSE);
+  GstBuffer *ob = wrap_frame (&rc->out_info, out_data, out_size, TRUE);
+  GstVideoFrame inf, outf;
+  double secs = -1.0;
+  int i;
+  if (gst_video_frame_map (&inf, &rc->in_info, ib, GST_MAP_READ)) {
+    if (gst_video_frame_map (&outf, &rc->out_info, ob, GST_MAP_WRITE)) {
+      gint64 t0 = g_get_monotonic_time ();
+      for (i = 0; i < n_frames; i++)
+        gst_video_converter_frame (rc->conv, &inf, &outf);
+      secs = (g_get_monotonic_time () - t0) * 1e-6;
+      gst_video_frame_unmap (&outf);
+    }
+    gst_video_frame_unmap (&inf);
+  }
+  gst_buffer_unref (ib);
+  gst_buffer_unref (ob);
+  return secs;
+}
+
+void
+ref_video_converter_free (void *h)
+{
+  RefConverter *rc = h;
+  if (!rc)
+    return;
+  gst_video_converter_free (rc->conv);
+  g_free (rc);
+}
+
+/* ---- compositor ------------------------------------------------------------------------- */
+
+static gboolean
+map_simple (GstVideoFrame * f, GstVideoInfo * info, GstBuffer ** buf, const char *format, int w,
+    int h, guint8 * data, gsize size, gboolean writable)
+{
+  if (!make_info (info, format, w, h, NULL, NULL, NULL, NULL))
+    return FALSE;
+  if (size < info->size)
+    return FALSE;
+  *buf = wrap_frame (info, data, size, writable);
+  return gst_video_frame_map (f, info, *buf, writable ? GST_MAP_READWRITE : GST_MAP_READ);
+}
+
+/* func: "blend_bgra" | "blend_argb" | "overlay_bgra" | "overlay_argb" | "blend_i420" | "blend_nv12" ... */
+int
+ref_compositor_blend (const char *func, const char *format, const guint8 * src, gsize src_size,
+    int sw, int sh, int xpos, int ypos, double alpha, guint8 * dst, gsize dst_size, int dw, int dh,
+    int y0, int y1, int mode)
+{
+  BlendFunction fn = NULL;
+  GstVideoInfo si, di;
+  GstVideoFrame sf, df;
+  GstBuffer *sb = NULL, *db = NULL;
+  ref_init ();
+  if (!strcmp (func, "blend_bgra"))
+    fn = gst_compositor_blend_bgra;
+  else if (!strcmp (func, "blend_argb"))
+    fn = gst_compositor_blend_argb;
+  else if (!strcmp (func, "overlay_bgra"))
+    fn = gst_compositor_overlay_bgra;
+  else if (!strcmp (func, "overlay_argb"))
+    fn = gst_compositor_overlay_argb;
+  else if (!strcmp (func, "blend_i420"))
+    fn = gst_compositor_blend_i420;
+  else if (!strcmp (func, "blend_nv12"))
+    fn = gst_compositor_blend_nv12;
+  else if (!strcmp (func, "blend_y444"))
+    fn = gst_compositor_blend_y444;
+  else if (!strcmp (func, "blend_xrgb"))
+    fn = gst_compositor_blend_xrgb;
+  else if (!strcmp (func, "blend_rgb"))
+    fn = gst_compositor_blend_rgb;
+  if (!fn)
+    return -1;
+  if (!map_simple (&sf, &si, &sb, format, sw, sh, (guint8 *) src, src_size, FALSE))
+    return -2;
+  if (!map_simple (&df, &di, &db, format, dw, dh, dst, dst_size, TRUE))
+    return -3;
+  fn (&sf, xpos, ypos, alpha, &df, y0, y1, (GstCompositorBlendMode) mode);
+  gst_video_frame_unmap (&sf);
+  gst_video_frame_unmap (&df);
+  gst_buffer_unref (sb);
+  gst_buffer_unref (db);
+  return 0;
+}
+
+/* kind: 0 = checker, 1 = fill_color(c1,c2,c3) ; fmt_func e.g. "bgra", "argb", "rgba", "abgr" */
+int
+ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 * dst,
+    gsize dst_size, int dw, int dh, int y0, int y1, int c1, int c2, int c3)
+{
+  GstVideoInfo di;
+  GstVideoFrame df;
+  GstBuffer *db = NULL;
+  ref_init ();
+  if (!map_simple (&df, &di, &db, format, dw, dh, dst, dst_size, TRUE))
+    return -3;
+  if (kind == 0) {
+    FillCheckerFunction fn = NULL;
+    if (!strcmp (fmt_func, "bgra"))
+      fn = gst_compositor_fill_checker_bgra;
+    else if (!strcmp (fmt_func, "argb"))
+      fn = gst_compositor_fill_checker_argb;
+    if (!fn)
+      return -1;
+    fn (&df, y0, y1);
+  } else {
+    FillColorFunction fn = NULL;
+    if (!strcmp (fmt_func, "bgra"))
+      fn = gst_compositor_fill_color_bgra;
+    else if (!strcmp (fmt_func, "argb"))
+      fn = gst_compositor_fill_color_argb;
+    else if (!strcmp (fmt_func, "rgba"))
+      fn = gst_compositor_fill_color_rgba;
+    else if (!strcmp (fmt_func, "abgr"))
+      fn = gst_compositor_fill_color_abgr;
+    if (!fn)
+      return -1;
+    fn (&df, y0, y1, c1, c2, c3);
+  }
+  gst_video_frame_unmap (&df);
+  gst_buffer_unref (db);
+  return 0;
+}
+
+/* ---- audio resampler -------------------------------------------------------------------- */
+
+/* method: GstAudioResamplerMethod (0 nearest,1 linear,2 cubic,3 blackman-nuttall,4 kaiser);
+ * quality <0 -> no quality option (library default); options: extra serialized GstStructure or NULL */
+void *
+ref_audio_resampler_new (int method, int flags, const char *format, int channels, int in_rate,
+    int out_rate, int quality, const char *options)
+{
+  GstStructure *s;
+  GstAudioFormat f;
+  ref_init ();
+  f = gst_audio_format_from_string (format);
+  if (f == GST_AUDIO_FORMAT_UNKNOWN)
+    return NULL;
+  if (options && *options)
+    s = gst_structure_from_string (options, NULL);
+  else
+    s = gst_structure_new_empty ("GstAudioResampler");
+  if (!s)
+    return NULL;
+  if (quality >= 0)
+    gst_audio_resampler_options_set_quality ((GstAudioResamplerMethod) method, quality, in_rate,
+        out_rate, s);
+  {
+    GstAudioResampler *r = gst_audio_resampler_new ((GstAudioResamplerMethod) method,
+        (GstAudioResamplerFlags) flags, f, channels, in_rate, out_rate, s);
+    gst_structure_free (s);
+    return r;
+  }
+}
+
+gsize
+ref_audio_resampler_get_out_frames (void *r, gsize in_frames)
+{
+  return gst_audio_resampler_get_out_frames (r, in_frames);
+}
+
+gsize
+ref_audio_resampler_get_in_frames (void *r, gsize out_frames)
+{
+  return gst_audio_resampler_get_in_frames (r, out_frames);
+}
+
+gsize
+ref_audio_resampler_get_max_latency (void *r)
+{
+  return gst_audio_resampler_get_max_latency (r);
+}
+
+/* interleaved in/out (flags==0): in[0]/out[0] are the single interleaved block; in may be NULL
+ * (the reference then feeds silence, audio-resampler.c:1750-1806) */
+void
+ref_audio_resampler_resample (void *r, const void *in, gsize in_frames, void *out,
+    gsize out_frames)
+{
+  gpointer ina[1] = { (gpointer) in };
+  gpointer outa[1] = { out };
+  gst_audio_resampler_resample (r, in ? ina : NULL, in_frames, outa, out_frames);
+}
+
+void
+ref_audio_resampler_reset (void *r)
+{
+  gst_audio_resampler_reset (r);
+}
+
+void
+ref_audio_resampler_free (void *r)
+{
+  gst_audio_resampler_free (r);
+}

@@ -1,0 +1,309 @@
+// capi_video.cpp - C ABI (include/gstamd_video.h) over the planner and the HIP kernels.
+// There is deliberately NO CPU implementation behind these entry points: without a HIP device the
+// frame calls fail with GSTAMD_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/gstamd_video.h"
+#include "planner.h"
+#include "video_kernels.h"
+
+using namespace gstamd;
+
+static thread_local std::string g_last_error;
+
+static int set_error (int code, const std::string &msg)
+{
+  g_last_error = msg;
+  return code;
+}
+
+static int hip_fail (hipError_t e, const char *what)
+{
+  return set_error (GSTAMD_ERR_HIP, std::string (what) + ": " + hipGetErrorString (e));
+}
+
+struct GstAmdVideoConverter {
+  VideoPlan plan;
+  std::mutex lock;
+  bool tables_ready = false;
+  int device = -1;
+  int *vpair_dev = nullptr;
+  struct PassDev {
+    uint32_t *offset = nullptr;
+    int16_t *taps = nullptr;
+  } pass_dev[2];
+  uint8_t *tmp = nullptr;       // intermediate image between two scaler passes
+  size_t tmp_size = 0;
+  int tmp_w = 0, tmp_h = 0;
+};
+
+extern "C" {
+
+const char *gstamd_last_error (void) { return g_last_error.c_str (); }
+
+int gstamd_video_info_set_format (GstAmdVideoInfo *info, int format, int width, int height)
+{
+  int r = video_info_set_format (info, format, width, height);
+  if (r != GSTAMD_OK)
+    set_error (r, "unsupported format or bad size");
+  return r;
+}
+
+void gstamd_video_converter_config_init (GstAmdVideoConverterConfig *config)
+{
+  if (config)
+    converter_config_init (config);
+}
+
+GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info, const GstAmdVideoInfo *out_info,
+    const GstAmdVideoConverterConfig *config, int *status)
+{
+  GstAmdVideoConverter *c = new GstAmdVideoConverter ();
+  std::string err;
+  int r = plan_video_converter (in_info, out_info, config, &c->plan, &err);
+  if (status)
+    *status = r;
+  if (r != GSTAMD_OK) {
+    set_error (r, err);
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+static int ensure_tables (GstAmdVideoConverter *c)
+{
+  std::lock_guard<std::mutex> g (c->lock);
+  if (c->tables_ready)
+    return GSTAMD_OK;
+  hipError_t e;
+  VideoPlan &p = c->plan;
+  if ((e = hipGetDevice (&c->device)) != hipSuccess)
+    return hip_fail (e, "hipGetDevice");
+  if (!p.vpair.empty ()) {
+    if ((e = hipMalloc ((void **) &c->vpair_dev, p.vpair.size () * sizeof (int32_t))) != hipSuccess)
+      return hip_fail (e, "hipMalloc(vpair)");
+    if ((e = hipMemcpy (c->vpair_dev, p.vpair.data (), p.vpair.size () * sizeof (int32_t), hipMemcpyHostToDevice)) != hipSuccess)
+      return hip_fail (e, "hipMemcpy(vpair)");
+  }
+  for (size_t i = 0; i < p.passes.size () && i < 2; i++) {
+    const ScalePass &sp = p.passes[i];
+    if ((e = hipMalloc ((void **) &c->pass_dev[i].offset, sp.offset.size () * sizeof (uint32_t))) != hipSuccess)
+      return hip_fail (e, "hipMalloc(offset)");
+    if ((e = hipMemcpy (c->pass_dev[i].offset, sp.offset.data (), sp.offset.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
+      return hip_fail (e, "hipMemcpy(offset)");
+    if (!sp.taps.empty ()) {
+      if ((e = hipMalloc ((void **) &c->pass_dev[i].taps, sp.taps.size () * sizeof (int16_t))) != hipSuccess)
+        return hip_fail (e, "hipMalloc(taps)");
+      if ((e = hipMemcpy (c->pass_dev[i].taps, sp.taps.data (), sp.taps.size () * sizeof (int16_t), hipMemcpyHostToDevice)) != hipSuccess)
+        return hip_fail (e, "hipMemcpy(taps)");
+    }
+  }
+  if (p.passes.size () == 2) {
+    const ScalePass &s0 = p.passes[0];
+    c->tmp_w = s0.horizontal ? s0.out_size : p.in_info.width;
+    c->tmp_h = s0.horizontal ? p.in_info.height : s0.out_size;
+    c->tmp_size = (size_t) c->tmp_w * 4 * c->tmp_h;
+    if ((e = hipMalloc ((void **) &c->tmp, c->tmp_size)) != hipSuccess)
+      return hip_fail (e, "hipMalloc(tmp)");
+  }
+  c->tables_ready = true;
+  return GSTAMD_OK;
+}
+
+int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *const src_planes[GSTAMD_VIDEO_MAX_PLANES],
+    const int32_t src_stride[GSTAMD_VIDEO_MAX_PLANES], void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
+    const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES], void *stream_)
+{
+  if (!c || !src_planes || !dest_planes || !src_planes[0] || !dest_planes[0])
+    return set_error (GSTAMD_ERR_INVALID, "NULL converter or frame");
+  int r = ensure_tables (c);
+  if (r != GSTAMD_OK)
+    return r;
+  hipStream_t stream = (hipStream_t) stream_;
+  const VideoPlan &p = c->plan;
+  Planes pl;
+  memset (&pl, 0, sizeof (pl));
+  for (int i = 0; i < p.in_info.n_planes; i++) {
+    pl.p[i] = (const uint8_t *) src_planes[i];
+    pl.stride[i] = src_stride ? src_stride[i] : p.in_info.stride[i];
+    if (!pl.p[i])
+      return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
+  }
+  uint8_t *dst = (uint8_t *) dest_planes[0];
+  const int dstride = dest_stride ? dest_stride[0] : p.out_info.stride[0];
+
+  ColorParams color, none;
+  memset (&none, 0, sizeof (none));
+  color.matrix = p.matrix;
+  color.alpha_kind = p.post.alpha_kind;
+  color.alpha_value = p.post.alpha_value;
+  hipError_t e;
+  if (p.passes.empty ()) {
+    e = launch_convert (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, stream);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert");
+  }
+  /* downscale: scale, then matrix+alpha in the post stage; upscale: matrix+alpha first */
+  const ColorParams &pre = p.matrix_before_scale ? color : none;
+  const ColorParams &post = p.matrix_before_scale ? none : color;
+  ScaleDev sd[2];
+  for (size_t i = 0; i < p.passes.size (); i++) {
+    sd[i].kind = p.passes[i].kind;
+    sd[i].n_taps = p.passes[i].n_taps;
+    sd[i].inc = p.passes[i].inc;
+    sd[i].offset = c->pass_dev[i].offset;
+    sd[i].taps = c->pass_dev[i].taps;
+  }
+  const int out_w = p.out_info.width, out_h = p.out_info.height;
+  if (p.passes.size () == 1) {
+    e = launch_scale_from_front (p.passes[0].horizontal, p.front, pl, c->vpair_dev, pre, sd[0], dst, dstride, true,
+        post, p.post.pack_pos, out_w, out_h, stream);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "scale pass");
+  }
+  e = launch_scale_from_front (p.passes[0].horizontal, p.front, pl, c->vpair_dev, pre, sd[0], c->tmp, c->tmp_w * 4,
+      false, none, p.post.pack_pos, c->tmp_w, c->tmp_h, stream);
+  if (e != hipSuccess)
+    return hip_fail (e, "scale pass 1");
+  e = launch_scale_from_image (p.passes[1].horizontal, c->tmp, c->tmp_w * 4, sd[1], dst, dstride, true, post,
+      p.post.pack_pos, out_w, out_h, stream);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "scale pass 2");
+}
+
+int gstamd_video_converter_frame (GstAmdVideoConverter *c, const void *src, void *dest, void *stream)
+{
+  if (!c || !src || !dest)
+    return set_error (GSTAMD_ERR_INVALID, "NULL converter or frame");
+  const void *sp[GSTAMD_VIDEO_MAX_PLANES] = {nullptr, nullptr, nullptr, nullptr};
+  void *dp[GSTAMD_VIDEO_MAX_PLANES] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < c->plan.in_info.n_planes; i++)
+    sp[i] = (const uint8_t *) src + c->plan.in_info.offset[i];
+  for (int i = 0; i < c->plan.out_info.n_planes; i++)
+    dp[i] = (uint8_t *) dest + c->plan.out_info.offset[i];
+  return gstamd_video_converter_frame_planes (c, sp, nullptr, dp, nullptr, stream);
+}
+
+void gstamd_video_converter_free (GstAmdVideoConverter *c)
+{
+  if (!c)
+    return;
+  if (c->vpair_dev)
+    (void) hipFree (c->vpair_dev);
+  for (auto &pd : c->pass_dev) {
+    if (pd.offset)
+      (void) hipFree (pd.offset);
+    if (pd.taps)
+      (void) hipFree (pd.taps);
+  }
+  if (c->tmp)
+    (void) hipFree (c->tmp);
+  delete c;
+}
+
+const char *gstamd_video_converter_describe (const GstAmdVideoConverter *c)
+{
+  return c ? c->plan.description.c_str () : "";
+}
+
+uint64_t gstamd_video_converter_algorithmic_bytes (const GstAmdVideoConverter *c)
+{
+  return c ? c->plan.algorithmic_bytes : 0;
+}
+
+/* test introspection (not part of the drop-in surface): copies planner tables out.
+ * what: 0 = matrix {kind, p[5], im[3][4]} (18 ints), 1 = vpair (2*in_height ints),
+ *       10+i = offsets of pass i (uint32), 20+i = taps of pass i (int16 widened to int32),
+ *       30+i = {kind, horizontal, n_taps, inc, in_size, out_size} of pass i.  Returns #ints or <0. */
+int gstamd_video_converter_debug_get (const GstAmdVideoConverter *c, int what, int32_t *out, int max_out)
+{
+  if (!c)
+    return -1;
+  const VideoPlan &p = c->plan;
+  std::vector<int32_t> v;
+  if (what == 0) {
+    v.push_back (p.matrix.kind);
+    for (int i = 0; i < 5; i++)
+      v.push_back (p.matrix.p[i]);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 4; j++)
+        v.push_back (p.matrix.im[i][j]);
+  } else if (what == 1) {
+    v.assign (p.vpair.begin (), p.vpair.end ());
+  } else if (what >= 10 && what < 40) {
+    size_t i = (size_t) (what % 10);
+    if (i >= p.passes.size ())
+      return -1;
+    const ScalePass &sp = p.passes[i];
+    if (what < 20)
+      v.assign (sp.offset.begin (), sp.offset.end ());
+    else if (what < 30)
+      v.assign (sp.taps.begin (), sp.taps.end ());
+    else
+      v = {sp.kind, sp.horizontal ? 1 : 0, sp.n_taps, sp.inc, sp.in_size, sp.out_size};
+  } else {
+    return -1;
+  }
+  if (out) {
+    int n = (int) v.size () < max_out ? (int) v.size () : max_out;
+    memcpy (out, v.data (), (size_t) n * sizeof (int32_t));
+  }
+  return (int) v.size ();
+}
+
+/* ---- device helpers ------------------------------------------------------------------- */
+void *gstamd_device_alloc (size_t size)
+{
+  void *p = nullptr;
+  hipError_t e = hipMalloc (&p, size);
+  if (e != hipSuccess) {
+    hip_fail (e, "hipMalloc");
+    return nullptr;
+  }
+  return p;
+}
+
+void gstamd_device_free (void *ptr)
+{
+  if (ptr)
+    (void) hipFree (ptr);
+}
+
+int gstamd_device_upload (void *dst_device, const void *src_host, size_t size, void *stream)
+{
+  hipError_t e = hipMemcpyAsync (dst_device, src_host, size, hipMemcpyHostToDevice, (hipStream_t) stream);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "upload");
+}
+
+int gstamd_device_download (void *dst_host, const void *src_device, size_t size, void *stream)
+{
+  hipError_t e = hipMemcpyAsync (dst_host, src_device, size, hipMemcpyDeviceToHost, (hipStream_t) stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize ((hipStream_t) stream);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "download");
+}
+
+int gstamd_stream_synchronize (void *stream)
+{
+  hipError_t e = hipStreamSynchronize ((hipStream_t) stream);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "hipStreamSynchronize");
+}
+
+int gstamd_device_count (void)
+{
+  int n = 0;
+  if (hipGetDeviceCount (&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+int gstamd_set_device (int device)
+{
+  hipError_t e = hipSetDevice (device);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "hipSetDevice");
+}
+
+}  // extern "C"

@@ -1,0 +1,877 @@
+// planner.cpp - see planner.h.  Host-only set-up math; compiled with -ffp-contract=off so that the
+// double computations round exactly like the reference's C code.
+#include "planner.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace gstamd {
+
+// ------------------------------------------------------------------------------------------------
+// format table (facts: video-format.c:8190-8235; byte orders: video-orc.orc:334-411)
+// ------------------------------------------------------------------------------------------------
+static const FormatDesc g_formats[] = {
+  // format, name, yuv, alpha, planes, kind, w_sub, h_sub, u_plane, v_plane, pos{A,c1,c2,c3}
+  {GSTAMD_VIDEO_FORMAT_I420, "I420", true, false, 3, UNPACK_PLANAR, 1, 1, 1, 2, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_YV12, "YV12", true, false, 3, UNPACK_PLANAR, 1, 1, 2, 1, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_Y42B, "Y42B", true, false, 3, UNPACK_PLANAR, 1, 0, 1, 2, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_Y444, "Y444", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_NV12, "NV12", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_NV21, "NV21", true, false, 2, UNPACK_SEMI, 1, 1, 0, 1, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_AYUV, "AYUV", true, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}},
+  {GSTAMD_VIDEO_FORMAT_ARGB, "ARGB", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}},
+  {GSTAMD_VIDEO_FORMAT_xRGB, "xRGB", false, false, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}},
+  {GSTAMD_VIDEO_FORMAT_BGRA, "BGRA", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {3, 2, 1, 0}},
+  {GSTAMD_VIDEO_FORMAT_BGRx, "BGRx", false, false, 1, UNPACK_PACKED4, 0, 0, 0, 0, {3, 2, 1, 0}},
+  {GSTAMD_VIDEO_FORMAT_RGBA, "RGBA", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {3, 0, 1, 2}},
+  {GSTAMD_VIDEO_FORMAT_RGBx, "RGBx", false, false, 1, UNPACK_PACKED4, 0, 0, 0, 0, {3, 0, 1, 2}},
+  {GSTAMD_VIDEO_FORMAT_ABGR, "ABGR", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 3, 2, 1}},
+  {GSTAMD_VIDEO_FORMAT_xBGR, "xBGR", false, false, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 3, 2, 1}},
+};
+
+const FormatDesc *format_desc (int format)
+{
+  for (const FormatDesc &f : g_formats)
+    if (f.format == format)
+      return &f;
+  return nullptr;
+}
+
+static inline int round_up (int v, int n) { return (v + n - 1) / n * n; }
+
+// gst_video_info_set_format's fill_planes (video-info.c:863-1100) + the caps defaults applied by
+// gst_video_info_from_caps (set_default_colorimetry :165-190, set_default_chroma_site :212-225).
+int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int height)
+{
+  const FormatDesc *f = format_desc (format);
+  if (!info || !f || width <= 0 || height <= 0)
+    return GSTAMD_ERR_INVALID;
+  memset (info, 0, sizeof (*info));
+  info->format = format;
+  info->width = width;
+  info->height = height;
+  info->n_planes = f->n_planes;
+  uint64_t w = (uint64_t) width, h = (uint64_t) height;
+  switch (format) {
+    case GSTAMD_VIDEO_FORMAT_I420:
+    case GSTAMD_VIDEO_FORMAT_YV12: {
+      info->stride[0] = round_up (width, 4);
+      info->stride[1] = round_up (round_up (width, 2) / 2, 4);
+      info->stride[2] = info->stride[1];
+      info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
+      uint64_t cr_h = round_up (height, 2) / 2;
+      info->offset[2] = info->offset[1] + info->stride[1] * cr_h;
+      info->size = info->offset[2] + info->stride[2] * cr_h;
+      break;
+    }
+    case GSTAMD_VIDEO_FORMAT_Y42B:
+      info->stride[0] = round_up (width, 4);
+      info->stride[1] = round_up (width, 8) / 2;
+      info->stride[2] = info->stride[1];
+      info->offset[1] = (uint64_t) info->stride[0] * h;
+      info->offset[2] = info->offset[1] + info->stride[1] * h;
+      info->size = info->offset[2] + info->stride[2] * h;
+      break;
+    case GSTAMD_VIDEO_FORMAT_Y444:
+      info->stride[0] = info->stride[1] = info->stride[2] = round_up (width, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * h;
+      info->offset[2] = info->offset[1] * 2;
+      info->size = (uint64_t) info->stride[0] * h * 3;
+      break;
+    case GSTAMD_VIDEO_FORMAT_NV12:
+    case GSTAMD_VIDEO_FORMAT_NV21: {
+      info->stride[0] = round_up (width, 4);
+      info->stride[1] = info->stride[0];
+      info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
+      uint64_t cr_h = round_up (height, 2) / 2;
+      info->size = info->offset[1] + info->stride[0] * cr_h;
+      break;
+    }
+    default:                   /* 4-byte packed */
+      info->stride[0] = width * 4;
+      info->size = w * 4 * h;
+      break;
+  }
+  if (f->yuv) {
+    info->color_range = GSTAMD_COLOR_RANGE_16_235;
+    info->color_matrix = height > 576 ? GSTAMD_COLOR_MATRIX_BT709 : GSTAMD_COLOR_MATRIX_BT601;
+    info->chroma_site = height > 576 ? GSTAMD_CHROMA_SITE_H_COSITED : GSTAMD_CHROMA_SITE_NONE;
+  } else {
+    info->color_range = GSTAMD_COLOR_RANGE_0_255;
+    info->color_matrix = GSTAMD_COLOR_MATRIX_RGB;
+    info->chroma_site = GSTAMD_CHROMA_SITE_UNKNOWN;
+  }
+  return GSTAMD_OK;
+}
+
+// defaults of video-converter.c:778-796 and video-resampler.c:63-70
+void converter_config_init (GstAmdVideoConverterConfig *c)
+{
+  memset (c, 0, sizeof (*c));
+  c->resampler_method = GSTAMD_RESAMPLER_METHOD_CUBIC;
+  c->resampler_taps = 0;
+  c->max_taps = 128;
+  c->envelope = 2.0;
+  c->sharpness = 1.0;
+  c->sharpen = 0.0;
+  c->cubic_b = 1.0 / 3.0;
+  c->cubic_c = 1.0 / 3.0;
+  c->alpha_mode = GSTAMD_ALPHA_MODE_COPY;
+  c->alpha_value = 1.0;
+  c->chroma_mode = GSTAMD_CHROMA_MODE_FULL;
+  c->matrix_mode = GSTAMD_MATRIX_MODE_FULL;
+  c->dither_quantization = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// colour matrix (video-converter.c:901-1066, 1323-1442, 1719-1838)
+// ------------------------------------------------------------------------------------------------
+typedef double M44[4][4];
+
+static void m_identity (M44 m)
+{
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      m[i][j] = (i == j);
+}
+
+/* dst = a * b, dst may alias (video-converter.c:921-938) */
+static void m_multiply (M44 dst, M44 a, M44 b)
+{
+  M44 tmp;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double x = 0;
+      for (int k = 0; k < 4; k++)
+        x += a[i][k] * b[k][j];
+      tmp[i][j] = x;
+    }
+  memcpy (dst, tmp, sizeof (M44));
+}
+
+static void m_offset_components (M44 m, double a1, double a2, double a3)
+{
+  M44 a;
+  m_identity (a);
+  a[0][3] = a1;
+  a[1][3] = a2;
+  a[2][3] = a3;
+  m_multiply (m, a, m);
+}
+
+static void m_scale_components (M44 m, double a1, double a2, double a3)
+{
+  M44 a;
+  m_identity (a);
+  a[0][0] = a1;
+  a[1][1] = a2;
+  a[2][2] = a3;
+  m_multiply (m, a, m);
+}
+
+static void m_YCbCr_to_RGB (M44 m, double Kr, double Kb)
+{
+  double Kg = 1.0 - Kr - Kb;
+  M44 k = {
+    {1., 0., 2 * (1 - Kr), 0.},
+    {1., -2 * Kb * (1 - Kb) / Kg, -2 * Kr * (1 - Kr) / Kg, 0.},
+    {1., 2 * (1 - Kb), 0., 0.},
+    {0., 0., 0., 1.},
+  };
+  m_multiply (m, k, m);
+}
+
+static void m_RGB_to_YCbCr (M44 m, double Kr, double Kb)
+{
+  double Kg = 1.0 - Kr - Kb;
+  M44 k;
+  double x;
+  k[0][0] = Kr;
+  k[0][1] = Kg;
+  k[0][2] = Kb;
+  k[0][3] = 0;
+  x = 1 / (2 * (1 - Kb));
+  k[1][0] = -x * Kr;
+  k[1][1] = -x * Kg;
+  k[1][2] = x * (1 - Kb);
+  k[1][3] = 0;
+  x = 1 / (2 * (1 - Kr));
+  k[2][0] = x * (1 - Kr);
+  k[2][1] = -x * Kg;
+  k[2][2] = -x * Kb;
+  k[2][3] = 0;
+  k[3][0] = 0;
+  k[3][1] = 0;
+  k[3][2] = 0;
+  k[3][3] = 1;
+  m_multiply (m, k, m);
+}
+
+/* gst_video_color_matrix_get_Kr_Kb (video-color.c:423-459) */
+static bool get_Kr_Kb (int matrix, double *Kr, double *Kb)
+{
+  switch (matrix) {
+    case GSTAMD_COLOR_MATRIX_FCC: *Kr = 0.30; *Kb = 0.11; return true;
+    case GSTAMD_COLOR_MATRIX_BT709: *Kr = 0.2126; *Kb = 0.0722; return true;
+    case GSTAMD_COLOR_MATRIX_BT601: *Kr = 0.2990; *Kb = 0.1140; return true;
+    case GSTAMD_COLOR_MATRIX_SMPTE240M: *Kr = 0.212; *Kb = 0.087; return true;
+    case GSTAMD_COLOR_MATRIX_BT2020: *Kr = 0.2627; *Kb = 0.0593; return true;
+    default: return false;
+  }
+}
+
+/* gst_video_color_range_offsets for 8-bit AYUV / ARGB (video-color.c:204-252) */
+static void range_offsets (int range, bool yuv, int offset[3], int scale[3])
+{
+  if (range == GSTAMD_COLOR_RANGE_16_235) {
+    offset[0] = 16;
+    scale[0] = 219;
+    if (yuv) {
+      offset[1] = offset[2] = 128;
+      scale[1] = scale[2] = 224;
+    } else {
+      offset[1] = offset[2] = 16;
+      scale[1] = scale[2] = 219;
+    }
+  } else {
+    offset[0] = 0;
+    offset[1] = offset[2] = yuv ? 128 : 0;
+    scale[0] = scale[1] = scale[2] = 255;
+  }
+}
+
+void compute_convert_matrix (const VideoPlan &, int in_range, int in_matrix, int out_range,
+    int out_matrix, bool in_yuv, bool out_yuv, int matrix_mode, double dm[4][4])
+{
+  int offset[3], scale[3];
+  double Kr = 0, Kb = 0;
+  m_identity (dm);
+  /* compute_matrix_to_RGB (video-converter.c:1372-1402) */
+  range_offsets (in_range, in_yuv, offset, scale);
+  m_offset_components (dm, -offset[0], -offset[1], -offset[2]);
+  m_scale_components (dm, 1 / ((float) scale[0]), 1 / ((float) scale[1]), 1 / ((float) scale[2]));
+  if (in_yuv && matrix_mode != GSTAMD_MATRIX_MODE_NONE) {
+    int mtx = matrix_mode == GSTAMD_MATRIX_MODE_OUTPUT_ONLY ? out_matrix : in_matrix;
+    if (get_Kr_Kb (mtx, &Kr, &Kb))
+      m_YCbCr_to_RGB (dm, Kr, Kb);
+  }
+  /* compute_matrix_to_YUV (video-converter.c:1405-1441) */
+  if (out_yuv && matrix_mode != GSTAMD_MATRIX_MODE_NONE) {
+    int mtx = matrix_mode == GSTAMD_MATRIX_MODE_INPUT_ONLY ? in_matrix : out_matrix;
+    if (get_Kr_Kb (mtx, &Kr, &Kb))
+      m_RGB_to_YCbCr (dm, Kr, Kb);
+  }
+  range_offsets (out_range, out_yuv, offset, scale);
+  m_scale_components (dm, (float) scale[0], (float) scale[1], (float) scale[2]);
+  m_offset_components (dm, offset[0], offset[1], offset[2]);
+}
+
+/* prepare_matrix (video-converter.c:1323-1370) for current_bits == 8 */
+static void prepare_matrix8 (M44 dm, bool unpack_rgb, bool pack_rgb, MatrixParams *mp)
+{
+  int im[4][4];
+  m_scale_components (dm, 256.0f, 256.0f, 256.0f);      /* SCALE_F */
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      im[i][j] = (int) rint (dm[i][j]);
+  memset (mp, 0, sizeof (*mp));
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++)
+      mp->im[i][j] = im[i][j];
+  bool ayuv_to_rgb = (im[0][0] == im[1][0] && im[1][0] == im[2][0]) && im[0][1] == 0 && im[2][2] == 0;
+  if (!unpack_rgb && pack_rgb && ayuv_to_rgb) {
+    mp->kind = MATRIX_AYUV_ARGB;     /* video_converter_matrix8_AYUV_ARGB (:1209) */
+    mp->p[0] = im[0][0];
+    mp->p[1] = im[0][2];
+    mp->p[2] = im[2][1];
+    mp->p[3] = im[1][1];
+    mp->p[4] = im[1][2];
+    return;
+  }
+  /* is_no_clip_matrix (:1252-1293) */
+  static const uint8_t test[8][3] = {
+    {0, 0, 0}, {0, 0, 255}, {0, 255, 0}, {0, 255, 255},
+    {255, 0, 0}, {255, 0, 255}, {255, 255, 0}, {255, 255, 255}
+  };
+  bool no_clip = true;
+  for (int i = 0; i < 8 && no_clip; i++) {
+    int r = test[i][0], g = test[i][1], b = test[i][2];
+    for (int k = 0; k < 3; k++) {
+      int v = (im[k][0] * r + im[k][1] * g + im[k][2] * b + im[k][3]) >> 8;
+      if (v < 0 || v > 255)
+        no_clip = false;
+    }
+  }
+  if (no_clip) {
+    mp->kind = MATRIX_TABLE;         /* video_converter_matrix8_table (:1187) */
+  } else {
+    mp->kind = MATRIX_8;             /* _custom_video_orc_matrix8 (:1139): coefficients as gint16 */
+    for (int k = 0; k < 3; k++) {
+      for (int j = 0; j < 3; j++)
+        mp->im[k][j] = (int16_t) (uint16_t) im[k][j];
+      mp->im[k][3] = (int16_t) (uint16_t) (im[k][3] >> 8);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// resampler taps (video-resampler.c:144-429) and their int16 quantisation (video-scaler.c:339-449)
+// ------------------------------------------------------------------------------------------------
+struct TapParams {
+  int method;
+  double b, c;
+  double ex, fx, dx;
+  double envelope, sharpness, sharpen;
+};
+
+static double sinc (double x)
+{
+  if (x == 0)
+    return 1;
+  return sin (M_PI * x) / (M_PI * x);
+}
+
+static double envelope_fn (double x)
+{
+  if (x <= -1 || x >= 1)
+    return 0;
+  return sinc (x);
+}
+
+static double get_tap (const TapParams *p, int l, int xi, double x)
+{
+  int xl = xi + l;
+  switch (p->method) {
+    case GSTAMD_RESAMPLER_METHOD_NEAREST:
+      return 1.0;
+    case GSTAMD_RESAMPLER_METHOD_LINEAR: {
+      double a = fabs (x - xl) * p->fx;
+      return a < 1.0 ? 1.0 - a : 0.0;
+    }
+    case GSTAMD_RESAMPLER_METHOD_CUBIC: {
+      double a = fabs (x - xl) * p->fx, a2 = a * a, a3 = a2 * a, b = p->b, c = p->c;
+      if (a <= 1.0)
+        return ((12.0 - 9.0 * b - 6.0 * c) * a3 + (-18.0 + 12.0 * b + 6.0 * c) * a2 + (6.0 - 2.0 * b)) / 6.0;
+      else if (a <= 2.0)
+        return ((-b - 6.0 * c) * a3 + (6.0 * b + 30.0 * c) * a2 + (-12.0 * b - 48.0 * c) * a +
+            (8.0 * b + 24.0 * c)) / 6.0;
+      return 0.0;
+    }
+    case GSTAMD_RESAMPLER_METHOD_SINC:
+      return sinc ((x - xl) * p->fx);
+    case GSTAMD_RESAMPLER_METHOD_LANCZOS: {
+      double env = envelope_fn ((x - xl) * p->ex);
+      return (sinc ((x - xl) * p->fx) - p->sharpen) * env;
+    }
+  }
+  return 0.0;
+}
+
+/* gst_video_resampler_init + resampler_calculate_taps; returns max_taps, fills offset + double taps */
+static int resampler_init (int method, unsigned n_taps, const GstAmdVideoConverterConfig &cfg, int in_size,
+    int out_size, std::vector<uint32_t> &offset, std::vector<double> &taps)
+{
+  TapParams params;
+  memset (&params, 0, sizeof (params));
+  params.method = method;
+  params.sharpness = cfg.sharpness;
+  params.sharpen = cfg.sharpen;
+  double scale_factor = in_size / (double) out_size;
+  if (scale_factor > 1.0)
+    params.fx = (1.0 / scale_factor) * params.sharpness;
+  else
+    params.fx = (1.0) * params.sharpness;
+  int max_taps_opt = cfg.max_taps;
+  n_taps = std::min<unsigned> (n_taps, (unsigned) max_taps_opt);
+  switch (method) {
+    case GSTAMD_RESAMPLER_METHOD_NEAREST:
+      params.envelope = cfg.envelope;
+      if (n_taps == 0)
+        n_taps = 1;
+      break;
+    case GSTAMD_RESAMPLER_METHOD_LINEAR:
+      params.envelope = 1.0;
+      break;
+    case GSTAMD_RESAMPLER_METHOD_CUBIC:
+      params.b = cfg.cubic_b;
+      params.c = cfg.cubic_c;
+      params.envelope = 2.0;
+      break;
+    case GSTAMD_RESAMPLER_METHOD_SINC:
+    case GSTAMD_RESAMPLER_METHOD_LANCZOS:
+      params.envelope = cfg.envelope;
+      break;
+    default:
+      break;
+  }
+  if (n_taps == 0) {
+    params.dx = ceil (2.0 * params.envelope / params.fx);
+    double v = params.dx;
+    if (v < 0)
+      v = 0;
+    if (v > max_taps_opt)
+      v = max_taps_opt;
+    n_taps = (unsigned) v;            /* CLAMP (params.dx, 0, max_taps) assigned to guint */
+  }
+  params.fx = 2.0 * params.envelope / n_taps;
+  params.ex = 2.0 / n_taps;
+  if (n_taps > (unsigned) in_size)
+    n_taps = in_size;
+  int max_taps = (int) n_taps;
+
+  int tap_offs = (max_taps - 1) / 2;
+  double corr = (max_taps == 1 ? 0.0 : 0.5);
+  double shift = 0.0;
+  offset.assign (out_size, 0);
+  taps.assign ((size_t) out_size * max_taps, 0.0);
+  for (int j = 0; j < out_size; j++) {
+    double ox = (0.5 + (double) j - shift) / out_size;
+    double x = ox * (double) in_size - corr;
+    if (x < 0)
+      x = 0;
+    else if (x > in_size - 1)
+      x = in_size - 1;
+    int xi = (int) floor (x - tap_offs);
+    uint32_t off = (uint32_t) xi;
+    double weight = 0;
+    double *t = &taps[(size_t) j * max_taps];
+    for (int l = 0; l < max_taps; l++) {
+      t[l] = get_tap (&params, l, xi, x);
+      weight += t[l];
+    }
+    for (int l = 0; l < max_taps; l++)
+      t[l] /= weight;
+    if (xi < 0) {
+      int sh = -xi, l;
+      for (l = 0; l < sh; l++)
+        t[sh] += t[l];
+      for (l = 0; l < max_taps - sh; l++)
+        t[l] = t[sh + l];
+      for (; l < max_taps; l++)
+        t[l] = 0;
+      off += sh;
+    }
+    if (xi > in_size - max_taps) {
+      int sh = xi - (in_size - max_taps), l;
+      for (l = 0; l < sh; l++)
+        t[max_taps - sh - 1] += t[max_taps - sh + l];
+      for (l = 0; l < max_taps - sh; l++)
+        t[max_taps - 1 - l] = t[max_taps - 1 - sh - l];
+      for (l = 0; l < sh; l++)
+        t[l] = 0;
+      off -= sh;
+    }
+    offset[j] = off;
+  }
+  return max_taps;
+}
+
+/* resampler_convert_coeff (video-scaler.c:339-388) */
+static void convert_coeff (const double *src, int16_t *dest, int n, int precision)
+{
+  double multiplier = (1 << precision);
+  double l_offset = 0.0, h_offset = 1.0, offset = 0.5;
+  for (int i = 0; i < 64; i++) {
+    int sum = 0;
+    for (int j = 0; j < n; j++) {
+      int16_t tap = (int16_t) floor (offset + src[j] * multiplier);
+      dest[j] = tap;
+      sum += tap;
+    }
+    if (sum == (1 << precision))
+      break;
+    if (l_offset == h_offset)
+      break;
+    if (sum < (1 << precision)) {
+      if (offset > l_offset)
+        l_offset = offset;
+      offset += (h_offset - l_offset) / 2;
+    } else {
+      if (offset < h_offset)
+        h_offset = offset;
+      offset -= (h_offset - l_offset) / 2;
+    }
+  }
+}
+
+/* One gst_video_scaler_new + the function the reference would pick in get_functions
+ * (video-scaler.c:1202-1342) for 4x8-bit pixels. */
+bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverterConfig &cfg, int in_size,
+    int out_size, bool horizontal, ScalePass *pass)
+{
+  std::vector<double> dtaps;
+  int max_taps = resampler_init (method, n_taps_opt, cfg, in_size, out_size, pass->offset, dtaps);
+  pass->horizontal = horizontal;
+  pass->in_size = in_size;
+  pass->out_size = out_size;
+  pass->n_taps = max_taps;
+  pass->inc = out_size == 1 ? 0 : (int) ((((unsigned) (in_size - 1)) << 16) / (unsigned) (out_size - 1)) - 1;
+  pass->precision = 0;
+  pass->taps.clear ();
+  if (max_taps == 1) {
+    pass->kind = SCALE_NEAREST;               /* h_near_u32 / v_near: copies s[offset[i]] */
+    return true;
+  }
+  if (max_taps == 2 && horizontal) {
+    pass->kind = SCALE_2TAP;                  /* video_scale_h_2tap_4u8 -> ldreslinl with scale->inc */
+    return true;
+  }
+  if (max_taps == 2) {
+    pass->kind = SCALE_2TAP;                  /* video_scale_v_2tap_u8: taps at SCALE_U8_LQ + 2 bits */
+    pass->precision = 8;
+  } else {
+    pass->kind = SCALE_NTAP;                  /* h_ntap_u8 / v_4tap_u8 / v_ntap_u8 at SCALE_U8_LQ bits */
+    pass->precision = 6;
+  }
+  pass->taps.assign ((size_t) out_size * max_taps, 0);
+  for (int i = 0; i < out_size; i++)
+    convert_coeff (&dtaps[(size_t) i * max_taps], &pass->taps[(size_t) i * max_taps], max_taps, pass->precision);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// line-cache simulation: which two source lines does the vertical chroma upsampler pair?
+// Mirrors gst_line_cache_get_lines / _add_line (video-converter.c:571-629) and the need_line
+// callbacks do_unpack_lines / do_upsample_lines / do_hscale_lines / do_vscale_lines (:2966-3094)
+// on line INDICES only, for a fresh converter's first frame with one thread.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct SimCache {
+  int first = 0, len = 0, backlog = 0;
+  SimCache *prev = nullptr;
+  int kind = 0;    // 0 unpack, 1 upsample, 2 passthrough (hscale/convert/alpha), 3 vscale
+  const ScalePass *vpass = nullptr;
+  int out_height = 0;
+};
+
+struct Sim {
+  std::vector<int32_t> *vpair;
+  int in_height;
+  int h_sub;
+  int up_n_lines, up_offset;
+
+  void clear (SimCache *c) { c->len = 0; c->first = 0; }
+  void add_line (SimCache *c, int idx)
+  {
+    if (c->first + c->len != idx) {
+      clear (c);
+      c->first = idx;
+    }
+    c->len++;
+  }
+  bool get_lines (SimCache *c, int out_line, int in_line, int n_lines)
+  {
+    if (c->first + c->backlog < in_line) {
+      int to_remove = std::min (in_line - (c->first + c->backlog), c->len);
+      if (to_remove > 0)
+        c->len -= to_remove;
+      c->first += to_remove;
+    } else if (in_line < c->first) {
+      clear (c);
+      c->first = in_line;
+    }
+    for (int guard = 0; guard < (1 << 24); guard++) {
+      if (c->first <= in_line && in_line + n_lines <= c->first + c->len)
+        return true;
+      if (c->len == 0 && c->first + c->backlog < in_line)
+        c->first = in_line - c->backlog;
+      int oline = out_line + c->first + c->len - in_line;
+      if (!need_line (c, oline, c->first + c->len))
+        break;
+    }
+    return false;
+  }
+  int chroma_row (int line) const
+  {
+    int cl = std::min (std::max (line, 0), in_height - 1);
+    return cl >> h_sub;
+  }
+  bool need_line (SimCache *c, int out_line, int in_line)
+  {
+    switch (c->kind) {
+      case 0:
+        add_line (c, in_line);
+        return true;
+      case 1: {
+        int n_lines = up_n_lines, start_line = in_line;
+        if (start_line < n_lines + up_offset) {
+          start_line += up_offset;
+          out_line += up_offset;
+        }
+        if (!get_lines (c->prev, out_line, start_line, n_lines))
+          return false;
+        if (n_lines == 2) {
+          int ra = chroma_row (start_line), rb = chroma_row (start_line + 1);
+          for (int i = 0; i < 2; i++) {
+            int line = start_line + i;
+            if (line >= 0 && line < in_height) {
+              (*vpair)[2 * line + 0] = ra | (i << 30);
+              (*vpair)[2 * line + 1] = rb;
+            }
+          }
+        }
+        for (int i = 0; i < n_lines; i++)
+          add_line (c, start_line + i);
+        return true;
+      }
+      case 2:
+        if (!get_lines (c->prev, out_line, in_line, 1))
+          return false;
+        add_line (c, in_line);
+        return true;
+      case 3: {
+        int cline = std::min (std::max (in_line, 0), c->out_height - 1);
+        int sline = (int) c->vpass->offset[cline], n = c->vpass->n_taps;
+        if (!get_lines (c->prev, out_line, sline, n))
+          return false;
+        add_line (c, in_line);
+        return true;
+      }
+    }
+    return false;
+  }
+};
+}  // namespace
+
+static void simulate_vpairs (VideoPlan *plan, int out_height)
+{
+  const int H = plan->front.height;
+  plan->vpair.assign ((size_t) H * 2, 0);
+  for (int y = 0; y < H; y++) {
+    int r = y >> plan->front.h_sub;
+    plan->vpair[2 * y] = r;
+    plan->vpair[2 * y + 1] = r;
+  }
+  if (!plan->front.chroma_v2)
+    return;
+  Sim sim;
+  sim.vpair = &plan->vpair;
+  sim.in_height = H;
+  sim.h_sub = plan->front.h_sub;
+  sim.up_n_lines = 2;
+  sim.up_offset = -1;
+  std::vector<SimCache> caches (2 + plan->passes.size ());
+  caches[0].kind = 0;
+  caches[1].kind = 1;
+  caches[1].prev = &caches[0];
+  SimCache *prev = &caches[1];
+  size_t ci = 2;
+  for (const ScalePass &p : plan->passes) {
+    SimCache *c = &caches[ci++];
+    c->prev = prev;
+    if (p.horizontal) {
+      c->kind = 2;
+    } else {
+      c->kind = 3;
+      c->vpass = &p;
+      c->out_height = p.out_size;
+      prev->backlog = 0;     /* chain_vscale: prev->backlog = taps_i (interlaced only) */
+    }
+    prev = c;
+  }
+  /* convert_generic_task: one thread, lines 0 .. out_height-1, one at a time */
+  for (int i = 0; i < out_height; i++)
+    sim.get_lines (prev, i, i, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fastpath detection (video-converter.c:8907-9017 + transforms[] :8413-8905), restricted to the
+// formats this library knows.  Returns a short name of the reference fastpath or nullptr.
+// ------------------------------------------------------------------------------------------------
+static const char *lookup_fastpath (const VideoPlan &p, int alpha_mode_bits, bool same_matrix)
+{
+  const int in = p.in_info.format, out = p.out_info.format;
+  const bool same_size = p.in_info.width == p.out_info.width && p.in_info.height == p.out_info.height;
+  const bool need_copy = alpha_mode_bits & 1, need_set = alpha_mode_bits & 2, need_mult = alpha_mode_bits & 4;
+  if (p.config.dither_quantization != 1)
+    return nullptr;
+  auto is420 = [](int f) { return f == GSTAMD_VIDEO_FORMAT_I420 || f == GSTAMD_VIDEO_FORMAT_YV12; };
+  auto is_rgb4 = [](int f) {
+    switch (f) {
+      case GSTAMD_VIDEO_FORMAT_RGBx: case GSTAMD_VIDEO_FORMAT_BGRx: case GSTAMD_VIDEO_FORMAT_xRGB:
+      case GSTAMD_VIDEO_FORMAT_xBGR: case GSTAMD_VIDEO_FORMAT_RGBA: case GSTAMD_VIDEO_FORMAT_BGRA:
+      case GSTAMD_VIDEO_FORMAT_ARGB: case GSTAMD_VIDEO_FORMAT_ABGR:
+        return true;
+      default:
+        return false;
+    }
+  };
+  /* same format: convert_scale_planes (keeps_size FALSE, alpha_copy for the alpha formats) */
+  if (in == out && same_matrix && !need_set && !need_mult && (!need_copy || p.fin->alpha))
+    return "convert_scale_planes";
+  /* I420/YV12 -> 4-byte RGB: convert_I420_BGRA / _ARGB / _pack_ARGB (needs_color_matrix, keeps_size,
+   * no alpha handling) */
+  if (is420 (in) && is_rgb4 (out) && same_size && !need_copy && !need_set && !need_mult)
+    return "convert_I420_xRGB";
+  /* AYUV -> 4-byte RGB: convert_AYUV_* (keeps_size, alpha_copy only for the alpha outputs) */
+  if (in == GSTAMD_VIDEO_FORMAT_AYUV && is_rgb4 (out) && same_size && !need_set && !need_mult
+      && (!need_copy || p.fout->alpha))
+    return "convert_AYUV_xRGB";
+  /* planar YUV -> AYUV (keeps_size, no colour matrix) */
+  if ((is420 (in) || in == GSTAMD_VIDEO_FORMAT_Y42B || in == GSTAMD_VIDEO_FORMAT_Y444)
+      && out == GSTAMD_VIDEO_FORMAT_AYUV && same_size && same_matrix && !need_copy && !need_set && !need_mult)
+    return "convert_planar_AYUV";
+  return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
+    const GstAmdVideoConverterConfig *config, VideoPlan *plan, std::string *error)
+{
+  auto fail = [&](int code, const std::string &msg) {
+    if (error)
+      *error = msg;
+    return code;
+  };
+  if (!in || !out || !plan)
+    return fail (GSTAMD_ERR_INVALID, "NULL argument");
+  plan->in_info = *in;
+  plan->out_info = *out;
+  if (config)
+    plan->config = *config;
+  else
+    converter_config_init (&plan->config);
+  const GstAmdVideoConverterConfig &cfg = plan->config;
+  plan->fin = format_desc (in->format);
+  plan->fout = format_desc (out->format);
+  if (!plan->fin || !plan->fout)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "format not implemented on the GPU path");
+  if (in->width <= 0 || in->height <= 0 || out->width <= 0 || out->height <= 0)
+    return fail (GSTAMD_ERR_INVALID, "bad frame size");
+  if (plan->fout->kind != UNPACK_PACKED4)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "planar/semi-planar output (chroma downsample + pack) not implemented yet");
+  if (cfg.dither_quantization != 1)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "dither-quantization != 1 not implemented");
+
+  const bool unpack_rgb = !plan->fin->yuv, pack_rgb = !plan->fout->yuv;
+  /* gst_video_converter_init_from_config (:2380-2404): RGB formats force the RGB matrix */
+  int in_matrix = unpack_rgb ? GSTAMD_COLOR_MATRIX_RGB : in->color_matrix;
+  int out_matrix = pack_rgb ? GSTAMD_COLOR_MATRIX_RGB : out->color_matrix;
+  if (!unpack_rgb && (in_matrix == GSTAMD_COLOR_MATRIX_UNKNOWN || in_matrix == GSTAMD_COLOR_MATRIX_RGB))
+    return fail (GSTAMD_ERR_INVALID, "YUV input needs a YUV colour matrix");
+  if (!pack_rgb && (out_matrix == GSTAMD_COLOR_MATRIX_UNKNOWN || out_matrix == GSTAMD_COLOR_MATRIX_RGB))
+    return fail (GSTAMD_ERR_INVALID, "YUV output needs a YUV colour matrix");
+
+  /* convert_get_alpha_mode (:2264-2294); bits: COPY 1, SET 2, MULT 4 */
+  int alpha_bits = 0;
+  if (plan->fout->alpha) {
+    bool decided = false;
+    if (plan->fin->alpha) {
+      if (cfg.alpha_mode == GSTAMD_ALPHA_MODE_COPY) {
+        alpha_bits = 1;
+        decided = true;
+      } else if (cfg.alpha_mode == GSTAMD_ALPHA_MODE_MULT) {
+        alpha_bits = cfg.alpha_value == 1.0 ? 1 : 4;
+        decided = true;
+      }
+    }
+    if (!decided)
+      alpha_bits = cfg.alpha_value == 1.0 ? 0 : 2;
+  }
+
+  const bool same_matrix = cfg.matrix_mode == GSTAMD_MATRIX_MODE_NONE ? true : in_matrix == out_matrix;
+  if (const char *fp = lookup_fastpath (*plan, alpha_bits, same_matrix))
+    return fail (GSTAMD_ERR_UNSUPPORTED, std::string ("reference takes fastpath ") + fp +
+        " for this conversion; no GPU kernel for it yet");
+
+  // ---- front: unpack + chroma upsample (chain_unpack_line, chain_upsample) ----------------------
+  FrontParams &fr = plan->front;
+  memset (&fr, 0, sizeof (fr));
+  fr.kind = plan->fin->kind;
+  fr.width = in->width;
+  fr.height = in->height;
+  fr.w_sub = plan->fin->w_sub;
+  fr.h_sub = plan->fin->h_sub;
+  fr.u_plane = plan->fin->u_plane;
+  fr.v_plane = plan->fin->v_plane;
+  memcpy (fr.pos, plan->fin->pos, sizeof (fr.pos));
+  fr.chroma_h = CHROMA_H_NONE;
+  fr.chroma_v2 = 0;
+  /* video_converter_compute_resample (:2850-2895) + gst_video_chroma_resample_new (video-chroma.c:1041-1109) */
+  if (cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY
+      && plan->fin->yuv) {
+    bool differs = plan->fin->w_sub != plan->fout->w_sub || plan->fin->h_sub != plan->fout->h_sub ||
+        in->chroma_site != out->chroma_site || in->width != out->width || in->height != out->height;
+    if (differs && (fr.w_sub || fr.h_sub)) {
+      if (fr.w_sub == 1)
+        fr.chroma_h = (in->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? CHROMA_H_H2_CS : CHROMA_H_H2;
+      if (fr.h_sub == 1 && !(in->chroma_site & GSTAMD_CHROMA_SITE_V_COSITED))
+        fr.chroma_v2 = 1;      /* video_chroma_up_v2_u8; the cosited variant is an h-only stub */
+    }
+  }
+
+  // ---- scaling (chain_scale :1685-1717 decides WHERE and in which ORDER) -------------------------
+  plan->passes.clear ();
+  const int in_w = in->width, in_h = in->height, out_w = out->width, out_h = out->height;
+  const long s0 = (long) in_w * in_h, s3 = (long) out_w * out_h;
+  const bool need_scale = in_w != out_w || in_h != out_h;
+  plan->matrix_before_scale = need_scale && !(s3 <= s0);
+  if (need_scale) {
+    const long s1 = (long) out_w * in_h, s2 = (long) in_w * out_h;
+    const bool h_first = s1 <= s2;
+    for (int step = 0; step < 2; step++) {
+      bool horizontal = (step == 0) == h_first;
+      int isz = horizontal ? in_w : in_h, osz = horizontal ? out_w : out_h;
+      if (isz == osz)
+        continue;
+      ScalePass pass;
+      make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, isz, osz, horizontal, &pass);
+      plan->passes.push_back (pass);
+    }
+  }
+
+  /* Reference quirk: when the vertical scaler comes first and pulls straight from the 2-line chroma
+   * upsampler, the unpack temp-line ring (setup_allocators :2115-2187, sized MAX(n_taps, 5)) is one
+   * line short: the pair mate of the window's last line overwrites the window's first line, so the
+   * reference output depends on buffer reuse (verified against oracle/_ref: >15 % of bytes differ
+   * from the intended filter).  We refuse such plans instead of silently diverging. */
+  if (!plan->passes.empty () && !plan->passes[0].horizontal && fr.chroma_v2 && plan->passes[0].n_taps >= 5)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "vertical-first N-tap scaling fed by the 4:2:0 chroma upsampler hits a "
+        "temp-line aliasing bug in the reference; not reproduced");
+
+  // ---- colour matrix (chain_convert :1719-1868) --------------------------------------------------
+  memset (&plan->matrix, 0, sizeof (plan->matrix));
+  if (!same_matrix) {
+    M44 dm;
+    compute_convert_matrix (*plan, in->color_range, in_matrix, out->color_range, out_matrix, plan->fin->yuv,
+        plan->fout->yuv, cfg.matrix_mode, dm);
+    prepare_matrix8 (dm, unpack_rgb, pack_rgb, &plan->matrix);
+  }
+
+  // ---- alpha + pack ------------------------------------------------------------------------------
+  PostParams &post = plan->post;
+  memset (&post, 0, sizeof (post));
+  post.matrix = plan->matrix;
+  post.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
+  post.alpha_value = (int) (255 * cfg.alpha_value);
+  memcpy (post.pack_pos, plan->fout->pos, sizeof (post.pack_pos));
+
+  simulate_vpairs (plan, out_h);
+
+  plan->algorithmic_bytes = 0;
+  {
+    /* source planes read once + destination written once */
+    uint64_t rd = 0;
+    const FormatDesc *f = plan->fin;
+    if (f->kind == UNPACK_PACKED4)
+      rd = (uint64_t) in_w * in_h * 4;
+    else {
+      uint64_t cw = ((uint64_t) in_w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) in_h + (1 << f->h_sub) - 1) >> f->h_sub;
+      rd = (uint64_t) in_w * in_h + 2 * cw * ch;
+    }
+    plan->algorithmic_bytes = rd + (uint64_t) out_w * out_h * 4;
+  }
+  std::string d = plan->passes.empty () ? "fused_convert" : "scale";
+  d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;
+  d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : "";
+  d += fr.chroma_v2 ? ",v2" : "";
+  for (const ScalePass &p : plan->passes)
+    d += std::string (p.horizontal ? ",H" : ",V") + std::to_string (p.n_taps);
+  static const char *mk[] = {"none", "ayuv_argb", "table", "matrix8"};
+  d += std::string (",matrix=") + mk[plan->matrix.kind] + (plan->matrix_before_scale ? "(pre)" : "") + "]";
+  plan->description = d;
+  return GSTAMD_OK;
+}
+
+}  // namespace gstamd

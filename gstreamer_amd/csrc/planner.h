@@ -1,0 +1,108 @@
+// planner.h - host-side "bit-exactness brain" of the GPU GstVideoConverter.
+//
+// Reproduces the DECISIONS gst_video_converter_new() takes (reference:
+// subprojects/gst-plugins-base/gst-libs/gst/video/video-converter.c:2421-2563 and the chain_*
+// builders :851-2112) and turns them into a launch plan of fused HIP kernels.  No pixel is touched
+// here; everything is integer/double set-up math that must agree with the reference bit for bit
+// (matrix coefficients, resampler taps, chroma line pairing).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/gstamd_video.h"
+
+namespace gstamd {
+
+// ---- per-format description (own table; facts from video-format.c:8190-8235) ------------------
+enum UnpackKind : int {
+  UNPACK_PACKED4 = 0,   // one plane, 4 bytes / pixel, pure byte permutation to A,c1,c2,c3
+  UNPACK_PLANAR = 1,    // separate Y, U, V planes (I420, YV12, Y42B, Y444)
+  UNPACK_SEMI = 2,      // Y plane + interleaved UV plane (NV12, NV21)
+};
+
+struct FormatDesc {
+  int format;
+  const char *name;
+  bool yuv;             // GST_VIDEO_FORMAT_FLAG_YUV (else RGB)
+  bool alpha;           // GST_VIDEO_FORMAT_FLAG_ALPHA
+  int n_planes;
+  int kind;             // UnpackKind
+  int w_sub, h_sub;     // log2 chroma subsampling (finfo->w_sub[1], h_sub[1])
+  int u_plane, v_plane; // planar: plane index of U and V; semi: u_first (1) / v_first (0) in u_plane
+  int pos[4];           // packed4: memory byte index of unpacked component 0..3 (A,R,G,B / A,Y,U,V)
+};
+const FormatDesc *format_desc (int format);
+
+// ---- device-consumable plan pieces (POD, passed to kernels by value) --------------------------
+enum ChromaH : int { CHROMA_H_NONE = 0, CHROMA_H_H2 = 1, CHROMA_H_H2_CS = 2 };
+enum MatrixKind : int { MATRIX_NONE = 0, MATRIX_AYUV_ARGB = 1, MATRIX_TABLE = 2, MATRIX_8 = 3 };
+enum AlphaKind : int { ALPHA_NONE = 0, ALPHA_SET = 1, ALPHA_MULT = 2 };
+
+struct MatrixParams {
+  int kind;
+  int p[5];        // MATRIX_AYUV_ARGB: p1..p5 of video_orc_convert_AYUV_ARGB
+  int im[3][4];    // MATRIX_TABLE / MATRIX_8: integer matrix rows (im[k][3] = offset)
+};
+
+struct PostParams {     // stages after the (optional) scaler, fused into the last kernel
+  MatrixParams matrix;
+  int alpha_kind;
+  int alpha_value;      // convert->alpha_value = 255 * alpha (video-converter.c:2368)
+  int pack_pos[4];      // destination byte index of component 0..3
+};
+
+struct FrontParams {    // unpack + chroma upsample of the source frame (functional form)
+  int kind;             // UnpackKind
+  int width, height;    // in_width / in_height (no crop support yet: == maxwidth/maxheight)
+  int w_sub, h_sub;
+  int u_plane, v_plane; // see FormatDesc
+  int pos[4];
+  int chroma_h;         // ChromaH
+  int chroma_v2;        // 1: vertical 2x upsample through the pair table
+};
+
+enum ScaleKind : int { SCALE_NONE = 0, SCALE_NEAREST = 1, SCALE_2TAP = 2, SCALE_NTAP = 3 };
+
+struct ScalePass {
+  int kind;             // ScaleKind
+  bool horizontal;
+  int in_size, out_size;
+  int n_taps;
+  int inc;              // scale->inc for the ldreslinl horizontal 2-tap (video-scaler.c:254-257)
+  std::vector<uint32_t> offset;   // [out_size] first source index
+  std::vector<int16_t> taps;      // [out_size][n_taps] quantised taps (precision depends on kind)
+  int precision;
+};
+
+struct VideoPlan {
+  GstAmdVideoInfo in_info, out_info;
+  GstAmdVideoConverterConfig config;
+  const FormatDesc *fin, *fout;
+  FrontParams front;
+  bool matrix_before_scale;   // false: scale first (downscale), matrix in the post stage
+  MatrixParams matrix;        // the convert_matrix stage
+  PostParams post;
+  std::vector<ScalePass> passes;  // 0, 1 or 2 passes in execution order
+  // chroma vertical pairing, one entry per source line: chroma rows of the pair's first and second
+  // line and which of the two this line is (0 first / 1 second); rows equal => plain copy
+  std::vector<int32_t> vpair;     // [in_height][2]: (row_a | role << 30), row_b
+  std::string description;
+  uint64_t algorithmic_bytes;
+};
+
+// Returns GSTAMD_OK and fills `plan`, or an error code (GSTAMD_ERR_UNSUPPORTED for conversions the
+// reference would run through a path this library has no kernel for yet).
+int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
+    const GstAmdVideoConverterConfig *config, VideoPlan *plan, std::string *error);
+
+int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int height);
+void converter_config_init (GstAmdVideoConverterConfig *config);
+
+// building blocks exposed for tests
+void compute_convert_matrix (const VideoPlan &plan_inputs, int in_range, int in_matrix, int out_range,
+    int out_matrix, bool in_yuv, bool out_yuv, int matrix_mode, double dm[4][4]);
+bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverterConfig &cfg, int in_size,
+    int out_size, bool horizontal, ScalePass *pass);
+
+}  // namespace gstamd

@@ -1,0 +1,439 @@
+// video_device.h - per-pixel device code of the GstVideoConverter kernels (bodies only).
+//
+// Included by video_kernels.hip (compiled for gfx950, GSTAMD_HD = __device__ __forceinline__) and by
+// the test-only host emulator tests/emu/emu_video.cpp (GSTAMD_HD = inline), which runs the very same
+// bodies over the launch grid on the CPU so kernel logic can be debugged without a GPU.  The
+// emulator is test infrastructure; nothing in the product calls it.
+//
+// Reference semantics being reproduced bit-exactly (paths under
+// /root/reference/subprojects/gst-plugins-base/gst-libs/gst/video/):
+//   unpack      video-format.c:92-151 (planar 4:2:0), :1593-1640 (NV12/NV21), video-orc.orc:334-411
+//   chroma up   video-chroma.c:277-327 (h2, v2), :687-699 (h2 cosited), pairing video-converter.c:2991-3021
+//   matrix      video-orc.orc:1634-1693 (AYUV_ARGB), video-converter.c:1139-1207 (matrix8, table)
+//   alpha       video-converter.c:1871-1920
+//   scalers     video-orc-dist.c:26162-26195 (ldreslinl), video-orc.orc:2208-2224 (v_2tap_lq),
+//               :2388-2480 / :2557-2655 (N-tap LQ H/V), video-scaler.c:546-760, 829-1072
+//   pack        video-orc.orc:340-411 (byte permutations)
+//
+// A pixel in flight is a uint32 holding the reference's intermediate "AYUV"/"ARGB" pixel:
+// byte0 = A, byte1 = Y|R, byte2 = U|G, byte3 = V|B.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#include "planner.h"
+#include "video_types.h"
+
+#ifdef __HIPCC__
+#define GSTAMD_HD __device__ __forceinline__
+#define gstamd_make_uint4 make_uint4
+#else
+#define GSTAMD_HD inline
+#ifndef __restrict__
+#define __restrict__
+#endif
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 gstamd_make_uint4 (uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 r = {x, y, z, w}; return r; }
+#endif
+
+namespace gstamd {
+
+// ------------------------------------------------------------------------------------------------
+// per-pixel stages
+// ------------------------------------------------------------------------------------------------
+GSTAMD_HD int clampi (int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// video_orc_convert_AYUV_ARGB, C semantics of video-orc-dist.c:22162-22318
+GSTAMD_HD uint32_t matrix_ayuv_argb (uint32_t px, const int *p)
+{
+  const int a = px & 0xff;
+  const int y = (int) ((px >> 8) & 0xff) - 128, u = (int) ((px >> 16) & 0xff) - 128, v = (int) ((px >> 24) & 0xff) - 128;
+  // splatbw: ((b & 0xff) << 8) | (b & 0xff) reinterpreted as int16
+  const int yb = y & 0xff, ub = u & 0xff, vb = v & 0xff;
+  const int wy0 = (int) (int16_t) ((yb << 8) | yb), wu = (int) (int16_t) ((ub << 8) | ub), wv = (int) (int16_t) ((vb << 8) | vb);
+  const int wy = (int) (int16_t) ((wy0 * (int) (int16_t) p[0]) >> 16);                 // mulhsw
+  const int r16 = (int) (int16_t) (wy + (int) (int16_t) ((wv * (int) (int16_t) p[1]) >> 16));   // addw wraps
+  const int b16 = (int) (int16_t) (wy + (int) (int16_t) ((wu * (int) (int16_t) p[2]) >> 16));
+  int g16 = (int) (int16_t) (wy + (int) (int16_t) ((wu * (int) (int16_t) p[3]) >> 16));
+  g16 = (int) (int16_t) (g16 + (int) (int16_t) ((wv * (int) (int16_t) p[4]) >> 16));
+  const int r = clampi (r16, -128, 127) + 128, g = clampi (g16, -128, 127) + 128, b = clampi (b16, -128, 127) + 128;
+  return (uint32_t) a | ((uint32_t) r << 8) | ((uint32_t) g << 16) | ((uint32_t) b << 24);
+}
+
+GSTAMD_HD uint32_t apply_matrix (const MatrixParams &m, uint32_t px)
+{
+  if (m.kind == MATRIX_NONE)
+    return px;
+  if (m.kind == MATRIX_AYUV_ARGB)
+    return matrix_ayuv_argb (px, m.p);
+  const int r = (px >> 8) & 0xff, g = (px >> 16) & 0xff, b = (px >> 24) & 0xff;
+  if (m.kind == MATRIX_TABLE) {
+    // video_converter_matrix8_table: three 16-bit lanes in one int64, borrows included
+    const long long s0 = (long long) (m.im[0][0] * r + m.im[0][1] * g + m.im[0][2] * b + m.im[0][3]);
+    const long long s1 = (long long) (m.im[1][0] * r + m.im[1][1] * g + m.im[1][2] * b + m.im[1][3]);
+    const long long s2 = (long long) (m.im[2][0] * r + m.im[2][1] * g + m.im[2][2] * b + m.im[2][3]);
+    const long long x = (s0 << 32) + (s1 << 16) + s2;
+    const uint32_t o1 = (uint32_t) (x >> 40) & 0xff, o2 = (uint32_t) (x >> 24) & 0xff, o3 = (uint32_t) (x >> 8) & 0xff;
+    return (px & 0xff) | (o1 << 8) | (o2 << 16) | (o3 << 24);
+  }
+  // _custom_video_orc_matrix8
+  const int y = clampi (((m.im[0][0] * r + m.im[0][1] * g + m.im[0][2] * b) >> 8) + m.im[0][3], 0, 255);
+  const int u = clampi (((m.im[1][0] * r + m.im[1][1] * g + m.im[1][2] * b) >> 8) + m.im[1][3], 0, 255);
+  const int v = clampi (((m.im[2][0] * r + m.im[2][1] * g + m.im[2][2] * b) >> 8) + m.im[2][3], 0, 255);
+  return (px & 0xff) | ((uint32_t) y << 8) | ((uint32_t) u << 16) | ((uint32_t) v << 24);
+}
+
+GSTAMD_HD uint32_t apply_alpha (int kind, unsigned value, uint32_t px)
+{
+  if (kind == ALPHA_NONE)
+    return px;
+  if (kind == ALPHA_SET)
+    return (px & 0xffffff00u) | (value < 255u ? value : 255u);
+  const int a = (int) (((px & 0xff) * value) / 255u);
+  return (px & 0xffffff00u) | (uint32_t) clampi (a, 0, 255);
+}
+
+GSTAMD_HD uint32_t apply_color (const ColorParams &c, uint32_t px)
+{
+  return apply_alpha (c.alpha_kind, (unsigned) c.alpha_value, apply_matrix (c.matrix, px));
+}
+
+// pack: destination byte pos[i] receives component i
+GSTAMD_HD uint32_t pack_px (const int *pos, uint32_t px)
+{
+  return ((px & 0xff) << (8 * pos[0])) | (((px >> 8) & 0xff) << (8 * pos[1])) |
+      (((px >> 16) & 0xff) << (8 * pos[2])) | (((px >> 24) & 0xff) << (8 * pos[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// front: unpack + chroma upsample, functional (one pixel)
+// ------------------------------------------------------------------------------------------------
+struct UV { int u, v; };
+
+GSTAMD_HD UV load_uv (const FrontParams &f, const Planes &pl, int crow, int k)
+{
+  UV r;
+  if (f.kind == UNPACK_SEMI) {
+    const uint8_t *p = pl.p[1] + (size_t) crow * pl.stride[1] + 2 * k;
+    const int c0 = p[0], c1 = p[1];
+    r.u = f.u_plane ? c0 : c1;           // NV12: U first; NV21: V first
+    r.v = f.u_plane ? c1 : c0;
+  } else {
+    r.u = pl.p[f.u_plane][(size_t) crow * pl.stride[f.u_plane] + k];
+    r.v = pl.p[f.v_plane][(size_t) crow * pl.stride[f.v_plane] + k];
+  }
+  return r;
+}
+
+// horizontally filtered chroma of chroma row `crow` at luma position x
+GSTAMD_HD UV chroma_h_at (const FrontParams &f, const Planes &pl, int crow, int x)
+{
+  if (f.w_sub == 0)
+    return load_uv (f, pl, crow, x);
+  const int k = x >> 1, w = f.width;
+  UV c = load_uv (f, pl, crow, k);
+  if (f.chroma_h == CHROMA_H_H2_CS) {
+    if ((x & 1) && x < w - 1) {           // PR(i) = FILT_1_1 (PR(i-1), PR(i+1)), odd i < width-1
+      const UV n = load_uv (f, pl, crow, k + 1);
+      c.u = (c.u + n.u + 1) >> 1;
+      c.v = (c.v + n.v + 1) >> 1;
+    }
+  } else if (f.chroma_h == CHROMA_H_H2) {
+    if ((x & 1) && x < w - 1) {           // FILT_3_1 (tr0, tr1)
+      const UV n = load_uv (f, pl, crow, k + 1);
+      c.u = (3 * c.u + n.u + 2) >> 2;
+      c.v = (3 * c.v + n.v + 2) >> 2;
+    } else if (!(x & 1) && x >= 2) {      // FILT_1_3 (tr0, tr1) written to PR(i+1)
+      const UV pv = load_uv (f, pl, crow, k - 1);
+      c.u = (pv.u + 3 * c.u + 2) >> 2;
+      c.v = (pv.v + 3 * c.v + 2) >> 2;
+    }
+  }
+  return c;
+}
+
+GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair,
+    int x, int y)
+{
+  if (f.kind == UNPACK_PACKED4) {
+    const uint32_t raw = *(const uint32_t *) (pl.p[0] + (size_t) y * pl.stride[0] + 4 * (size_t) x);
+    return ((raw >> (8 * f.pos[0])) & 0xff) | (((raw >> (8 * f.pos[1])) & 0xff) << 8) |
+        (((raw >> (8 * f.pos[2])) & 0xff) << 16) | (((raw >> (8 * f.pos[3])) & 0xff) << 24);
+  }
+  const int Y = pl.p[0][(size_t) y * pl.stride[0] + x];
+  UV c;
+  if (f.chroma_v2) {
+    const int e0 = vpair[2 * y], rb = vpair[2 * y + 1];
+    const int ra = e0 & 0x3fffffff, role = e0 >> 30;
+    const UV a = chroma_h_at (f, pl, ra, x);
+    if (ra == rb) {
+      c = a;
+    } else {
+      const UV b = chroma_h_at (f, pl, rb, x);
+      if (role == 0) {                    // d1 = (3*s1 + s2 + 2) >> 2
+        c.u = (3 * a.u + b.u + 2) >> 2;
+        c.v = (3 * a.v + b.v + 2) >> 2;
+      } else {                            // d2 = (s1 + 3*s2 + 2) >> 2
+        c.u = (a.u + 3 * b.u + 2) >> 2;
+        c.v = (a.v + 3 * b.v + 2) >> 2;
+      }
+    }
+  } else {
+    c = chroma_h_at (f, pl, y >> f.h_sub, x);
+  }
+  return 0xffu | ((uint32_t) Y << 8) | ((uint32_t) c.u << 16) | ((uint32_t) c.v << 24);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sources for the scaler kernels
+// ------------------------------------------------------------------------------------------------
+struct SrcFront {
+  FrontParams f;
+  Planes pl;
+  const int *vpair;
+  ColorParams pre;      // matrix+alpha applied before scaling (upscale case), kind NONE otherwise
+  GSTAMD_HD uint32_t at (int x, int y) const { return apply_color (pre, fetch_front (f, pl, vpair, x, y)); }
+};
+
+struct SrcImage {
+  const uint8_t *p;
+  int stride;
+  GSTAMD_HD uint32_t at (int x, int y) const
+  {
+    return *(const uint32_t *) (p + (size_t) y * stride + 4 * (size_t) x);
+  }
+};
+
+struct Dst {
+  uint8_t *p;
+  int stride;
+  int final;            // 1: apply post colour + pack (last kernel), 0: raw intermediate
+  ColorParams post;
+  int pack_pos[4];
+  GSTAMD_HD void put (int x, int y, uint32_t px) const
+  {
+    if (final)
+      px = pack_px (pack_pos, apply_color (post, px));
+    *(uint32_t *) (p + (size_t) y * stride + 4 * (size_t) x) = px;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// K1: fused unscaled convert.  One lane = 8 consecutive pixels of one row.
+// Fast path (4:2:x sources, full span inside the row): Y as one 8-byte load, the 4 chroma samples
+// under the span as one vector load per chroma row (+2 scalar neighbours), two 16-byte stores.
+// ------------------------------------------------------------------------------------------------
+#define K1_PX 8
+
+struct Chroma6 { int u[6], v[6]; };     // samples k0-1 .. k0+4
+
+GSTAMD_HD void load_chroma6 (const FrontParams &f, const Planes &pl, int crow, int k0, int cw, Chroma6 &c)
+{
+  if (f.kind == UNPACK_SEMI) {
+    const uint8_t *row = pl.p[1] + (size_t) crow * pl.stride[1];
+    const uint2 mid = *(const uint2 *) (row + 2 * k0);           // samples k0..k0+3 (8-byte aligned: k0 % 4 == 0)
+    const uint32_t w[2] = {mid.x, mid.y};
+    const int su = f.u_plane ? 0 : 8, sv = f.u_plane ? 8 : 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t pair = (w[i >> 1] >> (16 * (i & 1))) & 0xffff;
+      c.u[i + 1] = (pair >> su) & 0xff;
+      c.v[i + 1] = (pair >> sv) & 0xff;
+    }
+    const int km = k0 > 0 ? k0 - 1 : 0, kp = k0 + 4 < cw ? k0 + 4 : cw - 1;
+    const uint32_t pm = *(const uint16_t *) (row + 2 * km), pp = *(const uint16_t *) (row + 2 * kp);
+    c.u[0] = (pm >> su) & 0xff;
+    c.v[0] = (pm >> sv) & 0xff;
+    c.u[5] = (pp >> su) & 0xff;
+    c.v[5] = (pp >> sv) & 0xff;
+  } else {
+    const uint8_t *ru = pl.p[f.u_plane] + (size_t) crow * pl.stride[f.u_plane];
+    const uint8_t *rv = pl.p[f.v_plane] + (size_t) crow * pl.stride[f.v_plane];
+    const uint32_t mu = *(const uint32_t *) (ru + k0), mv = *(const uint32_t *) (rv + k0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      c.u[i + 1] = (mu >> (8 * i)) & 0xff;
+      c.v[i + 1] = (mv >> (8 * i)) & 0xff;
+    }
+    const int km = k0 > 0 ? k0 - 1 : 0, kp = k0 + 4 < cw ? k0 + 4 : cw - 1;
+    c.u[0] = ru[km];
+    c.v[0] = rv[km];
+    c.u[5] = ru[kp];
+    c.v[5] = rv[kp];
+  }
+}
+
+// h-filtered chroma for the 8 pixels x0..x0+7 out of the 6 samples
+template <int CH>
+GSTAMD_HD void hfilter8 (const Chroma6 &c, int x0, int w, int *u, int *v)
+{
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int x = x0 + i, j = (i >> 1) + 1;     // j: index of sample x>>1
+    int uu = c.u[j], vv = c.v[j];
+    if (CH == CHROMA_H_H2_CS) {
+      if ((i & 1) && x < w - 1) {
+        uu = (uu + c.u[j + 1] + 1) >> 1;
+        vv = (vv + c.v[j + 1] + 1) >> 1;
+      }
+    } else if (CH == CHROMA_H_H2) {
+      if ((i & 1) && x < w - 1) {
+        uu = (3 * uu + c.u[j + 1] + 2) >> 2;
+        vv = (3 * vv + c.v[j + 1] + 2) >> 2;
+      } else if (!(i & 1) && x >= 2) {
+        uu = (c.u[j - 1] + 3 * uu + 2) >> 2;
+        vv = (c.v[j - 1] + 3 * vv + 2) >> 2;
+      }
+    }
+    u[i] = uu;
+    v[i] = vv;
+  }
+}
+
+template <int CH>
+GSTAMD_HD void convert_body (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, const ColorParams &color,
+    int pack0, int pack1, int pack2, int pack3, uint8_t *__restrict__ dst, int dstride, int spans_per_row, int vec_ok,
+    int span, int y)
+{
+  if (span >= spans_per_row)
+    return;
+  const int x0 = span * K1_PX, w = f.width;
+  const int pos[4] = {pack0, pack1, pack2, pack3};
+  uint8_t *drow = dst + (size_t) y * dstride;
+  if (vec_ok && f.w_sub == 1 && x0 + K1_PX <= w) {
+    const uint2 yy = *(const uint2 *) (pl.p[0] + (size_t) y * pl.stride[0] + x0);
+    const int cw = (w + 1) >> 1, k0 = x0 >> 1;
+    int ra, rb, role = 0;
+    if (f.chroma_v2) {
+      const int e0 = vpair[2 * y];
+      ra = e0 & 0x3fffffff;
+      role = e0 >> 30;
+      rb = vpair[2 * y + 1];
+    } else {
+      ra = rb = y >> f.h_sub;
+    }
+    int u[8], v[8];
+    {
+      Chroma6 c;
+      load_chroma6 (f, pl, ra, k0, cw, c);
+      hfilter8<CH> (c, x0, w, u, v);
+    }
+    if (ra != rb) {
+      Chroma6 c;
+      int u2[8], v2[8];
+      load_chroma6 (f, pl, rb, k0, cw, c);
+      hfilter8<CH> (c, x0, w, u2, v2);
+      const int wa = role == 0 ? 3 : 1, wb = 4 - wa;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        u[i] = (wa * u[i] + wb * u2[i] + 2) >> 2;
+        v[i] = (wa * v[i] + wb * v2[i] + 2) >> 2;
+      }
+    }
+    uint32_t out[8];
+    const uint32_t yw[2] = {yy.x, yy.y};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint32_t Y = (yw[i >> 2] >> (8 * (i & 3))) & 0xff;
+      const uint32_t px = 0xffu | (Y << 8) | ((uint32_t) u[i] << 16) | ((uint32_t) v[i] << 24);
+      out[i] = pack_px (pos, apply_color (color, px));
+    }
+    uint4 *d = (uint4 *) (drow + 4 * (size_t) x0);
+    d[0] = gstamd_make_uint4 (out[0], out[1], out[2], out[3]);
+    d[1] = gstamd_make_uint4 (out[4], out[5], out[6], out[7]);
+    return;
+  }
+  const int x1 = x0 + K1_PX < w ? x0 + K1_PX : w;
+  for (int x = x0; x < x1; x++) {
+    const uint32_t px = fetch_front (f, pl, vpair, x, y);
+    *(uint32_t *) (drow + 4 * (size_t) x) = pack_px (pos, apply_color (color, px));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scaler kernels: one lane per output pixel, x fastest
+// ------------------------------------------------------------------------------------------------
+GSTAMD_HD uint32_t lq_finish (int a0, int a1, int a2, int a3)
+{
+  // addw 32 (wrap), shrsw 6, convsuswb
+  const int r0 = clampi (((int) (int16_t) (a0 + 32)) >> 6, 0, 255), r1 = clampi (((int) (int16_t) (a1 + 32)) >> 6, 0, 255);
+  const int r2 = clampi (((int) (int16_t) (a2 + 32)) >> 6, 0, 255), r3 = clampi (((int) (int16_t) (a3 + 32)) >> 6, 0, 255);
+  return (uint32_t) r0 | ((uint32_t) r1 << 8) | ((uint32_t) r2 << 16) | ((uint32_t) r3 << 24);
+}
+
+template <class SRC>
+GSTAMD_HD void hscale_body (const SRC &src, const ScaleDev &sd, const Dst &dst, int out_w, int rows, int x, int y)
+{
+  if (x >= out_w || y >= rows)
+    return;
+  uint32_t r;
+  if (sd.kind == SCALE_NEAREST) {
+    r = src.at ((int) sd.offset[x], y);
+  } else if (sd.kind == SCALE_2TAP) {
+    const int tmp = x * sd.inc;                      // ldreslinl, p1 = 0
+    const int idx = tmp >> 16, fr = (tmp >> 8) & 0xff;
+    const uint32_t a = src.at (idx, y), b = src.at (idx + 1, y);
+    r = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int av = (a >> (8 * c)) & 0xff, bv = (b >> (8 * c)) & 0xff;
+      r |= (uint32_t) (((av * (256 - fr) + bv * fr) >> 8) & 0xff) << (8 * c);
+    }
+  } else {
+    const int off = (int) sd.offset[x];
+    const int16_t *t = sd.taps + (size_t) x * sd.n_taps;
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int l = 0; l < sd.n_taps; l++) {
+      const uint32_t p = src.at (off + l, y);
+      const int tp = t[l];
+      a0 += (int) (p & 0xff) * tp;                   // mullw/addw: only the low 16 bits survive
+      a1 += (int) ((p >> 8) & 0xff) * tp;
+      a2 += (int) ((p >> 16) & 0xff) * tp;
+      a3 += (int) (p >> 24) * tp;
+    }
+    r = lq_finish (a0, a1, a2, a3);
+  }
+  dst.put (x, y, r);
+}
+
+template <class SRC>
+GSTAMD_HD void vscale_body (const SRC &src, const ScaleDev &sd, const Dst &dst, int width, int out_h, int x, int y)
+{
+  if (x >= width || y >= out_h)
+    return;
+  uint32_t r;
+  const int off = (int) sd.offset[y];
+  if (sd.kind == SCALE_NEAREST) {
+    r = src.at (x, off);
+  } else if (sd.kind == SCALE_2TAP) {
+    const int p1 = sd.taps[(size_t) y * 2 + 1];
+    const uint32_t a = src.at (x, off), b = src.at (x, off + 1);
+    r = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int s1 = (a >> (8 * c)) & 0xff, s2 = (b >> (8 * c)) & 0xff;
+      int w2 = (int) (int16_t) (s2 - s1);
+      w2 = (int) (int16_t) (w2 * p1);               // mullw
+      w2 = (int) (int16_t) (w2 + 128);              // addw
+      const int t = (w2 >> 8) & 0xff;               // convhwb
+      r |= (uint32_t) ((t + s1) & 0xff) << (8 * c); // addb
+    }
+  } else {
+    const int16_t *t = sd.taps + (size_t) y * sd.n_taps;
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int l = 0; l < sd.n_taps; l++) {
+      const uint32_t p = src.at (x, off + l);
+      const int tp = t[l];
+      a0 += (int) (p & 0xff) * tp;
+      a1 += (int) ((p >> 8) & 0xff) * tp;
+      a2 += (int) ((p >> 16) & 0xff) * tp;
+      a3 += (int) (p >> 24) * tp;
+    }
+    r = lq_finish (a0, a1, a2, a3);
+  }
+  dst.put (x, y, r);
+}
+
+
+}  // namespace gstamd

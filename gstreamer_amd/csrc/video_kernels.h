@@ -1,0 +1,21 @@
+// video_kernels.h - device-side parameter blocks and host launchers of video_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "planner.h"
+#include "video_types.h"
+
+namespace gstamd {
+
+hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color,
+    const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream);
+
+hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const Planes &pl, const int *vpair_dev,
+    const ColorParams &pre, const ScaleDev &sd, uint8_t *dst, int dstride, bool final, const ColorParams &post,
+    const int pack_pos[4], int out_w, int out_h, hipStream_t stream);
+
+hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int sstride, const ScaleDev &sd, uint8_t *dst,
+    int dstride, bool final, const ColorParams &post, const int pack_pos[4], int out_w, int out_h, hipStream_t stream);
+
+}  // namespace gstamd

@@ -1,0 +1,198 @@
+"""ctypes binding of include/gstamd_video.h (libgstamddsp.so).
+
+Mirrors the reference's library API for this path - GstVideoInfo / gst_video_converter_new /
+gst_video_converter_frame (gst-libs/gst/video/video-converter.h:291-316) - with the same argument
+meaning.  Frames live in HBM: `frame()` takes device pointers (ints) or torch CUDA tensors.
+There is no CPU implementation behind this module; without the native library or without a GPU it
+raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgstamddsp.so")
+
+FORMATS = {"I420": 2, "YV12": 3, "AYUV": 6, "RGBx": 7, "BGRx": 8, "xRGB": 9, "xBGR": 10, "RGBA": 11, "BGRA": 12,
+           "ARGB": 13, "ABGR": 14, "Y42B": 18, "Y444": 20, "NV12": 23, "NV21": 24}
+COLOR_RANGE = {"unknown": 0, "0-255": 1, "16-235": 2}
+COLOR_MATRIX = {"unknown": 0, "rgb": 1, "fcc": 2, "bt709": 3, "bt601": 4, "smpte240m": 5, "bt2020": 6}
+CHROMA_SITE = {"unknown": 0, "none": 1, "jpeg": 1, "h-cosited": 2, "mpeg2": 2, "v-cosited": 4, "cosited": 6,
+               "alt-line": 8, "dv": 14}
+RESAMPLER_METHOD = {"nearest": 0, "linear": 1, "cubic": 2, "sinc": 3, "lanczos": 4}
+ALPHA_MODE = {"copy": 0, "set": 1, "mult": 2}
+CHROMA_MODE = {"full": 0, "upsample-only": 1, "downsample-only": 2, "none": 3}
+MATRIX_MODE = {"full": 0, "input-only": 1, "output-only": 2, "none": 3}
+# colorimetry strings of video-color.c:72-86 -> (range, matrix)
+COLORIMETRY = {"bt601": ("16-235", "bt601"), "bt709": ("16-235", "bt709"), "smpte240m": ("16-235", "smpte240m"),
+               "sRGB": ("0-255", "rgb"), "bt2020": ("16-235", "bt2020")}
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP = 0, -1, -2, -3
+
+
+class VideoInfo(C.Structure):
+    _fields_ = [("format", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("n_planes", C.c_int32),
+                ("stride", C.c_int32 * 4), ("offset", C.c_uint64 * 4), ("size", C.c_uint64),
+                ("color_range", C.c_int32), ("color_matrix", C.c_int32), ("chroma_site", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+class ConverterConfig(C.Structure):
+    _fields_ = [("resampler_method", C.c_int32), ("resampler_taps", C.c_uint32), ("max_taps", C.c_int32),
+                ("envelope", C.c_double), ("sharpness", C.c_double), ("sharpen", C.c_double),
+                ("cubic_b", C.c_double), ("cubic_c", C.c_double), ("alpha_mode", C.c_int32),
+                ("alpha_value", C.c_double), ("chroma_mode", C.c_int32), ("matrix_mode", C.c_int32),
+                ("dither_quantization", C.c_uint32), ("reserved", C.c_int32 * 8)]
+
+
+class CompositorPad(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
+                ("xpos", C.c_int32), ("ypos", C.c_int32), ("alpha", C.c_double), ("blend_mode", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the native library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing("%s not built - run `python -m gstreamer_amd.build`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.gstamd_last_error.restype = C.c_char_p
+        L.gstamd_video_info_set_format.argtypes = [C.POINTER(VideoInfo), C.c_int, C.c_int, C.c_int]
+        L.gstamd_video_converter_config_init.argtypes = [C.POINTER(ConverterConfig)]
+        L.gstamd_video_converter_new.restype = C.c_void_p
+        L.gstamd_video_converter_new.argtypes = [C.POINTER(VideoInfo), C.POINTER(VideoInfo), C.POINTER(ConverterConfig),
+                                                 C.POINTER(C.c_int)]
+        L.gstamd_video_converter_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gstamd_video_converter_frame_planes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                                          C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_void_p]
+        L.gstamd_video_converter_free.argtypes = [C.c_void_p]
+        L.gstamd_video_converter_describe.restype = C.c_char_p
+        L.gstamd_video_converter_describe.argtypes = [C.c_void_p]
+        L.gstamd_video_converter_algorithmic_bytes.restype = C.c_uint64
+        L.gstamd_video_converter_algorithmic_bytes.argtypes = [C.c_void_p]
+        L.gstamd_video_converter_debug_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int]
+        L.gstamd_device_alloc.restype = C.c_void_p
+        L.gstamd_device_alloc.argtypes = [C.c_size_t]
+        L.gstamd_device_free.argtypes = [C.c_void_p]
+        L.gstamd_device_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gstamd_device_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gstamd_stream_synchronize.argtypes = [C.c_void_p]
+        if hasattr(L, "gstamd_compositor_blend"):
+            L.gstamd_compositor_blend.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.c_int, C.c_int, C.c_void_p]
+            L.gstamd_compositor_fill_checker.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                         C.c_int, C.c_void_p]
+            L.gstamd_compositor_fill_color.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                       C.c_int, C.c_int, C.c_int, C.c_void_p]
+            L.gstamd_compositor_aggregate.argtypes = [C.c_int, C.c_int, C.POINTER(CompositorPad), C.c_int, C.c_void_p,
+                                                      C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().gstamd_last_error().decode()
+
+
+class GstAmdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (status %d)" % (msg, code))
+        self.code = code
+
+
+def _check(code):
+    if code != OK:
+        raise GstAmdError(code, last_error())
+
+
+def video_info(fmt, width, height, colorimetry=None, chroma_site=None, stride=None, offset=None):
+    """GstVideoInfo as the elements negotiate it (defaults by height), optional overrides."""
+    info = VideoInfo()
+    _check(lib().gstamd_video_info_set_format(C.byref(info), FORMATS[fmt], width, height))
+    if colorimetry:
+        rng, mtx = COLORIMETRY[colorimetry]
+        info.color_range = COLOR_RANGE[rng]
+        info.color_matrix = COLOR_MATRIX[mtx]
+    if chroma_site:
+        info.chroma_site = CHROMA_SITE[chroma_site]
+    if stride is not None:
+        for i, s in enumerate(stride):
+            info.stride[i] = s
+    if offset is not None:
+        for i, o in enumerate(offset):
+            info.offset[i] = o
+    return info
+
+
+def converter_config(**kw):
+    """Library defaults of video-converter.c:778-796; keyword overrides use the field names."""
+    cfg = ConverterConfig()
+    lib().gstamd_video_converter_config_init(C.byref(cfg))
+    enums = {"resampler_method": RESAMPLER_METHOD, "alpha_mode": ALPHA_MODE, "chroma_mode": CHROMA_MODE,
+             "matrix_mode": MATRIX_MODE}
+    for k, v in kw.items():
+        if k in enums and isinstance(v, str):
+            v = enums[k][v]
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):        # torch tensor in HBM
+        if not x.is_cuda:
+            raise ValueError("frames must be device (HBM) tensors")
+        return x.data_ptr()
+    raise TypeError("expected device pointer or CUDA tensor")
+
+
+class VideoConverter:
+    """gst_video_converter_new(in_info, out_info, config) -> .frame(src, dest)."""
+
+    def __init__(self, in_info, out_info, config=None):
+        status = C.c_int(0)
+        self.in_info, self.out_info = in_info, out_info
+        self._h = lib().gstamd_video_converter_new(C.byref(in_info), C.byref(out_info),
+                                                   C.byref(config) if config is not None else None, C.byref(status))
+        if not self._h:
+            raise GstAmdError(status.value, last_error())
+
+    def frame(self, src, dest, stream=None):
+        _check(lib().gstamd_video_converter_frame(self._h, _ptr(src), _ptr(dest), stream))
+
+    def describe(self):
+        return lib().gstamd_video_converter_describe(self._h).decode()
+
+    def algorithmic_bytes(self):
+        return lib().gstamd_video_converter_algorithmic_bytes(self._h)
+
+    def debug_get(self, what):
+        n = lib().gstamd_video_converter_debug_get(self._h, what, None, 0)
+        if n < 0:
+            return None
+        buf = (C.c_int32 * max(n, 1))()
+        lib().gstamd_video_converter_debug_get(self._h, what, buf, n)
+        return list(buf[:n])
+
+    def free(self):
+        if self._h:
+            lib().gstamd_video_converter_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,210 @@
+/* gstamd_video.h - C ABI of the MI355X-native GstVideoConverter / compositor-blend replacement.
+ *
+ * This is the drop-in boundary for the video half of the hot path (SURVEY.md section 8b,
+ * "Library-level C ABI").  Every entry point names the reference interface it replaces
+ * (paths relative to /root/reference/subprojects/gst-plugins-base):
+ *
+ *   gstamd_video_converter_new      <- gst_video_converter_new        gst-libs/gst/video/video-converter.h:291
+ *   gstamd_video_converter_frame    <- gst_video_converter_frame      gst-libs/gst/video/video-converter.h:313
+ *   gstamd_video_converter_free     <- gst_video_converter_free       gst-libs/gst/video/video-converter.h:304
+ *   gstamd_video_info_set_format    <- gst_video_info_set_format +    gst-libs/gst/video/video-info.c:890-1100
+ *                                      the caps defaults of           gst-libs/gst/video/video-info.c:155-225, 540-600
+ *   gstamd_compositor_*             <- BlendFunction / FillChecker /  gst/compositor/blend.h:50-52,
+ *                                      blend_pads / _draw_background  gst/compositor/compositor.c:1619-1697
+ *
+ * Plain C types only: pointers, sizes, ints, doubles.  All frame pointers are DEVICE pointers
+ * (HBM, e.g. from gstamd_device_alloc, a GstAmdHipMemory or a torch tensor's data_ptr());
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work on
+ * `stream` and return without synchronising, exactly like a HIP kernel launch.
+ *
+ * Integer enum values are numerically identical to the reference's public enums
+ * (GstVideoFormat video-format.h:195-, GstVideoColorRange/Matrix/... video-color.h,
+ * GstVideoChromaSite video-chroma.h:43-52, GstVideoResamplerMethod video-resampler.h:45-49,
+ * GstVideoAlphaMode/ChromaMode/MatrixMode video-converter.h) so a binding can pass them through.
+ */
+#ifndef GSTAMD_VIDEO_H
+#define GSTAMD_VIDEO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSTAMD_VIDEO_MAX_PLANES 4
+
+/* GstVideoFormat subset (same numeric values as video-format.h:195-) */
+enum {
+  GSTAMD_VIDEO_FORMAT_UNKNOWN = 0,
+  GSTAMD_VIDEO_FORMAT_I420 = 2,
+  GSTAMD_VIDEO_FORMAT_YV12 = 3,
+  GSTAMD_VIDEO_FORMAT_AYUV = 6,
+  GSTAMD_VIDEO_FORMAT_RGBx = 7,
+  GSTAMD_VIDEO_FORMAT_BGRx = 8,
+  GSTAMD_VIDEO_FORMAT_xRGB = 9,
+  GSTAMD_VIDEO_FORMAT_xBGR = 10,
+  GSTAMD_VIDEO_FORMAT_RGBA = 11,
+  GSTAMD_VIDEO_FORMAT_BGRA = 12,
+  GSTAMD_VIDEO_FORMAT_ARGB = 13,
+  GSTAMD_VIDEO_FORMAT_ABGR = 14,
+  GSTAMD_VIDEO_FORMAT_Y42B = 18,
+  GSTAMD_VIDEO_FORMAT_Y444 = 20,
+  GSTAMD_VIDEO_FORMAT_NV12 = 23,
+  GSTAMD_VIDEO_FORMAT_NV21 = 24
+};
+
+enum { GSTAMD_COLOR_RANGE_UNKNOWN = 0, GSTAMD_COLOR_RANGE_0_255 = 1, GSTAMD_COLOR_RANGE_16_235 = 2 };
+enum {
+  GSTAMD_COLOR_MATRIX_UNKNOWN = 0, GSTAMD_COLOR_MATRIX_RGB = 1, GSTAMD_COLOR_MATRIX_FCC = 2,
+  GSTAMD_COLOR_MATRIX_BT709 = 3, GSTAMD_COLOR_MATRIX_BT601 = 4, GSTAMD_COLOR_MATRIX_SMPTE240M = 5,
+  GSTAMD_COLOR_MATRIX_BT2020 = 6
+};
+enum {
+  GSTAMD_CHROMA_SITE_UNKNOWN = 0, GSTAMD_CHROMA_SITE_NONE = 1, GSTAMD_CHROMA_SITE_H_COSITED = 2,
+  GSTAMD_CHROMA_SITE_V_COSITED = 4, GSTAMD_CHROMA_SITE_ALT_LINE = 8
+};
+enum {
+  GSTAMD_RESAMPLER_METHOD_NEAREST = 0, GSTAMD_RESAMPLER_METHOD_LINEAR = 1,
+  GSTAMD_RESAMPLER_METHOD_CUBIC = 2, GSTAMD_RESAMPLER_METHOD_SINC = 3,
+  GSTAMD_RESAMPLER_METHOD_LANCZOS = 4
+};
+enum { GSTAMD_ALPHA_MODE_COPY = 0, GSTAMD_ALPHA_MODE_SET = 1, GSTAMD_ALPHA_MODE_MULT = 2 };
+enum {
+  GSTAMD_CHROMA_MODE_FULL = 0, GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY = 1,
+  GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY = 2, GSTAMD_CHROMA_MODE_NONE = 3
+};
+enum {
+  GSTAMD_MATRIX_MODE_FULL = 0, GSTAMD_MATRIX_MODE_INPUT_ONLY = 1,
+  GSTAMD_MATRIX_MODE_OUTPUT_ONLY = 2, GSTAMD_MATRIX_MODE_NONE = 3
+};
+
+/* status codes (0 = ok).  The library never falls back to a CPU path: a conversion it does not
+ * implement on the GPU is refused with GSTAMD_ERR_UNSUPPORTED, mirroring the reference returning
+ * NULL from gst_video_converter_new for an impossible conversion (video-converter.c:2543-2562). */
+enum {
+  GSTAMD_OK = 0,
+  GSTAMD_ERR_INVALID = -1,
+  GSTAMD_ERR_UNSUPPORTED = -2,
+  GSTAMD_ERR_HIP = -3
+};
+
+/* Mirror of the GstVideoInfo fields the converter reads (video-info.h:400-440). */
+typedef struct GstAmdVideoInfo {
+  int32_t format;                               /* GSTAMD_VIDEO_FORMAT_* */
+  int32_t width, height;
+  int32_t n_planes;
+  int32_t stride[GSTAMD_VIDEO_MAX_PLANES];      /* pitch in bytes */
+  uint64_t offset[GSTAMD_VIDEO_MAX_PLANES];     /* plane offsets from the frame base */
+  uint64_t size;                                /* total frame bytes for the default layout */
+  int32_t color_range;                          /* GstVideoColorRange */
+  int32_t color_matrix;                         /* GstVideoColorMatrix */
+  int32_t chroma_site;                          /* GstVideoChromaSite flags */
+  int32_t reserved[5];
+} GstAmdVideoInfo;
+
+/* Mirror of the GstVideoConverter option keys (video-converter.h:34-286) that this
+ * implementation honours; gstamd_video_converter_config_init() sets the library defaults of
+ * video-converter.c:778-796 (NB: resampler-method CUBIC; the videoconvertscale element itself
+ * defaults to LINEAR with max-taps 2, gstvideoconvertscale.c:1000-1005). */
+typedef struct GstAmdVideoConverterConfig {
+  int32_t resampler_method;      /* GstVideoConverter.resampler-method */
+  uint32_t resampler_taps;       /* GstVideoConverter.resampler-taps (0 = auto) */
+  int32_t max_taps;              /* GstVideoResampler.max-taps (default 128) */
+  double envelope;               /* GstVideoResampler.envelope (2.0) */
+  double sharpness;              /* GstVideoResampler.sharpness (1.0) */
+  double sharpen;                /* GstVideoResampler.sharpen (0.0) */
+  double cubic_b, cubic_c;       /* GstVideoResampler.cubic-b/-c (1/3, 1/3) */
+  int32_t alpha_mode;            /* GstVideoConverter.alpha-mode */
+  double alpha_value;            /* GstVideoConverter.alpha-value (1.0) */
+  int32_t chroma_mode;           /* GstVideoConverter.chroma-mode */
+  int32_t matrix_mode;           /* GstVideoConverter.matrix-mode */
+  uint32_t dither_quantization;  /* GstVideoConverter.dither-quantization (1) */
+  int32_t reserved[8];
+} GstAmdVideoConverterConfig;
+
+typedef struct GstAmdVideoConverter GstAmdVideoConverter;
+
+/* Fill `info` like the elements do: gst_video_info_set_format's default pitch-linear layout plus
+ * the caps defaults (colorimetry by height, chroma-site by height).  Returns GSTAMD_OK or an error. */
+int gstamd_video_info_set_format (GstAmdVideoInfo *info, int format, int width, int height);
+
+void gstamd_video_converter_config_init (GstAmdVideoConverterConfig *config);
+
+/* Plan a conversion.  `config` may be NULL (library defaults).  On failure returns NULL and, when
+ * `status` is non-NULL, stores the reason there. */
+GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info,
+    const GstAmdVideoInfo *out_info, const GstAmdVideoConverterConfig *config, int *status);
+
+/* Convert one frame.  `src`/`dest` are device pointers to the frame base (planes are found
+ * through info.offset[] / info.stride[]).  Enqueues on `stream`; does not synchronise. */
+int gstamd_video_converter_frame (GstAmdVideoConverter *convert, const void *src, void *dest,
+    void *stream);
+
+/* Same with one device pointer per plane (what a GstVideoFrame carries in data[] after a
+ * device map) and explicit pitches overriding the infos'. */
+int gstamd_video_converter_frame_planes (GstAmdVideoConverter *convert,
+    const void *const src_planes[GSTAMD_VIDEO_MAX_PLANES], const int32_t src_stride[GSTAMD_VIDEO_MAX_PLANES],
+    void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES], const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES],
+    void *stream);
+
+void gstamd_video_converter_free (GstAmdVideoConverter *convert);
+
+/* Introspection used by tests / bench: name of the kernel plan chosen ("fused_convert",
+ * "front+hscale+vscale_back", ...) and algorithmic bytes per frame (source planes read once +
+ * destination written once). */
+const char *gstamd_video_converter_describe (const GstAmdVideoConverter *convert);
+uint64_t gstamd_video_converter_algorithmic_bytes (const GstAmdVideoConverter *convert);
+
+/* ---- compositor ----------------------------------------------------------------------- */
+
+enum { GSTAMD_COMPOSITOR_BLEND_MODE_SOURCE = 0, GSTAMD_COMPOSITOR_BLEND_MODE_OVER = 1,
+  GSTAMD_COMPOSITOR_BLEND_MODE_ADD = 2 };       /* GstCompositorBlendMode, blend.h:35-40 */
+enum { GSTAMD_COMPOSITOR_BACKGROUND_CHECKER = 0, GSTAMD_COMPOSITOR_BACKGROUND_BLACK = 1,
+  GSTAMD_COMPOSITOR_BACKGROUND_WHITE = 2, GSTAMD_COMPOSITOR_BACKGROUND_TRANSPARENT = 3 };
+                                                /* GstCompositorBackground, compositor.h */
+
+/* One BlendFunction call (blend.h:50): composite `src` (sw x sh, pitch sstride) at (xpos,ypos) with
+ * pad alpha `src_alpha` onto `dest` rows [dst_y_start, dst_y_end).  format: BGRA/RGBA ("bgra"
+ * family, alpha in byte 3) or ARGB/ABGR/AYUV (alpha in byte 0).  `overlay` selects the
+ * gst_compositor_overlay_* variant used on a transparent background (compositor.c:850-854). */
+int gstamd_compositor_blend (int format, int overlay, const void *src, int sw, int sh, int sstride,
+    int xpos, int ypos, double src_alpha, void *dest, int dw, int dh, int dstride,
+    int dst_y_start, int dst_y_end, int mode, void *stream);
+
+/* FillCheckerFunction / FillColorFunction (blend.h:51-52) on rows [y_start, y_end). */
+int gstamd_compositor_fill_checker (int format, void *dest, int dw, int dh, int dstride,
+    int y_start, int y_end, void *stream);
+int gstamd_compositor_fill_color (int format, void *dest, int dw, int dh, int dstride,
+    int y_start, int y_end, int c1, int c2, int c3, void *stream);
+
+typedef struct GstAmdCompositorPad {
+  const void *data;             /* device pointer, same format as the output */
+  int32_t width, height, stride;
+  int32_t xpos, ypos;
+  double alpha;                 /* pad alpha 0..1 */
+  int32_t blend_mode;           /* per-pad operator -> GstCompositorBlendMode */
+  int32_t reserved;
+} GstAmdCompositorPad;
+
+/* Whole aggregate step of one output frame = _draw_background + blend_pads loop
+ * (compositor.c:1619-1697, 1739-1870) in ONE fused pass over the canvas: every output pixel is
+ * written once, pads are applied in array order (= zorder) in registers.  Result is identical
+ * to calling fill + gstamd_compositor_blend per pad. */
+int gstamd_compositor_aggregate (int format, int background, const GstAmdCompositorPad *pads,
+    int n_pads, void *dest, int dw, int dh, int dstride, void *stream);
+
+/* ---- device memory helpers (thin wrappers so non-HIP hosts can manage HBM) -------------- */
+void *gstamd_device_alloc (size_t size);
+void gstamd_device_free (void *ptr);
+int gstamd_device_upload (void *dst_device, const void *src_host, size_t size, void *stream);
+int gstamd_device_download (void *dst_host, const void *src_device, size_t size, void *stream);
+int gstamd_stream_synchronize (void *stream);
+int gstamd_device_count (void);
+int gstamd_set_device (int device);
+const char *gstamd_last_error (void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSTAMD_VIDEO_H */

@@ -1,0 +1,202 @@
+"""ctypes binding of oracle/_ref/libgstref.so - the REFERENCE's own code (built by oracle/ref_build.py).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke().
+The product package (gstreamer_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_ref", "libgstref.so")
+
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(LIB_PATH)
+        L.ref_init.restype = C.c_int
+        L.ref_video_info.restype = C.c_int
+        L.ref_video_info.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t),
+                                     C.POINTER(C.c_size_t), C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.ref_video_converter_new.restype = C.c_void_p
+        L.ref_video_converter_new.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p,
+                                              C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p,
+                                              C.c_char_p]
+        L.ref_video_converter_frame.restype = C.c_int
+        L.ref_video_converter_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ref_video_converter_bench.restype = C.c_double
+        L.ref_video_converter_bench.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        L.ref_video_converter_free.argtypes = [C.c_void_p]
+        L.ref_compositor_blend.restype = C.c_int
+        L.ref_compositor_blend.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int]
+        L.ref_compositor_fill.restype = C.c_int
+        L.ref_compositor_fill.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_audio_resampler_new.restype = C.c_void_p
+        L.ref_audio_resampler_new.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+        for n in ("get_out_frames", "get_in_frames"):
+            f = getattr(L, "ref_audio_resampler_" + n)
+            f.restype = C.c_size_t
+            f.argtypes = [C.c_void_p, C.c_size_t]
+        L.ref_audio_resampler_get_max_latency.restype = C.c_size_t
+        L.ref_audio_resampler_get_max_latency.argtypes = [C.c_void_p]
+        L.ref_audio_resampler_resample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ref_audio_resampler_reset.argtypes = [C.c_void_p]
+        L.ref_audio_resampler_free.argtypes = [C.c_void_p]
+        L.ref_init()
+        _lib = L
+    return _lib
+
+
+def _b(s):
+    return s.encode() if isinstance(s, str) and s else None
+
+
+def video_info(fmt, w, h):
+    """Default layout + caps defaults as the reference negotiates them."""
+    stride = (C.c_int * 4)()
+    off = (C.c_size_t * 4)()
+    size = C.c_size_t()
+    col = C.create_string_buffer(64)
+    chroma = C.create_string_buffer(64)
+    n = lib().ref_video_info(fmt.encode(), w, h, stride, off, C.byref(size), col, 64, chroma, 64)
+    if n < 0:
+        raise ValueError("reference rejects %s %dx%d" % (fmt, w, h))
+    return dict(n_planes=n, stride=list(stride), offset=list(off), size=size.value,
+                colorimetry=col.value.decode(), chroma_site=chroma.value.decode())
+
+
+def config_string(**opts):
+    """Serialise converter options the way gst_structure_from_string wants them.
+
+    Keys use '_' for '-' and '__' for '.': e.g. GstVideoConverter__resampler_method='lanczos'."""
+    types = {
+        "GstVideoConverter.resampler-method": "GstVideoResamplerMethod",
+        "GstVideoConverter.chroma-resampler-method": "GstVideoResamplerMethod",
+        "GstVideoConverter.dither-method": "GstVideoDitherMethod",
+        "GstVideoConverter.alpha-mode": "GstVideoAlphaMode",
+        "GstVideoConverter.chroma-mode": "GstVideoChromaMode",
+        "GstVideoConverter.matrix-mode": "GstVideoMatrixMode",
+        "GstVideoConverter.gamma-mode": "GstVideoGammaMode",
+        "GstVideoConverter.primaries-mode": "GstVideoPrimariesMode",
+    }
+    parts = ["GstVideoConverter"]
+    for k, v in opts.items():
+        key = k.replace("__", ".").replace("_", "-")
+        if key in types:
+            parts.append("%s=(%s)%s" % (key, types[key], v))
+        elif isinstance(v, bool):
+            parts.append("%s=(boolean)%s" % (key, "true" if v else "false"))
+        elif isinstance(v, float):
+            parts.append("%s=(double)%r" % (key, v))
+        elif key.endswith("threads") or key.endswith("resampler-taps") or key.endswith("quantization"):
+            parts.append("%s=(uint)%d" % (key, v))
+        else:
+            parts.append("%s=(int)%d" % (key, v))
+    return ", ".join(parts)
+
+
+class VideoConverter:
+    """gst_video_converter_new/frame of the reference on host numpy buffers."""
+
+    def __init__(self, in_fmt, in_w, in_h, out_fmt, out_w, out_h, in_colorimetry=None, in_chroma_site=None,
+                 out_colorimetry=None, out_chroma_site=None, config=None):
+        self.h = lib().ref_video_converter_new(_b(in_fmt), in_w, in_h, _b(in_colorimetry), _b(in_chroma_site), None, None,
+                                               _b(out_fmt), out_w, out_h, _b(out_colorimetry), _b(out_chroma_site), None,
+                                               None, _b(config))
+        if not self.h:
+            raise ValueError("reference could not create converter")
+        self.in_info = video_info(in_fmt, in_w, in_h)
+        self.out_info = video_info(out_fmt, out_w, out_h)
+
+    def frame(self, src):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        assert src.size == self.in_info["size"], (src.size, self.in_info["size"])
+        dst = np.zeros(self.out_info["size"], dtype=np.uint8)
+        r = lib().ref_video_converter_frame(self.h, src.ctypes.data, src.size, dst.ctypes.data, dst.size)
+        assert r == 0
+        return dst
+
+    def bench(self, src, n_frames):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.zeros(self.out_info["size"], dtype=np.uint8)
+        return lib().ref_video_converter_bench(self.h, src.ctypes.data, src.size, dst.ctypes.data, dst.size, n_frames)
+
+    def close(self):
+        if self.h:
+            lib().ref_video_converter_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def compositor_blend(func, fmt, src, sw, sh, xpos, ypos, alpha, dst, dw, dh, y0, y1, mode):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    assert dst.flags["C_CONTIGUOUS"] and dst.dtype == np.uint8
+    r = lib().ref_compositor_blend(func.encode(), fmt.encode(), src.ctypes.data, src.size, sw, sh, xpos, ypos, float(alpha),
+                                   dst.ctypes.data, dst.size, dw, dh, y0, y1, mode)
+    assert r == 0, r
+    return dst
+
+
+def compositor_fill(kind, fmt_func, fmt, dst, dw, dh, y0, y1, c1=0, c2=0, c3=0):
+    r = lib().ref_compositor_fill(kind, fmt_func.encode(), fmt.encode(), dst.ctypes.data, dst.size, dw, dh, y0, y1, c1, c2, c3)
+    assert r == 0, r
+    return dst
+
+
+class AudioResampler:
+    """gst_audio_resampler_* of the reference (interleaved in/out)."""
+    METHODS = {"nearest": 0, "linear": 1, "cubic": 2, "blackman-nuttall": 3, "kaiser": 4}
+
+    def __init__(self, fmt, channels, in_rate, out_rate, method="kaiser", quality=4, options=None):
+        self.channels = channels
+        self.fmt = fmt
+        self.dtype = {"F32LE": np.float32, "F64LE": np.float64, "S16LE": np.int16, "S32LE": np.int32}[fmt]
+        self.h = lib().ref_audio_resampler_new(self.METHODS[method], 0, fmt.encode(), channels, in_rate, out_rate, quality,
+                                               _b(options))
+        if not self.h:
+            raise ValueError("reference could not create resampler")
+
+    def get_out_frames(self, in_frames):
+        return lib().ref_audio_resampler_get_out_frames(self.h, in_frames)
+
+    def get_in_frames(self, out_frames):
+        return lib().ref_audio_resampler_get_in_frames(self.h, out_frames)
+
+    def get_max_latency(self):
+        return lib().ref_audio_resampler_get_max_latency(self.h)
+
+    def resample(self, data, in_frames=None, out_frames=None):
+        """data: interleaved [frames, channels] array or None (silence / drain)."""
+        if data is not None:
+            data = np.ascontiguousarray(data, dtype=self.dtype)
+            in_frames = data.size // self.channels
+        if out_frames is None:
+            out_frames = self.get_out_frames(in_frames)
+        out = np.zeros((out_frames, self.channels), dtype=self.dtype)
+        lib().ref_audio_resampler_resample(self.h, data.ctypes.data if data is not None else None, in_frames,
+                                           out.ctypes.data, out_frames)
+        return out
+
+    def reset(self):
+        lib().ref_audio_resampler_reset(self.h)
+
+    def close(self):
+        if self.h:
+            lib().ref_audio_resampler_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

@@ -1,0 +1,109 @@
+// tests/emu/emu_video.cpp - TEST INFRASTRUCTURE: runs the product's kernel BODIES
+// (gstreamer_amd/csrc/video_device.h) over the launch grid on the host CPU, so the kernel logic and
+// the planner can be checked against the oracle in this GPU-less container.  Not linked into the
+// product, never used as a fallback.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../gstreamer_amd/csrc/planner.h"
+#include "../../gstreamer_amd/csrc/video_device.h"
+
+using namespace gstamd;
+
+template <class SRC>
+static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h)
+{
+  for (int y = 0; y < out_h; y++)
+    for (int x = 0; x < out_w; x++) {
+      if (horizontal)
+        hscale_body<SRC> (src, sd, d, out_w, out_h, x, y);
+      else
+        vscale_body<SRC> (src, sd, d, out_w, out_h, x, y);
+    }
+}
+
+extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
+    const GstAmdVideoConverterConfig *cfg, const uint8_t *src, uint8_t *dst, int vec_ok, char *desc, int desc_len)
+{
+  VideoPlan p;
+  std::string err;
+  int r = plan_video_converter (in, out, cfg, &p, &err);
+  if (r != GSTAMD_OK) {
+    if (desc)
+      strncpy (desc, err.c_str (), desc_len - 1);
+    return r;
+  }
+  if (desc)
+    strncpy (desc, p.description.c_str (), desc_len - 1);
+  Planes pl;
+  memset (&pl, 0, sizeof (pl));
+  for (int i = 0; i < in->n_planes; i++) {
+    pl.p[i] = src + in->offset[i];
+    pl.stride[i] = in->stride[i];
+  }
+  ColorParams color, none;
+  memset (&none, 0, sizeof (none));
+  color.matrix = p.matrix;
+  color.alpha_kind = p.post.alpha_kind;
+  color.alpha_value = p.post.alpha_value;
+  const int *vpair = p.vpair.data ();
+  uint8_t *d0 = dst + out->offset[0];
+  const int dstride = out->stride[0];
+  if (p.passes.empty ()) {
+    const int spans = (p.front.width + K1_PX - 1) / K1_PX;
+    for (int y = 0; y < p.front.height; y++)
+      for (int s = 0; s < spans; s++) {
+        const int *pp = p.post.pack_pos;
+        switch (p.front.chroma_h) {
+          case CHROMA_H_H2_CS:
+            convert_body<CHROMA_H_H2_CS> (p.front, pl, vpair, color, pp[0], pp[1], pp[2], pp[3], d0, dstride, spans, vec_ok, s, y);
+            break;
+          case CHROMA_H_H2:
+            convert_body<CHROMA_H_H2> (p.front, pl, vpair, color, pp[0], pp[1], pp[2], pp[3], d0, dstride, spans, vec_ok, s, y);
+            break;
+          default:
+            convert_body<CHROMA_H_NONE> (p.front, pl, vpair, color, pp[0], pp[1], pp[2], pp[3], d0, dstride, spans, vec_ok, s, y);
+            break;
+        }
+      }
+    return GSTAMD_OK;
+  }
+  const ColorParams &pre = p.matrix_before_scale ? color : none;
+  const ColorParams &post = p.matrix_before_scale ? none : color;
+  ScaleDev sd[2];
+  for (size_t i = 0; i < p.passes.size (); i++) {
+    sd[i].kind = p.passes[i].kind;
+    sd[i].n_taps = p.passes[i].n_taps;
+    sd[i].inc = p.passes[i].inc;
+    sd[i].offset = p.passes[i].offset.data ();
+    sd[i].taps = p.passes[i].taps.data ();
+  }
+  SrcFront sf;
+  sf.f = p.front;
+  sf.pl = pl;
+  sf.vpair = vpair;
+  sf.pre = pre;
+  auto mk = [&](uint8_t *ptr, int stride, bool fin) {
+    Dst d;
+    d.p = ptr;
+    d.stride = stride;
+    d.final = fin;
+    d.post = fin ? post : none;
+    memcpy (d.pack_pos, p.post.pack_pos, sizeof (d.pack_pos));
+    return d;
+  };
+  if (p.passes.size () == 1) {
+    run_scale (p.passes[0].horizontal, sf, sd[0], mk (d0, dstride, true), out->width, out->height);
+    return GSTAMD_OK;
+  }
+  const ScalePass &s0 = p.passes[0];
+  const int tw = s0.horizontal ? s0.out_size : in->width, th = s0.horizontal ? in->height : s0.out_size;
+  std::vector<uint8_t> tmp ((size_t) tw * 4 * th);
+  run_scale (s0.horizontal, sf, sd[0], mk (tmp.data (), tw * 4, false), tw, th);
+  SrcImage si;
+  si.p = tmp.data ();
+  si.stride = tw * 4;
+  run_scale (p.passes[1].horizontal, si, sd[1], mk (d0, dstride, true), out->width, out->height);
+  return GSTAMD_OK;
+}

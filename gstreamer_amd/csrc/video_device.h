@@ -354,12 +354,24 @@ GSTAMD_HD void convert_body (const FrontParams &f, const Planes &pl, const int *
 // ------------------------------------------------------------------------------------------------
 // scaler kernels: one lane per output pixel, x fastest
 // ------------------------------------------------------------------------------------------------
+// (acc + 32) as int16, arithmetic >> 6, unsigned saturate to a byte.
+// NB gfx950: hipcc (ROCm 7.2) fuses "clamp (x >> n, 0, 255)" pairs into v_ashr_pk_u8_i32, whose second
+// lane came back wrong on MI355X for this pattern (first GPU run, 2 of 4 channels off).  The opaque
+// register barrier keeps shift and saturate as separate VALU ops.
+GSTAMD_HD int lq_round (int acc)
+{
+  int v = ((int) (int16_t) (uint16_t) (acc + 32)) >> 6;
+#ifdef __HIPCC__
+  asm volatile ("" : "+v" (v));
+#endif
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
 GSTAMD_HD uint32_t lq_finish (int a0, int a1, int a2, int a3)
 {
   // addw 32 (wrap), shrsw 6, convsuswb
-  const int r0 = clampi (((int) (int16_t) (a0 + 32)) >> 6, 0, 255), r1 = clampi (((int) (int16_t) (a1 + 32)) >> 6, 0, 255);
-  const int r2 = clampi (((int) (int16_t) (a2 + 32)) >> 6, 0, 255), r3 = clampi (((int) (int16_t) (a3 + 32)) >> 6, 0, 255);
-  return (uint32_t) r0 | ((uint32_t) r1 << 8) | ((uint32_t) r2 << 16) | ((uint32_t) r3 << 24);
+  return (uint32_t) lq_round (a0) | ((uint32_t) lq_round (a1) << 8) | ((uint32_t) lq_round (a2) << 16) |
+      ((uint32_t) lq_round (a3) << 24);
 }
 
 template <class SRC>

@@ -1,0 +1,115 @@
+"""Shared parity case list + deterministic synthetic frames (xorshift64* seeds)."""
+import hashlib
+
+import numpy as np
+
+MASK = (1 << 64) - 1
+
+
+def xorshift_bytes(seed, n):
+    """xorshift64* byte stream, vectorised by running 4096 independent lanes (deterministic)."""
+    lanes = 4096
+    s = (np.arange(lanes, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed | 1)) | np.uint64(1)
+    out = np.empty(((n + 8 * lanes - 1) // (8 * lanes), lanes), dtype=np.uint64)
+    for i in range(out.shape[0]):
+        s ^= s >> np.uint64(12)
+        s ^= s << np.uint64(25)
+        s ^= s >> np.uint64(27)
+        out[i] = s * np.uint64(0x2545F4914F6CDD1D)
+    return out.reshape(-1).view(np.uint8)[:n].copy()
+
+
+def frame_bytes(size, pattern, seed, width=0):
+    if pattern == "random":
+        return xorshift_bytes(0x9E3779B97F4A7C15 ^ seed, size)
+    if pattern == "zeros":
+        return np.zeros(size, np.uint8)
+    if pattern == "ones":
+        return np.full(size, 255, np.uint8)
+    if pattern == "c16":
+        return np.full(size, 16, np.uint8)
+    if pattern == "c235":
+        return np.full(size, 235, np.uint8)
+    if pattern == "ramp":
+        return (np.arange(size, dtype=np.uint64) % 256).astype(np.uint8)
+    if pattern == "checker":
+        return ((np.arange(size, dtype=np.uint64) & 1) * 255).astype(np.uint8)
+    raise ValueError(pattern)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+LIN = dict(resampler_method="linear", max_taps=2)          # what the videoconvertscale element sets by default
+LAN = dict(resampler_method="lanczos")
+NEAR = dict(resampler_method="nearest")
+
+# (name, in_fmt, w, h, out_fmt, ow, oh, cfg, in_colorimetry, in_chroma_site, pattern)
+VIDEO_CASES = [
+    ("nv12_bgra_2x2", "NV12", 2, 2, "BGRA", 2, 2, {}, None, None, "random"),
+    ("nv12_rgba_3x3", "NV12", 3, 3, "RGBA", 3, 3, {}, None, None, "random"),
+    ("nv12_bgra_322x241", "NV12", 322, 241, "BGRA", 322, 241, {}, None, None, "random"),
+    ("nv12_bgra_322x241_bt709", "NV12", 322, 241, "BGRA", 322, 241, {}, "bt709", None, "random"),
+    ("nv12_bgra_640x360_mpeg2", "NV12", 640, 360, "BGRA", 640, 360, {}, None, "mpeg2", "random"),
+    ("nv12_bgra_640x360_cosited", "NV12", 640, 360, "BGRA", 640, 360, {}, None, "cosited", "random"),
+    ("nv12_bgra_1280x720", "NV12", 1280, 720, "BGRA", 1280, 720, {}, None, None, "random"),
+    ("nv12_bgra_1280x720_bt601", "NV12", 1280, 720, "BGRA", 1280, 720, {}, "bt601", None, "random"),
+    ("nv12_bgra_1280x720_jpeg", "NV12", 1280, 720, "BGRA", 1280, 720, {}, None, "jpeg", "random"),
+    ("nv12_bgra_1919x1079", "NV12", 1919, 1079, "BGRA", 1919, 1079, {}, None, None, "random"),
+    ("nv12_bgra_1080p", "NV12", 1920, 1080, "BGRA", 1920, 1080, {}, None, None, "random"),
+    ("nv12_bgra_1080p_ramp", "NV12", 1920, 1080, "BGRA", 1920, 1080, {}, None, None, "ramp"),
+    ("nv12_bgra_1080p_checker", "NV12", 1920, 1080, "BGRA", 1920, 1080, {}, None, None, "checker"),
+    ("nv12_bgra_720p_zeros", "NV12", 1280, 720, "BGRA", 1280, 720, {}, None, None, "zeros"),
+    ("nv12_bgra_720p_ones", "NV12", 1280, 720, "BGRA", 1280, 720, {}, None, None, "ones"),
+    ("nv12_bgra_720p_c16", "NV12", 1280, 720, "BGRA", 1280, 720, {}, None, None, "c16"),
+    ("nv12_bgra_720p_c235", "NV12", 1280, 720, "BGRA", 1280, 720, {}, None, None, "c235"),
+    ("nv21_abgr_130x70", "NV21", 130, 70, "ABGR", 130, 70, {}, None, None, "random"),
+    ("nv12_argb_640x360", "NV12", 640, 360, "ARGB", 640, 360, {}, None, None, "random"),
+    ("nv12_xrgb_640x360", "NV12", 640, 360, "xRGB", 640, 360, {}, None, None, "random"),
+    ("nv12_bgrx_alpha_set", "NV12", 320, 240, "BGRA", 320, 240, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+    ("y42b_bgra_322x241", "Y42B", 322, 241, "BGRA", 322, 241, {}, None, None, "random"),
+    ("y444_rgba_322x241", "Y444", 322, 241, "RGBA", 322, 241, {}, None, None, "random"),
+    ("bgra_rgba_100x60", "BGRA", 100, 60, "RGBA", 100, 60, {}, None, None, "random"),
+    ("rgba_ayuv_100x60", "RGBA", 100, 60, "AYUV", 100, 60, {}, None, None, "random"),
+    ("nv12_ayuv_100x60", "NV12", 100, 60, "AYUV", 100, 60, {}, None, None, "random"),
+    ("ayuv_bgra_mult", "AYUV", 100, 60, "BGRA", 100, 60, dict(alpha_mode="mult", alpha_value=0.3), None, None, "random"),
+    # scaling (generic path; chain_scale ordering, tap tables, chroma pairing under line skipping)
+    ("nv12_bgra_half_cubic", "NV12", 640, 360, "BGRA", 320, 180, {}, None, None, "random"),
+    ("nv12_bgra_half_bilinear", "NV12", 640, 360, "BGRA", 320, 180, LIN, None, None, "random"),
+    ("nv12_bgra_quarter_bilinear", "NV12", 640, 360, "BGRA", 160, 90, LIN, None, None, "random"),
+    ("nv12_bgra_third_bilinear", "NV12", 640, 360, "BGRA", 213, 120, LIN, None, None, "random"),
+    ("nv12_bgra_quarter_lanczos", "NV12", 640, 360, "BGRA", 160, 90, LAN, None, None, "random"),
+    ("i420_rgba_quarter_lanczos", "I420", 640, 360, "RGBA", 160, 90, LAN, None, None, "random"),
+    ("i420_rgba_1080p_to_270p_lanczos", "I420", 1920, 1080, "RGBA", 480, 270, LAN, None, None, "random"),
+    ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
+    ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
+    ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),
+    ("nv12_bgra_anamorphic_nearest", "NV12", 321, 181, "BGRA", 100, 300, NEAR, None, None, "random"),
+    ("nv12_bgra_vfirst_bilinear", "NV12", 320, 180, "BGRA", 640, 100, LIN, None, None, "random"),
+    ("y42b_bgra_vfirst_lanczos", "Y42B", 320, 180, "BGRA", 640, 100, LAN, None, None, "random"),
+    ("bgra_rgba_half_lanczos", "BGRA", 200, 100, "RGBA", 100, 50, LAN, None, None, "random"),
+    ("bgra_ayuv_mixed_lanczos", "BGRA", 200, 100, "AYUV", 300, 50, LAN, None, None, "random"),
+    ("y444_bgra_nonint_lanczos", "Y444", 320, 180, "BGRA", 333, 177, LAN, None, None, "random"),
+]
+
+# conversions the reference runs through code this library has no kernel for -> must be REFUSED
+VIDEO_REFUSED = [
+    ("I420", 322, 241, "BGRA", 322, 241, {}),            # convert_I420_BGRA fastpath
+    ("BGRA", 200, 100, "BGRA", 100, 50, LAN),            # convert_scale_planes fastpath
+    ("AYUV", 64, 64, "ARGB", 64, 64, {}),                # convert_AYUV_ARGB fastpath
+    ("NV12", 320, 180, "BGRA", 640, 100, LAN),           # reference temp-line aliasing (see planner.cpp)
+    ("NV12", 64, 64, "NV12", 32, 32, {}),                # planar output not implemented
+]
+
+
+def ref_config_string(ref, cfg):
+    m = {}
+    for k, v in cfg.items():
+        if k == "max_taps":
+            m["GstVideoResampler__max_taps"] = v
+        elif k in ("envelope", "sharpness", "sharpen"):
+            m["GstVideoResampler__" + k] = float(v)
+        else:
+            m["GstVideoConverter__" + k] = v
+    return ref.config_string(**m) if m else None

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/video_golden.json from the REFERENCE itself (oracle/_ref, built from
+/root/reference by oracle/ref_build.py).  Run in the build container:  python tests/golden/make_golden.py
+
+For every case of tests/cases.py it stores the sha256 of the reference's output for the seeded
+synthetic input (inputs are regenerated from the seed at test time, so only hashes are stored),
+plus the first 64 output bytes for eyeballing."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import cases  # noqa: E402
+from oracle import ref  # noqa: E402
+
+
+def main():
+    out = {}
+    for i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) in enumerate(cases.VIDEO_CASES):
+        ii = ref.video_info(ifmt, w, h)
+        src = cases.frame_bytes(ii["size"], pattern, 1000 + i, w)
+        rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site,
+                                config=cases.ref_config_string(ref, cfg))
+        dst = rc.frame(src)
+        out[name] = dict(sha256=cases.sha(dst), head=[int(x) for x in dst[:64]], in_sha256=cases.sha(src), size=int(dst.size))
+        print(name, out[name]["sha256"][:16])
+    with open(os.path.join(ROOT, "tests", "golden", "video_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

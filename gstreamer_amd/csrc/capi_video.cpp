@@ -7,10 +7,12 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/gstamd_video.h"
 #include "planner.h"
 #include "video_kernels.h"
+#include "video_fast.h"
 
 using namespace gstamd;
 
@@ -41,6 +43,25 @@ struct GstAmdVideoConverter {
   size_t tmp_size = 0;
   int tmp_w = 0, tmp_h = 0;
 };
+
+static bool fast_pair_usable (const VideoPlan &p, const Planes &pl, const uint8_t *dst, int dstride)
+{
+  return p.passes.empty () && p.fast_pair && ((uintptr_t) dst % 16) == 0 && (dstride % 16) == 0 &&
+      ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0 && ((uintptr_t) pl.p[1] % 4) == 0 && (pl.stride[1] % 4) == 0;
+}
+
+static FastParams make_fast_params (const VideoPlan &p)
+{
+  FastParams fp;
+  fp.width = p.front.width;
+  fp.height = p.front.height;
+  for (int i = 0; i < 5; i++)
+    fp.p8[i] = p.matrix.p[i] * 256;
+  fp.pack_sel = (0x0du << (8 * p.post.pack_pos[0])) | (0x00u << (8 * p.post.pack_pos[1])) |
+      (0x01u << (8 * p.post.pack_pos[2])) | (0x04u << (8 * p.post.pack_pos[3]));
+  fp.u_first = p.front.u_plane;
+  return fp;
+}
 
 extern "C" {
 
@@ -144,6 +165,12 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
   color.alpha_kind = p.post.alpha_kind;
   color.alpha_value = p.post.alpha_value;
   hipError_t e;
+  if (fast_pair_usable (p, pl, dst, dstride)) {
+    const FastParams fp = make_fast_params (p);
+    const uint8_t *y = pl.p[0], *uv = pl.p[1];
+    e = launch_convert_pair (fp, p.front.chroma_h, 1, &y, &uv, &dst, pl.stride[0], pl.stride[1], dstride, stream);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair");
+  }
   if (p.passes.empty ()) {
     e = launch_convert (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert");
@@ -185,6 +212,48 @@ int gstamd_video_converter_frame (GstAmdVideoConverter *c, const void *src, void
   for (int i = 0; i < c->plan.out_info.n_planes; i++)
     dp[i] = (uint8_t *) dest + c->plan.out_info.offset[i];
   return gstamd_video_converter_frame_planes (c, sp, nullptr, dp, nullptr, stream);
+}
+
+int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const void *const *src, void *const *dest, void *stream_)
+{
+  if (!c || n_frames < 0 || (n_frames > 0 && (!src || !dest)))
+    return set_error (GSTAMD_ERR_INVALID, "NULL converter or frame list");
+  if (n_frames == 0)
+    return GSTAMD_OK;
+  const VideoPlan &p = c->plan;
+  int r = ensure_tables (c);
+  if (r != GSTAMD_OK)
+    return r;
+  /* one launch for the whole list when the line-pair kernel applies to every frame */
+  bool all_fast = true;
+  std::vector<const uint8_t *> y (n_frames), uv (n_frames);
+  std::vector<uint8_t *> d (n_frames);
+  for (int i = 0; i < n_frames && all_fast; i++) {
+    if (!src[i] || !dest[i])
+      return set_error (GSTAMD_ERR_INVALID, "NULL frame in list");
+    Planes pl;
+    memset (&pl, 0, sizeof (pl));
+    pl.p[0] = (const uint8_t *) src[i] + p.in_info.offset[0];
+    pl.p[1] = (const uint8_t *) src[i] + p.in_info.offset[1];
+    pl.stride[0] = p.in_info.stride[0];
+    pl.stride[1] = p.in_info.stride[1];
+    d[i] = (uint8_t *) dest[i] + p.out_info.offset[0];
+    all_fast = fast_pair_usable (p, pl, d[i], p.out_info.stride[0]);
+    y[i] = pl.p[0];
+    uv[i] = pl.p[1];
+  }
+  if (all_fast) {
+    const FastParams fp = make_fast_params (p);
+    hipError_t e = launch_convert_pair (fp, p.front.chroma_h, n_frames, y.data (), uv.data (), d.data (), p.in_info.stride[0],
+        p.in_info.stride[1], p.out_info.stride[0], (hipStream_t) stream_);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair(batch)");
+  }
+  for (int i = 0; i < n_frames; i++) {
+    r = gstamd_video_converter_frame (c, src[i], dest[i], stream_);
+    if (r != GSTAMD_OK)
+      return r;
+  }
+  return GSTAMD_OK;
 }
 
 void gstamd_video_converter_free (GstAmdVideoConverter *c)

@@ -862,7 +862,22 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     }
     plan->algorithmic_bytes = rd + (uint64_t) out_w * out_h * 4;
   }
-  std::string d = plan->passes.empty () ? "fused_convert" : "scale";
+  /* the line-pair kernel (video_fast.h): unscaled 4:2:0 semi-planar -> 4-byte RGB through the AYUV_ARGB
+   * matrix, with ORC's 16-bit addw wrap provably out of reach: |mulhsw (s, p)| <= (32896 * |p| >> 16) + 1 */
+  plan->fast_pair = false;
+  if (plan->passes.empty () && fr.kind == UNPACK_SEMI && fr.chroma_v2 && (in_w % 4) == 0 && in_h >= 2 &&
+      plan->matrix.kind == MATRIX_AYUV_ARGB && post.alpha_kind == ALPHA_NONE) {
+    long t[5];
+    bool fits = true;
+    for (int i = 0; i < 5; i++) {
+      long ap = labs ((long) plan->matrix.p[i]);
+      fits = fits && ap < 32768;
+      t[i] = ((32896L * ap) >> 16) + 1;
+    }
+    long worst = t[0] + std::max (std::max (t[1], t[2]), t[3] + t[4]);
+    plan->fast_pair = fits && worst < 32000;
+  }
+  std::string d = plan->passes.empty () ? (plan->fast_pair ? "fused_convert_pair" : "fused_convert") : "scale";
   d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;
   d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : "";
   d += fr.chroma_v2 ? ",v2" : "";

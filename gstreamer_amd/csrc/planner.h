@@ -87,6 +87,7 @@ struct VideoPlan {
   // chroma vertical pairing, one entry per source line: chroma rows of the pair's first and second
   // line and which of the two this line is (0 first / 1 second); rows equal => plain copy
   std::vector<int32_t> vpair;     // [in_height][2]: (row_a | role << 30), row_b
+  bool fast_pair;             // BASELINE C2 shape: line-pair kernel of video_fast.h is applicable
   std::string description;
   uint64_t algorithmic_bytes;
 };

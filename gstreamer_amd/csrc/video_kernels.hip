@@ -5,10 +5,14 @@
 // byte written once with 16-byte stores per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "planner.h"
 #include "video_kernels.h"
 #include "video_device.h"
+#include "video_fast.h"
 
 namespace gstamd {
 
@@ -18,6 +22,47 @@ __global__ __launch_bounds__ (256) void k_convert (FrontParams f, Planes pl, con
 {
   convert_body<CH> (f, pl, vpair, color, pack0, pack1, pack2, pack3, dst, dstride, spans_per_row, vec_ok,
       (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+// up to 16 independent frames of one format per launch (blockIdx.z = frame): amortises launch ramp/tail
+#define GSTAMD_MAX_BATCH 16
+struct FrameBatch {
+  const uint8_t *y[GSTAMD_MAX_BATCH];
+  const uint8_t *uv[GSTAMD_MAX_BATCH];
+  uint8_t *dst[GSTAMD_MAX_BATCH];
+  int ystride, uvstride, dstride;
+};
+
+__device__ __forceinline__ Planes batch_planes (const FrameBatch &b, int f)
+{
+  Planes pl;
+  pl.p[0] = b.y[f];
+  pl.p[1] = b.uv[f];
+  pl.p[2] = pl.p[3] = nullptr;
+  pl.stride[0] = b.ystride;
+  pl.stride[1] = b.uvstride;
+  pl.stride[2] = pl.stride[3] = 0;
+  return pl;
+}
+
+// fast pair kernel.  blockDim = (bx lanes along x, 256 / bx line pairs).  Each lane converts GROUPS spans
+// of NPX pixels; with GROUPS > 1 the spans of one lane are bx * NPX pixels apart so that every store
+// instruction of a wave covers one contiguous run of the row.
+template <int CH, int NPX, int ABL, int GROUPS>
+__global__ __launch_bounds__ (256) void k_convert_pair (FastParams fp, FrameBatch batch, int pairs)
+{
+  const Planes pl = batch_planes (batch, blockIdx.z);
+  uint8_t *__restrict__ dst = batch.dst[blockIdx.z];
+  const int dstride = batch.dstride;
+  const int p = blockIdx.y * blockDim.y + threadIdx.y;
+  if (p >= pairs)
+    return;
+#pragma unroll
+  for (int g = 0; g < GROUPS; g++) {
+    const int x0 = ((blockIdx.x * GROUPS + g) * blockDim.x + threadIdx.x) * NPX;
+    if (x0 + NPX <= fp.width)
+      fast_pair_span<CH, NPX, ABL> (fp, pl, dst, dstride, x0, p);
+  }
 }
 
 template <class SRC>
@@ -64,6 +109,126 @@ hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vp
       hipLaunchKernelGGL (k_convert<CHROMA_H_NONE>, grid, block, 0, stream, f, pl, vpair_dev, color, pack_pos[0],
           pack_pos[1], pack_pos[2], pack_pos[3], dst, dstride, spans, vec_ok);
       break;
+  }
+  return hipGetLastError ();
+}
+
+// single-line variant (experiments): grid.y = lines
+template <int CH, int NPX, int ABL>
+__global__ __launch_bounds__ (256) void k_convert_line (FastParams fp, FrameBatch batch)
+{
+  const Planes pl = batch_planes (batch, blockIdx.z);
+  uint8_t *__restrict__ dst = batch.dst[blockIdx.z];
+  const int dstride = batch.dstride;
+  const int line = blockIdx.y * blockDim.y + threadIdx.y;
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * NPX;
+  if (line < fp.height && x0 + NPX <= fp.width)
+    fast_line_span<CH, NPX, ABL> (fp, pl, dst, dstride, x0, line);
+}
+
+template <int CH, int NPX, int ABL>
+static void launch_line_variant (const FastParams &fp, const FrameBatch &batch, int n, int bx, hipStream_t stream)
+{
+  const int per_block = bx * NPX;
+  dim3 block (bx, 256 / bx), grid ((fp.width + per_block - 1) / per_block, (fp.height + block.y - 1) / block.y, n);
+  hipLaunchKernelGGL ((k_convert_line<CH, NPX, ABL>), grid, block, 0, stream, fp, batch);
+}
+
+// strip variant: grid.y = strips of K line pairs; blockDim = (bx, 256 / bx)
+template <int CH, int NPX, int ABL>
+__global__ __launch_bounds__ (256) void k_convert_strip (FastParams fp, FrameBatch batch, int pairs, int K)
+{
+  const Planes pl = batch_planes (batch, blockIdx.z);
+  uint8_t *__restrict__ dst = batch.dst[blockIdx.z];
+  const int dstride = batch.dstride;
+  const int strip = blockIdx.y * blockDim.y + threadIdx.y;
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * NPX;
+  const int p0 = strip * K;
+  if (p0 < pairs && x0 + NPX <= fp.width)
+    fast_strip<CH, NPX, ABL> (fp, pl, dst, dstride, x0, p0, p0 + K < pairs ? p0 + K : pairs);
+}
+
+template <int CH, int NPX, int ABL>
+static void launch_strip_variant (const FastParams &fp, const FrameBatch &batch, int n, int bx, int K, hipStream_t stream)
+{
+  const int pairs = fp.height / 2 + 1, strips = (pairs + K - 1) / K;
+  const int per_block = bx * NPX;
+  dim3 block (bx, 256 / bx), grid ((fp.width + per_block - 1) / per_block, (strips + block.y - 1) / block.y, n);
+  hipLaunchKernelGGL ((k_convert_strip<CH, NPX, ABL>), grid, block, 0, stream, fp, batch, pairs, K);
+}
+
+template <int CH, int NPX, int ABL, int GROUPS>
+static void launch_pair_variant (const FastParams &fp, const FrameBatch &batch, int n, int bx, hipStream_t stream)
+{
+  const int pairs = fp.height / 2 + 1;
+  const int per_block = bx * NPX * GROUPS;
+  dim3 block (bx, 256 / bx), grid ((fp.width + per_block - 1) / per_block, (pairs + block.y - 1) / block.y, n);
+  hipLaunchKernelGGL ((k_convert_pair<CH, NPX, ABL, GROUPS>), grid, block, 0, stream, fp, batch, pairs);
+}
+
+// Tuning knob for profiling sessions: GSTAMD_FAST_VARIANT="npx,abl,groups,bx" (h2cs only).  Unset = shipped config.
+static bool launch_pair_experiment (const FastParams &fp, const FrameBatch &batch, int n, hipStream_t stream)
+{
+  static int cfg[4] = {-1, 0, 0, 0};
+  if (cfg[0] == -1) {
+    const char *e = getenv ("GSTAMD_FAST_VARIANT");
+    cfg[0] = 0;
+    if (e)
+      sscanf (e, "%d,%d,%d,%d", &cfg[0], &cfg[1], &cfg[2], &cfg[3]);
+  }
+  if (cfg[0] == 0)
+    return false;
+  const int npx = cfg[0], abl = cfg[1], groups = cfg[2], bx = cfg[3];
+  if (groups >= 100) {                    /* strip variant: groups = 100 + K */
+    const int K = groups - 100;
+#define S(N, A) if (npx == N && abl == A) { launch_strip_variant<CHROMA_H_H2_CS, N, A> (fp, batch, n, bx, K, stream); return true; }
+    S (4, 0) S (4, 1) S (8, 0) S (8, 1)
+#undef S
+    return false;
+  }
+  if (fp.width % (npx) != 0)
+    return false;
+#define V(N, A, G) if (npx == N && abl == A && groups == G) { launch_pair_variant<CHROMA_H_H2_CS, N, A, G> (fp, batch, n, bx, stream); return true; }
+#define L(N, A) if (npx == N && abl == A && groups == 0) { launch_line_variant<CHROMA_H_H2_CS, N, A> (fp, batch, n, bx, stream); return true; }
+  L (4, 0) L (4, 1) L (8, 0) L (8, 1)
+#undef L
+  V (4, 0, 1) V (4, 1, 1) V (4, 0, 2) V (4, 1, 2) V (4, 0, 4) V (4, 1, 4)
+  V (8, 0, 1) V (8, 1, 1) V (8, 0, 2) V (8, 1, 2)
+  V (16, 0, 1) V (16, 1, 1)
+#undef V
+  return false;
+}
+
+hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames, const uint8_t *const *y, const uint8_t *const *uv,
+    uint8_t *const *dst, int ystride, int uvstride, int dstride, hipStream_t stream)
+{
+  for (int base = 0; base < n_frames; base += GSTAMD_MAX_BATCH) {
+    const int n = n_frames - base < GSTAMD_MAX_BATCH ? n_frames - base : GSTAMD_MAX_BATCH;
+    FrameBatch batch;
+    memset (&batch, 0, sizeof (batch));
+    for (int i = 0; i < n; i++) {
+      batch.y[i] = y[base + i];
+      batch.uv[i] = uv[base + i];
+      batch.dst[i] = dst[base + i];
+    }
+    batch.ystride = ystride;
+    batch.uvstride = uvstride;
+    batch.dstride = dstride;
+    if (chroma_h == CHROMA_H_H2_CS && launch_pair_experiment (fp, batch, n, stream))
+      continue;
+    /* shipped configuration (MI355X sweep, profiles/r01_c2_variants.txt): 4-pixel columns, 2 line pairs per
+     * lane with the second pair's loads in flight during the first pair's math, 64 x 4 lanes per block */
+    switch (chroma_h) {
+      case CHROMA_H_H2_CS:
+        launch_strip_variant<CHROMA_H_H2_CS, 4, 0> (fp, batch, n, 64, 2, stream);
+        break;
+      case CHROMA_H_H2:
+        launch_strip_variant<CHROMA_H_H2, 4, 0> (fp, batch, n, 64, 2, stream);
+        break;
+      default:
+        launch_strip_variant<CHROMA_H_NONE, 4, 0> (fp, batch, n, 64, 2, stream);
+        break;
+    }
   }
   return hipGetLastError ();
 }

@@ -73,6 +73,8 @@ def lib():
         L.gstamd_video_converter_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gstamd_video_converter_frame_planes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_void_p]
+        L.gstamd_video_converter_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                    C.c_void_p]
         L.gstamd_video_converter_free.argtypes = [C.c_void_p]
         L.gstamd_video_converter_describe.restype = C.c_char_p
         L.gstamd_video_converter_describe.argtypes = [C.c_void_p]
@@ -171,6 +173,14 @@ class VideoConverter:
 
     def frame(self, src, dest, stream=None):
         _check(lib().gstamd_video_converter_frame(self._h, _ptr(src), _ptr(dest), stream))
+
+    def frames(self, srcs, dests, stream=None):
+        """Convert a list of frames (GstBufferList analogue) - one launch when the plan allows."""
+        n = len(srcs)
+        assert n == len(dests)
+        sp = (C.c_void_p * n)(*[_ptr(x) for x in srcs])
+        dp = (C.c_void_p * n)(*[_ptr(x) for x in dests])
+        _check(lib().gstamd_video_converter_frames(self._h, n, sp, dp, stream))
 
     def describe(self):
         return lib().gstamd_video_converter_describe(self._h).decode()

@@ -64,6 +64,8 @@ VIDEO_CASES = [
     ("nv12_bgra_720p_ones", "NV12", 1280, 720, "BGRA", 1280, 720, {}, None, None, "ones"),
     ("nv12_bgra_720p_c16", "NV12", 1280, 720, "BGRA", 1280, 720, {}, None, None, "c16"),
     ("nv12_bgra_720p_c235", "NV12", 1280, 720, "BGRA", 1280, 720, {}, None, None, "c235"),
+    ("nv12_bgra_324x242_w4mod8", "NV12", 324, 242, "BGRA", 324, 242, {}, None, "mpeg2", "random"),
+    ("nv12_rgba_1284x721_odd_h", "NV12", 1284, 721, "RGBA", 1284, 721, {}, None, None, "random"),
     ("nv21_abgr_130x70", "NV21", 130, 70, "ABGR", 130, 70, {}, None, None, "random"),
     ("nv12_argb_640x360", "NV12", 640, 360, "ARGB", 640, 360, {}, None, None, "random"),
     ("nv12_xrgb_640x360", "NV12", 640, 360, "xRGB", 640, 360, {}, None, None, "random"),
@@ -101,6 +103,11 @@ VIDEO_REFUSED = [
     ("NV12", 320, 180, "BGRA", 640, 100, LAN),           # reference temp-line aliasing (see planner.cpp)
     ("NV12", 64, 64, "NV12", 32, 32, {}),                # planar output not implemented
 ]
+
+
+def case_seed(name):
+    """Stable per-case seed (independent of the case's position in the list)."""
+    return int(hashlib.sha256(name.encode()).hexdigest()[:8], 16)
 
 
 def ref_config_string(ref, cfg):

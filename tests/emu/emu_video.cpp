@@ -8,6 +8,7 @@
 
 #include "../../gstreamer_amd/csrc/planner.h"
 #include "../../gstreamer_amd/csrc/video_device.h"
+#include "../../gstreamer_amd/csrc/video_fast.h"
 
 using namespace gstamd;
 
@@ -50,6 +51,52 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   const int *vpair = p.vpair.data ();
   uint8_t *d0 = dst + out->offset[0];
   const int dstride = out->stride[0];
+  if (p.passes.empty () && p.fast_pair && vec_ok) {
+    FastParams fp;
+    fp.width = p.front.width;
+    fp.height = p.front.height;
+    for (int i = 0; i < 5; i++)
+      fp.p8[i] = p.matrix.p[i] * 256;
+    fp.pack_sel = (0x0du << (8 * p.post.pack_pos[0])) | (0x00u << (8 * p.post.pack_pos[1])) |
+        (0x01u << (8 * p.post.pack_pos[2])) | (0x04u << (8 * p.post.pack_pos[3]));
+    fp.u_first = p.front.u_plane;
+    if (vec_ok >= 2) {                    /* strip variant with K = vec_ok pairs per lane, 4- and 8-pixel columns */
+      const int pairs = fp.height / 2 + 1, K = vec_ok;
+      for (int p0 = 0; p0 < pairs; p0 += K)
+        for (int x0 = 0; x0 + 8 <= fp.width; x0 += 8) {
+          const int p1 = p0 + K < pairs ? p0 + K : pairs;
+          const bool four = ((x0 / 8) & 1) != 0;
+          switch (p.front.chroma_h) {
+            case CHROMA_H_H2_CS:
+              if (four) { fast_strip<CHROMA_H_H2_CS, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); fast_strip<CHROMA_H_H2_CS, 4, 0> (fp, pl, d0, dstride, x0 + 4, p0, p1); }
+              else fast_strip<CHROMA_H_H2_CS, 8, 0> (fp, pl, d0, dstride, x0, p0, p1);
+              break;
+            case CHROMA_H_H2:
+              if (four) { fast_strip<CHROMA_H_H2, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); fast_strip<CHROMA_H_H2, 4, 0> (fp, pl, d0, dstride, x0 + 4, p0, p1); }
+              else fast_strip<CHROMA_H_H2, 8, 0> (fp, pl, d0, dstride, x0, p0, p1);
+              break;
+            default:
+              if (four) { fast_strip<CHROMA_H_NONE, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); fast_strip<CHROMA_H_NONE, 4, 0> (fp, pl, d0, dstride, x0 + 4, p0, p1); }
+              else fast_strip<CHROMA_H_NONE, 8, 0> (fp, pl, d0, dstride, x0, p0, p1);
+              break;
+          }
+        }
+      return GSTAMD_OK;
+    }
+    {                                     /* shipped configuration: 4-pixel columns, K = 2 */
+      const int pairs = fp.height / 2 + 1;
+      for (int p0 = 0; p0 < pairs; p0 += 2)
+        for (int x0 = 0; x0 + 4 <= fp.width; x0 += 4) {
+          const int p1 = p0 + 2 < pairs ? p0 + 2 : pairs;
+          switch (p.front.chroma_h) {
+            case CHROMA_H_H2_CS: fast_strip<CHROMA_H_H2_CS, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); break;
+            case CHROMA_H_H2: fast_strip<CHROMA_H_H2, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); break;
+            default: fast_strip<CHROMA_H_NONE, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); break;
+          }
+        }
+    }
+    return GSTAMD_OK;
+  }
   if (p.passes.empty ()) {
     const int spans = (p.front.width + K1_PX - 1) / K1_PX;
     for (int y = 0; y < p.front.height; y++)

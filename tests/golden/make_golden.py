@@ -21,7 +21,7 @@ def main():
     out = {}
     for i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) in enumerate(cases.VIDEO_CASES):
         ii = ref.video_info(ifmt, w, h)
-        src = cases.frame_bytes(ii["size"], pattern, 1000 + i, w)
+        src = cases.frame_bytes(ii["size"], pattern, cases.case_seed(name), w)
         rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site,
                                 config=cases.ref_config_string(ref, cfg))
         dst = rc.frame(src)

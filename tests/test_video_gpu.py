@@ -33,7 +33,7 @@ def gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src, in_stride=No
 def test_hip_matches_reference_golden(native_lib, gpu, idx_case):
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     ii = V.video_info(ifmt, w, h)
-    src = cases.frame_bytes(int(ii.size), pattern, 1000 + i, w)
+    src = cases.frame_bytes(int(ii.size), pattern, cases.case_seed(name), w)
     out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
     assert cases.sha(out) == GOLDEN[name]["sha256"], (name, list(out[:16]), GOLDEN[name]["head"][:16])
 
@@ -114,6 +114,34 @@ def test_full_size_properties_8k(native_lib, gpu):
     assert int(px[0, 0]) == 84          # what the reference yields: its AYUV->ARGB kernel ignores the matrix offsets (-128/+128 instead of -16)
     conv.free()
     conv2.free()
+
+
+def test_frame_list_equals_single_frames(native_lib, gpu):
+    """gstamd_video_converter_frames (one launch for a list) == n x gstamd_video_converter_frame."""
+    import torch
+    w, h, n = 1280, 720, 19          # 19 > the 16-frame launch chunk
+    ii, oi = V.video_info("NV12", w, h), V.video_info("BGRA", w, h)
+    conv = V.VideoConverter(ii, oi)
+    srcs = [torch.from_numpy(cases.frame_bytes(int(ii.size), "random", 300 + i)).to(gpu) for i in range(n)]
+    one = [torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu) for _ in range(n)]
+    lst = [torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu) for _ in range(n)]
+    for s_, d_ in zip(srcs, one):
+        conv.frame(s_, d_)
+    conv.frames(srcs, lst)
+    torch.cuda.synchronize()
+    for a, b in zip(one, lst):
+        assert torch.equal(a, b)
+    # a plan the batch kernel does not cover falls back to per-frame launches with the same results
+    oi2 = V.video_info("BGRA", 640, 360)
+    conv2 = V.VideoConverter(ii, oi2, V.converter_config(**cases.LIN))
+    a = [torch.zeros(int(oi2.size), dtype=torch.uint8, device=gpu) for _ in range(3)]
+    b = [torch.zeros(int(oi2.size), dtype=torch.uint8, device=gpu) for _ in range(3)]
+    for s_, d_ in zip(srcs[:3], a):
+        conv2.frame(s_, d_)
+    conv2.frames(srcs[:3], b)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
 
 
 def test_frame_without_gpu_library_fails_loudly(native_lib):

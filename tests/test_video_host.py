@@ -60,7 +60,7 @@ def test_matrix_coefficients_pinned(native_lib):
 
 def test_c2_plan_and_algorithmic_bytes(native_lib):
     c = V.VideoConverter(V.video_info("NV12", 3840, 2160), V.video_info("BGRA", 3840, 2160))
-    assert c.describe() == "fused_convert[NV12->BGRA,h2cs,v2,matrix=ayuv_argb]"
+    assert c.describe() == "fused_convert_pair[NV12->BGRA,h2cs,v2,matrix=ayuv_argb]"
     assert c.algorithmic_bytes() == 45619200
     vp = c.debug_get(1)
     # regular pairing (2k-1, 2k): line 0 and the last line unpaired
@@ -115,7 +115,7 @@ def test_kernel_bodies_on_host_match_golden(native_lib, emu_lib, idx_case):
     """Kernel bodies (same source as the HIP kernels) on the host CPU vs the reference's golden hashes."""
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     ii = V.video_info(ifmt, w, h)
-    src = cases.frame_bytes(ii.size, pattern, 1000 + i, w)
+    src = cases.frame_bytes(ii.size, pattern, cases.case_seed(name), w)
     assert cases.sha(src) == GOLDEN[name]["in_sha256"]
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
     assert cases.sha(dst) == GOLDEN[name]["sha256"], (name, list(dst[:16]), GOLDEN[name]["head"][:16])
@@ -125,7 +125,7 @@ def test_kernel_bodies_on_host_match_golden(native_lib, emu_lib, idx_case):
 def test_golden_vectors_are_the_references_output(ref, idx_case):
     """Pins the committed golden hashes to the reference implementation itself (oracle/_ref)."""
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
-    src = cases.frame_bytes(ref.video_info(ifmt, w, h)["size"], pattern, 1000 + i, w)
+    src = cases.frame_bytes(ref.video_info(ifmt, w, h)["size"], pattern, cases.case_seed(name), w)
     rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site,
                             config=cases.ref_config_string(ref, cfg))
     assert cases.sha(rc.frame(src)) == GOLDEN[name]["sha256"]

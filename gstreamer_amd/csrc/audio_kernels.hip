@@ -1,0 +1,272 @@
+// audio_kernels.hip - gfx950 kernels + C ABI (include/gstamd_audio.h) of the polyphase FIR resampler.
+//
+// Two kernels per resample() call, both on the caller's stream:
+//   k_fir      one lane per output sample-channel; the phase's taps row (<= a few hundred bytes) and the
+//              input window come through L1/L2 (the whole 147 x 72 f32 table of 48k->44.1k is 42 KB);
+//   k_history  writes the frames the next call still needs into the other history buffer.
+// Input samples are read straight from the caller's buffer (no deinterleaved staging copy as in the
+// reference, audio-resampler.c:879-897): algorithmic traffic is in + out once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gstamd_audio.h"
+#include "audio_device.h"
+#include "audio_taps.h"
+
+using namespace gstamd;
+
+template <typename T>
+__global__ __launch_bounds__ (256) void k_fir (FirParams p, const T *__restrict__ hist, const T *__restrict__ in,
+    const T *__restrict__ table, T *__restrict__ out, long long n_out)
+{
+  const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;   // i = j * channels + c
+  if (i >= n_out * p.channels)
+    return;
+  const long long j = i / p.channels;
+  const int c = (int) (i % p.channels);
+  out[i] = fir_output<T> (p, hist, in, table, j, c);
+}
+
+template <typename T>
+__global__ __launch_bounds__ (256) void k_history (FirParams p, const T *__restrict__ hist, const T *__restrict__ in,
+    T *__restrict__ new_hist, long long src_start, long long moved, long long keep)
+{
+  const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= keep * p.channels)
+    return;
+  new_hist[i] = history_sample<T> (p, hist, in, src_start, moved, i / p.channels, (int) (i % p.channels));
+}
+
+struct GstAmdAudioResampler {
+  AudioPlan plan;
+  std::mutex lock;
+  AudioState st;
+  // device state
+  bool device_ready = false;
+  void *table_dev = nullptr;
+  void *hist[2] = {nullptr, nullptr};
+  size_t hist_cap[2] = {0, 0};      // frames
+  int cur = 0;
+};
+
+static thread_local std::string g_audio_error;
+extern "C" const char *gstamd_last_error (void);
+
+static int ensure_hist (GstAmdAudioResampler *r, int which, size_t frames)
+{
+  if (r->hist_cap[which] >= frames)
+    return GSTAMD_OK;
+  size_t cap = frames + frames / 2 + 256;
+  void *n = nullptr;
+  const size_t fbytes = (size_t) r->plan.bps * r->plan.channels;
+  if (hipMalloc (&n, cap * fbytes) != hipSuccess)
+    return GSTAMD_ERR_HIP;
+  if (hipMemset (n, 0, cap * fbytes) != hipSuccess)
+    return GSTAMD_ERR_HIP;
+  if (r->hist[which]) {
+    /* keep the valid frames (only matters for the current buffer) */
+    if (hipMemcpy (n, r->hist[which], r->hist_cap[which] * fbytes, hipMemcpyDeviceToDevice) != hipSuccess)
+      return GSTAMD_ERR_HIP;
+    (void) hipFree (r->hist[which]);
+  }
+  r->hist[which] = n;
+  r->hist_cap[which] = cap;
+  return GSTAMD_OK;
+}
+
+static int ensure_device (GstAmdAudioResampler *r)
+{
+  if (r->device_ready)
+    return GSTAMD_OK;
+  if (!r->plan.table.empty ()) {
+    if (hipMalloc (&r->table_dev, r->plan.table.size ()) != hipSuccess)
+      return GSTAMD_ERR_HIP;
+    if (hipMemcpy (r->table_dev, r->plan.table.data (), r->plan.table.size (), hipMemcpyHostToDevice) != hipSuccess)
+      return GSTAMD_ERR_HIP;
+  }
+  int e = ensure_hist (r, 0, (size_t) r->plan.n_taps + 64);
+  if (e == GSTAMD_OK)
+    e = ensure_hist (r, 1, (size_t) r->plan.n_taps + 64);
+  if (e != GSTAMD_OK)
+    return e;
+  r->device_ready = true;
+  return GSTAMD_OK;
+}
+
+static FirParams make_fir_params (const AudioPlan &pl, const AudioStep &s, bool in_null)
+{
+  FirParams p;
+  memset (&p, 0, sizeof (p));
+  p.channels = pl.channels;
+  p.n_taps_padded = pl.taps_stride;
+  p.nearest = (pl.method == GSTAMD_AUDIO_RESAMPLER_METHOD_NEAREST || pl.in_rate == pl.out_rate) ? 1 : 0;
+  p.samp_inc = pl.samp_inc;
+  p.samp_frac = pl.samp_frac;
+  p.out_rate = pl.out_rate;
+  p.samp_index0 = s.samp_index0;
+  p.samp_phase0 = s.samp_phase0;
+  p.hist_frames = s.hist_frames;
+  p.total_frames = s.total_frames;
+  p.in_is_null = in_null;
+  return p;
+}
+
+template <typename T>
+static int run_resample (GstAmdAudioResampler *r, const void *in, size_t in_frames, void *out, size_t out_frames,
+    hipStream_t stream)
+{
+  const AudioPlan &pl = r->plan;
+  const AudioStep s = audio_step (pl, &r->st, in_frames, out_frames);
+  if (s.skipped_all)
+    return GSTAMD_OK;
+  const FirParams p = make_fir_params (pl, s, in == nullptr);
+  const int cur = r->cur, nxt = cur ^ 1;
+  if (s.run_fir) {
+    const long long total = s.n_out * pl.channels;
+    hipLaunchKernelGGL (k_fir<T>, dim3 ((unsigned) ((total + 255) / 256)), dim3 (256), 0, stream, p, (const T *) r->hist[cur],
+        (const T *) in, (const T *) r->table_dev, (T *) out, s.n_out);
+    if (hipGetLastError () != hipSuccess)
+      return GSTAMD_ERR_HIP;
+  }
+  if (s.keep > 0) {
+    int e = ensure_hist (r, nxt, (size_t) s.keep + 64);
+    if (e != GSTAMD_OK)
+      return e;
+    const long long total = s.keep * pl.channels;
+    hipLaunchKernelGGL (k_history<T>, dim3 ((unsigned) ((total + 255) / 256)), dim3 (256), 0, stream, p, (const T *) r->hist[cur],
+        (const T *) in, (T *) r->hist[nxt], s.src_start, s.moved, s.keep);
+    if (hipGetLastError () != hipSuccess)
+      return GSTAMD_ERR_HIP;
+  }
+  r->cur = nxt;
+  return GSTAMD_OK;
+}
+
+extern "C" {
+
+void gstamd_audio_resampler_options_init (GstAmdAudioResamplerOptions *options)
+{
+  if (options)
+    audio_options_init (options);
+}
+
+void gstamd_audio_resampler_options_set_quality (int method, unsigned quality, int in_rate, int out_rate,
+    GstAmdAudioResamplerOptions *options)
+{
+  audio_options_set_quality (method, quality, in_rate, out_rate, options);
+}
+
+GstAmdAudioResampler *gstamd_audio_resampler_new (int method, int flags, int format, int channels, int in_rate, int out_rate,
+    const GstAmdAudioResamplerOptions *options, int *status)
+{
+  GstAmdAudioResampler *r = new GstAmdAudioResampler ();
+  std::string err;
+  int e = plan_audio_resampler (method, flags, format, channels, in_rate, out_rate, options, &r->plan, &err);
+  if (status)
+    *status = e;
+  if (e != GSTAMD_OK) {
+    g_audio_error = err;
+    delete r;
+    return nullptr;
+  }
+  gstamd_audio_resampler_reset (r);
+  return r;
+}
+
+void gstamd_audio_resampler_free (GstAmdAudioResampler *r)
+{
+  if (!r)
+    return;
+  if (r->table_dev)
+    (void) hipFree (r->table_dev);
+  for (void *h : r->hist)
+    if (h)
+      (void) hipFree (h);
+  delete r;
+}
+
+/* gst_audio_resampler_reset (audio-resampler.c:1466-1488): half of the filter is filled with 0 */
+void gstamd_audio_resampler_reset (GstAmdAudioResampler *r)
+{
+  if (!r)
+    return;
+  std::lock_guard<std::mutex> g (r->lock);
+  audio_state_reset (r->plan, &r->st);
+  if (r->device_ready) {
+    const size_t fbytes = (size_t) r->plan.bps * r->plan.channels;
+    (void) hipMemset (r->hist[r->cur], 0, (size_t) (r->plan.n_taps / 2) * fbytes);
+  }
+}
+
+size_t gstamd_audio_resampler_get_out_frames (GstAmdAudioResampler *r, size_t in_frames)
+{
+  return r ? audio_get_out_frames (r->plan, r->st, in_frames) : 0;
+}
+
+size_t gstamd_audio_resampler_get_in_frames (GstAmdAudioResampler *r, size_t out_frames)
+{
+  return r ? audio_get_in_frames (r->plan, r->st, out_frames) : 0;
+}
+
+size_t gstamd_audio_resampler_get_max_latency (GstAmdAudioResampler *r)
+{
+  return r ? (size_t) (r->plan.n_taps / 2) : 0;
+}
+
+int gstamd_audio_resampler_resample (GstAmdAudioResampler *r, const void *in, size_t in_frames, void *out, size_t out_frames,
+    void *stream)
+{
+  if (!r || (out_frames > 0 && !out))
+    return GSTAMD_ERR_INVALID;
+  std::lock_guard<std::mutex> g (r->lock);
+  int e = ensure_device (r);
+  if (e != GSTAMD_OK)
+    return e;
+  switch (r->plan.format) {
+    case GSTAMD_AUDIO_FORMAT_S16: return run_resample<int16_t> (r, in, in_frames, out, out_frames, (hipStream_t) stream);
+    case GSTAMD_AUDIO_FORMAT_S32: return run_resample<int32_t> (r, in, in_frames, out, out_frames, (hipStream_t) stream);
+    case GSTAMD_AUDIO_FORMAT_F32: return run_resample<float> (r, in, in_frames, out, out_frames, (hipStream_t) stream);
+    default: return run_resample<double> (r, in, in_frames, out, out_frames, (hipStream_t) stream);
+  }
+}
+
+int gstamd_audio_resampler_debug_get (GstAmdAudioResampler *r, int32_t *out, int max_out)
+{
+  if (!r)
+    return -1;
+  const int32_t v[] = {r->plan.n_taps, r->plan.n_phases, r->plan.in_rate, r->plan.oversample, r->plan.filter_mode,
+    r->plan.filter_interpolation, r->plan.taps_stride, (int32_t) r->st.samples_avail, (int32_t) r->st.samp_phase, (int32_t) r->st.skip};
+  const int n = (int) (sizeof (v) / sizeof (v[0]));
+  for (int i = 0; i < n && i < max_out; i++)
+    out[i] = v[i];
+  return n;
+}
+
+long gstamd_audio_resampler_debug_taps (GstAmdAudioResampler *r, double *out, long max_out)
+{
+  if (!r)
+    return -1;
+  const AudioPlan &p = r->plan;
+  const long n = (long) p.n_phases * p.n_taps;
+  if (!out)
+    return n;
+  long k = 0;
+  for (int ph = 0; ph < p.n_phases; ph++)
+    for (int t = 0; t < p.n_taps && k < max_out; t++, k++) {
+      const size_t idx = (size_t) ph * p.taps_stride + t;
+      switch (p.format) {
+        case GSTAMD_AUDIO_FORMAT_S16: out[k] = ((const int16_t *) p.table.data ())[idx]; break;
+        case GSTAMD_AUDIO_FORMAT_S32: out[k] = ((const int32_t *) p.table.data ())[idx]; break;
+        case GSTAMD_AUDIO_FORMAT_F32: out[k] = ((const float *) p.table.data ())[idx]; break;
+        default: out[k] = ((const double *) p.table.data ())[idx]; break;
+      }
+    }
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+/* gstamd_audio.h - C ABI of the MI355X-native GstAudioResampler replacement (polyphase FIR).
+ *
+ * Drop-in boundary for the audio half of the hot path.  Reference interface being
+ * replaced (subprojects/gst-plugins-base/gst-libs/gst/audio/audio-resampler.h):
+ *
+ *   gstamd_audio_resampler_options_set_quality <- gst_audio_resampler_options_set_quality  :218
+ *   gstamd_audio_resampler_new                 <- gst_audio_resampler_new                  :224
+ *   gstamd_audio_resampler_free / _reset       <- gst_audio_resampler_free / _reset        :231, :234
+ *   gstamd_audio_resampler_get_out_frames      <- gst_audio_resampler_get_out_frames       :242
+ *   gstamd_audio_resampler_get_in_frames       <- gst_audio_resampler_get_in_frames        :246
+ *   gstamd_audio_resampler_get_max_latency     <- gst_audio_resampler_get_max_latency      :250
+ *   gstamd_audio_resampler_resample            <- gst_audio_resampler_resample             :253
+ *
+ * Sample buffers are DEVICE pointers (interleaved frames); the FIR runs as HIP kernels on `stream`
+ * (hipStream_t as void*, NULL = default stream) and the call returns without synchronising.  All
+ * bookkeeping (history length, sample index/phase, skip) is host state that follows the reference
+ * function for function, so get_out_frames() etc. give the reference's numbers.  The taps tables are
+ * computed on the host with the reference's double-precision recipe and uploaded once.
+ * Float summation order is the reference's C order (4 interleaved partial sums, ((r0+r1)+r2)+r3,
+ * audio-resampler.c:693-707), without FMA contraction: results are bit-identical to the C path.
+ */
+#ifndef GSTAMD_AUDIO_H
+#define GSTAMD_AUDIO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* GstAudioResamplerMethod (audio-resampler.h:181-187) */
+enum {
+  GSTAMD_AUDIO_RESAMPLER_METHOD_NEAREST = 0, GSTAMD_AUDIO_RESAMPLER_METHOD_LINEAR = 1,
+  GSTAMD_AUDIO_RESAMPLER_METHOD_CUBIC = 2, GSTAMD_AUDIO_RESAMPLER_METHOD_BLACKMAN_NUTTALL = 3,
+  GSTAMD_AUDIO_RESAMPLER_METHOD_KAISER = 4
+};
+/* GstAudioResamplerFilterMode / FilterInterpolation (audio-resampler.h:103-107, 137-141) */
+enum { GSTAMD_AUDIO_FILTER_MODE_INTERPOLATED = 0, GSTAMD_AUDIO_FILTER_MODE_FULL = 1, GSTAMD_AUDIO_FILTER_MODE_AUTO = 2 };
+enum { GSTAMD_AUDIO_FILTER_INTERPOLATION_NONE = 0, GSTAMD_AUDIO_FILTER_INTERPOLATION_LINEAR = 1,
+  GSTAMD_AUDIO_FILTER_INTERPOLATION_CUBIC = 2 };
+/* sample formats (native endian): the four GstAudioResampler accepts (audio-resampler.c:1358-1360) */
+enum { GSTAMD_AUDIO_FORMAT_S16 = 0, GSTAMD_AUDIO_FORMAT_S32 = 1, GSTAMD_AUDIO_FORMAT_F32 = 2, GSTAMD_AUDIO_FORMAT_F64 = 3 };
+
+/* Mirror of the GstAudioResampler.* option keys (audio-resampler.h:42-165).  A field left at its
+ * "unset" value (NaN for doubles, -1 for ints) means the key is absent from the options structure. */
+typedef struct GstAmdAudioResamplerOptions {
+  double cutoff;                 /* GstAudioResampler.cutoff */
+  double stop_attenuation;       /* GstAudioResampler.stop-attenutation */
+  double transition_bandwidth;   /* GstAudioResampler.transition-bandwidth */
+  double cubic_b, cubic_c;       /* GstAudioResampler.cubic-b / cubic-c */
+  double max_phase_error;        /* GstAudioResampler.max-phase-error */
+  int32_t n_taps;                /* GstAudioResampler.n-taps */
+  int32_t filter_mode;           /* GstAudioResampler.filter-mode */
+  int32_t filter_mode_threshold; /* GstAudioResampler.filter-mode-threshold */
+  int32_t filter_interpolation;  /* GstAudioResampler.filter-interpolation */
+  int32_t filter_oversample;     /* GstAudioResampler.filter-oversample */
+  int32_t reserved[7];
+} GstAmdAudioResamplerOptions;
+
+typedef struct GstAmdAudioResampler GstAmdAudioResampler;
+
+/* all keys unset (an empty options structure) */
+void gstamd_audio_resampler_options_init (GstAmdAudioResamplerOptions *options);
+void gstamd_audio_resampler_options_set_quality (int method, unsigned quality, int in_rate, int out_rate,
+    GstAmdAudioResamplerOptions *options);
+
+/* options == NULL: Kaiser quality 4 like the reference (audio-resampler.c:1414-1419).  flags must be 0
+ * (interleaved in and out).  Returns NULL and sets *status (GSTAMD_ERR_* of gstamd_video.h) on failure;
+ * configurations that resolve to the interpolated filter mode are refused (not implemented yet). */
+GstAmdAudioResampler *gstamd_audio_resampler_new (int method, int flags, int format, int channels, int in_rate,
+    int out_rate, const GstAmdAudioResamplerOptions *options, int *status);
+void gstamd_audio_resampler_free (GstAmdAudioResampler *resampler);
+void gstamd_audio_resampler_reset (GstAmdAudioResampler *resampler);
+size_t gstamd_audio_resampler_get_out_frames (GstAmdAudioResampler *resampler, size_t in_frames);
+size_t gstamd_audio_resampler_get_in_frames (GstAmdAudioResampler *resampler, size_t out_frames);
+size_t gstamd_audio_resampler_get_max_latency (GstAmdAudioResampler *resampler);
+
+/* in: device pointer to in_frames interleaved frames, or NULL for silence (drain); out: device pointer
+ * with room for out_frames frames. */
+int gstamd_audio_resampler_resample (GstAmdAudioResampler *resampler, const void *in, size_t in_frames, void *out,
+    size_t out_frames, void *stream);
+
+/* introspection for tests: n_taps, n_phases (reduced out_rate), reduced in_rate, oversample, filter mode */
+int gstamd_audio_resampler_debug_get (GstAmdAudioResampler *resampler, int32_t *out, int max_out);
+/* copies the [n_phases][n_taps] taps table (as doubles) out; returns number of values or < 0 */
+long gstamd_audio_resampler_debug_taps (GstAmdAudioResampler *resampler, double *out, long max_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSTAMD_AUDIO_H */

@@ -120,3 +120,45 @@ def ref_config_string(ref, cfg):
         else:
             m["GstVideoConverter__" + k] = v
     return ref.config_string(**m) if m else None
+
+
+# ---- audio resampler cases: (name, fmt, channels, in_rate, out_rate, method, quality, buffer sizes) -------
+AUDIO_CASES = [
+    ("f32_48k_44k1_q4_stereo", "F32LE", 2, 48000, 44100, "kaiser", 4, (1024,) * 12),
+    ("f32_48k_44k1_q4_mono", "F32LE", 1, 48000, 44100, "kaiser", 4, (1024,) * 6),
+    ("f32_44k1_48k_q4", "F32LE", 2, 44100, 48000, "kaiser", 4, (1024,) * 6),
+    ("f64_48k_44k1_q4", "F64LE", 2, 48000, 44100, "kaiser", 4, (1024,) * 4),
+    ("s16_48k_44k1_q4", "S16LE", 2, 48000, 44100, "kaiser", 4, (1024,) * 4),
+    ("s32_48k_44k1_q4", "S32LE", 2, 48000, 44100, "kaiser", 4, (1024,) * 4),
+    ("f32_8k_16k_gappy", "F32LE", 2, 8000, 16000, "kaiser", 4, (255, 320, 320, 320, 1, 2, 3, 1000)),
+    ("f32_48k_44k1_q0", "F32LE", 2, 48000, 44100, "kaiser", 0, (1024,) * 3),
+    ("f32_48k_44k1_q10", "F32LE", 2, 48000, 44100, "kaiser", 10, (1024,) * 3),
+    ("f32_96k_8k_q4", "F32LE", 2, 96000, 8000, "kaiser", 4, (4096,) * 3),
+    ("f32_6ch_cubic", "F32LE", 6, 48000, 32000, "cubic", 4, (1024,) * 3),
+    ("f32_linear", "F32LE", 2, 48000, 32000, "linear", 4, (1024,) * 3),
+    ("f32_nearest", "F32LE", 2, 48000, 32000, "nearest", 4, (1024,) * 3),
+    ("f32_blackman", "F32LE", 2, 48000, 32000, "blackman-nuttall", 4, (1024,) * 3),
+    ("f32_same_rate", "F32LE", 2, 44100, 44100, "kaiser", 4, (1024,) * 3),
+    ("s16_cubic", "S16LE", 1, 48000, 44100, "cubic", 4, (1024,) * 3),
+    ("s16_linear_up", "S16LE", 1, 44100, 48000, "linear", 4, (1024,) * 3),
+]
+AUDIO_DTYPES = {"F32LE": np.float32, "F64LE": np.float64, "S16LE": np.int16, "S32LE": np.int32}
+
+
+def audio_buffer(fmt, channels, n, seed):
+    """Deterministic interleaved test signal: U(-1,1) noise (floats) or full-range ints from xorshift bytes."""
+    dt = AUDIO_DTYPES[fmt]
+    raw = xorshift_bytes(0xA0D10 ^ seed, n * channels * 8)
+    if np.issubdtype(dt, np.floating):
+        u = raw.view(np.uint64).astype(np.float64) / 2.0 ** 64
+        return (u * 2.0 - 1.0).astype(dt).reshape(n, channels)
+    return raw.view(np.int64).astype(dt).reshape(n, channels)
+
+
+def audio_stream(ref_resampler_factory, resample_fn, case):
+    """Feeds the case's buffers (then a drain of max-latency silent frames) and returns the concatenated output."""
+    name, fmt, ch, ir, orr, method, quality, bufs = case
+    outs = []
+    for i, n in enumerate(list(bufs) + [None]):
+        outs.append(resample_fn(i, n))
+    return np.concatenate([o.reshape(-1) for o in outs])

@@ -30,6 +30,7 @@ def emu_lib():
     so = os.path.join(emu_dir, "libgstamdemu.so")
     srcs = [os.path.join(emu_dir, f) for f in sorted(os.listdir(emu_dir)) if f.endswith(".cpp")]
     srcs.append(os.path.join(ROOT, "gstreamer_amd", "csrc", "planner.cpp"))
+    srcs.append(os.path.join(ROOT, "gstreamer_amd", "csrc", "audio_taps.cpp"))
     deps = srcs + [os.path.join(ROOT, "gstreamer_amd", "csrc", f)
                    for f in os.listdir(os.path.join(ROOT, "gstreamer_amd", "csrc")) if f.endswith(".h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):

@@ -1,0 +1,87 @@
+// tests/emu/emu_audio.cpp - TEST INFRASTRUCTURE: host loop over the FIR kernel bodies (audio_device.h)
+// with the product's host bookkeeping (audio_taps.cpp), so the resampler can be checked against the
+// reference in this GPU-less container.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../gstreamer_amd/csrc/audio_device.h"
+#include "../../gstreamer_amd/csrc/audio_taps.h"
+
+using namespace gstamd;
+
+struct EmuResampler {
+  AudioPlan plan;
+  AudioState st;
+  std::vector<uint8_t> hist;
+};
+
+template <typename T>
+static void emu_run (EmuResampler *r, const void *in, size_t in_frames, void *out, size_t out_frames)
+{
+  const AudioPlan &pl = r->plan;
+  const AudioStep s = audio_step (pl, &r->st, in_frames, out_frames);
+  if (s.skipped_all)
+    return;
+  FirParams p;
+  memset (&p, 0, sizeof (p));
+  p.channels = pl.channels;
+  p.n_taps_padded = pl.taps_stride;
+  p.nearest = (pl.method == GSTAMD_AUDIO_RESAMPLER_METHOD_NEAREST || pl.in_rate == pl.out_rate) ? 1 : 0;
+  p.samp_inc = pl.samp_inc;
+  p.samp_frac = pl.samp_frac;
+  p.out_rate = pl.out_rate;
+  p.samp_index0 = s.samp_index0;
+  p.samp_phase0 = s.samp_phase0;
+  p.hist_frames = s.hist_frames;
+  p.total_frames = s.total_frames;
+  p.in_is_null = in == nullptr;
+  const T *hist = (const T *) r->hist.data ();
+  if (s.run_fir)
+    for (long long j = 0; j < s.n_out; j++)
+      for (int c = 0; c < pl.channels; c++)
+        ((T *) out)[j * pl.channels + c] = fir_output<T> (p, hist, (const T *) in, (const T *) pl.table.data (), j, c);
+  std::vector<uint8_t> nh ((size_t) (s.keep + 1) * pl.channels * sizeof (T));
+  for (long long i = 0; i < s.keep; i++)
+    for (int c = 0; c < pl.channels; c++)
+      ((T *) nh.data ())[i * pl.channels + c] = history_sample<T> (p, hist, (const T *) in, s.src_start, s.moved, i, c);
+  r->hist.swap (nh);
+}
+
+extern "C" {
+
+void *emu_audio_new (int method, int flags, int format, int channels, int in_rate, int out_rate,
+    const GstAmdAudioResamplerOptions *options, int *status, char *err, int err_len)
+{
+  EmuResampler *r = new EmuResampler ();
+  std::string e;
+  int st = plan_audio_resampler (method, flags, format, channels, in_rate, out_rate, options, &r->plan, &e);
+  if (status)
+    *status = st;
+  if (st != GSTAMD_OK) {
+    if (err)
+      strncpy (err, e.c_str (), err_len - 1);
+    delete r;
+    return nullptr;
+  }
+  audio_state_reset (r->plan, &r->st);
+  r->hist.assign ((size_t) (r->plan.n_taps + 8) * channels * r->plan.bps, 0);
+  return r;
+}
+
+void emu_audio_free (void *h) { delete (EmuResampler *) h; }
+size_t emu_audio_get_out_frames (void *h, size_t in_frames) { EmuResampler *r = (EmuResampler *) h; return audio_get_out_frames (r->plan, r->st, in_frames); }
+int emu_audio_n_taps (void *h) { return ((EmuResampler *) h)->plan.n_taps; }
+
+void emu_audio_resample (void *h, const void *in, size_t in_frames, void *out, size_t out_frames)
+{
+  EmuResampler *r = (EmuResampler *) h;
+  switch (r->plan.format) {
+    case GSTAMD_AUDIO_FORMAT_S16: emu_run<int16_t> (r, in, in_frames, out, out_frames); break;
+    case GSTAMD_AUDIO_FORMAT_S32: emu_run<int32_t> (r, in, in_frames, out, out_frames); break;
+    case GSTAMD_AUDIO_FORMAT_F32: emu_run<float> (r, in, in_frames, out, out_frames); break;
+    default: emu_run<double> (r, in, in_frames, out, out_frames); break;
+  }
+}
+
+}  // extern "C"

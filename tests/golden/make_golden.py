@@ -31,5 +31,25 @@ def main():
         json.dump(out, f, indent=1, sort_keys=True)
 
 
+def audio():
+    out = {}
+    for case in cases.AUDIO_CASES:
+        name, fmt, ch, ir, orr, method, quality, bufs = case
+        rr = ref.AudioResampler(fmt, ch, ir, orr, method=method, quality=quality)
+        chunks, counts = [], []
+        for i, n in enumerate(list(bufs) + [None]):
+            data = None if n is None else cases.audio_buffer(fmt, ch, n, cases.case_seed(name) + i)
+            n_in = rr.get_max_latency() if n is None else n
+            no = rr.get_out_frames(n_in)
+            chunks.append(rr.resample(data, in_frames=n_in, out_frames=no).reshape(-1))
+            counts.append(int(no))
+        full = __import__("numpy").concatenate(chunks)
+        out[name] = dict(sha256=cases.sha(full), out_frames=counts, head=[float(x) for x in full[:8]])
+        print(name, out[name]["sha256"][:16], counts[:4])
+    with open(os.path.join(ROOT, "tests", "golden", "audio_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
+    audio()
     main()

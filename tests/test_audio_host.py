@@ -1,0 +1,90 @@
+"""CPU-side audio resampler tests: host bookkeeping + taps + FIR kernel bodies (host emulator) against the
+reference (oracle/_ref) and its golden hashes.  Bit-exact for every format, as the C summation order is kept."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from gstreamer_amd import audio as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "audio_golden.json")))
+
+
+def _emu(emu_lib):
+    emu_lib.emu_audio_new.restype = C.c_void_p
+    emu_lib.emu_audio_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(A.ResamplerOptions),
+                                      C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    emu_lib.emu_audio_get_out_frames.restype = C.c_size_t
+    emu_lib.emu_audio_get_out_frames.argtypes = [C.c_void_p, C.c_size_t]
+    emu_lib.emu_audio_resample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    emu_lib.emu_audio_free.argtypes = [C.c_void_p]
+    return emu_lib
+
+
+@pytest.mark.parametrize("case", cases.AUDIO_CASES, ids=lambda c: c[0])
+def test_fir_bodies_on_host_match_golden(native_lib, emu_lib, case):
+    E = _emu(emu_lib)
+    name, fmt, ch, ir, orr, method, quality, bufs = case
+    o = A.options(method, quality, ir, orr)
+    st = C.c_int(0)
+    h = E.emu_audio_new(A.METHODS[method], 0, A.FORMATS[fmt], ch, ir, orr, C.byref(o), C.byref(st), None, 0)
+    assert h, st.value
+    dt = cases.AUDIO_DTYPES[fmt]
+    chunks = []
+    latency = None
+    for i, n in enumerate(list(bufs) + [None]):
+        data = None if n is None else cases.audio_buffer(fmt, ch, n, cases.case_seed(name) + i)
+        if n is None:
+            r = A.AudioResampler(fmt, ch, ir, orr, method, o)
+            n = r.get_max_latency()
+            r.free()
+        no = E.emu_audio_get_out_frames(h, n)
+        assert no == GOLDEN[name]["out_frames"][i]         # gst_audio_resampler_get_out_frames parity
+        got = np.zeros((no, ch), dt)
+        E.emu_audio_resample(h, data.ctypes.data if data is not None else None, n, got.ctypes.data, no)
+        chunks.append(got.reshape(-1))
+    E.emu_audio_free(h)
+    assert cases.sha(np.concatenate(chunks)) == GOLDEN[name]["sha256"]
+
+
+@pytest.mark.parametrize("case", cases.AUDIO_CASES[::3], ids=lambda c: c[0])
+def test_golden_is_the_references_output(ref, case):
+    name, fmt, ch, ir, orr, method, quality, bufs = case
+    rr = ref.AudioResampler(fmt, ch, ir, orr, method=method, quality=quality)
+    chunks = []
+    for i, n in enumerate(list(bufs) + [None]):
+        data = None if n is None else cases.audio_buffer(fmt, ch, n, cases.case_seed(name) + i)
+        n_in = rr.get_max_latency() if n is None else n
+        chunks.append(rr.resample(data, in_frames=n_in, out_frames=rr.get_out_frames(n_in)).reshape(-1))
+    assert cases.sha(np.concatenate(chunks)) == GOLDEN[name]["sha256"]
+
+
+def test_c4_plan_48k_to_44k1(native_lib):
+    """160/147 reduction, 72 taps, FULL mode with 147 cached phases, 8x oversampled cubic build."""
+    r = A.AudioResampler("F32LE", 2, 48000, 44100, "kaiser", A.options("kaiser", 4, 48000, 44100))
+    d = r.debug()
+    assert (d["in_rate"], d["n_phases"], d["n_taps"], d["oversample"]) == (160, 147, 72, 8)
+    assert d["filter_mode"] == A.FILTER_MODE["full"] and d["filter_interpolation"] == A.FILTER_INTERPOLATION["cubic"]
+    assert d["samples_avail"] == 35 and r.get_max_latency() == 36
+    taps = r.taps()
+    assert taps.shape == (147, 72)
+    assert np.allclose(taps.sum(axis=1), 1.0, atol=2e-3)      # every phase is DC-normalised
+    # NULL options == Kaiser quality 4 (audio-resampler.c:1414-1419)
+    r2 = A.AudioResampler("F32LE", 2, 48000, 44100, "kaiser", None)
+    assert (r2.taps() == taps).all()
+    # reference test_gap_no_extra_samples (tests/check/elements/audioresample.c:1283): 8k -> 16k sample counts
+    r3 = A.AudioResampler("S16LE", 1, 8000, 16000, "kaiser", A.options("kaiser", 4, 8000, 16000))
+    assert r3.get_out_frames(255) > 0 and r3.get_in_frames(320) == 160
+    for x in (r, r2, r3):
+        x.free()
+
+
+def test_interpolated_mode_is_refused(native_lib):
+    from gstreamer_amd import video as V
+    with pytest.raises(V.GstAmdError) as e:
+        A.AudioResampler("F32LE", 2, 48000, 44101, "kaiser", A.options("kaiser", 4, 48000, 44101))
+    assert e.value.code == V.ERR_UNSUPPORTED

@@ -1,0 +1,162 @@
+"""Compositor blend path: kernel bodies on the host emulator (CPU tests) and the HIP kernel (-m gpu)
+against the reference's BlendFunction / fill functions (oracle/_ref: blend.c + compositororc-dist.c)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+from gstreamer_amd import video as V
+
+FAM = {"BGRA": "bgra", "RGBA": "bgra", "ARGB": "argb", "ABGR": "argb", "AYUV": "argb"}
+
+BLEND_CASES = []
+for fmt in ("BGRA", "ARGB", "RGBA", "AYUV"):
+    for mode in (0, 1, 2):
+        for alpha in (1.0, 0.5, 0.3, 0.004, 0.0):
+            BLEND_CASES.append((fmt, 0, 37, 21, 64, 48, 5, 7, alpha, mode, 0, 48))
+            BLEND_CASES.append((fmt, 1, 37, 21, 64, 48, -9, -4, alpha, mode, 0, 48))
+BLEND_CASES += [("BGRA", 0, 100, 80, 64, 48, 40, 30, 0.7, 1, 10, 40), ("BGRA", 1, 100, 80, 64, 48, -20, -30, 0.7, 1, 10, 40),
+                ("BGRA", 0, 10, 10, 64, 48, 70, 30, 0.7, 1, 0, 48), ("ARGB", 0, 64, 48, 64, 48, 0, 0, 1.0, 0, 0, 48)]
+
+
+class PadDev(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride", C.c_int), ("xpos", C.c_int),
+                ("ypos", C.c_int), ("s_alpha", C.c_int), ("mode", C.c_int)]
+
+
+class AggParams(C.Structure):
+    _fields_ = [("ashift", C.c_int), ("overlay", C.c_int), ("bg_kind", C.c_int), ("checker_yuv", C.c_int),
+                ("bg_word", C.c_uint32), ("n_pads", C.c_int), ("pads", PadDev * 32)]
+
+
+def ref_blend(ref, case, src, dst):
+    fmt, overlay, sw, sh, dw, dh, xpos, ypos, alpha, mode, y0, y1 = case
+    func = ("overlay_" if overlay else "blend_") + FAM[fmt]
+    return ref.compositor_blend(func, fmt, src, sw, sh, xpos, ypos, alpha, dst, dw, dh, y0, y1, mode)
+
+
+def make_blend_inputs(case, i):
+    fmt, overlay, sw, sh, dw, dh = case[:6]
+    return cases.frame_bytes(sw * sh * 4, "random", 500 + i), cases.frame_bytes(dw * dh * 4, "random", 900 + i)
+
+
+@pytest.mark.parametrize("i_case", list(enumerate(BLEND_CASES))[::3], ids=lambda c: "%s_%d_%s_m%d" % (c[1][0], c[1][1], c[1][8], c[1][9]))
+def test_blend_body_on_host_matches_reference(emu_lib, ref, i_case):
+    i, case = i_case
+    fmt, overlay, sw, sh, dw, dh, xpos, ypos, alpha, mode, y0, y1 = case
+    emu_lib.emu_compositor_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    assert C.sizeof(AggParams) == emu_lib.emu_sizeof_params()
+    src, dst = make_blend_inputs(case, i)
+    exp = ref_blend(ref, case, src, dst.copy())
+    got = dst.copy()
+    sa = max(0, min(255, int(alpha * 255)))
+    if sa:
+        p = AggParams()
+        p.ashift = 0 if FAM[fmt] == "argb" else 24
+        p.overlay, p.bg_kind, p.n_pads = overlay, 2, 1
+        pd = p.pads[0]
+        pd.data, pd.width, pd.height, pd.stride, pd.xpos, pd.ypos, pd.s_alpha, pd.mode = src.ctypes.data, sw, sh, sw * 4, xpos, ypos, sa, mode
+        yy1 = min(y1, dh)
+        x0, r0, x1, r1 = max(xpos, 0), max(ypos, y0), min(xpos + sw, dw), min(ypos + sh, yy1)
+        if x1 > x0 and r1 > r0:
+            emu_lib.emu_compositor_run(C.byref(p), got.ctypes.data, dw * 4, x0, r0, x1 - x0, r1 - r0)
+    assert (exp == got).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i_case", list(enumerate(BLEND_CASES)), ids=lambda c: "%s_%d_%s_m%d" % (c[1][0], c[1][1], c[1][8], c[1][9]))
+def test_hip_blend_matches_reference(native_lib, gpu, ref, i_case):
+    import torch
+    i, case = i_case
+    fmt, overlay, sw, sh, dw, dh, xpos, ypos, alpha, mode, y0, y1 = case
+    src, dst = make_blend_inputs(case, i)
+    exp = ref_blend(ref, case, src, dst.copy())
+    d_src, d_dst = torch.from_numpy(src).to(gpu), torch.from_numpy(dst).to(gpu)
+    r = V.lib().gstamd_compositor_blend(V.FORMATS[fmt], overlay, d_src.data_ptr(), sw, sh, sw * 4, xpos, ypos, alpha,
+                                        d_dst.data_ptr(), dw, dh, dw * 4, y0, y1, mode, None)
+    assert r == 0
+    torch.cuda.synchronize()
+    assert (d_dst.cpu().numpy() == exp).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["BGRA", "ARGB", "RGBA", "ABGR", "AYUV"])
+def test_hip_fills_match_reference(native_lib, gpu, ref, fmt):
+    import torch
+    w, h = 70, 33
+    exp = np.zeros(w * h * 4, np.uint8)
+    checker_fn = {"BGRA": "bgra", "RGBA": "bgra", "ARGB": "argb", "ABGR": "argb"}.get(fmt)
+    d = torch.zeros(w * h * 4, dtype=torch.uint8, device=gpu)
+    if checker_fn:
+        ref.compositor_fill(0, checker_fn, fmt, exp, w, h, 3, 30)
+        assert V.lib().gstamd_compositor_fill_checker(V.FORMATS[fmt], d.data_ptr(), w, h, w * 4, 3, 30, None) == 0
+        torch.cuda.synchronize()
+        assert (d.cpu().numpy() == exp).all()
+    if fmt != "AYUV":
+        exp[:] = 0
+        d.zero_()
+        ref.compositor_fill(1, fmt.lower(), fmt, exp, w, h, 2, 31, 10, 200, 77)
+        assert V.lib().gstamd_compositor_fill_color(V.FORMATS[fmt], d.data_ptr(), w, h, w * 4, 2, 31, 10, 200, 77, None) == 0
+        torch.cuda.synchronize()
+        assert (d.cpu().numpy() == exp).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("background", [0, 1, 2, 3])
+def test_hip_aggregate_equals_reference_pad_by_pad(native_lib, gpu, ref, background):
+    """Fused aggregate (one pass) == the reference's _draw_background + blend_pads loop
+    (compositor.c:1619-1697): C4 layout scaled down (16 overlapping pads, alpha 0.25+0.05 i), 35 pads too
+    to cross the 32-pad launch chunk."""
+    import torch
+    dw, dh, pw, ph = 480, 270, 240, 136
+    for n_pads in (16, 35):
+        pads_np = [cases.frame_bytes(pw * ph * 4, "random", 7000 + i) for i in range(n_pads)]
+        exp = np.zeros(dw * dh * 4, np.uint8)
+        if background == 0:
+            ref.compositor_fill(0, "bgra", "BGRA", exp, dw, dh, 0, dh)
+        elif background == 1:
+            ref.compositor_fill(1, "bgra", "BGRA", exp, dw, dh, 0, dh, 0, 0, 0)
+        elif background == 2:
+            ref.compositor_fill(1, "bgra", "BGRA", exp, dw, dh, 0, dh, 255, 255, 255)
+        func = "overlay_bgra" if background == 3 else "blend_bgra"
+        geo = []
+        for i in range(n_pads):
+            xpos, ypos, alpha = (i % 4) * 80 - 10, (i // 4) * 45 - 5, min(1.0, 0.25 + 0.05 * i)
+            mode = 1 if i % 5 else (0 if i % 2 else 2)
+            geo.append((xpos, ypos, alpha, mode))
+            ref.compositor_blend(func, "BGRA", pads_np[i], pw, ph, xpos, ypos, alpha, exp, dw, dh, 0, dh, mode)
+        d_pads = [torch.from_numpy(p).to(gpu) for p in pads_np]
+        arr = (V.CompositorPad * n_pads)()
+        for i, (xpos, ypos, alpha, mode) in enumerate(geo):
+            arr[i].data, arr[i].width, arr[i].height, arr[i].stride = d_pads[i].data_ptr(), pw, ph, pw * 4
+            arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = xpos, ypos, alpha, mode
+        d_out = torch.zeros(dw * dh * 4, dtype=torch.uint8, device=gpu)
+        assert V.lib().gstamd_compositor_aggregate(V.FORMATS["BGRA"], background, arr, n_pads, d_out.data_ptr(), dw, dh, dw * 4, None) == 0
+        torch.cuda.synchronize()
+        assert (d_out.cpu().numpy() == exp).all(), (background, n_pads)
+
+
+@pytest.mark.gpu
+def test_hip_aggregate_c4_full_size_properties(native_lib, gpu):
+    """BASELINE config 4 at full size (16 x 1080p onto 4K): fused aggregate == pad-by-pad gstamd_compositor_blend
+    on the GPU itself (the latter is pinned to the reference above), output alpha is opaque."""
+    import torch
+    dw, dh, pw, ph = 3840, 2160, 1920, 1080
+    base = torch.from_numpy(cases.frame_bytes(pw * ph * 4, "random", 31)).to(gpu)
+    pads = [torch.roll(base, shifts=i * 4099) for i in range(16)]
+    arr = (V.CompositorPad * 16)()
+    a = torch.zeros(dw * dh * 4, dtype=torch.uint8, device=gpu)
+    b = torch.zeros_like(a)
+    L = V.lib()
+    assert L.gstamd_compositor_fill_checker(V.FORMATS["BGRA"], b.data_ptr(), dw, dh, dw * 4, 0, dh, None) == 0
+    for i in range(16):
+        xpos, ypos, alpha = (i % 4) * 640, (i // 4) * 360, 0.25 + 0.05 * i
+        arr[i].data, arr[i].width, arr[i].height, arr[i].stride = pads[i].data_ptr(), pw, ph, pw * 4
+        arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = xpos, ypos, alpha, 1
+        assert L.gstamd_compositor_blend(V.FORMATS["BGRA"], 0, pads[i].data_ptr(), pw, ph, pw * 4, xpos, ypos, alpha,
+                                         b.data_ptr(), dw, dh, dw * 4, 0, dh, 1, None) == 0
+    assert L.gstamd_compositor_aggregate(V.FORMATS["BGRA"], 0, arr, 16, a.data_ptr(), dw, dh, dw * 4, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert bool((a.view(-1, 4)[:, 3] == 255).all())

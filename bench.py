@@ -59,6 +59,19 @@ def cpu_baseline(sample_frames=40):
         return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
 
 
+def reduce_job(wall_s, frames_this_rank, device, distributed):
+    """Whole-job numbers from per-rank measurements: ranks convert independent streams (no data-path
+    collective), so the job time is the MAX over ranks and the job's frames are the SUM over ranks."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([wall_s], dtype=torch.float64, device=device)
+    n = torch.tensor([float(frames_this_rank)], dtype=torch.float64, device=device)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(round(float(n.item())))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,7 +81,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8,
                     help="frames per kernel launch (gstamd_video_converter_frames, the GstBufferList analogue); "
                          "1 = one launch per frame")
+    ap.add_argument("--size", default="3840x2160", help="experiments only: frame size (the headline metric is 3840x2160)")
     args = ap.parse_args()
+    global W, H
+    W, H = [int(v) for v in args.size.split("x")]
 
     import torch
     import torch.distributed as dist
@@ -133,10 +149,7 @@ def main():
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
 
-    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if distributed:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall_max = float(tmax.item())
+    wall_max, total_frames = reduce_job(wall, args.steps * FRAMES_PER_STEP, dev, distributed)
 
     if rank == 0:
         launches = args.steps * FRAMES_PER_STEP // B
@@ -149,7 +162,7 @@ def main():
                 traffic = int(json.load(open(tpath)).get("hbm_bytes_per_frame") * B)
             except Exception:
                 traffic = None
-        total_frames = launches * B * world
+        assert total_frames == launches * B * world
         line = {
             "metric": "4K frames/s (videoconvertscale NV12->BGRA) per GPU; % HBM roofline",
             "value": round(total_frames / wall_max, 1),

@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 : > gpurun_out/variants.log
 for v in "" $VARIANTS; do
-  GSTAMD_FAST_VARIANT="$v" python bench.py --steps 40 --warmup 5 --no-cpu-baseline --batch ${BATCH:-1} 2>&1 | python -c "
+  GSTAMD_FAST_VARIANT="$v" python bench.py --steps 40 --warmup 5 --no-cpu-baseline --batch ${BATCH:-1} ${EXTRA} 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -1,0 +1,30 @@
+"""Builds plugins/libgstamdhipdsp.so (GStreamer elements) against the GStreamer development files in
+/opt/conda (1.14) and the product library.  python plugins/build.py"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CONDA = os.environ.get("GST_PREFIX", "/opt/conda")
+OUT = os.path.join(HERE, "libgstamdhipdsp.so")
+
+
+def build():
+    srcs = [os.path.join(HERE, f) for f in ("gstamdplugin.c", "gstamdhipmemory.c", "gstamdvideoconvertscale.c", "gstamdaudioresample.c")]
+    inc = ["-I%s/include/gstreamer-1.0" % CONDA, "-I%s/lib/gstreamer-1.0/include" % CONDA, "-I%s/include/glib-2.0" % CONDA,
+           "-I%s/lib/glib-2.0/include" % CONDA]
+    libdir = os.path.join(ROOT, "gstreamer_amd", "lib")
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-deprecated-declarations", "-o", OUT] + srcs + inc + [
+        "-L%s/lib" % CONDA, "-Wl,-rpath,%s/lib" % CONDA, "-L" + libdir, "-Wl,-rpath,$ORIGIN/../gstreamer_amd/lib",
+        "-lgstamddsp", "-lgstvideo-1.0", "-lgstaudio-1.0", "-lgstbase-1.0", "-lgstreamer-1.0", "-lgobject-2.0", "-lglib-2.0"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("plugin build failed:\n" + r.stdout)
+    if r.stdout.strip():
+        print(r.stdout)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build())

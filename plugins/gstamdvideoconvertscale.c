@@ -1,0 +1,514 @@
+/* gstamdvideoconvertscale.c - `videoconvertscale` / `videoconvert` / `videoscale` elements backed by the
+ * MI355X kernels (C ABI of include/gstamd_video.h).
+ *
+ * Mirrors the reference element's contract for this path
+ * (subprojects/gst-plugins-base/gst/videoconvertscale/gstvideoconvertscale.c):
+ *   - factory names and ranks            gstvideoconvertscaleplugin.c:33-53, gstvideoconvertscale.c:121
+ *   - properties method / n-threads / alpha-mode / alpha-value / chroma-mode / matrix-mode / envelope /
+ *     sharpness / sharpen / dither-quantization with the reference names and defaults  :130-144, 300-391
+ *   - transform_caps: drop format/colorimetry/chroma-site, rangify size                :703-772
+ *   - set_caps -> converter config per method                                          :985-1095
+ *   - transform: one converter call per buffer                                         :1981
+ * It subclasses GstBaseTransform directly (GstVideoFilter would CPU-map every buffer,
+ * gstvideofilter.c:285-290).  Frames negotiated as video/x-raw(memory:AMDHIPMemory) never leave HBM between
+ * chained elements; plain system-memory caps still work (upload + download inside the element), so a
+ * pipeline like BASELINE config 1 negotiates unchanged.  Conversions the GPU path refuses
+ * (GSTAMD_ERR_UNSUPPORTED) make set_caps fail -> not-negotiated, like the reference's "no_convert" :1111-1120.
+ *
+ * Simplifications kept honest: fixate_caps keeps the input size / PAR instead of the reference's 450-line
+ * DAR solver (:1248-1975); add-borders, the converter-config property, interlaced content and overlay
+ * composition metas are not implemented.
+ */
+#include <gst/base/gstbasetransform.h>
+#include <gst/gst.h>
+#include <gst/video/video.h>
+#include <string.h>
+
+#include "../include/gstamd_video.h"
+#include "gstamdhipmemory.h"
+
+GST_DEBUG_CATEGORY_STATIC (amd_vcs_debug);
+GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
+#define GST_CAT_DEFAULT amd_vcs_debug
+
+#define AMD_FORMATS "{ NV12, NV21, I420, YV12, Y42B, Y444, AYUV, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR }"
+#define AMD_OUT_FORMATS "{ AYUV, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR }"
+
+static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_FORMATS) ";"
+        GST_VIDEO_CAPS_MAKE (AMD_FORMATS)));
+static GstStaticPadTemplate src_tmpl = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_OUT_FORMATS) ";"
+        GST_VIDEO_CAPS_MAKE (AMD_OUT_FORMATS)));
+
+/* GstVideoScaleMethod of the reference (gstvideoconvertscale.h) */
+typedef enum {
+  AMD_SCALE_NEAREST, AMD_SCALE_BILINEAR, AMD_SCALE_4TAP, AMD_SCALE_LANCZOS, AMD_SCALE_BILINEAR2, AMD_SCALE_SINC,
+  AMD_SCALE_HERMITE, AMD_SCALE_SPLINE, AMD_SCALE_CATROM, AMD_SCALE_MITCHELL
+} AmdScaleMethod;
+
+static GType
+amd_scale_method_get_type (void)
+{
+  static GType t = 0;
+  static const GEnumValue v[] = {
+    {AMD_SCALE_NEAREST, "Nearest Neighbour", "nearest-neighbour"}, {AMD_SCALE_BILINEAR, "Bilinear (2-tap)", "bilinear"},
+    {AMD_SCALE_4TAP, "4-tap Sinc", "4-tap"}, {AMD_SCALE_LANCZOS, "Lanczos", "lanczos"},
+    {AMD_SCALE_BILINEAR2, "Bilinear (multi-tap)", "bilinear2"}, {AMD_SCALE_SINC, "Sinc (multi-tap)", "sinc"},
+    {AMD_SCALE_HERMITE, "Hermite (multi-tap)", "hermite"}, {AMD_SCALE_SPLINE, "Spline (multi-tap)", "spline"},
+    {AMD_SCALE_CATROM, "Catmull-Rom (multi-tap)", "catrom"}, {AMD_SCALE_MITCHELL, "Mitchell (multi-tap)", "mitchell"},
+    {0, NULL, NULL},
+  };
+  if (!t)
+    t = g_enum_register_static ("GstAmdVideoScaleMethod", v);
+  return t;
+}
+
+typedef struct {
+  GstBaseTransform parent;
+  /* properties (reference names) */
+  gint method;
+  guint n_threads;             /* accepted for compatibility; the GPU grid replaces the thread slices */
+  gint alpha_mode, chroma_mode, matrix_mode;
+  gdouble alpha_value, envelope, sharpness, sharpen;
+  guint dither_quantization;
+  /* negotiated */
+  GstVideoInfo in_info, out_info;
+  gboolean in_hip, out_hip;
+  GstAmdVideoConverter *convert;
+  /* device staging for system-memory pads */
+  gpointer d_in, d_out;
+  gsize d_in_size, d_out_size;
+} GstAmdVideoConvertScale;
+
+typedef struct {
+  GstBaseTransformClass parent_class;
+  gboolean converts, scales;
+} GstAmdVideoConvertScaleClass;
+
+enum { PROP_0, PROP_METHOD, PROP_N_THREADS, PROP_ALPHA_MODE, PROP_ALPHA_VALUE, PROP_CHROMA_MODE, PROP_MATRIX_MODE,
+  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION };
+
+G_DEFINE_TYPE (GstAmdVideoConvertScale, gst_amd_vcs, GST_TYPE_BASE_TRANSFORM);
+#define AMD_VCS(o) ((GstAmdVideoConvertScale *) (o))
+#define AMD_VCS_GET_CLASS(o) ((GstAmdVideoConvertScaleClass *) G_OBJECT_GET_CLASS (o))
+
+static void
+amd_vcs_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (object);
+  GST_OBJECT_LOCK (s);
+  switch (id) {
+    case PROP_METHOD: s->method = g_value_get_enum (value); break;
+    case PROP_N_THREADS: s->n_threads = g_value_get_uint (value); break;
+    case PROP_ALPHA_MODE: s->alpha_mode = g_value_get_enum (value); break;
+    case PROP_ALPHA_VALUE: s->alpha_value = g_value_get_double (value); break;
+    case PROP_CHROMA_MODE: s->chroma_mode = g_value_get_enum (value); break;
+    case PROP_MATRIX_MODE: s->matrix_mode = g_value_get_enum (value); break;
+    case PROP_ENVELOPE: s->envelope = g_value_get_double (value); break;
+    case PROP_SHARPNESS: s->sharpness = g_value_get_double (value); break;
+    case PROP_SHARPEN: s->sharpen = g_value_get_double (value); break;
+    case PROP_DITHER_QUANTIZATION: s->dither_quantization = g_value_get_uint (value); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+  GST_OBJECT_UNLOCK (s);
+}
+
+static void
+amd_vcs_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (object);
+  GST_OBJECT_LOCK (s);
+  switch (id) {
+    case PROP_METHOD: g_value_set_enum (value, s->method); break;
+    case PROP_N_THREADS: g_value_set_uint (value, s->n_threads); break;
+    case PROP_ALPHA_MODE: g_value_set_enum (value, s->alpha_mode); break;
+    case PROP_ALPHA_VALUE: g_value_set_double (value, s->alpha_value); break;
+    case PROP_CHROMA_MODE: g_value_set_enum (value, s->chroma_mode); break;
+    case PROP_MATRIX_MODE: g_value_set_enum (value, s->matrix_mode); break;
+    case PROP_ENVELOPE: g_value_set_double (value, s->envelope); break;
+    case PROP_SHARPNESS: g_value_set_double (value, s->sharpness); break;
+    case PROP_SHARPEN: g_value_set_double (value, s->sharpen); break;
+    case PROP_DITHER_QUANTIZATION: g_value_set_uint (value, s->dither_quantization); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+  GST_OBJECT_UNLOCK (s);
+}
+
+static gboolean
+features_convertible (const GstCapsFeatures * f)
+{
+  if (gst_caps_features_is_any (f))
+    return FALSE;
+  return gst_caps_features_is_equal (f, GST_CAPS_FEATURES_MEMORY_SYSTEM_MEMORY) ||
+      (gst_caps_features_get_size (f) == 1 && gst_caps_features_contains (f, GST_CAPS_FEATURE_MEMORY_AMD_HIP));
+}
+
+/* gst_video_convert_caps_remove_format_and_rangify_size_info (:703-748); additionally both memory kinds are
+ * offered on the other side, since the element can upload/download itself */
+static GstCaps *
+amd_vcs_transform_caps (GstBaseTransform * trans, GstPadDirection direction, GstCaps * caps, GstCaps * filter)
+{
+  GstAmdVideoConvertScaleClass *klass = AMD_VCS_GET_CLASS (trans);
+  GstCaps *ret = gst_caps_new_empty ();
+  guint i, n = gst_caps_get_size (caps);
+
+  for (i = 0; i < n; i++) {
+    GstStructure *st = gst_structure_copy (gst_caps_get_structure (caps, i));
+    GstCapsFeatures *f = gst_caps_get_features (caps, i);
+
+    if (features_convertible (f)) {
+      if (klass->scales) {
+        gst_structure_set (st, "width", GST_TYPE_INT_RANGE, 1, G_MAXINT, "height", GST_TYPE_INT_RANGE, 1, G_MAXINT, NULL);
+        if (gst_structure_has_field (st, "pixel-aspect-ratio"))
+          gst_structure_set (st, "pixel-aspect-ratio", GST_TYPE_FRACTION_RANGE, 1, G_MAXINT, G_MAXINT, 1, NULL);
+      }
+      if (klass->converts)
+        gst_structure_remove_fields (st, "format", "colorimetry", "chroma-site", NULL);
+      gst_caps_append_structure_full (ret, gst_structure_copy (st), gst_caps_features_new (GST_CAPS_FEATURE_MEMORY_AMD_HIP, NULL));
+      gst_caps_append_structure_full (ret, st, gst_caps_features_new (GST_CAPS_FEATURE_MEMORY_SYSTEM_MEMORY, NULL));
+    } else {
+      gst_caps_append_structure_full (ret, st, gst_caps_features_copy (f));
+    }
+  }
+  {
+    /* restrict to what the pad template on the other side allows */
+    GstPad *other = direction == GST_PAD_SINK ? GST_BASE_TRANSFORM_SRC_PAD (trans) : GST_BASE_TRANSFORM_SINK_PAD (trans);
+    GstCaps *tmpl = gst_pad_get_pad_template_caps (other);
+    GstCaps *tmp = gst_caps_intersect_full (ret, tmpl, GST_CAPS_INTERSECT_FIRST);
+    gst_caps_unref (ret);
+    gst_caps_unref (tmpl);
+    ret = tmp;
+  }
+  if (filter) {
+    GstCaps *tmp = gst_caps_intersect_full (filter, ret, GST_CAPS_INTERSECT_FIRST);
+    gst_caps_unref (ret);
+    ret = tmp;
+  }
+  return ret;
+}
+
+static GstCaps *
+amd_vcs_fixate_caps (GstBaseTransform * trans, GstPadDirection direction, GstCaps * caps, GstCaps * othercaps)
+{
+  GstStructure *ins = gst_caps_get_structure (caps, 0), *outs;
+  gint w = 0, h = 0;
+  const gchar *fmt;
+
+  othercaps = gst_caps_truncate (gst_caps_make_writable (othercaps));
+  outs = gst_caps_get_structure (othercaps, 0);
+  /* simplified fixation: keep the size and (when allowed) the format of the other side */
+  if (gst_structure_get_int (ins, "width", &w))
+    gst_structure_fixate_field_nearest_int (outs, "width", w);
+  if (gst_structure_get_int (ins, "height", &h))
+    gst_structure_fixate_field_nearest_int (outs, "height", h);
+  if ((fmt = gst_structure_get_string (ins, "format")) && gst_structure_has_field (outs, "format"))
+    gst_structure_fixate_field_string (outs, "format", fmt);
+  if (gst_structure_has_field (outs, "pixel-aspect-ratio")) {
+    gint pn = 1, pd = 1;
+    gst_structure_get_fraction (ins, "pixel-aspect-ratio", &pn, &pd);
+    gst_structure_fixate_field_nearest_fraction (outs, "pixel-aspect-ratio", pn, pd);
+  }
+  return gst_caps_fixate (othercaps);
+}
+
+static gboolean
+fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
+{
+  guint i;
+  static const struct { GstVideoFormat f; int a; } map[] = {
+    {GST_VIDEO_FORMAT_I420, GSTAMD_VIDEO_FORMAT_I420}, {GST_VIDEO_FORMAT_YV12, GSTAMD_VIDEO_FORMAT_YV12},
+    {GST_VIDEO_FORMAT_AYUV, GSTAMD_VIDEO_FORMAT_AYUV}, {GST_VIDEO_FORMAT_RGBx, GSTAMD_VIDEO_FORMAT_RGBx},
+    {GST_VIDEO_FORMAT_BGRx, GSTAMD_VIDEO_FORMAT_BGRx}, {GST_VIDEO_FORMAT_xRGB, GSTAMD_VIDEO_FORMAT_xRGB},
+    {GST_VIDEO_FORMAT_xBGR, GSTAMD_VIDEO_FORMAT_xBGR}, {GST_VIDEO_FORMAT_RGBA, GSTAMD_VIDEO_FORMAT_RGBA},
+    {GST_VIDEO_FORMAT_BGRA, GSTAMD_VIDEO_FORMAT_BGRA}, {GST_VIDEO_FORMAT_ARGB, GSTAMD_VIDEO_FORMAT_ARGB},
+    {GST_VIDEO_FORMAT_ABGR, GSTAMD_VIDEO_FORMAT_ABGR}, {GST_VIDEO_FORMAT_Y42B, GSTAMD_VIDEO_FORMAT_Y42B},
+    {GST_VIDEO_FORMAT_Y444, GSTAMD_VIDEO_FORMAT_Y444}, {GST_VIDEO_FORMAT_NV12, GSTAMD_VIDEO_FORMAT_NV12},
+    {GST_VIDEO_FORMAT_NV21, GSTAMD_VIDEO_FORMAT_NV21},
+  };
+  int fmt = 0;
+  for (i = 0; i < G_N_ELEMENTS (map); i++)
+    if (map[i].f == GST_VIDEO_INFO_FORMAT (vi))
+      fmt = map[i].a;
+  if (!fmt || gstamd_video_info_set_format (ai, fmt, GST_VIDEO_INFO_WIDTH (vi), GST_VIDEO_INFO_HEIGHT (vi)) != GSTAMD_OK)
+    return FALSE;
+  for (i = 0; i < GST_VIDEO_INFO_N_PLANES (vi); i++) {
+    ai->stride[i] = GST_VIDEO_INFO_PLANE_STRIDE (vi, i);
+    ai->offset[i] = GST_VIDEO_INFO_PLANE_OFFSET (vi, i);
+  }
+  ai->size = GST_VIDEO_INFO_SIZE (vi);
+  /* GstVideoColorRange / GstVideoColorMatrix / GstVideoChromaSite share their numeric values with the ABI */
+  ai->color_range = vi->colorimetry.range;
+  ai->color_matrix = vi->colorimetry.matrix;
+  ai->chroma_site = vi->chroma_site;
+  return TRUE;
+}
+
+static gboolean
+caps_are_hip (GstCaps * caps)
+{
+  GstCapsFeatures *f = gst_caps_get_features (caps, 0);
+  return f && gst_caps_features_contains (f, GST_CAPS_FEATURE_MEMORY_AMD_HIP);
+}
+
+static gboolean
+amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (trans);
+  GstAmdVideoInfo ai, ao;
+  GstAmdVideoConverterConfig cfg;
+  int status = 0;
+
+  if (!gst_video_info_from_caps (&s->in_info, incaps) || !gst_video_info_from_caps (&s->out_info, outcaps))
+    return FALSE;
+  s->in_hip = caps_are_hip (incaps);
+  s->out_hip = caps_are_hip (outcaps);
+  if (!fill_amd_info (&s->in_info, &ai) || !fill_amd_info (&s->out_info, &ao)) {
+    GST_ERROR_OBJECT (s, "format not supported by the HIP converter");
+    return FALSE;
+  }
+  gstamd_video_converter_config_init (&cfg);
+  /* method -> converter options, as gstvideoconvertscale.c:993-1062 */
+  switch (s->method) {
+    case AMD_SCALE_NEAREST: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_NEAREST; break;
+    case AMD_SCALE_BILINEAR: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_LINEAR; cfg.max_taps = 2; break;
+    case AMD_SCALE_4TAP: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_SINC; cfg.max_taps = 4; break;
+    case AMD_SCALE_LANCZOS: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_LANCZOS; break;
+    case AMD_SCALE_BILINEAR2: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_LINEAR; break;
+    case AMD_SCALE_SINC: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_SINC; break;
+    case AMD_SCALE_HERMITE: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_CUBIC; cfg.cubic_b = 0.0; cfg.cubic_c = 0.0; break;
+    case AMD_SCALE_SPLINE: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_CUBIC; cfg.cubic_b = 1.0; cfg.cubic_c = 0.0; break;
+    case AMD_SCALE_CATROM: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_CUBIC; cfg.cubic_b = 0.0; cfg.cubic_c = 0.5; break;
+    case AMD_SCALE_MITCHELL: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_CUBIC; cfg.cubic_b = 1.0 / 3.0; cfg.cubic_c = 1.0 / 3.0; break;
+  }
+  cfg.envelope = s->envelope;
+  cfg.sharpness = s->sharpness;
+  cfg.sharpen = s->sharpen;
+  cfg.alpha_mode = s->alpha_mode;
+  cfg.alpha_value = s->alpha_value;
+  cfg.chroma_mode = s->chroma_mode;
+  cfg.matrix_mode = s->matrix_mode;
+  cfg.dither_quantization = s->dither_quantization;
+
+  if (s->convert)
+    gstamd_video_converter_free (s->convert);
+  s->convert = gstamd_video_converter_new (&ai, &ao, &cfg, &status);
+  if (!s->convert) {
+    GST_ERROR_OBJECT (s, "no HIP conversion for these caps: %s", gstamd_last_error ());
+    return FALSE;
+  }
+  GST_CAT_DEBUG_OBJECT (CAT_PERFORMANCE, s, "HIP plan: %s", gstamd_video_converter_describe (s->convert));
+  return TRUE;
+}
+
+static gboolean
+amd_vcs_get_unit_size (GstBaseTransform * trans, GstCaps * caps, gsize * size)
+{
+  GstVideoInfo info;
+  if (!gst_video_info_from_caps (&info, caps))
+    return FALSE;
+  *size = GST_VIDEO_INFO_SIZE (&info);
+  return TRUE;
+}
+
+/* HIP output: allocate AMDHIPMemory ourselves (a pool is the obvious next step); system output: default */
+static GstFlowReturn
+amd_vcs_prepare_output_buffer (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer ** outbuf)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (trans);
+
+  if (gst_base_transform_is_passthrough (trans)) {
+    *outbuf = inbuf;
+    return GST_FLOW_OK;
+  }
+  if (!s->out_hip)
+    return GST_BASE_TRANSFORM_CLASS (gst_amd_vcs_parent_class)->prepare_output_buffer (trans, inbuf, outbuf);
+  *outbuf = gst_amd_hip_buffer_new_video (&s->out_info);
+  if (!*outbuf)
+    return GST_FLOW_ERROR;
+  gst_buffer_copy_into (*outbuf, inbuf, GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS, 0, -1);
+  return GST_FLOW_OK;
+}
+
+static gboolean
+ensure_staging (gpointer * p, gsize * have, gsize need)
+{
+  if (*have >= need)
+    return TRUE;
+  gstamd_device_free (*p);
+  *p = gstamd_device_alloc (need);
+  *have = *p ? need : 0;
+  return *p != NULL;
+}
+
+static GstFlowReturn
+amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (trans);
+  GstMapInfo imap, omap;
+  GstMemory *imem = gst_buffer_peek_memory (inbuf, 0), *omem = gst_buffer_peek_memory (outbuf, 0);
+  const gboolean in_dev = gst_buffer_n_memory (inbuf) == 1 && gst_is_amd_hip_memory (imem);
+  const gboolean out_dev = gst_buffer_n_memory (outbuf) == 1 && gst_is_amd_hip_memory (omem);
+  gconstpointer src;
+  gpointer dst;
+  int r;
+
+  if (!s->convert)
+    return GST_FLOW_NOT_NEGOTIATED;
+  /* source */
+  if (in_dev) {
+    if (!gst_memory_map (imem, &imap, GST_MAP_READ | GST_MAP_AMDHIP))
+      return GST_FLOW_ERROR;
+    src = imap.data;
+  } else {
+    if (!gst_buffer_map (inbuf, &imap, GST_MAP_READ))
+      return GST_FLOW_ERROR;
+    if (!ensure_staging (&s->d_in, &s->d_in_size, imap.size) ||
+        gstamd_device_upload (s->d_in, imap.data, imap.size, NULL) != GSTAMD_OK) {
+      gst_buffer_unmap (inbuf, &imap);
+      return GST_FLOW_ERROR;
+    }
+    src = s->d_in;
+  }
+  /* destination */
+  if (out_dev) {
+    if (!gst_memory_map (omem, &omap, GST_MAP_WRITE | GST_MAP_AMDHIP))
+      goto map_fail;
+    dst = omap.data;
+  } else {
+    if (!gst_buffer_map (outbuf, &omap, GST_MAP_WRITE))
+      goto map_fail;
+    if (!ensure_staging (&s->d_out, &s->d_out_size, omap.size)) {
+      gst_buffer_unmap (outbuf, &omap);
+      goto map_fail;
+    }
+    dst = s->d_out;
+  }
+
+  GST_CAT_DEBUG_OBJECT (CAT_PERFORMANCE, s, "HIP convert %s", gstamd_video_converter_describe (s->convert));
+  r = gstamd_video_converter_frame (s->convert, src, dst, NULL);
+  if (r == GSTAMD_OK && !out_dev)
+    r = gstamd_device_download (omap.data, s->d_out, omap.size, NULL);    /* synchronises */
+  else if (r == GSTAMD_OK && !in_dev)
+    r = gstamd_stream_synchronize (NULL);   /* the staged input is reused by the next buffer */
+
+  if (out_dev)
+    gst_memory_unmap (omem, &omap);
+  else
+    gst_buffer_unmap (outbuf, &omap);
+  if (in_dev)
+    gst_memory_unmap (imem, &imap);
+  else
+    gst_buffer_unmap (inbuf, &imap);
+  if (r != GSTAMD_OK) {
+    GST_ELEMENT_ERROR (s, LIBRARY, FAILED, ("HIP conversion failed"), ("%s", gstamd_last_error ()));
+    return GST_FLOW_ERROR;
+  }
+  return GST_FLOW_OK;
+
+map_fail:
+  if (in_dev)
+    gst_memory_unmap (imem, &imap);
+  else
+    gst_buffer_unmap (inbuf, &imap);
+  return GST_FLOW_ERROR;
+}
+
+static gboolean
+amd_vcs_stop (GstBaseTransform * trans)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (trans);
+  if (s->convert)
+    gstamd_video_converter_free (s->convert);
+  s->convert = NULL;
+  gstamd_device_free (s->d_in);
+  gstamd_device_free (s->d_out);
+  s->d_in = s->d_out = NULL;
+  s->d_in_size = s->d_out_size = 0;
+  return TRUE;
+}
+
+static GType
+amd_enum_type (const gchar * name, const GEnumValue * values)
+{
+  GType t = g_type_from_name (name);
+  return t ? t : g_enum_register_static (name, values);
+}
+
+static void
+gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
+{
+  GObjectClass *oc = G_OBJECT_CLASS (klass);
+  GstElementClass *ec = GST_ELEMENT_CLASS (klass);
+  GstBaseTransformClass *tc = GST_BASE_TRANSFORM_CLASS (klass);
+  static const GEnumValue alpha_v[] = {{0, "copy", "copy"}, {1, "set", "set"}, {2, "mult", "mult"}, {0, NULL, NULL}};
+  static const GEnumValue chroma_v[] = {{0, "full", "full"}, {1, "upsample-only", "upsample-only"},
+    {2, "downsample-only", "downsample-only"}, {3, "none", "none"}, {0, NULL, NULL}};
+  static const GEnumValue matrix_v[] = {{0, "full", "full"}, {1, "input-only", "input-only"},
+    {2, "output-only", "output-only"}, {3, "none", "none"}, {0, NULL, NULL}};
+
+  GST_DEBUG_CATEGORY_INIT (amd_vcs_debug, "amdvideoconvertscale", 0, "MI355X videoconvertscale");
+  GST_DEBUG_CATEGORY_GET (CAT_PERFORMANCE, "GST_PERFORMANCE");
+  oc->set_property = amd_vcs_set_property;
+  oc->get_property = amd_vcs_get_property;
+  g_object_class_install_property (oc, PROP_METHOD, g_param_spec_enum ("method", "method", "method",
+          amd_scale_method_get_type (), AMD_SCALE_BILINEAR, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_N_THREADS, g_param_spec_uint ("n-threads", "Threads",
+          "Accepted for compatibility (the GPU grid replaces CPU thread slices)", 0, G_MAXUINT, 1,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_ALPHA_MODE, g_param_spec_enum ("alpha-mode", "Alpha Mode",
+          "Alpha Mode to use", amd_enum_type ("GstAmdVideoAlphaMode", alpha_v), 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_ALPHA_VALUE, g_param_spec_double ("alpha-value", "Alpha Value",
+          "Alpha Value to use", 0.0, 1.0, 1.0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_CHROMA_MODE, g_param_spec_enum ("chroma-mode", "Chroma Mode",
+          "Chroma Resampling Mode", amd_enum_type ("GstAmdVideoChromaMode", chroma_v), 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_MATRIX_MODE, g_param_spec_enum ("matrix-mode", "Matrix Mode",
+          "Matrix Conversion Mode", amd_enum_type ("GstAmdVideoMatrixMode", matrix_v), 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_ENVELOPE, g_param_spec_double ("envelope", "Envelope",
+          "Size of filter envelope", 1.0, 5.0, 2.0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_SHARPNESS, g_param_spec_double ("sharpness", "Sharpness",
+          "Sharpness of filter", 0.5, 1.5, 1.0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_SHARPEN, g_param_spec_double ("sharpen", "Sharpen",
+          "Sharpening", 0.0, 1.0, 0.0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_DITHER_QUANTIZATION, g_param_spec_uint ("dither-quantization",
+          "Dither Quantize", "Quantizer to use", 0, G_MAXUINT, 1, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+
+  gst_element_class_set_static_metadata (ec, "Video colorspace converter and scaler (MI355X/HIP)",
+      "Filter/Converter/Video/Scaler/Colorspace",
+      "Converts and resizes raw video on an AMD Instinct GPU with kernels bit-exact to GstVideoConverter", "gstreamer_amd");
+  gst_element_class_add_static_pad_template (ec, &sink_tmpl);
+  gst_element_class_add_static_pad_template (ec, &src_tmpl);
+
+  tc->passthrough_on_same_caps = TRUE;
+  tc->transform_caps = GST_DEBUG_FUNCPTR (amd_vcs_transform_caps);
+  tc->fixate_caps = GST_DEBUG_FUNCPTR (amd_vcs_fixate_caps);
+  tc->set_caps = GST_DEBUG_FUNCPTR (amd_vcs_set_caps);
+  tc->get_unit_size = GST_DEBUG_FUNCPTR (amd_vcs_get_unit_size);
+  tc->prepare_output_buffer = GST_DEBUG_FUNCPTR (amd_vcs_prepare_output_buffer);
+  tc->transform = GST_DEBUG_FUNCPTR (amd_vcs_transform);
+  tc->stop = GST_DEBUG_FUNCPTR (amd_vcs_stop);
+  klass->converts = TRUE;
+  klass->scales = TRUE;
+}
+
+static void
+gst_amd_vcs_init (GstAmdVideoConvertScale * s)
+{
+  s->method = AMD_SCALE_BILINEAR;          /* DEFAULT_PROP_METHOD (:130) */
+  s->n_threads = 1;
+  s->alpha_mode = GSTAMD_ALPHA_MODE_COPY;
+  s->alpha_value = 1.0;
+  s->chroma_mode = GSTAMD_CHROMA_MODE_FULL;
+  s->matrix_mode = GSTAMD_MATRIX_MODE_FULL;
+  s->envelope = 2.0;
+  s->sharpness = 1.0;
+  s->sharpen = 0.0;
+  s->dither_quantization = 1;
+  gst_amd_hip_allocator_get ();
+}
+
+GType
+gst_amd_video_convert_scale_get_type (void)
+{
+  return gst_amd_vcs_get_type ();
+}

@@ -817,6 +817,23 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         continue;
       ScalePass pass;
       make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, isz, osz, horizontal, &pass);
+      pass.max_span = 1 << 30;
+      if (horizontal) {
+        int worst = 0;
+        for (int t0 = 0; t0 < osz; t0 += 256) {
+          const int t1 = std::min (t0 + 256, osz);
+          int lo, hi;
+          if (pass.kind == SCALE_2TAP) {
+            lo = (t0 * pass.inc) >> 16;
+            hi = (((t1 - 1) * pass.inc) >> 16) + 2;
+          } else {
+            lo = (int) pass.offset[t0];
+            hi = (int) pass.offset[t1 - 1] + (pass.kind == SCALE_NEAREST ? 1 : pass.n_taps);
+          }
+          worst = std::max (worst, hi - lo);
+        }
+        pass.max_span = worst;
+      }
       plan->passes.push_back (pass);
     }
   }

@@ -73,6 +73,7 @@ struct ScalePass {
   std::vector<uint32_t> offset;   // [out_size] first source index
   std::vector<int16_t> taps;      // [out_size][n_taps] quantised taps (precision depends on kind)
   int precision;
+  int max_span;        // horizontal passes: largest source span under any 256-output tile (LDS staging)
 };
 
 struct VideoPlan {

@@ -188,12 +188,40 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
 // ------------------------------------------------------------------------------------------------
 // sources for the scaler kernels
 // ------------------------------------------------------------------------------------------------
+GSTAMD_HD void front_span8_any (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint32_t *out);
+
 struct SrcFront {
   FrontParams f;
   Planes pl;
   const int *vpair;
   ColorParams pre;      // matrix+alpha applied before scaling (upscale case), kind NONE otherwise
+  int vec_ok;           // planes aligned for front_span8
   GSTAMD_HD uint32_t at (int x, int y) const { return apply_color (pre, fetch_front (f, pl, vpair, x, y)); }
+  // stage pixels [x_lo, x_hi) of line y into lds[0 ..): 8-pixel groups with word loads where possible
+  GSTAMD_HD void stage (uint32_t *lds, int x_lo, int x_hi, int y, int tid, int nthreads) const
+  {
+    if (vec_ok && f.w_sub == 1 && f.kind != UNPACK_PACKED4) {
+      const int xa = x_lo & ~7;
+      const int groups = (x_hi - xa + 7) >> 3;
+      for (int g = tid; g < groups; g += nthreads) {
+        const int x0 = xa + 8 * g;
+        if (x0 + 8 <= f.width) {
+          uint32_t px[8];
+          front_span8_any (f, pl, vpair, x0, y, px);
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+            if (x0 + i >= x_lo && x0 + i < x_hi)
+              lds[x0 + i - x_lo] = apply_color (pre, px[i]);
+        } else {
+          for (int x = x0 > x_lo ? x0 : x_lo; x < x_hi && x < x0 + 8; x++)
+            lds[x - x_lo] = at (x, y);
+        }
+      }
+    } else {
+      for (int i = tid; i < x_hi - x_lo; i += nthreads)
+        lds[i] = at (x_lo + i, y);
+    }
+  }
 };
 
 struct SrcImage {
@@ -202,6 +230,11 @@ struct SrcImage {
   GSTAMD_HD uint32_t at (int x, int y) const
   {
     return *(const uint32_t *) (p + (size_t) y * stride + 4 * (size_t) x);
+  }
+  GSTAMD_HD void stage (uint32_t *lds, int x_lo, int x_hi, int y, int tid, int nthreads) const
+  {
+    for (int i = tid; i < x_hi - x_lo; i += nthreads)
+      lds[i] = at (x_lo + i, y);
   }
 };
 
@@ -291,6 +324,59 @@ GSTAMD_HD void hfilter8 (const Chroma6 &c, int x0, int w, int *u, int *v)
   }
 }
 
+// 8 unpacked + chroma-upsampled pixels x0 .. x0+7 of line y (x0 % 8 == 0, x0 + 8 <= width, w_sub == 1, vector
+// alignment as checked by the launcher): the word-load version of fetch_front
+template <int CH>
+GSTAMD_HD void front_span8 (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint32_t *out)
+{
+  const int w = f.width;
+  const uint2 yy = *(const uint2 *) (pl.p[0] + (size_t) y * pl.stride[0] + x0);
+  const int cw = (w + 1) >> 1, k0 = x0 >> 1;
+  int ra, rb, role = 0;
+  if (f.chroma_v2) {
+    const int e0 = vpair[2 * y];
+    ra = e0 & 0x3fffffff;
+    role = e0 >> 30;
+    rb = vpair[2 * y + 1];
+  } else {
+    ra = rb = y >> f.h_sub;
+  }
+  int u[8], v[8];
+  {
+    Chroma6 c;
+    load_chroma6 (f, pl, ra, k0, cw, c);
+    hfilter8<CH> (c, x0, w, u, v);
+  }
+  if (ra != rb) {
+    Chroma6 c;
+    int u2[8], v2[8];
+    load_chroma6 (f, pl, rb, k0, cw, c);
+    hfilter8<CH> (c, x0, w, u2, v2);
+    const int wa = role == 0 ? 3 : 1, wb = 4 - wa;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      u[i] = (wa * u[i] + wb * u2[i] + 2) >> 2;
+      v[i] = (wa * v[i] + wb * v2[i] + 2) >> 2;
+    }
+  }
+  const uint32_t yw[2] = {yy.x, yy.y};
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t Y = (yw[i >> 2] >> (8 * (i & 3))) & 0xff;
+    out[i] = 0xffu | (Y << 8) | ((uint32_t) u[i] << 16) | ((uint32_t) v[i] << 24);
+  }
+}
+
+GSTAMD_HD void front_span8_any (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint32_t *out)
+{
+  if (f.chroma_h == CHROMA_H_H2_CS)
+    front_span8<CHROMA_H_H2_CS> (f, pl, vpair, x0, y, out);
+  else if (f.chroma_h == CHROMA_H_H2)
+    front_span8<CHROMA_H_H2> (f, pl, vpair, x0, y, out);
+  else
+    front_span8<CHROMA_H_NONE> (f, pl, vpair, x0, y, out);
+}
+
 template <int CH>
 GSTAMD_HD void convert_body (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, const ColorParams &color,
     int pack0, int pack1, int pack2, int pack3, uint8_t *__restrict__ dst, int dstride, int spans_per_row, int vec_ok,
@@ -302,43 +388,11 @@ GSTAMD_HD void convert_body (const FrontParams &f, const Planes &pl, const int *
   const int pos[4] = {pack0, pack1, pack2, pack3};
   uint8_t *drow = dst + (size_t) y * dstride;
   if (vec_ok && f.w_sub == 1 && x0 + K1_PX <= w) {
-    const uint2 yy = *(const uint2 *) (pl.p[0] + (size_t) y * pl.stride[0] + x0);
-    const int cw = (w + 1) >> 1, k0 = x0 >> 1;
-    int ra, rb, role = 0;
-    if (f.chroma_v2) {
-      const int e0 = vpair[2 * y];
-      ra = e0 & 0x3fffffff;
-      role = e0 >> 30;
-      rb = vpair[2 * y + 1];
-    } else {
-      ra = rb = y >> f.h_sub;
-    }
-    int u[8], v[8];
-    {
-      Chroma6 c;
-      load_chroma6 (f, pl, ra, k0, cw, c);
-      hfilter8<CH> (c, x0, w, u, v);
-    }
-    if (ra != rb) {
-      Chroma6 c;
-      int u2[8], v2[8];
-      load_chroma6 (f, pl, rb, k0, cw, c);
-      hfilter8<CH> (c, x0, w, u2, v2);
-      const int wa = role == 0 ? 3 : 1, wb = 4 - wa;
+    uint32_t px[8], out[8];
+    front_span8<CH> (f, pl, vpair, x0, y, px);
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        u[i] = (wa * u[i] + wb * u2[i] + 2) >> 2;
-        v[i] = (wa * v[i] + wb * v2[i] + 2) >> 2;
-      }
-    }
-    uint32_t out[8];
-    const uint32_t yw[2] = {yy.x, yy.y};
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const uint32_t Y = (yw[i >> 2] >> (8 * (i & 3))) & 0xff;
-      const uint32_t px = 0xffu | (Y << 8) | ((uint32_t) u[i] << 16) | ((uint32_t) v[i] << 24);
-      out[i] = pack_px (pos, apply_color (color, px));
-    }
+    for (int i = 0; i < 8; i++)
+      out[i] = pack_px (pos, apply_color (color, px[i]));
     uint4 *d = (uint4 *) (drow + 4 * (size_t) x0);
     d[0] = gstamd_make_uint4 (out[0], out[1], out[2], out[3]);
     d[1] = gstamd_make_uint4 (out[4], out[5], out[6], out[7]);
@@ -374,37 +428,166 @@ GSTAMD_HD uint32_t lq_finish (int a0, int a1, int a2, int a3)
       ((uint32_t) lq_round (a3) << 24);
 }
 
-template <class SRC>
-GSTAMD_HD void hscale_body (const SRC &src, const ScaleDev &sd, const Dst &dst, int out_w, int rows, int x, int y)
+// one horizontally scaled pixel; ROW::at (xs) yields source pixel xs of the current row
+template <class ROW>
+GSTAMD_HD uint32_t hscale_px (const ROW &row, const ScaleDev &sd, int x)
 {
-  if (x >= out_w || y >= rows)
-    return;
-  uint32_t r;
-  if (sd.kind == SCALE_NEAREST) {
-    r = src.at ((int) sd.offset[x], y);
-  } else if (sd.kind == SCALE_2TAP) {
+  if (sd.kind == SCALE_NEAREST)
+    return row.at ((int) sd.offset[x]);
+  if (sd.kind == SCALE_2TAP) {
     const int tmp = x * sd.inc;                      // ldreslinl, p1 = 0
     const int idx = tmp >> 16, fr = (tmp >> 8) & 0xff;
-    const uint32_t a = src.at (idx, y), b = src.at (idx + 1, y);
-    r = 0;
+    const uint32_t a = row.at (idx), b = row.at (idx + 1);
+    uint32_t r = 0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const int av = (a >> (8 * c)) & 0xff, bv = (b >> (8 * c)) & 0xff;
       r |= (uint32_t) (((av * (256 - fr) + bv * fr) >> 8) & 0xff) << (8 * c);
     }
+    return r;
+  }
+  const int off = (int) sd.offset[x];
+  const int16_t *t = sd.taps + (size_t) x * sd.n_taps;
+  int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int l = 0; l < sd.n_taps; l++) {
+    const uint32_t p = row.at (off + l);
+    const int tp = t[l];
+    a0 += (int) (p & 0xff) * tp;                     // mullw/addw: only the low 16 bits survive
+    a1 += (int) ((p >> 8) & 0xff) * tp;
+    a2 += (int) ((p >> 16) & 0xff) * tp;
+    a3 += (int) (p >> 24) * tp;
+  }
+  return lq_finish (a0, a1, a2, a3);
+}
+
+// video_orc_resample_v_2tap_u8_lq on two pixels
+GSTAMD_HD uint32_t v2tap_px (uint32_t a, uint32_t b, int p1)
+{
+  uint32_t r = 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int s1 = (a >> (8 * c)) & 0xff, s2 = (b >> (8 * c)) & 0xff;
+    int w2 = (int) (int16_t) (s2 - s1);
+    w2 = (int) (int16_t) (w2 * p1);               // mullw
+    w2 = (int) (int16_t) (w2 + 128);              // addw
+    const int t = (w2 >> 8) & 0xff;               // convhwb
+    r |= (uint32_t) ((t + s1) & 0xff) << (8 * c); // addb
+  }
+  return r;
+}
+
+template <class SRC>
+struct RowOfSrc {
+  const SRC &src;
+  int y;
+  GSTAMD_HD uint32_t at (int x) const { return src.at (x, y); }
+};
+
+template <class SRC>
+struct RowVFiltered {
+  const SRC &src;
+  int ya, p1;
+  bool v2;
+  GSTAMD_HD uint32_t at (int xs) const
+  {
+    const uint32_t a = src.at (xs, ya);
+    return v2 ? v2tap_px (a, src.at (xs, ya + 1), p1) : a;
+  }
+};
+
+struct RowVLds {
+  const uint32_t *a, *b;
+  int x_lo, p1;
+  bool v2;
+  GSTAMD_HD uint32_t at (int x) const { return v2 ? v2tap_px (a[x - x_lo], b[x - x_lo], p1) : a[x - x_lo]; }
+};
+
+struct RowOfLds {
+  const uint32_t *lds;
+  int x_lo;
+  GSTAMD_HD uint32_t at (int x) const { return lds[x - x_lo]; }
+};
+
+template <class SRC>
+GSTAMD_HD void hscale_body (const SRC &src, const ScaleDev &sd, const Dst &dst, int out_w, int rows, int x, int y)
+{
+  if (x >= out_w || y >= rows)
+    return;
+  const RowOfSrc<SRC> row = {src, y};
+  dst.put (x, y, hscale_px (row, sd, x));
+}
+
+// source span [x_lo, x_hi) of row pixels needed by outputs [t0, t1)
+GSTAMD_HD void hscale_span (const ScaleDev &sd, int t0, int t1, int *x_lo, int *x_hi)
+{
+  if (sd.kind == SCALE_2TAP) {
+    *x_lo = (t0 * sd.inc) >> 16;
+    *x_hi = (((t1 - 1) * sd.inc) >> 16) + 2;
   } else {
-    const int off = (int) sd.offset[x];
-    const int16_t *t = sd.taps + (size_t) x * sd.n_taps;
-    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int l = 0; l < sd.n_taps; l++) {
-      const uint32_t p = src.at (off + l, y);
-      const int tp = t[l];
-      a0 += (int) (p & 0xff) * tp;                   // mullw/addw: only the low 16 bits survive
-      a1 += (int) ((p >> 8) & 0xff) * tp;
-      a2 += (int) ((p >> 16) & 0xff) * tp;
-      a3 += (int) (p >> 24) * tp;
+    const int n = sd.kind == SCALE_NEAREST ? 1 : sd.n_taps;
+    *x_lo = (int) sd.offset[t0];
+    *x_hi = (int) sd.offset[t1 - 1] + n;
+  }
+}
+
+// LDS-staged horizontal pass, phase 1: lane `tid` of `nthreads` evaluates its share of the span ONCE
+// (the front functor - unpack + chroma upsample - is no longer re-evaluated per tap)
+template <class SRC>
+GSTAMD_HD void hscale_stage (const SRC &src, uint32_t *lds, int x_lo, int x_hi, int y, int tid, int nthreads)
+{
+  src.stage (lds, x_lo, x_hi, y, tid, nthreads);
+}
+
+// fused 2x2 scaler from staged rows: lds_a / lds_b hold pixels [x_lo, x_hi) of source lines ya / ya+1
+GSTAMD_HD uint32_t scale2x2_from_lds (const uint32_t *lds_a, const uint32_t *lds_b, int x_lo, const ScaleDev &sh, const ScaleDev &sv,
+    int h_first, int x, int y)
+{
+  const bool v2 = sv.kind == SCALE_2TAP;
+  const int p1 = v2 ? (int) sv.taps[(size_t) y * 2 + 1] : 0;
+  if (h_first) {
+    const RowOfLds ra = {lds_a, x_lo};
+    const uint32_t ha = hscale_px (ra, sh, x);
+    if (!v2)
+      return ha;
+    const RowOfLds rb = {lds_b, x_lo};
+    return v2tap_px (ha, hscale_px (rb, sh, x), p1);
+  }
+  const RowVLds vr = {lds_a, lds_b, x_lo, p1, v2};
+  return hscale_px (vr, sh, x);
+}
+
+// phase 2 (after the barrier): one output pixel from the staged row
+GSTAMD_HD void hscale_from_lds (const uint32_t *lds, int x_lo, const ScaleDev &sd, const Dst &dst, int x, int y)
+{
+  const RowOfLds row = {lds, x_lo};
+  dst.put (x, y, hscale_px (row, sd, x));
+}
+
+// Fused 2x2 scaler: both passes are nearest or 2-tap ("bilinear", the element default): one lane = one output
+// pixel computed straight from <= 4 source pixels, pass order as planned (h_first), no intermediate image.
+template <class SRC>
+GSTAMD_HD void scale2x2_body (const SRC &src, const ScaleDev &sh, const ScaleDev &sv, int h_first, const Dst &dst, int out_w,
+    int out_h, int x, int y)
+{
+  if (x >= out_w || y >= out_h)
+    return;
+  const int ya = (int) sv.offset[y];
+  const bool v2 = sv.kind == SCALE_2TAP;
+  const int p1 = v2 ? (int) sv.taps[(size_t) y * 2 + 1] : 0;
+  uint32_t r;
+  if (h_first) {
+    const RowOfSrc<SRC> ra = {src, ya};
+    const uint32_t ha = hscale_px (ra, sh, x);
+    if (v2) {
+      const RowOfSrc<SRC> rb = {src, ya + 1};
+      r = v2tap_px (ha, hscale_px (rb, sh, x), p1);
+    } else {
+      r = ha;
     }
-    r = lq_finish (a0, a1, a2, a3);
+  } else {
+    // vertical first: the horizontal filter then reads vertically filtered pixels
+    const RowVFiltered<SRC> vr = {src, ya, p1, v2};
+    r = hscale_px (vr, sh, x);
   }
   dst.put (x, y, r);
 }
@@ -420,17 +603,7 @@ GSTAMD_HD void vscale_body (const SRC &src, const ScaleDev &sd, const Dst &dst, 
     r = src.at (x, off);
   } else if (sd.kind == SCALE_2TAP) {
     const int p1 = sd.taps[(size_t) y * 2 + 1];
-    const uint32_t a = src.at (x, off), b = src.at (x, off + 1);
-    r = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int s1 = (a >> (8 * c)) & 0xff, s2 = (b >> (8 * c)) & 0xff;
-      int w2 = (int) (int16_t) (s2 - s1);
-      w2 = (int) (int16_t) (w2 * p1);               // mullw
-      w2 = (int) (int16_t) (w2 + 128);              // addw
-      const int t = (w2 >> 8) & 0xff;               // convhwb
-      r |= (uint32_t) ((t + s1) & 0xff) << (8 * c); // addb
-    }
+    r = v2tap_px (src.at (x, off), src.at (x, off + 1), p1);
   } else {
     const int16_t *t = sd.taps + (size_t) y * sd.n_taps;
     int a0 = 0, a1 = 0, a2 = 0, a3 = 0;

@@ -71,6 +71,52 @@ __global__ __launch_bounds__ (256) void k_hscale (SRC src, ScaleDev sd, Dst dst,
   hscale_body<SRC> (src, sd, dst, out_w, rows, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
 }
 
+// LDS-staged horizontal pass: block = 256 consecutive outputs of one row; the source span under them is
+// evaluated once into LDS (<= HSCALE_LDS_PX pixels), then every lane filters from LDS.
+#define HSCALE_LDS_PX 12288
+template <class SRC>
+__global__ __launch_bounds__ (256) void k_hscale_lds (SRC src, ScaleDev sd, Dst dst, int out_w, int rows)
+{
+  extern __shared__ uint32_t lds[];     // max_span pixels (launcher sizes it)
+  const int y = blockIdx.y, t0 = blockIdx.x * blockDim.x;
+  const int t1 = t0 + (int) blockDim.x < out_w ? t0 + (int) blockDim.x : out_w;
+  int x_lo, x_hi;
+  hscale_span (sd, t0, t1, &x_lo, &x_hi);
+  hscale_stage<SRC> (src, lds, x_lo, x_hi, y, (int) threadIdx.x, (int) blockDim.x);
+  __syncthreads ();
+  const int x = t0 + (int) threadIdx.x;
+  if (x < out_w)
+    hscale_from_lds (lds, x_lo, sd, dst, x, y);
+}
+
+// fused nearest/2-tap scaler with the two source lines staged in LDS (spans <= SCALE2_LDS_PX pixels each)
+#define SCALE2_LDS_PX 6144
+template <class SRC>
+__global__ __launch_bounds__ (256) void k_scale2x2_lds (SRC src, ScaleDev sh, ScaleDev sv, int h_first, Dst dst, int out_w, int out_h,
+    int span)
+{
+  extern __shared__ uint32_t lds2[];    // 2 x span pixels
+  uint32_t *lds_a = lds2, *lds_b = lds2 + span;
+  const int y = blockIdx.y, t0 = blockIdx.x * blockDim.x;
+  const int t1 = t0 + (int) blockDim.x < out_w ? t0 + (int) blockDim.x : out_w;
+  int x_lo, x_hi;
+  hscale_span (sh, t0, t1, &x_lo, &x_hi);
+  const int ya = (int) sv.offset[y];
+  src.stage (lds_a, x_lo, x_hi, ya, (int) threadIdx.x, (int) blockDim.x);
+  if (sv.kind == SCALE_2TAP)
+    src.stage (lds_b, x_lo, x_hi, ya + 1, (int) threadIdx.x, (int) blockDim.x);
+  __syncthreads ();
+  const int x = t0 + (int) threadIdx.x;
+  if (x < out_w)
+    dst.put (x, y, scale2x2_from_lds (lds_a, lds_b, x_lo, sh, sv, h_first, x, y));
+}
+
+template <class SRC>
+__global__ __launch_bounds__ (256) void k_scale2x2 (SRC src, ScaleDev sh, ScaleDev sv, int h_first, Dst dst, int out_w, int out_h)
+{
+  scale2x2_body<SRC> (src, sh, sv, h_first, dst, out_w, out_h, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
 template <class SRC>
 __global__ __launch_bounds__ (256) void k_vscale (SRC src, ScaleDev sd, Dst dst, int width, int out_h)
 {
@@ -233,6 +279,18 @@ hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames
   return hipGetLastError ();
 }
 
+static int front_vec_ok (const FrontParams &f, const Planes &pl)
+{
+  if (f.kind == UNPACK_PACKED4 || f.w_sub != 1)
+    return 0;
+  int ok = aligned (pl.p[0], 8) && (pl.stride[0] % 8) == 0;
+  if (f.kind == UNPACK_SEMI)
+    ok = ok && aligned (pl.p[1], 8) && (pl.stride[1] % 8) == 0;
+  else
+    ok = ok && aligned (pl.p[1], 4) && aligned (pl.p[2], 4) && (pl.stride[1] % 4) == 0 && (pl.stride[2] % 4) == 0;
+  return ok;
+}
+
 static Dst make_dst (uint8_t *p, int stride, bool final, const ColorParams &post, const int pack_pos[4])
 {
   Dst d;
@@ -247,16 +305,19 @@ static Dst make_dst (uint8_t *p, int stride, bool final, const ColorParams &post
 
 hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const Planes &pl, const int *vpair_dev,
     const ColorParams &pre, const ScaleDev &sd, uint8_t *dst, int dstride, bool final, const ColorParams &post,
-    const int pack_pos[4], int out_w, int out_h, hipStream_t stream)
+    const int pack_pos[4], int out_w, int out_h, int max_span, hipStream_t stream)
 {
   SrcFront src;
   src.f = f;
   src.pl = pl;
   src.vpair = vpair_dev;
   src.pre = pre;
+  src.vec_ok = front_vec_ok (f, pl);
   Dst d = make_dst (dst, dstride, final, post, pack_pos);
   dim3 block (256), grid ((out_w + 255) / 256, out_h);
-  if (horizontal)
+  if (horizontal && max_span <= HSCALE_LDS_PX)
+    hipLaunchKernelGGL (k_hscale_lds<SrcFront>, grid, block, (size_t) max_span * 4, stream, src, sd, d, out_w, out_h);
+  else if (horizontal)
     hipLaunchKernelGGL (k_hscale<SrcFront>, grid, block, 0, stream, src, sd, d, out_w, out_h);
   else
     hipLaunchKernelGGL (k_vscale<SrcFront>, grid, block, 0, stream, src, sd, d, out_w, out_h);
@@ -264,17 +325,38 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
 }
 
 hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int sstride, const ScaleDev &sd, uint8_t *dst,
-    int dstride, bool final, const ColorParams &post, const int pack_pos[4], int out_w, int out_h, hipStream_t stream)
+    int dstride, bool final, const ColorParams &post, const int pack_pos[4], int out_w, int out_h, int max_span, hipStream_t stream)
 {
   SrcImage src;
   src.p = simg;
   src.stride = sstride;
   Dst d = make_dst (dst, dstride, final, post, pack_pos);
   dim3 block (256), grid ((out_w + 255) / 256, out_h);
-  if (horizontal)
+  if (horizontal && max_span <= HSCALE_LDS_PX)
+    hipLaunchKernelGGL (k_hscale_lds<SrcImage>, grid, block, (size_t) max_span * 4, stream, src, sd, d, out_w, out_h);
+  else if (horizontal)
     hipLaunchKernelGGL (k_hscale<SrcImage>, grid, block, 0, stream, src, sd, d, out_w, out_h);
   else
     hipLaunchKernelGGL (k_vscale<SrcImage>, grid, block, 0, stream, src, sd, d, out_w, out_h);
+  return hipGetLastError ();
+}
+
+hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &pre,
+    const ScaleDev &sh, const ScaleDev &sv, bool h_first, uint8_t *dst, int dstride, const ColorParams &post,
+    const int pack_pos[4], int out_w, int out_h, int h_span, hipStream_t stream)
+{
+  SrcFront src;
+  src.f = f;
+  src.pl = pl;
+  src.vpair = vpair_dev;
+  src.pre = pre;
+  src.vec_ok = front_vec_ok (f, pl);
+  Dst d = make_dst (dst, dstride, true, post, pack_pos);
+  dim3 block (256), grid ((out_w + 255) / 256, out_h);
+  if (h_span <= SCALE2_LDS_PX)
+    hipLaunchKernelGGL (k_scale2x2_lds<SrcFront>, grid, block, (size_t) h_span * 8, stream, src, sh, sv, h_first ? 1 : 0, d, out_w, out_h, h_span);
+  else
+    hipLaunchKernelGGL (k_scale2x2<SrcFront>, grid, block, 0, stream, src, sh, sv, h_first ? 1 : 0, d, out_w, out_h);
   return hipGetLastError ();
 }
 

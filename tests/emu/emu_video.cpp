@@ -13,8 +13,28 @@
 using namespace gstamd;
 
 template <class SRC>
-static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h)
+static void run_hscale_lds (const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h)
 {
+  std::vector<uint32_t> lds (12288);
+  for (int y = 0; y < out_h; y++)
+    for (int t0 = 0; t0 < out_w; t0 += 256) {
+      const int t1 = t0 + 256 < out_w ? t0 + 256 : out_w;
+      int lo, hi;
+      hscale_span (sd, t0, t1, &lo, &hi);
+      for (int tid = 0; tid < 256; tid++)
+        hscale_stage<SRC> (src, lds.data (), lo, hi, y, tid, 256);
+      for (int x = t0; x < t1; x++)
+        hscale_from_lds (lds.data (), lo, sd, d, x, y);
+    }
+}
+
+template <class SRC>
+static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h, int max_span = 1 << 30)
+{
+  if (horizontal && max_span <= 12288) {
+    run_hscale_lds (src, sd, d, out_w, out_h);
+    return;
+  }
   for (int y = 0; y < out_h; y++)
     for (int x = 0; x < out_w; x++) {
       if (horizontal)
@@ -131,6 +151,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   sf.pl = pl;
   sf.vpair = vpair;
   sf.pre = pre;
+  sf.vec_ok = vec_ok ? 1 : 0;
   auto mk = [&](uint8_t *ptr, int stride, bool fin) {
     Dst d;
     d.p = ptr;
@@ -140,17 +161,46 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     memcpy (d.pack_pos, p.post.pack_pos, sizeof (d.pack_pos));
     return d;
   };
+  const auto small_kind = [](int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; };
+  if (p.passes.size () == 2 && small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)) {
+    const bool h_first = p.passes[0].horizontal;
+    const ScaleDev &sh = h_first ? sd[0] : sd[1], &sv = h_first ? sd[1] : sd[0];
+    const Dst d = mk (d0, dstride, true);
+    const int span = p.passes[h_first ? 0 : 1].max_span;
+    if (span <= 6144) {                    /* k_scale2x2_lds */
+      std::vector<uint32_t> la (6144), lb (6144);
+      for (int y = 0; y < out->height; y++)
+        for (int t0 = 0; t0 < out->width; t0 += 256) {
+          const int t1 = t0 + 256 < out->width ? t0 + 256 : out->width;
+          int lo, hi;
+          hscale_span (sh, t0, t1, &lo, &hi);
+          const int ya = (int) sv.offset[y];
+          for (int tid = 0; tid < 256; tid++) {
+            sf.stage (la.data (), lo, hi, ya, tid, 256);
+            if (sv.kind == SCALE_2TAP)
+              sf.stage (lb.data (), lo, hi, ya + 1, tid, 256);
+          }
+          for (int x = t0; x < t1; x++)
+            d.put (x, y, scale2x2_from_lds (la.data (), lb.data (), lo, sh, sv, h_first ? 1 : 0, x, y));
+        }
+      return GSTAMD_OK;
+    }
+    for (int y = 0; y < out->height; y++)
+      for (int x = 0; x < out->width; x++)
+        scale2x2_body<SrcFront> (sf, sh, sv, h_first ? 1 : 0, d, out->width, out->height, x, y);
+    return GSTAMD_OK;
+  }
   if (p.passes.size () == 1) {
-    run_scale (p.passes[0].horizontal, sf, sd[0], mk (d0, dstride, true), out->width, out->height);
+    run_scale (p.passes[0].horizontal, sf, sd[0], mk (d0, dstride, true), out->width, out->height, p.passes[0].max_span);
     return GSTAMD_OK;
   }
   const ScalePass &s0 = p.passes[0];
   const int tw = s0.horizontal ? s0.out_size : in->width, th = s0.horizontal ? in->height : s0.out_size;
   std::vector<uint8_t> tmp ((size_t) tw * 4 * th);
-  run_scale (s0.horizontal, sf, sd[0], mk (tmp.data (), tw * 4, false), tw, th);
+  run_scale (s0.horizontal, sf, sd[0], mk (tmp.data (), tw * 4, false), tw, th, s0.max_span);
   SrcImage si;
   si.p = tmp.data ();
   si.stride = tw * 4;
-  run_scale (p.passes[1].horizontal, si, sd[1], mk (d0, dstride, true), out->width, out->height);
+  run_scale (p.passes[1].horizontal, si, sd[1], mk (d0, dstride, true), out->width, out->height, p.passes[1].max_span);
   return GSTAMD_OK;
 }

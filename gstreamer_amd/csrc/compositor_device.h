@@ -28,6 +28,7 @@
 namespace gstamd {
 
 #define GSTAMD_MAX_FUSED_PADS 32
+#define AGG_GROUP 8
 
 struct PadDev {
   const uint8_t *data;
@@ -44,6 +45,7 @@ struct AggregateParams {
   int checker_yuv;  // checker for AYUV: Y = tab, U = V = 128
   uint32_t bg_word;
   int n_pads;
+  int fast;         // every pad takes the opaque blend (px2_blend): !overlay and no SOURCE operator
   PadDev pads[GSTAMD_MAX_FUSED_PADS];
 };
 
@@ -129,6 +131,166 @@ GSTAMD_CD uint32_t aggregate_px (const AggregateParams &p, uint32_t dest_in, int
     }
   }
   return d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4 pixels per lane.  Opaque-destination blend (compositor_orc_blend_*) on two packed halves:
+// e = bytes 0,2 and o = bytes 1,3 of the pixel, each in its own 16-bit lane of a 32-bit register.
+// All reference intermediates are < 2^16 here (s*a + d*(255-a) <= 255*255), so the "& 0xffff" wraps of
+// the ORC program never trigger and one 24-bit multiply serves two channels; div255w (x) =
+// (x * 0x8081) >> 23 equals (x + 1 + ((x + 1) >> 8)) >> 8 for every x <= 65025 (checked exhaustively
+// in tests/test_compositor.py), which needs no multiply and works per 16-bit lane.
+struct Px2 {
+  uint32_t e, o;
+};
+
+GSTAMD_CD uint32_t pk16_shr8 (uint32_t x)
+{
+#ifdef __HIPCC__
+  typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
+  us2 v = __builtin_bit_cast (us2, x);
+  v = v >> (unsigned short) 8;
+  return __builtin_bit_cast (uint32_t, v);
+#else
+  return (x >> 8) & 0x00ff00ffu;
+#endif
+}
+
+GSTAMD_CD Px2 px2_unpack (uint32_t v)
+{
+  Px2 r;
+  r.e = v & 0x00ff00ffu;
+  r.o = (v >> 8) & 0x00ff00ffu;
+  return r;
+}
+
+GSTAMD_CD uint32_t px2_pack (const Px2 &v) { return v.e | (v.o << 8); }
+
+GSTAMD_CD uint32_t pk16_div255 (uint32_t x)
+{
+  const uint32_t t = x + 0x00010001u;
+  return pk16_shr8 (t + pk16_shr8 (t));
+}
+
+// 24-bit x 24-bit multiply (v_mul_u32_u24); every operand below is < 2^24
+GSTAMD_CD uint32_t mul24 (uint32_t a, uint32_t b)
+{
+#ifdef __HIPCC__
+  uint32_t r;
+  asm ("v_mul_u32_u24 %0, %1, %2" : "=v" (r) : "v" (a), "v" (b));
+  return r;
+#else
+  return a * b;
+#endif
+}
+
+// same with a wave-uniform second factor (pad alpha, constants)
+GSTAMD_CD uint32_t mul24_uniform (uint32_t a, uint32_t b)
+{
+#ifdef __HIPCC__
+  uint32_t r;
+  asm ("v_mul_u32_u24 %0, %1, %2" : "=v" (r) : "v" (a), "s" (b));
+  return r;
+#else
+  return a * b;
+#endif
+}
+
+GSTAMD_CD void px2_blend (Px2 &d, uint32_t s, uint32_t alpha, int ashift)
+{
+  const uint32_t a = mul24_uniform (mul24_uniform ((s >> ashift) & 0xff, alpha), 0x8081u) >> 23;     // div255w: product < 2^16
+  const uint32_t ia = 0xffu - a;
+  const Px2 sp = px2_unpack (s);
+  d.e = pk16_div255 (mul24 (sp.e, a) + mul24 (d.e, ia)) | (ashift == 0 ? 0xffu : 0u);
+  d.o = pk16_div255 (mul24 (sp.o, a) + mul24 (d.o, ia)) | (ashift == 0 ? 0u : 0x00ff0000u);
+}
+
+struct __attribute__ ((aligned (4))) Px4Words {
+  uint32_t v[4];
+};
+
+// A pad that intersects one block's strip (destination row y, columns [bx0, bx1)): everything the lanes need,
+// resolved once per block (k_aggregate builds the list with one lane per pad and a ballot).
+struct PadHit {
+  const uint8_t *row;   // first byte of the pad's source row under destination row y
+  int xpos, width;
+  int s_alpha, mode;
+};
+
+GSTAMD_CD bool pad_hit_test (const AggregateParams &p, int k, int bx0, int bx1, int y, PadHit *h)
+{
+  const PadDev &pad = p.pads[k];
+  const int sy = y - pad.ypos;
+  if (sy < 0 || sy >= pad.height || pad.xpos >= bx1 || pad.xpos + pad.width <= bx0)
+    return false;
+  h->row = pad.data + (size_t) sy * pad.stride;
+  h->xpos = pad.xpos;
+  h->width = pad.width;
+  h->s_alpha = pad.s_alpha;
+  h->mode = pad.mode;
+  return true;
+}
+
+// pixels x .. x+3 of destination row y from the block's hit list.  p.fast = every pad of the chunk takes the
+// opaque blend (no transparent background, no SOURCE operator), decided on the host.
+GSTAMD_CD void aggregate_span4 (const AggregateParams &p, const PadHit *hits, int n_hits, uint32_t *d, int x, int y)
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    d[i] = p.bg_kind == 0 ? checker_px (x + i, y, p.ashift, p.checker_yuv) : (p.bg_kind == 1 ? p.bg_word : d[i]);
+  if (!p.fast) {
+    for (int k = 0; k < n_hits; k++) {
+      const PadHit h = hits[k];
+      const int sx = x - h.xpos;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (sx + i >= 0 && sx + i < h.width)
+          d[i] = apply_pad (d[i], *(const uint32_t *) (h.row + 4 * (size_t) (sx + i)), h.s_alpha, h.mode, p.ashift, p.overlay);
+    }
+    return;
+  }
+  Px2 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    acc[i] = px2_unpack (d[i]);
+  // hits in groups of AGG_GROUP: first issue every member's 16-byte load (independent of the blend chain, so they
+  // are all in flight together), then run the order-dependent blends from registers
+  for (int k0 = 0; k0 < n_hits; k0 += AGG_GROUP) {
+    Px4Words sv[AGG_GROUP];
+    int st[AGG_GROUP];                            // 0 = no overlap, 1 = four pixels loaded, 2 = partial overlap
+#pragma unroll
+    for (int j = 0; j < AGG_GROUP; j++) {
+      st[j] = 0;
+      if (k0 + j < n_hits) {
+        const int sx = x - hits[k0 + j].xpos, w = hits[k0 + j].width;
+        if (sx >= 0 && sx + 4 <= w) {
+          sv[j] = *(const Px4Words *) (hits[k0 + j].row + 4 * (size_t) sx);
+          st[j] = 1;
+        } else if (sx + 3 >= 0 && sx < w) {
+          st[j] = 2;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < AGG_GROUP; j++) {
+      if (st[j] == 1) {
+        const uint32_t alpha = (uint32_t) hits[k0 + j].s_alpha;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          px2_blend (acc[i], sv[j].v[i], alpha, p.ashift);
+      } else if (st[j] == 2) {
+        const PadHit h = hits[k0 + j];
+        const int sx = x - h.xpos;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (sx + i >= 0 && sx + i < h.width)
+            px2_blend (acc[i], *(const uint32_t *) (h.row + 4 * (size_t) (sx + i)), (uint32_t) h.s_alpha, p.ashift);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    d[i] = px2_pack (acc[i]);
 }
 
 }  // namespace gstamd

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -20,22 +21,38 @@ struct __attribute__ ((aligned (4))) px4 { uint32_t v[4]; };
 __global__ __launch_bounds__ (256) void k_aggregate (AggregateParams p, uint8_t *__restrict__ dst, int dstride, int rx0,
     int ry0, int rw, int rh)
 {
+  __shared__ PadHit hits[GSTAMD_MAX_FUSED_PADS];
+  __shared__ int n_hits;
   const int gx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int gy = blockIdx.y;
-  if (gx >= rw || gy >= rh)
+  const int y = ry0 + gy;
+  // wave 0, one lane per pad: which pads touch this block's strip?  (ballot-compacted, order preserved)
+  if (threadIdx.x < 64) {
+    const int k = (int) threadIdx.x;
+    const int bx0 = rx0 + (int) (blockIdx.x * blockDim.x) * 4;
+    const int bx1 = bx0 + (int) blockDim.x * 4 < rx0 + rw ? bx0 + (int) blockDim.x * 4 : rx0 + rw;
+    PadHit h;
+    const bool hit = k < p.n_pads && pad_hit_test (p, k, bx0, bx1, y, &h);
+    const unsigned long long m = __ballot (hit);
+    if (hit)
+      hits[__popcll (m & ((1ull << k) - 1ull))] = h;
+    if (k == 0)
+      n_hits = __popcll (m);
+  }
+  __syncthreads ();
+  if (gx >= rw)
     return;
-  const int x = rx0 + gx, y = ry0 + gy;
+  const int x = rx0 + gx;
   uint8_t *row = dst + (size_t) y * dstride;
   const int n = rw - gx < 4 ? rw - gx : 4;
+  const int nh = n_hits;
   if (n == 4) {
     px4 d;
     if (p.bg_kind == 2)
       d = *(const px4 *) (row + 4 * (size_t) x);
     else
       d.v[0] = d.v[1] = d.v[2] = d.v[3] = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      d.v[i] = aggregate_px (p, d.v[i], x + i, y);
+    aggregate_span4 (p, hits, nh, d.v, x, y);
     *(px4 *) (row + 4 * (size_t) x) = d;
   } else {
     for (int i = 0; i < n; i++) {
@@ -64,10 +81,17 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
 {
   if (rw <= 0 || rh <= 0)
     return GSTAMD_OK;
+  AggregateParams q = p;
+  q.fast = !p.overlay;
+  for (int i = 0; i < p.n_pads; i++)
+    if (p.pads[i].mode == GSTAMD_COMPOSITOR_BLEND_MODE_SOURCE)
+      q.fast = 0;
+  if (q.fast && getenv ("GSTAMD_AGG_ABLATE"))
+    q.fast = atoi (getenv ("GSTAMD_AGG_ABLATE"));
   const int lanes = (rw + 3) / 4;
   const int bx = lanes >= 256 ? 256 : (lanes > 64 ? 128 : 64);
   dim3 grid ((lanes + bx - 1) / bx, rh), block (bx);
-  hipLaunchKernelGGL (k_aggregate, grid, block, 0, (hipStream_t) stream, p, (uint8_t *) dest, dstride, rx0, ry0, rw, rh);
+  hipLaunchKernelGGL (k_aggregate, grid, block, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh);
   return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
 }
 

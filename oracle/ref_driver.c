@@ -284,6 +284,8 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
       fn = gst_compositor_fill_checker_bgra;
     else if (!strcmp (fmt_func, "argb"))
       fn = gst_compositor_fill_checker_argb;
+    else if (!strcmp (fmt_func, "ayuv"))
+      fn = gst_compositor_fill_checker_ayuv;
     if (!fn)
       return -1;
     fn (&df, y0, y1);
@@ -297,6 +299,8 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
       fn = gst_compositor_fill_color_rgba;
     else if (!strcmp (fmt_func, "abgr"))
       fn = gst_compositor_fill_color_abgr;
+    else if (!strcmp (fmt_func, "ayuv"))
+      fn = gst_compositor_fill_color_ayuv;
     if (!fn)
       return -1;
     fn (&df, y0, y1, c1, c2, c3);

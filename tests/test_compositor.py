@@ -27,7 +27,7 @@ class PadDev(C.Structure):
 
 class AggParams(C.Structure):
     _fields_ = [("ashift", C.c_int), ("overlay", C.c_int), ("bg_kind", C.c_int), ("checker_yuv", C.c_int),
-                ("bg_word", C.c_uint32), ("n_pads", C.c_int), ("pads", PadDev * 32)]
+                ("bg_word", C.c_uint32), ("n_pads", C.c_int), ("fast", C.c_int), ("pads", PadDev * 32)]
 
 
 def ref_blend(ref, case, src, dst):
@@ -86,7 +86,7 @@ def test_hip_fills_match_reference(native_lib, gpu, ref, fmt):
     import torch
     w, h = 70, 33
     exp = np.zeros(w * h * 4, np.uint8)
-    checker_fn = {"BGRA": "bgra", "RGBA": "bgra", "ARGB": "argb", "ABGR": "argb"}.get(fmt)
+    checker_fn = {"BGRA": "bgra", "RGBA": "bgra", "ARGB": "argb", "ABGR": "argb", "AYUV": "ayuv"}.get(fmt)
     d = torch.zeros(w * h * 4, dtype=torch.uint8, device=gpu)
     if checker_fn:
         ref.compositor_fill(0, checker_fn, fmt, exp, w, h, 3, 30)
@@ -100,6 +100,73 @@ def test_hip_fills_match_reference(native_lib, gpu, ref, fmt):
         assert V.lib().gstamd_compositor_fill_color(V.FORMATS[fmt], d.data_ptr(), w, h, w * 4, 2, 31, 10, 200, 77, None) == 0
         torch.cuda.synchronize()
         assert (d.cpu().numpy() == exp).all()
+
+
+def _aggregate_expected(ref, fmt, background, geo, pads_np, pw, ph, dw, dh):
+    fam = FAM[fmt]
+    exp = np.zeros(dw * dh * 4, np.uint8)
+    if background == 0:
+        ref.compositor_fill(0, "ayuv" if fmt == "AYUV" else fam, fmt, exp, dw, dh, 0, dh)
+    elif background == 1:
+        ref.compositor_fill(1, fmt.lower(), fmt, exp, dw, dh, 0, dh, 0, 0, 0)
+    elif background == 2:
+        ref.compositor_fill(1, fmt.lower(), fmt, exp, dw, dh, 0, dh, 255, 255, 255)
+    func = ("overlay_" if background == 3 else "blend_") + fam
+    for i, (xpos, ypos, alpha, mode) in enumerate(geo):
+        ref.compositor_blend(func, fmt, pads_np[i], pw, ph, xpos, ypos, alpha, exp, dw, dh, 0, dh, mode)
+    return exp
+
+
+def _over_geometry(n_pads):
+    """all-OVER / ADD pads at odd offsets, partly outside the canvas: the packed 4-pixel blend path"""
+    return [((i % 4) * 43 - 11, (i // 4) * 29 - 7, min(1.0, 0.25 + 0.05 * i), 1 if i % 3 else 2) for i in range(n_pads)]
+
+
+@pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("ARGB", 1), ("AYUV", 0), ("RGBA", 2)])
+def test_aggregate_packed_path_on_host_matches_reference(emu_lib, ref, fmt, background):
+    emu_lib.emu_compositor_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    dw, dh, pw, ph, n_pads = 203, 97, 90, 41, 12
+    pads_np = [cases.frame_bytes(pw * ph * 4, "random", 7100 + i) for i in range(n_pads)]
+    geo = _over_geometry(n_pads)
+    exp = _aggregate_expected(ref, fmt, background, geo, pads_np, pw, ph, dw, dh)
+    p = AggParams()
+    p.ashift = 0 if FAM[fmt] == "argb" else 24
+    p.overlay, p.bg_kind, p.checker_yuv = 0, (0 if background == 0 else 1), int(fmt == "AYUV")
+    if background:
+        word = np.zeros(4, np.uint8)
+        ref.compositor_fill(1, fmt.lower(), fmt, word, 1, 1, 0, 1, *((0, 0, 0) if background == 1 else (255, 255, 255)))
+        p.bg_word = int(word.view(np.uint32)[0])
+    k = 0
+    for i, (xpos, ypos, alpha, mode) in enumerate(geo):
+        sa = max(0, min(255, int(alpha * 255)))
+        if not sa:
+            continue
+        pd = p.pads[k]
+        pd.data, pd.width, pd.height, pd.stride, pd.xpos, pd.ypos, pd.s_alpha, pd.mode = pads_np[i].ctypes.data, pw, ph, pw * 4, xpos, ypos, sa, mode
+        k += 1
+    p.n_pads = k
+    got = np.zeros(dw * dh * 4, np.uint8)
+    emu_lib.emu_compositor_run(C.byref(p), got.ctypes.data, dw * 4, 0, 0, dw, dh)
+    assert (exp == got).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("ARGB", 1), ("AYUV", 0), ("RGBA", 2)])
+def test_hip_aggregate_packed_path_matches_reference(native_lib, gpu, ref, fmt, background):
+    import torch
+    dw, dh, pw, ph, n_pads = 203, 97, 90, 41, 12
+    pads_np = [cases.frame_bytes(pw * ph * 4, "random", 7100 + i) for i in range(n_pads)]
+    geo = _over_geometry(n_pads)
+    exp = _aggregate_expected(ref, fmt, background, geo, pads_np, pw, ph, dw, dh)
+    d_pads = [torch.from_numpy(p).to(gpu) for p in pads_np]
+    arr = (V.CompositorPad * n_pads)()
+    for i, (xpos, ypos, alpha, mode) in enumerate(geo):
+        arr[i].data, arr[i].width, arr[i].height, arr[i].stride = d_pads[i].data_ptr(), pw, ph, pw * 4
+        arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = xpos, ypos, alpha, mode
+    d_out = torch.zeros(dw * dh * 4, dtype=torch.uint8, device=gpu)
+    assert V.lib().gstamd_compositor_aggregate(V.FORMATS[fmt], background, arr, n_pads, d_out.data_ptr(), dw, dh, dw * 4, None) == 0
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy() == exp).all()
 
 
 @pytest.mark.gpu
@@ -160,3 +227,9 @@ def test_hip_aggregate_c4_full_size_properties(native_lib, gpu):
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     assert bool((a.view(-1, 4)[:, 3] == 255).all())
+
+
+def test_div255_identity_used_by_packed_blend():
+    """compositor_device.h pk16_div255: (x*0x8081)>>23 == (x+1+((x+1)>>8))>>8 for every reachable x (<= 255*255)."""
+    x = np.arange(0, 255 * 255 + 1, dtype=np.int64)
+    assert np.array_equal((x * 0x8081) >> 23, (x + 1 + ((x + 1) >> 8)) >> 8)

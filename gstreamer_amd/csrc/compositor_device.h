@@ -28,7 +28,6 @@
 namespace gstamd {
 
 #define GSTAMD_MAX_FUSED_PADS 32
-#define AGG_GROUP 8
 
 struct PadDev {
   const uint8_t *data;
@@ -196,9 +195,10 @@ GSTAMD_CD uint32_t mul24_uniform (uint32_t a, uint32_t b)
 #endif
 }
 
-GSTAMD_CD void px2_blend (Px2 &d, uint32_t s, uint32_t alpha, int ashift)
+// alpha8081 = pad alpha * 0x8081 (< 2^24): div255w (sA * alpha) = (sA * alpha * 0x8081) >> 23 in one multiply
+GSTAMD_CD void px2_blend (Px2 &d, uint32_t s, uint32_t alpha8081, int ashift)
 {
-  const uint32_t a = mul24_uniform (mul24_uniform ((s >> ashift) & 0xff, alpha), 0x8081u) >> 23;     // div255w: product < 2^16
+  const uint32_t a = mul24_uniform ((s >> ashift) & 0xff, alpha8081) >> 23;
   const uint32_t ia = 0xffu - a;
   const Px2 sp = px2_unpack (s);
   d.e = pk16_div255 (mul24 (sp.e, a) + mul24 (d.e, ia)) | (ashift == 0 ? 0xffu : 0u);
@@ -209,6 +209,32 @@ struct __attribute__ ((aligned (4))) Px4Words {
   uint32_t v[4];
 };
 
+// 16 bytes at a 4-byte aligned address of a pad image (device: global address space, so the pointer that came
+// through LDS does not turn the access into a flat load)
+GSTAMD_CD Px4Words load_px4 (const uint8_t *p)
+{
+  Px4Words r;
+#ifdef __HIPCC__
+  const __attribute__ ((address_space (1))) uint32_t *g = (const __attribute__ ((address_space (1))) uint32_t *) (uintptr_t) p;
+#else
+  const uint32_t *g = (const uint32_t *) p;
+#endif
+  r.v[0] = g[0];
+  r.v[1] = g[1];
+  r.v[2] = g[2];
+  r.v[3] = g[3];
+  return r;
+}
+
+GSTAMD_CD uint32_t load_px1 (const uint8_t *p)
+{
+#ifdef __HIPCC__
+  return *(const __attribute__ ((address_space (1))) uint32_t *) (uintptr_t) p;
+#else
+  return *(const uint32_t *) p;
+#endif
+}
+
 // A pad that intersects one block's strip (destination row y, columns [bx0, bx1)): everything the lanes need,
 // resolved once per block (k_aggregate builds the list with one lane per pad and a ballot).
 struct PadHit {
@@ -217,28 +243,84 @@ struct PadHit {
   int s_alpha, mode;
 };
 
+// branch-free on purpose: on the device one lane per pad runs this and the whole descriptor should arrive in
+// one round trip instead of a load-compare-load chain
 GSTAMD_CD bool pad_hit_test (const AggregateParams &p, int k, int bx0, int bx1, int y, PadHit *h)
 {
-  const PadDev &pad = p.pads[k];
+  const PadDev pad = p.pads[k];
   const int sy = y - pad.ypos;
-  if (sy < 0 || sy >= pad.height || pad.xpos >= bx1 || pad.xpos + pad.width <= bx0)
-    return false;
-  h->row = pad.data + (size_t) sy * pad.stride;
+  h->row = pad.data + (ptrdiff_t) sy * pad.stride;
   h->xpos = pad.xpos;
   h->width = pad.width;
   h->s_alpha = pad.s_alpha;
   h->mode = pad.mode;
-  return true;
+  return (sy >= 0) & (sy < pad.height) & (pad.xpos < bx1) & (pad.xpos + pad.width > bx0);
+}
+
+// a value that is the same in every lane of the wave (hit-list entries): on the device move it to a scalar register
+// so that the arithmetic on it runs on the scalar unit and does not take VALU issue slots
+GSTAMD_CD int uniform_i32 (int v)
+{
+#ifdef __HIPCC__
+  return __builtin_amdgcn_readfirstlane (v);
+#else
+  return v;
+#endif
+}
+
+GSTAMD_CD const uint8_t *uniform_ptr (const uint8_t *p)
+{
+#ifdef __HIPCC__
+  const uint64_t v = (uint64_t) (uintptr_t) p;
+  const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane ((int) (uint32_t) v);
+  const uint32_t hi = (uint32_t) __builtin_amdgcn_readfirstlane ((int) (uint32_t) (v >> 32));
+  return (const uint8_t *) (uintptr_t) (((uint64_t) hi << 32) | lo);
+#else
+  return p;
+#endif
+}
+
+GSTAMD_CD int span4_clamp (int sx, int w)
+{
+  return sx < 0 ? 0 : (sx > w - 4 ? w - 4 : sx);
+}
+
+#define AGG_DEPTH 4
+
+GSTAMD_CD void issue_order_fence ()
+{
+#ifdef __HIPCC__
+  __builtin_amdgcn_sched_barrier (0);
+#endif
+}
+
+// the (clamped) 16 bytes of hit min (k, n_hits - 1) under destination pixels x .. x+3
+template <int ABL>
+GSTAMD_CD Px4Words span4_fetch (const PadHit *hits, int k, int n_hits, int x)
+{
+  const int kc = k < n_hits ? k : n_hits - 1;
+  if (ABL == 2 || ABL == 4) {
+    Px4Words r;
+    r.v[0] = r.v[1] = r.v[2] = r.v[3] = (uint32_t) (x + kc) * 0x01010101u;
+    return r;
+  }
+  const uint8_t *row = uniform_ptr (hits[kc].row);
+  const int xpos = uniform_i32 (hits[kc].xpos), w = uniform_i32 (hits[kc].width);
+  return load_px4 (row + 4 * (size_t) (unsigned) span4_clamp (x - xpos, w));
 }
 
 // pixels x .. x+3 of destination row y from the block's hit list.  p.fast = every pad of the chunk takes the
 // opaque blend (no transparent background, no SOURCE operator), decided on the host.
+template <int ABL, int ASH>
 GSTAMD_CD void aggregate_span4 (const AggregateParams &p, const PadHit *hits, int n_hits, uint32_t *d, int x, int y)
 {
+  const int ashift = ASH;       // compile-time alpha position on this path (0 or 24)
 #pragma unroll
   for (int i = 0; i < 4; i++)
     d[i] = p.bg_kind == 0 ? checker_px (x + i, y, p.ashift, p.checker_yuv) : (p.bg_kind == 1 ? p.bg_word : d[i]);
-  if (!p.fast) {
+  if (ABL == 3)
+    n_hits = 0;
+  if (!p.fast || n_hits == 0) {
     for (int k = 0; k < n_hits; k++) {
       const PadHit h = hits[k];
       const int sx = x - h.xpos;
@@ -253,38 +335,38 @@ GSTAMD_CD void aggregate_span4 (const AggregateParams &p, const PadHit *hits, in
 #pragma unroll
   for (int i = 0; i < 4; i++)
     acc[i] = px2_unpack (d[i]);
-  // hits in groups of AGG_GROUP: first issue every member's 16-byte load (independent of the blend chain, so they
-  // are all in flight together), then run the order-dependent blends from registers
-  for (int k0 = 0; k0 < n_hits; k0 += AGG_GROUP) {
-    Px4Words sv[AGG_GROUP];
-    int st[AGG_GROUP];                            // 0 = no overlap, 1 = four pixels loaded, 2 = partial overlap
+  // One 16-byte load per hit, always issued (clamped into the pad row; the host guarantees width >= 4 on this path)
+  // and requested AGG_DEPTH hits ahead of the blend chain that consumes it: a wave keeps AGG_DEPTH KB in flight,
+  // which is what it takes to cover HBM latency with 8 waves per SIMD (1-deep left the VALU ~40 % idle).
+  Px4Words buf[AGG_DEPTH];
 #pragma unroll
-    for (int j = 0; j < AGG_GROUP; j++) {
-      st[j] = 0;
-      if (k0 + j < n_hits) {
-        const int sx = x - hits[k0 + j].xpos, w = hits[k0 + j].width;
-        if (sx >= 0 && sx + 4 <= w) {
-          sv[j] = *(const Px4Words *) (hits[k0 + j].row + 4 * (size_t) sx);
-          st[j] = 1;
-        } else if (sx + 3 >= 0 && sx < w) {
-          st[j] = 2;
+  for (int j = 0; j < AGG_DEPTH; j++) {
+    buf[j] = span4_fetch<ABL> (hits, j, n_hits, x);
+    issue_order_fence ();       // oldest request first: the loop's s_waitcnt vmcnt(AGG_DEPTH) relies on it
+  }
+  for (int k0 = 0; k0 < n_hits; k0 += AGG_DEPTH) {
+#pragma unroll
+    for (int j = 0; j < AGG_DEPTH; j++) {
+      const int k = k0 + j;
+      const Px4Words cur = buf[j];
+      buf[j] = span4_fetch<ABL> (hits, k + AGG_DEPTH, n_hits, x);
+      if (k < n_hits) {
+        const int sx = x - uniform_i32 (hits[k].xpos), w = uniform_i32 (hits[k].width);
+        const uint32_t alpha8081 = (uint32_t) uniform_i32 (hits[k].s_alpha) * 0x8081u;
+        if ((unsigned) sx <= (unsigned) (w - 4)) {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (ABL == 1 || ABL == 4)
+              acc[i].e ^= cur.v[i];
+            else
+              px2_blend (acc[i], cur.v[i], alpha8081, ashift);
+        } else if ((unsigned) (sx + 3) < (unsigned) (w + 3)) {           // lane straddles a pad edge
+          const uint8_t *row = uniform_ptr (hits[k].row);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (sx + i >= 0 && sx + i < w)
+              px2_blend (acc[i], load_px1 (row + 4 * (size_t) (sx + i)), alpha8081, ashift);
         }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < AGG_GROUP; j++) {
-      if (st[j] == 1) {
-        const uint32_t alpha = (uint32_t) hits[k0 + j].s_alpha;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          px2_blend (acc[i], sv[j].v[i], alpha, p.ashift);
-      } else if (st[j] == 2) {
-        const PadHit h = hits[k0 + j];
-        const int sx = x - h.xpos;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (sx + i >= 0 && sx + i < h.width)
-            px2_blend (acc[i], *(const uint32_t *) (h.row + 4 * (size_t) (sx + i)), (uint32_t) h.s_alpha, p.ashift);
       }
     }
   }

@@ -11,13 +11,11 @@ extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int 
   AggregateParams q = *p;
   q.fast = !p->overlay;
   for (int i = 0; i < p->n_pads; i++)
-    if (p->pads[i].mode == GSTAMD_COMPOSITOR_BLEND_MODE_SOURCE)
+    if (p->pads[i].mode == GSTAMD_COMPOSITOR_BLEND_MODE_SOURCE || p->pads[i].width < 4)
       q.fast = 0;
-  const int lanes = (rw + 3) / 4, bx = lanes >= 256 ? 256 : (lanes > 64 ? 128 : 64);     /* launch () block width */
   for (int y = ry0; y < ry0 + rh; y++)
     for (int gx = 0; gx < rw; gx += 4) {
-      const int blk = gx / (4 * bx);
-      const int bx0 = rx0 + blk * bx * 4, bx1 = bx0 + bx * 4 < rx0 + rw ? bx0 + bx * 4 : rx0 + rw;
+      const int bx0 = rx0 + (gx / 256) * 256, bx1 = bx0 + 256 < rx0 + rw ? bx0 + 256 : rx0 + rw;    /* the wave's strip */
       PadHit hits[GSTAMD_MAX_FUSED_PADS];
       int nh = 0;
       for (int k = 0; k < q.n_pads; k++)
@@ -29,7 +27,10 @@ extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int 
         uint32_t d[4];
         for (int i = 0; i < 4; i++)
           d[i] = q.bg_kind == 2 ? dp[i] : 0u;
-        aggregate_span4 (q, hits, nh, d, x, y);
+        if (q.ashift == 0)
+          aggregate_span4<0, 0> (q, hits, nh, d, x, y);
+        else
+          aggregate_span4<0, 24> (q, hits, nh, d, x, y);
         memcpy (dp, d, 16);
       } else {
         for (int i = 0; i < n; i++)

@@ -42,6 +42,7 @@ struct GstAmdVideoConverter {
   uint8_t *tmp = nullptr;       // intermediate image between two scaler passes
   size_t tmp_size = 0;
   int tmp_w = 0, tmp_h = 0;
+  TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
 };
 
 static bool fast_pair_usable (const VideoPlan &p, const Planes &pl, const uint8_t *dst, int dstride)
@@ -125,6 +126,9 @@ static int ensure_tables (GstAmdVideoConverter *c)
         return hip_fail (e, "hipMemcpy(taps)");
     }
   }
+  for (size_t i = 0; i < p.passes.size (); i++)
+    if (p.passes[i].horizontal)
+      c->geom[i] = pass_tile_geom (p.passes[i]);
   if (p.passes.size () == 2) {
     const ScalePass &s0 = p.passes[0];
     c->tmp_w = s0.horizontal ? s0.out_size : p.in_info.width;
@@ -187,26 +191,30 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
     sd[i].taps = c->pass_dev[i].taps;
   }
   const int out_w = p.out_info.width, out_h = p.out_info.height;
+  PostFast pf, pf_none;
+  memset (&pf_none, 0, sizeof (pf_none));
+  pf.use = p.fast_post ? 1 : 0;
+  pf.fp = make_fast_params (p);
   const auto small_kind = [](int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; };
   if (p.passes.size () == 2 && small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)) {
     /* nearest / 2-tap in both directions ("bilinear"): one fused kernel, no intermediate image */
     const bool h_first = p.passes[0].horizontal;
     const ScaleDev &sh = h_first ? sd[0] : sd[1], &sv = h_first ? sd[1] : sd[0];
     e = launch_scale2x2_from_front (p.front, pl, c->vpair_dev, pre, sh, sv, h_first, dst, dstride, post, p.post.pack_pos,
-        out_w, out_h, p.passes[h_first ? 0 : 1].max_span, stream);
+        out_w, out_h, p.passes[h_first ? 0 : 1].max_span, c->geom[h_first ? 0 : 1], pf, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_scale2x2");
   }
   if (p.passes.size () == 1) {
     e = launch_scale_from_front (p.passes[0].horizontal, p.front, pl, c->vpair_dev, pre, sd[0], dst, dstride, true,
-        post, p.post.pack_pos, out_w, out_h, p.passes[0].max_span, stream);
+        post, p.post.pack_pos, out_w, out_h, p.passes[0].max_span, c->geom[0], pf, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "scale pass");
   }
   e = launch_scale_from_front (p.passes[0].horizontal, p.front, pl, c->vpair_dev, pre, sd[0], c->tmp, c->tmp_w * 4,
-      false, none, p.post.pack_pos, c->tmp_w, c->tmp_h, p.passes[0].max_span, stream);
+      false, none, p.post.pack_pos, c->tmp_w, c->tmp_h, p.passes[0].max_span, c->geom[0], pf_none, stream);
   if (e != hipSuccess)
     return hip_fail (e, "scale pass 1");
   e = launch_scale_from_image (p.passes[1].horizontal, c->tmp, c->tmp_w * 4, sd[1], dst, dstride, true, post,
-      p.post.pack_pos, out_w, out_h, p.passes[1].max_span, stream);
+      p.post.pack_pos, out_w, out_h, p.passes[1].max_span, c->tmp_w, c->geom[1], pf, stream);
   return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "scale pass 2");
 }
 

@@ -716,6 +716,47 @@ static const char *lookup_fastpath (const VideoPlan &p, int alpha_mode_bits, boo
 }
 
 // ------------------------------------------------------------------------------------------------
+// Source span of the outputs [t0, t1) of a horizontal pass (same rule as hscale_span on the device)
+static void pass_span (const ScalePass &pass, int t0, int t1, int *lo, int *hi)
+{
+  if (pass.kind == SCALE_2TAP) {
+    *lo = (t0 * pass.inc) >> 16;
+    *hi = (((t1 - 1) * pass.inc) >> 16) + 2;
+  } else {
+    *lo = (int) pass.offset[t0];
+    *hi = (int) pass.offset[t1 - 1] + (pass.kind == SCALE_NEAREST ? 1 : pass.n_taps);
+  }
+}
+
+// Pick the tile width whose staging step wastes the fewest lane slots: a wave stages ceil (span / 8) 8-pixel groups
+// in rounds of 64 lanes, so e.g. a 2:1 reduction is best served by 252 outputs (span 506 -> 64 groups, one round)
+// rather than 256 (span 514 -> 65 groups, two rounds).
+TileGeom pass_tile_geom (const ScalePass &pass)
+{
+  TileGeom best = {0, 0};
+  double best_cost = 1e30;
+  const int osz = pass.out_size;
+  for (int tw = 256; tw >= 64; tw -= 4) {
+    int worst = 0;
+    for (int t0 = 0; t0 < osz; t0 += tw) {
+      int lo, hi;
+      pass_span (pass, t0, std::min (t0 + tw, osz), &lo, &hi);
+      worst = std::max (worst, hi - (lo & ~7));
+    }
+    const int groups = (worst + 7) / 8;
+    const int rounds = (groups + 63) / 64;
+    const double cost = (double) rounds * 64.0 / (double) std::min (tw, osz);
+    if (cost < best_cost - 1e-12) {
+      best_cost = cost;
+      best.tile_w = tw;
+      best.lds_px = groups * 8;
+    }
+    if (tw >= osz && rounds == 1)
+      break;
+  }
+  return best;
+}
+
 int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *config, VideoPlan *plan, std::string *error)
 {
@@ -881,9 +922,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   }
   /* the line-pair kernel (video_fast.h): unscaled 4:2:0 semi-planar -> 4-byte RGB through the AYUV_ARGB
    * matrix, with ORC's 16-bit addw wrap provably out of reach: |mulhsw (s, p)| <= (32896 * |p| >> 16) + 1 */
-  plan->fast_pair = false;
-  if (plan->passes.empty () && fr.kind == UNPACK_SEMI && fr.chroma_v2 && (in_w % 4) == 0 && in_h >= 2 &&
-      plan->matrix.kind == MATRIX_AYUV_ARGB && post.alpha_kind == ALPHA_NONE) {
+  bool matrix_no_wrap = false;
+  if (plan->matrix.kind == MATRIX_AYUV_ARGB && post.alpha_kind == ALPHA_NONE) {
     long t[5];
     bool fits = true;
     for (int i = 0; i < 5; i++) {
@@ -892,7 +932,22 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       t[i] = ((32896L * ap) >> 16) + 1;
     }
     long worst = t[0] + std::max (std::max (t[1], t[2]), t[3] + t[4]);
-    plan->fast_pair = fits && worst < 32000;
+    matrix_no_wrap = fits && worst < 32000;
+  }
+  plan->fast_pair = plan->passes.empty () && fr.kind == UNPACK_SEMI && fr.chroma_v2 && (in_w % 4) == 0 && in_h >= 2 && matrix_no_wrap;
+  /* scaled plans: the same matrix code after the scaler, if the alpha channel provably arrives as 0xff: opaque source
+   * and every N-tap phase summing to exactly 1.0 (the 2-tap and nearest kernels keep a constant channel as it is) */
+  plan->fast_post = !plan->passes.empty () && !plan->matrix_before_scale && matrix_no_wrap && fr.kind != UNPACK_PACKED4;
+  for (const ScalePass &ps : plan->passes) {
+    if (ps.kind != SCALE_NTAP)
+      continue;
+    for (int i = 0; i < ps.out_size && plan->fast_post; i++) {
+      int sum = 0;
+      for (int l = 0; l < ps.n_taps; l++)
+        sum += ps.taps[(size_t) i * ps.n_taps + l];
+      if (sum != (1 << ps.precision))
+        plan->fast_post = false;
+    }
   }
   std::string d = plan->passes.empty () ? (plan->fast_pair ? "fused_convert_pair" : "fused_convert") : "scale";
   d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;

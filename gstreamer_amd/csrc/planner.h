@@ -76,6 +76,13 @@ struct ScalePass {
   int max_span;        // horizontal passes: largest source span under any 256-output tile (LDS staging)
 };
 
+// wave-tile geometry of a horizontal pass (video_scale_fast.h): outputs per wave and LDS words per staged row
+struct TileGeom {
+  int tile_w;           // multiple of 4, <= 256
+  int lds_px;           // multiple of 8: covers [x_lo & ~7, x_hi) of every tile
+};
+TileGeom pass_tile_geom (const ScalePass &pass);
+
 struct VideoPlan {
   GstAmdVideoInfo in_info, out_info;
   GstAmdVideoConverterConfig config;
@@ -89,6 +96,7 @@ struct VideoPlan {
   // line and which of the two this line is (0 first / 1 second); rows equal => plain copy
   std::vector<int32_t> vpair;     // [in_height][2]: (row_a | role << 30), row_b
   bool fast_pair;             // BASELINE C2 shape: line-pair kernel of video_fast.h is applicable
+  bool fast_post;             // scaled plans: the post stage may run fast_pixel (matrix provably wrap-free, alpha stays 0xff)
   std::string description;
   uint64_t algorithmic_bytes;
 };

@@ -227,6 +227,7 @@ struct SrcFront {
 struct SrcImage {
   const uint8_t *p;
   int stride;
+  int width;            // pixels per row (wave-tile staging stops there)
   GSTAMD_HD uint32_t at (int x, int y) const
   {
     return *(const uint32_t *) (p + (size_t) y * stride + 4 * (size_t) x);

@@ -5,6 +5,7 @@
 
 #include "planner.h"
 #include "video_types.h"
+#include "video_scale_fast.h"
 
 namespace gstamd {
 
@@ -17,13 +18,14 @@ hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames
 
 hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const Planes &pl, const int *vpair_dev,
     const ColorParams &pre, const ScaleDev &sd, uint8_t *dst, int dstride, bool final, const ColorParams &post,
-    const int pack_pos[4], int out_w, int out_h, int max_span, hipStream_t stream);
+    const int pack_pos[4], int out_w, int out_h, int max_span, TileGeom geom, const PostFast &pf, hipStream_t stream);
 
 hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int sstride, const ScaleDev &sd, uint8_t *dst,
-    int dstride, bool final, const ColorParams &post, const int pack_pos[4], int out_w, int out_h, int max_span, hipStream_t stream);
+    int dstride, bool final, const ColorParams &post, const int pack_pos[4], int out_w, int out_h, int max_span, int src_w,
+    TileGeom geom, const PostFast &pf, hipStream_t stream);
 
 hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &pre,
     const ScaleDev &sh, const ScaleDev &sv, bool h_first, uint8_t *dst, int dstride, const ColorParams &post,
-    const int pack_pos[4], int out_w, int out_h, int h_span, hipStream_t stream);
+    const int pack_pos[4], int out_w, int out_h, int h_span, TileGeom geom, const PostFast &pf, hipStream_t stream);
 
 }  // namespace gstamd

@@ -13,6 +13,7 @@
 #include "video_kernels.h"
 #include "video_device.h"
 #include "video_fast.h"
+#include "video_scale_fast.h"
 
 namespace gstamd {
 
@@ -74,6 +75,7 @@ __global__ __launch_bounds__ (256) void k_hscale (SRC src, ScaleDev sd, Dst dst,
 // LDS-staged horizontal pass: block = 256 consecutive outputs of one row; the source span under them is
 // evaluated once into LDS (<= HSCALE_LDS_PX pixels), then every lane filters from LDS.
 #define HSCALE_LDS_PX 12288
+#define WAVE_TILE_LDS_BYTES 16384      // per wave: above this the 256-lane LDS kernels take over
 template <class SRC>
 __global__ __launch_bounds__ (256) void k_hscale_lds (SRC src, ScaleDev sd, Dst dst, int out_w, int rows)
 {
@@ -109,6 +111,49 @@ __global__ __launch_bounds__ (256) void k_scale2x2_lds (SRC src, ScaleDev sh, Sc
   const int x = t0 + (int) threadIdx.x;
   if (x < out_w)
     dst.put (x, y, scale2x2_from_lds (lds_a, lds_b, x_lo, sh, sv, h_first, x, y));
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-tile scalers (video_scale_fast.h): workgroup = one wave = tile_w outputs of one row
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void wave_lds_sync ()
+{
+  __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier ();
+  __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class SRC>
+__global__ __launch_bounds__ (64) void k_scale2x2_wave (SRC src, ScaleDev sh, ScaleDev sv, int h_first, Dst dst, PostFast pf, int out_w,
+    int out_h, int tile_w, int lds_px, int packed)
+{
+  extern __shared__ uint32_t lds_w[];
+  uint32_t *la = lds_w, *lb = lds_w + lds_px;
+  const int lane = (int) threadIdx.x, y = (int) blockIdx.y, t0 = (int) blockIdx.x * tile_w;
+  const int t1 = t0 + tile_w < out_w ? t0 + tile_w : out_w;
+  int x_lo, x_hi;
+  hscale_span (sh, t0, t1, &x_lo, &x_hi);
+  const int xa = x_lo & ~7, ya = (int) sv.offset[y];
+  tile_stage_row (src, la, xa, x_hi, ya, lane, packed);
+  if (sv.kind == SCALE_2TAP)
+    tile_stage_row (src, lb, xa, x_hi, ya + 1, lane, packed);
+  wave_lds_sync ();
+  scale2x2_tile_lane (la, lb, xa, sh, sv, h_first, dst, pf, t0, t1, y, lane);
+}
+
+template <class SRC>
+__global__ __launch_bounds__ (64) void k_hscale_wave (SRC src, ScaleDev sd, Dst dst, PostFast pf, int out_w, int rows, int tile_w,
+    int lds_px, int packed)
+{
+  extern __shared__ uint32_t lds_w[];
+  const int lane = (int) threadIdx.x, y = (int) blockIdx.y, t0 = (int) blockIdx.x * tile_w;
+  const int t1 = t0 + tile_w < out_w ? t0 + tile_w : out_w;
+  int x_lo, x_hi;
+  hscale_span (sd, t0, t1, &x_lo, &x_hi);
+  const int xa = x_lo & ~7;
+  tile_stage_row (src, lds_w, xa, x_hi, y, lane, packed);
+  wave_lds_sync ();
+  hscale_tile_lane (lds_w, xa, sd, dst, pf, t0, t1, y, lane);
 }
 
 template <class SRC>
@@ -291,6 +336,13 @@ static int front_vec_ok (const FrontParams &f, const Planes &pl)
   return ok;
 }
 
+// word-load staging (front_span8_packed) applies: planes aligned, 2x horizontally subsampled chroma, no colour step
+// before the scaler
+static int front_packed_ok (const SrcFront &s)
+{
+  return s.vec_ok && s.f.w_sub == 1 && s.f.kind != UNPACK_PACKED4 && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
+}
+
 static Dst make_dst (uint8_t *p, int stride, bool final, const ColorParams &post, const int pack_pos[4])
 {
   Dst d;
@@ -305,7 +357,7 @@ static Dst make_dst (uint8_t *p, int stride, bool final, const ColorParams &post
 
 hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const Planes &pl, const int *vpair_dev,
     const ColorParams &pre, const ScaleDev &sd, uint8_t *dst, int dstride, bool final, const ColorParams &post,
-    const int pack_pos[4], int out_w, int out_h, int max_span, hipStream_t stream)
+    const int pack_pos[4], int out_w, int out_h, int max_span, TileGeom geom, const PostFast &pf, hipStream_t stream)
 {
   SrcFront src;
   src.f = f;
@@ -315,7 +367,11 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
   src.vec_ok = front_vec_ok (f, pl);
   Dst d = make_dst (dst, dstride, final, post, pack_pos);
   dim3 block (256), grid ((out_w + 255) / 256, out_h);
-  if (horizontal && max_span <= HSCALE_LDS_PX)
+  if (horizontal && geom.tile_w > 0 && geom.lds_px * 4 <= WAVE_TILE_LDS_BYTES) {
+    dim3 wgrid ((out_w + geom.tile_w - 1) / geom.tile_w, out_h);
+    hipLaunchKernelGGL (k_hscale_wave<SrcFront>, wgrid, dim3 (64), (size_t) geom.lds_px * 4, stream, src, sd, d, pf, out_w, out_h,
+        geom.tile_w, geom.lds_px, front_packed_ok (src));
+  } else if (horizontal && max_span <= HSCALE_LDS_PX)
     hipLaunchKernelGGL (k_hscale_lds<SrcFront>, grid, block, (size_t) max_span * 4, stream, src, sd, d, out_w, out_h);
   else if (horizontal)
     hipLaunchKernelGGL (k_hscale<SrcFront>, grid, block, 0, stream, src, sd, d, out_w, out_h);
@@ -325,14 +381,20 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
 }
 
 hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int sstride, const ScaleDev &sd, uint8_t *dst,
-    int dstride, bool final, const ColorParams &post, const int pack_pos[4], int out_w, int out_h, int max_span, hipStream_t stream)
+    int dstride, bool final, const ColorParams &post, const int pack_pos[4], int out_w, int out_h, int max_span, int src_w,
+    TileGeom geom, const PostFast &pf, hipStream_t stream)
 {
   SrcImage src;
   src.p = simg;
   src.stride = sstride;
+  src.width = src_w;
   Dst d = make_dst (dst, dstride, final, post, pack_pos);
   dim3 block (256), grid ((out_w + 255) / 256, out_h);
-  if (horizontal && max_span <= HSCALE_LDS_PX)
+  if (horizontal && geom.tile_w > 0 && geom.lds_px * 4 <= WAVE_TILE_LDS_BYTES) {
+    dim3 wgrid ((out_w + geom.tile_w - 1) / geom.tile_w, out_h);
+    hipLaunchKernelGGL (k_hscale_wave<SrcImage>, wgrid, dim3 (64), (size_t) geom.lds_px * 4, stream, src, sd, d, pf, out_w, out_h,
+        geom.tile_w, geom.lds_px, 1);
+  } else if (horizontal && max_span <= HSCALE_LDS_PX)
     hipLaunchKernelGGL (k_hscale_lds<SrcImage>, grid, block, (size_t) max_span * 4, stream, src, sd, d, out_w, out_h);
   else if (horizontal)
     hipLaunchKernelGGL (k_hscale<SrcImage>, grid, block, 0, stream, src, sd, d, out_w, out_h);
@@ -343,7 +405,7 @@ hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int ss
 
 hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &pre,
     const ScaleDev &sh, const ScaleDev &sv, bool h_first, uint8_t *dst, int dstride, const ColorParams &post,
-    const int pack_pos[4], int out_w, int out_h, int h_span, hipStream_t stream)
+    const int pack_pos[4], int out_w, int out_h, int h_span, TileGeom geom, const PostFast &pf, hipStream_t stream)
 {
   SrcFront src;
   src.f = f;
@@ -353,7 +415,11 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
   src.vec_ok = front_vec_ok (f, pl);
   Dst d = make_dst (dst, dstride, true, post, pack_pos);
   dim3 block (256), grid ((out_w + 255) / 256, out_h);
-  if (h_span <= SCALE2_LDS_PX)
+  if (geom.tile_w > 0 && geom.lds_px * 8 <= WAVE_TILE_LDS_BYTES) {
+    dim3 wgrid ((out_w + geom.tile_w - 1) / geom.tile_w, out_h);
+    hipLaunchKernelGGL (k_scale2x2_wave<SrcFront>, wgrid, dim3 (64), (size_t) geom.lds_px * 8, stream, src, sh, sv, h_first ? 1 : 0, d,
+        pf, out_w, out_h, geom.tile_w, geom.lds_px, front_packed_ok (src));
+  } else if (h_span <= SCALE2_LDS_PX)
     hipLaunchKernelGGL (k_scale2x2_lds<SrcFront>, grid, block, (size_t) h_span * 8, stream, src, sh, sv, h_first ? 1 : 0, d, out_w, out_h, h_span);
   else
     hipLaunchKernelGGL (k_scale2x2<SrcFront>, grid, block, 0, stream, src, sh, sv, h_first ? 1 : 0, d, out_w, out_h);

@@ -1,0 +1,319 @@
+// video_scale_fast.h - wave-tile scalers: the speed path of the GstVideoScaler passes.
+//
+// One wave (a 64-lane workgroup of its own) produces `tile_w` (<= 256) consecutive output pixels of one output
+// row, 4 per lane.  It first evaluates the source pixels under the tile ONCE into its LDS slice - unpack + chroma
+// upsample of the source frame in packed 16-bit arithmetic, 8 pixels per lane per step - and then every lane
+// filters from LDS and stores 16 bytes.  Same arithmetic as the per-pixel bodies in video_device.h (fetch_front,
+// hscale_px, v2tap_px), restructured for VALU issue:
+//
+//   * chroma samples travel as {U, V} in the two 16-bit halves of one register; the (a+b+1)>>1 and
+//     (3a+b+2)>>2 filters of video-chroma.c:277-327, 687-699 are one add/multiply-add + one packed shift for
+//     both components (values <= 1022, no carry between the halves);
+//   * the AYUV word is assembled with one v_perm_b32 per pixel;
+//   * pixels are split into even / odd byte pairs (0x00CC00AA, 0x00DD00BB) so that a 2-tap blend or an N-tap
+//     multiply-accumulate is one packed 16-bit operation per two channels - exactly the 16-bit wrapping
+//     arithmetic of the ORC programs (video-orc.orc:2208-2224, 2388-2480).
+//
+// Reference: video-scaler.c:546-760 (horizontal), 829-1072 (vertical); video-orc-dist.c:26162-26195 (ldreslinl).
+#pragma once
+#include "video_fast.h"
+
+namespace gstamd {
+
+// ------------------------------------------------------------------------------------------------
+// packed front: 8 pixels x0 .. x0+7 of line y (x0 % 8 == 0, x0 + 8 <= width, w_sub == 1, planes aligned as
+// front_vec_ok checks)
+// ------------------------------------------------------------------------------------------------
+struct ChromaP6 {
+  uint32_t c[6];        // samples k0-1 .. k0+4, each U | V << 16
+};
+
+GSTAMD_HD void load_chroma6_packed (const FrontParams &f, const Planes &pl, int crow, int k0, int cw, ChromaP6 &c)
+{
+  const int km = k0 > 0 ? k0 - 1 : 0, kp = k0 + 4 < cw ? k0 + 4 : cw - 1;
+  if (f.kind == UNPACK_SEMI) {
+    const uint8_t *row = pl.p[1] + (size_t) crow * pl.stride[1];
+    const uint2 mid = *(const uint2 *) (row + 2 * k0);           // samples k0..k0+3
+    const uint32_t pm = *(const uint16_t *) (row + 2 * km), pp = *(const uint16_t *) (row + 2 * kp);
+    // byte pair (b0, b1) -> U | V << 16; NV12 (u_plane != 0): U first
+    const uint32_t sel_lo = f.u_plane ? 0x0c010c00u : 0x0c000c01u, sel_hi = f.u_plane ? 0x0c030c02u : 0x0c020c03u;
+    c.c[0] = bperm (0, pm, sel_lo);
+    c.c[1] = bperm (0, mid.x, sel_lo);
+    c.c[2] = bperm (0, mid.x, sel_hi);
+    c.c[3] = bperm (0, mid.y, sel_lo);
+    c.c[4] = bperm (0, mid.y, sel_hi);
+    c.c[5] = bperm (0, pp, sel_lo);
+  } else {
+    const uint8_t *ru = pl.p[f.u_plane] + (size_t) crow * pl.stride[f.u_plane];
+    const uint8_t *rv = pl.p[f.v_plane] + (size_t) crow * pl.stride[f.v_plane];
+    const uint32_t mu = *(const uint32_t *) (ru + k0), mv = *(const uint32_t *) (rv + k0);
+    c.c[0] = (uint32_t) ru[km] | ((uint32_t) rv[km] << 16);
+    c.c[1] = bperm (mv, mu, 0x0c040c00u);
+    c.c[2] = bperm (mv, mu, 0x0c050c01u);
+    c.c[3] = bperm (mv, mu, 0x0c060c02u);
+    c.c[4] = bperm (mv, mu, 0x0c070c03u);
+    c.c[5] = (uint32_t) ru[kp] | ((uint32_t) rv[kp] << 16);
+  }
+}
+
+// horizontally filtered chroma under the 8 pixels (same cases as hfilter8)
+template <int CH>
+GSTAMD_HD void hfilter8_packed (const ChromaP6 &c, int x0, int w, uint32_t *o)
+{
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int x = x0 + i, j = (i >> 1) + 1;
+    uint32_t cc = c.c[j];
+    if (CH == CHROMA_H_H2_CS) {
+      if ((i & 1) && x < w - 1)
+        cc = pk_shr<1> (c.c[j] + c.c[j + 1] + 0x00010001u);
+    } else if (CH == CHROMA_H_H2) {
+      if ((i & 1) && x < w - 1)
+        cc = pk_shr<2> (3u * c.c[j] + c.c[j + 1] + 0x00020002u);
+      else if (!(i & 1) && x >= 2)
+        cc = pk_shr<2> (c.c[j - 1] + 3u * c.c[j] + 0x00020002u);
+    }
+    o[i] = cc;
+  }
+}
+
+template <int CH>
+GSTAMD_HD void front_span8_packed (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint32_t *out)
+{
+  const int w = f.width;
+  const uint2 yy = *(const uint2 *) (pl.p[0] + (size_t) y * pl.stride[0] + x0);
+  const int cw = (w + 1) >> 1, k0 = x0 >> 1;
+  int ra, rb, role = 0;
+  if (f.chroma_v2) {
+    const int e0 = vpair[2 * y];
+    ra = e0 & 0x3fffffff;
+    role = e0 >> 30;
+    rb = vpair[2 * y + 1];
+  } else {
+    ra = rb = y >> f.h_sub;
+  }
+  uint32_t ca[8];
+  {
+    ChromaP6 c;
+    load_chroma6_packed (f, pl, ra, k0, cw, c);
+    hfilter8_packed<CH> (c, x0, w, ca);
+  }
+  if (ra != rb) {                         // uniform over the row
+    ChromaP6 c;
+    uint32_t cb[8];
+    load_chroma6_packed (f, pl, rb, k0, cw, c);
+    hfilter8_packed<CH> (c, x0, w, cb);
+    if (role == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        ca[i] = pk_shr<2> (3u * ca[i] + cb[i] + 0x00020002u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        ca[i] = pk_shr<2> (ca[i] + 3u * cb[i] + 0x00020002u);
+    }
+  }
+  // byte0 = 0xff, byte1 = Y, byte2 = U (chroma byte 0), byte3 = V (chroma byte 2)
+  static const uint32_t ysel[4] = {0x0604000du, 0x0604010du, 0x0604020du, 0x0604030du};
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    out[i] = bperm (ca[i], i < 4 ? yy.x : yy.y, ysel[i & 3]);
+}
+
+GSTAMD_HD void front_span8_packed_any (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint32_t *out)
+{
+  if (f.chroma_h == CHROMA_H_H2_CS)
+    front_span8_packed<CHROMA_H_H2_CS> (f, pl, vpair, x0, y, out);
+  else if (f.chroma_h == CHROMA_H_H2)
+    front_span8_packed<CHROMA_H_H2> (f, pl, vpair, x0, y, out);
+  else
+    front_span8_packed<CHROMA_H_NONE> (f, pl, vpair, x0, y, out);
+}
+
+// can the 8 pixels starting at x0 take the word-load path?
+GSTAMD_HD bool src_span8_ok (const SrcFront &s, int x0) { return s.vec_ok && x0 + 8 <= s.f.width; }
+GSTAMD_HD bool src_span8_ok (const SrcImage &s, int x0) { return x0 + 8 <= s.width; }
+
+// 8 source pixels x0 .. x0+7 (x0 % 8 == 0, src_span8_ok) of line y
+GSTAMD_HD void src_span8 (const SrcFront &s, int x0, int y, uint32_t *px)
+{
+  front_span8_packed_any (s.f, s.pl, s.vpair, x0, y, px);
+}
+
+GSTAMD_HD void src_span8 (const SrcImage &s, int x0, int y, uint32_t *px)
+{
+  struct __attribute__ ((aligned (4))) W8 { uint32_t v[8]; };
+  const W8 v = *(const W8 *) (s.p + (size_t) y * s.stride + 4 * (size_t) x0);
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    px[i] = v.v[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave tiles
+// ------------------------------------------------------------------------------------------------
+// stage pixels [xa, x_hi) (xa % 8 == 0) of source line y into lds[0 ..): lane handles 8-pixel groups lane, lane+64, ..
+// `packed` (wave-uniform, from the launcher): the source allows the word-load path and needs no colour step before
+// the scaler; groups that cannot take it (right edge) and all other sources go pixel by pixel, in a rolled loop so
+// that the per-pixel front is instantiated once.
+template <class SRC>
+GSTAMD_HD void tile_stage_row (const SRC &src, uint32_t *lds, int xa, int x_hi, int y, int lane, int packed)
+{
+  for (int x0 = xa + 8 * lane; x0 < x_hi; x0 += 8 * 64) {
+    if (packed && src_span8_ok (src, x0)) {
+      uint32_t px[8];
+      src_span8 (src, x0, y, px);
+      uint4 *d = (uint4 *) (lds + (x0 - xa));
+      d[0] = gstamd_make_uint4 (px[0], px[1], px[2], px[3]);
+      d[1] = gstamd_make_uint4 (px[4], px[5], px[6], px[7]);
+    } else {
+      const int xe = x0 + 8 < x_hi ? x0 + 8 : x_hi;
+#pragma unroll 1
+      for (int x = x0; x < xe; x++)
+        lds[x - xa] = src.at (x, y);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed 16-bit arithmetic on pixel halves (e = bytes 0,2; o = bytes 1,3; one byte per 16-bit lane)
+// ------------------------------------------------------------------------------------------------
+GSTAMD_HD uint32_t pk_sub16 (uint32_t a, uint32_t b)
+{
+#ifdef __HIPCC__
+  typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
+  return __builtin_bit_cast (uint32_t, (us2) (__builtin_bit_cast (us2, a) - __builtin_bit_cast (us2, b)));
+#else
+  return (((a & 0xffffu) - (b & 0xffffu)) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16);
+#endif
+}
+
+// a * b + c per 16-bit lane, wrapping (v_pk_mad_u16): mullw + addw of the ORC programs
+GSTAMD_HD uint32_t pk_mad16 (uint32_t a, uint32_t b, uint32_t c)
+{
+#ifdef __HIPCC__
+  typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
+  return __builtin_bit_cast (uint32_t, (us2) (__builtin_bit_cast (us2, a) * __builtin_bit_cast (us2, b) + __builtin_bit_cast (us2, c)));
+#else
+  const uint32_t lo = ((a & 0xffffu) * (b & 0xffffu) + (c & 0xffffu)) & 0xffffu;
+  const uint32_t hi = ((a >> 16) * (b >> 16) + (c >> 16)) & 0xffffu;
+  return lo | (hi << 16);
+#endif
+}
+
+GSTAMD_HD uint32_t umul24 (uint32_t a, uint32_t b)
+{
+#ifdef __HIPCC__
+  uint32_t r;
+  asm ("v_mul_u32_u24 %0, %1, %2" : "=v" (r) : "v" (a), "v" (b));
+  return r;
+#else
+  return a * b;
+#endif
+}
+
+// ldreslinl on two source pixels (video-orc-dist.c:26162-26195): per channel (a * (256 - f) + b * f) >> 8, never above
+// 255 * 256, so two channels share one 24-bit multiply-add
+GSTAMD_HD void h2tap_eo (uint32_t a, uint32_t b, uint32_t fr, uint32_t &e, uint32_t &o)
+{
+  const uint32_t nf = 256u - fr;
+  e = pk_shr<8> (umul24 (a & 0x00ff00ffu, nf) + umul24 (b & 0x00ff00ffu, fr));
+  o = pk_shr<8> (umul24 (pk_shr<8> (a), nf) + umul24 (pk_shr<8> (b), fr));
+}
+
+// video_orc_resample_v_2tap_u8_lq on two channels: s1 + (((s2 - s1) * p1 + 128) >> 8), 16-bit wrapping, low byte kept
+GSTAMD_HD uint32_t v2tap_pk (uint32_t s1, uint32_t s2, uint32_t p1_splat)
+{
+  const uint32_t m = pk_mad16 (pk_sub16 (s2, s1), p1_splat, 0x00800080u);
+  return (pk_shr<8> (m) + s1) & 0x00ff00ffu;
+}
+
+// last stage of a converter whose post step is the AYUV->ARGB matrix with provably no 16-bit wrap, no alpha
+// operation and an alpha channel known to be 0xff (planner: VideoPlan::fast_post): fast_pixel of video_fast.h
+struct PostFast {
+  int use;
+  FastParams fp;
+};
+
+GSTAMD_HD uint32_t post_px (const Dst &dst, const PostFast &pf, uint32_t px)
+{
+  if (pf.use) {
+    const uint32_t z = px ^ 0x80808080u;
+    return fast_pixel (pf.fp, z, 0x0c01010cu, z, 0x0c02020cu, 0x0c03030cu);
+  }
+  return dst.final ? pack_px (dst.pack_pos, apply_color (dst.post, px)) : px;
+}
+
+GSTAMD_HD void store_px (const Dst &dst, int x, int y, uint32_t v)
+{
+  uint32_t *p = (uint32_t *) (dst.p + (size_t) y * dst.stride + 4 * (size_t) x);
+#ifdef __HIPCC__
+  __builtin_nontemporal_store (v, p);
+#else
+  *p = v;
+#endif
+}
+
+// lane part of the fused nearest/2-tap scaler: outputs t0 + lane + 64 * i (i < 4) of row y from the staged rows.
+// Neighbouring lanes take neighbouring outputs, so their LDS reads fall into neighbouring banks.
+GSTAMD_HD void scale2x2_tile_lane (const uint32_t *la, const uint32_t *lb, int xa, const ScaleDev &sh, const ScaleDev &sv, int h_first,
+    const Dst &dst, const PostFast &pf, int t0, int t1, int y, int lane)
+{
+  const bool v2 = sv.kind == SCALE_2TAP, h2 = sh.kind == SCALE_2TAP;
+  const uint32_t p1s = v2 ? ((uint32_t) (uint16_t) sv.taps[(size_t) y * 2 + 1]) * 0x00010001u : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = t0 + lane + 64 * i;
+    if (x >= t1)
+      break;
+    uint32_t e, o;
+    if (h2) {
+      const int tmp = x * sh.inc;
+      const int idx = (tmp >> 16) - xa;
+      const uint32_t fr = (uint32_t) (tmp >> 8) & 0xffu;
+      if (!v2) {
+        h2tap_eo (la[idx], la[idx + 1], fr, e, o);
+      } else if (h_first) {
+        uint32_t e2, o2;
+        h2tap_eo (la[idx], la[idx + 1], fr, e, o);
+        h2tap_eo (lb[idx], lb[idx + 1], fr, e2, o2);
+        e = v2tap_pk (e, e2, p1s);
+        o = v2tap_pk (o, o2, p1s);
+      } else {                            // vertical first: filter the two source columns, then blend them
+        const uint32_t a1 = la[idx], a2 = lb[idx], b1 = la[idx + 1], b2 = lb[idx + 1];
+        const uint32_t ae = v2tap_pk (a1 & 0x00ff00ffu, a2 & 0x00ff00ffu, p1s), ao = v2tap_pk (pk_shr<8> (a1), pk_shr<8> (a2), p1s);
+        const uint32_t be = v2tap_pk (b1 & 0x00ff00ffu, b2 & 0x00ff00ffu, p1s), bo = v2tap_pk (pk_shr<8> (b1), pk_shr<8> (b2), p1s);
+        const uint32_t nf = 256u - fr;
+        e = pk_shr<8> (umul24 (ae, nf) + umul24 (be, fr));
+        o = pk_shr<8> (umul24 (ao, nf) + umul24 (bo, fr));
+      }
+    } else {
+      const int idx = (int) sh.offset[x] - xa;
+      const uint32_t a1 = la[idx];
+      e = a1 & 0x00ff00ffu;
+      o = pk_shr<8> (a1);
+      if (v2) {
+        const uint32_t a2 = lb[idx];
+        e = v2tap_pk (e, a2 & 0x00ff00ffu, p1s);
+        o = v2tap_pk (o, pk_shr<8> (a2), p1s);
+      }
+    }
+    store_px (dst, x, y, post_px (dst, pf, e | (o << 8)));
+  }
+}
+
+// lane part of a horizontal pass (any kind): outputs t0 + lane + 64 * i
+GSTAMD_HD void hscale_tile_lane (const uint32_t *lds, int xa, const ScaleDev &sd, const Dst &dst, const PostFast &pf, int t0, int t1, int y,
+    int lane)
+{
+  const RowOfLds row = {lds, xa};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = t0 + lane + 64 * i;
+    if (x >= t1)
+      break;
+    store_px (dst, x, y, post_px (dst, pf, hscale_px (row, sd, x)));
+  }
+}
+
+}  // namespace gstamd

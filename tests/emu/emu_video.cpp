@@ -9,6 +9,7 @@
 #include "../../gstreamer_amd/csrc/planner.h"
 #include "../../gstreamer_amd/csrc/video_device.h"
 #include "../../gstreamer_amd/csrc/video_fast.h"
+#include "../../gstreamer_amd/csrc/video_scale_fast.h"
 
 using namespace gstamd;
 
@@ -28,9 +29,51 @@ static void run_hscale_lds (const SRC &src, const ScaleDev &sd, const Dst &d, in
     }
 }
 
-template <class SRC>
-static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h, int max_span = 1 << 30)
+static FastParams emu_fast_params (const VideoPlan &p)      /* make_fast_params of capi_video.cpp */
 {
+  FastParams fp;
+  fp.width = p.front.width;
+  fp.height = p.front.height;
+  for (int i = 0; i < 5; i++)
+    fp.p8[i] = p.matrix.p[i] * 256;
+  fp.pack_sel = (0x0du << (8 * p.post.pack_pos[0])) | (0x00u << (8 * p.post.pack_pos[1])) |
+      (0x01u << (8 * p.post.pack_pos[2])) | (0x04u << (8 * p.post.pack_pos[3]));
+  fp.u_first = p.front.u_plane;
+  return fp;
+}
+
+static int emu_packed_ok (const SrcFront &s)           /* front_packed_ok of video_kernels.hip */
+{
+  return s.vec_ok && s.f.w_sub == 1 && s.f.kind != UNPACK_PACKED4 && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
+}
+static int emu_packed_ok (const SrcImage &) { return 1; }
+
+// k_hscale_wave: one wave per tile, staging phase for all 64 lanes, then the filter phase
+template <class SRC>
+static void run_hscale_wave (const SRC &src, const ScaleDev &sd, const Dst &d, const PostFast &pf, int out_w, int out_h, TileGeom g)
+{
+  std::vector<uint32_t> lds (g.lds_px);
+  for (int y = 0; y < out_h; y++)
+    for (int t0 = 0; t0 < out_w; t0 += g.tile_w) {
+      const int t1 = t0 + g.tile_w < out_w ? t0 + g.tile_w : out_w;
+      int lo, hi;
+      hscale_span (sd, t0, t1, &lo, &hi);
+      const int xa = lo & ~7;
+      for (int lane = 0; lane < 64; lane++)
+        tile_stage_row (src, lds.data (), xa, hi, y, lane, emu_packed_ok (src));
+      for (int lane = 0; lane < 64; lane++)
+        hscale_tile_lane (lds.data (), xa, sd, d, pf, t0, t1, y, lane);
+    }
+}
+
+template <class SRC>
+static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h, int max_span, TileGeom g,
+    const PostFast &pf)
+{
+  if (horizontal && g.tile_w > 0 && g.lds_px * 4 <= 16384) {
+    run_hscale_wave (src, sd, d, pf, out_w, out_h, g);
+    return;
+  }
   if (horizontal && max_span <= 12288) {
     run_hscale_lds (src, sd, d, out_w, out_h);
     return;
@@ -72,14 +115,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   uint8_t *d0 = dst + out->offset[0];
   const int dstride = out->stride[0];
   if (p.passes.empty () && p.fast_pair && vec_ok) {
-    FastParams fp;
-    fp.width = p.front.width;
-    fp.height = p.front.height;
-    for (int i = 0; i < 5; i++)
-      fp.p8[i] = p.matrix.p[i] * 256;
-    fp.pack_sel = (0x0du << (8 * p.post.pack_pos[0])) | (0x00u << (8 * p.post.pack_pos[1])) |
-        (0x01u << (8 * p.post.pack_pos[2])) | (0x04u << (8 * p.post.pack_pos[3]));
-    fp.u_first = p.front.u_plane;
+    const FastParams fp = emu_fast_params (p);
     if (vec_ok >= 2) {                    /* strip variant with K = vec_ok pairs per lane, 4- and 8-pixel columns */
       const int pairs = fp.height / 2 + 1, K = vec_ok;
       for (int p0 = 0; p0 < pairs; p0 += K)
@@ -161,12 +197,35 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     memcpy (d.pack_pos, p.post.pack_pos, sizeof (d.pack_pos));
     return d;
   };
+  PostFast pf, pf_none;
+  memset (&pf_none, 0, sizeof (pf_none));
+  pf.use = p.fast_post ? 1 : 0;
+  pf.fp = emu_fast_params (p);
   const auto small_kind = [](int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; };
   if (p.passes.size () == 2 && small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)) {
     const bool h_first = p.passes[0].horizontal;
     const ScaleDev &sh = h_first ? sd[0] : sd[1], &sv = h_first ? sd[1] : sd[0];
     const Dst d = mk (d0, dstride, true);
     const int span = p.passes[h_first ? 0 : 1].max_span;
+    const TileGeom g = pass_tile_geom (p.passes[h_first ? 0 : 1]);
+    if (g.tile_w > 0 && g.lds_px * 8 <= 16384) {      /* k_scale2x2_wave */
+      std::vector<uint32_t> la (g.lds_px), lb (g.lds_px);
+      for (int y = 0; y < out->height; y++)
+        for (int t0 = 0; t0 < out->width; t0 += g.tile_w) {
+          const int t1 = t0 + g.tile_w < out->width ? t0 + g.tile_w : out->width;
+          int lo, hi;
+          hscale_span (sh, t0, t1, &lo, &hi);
+          const int xa = lo & ~7, ya = (int) sv.offset[y];
+          for (int lane = 0; lane < 64; lane++) {
+            tile_stage_row (sf, la.data (), xa, hi, ya, lane, emu_packed_ok (sf));
+            if (sv.kind == SCALE_2TAP)
+              tile_stage_row (sf, lb.data (), xa, hi, ya + 1, lane, emu_packed_ok (sf));
+          }
+          for (int lane = 0; lane < 64; lane++)
+            scale2x2_tile_lane (la.data (), lb.data (), xa, sh, sv, h_first ? 1 : 0, d, pf, t0, t1, y, lane);
+        }
+      return GSTAMD_OK;
+    }
     if (span <= 6144) {                    /* k_scale2x2_lds */
       std::vector<uint32_t> la (6144), lb (6144);
       for (int y = 0; y < out->height; y++)
@@ -191,16 +250,20 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     return GSTAMD_OK;
   }
   if (p.passes.size () == 1) {
-    run_scale (p.passes[0].horizontal, sf, sd[0], mk (d0, dstride, true), out->width, out->height, p.passes[0].max_span);
+    run_scale (p.passes[0].horizontal, sf, sd[0], mk (d0, dstride, true), out->width, out->height, p.passes[0].max_span,
+        p.passes[0].horizontal ? pass_tile_geom (p.passes[0]) : TileGeom {0, 0}, pf);
     return GSTAMD_OK;
   }
   const ScalePass &s0 = p.passes[0];
   const int tw = s0.horizontal ? s0.out_size : in->width, th = s0.horizontal ? in->height : s0.out_size;
   std::vector<uint8_t> tmp ((size_t) tw * 4 * th);
-  run_scale (s0.horizontal, sf, sd[0], mk (tmp.data (), tw * 4, false), tw, th, s0.max_span);
+  run_scale (s0.horizontal, sf, sd[0], mk (tmp.data (), tw * 4, false), tw, th, s0.max_span,
+      s0.horizontal ? pass_tile_geom (s0) : TileGeom {0, 0}, pf_none);
   SrcImage si;
   si.p = tmp.data ();
   si.stride = tw * 4;
-  run_scale (p.passes[1].horizontal, si, sd[1], mk (d0, dstride, true), out->width, out->height, p.passes[1].max_span);
+  si.width = tw;
+  run_scale (p.passes[1].horizontal, si, sd[1], mk (d0, dstride, true), out->width, out->height, p.passes[1].max_span,
+      p.passes[1].horizontal ? pass_tile_geom (p.passes[1]) : TileGeom {0, 0}, pf);
   return GSTAMD_OK;
 }

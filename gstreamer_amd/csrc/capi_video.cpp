@@ -38,6 +38,7 @@ struct GstAmdVideoConverter {
   struct PassDev {
     uint32_t *offset = nullptr;
     int16_t *taps = nullptr;
+    uint32_t *tapw = nullptr;
   } pass_dev[2];
   uint8_t *tmp = nullptr;       // intermediate image between two scaler passes
   size_t tmp_size = 0;
@@ -125,6 +126,12 @@ static int ensure_tables (GstAmdVideoConverter *c)
       if ((e = hipMemcpy (c->pass_dev[i].taps, sp.taps.data (), sp.taps.size () * sizeof (int16_t), hipMemcpyHostToDevice)) != hipSuccess)
         return hip_fail (e, "hipMemcpy(taps)");
     }
+    if (sp.dot4_ok) {
+      if ((e = hipMalloc ((void **) &c->pass_dev[i].tapw, sp.tapw.size () * sizeof (uint32_t))) != hipSuccess)
+        return hip_fail (e, "hipMalloc(tapw)");
+      if ((e = hipMemcpy (c->pass_dev[i].tapw, sp.tapw.data (), sp.tapw.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
+        return hip_fail (e, "hipMemcpy(tapw)");
+    }
   }
   for (size_t i = 0; i < p.passes.size (); i++)
     if (p.passes[i].horizontal)
@@ -189,6 +196,9 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
     sd[i].inc = p.passes[i].inc;
     sd[i].offset = c->pass_dev[i].offset;
     sd[i].taps = c->pass_dev[i].taps;
+    sd[i].tapw = c->pass_dev[i].tapw;
+    sd[i].nw = p.passes[i].nw;
+    sd[i].nw4 = p.passes[i].nw4;
   }
   const int out_w = p.out_info.width, out_h = p.out_info.height;
   PostFast pf, pf_none;
@@ -284,6 +294,8 @@ void gstamd_video_converter_free (GstAmdVideoConverter *c)
       (void) hipFree (pd.offset);
     if (pd.taps)
       (void) hipFree (pd.taps);
+    if (pd.tapw)
+      (void) hipFree (pd.tapw);
   }
   if (c->tmp)
     (void) hipFree (c->tmp);

@@ -509,6 +509,9 @@ bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverte
   pass->inc = out_size == 1 ? 0 : (int) ((((unsigned) (in_size - 1)) << 16) / (unsigned) (out_size - 1)) - 1;
   pass->precision = 0;
   pass->taps.clear ();
+  pass->dot4_ok = false;
+  pass->nw = pass->nw4 = 0;
+  pass->tapw.clear ();
   if (max_taps == 1) {
     pass->kind = SCALE_NEAREST;               /* h_near_u32 / v_near: copies s[offset[i]] */
     return true;
@@ -527,6 +530,35 @@ bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverte
   pass->taps.assign ((size_t) out_size * max_taps, 0);
   for (int i = 0; i < out_size; i++)
     convert_coeff (&dtaps[(size_t) i * max_taps], &pass->taps[(size_t) i * max_taps], max_taps, pass->precision);
+  /* byte-dot-product form of a horizontal N-tap pass: the filter window is read from a 4-byte aligned LDS address,
+   * so the taps are shifted right by (offset & 3) places inside nw zero-padded words (a zero tap adds nothing to
+   * the 16-bit wrapping sum, so the result is unchanged) */
+  if (horizontal && pass->kind == SCALE_NTAP) {
+    bool ok = true;
+    for (int i = 0; i < out_size && ok; i++) {
+      int sum = 0;
+      for (int l = 0; l < max_taps; l++) {
+        const int t = pass->taps[(size_t) i * max_taps + l];
+        ok = ok && t >= -128 && t <= 127;
+        sum += t;
+      }
+      ok = ok && sum == (1 << pass->precision);
+    }
+    if (ok) {
+      pass->dot4_ok = true;
+      pass->nw = (max_taps + 3 + 3) / 4;
+      pass->nw4 = (pass->nw + 3) & ~3;
+      pass->tapw.assign ((size_t) out_size * pass->nw4, 0);
+      for (int i = 0; i < out_size; i++) {
+        const int shift = (int) (pass->offset[i] & 3);
+        for (int l = 0; l < max_taps; l++) {
+          const int j = l + shift;
+          const uint32_t b = (uint32_t) (uint8_t) (int8_t) pass->taps[(size_t) i * max_taps + l];
+          pass->tapw[(size_t) i * pass->nw4 + (j >> 2)] |= b << (8 * (j & 3));
+        }
+      }
+    }
+  }
   return true;
 }
 
@@ -954,7 +986,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : "";
   d += fr.chroma_v2 ? ",v2" : "";
   for (const ScalePass &p : plan->passes)
-    d += std::string (p.horizontal ? ",H" : ",V") + std::to_string (p.n_taps);
+    d += std::string (p.horizontal ? ",H" : ",V") + std::to_string (p.n_taps) + (p.dot4_ok ? "b" : "");    /* b: byte-dot-product taps */
   static const char *mk[] = {"none", "ayuv_argb", "table", "matrix8"};
   d += std::string (",matrix=") + mk[plan->matrix.kind] + (plan->matrix_before_scale ? "(pre)" : "") + "]";
   plan->description = d;

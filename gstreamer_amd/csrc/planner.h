@@ -73,6 +73,10 @@ struct ScalePass {
   std::vector<uint32_t> offset;   // [out_size] first source index
   std::vector<int16_t> taps;      // [out_size][n_taps] quantised taps (precision depends on kind)
   int precision;
+  // horizontal N-tap passes whose taps fit int8 and sum to 1.0 in every phase: byte-dot-product form (video_scale_fast.h)
+  bool dot4_ok;
+  int nw, nw4;                    // tap words per output that are used / allocated (row stride of tapw)
+  std::vector<uint32_t> tapw;     // [out_size][nw4]: 4 int8 taps per word, shifted by (offset & 3), zero padded
   int max_span;        // horizontal passes: largest source span under any 256-output tile (LDS staging)
 };
 

@@ -156,6 +156,23 @@ __global__ __launch_bounds__ (64) void k_hscale_wave (SRC src, ScaleDev sd, Dst 
   hscale_tile_lane (lds_w, xa, sd, dst, pf, t0, t1, y, lane);
 }
 
+// horizontal N-tap pass from the source frame as byte dot products: three byte planes of plane_w words each in LDS
+template <int NW>
+__global__ __launch_bounds__ (64) void k_hscale_dot4_wave (SrcFront src, ScaleDev sd, Dst dst, PostFast pf, int out_w, int rows, int tile_w,
+    int plane_w, int packed)
+{
+  extern __shared__ uint32_t lds_w[];
+  uint32_t *py = lds_w, *pu = lds_w + plane_w, *pv = lds_w + 2 * plane_w;
+  const int lane = (int) threadIdx.x, y = (int) blockIdx.y, t0 = (int) blockIdx.x * tile_w;
+  const int t1 = t0 + tile_w < out_w ? t0 + tile_w : out_w;
+  int x_lo, x_hi;
+  hscale_span (sd, t0, t1, &x_lo, &x_hi);
+  const int xa = x_lo & ~7;
+  tile_stage_row_planes (src, py, pu, pv, xa, x_hi, y, lane, packed);
+  wave_lds_sync ();
+  hscale_dot4_lane<NW> (py, pu, pv, xa, sd, sd.nw, dst, pf, t0, t1, y, lane);
+}
+
 template <class SRC>
 __global__ __launch_bounds__ (256) void k_scale2x2 (SRC src, ScaleDev sh, ScaleDev sv, int h_first, Dst dst, int out_w, int out_h)
 {
@@ -343,6 +360,12 @@ static int front_packed_ok (const SrcFront &s)
   return s.vec_ok && s.f.w_sub == 1 && s.f.kind != UNPACK_PACKED4 && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
 }
 
+// byte-dot-product N-tap pass: opaque source (alpha 0xff in, 0xff out) and no colour step before the scaler
+static int dot4_source_ok (const SrcFront &s)
+{
+  return s.f.kind != UNPACK_PACKED4 && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
+}
+
 static Dst make_dst (uint8_t *p, int stride, bool final, const ColorParams &post, const int pack_pos[4])
 {
   Dst d;
@@ -367,7 +390,17 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
   src.vec_ok = front_vec_ok (f, pl);
   Dst d = make_dst (dst, dstride, final, post, pack_pos);
   dim3 block (256), grid ((out_w + 255) / 256, out_h);
-  if (horizontal && geom.tile_w > 0 && geom.lds_px * 4 <= WAVE_TILE_LDS_BYTES) {
+  if (horizontal && geom.tile_w > 0 && sd.tapw && dot4_source_ok (src)) {
+    /* planes of lds_px bytes + 8 (the aligned filter window may run a few zero-tap bytes past the span) */
+    const int plane_w = (geom.lds_px + 8) / 4;
+    dim3 wgrid ((out_w + geom.tile_w - 1) / geom.tile_w, out_h);
+    if (sd.nw == 5)
+      hipLaunchKernelGGL (k_hscale_dot4_wave<5>, wgrid, dim3 (64), (size_t) plane_w * 12, stream, src, sd, d, pf, out_w, out_h, geom.tile_w,
+          plane_w, front_packed_ok (src));
+    else
+      hipLaunchKernelGGL (k_hscale_dot4_wave<0>, wgrid, dim3 (64), (size_t) plane_w * 12, stream, src, sd, d, pf, out_w, out_h, geom.tile_w,
+          plane_w, front_packed_ok (src));
+  } else if (horizontal && geom.tile_w > 0 && geom.lds_px * 4 <= WAVE_TILE_LDS_BYTES) {
     dim3 wgrid ((out_w + geom.tile_w - 1) / geom.tile_w, out_h);
     hipLaunchKernelGGL (k_hscale_wave<SrcFront>, wgrid, dim3 (64), (size_t) geom.lds_px * 4, stream, src, sd, d, pf, out_w, out_h,
         geom.tile_w, geom.lds_px, front_packed_ok (src));

@@ -77,11 +77,13 @@ GSTAMD_HD void hfilter8_packed (const ChromaP6 &c, int x0, int w, uint32_t *o)
   }
 }
 
+// luma words and the upsampled chroma (U | V << 16 per pixel) of the 8 pixels
 template <int CH>
-GSTAMD_HD void front_span8_packed (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint32_t *out)
+GSTAMD_HD void front_chroma8_packed (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint2 &yy,
+    uint32_t *ca)
 {
   const int w = f.width;
-  const uint2 yy = *(const uint2 *) (pl.p[0] + (size_t) y * pl.stride[0] + x0);
+  yy = *(const uint2 *) (pl.p[0] + (size_t) y * pl.stride[0] + x0);
   const int cw = (w + 1) >> 1, k0 = x0 >> 1;
   int ra, rb, role = 0;
   if (f.chroma_v2) {
@@ -92,7 +94,6 @@ GSTAMD_HD void front_span8_packed (const FrontParams &f, const Planes &pl, const
   } else {
     ra = rb = y >> f.h_sub;
   }
-  uint32_t ca[8];
   {
     ChromaP6 c;
     load_chroma6_packed (f, pl, ra, k0, cw, c);
@@ -113,6 +114,25 @@ GSTAMD_HD void front_span8_packed (const FrontParams &f, const Planes &pl, const
         ca[i] = pk_shr<2> (ca[i] + 3u * cb[i] + 0x00020002u);
     }
   }
+}
+
+GSTAMD_HD void front_chroma8_packed_any (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint2 &yy,
+    uint32_t *ca)
+{
+  if (f.chroma_h == CHROMA_H_H2_CS)
+    front_chroma8_packed<CHROMA_H_H2_CS> (f, pl, vpair, x0, y, yy, ca);
+  else if (f.chroma_h == CHROMA_H_H2)
+    front_chroma8_packed<CHROMA_H_H2> (f, pl, vpair, x0, y, yy, ca);
+  else
+    front_chroma8_packed<CHROMA_H_NONE> (f, pl, vpair, x0, y, yy, ca);
+}
+
+template <int CH>
+GSTAMD_HD void front_span8_packed (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint32_t *out)
+{
+  uint2 yy;
+  uint32_t ca[8];
+  front_chroma8_packed<CH> (f, pl, vpair, x0, y, yy, ca);
   // byte0 = 0xff, byte1 = Y, byte2 = U (chroma byte 0), byte3 = V (chroma byte 2)
   static const uint32_t ysel[4] = {0x0604000du, 0x0604010du, 0x0604020du, 0x0604030du};
 #pragma unroll
@@ -299,6 +319,89 @@ GSTAMD_HD void scale2x2_tile_lane (const uint32_t *la, const uint32_t *lb, int x
       }
     }
     store_px (dst, x, y, post_px (dst, pf, e | (o << 8)));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// N-tap horizontal pass as byte dot products (v_dot4_i32_i8).  The wave stages Y, U, V of the source span as three
+// byte planes, each byte XOR 0x80 (= value - 128 as int8); one output channel is
+//     sum (px * tap) = sum ((px - 128) * tap) + 128 * sum (tap),      sum (tap) = 64 (checked by the planner)
+// i.e. nw dot4 instructions instead of 4 * n_taps multiply-adds; the 16-bit wrap of the ORC program
+// (video-orc.orc:2388-2480) is applied to the exact sum afterwards, which is the same thing.  Alpha is 0xff on both
+// sides (opaque source, taps sum to 1.0).
+// ------------------------------------------------------------------------------------------------
+GSTAMD_HD int dot4_i8 (uint32_t a, uint32_t b, int acc)
+{
+#ifdef __HIPCC__
+  return __builtin_amdgcn_sdot4 ((int) a, (int) b, acc, false);
+#else
+  for (int k = 0; k < 4; k++)
+    acc += (int) (int8_t) (a >> (8 * k)) * (int) (int8_t) (b >> (8 * k));
+  return acc;
+#endif
+}
+
+// stage source pixels [xa, x_hi) of line y as byte planes py/pu/pv (byte i = pixel xa + i, XOR 0x80)
+GSTAMD_HD void tile_stage_row_planes (const SrcFront &src, uint32_t *py, uint32_t *pu, uint32_t *pv, int xa, int x_hi, int y, int lane,
+    int packed)
+{
+  for (int x0 = xa + 8 * lane; x0 < x_hi; x0 += 8 * 64) {
+    const int w0 = (x0 - xa) >> 2;
+    if (packed && src_span8_ok (src, x0)) {
+      uint2 yy;
+      uint32_t ca[8];
+      front_chroma8_packed_any (src.f, src.pl, src.vpair, x0, y, yy, ca);
+      py[w0] = yy.x ^ 0x80808080u;
+      py[w0 + 1] = yy.y ^ 0x80808080u;
+      // ca = [U, 0, V, 0]: two pixels -> [U0, U1, V0, V1], then two of those -> four U bytes / four V bytes
+      const uint32_t t01 = ca[0] | (ca[1] << 8), t23 = ca[2] | (ca[3] << 8), t45 = ca[4] | (ca[5] << 8), t67 = ca[6] | (ca[7] << 8);
+      pu[w0] = bperm (t23, t01, 0x05040100u) ^ 0x80808080u;
+      pv[w0] = bperm (t23, t01, 0x07060302u) ^ 0x80808080u;
+      pu[w0 + 1] = bperm (t67, t45, 0x05040100u) ^ 0x80808080u;
+      pv[w0 + 1] = bperm (t67, t45, 0x07060302u) ^ 0x80808080u;
+    } else {
+      const int xe = x0 + 8 < x_hi ? x0 + 8 : x_hi;
+#pragma unroll 1
+      for (int x = x0; x < xe; x++) {
+        const uint32_t px = src.at (x, y) ^ 0x80808080u;
+        ((uint8_t *) py)[x - xa] = (uint8_t) (px >> 8);
+        ((uint8_t *) pu)[x - xa] = (uint8_t) (px >> 16);
+        ((uint8_t *) pv)[x - xa] = (uint8_t) (px >> 24);
+      }
+    }
+  }
+}
+
+template <int NW>
+GSTAMD_HD void hscale_dot4_lane (const uint32_t *py, const uint32_t *pu, const uint32_t *pv, int xa, const ScaleDev &sd, int nw, const Dst &dst,
+    const PostFast &pf, int t0, int t1, int y, int lane)
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = t0 + lane + 64 * i;
+    if (x >= t1)
+      break;
+    const int w0 = ((int) sd.offset[x] - xa) >> 2;
+    const uint32_t *tw = sd.tapw + (size_t) x * sd.nw4;
+    int ay = 128 * 64, au = 128 * 64, av = 128 * 64;
+    if (NW > 0) {
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        const uint32_t t = tw[k];
+        ay = dot4_i8 (py[w0 + k], t, ay);
+        au = dot4_i8 (pu[w0 + k], t, au);
+        av = dot4_i8 (pv[w0 + k], t, av);
+      }
+    } else {
+      for (int k = 0; k < nw; k++) {
+        const uint32_t t = tw[k];
+        ay = dot4_i8 (py[w0 + k], t, ay);
+        au = dot4_i8 (pu[w0 + k], t, au);
+        av = dot4_i8 (pv[w0 + k], t, av);
+      }
+    }
+    const uint32_t px = 0xffu | ((uint32_t) lq_round (ay) << 8) | ((uint32_t) lq_round (au) << 16) | ((uint32_t) lq_round (av) << 24);
+    store_px (dst, x, y, post_px (dst, pf, px));
   }
 }
 

@@ -23,6 +23,8 @@ struct ScaleDev {         // one scaler pass, tables resident in HBM
   int inc;
   const uint32_t *offset;
   const int16_t *taps;
+  const uint32_t *tapw;   // ScalePass::tapw (byte-dot-product form), NULL when not applicable
+  int nw, nw4;
 };
 
 }  // namespace gstamd

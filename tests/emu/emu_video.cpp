@@ -66,10 +66,44 @@ static void run_hscale_wave (const SRC &src, const ScaleDev &sd, const Dst &d, c
     }
 }
 
+// k_hscale_dot4_wave
+static void run_hscale_dot4 (const SrcFront &src, const ScaleDev &sd, const Dst &d, const PostFast &pf, int out_w, int out_h, TileGeom g)
+{
+  const int plane_w = (g.lds_px + 8) / 4;
+  std::vector<uint32_t> lds (3 * plane_w);
+  uint32_t *py = lds.data (), *pu = py + plane_w, *pv = pu + plane_w;
+  for (int y = 0; y < out_h; y++)
+    for (int t0 = 0; t0 < out_w; t0 += g.tile_w) {
+      const int t1 = t0 + g.tile_w < out_w ? t0 + g.tile_w : out_w;
+      int lo, hi;
+      hscale_span (sd, t0, t1, &lo, &hi);
+      const int xa = lo & ~7;
+      for (int lane = 0; lane < 64; lane++)
+        tile_stage_row_planes (src, py, pu, pv, xa, hi, y, lane, emu_packed_ok (src));
+      for (int lane = 0; lane < 64; lane++) {
+        if (sd.nw == 5)
+          hscale_dot4_lane<5> (py, pu, pv, xa, sd, sd.nw, d, pf, t0, t1, y, lane);
+        else
+          hscale_dot4_lane<0> (py, pu, pv, xa, sd, sd.nw, d, pf, t0, t1, y, lane);
+      }
+    }
+}
+
+static bool emu_dot4_ok (const SrcFront &s, const ScaleDev &sd)
+{
+  return sd.tapw && s.f.kind != UNPACK_PACKED4 && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
+}
+static bool emu_dot4_ok (const SrcImage &, const ScaleDev &) { return false; }
+static void run_hscale_dot4 (const SrcImage &, const ScaleDev &, const Dst &, const PostFast &, int, int, TileGeom) {}
+
 template <class SRC>
 static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h, int max_span, TileGeom g,
     const PostFast &pf)
 {
+  if (horizontal && g.tile_w > 0 && emu_dot4_ok (src, sd)) {
+    run_hscale_dot4 (src, sd, d, pf, out_w, out_h, g);
+    return;
+  }
   if (horizontal && g.tile_w > 0 && g.lds_px * 4 <= 16384) {
     run_hscale_wave (src, sd, d, pf, out_w, out_h, g);
     return;
@@ -181,6 +215,9 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     sd[i].inc = p.passes[i].inc;
     sd[i].offset = p.passes[i].offset.data ();
     sd[i].taps = p.passes[i].taps.data ();
+    sd[i].tapw = p.passes[i].dot4_ok ? p.passes[i].tapw.data () : nullptr;
+    sd[i].nw = p.passes[i].nw;
+    sd[i].nw4 = p.passes[i].nw4;
   }
   SrcFront sf;
   sf.f = p.front;

@@ -73,7 +73,7 @@ def test_c2_plan_and_algorithmic_bytes(native_lib):
 def test_c3_plan(native_lib):
     cfg = V.converter_config(resampler_method="lanczos")
     c = V.VideoConverter(V.video_info("I420", 7680, 4320), V.video_info("RGBA", 1920, 1080), cfg)
-    assert c.describe() == "scale[I420->RGBA,h2cs,v2,H16,V16,matrix=ayuv_argb]"
+    assert c.describe() == "scale[I420->RGBA,h2cs,v2,H16b,V16,matrix=ayuv_argb]"
     assert c.algorithmic_bytes() == 58060800
     info = c.debug_get(30)
     assert info[:3] == [3, 1, 16]            # N-tap, horizontal first, 16 taps

@@ -178,7 +178,11 @@ template <int NPX>
 GSTAMD_HD void fast_load_y (const uint8_t *__restrict__ p, uint32_t *y)
 {
   if (NPX == 4) {
+#ifdef __HIPCC__
+    y[0] = __builtin_nontemporal_load ((const uint32_t *) p);     // luma is read exactly once: streaming load
+#else
     y[0] = *(const uint32_t *) p;
+#endif
   } else if (NPX == 8) {
     const uint2 m = *(const uint2 *) p;
     y[0] = m.x;

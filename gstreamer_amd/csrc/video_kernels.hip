@@ -257,11 +257,11 @@ __global__ __launch_bounds__ (256) void k_convert_strip (FastParams fp, FrameBat
 }
 
 template <int CH, int NPX, int ABL>
-static void launch_strip_variant (const FastParams &fp, const FrameBatch &batch, int n, int bx, int K, hipStream_t stream)
+static void launch_strip_variant (const FastParams &fp, const FrameBatch &batch, int n, int bx, int K, hipStream_t stream, int by = 0)
 {
   const int pairs = fp.height / 2 + 1, strips = (pairs + K - 1) / K;
   const int per_block = bx * NPX;
-  dim3 block (bx, 256 / bx), grid ((fp.width + per_block - 1) / per_block, (strips + block.y - 1) / block.y, n);
+  dim3 block (bx, by > 0 ? by : 256 / bx), grid ((fp.width + per_block - 1) / per_block, (strips + block.y - 1) / block.y, n);
   hipLaunchKernelGGL ((k_convert_strip<CH, NPX, ABL>), grid, block, 0, stream, fp, batch, pairs, K);
 }
 
@@ -277,19 +277,19 @@ static void launch_pair_variant (const FastParams &fp, const FrameBatch &batch, 
 // Tuning knob for profiling sessions: GSTAMD_FAST_VARIANT="npx,abl,groups,bx" (h2cs only).  Unset = shipped config.
 static bool launch_pair_experiment (const FastParams &fp, const FrameBatch &batch, int n, hipStream_t stream)
 {
-  static int cfg[4] = {-1, 0, 0, 0};
+  static int cfg[5] = {-1, 0, 0, 0, 0};
   if (cfg[0] == -1) {
     const char *e = getenv ("GSTAMD_FAST_VARIANT");
     cfg[0] = 0;
     if (e)
-      sscanf (e, "%d,%d,%d,%d", &cfg[0], &cfg[1], &cfg[2], &cfg[3]);
+      sscanf (e, "%d,%d,%d,%d,%d", &cfg[0], &cfg[1], &cfg[2], &cfg[3], &cfg[4]);
   }
   if (cfg[0] == 0)
     return false;
   const int npx = cfg[0], abl = cfg[1], groups = cfg[2], bx = cfg[3];
   if (groups >= 100) {                    /* strip variant: groups = 100 + K */
     const int K = groups - 100;
-#define S(N, A) if (npx == N && abl == A) { launch_strip_variant<CHROMA_H_H2_CS, N, A> (fp, batch, n, bx, K, stream); return true; }
+#define S(N, A) if (npx == N && abl == A) { launch_strip_variant<CHROMA_H_H2_CS, N, A> (fp, batch, n, bx, K, stream, cfg[4]); return true; }
     S (4, 0) S (4, 1) S (8, 0) S (8, 1)
 #undef S
     return false;
@@ -324,17 +324,17 @@ hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames
     batch.dstride = dstride;
     if (chroma_h == CHROMA_H_H2_CS && launch_pair_experiment (fp, batch, n, stream))
       continue;
-    /* shipped configuration (MI355X sweep, profiles/r01_c2_variants.txt): 4-pixel columns, 2 line pairs per
-     * lane with the second pair's loads in flight during the first pair's math, 64 x 4 lanes per block */
+    /* shipped configuration (MI355X sweeps, profiles/r01_c2_variants*.txt): 4-pixel columns, 3 line pairs per lane
+     * with the next pair's loads in flight during the current pair's math, one wave per workgroup */
     switch (chroma_h) {
       case CHROMA_H_H2_CS:
-        launch_strip_variant<CHROMA_H_H2_CS, 4, 0> (fp, batch, n, 64, 2, stream);
+        launch_strip_variant<CHROMA_H_H2_CS, 4, 0> (fp, batch, n, 64, 3, stream, 1);
         break;
       case CHROMA_H_H2:
-        launch_strip_variant<CHROMA_H_H2, 4, 0> (fp, batch, n, 64, 2, stream);
+        launch_strip_variant<CHROMA_H_H2, 4, 0> (fp, batch, n, 64, 3, stream, 1);
         break;
       default:
-        launch_strip_variant<CHROMA_H_NONE, 4, 0> (fp, batch, n, 64, 2, stream);
+        launch_strip_variant<CHROMA_H_NONE, 4, 0> (fp, batch, n, 64, 3, stream, 1);
         break;
     }
   }

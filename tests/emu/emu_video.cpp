@@ -173,11 +173,11 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         }
       return GSTAMD_OK;
     }
-    {                                     /* shipped configuration: 4-pixel columns, K = 2 */
+    {                                     /* shipped configuration: 4-pixel columns, K = 3 */
       const int pairs = fp.height / 2 + 1;
-      for (int p0 = 0; p0 < pairs; p0 += 2)
+      for (int p0 = 0; p0 < pairs; p0 += 3)
         for (int x0 = 0; x0 + 4 <= fp.width; x0 += 4) {
-          const int p1 = p0 + 2 < pairs ? p0 + 2 : pairs;
+          const int p1 = p0 + 3 < pairs ? p0 + 3 : pairs;
           switch (p.front.chroma_h) {
             case CHROMA_H_H2_CS: fast_strip<CHROMA_H_H2_CS, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); break;
             case CHROMA_H_H2: fast_strip<CHROMA_H_H2, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); break;

@@ -168,9 +168,17 @@ __global__ __launch_bounds__ (64) void k_hscale_dot4_wave (SrcFront src, ScaleDe
   int x_lo, x_hi;
   hscale_span (sd, t0, t1, &x_lo, &x_hi);
   const int xa = x_lo & ~7;
+  Dot4Taps<NW> ft;
+  hscale_dot4_fetch<NW> (sd, xa, t0, t1, lane, ft);
   tile_stage_row_planes (src, py, pu, pv, xa, x_hi, y, lane, packed);
   wave_lds_sync ();
-  hscale_dot4_lane<NW> (py, pu, pv, xa, sd, sd.nw, dst, pf, t0, t1, y, lane);
+  hscale_dot4_lane<NW> (py, pu, pv, ft, sd, sd.nw, dst, pf, t0, t1, y, lane);
+}
+
+// vertical N-tap pass over an AYUV image, 4 pixels per lane, one wave per workgroup
+__global__ __launch_bounds__ (64) void k_vscale_pk (SrcImage src, ScaleDev sd, Dst dst, PostFast pf, int width, int out_h)
+{
+  vscale_pk_lane (src, sd, dst, pf, width, out_h, (int) (blockIdx.x * 64 + threadIdx.x) * 4, (int) blockIdx.y);
 }
 
 template <class SRC>
@@ -431,7 +439,11 @@ hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int ss
     hipLaunchKernelGGL (k_hscale_lds<SrcImage>, grid, block, (size_t) max_span * 4, stream, src, sd, d, out_w, out_h);
   else if (horizontal)
     hipLaunchKernelGGL (k_hscale<SrcImage>, grid, block, 0, stream, src, sd, d, out_w, out_h);
-  else
+  else if (sd.kind == SCALE_NTAP) {
+    /* the packed kernel runs the generic post stage too (post_px), so it serves every N-tap vertical pass */
+    dim3 vgrid ((out_w + 255) / 256, out_h);
+    hipLaunchKernelGGL (k_vscale_pk, vgrid, dim3 (64), 0, stream, src, sd, d, pf, out_w, out_h);
+  } else
     hipLaunchKernelGGL (k_vscale<SrcImage>, grid, block, 0, stream, src, sd, d, out_w, out_h);
   return hipGetLastError ();
 }

@@ -372,27 +372,52 @@ GSTAMD_HD void tile_stage_row_planes (const SrcFront &src, uint32_t *py, uint32_
   }
 }
 
+// per-lane filter data of the (up to) 4 outputs t0 + lane + 64 * i: requested before the staging step so that the
+// table reads overlap it
 template <int NW>
-GSTAMD_HD void hscale_dot4_lane (const uint32_t *py, const uint32_t *pu, const uint32_t *pv, int xa, const ScaleDev &sd, int nw, const Dst &dst,
-    const PostFast &pf, int t0, int t1, int y, int lane)
+struct Dot4Taps {
+  int w0[4];                          // first LDS word of the aligned filter window
+  uint32_t t[4][NW > 0 ? NW : 1];
+};
+
+template <int NW>
+GSTAMD_HD void hscale_dot4_fetch (const ScaleDev &sd, int xa, int t0, int t1, int lane, Dot4Taps<NW> &ft)
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = t0 + lane + 64 * i;
+    const int xc = x < t1 ? x : t1 - 1;
+    ft.w0[i] = ((int) sd.offset[xc] - xa) >> 2;
+    if (NW > 0) {
+      const uint32_t *tw = sd.tapw + (size_t) xc * sd.nw4;
+#pragma unroll
+      for (int k = 0; k < NW; k++)
+        ft.t[i][k] = tw[k];
+    }
+  }
+}
+
+template <int NW>
+GSTAMD_HD void hscale_dot4_lane (const uint32_t *py, const uint32_t *pu, const uint32_t *pv, const Dot4Taps<NW> &ft, const ScaleDev &sd, int nw,
+    const Dst &dst, const PostFast &pf, int t0, int t1, int y, int lane)
 {
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int x = t0 + lane + 64 * i;
     if (x >= t1)
       break;
-    const int w0 = ((int) sd.offset[x] - xa) >> 2;
-    const uint32_t *tw = sd.tapw + (size_t) x * sd.nw4;
+    const int w0 = ft.w0[i];
     int ay = 128 * 64, au = 128 * 64, av = 128 * 64;
     if (NW > 0) {
 #pragma unroll
       for (int k = 0; k < NW; k++) {
-        const uint32_t t = tw[k];
+        const uint32_t t = ft.t[i][k];
         ay = dot4_i8 (py[w0 + k], t, ay);
         au = dot4_i8 (pu[w0 + k], t, au);
         av = dot4_i8 (pv[w0 + k], t, av);
       }
     } else {
+      const uint32_t *tw = sd.tapw + (size_t) x * sd.nw4;
       for (int k = 0; k < nw; k++) {
         const uint32_t t = tw[k];
         ay = dot4_i8 (py[w0 + k], t, ay);
@@ -402,6 +427,78 @@ GSTAMD_HD void hscale_dot4_lane (const uint32_t *py, const uint32_t *pu, const u
     }
     const uint32_t px = 0xffu | ((uint32_t) lq_round (ay) << 8) | ((uint32_t) lq_round (au) << 16) | ((uint32_t) lq_round (av) << 24);
     store_px (dst, x, y, post_px (dst, pf, px));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vertical N-tap pass, 4 pixels per lane, packed 16-bit accumulators (video_orc_resample_v_multaps*_u8_lq:
+// mullw / addw accumulate with 16-bit wrap, then (acc + 32) >> 6 arithmetic and unsigned saturation)
+// ------------------------------------------------------------------------------------------------
+// per 16-bit lane: clamp (((int16) (x + 32)) >> 6, 0, 255)
+GSTAMD_HD uint32_t pk_lq_finish (uint32_t acc)
+{
+#ifdef __HIPCC__
+  typedef short s2 __attribute__ ((ext_vector_type (2)));
+  s2 v = __builtin_bit_cast (s2, acc) + (s2) (short) 32;
+  v = v >> (short) 6;
+  v = __builtin_elementwise_min (__builtin_elementwise_max (v, (s2) (short) 0), (s2) (short) 255);
+  return __builtin_bit_cast (uint32_t, v);
+#else
+  uint32_t r = 0;
+  for (int h = 0; h < 2; h++) {
+    int v = (int) (int16_t) (uint16_t) (((acc >> (16 * h)) & 0xffffu) + 32u);
+    v >>= 6;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    r |= (uint32_t) v << (16 * h);
+  }
+  return r;
+#endif
+}
+
+// outputs x0 .. x0+3 (x0 + 4 <= width) of row y from an AYUV image
+GSTAMD_HD void vscale_ntap_lane4 (const SrcImage &src, const ScaleDev &sd, const Dst &dst, const PostFast &pf, int x0, int y)
+{
+  struct __attribute__ ((aligned (4))) W4 { uint32_t v[4]; };
+  const int off = (int) sd.offset[y];
+  const int16_t *t = sd.taps + (size_t) y * sd.n_taps;
+  uint32_t ae[4] = {0, 0, 0, 0}, ao[4] = {0, 0, 0, 0};
+  const uint8_t *p = src.p + (size_t) off * src.stride + 4 * (size_t) x0;
+#pragma unroll 8
+  for (int l = 0; l < sd.n_taps; l++) {
+    const W4 w = *(const W4 *) (p + (size_t) l * src.stride);
+    const uint32_t ts = (uint32_t) (uint16_t) t[l] * 0x00010001u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      ae[i] = pk_mad16 (w.v[i] & 0x00ff00ffu, ts, ae[i]);
+      ao[i] = pk_mad16 (pk_shr<8> (w.v[i]), ts, ao[i]);
+    }
+  }
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    o[i] = post_px (dst, pf, pk_lq_finish (ae[i]) | (pk_lq_finish (ao[i]) << 8));
+  uint8_t *d = dst.p + (size_t) y * dst.stride + 4 * (size_t) x0;
+#ifdef __HIPCC__
+  typedef unsigned int u32x4_a4 __attribute__ ((ext_vector_type (4), aligned (4)));
+  const u32x4_a4 v = {o[0], o[1], o[2], o[3]};
+  __builtin_nontemporal_store (v, (u32x4_a4 *) d);
+#else
+  W4 v = {{o[0], o[1], o[2], o[3]}};
+  *(W4 *) d = v;
+#endif
+}
+
+// lane of the vertical pass kernel: 4 pixels from x0, the last lane of a row finishes pixel by pixel
+GSTAMD_HD void vscale_pk_lane (const SrcImage &src, const ScaleDev &sd, const Dst &dst, const PostFast &pf, int width, int out_h, int x0, int y)
+{
+  if (x0 >= width || y >= out_h)
+    return;
+  if (x0 + 4 <= width) {
+    vscale_ntap_lane4 (src, sd, dst, pf, x0, y);
+  } else {
+#pragma unroll 1
+    for (int x = x0; x < width; x++)
+      vscale_body<SrcImage> (src, sd, dst, width, out_h, x, y);
   }
 }
 

@@ -81,10 +81,15 @@ static void run_hscale_dot4 (const SrcFront &src, const ScaleDev &sd, const Dst 
       for (int lane = 0; lane < 64; lane++)
         tile_stage_row_planes (src, py, pu, pv, xa, hi, y, lane, emu_packed_ok (src));
       for (int lane = 0; lane < 64; lane++) {
-        if (sd.nw == 5)
-          hscale_dot4_lane<5> (py, pu, pv, xa, sd, sd.nw, d, pf, t0, t1, y, lane);
-        else
-          hscale_dot4_lane<0> (py, pu, pv, xa, sd, sd.nw, d, pf, t0, t1, y, lane);
+        if (sd.nw == 5) {
+          Dot4Taps<5> ft;
+          hscale_dot4_fetch<5> (sd, xa, t0, t1, lane, ft);
+          hscale_dot4_lane<5> (py, pu, pv, ft, sd, sd.nw, d, pf, t0, t1, y, lane);
+        } else {
+          Dot4Taps<0> ft;
+          hscale_dot4_fetch<0> (sd, xa, t0, t1, lane, ft);
+          hscale_dot4_lane<0> (py, pu, pv, ft, sd, sd.nw, d, pf, t0, t1, y, lane);
+        }
       }
     }
 }
@@ -95,6 +100,14 @@ static bool emu_dot4_ok (const SrcFront &s, const ScaleDev &sd)
 }
 static bool emu_dot4_ok (const SrcImage &, const ScaleDev &) { return false; }
 static void run_hscale_dot4 (const SrcImage &, const ScaleDev &, const Dst &, const PostFast &, int, int, TileGeom) {}
+
+static bool emu_is_image (const SrcImage &) { return true; }
+static bool emu_is_image (const SrcFront &) { return false; }
+static void emu_vscale_pk (const SrcImage &src, const ScaleDev &sd, const Dst &d, const PostFast &pf, int w, int h, int x0, int y)
+{
+  vscale_pk_lane (src, sd, d, pf, w, h, x0, y);
+}
+static void emu_vscale_pk (const SrcFront &, const ScaleDev &, const Dst &, const PostFast &, int, int, int, int) {}
 
 template <class SRC>
 static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h, int max_span, TileGeom g,
@@ -110,6 +123,12 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
   }
   if (horizontal && max_span <= 12288) {
     run_hscale_lds (src, sd, d, out_w, out_h);
+    return;
+  }
+  if (!horizontal && sd.kind == SCALE_NTAP && emu_is_image (src)) {      /* k_vscale_pk */
+    for (int y = 0; y < out_h; y++)
+      for (int x0 = 0; x0 < out_w; x0 += 4)
+        emu_vscale_pk (src, sd, d, pf, out_w, out_h, x0, y);
     return;
   }
   for (int y = 0; y < out_h; y++)

@@ -57,11 +57,7 @@ static FastParams make_fast_params (const VideoPlan &p)
   FastParams fp;
   fp.width = p.front.width;
   fp.height = p.front.height;
-  for (int i = 0; i < 5; i++)
-    fp.p8[i] = p.matrix.p[i] * 256;
-  fp.pack_sel = (0x0du << (8 * p.post.pack_pos[0])) | (0x00u << (8 * p.post.pack_pos[1])) |
-      (0x01u << (8 * p.post.pack_pos[2])) | (0x04u << (8 * p.post.pack_pos[3]));
-  fp.u_first = p.front.u_plane;
+  fast_params_finish (fp, p.matrix.p, p.post.pack_pos, p.front.u_plane);
   return fp;
 }
 

@@ -24,7 +24,27 @@ struct FastParams {
   int p8[5];            // p1..p5 << 8
   uint32_t pack_sel;    // v_perm selector: dest byte pos[A] <- 0xff, pos[R] <- lo.0, pos[G] <- lo.1, pos[B] <- hi.0
   int u_first;          // 1: NV12 (U,V), 0: NV21 (V,U)
+  // word form (fast_pixel_w): raw p1..p5, selector of the final perm over {hi = [B, 0xff], lo = [G, R]} and the
+  // selector that splats packed chroma {c0, c1} to words [U U | V V]
+  int pc[5];
+  uint32_t pack_sel_w;
+  uint32_t csel_w;
+  int pack_pos[4];      // destination byte of A, R, G, B
 };
+
+inline void fast_params_finish (FastParams &fp, const int p[5], const int pack_pos[4], int u_first)
+{
+  for (int i = 0; i < 5; i++) {
+    fp.p8[i] = p[i] * 256;
+    fp.pc[i] = p[i];
+  }
+  fp.pack_sel = (0x0du << (8 * pack_pos[0])) | (0x00u << (8 * pack_pos[1])) | (0x01u << (8 * pack_pos[2])) | (0x04u << (8 * pack_pos[3]));
+  fp.pack_sel_w = (0x05u << (8 * pack_pos[0])) | (0x01u << (8 * pack_pos[1])) | (0x00u << (8 * pack_pos[2])) | (0x04u << (8 * pack_pos[3]));
+  fp.u_first = u_first;
+  for (int i = 0; i < 4; i++)
+    fp.pack_pos[i] = pack_pos[i];
+  fp.csel_w = u_first ? 0x02020000u : 0x00000202u;
+}
 
 #ifdef __HIPCC__
 GSTAMD_HD uint32_t bperm (uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm (hi, lo, sel); }
@@ -115,6 +135,240 @@ GSTAMD_HD uint32_t fast_pixel (const FastParams &fp, uint32_t yx, uint32_t ysel,
   const int g = med3_0_255 (wy + mulhi24 (su, fp.p8[3]) + mulhi24 (sv, fp.p8[4]) + 128);
   // bytes: lo = {r, g, 0, 0}, hi = {b, ...}; pack_sel routes r/g/b and the constant 0xff alpha
   return bperm ((uint32_t) b, ((uint32_t) g << 8) | (uint32_t) r, fp.pack_sel);
+}
+
+// ---- word form of the same pixel: sub-dword operand selects (SDWA) instead of byte shuffles ---------------
+// mulhsw (t, p) is the high word of the exact 32-bit product t * p, so the products stay whole
+// (v_mul_i32_i24 on a sign-extended WORD of the splat register) and the adds pick their WORD_1 directly; sums
+// land in the halves of two registers, v_sat_pk_u8_i16 does the signed-saturate + 128 of two channels at once.
+// 13 VALU ops per pixel instead of 20; same integers at every step (the planner's no-wrap proof covers the sums).
+template <int W>
+GSTAMD_HD int mul_word (uint32_t v, int coef)            // sext16 (word W of v) * coef
+{
+#ifdef __HIPCC__
+  int r;
+  if (W == 0)
+    asm ("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v" (r) : "v" (v), "s" (coef));
+  else
+    asm ("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v" (r) : "v" (v), "s" (coef));
+  return r;
+#else
+  return (int) (int16_t) (v >> (16 * W)) * coef;
+#endif
+}
+
+GSTAMD_HD int add_hiword (int a, int prod)                // a + (prod >> 16)
+{
+#ifdef __HIPCC__
+  int r;
+  asm ("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v" (r) : "v" (a), "v" (prod));
+  return r;
+#else
+  return a + (prod >> 16);
+#endif
+}
+
+template <int W>
+GSTAMD_HD void add_hiword_into (uint32_t &dst, int a, int prod)   // word W of dst = low16 (a + (prod >> 16)), other word kept
+{
+#ifdef __HIPCC__
+  if (W == 0)
+    asm ("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_1" : "+v" (dst) : "v" (a), "v" (prod));
+  else
+    asm ("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_1" : "+v" (dst) : "v" (a), "v" (prod));
+#else
+  const uint32_t r = (uint32_t) (a + (prod >> 16)) & 0xffffu;
+  dst = W == 0 ? (dst & 0xffff0000u) | r : (dst & 0x0000ffffu) | (r << 16);
+#endif
+}
+
+GSTAMD_HD uint32_t sat_pk_u8 (uint32_t v)                  // {sat_u8 (i16 lane 0), sat_u8 (i16 lane 1)} in bytes 0, 1
+{
+#ifdef __HIPCC__
+  uint32_t r;
+  asm ("v_sat_pk_u8_i16 %0, %1" : "=v" (r) : "v" (v));
+  return r;
+#else
+  const int a = (int16_t) (v & 0xffff), b = (int16_t) (v >> 16);
+  return (uint32_t) (a < 0 ? 0 : a > 255 ? 255 : a) | ((uint32_t) (b < 0 ? 0 : b > 255 ? 255 : b) << 8);
+#endif
+}
+
+GSTAMD_HD int add_hiwords (int pa, int pb)                 // (pa >> 16) + (pb >> 16)
+{
+#ifdef __HIPCC__
+  int r;
+  asm ("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v" (r) : "v" (pa), "v" (pb));
+  return r;
+#else
+  return (pa >> 16) + (pb >> 16);
+#endif
+}
+
+template <int W>
+GSTAMD_HD void add_hiwords_into (uint32_t &dst, int pa, int pb)   // word W of dst = low16 ((pa >> 16) + (pb >> 16)), other word kept
+{
+#ifdef __HIPCC__
+  if (W == 0)
+    asm ("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v" (dst) : "v" (pa), "v" (pb));
+  else
+    asm ("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v" (dst) : "v" (pa), "v" (pb));
+#else
+  const uint32_t r = (uint32_t) ((pa >> 16) + (pb >> 16)) & 0xffffu;
+  dst = W == 0 ? (dst & 0xffff0000u) | r : (dst & 0x0000ffffu) | (r << 16);
+#endif
+}
+
+// ys: words [t(y_a) | t(y_b)] of two pixels, t = splatbw (y - 128); YW picks the pixel.  cs: words [t(U) | t(V)].
+// rg / ba are scratch registers threaded through consecutive pixels (ba's high word stays 255 = opaque alpha).
+// The "+ 128" of the final signed-saturate rides in the high word of the luma product.
+template <int YW>
+GSTAMD_HD uint32_t fast_pixel_w (const FastParams &fp, uint32_t ys, uint32_t cs, uint32_t &rg, uint32_t &ba)
+{
+  const int wy = mul_word<YW> (ys, fp.pc[0]) + 0x00800000;                              // high word: ((Y * p1) >> 16) + 128
+  add_hiwords_into<1> (rg, wy, mul_word<1> (cs, fp.pc[1]));                             // R = wy + ((V * p2) >> 16)
+  add_hiword_into<0> (rg, add_hiwords (wy, mul_word<0> (cs, fp.pc[3])), mul_word<1> (cs, fp.pc[4]));   // G
+  add_hiwords_into<0> (ba, wy, mul_word<0> (cs, fp.pc[2]));                             // B
+  return bperm (sat_pk_u8 (ba), sat_pk_u8 (rg), fp.pack_sel_w);
+}
+
+// ---- layout-specialised form (wide kernel): no final byte shuffle, no chroma XOR ---------------------------
+// PR / PG / PB = destination byte of R, G, B (alpha takes the fourth).  Bytes 0, 1 are the saturated i16 lanes of
+// q[0], bytes 2, 3 those of q[1]; every add writes its sum straight into the lane of its channel, the second
+// v_sat_pk writes the upper half of the pixel (SDWA dst_sel).  q[][] lives across pixels: the alpha lane is set once.
+GSTAMD_HD void sat_pk_u8_hi (uint32_t &dst, uint32_t v)     // bytes 2, 3 of dst = sat_u8 of v's i16 lanes; bytes 0, 1 kept
+{
+#ifdef __HIPCC__
+  asm ("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v" (dst) : "v" (v));
+#else
+  dst = (dst & 0xffffu) | (sat_pk_u8 (v) << 16);
+#endif
+}
+
+// both u16 lanes: a * k + c (mod 2^16); k_splat carries the multiplier in both halves
+GSTAMD_HD uint32_t pk_mad (uint32_t a, uint32_t k_splat, uint32_t c)
+{
+#ifdef __HIPCC__
+  uint32_t r;           // written out: the compiler would expand a power-of-two multiplier into shift + add
+  asm ("v_pk_mad_u16 %0, %1, %2, %3" : "=v" (r) : "v" (a), "s" (k_splat), "v" (c));
+  return r;
+#else
+  const uint32_t lo = ((a & 0xffffu) * (k_splat & 0xffffu) + (c & 0xffffu)) & 0xffffu;
+  const uint32_t hi = ((a >> 16) * (k_splat >> 16) + (c >> 16)) & 0xffffu;
+  return lo | (hi << 16);
+#endif
+}
+
+// vertical 2x chroma blend of two filtered rows a, b (8-bit values in u16 lanes), both roles at once.  The sums are
+// kept scaled by 64 so the blended value sits in the HIGH byte of each lane - no shift - and the constant carries the
+// rounding (2 * 64) plus 0x8000, which is the "- 128" (XOR 0x80) the colour matrix wants on that byte:
+//   x0.hi = ((3a + b + 2) >> 2) ^ 0x80,  x1.hi = ((a + 3b + 2) >> 2) ^ 0x80;   64 * (4 * 255 + 2) < 2^16.
+GSTAMD_HD void blend_rows_hi (uint32_t a, uint32_t b, uint32_t &x0, uint32_t &x1)
+{
+  x0 = pk_mad (a, 0x00c000c0u, pk_mad (b, 0x00400040u, 0x80808080u));
+  x1 = pk_mad (b, 0x00c000c0u, pk_mad (a, 0x00400040u, 0x80808080u));
+}
+
+#define GSTAMD_LAYOUT(pr, pg, pb) ((pr) | ((pg) << 2) | ((pb) << 4))
+
+template <int L>
+GSTAMD_HD void layout_init (uint32_t (&q)[4][2])
+{
+  constexpr int PA = 6 - (L & 3) - ((L >> 2) & 3) - ((L >> 4) & 3);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    q[j][0] = q[j][1] = 0;
+    q[j][PA >> 1] = 255u << (16 * (PA & 1));
+#ifdef __HIPCC__
+    // opaque to the optimiser: otherwise it re-materialises these constants in front of every tied ("+v") use
+    asm volatile ("" : "+v" (q[j][0]), "+v" (q[j][1]));
+#endif
+  }
+}
+
+// four pixels of one line.  yw: luma bytes y0..y3; xh[j]: blended chroma of pixel j in the high bytes of the u16 lanes
+// (already XOR 0x80).  Step-major order keeps dependent SDWA instructions apart (gfx950 needs a wait state between them).
+template <int L, int ABL>
+GSTAMD_HD void fast_emit4_l (const FastParams &fp, uint8_t *__restrict__ d, bool store, uint32_t yw, const uint32_t *xh, uint32_t (&q)[4][2])
+{
+  constexpr int PR = L & 3, PG = (L >> 2) & 3, PB = (L >> 4) & 3;
+  uint32_t o[4];
+  if (ABL == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      o[j] = yw ^ xh[j];
+  } else {
+    const uint32_t yx = yw ^ 0x80808080u;
+    const uint32_t ys01 = bperm (yx, yx, 0x01010000u), ys23 = bperm (yx, yx, 0x03030202u);
+    const uint32_t csel = fp.u_first ? 0x03030101u : 0x01010303u;
+    uint32_t cs[4];
+    int wy[4], prv[4], pbu[4], pgu[4], pgv[4], g0[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      cs[j] = bperm (xh[j], xh[j], csel);
+    wy[0] = mul_word<0> (ys01, fp.pc[0]) + 0x00800000;
+    wy[1] = mul_word<1> (ys01, fp.pc[0]) + 0x00800000;
+    wy[2] = mul_word<0> (ys23, fp.pc[0]) + 0x00800000;
+    wy[3] = mul_word<1> (ys23, fp.pc[0]) + 0x00800000;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      pgu[j] = mul_word<0> (cs[j], fp.pc[3]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      prv[j] = mul_word<1> (cs[j], fp.pc[1]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      g0[j] = add_hiwords (wy[j], pgu[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      pgv[j] = mul_word<1> (cs[j], fp.pc[4]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      add_hiwords_into<PR & 1> (q[j][PR >> 1], wy[j], prv[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      pbu[j] = mul_word<0> (cs[j], fp.pc[2]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      add_hiword_into<PG & 1> (q[j][PG >> 1], g0[j], pgv[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      add_hiwords_into<PB & 1> (q[j][PB >> 1], wy[j], pbu[j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      o[j] = sat_pk_u8 (q[j][0]);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      sat_pk_u8_hi (o[j], q[j][1]);
+  }
+  if (store)
+    store16_stream (d, o[0], o[1], o[2], o[3]);
+}
+
+// four pixels of one line: luma word yw (bytes y0..y3), final packed chroma c[0..3] ({c0, c1} u16 lanes)
+template <int ABL>
+GSTAMD_HD void fast_emit4_w (const FastParams &fp, uint8_t *__restrict__ d, uint32_t yw, const uint32_t *c, uint32_t &rg, uint32_t &ba)
+{
+  uint32_t o[4];
+  if (ABL == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      o[j] = yw ^ c[j];
+  } else {
+    const uint32_t yx = yw ^ 0x80808080u;
+    const uint32_t ys01 = bperm (yx, yx, 0x01010000u), ys23 = bperm (yx, yx, 0x03030202u);
+    uint32_t cs[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t cx = c[j] ^ 0x00800080u;
+      cs[j] = bperm (cx, cx, fp.csel_w);
+    }
+    o[0] = fast_pixel_w<0> (fp, ys01, cs[0], rg, ba);
+    o[1] = fast_pixel_w<1> (fp, ys01, cs[1], rg, ba);
+    o[2] = fast_pixel_w<0> (fp, ys23, cs[2], rg, ba);
+    o[3] = fast_pixel_w<1> (fp, ys23, cs[3], rg, ba);
+  }
+  store16_stream (d, o[0], o[1], o[2], o[3]);
 }
 
 // horizontally filtered chroma for the NPX pixels x0 .. x0+NPX-1 of one chroma row: out[i] packed
@@ -358,22 +612,20 @@ template <int NPX, int ABL>
 GSTAMD_HD void fast_emit_line (const FastParams &fp, uint8_t *__restrict__ dst, int dstride, int line, int x0, const uint32_t *yy,
     const uint32_t *ca, const uint32_t *cb, bool blend, int role, uint32_t usel, uint32_t vsel)
 {
-  static const uint32_t ysel[4] = {0x0c00000cu, 0x0c01010cu, 0x0c02020cu, 0x0c03030cu};
-  uint32_t o[NPX];
-#pragma unroll
-  for (int i = 0; i < NPX; i++) {
-    uint32_t c = ca[i];
-    if (blend)
-      c = role == 0 ? pk_shr<2> (3u * ca[i] + cb[i] + 0x00020002u) : pk_shr<2> (ca[i] + 3u * cb[i] + 0x00020002u);
-    if (ABL == 1)
-      o[i] = yy[i >> 2] ^ c;
-    else
-      o[i] = fast_pixel (fp, yy[i >> 2] ^ 0x80808080u, ysel[i & 3], c ^ 0x00800080u, usel, vsel);
-  }
+  uint32_t rg = 0, ba = 0x00ff0000u;
   uint8_t *d = dst + (size_t) line * dstride + 4 * (size_t) x0;
 #pragma unroll
-  for (int q = 0; q < NPX / 4; q++)
-    store16_stream (d + 16 * q, o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+  for (int q = 0; q < NPX / 4; q++) {
+    uint32_t c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = 4 * q + j;
+      c[j] = ca[i];
+      if (blend)
+        c[j] = role == 0 ? pk_shr<2> (3u * ca[i] + cb[i] + 0x00020002u) : pk_shr<2> (ca[i] + 3u * cb[i] + 0x00020002u);
+    }
+    fast_emit4_w<ABL> (fp, d + 16 * q, yy[q], c, rg, ba);
+  }
 }
 
 // pairs [p_begin, p_end) of the column x0 .. x0+NPX-1; pair p = lines (2p-1, 2p), chroma rows (p-1, p)
@@ -434,6 +686,199 @@ GSTAMD_HD void fast_strip (const FastParams &fp, const Planes &pl, uint8_t *__re
         cprev[i] = ccur[i];
     }
   }
+}
+
+// ---- wide variant: one wave = a 1024-pixel run of ONE line pair, staged through LDS ---------------------
+// Every source row segment is fetched with ONE 16-byte load per lane (1 KB contiguous per wave instruction), parked in
+// LDS and read back in the 4-pixels-per-lane layout of fast_emit_line, so each store instruction still writes 1 KB
+// contiguous and four of them cover a 4 KB run of the destination row.  Measured on MI355X with the memory skeleton
+// (scripts/membench3.hip): 7.9 us per 4K frame against 8.5 us for the strip shape and 7.6 us for a perfectly linear
+// kernel moving the same bytes.  Arithmetic and results are those of fast_strip.
+#define GSTAMD_WIDE_PX 1024
+struct WideLds {
+  uint32_t y[2][256];
+  uint32_t c[2][4 + 256 + 4];     // [3] = dword left of the run, [4 ..] = the run, then the dword right of it
+};
+
+#ifdef __HIPCC__
+typedef unsigned int gstamd_u32x4 __attribute__ ((ext_vector_type (4)));
+#endif
+
+// 16 bytes of a row at byte offset xl (row + xl 16-byte aligned when `vec`), limited to the first `nd` dwords
+template <bool STREAM>
+GSTAMD_HD void wide_load16 (const uint8_t *__restrict__ p, int nd, bool vec, uint32_t *out)
+{
+  if (nd >= 4 && vec) {
+#ifdef __HIPCC__
+    const gstamd_u32x4 v = STREAM ? __builtin_nontemporal_load ((const gstamd_u32x4 *) p) : *(const gstamd_u32x4 *) p;
+    out[0] = v.x;
+    out[1] = v.y;
+    out[2] = v.z;
+    out[3] = v.w;
+#else
+    const uint4 v = *(const uint4 *) p;
+    out[0] = v.x;
+    out[1] = v.y;
+    out[2] = v.z;
+    out[3] = v.w;
+#endif
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      out[j] = j < nd ? *(const uint32_t *) (p + 4 * j) : 0u;
+  }
+}
+
+GSTAMD_HD void wide_put16 (uint32_t *l, const uint32_t *v)
+{
+  *(uint4 *) l = gstamd_make_uint4 (v[0], v[1], v[2], v[3]);
+}
+
+// One lane's share of the rows a pair needs, held in registers between the fetch (global loads, issued one pair ahead)
+// and the commit (LDS writes, after the previous pair has been emitted).
+struct WideRegs {
+  uint32_t y0[4], y1[4], c[4];
+  uint32_t cn, cp;                 // chroma dwords right / left of the run (only some lanes, see wide_fetch_chroma)
+};
+
+// chroma row `crow` of the run starting at xw: this lane's 16 bytes plus, on the lanes that own them, the pad dwords
+template <int CH>
+GSTAMD_HD void wide_fetch_chroma (const FastParams &fp, const Planes &pl, int xw, int crow, int lane, bool vec, WideRegs &r)
+{
+  const int w = fp.width, xl = xw + 16 * lane;
+  if (xl >= w)
+    return;
+  const int nd = (w - xl) >> 2;            // dwords of this lane that lie inside the row (w % 4 == 0)
+  const uint8_t *row = pl.p[1] + (size_t) crow * pl.stride[1];
+  wide_load16<false> (row + xl, nd, vec, r.c);
+  if (CH != CHROMA_H_NONE && (lane == 63 || nd <= 4)) {
+    // the sample right of this lane's last one: the next dword of the row, or the row's last sample again
+    const int xn = xl + 4 * (nd < 4 ? nd : 4);
+    r.cn = xn < w ? *(const uint32_t *) (row + xn) : (uint32_t) * (const uint16_t *) (row + w - 2);
+  }
+  if (CH == CHROMA_H_H2 && lane == 0)         // the sample left of the run (high half of the dword), clamped at the row start
+    r.cp = xw > 0 ? *(const uint32_t *) (row + xw - 4) : 0u;
+}
+
+template <int CH>
+GSTAMD_HD void wide_commit_chroma (const FastParams &fp, int xw, int lane, const WideRegs &r, uint32_t *crow_lds)
+{
+  const int w = fp.width, xl = xw + 16 * lane;
+  if (xl >= w)
+    return;
+  const int nd = (w - xl) >> 2;
+  wide_put16 (&crow_lds[4 + 4 * lane], r.c);
+  if (CH != CHROMA_H_NONE && (lane == 63 || nd <= 4))
+    crow_lds[4 + 4 * lane + (nd < 4 ? nd : 4)] = r.cn;
+  if (CH == CHROMA_H_H2 && lane == 0)
+    crow_lds[3] = xw > 0 ? r.cp : r.c[0] << 16;
+}
+
+// rows of pair p (lines 2p-1, 2p clamped into the frame; chroma row p clamped): the pair's upper chroma row p-1 is
+// already in LDS (previous pair of the strip, or the strip prologue)
+template <int CH>
+GSTAMD_HD void wide_fetch (const FastParams &fp, const Planes &pl, int xw, int p, int lane, bool vec, WideRegs &r)
+{
+  const int w = fp.width, h = fp.height, n_crows = (h + 1) >> 1;
+  const int xl = xw + 16 * lane;
+  if (xl >= w)
+    return;
+  const int nd = (w - xl) >> 2;
+  const int l0 = 2 * p - 1, l1 = 2 * p;
+  const int r0 = l0 >= 0 ? l0 : 0, r1 = l1 < h ? l1 : h - 1;
+  wide_load16<true> (pl.p[0] + (size_t) r0 * pl.stride[0] + xl, nd, vec, r.y0);
+  wide_load16<true> (pl.p[0] + (size_t) r1 * pl.stride[0] + xl, nd, vec, r.y1);
+  wide_fetch_chroma<CH> (fp, pl, xw, p < n_crows ? p : n_crows - 1, lane, vec, r);
+}
+
+template <int CH>
+GSTAMD_HD void wide_commit (const FastParams &fp, int xw, int lane, const WideRegs &r, WideLds *lds, int cslot)
+{
+  if (xw + 16 * lane >= fp.width)
+    return;
+  wide_put16 (&lds->y[0][4 * lane], r.y0);
+  wide_put16 (&lds->y[1][4 * lane], r.y1);
+  wide_commit_chroma<CH> (fp, xw, lane, r, lds->c[cslot]);
+}
+
+// Horizontal chroma filter of 4 pixels without edge cases: wide_commit_chroma stores the row's last sample again right of the
+// row end and its first sample left of the start, and (a + a + 1) >> 1 == (3a + a + 2) >> 2 == a, so the formulas of
+// video_chroma_up_h2_cs_u8 / up_h2_u8 (video-chroma.c:687, 277) reproduce their own edge rules.
+// raw = 2 samples {c0 c1 c0 c1} under the span, nxt / prv = dwords right / left of it.
+template <int CH>
+GSTAMD_HD void wide_chroma_filter (uint32_t raw, uint32_t nxt, uint32_t prv, uint32_t *out)
+{
+  const uint32_t s1 = bperm (raw, raw, 0x0c010c00u), s2 = bperm (raw, raw, 0x0c030c02u);
+  if (CH == CHROMA_H_NONE) {
+    out[0] = out[1] = s1;
+    out[2] = out[3] = s2;
+    return;
+  }
+  const uint32_t s3 = bperm (nxt, nxt, 0x0c010c00u);
+  if (CH == CHROMA_H_H2_CS) {
+    out[0] = s1;
+    out[1] = pk_shr<1> (s1 + s2 + 0x00010001u);
+    out[2] = s2;
+    out[3] = pk_shr<1> (s2 + s3 + 0x00010001u);
+  } else {
+    const uint32_t s0 = bperm (prv, prv, 0x0c030c02u);
+    out[0] = pk_shr<2> (s0 + 3u * s1 + 0x00020002u);
+    out[1] = pk_shr<2> (3u * s1 + s2 + 0x00020002u);
+    out[2] = pk_shr<2> (s1 + 3u * s2 + 0x00020002u);
+    out[3] = pk_shr<2> (3u * s2 + s3 + 0x00020002u);
+  }
+}
+
+// phase 2, lane `lane`: four 4-pixel groups (x = xw + 256 g + 4 lane) of both lines, from LDS.  The first and the last
+// pair of a frame have one line only; the same chroma row is then staged twice (clamped row index), and (3a + a + 2) >> 2 == a makes
+// the blend the identity, so no case distinction is needed in the arithmetic.
+template <int CH, int L, int ABL>
+GSTAMD_HD void wide_emit (const FastParams &fp, uint8_t *__restrict__ dst, int dstride, int xw, int p, int lane, const WideLds *lds, int aslot)
+{
+  const int w = fp.width, h = fp.height;
+  const int l0 = 2 * p - 1, l1 = 2 * p;
+  const bool have0 = l0 >= 0, have1 = l1 < h;
+  uint8_t *d0 = dst + (size_t) (have0 ? l0 : l1) * dstride + 4 * (size_t) (xw + 4 * lane);
+  uint8_t *d1 = dst + (size_t) (have1 ? l1 : l0) * dstride + 4 * (size_t) (xw + 4 * lane);
+  uint32_t q[4][2];
+  layout_init<L> (q);
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int x0 = xw + 256 * g + 4 * lane, idx = 64 * g + lane;
+    uint32_t ca[4], cb[4], c0[4], c1[4];
+    // lanes right of the row end compute on whatever LDS holds (in bounds) and skip the store
+    const uint32_t *ra = lds->c[aslot], *rb = lds->c[aslot ^ 1];
+    wide_chroma_filter<CH> (ra[4 + idx], ra[5 + idx], ra[3 + idx], ca);
+    wide_chroma_filter<CH> (rb[4 + idx], rb[5 + idx], rb[3 + idx], cb);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      blend_rows_hi (ca[j], cb[j], c0[j], c1[j]);
+    // a frame's first / last pair has one line only: the other one is computed (on in-bounds data) and not stored
+    fast_emit4_l<L, ABL> (fp, d0 + 1024 * g, have0 && x0 < w, lds->y[0][idx], c0, q);
+    fast_emit4_l<L, ABL> (fp, d1 + 1024 * g, have1 && x0 < w, lds->y[1][idx], c1, q);
+  }
+}
+
+// Block order of the wide kernel (1-D grid).  One wave = one strip: a 1024-px column x K consecutive line pairs, walked
+// pair by pair with the next pair's rows in flight.  Hardware places block b on XCD b % 8, each XCD with its own L2.
+// Units of (column, band of GSTAMD_WIDE_BAND consecutive strips) are dealt round-robin to the XCDs and every XCD walks
+// its unit strip by strip: the chroma row two neighbouring strips share is re-read from that XCD's L2, not from HBM,
+// while all eight XCDs still sweep the same region of the frame together.  Strips of the batch's frames are numbered
+// consecutively (S = frame * strips_per_frame + strip).  Returns false for padding blocks.
+#define GSTAMD_WIDE_BAND 32
+GSTAMD_HD bool wide_block_map (int block, int nxb, int total_strips, int *x, int *S)
+{
+  const int xcd = block & 7, i = block >> 3;
+  const int unit = (i / GSTAMD_WIDE_BAND) * 8 + xcd, sb = i % GSTAMD_WIDE_BAND;
+  *x = unit % nxb;
+  *S = (unit / nxb) * GSTAMD_WIDE_BAND + sb;
+  return *S < total_strips;
+}
+
+inline int wide_grid_blocks (int nxb, int total_strips)
+{
+  const int units = nxb * ((total_strips + GSTAMD_WIDE_BAND - 1) / GSTAMD_WIDE_BAND);
+  return (units + 7) / 8 * 8 * GSTAMD_WIDE_BAND;
 }
 
 // the shipped shape (8 pixels per lane); kept as the emulator's and the launcher's default entry

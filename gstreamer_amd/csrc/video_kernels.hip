@@ -26,7 +26,7 @@ __global__ __launch_bounds__ (256) void k_convert (FrontParams f, Planes pl, con
 }
 
 // up to 16 independent frames of one format per launch (blockIdx.z = frame): amortises launch ramp/tail
-#define GSTAMD_MAX_BATCH 16
+#define GSTAMD_MAX_BATCH 32
 struct FrameBatch {
   const uint8_t *y[GSTAMD_MAX_BATCH];
   const uint8_t *uv[GSTAMD_MAX_BATCH];
@@ -273,6 +273,78 @@ static void launch_strip_variant (const FastParams &fp, const FrameBatch &batch,
   hipLaunchKernelGGL ((k_convert_strip<CH, NPX, ABL>), grid, block, 0, stream, fp, batch, pairs, K);
 }
 
+// wide variant (video_fast.h): 1-D grid of one-wave workgroups, XCD-aware block order, rows staged through LDS
+template <int CH, int L, int ABL>
+__global__ __launch_bounds__ (64) void k_convert_wide (FastParams fp, FrameBatch batch, int nxb, int pairs, int K, int strips, int total_strips,
+    int vec)
+{
+  __shared__ WideLds lds;
+  int xb, S;
+  if (!wide_block_map (blockIdx.x, nxb, total_strips, &xb, &S))
+    return;
+  const int z = S / strips, p0 = (S - z * strips) * K, p1 = p0 + K < pairs ? p0 + K : pairs;
+  const Planes pl = batch_planes (batch, z);
+  const int xw = xb * GSTAMD_WIDE_PX, lane = threadIdx.x;
+  const bool v = vec != 0;
+  WideRegs r;
+  wide_fetch_chroma<CH> (fp, pl, xw, p0 > 0 ? p0 - 1 : 0, lane, v, r);
+  wide_commit_chroma<CH> (fp, xw, lane, r, lds.c[0]);
+  wide_fetch<CH> (fp, pl, xw, p0, lane, v, r);
+  for (int p = p0; p < p1; p++) {
+    const int k = p - p0;
+    wide_commit<CH> (fp, xw, lane, r, &lds, (k + 1) & 1);
+    __syncthreads ();                     /* one wave per workgroup: orders the LDS writes before the reads */
+    if (p + 1 < p1)
+      wide_fetch<CH> (fp, pl, xw, p + 1, lane, v, r);      /* in flight while this pair is converted */
+    wide_emit<CH, L, ABL> (fp, batch.dst[z], batch.dstride, xw, p, lane, &lds, k & 1);
+    __syncthreads ();
+  }
+}
+
+static bool wide_vec_ok (const FrameBatch &batch, int n)
+{
+  bool ok = (batch.ystride % 16) == 0 && (batch.uvstride % 16) == 0;
+  for (int i = 0; i < n; i++)
+    ok = ok && aligned (batch.y[i], 16) && aligned (batch.uv[i], 16);
+  return ok;
+}
+
+// destination byte order -> layout template argument (the four orders of the eight 4-byte RGB formats)
+static int wide_layout (const FastParams &fp)
+{
+  return GSTAMD_LAYOUT (fp.pack_pos[1], fp.pack_pos[2], fp.pack_pos[3]);
+}
+
+static int wide_pairs_per_wave ()
+{
+  static int k = 0;
+  if (k == 0) {
+    const char *e = getenv ("GSTAMD_WIDE_K");      /* tuning knob for profiling sessions */
+    k = e && atoi (e) > 0 ? atoi (e) : 2;
+  }
+  return k;
+}
+
+template <int CH, int ABL>
+static bool launch_wide_variant (const FastParams &fp, const FrameBatch &batch, int n, hipStream_t stream)
+{
+  const int pairs = fp.height / 2 + 1, nxb = (fp.width + GSTAMD_WIDE_PX - 1) / GSTAMD_WIDE_PX;
+  const int K = wide_pairs_per_wave (), strips = (pairs + K - 1) / K;
+  const int blocks = wide_grid_blocks (nxb, strips * n);
+  const int vec = wide_vec_ok (batch, n) ? 1 : 0;
+#define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \
+    hipLaunchKernelGGL ((k_convert_wide<CH, GSTAMD_LAYOUT (pr, pg, pb), ABL>), dim3 (blocks), dim3 (64), 0, stream, fp, batch, nxb, pairs, K, strips, strips * n, vec); \
+    return true;
+  switch (wide_layout (fp)) {
+    W (2, 1, 0)      /* BGRA, BGRx */
+    W (0, 1, 2)      /* RGBA, RGBx */
+    W (1, 2, 3)      /* ARGB, xRGB */
+    W (3, 2, 1)      /* ABGR, xBGR */
+  }
+#undef W
+  return false;
+}
+
 template <int CH, int NPX, int ABL, int GROUPS>
 static void launch_pair_variant (const FastParams &fp, const FrameBatch &batch, int n, int bx, hipStream_t stream)
 {
@@ -295,6 +367,15 @@ static bool launch_pair_experiment (const FastParams &fp, const FrameBatch &batc
   if (cfg[0] == 0)
     return false;
   const int npx = cfg[0], abl = cfg[1], groups = cfg[2], bx = cfg[3];
+  if (npx == 1024) {                      /* wide variant */
+    if (abl)
+      launch_wide_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, stream);
+    else
+      launch_wide_variant<CHROMA_H_H2_CS, 0> (fp, batch, n, stream);
+    return true;
+  }
+  if (npx == 4096)                        /* force the strip shape */
+    return false;
   if (groups >= 100) {                    /* strip variant: groups = 100 + K */
     const int K = groups - 100;
 #define S(N, A) if (npx == N && abl == A) { launch_strip_variant<CHROMA_H_H2_CS, N, A> (fp, batch, n, bx, K, stream, cfg[4]); return true; }
@@ -332,17 +413,35 @@ hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames
     batch.dstride = dstride;
     if (chroma_h == CHROMA_H_H2_CS && launch_pair_experiment (fp, batch, n, stream))
       continue;
-    /* shipped configuration (MI355X sweeps, profiles/r01_c2_variants*.txt): 4-pixel columns, 3 line pairs per lane
-     * with the next pair's loads in flight during the current pair's math, one wave per workgroup */
+    /* shipped configuration (MI355X sweeps, profiles/r01_c2_variants*.txt, scripts/membench3.hip): images at least
+     * half a wave-run wide take the LDS-staged wide kernel, narrower ones the strip kernel (4-pixel columns, 3 line
+     * pairs per lane, one wave per workgroup) */
+    static int force_strip = -1;
+    if (force_strip < 0) {
+      const char *e = getenv ("GSTAMD_FAST_VARIANT");
+      force_strip = e && atoi (e) == 4096;
+    }
+    const int lay = wide_layout (fp);
+    const bool wide = fp.width >= GSTAMD_WIDE_PX / 2 && !force_strip && (lay == GSTAMD_LAYOUT (2, 1, 0) || lay == GSTAMD_LAYOUT (0, 1, 2) ||
+        lay == GSTAMD_LAYOUT (1, 2, 3) || lay == GSTAMD_LAYOUT (3, 2, 1));
     switch (chroma_h) {
       case CHROMA_H_H2_CS:
-        launch_strip_variant<CHROMA_H_H2_CS, 4, 0> (fp, batch, n, 64, 3, stream, 1);
+        if (wide)
+          launch_wide_variant<CHROMA_H_H2_CS, 0> (fp, batch, n, stream);
+        else
+          launch_strip_variant<CHROMA_H_H2_CS, 4, 0> (fp, batch, n, 64, 3, stream, 1);
         break;
       case CHROMA_H_H2:
-        launch_strip_variant<CHROMA_H_H2, 4, 0> (fp, batch, n, 64, 3, stream, 1);
+        if (wide)
+          launch_wide_variant<CHROMA_H_H2, 0> (fp, batch, n, stream);
+        else
+          launch_strip_variant<CHROMA_H_H2, 4, 0> (fp, batch, n, 64, 3, stream, 1);
         break;
       default:
-        launch_strip_variant<CHROMA_H_NONE, 4, 0> (fp, batch, n, 64, 3, stream, 1);
+        if (wide)
+          launch_wide_variant<CHROMA_H_NONE, 0> (fp, batch, n, stream);
+        else
+          launch_strip_variant<CHROMA_H_NONE, 4, 0> (fp, batch, n, 64, 3, stream, 1);
         break;
     }
   }

@@ -67,6 +67,12 @@ VIDEO_CASES = [
     ("nv12_bgra_324x242_w4mod8", "NV12", 324, 242, "BGRA", 324, 242, {}, None, "mpeg2", "random"),
     ("nv12_rgba_1284x721_odd_h", "NV12", 1284, 721, "RGBA", 1284, 721, {}, None, None, "random"),
     ("nv21_abgr_130x70", "NV21", 130, 70, "ABGR", 130, 70, {}, None, None, "random"),
+    # wide-kernel tile edges: row ends exactly at a 1024-px run / one dword past it / inside a lane
+    ("nv12_bgra_1024x34_jpeg", "NV12", 1024, 34, "BGRA", 1024, 34, {}, None, "jpeg", "random"),
+    ("nv21_rgba_2048x18_mpeg2", "NV21", 2048, 18, "RGBA", 2048, 18, {}, None, "mpeg2", "random"),
+    ("nv12_bgra_1028x11_jpeg", "NV12", 1028, 11, "BGRA", 1028, 11, {}, None, "jpeg", "random"),
+    ("nv12_argb_1036x6_mpeg2", "NV12", 1036, 6, "ARGB", 1036, 6, {}, None, "mpeg2", "random"),
+    ("nv12_bgra_516x4_none", "NV12", 516, 4, "BGRA", 516, 4, {}, None, "none", "random"),
     ("nv12_argb_640x360", "NV12", 640, 360, "ARGB", 640, 360, {}, None, None, "random"),
     ("nv12_xrgb_640x360", "NV12", 640, 360, "xRGB", 640, 360, {}, None, None, "random"),
     ("nv12_bgrx_alpha_set", "NV12", 320, 240, "BGRA", 320, 240, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),

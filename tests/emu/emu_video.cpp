@@ -34,11 +34,7 @@ static FastParams emu_fast_params (const VideoPlan &p)      /* make_fast_params 
   FastParams fp;
   fp.width = p.front.width;
   fp.height = p.front.height;
-  for (int i = 0; i < 5; i++)
-    fp.p8[i] = p.matrix.p[i] * 256;
-  fp.pack_sel = (0x0du << (8 * p.post.pack_pos[0])) | (0x00u << (8 * p.post.pack_pos[1])) |
-      (0x01u << (8 * p.post.pack_pos[2])) | (0x04u << (8 * p.post.pack_pos[3]));
-  fp.u_first = p.front.u_plane;
+  fast_params_finish (fp, p.matrix.p, p.post.pack_pos, p.front.u_plane);
   return fp;
 }
 
@@ -169,7 +165,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   const int dstride = out->stride[0];
   if (p.passes.empty () && p.fast_pair && vec_ok) {
     const FastParams fp = emu_fast_params (p);
-    if (vec_ok >= 2) {                    /* strip variant with K = vec_ok pairs per lane, 4- and 8-pixel columns */
+    if (vec_ok >= 2 && vec_ok < 200) {    /* strip variant with K = vec_ok pairs per lane, 4- and 8-pixel columns */
       const int pairs = fp.height / 2 + 1, K = vec_ok;
       for (int p0 = 0; p0 < pairs; p0 += K)
         for (int x0 = 0; x0 + 8 <= fp.width; x0 += 8) {
@@ -192,7 +188,47 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         }
       return GSTAMD_OK;
     }
-    {                                     /* shipped configuration: 4-pixel columns, K = 3 */
+    if (fp.width >= GSTAMD_WIDE_PX / 2) { /* shipped configuration, wide images: the LDS-staged wide kernel, wave by wave */
+      const int pairs = fp.height / 2 + 1, nxb = (fp.width + GSTAMD_WIDE_PX - 1) / GSTAMD_WIDE_PX;
+      const int K = vec_ok >= 200 ? vec_ok - 200 : 2, strips = (pairs + K - 1) / K;
+      const int blocks = wide_grid_blocks (nxb, strips);
+      const bool vec = (((uintptr_t) pl.p[0] | (uintptr_t) pl.p[1]) % 16) == 0 && pl.stride[0] % 16 == 0 && pl.stride[1] % 16 == 0;
+      const int lay = GSTAMD_LAYOUT (fp.pack_pos[1], fp.pack_pos[2], fp.pack_pos[3]);
+      static WideLds lds;
+      static WideRegs regs[64];
+#define EMIT_L(CH, pr, pg, pb) if (lay == GSTAMD_LAYOUT (pr, pg, pb)) wide_emit<CH, GSTAMD_LAYOUT (pr, pg, pb), 0> (fp, d0, dstride, xw, pp, lane, &lds, k & 1);
+#define WAVE(CH) \
+      for (int b = 0; b < blocks; b++) { \
+        int xb, S; \
+        if (!wide_block_map (b, nxb, strips, &xb, &S)) \
+          continue; \
+        const int xw = xb * GSTAMD_WIDE_PX, p0 = S * K, p1 = p0 + K < pairs ? p0 + K : pairs; \
+        for (int lane = 0; lane < 64; lane++) { \
+          wide_fetch_chroma<CH> (fp, pl, xw, p0 > 0 ? p0 - 1 : 0, lane, vec, regs[lane]); \
+          wide_commit_chroma<CH> (fp, xw, lane, regs[lane], lds.c[0]); \
+          wide_fetch<CH> (fp, pl, xw, p0, lane, vec, regs[lane]); \
+        } \
+        for (int pp = p0; pp < p1; pp++) { \
+          const int k = pp - p0; \
+          for (int lane = 0; lane < 64; lane++) \
+            wide_commit<CH> (fp, xw, lane, regs[lane], &lds, (k + 1) & 1); \
+          for (int lane = 0; lane < 64; lane++) { \
+            if (pp + 1 < p1) \
+              wide_fetch<CH> (fp, pl, xw, pp + 1, lane, vec, regs[lane]); \
+            EMIT_L (CH, 2, 1, 0) EMIT_L (CH, 0, 1, 2) EMIT_L (CH, 1, 2, 3) EMIT_L (CH, 3, 2, 1) \
+          } \
+        } \
+      }
+      switch (p.front.chroma_h) {
+        case CHROMA_H_H2_CS: WAVE (CHROMA_H_H2_CS) break;
+        case CHROMA_H_H2: WAVE (CHROMA_H_H2) break;
+        default: WAVE (CHROMA_H_NONE) break;
+      }
+#undef WAVE
+#undef EMIT_L
+      return GSTAMD_OK;
+    }
+    {                                     /* narrow images: 4-pixel columns, K = 3 */
       const int pairs = fp.height / 2 + 1;
       for (int p0 = 0; p0 < pairs; p0 += 3)
         for (int x0 = 0; x0 + 4 <= fp.width; x0 += 4) {

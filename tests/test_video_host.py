@@ -121,6 +121,20 @@ def test_kernel_bodies_on_host_match_golden(native_lib, emu_lib, idx_case):
     assert cases.sha(dst) == GOLDEN[name]["sha256"], (name, list(dst[:16]), GOLDEN[name]["head"][:16])
 
 
+WIDE = [c for c in SMALL if c[1][1] in ("NV12", "NV21") and c[1][2] >= 512 and (c[1][2], c[1][3]) == (c[1][5], c[1][6])
+        and c[1][4] not in ("AYUV",)]
+
+
+@pytest.mark.parametrize("k", [1, 3, 5])
+@pytest.mark.parametrize("idx_case", WIDE, ids=lambda c: c[1][0])
+def test_wide_kernel_body_any_pairs_per_wave(native_lib, emu_lib, idx_case, k):
+    """The wide kernel's strip length (line pairs per wave) is a tuning knob: results must not depend on it."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src, vec=200 + k)
+    assert cases.sha(dst) == GOLDEN[name]["sha256"], name
+
+
 @pytest.mark.parametrize("idx_case", SMALL[::4], ids=lambda c: c[1][0])
 def test_golden_vectors_are_the_references_output(ref, idx_case):
     """Pins the committed golden hashes to the reference implementation itself (oracle/_ref)."""

@@ -1,19 +1,22 @@
-// video_fast.h - the speed-of-light variant of the unscaled NV12/NV21 -> 4-byte RGB conversion
-// (BASELINE config 2).  Same arithmetic as convert_body in video_device.h, restructured so the
-// kernel is bounded by HBM and not by VALU issue:
+// video_fast.h - the speed-of-light variants of the unscaled NV12/NV21 -> 4-byte RGB conversion
+// (BASELINE config 2).  Same integers as convert_body in video_device.h at every step, restructured so the
+// kernels are bounded by HBM and not by VALU issue (a wave64 VALU instruction occupies its SIMD for 4 cycles:
+// at 6 TB/s every instruction per pixel costs about 0.2 us per 4K frame):
 //
-//   * one lane converts an 8-pixel span of a chroma LINE PAIR (2p-1, 2p) - the pairing the reference's
+//   * a lane converts 4-pixel spans of a chroma LINE PAIR (2p-1, 2p) - the pairing the reference's
 //     do_upsample_lines produces (video-converter.c:2991-3021) - so each chroma row is loaded and
 //     horizontally filtered once for the two luma lines that use it;
-//   * chroma lives in packed 16-bit lanes {U, V} of one VGPR; the 3:1 blends are single multiply-adds
-//     over both lanes (no carries: values <= 1022);
-//   * mulhsw (splatbw (x - 128), p) of video_orc_convert_AYUV_ARGB is ONE v_mul_hi_i32_i24:
-//     splatbw(b) << 8 == (b ^ 0x80) * 0x10100 is a sign-correct 24-bit operand, p << 8 the other;
-//     their 48-bit product >> 32 is (splat * p) >> 16;
-//   * bytes move with v_perm_b32; clamp (x, -128, 127) + 128 == med3 (x + 128, 0, 255).
+//   * chroma lives in packed 16-bit lanes {U, V} of one VGPR; the vertical 3:1 blends of both lines are four
+//     v_pk_mad_u16 with the result left in the high byte of each lane (no shift, the "- 128" folded into the constant);
+//   * mulhsw (splatbw (x - 128), p) of video_orc_convert_AYUV_ARGB is the high word of the exact product
+//     splat * p: v_mul_i32_i24 on a sign-extended WORD operand (SDWA), the adds take WORD_1 of the products and
+//     write the halves of two registers, v_sat_pk_u8_i16 saturates two channels at once and writes the pixel's
+//     bytes in place: 13 VALU instructions per pixel for matrix + saturate + pack;
+//   * edge rules (first / last chroma sample, first / last line) come out of the same formulas on clamped
+//     indices: (a + a + 1) >> 1 == (3a + a + 2) >> 2 == a.
 //
-// The 16-bit wrap of ORC's addw cannot trigger for the matrices this kernel accepts; the planner
-// proves that (fast_matrix_ok) before selecting it, otherwise convert_body runs.
+// The 16-bit wrap of ORC's addw cannot trigger for the matrices these kernels accept; the planner
+// proves that (fast_matrix_ok) before selecting them, otherwise convert_body runs.
 #pragma once
 #include "video_device.h"
 
@@ -24,11 +27,7 @@ struct FastParams {
   int p8[5];            // p1..p5 << 8
   uint32_t pack_sel;    // v_perm selector: dest byte pos[A] <- 0xff, pos[R] <- lo.0, pos[G] <- lo.1, pos[B] <- hi.0
   int u_first;          // 1: NV12 (U,V), 0: NV21 (V,U)
-  // word form (fast_pixel_w): raw p1..p5, selector of the final perm over {hi = [B, 0xff], lo = [G, R]} and the
-  // selector that splats packed chroma {c0, c1} to words [U U | V V]
-  int pc[5];
-  uint32_t pack_sel_w;
-  uint32_t csel_w;
+  int pc[5];            // raw p1..p5 (word form, fast_emit4_l)
   int pack_pos[4];      // destination byte of A, R, G, B
 };
 
@@ -39,11 +38,9 @@ inline void fast_params_finish (FastParams &fp, const int p[5], const int pack_p
     fp.pc[i] = p[i];
   }
   fp.pack_sel = (0x0du << (8 * pack_pos[0])) | (0x00u << (8 * pack_pos[1])) | (0x01u << (8 * pack_pos[2])) | (0x04u << (8 * pack_pos[3]));
-  fp.pack_sel_w = (0x05u << (8 * pack_pos[0])) | (0x01u << (8 * pack_pos[1])) | (0x00u << (8 * pack_pos[2])) | (0x04u << (8 * pack_pos[3]));
   fp.u_first = u_first;
   for (int i = 0; i < 4; i++)
     fp.pack_pos[i] = pack_pos[i];
-  fp.csel_w = u_first ? 0x02020000u : 0x00000202u;
 }
 
 #ifdef __HIPCC__
@@ -219,20 +216,7 @@ GSTAMD_HD void add_hiwords_into (uint32_t &dst, int pa, int pb)   // word W of d
 #endif
 }
 
-// ys: words [t(y_a) | t(y_b)] of two pixels, t = splatbw (y - 128); YW picks the pixel.  cs: words [t(U) | t(V)].
-// rg / ba are scratch registers threaded through consecutive pixels (ba's high word stays 255 = opaque alpha).
-// The "+ 128" of the final signed-saturate rides in the high word of the luma product.
-template <int YW>
-GSTAMD_HD uint32_t fast_pixel_w (const FastParams &fp, uint32_t ys, uint32_t cs, uint32_t &rg, uint32_t &ba)
-{
-  const int wy = mul_word<YW> (ys, fp.pc[0]) + 0x00800000;                              // high word: ((Y * p1) >> 16) + 128
-  add_hiwords_into<1> (rg, wy, mul_word<1> (cs, fp.pc[1]));                             // R = wy + ((V * p2) >> 16)
-  add_hiword_into<0> (rg, add_hiwords (wy, mul_word<0> (cs, fp.pc[3])), mul_word<1> (cs, fp.pc[4]));   // G
-  add_hiwords_into<0> (ba, wy, mul_word<0> (cs, fp.pc[2]));                             // B
-  return bperm (sat_pk_u8 (ba), sat_pk_u8 (rg), fp.pack_sel_w);
-}
-
-// ---- layout-specialised form (wide kernel): no final byte shuffle, no chroma XOR ---------------------------
+// ---- layout-specialised pixels: no final byte shuffle, no chroma XOR -------------------------------------------
 // PR / PG / PB = destination byte of R, G, B (alpha takes the fourth).  Bytes 0, 1 are the saturated i16 lanes of
 // q[0], bytes 2, 3 those of q[1]; every add writes its sum straight into the lane of its channel, the second
 // v_sat_pk writes the upper half of the pixel (SDWA dst_sel).  q[][] lives across pixels: the alpha lane is set once.
@@ -345,352 +329,131 @@ GSTAMD_HD void fast_emit4_l (const FastParams &fp, uint8_t *__restrict__ d, bool
     store16_stream (d, o[0], o[1], o[2], o[3]);
 }
 
-// four pixels of one line: luma word yw (bytes y0..y3), final packed chroma c[0..3] ({c0, c1} u16 lanes)
-template <int ABL>
-GSTAMD_HD void fast_emit4_w (const FastParams &fp, uint8_t *__restrict__ d, uint32_t yw, const uint32_t *c, uint32_t &rg, uint32_t &ba)
+// Horizontal chroma filter of 4 pixels without edge cases.  raw = the 2 samples {c0 c1 c0 c1} under the span, nxt = the
+// dword right of it (its first sample is used), prv_hi = the dword left of it (its second sample is used).  Callers
+// pass the row's last sample again right of the row end and its first sample left of the start, and
+// (a + a + 1) >> 1 == (3a + a + 2) >> 2 == a, so the formulas of video_chroma_up_h2_cs_u8 / up_h2_u8
+// (video-chroma.c:687, 277) reproduce their own edge rules.  out[i] = packed {c0, c1} in u16 lanes.
+template <int CH>
+GSTAMD_HD void chroma_filter4 (uint32_t raw, uint32_t nxt, uint32_t prv_hi, uint32_t *out)
 {
-  uint32_t o[4];
-  if (ABL == 1) {
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      o[j] = yw ^ c[j];
+  const uint32_t s1 = bperm (raw, raw, 0x0c010c00u), s2 = bperm (raw, raw, 0x0c030c02u);
+  if (CH == CHROMA_H_NONE) {
+    out[0] = out[1] = s1;
+    out[2] = out[3] = s2;
+    return;
+  }
+  const uint32_t s3 = bperm (nxt, nxt, 0x0c010c00u);
+  if (CH == CHROMA_H_H2_CS) {
+    out[0] = s1;
+    out[1] = pk_shr<1> (s1 + s2 + 0x00010001u);
+    out[2] = s2;
+    out[3] = pk_shr<1> (s2 + s3 + 0x00010001u);
   } else {
-    const uint32_t yx = yw ^ 0x80808080u;
-    const uint32_t ys01 = bperm (yx, yx, 0x01010000u), ys23 = bperm (yx, yx, 0x03030202u);
-    uint32_t cs[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t cx = c[j] ^ 0x00800080u;
-      cs[j] = bperm (cx, cx, fp.csel_w);
-    }
-    o[0] = fast_pixel_w<0> (fp, ys01, cs[0], rg, ba);
-    o[1] = fast_pixel_w<1> (fp, ys01, cs[1], rg, ba);
-    o[2] = fast_pixel_w<0> (fp, ys23, cs[2], rg, ba);
-    o[3] = fast_pixel_w<1> (fp, ys23, cs[3], rg, ba);
-  }
-  store16_stream (d, o[0], o[1], o[2], o[3]);
-}
-
-// horizontally filtered chroma for the NPX pixels x0 .. x0+NPX-1 of one chroma row: out[i] packed
-// {c0, c1} in u16 lanes (c0 = first byte of the interleaved pair).  x0 % NPX == 0, rows NPX-byte aligned.
-template <int CH, int NPX>
-GSTAMD_HD void fast_hchroma (const uint8_t *__restrict__ row, int cw, int x0, int w, uint32_t *out)
-{
-  constexpr int NS = NPX / 2;        // chroma samples under the span
-  const int k0 = x0 >> 1;
-  uint32_t raw[NPX / 4];
-  if (NPX == 4) {
-    raw[0] = *(const uint32_t *) (row + 2 * (size_t) k0);
-  } else if (NPX == 8) {
-    const uint2 m = *(const uint2 *) (row + 2 * (size_t) k0);
-    raw[0] = m.x;
-    raw[NPX >= 8 ? 1 : 0] = m.y;
-  } else {
-    const uint4 m = *(const uint4 *) (row + 2 * (size_t) k0);
-    raw[0] = m.x;
-    raw[NPX >= 16 ? 1 : 0] = m.y;
-    raw[NPX >= 16 ? 2 : 0] = m.z;
-    raw[NPX >= 16 ? 3 : 0] = m.w;
-  }
-  uint32_t S[NS + 2];                // samples k0-1 .. k0+NS as {c0, c1} 16-bit lanes
-#pragma unroll
-  for (int j = 0; j < NS; j++)
-    S[j + 1] = bperm (raw[j >> 1], raw[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u);
-  if (CH != CHROMA_H_NONE) {
-    const int kp = k0 + NS < cw ? k0 + NS : cw - 1;
-    const uint32_t pp = *(const uint16_t *) (row + 2 * (size_t) kp);
-    S[NS + 1] = bperm (pp, pp, 0x0c010c00u);
-  } else {
-    S[NS + 1] = S[NS];
-  }
-  if (CH == CHROMA_H_H2) {
-    const int km = k0 > 0 ? k0 - 1 : 0;
-    const uint32_t pm = *(const uint16_t *) (row + 2 * (size_t) km);
-    S[0] = bperm (pm, pm, 0x0c010c00u);
-  } else {
-    S[0] = S[1];
-  }
-#pragma unroll
-  for (int j = 0; j < NS; j++) {
-    const int xe = x0 + 2 * j, xo = xe + 1;
-    uint32_t e = S[j + 1], o = S[j + 1];
-    if (CH == CHROMA_H_H2_CS) {
-      if (xo < w - 1)
-        o = pk_shr<1> (S[j + 1] + S[j + 2] + 0x00010001u);
-    } else if (CH == CHROMA_H_H2) {
-      if (xo < w - 1)
-        o = pk_shr<2> (3u * S[j + 1] + S[j + 2] + 0x00020002u);
-      if (xe >= 2)
-        e = pk_shr<2> (S[j] + 3u * S[j + 1] + 0x00020002u);
-    }
-    out[2 * j] = e;
-    out[2 * j + 1] = o;
+    const uint32_t s0 = bperm (prv_hi, prv_hi, 0x0c030c02u);
+    out[0] = pk_shr<2> (s0 + 3u * s1 + 0x00020002u);
+    out[1] = pk_shr<2> (3u * s1 + s2 + 0x00020002u);
+    out[2] = pk_shr<2> (s1 + 3u * s2 + 0x00020002u);
+    out[3] = pk_shr<2> (3u * s2 + s3 + 0x00020002u);
   }
 }
 
-template <int NPX>
-GSTAMD_HD void fast_load_y (const uint8_t *__restrict__ p, uint32_t *y)
-{
-  if (NPX == 4) {
-#ifdef __HIPCC__
-    y[0] = __builtin_nontemporal_load ((const uint32_t *) p);     // luma is read exactly once: streaming load
-#else
-    y[0] = *(const uint32_t *) p;
-#endif
-  } else if (NPX == 8) {
-    const uint2 m = *(const uint2 *) p;
-    y[0] = m.x;
-    y[NPX >= 8 ? 1 : 0] = m.y;
-  } else {
-    const uint4 m = *(const uint4 *) p;
-    y[0] = m.x;
-    y[NPX >= 16 ? 1 : 0] = m.y;
-    y[NPX >= 16 ? 2 : 0] = m.z;
-    y[NPX >= 16 ? 3 : 0] = m.w;
-  }
-}
-
-// One line of the pair: blend the two chroma rows (role 0: (3a+b+2)>>2, role 1: (a+3b+2)>>2), convert, store.
-// ABL (ablation, benchmarking only): 0 = real kernel, 1 = loads + stores with trivial math.
-template <int NPX, int ABL>
-GSTAMD_HD void fast_line (const FastParams &fp, const Planes &pl, uint8_t *__restrict__ dst, int dstride, int line, int x0,
-    const uint32_t *ca, const uint32_t *cb, bool blend, int role, uint32_t usel, uint32_t vsel)
-{
-  static const uint32_t ysel[4] = {0x0c00000cu, 0x0c01010cu, 0x0c02020cu, 0x0c03030cu};
-  uint32_t yy[NPX / 4], o[NPX];
-  fast_load_y<NPX> (pl.p[0] + (size_t) line * pl.stride[0] + x0, yy);
-#pragma unroll
-  for (int i = 0; i < NPX; i++) {
-    uint32_t c = ca[i];
-    if (blend)
-      c = role == 0 ? pk_shr<2> (3u * ca[i] + cb[i] + 0x00020002u) : pk_shr<2> (ca[i] + 3u * cb[i] + 0x00020002u);
-    if (ABL == 1)
-      o[i] = yy[i >> 2] ^ c;
-    else
-      o[i] = fast_pixel (fp, yy[i >> 2] ^ 0x80808080u, ysel[i & 3], c ^ 0x00800080u, usel, vsel);
-  }
-  uint8_t *d = dst + (size_t) line * dstride + 4 * (size_t) x0;
-#pragma unroll
-  for (int q = 0; q < NPX / 4; q++)
-    store16_stream (d + 16 * q, o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
-}
-
-// Pair index p (lines 2p-1 and 2p), NPX pixels starting at x0.  Requires: 4:2:0 semi-planar source,
-// x0 + NPX <= width, NPX-byte aligned luma/chroma rows, 16-byte aligned destination rows.
-template <int CH, int NPX, int ABL>
-GSTAMD_HD void fast_pair_span (const FastParams &fp, const Planes &pl, uint8_t *__restrict__ dst, int dstride, int x0, int p)
-{
-  const int w = fp.width, h = fp.height;
-  const int l0 = 2 * p - 1, l1 = 2 * p;
-  const bool have0 = l0 >= 0, have1 = l1 < h;
-  const int cw = (w + 1) >> 1;
-  const int ra = have0 ? p - 1 : p;            // chroma row of line l0 (or of l1 when l0 is absent)
-  const int rb = have1 ? p : p - 1;            // chroma row of line l1 (or of l0 when l1 is absent)
-  uint32_t ca[NPX], cb[NPX];
-  fast_hchroma<CH, NPX> (pl.p[1] + (size_t) ra * pl.stride[1], cw, x0, w, ca);
-  const bool blend = rb != ra;
-  if (blend)
-    fast_hchroma<CH, NPX> (pl.p[1] + (size_t) rb * pl.stride[1], cw, x0, w, cb);
-  // byte selectors: 16-bit lane0 / lane1 low byte -> bits 8..23
-  const uint32_t sel_l0 = 0x0c00000cu, sel_l1 = 0x0c02020cu;
-  const uint32_t usel = fp.u_first ? sel_l0 : sel_l1, vsel = fp.u_first ? sel_l1 : sel_l0;
-  if (have0)
-    fast_line<NPX, ABL> (fp, pl, dst, dstride, l0, x0, ca, cb, blend, 0, usel, vsel);
-  if (have1)
-    fast_line<NPX, ABL> (fp, pl, dst, dstride, l1, x0, ca, cb, blend, 1, usel, vsel);
-}
-
-// Single-line variant: one lane converts NPX pixels of ONE line (the chroma rows are fetched again by the
-// partner line's lane, from L2).  Same results as fast_pair_span.
-template <int CH, int NPX, int ABL>
-GSTAMD_HD void fast_line_span (const FastParams &fp, const Planes &pl, uint8_t *__restrict__ dst, int dstride, int x0, int line)
-{
-  const int w = fp.width, h = fp.height;
-  const int p = (line + 1) >> 1, l0 = 2 * p - 1, l1 = 2 * p;
-  const bool have0 = l0 >= 0, have1 = l1 < h;
-  const int cw = (w + 1) >> 1;
-  const int ra = have0 ? p - 1 : p, rb = have1 ? p : p - 1;
-  uint32_t ca[NPX], cb[NPX];
-  fast_hchroma<CH, NPX> (pl.p[1] + (size_t) ra * pl.stride[1], cw, x0, w, ca);
-  const bool blend = rb != ra;
-  if (blend)
-    fast_hchroma<CH, NPX> (pl.p[1] + (size_t) rb * pl.stride[1], cw, x0, w, cb);
-  const uint32_t sel_l0 = 0x0c00000cu, sel_l1 = 0x0c02020cu;
-  const uint32_t usel = fp.u_first ? sel_l0 : sel_l1, vsel = fp.u_first ? sel_l1 : sel_l0;
-  fast_line<NPX, ABL> (fp, pl, dst, dstride, line, x0, ca, cb, blend, line == l0 ? 0 : 1, usel, vsel);
-}
-
-// ---- strip variant: one lane walks K consecutive line pairs of its NPX-pixel column --------------------
+// ---- strip variant: one lane walks K consecutive line pairs of its 4-pixel column ---------------------------
 // Loads of pair p+1 are issued before pair p is computed (software prefetch: with ~16 waves per SIMD in the
 // whole grid the hardware alone cannot overlap the load, VALU and store phases), and the horizontally
 // filtered chroma row of pair p is reused as the upper row of pair p+1 (each chroma row is loaded and
-// filtered exactly once).
-template <int CH, int NPX>
-struct ChromaRaw {
-  uint32_t raw[NPX / 4];
-  uint32_t nxt, prv;
+// filtered exactly once per strip).
+struct ChromaRaw4 {
+  uint32_t raw, nxt, prv_hi;
 };
 
 struct __attribute__ ((aligned (4))) u32x2u { uint32_t a, b; };
-struct __attribute__ ((aligned (4))) u32x3u { uint32_t a, b, c; };
 
-template <int CH, int NPX>
-GSTAMD_HD void fast_chroma_load (const uint8_t *__restrict__ row, int cw, int x0, ChromaRaw<CH, NPX> &r)
+GSTAMD_HD uint32_t load_stream32 (const uint8_t *__restrict__ p)
+{
+#ifdef __HIPCC__
+  return __builtin_nontemporal_load ((const uint32_t *) p);       // luma is read exactly once: streaming load
+#else
+  return *(const uint32_t *) p;
+#endif
+}
+
+// the 4 chroma bytes under pixels x0 .. x0+3 of a row (cw samples) plus the neighbours the filter needs
+template <int CH>
+GSTAMD_HD void chroma_load4 (const uint8_t *__restrict__ row, int cw, int x0, ChromaRaw4 &r)
 {
   const int k0 = x0 >> 1;
-  constexpr int NS = NPX / 2;
   const uint8_t *p = row + 2 * (size_t) k0;
-  r.nxt = r.prv = 0;
+  r.nxt = r.prv_hi = 0;
   // the sample right of the span rides in the same (dword-aligned) load unless the span ends the row
-  const bool inner = CH != CHROMA_H_NONE && k0 + NS < cw;
-  if (NPX == 4) {
-    if (inner) {
-      const u32x2u m = *(const u32x2u *) p;
-      r.raw[0] = m.a;
-      r.nxt = m.b;
-    } else {
-      r.raw[0] = *(const uint32_t *) p;
-    }
-  } else if (NPX == 8) {
-    if (inner) {
-      const u32x3u m = *(const u32x3u *) p;
-      r.raw[0] = m.a;
-      r.raw[NPX >= 8 ? 1 : 0] = m.b;
-      r.nxt = m.c;
-    } else {
-      const uint2 m = *(const uint2 *) p;
-      r.raw[0] = m.x;
-      r.raw[NPX >= 8 ? 1 : 0] = m.y;
-    }
+  if (CH != CHROMA_H_NONE && k0 + 2 < cw) {
+    const u32x2u m = *(const u32x2u *) p;
+    r.raw = m.a;
+    r.nxt = m.b;
   } else {
-    const uint4 m = *(const uint4 *) p;
-    r.raw[0] = m.x;
-    r.raw[NPX >= 16 ? 1 : 0] = m.y;
-    r.raw[NPX >= 16 ? 2 : 0] = m.z;
-    r.raw[NPX >= 16 ? 3 : 0] = m.w;
-    if (inner)
-      r.nxt = *(const uint16_t *) (p + 2 * NS);
+    r.raw = *(const uint32_t *) p;
+    if (CH != CHROMA_H_NONE)
+      r.nxt = *(const uint16_t *) (row + 2 * (size_t) (cw - 1));
   }
-  if (CH != CHROMA_H_NONE && !inner)
-    r.nxt = *(const uint16_t *) (row + 2 * (size_t) (cw - 1));
-  if (CH == CHROMA_H_H2) {
-    const int km = k0 > 0 ? k0 - 1 : 0;
-    r.prv = *(const uint16_t *) (row + 2 * (size_t) km);
-  }
+  if (CH == CHROMA_H_H2)
+    r.prv_hi = (uint32_t) * (const uint16_t *) (row + 2 * (size_t) (k0 > 0 ? k0 - 1 : 0)) << 16;
 }
 
-template <int CH, int NPX>
-GSTAMD_HD void fast_chroma_filter (const ChromaRaw<CH, NPX> &r, int x0, int w, uint32_t *out)
-{
-  constexpr int NS = NPX / 2;
-  uint32_t S[NS + 2];
-#pragma unroll
-  for (int j = 0; j < NS; j++)
-    S[j + 1] = bperm (r.raw[j >> 1], r.raw[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u);
-  S[NS + 1] = CH != CHROMA_H_NONE ? bperm (r.nxt, r.nxt, 0x0c010c00u) : S[NS];
-  S[0] = CH == CHROMA_H_H2 ? bperm (r.prv, r.prv, 0x0c010c00u) : S[1];
-#pragma unroll
-  for (int j = 0; j < NS; j++) {
-    const int xe = x0 + 2 * j, xo = xe + 1;
-    uint32_t e = S[j + 1], o = S[j + 1];
-    if (CH == CHROMA_H_H2_CS) {
-      if (xo < w - 1)
-        o = pk_shr<1> (S[j + 1] + S[j + 2] + 0x00010001u);
-    } else if (CH == CHROMA_H_H2) {
-      if (xo < w - 1)
-        o = pk_shr<2> (3u * S[j + 1] + S[j + 2] + 0x00020002u);
-      if (xe >= 2)
-        e = pk_shr<2> (S[j] + 3u * S[j + 1] + 0x00020002u);
-    }
-    out[2 * j] = e;
-    out[2 * j + 1] = o;
-  }
-}
-
-// convert + store one line whose luma words are already in registers
-template <int NPX, int ABL>
-GSTAMD_HD void fast_emit_line (const FastParams &fp, uint8_t *__restrict__ dst, int dstride, int line, int x0, const uint32_t *yy,
-    const uint32_t *ca, const uint32_t *cb, bool blend, int role, uint32_t usel, uint32_t vsel)
-{
-  uint32_t rg = 0, ba = 0x00ff0000u;
-  uint8_t *d = dst + (size_t) line * dstride + 4 * (size_t) x0;
-#pragma unroll
-  for (int q = 0; q < NPX / 4; q++) {
-    uint32_t c[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int i = 4 * q + j;
-      c[j] = ca[i];
-      if (blend)
-        c[j] = role == 0 ? pk_shr<2> (3u * ca[i] + cb[i] + 0x00020002u) : pk_shr<2> (ca[i] + 3u * cb[i] + 0x00020002u);
-    }
-    fast_emit4_w<ABL> (fp, d + 16 * q, yy[q], c, rg, ba);
-  }
-}
-
-// pairs [p_begin, p_end) of the column x0 .. x0+NPX-1; pair p = lines (2p-1, 2p), chroma rows (p-1, p)
-template <int CH, int NPX, int ABL>
+// pairs [p_begin, p_end) of the column x0 .. x0+3; pair p = lines (2p-1, 2p), chroma rows (p-1, p), all clamped into
+// the frame: a frame's first / last pair has one line only, its two chroma rows are then the same row, the blend is
+// the identity and the missing line is computed but not stored.
+template <int CH, int L, int ABL>
 GSTAMD_HD void fast_strip (const FastParams &fp, const Planes &pl, uint8_t *__restrict__ dst, int dstride, int x0, int p_begin,
     int p_end)
 {
   const int w = fp.width, h = fp.height, cw = (w + 1) >> 1;
   const int n_crows = (h + 1) >> 1;
-  const uint32_t sel_l0 = 0x0c00000cu, sel_l1 = 0x0c02020cu;
-  const uint32_t usel = fp.u_first ? sel_l0 : sel_l1, vsel = fp.u_first ? sel_l1 : sel_l0;
   const uint8_t *yb = pl.p[0] + x0, *cbase = pl.p[1];
   const int ys = pl.stride[0], cs = pl.stride[1];
+  uint8_t *db = dst + 4 * (size_t) x0;
+  uint32_t q[4][2];
+  layout_init<L> (q);
 
-  uint32_t cprev[NPX], ccur[NPX];
-  ChromaRaw<CH, NPX> craw;
-  uint32_t y0[NPX / 4], y1[NPX / 4];
+  uint32_t cprev[4], ccur[4], c0[4], c1[4];
+  ChromaRaw4 craw;
+  uint32_t y0, y1;
   {                                       // upper chroma row of the first pair
-    ChromaRaw<CH, NPX> r0;
-    const int r = p_begin > 0 ? p_begin - 1 : 0;
-    fast_chroma_load<CH, NPX> (cbase + (size_t) r * cs, cw, x0, r0);
-    fast_chroma_filter<CH, NPX> (r0, x0, w, cprev);
+    ChromaRaw4 r0;
+    chroma_load4<CH> (cbase + (size_t) (p_begin > 0 ? p_begin - 1 : 0) * cs, cw, x0, r0);
+    chroma_filter4<CH> (r0.raw, r0.nxt, r0.prv_hi, cprev);
   }
-  // prefetch pair p_begin
-  {
+  {                                       // prefetch pair p_begin
     const int p = p_begin, l0 = 2 * p - 1, l1 = 2 * p;
-    const int cr = p < n_crows ? p : n_crows - 1;
-    fast_chroma_load<CH, NPX> (cbase + (size_t) cr * cs, cw, x0, craw);
-    fast_load_y<NPX> (yb + (size_t) (l0 >= 0 ? l0 : 0) * ys, y0);
-    fast_load_y<NPX> (yb + (size_t) (l1 < h ? l1 : h - 1) * ys, y1);
+    chroma_load4<CH> (cbase + (size_t) (p < n_crows ? p : n_crows - 1) * cs, cw, x0, craw);
+    y0 = load_stream32 (yb + (size_t) (l0 >= 0 ? l0 : 0) * ys);
+    y1 = load_stream32 (yb + (size_t) (l1 < h ? l1 : h - 1) * ys);
   }
   for (int p = p_begin; p < p_end; p++) {
     const int l0 = 2 * p - 1, l1 = 2 * p;
     const bool have0 = l0 >= 0, have1 = l1 < h;
-    uint32_t cy0[NPX / 4], cy1[NPX / 4];
-    ChromaRaw<CH, NPX> cr_now = craw;
-#pragma unroll
-    for (int q = 0; q < NPX / 4; q++) {
-      cy0[q] = y0[q];
-      cy1[q] = y1[q];
-    }
+    const uint32_t cy0 = y0, cy1 = y1;
+    const ChromaRaw4 cr_now = craw;
     if (p + 1 < p_end) {                  // issue the next pair's loads before this pair's math
       const int pn = p + 1, n0 = 2 * pn - 1, n1 = 2 * pn;
-      const int cr = pn < n_crows ? pn : n_crows - 1;
-      fast_chroma_load<CH, NPX> (cbase + (size_t) cr * cs, cw, x0, craw);
-      fast_load_y<NPX> (yb + (size_t) n0 * ys, y0);
-      fast_load_y<NPX> (yb + (size_t) (n1 < h ? n1 : h - 1) * ys, y1);
+      chroma_load4<CH> (cbase + (size_t) (pn < n_crows ? pn : n_crows - 1) * cs, cw, x0, craw);
+      y0 = load_stream32 (yb + (size_t) n0 * ys);
+      y1 = load_stream32 (yb + (size_t) (n1 < h ? n1 : h - 1) * ys);
     }
-    if (have1)
-      fast_chroma_filter<CH, NPX> (cr_now, x0, w, ccur);
-    const bool blend = have0 && have1;
-    if (have0)
-      fast_emit_line<NPX, ABL> (fp, dst, dstride, l0, x0, cy0, cprev, ccur, blend, 0, usel, vsel);
-    if (have1) {
-      fast_emit_line<NPX, ABL> (fp, dst, dstride, l1, x0, cy1, blend ? cprev : ccur, ccur, blend, 1, usel, vsel);
+    chroma_filter4<CH> (cr_now.raw, cr_now.nxt, cr_now.prv_hi, ccur);
 #pragma unroll
-      for (int i = 0; i < NPX; i++)
-        cprev[i] = ccur[i];
-    }
+    for (int j = 0; j < 4; j++)
+      blend_rows_hi (cprev[j], ccur[j], c0[j], c1[j]);
+    fast_emit4_l<L, ABL> (fp, db + (size_t) (have0 ? l0 : l1) * dstride, have0, cy0, c0, q);
+    fast_emit4_l<L, ABL> (fp, db + (size_t) (have1 ? l1 : l0) * dstride, have1, cy1, c1, q);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      cprev[i] = ccur[i];
   }
 }
 
 // ---- wide variant: one wave = a 1024-pixel run of ONE line pair, staged through LDS ---------------------
 // Every source row segment is fetched with ONE 16-byte load per lane (1 KB contiguous per wave instruction), parked in
-// LDS and read back in the 4-pixels-per-lane layout of fast_emit_line, so each store instruction still writes 1 KB
+// LDS and read back in the 4-pixels-per-lane layout of fast_emit4_l, so each store instruction still writes 1 KB
 // contiguous and four of them cover a 4 KB run of the destination row.  Measured on MI355X with the memory skeleton
 // (scripts/membench3.hip): 7.9 us per 4K frame against 8.5 us for the strip shape and 7.6 us for a perfectly linear
 // kernel moving the same bytes.  Arithmetic and results are those of fast_strip.
@@ -801,34 +564,6 @@ GSTAMD_HD void wide_commit (const FastParams &fp, int xw, int lane, const WideRe
   wide_commit_chroma<CH> (fp, xw, lane, r, lds->c[cslot]);
 }
 
-// Horizontal chroma filter of 4 pixels without edge cases: wide_commit_chroma stores the row's last sample again right of the
-// row end and its first sample left of the start, and (a + a + 1) >> 1 == (3a + a + 2) >> 2 == a, so the formulas of
-// video_chroma_up_h2_cs_u8 / up_h2_u8 (video-chroma.c:687, 277) reproduce their own edge rules.
-// raw = 2 samples {c0 c1 c0 c1} under the span, nxt / prv = dwords right / left of it.
-template <int CH>
-GSTAMD_HD void wide_chroma_filter (uint32_t raw, uint32_t nxt, uint32_t prv, uint32_t *out)
-{
-  const uint32_t s1 = bperm (raw, raw, 0x0c010c00u), s2 = bperm (raw, raw, 0x0c030c02u);
-  if (CH == CHROMA_H_NONE) {
-    out[0] = out[1] = s1;
-    out[2] = out[3] = s2;
-    return;
-  }
-  const uint32_t s3 = bperm (nxt, nxt, 0x0c010c00u);
-  if (CH == CHROMA_H_H2_CS) {
-    out[0] = s1;
-    out[1] = pk_shr<1> (s1 + s2 + 0x00010001u);
-    out[2] = s2;
-    out[3] = pk_shr<1> (s2 + s3 + 0x00010001u);
-  } else {
-    const uint32_t s0 = bperm (prv, prv, 0x0c030c02u);
-    out[0] = pk_shr<2> (s0 + 3u * s1 + 0x00020002u);
-    out[1] = pk_shr<2> (3u * s1 + s2 + 0x00020002u);
-    out[2] = pk_shr<2> (s1 + 3u * s2 + 0x00020002u);
-    out[3] = pk_shr<2> (3u * s2 + s3 + 0x00020002u);
-  }
-}
-
 // phase 2, lane `lane`: four 4-pixel groups (x = xw + 256 g + 4 lane) of both lines, from LDS.  The first and the last
 // pair of a frame have one line only; the same chroma row is then staged twice (clamped row index), and (3a + a + 2) >> 2 == a makes
 // the blend the identity, so no case distinction is needed in the arithmetic.
@@ -848,8 +583,8 @@ GSTAMD_HD void wide_emit (const FastParams &fp, uint8_t *__restrict__ dst, int d
     uint32_t ca[4], cb[4], c0[4], c1[4];
     // lanes right of the row end compute on whatever LDS holds (in bounds) and skip the store
     const uint32_t *ra = lds->c[aslot], *rb = lds->c[aslot ^ 1];
-    wide_chroma_filter<CH> (ra[4 + idx], ra[5 + idx], ra[3 + idx], ca);
-    wide_chroma_filter<CH> (rb[4 + idx], rb[5 + idx], rb[3 + idx], cb);
+    chroma_filter4<CH> (ra[4 + idx], ra[5 + idx], ra[3 + idx], ca);
+    chroma_filter4<CH> (rb[4 + idx], rb[5 + idx], rb[3 + idx], cb);
 #pragma unroll
     for (int j = 0; j < 4; j++)
       blend_rows_hi (ca[j], cb[j], c0[j], c1[j]);
@@ -879,13 +614,6 @@ inline int wide_grid_blocks (int nxb, int total_strips)
 {
   const int units = nxb * ((total_strips + GSTAMD_WIDE_BAND - 1) / GSTAMD_WIDE_BAND);
   return (units + 7) / 8 * 8 * GSTAMD_WIDE_BAND;
-}
-
-// the shipped shape (8 pixels per lane); kept as the emulator's and the launcher's default entry
-template <int CH>
-GSTAMD_HD void fast_pair_body (const FastParams &fp, const Planes &pl, uint8_t *__restrict__ dst, int dstride, int span, int p)
-{
-  fast_pair_span<CH, 8, 0> (fp, pl, dst, dstride, span * 8, p);
 }
 
 }  // namespace gstamd

@@ -46,25 +46,6 @@ __device__ __forceinline__ Planes batch_planes (const FrameBatch &b, int f)
   return pl;
 }
 
-// fast pair kernel.  blockDim = (bx lanes along x, 256 / bx line pairs).  Each lane converts GROUPS spans
-// of NPX pixels; with GROUPS > 1 the spans of one lane are bx * NPX pixels apart so that every store
-// instruction of a wave covers one contiguous run of the row.
-template <int CH, int NPX, int ABL, int GROUPS>
-__global__ __launch_bounds__ (256) void k_convert_pair (FastParams fp, FrameBatch batch, int pairs)
-{
-  const Planes pl = batch_planes (batch, blockIdx.z);
-  uint8_t *__restrict__ dst = batch.dst[blockIdx.z];
-  const int dstride = batch.dstride;
-  const int p = blockIdx.y * blockDim.y + threadIdx.y;
-  if (p >= pairs)
-    return;
-#pragma unroll
-  for (int g = 0; g < GROUPS; g++) {
-    const int x0 = ((blockIdx.x * GROUPS + g) * blockDim.x + threadIdx.x) * NPX;
-    if (x0 + NPX <= fp.width)
-      fast_pair_span<CH, NPX, ABL> (fp, pl, dst, dstride, x0, p);
-  }
-}
 
 template <class SRC>
 __global__ __launch_bounds__ (256) void k_hscale (SRC src, ScaleDev sd, Dst dst, int out_w, int rows)
@@ -229,48 +210,59 @@ hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vp
   return hipGetLastError ();
 }
 
-// single-line variant (experiments): grid.y = lines
-template <int CH, int NPX, int ABL>
-__global__ __launch_bounds__ (256) void k_convert_line (FastParams fp, FrameBatch batch)
+// strip kernel: grid.x = 256-pixel columns, grid.y = strips of K line pairs, grid.z = frame; one wave per workgroup
+template <int CH, int L, int ABL>
+__global__ __launch_bounds__ (64) void k_convert_strip (FastParams fp, FrameBatch batch, int pairs, int K)
 {
   const Planes pl = batch_planes (batch, blockIdx.z);
-  uint8_t *__restrict__ dst = batch.dst[blockIdx.z];
-  const int dstride = batch.dstride;
-  const int line = blockIdx.y * blockDim.y + threadIdx.y;
-  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * NPX;
-  if (line < fp.height && x0 + NPX <= fp.width)
-    fast_line_span<CH, NPX, ABL> (fp, pl, dst, dstride, x0, line);
+  const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int p0 = blockIdx.y * K;
+  if (x0 + 4 <= fp.width)
+    fast_strip<CH, L, ABL> (fp, pl, batch.dst[blockIdx.z], batch.dstride, x0, p0, p0 + K < pairs ? p0 + K : pairs);
 }
 
-template <int CH, int NPX, int ABL>
-static void launch_line_variant (const FastParams &fp, const FrameBatch &batch, int n, int bx, hipStream_t stream)
+// the same under the XCD-aware block order of the wide kernel (wide_block_map): 1-D grid
+template <int CH, int L, int ABL>
+__global__ __launch_bounds__ (64) void k_convert_strip_xcd (FastParams fp, FrameBatch batch, int ncol, int pairs, int K, int strips, int total_strips)
 {
-  const int per_block = bx * NPX;
-  dim3 block (bx, 256 / bx), grid ((fp.width + per_block - 1) / per_block, (fp.height + block.y - 1) / block.y, n);
-  hipLaunchKernelGGL ((k_convert_line<CH, NPX, ABL>), grid, block, 0, stream, fp, batch);
+  int col, S;
+  if (!wide_block_map (blockIdx.x, ncol, total_strips, &col, &S))
+    return;
+  const int z = S / strips, p0 = (S - z * strips) * K;
+  const Planes pl = batch_planes (batch, z);
+  const int x0 = (col * 64 + threadIdx.x) * 4;
+  if (x0 + 4 <= fp.width)
+    fast_strip<CH, L, ABL> (fp, pl, batch.dst[z], batch.dstride, x0, p0, p0 + K < pairs ? p0 + K : pairs);
 }
 
-// strip variant: grid.y = strips of K line pairs; blockDim = (bx, 256 / bx)
-template <int CH, int NPX, int ABL>
-__global__ __launch_bounds__ (256) void k_convert_strip (FastParams fp, FrameBatch batch, int pairs, int K)
+// destination byte order -> layout template argument (the four orders of the eight 4-byte RGB formats)
+static int fast_layout (const FastParams &fp)
 {
-  const Planes pl = batch_planes (batch, blockIdx.z);
-  uint8_t *__restrict__ dst = batch.dst[blockIdx.z];
-  const int dstride = batch.dstride;
-  const int strip = blockIdx.y * blockDim.y + threadIdx.y;
-  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * NPX;
-  const int p0 = strip * K;
-  if (p0 < pairs && x0 + NPX <= fp.width)
-    fast_strip<CH, NPX, ABL> (fp, pl, dst, dstride, x0, p0, p0 + K < pairs ? p0 + K : pairs);
+  return GSTAMD_LAYOUT (fp.pack_pos[1], fp.pack_pos[2], fp.pack_pos[3]);
 }
 
-template <int CH, int NPX, int ABL>
-static void launch_strip_variant (const FastParams &fp, const FrameBatch &batch, int n, int bx, int K, hipStream_t stream, int by = 0)
+#define GSTAMD_FOR_LAYOUTS(W) \
+    W (2, 1, 0)      /* BGRA, BGRx */ \
+    W (0, 1, 2)      /* RGBA, RGBx */ \
+    W (1, 2, 3)      /* ARGB, xRGB */ \
+    W (3, 2, 1)      /* ABGR, xBGR */
+
+template <int CH, int ABL>
+static bool launch_strip_variant (const FastParams &fp, const FrameBatch &batch, int n, int K, bool xcd_order, hipStream_t stream)
 {
-  const int pairs = fp.height / 2 + 1, strips = (pairs + K - 1) / K;
-  const int per_block = bx * NPX;
-  dim3 block (bx, by > 0 ? by : 256 / bx), grid ((fp.width + per_block - 1) / per_block, (strips + block.y - 1) / block.y, n);
-  hipLaunchKernelGGL ((k_convert_strip<CH, NPX, ABL>), grid, block, 0, stream, fp, batch, pairs, K);
+  const int pairs = fp.height / 2 + 1, strips = (pairs + K - 1) / K, ncol = (fp.width + 255) / 256;
+#define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \
+    if (xcd_order) \
+      hipLaunchKernelGGL ((k_convert_strip_xcd<CH, GSTAMD_LAYOUT (pr, pg, pb), ABL>), dim3 (wide_grid_blocks (ncol, strips * n)), dim3 (64), 0, stream, \
+          fp, batch, ncol, pairs, K, strips, strips * n); \
+    else \
+      hipLaunchKernelGGL ((k_convert_strip<CH, GSTAMD_LAYOUT (pr, pg, pb), ABL>), dim3 (ncol, strips, n), dim3 (64), 0, stream, fp, batch, pairs, K); \
+    return true;
+  switch (fast_layout (fp)) {
+    GSTAMD_FOR_LAYOUTS (W)
+  }
+#undef W
+  return false;
 }
 
 // wide variant (video_fast.h): 1-D grid of one-wave workgroups, XCD-aware block order, rows staged through LDS
@@ -309,91 +301,49 @@ static bool wide_vec_ok (const FrameBatch &batch, int n)
   return ok;
 }
 
-// destination byte order -> layout template argument (the four orders of the eight 4-byte RGB formats)
-static int wide_layout (const FastParams &fp)
-{
-  return GSTAMD_LAYOUT (fp.pack_pos[1], fp.pack_pos[2], fp.pack_pos[3]);
-}
-
-static int wide_pairs_per_wave ()
-{
-  static int k = 0;
-  if (k == 0) {
-    const char *e = getenv ("GSTAMD_WIDE_K");      /* tuning knob for profiling sessions */
-    k = e && atoi (e) > 0 ? atoi (e) : 2;
-  }
-  return k;
-}
-
 template <int CH, int ABL>
-static bool launch_wide_variant (const FastParams &fp, const FrameBatch &batch, int n, hipStream_t stream)
+static bool launch_wide_variant (const FastParams &fp, const FrameBatch &batch, int n, int K, hipStream_t stream)
 {
   const int pairs = fp.height / 2 + 1, nxb = (fp.width + GSTAMD_WIDE_PX - 1) / GSTAMD_WIDE_PX;
-  const int K = wide_pairs_per_wave (), strips = (pairs + K - 1) / K;
+  const int strips = (pairs + K - 1) / K;
   const int blocks = wide_grid_blocks (nxb, strips * n);
   const int vec = wide_vec_ok (batch, n) ? 1 : 0;
 #define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \
     hipLaunchKernelGGL ((k_convert_wide<CH, GSTAMD_LAYOUT (pr, pg, pb), ABL>), dim3 (blocks), dim3 (64), 0, stream, fp, batch, nxb, pairs, K, strips, strips * n, vec); \
     return true;
-  switch (wide_layout (fp)) {
-    W (2, 1, 0)      /* BGRA, BGRx */
-    W (0, 1, 2)      /* RGBA, RGBx */
-    W (1, 2, 3)      /* ARGB, xRGB */
-    W (3, 2, 1)      /* ABGR, xBGR */
+  switch (fast_layout (fp)) {
+    GSTAMD_FOR_LAYOUTS (W)
   }
 #undef W
   return false;
 }
 
-template <int CH, int NPX, int ABL, int GROUPS>
-static void launch_pair_variant (const FastParams &fp, const FrameBatch &batch, int n, int bx, hipStream_t stream)
+// Tuning knob for profiling sessions: GSTAMD_FAST_VARIANT="shape,abl,K,order" with shape 0 = strip, 1 = wide; abl 1 =
+// memory-only ablation (h2cs only); K = line pairs per wave; order 1 = XCD-aware block order (strip).  Unset = shipped.
+struct FastVariant { int set, shape, abl, K, order; };
+static const FastVariant &fast_variant ()
 {
-  const int pairs = fp.height / 2 + 1;
-  const int per_block = bx * NPX * GROUPS;
-  dim3 block (bx, 256 / bx), grid ((fp.width + per_block - 1) / per_block, (pairs + block.y - 1) / block.y, n);
-  hipLaunchKernelGGL ((k_convert_pair<CH, NPX, ABL, GROUPS>), grid, block, 0, stream, fp, batch, pairs);
+  static FastVariant v = {-1, 0, 0, 0, 0};
+  if (v.set < 0) {
+    const char *e = getenv ("GSTAMD_FAST_VARIANT");
+    v.set = e && sscanf (e, "%d,%d,%d,%d", &v.shape, &v.abl, &v.K, &v.order) >= 1;
+  }
+  return v;
 }
 
-// Tuning knob for profiling sessions: GSTAMD_FAST_VARIANT="npx,abl,groups,bx" (h2cs only).  Unset = shipped config.
-static bool launch_pair_experiment (const FastParams &fp, const FrameBatch &batch, int n, hipStream_t stream)
+template <int CH>
+static bool launch_fast (const FastParams &fp, const FrameBatch &batch, int n, hipStream_t stream)
 {
-  static int cfg[5] = {-1, 0, 0, 0, 0};
-  if (cfg[0] == -1) {
-    const char *e = getenv ("GSTAMD_FAST_VARIANT");
-    cfg[0] = 0;
-    if (e)
-      sscanf (e, "%d,%d,%d,%d,%d", &cfg[0], &cfg[1], &cfg[2], &cfg[3], &cfg[4]);
-  }
-  if (cfg[0] == 0)
-    return false;
-  const int npx = cfg[0], abl = cfg[1], groups = cfg[2], bx = cfg[3];
-  if (npx == 1024) {                      /* wide variant */
-    if (abl)
-      launch_wide_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, stream);
-    else
-      launch_wide_variant<CHROMA_H_H2_CS, 0> (fp, batch, n, stream);
-    return true;
-  }
-  if (npx == 4096)                        /* force the strip shape */
-    return false;
-  if (groups >= 100) {                    /* strip variant: groups = 100 + K */
-    const int K = groups - 100;
-#define S(N, A) if (npx == N && abl == A) { launch_strip_variant<CHROMA_H_H2_CS, N, A> (fp, batch, n, bx, K, stream, cfg[4]); return true; }
-    S (4, 0) S (4, 1) S (8, 0) S (8, 1)
-#undef S
-    return false;
-  }
-  if (fp.width % (npx) != 0)
-    return false;
-#define V(N, A, G) if (npx == N && abl == A && groups == G) { launch_pair_variant<CHROMA_H_H2_CS, N, A, G> (fp, batch, n, bx, stream); return true; }
-#define L(N, A) if (npx == N && abl == A && groups == 0) { launch_line_variant<CHROMA_H_H2_CS, N, A> (fp, batch, n, bx, stream); return true; }
-  L (4, 0) L (4, 1) L (8, 0) L (8, 1)
-#undef L
-  V (4, 0, 1) V (4, 1, 1) V (4, 0, 2) V (4, 1, 2) V (4, 0, 4) V (4, 1, 4)
-  V (8, 0, 1) V (8, 1, 1) V (8, 0, 2) V (8, 1, 2)
-  V (16, 0, 1) V (16, 1, 1)
-#undef V
-  return false;
+  /* shipped configuration (MI355X sweeps, profiles/r01_c2_variants.txt): strip kernel, 4-pixel columns, 3 line pairs per
+   * lane with the next pair's loads in flight during the current pair's math, one wave per workgroup */
+  const FastVariant &v = fast_variant ();
+  const int shape = v.set ? v.shape : 0, K = v.set && v.K > 0 ? v.K : 3;
+  if (v.set && v.abl && CH == CHROMA_H_H2_CS)
+    return shape == 1 ? launch_wide_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, K, stream) :
+        launch_strip_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, K, v.order != 0, stream);
+  if (shape == 1 && fp.width >= GSTAMD_WIDE_PX / 2)
+    return launch_wide_variant<CH, 0> (fp, batch, n, K, stream);
+  return launch_strip_variant<CH, 0> (fp, batch, n, K, v.set && v.order != 0, stream);
 }
 
 hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames, const uint8_t *const *y, const uint8_t *const *uv,
@@ -411,39 +361,20 @@ hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames
     batch.ystride = ystride;
     batch.uvstride = uvstride;
     batch.dstride = dstride;
-    if (chroma_h == CHROMA_H_H2_CS && launch_pair_experiment (fp, batch, n, stream))
-      continue;
-    /* shipped configuration (MI355X sweeps, profiles/r01_c2_variants*.txt, scripts/membench3.hip): images at least
-     * half a wave-run wide take the LDS-staged wide kernel, narrower ones the strip kernel (4-pixel columns, 3 line
-     * pairs per lane, one wave per workgroup) */
-    static int force_strip = -1;
-    if (force_strip < 0) {
-      const char *e = getenv ("GSTAMD_FAST_VARIANT");
-      force_strip = e && atoi (e) == 4096;
-    }
-    const int lay = wide_layout (fp);
-    const bool wide = fp.width >= GSTAMD_WIDE_PX / 2 && !force_strip && (lay == GSTAMD_LAYOUT (2, 1, 0) || lay == GSTAMD_LAYOUT (0, 1, 2) ||
-        lay == GSTAMD_LAYOUT (1, 2, 3) || lay == GSTAMD_LAYOUT (3, 2, 1));
+    bool ok;
     switch (chroma_h) {
       case CHROMA_H_H2_CS:
-        if (wide)
-          launch_wide_variant<CHROMA_H_H2_CS, 0> (fp, batch, n, stream);
-        else
-          launch_strip_variant<CHROMA_H_H2_CS, 4, 0> (fp, batch, n, 64, 3, stream, 1);
+        ok = launch_fast<CHROMA_H_H2_CS> (fp, batch, n, stream);
         break;
       case CHROMA_H_H2:
-        if (wide)
-          launch_wide_variant<CHROMA_H_H2, 0> (fp, batch, n, stream);
-        else
-          launch_strip_variant<CHROMA_H_H2, 4, 0> (fp, batch, n, 64, 3, stream, 1);
+        ok = launch_fast<CHROMA_H_H2> (fp, batch, n, stream);
         break;
       default:
-        if (wide)
-          launch_wide_variant<CHROMA_H_NONE, 0> (fp, batch, n, stream);
-        else
-          launch_strip_variant<CHROMA_H_NONE, 4, 0> (fp, batch, n, 64, 3, stream, 1);
+        ok = launch_fast<CHROMA_H_NONE> (fp, batch, n, stream);
         break;
     }
+    if (!ok)
+      return hipErrorInvalidValue;      /* destination byte order outside the four the planner admits */
   }
   return hipGetLastError ();
 }

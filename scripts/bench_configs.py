@@ -26,7 +26,14 @@ PEAK = 8000.0
 dev = torch.device("cuda:0")
 
 
-def timed(fn, iters, warmup=3):
+def timed(fn, iters, warmup=3, preheat_ms=60.0):
+    # from idle the device needs 20-30 ms of sustained load to reach its steady rate (scripts/clock_ramp.py)
+    t0, n = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < preheat_ms:
+        fn()
+        n += 1
+        if n % 16 == 0:
+            torch.cuda.synchronize()
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()

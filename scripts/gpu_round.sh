@@ -7,7 +7,8 @@ timeout 900 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pyt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke exit $?" >> $R/smoke.log
 timeout 600 python bench.py > $R/bench.log 2>&1; echo "bench exit $?" >> $R/bench.log
 timeout 600 python bench.py --batch 1 --no-cpu-baseline > $R/bench_batch1.log 2>&1
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 3 --no-cpu-baseline"
+timeout 600 python bench.py --batch 8 --no-cpu-baseline > $R/bench_batch8.log 2>&1
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
 rm -rf $R/prof; cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$R/prof/trace" -o c2 -- $BENCH > "$GRAFT_REPO_ROOT/$R/prof_trace.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$R/prof/pmc_fetch" -o c2 -- $BENCH > "$GRAFT_REPO_ROOT/$R/prof_fetch.log" 2>&1

@@ -164,40 +164,31 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   uint8_t *d0 = dst + out->offset[0];
   const int dstride = out->stride[0];
   if (p.passes.empty () && p.fast_pair && vec_ok) {
+    /* vec_ok: 1 = shipped configuration (strip kernel, 3 line pairs per lane); 100 + K = strip kernel with K pairs;
+     * 200 + K = wide kernel (LDS-staged 1024-px runs) with K pairs per wave */
     const FastParams fp = emu_fast_params (p);
-    if (vec_ok >= 2 && vec_ok < 200) {    /* strip variant with K = vec_ok pairs per lane, 4- and 8-pixel columns */
-      const int pairs = fp.height / 2 + 1, K = vec_ok;
-      for (int p0 = 0; p0 < pairs; p0 += K)
-        for (int x0 = 0; x0 + 8 <= fp.width; x0 += 8) {
-          const int p1 = p0 + K < pairs ? p0 + K : pairs;
-          const bool four = ((x0 / 8) & 1) != 0;
-          switch (p.front.chroma_h) {
-            case CHROMA_H_H2_CS:
-              if (four) { fast_strip<CHROMA_H_H2_CS, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); fast_strip<CHROMA_H_H2_CS, 4, 0> (fp, pl, d0, dstride, x0 + 4, p0, p1); }
-              else fast_strip<CHROMA_H_H2_CS, 8, 0> (fp, pl, d0, dstride, x0, p0, p1);
-              break;
-            case CHROMA_H_H2:
-              if (four) { fast_strip<CHROMA_H_H2, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); fast_strip<CHROMA_H_H2, 4, 0> (fp, pl, d0, dstride, x0 + 4, p0, p1); }
-              else fast_strip<CHROMA_H_H2, 8, 0> (fp, pl, d0, dstride, x0, p0, p1);
-              break;
-            default:
-              if (four) { fast_strip<CHROMA_H_NONE, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); fast_strip<CHROMA_H_NONE, 4, 0> (fp, pl, d0, dstride, x0 + 4, p0, p1); }
-              else fast_strip<CHROMA_H_NONE, 8, 0> (fp, pl, d0, dstride, x0, p0, p1);
-              break;
-          }
-        }
-      return GSTAMD_OK;
+    const int pairs = fp.height / 2 + 1;
+    const int lay = GSTAMD_LAYOUT (fp.pack_pos[1], fp.pack_pos[2], fp.pack_pos[3]);
+#define FOR_LAYOUT(CH, CALL) \
+    if (lay == GSTAMD_LAYOUT (2, 1, 0)) { CALL (CH, GSTAMD_LAYOUT (2, 1, 0)) } \
+    else if (lay == GSTAMD_LAYOUT (0, 1, 2)) { CALL (CH, GSTAMD_LAYOUT (0, 1, 2)) } \
+    else if (lay == GSTAMD_LAYOUT (1, 2, 3)) { CALL (CH, GSTAMD_LAYOUT (1, 2, 3)) } \
+    else if (lay == GSTAMD_LAYOUT (3, 2, 1)) { CALL (CH, GSTAMD_LAYOUT (3, 2, 1)) } \
+    else return GSTAMD_ERR_UNSUPPORTED;
+#define FOR_CH(CALL) \
+    switch (p.front.chroma_h) { \
+      case CHROMA_H_H2_CS: FOR_LAYOUT (CHROMA_H_H2_CS, CALL) break; \
+      case CHROMA_H_H2: FOR_LAYOUT (CHROMA_H_H2, CALL) break; \
+      default: FOR_LAYOUT (CHROMA_H_NONE, CALL) break; \
     }
-    if (fp.width >= GSTAMD_WIDE_PX / 2) { /* shipped configuration, wide images: the LDS-staged wide kernel, wave by wave */
-      const int pairs = fp.height / 2 + 1, nxb = (fp.width + GSTAMD_WIDE_PX - 1) / GSTAMD_WIDE_PX;
-      const int K = vec_ok >= 200 ? vec_ok - 200 : 2, strips = (pairs + K - 1) / K;
+    if (vec_ok >= 200 && fp.width >= GSTAMD_WIDE_PX / 2) {
+      const int nxb = (fp.width + GSTAMD_WIDE_PX - 1) / GSTAMD_WIDE_PX;
+      const int K = vec_ok - 200 > 0 ? vec_ok - 200 : 1, strips = (pairs + K - 1) / K;
       const int blocks = wide_grid_blocks (nxb, strips);
       const bool vec = (((uintptr_t) pl.p[0] | (uintptr_t) pl.p[1]) % 16) == 0 && pl.stride[0] % 16 == 0 && pl.stride[1] % 16 == 0;
-      const int lay = GSTAMD_LAYOUT (fp.pack_pos[1], fp.pack_pos[2], fp.pack_pos[3]);
       static WideLds lds;
       static WideRegs regs[64];
-#define EMIT_L(CH, pr, pg, pb) if (lay == GSTAMD_LAYOUT (pr, pg, pb)) wide_emit<CH, GSTAMD_LAYOUT (pr, pg, pb), 0> (fp, d0, dstride, xw, pp, lane, &lds, k & 1);
-#define WAVE(CH) \
+#define WAVE(CH, LAY) \
       for (int b = 0; b < blocks; b++) { \
         int xb, S; \
         if (!wide_block_map (b, nxb, strips, &xb, &S)) \
@@ -215,31 +206,25 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
           for (int lane = 0; lane < 64; lane++) { \
             if (pp + 1 < p1) \
               wide_fetch<CH> (fp, pl, xw, pp + 1, lane, vec, regs[lane]); \
-            EMIT_L (CH, 2, 1, 0) EMIT_L (CH, 0, 1, 2) EMIT_L (CH, 1, 2, 3) EMIT_L (CH, 3, 2, 1) \
+            wide_emit<CH, LAY, 0> (fp, d0, dstride, xw, pp, lane, &lds, k & 1); \
           } \
         } \
       }
-      switch (p.front.chroma_h) {
-        case CHROMA_H_H2_CS: WAVE (CHROMA_H_H2_CS) break;
-        case CHROMA_H_H2: WAVE (CHROMA_H_H2) break;
-        default: WAVE (CHROMA_H_NONE) break;
-      }
+      FOR_CH (WAVE)
 #undef WAVE
-#undef EMIT_L
       return GSTAMD_OK;
     }
-    {                                     /* narrow images: 4-pixel columns, K = 3 */
-      const int pairs = fp.height / 2 + 1;
-      for (int p0 = 0; p0 < pairs; p0 += 3)
-        for (int x0 = 0; x0 + 4 <= fp.width; x0 += 4) {
-          const int p1 = p0 + 3 < pairs ? p0 + 3 : pairs;
-          switch (p.front.chroma_h) {
-            case CHROMA_H_H2_CS: fast_strip<CHROMA_H_H2_CS, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); break;
-            case CHROMA_H_H2: fast_strip<CHROMA_H_H2, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); break;
-            default: fast_strip<CHROMA_H_NONE, 4, 0> (fp, pl, d0, dstride, x0, p0, p1); break;
-          }
-        }
+    {
+      const int K = vec_ok >= 100 && vec_ok < 200 && vec_ok - 100 > 0 ? vec_ok - 100 : 3;
+#define STRIP(CH, LAY) \
+      for (int p0 = 0; p0 < pairs; p0 += K) \
+        for (int x0 = 0; x0 + 4 <= fp.width; x0 += 4) \
+          fast_strip<CH, LAY, 0> (fp, pl, d0, dstride, x0, p0, p0 + K < pairs ? p0 + K : pairs);
+      FOR_CH (STRIP)
+#undef STRIP
     }
+#undef FOR_CH
+#undef FOR_LAYOUT
     return GSTAMD_OK;
   }
   if (p.passes.empty ()) {

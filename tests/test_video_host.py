@@ -125,13 +125,14 @@ WIDE = [c for c in SMALL if c[1][1] in ("NV12", "NV21") and c[1][2] >= 512 and (
         and c[1][4] not in ("AYUV",)]
 
 
-@pytest.mark.parametrize("k", [1, 3, 5])
+@pytest.mark.parametrize("k", [101, 102, 105, 201, 203, 205])
 @pytest.mark.parametrize("idx_case", WIDE, ids=lambda c: c[1][0])
-def test_wide_kernel_body_any_pairs_per_wave(native_lib, emu_lib, idx_case, k):
-    """The wide kernel's strip length (line pairs per wave) is a tuning knob: results must not depend on it."""
+def test_fast_kernel_bodies_any_pairs_per_wave(native_lib, emu_lib, idx_case, k):
+    """Strip (100 + K) and wide (200 + K) kernel bodies: the strip length (line pairs per wave) is a tuning knob,
+    results must not depend on it."""
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
-    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src, vec=200 + k)
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src, vec=k)
     assert cases.sha(dst) == GOLDEN[name]["sha256"], name
 
 

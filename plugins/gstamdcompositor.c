@@ -1,0 +1,642 @@
+/* gstamdcompositor.c - `compositor` element backed by the MI355X aggregate kernel (C ABI of include/gstamd_video.h).
+ *
+ * Mirrors the reference element's contract for the blend path
+ * (subprojects/gst-plugins-base/gst/compositor/compositor.c):
+ *   - factory name `compositor`, request pads `sink_%u`                        compositor.c:112, 2180
+ *   - pad properties xpos / ypos / width / height / alpha / operator (+ zorder, which the reference inherits from
+ *     GstVideoAggregatorPad) with the reference names, ranges and defaults      compositor.c:678-714
+ *   - element property background (checker / black / white / transparent)       compositor.c:2103-2120
+ *   - output size = bounding box of the pads (xpos + width, ypos + height)       compositor.c:1060-1160 (_fixate_caps)
+ *   - one output frame = background fill + pads blended in zorder               compositor.c:1619-1697, 1739-1870
+ * The reference subclasses GstVideoAggregator; this element sits directly on GstAggregator (public in libgstbase
+ * since 1.14, which is the runtime available here) and does the small part of GstVideoAggregator the blend path
+ * needs.  All pads of one frame go to the GPU in ONE fused kernel launch (gstamd_compositor_aggregate): every canvas
+ * pixel is written once, where the reference read-modify-writes the canvas once per pad.
+ *
+ * Simplifications kept honest: every aggregate() consumes one buffer from each pad that has one (lock-step, no
+ * timestamp-based frame selection / repeat as in gstvideoaggregator.c:1700-2000); pads must carry the output
+ * format (put `videoconvertscale` in front; the reference converts per pad through GstVideoAggregatorConvertPad);
+ * width / height different from the pad's frame size (per-pad scaling) are refused; sizing-policy,
+ * zero-size-is-unscaled, max-threads and ignore-inactive-pads are not implemented.
+ */
+#include <gst/base/gstaggregator.h>
+#include <gst/gst.h>
+#include <gst/video/video.h>
+#include <string.h>
+
+#include "../include/gstamd_video.h"
+#include "gstamdhipmemory.h"
+
+GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
+#define GST_CAT_DEFAULT amd_comp_debug
+
+#define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV }"
+#define AMD_COMP_MAX_PADS 64
+
+static GstStaticPadTemplate comp_sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_COMP_FORMATS) ";"
+        GST_VIDEO_CAPS_MAKE (AMD_COMP_FORMATS)));
+static GstStaticPadTemplate comp_src_tmpl = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_COMP_FORMATS) ";"
+        GST_VIDEO_CAPS_MAKE (AMD_COMP_FORMATS)));
+
+/* ---- pad ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  GstAggregatorPad parent;
+  gint xpos, ypos, width, height;
+  gdouble alpha;
+  gint op;                     /* GstCompositorOperator: 0 source, 1 over, 2 add */
+  guint zorder;
+  GstVideoInfo info;
+  gboolean have_info;
+  gpointer staging;            /* device copy of a system-memory input frame */
+  gsize staging_size;
+} GstAmdCompositorPadObj;
+
+typedef struct { GstAggregatorPadClass parent_class; } GstAmdCompositorPadObjClass;
+
+enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_ZORDER };
+
+G_DEFINE_TYPE (GstAmdCompositorPadObj, gst_amd_compositor_pad, GST_TYPE_AGGREGATOR_PAD);
+#define AMD_COMP_PAD(o) ((GstAmdCompositorPadObj *) (o))
+
+static GType
+amd_comp_operator_get_type (void)
+{
+  static GType t = 0;
+  static const GEnumValue v[] = { {0, "Source", "source"}, {1, "Over", "over"}, {2, "Add", "add"}, {0, NULL, NULL} };
+  if (!t)
+    t = g_enum_register_static ("GstAmdCompositorOperator", v);
+  return t;
+}
+
+static GType
+amd_comp_background_get_type (void)
+{
+  static GType t = 0;
+  static const GEnumValue v[] = { {0, "Checker pattern", "checker"}, {1, "Black", "black"}, {2, "White", "white"},
+    {3, "Transparent Background to enable further compositing", "transparent"}, {0, NULL, NULL} };
+  if (!t)
+    t = g_enum_register_static ("GstAmdCompositorBackground", v);
+  return t;
+}
+
+static void
+amd_comp_pad_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
+{
+  GstAmdCompositorPadObj *p = AMD_COMP_PAD (object);
+  GST_OBJECT_LOCK (p);
+  switch (id) {
+    case PAD_PROP_XPOS: p->xpos = g_value_get_int (value); break;
+    case PAD_PROP_YPOS: p->ypos = g_value_get_int (value); break;
+    case PAD_PROP_WIDTH: p->width = g_value_get_int (value); break;
+    case PAD_PROP_HEIGHT: p->height = g_value_get_int (value); break;
+    case PAD_PROP_ALPHA: p->alpha = g_value_get_double (value); break;
+    case PAD_PROP_OPERATOR: p->op = g_value_get_enum (value); break;
+    case PAD_PROP_ZORDER: p->zorder = g_value_get_uint (value); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+  GST_OBJECT_UNLOCK (p);
+}
+
+static void
+amd_comp_pad_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
+{
+  GstAmdCompositorPadObj *p = AMD_COMP_PAD (object);
+  GST_OBJECT_LOCK (p);
+  switch (id) {
+    case PAD_PROP_XPOS: g_value_set_int (value, p->xpos); break;
+    case PAD_PROP_YPOS: g_value_set_int (value, p->ypos); break;
+    case PAD_PROP_WIDTH: g_value_set_int (value, p->width); break;
+    case PAD_PROP_HEIGHT: g_value_set_int (value, p->height); break;
+    case PAD_PROP_ALPHA: g_value_set_double (value, p->alpha); break;
+    case PAD_PROP_OPERATOR: g_value_set_enum (value, p->op); break;
+    case PAD_PROP_ZORDER: g_value_set_uint (value, p->zorder); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+  GST_OBJECT_UNLOCK (p);
+}
+
+static void
+amd_comp_pad_finalize (GObject * object)
+{
+  GstAmdCompositorPadObj *p = AMD_COMP_PAD (object);
+  gstamd_device_free (p->staging);
+  G_OBJECT_CLASS (gst_amd_compositor_pad_parent_class)->finalize (object);
+}
+
+static void
+gst_amd_compositor_pad_class_init (GstAmdCompositorPadObjClass * klass)
+{
+  GObjectClass *oc = (GObjectClass *) klass;
+  const GParamFlags f = G_PARAM_READWRITE | GST_PARAM_CONTROLLABLE | G_PARAM_STATIC_STRINGS;
+  oc->set_property = amd_comp_pad_set_property;
+  oc->get_property = amd_comp_pad_get_property;
+  oc->finalize = amd_comp_pad_finalize;
+  /* names, ranges and defaults of compositor.c:678-714 (+ zorder of gstvideoaggregator.c:150-160) */
+  g_object_class_install_property (oc, PAD_PROP_XPOS, g_param_spec_int ("xpos", "X Position", "X Position of the picture", G_MININT, G_MAXINT, 0, f));
+  g_object_class_install_property (oc, PAD_PROP_YPOS, g_param_spec_int ("ypos", "Y Position", "Y Position of the picture", G_MININT, G_MAXINT, 0, f));
+  g_object_class_install_property (oc, PAD_PROP_WIDTH, g_param_spec_int ("width", "Width", "Width of the picture", G_MININT, G_MAXINT, -1, f));
+  g_object_class_install_property (oc, PAD_PROP_HEIGHT, g_param_spec_int ("height", "Height", "Height of the picture", G_MININT, G_MAXINT, -1, f));
+  g_object_class_install_property (oc, PAD_PROP_ALPHA, g_param_spec_double ("alpha", "Alpha", "Alpha of the picture", 0.0, 1.0, 1.0, f));
+  g_object_class_install_property (oc, PAD_PROP_OPERATOR, g_param_spec_enum ("operator", "Operator",
+          "Blending operator to use for blending this pad over the previous ones", amd_comp_operator_get_type (), 1, f));
+  g_object_class_install_property (oc, PAD_PROP_ZORDER, g_param_spec_uint ("zorder", "Z-Order", "Z Order of the picture", 0, G_MAXUINT, 0, f));
+}
+
+static void
+gst_amd_compositor_pad_init (GstAmdCompositorPadObj * p)
+{
+  p->xpos = p->ypos = 0;
+  p->width = p->height = -1;
+  p->alpha = 1.0;
+  p->op = 1;
+  p->zorder = 0;
+  p->have_info = FALSE;
+}
+
+/* ---- element -------------------------------------------------------------------------------------------- */
+typedef struct {
+  GstAggregator parent;
+  gint background;
+  GstVideoInfo out_info;
+  gboolean have_out, out_hip;
+  gpointer d_out;              /* device canvas when downstream wants system memory */
+  gsize d_out_size;
+  guint64 n_frames;
+  guint next_pad;
+} GstAmdCompositor;
+
+typedef struct { GstAggregatorClass parent_class; } GstAmdCompositorClass;
+
+enum { PROP_0, PROP_BACKGROUND };
+
+/* GstChildProxy (as gstvideoaggregator.c does): lets `sink_1::xpos=..` address pad properties from gst-launch */
+static GObject *
+amd_comp_child_by_index (GstChildProxy * proxy, guint index)
+{
+  GObject *obj;
+  GST_OBJECT_LOCK (proxy);
+  obj = g_list_nth_data (GST_ELEMENT_CAST (proxy)->sinkpads, index);
+  if (obj)
+    gst_object_ref (obj);
+  GST_OBJECT_UNLOCK (proxy);
+  return obj;
+}
+
+static guint
+amd_comp_children_count (GstChildProxy * proxy)
+{
+  guint n;
+  GST_OBJECT_LOCK (proxy);
+  n = GST_ELEMENT_CAST (proxy)->numsinkpads;
+  GST_OBJECT_UNLOCK (proxy);
+  return n;
+}
+
+static void
+amd_comp_child_proxy_init (gpointer g_iface, gpointer iface_data)
+{
+  GstChildProxyInterface *iface = g_iface;
+  iface->get_child_by_index = amd_comp_child_by_index;
+  iface->get_children_count = amd_comp_children_count;
+}
+
+G_DEFINE_TYPE_WITH_CODE (GstAmdCompositor, gst_amd_compositor, GST_TYPE_AGGREGATOR,
+    G_IMPLEMENT_INTERFACE (GST_TYPE_CHILD_PROXY, amd_comp_child_proxy_init));
+#define AMD_COMP(o) ((GstAmdCompositor *) (o))
+
+static GstPad *
+amd_comp_request_new_pad (GstElement * element, GstPadTemplate * templ, const gchar * req_name, const GstCaps * caps)
+{
+  GstPad *pad = GST_ELEMENT_CLASS (g_type_class_peek_parent (G_OBJECT_GET_CLASS (element)))->request_new_pad (element, templ, req_name, caps);
+  if (pad)
+    gst_child_proxy_child_added (GST_CHILD_PROXY (element), G_OBJECT (pad), GST_OBJECT_NAME (pad));
+  return pad;
+}
+
+static void
+amd_comp_release_pad (GstElement * element, GstPad * pad)
+{
+  gst_child_proxy_child_removed (GST_CHILD_PROXY (element), G_OBJECT (pad), GST_OBJECT_NAME (pad));
+  GST_ELEMENT_CLASS (g_type_class_peek_parent (G_OBJECT_GET_CLASS (element)))->release_pad (element, pad);
+}
+
+static int
+amd_format_of (GstVideoFormat f)
+{
+  switch (f) {
+    case GST_VIDEO_FORMAT_BGRA: return GSTAMD_VIDEO_FORMAT_BGRA;
+    case GST_VIDEO_FORMAT_RGBA: return GSTAMD_VIDEO_FORMAT_RGBA;
+    case GST_VIDEO_FORMAT_ARGB: return GSTAMD_VIDEO_FORMAT_ARGB;
+    case GST_VIDEO_FORMAT_ABGR: return GSTAMD_VIDEO_FORMAT_ABGR;
+    case GST_VIDEO_FORMAT_AYUV: return GSTAMD_VIDEO_FORMAT_AYUV;
+    default: return 0;
+  }
+}
+
+static void
+amd_comp_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
+{
+  if (id == PROP_BACKGROUND)
+    AMD_COMP (object)->background = g_value_get_enum (value);
+  else
+    G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
+}
+
+static void
+amd_comp_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
+{
+  if (id == PROP_BACKGROUND)
+    g_value_set_enum (value, AMD_COMP (object)->background);
+  else
+    G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
+}
+
+static GstAggregatorPad *
+amd_comp_create_new_pad (GstAggregator * agg, GstPadTemplate * templ, const gchar * req_name, const GstCaps * caps)
+{
+  GstAmdCompositor *c = AMD_COMP (agg);
+  guint serial = 0;
+  gchar *name;
+  GstAmdCompositorPadObj *pad;
+
+  if (templ->direction != GST_PAD_SINK || !g_str_has_prefix (templ->name_template, "sink_"))
+    return NULL;
+  GST_OBJECT_LOCK (agg);
+  if (req_name && strlen (req_name) > 5 && g_str_has_prefix (req_name, "sink_")) {
+    serial = (guint) g_ascii_strtoull (req_name + 5, NULL, 10);
+    if (serial >= c->next_pad)
+      c->next_pad = serial + 1;
+  } else {
+    serial = c->next_pad++;
+  }
+  GST_OBJECT_UNLOCK (agg);
+  name = g_strdup_printf ("sink_%u", serial);
+  pad = g_object_new (gst_amd_compositor_pad_get_type (), "name", name, "direction", GST_PAD_SINK, "template", templ, NULL);
+  g_free (name);
+  pad->zorder = serial;        /* new pads go on top, as in gst_video_aggregator_request_new_pad */
+  return GST_AGGREGATOR_PAD (pad);
+}
+
+static gboolean
+amd_comp_sink_event (GstAggregator * agg, GstAggregatorPad * apad, GstEvent * event)
+{
+  if (GST_EVENT_TYPE (event) == GST_EVENT_CAPS) {
+    GstAmdCompositorPadObj *p = AMD_COMP_PAD (apad);
+    GstCaps *caps;
+    gst_event_parse_caps (event, &caps);
+    GST_OBJECT_LOCK (p);
+    p->have_info = gst_video_info_from_caps (&p->info, caps) && amd_format_of (GST_VIDEO_INFO_FORMAT (&p->info)) != 0;
+    GST_OBJECT_UNLOCK (p);
+    if (!p->have_info) {
+      GST_ERROR_OBJECT (apad, "unsupported caps %" GST_PTR_FORMAT, caps);
+      gst_event_unref (event);
+      return FALSE;
+    }
+    gst_pad_mark_reconfigure (agg->srcpad);
+  }
+  return GST_AGGREGATOR_CLASS (gst_amd_compositor_parent_class)->sink_event (agg, apad, event);
+}
+
+static gboolean
+amd_comp_sink_query (GstAggregator * agg, GstAggregatorPad * apad, GstQuery * query)
+{
+  if (GST_QUERY_TYPE (query) == GST_QUERY_CAPS) {
+    /* any size / framerate; the format has to be the one the output uses once that is known */
+    GstAmdCompositor *c = AMD_COMP (agg);
+    GstCaps *filter, *tmpl = gst_pad_get_pad_template_caps (GST_PAD (apad)), *res;
+    gst_query_parse_caps (query, &filter);
+    if (c->have_out) {
+      GstCaps *fmt = gst_caps_new_simple ("video/x-raw", "format", G_TYPE_STRING,
+          gst_video_format_to_string (GST_VIDEO_INFO_FORMAT (&c->out_info)), NULL);
+      GstCaps *fmt_hip = gst_caps_copy (fmt);
+      gst_caps_set_features (fmt_hip, 0, gst_caps_features_from_string (GST_CAPS_FEATURE_MEMORY_AMD_HIP));
+      gst_caps_append (fmt_hip, fmt);
+      res = gst_caps_intersect_full (tmpl, fmt_hip, GST_CAPS_INTERSECT_FIRST);
+      gst_caps_unref (fmt_hip);
+      gst_caps_unref (tmpl);
+      tmpl = res;
+    }
+    if (filter) {
+      res = gst_caps_intersect_full (filter, tmpl, GST_CAPS_INTERSECT_FIRST);
+      gst_caps_unref (tmpl);
+    } else {
+      res = tmpl;
+    }
+    gst_query_set_caps_result (query, res);
+    gst_caps_unref (res);
+    return TRUE;
+  }
+  if (GST_QUERY_TYPE (query) == GST_QUERY_ACCEPT_CAPS) {
+    GstCaps *caps, *tmpl = gst_pad_get_pad_template_caps (GST_PAD (apad));
+    gst_query_parse_accept_caps (query, &caps);
+    gst_query_set_accept_caps_result (query, gst_caps_can_intersect (caps, tmpl));
+    gst_caps_unref (tmpl);
+    return TRUE;
+  }
+  return GST_AGGREGATOR_CLASS (gst_amd_compositor_parent_class)->sink_query (agg, apad, query);
+}
+
+/* bounding box of the pads, best framerate, the pads' common format (compositor.c _fixate_caps / _update_caps) */
+static GstFlowReturn
+amd_comp_update_src_caps (GstAggregator * agg, GstCaps * caps, GstCaps ** ret)
+{
+  GList *l;
+  gint best_w = 0, best_h = 0, fps_n = 0, fps_d = 1;
+  gdouble best_fps = -1.0;
+  GstVideoFormat fmt = GST_VIDEO_FORMAT_UNKNOWN;
+  gboolean all = TRUE, any = FALSE;
+  GstCaps *want, *want_hip;
+
+  GST_OBJECT_LOCK (agg);
+  for (l = GST_ELEMENT (agg)->sinkpads; l; l = l->next) {
+    GstAmdCompositorPadObj *p = AMD_COMP_PAD (l->data);
+    gint w, h;
+    gdouble fps;
+    if (!p->have_info) {
+      all = FALSE;
+      continue;
+    }
+    any = TRUE;
+    w = p->xpos + GST_VIDEO_INFO_WIDTH (&p->info);
+    h = p->ypos + GST_VIDEO_INFO_HEIGHT (&p->info);
+    best_w = MAX (best_w, w);
+    best_h = MAX (best_h, h);
+    if (fmt == GST_VIDEO_FORMAT_UNKNOWN)
+      fmt = GST_VIDEO_INFO_FORMAT (&p->info);
+    fps = GST_VIDEO_INFO_FPS_D (&p->info) ? (gdouble) GST_VIDEO_INFO_FPS_N (&p->info) / GST_VIDEO_INFO_FPS_D (&p->info) : 0.0;
+    if (fps > best_fps) {
+      best_fps = fps;
+      fps_n = GST_VIDEO_INFO_FPS_N (&p->info);
+      fps_d = GST_VIDEO_INFO_FPS_D (&p->info);
+    }
+  }
+  GST_OBJECT_UNLOCK (agg);
+  if (!any || !all)
+    return GST_AGGREGATOR_FLOW_NEED_DATA;
+  if (fps_d == 0 || fps_n == 0) {
+    fps_n = 25;
+    fps_d = 1;
+  }
+  /* preferences: pads' format; downstream may still pick another size (the canvas is simply that big) */
+  want = gst_caps_new_simple ("video/x-raw", "format", G_TYPE_STRING, gst_video_format_to_string (fmt),
+      "framerate", GST_TYPE_FRACTION, fps_n, fps_d, "pixel-aspect-ratio", GST_TYPE_FRACTION, 1, 1, NULL);
+  want_hip = gst_caps_copy (want);
+  gst_caps_set_features (want_hip, 0, gst_caps_features_from_string (GST_CAPS_FEATURE_MEMORY_AMD_HIP));
+  gst_caps_append (want_hip, want);
+  *ret = gst_caps_intersect_full (caps, want_hip, GST_CAPS_INTERSECT_FIRST);
+  gst_caps_unref (want_hip);
+  g_object_set_data (G_OBJECT (agg), "amd-best-w", GINT_TO_POINTER (best_w));
+  g_object_set_data (G_OBJECT (agg), "amd-best-h", GINT_TO_POINTER (best_h));
+  return GST_FLOW_OK;
+}
+
+static GstCaps *
+amd_comp_fixate_src_caps (GstAggregator * agg, GstCaps * caps)
+{
+  const gint best_w = GPOINTER_TO_INT (g_object_get_data (G_OBJECT (agg), "amd-best-w"));
+  const gint best_h = GPOINTER_TO_INT (g_object_get_data (G_OBJECT (agg), "amd-best-h"));
+  GstStructure *s;
+  caps = gst_caps_truncate (gst_caps_make_writable (caps));
+  s = gst_caps_get_structure (caps, 0);
+  gst_structure_fixate_field_nearest_int (s, "width", best_w > 0 ? best_w : 320);
+  gst_structure_fixate_field_nearest_int (s, "height", best_h > 0 ? best_h : 240);
+  return gst_caps_fixate (caps);
+}
+
+static gboolean
+amd_comp_negotiated_src_caps (GstAggregator * agg, GstCaps * caps)
+{
+  GstAmdCompositor *c = AMD_COMP (agg);
+  GstCapsFeatures *f = gst_caps_get_features (caps, 0);
+  if (!gst_video_info_from_caps (&c->out_info, caps) || !amd_format_of (GST_VIDEO_INFO_FORMAT (&c->out_info)))
+    return FALSE;
+  c->out_hip = f && gst_caps_features_contains (f, GST_CAPS_FEATURE_MEMORY_AMD_HIP);
+  c->have_out = TRUE;
+  GST_INFO_OBJECT (c, "output %" GST_PTR_FORMAT, caps);
+  return TRUE;
+}
+
+static gint
+pad_zorder_cmp (gconstpointer a, gconstpointer b)
+{
+  const GstAmdCompositorPadObj *pa = *(GstAmdCompositorPadObj * const *) a, *pb = *(GstAmdCompositorPadObj * const *) b;
+  return pa->zorder < pb->zorder ? -1 : (pa->zorder > pb->zorder ? 1 : 0);
+}
+
+static gboolean
+ensure_device (gpointer * p, gsize * have, gsize need)
+{
+  if (*have >= need)
+    return TRUE;
+  gstamd_device_free (*p);
+  *p = gstamd_device_alloc (need);
+  *have = *p ? need : 0;
+  return *p != NULL;
+}
+
+static GstFlowReturn
+amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
+{
+  GstAmdCompositor *c = AMD_COMP (agg);
+  GstAmdCompositorPadObj *pads[AMD_COMP_MAX_PADS];
+  GstBuffer *bufs[AMD_COMP_MAX_PADS];
+  GstMapInfo maps[AMD_COMP_MAX_PADS];
+  gboolean mapped_dev[AMD_COMP_MAX_PADS];
+  GstAmdCompositorPad desc[AMD_COMP_MAX_PADS];
+  GstBuffer *outbuf = NULL;
+  GstMapInfo omap;
+  GstMemory *omem = NULL;
+  gpointer canvas;
+  GstFlowReturn flow = GST_FLOW_OK;
+  GList *l;
+  guint n = 0, i, n_desc = 0;
+  gboolean all_eos = TRUE;
+  const int fmt = amd_format_of (GST_VIDEO_INFO_FORMAT (&c->out_info));
+  int r;
+
+  if (!c->have_out)
+    return GST_FLOW_NOT_NEGOTIATED;
+  memset (mapped_dev, 0, sizeof (mapped_dev));
+
+  GST_OBJECT_LOCK (agg);
+  for (l = GST_ELEMENT (agg)->sinkpads; l && n < AMD_COMP_MAX_PADS; l = l->next)
+    pads[n++] = gst_object_ref (l->data);
+  GST_OBJECT_UNLOCK (agg);
+  qsort (pads, n, sizeof (pads[0]), pad_zorder_cmp);
+
+  for (i = 0; i < n; i++) {
+    bufs[i] = gst_aggregator_pad_pop_buffer (GST_AGGREGATOR_PAD (pads[i]));
+    if (bufs[i] || !gst_aggregator_pad_is_eos (GST_AGGREGATOR_PAD (pads[i])))
+      all_eos = FALSE;
+  }
+  GST_LOG_OBJECT (c, "aggregate: %u pads, all_eos %d, timeout %d", n, all_eos, timeout);
+  if (all_eos) {
+    for (i = 0; i < n; i++)
+      gst_object_unref (pads[i]);
+    return GST_FLOW_EOS;
+  }
+
+  /* pads -> device pointers */
+  for (i = 0; i < n; i++) {
+    GstAmdCompositorPadObj *p = pads[i];
+    GstMemory *mem;
+    GstVideoMeta *vmeta;
+    const guint8 *base;
+    if (!bufs[i] || !p->have_info)
+      continue;
+    if (GST_VIDEO_INFO_FORMAT (&p->info) != GST_VIDEO_INFO_FORMAT (&c->out_info) ||
+        (p->width > 0 && p->width != GST_VIDEO_INFO_WIDTH (&p->info)) || (p->height > 0 && p->height != GST_VIDEO_INFO_HEIGHT (&p->info))) {
+      GST_ELEMENT_ERROR (c, STREAM, FORMAT, ("pad %s needs a conversion or scaling step", GST_OBJECT_NAME (p)),
+          ("put videoconvertscale in front of the pad: per-pad conversion is not built into this element"));
+      flow = GST_FLOW_NOT_NEGOTIATED;
+      goto done_inputs;
+    }
+    mem = gst_buffer_peek_memory (bufs[i], 0);
+    if (gst_buffer_n_memory (bufs[i]) == 1 && gst_is_amd_hip_memory (mem)) {
+      if (!gst_memory_map (mem, &maps[i], GST_MAP_READ | GST_MAP_AMDHIP)) {
+        flow = GST_FLOW_ERROR;
+        goto done_inputs;
+      }
+      mapped_dev[i] = TRUE;
+      base = maps[i].data;
+    } else {
+      GstMapInfo m;
+      if (!gst_buffer_map (bufs[i], &m, GST_MAP_READ)) {
+        flow = GST_FLOW_ERROR;
+        goto done_inputs;
+      }
+      if (!ensure_device (&p->staging, &p->staging_size, m.size) || gstamd_device_upload (p->staging, m.data, m.size, NULL) != GSTAMD_OK) {
+        gst_buffer_unmap (bufs[i], &m);
+        flow = GST_FLOW_ERROR;
+        goto done_inputs;
+      }
+      gst_buffer_unmap (bufs[i], &m);
+      base = p->staging;
+    }
+    vmeta = gst_buffer_get_video_meta (bufs[i]);
+    desc[n_desc].data = base + (vmeta ? vmeta->offset[0] : GST_VIDEO_INFO_PLANE_OFFSET (&p->info, 0));
+    desc[n_desc].width = GST_VIDEO_INFO_WIDTH (&p->info);
+    desc[n_desc].height = GST_VIDEO_INFO_HEIGHT (&p->info);
+    desc[n_desc].stride = vmeta ? vmeta->stride[0] : GST_VIDEO_INFO_PLANE_STRIDE (&p->info, 0);
+    desc[n_desc].xpos = p->xpos;
+    desc[n_desc].ypos = p->ypos;
+    desc[n_desc].alpha = p->alpha;
+    desc[n_desc].blend_mode = p->op;
+    desc[n_desc].reserved = 0;
+    n_desc++;
+  }
+
+  /* canvas */
+  if (c->out_hip) {
+    outbuf = gst_amd_hip_buffer_new_video (&c->out_info);
+    omem = outbuf ? gst_buffer_peek_memory (outbuf, 0) : NULL;
+    if (!omem || !gst_memory_map (omem, &omap, GST_MAP_WRITE | GST_MAP_AMDHIP)) {
+      flow = GST_FLOW_ERROR;
+      goto done_inputs;
+    }
+    canvas = omap.data;
+  } else {
+    outbuf = gst_buffer_new_allocate (NULL, GST_VIDEO_INFO_SIZE (&c->out_info), NULL);
+    if (!outbuf || !ensure_device (&c->d_out, &c->d_out_size, GST_VIDEO_INFO_SIZE (&c->out_info))) {
+      flow = GST_FLOW_ERROR;
+      goto done_inputs;
+    }
+    canvas = c->d_out;
+  }
+  r = gstamd_compositor_aggregate (fmt, c->background, desc, (int) n_desc, canvas, GST_VIDEO_INFO_WIDTH (&c->out_info),
+      GST_VIDEO_INFO_HEIGHT (&c->out_info), GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, 0), NULL);
+  if (c->out_hip) {
+    if (r == GSTAMD_OK)
+      r = gstamd_stream_synchronize (NULL);     /* staged inputs are reused by the next frame */
+    gst_memory_unmap (omem, &omap);
+  } else if (r == GSTAMD_OK) {
+    GstMapInfo m;
+    if (gst_buffer_map (outbuf, &m, GST_MAP_WRITE)) {
+      r = gstamd_device_download (m.data, c->d_out, m.size, NULL);        /* synchronises */
+      gst_buffer_unmap (outbuf, &m);
+    } else {
+      r = GSTAMD_ERR_INVALID;
+    }
+  }
+  if (r != GSTAMD_OK) {
+    flow = GST_FLOW_ERROR;
+    goto done_inputs;
+  }
+  /* timestamps: the running frame count at the output framerate (gst_video_aggregator_do_aggregate) */
+  if (GST_VIDEO_INFO_FPS_N (&c->out_info) > 0) {
+    const guint64 fn = GST_VIDEO_INFO_FPS_N (&c->out_info), fd = GST_VIDEO_INFO_FPS_D (&c->out_info);
+    GST_BUFFER_PTS (outbuf) = gst_util_uint64_scale (c->n_frames, fd * GST_SECOND, fn);
+    GST_BUFFER_DURATION (outbuf) = gst_util_uint64_scale (c->n_frames + 1, fd * GST_SECOND, fn) - GST_BUFFER_PTS (outbuf);
+  }
+  c->n_frames++;
+
+done_inputs:
+  for (i = 0; i < n; i++) {
+    if (bufs[i]) {
+      if (mapped_dev[i])
+        gst_memory_unmap (gst_buffer_peek_memory (bufs[i], 0), &maps[i]);
+      gst_buffer_unref (bufs[i]);
+    }
+    gst_object_unref (pads[i]);
+  }
+  if (flow != GST_FLOW_OK) {
+    if (outbuf)
+      gst_buffer_unref (outbuf);
+    if (flow == GST_FLOW_ERROR)
+      GST_ELEMENT_ERROR (c, LIBRARY, FAILED, ("HIP compositing failed"), ("%s", gstamd_last_error ()));
+    return flow;
+  }
+  return gst_aggregator_finish_buffer (agg, outbuf);
+}
+
+static gboolean
+amd_comp_stop (GstAggregator * agg)
+{
+  GstAmdCompositor *c = AMD_COMP (agg);
+  gstamd_device_free (c->d_out);
+  c->d_out = NULL;
+  c->d_out_size = 0;
+  c->have_out = FALSE;
+  c->n_frames = 0;
+  return TRUE;
+}
+
+static void
+gst_amd_compositor_class_init (GstAmdCompositorClass * klass)
+{
+  GObjectClass *oc = (GObjectClass *) klass;
+  GstElementClass *ec = (GstElementClass *) klass;
+  GstAggregatorClass *ac = (GstAggregatorClass *) klass;
+
+  GST_DEBUG_CATEGORY_INIT (amd_comp_debug, "amdcompositor", 0, "MI355X compositor");
+  oc->set_property = amd_comp_set_property;
+  oc->get_property = amd_comp_get_property;
+  g_object_class_install_property (oc, PROP_BACKGROUND, g_param_spec_enum ("background", "Background", "Background type",
+          amd_comp_background_get_type (), 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  gst_element_class_add_static_pad_template_with_gtype (ec, &comp_sink_tmpl, gst_amd_compositor_pad_get_type ());
+  /* the base class keeps its output segment in the src pad: it has to be a GstAggregatorPad */
+  gst_element_class_add_static_pad_template_with_gtype (ec, &comp_src_tmpl, GST_TYPE_AGGREGATOR_PAD);
+  gst_element_class_set_static_metadata (ec, "Compositor (MI355X/HIP)", "Filter/Editor/Video/Compositor",
+      "Composite multiple video streams in one fused GPU pass", "gstreamer_amd");
+  ec->request_new_pad = amd_comp_request_new_pad;
+  ec->release_pad = amd_comp_release_pad;
+  ac->create_new_pad = amd_comp_create_new_pad;
+  ac->sink_event = amd_comp_sink_event;
+  ac->sink_query = amd_comp_sink_query;
+  ac->update_src_caps = amd_comp_update_src_caps;
+  ac->fixate_src_caps = amd_comp_fixate_src_caps;
+  ac->negotiated_src_caps = amd_comp_negotiated_src_caps;
+  ac->aggregate = amd_comp_aggregate;
+  ac->stop = amd_comp_stop;
+}
+
+static void
+gst_amd_compositor_init (GstAmdCompositor * c)
+{
+  c->background = 0;
+  c->have_out = FALSE;
+  c->n_frames = 0;
+  c->next_pad = 0;
+}

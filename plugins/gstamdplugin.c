@@ -7,6 +7,7 @@
 
 GType gst_amd_video_convert_scale_get_type (void);
 GType gst_amd_audio_resample_get_type (void);
+GType gst_amd_compositor_get_type (void);
 
 static gboolean
 plugin_init (GstPlugin * plugin)
@@ -16,6 +17,8 @@ plugin_init (GstPlugin * plugin)
   ok &= gst_element_register (plugin, "amdvideoconvert", GST_RANK_MARGINAL + 1, gst_amd_video_convert_scale_get_type ());
   ok &= gst_element_register (plugin, "amdvideoscale", GST_RANK_MARGINAL + 1, gst_amd_video_convert_scale_get_type ());
   ok &= gst_element_register (plugin, "amdaudioresample", GST_RANK_PRIMARY + 1, gst_amd_audio_resample_get_type ());
+  /* the reference registers `compositor` with GST_RANK_PRIMARY + 1 (compositor.c, GST_ELEMENT_REGISTER_DEFINE) */
+  ok &= gst_element_register (plugin, "compositor", GST_RANK_PRIMARY + 1, gst_amd_compositor_get_type ());
   return ok;
 }
 

@@ -96,3 +96,48 @@ def test_audioresample_element_matches_reference(gst_env, ref):
     exp.append(rr.resample(None, in_frames=lat, out_frames=rr.get_out_frames(lat)))       # EOS drain
     exp = np.concatenate(exp)
     assert out.shape == exp.shape and (out == exp).all()
+
+
+def test_compositor_element_matches_reference(gst_env, ref):
+    """`compositor` element (GstAggregator subclass, plugins/gstamdcompositor.c): three BGRA pads with positions, pad
+    alpha, zorder and the `source` operator over the checker background, then a transparent background whose first pad
+    is a videoconvertscale output that stays in HBM.  Expected frames: the reference's own fill + blend functions
+    applied pad by pad in zorder (compositor.c:1619-1697)."""
+    env, tmp = gst_env
+    n, dw, dh = 3, 320, 240
+    pads = [("smpte", 320, 240, 0, 0, 1.0, 1), ("ball", 160, 120, 100, 80, 0.6, 1), ("snow", 64, 48, -10, 200, 0.8, 0)]
+    files = [tmp / ("cin%d.bgra" % i) for i in range(len(pads))]
+    fout = tmp / "cout.bgra"
+    desc = "compositor name=c background=checker"
+    for i, (pat, w, h, x, y, a, op) in enumerate(pads):
+        desc += " sink_%d::xpos=%d sink_%d::ypos=%d sink_%d::alpha=%s sink_%d::operator=%d" % (i, x, i, y, i, a, i, op)
+    desc += " ! video/x-raw,format=BGRA,width=%d,height=%d ! filesink location=%s" % (dw, dh, fout)
+    for i, (pat, w, h, x, y, a, op) in enumerate(pads):
+        desc += (" videotestsrc num-buffers=%d pattern=%s foreground-color=0x80ff4020 ! video/x-raw,format=BGRA,width=%d,height=%d,framerate=30/1 "
+                 "! tee name=t%d t%d. ! queue ! filesink location=%s t%d. ! queue ! c.sink_%d" % (n, pat, w, h, i, i, files[i], i, i))
+    launch(env, desc)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    ins = [np.fromfile(f, np.uint8).reshape(n, -1) for f in files]
+    for f in range(n):
+        canvas = np.zeros(dw * dh * 4, np.uint8)
+        ref.compositor_fill(0, "bgra", "BGRA", canvas, dw, dh, 0, dh)
+        for i, (pat, w, h, x, y, a, op) in enumerate(pads):
+            ref.compositor_blend("blend_bgra", "BGRA", ins[i][f], w, h, x, y, a, canvas, dw, dh, 0, dh, op)
+        assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
+
+    # transparent background -> overlay functions; pad 0 arrives as memory:AMDHIPMemory from videoconvertscale
+    fin0, fin1, fout2 = tmp / "o0.nv12", tmp / "o1.argb", tmp / "o.argb"
+    launch(env, "compositor name=c background=transparent sink_1::xpos=40 sink_1::ypos=30 sink_1::alpha=0.5 ! video/x-raw,format=ARGB ! filesink location=%s "
+                "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=256,height=144,framerate=30/1,colorimetry=bt601,chroma-site=jpeg "
+                "! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! videoconvertscale ! video/x-raw(memory:AMDHIPMemory),format=ARGB ! c.sink_0 "
+                "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=ARGB,width=128,height=72,framerate=30/1 "
+                "! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1" % (fout2, n, fin0, n, fin1))
+    out = np.fromfile(fout2, np.uint8).reshape(n, -1)
+    s0 = np.fromfile(fin0, np.uint8).reshape(n, -1)
+    s1 = np.fromfile(fin1, np.uint8).reshape(n, -1)
+    cv = ref.VideoConverter("NV12", 256, 144, "ARGB", 256, 144, in_colorimetry="bt601", in_chroma_site="jpeg")
+    for f in range(n):
+        canvas = np.zeros(256 * 144 * 4, np.uint8)        # transparent background = zero fill (compositor.c:1650)
+        ref.compositor_blend("overlay_argb", "ARGB", cv.frame(s0[f]), 256, 144, 0, 0, 1.0, canvas, 256, 144, 0, 144, 1)
+        ref.compositor_blend("overlay_argb", "ARGB", s1[f], 128, 72, 40, 30, 0.5, canvas, 256, 144, 0, 144, 1)
+        assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))

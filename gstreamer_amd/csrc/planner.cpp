@@ -268,7 +268,7 @@ void compute_convert_matrix (const VideoPlan &, int in_range, int in_matrix, int
 }
 
 /* prepare_matrix (video-converter.c:1323-1370) for current_bits == 8 */
-static void prepare_matrix8 (M44 dm, bool unpack_rgb, bool pack_rgb, MatrixParams *mp)
+static void prepare_matrix8 (M44 dm, bool unpack_rgb, bool pack_rgb, MatrixParams *mp, int im_raw[3][4])
 {
   int im[4][4];
   m_scale_components (dm, 256.0f, 256.0f, 256.0f);      /* SCALE_F */
@@ -278,7 +278,7 @@ static void prepare_matrix8 (M44 dm, bool unpack_rgb, bool pack_rgb, MatrixParam
   memset (mp, 0, sizeof (*mp));
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 4; j++)
-      mp->im[i][j] = im[i][j];
+      mp->im[i][j] = im_raw[i][j] = im[i][j];
   bool ayuv_to_rgb = (im[0][0] == im[1][0] && im[1][0] == im[2][0]) && im[0][1] == 0 && im[2][2] == 0;
   if (!unpack_rgb && pack_rgb && ayuv_to_rgb) {
     mp->kind = MATRIX_AYUV_ARGB;     /* video_converter_matrix8_AYUV_ARGB (:1209) */
@@ -844,9 +844,31 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   }
 
   const bool same_matrix = cfg.matrix_mode == GSTAMD_MATRIX_MODE_NONE ? true : in_matrix == out_matrix;
-  if (const char *fp = lookup_fastpath (*plan, alpha_bits, same_matrix))
-    return fail (GSTAMD_ERR_UNSUPPORTED, std::string ("reference takes fastpath ") + fp +
-        " for this conversion; no GPU kernel for it yet");
+  /* Fastpaths of the reference that are the generic chain with two decisions forced, reproduced by forcing them here:
+   *  - convert_I420_BGRA / _ARGB / _pack_ARGB (:6772-6990) and convert_I420_AYUV / Y42B_AYUV / Y444_AYUV (:3563, ..):
+   *    chroma is sampled nearest (row y >> 1, loadupdb), no interpolation;
+   *  - convert_I420_* and convert_AYUV_ARGB / _BGRA / _ABGR / _RGBA (:6544-6770): video_orc_convert_{I420,AYUV}_* with
+   *    (im[0][0], im[0][2], im[2][1], im[1][1], im[1][2]) of video_converter_compute_matrix (:1444), whatever the
+   *    matrix looks like - the arithmetic of video_orc_convert_AYUV_ARGB (video-orc.orc:1634, 1859);
+   *  - convert_scale_planes on a one-plane 4-byte format (setup_scale :7958-8075, convert_plane_hv :7693): the plane
+   *    goes through gst_video_scaler_2d as raw 4 x u8 pixels - no unpack / matrix / alpha / pack - and the order of the
+   *    two passes is the 2-D scaler's own rule (video-scaler.c:1542-1545), not chain_scale's. */
+  bool force_nearest = false, force_ayuv_argb = false, plane_scale = false;
+  if (const char *fp = lookup_fastpath (*plan, alpha_bits, same_matrix)) {
+    const std::string name = fp;
+    if (name == "convert_I420_xRGB")
+      force_nearest = force_ayuv_argb = true;
+    else if (name == "convert_AYUV_xRGB")
+      force_ayuv_argb = true;
+    else if (name == "convert_planar_AYUV")
+      force_nearest = true;
+    else if (name == "convert_scale_planes" && plan->fin->kind == UNPACK_PACKED4)
+      plane_scale = true;
+    else
+      return fail (GSTAMD_ERR_UNSUPPORTED, std::string ("reference takes fastpath ") + fp +
+          " for this conversion; no GPU kernel for it yet");
+    plan->ref_fastpath = fp;
+  }
 
   // ---- front: unpack + chroma upsample (chain_unpack_line, chain_upsample) ----------------------
   FrontParams &fr = plan->front;
@@ -873,6 +895,10 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         fr.chroma_v2 = 1;      /* video_chroma_up_v2_u8; the cosited variant is an h-only stub */
     }
   }
+  if (force_nearest) {
+    fr.chroma_h = CHROMA_H_NONE;
+    fr.chroma_v2 = 0;
+  }
 
   // ---- scaling (chain_scale :1685-1717 decides WHERE and in which ORDER) -------------------------
   plan->passes.clear ();
@@ -882,7 +908,13 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   plan->matrix_before_scale = need_scale && !(s3 <= s0);
   if (need_scale) {
     const long s1 = (long) out_w * in_h, s2 = (long) in_w * out_h;
-    const bool h_first = s1 <= s2;
+    bool h_first = s1 <= s2;
+    if (plane_scale && in_w != out_w && in_h != out_h) {
+      /* gst_video_scaler_2d: horizontal first iff width * voffset[height - 1] <= width * height */
+      ScalePass vp;
+      make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, in_h, out_h, false, &vp);
+      h_first = (long) out_w * (long) vp.offset[out_h - 1] <= (long) out_w * out_h;
+    }
     for (int step = 0; step < 2; step++) {
       bool horizontal = (step == 0) == h_first;
       int isz = horizontal ? in_w : in_h, osz = horizontal ? out_w : out_h;
@@ -922,11 +954,20 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
 
   // ---- colour matrix (chain_convert :1719-1868) --------------------------------------------------
   memset (&plan->matrix, 0, sizeof (plan->matrix));
-  if (!same_matrix) {
+  if (!same_matrix || force_ayuv_argb) {
     M44 dm;
     compute_convert_matrix (*plan, in->color_range, in_matrix, out->color_range, out_matrix, plan->fin->yuv,
         plan->fout->yuv, cfg.matrix_mode, dm);
-    prepare_matrix8 (dm, unpack_rgb, pack_rgb, &plan->matrix);
+    prepare_matrix8 (dm, unpack_rgb, pack_rgb, &plan->matrix, plan->im_raw);
+    if (force_ayuv_argb) {             /* the ORC parameters are 16-bit (.param 2) */
+      const int (*im)[4] = plan->im_raw;
+      plan->matrix.kind = MATRIX_AYUV_ARGB;
+      plan->matrix.p[0] = (int16_t) im[0][0];
+      plan->matrix.p[1] = (int16_t) im[0][2];
+      plan->matrix.p[2] = (int16_t) im[2][1];
+      plan->matrix.p[3] = (int16_t) im[1][1];
+      plan->matrix.p[4] = (int16_t) im[1][2];
+    }
   }
 
   // ---- alpha + pack ------------------------------------------------------------------------------
@@ -936,6 +977,12 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   post.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
   post.alpha_value = (int) (255 * cfg.alpha_value);
   memcpy (post.pack_pos, plan->fout->pos, sizeof (post.pack_pos));
+  if (plane_scale) {                   /* raw bytes in, raw bytes out */
+    for (int i = 0; i < 4; i++)
+      fr.pos[i] = post.pack_pos[i] = i;
+    post.alpha_kind = ALPHA_NONE;
+    plan->matrix_before_scale = false;
+  }
 
   simulate_vpairs (plan, out_h);
 
@@ -989,6 +1036,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     d += std::string (p.horizontal ? ",H" : ",V") + std::to_string (p.n_taps) + (p.dot4_ok ? "b" : "");    /* b: byte-dot-product taps */
   static const char *mk[] = {"none", "ayuv_argb", "table", "matrix8"};
   d += std::string (",matrix=") + mk[plan->matrix.kind] + (plan->matrix_before_scale ? "(pre)" : "") + "]";
+  if (!plan->ref_fastpath.empty ())
+    d += "{as " + plan->ref_fastpath + "}";
   plan->description = d;
   return GSTAMD_OK;
 }

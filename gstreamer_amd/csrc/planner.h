@@ -101,6 +101,8 @@ struct VideoPlan {
   std::vector<int32_t> vpair;     // [in_height][2]: (row_a | role << 30), row_b
   bool fast_pair;             // BASELINE C2 shape: line-pair kernel of video_fast.h is applicable
   bool fast_post;             // scaled plans: the post stage may run fast_pixel (matrix provably wrap-free, alpha stays 0xff)
+  int im_raw[3][4];           // the rint()ed 8-bit matrix before the per-kind adjustments
+  std::string ref_fastpath;   // name of the reference fastpath this plan reproduces (empty: generic chain)
   std::string description;
   uint64_t algorithmic_bytes;
 };

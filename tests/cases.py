@@ -67,6 +67,26 @@ VIDEO_CASES = [
     ("nv12_bgra_324x242_w4mod8", "NV12", 324, 242, "BGRA", 324, 242, {}, None, "mpeg2", "random"),
     ("nv12_rgba_1284x721_odd_h", "NV12", 1284, 721, "RGBA", 1284, 721, {}, None, None, "random"),
     ("nv21_abgr_130x70", "NV21", 130, 70, "ABGR", 130, 70, {}, None, None, "random"),
+    # reference fastpaths reproduced by the planner (nearest chroma / forced AYUV_ARGB matrix)
+    ("i420_bgra_322x241_fastpath", "I420", 322, 241, "BGRA", 322, 241, {}, None, None, "random"),
+    ("yv12_xrgb_640x360_fastpath", "YV12", 640, 360, "xRGB", 640, 360, {}, None, None, "random"),
+    ("i420_rgba_1280x720_fastpath_bt601", "I420", 1280, 720, "RGBA", 1280, 720, {}, "bt601", None, "random"),
+    ("i420_abgr_33x17_fastpath", "I420", 33, 17, "ABGR", 33, 17, {}, None, None, "random"),
+    ("ayuv_argb_64x64_fastpath", "AYUV", 64, 64, "ARGB", 64, 64, {}, None, None, "random"),
+    ("ayuv_bgrx_321x33_fastpath", "AYUV", 321, 33, "BGRx", 321, 33, {}, None, None, "random"),
+    ("i420_ayuv_322x241_fastpath", "I420", 322, 241, "AYUV", 322, 241, {}, None, None, "random"),
+    ("y42b_ayuv_130x70_fastpath", "Y42B", 130, 70, "AYUV", 130, 70, {}, None, None, "random"),
+    ("y444_ayuv_64x48_fastpath_alpha", "Y444", 64, 48, "AYUV", 64, 48, dict(alpha_mode="set", alpha_value=0.25), None, None, "random"),
+    ("i420_bgra_640x360_fastpath_matrix_none", "I420", 640, 360, "BGRA", 640, 360, dict(matrix_mode="none"), None, None, "random"),
+    # convert_scale_planes on one-plane 4-byte formats: raw 4 x u8 through the 2-D scaler's own pass order
+    ("bgra_bgra_half_lanczos_planes", "BGRA", 200, 100, "BGRA", 100, 50, LAN, None, None, "random"),
+    ("bgra_bgra_1080p_to_540p_cubic_planes", "BGRA", 1920, 1080, "BGRA", 960, 540, {}, None, None, "random"),
+    ("bgrx_bgrx_up_bilinear_planes", "BGRx", 160, 90, "BGRx", 333, 200, LIN, None, None, "random"),
+    ("argb_argb_mixed_lanczos_planes", "ARGB", 200, 100, "ARGB", 300, 50, LAN, None, None, "random"),
+    ("rgba_rgba_mixed2_cubic_planes", "RGBA", 200, 100, "RGBA", 120, 260, {}, None, None, "random"),
+    ("ayuv_ayuv_honly_nearest_planes", "AYUV", 200, 100, "AYUV", 77, 100, NEAR, None, None, "random"),
+    ("abgr_abgr_vonly_bilinear_planes", "ABGR", 200, 100, "ABGR", 200, 61, LIN, None, None, "random"),
+    ("bgra_bgra_copy_planes", "BGRA", 322, 241, "BGRA", 322, 241, {}, None, None, "random"),
     # wide-kernel tile edges: row ends exactly at a 1024-px run / one dword past it / inside a lane
     ("nv12_bgra_1024x34_jpeg", "NV12", 1024, 34, "BGRA", 1024, 34, {}, None, "jpeg", "random"),
     ("nv21_rgba_2048x18_mpeg2", "NV21", 2048, 18, "RGBA", 2048, 18, {}, None, "mpeg2", "random"),
@@ -103,9 +123,7 @@ VIDEO_CASES = [
 
 # conversions the reference runs through code this library has no kernel for -> must be REFUSED
 VIDEO_REFUSED = [
-    ("I420", 322, 241, "BGRA", 322, 241, {}),            # convert_I420_BGRA fastpath
-    ("BGRA", 200, 100, "BGRA", 100, 50, LAN),            # convert_scale_planes fastpath
-    ("AYUV", 64, 64, "ARGB", 64, 64, {}),                # convert_AYUV_ARGB fastpath
+    ("I420", 64, 64, "I420", 32, 32, {}),                # convert_scale_planes on planar formats: planar output
     ("NV12", 320, 180, "BGRA", 640, 100, LAN),           # reference temp-line aliasing (see planner.cpp)
     ("NV12", 64, 64, "NV12", 32, 32, {}),                # planar output not implemented
 ]

@@ -43,6 +43,7 @@ struct GstAmdVideoConverter {
   uint8_t *tmp = nullptr;       // intermediate image between two scaler passes
   size_t tmp_size = 0;
   int tmp_w = 0, tmp_h = 0;
+  uint8_t *pk_img = nullptr;              // planar destinations: the chain's AYUV image before chroma downsample + pack
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
 };
 
@@ -140,9 +141,16 @@ static int ensure_tables (GstAmdVideoConverter *c)
     if ((e = hipMalloc ((void **) &c->tmp, c->tmp_size)) != hipSuccess)
       return hip_fail (e, "hipMalloc(tmp)");
   }
+  if (p.out_planar) {
+    if ((e = hipMalloc ((void **) &c->pk_img, (size_t) p.out_info.width * 4 * p.out_info.height)) != hipSuccess)
+      return hip_fail (e, "hipMalloc(pack image)");
+  }
   c->tables_ready = true;
   return GSTAMD_OK;
 }
+
+// the chain up to a packed 4-byte image: unpack, chroma upsample, scale, matrix, alpha, byte order
+static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream);
 
 int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *const src_planes[GSTAMD_VIDEO_MAX_PLANES],
     const int32_t src_stride[GSTAMD_VIDEO_MAX_PLANES], void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
@@ -163,9 +171,28 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
     if (!pl.p[i])
       return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
   }
-  uint8_t *dst = (uint8_t *) dest_planes[0];
-  const int dstride = dest_stride ? dest_stride[0] : p.out_info.stride[0];
+  if (p.out_planar) {
+    /* chain -> AYUV image in HBM, then chroma downsample + pack into the destination planes */
+    uint8_t *planes[3] = {nullptr, nullptr, nullptr};
+    int strides[3] = {0, 0, 0};
+    for (int i = 0; i < p.out_info.n_planes && i < 3; i++) {
+      planes[i] = (uint8_t *) dest_planes[i];
+      strides[i] = dest_stride ? dest_stride[i] : p.out_info.stride[i];
+      if (!planes[i])
+        return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+    }
+    r = convert_to_packed (c, pl, c->pk_img, p.out_info.width * 4, stream);
+    if (r != GSTAMD_OK)
+      return r;
+    hipError_t e = launch_pack_planar (p.pack, c->pk_img, p.out_info.width * 4, planes, strides, stream);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_pack_planar");
+  }
+  return convert_to_packed (c, pl, (uint8_t *) dest_planes[0], dest_stride ? dest_stride[0] : p.out_info.stride[0], stream);
+}
 
+static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
+{
+  const VideoPlan &p = c->plan;
   ColorParams color, none;
   memset (&none, 0, sizeof (none));
   color.matrix = p.matrix;
@@ -295,6 +322,8 @@ void gstamd_video_converter_free (GstAmdVideoConverter *c)
   }
   if (c->tmp)
     (void) hipFree (c->tmp);
+  if (c->pk_img)
+    (void) hipFree (c->pk_img);
   delete c;
 }
 

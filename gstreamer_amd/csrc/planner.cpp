@@ -740,6 +740,16 @@ static const char *lookup_fastpath (const VideoPlan &p, int alpha_mode_bits, boo
   if (in == GSTAMD_VIDEO_FORMAT_AYUV && is_rgb4 (out) && same_size && !need_set && !need_mult
       && (!need_copy || p.fout->alpha))
     return "convert_AYUV_xRGB";
+  auto is_planar = [&](int f) { return is420 (f) || f == GSTAMD_VIDEO_FORMAT_Y42B || f == GSTAMD_VIDEO_FORMAT_Y444; };
+  /* planar -> planar, any size: convert_scale_planes plane by plane (no colour matrix) */
+  if (is_planar (in) && is_planar (out) && same_matrix && !need_copy && !need_set && !need_mult)
+    return "convert_scale_planes";
+  /* AYUV -> planar: convert_AYUV_I420 (even width and height) / _Y42B (even width) / _Y444, same size */
+  if (in == GSTAMD_VIDEO_FORMAT_AYUV && is_planar (out) && same_size && same_matrix && !need_copy && !need_mult) {
+    const int w = p.in_info.width, h = p.in_info.height;
+    if (is420 (out) ? (w % 2 == 0 && h % 2 == 0) : out == GSTAMD_VIDEO_FORMAT_Y42B ? w % 2 == 0 : true)
+      return "convert_AYUV_planar";
+  }
   /* planar YUV -> AYUV (keeps_size, no colour matrix) */
   if ((is420 (in) || in == GSTAMD_VIDEO_FORMAT_Y42B || in == GSTAMD_VIDEO_FORMAT_Y444)
       && out == GSTAMD_VIDEO_FORMAT_AYUV && same_size && same_matrix && !need_copy && !need_set && !need_mult)
@@ -812,8 +822,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     return fail (GSTAMD_ERR_UNSUPPORTED, "format not implemented on the GPU path");
   if (in->width <= 0 || in->height <= 0 || out->width <= 0 || out->height <= 0)
     return fail (GSTAMD_ERR_INVALID, "bad frame size");
-  if (plan->fout->kind != UNPACK_PACKED4)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "planar/semi-planar output (chroma downsample + pack) not implemented yet");
+  plan->out_planar = plan->fout->kind != UNPACK_PACKED4;
   if (cfg.dither_quantization != 1)
     return fail (GSTAMD_ERR_UNSUPPORTED, "dither-quantization != 1 not implemented");
 
@@ -977,6 +986,31 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   post.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
   post.alpha_value = (int) (255 * cfg.alpha_value);
   memcpy (post.pack_pos, plan->fout->pos, sizeof (post.pack_pos));
+  memset (&plan->pack, 0, sizeof (plan->pack));
+  if (plan->out_planar) {
+    /* the chain ends in AYUV (the unpack format of every planar YUV format); chain_downsample (:2040) +
+     * video_converter_compute_resample (:2850-2895): the downsampler exists when anything about the chroma grid
+     * differs between input and output and the chroma mode allows it */
+    const FormatDesc *fo = plan->fout;
+    PackPlanarParams &pk = plan->pack;
+    pk.width = out->width;
+    pk.height = out->height;
+    pk.kind = fo->kind;
+    pk.w_sub = fo->w_sub;
+    pk.h_sub = fo->h_sub;
+    pk.u_plane = fo->u_plane;
+    pk.v_plane = fo->v_plane;
+    const bool differs = plan->fin->w_sub != fo->w_sub || plan->fin->h_sub != fo->h_sub ||
+        in->chroma_site != out->chroma_site || in->width != out->width || in->height != out->height;
+    if (differs && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY) {
+      if (fo->w_sub == 1)
+        pk.down_h = (out->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? 2 : 1;
+      if (fo->h_sub == 1 && !(out->chroma_site & GSTAMD_CHROMA_SITE_V_COSITED))
+        pk.down_v = 1;          /* the cosited vertical variant is an h-only stub (video-chroma.c:996) */
+    }
+    for (int i = 0; i < 4; i++)
+      post.pack_pos[i] = i;
+  }
   if (plane_scale) {                   /* raw bytes in, raw bytes out */
     for (int i = 0; i < 4; i++)
       fr.pos[i] = post.pack_pos[i] = i;
@@ -997,7 +1031,13 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       uint64_t cw = ((uint64_t) in_w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) in_h + (1 << f->h_sub) - 1) >> f->h_sub;
       rd = (uint64_t) in_w * in_h + 2 * cw * ch;
     }
-    plan->algorithmic_bytes = rd + (uint64_t) out_w * out_h * 4;
+    uint64_t wr = (uint64_t) out_w * out_h * 4;
+    if (plan->out_planar) {
+      const FormatDesc *fo = plan->fout;
+      uint64_t cw = ((uint64_t) out_w + (1 << fo->w_sub) - 1) >> fo->w_sub, ch = ((uint64_t) out_h + (1 << fo->h_sub) - 1) >> fo->h_sub;
+      wr = (uint64_t) out_w * out_h + 2 * cw * ch;
+    }
+    plan->algorithmic_bytes = rd + wr;
   }
   /* the line-pair kernel (video_fast.h): unscaled 4:2:0 semi-planar -> 4-byte RGB through the AYUV_ARGB
    * matrix, with ORC's 16-bit addw wrap provably out of reach: |mulhsw (s, p)| <= (32896 * |p| >> 16) + 1 */
@@ -1038,6 +1078,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   d += std::string (",matrix=") + mk[plan->matrix.kind] + (plan->matrix_before_scale ? "(pre)" : "") + "]";
   if (!plan->ref_fastpath.empty ())
     d += "{as " + plan->ref_fastpath + "}";
+  if (plan->out_planar)
+    d += std::string ("+pack_planar[h") + std::to_string (plan->pack.down_h) + ",v" + std::to_string (plan->pack.down_v) + "]";
   plan->description = d;
   return GSTAMD_OK;
 }

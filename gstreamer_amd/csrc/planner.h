@@ -62,6 +62,17 @@ struct FrontParams {    // unpack + chroma upsample of the source frame (functio
   int chroma_v2;        // 1: vertical 2x upsample through the pair table
 };
 
+// planar / semi-planar destination: chroma downsample (video-chroma.c) + pack (video-format.c pack_planar_420 / pack_NV12 /
+// pack_Y42B / pack_Y444) of the final AYUV image
+struct PackPlanarParams {
+  int width, height;    // output size
+  int kind;             // UnpackKind of the destination: UNPACK_PLANAR or UNPACK_SEMI
+  int w_sub, h_sub;
+  int u_plane, v_plane; // planar: plane index of U and V; semi: u_first (1) / v_first (0) in u_plane
+  int down_h;           // 0: the even pixel's chroma as it is, 1: video_orc_chroma_down_h2_u8, 2: video_chroma_down_h2_cs_u8
+  int down_v;           // 0: the even line's chroma as it is, 1: video_orc_chroma_down_v2_u8 over lines (2r, 2r+1)
+};
+
 enum ScaleKind : int { SCALE_NONE = 0, SCALE_NEAREST = 1, SCALE_2TAP = 2, SCALE_NTAP = 3 };
 
 struct ScalePass {
@@ -99,6 +110,8 @@ struct VideoPlan {
   // chroma vertical pairing, one entry per source line: chroma rows of the pair's first and second
   // line and which of the two this line is (0 first / 1 second); rows equal => plain copy
   std::vector<int32_t> vpair;     // [in_height][2]: (row_a | role << 30), row_b
+  bool out_planar;            // destination is planar / semi-planar: the chain renders AYUV, pack_planar finishes
+  PackPlanarParams pack;
   bool fast_pair;             // BASELINE C2 shape: line-pair kernel of video_fast.h is applicable
   bool fast_post;             // scaled plans: the post stage may run fast_pixel (matrix provably wrap-free, alpha stays 0xff)
   int im_raw[3][4];           // the rint()ed 8-bit matrix before the per-kind adjustments

@@ -28,4 +28,7 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
     const ScaleDev &sh, const ScaleDev &sv, bool h_first, uint8_t *dst, int dstride, const ColorParams &post,
     const int pack_pos[4], int out_w, int out_h, int h_span, TileGeom geom, const PostFast &pf, hipStream_t stream);
 
+hipError_t launch_pack_planar (const PackPlanarParams &pk, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],
+    hipStream_t stream);
+
 }  // namespace gstamd

@@ -14,6 +14,7 @@
 #include "video_device.h"
 #include "video_fast.h"
 #include "video_scale_fast.h"
+#include "video_pack.h"
 
 namespace gstamd {
 
@@ -172,6 +173,11 @@ template <class SRC>
 __global__ __launch_bounds__ (256) void k_vscale (SRC src, ScaleDev sd, Dst dst, int width, int out_h)
 {
   vscale_body<SRC> (src, sd, dst, width, out_h, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+__global__ __launch_bounds__ (256) void k_pack_planar (PackPlanarParams pk, const uint8_t *__restrict__ src, int sstride, DstPlanes d)
+{
+  pack_planar_body (pk, src, sstride, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,6 +504,19 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
     hipLaunchKernelGGL (k_scale2x2_lds<SrcFront>, grid, block, (size_t) h_span * 8, stream, src, sh, sv, h_first ? 1 : 0, d, out_w, out_h, h_span);
   else
     hipLaunchKernelGGL (k_scale2x2<SrcFront>, grid, block, 0, stream, src, sh, sv, h_first ? 1 : 0, d, out_w, out_h);
+  return hipGetLastError ();
+}
+
+hipError_t launch_pack_planar (const PackPlanarParams &pk, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],
+    hipStream_t stream)
+{
+  DstPlanes d;
+  for (int i = 0; i < 3; i++) {
+    d.p[i] = planes[i];
+    d.stride[i] = strides[i];
+  }
+  const int lanes = (pk.width + 3) / 4, rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
+  hipLaunchKernelGGL (k_pack_planar, dim3 ((lanes + 255) / 256, rows), dim3 (256), 0, stream, pk, src, sstride, d);
   return hipGetLastError ();
 }
 

@@ -1,0 +1,86 @@
+// video_pack.h - last stage for planar / semi-planar destinations: chroma downsample + pack of the final AYUV image.
+//
+// Reference: chain_downsample / do_downsample_lines (video-converter.c:2040, 3192) feed line pairs (2r, 2r+1) - a clamped
+// copy of the last line when the height is odd - to gst_video_chroma_resample; video_orc_chroma_down_v2_u8
+// (video-orc.orc:2692) averages U and V of the pair into the even line, then the horizontal resampler rewrites the
+// even pixels of that line: video_orc_chroma_down_h2_u8 (:2657, pairs, an odd last pixel stays) or
+// video_chroma_down_h2_cs_u8 (video-chroma.c:740-762, 3-1 / 1-2-1 / 1-3 taps); pack_planar_420 / pack_NV12 / pack_Y42B /
+// pack_Y444 (video-format.c:100-151, 1644-1675, ..) then store Y of every pixel and U, V of the even pixels of the even
+// lines.  All of it is per-pixel selection of a few neighbours, so one lane produces a 4-pixel-wide block directly.
+#pragma once
+#include "video_device.h"
+
+namespace gstamd {
+
+struct DstPlanes {
+  uint8_t *p[3];
+  int stride[3];
+};
+
+// U | V << 16 of AYUV word px (bytes A, Y, U, V)
+GSTAMD_HD uint32_t ayuv_uv (uint32_t px) { return ((px >> 16) & 0xffu) | ((px >> 24) << 16); }
+
+// per-lane block: pixels x0 .. x0+3 of the lines (yb << h_sub) .. ; x0 % 4 == 0
+GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__restrict__ src, int sstride, const DstPlanes &d, int x0, int yb)
+{
+  const int w = pk.width, h = pk.height;
+  const int y0 = yb << pk.h_sub;
+  if (x0 >= w || y0 >= h)
+    return;
+  const int nlines = 1 << pk.h_sub;
+  // ---- luma of every line of the block
+  for (int r = 0; r < nlines; r++) {
+    const int y = y0 + r;
+    if (y >= h)
+      break;
+    const uint32_t *row = (const uint32_t *) (src + (size_t) y * sstride);
+    uint8_t *dy = d.p[0] + (size_t) y * d.stride[0] + x0;
+    for (int i = 0; i < 4 && x0 + i < w; i++)
+      dy[i] = (uint8_t) (row[x0 + i] >> 8);
+  }
+  // ---- chroma of the block's first line (the "chroma line"), vertically averaged with the next one
+  const uint32_t *ra = (const uint32_t *) (src + (size_t) y0 * sstride);
+  const uint32_t *rb = (const uint32_t *) (src + (size_t) (y0 + 1 < h ? y0 + 1 : h - 1) * sstride);
+  uint32_t v[6];                            // packed {U, V} of pixels x0-1 .. x0+4, clamped into the row
+  for (int i = 0; i < 6; i++) {
+    int x = x0 - 1 + i;
+    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+    uint32_t c = ayuv_uv (ra[x]);
+    if (pk.down_v)
+      c = ((c + ayuv_uv (rb[x]) + 0x00010001u) >> 1) & 0x00ff00ffu;      // avgub on both components
+    v[i] = c;
+  }
+  const int step = 1 << pk.w_sub;
+  for (int i = 0; i < 4; i += step) {
+    const int x = x0 + i;                   // an even pixel when w_sub == 1
+    if (x >= w)
+      break;
+    const uint32_t cm = v[i], c0 = v[i + 1], cp = v[i + 2];      // pixels x-1, x, x+1
+    uint32_t c = c0;
+    if (pk.w_sub == 1) {
+      if (pk.down_h == 1) {
+        if (x + 1 < w)
+          c = ((c0 + cp + 0x00010001u) >> 1) & 0x00ff00ffu;
+      } else if (pk.down_h == 2 && w >= 2) {
+        if (x == 0)
+          c = ((3u * c0 + cp + 0x00020002u) >> 2) & 0x00ff00ffu;
+        else if (x < w - 2)
+          c = ((cm + 2u * c0 + cp + 0x00020002u) >> 2) & 0x00ff00ffu;
+        else
+          c = ((cm + 3u * c0 + 0x00020002u) >> 2) & 0x00ff00ffu;
+      }
+    }
+    const uint8_t cu = (uint8_t) c, cv = (uint8_t) (c >> 16);
+    const int k = x >> pk.w_sub;
+    if (pk.kind == UNPACK_SEMI) {
+      uint8_t *duv = d.p[1] + (size_t) yb * d.stride[1] + 2 * k;
+      duv[0] = pk.u_plane ? cu : cv;
+      duv[1] = pk.u_plane ? cv : cu;
+    } else {
+      d.p[pk.u_plane][(size_t) yb * d.stride[pk.u_plane] + k] = cu;
+      d.p[pk.v_plane][(size_t) yb * d.stride[pk.v_plane] + k] = cv;
+    }
+  }
+}
+
+}  // namespace gstamd

@@ -32,7 +32,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #define GST_CAT_DEFAULT amd_vcs_debug
 
 #define AMD_FORMATS "{ NV12, NV21, I420, YV12, Y42B, Y444, AYUV, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR }"
-#define AMD_OUT_FORMATS "{ AYUV, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR }"
+#define AMD_OUT_FORMATS AMD_FORMATS
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_FORMATS) ";"

@@ -87,6 +87,24 @@ VIDEO_CASES = [
     ("ayuv_ayuv_honly_nearest_planes", "AYUV", 200, 100, "AYUV", 77, 100, NEAR, None, None, "random"),
     ("abgr_abgr_vonly_bilinear_planes", "ABGR", 200, 100, "ABGR", 200, 61, LIN, None, None, "random"),
     ("bgra_bgra_copy_planes", "BGRA", 322, 241, "BGRA", 322, 241, {}, None, None, "random"),
+    # planar / semi-planar destinations: matrix to YUV, chroma downsample (video-chroma.c), pack
+    ("bgra_nv12_1280x720", "BGRA", 1280, 720, "NV12", 1280, 720, {}, None, None, "random"),
+    ("bgra_i420_322x241", "BGRA", 322, 241, "I420", 322, 241, {}, None, None, "random"),
+    ("rgba_yv12_321x33", "RGBA", 321, 33, "YV12", 321, 33, {}, None, None, "random"),
+    ("argb_nv21_130x70", "ARGB", 130, 70, "NV21", 130, 70, {}, None, None, "random"),
+    ("bgrx_y42b_131x7", "BGRx", 131, 7, "Y42B", 131, 7, {}, None, None, "random"),
+    ("xrgb_y444_64x48", "xRGB", 64, 48, "Y444", 64, 48, {}, None, None, "random"),
+    ("bgra_nv12_1080p_to_720p_bilinear", "BGRA", 1920, 1080, "NV12", 1280, 720, LIN, None, None, "random"),
+    ("bgra_i420_up_lanczos", "BGRA", 160, 90, "I420", 333, 201, LAN, None, None, "random"),
+    ("nv12_i420_640x360", "NV12", 640, 360, "I420", 640, 360, {}, None, None, "random"),
+    ("i420_nv12_323x241", "I420", 323, 241, "NV12", 323, 241, {}, None, None, "random"),
+    ("nv12_i420_half_cubic", "NV12", 640, 360, "I420", 320, 180, {}, None, None, "random"),
+    ("y444_nv12_130x70", "Y444", 130, 70, "NV12", 130, 70, {}, None, None, "random"),
+    ("ayuv_nv12_66x35", "AYUV", 66, 35, "NV12", 66, 35, {}, None, None, "random"),
+    ("i420_i420_bt709_to_default_bt601", "I420", 320, 240, "I420", 320, 240, {}, "bt709", None, "random"),
+    ("bgra_nv12_2x2", "BGRA", 2, 2, "NV12", 2, 2, {}, None, None, "random"),
+    ("bgra_i420_3x3", "BGRA", 3, 3, "I420", 3, 3, {}, None, None, "random"),
+    ("bgra_nv12_1x1", "BGRA", 1, 1, "NV12", 1, 1, {}, None, None, "random"),
     # wide-kernel tile edges: row ends exactly at a 1024-px run / one dword past it / inside a lane
     ("nv12_bgra_1024x34_jpeg", "NV12", 1024, 34, "BGRA", 1024, 34, {}, None, "jpeg", "random"),
     ("nv21_rgba_2048x18_mpeg2", "NV21", 2048, 18, "RGBA", 2048, 18, {}, None, "mpeg2", "random"),
@@ -125,7 +143,8 @@ VIDEO_CASES = [
 VIDEO_REFUSED = [
     ("I420", 64, 64, "I420", 32, 32, {}),                # convert_scale_planes on planar formats: planar output
     ("NV12", 320, 180, "BGRA", 640, 100, LAN),           # reference temp-line aliasing (see planner.cpp)
-    ("NV12", 64, 64, "NV12", 32, 32, {}),                # planar output not implemented
+    ("NV12", 64, 64, "NV12", 32, 32, {}),                # convert_scale_planes on semi-planar formats
+    ("AYUV", 64, 64, "I420", 64, 64, {}),                # convert_AYUV_I420 fastpath
 ]
 
 

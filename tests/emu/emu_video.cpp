@@ -10,6 +10,7 @@
 #include "../../gstreamer_amd/csrc/video_device.h"
 #include "../../gstreamer_amd/csrc/video_fast.h"
 #include "../../gstreamer_amd/csrc/video_scale_fast.h"
+#include "../../gstreamer_amd/csrc/video_pack.h"
 
 using namespace gstamd;
 
@@ -136,6 +137,8 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
     }
 }
 
+static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok);
+
 extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *cfg, const uint8_t *src, uint8_t *dst, int vec_ok, char *desc, int desc_len)
 {
@@ -155,14 +158,34 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     pl.p[i] = src + in->offset[i];
     pl.stride[i] = in->stride[i];
   }
+  if (p.out_planar) {                     /* chain -> AYUV image, then the pack kernel body over its grid */
+    std::vector<uint8_t> img ((size_t) out->width * 4 * out->height);
+    r = emu_convert_packed (p, in, pl, img.data (), out->width * 4, vec_ok);
+    if (r != GSTAMD_OK)
+      return r;
+    DstPlanes d;
+    memset (&d, 0, sizeof (d));
+    for (int i = 0; i < out->n_planes && i < 3; i++) {
+      d.p[i] = dst + out->offset[i];
+      d.stride[i] = out->stride[i];
+    }
+    const int rows = (out->height + (1 << p.pack.h_sub) - 1) >> p.pack.h_sub;
+    for (int yb = 0; yb < rows; yb++)
+      for (int x0 = 0; x0 < out->width; x0 += 4)
+        pack_planar_body (p.pack, img.data (), out->width * 4, d, x0, yb);
+    return GSTAMD_OK;
+  }
+  return emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok);
+}
+
+static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok)
+{
   ColorParams color, none;
   memset (&none, 0, sizeof (none));
   color.matrix = p.matrix;
   color.alpha_kind = p.post.alpha_kind;
   color.alpha_value = p.post.alpha_value;
   const int *vpair = p.vpair.data ();
-  uint8_t *d0 = dst + out->offset[0];
-  const int dstride = out->stride[0];
   if (p.passes.empty () && p.fast_pair && vec_ok) {
     /* vec_ok: 1 = shipped configuration (strip kernel, 3 line pairs per lane); 100 + K = strip kernel with K pairs;
      * 200 + K = wide kernel (LDS-staged 1024-px runs) with K pairs per wave */
@@ -287,9 +310,9 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     const TileGeom g = pass_tile_geom (p.passes[h_first ? 0 : 1]);
     if (g.tile_w > 0 && g.lds_px * 8 <= 16384) {      /* k_scale2x2_wave */
       std::vector<uint32_t> la (g.lds_px), lb (g.lds_px);
-      for (int y = 0; y < out->height; y++)
-        for (int t0 = 0; t0 < out->width; t0 += g.tile_w) {
-          const int t1 = t0 + g.tile_w < out->width ? t0 + g.tile_w : out->width;
+      for (int y = 0; y < p.out_info.height; y++)
+        for (int t0 = 0; t0 < p.out_info.width; t0 += g.tile_w) {
+          const int t1 = t0 + g.tile_w < p.out_info.width ? t0 + g.tile_w : p.out_info.width;
           int lo, hi;
           hscale_span (sh, t0, t1, &lo, &hi);
           const int xa = lo & ~7, ya = (int) sv.offset[y];
@@ -305,9 +328,9 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     }
     if (span <= 6144) {                    /* k_scale2x2_lds */
       std::vector<uint32_t> la (6144), lb (6144);
-      for (int y = 0; y < out->height; y++)
-        for (int t0 = 0; t0 < out->width; t0 += 256) {
-          const int t1 = t0 + 256 < out->width ? t0 + 256 : out->width;
+      for (int y = 0; y < p.out_info.height; y++)
+        for (int t0 = 0; t0 < p.out_info.width; t0 += 256) {
+          const int t1 = t0 + 256 < p.out_info.width ? t0 + 256 : p.out_info.width;
           int lo, hi;
           hscale_span (sh, t0, t1, &lo, &hi);
           const int ya = (int) sv.offset[y];
@@ -321,13 +344,13 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         }
       return GSTAMD_OK;
     }
-    for (int y = 0; y < out->height; y++)
-      for (int x = 0; x < out->width; x++)
-        scale2x2_body<SrcFront> (sf, sh, sv, h_first ? 1 : 0, d, out->width, out->height, x, y);
+    for (int y = 0; y < p.out_info.height; y++)
+      for (int x = 0; x < p.out_info.width; x++)
+        scale2x2_body<SrcFront> (sf, sh, sv, h_first ? 1 : 0, d, p.out_info.width, p.out_info.height, x, y);
     return GSTAMD_OK;
   }
   if (p.passes.size () == 1) {
-    run_scale (p.passes[0].horizontal, sf, sd[0], mk (d0, dstride, true), out->width, out->height, p.passes[0].max_span,
+    run_scale (p.passes[0].horizontal, sf, sd[0], mk (d0, dstride, true), p.out_info.width, p.out_info.height, p.passes[0].max_span,
         p.passes[0].horizontal ? pass_tile_geom (p.passes[0]) : TileGeom {0, 0}, pf);
     return GSTAMD_OK;
   }
@@ -340,7 +363,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   si.p = tmp.data ();
   si.stride = tw * 4;
   si.width = tw;
-  run_scale (p.passes[1].horizontal, si, sd[1], mk (d0, dstride, true), out->width, out->height, p.passes[1].max_span,
+  run_scale (p.passes[1].horizontal, si, sd[1], mk (d0, dstride, true), p.out_info.width, p.out_info.height, p.passes[1].max_span,
       p.passes[1].horizontal ? pass_tile_geom (p.passes[1]) : TileGeom {0, 0}, pf);
   return GSTAMD_OK;
 }

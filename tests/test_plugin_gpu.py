@@ -141,3 +141,24 @@ def test_compositor_element_matches_reference(gst_env, ref):
         ref.compositor_blend("overlay_argb", "ARGB", cv.frame(s0[f]), 256, 144, 0, 0, 1.0, canvas, 256, 144, 0, 144, 1)
         ref.compositor_blend("overlay_argb", "ARGB", s1[f], 128, 72, 40, 30, 0.5, canvas, 256, 144, 0, 144, 1)
         assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
+
+
+def test_videoconvertscale_element_planar_output(gst_env, ref):
+    """RGB -> NV12 (the encoder-feeding direction) with a bilinear downscale, and NV12 -> I420, through the element."""
+    env, tmp = gst_env
+    n = 3
+    fin, fout, fout2 = tmp / "p_in.bgra", tmp / "p_out.nv12", tmp / "p_out.i420"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=640,height=360 ! tee name=t "
+                "t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw,format=NV12,width=320,height=180,colorimetry=bt709,chroma-site=mpeg2 "
+                "! tee name=u u. ! queue ! filesink location=%s u. ! queue ! videoconvertscale ! video/x-raw,format=I420,colorimetry=bt709,chroma-site=mpeg2 ! filesink location=%s"
+           % (n, fin, fout, fout2))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    nv12 = np.fromfile(fout, np.uint8).reshape(n, -1)
+    i420 = np.fromfile(fout2, np.uint8).reshape(n, -1)
+    a = ref.VideoConverter("BGRA", 640, 360, "NV12", 320, 180, out_colorimetry="bt709", out_chroma_site="mpeg2",
+                           config=cases.ref_config_string(ref, cases.LIN))
+    b = ref.VideoConverter("NV12", 320, 180, "I420", 320, 180, in_colorimetry="bt709", in_chroma_site="mpeg2",
+                           out_colorimetry="bt709", out_chroma_site="mpeg2")
+    for i in range(n):
+        assert (a.frame(src[i]) == nv12[i]).all(), i
+        assert (b.frame(nv12[i]) == i420[i]).all(), i

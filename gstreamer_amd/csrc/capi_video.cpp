@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -232,6 +233,44 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
   if (p.passes.size () == 2 && small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)) {
     /* nearest / 2-tap in both directions ("bilinear"): one fused kernel, no intermediate image */
     const bool h_first = p.passes[0].horizontal;
+    if (h_first && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && p.front.kind == UNPACK_SEMI && p.front.w_sub == 1 &&
+        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && ((uintptr_t) dst % 4) == 0 && (dstride % 4) == 0 &&
+        getenv ("GSTAMD_NO_BILINEAR420") == nullptr) {
+      /* semi-planar 4:2:0 source, horizontal-first 2-tap x 2-tap, fast matrix: the direct kernel of video_bilinear_fast.h */
+      BilParams bp;
+      bp.tile_w = bil_pick_tile (out_w, p.passes[0].inc, &bp.ylen);
+      if (const char *e_tw = getenv ("GSTAMD_BIL_TILE")) {      /* tuning knob for profiling sessions */
+        bp.tile_w = atoi (e_tw);
+        bp.ylen = bil_ylen (out_w, p.passes[0].inc, bp.tile_w);
+      }
+      if (bp.tile_w > 0 && bp.ylen > 0) {
+      bp.fp = pf.fp;
+      bp.out_w = out_w;
+      bp.out_h = out_h;
+      bp.inc = p.passes[0].inc;
+      bp.voffset = sd[1].offset;
+      bp.vtaps = sd[1].taps;
+      bp.vpair = p.front.chroma_v2 ? c->vpair_dev : nullptr;
+      bp.regular_pairs = 0;
+      if (p.front.chroma_v2 && getenv ("GSTAMD_BIL_TABLE") == nullptr) {
+        /* are the pairs of every source line the kernel will touch the closed form of bil_rows? */
+        bool regular = true;
+        BilParams probe = bp;
+        probe.regular_pairs = 1;
+        for (int y = 0; y < out_h && regular; y++)
+          for (int l = 0; l < 2 && regular; l++) {
+            const int line = (int) p.passes[1].offset[y] + l;
+            int ra, rb, role;
+            bil_rows (probe, line, &ra, &rb, &role);
+            const int e0 = p.vpair[2 * line], ta = e0 & 0x3fffffff, trole = e0 >> 30, tb = p.vpair[2 * line + 1];
+            regular = ta == ra && tb == rb && (ra == rb || trole == role);
+          }
+        bp.regular_pairs = regular ? 1 : 0;
+      }
+      e = launch_bilinear420 (bp, p.front.chroma_h, pl, dst, dstride, stream);
+      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420");
+      }
+    }
     const ScaleDev &sh = h_first ? sd[0] : sd[1], &sv = h_first ? sd[1] : sd[0];
     e = launch_scale2x2_from_front (p.front, pl, c->vpair_dev, pre, sh, sv, h_first, dst, dstride, post, p.post.pack_pos,
         out_w, out_h, p.passes[h_first ? 0 : 1].max_span, c->geom[h_first ? 0 : 1], pf, stream);

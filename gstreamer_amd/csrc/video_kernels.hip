@@ -15,6 +15,7 @@
 #include "video_fast.h"
 #include "video_scale_fast.h"
 #include "video_pack.h"
+#include "video_bilinear_fast.h"
 
 namespace gstamd {
 
@@ -173,6 +174,22 @@ template <class SRC>
 __global__ __launch_bounds__ (256) void k_vscale (SRC src, ScaleDev sd, Dst dst, int width, int out_h)
 {
   vscale_body<SRC> (src, sd, dst, width, out_h, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+// fused bilinear scaler from semi-planar 4:2:0 (video_bilinear_fast.h): workgroup = one wave = 256 outputs of one row
+template <int CH, int L>
+__global__ __launch_bounds__ (64) void k_bilinear420 (BilParams bp, Planes pl, uint8_t *__restrict__ dst, int dstride, int vec)
+{
+  extern __shared__ uint32_t lds_w[];
+  const BilLds lds = bil_lds (lds_w, bp.ylen);
+  const int lane = (int) threadIdx.x, y = (int) blockIdx.y, t0 = (int) blockIdx.x * bp.tile_w;
+  const int t1 = t0 + bp.tile_w < bp.out_w ? t0 + bp.tile_w : bp.out_w;
+  const int r0 = (int) bp.voffset[y];
+  BilRegs r;
+  bil_fetch (bp, pl, t0, t1, r0, lane, vec != 0, r);
+  bil_commit (bp, t0, t1, lane, r, &lds);
+  __syncthreads ();                       /* one wave per workgroup: orders the LDS writes before the reads */
+  bil_emit<CH, L> (bp, dst, dstride, t0, t1, y, r0, lane, &lds);
 }
 
 __global__ __launch_bounds__ (256) void k_pack_planar (PackPlanarParams pk, const uint8_t *__restrict__ src, int sstride, DstPlanes d)
@@ -505,6 +522,26 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
   else
     hipLaunchKernelGGL (k_scale2x2<SrcFront>, grid, block, 0, stream, src, sh, sv, h_first ? 1 : 0, d, out_w, out_h);
   return hipGetLastError ();
+}
+
+hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
+{
+  const int vec = aligned (pl.p[0], 16) && aligned (pl.p[1], 16) && (pl.stride[0] % 16) == 0 && (pl.stride[1] % 16) == 0;
+  dim3 grid ((bp.out_w + bp.tile_w - 1) / bp.tile_w, bp.out_h);
+  const size_t lds_bytes = bil_lds_words (bp.ylen) * 4;
+#define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \
+    if (chroma_h == CHROMA_H_H2_CS) \
+      hipLaunchKernelGGL ((k_bilinear420<CHROMA_H_H2_CS, GSTAMD_LAYOUT (pr, pg, pb)>), grid, dim3 (64), lds_bytes, stream, bp, pl, dst, dstride, vec); \
+    else if (chroma_h == CHROMA_H_H2) \
+      hipLaunchKernelGGL ((k_bilinear420<CHROMA_H_H2, GSTAMD_LAYOUT (pr, pg, pb)>), grid, dim3 (64), lds_bytes, stream, bp, pl, dst, dstride, vec); \
+    else \
+      hipLaunchKernelGGL ((k_bilinear420<CHROMA_H_NONE, GSTAMD_LAYOUT (pr, pg, pb)>), grid, dim3 (64), lds_bytes, stream, bp, pl, dst, dstride, vec); \
+    return hipGetLastError ();
+  switch (fast_layout (bp.fp)) {
+    GSTAMD_FOR_LAYOUTS (W)
+  }
+#undef W
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_pack_planar (const PackPlanarParams &pk, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],

@@ -105,6 +105,13 @@ VIDEO_CASES = [
     ("bgra_nv12_2x2", "BGRA", 2, 2, "NV12", 2, 2, {}, None, None, "random"),
     ("bgra_i420_3x3", "BGRA", 3, 3, "I420", 3, 3, {}, None, None, "random"),
     ("bgra_nv12_1x1", "BGRA", 1, 1, "NV12", 1, 1, {}, None, None, "random"),
+    # fused semi-planar bilinear kernel (video_bilinear_fast.h): ratios, odd sizes, chroma sitings, NV21, layouts
+    ("nv12_bgra_2to1_bilinear_1280x720", "NV12", 1280, 720, "BGRA", 640, 360, LIN, None, None, "random"),
+    ("nv12_rgba_odd_down_bilinear", "NV12", 1283, 721, "RGBA", 701, 397, LIN, None, None, "random"),
+    ("nv21_argb_3to1_bilinear_jpeg", "NV21", 960, 540, "ARGB", 320, 180, LIN, None, "jpeg", "random"),
+    ("nv12_abgr_1p5_bilinear_none", "NV12", 642, 362, "ABGR", 428, 241, LIN, None, "none", "random"),
+    ("nv12_bgrx_narrow_bilinear", "NV12", 130, 70, "BGRx", 65, 35, LIN, None, None, "random"),
+    ("nv12_bgra_hdown_vsame_bilinear_cosited", "NV12", 640, 360, "BGRA", 320, 359, LIN, None, "cosited", "random"),
     # wide-kernel tile edges: row ends exactly at a 1024-px run / one dword past it / inside a lane
     ("nv12_bgra_1024x34_jpeg", "NV12", 1024, 34, "BGRA", 1024, 34, {}, None, "jpeg", "random"),
     ("nv21_rgba_2048x18_mpeg2", "NV21", 2048, 18, "RGBA", 2048, 18, {}, None, "mpeg2", "random"),

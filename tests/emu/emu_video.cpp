@@ -11,6 +11,7 @@
 #include "../../gstreamer_amd/csrc/video_fast.h"
 #include "../../gstreamer_amd/csrc/video_scale_fast.h"
 #include "../../gstreamer_amd/csrc/video_pack.h"
+#include "../../gstreamer_amd/csrc/video_bilinear_fast.h"
 
 using namespace gstamd;
 
@@ -308,6 +309,48 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     const Dst d = mk (d0, dstride, true);
     const int span = p.passes[h_first ? 0 : 1].max_span;
     const TileGeom g = pass_tile_geom (p.passes[h_first ? 0 : 1]);
+    int bil_yl = 0;
+    const int bil_tw = vec_ok >= 400 ? vec_ok - 400 : bil_pick_tile (p.out_info.width, p.passes[0].inc, &bil_yl);     /* 400 + w: tiles of w outputs */
+    if (vec_ok >= 400)
+      bil_yl = bil_ylen (p.out_info.width, p.passes[0].inc, bil_tw);
+    if (h_first && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && p.front.kind == UNPACK_SEMI && p.front.w_sub == 1 &&
+        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && bil_tw > 0 && bil_yl > 0 && vec_ok != 300) {
+      /* k_bilinear420 (video_bilinear_fast.h); vec_ok == 300 selects the generic tile kernel below instead */
+      BilParams bp;
+      bp.fp = pf.fp;
+      bp.out_w = p.out_info.width;
+      bp.out_h = p.out_info.height;
+      bp.inc = p.passes[0].inc;
+      bp.tile_w = bil_tw;
+      bp.ylen = bil_yl;
+      bp.voffset = sd[1].offset;
+      bp.vtaps = sd[1].taps;
+      bp.vpair = p.front.chroma_v2 ? vpair : nullptr;
+      const bool vec = (((uintptr_t) pl.p[0] | (uintptr_t) pl.p[1]) % 16) == 0 && pl.stride[0] % 16 == 0 && pl.stride[1] % 16 == 0;
+      const int lay = GSTAMD_LAYOUT (bp.fp.pack_pos[1], bp.fp.pack_pos[2], bp.fp.pack_pos[3]);
+      std::vector<uint32_t> lds_w (bil_lds_words (bp.ylen));
+      const BilLds lds = bil_lds (lds_w.data (), bp.ylen);
+#define BIL_L(CH, pr, pg, pb) if (lay == GSTAMD_LAYOUT (pr, pg, pb)) bil_emit<CH, GSTAMD_LAYOUT (pr, pg, pb)> (bp, d0, dstride, t0, t1, y, r0, lane, &lds);
+#define BIL(CH) { BIL_L (CH, 2, 1, 0) BIL_L (CH, 0, 1, 2) BIL_L (CH, 1, 2, 3) BIL_L (CH, 3, 2, 1) }
+      bp.regular_pairs = 0;
+      static BilRegs regs[64];
+      for (int y = 0; y < bp.out_h; y++)
+        for (int t0 = 0; t0 < bp.out_w; t0 += bp.tile_w) {
+          const int t1 = t0 + bp.tile_w < bp.out_w ? t0 + bp.tile_w : bp.out_w, r0 = (int) bp.voffset[y];
+          for (int lane = 0; lane < 64; lane++) {
+            bil_fetch (bp, pl, t0, t1, r0, lane, vec, regs[lane]);
+            bil_commit (bp, t0, t1, lane, regs[lane], &lds);
+          }
+          for (int lane = 0; lane < 64; lane++) {
+            if (p.front.chroma_h == CHROMA_H_H2_CS) BIL (CHROMA_H_H2_CS)
+            else if (p.front.chroma_h == CHROMA_H_H2) BIL (CHROMA_H_H2)
+            else BIL (CHROMA_H_NONE)
+          }
+        }
+#undef BIL
+#undef BIL_L
+      return GSTAMD_OK;
+    }
     if (g.tile_w > 0 && g.lds_px * 8 <= 16384) {      /* k_scale2x2_wave */
       std::vector<uint32_t> la (g.lds_px), lb (g.lds_px);
       for (int y = 0; y < p.out_info.height; y++)

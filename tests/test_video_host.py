@@ -136,6 +136,20 @@ def test_fast_kernel_bodies_any_pairs_per_wave(native_lib, emu_lib, idx_case, k)
     assert cases.sha(dst) == GOLDEN[name]["sha256"], name
 
 
+BIL = [c for c in SMALL if c[1][1] in ("NV12", "NV21") and c[1][7] == cases.LIN and c[1][0] != "nv12_bgra_up2_bilinear"]
+
+
+@pytest.mark.parametrize("variant", [300, 464, 528, 656])
+@pytest.mark.parametrize("idx_case", BIL, ids=lambda c: c[1][0])
+def test_bilinear_kernel_bodies_agree(native_lib, emu_lib, idx_case, variant):
+    """Bilinear plans from semi-planar 4:2:0: the generic wave-tile kernel (300) and the fused kernel with tiles of
+    64 / 128 / 256 outputs per wave (400 + w) all reproduce the reference."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src, vec=variant)
+    assert cases.sha(dst) == GOLDEN[name]["sha256"], name
+
+
 @pytest.mark.parametrize("idx_case", SMALL[::4], ids=lambda c: c[1][0])
 def test_golden_vectors_are_the_references_output(ref, idx_case):
     """Pins the committed golden hashes to the reference implementation itself (oracle/_ref)."""

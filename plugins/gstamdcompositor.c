@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include "../include/gstamd_video.h"
+#include "gstamdhipbufferpool.h"
 #include "gstamdhipmemory.h"
 
 GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
@@ -161,6 +162,7 @@ typedef struct {
   gint background;
   GstVideoInfo out_info;
   gboolean have_out, out_hip;
+  GstBufferPool *out_pool;     /* HBM output frames (downstream negotiated memory:AMDHIPMemory) */
   gpointer d_out;              /* device canvas when downstream wants system memory */
   gsize d_out_size;
   guint64 n_frames;
@@ -413,6 +415,13 @@ amd_comp_negotiated_src_caps (GstAggregator * agg, GstCaps * caps)
   if (!gst_video_info_from_caps (&c->out_info, caps) || !amd_format_of (GST_VIDEO_INFO_FORMAT (&c->out_info)))
     return FALSE;
   c->out_hip = f && gst_caps_features_contains (f, GST_CAPS_FEATURE_MEMORY_AMD_HIP);
+  if (c->out_pool) {
+    gst_buffer_pool_set_active (c->out_pool, FALSE);
+    gst_object_unref (c->out_pool);
+    c->out_pool = NULL;
+  }
+  if (c->out_hip && !(c->out_pool = gst_amd_hip_buffer_pool_new_for_caps (caps, 2)))
+    return FALSE;
   c->have_out = TRUE;
   GST_INFO_OBJECT (c, "output %" GST_PTR_FORMAT, caps);
   return TRUE;
@@ -530,7 +539,8 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
 
   /* canvas */
   if (c->out_hip) {
-    outbuf = gst_amd_hip_buffer_new_video (&c->out_info);
+    if (!c->out_pool || gst_buffer_pool_acquire_buffer (c->out_pool, &outbuf, NULL) != GST_FLOW_OK)
+      outbuf = NULL;
     omem = outbuf ? gst_buffer_peek_memory (outbuf, 0) : NULL;
     if (!omem || !gst_memory_map (omem, &omap, GST_MAP_WRITE | GST_MAP_AMDHIP)) {
       flow = GST_FLOW_ERROR;
@@ -595,6 +605,11 @@ static gboolean
 amd_comp_stop (GstAggregator * agg)
 {
   GstAmdCompositor *c = AMD_COMP (agg);
+  if (c->out_pool) {
+    gst_buffer_pool_set_active (c->out_pool, FALSE);
+    gst_object_unref (c->out_pool);
+    c->out_pool = NULL;
+  }
   gstamd_device_free (c->d_out);
   c->d_out = NULL;
   c->d_out_size = 0;

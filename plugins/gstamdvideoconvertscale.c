@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include "../include/gstamd_video.h"
+#include "gstamdhipbufferpool.h"
 #include "gstamdhipmemory.h"
 
 GST_DEBUG_CATEGORY_STATIC (amd_vcs_debug);
@@ -76,6 +77,7 @@ typedef struct {
   GstVideoInfo in_info, out_info;
   gboolean in_hip, out_hip;
   GstAmdVideoConverter *convert;
+  GstBufferPool *out_pool;     /* HBM output frames are recycled through a GstAmdHipBufferPool */
   /* device staging for system-memory pads */
   gpointer d_in, d_out;
   gsize d_in_size, d_out_size;
@@ -263,6 +265,15 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
     return FALSE;
   s->in_hip = caps_are_hip (incaps);
   s->out_hip = caps_are_hip (outcaps);
+  if (s->out_pool) {
+    gst_buffer_pool_set_active (s->out_pool, FALSE);
+    gst_object_unref (s->out_pool);
+    s->out_pool = NULL;
+  }
+  if (s->out_hip && !(s->out_pool = gst_amd_hip_buffer_pool_new_for_caps (outcaps, 2))) {
+    GST_ERROR_OBJECT (s, "could not set up the HBM output pool");
+    return FALSE;
+  }
   if (!fill_amd_info (&s->in_info, &ai) || !fill_amd_info (&s->out_info, &ao)) {
     GST_ERROR_OBJECT (s, "format not supported by the HIP converter");
     return FALSE;
@@ -311,7 +322,7 @@ amd_vcs_get_unit_size (GstBaseTransform * trans, GstCaps * caps, gsize * size)
   return TRUE;
 }
 
-/* HIP output: allocate AMDHIPMemory ourselves (a pool is the obvious next step); system output: default */
+/* HIP output: frames come from our own GstAmdHipBufferPool; system output: default */
 static GstFlowReturn
 amd_vcs_prepare_output_buffer (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer ** outbuf)
 {
@@ -323,8 +334,7 @@ amd_vcs_prepare_output_buffer (GstBaseTransform * trans, GstBuffer * inbuf, GstB
   }
   if (!s->out_hip)
     return GST_BASE_TRANSFORM_CLASS (gst_amd_vcs_parent_class)->prepare_output_buffer (trans, inbuf, outbuf);
-  *outbuf = gst_amd_hip_buffer_new_video (&s->out_info);
-  if (!*outbuf)
+  if (!s->out_pool || gst_buffer_pool_acquire_buffer (s->out_pool, outbuf, NULL) != GST_FLOW_OK)
     return GST_FLOW_ERROR;
   gst_buffer_copy_into (*outbuf, inbuf, GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS, 0, -1);
   return GST_FLOW_OK;
@@ -421,6 +431,11 @@ amd_vcs_stop (GstBaseTransform * trans)
   if (s->convert)
     gstamd_video_converter_free (s->convert);
   s->convert = NULL;
+  if (s->out_pool) {
+    gst_buffer_pool_set_active (s->out_pool, FALSE);
+    gst_object_unref (s->out_pool);
+    s->out_pool = NULL;
+  }
   gstamd_device_free (s->d_in);
   gstamd_device_free (s->d_out);
   s->d_in = s->d_out = NULL;

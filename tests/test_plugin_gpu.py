@@ -111,7 +111,9 @@ def test_compositor_element_matches_reference(gst_env, ref):
     desc = "compositor name=c background=checker"
     for i, (pat, w, h, x, y, a, op) in enumerate(pads):
         desc += " sink_%d::xpos=%d sink_%d::ypos=%d sink_%d::alpha=%s sink_%d::operator=%d" % (i, x, i, y, i, a, i, op)
-    desc += " ! video/x-raw,format=BGRA,width=%d,height=%d ! filesink location=%s" % (dw, dh, fout)
+    # the canvas leaves the compositor as HBM buffers of its GstAmdHipBufferPool; videoconvertscale brings it to RGBA
+    desc += (" ! video/x-raw(memory:AMDHIPMemory),format=BGRA,width=%d,height=%d ! videoconvertscale ! video/x-raw,format=RGBA "
+             "! filesink location=%s" % (dw, dh, fout))
     for i, (pat, w, h, x, y, a, op) in enumerate(pads):
         desc += (" videotestsrc num-buffers=%d pattern=%s foreground-color=0x80ff4020 ! video/x-raw,format=BGRA,width=%d,height=%d,framerate=30/1 "
                  "! tee name=t%d t%d. ! queue ! filesink location=%s t%d. ! queue ! c.sink_%d" % (n, pat, w, h, i, i, files[i], i, i))
@@ -123,7 +125,8 @@ def test_compositor_element_matches_reference(gst_env, ref):
         ref.compositor_fill(0, "bgra", "BGRA", canvas, dw, dh, 0, dh)
         for i, (pat, w, h, x, y, a, op) in enumerate(pads):
             ref.compositor_blend("blend_bgra", "BGRA", ins[i][f], w, h, x, y, a, canvas, dw, dh, 0, dh, op)
-        assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
+        exp = canvas.reshape(-1, 4)[:, [2, 1, 0, 3]].reshape(-1)      # BGRA -> RGBA
+        assert (exp == out[f]).all(), (f, int((exp != out[f]).sum()))
 
     # transparent background -> overlay functions; pad 0 arrives as memory:AMDHIPMemory from videoconvertscale
     fin0, fin1, fout2 = tmp / "o0.nv12", tmp / "o1.argb", tmp / "o.argb"

@@ -3,6 +3,7 @@
 // frame calls fail with GSTAMD_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,9 @@ struct GstAmdVideoConverter {
   uint8_t *tmp = nullptr;       // intermediate image between two scaler passes
   size_t tmp_size = 0;
   int tmp_w = 0, tmp_h = 0;
+  struct PlaneDev { uint32_t *offset = nullptr; int16_t *taps = nullptr; };
+  std::vector<std::vector<PlaneDev>> plane_dev;      // plane mode: tables of every pass of every plane
+  uint8_t *plane_tmp = nullptr;           // plane mode: intermediate plane of a two-pass scale
   uint8_t *pk_img = nullptr;              // planar destinations: the chain's AYUV image before chroma downsample + pack
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
 };
@@ -142,6 +146,32 @@ static int ensure_tables (GstAmdVideoConverter *c)
     if ((e = hipMalloc ((void **) &c->tmp, c->tmp_size)) != hipSuccess)
       return hip_fail (e, "hipMalloc(tmp)");
   }
+  if (p.plane_mode) {
+    size_t tmp_bytes = 0;
+    c->plane_dev.resize (p.planes.size ());
+    for (size_t i = 0; i < p.planes.size (); i++) {
+      const PlanePlan &pp = p.planes[i];
+      c->plane_dev[i].resize (pp.passes.size ());
+      for (size_t k = 0; k < pp.passes.size (); k++) {
+        const ScalePass &sp = pp.passes[k];
+        GstAmdVideoConverter::PlaneDev &pd = c->plane_dev[i][k];
+        if ((e = hipMalloc ((void **) &pd.offset, sp.offset.size () * sizeof (uint32_t))) != hipSuccess ||
+            (e = hipMemcpy (pd.offset, sp.offset.data (), sp.offset.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
+          return hip_fail (e, "plane offsets");
+        if (!sp.taps.empty () && ((e = hipMalloc ((void **) &pd.taps, sp.taps.size () * sizeof (int16_t))) != hipSuccess ||
+            (e = hipMemcpy (pd.taps, sp.taps.data (), sp.taps.size () * sizeof (int16_t), hipMemcpyHostToDevice)) != hipSuccess))
+          return hip_fail (e, "plane taps");
+      }
+      if (pp.passes.size () == 2) {
+        const size_t tw = pp.passes[0].horizontal ? pp.ow : pp.iw, th = pp.passes[0].horizontal ? pp.ih : pp.oh;
+        tmp_bytes = std::max (tmp_bytes, tw * th * (size_t) pp.n_elems);
+      }
+    }
+    if (tmp_bytes && (e = hipMalloc ((void **) &c->plane_tmp, tmp_bytes)) != hipSuccess)
+      return hip_fail (e, "hipMalloc(plane tmp)");
+    c->tables_ready = true;
+    return GSTAMD_OK;
+  }
   if (p.out_planar) {
     if ((e = hipMalloc ((void **) &c->pk_img, (size_t) p.out_info.width * 4 * p.out_info.height)) != hipSuccess)
       return hip_fail (e, "hipMalloc(pack image)");
@@ -171,6 +201,43 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
     pl.stride[i] = src_stride ? src_stride[i] : p.in_info.stride[i];
     if (!pl.p[i])
       return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
+  }
+  if (p.plane_mode) {
+    /* convert_scale_planes: every destination plane from one source plane */
+    for (size_t i = 0; i < p.planes.size (); i++) {
+      const PlanePlan &pp = p.planes[i];
+      const uint8_t *sp = pl.p[pp.src_plane];
+      const int ss = pl.stride[pp.src_plane];
+      uint8_t *dp = (uint8_t *) dest_planes[pp.dst_plane];
+      const int ds = dest_stride ? dest_stride[pp.dst_plane] : p.out_info.stride[pp.dst_plane];
+      if (!sp || !dp)
+        return set_error (GSTAMD_ERR_INVALID, "NULL plane");
+      hipError_t e;
+      if (pp.kind != PLANE_SCALE) {
+        e = launch_plane_simple (pp.kind, sp, ss, dp, ds, pp.n_elems, pp.ow, pp.oh, stream);
+      } else {
+        ScaleDev sd[2];
+        for (size_t k = 0; k < pp.passes.size (); k++) {
+          memset (&sd[k], 0, sizeof (sd[k]));
+          sd[k].kind = pp.passes[k].kind;
+          sd[k].n_taps = pp.passes[k].n_taps;
+          sd[k].inc = pp.passes[k].inc;
+          sd[k].offset = c->plane_dev[i][k].offset;
+          sd[k].taps = c->plane_dev[i][k].taps;
+        }
+        if (pp.passes.size () == 1) {
+          e = launch_plane_pass (pp.passes[0].horizontal, sd[0], sp, ss, dp, ds, pp.n_elems, pp.ow, pp.oh, stream);
+        } else {
+          const int tw = pp.passes[0].horizontal ? pp.ow : pp.iw, th = pp.passes[0].horizontal ? pp.ih : pp.oh;
+          e = launch_plane_pass (pp.passes[0].horizontal, sd[0], sp, ss, c->plane_tmp, tw * pp.n_elems, pp.n_elems, tw, th, stream);
+          if (e == hipSuccess)
+            e = launch_plane_pass (pp.passes[1].horizontal, sd[1], c->plane_tmp, tw * pp.n_elems, dp, ds, pp.n_elems, pp.ow, pp.oh, stream);
+        }
+      }
+      if (e != hipSuccess)
+        return hip_fail (e, "plane scaler");
+    }
+    return GSTAMD_OK;
   }
   if (p.out_planar) {
     /* chain -> AYUV image in HBM, then chroma downsample + pack into the destination planes */
@@ -363,6 +430,15 @@ void gstamd_video_converter_free (GstAmdVideoConverter *c)
     (void) hipFree (c->tmp);
   if (c->pk_img)
     (void) hipFree (c->pk_img);
+  if (c->plane_tmp)
+    (void) hipFree (c->plane_tmp);
+  for (auto &v : c->plane_dev)
+    for (auto &pd : v) {
+      if (pd.offset)
+        (void) hipFree (pd.offset);
+      if (pd.taps)
+        (void) hipFree (pd.taps);
+    }
   delete c;
 }
 

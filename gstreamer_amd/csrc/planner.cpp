@@ -122,6 +122,7 @@ void converter_config_init (GstAmdVideoConverterConfig *c)
   c->chroma_mode = GSTAMD_CHROMA_MODE_FULL;
   c->matrix_mode = GSTAMD_MATRIX_MODE_FULL;
   c->dither_quantization = 1;
+  c->chroma_resampler_method = GSTAMD_RESAMPLER_METHOD_LINEAR;     /* DEFAULT_OPT_CHROMA_RESAMPLER_METHOD (:786) */
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,7 +499,7 @@ static void convert_coeff (const double *src, int16_t *dest, int n, int precisio
 /* One gst_video_scaler_new + the function the reference would pick in get_functions
  * (video-scaler.c:1202-1342) for 4x8-bit pixels. */
 bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverterConfig &cfg, int in_size,
-    int out_size, bool horizontal, ScalePass *pass)
+    int out_size, bool horizontal, ScalePass *pass, bool h2_as_ntap)
 {
   std::vector<double> dtaps;
   int max_taps = resampler_init (method, n_taps_opt, cfg, in_size, out_size, pass->offset, dtaps);
@@ -516,11 +517,11 @@ bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverte
     pass->kind = SCALE_NEAREST;               /* h_near_u32 / v_near: copies s[offset[i]] */
     return true;
   }
-  if (max_taps == 2 && horizontal) {
+  if (max_taps == 2 && horizontal && !h2_as_ntap) {
     pass->kind = SCALE_2TAP;                  /* video_scale_h_2tap_4u8 -> ldreslinl with scale->inc */
     return true;
   }
-  if (max_taps == 2) {
+  if (max_taps == 2 && !horizontal) {
     pass->kind = SCALE_2TAP;                  /* video_scale_v_2tap_u8: taps at SCALE_U8_LQ + 2 bits */
     pass->precision = 8;
   } else {
@@ -758,6 +759,108 @@ static const char *lookup_fastpath (const VideoPlan &p, int alpha_mode_bits, boo
 }
 
 // ------------------------------------------------------------------------------------------------
+// convert_scale_planes on planar / semi-planar formats: setup_scale (video-converter.c:7958-8200)
+// ------------------------------------------------------------------------------------------------
+static int plan_planes (VideoPlan *plan, const char *fastpath)
+{
+  const GstAmdVideoInfo &in = plan->in_info, &out = plan->out_info;
+  const GstAmdVideoConverterConfig &cfg = plan->config;
+  const FormatDesc *fi = plan->fin, *fo = plan->fout;
+  const int method = cfg.resampler_method;
+  const int cr_method = method == GSTAMD_RESAMPLER_METHOD_NEAREST ? method : cfg.chroma_resampler_method;
+  plan->plane_mode = true;
+  plan->planes.clear ();
+  plan->ref_fastpath = fastpath;
+  uint64_t bytes = 0;
+  auto up = [](int v, int sub) { return -((-v) >> sub); };       /* GST_VIDEO_SUB_SCALE */
+  for (int i = 0; i < fo->n_planes; i++) {
+    PlanePlan pp;
+    pp.dst_plane = i;
+    pp.n_elems = 1;
+    int isub_w = 0, isub_h = 0, osub_w = 0, osub_h = 0;
+    if (i == 0) {
+      pp.src_plane = 0;
+    } else if (fo->kind == UNPACK_SEMI) {
+      pp.src_plane = 1;
+      pp.n_elems = 2;
+      isub_w = fi->w_sub, isub_h = fi->h_sub, osub_w = fo->w_sub, osub_h = fo->h_sub;
+    } else {
+      /* component of this destination plane -> the source plane holding the same component */
+      const bool is_u = i == fo->u_plane;
+      pp.src_plane = is_u ? fi->u_plane : fi->v_plane;
+      isub_w = fi->w_sub, isub_h = fi->h_sub, osub_w = fo->w_sub, osub_h = fo->h_sub;
+    }
+    pp.iw = up (in.width, isub_w);
+    pp.ih = up (in.height, isub_h);
+    pp.ow = up (out.width, osub_w);
+    pp.oh = up (out.height, osub_h);
+    const int rm = i == 0 ? method : cr_method;
+    const bool p1 = pp.n_elems == 1, lin = rm == GSTAMD_RESAMPLER_METHOD_LINEAR, near = rm == GSTAMD_RESAMPLER_METHOD_NEAREST;
+    bool need_h = false, need_v = false;
+    pp.kind = PLANE_SCALE;
+    if (pp.iw == pp.ow) {
+      if (pp.ih == pp.oh)
+        pp.kind = PLANE_COPY;
+      else if (pp.ih == 2 * pp.oh && p1 && lin)
+        pp.kind = PLANE_V_HALVE;
+      else if (2 * pp.ih == pp.oh && p1 && near)
+        pp.kind = PLANE_V_DOUBLE;
+      else
+        need_v = true;
+    } else if (pp.ih == pp.oh) {
+      if (pp.iw == 2 * pp.ow && p1 && lin)
+        pp.kind = PLANE_H_HALVE;
+      else if (2 * pp.iw == pp.ow && p1 && near)
+        pp.kind = PLANE_H_DOUBLE;
+      else
+        need_h = true;
+    } else {
+      if (pp.iw == 2 * pp.ow && pp.ih == 2 * pp.oh && p1 && lin)
+        pp.kind = PLANE_HV_HALVE;
+      else if (2 * pp.iw == pp.ow && 2 * pp.ih == pp.oh && p1 && near)
+        pp.kind = PLANE_HV_DOUBLE;
+      else
+        need_h = need_v = true;
+    }
+    if (pp.kind == PLANE_SCALE) {
+      ScalePass hp, vp;
+      /* get_functions (video-scaler.c:1202-1342): a 2-tap horizontal pass is ldreslin only for 1- and 4-byte pixels;
+       * the 2-byte UV pixels take video_scale_h_ntap_u8 with two 6-bit taps */
+      if (need_h)
+        make_scale_pass (rm, cfg.resampler_taps, cfg, pp.iw, pp.ow, true, &hp, pp.n_elems == 2);
+      if (need_v)
+        make_scale_pass (rm, cfg.resampler_taps, cfg, pp.ih, pp.oh, false, &vp, false);
+      hp.max_span = vp.max_span = 1 << 30;
+      if (need_h && need_v) {
+        /* gst_video_scaler_2d: horizontal first iff width * voffset[height - 1] <= width * height */
+        const bool h_first = (long) pp.ow * (long) vp.offset[pp.oh - 1] <= (long) pp.ow * pp.oh;
+        if (h_first) {
+          pp.passes.push_back (hp);
+          pp.passes.push_back (vp);
+        } else {
+          pp.passes.push_back (vp);
+          pp.passes.push_back (hp);
+        }
+      } else {
+        pp.passes.push_back (need_h ? hp : vp);
+      }
+    }
+    bytes += (uint64_t) pp.iw * pp.ih * pp.n_elems + (uint64_t) pp.ow * pp.oh * pp.n_elems;
+    plan->planes.push_back (pp);
+  }
+  plan->algorithmic_bytes = bytes;
+  std::string d = std::string ("scale_planes[") + fi->name + "->" + fo->name;
+  static const char *kn[] = {"copy", "h/2", "hx2", "v/2", "vx2", "hv/2", "hvx2", "scale"};
+  for (const PlanePlan &pp : plan->planes) {
+    d += std::string (",") + kn[pp.kind];
+    for (const ScalePass &ps : pp.passes)
+      d += std::string (ps.horizontal ? ":H" : ":V") + std::to_string (ps.n_taps);
+  }
+  plan->description = d + "]";
+  return GSTAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Source span of the outputs [t0, t1) of a horizontal pass (same rule as hscale_span on the device)
 static void pass_span (const ScalePass &pass, int t0, int t1, int *lo, int *hi)
 {
@@ -823,6 +926,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   if (in->width <= 0 || in->height <= 0 || out->width <= 0 || out->height <= 0)
     return fail (GSTAMD_ERR_INVALID, "bad frame size");
   plan->out_planar = plan->fout->kind != UNPACK_PACKED4;
+  plan->plane_mode = false;
   if (cfg.dither_quantization != 1)
     return fail (GSTAMD_ERR_UNSUPPORTED, "dither-quantization != 1 not implemented");
 
@@ -873,6 +977,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       force_nearest = true;
     else if (name == "convert_scale_planes" && plan->fin->kind == UNPACK_PACKED4)
       plane_scale = true;
+    else if (name == "convert_scale_planes" && plan->fin->kind == plan->fout->kind)
+      return plan_planes (plan, fp);
     else
       return fail (GSTAMD_ERR_UNSUPPORTED, std::string ("reference takes fastpath ") + fp +
           " for this conversion; no GPU kernel for it yet");

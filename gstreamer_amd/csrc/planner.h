@@ -98,6 +98,16 @@ struct TileGeom {
 };
 TileGeom pass_tile_geom (const ScalePass &pass);
 
+// one destination plane of convert_scale_planes on a planar / semi-planar format
+enum PlaneKind : int { PLANE_COPY = 0, PLANE_H_HALVE, PLANE_H_DOUBLE, PLANE_V_HALVE, PLANE_V_DOUBLE, PLANE_HV_HALVE, PLANE_HV_DOUBLE, PLANE_SCALE };
+struct PlanePlan {
+  int kind;                       // PlaneKind
+  int src_plane, dst_plane;
+  int n_elems;                    // bytes per pixel of the plane (1; 2 for the UV plane of NV12 / NV21)
+  int iw, ih, ow, oh;             // plane sizes in pixels
+  std::vector<ScalePass> passes;  // PLANE_SCALE: 1 or 2 passes in execution order
+};
+
 struct VideoPlan {
   GstAmdVideoInfo in_info, out_info;
   GstAmdVideoConverterConfig config;
@@ -110,6 +120,8 @@ struct VideoPlan {
   // chroma vertical pairing, one entry per source line: chroma rows of the pair's first and second
   // line and which of the two this line is (0 first / 1 second); rows equal => plain copy
   std::vector<int32_t> vpair;     // [in_height][2]: (row_a | role << 30), row_b
+  bool plane_mode;            // convert_scale_planes on a planar / semi-planar format: `planes` is the whole plan
+  std::vector<PlanePlan> planes;
   bool out_planar;            // destination is planar / semi-planar: the chain renders AYUV, pack_planar finishes
   PackPlanarParams pack;
   bool fast_pair;             // BASELINE C2 shape: line-pair kernel of video_fast.h is applicable
@@ -132,6 +144,6 @@ void converter_config_init (GstAmdVideoConverterConfig *config);
 void compute_convert_matrix (const VideoPlan &plan_inputs, int in_range, int in_matrix, int out_range,
     int out_matrix, bool in_yuv, bool out_yuv, int matrix_mode, double dm[4][4]);
 bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverterConfig &cfg, int in_size,
-    int out_size, bool horizontal, ScalePass *pass);
+    int out_size, bool horizontal, ScalePass *pass, bool h2_as_ntap = false);
 
 }  // namespace gstamd

@@ -593,32 +593,36 @@ GSTAMD_HD void scale2x2_body (const SRC &src, const ScaleDev &sh, const ScaleDev
   dst.put (x, y, r);
 }
 
+// vertical pass, one output pixel (4 x u8 word): video_scale_v_near_u8 / v_2tap_u8 / v_4tap_u8 / v_ntap_u8
+template <class SRC>
+GSTAMD_HD uint32_t vscale_px (const SRC &src, const ScaleDev &sd, int x, int y)
+{
+  const int off = (int) sd.offset[y];
+  if (sd.kind == SCALE_NEAREST)
+    return src.at (x, off);
+  if (sd.kind == SCALE_2TAP) {
+    const int p1 = sd.taps[(size_t) y * 2 + 1];
+    return v2tap_px (src.at (x, off), src.at (x, off + 1), p1);
+  }
+  const int16_t *t = sd.taps + (size_t) y * sd.n_taps;
+  int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int l = 0; l < sd.n_taps; l++) {
+    const uint32_t p = src.at (x, off + l);
+    const int tp = t[l];
+    a0 += (int) (p & 0xff) * tp;
+    a1 += (int) ((p >> 8) & 0xff) * tp;
+    a2 += (int) ((p >> 16) & 0xff) * tp;
+    a3 += (int) (p >> 24) * tp;
+  }
+  return lq_finish (a0, a1, a2, a3);
+}
+
 template <class SRC>
 GSTAMD_HD void vscale_body (const SRC &src, const ScaleDev &sd, const Dst &dst, int width, int out_h, int x, int y)
 {
   if (x >= width || y >= out_h)
     return;
-  uint32_t r;
-  const int off = (int) sd.offset[y];
-  if (sd.kind == SCALE_NEAREST) {
-    r = src.at (x, off);
-  } else if (sd.kind == SCALE_2TAP) {
-    const int p1 = sd.taps[(size_t) y * 2 + 1];
-    r = v2tap_px (src.at (x, off), src.at (x, off + 1), p1);
-  } else {
-    const int16_t *t = sd.taps + (size_t) y * sd.n_taps;
-    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int l = 0; l < sd.n_taps; l++) {
-      const uint32_t p = src.at (x, off + l);
-      const int tp = t[l];
-      a0 += (int) (p & 0xff) * tp;
-      a1 += (int) ((p >> 8) & 0xff) * tp;
-      a2 += (int) ((p >> 16) & 0xff) * tp;
-      a3 += (int) (p >> 24) * tp;
-    }
-    r = lq_finish (a0, a1, a2, a3);
-  }
-  dst.put (x, y, r);
+  dst.put (x, y, vscale_px (src, sd, x, y));
 }
 
 

@@ -16,6 +16,7 @@
 #include "video_scale_fast.h"
 #include "video_pack.h"
 #include "video_bilinear_fast.h"
+#include "video_planes.h"
 
 namespace gstamd {
 
@@ -190,6 +191,22 @@ __global__ __launch_bounds__ (64) void k_bilinear420 (BilParams bp, Planes pl, u
   bil_commit (bp, t0, t1, lane, r, &lds);
   __syncthreads ();                       /* one wave per workgroup: orders the LDS writes before the reads */
   bil_emit<CH, L> (bp, dst, dstride, t0, t1, y, r0, lane, &lds);
+}
+
+// plane scaler of planar / semi-planar formats (video_planes.h): one lane per output pixel of the plane
+__global__ __launch_bounds__ (256) void k_plane_simple (int kind, SrcPlane s, DstPlane d, int ow, int oh)
+{
+  plane_simple_body (kind, s, d, ow, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+__global__ __launch_bounds__ (256) void k_plane_hscale (SrcPlane s, ScaleDev sd, DstPlane d, int ow, int rows)
+{
+  plane_hscale_body (s, sd, d, ow, rows, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+__global__ __launch_bounds__ (256) void k_plane_vscale (SrcPlane s, ScaleDev sd, DstPlane d, int width, int oh)
+{
+  plane_vscale_body (s, sd, d, width, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
 }
 
 __global__ __launch_bounds__ (256) void k_pack_planar (PackPlanarParams pk, const uint8_t *__restrict__ src, int sstride, DstPlanes d)
@@ -542,6 +559,26 @@ hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &
   }
 #undef W
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_plane_simple (int kind, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems, int ow, int oh, hipStream_t stream)
+{
+  const SrcPlane s = {src, sstride, n_elems};
+  const DstPlane d = {dst, dstride, n_elems};
+  hipLaunchKernelGGL (k_plane_simple, dim3 ((ow + 255) / 256, oh), dim3 (256), 0, stream, kind, s, d, ow, oh);
+  return hipGetLastError ();
+}
+
+hipError_t launch_plane_pass (bool horizontal, const ScaleDev &sd, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems,
+    int ow, int oh, hipStream_t stream)
+{
+  const SrcPlane s = {src, sstride, n_elems};
+  const DstPlane d = {dst, dstride, n_elems};
+  if (horizontal)
+    hipLaunchKernelGGL (k_plane_hscale, dim3 ((ow + 255) / 256, oh), dim3 (256), 0, stream, s, sd, d, ow, oh);
+  else
+    hipLaunchKernelGGL (k_plane_vscale, dim3 ((ow + 255) / 256, oh), dim3 (256), 0, stream, s, sd, d, ow, oh);
+  return hipGetLastError ();
 }
 
 hipError_t launch_pack_planar (const PackPlanarParams &pk, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],

@@ -41,7 +41,7 @@ class ConverterConfig(C.Structure):
                 ("envelope", C.c_double), ("sharpness", C.c_double), ("sharpen", C.c_double),
                 ("cubic_b", C.c_double), ("cubic_c", C.c_double), ("alpha_mode", C.c_int32),
                 ("alpha_value", C.c_double), ("chroma_mode", C.c_int32), ("matrix_mode", C.c_int32),
-                ("dither_quantization", C.c_uint32), ("reserved", C.c_int32 * 8)]
+                ("dither_quantization", C.c_uint32), ("chroma_resampler_method", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class CompositorPad(C.Structure):

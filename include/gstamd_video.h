@@ -120,7 +120,8 @@ typedef struct GstAmdVideoConverterConfig {
   int32_t chroma_mode;           /* GstVideoConverter.chroma-mode */
   int32_t matrix_mode;           /* GstVideoConverter.matrix-mode */
   uint32_t dither_quantization;  /* GstVideoConverter.dither-quantization (1) */
-  int32_t reserved[8];
+  int32_t chroma_resampler_method; /* GstVideoConverter.chroma-resampler-method (LINEAR): chroma planes of the plane scaler */
+  int32_t reserved[7];
 } GstAmdVideoConverterConfig;
 
 typedef struct GstAmdVideoConverter GstAmdVideoConverter;

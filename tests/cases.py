@@ -112,6 +112,20 @@ VIDEO_CASES = [
     ("nv12_abgr_1p5_bilinear_none", "NV12", 642, 362, "ABGR", 428, 241, LIN, None, "none", "random"),
     ("nv12_bgrx_narrow_bilinear", "NV12", 130, 70, "BGRx", 65, 35, LIN, None, None, "random"),
     ("nv12_bgra_hdown_vsame_bilinear_cosited", "NV12", 640, 360, "BGRA", 320, 359, LIN, None, "cosited", "random"),
+    # convert_scale_planes on planar / semi-planar formats: plane by plane (copy, halve / double helpers, 2-D scaler)
+    ("i420_i420_half_bilinear_planes", "I420", 640, 360, "I420", 320, 180, LIN, None, None, "random"),
+    ("i420_i420_1080p_to_720p_bilinear_planes", "I420", 1920, 1080, "I420", 1280, 720, LIN, None, None, "random"),
+    ("nv12_nv12_half_bilinear_planes", "NV12", 640, 360, "NV12", 320, 180, LIN, None, None, "random"),
+    ("nv12_nv12_odd_cubic_planes", "NV12", 322, 241, "NV12", 201, 133, {}, None, None, "random"),
+    ("nv21_nv21_up_lanczos_planes", "NV21", 160, 90, "NV21", 333, 200, LAN, None, None, "random"),
+    ("i420_yv12_copy_planes", "I420", 322, 241, "YV12", 322, 241, {}, None, None, "random"),
+    ("i420_y444_planes", "I420", 320, 240, "Y444", 320, 240, {}, None, None, "random"),
+    ("y444_i420_planes_linear_halve", "Y444", 320, 240, "I420", 320, 240, LIN, None, None, "random"),
+    ("y42b_i420_planes", "Y42B", 130, 70, "I420", 130, 70, {}, None, None, "random"),
+    ("i420_y42b_nearest_double_planes", "I420", 64, 48, "Y42B", 64, 48, NEAR, None, None, "random"),
+    ("yv12_y444_up_nearest_planes", "YV12", 64, 48, "Y444", 128, 96, NEAR, None, None, "random"),
+    ("y444_y444_vonly_lanczos_planes", "Y444", 100, 80, "Y444", 100, 37, LAN, None, None, "random"),
+    ("i420_i420_mixed_cubic_planes", "I420", 200, 100, "I420", 300, 50, {}, None, None, "random"),
     # wide-kernel tile edges: row ends exactly at a 1024-px run / one dword past it / inside a lane
     ("nv12_bgra_1024x34_jpeg", "NV12", 1024, 34, "BGRA", 1024, 34, {}, None, "jpeg", "random"),
     ("nv21_rgba_2048x18_mpeg2", "NV21", 2048, 18, "RGBA", 2048, 18, {}, None, "mpeg2", "random"),
@@ -148,9 +162,7 @@ VIDEO_CASES = [
 
 # conversions the reference runs through code this library has no kernel for -> must be REFUSED
 VIDEO_REFUSED = [
-    ("I420", 64, 64, "I420", 32, 32, {}),                # convert_scale_planes on planar formats: planar output
     ("NV12", 320, 180, "BGRA", 640, 100, LAN),           # reference temp-line aliasing (see planner.cpp)
-    ("NV12", 64, 64, "NV12", 32, 32, {}),                # convert_scale_planes on semi-planar formats
     ("AYUV", 64, 64, "I420", 64, 64, {}),                # convert_AYUV_I420 fastpath
 ]
 

@@ -12,6 +12,7 @@
 #include "../../gstreamer_amd/csrc/video_scale_fast.h"
 #include "../../gstreamer_amd/csrc/video_pack.h"
 #include "../../gstreamer_amd/csrc/video_bilinear_fast.h"
+#include "../../gstreamer_amd/csrc/video_planes.h"
 
 using namespace gstamd;
 
@@ -158,6 +159,47 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   for (int i = 0; i < in->n_planes; i++) {
     pl.p[i] = src + in->offset[i];
     pl.stride[i] = in->stride[i];
+  }
+  if (p.plane_mode) {                     /* convert_scale_planes: the plane kernels' bodies over their grids */
+    for (const PlanePlan &pp : p.planes) {
+      const SrcPlane sp = {pl.p[pp.src_plane], pl.stride[pp.src_plane], pp.n_elems};
+      const DstPlane dp = {dst + out->offset[pp.dst_plane], out->stride[pp.dst_plane], pp.n_elems};
+      if (pp.kind != PLANE_SCALE) {
+        for (int y = 0; y < pp.oh; y++)
+          for (int x = 0; x < pp.ow; x++)
+            plane_simple_body (pp.kind, sp, dp, pp.ow, pp.oh, x, y);
+        continue;
+      }
+      ScaleDev sd[2];
+      for (size_t k = 0; k < pp.passes.size (); k++) {
+        memset (&sd[k], 0, sizeof (sd[k]));
+        sd[k].kind = pp.passes[k].kind;
+        sd[k].n_taps = pp.passes[k].n_taps;
+        sd[k].inc = pp.passes[k].inc;
+        sd[k].offset = pp.passes[k].offset.data ();
+        sd[k].taps = pp.passes[k].taps.data ();
+      }
+      auto run = [&](bool horizontal, const ScaleDev &s1, const SrcPlane &a, const DstPlane &b, int w, int h) {
+        for (int y = 0; y < h; y++)
+          for (int x = 0; x < w; x++) {
+            if (horizontal)
+              plane_hscale_body (a, s1, b, w, h, x, y);
+            else
+              plane_vscale_body (a, s1, b, w, h, x, y);
+          }
+      };
+      if (pp.passes.size () == 1) {
+        run (pp.passes[0].horizontal, sd[0], sp, dp, pp.ow, pp.oh);
+      } else {
+        const int tw = pp.passes[0].horizontal ? pp.ow : pp.iw, th = pp.passes[0].horizontal ? pp.ih : pp.oh;
+        std::vector<uint8_t> tmp ((size_t) tw * th * pp.n_elems);
+        const DstPlane td = {tmp.data (), tw * pp.n_elems, pp.n_elems};
+        const SrcPlane ts = {tmp.data (), tw * pp.n_elems, pp.n_elems};
+        run (pp.passes[0].horizontal, sd[0], sp, td, tw, th);
+        run (pp.passes[1].horizontal, sd[1], ts, dp, pp.ow, pp.oh);
+      }
+    }
+    return GSTAMD_OK;
   }
   if (p.out_planar) {                     /* chain -> AYUV image, then the pack kernel body over its grid */
     std::vector<uint8_t> img ((size_t) out->width * 4 * out->height);

@@ -963,10 +963,12 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    *  - convert_I420_* and convert_AYUV_ARGB / _BGRA / _ABGR / _RGBA (:6544-6770): video_orc_convert_{I420,AYUV}_* with
    *    (im[0][0], im[0][2], im[2][1], im[1][1], im[1][2]) of video_converter_compute_matrix (:1444), whatever the
    *    matrix looks like - the arithmetic of video_orc_convert_AYUV_ARGB (video-orc.orc:1634, 1859);
+   *  - convert_AYUV_I420 / _Y42B / _Y444 (:5575-5800; video-orc.orc:1445-1540): plain avgub of the chroma of the two lines,
+   *    then of the pixel pair - the non-cosited downsampler whatever the chroma sites say;
    *  - convert_scale_planes on a one-plane 4-byte format (setup_scale :7958-8075, convert_plane_hv :7693): the plane
    *    goes through gst_video_scaler_2d as raw 4 x u8 pixels - no unpack / matrix / alpha / pack - and the order of the
    *    two passes is the 2-D scaler's own rule (video-scaler.c:1542-1545), not chain_scale's. */
-  bool force_nearest = false, force_ayuv_argb = false, plane_scale = false;
+  bool force_nearest = false, force_ayuv_argb = false, plane_scale = false, force_avg_down = false;
   if (const char *fp = lookup_fastpath (*plan, alpha_bits, same_matrix)) {
     const std::string name = fp;
     if (name == "convert_I420_xRGB")
@@ -975,6 +977,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       force_ayuv_argb = true;
     else if (name == "convert_planar_AYUV")
       force_nearest = true;
+    else if (name == "convert_AYUV_planar")
+      force_avg_down = true;
     else if (name == "convert_scale_planes" && plan->fin->kind == UNPACK_PACKED4)
       plane_scale = true;
     else if (name == "convert_scale_planes" && plan->fin->kind == plan->fout->kind)
@@ -1113,6 +1117,10 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         pk.down_h = (out->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? 2 : 1;
       if (fo->h_sub == 1 && !(out->chroma_site & GSTAMD_CHROMA_SITE_V_COSITED))
         pk.down_v = 1;          /* the cosited vertical variant is an h-only stub (video-chroma.c:996) */
+    }
+    if (force_avg_down) {
+      pk.down_h = fo->w_sub == 1 ? 1 : 0;
+      pk.down_v = fo->h_sub == 1 ? 1 : 0;
     }
     for (int i = 0; i < 4; i++)
       post.pack_pos[i] = i;

@@ -126,6 +126,12 @@ VIDEO_CASES = [
     ("yv12_y444_up_nearest_planes", "YV12", 64, 48, "Y444", 128, 96, NEAR, None, None, "random"),
     ("y444_y444_vonly_lanczos_planes", "Y444", 100, 80, "Y444", 100, 37, LAN, None, None, "random"),
     ("i420_i420_mixed_cubic_planes", "I420", 200, 100, "I420", 300, 50, {}, None, None, "random"),
+    # convert_AYUV_I420 / _Y42B / _Y444 fastpaths (plain 2x2 / pair averages)
+    ("ayuv_i420_64x64_fastpath", "AYUV", 64, 64, "I420", 64, 64, {}, None, None, "random"),
+    ("ayuv_yv12_322x240_fastpath_cosited_sites", "AYUV", 322, 240, "YV12", 322, 240, {}, None, "cosited", "random"),
+    ("ayuv_y42b_130x71_fastpath", "AYUV", 130, 71, "Y42B", 130, 71, {}, None, None, "random"),
+    ("ayuv_y444_33x17_fastpath", "AYUV", 33, 17, "Y444", 33, 17, {}, None, None, "random"),
+    ("ayuv_i420_65x64_generic_odd_width", "AYUV", 65, 64, "I420", 65, 64, {}, None, None, "random"),
     # wide-kernel tile edges: row ends exactly at a 1024-px run / one dword past it / inside a lane
     ("nv12_bgra_1024x34_jpeg", "NV12", 1024, 34, "BGRA", 1024, 34, {}, None, "jpeg", "random"),
     ("nv21_rgba_2048x18_mpeg2", "NV21", 2048, 18, "RGBA", 2048, 18, {}, None, "mpeg2", "random"),
@@ -163,7 +169,6 @@ VIDEO_CASES = [
 # conversions the reference runs through code this library has no kernel for -> must be REFUSED
 VIDEO_REFUSED = [
     ("NV12", 320, 180, "BGRA", 640, 100, LAN),           # reference temp-line aliasing (see planner.cpp)
-    ("AYUV", 64, 64, "I420", 64, 64, {}),                # convert_AYUV_I420 fastpath
 ]
 
 

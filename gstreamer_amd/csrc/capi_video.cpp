@@ -64,7 +64,38 @@ static FastParams make_fast_params (const VideoPlan &p)
   fp.width = p.front.width;
   fp.height = p.front.height;
   fast_params_finish (fp, p.matrix.p, p.post.pack_pos, p.front.u_plane);
+  /* with a source crop the chroma upsampler still sees the frame's rows above / below the crop (do_unpack_lines :2966) */
+  fp.crow_lo = -(p.rect.in_y >> 1);
+  fp.crow_hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
   return fp;
+}
+
+// rectangle complement of every destination plane <- the border pixel (convert_fill_border :7190-7290)
+static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[3], const int strides[3], hipStream_t stream)
+{
+  const FormatDesc *f = p.fout;
+  const RectPlan &rc = p.rect;
+  const int w = p.out_info.width, h = p.out_info.height;
+  auto up = [](int v, int sub) { return -((-v) >> sub); };
+  hipError_t e = hipSuccess;
+  if (f->kind == UNPACK_PACKED4) {
+    uint32_t v = 0;
+    for (int c = 0; c < 4; c++)
+      v |= (uint32_t) rc.border[c] << (8 * f->pos[c]);
+    return launch_fill_border (planes[0], strides[0], 4, v, rc.out_maxw, rc.out_maxh, rc.out_x, rc.out_y, w, h, stream);
+  }
+  e = launch_fill_border (planes[0], strides[0], 1, rc.border[1], rc.out_maxw, rc.out_maxh, rc.out_x, rc.out_y, w, h, stream);
+  const int cmw = up (rc.out_maxw, f->w_sub), cmh = up (rc.out_maxh, f->h_sub), cx = rc.out_x >> f->w_sub, cy = rc.out_y >> f->h_sub;
+  const int cw = up (w, f->w_sub), ch = up (h, f->h_sub);
+  if (e == hipSuccess && f->kind == UNPACK_SEMI) {
+    const uint32_t uv = f->u_plane ? (uint32_t) rc.border[2] | ((uint32_t) rc.border[3] << 8) : (uint32_t) rc.border[3] | ((uint32_t) rc.border[2] << 8);
+    e = launch_fill_border (planes[1], strides[1], 2, uv, cmw, cmh, cx, cy, cw, ch, stream);
+  } else if (e == hipSuccess) {
+    e = launch_fill_border (planes[f->u_plane], strides[f->u_plane], 1, rc.border[2], cmw, cmh, cx, cy, cw, ch, stream);
+    if (e == hipSuccess)
+      e = launch_fill_border (planes[f->v_plane], strides[f->v_plane], 1, rc.border[3], cmw, cmh, cx, cy, cw, ch, stream);
+  }
+  return e;
 }
 
 extern "C" {
@@ -182,6 +213,8 @@ static int ensure_tables (GstAmdVideoConverter *c)
 
 // the chain up to a packed 4-byte image: unpack, chroma upsample, scale, matrix, alpha, byte order
 static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream);
+static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
+    const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES], hipStream_t stream);
 
 int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *const src_planes[GSTAMD_VIDEO_MAX_PLANES],
     const int32_t src_stride[GSTAMD_VIDEO_MAX_PLANES], void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
@@ -201,7 +234,32 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
     pl.stride[i] = src_stride ? src_stride[i] : p.in_info.stride[i];
     if (!pl.p[i])
       return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
+    pl.p[i] += plane_origin (p.fin, i, p.rect.in_x, p.rect.in_y, pl.stride[i]);
   }
+  /* destination rectangle: the picture is written at (out_x, out_y), the rest of the frame gets the border */
+  void *dest_rect[GSTAMD_VIDEO_MAX_PLANES] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t dest_rect_stride[GSTAMD_VIDEO_MAX_PLANES] = {0, 0, 0, 0};
+  for (int i = 0; i < p.out_info.n_planes; i++) {
+    dest_rect_stride[i] = dest_stride ? dest_stride[i] : p.out_info.stride[i];
+    if (!dest_planes[i])
+      return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+    dest_rect[i] = (uint8_t *) dest_planes[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, dest_rect_stride[i]);
+  }
+  if (p.rect.fill) {
+    uint8_t *bp[3] = {(uint8_t *) dest_planes[0], (uint8_t *) dest_planes[1], (uint8_t *) dest_planes[2]};
+    hipError_t be = fill_borders (p, bp, dest_rect_stride, stream);
+    if (be != hipSuccess)
+      return hip_fail (be, "k_fill_border");
+  }
+  return convert_rect (c, pl, dest_rect, dest_rect_stride, stream);
+}
+
+// the conversion proper: source planes already at the crop origin, destination planes at the rectangle origin
+static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
+    const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES], hipStream_t stream)
+{
+  const VideoPlan &p = c->plan;
+  int r = GSTAMD_OK;
   if (p.plane_mode) {
     /* convert_scale_planes: every destination plane from one source plane */
     for (size_t i = 0; i < p.planes.size (); i++) {
@@ -329,7 +387,7 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
             const int line = (int) p.passes[1].offset[y] + l;
             int ra, rb, role;
             bil_rows (probe, line, &ra, &rb, &role);
-            const int e0 = p.vpair[2 * line], ta = e0 & 0x3fffffff, trole = e0 >> 30, tb = p.vpair[2 * line + 1];
+            const int e0 = p.vpair[2 * line], ta = vpair_row (e0), trole = vpair_role (e0), tb = p.vpair[2 * line + 1];
             regular = ta == ra && tb == rb && (ra == rb || trole == role);
           }
         bp.regular_pairs = regular ? 1 : 0;
@@ -394,7 +452,8 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     pl.stride[0] = p.in_info.stride[0];
     pl.stride[1] = p.in_info.stride[1];
     d[i] = (uint8_t *) dest[i] + p.out_info.offset[0];
-    all_fast = fast_pair_usable (p, pl, d[i], p.out_info.stride[0]);
+    all_fast = fast_pair_usable (p, pl, d[i], p.out_info.stride[0]) && p.rect.in_x == 0 && p.rect.in_y == 0 && p.rect.out_x == 0 &&
+        p.rect.out_y == 0 && !p.rect.fill;
     y[i] = pl.p[0];
     uv[i] = pl.p[1];
   }

@@ -122,7 +122,10 @@ void converter_config_init (GstAmdVideoConverterConfig *c)
   c->chroma_mode = GSTAMD_CHROMA_MODE_FULL;
   c->matrix_mode = GSTAMD_MATRIX_MODE_FULL;
   c->dither_quantization = 1;
-  c->chroma_resampler_method = GSTAMD_RESAMPLER_METHOD_LINEAR;     /* DEFAULT_OPT_CHROMA_RESAMPLER_METHOD (:786) */
+  c->chroma_resampler_method = GSTAMD_RESAMPLER_METHOD_LINEAR;
+  c->fill_border = 1;                                                /* DEFAULT_OPT_FILL_BORDER */
+  c->border_argb = 0xff000000u;                                      /* DEFAULT_OPT_BORDER_ARGB */
+      /* DEFAULT_OPT_CHROMA_RESAMPLER_METHOD (:786) */
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -581,6 +584,7 @@ struct SimCache {
 struct Sim {
   std::vector<int32_t> *vpair;
   int in_height;
+  int line_lo, line_hi;     // lines the unpacker can deliver, relative to the crop origin: do_unpack_lines (:2966) clamps to the FRAME
   int h_sub;
   int up_n_lines, up_offset;
 
@@ -617,8 +621,8 @@ struct Sim {
   }
   int chroma_row (int line) const
   {
-    int cl = std::min (std::max (line, 0), in_height - 1);
-    return cl >> h_sub;
+    int cl = std::min (std::max (line, line_lo), line_hi);
+    return cl >> h_sub;                   /* arithmetic: line -1 -> row -1 */
   }
   bool need_line (SimCache *c, int out_line, int in_line)
   {
@@ -639,7 +643,7 @@ struct Sim {
           for (int i = 0; i < 2; i++) {
             int line = start_line + i;
             if (line >= 0 && line < in_height) {
-              (*vpair)[2 * line + 0] = ra | (i << 30);
+              (*vpair)[2 * line + 0] = vpair_pack (ra, i);
               (*vpair)[2 * line + 1] = rb;
             }
           }
@@ -681,6 +685,8 @@ static void simulate_vpairs (VideoPlan *plan, int out_height)
   Sim sim;
   sim.vpair = &plan->vpair;
   sim.in_height = H;
+  sim.line_lo = -plan->rect.in_y;
+  sim.line_hi = plan->rect.in_maxh - 1 - plan->rect.in_y;
   sim.h_sub = plan->front.h_sub;
   sim.up_n_lines = 2;
   sim.up_offset = -1;
@@ -715,7 +721,7 @@ static void simulate_vpairs (VideoPlan *plan, int out_height)
 static const char *lookup_fastpath (const VideoPlan &p, int alpha_mode_bits, bool same_matrix)
 {
   const int in = p.in_info.format, out = p.out_info.format;
-  const bool same_size = p.in_info.width == p.out_info.width && p.in_info.height == p.out_info.height;
+  const bool same_size = p.ref_same_size;
   const bool need_copy = alpha_mode_bits & 1, need_set = alpha_mode_bits & 2, need_mult = alpha_mode_bits & 4;
   if (p.config.dither_quantization != 1)
     return nullptr;
@@ -902,7 +908,7 @@ TileGeom pass_tile_geom (const ScalePass &pass)
   return best;
 }
 
-int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
+static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *config, VideoPlan *plan, std::string *error)
 {
   auto fail = [&](int code, const std::string &msg) {
@@ -987,6 +993,9 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       return fail (GSTAMD_ERR_UNSUPPORTED, std::string ("reference takes fastpath ") + fp +
           " for this conversion; no GPU kernel for it yet");
     plan->ref_fastpath = fp;
+    if ((force_nearest || force_ayuv_argb || force_avg_down) && (in->width != out->width || in->height != out->height))
+      return fail (GSTAMD_ERR_UNSUPPORTED, "the reference selects a same-size fastpath by the uncropped input size while the crop differs from the "
+          "destination rectangle; not reproduced");
   }
 
   // ---- front: unpack + chroma upsample (chain_unpack_line, chain_upsample) ----------------------
@@ -1196,6 +1205,104 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     d += std::string ("+pack_planar[h") + std::to_string (plan->pack.down_h) + ",v" + std::to_string (plan->pack.down_v) + "]";
   plan->description = d;
   return GSTAMD_OK;
+}
+
+// gst_video_converter_new's rectangle options (:2307-2366), then the plan for the cropped picture
+int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
+    const GstAmdVideoConverterConfig *config, VideoPlan *plan, std::string *error)
+{
+  if (!in || !out || !plan) {
+    if (error)
+      *error = "NULL argument";
+    return GSTAMD_ERR_INVALID;
+  }
+  GstAmdVideoConverterConfig cfg;
+  if (config)
+    cfg = *config;
+  else
+    converter_config_init (&cfg);
+  const FormatDesc *fi = format_desc (in->format), *fo = format_desc (out->format);
+  RectPlan rc;
+  memset (&rc, 0, sizeof (rc));
+  GstAmdVideoInfo ein = *in, eout = *out;
+  if (fi && fo && in->width > 0 && in->height > 0 && out->width > 0 && out->height > 0) {
+    const int in_maxw = in->width, in_maxh = in->height, out_maxw = out->width, out_maxh = out->height;
+    int in_x = cfg.src_x & ~((1 << fi->w_sub) - 1), in_y = cfg.src_y & ~((1 << fi->h_sub) - 1);
+    int in_w = cfg.src_width > 0 ? cfg.src_width : in_maxw - in_x, in_h = cfg.src_height > 0 ? cfg.src_height : in_maxh - in_y;
+    in_w = std::min (in_w, in_maxw - in_x);
+    if (in_w + in_x < 0 || in_w + in_x > in_maxw)
+      in_w = 0;
+    in_h = std::min (in_h, in_maxh - in_y);
+    if (in_h + in_y < 0 || in_h + in_y > in_maxh)
+      in_h = 0;
+    int out_x = cfg.dest_x & ~((1 << fo->w_sub) - 1), out_y = cfg.dest_y & ~((1 << fo->h_sub) - 1);
+    int out_w = cfg.dest_width > 0 ? cfg.dest_width : out_maxw - out_x, out_h = cfg.dest_height > 0 ? cfg.dest_height : out_maxh - out_y;
+    if (out_w > out_maxw - out_x)
+      out_w = out_maxw - out_x;
+    out_w = std::max (0, std::min (out_w, out_maxw));
+    if (out_w + out_x < 0 || out_w + out_x > out_maxw)
+      out_w = 0;
+    if (out_h > out_maxh - out_y)
+      out_h = out_maxh - out_y;
+    out_h = std::max (0, std::min (out_h, out_maxh));
+    if (out_h + out_y < 0 || out_h + out_y > out_maxh)
+      out_h = 0;
+    if (in_x < 0 || in_y < 0 || out_x < 0 || out_y < 0 || in_w <= 0 || in_h <= 0 || out_w <= 0 || out_h <= 0) {
+      if (error)
+        *error = "empty or negative source / destination rectangle";
+      return GSTAMD_ERR_UNSUPPORTED;
+    }
+    rc.in_x = in_x;
+    rc.in_y = in_y;
+    rc.out_x = out_x;
+    rc.out_y = out_y;
+    rc.out_maxw = out_maxw;
+    rc.out_maxh = out_maxh;
+    rc.in_maxw = in_maxw;
+    rc.in_maxh = in_maxh;
+    rc.fill = cfg.fill_border != 0 && (out_h < out_maxh || out_w < out_maxw);
+    ein.width = in_w;
+    ein.height = in_h;
+    eout.width = out_w;
+    eout.height = out_h;
+    plan->ref_same_size = in_maxw == out_w && in_maxh == out_h;
+    /* setup_borderline (:2189-2262): the border pixel in unpack order */
+    const uint32_t argb = cfg.border_argb;
+    const int a = argb >> 24, r = (argb >> 16) & 0xff, g = (argb >> 8) & 0xff, b = argb & 0xff;
+    rc.border[0] = (uint8_t) a;
+    rc.border[1] = (uint8_t) r;
+    rc.border[2] = (uint8_t) g;
+    rc.border[3] = (uint8_t) b;
+    if (fo->yuv) {
+      /* identity -> compute_matrix_to_YUV (force) -> rint; then 16 / 128 / 128 are added whatever the range */
+      M44 dm;
+      m_identity (dm);
+      double Kr = 0, Kb = 0;
+      const int mtx = cfg.matrix_mode == GSTAMD_MATRIX_MODE_INPUT_ONLY ? (fi->yuv ? in->color_matrix : GSTAMD_COLOR_MATRIX_RGB) : out->color_matrix;
+      if (get_Kr_Kb (mtx, &Kr, &Kb))
+        m_RGB_to_YCbCr (dm, Kr, Kb);
+      int offset[4], scale[4];
+      range_offsets (out->color_range, true, offset, scale);
+      m_scale_components (dm, (float) scale[0], (float) scale[1], (float) scale[2]);
+      m_offset_components (dm, offset[0], offset[1], offset[2]);
+      int im[3][3];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+          im[i][j] = (int) rint (dm[i][j]);
+      auto clamp8 = [](int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); };
+      rc.border[1] = (uint8_t) clamp8 (16 + ((r * im[0][0] + g * im[0][1] + b * im[0][2]) >> 8));
+      rc.border[2] = (uint8_t) clamp8 (128 + ((r * im[1][0] + g * im[1][1] + b * im[1][2]) >> 8));
+      rc.border[3] = (uint8_t) clamp8 (128 + ((r * im[2][0] + g * im[2][1] + b * im[2][2]) >> 8));
+    }
+  } else {
+    plan->ref_same_size = in->width == out->width && in->height == out->height;
+  }
+  if (rc.in_maxh == 0) {
+    rc.in_maxw = in->width;
+    rc.in_maxh = in->height;
+  }
+  plan->rect = rc;
+  return plan_core (&ein, &eout, &cfg, plan, error);
 }
 
 }  // namespace gstamd

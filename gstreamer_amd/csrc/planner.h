@@ -108,6 +108,16 @@ struct PlanePlan {
   std::vector<ScalePass> passes;  // PLANE_SCALE: 1 or 2 passes in execution order
 };
 
+// source crop / destination rectangle / borders (gst_video_converter_new :2307-2366, convert_fill_border :7190)
+struct RectPlan {
+  int in_x, in_y;               // crop origin in the source frame
+  int out_x, out_y;             // origin of the converted picture in the destination frame
+  int out_maxw, out_maxh;       // destination frame size
+  int in_maxw, in_maxh;         // source frame size (lines above / below the crop exist and are read by the chroma upsampler)
+  bool fill;                    // borders exist and are to be filled
+  uint8_t border[4];            // border pixel in unpack order: A, R, G, B or A, Y, U, V
+};
+
 struct VideoPlan {
   GstAmdVideoInfo in_info, out_info;
   GstAmdVideoConverterConfig config;
@@ -120,6 +130,8 @@ struct VideoPlan {
   // chroma vertical pairing, one entry per source line: chroma rows of the pair's first and second
   // line and which of the two this line is (0 first / 1 second); rows equal => plain copy
   std::vector<int32_t> vpair;     // [in_height][2]: (row_a | role << 30), row_b
+  RectPlan rect;
+  bool ref_same_size;         // video_converter_lookup_fastpath's same_size: FULL input size == destination rectangle (:8942)
   bool plane_mode;            // convert_scale_planes on a planar / semi-planar format: `planes` is the whole plan
   std::vector<PlanePlan> planes;
   bool out_planar;            // destination is planar / semi-planar: the chain renders AYUV, pack_planar finishes
@@ -131,6 +143,28 @@ struct VideoPlan {
   std::string description;
   uint64_t algorithmic_bytes;
 };
+
+// byte offset of pixel (x, y) inside plane `plane` of a frame of format f (x, y multiples of the subsampling)
+inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int stride)
+{
+  if (f->kind == UNPACK_PACKED4)
+    return (size_t) y * stride + (size_t) x * 4;
+  if (plane == 0)
+    return (size_t) y * stride + (size_t) x;
+  const size_t row = (size_t) (y >> f->h_sub) * stride;
+  return f->kind == UNPACK_SEMI ? row + (size_t) (x >> f->w_sub) * 2 : row + (size_t) (x >> f->w_sub);
+}
+
+// vpair table entry 0: chroma row of the pair's first line (signed 30 bits: with a source crop the row above the crop
+// origin is -1) | role << 30; entry 1: row of the second line
+#if defined(__HIPCC__)
+#define GSTAMD_VP __host__ __device__ inline
+#else
+#define GSTAMD_VP inline
+#endif
+GSTAMD_VP int vpair_row (int e0) { return (int) ((uint32_t) e0 << 2) >> 2; }
+GSTAMD_VP int vpair_role (int e0) { return (e0 >> 30) & 1; }
+GSTAMD_VP int vpair_pack (int row, int role) { return (int) (((uint32_t) row & 0x3fffffffu) | ((uint32_t) role << 30)); }
 
 // Returns GSTAMD_OK and fills `plan`, or an error code (GSTAMD_ERR_UNSUPPORTED for conversions the
 // reference would run through a path this library has no kernel for yet).

@@ -54,9 +54,9 @@ GSTAMD_HOSTDEV void bil_rows (const BilParams &bp, int line, int *ra, int *rb, i
   if (bp.regular_pairs) {
     // pairs (2p - 1, 2p) over chroma rows (p - 1, p), clamped into the plane: what do_upsample_lines produces when every
     // source line is consumed in order (the planner checks its simulated table against this form)
-    const int n_crows = (bp.fp.height + 1) >> 1, p = (line + 1) >> 1;
-    *ra = p > 0 ? p - 1 : 0;
-    *rb = p < n_crows ? p : n_crows - 1;
+    const int p = (line + 1) >> 1;
+    *ra = p - 1 > bp.fp.crow_lo ? p - 1 : bp.fp.crow_lo;
+    *rb = p < bp.fp.crow_hi ? p : bp.fp.crow_hi;
     *role = (line & 1) ? 0 : 1;
     if (*ra == *rb)
       *role = 0;
@@ -64,8 +64,8 @@ GSTAMD_HOSTDEV void bil_rows (const BilParams &bp, int line, int *ra, int *rb, i
   }
   if (bp.vpair) {
     const int e0 = bp.vpair[2 * line];
-    *ra = e0 & 0x3fffffff;
-    *role = e0 >> 30;
+    *ra = vpair_row (e0);
+    *role = vpair_role (e0);
     *rb = bp.vpair[2 * line + 1];
   } else {
     *ra = *rb = line >> 1;
@@ -124,7 +124,7 @@ GSTAMD_HD void bil_fetch (const BilParams &bp, const Planes &pl, int t0, int t1,
     for (int s = 0; s < 4; s++) {
       int ra, rb, role;
       bil_rows (bp, r0 + (s >> 1), &ra, &rb, &role);
-      const uint8_t *row = pl.p[1] + (size_t) ((s & 1) ? rb : ra) * pl.stride[1];
+      const uint8_t *row = pl.p[1] + (ptrdiff_t) ((s & 1) ? rb : ra) * pl.stride[1];
       if (k + 8 <= cw && vec) {
         wide_load16<false> (row + 2 * k, 4, true, r.m[s]);
       } else {

@@ -115,13 +115,13 @@ GSTAMD_HD UV load_uv (const FrontParams &f, const Planes &pl, int crow, int k)
 {
   UV r;
   if (f.kind == UNPACK_SEMI) {
-    const uint8_t *p = pl.p[1] + (size_t) crow * pl.stride[1] + 2 * k;
+    const uint8_t *p = pl.p[1] + (ptrdiff_t) crow * pl.stride[1] + 2 * k;
     const int c0 = p[0], c1 = p[1];
     r.u = f.u_plane ? c0 : c1;           // NV12: U first; NV21: V first
     r.v = f.u_plane ? c1 : c0;
   } else {
-    r.u = pl.p[f.u_plane][(size_t) crow * pl.stride[f.u_plane] + k];
-    r.v = pl.p[f.v_plane][(size_t) crow * pl.stride[f.v_plane] + k];
+    r.u = pl.p[f.u_plane][(ptrdiff_t) crow * pl.stride[f.u_plane] + k];
+    r.v = pl.p[f.v_plane][(ptrdiff_t) crow * pl.stride[f.v_plane] + k];
   }
   return r;
 }
@@ -165,7 +165,7 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
   UV c;
   if (f.chroma_v2) {
     const int e0 = vpair[2 * y], rb = vpair[2 * y + 1];
-    const int ra = e0 & 0x3fffffff, role = e0 >> 30;
+    const int ra = vpair_row (e0), role = vpair_role (e0);
     const UV a = chroma_h_at (f, pl, ra, x);
     if (ra == rb) {
       c = a;
@@ -265,7 +265,7 @@ struct Chroma6 { int u[6], v[6]; };     // samples k0-1 .. k0+4
 GSTAMD_HD void load_chroma6 (const FrontParams &f, const Planes &pl, int crow, int k0, int cw, Chroma6 &c)
 {
   if (f.kind == UNPACK_SEMI) {
-    const uint8_t *row = pl.p[1] + (size_t) crow * pl.stride[1];
+    const uint8_t *row = pl.p[1] + (ptrdiff_t) crow * pl.stride[1];
     const uint2 mid = *(const uint2 *) (row + 2 * k0);           // samples k0..k0+3 (8-byte aligned: k0 % 4 == 0)
     const uint32_t w[2] = {mid.x, mid.y};
     const int su = f.u_plane ? 0 : 8, sv = f.u_plane ? 8 : 0;
@@ -282,8 +282,8 @@ GSTAMD_HD void load_chroma6 (const FrontParams &f, const Planes &pl, int crow, i
     c.u[5] = (pp >> su) & 0xff;
     c.v[5] = (pp >> sv) & 0xff;
   } else {
-    const uint8_t *ru = pl.p[f.u_plane] + (size_t) crow * pl.stride[f.u_plane];
-    const uint8_t *rv = pl.p[f.v_plane] + (size_t) crow * pl.stride[f.v_plane];
+    const uint8_t *ru = pl.p[f.u_plane] + (ptrdiff_t) crow * pl.stride[f.u_plane];
+    const uint8_t *rv = pl.p[f.v_plane] + (ptrdiff_t) crow * pl.stride[f.v_plane];
     const uint32_t mu = *(const uint32_t *) (ru + k0), mv = *(const uint32_t *) (rv + k0);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -336,8 +336,8 @@ GSTAMD_HD void front_span8 (const FrontParams &f, const Planes &pl, const int *_
   int ra, rb, role = 0;
   if (f.chroma_v2) {
     const int e0 = vpair[2 * y];
-    ra = e0 & 0x3fffffff;
-    role = e0 >> 30;
+    ra = vpair_row (e0);
+    role = vpair_role (e0);
     rb = vpair[2 * y + 1];
   } else {
     ra = rb = y >> f.h_sub;

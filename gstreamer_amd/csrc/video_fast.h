@@ -28,11 +28,14 @@ struct FastParams {
   uint32_t pack_sel;    // v_perm selector: dest byte pos[A] <- 0xff, pos[R] <- lo.0, pos[G] <- lo.1, pos[B] <- hi.0
   int u_first;          // 1: NV12 (U,V), 0: NV21 (V,U)
   int pc[5];            // raw p1..p5 (word form, fast_emit4_l)
+  int crow_lo, crow_hi; // chroma rows that exist, relative to the plane pointer (0 .. rows - 1; a source crop widens it)
   int pack_pos[4];      // destination byte of A, R, G, B
 };
 
 inline void fast_params_finish (FastParams &fp, const int p[5], const int pack_pos[4], int u_first)
 {
+  fp.crow_lo = 0;
+  fp.crow_hi = ((fp.height + 1) >> 1) - 1;
   for (int i = 0; i < 5; i++) {
     fp.p8[i] = p[i] * 256;
     fp.pc[i] = p[i];
@@ -407,7 +410,6 @@ GSTAMD_HD void fast_strip (const FastParams &fp, const Planes &pl, uint8_t *__re
     int p_end)
 {
   const int w = fp.width, h = fp.height, cw = (w + 1) >> 1;
-  const int n_crows = (h + 1) >> 1;
   const uint8_t *yb = pl.p[0] + x0, *cbase = pl.p[1];
   const int ys = pl.stride[0], cs = pl.stride[1];
   uint8_t *db = dst + 4 * (size_t) x0;
@@ -419,12 +421,12 @@ GSTAMD_HD void fast_strip (const FastParams &fp, const Planes &pl, uint8_t *__re
   uint32_t y0, y1;
   {                                       // upper chroma row of the first pair
     ChromaRaw4 r0;
-    chroma_load4<CH> (cbase + (size_t) (p_begin > 0 ? p_begin - 1 : 0) * cs, cw, x0, r0);
+    chroma_load4<CH> (cbase + (ptrdiff_t) (p_begin - 1 > fp.crow_lo ? p_begin - 1 : fp.crow_lo) * cs, cw, x0, r0);
     chroma_filter4<CH> (r0.raw, r0.nxt, r0.prv_hi, cprev);
   }
   {                                       // prefetch pair p_begin
     const int p = p_begin, l0 = 2 * p - 1, l1 = 2 * p;
-    chroma_load4<CH> (cbase + (size_t) (p < n_crows ? p : n_crows - 1) * cs, cw, x0, craw);
+    chroma_load4<CH> (cbase + (ptrdiff_t) (p < fp.crow_hi ? p : fp.crow_hi) * cs, cw, x0, craw);
     y0 = load_stream32 (yb + (size_t) (l0 >= 0 ? l0 : 0) * ys);
     y1 = load_stream32 (yb + (size_t) (l1 < h ? l1 : h - 1) * ys);
   }
@@ -435,7 +437,7 @@ GSTAMD_HD void fast_strip (const FastParams &fp, const Planes &pl, uint8_t *__re
     const ChromaRaw4 cr_now = craw;
     if (p + 1 < p_end) {                  // issue the next pair's loads before this pair's math
       const int pn = p + 1, n0 = 2 * pn - 1, n1 = 2 * pn;
-      chroma_load4<CH> (cbase + (size_t) (pn < n_crows ? pn : n_crows - 1) * cs, cw, x0, craw);
+      chroma_load4<CH> (cbase + (ptrdiff_t) (pn < fp.crow_hi ? pn : fp.crow_hi) * cs, cw, x0, craw);
       y0 = load_stream32 (yb + (size_t) n0 * ys);
       y1 = load_stream32 (yb + (size_t) (n1 < h ? n1 : h - 1) * ys);
     }
@@ -512,7 +514,7 @@ GSTAMD_HD void wide_fetch_chroma (const FastParams &fp, const Planes &pl, int xw
   if (xl >= w)
     return;
   const int nd = (w - xl) >> 2;            // dwords of this lane that lie inside the row (w % 4 == 0)
-  const uint8_t *row = pl.p[1] + (size_t) crow * pl.stride[1];
+  const uint8_t *row = pl.p[1] + (ptrdiff_t) crow * pl.stride[1];
   wide_load16<false> (row + xl, nd, vec, r.c);
   if (CH != CHROMA_H_NONE && (lane == 63 || nd <= 4)) {
     // the sample right of this lane's last one: the next dword of the row, or the row's last sample again
@@ -542,7 +544,7 @@ GSTAMD_HD void wide_commit_chroma (const FastParams &fp, int xw, int lane, const
 template <int CH>
 GSTAMD_HD void wide_fetch (const FastParams &fp, const Planes &pl, int xw, int p, int lane, bool vec, WideRegs &r)
 {
-  const int w = fp.width, h = fp.height, n_crows = (h + 1) >> 1;
+  const int w = fp.width, h = fp.height;
   const int xl = xw + 16 * lane;
   if (xl >= w)
     return;
@@ -551,7 +553,7 @@ GSTAMD_HD void wide_fetch (const FastParams &fp, const Planes &pl, int xw, int p
   const int r0 = l0 >= 0 ? l0 : 0, r1 = l1 < h ? l1 : h - 1;
   wide_load16<true> (pl.p[0] + (size_t) r0 * pl.stride[0] + xl, nd, vec, r.y0);
   wide_load16<true> (pl.p[0] + (size_t) r1 * pl.stride[0] + xl, nd, vec, r.y1);
-  wide_fetch_chroma<CH> (fp, pl, xw, p < n_crows ? p : n_crows - 1, lane, vec, r);
+  wide_fetch_chroma<CH> (fp, pl, xw, p < fp.crow_hi ? p : fp.crow_hi, lane, vec, r);
 }
 
 template <int CH>

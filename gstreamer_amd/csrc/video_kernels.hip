@@ -209,6 +209,23 @@ __global__ __launch_bounds__ (256) void k_plane_vscale (SrcPlane s, ScaleDev sd,
   plane_vscale_body (s, sd, d, width, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
 }
 
+// borders (convert_fill_border, video-converter.c:7190): every pixel of a destination plane outside the picture rectangle
+// gets the plane's border value; es = bytes per pixel of the plane (1, 2 or 4)
+__global__ __launch_bounds__ (256) void k_fill_border (uint8_t *__restrict__ p, int stride, int es, uint32_t value, int maxw, int maxh,
+    int x0, int y0, int w, int h)
+{
+  const int x = (int) (blockIdx.x * blockDim.x + threadIdx.x), y = (int) blockIdx.y;
+  if (x >= maxw || y >= maxh || (x >= x0 && x < x0 + w && y >= y0 && y < y0 + h))
+    return;
+  uint8_t *q = p + (size_t) y * stride + (size_t) x * es;
+  if (es == 4)
+    *(uint32_t *) q = value;
+  else if (es == 2)
+    *(uint16_t *) q = (uint16_t) value;
+  else
+    *q = (uint8_t) value;
+}
+
 __global__ __launch_bounds__ (256) void k_pack_planar (PackPlanarParams pk, const uint8_t *__restrict__ src, int sstride, DstPlanes d)
 {
   pack_planar_body (pk, src, sstride, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
@@ -319,7 +336,7 @@ __global__ __launch_bounds__ (64) void k_convert_wide (FastParams fp, FrameBatch
   const int xw = xb * GSTAMD_WIDE_PX, lane = threadIdx.x;
   const bool v = vec != 0;
   WideRegs r;
-  wide_fetch_chroma<CH> (fp, pl, xw, p0 > 0 ? p0 - 1 : 0, lane, v, r);
+  wide_fetch_chroma<CH> (fp, pl, xw, p0 - 1 > fp.crow_lo ? p0 - 1 : fp.crow_lo, lane, v, r);
   wide_commit_chroma<CH> (fp, xw, lane, r, lds.c[0]);
   wide_fetch<CH> (fp, pl, xw, p0, lane, v, r);
   for (int p = p0; p < p1; p++) {
@@ -578,6 +595,13 @@ hipError_t launch_plane_pass (bool horizontal, const ScaleDev &sd, const uint8_t
     hipLaunchKernelGGL (k_plane_hscale, dim3 ((ow + 255) / 256, oh), dim3 (256), 0, stream, s, sd, d, ow, oh);
   else
     hipLaunchKernelGGL (k_plane_vscale, dim3 ((ow + 255) / 256, oh), dim3 (256), 0, stream, s, sd, d, ow, oh);
+  return hipGetLastError ();
+}
+
+hipError_t launch_fill_border (uint8_t *p, int stride, int es, uint32_t value, int maxw, int maxh, int x0, int y0, int w, int h,
+    hipStream_t stream)
+{
+  hipLaunchKernelGGL (k_fill_border, dim3 ((maxw + 255) / 256, maxh), dim3 (256), 0, stream, p, stride, es, value, maxw, maxh, x0, y0, w, h);
   return hipGetLastError ();
 }
 

@@ -32,7 +32,7 @@ GSTAMD_HD void load_chroma6_packed (const FrontParams &f, const Planes &pl, int 
 {
   const int km = k0 > 0 ? k0 - 1 : 0, kp = k0 + 4 < cw ? k0 + 4 : cw - 1;
   if (f.kind == UNPACK_SEMI) {
-    const uint8_t *row = pl.p[1] + (size_t) crow * pl.stride[1];
+    const uint8_t *row = pl.p[1] + (ptrdiff_t) crow * pl.stride[1];
     const uint2 mid = *(const uint2 *) (row + 2 * k0);           // samples k0..k0+3
     const uint32_t pm = *(const uint16_t *) (row + 2 * km), pp = *(const uint16_t *) (row + 2 * kp);
     // byte pair (b0, b1) -> U | V << 16; NV12 (u_plane != 0): U first
@@ -44,8 +44,8 @@ GSTAMD_HD void load_chroma6_packed (const FrontParams &f, const Planes &pl, int 
     c.c[4] = bperm (0, mid.y, sel_hi);
     c.c[5] = bperm (0, pp, sel_lo);
   } else {
-    const uint8_t *ru = pl.p[f.u_plane] + (size_t) crow * pl.stride[f.u_plane];
-    const uint8_t *rv = pl.p[f.v_plane] + (size_t) crow * pl.stride[f.v_plane];
+    const uint8_t *ru = pl.p[f.u_plane] + (ptrdiff_t) crow * pl.stride[f.u_plane];
+    const uint8_t *rv = pl.p[f.v_plane] + (ptrdiff_t) crow * pl.stride[f.v_plane];
     const uint32_t mu = *(const uint32_t *) (ru + k0), mv = *(const uint32_t *) (rv + k0);
     c.c[0] = (uint32_t) ru[km] | ((uint32_t) rv[km] << 16);
     c.c[1] = bperm (mv, mu, 0x0c040c00u);
@@ -88,8 +88,8 @@ GSTAMD_HD void front_chroma8_packed (const FrontParams &f, const Planes &pl, con
   int ra, rb, role = 0;
   if (f.chroma_v2) {
     const int e0 = vpair[2 * y];
-    ra = e0 & 0x3fffffff;
-    role = e0 >> 30;
+    ra = vpair_row (e0);
+    role = vpair_role (e0);
     rb = vpair[2 * y + 1];
   } else {
     ra = rb = y >> f.h_sub;

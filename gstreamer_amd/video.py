@@ -41,7 +41,10 @@ class ConverterConfig(C.Structure):
                 ("envelope", C.c_double), ("sharpness", C.c_double), ("sharpen", C.c_double),
                 ("cubic_b", C.c_double), ("cubic_c", C.c_double), ("alpha_mode", C.c_int32),
                 ("alpha_value", C.c_double), ("chroma_mode", C.c_int32), ("matrix_mode", C.c_int32),
-                ("dither_quantization", C.c_uint32), ("chroma_resampler_method", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("dither_quantization", C.c_uint32), ("chroma_resampler_method", C.c_int32), ("reserved", C.c_int32 * 7),
+                ("src_x", C.c_int32), ("src_y", C.c_int32), ("src_width", C.c_int32), ("src_height", C.c_int32),
+                ("dest_x", C.c_int32), ("dest_y", C.c_int32), ("dest_width", C.c_int32), ("dest_height", C.c_int32),
+                ("fill_border", C.c_int32), ("border_argb", C.c_uint32)]
 
 
 class CompositorPad(C.Structure):

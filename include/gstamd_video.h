@@ -122,6 +122,12 @@ typedef struct GstAmdVideoConverterConfig {
   uint32_t dither_quantization;  /* GstVideoConverter.dither-quantization (1) */
   int32_t chroma_resampler_method; /* GstVideoConverter.chroma-resampler-method (LINEAR): chroma planes of the plane scaler */
   int32_t reserved[7];
+  /* source crop and destination rectangle (GstVideoConverter.src-x/-y/-width/-height, dest-x/-y/-width/-height,
+   * video-converter.h:64-131); width / height 0 = "to the frame's edge" (the option absent) */
+  int32_t src_x, src_y, src_width, src_height;
+  int32_t dest_x, dest_y, dest_width, dest_height;
+  int32_t fill_border;           /* GstVideoConverter.fill-border (TRUE) */
+  uint32_t border_argb;          /* GstVideoConverter.border-argb (0xff000000) */
 } GstAmdVideoConverterConfig;
 
 typedef struct GstAmdVideoConverter GstAmdVideoConverter;

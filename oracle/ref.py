@@ -99,7 +99,7 @@ def config_string(**opts):
             parts.append("%s=(boolean)%s" % (key, "true" if v else "false"))
         elif isinstance(v, float):
             parts.append("%s=(double)%r" % (key, v))
-        elif key.endswith("threads") or key.endswith("resampler-taps") or key.endswith("quantization"):
+        elif key.endswith("threads") or key.endswith("resampler-taps") or key.endswith("quantization") or key.endswith("border-argb"):
             parts.append("%s=(uint)%d" % (key, v))
         else:
             parts.append("%s=(int)%d" % (key, v))

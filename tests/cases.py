@@ -132,6 +132,14 @@ VIDEO_CASES = [
     ("ayuv_y42b_130x71_fastpath", "AYUV", 130, 71, "Y42B", 130, 71, {}, None, None, "random"),
     ("ayuv_y444_33x17_fastpath", "AYUV", 33, 17, "Y444", 33, 17, {}, None, None, "random"),
     ("ayuv_i420_65x64_generic_odd_width", "AYUV", 65, 64, "I420", 65, 64, {}, None, None, "random"),
+    # source crop / destination rectangle / borders (GstVideoConverter.src-*, dest-*, fill-border, border-argb)
+    ("nv12_bgra_crop_dest_border", "NV12", 640, 360, "BGRA", 400, 300, dict(src_x=100, src_y=50, src_width=320, src_height=180, dest_x=40, dest_y=60, dest_width=320, dest_height=180), None, None, "random"),
+    ("nv12_bgra_letterbox_bilinear", "NV12", 640, 360, "BGRA", 400, 400, dict(LIN, dest_x=0, dest_y=88, dest_width=400, dest_height=225, border_argb=0xff203040), None, None, "random"),
+    ("bgra_nv12_pillarbox_bilinear", "BGRA", 320, 240, "NV12", 640, 360, dict(LIN, dest_x=80, dest_y=0, dest_width=480, dest_height=360, border_argb=0xffc08040), None, None, "random"),
+    ("i420_bgra_crop_fastpath_border", "I420", 322, 240, "BGRA", 400, 300, dict(src_x=2, src_y=0, src_width=320, src_height=240, dest_x=50, dest_y=30, dest_width=320, dest_height=240), None, None, "random"),
+    ("bgra_bgra_planes_border_odd", "BGRA", 200, 100, "BGRA", 333, 111, dict(LAN, dest_x=33, dest_y=7, dest_width=250, dest_height=99, border_argb=0x80112233), None, None, "random"),
+    ("i420_i420_planes_crop_border", "I420", 640, 360, "I420", 400, 300, dict(LIN, src_x=64, src_y=32, src_width=512, src_height=288, dest_x=40, dest_y=38, dest_width=320, dest_height=224), None, None, "random"),
+    ("bgra_i420_border_odd_rect", "BGRA", 161, 91, "I420", 200, 120, dict(dest_x=20, dest_y=14, dest_width=161, dest_height=91, border_argb=0xffffffff), None, None, "random"),
     # wide-kernel tile edges: row ends exactly at a 1024-px run / one dword past it / inside a lane
     ("nv12_bgra_1024x34_jpeg", "NV12", 1024, 34, "BGRA", 1024, 34, {}, None, "jpeg", "random"),
     ("nv21_rgba_2048x18_mpeg2", "NV21", 2048, 18, "RGBA", 2048, 18, {}, None, "mpeg2", "random"),

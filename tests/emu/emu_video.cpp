@@ -38,6 +38,9 @@ static FastParams emu_fast_params (const VideoPlan &p)      /* make_fast_params 
   fp.width = p.front.width;
   fp.height = p.front.height;
   fast_params_finish (fp, p.matrix.p, p.post.pack_pos, p.front.u_plane);
+  /* with a source crop the chroma upsampler still sees the frame's rows above / below the crop (do_unpack_lines :2966) */
+  fp.crow_lo = -(p.rect.in_y >> 1);
+  fp.crow_hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
   return fp;
 }
 
@@ -157,9 +160,41 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   Planes pl;
   memset (&pl, 0, sizeof (pl));
   for (int i = 0; i < in->n_planes; i++) {
-    pl.p[i] = src + in->offset[i];
+    pl.p[i] = src + in->offset[i] + plane_origin (p.fin, i, p.rect.in_x, p.rect.in_y, in->stride[i]);
     pl.stride[i] = in->stride[i];
   }
+  /* destination rectangle + borders (k_fill_border's rule, plane by plane) */
+  GstAmdVideoInfo orect = *out;
+  if (p.rect.fill) {
+    const FormatDesc *f = p.fout;
+    auto up = [](int v, int sub) { return -((-v) >> sub); };
+    for (int i = 0; i < out->n_planes; i++) {
+      const bool chroma = f->kind != UNPACK_PACKED4 && i > 0;
+      const int es = f->kind == UNPACK_PACKED4 ? 4 : (chroma && f->kind == UNPACK_SEMI ? 2 : 1);
+      const int ws = chroma ? f->w_sub : 0, hs = chroma ? f->h_sub : 0;
+      const int mw = up (p.rect.out_maxw, ws), mh = up (p.rect.out_maxh, hs), x0 = p.rect.out_x >> ws, y0 = p.rect.out_y >> hs;
+      const int w = up (p.out_info.width, ws), h = up (p.out_info.height, hs);
+      uint8_t v[4] = {0, 0, 0, 0};
+      if (f->kind == UNPACK_PACKED4) {
+        for (int c = 0; c < 4; c++)
+          v[f->pos[c]] = p.rect.border[c];
+      } else if (!chroma) {
+        v[0] = p.rect.border[1];
+      } else if (f->kind == UNPACK_SEMI) {
+        v[0] = f->u_plane ? p.rect.border[2] : p.rect.border[3];
+        v[1] = f->u_plane ? p.rect.border[3] : p.rect.border[2];
+      } else {
+        v[0] = i == f->u_plane ? p.rect.border[2] : p.rect.border[3];
+      }
+      for (int y = 0; y < mh; y++)
+        for (int x = 0; x < mw; x++)
+          if (!(x >= x0 && x < x0 + w && y >= y0 && y < y0 + h))
+            memcpy (dst + out->offset[i] + (size_t) y * out->stride[i] + (size_t) x * es, v, es);
+    }
+  }
+  for (int i = 0; i < out->n_planes; i++)
+    orect.offset[i] = out->offset[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]);
+  out = &orect;
   if (p.plane_mode) {                     /* convert_scale_planes: the plane kernels' bodies over their grids */
     for (const PlanePlan &pp : p.planes) {
       const SrcPlane sp = {pl.p[pp.src_plane], pl.stride[pp.src_plane], pp.n_elems};
@@ -202,8 +237,8 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     return GSTAMD_OK;
   }
   if (p.out_planar) {                     /* chain -> AYUV image, then the pack kernel body over its grid */
-    std::vector<uint8_t> img ((size_t) out->width * 4 * out->height);
-    r = emu_convert_packed (p, in, pl, img.data (), out->width * 4, vec_ok);
+    std::vector<uint8_t> img ((size_t) p.out_info.width * 4 * p.out_info.height);
+    r = emu_convert_packed (p, in, pl, img.data (), p.out_info.width * 4, vec_ok);
     if (r != GSTAMD_OK)
       return r;
     DstPlanes d;
@@ -212,10 +247,10 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       d.p[i] = dst + out->offset[i];
       d.stride[i] = out->stride[i];
     }
-    const int rows = (out->height + (1 << p.pack.h_sub) - 1) >> p.pack.h_sub;
+    const int rows = (p.out_info.height + (1 << p.pack.h_sub) - 1) >> p.pack.h_sub;
     for (int yb = 0; yb < rows; yb++)
-      for (int x0 = 0; x0 < out->width; x0 += 4)
-        pack_planar_body (p.pack, img.data (), out->width * 4, d, x0, yb);
+      for (int x0 = 0; x0 < p.out_info.width; x0 += 4)
+        pack_planar_body (p.pack, img.data (), p.out_info.width * 4, d, x0, yb);
     return GSTAMD_OK;
   }
   return emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok);
@@ -261,7 +296,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
           continue; \
         const int xw = xb * GSTAMD_WIDE_PX, p0 = S * K, p1 = p0 + K < pairs ? p0 + K : pairs; \
         for (int lane = 0; lane < 64; lane++) { \
-          wide_fetch_chroma<CH> (fp, pl, xw, p0 > 0 ? p0 - 1 : 0, lane, vec, regs[lane]); \
+          wide_fetch_chroma<CH> (fp, pl, xw, p0 - 1 > fp.crow_lo ? p0 - 1 : fp.crow_lo, lane, vec, regs[lane]); \
           wide_commit_chroma<CH> (fp, xw, lane, regs[lane], lds.c[0]); \
           wide_fetch<CH> (fp, pl, xw, p0, lane, vec, regs[lane]); \
         } \
@@ -440,7 +475,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     return GSTAMD_OK;
   }
   const ScalePass &s0 = p.passes[0];
-  const int tw = s0.horizontal ? s0.out_size : in->width, th = s0.horizontal ? in->height : s0.out_size;
+  const int tw = s0.horizontal ? s0.out_size : p.in_info.width, th = s0.horizontal ? p.in_info.height : s0.out_size;
   std::vector<uint8_t> tmp ((size_t) tw * 4 * th);
   run_scale (s0.horizontal, sf, sd[0], mk (tmp.data (), tw * 4, false), tw, th, s0.max_span,
       s0.horizontal ? pass_tile_geom (s0) : TileGeom {0, 0}, pf_none);

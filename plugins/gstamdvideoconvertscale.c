@@ -16,8 +16,8 @@
  * (GSTAMD_ERR_UNSUPPORTED) make set_caps fail -> not-negotiated, like the reference's "no_convert" :1111-1120.
  *
  * Simplifications kept honest: fixate_caps keeps the input size / PAR instead of the reference's 450-line
- * DAR solver (:1248-1975); add-borders, the converter-config property, interlaced content and overlay
- * composition metas are not implemented.
+ * DAR solver (:1248-1975); the converter-config property, interlaced content and overlay composition metas are not
+ * implemented.  add-borders works as in the reference once the caps fix a size whose DAR differs.
  */
 #include <gst/base/gstbasetransform.h>
 #include <gst/gst.h>
@@ -73,6 +73,8 @@ typedef struct {
   gint alpha_mode, chroma_mode, matrix_mode;
   gdouble alpha_value, envelope, sharpness, sharpen;
   guint dither_quantization;
+  gboolean add_borders;        /* add-borders (:312): letterbox / pillarbox instead of stretching when the DAR changes */
+  gint borders_w, borders_h;
   /* negotiated */
   GstVideoInfo in_info, out_info;
   gboolean in_hip, out_hip;
@@ -88,7 +90,7 @@ typedef struct {
   gboolean converts, scales;
 } GstAmdVideoConvertScaleClass;
 
-enum { PROP_0, PROP_METHOD, PROP_N_THREADS, PROP_ALPHA_MODE, PROP_ALPHA_VALUE, PROP_CHROMA_MODE, PROP_MATRIX_MODE,
+enum { PROP_0, PROP_METHOD, PROP_ADD_BORDERS, PROP_N_THREADS, PROP_ALPHA_MODE, PROP_ALPHA_VALUE, PROP_CHROMA_MODE, PROP_MATRIX_MODE,
   PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION };
 
 G_DEFINE_TYPE (GstAmdVideoConvertScale, gst_amd_vcs, GST_TYPE_BASE_TRANSFORM);
@@ -102,6 +104,7 @@ amd_vcs_set_property (GObject * object, guint id, const GValue * value, GParamSp
   GST_OBJECT_LOCK (s);
   switch (id) {
     case PROP_METHOD: s->method = g_value_get_enum (value); break;
+    case PROP_ADD_BORDERS: s->add_borders = g_value_get_boolean (value); break;
     case PROP_N_THREADS: s->n_threads = g_value_get_uint (value); break;
     case PROP_ALPHA_MODE: s->alpha_mode = g_value_get_enum (value); break;
     case PROP_ALPHA_VALUE: s->alpha_value = g_value_get_double (value); break;
@@ -123,6 +126,7 @@ amd_vcs_get_property (GObject * object, guint id, GValue * value, GParamSpec * p
   GST_OBJECT_LOCK (s);
   switch (id) {
     case PROP_METHOD: g_value_set_enum (value, s->method); break;
+    case PROP_ADD_BORDERS: g_value_set_boolean (value, s->add_borders); break;
     case PROP_N_THREADS: g_value_set_uint (value, s->n_threads); break;
     case PROP_ALPHA_MODE: g_value_set_enum (value, s->alpha_mode); break;
     case PROP_ALPHA_VALUE: g_value_set_double (value, s->alpha_value); break;
@@ -292,6 +296,31 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
     case AMD_SCALE_CATROM: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_CUBIC; cfg.cubic_b = 0.0; cfg.cubic_c = 0.5; break;
     case AMD_SCALE_MITCHELL: cfg.resampler_method = GSTAMD_RESAMPLER_METHOD_CUBIC; cfg.cubic_b = 1.0 / 3.0; cfg.cubic_c = 1.0 / 3.0; break;
   }
+  /* borders that keep the display aspect ratio (gstvideoconvertscale.c:920-957, 1068-1072) */
+  s->borders_w = s->borders_h = 0;
+  {
+    gint from_n, from_d, to_n, to_d;
+    if (!gst_util_fraction_multiply (s->in_info.width, s->in_info.height, s->in_info.par_n, s->in_info.par_d, &from_n, &from_d))
+      from_n = from_d = -1;
+    if (!gst_util_fraction_multiply (s->out_info.width, s->out_info.height, s->out_info.par_n, s->out_info.par_d, &to_n, &to_d))
+      to_n = to_d = -1;
+    if ((to_n != from_n || to_d != from_d) && s->add_borders) {
+      gint n, d;
+      if (from_n != -1 && from_d != -1 && gst_util_fraction_multiply (from_n, from_d, s->out_info.par_d, s->out_info.par_n, &n, &d)) {
+        const gint to_h = gst_util_uint64_scale_int (s->out_info.width, d, n);
+        if (to_h <= s->out_info.height)
+          s->borders_h = s->out_info.height - to_h;
+        else
+          s->borders_w = s->out_info.width - (gint) gst_util_uint64_scale_int (s->out_info.height, n, d);
+      } else {
+        GST_WARNING_OBJECT (s, "Can't calculate borders");
+      }
+    }
+  }
+  cfg.dest_x = s->borders_w / 2;
+  cfg.dest_y = s->borders_h / 2;
+  cfg.dest_width = s->out_info.width - s->borders_w;
+  cfg.dest_height = s->out_info.height - s->borders_h;
   cfg.envelope = s->envelope;
   cfg.sharpness = s->sharpness;
   cfg.sharpen = s->sharpen;
@@ -468,6 +497,8 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
   oc->get_property = amd_vcs_get_property;
   g_object_class_install_property (oc, PROP_METHOD, g_param_spec_enum ("method", "method", "method",
           amd_scale_method_get_type (), AMD_SCALE_BILINEAR, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_ADD_BORDERS, g_param_spec_boolean ("add-borders", "Add Borders",
+          "Add black borders if necessary to keep the display aspect ratio", TRUE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_N_THREADS, g_param_spec_uint ("n-threads", "Threads",
           "Accepted for compatibility (the GPU grid replaces CPU thread slices)", 0, G_MAXUINT, 1,
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
@@ -510,6 +541,7 @@ static void
 gst_amd_vcs_init (GstAmdVideoConvertScale * s)
 {
   s->method = AMD_SCALE_BILINEAR;          /* DEFAULT_PROP_METHOD (:130) */
+  s->add_borders = TRUE;                   /* DEFAULT_PROP_ADD_BORDERS (:131) */
   s->n_threads = 1;
   s->alpha_mode = GSTAMD_ALPHA_MODE_COPY;
   s->alpha_value = 1.0;

@@ -165,3 +165,21 @@ def test_videoconvertscale_element_planar_output(gst_env, ref):
     for i in range(n):
         assert (a.frame(src[i]) == nv12[i]).all(), i
         assert (b.frame(nv12[i]) == i420[i]).all(), i
+
+
+def test_videoconvertscale_element_add_borders(gst_env, ref):
+    """16:9 into a square frame with add-borders (default): the element letterboxes through dest-x/-y/-width/-height."""
+    env, tmp = gst_env
+    n, w, h, ow, oh = 2, 640, 360, 400, 400
+    fin, fout = tmp / "b_in.nv12", tmp / "b_out.bgra"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=%d,height=%d,pixel-aspect-ratio=1/1,colorimetry=bt709,chroma-site=mpeg2 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw,format=BGRA,width=%d,height=%d,pixel-aspect-ratio=1/1 "
+                "! filesink location=%s" % (n, w, h, fin, ow, oh, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    to_h = ow * h // w                       # 225: borders_h = 175, dest_y = 87
+    cfg = dict(cases.LIN, dest_x=0, dest_y=(oh - to_h) // 2, dest_width=ow, dest_height=to_h)
+    rc = ref.VideoConverter("NV12", w, h, "BGRA", ow, oh, in_colorimetry="bt709", in_chroma_site="mpeg2",
+                            config=cases.ref_config_string(ref, cfg))
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), i

@@ -14,10 +14,10 @@
  * pixel is written once, where the reference read-modify-writes the canvas once per pad.
  *
  * Simplifications kept honest: every aggregate() consumes one buffer from each pad that has one (lock-step, no
- * timestamp-based frame selection / repeat as in gstvideoaggregator.c:1700-2000); pads must carry the output
- * format (put `videoconvertscale` in front; the reference converts per pad through GstVideoAggregatorConvertPad);
- * width / height different from the pad's frame size (per-pad scaling) are refused; sizing-policy,
- * zero-size-is-unscaled, max-threads and ignore-inactive-pads are not implemented.
+ * timestamp-based frame selection / repeat as in gstvideoaggregator.c:1700-2000); pads of another format or with
+ * width / height properties are converted / scaled individually by a per-pad GstAmdVideoConverter with the library's
+ * default config (what GstVideoAggregatorConvertPad does), assuming equal pixel aspect ratios; sizing-policy,
+ * zero-size-is-unscaled, converter-config, max-threads and ignore-inactive-pads are not implemented.
  */
 #include <gst/base/gstaggregator.h>
 #include <gst/gst.h>
@@ -32,11 +32,14 @@ GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
 #define GST_CAT_DEFAULT amd_comp_debug
 
 #define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV }"
+/* what a pad may carry: anything the converter takes; it is brought to the output format / the pad's width x height by a
+ * per-pad GstAmdVideoConverter (the reference's GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) */
+#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, RGBx, BGRx, xRGB, xBGR, NV12, NV21, I420, YV12, Y42B, Y444 }"
 #define AMD_COMP_MAX_PADS 64
 
 static GstStaticPadTemplate comp_sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_COMP_FORMATS) ";"
-        GST_VIDEO_CAPS_MAKE (AMD_COMP_FORMATS)));
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_COMP_PAD_FORMATS) ";"
+        GST_VIDEO_CAPS_MAKE (AMD_COMP_PAD_FORMATS)));
 static GstStaticPadTemplate comp_src_tmpl = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
     GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_COMP_FORMATS) ";"
         GST_VIDEO_CAPS_MAKE (AMD_COMP_FORMATS)));
@@ -52,6 +55,11 @@ typedef struct {
   gboolean have_info;
   gpointer staging;            /* device copy of a system-memory input frame */
   gsize staging_size;
+  /* per-pad conversion (format and / or size): converter, its key, its device output frame */
+  GstAmdVideoConverter *conv;
+  gint conv_key[6];            /* in format, in w, in h, out format, out w, out h */
+  gpointer conv_buf;
+  gsize conv_buf_size;
 } GstAmdCompositorPadObj;
 
 typedef struct { GstAggregatorPadClass parent_class; } GstAmdCompositorPadObjClass;
@@ -123,6 +131,9 @@ amd_comp_pad_finalize (GObject * object)
 {
   GstAmdCompositorPadObj *p = AMD_COMP_PAD (object);
   gstamd_device_free (p->staging);
+  gstamd_device_free (p->conv_buf);
+  if (p->conv)
+    gstamd_video_converter_free (p->conv);
   G_OBJECT_CLASS (gst_amd_compositor_pad_parent_class)->finalize (object);
 }
 
@@ -237,6 +248,47 @@ amd_format_of (GstVideoFormat f)
   }
 }
 
+static int
+amd_pad_format_of (GstVideoFormat f)
+{
+  switch (f) {
+    case GST_VIDEO_FORMAT_RGBx: return GSTAMD_VIDEO_FORMAT_RGBx;
+    case GST_VIDEO_FORMAT_BGRx: return GSTAMD_VIDEO_FORMAT_BGRx;
+    case GST_VIDEO_FORMAT_xRGB: return GSTAMD_VIDEO_FORMAT_xRGB;
+    case GST_VIDEO_FORMAT_xBGR: return GSTAMD_VIDEO_FORMAT_xBGR;
+    case GST_VIDEO_FORMAT_NV12: return GSTAMD_VIDEO_FORMAT_NV12;
+    case GST_VIDEO_FORMAT_NV21: return GSTAMD_VIDEO_FORMAT_NV21;
+    case GST_VIDEO_FORMAT_I420: return GSTAMD_VIDEO_FORMAT_I420;
+    case GST_VIDEO_FORMAT_YV12: return GSTAMD_VIDEO_FORMAT_YV12;
+    case GST_VIDEO_FORMAT_Y42B: return GSTAMD_VIDEO_FORMAT_Y42B;
+    case GST_VIDEO_FORMAT_Y444: return GSTAMD_VIDEO_FORMAT_Y444;
+    default: return amd_format_of (f);
+  }
+}
+
+/* GstVideoInfo -> GstAmdVideoInfo with the caps' colorimetry / chroma site (as the videoconvertscale element does) */
+static gboolean
+amd_fill_info (const GstVideoInfo * vi, int w, int h, int fmt, GstAmdVideoInfo * ai)
+{
+  if (!fmt || gstamd_video_info_set_format (ai, fmt, w, h) != GSTAMD_OK)
+    return FALSE;
+  if (vi) {
+    ai->color_range = vi->colorimetry.range;
+    ai->color_matrix = vi->colorimetry.matrix;
+    ai->chroma_site = vi->chroma_site;
+  }
+  return TRUE;
+}
+
+/* size the pad's picture takes on the canvas: the width / height properties, else the frame size (_mixer_pad_get_output_size
+ * of compositor.c:290-400 for equal pixel aspect ratios and sizing-policy none) */
+static void
+amd_comp_pad_target_size (GstAmdCompositorPadObj * p, gint * w, gint * h)
+{
+  *w = p->width > 0 ? p->width : GST_VIDEO_INFO_WIDTH (&p->info);
+  *h = p->height > 0 ? p->height : GST_VIDEO_INFO_HEIGHT (&p->info);
+}
+
 static void
 amd_comp_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
 {
@@ -289,7 +341,7 @@ amd_comp_sink_event (GstAggregator * agg, GstAggregatorPad * apad, GstEvent * ev
     GstCaps *caps;
     gst_event_parse_caps (event, &caps);
     GST_OBJECT_LOCK (p);
-    p->have_info = gst_video_info_from_caps (&p->info, caps) && amd_format_of (GST_VIDEO_INFO_FORMAT (&p->info)) != 0;
+    p->have_info = gst_video_info_from_caps (&p->info, caps) && amd_pad_format_of (GST_VIDEO_INFO_FORMAT (&p->info)) != 0;
     GST_OBJECT_UNLOCK (p);
     if (!p->have_info) {
       GST_ERROR_OBJECT (apad, "unsupported caps %" GST_PTR_FORMAT, caps);
@@ -305,21 +357,9 @@ static gboolean
 amd_comp_sink_query (GstAggregator * agg, GstAggregatorPad * apad, GstQuery * query)
 {
   if (GST_QUERY_TYPE (query) == GST_QUERY_CAPS) {
-    /* any size / framerate; the format has to be the one the output uses once that is known */
-    GstAmdCompositor *c = AMD_COMP (agg);
+    /* any supported format, size and framerate: pads are converted / scaled individually */
     GstCaps *filter, *tmpl = gst_pad_get_pad_template_caps (GST_PAD (apad)), *res;
     gst_query_parse_caps (query, &filter);
-    if (c->have_out) {
-      GstCaps *fmt = gst_caps_new_simple ("video/x-raw", "format", G_TYPE_STRING,
-          gst_video_format_to_string (GST_VIDEO_INFO_FORMAT (&c->out_info)), NULL);
-      GstCaps *fmt_hip = gst_caps_copy (fmt);
-      gst_caps_set_features (fmt_hip, 0, gst_caps_features_from_string (GST_CAPS_FEATURE_MEMORY_AMD_HIP));
-      gst_caps_append (fmt_hip, fmt);
-      res = gst_caps_intersect_full (tmpl, fmt_hip, GST_CAPS_INTERSECT_FIRST);
-      gst_caps_unref (fmt_hip);
-      gst_caps_unref (tmpl);
-      tmpl = res;
-    }
     if (filter) {
       res = gst_caps_intersect_full (filter, tmpl, GST_CAPS_INTERSECT_FIRST);
       gst_caps_unref (tmpl);
@@ -361,11 +401,12 @@ amd_comp_update_src_caps (GstAggregator * agg, GstCaps * caps, GstCaps ** ret)
       continue;
     }
     any = TRUE;
-    w = p->xpos + GST_VIDEO_INFO_WIDTH (&p->info);
-    h = p->ypos + GST_VIDEO_INFO_HEIGHT (&p->info);
+    amd_comp_pad_target_size (p, &w, &h);
+    w += p->xpos;
+    h += p->ypos;
     best_w = MAX (best_w, w);
     best_h = MAX (best_h, h);
-    if (fmt == GST_VIDEO_FORMAT_UNKNOWN)
+    if (fmt == GST_VIDEO_FORMAT_UNKNOWN && amd_format_of (GST_VIDEO_INFO_FORMAT (&p->info)))
       fmt = GST_VIDEO_INFO_FORMAT (&p->info);
     fps = GST_VIDEO_INFO_FPS_D (&p->info) ? (gdouble) GST_VIDEO_INFO_FPS_N (&p->info) / GST_VIDEO_INFO_FPS_D (&p->info) : 0.0;
     if (fps > best_fps) {
@@ -381,6 +422,8 @@ amd_comp_update_src_caps (GstAggregator * agg, GstCaps * caps, GstCaps ** ret)
     fps_n = 25;
     fps_d = 1;
   }
+  if (fmt == GST_VIDEO_FORMAT_UNKNOWN)
+    fmt = GST_VIDEO_FORMAT_BGRA;        /* no pad carries a blendable format: composite in BGRA */
   /* preferences: pads' format; downstream may still pick another size (the canvas is simply that big) */
   want = gst_caps_new_simple ("video/x-raw", "format", G_TYPE_STRING, gst_video_format_to_string (fmt),
       "framerate", GST_TYPE_FRACTION, fps_n, fps_d, "pixel-aspect-ratio", GST_TYPE_FRACTION, 1, 1, NULL);
@@ -389,6 +432,17 @@ amd_comp_update_src_caps (GstAggregator * agg, GstCaps * caps, GstCaps ** ret)
   gst_caps_append (want_hip, want);
   *ret = gst_caps_intersect_full (caps, want_hip, GST_CAPS_INTERSECT_FIRST);
   gst_caps_unref (want_hip);
+  if (gst_caps_is_empty (*ret)) {
+    /* downstream insists on another blendable format: composite in that one, every pad gets converted */
+    GstCaps *any = gst_caps_new_simple ("video/x-raw", "framerate", GST_TYPE_FRACTION, fps_n, fps_d, "pixel-aspect-ratio",
+        GST_TYPE_FRACTION, 1, 1, NULL);
+    GstCaps *any_hip = gst_caps_copy (any);
+    gst_caps_set_features (any_hip, 0, gst_caps_features_from_string (GST_CAPS_FEATURE_MEMORY_AMD_HIP));
+    gst_caps_append (any_hip, any);
+    gst_caps_unref (*ret);
+    *ret = gst_caps_intersect_full (caps, any_hip, GST_CAPS_INTERSECT_FIRST);
+    gst_caps_unref (any_hip);
+  }
   g_object_set_data (G_OBJECT (agg), "amd-best-w", GINT_TO_POINTER (best_w));
   g_object_set_data (G_OBJECT (agg), "amd-best-h", GINT_TO_POINTER (best_h));
   return GST_FLOW_OK;
@@ -495,13 +549,6 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
     const guint8 *base;
     if (!bufs[i] || !p->have_info)
       continue;
-    if (GST_VIDEO_INFO_FORMAT (&p->info) != GST_VIDEO_INFO_FORMAT (&c->out_info) ||
-        (p->width > 0 && p->width != GST_VIDEO_INFO_WIDTH (&p->info)) || (p->height > 0 && p->height != GST_VIDEO_INFO_HEIGHT (&p->info))) {
-      GST_ELEMENT_ERROR (c, STREAM, FORMAT, ("pad %s needs a conversion or scaling step", GST_OBJECT_NAME (p)),
-          ("put videoconvertscale in front of the pad: per-pad conversion is not built into this element"));
-      flow = GST_FLOW_NOT_NEGOTIATED;
-      goto done_inputs;
-    }
     mem = gst_buffer_peek_memory (bufs[i], 0);
     if (gst_buffer_n_memory (bufs[i]) == 1 && gst_is_amd_hip_memory (mem)) {
       if (!gst_memory_map (mem, &maps[i], GST_MAP_READ | GST_MAP_AMDHIP)) {
@@ -524,11 +571,50 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
       gst_buffer_unmap (bufs[i], &m);
       base = p->staging;
     }
-    vmeta = gst_buffer_get_video_meta (bufs[i]);
-    desc[n_desc].data = base + (vmeta ? vmeta->offset[0] : GST_VIDEO_INFO_PLANE_OFFSET (&p->info, 0));
-    desc[n_desc].width = GST_VIDEO_INFO_WIDTH (&p->info);
-    desc[n_desc].height = GST_VIDEO_INFO_HEIGHT (&p->info);
-    desc[n_desc].stride = vmeta ? vmeta->stride[0] : GST_VIDEO_INFO_PLANE_STRIDE (&p->info, 0);
+    {
+      gint tw, th;
+      const int ifmt = amd_pad_format_of (GST_VIDEO_INFO_FORMAT (&p->info));
+      amd_comp_pad_target_size (p, &tw, &th);
+      if (ifmt != fmt || tw != GST_VIDEO_INFO_WIDTH (&p->info) || th != GST_VIDEO_INFO_HEIGHT (&p->info)) {
+        /* GstVideoAggregatorConvertPad: library-default converter config (cubic), pad format / size -> canvas format / target size */
+        const gint key[6] = { ifmt, GST_VIDEO_INFO_WIDTH (&p->info), GST_VIDEO_INFO_HEIGHT (&p->info), fmt, tw, th };
+        if (!p->conv || memcmp (key, p->conv_key, sizeof (key)) != 0) {
+          GstAmdVideoInfo ai, ao;
+          int status = 0;
+          if (p->conv)
+            gstamd_video_converter_free (p->conv);
+          p->conv = NULL;
+          if (amd_fill_info (&p->info, key[1], key[2], ifmt, &ai) && amd_fill_info (NULL, tw, th, fmt, &ao)) {
+            if (GST_VIDEO_INFO_IS_YUV (&c->out_info)) {
+              ao.color_range = c->out_info.colorimetry.range;
+              ao.color_matrix = c->out_info.colorimetry.matrix;
+            }
+            p->conv = gstamd_video_converter_new (&ai, &ao, NULL, &status);
+          }
+          if (!p->conv) {
+            GST_ELEMENT_ERROR (c, STREAM, FORMAT, ("no HIP conversion for pad %s", GST_OBJECT_NAME (p)), ("%s", gstamd_last_error ()));
+            flow = GST_FLOW_NOT_NEGOTIATED;
+            goto done_inputs;
+          }
+          memcpy (p->conv_key, key, sizeof (key));
+        }
+        if (!ensure_device (&p->conv_buf, &p->conv_buf_size, (gsize) tw * th * 4) ||
+            gstamd_video_converter_frame (p->conv, base, p->conv_buf, NULL) != GSTAMD_OK) {
+          flow = GST_FLOW_ERROR;
+          goto done_inputs;
+        }
+        desc[n_desc].data = p->conv_buf;
+        desc[n_desc].width = tw;
+        desc[n_desc].height = th;
+        desc[n_desc].stride = tw * 4;
+      } else {
+        vmeta = gst_buffer_get_video_meta (bufs[i]);
+        desc[n_desc].data = base + (vmeta ? vmeta->offset[0] : GST_VIDEO_INFO_PLANE_OFFSET (&p->info, 0));
+        desc[n_desc].width = GST_VIDEO_INFO_WIDTH (&p->info);
+        desc[n_desc].height = GST_VIDEO_INFO_HEIGHT (&p->info);
+        desc[n_desc].stride = vmeta ? vmeta->stride[0] : GST_VIDEO_INFO_PLANE_STRIDE (&p->info, 0);
+      }
+    }
     desc[n_desc].xpos = p->xpos;
     desc[n_desc].ypos = p->ypos;
     desc[n_desc].alpha = p->alpha;

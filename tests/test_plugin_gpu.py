@@ -183,3 +183,28 @@ def test_videoconvertscale_element_add_borders(gst_env, ref):
                             config=cases.ref_config_string(ref, cfg))
     for i in range(n):
         assert (rc.frame(src[i]) == out[i]).all(), i
+
+
+def test_compositor_element_scales_and_converts_pads(gst_env, ref):
+    """BASELINE C4 variant A in small: pads with width / height properties are scaled, an NV12 pad is converted, each by
+    its own converter with the library defaults (what GstVideoAggregatorConvertPad does), then blended."""
+    env, tmp = gst_env
+    n, dw, dh = 2, 320, 240
+    f0, f1, fout = tmp / "s0.bgra", tmp / "s1.nv12", tmp / "s_out.bgra"
+    launch(env, "compositor name=c background=black sink_0::width=160 sink_0::height=120 sink_0::xpos=10 sink_0::ypos=20 "
+                "sink_1::xpos=150 sink_1::ypos=100 sink_1::alpha=0.7 sink_1::width=128 sink_1::height=96 "
+                "! video/x-raw,format=BGRA,width=%d,height=%d ! filesink location=%s "
+                "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=320,height=240,framerate=30/1 ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
+                "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=NV12,width=256,height=192,framerate=30/1,colorimetry=bt601,chroma-site=jpeg ! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1"
+           % (dw, dh, fout, n, f0, n, f1))
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    s0 = np.fromfile(f0, np.uint8).reshape(n, -1)
+    s1 = np.fromfile(f1, np.uint8).reshape(n, -1)
+    c0 = ref.VideoConverter("BGRA", 320, 240, "BGRA", 160, 120)
+    c1 = ref.VideoConverter("NV12", 256, 192, "BGRA", 128, 96, in_colorimetry="bt601", in_chroma_site="jpeg")
+    for f in range(n):
+        canvas = np.zeros(dw * dh * 4, np.uint8)
+        ref.compositor_fill(1, "bgra", "BGRA", canvas, dw, dh, 0, dh, 0, 0, 0)
+        ref.compositor_blend("blend_bgra", "BGRA", c0.frame(s0[f]), 160, 120, 10, 20, 1.0, canvas, dw, dh, 0, dh, 1)
+        ref.compositor_blend("blend_bgra", "BGRA", c1.frame(s1[f]), 128, 96, 150, 100, 0.7, canvas, dw, dh, 0, dh, 1)
+        assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))

@@ -30,6 +30,8 @@ struct FirParams {
   long long hist_frames;    // frames in the history buffer
   long long total_frames;   // hist_frames + in_frames
   int in_is_null;           // new input is silence
+  int interp;               // 0: FULL table [out_rate][n_taps]; 1 / 2: INTERPOLATED mode, linear / cubic blend of the oversampled table per output
+  int oversample;
 };
 
 template <typename T> struct Acc;
@@ -63,6 +65,119 @@ template <> GSTAMD_AD int32_t fir_finish<int32_t> (int64_t r)
   return (int32_t) (r < -lim ? -lim : (r > lim - 1 ? lim - 1 : r));
 }
 
+// make_coeff_<type>_linear / _cubic (audio-resampler.c:321-373): blend weights of the oversampled rows for frac = num / denom
+template <typename T> struct FirPrec;
+template <> struct FirPrec<int16_t> { static const int prec = 15; };
+template <> struct FirPrec<int32_t> { static const int prec = 31; };
+
+GSTAMD_AD void fir_coeff_linear (int num, int denom, float *ic) { const float x = (float) num / denom; ic[0] = ic[2] = x; ic[1] = ic[3] = 1.0f - x; }
+GSTAMD_AD void fir_coeff_linear (int num, int denom, double *ic) { const double x = (double) num / denom; ic[0] = ic[2] = x; ic[1] = ic[3] = 1.0 - x; }
+GSTAMD_AD void fir_coeff_linear (int num, int denom, int16_t *ic)
+{
+  const int16_t x = (int16_t) (((int64_t) num << 15) / denom);
+  ic[0] = ic[2] = x;
+  ic[1] = ic[3] = (int16_t) ((int16_t) (((int32_t) 1 << 15) - 1) - x);
+}
+GSTAMD_AD void fir_coeff_linear (int num, int denom, int32_t *ic)
+{
+  const int32_t x = (int32_t) (((int64_t) num << 31) / denom);
+  ic[0] = ic[2] = x;
+  ic[1] = ic[3] = (int32_t) ((int32_t) (((int64_t) 1 << 31) - 1) - x);
+}
+GSTAMD_AD void fir_coeff_cubic (int num, int denom, float *ic)
+{
+  const float x = (float) num / denom, x2 = x * x, x3 = x2 * x;
+  ic[0] = 0.16667f * (x3 - x);
+  ic[1] = x + 0.5f * (x2 - x3);
+  ic[3] = -0.33333f * x + 0.5f * x2 - 0.16667f * x3;
+  ic[2] = (float) 1.0 - ic[0] - ic[1] - ic[3];
+}
+GSTAMD_AD void fir_coeff_cubic (int num, int denom, double *ic)
+{
+  const double x = (double) num / denom, x2 = x * x, x3 = x2 * x;
+  ic[0] = 0.16667f * (x3 - x);
+  ic[1] = x + 0.5f * (x2 - x3);
+  ic[3] = -0.33333f * x + 0.5f * x2 - 0.16667f * x3;
+  ic[2] = (double) 1.0 - ic[0] - ic[1] - ic[3];
+}
+template <typename T, typename T2, int prec>
+GSTAMD_AD void fir_coeff_cubic_int (int num, int denom, T *ic)
+{
+  const T2 one = ((T2) 1 << prec) - 1;
+  const T2 x = (T2) (((int64_t) num << prec) / denom);
+  const T2 x2 = (x * x) >> prec;
+  const T2 x3 = (x2 * x) >> prec;
+  ic[0] = (T) ((((x3 - x) << prec) / 6) >> prec);
+  ic[1] = (T) (x + ((x2 - x3) >> 1));
+  ic[3] = (T) (-(((x << prec) / 3) >> prec) + (x2 >> 1) - (((x3 << prec) / 6) >> prec));
+  ic[2] = (T) (one - ic[0] - ic[1] - ic[3]);
+}
+GSTAMD_AD void fir_coeff_cubic (int num, int denom, int16_t *ic) { fir_coeff_cubic_int<int16_t, int32_t, 15> (num, denom, ic); }
+GSTAMD_AD void fir_coeff_cubic (int num, int denom, int32_t *ic) { fir_coeff_cubic_int<int32_t, int64_t, 31> (num, denom, ic); }
+
+// inner_product_<T>_linear_1_c / _cubic_1_c (audio-resampler.c:636-687 int, 709-755 float): the input window against 2 / 4
+// neighbouring rows of the oversampled table, the row sums blended with ic[]
+template <typename T>
+GSTAMD_AD T fir_interp_finish_linear (typename Acc<T>::type r0, typename Acc<T>::type r1, typename Acc<T>::type r2, typename Acc<T>::type r3, const T *ic);
+template <> GSTAMD_AD float fir_interp_finish_linear<float> (float r0, float r1, float r2, float r3, const float *ic)
+{
+  r0 += r2;
+  r1 += r3;
+  return (r0 - r1) * ic[0] + r1;
+}
+template <> GSTAMD_AD double fir_interp_finish_linear<double> (double r0, double r1, double r2, double r3, const double *ic)
+{
+  r0 += r2;
+  r1 += r3;
+  return (r0 - r1) * ic[0] + r1;
+}
+template <typename T, typename T2, int prec>
+GSTAMD_AD T fir_interp_finish_linear_int (T2 r0, T2 r1, T2 r2, T2 r3, const T *ic)
+{
+  const T2 c0 = ic[0], lim = (T2) 1 << prec;
+  r0 = (r0 + r2) >> prec;
+  r1 = (r1 + r3) >> prec;
+  r0 = ((T2) (T) r0 - (T2) (T) r1) * c0 + ((T2) (T) r1 << prec);
+  r0 = (r0 + ((T2) 1 << (prec - 1))) >> prec;
+  return (T) (r0 < -lim ? -lim : (r0 > lim - 1 ? lim - 1 : r0));
+}
+template <> GSTAMD_AD int16_t fir_interp_finish_linear<int16_t> (int32_t r0, int32_t r1, int32_t r2, int32_t r3, const int16_t *ic)
+{
+  return fir_interp_finish_linear_int<int16_t, int32_t, 15> (r0, r1, r2, r3, ic);
+}
+template <> GSTAMD_AD int32_t fir_interp_finish_linear<int32_t> (int64_t r0, int64_t r1, int64_t r2, int64_t r3, const int32_t *ic)
+{
+  return fir_interp_finish_linear_int<int32_t, int64_t, 31> (r0, r1, r2, r3, ic);
+}
+
+template <typename T>
+GSTAMD_AD T fir_interp_finish_cubic (typename Acc<T>::type r0, typename Acc<T>::type r1, typename Acc<T>::type r2, typename Acc<T>::type r3, const T *ic);
+template <> GSTAMD_AD float fir_interp_finish_cubic<float> (float r0, float r1, float r2, float r3, const float *ic)
+{
+  return r0 * ic[0] + r1 * ic[1] + r2 * ic[2] + r3 * ic[3];
+}
+template <> GSTAMD_AD double fir_interp_finish_cubic<double> (double r0, double r1, double r2, double r3, const double *ic)
+{
+  return r0 * ic[0] + r1 * ic[1] + r2 * ic[2] + r3 * ic[3];
+}
+template <typename T, typename T2, int prec>
+GSTAMD_AD T fir_interp_finish_cubic_int (T2 r0, T2 r1, T2 r2, T2 r3, const T *ic)
+{
+  const T2 lim = (T2) 1 << prec;
+  T2 r = (T2) (T) (r0 >> prec) * (T2) ic[0] + (T2) (T) (r1 >> prec) * (T2) ic[1] + (T2) (T) (r2 >> prec) * (T2) ic[2] +
+      (T2) (T) (r3 >> prec) * (T2) ic[3];
+  r = (r + ((T2) 1 << (prec - 1))) >> prec;
+  return (T) (r < -lim ? -lim : (r > lim - 1 ? lim - 1 : r));
+}
+template <> GSTAMD_AD int16_t fir_interp_finish_cubic<int16_t> (int32_t r0, int32_t r1, int32_t r2, int32_t r3, const int16_t *ic)
+{
+  return fir_interp_finish_cubic_int<int16_t, int32_t, 15> (r0, r1, r2, r3, ic);
+}
+template <> GSTAMD_AD int32_t fir_interp_finish_cubic<int32_t> (int64_t r0, int64_t r1, int64_t r2, int64_t r3, const int32_t *ic)
+{
+  return fir_interp_finish_cubic_int<int32_t, int64_t, 31> (r0, r1, r2, r3, ic);
+}
+
 // output frame j, channel c
 template <typename T>
 GSTAMD_AD T fir_output (const FirParams &p, const T *__restrict__ hist, const T *__restrict__ in, const T *__restrict__ table,
@@ -74,6 +189,35 @@ GSTAMD_AD T fir_output (const FirParams &p, const T *__restrict__ hist, const T 
   const int phase = (int) (t % p.out_rate);
   if (p.nearest)
     return logical_sample<T> (p, hist, in, idx, c);
+  if (p.interp) {
+    /* get_taps_<T>_<inter> (audio-resampler.c:567-590): rows `offset` .. of the oversampled table, blend weights from frac */
+    const int pos = phase * p.oversample;
+    const int offset = (p.oversample - 1) - pos / p.out_rate, frac = pos % p.out_rate;
+    const T *__restrict__ c0 = table + (size_t) offset * p.n_taps_padded, *__restrict__ c1 = c0 + p.n_taps_padded;
+    T ic[4];
+    A r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    if (p.interp == 1) {
+      fir_coeff_linear (frac, p.out_rate, ic);
+      for (int i = 0; i < p.n_taps_padded; i += 2) {
+        const A a0 = (A) logical_sample<T> (p, hist, in, idx + i, c), a1 = (A) logical_sample<T> (p, hist, in, idx + i + 1, c);
+        r0 += a0 * (A) c0[i];
+        r1 += a0 * (A) c1[i];
+        r2 += a1 * (A) c0[i + 1];
+        r3 += a1 * (A) c1[i + 1];
+      }
+      return fir_interp_finish_linear<T> (r0, r1, r2, r3, ic);
+    }
+    const T *__restrict__ c2 = c1 + p.n_taps_padded, *__restrict__ c3 = c2 + p.n_taps_padded;
+    fir_coeff_cubic (frac, p.out_rate, ic);
+    for (int i = 0; i < p.n_taps_padded; i++) {
+      const A a = (A) logical_sample<T> (p, hist, in, idx + i, c);
+      r0 += a * (A) c0[i];
+      r1 += a * (A) c1[i];
+      r2 += a * (A) c2[i];
+      r3 += a * (A) c3[i];
+    }
+    return fir_interp_finish_cubic<T> (r0, r1, r2, r3, ic);
+  }
   const T *__restrict__ taps = table + (size_t) phase * p.n_taps_padded;
   A r0 = 0, r1 = 0, r2 = 0, r3 = 0;
   for (int i = 0; i < p.n_taps_padded; i += 4) {

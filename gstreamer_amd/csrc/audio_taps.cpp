@@ -278,6 +278,19 @@ static void build_table (AudioPlan &p)
   std::vector<double> tmp (n_taps);
   if (p.method == GSTAMD_AUDIO_RESAMPLER_METHOD_NEAREST)
     return;
+  if (p.filter_mode == GSTAMD_AUDIO_FILTER_MODE_INTERPOLATED) {
+    /* INTERPOLATED mode: the device blends per output sample; the table is the oversampled main table itself
+     * (resampler_calculate_taps :1176-1206), rows of taps_stride elements */
+    const bool cubic = p.filter_interpolation == GSTAMD_AUDIO_FILTER_INTERPOLATION_CUBIC;
+    const int rows = p.oversample + (cubic ? 4 : 2);
+    p.table.assign ((size_t) rows * p.taps_stride * sizeof (T), 0);
+    table = (T *) p.table.data ();
+    for (int i = 0; i < rows; i++) {
+      double x = -(n_taps / 2) + i / (double) p.oversample;
+      make_taps<T> (p, tmp, table + (size_t) i * p.taps_stride, x, n_taps);
+    }
+    return;
+  }
   if (p.filter_interpolation == GSTAMD_AUDIO_FILTER_INTERPOLATION_NONE) {
     /* get_taps_*_full, INTERPOLATION_NONE branch (:503-525) */
     for (int phase = 0; phase < n_phases; phase++) {
@@ -451,8 +464,6 @@ int plan_audio_resampler (int method, int flags, int format, int channels, int i
     filter_interpolation = GSTAMD_AUDIO_FILTER_INTERPOLATION_CUBIC;
   p->filter_mode = filter_mode;
   p->filter_interpolation = filter_interpolation;
-  if (filter_mode != GSTAMD_AUDIO_FILTER_MODE_FULL && method != GSTAMD_AUDIO_RESAMPLER_METHOD_NEAREST)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "interpolated filter mode (taps blended per output sample) not implemented yet");
   if (oversample < 1)
     return fail (GSTAMD_ERR_INVALID, "bad filter-oversample");
   p->n_phases = p->out_rate;

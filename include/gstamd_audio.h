@@ -66,8 +66,9 @@ void gstamd_audio_resampler_options_set_quality (int method, unsigned quality, i
     GstAmdAudioResamplerOptions *options);
 
 /* options == NULL: Kaiser quality 4 like the reference (audio-resampler.c:1414-1419).  flags must be 0
- * (interleaved in and out).  Returns NULL and sets *status (GSTAMD_ERR_* of gstamd_video.h) on failure;
- * configurations that resolve to the interpolated filter mode are refused (not implemented yet). */
+ * (interleaved in and out).  Returns NULL and sets *status (GSTAMD_ERR_* of gstamd_video.h) on failure.  Both filter
+ * modes are implemented: FULL (one row of taps per phase) and INTERPOLATED (the taps of every output sample are blended
+ * on the device from the oversampled table, linear or cubic, audio-resampler.c:567-757). */
 GstAmdAudioResampler *gstamd_audio_resampler_new (int method, int flags, int format, int channels, int in_rate,
     int out_rate, const GstAmdAudioResamplerOptions *options, int *status);
 void gstamd_audio_resampler_free (GstAmdAudioResampler *resampler);

@@ -160,12 +160,19 @@ class AudioResampler:
     """gst_audio_resampler_* of the reference (interleaved in/out)."""
     METHODS = {"nearest": 0, "linear": 1, "cubic": 2, "blackman-nuttall": 3, "kaiser": 4}
 
-    def __init__(self, fmt, channels, in_rate, out_rate, method="kaiser", quality=4, options=None):
+    FILTER_MODE = {"interpolated": 0, "full": 1, "auto": 2}
+    FILTER_INTERPOLATION = {"none": 0, "linear": 1, "cubic": 2}
+
+    def __init__(self, fmt, channels, in_rate, out_rate, method="kaiser", quality=4, options=None, filter_mode=None,
+                 filter_interpolation=None):
         self.channels = channels
         self.fmt = fmt
         self.dtype = {"F32LE": np.float32, "F64LE": np.float64, "S16LE": np.int16, "S32LE": np.int32}[fmt]
+        lib().ref_audio_resampler_set_filter(-1 if filter_mode is None else self.FILTER_MODE[filter_mode],
+                                              -1 if filter_interpolation is None else self.FILTER_INTERPOLATION[filter_interpolation])
         self.h = lib().ref_audio_resampler_new(self.METHODS[method], 0, fmt.encode(), channels, in_rate, out_rate, quality,
                                                _b(options))
+        lib().ref_audio_resampler_set_filter(-1, -1)
         if not self.h:
             raise ValueError("reference could not create resampler")
 

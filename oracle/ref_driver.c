@@ -312,6 +312,15 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
 
 /* ---- audio resampler -------------------------------------------------------------------- */
 
+/* filter-mode / filter-interpolation for the next ref_audio_resampler_new (-1: leave the option out) */
+static int ref_filter_mode = -1, ref_filter_interpolation = -1;
+void
+ref_audio_resampler_set_filter (int filter_mode, int filter_interpolation)
+{
+  ref_filter_mode = filter_mode;
+  ref_filter_interpolation = filter_interpolation;
+}
+
 /* method: GstAudioResamplerMethod (0 nearest,1 linear,2 cubic,3 blackman-nuttall,4 kaiser);
  * quality <0 -> no quality option (library default); options: extra serialized GstStructure or NULL */
 void *
@@ -333,6 +342,12 @@ ref_audio_resampler_new (int method, int flags, const char *format, int channels
   if (quality >= 0)
     gst_audio_resampler_options_set_quality ((GstAudioResamplerMethod) method, quality, in_rate,
         out_rate, s);
+  /* typed enum options (a serialized structure would need the enum GTypes registered by name first) */
+  if (ref_filter_mode >= 0)
+    gst_structure_set (s, GST_AUDIO_RESAMPLER_OPT_FILTER_MODE, GST_TYPE_AUDIO_RESAMPLER_FILTER_MODE, ref_filter_mode, NULL);
+  if (ref_filter_interpolation >= 0)
+    gst_structure_set (s, GST_AUDIO_RESAMPLER_OPT_FILTER_INTERPOLATION, GST_TYPE_AUDIO_RESAMPLER_FILTER_INTERPOLATION,
+        ref_filter_interpolation, NULL);
   {
     GstAudioResampler *r = gst_audio_resampler_new ((GstAudioResamplerMethod) method,
         (GstAudioResamplerFlags) flags, f, channels, in_rate, out_rate, s);

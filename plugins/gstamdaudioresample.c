@@ -2,7 +2,7 @@
  *
  * Mirrors the reference element's contract for this path
  * (subprojects/gst-plugins-base/gst/audioresample/gstaudioresample.c): factory name / rank PRIMARY (:139-142),
- * properties quality (0-10, default 4) and resample-method (:150-163), caps audio/x-raw {F32,F64,S16,S32}
+ * properties quality (0-10, default 4), resample-method, sinc-filter-mode / -auto-threshold / -interpolation (:150-185), caps audio/x-raw {F32,F64,S16,S32}
  * interleaved with the rate made a range by transform_caps, output sizes from
  * gst_audio_resampler_get_out_frames, one resample() per buffer (:745-860), drain of the filter history at EOS.
  * Samples are staged to HBM per buffer (audio buffers are tiny; a HIP-memory audio path would not change
@@ -28,6 +28,8 @@ static GstStaticPadTemplate ar_src = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC
 typedef struct {
   GstBaseTransform parent;
   gint quality, method;
+  gint sinc_filter_mode, sinc_filter_interpolation;      /* sinc-filter-mode (auto), sinc-filter-interpolation (cubic) */
+  guint sinc_filter_auto_threshold;                      /* sinc-filter-auto-threshold (1 MiB) */
   GstAudioInfo in, out;
   GstAmdAudioResampler *r;
   gpointer d_in, d_out;
@@ -37,7 +39,7 @@ typedef struct {
 } GstAmdAudioResample;
 typedef struct { GstBaseTransformClass parent_class; } GstAmdAudioResampleClass;
 
-enum { PROP_0, PROP_QUALITY, PROP_METHOD };
+enum { PROP_0, PROP_QUALITY, PROP_METHOD, PROP_SINC_FILTER_MODE, PROP_SINC_FILTER_AUTO_THRESHOLD, PROP_SINC_FILTER_INTERPOLATION };
 G_DEFINE_TYPE (GstAmdAudioResample, gst_amd_ar, GST_TYPE_BASE_TRANSFORM);
 #define AMD_AR(o) ((GstAmdAudioResample *) (o))
 
@@ -49,6 +51,12 @@ amd_ar_set_property (GObject * o, guint id, const GValue * v, GParamSpec * p)
     s->quality = g_value_get_int (v);
   else if (id == PROP_METHOD)
     s->method = g_value_get_enum (v);
+  else if (id == PROP_SINC_FILTER_MODE)
+    s->sinc_filter_mode = g_value_get_enum (v);
+  else if (id == PROP_SINC_FILTER_AUTO_THRESHOLD)
+    s->sinc_filter_auto_threshold = g_value_get_uint (v);
+  else if (id == PROP_SINC_FILTER_INTERPOLATION)
+    s->sinc_filter_interpolation = g_value_get_enum (v);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (o, id, p);
 }
@@ -61,6 +69,12 @@ amd_ar_get_property (GObject * o, guint id, GValue * v, GParamSpec * p)
     g_value_set_int (v, s->quality);
   else if (id == PROP_METHOD)
     g_value_set_enum (v, s->method);
+  else if (id == PROP_SINC_FILTER_MODE)
+    g_value_set_enum (v, s->sinc_filter_mode);
+  else if (id == PROP_SINC_FILTER_AUTO_THRESHOLD)
+    g_value_set_uint (v, s->sinc_filter_auto_threshold);
+  else if (id == PROP_SINC_FILTER_INTERPOLATION)
+    g_value_set_enum (v, s->sinc_filter_interpolation);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (o, id, p);
 }
@@ -122,6 +136,10 @@ amd_ar_set_caps (GstBaseTransform * t, GstCaps * incaps, GstCaps * outcaps)
   gstamd_audio_resampler_options_init (&o);
   gstamd_audio_resampler_options_set_quality (s->method, (unsigned) s->quality, GST_AUDIO_INFO_RATE (&s->in),
       GST_AUDIO_INFO_RATE (&s->out), &o);
+  /* gst_audio_resample_update_state (gstaudioresample.c:~370): the three sinc-filter-* properties go into the options */
+  o.filter_mode = s->sinc_filter_mode;
+  o.filter_mode_threshold = (int32_t) s->sinc_filter_auto_threshold;
+  o.filter_interpolation = s->sinc_filter_interpolation;
   s->r = gstamd_audio_resampler_new (s->method, 0, amd_format (&s->in), GST_AUDIO_INFO_CHANNELS (&s->in),
       GST_AUDIO_INFO_RATE (&s->in), GST_AUDIO_INFO_RATE (&s->out), &o, &status);
   if (!s->r) {
@@ -309,6 +327,25 @@ gst_amd_ar_class_init (GstAmdAudioResampleClass * klass)
           G_PARAM_READWRITE | G_PARAM_CONSTRUCT | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_METHOD, g_param_spec_enum ("resample-method", "Resample method to use",
           "What resample method to use", mt, 4, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  {
+    static const GEnumValue fm[] = {{0, "Use interpolated filter tables", "interpolated"}, {1, "Use full filter table", "full"},
+      {2, "Automatically choose based on filter table size", "auto"}, {0, NULL, NULL}};
+    static const GEnumValue fi[] = {{0, "No interpolation", "none"}, {1, "Linear interpolation of the filter coefficients", "linear"},
+      {2, "Cubic interpolation of the filter coefficients", "cubic"}, {0, NULL, NULL}};
+    GType fmt = g_type_from_name ("GstAmdAudioResamplerFilterMode"), fit = g_type_from_name ("GstAmdAudioResamplerFilterInterpolation");
+    if (!fmt)
+      fmt = g_enum_register_static ("GstAmdAudioResamplerFilterMode", fm);
+    if (!fit)
+      fit = g_enum_register_static ("GstAmdAudioResamplerFilterInterpolation", fi);
+    /* names, ranges and defaults of gstaudioresample.c:165-185 */
+    g_object_class_install_property (oc, PROP_SINC_FILTER_MODE, g_param_spec_enum ("sinc-filter-mode", "Sinc filter table mode",
+            "What sinc filter table mode to use", fmt, 2, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+    g_object_class_install_property (oc, PROP_SINC_FILTER_AUTO_THRESHOLD, g_param_spec_uint ("sinc-filter-auto-threshold",
+            "Sinc filter auto mode threshold", "Memory usage threshold to use if sinc filter mode is AUTO, given in bytes", 0, G_MAXUINT,
+            1048576, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+    g_object_class_install_property (oc, PROP_SINC_FILTER_INTERPOLATION, g_param_spec_enum ("sinc-filter-interpolation",
+            "Sinc filter interpolation", "How to interpolate the sinc filter table", fit, 2, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  }
   gst_element_class_set_static_metadata (ec, "Audio resampler (MI355X/HIP)", "Filter/Converter/Audio",
       "Resamples audio with a polyphase FIR on an AMD Instinct GPU, bit-exact to GstAudioResampler", "gstreamer_amd");
   gst_element_class_add_static_pad_template (ec, &ar_sink);
@@ -329,6 +366,9 @@ gst_amd_ar_init (GstAmdAudioResample * s)
 {
   s->quality = 4;
   s->method = GSTAMD_AUDIO_RESAMPLER_METHOD_KAISER;
+  s->sinc_filter_mode = GSTAMD_AUDIO_FILTER_MODE_AUTO;
+  s->sinc_filter_interpolation = GSTAMD_AUDIO_FILTER_INTERPOLATION_CUBIC;
+  s->sinc_filter_auto_threshold = 1048576;
   s->t0 = GST_CLOCK_TIME_NONE;
 }
 

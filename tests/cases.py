@@ -217,7 +217,36 @@ AUDIO_CASES = [
     ("f32_same_rate", "F32LE", 2, 44100, 44100, "kaiser", 4, (1024,) * 3),
     ("s16_cubic", "S16LE", 1, 48000, 44100, "cubic", 4, (1024,) * 3),
     ("s16_linear_up", "S16LE", 1, 44100, 48000, "linear", 4, (1024,) * 3),
+    # INTERPOLATED filter mode (taps blended per output sample from the oversampled table), see AUDIO_FILTER
+    ("f32_interp_cubic_48k_44k1", "F32LE", 2, 48000, 44100, "kaiser", 4, (1024,) * 4),
+    ("f32_interp_linear_48k_44k1", "F32LE", 2, 48000, 44100, "kaiser", 4, (1024,) * 4),
+    ("f64_interp_cubic_44k1_48k", "F64LE", 1, 44100, 48000, "kaiser", 6, (1024,) * 3),
+    ("s16_interp_cubic_48k_44k1", "S16LE", 2, 48000, 44100, "kaiser", 4, (1024,) * 3),
+    ("s16_interp_linear_up", "S16LE", 1, 44100, 48000, "kaiser", 4, (1024,) * 3),
+    ("s32_interp_cubic_48k_32k", "S32LE", 2, 48000, 32000, "kaiser", 4, (1024,) * 3),
+    ("s32_interp_linear_48k_44k1", "S32LE", 1, 48000, 44100, "kaiser", 2, (1024,) * 3),
+    ("f32_interp_auto_prime_ratio", "F32LE", 1, 48000, 44101, "kaiser", 4, (2048,) * 3),
+    ("f32_interp_blackman_cubic", "F32LE", 2, 48000, 32000, "blackman-nuttall", 4, (1024,) * 3),
 ]
+# GstAudioResampler.filter-mode / filter-interpolation of a case (absent: the library defaults, mode auto)
+AUDIO_FILTER = {
+    "f32_interp_cubic_48k_44k1": ("interpolated", "cubic"),
+    "f32_interp_linear_48k_44k1": ("interpolated", "linear"),
+    "f64_interp_cubic_44k1_48k": ("interpolated", "cubic"),
+    "s16_interp_cubic_48k_44k1": ("interpolated", "cubic"),
+    "s16_interp_linear_up": ("interpolated", "linear"),
+    "s32_interp_cubic_48k_32k": ("interpolated", "cubic"),
+    "s32_interp_linear_48k_44k1": ("interpolated", "linear"),
+    "f32_interp_blackman_cubic": ("interpolated", "cubic"),
+}
+
+
+def audio_filter_kwargs(name):
+    """Keyword arguments (filter_mode=..., filter_interpolation=...) of a case for A.options / ref.AudioResampler."""
+    if name not in AUDIO_FILTER:
+        return {}
+    mode, interp = AUDIO_FILTER[name]
+    return dict(filter_mode=mode, filter_interpolation=interp)
 AUDIO_DTYPES = {"F32LE": np.float32, "F64LE": np.float64, "S16LE": np.int16, "S32LE": np.int32}
 
 

@@ -27,6 +27,9 @@ static void emu_run (EmuResampler *r, const void *in, size_t in_frames, void *ou
   memset (&p, 0, sizeof (p));
   p.channels = pl.channels;
   p.n_taps_padded = pl.taps_stride;
+  p.interp = pl.filter_mode == GSTAMD_AUDIO_FILTER_MODE_INTERPOLATED && pl.method != GSTAMD_AUDIO_RESAMPLER_METHOD_NEAREST ?
+      (pl.filter_interpolation == GSTAMD_AUDIO_FILTER_INTERPOLATION_CUBIC ? 2 : 1) : 0;
+  p.oversample = pl.oversample;
   p.nearest = (pl.method == GSTAMD_AUDIO_RESAMPLER_METHOD_NEAREST || pl.in_rate == pl.out_rate) ? 1 : 0;
   p.samp_inc = pl.samp_inc;
   p.samp_frac = pl.samp_frac;

@@ -35,7 +35,7 @@ def audio():
     out = {}
     for case in cases.AUDIO_CASES:
         name, fmt, ch, ir, orr, method, quality, bufs = case
-        rr = ref.AudioResampler(fmt, ch, ir, orr, method=method, quality=quality)
+        rr = ref.AudioResampler(fmt, ch, ir, orr, method=method, quality=quality, **cases.audio_filter_kwargs(name))
         chunks, counts = [], []
         for i, n in enumerate(list(bufs) + [None]):
             data = None if n is None else cases.audio_buffer(fmt, ch, n, cases.case_seed(name) + i)

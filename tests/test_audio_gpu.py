@@ -20,7 +20,7 @@ def gpu_stream(gpu, case):
     import torch
     name, fmt, ch, ir, orr, method, quality, bufs = case
     dt = cases.AUDIO_DTYPES[fmt]
-    r = A.AudioResampler(fmt, ch, ir, orr, method, A.options(method, quality, ir, orr))
+    r = A.AudioResampler(fmt, ch, ir, orr, method, A.options(method, quality, ir, orr, **cases.audio_filter_kwargs(name)))
     chunks, counts = [], []
     for i, n in enumerate(list(bufs) + [None]):
         if n is None:

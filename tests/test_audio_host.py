@@ -29,7 +29,7 @@ def _emu(emu_lib):
 def test_fir_bodies_on_host_match_golden(native_lib, emu_lib, case):
     E = _emu(emu_lib)
     name, fmt, ch, ir, orr, method, quality, bufs = case
-    o = A.options(method, quality, ir, orr)
+    o = A.options(method, quality, ir, orr, **cases.audio_filter_kwargs(name))
     st = C.c_int(0)
     h = E.emu_audio_new(A.METHODS[method], 0, A.FORMATS[fmt], ch, ir, orr, C.byref(o), C.byref(st), None, 0)
     assert h, st.value
@@ -54,7 +54,7 @@ def test_fir_bodies_on_host_match_golden(native_lib, emu_lib, case):
 @pytest.mark.parametrize("case", cases.AUDIO_CASES[::3], ids=lambda c: c[0])
 def test_golden_is_the_references_output(ref, case):
     name, fmt, ch, ir, orr, method, quality, bufs = case
-    rr = ref.AudioResampler(fmt, ch, ir, orr, method=method, quality=quality)
+    rr = ref.AudioResampler(fmt, ch, ir, orr, method=method, quality=quality, **cases.audio_filter_kwargs(name))
     chunks = []
     for i, n in enumerate(list(bufs) + [None]):
         data = None if n is None else cases.audio_buffer(fmt, ch, n, cases.case_seed(name) + i)
@@ -83,8 +83,16 @@ def test_c4_plan_48k_to_44k1(native_lib):
         x.free()
 
 
-def test_interpolated_mode_is_refused(native_lib):
+def test_filter_mode_auto_picks_interpolated_for_big_tables(native_lib):
+    """audio-resampler.c:1110-1130: 48000 -> 44101 would need 44101 phases x 72 taps x 4 B > the 1 MiB threshold, so
+    mode AUTO resolves to INTERPOLATED (cubic, 8x oversampled table of 8 + 4 rows); non-interleaved layouts are refused."""
     from gstreamer_amd import video as V
-    with pytest.raises(V.GstAmdError) as e:
-        A.AudioResampler("F32LE", 2, 48000, 44101, "kaiser", A.options("kaiser", 4, 48000, 44101))
-    assert e.value.code == V.ERR_UNSUPPORTED
+    r = A.AudioResampler("F32LE", 2, 48000, 44101, "kaiser", A.options("kaiser", 4, 48000, 44101))
+    d = r.debug()
+    assert d["filter_mode"] == A.FILTER_MODE["interpolated"] and d["filter_interpolation"] == A.FILTER_INTERPOLATION["cubic"]
+    assert d["oversample"] == 8
+    r.free()
+    L = A.lib()
+    st = C.c_int(0)
+    assert not L.gstamd_audio_resampler_new(A.METHODS["kaiser"], 1, A.FORMATS["F32LE"], 2, 48000, 44100, None, C.byref(st))
+    assert st.value == V.ERR_UNSUPPORTED

@@ -208,3 +208,23 @@ def test_compositor_element_scales_and_converts_pads(gst_env, ref):
         ref.compositor_blend("blend_bgra", "BGRA", c0.frame(s0[f]), 160, 120, 10, 20, 1.0, canvas, dw, dh, 0, dh, 1)
         ref.compositor_blend("blend_bgra", "BGRA", c1.frame(s1[f]), 128, 96, 150, 100, 0.7, canvas, dw, dh, 0, dh, 1)
         assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
+
+
+def test_audioresample_element_interpolated_filter(gst_env, ref):
+    """sinc-filter-mode=interpolated sinc-filter-interpolation=linear through the element, S16."""
+    env, tmp = gst_env
+    fin, fout = tmp / "in.s16", tmp / "out.s16"
+    launch(env, "audiotestsrc num-buffers=20 wave=white-noise samplesperbuffer=1024 ! audio/x-raw,format=S16LE,rate=48000,channels=2 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! amdaudioresample quality=4 sinc-filter-mode=interpolated "
+                "sinc-filter-interpolation=linear ! audio/x-raw,rate=44100 ! filesink location=%s" % (fin, fout))
+    src = np.fromfile(fin, np.int16).reshape(-1, 2)
+    out = np.fromfile(fout, np.int16).reshape(-1, 2)
+    rr = ref.AudioResampler("S16LE", 2, 48000, 44100, quality=4, filter_mode="interpolated", filter_interpolation="linear")
+    exp = []
+    for off in range(0, len(src), 1024):
+        blk = src[off:off + 1024]
+        exp.append(rr.resample(blk, in_frames=len(blk), out_frames=rr.get_out_frames(len(blk))))
+    lat = rr.get_max_latency()
+    exp.append(rr.resample(None, in_frames=lat, out_frames=rr.get_out_frames(lat)))
+    exp = np.concatenate(exp)
+    assert out.shape == exp.shape and (out == exp).all()

@@ -19,6 +19,17 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_Y444, "Y444", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV12, "NV12", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV21, "NV21", true, false, 2, UNPACK_SEMI, 1, 1, 0, 1, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_NV16, "NV16", true, false, 2, UNPACK_SEMI, 1, 0, 1, 0, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_NV61, "NV61", true, false, 2, UNPACK_SEMI, 1, 0, 0, 1, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_NV24, "NV24", true, false, 2, UNPACK_SEMI, 0, 0, 1, 0, {0, 0, 0, 0}},
+  // packed 4:2:2 (video-format.c:153-460): pos[1..3] = byte of Y0, U, V inside the 4-byte macropixel
+  {GSTAMD_VIDEO_FORMAT_YUY2, "YUY2", true, false, 1, UNPACK_PACKED422, 1, 0, 0, 0, {0, 0, 1, 3}},
+  {GSTAMD_VIDEO_FORMAT_UYVY, "UYVY", true, false, 1, UNPACK_PACKED422, 1, 0, 0, 0, {0, 1, 0, 2}},
+  {GSTAMD_VIDEO_FORMAT_YVYU, "YVYU", true, false, 1, UNPACK_PACKED422, 1, 0, 0, 0, {0, 0, 3, 1}},
+  {GSTAMD_VIDEO_FORMAT_VYUY, "VYUY", true, false, 1, UNPACK_PACKED422, 1, 0, 0, 0, {0, 1, 2, 0}},
+  // 3 bytes per pixel (video-format.c:1519-1593)
+  {GSTAMD_VIDEO_FORMAT_RGB, "RGB", false, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 0, 1, 2}},
+  {GSTAMD_VIDEO_FORMAT_BGR, "BGR", false, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 2, 1, 0}},
   {GSTAMD_VIDEO_FORMAT_AYUV, "AYUV", true, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}},
   {GSTAMD_VIDEO_FORMAT_ARGB, "ARGB", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}},
   {GSTAMD_VIDEO_FORMAT_xRGB, "xRGB", false, false, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}},
@@ -88,6 +99,30 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = info->offset[1] + info->stride[0] * cr_h;
       break;
     }
+    case GSTAMD_VIDEO_FORMAT_NV16:
+    case GSTAMD_VIDEO_FORMAT_NV61:
+      info->stride[0] = info->stride[1] = round_up (width, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * h;
+      info->size = (uint64_t) info->stride[0] * h * 2;
+      break;
+    case GSTAMD_VIDEO_FORMAT_NV24:
+      info->stride[0] = round_up (width, 4);
+      info->stride[1] = round_up (width * 2, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * h;
+      info->size = info->offset[1] + (uint64_t) info->stride[1] * h;
+      break;
+    case GSTAMD_VIDEO_FORMAT_YUY2:
+    case GSTAMD_VIDEO_FORMAT_UYVY:
+    case GSTAMD_VIDEO_FORMAT_YVYU:
+    case GSTAMD_VIDEO_FORMAT_VYUY:
+      info->stride[0] = round_up (width * 2, 4);
+      info->size = (uint64_t) info->stride[0] * h;
+      break;
+    case GSTAMD_VIDEO_FORMAT_RGB:
+    case GSTAMD_VIDEO_FORMAT_BGR:
+      info->stride[0] = round_up (width * 3, 4);
+      info->size = (uint64_t) info->stride[0] * h;
+      break;
     default:                   /* 4-byte packed */
       info->stride[0] = width * 4;
       info->size = w * 4 * h;
@@ -718,49 +753,81 @@ static void simulate_vpairs (VideoPlan *plan, int out_height)
 // fastpath detection (video-converter.c:8907-9017 + transforms[] :8413-8905), restricted to the
 // formats this library knows.  Returns a short name of the reference fastpath or nullptr.
 // ------------------------------------------------------------------------------------------------
+// The reference's transforms[] (video-converter.c:8413-8905) restricted to the formats of this library, one row per
+// conversion function: which format pairs it serves and the conditions video_converter_lookup_fastpath (:8907-9010) tests.
+namespace {
+enum : unsigned {
+  FP_MATRIX = 1,      /* needs_color_matrix: usable when the matrices differ */
+  FP_SIZE = 2,        /* keeps_size: only when the FULL input size equals the destination rectangle */
+  FP_CROP = 4,        /* do_crop */
+  FP_BORDER = 8,      /* do_border */
+  FP_ACOPY = 16, FP_ASET = 32, FP_AMULT = 64,
+  FP_WEVEN = 128, FP_HEVEN = 256,   /* width_align / height_align == 1 */
+};
+constexpr uint64_t fbit (int f) { return 1ull << f; }
+constexpr uint64_t F_I420 = fbit (GSTAMD_VIDEO_FORMAT_I420), F_YV12 = fbit (GSTAMD_VIDEO_FORMAT_YV12), F_420 = F_I420 | F_YV12;
+constexpr uint64_t F_Y42B = fbit (GSTAMD_VIDEO_FORMAT_Y42B), F_Y444 = fbit (GSTAMD_VIDEO_FORMAT_Y444);
+constexpr uint64_t F_AYUV = fbit (GSTAMD_VIDEO_FORMAT_AYUV), F_YUY2 = fbit (GSTAMD_VIDEO_FORMAT_YUY2), F_UYVY = fbit (GSTAMD_VIDEO_FORMAT_UYVY);
+constexpr uint64_t F_RGB4X = fbit (GSTAMD_VIDEO_FORMAT_RGBx) | fbit (GSTAMD_VIDEO_FORMAT_BGRx) | fbit (GSTAMD_VIDEO_FORMAT_xRGB) | fbit (GSTAMD_VIDEO_FORMAT_xBGR);
+constexpr uint64_t F_RGB4A = fbit (GSTAMD_VIDEO_FORMAT_RGBA) | fbit (GSTAMD_VIDEO_FORMAT_BGRA) | fbit (GSTAMD_VIDEO_FORMAT_ARGB) | fbit (GSTAMD_VIDEO_FORMAT_ABGR);
+constexpr uint64_t F_RGB3 = fbit (GSTAMD_VIDEO_FORMAT_RGB) | fbit (GSTAMD_VIDEO_FORMAT_BGR);
+constexpr uint64_t F_NV12 = fbit (GSTAMD_VIDEO_FORMAT_NV12), F_NV16 = fbit (GSTAMD_VIDEO_FORMAT_NV16), F_NV24 = fbit (GSTAMD_VIDEO_FORMAT_NV24);
+struct FastRow {
+  uint64_t in, out;     /* format sets; `same` rows need in == out on top */
+  bool same;
+  unsigned flags;
+  const char *name;
+};
+const FastRow g_fast_rows[] = {
+  {F_420, F_RGB4X | F_RGB4A | F_RGB3, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_I420_xRGB"},
+  {F_AYUV, F_RGB4X, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_AYUV_xRGB"},
+  {F_AYUV, F_RGB4A, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY, "convert_AYUV_xRGB"},
+  {F_420, F_AYUV, false, FP_SIZE | FP_ASET, "convert_I420_AYUV"},
+  {F_Y42B, F_AYUV, false, FP_SIZE | FP_CROP | FP_BORDER | FP_ASET | FP_WEVEN, "convert_Y42B_AYUV"},
+  {F_Y444, F_AYUV, false, FP_SIZE | FP_CROP | FP_BORDER | FP_ASET, "convert_Y444_AYUV"},
+  {F_YUY2, F_AYUV, false, FP_SIZE | FP_CROP | FP_BORDER | FP_ASET | FP_WEVEN, "convert_YUY2_AYUV"},
+  {F_UYVY, F_AYUV, false, FP_SIZE | FP_CROP | FP_BORDER | FP_ASET, "convert_UYVY_AYUV"},
+  {F_AYUV, F_420, false, FP_SIZE | FP_CROP | FP_BORDER | FP_WEVEN | FP_HEVEN, "convert_AYUV_I420"},
+  {F_AYUV, F_Y42B | F_YUY2 | F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER | FP_WEVEN, "convert_AYUV_422"},
+  {F_AYUV, F_Y444, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_AYUV_Y444"},
+  {F_420, F_YUY2 | F_UYVY, false, FP_SIZE, "convert_I420_YUY2"},
+  {F_YUY2 | F_UYVY, F_420, false, FP_SIZE, "convert_YUY2_I420"},
+  {F_Y42B, F_YUY2 | F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_Y42B_YUY2"},
+  {F_Y444, F_YUY2 | F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER | FP_WEVEN, "convert_Y444_YUY2"},
+  {F_YUY2 | F_UYVY, F_Y42B | F_Y444, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_YUY2_planar"},
+  {F_YUY2, F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
+  {F_UYVY, F_YUY2, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
+  /* convert_scale_planes: every same-format pair, planar <-> planar and the NV12 / NV16 / NV24 family */
+  {F_RGB4A | F_AYUV, ~0ull, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
+  {F_RGB4X | F_RGB3 | F_420 | F_Y42B | F_Y444 | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
+        F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_YVYU), ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {F_420 | F_Y42B | F_Y444, F_420 | F_Y42B | F_Y444, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {F_NV12 | F_NV16 | F_NV24, F_NV12 | F_NV16 | F_NV24, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+};
+}  // namespace
+
 static const char *lookup_fastpath (const VideoPlan &p, int alpha_mode_bits, bool same_matrix)
 {
   const int in = p.in_info.format, out = p.out_info.format;
   const bool same_size = p.ref_same_size;
   const bool need_copy = alpha_mode_bits & 1, need_set = alpha_mode_bits & 2, need_mult = alpha_mode_bits & 4;
-  if (p.config.dither_quantization != 1)
+  if (p.config.dither_quantization != 1 || in >= 64 || out >= 64)
     return nullptr;
-  auto is420 = [](int f) { return f == GSTAMD_VIDEO_FORMAT_I420 || f == GSTAMD_VIDEO_FORMAT_YV12; };
-  auto is_rgb4 = [](int f) {
-    switch (f) {
-      case GSTAMD_VIDEO_FORMAT_RGBx: case GSTAMD_VIDEO_FORMAT_BGRx: case GSTAMD_VIDEO_FORMAT_xRGB:
-      case GSTAMD_VIDEO_FORMAT_xBGR: case GSTAMD_VIDEO_FORMAT_RGBA: case GSTAMD_VIDEO_FORMAT_BGRA:
-      case GSTAMD_VIDEO_FORMAT_ARGB: case GSTAMD_VIDEO_FORMAT_ABGR:
-        return true;
-      default:
-        return false;
-    }
-  };
-  /* same format: convert_scale_planes (keeps_size FALSE, alpha_copy for the alpha formats) */
-  if (in == out && same_matrix && !need_set && !need_mult && (!need_copy || p.fin->alpha))
-    return "convert_scale_planes";
-  /* I420/YV12 -> 4-byte RGB: convert_I420_BGRA / _ARGB / _pack_ARGB (needs_color_matrix, keeps_size,
-   * no alpha handling) */
-  if (is420 (in) && is_rgb4 (out) && same_size && !need_copy && !need_set && !need_mult)
-    return "convert_I420_xRGB";
-  /* AYUV -> 4-byte RGB: convert_AYUV_* (keeps_size, alpha_copy only for the alpha outputs) */
-  if (in == GSTAMD_VIDEO_FORMAT_AYUV && is_rgb4 (out) && same_size && !need_set && !need_mult
-      && (!need_copy || p.fout->alpha))
-    return "convert_AYUV_xRGB";
-  auto is_planar = [&](int f) { return is420 (f) || f == GSTAMD_VIDEO_FORMAT_Y42B || f == GSTAMD_VIDEO_FORMAT_Y444; };
-  /* planar -> planar, any size: convert_scale_planes plane by plane (no colour matrix) */
-  if (is_planar (in) && is_planar (out) && same_matrix && !need_copy && !need_set && !need_mult)
-    return "convert_scale_planes";
-  /* AYUV -> planar: convert_AYUV_I420 (even width and height) / _Y42B (even width) / _Y444, same size */
-  if (in == GSTAMD_VIDEO_FORMAT_AYUV && is_planar (out) && same_size && same_matrix && !need_copy && !need_mult) {
-    const int w = p.in_info.width, h = p.in_info.height;
-    if (is420 (out) ? (w % 2 == 0 && h % 2 == 0) : out == GSTAMD_VIDEO_FORMAT_Y42B ? w % 2 == 0 : true)
-      return "convert_AYUV_planar";
+  const RectPlan &rc = p.rect;
+  const bool crop = rc.in_x || rc.in_y || p.in_info.width < rc.in_maxw || p.in_info.height < rc.in_maxh;
+  const bool border = rc.out_x || rc.out_y || (rc.out_maxw && p.out_info.width < rc.out_maxw) || (rc.out_maxh && p.out_info.height < rc.out_maxh);
+  const int full_w = rc.in_maxw ? rc.in_maxw : p.in_info.width, full_h = rc.in_maxh ? rc.in_maxh : p.in_info.height;
+  for (const FastRow &r : g_fast_rows) {
+    if (!(r.in & fbit (in)) || !(r.out & fbit (out)) || (r.same && in != out))
+      continue;
+    const unsigned f = r.flags;
+    if (((f & FP_MATRIX) || same_matrix) && (!(f & FP_SIZE) || same_size) && (!(f & FP_WEVEN) || !(full_w & 1)) &&
+        (!(f & FP_HEVEN) || !(full_h & 1)) && ((f & FP_CROP) || !crop) && ((f & FP_BORDER) || !border) &&
+        ((f & FP_ACOPY) || !need_copy) && ((f & FP_ASET) || !need_set) && ((f & FP_AMULT) || !need_mult))
+      return r.name;
+    /* the reference's loop goes on to later rows of the same pair; there is one row per pair here except the same-format
+     * rows, which come last */
   }
-  /* planar YUV -> AYUV (keeps_size, no colour matrix) */
-  if ((is420 (in) || in == GSTAMD_VIDEO_FORMAT_Y42B || in == GSTAMD_VIDEO_FORMAT_Y444)
-      && out == GSTAMD_VIDEO_FORMAT_AYUV && same_size && same_matrix && !need_copy && !need_set && !need_mult)
-    return "convert_planar_AYUV";
   return nullptr;
 }
 
@@ -800,8 +867,15 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
     pp.ih = up (in.height, isub_h);
     pp.ow = up (out.width, osub_w);
     pp.oh = up (out.height, osub_h);
+    if (fo->kind == UNPACK_PACKED3) {
+      pp.n_elems = 3;          /* get_functions (video-scaler.c:1222): RGB / BGR are 3 x u8 pixels */
+    } else if (fo->kind == UNPACK_PACKED422) {
+      /* get_functions (:1215): the line is ROUND_UP_4 (width * 2) single bytes; only the vertical scaler can exist here */
+      pp.iw = pp.ow = round_up (out.width * 2, 4);
+    }
     const int rm = i == 0 ? method : cr_method;
-    const bool p1 = pp.n_elems == 1, lin = rm == GSTAMD_RESAMPLER_METHOD_LINEAR, near = rm == GSTAMD_RESAMPLER_METHOD_NEAREST;
+    /* the halve / double shortcuts exist for the planes of multi-plane formats only (setup_scale :8092-8180) */
+    const bool p1 = pp.n_elems == 1 && fo->n_planes > 1, lin = rm == GSTAMD_RESAMPLER_METHOD_LINEAR, near = rm == GSTAMD_RESAMPLER_METHOD_NEAREST;
     bool need_h = false, need_v = false;
     pp.kind = PLANE_SCALE;
     if (pp.iw == pp.ow) {
@@ -831,9 +905,9 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
     if (pp.kind == PLANE_SCALE) {
       ScalePass hp, vp;
       /* get_functions (video-scaler.c:1202-1342): a 2-tap horizontal pass is ldreslin only for 1- and 4-byte pixels;
-       * the 2-byte UV pixels take video_scale_h_ntap_u8 with two 6-bit taps */
+       * the 2-byte UV pixels and the 3-byte RGB pixels take video_scale_h_ntap_u8 with two 6-bit taps */
       if (need_h)
-        make_scale_pass (rm, cfg.resampler_taps, cfg, pp.iw, pp.ow, true, &hp, pp.n_elems == 2);
+        make_scale_pass (rm, cfg.resampler_taps, cfg, pp.iw, pp.ow, true, &hp, pp.n_elems != 1);
       if (need_v)
         make_scale_pass (rm, cfg.resampler_taps, cfg, pp.ih, pp.oh, false, &vp, false);
       hp.max_span = vp.max_span = 1 << 30;
@@ -977,17 +1051,27 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   bool force_nearest = false, force_ayuv_argb = false, plane_scale = false, force_avg_down = false;
   if (const char *fp = lookup_fastpath (*plan, alpha_bits, same_matrix)) {
     const std::string name = fp;
+    const int ki = plan->fin->kind, ko = plan->fout->kind;
     if (name == "convert_I420_xRGB")
       force_nearest = force_ayuv_argb = true;
     else if (name == "convert_AYUV_xRGB")
       force_ayuv_argb = true;
-    else if (name == "convert_planar_AYUV")
+    else if (name == "convert_I420_AYUV" || name == "convert_Y42B_AYUV" || name == "convert_Y444_AYUV" || name == "convert_YUY2_AYUV" ||
+        name == "convert_UYVY_AYUV")
       force_nearest = true;
-    else if (name == "convert_AYUV_planar")
+    else if (name == "convert_AYUV_I420" || name == "convert_AYUV_422" || name == "convert_AYUV_Y444")
       force_avg_down = true;
-    else if (name == "convert_scale_planes" && plan->fin->kind == UNPACK_PACKED4)
+    else if (name == "convert_I420_YUY2" || name == "convert_YUY2_I420" || name == "convert_Y42B_YUY2" || name == "convert_Y444_YUY2" ||
+        name == "convert_YUY2_planar" || name == "convert_UYVY_YUY2")
+      /* video_orc_convert_{I420,Y42B,Y444}_{YUY2,UYVY}, _{YUY2,UYVY}_{I420,Y42B,Y444}, _UYVY_YUY2 (video-orc.orc:1193-1620): chroma is
+       * duplicated where the destination has more of it and avgub'ed (lines, then pixel pairs) where it has less */
+      force_nearest = force_avg_down = true;
+    else if (name == "convert_scale_planes" && ki == UNPACK_PACKED4)
       plane_scale = true;
-    else if (name == "convert_scale_planes" && plan->fin->kind == plan->fout->kind)
+    else if (name == "convert_scale_planes" && ki == UNPACK_PACKED422 && in->width != out->width)
+      return fail (GSTAMD_ERR_UNSUPPORTED, "horizontal scaling of packed 4:2:2 in its own format (gst_video_scaler_combine_packed_YUV) "
+          "is not implemented on the GPU path");
+    else if (name == "convert_scale_planes" && (ki == ko || (kind_has_planes (ki) && kind_has_planes (ko))))
       return plan_planes (plan, fp);
     else
       return fail (GSTAMD_ERR_UNSUPPORTED, std::string ("reference takes fastpath ") + fp +
@@ -999,6 +1083,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   }
 
   // ---- front: unpack + chroma upsample (chain_unpack_line, chain_upsample) ----------------------
+  const int full_in_w = plan->rect.in_maxw ? plan->rect.in_maxw : in->width, full_in_h = plan->rect.in_maxh ? plan->rect.in_maxh : in->height;
+  const int full_out_w = plan->rect.out_maxw ? plan->rect.out_maxw : out->width, full_out_h = plan->rect.out_maxh ? plan->rect.out_maxh : out->height;
   FrontParams &fr = plan->front;
   memset (&fr, 0, sizeof (fr));
   fr.kind = plan->fin->kind;
@@ -1011,11 +1097,13 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   memcpy (fr.pos, plan->fin->pos, sizeof (fr.pos));
   fr.chroma_h = CHROMA_H_NONE;
   fr.chroma_v2 = 0;
+  fr.swap_k = in->format == GSTAMD_VIDEO_FORMAT_VYUY && (in->width & 1) ? (in->width - 1) >> 1 : -1;
   /* video_converter_compute_resample (:2850-2895) + gst_video_chroma_resample_new (video-chroma.c:1041-1109) */
   if (cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY
       && plan->fin->yuv) {
+    /* the FULL frame sizes are compared (in_info / out_info), not the crop / destination rectangles */
     bool differs = plan->fin->w_sub != plan->fout->w_sub || plan->fin->h_sub != plan->fout->h_sub ||
-        in->chroma_site != out->chroma_site || in->width != out->width || in->height != out->height;
+        in->chroma_site != out->chroma_site || full_in_w != full_out_w || full_in_h != full_out_h;
     if (differs && (fr.w_sub || fr.h_sub)) {
       if (fr.w_sub == 1)
         fr.chroma_h = (in->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? CHROMA_H_H2_CS : CHROMA_H_H2;
@@ -1115,12 +1203,14 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     pk.width = out->width;
     pk.height = out->height;
     pk.kind = fo->kind;
+    memcpy (pk.pos, fo->pos, sizeof (pk.pos));
+    pk.tail_swap = (out->format == GSTAMD_VIDEO_FORMAT_VYUY || out->format == GSTAMD_VIDEO_FORMAT_NV61) && (out->width & 1);
     pk.w_sub = fo->w_sub;
     pk.h_sub = fo->h_sub;
     pk.u_plane = fo->u_plane;
     pk.v_plane = fo->v_plane;
     const bool differs = plan->fin->w_sub != fo->w_sub || plan->fin->h_sub != fo->h_sub ||
-        in->chroma_site != out->chroma_site || in->width != out->width || in->height != out->height;
+        in->chroma_site != out->chroma_site || full_in_w != full_out_w || full_in_h != full_out_h;
     if (differs && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY) {
       if (fo->w_sub == 1)
         pk.down_h = (out->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? 2 : 1;
@@ -1150,6 +1240,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const FormatDesc *f = plan->fin;
     if (f->kind == UNPACK_PACKED4)
       rd = (uint64_t) in_w * in_h * 4;
+    else if (f->kind == UNPACK_PACKED3)
+      rd = (uint64_t) in_w * in_h * 3;
     else {
       uint64_t cw = ((uint64_t) in_w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) in_h + (1 << f->h_sub) - 1) >> f->h_sub;
       rd = (uint64_t) in_w * in_h + 2 * cw * ch;
@@ -1158,7 +1250,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     if (plan->out_planar) {
       const FormatDesc *fo = plan->fout;
       uint64_t cw = ((uint64_t) out_w + (1 << fo->w_sub) - 1) >> fo->w_sub, ch = ((uint64_t) out_h + (1 << fo->h_sub) - 1) >> fo->h_sub;
-      wr = (uint64_t) out_w * out_h + 2 * cw * ch;
+      wr = fo->kind == UNPACK_PACKED3 ? (uint64_t) out_w * out_h * 3 : (uint64_t) out_w * out_h + 2 * cw * ch;
     }
     plan->algorithmic_bytes = rd + wr;
   }
@@ -1179,7 +1271,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   plan->fast_pair = plan->passes.empty () && fr.kind == UNPACK_SEMI && fr.chroma_v2 && (in_w % 4) == 0 && in_h >= 2 && matrix_no_wrap;
   /* scaled plans: the same matrix code after the scaler, if the alpha channel provably arrives as 0xff: opaque source
    * and every N-tap phase summing to exactly 1.0 (the 2-tap and nearest kernels keep a constant channel as it is) */
-  plan->fast_post = !plan->passes.empty () && !plan->matrix_before_scale && matrix_no_wrap && fr.kind != UNPACK_PACKED4;
+  plan->fast_post = !plan->passes.empty () && !plan->matrix_before_scale && matrix_no_wrap && kind_has_planes (fr.kind);
   for (const ScalePass &ps : plan->passes) {
     if (ps.kind != SCALE_NTAP)
       continue;
@@ -1302,6 +1394,11 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     rc.in_maxh = in->height;
   }
   plan->rect = rc;
+  if (rc.fill && fo && fo->kind == UNPACK_PACKED422) {
+    if (error)
+      *error = "borders on a packed 4:2:2 destination (the macropixel border of convert_fill_border) are not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
   return plan_core (&ein, &eout, &cfg, plan, error);
 }
 

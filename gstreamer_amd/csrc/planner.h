@@ -18,7 +18,9 @@ namespace gstamd {
 enum UnpackKind : int {
   UNPACK_PACKED4 = 0,   // one plane, 4 bytes / pixel, pure byte permutation to A,c1,c2,c3
   UNPACK_PLANAR = 1,    // separate Y, U, V planes (I420, YV12, Y42B, Y444)
-  UNPACK_SEMI = 2,      // Y plane + interleaved UV plane (NV12, NV21)
+  UNPACK_SEMI = 2,      // Y plane + interleaved UV plane (NV12, NV21, NV16, NV61, NV24)
+  UNPACK_PACKED3 = 3,   // one plane, 3 bytes / pixel (RGB, BGR)
+  UNPACK_PACKED422 = 4, // one plane, 4-byte macropixels of two pixels (YUY2, UYVY, YVYU, VYUY)
 };
 
 struct FormatDesc {
@@ -30,7 +32,8 @@ struct FormatDesc {
   int kind;             // UnpackKind
   int w_sub, h_sub;     // log2 chroma subsampling (finfo->w_sub[1], h_sub[1])
   int u_plane, v_plane; // planar: plane index of U and V; semi: u_first (1) / v_first (0) in u_plane
-  int pos[4];           // packed4: memory byte index of unpacked component 0..3 (A,R,G,B / A,Y,U,V)
+  int pos[4];           // packed4 / packed3: memory byte index of unpacked component 0..3 (A,R,G,B / A,Y,U,V; packed3 has no A);
+                        // packed422: byte of Y0, U, V inside the macropixel in pos[1..3] (Y1 is at pos[1] + 2)
 };
 const FormatDesc *format_desc (int format);
 
@@ -60,17 +63,22 @@ struct FrontParams {    // unpack + chroma upsample of the source frame (functio
   int pos[4];
   int chroma_h;         // ChromaH
   int chroma_v2;        // 1: vertical 2x upsample through the pair table
+  int swap_k;           // chroma sample whose U and V trade places, -1: none.  unpack_VYUY (video-format.c:346-352) reads the last
+                        // pixel of an odd-width line in UYVY order
 };
 
 // planar / semi-planar destination: chroma downsample (video-chroma.c) + pack (video-format.c pack_planar_420 / pack_NV12 /
 // pack_Y42B / pack_Y444) of the final AYUV image
 struct PackPlanarParams {
   int width, height;    // output size
-  int kind;             // UnpackKind of the destination: UNPACK_PLANAR or UNPACK_SEMI
+  int kind;             // UnpackKind of the destination (anything but UNPACK_PACKED4)
+  int pos[4];           // FormatDesc::pos of the destination (packed3 / packed422)
   int w_sub, h_sub;
   int u_plane, v_plane; // planar: plane index of U and V; semi: u_first (1) / v_first (0) in u_plane
   int down_h;           // 0: the even pixel's chroma as it is, 1: video_orc_chroma_down_h2_u8, 2: video_chroma_down_h2_cs_u8
   int down_v;           // 0: the even line's chroma as it is, 1: video_orc_chroma_down_v2_u8 over lines (2r, 2r+1)
+  int tail_swap;        // 1: the last pixel of an odd-width line stores U and V the other way round - pack_VYUY writes it in UYVY
+                        // order (video-format.c:374-380), pack_NV61 in NV16 order (:2005-2011)
 };
 
 enum ScaleKind : int { SCALE_NONE = 0, SCALE_NEAREST = 1, SCALE_2TAP = 2, SCALE_NTAP = 3 };
@@ -149,6 +157,10 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
 {
   if (f->kind == UNPACK_PACKED4)
     return (size_t) y * stride + (size_t) x * 4;
+  if (f->kind == UNPACK_PACKED3)
+    return (size_t) y * stride + (size_t) x * 3;
+  if (f->kind == UNPACK_PACKED422)
+    return (size_t) y * stride + (size_t) x * 2;
   if (plane == 0)
     return (size_t) y * stride + (size_t) x;
   const size_t row = (size_t) (y >> f->h_sub) * stride;
@@ -162,6 +174,7 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
 #else
 #define GSTAMD_VP inline
 #endif
+GSTAMD_VP bool kind_has_planes (int kind) { return kind == UNPACK_PLANAR || kind == UNPACK_SEMI; }
 GSTAMD_VP int vpair_row (int e0) { return (int) ((uint32_t) e0 << 2) >> 2; }
 GSTAMD_VP int vpair_role (int e0) { return (e0 >> 30) & 1; }
 GSTAMD_VP int vpair_pack (int row, int role) { return (int) (((uint32_t) row & 0x3fffffffu) | ((uint32_t) role << 30)); }

@@ -114,7 +114,12 @@ struct UV { int u, v; };
 GSTAMD_HD UV load_uv (const FrontParams &f, const Planes &pl, int crow, int k)
 {
   UV r;
-  if (f.kind == UNPACK_SEMI) {
+  if (f.kind == UNPACK_PACKED422) {      // macropixel k of line crow: U and V at their bytes (unpack_YUY2 & co, video-format.c:155-460)
+    const uint8_t *p = pl.p[0] + (ptrdiff_t) crow * pl.stride[0] + 4 * k;
+    const bool swap = k == f.swap_k;
+    r.u = p[f.pos[swap ? 3 : 2]];
+    r.v = p[f.pos[swap ? 2 : 3]];
+  } else if (f.kind == UNPACK_SEMI) {
     const uint8_t *p = pl.p[1] + (ptrdiff_t) crow * pl.stride[1] + 2 * k;
     const int c0 = p[0], c1 = p[1];
     r.u = f.u_plane ? c0 : c1;           // NV12: U first; NV21: V first
@@ -161,7 +166,12 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
     return ((raw >> (8 * f.pos[0])) & 0xff) | (((raw >> (8 * f.pos[1])) & 0xff) << 8) |
         (((raw >> (8 * f.pos[2])) & 0xff) << 16) | (((raw >> (8 * f.pos[3])) & 0xff) << 24);
   }
-  const int Y = pl.p[0][(size_t) y * pl.stride[0] + x];
+  if (f.kind == UNPACK_PACKED3) {          // unpack_RGB / unpack_BGR (video-format.c:1521, 1558)
+    const uint8_t *q = pl.p[0] + (size_t) y * pl.stride[0] + 3 * (size_t) x;
+    return 0xffu | ((uint32_t) q[f.pos[1]] << 8) | ((uint32_t) q[f.pos[2]] << 16) | ((uint32_t) q[f.pos[3]] << 24);
+  }
+  const int Y = f.kind == UNPACK_PACKED422 ? pl.p[0][(size_t) y * pl.stride[0] + 4 * (size_t) (x >> 1) + f.pos[1] + 2 * (x & 1)]
+      : pl.p[0][(size_t) y * pl.stride[0] + x];
   UV c;
   if (f.chroma_v2) {
     const int e0 = vpair[2 * y], rb = vpair[2 * y + 1];
@@ -200,7 +210,7 @@ struct SrcFront {
   // stage pixels [x_lo, x_hi) of line y into lds[0 ..): 8-pixel groups with word loads where possible
   GSTAMD_HD void stage (uint32_t *lds, int x_lo, int x_hi, int y, int tid, int nthreads) const
   {
-    if (vec_ok && f.w_sub == 1 && f.kind != UNPACK_PACKED4) {
+    if (vec_ok && f.w_sub == 1 && kind_has_planes (f.kind)) {
       const int xa = x_lo & ~7;
       const int groups = (x_hi - xa + 7) >> 3;
       for (int g = tid; g < groups; g += nthreads) {
@@ -388,7 +398,7 @@ GSTAMD_HD void convert_body (const FrontParams &f, const Planes &pl, const int *
   const int x0 = span * K1_PX, w = f.width;
   const int pos[4] = {pack0, pack1, pack2, pack3};
   uint8_t *drow = dst + (size_t) y * dstride;
-  if (vec_ok && f.w_sub == 1 && x0 + K1_PX <= w) {
+  if (vec_ok && f.w_sub == 1 && kind_has_planes (f.kind) && x0 + K1_PX <= w) {
     uint32_t px[8], out[8];
     front_span8<CH> (f, pl, vpair, x0, y, px);
 #pragma unroll

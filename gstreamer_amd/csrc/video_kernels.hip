@@ -210,7 +210,7 @@ __global__ __launch_bounds__ (256) void k_plane_vscale (SrcPlane s, ScaleDev sd,
 }
 
 // borders (convert_fill_border, video-converter.c:7190): every pixel of a destination plane outside the picture rectangle
-// gets the plane's border value; es = bytes per pixel of the plane (1, 2 or 4)
+// gets the plane's border value; es = bytes per pixel of the plane (1, 2, 3 or 4)
 __global__ __launch_bounds__ (256) void k_fill_border (uint8_t *__restrict__ p, int stride, int es, uint32_t value, int maxw, int maxh,
     int x0, int y0, int w, int h)
 {
@@ -222,7 +222,11 @@ __global__ __launch_bounds__ (256) void k_fill_border (uint8_t *__restrict__ p, 
     *(uint32_t *) q = value;
   else if (es == 2)
     *(uint16_t *) q = (uint16_t) value;
-  else
+  else if (es == 3) {                      /* memset_u24 */
+    q[0] = (uint8_t) value;
+    q[1] = (uint8_t) (value >> 8);
+    q[2] = (uint8_t) (value >> 16);
+  } else
     *q = (uint8_t) value;
 }
 
@@ -240,7 +244,7 @@ hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vp
     const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream)
 {
   const int spans = (f.width + K1_PX - 1) / K1_PX;
-  int vec_ok = aligned (dst, 16) && (dstride % 16) == 0 && f.kind != UNPACK_PACKED4 && f.w_sub == 1;
+  int vec_ok = aligned (dst, 16) && (dstride % 16) == 0 && kind_has_planes (f.kind) && f.w_sub == 1;
   if (vec_ok) {
     vec_ok = aligned (pl.p[0], 8) && (pl.stride[0] % 8) == 0;
     if (f.kind == UNPACK_SEMI)
@@ -438,7 +442,7 @@ hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames
 
 static int front_vec_ok (const FrontParams &f, const Planes &pl)
 {
-  if (f.kind == UNPACK_PACKED4 || f.w_sub != 1)
+  if (!kind_has_planes (f.kind) || f.w_sub != 1)
     return 0;
   int ok = aligned (pl.p[0], 8) && (pl.stride[0] % 8) == 0;
   if (f.kind == UNPACK_SEMI)
@@ -452,13 +456,13 @@ static int front_vec_ok (const FrontParams &f, const Planes &pl)
 // before the scaler
 static int front_packed_ok (const SrcFront &s)
 {
-  return s.vec_ok && s.f.w_sub == 1 && s.f.kind != UNPACK_PACKED4 && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
+  return s.vec_ok && s.f.w_sub == 1 && kind_has_planes (s.f.kind) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
 }
 
 // byte-dot-product N-tap pass: opaque source (alpha 0xff in, 0xff out) and no colour step before the scaler
 static int dot4_source_ok (const SrcFront &s)
 {
-  return s.f.kind != UNPACK_PACKED4 && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
+  return kind_has_planes (s.f.kind) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
 }
 
 static Dst make_dst (uint8_t *p, int stride, bool final, const ColorParams &post, const int pack_pos[4])

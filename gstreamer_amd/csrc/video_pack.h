@@ -1,4 +1,4 @@
-// video_pack.h - last stage for planar / semi-planar destinations: chroma downsample + pack of the final AYUV image.
+// video_pack.h - last stage for every destination that is not a 4-byte packed format (planar, semi-planar, RGB / BGR, packed 4:2:2): chroma downsample + pack of the final AYUV image.
 //
 // Reference: chain_downsample / do_downsample_lines (video-converter.c:2040, 3192) feed line pairs (2r, 2r+1) - a clamped
 // copy of the last line when the height is odd - to gst_video_chroma_resample; video_orc_chroma_down_v2_u8
@@ -27,9 +27,26 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__re
   const int y0 = yb << pk.h_sub;
   if (x0 >= w || y0 >= h)
     return;
+  if (pk.kind == UNPACK_PACKED3) {          // pack_RGB / pack_BGR (video-format.c:1540, 1577): 4 pixels = 12 bytes
+    const uint32_t *row = (const uint32_t *) (src + (size_t) y0 * sstride);
+    uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 3 * (size_t) x0;
+    for (int i = 0; i < 4 && x0 + i < w; i++) {
+      const uint32_t px = row[x0 + i];
+      q[3 * i + pk.pos[1]] = (uint8_t) (px >> 8);
+      q[3 * i + pk.pos[2]] = (uint8_t) (px >> 16);
+      q[3 * i + pk.pos[3]] = (uint8_t) (px >> 24);
+    }
+    return;
+  }
   const int nlines = 1 << pk.h_sub;
+  if (pk.kind == UNPACK_PACKED422) {       // luma into the macropixels (pack_YUY2 & co, video-format.c:201-460)
+    const uint32_t *row = (const uint32_t *) (src + (size_t) y0 * sstride);
+    uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 2 * (size_t) x0;
+    for (int i = 0; i < 4 && x0 + i < w; i++)
+      q[4 * (i >> 1) + pk.pos[1] + 2 * (i & 1)] = (uint8_t) (row[x0 + i] >> 8);
+  }
   // ---- luma of every line of the block
-  for (int r = 0; r < nlines; r++) {
+  for (int r = 0; r < nlines && pk.kind != UNPACK_PACKED422; r++) {
     const int y = y0 + r;
     if (y >= h)
       break;
@@ -70,9 +87,18 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__re
           c = ((cm + 3u * c0 + 0x00020002u) >> 2) & 0x00ff00ffu;
       }
     }
-    const uint8_t cu = (uint8_t) c, cv = (uint8_t) (c >> 16);
+    uint8_t cu = (uint8_t) c, cv = (uint8_t) (c >> 16);
+    if (pk.tail_swap && x == w - 1) {
+      const uint8_t t = cu;
+      cu = cv;
+      cv = t;
+    }
     const int k = x >> pk.w_sub;
-    if (pk.kind == UNPACK_SEMI) {
+    if (pk.kind == UNPACK_PACKED422) {
+      uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 4 * (size_t) k;
+      q[pk.pos[2]] = cu;
+      q[pk.pos[3]] = cv;
+    } else if (pk.kind == UNPACK_SEMI) {
       uint8_t *duv = d.p[1] + (size_t) yb * d.stride[1] + 2 * k;
       duv[0] = pk.u_plane ? cu : cv;
       duv[1] = pk.u_plane ? cv : cu;

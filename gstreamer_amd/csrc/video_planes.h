@@ -1,7 +1,8 @@
 // video_planes.h - convert_scale_planes of the reference (video-converter.c:7757, setup_scale :7958-8200) for planar and
 // semi-planar formats: every destination plane is produced from one source plane on its own - copied, halved / doubled
 // by the video_orc_planar_chroma_* helpers (video-orc.orc:1271-1334) or sent through gst_video_scaler_2d as 1-byte
-// (GRAY8) or 2-byte (the UV plane of NV12 / NV21) pixels.  The scaler arithmetic is the 4 x u8 one of video_device.h
+// (GRAY8), 2-byte (the UV plane of the NV12 family) or 3-byte (RGB / BGR) pixels; a packed 4:2:2 line is scaled
+// vertically as plain bytes.  The scaler arithmetic is the 4 x u8 one of video_device.h
 // applied to the bytes the plane has (hscale_px / vscale_px on words whose upper bytes are zero).
 #pragma once
 #include "video_device.h"
@@ -11,11 +12,16 @@ namespace gstamd {
 struct SrcPlane {
   const uint8_t *p;
   int stride;
-  int n;                // bytes per pixel: 1 or 2
+  int n;                // bytes per pixel: 1, 2 or 3 (RGB / BGR)
   GSTAMD_HD uint32_t at (int x, int y) const
   {
     const uint8_t *q = p + (size_t) y * stride + (size_t) x * n;
-    return n == 1 ? (uint32_t) q[0] : ((uint32_t) q[0] | ((uint32_t) q[1] << 8));
+    uint32_t v = q[0];
+    if (n >= 2)
+      v |= (uint32_t) q[1] << 8;
+    if (n >= 3)
+      v |= (uint32_t) q[2] << 16;
+    return v;
   }
 };
 
@@ -27,8 +33,10 @@ struct DstPlane {
   {
     uint8_t *q = p + (size_t) y * stride + (size_t) x * n;
     q[0] = (uint8_t) px;
-    if (n == 2)
+    if (n >= 2)
       q[1] = (uint8_t) (px >> 8);
+    if (n >= 3)
+      q[2] = (uint8_t) (px >> 16);
   }
 };
 

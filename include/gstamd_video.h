@@ -39,6 +39,8 @@ enum {
   GSTAMD_VIDEO_FORMAT_UNKNOWN = 0,
   GSTAMD_VIDEO_FORMAT_I420 = 2,
   GSTAMD_VIDEO_FORMAT_YV12 = 3,
+  GSTAMD_VIDEO_FORMAT_YUY2 = 4,
+  GSTAMD_VIDEO_FORMAT_UYVY = 5,
   GSTAMD_VIDEO_FORMAT_AYUV = 6,
   GSTAMD_VIDEO_FORMAT_RGBx = 7,
   GSTAMD_VIDEO_FORMAT_BGRx = 8,
@@ -48,10 +50,17 @@ enum {
   GSTAMD_VIDEO_FORMAT_BGRA = 12,
   GSTAMD_VIDEO_FORMAT_ARGB = 13,
   GSTAMD_VIDEO_FORMAT_ABGR = 14,
+  GSTAMD_VIDEO_FORMAT_RGB = 15,
+  GSTAMD_VIDEO_FORMAT_BGR = 16,
   GSTAMD_VIDEO_FORMAT_Y42B = 18,
+  GSTAMD_VIDEO_FORMAT_YVYU = 19,
   GSTAMD_VIDEO_FORMAT_Y444 = 20,
   GSTAMD_VIDEO_FORMAT_NV12 = 23,
-  GSTAMD_VIDEO_FORMAT_NV21 = 24
+  GSTAMD_VIDEO_FORMAT_NV21 = 24,
+  GSTAMD_VIDEO_FORMAT_NV16 = 51,
+  GSTAMD_VIDEO_FORMAT_NV24 = 52,
+  GSTAMD_VIDEO_FORMAT_NV61 = 60,
+  GSTAMD_VIDEO_FORMAT_VYUY = 64
 };
 
 enum { GSTAMD_COLOR_RANGE_UNKNOWN = 0, GSTAMD_COLOR_RANGE_0_255 = 1, GSTAMD_COLOR_RANGE_16_235 = 2 };

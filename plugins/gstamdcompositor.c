@@ -34,7 +34,7 @@ GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
 #define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV }"
 /* what a pad may carry: anything the converter takes; it is brought to the output format / the pad's width x height by a
  * per-pad GstAmdVideoConverter (the reference's GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) */
-#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, RGBx, BGRx, xRGB, xBGR, NV12, NV21, I420, YV12, Y42B, Y444 }"
+#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY }"
 #define AMD_COMP_MAX_PADS 64
 
 static GstStaticPadTemplate comp_sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
@@ -262,6 +262,15 @@ amd_pad_format_of (GstVideoFormat f)
     case GST_VIDEO_FORMAT_YV12: return GSTAMD_VIDEO_FORMAT_YV12;
     case GST_VIDEO_FORMAT_Y42B: return GSTAMD_VIDEO_FORMAT_Y42B;
     case GST_VIDEO_FORMAT_Y444: return GSTAMD_VIDEO_FORMAT_Y444;
+    case GST_VIDEO_FORMAT_NV16: return GSTAMD_VIDEO_FORMAT_NV16;
+    case GST_VIDEO_FORMAT_NV61: return GSTAMD_VIDEO_FORMAT_NV61;
+    case GST_VIDEO_FORMAT_NV24: return GSTAMD_VIDEO_FORMAT_NV24;
+    case GST_VIDEO_FORMAT_YUY2: return GSTAMD_VIDEO_FORMAT_YUY2;
+    case GST_VIDEO_FORMAT_UYVY: return GSTAMD_VIDEO_FORMAT_UYVY;
+    case GST_VIDEO_FORMAT_YVYU: return GSTAMD_VIDEO_FORMAT_YVYU;
+    case GST_VIDEO_FORMAT_VYUY: return GSTAMD_VIDEO_FORMAT_VYUY;
+    case GST_VIDEO_FORMAT_RGB: return GSTAMD_VIDEO_FORMAT_RGB;
+    case GST_VIDEO_FORMAT_BGR: return GSTAMD_VIDEO_FORMAT_BGR;
     default: return amd_format_of (f);
   }
 }

@@ -32,7 +32,7 @@ GST_DEBUG_CATEGORY_STATIC (amd_vcs_debug);
 GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #define GST_CAT_DEFAULT amd_vcs_debug
 
-#define AMD_FORMATS "{ NV12, NV21, I420, YV12, Y42B, Y444, AYUV, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR }"
+#define AMD_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR }"
 #define AMD_OUT_FORMATS AMD_FORMATS
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
@@ -230,7 +230,12 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_BGRA, GSTAMD_VIDEO_FORMAT_BGRA}, {GST_VIDEO_FORMAT_ARGB, GSTAMD_VIDEO_FORMAT_ARGB},
     {GST_VIDEO_FORMAT_ABGR, GSTAMD_VIDEO_FORMAT_ABGR}, {GST_VIDEO_FORMAT_Y42B, GSTAMD_VIDEO_FORMAT_Y42B},
     {GST_VIDEO_FORMAT_Y444, GSTAMD_VIDEO_FORMAT_Y444}, {GST_VIDEO_FORMAT_NV12, GSTAMD_VIDEO_FORMAT_NV12},
-    {GST_VIDEO_FORMAT_NV21, GSTAMD_VIDEO_FORMAT_NV21},
+    {GST_VIDEO_FORMAT_NV21, GSTAMD_VIDEO_FORMAT_NV21}, {GST_VIDEO_FORMAT_NV16, GSTAMD_VIDEO_FORMAT_NV16},
+    {GST_VIDEO_FORMAT_NV61, GSTAMD_VIDEO_FORMAT_NV61}, {GST_VIDEO_FORMAT_NV24, GSTAMD_VIDEO_FORMAT_NV24},
+    {GST_VIDEO_FORMAT_YUY2, GSTAMD_VIDEO_FORMAT_YUY2}, {GST_VIDEO_FORMAT_UYVY, GSTAMD_VIDEO_FORMAT_UYVY},
+    {GST_VIDEO_FORMAT_YVYU, GSTAMD_VIDEO_FORMAT_YVYU}, {GST_VIDEO_FORMAT_VYUY, GSTAMD_VIDEO_FORMAT_VYUY},
+    {GST_VIDEO_FORMAT_RGB, GSTAMD_VIDEO_FORMAT_RGB},
+    {GST_VIDEO_FORMAT_BGR, GSTAMD_VIDEO_FORMAT_BGR},
   };
   int fmt = 0;
   for (i = 0; i < G_N_ELEMENTS (map); i++)

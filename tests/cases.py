@@ -41,6 +41,41 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def visible_planes(fmt, w, h):
+    """[(bytes per visible row, rows)] per plane of a frame (the bytes that belong to the picture, without stride padding)."""
+    up2 = lambda v: (v + 1) // 2
+    if fmt in ("I420", "YV12"):
+        return [(w, h), (up2(w), up2(h)), (up2(w), up2(h))]
+    if fmt == "Y42B":
+        return [(w, h), (up2(w), h), (up2(w), h)]
+    if fmt == "Y444":
+        return [(w, h)] * 3
+    if fmt in ("NV12", "NV21"):
+        return [(w, h), (2 * up2(w), up2(h))]
+    if fmt in ("NV16", "NV61"):
+        return [(w, h), (2 * up2(w), h)]
+    if fmt == "NV24":
+        return [(w, h), (2 * w, h)]
+    if fmt in ("YUY2", "UYVY", "YVYU", "VYUY"):
+        return [(4 * up2(w), h)]         # whole macropixels; visible_bytes blanks the unused luma slot of an odd last pixel
+    if fmt in ("RGB", "BGR"):
+        return [(3 * w, h)]
+    return [(4 * w, h)]
+
+
+def visible_bytes(fmt, w, h, strides, offsets, buf):
+    """Concatenation of the visible bytes of every plane of `buf`."""
+    out = []
+    for i, (rb, rows) in enumerate(visible_planes(fmt, w, h)):
+        st, off = int(strides[i]), int(offsets[i])
+        plane = np.asarray(buf[off:off + st * rows]).reshape(rows, st)[:, :rb]
+        if fmt in ("YUY2", "UYVY", "YVYU", "VYUY") and w % 2:
+            plane = plane.copy()
+            plane[:, 2 * (w - 1) + (2 if fmt in ("YUY2", "YVYU") else 3)] = 0      # second luma slot of the last macropixel
+        out.append(plane.reshape(-1))
+    return np.concatenate(out)
+
+
 LIN = dict(resampler_method="linear", max_taps=2)          # what the videoconvertscale element sets by default
 LAN = dict(resampler_method="lanczos")
 NEAR = dict(resampler_method="nearest")
@@ -172,13 +207,115 @@ VIDEO_CASES = [
     ("bgra_rgba_half_lanczos", "BGRA", 200, 100, "RGBA", 100, 50, LAN, None, None, "random"),
     ("bgra_ayuv_mixed_lanczos", "BGRA", 200, 100, "AYUV", 300, 50, LAN, None, None, "random"),
     ("y444_bgra_nonint_lanczos", "Y444", 320, 180, "BGRA", 333, 177, LAN, None, None, "random"),
+    # ---- 3-byte RGB / BGR (video-format.c:1519-1593): generic chain, convert_I420_pack_ARGB, convert_scale_planes on 3 x u8 pixels
+    ("nv12_rgb_322x241", "NV12", 322, 241, "RGB", 322, 241, {}, None, None, "random"),
+    ("nv12_bgr_640x360_pair", "NV12", 640, 360, "BGR", 640, 360, {}, None, None, "random"),
+    ("nv12_rgb_down_bilinear", "NV12", 640, 360, "RGB", 224, 224, LIN, None, None, "random"),
+    ("i420_rgb_33x17_fastpath", "I420", 33, 17, "RGB", 33, 17, {}, None, None, "random"),
+    ("yv12_bgr_320x240_fastpath", "YV12", 320, 240, "BGR", 320, 240, {}, None, None, "random"),
+    ("rgb_nv12_161x91", "RGB", 161, 91, "NV12", 161, 91, {}, None, None, "random"),
+    ("bgr_i420_up_lanczos", "BGR", 160, 90, "I420", 333, 200, LAN, None, None, "random"),
+    ("rgb_bgra_64x48", "RGB", 64, 48, "BGRA", 64, 48, {}, None, None, "random"),
+    ("bgra_bgr_130x70_alpha_dropped", "BGRA", 130, 70, "BGR", 130, 70, {}, None, None, "random"),
+    ("rgb_rgb_copy_33x17_planes", "RGB", 33, 17, "RGB", 33, 17, {}, None, None, "random"),
+    ("rgb_rgb_down_bilinear_planes", "RGB", 320, 180, "RGB", 200, 100, LIN, None, None, "random"),
+    ("bgr_bgr_up_lanczos_planes", "BGR", 100, 60, "BGR", 333, 177, LAN, None, None, "random"),
+    ("rgb_bgr_64x48", "RGB", 64, 48, "BGR", 64, 48, {}, None, None, "random"),
+    ("nv12_rgb_letterbox_bilinear", "NV12", 640, 360, "RGB", 400, 400, dict(LIN, dest_x=0, dest_y=88, dest_width=400, dest_height=225, border_argb=0xff203040), None, None, "random"),
+    ("rgb_rgb_crop_planes", "RGB", 320, 180, "RGB", 160, 90, dict(src_x=33, src_y=20, src_width=160, src_height=90), None, None, "random"),
+    # ---- packed 4:2:2 (YUY2 / UYVY / YVYU / VYUY, video-format.c:153-460): generic chain and the reference's fastpaths
+    ("yuy2_bgra_640x360", "YUY2", 640, 360, "BGRA", 640, 360, {}, None, None, "random"),
+    ("uyvy_rgba_33x17", "UYVY", 33, 17, "RGBA", 33, 17, {}, None, None, "random"),
+    ("yvyu_argb_130x70_mpeg2", "YVYU", 130, 70, "ARGB", 130, 70, {}, None, "mpeg2", "random"),
+    ("vyuy_bgra_33x17_odd_tail_quirk", "VYUY", 33, 17, "BGRA", 33, 17, {}, None, None, "random"),
+    ("yuy2_bgra_720p_to_360p_bilinear", "YUY2", 1280, 720, "BGRA", 640, 360, LIN, None, None, "random"),
+    ("uyvy_nv12_322x241", "UYVY", 322, 241, "NV12", 322, 241, {}, None, None, "random"),
+    ("yuy2_nv12_640x600_cosited", "YUY2", 640, 600, "NV12", 640, 600, {}, None, None, "random"),
+    ("bgra_yuy2_161x91", "BGRA", 161, 91, "YUY2", 161, 91, {}, None, None, "random"),
+    ("bgra_uyvy_up_lanczos", "BGRA", 100, 60, "UYVY", 333, 177, LAN, None, None, "random"),
+    ("bgra_vyuy_33x17_odd_tail_quirk", "BGRA", 33, 17, "VYUY", 33, 17, {}, None, None, "random"),
+    ("nv12_yuy2_640x360", "NV12", 640, 360, "YUY2", 640, 360, {}, None, None, "random"),
+    ("vyuy_vyuy_33x17_generic", "VYUY", 33, 17, "VYUY", 33, 17, {}, None, None, "random"),
+    ("i420_yuy2_322x240_fastpath", "I420", 322, 240, "YUY2", 322, 240, {}, None, None, "random"),
+    ("yv12_uyvy_64x49_fastpath_odd_h", "YV12", 64, 49, "UYVY", 64, 49, {}, None, None, "random"),
+    ("yuy2_i420_322x241_fastpath", "YUY2", 322, 241, "I420", 322, 241, {}, None, None, "random"),
+    ("uyvy_yv12_33x17_fastpath", "UYVY", 33, 17, "YV12", 33, 17, {}, None, None, "random"),
+    ("yuy2_y42b_130x70_fastpath", "YUY2", 130, 70, "Y42B", 130, 70, {}, None, None, "random"),
+    ("uyvy_y444_33x18_fastpath", "UYVY", 33, 18, "Y444", 33, 18, {}, None, None, "random"),
+    ("y42b_uyvy_130x70_fastpath", "Y42B", 130, 70, "UYVY", 130, 70, {}, None, None, "random"),
+    ("y444_yuy2_64x48_fastpath", "Y444", 64, 48, "YUY2", 64, 48, {}, None, None, "random"),
+    ("y444_yuy2_33x17_generic_odd_w", "Y444", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
+    ("yuy2_ayuv_64x48_fastpath_alpha", "YUY2", 64, 48, "AYUV", 64, 48, dict(alpha_mode="set", alpha_value=0.25), None, None, "random"),
+    ("ayuv_uyvy_64x48_fastpath", "AYUV", 64, 48, "UYVY", 64, 48, {}, None, None, "random"),
+    ("yuy2_uyvy_322x241_fastpath", "YUY2", 322, 241, "UYVY", 322, 241, {}, None, None, "random"),
+    ("uyvy_yuy2_33x17_fastpath", "UYVY", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
+    ("yuy2_yuy2_copy_33x17_planes", "YUY2", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
+    ("uyvy_uyvy_vonly_bilinear_planes", "UYVY", 322, 240, "UYVY", 322, 100, LIN, None, None, "random"),
+    ("yvyu_yvyu_vonly_lanczos_planes", "YVYU", 64, 48, "YVYU", 64, 111, LAN, None, None, "random"),
+    ("yuy2_y42b_crop_generic", "YUY2", 64, 48, "Y42B", 32, 24, dict(src_x=16, src_y=8, src_width=32, src_height=24), None, None, "random"),
+    ("y42b_ayuv_33x17_generic_odd_w", "Y42B", 33, 17, "AYUV", 33, 17, {}, None, None, "random"),
+    # ---- NV16 / NV61 / NV24: generic chain and convert_scale_planes inside the NV12 family
+    ("nv16_bgra_322x241", "NV16", 322, 241, "BGRA", 322, 241, {}, None, None, "random"),
+    ("nv61_rgba_33x17", "NV61", 33, 17, "RGBA", 33, 17, {}, None, None, "random"),
+    ("nv24_bgra_130x70", "NV24", 130, 70, "BGRA", 130, 70, {}, None, None, "random"),
+    ("bgra_nv16_161x91", "BGRA", 161, 91, "NV16", 161, 91, {}, None, None, "random"),
+    ("bgra_nv61_33x17_odd_tail_quirk", "BGRA", 33, 17, "NV61", 33, 17, {}, None, None, "random"),
+    ("bgra_nv24_64x48", "BGRA", 64, 48, "NV24", 64, 48, {}, None, None, "random"),
+    ("nv12_nv16_322x241_planes", "NV12", 322, 241, "NV16", 322, 241, {}, None, None, "random"),
+    ("nv16_nv12_planes_bilinear", "NV16", 320, 240, "NV12", 320, 240, LIN, None, None, "random"),
+    ("nv24_nv12_down_bilinear_planes", "NV24", 320, 240, "NV12", 160, 120, LIN, None, None, "random"),
+    ("nv16_nv24_up_lanczos_planes", "NV16", 160, 90, "NV24", 333, 200, LAN, None, None, "random"),
+    ("nv61_nv61_down_bilinear_planes", "NV61", 320, 240, "NV61", 200, 100, LIN, None, None, "random"),
+    ("nv16_i420_64x48", "NV16", 64, 48, "I420", 64, 48, {}, None, None, "random"),
+    ("nv12_i420_border_full_frame_resample_rule", "NV12", 64, 48, "I420", 80, 60, dict(dest_x=8, dest_y=4, dest_width=64, dest_height=48, border_argb=0xff336699), None, None, "random"),
 ]
+
+# Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd
+# width they copy one byte of source row padding into the destination row padding (video-converter.c:3409-3560, 3954-4030, ..);
+# this library writes picture bytes only.
+VISIBLE_ONLY = {"uyvy_yv12_33x17_fastpath", "uyvy_y444_33x18_fastpath", "uyvy_yuy2_33x17_fastpath"}
 
 # conversions the reference runs through code this library has no kernel for -> must be REFUSED
 VIDEO_REFUSED = [
     ("NV12", 320, 180, "BGRA", 640, 100, LAN),           # reference temp-line aliasing (see planner.cpp)
     ("NV12", 64, 64, "BGRA", 64, 64, dict(dither_quantization=4)),      # dither stage (video-dither.c) not built
 ]
+
+
+def default_layout(fmt, w, h):
+    """(strides, offsets) of gst_video_info_set_format for the formats of this library (video-info.c:863-1100)."""
+    r4 = lambda v: (v + 3) // 4 * 4
+    r2 = lambda v: (v + 1) // 2 * 2
+    if fmt in ("I420", "YV12"):
+        s0, s1 = r4(w), r4(r2(w) // 2)
+        o1 = s0 * r2(h)
+        return [s0, s1, s1], [0, o1, o1 + s1 * (r2(h) // 2)]
+    if fmt == "Y42B":
+        s0, s1 = r4(w), (w + 7) // 8 * 8 // 2
+        return [s0, s1, s1], [0, s0 * h, s0 * h + s1 * h]
+    if fmt == "Y444":
+        return [r4(w)] * 3, [0, r4(w) * h, 2 * r4(w) * h]
+    if fmt in ("NV12", "NV21"):
+        return [r4(w), r4(w)], [0, r4(w) * r2(h)]
+    if fmt in ("NV16", "NV61"):
+        return [r4(w), r4(w)], [0, r4(w) * h]
+    if fmt == "NV24":
+        return [r4(w), r4(2 * w)], [0, r4(w) * h]
+    if fmt in ("YUY2", "UYVY", "YVYU", "VYUY"):
+        return [r4(2 * w)], [0]
+    if fmt in ("RGB", "BGR"):
+        return [r4(3 * w)], [0]
+    return [4 * w], [0]
+
+
+def video_digest(name, dst):
+    """sha256 a video case is compared on: the whole destination buffer, or its picture bytes for VISIBLE_ONLY cases."""
+    if name not in VISIBLE_ONLY:
+        return sha(dst)
+    case = next(c for c in VIDEO_CASES if c[0] == name)
+    ofmt, ow, oh = case[4], case[5], case[6]
+    strides, offsets = default_layout(ofmt, ow, oh)
+    return sha(visible_bytes(ofmt, ow, oh, strides, offsets, dst))
 
 
 def case_seed(name):

@@ -46,7 +46,7 @@ static FastParams emu_fast_params (const VideoPlan &p)      /* make_fast_params 
 
 static int emu_packed_ok (const SrcFront &s)           /* front_packed_ok of video_kernels.hip */
 {
-  return s.vec_ok && s.f.w_sub == 1 && s.f.kind != UNPACK_PACKED4 && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
+  return s.vec_ok && s.f.w_sub == 1 && kind_has_planes (s.f.kind) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
 }
 static int emu_packed_ok (const SrcImage &) { return 1; }
 
@@ -98,7 +98,7 @@ static void run_hscale_dot4 (const SrcFront &src, const ScaleDev &sd, const Dst 
 
 static bool emu_dot4_ok (const SrcFront &s, const ScaleDev &sd)
 {
-  return sd.tapw && s.f.kind != UNPACK_PACKED4 && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
+  return sd.tapw && kind_has_planes (s.f.kind) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
 }
 static bool emu_dot4_ok (const SrcImage &, const ScaleDev &) { return false; }
 static void run_hscale_dot4 (const SrcImage &, const ScaleDev &, const Dst &, const PostFast &, int, int, TileGeom) {}
@@ -169,14 +169,17 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     const FormatDesc *f = p.fout;
     auto up = [](int v, int sub) { return -((-v) >> sub); };
     for (int i = 0; i < out->n_planes; i++) {
-      const bool chroma = f->kind != UNPACK_PACKED4 && i > 0;
-      const int es = f->kind == UNPACK_PACKED4 ? 4 : (chroma && f->kind == UNPACK_SEMI ? 2 : 1);
+      const bool chroma = kind_has_planes (f->kind) && i > 0;
+      const int es = f->kind == UNPACK_PACKED4 ? 4 : f->kind == UNPACK_PACKED3 ? 3 : (chroma && f->kind == UNPACK_SEMI ? 2 : 1);
       const int ws = chroma ? f->w_sub : 0, hs = chroma ? f->h_sub : 0;
       const int mw = up (p.rect.out_maxw, ws), mh = up (p.rect.out_maxh, hs), x0 = p.rect.out_x >> ws, y0 = p.rect.out_y >> hs;
       const int w = up (p.out_info.width, ws), h = up (p.out_info.height, hs);
       uint8_t v[4] = {0, 0, 0, 0};
       if (f->kind == UNPACK_PACKED4) {
         for (int c = 0; c < 4; c++)
+          v[f->pos[c]] = p.rect.border[c];
+      } else if (f->kind == UNPACK_PACKED3) {
+        for (int c = 1; c < 4; c++)
           v[f->pos[c]] = p.rect.border[c];
       } else if (!chroma) {
         v[0] = p.rect.border[1];

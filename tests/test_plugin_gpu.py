@@ -228,3 +228,29 @@ def test_audioresample_element_interpolated_filter(gst_env, ref):
     exp.append(rr.resample(None, in_frames=lat, out_frames=rr.get_out_frames(lat)))
     exp = np.concatenate(exp)
     assert out.shape == exp.shape and (out == exp).all()
+
+
+def test_videoconvertscale_element_packed422_and_rgb24(gst_env, ref):
+    """Capture-style formats: YUY2 720p -> RGB 24-bit 360p (bilinear, the element default) and UYVY -> NV12 same size."""
+    env, tmp = gst_env
+    w, h, n = 1280, 720, 3
+    fin, frgb = tmp / "in.yuy2", tmp / "out.rgb"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=YUY2,width=%d,height=%d,colorimetry=bt709,chroma-site=mpeg2 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw,format=RGB,width=640,height=360 "
+                "! filesink location=%s" % (n, w, h, fin, frgb))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    out = np.fromfile(frgb, np.uint8).reshape(n, -1)
+    rc = ref.VideoConverter("YUY2", w, h, "RGB", 640, 360, in_colorimetry="bt709", in_chroma_site="mpeg2",
+                            config=cases.ref_config_string(ref, cases.LIN))
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), i
+    fin2, fnv = tmp / "in.uyvy", tmp / "out.nv12"
+    launch(env, "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=UYVY,width=640,height=360,colorimetry=bt601,chroma-site=jpeg "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale "
+                "! video/x-raw,format=NV12,colorimetry=bt601,chroma-site=jpeg ! filesink location=%s" % (n, fin2, fnv))
+    src = np.fromfile(fin2, np.uint8).reshape(n, -1)
+    out = np.fromfile(fnv, np.uint8).reshape(n, -1)
+    rc = ref.VideoConverter("UYVY", 640, 360, "NV12", 640, 360, in_colorimetry="bt601", in_chroma_site="jpeg", out_colorimetry="bt601",
+                            out_chroma_site="jpeg")
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), i

@@ -35,7 +35,7 @@ def test_hip_matches_reference_golden(native_lib, gpu, idx_case):
     ii = V.video_info(ifmt, w, h)
     src = cases.frame_bytes(int(ii.size), pattern, cases.case_seed(name), w)
     out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
-    assert cases.sha(out) == GOLDEN[name]["sha256"], (name, list(out[:16]), GOLDEN[name]["head"][:16])
+    assert cases.video_digest(name, out) == GOLDEN[name]["sha256"], (name, list(out[:16]), GOLDEN[name]["head"][:16])
 
 
 @pytest.mark.parametrize("size", [(3840, 2160), (1920, 1080), (1918, 1078), (4095, 31)])

@@ -118,7 +118,7 @@ def test_kernel_bodies_on_host_match_golden(native_lib, emu_lib, idx_case):
     src = cases.frame_bytes(ii.size, pattern, cases.case_seed(name), w)
     assert cases.sha(src) == GOLDEN[name]["in_sha256"]
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
-    assert cases.sha(dst) == GOLDEN[name]["sha256"], (name, list(dst[:16]), GOLDEN[name]["head"][:16])
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], (name, list(dst[:16]), GOLDEN[name]["head"][:16])
 
 
 WIDE = [c for c in SMALL if c[1][1] in ("NV12", "NV21") and c[1][2] >= 512 and (c[1][2], c[1][3]) == (c[1][5], c[1][6])
@@ -133,7 +133,7 @@ def test_fast_kernel_bodies_any_pairs_per_wave(native_lib, emu_lib, idx_case, k)
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src, vec=k)
-    assert cases.sha(dst) == GOLDEN[name]["sha256"], name
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
 
 
 BIL = [c for c in SMALL if c[1][1] in ("NV12", "NV21") and c[1][7] == cases.LIN and c[1][0] != "nv12_bgra_up2_bilinear"]
@@ -147,7 +147,7 @@ def test_bilinear_kernel_bodies_agree(native_lib, emu_lib, idx_case, variant):
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src, vec=variant)
-    assert cases.sha(dst) == GOLDEN[name]["sha256"], name
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
 
 
 @pytest.mark.parametrize("idx_case", SMALL[::4], ids=lambda c: c[1][0])
@@ -157,7 +157,7 @@ def test_golden_vectors_are_the_references_output(ref, idx_case):
     src = cases.frame_bytes(ref.video_info(ifmt, w, h)["size"], pattern, cases.case_seed(name), w)
     rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site,
                             config=cases.ref_config_string(ref, cfg))
-    assert cases.sha(rc.frame(src)) == GOLDEN[name]["sha256"]
+    assert cases.video_digest(name, rc.frame(src)) == GOLDEN[name]["sha256"]
 
 
 def test_reference_output_depends_on_thread_slicing_for_420(ref):

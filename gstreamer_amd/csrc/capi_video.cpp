@@ -15,6 +15,7 @@
 #include "planner.h"
 #include "video_kernels.h"
 #include "video_fast.h"
+#include "video_encode_fast.h"
 
 using namespace gstamd;
 
@@ -52,13 +53,13 @@ struct GstAmdVideoConverter {
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
 };
 
-static bool fast_pair_usable (const VideoPlan &p, const Planes &pl, const uint8_t *dst, int dstride)
+static bool fast_pair_usable (const VideoPlan &p, const Planes &pl, const uint8_t *dst, int dstride, int dalign = 16)
 {
-  return p.passes.empty () && p.fast_pair && ((uintptr_t) dst % 16) == 0 && (dstride % 16) == 0 &&
+  return p.passes.empty () && p.fast_pair && ((uintptr_t) dst % dalign) == 0 && (dstride % dalign) == 0 &&
       ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0 && ((uintptr_t) pl.p[1] % 4) == 0 && (pl.stride[1] % 4) == 0;
 }
 
-static FastParams make_fast_params (const VideoPlan &p)
+static FastParams make_fast_params (const VideoPlan &p, bool rgb24 = false)
 {
   FastParams fp;
   fp.width = p.front.width;
@@ -67,6 +68,8 @@ static FastParams make_fast_params (const VideoPlan &p)
   /* with a source crop the chroma upsampler still sees the frame's rows above / below the crop (do_unpack_lines :2966) */
   fp.crow_lo = -(p.rect.in_y >> 1);
   fp.crow_hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
+  if (rgb24)
+    fast_params_rgb24 (fp, p.matrix.p, p.fout->pos, p.front.u_plane);
   return fp;
 }
 
@@ -313,6 +316,18 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
       if (!planes[i])
         return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
     }
+    if (p.fout->kind == UNPACK_PACKED3 && fast_pair_usable (p, pl, planes[0], strides[0], 4)) {
+      /* NV12 / NV21 -> RGB / BGR, same size: the line-pair kernel stores the 3-byte pixels itself (12 bytes per lane and line) */
+      const FastParams fp = make_fast_params (p, true);
+      const uint8_t *y = pl.p[0], *uv = pl.p[1];
+      hipError_t e = launch_convert_pair (fp, p.front.chroma_h, 1, &y, &uv, &planes[0], pl.stride[0], pl.stride[1], strides[0], stream);
+      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair(rgb24)");
+    }
+    if (p.fast_enc420 && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && ((uintptr_t) planes[0] % 4) == 0 && (strides[0] % 4) == 0 &&
+        ((uintptr_t) planes[1] % 4) == 0 && (strides[1] % 4) == 0 && (p.fout->kind == UNPACK_SEMI || (((uintptr_t) planes[2] % 4) == 0 && (strides[2] % 4) == 0))) {
+      hipError_t e = launch_encode420 (make_enc420_params (p), p.fout->kind == UNPACK_SEMI, pl.p[0], pl.stride[0], planes, strides, stream);
+      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_encode420");
+    }
     r = convert_to_packed (c, pl, c->pk_img, p.out_info.width * 4, stream);
     if (r != GSTAMD_OK)
       return r;
@@ -458,13 +473,14 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     pl.stride[0] = p.in_info.stride[0];
     pl.stride[1] = p.in_info.stride[1];
     d[i] = (uint8_t *) dest[i] + p.out_info.offset[0];
-    all_fast = fast_pair_usable (p, pl, d[i], p.out_info.stride[0]) && p.rect.in_x == 0 && p.rect.in_y == 0 && p.rect.out_x == 0 &&
+    all_fast = (p.fout->kind == UNPACK_PACKED4 || p.fout->kind == UNPACK_PACKED3) &&
+        fast_pair_usable (p, pl, d[i], p.out_info.stride[0], p.fout->kind == UNPACK_PACKED3 ? 4 : 16) && p.rect.in_x == 0 && p.rect.in_y == 0 && p.rect.out_x == 0 &&
         p.rect.out_y == 0 && !p.rect.fill;
     y[i] = pl.p[0];
     uv[i] = pl.p[1];
   }
   if (all_fast) {
-    const FastParams fp = make_fast_params (p);
+    const FastParams fp = make_fast_params (p, p.fout->kind == UNPACK_PACKED3);
     hipError_t e = launch_convert_pair (fp, p.front.chroma_h, n_frames, y.data (), uv.data (), d.data (), p.in_info.stride[0],
         p.in_info.stride[1], p.out_info.stride[0], (hipStream_t) stream_);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair(batch)");

@@ -1269,6 +1269,17 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     matrix_no_wrap = fits && worst < 32000;
   }
   plan->fast_pair = plan->passes.empty () && fr.kind == UNPACK_SEMI && fr.chroma_v2 && (in_w % 4) == 0 && in_h >= 2 && matrix_no_wrap;
+  /* the encoder-facing block kernel (video_encode_fast.h): unscaled 4-byte RGB -> 4:2:0 planar / semi-planar through the table
+   * matrix (which the reference only picks when no pixel can clip, so every row sum stays inside 16 bits) with byte coefficients */
+  plan->fast_enc420 = false;
+  if (plan->passes.empty () && plan->out_planar && kind_has_planes (plan->fout->kind) && plan->fout->w_sub == 1 && plan->fout->h_sub == 1 &&
+      fr.kind == UNPACK_PACKED4 && !plan->fin->yuv && plan->matrix.kind == MATRIX_TABLE && (in_w % 4) == 0) {
+    bool fits = true;
+    for (int k = 0; k < 3; k++)
+      for (int j = 0; j < 3; j++)
+        fits = fits && abs (plan->matrix.im[k][j]) <= 255;
+    plan->fast_enc420 = fits;
+  }
   /* scaled plans: the same matrix code after the scaler, if the alpha channel provably arrives as 0xff: opaque source
    * and every N-tap phase summing to exactly 1.0 (the 2-tap and nearest kernels keep a constant channel as it is) */
   plan->fast_post = !plan->passes.empty () && !plan->matrix_before_scale && matrix_no_wrap && kind_has_planes (fr.kind);
@@ -1283,7 +1294,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         plan->fast_post = false;
     }
   }
-  std::string d = plan->passes.empty () ? (plan->fast_pair ? "fused_convert_pair" : "fused_convert") : "scale";
+  std::string d = plan->passes.empty () ? (plan->fast_pair ? "fused_convert_pair" : plan->fast_enc420 ? "fused_encode_420" : "fused_convert") : "scale";
   d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;
   d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : "";
   d += fr.chroma_v2 ? ",v2" : "";

@@ -30,6 +30,7 @@ struct FastParams {
   int pc[5];            // raw p1..p5 (word form, fast_emit4_l)
   int crow_lo, crow_hi; // chroma rows that exist, relative to the plane pointer (0 .. rows - 1; a source crop widens it)
   int pack_pos[4];      // destination byte of A, R, G, B
+  int px_bytes;         // 4; 3: RGB / BGR destination - the pixel is formed as RGBx / BGRx and its three colour bytes are stored
 };
 
 inline void fast_params_finish (FastParams &fp, const int p[5], const int pack_pos[4], int u_first)
@@ -44,6 +45,18 @@ inline void fast_params_finish (FastParams &fp, const int p[5], const int pack_p
   fp.u_first = u_first;
   for (int i = 0; i < 4; i++)
     fp.pack_pos[i] = pack_pos[i];
+  fp.px_bytes = 4;
+}
+
+// RGB / BGR destination: the kernel forms RGBx / BGRx pixels (alpha in byte 3) and stores their three colour bytes
+inline void fast_params_rgb24 (FastParams &fp, const int p[5], const int pos[4], int u_first)
+{
+  const int pos4[4] = {3, pos[1], pos[2], pos[3]};
+  const int lo = fp.crow_lo, hi = fp.crow_hi;
+  fast_params_finish (fp, p, pos4, u_first);
+  fp.crow_lo = lo;
+  fp.crow_hi = hi;
+  fp.px_bytes = 3;
 }
 
 #ifdef __HIPCC__
@@ -108,6 +121,22 @@ GSTAMD_HD void store16_stream (uint8_t *p, uint32_t a, uint32_t b, uint32_t c, u
   __builtin_nontemporal_store (v, (u32x4 *) p);
 #else
   *(uint4 *) p = gstamd_make_uint4 (a, b, c, d);
+#endif
+}
+
+// four 3-byte pixels (colour bytes 0..2 of a..d) as one streaming 12-byte store (pack_RGB / pack_BGR, video-format.c:1540, 1577)
+GSTAMD_HD void store12_stream (uint8_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+  const uint32_t w0 = bperm (b, a, 0x04020100u), w1 = bperm (c, b, 0x05040201u), w2 = bperm (d, c, 0x06050402u);
+#ifdef __HIPCC__
+  typedef unsigned int u32x3 __attribute__ ((ext_vector_type (3)));
+  u32x3 v = {w0, w1, w2};
+  __builtin_nontemporal_store (v, (u32x3 *) p);
+#else
+  uint32_t *q = (uint32_t *) p;
+  q[0] = w0;
+  q[1] = w1;
+  q[2] = w2;
 #endif
 }
 
@@ -328,8 +357,12 @@ GSTAMD_HD void fast_emit4_l (const FastParams &fp, uint8_t *__restrict__ d, bool
     for (int j = 0; j < 4; j++)
       sat_pk_u8_hi (o[j], q[j][1]);
   }
-  if (store)
-    store16_stream (d, o[0], o[1], o[2], o[3]);
+  if (store) {
+    if (fp.px_bytes == 3)                   // wave-uniform
+      store12_stream (d, o[0], o[1], o[2], o[3]);
+    else
+      store16_stream (d, o[0], o[1], o[2], o[3]);
+  }
 }
 
 // Horizontal chroma filter of 4 pixels without edge cases.  raw = the 2 samples {c0 c1 c0 c1} under the span, nxt = the
@@ -412,7 +445,7 @@ GSTAMD_HD void fast_strip (const FastParams &fp, const Planes &pl, uint8_t *__re
   const int w = fp.width, h = fp.height, cw = (w + 1) >> 1;
   const uint8_t *yb = pl.p[0] + x0, *cbase = pl.p[1];
   const int ys = pl.stride[0], cs = pl.stride[1];
-  uint8_t *db = dst + 4 * (size_t) x0;
+  uint8_t *db = dst + (size_t) fp.px_bytes * (size_t) x0;
   uint32_t q[4][2];
   layout_init<L> (q);
 

@@ -35,6 +35,9 @@ hipError_t launch_plane_pass (bool horizontal, const ScaleDev &sd, const uint8_t
     int ow, int oh, hipStream_t stream);
 hipError_t launch_fill_border (uint8_t *p, int stride, int es, uint32_t value, int maxw, int maxh, int x0, int y0, int w, int h,
     hipStream_t stream);
+struct Enc420Params;
+hipError_t launch_encode420 (const Enc420Params &ep, bool semi, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],
+    hipStream_t stream);
 hipError_t launch_pack_planar (const PackPlanarParams &pk, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],
     hipStream_t stream);
 

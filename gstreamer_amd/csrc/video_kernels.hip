@@ -16,6 +16,7 @@
 #include "video_scale_fast.h"
 #include "video_pack.h"
 #include "video_bilinear_fast.h"
+#include "video_encode_fast.h"
 #include "video_planes.h"
 
 namespace gstamd {
@@ -235,6 +236,13 @@ __global__ __launch_bounds__ (256) void k_pack_planar (PackPlanarParams pk, cons
   pack_planar_body (pk, src, sstride, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
 }
 
+// 4-byte RGB -> 4:2:0 (video_encode_fast.h): one lane = a 4 x 2 pixel block, one wave per workgroup
+template <int SEMI>
+__global__ __launch_bounds__ (64) void k_encode420 (Enc420Params ep, const uint8_t *__restrict__ src, int sstride, DstPlanes d)
+{
+  enc420_block<SEMI> (ep, src, sstride, d, (int) (blockIdx.x * 64 + threadIdx.x) * 4, (int) blockIdx.y);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
@@ -402,7 +410,7 @@ static bool launch_fast (const FastParams &fp, const FrameBatch &batch, int n, h
   if (v.set && v.abl && CH == CHROMA_H_H2_CS)
     return shape == 1 ? launch_wide_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, K, stream) :
         launch_strip_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, K, v.order != 0, stream);
-  if (shape == 1 && fp.width >= GSTAMD_WIDE_PX / 2)
+  if (shape == 1 && fp.width >= GSTAMD_WIDE_PX / 2 && fp.px_bytes == 4)
     return launch_wide_variant<CH, 0> (fp, batch, n, K, stream);
   return launch_strip_variant<CH, 0> (fp, batch, n, K, v.set && v.order != 0, stream);
 }
@@ -606,6 +614,22 @@ hipError_t launch_fill_border (uint8_t *p, int stride, int es, uint32_t value, i
     hipStream_t stream)
 {
   hipLaunchKernelGGL (k_fill_border, dim3 ((maxw + 255) / 256, maxh), dim3 (256), 0, stream, p, stride, es, value, maxw, maxh, x0, y0, w, h);
+  return hipGetLastError ();
+}
+
+hipError_t launch_encode420 (const Enc420Params &ep, bool semi, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],
+    hipStream_t stream)
+{
+  DstPlanes d;
+  for (int i = 0; i < 3; i++) {
+    d.p[i] = planes[i];
+    d.stride[i] = strides[i];
+  }
+  const dim3 grid ((ep.width / 4 + 63) / 64, (ep.height + 1) / 2);
+  if (semi)
+    hipLaunchKernelGGL (k_encode420<1>, grid, dim3 (64), 0, stream, ep, src, sstride, d);
+  else
+    hipLaunchKernelGGL (k_encode420<0>, grid, dim3 (64), 0, stream, ep, src, sstride, d);
   return hipGetLastError ();
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One of the secondary configs (see scripts/bench_configs.py):  bench_one.py c1|c3|c5|8k|c4|audio [iters]"""
+"""One of the secondary configs (see scripts/bench_configs.py):  bench_one.py c1|c3|c5|8k|rgb24|rgb24s|yuy2|nv12enc|c4|audio [iters]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,6 +15,14 @@ elif which == "c5":
     B.video_case("C5 (per GPU): 7680x4320 NV12 -> 3840x2160 BGRA, bilinear", "NV12", 7680, 4320, "BGRA", 3840, 2160, cases.LIN, it)
 elif which == "8k":
     B.video_case("8K same-size: 7680x4320 NV12 -> BGRA", "NV12", 7680, 4320, "BGRA", 7680, 4320, {}, it)
+elif which == "rgb24":
+    B.video_case("4K NV12 -> RGB (24-bit), same size", "NV12", 3840, 2160, "RGB", 3840, 2160, {}, it * 2)
+elif which == "rgb24s":
+    B.video_case("4K NV12 -> RGB 224x224 bilinear (inference pre-processing)", "NV12", 3840, 2160, "RGB", 224, 224, cases.LIN, it * 2)
+elif which == "yuy2":
+    B.video_case("1080p YUY2 -> BGRA", "YUY2", 1920, 1080, "BGRA", 1920, 1080, {}, it * 4)
+elif which == "nv12enc":
+    B.video_case("4K BGRA -> NV12 (encoder feed)", "BGRA", 3840, 2160, "NV12", 3840, 2160, {}, it * 2)
 elif which == "c4":
     B.compositor_case(it)
 else:

@@ -254,6 +254,19 @@ VIDEO_CASES = [
     ("yvyu_yvyu_vonly_lanczos_planes", "YVYU", 64, 48, "YVYU", 64, 111, LAN, None, None, "random"),
     ("yuy2_y42b_crop_generic", "YUY2", 64, 48, "Y42B", 32, 24, dict(src_x=16, src_y=8, src_width=32, src_height=24), None, None, "random"),
     ("y42b_ayuv_33x17_generic_odd_w", "Y42B", 33, 17, "AYUV", 33, 17, {}, None, None, "random"),
+    # ---- encoder-facing block kernel (video_encode_fast.h): 4-byte RGB -> 4:2:0, width % 4 == 0, table matrix
+    ("bgra_nv12_640x360_enc", "BGRA", 640, 360, "NV12", 640, 360, {}, None, None, "random"),
+    ("rgba_nv12_1280x720_enc_cosited", "RGBA", 1280, 720, "NV12", 1280, 720, {}, None, None, "random"),
+    ("argb_i420_644x361_enc_odd_h", "ARGB", 644, 361, "I420", 644, 361, {}, None, None, "random"),
+    ("xbgr_yv12_640x600_enc_cosited", "xBGR", 640, 600, "YV12", 640, 600, {}, None, None, "random"),
+    ("bgrx_nv21_132x71_enc", "BGRx", 132, 71, "NV21", 132, 71, {}, None, None, "random"),
+    ("bgra_nv12_4x2_enc", "BGRA", 4, 2, "NV12", 4, 2, {}, None, None, "random"),
+    ("bgra_i420_8x1_enc", "BGRA", 8, 1, "I420", 8, 1, {}, None, None, "random"),
+    ("bgra_nv12_enc_chroma_none", "BGRA", 64, 48, "NV12", 64, 48, dict(chroma_mode="none"), None, None, "random"),
+    ("bgra_nv12_enc_border", "BGRA", 64, 48, "NV12", 80, 60, dict(dest_x=8, dest_y=4, dest_width=64, dest_height=48, border_argb=0xff336699), None, None, "random"),
+    ("bgra_nv12_enc_crop", "BGRA", 128, 96, "NV12", 64, 48, dict(src_x=16, src_y=8, src_width=64, src_height=48), None, None, "random"),
+    ("bgra_nv12_1080p_enc_ramp", "BGRA", 1920, 1080, "NV12", 1920, 1080, {}, None, None, "ramp"),
+    ("bgra_nv12_720p_enc_ones", "BGRA", 1280, 720, "NV12", 1280, 720, {}, None, None, "ones"),
     # ---- NV16 / NV61 / NV24: generic chain and convert_scale_planes inside the NV12 family
     ("nv16_bgra_322x241", "NV16", 322, 241, "BGRA", 322, 241, {}, None, None, "random"),
     ("nv61_rgba_33x17", "NV61", 33, 17, "RGBA", 33, 17, {}, None, None, "random"),

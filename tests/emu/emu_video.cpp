@@ -13,6 +13,7 @@
 #include "../../gstreamer_amd/csrc/video_pack.h"
 #include "../../gstreamer_amd/csrc/video_bilinear_fast.h"
 #include "../../gstreamer_amd/csrc/video_planes.h"
+#include "../../gstreamer_amd/csrc/video_encode_fast.h"
 
 using namespace gstamd;
 
@@ -32,7 +33,7 @@ static void run_hscale_lds (const SRC &src, const ScaleDev &sd, const Dst &d, in
     }
 }
 
-static FastParams emu_fast_params (const VideoPlan &p)      /* make_fast_params of capi_video.cpp */
+static FastParams emu_fast_params (const VideoPlan &p, bool rgb24 = false)      /* make_fast_params of capi_video.cpp */
 {
   FastParams fp;
   fp.width = p.front.width;
@@ -41,6 +42,8 @@ static FastParams emu_fast_params (const VideoPlan &p)      /* make_fast_params 
   /* with a source crop the chroma upsampler still sees the frame's rows above / below the crop (do_unpack_lines :2966) */
   fp.crow_lo = -(p.rect.in_y >> 1);
   fp.crow_hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
+  if (rgb24)
+    fast_params_rgb24 (fp, p.matrix.p, p.fout->pos, p.front.u_plane);
   return fp;
 }
 
@@ -142,7 +145,7 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
     }
 }
 
-static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok);
+static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok, bool rgb24);
 
 extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *cfg, const uint8_t *src, uint8_t *dst, int vec_ok, char *desc, int desc_len)
@@ -239,9 +242,28 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     }
     return GSTAMD_OK;
   }
+  if (p.out_planar && p.fout->kind == UNPACK_PACKED3 && p.passes.empty () && p.fast_pair && vec_ok)
+    return emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok >= 200 ? 1 : vec_ok, true);     /* the line-pair kernel stores 3-byte pixels itself */
+  if (p.out_planar && p.fast_enc420 && vec_ok) {      /* k_encode420's grid: 4 x 2 pixel blocks */
+    const Enc420Params ep = make_enc420_params (p);
+    DstPlanes d;
+    memset (&d, 0, sizeof (d));
+    for (int i = 0; i < out->n_planes && i < 3; i++) {
+      d.p[i] = dst + out->offset[i];
+      d.stride[i] = out->stride[i];
+    }
+    for (int r2 = 0; r2 < (ep.height + 1) / 2; r2++)
+      for (int x0 = 0; x0 < (ep.width / 4 + 63) / 64 * 256; x0 += 4) {
+        if (p.fout->kind == UNPACK_SEMI)
+          enc420_block<1> (ep, pl.p[0], pl.stride[0], d, x0, r2);
+        else
+          enc420_block<0> (ep, pl.p[0], pl.stride[0], d, x0, r2);
+      }
+    return GSTAMD_OK;
+  }
   if (p.out_planar) {                     /* chain -> AYUV image, then the pack kernel body over its grid */
     std::vector<uint8_t> img ((size_t) p.out_info.width * 4 * p.out_info.height);
-    r = emu_convert_packed (p, in, pl, img.data (), p.out_info.width * 4, vec_ok);
+    r = emu_convert_packed (p, in, pl, img.data (), p.out_info.width * 4, vec_ok, false);
     if (r != GSTAMD_OK)
       return r;
     DstPlanes d;
@@ -256,10 +278,10 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         pack_planar_body (p.pack, img.data (), p.out_info.width * 4, d, x0, yb);
     return GSTAMD_OK;
   }
-  return emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok);
+  return emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok, false);
 }
 
-static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok)
+static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok, bool rgb24)
 {
   ColorParams color, none;
   memset (&none, 0, sizeof (none));
@@ -270,7 +292,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
   if (p.passes.empty () && p.fast_pair && vec_ok) {
     /* vec_ok: 1 = shipped configuration (strip kernel, 3 line pairs per lane); 100 + K = strip kernel with K pairs;
      * 200 + K = wide kernel (LDS-staged 1024-px runs) with K pairs per wave */
-    const FastParams fp = emu_fast_params (p);
+    const FastParams fp = emu_fast_params (p, rgb24);
     const int pairs = fp.height / 2 + 1;
     const int lay = GSTAMD_LAYOUT (fp.pack_pos[1], fp.pack_pos[2], fp.pack_pos[3]);
 #define FOR_LAYOUT(CH, CALL) \

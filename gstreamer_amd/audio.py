@@ -39,6 +39,7 @@ def lib():
         L.gstamd_audio_resampler_get_max_latency.restype = C.c_size_t
         L.gstamd_audio_resampler_get_max_latency.argtypes = [C.c_void_p]
         L.gstamd_audio_resampler_resample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gstamd_audio_resampler_resample_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.gstamd_audio_resampler_debug_get.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.gstamd_audio_resampler_debug_taps.restype = C.c_long
         L.gstamd_audio_resampler_debug_taps.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_long]
@@ -63,10 +64,11 @@ def options(method="kaiser", quality=None, in_rate=0, out_rate=0, **kw):
 class AudioResampler:
     """gst_audio_resampler_new (method, flags, format, channels, in_rate, out_rate, options)."""
 
-    def __init__(self, fmt, channels, in_rate, out_rate, method="kaiser", opts=None):
+    def __init__(self, fmt, channels, in_rate, out_rate, method="kaiser", opts=None, in_planar=False, out_planar=False):
         status = C.c_int(0)
         self.channels, self.fmt = channels, fmt
-        self._h = lib().gstamd_audio_resampler_new(METHODS[method], 0, FORMATS[fmt], channels, in_rate, out_rate,
+        flags = (1 if in_planar else 0) | (2 if out_planar else 0)        # GstAudioResamplerFlags
+        self._h = lib().gstamd_audio_resampler_new(METHODS[method], flags, FORMATS[fmt], channels, in_rate, out_rate,
                                                    C.byref(opts) if opts is not None else None, C.byref(status))
         if not self._h:
             raise _v.GstAmdError(status.value, "audio resampler plan refused")
@@ -82,6 +84,12 @@ class AudioResampler:
 
     def resample(self, src, in_frames, dst, out_frames, stream=None):
         _v._check(lib().gstamd_audio_resampler_resample(self._h, _v._ptr(src), in_frames, _v._ptr(dst), out_frames, stream))
+
+    def resample_planes(self, src_planes, in_frames, dst_planes, out_frames, stream=None):
+        """gst_audio_resampler_resample's argument shape: lists of device pointers (one per plane; one for an interleaved side)."""
+        ia = (C.c_void_p * len(src_planes))(*[_v._ptr(p) for p in src_planes]) if src_planes is not None else None
+        oa = (C.c_void_p * len(dst_planes))(*[_v._ptr(p) for p in dst_planes])
+        _v._check(lib().gstamd_audio_resampler_resample_planes(self._h, ia, in_frames, oa, out_frames, stream))
 
     def reset(self):
         lib().gstamd_audio_resampler_reset(self._h)

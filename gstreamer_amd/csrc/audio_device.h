@@ -7,6 +7,7 @@
 //   inner_product_<T>_nearest_1_c  audio-resampler.c:606-615
 //   resample loop / history        audio-resampler-macros.h:62-100, audio-resampler.c:879-897, 1750-1806
 //
+// fir_out_index: where output frame j of channel c goes (interleaved, or plane c of a non-interleaved buffer).
 // "Logical" input of channel c: the retained history frames followed by the new input frames.
 #pragma once
 #include <stdint.h>
@@ -32,7 +33,14 @@ struct FirParams {
   int in_is_null;           // new input is silence
   int interp;               // 0: FULL table [out_rate][n_taps]; 1 / 2: INTERPOLATED mode, linear / cubic blend of the oversampled table per output
   int oversample;
+  long long in_plane_stride;   // 0: interleaved input; else channel c of the new input starts at in + c * in_plane_stride (samples)
+  long long out_plane_stride;  // same for the output (GST_AUDIO_RESAMPLER_FLAG_NON_INTERLEAVED_IN / _OUT, audio-resampler.h:177-182)
 };
+
+GSTAMD_AD long long fir_out_index (const FirParams &p, long long j, int c)
+{
+  return p.out_plane_stride ? (long long) c * p.out_plane_stride + j : j * p.channels + c;
+}
 
 template <typename T> struct Acc;
 template <> struct Acc<int16_t> { typedef int32_t type; };
@@ -47,7 +55,7 @@ GSTAMD_AD T logical_sample (const FirParams &p, const T *__restrict__ hist, cons
     return hist[idx * p.channels + c];
   if (idx >= p.total_frames || p.in_is_null)
     return (T) 0;
-  return in[(idx - p.hist_frames) * p.channels + c];
+  return p.in_plane_stride ? in[(long long) c * p.in_plane_stride + (idx - p.hist_frames)] : in[(idx - p.hist_frames) * p.channels + c];
 }
 
 template <typename T> GSTAMD_AD T fir_finish (typename Acc<T>::type r);

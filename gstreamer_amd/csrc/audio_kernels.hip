@@ -29,7 +29,7 @@ __global__ __launch_bounds__ (256) void k_fir (FirParams p, const T *__restrict_
     return;
   const long long j = i / p.channels;
   const int c = (int) (i % p.channels);
-  out[i] = fir_output<T> (p, hist, in, table, j, c);
+  out[fir_out_index (p, j, c)] = fir_output<T> (p, hist, in, table, j, c);
 }
 
 template <typename T>
@@ -98,7 +98,7 @@ static int ensure_device (GstAmdAudioResampler *r)
   return GSTAMD_OK;
 }
 
-static FirParams make_fir_params (const AudioPlan &pl, const AudioStep &s, bool in_null)
+static FirParams make_fir_params (const AudioPlan &pl, const AudioStep &s, bool in_null, long long in_stride, long long out_stride)
 {
   FirParams p;
   memset (&p, 0, sizeof (p));
@@ -116,18 +116,20 @@ static FirParams make_fir_params (const AudioPlan &pl, const AudioStep &s, bool 
   p.hist_frames = s.hist_frames;
   p.total_frames = s.total_frames;
   p.in_is_null = in_null;
+  p.in_plane_stride = pl.in_planar ? in_stride : 0;
+  p.out_plane_stride = pl.out_planar ? out_stride : 0;
   return p;
 }
 
 template <typename T>
 static int run_resample (GstAmdAudioResampler *r, const void *in, size_t in_frames, void *out, size_t out_frames,
-    hipStream_t stream)
+    long long in_stride, long long out_stride, hipStream_t stream)
 {
   const AudioPlan &pl = r->plan;
   const AudioStep s = audio_step (pl, &r->st, in_frames, out_frames);
   if (s.skipped_all)
     return GSTAMD_OK;
-  const FirParams p = make_fir_params (pl, s, in == nullptr);
+  const FirParams p = make_fir_params (pl, s, in == nullptr, in_stride, out_stride);
   const int cur = r->cur, nxt = cur ^ 1;
   if (s.run_fir) {
     const long long total = s.n_out * pl.channels;
@@ -221,8 +223,8 @@ size_t gstamd_audio_resampler_get_max_latency (GstAmdAudioResampler *r)
   return r ? (size_t) (r->plan.n_taps / 2) : 0;
 }
 
-int gstamd_audio_resampler_resample (GstAmdAudioResampler *r, const void *in, size_t in_frames, void *out, size_t out_frames,
-    void *stream)
+static int resample_strided (GstAmdAudioResampler *r, const void *in, size_t in_frames, void *out, size_t out_frames, long long in_stride,
+    long long out_stride, void *stream)
 {
   if (!r || (out_frames > 0 && !out))
     return GSTAMD_ERR_INVALID;
@@ -231,11 +233,50 @@ int gstamd_audio_resampler_resample (GstAmdAudioResampler *r, const void *in, si
   if (e != GSTAMD_OK)
     return e;
   switch (r->plan.format) {
-    case GSTAMD_AUDIO_FORMAT_S16: return run_resample<int16_t> (r, in, in_frames, out, out_frames, (hipStream_t) stream);
-    case GSTAMD_AUDIO_FORMAT_S32: return run_resample<int32_t> (r, in, in_frames, out, out_frames, (hipStream_t) stream);
-    case GSTAMD_AUDIO_FORMAT_F32: return run_resample<float> (r, in, in_frames, out, out_frames, (hipStream_t) stream);
-    default: return run_resample<double> (r, in, in_frames, out, out_frames, (hipStream_t) stream);
+    case GSTAMD_AUDIO_FORMAT_S16: return run_resample<int16_t> (r, in, in_frames, out, out_frames, in_stride, out_stride, (hipStream_t) stream);
+    case GSTAMD_AUDIO_FORMAT_S32: return run_resample<int32_t> (r, in, in_frames, out, out_frames, in_stride, out_stride, (hipStream_t) stream);
+    case GSTAMD_AUDIO_FORMAT_F32: return run_resample<float> (r, in, in_frames, out, out_frames, in_stride, out_stride, (hipStream_t) stream);
+    default: return run_resample<double> (r, in, in_frames, out, out_frames, in_stride, out_stride, (hipStream_t) stream);
   }
+}
+
+int gstamd_audio_resampler_resample (GstAmdAudioResampler *r, const void *in, size_t in_frames, void *out, size_t out_frames,
+    void *stream)
+{
+  /* non-interleaved sides: the planes follow each other, in_frames / out_frames samples apart */
+  return resample_strided (r, in, in_frames, out, out_frames, (long long) in_frames, (long long) out_frames, stream);
+}
+
+int gstamd_audio_resampler_resample_planes (GstAmdAudioResampler *r, const void *const in[], size_t in_frames, void *const out[],
+    size_t out_frames, void *stream)
+{
+  if (!r || (out_frames > 0 && (!out || !out[0])))
+    return GSTAMD_ERR_INVALID;
+  const AudioPlan &pl = r->plan;
+  /* plane c must sit at plane 0 + c * stride (what a GstBuffer's GstAudioMeta holds in practice); the stride is free */
+  auto stride_of = [&](const void *const *pp, bool planar, long long *stride) {
+    *stride = 0;
+    if (!planar || pl.channels < 2 || !pp)
+      return true;
+    const ptrdiff_t d = (const uint8_t *) pp[1] - (const uint8_t *) pp[0];
+    if (d <= 0 || d % pl.bps)
+      return false;
+    for (int c = 2; c < pl.channels; c++)
+      if ((const uint8_t *) pp[c] - (const uint8_t *) pp[c - 1] != d)
+        return false;
+    *stride = d / pl.bps;
+    return true;
+  };
+  long long is = 0, os = 0;
+  if (!stride_of (in, pl.in_planar, &is) || !stride_of ((const void *const *) out, pl.out_planar, &os)) {
+    g_audio_error = "non-interleaved planes must be equally spaced in ascending order";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  if (pl.in_planar && pl.channels < 2)
+    is = (long long) in_frames;
+  if (pl.out_planar && pl.channels < 2)
+    os = (long long) out_frames;
+  return resample_strided (r, in ? in[0] : nullptr, in_frames, out ? out[0] : nullptr, out_frames, is, os, stream);
 }
 
 int gstamd_audio_resampler_debug_get (GstAmdAudioResampler *r, int32_t *out, int max_out)

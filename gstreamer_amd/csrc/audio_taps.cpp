@@ -329,8 +329,6 @@ int plan_audio_resampler (int method, int flags, int format, int channels, int i
   };
   if (method < 0 || method > 4 || format < 0 || format > 3 || channels <= 0 || in_rate <= 0 || out_rate <= 0)
     return fail (GSTAMD_ERR_INVALID, "bad resampler arguments");
-  if (flags & 3)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "non-interleaved in/out not implemented");
   GstAmdAudioResamplerOptions o;
   if (options_in)
     o = *options_in;
@@ -343,6 +341,8 @@ int plan_audio_resampler (int method, int flags, int format, int channels, int i
   p->channels = channels;
   p->bps = format == GSTAMD_AUDIO_FORMAT_S16 ? 2 : (format == GSTAMD_AUDIO_FORMAT_F64 ? 8 : 4);
   p->variable_rate = (flags & 4) != 0;
+  p->in_planar = (flags & 1) != 0;
+  p->out_planar = (flags & 2) != 0;
 
   /* gst_audio_resampler_update (:1503-1560): reduce the rates; samp_phase is 0 for a new resampler.
    * NB the reference reads max-phase-error from resampler->options, which is still NULL here, so the

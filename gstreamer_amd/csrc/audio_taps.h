@@ -12,6 +12,7 @@ namespace gstamd {
 struct AudioPlan {
   int method, format, channels, bps;
   bool variable_rate;
+  bool in_planar, out_planar;     // GST_AUDIO_RESAMPLER_FLAG_NON_INTERLEAVED_IN / _OUT
   int in_rate, out_rate;          // gcd-reduced
   int samp_inc, samp_frac;
   int n_taps, oversample;

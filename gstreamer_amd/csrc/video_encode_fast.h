@@ -90,6 +90,27 @@ GSTAMD_HD uint32_t enc_luma4 (const Enc420Params &ep, const uint4 &p)
   return lo | hi;
 }
 
+// source pixels are read once and destination bytes written once: streaming (nontemporal) accesses, as in video_fast.h
+GSTAMD_HD uint4 enc_load16 (const uint8_t *p)
+{
+#ifdef __HIPCC__
+  typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
+  const u32x4 v = __builtin_nontemporal_load ((const u32x4 *) p);
+  return make_uint4 (v.x, v.y, v.z, v.w);
+#else
+  return *(const uint4 *) p;
+#endif
+}
+
+GSTAMD_HD void enc_store32 (uint8_t *p, uint32_t v)
+{
+#ifdef __HIPCC__
+  __builtin_nontemporal_store (v, (uint32_t *) p);
+#else
+  *(uint32_t *) p = v;
+#endif
+}
+
 GSTAMD_HD uint32_t pk_avg (uint32_t a, uint32_t b) { return pk_shr<1> (a + b + 0x00010001u); }
 
 // one lane: pixels x0 .. x0+3 of the lines 2r, 2r+1 (x0 % 4 == 0, x0 < width)
@@ -101,7 +122,7 @@ GSTAMD_HD void enc420_block (const Enc420Params &ep, const uint8_t *__restrict__
   if (x0 >= w || y0 >= h)
     return;
   const uint8_t *row0 = src + (size_t) y0 * sstride, *row1 = src + (size_t) y1 * sstride;
-  const uint4 a = *(const uint4 *) (row0 + 4 * (size_t) x0), b = *(const uint4 *) (row1 + 4 * (size_t) x0);
+  const uint4 a = enc_load16 (row0 + 4 * (size_t) x0), b = enc_load16 (row1 + 4 * (size_t) x0);
   const int xm = x0 > 0 ? x0 - 1 : 0;
   uint32_t am = 0, bm = 0;
   if (ep.down_h == 2) {
@@ -109,9 +130,9 @@ GSTAMD_HD void enc420_block (const Enc420Params &ep, const uint8_t *__restrict__
     bm = *(const uint32_t *) (row1 + 4 * (size_t) xm);
   }
   // ---- luma
-  *(uint32_t *) (d.p[0] + (size_t) y0 * d.stride[0] + x0) = enc_luma4 (ep, a);
+  enc_store32 (d.p[0] + (size_t) y0 * d.stride[0] + x0, enc_luma4 (ep, a));
   if (y1 != y0)
-    *(uint32_t *) (d.p[0] + (size_t) y1 * d.stride[0] + x0) = enc_luma4 (ep, b);
+    enc_store32 (d.p[0] + (size_t) y1 * d.stride[0] + x0, enc_luma4 (ep, b));
   // ---- chroma columns x0 .. x0+3 (and x0-1 for the cosited filter), lines averaged first
   uint32_t c[4], cm = 0;
   c[0] = enc_chroma (ep, a.x);
@@ -143,7 +164,7 @@ GSTAMD_HD void enc420_block (const Enc420Params &ep, const uint8_t *__restrict__
     o1 = x0 + 2 < w - 2 ? pk_shr<2> (c[1] + 2u * c[2] + c[3] + 0x00020002u) : pk_shr<2> (c[1] + 3u * c[2] + 0x00020002u);
   }
   if (SEMI) {
-    *(uint32_t *) (d.p[1] + (size_t) r * d.stride[1] + x0) = bperm (o1, o0, ep.u_first ? 0x06040200u : 0x04060002u);
+    enc_store32 (d.p[1] + (size_t) r * d.stride[1] + x0, bperm (o1, o0, ep.u_first ? 0x06040200u : 0x04060002u));
   } else {
     *(uint16_t *) (d.p[ep.u_plane] + (size_t) r * d.stride[ep.u_plane] + (x0 >> 1)) = (uint16_t) bperm (o1, o0, 0x0c0c0400u);
     *(uint16_t *) (d.p[ep.v_plane] + (size_t) r * d.stride[ep.v_plane] + (x0 >> 1)) = (uint16_t) bperm (o1, o0, 0x0c0c0602u);

@@ -9,7 +9,7 @@
  *   gstamd_audio_resampler_get_out_frames      <- gst_audio_resampler_get_out_frames       :242
  *   gstamd_audio_resampler_get_in_frames       <- gst_audio_resampler_get_in_frames        :246
  *   gstamd_audio_resampler_get_max_latency     <- gst_audio_resampler_get_max_latency      :250
- *   gstamd_audio_resampler_resample            <- gst_audio_resampler_resample             :253
+ *   gstamd_audio_resampler_resample(_planes)   <- gst_audio_resampler_resample             :253
  *
  * Sample buffers are DEVICE pointers (interleaved frames); the FIR runs as HIP kernels on `stream`
  * (hipStream_t as void*, NULL = default stream) and the call returns without synchronising.  All
@@ -65,8 +65,8 @@ void gstamd_audio_resampler_options_init (GstAmdAudioResamplerOptions *options);
 void gstamd_audio_resampler_options_set_quality (int method, unsigned quality, int in_rate, int out_rate,
     GstAmdAudioResamplerOptions *options);
 
-/* options == NULL: Kaiser quality 4 like the reference (audio-resampler.c:1414-1419).  flags must be 0
- * (interleaved in and out).  Returns NULL and sets *status (GSTAMD_ERR_* of gstamd_video.h) on failure.  Both filter
+/* options == NULL: Kaiser quality 4 like the reference (audio-resampler.c:1414-1419).  flags: GstAudioResamplerFlags
+ * (audio-resampler.h:177-182) - 1 non-interleaved input, 2 non-interleaved output, 4 variable rate.  Returns NULL and sets *status (GSTAMD_ERR_* of gstamd_video.h) on failure.  Both filter
  * modes are implemented: FULL (one row of taps per phase) and INTERPOLATED (the taps of every output sample are blended
  * on the device from the oversampled table, linear or cubic, audio-resampler.c:567-757). */
 GstAmdAudioResampler *gstamd_audio_resampler_new (int method, int flags, int format, int channels, int in_rate,
@@ -78,9 +78,16 @@ size_t gstamd_audio_resampler_get_in_frames (GstAmdAudioResampler *resampler, si
 size_t gstamd_audio_resampler_get_max_latency (GstAmdAudioResampler *resampler);
 
 /* in: device pointer to in_frames interleaved frames, or NULL for silence (drain); out: device pointer
- * with room for out_frames frames. */
+ * with room for out_frames frames.  A non-interleaved side holds its channels one after the other, in_frames
+ * (out_frames) samples apart. */
 int gstamd_audio_resampler_resample (GstAmdAudioResampler *resampler, const void *in, size_t in_frames, void *out,
     size_t out_frames, void *stream);
+
+/* gst_audio_resampler_resample's own argument shape (audio-resampler.h:253): in[] / out[] hold ONE pointer for an
+ * interleaved side and `channels` pointers for a non-interleaved one (equally spaced planes in ascending order; anything
+ * else is GSTAMD_ERR_UNSUPPORTED); in == NULL feeds silence. */
+int gstamd_audio_resampler_resample_planes (GstAmdAudioResampler *resampler, const void *const in[], size_t in_frames,
+    void *const out[], size_t out_frames, void *stream);
 
 /* introspection for tests: n_taps, n_phases (reduced out_rate), reduced in_rate, oversample, filter mode */
 int gstamd_audio_resampler_debug_get (GstAmdAudioResampler *resampler, int32_t *out, int max_out);

@@ -51,6 +51,7 @@ def lib():
         L.ref_audio_resampler_get_max_latency.restype = C.c_size_t
         L.ref_audio_resampler_get_max_latency.argtypes = [C.c_void_p]
         L.ref_audio_resampler_resample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ref_audio_resampler_resample_planar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ref_audio_resampler_reset.argtypes = [C.c_void_p]
         L.ref_audio_resampler_free.argtypes = [C.c_void_p]
         L.ref_init()
@@ -164,13 +165,14 @@ class AudioResampler:
     FILTER_INTERPOLATION = {"none": 0, "linear": 1, "cubic": 2}
 
     def __init__(self, fmt, channels, in_rate, out_rate, method="kaiser", quality=4, options=None, filter_mode=None,
-                 filter_interpolation=None):
+                 filter_interpolation=None, in_planar=False, out_planar=False):
         self.channels = channels
+        self.in_planar, self.out_planar = in_planar, out_planar
         self.fmt = fmt
         self.dtype = {"F32LE": np.float32, "F64LE": np.float64, "S16LE": np.int16, "S32LE": np.int32}[fmt]
         lib().ref_audio_resampler_set_filter(-1 if filter_mode is None else self.FILTER_MODE[filter_mode],
                                               -1 if filter_interpolation is None else self.FILTER_INTERPOLATION[filter_interpolation])
-        self.h = lib().ref_audio_resampler_new(self.METHODS[method], 0, fmt.encode(), channels, in_rate, out_rate, quality,
+        self.h = lib().ref_audio_resampler_new(self.METHODS[method], (1 if in_planar else 0) | (2 if out_planar else 0), fmt.encode(), channels, in_rate, out_rate, quality,
                                                _b(options))
         lib().ref_audio_resampler_set_filter(-1, -1)
         if not self.h:
@@ -192,6 +194,13 @@ class AudioResampler:
             in_frames = data.size // self.channels
         if out_frames is None:
             out_frames = self.get_out_frames(in_frames)
+        if self.in_planar or self.out_planar:
+            # a non-interleaved side is a [channels, frames] array
+            out = np.zeros((self.channels, out_frames) if self.out_planar else (out_frames, self.channels), dtype=self.dtype)
+            lib().ref_audio_resampler_resample_planar(self.h, data.ctypes.data if data is not None else None, in_frames,
+                                                      out.ctypes.data, out_frames, self.channels, out.itemsize,
+                                                      int(self.in_planar), int(self.out_planar))
+            return out
         out = np.zeros((out_frames, self.channels), dtype=self.dtype)
         lib().ref_audio_resampler_resample(self.h, data.ctypes.data if data is not None else None, in_frames,
                                            out.ctypes.data, out_frames)

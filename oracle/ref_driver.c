@@ -385,6 +385,23 @@ ref_audio_resampler_resample (void *r, const void *in, gsize in_frames, void *ou
   gst_audio_resampler_resample (r, in ? ina : NULL, in_frames, outa, out_frames);
 }
 
+/* flags != 0: a non-interleaved side holds `channels` planes one after the other (in_frames / out_frames samples of
+ * `bps` bytes apart); the pointer arrays gst_audio_resampler_resample wants are built here */
+void
+ref_audio_resampler_resample_planar (void *r, const void *in, gsize in_frames, void *out, gsize out_frames,
+    int channels, int bps, int in_planar, int out_planar)
+{
+  gpointer ina[64], outa[64];
+  int c;
+  if (channels > 64)
+    return;
+  for (c = 0; c < channels; c++) {
+    ina[c] = in_planar ? (gpointer) ((const guint8 *) in + (gsize) c * in_frames * bps) : (gpointer) in;
+    outa[c] = out_planar ? (gpointer) ((guint8 *) out + (gsize) c * out_frames * bps) : out;
+  }
+  gst_audio_resampler_resample (r, in ? ina : NULL, in_frames, outa, out_frames);
+}
+
 void
 ref_audio_resampler_reset (void *r)
 {

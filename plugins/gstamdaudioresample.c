@@ -20,7 +20,7 @@ GST_DEBUG_CATEGORY_STATIC (amd_ar_debug);
 #define GST_CAT_DEFAULT amd_ar_debug
 
 #define AMD_AUDIO_CAPS "audio/x-raw, format = (string) { F32LE, F64LE, S16LE, S32LE }, rate = (int) [ 1, MAX ], " \
-    "channels = (int) [ 1, MAX ], layout = (string) interleaved"
+    "channels = (int) [ 1, MAX ], layout = (string) { interleaved, non-interleaved }"
 
 static GstStaticPadTemplate ar_sink = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS, GST_STATIC_CAPS (AMD_AUDIO_CAPS));
 static GstStaticPadTemplate ar_src = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS, GST_STATIC_CAPS (AMD_AUDIO_CAPS));
@@ -129,7 +129,7 @@ amd_ar_set_caps (GstBaseTransform * t, GstCaps * incaps, GstCaps * outcaps)
   if (!gst_audio_info_from_caps (&s->in, incaps) || !gst_audio_info_from_caps (&s->out, outcaps))
     return FALSE;
   if (amd_format (&s->in) < 0 || GST_AUDIO_INFO_FORMAT (&s->in) != GST_AUDIO_INFO_FORMAT (&s->out) ||
-      GST_AUDIO_INFO_CHANNELS (&s->in) != GST_AUDIO_INFO_CHANNELS (&s->out))
+      GST_AUDIO_INFO_CHANNELS (&s->in) != GST_AUDIO_INFO_CHANNELS (&s->out) || GST_AUDIO_INFO_LAYOUT (&s->in) != GST_AUDIO_INFO_LAYOUT (&s->out))
     return FALSE;
   if (s->r)
     gstamd_audio_resampler_free (s->r);
@@ -140,7 +140,9 @@ amd_ar_set_caps (GstBaseTransform * t, GstCaps * incaps, GstCaps * outcaps)
   o.filter_mode = s->sinc_filter_mode;
   o.filter_mode_threshold = (int32_t) s->sinc_filter_auto_threshold;
   o.filter_interpolation = s->sinc_filter_interpolation;
-  s->r = gstamd_audio_resampler_new (s->method, 0, amd_format (&s->in), GST_AUDIO_INFO_CHANNELS (&s->in),
+  /* non-interleaved buffers hold their planes back to back, one buffer's frames apart (gstaudioresample.c:~960 builds the plane
+   * pointers the same way); GST_AUDIO_RESAMPLER_FLAG_NON_INTERLEAVED_IN | _OUT */
+  s->r = gstamd_audio_resampler_new (s->method, GST_AUDIO_INFO_LAYOUT (&s->in) == GST_AUDIO_LAYOUT_NON_INTERLEAVED ? 3 : 0, amd_format (&s->in), GST_AUDIO_INFO_CHANNELS (&s->in),
       GST_AUDIO_INFO_RATE (&s->in), GST_AUDIO_INFO_RATE (&s->out), &o, &status);
   if (!s->r) {
     GST_ERROR_OBJECT (s, "HIP resampler refused this configuration (status %d)", status);

@@ -39,11 +39,13 @@ static void emu_run (EmuResampler *r, const void *in, size_t in_frames, void *ou
   p.hist_frames = s.hist_frames;
   p.total_frames = s.total_frames;
   p.in_is_null = in == nullptr;
+  p.in_plane_stride = pl.in_planar ? (long long) in_frames : 0;
+  p.out_plane_stride = pl.out_planar ? (long long) out_frames : 0;
   const T *hist = (const T *) r->hist.data ();
   if (s.run_fir)
     for (long long j = 0; j < s.n_out; j++)
       for (int c = 0; c < pl.channels; c++)
-        ((T *) out)[j * pl.channels + c] = fir_output<T> (p, hist, (const T *) in, (const T *) pl.table.data (), j, c);
+        ((T *) out)[fir_out_index (p, j, c)] = fir_output<T> (p, hist, (const T *) in, (const T *) pl.table.data (), j, c);
   std::vector<uint8_t> nh ((size_t) (s.keep + 1) * pl.channels * sizeof (T));
   for (long long i = 0; i < s.keep; i++)
     for (int c = 0; c < pl.channels; c++)

@@ -44,6 +44,48 @@ def test_hip_fir_matches_reference_golden(native_lib, gpu, case):
     assert cases.sha(out) == GOLDEN[case[0]]["sha256"], (list(out[:8]), GOLDEN[case[0]]["head"])
 
 
+@pytest.mark.parametrize("layout", [(True, True), (True, False), (False, True)], ids=["planar_planar", "planar_in", "planar_out"])
+@pytest.mark.parametrize("name", ["f32_48k_44k1_q4_stereo", "f32_6ch_cubic", "s16_48k_44k1_q4", "f32_8k_16k_gappy", "s32_interp_cubic_48k_32k"])
+def test_hip_fir_non_interleaved_layouts(native_lib, gpu, name, layout):
+    """Non-interleaved input / output (GstAudioResamplerFlags): same samples as the interleaved golden, planes [channels][frames];
+    the planar-planar leg goes through gstamd_audio_resampler_resample_planes with one pointer per plane."""
+    import torch
+    case = next(c for c in cases.AUDIO_CASES if c[0] == name)
+    _, fmt, ch, ir, orr, method, quality, bufs = case
+    in_planar, out_planar = layout
+    dt = cases.AUDIO_DTYPES[fmt]
+    tdt = getattr(torch, np.dtype(dt).name)
+    r = A.AudioResampler(fmt, ch, ir, orr, method, A.options(method, quality, ir, orr, **cases.audio_filter_kwargs(name)),
+                         in_planar=in_planar, out_planar=out_planar)
+    chunks = []
+    for i, n in enumerate(list(bufs) + [None]):
+        if n is None:
+            n, d_in = r.get_max_latency(), None
+        else:
+            a = cases.audio_buffer(fmt, ch, n, cases.case_seed(name) + i)
+            d_in = torch.from_numpy(np.ascontiguousarray(a.T) if in_planar else a).to(gpu)
+        no = r.get_out_frames(n)
+        d_out = torch.zeros((ch, max(no, 1)) if out_planar else (max(no, 1), ch), dtype=tdt, device=gpu)
+        if in_planar and out_planar and no > 0:
+            # planes with a pitch of their own: rows of wider buffers
+            wide_in = None
+            if d_in is not None:
+                wide_in = torch.zeros((ch, n + 7), dtype=tdt, device=gpu)
+                wide_in[:, :n] = d_in
+            wide_out = torch.zeros((ch, no + 5), dtype=tdt, device=gpu)
+            r.resample_planes(None if wide_in is None else [wide_in[c] for c in range(ch)], n, [wide_out[c] for c in range(ch)], no)
+            d_out = wide_out[:, :no]
+        else:
+            if out_planar:
+                d_out = torch.zeros((ch, no), dtype=tdt, device=gpu) if no > 0 else d_out
+            r.resample(d_in, n, d_out, no)
+        torch.cuda.synchronize()
+        o = d_out.cpu().numpy()
+        chunks.append((o.T if out_planar else o[:no]).reshape(-1) if no > 0 else np.zeros(0, dt))
+    r.free()
+    assert cases.sha(np.concatenate(chunks)) == GOLDEN[name]["sha256"]
+
+
 def test_hip_fir_c4_ten_seconds_bitwise(native_lib, gpu, ref):
     """BASELINE config 4's audio leg: 2-ch F32, 10 s of noise + a 997 Hz sine block,
     48000 -> 44100, quality 4, buffers of 1024 frames; compared sample by sample with the reference."""

@@ -63,6 +63,53 @@ def test_golden_is_the_references_output(ref, case):
     assert cases.sha(np.concatenate(chunks)) == GOLDEN[name]["sha256"]
 
 
+LAYOUT_CASES = [c for c in cases.AUDIO_CASES if c[0] in ("f32_48k_44k1_q4_stereo", "f32_6ch_cubic", "s16_48k_44k1_q4", "f32_8k_16k_gappy",
+                                                         "s32_interp_cubic_48k_32k", "f64_48k_44k1_q4")]
+
+
+@pytest.mark.parametrize("layout", [(True, True), (True, False), (False, True)], ids=["planar_planar", "planar_in", "planar_out"])
+@pytest.mark.parametrize("case", LAYOUT_CASES, ids=lambda c: c[0])
+def test_non_interleaved_layouts_on_host_match_golden(native_lib, emu_lib, case, layout):
+    """GST_AUDIO_RESAMPLER_FLAG_NON_INTERLEAVED_IN / _OUT: the samples are those of the interleaved stream (the golden), only
+    laid out as [channels][frames] on the flagged side."""
+    E = _emu(emu_lib)
+    name, fmt, ch, ir, orr, method, quality, bufs = case
+    in_planar, out_planar = layout
+    o = A.options(method, quality, ir, orr, **cases.audio_filter_kwargs(name))
+    st = C.c_int(0)
+    h = E.emu_audio_new(A.METHODS[method], (1 if in_planar else 0) | (2 if out_planar else 0), A.FORMATS[fmt], ch, ir, orr, C.byref(o),
+                        C.byref(st), None, 0)
+    assert h, st.value
+    dt = cases.AUDIO_DTYPES[fmt]
+    chunks = []
+    for i, n in enumerate(list(bufs) + [None]):
+        data = None if n is None else cases.audio_buffer(fmt, ch, n, cases.case_seed(name) + i)
+        if data is not None and in_planar:
+            data = np.ascontiguousarray(data.T)
+        if n is None:
+            r = A.AudioResampler(fmt, ch, ir, orr, method, o)
+            n = r.get_max_latency()
+            r.free()
+        no = E.emu_audio_get_out_frames(h, n)
+        got = np.zeros((ch, no) if out_planar else (no, ch), dt)
+        E.emu_audio_resample(h, data.ctypes.data if data is not None else None, n, got.ctypes.data, no)
+        chunks.append((got.T if out_planar else got).reshape(-1))
+    E.emu_audio_free(h)
+    assert cases.sha(np.concatenate(chunks)) == GOLDEN[name]["sha256"]
+
+
+def test_reference_layouts_carry_the_same_samples(ref):
+    """The premise of the layout tests, checked on the reference itself: planar in / out == the interleaved stream transposed."""
+    name, fmt, ch, ir, orr, method, quality, bufs = next(c for c in cases.AUDIO_CASES if c[0] == "f32_6ch_cubic")
+    rr = ref.AudioResampler(fmt, ch, ir, orr, method=method, quality=quality, in_planar=True, out_planar=True)
+    chunks = []
+    for i, n in enumerate(list(bufs) + [None]):
+        data = None if n is None else np.ascontiguousarray(cases.audio_buffer(fmt, ch, n, cases.case_seed(name) + i).T)
+        n_in = rr.get_max_latency() if n is None else n
+        chunks.append(rr.resample(data, in_frames=n_in, out_frames=rr.get_out_frames(n_in)).T.reshape(-1))
+    assert cases.sha(np.concatenate(chunks)) == GOLDEN[name]["sha256"]
+
+
 def test_c4_plan_48k_to_44k1(native_lib):
     """160/147 reduction, 72 taps, FULL mode with 147 cached phases, 8x oversampled cubic build."""
     r = A.AudioResampler("F32LE", 2, 48000, 44100, "kaiser", A.options("kaiser", 4, 48000, 44100))
@@ -85,14 +132,10 @@ def test_c4_plan_48k_to_44k1(native_lib):
 
 def test_filter_mode_auto_picks_interpolated_for_big_tables(native_lib):
     """audio-resampler.c:1110-1130: 48000 -> 44101 would need 44101 phases x 72 taps x 4 B > the 1 MiB threshold, so
-    mode AUTO resolves to INTERPOLATED (cubic, 8x oversampled table of 8 + 4 rows); non-interleaved layouts are refused."""
+    mode AUTO resolves to INTERPOLATED (cubic, 8x oversampled table of 8 + 4 rows)."""
     from gstreamer_amd import video as V
     r = A.AudioResampler("F32LE", 2, 48000, 44101, "kaiser", A.options("kaiser", 4, 48000, 44101))
     d = r.debug()
     assert d["filter_mode"] == A.FILTER_MODE["interpolated"] and d["filter_interpolation"] == A.FILTER_INTERPOLATION["cubic"]
     assert d["oversample"] == 8
     r.free()
-    L = A.lib()
-    st = C.c_int(0)
-    assert not L.gstamd_audio_resampler_new(A.METHODS["kaiser"], 1, A.FORMATS["F32LE"], 2, 48000, 44100, None, C.byref(st))
-    assert st.value == V.ERR_UNSUPPORTED

@@ -254,3 +254,23 @@ def test_videoconvertscale_element_packed422_and_rgb24(gst_env, ref):
                             out_chroma_site="jpeg")
     for i in range(n):
         assert (rc.frame(src[i]) == out[i]).all(), i
+
+
+def test_audioresample_element_non_interleaved_layout(gst_env, ref):
+    """layout=non-interleaved: every buffer is [channels][frames]; a caps filter labels 1024-frame blocks of a planar file
+    (rawaudioparse 1.14 ignores its interleaved property)."""
+    env, tmp = gst_env
+    ch, blk, nblk = 2, 1024, 24
+    src = (cases.audio_buffer("F32LE", ch, blk * nblk, 777)).reshape(nblk, blk, ch).transpose(0, 2, 1).copy()      # [block][channel][frame]
+    fin, fout = tmp / "in_planar.f32", tmp / "out_planar.f32"
+    src.tofile(fin)
+    launch(env, "filesrc location=%s blocksize=%d ! audio/x-raw,format=F32LE,layout=non-interleaved,rate=48000,channels=%d "
+                "! amdaudioresample quality=4 ! audio/x-raw,rate=44100 ! filesink location=%s" % (fin, blk * ch * 4, ch, fout))
+    out = np.fromfile(fout, np.float32)
+    rr = ref.AudioResampler("F32LE", ch, 48000, 44100, quality=4, in_planar=True, out_planar=True)
+    exp = [rr.resample(src[i], in_frames=blk, out_frames=rr.get_out_frames(blk)).reshape(-1) for i in range(nblk)]
+    lat = rr.get_max_latency()
+    exp.append(rr.resample(None, in_frames=lat, out_frames=rr.get_out_frames(lat)).reshape(-1))       # EOS drain
+    exp = np.concatenate(exp)
+    assert out.shape == exp.shape, (out.shape, exp.shape)
+    assert (out == exp).all(), int(np.argmax(out != exp))

@@ -13,6 +13,7 @@
 
 #include "../../include/gstamd_video.h"
 #include "compositor_device.h"
+#include "compositor_planes.h"
 
 using namespace gstamd;
 
@@ -145,6 +146,11 @@ static bool color_word (int format, int c1, int c2, int c3, uint32_t *out)
   return true;
 }
 
+__global__ __launch_bounds__ (256) void k_aggregate_plane (PlaneJob job)
+{
+  plane_word_body (job, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
+}
+
 extern "C" {
 
 int gstamd_compositor_blend (int format, int overlay, const void *src, int sw, int sh, int sstride, int xpos, int ypos,
@@ -261,6 +267,65 @@ int gstamd_compositor_aggregate (int format, int background, const GstAmdComposi
       return r;
     p.bg_kind = 2;                                /* further chunks continue on the canvas */
     first = false;
+  }
+  return GSTAMD_OK;
+}
+
+/* ---- outputs without per-pixel alpha: plane-by-plane aggregation (compositor_planes.h) ------------------- */
+static hipError_t launch_plane_job (const PlaneJob &job, hipStream_t stream)
+{
+  const int lanes = (job.wbytes + 3) / 4;
+  hipLaunchKernelGGL (k_aggregate_plane, dim3 ((lanes + 255) / 256, job.rows), dim3 (256), 0, stream, job);
+  return hipGetLastError ();
+}
+
+int gstamd_compositor_aggregate_frame (int format, int background, const int32_t black[3], const int32_t white[3],
+    const GstAmdCompositorFramePad *pads, int n_pads, void *const dest[3], const int32_t dstride[3], int dw, int dh, void *stream)
+{
+  const FormatDesc *f = format_desc (format);
+  PlaneGeom geom[3];
+  const int n_planes = compositor_plane_geometry (f, geom);
+  if (!n_planes || !dest || !dstride || dw <= 0 || dh <= 0 || (n_pads > 0 && !pads) || background < 0 || background > 3)
+    return GSTAMD_ERR_INVALID;
+  const int yuv = f->yuv ? 1 : 0;
+  const int dblack[3] = {yuv ? 16 : 0, yuv ? 128 : 0, yuv ? 128 : 0}, dwhite[3] = {yuv ? 235 : 255, yuv ? 128 : 255, yuv ? 128 : 255};
+  const int bk[3] = {black ? black[0] : dblack[0], black ? black[1] : dblack[1], black ? black[2] : dblack[2]};
+  const int wh[3] = {white ? white[0] : dwhite[0], white ? white[1] : dwhite[1], white ? white[2] : dwhite[2]};
+  for (int pl = 0; pl < n_planes; pl++) {
+    if (!dest[pl])
+      return GSTAMD_ERR_INVALID;
+    PlaneJob job;
+    memset (&job, 0, sizeof (job));
+    job.dst = (uint8_t *) dest[pl];
+    job.dstride = dstride[pl];
+    job.wbytes = sub_scale (dw, geom[pl].w_sub) * geom[pl].px_bytes;
+    job.rows = sub_scale (dh, geom[pl].h_sub);
+    compositor_plane_background (f, geom[pl], pl, background, bk, wh, &job);
+    int done = 0;
+    bool first = true;
+    while (first || done < n_pads) {
+      job.n = 0;
+      while (done < n_pads && job.n < GSTAMD_PLANE_MAX_PADS) {
+        const GstAmdCompositorFramePad &in = pads[done++];
+        FramePad fp;
+        for (int k = 0; k < 3; k++) {
+          fp.data[k] = (const uint8_t *) in.data[k];
+          fp.stride[k] = in.stride[k];
+        }
+        fp.width = in.width;
+        fp.height = in.height;
+        fp.xpos = in.xpos;
+        fp.ypos = in.ypos;
+        fp.alpha = in.alpha;
+        fp.mode = in.blend_mode;
+        if (compositor_pad_rect (f, geom[pl], pl, fp, dw, dh, &job.r[job.n]))
+          job.n++;
+      }
+      if (launch_plane_job (job, (hipStream_t) stream) != hipSuccess)
+        return GSTAMD_ERR_HIP;
+      job.bg_kind = 2;                            /* further chunks continue on the canvas */
+      first = false;
+    }
   }
   return GSTAMD_OK;
 }

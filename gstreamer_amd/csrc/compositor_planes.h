@@ -1,0 +1,212 @@
+// compositor_planes.h - compositor output in the formats that have no per-pixel alpha: planar YUV (I420, YV12, Y42B, Y444),
+// semi-planar (NV12, NV21) and 24-bit RGB / BGR.  The reference converts every pad to the output format first and then
+// blends PLANE BY PLANE with the pad alpha only (gst/compositor/blend.c: PLANAR_YUV_BLEND :247-405, NV_YUV_BLEND :1387-1500,
+// RGB_BLEND :1610-1684): a plane rectangle is copied (alpha 1.0 or operator `source`), left alone (alpha 0.0) or run
+// through compositor_orc_blend_u8 (compositororc.orc:20-36: d = (d * 256 + (s - d) * alpha) >> 8 in 16 bits, alpha =
+// (int) (pad_alpha * 255)), byte by byte - chroma bytes included.  Background: fill_checker_* (:405-450, 1500-1540,
+// 1686-1711: 80 / 160 in 8 x 8 pixel squares on luma / on R, G and B; chroma 0x80), fill_color_*, or memset 0
+// (compositor.c:1641-1668).
+//
+// GPU shape: ONE pass per destination plane; a lane owns 4 consecutive bytes of a row, starts from the background (or the
+// canvas for follow-up chunks) and applies the pads' rectangles in z-order in registers - every destination byte is
+// written once, whatever the number of pads.  The host computes the rectangles with the reference's own clipping rules.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "planner.h"
+
+#ifdef __HIPCC__
+#define GSTAMD_CP __device__ __forceinline__
+#else
+#define GSTAMD_CP inline
+#endif
+
+namespace gstamd {
+
+#define GSTAMD_PLANE_MAX_PADS 24
+
+struct PlaneRect {
+  const uint8_t *src;     // first source byte of the rectangle
+  int sstride;
+  int x, y, w, h;         // destination rectangle in BYTES x ROWS of the plane
+  int mode;               // 1: copy, 2: blend with `alpha`
+  int alpha;              // 0 .. 255
+};
+
+struct PlaneJob {
+  uint8_t *dst;
+  int dstride;
+  int wbytes, rows;       // plane size
+  int bg_kind;            // 0: checker, 1: constant bytes, 2: keep the canvas (follow-up chunk)
+  int px_bytes;           // bytes per pixel of the plane (checker squares are 8 PIXELS wide; constants repeat per pixel)
+  uint8_t bg[4];          // constant background: byte k of every pixel
+  int n;
+  PlaneRect r[GSTAMD_PLANE_MAX_PADS];
+};
+
+// one destination byte
+GSTAMD_CP uint32_t plane_byte (const PlaneJob &j, int x, int y, uint32_t canvas)
+{
+  uint32_t d;
+  if (j.bg_kind == 2)
+    d = canvas;
+  else if (j.bg_kind == 0)
+    d = ((((unsigned) y & 8u) >> 3) + ((((unsigned) (x / j.px_bytes)) & 8u) >> 3)) & 1u ? 160u : 80u;
+  else
+    d = j.bg[x % j.px_bytes];
+  for (int k = 0; k < j.n; k++) {
+    const PlaneRect &r = j.r[k];
+    if (x < r.x || x >= r.x + r.w || y < r.y || y >= r.y + r.h)
+      continue;
+    const uint32_t s = r.src[(size_t) (y - r.y) * r.sstride + (x - r.x)];
+    d = r.mode == 1 ? s : ((d << 8) + (uint32_t) (((int) s - (int) d) * r.alpha)) >> 8 & 0xffu;
+  }
+  return d;
+}
+
+// one lane: bytes x0 .. x0+3 of row y
+GSTAMD_CP void plane_word_body (const PlaneJob &j, int x0, int y)
+{
+  if (x0 >= j.wbytes || y >= j.rows)
+    return;
+  uint8_t *q = j.dst + (size_t) y * j.dstride + x0;
+  const int n = j.wbytes - x0 < 4 ? j.wbytes - x0 : 4;
+  uint32_t v[4];
+  for (int i = 0; i < n; i++)
+    v[i] = plane_byte (j, x0 + i, y, j.bg_kind == 2 ? q[i] : 0);
+  if (n == 4 && (((uintptr_t) q) & 3) == 0)
+    *(uint32_t *) q = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+  else
+    for (int i = 0; i < n; i++)
+      q[i] = (uint8_t) v[i];
+}
+
+// ---- host side: the reference's rectangle arithmetic ---------------------------------------------------------------------
+struct FramePad {           // one pad, already in the output format
+  const uint8_t *data[3];
+  int stride[3];
+  int width, height, xpos, ypos;
+  double alpha;
+  int mode;                 // GstCompositorBlendMode
+};
+
+struct PlaneGeom {          // plane i of a format: which bytes it holds
+  int w_sub, h_sub;         // subsampling of the plane's component(s)
+  int px_bytes;             // bytes per (subsampled) pixel
+};
+
+// planes of the supported output formats; returns the number of planes or 0
+inline int compositor_plane_geometry (const FormatDesc *f, PlaneGeom g[3])
+{
+  if (!f)
+    return 0;
+  if (f->kind == UNPACK_PLANAR) {
+    g[0] = {0, 0, 1};
+    g[1] = g[2] = {f->w_sub, f->h_sub, 1};
+    return 3;
+  }
+  if (f->kind == UNPACK_SEMI && f->w_sub == 1 && f->h_sub == 1) {
+    g[0] = {0, 0, 1};
+    g[1] = {1, 1, 2};
+    return 2;
+  }
+  if (f->kind == UNPACK_PACKED3) {
+    g[0] = {0, 0, 3};
+    return 1;
+  }
+  return 0;
+}
+
+inline int sub_scale (int v, int sub) { return -((-v) >> sub); }     /* GST_VIDEO_SUB_SCALE */
+
+// the rectangle of plane `pl` one pad contributes (blend_<format> of blend.c); false: nothing to do
+inline bool compositor_pad_rect (const FormatDesc *f, const PlaneGeom &g, int pl, const FramePad &pad, int dest_w, int dest_h, PlaneRect *out)
+{
+  double alpha = pad.mode == 0 /* SOURCE */ ? 1.0 : pad.alpha;
+  if (alpha == 0.0 || !pad.data[pl])
+    return false;
+  int xpos = pad.xpos, ypos = pad.ypos;
+  if (f->kind != UNPACK_PACKED3) {
+    /* x_round / y_round: GST_ROUND_UP_2 where the format subsamples (i420, nv12: both; y42b: x only) */
+    if (f->w_sub)
+      xpos = (xpos + 1) & ~1;
+    if (f->h_sub)
+      ypos = (ypos + 1) & ~1;
+  }
+  int bw = pad.width, bh = pad.height, xoff = 0, yoff = 0;
+  if (xpos < 0) {
+    xoff = -xpos;
+    bw -= -xpos;
+    xpos = 0;
+  }
+  if (ypos < 0) {
+    yoff = -ypos;
+    bh -= -ypos;
+    ypos = 0;
+  }
+  if (xoff >= pad.width || yoff >= pad.height)
+    return false;
+  if (xpos + bw > dest_w)
+    bw = dest_w - xpos;
+  if (ypos + bh > dest_h)
+    bh = dest_h - ypos;
+  if (bw <= 0 || bh <= 0)
+    return false;
+  /* component geometry: sizes round up, positions and offsets of the chroma planes: x rounds up, y rounds DOWN (:358-367) */
+  const int cw = sub_scale (bw, g.w_sub), ch = sub_scale (bh, g.h_sub);
+  const int cx = xpos == 0 ? 0 : sub_scale (xpos, g.w_sub), cxo = xoff == 0 ? 0 : sub_scale (xoff, g.w_sub);
+  const int cy = pl == 0 ? ypos : ypos >> g.h_sub, cyo = pl == 0 ? yoff : yoff >> g.h_sub;
+  out->src = pad.data[pl] + (size_t) cyo * pad.stride[pl] + (size_t) cxo * g.px_bytes;
+  out->sstride = pad.stride[pl];
+  out->x = cx * g.px_bytes;
+  out->y = cy;
+  out->w = cw * g.px_bytes;
+  out->h = ch;
+  if (alpha == 1.0) {
+    out->mode = 1;
+    out->alpha = 255;
+  } else {
+    int a = (int) (alpha * 255);
+    out->mode = 2;
+    out->alpha = a < 0 ? 0 : (a > 255 ? 255 : a);
+  }
+  return true;
+}
+
+// background of plane `pl`: kind (GstCompositorBackground) + the black / white colours in component order (Y,U,V or R,G,B)
+inline void compositor_plane_background (const FormatDesc *f, const PlaneGeom &g, int pl, int background, const int black[3], const int white[3],
+    PlaneJob *job)
+{
+  job->px_bytes = g.px_bytes;
+  memset (job->bg, 0, sizeof (job->bg));
+  if (background == 3) {                  /* transparent: memset 0 */
+    job->bg_kind = 1;
+    return;
+  }
+  const bool luma_like = pl == 0;         /* the Y plane, or the single RGB plane */
+  if (background == 0) {                  /* checker */
+    if (luma_like)
+      job->bg_kind = 0;
+    else {
+      job->bg_kind = 1;
+      job->bg[0] = job->bg[1] = 0x80;
+    }
+    return;
+  }
+  const int *c = background == 1 ? black : white;
+  job->bg_kind = 1;
+  if (f->kind == UNPACK_PACKED3) {
+    for (int k = 1; k < 4; k++)
+      job->bg[f->pos[k]] = (uint8_t) c[k - 1];
+  } else if (pl == 0) {
+    job->bg[0] = (uint8_t) c[0];
+  } else if (f->kind == UNPACK_SEMI) {
+    job->bg[0] = (uint8_t) (f->u_plane ? c[1] : c[2]);
+    job->bg[1] = (uint8_t) (f->u_plane ? c[2] : c[1]);
+  } else {
+    job->bg[0] = (uint8_t) (pl == f->u_plane ? c[1] : c[2]);
+  }
+}
+
+}  // namespace gstamd

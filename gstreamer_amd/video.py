@@ -54,6 +54,11 @@ class CompositorPad(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class CompositorFramePad(C.Structure):
+    _fields_ = [("data", C.c_void_p * 3), ("stride", C.c_int32 * 3), ("width", C.c_int32), ("height", C.c_int32),
+                ("xpos", C.c_int32), ("ypos", C.c_int32), ("alpha", C.c_double), ("blend_mode", C.c_int32), ("reserved", C.c_int32)]
+
+
 class NativeLibraryMissing(RuntimeError):
     pass
 
@@ -101,6 +106,9 @@ def lib():
                                                        C.c_int, C.c_int, C.c_int, C.c_void_p]
             L.gstamd_compositor_aggregate.argtypes = [C.c_int, C.c_int, C.POINTER(CompositorPad), C.c_int, C.c_void_p,
                                                       C.c_int, C.c_int, C.c_int, C.c_void_p]
+            L.gstamd_compositor_aggregate_frame.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                            C.POINTER(CompositorFramePad), C.c_int, C.POINTER(C.c_void_p),
+                                                            C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 

@@ -216,6 +216,24 @@ typedef struct GstAmdCompositorPad {
 int gstamd_compositor_aggregate (int format, int background, const GstAmdCompositorPad *pads,
     int n_pads, void *dest, int dw, int dh, int dstride, void *stream);
 
+/* Outputs WITHOUT per-pixel alpha - I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR: the reference converts every pad to the
+ * output format and blends plane by plane with the pad alpha only (blend.c PLANAR_YUV_BLEND / NV_YUV_BLEND / RGB_BLEND,
+ * fill_checker_* / fill_color_*; compositor.c:1619-1697).  One pass per destination plane, pads applied in array order.
+ * black / white: the element's black_color / white_color in component order (compositor.c:1131-1149); NULL = 16,128,128 /
+ * 235,128,128 for YUV and 0 / 255 for RGB. */
+typedef struct GstAmdCompositorFramePad {
+  const void *data[3];          /* device pointers of the pad's planes, same format as the output */
+  int32_t stride[3];
+  int32_t width, height;
+  int32_t xpos, ypos;
+  double alpha;
+  int32_t blend_mode;
+  int32_t reserved;
+} GstAmdCompositorFramePad;
+int gstamd_compositor_aggregate_frame (int format, int background, const int32_t black[3], const int32_t white[3],
+    const GstAmdCompositorFramePad *pads, int n_pads, void *const dest[3], const int32_t dstride[3], int dw, int dh,
+    void *stream);
+
 /* ---- device memory helpers (thin wrappers so non-HIP hosts can manage HBM) -------------- */
 void *gstamd_device_alloc (size_t size);
 void gstamd_device_free (void *ptr);

@@ -249,6 +249,14 @@ ref_compositor_blend (const char *func, const char *format, const guint8 * src, 
     fn = gst_compositor_blend_nv12;
   else if (!strcmp (func, "blend_y444"))
     fn = gst_compositor_blend_y444;
+  else if (!strcmp (func, "blend_yv12"))
+    fn = gst_compositor_blend_yv12;
+  else if (!strcmp (func, "blend_y42b"))
+    fn = gst_compositor_blend_y42b;
+  else if (!strcmp (func, "blend_nv21"))
+    fn = gst_compositor_blend_nv21;
+  else if (!strcmp (func, "blend_bgr"))
+    fn = gst_compositor_blend_bgr;
   else if (!strcmp (func, "blend_xrgb"))
     fn = gst_compositor_blend_xrgb;
   else if (!strcmp (func, "blend_rgb"))
@@ -286,6 +294,22 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
       fn = gst_compositor_fill_checker_argb;
     else if (!strcmp (fmt_func, "ayuv"))
       fn = gst_compositor_fill_checker_ayuv;
+    else if (!strcmp (fmt_func, "i420"))
+      fn = gst_compositor_fill_checker_i420;
+    else if (!strcmp (fmt_func, "yv12"))
+      fn = gst_compositor_fill_checker_yv12;
+    else if (!strcmp (fmt_func, "y42b"))
+      fn = gst_compositor_fill_checker_y42b;
+    else if (!strcmp (fmt_func, "y444"))
+      fn = gst_compositor_fill_checker_y444;
+    else if (!strcmp (fmt_func, "nv12"))
+      fn = gst_compositor_fill_checker_nv12;
+    else if (!strcmp (fmt_func, "nv21"))
+      fn = gst_compositor_fill_checker_nv21;
+    else if (!strcmp (fmt_func, "rgb"))
+      fn = gst_compositor_fill_checker_rgb;
+    else if (!strcmp (fmt_func, "bgr"))
+      fn = gst_compositor_fill_checker_bgr;
     if (!fn)
       return -1;
     fn (&df, y0, y1);
@@ -301,6 +325,22 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
       fn = gst_compositor_fill_color_abgr;
     else if (!strcmp (fmt_func, "ayuv"))
       fn = gst_compositor_fill_color_ayuv;
+    else if (!strcmp (fmt_func, "i420"))
+      fn = gst_compositor_fill_color_i420;
+    else if (!strcmp (fmt_func, "yv12"))
+      fn = gst_compositor_fill_color_yv12;
+    else if (!strcmp (fmt_func, "y42b"))
+      fn = gst_compositor_fill_color_y42b;
+    else if (!strcmp (fmt_func, "y444"))
+      fn = gst_compositor_fill_color_y444;
+    else if (!strcmp (fmt_func, "nv12"))
+      fn = gst_compositor_fill_color_nv12;
+    else if (!strcmp (fmt_func, "nv21"))
+      fn = gst_compositor_fill_color_nv12;      /* blend.h:149: the same component-addressed function */
+    else if (!strcmp (fmt_func, "rgb"))
+      fn = gst_compositor_fill_color_rgb;
+    else if (!strcmp (fmt_func, "bgr"))
+      fn = gst_compositor_fill_color_bgr;
     if (!fn)
       return -1;
     fn (&df, y0, y1, c1, c2, c3);

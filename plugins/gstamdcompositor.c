@@ -31,7 +31,7 @@
 GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
 #define GST_CAT_DEFAULT amd_comp_debug
 
-#define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV }"
+#define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR }"
 /* what a pad may carry: anything the converter takes; it is brought to the output format / the pad's width x height by a
  * per-pad GstAmdVideoConverter (the reference's GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) */
 #define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY }"
@@ -60,6 +60,7 @@ typedef struct {
   gint conv_key[6];            /* in format, in w, in h, out format, out w, out h */
   gpointer conv_buf;
   gsize conv_buf_size;
+  GstAmdVideoInfo conv_out;      /* layout of the converted frame in conv_buf */
 } GstAmdCompositorPadObj;
 
 typedef struct { GstAggregatorPadClass parent_class; } GstAmdCompositorPadObjClass;
@@ -244,6 +245,15 @@ amd_format_of (GstVideoFormat f)
     case GST_VIDEO_FORMAT_ARGB: return GSTAMD_VIDEO_FORMAT_ARGB;
     case GST_VIDEO_FORMAT_ABGR: return GSTAMD_VIDEO_FORMAT_ABGR;
     case GST_VIDEO_FORMAT_AYUV: return GSTAMD_VIDEO_FORMAT_AYUV;
+    /* outputs without per-pixel alpha: pads are blended plane by plane (gstamd_compositor_aggregate_frame) */
+    case GST_VIDEO_FORMAT_I420: return GSTAMD_VIDEO_FORMAT_I420;
+    case GST_VIDEO_FORMAT_YV12: return GSTAMD_VIDEO_FORMAT_YV12;
+    case GST_VIDEO_FORMAT_Y42B: return GSTAMD_VIDEO_FORMAT_Y42B;
+    case GST_VIDEO_FORMAT_Y444: return GSTAMD_VIDEO_FORMAT_Y444;
+    case GST_VIDEO_FORMAT_NV12: return GSTAMD_VIDEO_FORMAT_NV12;
+    case GST_VIDEO_FORMAT_NV21: return GSTAMD_VIDEO_FORMAT_NV21;
+    case GST_VIDEO_FORMAT_RGB: return GSTAMD_VIDEO_FORMAT_RGB;
+    case GST_VIDEO_FORMAT_BGR: return GSTAMD_VIDEO_FORMAT_BGR;
     default: return 0;
   }
 }
@@ -526,6 +536,8 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
   guint n = 0, i, n_desc = 0;
   gboolean all_eos = TRUE;
   const int fmt = amd_format_of (GST_VIDEO_INFO_FORMAT (&c->out_info));
+  const gboolean by_planes = !GST_VIDEO_INFO_HAS_ALPHA (&c->out_info);
+  GstAmdCompositorFramePad fdesc[AMD_COMP_MAX_PADS];
   int r;
 
   if (!c->have_out)
@@ -581,7 +593,7 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
       base = p->staging;
     }
     {
-      gint tw, th;
+      gint tw, th, k;
       const int ifmt = amd_pad_format_of (GST_VIDEO_INFO_FORMAT (&p->info));
       amd_comp_pad_target_size (p, &tw, &th);
       if (ifmt != fmt || tw != GST_VIDEO_INFO_WIDTH (&p->info) || th != GST_VIDEO_INFO_HEIGHT (&p->info)) {
@@ -599,6 +611,7 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
               ao.color_matrix = c->out_info.colorimetry.matrix;
             }
             p->conv = gstamd_video_converter_new (&ai, &ao, NULL, &status);
+            p->conv_out = ao;
           }
           if (!p->conv) {
             GST_ELEMENT_ERROR (c, STREAM, FORMAT, ("no HIP conversion for pad %s", GST_OBJECT_NAME (p)), ("%s", gstamd_last_error ()));
@@ -607,7 +620,7 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
           }
           memcpy (p->conv_key, key, sizeof (key));
         }
-        if (!ensure_device (&p->conv_buf, &p->conv_buf_size, (gsize) tw * th * 4) ||
+        if (!ensure_device (&p->conv_buf, &p->conv_buf_size, (gsize) p->conv_out.size) ||
             gstamd_video_converter_frame (p->conv, base, p->conv_buf, NULL) != GSTAMD_OK) {
           flow = GST_FLOW_ERROR;
           goto done_inputs;
@@ -615,13 +628,23 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
         desc[n_desc].data = p->conv_buf;
         desc[n_desc].width = tw;
         desc[n_desc].height = th;
-        desc[n_desc].stride = tw * 4;
+        desc[n_desc].stride = p->conv_out.stride[0];
+        memset (&fdesc[n_desc], 0, sizeof (fdesc[n_desc]));
+        for (k = 0; k < p->conv_out.n_planes && k < 3; k++) {
+          fdesc[n_desc].data[k] = (const guint8 *) p->conv_buf + p->conv_out.offset[k];
+          fdesc[n_desc].stride[k] = p->conv_out.stride[k];
+        }
       } else {
         vmeta = gst_buffer_get_video_meta (bufs[i]);
         desc[n_desc].data = base + (vmeta ? vmeta->offset[0] : GST_VIDEO_INFO_PLANE_OFFSET (&p->info, 0));
         desc[n_desc].width = GST_VIDEO_INFO_WIDTH (&p->info);
         desc[n_desc].height = GST_VIDEO_INFO_HEIGHT (&p->info);
         desc[n_desc].stride = vmeta ? vmeta->stride[0] : GST_VIDEO_INFO_PLANE_STRIDE (&p->info, 0);
+        memset (&fdesc[n_desc], 0, sizeof (fdesc[n_desc]));
+        for (k = 0; k < (gint) GST_VIDEO_INFO_N_PLANES (&p->info) && k < 3; k++) {
+          fdesc[n_desc].data[k] = base + (vmeta ? vmeta->offset[k] : GST_VIDEO_INFO_PLANE_OFFSET (&p->info, k));
+          fdesc[n_desc].stride[k] = vmeta ? vmeta->stride[k] : GST_VIDEO_INFO_PLANE_STRIDE (&p->info, k);
+        }
       }
     }
     desc[n_desc].xpos = p->xpos;
@@ -629,6 +652,12 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
     desc[n_desc].alpha = p->alpha;
     desc[n_desc].blend_mode = p->op;
     desc[n_desc].reserved = 0;
+    fdesc[n_desc].width = desc[n_desc].width;
+    fdesc[n_desc].height = desc[n_desc].height;
+    fdesc[n_desc].xpos = p->xpos;
+    fdesc[n_desc].ypos = p->ypos;
+    fdesc[n_desc].alpha = p->alpha;
+    fdesc[n_desc].blend_mode = p->op;
     n_desc++;
   }
 
@@ -650,8 +679,24 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
     }
     canvas = c->d_out;
   }
-  r = gstamd_compositor_aggregate (fmt, c->background, desc, (int) n_desc, canvas, GST_VIDEO_INFO_WIDTH (&c->out_info),
-      GST_VIDEO_INFO_HEIGHT (&c->out_info), GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, 0), NULL);
+  if (by_planes) {
+    /* black_color / white_color of the element (compositor.c:1131-1149): the range's offset and offset + scale */
+    const gboolean yuv = GST_VIDEO_INFO_IS_YUV (&c->out_info), full = c->out_info.colorimetry.range == GST_VIDEO_COLOR_RANGE_0_255;
+    const int32_t black[3] = { yuv && !full ? 16 : 0, yuv ? 128 : 0, yuv ? 128 : 0 };
+    const int32_t white[3] = { yuv && !full ? 235 : 255, yuv ? 128 : 255, yuv ? 128 : 255 };
+    void *dplanes[3] = { NULL, NULL, NULL };
+    int32_t dstrides[3] = { 0, 0, 0 };
+    gint k;
+    for (k = 0; k < (gint) GST_VIDEO_INFO_N_PLANES (&c->out_info) && k < 3; k++) {
+      dplanes[k] = (guint8 *) canvas + GST_VIDEO_INFO_PLANE_OFFSET (&c->out_info, k);
+      dstrides[k] = GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, k);
+    }
+    r = gstamd_compositor_aggregate_frame (fmt, c->background, black, white, fdesc, (int) n_desc, dplanes, dstrides,
+        GST_VIDEO_INFO_WIDTH (&c->out_info), GST_VIDEO_INFO_HEIGHT (&c->out_info), NULL);
+  } else {
+    r = gstamd_compositor_aggregate (fmt, c->background, desc, (int) n_desc, canvas, GST_VIDEO_INFO_WIDTH (&c->out_info),
+        GST_VIDEO_INFO_HEIGHT (&c->out_info), GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, 0), NULL);
+  }
   if (c->out_hip) {
     if (r == GSTAMD_OK)
       r = gstamd_stream_synchronize (NULL);     /* staged inputs are reused by the next frame */

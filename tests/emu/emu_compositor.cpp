@@ -40,3 +40,60 @@ extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int 
 }
 
 extern "C" int emu_sizeof_params (void) { return (int) sizeof (AggregateParams); }
+
+// ---- plane-by-plane aggregation (compositor_planes.h): the host rectangle arithmetic + k_aggregate_plane's grid
+#include "../../gstreamer_amd/csrc/compositor_planes.h"
+
+struct EmuFramePad {
+  const uint8_t *data[3];
+  int stride[3];
+  int width, height, xpos, ypos;
+  double alpha;
+  int mode;
+};
+
+extern "C" int emu_compositor_aggregate_frame (int format, int background, const int *black, const int *white, const EmuFramePad *pads, int n_pads,
+    uint8_t *const *dest, const int *dstride, int dw, int dh)
+{
+  const FormatDesc *f = format_desc (format);
+  PlaneGeom geom[3];
+  const int n_planes = compositor_plane_geometry (f, geom);
+  if (!n_planes)
+    return -1;
+  for (int pl = 0; pl < n_planes; pl++) {
+    PlaneJob job;
+    memset (&job, 0, sizeof (job));
+    job.dst = dest[pl];
+    job.dstride = dstride[pl];
+    job.wbytes = sub_scale (dw, geom[pl].w_sub) * geom[pl].px_bytes;
+    job.rows = sub_scale (dh, geom[pl].h_sub);
+    compositor_plane_background (f, geom[pl], pl, background, black, white, &job);
+    int done = 0;
+    bool first = true;
+    while (first || done < n_pads) {
+      job.n = 0;
+      while (done < n_pads && job.n < GSTAMD_PLANE_MAX_PADS) {
+        const EmuFramePad &in = pads[done++];
+        FramePad fp;
+        for (int k = 0; k < 3; k++) {
+          fp.data[k] = in.data[k];
+          fp.stride[k] = in.stride[k];
+        }
+        fp.width = in.width;
+        fp.height = in.height;
+        fp.xpos = in.xpos;
+        fp.ypos = in.ypos;
+        fp.alpha = in.alpha;
+        fp.mode = in.mode;
+        if (compositor_pad_rect (f, geom[pl], pl, fp, dw, dh, &job.r[job.n]))
+          job.n++;
+      }
+      for (int y = 0; y < job.rows; y++)
+        for (int x0 = 0; x0 < job.wbytes; x0 += 4)
+          plane_word_body (job, x0, y);
+      job.bg_kind = 2;
+      first = false;
+    }
+  }
+  return 0;
+}

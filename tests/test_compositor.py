@@ -233,3 +233,99 @@ def test_div255_identity_used_by_packed_blend():
     """compositor_device.h pk16_div255: (x*0x8081)>>23 == (x+1+((x+1)>>8))>>8 for every reachable x (<= 255*255)."""
     x = np.arange(0, 255 * 255 + 1, dtype=np.int64)
     assert np.array_equal((x * 0x8081) >> 23, (x + 1 + ((x + 1) >> 8)) >> 8)
+
+
+# ---- outputs without per-pixel alpha: plane-by-plane aggregation (compositor_planes.h) ---------------------------------------
+FRAME_FMTS = ["I420", "YV12", "Y42B", "Y444", "NV12", "NV21", "RGB", "BGR"]
+# (width, height, xpos, ypos, alpha, mode) per pad: odd positions (rounded up to even where the format subsamples), negative
+# offsets, a pad hanging over the right / bottom edge, opaque, `source`, transparent and tiny-alpha pads
+FRAME_PADS = [(64, 48, 5, 7, 0.5, 1), (37, 21, -9, -3, 0.3, 1), (40, 30, 70, 40, 1.0, 1), (33, 17, 20, 10, 0.7, 0),
+              (16, 16, 1, 30, 0.0, 1), (21, 9, 50, 3, 0.004, 1), (64, 48, 30, 20, 0.996, 1)]
+FDW, FDH = 101, 67
+
+
+class EmuFramePad(C.Structure):
+    _fields_ = [("data", C.c_void_p * 3), ("stride", C.c_int * 3), ("width", C.c_int), ("height", C.c_int), ("xpos", C.c_int),
+                ("ypos", C.c_int), ("alpha", C.c_double), ("mode", C.c_int)]
+
+
+def _frame_size(fmt, w, h):
+    return int(V.video_info(fmt, w, h).size)
+
+
+def _frame_inputs(fmt):
+    return [cases.frame_bytes(_frame_size(fmt, w, h), "random", 7000 + k) for k, (w, h, *_r) in enumerate(FRAME_PADS)]
+
+
+def _frame_expected(ref, fmt, background):
+    """_draw_background + the reference's BlendFunction pad by pad (compositor.c:1619-1697)."""
+    dst = cases.frame_bytes(_frame_size(fmt, FDW, FDH), "random", 6999)           # stale canvas: every byte must be rewritten
+    low = fmt.lower()
+    if background == 0:
+        ref.compositor_fill(0, low, fmt, dst, FDW, FDH, 0, FDH)
+    elif background == 3:
+        strides, offsets = cases.default_layout(fmt, FDW, FDH)
+        for i, (rb, rows) in enumerate(cases.visible_planes(fmt, FDW, FDH)):
+            plane = dst[offsets[i]:offsets[i] + strides[i] * rows].reshape(rows, strides[i])
+            plane[:, :rb] = 0
+    else:
+        yuv = fmt not in ("RGB", "BGR")
+        c = ((16, 128, 128) if yuv else (0, 0, 0)) if background == 1 else ((235, 128, 128) if yuv else (255, 255, 255))
+        ref.compositor_fill(1, low, fmt, dst, FDW, FDH, 0, FDH, *c)
+    func = {"YV12": "blend_i420", "BGR": "blend_rgb"}.get(fmt, "blend_" + low)
+    for src, (w, h, x, y, alpha, mode) in zip(_frame_inputs(fmt), FRAME_PADS):
+        ref.compositor_blend(func, fmt, src, w, h, x, y, alpha, dst, FDW, FDH, 0, FDH, mode)
+    return dst
+
+
+def _visible(fmt, buf):
+    strides, offsets = cases.default_layout(fmt, FDW, FDH)
+    return cases.visible_bytes(fmt, FDW, FDH, strides, offsets, buf)
+
+
+@pytest.mark.parametrize("background", [0, 1, 2, 3])
+@pytest.mark.parametrize("fmt", FRAME_FMTS)
+def test_aggregate_frame_on_host_matches_reference(emu_lib, ref, fmt, background):
+    srcs = _frame_inputs(fmt)
+    pads = (EmuFramePad * len(FRAME_PADS))()
+    for k, (w, h, x, y, alpha, mode) in enumerate(FRAME_PADS):
+        strides, offsets = cases.default_layout(fmt, w, h)
+        for i in range(len(strides)):
+            pads[k].data[i] = srcs[k].ctypes.data + offsets[i]
+            pads[k].stride[i] = strides[i]
+        pads[k].width, pads[k].height, pads[k].xpos, pads[k].ypos, pads[k].alpha, pads[k].mode = w, h, x, y, alpha, mode
+    dst = cases.frame_bytes(_frame_size(fmt, FDW, FDH), "random", 6999)
+    strides, offsets = cases.default_layout(fmt, FDW, FDH)
+    dp = (C.c_void_p * 3)(*[dst.ctypes.data + o for o in offsets] + [None] * (3 - len(offsets)))
+    ds = (C.c_int * 3)(*strides + [0] * (3 - len(strides)))
+    yuv = fmt not in ("RGB", "BGR")
+    black = (C.c_int * 3)(*((16, 128, 128) if yuv else (0, 0, 0)))
+    white = (C.c_int * 3)(*((235, 128, 128) if yuv else (255, 255, 255)))
+    emu_lib.emu_compositor_aggregate_frame.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                       C.c_int, C.c_int]
+    assert emu_lib.emu_compositor_aggregate_frame(V.FORMATS[fmt], background, black, white, pads, len(FRAME_PADS), dp, ds, FDW, FDH) == 0
+    exp = _frame_expected(ref, fmt, background)
+    assert (_visible(fmt, dst) == _visible(fmt, exp)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("background", [0, 1, 2, 3])
+@pytest.mark.parametrize("fmt", FRAME_FMTS)
+def test_hip_aggregate_frame_matches_reference(native_lib, gpu, ref, fmt, background):
+    import torch
+    srcs = [torch.from_numpy(s).to(gpu) for s in _frame_inputs(fmt)]
+    pads = (V.CompositorFramePad * len(FRAME_PADS))()
+    for k, (w, h, x, y, alpha, mode) in enumerate(FRAME_PADS):
+        strides, offsets = cases.default_layout(fmt, w, h)
+        for i in range(len(strides)):
+            pads[k].data[i] = srcs[k].data_ptr() + offsets[i]
+            pads[k].stride[i] = strides[i]
+        pads[k].width, pads[k].height, pads[k].xpos, pads[k].ypos, pads[k].alpha, pads[k].blend_mode = w, h, x, y, alpha, mode
+    d = torch.from_numpy(cases.frame_bytes(_frame_size(fmt, FDW, FDH), "random", 6999)).to(gpu)
+    strides, offsets = cases.default_layout(fmt, FDW, FDH)
+    dp = (C.c_void_p * 3)(*[d.data_ptr() + o for o in offsets] + [None] * (3 - len(offsets)))
+    ds = (C.c_int32 * 3)(*strides + [0] * (3 - len(strides)))
+    V._check(V.lib().gstamd_compositor_aggregate_frame(V.FORMATS[fmt], background, None, None, pads, len(FRAME_PADS), dp, ds, FDW, FDH, None))
+    torch.cuda.synchronize()
+    exp = _frame_expected(ref, fmt, background)
+    assert (_visible(fmt, d.cpu().numpy()) == _visible(fmt, exp)).all()

@@ -274,3 +274,31 @@ def test_audioresample_element_non_interleaved_layout(gst_env, ref):
     exp = np.concatenate(exp)
     assert out.shape == exp.shape, (out.shape, exp.shape)
     assert (out == exp).all(), int(np.argmax(out != exp))
+
+
+def test_compositor_element_i420_and_nv12_output(gst_env, ref):
+    """Outputs without per-pixel alpha are aggregated plane by plane: an I420 canvas from an I420 pad (odd position: rounded up to
+    even) and a BGRA pad converted to I420 by its pad converter; then an NV12 canvas over the checker background."""
+    env, tmp = gst_env
+    n, dw, dh = 2, 320, 240
+    for ofmt, bg, bgkind in (("I420", "black", 1), ("NV12", "checker", 0)):
+        f0, f1, fout = tmp / ("p0_%s.yuv" % ofmt), tmp / ("p1_%s.bgra" % ofmt), tmp / ("pout_%s.yuv" % ofmt)
+        launch(env, "compositor name=c background=%s sink_0::xpos=11 sink_0::ypos=21 sink_0::alpha=0.6 sink_1::xpos=150 sink_1::ypos=100 sink_1::alpha=0.7 "
+                    "! video/x-raw,format=%s,width=%d,height=%d,colorimetry=bt601,chroma-site=jpeg ! filesink location=%s "
+                    "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=%s,width=160,height=120,framerate=30/1,colorimetry=bt601,chroma-site=jpeg ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
+                    "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=BGRA,width=128,height=96,framerate=30/1 ! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1"
+               % (bg, ofmt, dw, dh, fout, n, ofmt, f0, n, f1))
+        out = np.fromfile(fout, np.uint8).reshape(n, -1)
+        s0 = np.fromfile(f0, np.uint8).reshape(n, -1)
+        s1 = np.fromfile(f1, np.uint8).reshape(n, -1)
+        c1 = ref.VideoConverter("BGRA", 128, 96, ofmt, 128, 96, out_colorimetry="bt601", out_chroma_site="jpeg")
+        low = ofmt.lower()
+        for f in range(n):
+            canvas = np.zeros(out.shape[1], np.uint8)
+            if bgkind == 0:
+                ref.compositor_fill(0, low, ofmt, canvas, dw, dh, 0, dh)
+            else:
+                ref.compositor_fill(1, low, ofmt, canvas, dw, dh, 0, dh, 16, 128, 128)
+            ref.compositor_blend("blend_" + low, ofmt, s0[f], 160, 120, 11, 21, 0.6, canvas, dw, dh, 0, dh, 1)
+            ref.compositor_blend("blend_" + low, ofmt, c1.frame(s1[f]), 128, 96, 150, 100, 0.7, canvas, dw, dh, 0, dh, 1)
+            assert (canvas == out[f]).all(), (ofmt, f, int((canvas != out[f]).sum()))

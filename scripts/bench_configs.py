@@ -172,6 +172,9 @@ def main():
     video_case("C3: 7680x4320 I420 -> 1920x1080 RGBA, Lanczos", "I420", 7680, 4320, "RGBA", 1920, 1080, cases.LAN, a.iters, cpu=a.cpu, cpu_frames=1)
     video_case("C5 (per GPU): 7680x4320 NV12 -> 3840x2160 BGRA, bilinear", "NV12", 7680, 4320, "BGRA", 3840, 2160, cases.LIN, a.iters, cpu=a.cpu, cpu_frames=2)
     video_case("8K same-size: 7680x4320 NV12 -> BGRA", "NV12", 7680, 4320, "BGRA", 7680, 4320, {}, a.iters, cpu=False)
+    video_case("encoder feed: 3840x2160 BGRA -> NV12", "BGRA", 3840, 2160, "NV12", 3840, 2160, {}, a.iters, cpu=a.cpu, cpu_frames=3)
+    video_case("inference feed: 3840x2160 NV12 -> RGB (24-bit)", "NV12", 3840, 2160, "RGB", 3840, 2160, {}, a.iters, cpu=False)
+    video_case("capture: 1920x1080 YUY2 -> BGRA", "YUY2", 1920, 1080, "BGRA", 1920, 1080, {}, a.iters * 2, cpu=False)
     compositor_case(a.iters, cpu=a.cpu)
     audio_case(max(3, a.iters // 3), cpu=a.cpu)
 

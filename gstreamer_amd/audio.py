@@ -32,6 +32,7 @@ def lib():
                                                  C.POINTER(ResamplerOptions), C.POINTER(C.c_int)]
         L.gstamd_audio_resampler_free.argtypes = [C.c_void_p]
         L.gstamd_audio_resampler_reset.argtypes = [C.c_void_p]
+        L.gstamd_audio_resampler_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(ResamplerOptions)]
         for n in ("get_out_frames", "get_in_frames"):
             f = getattr(L, "gstamd_audio_resampler_" + n)
             f.restype = C.c_size_t
@@ -90,6 +91,10 @@ class AudioResampler:
         ia = (C.c_void_p * len(src_planes))(*[_v._ptr(p) for p in src_planes]) if src_planes is not None else None
         oa = (C.c_void_p * len(dst_planes))(*[_v._ptr(p) for p in dst_planes])
         _v._check(lib().gstamd_audio_resampler_resample_planes(self._h, ia, in_frames, oa, out_frames, stream))
+
+    def update(self, in_rate=0, out_rate=0, opts=None):
+        """gst_audio_resampler_update (resampler, in_rate, out_rate, options); opts None keeps the previous filter design."""
+        _v._check(lib().gstamd_audio_resampler_update(self._h, in_rate, out_rate, C.byref(opts) if opts is not None else None))
 
     def reset(self):
         lib().gstamd_audio_resampler_reset(self._h)

@@ -208,6 +208,57 @@ void gstamd_audio_resampler_reset (GstAmdAudioResampler *r)
   }
 }
 
+/* gst_audio_resampler_update (audio-resampler.c:1503-1614).  Rare and synchronous: the device is drained, the filter
+ * table is replaced and, when the tap count changed, the few history frames are shifted on a host copy. */
+int gstamd_audio_resampler_update (GstAmdAudioResampler *r, int in_rate, int out_rate, const GstAmdAudioResamplerOptions *options)
+{
+  if (!r)
+    return GSTAMD_ERR_INVALID;
+  std::lock_guard<std::mutex> g (r->lock);
+  AudioPlan plan = r->plan;
+  AudioState st = r->st;
+  const size_t old_avail = st.samples_avail + (size_t) st.samp_index;
+  AudioHistoryShift shift;
+  std::string err;
+  int e = audio_update (&plan, &st, in_rate, out_rate, options, &shift, &err);
+  if (e != GSTAMD_OK) {
+    g_audio_error = err;
+    return e;
+  }
+  const bool new_table = plan.table != r->plan.table;
+  r->plan = std::move (plan);
+  r->st = st;
+  if (!r->device_ready)
+    return GSTAMD_OK;
+  if (hipDeviceSynchronize () != hipSuccess)
+    return GSTAMD_ERR_HIP;
+  if (new_table) {
+    if (r->table_dev)
+      (void) hipFree (r->table_dev);
+    r->table_dev = nullptr;
+    if (!r->plan.table.empty ()) {
+      if (hipMalloc (&r->table_dev, r->plan.table.size ()) != hipSuccess)
+        return GSTAMD_ERR_HIP;
+      if (hipMemcpy (r->table_dev, r->plan.table.data (), r->plan.table.size (), hipMemcpyHostToDevice) != hipSuccess)
+        return GSTAMD_ERR_HIP;
+    }
+  }
+  if (shift.changed) {
+    const size_t fbytes = (size_t) r->plan.bps * r->plan.channels;
+    const size_t have = old_avail < r->hist_cap[r->cur] ? old_avail : r->hist_cap[r->cur];
+    std::vector<uint8_t> h (have * fbytes);
+    if (have && hipMemcpy (h.data (), r->hist[r->cur], h.size (), hipMemcpyDeviceToHost) != hipSuccess)
+      return GSTAMD_ERR_HIP;
+    audio_history_shift (shift, fbytes, &h);
+    e = ensure_hist (r, r->cur, h.size () / fbytes + 64);
+    if (e != GSTAMD_OK)
+      return e;
+    if (!h.empty () && hipMemcpy (r->hist[r->cur], h.data (), h.size (), hipMemcpyHostToDevice) != hipSuccess)
+      return GSTAMD_ERR_HIP;
+  }
+  return GSTAMD_OK;
+}
+
 size_t gstamd_audio_resampler_get_out_frames (GstAmdAudioResampler *r, size_t in_frames)
 {
   return r ? audio_get_out_frames (r->plan, r->st, in_frames) : 0;

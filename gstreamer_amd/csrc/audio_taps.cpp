@@ -319,56 +319,25 @@ static void build_table (AudioPlan &p)
   }
 }
 
-int plan_audio_resampler (int method, int flags, int format, int channels, int in_rate, int out_rate,
-    const GstAmdAudioResamplerOptions *options_in, AudioPlan *p, std::string *error)
+static void rebuild_table (AudioPlan *p)
+{
+  switch (p->format) {
+    case GSTAMD_AUDIO_FORMAT_S16: build_table<int16_t> (*p); break;
+    case GSTAMD_AUDIO_FORMAT_S32: build_table<int32_t> (*p); break;
+    case GSTAMD_AUDIO_FORMAT_F32: build_table<float> (*p); break;
+    default: build_table<double> (*p); break;
+  }
+}
+
+// resampler_calculate_taps (audio-resampler.c:1063-1208) for the rates, method and format already in *p, then the table
+static int design_filter (AudioPlan *p, const GstAmdAudioResamplerOptions &o, std::string *error)
 {
   auto fail = [&](int code, const char *msg) {
     if (error)
       *error = msg;
     return code;
   };
-  if (method < 0 || method > 4 || format < 0 || format > 3 || channels <= 0 || in_rate <= 0 || out_rate <= 0)
-    return fail (GSTAMD_ERR_INVALID, "bad resampler arguments");
-  GstAmdAudioResamplerOptions o;
-  if (options_in)
-    o = *options_in;
-  else {                      /* gst_audio_resampler_new with NULL options (:1414-1419) */
-    audio_options_init (&o);
-    audio_options_set_quality (GSTAMD_AUDIO_RESAMPLER_METHOD_KAISER, DEFAULT_QUALITY, in_rate, out_rate, &o);
-  }
-  p->method = method;
-  p->format = format;
-  p->channels = channels;
-  p->bps = format == GSTAMD_AUDIO_FORMAT_S16 ? 2 : (format == GSTAMD_AUDIO_FORMAT_F64 ? 8 : 4);
-  p->variable_rate = (flags & 4) != 0;
-  p->in_planar = (flags & 1) != 0;
-  p->out_planar = (flags & 2) != 0;
-
-  /* gst_audio_resampler_update (:1503-1560): reduce the rates; samp_phase is 0 for a new resampler.
-   * NB the reference reads max-phase-error from resampler->options, which is still NULL here, so the
-   * default 0.1 applies on creation whatever the caller passed. */
-  int gcd = gcd_int (in_rate, out_rate);
-  const double max_error = 0.1;
-  const int samp_phase = 0;
-  if (max_error < 1.0e-8) {
-    gcd = gcd_int (gcd, samp_phase);
-  } else {
-    while (gcd > 1) {
-      double ph1 = (double) samp_phase / out_rate;
-      int factor = 2;
-      double ph2 = (double) (samp_phase / gcd) / (out_rate / gcd);
-      if (fabs (ph1 - ph2) < max_error)
-        break;
-      while (gcd % factor != 0)
-        factor++;
-      gcd /= factor;
-    }
-  }
-  p->in_rate = in_rate / gcd;
-  p->out_rate = out_rate / gcd;
-  p->samp_inc = p->in_rate / p->out_rate;
-  p->samp_frac = p->in_rate % p->out_rate;
-
+  const int method = p->method;
   /* resampler_calculate_taps (:1063-1208) */
   bool scale = true, sinc_table = false;
   p->cutoff = 0;
@@ -467,14 +436,137 @@ int plan_audio_resampler (int method, int flags, int format, int channels, int i
   if (oversample < 1)
     return fail (GSTAMD_ERR_INVALID, "bad filter-oversample");
   p->n_phases = p->out_rate;
+  rebuild_table (p);
+  return GSTAMD_OK;
+}
 
-  switch (format) {
-    case GSTAMD_AUDIO_FORMAT_S16: build_table<int16_t> (*p); break;
-    case GSTAMD_AUDIO_FORMAT_S32: build_table<int32_t> (*p); break;
-    case GSTAMD_AUDIO_FORMAT_F32: build_table<float> (*p); break;
-    default: build_table<double> (*p); break;
+/* the rate part of gst_audio_resampler_update (audio-resampler.c:1527-1560): the common divisor of the two rates is
+ * taken out as far as the rescaled phase stays within max_error of where it was */
+static void reduce_rates (AudioPlan *p, int in_rate, int out_rate, double max_error, long long *samp_phase_io)
+{
+  int samp_phase = (int) *samp_phase_io;
+  int gcd = gcd_int (in_rate, out_rate);
+  if (max_error < 1.0e-8) {
+    gcd = gcd_int (gcd, samp_phase);
+  } else {
+    while (gcd > 1) {
+      double ph1 = (double) samp_phase / out_rate;
+      int factor = 2;
+      double ph2 = (double) (samp_phase / gcd) / (out_rate / gcd);
+      if (fabs (ph1 - ph2) < max_error)
+        break;
+      while (gcd % factor != 0)
+        factor++;
+      gcd /= factor;
+    }
+  }
+  *samp_phase_io = samp_phase / gcd;
+  p->in_rate = in_rate / gcd;
+  p->out_rate = out_rate / gcd;
+  p->samp_inc = p->in_rate / p->out_rate;
+  p->samp_frac = p->in_rate % p->out_rate;
+}
+
+int plan_audio_resampler (int method, int flags, int format, int channels, int in_rate, int out_rate,
+    const GstAmdAudioResamplerOptions *options_in, AudioPlan *p, std::string *error)
+{
+  auto fail = [&](int code, const char *msg) {
+    if (error)
+      *error = msg;
+    return code;
+  };
+  if (method < 0 || method > 4 || format < 0 || format > 3 || channels <= 0 || in_rate <= 0 || out_rate <= 0)
+    return fail (GSTAMD_ERR_INVALID, "bad resampler arguments");
+  GstAmdAudioResamplerOptions o;
+  if (options_in)
+    o = *options_in;
+  else {                      /* gst_audio_resampler_new with NULL options (:1414-1419) */
+    audio_options_init (&o);
+    audio_options_set_quality (GSTAMD_AUDIO_RESAMPLER_METHOD_KAISER, DEFAULT_QUALITY, in_rate, out_rate, &o);
+  }
+  p->method = method;
+  p->format = format;
+  p->channels = channels;
+  p->bps = format == GSTAMD_AUDIO_FORMAT_S16 ? 2 : (format == GSTAMD_AUDIO_FORMAT_F64 ? 8 : 4);
+  p->variable_rate = (flags & 4) != 0;
+  p->in_planar = (flags & 1) != 0;
+  p->out_planar = (flags & 2) != 0;
+
+  /* gst_audio_resampler_update (:1503-1560): reduce the rates; samp_phase is 0 for a new resampler.
+   * NB the reference reads max-phase-error from resampler->options, which is still NULL here, so the
+   * default 0.1 applies on creation whatever the caller passed. */
+  long long samp_phase = 0;
+  reduce_rates (p, in_rate, out_rate, 0.1, &samp_phase);
+
+  p->max_phase_error = is_set (o.max_phase_error) ? o.max_phase_error : 0.1;      /* what a later update () reads back from the options */
+  return design_filter (p, o, error);
+}
+
+/* gst_audio_resampler_update (audio-resampler.c:1503-1614) on an existing stream.  Rates <= 0 keep the (reduced) current
+ * ones.  With options the filter is designed again for the new rates and, when the tap count changes, the history is
+ * shifted by half the difference (*shift says how); without options the reference keeps the OLD filter design (cutoff,
+ * tap count, oversampled prototype - even when the ratio now calls for another one) and only re-derives the per-phase
+ * rows for the new number of phases. */
+int audio_update (AudioPlan *p, AudioState *st, int in_rate, int out_rate, const GstAmdAudioResamplerOptions *options,
+    AudioHistoryShift *shift, std::string *error)
+{
+  memset (shift, 0, sizeof (*shift));
+  if (in_rate <= 0)
+    in_rate = p->in_rate;
+  if (out_rate <= 0)
+    out_rate = p->out_rate;
+  /* gst_util_uint64_scale_int (samp_phase, out_rate, old out_rate) */
+  long long samp_phase = p->out_rate > 0 ? (long long) (((unsigned __int128) (uint64_t) st->samp_phase * (uint64_t) out_rate) / (uint64_t) p->out_rate) : 0;
+  reduce_rates (p, in_rate, out_rate, p->max_phase_error, &samp_phase);
+  st->samp_phase = samp_phase;
+  if (options) {
+    const int old_n_taps = p->n_taps;
+    p->max_phase_error = is_set (options->max_phase_error) ? options->max_phase_error : 0.1;
+    int e = design_filter (p, *options, error);
+    if (e != GSTAMD_OK)
+      return e;
+    if (old_n_taps > 0 && old_n_taps != p->n_taps) {
+      const long long diff = ((long long) p->n_taps - old_n_taps) / 2;
+      long long frames = (long long) st->samples_avail, soff = st->samp_index, doff = st->samp_index;
+      if (diff < 0) {
+        soff += -diff;
+        frames -= -diff;
+      } else {
+        doff += diff;
+      }
+      shift->changed = true;
+      shift->src_off = soff;
+      shift->dst_off = doff;
+      shift->frames = frames > 0 ? frames : 0;
+      st->samples_avail = (size_t) ((long long) st->samples_avail + diff > 0 ? (long long) st->samples_avail + diff : 0);
+    }
+  } else if (p->filter_mode == GSTAMD_AUDIO_FILTER_MODE_FULL) {
+    p->n_phases = p->out_rate;
+    rebuild_table (p);
   }
   return GSTAMD_OK;
+}
+
+/* the memmove of gst_audio_resampler_update (:1592-1593) on a host copy of the interleaved history; frames the old buffer
+ * did not hold read as silence (the reference's buffers are zero-initialised, get_sample_bufs :1439) */
+void audio_history_shift (const AudioHistoryShift &s, size_t frame_bytes, std::vector<uint8_t> *hist)
+{
+  if (!s.changed)
+    return;
+  const size_t old_frames = hist->size () / frame_bytes;
+  std::vector<uint8_t> n (*hist);
+  const size_t need = (size_t) (s.dst_off + s.frames);
+  if (n.size () < need * frame_bytes)
+    n.resize (need * frame_bytes, 0);
+  for (long long i = 0; i < s.frames; i++) {
+    const size_t si = (size_t) (s.src_off + i);
+    uint8_t *d = &n[(size_t) (s.dst_off + i) * frame_bytes];
+    if (si < old_frames)
+      memcpy (d, hist->data () + si * frame_bytes, frame_bytes);
+    else
+      memset (d, 0, frame_bytes);
+  }
+  hist->swap (n);
 }
 
 /* gst_audio_resampler_reset (audio-resampler.c:1466-1488) */

@@ -18,6 +18,7 @@ struct AudioPlan {
   int n_taps, oversample;
   int filter_mode, filter_interpolation;
   double cutoff, kaiser_beta, b, c;
+  double max_phase_error;         // GstAudioResampler.max-phase-error of the stored options (read by the next update)
   int n_phases;                   // == out_rate in FULL mode
   int taps_stride;                // elements per table row (n_taps rounded up to 4, zero padded)
   std::vector<uint8_t> table;     // [n_phases][taps_stride] in the sample format
@@ -42,7 +43,16 @@ struct AudioStep {
   long long src_start, moved, keep;
 };
 
+// history move of gst_audio_resampler_update when the tap count changes (audio-resampler.c:1572-1596), in frames
+struct AudioHistoryShift {
+  bool changed;
+  long long src_off, dst_off, frames;
+};
+
 void audio_state_reset (const AudioPlan &plan, AudioState *st);
+int audio_update (AudioPlan *plan, AudioState *st, int in_rate, int out_rate, const GstAmdAudioResamplerOptions *options,
+    AudioHistoryShift *shift, std::string *error);
+void audio_history_shift (const AudioHistoryShift &shift, size_t frame_bytes, std::vector<uint8_t> *hist);
 AudioStep audio_step (const AudioPlan &plan, AudioState *st, size_t in_frames, size_t out_frames);
 size_t audio_get_out_frames (const AudioPlan &plan, const AudioState &st, size_t in_frames);
 size_t audio_get_in_frames (const AudioPlan &plan, const AudioState &st, size_t out_frames);

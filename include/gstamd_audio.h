@@ -73,6 +73,12 @@ GstAmdAudioResampler *gstamd_audio_resampler_new (int method, int flags, int for
     int out_rate, const GstAmdAudioResamplerOptions *options, int *status);
 void gstamd_audio_resampler_free (GstAmdAudioResampler *resampler);
 void gstamd_audio_resampler_reset (GstAmdAudioResampler *resampler);
+/* gst_audio_resampler_update (audio-resampler.h:231, audio-resampler.c:1503-1614): new rates (<= 0: unchanged) and / or new
+ * options on a running stream; the phase is rescaled, and when the tap count changes the history moves by half the difference.
+ * options == NULL keeps the previous filter design, as the reference does.  Returns GSTAMD_OK (the reference's TRUE) or an
+ * error with the resampler left as it was. */
+int gstamd_audio_resampler_update (GstAmdAudioResampler *resampler, int in_rate, int out_rate,
+    const GstAmdAudioResamplerOptions *options);
 size_t gstamd_audio_resampler_get_out_frames (GstAmdAudioResampler *resampler, size_t in_frames);
 size_t gstamd_audio_resampler_get_in_frames (GstAmdAudioResampler *resampler, size_t out_frames);
 size_t gstamd_audio_resampler_get_max_latency (GstAmdAudioResampler *resampler);

@@ -53,6 +53,7 @@ def lib():
         L.ref_audio_resampler_resample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.ref_audio_resampler_resample_planar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ref_audio_resampler_reset.argtypes = [C.c_void_p]
+        L.ref_audio_resampler_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
         L.ref_audio_resampler_free.argtypes = [C.c_void_p]
         L.ref_init()
         _lib = L
@@ -169,6 +170,7 @@ class AudioResampler:
         self.channels = channels
         self.in_planar, self.out_planar = in_planar, out_planar
         self.fmt = fmt
+        self.method = self.METHODS[method]
         self.dtype = {"F32LE": np.float32, "F64LE": np.float64, "S16LE": np.int16, "S32LE": np.int32}[fmt]
         lib().ref_audio_resampler_set_filter(-1 if filter_mode is None else self.FILTER_MODE[filter_mode],
                                               -1 if filter_interpolation is None else self.FILTER_INTERPOLATION[filter_interpolation])
@@ -205,6 +207,19 @@ class AudioResampler:
         lib().ref_audio_resampler_resample(self.h, data.ctypes.data if data is not None else None, in_frames,
                                            out.ctypes.data, out_frames)
         return out
+
+    def update(self, in_rate=0, out_rate=0, quality=None, filter_mode=None, filter_interpolation=None, with_options=None,
+               q_rates=None):
+        """gst_audio_resampler_update: quality / filter_* given -> new options (set_quality for q_rates), else NULL options."""
+        if with_options is None:
+            with_options = quality is not None or filter_mode is not None or filter_interpolation is not None
+        qi, qo = q_rates if q_rates else (in_rate, out_rate)
+        lib().ref_audio_resampler_set_filter(-1 if filter_mode is None else self.FILTER_MODE[filter_mode],
+                                              -1 if filter_interpolation is None else self.FILTER_INTERPOLATION[filter_interpolation])
+        ok = lib().ref_audio_resampler_update(self.h, in_rate, out_rate, int(bool(with_options)), self.method,
+                                              -1 if quality is None else quality, qi, qo, None)
+        lib().ref_audio_resampler_set_filter(-1, -1)
+        return bool(ok)
 
     def reset(self):
         lib().ref_audio_resampler_reset(self.h)

@@ -396,6 +396,35 @@ ref_audio_resampler_new (int method, int flags, const char *format, int channels
   }
 }
 
+/* gst_audio_resampler_update (audio-resampler.c:1503): with_options 0 passes NULL (keep the previous options), else an
+ * options structure built like ref_audio_resampler_new builds it (quality for the rates given, plus the set_filter enums) */
+int
+ref_audio_resampler_update (void *r, int in_rate, int out_rate, int with_options, int method, int quality,
+    int q_in_rate, int q_out_rate, const char *options)
+{
+  GstStructure *s = NULL;
+  gboolean ok;
+  if (with_options) {
+    if (options && *options)
+      s = gst_structure_from_string (options, NULL);
+    else
+      s = gst_structure_new_empty ("GstAudioResampler");
+    if (!s)
+      return 0;
+    if (quality >= 0)
+      gst_audio_resampler_options_set_quality ((GstAudioResamplerMethod) method, quality, q_in_rate, q_out_rate, s);
+    if (ref_filter_mode >= 0)
+      gst_structure_set (s, GST_AUDIO_RESAMPLER_OPT_FILTER_MODE, GST_TYPE_AUDIO_RESAMPLER_FILTER_MODE, ref_filter_mode, NULL);
+    if (ref_filter_interpolation >= 0)
+      gst_structure_set (s, GST_AUDIO_RESAMPLER_OPT_FILTER_INTERPOLATION, GST_TYPE_AUDIO_RESAMPLER_FILTER_INTERPOLATION,
+          ref_filter_interpolation, NULL);
+  }
+  ok = gst_audio_resampler_update (r, in_rate, out_rate, s);
+  if (s)
+    gst_structure_free (s);
+  return ok;
+}
+
 gsize
 ref_audio_resampler_get_out_frames (void *r, gsize in_frames)
 {

@@ -32,6 +32,7 @@ typedef struct {
   guint sinc_filter_auto_threshold;                      /* sinc-filter-auto-threshold (1 MiB) */
   GstAudioInfo in, out;
   GstAmdAudioResampler *r;
+  gint r_method;                                         /* the method s->r was made with */
   gpointer d_in, d_out;
   gsize d_in_size, d_out_size;
   guint64 samples_out;
@@ -119,6 +120,8 @@ amd_format (const GstAudioInfo * i)
   }
 }
 
+static void amd_ar_drain (GstAmdAudioResample * s);
+
 static gboolean
 amd_ar_set_caps (GstBaseTransform * t, GstCaps * incaps, GstCaps * outcaps)
 {
@@ -126,28 +129,56 @@ amd_ar_set_caps (GstBaseTransform * t, GstCaps * incaps, GstCaps * outcaps)
   GstAmdAudioResamplerOptions o;
   int status = 0;
 
-  if (!gst_audio_info_from_caps (&s->in, incaps) || !gst_audio_info_from_caps (&s->out, outcaps))
+  GstAudioInfo in, out;
+  gboolean same_stream;
+
+  if (!gst_audio_info_from_caps (&in, incaps) || !gst_audio_info_from_caps (&out, outcaps))
     return FALSE;
-  if (amd_format (&s->in) < 0 || GST_AUDIO_INFO_FORMAT (&s->in) != GST_AUDIO_INFO_FORMAT (&s->out) ||
-      GST_AUDIO_INFO_CHANNELS (&s->in) != GST_AUDIO_INFO_CHANNELS (&s->out) || GST_AUDIO_INFO_LAYOUT (&s->in) != GST_AUDIO_INFO_LAYOUT (&s->out))
+  if (amd_format (&in) < 0 || GST_AUDIO_INFO_FORMAT (&in) != GST_AUDIO_INFO_FORMAT (&out) ||
+      GST_AUDIO_INFO_CHANNELS (&in) != GST_AUDIO_INFO_CHANNELS (&out) || GST_AUDIO_INFO_LAYOUT (&in) != GST_AUDIO_INFO_LAYOUT (&out))
     return FALSE;
-  if (s->r)
-    gstamd_audio_resampler_free (s->r);
+  /* gst_audio_resample_update_state (gstaudioresample.c:398-446): a change of format, channels or layout destroys the
+   * resampler; a change of rates only goes through gst_audio_resampler_update with freshly made options, so the
+   * stream keeps its history and phase */
+  same_stream = s->r != NULL && GST_AUDIO_INFO_FORMAT (&in) == GST_AUDIO_INFO_FORMAT (&s->in) &&
+      GST_AUDIO_INFO_CHANNELS (&in) == GST_AUDIO_INFO_CHANNELS (&s->in) && GST_AUDIO_INFO_LAYOUT (&in) == GST_AUDIO_INFO_LAYOUT (&s->in);
+  /* gst_audio_resample_set_caps (gstaudioresample.c:519-538): a change of either side drains the old stream with its own caps,
+   * resets the history and restarts the timestamp tracking */
+  if (s->r && (!gst_audio_info_is_equal (&in, &s->in) || !gst_audio_info_is_equal (&out, &s->out))) {
+    amd_ar_drain (s);
+    gstamd_audio_resampler_reset (s->r);
+    s->samples_out = 0;
+    s->t0 = GST_CLOCK_TIME_NONE;
+  }
+  s->in = in;
+  s->out = out;
   gstamd_audio_resampler_options_init (&o);
   gstamd_audio_resampler_options_set_quality (s->method, (unsigned) s->quality, GST_AUDIO_INFO_RATE (&s->in),
       GST_AUDIO_INFO_RATE (&s->out), &o);
-  /* gst_audio_resample_update_state (gstaudioresample.c:~370): the three sinc-filter-* properties go into the options */
+  /* make_options (gstaudioresample.c:374-395): the three sinc-filter-* properties go into the options */
   o.filter_mode = s->sinc_filter_mode;
   o.filter_mode_threshold = (int32_t) s->sinc_filter_auto_threshold;
   o.filter_interpolation = s->sinc_filter_interpolation;
+  if (same_stream && s->r_method == s->method) {
+    status = gstamd_audio_resampler_update (s->r, GST_AUDIO_INFO_RATE (&s->in), GST_AUDIO_INFO_RATE (&s->out), &o);
+    if (status != 0) {
+      GST_ERROR_OBJECT (s, "failed to update resampler (status %d)", status);
+      return FALSE;
+    }
+    return TRUE;
+  }
+  if (s->r)
+    gstamd_audio_resampler_free (s->r);
   /* non-interleaved buffers hold their planes back to back, one buffer's frames apart (gstaudioresample.c:~960 builds the plane
-   * pointers the same way); GST_AUDIO_RESAMPLER_FLAG_NON_INTERLEAVED_IN | _OUT */
-  s->r = gstamd_audio_resampler_new (s->method, GST_AUDIO_INFO_LAYOUT (&s->in) == GST_AUDIO_LAYOUT_NON_INTERLEAVED ? 3 : 0, amd_format (&s->in), GST_AUDIO_INFO_CHANNELS (&s->in),
+   * pointers the same way); GST_AUDIO_RESAMPLER_FLAG_NON_INTERLEAVED_IN | _OUT, and _VARIABLE_RATE as the element's converter
+   * is made with GST_AUDIO_CONVERTER_FLAG_VARIABLE_RATE (gstaudioresample.c:422, audio-converter.c:929) */
+  s->r = gstamd_audio_resampler_new (s->method, (GST_AUDIO_INFO_LAYOUT (&s->in) == GST_AUDIO_LAYOUT_NON_INTERLEAVED ? 3 : 0) | 4, amd_format (&s->in), GST_AUDIO_INFO_CHANNELS (&s->in),
       GST_AUDIO_INFO_RATE (&s->in), GST_AUDIO_INFO_RATE (&s->out), &o, &status);
   if (!s->r) {
     GST_ERROR_OBJECT (s, "HIP resampler refused this configuration (status %d)", status);
     return FALSE;
   }
+  s->r_method = s->method;
   s->samples_out = 0;
   s->t0 = GST_CLOCK_TIME_NONE;
   return TRUE;

@@ -397,6 +397,35 @@ def audio_filter_kwargs(name):
         return {}
     mode, interp = AUDIO_FILTER[name]
     return dict(filter_mode=mode, filter_interpolation=interp)
+# ---- gst_audio_resampler_update streams: script items are buffer sizes or dicts for update():
+#   dict(in_rate, out_rate[, quality][, filter_mode][, filter_interpolation][, raw]) - quality / filter_* present -> new options
+#   (set_quality for these rates), absent -> NULL options (the previous filter design is kept); raw=(i, o) passes those values
+#   to update() instead (0 = unchanged) while the options are still made for in_rate / out_rate.
+AUDIO_UPDATE_CASES = [
+    ("upd_f32_rates_with_options", "F32LE", 2, 48000, 44100, "kaiser", 4,
+     (1024, 1024, dict(in_rate=48000, out_rate=32000, quality=4), 1024, 1000, dict(in_rate=32000, out_rate=48000, quality=4), 1024, 777,
+      dict(in_rate=48000, out_rate=44100, quality=4), 1024)),
+    ("upd_f32_rates_null_options", "F32LE", 2, 48000, 44100, "kaiser", 4,
+     (1024, 1024, dict(in_rate=48000, out_rate=40000), 1024, 1024, dict(in_rate=44100, out_rate=48000), 1024, 1024)),
+    ("upd_f32_quality_only", "F32LE", 1, 48000, 44100, "kaiser", 4,
+     (1024, 500, dict(in_rate=48000, out_rate=44100, quality=8, raw=(0, 0)), 1024, 1024, dict(in_rate=48000, out_rate=44100, quality=1, raw=(0, 0)),
+      1024, 1024)),
+    ("upd_s16_rates_with_options", "S16LE", 2, 44100, 48000, "kaiser", 4,
+     (1024, 1024, dict(in_rate=44100, out_rate=22050, quality=5), 1024, 1024, dict(in_rate=44100, out_rate=96000, quality=3), 512, 512)),
+    ("upd_s32_cubic_null_options", "S32LE", 2, 48000, 32000, "cubic", 4,
+     (1024, 1024, dict(in_rate=48000, out_rate=44100), 1024, 1024)),
+    ("upd_f64_to_same_rate_and_back", "F64LE", 1, 48000, 44100, "kaiser", 4,
+     (1024, 1024, dict(in_rate=48000, out_rate=48000, quality=4), 1024, 1024, dict(in_rate=48000, out_rate=44100, quality=4), 1024)),
+    ("upd_f32_interp_null_options", "F32LE", 2, 48000, 44100, "kaiser", 4,
+     (1024, 1024, dict(in_rate=48000, out_rate=44000), 1024, 1024)),
+    ("upd_f32_full_to_interpolated", "F32LE", 1, 48000, 44100, "kaiser", 4,
+     (2048, dict(in_rate=48000, out_rate=44101, quality=4), 2048, 2048, dict(in_rate=48000, out_rate=44100, quality=4), 2048)),
+    ("upd_f32_phase_rescale_odd", "F32LE", 2, 44100, 48000, "kaiser", 2,
+     (333, 1001, dict(in_rate=44100, out_rate=47999, quality=2), 1024, 13, dict(in_rate=44100, out_rate=48000), 1024)),
+]
+AUDIO_FILTER["upd_f32_interp_null_options"] = ("interpolated", "cubic")
+
+
 AUDIO_DTYPES = {"F32LE": np.float32, "F64LE": np.float64, "S16LE": np.int16, "S32LE": np.int32}
 
 
@@ -417,3 +446,24 @@ def audio_stream(ref_resampler_factory, resample_fn, case):
     for i, n in enumerate(list(bufs) + [None]):
         outs.append(resample_fn(i, n))
     return np.concatenate([o.reshape(-1) for o in outs])
+
+
+def audio_update_stream(case, do_update, do_resample, max_latency):
+    """Runs an AUDIO_UPDATE_CASES script: do_update(dict), do_resample(data or None, n_in) -> array; ends with a drain of
+    max_latency() silent frames.  Returns the concatenated output."""
+    name, fmt, ch, ir, orr, method, quality, script = case
+    chunks = []
+    k = 0
+    for item in list(script) + [None]:
+        if isinstance(item, dict):
+            do_update(item)
+        elif item is None:
+            chunks.append(do_resample(None, max_latency()))
+        else:
+            chunks.append(do_resample(audio_buffer(fmt, ch, item, case_seed(name) + k), item))
+            k += 1
+    return np.concatenate([c.reshape(-1) for c in chunks])
+
+
+def audio_update_has_options(item):
+    return any(k in item for k in ("quality", "filter_mode", "filter_interpolation"))

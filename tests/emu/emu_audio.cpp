@@ -78,6 +78,35 @@ void emu_audio_free (void *h) { delete (EmuResampler *) h; }
 size_t emu_audio_get_out_frames (void *h, size_t in_frames) { EmuResampler *r = (EmuResampler *) h; return audio_get_out_frames (r->plan, r->st, in_frames); }
 int emu_audio_n_taps (void *h) { return ((EmuResampler *) h)->plan.n_taps; }
 
+int emu_audio_update (void *h, int in_rate, int out_rate, const GstAmdAudioResamplerOptions *options)
+{
+  EmuResampler *r = (EmuResampler *) h;
+  AudioHistoryShift shift;
+  std::string e;
+  const size_t old_avail = r->st.samples_avail + (size_t) r->st.samp_index;
+  int st = audio_update (&r->plan, &r->st, in_rate, out_rate, options, &shift, &e);
+  if (st != GSTAMD_OK)
+    return st;
+  const size_t fbytes = (size_t) r->plan.channels * r->plan.bps;
+  if (r->hist.size () > old_avail * fbytes)
+    r->hist.resize (old_avail * fbytes);
+  audio_history_shift (shift, fbytes, &r->hist);
+  r->hist.resize (r->hist.size () + 8 * fbytes, 0);
+  return st;
+}
+int emu_audio_state (void *h, int which)
+{
+  EmuResampler *r = (EmuResampler *) h;
+  switch (which) {
+    case 0: return r->plan.n_taps;
+    case 1: return r->plan.in_rate;
+    case 2: return r->plan.out_rate;
+    case 3: return (int) r->st.samp_phase;
+    case 4: return (int) r->st.samples_avail;
+    default: return r->plan.filter_mode;
+  }
+}
+
 void emu_audio_resample (void *h, const void *in, size_t in_frames, void *out, size_t out_frames)
 {
   EmuResampler *r = (EmuResampler *) h;

@@ -46,6 +46,24 @@ def audio():
         full = __import__("numpy").concatenate(chunks)
         out[name] = dict(sha256=cases.sha(full), out_frames=counts, head=[float(x) for x in full[:8]])
         print(name, out[name]["sha256"][:16], counts[:4])
+    for case in cases.AUDIO_UPDATE_CASES:
+        name, fmt, ch, ir, orr, method, quality, script = case
+        rr = ref.AudioResampler(fmt, ch, ir, orr, method=method, quality=quality, **cases.audio_filter_kwargs(name))
+        counts = []
+
+        def do_update(item):
+            raw = item.get("raw", (item["in_rate"], item["out_rate"]))
+            assert rr.update(raw[0], raw[1], quality=item.get("quality"), filter_mode=item.get("filter_mode"),
+                             filter_interpolation=item.get("filter_interpolation"), q_rates=(item["in_rate"], item["out_rate"]))
+
+        def do_resample(data, n_in):
+            no = rr.get_out_frames(n_in)
+            counts.append(int(no))
+            return rr.resample(data, in_frames=n_in, out_frames=no)
+
+        full = cases.audio_update_stream(case, do_update, do_resample, rr.get_max_latency)
+        out[name] = dict(sha256=cases.sha(full), out_frames=counts, head=[float(x) for x in full[:8]])
+        print(name, out[name]["sha256"][:16], counts)
     with open(os.path.join(ROOT, "tests", "golden", "audio_golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
 

@@ -44,6 +44,39 @@ def test_hip_fir_matches_reference_golden(native_lib, gpu, case):
     assert cases.sha(out) == GOLDEN[case[0]]["sha256"], (list(out[:8]), GOLDEN[case[0]]["head"])
 
 
+@pytest.mark.parametrize("case", cases.AUDIO_UPDATE_CASES, ids=lambda c: c[0])
+def test_hip_update_streams_match_reference_golden(native_lib, gpu, case):
+    """gst_audio_resampler_update in mid-stream (rates and / or options; NULL options keep the old filter design): the device
+    table is replaced and the HBM history shifted - output identical to the reference's for the whole stream."""
+    import torch
+    name, fmt, ch, ir, orr, method, quality, script = case
+    dt = cases.AUDIO_DTYPES[fmt]
+    r = A.AudioResampler(fmt, ch, ir, orr, method, A.options(method, quality, ir, orr, **cases.audio_filter_kwargs(name)))
+    counts = []
+
+    def do_update(item):
+        raw = item.get("raw", (item["in_rate"], item["out_rate"]))
+        uo = None
+        if cases.audio_update_has_options(item):
+            kw = {k: item[k] for k in ("filter_mode", "filter_interpolation") if k in item}
+            uo = A.options(method, item.get("quality"), item["in_rate"], item["out_rate"], **kw)
+        r.update(raw[0], raw[1], uo)
+
+    def do_resample(data, n_in):
+        d_in = torch.from_numpy(data).to(gpu) if data is not None else None
+        no = r.get_out_frames(n_in)
+        counts.append(int(no))
+        d_out = torch.zeros((max(no, 1), ch), dtype=getattr(torch, np.dtype(dt).name), device=gpu)
+        r.resample(d_in, n_in, d_out, no)
+        torch.cuda.synchronize()
+        return d_out[:no].cpu().numpy()
+
+    out = cases.audio_update_stream(case, do_update, do_resample, r.get_max_latency)
+    r.free()
+    assert counts == GOLDEN[name]["out_frames"]
+    assert cases.sha(out) == GOLDEN[name]["sha256"], (list(out[:8]), GOLDEN[name]["head"])
+
+
 @pytest.mark.parametrize("layout", [(True, True), (True, False), (False, True)], ids=["planar_planar", "planar_in", "planar_out"])
 @pytest.mark.parametrize("name", ["f32_48k_44k1_q4_stereo", "f32_6ch_cubic", "s16_48k_44k1_q4", "f32_8k_16k_gappy", "s32_interp_cubic_48k_32k"])
 def test_hip_fir_non_interleaved_layouts(native_lib, gpu, name, layout):

@@ -22,6 +22,8 @@ def _emu(emu_lib):
     emu_lib.emu_audio_get_out_frames.argtypes = [C.c_void_p, C.c_size_t]
     emu_lib.emu_audio_resample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     emu_lib.emu_audio_free.argtypes = [C.c_void_p]
+    emu_lib.emu_audio_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(A.ResamplerOptions)]
+    emu_lib.emu_audio_state.argtypes = [C.c_void_p, C.c_int]
     return emu_lib
 
 
@@ -139,3 +141,71 @@ def test_filter_mode_auto_picks_interpolated_for_big_tables(native_lib):
     assert d["filter_mode"] == A.FILTER_MODE["interpolated"] and d["filter_interpolation"] == A.FILTER_INTERPOLATION["cubic"]
     assert d["oversample"] == 8
     r.free()
+
+
+def update_options(case, item):
+    """The options structure an update item stands for (None = NULL options), built like the reference driver builds it."""
+    if not cases.audio_update_has_options(item):
+        return None
+    kw = {k: item[k] for k in ("filter_mode", "filter_interpolation") if k in item}
+    return A.options(case[5], item.get("quality"), item["in_rate"], item["out_rate"], **kw)
+
+
+@pytest.mark.parametrize("case", cases.AUDIO_UPDATE_CASES, ids=lambda c: c[0])
+def test_update_streams_on_host_match_golden(native_lib, emu_lib, case):
+    """gst_audio_resampler_update (audio-resampler.c:1503-1614) in mid-stream: phase rescale, rate reduction, filter
+    redesign with history shift, and the NULL-options variant that keeps the old design."""
+    E = _emu(emu_lib)
+    name, fmt, ch, ir, orr, method, quality, script = case
+    o = A.options(method, quality, ir, orr, **cases.audio_filter_kwargs(name))
+    st = C.c_int(0)
+    h = E.emu_audio_new(A.METHODS[method], 0, A.FORMATS[fmt], ch, ir, orr, C.byref(o), C.byref(st), None, 0)
+    assert h, st.value
+    dt = cases.AUDIO_DTYPES[fmt]
+    counts = []
+
+    def do_update(item):
+        raw = item.get("raw", (item["in_rate"], item["out_rate"]))
+        uo = update_options(case, item)
+        assert E.emu_audio_update(h, raw[0], raw[1], C.byref(uo) if uo is not None else None) == 0
+
+    def do_resample(data, n_in):
+        no = E.emu_audio_get_out_frames(h, n_in)
+        counts.append(no)
+        got = np.zeros((no, ch), dt)
+        E.emu_audio_resample(h, data.ctypes.data if data is not None else None, n_in, got.ctypes.data, no)
+        return got
+
+    full = cases.audio_update_stream(case, do_update, do_resample, lambda: E.emu_audio_state(h, 0) // 2)
+    E.emu_audio_free(h)
+    assert counts == GOLDEN[name]["out_frames"]
+    assert cases.sha(full) == GOLDEN[name]["sha256"]
+
+
+@pytest.mark.parametrize("case", cases.AUDIO_UPDATE_CASES[::2], ids=lambda c: c[0])
+def test_update_golden_is_the_references_output(ref, case):
+    name, fmt, ch, ir, orr, method, quality, script = case
+    rr = ref.AudioResampler(fmt, ch, ir, orr, method=method, quality=quality, **cases.audio_filter_kwargs(name))
+
+    def do_update(item):
+        raw = item.get("raw", (item["in_rate"], item["out_rate"]))
+        assert rr.update(raw[0], raw[1], quality=item.get("quality"), filter_mode=item.get("filter_mode"),
+                         filter_interpolation=item.get("filter_interpolation"), q_rates=(item["in_rate"], item["out_rate"]))
+
+    full = cases.audio_update_stream(case, do_update, lambda d, n: rr.resample(d, in_frames=n, out_frames=rr.get_out_frames(n)),
+                                     rr.get_max_latency)
+    assert cases.sha(full) == GOLDEN[name]["sha256"]
+
+
+def test_failed_update_leaves_the_resampler_alone(native_lib):
+    r = A.AudioResampler("F32LE", 2, 48000, 44100)
+    before = r.debug()
+    bad = A.options("kaiser", 4, 48000, 32000, n_taps=0)
+    # kaiser ignores n-taps; linear takes it: a non-positive count is refused
+    r2 = A.AudioResampler("F32LE", 2, 48000, 44100, "linear")
+    with pytest.raises(Exception):
+        r2.update(48000, 32000, bad)
+    assert r2.debug() == A.AudioResampler("F32LE", 2, 48000, 44100, "linear").debug()
+    r.update(48000, 32000, A.options("kaiser", 4, 48000, 32000))
+    after = r.debug()
+    assert (after["n_phases"], after["in_rate"]) == (2, 3) and after["n_taps"] > before["n_taps"]

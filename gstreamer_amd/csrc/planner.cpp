@@ -958,7 +958,7 @@ static void pass_span (const ScalePass &pass, int t0, int t1, int *lo, int *hi)
 // rather than 256 (span 514 -> 65 groups, two rounds).
 TileGeom pass_tile_geom (const ScalePass &pass)
 {
-  TileGeom best = {0, 0};
+  TileGeom best = {0, 0, 0};
   double best_cost = 1e30;
   const int osz = pass.out_size;
   for (int tw = 256; tw >= 64; tw -= 4) {
@@ -978,6 +978,23 @@ TileGeom pass_tile_geom (const ScalePass &pass)
     }
     if (tw >= osz && rounds == 1)
       break;
+  }
+  /* 16-pixel staging (video_hscale420.h): the fewest tiles whose spans fit one round of 64 lanes x 16 pixels, evenly wide */
+  best.tile16_w = 0;
+  if (pass.kind == SCALE_NTAP) {
+    for (int tiles = (osz + 255) / 256; tiles <= (osz + 63) / 64; tiles++) {
+      const int tw = std::min (256, ((osz + tiles - 1) / tiles + 3) & ~3);
+      int worst = 0;
+      for (int t0 = 0; t0 < osz; t0 += tw) {
+        int lo, hi;
+        pass_span (pass, t0, std::min (t0 + tw, osz), &lo, &hi);
+        worst = std::max (worst, hi - (lo & ~15));
+      }
+      if (worst <= 1024) {
+        best.tile16_w = tw;
+        break;
+      }
+    }
   }
   return best;
 }

@@ -103,6 +103,7 @@ struct ScalePass {
 struct TileGeom {
   int tile_w;           // multiple of 4, <= 256
   int lds_px;           // multiple of 8: covers [x_lo & ~7, x_hi) of every tile
+  int tile16_w;         // video_hscale420.h: tile width whose spans [x_lo & ~15, x_hi) all fit 1024 pixels (64 lanes x 16), 0: none
 };
 TileGeom pass_tile_geom (const ScalePass &pass);
 

@@ -14,6 +14,7 @@
 #include "video_device.h"
 #include "video_fast.h"
 #include "video_scale_fast.h"
+#include "video_hscale420.h"
 #include "video_pack.h"
 #include "video_bilinear_fast.h"
 #include "video_encode_fast.h"
@@ -155,9 +156,43 @@ __global__ __launch_bounds__ (64) void k_hscale_dot4_wave (SrcFront src, ScaleDe
   const int xa = x_lo & ~7;
   Dot4Taps<NW> ft;
   hscale_dot4_fetch<NW> (sd, xa, t0, t1, lane, ft);
-  tile_stage_row_planes (src, py, pu, pv, xa, x_hi, y, lane, packed);
+  if (!(packed & 0x200))
+    tile_stage_row_planes (src, py, pu, pv, xa, x_hi, y, lane, packed & 1);
   wave_lds_sync ();
-  hscale_dot4_lane<NW> (py, pu, pv, ft, sd, sd.nw, dst, pf, t0, t1, y, lane);
+  if (!(packed & 0x100))
+    hscale_dot4_lane<NW> (py, pu, pv, ft, sd, sd.nw, dst, pf, t0, t1, y, lane);
+}
+
+// horizontal N-tap pass from a 2x horizontally subsampled planar / semi-planar frame (video_hscale420.h): a wave walks
+// rows_per_wave lines of its tile, taps in registers, 16 source pixels per lane and line
+template <int NW>
+__global__ __launch_bounds__ (64) void k_hscale420_dot4 (SrcFront src, ScaleDev sd, Dst dst, PostFast pf, int out_w, int rows, int tile_w,
+    int rows_per_wave, int ablate)
+{
+  extern __shared__ uint32_t lds_w[];
+  const int plane_w = GSTAMD_H420_PLANE_BYTES / 4;
+  uint32_t *py = lds_w, *pu = lds_w + plane_w, *pv = lds_w + 2 * plane_w;
+  const int lane = (int) threadIdx.x, t0 = (int) blockIdx.x * tile_w;
+  const int t1 = t0 + tile_w < out_w ? t0 + tile_w : out_w;
+  const int y0 = (int) blockIdx.y * rows_per_wave, y1 = y0 + rows_per_wave < rows ? y0 + rows_per_wave : rows;
+  int x_lo, x_hi;
+  hscale_span (sd, t0, t1, &x_lo, &x_hi);
+  const int xa = x_lo & ~15;
+  Dot4Taps<NW> ft;
+  hscale_dot4_fetch<NW> (sd, xa, t0, t1, lane, ft);
+  H420State c;
+  h420_begin (src, c, xa, x_hi, y0, lane);
+  for (int y = y0; y < y1; y++) {
+    const int late = ablate & 1;
+    if (!(ablate & 0x200))
+      h420_stage_line_any (src, c, py, pu, pv, xa, x_hi, y, (y + 1 < y1 && !late) ? y + 1 : -1, lane);
+    wave_lds_sync ();
+    if (!(ablate & 0x100))
+      hscale_dot4_lane<NW> (py, pu, pv, ft, sd, sd.nw, dst, pf, t0, t1, y, lane);
+    if (late && y + 1 < y1)
+      h420_request_line (src, c, xa, x_hi, y + 1, lane);
+    wave_lds_sync ();
+  }
 }
 
 // vertical N-tap pass over an AYUV image, 4 pixels per lane, one wave per workgroup
@@ -473,6 +508,21 @@ static int dot4_source_ok (const SrcFront &s)
   return kind_has_planes (s.f.kind) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
 }
 
+// 16-pixel staging of video_hscale420.h: planes with 2x horizontal subsampling, 16-byte luma / interleaved-chroma and 8-byte
+// planar-chroma loads aligned, whole 16-pixel groups only
+static int h420_source_ok (const SrcFront &s)
+{
+  const FrontParams &f = s.f;
+  if (!kind_has_planes (f.kind) || f.w_sub != 1 || (f.width % 16) != 0)
+    return 0;
+  int ok = aligned (s.pl.p[0], 16) && (s.pl.stride[0] % 16) == 0;
+  if (f.kind == UNPACK_SEMI)
+    ok = ok && aligned (s.pl.p[1], 16) && (s.pl.stride[1] % 16) == 0;
+  else
+    ok = ok && aligned (s.pl.p[1], 8) && aligned (s.pl.p[2], 8) && (s.pl.stride[1] % 8) == 0 && (s.pl.stride[2] % 8) == 0;
+  return ok;
+}
+
 static Dst make_dst (uint8_t *p, int stride, bool final, const ColorParams &post, const int pack_pos[4])
 {
   Dst d;
@@ -497,13 +547,43 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
   src.vec_ok = front_vec_ok (f, pl);
   Dst d = make_dst (dst, dstride, final, post, pack_pos);
   dim3 block (256), grid ((out_w + 255) / 256, out_h);
-  if (horizontal && geom.tile_w > 0 && sd.tapw && dot4_source_ok (src)) {
+  static const int ablate = getenv ("GSTAMD_ABLATE") ? atoi (getenv ("GSTAMD_ABLATE")) : 0;
+  static const int h420_rows_env = getenv ("GSTAMD_H420_ROWS") ? atoi (getenv ("GSTAMD_H420_ROWS")) : -1;      /* 0: kernel off */
+  if (horizontal && geom.tile16_w > 0 && sd.tapw && dot4_source_ok (src) && h420_source_ok (src) && h420_rows_env != 0) {
+    /* lines per wave: the waves of the launch should all be resident at once (one round, no tail of late waves), each walking
+     * down as many lines as that takes - but at least 4, for the chroma rows and the taps a wave keeps between lines */
+    const int tiles = (out_w + geom.tile16_w - 1) / geom.tile16_w;
+    int h420_rows = h420_rows_env;
+    if (h420_rows < 0) {
+      static int slots = 0;
+      if (!slots) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        const void *fn = sd.nw == 5 ? (const void *) k_hscale420_dot4<5> : (const void *) k_hscale420_dot4<0>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, fn, 64, (size_t) GSTAMD_H420_PLANE_BYTES * 3) != hipSuccess || per_cu <= 0)
+          per_cu = 16;
+        if (hipGetDevice (&dev) != hipSuccess || hipGetDeviceProperties (&prop, dev) != hipSuccess)
+          prop.multiProcessorCount = 256;
+        slots = per_cu * prop.multiProcessorCount;
+      }
+      h420_rows = (int) (((long long) tiles * out_h + slots - 1) / slots);
+      if (h420_rows < 4)
+        h420_rows = 4;
+    }
+    dim3 wgrid (tiles, (out_h + h420_rows - 1) / h420_rows);
+    if (sd.nw == 5)
+      hipLaunchKernelGGL (k_hscale420_dot4<5>, wgrid, dim3 (64), (size_t) GSTAMD_H420_PLANE_BYTES * 3, stream, src, sd, d, pf, out_w, out_h,
+          geom.tile16_w, h420_rows, ablate);
+    else
+      hipLaunchKernelGGL (k_hscale420_dot4<0>, wgrid, dim3 (64), (size_t) GSTAMD_H420_PLANE_BYTES * 3, stream, src, sd, d, pf, out_w, out_h,
+          geom.tile16_w, h420_rows, ablate);
+  } else if (horizontal && geom.tile_w > 0 && sd.tapw && dot4_source_ok (src)) {
     /* planes of lds_px bytes + 8 (the aligned filter window may run a few zero-tap bytes past the span) */
     const int plane_w = (geom.lds_px + 8) / 4;
     dim3 wgrid ((out_w + geom.tile_w - 1) / geom.tile_w, out_h);
     if (sd.nw == 5)
       hipLaunchKernelGGL (k_hscale_dot4_wave<5>, wgrid, dim3 (64), (size_t) plane_w * 12, stream, src, sd, d, pf, out_w, out_h, geom.tile_w,
-          plane_w, front_packed_ok (src));
+          plane_w, front_packed_ok (src) | ablate);
     else
       hipLaunchKernelGGL (k_hscale_dot4_wave<0>, wgrid, dim3 (64), (size_t) plane_w * 12, stream, src, sd, d, pf, out_w, out_h, geom.tile_w,
           plane_w, front_packed_ok (src));

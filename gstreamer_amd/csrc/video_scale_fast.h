@@ -268,7 +268,10 @@ GSTAMD_HD void store_px (const Dst &dst, int x, int y, uint32_t v)
 {
   uint32_t *p = (uint32_t *) (dst.p + (size_t) y * dst.stride + 4 * (size_t) x);
 #ifdef __HIPCC__
-  __builtin_nontemporal_store (v, p);
+  if (dst.final)
+    __builtin_nontemporal_store (v, p);     // write-once output
+  else
+    *p = v;                                 // intermediate image: the next pass reads it straight back (L2 / Infinity Cache)
 #else
   *p = v;
 #endif

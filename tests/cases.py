@@ -198,6 +198,15 @@ VIDEO_CASES = [
     ("nv12_bgra_quarter_lanczos", "NV12", 640, 360, "BGRA", 160, 90, LAN, None, None, "random"),
     ("i420_rgba_quarter_lanczos", "I420", 640, 360, "RGBA", 160, 90, LAN, None, None, "random"),
     ("i420_rgba_1080p_to_270p_lanczos", "I420", 1920, 1080, "RGBA", 480, 270, LAN, None, None, "random"),
+    # ---- 16-pixel-per-lane horizontal pass from 2x subsampled planes (video_hscale420.h): chroma sites, U/V orders, 4:2:2, tiles, crop
+    ("i420_rgba_h420_nonint_2tiles_lanczos", "I420", 1280, 362, "RGBA", 500, 177, LAN, None, None, "random"),
+    ("nv21_bgra_h420_jpeg_lanczos", "NV21", 640, 360, "BGRA", 300, 170, LAN, None, "jpeg", "random"),
+    ("yv12_argb_h420_none_site_lanczos", "YV12", 640, 362, "ARGB", 200, 120, LAN, None, "none", "random"),
+    ("y42b_bgra_h420_hfirst_lanczos", "Y42B", 640, 100, "BGRA", 160, 90, LAN, None, None, "random"),
+    ("nv16_rgba_h420_jpeg_lanczos", "NV16", 640, 100, "RGBA", 200, 64, LAN, None, "jpeg", "random"),
+    ("i420_bgra_h420_crop_lanczos", "I420", 1280, 720, "BGRA", 160, 90, dict(LAN, src_x=32, src_y=17, src_width=640, src_height=359), None, None, "random"),
+    ("nv12_bgra_h420_cubic_down", "NV12", 1280, 720, "BGRA", 852, 480, {}, None, None, "random"),
+    ("nv12_xrgb_h420_sinc_down", "NV12", 1024, 96, "xRGB", 300, 40, dict(resampler_method="sinc"), None, "mpeg2", "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),

@@ -10,6 +10,9 @@
 #include "../../gstreamer_amd/csrc/video_device.h"
 #include "../../gstreamer_amd/csrc/video_fast.h"
 #include "../../gstreamer_amd/csrc/video_scale_fast.h"
+#include "../../gstreamer_amd/csrc/video_hscale420.h"
+#include <cstdlib>
+#include <algorithm>
 #include "../../gstreamer_amd/csrc/video_pack.h"
 #include "../../gstreamer_amd/csrc/video_bilinear_fast.h"
 #include "../../gstreamer_amd/csrc/video_planes.h"
@@ -99,6 +102,63 @@ static void run_hscale_dot4 (const SrcFront &src, const ScaleDev &sd, const Dst 
     }
 }
 
+// k_hscale420_dot4: per-lane chroma cache carried down the lines of a tile
+static int g_h420_runs = 0;
+static int emu_h420_rows ()
+{
+  const char *e = getenv ("GSTAMD_H420_ROWS");
+  return e ? atoi (e) : 4;
+}
+static bool emu_h420_ok (const SrcFront &s)
+{
+  const FrontParams &f = s.f;
+  auto al = [](const void *p, int a) { return ((uintptr_t) p % a) == 0; };
+  if (!kind_has_planes (f.kind) || f.w_sub != 1 || (f.width % 16) != 0 || emu_h420_rows () <= 0)
+    return false;
+  bool ok = al (s.pl.p[0], 16) && (s.pl.stride[0] % 16) == 0;
+  if (f.kind == UNPACK_SEMI)
+    ok = ok && al (s.pl.p[1], 16) && (s.pl.stride[1] % 16) == 0;
+  else
+    ok = ok && al (s.pl.p[1], 8) && al (s.pl.p[2], 8) && (s.pl.stride[1] % 8) == 0 && (s.pl.stride[2] % 8) == 0;
+  return ok;
+}
+static bool emu_h420_ok (const SrcImage &) { return false; }
+static void run_hscale420 (const SrcImage &, const ScaleDev &, const Dst &, const PostFast &, int, int, TileGeom) {}
+static void run_hscale420 (const SrcFront &src, const ScaleDev &sd, const Dst &d, const PostFast &pf, int out_w, int out_h, TileGeom g)
+{
+  g_h420_runs++;
+  const int plane_w = GSTAMD_H420_PLANE_BYTES / 4, rpw = emu_h420_rows ();
+  std::vector<uint32_t> lds (3 * plane_w + 4);
+  /* 16-byte aligned planes like the LDS allocation */
+  uint32_t *py = (uint32_t *) (((uintptr_t) lds.data () + 15) & ~(uintptr_t) 15), *pu = py + plane_w, *pv = pu + plane_w;
+  for (int y0 = 0; y0 < out_h; y0 += rpw)
+    for (int t0 = 0; t0 < out_w; t0 += g.tile16_w) {
+      const int t1 = t0 + g.tile16_w < out_w ? t0 + g.tile16_w : out_w;
+      int lo, hi;
+      hscale_span (sd, t0, t1, &lo, &hi);
+      const int xa = lo & ~15;
+      std::vector<H420State> c (64);
+      const int y1 = std::min (y0 + rpw, out_h);
+      for (int lane = 0; lane < 64; lane++)
+        h420_begin (src, c[lane], xa, hi, y0, lane);
+      for (int y = y0; y < y1; y++) {
+        for (int lane = 0; lane < 64; lane++)
+          h420_stage_line_any (src, c[lane], py, pu, pv, xa, hi, y, y + 1 < y1 ? y + 1 : -1, lane);
+        for (int lane = 0; lane < 64; lane++) {
+          if (sd.nw == 5) {
+            Dot4Taps<5> ft;
+            hscale_dot4_fetch<5> (sd, xa, t0, t1, lane, ft);
+            hscale_dot4_lane<5> (py, pu, pv, ft, sd, sd.nw, d, pf, t0, t1, y, lane);
+          } else {
+            Dot4Taps<0> ft;
+            hscale_dot4_fetch<0> (sd, xa, t0, t1, lane, ft);
+            hscale_dot4_lane<0> (py, pu, pv, ft, sd, sd.nw, d, pf, t0, t1, y, lane);
+          }
+        }
+      }
+    }
+}
+
 static bool emu_dot4_ok (const SrcFront &s, const ScaleDev &sd)
 {
   return sd.tapw && kind_has_planes (s.f.kind) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
@@ -118,6 +178,10 @@ template <class SRC>
 static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h, int max_span, TileGeom g,
     const PostFast &pf)
 {
+  if (horizontal && g.tile16_w > 0 && emu_dot4_ok (src, sd) && emu_h420_ok (src)) {
+    run_hscale420 (src, sd, d, pf, out_w, out_h, g);
+    return;
+  }
   if (horizontal && g.tile_w > 0 && emu_dot4_ok (src, sd)) {
     run_hscale_dot4 (src, sd, d, pf, out_w, out_h, g);
     return;
@@ -146,6 +210,8 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
 }
 
 static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok, bool rgb24);
+
+extern "C" int emu_h420_runs (void) { return g_h420_runs; }
 
 extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *cfg, const uint8_t *src, uint8_t *dst, int vec_ok, char *desc, int desc_len)

@@ -121,6 +121,33 @@ def test_kernel_bodies_on_host_match_golden(native_lib, emu_lib, idx_case):
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], (name, list(dst[:16]), GOLDEN[name]["head"][:16])
 
 
+H420 = [c for c in SMALL if "_h420_" in c[1][0] or c[1][0] in ("nv12_bgra_quarter_lanczos", "i420_rgba_quarter_lanczos")]
+
+
+@pytest.mark.parametrize("rows", [1, 3, 4, 7])
+@pytest.mark.parametrize("idx_case", H420, ids=lambda c: c[1][0])
+def test_hscale420_bodies_any_rows_per_wave(native_lib, emu_lib, idx_case, rows, monkeypatch):
+    """k_hscale420_dot4 (video_hscale420.h): the lanes' chroma-row cache gives the same bytes wherever a wave starts and however many
+    lines it walks; the path must actually be the one taken."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    monkeypatch.setenv("GSTAMD_H420_ROWS", str(rows))
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    before = emu_lib.emu_h420_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_h420_runs() == before + 1
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
+def test_hscale420_switch_off_gives_the_same_bytes(native_lib, emu_lib, monkeypatch):
+    name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == "nv21_bgra_h420_jpeg_lanczos"][0]
+    monkeypatch.setenv("GSTAMD_H420_ROWS", "0")
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    before = emu_lib.emu_h420_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_h420_runs() == before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
 WIDE = [c for c in SMALL if c[1][1] in ("NV12", "NV21") and c[1][2] >= 512 and (c[1][2], c[1][3]) == (c[1][5], c[1][6])
         and c[1][4] not in ("AYUV",)]
 

@@ -51,6 +51,8 @@ struct GstAmdVideoConverter {
   uint8_t *plane_tmp = nullptr;           // plane mode: intermediate plane of a two-pass scale
   uint8_t *pk_img = nullptr;              // planar destinations: the chain's AYUV image before chroma downsample + pack
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
+  bool reg420 = false;                    // first pass horizontal from a 4:2:0 source whose chroma pairing is the closed form of h420r_rows
+  int reg_lo = 0, reg_hi = 0;
 };
 
 static bool fast_pair_usable (const VideoPlan &p, const Planes &pl, const uint8_t *dst, int dstride, int dalign = 16)
@@ -178,6 +180,22 @@ static int ensure_tables (GstAmdVideoConverter *c)
   for (size_t i = 0; i < p.passes.size (); i++)
     if (p.passes[i].horizontal)
       c->geom[i] = pass_tile_geom (p.passes[i]);
+  if (p.passes.size () == 2 && p.passes[0].horizontal && p.passes[0].kind == SCALE_NTAP && p.passes[0].dot4_ok && c->geom[0].tile16_w > 0 &&
+      p.front.chroma_v2 && kind_has_planes (p.front.kind) && p.front.w_sub == 1 && p.front.h_sub == 1 && !p.matrix_before_scale &&
+      (int) p.vpair.size () >= 2 * p.front.height) {
+    /* k_hscale420_reg: is the planner's simulated pair table the closed form (every line consumed in order)? */
+    c->reg_lo = -(p.rect.in_y >> 1);
+    c->reg_hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
+    bool regular = true;
+    for (int y = 0; y < p.front.height && regular; y++) {
+      int heavy, light;
+      h420r_rows (c->reg_lo, c->reg_hi, y, &heavy, &light);
+      const int e0 = p.vpair[2 * y], ta = vpair_row (e0), tb = p.vpair[2 * y + 1];
+      const int th = vpair_role (e0) == 0 ? ta : tb, tl = vpair_role (e0) == 0 ? tb : ta;
+      regular = th == heavy && tl == light;
+    }
+    c->reg420 = regular;
+  }
   if (p.passes.size () == 2) {
     const ScalePass &s0 = p.passes[0];
     c->tmp_w = s0.horizontal ? s0.out_size : p.in_info.width;
@@ -427,6 +445,34 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
         post, p.post.pack_pos, out_w, out_h, p.passes[0].max_span, c->geom[0], pf, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "scale pass");
   }
+  e = hipErrorNotSupported;
+  if (c->reg420 && pre.matrix.kind == MATRIX_NONE && pre.alpha_kind == ALPHA_NONE &&
+      (p.front.kind == UNPACK_SEMI || pl.stride[p.front.u_plane] == pl.stride[p.front.v_plane])) {
+    H420RegParams hp;
+    memset (&hp, 0, sizeof (hp));
+    hp.y = pl.p[0];
+    hp.ystride = pl.stride[0];
+    hp.semi = p.front.kind == UNPACK_SEMI;
+    hp.u_first = p.front.u_plane != 0;
+    hp.c0 = hp.semi ? pl.p[1] : pl.p[p.front.u_plane];
+    hp.c1 = hp.semi ? pl.p[1] : pl.p[p.front.v_plane];
+    hp.cstride = hp.semi ? pl.stride[1] : pl.stride[p.front.u_plane];
+    hp.width = p.front.width;
+    hp.height = p.front.height;
+    hp.crow_lo = c->reg_lo;
+    hp.crow_hi = c->reg_hi;
+    hp.offset = sd[0].offset;
+    hp.tapw = sd[0].tapw;
+    hp.nw4 = sd[0].nw4;
+    hp.dst = c->tmp;
+    hp.dstride = c->tmp_w * 4;
+    hp.out_w = c->tmp_w;
+    hp.tile_w = c->geom[0].tile16_w;
+    e = launch_hscale420_reg (hp, p.front.chroma_h, sd[0].nw, sd[0].n_taps, stream);
+    if (e != hipSuccess && e != hipErrorNotSupported)
+      return hip_fail (e, "k_hscale420_reg");
+  }
+  if (e == hipErrorNotSupported)
   e = launch_scale_from_front (p.passes[0].horizontal, p.front, pl, c->vpair_dev, pre, sd[0], c->tmp, c->tmp_w * 4,
       false, none, p.post.pack_pos, c->tmp_w, c->tmp_h, p.passes[0].max_span, c->geom[0], pf_none, stream);
   if (e != hipSuccess)

@@ -17,6 +17,9 @@
 #pragma once
 #include "video_scale_fast.h"
 
+// bytes per LDS plane: 1024 staged + the aligned filter window's run past the span, a multiple of 16
+#define GSTAMD_H420_PLANE_BYTES 1056
+
 namespace gstamd {
 
 GSTAMD_HD uint32_t lerp_u8 (uint32_t a, uint32_t b, uint32_t c)
@@ -94,14 +97,14 @@ GSTAMD_HD void h420_load_raw (const FrontParams &f, const Planes &pl, int crow, 
 }
 
 template <int CH>
-GSTAMD_HD void h420_filter_raw (const FrontParams &f, const H420Raw &r, uint32_t *o)
+GSTAMD_HD void h420_filter_raw2 (bool semi, bool u_first, const H420Raw &r, uint32_t *o)
 {
   uint32_t u0, u1, v0, v1, um, up, vm, vp;
-  if (f.kind == UNPACK_SEMI) {
+  if (semi) {
     // first bytes of the pairs / second bytes of the pairs
     const uint32_t a0 = bperm (r.u1, r.u0, 0x06040200u), a1 = bperm (r.v1, r.v0, 0x06040200u);
     const uint32_t b0 = bperm (r.u1, r.u0, 0x07050301u), b1 = bperm (r.v1, r.v0, 0x07050301u);
-    if (f.u_plane) {            // NV12 / NV16: U first
+    if (u_first) {              // NV12 / NV16: U first
       u0 = a0, u1 = a1, v0 = b0, v1 = b1;
       um = r.um & 0xffu, vm = r.um >> 8, up = r.up & 0xffu, vp = r.up >> 8;
     } else {
@@ -131,6 +134,12 @@ GSTAMD_HD void h420_filter_raw (const FrontParams &f, const H420Raw &r, uint32_t
   } else {
     o[2] = u0, o[3] = u1, o[6] = v0, o[7] = v1;
   }
+}
+
+template <int CH>
+GSTAMD_HD void h420_filter_raw (const FrontParams &f, const H420Raw &r, uint32_t *o)
+{
+  h420_filter_raw2<CH> (f.kind == UNPACK_SEMI, f.u_plane != 0, r, o);
 }
 
 // 3:1 blend of the heavy and the light chroma row, pixel order, XOR 0x80 -> 16 bytes of the U plane and of the V plane
@@ -249,7 +258,181 @@ GSTAMD_HD void h420_stage_line_any (const SrcFront &src, H420State &s, uint32_t 
     h420_stage_line<CHROMA_H_NONE> (src, s, py, pu, pv, xa, x_hi, y, y_next, lane);
 }
 
-// bytes per LDS plane: 1024 staged + the aligned filter window's run past the span, a multiple of 16
-#define GSTAMD_H420_PLANE_BYTES 1056
+// ------------------------------------------------------------------------------------------------
+// The same pass for the regular case, lean: 4:2:0 source whose chroma line pairing is the closed form (lines 2u-1, 2u blend
+// chroma rows u-1 and u, clamped into [crow_lo, crow_hi]; what do_upsample_lines produces when every line is consumed in
+// order - checked by the launcher against the planner's table), AYUV intermediate as destination, filter window of NW words.
+// A wave walks line PAIRS: both lines of a pair blend the same two h-filtered rows P and Q (3:1 and 1:3), the next pair
+// replaces the older of the two, so with two pairs per loop turn every register has a fixed role - no table reads, no
+// row bookkeeping, two lines' worth of independent loads, LDS traffic and dot products per synchronisation.
+// ------------------------------------------------------------------------------------------------
+struct H420RegParams {
+  const uint8_t *y, *c0, *c1;     // luma; planar: U plane, V plane; semi-planar: the interleaved plane (c1 unused)
+  int ystride, cstride;
+  int width, height;              // source picture in pixels / lines, width % 16 == 0
+  int semi, u_first;
+  int crow_lo, crow_hi;           // chroma rows the upsampler may touch (frame rows around a crop)
+  const uint32_t *offset, *tapw;  // ScaleDev::offset / tapw
+  int nw4;
+  uint8_t *dst;                   // AYUV image, out_w x height
+  int dstride;
+  int out_w, tile_w, lines_per_wave;      // lines_per_wave % 4 == 0; wave b covers lines [b * lpw - 1, (b + 1) * lpw - 1)
+};
+
+struct H420Pair {                 // one line pair in flight: luma of lines 2u-1 and 2u, raw chroma row u
+  uint4 la, lb;
+  H420Raw raw;
+};
+
+// closed form of the pairing: heavy and light chroma row of line y
+#ifdef __HIPCC__
+#define GSTAMD_H420_HOSTDEV __host__ __device__ inline
+#else
+#define GSTAMD_H420_HOSTDEV inline
+#endif
+GSTAMD_H420_HOSTDEV void h420r_rows (int crow_lo, int crow_hi, int y, int *heavy, int *light)
+{
+  const int u = (y + 1) >> 1;
+  const int ra = u - 1 < crow_lo ? crow_lo : (u - 1 > crow_hi ? crow_hi : u - 1), rb = u < crow_lo ? crow_lo : (u > crow_hi ? crow_hi : u);
+  *heavy = (y & 1) ? ra : rb;
+  *light = (y & 1) ? rb : ra;
+}
+
+GSTAMD_HD int h420r_crow (const H420RegParams &p, int r) { return r < p.crow_lo ? p.crow_lo : (r > p.crow_hi ? p.crow_hi : r); }
+
+GSTAMD_HD void h420r_load_raw (const H420RegParams &p, int crow, int k0, H420Raw &r)
+{
+  const int cw = p.width >> 1, km = k0 > 0 ? k0 - 1 : 0, kp = k0 + 8 < cw ? k0 + 8 : cw - 1;
+  if (p.semi) {
+    const uint8_t *row = p.c0 + (ptrdiff_t) crow * p.cstride;
+    const uint4 m = *(const uint4 *) (row + 2 * k0);
+    r.u0 = m.x, r.u1 = m.y, r.v0 = m.z, r.v1 = m.w;
+    r.um = *(const uint16_t *) (row + 2 * km);
+    r.up = *(const uint16_t *) (row + 2 * kp);
+    r.vm = r.vp = 0;
+  } else {
+    const uint8_t *ru = p.c0 + (ptrdiff_t) crow * p.cstride, *rv = p.c1 + (ptrdiff_t) crow * p.cstride;
+    const uint2 mu = *(const uint2 *) (ru + k0), mv = *(const uint2 *) (rv + k0);
+    r.u0 = mu.x, r.u1 = mu.y, r.v0 = mv.x, r.v1 = mv.y;
+    r.um = ru[km], r.up = ru[kp], r.vm = rv[km], r.vp = rv[kp];
+  }
+}
+
+// loads of pair u (lines 2u-1, 2u; line numbers clamped into the picture, the caller skips lines outside it)
+GSTAMD_HD void h420r_request (const H420RegParams &p, int u, int x0, H420Pair &q)
+{
+  const int ya = 2 * u - 1 < 0 ? 0 : 2 * u - 1, yb = 2 * u < p.height ? 2 * u : p.height - 1;
+  q.la = *(const uint4 *) (p.y + (ptrdiff_t) ya * p.ystride + (uint32_t) x0);
+  q.lb = *(const uint4 *) (p.y + (ptrdiff_t) yb * p.ystride + (uint32_t) x0);
+  h420r_load_raw (p, h420r_crow (p, u), x0 >> 1, q.raw);
+}
+
+GSTAMD_HD void h420r_stage_luma (const uint4 &l, uint32_t *py16)
+{
+  *(uint4 *) py16 = gstamd_make_uint4 (l.x ^ 0x80808080u, l.y ^ 0x80808080u, l.z ^ 0x80808080u, l.w ^ 0x80808080u);
+}
+
+// (int16) acc >> 6 (the ORC program's 16-bit accumulator, shrsw 6), clamped to a byte; the rounding 32 is in the accumulator's start value
+GSTAMD_HD uint32_t h420r_finish (int acc)
+{
+#ifdef __HIPCC__
+  int v = __builtin_amdgcn_sbfe (acc, 6, 10);
+  asm volatile ("" : "+v" (v));                  // see lq_round: keep shift and clamp apart
+  return (uint32_t) (v < 0 ? 0 : (v > 255 ? 255 : v));
+#else
+  const int v = ((int) (int16_t) (uint16_t) acc) >> 6;
+  return (uint32_t) (v < 0 ? 0 : (v > 255 ? 255 : v));
+#endif
+}
+
+// LDS word read that the compiler leaves alone: one ds_read_b32 with an immediate offset from the output's base register
+// (merged ds_read2_b32 pairs cannot reach across the 1056-byte planes and cost an address add each)
+GSTAMD_HD uint32_t h420r_lds (const uint32_t *p)
+{
+#ifdef __HIPCC__
+  return *(const volatile __attribute__ ((address_space (3))) uint32_t *) p;
+#else
+  return *p;
+#endif
+}
+
+// outputs t0 + lane + 64 i of one line from its byte planes; AYUV words, plain stores (the vertical pass reads them next).
+// xo[i] = 4 * x: byte offset of the output in its row
+template <int NW>
+GSTAMD_HD void h420r_filter_line (const uint32_t *line, const Dot4Taps<NW> &ft, uint8_t *drow, int t0, int t1, int lane)
+{
+  const int pw = GSTAMD_H420_PLANE_BYTES / 4;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = t0 + lane + 64 * i;
+    if (x >= t1)
+      break;
+    const uint32_t *b = line + ft.w0[i];
+    uint32_t wy[NW], wu[NW], wv[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      wy[k] = h420r_lds (b + k);
+      wu[k] = h420r_lds (b + pw + k);
+      wv[k] = h420r_lds (b + 2 * pw + k);
+    }
+    int ay = 128 * 64 + 32, au = 128 * 64 + 32, av = 128 * 64 + 32;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      const uint32_t t = ft.t[i][k];
+      ay = dot4_i8 (wy[k], t, ay);
+      au = dot4_i8 (wu[k], t, au);
+      av = dot4_i8 (wv[k], t, av);
+    }
+    *(uint32_t *) (drow + (uint32_t) (4 * x)) = 0xffu | (h420r_finish (ay) << 8) | (h420r_finish (au) << 16) | (h420r_finish (av) << 24);
+  }
+}
+
+template <int NW>
+GSTAMD_HD void h420r_fetch_taps (const H420RegParams &p, int xa, int t0, int t1, int lane, Dot4Taps<NW> &ft)
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = t0 + lane + 64 * i;
+    const int xc = x < t1 ? x : t1 - 1;
+    ft.w0[i] = ((int) p.offset[xc] - xa) >> 2;
+    const uint32_t *tw = p.tapw + (size_t) xc * p.nw4;
+#pragma unroll
+    for (int k = 0; k < NW; k++)
+      ft.t[i][k] = tw[k];
+  }
+}
+
+// LDS words of one line (three planes) in the two-line layout
+#define GSTAMD_H420_LINE_WORDS (3 * GSTAMD_H420_PLANE_BYTES / 4)
+
+// stage pair u from `q`: install its chroma row into `fresh` (the set that held the older row), then line 2u-1 = 3 * older + newer,
+// line 2u = older + 3 * newer.  `older` is the other set.
+template <int CH>
+GSTAMD_HD void h420r_stage_pair (const H420RegParams &p, const H420Pair &q, const uint32_t *older, uint32_t *fresh, uint32_t *lds, int w0)
+{
+  const int pw = GSTAMD_H420_PLANE_BYTES / 4;
+  h420_filter_raw2<CH> (p.semi != 0, p.u_first != 0, q.raw, fresh);
+  h420r_stage_luma (q.la, lds + w0);
+  h420_blend_store (older, fresh, lds + pw + w0, lds + 2 * pw + w0);
+  h420r_stage_luma (q.lb, lds + GSTAMD_H420_LINE_WORDS + w0);
+  h420_blend_store (fresh, older, lds + GSTAMD_H420_LINE_WORDS + pw + w0, lds + GSTAMD_H420_LINE_WORDS + 2 * pw + w0);
+}
+
+template <int NW>
+GSTAMD_HD void h420r_filter_pair (const H420RegParams &p, const uint32_t *lds, const Dot4Taps<NW> &ft, int u, int t0, int t1, int lane)
+{
+  const int ya = 2 * u - 1, yb = 2 * u;
+  if (ya >= 0)
+    h420r_filter_line<NW> (lds, ft, p.dst + (ptrdiff_t) ya * p.dstride, t0, t1, lane);
+  if (yb < p.height)
+    h420r_filter_line<NW> (lds + GSTAMD_H420_LINE_WORDS, ft, p.dst + (ptrdiff_t) yb * p.dstride, t0, t1, lane);
+}
+
+// source span of the outputs [t0, t1)
+GSTAMD_HD void h420r_span (const H420RegParams &p, int n_taps, int t0, int t1, int *x_lo, int *x_hi)
+{
+  *x_lo = (int) p.offset[t0];
+  *x_hi = (int) p.offset[t1 - 1] + n_taps;
+}
 
 }  // namespace gstamd

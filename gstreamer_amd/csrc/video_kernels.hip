@@ -195,6 +195,53 @@ __global__ __launch_bounds__ (64) void k_hscale420_dot4 (SrcFront src, ScaleDev 
   }
 }
 
+// the regular 4:2:0 case of the same pass (video_hscale420.h, second half): line pairs, fixed register roles
+template <int NW, int CH>
+__global__ __launch_bounds__ (64) void k_hscale420_reg (H420RegParams p, int n_taps, int late)
+{
+  extern __shared__ uint32_t lds_w[];
+  const int lane = (int) threadIdx.x, t0 = (int) blockIdx.x * p.tile_w;
+  const int t1 = t0 + p.tile_w < p.out_w ? t0 + p.tile_w : p.out_w;
+  const int pairs = p.height / 2 + 1, ppw = p.lines_per_wave / 2;
+  const int u0 = (int) blockIdx.y * ppw, u1 = u0 + ppw < pairs ? u0 + ppw : pairs;
+  int x_lo, x_hi;
+  h420r_span (p, n_taps, t0, t1, &x_lo, &x_hi);
+  const int xa = x_lo & ~15, w0 = 4 * lane;
+  int x0 = xa + 16 * lane;
+  if (x0 + 16 > p.width)
+    x0 = p.width - 16;                  // lanes past the span: harmless loads, their LDS bytes meet zero taps only
+  Dot4Taps<NW> ft;
+  h420r_fetch_taps<NW> (p, xa, t0, t1, lane, ft);
+  uint32_t P[8], Q[8];
+  {
+    H420Raw r;
+    h420r_load_raw (p, h420r_crow (p, u0 - 1), x0 >> 1, r);
+    h420_filter_raw2<CH> (p.semi != 0, p.u_first != 0, r, P);
+  }
+  H420Pair cur, nxt;
+  h420r_request (p, u0, x0, cur);
+  for (int u = u0; u < u1; u += 2) {
+    h420r_stage_pair<CH> (p, cur, P, Q, lds_w, w0);
+    if (!late)
+      h420r_request (p, u + 1 < u1 ? u + 1 : u1 - 1, x0, nxt);
+    wave_lds_sync ();
+    h420r_filter_pair<NW> (p, lds_w, ft, u, t0, t1, lane);
+    if (late)
+      h420r_request (p, u + 1 < u1 ? u + 1 : u1 - 1, x0, nxt);
+    wave_lds_sync ();
+    if (u + 1 >= u1)
+      break;
+    h420r_stage_pair<CH> (p, nxt, Q, P, lds_w, w0);
+    if (!late)
+      h420r_request (p, u + 2 < u1 ? u + 2 : u1 - 1, x0, cur);
+    wave_lds_sync ();
+    h420r_filter_pair<NW> (p, lds_w, ft, u + 1, t0, t1, lane);
+    if (late)
+      h420r_request (p, u + 2 < u1 ? u + 2 : u1 - 1, x0, cur);
+    wave_lds_sync ();
+  }
+}
+
 // vertical N-tap pass over an AYUV image, 4 pixels per lane, one wave per workgroup
 __global__ __launch_bounds__ (64) void k_vscale_pk (SrcImage src, ScaleDev sd, Dst dst, PostFast pf, int width, int out_h)
 {
@@ -598,6 +645,63 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
   else
     hipLaunchKernelGGL (k_vscale<SrcFront>, grid, block, 0, stream, src, sd, d, out_w, out_h);
   return hipGetLastError ();
+}
+
+template <int NW>
+static hipError_t launch_h420_reg_nw (H420RegParams p, int chroma_h, int n_taps, hipStream_t stream)
+{
+  static const int late = getenv ("GSTAMD_H420_LATE") ? atoi (getenv ("GSTAMD_H420_LATE")) : 0;
+  static const int lpw_env = getenv ("GSTAMD_H420_ROWS") ? atoi (getenv ("GSTAMD_H420_ROWS")) : -1;
+  const size_t lds = (size_t) GSTAMD_H420_LINE_WORDS * 4 * 2;
+  const void *fn = chroma_h == CHROMA_H_H2_CS ? (const void *) k_hscale420_reg<NW, CHROMA_H_H2_CS> :
+      (chroma_h == CHROMA_H_H2 ? (const void *) k_hscale420_reg<NW, CHROMA_H_H2> : (const void *) k_hscale420_reg<NW, CHROMA_H_NONE>);
+  const int tiles = (p.out_w + p.tile_w - 1) / p.tile_w;
+  /* lines per wave: every wave of the launch resident at once (one round, no tail), a multiple of 4 */
+  static int slots[3] = {0, 0, 0};
+  int &sl = slots[chroma_h == CHROMA_H_H2_CS ? 0 : (chroma_h == CHROMA_H_H2 ? 1 : 2)];
+  if (!sl) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, fn, 64, lds) != hipSuccess || per_cu <= 0)
+      per_cu = 16;
+    if (hipGetDevice (&dev) != hipSuccess || hipGetDeviceProperties (&prop, dev) != hipSuccess)
+      prop.multiProcessorCount = 256;
+    sl = per_cu * prop.multiProcessorCount;
+  }
+  int lpw = lpw_env > 0 ? lpw_env : (int) (((long long) tiles * (p.height + 1) + sl - 1) / sl);
+  lpw = (lpw + 3) & ~3;
+  if (lpw < 4)
+    lpw = 4;
+  p.lines_per_wave = lpw;
+  const int pairs = p.height / 2 + 1, ppw = lpw / 2;
+  dim3 grid (tiles, (pairs + ppw - 1) / ppw);
+  if (chroma_h == CHROMA_H_H2_CS)
+    hipLaunchKernelGGL ((k_hscale420_reg<NW, CHROMA_H_H2_CS>), grid, dim3 (64), lds, stream, p, n_taps, late);
+  else if (chroma_h == CHROMA_H_H2)
+    hipLaunchKernelGGL ((k_hscale420_reg<NW, CHROMA_H_H2>), grid, dim3 (64), lds, stream, p, n_taps, late);
+  else
+    hipLaunchKernelGGL ((k_hscale420_reg<NW, CHROMA_H_NONE>), grid, dim3 (64), lds, stream, p, n_taps, late);
+  return hipGetLastError ();
+}
+
+// regular 4:2:0 horizontal pass into the AYUV intermediate; hipErrorNotSupported: the caller takes the general kernels
+hipError_t launch_hscale420_reg (const H420RegParams &p, int chroma_h, int nw, int n_taps, hipStream_t stream)
+{
+  if (getenv ("GSTAMD_NO_H420_REG"))
+    return hipErrorNotSupported;
+  int ok = (p.width % 16) == 0 && aligned (p.y, 16) && (p.ystride % 16) == 0 && aligned (p.dst, 4) && (p.dstride % 4) == 0;
+  if (p.semi)
+    ok = ok && aligned (p.c0, 16) && (p.cstride % 16) == 0;
+  else
+    ok = ok && aligned (p.c0, 8) && aligned (p.c1, 8) && (p.cstride % 8) == 0;
+  if (!ok)
+    return hipErrorNotSupported;
+  switch (nw) {
+    case 3: return launch_h420_reg_nw<3> (p, chroma_h, n_taps, stream);
+    case 4: return launch_h420_reg_nw<4> (p, chroma_h, n_taps, stream);
+    case 5: return launch_h420_reg_nw<5> (p, chroma_h, n_taps, stream);
+    default: return hipErrorNotSupported;
+  }
 }
 
 hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int sstride, const ScaleDev &sd, uint8_t *dst,

@@ -159,6 +159,125 @@ static void run_hscale420 (const SrcFront &src, const ScaleDev &sd, const Dst &d
     }
 }
 
+// k_hscale420_reg: the decision of capi_video.cpp (closed-form pairing) + launch_hscale420_reg (alignment, window words), then the
+// kernel's loop with per-lane register state
+static int g_h420_reg_runs = 0;
+template <int NW, int CH>
+static void run_h420_reg (H420RegParams p, int n_taps)
+{
+  std::vector<uint32_t> ldsv (2 * GSTAMD_H420_LINE_WORDS + 4);
+  uint32_t *lds = (uint32_t *) (((uintptr_t) ldsv.data () + 15) & ~(uintptr_t) 15);
+  const int pairs = p.height / 2 + 1, ppw = p.lines_per_wave / 2;
+  struct LaneState { uint32_t P[8], Q[8]; H420Pair cur, nxt; Dot4Taps<NW> ft; int x0; };
+  for (int b = 0; b * ppw < pairs; b++)
+    for (int t0 = 0; t0 < p.out_w; t0 += p.tile_w) {
+      const int t1 = std::min (t0 + p.tile_w, p.out_w);
+      const int u0 = b * ppw, u1 = std::min (u0 + ppw, pairs);
+      int x_lo, x_hi;
+      h420r_span (p, n_taps, t0, t1, &x_lo, &x_hi);
+      const int xa = x_lo & ~15;
+      std::vector<LaneState> L (64);
+      for (int lane = 0; lane < 64; lane++) {
+        LaneState &s = L[lane];
+        s.x0 = xa + 16 * lane;
+        if (s.x0 + 16 > p.width)
+          s.x0 = p.width - 16;
+        h420r_fetch_taps<NW> (p, xa, t0, t1, lane, s.ft);
+        H420Raw r;
+        h420r_load_raw (p, h420r_crow (p, u0 - 1), s.x0 >> 1, r);
+        h420_filter_raw2<CH> (p.semi != 0, p.u_first != 0, r, s.P);
+        h420r_request (p, u0, s.x0, s.cur);
+      }
+      for (int u = u0; u < u1; u += 2) {
+        for (int lane = 0; lane < 64; lane++) {
+          h420r_stage_pair<CH> (p, L[lane].cur, L[lane].P, L[lane].Q, lds, 4 * lane);
+          h420r_request (p, u + 1 < u1 ? u + 1 : u1 - 1, L[lane].x0, L[lane].nxt);
+        }
+        for (int lane = 0; lane < 64; lane++)
+          h420r_filter_pair<NW> (p, lds, L[lane].ft, u, t0, t1, lane);
+        if (u + 1 >= u1)
+          break;
+        for (int lane = 0; lane < 64; lane++) {
+          h420r_stage_pair<CH> (p, L[lane].nxt, L[lane].Q, L[lane].P, lds, 4 * lane);
+          h420r_request (p, u + 2 < u1 ? u + 2 : u1 - 1, L[lane].x0, L[lane].cur);
+        }
+        for (int lane = 0; lane < 64; lane++)
+          h420r_filter_pair<NW> (p, lds, L[lane].ft, u + 1, t0, t1, lane);
+      }
+    }
+}
+
+template <int NW>
+static void run_h420_reg_ch (const H420RegParams &p, int chroma_h, int n_taps)
+{
+  if (chroma_h == CHROMA_H_H2_CS)
+    run_h420_reg<NW, CHROMA_H_H2_CS> (p, n_taps);
+  else if (chroma_h == CHROMA_H_H2)
+    run_h420_reg<NW, CHROMA_H_H2> (p, n_taps);
+  else
+    run_h420_reg<NW, CHROMA_H_NONE> (p, n_taps);
+}
+
+static bool emu_hscale420_reg (const VideoPlan &p, const SrcFront &sf, const ScaleDev &sd0, uint8_t *tmp, int tmp_w)
+{
+  if (getenv ("GSTAMD_NO_H420_REG"))
+    return false;
+  const TileGeom g = p.passes[0].horizontal ? pass_tile_geom (p.passes[0]) : TileGeom {0, 0, 0};
+  if (!(p.passes.size () == 2 && p.passes[0].horizontal && p.passes[0].kind == SCALE_NTAP && p.passes[0].dot4_ok && g.tile16_w > 0 &&
+      p.front.chroma_v2 && kind_has_planes (p.front.kind) && p.front.w_sub == 1 && p.front.h_sub == 1 && !p.matrix_before_scale &&
+      (int) p.vpair.size () >= 2 * p.front.height))
+    return false;
+  const int lo = -(p.rect.in_y >> 1), hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
+  for (int y = 0; y < p.front.height; y++) {
+    int heavy, light;
+    h420r_rows (lo, hi, y, &heavy, &light);
+    const int e0 = p.vpair[2 * y], ta = vpair_row (e0), tb = p.vpair[2 * y + 1];
+    const int th = vpair_role (e0) == 0 ? ta : tb, tl = vpair_role (e0) == 0 ? tb : ta;
+    if (th != heavy || tl != light)
+      return false;
+  }
+  const Planes &pl = sf.pl;
+  const bool semi = p.front.kind == UNPACK_SEMI;
+  if (!semi && pl.stride[p.front.u_plane] != pl.stride[p.front.v_plane])
+    return false;
+  H420RegParams hp;
+  memset (&hp, 0, sizeof (hp));
+  hp.y = pl.p[0];
+  hp.ystride = pl.stride[0];
+  hp.semi = semi;
+  hp.u_first = p.front.u_plane != 0;
+  hp.c0 = semi ? pl.p[1] : pl.p[p.front.u_plane];
+  hp.c1 = semi ? pl.p[1] : pl.p[p.front.v_plane];
+  hp.cstride = semi ? pl.stride[1] : pl.stride[p.front.u_plane];
+  hp.width = p.front.width;
+  hp.height = p.front.height;
+  hp.crow_lo = lo;
+  hp.crow_hi = hi;
+  hp.offset = sd0.offset;
+  hp.tapw = sd0.tapw;
+  hp.nw4 = sd0.nw4;
+  hp.dst = tmp;
+  hp.dstride = tmp_w * 4;
+  hp.out_w = tmp_w;
+  hp.tile_w = g.tile16_w;
+  auto al = [](const void *q, int a) { return ((uintptr_t) q % a) == 0; };
+  bool ok = (hp.width % 16) == 0 && al (hp.y, 16) && (hp.ystride % 16) == 0;
+  ok = ok && (semi ? (al (hp.c0, 16) && (hp.cstride % 16) == 0) : (al (hp.c0, 8) && al (hp.c1, 8) && (hp.cstride % 8) == 0));
+  if (!ok || sd0.nw < 3 || sd0.nw > 5)
+    return false;
+  const char *e = getenv ("GSTAMD_H420_ROWS");
+  int lpw = e && atoi (e) > 0 ? atoi (e) : 12;
+  hp.lines_per_wave = std::max (4, (lpw + 3) & ~3);
+  g_h420_reg_runs++;
+  if (sd0.nw == 3)
+    run_h420_reg_ch<3> (hp, p.front.chroma_h, sd0.n_taps);
+  else if (sd0.nw == 4)
+    run_h420_reg_ch<4> (hp, p.front.chroma_h, sd0.n_taps);
+  else
+    run_h420_reg_ch<5> (hp, p.front.chroma_h, sd0.n_taps);
+  return true;
+}
+
 static bool emu_dot4_ok (const SrcFront &s, const ScaleDev &sd)
 {
   return sd.tapw && kind_has_planes (s.f.kind) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
@@ -212,6 +331,7 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
 static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok, bool rgb24);
 
 extern "C" int emu_h420_runs (void) { return g_h420_runs; }
+extern "C" int emu_h420_reg_runs (void) { return g_h420_reg_runs; }
 
 extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *cfg, const uint8_t *src, uint8_t *dst, int vec_ok, char *desc, int desc_len)
@@ -568,6 +688,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
   const ScalePass &s0 = p.passes[0];
   const int tw = s0.horizontal ? s0.out_size : p.in_info.width, th = s0.horizontal ? p.in_info.height : s0.out_size;
   std::vector<uint8_t> tmp ((size_t) tw * 4 * th);
+  if (!emu_hscale420_reg (p, sf, sd[0], tmp.data (), tw))
   run_scale (s0.horizontal, sf, sd[0], mk (tmp.data (), tw * 4, false), tw, th, s0.max_span,
       s0.horizontal ? pass_tile_geom (s0) : TileGeom {0, 0}, pf_none);
   SrcImage si;

@@ -38,6 +38,19 @@ def test_hip_matches_reference_golden(native_lib, gpu, idx_case):
     assert cases.video_digest(name, out) == GOLDEN[name]["sha256"], (name, list(out[:16]), GOLDEN[name]["head"][:16])
 
 
+H420_GENERAL = [c for c in enumerate(cases.VIDEO_CASES) if "_h420_" in c[1][0] or c[1][0] in ("nv12_bgra_quarter_lanczos", "i420_rgba_1080p_to_270p_lanczos")]
+
+
+@pytest.mark.parametrize("idx_case", H420_GENERAL, ids=lambda c: c[1][0])
+def test_hip_general_hscale420_kernel_matches_golden(native_lib, gpu, idx_case, monkeypatch):
+    """The 4:2:0 cases again with k_hscale420_reg switched off: k_hscale420_dot4 (pair table, chroma-row cache) serves them."""
+    monkeypatch.setenv("GSTAMD_NO_H420_REG", "1")
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(int(V.video_info(ifmt, w, h).size), pattern, cases.case_seed(name), w)
+    out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert cases.video_digest(name, out) == GOLDEN[name]["sha256"]
+
+
 @pytest.mark.parametrize("size", [(3840, 2160), (1920, 1080), (1918, 1078), (4095, 31)])
 def test_hip_matches_reference_bytewise_c2(native_lib, gpu, ref, size):
     """BASELINE config 2 (and neighbours) memcmp'd against the reference run on this host."""

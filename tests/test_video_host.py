@@ -131,6 +131,7 @@ def test_hscale420_bodies_any_rows_per_wave(native_lib, emu_lib, idx_case, rows,
     lines it walks; the path must actually be the one taken."""
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     monkeypatch.setenv("GSTAMD_H420_ROWS", str(rows))
+    monkeypatch.setenv("GSTAMD_NO_H420_REG", "1")
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     before = emu_lib.emu_h420_runs()
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
@@ -138,9 +139,27 @@ def test_hscale420_bodies_any_rows_per_wave(native_lib, emu_lib, idx_case, rows,
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
 
 
+H420_REG = [c for c in H420 if c[1][1] in ("I420", "YV12", "NV12", "NV21")]
+
+
+@pytest.mark.parametrize("rows", [4, 8, 20])
+@pytest.mark.parametrize("idx_case", H420_REG, ids=lambda c: c[1][0])
+def test_hscale420_reg_bodies_any_lines_per_wave(native_lib, emu_lib, idx_case, rows, monkeypatch):
+    """k_hscale420_reg (line pairs, closed-form chroma pairing, fixed register roles): same bytes for any block height, crop and
+    chroma site included; the path must be the one taken for these 4:2:0 cases."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    monkeypatch.setenv("GSTAMD_H420_ROWS", str(rows))
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    before = emu_lib.emu_h420_reg_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_h420_reg_runs() == before + 1
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
 def test_hscale420_switch_off_gives_the_same_bytes(native_lib, emu_lib, monkeypatch):
     name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == "nv21_bgra_h420_jpeg_lanczos"][0]
     monkeypatch.setenv("GSTAMD_H420_ROWS", "0")
+    monkeypatch.setenv("GSTAMD_NO_H420_REG", "1")
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     before = emu_lib.emu_h420_runs()
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)

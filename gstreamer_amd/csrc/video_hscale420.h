@@ -276,7 +276,7 @@ struct H420RegParams {
   int nw4;
   uint8_t *dst;                   // AYUV image, out_w x height
   int dstride;
-  int out_w, tile_w, lines_per_wave;      // lines_per_wave % 4 == 0; wave b covers lines [b * lpw - 1, (b + 1) * lpw - 1)
+  int out_w, tile_w, lines_per_wave;      // even; wave b covers lines [b * lpw - 1, (b + 1) * lpw - 1)
 };
 
 struct H420Pair {                 // one line pair in flight: luma of lines 2u-1 and 2u, raw chroma row u

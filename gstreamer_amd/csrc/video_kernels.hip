@@ -248,6 +248,12 @@ __global__ __launch_bounds__ (64) void k_vscale_pk (SrcImage src, ScaleDev sd, D
   vscale_pk_lane (src, sd, dst, pf, width, out_h, (int) (blockIdx.x * 64 + threadIdx.x) * 4, (int) blockIdx.y);
 }
 
+template <int R>
+__global__ __launch_bounds__ (64) void k_vscale_pk_rows (SrcImage src, ScaleDev sd, Dst dst, PostFast pf, int width, int out_h)
+{
+  vscale_pk_rows_lane<R> (src, sd, dst, pf, width, out_h, (int) (blockIdx.x * 64 + threadIdx.x) * 4, (int) blockIdx.y * R);
+}
+
 template <class SRC>
 __global__ __launch_bounds__ (256) void k_scale2x2 (SRC src, ScaleDev sh, ScaleDev sv, int h_first, Dst dst, int out_w, int out_h)
 {
@@ -656,7 +662,7 @@ static hipError_t launch_h420_reg_nw (H420RegParams p, int chroma_h, int n_taps,
   const void *fn = chroma_h == CHROMA_H_H2_CS ? (const void *) k_hscale420_reg<NW, CHROMA_H_H2_CS> :
       (chroma_h == CHROMA_H_H2 ? (const void *) k_hscale420_reg<NW, CHROMA_H_H2> : (const void *) k_hscale420_reg<NW, CHROMA_H_NONE>);
   const int tiles = (p.out_w + p.tile_w - 1) / p.tile_w;
-  /* lines per wave: every wave of the launch resident at once (one round, no tail), a multiple of 4 */
+  /* line pairs per wave: every wave of the launch resident at once (one round, no tail) */
   static int slots[3] = {0, 0, 0};
   int &sl = slots[chroma_h == CHROMA_H_H2_CS ? 0 : (chroma_h == CHROMA_H_H2 ? 1 : 2)];
   if (!sl) {
@@ -668,12 +674,11 @@ static hipError_t launch_h420_reg_nw (H420RegParams p, int chroma_h, int n_taps,
       prop.multiProcessorCount = 256;
     sl = per_cu * prop.multiProcessorCount;
   }
-  int lpw = lpw_env > 0 ? lpw_env : (int) (((long long) tiles * (p.height + 1) + sl - 1) / sl);
-  lpw = (lpw + 3) & ~3;
-  if (lpw < 4)
-    lpw = 4;
-  p.lines_per_wave = lpw;
-  const int pairs = p.height / 2 + 1, ppw = lpw / 2;
+  const int pairs = p.height / 2 + 1;
+  int ppw = lpw_env > 0 ? (lpw_env + 1) / 2 : (int) (((long long) tiles * pairs + sl - 1) / sl);
+  if (ppw < 2)
+    ppw = 2;
+  p.lines_per_wave = 2 * ppw;
   dim3 grid (tiles, (pairs + ppw - 1) / ppw);
   if (chroma_h == CHROMA_H_H2_CS)
     hipLaunchKernelGGL ((k_hscale420_reg<NW, CHROMA_H_H2_CS>), grid, dim3 (64), lds, stream, p, n_taps, late);
@@ -724,8 +729,18 @@ hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int ss
     hipLaunchKernelGGL (k_hscale<SrcImage>, grid, block, 0, stream, src, sd, d, out_w, out_h);
   else if (sd.kind == SCALE_NTAP) {
     /* the packed kernel runs the generic post stage too (post_px), so it serves every N-tap vertical pass */
-    dim3 vgrid ((out_w + 255) / 256, out_h);
-    hipLaunchKernelGGL (k_vscale_pk, vgrid, dim3 (64), 0, stream, src, sd, d, pf, out_w, out_h);
+    static const int vrows = getenv ("GSTAMD_VSCALE_ROWS") ? atoi (getenv ("GSTAMD_VSCALE_ROWS")) : 2;
+    /* neighbouring output rows of an N-tap filter always share source rows (the window is 2a steps wide) */
+    if (vrows == 4) {
+      dim3 vgrid ((out_w + 255) / 256, (out_h + 3) / 4);
+      hipLaunchKernelGGL (k_vscale_pk_rows<4>, vgrid, dim3 (64), 0, stream, src, sd, d, pf, out_w, out_h);
+    } else if (vrows == 2) {
+      dim3 vgrid ((out_w + 255) / 256, (out_h + 1) / 2);
+      hipLaunchKernelGGL (k_vscale_pk_rows<2>, vgrid, dim3 (64), 0, stream, src, sd, d, pf, out_w, out_h);
+    } else {
+      dim3 vgrid ((out_w + 255) / 256, out_h);
+      hipLaunchKernelGGL (k_vscale_pk, vgrid, dim3 (64), 0, stream, src, sd, d, pf, out_w, out_h);
+    }
   } else
     hipLaunchKernelGGL (k_vscale<SrcImage>, grid, block, 0, stream, src, sd, d, out_w, out_h);
   return hipGetLastError ();

@@ -491,6 +491,93 @@ GSTAMD_HD void vscale_ntap_lane4 (const SrcImage &src, const ScaleDev &sd, const
 #endif
 }
 
+// the same for R consecutive output rows y0 .. y0+R-1 at once: every source row under the union of their tap windows is
+// loaded and unpacked ONCE and multiply-accumulated into the rows it belongs to (a 4:1 reduction with 16 taps shares 12 of
+// the 16 rows between neighbouring outputs: 28 row loads instead of 64 for R = 4).  The 16-bit accumulators wrap like the ORC
+// program's, so the order of the additions is immaterial.  Which rows a source line feeds is wave-uniform.
+template <int R>
+GSTAMD_HD void vscale_ntap_lane4_rows (const SrcImage &src, const ScaleDev &sd, const Dst &dst, const PostFast &pf, int x0, int y0, int out_h)
+{
+  struct __attribute__ ((aligned (4))) W4 { uint32_t v[4]; };
+  int off[R], lo = 0x7fffffff, hi = -0x7fffffff;
+  const int16_t *t[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int yc = y0 + r < out_h ? y0 + r : out_h - 1;
+    off[r] = (int) sd.offset[yc];
+    t[r] = sd.taps + (size_t) yc * sd.n_taps;
+    lo = off[r] < lo ? off[r] : lo;
+    hi = off[r] + sd.n_taps > hi ? off[r] + sd.n_taps : hi;
+  }
+  uint32_t ae[R][4], ao[R][4];
+#pragma unroll
+  for (int r = 0; r < R; r++)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      ae[r][i] = ao[r][i] = 0;
+  const uint8_t *p = src.p + 4 * (size_t) x0;
+#pragma unroll 2
+  for (int l = lo; l < hi; l++) {
+    const W4 w = *(const W4 *) (p + (size_t) l * src.stride);
+    uint32_t e[4], o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      e[i] = w.v[i] & 0x00ff00ffu;
+      o[i] = pk_shr<8> (w.v[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int k = l - off[r];
+      if (y0 + r < out_h && k >= 0 && k < sd.n_taps) {
+        const uint32_t ts = (uint32_t) (uint16_t) t[r][k] * 0x00010001u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          ae[r][i] = pk_mad16 (e[i], ts, ae[r][i]);
+          ao[r][i] = pk_mad16 (o[i], ts, ao[r][i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    if (y0 + r >= out_h)
+      break;
+    uint32_t q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      q[i] = post_px (dst, pf, pk_lq_finish (ae[r][i]) | (pk_lq_finish (ao[r][i]) << 8));
+    uint8_t *d = dst.p + (size_t) (y0 + r) * dst.stride + 4 * (size_t) x0;
+#ifdef __HIPCC__
+    typedef unsigned int u32x4_a4 __attribute__ ((ext_vector_type (4), aligned (4)));
+    const u32x4_a4 v = {q[0], q[1], q[2], q[3]};
+    if (dst.final)
+      __builtin_nontemporal_store (v, (u32x4_a4 *) d);
+    else
+      *(u32x4_a4 *) d = v;
+#else
+    W4 v = {{q[0], q[1], q[2], q[3]}};
+    *(W4 *) d = v;
+#endif
+  }
+}
+
+// lane of the multi-row vertical kernel: 4 pixels from x0 of R rows from y0; a ragged last lane goes row by row
+template <int R>
+GSTAMD_HD void vscale_pk_rows_lane (const SrcImage &src, const ScaleDev &sd, const Dst &dst, const PostFast &pf, int width, int out_h, int x0, int y0)
+{
+  if (x0 >= width || y0 >= out_h)
+    return;
+  if (x0 + 4 <= width) {
+    vscale_ntap_lane4_rows<R> (src, sd, dst, pf, x0, y0, out_h);
+  } else {
+#pragma unroll 1
+    for (int y = y0; y < y0 + R && y < out_h; y++)
+#pragma unroll 1
+      for (int x = x0; x < width; x++)
+        vscale_body<SrcImage> (src, sd, dst, width, out_h, x, y);
+  }
+}
+
 // lane of the vertical pass kernel: 4 pixels from x0, the last lane of a row finishes pixel by pixel
 GSTAMD_HD void vscale_pk_lane (const SrcImage &src, const ScaleDev &sd, const Dst &dst, const PostFast &pf, int width, int out_h, int x0, int y)
 {

@@ -267,7 +267,7 @@ static bool emu_hscale420_reg (const VideoPlan &p, const SrcFront &sf, const Sca
     return false;
   const char *e = getenv ("GSTAMD_H420_ROWS");
   int lpw = e && atoi (e) > 0 ? atoi (e) : 12;
-  hp.lines_per_wave = std::max (4, (lpw + 3) & ~3);
+  hp.lines_per_wave = std::max (4, (lpw + 1) & ~1);
   g_h420_reg_runs++;
   if (sd0.nw == 3)
     run_h420_reg_ch<3> (hp, p.front.chroma_h, sd0.n_taps);
@@ -292,6 +292,22 @@ static void emu_vscale_pk (const SrcImage &src, const ScaleDev &sd, const Dst &d
   vscale_pk_lane (src, sd, d, pf, w, h, x0, y);
 }
 static void emu_vscale_pk (const SrcFront &, const ScaleDev &, const Dst &, const PostFast &, int, int, int, int) {}
+static int emu_vscale_rows ()
+{
+  const char *e = getenv ("GSTAMD_VSCALE_ROWS");
+  return e ? atoi (e) : 2;
+}
+static void emu_vscale_pk_rows (const SrcImage &src, const ScaleDev &sd, const Dst &d, const PostFast &pf, int w, int h, int rows)
+{
+  for (int y0 = 0; y0 < h; y0 += rows)
+    for (int x0 = 0; x0 < w; x0 += 4) {
+      if (rows == 4)
+        vscale_pk_rows_lane<4> (src, sd, d, pf, w, h, x0, y0);
+      else
+        vscale_pk_rows_lane<2> (src, sd, d, pf, w, h, x0, y0);
+    }
+}
+static void emu_vscale_pk_rows (const SrcFront &, const ScaleDev &, const Dst &, const PostFast &, int, int, int) {}
 
 template <class SRC>
 static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h, int max_span, TileGeom g,
@@ -314,6 +330,10 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
     return;
   }
   if (!horizontal && sd.kind == SCALE_NTAP && emu_is_image (src)) {      /* k_vscale_pk */
+    if (emu_vscale_rows () == 2 || emu_vscale_rows () == 4) {
+      emu_vscale_pk_rows (src, sd, d, pf, out_w, out_h, emu_vscale_rows ());
+      return;
+    }
     for (int y = 0; y < out_h; y++)
       for (int x0 = 0; x0 < out_w; x0 += 4)
         emu_vscale_pk (src, sd, d, pf, out_w, out_h, x0, y);

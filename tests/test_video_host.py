@@ -142,7 +142,7 @@ def test_hscale420_bodies_any_rows_per_wave(native_lib, emu_lib, idx_case, rows,
 H420_REG = [c for c in H420 if c[1][1] in ("I420", "YV12", "NV12", "NV21")]
 
 
-@pytest.mark.parametrize("rows", [4, 8, 20])
+@pytest.mark.parametrize("rows", [4, 6, 10, 20])
 @pytest.mark.parametrize("idx_case", H420_REG, ids=lambda c: c[1][0])
 def test_hscale420_reg_bodies_any_lines_per_wave(native_lib, emu_lib, idx_case, rows, monkeypatch):
     """k_hscale420_reg (line pairs, closed-form chroma pairing, fixed register roles): same bytes for any block height, crop and

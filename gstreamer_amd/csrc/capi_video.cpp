@@ -200,7 +200,7 @@ static int ensure_tables (GstAmdVideoConverter *c)
     const ScalePass &s0 = p.passes[0];
     c->tmp_w = s0.horizontal ? s0.out_size : p.in_info.width;
     c->tmp_h = s0.horizontal ? p.in_info.height : s0.out_size;
-    c->tmp_size = (size_t) c->tmp_w * 4 * c->tmp_h;
+    c->tmp_size = (size_t) c->tmp_w * 4 * (c->tmp_h + 1);      /* + the spare row k_hscale420_reg sends its out-of-picture lines to */
     if ((e = hipMalloc ((void **) &c->tmp, c->tmp_size)) != hipSuccess)
       return hip_fail (e, "hipMalloc(tmp)");
   }

@@ -274,7 +274,7 @@ struct H420RegParams {
   int crow_lo, crow_hi;           // chroma rows the upsampler may touch (frame rows around a crop)
   const uint32_t *offset, *tapw;  // ScaleDev::offset / tapw
   int nw4;
-  uint8_t *dst;                   // AYUV image, out_w x height
+  uint8_t *dst;                   // AYUV image, out_w x (height + 1): one spare row takes the stores of lines outside the picture
   int dstride;
   int out_w, tile_w, lines_per_wave;      // even; wave b covers lines [b * lpw - 1, (b + 1) * lpw - 1)
 };
@@ -300,31 +300,33 @@ GSTAMD_H420_HOSTDEV void h420r_rows (int crow_lo, int crow_hi, int y, int *heavy
 
 GSTAMD_HD int h420r_crow (const H420RegParams &p, int r) { return r < p.crow_lo ? p.crow_lo : (r > p.crow_hi ? p.crow_hi : r); }
 
+template <int SEMI>
 GSTAMD_HD void h420r_load_raw (const H420RegParams &p, int crow, int k0, H420Raw &r)
 {
   const int cw = p.width >> 1, km = k0 > 0 ? k0 - 1 : 0, kp = k0 + 8 < cw ? k0 + 8 : cw - 1;
-  if (p.semi) {
+  if (SEMI) {
     const uint8_t *row = p.c0 + (ptrdiff_t) crow * p.cstride;
-    const uint4 m = *(const uint4 *) (row + 2 * k0);
+    const uint4 m = *(const uint4 *) (row + (uint32_t) (2 * k0));
     r.u0 = m.x, r.u1 = m.y, r.v0 = m.z, r.v1 = m.w;
-    r.um = *(const uint16_t *) (row + 2 * km);
-    r.up = *(const uint16_t *) (row + 2 * kp);
+    r.um = *(const uint16_t *) (row + (uint32_t) (2 * km));
+    r.up = *(const uint16_t *) (row + (uint32_t) (2 * kp));
     r.vm = r.vp = 0;
   } else {
     const uint8_t *ru = p.c0 + (ptrdiff_t) crow * p.cstride, *rv = p.c1 + (ptrdiff_t) crow * p.cstride;
-    const uint2 mu = *(const uint2 *) (ru + k0), mv = *(const uint2 *) (rv + k0);
+    const uint2 mu = *(const uint2 *) (ru + (uint32_t) k0), mv = *(const uint2 *) (rv + (uint32_t) k0);
     r.u0 = mu.x, r.u1 = mu.y, r.v0 = mv.x, r.v1 = mv.y;
-    r.um = ru[km], r.up = ru[kp], r.vm = rv[km], r.vp = rv[kp];
+    r.um = ru[(uint32_t) km], r.up = ru[(uint32_t) kp], r.vm = rv[(uint32_t) km], r.vp = rv[(uint32_t) kp];
   }
 }
 
 // loads of pair u (lines 2u-1, 2u; line numbers clamped into the picture, the caller skips lines outside it)
+template <int SEMI>
 GSTAMD_HD void h420r_request (const H420RegParams &p, int u, int x0, H420Pair &q)
 {
   const int ya = 2 * u - 1 < 0 ? 0 : 2 * u - 1, yb = 2 * u < p.height ? 2 * u : p.height - 1;
   q.la = *(const uint4 *) (p.y + (ptrdiff_t) ya * p.ystride + (uint32_t) x0);
   q.lb = *(const uint4 *) (p.y + (ptrdiff_t) yb * p.ystride + (uint32_t) x0);
-  h420r_load_raw (p, h420r_crow (p, u), x0 >> 1, q.raw);
+  h420r_load_raw<SEMI> (p, h420r_crow (p, u), x0 >> 1, q.raw);
 }
 
 GSTAMD_HD void h420r_stage_luma (const uint4 &l, uint32_t *py16)
@@ -357,16 +359,15 @@ GSTAMD_HD uint32_t h420r_lds (const uint32_t *p)
 }
 
 // outputs t0 + lane + 64 i of one line from its byte planes; AYUV words, plain stores (the vertical pass reads them next).
-// xo[i] = 4 * x: byte offset of the output in its row
+// No predicates: lanes past the tile's end repeat its last output (same taps, same bytes, same address) so that every line costs
+// exactly four stores - the waits on the prefetched loads of the next pair can then count past them instead of draining them.
 template <int NW>
 GSTAMD_HD void h420r_filter_line (const uint32_t *line, const Dot4Taps<NW> &ft, uint8_t *drow, int t0, int t1, int lane)
 {
   const int pw = GSTAMD_H420_PLANE_BYTES / 4;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int x = t0 + lane + 64 * i;
-    if (x >= t1)
-      break;
+    const int x = t0 + lane + 64 * i, xc = x < t1 ? x : t1 - 1;
     const uint32_t *b = line + ft.w0[i];
     uint32_t wy[NW], wu[NW], wv[NW];
 #pragma unroll
@@ -383,7 +384,7 @@ GSTAMD_HD void h420r_filter_line (const uint32_t *line, const Dot4Taps<NW> &ft, 
       au = dot4_i8 (wu[k], t, au);
       av = dot4_i8 (wv[k], t, av);
     }
-    *(uint32_t *) (drow + (uint32_t) (4 * x)) = 0xffu | (h420r_finish (ay) << 8) | (h420r_finish (au) << 16) | (h420r_finish (av) << 24);
+    *(uint32_t *) (drow + (uint32_t) (4 * xc)) = 0xffu | (h420r_finish (ay) << 8) | (h420r_finish (au) << 16) | (h420r_finish (av) << 24);
   }
 }
 
@@ -407,11 +408,11 @@ GSTAMD_HD void h420r_fetch_taps (const H420RegParams &p, int xa, int t0, int t1,
 
 // stage pair u from `q`: install its chroma row into `fresh` (the set that held the older row), then line 2u-1 = 3 * older + newer,
 // line 2u = older + 3 * newer.  `older` is the other set.
-template <int CH>
+template <int CH, int SEMI>
 GSTAMD_HD void h420r_stage_pair (const H420RegParams &p, const H420Pair &q, const uint32_t *older, uint32_t *fresh, uint32_t *lds, int w0)
 {
   const int pw = GSTAMD_H420_PLANE_BYTES / 4;
-  h420_filter_raw2<CH> (p.semi != 0, p.u_first != 0, q.raw, fresh);
+  h420_filter_raw2<CH> (SEMI != 0, p.u_first != 0, q.raw, fresh);
   h420r_stage_luma (q.la, lds + w0);
   h420_blend_store (older, fresh, lds + pw + w0, lds + 2 * pw + w0);
   h420r_stage_luma (q.lb, lds + GSTAMD_H420_LINE_WORDS + w0);
@@ -422,10 +423,9 @@ template <int NW>
 GSTAMD_HD void h420r_filter_pair (const H420RegParams &p, const uint32_t *lds, const Dot4Taps<NW> &ft, int u, int t0, int t1, int lane)
 {
   const int ya = 2 * u - 1, yb = 2 * u;
-  if (ya >= 0)
-    h420r_filter_line<NW> (lds, ft, p.dst + (ptrdiff_t) ya * p.dstride, t0, t1, lane);
-  if (yb < p.height)
-    h420r_filter_line<NW> (lds + GSTAMD_H420_LINE_WORDS, ft, p.dst + (ptrdiff_t) yb * p.dstride, t0, t1, lane);
+  // lines -1 and `height` (first / last pair) land in the spare row after the image
+  h420r_filter_line<NW> (lds, ft, p.dst + (ptrdiff_t) (ya >= 0 ? ya : p.height) * p.dstride, t0, t1, lane);
+  h420r_filter_line<NW> (lds + GSTAMD_H420_LINE_WORDS, ft, p.dst + (ptrdiff_t) (yb < p.height ? yb : p.height) * p.dstride, t0, t1, lane);
 }
 
 // source span of the outputs [t0, t1)

@@ -195,9 +195,10 @@ __global__ __launch_bounds__ (64) void k_hscale420_dot4 (SrcFront src, ScaleDev 
   }
 }
 
-// the regular 4:2:0 case of the same pass (video_hscale420.h, second half): line pairs, fixed register roles
-template <int NW, int CH>
-__global__ __launch_bounds__ (64) void k_hscale420_reg (H420RegParams p, int n_taps, int late)
+// the regular 4:2:0 case of the same pass (video_hscale420.h, second half): line pairs, fixed register roles, straight-line
+// memory operations (every pair: 2 luma + the chroma-row loads, then 8 stores)
+template <int NW, int CH, int SEMI>
+__global__ __launch_bounds__ (64) void k_hscale420_reg (H420RegParams p, int n_taps)
 {
   extern __shared__ uint32_t lds_w[];
   const int lane = (int) threadIdx.x, t0 = (int) blockIdx.x * p.tile_w;
@@ -215,29 +216,23 @@ __global__ __launch_bounds__ (64) void k_hscale420_reg (H420RegParams p, int n_t
   uint32_t P[8], Q[8];
   {
     H420Raw r;
-    h420r_load_raw (p, h420r_crow (p, u0 - 1), x0 >> 1, r);
-    h420_filter_raw2<CH> (p.semi != 0, p.u_first != 0, r, P);
+    h420r_load_raw<SEMI> (p, h420r_crow (p, u0 - 1), x0 >> 1, r);
+    h420_filter_raw2<CH> (SEMI != 0, p.u_first != 0, r, P);
   }
   H420Pair cur, nxt;
-  h420r_request (p, u0, x0, cur);
+  h420r_request<SEMI> (p, u0, x0, cur);
   for (int u = u0; u < u1; u += 2) {
-    h420r_stage_pair<CH> (p, cur, P, Q, lds_w, w0);
-    if (!late)
-      h420r_request (p, u + 1 < u1 ? u + 1 : u1 - 1, x0, nxt);
+    h420r_stage_pair<CH, SEMI> (p, cur, P, Q, lds_w, w0);
+    h420r_request<SEMI> (p, u + 1 < u1 ? u + 1 : u1 - 1, x0, nxt);
     wave_lds_sync ();
     h420r_filter_pair<NW> (p, lds_w, ft, u, t0, t1, lane);
-    if (late)
-      h420r_request (p, u + 1 < u1 ? u + 1 : u1 - 1, x0, nxt);
     wave_lds_sync ();
     if (u + 1 >= u1)
       break;
-    h420r_stage_pair<CH> (p, nxt, Q, P, lds_w, w0);
-    if (!late)
-      h420r_request (p, u + 2 < u1 ? u + 2 : u1 - 1, x0, cur);
+    h420r_stage_pair<CH, SEMI> (p, nxt, Q, P, lds_w, w0);
+    h420r_request<SEMI> (p, u + 2 < u1 ? u + 2 : u1 - 1, x0, cur);
     wave_lds_sync ();
     h420r_filter_pair<NW> (p, lds_w, ft, u + 1, t0, t1, lane);
-    if (late)
-      h420r_request (p, u + 2 < u1 ? u + 2 : u1 - 1, x0, cur);
     wave_lds_sync ();
   }
 }
@@ -653,14 +648,13 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
   return hipGetLastError ();
 }
 
-template <int NW>
+template <int NW, int SEMI>
 static hipError_t launch_h420_reg_nw (H420RegParams p, int chroma_h, int n_taps, hipStream_t stream)
 {
-  static const int late = getenv ("GSTAMD_H420_LATE") ? atoi (getenv ("GSTAMD_H420_LATE")) : 0;
   static const int lpw_env = getenv ("GSTAMD_H420_ROWS") ? atoi (getenv ("GSTAMD_H420_ROWS")) : -1;
   const size_t lds = (size_t) GSTAMD_H420_LINE_WORDS * 4 * 2;
-  const void *fn = chroma_h == CHROMA_H_H2_CS ? (const void *) k_hscale420_reg<NW, CHROMA_H_H2_CS> :
-      (chroma_h == CHROMA_H_H2 ? (const void *) k_hscale420_reg<NW, CHROMA_H_H2> : (const void *) k_hscale420_reg<NW, CHROMA_H_NONE>);
+  const void *fn = chroma_h == CHROMA_H_H2_CS ? (const void *) k_hscale420_reg<NW, CHROMA_H_H2_CS, SEMI> :
+      (chroma_h == CHROMA_H_H2 ? (const void *) k_hscale420_reg<NW, CHROMA_H_H2, SEMI> : (const void *) k_hscale420_reg<NW, CHROMA_H_NONE, SEMI>);
   const int tiles = (p.out_w + p.tile_w - 1) / p.tile_w;
   /* line pairs per wave: every wave of the launch resident at once (one round, no tail) */
   static int slots[3] = {0, 0, 0};
@@ -681,11 +675,11 @@ static hipError_t launch_h420_reg_nw (H420RegParams p, int chroma_h, int n_taps,
   p.lines_per_wave = 2 * ppw;
   dim3 grid (tiles, (pairs + ppw - 1) / ppw);
   if (chroma_h == CHROMA_H_H2_CS)
-    hipLaunchKernelGGL ((k_hscale420_reg<NW, CHROMA_H_H2_CS>), grid, dim3 (64), lds, stream, p, n_taps, late);
+    hipLaunchKernelGGL ((k_hscale420_reg<NW, CHROMA_H_H2_CS, SEMI>), grid, dim3 (64), lds, stream, p, n_taps);
   else if (chroma_h == CHROMA_H_H2)
-    hipLaunchKernelGGL ((k_hscale420_reg<NW, CHROMA_H_H2>), grid, dim3 (64), lds, stream, p, n_taps, late);
+    hipLaunchKernelGGL ((k_hscale420_reg<NW, CHROMA_H_H2, SEMI>), grid, dim3 (64), lds, stream, p, n_taps);
   else
-    hipLaunchKernelGGL ((k_hscale420_reg<NW, CHROMA_H_NONE>), grid, dim3 (64), lds, stream, p, n_taps, late);
+    hipLaunchKernelGGL ((k_hscale420_reg<NW, CHROMA_H_NONE, SEMI>), grid, dim3 (64), lds, stream, p, n_taps);
   return hipGetLastError ();
 }
 
@@ -702,9 +696,9 @@ hipError_t launch_hscale420_reg (const H420RegParams &p, int chroma_h, int nw, i
   if (!ok)
     return hipErrorNotSupported;
   switch (nw) {
-    case 3: return launch_h420_reg_nw<3> (p, chroma_h, n_taps, stream);
-    case 4: return launch_h420_reg_nw<4> (p, chroma_h, n_taps, stream);
-    case 5: return launch_h420_reg_nw<5> (p, chroma_h, n_taps, stream);
+    case 3: return p.semi ? launch_h420_reg_nw<3, 1> (p, chroma_h, n_taps, stream) : launch_h420_reg_nw<3, 0> (p, chroma_h, n_taps, stream);
+    case 4: return p.semi ? launch_h420_reg_nw<4, 1> (p, chroma_h, n_taps, stream) : launch_h420_reg_nw<4, 0> (p, chroma_h, n_taps, stream);
+    case 5: return p.semi ? launch_h420_reg_nw<5, 1> (p, chroma_h, n_taps, stream) : launch_h420_reg_nw<5, 0> (p, chroma_h, n_taps, stream);
     default: return hipErrorNotSupported;
   }
 }
@@ -729,7 +723,7 @@ hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int ss
     hipLaunchKernelGGL (k_hscale<SrcImage>, grid, block, 0, stream, src, sd, d, out_w, out_h);
   else if (sd.kind == SCALE_NTAP) {
     /* the packed kernel runs the generic post stage too (post_px), so it serves every N-tap vertical pass */
-    static const int vrows = getenv ("GSTAMD_VSCALE_ROWS") ? atoi (getenv ("GSTAMD_VSCALE_ROWS")) : 2;
+    static const int vrows = getenv ("GSTAMD_VSCALE_ROWS") ? atoi (getenv ("GSTAMD_VSCALE_ROWS")) : 1;
     /* neighbouring output rows of an N-tap filter always share source rows (the window is 2a steps wide) */
     if (vrows == 4) {
       dim3 vgrid ((out_w + 255) / 256, (out_h + 3) / 4);

@@ -162,7 +162,7 @@ static void run_hscale420 (const SrcFront &src, const ScaleDev &sd, const Dst &d
 // k_hscale420_reg: the decision of capi_video.cpp (closed-form pairing) + launch_hscale420_reg (alignment, window words), then the
 // kernel's loop with per-lane register state
 static int g_h420_reg_runs = 0;
-template <int NW, int CH>
+template <int NW, int CH, int SEMI>
 static void run_h420_reg (H420RegParams p, int n_taps)
 {
   std::vector<uint32_t> ldsv (2 * GSTAMD_H420_LINE_WORDS + 4);
@@ -184,22 +184,22 @@ static void run_h420_reg (H420RegParams p, int n_taps)
           s.x0 = p.width - 16;
         h420r_fetch_taps<NW> (p, xa, t0, t1, lane, s.ft);
         H420Raw r;
-        h420r_load_raw (p, h420r_crow (p, u0 - 1), s.x0 >> 1, r);
-        h420_filter_raw2<CH> (p.semi != 0, p.u_first != 0, r, s.P);
-        h420r_request (p, u0, s.x0, s.cur);
+        h420r_load_raw<SEMI> (p, h420r_crow (p, u0 - 1), s.x0 >> 1, r);
+        h420_filter_raw2<CH> (SEMI != 0, p.u_first != 0, r, s.P);
+        h420r_request<SEMI> (p, u0, s.x0, s.cur);
       }
       for (int u = u0; u < u1; u += 2) {
         for (int lane = 0; lane < 64; lane++) {
-          h420r_stage_pair<CH> (p, L[lane].cur, L[lane].P, L[lane].Q, lds, 4 * lane);
-          h420r_request (p, u + 1 < u1 ? u + 1 : u1 - 1, L[lane].x0, L[lane].nxt);
+          h420r_stage_pair<CH, SEMI> (p, L[lane].cur, L[lane].P, L[lane].Q, lds, 4 * lane);
+          h420r_request<SEMI> (p, u + 1 < u1 ? u + 1 : u1 - 1, L[lane].x0, L[lane].nxt);
         }
         for (int lane = 0; lane < 64; lane++)
           h420r_filter_pair<NW> (p, lds, L[lane].ft, u, t0, t1, lane);
         if (u + 1 >= u1)
           break;
         for (int lane = 0; lane < 64; lane++) {
-          h420r_stage_pair<CH> (p, L[lane].nxt, L[lane].Q, L[lane].P, lds, 4 * lane);
-          h420r_request (p, u + 2 < u1 ? u + 2 : u1 - 1, L[lane].x0, L[lane].cur);
+          h420r_stage_pair<CH, SEMI> (p, L[lane].nxt, L[lane].Q, L[lane].P, lds, 4 * lane);
+          h420r_request<SEMI> (p, u + 2 < u1 ? u + 2 : u1 - 1, L[lane].x0, L[lane].cur);
         }
         for (int lane = 0; lane < 64; lane++)
           h420r_filter_pair<NW> (p, lds, L[lane].ft, u + 1, t0, t1, lane);
@@ -207,15 +207,23 @@ static void run_h420_reg (H420RegParams p, int n_taps)
     }
 }
 
+template <int NW, int SEMI>
+static void run_h420_reg_ch2 (const H420RegParams &p, int chroma_h, int n_taps)
+{
+  if (chroma_h == CHROMA_H_H2_CS)
+    run_h420_reg<NW, CHROMA_H_H2_CS, SEMI> (p, n_taps);
+  else if (chroma_h == CHROMA_H_H2)
+    run_h420_reg<NW, CHROMA_H_H2, SEMI> (p, n_taps);
+  else
+    run_h420_reg<NW, CHROMA_H_NONE, SEMI> (p, n_taps);
+}
 template <int NW>
 static void run_h420_reg_ch (const H420RegParams &p, int chroma_h, int n_taps)
 {
-  if (chroma_h == CHROMA_H_H2_CS)
-    run_h420_reg<NW, CHROMA_H_H2_CS> (p, n_taps);
-  else if (chroma_h == CHROMA_H_H2)
-    run_h420_reg<NW, CHROMA_H_H2> (p, n_taps);
+  if (p.semi)
+    run_h420_reg_ch2<NW, 1> (p, chroma_h, n_taps);
   else
-    run_h420_reg<NW, CHROMA_H_NONE> (p, n_taps);
+    run_h420_reg_ch2<NW, 0> (p, chroma_h, n_taps);
 }
 
 static bool emu_hscale420_reg (const VideoPlan &p, const SrcFront &sf, const ScaleDev &sd0, uint8_t *tmp, int tmp_w)
@@ -295,7 +303,7 @@ static void emu_vscale_pk (const SrcFront &, const ScaleDev &, const Dst &, cons
 static int emu_vscale_rows ()
 {
   const char *e = getenv ("GSTAMD_VSCALE_ROWS");
-  return e ? atoi (e) : 2;
+  return e ? atoi (e) : 1;
 }
 static void emu_vscale_pk_rows (const SrcImage &src, const ScaleDev &sd, const Dst &d, const PostFast &pf, int w, int h, int rows)
 {
@@ -707,7 +715,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
   }
   const ScalePass &s0 = p.passes[0];
   const int tw = s0.horizontal ? s0.out_size : p.in_info.width, th = s0.horizontal ? p.in_info.height : s0.out_size;
-  std::vector<uint8_t> tmp ((size_t) tw * 4 * th);
+  std::vector<uint8_t> tmp ((size_t) tw * 4 * (th + 1));
   if (!emu_hscale420_reg (p, sf, sd[0], tmp.data (), tw))
   run_scale (s0.horizontal, sf, sd[0], mk (tmp.data (), tw * 4, false), tw, th, s0.max_span,
       s0.horizontal ? pass_tile_geom (s0) : TileGeom {0, 0}, pf_none);

@@ -365,26 +365,34 @@ template <int NW>
 GSTAMD_HD void h420r_filter_line (const uint32_t *line, const Dot4Taps<NW> &ft, uint8_t *drow, int t0, int t1, int lane)
 {
   const int pw = GSTAMD_H420_PLANE_BYTES / 4;
+  // two outputs per round: their 6 * NW LDS reads go out back to back before the first dot product needs one (the LDS reaches its
+  // rate only with many reads in flight per wait)
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int x = t0 + lane + 64 * i, xc = x < t1 ? x : t1 - 1;
-    const uint32_t *b = line + ft.w0[i];
-    uint32_t wy[NW], wu[NW], wv[NW];
+  for (int i0 = 0; i0 < 4; i0 += 2) {
+    uint32_t wy[2][NW], wu[2][NW], wv[2][NW];
 #pragma unroll
-    for (int k = 0; k < NW; k++) {
-      wy[k] = h420r_lds (b + k);
-      wu[k] = h420r_lds (b + pw + k);
-      wv[k] = h420r_lds (b + 2 * pw + k);
+    for (int j = 0; j < 2; j++) {
+      const uint32_t *b = line + ft.w0[i0 + j];
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        wy[j][k] = h420r_lds (b + k);
+        wu[j][k] = h420r_lds (b + pw + k);
+        wv[j][k] = h420r_lds (b + 2 * pw + k);
+      }
     }
-    int ay = 128 * 64 + 32, au = 128 * 64 + 32, av = 128 * 64 + 32;
 #pragma unroll
-    for (int k = 0; k < NW; k++) {
-      const uint32_t t = ft.t[i][k];
-      ay = dot4_i8 (wy[k], t, ay);
-      au = dot4_i8 (wu[k], t, au);
-      av = dot4_i8 (wv[k], t, av);
+    for (int j = 0; j < 2; j++) {
+      const int i = i0 + j, x = t0 + lane + 64 * i, xc = x < t1 ? x : t1 - 1;
+      int ay = 128 * 64 + 32, au = 128 * 64 + 32, av = 128 * 64 + 32;
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        const uint32_t t = ft.t[i][k];
+        ay = dot4_i8 (wy[j][k], t, ay);
+        au = dot4_i8 (wu[j][k], t, au);
+        av = dot4_i8 (wv[j][k], t, av);
+      }
+      *(uint32_t *) (drow + (uint32_t) (4 * xc)) = 0xffu | (h420r_finish (ay) << 8) | (h420r_finish (au) << 16) | (h420r_finish (av) << 24);
     }
-    *(uint32_t *) (drow + (uint32_t) (4 * xc)) = 0xffu | (h420r_finish (ay) << 8) | (h420r_finish (au) << 16) | (h420r_finish (av) << 24);
   }
 }
 

@@ -100,6 +100,26 @@ GSTAMD_HD void bil_fetch (const BilParams &bp, const Planes &pl, int t0, int t1,
   bil_span (bp, t0, t1, &x_lo, &x_hi, &k_lo, &k_hi);
   const int x = (x_lo & ~15) + 16 * lane, k = (k_lo & ~7) + 8 * lane;
   const uint8_t *y0 = pl.p[0] + (size_t) r0 * pl.stride[0], *y1 = y0 + pl.stride[0];
+  if (vec && (w & 15) == 0) {
+    // every piece of every row is whole (width % 16 == 0): all six loads in ONE straight line, lanes outside the span reading a
+    // valid piece they will not commit.  With the per-piece edge fallbacks in the same control flow the compiler has to assume
+    // their byte loads may still be writing these registers and drains the queue before every wide load - five serial round
+    // trips per tile instead of one.
+    const int xc = x < x_hi ? x : (x_lo & ~15), kc = k <= k_hi ? k : (k_lo & ~7);
+    const uint8_t *rows[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      int ra, rb, role;
+      bil_rows (bp, r0 + (s >> 1), &ra, &rb, &role);
+      rows[s] = pl.p[1] + (ptrdiff_t) ((s & 1) ? rb : ra) * pl.stride[1] + 2 * kc;
+    }
+    wide_load16<true> (y0 + xc, 4, true, r.a);
+    wide_load16<true> (y1 + xc, 4, true, r.b);
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+      wide_load16<false> (rows[s], 4, true, r.m[s]);
+    return;
+  }
   if (x < x_hi) {
     if (((w - x) >> 2) >= 4 && vec) {
       wide_load16<true> (y0 + x, 4, true, r.a);

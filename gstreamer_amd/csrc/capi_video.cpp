@@ -370,6 +370,15 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     e = launch_convert_pair (fp, p.front.chroma_h, 1, &y, &uv, &dst, pl.stride[0], pl.stride[1], dstride, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair");
   }
+  if (p.fast_422 && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && ((uintptr_t) dst % 16) == 0 && (dstride % 16) == 0 &&
+      getenv ("GSTAMD_NO_FAST422") == nullptr) {
+    Fast422Params q;
+    q.fp = make_fast_params (p);
+    q.chroma_h = p.front.chroma_h;
+    fast422_selectors (p.front.pos[1], p.front.pos[2], p.front.pos[3], &q);
+    e = launch_convert422 (q, pl.p[0], pl.stride[0], dst, dstride, stream);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert422");
+  }
   if (p.passes.empty ()) {
     e = launch_convert (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert");

@@ -237,6 +237,14 @@ __global__ __launch_bounds__ (64) void k_hscale420_reg (H420RegParams p, int n_t
   }
 }
 
+// unscaled packed 4:2:2 -> 4-byte RGB (video_422_fast.h): a lane = 8 pixels of one line
+__global__ __launch_bounds__ (256) void k_convert422 (Fast422Params p, const uint8_t *src, int sstride, uint8_t *dst, int dstride)
+{
+  const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 8, y = (int) blockIdx.y;
+  if (x0 < p.fp.width)
+    convert422_lane8_any (p, src + (size_t) y * sstride, dst + (size_t) y * dstride, x0);
+}
+
 // vertical N-tap pass over an AYUV image, 4 pixels per lane, one wave per workgroup
 __global__ __launch_bounds__ (64) void k_vscale_pk (SrcImage src, ScaleDev sd, Dst dst, PostFast pf, int width, int out_h)
 {
@@ -701,6 +709,13 @@ hipError_t launch_hscale420_reg (const H420RegParams &p, int chroma_h, int nw, i
     case 5: return p.semi ? launch_h420_reg_nw<5, 1> (p, chroma_h, n_taps, stream) : launch_h420_reg_nw<5, 0> (p, chroma_h, n_taps, stream);
     default: return hipErrorNotSupported;
   }
+}
+
+hipError_t launch_convert422 (const Fast422Params &p, const uint8_t *src, int sstride, uint8_t *dst, int dstride, hipStream_t stream)
+{
+  dim3 grid ((p.fp.width / 8 + 255) / 256, p.fp.height);
+  hipLaunchKernelGGL (k_convert422, grid, dim3 (256), 0, stream, p, src, sstride, dst, dstride);
+  return hipGetLastError ();
 }
 
 hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int sstride, const ScaleDev &sd, uint8_t *dst,

@@ -237,6 +237,13 @@ VIDEO_CASES = [
     ("uyvy_rgba_33x17", "UYVY", 33, 17, "RGBA", 33, 17, {}, None, None, "random"),
     ("yvyu_argb_130x70_mpeg2", "YVYU", 130, 70, "ARGB", 130, 70, {}, None, "mpeg2", "random"),
     ("vyuy_bgra_33x17_odd_tail_quirk", "VYUY", 33, 17, "BGRA", 33, 17, {}, None, None, "random"),
+    # ---- k_convert422 (video_422_fast.h): every macropixel order, chroma site and a few RGB orders, edge groups
+    ("uyvy_argb_fast422_jpeg", "UYVY", 640, 48, "ARGB", 640, 48, {}, None, "jpeg", "random"),
+    ("yvyu_rgba_fast422_mpeg2", "YVYU", 648, 40, "RGBA", 648, 40, {}, None, "mpeg2", "random"),
+    ("vyuy_abgr_fast422_none", "VYUY", 64, 33, "ABGR", 64, 33, {}, None, "none", "random"),
+    ("yuy2_bgrx_fast422_cosited_8px", "YUY2", 8, 5, "BGRx", 8, 5, {}, None, "cosited", "random"),
+    ("yuy2_bgra_fast422_1080p", "YUY2", 1920, 1080, "BGRA", 1920, 1080, {}, None, None, "random"),
+    ("uyvy_xrgb_fast422_bt601", "UYVY", 720, 480, "xRGB", 720, 480, {}, "bt601", None, "random"),
     ("yuy2_bgra_720p_to_360p_bilinear", "YUY2", 1280, 720, "BGRA", 640, 360, LIN, None, None, "random"),
     ("uyvy_nv12_322x241", "UYVY", 322, 241, "NV12", 322, 241, {}, None, None, "random"),
     ("yuy2_nv12_640x600_cosited", "YUY2", 640, 600, "NV12", 640, 600, {}, None, None, "random"),

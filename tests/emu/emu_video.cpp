@@ -11,6 +11,7 @@
 #include "../../gstreamer_amd/csrc/video_fast.h"
 #include "../../gstreamer_amd/csrc/video_scale_fast.h"
 #include "../../gstreamer_amd/csrc/video_hscale420.h"
+#include "../../gstreamer_amd/csrc/video_422_fast.h"
 #include <cstdlib>
 #include <algorithm>
 #include "../../gstreamer_amd/csrc/video_pack.h"
@@ -356,6 +357,8 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
     }
 }
 
+static int g_fast422_runs = 0;
+extern "C" int emu_fast422_runs (void) { return g_fast422_runs; }
 static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok, bool rgb24);
 
 extern "C" int emu_h420_runs (void) { return g_h420_runs; }
@@ -565,6 +568,18 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     }
 #undef FOR_CH
 #undef FOR_LAYOUT
+    return GSTAMD_OK;
+  }
+  if (p.fast_422 && vec_ok && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && ((uintptr_t) d0 % 16) == 0 && (dstride % 16) == 0 &&
+      getenv ("GSTAMD_NO_FAST422") == nullptr) {        /* k_convert422 */
+    Fast422Params q;
+    q.fp = emu_fast_params (p);
+    q.chroma_h = p.front.chroma_h;
+    fast422_selectors (p.front.pos[1], p.front.pos[2], p.front.pos[3], &q);
+    g_fast422_runs++;
+    for (int y = 0; y < p.front.height; y++)
+      for (int x0 = 0; x0 < p.front.width; x0 += 8)
+        convert422_lane8_any (q, pl.p[0] + (size_t) y * pl.stride[0], d0 + (size_t) y * dstride, x0);
     return GSTAMD_OK;
   }
   if (p.passes.empty ()) {

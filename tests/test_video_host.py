@@ -167,6 +167,25 @@ def test_hscale420_switch_off_gives_the_same_bytes(native_lib, emu_lib, monkeypa
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
 
 
+FAST422 = [c for c in SMALL if "_fast422_" in c[1][0] or c[1][0] == "yuy2_bgra_640x360"]
+
+
+@pytest.mark.parametrize("idx_case", FAST422, ids=lambda c: c[1][0])
+def test_convert422_body_is_the_path_taken(native_lib, emu_lib, idx_case, monkeypatch):
+    """k_convert422 (video_422_fast.h) serves unscaled packed 4:2:2 -> RGB with whole 8-pixel groups; switched off, the generic kernel
+    gives the same bytes."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    before = emu_lib.emu_fast422_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_fast422_runs() == before + 1
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+    monkeypatch.setenv("GSTAMD_NO_FAST422", "1")
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_fast422_runs() == before + 1
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
 WIDE = [c for c in SMALL if c[1][1] in ("NV12", "NV21") and c[1][2] >= 512 and (c[1][2], c[1][3]) == (c[1][5], c[1][6])
         and c[1][4] not in ("AYUV",)]
 

@@ -370,6 +370,19 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     e = launch_convert_pair (fp, p.front.chroma_h, 1, &y, &uv, &dst, pl.stride[0], pl.stride[1], dstride, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair");
   }
+  if (p.fast_420p && ((uintptr_t) pl.p[0] % 8) == 0 && (pl.stride[0] % 8) == 0 && ((uintptr_t) pl.p[1] % 4) == 0 && ((uintptr_t) pl.p[2] % 4) == 0 &&
+      (pl.stride[1] % 4) == 0 && pl.stride[1] == pl.stride[2] && ((uintptr_t) dst % 16) == 0 && (dstride % 16) == 0 &&
+      getenv ("GSTAMD_NO_FAST420P") == nullptr) {
+    Fast420pParams q;
+    q.fp = make_fast_params (p);
+    q.y = pl.p[0];
+    q.u = pl.p[p.front.u_plane];
+    q.v = pl.p[p.front.v_plane];
+    q.ystride = pl.stride[0];
+    q.cstride = pl.stride[1];
+    e = launch_convert420p (q, dst, dstride, stream);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert420p");
+  }
   if (p.fast_422 && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && ((uintptr_t) dst % 16) == 0 && (dstride % 16) == 0 &&
       getenv ("GSTAMD_NO_FAST422") == nullptr) {
     Fast422Params q;

@@ -1289,6 +1289,9 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   /* capture direction (video_422_fast.h): unscaled packed 4:2:2 -> 4-byte RGB, whole 8-pixel groups, no odd-width tail quirk */
   plan->fast_422 = plan->passes.empty () && fr.kind == UNPACK_PACKED422 && !plan->out_planar && matrix_no_wrap && (in_w % 8) == 0 &&
       fr.swap_k < 0 && !fr.chroma_v2;
+  /* decoder-output direction: the reference's I420 / YV12 -> RGB same-size fastpaths (nearest chroma), whole 8-pixel groups */
+  plan->fast_420p = plan->passes.empty () && fr.kind == UNPACK_PLANAR && fr.w_sub == 1 && fr.h_sub == 1 && fr.chroma_h == CHROMA_H_NONE &&
+      !fr.chroma_v2 && !plan->out_planar && matrix_no_wrap && (in_w % 8) == 0;
   /* the encoder-facing block kernel (video_encode_fast.h): unscaled 4-byte RGB -> 4:2:0 planar / semi-planar through the table
    * matrix (which the reference only picks when no pixel can clip, so every row sum stays inside 16 bits) with byte coefficients */
   plan->fast_enc420 = false;
@@ -1314,7 +1317,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         plan->fast_post = false;
     }
   }
-  std::string d = plan->passes.empty () ? (plan->fast_pair ? "fused_convert_pair" : plan->fast_enc420 ? "fused_encode_420" : plan->fast_422 ? "fused_convert_422" : "fused_convert") : "scale";
+  std::string d = plan->passes.empty () ? (plan->fast_pair ? "fused_convert_pair" : plan->fast_enc420 ? "fused_encode_420" : plan->fast_422 ? "fused_convert_422" : plan->fast_420p ? "fused_convert_420p" : "fused_convert") : "scale";
   d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;
   d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : "";
   d += fr.chroma_v2 ? ",v2" : "";

@@ -147,6 +147,7 @@ struct VideoPlan {
   PackPlanarParams pack;
   bool fast_pair;             // BASELINE C2 shape: line-pair kernel of video_fast.h is applicable
   bool fast_enc420;           // unscaled 4-byte RGB -> 4:2:0 YUV through the table matrix: the block kernel of video_encode_fast.h applies
+  bool fast_420p;             // unscaled planar 4:2:0 -> 4-byte RGB with nearest chroma (the reference's convert_I420_BGRA family): video_422_fast.h
   bool fast_422;              // unscaled packed 4:2:2 -> 4-byte RGB through the no-wrap AYUV_ARGB matrix: video_422_fast.h applies
   bool fast_post;             // scaled plans: the post stage may run fast_pixel (matrix provably wrap-free, alpha stays 0xff)
   int im_raw[3][4];           // the rint()ed 8-bit matrix before the per-kind adjustments

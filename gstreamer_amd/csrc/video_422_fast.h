@@ -98,4 +98,50 @@ GSTAMD_HD void convert422_lane8_any (const Fast422Params &p, const uint8_t *srow
     convert422_lane8<CHROMA_H_NONE> (p, srow, drow, x0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The reference's own same-size fastpaths convert_I420_BGRA / _ARGB / _pack_ARGB (video-converter.c:3409-3530, I420 / YV12 -> any
+// 4-byte RGB): chroma is NOT interpolated there - sample x >> 1 of row y >> 1 (loadupdb) - and the matrix is the AYUV_ARGB arithmetic.
+// Decoder output -> display is this conversion.  One lane owns 8 pixels of the two lines that share a chroma row: 8 + 8 luma bytes,
+// 4 U and 4 V bytes in, 64 bytes out.  Planner condition: VideoPlan::fast_420p.
+// ------------------------------------------------------------------------------------------------
+struct Fast420pParams {
+  FastParams fp;
+  const uint8_t *y, *u, *v;
+  int ystride, cstride;
+};
+
+GSTAMD_HD void store8_stream (uint8_t *d, const uint32_t *o)
+{
+#ifdef __HIPCC__
+  typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
+  const u32x4 v0 = {o[0], o[1], o[2], o[3]}, v1 = {o[4], o[5], o[6], o[7]};
+  __builtin_nontemporal_store (v0, (u32x4 *) d);
+  __builtin_nontemporal_store (v1, (u32x4 *) (d + 16));
+#else
+  for (int i = 0; i < 8; i++)
+    ((uint32_t *) d)[i] = o[i];
+#endif
+}
+
+// pixels x0 .. x0+7 (x0 % 8 == 0, x0 + 8 <= width) of lines 2r and 2r+1 (the second one only if it exists)
+GSTAMD_HD void convert420p_lane8x2 (const Fast420pParams &p, uint8_t *__restrict__ dst, int dstride, int x0, int r)
+{
+  const int ya = 2 * r, yb = ya + 1 < p.fp.height ? ya + 1 : ya;
+  const uint2 la = *(const uint2 *) (p.y + (size_t) ya * p.ystride + x0), lb = *(const uint2 *) (p.y + (size_t) yb * p.ystride + x0);
+  const uint32_t u4 = *(const uint32_t *) (p.u + (size_t) r * p.cstride + (x0 >> 1)) ^ 0x80808080u;
+  const uint32_t v4 = *(const uint32_t *) (p.v + (size_t) r * p.cstride + (x0 >> 1)) ^ 0x80808080u;
+  const uint32_t ya0 = la.x ^ 0x80808080u, ya1 = la.y ^ 0x80808080u, yb0 = lb.x ^ 0x80808080u, yb1 = lb.y ^ 0x80808080u;
+  uint32_t oa[8], ob[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t ysel = 0x0c00000cu | ((uint32_t) (i & 3) << 8) | ((uint32_t) (i & 3) << 16);
+    const uint32_t csel = 0x0c00000cu | ((uint32_t) (i >> 1) << 8) | ((uint32_t) (i >> 1) << 16);
+    oa[i] = fast_pixel_uv (p.fp, i < 4 ? ya0 : ya1, ysel, u4, v4, csel);
+    ob[i] = fast_pixel_uv (p.fp, i < 4 ? yb0 : yb1, ysel, u4, v4, csel);
+  }
+  store8_stream (dst + (size_t) ya * dstride + 4 * (size_t) x0, oa);
+  if (ya + 1 < p.fp.height)
+    store8_stream (dst + (size_t) (ya + 1) * dstride + 4 * (size_t) x0, ob);
+}
+
 }  // namespace gstamd

@@ -245,6 +245,14 @@ __global__ __launch_bounds__ (256) void k_convert422 (Fast422Params p, const uin
     convert422_lane8_any (p, src + (size_t) y * sstride, dst + (size_t) y * dstride, x0);
 }
 
+// unscaled planar 4:2:0 -> 4-byte RGB, nearest chroma (video_422_fast.h): a lane = 8 pixels of a line pair
+__global__ __launch_bounds__ (256) void k_convert420p (Fast420pParams p, uint8_t *dst, int dstride)
+{
+  const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 8, r = (int) blockIdx.y;
+  if (x0 < p.fp.width)
+    convert420p_lane8x2 (p, dst, dstride, x0, r);
+}
+
 // vertical N-tap pass over an AYUV image, 4 pixels per lane, one wave per workgroup
 __global__ __launch_bounds__ (64) void k_vscale_pk (SrcImage src, ScaleDev sd, Dst dst, PostFast pf, int width, int out_h)
 {
@@ -709,6 +717,13 @@ hipError_t launch_hscale420_reg (const H420RegParams &p, int chroma_h, int nw, i
     case 5: return p.semi ? launch_h420_reg_nw<5, 1> (p, chroma_h, n_taps, stream) : launch_h420_reg_nw<5, 0> (p, chroma_h, n_taps, stream);
     default: return hipErrorNotSupported;
   }
+}
+
+hipError_t launch_convert420p (const Fast420pParams &p, uint8_t *dst, int dstride, hipStream_t stream)
+{
+  dim3 grid ((p.fp.width / 8 + 255) / 256, (p.fp.height + 1) / 2);
+  hipLaunchKernelGGL (k_convert420p, grid, dim3 (256), 0, stream, p, dst, dstride);
+  return hipGetLastError ();
 }
 
 hipError_t launch_convert422 (const Fast422Params &p, const uint8_t *src, int sstride, uint8_t *dst, int dstride, hipStream_t stream)

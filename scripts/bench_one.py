@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One of the secondary configs (see scripts/bench_configs.py):  bench_one.py c1|c3|c5|8k|rgb24|rgb24s|yuy2|nv12enc|c4|audio [iters]"""
+"""One of the secondary configs (see scripts/bench_configs.py):  bench_one.py c1|c3|c5|8k|rgb24|rgb24s|yuy2|i420|nv12enc|c4|audio [iters]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -23,6 +23,8 @@ elif which == "yuy2":
     B.video_case("1080p YUY2 -> BGRA", "YUY2", 1920, 1080, "BGRA", 1920, 1080, {}, it * 4)
 elif which == "nv12enc":
     B.video_case("4K BGRA -> NV12 (encoder feed)", "BGRA", 3840, 2160, "NV12", 3840, 2160, {}, it * 2)
+elif which == "i420":
+    B.video_case("4K I420 -> BGRA (decoder output -> display; the reference's convert_I420_BGRA fastpath)", "I420", 3840, 2160, "BGRA", 3840, 2160, {}, it * 2)
 elif which == "c4":
     B.compositor_case(it)
 else:

@@ -109,6 +109,12 @@ VIDEO_CASES = [
     ("i420_abgr_33x17_fastpath", "I420", 33, 17, "ABGR", 33, 17, {}, None, None, "random"),
     ("ayuv_argb_64x64_fastpath", "AYUV", 64, 64, "ARGB", 64, 64, {}, None, None, "random"),
     ("ayuv_bgrx_321x33_fastpath", "AYUV", 321, 33, "BGRx", 321, 33, {}, None, None, "random"),
+    # k_convert420p (video_422_fast.h): the same fastpaths with whole 8-pixel groups; odd height, smallest frame, 4K; with a crop the
+    # reference (and the planner) interpolates chroma instead, which the generic kernel serves
+    ("i420_bgra_fast420p_648x37", "I420", 648, 37, "BGRA", 648, 37, {}, None, None, "random"),
+    ("yv12_argb_fast420p_8x2", "YV12", 8, 2, "ARGB", 8, 2, {}, None, None, "random"),
+    ("i420_bgra_fast420p_4k", "I420", 3840, 2160, "BGRA", 3840, 2160, {}, None, None, "random"),
+    ("i420_rgbx_fast420p_crop", "I420", 1280, 720, "RGBx", 640, 360, dict(src_x=64, src_y=18, src_width=640, src_height=360), None, None, "random"),
     ("i420_ayuv_322x241_fastpath", "I420", 322, 241, "AYUV", 322, 241, {}, None, None, "random"),
     ("y42b_ayuv_130x70_fastpath", "Y42B", 130, 70, "AYUV", 130, 70, {}, None, None, "random"),
     ("y444_ayuv_64x48_fastpath_alpha", "Y444", 64, 48, "AYUV", 64, 48, dict(alpha_mode="set", alpha_value=0.25), None, None, "random"),

@@ -358,6 +358,8 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
 }
 
 static int g_fast422_runs = 0;
+static int g_fast420p_runs = 0;
+extern "C" int emu_fast420p_runs (void) { return g_fast420p_runs; }
 extern "C" int emu_fast422_runs (void) { return g_fast422_runs; }
 static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok, bool rgb24);
 
@@ -568,6 +570,22 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     }
 #undef FOR_CH
 #undef FOR_LAYOUT
+    return GSTAMD_OK;
+  }
+  if (p.fast_420p && vec_ok && ((uintptr_t) pl.p[0] % 8) == 0 && (pl.stride[0] % 8) == 0 && ((uintptr_t) pl.p[1] % 4) == 0 && ((uintptr_t) pl.p[2] % 4) == 0 &&
+      (pl.stride[1] % 4) == 0 && pl.stride[1] == pl.stride[2] && ((uintptr_t) d0 % 16) == 0 && (dstride % 16) == 0 &&
+      getenv ("GSTAMD_NO_FAST420P") == nullptr) {        /* k_convert420p */
+    Fast420pParams q;
+    q.fp = emu_fast_params (p);
+    q.y = pl.p[0];
+    q.u = pl.p[p.front.u_plane];
+    q.v = pl.p[p.front.v_plane];
+    q.ystride = pl.stride[0];
+    q.cstride = pl.stride[1];
+    g_fast420p_runs++;
+    for (int r = 0; r < (p.front.height + 1) / 2; r++)
+      for (int x0 = 0; x0 < p.front.width; x0 += 8)
+        convert420p_lane8x2 (q, d0, dstride, x0, r);
     return GSTAMD_OK;
   }
   if (p.fast_422 && vec_ok && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && ((uintptr_t) d0 % 16) == 0 && (dstride % 16) == 0 &&

@@ -186,6 +186,25 @@ def test_convert422_body_is_the_path_taken(native_lib, emu_lib, idx_case, monkey
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
 
 
+FAST420P = [c for c in SMALL if ("_fast420p_" in c[1][0] and "crop" not in c[1][0]) or c[1][0] in ("yv12_xrgb_640x360_fastpath", "i420_rgba_1280x720_fastpath_bt601")]
+
+
+@pytest.mark.parametrize("idx_case", FAST420P, ids=lambda c: c[1][0])
+def test_convert420p_body_is_the_path_taken(native_lib, emu_lib, idx_case, monkeypatch):
+    """k_convert420p serves the reference's I420 / YV12 -> RGB same-size fastpaths (nearest chroma) with whole 8-pixel groups; switched
+    off, the generic kernel gives the same bytes."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    before = emu_lib.emu_fast420p_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_fast420p_runs() == before + 1
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+    monkeypatch.setenv("GSTAMD_NO_FAST420P", "1")
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_fast420p_runs() == before + 1
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
 WIDE = [c for c in SMALL if c[1][1] in ("NV12", "NV21") and c[1][2] >= 512 and (c[1][2], c[1][3]) == (c[1][5], c[1][6])
         and c[1][4] not in ("AYUV",)]
 

@@ -175,6 +175,7 @@ def main():
     video_case("encoder feed: 3840x2160 BGRA -> NV12", "BGRA", 3840, 2160, "NV12", 3840, 2160, {}, a.iters, cpu=a.cpu, cpu_frames=3)
     video_case("inference feed: 3840x2160 NV12 -> RGB (24-bit)", "NV12", 3840, 2160, "RGB", 3840, 2160, {}, a.iters, cpu=False)
     video_case("capture: 1920x1080 YUY2 -> BGRA", "YUY2", 1920, 1080, "BGRA", 1920, 1080, {}, a.iters * 2, cpu=False)
+    video_case("decoder output: 3840x2160 I420 -> BGRA (the reference's convert_I420_BGRA fastpath)", "I420", 3840, 2160, "BGRA", 3840, 2160, {}, a.iters, cpu=False)
     compositor_case(a.iters, cpu=a.cpu)
     audio_case(max(3, a.iters // 3), cpu=a.cpu)
 

@@ -466,7 +466,11 @@ GSTAMD_HD void vscale_ntap_lane4 (const SrcImage &src, const ScaleDev &sd, const
   const int16_t *t = sd.taps + (size_t) y * sd.n_taps;
   uint32_t ae[4] = {0, 0, 0, 0}, ao[4] = {0, 0, 0, 0};
   const uint8_t *p = src.p + (size_t) off * src.stride + 4 * (size_t) x0;
+#ifndef GSTAMD_VSCALE_UNROLL8
+#pragma unroll 16
+#else
 #pragma unroll 8
+#endif
   for (int l = 0; l < sd.n_taps; l++) {
     const W4 w = *(const W4 *) (p + (size_t) l * src.stride);
     const uint32_t ts = (uint32_t) (uint16_t) t[l] * 0x00010001u;

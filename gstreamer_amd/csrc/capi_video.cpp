@@ -419,7 +419,7 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
   if (p.passes.size () == 2 && small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)) {
     /* nearest / 2-tap in both directions ("bilinear"): one fused kernel, no intermediate image */
     const bool h_first = p.passes[0].horizontal;
-    if (h_first && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && p.front.kind == UNPACK_SEMI && p.front.w_sub == 1 &&
+    if (h_first && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && kind_has_planes (p.front.kind) && p.front.w_sub == 1 &&
         p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && ((uintptr_t) dst % 4) == 0 && (dstride % 4) == 0 &&
         getenv ("GSTAMD_NO_BILINEAR420") == nullptr) {
       /* semi-planar 4:2:0 source, horizontal-first 2-tap x 2-tap, fast matrix: the direct kernel of video_bilinear_fast.h */
@@ -438,6 +438,9 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
       bp.vtaps = sd[1].taps;
       bp.vpair = p.front.chroma_v2 ? c->vpair_dev : nullptr;
       bp.regular_pairs = 0;
+      bp.planar = p.front.kind == UNPACK_PLANAR;
+      bp.u_plane = p.front.u_plane;
+      bp.v_plane = p.front.v_plane;
       if (p.front.chroma_v2 && getenv ("GSTAMD_BIL_TABLE") == nullptr) {
         /* are the pairs of every source line the kernel will touch the closed form of bil_rows? */
         bool regular = true;
@@ -454,7 +457,8 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
         bp.regular_pairs = regular ? 1 : 0;
       }
       e = launch_bilinear420 (bp, p.front.chroma_h, pl, dst, dstride, stream);
-      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420");
+      if (e != hipErrorNotSupported)
+        return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420");
       }
     }
     const ScaleDev &sh = h_first ? sd[0] : sd[1], &sv = h_first ? sd[1] : sd[0];

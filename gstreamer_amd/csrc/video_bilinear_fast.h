@@ -47,6 +47,8 @@ struct BilParams {
   const int16_t *vtaps;      // [out_h][2]
   const int *vpair;          // chroma line pairing of the source (planner), or NULL: rows y >> 1
   int regular_pairs;         // the pairing is the closed form of bil_rows: no table reads
+  int planar;                // 1: I420 / YV12 - U in plane u_plane, V in plane v_plane (width % 16 == 0, 8-byte aligned chroma rows); 0: interleaved plane 1
+  int u_plane, v_plane;
 };
 
 GSTAMD_HOSTDEV void bil_rows (const BilParams &bp, int line, int *ra, int *rb, int *role)
@@ -106,18 +108,28 @@ GSTAMD_HD void bil_fetch (const BilParams &bp, const Planes &pl, int t0, int t1,
     // their byte loads may still be writing these registers and drains the queue before every wide load - five serial round
     // trips per tile instead of one.
     const int xc = x < x_hi ? x : (x_lo & ~15), kc = k <= k_hi ? k : (k_lo & ~7);
-    const uint8_t *rows[4];
+    int crow[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       int ra, rb, role;
       bil_rows (bp, r0 + (s >> 1), &ra, &rb, &role);
-      rows[s] = pl.p[1] + (ptrdiff_t) ((s & 1) ? rb : ra) * pl.stride[1] + 2 * kc;
+      crow[s] = (s & 1) ? rb : ra;
     }
     wide_load16<true> (y0 + xc, 4, true, r.a);
     wide_load16<true> (y1 + xc, 4, true, r.b);
+    if (bp.planar) {
+      // 8 U bytes in m[s][0..1], 8 V bytes in m[s][2..3]
 #pragma unroll
-    for (int s = 0; s < 4; s++)
-      wide_load16<false> (rows[s], 4, true, r.m[s]);
+      for (int s = 0; s < 4; s++) {
+        const uint2 mu = *(const uint2 *) (pl.p[bp.u_plane] + (ptrdiff_t) crow[s] * pl.stride[bp.u_plane] + kc);
+        const uint2 mv = *(const uint2 *) (pl.p[bp.v_plane] + (ptrdiff_t) crow[s] * pl.stride[bp.v_plane] + kc);
+        r.m[s][0] = mu.x, r.m[s][1] = mu.y, r.m[s][2] = mv.x, r.m[s][3] = mv.y;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+        wide_load16<false> (pl.p[1] + (ptrdiff_t) crow[s] * pl.stride[1] + 2 * kc, 4, true, r.m[s]);
+    }
     return;
   }
   if (x < x_hi) {
@@ -183,6 +195,13 @@ GSTAMD_HD void bil_commit (const BilParams &bp, int t0, int t1, int lane, const 
     for (int s = 0; s < 4; s++) {
       const uint32_t *m = r.m[s];
       uint32_t *d = &lds->c[s][k - ka];
+      if (bp.planar) {        // sample j = U byte j | V byte j << 16
+        *(uint4 *) d = gstamd_make_uint4 (bperm (m[2], m[0], 0x0c040c00u), bperm (m[2], m[0], 0x0c050c01u), bperm (m[2], m[0], 0x0c060c02u),
+            bperm (m[2], m[0], 0x0c070c03u));
+        *(uint4 *) (d + 4) = gstamd_make_uint4 (bperm (m[3], m[1], 0x0c040c00u), bperm (m[3], m[1], 0x0c050c01u), bperm (m[3], m[1], 0x0c060c02u),
+            bperm (m[3], m[1], 0x0c070c03u));
+        continue;
+      }
       *(uint4 *) d = gstamd_make_uint4 (bperm (0, m[0], sel_lo), bperm (0, m[0], sel_hi), bperm (0, m[1], sel_lo), bperm (0, m[1], sel_hi));
       *(uint4 *) (d + 4) = gstamd_make_uint4 (bperm (0, m[2], sel_lo), bperm (0, m[2], sel_hi), bperm (0, m[3], sel_lo), bperm (0, m[3], sel_hi));
     }

@@ -795,7 +795,14 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
 
 hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
 {
-  const int vec = aligned (pl.p[0], 16) && aligned (pl.p[1], 16) && (pl.stride[0] % 16) == 0 && (pl.stride[1] % 16) == 0;
+  int vec = aligned (pl.p[0], 16) && aligned (pl.p[1], 16) && (pl.stride[0] % 16) == 0 && (pl.stride[1] % 16) == 0;
+  if (bp.planar) {
+    /* planar sources only through the straight-line fetch: whole 16-pixel pieces, 8-byte chroma loads */
+    vec = aligned (pl.p[0], 16) && (pl.stride[0] % 16) == 0 && aligned (pl.p[1], 8) && aligned (pl.p[2], 8) && (pl.stride[1] % 8) == 0 &&
+        (pl.stride[2] % 8) == 0 && (bp.fp.width % 16) == 0;
+    if (!vec)
+      return hipErrorNotSupported;
+  }
   dim3 grid ((bp.out_w + bp.tile_w - 1) / bp.tile_w, bp.out_h);
   const size_t lds_bytes = bil_lds_words (bp.ylen) * 4;
 #define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \

@@ -25,6 +25,10 @@ elif which == "nv12enc":
     B.video_case("4K BGRA -> NV12 (encoder feed)", "BGRA", 3840, 2160, "NV12", 3840, 2160, {}, it * 2)
 elif which == "i420":
     B.video_case("4K I420 -> BGRA (decoder output -> display; the reference's convert_I420_BGRA fastpath)", "I420", 3840, 2160, "BGRA", 3840, 2160, {}, it * 2)
+elif which == "i420bil":
+    B.video_case("4K I420 -> 1080p BGRA, bilinear", "I420", 3840, 2160, "BGRA", 1920, 1080, cases.LIN, it * 2)
+elif which == "nv12bil":
+    B.video_case("4K NV12 -> 1080p BGRA, bilinear", "NV12", 3840, 2160, "BGRA", 1920, 1080, cases.LIN, it * 2)
 elif which == "c4":
     B.compositor_case(it)
 else:

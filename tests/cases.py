@@ -213,6 +213,10 @@ VIDEO_CASES = [
     ("i420_bgra_h420_crop_lanczos", "I420", 1280, 720, "BGRA", 160, 90, dict(LAN, src_x=32, src_y=17, src_width=640, src_height=359), None, None, "random"),
     ("nv12_bgra_h420_cubic_down", "NV12", 1280, 720, "BGRA", 852, 480, {}, None, None, "random"),
     ("nv12_xrgb_h420_sinc_down", "NV12", 1024, 96, "xRGB", 300, 40, dict(resampler_method="sinc"), None, "mpeg2", "random"),
+    # k_bilinear420 from planar sources (I420 / YV12): 2:1, non-integer, sites, crop rows
+    ("i420_bgra_bil420_half", "I420", 1280, 720, "BGRA", 640, 360, LIN, None, None, "random"),
+    ("yv12_argb_bil420_nonint_jpeg", "YV12", 1024, 600, "ARGB", 600, 352, LIN, None, "jpeg", "random"),
+    ("i420_rgba_bil420_third_none", "I420", 960, 540, "RGBA", 320, 180, LIN, None, "none", "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),

@@ -358,6 +358,8 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
 }
 
 static int g_fast422_runs = 0;
+static int g_bil_runs = 0;
+extern "C" int emu_bil_runs (void) { return g_bil_runs; }
 static int g_fast420p_runs = 0;
 extern "C" int emu_fast420p_runs (void) { return g_fast420p_runs; }
 extern "C" int emu_fast422_runs (void) { return g_fast422_runs; }
@@ -662,7 +664,10 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     const int bil_tw = vec_ok >= 400 ? vec_ok - 400 : bil_pick_tile (p.out_info.width, p.passes[0].inc, &bil_yl);     /* 400 + w: tiles of w outputs */
     if (vec_ok >= 400)
       bil_yl = bil_ylen (p.out_info.width, p.passes[0].inc, bil_tw);
-    if (h_first && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && p.front.kind == UNPACK_SEMI && p.front.w_sub == 1 &&
+    const bool bil_planar = p.front.kind == UNPACK_PLANAR;
+    const bool bil_planar_ok = bil_planar && ((uintptr_t) pl.p[0] % 16) == 0 && pl.stride[0] % 16 == 0 && ((uintptr_t) pl.p[1] % 8) == 0 &&
+        ((uintptr_t) pl.p[2] % 8) == 0 && pl.stride[1] % 8 == 0 && pl.stride[2] % 8 == 0 && (p.front.width % 16) == 0;
+    if (h_first && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && (p.front.kind == UNPACK_SEMI || bil_planar_ok) && p.front.w_sub == 1 &&
         p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && bil_tw > 0 && bil_yl > 0 && vec_ok != 300) {
       /* k_bilinear420 (video_bilinear_fast.h); vec_ok == 300 selects the generic tile kernel below instead */
       BilParams bp;
@@ -675,7 +680,11 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
       bp.voffset = sd[1].offset;
       bp.vtaps = sd[1].taps;
       bp.vpair = p.front.chroma_v2 ? vpair : nullptr;
-      const bool vec = (((uintptr_t) pl.p[0] | (uintptr_t) pl.p[1]) % 16) == 0 && pl.stride[0] % 16 == 0 && pl.stride[1] % 16 == 0;
+      const bool vec = bil_planar ? true : (((uintptr_t) pl.p[0] | (uintptr_t) pl.p[1]) % 16) == 0 && pl.stride[0] % 16 == 0 && pl.stride[1] % 16 == 0;
+      bp.planar = bil_planar ? 1 : 0;
+      bp.u_plane = p.front.u_plane;
+      bp.v_plane = p.front.v_plane;
+      g_bil_runs++;
       const int lay = GSTAMD_LAYOUT (bp.fp.pack_pos[1], bp.fp.pack_pos[2], bp.fp.pack_pos[3]);
       std::vector<uint32_t> lds_w (bil_lds_words (bp.ylen));
       const BilLds lds = bil_lds (lds_w.data (), bp.ylen);

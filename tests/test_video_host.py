@@ -205,6 +205,16 @@ def test_convert420p_body_is_the_path_taken(native_lib, emu_lib, idx_case, monke
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
 
 
+@pytest.mark.parametrize("idx_case", [c for c in SMALL if "_bil420_" in c[1][0]], ids=lambda c: c[1][0])
+def test_bilinear420_serves_planar_sources(native_lib, emu_lib, idx_case):
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    before = emu_lib.emu_bil_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_bil_runs() == before + 1
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
 WIDE = [c for c in SMALL if c[1][1] in ("NV12", "NV21") and c[1][2] >= 512 and (c[1][2], c[1][3]) == (c[1][5], c[1][6])
         and c[1][4] not in ("AYUV",)]
 

@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py - headline benchmark: 4K frames/s of videoconvertscale's NV12->BGRA path per GPU.
+"""bench.py - headline benchmark: 4K frames/s of videoconvertscale's NV12->BGRA path per GPU (BASELINE C2),
+plus the other BASELINE configs behind --config.
 
-Workload (BASELINE.json configs[1]): 3840x2160 NV12 (bt709, 16-235, chroma-site mpeg2) -> BGRA, frames
-resident in HBM, HIP kernels behind the C ABI of include/gstamd_video.h.  One "step" converts
-FRAMES_PER_STEP frames, cycling through an input pool and an output pool that together exceed the
-256 MiB Infinity Cache, so the kernel really streams from/to HBM.
-
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--config c2|c3|c4|c4audio|c5] [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
 
-Independent streams shard one-per-GPU (no collective on the data path); the only torch.distributed
-use is the timing barrier.  Rank 0 prints ONE JSON line.
+`--gpus N` without a torchrun environment re-executes itself under torch.distributed.run with N ranks
+(127.0.0.1 rendezvous); a rank count that differs from --gpus is an error, never a silent 1-GPU run.
+Independent streams shard one per GPU (no collective on the data path): the only torch.distributed use
+is the timing barrier and the MAX / SUM of the per-rank numbers.  Rank 0 prints ONE JSON line.
+
+Every config: frames resident in HBM, pools of distinct frames larger than the 256 MiB Infinity Cache on
+both sides, output pool >= frames per step (no two frames of one step share a buffer), 60 ms untimed
+pre-heat, W warm-up steps, K timed steps between barrier + synchronize, HIP events on the launch stream.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,184 +25,459 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-W, H = 3840, 2160
-FRAMES_PER_STEP = 32
-POOL_IN = 32          # 32 x 12.4 MB = 398 MB of distinct input frames
-POOL_OUT = 16         # 16 x 33.2 MB = 531 MB of distinct output frames
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HEADLINE = "4K frames/s (videoconvertscale NV12->BGRA) per GPU; % HBM roofline"
+
+# name -> (in format, w, h, out format, ow, oh, converter options, frames per step, frames per launch, metric, dominant kernel)
+VIDEO_CONFIGS = {
+    "c2": ("NV12", 3840, 2160, "BGRA", 3840, 2160, {}, 32, 32, HEADLINE, "k_convert_strip<CHROMA_H_H2_CS, layout BGRA>"),
+    "c1": ("NV12", 1920, 1080, "BGRA", 1920, 1080, {}, 32, 32,
+           "1080p frames/s (videoconvertscale NV12->BGRA) per GPU; % HBM roofline", "k_convert_strip<CHROMA_H_H2_CS, layout BGRA>"),
+    "c3": ("I420", 7680, 4320, "RGBA", 1920, 1080, {"resampler_method": "lanczos"}, 8, 1,
+           "8K->1080p frames/s (videoconvertscale I420->RGBA, Lanczos) per GPU; % HBM roofline", "k_scale420_fused / k_hscale420_reg + k_vscale_pk"),
+    "c5": ("NV12", 7680, 4320, "BGRA", 3840, 2160, {"resampler_method": "linear", "max_taps": 2}, 8, 1,
+           "8K->4K frames/s (videoconvertscale NV12->BGRA, bilinear) per GPU; % HBM roofline", "k_bilinear420"),
+}
+CONFIG_TEXT = {
+    "c2": "C2: 3840x2160 NV12 (bt709 limited, chroma-site mpeg2) -> BGRA, fused unpack + chroma upsample + matrix + pack",
+    "c1": "C1 size on the GPU: 1920x1080 NV12 -> BGRA (the reference's CPU-runnable case)",
+    "c3": "C3: 7680x4320 I420 -> 1920x1080 RGBA, Lanczos (16 x 16 taps), horizontal then vertical like chain_scale",
+    "c5": "C5 (per GPU): 7680x4320 NV12 -> 3840x2160 BGRA, bilinear (element default method)",
+    "c4": "C4: compositor, 16 x 1920x1080 BGRA pads (xpos 640*(i%4), ypos 360*(i/4), alpha 0.25+0.05i, random pixel alpha, "
+          "operator over) on a checker background -> 3840x2160 BGRA, one fused launch per output frame",
+    "c4audio": "C4 audio: audioresample 48000 -> 44100 Hz, F32 stereo interleaved, Kaiser quality 4 (72 taps x 147 phases)",
+}
 
 
-def cpu_baseline(sample_frames=40):
-    """The reference's own gst_video_converter_frame (oracle/_ref, C-backup ORC, -O2) on this host,
-    element-default n-threads=1, bounded sample of the same 4K workload."""
-    try:
+# ------------------------------------------------------------------------------------------------
+# workloads: setup() allocates the HBM pools, step(s) enqueues one step on `stream`
+# ------------------------------------------------------------------------------------------------
+class VideoWorkload:
+    def __init__(self, name, batch=None, size=None):
+        self.name = name
+        (self.ifmt, self.w, self.h, self.ofmt, self.ow, self.oh, self.cfg, self.frames_per_step, self.batch, self.metric,
+         self.kernel) = VIDEO_CONFIGS[name]
+        if size:
+            self.w, self.h = size
+            if name in ("c2", "c1"):
+                self.ow, self.oh = size
+        if batch:
+            self.batch = max(1, min(batch, self.frames_per_step))
+        assert self.frames_per_step % self.batch == 0
+        self.unit = "frames/s"
+        self.dtype = "u8"
+
+    def setup(self, dev, rank):
+        import torch
+
+        import cases
+        from gstreamer_amd import video as V
+        self.V = V
+        ii, oi = V.video_info(self.ifmt, self.w, self.h), V.video_info(self.ofmt, self.ow, self.oh)
+        self.conv = V.VideoConverter(ii, oi, V.converter_config(**self.cfg))
+        self.alg_bytes = self.conv.algorithmic_bytes()
+        self.pool_in = max(self.frames_per_step, int(400e6 // int(ii.size)) + 1)
+        self.pool_out = max(self.frames_per_step, int(530e6 // int(oi.size)) + 1)       # >= the frames of one step
+        pin = torch.empty((self.pool_in, int(ii.size)), dtype=torch.uint8, device=dev)
+        base = torch.from_numpy(cases.frame_bytes(int(ii.size), "random", 2000 + rank)).to(dev)
+        for i in range(self.pool_in):
+            pin[i] = torch.roll(base, shifts=i * 4099)
+        pout = torch.zeros((self.pool_out, int(oi.size)), dtype=torch.uint8, device=dev)
+        self.keep = (pin, pout)
+        self.in_ptrs = [pin[i].data_ptr() for i in range(self.pool_in)]
+        self.out_ptrs = [pout[i].data_ptr() for i in range(self.pool_out)]
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.launches_per_step = self.frames_per_step // self.batch
+        self.units_per_step = self.frames_per_step
+        self.alg_bytes_per_launch = self.alg_bytes * self.batch
+
+    def step(self, s):
+        B = self.batch
+        for f in range(0, self.frames_per_step, B):
+            n = s * self.frames_per_step + f
+            if B == 1:
+                self.conv.frame(self.in_ptrs[n % self.pool_in], self.out_ptrs[n % self.pool_out], self.stream)
+            else:
+                self.conv.frames([self.in_ptrs[(n + i) % self.pool_in] for i in range(B)],
+                                 [self.out_ptrs[(n + i) % self.pool_out] for i in range(B)], self.stream)
+
+    def config(self, world):
+        return {"workload": "%s, %d frames/step, pools %d in / %d out resident in HBM, 1 stream per GPU, %d frame(s) per kernel launch"
+                            % (CONFIG_TEXT[self.name], self.frames_per_step, self.pool_in, self.pool_out, self.batch),
+                "plan": self.conv.describe(), "frames_per_step": self.frames_per_step, "frames_per_launch": self.batch,
+                "parallelism": "stream-per-gpu x%d" % world}
+
+    def cpu_baseline(self):
+        """The reference's own gst_video_converter_frame (oracle/_ref, C-backup ORC, -O2) on this host, element-default
+        n-threads=1, bounded sample of the same workload."""
         import cases
         from oracle import ref
         if not ref.available():
             return None
-        src = cases.frame_bytes(ref.video_info("NV12", W, H)["size"], "random", 1)
-        rc = ref.VideoConverter("NV12", W, H, "BGRA", W, H, config=ref.config_string(GstVideoConverter__threads=1))
-        rc.bench(src, 3)
-        secs = rc.bench(src, sample_frames)
-        out = {"value": round(sample_frames / secs, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
-               "sample": "%d frames of 3840x2160 NV12->BGRA, gst_video_converter_frame of the reference built "
-                         "from /root/reference with -O2 -DDISABLE_ORC (ORC C backups, no JIT SIMD), n-threads=1 "
-                         "(element default)" % sample_frames}
+        n = {"c2": 40, "c1": 150, "c3": 12, "c5": 20}.get(self.name, 10)
+        src = cases.frame_bytes(ref.video_info(self.ifmt, self.w, self.h)["size"], "random", 1)
+
+        def conv(threads):
+            cfg = dict(self.cfg, threads=threads)
+            return ref.VideoConverter(self.ifmt, self.w, self.h, self.ofmt, self.ow, self.oh, config=cases.ref_config_string(ref, cfg))
+        rc = conv(1)
+        rc.bench(src, 2)
+        secs = rc.bench(src, n)
+        out = {"value": round(n / secs, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+               "sample": "%d frames of %dx%d %s -> %dx%d %s, gst_video_converter_frame of the reference built from /root/reference "
+                         "with -O2 -DDISABLE_ORC (ORC C backups, no JIT SIMD), n-threads=1 (element default)"
+                         % (n, self.w, self.h, self.ifmt, self.ow, self.oh, self.ofmt)}
         ncpu = os.cpu_count() or 1
         if ncpu > 1:
-            rc2 = ref.VideoConverter("NV12", W, H, "BGRA", W, H,
-                                     config=ref.config_string(GstVideoConverter__threads=ncpu))
-            rc2.bench(src, 3)
-            s2 = rc2.bench(src, sample_frames)
-            out["all_cores"] = {"value": round(sample_frames / s2, 3), "cores": ncpu,
-                                "note": "n-threads=%d; NB the reference's output for 4:2:0 input changes with "
-                                        "n-threads (tests/test_video_host.py)" % ncpu}
+            rc2 = conv(ncpu)
+            rc2.bench(src, 2)
+            s2 = rc2.bench(src, n)
+            out["all_cores"] = {"value": round(n / s2, 3), "cores": ncpu,
+                                "note": "n-threads=%d; NB the reference's output for 4:2:0 input changes with n-threads "
+                                        "(tests/test_video_host.py)" % ncpu}
         return out
-    except Exception as e:  # the baseline is a report, never a reason to fail the bench
-        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
 
 
-def reduce_job(wall_s, frames_this_rank, device, distributed):
+class CompositorWorkload:
+    """BASELINE C4, video half: SURVEY.md 8d's primary layout."""
+    name, unit, dtype = "c4", "frames/s", "u8"
+    metric = "4K output frames/s (compositor, 16 x 1080p BGRA pads alpha-blended) per GPU; % HBM roofline"
+    kernel = "k_aggregate"
+    DW, DH, PW, PH, N = 3840, 2160, 1920, 1080, 16
+    frames_per_step = 8
+    SETS = 5                # 5 x 16 pad frames of 8.3 MB = 663 MB of distinct pad pixels
+
+    def pad_geometry(self, i):
+        return (i % 4) * 640, (i // 4) * 360, 0.25 + 0.05 * i
+
+    def setup(self, dev, rank):
+        import torch
+
+        import cases
+        from gstreamer_amd import video as V
+        self.V = V
+        n, pw, ph = self.N, self.PW, self.PH
+        base = torch.from_numpy(cases.frame_bytes(pw * ph * 4, "random", 31 + rank)).to(dev)
+        self.pads = [torch.roll(base, shifts=i * 4099) for i in range(n * self.SETS)]
+        self.arrs = []
+        for s_ in range(self.SETS):
+            arr = (V.CompositorPad * n)()
+            for i in range(n):
+                x, y, a = self.pad_geometry(i)
+                arr[i].data, arr[i].width, arr[i].height, arr[i].stride = self.pads[s_ * n + i].data_ptr(), pw, ph, pw * 4
+                arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = x, y, a, 1
+            self.arrs.append(arr)
+        self.pool_out = 16
+        self.outs = [torch.zeros(self.DW * self.DH * 4, dtype=torch.uint8, device=dev) for _ in range(self.pool_out)]
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.L = V.lib()
+        self.alg_bytes = n * pw * ph * 4 + self.DW * self.DH * 4        # SURVEY.md 8d: every pad read once + one canvas write
+        self.alg_bytes_per_launch = self.alg_bytes
+        self.launches_per_step = self.frames_per_step
+        self.units_per_step = self.frames_per_step
+
+    def step(self, s):
+        for f in range(self.frames_per_step):
+            k = s * self.frames_per_step + f
+            r = self.L.gstamd_compositor_aggregate(self.V.FORMATS["BGRA"], 0, self.arrs[k % self.SETS], self.N,
+                                                   self.outs[k % self.pool_out].data_ptr(), self.DW, self.DH, self.DW * 4, self.stream)
+            assert r == 0, self.V.last_error()
+
+    def config(self, world):
+        return {"workload": "%s, %d output frames/step, %d pad frames / %d canvases resident in HBM" %
+                            (CONFIG_TEXT["c4"], self.frames_per_step, len(self.pads), self.pool_out),
+                "frames_per_step": self.frames_per_step, "frames_per_launch": 1, "parallelism": "stream-per-gpu x%d" % world}
+
+    def cpu_baseline(self):
+        import numpy as np
+
+        import cases
+        from oracle import ref
+        if not ref.available():
+            return None
+        pad_np = cases.frame_bytes(self.PW * self.PH * 4, "random", 31)
+        canvas = np.zeros(self.DW * self.DH * 4, np.uint8)
+        n_frames = 6
+        t0 = time.perf_counter()
+        for _ in range(n_frames):
+            ref.compositor_fill(0, "bgra", "BGRA", canvas, self.DW, self.DH, 0, self.DH)
+            for i in range(self.N):
+                x, y, a = self.pad_geometry(i)
+                ref.compositor_blend("blend_bgra", "BGRA", pad_np, self.PW, self.PH, x, y, a, canvas, self.DW, self.DH, 0, self.DH, 1)
+        secs = time.perf_counter() - t0
+        return {"value": round(n_frames / secs, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+                "sample": "%d output frames: fill_checker + 16 x blend_bgra of the reference (compositor/blend.c, ORC C backups), "
+                          "one thread (max-threads default)" % n_frames}
+
+
+class AudioWorkload:
+    """BASELINE C4, audio half.  A step = 10 s of stereo F32 handed over in `block`-frame buffers (1024 = what the element sees)."""
+    name, unit, dtype = "c4audio", "input frames/s", "f32"
+    metric = "audio input frames/s (audioresample 48k->44.1k F32 stereo, polyphase FIR) per GPU"
+    kernel = "k_fir<float>"
+    CH, N = 2, 48000 * 10
+
+    def __init__(self, block=1024):
+        self.block = block
+
+    def setup(self, dev, rank):
+        import torch
+
+        import cases
+        from gstreamer_amd import audio as A
+        self.sig = torch.from_numpy(cases.audio_buffer("F32LE", self.CH, self.N, 4242 + rank)).to(dev)
+        self.r = A.AudioResampler("F32LE", self.CH, 48000, 44100, "kaiser", None)
+        self.out = torch.zeros((self.N + 4096, self.CH), dtype=torch.float32, device=dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.blocks = [(o, min(self.block, self.N - o)) for o in range(0, self.N, self.block)]
+        self.launches_per_step = len(self.blocks)
+        self.units_per_step = self.N
+        no = self.N * 147 // 160
+        self.alg_bytes = self.N * self.CH * 4 + no * self.CH * 4
+        self.alg_bytes_per_launch = self.alg_bytes / len(self.blocks)
+        self.flops_per_step = 2.0 * 72 * no * self.CH
+
+    def step(self, s):
+        po = 0
+        fsz = self.CH * 4
+        for o, n in self.blocks:
+            m = self.r.get_out_frames(n)
+            self.r.resample(self.sig.data_ptr() + o * fsz, n, self.out.data_ptr() + po * fsz, m, self.stream)
+            po += m
+
+    def config(self, world):
+        return {"workload": "%s, a step = 10 s of audio in buffers of %d frames (%d launches)" % (CONFIG_TEXT["c4audio"], self.block,
+                                                                                                len(self.blocks)),
+                "block_frames": self.block, "parallelism": "stream-per-gpu x%d" % world}
+
+    def cpu_baseline(self):
+        import cases
+        from oracle import ref
+        if not ref.available():
+            return None
+        rr = ref.AudioResampler("F32LE", self.CH, 48000, 44100, quality=4)
+        n = 48000 * 60
+        data = cases.audio_buffer("F32LE", self.CH, n, 4242)
+        t0 = time.perf_counter()
+        rr.resample(data, in_frames=n, out_frames=rr.get_out_frames(n))
+        secs = time.perf_counter() - t0
+        return {"value": round(n / secs, 1), "unit": "input frames/s", "cores": 1, "kind": "reference",
+                "sample": "60 s of stereo F32 48k->44.1k in one gst_audio_resampler_resample call (C inner product, no SSE: the summation "
+                          "order parity is defined on)"}
+
+
+class StubWorkload:
+    """CPU stand-in used by tests/test_bench_dist.py to run THIS file's N>1 control flow under gloo: no converter, a step just takes
+    a rank-dependent time.  Never part of a measurement."""
+    name, unit, dtype, metric, kernel = "stub", "frames/s", "none", "stub", "none"
+    frames_per_step = 4
+
+    def setup(self, dev, rank):
+        self.rank = rank
+        self.launches_per_step = 1
+        self.units_per_step = self.frames_per_step
+        self.alg_bytes = self.alg_bytes_per_launch = 1000
+
+    def step(self, s):
+        time.sleep(0.001 * (1 + self.rank))
+
+    def config(self, world):
+        return {"workload": "stub", "parallelism": "stream-per-gpu x%d" % world}
+
+    def cpu_baseline(self):
+        return None
+
+
+def make_workload(args):
+    size = tuple(int(v) for v in args.size.split("x")) if args.size else None
+    if args.config in VIDEO_CONFIGS:
+        return VideoWorkload(args.config, args.batch, size)
+    if args.config == "c4":
+        return CompositorWorkload()
+    if args.config == "c4audio":
+        return AudioWorkload(args.audio_block)
+    if args.config == "stub":
+        return StubWorkload()
+    raise SystemExit("unknown --config %r" % args.config)
+
+
+# ------------------------------------------------------------------------------------------------
+def reduce_job(wall_s, units_this_rank, device, distributed):
     """Whole-job numbers from per-rank measurements: ranks convert independent streams (no data-path
     collective), so the job time is the MAX over ranks and the job's frames are the SUM over ranks."""
     import torch
     import torch.distributed as dist
     t = torch.tensor([wall_s], dtype=torch.float64, device=device)
-    n = torch.tensor([float(frames_this_rank)], dtype=torch.float64, device=device)
+    n = torch.tensor([float(units_this_rank)], dtype=torch.float64, device=device)
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return float(t.item()), int(round(float(n.item())))
 
 
+def gather_ranks(values, device, distributed, world):
+    """[values of rank 0, values of rank 1, ...] (a short list of floats per rank) on every rank."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    if not distributed:
+        return [list(map(float, t.tolist()))]
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [list(map(float, o.tolist())) for o in out]
+
+
+def stored_traffic(name):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    runs of this same command; scripts/gpu_round.sh).  A stored figure, not a per-run measurement: the source says so."""
+    for path in (os.path.join(ROOT, "profiles", "traffic_%s.json" % name),):
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path))
+                return int(d["hbm_bytes_per_launch"]), "stored PMC figure: profiles/%s (%s)" % (os.path.basename(path), d.get("measured", "round 1"))
+            except Exception:
+                pass
+    return None, None
+
+
+def spawn_ranks(args):
+    """`--gpus N` given without a torchrun environment: run N ranks of this file under torch.distributed.run."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed sustained load before the W warmup steps: from idle an MI355X needs 20-30 ms of load "
                          "to reach its steady rate (scripts/clock_ramp.py, profiles/r01_clock_ramp.log)")
-    ap.add_argument("--batch", type=int, default=32,
-                    help="frames per kernel launch (gstamd_video_converter_frames, the GstBufferList analogue); "
-                         "1 = one launch per frame")
-    ap.add_argument("--size", default="3840x2160", help="experiments only: frame size (the headline metric is 3840x2160)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="frames per kernel launch (gstamd_video_converter_frames, the GstBufferList analogue); 1 = one launch per frame")
+    ap.add_argument("--audio-block", type=int, default=1024, help="c4audio: frames per resample call")
+    ap.add_argument("--size", default=None, help="experiments only: frame size (the headline metric is 3840x2160)")
+    ap.add_argument("--backend", default=None, help=argparse.SUPPRESS)      # tests: gloo + the stub workload on CPU
     args = ap.parse_args()
-    global W, H
-    W, H = [int(v) for v in args.size.split("x")]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
 
     import torch
     import torch.distributed as dist
 
-    import cases
-    from gstreamer_amd import video as V
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE) - refusing to report a %d-GPU number"
+                         % (args.gpus, world, args.gpus))
+    cpu_mode = args.backend == "gloo"
+    if cpu_mode:
+        if args.config != "stub":
+            raise SystemExit("--backend gloo is for the stub workload (tests) only: the HIP path has no CPU fallback")
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        if torch.cuda.device_count() < world and world > 1 and os.environ.get("GSTAMD_BENCH_SHARE_GPU") != "1":
+            raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
+        local_dev = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_dev)
+        dev = torch.device("cuda", local_dev)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if cpu_mode:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    ii, oi = V.video_info("NV12", W, H), V.video_info("BGRA", W, H)
-    conv = V.VideoConverter(ii, oi)          # element defaults: no scaling here, generic fused path
-    alg_bytes = conv.algorithmic_bytes()
+    wl = make_workload(args)
+    steps = args.steps if args.steps is not None else {"c2": 400, "c1": 800, "c3": 150, "c5": 150, "c4": 150, "c4audio": 20, "stub": 5}[args.config]
+    warmup = args.warmup if args.warmup is not None else {"c4audio": 2, "stub": 1}.get(args.config, 20)
+    wl.setup(dev, rank)
 
-    # synthetic frames: full-range xorshift bytes, a different seed per pool slot and per rank
-    pool_in = torch.empty((POOL_IN, int(ii.size)), dtype=torch.uint8, device=dev)
-    base = torch.from_numpy(cases.frame_bytes(int(ii.size), "random", 2000 + rank)).to(dev)
-    for i in range(POOL_IN):
-        pool_in[i] = torch.roll(base, shifts=i * 4099)
-    pool_out = torch.zeros((POOL_OUT, int(oi.size)), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream   # kernels go on torch's current stream
-    in_ptrs = [pool_in[i].data_ptr() for i in range(POOL_IN)]
-    out_ptrs = [pool_out[i].data_ptr() for i in range(POOL_OUT)]
-
-    B = max(1, min(args.batch, FRAMES_PER_STEP))
-    assert FRAMES_PER_STEP % B == 0
-
-    def step(s):
-        for f in range(0, FRAMES_PER_STEP, B):
-            n = s * FRAMES_PER_STEP + f
-            if B == 1:
-                conv.frame(in_ptrs[n % POOL_IN], out_ptrs[n % POOL_OUT], stream)
-            else:
-                conv.frames([in_ptrs[(n + i) % POOL_IN] for i in range(B)],
-                            [out_ptrs[(n + i) % POOL_OUT] for i in range(B)], stream)
+    def sync():
+        if not cpu_mode:
+            torch.cuda.synchronize()
 
     # untimed: bring the device from idle to its steady state, then the W warmup steps of the contract
-    t_pre = time.perf_counter()
-    s_pre = 0
-    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
-        step(s_pre)
+    t_pre, s_pre = time.perf_counter(), 0
+    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms and not cpu_mode:
+        wl.step(s_pre)
         s_pre += 1
         if s_pre % 8 == 0:
-            torch.cuda.synchronize()
-    for s in range(args.warmup):
-        step(s)
-    torch.cuda.synchronize()
+            sync()
+    for s in range(warmup):
+        wl.step(s)
+    sync()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    if not cpu_mode:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
-    for s in range(args.steps):
-        step(s)
-    ev1.record()
-    torch.cuda.synchronize()
+    if not cpu_mode:
+        ev0.record()
+    for s in range(steps):
+        wl.step(s)
+    if not cpu_mode:
+        ev1.record()
+    sync()
+    t_rank = time.perf_counter() - t0               # this rank's own time (before the closing barrier)
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     wall = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    ev_ms = ev0.elapsed_time(ev1) if not cpu_mode else t_rank * 1e3
 
-    wall_max, total_frames = reduce_job(wall, args.steps * FRAMES_PER_STEP, dev, distributed)
+    wall_max, total_units = reduce_job(wall, steps * wl.units_per_step, dev, distributed)
+    launches = steps * wl.launches_per_step
+    per_launch_us = ev_ms * 1e3 / launches
+    achieved = wl.alg_bytes_per_launch / (per_launch_us * 1e-6) / 1e9
+    per_rank = gather_ranks([steps * wl.units_per_step / t_rank, achieved], dev, distributed, world)
 
     if rank == 0:
-        launches = args.steps * FRAMES_PER_STEP // B
-        per_launch_us = ev_ms * 1e3 / launches
-        achieved = alg_bytes * B / (per_launch_us * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = int(json.load(open(tpath)).get("hbm_bytes_per_frame") * B)
-            except Exception:
-                traffic = None
-        assert total_frames == launches * B * world
+        assert total_units == steps * wl.units_per_step * world
+        traffic, traffic_src = stored_traffic(args.config)
         line = {
-            "metric": "4K frames/s (videoconvertscale NV12->BGRA) per GPU; % HBM roofline",
-            "value": round(total_frames / wall_max, 1),
-            "unit": "frames/s",
+            "metric": wl.metric,
+            "value": round(total_units / wall_max, 1),
+            "unit": wl.unit,
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(wall_max * 1e3 / args.steps, 4),
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(wall_max * 1e3 / steps, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8",
+            "dtype": wl.dtype,
             "data": "synthetic",
-            "config": {"workload": "C2: 3840x2160 NV12 (bt709 limited, chroma-site mpeg2) -> BGRA, fused unpack+chroma "
-                                   "upsample+matrix+pack, %d frames/step, pools %d in / %d out resident in HBM, "
-                                   "1 stream per GPU, %d frame(s) per kernel launch" % (FRAMES_PER_STEP, POOL_IN, POOL_OUT, B),
-                       "plan": conv.describe(), "frames_per_step": FRAMES_PER_STEP, "frames_per_launch": B, "preheat_ms": args.preheat_ms,
-                       "parallelism": "stream-per-gpu x%d" % world},
+            "config": dict(wl.config(world), preheat_ms=args.preheat_ms),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_convert_strip<CHROMA_H_H2_CS, layout BGRA, 0>", "algorithmic_bytes_per_launch": alg_bytes * B,
-                         "algorithmic_bytes_per_frame": alg_bytes,
-                         "avg_launch_us": round(per_launch_us, 3)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": wl.kernel, "algorithmic_bytes_per_launch": int(wl.alg_bytes_per_launch),
+                         "algorithmic_bytes_per_unit": wl.alg_bytes, "avg_launch_us": round(per_launch_us, 3)},
+            "per_rank": [{"rank": i, "value": round(v[0], 1), "hbm_gbs": round(v[1], 1)} for i, v in enumerate(per_rank)],
         }
+        if hasattr(wl, "flops_per_step"):
+            line["roofline"]["gflops"] = round(wl.flops_per_step * steps / (ev_ms * 1e-3) / 1e9, 1)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            try:
+                line["cpu_baseline"] = wl.cpu_baseline()
+            except Exception as e:  # the baseline is a report, never a reason to fail the bench
+                line["cpu_baseline"] = {"value": None, "unit": wl.unit, "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

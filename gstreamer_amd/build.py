@@ -27,16 +27,18 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, tuning=False):
+    """tuning=True adds -DGSTAMD_TUNING: the ablation switches (kernels that skip arithmetic on purpose, for profiling sessions)
+    exist only in such a build - never commit / ship one; rebuild without it afterwards."""
     os.makedirs(LIBDIR, exist_ok=True)
-    if not force and up_to_date():
+    if not force and not tuning and up_to_date():
         return LIB
     objs = []
     procs = []
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + (["-DGSTAMD_TUNING"] if tuning else []) + ["-x", "hip", "-c", src, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for src, p in procs:
         out, _ = p.communicate()
@@ -52,4 +54,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, tuning="--tuning" in sys.argv))

@@ -104,25 +104,33 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
   int bx = 64;
   /* development knobs (not a product interface): ablation of the blend (1), the pad loads (2), the hit loop (3),
    * both (4); workgroup width */
+#ifdef GSTAMD_TUNING
   const int abl = getenv ("GSTAMD_AGG_ABLATE") ? atoi (getenv ("GSTAMD_AGG_ABLATE")) : 0;
   if (getenv ("GSTAMD_AGG_BX"))
     bx = atoi (getenv ("GSTAMD_AGG_BX"));
+#else
+  const int abl = 0;
+#endif
   dim3 grid ((lanes + bx - 1) / bx, rh), block (bx);
 #define AGG_LAUNCH(A, S) hipLaunchKernelGGL ((k_aggregate<A, S>), grid, block, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh)
   if (q.ashift == 0) {
     switch (abl) {
+#ifdef GSTAMD_TUNING
       case 1: AGG_LAUNCH (1, 0); break;
       case 2: AGG_LAUNCH (2, 0); break;
       case 3: AGG_LAUNCH (3, 0); break;
       case 4: AGG_LAUNCH (4, 0); break;
+#endif
       default: AGG_LAUNCH (0, 0); break;
     }
   } else {
     switch (abl) {
+#ifdef GSTAMD_TUNING
       case 1: AGG_LAUNCH (1, 24); break;
       case 2: AGG_LAUNCH (2, 24); break;
       case 3: AGG_LAUNCH (3, 24); break;
       case 4: AGG_LAUNCH (4, 24); break;
+#endif
       default: AGG_LAUNCH (0, 24); break;
     }
   }

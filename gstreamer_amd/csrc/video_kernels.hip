@@ -156,10 +156,14 @@ __global__ __launch_bounds__ (64) void k_hscale_dot4_wave (SrcFront src, ScaleDe
   const int xa = x_lo & ~7;
   Dot4Taps<NW> ft;
   hscale_dot4_fetch<NW> (sd, xa, t0, t1, lane, ft);
+#ifdef GSTAMD_TUNING
   if (!(packed & 0x200))
+#endif
     tile_stage_row_planes (src, py, pu, pv, xa, x_hi, y, lane, packed & 1);
   wave_lds_sync ();
+#ifdef GSTAMD_TUNING
   if (!(packed & 0x100))
+#endif
     hscale_dot4_lane<NW> (py, pu, pv, ft, sd, sd.nw, dst, pf, t0, t1, y, lane);
 }
 
@@ -182,6 +186,9 @@ __global__ __launch_bounds__ (64) void k_hscale420_dot4 (SrcFront src, ScaleDev 
   hscale_dot4_fetch<NW> (sd, xa, t0, t1, lane, ft);
   H420State c;
   h420_begin (src, c, xa, x_hi, y0, lane);
+#ifndef GSTAMD_TUNING
+  ablate = 0;                   /* stage skipping is for -DGSTAMD_TUNING profiling builds only */
+#endif
   for (int y = y0; y < y1; y++) {
     const int late = ablate & 1;
     if (!(ablate & 0x200))
@@ -486,8 +493,9 @@ static bool launch_wide_variant (const FastParams &fp, const FrameBatch &batch, 
   return false;
 }
 
-// Tuning knob for profiling sessions: GSTAMD_FAST_VARIANT="shape,abl,K,order" with shape 0 = strip, 1 = wide; abl 1 =
-// memory-only ablation (h2cs only); K = line pairs per wave; order 1 = XCD-aware block order (strip).  Unset = shipped.
+// Kernel-shape selector for profiling sessions and the variant parity tests: GSTAMD_FAST_VARIANT="shape,abl,K,order" with shape 0 = strip,
+// 1 = wide; K = line pairs per wave; order 1 = XCD-aware block order (strip) - every combination computes the same bytes.  abl 1 =
+// memory-only ablation (h2cs only) exists in -DGSTAMD_TUNING builds alone (python -m gstreamer_amd.build --tuning).  Unset = shipped.
 struct FastVariant { int set, shape, abl, K, order; };
 static const FastVariant &fast_variant ()
 {
@@ -506,9 +514,11 @@ static bool launch_fast (const FastParams &fp, const FrameBatch &batch, int n, h
    * lane with the next pair's loads in flight during the current pair's math, one wave per workgroup */
   const FastVariant &v = fast_variant ();
   const int shape = v.set ? v.shape : 0, K = v.set && v.K > 0 ? v.K : 3;
+#ifdef GSTAMD_TUNING       /* memory-only ablation (wrong pixels on purpose): profiling builds only, never in the product library */
   if (v.set && v.abl && CH == CHROMA_H_H2_CS)
     return shape == 1 ? launch_wide_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, K, stream) :
         launch_strip_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, K, v.order != 0, stream);
+#endif
   if (shape == 1 && fp.width >= GSTAMD_WIDE_PX / 2 && fp.px_bytes == 4)
     return launch_wide_variant<CH, 0> (fp, batch, n, K, stream);
   return launch_strip_variant<CH, 0> (fp, batch, n, K, v.set && v.order != 0, stream);
@@ -611,7 +621,11 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
   src.vec_ok = front_vec_ok (f, pl);
   Dst d = make_dst (dst, dstride, final, post, pack_pos);
   dim3 block (256), grid ((out_w + 255) / 256, out_h);
+#ifdef GSTAMD_TUNING
   static const int ablate = getenv ("GSTAMD_ABLATE") ? atoi (getenv ("GSTAMD_ABLATE")) : 0;
+#else
+  const int ablate = 0;         /* the stage-skipping switches of k_hscale420_dot4 are dead code in the product build */
+#endif
   static const int h420_rows_env = getenv ("GSTAMD_H420_ROWS") ? atoi (getenv ("GSTAMD_H420_ROWS")) : -1;      /* 0: kernel off */
   if (horizontal && geom.tile16_w > 0 && sd.tapw && dot4_source_ok (src) && h420_source_ok (src) && h420_rows_env != 0) {
     /* lines per wave: the waves of the launch should all be resident at once (one round, no tail of late waves), each walking

@@ -229,6 +229,29 @@ def test_hip_aggregate_c4_full_size_properties(native_lib, gpu):
     assert bool((a.view(-1, 4)[:, 3] == 255).all())
 
 
+def test_hip_aggregate_c4_full_size_matches_reference(native_lib, gpu, ref):
+    """BASELINE config 4 at its own size (16 x 1080p BGRA pads onto a 4K checker canvas, SURVEY 8d's layout), fused aggregate
+    memcmp'd against the REFERENCE: fill_checker + 16 x blend_bgra of compositor/blend.c run on this host (compositor.c:1678-1697)."""
+    import torch
+    dw, dh, pw, ph = 3840, 2160, 1920, 1080
+    base_np = cases.frame_bytes(pw * ph * 4, "random", 31)
+    pads_np = [np.roll(base_np, i * 4099) for i in range(16)]
+    exp = np.zeros(dw * dh * 4, np.uint8)
+    ref.compositor_fill(0, "bgra", "BGRA", exp, dw, dh, 0, dh)
+    pads = [torch.from_numpy(p).to(gpu) for p in pads_np]
+    arr = (V.CompositorPad * 16)()
+    for i in range(16):
+        xpos, ypos, alpha = (i % 4) * 640, (i // 4) * 360, 0.25 + 0.05 * i
+        ref.compositor_blend("blend_bgra", "BGRA", pads_np[i], pw, ph, xpos, ypos, alpha, exp, dw, dh, 0, dh, 1)
+        arr[i].data, arr[i].width, arr[i].height, arr[i].stride = pads[i].data_ptr(), pw, ph, pw * 4
+        arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = xpos, ypos, alpha, 1
+    a = torch.zeros(dw * dh * 4, dtype=torch.uint8, device=gpu)
+    assert V.lib().gstamd_compositor_aggregate(V.FORMATS["BGRA"], 0, arr, 16, a.data_ptr(), dw, dh, dw * 4, None) == 0
+    torch.cuda.synchronize()
+    out = a.cpu().numpy()
+    assert (out == exp).all(), int((out != exp).sum())
+
+
 def test_div255_identity_used_by_packed_blend():
     """compositor_device.h pk16_div255: (x*0x8081)>>23 == (x+1+((x+1)>>8))>>8 for every reachable x (<= 255*255)."""
     x = np.arange(0, 255 * 255 + 1, dtype=np.int64)

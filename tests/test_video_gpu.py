@@ -70,6 +70,46 @@ def test_hip_matches_reference_bytewise_c3_shape(native_lib, gpu, ref):
     assert (out == exp).all(), int((out != exp).sum())
 
 
+def test_hip_matches_reference_bytewise_c3_full_size(native_lib, gpu, ref):
+    """BASELINE config 3 at its own size: 7680x4320 I420 -> 1920x1080 RGBA Lanczos, memcmp'd against the reference (n-threads=1)
+    run on this host - the benched shape with its own tile counts, lines-per-wave and 8K strides."""
+    w, h, ow, oh = 7680, 4320, 1920, 1080
+    src = cases.frame_bytes(ref.video_info("I420", w, h)["size"], "random", 7680)
+    exp = ref.VideoConverter("I420", w, h, "RGBA", ow, oh, config=cases.ref_config_string(ref, cases.LAN)).frame(src)
+    for _ in range(2):
+        out = gpu_convert(gpu, "I420", w, h, "RGBA", ow, oh, cases.LAN, None, None, src)
+        assert (out == exp).all(), int((out != exp).sum())
+
+
+def test_hip_matches_reference_bytewise_c5_full_size(native_lib, gpu, ref):
+    """BASELINE config 5 (per GPU) at its own size: 7680x4320 NV12 -> 3840x2160 BGRA, bilinear (the element's default method)."""
+    w, h, ow, oh = 7680, 4320, 3840, 2160
+    src = cases.frame_bytes(ref.video_info("NV12", w, h)["size"], "random", 4320)
+    exp = ref.VideoConverter("NV12", w, h, "BGRA", ow, oh, config=cases.ref_config_string(ref, cases.LIN)).frame(src)
+    out = gpu_convert(gpu, "NV12", w, h, "BGRA", ow, oh, cases.LIN, None, None, src)
+    assert (out == exp).all(), int((out != exp).sum())
+
+
+def test_hip_frame_list_32x4k_matches_reference(native_lib, gpu, ref):
+    """The launch bench.py times - 32 frames of 3840x2160 NV12 -> BGRA in ONE gstamd_video_converter_frames call, 32 distinct
+    output buffers - against 32 reference frames (sha256 per frame)."""
+    import torch
+    w, h, n = 3840, 2160, 32
+    ii, oi = V.video_info("NV12", w, h), V.video_info("BGRA", w, h)
+    base = cases.frame_bytes(int(ii.size), "random", 3232)
+    rc = ref.VideoConverter("NV12", w, h, "BGRA", w, h)
+    srcs_np = [np.roll(base, i * 4099) for i in range(n)]
+    exp = [cases.sha(rc.frame(s_)) for s_ in srcs_np]
+    conv = V.VideoConverter(ii, oi)
+    srcs = [torch.from_numpy(s_).to(gpu) for s_ in srcs_np]
+    outs = [torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu) for _ in range(n)]
+    conv.frames(srcs, outs)
+    torch.cuda.synchronize()
+    got = [cases.sha(o.cpu().numpy()) for o in outs]
+    assert got == exp, [i for i in range(n) if got[i] != exp[i]]
+    conv.free()
+
+
 H420_SHAPES = [("NV12", 1280, 720, "BGRA", 320, 180, "lanczos"), ("NV21", 1920, 1080, "RGBA", 480, 270, "lanczos"),
                ("I420", 2048, 856, "ARGB", 512, 214, "lanczos"), ("YV12", 640, 359, "BGRA", 160, 90, "lanczos"),
                ("NV12", 1920, 1080, "BGRA", 640, 360, "lanczos"), ("I420", 1280, 720, "RGBA", 640, 360, "lanczos"),

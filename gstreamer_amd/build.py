@@ -33,10 +33,13 @@ def build(force=False, verbose=True, tuning=False):
     os.makedirs(LIBDIR, exist_ok=True)
     if not force and not tuning and up_to_date():
         return LIB
+    lib = os.path.join(LIBDIR, "libgstamddsp_tuning.so") if tuning else LIB      # a tuning build never replaces the product library
+    objdir = os.path.join(LIBDIR, "tuning") if tuning else LIBDIR
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         cmd = [HIPCC] + FLAGS + (["-DGSTAMD_TUNING"] if tuning else []) + ["-x", "hip", "-c", src, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -46,11 +49,11 @@ def build(force=False, verbose=True, tuning=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
         if verbose and out.strip():
             print(out)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,--no-undefined"]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-Wl,--no-undefined"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -237,6 +237,95 @@ GSTAMD_AD T fir_output (const FirParams &p, const T *__restrict__ hist, const T 
   return fir_finish<T> (r0 + r1 + r2 + r3);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-staged form of the FULL-table inner product (k_fir_lds).  A workgroup of 256 lanes owns FIR_LDS_FRAMES consecutive output
+// frames: it stages (a) the logical input window under them, deinterleaved, [channel][frame] - the history / input / silence
+// decision of logical_sample is taken once per sample instead of once per tap - and (b) the taps row of every frame's phase
+// (rows padded to n_taps + 4 words: consecutive frames' rows then start 12 banks apart and the lanes' tap reads are
+// conflict-free).  Four lanes share one output frame: lane q accumulates the taps i = q (mod 4) - exactly the partial sum
+// res[q] of inner_product_<T>_full_1_c (audio-resampler.c:693-707) in the same order, a * b rounded then added - and the four
+// partial sums are combined ((r0 + r1) + r2) + r3 by every lane of the quad.
+// ------------------------------------------------------------------------------------------------
+#define FIR_LDS_FRAMES 64
+
+struct FirLdsGeom {
+  int row_stride;       // words per staged taps row: n_taps_padded + 4
+  int win_frames;       // staged frames per channel (multiple of 32, + 16 so that channels start 16 banks apart)
+};
+
+GSTAMD_AD void fir_position (const FirParams &p, long long j, long long *idx, int *phase)
+{
+  const long long t = (long long) p.samp_phase0 + j * (long long) p.samp_frac;
+  *idx = p.samp_index0 + j * (long long) p.samp_inc + t / p.out_rate;
+  *phase = (int) (t % p.out_rate);
+}
+
+// frames of the logical stream the outputs [jb, jb + nj) touch: [*lo, *lo + *span)
+GSTAMD_AD void fir_lds_span (const FirParams &p, long long jb, int nj, long long *lo, int *span)
+{
+  long long a, b;
+  int ph;
+  fir_position (p, jb, &a, &ph);
+  fir_position (p, jb + nj - 1, &b, &ph);
+  *lo = a;
+  *span = (int) (b - a) + p.n_taps_padded;
+}
+
+// position table of the workgroup's frames, filled once (the 64-bit division of fir_position is paid once per frame, not per tap):
+// pos[2 fr] = first window sample relative to the staged window, pos[2 fr + 1] = phase
+GSTAMD_AD void fir_lds_positions (const FirParams &p, long long jb, int nj, int *pos, int tid, int nthreads)
+{
+  long long lo, idx;
+  int span, phase;
+  fir_lds_span (p, jb, nj, &lo, &span);
+  for (int fr = tid; fr < nj; fr += nthreads) {
+    fir_position (p, jb + fr, &idx, &phase);
+    pos[2 * fr] = (int) (idx - lo);
+    pos[2 * fr + 1] = phase;
+  }
+}
+
+// staging, thread tid of nthreads (after fir_lds_positions and a barrier): taps rows of the frames' phases, four taps (one 16-byte
+// piece for float) per step, and the input window
+template <typename T>
+GSTAMD_AD void fir_lds_stage (const FirParams &p, const FirLdsGeom &g, const T *__restrict__ hist, const T *__restrict__ in,
+    const T *__restrict__ table, long long jb, int nj, const int *pos, T *rows, T *win, int tid, int nthreads)
+{
+  struct __attribute__ ((aligned (4 * sizeof (T) > 16 ? 16 : 4 * sizeof (T)))) Q4 { T v[4]; };
+  const int n4 = p.n_taps_padded >> 2;
+  for (int k = tid; k < nj * n4; k += nthreads) {
+    const int fr = k / n4, i4 = k - fr * n4;
+    *(Q4 *) (rows + fr * g.row_stride + 4 * i4) = *(const Q4 *) (table + (size_t) pos[2 * fr + 1] * p.n_taps_padded + 4 * i4);
+  }
+  long long lo;
+  int span;
+  fir_lds_span (p, jb, nj, &lo, &span);
+  const int C = p.channels;
+  for (int k = tid; k < span * C; k += nthreads) {
+    const int f = k / C, c = k - f * C;          /* interleaved order: neighbouring lanes read neighbouring samples */
+    win[c * g.win_frames + f] = logical_sample<T> (p, hist, in, lo + f, c);
+  }
+}
+
+// partial sum q of output frame fr of the workgroup, channel c
+template <typename T>
+GSTAMD_AD typename Acc<T>::type fir_lds_partial (const FirParams &p, const FirLdsGeom &g, const int *pos, const T *rows, const T *win, int fr,
+    int q, int c)
+{
+  typedef typename Acc<T>::type A;
+  const T *row = rows + fr * g.row_stride + q, *w = win + c * g.win_frames + pos[2 * fr] + q;
+  A r = 0;
+  for (int i = 0; i < p.n_taps_padded; i += 4)
+    r += (A) w[i] * (A) row[i];
+  return r;
+}
+
+template <typename T>
+GSTAMD_AD T fir_lds_combine (typename Acc<T>::type r0, typename Acc<T>::type r1, typename Acc<T>::type r2, typename Acc<T>::type r3)
+{
+  return fir_finish<T> (r0 + r1 + r2 + r3);
+}
+
 // new history: first `keep` frames are logical[src_start + i] for i < moved, else the OLD history frame i
 // (memmove semantics of audio-resampler-macros.h:94-96 when fewer frames are moved than are kept)
 template <typename T>

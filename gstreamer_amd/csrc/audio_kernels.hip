@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -40,6 +41,40 @@ __global__ __launch_bounds__ (256) void k_history (FirParams p, const T *__restr
   if (i >= keep * p.channels)
     return;
   new_hist[i] = history_sample<T> (p, hist, in, src_start, moved, i / p.channels, (int) (i % p.channels));
+}
+
+// FULL-table mode through LDS (audio_device.h, second half): FIR_LDS_FRAMES output frames per 256-lane workgroup, four lanes per
+// frame.  The workgroups past the FIR ones write the history the next call needs (k_history's job, one launch instead of two).
+template <typename T>
+__global__ __launch_bounds__ (256) void k_fir_lds (FirParams p, FirLdsGeom g, const T *__restrict__ hist, const T *__restrict__ in,
+    const T *__restrict__ table, T *__restrict__ out, long long n_out, int fir_blocks, T *__restrict__ new_hist, long long src_start,
+    long long moved, long long keep)
+{
+  extern __shared__ __attribute__ ((aligned (16))) unsigned char fir_lds_raw[];
+  if ((int) blockIdx.x >= fir_blocks) {
+    const long long i = (long long) (blockIdx.x - fir_blocks) * blockDim.x + threadIdx.x;
+    if (i < keep * p.channels)
+      new_hist[i] = history_sample<T> (p, hist, in, src_start, moved, i / p.channels, (int) (i % p.channels));
+    return;
+  }
+  typedef typename Acc<T>::type A;
+  T *rows = (T *) fir_lds_raw, *win = rows + FIR_LDS_FRAMES * g.row_stride;
+  int *pos = (int *) (win + (size_t) p.channels * g.win_frames);
+  const long long jb = (long long) blockIdx.x * FIR_LDS_FRAMES;
+  const int nj = n_out - jb < FIR_LDS_FRAMES ? (int) (n_out - jb) : FIR_LDS_FRAMES;
+  fir_lds_positions (p, jb, nj, pos, (int) threadIdx.x, 256);
+  __syncthreads ();
+  fir_lds_stage<T> (p, g, hist, in, table, jb, nj, pos, rows, win, (int) threadIdx.x, 256);
+  __syncthreads ();
+  const int fr = (int) threadIdx.x >> 2, q = (int) threadIdx.x & 3;
+  const int frc = fr < nj ? fr : nj - 1;        /* idle quads repeat the last frame (no divergence before the shuffles) */
+  for (int c = 0; c < p.channels; c++) {
+    const A r = fir_lds_partial<T> (p, g, pos, rows, win, frc, q, c);
+    const int lane = (int) (threadIdx.x & 63), base = lane & ~3;
+    const A r0 = __shfl (r, base, 64), r1 = __shfl (r, base + 1, 64), r2 = __shfl (r, base + 2, 64), r3 = __shfl (r, base + 3, 64);
+    if (fr < nj && q == (c & 3))
+      out[fir_out_index (p, jb + fr, c)] = fir_lds_combine<T> (r0, r1, r2, r3);
+  }
 }
 
 struct GstAmdAudioResampler {
@@ -131,6 +166,29 @@ static int run_resample (GstAmdAudioResampler *r, const void *in, size_t in_fram
     return GSTAMD_OK;
   const FirParams p = make_fir_params (pl, s, in == nullptr, in_stride, out_stride);
   const int cur = r->cur, nxt = cur ^ 1;
+  /* FULL mode: one launch of the LDS-staged kernel does the FIR and the history hand-over */
+  if (s.run_fir && !p.nearest && !p.interp && getenv ("GSTAMD_NO_FIR_LDS") == nullptr) {
+    FirLdsGeom g;
+    g.row_stride = p.n_taps_padded + 4;
+    const int span_max = FIR_LDS_FRAMES * (p.samp_inc + 1) + p.n_taps_padded + 2;
+    g.win_frames = ((span_max + 31) & ~31) + 16;
+    const size_t lds = ((size_t) FIR_LDS_FRAMES * g.row_stride + (size_t) pl.channels * g.win_frames) * sizeof (T) + 2 * FIR_LDS_FRAMES * sizeof (int);
+    if (lds <= 64 * 1024) {
+      if (s.keep > 0) {
+        int e = ensure_hist (r, nxt, (size_t) s.keep + 64);
+        if (e != GSTAMD_OK)
+          return e;
+      }
+      const int fir_blocks = (int) ((s.n_out + FIR_LDS_FRAMES - 1) / FIR_LDS_FRAMES);
+      const int hist_blocks = s.keep > 0 ? (int) ((s.keep * pl.channels + 255) / 256) : 0;
+      hipLaunchKernelGGL (k_fir_lds<T>, dim3 ((unsigned) (fir_blocks + hist_blocks)), dim3 (256), lds, stream, p, g, (const T *) r->hist[cur],
+          (const T *) in, (const T *) r->table_dev, (T *) out, s.n_out, fir_blocks, (T *) r->hist[nxt], s.src_start, s.moved, s.keep);
+      if (hipGetLastError () != hipSuccess)
+        return GSTAMD_ERR_HIP;
+      r->cur = nxt;
+      return GSTAMD_OK;
+    }
+  }
   if (s.run_fir) {
     const long long total = s.n_out * pl.channels;
     hipLaunchKernelGGL (k_fir<T>, dim3 ((unsigned) ((total + 255) / 256)), dim3 (256), 0, stream, p, (const T *) r->hist[cur],

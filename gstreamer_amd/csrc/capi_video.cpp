@@ -16,6 +16,7 @@
 #include "video_kernels.h"
 #include "video_fast.h"
 #include "video_encode_fast.h"
+#include "video_scale420_fused.h"
 
 using namespace gstamd;
 
@@ -53,7 +54,55 @@ struct GstAmdVideoConverter {
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
   bool reg420 = false;                    // first pass horizontal from a 4:2:0 source whose chroma pairing is the closed form of h420r_rows
   int reg_lo = 0, reg_hi = 0;
+  // k_scale420_fused (video_scale420_fused.h): both N-tap passes of a regular 4:2:0 source in one kernel
+  bool fused_ok = false;
+  Fused420Tables fused;
+  int32_t *vgroup_dev = nullptr;
+  uint32_t *vtapw_dev = nullptr;
+  int fused_waves = 0, fused_rpc = 0, fused_ring = 0;
 };
+
+namespace gstamd {
+size_t fused420_lds_bytes (int ring, int nwaves);
+int fused420_blocks_per_cu (int nwaves, size_t lds);
+hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
+    const int pack_pos[4], const PostFast &pf, hipStream_t stream);
+}
+
+// geometry of the fused scaler: waves per workgroup, output rows per workgroup (every workgroup of the launch resident at once where
+// possible), ring slots.  GSTAMD_FUSED_WAVES / GSTAMD_FUSED_ROWS select other (equally correct) shapes for tuning sessions and tests.
+static bool fused_pick_geometry (GstAmdVideoConverter *c, int tiles)
+{
+  const int out_h = c->plan.out_info.height;
+  const char *ew = getenv ("GSTAMD_FUSED_WAVES"), *er = getenv ("GSTAMD_FUSED_ROWS");
+  const int first = ew && atoi (ew) > 0 ? atoi (ew) : 16;      /* MI355X, C3: 16 waves 30.8 us, 8: 34.5, 4: 32.7, two-pass 33.7 (profiles/r02_c3_variants.log) */
+  int n_cu = 256, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    n_cu = prop.multiProcessorCount;
+  for (int nwaves = first; nwaves >= 2; nwaves /= 2) {
+    if (nwaves > 16)
+      continue;
+    int ring = fused420_ring_groups (c->fused, out_h, nwaves);
+    size_t lds = fused420_lds_bytes (ring, nwaves);
+    if (lds > 160 * 1024)
+      continue;
+    const int per_cu = fused420_blocks_per_cu (nwaves, lds);
+    if (per_cu <= 0)
+      continue;
+    const int chunks = std::max (1, per_cu * n_cu / std::max (1, tiles));
+    int rpc = er && atoi (er) > 0 ? atoi (er) : (out_h + chunks - 1) / chunks;
+    rpc = std::max (rpc, nwaves);
+    ring = fused420_ring_groups (c->fused, rpc, nwaves);
+    if (fused420_lds_bytes (ring, nwaves) > lds)
+      continue;
+    c->fused_waves = nwaves;
+    c->fused_rpc = rpc;
+    c->fused_ring = ring;
+    return true;
+  }
+  return false;
+}
 
 static bool fast_pair_usable (const VideoPlan &p, const Planes &pl, const uint8_t *dst, int dstride, int dalign = 16)
 {
@@ -195,14 +244,23 @@ static int ensure_tables (GstAmdVideoConverter *c)
       regular = th == heavy && tl == light;
     }
     c->reg420 = regular;
+    if (regular && !p.passes[1].horizontal && p.passes[1].kind == SCALE_NTAP && p.passes[0].nw >= 3 && p.passes[0].nw <= 5 &&
+        getenv ("GSTAMD_NO_FUSED420") == nullptr && make_fused420_tables (p.passes[1], p.front.height, &c->fused) &&
+        fused_pick_geometry (c, (p.passes[0].out_size + c->geom[0].tile16_w - 1) / c->geom[0].tile16_w)) {
+      if ((e = hipMalloc ((void **) &c->vgroup_dev, c->fused.vgroup.size () * sizeof (int32_t))) != hipSuccess ||
+          (e = hipMemcpy (c->vgroup_dev, c->fused.vgroup.data (), c->fused.vgroup.size () * sizeof (int32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+          (e = hipMalloc ((void **) &c->vtapw_dev, c->fused.vtapw.size () * sizeof (uint32_t))) != hipSuccess ||
+          (e = hipMemcpy (c->vtapw_dev, c->fused.vtapw.data (), c->fused.vtapw.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
+        return hip_fail (e, "fused scaler tables");
+      c->fused_ok = true;
+    }
   }
   if (p.passes.size () == 2) {
     const ScalePass &s0 = p.passes[0];
     c->tmp_w = s0.horizontal ? s0.out_size : p.in_info.width;
     c->tmp_h = s0.horizontal ? p.in_info.height : s0.out_size;
     c->tmp_size = (size_t) c->tmp_w * 4 * (c->tmp_h + 1);      /* + the spare row k_hscale420_reg sends its out-of-picture lines to */
-    if ((e = hipMalloc ((void **) &c->tmp, c->tmp_size)) != hipSuccess)
-      return hip_fail (e, "hipMalloc(tmp)");
+    /* allocated by the first frame that takes the two-pass form (ensure_tmp): the fused scaler needs no intermediate image */
   }
   if (p.plane_mode) {
     size_t tmp_bytes = 0;
@@ -472,8 +530,65 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "scale pass");
   }
   e = hipErrorNotSupported;
-  if (c->reg420 && pre.matrix.kind == MATRIX_NONE && pre.alpha_kind == ALPHA_NONE &&
-      (p.front.kind == UNPACK_SEMI || pl.stride[p.front.u_plane] == pl.stride[p.front.v_plane])) {
+  const bool reg_usable = c->reg420 && pre.matrix.kind == MATRIX_NONE && pre.alpha_kind == ALPHA_NONE &&
+      (p.front.kind == UNPACK_SEMI || pl.stride[p.front.u_plane] == pl.stride[p.front.v_plane]);
+  if (reg_usable && c->fused_ok) {
+    Fused420Params fq;
+    memset (&fq, 0, sizeof (fq));
+    H420RegParams &hp = fq.h;
+    hp.y = pl.p[0];
+    hp.ystride = pl.stride[0];
+    hp.semi = p.front.kind == UNPACK_SEMI;
+    hp.u_first = p.front.u_plane != 0;
+    hp.c0 = hp.semi ? pl.p[1] : pl.p[p.front.u_plane];
+    hp.c1 = hp.semi ? pl.p[1] : pl.p[p.front.v_plane];
+    hp.cstride = hp.semi ? pl.stride[1] : pl.stride[p.front.u_plane];
+    hp.width = p.front.width;
+    hp.height = p.front.height;
+    hp.crow_lo = c->reg_lo;
+    hp.crow_hi = c->reg_hi;
+    hp.offset = sd[0].offset;
+    hp.tapw = sd[0].tapw;
+    hp.nw4 = sd[0].nw4;
+    hp.out_w = p.passes[0].out_size;
+    hp.tile_w = c->geom[0].tile16_w;
+    fq.n_taps_h = sd[0].n_taps;
+    fq.vgroup = c->vgroup_dev;
+    fq.vtapw = c->vtapw_dev;
+    fq.ngv = c->fused.ngv;
+    fq.out_h = out_h;
+    fq.rows_per_chunk = c->fused_rpc;
+    fq.ring = c->fused_ring;
+    fq.n_groups = c->fused.n_groups;
+#ifdef GSTAMD_TUNING
+    /* profiling builds: GSTAMD_FUSED_TRACE=<file> dumps the per-wave stage stamps of every launch (the last one stays) */
+    const char *trace_path = getenv ("GSTAMD_FUSED_TRACE");
+    const size_t trace_n = (size_t) ((hp.out_w + hp.tile_w - 1) / hp.tile_w) * ((out_h + fq.rows_per_chunk - 1) / fq.rows_per_chunk) * 16 * 32;
+    if (trace_path && hipMalloc ((void **) &fq.trace, trace_n * 8) == hipSuccess)
+      (void) hipMemset (fq.trace, 0, trace_n * 8);
+#endif
+    e = launch_scale420_fused (fq, p.front.chroma_h, sd[0].nw, c->fused_waves, dst, dstride, post, p.post.pack_pos, pf, stream);
+#ifdef GSTAMD_TUNING
+    if (fq.trace) {
+      std::vector<unsigned long long> h (trace_n);
+      (void) hipStreamSynchronize (stream);
+      (void) hipMemcpy (h.data (), fq.trace, trace_n * 8, hipMemcpyDeviceToHost);
+      (void) hipFree (fq.trace);
+      if (FILE *f = fopen (trace_path, "wb")) {
+        fwrite (h.data (), 8, trace_n, f);
+        fclose (f);
+      }
+    }
+#endif
+    if (e == hipSuccess)
+      return GSTAMD_OK;
+    if (e != hipErrorNotSupported)
+      return hip_fail (e, "k_scale420_fused");
+  }
+  if (!c->tmp && (e = hipMalloc ((void **) &c->tmp, c->tmp_size)) != hipSuccess)
+    return hip_fail (e, "hipMalloc(tmp)");
+  e = hipErrorNotSupported;
+  if (reg_usable) {
     H420RegParams hp;
     memset (&hp, 0, sizeof (hp));
     hp.y = pl.p[0];
@@ -581,6 +696,10 @@ void gstamd_video_converter_free (GstAmdVideoConverter *c)
   }
   if (c->tmp)
     (void) hipFree (c->tmp);
+  if (c->vgroup_dev)
+    (void) hipFree (c->vgroup_dev);
+  if (c->vtapw_dev)
+    (void) hipFree (c->vtapw_dev);
   if (c->pk_img)
     (void) hipFree (c->pk_img);
   if (c->plane_tmp)

@@ -601,6 +601,51 @@ bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverte
   return true;
 }
 
+bool make_fused420_tables (const ScalePass &v, int height, Fused420Tables *t)
+{
+  if (v.horizontal || v.kind != SCALE_NTAP || v.precision != 6 || v.n_taps < 2)
+    return false;
+  const int n = v.n_taps, out_h = v.out_size;
+  t->ngv = (n + 3 + 3) / 4;
+  t->n_groups = (height / 2 + 2) / 2;
+  t->vgroup.assign (out_h, 0);
+  t->vtapw.assign ((size_t) out_h * t->ngv, 0);
+  for (int j = 0; j < out_h; j++) {
+    const int off = (int) v.offset[j];
+    if (off < 0 || off + n > height || (j > 0 && off < (int) v.offset[j - 1]))
+      return false;
+    int sum = 0;
+    const int g = (off + 1) >> 2, shift = (off + 1) & 3;
+    t->vgroup[j] = g;
+    for (int l = 0; l < n; l++) {
+      const int tap = v.taps[(size_t) j * n + l];
+      if (tap < -128 || tap > 127)
+        return false;
+      sum += tap;
+      const int k = l + shift;
+      t->vtapw[(size_t) j * t->ngv + (k >> 2)] |= (uint32_t) (uint8_t) (int8_t) tap << (8 * (k & 3));
+    }
+    if (sum != 64)
+      return false;
+  }
+  return true;
+}
+
+int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwaves)
+{
+  const int out_h = (int) t.vgroup.size ();
+  int worst = 0;
+  for (int j0 = 0; j0 < out_h; j0 += rows_per_chunk) {
+    const int j1 = std::min (j0 + rows_per_chunk, out_h);
+    for (int jr = j0; jr < j1; jr += nwaves) {
+      const int jl = std::min (jr + nwaves, j1) - 1;
+      const int gh = std::min (t.vgroup[jl] + t.ngv - 1, t.n_groups - 1);
+      worst = std::max (worst, gh - t.vgroup[jr] + 1);
+    }
+  }
+  return worst;
+}
+
 // ------------------------------------------------------------------------------------------------
 // line-cache simulation: which two source lines does the vertical chroma upsampler pair?
 // Mirrors gst_line_cache_get_lines / _add_line (video-converter.c:571-629) and the need_line

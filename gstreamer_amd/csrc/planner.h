@@ -107,6 +107,19 @@ struct TileGeom {
 };
 TileGeom pass_tile_geom (const ScalePass &pass);
 
+// tables of the fused 4:2:0 scaler (video_scale420_fused.h): the vertical N-tap pass as byte dot products over GROUPS of four
+// source lines (lines 4g-1 .. 4g+2), built from the pass's offsets and 6-bit taps
+struct Fused420Tables {
+  int ngv;                        // tap words per output row
+  int n_groups;                   // line groups of a picture of `height` lines
+  std::vector<int32_t> vgroup;    // [out_h] first group of the row's window
+  std::vector<uint32_t> vtapw;    // [out_h][ngv]
+};
+// false: the pass cannot take the byte form (a tap outside int8, a phase whose taps do not sum to 64, offsets not ascending)
+bool make_fused420_tables (const ScalePass &vpass, int height, Fused420Tables *t);
+// most groups any round of any chunk needs in the ring at once (rounds of `nwaves` rows inside chunks of rows_per_chunk rows)
+int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwaves);
+
 // one destination plane of convert_scale_planes on a planar / semi-planar format
 enum PlaneKind : int { PLANE_COPY = 0, PLANE_H_HALVE, PLANE_H_DOUBLE, PLANE_V_HALVE, PLANE_V_DOUBLE, PLANE_HV_HALVE, PLANE_HV_DOUBLE, PLANE_SCALE };
 struct PlanePlan {

@@ -11,6 +11,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgstamddsp.so")
+if os.environ.get("GSTAMD_TUNING_LIB") == "1":         # profiling sessions only: the -DGSTAMD_TUNING build (python -m gstreamer_amd.build --tuning)
+    LIB_PATH = os.path.join(HERE, "lib", "libgstamddsp_tuning.so")
 
 FORMATS = {"I420": 2, "YV12": 3, "AYUV": 6, "RGBx": 7, "BGRx": 8, "xRGB": 9, "xBGR": 10, "RGBA": 11, "BGRA": 12,
            "ARGB": 13, "ABGR": 14, "Y42B": 18, "Y444": 20, "NV12": 23, "NV21": 24,

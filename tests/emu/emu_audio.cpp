@@ -1,6 +1,7 @@
 // tests/emu/emu_audio.cpp - TEST INFRASTRUCTURE: host loop over the FIR kernel bodies (audio_device.h)
 // with the product's host bookkeeping (audio_taps.cpp), so the resampler can be checked against the
 // reference in this GPU-less container.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -15,6 +16,9 @@ struct EmuResampler {
   AudioState st;
   std::vector<uint8_t> hist;
 };
+
+static int g_fir_lds_runs = 0;
+extern "C" int emu_fir_lds_runs (void) { return g_fir_lds_runs; }
 
 template <typename T>
 static void emu_run (EmuResampler *r, const void *in, size_t in_frames, void *out, size_t out_frames)
@@ -42,7 +46,39 @@ static void emu_run (EmuResampler *r, const void *in, size_t in_frames, void *ou
   p.in_plane_stride = pl.in_planar ? (long long) in_frames : 0;
   p.out_plane_stride = pl.out_planar ? (long long) out_frames : 0;
   const T *hist = (const T *) r->hist.data ();
-  if (s.run_fir)
+  bool lds_done = false;
+  if (s.run_fir && !p.nearest && !p.interp && getenv ("GSTAMD_NO_FIR_LDS") == nullptr) {
+    /* k_fir_lds: workgroups of FIR_LDS_FRAMES frames, staging phase by all 256 threads, then four lanes per frame */
+    typedef typename Acc<T>::type A;
+    FirLdsGeom g;
+    g.row_stride = p.n_taps_padded + 4;
+    const int span_max = FIR_LDS_FRAMES * (p.samp_inc + 1) + p.n_taps_padded + 2;
+    g.win_frames = ((span_max + 31) & ~31) + 16;
+    const size_t words = (size_t) FIR_LDS_FRAMES * g.row_stride + (size_t) pl.channels * g.win_frames;
+    if (words * sizeof (T) <= 64 * 1024) {
+      std::vector<T> lds (words);
+      for (long long jb = 0; jb < s.n_out; jb += FIR_LDS_FRAMES) {
+        memset (lds.data (), 0x5a, words * sizeof (T));
+        T *rows = lds.data (), *win = rows + FIR_LDS_FRAMES * g.row_stride;
+        const int nj = s.n_out - jb < FIR_LDS_FRAMES ? (int) (s.n_out - jb) : FIR_LDS_FRAMES;
+        int pos[2 * FIR_LDS_FRAMES];
+        for (int tid = 0; tid < 256; tid++)
+          fir_lds_positions (p, jb, nj, pos, tid, 256);
+        for (int tid = 0; tid < 256; tid++)
+          fir_lds_stage<T> (p, g, hist, (const T *) in, (const T *) pl.table.data (), jb, nj, pos, rows, win, tid, 256);
+        for (int fr = 0; fr < nj; fr++)
+          for (int c = 0; c < pl.channels; c++) {
+            A rq[4];
+            for (int q = 0; q < 4; q++)
+              rq[q] = fir_lds_partial<T> (p, g, pos, rows, win, fr, q, c);
+            ((T *) out)[fir_out_index (p, jb + fr, c)] = fir_lds_combine<T> (rq[0], rq[1], rq[2], rq[3]);
+          }
+      }
+      lds_done = true;
+      g_fir_lds_runs++;
+    }
+  }
+  if (s.run_fir && !lds_done)
     for (long long j = 0; j < s.n_out; j++)
       for (int c = 0; c < pl.channels; c++)
         ((T *) out)[fir_out_index (p, j, c)] = fir_output<T> (p, hist, (const T *) in, (const T *) pl.table.data (), j, c);

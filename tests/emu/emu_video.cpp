@@ -11,6 +11,7 @@
 #include "../../gstreamer_amd/csrc/video_fast.h"
 #include "../../gstreamer_amd/csrc/video_scale_fast.h"
 #include "../../gstreamer_amd/csrc/video_hscale420.h"
+#include "../../gstreamer_amd/csrc/video_scale420_fused.h"
 #include "../../gstreamer_amd/csrc/video_422_fast.h"
 #include <cstdlib>
 #include <algorithm>
@@ -227,7 +228,9 @@ static void run_h420_reg_ch (const H420RegParams &p, int chroma_h, int n_taps)
     run_h420_reg_ch2<NW, 0> (p, chroma_h, n_taps);
 }
 
-static bool emu_hscale420_reg (const VideoPlan &p, const SrcFront &sf, const ScaleDev &sd0, uint8_t *tmp, int tmp_w)
+static bool emu_scale420_fused (const VideoPlan &p, H420RegParams hp, int nw, int n_taps_h, const Dst &dst, const PostFast &pf);
+// returns 1: the horizontal pass went to tmp, 2: the fused kernel rendered the final image, 0: not applicable
+static int emu_hscale420_reg (const VideoPlan &p, const SrcFront &sf, const ScaleDev &sd0, uint8_t *tmp, int tmp_w, const Dst *final_dst, const PostFast *pf)
 {
   if (getenv ("GSTAMD_NO_H420_REG"))
     return false;
@@ -274,6 +277,8 @@ static bool emu_hscale420_reg (const VideoPlan &p, const SrcFront &sf, const Sca
   ok = ok && (semi ? (al (hp.c0, 16) && (hp.cstride % 16) == 0) : (al (hp.c0, 8) && al (hp.c1, 8) && (hp.cstride % 8) == 0));
   if (!ok || sd0.nw < 3 || sd0.nw > 5)
     return false;
+  if (final_dst && emu_scale420_fused (p, hp, sd0.nw, sd0.n_taps, *final_dst, *pf))
+    return 2;
   const char *e = getenv ("GSTAMD_H420_ROWS");
   int lpw = e && atoi (e) > 0 ? atoi (e) : 12;
   hp.lines_per_wave = std::max (4, (lpw + 1) & ~1);
@@ -284,6 +289,120 @@ static bool emu_hscale420_reg (const VideoPlan &p, const SrcFront &sf, const Sca
     run_h420_reg_ch<4> (hp, p.front.chroma_h, sd0.n_taps);
   else
     run_h420_reg_ch<5> (hp, p.front.chroma_h, sd0.n_taps);
+  return 1;
+}
+
+// k_scale420_fused (video_fused_kernels.hip): the same phases in the same order, waves one after the other between barriers
+static int g_fused_runs = 0;
+extern "C" int emu_fused_runs (void) { return g_fused_runs; }
+
+template <int NW, int CH, int SEMI>
+static void run_fused420 (const Fused420Params &p, const Dst &dst, const PostFast &pf, int nwaves)
+{
+  const int tiles = (p.h.out_w + p.h.tile_w - 1) / p.h.tile_w, chunks = (p.out_h + p.rows_per_chunk - 1) / p.rows_per_chunk;
+  std::vector<uint32_t> lds ((size_t) p.ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) nwaves * 2 * GSTAMD_H420_LINE_WORDS + 4);
+  uint32_t *base = (uint32_t *) (((uintptr_t) lds.data () + 15) & ~(uintptr_t) 15);
+  std::vector<Fused420Lane<NW>> L ((size_t) nwaves * 64);
+  std::vector<int> gnext (nwaves);
+  for (int by = 0; by < chunks; by++)
+    for (int bx = 0; bx < tiles; bx++) {
+      memset (base, 0xAB, ((size_t) p.ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) nwaves * 2 * GSTAMD_H420_LINE_WORDS) * 4);    /* LDS starts as garbage */
+      uint32_t *ring = base;
+      const int t0 = bx * p.h.tile_w, t1 = std::min (t0 + p.h.tile_w, p.h.out_w);
+      const int j0 = by * p.rows_per_chunk, j1 = std::min (j0 + p.rows_per_chunk, p.out_h);
+      int x_lo, x_hi;
+      h420r_span (p.h, p.n_taps_h, t0, t1, &x_lo, &x_hi);
+      const int xa = x_lo & ~15;
+      int gl, g_last;
+      fused_round_groups (p, j0, j1 - 1, &gl, &g_last);
+      for (int w = 0; w < nwaves; w++) {
+        gnext[w] = gl + w;
+        for (int lane = 0; lane < 64; lane++) {
+          Fused420Lane<NW> &s = L[(size_t) w * 64 + lane];
+          s.x0 = xa + 16 * lane;
+          if (s.x0 + 16 > p.h.width)
+            s.x0 = p.h.width - 16;
+          h420r_fetch_taps<NW> (p.h, xa, t0, t1, lane, s.ft);
+          fused_request_group<NW, SEMI> (p.h, std::min (gnext[w], g_last), s);
+        }
+      }
+      for (int jr = j0; jr < j1; jr += nwaves) {
+        const int jl = std::min (jr + nwaves, j1) - 1;
+        int gl_r, gh;
+        fused_round_groups (p, jr, jl, &gl_r, &gh);
+        for (int w = 0; w < nwaves; w++) {
+          uint32_t *stage = base + (size_t) p.ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) w * 2 * GSTAMD_H420_LINE_WORDS;
+          Fused420Lane<NW> *Lw = &L[(size_t) w * 64];
+          int &g = gnext[w];
+          while (g <= gh) {
+            const int gn = std::min (g + nwaves, g_last);
+            for (int lane = 0; lane < 64; lane++)
+              fused_phase_a<NW, CH, SEMI> (p.h, Lw[lane], stage, g, lane);
+            for (int lane = 0; lane < 64; lane++)
+              fused_phase_b<NW> (Lw[lane], stage);
+            for (int lane = 0; lane < 64; lane++)
+              fused_phase_c<NW, CH, SEMI> (p.h, Lw[lane], stage, gn, lane);
+            for (int lane = 0; lane < 64; lane++)
+              fused_phase_d<NW> (Lw[lane], stage, ring + (size_t) (g % p.ring) * GSTAMD_FUSED_GROUP_WORDS, lane);
+            g += nwaves;
+          }
+        }
+        for (int w = 0; w < nwaves; w++) {
+          const int j = jr + w;
+          if (j <= jl)
+            for (int lane = 0; lane < 64; lane++) {
+              if (p.ngv == 5)
+                fused_vrow<5> (p, ring, dst, pf, j, t0, t1, lane);
+              else
+                fused_vrow<0> (p, ring, dst, pf, j, t0, t1, lane);
+            }
+        }
+      }
+    }
+}
+
+template <int NW, int SEMI>
+static void run_fused420_ch (const Fused420Params &p, int chroma_h, const Dst &dst, const PostFast &pf, int nwaves)
+{
+  if (chroma_h == CHROMA_H_H2_CS)
+    run_fused420<NW, CHROMA_H_H2_CS, SEMI> (p, dst, pf, nwaves);
+  else if (chroma_h == CHROMA_H_H2)
+    run_fused420<NW, CHROMA_H_H2, SEMI> (p, dst, pf, nwaves);
+  else
+    run_fused420<NW, CHROMA_H_NONE, SEMI> (p, dst, pf, nwaves);
+}
+
+// the decision of capi_video.cpp (ensure_tables + convert_to_packed) for k_scale420_fused; hp = the k_hscale420_reg parameters
+static bool emu_scale420_fused (const VideoPlan &p, H420RegParams hp, int nw, int n_taps_h, const Dst &dst, const PostFast &pf)
+{
+  if (getenv ("GSTAMD_NO_FUSED420") || p.passes[1].horizontal || p.passes[1].kind != SCALE_NTAP || nw < 3 || nw > 5)
+    return false;
+  Fused420Tables t;
+  if (!make_fused420_tables (p.passes[1], p.front.height, &t))
+    return false;
+  const char *ew = getenv ("GSTAMD_FUSED_WAVES"), *er = getenv ("GSTAMD_FUSED_ROWS");
+  const int nwaves = ew && atoi (ew) > 0 ? atoi (ew) : 8;
+  const int rpc = std::max (nwaves, er && atoi (er) > 0 ? atoi (er) : 17);
+  Fused420Params q;
+  memset (&q, 0, sizeof (q));
+  q.h = hp;
+  q.n_taps_h = n_taps_h;
+  q.vgroup = t.vgroup.data ();
+  q.vtapw = t.vtapw.data ();
+  q.ngv = t.ngv;
+  q.out_h = p.out_info.height;
+  q.rows_per_chunk = rpc;
+  q.ring = fused420_ring_groups (t, rpc, nwaves);
+  q.n_groups = t.n_groups;
+  if (((uintptr_t) dst.p % 4) != 0 || (dst.stride % 4) != 0)
+    return false;
+  g_fused_runs++;
+  if (nw == 3)
+    hp.semi ? run_fused420_ch<3, 1> (q, p.front.chroma_h, dst, pf, nwaves) : run_fused420_ch<3, 0> (q, p.front.chroma_h, dst, pf, nwaves);
+  else if (nw == 4)
+    hp.semi ? run_fused420_ch<4, 1> (q, p.front.chroma_h, dst, pf, nwaves) : run_fused420_ch<4, 0> (q, p.front.chroma_h, dst, pf, nwaves);
+  else
+    hp.semi ? run_fused420_ch<5, 1> (q, p.front.chroma_h, dst, pf, nwaves) : run_fused420_ch<5, 0> (q, p.front.chroma_h, dst, pf, nwaves);
   return true;
 }
 
@@ -758,7 +877,11 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
   const ScalePass &s0 = p.passes[0];
   const int tw = s0.horizontal ? s0.out_size : p.in_info.width, th = s0.horizontal ? p.in_info.height : s0.out_size;
   std::vector<uint8_t> tmp ((size_t) tw * 4 * (th + 1));
-  if (!emu_hscale420_reg (p, sf, sd[0], tmp.data (), tw))
+  const Dst final_dst = mk (d0, dstride, true);
+  const int reg = emu_hscale420_reg (p, sf, sd[0], tmp.data (), tw, &final_dst, &pf);
+  if (reg == 2)
+    return GSTAMD_OK;
+  if (!reg)
   run_scale (s0.horizontal, sf, sd[0], mk (tmp.data (), tw * 4, false), tw, th, s0.max_span,
       s0.horizontal ? pass_tile_geom (s0) : TileGeom {0, 0}, pf_none);
   SrcImage si;

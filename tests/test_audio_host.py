@@ -53,6 +53,20 @@ def test_fir_bodies_on_host_match_golden(native_lib, emu_lib, case):
     assert cases.sha(np.concatenate(chunks)) == GOLDEN[name]["sha256"]
 
 
+@pytest.mark.parametrize("lds", [True, False], ids=["k_fir_lds", "k_fir"])
+def test_lds_fir_body_is_the_path_taken_for_full_tables(native_lib, emu_lib, lds, monkeypatch):
+    """FULL-table streams go through the LDS-staged kernel body (four lanes per output frame, the reference's four partial sums);
+    with it switched off the one-lane-per-sample body gives the same samples.  C4's stream: 48k -> 44.1k F32 stereo."""
+    E = _emu(emu_lib)
+    E.emu_fir_lds_runs.restype = C.c_int
+    if not lds:
+        monkeypatch.setenv("GSTAMD_NO_FIR_LDS", "1")
+    case = [c for c in cases.AUDIO_CASES if c[1] == "F32LE" and c[3] == 48000 and c[4] == 44100 and c[2] == 2][0]
+    before = E.emu_fir_lds_runs()
+    test_fir_bodies_on_host_match_golden(native_lib, emu_lib, case)
+    assert (E.emu_fir_lds_runs() > before) == lds
+
+
 @pytest.mark.parametrize("case", cases.AUDIO_CASES[::3], ids=lambda c: c[0])
 def test_golden_is_the_references_output(ref, case):
     name, fmt, ch, ir, orr, method, quality, bufs = case

@@ -229,6 +229,7 @@ def test_hip_aggregate_c4_full_size_properties(native_lib, gpu):
     assert bool((a.view(-1, 4)[:, 3] == 255).all())
 
 
+@pytest.mark.gpu
 def test_hip_aggregate_c4_full_size_matches_reference(native_lib, gpu, ref):
     """BASELINE config 4 at its own size (16 x 1080p BGRA pads onto a 4K checker canvas, SURVEY 8d's layout), fused aggregate
     memcmp'd against the REFERENCE: fill_checker + 16 x blend_bgra of compositor/blend.c run on this host (compositor.c:1678-1697)."""

@@ -149,10 +149,38 @@ def test_hscale420_reg_bodies_any_lines_per_wave(native_lib, emu_lib, idx_case, 
     chroma site included; the path must be the one taken for these 4:2:0 cases."""
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     monkeypatch.setenv("GSTAMD_H420_ROWS", str(rows))
+    monkeypatch.setenv("GSTAMD_NO_FUSED420", "1")           # the two-pass form (the fused scaler is tested below)
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     before = emu_lib.emu_h420_reg_runs()
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
     assert emu_lib.emu_h420_reg_runs() == before + 1
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
+@pytest.mark.parametrize("geom", [(8, 17), (4, 4), (8, 8), (2, 5), (16, 1000), (3, 7)], ids=lambda g: "waves%d_rows%d" % g)
+@pytest.mark.parametrize("idx_case", H420_REG, ids=lambda c: c[1][0])
+def test_scale420_fused_bodies_any_geometry(native_lib, emu_lib, idx_case, geom, monkeypatch):
+    """k_scale420_fused (video_scale420_fused.h: horizontal pass into an LDS ring of four-line groups, vertical pass as byte dot
+    products down the ring) gives the reference's bytes for any waves-per-workgroup / rows-per-workgroup split (partial rounds,
+    one chunk, tiny chunks), crop and chroma sites included; where the vertical pass is N-tap it must be the path taken."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    monkeypatch.setenv("GSTAMD_FUSED_WAVES", str(geom[0]))
+    monkeypatch.setenv("GSTAMD_FUSED_ROWS", str(geom[1]))
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    emu_lib.emu_fused_runs.restype = C.c_int
+    before, before_reg = emu_lib.emu_fused_runs(), emu_lib.emu_h420_reg_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_fused_runs() + emu_lib.emu_h420_reg_runs() == before + before_reg + 1
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
+def test_scale420_fused_is_taken_for_the_c3_shape(native_lib, emu_lib):
+    name = "i420_rgba_quarter_lanczos"
+    _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    before = emu_lib.emu_fused_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_fused_runs() == before + 1
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
 
 

@@ -89,8 +89,15 @@ struct GstAmdAudioResampler {
   int cur = 0;
 };
 
-static thread_local std::string g_audio_error;
 extern "C" const char *gstamd_last_error (void);
+extern "C" void gstamd_internal_set_error (const char *msg);
+
+static int audio_hip_fail (const char *where)
+{
+  const hipError_t e = hipGetLastError ();
+  gstamd_internal_set_error ((std::string ("audio resampler, ") + where + ": " + (e != hipSuccess ? hipGetErrorString (e) : "HIP call failed")).c_str ());
+  return GSTAMD_ERR_HIP;
+}
 
 static int ensure_hist (GstAmdAudioResampler *r, int which, size_t frames)
 {
@@ -100,13 +107,13 @@ static int ensure_hist (GstAmdAudioResampler *r, int which, size_t frames)
   void *n = nullptr;
   const size_t fbytes = (size_t) r->plan.bps * r->plan.channels;
   if (hipMalloc (&n, cap * fbytes) != hipSuccess)
-    return GSTAMD_ERR_HIP;
+    return audio_hip_fail (__func__);
   if (hipMemset (n, 0, cap * fbytes) != hipSuccess)
-    return GSTAMD_ERR_HIP;
+    return audio_hip_fail (__func__);
   if (r->hist[which]) {
     /* keep the valid frames (only matters for the current buffer) */
     if (hipMemcpy (n, r->hist[which], r->hist_cap[which] * fbytes, hipMemcpyDeviceToDevice) != hipSuccess)
-      return GSTAMD_ERR_HIP;
+      return audio_hip_fail (__func__);
     (void) hipFree (r->hist[which]);
   }
   r->hist[which] = n;
@@ -120,9 +127,9 @@ static int ensure_device (GstAmdAudioResampler *r)
     return GSTAMD_OK;
   if (!r->plan.table.empty ()) {
     if (hipMalloc (&r->table_dev, r->plan.table.size ()) != hipSuccess)
-      return GSTAMD_ERR_HIP;
+      return audio_hip_fail (__func__);
     if (hipMemcpy (r->table_dev, r->plan.table.data (), r->plan.table.size (), hipMemcpyHostToDevice) != hipSuccess)
-      return GSTAMD_ERR_HIP;
+      return audio_hip_fail (__func__);
   }
   int e = ensure_hist (r, 0, (size_t) r->plan.n_taps + 64);
   if (e == GSTAMD_OK)
@@ -184,7 +191,7 @@ static int run_resample (GstAmdAudioResampler *r, const void *in, size_t in_fram
       hipLaunchKernelGGL (k_fir_lds<T>, dim3 ((unsigned) (fir_blocks + hist_blocks)), dim3 (256), lds, stream, p, g, (const T *) r->hist[cur],
           (const T *) in, (const T *) r->table_dev, (T *) out, s.n_out, fir_blocks, (T *) r->hist[nxt], s.src_start, s.moved, s.keep);
       if (hipGetLastError () != hipSuccess)
-        return GSTAMD_ERR_HIP;
+        return audio_hip_fail (__func__);
       r->cur = nxt;
       return GSTAMD_OK;
     }
@@ -194,7 +201,7 @@ static int run_resample (GstAmdAudioResampler *r, const void *in, size_t in_fram
     hipLaunchKernelGGL (k_fir<T>, dim3 ((unsigned) ((total + 255) / 256)), dim3 (256), 0, stream, p, (const T *) r->hist[cur],
         (const T *) in, (const T *) r->table_dev, (T *) out, s.n_out);
     if (hipGetLastError () != hipSuccess)
-      return GSTAMD_ERR_HIP;
+      return audio_hip_fail (__func__);
   }
   if (s.keep > 0) {
     int e = ensure_hist (r, nxt, (size_t) s.keep + 64);
@@ -204,7 +211,7 @@ static int run_resample (GstAmdAudioResampler *r, const void *in, size_t in_fram
     hipLaunchKernelGGL (k_history<T>, dim3 ((unsigned) ((total + 255) / 256)), dim3 (256), 0, stream, p, (const T *) r->hist[cur],
         (const T *) in, (T *) r->hist[nxt], s.src_start, s.moved, s.keep);
     if (hipGetLastError () != hipSuccess)
-      return GSTAMD_ERR_HIP;
+      return audio_hip_fail (__func__);
   }
   r->cur = nxt;
   return GSTAMD_OK;
@@ -233,7 +240,7 @@ GstAmdAudioResampler *gstamd_audio_resampler_new (int method, int flags, int for
   if (status)
     *status = e;
   if (e != GSTAMD_OK) {
-    g_audio_error = err;
+    gstamd_internal_set_error (err.c_str ());
     delete r;
     return nullptr;
   }
@@ -280,7 +287,7 @@ int gstamd_audio_resampler_update (GstAmdAudioResampler *r, int in_rate, int out
   std::string err;
   int e = audio_update (&plan, &st, in_rate, out_rate, options, &shift, &err);
   if (e != GSTAMD_OK) {
-    g_audio_error = err;
+    gstamd_internal_set_error (err.c_str ());
     return e;
   }
   const bool new_table = plan.table != r->plan.table;
@@ -289,16 +296,16 @@ int gstamd_audio_resampler_update (GstAmdAudioResampler *r, int in_rate, int out
   if (!r->device_ready)
     return GSTAMD_OK;
   if (hipDeviceSynchronize () != hipSuccess)
-    return GSTAMD_ERR_HIP;
+    return audio_hip_fail (__func__);
   if (new_table) {
     if (r->table_dev)
       (void) hipFree (r->table_dev);
     r->table_dev = nullptr;
     if (!r->plan.table.empty ()) {
       if (hipMalloc (&r->table_dev, r->plan.table.size ()) != hipSuccess)
-        return GSTAMD_ERR_HIP;
+        return audio_hip_fail (__func__);
       if (hipMemcpy (r->table_dev, r->plan.table.data (), r->plan.table.size (), hipMemcpyHostToDevice) != hipSuccess)
-        return GSTAMD_ERR_HIP;
+        return audio_hip_fail (__func__);
     }
   }
   if (shift.changed) {
@@ -306,13 +313,13 @@ int gstamd_audio_resampler_update (GstAmdAudioResampler *r, int in_rate, int out
     const size_t have = old_avail < r->hist_cap[r->cur] ? old_avail : r->hist_cap[r->cur];
     std::vector<uint8_t> h (have * fbytes);
     if (have && hipMemcpy (h.data (), r->hist[r->cur], h.size (), hipMemcpyDeviceToHost) != hipSuccess)
-      return GSTAMD_ERR_HIP;
+      return audio_hip_fail (__func__);
     audio_history_shift (shift, fbytes, &h);
     e = ensure_hist (r, r->cur, h.size () / fbytes + 64);
     if (e != GSTAMD_OK)
       return e;
     if (!h.empty () && hipMemcpy (r->hist[r->cur], h.data (), h.size (), hipMemcpyHostToDevice) != hipSuccess)
-      return GSTAMD_ERR_HIP;
+      return audio_hip_fail (__func__);
   }
   return GSTAMD_OK;
 }
@@ -378,7 +385,7 @@ int gstamd_audio_resampler_resample_planes (GstAmdAudioResampler *r, const void 
   };
   long long is = 0, os = 0;
   if (!stride_of (in, pl.in_planar, &is) || !stride_of ((const void *const *) out, pl.out_planar, &os)) {
-    g_audio_error = "non-interleaved planes must be equally spaced in ascending order";
+    gstamd_internal_set_error ("non-interleaved planes must be equally spaced in ascending order");
     return GSTAMD_ERR_UNSUPPORTED;
   }
   if (pl.in_planar && pl.channels < 2)

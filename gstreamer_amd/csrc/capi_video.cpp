@@ -161,6 +161,8 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[3], co
 extern "C" {
 
 const char *gstamd_last_error (void) { return g_last_error.c_str (); }
+/* the audio and compositor translation units report through the same thread-local (not part of the drop-in surface) */
+void gstamd_internal_set_error (const char *msg) { g_last_error = msg ? msg : ""; }
 
 int gstamd_video_info_set_format (GstAmdVideoInfo *info, int format, int width, int height)
 {
@@ -192,11 +194,26 @@ GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info
   return c;
 }
 
+static void release_tables (GstAmdVideoConverter *c);
+static int build_tables (GstAmdVideoConverter *c);
+
+// device tables on first use; a failure part-way releases what was allocated (a retry starts from nothing)
 static int ensure_tables (GstAmdVideoConverter *c)
 {
   std::lock_guard<std::mutex> g (c->lock);
   if (c->tables_ready)
     return GSTAMD_OK;
+  const int r = build_tables (c);
+  if (r != GSTAMD_OK) {
+    const std::string keep = g_last_error;
+    release_tables (c);
+    g_last_error = keep;
+  }
+  return r;
+}
+
+static int build_tables (GstAmdVideoConverter *c)
+{
   hipError_t e;
   VideoPlan &p = c->plan;
   if ((e = hipGetDevice (&c->device)) != hipSuccess)
@@ -680,12 +697,12 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
   return GSTAMD_OK;
 }
 
-void gstamd_video_converter_free (GstAmdVideoConverter *c)
+// every device table / scratch image of the converter; the plan stays
+static void release_tables (GstAmdVideoConverter *c)
 {
-  if (!c)
-    return;
   if (c->vpair_dev)
     (void) hipFree (c->vpair_dev);
+  c->vpair_dev = nullptr;
   for (auto &pd : c->pass_dev) {
     if (pd.offset)
       (void) hipFree (pd.offset);
@@ -693,6 +710,7 @@ void gstamd_video_converter_free (GstAmdVideoConverter *c)
       (void) hipFree (pd.taps);
     if (pd.tapw)
       (void) hipFree (pd.tapw);
+    pd = GstAmdVideoConverter::PassDev ();
   }
   if (c->tmp)
     (void) hipFree (c->tmp);
@@ -704,6 +722,9 @@ void gstamd_video_converter_free (GstAmdVideoConverter *c)
     (void) hipFree (c->pk_img);
   if (c->plane_tmp)
     (void) hipFree (c->plane_tmp);
+  c->tmp = c->pk_img = c->plane_tmp = nullptr;
+  c->vgroup_dev = nullptr;
+  c->vtapw_dev = nullptr;
   for (auto &v : c->plane_dev)
     for (auto &pd : v) {
       if (pd.offset)
@@ -711,7 +732,35 @@ void gstamd_video_converter_free (GstAmdVideoConverter *c)
       if (pd.taps)
         (void) hipFree (pd.taps);
     }
+  c->plane_dev.clear ();
+  c->fused_ok = false;
+  c->reg420 = false;
+  c->tables_ready = false;
+}
+
+void gstamd_video_converter_free (GstAmdVideoConverter *c)
+{
+  if (!c)
+    return;
+  release_tables (c);
   delete c;
+}
+
+int gstamd_video_converter_set_config (GstAmdVideoConverter *c, const GstAmdVideoConverterConfig *config)
+{
+  if (!c || !config)
+    return set_error (GSTAMD_ERR_INVALID, "NULL converter or config");
+  VideoPlan np;
+  std::string err;
+  const GstAmdVideoInfo in = c->plan.in_info, out = c->plan.out_info;
+  int r = plan_video_converter (&in, &out, config, &np, &err);
+  if (r != GSTAMD_OK)
+    return set_error (r, err);          /* the old plan stays, like a failed gst_video_converter_set_config leaves the converter usable */
+  std::lock_guard<std::mutex> g (c->lock);
+  (void) hipDeviceSynchronize ();       /* frames in flight still read the old tables */
+  release_tables (c);
+  c->plan = std::move (np);
+  return GSTAMD_OK;
 }
 
 const char *gstamd_video_converter_describe (const GstAmdVideoConverter *c)
@@ -800,6 +849,142 @@ int gstamd_stream_synchronize (void *stream)
 {
   hipError_t e = hipStreamSynchronize ((hipStream_t) stream);
   return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "hipStreamSynchronize");
+}
+
+void *gstamd_stream_new (void)
+{
+  hipStream_t st = nullptr;
+  hipError_t e = hipStreamCreateWithFlags (&st, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    hip_fail (e, "hipStreamCreate");
+    return nullptr;
+  }
+  return st;
+}
+
+void gstamd_stream_free (void *stream)
+{
+  if (stream)
+    (void) hipStreamDestroy ((hipStream_t) stream);
+}
+
+void *gstamd_event_new (void)
+{
+  hipEvent_t ev = nullptr;
+  hipError_t e = hipEventCreateWithFlags (&ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    hip_fail (e, "hipEventCreate");
+    return nullptr;
+  }
+  return ev;
+}
+
+void gstamd_event_free (void *event)
+{
+  if (event)
+    (void) hipEventDestroy ((hipEvent_t) event);
+}
+
+int gstamd_event_record (void *event, void *stream)
+{
+  hipError_t e = hipEventRecord ((hipEvent_t) event, (hipStream_t) stream);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "hipEventRecord");
+}
+
+int gstamd_stream_wait_event (void *stream, void *event)
+{
+  hipError_t e = hipStreamWaitEvent ((hipStream_t) stream, (hipEvent_t) event, 0);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "hipStreamWaitEvent");
+}
+
+int gstamd_event_synchronize (void *event)
+{
+  hipError_t e = hipEventSynchronize ((hipEvent_t) event);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "hipEventSynchronize");
+}
+
+int gstamd_event_query (void *event)
+{
+  hipError_t e = hipEventQuery ((hipEvent_t) event);
+  if (e == hipSuccess)
+    return 1;
+  if (e == hipErrorNotReady)
+    return 0;
+  return hip_fail (e, "hipEventQuery");
+}
+
+void *gstamd_host_alloc (size_t size)
+{
+  void *p = nullptr;
+  hipError_t e = hipHostMalloc (&p, size, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    hip_fail (e, "hipHostMalloc");
+    return nullptr;
+  }
+  return p;
+}
+
+void gstamd_host_free (void *ptr)
+{
+  if (ptr)
+    (void) hipHostFree (ptr);
+}
+
+int gstamd_device_copy (void *dst_device, const void *src_device, size_t size, void *stream)
+{
+  hipError_t e = hipMemcpyAsync (dst_device, src_device, size, hipMemcpyDeviceToDevice, (hipStream_t) stream);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "device copy");
+}
+
+int gstamd_device_upload_async (void *dst_device, const void *src_host, size_t size, void *stream)
+{
+  hipError_t e = hipMemcpyAsync (dst_device, src_host, size, hipMemcpyHostToDevice, (hipStream_t) stream);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "upload");
+}
+
+int gstamd_device_download_async (void *dst_host, const void *src_device, size_t size, void *stream)
+{
+  hipError_t e = hipMemcpyAsync (dst_host, src_device, size, hipMemcpyDeviceToHost, (hipStream_t) stream);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "download");
+}
+
+int gstamd_get_device (void)
+{
+  int d = -1;
+  if (hipGetDevice (&d) != hipSuccess)
+    return -1;
+  return d;
+}
+
+int gstamd_video_converter_is_reentrant (GstAmdVideoConverter *c)
+{
+  if (!c || ensure_tables (c) != GSTAMD_OK)
+    return 0;
+  const VideoPlan &p = c->plan;
+  if (p.plane_mode || p.out_planar)
+    return 0;                   /* plane_tmp / pk_img: one scratch image per converter */
+  if (p.passes.size () == 2) {
+    const auto small_kind = [](int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; };
+    if (!(small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)))
+      return 0;                 /* N-tap in both directions: the fused scaler needs no scratch, but a frame whose planes miss its
+                                 * alignment takes the two-pass form with the AYUV image in between */
+  }
+  return 1;
+}
+
+int gstamd_video_converter_get_config (const GstAmdVideoConverter *c, GstAmdVideoConverterConfig *config)
+{
+  if (!c || !config)
+    return set_error (GSTAMD_ERR_INVALID, "NULL converter or config");
+  *config = c->plan.config;
+  return GSTAMD_OK;
+}
+
+int gstamd_video_converter_frame_finish (GstAmdVideoConverter *c, void *stream)
+{
+  if (!c)
+    return set_error (GSTAMD_ERR_INVALID, "NULL converter");
+  return gstamd_stream_synchronize (stream);
 }
 
 int gstamd_device_count (void)

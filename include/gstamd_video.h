@@ -242,7 +242,40 @@ int gstamd_device_download (void *dst_host, const void *src_device, size_t size,
 int gstamd_stream_synchronize (void *stream);
 int gstamd_device_count (void);
 int gstamd_set_device (int device);
+int gstamd_get_device (void);
 const char *gstamd_last_error (void);
+
+/* ---- streams and events: what an element instance needs to run without device-wide synchronisation ----
+ * (SURVEY 8b Threading: "one HIP stream per element instance, synchronise before a CPU gst_buffer_map (READ)").  A stream belongs to
+ * the device that is current when it is created (gstamd_set_device).  Events order work ACROSS streams: the producer of a
+ * frame records an event after its kernel, a consumer on another stream makes its stream wait on it - no host round trip. */
+void *gstamd_stream_new (void);                  /* non-blocking stream; NULL on failure */
+void gstamd_stream_free (void *stream);
+void *gstamd_event_new (void);                   /* timing disabled */
+void gstamd_event_free (void *event);
+int gstamd_event_record (void *event, void *stream);
+int gstamd_stream_wait_event (void *stream, void *event);
+int gstamd_event_synchronize (void *event);      /* host waits for the event */
+int gstamd_event_query (void *event);            /* 1: reached, 0: not yet, < 0: error */
+/* page-locked host memory for system-memory pads (pageable memory makes hipMemcpyAsync synchronous and slow) */
+void *gstamd_host_alloc (size_t size);
+void gstamd_host_free (void *ptr);
+int gstamd_device_copy (void *dst_device, const void *src_device, size_t size, void *stream);
+int gstamd_device_upload_async (void *dst_device, const void *src_host, size_t size, void *stream);
+int gstamd_device_download_async (void *dst_host, const void *src_device, size_t size, void *stream);
+
+/* 1: frames of this converter may be in flight on several streams at once (the plan keeps no scratch image between its kernels);
+ * 0: one stream at a time (two-pass scalers and planar packers own one intermediate image per converter). */
+int gstamd_video_converter_is_reentrant (GstAmdVideoConverter *convert);
+
+/* gst_video_converter_get_config / _set_config (video-converter.c:2736-2790) for the options this library reads: the config the
+ * converter was planned with; set_config re-plans with the new options applied on top (unknown conversions: GSTAMD_ERR_UNSUPPORTED,
+ * the converter keeps its old plan). */
+int gstamd_video_converter_get_config (const GstAmdVideoConverter *convert, GstAmdVideoConverterConfig *config);
+int gstamd_video_converter_set_config (GstAmdVideoConverter *convert, const GstAmdVideoConverterConfig *config);
+/* gst_video_converter_frame_finish (video-converter.c:2827): waits for the conversions enqueued on `stream` (the async-tasks
+ * analogue: _frame enqueues, _frame_finish joins). */
+int gstamd_video_converter_frame_finish (GstAmdVideoConverter *convert, void *stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 
 #include "../include/gstamd_audio.h"
 #include "../include/gstamd_video.h"
+#include "gstamdhipmemory.h"
 
 GST_DEBUG_CATEGORY_STATIC (amd_ar_debug);
 #define GST_CAT_DEFAULT amd_ar_debug
@@ -35,12 +36,14 @@ typedef struct {
   gint r_method;                                         /* the method s->r was made with */
   gpointer d_in, d_out;
   gsize d_in_size, d_out_size;
+  gpointer stream;             /* this instance's HIP stream */
+  gint device_id;              /* device-id property: -1 = the process's current device */
   guint64 samples_out;
   GstClockTime t0;
 } GstAmdAudioResample;
 typedef struct { GstBaseTransformClass parent_class; } GstAmdAudioResampleClass;
 
-enum { PROP_0, PROP_QUALITY, PROP_METHOD, PROP_SINC_FILTER_MODE, PROP_SINC_FILTER_AUTO_THRESHOLD, PROP_SINC_FILTER_INTERPOLATION };
+enum { PROP_0, PROP_QUALITY, PROP_METHOD, PROP_SINC_FILTER_MODE, PROP_SINC_FILTER_AUTO_THRESHOLD, PROP_SINC_FILTER_INTERPOLATION, PROP_DEVICE_ID };
 G_DEFINE_TYPE (GstAmdAudioResample, gst_amd_ar, GST_TYPE_BASE_TRANSFORM);
 #define AMD_AR(o) ((GstAmdAudioResample *) (o))
 
@@ -58,6 +61,8 @@ amd_ar_set_property (GObject * o, guint id, const GValue * v, GParamSpec * p)
     s->sinc_filter_auto_threshold = g_value_get_uint (v);
   else if (id == PROP_SINC_FILTER_INTERPOLATION)
     s->sinc_filter_interpolation = g_value_get_enum (v);
+  else if (id == PROP_DEVICE_ID)
+    s->device_id = g_value_get_int (v);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (o, id, p);
 }
@@ -76,6 +81,8 @@ amd_ar_get_property (GObject * o, guint id, GValue * v, GParamSpec * p)
     g_value_set_uint (v, s->sinc_filter_auto_threshold);
   else if (id == PROP_SINC_FILTER_INTERPOLATION)
     g_value_set_enum (v, s->sinc_filter_interpolation);
+  else if (id == PROP_DEVICE_ID)
+    g_value_set_int (v, s->device_id);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (o, id, p);
 }
@@ -219,27 +226,51 @@ ar_staging (gpointer * p, gsize * have, gsize need)
   return *p != NULL;
 }
 
-/* resample in_frames from host memory (NULL = silence) into a host buffer; returns frames produced or -1 */
+/* resample in_frames from host memory (NULL = silence) into a host buffer; returns frames produced or -1.
+ * in_planes: NULL, or one pointer per channel (a non-interleaved buffer whose GstAudioMeta places the planes; they are gathered
+ * back to back in the device staging buffer, which is the layout the resampler was created for) */
 static gssize
-amd_ar_process (GstAmdAudioResample * s, const guint8 * in, gsize in_frames, guint8 * out, gsize out_cap_frames)
+amd_ar_process (GstAmdAudioResample * s, const guint8 * in, gpointer * in_planes, gsize in_frames, guint8 * out, gsize out_cap_frames)
 {
   const gsize bpf = GST_AUDIO_INFO_BPF (&s->in);
   gsize out_frames = gstamd_audio_resampler_get_out_frames (s->r, in_frames);
 
+  gst_amd_hip_select_device (s->device_id);
+  if (!s->stream && !(s->stream = gstamd_stream_new ()))
+    return -1;
   if (out_frames > out_cap_frames)
     out_frames = out_cap_frames;
-  if (in && !(ar_staging (&s->d_in, &s->d_in_size, in_frames * bpf) &&
-          gstamd_device_upload (s->d_in, in, in_frames * bpf, NULL) == GSTAMD_OK))
+  if ((in || in_planes) && !ar_staging (&s->d_in, &s->d_in_size, in_frames * bpf))
     return -1;
+  if (in_planes) {
+    const gsize plane = in_frames * (bpf / GST_AUDIO_INFO_CHANNELS (&s->in));
+    gint c;
+    for (c = 0; c < GST_AUDIO_INFO_CHANNELS (&s->in); c++)
+      if (gstamd_device_upload_async ((guint8 *) s->d_in + c * plane, in_planes[c], plane, s->stream) != GSTAMD_OK)
+        return -1;
+  } else if (in && gstamd_device_upload_async (s->d_in, in, in_frames * bpf, s->stream) != GSTAMD_OK) {
+    return -1;
+  }
   if (!ar_staging (&s->d_out, &s->d_out_size, out_frames * bpf))
     return -1;
-  if (gstamd_audio_resampler_resample (s->r, in ? s->d_in : NULL, in_frames, s->d_out, out_frames, NULL) != GSTAMD_OK)
+  if (gstamd_audio_resampler_resample (s->r, (in || in_planes) ? s->d_in : NULL, in_frames, s->d_out, out_frames, s->stream) != GSTAMD_OK)
     return -1;
-  if (out_frames && gstamd_device_download (out, s->d_out, out_frames * bpf, NULL) != GSTAMD_OK)
+  if (out_frames && gstamd_device_download_async (out, s->d_out, out_frames * bpf, s->stream) != GSTAMD_OK)
     return -1;
-  if (!out_frames)
-    gstamd_stream_synchronize (NULL);
+  if (gstamd_stream_synchronize (s->stream) != GSTAMD_OK)       /* the CPU reads `out` next; the staging buffers are free again */
+    return -1;
   return (gssize) out_frames;
+}
+
+/* a non-interleaved output buffer of `frames` frames: planes back to back + (GStreamer >= 1.16) the GstAudioMeta that
+ * gst_audio_buffer_map requires for this layout */
+static void
+amd_ar_finish_layout (GstAmdAudioResample * s, GstBuffer * buf, gsize frames)
+{
+#if GST_CHECK_VERSION (1, 16, 0)
+  if (GST_AUDIO_INFO_LAYOUT (&s->out) == GST_AUDIO_LAYOUT_NON_INTERLEAVED)
+    gst_buffer_add_audio_meta (buf, &s->out, frames, NULL);
+#endif
 }
 
 static void
@@ -272,7 +303,23 @@ amd_ar_transform (GstBaseTransform * t, GstBuffer * inbuf, GstBuffer * outbuf)
     gst_buffer_unmap (inbuf, &im);
     return GST_FLOW_ERROR;
   }
-  n = amd_ar_process (s, im.data, im.size / GST_AUDIO_INFO_BPF (&s->in), om.data, om.size / GST_AUDIO_INFO_BPF (&s->out));
+  {
+    gpointer *planes = NULL;
+    gsize in_frames = im.size / GST_AUDIO_INFO_BPF (&s->in);
+#if GST_CHECK_VERSION (1, 16, 0)
+    /* non-interleaved input: the planes are where the buffer's GstAudioMeta says, not necessarily back to back */
+    GstAudioMeta *ameta = gst_buffer_get_audio_meta (inbuf);
+    gpointer plane_ptrs[64];
+    if (ameta && GST_AUDIO_INFO_LAYOUT (&s->in) == GST_AUDIO_LAYOUT_NON_INTERLEAVED && GST_AUDIO_INFO_CHANNELS (&s->in) <= 64) {
+      gint c;
+      for (c = 0; c < GST_AUDIO_INFO_CHANNELS (&s->in); c++)
+        plane_ptrs[c] = im.data + ameta->offsets[c];
+      planes = plane_ptrs;
+      in_frames = ameta->samples;
+    }
+#endif
+    n = amd_ar_process (s, im.data, planes, in_frames, om.data, om.size / GST_AUDIO_INFO_BPF (&s->out));
+  }
   gst_buffer_unmap (outbuf, &om);
   gst_buffer_unmap (inbuf, &im);
   if (n < 0) {
@@ -280,6 +327,7 @@ amd_ar_transform (GstBaseTransform * t, GstBuffer * inbuf, GstBuffer * outbuf)
     return GST_FLOW_ERROR;
   }
   gst_buffer_set_size (outbuf, (gsize) n * GST_AUDIO_INFO_BPF (&s->out));
+  amd_ar_finish_layout (s, outbuf, (gsize) n);
   amd_ar_stamp (s, outbuf, (gsize) n);
   return n > 0 ? GST_FLOW_OK : GST_BASE_TRANSFORM_FLOW_DROPPED;
 }
@@ -301,13 +349,14 @@ amd_ar_drain (GstAmdAudioResample * s)
     return;
   buf = gst_buffer_new_and_alloc (out_frames * GST_AUDIO_INFO_BPF (&s->out));
   gst_buffer_map (buf, &om, GST_MAP_WRITE);
-  n = amd_ar_process (s, NULL, lat, om.data, out_frames);
+  n = amd_ar_process (s, NULL, NULL, lat, om.data, out_frames);
   gst_buffer_unmap (buf, &om);
   if (n <= 0) {
     gst_buffer_unref (buf);
     return;
   }
   gst_buffer_set_size (buf, (gsize) n * GST_AUDIO_INFO_BPF (&s->out));
+  amd_ar_finish_layout (s, buf, (gsize) n);
   amd_ar_stamp (s, buf, (gsize) n);
   gst_pad_push (GST_BASE_TRANSFORM_SRC_PAD (s), buf);
 }
@@ -333,6 +382,12 @@ amd_ar_stop (GstBaseTransform * t)
   if (s->r)
     gstamd_audio_resampler_free (s->r);
   s->r = NULL;
+  gst_amd_hip_select_device (s->device_id);
+  if (s->stream) {
+    gstamd_stream_synchronize (s->stream);
+    gstamd_stream_free (s->stream);
+    s->stream = NULL;
+  }
   gstamd_device_free (s->d_in);
   gstamd_device_free (s->d_out);
   s->d_in = s->d_out = NULL;
@@ -379,6 +434,8 @@ gst_amd_ar_class_init (GstAmdAudioResampleClass * klass)
     g_object_class_install_property (oc, PROP_SINC_FILTER_INTERPOLATION, g_param_spec_enum ("sinc-filter-interpolation",
             "Sinc filter interpolation", "How to interpolate the sinc filter table", fit, 2, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   }
+  g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
+          "HIP device this instance runs on (-1 = the process's current device)", -1, G_MAXINT, -1, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   gst_element_class_set_static_metadata (ec, "Audio resampler (MI355X/HIP)", "Filter/Converter/Audio",
       "Resamples audio with a polyphase FIR on an AMD Instinct GPU, bit-exact to GstAudioResampler", "gstreamer_amd");
   gst_element_class_add_static_pad_template (ec, &ar_sink);
@@ -403,6 +460,7 @@ gst_amd_ar_init (GstAmdAudioResample * s)
   s->sinc_filter_interpolation = GSTAMD_AUDIO_FILTER_INTERPOLATION_CUBIC;
   s->sinc_filter_auto_threshold = 1048576;
   s->t0 = GST_CLOCK_TIME_NONE;
+  s->device_id = -1;
 }
 
 GType

@@ -178,12 +178,14 @@ typedef struct {
   gpointer d_out;              /* device canvas when downstream wants system memory */
   gsize d_out_size;
   guint64 n_frames;
+  gpointer stream;             /* this instance's HIP stream (SURVEY 8b Threading); buffers are ordered by the tickets of gstamdhipmemory.h */
+  gint device_id;              /* device-id property: -1 = the process's current device */
   guint next_pad;
 } GstAmdCompositor;
 
 typedef struct { GstAggregatorClass parent_class; } GstAmdCompositorClass;
 
-enum { PROP_0, PROP_BACKGROUND };
+enum { PROP_0, PROP_BACKGROUND, PROP_DEVICE_ID };
 
 /* GstChildProxy (as gstvideoaggregator.c does): lets `sink_1::xpos=..` address pad properties from gst-launch */
 static GObject *
@@ -313,6 +315,8 @@ amd_comp_set_property (GObject * object, guint id, const GValue * value, GParamS
 {
   if (id == PROP_BACKGROUND)
     AMD_COMP (object)->background = g_value_get_enum (value);
+  else if (id == PROP_DEVICE_ID)
+    AMD_COMP (object)->device_id = g_value_get_int (value);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
 }
@@ -322,6 +326,8 @@ amd_comp_get_property (GObject * object, guint id, GValue * value, GParamSpec * 
 {
   if (id == PROP_BACKGROUND)
     g_value_set_enum (value, AMD_COMP (object)->background);
+  else if (id == PROP_DEVICE_ID)
+    g_value_set_int (value, AMD_COMP (object)->device_id);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
 }
@@ -360,7 +366,10 @@ amd_comp_sink_event (GstAggregator * agg, GstAggregatorPad * apad, GstEvent * ev
     GstCaps *caps;
     gst_event_parse_caps (event, &caps);
     GST_OBJECT_LOCK (p);
-    p->have_info = gst_video_info_from_caps (&p->info, caps) && amd_pad_format_of (GST_VIDEO_INFO_FORMAT (&p->info)) != 0;
+    /* progressive frames only: neither the blend nor the per-pad converter has a field-aware path (an interlaced pad would be
+     * composited as if progressive), so such caps are refused like any other unsupported format */
+    p->have_info = gst_video_info_from_caps (&p->info, caps) && amd_pad_format_of (GST_VIDEO_INFO_FORMAT (&p->info)) != 0 &&
+        !GST_VIDEO_INFO_IS_INTERLACED (&p->info);
     GST_OBJECT_UNLOCK (p);
     if (!p->have_info) {
       GST_ERROR_OBJECT (apad, "unsupported caps %" GST_PTR_FORMAT, caps);
@@ -543,6 +552,11 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
   if (!c->have_out)
     return GST_FLOW_NOT_NEGOTIATED;
   memset (mapped_dev, 0, sizeof (mapped_dev));
+  gst_amd_hip_select_device (c->device_id);
+  if (!c->stream && !(c->stream = gstamd_stream_new ())) {
+    GST_ELEMENT_ERROR (c, LIBRARY, INIT, ("no HIP stream"), ("%s", gstamd_last_error ()));
+    return GST_FLOW_ERROR;
+  }
 
   GST_OBJECT_LOCK (agg);
   for (l = GST_ELEMENT (agg)->sinkpads; l && n < AMD_COMP_MAX_PADS; l = l->next)
@@ -577,6 +591,7 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
         goto done_inputs;
       }
       mapped_dev[i] = TRUE;
+      gst_amd_hip_memory_wait_written (mem, c->stream);       /* produced on another element's stream */
       base = maps[i].data;
     } else {
       GstMapInfo m;
@@ -584,7 +599,7 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
         flow = GST_FLOW_ERROR;
         goto done_inputs;
       }
-      if (!ensure_device (&p->staging, &p->staging_size, m.size) || gstamd_device_upload (p->staging, m.data, m.size, NULL) != GSTAMD_OK) {
+      if (!ensure_device (&p->staging, &p->staging_size, m.size) || gstamd_device_upload_async (p->staging, m.data, m.size, c->stream) != GSTAMD_OK) {
         gst_buffer_unmap (bufs[i], &m);
         flow = GST_FLOW_ERROR;
         goto done_inputs;
@@ -621,7 +636,7 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
           memcpy (p->conv_key, key, sizeof (key));
         }
         if (!ensure_device (&p->conv_buf, &p->conv_buf_size, (gsize) p->conv_out.size) ||
-            gstamd_video_converter_frame (p->conv, base, p->conv_buf, NULL) != GSTAMD_OK) {
+            gstamd_video_converter_frame (p->conv, base, p->conv_buf, c->stream) != GSTAMD_OK) {
           flow = GST_FLOW_ERROR;
           goto done_inputs;
         }
@@ -670,6 +685,7 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
       flow = GST_FLOW_ERROR;
       goto done_inputs;
     }
+    gst_amd_hip_memory_wait_idle (omem, c->stream);           /* a recycled canvas may still be read downstream */
     canvas = omap.data;
   } else {
     outbuf = gst_buffer_new_allocate (NULL, GST_VIDEO_INFO_SIZE (&c->out_info), NULL);
@@ -692,19 +708,30 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
       dstrides[k] = GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, k);
     }
     r = gstamd_compositor_aggregate_frame (fmt, c->background, black, white, fdesc, (int) n_desc, dplanes, dstrides,
-        GST_VIDEO_INFO_WIDTH (&c->out_info), GST_VIDEO_INFO_HEIGHT (&c->out_info), NULL);
+        GST_VIDEO_INFO_WIDTH (&c->out_info), GST_VIDEO_INFO_HEIGHT (&c->out_info), c->stream);
   } else {
     r = gstamd_compositor_aggregate (fmt, c->background, desc, (int) n_desc, canvas, GST_VIDEO_INFO_WIDTH (&c->out_info),
-        GST_VIDEO_INFO_HEIGHT (&c->out_info), GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, 0), NULL);
+        GST_VIDEO_INFO_HEIGHT (&c->out_info), GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, 0), c->stream);
+  }
+  if (r == GSTAMD_OK) {
+    /* one ticket for the whole frame: `written` on the canvas, `read` on every HBM pad frame (staged inputs and per-pad
+     * conversions are reused by the next frame on the same stream, which orders them) */
+    GstAmdHipTicket *t = gst_amd_hip_ticket_new (c->stream);
+    if (c->out_hip)
+      gst_amd_hip_memory_set_written (omem, t);
+    for (i = 0; i < n; i++)
+      if (bufs[i] && mapped_dev[i])
+        gst_amd_hip_memory_set_read (gst_buffer_peek_memory (bufs[i], 0), t);
+    gst_amd_hip_ticket_unref (t);
   }
   if (c->out_hip) {
-    if (r == GSTAMD_OK)
-      r = gstamd_stream_synchronize (NULL);     /* staged inputs are reused by the next frame */
     gst_memory_unmap (omem, &omap);
   } else if (r == GSTAMD_OK) {
     GstMapInfo m;
     if (gst_buffer_map (outbuf, &m, GST_MAP_WRITE)) {
-      r = gstamd_device_download (m.data, c->d_out, m.size, NULL);        /* synchronises */
+      r = gstamd_device_download_async (m.data, c->d_out, m.size, c->stream);
+      if (r == GSTAMD_OK)
+        r = gstamd_stream_synchronize (c->stream);            /* the CPU is about to look at the frame */
       gst_buffer_unmap (outbuf, &m);
     } else {
       r = GSTAMD_ERR_INVALID;
@@ -750,6 +777,12 @@ amd_comp_stop (GstAggregator * agg)
     gst_object_unref (c->out_pool);
     c->out_pool = NULL;
   }
+  gst_amd_hip_select_device (c->device_id);
+  if (c->stream) {
+    gstamd_stream_synchronize (c->stream);
+    gstamd_stream_free (c->stream);
+    c->stream = NULL;
+  }
   gstamd_device_free (c->d_out);
   c->d_out = NULL;
   c->d_out_size = 0;
@@ -770,6 +803,8 @@ gst_amd_compositor_class_init (GstAmdCompositorClass * klass)
   oc->get_property = amd_comp_get_property;
   g_object_class_install_property (oc, PROP_BACKGROUND, g_param_spec_enum ("background", "Background", "Background type",
           amd_comp_background_get_type (), 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
+          "HIP device this instance runs on (-1 = the process's current device)", -1, G_MAXINT, -1, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   gst_element_class_add_static_pad_template_with_gtype (ec, &comp_sink_tmpl, gst_amd_compositor_pad_get_type ());
   /* the base class keeps its output segment in the src pad: it has to be a GstAggregatorPad */
   gst_element_class_add_static_pad_template_with_gtype (ec, &comp_src_tmpl, GST_TYPE_AGGREGATOR_PAD);
@@ -794,4 +829,6 @@ gst_amd_compositor_init (GstAmdCompositor * c)
   c->have_out = FALSE;
   c->n_frames = 0;
   c->next_pad = 0;
+  c->device_id = -1;
+  c->stream = NULL;
 }

@@ -1,5 +1,5 @@
-/* gstamdhipmemory.c - see gstamdhipmemory.h.  Device memory comes from the C ABI's helpers
- * (gstamd_device_alloc & co., include/gstamd_video.h), so this file has no HIP dependency of its own. */
+/* gstamdhipmemory.c - see gstamdhipmemory.h.  Device memory, streams and events come from the C ABI's helpers
+ * (include/gstamd_video.h), so this file has no HIP dependency of its own. */
 #include "gstamdhipmemory.h"
 
 #include <string.h>
@@ -10,6 +10,109 @@ typedef struct { GstAllocator parent; } GstAmdHipAllocator;
 typedef struct { GstAllocatorClass parent_class; } GstAmdHipAllocatorClass;
 
 G_DEFINE_TYPE (GstAmdHipAllocator, gst_amd_hip_allocator, GST_TYPE_ALLOCATOR);
+
+void
+gst_amd_hip_select_device (gint device_id)
+{
+  if (device_id >= 0 && gstamd_get_device () != device_id)
+    gstamd_set_device (device_id);
+}
+
+/* ---- tickets ----------------------------------------------------------------------------------------------------------- */
+static GMutex ticket_lock;
+static GSList *free_events = NULL;      /* recycled gstamd events (creating one costs more than recording it) */
+
+#define AMD_STREAM_SLOTS 64
+static struct { gpointer stream; guint64 next_seq, done_seq; } stream_table[AMD_STREAM_SLOTS];   /* under ticket_lock */
+
+static gint
+stream_slot_locked (gpointer stream)
+{
+  gint i, free_slot = -1;
+  for (i = 0; i < AMD_STREAM_SLOTS; i++) {
+    if (stream_table[i].next_seq && stream_table[i].stream == stream)
+      return i;
+    if (!stream_table[i].next_seq && free_slot < 0)
+      free_slot = i;
+  }
+  if (free_slot >= 0) {
+    stream_table[free_slot].stream = stream;
+    stream_table[free_slot].next_seq = 1;
+    stream_table[free_slot].done_seq = 0;
+  }
+  return free_slot;             /* -1: table full, the ticket falls back to plain event queries */
+}
+
+GstAmdHipTicket *
+gst_amd_hip_ticket_new (gpointer stream)
+{
+  GstAmdHipTicket *t;
+  gpointer ev = NULL;
+
+  g_mutex_lock (&ticket_lock);
+  if (free_events) {
+    ev = free_events->data;
+    free_events = g_slist_delete_link (free_events, free_events);
+  }
+  g_mutex_unlock (&ticket_lock);
+  if (!ev)
+    ev = gstamd_event_new ();
+  if (!ev || gstamd_event_record (ev, stream) != GSTAMD_OK) {
+    gstamd_event_free (ev);
+    gstamd_stream_synchronize (stream);       /* no event: fall back to a host wait, nothing is pending afterwards */
+    return NULL;
+  }
+  t = g_new0 (GstAmdHipTicket, 1);
+  t->event = ev;
+  t->refcount = 1;
+  g_mutex_lock (&ticket_lock);
+  t->stream_slot = stream_slot_locked (stream);
+  if (t->stream_slot >= 0)
+    t->seq = stream_table[t->stream_slot].next_seq++;
+  g_mutex_unlock (&ticket_lock);
+  return t;
+}
+
+gboolean
+gst_amd_hip_ticket_is_done (GstAmdHipTicket * t)
+{
+  gboolean done = FALSE;
+
+  if (!t)
+    return TRUE;
+  g_mutex_lock (&ticket_lock);
+  if (t->stream_slot >= 0 && t->seq <= stream_table[t->stream_slot].done_seq)
+    done = TRUE;
+  g_mutex_unlock (&ticket_lock);
+  if (done)
+    return TRUE;
+  if (gstamd_event_query (t->event) != 1)
+    return FALSE;
+  g_mutex_lock (&ticket_lock);
+  if (t->stream_slot >= 0 && stream_table[t->stream_slot].done_seq < t->seq)
+    stream_table[t->stream_slot].done_seq = t->seq;
+  g_mutex_unlock (&ticket_lock);
+  return TRUE;
+}
+
+GstAmdHipTicket *
+gst_amd_hip_ticket_ref (GstAmdHipTicket * t)
+{
+  if (t)
+    g_atomic_int_inc (&t->refcount);
+  return t;
+}
+
+void
+gst_amd_hip_ticket_unref (GstAmdHipTicket * t)
+{
+  if (!t || !g_atomic_int_dec_and_test (&t->refcount))
+    return;
+  g_mutex_lock (&ticket_lock);
+  free_events = g_slist_prepend (free_events, t->event);
+  g_mutex_unlock (&ticket_lock);
+  g_free (t);
+}
 
 static GstMemory *
 amd_hip_alloc (GstAllocator * allocator, gsize size, GstAllocationParams * params)
@@ -23,8 +126,10 @@ amd_hip_alloc (GstAllocator * allocator, gsize size, GstAllocationParams * param
     g_free (m);
     return NULL;
   }
+  m->device_id = gstamd_get_device ();
   g_mutex_init (&m->lock);
-  gst_memory_init (GST_MEMORY_CAST (m), 0, allocator, NULL, maxsize, 255, params ? params->prefix : 0, size);
+  /* NO_SHARE: there is no mem_share (a sub-memory would need its own events); gst_buffer_copy_region & co. then copy */
+  gst_memory_init (GST_MEMORY_CAST (m), GST_MEMORY_FLAG_NO_SHARE, allocator, NULL, maxsize, 255, params ? params->prefix : 0, size);
   return GST_MEMORY_CAST (m);
 }
 
@@ -33,10 +138,51 @@ amd_hip_free (GstAllocator * allocator, GstMemory * mem)
 {
   GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
 
+  /* work that still reads or writes the allocation must finish before it goes back to the driver */
+  if (m->written)
+    gstamd_event_synchronize (m->written->event);
+  gst_amd_hip_ticket_unref (m->written);
+  {
+    guint i;
+    for (i = 0; i < GST_AMD_HIP_MAX_READERS; i++) {
+      if (m->read[i])
+        gstamd_event_synchronize (m->read[i]->event);
+      gst_amd_hip_ticket_unref (m->read[i]);
+    }
+  }
   gstamd_device_free (m->device_ptr);
-  g_free (m->host_staging);
+  gstamd_host_free (m->host_staging);
   g_mutex_clear (&m->lock);
   g_free (m);
+}
+
+static void
+host_wait (GstAmdHipMemory * m, gboolean also_reads)
+{
+  if (m->written) {
+    gstamd_event_synchronize (m->written->event);
+    gst_amd_hip_ticket_unref (m->written);
+    m->written = NULL;
+  }
+  if (also_reads) {
+    guint i;
+    for (i = 0; i < GST_AMD_HIP_MAX_READERS; i++)
+      if (m->read[i]) {
+        gstamd_event_synchronize (m->read[i]->event);
+        gst_amd_hip_ticket_unref (m->read[i]);
+        m->read[i] = NULL;
+      }
+  }
+}
+
+void
+gst_amd_hip_memory_host_wait (GstMemory * mem)
+{
+  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+
+  g_mutex_lock (&m->lock);
+  host_wait (m, TRUE);
+  g_mutex_unlock (&m->lock);
 }
 
 static gpointer
@@ -47,15 +193,23 @@ amd_hip_map_full (GstMemory * mem, GstMapInfo * info, gsize maxsize)
 
   g_mutex_lock (&m->lock);
   if (info->flags & GST_MAP_AMDHIP) {
-    /* device map: pending host writes were uploaded at their unmap; the host mirror goes stale on write */
+    /* device map: pending host writes were uploaded at their unmap; the host mirror goes stale on write.  Ordering against
+     * other streams is the caller's job (gst_amd_hip_memory_wait_written / _wait_idle) */
     if (info->flags & GST_MAP_WRITE)
       m->host_valid = FALSE;
     ret = m->device_ptr;
   } else {
+    gst_amd_hip_select_device (m->device_id);
     if (!m->host_staging)
-      m->host_staging = g_malloc (mem->maxsize);
-    if ((info->flags & GST_MAP_READ) && !m->host_valid) {
-      /* kernels run asynchronously on the default stream: download synchronises before the CPU looks */
+      m->host_staging = gstamd_host_alloc (mem->maxsize);
+    if (!m->host_staging) {
+      g_mutex_unlock (&m->lock);
+      return NULL;
+    }
+    /* a READ needs the device's bytes; so does a WRITE-only map of a stale mirror, or the unmap's upload of the whole mirror
+     * would clobber the bytes the caller did not write */
+    if (!m->host_valid) {
+      host_wait (m, FALSE);
       if (gstamd_device_download (m->host_staging, m->device_ptr, mem->maxsize, NULL) != GSTAMD_OK) {
         g_mutex_unlock (&m->lock);
         return NULL;
@@ -77,12 +231,110 @@ amd_hip_unmap_full (GstMemory * mem, GstMapInfo * info)
 
   g_mutex_lock (&m->lock);
   if (!(info->flags & GST_MAP_AMDHIP) && (info->flags & GST_MAP_WRITE) && m->device_dirty_from_host) {
+    gst_amd_hip_select_device (m->device_id);
+    host_wait (m, TRUE);                /* kernels still reading the old contents */
     gstamd_device_upload (m->device_ptr, m->host_staging, mem->maxsize, NULL);
     gstamd_stream_synchronize (NULL);
     m->device_dirty_from_host = FALSE;
     m->host_valid = TRUE;
   }
   g_mutex_unlock (&m->lock);
+}
+
+/* make `stream` wait for ticket *t unless its event has been reached already (then the ticket is dropped) */
+static void
+stream_wait_ticket (GstAmdHipTicket ** t, gpointer stream)
+{
+  if (!*t)
+    return;
+  if (gst_amd_hip_ticket_is_done (*t)) {
+    gst_amd_hip_ticket_unref (*t);
+    *t = NULL;
+  } else if ((*t)->waited_stream != stream) {
+    gstamd_stream_wait_event (stream, (*t)->event);
+    (*t)->waited_stream = stream;     /* the same stream need not wait on it again (buffers of one list share their ticket) */
+  }
+}
+
+void
+gst_amd_hip_memory_wait_written (GstMemory * mem, gpointer stream)
+{
+  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+
+  g_mutex_lock (&m->lock);
+  stream_wait_ticket (&m->written, stream);
+  g_mutex_unlock (&m->lock);
+}
+
+void
+gst_amd_hip_memory_wait_idle (GstMemory * mem, gpointer stream)
+{
+  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+
+  g_mutex_lock (&m->lock);
+  stream_wait_ticket (&m->written, stream);
+  {
+    guint i;
+    for (i = 0; i < GST_AMD_HIP_MAX_READERS; i++)
+      stream_wait_ticket (&m->read[i], stream);
+  }
+  g_mutex_unlock (&m->lock);
+}
+
+void
+gst_amd_hip_memory_set_written (GstMemory * mem, GstAmdHipTicket * t)
+{
+  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+
+  g_mutex_lock (&m->lock);
+  gst_amd_hip_ticket_unref (m->written);        /* the writer waited for it (wait_idle) before it wrote */
+  m->written = gst_amd_hip_ticket_ref (t);
+  m->host_valid = FALSE;
+  g_mutex_unlock (&m->lock);
+}
+
+void
+gst_amd_hip_memory_set_read (GstMemory * mem, GstAmdHipTicket * t)
+{
+  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+
+  g_mutex_lock (&m->lock);
+  /* readers do not wait for each other: the memory remembers up to GST_AMD_HIP_MAX_READERS launches that may still be reading it
+   * (finished ones leave their slot); only when every slot holds a running reader does the host wait for the oldest */
+  {
+    guint i, slot = GST_AMD_HIP_MAX_READERS;
+    for (i = 0; i < GST_AMD_HIP_MAX_READERS; i++) {
+      if (m->read[i] && gst_amd_hip_ticket_is_done (m->read[i])) {
+        gst_amd_hip_ticket_unref (m->read[i]);
+        m->read[i] = NULL;
+      }
+      if (!m->read[i] && slot == GST_AMD_HIP_MAX_READERS)
+        slot = i;
+    }
+    if (slot == GST_AMD_HIP_MAX_READERS) {
+      gstamd_event_synchronize (m->read[0]->event);
+      gst_amd_hip_ticket_unref (m->read[0]);
+      slot = 0;
+    }
+    m->read[slot] = gst_amd_hip_ticket_ref (t);
+  }
+  g_mutex_unlock (&m->lock);
+}
+
+void
+gst_amd_hip_memory_mark_written (GstMemory * mem, gpointer stream)
+{
+  GstAmdHipTicket *t = gst_amd_hip_ticket_new (stream);
+  gst_amd_hip_memory_set_written (mem, t);
+  gst_amd_hip_ticket_unref (t);
+}
+
+void
+gst_amd_hip_memory_mark_read (GstMemory * mem, gpointer stream)
+{
+  GstAmdHipTicket *t = gst_amd_hip_ticket_new (stream);
+  gst_amd_hip_memory_set_read (mem, t);
+  gst_amd_hip_ticket_unref (t);
 }
 
 static void
@@ -102,7 +354,7 @@ gst_amd_hip_allocator_init (GstAmdHipAllocator * self)
   a->mem_type = GST_AMD_HIP_MEMORY_TYPE;
   a->mem_map_full = amd_hip_map_full;
   a->mem_unmap_full = amd_hip_unmap_full;
-  /* mem_copy / mem_share / mem_is_span: GstAllocator's defaults (copy goes through map) */
+  /* mem_copy: GstAllocator's default (through a CPU map); mem_share: none - memories are created NO_SHARE */
   GST_OBJECT_FLAG_SET (self, GST_ALLOCATOR_FLAG_CUSTOM_ALLOC);
 }
 

@@ -1,11 +1,17 @@
 /* gstamdhipmemory.h - GstAllocator for frames that stay in MI355X HBM across chained elements.
  *
  * Boundary contract ("Memory / ownership"): a GstAllocator subclass with its own mem_type and
- * caps feature; a CPU gst_buffer_map() stages through host memory (download on READ, upload on unmap after
- * WRITE), a device map (GST_MAP_AMDHIP) hands out the HBM pointer with no copy.  Precedent for the flag
+ * caps feature; a CPU gst_buffer_map() stages through (page-locked) host memory (download on READ, upload on unmap
+ * after WRITE), a device map (GST_MAP_AMDHIP) hands out the HBM pointer with no copy.  Precedent for the flag
  * convention in the reference: GST_MAP_HIP = GST_MAP_FLAG_LAST << 1
  * (subprojects/gst-plugins-bad/gst-libs/gst/hip/gsthipmemory.h:48) - names here are our own, and none of that
- * plugin's code is used. */
+ * plugin's code is used.
+ *
+ * Ordering without host synchronisation (SURVEY 8b Threading: one HIP stream per element instance): an element records ONE event
+ * per launch (a "ticket", reference counted, events recycled through a free list) on its stream and hangs it on every memory
+ * the launch touched - as `written` on the frames it produced, as `read` on the frames it consumed.  An element that READS a
+ * memory on another stream first makes its stream wait on the `written` ticket (gst_amd_hip_memory_wait_written); the next
+ * writer of a recycled pool buffer waits on both tickets (gst_amd_hip_memory_wait_idle).  A CPU map waits on the host. */
 #ifndef GST_AMD_HIP_MEMORY_H
 #define GST_AMD_HIP_MEMORY_H
 
@@ -17,15 +23,34 @@ G_BEGIN_DECLS
 #define GST_AMD_HIP_MEMORY_TYPE "AMDHIPMemory"
 #define GST_CAPS_FEATURE_MEMORY_AMD_HIP "memory:AMDHIPMemory"
 #define GST_MAP_AMDHIP (GST_MAP_FLAG_LAST << 1)
+#define GST_AMD_HIP_MAX_READERS 4
 
 typedef struct _GstAmdHipMemory {
   GstMemory mem;
   gpointer device_ptr;      /* HBM */
-  gpointer host_staging;    /* lazily allocated mirror for CPU maps */
+  gint device_id;           /* device the allocation lives on */
+  gpointer host_staging;    /* lazily allocated page-locked mirror for CPU maps */
   gboolean host_valid;      /* staging holds the current contents */
   gboolean device_dirty_from_host; /* a CPU WRITE map is outstanding / needs upload at unmap */
+  struct _GstAmdHipTicket *written;         /* the launch that last wrote this memory, NULL: nothing pending */
+  struct _GstAmdHipTicket *read[GST_AMD_HIP_MAX_READERS];    /* launches still reading it (several consumers of one buffer) */
   GMutex lock;
 } GstAmdHipMemory;
+
+/* one recorded event shared by everything a launch touched */
+typedef struct _GstAmdHipTicket {
+  gpointer event;           /* gstamd event */
+  gint refcount;
+  gint stream_slot;         /* index of the recording stream in the module's stream table */
+  guint64 seq;              /* position among the tickets recorded on that stream: work on a stream completes in order, so a
+                             * ticket is known to be done as soon as any later one of its stream has been seen done - most
+                             * completion checks then cost no HIP call (hipEventQuery is ~1.5 us on this stack) */
+  gpointer waited_stream;   /* last stream that was made to wait on this ticket (a second wait would be redundant) */
+} GstAmdHipTicket;
+gboolean gst_amd_hip_ticket_is_done (GstAmdHipTicket * t);
+GstAmdHipTicket *gst_amd_hip_ticket_new (gpointer stream);    /* records on `stream`; NULL when no event could be had (the stream was synchronised instead) */
+GstAmdHipTicket *gst_amd_hip_ticket_ref (GstAmdHipTicket * t);
+void gst_amd_hip_ticket_unref (GstAmdHipTicket * t);
 
 GType gst_amd_hip_allocator_get_type (void);
 GstAllocator *gst_amd_hip_allocator_get (void);          /* singleton, transfer none */
@@ -33,6 +58,21 @@ gboolean gst_is_amd_hip_memory (GstMemory * mem);
 /* buffer with one AMDHIPMemory of info->size bytes + a GstVideoMeta carrying pitches/offsets */
 GstBuffer *gst_amd_hip_buffer_new_video (const GstVideoInfo * info);
 GstBuffer *gst_amd_hip_buffer_new (gsize size);
+
+/* stream ordering, see the header comment; `stream` is the gstamd stream the caller enqueues its work on */
+void gst_amd_hip_memory_wait_written (GstMemory * mem, gpointer stream);    /* before reading on `stream` */
+void gst_amd_hip_memory_wait_idle (GstMemory * mem, gpointer stream);       /* before overwriting on `stream` */
+void gst_amd_hip_memory_set_written (GstMemory * mem, GstAmdHipTicket * t); /* after the writer's ticket was recorded (t may be NULL) */
+void gst_amd_hip_memory_set_read (GstMemory * mem, GstAmdHipTicket * t);    /* after the reader's ticket was recorded */
+/* convenience: a ticket of its own for one memory */
+void gst_amd_hip_memory_mark_written (GstMemory * mem, gpointer stream);
+void gst_amd_hip_memory_mark_read (GstMemory * mem, gpointer stream);
+
+/* the host waits until the device work pending on the memory is done (no copy; a CPU map does this and then downloads) */
+void gst_amd_hip_memory_host_wait (GstMemory * mem);
+
+/* device every thread of this process should select before touching HIP for an element: -1 = leave the current one */
+void gst_amd_hip_select_device (gint device_id);
 
 G_END_DECLS
 #endif

@@ -35,12 +35,18 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #define AMD_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR }"
 #define AMD_OUT_FORMATS AMD_FORMATS
 
+/* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path
+ * (video-converter.c:3304, 3383-3463), so interlaced caps are not negotiated rather than converted as if progressive
+ * (caps without the field are progressive by definition) */
+#define AMD_PROGRESSIVE ", interlace-mode=(string)progressive"
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_FORMATS) ";"
-        GST_VIDEO_CAPS_MAKE (AMD_FORMATS)));
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_FORMATS) AMD_PROGRESSIVE ";"
+        GST_VIDEO_CAPS_MAKE (AMD_FORMATS) AMD_PROGRESSIVE));
 static GstStaticPadTemplate src_tmpl = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_OUT_FORMATS) ";"
-        GST_VIDEO_CAPS_MAKE (AMD_OUT_FORMATS)));
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_OUT_FORMATS) AMD_PROGRESSIVE ";"
+        GST_VIDEO_CAPS_MAKE (AMD_OUT_FORMATS) AMD_PROGRESSIVE));
+
+#define AMD_MAX_STREAMS 4
 
 /* GstVideoScaleMethod of the reference (gstvideoconvertscale.h) */
 typedef enum {
@@ -80,9 +86,21 @@ typedef struct {
   gboolean in_hip, out_hip;
   GstAmdVideoConverter *convert;
   GstBufferPool *out_pool;     /* HBM output frames are recycled through a GstAmdHipBufferPool */
-  /* device staging for system-memory pads */
-  gpointer d_in, d_out;
-  gsize d_in_size, d_out_size;
+  /* one ring of HIP streams per element instance (SURVEY 8b Threading): frame k runs on stream k % n_streams, so the launch
+   * ramp of one frame overlaps the tail of the previous one and two elements of a process never serialise on the NULL stream;
+   * buffers are ordered across streams by the events of gstamdhipmemory.h, never by a host wait */
+  gint device_id;              /* device-id property: -1 = the process's current device */
+  guint hip_streams;           /* hip-streams property */
+  gpointer streams[AMD_MAX_STREAMS];
+  guint n_streams, next_stream;
+  /* device staging for system-memory pads, one per stream */
+  gpointer d_in[AMD_MAX_STREAMS], d_out[AMD_MAX_STREAMS];
+  gsize d_in_size[AMD_MAX_STREAMS], d_out_size[AMD_MAX_STREAMS];
+  GstPadChainFunction base_chain;       /* GstBaseTransform's chain function (the sink pad's, before chain_list was installed) */
+  /* GSTAMD_ELEMENT_STATS=1: host time spent in transform(), printed at stop (where does a buffer's CPU time go?) */
+  gboolean stats;
+  gint64 t_wait, t_convert, t_mark, t_total, t_prepare;
+  guint64 n_frames;
 } GstAmdVideoConvertScale;
 
 typedef struct {
@@ -91,7 +109,7 @@ typedef struct {
 } GstAmdVideoConvertScaleClass;
 
 enum { PROP_0, PROP_METHOD, PROP_ADD_BORDERS, PROP_N_THREADS, PROP_ALPHA_MODE, PROP_ALPHA_VALUE, PROP_CHROMA_MODE, PROP_MATRIX_MODE,
-  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION };
+  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION, PROP_DEVICE_ID, PROP_HIP_STREAMS };
 
 G_DEFINE_TYPE (GstAmdVideoConvertScale, gst_amd_vcs, GST_TYPE_BASE_TRANSFORM);
 #define AMD_VCS(o) ((GstAmdVideoConvertScale *) (o))
@@ -114,6 +132,8 @@ amd_vcs_set_property (GObject * object, guint id, const GValue * value, GParamSp
     case PROP_SHARPNESS: s->sharpness = g_value_get_double (value); break;
     case PROP_SHARPEN: s->sharpen = g_value_get_double (value); break;
     case PROP_DITHER_QUANTIZATION: s->dither_quantization = g_value_get_uint (value); break;
+    case PROP_DEVICE_ID: s->device_id = g_value_get_int (value); break;
+    case PROP_HIP_STREAMS: s->hip_streams = g_value_get_uint (value); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (s);
@@ -136,6 +156,8 @@ amd_vcs_get_property (GObject * object, guint id, GValue * value, GParamSpec * p
     case PROP_SHARPNESS: g_value_set_double (value, s->sharpness); break;
     case PROP_SHARPEN: g_value_set_double (value, s->sharpen); break;
     case PROP_DITHER_QUANTIZATION: g_value_set_uint (value, s->dither_quantization); break;
+    case PROP_DEVICE_ID: g_value_set_int (value, s->device_id); break;
+    case PROP_HIP_STREAMS: g_value_set_uint (value, s->hip_streams); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (s);
@@ -272,6 +294,11 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
 
   if (!gst_video_info_from_caps (&s->in_info, incaps) || !gst_video_info_from_caps (&s->out_info, outcaps))
     return FALSE;
+  if (GST_VIDEO_INFO_IS_INTERLACED (&s->in_info) || GST_VIDEO_INFO_INTERLACE_MODE (&s->in_info) != GST_VIDEO_INFO_INTERLACE_MODE (&s->out_info)) {
+    GST_ERROR_OBJECT (s, "interlaced content is not supported by the HIP converter");
+    return FALSE;
+  }
+  gst_amd_hip_select_device (s->device_id);
   s->in_hip = caps_are_hip (incaps);
   s->out_hip = caps_are_hip (outcaps);
   if (s->out_pool) {
@@ -279,7 +306,7 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
     gst_object_unref (s->out_pool);
     s->out_pool = NULL;
   }
-  if (s->out_hip && !(s->out_pool = gst_amd_hip_buffer_pool_new_for_caps (outcaps, 2))) {
+  if (s->out_hip && !(s->out_pool = gst_amd_hip_buffer_pool_new_for_caps (outcaps, 8))) {
     GST_ERROR_OBJECT (s, "could not set up the HBM output pool");
     return FALSE;
   }
@@ -343,6 +370,59 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
     return FALSE;
   }
   GST_CAT_DEBUG_OBJECT (CAT_PERFORMANCE, s, "HIP plan: %s", gstamd_video_converter_describe (s->convert));
+  {
+    /* the stream ring: as many streams as the plan allows in flight at once (plans with a scratch image: one) */
+    guint want = gstamd_video_converter_is_reentrant (s->convert) ? CLAMP (s->hip_streams, 1, AMD_MAX_STREAMS) : 1, i;
+    for (i = 0; i < AMD_MAX_STREAMS; i++)
+      if (i < want && !s->streams[i])
+        s->streams[i] = gstamd_stream_new ();
+    for (i = 0; i < want && s->streams[i]; i++);
+    if (i == 0) {
+      GST_ERROR_OBJECT (s, "could not create a HIP stream: %s", gstamd_last_error ());
+      return FALSE;
+    }
+    s->n_streams = i;
+  }
+  return TRUE;
+}
+
+/* upstream asks how to allocate the frames it will send us (gst_video_filter_propose_allocation, gstvideofilter.c:56-103, adds
+ * GstVideoMeta support; here HBM caps additionally get the HIP allocator and a GstAmdHipBufferPool, so a source or decoder that
+ * honours the query writes straight into device memory) */
+static gboolean
+amd_vcs_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query, GstQuery * query)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (trans);
+  GstCaps *caps = NULL;
+  gboolean need_pool = FALSE;
+
+  if (!GST_BASE_TRANSFORM_CLASS (gst_amd_vcs_parent_class)->propose_allocation (trans, decide_query, query))
+    return FALSE;
+  if (decide_query == NULL)           /* passthrough: the downstream answer was forwarded */
+    return TRUE;
+  gst_query_parse_allocation (query, &caps, &need_pool);
+  if (caps && caps_are_hip (caps)) {
+    GstVideoInfo info;
+    if (!gst_video_info_from_caps (&info, caps))
+      return FALSE;
+    gst_amd_hip_select_device (s->device_id);
+    gst_query_add_allocation_param (query, gst_amd_hip_allocator_get (), NULL);
+    if (need_pool) {
+      GstBufferPool *pool = gst_amd_hip_buffer_pool_new ();
+      GstStructure *config = gst_buffer_pool_get_config (pool);
+      gst_buffer_pool_config_set_params (config, caps, GST_VIDEO_INFO_SIZE (&info), 2, 0);
+      gst_buffer_pool_config_add_option (config, GST_BUFFER_POOL_OPTION_VIDEO_META);
+      if (!gst_buffer_pool_set_config (pool, config)) {
+        gst_object_unref (pool);
+        return FALSE;
+      }
+      gst_query_add_allocation_pool (query, pool, GST_VIDEO_INFO_SIZE (&info), 2, 0);
+      gst_object_unref (pool);
+    } else {
+      gst_query_add_allocation_pool (query, NULL, GST_VIDEO_INFO_SIZE (&info), 2, 0);
+    }
+  }
+  gst_query_add_allocation_meta (query, GST_VIDEO_META_API_TYPE, NULL);
   return TRUE;
 }
 
@@ -368,6 +448,17 @@ amd_vcs_prepare_output_buffer (GstBaseTransform * trans, GstBuffer * inbuf, GstB
   }
   if (!s->out_hip)
     return GST_BASE_TRANSFORM_CLASS (gst_amd_vcs_parent_class)->prepare_output_buffer (trans, inbuf, outbuf);
+  gst_amd_hip_select_device (s->device_id);
+  {
+    const gint64 t0 = s->stats ? g_get_monotonic_time () : 0;
+    const GstFlowReturn fr = s->out_pool ? gst_buffer_pool_acquire_buffer (s->out_pool, outbuf, NULL) : GST_FLOW_ERROR;
+    if (fr != GST_FLOW_OK)
+      return GST_FLOW_ERROR;
+    gst_buffer_copy_into (*outbuf, inbuf, GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS, 0, -1);
+    if (s->stats)
+      s->t_prepare += g_get_monotonic_time () - t0;
+    return GST_FLOW_OK;
+  }
   if (!s->out_pool || gst_buffer_pool_acquire_buffer (s->out_pool, outbuf, NULL) != GST_FLOW_OK)
     return GST_FLOW_ERROR;
   gst_buffer_copy_into (*outbuf, inbuf, GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS, 0, -1);
@@ -385,6 +476,30 @@ ensure_staging (gpointer * p, gsize * have, gsize need)
   return *p != NULL;
 }
 
+/* plane pointers / pitches of a frame whose first byte is `base`: the buffer's GstVideoMeta when it has one (a pool or decoder may pad
+ * rows or planes), else the negotiated GstVideoInfo */
+static void
+frame_planes (GstBuffer * buf, const GstVideoInfo * info, guint8 * base, gpointer planes[GSTAMD_VIDEO_MAX_PLANES],
+    gint32 strides[GSTAMD_VIDEO_MAX_PLANES])
+{
+  GstVideoMeta *vm = gst_buffer_get_video_meta (buf);
+  guint i, n = GST_VIDEO_INFO_N_PLANES (info);
+
+  for (i = 0; i < GSTAMD_VIDEO_MAX_PLANES; i++) {
+    planes[i] = NULL;
+    strides[i] = 0;
+  }
+  for (i = 0; i < n && i < GSTAMD_VIDEO_MAX_PLANES; i++) {
+    if (vm && vm->n_planes == n) {
+      planes[i] = base + vm->offset[i];
+      strides[i] = vm->stride[i];
+    } else {
+      planes[i] = base + GST_VIDEO_INFO_PLANE_OFFSET (info, i);
+      strides[i] = GST_VIDEO_INFO_PLANE_STRIDE (info, i);
+    }
+  }
+}
+
 static GstFlowReturn
 amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
 {
@@ -393,48 +508,76 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
   GstMemory *imem = gst_buffer_peek_memory (inbuf, 0), *omem = gst_buffer_peek_memory (outbuf, 0);
   const gboolean in_dev = gst_buffer_n_memory (inbuf) == 1 && gst_is_amd_hip_memory (imem);
   const gboolean out_dev = gst_buffer_n_memory (outbuf) == 1 && gst_is_amd_hip_memory (omem);
-  gconstpointer src;
-  gpointer dst;
+  gpointer sp[GSTAMD_VIDEO_MAX_PLANES], dp[GSTAMD_VIDEO_MAX_PLANES], stream;
+  gint32 ss[GSTAMD_VIDEO_MAX_PLANES], ds[GSTAMD_VIDEO_MAX_PLANES];
+  guint8 *src, *dst;
+  guint k;
   int r;
 
-  if (!s->convert)
+  gint64 ta = 0, tb = 0, tc = 0, td = 0;
+  if (!s->convert || !s->n_streams)
     return GST_FLOW_NOT_NEGOTIATED;
+  if (s->stats)
+    ta = g_get_monotonic_time ();
+  gst_amd_hip_select_device (s->device_id);       /* the streaming thread's current device */
+  k = s->next_stream++ % s->n_streams;
+  stream = s->streams[k];
   /* source */
   if (in_dev) {
     if (!gst_memory_map (imem, &imap, GST_MAP_READ | GST_MAP_AMDHIP))
       return GST_FLOW_ERROR;
+    gst_amd_hip_memory_wait_written (imem, stream);
     src = imap.data;
   } else {
     if (!gst_buffer_map (inbuf, &imap, GST_MAP_READ))
       return GST_FLOW_ERROR;
-    if (!ensure_staging (&s->d_in, &s->d_in_size, imap.size) ||
-        gstamd_device_upload (s->d_in, imap.data, imap.size, NULL) != GSTAMD_OK) {
+    /* pageable host memory: the copy call returns once the source has been staged, so the buffer may be unmapped after it */
+    if (!ensure_staging (&s->d_in[k], &s->d_in_size[k], imap.size) ||
+        gstamd_device_upload_async (s->d_in[k], imap.data, imap.size, stream) != GSTAMD_OK) {
       gst_buffer_unmap (inbuf, &imap);
       return GST_FLOW_ERROR;
     }
-    src = s->d_in;
+    src = s->d_in[k];
   }
   /* destination */
   if (out_dev) {
     if (!gst_memory_map (omem, &omap, GST_MAP_WRITE | GST_MAP_AMDHIP))
       goto map_fail;
+    gst_amd_hip_memory_wait_idle (omem, stream);    /* a recycled pool buffer may still be read downstream */
     dst = omap.data;
   } else {
     if (!gst_buffer_map (outbuf, &omap, GST_MAP_WRITE))
       goto map_fail;
-    if (!ensure_staging (&s->d_out, &s->d_out_size, omap.size)) {
+    if (!ensure_staging (&s->d_out[k], &s->d_out_size[k], omap.size)) {
       gst_buffer_unmap (outbuf, &omap);
       goto map_fail;
     }
-    dst = s->d_out;
+    dst = s->d_out[k];
   }
 
-  GST_CAT_DEBUG_OBJECT (CAT_PERFORMANCE, s, "HIP convert %s", gstamd_video_converter_describe (s->convert));
-  r = gstamd_video_converter_frame (s->convert, src, dst, NULL);
-  if (r == GSTAMD_OK && !out_dev)
-    r = gstamd_device_download (omap.data, s->d_out, omap.size, NULL);    /* synchronises */
-  else if (r == GSTAMD_OK && !in_dev)
-    r = gstamd_stream_synchronize (NULL);   /* the staged input is reused by the next buffer */
+  GST_CAT_DEBUG_OBJECT (CAT_PERFORMANCE, s, "HIP convert %s on stream %u", gstamd_video_converter_describe (s->convert), k);
+  frame_planes (inbuf, &s->in_info, src, sp, ss);
+  frame_planes (outbuf, &s->out_info, dst, dp, ds);
+  if (s->stats)
+    tb = g_get_monotonic_time ();
+  r = gstamd_video_converter_frame_planes (s->convert, (const void *const *) sp, ss, dp, ds, stream);
+  if (s->stats)
+    tc = g_get_monotonic_time ();
+  if (r == GSTAMD_OK && (out_dev || in_dev)) {
+    GstAmdHipTicket *t = gst_amd_hip_ticket_new (stream);       /* one event for the launch, shared by both buffers */
+    if (out_dev)
+      gst_amd_hip_memory_set_written (omem, t);
+    if (in_dev)
+      gst_amd_hip_memory_set_read (imem, t);
+    gst_amd_hip_ticket_unref (t);
+  }
+  if (s->stats)
+    td = g_get_monotonic_time ();
+  if (r == GSTAMD_OK && !out_dev) {
+    r = gstamd_device_download_async (omap.data, s->d_out[k], omap.size, stream);
+    if (r == GSTAMD_OK)
+      r = gstamd_stream_synchronize (stream);         /* the CPU is about to look at outbuf */
+  }
 
   if (out_dev)
     gst_memory_unmap (omem, &omap);
@@ -448,6 +591,13 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
     GST_ELEMENT_ERROR (s, LIBRARY, FAILED, ("HIP conversion failed"), ("%s", gstamd_last_error ()));
     return GST_FLOW_ERROR;
   }
+  if (s->stats) {
+    s->t_wait += tb - ta;
+    s->t_convert += tc - tb;
+    s->t_mark += td - tc;
+    s->t_total += g_get_monotonic_time () - ta;
+    s->n_frames++;
+  }
   return GST_FLOW_OK;
 
 map_fail:
@@ -456,6 +606,130 @@ map_fail:
   else
     gst_buffer_unmap (inbuf, &imap);
   return GST_FLOW_ERROR;
+}
+
+/* A GstBufferList arriving on the sink pad (gst_pad_push_list; the core would otherwise feed it to chain() buffer by buffer,
+ * gstpad.c gst_pad_chain_list_default): the list becomes ONE gstamd_video_converter_frames call (one kernel launch where the plan
+ * allows it), one ticket, and one GstBufferList pushed downstream (while a (re)negotiation is pending the first buffer takes the
+ * regular GstBaseTransform path and settles it).  The per-launch host cost (~7 us of HIP runtime per kernel on
+ * this stack) is then paid once per list instead of once per frame. */
+static gboolean
+buffer_is_plain_hip_frame (GstBuffer * buf, const GstVideoInfo * info)
+{
+  GstVideoMeta *vm;
+  guint i;
+
+  if (gst_buffer_n_memory (buf) != 1 || !gst_is_amd_hip_memory (gst_buffer_peek_memory (buf, 0)))
+    return FALSE;
+  vm = gst_buffer_get_video_meta (buf);
+  if (!vm)
+    return TRUE;
+  if (vm->n_planes != GST_VIDEO_INFO_N_PLANES (info))
+    return FALSE;
+  for (i = 0; i < vm->n_planes; i++)
+    if (vm->offset[i] != GST_VIDEO_INFO_PLANE_OFFSET (info, i) || vm->stride[i] != GST_VIDEO_INFO_PLANE_STRIDE (info, i))
+      return FALSE;
+  return TRUE;
+}
+
+#define AMD_LIST_CHUNK 32
+
+static GstFlowReturn
+amd_vcs_chain_list (GstPad * pad, GstObject * parent, GstBufferList * list)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (parent);
+  GstBaseTransform *trans = GST_BASE_TRANSFORM (parent);
+  const guint n = gst_buffer_list_length (list);
+  GstFlowReturn ret = GST_FLOW_OK;
+  guint i = 0;
+
+  if (n == 0) {
+    gst_buffer_list_unref (list);
+    return GST_FLOW_OK;
+  }
+  /* a negotiated, stable element (caps events are handled before the buffers that follow them; a pending downstream
+   * reconfigure shows on the src pad) converts the whole list at once; otherwise the first buffer takes the regular path and
+   * settles the negotiation */
+  if (!(s->convert && s->n_streams && !gst_pad_needs_reconfigure (GST_BASE_TRANSFORM_SRC_PAD (trans)))) {
+    ret = s->base_chain (pad, parent, gst_buffer_ref (gst_buffer_list_get (list, 0)));
+    i = 1;
+  }
+  while (ret == GST_FLOW_OK && i < n) {
+    gboolean batch = s->convert && s->n_streams && s->in_hip && s->out_hip && s->out_pool && !gst_base_transform_is_passthrough (trans) &&
+        !gst_pad_needs_reconfigure (GST_BASE_TRANSFORM_SRC_PAD (trans));
+    guint cnt = MIN (n - i, AMD_LIST_CHUNK), k;
+    for (k = 0; batch && k < cnt; k++)
+      batch = buffer_is_plain_hip_frame (gst_buffer_list_get (list, i + k), &s->in_info);
+    if (!batch) {
+      ret = s->base_chain (pad, parent, gst_buffer_ref (gst_buffer_list_get (list, i)));
+      i++;
+      continue;
+    }
+    {
+      GstBuffer *outs[AMD_LIST_CHUNK];
+      GstMapInfo imaps[AMD_LIST_CHUNK], omaps[AMD_LIST_CHUNK];
+      const void *srcs[AMD_LIST_CHUNK];
+      void *dsts[AMD_LIST_CHUNK];
+      gpointer stream;
+      guint got = 0, mapped = 0;
+      int r = GSTAMD_OK;
+
+      gst_amd_hip_select_device (s->device_id);
+      stream = s->streams[s->next_stream++ % s->n_streams];
+      for (k = 0; k < cnt; k++) {
+        if (gst_buffer_pool_acquire_buffer (s->out_pool, &outs[k], NULL) != GST_FLOW_OK)
+          break;
+        got++;
+        gst_buffer_copy_into (outs[k], gst_buffer_list_get (list, i + k), GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS, 0, -1);
+      }
+      for (k = 0; k < got; k++) {
+        GstMemory *im = gst_buffer_peek_memory (gst_buffer_list_get (list, i + k), 0), *om = gst_buffer_peek_memory (outs[k], 0);
+        if (!gst_memory_map (im, &imaps[k], GST_MAP_READ | GST_MAP_AMDHIP))
+          break;
+        if (!gst_memory_map (om, &omaps[k], GST_MAP_WRITE | GST_MAP_AMDHIP)) {
+          gst_memory_unmap (im, &imaps[k]);
+          break;
+        }
+        gst_amd_hip_memory_wait_written (im, stream);
+        gst_amd_hip_memory_wait_idle (om, stream);
+        srcs[k] = imaps[k].data;
+        dsts[k] = omaps[k].data;
+        mapped++;
+      }
+      if (mapped == cnt)
+        r = gstamd_video_converter_frames (s->convert, (int) cnt, srcs, dsts, stream);
+      else
+        r = GSTAMD_ERR_INVALID;
+      if (r == GSTAMD_OK) {
+        GstAmdHipTicket *t = gst_amd_hip_ticket_new (stream);
+        for (k = 0; k < cnt; k++) {
+          gst_amd_hip_memory_set_read (gst_buffer_peek_memory (gst_buffer_list_get (list, i + k), 0), t);
+          gst_amd_hip_memory_set_written (gst_buffer_peek_memory (outs[k], 0), t);
+        }
+        gst_amd_hip_ticket_unref (t);
+      }
+      for (k = 0; k < mapped; k++) {
+        gst_memory_unmap (gst_buffer_peek_memory (gst_buffer_list_get (list, i + k), 0), &imaps[k]);
+        gst_memory_unmap (gst_buffer_peek_memory (outs[k], 0), &omaps[k]);
+      }
+      if (r != GSTAMD_OK) {
+        for (k = 0; k < got; k++)
+          gst_buffer_unref (outs[k]);
+        GST_ELEMENT_ERROR (s, LIBRARY, FAILED, ("HIP conversion of a buffer list failed"), ("%s", gstamd_last_error ()));
+        ret = GST_FLOW_ERROR;
+        break;
+      }
+      {
+        GstBufferList *out_list = gst_buffer_list_new_sized (cnt);
+        for (k = 0; k < cnt; k++)
+          gst_buffer_list_add (out_list, outs[k]);
+        ret = gst_pad_push_list (GST_BASE_TRANSFORM_SRC_PAD (trans), out_list);
+      }
+      i += cnt;
+    }
+  }
+  gst_buffer_list_unref (list);
+  return ret;
 }
 
 static gboolean
@@ -470,10 +744,27 @@ amd_vcs_stop (GstBaseTransform * trans)
     gst_object_unref (s->out_pool);
     s->out_pool = NULL;
   }
-  gstamd_device_free (s->d_in);
-  gstamd_device_free (s->d_out);
-  s->d_in = s->d_out = NULL;
-  s->d_in_size = s->d_out_size = 0;
+  gst_amd_hip_select_device (s->device_id);
+  if (s->stats && s->n_frames)
+    g_printerr ("videoconvertscale host time per buffer over %" G_GUINT64_FORMAT " buffers: prepare_output %.2f us, transform %.2f us "
+        "(map + stream waits %.2f, converter call %.2f, event records %.2f)\n", s->n_frames, (double) s->t_prepare / s->n_frames,
+        (double) s->t_total / s->n_frames, (double) s->t_wait / s->n_frames, (double) s->t_convert / s->n_frames,
+        (double) s->t_mark / s->n_frames);
+  {
+    guint i;
+    for (i = 0; i < AMD_MAX_STREAMS; i++) {
+      if (s->streams[i]) {
+        gstamd_stream_synchronize (s->streams[i]);
+        gstamd_stream_free (s->streams[i]);
+      }
+      s->streams[i] = NULL;
+      gstamd_device_free (s->d_in[i]);
+      gstamd_device_free (s->d_out[i]);
+      s->d_in[i] = s->d_out[i] = NULL;
+      s->d_in_size[i] = s->d_out_size[i] = 0;
+    }
+    s->n_streams = 0;
+  }
   return TRUE;
 }
 
@@ -524,6 +815,15 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
   g_object_class_install_property (oc, PROP_DITHER_QUANTIZATION, g_param_spec_uint ("dither-quantization",
           "Dither Quantize", "Quantizer to use", 0, G_MAXUINT, 1, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
 
+  /* beyond the reference's properties: which GPU (one stream per GPU, device-id per element instance) and how many HIP
+   * streams the instance rotates its frames over */
+  g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
+          "HIP device this instance runs on (-1 = the process's current device)", -1, G_MAXINT, -1,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_HIP_STREAMS, g_param_spec_uint ("hip-streams", "HIP streams",
+          "HIP streams the instance rotates its frames over (the launch ramp of one frame overlaps the tail of the previous one)",
+          1, AMD_MAX_STREAMS, 3, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+
   gst_element_class_set_static_metadata (ec, "Video colorspace converter and scaler (MI355X/HIP)",
       "Filter/Converter/Video/Scaler/Colorspace",
       "Converts and resizes raw video on an AMD Instinct GPU with kernels bit-exact to GstVideoConverter", "gstreamer_amd");
@@ -536,6 +836,7 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
   tc->set_caps = GST_DEBUG_FUNCPTR (amd_vcs_set_caps);
   tc->get_unit_size = GST_DEBUG_FUNCPTR (amd_vcs_get_unit_size);
   tc->prepare_output_buffer = GST_DEBUG_FUNCPTR (amd_vcs_prepare_output_buffer);
+  tc->propose_allocation = GST_DEBUG_FUNCPTR (amd_vcs_propose_allocation);
   tc->transform = GST_DEBUG_FUNCPTR (amd_vcs_transform);
   tc->stop = GST_DEBUG_FUNCPTR (amd_vcs_stop);
   klass->converts = TRUE;
@@ -556,6 +857,11 @@ gst_amd_vcs_init (GstAmdVideoConvertScale * s)
   s->sharpness = 1.0;
   s->sharpen = 0.0;
   s->dither_quantization = 1;
+  s->device_id = -1;
+  s->hip_streams = 3;
+  s->stats = g_getenv ("GSTAMD_ELEMENT_STATS") != NULL;
+  s->base_chain = GST_PAD_CHAINFUNC (GST_BASE_TRANSFORM_SINK_PAD (s));
+  gst_pad_set_chain_list_function (GST_BASE_TRANSFORM_SINK_PAD (s), GST_DEBUG_FUNCPTR (amd_vcs_chain_list));
   gst_amd_hip_allocator_get ();
 }
 

@@ -870,3 +870,43 @@ gst_amd_video_convert_scale_get_type (void)
 {
   return gst_amd_vcs_get_type ();
 }
+
+/* `videoconvert` and `videoscale`: subclasses that only convert / only scale, exactly as the reference derives them from
+ * GstVideoConvertScale (gstvideoconvert.c:50-58 sets scales = FALSE, gstvideoscale.c:110-118 sets converts = FALSE) */
+typedef GstAmdVideoConvertScale GstAmdVideoConvert;
+typedef GstAmdVideoConvertScaleClass GstAmdVideoConvertClass;
+typedef GstAmdVideoConvertScale GstAmdVideoScale;
+typedef GstAmdVideoConvertScaleClass GstAmdVideoScaleClass;
+G_DEFINE_TYPE (GstAmdVideoConvert, gst_amd_video_convert, gst_amd_vcs_get_type ());
+G_DEFINE_TYPE (GstAmdVideoScale, gst_amd_video_scale, gst_amd_vcs_get_type ());
+
+static void
+gst_amd_video_convert_class_init (GstAmdVideoConvertClass * klass)
+{
+  klass->converts = TRUE;
+  klass->scales = FALSE;
+  gst_element_class_set_static_metadata (GST_ELEMENT_CLASS (klass), "Video colorspace converter (MI355X/HIP)", "Filter/Converter/Video/Colorspace",
+      "Converts video from one colorspace to another on an AMD Instinct GPU, bit-exact to GstVideoConverter", "gstreamer_amd");
+}
+
+static void
+gst_amd_video_convert_init (GstAmdVideoConvert * s)
+{
+}
+
+static void
+gst_amd_video_scale_class_init (GstAmdVideoScaleClass * klass)
+{
+  klass->converts = FALSE;
+  klass->scales = TRUE;
+  gst_element_class_set_static_metadata (GST_ELEMENT_CLASS (klass), "Video scaler (MI355X/HIP)", "Filter/Converter/Video/Scaler",
+      "Resizes video on an AMD Instinct GPU, bit-exact to GstVideoConverter", "gstreamer_amd");
+}
+
+static void
+gst_amd_video_scale_init (GstAmdVideoScale * s)
+{
+}
+
+GType gst_amd_video_convert_element_get_type (void) { return gst_amd_video_convert_get_type (); }
+GType gst_amd_video_scale_element_get_type (void) { return gst_amd_video_scale_get_type (); }

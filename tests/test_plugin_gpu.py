@@ -357,3 +357,54 @@ def test_element_throughput_hbm_resident(gst_env, streams):
         for res in out:
             f.write(__import__("json").dumps(res) + "\n")
     assert out[0]["frames_per_s"] > 30000 and out[1]["frames_per_s"] > 45000, out
+
+
+def test_upload_download_elements_bracket_an_hbm_pipeline(gst_env, ref):
+    """amdhipupload ! videoconvertscale (HBM in, HBM out) ! videoconvertscale ! amdhipdownload: the frames enter and leave HBM at
+    the edges only; bytes equal the reference's two conversions."""
+    env, tmp = gst_env
+    w, h, n = 640, 360, 3
+    fin, fout = tmp / "ud_in.nv12", tmp / "ud_out.rgba"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=%d,height=%d,colorimetry=bt709,chroma-site=mpeg2 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! amdhipupload ! video/x-raw(memory:AMDHIPMemory),format=NV12 "
+                "! videoconvertscale ! video/x-raw(memory:AMDHIPMemory),format=BGRA ! videoconvertscale ! video/x-raw(memory:AMDHIPMemory),format=RGBA "
+                "! amdhipdownload ! video/x-raw,format=RGBA ! filesink location=%s" % (n, w, h, fin, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    a = ref.VideoConverter("NV12", w, h, "BGRA", w, h, in_colorimetry="bt709", in_chroma_site="mpeg2")
+    b = ref.VideoConverter("BGRA", w, h, "RGBA", w, h)
+    for i in range(n):
+        assert (b.frame(a.frame(src[i])) == out[i]).all(), i
+
+
+def test_reference_factory_names_are_ours_in_a_registry_without_the_stock_elements(gst_env, ref):
+    """north_star: "register under the same factory names".  A registry keeps one feature per name, so the drop-in deployment is a
+    plugin directory that ships this plugin INSTEAD of gst-plugins-base's videoconvert / videoscale / audioresample plugins: there
+    `videoconvert`, `videoscale` and `audioresample` resolve to the MI355X elements and run unchanged pipelines."""
+    env, tmp = gst_env
+    pdir = tmp / "dropin_plugins"
+    pdir.mkdir()
+    stock = "/opt/conda/lib/gstreamer-1.0"
+    for f in os.listdir(stock):
+        if f.endswith(".so") and f not in ("libgstvideoconvert.so", "libgstvideoscale.so", "libgstaudioresample.so"):
+            os.symlink(os.path.join(stock, f), pdir / f)
+    os.symlink(os.path.join(ROOT, "plugins", "libgstamdhipdsp.so"), pdir / "libgstamdhipdsp.so")
+    env2 = dict(env, GST_PLUGIN_PATH=str(pdir), GST_REGISTRY=str(tmp / "registry_names.bin"))
+    insp = os.path.join(os.path.dirname(GST), "gst-inspect-1.0")
+    for name in ("videoconvert", "videoscale", "audioresample", "videoconvertscale", "compositor"):
+        r = subprocess.run([insp, name], env=env2, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+        assert r.returncode == 0 and "MI355X" in r.stdout, (name, r.stdout[:600])
+    w, h, n = 320, 240, 2
+    fin, fout, fsc = tmp / "nm_in.nv12", tmp / "nm_out.bgra", tmp / "nm_sc.nv12"
+    launch(env2, "videotestsrc num-buffers=%d ! video/x-raw,format=NV12,width=%d,height=%d,colorimetry=bt601,chroma-site=jpeg ! tee name=t "
+                 "t. ! queue ! filesink location=%s t. ! queue ! videoconvert ! video/x-raw,format=BGRA ! filesink location=%s "
+                 "t. ! queue ! videoscale ! video/x-raw,width=160,height=120 ! filesink location=%s" % (n, w, h, fin, fout, fsc))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    sc = np.fromfile(fsc, np.uint8).reshape(n, -1)
+    a = ref.VideoConverter("NV12", w, h, "BGRA", w, h, in_colorimetry="bt601", in_chroma_site="jpeg")
+    b = ref.VideoConverter("NV12", w, h, "NV12", 160, 120, in_colorimetry="bt601", in_chroma_site="jpeg", out_colorimetry="bt601",
+                           out_chroma_site="jpeg", config=cases.ref_config_string(ref, cases.LIN))
+    for i in range(n):
+        assert (a.frame(src[i]) == out[i]).all(), i
+        assert (b.frame(src[i]) == sc[i]).all(), i

@@ -15,9 +15,8 @@
  * pipeline like BASELINE config 1 negotiates unchanged.  Conversions the GPU path refuses
  * (GSTAMD_ERR_UNSUPPORTED) make set_caps fail -> not-negotiated, like the reference's "no_convert" :1111-1120.
  *
- * Simplifications kept honest: fixate_caps keeps the input size / PAR instead of the reference's 450-line
- * DAR solver (:1248-1975); the converter-config property, interlaced content and overlay composition metas are not
- * implemented.  add-borders works as in the reference once the caps fix a size whose DAR differs.
+ * fixate_caps follows the reference's format scoring and display-aspect-ratio rules (:1098-1975, restated below).  Not
+ * implemented: the converter-config property, interlaced content (such caps are refused) and overlay composition metas.
  */
 #include <gst/base/gstbasetransform.h>
 #include <gst/gst.h>
@@ -216,28 +215,394 @@ amd_vcs_transform_caps (GstBaseTransform * trans, GstPadDirection direction, Gst
   return ret;
 }
 
+/* ---- fixate_caps: the reference's decisions (gstvideoconvertscale.c:1098-1975), restated -------------------------------------
+ * format:  the output format that loses least against the input (score table of :1098-1246: a change costs 1, a LOSS of
+ *          colourspace 2, depth 4, alpha 8, chroma width 16, chroma height 32, palette 64, colour 128), then colorimetry and
+ *          chroma-site carried over from the input where they still mean the same (:1330-1425);
+ * size:    keep the display aspect ratio DAR = w/h * PAR through whatever is still free on the other side - both sizes fixed: only
+ *          the PAR can follow; one size fixed: the other one follows, through the PAR if that is free; nothing fixed: keep the
+ *          input size and let the PAR absorb the change, else scale one dimension (:1488-1930). */
+static gint
+format_loss (const GstVideoFormatInfo * in, const GstVideoFormatInfo * t)
+{
+  const guint ignore = GST_VIDEO_FORMAT_FLAG_LE | GST_VIDEO_FORMAT_FLAG_COMPLEX | GST_VIDEO_FORMAT_FLAG_UNPACK;
+  const guint cs = GST_VIDEO_FORMAT_FLAG_YUV | GST_VIDEO_FORMAT_FLAG_RGB | GST_VIDEO_FORMAT_FLAG_GRAY;
+  const guint fi = GST_VIDEO_FORMAT_INFO_FLAGS (in) & ~ignore, ft = GST_VIDEO_FORMAT_INFO_FLAGS (t) & ~ignore;
+  gint loss = 1;                /* any change of format */
+
+  if (in == t)
+    return 0;
+  if ((ft ^ fi) & GST_VIDEO_FORMAT_FLAG_PALETTE)
+    loss += 1 + ((ft & GST_VIDEO_FORMAT_FLAG_PALETTE) ? 64 : 0);
+  if ((ft & cs) != (fi & cs))
+    loss += 2 + ((ft & GST_VIDEO_FORMAT_FLAG_GRAY) ? 128 : 0);
+  if ((ft ^ fi) & GST_VIDEO_FORMAT_FLAG_ALPHA)
+    loss += 1 + ((fi & GST_VIDEO_FORMAT_FLAG_ALPHA) ? 8 : 0);
+  if (in->h_sub[1] != t->h_sub[1])
+    loss += 1 + (in->h_sub[1] < t->h_sub[1] ? 32 : 0);
+  if (in->w_sub[1] != t->w_sub[1])
+    loss += 1 + (in->w_sub[1] < t->w_sub[1] ? 16 : 0);
+  if (in->bits != t->bits)
+    loss += 1 + (in->bits > t->bits ? 4 : 0);
+  return loss;
+}
+
+static void
+consider_format (const GstVideoFormatInfo * in, const GValue * v, gint * best_loss, const GstVideoFormatInfo ** best)
+{
+  const GstVideoFormatInfo *t;
+  gint loss;
+
+  if (!G_VALUE_HOLDS_STRING (v) || *best_loss == 0)
+    return;
+  t = gst_video_format_get_info (gst_video_format_from_string (g_value_get_string (v)));
+  if (!t || GST_VIDEO_FORMAT_INFO_FORMAT (t) == GST_VIDEO_FORMAT_UNKNOWN)
+    return;
+  loss = format_loss (in, t);
+  if (loss < *best_loss) {
+    *best_loss = loss;
+    *best = t;
+  }
+}
+
+/* every structure of `result` loses its size fields; the first one gets the least lossy format found anywhere in `result` */
+static void
+pick_format (GstCaps * caps, GstCaps * result)
+{
+  const gchar *name = gst_structure_get_string (gst_caps_get_structure (caps, 0), "format");
+  const GstVideoFormatInfo *in = name ? gst_video_format_get_info (gst_video_format_from_string (name)) : NULL, *best = NULL;
+  gint best_loss = G_MAXINT;
+  guint i, j;
+
+  if (!in)
+    return;
+  for (i = 0; i < gst_caps_get_size (result); i++) {
+    GstStructure *st = gst_caps_get_structure (result, i);
+    const GValue *f = gst_structure_get_value (st, "format");
+    gst_structure_remove_fields (st, "height", "width", "pixel-aspect-ratio", "display-aspect-ratio", NULL);
+    if (!f)
+      continue;
+    if (GST_VALUE_HOLDS_LIST (f))
+      for (j = 0; j < gst_value_list_get_size (f); j++)
+        consider_format (in, gst_value_list_get_value (f, j), &best_loss, &best);
+    else
+      consider_format (in, f, &best_loss, &best);
+  }
+  if (best)
+    gst_structure_set (gst_caps_get_structure (result, 0), "format", G_TYPE_STRING, GST_VIDEO_FORMAT_INFO_NAME (best), NULL);
+}
+
+/* output caps without colorimetry / chroma-site take the input's where that is meaningful: the colorimetry whole inside one colour
+ * model, primaries + transfer only across RGB <-> YUV; the chroma siting only between YUV formats of equal subsampling */
+static void
+inherit_colorimetry (GstCaps * in_caps, GstCaps * out_caps)
+{
+  GstStructure *os = gst_caps_get_structure (out_caps, 0), *is = gst_caps_get_structure (in_caps, 0), *ts;
+  const gboolean have_col = gst_structure_has_field (os, "colorimetry"), have_site = gst_structure_has_field (os, "chroma-site");
+  const GValue *in_col = gst_structure_get_value (is, "colorimetry"), *in_site = gst_structure_get_value (is, "chroma-site");
+  GstVideoInfo ii, oi;
+  GstCaps *probe;
+  guint c;
+
+  if ((have_col && have_site) || !gst_video_info_from_caps (&ii, in_caps))
+    return;
+  /* the output size may still be open here: probe the colour model on a fixated copy that borrows the input size */
+  probe = gst_caps_fixate (gst_caps_copy (out_caps));
+  ts = gst_caps_get_structure (probe, 0);
+  if (!gst_structure_has_field (ts, "width"))
+    gst_structure_set_value (ts, "width", gst_structure_get_value (is, "width"));
+  if (!gst_structure_has_field (ts, "height"))
+    gst_structure_set_value (ts, "height", gst_structure_get_value (is, "height"));
+  if (!gst_video_info_from_caps (&oi, probe)) {
+    gst_caps_unref (probe);
+    return;
+  }
+  gst_caps_unref (probe);
+  if (!have_col && in_col) {
+    if ((GST_VIDEO_INFO_IS_YUV (&oi) && GST_VIDEO_INFO_IS_YUV (&ii)) || (GST_VIDEO_INFO_IS_RGB (&oi) && GST_VIDEO_INFO_IS_RGB (&ii)) ||
+        (GST_VIDEO_INFO_IS_GRAY (&oi) && GST_VIDEO_INFO_IS_GRAY (&ii))) {
+      gst_structure_set_value (os, "colorimetry", in_col);
+    } else {
+      gchar *str;
+      oi.colorimetry.primaries = ii.colorimetry.primaries;
+      oi.colorimetry.transfer = ii.colorimetry.transfer;
+      str = gst_video_colorimetry_to_string (&oi.colorimetry);
+      if (str)
+        gst_caps_set_simple (out_caps, "colorimetry", G_TYPE_STRING, str, NULL);
+      g_free (str);
+    }
+  }
+  if (!have_site && in_site && GST_VIDEO_INFO_IS_YUV (&oi) && GST_VIDEO_INFO_IS_YUV (&ii) &&
+      GST_VIDEO_INFO_N_COMPONENTS (&ii) == GST_VIDEO_INFO_N_COMPONENTS (&oi)) {
+    gboolean same = TRUE;
+    for (c = 0; c < GST_VIDEO_INFO_N_COMPONENTS (&ii); c++)
+      same = same && GST_VIDEO_FORMAT_INFO_W_SUB (ii.finfo, c) == GST_VIDEO_FORMAT_INFO_W_SUB (oi.finfo, c) &&
+          GST_VIDEO_FORMAT_INFO_H_SUB (ii.finfo, c) == GST_VIDEO_FORMAT_INFO_H_SUB (oi.finfo, c);
+    if (same)
+      gst_structure_set_value (os, "chroma-site", in_site);
+  }
+}
+
+static GstCaps *
+fixed_format_caps (GstPadDirection direction, GstCaps * caps, GstCaps * othercaps)
+{
+  GstCaps *r = gst_caps_intersect (othercaps, caps);
+
+  if (gst_caps_is_empty (r)) {
+    gst_caps_unref (r);
+    r = gst_caps_copy (othercaps);
+  }
+  r = gst_caps_make_writable (r);
+  pick_format (caps, r);
+  r = gst_caps_fixate (r);
+  if (direction == GST_PAD_SINK) {
+    if (gst_caps_is_subset (caps, r))
+      gst_caps_replace (&r, caps);
+    else
+      inherit_colorimetry (caps, r);
+  }
+  return r;
+}
+
+/* a * b as a reduced fraction; doubles when the integers overflow */
+static void
+frac_mul (gint an, gint ad, gint bn, gint bd, gint * rn, gint * rd)
+{
+  if (!gst_util_fraction_multiply (an, ad, bn, bd, rn, rd)) {
+    gdouble x, y;
+    gst_util_fraction_to_double (an, ad, &x);
+    gst_util_fraction_to_double (bn, bd, &y);
+    gst_util_double_to_fraction (x * y, rn, rd);
+  }
+}
+
+/* what field `name` of `st` would become when fixated towards `target` (on a copy) */
+static gint
+nearest_int (const GstStructure * st, const gchar * name, gint target)
+{
+  GstStructure *t = gst_structure_copy (st);
+  gint v = target;
+  gst_structure_fixate_field_nearest_int (t, name, target);
+  gst_structure_get_int (t, name, &v);
+  gst_structure_free (t);
+  return v;
+}
+
+/* the PAR the other side would accept closest to n / d (its PAR field, or `to_par` when the field is absent) */
+static void
+nearest_par (const GstStructure * st, const GValue * to_par, gint n, gint d, gint * set_n, gint * set_d)
+{
+  GstStructure *t = gst_structure_copy (st);
+  if (!gst_structure_has_field (t, "pixel-aspect-ratio"))
+    gst_structure_set_value (t, "pixel-aspect-ratio", to_par);
+  gst_structure_fixate_field_nearest_fraction (t, "pixel-aspect-ratio", n, d);
+  *set_n = n;
+  *set_d = d;
+  gst_structure_get_fraction (t, "pixel-aspect-ratio", set_n, set_d);
+  gst_structure_free (t);
+}
+
+static void
+put_par (GstStructure * outs, gint n, gint d)
+{
+  if (gst_structure_has_field (outs, "pixel-aspect-ratio") || n != d)
+    gst_structure_set (outs, "pixel-aspect-ratio", GST_TYPE_FRACTION, n, d, NULL);
+}
+
+static GstCaps *
+fixate_size (GstBaseTransform * base, GstPadDirection direction, GstCaps * caps, GstCaps * othercaps)
+{
+  GstStructure *ins, *outs;
+  const GValue *from_par, *to_par;
+  GValue fpar = G_VALUE_INIT, tpar = G_VALUE_INIT;
+  gint from_w = 0, from_h = 0, w = 0, h = 0, from_pn = 1, from_pd = 1, dar_n, dar_d;
+
+  othercaps = gst_caps_make_writable (gst_caps_truncate (othercaps));
+  ins = gst_caps_get_structure (caps, 0);
+  outs = gst_caps_get_structure (othercaps, 0);
+  from_par = gst_structure_get_value (ins, "pixel-aspect-ratio");
+  to_par = gst_structure_get_value (outs, "pixel-aspect-ratio");
+  /* a missing PAR means 1/1 on the side we come from; on the other side it means "anything" when fixating from the sink pad and
+   * 1/1 (which is then written into the caps) when fixating from the src pad */
+  if (!from_par) {
+    g_value_init (&fpar, GST_TYPE_FRACTION);
+    gst_value_set_fraction (&fpar, 1, 1);
+    from_par = &fpar;
+  }
+  if (!to_par) {
+    if (direction == GST_PAD_SINK) {
+      g_value_init (&tpar, GST_TYPE_FRACTION_RANGE);
+      gst_value_set_fraction_range_full (&tpar, 1, G_MAXINT, G_MAXINT, 1);
+    } else {
+      g_value_init (&tpar, GST_TYPE_FRACTION);
+      gst_value_set_fraction (&tpar, 1, 1);
+      gst_structure_set (outs, "pixel-aspect-ratio", GST_TYPE_FRACTION, 1, 1, NULL);
+    }
+    to_par = &tpar;
+  }
+  if (!gst_value_is_fixed (from_par))
+    goto done;
+  from_pn = gst_value_get_fraction_numerator (from_par);
+  from_pd = gst_value_get_fraction_denominator (from_par);
+  gst_structure_get_int (ins, "width", &from_w);
+  gst_structure_get_int (ins, "height", &from_h);
+  gst_structure_get_int (outs, "width", &w);
+  gst_structure_get_int (outs, "height", &h);
+
+  if (w && h) {
+    /* both sizes given: only the PAR can still follow the display ratio */
+    guint n, d;
+    if (!gst_value_is_fixed (to_par) && gst_video_calculate_display_ratio (&n, &d, from_w, from_h, from_pn, from_pd, w, h)) {
+      if (gst_structure_has_field (outs, "pixel-aspect-ratio"))
+        gst_structure_fixate_field_nearest_fraction (outs, "pixel-aspect-ratio", n, d);
+      else if (n != d)
+        gst_structure_set (outs, "pixel-aspect-ratio", GST_TYPE_FRACTION, n, d, NULL);
+    }
+    goto done;
+  }
+  frac_mul (from_w, from_h, from_pn, from_pd, &dar_n, &dar_d);
+
+  if (h || w) {
+    /* one dimension given (`fixed`), the other (`free_name`) follows the DAR; written for "height given", mirrored for "width given" */
+    const gboolean h_fixed = h != 0;
+    const gchar *free_name = h_fixed ? "width" : "height";
+    const gint fixed = h_fixed ? h : w, from_free = h_fixed ? from_w : from_h;
+    gint num, den, set_free, want_pn, want_pd, set_pn, set_pd;
+    guint64 t;
+
+    if (gst_value_is_fixed (to_par)) {
+      frac_mul (dar_n, dar_d, gst_value_get_fraction_denominator (to_par), gst_value_get_fraction_numerator (to_par), &num, &den);
+      t = h_fixed ? gst_util_uint64_scale_int_round (fixed, num, den) : gst_util_uint64_scale_int_round (fixed, den, num);
+      if (t > G_MAXINT) {
+        GST_ELEMENT_ERROR (base, CORE, NEGOTIATION, (NULL), ("Error calculating the output scaled size - integer overflow"));
+        goto done;
+      }
+      gst_structure_fixate_field_nearest_int (outs, free_name, (gint) t);
+      goto done;
+    }
+    /* free PAR: keep the input's size in the open dimension and let the PAR carry the DAR ... */
+    set_free = nearest_int (outs, free_name, from_free);
+    if (h_fixed)
+      frac_mul (dar_n, dar_d, fixed, set_free, &want_pn, &want_pd);
+    else
+      frac_mul (dar_n, dar_d, set_free, fixed, &want_pn, &want_pd);
+    nearest_par (outs, to_par, want_pn, want_pd, &set_pn, &set_pd);
+    if (set_pn == want_pn && set_pd == want_pd) {
+      if (gst_structure_has_field (outs, "pixel-aspect-ratio") || set_pn != set_pd)
+        gst_structure_set (outs, free_name, G_TYPE_INT, set_free, "pixel-aspect-ratio", GST_TYPE_FRACTION, set_pn, set_pd, NULL);
+      goto done;
+    }
+    /* ... or, with the PAR the other side does accept, scale the open dimension */
+    frac_mul (dar_n, dar_d, set_pd, set_pn, &num, &den);
+    t = h_fixed ? gst_util_uint64_scale_int_round (fixed, num, den) : gst_util_uint64_scale_int_round (fixed, den, num);
+    if (t > G_MAXINT) {
+      GST_ELEMENT_ERROR (base, CORE, NEGOTIATION, (NULL), ("Error calculating the output scaled size - integer overflow"));
+      goto done;
+    }
+    gst_structure_fixate_field_nearest_int (outs, free_name, (gint) t);
+    put_par (outs, set_pn, set_pd);
+    goto done;
+  }
+
+  if (gst_value_is_fixed (to_par)) {
+    /* sizes open, PAR given: keep the height (interlacing) and scale the width; failing that keep the width; failing that the
+     * pair whose DAR is closest */
+    gint num, den, set_h, set_w, alt_w, alt_h;
+    guint64 tw, th;
+
+    frac_mul (dar_n, dar_d, gst_value_get_fraction_denominator (to_par), gst_value_get_fraction_numerator (to_par), &num, &den);
+    set_h = nearest_int (outs, "height", from_h);
+    tw = gst_util_uint64_scale_int_round (set_h, num, den);
+    if (tw > G_MAXINT) {
+      GST_ELEMENT_ERROR (base, CORE, NEGOTIATION, (NULL), ("Error calculating the output scaled size - integer overflow"));
+      goto done;
+    }
+    set_w = nearest_int (outs, "width", (gint) tw);
+    if (set_w == (gint) tw) {
+      gst_structure_set (outs, "width", G_TYPE_INT, set_w, "height", G_TYPE_INT, set_h, NULL);
+      goto done;
+    }
+    alt_w = nearest_int (outs, "width", from_w);
+    th = gst_util_uint64_scale_int_round (alt_w, den, num);
+    if (th > G_MAXINT) {
+      GST_ELEMENT_ERROR (base, CORE, NEGOTIATION, (NULL), ("Error calculating the output scaled size - integer overflow"));
+      goto done;
+    }
+    alt_h = nearest_int (outs, "height", (gint) th);
+    if (alt_h == (gint) th) {
+      gst_structure_set (outs, "width", G_TYPE_INT, alt_w, "height", G_TYPE_INT, alt_h, NULL);
+      goto done;
+    }
+    if ((gint64) alt_w * ABS (alt_h - (gint) th) < (gint64) ABS (set_w - (gint) tw) * set_h) {
+      set_w = alt_w;
+      set_h = alt_h;
+    }
+    gst_structure_set (outs, "width", G_TYPE_INT, set_w, "height", G_TYPE_INT, set_h, NULL);
+    goto done;
+  }
+
+  {
+    /* everything open (and passthrough impossible): input size + a PAR that keeps the DAR; else one scaled dimension under the PAR
+     * that is accepted; else the first try as it is */
+    gint set_h = nearest_int (outs, "height", from_h), set_w = nearest_int (outs, "width", from_w);
+    gint want_pn, want_pd, set_pn, set_pd, num, den, got;
+    guint64 t;
+
+    frac_mul (dar_n, dar_d, set_h, set_w, &want_pn, &want_pd);
+    nearest_par (outs, to_par, want_pn, want_pd, &set_pn, &set_pd);
+    if (!(set_pn == want_pn && set_pd == want_pd)) {
+      frac_mul (dar_n, dar_d, set_pd, set_pn, &num, &den);
+      t = gst_util_uint64_scale_round (set_h, num, den);
+      got = nearest_int (outs, "width", (gint) t);
+      if (got == (gint) t) {
+        set_w = got;
+      } else {
+        t = gst_util_uint64_scale_round (set_w, den, num);
+        got = nearest_int (outs, "height", (gint) t);
+        if (got == (gint) t)
+          set_h = got;
+      }
+    }
+    gst_structure_set (outs, "width", G_TYPE_INT, set_w, "height", G_TYPE_INT, set_h, NULL);
+    put_par (outs, set_pn, set_pd);
+  }
+
+done:
+  othercaps = gst_caps_fixate (othercaps);
+  if (from_par == &fpar)
+    g_value_unset (&fpar);
+  if (to_par == &tpar)
+    g_value_unset (&tpar);
+  return othercaps;
+}
+
 static GstCaps *
 amd_vcs_fixate_caps (GstBaseTransform * trans, GstPadDirection direction, GstCaps * caps, GstCaps * othercaps)
 {
-  GstStructure *ins = gst_caps_get_structure (caps, 0), *outs;
-  gint w = 0, h = 0;
-  const gchar *fmt;
+  static const gchar *fields[] = { "format", "colorimetry", "chroma-site" };
+  GstCaps *format = fixed_format_caps (direction, caps, othercaps);
+  guint i;
 
-  othercaps = gst_caps_truncate (gst_caps_make_writable (othercaps));
-  outs = gst_caps_get_structure (othercaps, 0);
-  /* simplified fixation: keep the size and (when allowed) the format of the other side */
-  if (gst_structure_get_int (ins, "width", &w))
-    gst_structure_fixate_field_nearest_int (outs, "width", w);
-  if (gst_structure_get_int (ins, "height", &h))
-    gst_structure_fixate_field_nearest_int (outs, "height", h);
-  if ((fmt = gst_structure_get_string (ins, "format")) && gst_structure_has_field (outs, "format"))
-    gst_structure_fixate_field_string (outs, "format", fmt);
-  if (gst_structure_has_field (outs, "pixel-aspect-ratio")) {
-    gint pn = 1, pd = 1;
-    gst_structure_get_fraction (ins, "pixel-aspect-ratio", &pn, &pd);
-    gst_structure_fixate_field_nearest_fraction (outs, "pixel-aspect-ratio", pn, pd);
+  if (gst_caps_is_empty (format)) {
+    GST_ERROR_OBJECT (trans, "Could not convert formats");
+    gst_caps_unref (othercaps);
+    return format;
   }
-  return gst_caps_fixate (othercaps);
+  /* keep the memory kind the format pass settled on: the size pass truncates to the first structure of othercaps */
+  othercaps = fixate_size (trans, direction, caps, othercaps);
+  if (gst_caps_get_size (othercaps) == 1) {
+    GstStructure *fs = gst_caps_get_structure (format, 0), *os;
+    othercaps = gst_caps_make_writable (othercaps);
+    os = gst_caps_get_structure (othercaps, 0);
+    for (i = 0; i < G_N_ELEMENTS (fields); i++) {
+      if (gst_structure_has_field (fs, fields[i]))
+        gst_structure_set (os, fields[i], G_TYPE_STRING, gst_structure_get_string (fs, fields[i]), NULL);
+      else
+        gst_structure_remove_field (os, fields[i]);
+    }
+  }
+  gst_caps_unref (format);
+  return othercaps;
 }
 
 static gboolean

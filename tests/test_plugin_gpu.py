@@ -408,3 +408,36 @@ def test_reference_factory_names_are_ours_in_a_registry_without_the_stock_elemen
     for i in range(n):
         assert (a.frame(src[i]) == out[i]).all(), i
         assert (b.frame(src[i]) == sc[i]).all(), i
+
+
+# the table of tests/check/elements/videoscale.c:601-648 (test_negotiation): input caps, downstream restriction, expected width, height, PAR
+NEGOTIATION = [
+    ("width=720,height=576,pixel-aspect-ratio=16/15", "width=768,height=576", 768, 576, "1/1"),
+    ("width=320,height=240", "width=640,height=320", 640, 320, "2/3"),
+    ("width=320,height=240", "width=640,height=320,pixel-aspect-ratio=[0/1,1/1]", 640, 320, "2/3"),
+    ("width=1920,height=2560,pixel-aspect-ratio=1/1", "width=[1,2048],height=[1,2048],pixel-aspect-ratio=1/1", 1536, 2048, "1/1"),
+    ("width=1920,height=2560,pixel-aspect-ratio=1/1", "width=[1,2048],height=[1,2048]", 1920, 2048, "4/5"),
+    ("width=1920,height=2560", "width=[1,2048],height=[1,2048]", 1920, 2048, "4/5"),
+    ("width=1920,height=2560", "width=1200,height=[1,2048],pixel-aspect-ratio=1/1", 1200, 1600, "1/1"),
+    ("width=320,height=240,pixel-aspect-ratio=1/1", "width=200,height=200,pixel-aspect-ratio=1/2", 200, 200, "1/2"),
+    ("width=854,height=480", "width=[2,512,2],height=[2,512,2],pixel-aspect-ratio=1/1", 512, 288, "1/1"),
+]
+
+
+@pytest.mark.parametrize("case", NEGOTIATION, ids=lambda c: "%s->%s" % (c[0], c[1]))
+def test_fixate_caps_keeps_the_display_aspect_ratio_like_the_reference(gst_env, case):
+    """The reference's own negotiation table for videoscale (tests/check/elements/videoscale.c:601-648): what size and pixel aspect
+    ratio the element settles on for a given input and downstream restriction (gst_video_convert_scale_fixate_size)."""
+    import re
+    env, tmp = gst_env
+    in_caps, out_caps, w, h, par = case
+    r = subprocess.run([GST, "-v", "videotestsrc", "num-buffers=1", "!", "video/x-raw,format=AYUV,framerate=30/1," + in_caps, "!",
+                        "videoconvertscale", "!", "video/x-raw,format=AYUV," + out_caps, "!", "fakesink"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    lines = [l for l in r.stdout.splitlines() if "fakesink0.GstPad:sink: caps" in l]
+    assert lines, r.stdout[-2000:]
+    caps = lines[-1]
+    assert "width=(int)%d" % w in caps and "height=(int)%d" % h in caps, caps
+    m = re.search(r"pixel-aspect-ratio=\(fraction\)(\d+/\d+)", caps)
+    assert (m.group(1) if m else "1/1") == par, caps

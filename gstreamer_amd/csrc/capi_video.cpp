@@ -17,6 +17,7 @@
 #include "video_fast.h"
 #include "video_encode_fast.h"
 #include "video_scale420_fused.h"
+#include "video_scale420_mfma.h"
 
 using namespace gstamd;
 
@@ -60,6 +61,11 @@ struct GstAmdVideoConverter {
   int32_t *vgroup_dev = nullptr;
   uint32_t *vtapw_dev = nullptr;
   int fused_waves = 0, fused_rpc = 0, fused_ring = 0;
+  // k_scale420_mfma (video_scale420_mfma.h): the same with the horizontal pass on the matrix cores (64 source pixels per 16 outputs)
+  bool mfma_ok = false;
+  Mfma420Tables mfma;
+  uint32_t *btab_dev = nullptr;
+  int mfma_waves = 0, mfma_rpc = 0, mfma_ring = 0, mfma_tile_w = 0;
 };
 
 namespace gstamd {
@@ -67,6 +73,47 @@ size_t fused420_lds_bytes (int ring, int nwaves);
 int fused420_blocks_per_cu (int nwaves, size_t lds);
 hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
     const int pack_pos[4], const PostFast &pf, hipStream_t stream);
+size_t mfma420_lds_bytes (int ring);
+int mfma420_blocks_per_cu (int nwaves, size_t lds);
+hipError_t launch_scale420_mfma (const Mfma420Params &p, int chroma_h, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
+    const int pack_pos[4], const PostFast &pf, hipStream_t stream);
+}
+
+// geometry of the matrix-core scaler: column tiles of whole 16-output blocks (as even as possible, <= 256 outputs), waves per
+// workgroup (each takes a 16-line block per round, a round finishes 4 x waves output rows at 4:1), rows per workgroup
+static bool mfma_pick_geometry (GstAmdVideoConverter *c)
+{
+  const int out_h = c->plan.out_info.height;
+  const char *ew = getenv ("GSTAMD_MFMA_WAVES"), *er = getenv ("GSTAMD_MFMA_ROWS");
+  const int tiles = (c->mfma.n_blocks + 15) / 16, tile_blocks = (c->mfma.n_blocks + tiles - 1) / tiles;
+  int n_cu = 256, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    n_cu = prop.multiProcessorCount;
+  for (int nwaves = ew && atoi (ew) > 0 ? atoi (ew) : 4; nwaves >= 1; nwaves /= 2) {
+    if (nwaves > 4)
+      continue;
+    const int rpr = 4 * nwaves;
+    int ring = mfma420_ring_groups (c->fused, out_h, rpr);
+    const size_t lds = mfma420_lds_bytes (ring);
+    if (lds > 160 * 1024)
+      continue;
+    const int per_cu = mfma420_blocks_per_cu (nwaves, lds);
+    if (per_cu <= 0)
+      continue;
+    const int chunks = std::max (1, per_cu * n_cu / std::max (1, tiles));
+    int rpc = er && atoi (er) > 0 ? atoi (er) : (out_h + chunks - 1) / chunks;
+    rpc = std::max (rpc, rpr);
+    ring = mfma420_ring_groups (c->fused, rpc, rpr);
+    if (mfma420_lds_bytes (ring) > lds)
+      continue;
+    c->mfma_waves = nwaves;
+    c->mfma_rpc = rpc;
+    c->mfma_ring = ring;
+    c->mfma_tile_w = 16 * tile_blocks;
+    return true;
+  }
+  return false;
 }
 
 // geometry of the fused scaler: waves per workgroup, output rows per workgroup (every workgroup of the launch resident at once where
@@ -270,6 +317,16 @@ static int build_tables (GstAmdVideoConverter *c)
           (e = hipMemcpy (c->vtapw_dev, c->fused.vtapw.data (), c->fused.vtapw.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
         return hip_fail (e, "fused scaler tables");
       c->fused_ok = true;
+      /* the matrix-core form of the horizontal pass is parity-green but NOT the default: the MFMA operand layout puts 16 different
+       * lines in 16 neighbouring lanes, every load instruction then touches 16+ cache lines and costs ~64 texture-addresser
+       * cycles whatever its width - the kernel is bound by its 16 loads per block (70.8 us at C3 against 30.8 for the
+       * vector-ALU form; profiles/r02_c3_mfma_variants.log).  GSTAMD_MFMA420=1 selects it (tests, further work). */
+      if (getenv ("GSTAMD_MFMA420") != nullptr && make_mfma420_tables (p.passes[0], &c->mfma) && mfma_pick_geometry (c)) {
+        if ((e = hipMalloc ((void **) &c->btab_dev, c->mfma.btab.size () * sizeof (uint32_t))) != hipSuccess ||
+            (e = hipMemcpy (c->btab_dev, c->mfma.btab.data (), c->mfma.btab.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
+          return hip_fail (e, "matrix-core scaler tables");
+        c->mfma_ok = true;
+      }
     }
   }
   if (p.passes.size () == 2) {
@@ -584,6 +641,22 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     if (trace_path && hipMalloc ((void **) &fq.trace, trace_n * 8) == hipSuccess)
       (void) hipMemset (fq.trace, 0, trace_n * 8);
 #endif
+    e = hipErrorNotSupported;
+    if (c->mfma_ok) {
+      Mfma420Params mq;
+      mq.f = fq;
+      mq.f.h.tile_w = c->mfma_tile_w;
+      mq.f.rows_per_chunk = c->mfma_rpc;
+      mq.f.ring = c->mfma_ring;
+      mq.btab = (const uint4 *) c->btab_dev;
+      mq.d0 = c->mfma.d0;
+      mq.n_blocks = c->mfma.n_blocks;
+      e = launch_scale420_mfma (mq, p.front.chroma_h, c->mfma_waves, dst, dstride, post, p.post.pack_pos, pf, stream);
+      if (e == hipSuccess)
+        return GSTAMD_OK;
+      if (e != hipErrorNotSupported)
+        return hip_fail (e, "k_scale420_mfma");
+    }
     e = launch_scale420_fused (fq, p.front.chroma_h, sd[0].nw, c->fused_waves, dst, dstride, post, p.post.pack_pos, pf, stream);
 #ifdef GSTAMD_TUNING
     if (fq.trace) {
@@ -718,6 +791,10 @@ static void release_tables (GstAmdVideoConverter *c)
     (void) hipFree (c->vgroup_dev);
   if (c->vtapw_dev)
     (void) hipFree (c->vtapw_dev);
+  if (c->btab_dev)
+    (void) hipFree (c->btab_dev);
+  c->btab_dev = nullptr;
+  c->mfma_ok = false;
   if (c->pk_img)
     (void) hipFree (c->pk_img);
   if (c->plane_tmp)

@@ -631,6 +631,49 @@ bool make_fused420_tables (const ScalePass &v, int height, Fused420Tables *t)
   return true;
 }
 
+bool make_mfma420_tables (const ScalePass &hp, Mfma420Tables *t)
+{
+  if (!hp.horizontal || hp.kind != SCALE_NTAP || !hp.dot4_ok)
+    return false;
+  const int out_w = hp.out_size, n = hp.n_taps;
+  t->n_blocks = (out_w + 15) / 16;
+  /* d0 from a block in the middle of the line, then every block is checked against it */
+  const int mid = t->n_blocks / 2;
+  t->d0 = (int) (hp.offset[std::min (16 * mid, out_w - 1)] / 64) - mid;
+  t->btab.assign ((size_t) t->n_blocks * 3 * 64 * 4, 0);
+  for (int bg = 0; bg < t->n_blocks; bg++)
+    for (int col = 0; col < 16; col++) {
+      const int x = 16 * bg + col;
+      if (x >= out_w)
+        continue;
+      const int off = (int) hp.offset[x], lo = 64 * (bg + t->d0);
+      if (off < lo || off + n > lo + 64 * 3)
+        return false;
+      for (int l = 0; l < n; l++) {
+        const int rel = off + l - lo, chunk = rel / 64, kg = (rel % 64) / 16, j = rel % 16, lane = 16 * kg + col;
+        const uint32_t b = (uint32_t) (uint8_t) (int8_t) hp.taps[(size_t) x * n + l];
+        t->btab[(((size_t) bg * 3 + chunk) * 64 + lane) * 4 + (j >> 2)] |= b << (8 * (j & 3));
+      }
+    }
+  return true;
+}
+
+int mfma420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int rows_per_round)
+{
+  const int out_h = (int) t.vgroup.size ();
+  int worst = 0;
+  for (int j0 = 0; j0 < out_h; j0 += rows_per_chunk) {
+    const int j1 = std::min (j0 + rows_per_chunk, out_h);
+    for (int jr = j0; jr < j1; jr += rows_per_round) {
+      const int jl = std::min (jr + rows_per_round, j1) - 1;
+      const int gh = std::min (t.vgroup[jl] + t.ngv - 1, t.n_groups - 1);
+      /* whole line blocks are written: from the block holding the round's first group to the block holding gh */
+      worst = std::max (worst, 4 * (gh >> 2) + 3 - 4 * (t.vgroup[jr] >> 2) + 1);
+    }
+  }
+  return worst;
+}
+
 int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwaves)
 {
   const int out_h = (int) t.vgroup.size ();

@@ -120,6 +120,18 @@ bool make_fused420_tables (const ScalePass &vpass, int height, Fused420Tables *t
 // most groups any round of any chunk needs in the ring at once (rounds of `nwaves` rows inside chunks of rows_per_chunk rows)
 int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwaves);
 
+// B operands of the matrix-core horizontal pass (video_scale420_mfma.h): for every block of 16 outputs and each of its three
+// 64-pixel chunks, per lane (output n = lane & 15, pixels 64 c + 16 (lane >> 4) + j) the int8 taps, zero outside the window
+struct Mfma420Tables {
+  int d0;                         // block bg reads the chunks bg + d0 .. bg + d0 + 2
+  int n_blocks;
+  std::vector<uint32_t> btab;     // [n_blocks][3][64][4]
+};
+// false: some block's windows do not fit its three chunks (not 64 source pixels per 16 outputs), or the pass has no int8 form
+bool make_mfma420_tables (const ScalePass &hpass, Mfma420Tables *t);
+// ring slots the matrix-core kernel needs: whole line blocks of four groups are produced, rounds of rows_per_round rows
+int mfma420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int rows_per_round);
+
 // one destination plane of convert_scale_planes on a planar / semi-planar format
 enum PlaneKind : int { PLANE_COPY = 0, PLANE_H_HALVE, PLANE_H_DOUBLE, PLANE_V_HALVE, PLANE_V_DOUBLE, PLANE_HV_HALVE, PLANE_HV_DOUBLE, PLANE_SCALE };
 struct PlanePlan {

@@ -12,6 +12,7 @@
 #include "../../gstreamer_amd/csrc/video_scale_fast.h"
 #include "../../gstreamer_amd/csrc/video_hscale420.h"
 #include "../../gstreamer_amd/csrc/video_scale420_fused.h"
+#include "../../gstreamer_amd/csrc/video_scale420_mfma.h"
 #include "../../gstreamer_amd/csrc/video_422_fast.h"
 #include <cstdlib>
 #include <algorithm>
@@ -372,6 +373,124 @@ static void run_fused420_ch (const Fused420Params &p, int chroma_h, const Dst &d
     run_fused420<NW, CHROMA_H_NONE, SEMI> (p, dst, pf, nwaves);
 }
 
+// k_scale420_mfma: v_mfma_i32_16x16x64_i8 restated (A: lane = row + 16 kgroup, B: lane = col + 16 kgroup, 16 int8 each;
+// C: lane = col + 16 (row / 4), reg = row % 4), then the kernel's loop structure wave by wave
+static int g_mfma_runs = 0;
+extern "C" int emu_mfma_runs (void) { return g_mfma_runs; }
+
+static void emu_mfma_i8 (const uint4 *a, const uint4 *b, int (*c)[4])
+{
+  for (int row = 0; row < 16; row++)
+    for (int col = 0; col < 16; col++) {
+      int sum = 0;
+      for (int kg = 0; kg < 4; kg++) {
+        const uint32_t *wa = &a[row + 16 * kg].x, *wb = &b[col + 16 * kg].x;
+        for (int j = 0; j < 16; j++)
+          sum += (int) (int8_t) (wa[j >> 2] >> (8 * (j & 3))) * (int) (int8_t) (wb[j >> 2] >> (8 * (j & 3)));
+      }
+      c[col + 16 * (row / 4)][row % 4] += sum;
+    }
+}
+
+template <int CH, int SEMI>
+static void run_mfma420 (const Mfma420Params &p, const Dst &dst, const PostFast &pf, int nwaves)
+{
+  const int tile_blocks = p.f.h.tile_w >> 4, tiles = (p.n_blocks + tile_blocks - 1) / tile_blocks;
+  const int chunks = (p.f.out_h + p.f.rows_per_chunk - 1) / p.f.rows_per_chunk, rpr = 4 * nwaves;
+  std::vector<uint32_t> ring ((size_t) p.f.ring * GSTAMD_FUSED_GROUP_WORDS);
+  for (int by = 0; by < chunks; by++)
+    for (int bx = 0; bx < tiles; bx++) {
+      memset (ring.data (), 0xAB, ring.size () * 4);
+      const int B0 = bx * tile_blocks, B1 = std::min (B0 + tile_blocks, p.n_blocks);
+      const int t0 = 16 * B0, t1 = std::min (t0 + p.f.h.tile_w, p.f.h.out_w);
+      const int j0 = by * p.f.rows_per_chunk, j1 = std::min (j0 + p.f.rows_per_chunk, p.f.out_h);
+      int gl, g_last;
+      fused_round_groups (p.f, j0, j1 - 1, &gl, &g_last);
+      std::vector<int> kbw (nwaves);
+      for (int w = 0; w < nwaves; w++)
+        kbw[w] = (gl >> 2) + w;
+      for (int jr = j0; jr < j1; jr += rpr) {
+        const int jl = std::min (jr + rpr, j1) - 1;
+        int gl_r, gh;
+        fused_round_groups (p.f, jr, jl, &gl_r, &gh);
+        for (int w = 0; w < nwaves; w++)
+          for (int &kb = kbw[w]; kb <= (gh >> 2); kb += nwaves)
+            for (int bg = B0; bg < B1; bg++) {
+              uint4 a[3][3][64], b[3][64];         /* [chunk][plane][lane] */
+              for (int i = 0; i < 3; i++)
+                for (int lane = 0; lane < 64; lane++) {
+                  Mfma420Rows rows;
+                  Mfma420Loads q;
+                  Mfma420A aa;
+                  mfma_rows (p.f.h, 16 * kb - 1 + (lane & 15), rows);
+                  mfma_request<SEMI> (p.f.h, rows, bg + p.d0 + i, lane >> 4, q);
+                  mfma_make_a<CH, SEMI> (p.f.h, q, aa);
+                  a[i][0][lane] = aa.y, a[i][1][lane] = aa.u, a[i][2][lane] = aa.v;
+                  b[i][lane] = p.btab[((size_t) bg * 3 + i) * 64 + lane];
+                }
+              for (int pl = 0; pl < 3; pl++) {
+                int c[64][4];
+                for (int lane = 0; lane < 64; lane++)
+                  c[lane][0] = c[lane][1] = c[lane][2] = c[lane][3] = 128 * 64 + 32;
+                for (int i = 0; i < 3; i++)
+                  emu_mfma_i8 (a[i][pl], b[i], c);
+                for (int lane = 0; lane < 64; lane++) {
+                  int slot = (4 * kb) % p.f.ring + (lane >> 4);
+                  slot = slot >= p.f.ring ? slot - p.f.ring : slot;
+                  ring[(size_t) slot * GSTAMD_FUSED_GROUP_WORDS + 256 * pl + 16 * (bg - B0) + (lane & 15)] =
+                      mfma_group_word (c[lane][0], c[lane][1], c[lane][2], c[lane][3]);
+                }
+              }
+            }
+        for (int j = jr; j <= jl; j++)
+          for (int lane = 0; lane < 64; lane++) {
+            if (p.f.ngv == 5)
+              fused_vrow<5> (p.f, ring.data (), dst, pf, j, t0, t1, lane);
+            else
+              fused_vrow<0> (p.f, ring.data (), dst, pf, j, t0, t1, lane);
+          }
+      }
+    }
+}
+
+static bool emu_scale420_mfma (const VideoPlan &p, const H420RegParams &hp, int n_taps_h, const Fused420Tables &t, const Dst &dst, const PostFast &pf)
+{
+  Mfma420Tables m;
+  if (!getenv ("GSTAMD_MFMA420") || !make_mfma420_tables (p.passes[0], &m))
+    return false;
+  const char *ew = getenv ("GSTAMD_MFMA_WAVES"), *er = getenv ("GSTAMD_MFMA_ROWS");
+  const int nwaves = ew && atoi (ew) > 0 ? atoi (ew) : 4, rpr = 4 * nwaves;
+  const int tiles = (m.n_blocks + 15) / 16, tile_blocks = (m.n_blocks + tiles - 1) / tiles;
+  Mfma420Params q;
+  memset (&q, 0, sizeof (q));
+  q.f.h = hp;
+  q.f.h.tile_w = 16 * tile_blocks;
+  q.f.n_taps_h = n_taps_h;
+  q.f.vgroup = t.vgroup.data ();
+  q.f.vtapw = t.vtapw.data ();
+  q.f.ngv = t.ngv;
+  q.f.out_h = p.out_info.height;
+  q.f.rows_per_chunk = std::max (rpr, er && atoi (er) > 0 ? atoi (er) : 37);
+  q.f.ring = mfma420_ring_groups (t, q.f.rows_per_chunk, rpr);
+  q.f.n_groups = t.n_groups;
+  q.btab = (const uint4 *) m.btab.data ();
+  q.d0 = m.d0;
+  q.n_blocks = m.n_blocks;
+  if (((uintptr_t) m.btab.data () % 16) != 0)
+    return false;
+  g_mfma_runs++;
+  if (hp.semi) {
+    if (p.front.chroma_h == CHROMA_H_H2_CS) run_mfma420<CHROMA_H_H2_CS, 1> (q, dst, pf, nwaves);
+    else if (p.front.chroma_h == CHROMA_H_H2) run_mfma420<CHROMA_H_H2, 1> (q, dst, pf, nwaves);
+    else run_mfma420<CHROMA_H_NONE, 1> (q, dst, pf, nwaves);
+  } else {
+    if (p.front.chroma_h == CHROMA_H_H2_CS) run_mfma420<CHROMA_H_H2_CS, 0> (q, dst, pf, nwaves);
+    else if (p.front.chroma_h == CHROMA_H_H2) run_mfma420<CHROMA_H_H2, 0> (q, dst, pf, nwaves);
+    else run_mfma420<CHROMA_H_NONE, 0> (q, dst, pf, nwaves);
+  }
+  return true;
+}
+
 // the decision of capi_video.cpp (ensure_tables + convert_to_packed) for k_scale420_fused; hp = the k_hscale420_reg parameters
 static bool emu_scale420_fused (const VideoPlan &p, H420RegParams hp, int nw, int n_taps_h, const Dst &dst, const PostFast &pf)
 {
@@ -380,6 +499,8 @@ static bool emu_scale420_fused (const VideoPlan &p, H420RegParams hp, int nw, in
   Fused420Tables t;
   if (!make_fused420_tables (p.passes[1], p.front.height, &t))
     return false;
+  if (((uintptr_t) dst.p % 4) == 0 && (dst.stride % 4) == 0 && emu_scale420_mfma (p, hp, n_taps_h, t, dst, pf))
+    return true;
   const char *ew = getenv ("GSTAMD_FUSED_WAVES"), *er = getenv ("GSTAMD_FUSED_ROWS");
   const int nwaves = ew && atoi (ew) > 0 ? atoi (ew) : 8;
   const int rpc = std::max (nwaves, er && atoi (er) > 0 ? atoi (er) : 17);

@@ -110,6 +110,22 @@ def test_hip_frame_list_32x4k_matches_reference(native_lib, gpu, ref):
     conv.free()
 
 
+MFMA_SHAPES = [("I420", 7680, 4320, "RGBA", 1920, 1080), ("NV12", 1280, 720, "BGRA", 320, 180), ("NV21", 1920, 1080, "RGBA", 480, 270),
+               ("YV12", 640, 359, "BGRA", 160, 90), ("I420", 2048, 856, "ARGB", 512, 214)]
+
+
+@pytest.mark.parametrize("shape", MFMA_SHAPES, ids=lambda s: "%s_%dx%d" % (s[0], s[1], s[2]))
+def test_hip_scale420_mfma_matches_reference_bytewise(native_lib, gpu, ref, shape, monkeypatch):
+    """k_scale420_mfma (4:1 horizontal pass on v_mfma_i32_16x16x64_i8; opt-in, see capi_video.cpp) memcmp'd against the reference:
+    C3 at its own size, both plane layouts, odd height, several tiles."""
+    monkeypatch.setenv("GSTAMD_MFMA420", "1")
+    ifmt, w, h, ofmt, ow, oh = shape
+    src = cases.frame_bytes(ref.video_info(ifmt, w, h)["size"], "random", 31 + w)
+    exp = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, cases.LAN)).frame(src)
+    out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LAN, None, None, src)
+    assert (out == exp).all(), int((out != exp).sum())
+
+
 H420_SHAPES = [("NV12", 1280, 720, "BGRA", 320, 180, "lanczos"), ("NV21", 1920, 1080, "RGBA", 480, 270, "lanczos"),
                ("I420", 2048, 856, "ARGB", 512, 214, "lanczos"), ("YV12", 640, 359, "BGRA", 160, 90, "lanczos"),
                ("NV12", 1920, 1080, "BGRA", 640, 360, "lanczos"), ("I420", 1280, 720, "RGBA", 640, 360, "lanczos"),

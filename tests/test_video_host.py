@@ -174,13 +174,34 @@ def test_scale420_fused_bodies_any_geometry(native_lib, emu_lib, idx_case, geom,
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
 
 
-def test_scale420_fused_is_taken_for_the_c3_shape(native_lib, emu_lib):
+def test_scale420_fused_is_taken_for_the_c3_shape(native_lib, emu_lib, monkeypatch):
     name = "i420_rgba_quarter_lanczos"
     _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     before = emu_lib.emu_fused_runs()
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
     assert emu_lib.emu_fused_runs() == before + 1
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
+MFMA_CASES = [c for c in SMALL if c[1][0] in ("nv12_bgra_quarter_lanczos", "i420_rgba_quarter_lanczos")]
+
+
+@pytest.mark.parametrize("geom", [(4, 37), (1, 4), (2, 8), (4, 1000), (3, 13)], ids=lambda g: "waves%d_rows%d" % g)
+@pytest.mark.parametrize("idx_case", MFMA_CASES, ids=lambda c: c[1][0])
+def test_scale420_mfma_bodies_any_geometry(native_lib, emu_lib, idx_case, geom, monkeypatch):
+    """k_scale420_mfma (video_scale420_mfma.h): the 4:1 horizontal pass as v_mfma_i32_16x16x64_i8 over 64-pixel chunks (restated
+    on the host with the instruction's lane maps), ring + vertical pass of the fused scaler - the reference's bytes for any
+    waves / rows split, both plane layouts; with GSTAMD_MFMA420=1 it must be the path taken at 4:1."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    monkeypatch.setenv("GSTAMD_MFMA420", "1")               # opt-in: the vector-ALU form is the default (see capi_video.cpp)
+    monkeypatch.setenv("GSTAMD_MFMA_WAVES", str(geom[0]))
+    monkeypatch.setenv("GSTAMD_MFMA_ROWS", str(geom[1]))
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    emu_lib.emu_mfma_runs.restype = C.c_int
+    before = emu_lib.emu_mfma_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_mfma_runs() == before + 1
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
 
 

@@ -60,7 +60,7 @@ struct GstAmdVideoConverter {
   Fused420Tables fused;
   int32_t *vgroup_dev = nullptr;
   uint32_t *vtapw_dev = nullptr;
-  int fused_waves = 0, fused_rpc = 0, fused_ring = 0;
+  int fused_waves = 0, fused_rpc = 0, fused_ring = 0, fused_first = 0;
   // k_scale420_mfma (video_scale420_mfma.h): the same with the horizontal pass on the matrix cores (64 source pixels per 16 outputs)
   bool mfma_ok = false;
   Mfma420Tables mfma;
@@ -130,7 +130,8 @@ static bool fused_pick_geometry (GstAmdVideoConverter *c, int tiles)
   for (int nwaves = first; nwaves >= 2; nwaves /= 2) {
     if (nwaves > 16)
       continue;
-    int ring = fused420_ring_groups (c->fused, out_h, nwaves);
+    const int first = getenv ("GSTAMD_FUSED_FIRST") ? std::max (1, atoi (getenv ("GSTAMD_FUSED_FIRST"))) : fused420_first_rows (c->fused, nwaves);
+    int ring = fused420_ring_groups (c->fused, out_h, nwaves, first);
     size_t lds = fused420_lds_bytes (ring, nwaves);
     if (lds > 160 * 1024)
       continue;
@@ -140,9 +141,10 @@ static bool fused_pick_geometry (GstAmdVideoConverter *c, int tiles)
     const int chunks = std::max (1, per_cu * n_cu / std::max (1, tiles));
     int rpc = er && atoi (er) > 0 ? atoi (er) : (out_h + chunks - 1) / chunks;
     rpc = std::max (rpc, nwaves);
-    ring = fused420_ring_groups (c->fused, rpc, nwaves);
+    ring = fused420_ring_groups (c->fused, rpc, nwaves, first);
     if (fused420_lds_bytes (ring, nwaves) > lds)
       continue;
+    c->fused_first = std::min (first, nwaves);
     c->fused_waves = nwaves;
     c->fused_rpc = rpc;
     c->fused_ring = ring;
@@ -632,6 +634,7 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     fq.ngv = c->fused.ngv;
     fq.out_h = out_h;
     fq.rows_per_chunk = c->fused_rpc;
+    fq.first_rows = c->fused_first;
     fq.ring = c->fused_ring;
     fq.n_groups = c->fused.n_groups;
 #ifdef GSTAMD_TUNING

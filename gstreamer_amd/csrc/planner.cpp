@@ -674,19 +674,34 @@ int mfma420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int rows_p
   return worst;
 }
 
-int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwaves)
+int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwaves, int first_rows)
 {
   const int out_h = (int) t.vgroup.size ();
   int worst = 0;
+  if (first_rows <= 0)
+    first_rows = nwaves;
   for (int j0 = 0; j0 < out_h; j0 += rows_per_chunk) {
     const int j1 = std::min (j0 + rows_per_chunk, out_h);
-    for (int jr = j0; jr < j1; jr += nwaves) {
-      const int jl = std::min (jr + nwaves, j1) - 1;
+    int rows = first_rows;
+    for (int jr = j0; jr < j1; jr += rows, rows = nwaves) {
+      const int jl = std::min (jr + rows, j1) - 1;
       const int gh = std::min (t.vgroup[jl] + t.ngv - 1, t.n_groups - 1);
       worst = std::max (worst, gh - t.vgroup[jr] + 1);
     }
   }
   return worst;
+}
+
+int fused420_first_rows (const Fused420Tables &t, int nwaves)
+{
+  const int out_h = (int) t.vgroup.size ();
+  /* judged in the middle of the picture (the edges fold their windows) */
+  const int j0 = out_h / 2;
+  int best = 1;
+  for (int r = 1; r <= nwaves && j0 + r <= out_h; r++)
+    if (t.vgroup[j0 + r - 1] + t.ngv - 1 - t.vgroup[j0] + 1 <= nwaves)
+      best = r;
+  return best;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -118,7 +118,9 @@ struct Fused420Tables {
 // false: the pass cannot take the byte form (a tap outside int8, a phase whose taps do not sum to 64, offsets not ascending)
 bool make_fused420_tables (const ScalePass &vpass, int height, Fused420Tables *t);
 // most groups any round of any chunk needs in the ring at once (rounds of `nwaves` rows inside chunks of rows_per_chunk rows)
-int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwaves);
+int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwaves, int first_rows = 0);
+// rows for a chunk's first round: the most (<= nwaves) whose windows span no more than nwaves groups
+int fused420_first_rows (const Fused420Tables &t, int nwaves);
 
 // B operands of the matrix-core horizontal pass (video_scale420_mfma.h): for every block of 16 outputs and each of its three
 // 64-pixel chunks, per lane (output n = lane & 15, pixels 64 c + 16 (lane >> 4) + j) the int8 taps, zero outside the window

@@ -58,8 +58,9 @@ __global__ __launch_bounds__ (1024) void k_scale420_fused (Fused420Params p, Dst
   fused_request_group<NW, SEMI> (p.h, g < g_last ? g : g_last, s);
   FUSED_STAMP (1);
   int stamp = 2;
-  for (int jr = j0; jr < j1; jr += nwaves) {
-    const int jl = (jr + nwaves < j1 ? jr + nwaves : j1) - 1;
+  int rows = p.first_rows;
+  for (int jr = j0; jr < j1; jr += rows, rows = nwaves) {
+    const int jl = (jr + rows < j1 ? jr + rows : j1) - 1;
     int gl_r, gh;
     fused_round_groups (p, jr, jl, &gl_r, &gh);
     while (g <= gh) {

@@ -31,6 +31,8 @@ struct Fused420Params {
   int ngv;
   int out_h;
   int rows_per_chunk;           // output rows per workgroup (blockIdx.y)
+  int first_rows;               // rows of a chunk's first round (later rounds: one row per wave): chosen so that the first round, which
+                                // also fills the ring's run-in, has one group per wave like the others (no wave waits for a second)
   int ring;                     // ring slots (groups) in LDS
   int n_groups;                 // line groups of the picture: (height / 2 + 2) / 2
 #ifdef GSTAMD_TUNING

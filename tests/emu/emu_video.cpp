@@ -327,8 +327,9 @@ static void run_fused420 (const Fused420Params &p, const Dst &dst, const PostFas
           fused_request_group<NW, SEMI> (p.h, std::min (gnext[w], g_last), s);
         }
       }
-      for (int jr = j0; jr < j1; jr += nwaves) {
-        const int jl = std::min (jr + nwaves, j1) - 1;
+      int rows = p.first_rows;
+      for (int jr = j0; jr < j1; jr += rows, rows = nwaves) {
+        const int jl = std::min (jr + rows, j1) - 1;
         int gl_r, gh;
         fused_round_groups (p, jr, jl, &gl_r, &gh);
         for (int w = 0; w < nwaves; w++) {
@@ -513,7 +514,8 @@ static bool emu_scale420_fused (const VideoPlan &p, H420RegParams hp, int nw, in
   q.ngv = t.ngv;
   q.out_h = p.out_info.height;
   q.rows_per_chunk = rpc;
-  q.ring = fused420_ring_groups (t, rpc, nwaves);
+  q.first_rows = std::min (nwaves, getenv ("GSTAMD_FUSED_FIRST") ? std::max (1, atoi (getenv ("GSTAMD_FUSED_FIRST"))) : fused420_first_rows (t, nwaves));
+  q.ring = fused420_ring_groups (t, rpc, nwaves, q.first_rows);
   q.n_groups = t.n_groups;
   if (((uintptr_t) dst.p % 4) != 0 || (dst.stride % 4) != 0)
     return false;

@@ -195,14 +195,76 @@ GSTAMD_CD uint32_t mul24_uniform (uint32_t a, uint32_t b)
 #endif
 }
 
-// alpha8081 = pad alpha * 0x8081 (< 2^24): div255w (sA * alpha) = (sA * alpha * 0x8081) >> 23 in one multiply
+// a * b + c per 16-bit lane (v_pk_mad_u16); nothing here exceeds 65535, so the lanes never wrap
+GSTAMD_CD uint32_t cpk_mad16 (uint32_t a, uint32_t b, uint32_t c)
+{
+#ifdef __HIPCC__
+  typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
+  return __builtin_bit_cast (uint32_t, (us2) (__builtin_bit_cast (us2, a) * __builtin_bit_cast (us2, b) + __builtin_bit_cast (us2, c)));
+#else
+  const uint32_t lo = ((a & 0xffffu) * (b & 0xffffu) + (c & 0xffffu)) & 0xffffu;
+  const uint32_t hi = ((a >> 16) * (b >> 16) + (c >> 16)) & 0xffffu;
+  return lo | (hi << 16);
+#endif
+}
+
+// byte `ashift / 8` of s times a wave-uniform 24-bit factor: the byte select rides in the multiply (SDWA)
+template <int ASH>
+GSTAMD_CD uint32_t mul24_alpha_byte (uint32_t s, uint32_t k)
+{
+#ifdef __HIPCC__
+  uint32_t r;
+  if (ASH == 0)
+    asm ("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v" (r) : "v" (s), "v" (k));
+  else
+    asm ("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v" (r) : "v" (s), "v" (k));
+  return r;
+#else
+  return ((s >> ASH) & 0xffu) * k;
+#endif
+}
+
+GSTAMD_CD uint32_t cbperm (uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#ifdef __HIPCC__
+  return __builtin_amdgcn_perm (hi, lo, sel);
+#else
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t q = (sel >> (8 * i)) & 0xff;
+    const uint32_t b = q < 4 ? (lo >> (8 * q)) & 0xff : (q < 8 ? (hi >> (8 * (q - 4))) & 0xff : (q == 0x0c ? 0u : 0xffu));
+    r |= b << (8 * i);
+  }
+  return r;
+#endif
+}
+
+// alpha8081 = pad alpha * 0x8081 (< 2^24): a = div255w (sA * alpha) = (sA * alpha * 0x8081) >> 23 in one multiply.  Both channels
+// of a half then take   t = s * a + d * (255 - a) + 1   as two packed multiply-adds (the + 1 of the division rides in the first),
+// and div255 finishes as (t + (t >> 8)) >> 8.  The destination's alpha lane is NOT forced to 0xff here: it never feeds another
+// lane, every blend recomputes it from bytes <= 255, and aggregate_span4 sets it once after the last pad (16 VALU per
+// pixel-blend instead of 24).
+template <int ASH>
+GSTAMD_CD void px2_blend_lazy (Px2 &d, uint32_t s, uint32_t alpha8081)
+{
+  const uint32_t a = mul24_alpha_byte<ASH> (s, alpha8081) >> 23;
+  const uint32_t as = a | (a << 16), ias = 0x00ff00ffu - as;
+  const uint32_t se = cbperm (0, s, 0x0c020c00u), so = cbperm (0, s, 0x0c030c01u);
+  const uint32_t te = cpk_mad16 (se, as, cpk_mad16 (d.e, ias, 0x00010001u));
+  const uint32_t to = cpk_mad16 (so, as, cpk_mad16 (d.o, ias, 0x00010001u));
+  d.e = pk16_shr8 (te + pk16_shr8 (te));
+  d.o = pk16_shr8 (to + pk16_shr8 (to));
+}
+
 GSTAMD_CD void px2_blend (Px2 &d, uint32_t s, uint32_t alpha8081, int ashift)
 {
-  const uint32_t a = mul24_uniform ((s >> ashift) & 0xff, alpha8081) >> 23;
-  const uint32_t ia = 0xffu - a;
-  const Px2 sp = px2_unpack (s);
-  d.e = pk16_div255 (mul24 (sp.e, a) + mul24 (d.e, ia)) | (ashift == 0 ? 0xffu : 0u);
-  d.o = pk16_div255 (mul24 (sp.o, a) + mul24 (d.o, ia)) | (ashift == 0 ? 0u : 0x00ff0000u);
+  if (ashift == 0) {
+    px2_blend_lazy<0> (d, s, alpha8081);
+    d.e |= 0xffu;
+  } else {
+    px2_blend_lazy<24> (d, s, alpha8081);
+    d.o |= 0x00ff0000u;
+  }
 }
 
 struct __attribute__ ((aligned (4))) Px4Words {
@@ -359,20 +421,22 @@ GSTAMD_CD void aggregate_span4 (const AggregateParams &p, const PadHit *hits, in
             if (ABL == 1 || ABL == 4)
               acc[i].e ^= cur.v[i];
             else
-              px2_blend (acc[i], cur.v[i], alpha8081, ashift);
+              px2_blend_lazy<ASH> (acc[i], cur.v[i], alpha8081);
         } else if ((unsigned) (sx + 3) < (unsigned) (w + 3)) {           // lane straddles a pad edge
           const uint8_t *row = uniform_ptr (hits[k].row);
 #pragma unroll
           for (int i = 0; i < 4; i++)
             if (sx + i >= 0 && sx + i < w)
-              px2_blend (acc[i], load_px1 (row + 4 * (size_t) (sx + i)), alpha8081, ashift);
+              px2_blend_lazy<ASH> (acc[i], load_px1 (row + 4 * (size_t) (sx + i)), alpha8081);
         }
       }
     }
   }
+  /* the opaque blend leaves alpha 0xff (compositor_orc_blend_*: the destination's alpha byte is overwritten); the background's
+   * alpha is 0xff on this path as well (checker / opaque colour / an earlier chunk's output), so forcing it once is the same */
 #pragma unroll
   for (int i = 0; i < 4; i++)
-    d[i] = px2_pack (acc[i]);
+    d[i] = px2_pack (acc[i]) | (0xffu << ashift);
 }
 
 }  // namespace gstamd

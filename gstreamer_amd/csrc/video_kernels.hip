@@ -286,11 +286,17 @@ __global__ __launch_bounds__ (256) void k_vscale (SRC src, ScaleDev sd, Dst dst,
 
 // fused bilinear scaler from semi-planar 4:2:0 (video_bilinear_fast.h): workgroup = one wave = 256 outputs of one row
 template <int CH, int L>
-__global__ __launch_bounds__ (64) void k_bilinear420 (BilParams bp, Planes pl, uint8_t *__restrict__ dst, int dstride, int vec)
+__global__ __launch_bounds__ (64) void k_bilinear420 (BilParams bp, Planes pl, uint8_t *__restrict__ dst, int dstride, int vec, int tiles_x)
 {
   extern __shared__ uint32_t lds_w[];
   const BilLds lds = bil_lds (lds_w, bp.ylen);
-  const int lane = (int) threadIdx.x, y = (int) blockIdx.y, t0 = (int) blockIdx.x * bp.tile_w;
+  /* XCD-aware block order (wide_block_map): an XCD walks 32 consecutive output rows of one column tile, so the chroma rows that
+   * neighbouring output rows share (and the luma rows of overlapping windows) are found in ITS L2 - with the plain (tile, row)
+   * grid vertically adjacent tiles land on different XCDs and the L2 -> fabric read traffic was 1.83x the source bytes (PMC) */
+  int tile, y;
+  if (!wide_block_map ((int) blockIdx.x, tiles_x, bp.out_h, &tile, &y))
+    return;
+  const int lane = (int) threadIdx.x, t0 = tile * bp.tile_w;
   const int t1 = t0 + bp.tile_w < bp.out_w ? t0 + bp.tile_w : bp.out_w;
   const int r0 = (int) bp.voffset[y];
   BilRegs r;
@@ -817,15 +823,16 @@ hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &
     if (!vec)
       return hipErrorNotSupported;
   }
-  dim3 grid ((bp.out_w + bp.tile_w - 1) / bp.tile_w, bp.out_h);
+  const int tiles_x = (bp.out_w + bp.tile_w - 1) / bp.tile_w;
+  dim3 grid (wide_grid_blocks (tiles_x, bp.out_h));
   const size_t lds_bytes = bil_lds_words (bp.ylen) * 4;
 #define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \
     if (chroma_h == CHROMA_H_H2_CS) \
-      hipLaunchKernelGGL ((k_bilinear420<CHROMA_H_H2_CS, GSTAMD_LAYOUT (pr, pg, pb)>), grid, dim3 (64), lds_bytes, stream, bp, pl, dst, dstride, vec); \
+      hipLaunchKernelGGL ((k_bilinear420<CHROMA_H_H2_CS, GSTAMD_LAYOUT (pr, pg, pb)>), grid, dim3 (64), lds_bytes, stream, bp, pl, dst, dstride, vec, tiles_x); \
     else if (chroma_h == CHROMA_H_H2) \
-      hipLaunchKernelGGL ((k_bilinear420<CHROMA_H_H2, GSTAMD_LAYOUT (pr, pg, pb)>), grid, dim3 (64), lds_bytes, stream, bp, pl, dst, dstride, vec); \
+      hipLaunchKernelGGL ((k_bilinear420<CHROMA_H_H2, GSTAMD_LAYOUT (pr, pg, pb)>), grid, dim3 (64), lds_bytes, stream, bp, pl, dst, dstride, vec, tiles_x); \
     else \
-      hipLaunchKernelGGL ((k_bilinear420<CHROMA_H_NONE, GSTAMD_LAYOUT (pr, pg, pb)>), grid, dim3 (64), lds_bytes, stream, bp, pl, dst, dstride, vec); \
+      hipLaunchKernelGGL ((k_bilinear420<CHROMA_H_NONE, GSTAMD_LAYOUT (pr, pg, pb)>), grid, dim3 (64), lds_bytes, stream, bp, pl, dst, dstride, vec, tiles_x); \
     return hipGetLastError ();
   switch (fast_layout (bp.fp)) {
     GSTAMD_FOR_LAYOUTS (W)

@@ -526,6 +526,13 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     e = launch_convert422 (q, pl.p[0], pl.stride[0], dst, dstride, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert422");
   }
+  if (p.deep16) {
+    if (((uintptr_t) dst % 4) != 0 || (dstride % 4) != 0 || ((uintptr_t) pl.p[0] % 2) != 0 || (pl.stride[0] % 2) != 0 || ((uintptr_t) pl.p[1] % 2) != 0 ||
+        (pl.stride[1] % 2) != 0 || (p.front.kind == UNPACK_PLANAR && (((uintptr_t) pl.p[2] % 2) != 0 || (pl.stride[2] % 2) != 0)))
+      return set_error (GSTAMD_ERR_UNSUPPORTED, "10-bit frames need 2-byte aligned planes and pitches, the destination 4-byte aligned ones");
+    e = launch_convert16 (p.front, pl, c->vpair_dev, p.deep, p.post, dst, dstride, stream);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert16");
+  }
   if (p.passes.empty ()) {
     e = launch_convert (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert");

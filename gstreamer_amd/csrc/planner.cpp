@@ -39,6 +39,9 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_RGBx, "RGBx", false, false, 1, UNPACK_PACKED4, 0, 0, 0, 0, {3, 0, 1, 2}},
   {GSTAMD_VIDEO_FORMAT_ABGR, "ABGR", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 3, 2, 1}},
   {GSTAMD_VIDEO_FORMAT_xBGR, "xBGR", false, false, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 3, 2, 1}},
+  // 10 bits per sample in 16-bit little-endian words (video-format.c:3834-3873, 5329-5400); sources of the 16-bit chain
+  {GSTAMD_VIDEO_FORMAT_I420_10LE, "I420_10LE", true, false, 3, UNPACK_PLANAR, 1, 1, 1, 2, {0, 0, 0, 0}, 1},
+  {GSTAMD_VIDEO_FORMAT_P010_10LE, "P010_10LE", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}, 2},
 };
 
 const FormatDesc *format_desc (int format)
@@ -97,6 +100,21 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
       uint64_t cr_h = round_up (height, 2) / 2;
       info->size = info->offset[1] + info->stride[0] * cr_h;
+      break;
+    }
+    case GSTAMD_VIDEO_FORMAT_I420_10LE: {       /* video-info.c:1142-1156 */
+      info->stride[0] = round_up (width * 2, 4);
+      info->stride[1] = info->stride[2] = round_up (width, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
+      uint64_t cr_h = round_up (height, 2) / 2;
+      info->offset[2] = info->offset[1] + info->stride[1] * cr_h;
+      info->size = info->offset[2] + info->stride[2] * cr_h;
+      break;
+    }
+    case GSTAMD_VIDEO_FORMAT_P010_10LE: {       /* video-info.c:1309-1321 */
+      info->stride[0] = info->stride[1] = round_up (width * 2, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
+      info->size = info->offset[1] + (uint64_t) info->stride[0] * (round_up (height, 2) / 2);
       break;
     }
     case GSTAMD_VIDEO_FORMAT_NV16:
@@ -260,34 +278,46 @@ static bool get_Kr_Kb (int matrix, double *Kr, double *Kb)
   }
 }
 
-/* gst_video_color_range_offsets for 8-bit AYUV / ARGB (video-color.c:204-252) */
-static void range_offsets (int range, bool yuv, int offset[3], int scale[3])
+/* gst_video_color_range_offsets for the unpack formats AYUV / ARGB (depth 8) and AYUV64 / ARGB64 (depth 16) (video-color.c:204-252) */
+static void range_offsets (int range, bool yuv, int offset[3], int scale[3], int depth = 8)
 {
   if (range == GSTAMD_COLOR_RANGE_16_235) {
-    offset[0] = 16;
-    scale[0] = 219;
+    offset[0] = 1 << (depth - 4);
+    scale[0] = 219 << (depth - 8);
     if (yuv) {
-      offset[1] = offset[2] = 128;
-      scale[1] = scale[2] = 224;
+      offset[1] = offset[2] = 1 << (depth - 1);
+      scale[1] = scale[2] = 224 << (depth - 8);
     } else {
-      offset[1] = offset[2] = 16;
-      scale[1] = scale[2] = 219;
+      offset[1] = offset[2] = 1 << (depth - 4);
+      scale[1] = scale[2] = 219 << (depth - 8);
     }
   } else {
     offset[0] = 0;
-    offset[1] = offset[2] = yuv ? 128 : 0;
-    scale[0] = scale[1] = scale[2] = 255;
+    offset[1] = offset[2] = yuv ? 1 << (depth - 1) : 0;
+    scale[0] = scale[1] = scale[2] = (1 << depth) - 1;
   }
 }
 
+static void compute_convert_matrix_depth (int in_range, int in_matrix, int out_range, int out_matrix, bool in_yuv, bool out_yuv,
+    int matrix_mode, int in_depth, double dm[4][4]);
+
 void compute_convert_matrix (const VideoPlan &, int in_range, int in_matrix, int out_range,
     int out_matrix, bool in_yuv, bool out_yuv, int matrix_mode, double dm[4][4])
+{
+  compute_convert_matrix_depth (in_range, in_matrix, out_range, out_matrix, in_yuv, out_yuv, matrix_mode, 8, dm);
+}
+
+/* chain_convert's "no gamma, combine all conversions into 1" (video-converter.c:1803-1830) for an input unpack format of in_depth
+ * bits and an 8-bit output: the input side's offsets / scales are those of the 16-bit unpack format, and with in_bits > out_bits the
+ * whole matrix is scaled by 1 << (in_bits - out_bits) so that it produces 16-bit values again */
+static void compute_convert_matrix_depth (int in_range, int in_matrix, int out_range, int out_matrix, bool in_yuv, bool out_yuv,
+    int matrix_mode, int in_depth, double dm[4][4])
 {
   int offset[3], scale[3];
   double Kr = 0, Kb = 0;
   m_identity (dm);
   /* compute_matrix_to_RGB (video-converter.c:1372-1402) */
-  range_offsets (in_range, in_yuv, offset, scale);
+  range_offsets (in_range, in_yuv, offset, scale, in_depth);
   m_offset_components (dm, -offset[0], -offset[1], -offset[2]);
   m_scale_components (dm, 1 / ((float) scale[0]), 1 / ((float) scale[1]), 1 / ((float) scale[2]));
   if (in_yuv && matrix_mode != GSTAMD_MATRIX_MODE_NONE) {
@@ -304,6 +334,10 @@ void compute_convert_matrix (const VideoPlan &, int in_range, int in_matrix, int
   range_offsets (out_range, out_yuv, offset, scale);
   m_scale_components (dm, (float) scale[0], (float) scale[1], (float) scale[2]);
   m_offset_components (dm, offset[0], offset[1], offset[2]);
+  if (in_depth > 8) {
+    const int up = 1 << (in_depth - 8);
+    m_scale_components (dm, (float) up, (float) up, (float) up);
+  }
 }
 
 /* prepare_matrix (video-converter.c:1323-1370) for current_bits == 8 */
@@ -1157,6 +1191,20 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   }
 
   const bool same_matrix = cfg.matrix_mode == GSTAMD_MATRIX_MODE_NONE ? true : in_matrix == out_matrix;
+  /* 10-bit sources: the reference unpacks them to AYUV64 and runs the chain on 16-bit lines until the convert stage narrows to
+   * the 8-bit pack format.  Built so far: the unscaled chain into a 4-byte 8-bit destination (decoder output -> display). */
+  plan->deep16 = plan->fin->hi_depth != 0;
+  if (plan->fout->hi_depth)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destinations are not implemented on the GPU path");
+  if (plan->deep16) {
+    if (plan->out_planar)
+      return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit source to a planar / 3-byte destination is not implemented on the GPU path");
+    if (in->width != out->width || in->height != out->height || plan->rect.in_x || plan->rect.in_y || plan->rect.out_x || plan->rect.out_y ||
+        plan->rect.fill || (plan->rect.in_maxw && (plan->rect.in_maxw != in->width || plan->rect.in_maxh != in->height)) ||
+        (plan->rect.out_maxw && (plan->rect.out_maxw != out->width || plan->rect.out_maxh != out->height)))
+      return fail (GSTAMD_ERR_UNSUPPORTED, "scaling / cropping / borders of a 10-bit source (u16 scalers, video-scaler.c:763-1106) are not "
+          "implemented on the GPU path");
+  }
   /* Fastpaths of the reference that are the generic chain with two decisions forced, reproduced by forcing them here:
    *  - convert_I420_BGRA / _ARGB / _pack_ARGB (:6772-6990) and convert_I420_AYUV / Y42B_AYUV / Y444_AYUV (:3563, ..):
    *    chroma is sampled nearest (row y >> 1, loadupdb), no interpolation;
@@ -1218,6 +1266,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   fr.chroma_h = CHROMA_H_NONE;
   fr.chroma_v2 = 0;
   fr.swap_k = in->format == GSTAMD_VIDEO_FORMAT_VYUY && (in->width & 1) ? (in->width - 1) >> 1 : -1;
+  fr.hi_depth = plan->fin->hi_depth;
   /* video_converter_compute_resample (:2850-2895) + gst_video_chroma_resample_new (video-chroma.c:1041-1109) */
   if (cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY
       && plan->fin->yuv) {
@@ -1290,7 +1339,26 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
 
   // ---- colour matrix (chain_convert :1719-1868) --------------------------------------------------
   memset (&plan->matrix, 0, sizeof (plan->matrix));
-  if (!same_matrix || force_ayuv_argb) {
+  memset (&plan->deep, 0, sizeof (plan->deep));
+  if (plan->deep16) {
+    /* chain_convert with in_bits 16, out_bits 8: the matrix (when the colour matrices differ) is prepared for current_bits 16 ->
+     * video_converter_matrix16 on integers rint (m * 256) (prepare_matrix :1323-1370); without it the stage only narrows */
+    if (!same_matrix) {
+      M44 dm;
+      compute_convert_matrix_depth (in->color_range, in_matrix, out->color_range, out_matrix, plan->fin->yuv, plan->fout->yuv, cfg.matrix_mode, 16, dm);
+      bool identity = true;
+      for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+          identity = identity && dm[i][j] == (i == j ? 1.0 : 0.0);
+      if (!identity) {
+        m_scale_components (dm, 256.0f, 256.0f, 256.0f);      /* SCALE_F */
+        plan->deep.has_matrix = 1;
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 4; j++)
+            plan->deep.im[i][j] = plan->im_raw[i][j] = (int) rint (dm[i][j]);
+      }
+    }
+  } else if (!same_matrix || force_ayuv_argb) {
     M44 dm;
     compute_convert_matrix (*plan, in->color_range, in_matrix, out->color_range, out_matrix, plan->fin->yuv,
         plan->fout->yuv, cfg.matrix_mode, dm);
@@ -1365,6 +1433,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     else {
       uint64_t cw = ((uint64_t) in_w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) in_h + (1 << f->h_sub) - 1) >> f->h_sub;
       rd = (uint64_t) in_w * in_h + 2 * cw * ch;
+      if (f->hi_depth)
+        rd *= 2;                /* 16-bit words */
     }
     uint64_t wr = (uint64_t) out_w * out_h * 4;
     if (plan->out_planar) {
@@ -1420,7 +1490,9 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         plan->fast_post = false;
     }
   }
-  std::string d = plan->passes.empty () ? (plan->fast_pair ? "fused_convert_pair" : plan->fast_enc420 ? "fused_encode_420" : plan->fast_422 ? "fused_convert_422" : plan->fast_420p ? "fused_convert_420p" : "fused_convert") : "scale";
+  if (plan->deep16)
+    plan->fast_pair = plan->fast_420p = plan->fast_422 = plan->fast_enc420 = plan->fast_post = false;
+  std::string d = plan->passes.empty () ? (plan->deep16 ? "convert16" : plan->fast_pair ? "fused_convert_pair" : plan->fast_enc420 ? "fused_encode_420" : plan->fast_422 ? "fused_convert_422" : plan->fast_420p ? "fused_convert_420p" : "fused_convert") : "scale";
   d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;
   d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : "";
   d += fr.chroma_v2 ? ",v2" : "";

@@ -34,6 +34,8 @@ struct FormatDesc {
   int u_plane, v_plane; // planar: plane index of U and V; semi: u_first (1) / v_first (0) in u_plane
   int pos[4];           // packed4 / packed3: memory byte index of unpacked component 0..3 (A,R,G,B / A,Y,U,V; packed3 has no A);
                         // packed422: byte of Y0, U, V inside the macropixel in pos[1..3] (Y1 is at pos[1] + 2)
+  int hi_depth;         // 0: 8-bit samples.  1 / 2: 10-bit samples in little-endian 16-bit words, in the low bits (I420_10LE) / the
+                        // high bits (P010_10LE); such formats unpack to AYUV64 in the reference (video-format.c:3836, 5331)
 };
 const FormatDesc *format_desc (int format);
 
@@ -65,6 +67,14 @@ struct FrontParams {    // unpack + chroma upsample of the source frame (functio
   int chroma_v2;        // 1: vertical 2x upsample through the pair table
   int swap_k;           // chroma sample whose U and V trade places, -1: none.  unpack_VYUY (video-format.c:346-352) reads the last
                         // pixel of an odd-width line in UYVY order
+  int hi_depth;         // FormatDesc::hi_depth: samples are 16-bit words widened to 16 significant bits (v << 6 | v >> 4, or v | v >> 10)
+};
+
+// the 16-bit chain (unpack to AYUV64 -> chroma upsample on u16 -> video_converter_matrix16 -> video_orc_convert_u16_to_u8):
+// what a 10-bit source takes on its way to an 8-bit destination (video-converter.c:1719-1868, 3096-3145)
+struct Deep16Params {
+  int has_matrix;       // 0: same matrix on both sides, the stage only narrows 16 -> 8 bits
+  int im[3][4];         // video_converter_matrix16's integer matrix (8 fractional bits; im[k][3] the offset)
 };
 
 // planar / semi-planar destination: chroma downsample (video-chroma.c) + pack (video-format.c pack_planar_420 / pack_NV12 /
@@ -177,6 +187,8 @@ struct VideoPlan {
   bool fast_420p;             // unscaled planar 4:2:0 -> 4-byte RGB with nearest chroma (the reference's convert_I420_BGRA family): video_422_fast.h
   bool fast_422;              // unscaled packed 4:2:2 -> 4-byte RGB through the no-wrap AYUV_ARGB matrix: video_422_fast.h applies
   bool fast_post;             // scaled plans: the post stage may run fast_pixel (matrix provably wrap-free, alpha stays 0xff)
+  bool deep16;                // 10-bit source, unscaled, 8-bit 4-byte destination: k_convert16 (video_deep.h)
+  Deep16Params deep;
   int im_raw[3][4];           // the rint()ed 8-bit matrix before the per-kind adjustments
   std::string ref_fastpath;   // name of the reference fastpath this plan reproduces (empty: generic chain)
   std::string description;

@@ -15,6 +15,9 @@ namespace gstamd {
 hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color,
     const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream);
 
+hipError_t launch_convert16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const Deep16Params &d, const PostParams &post, uint8_t *dst,
+    int dstride, hipStream_t stream);
+
 struct FastParams;
 hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames, const uint8_t *const *y, const uint8_t *const *uv,
     uint8_t *const *dst, int ystride, int uvstride, int dstride, hipStream_t stream);

@@ -19,6 +19,7 @@
 #include "video_bilinear_fast.h"
 #include "video_encode_fast.h"
 #include "video_planes.h"
+#include "video_deep.h"
 
 namespace gstamd {
 
@@ -28,6 +29,21 @@ __global__ __launch_bounds__ (256) void k_convert (FrontParams f, Planes pl, con
 {
   convert_body<CH> (f, pl, vpair, color, pack0, pack1, pack2, pack3, dst, dstride, spans_per_row, vec_ok,
       (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+// the 16-bit chain of a 10-bit source into an 8-bit 4-byte destination (video_deep.h): a lane = 4 pixels of one row
+__global__ __launch_bounds__ (256) void k_convert16 (FrontParams f, Planes pl, const int *__restrict__ vpair, Deep16Params d, PostParams post,
+    uint8_t *__restrict__ dst, int dstride)
+{
+  convert16_lane4 (f, pl, vpair, d, post, dst, dstride, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
+}
+
+hipError_t launch_convert16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const Deep16Params &d, const PostParams &post, uint8_t *dst,
+    int dstride, hipStream_t stream)
+{
+  dim3 grid ((f.width / 4 + 256) / 256, f.height);
+  hipLaunchKernelGGL (k_convert16, grid, dim3 (256), 0, stream, f, pl, vpair_dev, d, post, dst, dstride);
+  return hipGetLastError ();
 }
 
 // up to 16 independent frames of one format per launch (blockIdx.z = frame): amortises launch ramp/tail

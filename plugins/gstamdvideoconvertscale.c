@@ -33,14 +33,17 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 
 #define AMD_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR }"
 #define AMD_OUT_FORMATS AMD_FORMATS
+/* 10-bit sources (decoder output) run the reference's 16-bit chain (video_deep.h): unscaled, into an 8-bit 4-byte destination;
+ * everything else about them makes set_caps fail (not-negotiated) */
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE }"
 
 /* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path
  * (video-converter.c:3304, 3383-3463), so interlaced caps are not negotiated rather than converted as if progressive
  * (caps without the field are progressive by definition) */
 #define AMD_PROGRESSIVE ", interlace-mode=(string)progressive"
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_FORMATS) AMD_PROGRESSIVE ";"
-        GST_VIDEO_CAPS_MAKE (AMD_FORMATS) AMD_PROGRESSIVE));
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_IN_FORMATS) AMD_PROGRESSIVE ";"
+        GST_VIDEO_CAPS_MAKE (AMD_IN_FORMATS) AMD_PROGRESSIVE));
 static GstStaticPadTemplate src_tmpl = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
     GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_OUT_FORMATS) AMD_PROGRESSIVE ";"
         GST_VIDEO_CAPS_MAKE (AMD_OUT_FORMATS) AMD_PROGRESSIVE));
@@ -623,6 +626,7 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_YVYU, GSTAMD_VIDEO_FORMAT_YVYU}, {GST_VIDEO_FORMAT_VYUY, GSTAMD_VIDEO_FORMAT_VYUY},
     {GST_VIDEO_FORMAT_RGB, GSTAMD_VIDEO_FORMAT_RGB},
     {GST_VIDEO_FORMAT_BGR, GSTAMD_VIDEO_FORMAT_BGR},
+    {GST_VIDEO_FORMAT_P010_10LE, GSTAMD_VIDEO_FORMAT_P010_10LE}, {GST_VIDEO_FORMAT_I420_10LE, GSTAMD_VIDEO_FORMAT_I420_10LE},
   };
   int fmt = 0;
   for (i = 0; i < G_N_ELEMENTS (map); i++)

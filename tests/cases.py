@@ -307,6 +307,17 @@ VIDEO_CASES = [
     ("nv61_nv61_down_bilinear_planes", "NV61", 320, 240, "NV61", 200, 100, LIN, None, None, "random"),
     ("nv16_i420_64x48", "NV16", 64, 48, "I420", 64, 48, {}, None, None, "random"),
     ("nv12_i420_border_full_frame_resample_rule", "NV12", 64, 48, "I420", 80, 60, dict(dest_x=8, dest_y=4, dest_width=64, dest_height=48, border_argb=0xff336699), None, None, "random"),
+    # ---- 10-bit sources through the 16-bit chain (unpack to AYUV64, u16 chroma upsampling, matrix16, narrow to 8 bits) ----
+    ("p010_bgra_64x36", "P010_10LE", 64, 36, "BGRA", 64, 36, {}, None, None, "random"),
+    ("p010_rgba_1080p", "P010_10LE", 1920, 1080, "RGBA", 1920, 1080, {}, None, None, "random"),
+    ("p010_argb_bt2020", "P010_10LE", 322, 242, "ARGB", 322, 242, {}, "bt2020", None, "random"),
+    ("p010_ayuv_same_matrix", "P010_10LE", 130, 50, "AYUV", 130, 50, {}, None, None, "random"),
+    ("p010_bgra_jpeg_site_odd", "P010_10LE", 33, 17, "BGRA", 33, 17, {}, "bt601", "jpeg", "random"),
+    ("p010_argb_alpha_set", "P010_10LE", 64, 36, "ARGB", 64, 36, dict(alpha_mode="set", alpha_value=0.5), None, None, "ramp"),
+    ("i42010_bgra_64x36", "I420_10LE", 64, 36, "BGRA", 64, 36, {}, None, None, "random"),
+    ("i42010_abgr_720p", "I420_10LE", 1280, 720, "ABGR", 1280, 720, {}, None, None, "random"),
+    ("i42010_rgbx_cosited_odd", "I420_10LE", 35, 19, "RGBx", 35, 19, {}, "bt709", "cosited", "random"),
+    ("i42010_ayuv_none_site", "I420_10LE", 66, 34, "AYUV", 66, 34, {}, "bt601", "none", "checker"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd

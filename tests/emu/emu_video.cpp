@@ -20,6 +20,7 @@
 #include "../../gstreamer_amd/csrc/video_bilinear_fast.h"
 #include "../../gstreamer_amd/csrc/video_planes.h"
 #include "../../gstreamer_amd/csrc/video_encode_fast.h"
+#include "../../gstreamer_amd/csrc/video_deep.h"
 
 using namespace gstamd;
 
@@ -842,6 +843,12 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     for (int y = 0; y < p.front.height; y++)
       for (int x0 = 0; x0 < p.front.width; x0 += 8)
         convert422_lane8_any (q, pl.p[0] + (size_t) y * pl.stride[0], d0 + (size_t) y * dstride, x0);
+    return GSTAMD_OK;
+  }
+  if (p.deep16) {                          /* k_convert16 */
+    for (int y = 0; y < p.front.height; y++)
+      for (int x0 = 0; x0 < p.front.width; x0 += 4)
+        convert16_lane4 (p.front, pl, vpair, p.deep, p.post, d0, dstride, x0, y);
     return GSTAMD_OK;
   }
   if (p.passes.empty ()) {

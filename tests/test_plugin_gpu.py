@@ -441,3 +441,19 @@ def test_fixate_caps_keeps_the_display_aspect_ratio_like_the_reference(gst_env, 
     assert "width=(int)%d" % w in caps and "height=(int)%d" % h in caps, caps
     m = re.search(r"pixel-aspect-ratio=\(fraction\)(\d+/\d+)", caps)
     assert (m.group(1) if m else "1/1") == par, caps
+
+
+def test_p010_decoder_output_to_bgra_through_the_element(gst_env, ref):
+    """A 10-bit source through the element: P010_10LE frames (videotestsrc's, converted by the stock videoconvert) ->
+    videoconvertscale -> BGRA equals the reference's 16-bit chain (unpack to AYUV64, u16 chroma upsampling, matrix16, narrow)."""
+    env, tmp = gst_env
+    w, h, n = 320, 240, 2
+    fin, fout = tmp / "p010_in.raw", tmp / "p010_out.bgra"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=P010_10LE,width=%d,height=%d,colorimetry=bt709,chroma-site=mpeg2 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw,format=BGRA ! filesink location=%s"
+           % (n, w, h, fin, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    rc = ref.VideoConverter("P010_10LE", w, h, "BGRA", w, h, in_colorimetry="bt709", in_chroma_site="mpeg2")
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), i

@@ -13,15 +13,19 @@
  * needs.  All pads of one frame go to the GPU in ONE fused kernel launch (gstamd_compositor_aggregate): every canvas
  * pixel is written once, where the reference read-modify-writes the canvas once per pad.
  *
- * Simplifications kept honest: every aggregate() consumes one buffer from each pad that has one (lock-step, no
- * timestamp-based frame selection / repeat as in gstvideoaggregator.c:1700-2000); pads of another format or with
- * width / height properties are converted / scaled individually by a per-pad GstAmdVideoConverter with the library's
- * default config (what GstVideoAggregatorConvertPad does), assuming equal pixel aspect ratios; sizing-policy,
- * zero-size-is-unscaled, converter-config, max-threads and ignore-inactive-pads are not implemented.
+ * What of GstVideoAggregator is here: frame selection by running time (a pad shows the queued frame that overlaps the output
+ * frame's interval, older ones are dropped, a slower pad's frame is repeated; gstvideoaggregator.c:1753-2000), repeat-after-eos,
+ * the pads' output size with sizing-policy and zero-size-is-unscaled and the pixel-aspect-ratio rules of
+ * _mixer_pad_get_output_size (compositor.c:290-412), and the visibility rules of prepare_frame_start (compositor.c:464-601):
+ * frames with alpha 0, off the canvas or fully under an opaque pad never reach the GPU.  Pads of another format or size are
+ * converted / scaled by a per-pad GstAmdVideoConverter with the library's default config (GstVideoAggregatorConvertPad).
+ * Not here: converter-config, QoS and the latency bookkeeping of the base class; max-threads, ignore-inactive-pads and
+ * max-last-buffer-repeat are accepted and have no effect.
  */
 #include <gst/base/gstaggregator.h>
 #include <gst/gst.h>
 #include <gst/video/video.h>
+#include <gst/video/gstvideosink.h>
 #include <string.h>
 
 #include "../include/gstamd_video.h"
@@ -51,8 +55,14 @@ typedef struct {
   gdouble alpha;
   gint op;                     /* GstCompositorOperator: 0 source, 1 over, 2 add */
   guint zorder;
+  gint sizing_policy;          /* GstCompositorSizingPolicy: 0 none, 1 keep-aspect-ratio (compositor.c:207-232) */
+  gboolean repeat_after_eos;   /* GstVideoAggregatorPad: keep showing the last frame after EOS (gstvideoaggregator.c:166-176) */
+  guint64 max_last_buffer_repeat;
   GstVideoInfo info;
   gboolean have_info;
+  /* frame selection by running time (gst_video_aggregator_fill_queues, gstvideoaggregator.c:1753-2000) */
+  GstBuffer *current;          /* the frame this pad shows now */
+  GstClockTime cur_start, cur_end;     /* its running-time interval (end NONE: until replaced) */
   gpointer staging;            /* device copy of a system-memory input frame */
   gsize staging_size;
   /* per-pad conversion (format and / or size): converter, its key, its device output frame */
@@ -65,7 +75,8 @@ typedef struct {
 
 typedef struct { GstAggregatorPadClass parent_class; } GstAmdCompositorPadObjClass;
 
-enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_ZORDER };
+enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_ZORDER,
+  PAD_PROP_SIZING_POLICY, PAD_PROP_REPEAT_AFTER_EOS, PAD_PROP_MAX_LAST_BUFFER_REPEAT };
 
 G_DEFINE_TYPE (GstAmdCompositorPadObj, gst_amd_compositor_pad, GST_TYPE_AGGREGATOR_PAD);
 #define AMD_COMP_PAD(o) ((GstAmdCompositorPadObj *) (o))
@@ -104,6 +115,9 @@ amd_comp_pad_set_property (GObject * object, guint id, const GValue * value, GPa
     case PAD_PROP_ALPHA: p->alpha = g_value_get_double (value); break;
     case PAD_PROP_OPERATOR: p->op = g_value_get_enum (value); break;
     case PAD_PROP_ZORDER: p->zorder = g_value_get_uint (value); break;
+    case PAD_PROP_SIZING_POLICY: p->sizing_policy = g_value_get_enum (value); break;
+    case PAD_PROP_REPEAT_AFTER_EOS: p->repeat_after_eos = g_value_get_boolean (value); break;
+    case PAD_PROP_MAX_LAST_BUFFER_REPEAT: p->max_last_buffer_repeat = g_value_get_uint64 (value); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (p);
@@ -122,6 +136,9 @@ amd_comp_pad_get_property (GObject * object, guint id, GValue * value, GParamSpe
     case PAD_PROP_ALPHA: g_value_set_double (value, p->alpha); break;
     case PAD_PROP_OPERATOR: g_value_set_enum (value, p->op); break;
     case PAD_PROP_ZORDER: g_value_set_uint (value, p->zorder); break;
+    case PAD_PROP_SIZING_POLICY: g_value_set_enum (value, p->sizing_policy); break;
+    case PAD_PROP_REPEAT_AFTER_EOS: g_value_set_boolean (value, p->repeat_after_eos); break;
+    case PAD_PROP_MAX_LAST_BUFFER_REPEAT: g_value_set_uint64 (value, p->max_last_buffer_repeat); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (p);
@@ -135,13 +152,23 @@ amd_comp_pad_finalize (GObject * object)
   gstamd_device_free (p->conv_buf);
   if (p->conv)
     gstamd_video_converter_free (p->conv);
+  gst_buffer_replace (&p->current, NULL);
   G_OBJECT_CLASS (gst_amd_compositor_pad_parent_class)->finalize (object);
+}
+
+static GstFlowReturn
+amd_comp_pad_flush (GstAggregatorPad * pad, GstAggregator * agg)
+{
+  (void) agg;
+  gst_buffer_replace (&AMD_COMP_PAD (pad)->current, NULL);
+  return GST_FLOW_OK;
 }
 
 static void
 gst_amd_compositor_pad_class_init (GstAmdCompositorPadObjClass * klass)
 {
   GObjectClass *oc = (GObjectClass *) klass;
+  ((GstAggregatorPadClass *) klass)->flush = amd_comp_pad_flush;
   const GParamFlags f = G_PARAM_READWRITE | GST_PARAM_CONTROLLABLE | G_PARAM_STATIC_STRINGS;
   oc->set_property = amd_comp_pad_set_property;
   oc->get_property = amd_comp_pad_get_property;
@@ -155,6 +182,20 @@ gst_amd_compositor_pad_class_init (GstAmdCompositorPadObjClass * klass)
   g_object_class_install_property (oc, PAD_PROP_OPERATOR, g_param_spec_enum ("operator", "Operator",
           "Blending operator to use for blending this pad over the previous ones", amd_comp_operator_get_type (), 1, f));
   g_object_class_install_property (oc, PAD_PROP_ZORDER, g_param_spec_uint ("zorder", "Z-Order", "Z Order of the picture", 0, G_MAXUINT, 0, f));
+  {
+    static const GEnumValue sp[] = { {0, "None: Image is scaled to fill configured destination rectangle without padding or keeping the aspect ratio", "none"},
+      {1, "Keep Aspect Ratio: Image is scaled to fit destination rectangle specified by GstCompositorPad:{xpos, ypos, width, height} "
+            "with preserved aspect ratio", "keep-aspect-ratio"}, {0, NULL, NULL} };
+    GType t = g_type_from_name ("GstAmdCompositorSizingPolicy");
+    if (!t)
+      t = g_enum_register_static ("GstAmdCompositorSizingPolicy", sp);
+    g_object_class_install_property (oc, PAD_PROP_SIZING_POLICY, g_param_spec_enum ("sizing-policy", "Sizing policy",
+            "Sizing policy to use for image scaling", t, 0, f));
+  }
+  g_object_class_install_property (oc, PAD_PROP_REPEAT_AFTER_EOS, g_param_spec_boolean ("repeat-after-eos", "Repeat After EOS",
+          "Repeat the last frame after EOS until all pads are EOS", FALSE, f));
+  g_object_class_install_property (oc, PAD_PROP_MAX_LAST_BUFFER_REPEAT, g_param_spec_uint64 ("max-last-buffer-repeat", "Max Last Buffer Repeat",
+          "Repeat last buffer for time (in ns, -1=until EOS), behaviour on EOS is not affected", 0, G_MAXUINT64, G_MAXUINT64, f));
 }
 
 static void
@@ -165,7 +206,12 @@ gst_amd_compositor_pad_init (GstAmdCompositorPadObj * p)
   p->alpha = 1.0;
   p->op = 1;
   p->zorder = 0;
+  p->sizing_policy = 0;
+  p->repeat_after_eos = FALSE;
+  p->max_last_buffer_repeat = G_MAXUINT64;
   p->have_info = FALSE;
+  p->current = NULL;
+  p->cur_start = p->cur_end = GST_CLOCK_TIME_NONE;
 }
 
 /* ---- element -------------------------------------------------------------------------------------------- */
@@ -181,11 +227,15 @@ typedef struct {
   gpointer stream;             /* this instance's HIP stream (SURVEY 8b Threading); buffers are ordered by the tickets of gstamdhipmemory.h */
   gint device_id;              /* device-id property: -1 = the process's current device */
   guint next_pad;
+  gboolean zero_size_is_unscaled;      /* compositor.c:2131: width / height 0 mean "unscaled" (TRUE) or "invisible" (FALSE) */
+  gboolean ignore_inactive_pads;       /* accepted (GstAggregator's inactive-pad tracking does not exist in this runtime) */
+  guint max_threads;                   /* accepted; the GPU grid replaces the blend thread pool */
+  guint64 n_culled;                    /* pad frames left out because nothing of them can be seen (culled-frames, read-only) */
 } GstAmdCompositor;
 
 typedef struct { GstAggregatorClass parent_class; } GstAmdCompositorClass;
 
-enum { PROP_0, PROP_BACKGROUND, PROP_DEVICE_ID };
+enum { PROP_0, PROP_BACKGROUND, PROP_DEVICE_ID, PROP_ZERO_SIZE_IS_UNSCALED, PROP_MAX_THREADS, PROP_IGNORE_INACTIVE_PADS, PROP_CULLED_FRAMES };
 
 /* GstChildProxy (as gstvideoaggregator.c does): lets `sink_1::xpos=..` address pad properties from gst-launch */
 static GObject *
@@ -301,13 +351,72 @@ amd_fill_info (const GstVideoInfo * vi, int w, int h, int fmt, GstAmdVideoInfo *
   return TRUE;
 }
 
-/* size the pad's picture takes on the canvas: the width / height properties, else the frame size (_mixer_pad_get_output_size
- * of compositor.c:290-400 for equal pixel aspect ratios and sizing-policy none) */
+/* Size and in-rectangle offset of the pad's picture on the canvas: _mixer_pad_get_output_size (compositor.c:290-412).  The width /
+ * height properties (or the frame size), corrected for the pixel aspect ratios of pad and canvas; sizing-policy none stretches the
+ * picture over that rectangle (preferring to keep the height), keep-aspect-ratio fits it inside, centred. */
+static void
+amd_comp_pad_output_size (gboolean zero_is_unscaled, GstAmdCompositorPadObj * p, gint out_par_n, gint out_par_d, gint * width, gint * height,
+    gint * x_off, gint * y_off)
+{
+  const gint fw = GST_VIDEO_INFO_WIDTH (&p->info), fh = GST_VIDEO_INFO_HEIGHT (&p->info);
+  const gint pn = GST_VIDEO_INFO_PAR_N (&p->info), pd = GST_VIDEO_INFO_PAR_D (&p->info);
+  gint pw, ph;
+  guint dar_n, dar_d;
+
+  *width = *height = *x_off = *y_off = 0;
+  if (!p->have_info)
+    return;
+  pw = zero_is_unscaled ? (p->width <= 0 ? fw : p->width) : (p->width < 0 ? fw : p->width);
+  ph = zero_is_unscaled ? (p->height <= 0 ? fh : p->height) : (p->height < 0 ? fh : p->height);
+  if (pw == 0 || ph == 0)
+    return;
+  if (!gst_video_calculate_display_ratio (&dar_n, &dar_d, pw, ph, pn, pd, out_par_n, out_par_d))
+    return;
+  if (p->sizing_policy == 0) {
+    if (ph % dar_n == 0)
+      pw = gst_util_uint64_scale_int (ph, dar_n, dar_d);
+    else if (pw % dar_d == 0)
+      ph = gst_util_uint64_scale_int (pw, dar_d, dar_n);
+    else
+      pw = gst_util_uint64_scale_int (ph, dar_n, dar_d);
+  } else {
+    gint from_n, from_d, to_n, to_d, num, den;
+    if (!gst_util_fraction_multiply (fw, fh, pn, pd, &from_n, &from_d))
+      from_n = from_d = -1;
+    if (!gst_util_fraction_multiply (pw, ph, out_par_n, out_par_d, &to_n, &to_d))
+      to_n = to_d = -1;
+    if (from_n != to_n || from_d != to_d) {
+      if (from_n != -1 && from_d != -1 && gst_util_fraction_multiply (from_n, from_d, out_par_d, out_par_n, &num, &den)) {
+        GstVideoRectangle src, dst, res;
+        src.x = src.y = 0;
+        src.w = pw;
+        src.h = gst_util_uint64_scale_int (pw, den, num);
+        if (src.h == 0)
+          return;
+        dst.x = dst.y = 0;
+        dst.w = pw;
+        dst.h = ph;
+        gst_video_sink_center_rect (src, dst, &res, TRUE);
+        *x_off = res.x;
+        *y_off = res.y;
+        pw = res.w;
+        ph = res.h;
+      } else {
+        return;
+      }
+    }
+  }
+  *width = pw;
+  *height = ph;
+}
+
 static void
 amd_comp_pad_target_size (GstAmdCompositorPadObj * p, gint * w, gint * h)
 {
-  *w = p->width > 0 ? p->width : GST_VIDEO_INFO_WIDTH (&p->info);
-  *h = p->height > 0 ? p->height : GST_VIDEO_INFO_HEIGHT (&p->info);
+  gint xo, yo;
+  GstAmdCompositor *c = GST_OBJECT_PARENT (p) ? (GstAmdCompositor *) GST_OBJECT_PARENT (p) : NULL;
+  amd_comp_pad_output_size (c ? c->zero_size_is_unscaled : TRUE, p, c && c->have_out ? GST_VIDEO_INFO_PAR_N (&c->out_info) : 1,
+      c && c->have_out ? GST_VIDEO_INFO_PAR_D (&c->out_info) : 1, w, h, &xo, &yo);
 }
 
 static void
@@ -317,6 +426,12 @@ amd_comp_set_property (GObject * object, guint id, const GValue * value, GParamS
     AMD_COMP (object)->background = g_value_get_enum (value);
   else if (id == PROP_DEVICE_ID)
     AMD_COMP (object)->device_id = g_value_get_int (value);
+  else if (id == PROP_ZERO_SIZE_IS_UNSCALED)
+    AMD_COMP (object)->zero_size_is_unscaled = g_value_get_boolean (value);
+  else if (id == PROP_MAX_THREADS)
+    AMD_COMP (object)->max_threads = g_value_get_uint (value);
+  else if (id == PROP_IGNORE_INACTIVE_PADS)
+    AMD_COMP (object)->ignore_inactive_pads = g_value_get_boolean (value);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
 }
@@ -328,6 +443,14 @@ amd_comp_get_property (GObject * object, guint id, GValue * value, GParamSpec * 
     g_value_set_enum (value, AMD_COMP (object)->background);
   else if (id == PROP_DEVICE_ID)
     g_value_set_int (value, AMD_COMP (object)->device_id);
+  else if (id == PROP_ZERO_SIZE_IS_UNSCALED)
+    g_value_set_boolean (value, AMD_COMP (object)->zero_size_is_unscaled);
+  else if (id == PROP_MAX_THREADS)
+    g_value_set_uint (value, AMD_COMP (object)->max_threads);
+  else if (id == PROP_IGNORE_INACTIVE_PADS)
+    g_value_set_boolean (value, AMD_COMP (object)->ignore_inactive_pads);
+  else if (id == PROP_CULLED_FRAMES)
+    g_value_set_uint64 (value, AMD_COMP (object)->n_culled);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
 }
@@ -527,6 +650,80 @@ ensure_device (gpointer * p, gsize * have, gsize need)
   return *p != NULL;
 }
 
+/* Which queued frame does the pad show during the output frame [out_start, out_end) (running time)?  The rule of
+ * gst_video_aggregator_fill_queues (gstvideoaggregator.c:1753-2000): frames that ended before the output frame starts are dropped,
+ * a frame that starts at or after its end stays queued (the pad keeps showing what it shows), anything else becomes the pad's
+ * current frame and stays that until replaced - a 15 fps pad under a 30 fps output is shown twice.  After EOS the last frame stays
+ * only with repeat-after-eos.  FALSE: the pad has nothing queued, is not EOS and its current frame does not reach out_end -
+ * the aggregator has to wait for data. */
+static gboolean
+amd_comp_pad_select (GstAmdCompositorPadObj * p, GstClockTime out_start, GstClockTime out_end, gboolean * is_eos)
+{
+  GstAggregatorPad *ap = GST_AGGREGATOR_PAD (p);
+
+  *is_eos = FALSE;
+  for (;;) {
+    GstBuffer *b = gst_aggregator_pad_peek_buffer (ap);
+    GstClockTime start, end = GST_CLOCK_TIME_NONE;
+
+    if (!b) {
+      if (gst_aggregator_pad_is_eos (ap)) {
+        /* the last frame is shown until it ends; after that only with repeat-after-eos (which never ends the stream by itself) */
+        if (p->current && !p->repeat_after_eos && GST_CLOCK_TIME_IS_VALID (p->cur_end) && p->cur_end > out_start)
+          return TRUE;
+        *is_eos = TRUE;
+        if (!p->repeat_after_eos)
+          gst_buffer_replace (&p->current, NULL);
+        return TRUE;
+      }
+      /* an untimed frame is used once; a frame without a duration ends where the next one starts, which is not known yet */
+      return p->current && GST_CLOCK_TIME_IS_VALID (p->cur_end) && p->cur_end >= out_end;
+    }
+    if (!GST_BUFFER_PTS_IS_VALID (b)) {         /* untimed: shown as it comes */
+      gst_buffer_replace (&p->current, b);
+      p->cur_start = p->cur_end = GST_CLOCK_TIME_NONE;
+      gst_buffer_unref (b);
+      gst_aggregator_pad_drop_buffer (ap);
+      return TRUE;
+    }
+    start = gst_segment_to_running_time (&ap->segment, GST_FORMAT_TIME, GST_BUFFER_PTS (b));
+    if (GST_BUFFER_DURATION_IS_VALID (b))
+      end = gst_segment_to_running_time (&ap->segment, GST_FORMAT_TIME, GST_BUFFER_PTS (b) + GST_BUFFER_DURATION (b));
+    if (!GST_CLOCK_TIME_IS_VALID (start)) {     /* outside the segment */
+      gst_buffer_unref (b);
+      gst_aggregator_pad_drop_buffer (ap);
+      continue;
+    }
+    if (GST_CLOCK_TIME_IS_VALID (end) && end <= out_start) {    /* over before this output frame begins */
+      gst_buffer_unref (b);
+      gst_aggregator_pad_drop_buffer (ap);
+      continue;
+    }
+    if (start >= out_end) {                     /* belongs to a later output frame */
+      gst_buffer_unref (b);
+      return p->current != NULL || start >= out_end;
+    }
+    gst_buffer_replace (&p->current, b);
+    p->cur_start = start;
+    p->cur_end = end;
+    gst_buffer_unref (b);
+    gst_aggregator_pad_drop_buffer (ap);
+    return TRUE;
+  }
+}
+
+/* rectangle (x, y, w, h) clamped to the canvas (clamp_rectangle, compositor.c:441-459) */
+static GstVideoRectangle
+amd_comp_clamp (gint x, gint y, gint w, gint h, gint cw, gint ch)
+{
+  GstVideoRectangle r;
+  r.x = CLAMP (x, 0, cw);
+  r.y = CLAMP (y, 0, ch);
+  r.w = CLAMP (x + w, 0, cw) - r.x;
+  r.h = CLAMP (y + h, 0, ch) - r.y;
+  return r;
+}
+
 static GstFlowReturn
 amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
 {
@@ -547,6 +744,8 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
   const int fmt = amd_format_of (GST_VIDEO_INFO_FORMAT (&c->out_info));
   const gboolean by_planes = !GST_VIDEO_INFO_HAS_ALPHA (&c->out_info);
   GstAmdCompositorFramePad fdesc[AMD_COMP_MAX_PADS];
+  gint pad_w[AMD_COMP_MAX_PADS], pad_h[AMD_COMP_MAX_PADS], pad_x[AMD_COMP_MAX_PADS], pad_y[AMD_COMP_MAX_PADS];
+  guint n_culled = 0;
   int r;
 
   if (!c->have_out)
@@ -564,16 +763,73 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
   GST_OBJECT_UNLOCK (agg);
   qsort (pads, n, sizeof (pads[0]), pad_zorder_cmp);
 
-  for (i = 0; i < n; i++) {
-    bufs[i] = gst_aggregator_pad_pop_buffer (GST_AGGREGATOR_PAD (pads[i]));
-    if (bufs[i] || !gst_aggregator_pad_is_eos (GST_AGGREGATOR_PAD (pads[i])))
-      all_eos = FALSE;
+  {
+    /* the output frame's running-time interval: frame counter at the output framerate, from running time 0 */
+    const guint64 fn = GST_VIDEO_INFO_FPS_N (&c->out_info) > 0 ? GST_VIDEO_INFO_FPS_N (&c->out_info) : 25;
+    const guint64 fd = GST_VIDEO_INFO_FPS_N (&c->out_info) > 0 ? GST_VIDEO_INFO_FPS_D (&c->out_info) : 1;
+    const GstClockTime out_start = gst_util_uint64_scale (c->n_frames, fd * GST_SECOND, fn);
+    const GstClockTime out_end = gst_util_uint64_scale (c->n_frames + 1, fd * GST_SECOND, fn);
+    gboolean need_data = FALSE;
+    for (i = 0; i < n; i++) {
+      gboolean eos = FALSE;
+      if (!amd_comp_pad_select (pads[i], out_start, out_end, &eos) && !timeout)
+        need_data = TRUE;
+      if (!eos)
+        all_eos = FALSE;
+    }
+    if (need_data && !all_eos) {
+      for (i = 0; i < n; i++)
+        gst_object_unref (pads[i]);
+      return GST_AGGREGATOR_FLOW_NEED_DATA;
+    }
+    for (i = 0; i < n; i++)
+      bufs[i] = pads[i]->current ? gst_buffer_ref (pads[i]->current) : NULL;
   }
   GST_LOG_OBJECT (c, "aggregate: %u pads, all_eos %d, timeout %d", n, all_eos, timeout);
   if (all_eos) {
-    for (i = 0; i < n; i++)
+    for (i = 0; i < n; i++) {
+      gst_buffer_replace (&bufs[i], NULL);
       gst_object_unref (pads[i]);
+    }
     return GST_FLOW_EOS;
+  }
+
+  /* where each pad lands, and which pads cannot be seen at all (_should_draw_background / prepare_frame_start,
+   * compositor.c:464-601): alpha 0, nothing left after clamping to the canvas, or fully under an opaque pad above */
+  {
+    const gint cw = GST_VIDEO_INFO_WIDTH (&c->out_info), ch = GST_VIDEO_INFO_HEIGHT (&c->out_info);
+    const gint opn = GST_VIDEO_INFO_PAR_N (&c->out_info), opd = GST_VIDEO_INFO_PAR_D (&c->out_info);
+    for (i = 0; i < n; i++) {
+      gint xo = 0, yo = 0;
+      pad_w[i] = pad_h[i] = pad_x[i] = pad_y[i] = 0;
+      if (!bufs[i] || !pads[i]->have_info)
+        continue;
+      amd_comp_pad_output_size (c->zero_size_is_unscaled, pads[i], opn, opd, &pad_w[i], &pad_h[i], &xo, &yo);
+      pad_x[i] = pads[i]->xpos + xo;
+      pad_y[i] = pads[i]->ypos + yo;
+    }
+    for (i = 0; i < n; i++) {
+      GstVideoRectangle fr;
+      guint j;
+      if (!bufs[i] || !pads[i]->have_info)
+        continue;
+      fr = amd_comp_clamp (pad_x[i], pad_y[i], pad_w[i], pad_h[i], cw, ch);
+      if (pads[i]->alpha == 0.0 || pad_w[i] <= 0 || pad_h[i] <= 0 || fr.w <= 0 || fr.h <= 0) {
+        gst_buffer_replace (&bufs[i], NULL);
+        n_culled++;
+        continue;
+      }
+      for (j = i + 1; j < n; j++) {
+        if (!pads[j]->current || !pads[j]->have_info || pads[j]->alpha != 1.0 || GST_VIDEO_INFO_HAS_ALPHA (&pads[j]->info))
+          continue;
+        if (pad_x[j] <= fr.x && pad_y[j] <= fr.y && pad_x[j] + pad_w[j] >= fr.x + fr.w && pad_y[j] + pad_h[j] >= fr.y + fr.h) {
+          gst_buffer_replace (&bufs[i], NULL);
+          n_culled++;
+          break;
+        }
+      }
+    }
+    c->n_culled += n_culled;
   }
 
   /* pads -> device pointers */
@@ -610,7 +866,8 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
     {
       gint tw, th, k;
       const int ifmt = amd_pad_format_of (GST_VIDEO_INFO_FORMAT (&p->info));
-      amd_comp_pad_target_size (p, &tw, &th);
+      tw = pad_w[i];
+      th = pad_h[i];
       if (ifmt != fmt || tw != GST_VIDEO_INFO_WIDTH (&p->info) || th != GST_VIDEO_INFO_HEIGHT (&p->info)) {
         /* GstVideoAggregatorConvertPad: library-default converter config (cubic), pad format / size -> canvas format / target size */
         const gint key[6] = { ifmt, GST_VIDEO_INFO_WIDTH (&p->info), GST_VIDEO_INFO_HEIGHT (&p->info), fmt, tw, th };
@@ -662,15 +919,15 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
         }
       }
     }
-    desc[n_desc].xpos = p->xpos;
-    desc[n_desc].ypos = p->ypos;
+    desc[n_desc].xpos = pad_x[i];
+    desc[n_desc].ypos = pad_y[i];
     desc[n_desc].alpha = p->alpha;
     desc[n_desc].blend_mode = p->op;
     desc[n_desc].reserved = 0;
     fdesc[n_desc].width = desc[n_desc].width;
     fdesc[n_desc].height = desc[n_desc].height;
-    fdesc[n_desc].xpos = p->xpos;
-    fdesc[n_desc].ypos = p->ypos;
+    fdesc[n_desc].xpos = pad_x[i];
+    fdesc[n_desc].ypos = pad_y[i];
     fdesc[n_desc].alpha = p->alpha;
     fdesc[n_desc].blend_mode = p->op;
     n_desc++;
@@ -751,6 +1008,8 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
 
 done_inputs:
   for (i = 0; i < n; i++) {
+    if (pads[i]->current && !GST_CLOCK_TIME_IS_VALID (pads[i]->cur_start))
+      gst_buffer_replace (&pads[i]->current, NULL);             /* untimed frames are shown once */
     if (bufs[i]) {
       if (mapped_dev[i])
         gst_memory_unmap (gst_buffer_peek_memory (bufs[i], 0), &maps[i]);
@@ -787,7 +1046,16 @@ amd_comp_stop (GstAggregator * agg)
   c->d_out = NULL;
   c->d_out_size = 0;
   c->have_out = FALSE;
+  if (g_getenv ("GSTAMD_ELEMENT_STATS"))
+    g_printerr ("amdcompositor %s: frames %" G_GUINT64_FORMAT " culled-frames %" G_GUINT64_FORMAT "\n", GST_OBJECT_NAME (c), c->n_frames, c->n_culled);
   c->n_frames = 0;
+  {
+    GList *l;
+    GST_OBJECT_LOCK (agg);
+    for (l = GST_ELEMENT (agg)->sinkpads; l; l = l->next)
+      gst_buffer_replace (&AMD_COMP_PAD (l->data)->current, NULL);
+    GST_OBJECT_UNLOCK (agg);
+  }
   return TRUE;
 }
 
@@ -805,6 +1073,17 @@ gst_amd_compositor_class_init (GstAmdCompositorClass * klass)
           amd_comp_background_get_type (), 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
           "HIP device this instance runs on (-1 = the process's current device)", -1, G_MAXINT, -1, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  /* names and defaults of compositor.c:2103-2162 */
+  g_object_class_install_property (oc, PROP_ZERO_SIZE_IS_UNSCALED, g_param_spec_boolean ("zero-size-is-unscaled", "Zero size is unscaled",
+          "If TRUE, then input video is unscaled in that dimension if width or height is 0 (for backwards compatibility)", TRUE,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_MAX_THREADS, g_param_spec_uint ("max-threads", "Max Threads",
+          "Accepted for compatibility (the GPU grid replaces the blend threads)", 0, G_MAXINT, 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_IGNORE_INACTIVE_PADS, g_param_spec_boolean ("ignore-inactive-pads", "Ignore inactive pads",
+          "Avoid timing out waiting for inactive pads", FALSE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_CULLED_FRAMES, g_param_spec_uint64 ("culled-frames", "Culled frames",
+          "Pad frames left out so far because nothing of them was visible (alpha 0, off canvas, or under an opaque pad)", 0, G_MAXUINT64, 0,
+          G_PARAM_READABLE | G_PARAM_STATIC_STRINGS));
   gst_element_class_add_static_pad_template_with_gtype (ec, &comp_sink_tmpl, gst_amd_compositor_pad_get_type ());
   /* the base class keeps its output segment in the src pad: it has to be a GstAggregatorPad */
   gst_element_class_add_static_pad_template_with_gtype (ec, &comp_src_tmpl, GST_TYPE_AGGREGATOR_PAD);
@@ -831,4 +1110,7 @@ gst_amd_compositor_init (GstAmdCompositor * c)
   c->next_pad = 0;
   c->device_id = -1;
   c->stream = NULL;
+  c->zero_size_is_unscaled = TRUE;
+  c->ignore_inactive_pads = FALSE;
+  c->max_threads = 0;
 }

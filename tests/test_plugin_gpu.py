@@ -210,6 +210,82 @@ def test_compositor_element_scales_and_converts_pads(gst_env, ref):
         assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
 
 
+def test_compositor_element_selects_frames_by_time_and_repeats_a_slower_pad(gst_env, ref):
+    """GstVideoAggregator's frame selection (gstvideoaggregator.c:1753-2000): a 15 fps pad under a 30 fps pad - the output runs at
+    30 fps (the best framerate) and every frame of the slower pad is shown twice."""
+    env, tmp = gst_env
+    n, dw, dh = 6, 320, 240
+    f0, f1, fout = tmp / "t0.bgra", tmp / "t1.bgra", tmp / "t_out.bgra"
+    launch(env, "compositor name=c background=black sink_1::xpos=100 sink_1::ypos=60 sink_1::alpha=0.75 ! video/x-raw,format=BGRA,width=%d,height=%d,framerate=30/1 ! filesink location=%s "
+                "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=BGRA,width=320,height=240,framerate=30/1 ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
+                "videotestsrc num-buffers=%d pattern=ball foreground-color=0xff20c040 ! video/x-raw,format=BGRA,width=160,height=120,framerate=15/1 ! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1"
+           % (dw, dh, fout, n, f0, n // 2, f1))
+    out = np.fromfile(fout, np.uint8).reshape(-1, dw * dh * 4)
+    s0 = np.fromfile(f0, np.uint8).reshape(n, -1)
+    s1 = np.fromfile(f1, np.uint8).reshape(n // 2, -1)
+    assert out.shape[0] == n
+    assert not (s1[0] == s1[1]).all()           # the ball moves: a wrong frame choice shows
+    for f in range(n):
+        canvas = np.zeros(dw * dh * 4, np.uint8)
+        ref.compositor_fill(1, "bgra", "BGRA", canvas, dw, dh, 0, dh, 0, 0, 0)
+        ref.compositor_blend("blend_bgra", "BGRA", s0[f], 320, 240, 0, 0, 1.0, canvas, dw, dh, 0, dh, 1)
+        ref.compositor_blend("blend_bgra", "BGRA", s1[f // 2], 160, 120, 100, 60, 0.75, canvas, dw, dh, 0, dh, 1)
+        assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
+
+
+def test_compositor_element_leaves_out_frames_nobody_can_see(gst_env, ref):
+    """prepare_frame_start's visibility rules (compositor.c:464-601): alpha 0, off-canvas and fully obscured pads never reach the
+    GPU - the picture equals blending all of them, and the element counts what it left out."""
+    env, tmp = gst_env
+    n, dw, dh = 2, 320, 240
+    names = ["v0.bgra", "v1.bgra", "v2.bgrx", "v3.bgra", "v4.bgra"]
+    f = [tmp / x for x in names]
+    fout = tmp / "v_out.bgra"
+    env2 = dict(env, GSTAMD_ELEMENT_STATS="1")
+    log = launch(env2,
+        "compositor name=c background=checker sink_0::zorder=0 sink_1::zorder=1 sink_1::xpos=20 sink_1::ypos=20 "
+        "sink_2::zorder=2 sink_2::xpos=-8 sink_2::ypos=-8 sink_3::zorder=3 sink_3::alpha=0 sink_4::zorder=4 sink_4::xpos=400 sink_4::alpha=0.5 "
+        "! video/x-raw,format=BGRA,width=%d,height=%d ! filesink location=%s "
+        "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=320,height=240,framerate=30/1 ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
+        "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=BGRA,width=160,height=120,framerate=30/1 ! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1 "
+        "videotestsrc num-buffers=%d pattern=snow ! video/x-raw,format=BGRx,width=336,height=256,framerate=30/1 ! tee name=t2 t2. ! queue ! filesink location=%s t2. ! queue ! c.sink_2 "
+        "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=BGRA,width=64,height=64,framerate=30/1 ! tee name=t3 t3. ! queue ! filesink location=%s t3. ! queue ! c.sink_3 "
+        "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=BGRA,width=64,height=64,framerate=30/1 ! tee name=t4 t4. ! queue ! filesink location=%s t4. ! queue ! c.sink_4"
+        % (dw, dh, fout, n, f[0], n, f[1], n, f[2], n, f[3], n, f[4]))
+    assert "culled-frames %d" % (4 * n) in log, log[-500:]
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    src = [np.fromfile(x, np.uint8).reshape(n, -1) for x in f]
+    cx = ref.VideoConverter("BGRx", 336, 256, "BGRA", 336, 256)
+    geo = [(320, 240, 0, 0, 1.0), (160, 120, 20, 20, 1.0), (336, 256, -8, -8, 1.0), (64, 64, 0, 0, 0.0), (64, 64, 400, 0, 0.5)]
+    for k in range(n):
+        canvas = np.zeros(dw * dh * 4, np.uint8)
+        ref.compositor_fill(0, "bgra", "BGRA", canvas, dw, dh, 0, dh)
+        for i, (w, h, x, y, a) in enumerate(geo):
+            frame = cx.frame(src[i][k]) if i == 2 else src[i][k]
+            ref.compositor_blend("blend_bgra", "BGRA", frame, w, h, x, y, a, canvas, dw, dh, 0, dh, 1)
+        assert (canvas == out[k]).all(), (k, int((canvas != out[k]).sum()))
+
+
+def test_compositor_element_sizing_policy_keeps_the_aspect_ratio(gst_env, ref):
+    """sizing-policy=keep-aspect-ratio (_mixer_pad_get_output_size, compositor.c:290-412): a 4:3 picture asked into 200 x 200 is
+    scaled to 200 x 150 and centred - 25 lines down from ypos."""
+    env, tmp = gst_env
+    n, dw, dh = 2, 320, 240
+    f0, fout = tmp / "k0.bgra", tmp / "k_out.bgra"
+    launch(env, "compositor name=c background=black sink_0::width=200 sink_0::height=200 sink_0::xpos=30 sink_0::ypos=10 sink_0::sizing-policy=keep-aspect-ratio "
+                "! video/x-raw,format=BGRA,width=%d,height=%d ! filesink location=%s "
+                "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=320,height=240,framerate=30/1 ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0"
+           % (dw, dh, fout, n, f0))
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    s0 = np.fromfile(f0, np.uint8).reshape(n, -1)
+    c0 = ref.VideoConverter("BGRA", 320, 240, "BGRA", 200, 150)
+    for k in range(n):
+        canvas = np.zeros(dw * dh * 4, np.uint8)
+        ref.compositor_fill(1, "bgra", "BGRA", canvas, dw, dh, 0, dh, 0, 0, 0)
+        ref.compositor_blend("blend_bgra", "BGRA", c0.frame(s0[k]), 200, 150, 30, 35, 1.0, canvas, dw, dh, 0, dh, 1)
+        assert (canvas == out[k]).all(), (k, int((canvas != out[k]).sum()))
+
+
 def test_audioresample_element_interpolated_filter(gst_env, ref):
     """sinc-filter-mode=interpolated sinc-filter-interpolation=linear through the element, S16."""
     env, tmp = gst_env

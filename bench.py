@@ -36,7 +36,7 @@ VIDEO_CONFIGS = {
     "c3": ("I420", 7680, 4320, "RGBA", 1920, 1080, {"resampler_method": "lanczos"}, 8, 1,
            "8K->1080p frames/s (videoconvertscale I420->RGBA, Lanczos) per GPU; % HBM roofline", "k_scale420_fused / k_hscale420_reg + k_vscale_pk"),
     "c5": ("NV12", 7680, 4320, "BGRA", 3840, 2160, {"resampler_method": "linear", "max_taps": 2}, 8, 1,
-           "8K->4K frames/s (videoconvertscale NV12->BGRA, bilinear) per GPU; % HBM roofline", "k_bilinear420"),
+           "8K->4K frames/s (videoconvertscale NV12->BGRA, bilinear) per GPU; % HBM roofline", "k_bilinear420_rows"),
 }
 CONFIG_TEXT = {
     "c2": "C2: 3840x2160 NV12 (bt709 limited, chroma-site mpeg2) -> BGRA, fused unpack + chroma upsample + matrix + pack",

@@ -597,6 +597,28 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
           }
         bp.regular_pairs = regular ? 1 : 0;
       }
+      /* rows per wave of k_bilinear420_rows: every source line pair has to sit in the three-row window of video_bilinear_rows.h */
+      bp.rows = 0;
+      if (bp.regular_pairs && (p.front.width % 16) == 0 && getenv ("GSTAMD_NO_BILINEAR_ROWS") == nullptr) {
+        bool fits = true;
+        for (int y = 0; y < out_h && fits; y++)
+          fits = bilr_window_matches (bp, (int) p.passes[1].offset[y]);
+        int rows_ylen = 0;
+        bp.rows_tile_w = bilr_pick_tile (out_w, p.passes[0].inc, &rows_ylen);
+#ifdef GSTAMD_TUNING
+        if (getenv ("GSTAMD_BIL_ROWS_TILE")) {
+          bp.rows_tile_w = atoi (getenv ("GSTAMD_BIL_ROWS_TILE"));
+          rows_ylen = bil_ylen (out_w, p.passes[0].inc, bp.rows_tile_w);
+        }
+#endif
+        fits = fits && bp.rows_tile_w > 0 && rows_ylen > 0;
+        if (fits)
+          bp.rows = -1;
+#ifdef GSTAMD_TUNING
+        if (fits && getenv ("GSTAMD_BIL_ROWS"))
+          bp.rows = atoi (getenv ("GSTAMD_BIL_ROWS"));
+#endif
+      }
       e = launch_bilinear420 (bp, p.front.chroma_h, pl, dst, dstride, stream);
       if (e != hipErrorNotSupported)
         return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420");

@@ -439,4 +439,138 @@ GSTAMD_CD void aggregate_span4 (const AggregateParams &p, const PadHit *hits, in
     d[i] = px2_pack (acc[i]) | (0xffu << ashift);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Several rows per wave (k_aggregate_rows).  A wave owns a strip of 256 destination columns over `rows` consecutive rows and
+// walks ONE flat list of (row, pad) entries: the pad descriptors are fetched once per wave instead of once per row, and the
+// load pipeline (AGG_DEPTH requests in flight per lane) runs across row boundaries instead of draining at the end of every row -
+// with one row per wave the wave's life was three dependent HBM round trips (descriptors, the first pad words, the last ones)
+// for 16 bytes of output per lane.  An entry flagged AGG_ROW_END finishes its row: the lanes store it and start the next one
+// from the background.  Rows no pad touches carry one AGG_ROW_SKIP entry.
+#define AGG_LIST_MAX 128
+#define AGG_ROW_END 0x100
+#define AGG_ROW_SKIP 0x200
+
+struct RowHit {
+  const uint8_t *row;   // first byte of the pad's source row under this destination row
+  int xpos, width;
+  int ctl;              // pad alpha (bits 0-7) | AGG_ROW_END | AGG_ROW_SKIP
+};
+
+GSTAMD_CD int agg_rows_per_pass (int n_xhits, int rows)
+{
+  const int per = AGG_LIST_MAX / (n_xhits > 0 ? n_xhits : 1);
+  return per < rows ? per : rows;
+}
+
+GSTAMD_CD bool pad_xhit (const PadDev &pad, int wx0, int wx1) { return (pad.xpos < wx1) & (pad.xpos + pad.width > wx0); }
+
+GSTAMD_CD void agg_store4 (uint8_t *p, const uint32_t d[4], int nv)
+{
+#ifdef __HIPCC__
+  typedef unsigned int u32x4_a4s __attribute__ ((ext_vector_type (4), aligned (4)));
+  if (nv == 4) {
+    const u32x4_a4s v = {d[0], d[1], d[2], d[3]};
+    __builtin_nontemporal_store (v, (u32x4_a4s *) p);
+    return;
+  }
+#endif
+  for (int i = 0; i < nv; i++)
+    ((uint32_t *) p)[i] = d[i];
+}
+
+GSTAMD_CD void agg_background4 (const AggregateParams &p, Px2 acc[4], int x, int y)
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    acc[i] = px2_unpack (p.bg_kind == 0 ? checker_px (x + i, y, p.ashift, p.checker_yuv) : p.bg_word);
+}
+
+GSTAMD_CD Px4Words rows_fetch (const RowHit *list, int k, int n, int x)
+{
+  const int kc = k < n ? k : n - 1;
+  const uint8_t *row = uniform_ptr (list[kc].row);
+  const int xpos = uniform_i32 (list[kc].xpos), w = uniform_i32 (list[kc].width);
+  return load_px4 (row + 4 * (size_t) (unsigned) span4_clamp (x - xpos, w));
+}
+
+// pixels x .. x+3 (the first nv of them inside the rectangle) of the rows starting at y, from the wave's entry list.  Opaque
+// blends only (p.fast), background checker or colour.
+template <int ASH, int DEPTH>
+GSTAMD_CD void aggregate_rows4 (const AggregateParams &p, const RowHit *list, int n, uint8_t *dst, int dstride, int x, int y, int nv)
+{
+  Px2 acc[4];
+  Px4Words buf[DEPTH];
+  agg_background4 (p, acc, x, y);
+#pragma unroll
+  for (int j = 0; j < DEPTH; j++) {
+    buf[j] = rows_fetch (list, j, n, x);
+    issue_order_fence ();
+  }
+  for (int k0 = 0; k0 < n; k0 += DEPTH) {
+#pragma unroll
+    for (int j = 0; j < DEPTH; j++) {
+      const int k = k0 + j;
+      const Px4Words cur = buf[j];
+      buf[j] = rows_fetch (list, k + DEPTH, n, x);
+      if (k < n) {
+        const int ctl = uniform_i32 (list[k].ctl);
+        if (!(ctl & AGG_ROW_SKIP)) {
+          const int sx = x - uniform_i32 (list[k].xpos), w = uniform_i32 (list[k].width);
+          const uint32_t alpha8081 = (uint32_t) (ctl & 0xff) * 0x8081u;
+          if ((unsigned) sx <= (unsigned) (w - 4)) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              px2_blend_lazy<ASH> (acc[i], cur.v[i], alpha8081);
+          } else if ((unsigned) (sx + 3) < (unsigned) (w + 3)) {         // lane straddles a pad edge
+            const uint8_t *row = uniform_ptr (list[k].row);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              if (sx + i >= 0 && sx + i < w)
+                px2_blend_lazy<ASH> (acc[i], load_px1 (row + 4 * (size_t) (sx + i)), alpha8081);
+          }
+        }
+        if (ctl & AGG_ROW_END) {
+          uint32_t d[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            d[i] = px2_pack (acc[i]) | (0xffu << ASH);
+          agg_store4 (dst + (ptrdiff_t) y * dstride + 4 * (ptrdiff_t) x, d, nv);
+          y++;
+          agg_background4 (p, acc, x, y);
+        }
+      }
+    }
+  }
+}
+
+// the entry list of rows y .. y + ny - 1 for the strip [wx0, wx1): host form (the kernel builds the same list with one lane per
+// pad and a ballot per row)
+GSTAMD_CD int agg_build_list_host (const AggregateParams &p, int wx0, int wx1, int y, int ny, RowHit *list)
+{
+  int n = 0;
+  for (int r = 0; r < ny; r++) {
+    const int first = n;
+    for (int k = 0; k < p.n_pads; k++) {
+      const PadDev &pad = p.pads[k];
+      const int sy = y + r - pad.ypos;
+      if (pad_xhit (pad, wx0, wx1) && sy >= 0 && sy < pad.height) {
+        list[n].row = pad.data + (ptrdiff_t) sy * pad.stride;
+        list[n].xpos = pad.xpos;
+        list[n].width = pad.width;
+        list[n].ctl = pad.s_alpha;
+        n++;
+      }
+    }
+    if (n == first) {
+      list[n].row = p.pads[0].data;
+      list[n].xpos = 0;
+      list[n].width = 4;
+      list[n].ctl = AGG_ROW_SKIP;
+      n++;
+    }
+    list[n - 1].ctl |= AGG_ROW_END;
+  }
+  return n;
+}
+
 }  // namespace gstamd

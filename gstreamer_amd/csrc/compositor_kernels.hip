@@ -74,6 +74,62 @@ __global__ __launch_bounds__ (256) void k_aggregate (AggregateParams p, uint8_t 
   }
 }
 
+// Several rows per wave (compositor_device.h, "Several rows per wave"): workgroup = one wave = 256 columns x `rows` rows.
+template <int ASH, int DEPTH>
+__global__ __launch_bounds__ (64) void k_aggregate_rows (AggregateParams p, uint8_t *__restrict__ dst, int dstride, int rx0, int ry0,
+    int rw, int rh, int rows, int strips)
+{
+  __shared__ RowHit list[AGG_LIST_MAX];
+  const int lane = (int) threadIdx.x;
+  const int strip = (int) blockIdx.x % strips, rg = (int) blockIdx.x / strips;
+  const int wx0 = rx0 + strip * 256, wx1 = wx0 + 256 < rx0 + rw ? wx0 + 256 : rx0 + rw;
+  const int x = wx0 + 4 * lane;
+  int nv = rx0 + rw - x;
+  nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+  int y = ry0 + rg * rows;
+  const int yend = y + rows < ry0 + rh ? y + rows : ry0 + rh;
+  const PadDev pad = p.pads[lane < p.n_pads ? lane : 0];
+  const bool xhit = (lane < p.n_pads) & pad_xhit (pad, wx0, wx1);
+  const int per = agg_rows_per_pass (__popcll (__ballot (xhit)), rows);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  while (y < yend) {
+    const int ny = per < yend - y ? per : yend - y;
+    int n = 0;
+    for (int r = 0; r < ny; r++) {
+      const int sy = y + r - pad.ypos;
+      const bool hit = xhit & (sy >= 0) & (sy < pad.height);
+      const unsigned long long m = __ballot (hit);
+      const int c = __popcll (m);
+      if (hit) {
+        const int at = n + __popcll (m & below);
+        RowHit e;
+        e.row = pad.data + (ptrdiff_t) sy * pad.stride;
+        e.xpos = pad.xpos;
+        e.width = pad.width;
+        e.ctl = pad.s_alpha | (at == n + c - 1 ? AGG_ROW_END : 0);
+        list[at] = e;
+      }
+      if (c == 0 && lane == 0) {
+        RowHit e;
+        e.row = pad.data;                         // lane 0 holds pad 0: any readable 16 bytes
+        e.xpos = 0;
+        e.width = 4;
+        e.ctl = AGG_ROW_SKIP | AGG_ROW_END;
+        list[n] = e;
+      }
+      n += c > 0 ? c : 1;
+    }
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier ();
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+    aggregate_rows4<ASH, DEPTH> (p, list, n, dst, dstride, x, y, nv);
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier ();
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+    y += ny;
+  }
+}
+
 static thread_local std::string g_comp_error;
 extern "C" const char *gstamd_last_error (void);
 
@@ -111,6 +167,35 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
 #else
   const int abl = 0;
 #endif
+  int rows = 4, depth = 4;
+  bool by_rows = q.fast && q.n_pads > 0 && q.bg_kind != 2;
+#ifdef GSTAMD_TUNING
+  if (getenv ("GSTAMD_AGG_ROWS"))
+    rows = atoi (getenv ("GSTAMD_AGG_ROWS"));
+  if (getenv ("GSTAMD_AGG_DEPTH"))
+    depth = atoi (getenv ("GSTAMD_AGG_DEPTH"));
+  if (rows <= 0)
+    by_rows = false;
+#endif
+  if (by_rows && abl == 0) {
+    const int strips = (rw + 255) / 256;
+    dim3 rgrid (strips * ((rh + rows - 1) / rows)), rblock (64);
+#define AGG_ROWS_LAUNCH(S, D) hipLaunchKernelGGL ((k_aggregate_rows<S, D>), rgrid, rblock, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh, rows, strips)
+    if (q.ashift == 0) {
+#ifdef GSTAMD_TUNING
+      if (depth == 8) AGG_ROWS_LAUNCH (0, 8); else if (depth == 6) AGG_ROWS_LAUNCH (0, 6); else
+#endif
+      AGG_ROWS_LAUNCH (0, 4);
+    } else {
+#ifdef GSTAMD_TUNING
+      if (depth == 8) AGG_ROWS_LAUNCH (24, 8); else if (depth == 6) AGG_ROWS_LAUNCH (24, 6); else
+#endif
+      AGG_ROWS_LAUNCH (24, 4);
+    }
+#undef AGG_ROWS_LAUNCH
+    (void) depth;
+    return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
+  }
   dim3 grid ((lanes + bx - 1) / bx, rh), block (bx);
 #define AGG_LAUNCH(A, S) hipLaunchKernelGGL ((k_aggregate<A, S>), grid, block, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh)
   if (q.ashift == 0) {

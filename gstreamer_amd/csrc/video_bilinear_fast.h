@@ -49,6 +49,10 @@ struct BilParams {
   int regular_pairs;         // the pairing is the closed form of bil_rows: no table reads
   int planar;                // 1: I420 / YV12 - U in plane u_plane, V in plane v_plane (width % 16 == 0, 8-byte aligned chroma rows); 0: interleaved plane 1
   int u_plane, v_plane;
+  int rows_tile_w;           // outputs per wave of k_bilinear420_rows (<= 384)
+  int rows;                  // > 0: k_bilinear420_rows (video_bilinear_rows.h) with this many output rows per wave; < 0: as many
+                             // waves as the chip holds at once; 0: k_bilinear420
+  int strips;                // row strips per tile column of k_bilinear420_rows: strip g covers rows [g h / strips, (g + 1) h / strips)
 };
 
 GSTAMD_HOSTDEV void bil_rows (const BilParams &bp, int line, int *ra, int *rb, int *role)

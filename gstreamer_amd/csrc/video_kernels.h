@@ -8,6 +8,7 @@
 #include "video_scale_fast.h"
 #include "video_bilinear_fast.h"
 #include "video_hscale420.h"
+#include "video_bilinear_rows.h"
 #include "video_422_fast.h"
 
 namespace gstamd {

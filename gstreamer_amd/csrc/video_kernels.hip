@@ -4,6 +4,8 @@
 // every source byte is read once (chroma rows are shared through L2) and every destination
 // byte written once with 16-byte stores per lane.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -320,6 +322,56 @@ __global__ __launch_bounds__ (64) void k_bilinear420 (BilParams bp, Planes pl, u
   bil_commit (bp, t0, t1, lane, r, &lds);
   __syncthreads ();                       /* one wave per workgroup: orders the LDS writes before the reads */
   bil_emit<CH, L> (bp, dst, dstride, t0, t1, y, r0, lane, &lds);
+}
+
+// the same path with the chroma work done once per source pixel in byte lanes (video_bilinear_rows.h): workgroup = one wave =
+// 256 outputs x `bp.rows` consecutive output rows
+template <int CH, int L, int NP>
+__global__ __launch_bounds__ (256) void k_bilinear420_rows (BilParams bp, Planes pl, uint8_t *__restrict__ dst, int dstride, int tiles_x)
+{
+  /* the waves of a workgroup are independent (no barrier, an LDS slice each); a workgroup of several only makes the dispatcher's
+   * job smaller - it places workgroups one at a time, and with thousands of single-wave groups the last waves start microseconds
+   * after the first.  Wave w of workgroup b plays block (b / 8 * waves + w) * 8 + b % 8 of the XCD-aware map. */
+  extern __shared__ __attribute__ ((aligned (16))) uint8_t lds_all[];
+  const int wave = __builtin_amdgcn_readfirstlane ((int) threadIdx.x >> 6), waves = (int) blockDim.x >> 6;      /* wave-uniform: keep it scalar */
+  uint8_t *lds = lds_all + wave * (BILR_PLANES * BILR_PLANE_BYTES);
+  int tile, g;
+  if (!wide_block_map ((((int) blockIdx.x >> 3) * waves + wave) * 8 + ((int) blockIdx.x & 7), tiles_x, bp.strips, &tile, &g))
+    return;
+  const int lane = (int) threadIdx.x & 63, t0 = tile * bp.rows_tile_w;
+  const int t1 = t0 + bp.rows_tile_w < bp.out_w ? t0 + bp.rows_tile_w : bp.out_w;
+  int x_lo, x_hi, k_lo, k_hi;
+  bil_span (bp, t0, t1, &x_lo, &x_hi, &k_lo, &k_hi);
+  const int xa = x_lo & ~15;
+  BilrLane c;
+  bilr_lane_setup<NP> (bp, t0, t1, xa, lane, c);
+  BilrState st;
+  bilr_state_init (st);
+  uint32_t q4[4][2];
+  layout_init<L> (q4);
+  uint32_t (&q)[2] = q4[0];
+  /* the strip's rows.  Their table entries (first source line, second vertical tap) are read once, one lane per row: a table read
+   * inside the loop is a vector load followed by s_waitcnt vmcnt(0), which also waits for the prefetch and the stores of the
+   * row before.  The first row's entry comes through the scalar cache on its own so that the first loads can go out sooner. */
+  const int y0 = (int) ((unsigned) g * (unsigned) bp.out_h / (unsigned) bp.strips);
+  const int y1 = (int) ((unsigned) (g + 1) * (unsigned) bp.out_h / (unsigned) bp.strips);
+  const int first_r0 = (int) bp.voffset[y0];
+  const int yl = y0 + lane < bp.out_h ? y0 + lane : bp.out_h - 1;
+  const int tab_r0 = (int) bp.voffset[yl], tab_p1 = (int) bp.vtaps[(size_t) yl * 2 + 1];
+  BilrReq rq;
+  bilr_request (bp, pl, st, first_r0, xa, x_hi, lane, rq);
+  for (int y = y0; y < y1; y++) {
+    bilr_install<CH> (bp, pl, st, rq, __builtin_amdgcn_readlane (tab_r0, y - y0), xa, x_hi, lane, lds);
+    if (y + 1 < y1)
+      bilr_request (bp, pl, st, __builtin_amdgcn_readlane (tab_r0, y + 1 - y0), xa, x_hi, lane, rq);   /* in flight while this row is emitted */
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier ();
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+    bilr_emit_row<L, NP> (bp, c, lds, dst, dstride, y, __builtin_amdgcn_readlane (tab_p1, y - y0), q);
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier ();
+    __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 
 // plane scaler of planar / semi-planar formats (video_planes.h): one lane per output pixel of the plane
@@ -829,6 +881,24 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
   return hipGetLastError ();
 }
 
+// waves of k_bilinear420_rows the device holds at once (one workgroup = one wave): the balanced strip count aims at exactly one
+// resident round, every SIMD with the same number of rows to do
+static int bilr_wave_slots ()
+{
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice (&dev) != hipSuccess || hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    const void *fn = (const void *) k_bilinear420_rows<CHROMA_H_H2_CS, GSTAMD_LAYOUT (2, 1, 0), 3>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, fn, 64, bilr_lds_bytes ()) != hipSuccess || per_cu <= 0)
+      per_cu = 16;
+    (void) hipGetLastError ();
+    slots = cus * per_cu;
+  }
+  return slots;
+}
+
 hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
 {
   int vec = aligned (pl.p[0], 16) && aligned (pl.p[1], 16) && (pl.stride[0] % 16) == 0 && (pl.stride[1] % 16) == 0;
@@ -840,6 +910,46 @@ hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &
       return hipErrorNotSupported;
   }
   const int tiles_x = (bp.out_w + bp.tile_w - 1) / bp.tile_w;
+  if (bp.rows != 0 && vec && (bp.fp.width % 16) == 0 && bp.regular_pairs) {
+    const int rtiles = (bp.out_w + bp.rows_tile_w - 1) / bp.rows_tile_w;
+    BilParams rp = bp;
+    int slots = bilr_wave_slots ();
+#ifdef GSTAMD_TUNING
+    if (getenv ("GSTAMD_BIL_SLOTS"))
+      slots = atoi (getenv ("GSTAMD_BIL_SLOTS"));
+    if (getenv ("GSTAMD_BIL_VERBOSE"))
+      fprintf (stderr, "k_bilinear420_rows: slots %d (device query %d), tiles %d, strips %d\n", slots, bilr_wave_slots (), rtiles,
+          bilr_strips (bp.out_h, bp.rows, rtiles, slots));
+#endif
+    rp.strips = bilr_strips (bp.out_h, bp.rows, rtiles, slots - slots / 16);      /* a full round that tips over into a second one costs 20 %: keep a margin */
+    int wg = 1;
+#ifdef GSTAMD_TUNING
+    if (getenv ("GSTAMD_BIL_WG"))
+      wg = atoi (getenv ("GSTAMD_BIL_WG"));
+#endif
+    dim3 rgrid (wide_grid_blocks (rtiles, rp.strips) / wg), rblock (64 * wg);      /* the grid is a multiple of 256 blocks */
+    const size_t rlds = (size_t) wg * bilr_lds_bytes ();
+#define WR(CH, LAY) \
+    if (bp.rows_tile_w > 256) \
+      hipLaunchKernelGGL ((k_bilinear420_rows<CH, LAY, 3>), rgrid, rblock, rlds, stream, rp, pl, dst, dstride, rtiles); \
+    else \
+      hipLaunchKernelGGL ((k_bilinear420_rows<CH, LAY, 2>), rgrid, rblock, rlds, stream, rp, pl, dst, dstride, rtiles);
+#define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \
+    if (chroma_h == CHROMA_H_H2_CS) { \
+      WR (CHROMA_H_H2_CS, GSTAMD_LAYOUT (pr, pg, pb)) \
+    } else if (chroma_h == CHROMA_H_H2) { \
+      WR (CHROMA_H_H2, GSTAMD_LAYOUT (pr, pg, pb)) \
+    } else { \
+      WR (CHROMA_H_NONE, GSTAMD_LAYOUT (pr, pg, pb)) \
+    } \
+    return hipGetLastError ();
+    switch (fast_layout (bp.fp)) {
+      GSTAMD_FOR_LAYOUTS (W)
+    }
+#undef W
+#undef WR
+    return hipErrorInvalidValue;
+  }
   dim3 grid (wide_grid_blocks (tiles_x, bp.out_h));
   const size_t lds_bytes = bil_lds_words (bp.ylen) * 4;
 #define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \

@@ -1,9 +1,13 @@
 // tests/emu/emu_compositor.cpp - TEST INFRASTRUCTURE: host loop over compositor_device.h bodies.
+#include <cstdlib>
 #include <cstring>
 
 #include "../../gstreamer_amd/csrc/compositor_device.h"
 
 using namespace gstamd;
+
+static int emu_rows_runs = 0;
+extern "C" int emu_compositor_rows_runs (void) { return emu_rows_runs; }
 
 extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int dstride, int rx0, int ry0, int rw, int rh)
 {
@@ -13,6 +17,34 @@ extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int 
   for (int i = 0; i < p->n_pads; i++)
     if (p->pads[i].mode == GSTAMD_COMPOSITOR_BLEND_MODE_SOURCE || p->pads[i].width < 4)
       q.fast = 0;
+  if (q.fast && q.n_pads > 0 && q.bg_kind != 2 && !getenv ("EMU_AGG_SINGLE_ROW")) {
+    /* k_aggregate_rows: strips of 256 columns x `rows` rows, one entry list per pass */
+    const int rows = getenv ("EMU_AGG_ROWS") ? atoi (getenv ("EMU_AGG_ROWS")) : 4;
+    emu_rows_runs++;
+    for (int y0 = ry0; y0 < ry0 + rh; y0 += rows)
+      for (int wx0 = rx0; wx0 < rx0 + rw; wx0 += 256) {
+        const int wx1 = wx0 + 256 < rx0 + rw ? wx0 + 256 : rx0 + rw, yend = y0 + rows < ry0 + rh ? y0 + rows : ry0 + rh;
+        int nhx = 0;
+        for (int k = 0; k < q.n_pads; k++)
+          nhx += pad_xhit (q.pads[k], wx0, wx1) ? 1 : 0;
+        const int per = agg_rows_per_pass (nhx, rows);
+        for (int y = y0; y < yend; y += per) {
+          RowHit list[AGG_LIST_MAX];
+          const int ny = per < yend - y ? per : yend - y;
+          const int n = agg_build_list_host (q, wx0, wx1, y, ny, list);
+          for (int lane = 0; lane < 64; lane++) {
+            const int x = wx0 + 4 * lane;
+            int nv = rx0 + rw - x;
+            nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+            if (q.ashift == 0)
+              aggregate_rows4<0, 4> (q, list, n, dst, dstride, x, y, nv);
+            else
+              aggregate_rows4<24, 4> (q, list, n, dst, dstride, x, y, nv);
+          }
+        }
+      }
+    return;
+  }
   for (int y = ry0; y < ry0 + rh; y++)
     for (int gx = 0; gx < rw; gx += 4) {
       const int bx0 = rx0 + (gx / 256) * 256, bx1 = bx0 + 256 < rx0 + rw ? bx0 + 256 : rx0 + rw;    /* the wave's strip */

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include "../../gstreamer_amd/csrc/video_pack.h"
 #include "../../gstreamer_amd/csrc/video_bilinear_fast.h"
+#include "../../gstreamer_amd/csrc/video_bilinear_rows.h"
 #include "../../gstreamer_amd/csrc/video_planes.h"
 #include "../../gstreamer_amd/csrc/video_encode_fast.h"
 #include "../../gstreamer_amd/csrc/video_deep.h"
@@ -601,8 +602,9 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
 }
 
 static int g_fast422_runs = 0;
-static int g_bil_runs = 0;
+static int g_bil_runs = 0, g_bilr_runs = 0;
 extern "C" int emu_bil_runs (void) { return g_bil_runs; }
+extern "C" int emu_bilr_runs (void) { return g_bilr_runs; }
 static int g_fast420p_runs = 0;
 extern "C" int emu_fast420p_runs (void) { return g_fast420p_runs; }
 extern "C" int emu_fast422_runs (void) { return g_fast422_runs; }
@@ -940,6 +942,84 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
 #define BIL_L(CH, pr, pg, pb) if (lay == GSTAMD_LAYOUT (pr, pg, pb)) bil_emit<CH, GSTAMD_LAYOUT (pr, pg, pb)> (bp, d0, dstride, t0, t1, y, r0, lane, &lds);
 #define BIL(CH) { BIL_L (CH, 2, 1, 0) BIL_L (CH, 0, 1, 2) BIL_L (CH, 1, 2, 3) BIL_L (CH, 3, 2, 1) }
       bp.regular_pairs = 0;
+      bp.rows = 0;
+      {
+        /* k_bilinear420_rows (video_bilinear_rows.h): the gate of capi_video.cpp, here against the pairing table itself */
+        bool fits = p.front.chroma_v2 && vec && (p.front.width % 16) == 0 && getenv ("EMU_NO_BILINEAR_ROWS") == nullptr;
+        if (getenv ("EMU_BILR_DEBUG"))
+          fprintf (stderr, "bilr gate: v2 %d vec %d w %d\n", (int) p.front.chroma_v2, (int) vec, p.front.width);
+        for (int y = 0; y < bp.out_h && fits; y++) {
+          fits = bilr_window_matches (bp, (int) bp.voffset[y]);
+          if (!fits && getenv ("EMU_BILR_DEBUG")) {
+            int ra, rb, role, wa, wb, wc;
+            bilr_window (bp, (int) bp.voffset[y], &wa, &wb, &wc);
+            fprintf (stderr, "bilr gate: y %d r0 %d window %d %d %d\n", y, (int) bp.voffset[y], wa, wb, wc);
+            for (int l = 0; l < 2; l++) {
+              bil_rows (bp, (int) bp.voffset[y] + l, &ra, &rb, &role);
+              fprintf (stderr, "   line %d: ra %d rb %d role %d\n", (int) bp.voffset[y] + l, ra, rb, role);
+            }
+          }
+        }
+        int rows_ylen = 0;
+        bp.rows_tile_w = getenv ("EMU_BIL_ROWS_TILE") ? atoi (getenv ("EMU_BIL_ROWS_TILE")) : bilr_pick_tile (bp.out_w, bp.inc, &rows_ylen);
+        if (getenv ("EMU_BIL_ROWS_TILE"))
+          rows_ylen = bil_ylen (bp.out_w, bp.inc, bp.rows_tile_w);
+        fits = fits && bp.rows_tile_w > 0 && rows_ylen > 0;
+        if (fits)
+          bp.rows = getenv ("EMU_BIL_ROWS") ? atoi (getenv ("EMU_BIL_ROWS")) : 4;
+      }
+      if (bp.rows != 0) {
+        g_bilr_runs++;
+        static BilrState st[64];
+        static BilrLane lc[64];
+        static uint32_t q[64][4][2];
+        std::vector<uint8_t> lds (bilr_lds_bytes ());
+#define BILR_L(CH, pr, pg, pb) if (lay == GSTAMD_LAYOUT (pr, pg, pb)) { \
+          if (phase == 0) layout_init<GSTAMD_LAYOUT (pr, pg, pb)> (q[lane]); \
+          else if (bp.rows_tile_w > 256) bilr_emit_row<GSTAMD_LAYOUT (pr, pg, pb), 3> (bp, lc[lane], lds.data (), d0, dstride, y, (int) bp.vtaps[(size_t) y * 2 + 1], q[lane][0]); \
+          else bilr_emit_row<GSTAMD_LAYOUT (pr, pg, pb), 2> (bp, lc[lane], lds.data (), d0, dstride, y, (int) bp.vtaps[(size_t) y * 2 + 1], q[lane][0]); }
+#define BILR_EMIT() { BILR_L (0, 2, 1, 0) BILR_L (0, 0, 1, 2) BILR_L (0, 1, 2, 3) BILR_L (0, 3, 2, 1) }
+        /* EMU_BIL_ROWS < 0: the balanced strips of the launcher for a device with -EMU_BIL_ROWS wave slots */
+        bp.strips = bilr_strips (bp.out_h, bp.rows, (bp.out_w + bp.rows_tile_w - 1) / bp.rows_tile_w, bp.rows < 0 ? -bp.rows : 0);
+        for (int g = 0; g < bp.strips; g++)
+          for (int t0 = 0; t0 < bp.out_w; t0 += bp.rows_tile_w) {
+            const int t1 = t0 + bp.rows_tile_w < bp.out_w ? t0 + bp.rows_tile_w : bp.out_w;
+            const int y0 = (int) ((unsigned) g * (unsigned) bp.out_h / (unsigned) bp.strips);
+            const int y1 = (int) ((unsigned) (g + 1) * (unsigned) bp.out_h / (unsigned) bp.strips);
+            int x_lo, x_hi, k_lo, k_hi, y = 0, phase = 0;
+            bil_span (bp, t0, t1, &x_lo, &x_hi, &k_lo, &k_hi);
+            const int xa = x_lo & ~15;
+            for (int lane = 0; lane < 64; lane++) {
+              if (bp.rows_tile_w > 256)
+                bilr_lane_setup<3> (bp, t0, t1, xa, lane, lc[lane]);
+              else
+                bilr_lane_setup<2> (bp, t0, t1, xa, lane, lc[lane]);
+              bilr_state_init (st[lane]);
+              BILR_EMIT ()
+            }
+            phase = 1;
+            static BilrReq rq[64];
+            for (int lane = 0; lane < 64; lane++)
+              bilr_request (bp, pl, st[lane], (int) bp.voffset[y0], xa, x_hi, lane, rq[lane]);
+            for (y = y0; y < y1; y++) {
+              for (int lane = 0; lane < 64; lane++) {
+                if (p.front.chroma_h == CHROMA_H_H2_CS)
+                  bilr_install<CHROMA_H_H2_CS> (bp, pl, st[lane], rq[lane], (int) bp.voffset[y], xa, x_hi, lane, lds.data ());
+                else if (p.front.chroma_h == CHROMA_H_H2)
+                  bilr_install<CHROMA_H_H2> (bp, pl, st[lane], rq[lane], (int) bp.voffset[y], xa, x_hi, lane, lds.data ());
+                else
+                  bilr_install<CHROMA_H_NONE> (bp, pl, st[lane], rq[lane], (int) bp.voffset[y], xa, x_hi, lane, lds.data ());
+                if (y + 1 < y1)
+                  bilr_request (bp, pl, st[lane], (int) bp.voffset[y + 1], xa, x_hi, lane, rq[lane]);
+              }
+              for (int lane = 0; lane < 64; lane++)
+                BILR_EMIT ()
+            }
+          }
+#undef BILR_EMIT
+#undef BILR_L
+        return GSTAMD_OK;
+      }
       static BilRegs regs[64];
       for (int y = 0; y < bp.out_h; y++)
         for (int t0 = 0; t0 < bp.out_w; t0 += bp.tile_w) {

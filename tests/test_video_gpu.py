@@ -126,6 +126,26 @@ def test_hip_scale420_mfma_matches_reference_bytewise(native_lib, gpu, ref, shap
     assert (out == exp).all(), int((out != exp).sum())
 
 
+BILR_SHAPES = [("NV12", 3840, 2160, "BGRA", 1920, 1080, None), ("NV12", 1920, 1080, "RGBA", 1280, 720, None), ("I420", 2048, 858, "ARGB", 1024, 429, "jpeg"),
+               ("NV21", 1280, 720, "BGRx", 1000, 562, None), ("YV12", 640, 480, "BGRA", 1280, 960, None), ("NV12", 4096, 2160, "BGRA", 2730, 1440, "mpeg2")]
+
+
+@pytest.mark.parametrize("shape", BILR_SHAPES, ids=lambda s: "%s_%dx%d_%dx%d" % (s[0], s[1], s[2], s[4], s[5]))
+def test_hip_bilinear420_rows_shapes_match_reference_bytewise(native_lib, gpu, ref, shape, monkeypatch):
+    """k_bilinear420_rows (chroma once per source pixel in byte lanes, balanced row strips): 2:1, 1.5:1, non-integer and upscaling
+    ratios, both plane layouts, tiles of 384 and fewer outputs, memcmp'd against the reference run on this host - and the older
+    k_bilinear420 on the same frames (GSTAMD_NO_BILINEAR_ROWS), which stays the path for sources the rows kernel does not take."""
+    ifmt, w, h, ofmt, ow, oh, site = shape
+    src = cases.frame_bytes(ref.video_info(ifmt, w, h)["size"], "random", 4243 + w + oh)
+    exp = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, cases.LIN), in_chroma_site=site).frame(src)
+    for _ in range(2):
+        out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LIN, None, site, src)
+        assert (out == exp).all(), int((out != exp).sum())
+    monkeypatch.setenv("GSTAMD_NO_BILINEAR_ROWS", "1")
+    out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LIN, None, site, src)
+    assert (out == exp).all(), int((out != exp).sum())
+
+
 H420_SHAPES = [("NV12", 1280, 720, "BGRA", 320, 180, "lanczos"), ("NV21", 1920, 1080, "RGBA", 480, 270, "lanczos"),
                ("I420", 2048, 856, "ARGB", 512, 214, "lanczos"), ("YV12", 640, 359, "BGRA", 160, 90, "lanczos"),
                ("NV12", 1920, 1080, "BGRA", 640, 360, "lanczos"), ("I420", 1280, 720, "RGBA", 640, 360, "lanczos"),

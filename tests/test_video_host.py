@@ -293,6 +293,33 @@ def test_bilinear_kernel_bodies_agree(native_lib, emu_lib, idx_case, variant):
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
 
 
+BILR = [c for c in SMALL if c[1][1] in ("NV12", "NV21", "I420", "YV12") and c[1][7] == cases.LIN and c[1][2] % 16 == 0
+        and c[1][4] in ("BGRA", "RGBA", "ARGB", "ABGR", "BGRx", "RGBx", "xRGB", "xBGR") and "letterbox" not in c[1][0]]
+
+
+@pytest.mark.parametrize("rows,tile", [(1, 0), (3, 0), (4, 0), (16, 0), (4, 256), (5, 128), (-100, 0), (-7, 0), (100, 0)])
+@pytest.mark.parametrize("idx_case", BILR, ids=lambda c: c[1][0])
+def test_bilinear_rows_kernel_body_any_rows_per_wave(native_lib, emu_lib, idx_case, rows, tile, monkeypatch):
+    """k_bilinear420_rows (video_bilinear_rows.h): chroma upsampled once per source pixel in byte lanes, a wave walking `rows`
+    output rows with the filtered chroma rows it carries.  The rows per wave are a tuning knob (negative: balanced strips for a device with that many wave
+    slots, as the launcher makes them; 100: more rows than the 64 a strip holds); where the three-row window form
+    does not apply (no vertical chroma upsampling, vertical-first plans) the older kernels serve the plan."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    monkeypatch.setenv("EMU_BIL_ROWS", str(rows))
+    if tile:
+        monkeypatch.setenv("EMU_BIL_ROWS_TILE", str(tile))     # default: 384 outputs per wave where the span fits, else 256 ...
+    emu_lib.emu_bilr_runs.restype = C.c_int
+    before = emu_lib.emu_bilr_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    took = emu_lib.emu_bilr_runs() - before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
+    if rows == 4 and not tile:
+        print(name, "rows kernel" if took else "older kernel")
+    if name in ("nv12_bgra_2to1_bilinear_1280x720", "i420_bgra_bil420_half", "nv12_bgra_half_bilinear"):
+        assert took == 1, name
+
+
 @pytest.mark.parametrize("idx_case", SMALL[::4], ids=lambda c: c[1][0])
 def test_golden_vectors_are_the_references_output(ref, idx_case):
     """Pins the committed golden hashes to the reference implementation itself (oracle/_ref)."""

@@ -35,14 +35,16 @@ VIDEO_CONFIGS = {
            "1080p frames/s (videoconvertscale NV12->BGRA) per GPU; % HBM roofline", "k_convert_strip<CHROMA_H_H2_CS, layout BGRA>"),
     "c3": ("I420", 7680, 4320, "RGBA", 1920, 1080, {"resampler_method": "lanczos"}, 8, 1,
            "8K->1080p frames/s (videoconvertscale I420->RGBA, Lanczos) per GPU; % HBM roofline", "k_scale420_fused / k_hscale420_reg + k_vscale_pk"),
-    "c5": ("NV12", 7680, 4320, "BGRA", 3840, 2160, {"resampler_method": "linear", "max_taps": 2}, 8, 1,
-           "8K->4K frames/s (videoconvertscale NV12->BGRA, bilinear) per GPU; % HBM roofline", "k_bilinear420_rows"),
+    "c5": ("NV12", 7680, 4320, "BGRA", 3840, 2160, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
+           "8K->4K frames/s (videoconvertscale NV12->BGRA, bilinear) per GPU; % HBM roofline",
+           "k_bilinear420_rows_frames (--batch 1: k_bilinear420_rows)"),
 }
 CONFIG_TEXT = {
     "c2": "C2: 3840x2160 NV12 (bt709 limited, chroma-site mpeg2) -> BGRA, fused unpack + chroma upsample + matrix + pack",
     "c1": "C1 size on the GPU: 1920x1080 NV12 -> BGRA (the reference's CPU-runnable case)",
     "c3": "C3: 7680x4320 I420 -> 1920x1080 RGBA, Lanczos (16 x 16 taps), horizontal then vertical like chain_scale",
-    "c5": "C5 (per GPU): 7680x4320 NV12 -> 3840x2160 BGRA, bilinear (element default method)",
+    "c5": "C5 (per GPU): 7680x4320 NV12 -> 3840x2160 BGRA, bilinear (element default method); frame lists "
+          "(gstamd_video_converter_frames, what the element's chain_list calls) - `--batch 1` for one launch per frame",
     "c4": "C4: compositor, 16 x 1920x1080 BGRA pads (xpos 640*(i%4), ypos 360*(i/4), alpha 0.25+0.05i, random pixel alpha, "
           "operator over) on a checker background -> 3840x2160 BGRA, one fused launch per output frame",
     "c4audio": "C4 audio: audioresample 48000 -> 44100 Hz, F32 stereo interleaved, Kaiser quality 4 (72 taps x 147 phases)",

@@ -489,6 +489,80 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
   return convert_to_packed (c, pl, (uint8_t *) dest_planes[0], dest_stride ? dest_stride[0] : p.out_info.stride[0], stream);
 }
 
+// Does the plan take the direct 4:2:0 bilinear kernels (video_bilinear_fast.h / video_bilinear_rows.h)?  Fills everything of
+// BilParams that does not depend on a particular frame's pointers.
+static bool bilinear420_params (GstAmdVideoConverter *c, BilParams *out)
+{
+  const VideoPlan &p = c->plan;
+  const auto small_kind = [](int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; };
+  if (p.out_planar || p.passes.size () != 2 || !small_kind (p.passes[0].kind) || !small_kind (p.passes[1].kind))
+    return false;
+  /* semi-planar / planar 4:2:0 source, horizontal-first 2-tap x 2-tap, fast matrix */
+  if (!(p.passes[0].horizontal && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && kind_has_planes (p.front.kind) && p.front.w_sub == 1 &&
+        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && getenv ("GSTAMD_NO_BILINEAR420") == nullptr))
+    return false;
+  const int out_w = p.out_info.width, out_h = p.out_info.height;
+  BilParams bp;
+  memset (&bp, 0, sizeof (bp));
+  bp.tile_w = bil_pick_tile (out_w, p.passes[0].inc, &bp.ylen);
+  if (const char *e_tw = getenv ("GSTAMD_BIL_TILE")) {      /* tuning knob for profiling sessions */
+    bp.tile_w = atoi (e_tw);
+    bp.ylen = bil_ylen (out_w, p.passes[0].inc, bp.tile_w);
+  }
+  if (bp.tile_w <= 0 || bp.ylen <= 0)
+    return false;
+  bp.fp = make_fast_params (p);
+  bp.out_w = out_w;
+  bp.out_h = out_h;
+  bp.inc = p.passes[0].inc;
+  bp.voffset = c->pass_dev[1].offset;
+  bp.vtaps = c->pass_dev[1].taps;
+  bp.vpair = p.front.chroma_v2 ? c->vpair_dev : nullptr;
+  bp.regular_pairs = 0;
+  bp.planar = p.front.kind == UNPACK_PLANAR;
+  bp.u_plane = p.front.u_plane;
+  bp.v_plane = p.front.v_plane;
+  if (p.front.chroma_v2 && getenv ("GSTAMD_BIL_TABLE") == nullptr) {
+    /* are the pairs of every source line the kernel will touch the closed form of bil_rows? */
+    bool regular = true;
+    BilParams probe = bp;
+    probe.regular_pairs = 1;
+    for (int y = 0; y < out_h && regular; y++)
+      for (int l = 0; l < 2 && regular; l++) {
+        const int line = (int) p.passes[1].offset[y] + l;
+        int ra, rb, role;
+        bil_rows (probe, line, &ra, &rb, &role);
+        const int e0 = p.vpair[2 * line], ta = vpair_row (e0), trole = vpair_role (e0), tb = p.vpair[2 * line + 1];
+        regular = ta == ra && tb == rb && (ra == rb || trole == role);
+      }
+    bp.regular_pairs = regular ? 1 : 0;
+  }
+  /* rows per wave of k_bilinear420_rows: every source line pair has to sit in the three-row window of video_bilinear_rows.h */
+  bp.rows = 0;
+  if (bp.regular_pairs && (p.front.width % 16) == 0 && getenv ("GSTAMD_NO_BILINEAR_ROWS") == nullptr) {
+    bool fits = true;
+    for (int y = 0; y < out_h && fits; y++)
+      fits = bilr_window_matches (bp, (int) p.passes[1].offset[y]);
+    int rows_ylen = 0;
+    bp.rows_tile_w = bilr_pick_tile (out_w, p.passes[0].inc, &rows_ylen);
+#ifdef GSTAMD_TUNING
+    if (getenv ("GSTAMD_BIL_ROWS_TILE")) {
+      bp.rows_tile_w = atoi (getenv ("GSTAMD_BIL_ROWS_TILE"));
+      rows_ylen = bil_ylen (out_w, p.passes[0].inc, bp.rows_tile_w);
+    }
+#endif
+    fits = fits && bp.rows_tile_w > 0 && rows_ylen > 0;
+    if (fits)
+      bp.rows = -1;
+#ifdef GSTAMD_TUNING
+    if (fits && getenv ("GSTAMD_BIL_ROWS"))
+      bp.rows = atoi (getenv ("GSTAMD_BIL_ROWS"));
+#endif
+  }
+  *out = bp;
+  return true;
+}
+
 static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
 {
   const VideoPlan &p = c->plan;
@@ -560,69 +634,11 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
   if (p.passes.size () == 2 && small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)) {
     /* nearest / 2-tap in both directions ("bilinear"): one fused kernel, no intermediate image */
     const bool h_first = p.passes[0].horizontal;
-    if (h_first && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && kind_has_planes (p.front.kind) && p.front.w_sub == 1 &&
-        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && ((uintptr_t) dst % 4) == 0 && (dstride % 4) == 0 &&
-        getenv ("GSTAMD_NO_BILINEAR420") == nullptr) {
-      /* semi-planar 4:2:0 source, horizontal-first 2-tap x 2-tap, fast matrix: the direct kernel of video_bilinear_fast.h */
-      BilParams bp;
-      bp.tile_w = bil_pick_tile (out_w, p.passes[0].inc, &bp.ylen);
-      if (const char *e_tw = getenv ("GSTAMD_BIL_TILE")) {      /* tuning knob for profiling sessions */
-        bp.tile_w = atoi (e_tw);
-        bp.ylen = bil_ylen (out_w, p.passes[0].inc, bp.tile_w);
-      }
-      if (bp.tile_w > 0 && bp.ylen > 0) {
-      bp.fp = pf.fp;
-      bp.out_w = out_w;
-      bp.out_h = out_h;
-      bp.inc = p.passes[0].inc;
-      bp.voffset = sd[1].offset;
-      bp.vtaps = sd[1].taps;
-      bp.vpair = p.front.chroma_v2 ? c->vpair_dev : nullptr;
-      bp.regular_pairs = 0;
-      bp.planar = p.front.kind == UNPACK_PLANAR;
-      bp.u_plane = p.front.u_plane;
-      bp.v_plane = p.front.v_plane;
-      if (p.front.chroma_v2 && getenv ("GSTAMD_BIL_TABLE") == nullptr) {
-        /* are the pairs of every source line the kernel will touch the closed form of bil_rows? */
-        bool regular = true;
-        BilParams probe = bp;
-        probe.regular_pairs = 1;
-        for (int y = 0; y < out_h && regular; y++)
-          for (int l = 0; l < 2 && regular; l++) {
-            const int line = (int) p.passes[1].offset[y] + l;
-            int ra, rb, role;
-            bil_rows (probe, line, &ra, &rb, &role);
-            const int e0 = p.vpair[2 * line], ta = vpair_row (e0), trole = vpair_role (e0), tb = p.vpair[2 * line + 1];
-            regular = ta == ra && tb == rb && (ra == rb || trole == role);
-          }
-        bp.regular_pairs = regular ? 1 : 0;
-      }
-      /* rows per wave of k_bilinear420_rows: every source line pair has to sit in the three-row window of video_bilinear_rows.h */
-      bp.rows = 0;
-      if (bp.regular_pairs && (p.front.width % 16) == 0 && getenv ("GSTAMD_NO_BILINEAR_ROWS") == nullptr) {
-        bool fits = true;
-        for (int y = 0; y < out_h && fits; y++)
-          fits = bilr_window_matches (bp, (int) p.passes[1].offset[y]);
-        int rows_ylen = 0;
-        bp.rows_tile_w = bilr_pick_tile (out_w, p.passes[0].inc, &rows_ylen);
-#ifdef GSTAMD_TUNING
-        if (getenv ("GSTAMD_BIL_ROWS_TILE")) {
-          bp.rows_tile_w = atoi (getenv ("GSTAMD_BIL_ROWS_TILE"));
-          rows_ylen = bil_ylen (out_w, p.passes[0].inc, bp.rows_tile_w);
-        }
-#endif
-        fits = fits && bp.rows_tile_w > 0 && rows_ylen > 0;
-        if (fits)
-          bp.rows = -1;
-#ifdef GSTAMD_TUNING
-        if (fits && getenv ("GSTAMD_BIL_ROWS"))
-          bp.rows = atoi (getenv ("GSTAMD_BIL_ROWS"));
-#endif
-      }
+    BilParams bp;
+    if (((uintptr_t) dst % 4) == 0 && (dstride % 4) == 0 && bilinear420_params (c, &bp)) {
       e = launch_bilinear420 (bp, p.front.chroma_h, pl, dst, dstride, stream);
       if (e != hipErrorNotSupported)
         return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420");
-      }
     }
     const ScaleDev &sh = h_first ? sd[0] : sd[1], &sv = h_first ? sd[1] : sd[0];
     e = launch_scale2x2_from_front (p.front, pl, c->vpair_dev, pre, sh, sv, h_first, dst, dstride, post, p.post.pack_pos,
@@ -793,6 +809,28 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     hipError_t e = launch_convert_pair (fp, p.front.chroma_h, n_frames, y.data (), uv.data (), d.data (), p.in_info.stride[0],
         p.in_info.stride[1], p.out_info.stride[0], (hipStream_t) stream_);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair(batch)");
+  }
+  /* one launch for the whole list through the bilinear 4:2:0 kernel as well (k_bilinear420_rows takes the frames as one grid) */
+  BilParams bp;
+  if (!p.rect.fill && p.rect.in_x == 0 && p.rect.in_y == 0 && p.rect.out_x == 0 && p.rect.out_y == 0 && bilinear420_params (c, &bp) && bp.rows != 0) {
+    std::vector<Planes> pls (n_frames);
+    bool ok = true;
+    for (int i = 0; i < n_frames && ok; i++) {
+      if (!src[i] || !dest[i])
+        return set_error (GSTAMD_ERR_INVALID, "NULL frame in list");
+      memset (&pls[i], 0, sizeof (Planes));
+      for (int k = 0; k < p.in_info.n_planes && k < 3; k++) {
+        pls[i].p[k] = (const uint8_t *) src[i] + p.in_info.offset[k];
+        pls[i].stride[k] = p.in_info.stride[k];
+      }
+      d[i] = (uint8_t *) dest[i] + p.out_info.offset[0];
+      ok = ((uintptr_t) d[i] % 4) == 0;
+    }
+    if (ok && (p.out_info.stride[0] % 4) == 0) {
+      hipError_t e = launch_bilinear420_frames (bp, p.front.chroma_h, n_frames, pls.data (), d.data (), p.out_info.stride[0], (hipStream_t) stream_);
+      if (e != hipErrorNotSupported)
+        return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420(batch)");
+    }
   }
   for (int i = 0; i < n_frames; i++) {
     r = gstamd_video_converter_frame (c, src[i], dest[i], stream_);

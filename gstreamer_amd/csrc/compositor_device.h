@@ -573,4 +573,177 @@ GSTAMD_CD int agg_build_list_host (const AggregateParams &p, int wx0, int wx1, i
   return n;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_aggregate_strip: a strip of 256 columns x a few rows per wave with everything that is the same for the whole wave - which pad
+// comes next, its row pointer, position, width and alpha - kept on the scalar side.  k_aggregate spent 559 vector instructions per
+// wave-row on C4 (18.1 M per frame, 81 % of the VALU issue slots: the kernel was bound by them, not by HBM), of which the blend
+// arithmetic is 4 x 16 per pad; the rest was the per-row prologue (descriptor fetch, hit test, list in LDS) and, per pad, reading
+// the list entry back from LDS and broadcasting it (v_readfirstlane is a vector instruction).  Here the pads that touch the strip's
+// columns are ONE bit mask (a ballot, once per wave), the pads of a row are that mask and a ballot of the row test (3 vector
+// instructions per row), and walking the set bits, loading the pad descriptor (s_load from the kernel arguments) and computing
+// the row pointer are scalar instructions, which issue beside the vector ones.
+#define AGGS_SKIP 1     // nothing to blend (a row no pad touches)
+#define AGGS_END 2      // last entry of its row: store the row, start the next from the background
+#define AGGS_NONE 4     // past the last row of the strip
+
+struct AggsEntry {
+  const uint8_t *row;   // the pad's source row under this destination row
+  int xpos, width;
+  uint32_t alpha8081;
+  int ctl;
+};
+
+// what a lane knows about "its" pad (lane k < n_pads holds pad k): enough for the row test
+struct AggsLanePad {
+  int xhit;             // the pad touches the strip's columns
+  int ypos, height;
+};
+
+struct AggsCursor {
+  uint32_t xmask;       // pads that touch the strip's columns
+  uint32_t left;        // pads of row y not yet handed out
+  int y, y_end;
+  int fresh;            // row y has not handed out anything yet
+};
+
+// pads (of xmask) that cover destination row y.  Device: one lane per pad and a ballot; host: the loop it stands for.
+GSTAMD_CD uint32_t aggs_rowmask (const AggregateParams &p, const AggsLanePad &lp, uint32_t xmask, int y)
+{
+#ifdef __HIPCC__
+  (void) p;
+  (void) xmask;
+  return (uint32_t) __ballot (lp.xhit && (unsigned) (y - lp.ypos) < (unsigned) lp.height);
+#else
+  (void) lp;
+  uint32_t m = 0;
+  for (int k = 0; k < p.n_pads; k++)
+    if (((xmask >> k) & 1u) && (unsigned) (y - p.pads[k].ypos) < (unsigned) p.pads[k].height)
+      m |= 1u << k;
+  return m;
+#endif
+}
+
+GSTAMD_CD int aggs_first_bit (uint32_t m)
+{
+#ifdef __HIPCC__
+  return __builtin_ctz (m);
+#else
+  int k = 0;
+  while (!((m >> k) & 1u))
+    k++;
+  return k;
+#endif
+}
+
+// next (row, pad) of the strip: pad index (or -1), flags and row of the entry
+GSTAMD_CD void aggs_advance (const AggregateParams &p, const AggsLanePad &lp, AggsCursor &c, int *k, int *ctl, int *y)
+{
+  if (c.y >= c.y_end) {
+    *k = -1, *ctl = AGGS_NONE, *y = c.y_end - 1;
+    return;
+  }
+  *y = c.y;
+  if (c.left == 0) {            /* only a fresh row gets here: no pad touches it */
+    *k = -1, *ctl = AGGS_SKIP | AGGS_END;
+  } else {
+    *k = aggs_first_bit (c.left);
+    c.left &= c.left - 1;
+    *ctl = c.left == 0 ? AGGS_END : 0;
+  }
+  if (*ctl & AGGS_END) {
+    c.y++;
+    c.left = c.y < c.y_end ? aggs_rowmask (p, lp, c.xmask, c.y) : 0;
+  }
+}
+
+// the entry of pad k on row y (k < 0: a dummy that reads pad 0's first row, which exists on this path)
+GSTAMD_CD AggsEntry aggs_entry (const PadDev &pad, int k, int ctl, int y)
+{
+  AggsEntry e;
+  e.ctl = ctl;
+  if (k < 0) {
+    e.row = pad.data;
+    e.xpos = 0;
+    e.width = 4;
+    e.alpha8081 = 0;
+  } else {
+    e.row = pad.data + (ptrdiff_t) (y - pad.ypos) * pad.stride;
+    e.xpos = pad.xpos;
+    e.width = pad.width;
+    e.alpha8081 = (uint32_t) pad.s_alpha * 0x8081u;
+  }
+  return e;
+}
+
+GSTAMD_CD Px4Words aggs_fetch (const AggsEntry &e, int x)
+{
+  int sx = x - e.xpos;
+  const int hi = e.width - 4;
+  sx = sx < 0 ? 0 : (sx > hi ? hi : sx);
+  return load_px4 (e.row + 4u * (uint32_t) sx);
+}
+
+// pixels x .. x+3 (the first nv inside the rectangle) of rows y0 .. y1-1.  Opaque blends only (p.fast), checker or colour background.
+template <int ASH, int DEPTH>
+GSTAMD_CD void aggregate_strip4 (const AggregateParams &p, const AggsLanePad &lp, uint32_t xmask, uint8_t *dst, int dstride, int x, int y0, int y1, int nv)
+{
+  AggsCursor c;
+  c.xmask = xmask;
+  c.y = y0;
+  c.y_end = y1;
+  c.left = aggs_rowmask (p, lp, xmask, y0);
+  // one entry ahead of the ring: its pad descriptor is on its way from the kernel arguments while the entry before it is set up
+  int pk, pctl, py;
+  aggs_advance (p, lp, c, &pk, &pctl, &py);
+  PadDev pend = p.pads[pk < 0 ? 0 : pk];
+  AggsEntry ring[DEPTH];
+  Px4Words buf[DEPTH];
+#pragma unroll
+  for (int j = 0; j < DEPTH; j++) {
+    ring[j] = aggs_entry (pend, pk, pctl, py);
+    aggs_advance (p, lp, c, &pk, &pctl, &py);
+    pend = p.pads[pk < 0 ? 0 : pk];
+    buf[j] = aggs_fetch (ring[j], x);
+    issue_order_fence ();
+  }
+  Px2 acc[4];
+  int y = y0;
+  agg_background4 (p, acc, x, y);
+  for (;;) {
+#pragma unroll
+    for (int j = 0; j < DEPTH; j++) {
+      const AggsEntry e = ring[j];
+      const Px4Words cur = buf[j];
+      ring[j] = aggs_entry (pend, pk, pctl, py);
+      aggs_advance (p, lp, c, &pk, &pctl, &py);
+      pend = p.pads[pk < 0 ? 0 : pk];
+      buf[j] = aggs_fetch (ring[j], x);
+      if (e.ctl & AGGS_NONE)
+        return;
+      if (!(e.ctl & AGGS_SKIP)) {
+        const int sx = x - e.xpos, w = e.width;
+        if ((unsigned) sx <= (unsigned) (w - 4)) {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            px2_blend_lazy<ASH> (acc[i], cur.v[i], e.alpha8081);
+        } else if ((unsigned) (sx + 3) < (unsigned) (w + 3)) {           // lane straddles a pad edge
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (sx + i >= 0 && sx + i < w)
+              px2_blend_lazy<ASH> (acc[i], load_px1 (e.row + 4 * (ptrdiff_t) (sx + i)), e.alpha8081);
+        }
+      }
+      if (e.ctl & AGGS_END) {
+        uint32_t d[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          d[i] = px2_pack (acc[i]) | (0xffu << ASH);
+        agg_store4 (dst + (ptrdiff_t) y * dstride + 4 * (ptrdiff_t) x, d, nv);
+        y++;
+        agg_background4 (p, acc, x, y);
+      }
+    }
+  }
+}
+
 }  // namespace gstamd

@@ -74,7 +74,11 @@ __global__ __launch_bounds__ (256) void k_aggregate (AggregateParams p, uint8_t 
   }
 }
 
-// Several rows per wave (compositor_device.h, "Several rows per wave"): workgroup = one wave = 256 columns x `rows` rows.
+#ifdef GSTAMD_TUNING
+// Several rows per wave (compositor_device.h, "Several rows per wave"): workgroup = one wave = 256 columns x `rows` rows.  Measured
+// on C4 and NOT used by the product library: 1 row 38.5 us, 2 rows 37.1, 4 rows 40.5, 8 rows 53 (k_aggregate: 36.1) - the
+// waves get fewer and the ones under nine pads longer, which costs more than the descriptor fetch and the pipeline drain it saves
+// (profiles/r02_c4_rows_variants.log).
 template <int ASH, int DEPTH>
 __global__ __launch_bounds__ (64) void k_aggregate_rows (AggregateParams p, uint8_t *__restrict__ dst, int dstride, int rx0, int ry0,
     int rw, int rh, int rows, int strips)
@@ -129,6 +133,29 @@ __global__ __launch_bounds__ (64) void k_aggregate_rows (AggregateParams p, uint
     y += ny;
   }
 }
+#endif
+
+// Strip form with the pad walk on the scalar unit (compositor_device.h, "k_aggregate_strip"): workgroup = one wave = 256 columns
+// x `rows` rows.
+template <int ASH, int DEPTH>
+__global__ __launch_bounds__ (64) void k_aggregate_strip (AggregateParams p, uint8_t *__restrict__ dst, int dstride, int rx0, int ry0, int rw,
+    int rh, int rows, int strips)
+{
+  const int lane = (int) threadIdx.x;
+  const int strip = (int) blockIdx.x % strips, rg = (int) blockIdx.x / strips;
+  const int wx0 = rx0 + strip * 256, wx1 = wx0 + 256 < rx0 + rw ? wx0 + 256 : rx0 + rw;
+  const int x = wx0 + 4 * lane;
+  int nv = rx0 + rw - x;
+  nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+  const int y0 = ry0 + rg * rows, y1 = y0 + rows < ry0 + rh ? y0 + rows : ry0 + rh;
+  const PadDev pad = p.pads[lane < p.n_pads ? lane : 0];
+  AggsLanePad lp;
+  lp.xhit = (lane < p.n_pads) & pad_xhit (pad, wx0, wx1);
+  lp.ypos = pad.ypos;
+  lp.height = pad.height;
+  const uint32_t xmask = (uint32_t) __ballot (lp.xhit);
+  aggregate_strip4<ASH, DEPTH> (p, lp, xmask, dst, dstride, x, y0, y1, nv);
+}
 
 static thread_local std::string g_comp_error;
 extern "C" const char *gstamd_last_error (void);
@@ -167,34 +194,37 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
 #else
   const int abl = 0;
 #endif
-  int rows = 4, depth = 4;
-  bool by_rows = q.fast && q.n_pads > 0 && q.bg_kind != 2;
 #ifdef GSTAMD_TUNING
-  if (getenv ("GSTAMD_AGG_ROWS"))
-    rows = atoi (getenv ("GSTAMD_AGG_ROWS"));
-  if (getenv ("GSTAMD_AGG_DEPTH"))
-    depth = atoi (getenv ("GSTAMD_AGG_DEPTH"));
-  if (rows <= 0)
-    by_rows = false;
-#endif
-  if (by_rows && abl == 0) {
+  const int rows = getenv ("GSTAMD_AGG_ROWS") ? atoi (getenv ("GSTAMD_AGG_ROWS")) : 0;
+  const int depth = getenv ("GSTAMD_AGG_DEPTH") ? atoi (getenv ("GSTAMD_AGG_DEPTH")) : 4;
+  if (rows > 0 && q.fast && q.n_pads > 0 && q.bg_kind != 2 && abl == 0) {
     const int strips = (rw + 255) / 256;
     dim3 rgrid (strips * ((rh + rows - 1) / rows)), rblock (64);
 #define AGG_ROWS_LAUNCH(S, D) hipLaunchKernelGGL ((k_aggregate_rows<S, D>), rgrid, rblock, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh, rows, strips)
     if (q.ashift == 0) {
-#ifdef GSTAMD_TUNING
-      if (depth == 8) AGG_ROWS_LAUNCH (0, 8); else if (depth == 6) AGG_ROWS_LAUNCH (0, 6); else
-#endif
-      AGG_ROWS_LAUNCH (0, 4);
+      if (depth == 8) AGG_ROWS_LAUNCH (0, 8); else if (depth == 6) AGG_ROWS_LAUNCH (0, 6); else AGG_ROWS_LAUNCH (0, 4);
     } else {
-#ifdef GSTAMD_TUNING
-      if (depth == 8) AGG_ROWS_LAUNCH (24, 8); else if (depth == 6) AGG_ROWS_LAUNCH (24, 6); else
-#endif
-      AGG_ROWS_LAUNCH (24, 4);
+      if (depth == 8) AGG_ROWS_LAUNCH (24, 8); else if (depth == 6) AGG_ROWS_LAUNCH (24, 6); else AGG_ROWS_LAUNCH (24, 4);
     }
 #undef AGG_ROWS_LAUNCH
-    (void) depth;
     return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
+  }
+#endif
+  {
+    int srows = 2;
+#ifdef GSTAMD_TUNING
+    if (getenv ("GSTAMD_AGG_STRIP_ROWS"))
+      srows = atoi (getenv ("GSTAMD_AGG_STRIP_ROWS"));
+#endif
+    if (srows > 0 && q.fast && q.n_pads > 0 && q.bg_kind != 2 && abl == 0) {
+      const int strips = (rw + 255) / 256;
+      dim3 sgrid (strips * ((rh + srows - 1) / srows)), sblock (64);
+      if (q.ashift == 0)
+        hipLaunchKernelGGL ((k_aggregate_strip<0, 4>), sgrid, sblock, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh, srows, strips);
+      else
+        hipLaunchKernelGGL ((k_aggregate_strip<24, 4>), sgrid, sblock, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh, srows, strips);
+      return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
+    }
   }
   dim3 grid ((lanes + bx - 1) / bx, rh), block (bx);
 #define AGG_LAUNCH(A, S) hipLaunchKernelGGL ((k_aggregate<A, S>), grid, block, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh)

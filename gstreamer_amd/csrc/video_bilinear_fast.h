@@ -37,6 +37,14 @@ GSTAMD_HD BilLds bil_lds (uint32_t *base, int ylen)
 }
 GSTAMD_HOSTDEV size_t bil_lds_words (int ylen) { return (size_t) ylen + 4 * (size_t) bil_clen (ylen); }
 
+// the frames of one launch of k_bilinear420_rows (same VideoInfo, hence same pitches): plane pointers per frame
+#define GSTAMD_BIL_MAX_BATCH 32
+struct BilBatch {
+  const uint8_t *p[3][GSTAMD_BIL_MAX_BATCH];
+  uint8_t *dst[GSTAMD_BIL_MAX_BATCH];
+  int stride[3];
+};
+
 struct BilParams {
   FastParams fp;        // width / height = SOURCE size; matrix, layout
   int out_w, out_h;

@@ -102,8 +102,10 @@ GSTAMD_HD void bilr_load_raw (const BilParams &bp, const Planes &pl, int crow, i
     r.up = *(const uint16_t *) (row + (uint32_t) (2 * kp));
     r.vm = r.vp = 0;
   } else {
-    const uint8_t *ru = pl.p[bp.u_plane] + (ptrdiff_t) crow * pl.stride[bp.u_plane];
-    const uint8_t *rv = pl.p[bp.v_plane] + (ptrdiff_t) crow * pl.stride[bp.v_plane];
+    /* a select of the two plane pointers, not pl.p[bp.u_plane]: indexing the array loses the pointers' address space and the loads
+     * come out as FLAT instructions, which wait on both counters */
+    const uint8_t *ru = (bp.u_plane == 1 ? pl.p[1] : pl.p[2]) + (ptrdiff_t) crow * (bp.u_plane == 1 ? pl.stride[1] : pl.stride[2]);
+    const uint8_t *rv = (bp.v_plane == 1 ? pl.p[1] : pl.p[2]) + (ptrdiff_t) crow * (bp.v_plane == 1 ? pl.stride[1] : pl.stride[2]);
     const uint2 mu = *(const uint2 *) (ru + (uint32_t) k0), mv = *(const uint2 *) (rv + (uint32_t) k0);
     r.u0 = mu.x, r.u1 = mu.y, r.v0 = mv.x, r.v1 = mv.y;
     r.um = ru[(uint32_t) km], r.up = ru[(uint32_t) kp], r.vm = rv[(uint32_t) km], r.vp = rv[(uint32_t) kp];

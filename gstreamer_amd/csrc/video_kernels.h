@@ -39,6 +39,8 @@ hipError_t launch_hscale420_reg (const H420RegParams &p, int chroma_h, int nw, i
 hipError_t launch_convert422 (const Fast422Params &p, const uint8_t *src, int sstride, uint8_t *dst, int dstride, hipStream_t stream);
 hipError_t launch_convert420p (const Fast420pParams &p, uint8_t *dst, int dstride, hipStream_t stream);
 hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream);
+// n frames of the same geometry in as few launches as the kernel allows (one, when k_bilinear420_rows takes them)
+hipError_t launch_bilinear420_frames (const BilParams &bp, int chroma_h, int n, const Planes *pl, uint8_t *const *dst, int dstride, hipStream_t stream);
 hipError_t launch_plane_simple (int kind, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems, int ow, int oh, hipStream_t stream);
 hipError_t launch_plane_pass (bool horizontal, const ScaleDev &sd, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems,
     int ow, int oh, hipStream_t stream);

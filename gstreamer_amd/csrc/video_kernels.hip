@@ -327,7 +327,7 @@ __global__ __launch_bounds__ (64) void k_bilinear420 (BilParams bp, Planes pl, u
 // the same path with the chroma work done once per source pixel in byte lanes (video_bilinear_rows.h): workgroup = one wave =
 // 256 outputs x `bp.rows` consecutive output rows
 template <int CH, int L, int NP>
-__global__ __launch_bounds__ (256) void k_bilinear420_rows (BilParams bp, Planes pl, uint8_t *__restrict__ dst, int dstride, int tiles_x)
+static __device__ __forceinline__ void bilinear420_rows_body (const BilParams &bp, const Planes &pl, uint8_t *__restrict__ dst, int dstride, int tiles_x, int fblock)
 {
   /* the waves of a workgroup are independent (no barrier, an LDS slice each); a workgroup of several only makes the dispatcher's
    * job smaller - it places workgroups one at a time, and with thousands of single-wave groups the last waves start microseconds
@@ -336,7 +336,7 @@ __global__ __launch_bounds__ (256) void k_bilinear420_rows (BilParams bp, Planes
   const int wave = __builtin_amdgcn_readfirstlane ((int) threadIdx.x >> 6), waves = (int) blockDim.x >> 6;      /* wave-uniform: keep it scalar */
   uint8_t *lds = lds_all + wave * (BILR_PLANES * BILR_PLANE_BYTES);
   int tile, g;
-  if (!wide_block_map ((((int) blockIdx.x >> 3) * waves + wave) * 8 + ((int) blockIdx.x & 7), tiles_x, bp.strips, &tile, &g))
+  if (!wide_block_map (((fblock >> 3) * waves + wave) * 8 + (fblock & 7), tiles_x, bp.strips, &tile, &g))
     return;
   const int lane = (int) threadIdx.x & 63, t0 = tile * bp.rows_tile_w;
   const int t1 = t0 + bp.rows_tile_w < bp.out_w ? t0 + bp.rows_tile_w : bp.out_w;
@@ -372,6 +372,30 @@ __global__ __launch_bounds__ (256) void k_bilinear420_rows (BilParams bp, Planes
     __builtin_amdgcn_wave_barrier ();
     __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
   }
+}
+
+template <int CH, int L, int NP>
+__global__ __launch_bounds__ (256) void k_bilinear420_rows (BilParams bp, Planes pl, uint8_t *__restrict__ dst, int dstride, int tiles_x)
+{
+  bilinear420_rows_body<CH, L, NP> (bp, pl, dst, dstride, tiles_x, (int) blockIdx.x);
+}
+
+// several frames per launch: workgroups [f * blocks_per_frame, (f + 1) * blocks_per_frame) are frame f (blocks_per_frame is a
+// multiple of 8, so a workgroup's XCD is the same with or without the frame offset)
+template <int CH, int L, int NP>
+__global__ __launch_bounds__ (256) void k_bilinear420_rows_frames (BilParams bp, BilBatch fb, int dstride, int tiles_x, int blocks_per_frame)
+{
+  const int frame = (int) blockIdx.x / blocks_per_frame;
+  /* a pointer read out of an indexed kernel-argument array is a generic pointer to the compiler: every access through it becomes a
+   * FLAT instruction, which counts on both vmcnt and lgkmcnt and turns each wait of the kernel into a full drain (3 us per frame
+   * here).  They are global memory: say so. */
+  typedef const __attribute__ ((address_space (1))) uint8_t *gptr_t;
+  Planes pl;
+  pl.p[0] = (const uint8_t *) (gptr_t) fb.p[0][frame], pl.p[1] = (const uint8_t *) (gptr_t) fb.p[1][frame];
+  pl.p[2] = (const uint8_t *) (gptr_t) fb.p[2][frame], pl.p[3] = nullptr;
+  pl.stride[0] = fb.stride[0], pl.stride[1] = fb.stride[1], pl.stride[2] = fb.stride[2], pl.stride[3] = 0;
+  uint8_t *dst = (uint8_t *) (__attribute__ ((address_space (1))) uint8_t *) fb.dst[frame];
+  bilinear420_rows_body<CH, L, NP> (bp, pl, dst, dstride, tiles_x, (int) blockIdx.x - frame * blocks_per_frame);
 }
 
 // plane scaler of planar / semi-planar formats (video_planes.h): one lane per output pixel of the plane
@@ -899,41 +923,58 @@ static int bilr_wave_slots ()
   return slots;
 }
 
-hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
+static int bil_vec_ok (const BilParams &bp, const Planes &pl)
 {
   int vec = aligned (pl.p[0], 16) && aligned (pl.p[1], 16) && (pl.stride[0] % 16) == 0 && (pl.stride[1] % 16) == 0;
-  if (bp.planar) {
+  if (bp.planar)
     /* planar sources only through the straight-line fetch: whole 16-pixel pieces, 8-byte chroma loads */
     vec = aligned (pl.p[0], 16) && (pl.stride[0] % 16) == 0 && aligned (pl.p[1], 8) && aligned (pl.p[2], 8) && (pl.stride[1] % 8) == 0 &&
         (pl.stride[2] % 8) == 0 && (bp.fp.width % 16) == 0;
-    if (!vec)
-      return hipErrorNotSupported;
-  }
-  const int tiles_x = (bp.out_w + bp.tile_w - 1) / bp.tile_w;
-  if (bp.rows != 0 && vec && (bp.fp.width % 16) == 0 && bp.regular_pairs) {
-    const int rtiles = (bp.out_w + bp.rows_tile_w - 1) / bp.rows_tile_w;
-    BilParams rp = bp;
-    int slots = bilr_wave_slots ();
+  return vec;
+}
+
+static hipError_t launch_bilinear420_rows (const BilParams &bp, int chroma_h, int n, const Planes *pl, uint8_t *const *dst, int dstride, hipStream_t stream)
+{
+  const int rtiles = (bp.out_w + bp.rows_tile_w - 1) / bp.rows_tile_w;
+  BilParams rp = bp;
+  int slots = bilr_wave_slots ();
 #ifdef GSTAMD_TUNING
-    if (getenv ("GSTAMD_BIL_SLOTS"))
-      slots = atoi (getenv ("GSTAMD_BIL_SLOTS"));
-    if (getenv ("GSTAMD_BIL_VERBOSE"))
-      fprintf (stderr, "k_bilinear420_rows: slots %d (device query %d), tiles %d, strips %d\n", slots, bilr_wave_slots (), rtiles,
-          bilr_strips (bp.out_h, bp.rows, rtiles, slots));
+  if (getenv ("GSTAMD_BIL_SLOTS"))
+    slots = atoi (getenv ("GSTAMD_BIL_SLOTS"));
 #endif
-    rp.strips = bilr_strips (bp.out_h, bp.rows, rtiles, slots - slots / 16);      /* a full round that tips over into a second one costs 20 %: keep a margin */
-    int wg = 1;
+  /* one frame: as many strips as make one resident round (a round that tips over into a second one costs 20 %: keep a margin);
+   * several frames: the rounds follow each other anyway, strips of six rows */
+  rp.strips = n > 1 && bp.rows < 0 ? bilr_strips (bp.out_h, 6, rtiles, 0) : bilr_strips (bp.out_h, bp.rows, rtiles, slots - slots / 16);
+  int wg = 1;
 #ifdef GSTAMD_TUNING
-    if (getenv ("GSTAMD_BIL_WG"))
-      wg = atoi (getenv ("GSTAMD_BIL_WG"));
+  if (getenv ("GSTAMD_BIL_WG"))
+    wg = atoi (getenv ("GSTAMD_BIL_WG"));
+  if (getenv ("GSTAMD_BIL_VERBOSE"))
+    fprintf (stderr, "k_bilinear420_rows: %d frame(s), slots %d, tiles %d, strips %d\n", n, slots, rtiles, rp.strips);
 #endif
-    dim3 rgrid (wide_grid_blocks (rtiles, rp.strips) / wg), rblock (64 * wg);      /* the grid is a multiple of 256 blocks */
-    const size_t rlds = (size_t) wg * bilr_lds_bytes ();
+  const int blocks_per_frame = wide_grid_blocks (rtiles, rp.strips) / wg;         /* a multiple of 256 / wg */
+  const size_t rlds = (size_t) wg * bilr_lds_bytes ();
+  for (int base = 0; base < n; base += GSTAMD_BIL_MAX_BATCH) {
+    const int nb = n - base < GSTAMD_BIL_MAX_BATCH ? n - base : GSTAMD_BIL_MAX_BATCH;
+    BilBatch fb;
+    memset (&fb, 0, sizeof (fb));
+    for (int f = 0; f < nb; f++) {
+      for (int k = 0; k < 3; k++)
+        fb.p[k][f] = pl[base + f].p[k];
+      fb.dst[f] = dst[base + f];
+    }
+    for (int k = 0; k < 3; k++)
+      fb.stride[k] = pl[0].stride[k];
+    dim3 rgrid ((unsigned) blocks_per_frame * (unsigned) nb), rblock (64 * wg);
 #define WR(CH, LAY) \
-    if (bp.rows_tile_w > 256) \
-      hipLaunchKernelGGL ((k_bilinear420_rows<CH, LAY, 3>), rgrid, rblock, rlds, stream, rp, pl, dst, dstride, rtiles); \
+    if (nb == 1 && bp.rows_tile_w > 256) \
+      hipLaunchKernelGGL ((k_bilinear420_rows<CH, LAY, 3>), rgrid, rblock, rlds, stream, rp, pl[base], dst[base], dstride, rtiles); \
+    else if (nb == 1) \
+      hipLaunchKernelGGL ((k_bilinear420_rows<CH, LAY, 2>), rgrid, rblock, rlds, stream, rp, pl[base], dst[base], dstride, rtiles); \
+    else if (bp.rows_tile_w > 256) \
+      hipLaunchKernelGGL ((k_bilinear420_rows_frames<CH, LAY, 3>), rgrid, rblock, rlds, stream, rp, fb, dstride, rtiles, blocks_per_frame); \
     else \
-      hipLaunchKernelGGL ((k_bilinear420_rows<CH, LAY, 2>), rgrid, rblock, rlds, stream, rp, pl, dst, dstride, rtiles);
+      hipLaunchKernelGGL ((k_bilinear420_rows_frames<CH, LAY, 2>), rgrid, rblock, rlds, stream, rp, fb, dstride, rtiles, blocks_per_frame);
 #define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \
     if (chroma_h == CHROMA_H_H2_CS) { \
       WR (CHROMA_H_H2_CS, GSTAMD_LAYOUT (pr, pg, pb)) \
@@ -942,14 +983,41 @@ hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &
     } else { \
       WR (CHROMA_H_NONE, GSTAMD_LAYOUT (pr, pg, pb)) \
     } \
-    return hipGetLastError ();
+    break;
     switch (fast_layout (bp.fp)) {
       GSTAMD_FOR_LAYOUTS (W)
+      default:
+        return hipErrorInvalidValue;
     }
 #undef W
 #undef WR
-    return hipErrorInvalidValue;
   }
+  return hipGetLastError ();
+}
+
+hipError_t launch_bilinear420_frames (const BilParams &bp, int chroma_h, int n, const Planes *pl, uint8_t *const *dst, int dstride, hipStream_t stream)
+{
+  bool rows_ok = bp.rows != 0 && (bp.fp.width % 16) == 0 && bp.regular_pairs;
+  for (int f = 0; f < n && rows_ok; f++)
+    rows_ok = bil_vec_ok (bp, pl[f]) && pl[f].stride[0] == pl[0].stride[0] && pl[f].stride[1] == pl[0].stride[1] && pl[f].stride[2] == pl[0].stride[2];
+  if (rows_ok)
+    return launch_bilinear420_rows (bp, chroma_h, n, pl, dst, dstride, stream);
+  for (int f = 0; f < n; f++) {
+    const hipError_t e = launch_bilinear420 (bp, chroma_h, pl[f], dst[f], dstride, stream);
+    if (e != hipSuccess)
+      return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
+{
+  const int vec = bil_vec_ok (bp, pl);
+  if (bp.planar && !vec)
+    return hipErrorNotSupported;
+  if (bp.rows != 0 && vec && (bp.fp.width % 16) == 0 && bp.regular_pairs)
+    return launch_bilinear420_rows (bp, chroma_h, 1, &pl, &dst, dstride, stream);
+  const int tiles_x = (bp.out_w + bp.tile_w - 1) / bp.tile_w;
   dim3 grid (wide_grid_blocks (tiles_x, bp.out_h));
   const size_t lds_bytes = bil_lds_words (bp.ylen) * 4;
 #define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \

@@ -6,8 +6,9 @@
 
 using namespace gstamd;
 
-static int emu_rows_runs = 0;
+static int emu_rows_runs = 0, emu_strip_runs = 0;
 extern "C" int emu_compositor_rows_runs (void) { return emu_rows_runs; }
+extern "C" int emu_compositor_strip_runs (void) { return emu_strip_runs; }
 
 extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int dstride, int rx0, int ry0, int rw, int rh)
 {
@@ -17,9 +18,9 @@ extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int 
   for (int i = 0; i < p->n_pads; i++)
     if (p->pads[i].mode == GSTAMD_COMPOSITOR_BLEND_MODE_SOURCE || p->pads[i].width < 4)
       q.fast = 0;
-  if (q.fast && q.n_pads > 0 && q.bg_kind != 2 && !getenv ("EMU_AGG_SINGLE_ROW")) {
-    /* k_aggregate_rows: strips of 256 columns x `rows` rows, one entry list per pass */
-    const int rows = getenv ("EMU_AGG_ROWS") ? atoi (getenv ("EMU_AGG_ROWS")) : 4;
+  if (q.fast && q.n_pads > 0 && q.bg_kind != 2 && getenv ("EMU_AGG_ROWS")) {
+    /* k_aggregate_rows (tuning builds only): strips of 256 columns x `rows` rows, one entry list per pass */
+    const int rows = atoi (getenv ("EMU_AGG_ROWS"));
     emu_rows_runs++;
     for (int y0 = ry0; y0 < ry0 + rh; y0 += rows)
       for (int wx0 = rx0; wx0 < rx0 + rw; wx0 += 256) {
@@ -41,6 +42,29 @@ extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int 
             else
               aggregate_rows4<24, 4> (q, list, n, dst, dstride, x, y, nv);
           }
+        }
+      }
+    return;
+  }
+  if (q.fast && q.n_pads > 0 && q.bg_kind != 2 && !getenv ("EMU_AGG_SINGLE_ROW")) {
+    /* k_aggregate_strip: strips of 256 columns x `rows` rows, the pad walk of aggregate_strip4 */
+    const int rows = getenv ("EMU_AGG_STRIP_ROWS") ? atoi (getenv ("EMU_AGG_STRIP_ROWS")) : 2;
+    emu_strip_runs++;
+    for (int y0 = ry0; y0 < ry0 + rh; y0 += rows)
+      for (int wx0 = rx0; wx0 < rx0 + rw; wx0 += 256) {
+        const int wx1 = wx0 + 256 < rx0 + rw ? wx0 + 256 : rx0 + rw, y1 = y0 + rows < ry0 + rh ? y0 + rows : ry0 + rh;
+        uint32_t xmask = 0;
+        for (int k = 0; k < q.n_pads; k++)
+          xmask |= pad_xhit (q.pads[k], wx0, wx1) ? 1u << k : 0u;
+        AggsLanePad lp = {0, 0, 0};
+        for (int lane = 0; lane < 64; lane++) {
+          const int x = wx0 + 4 * lane;
+          int nv = rx0 + rw - x;
+          nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+          if (q.ashift == 0)
+            aggregate_strip4<0, 4> (q, lp, xmask, dst, dstride, x, y0, y1, nv);
+          else
+            aggregate_strip4<24, 4> (q, lp, xmask, dst, dstride, x, y0, y1, nv);
         }
       }
     return;

@@ -146,19 +146,22 @@ def test_aggregate_packed_path_on_host_matches_reference(emu_lib, ref, fmt, back
         k += 1
     p.n_pads = k
     got = np.zeros(dw * dh * 4, np.uint8)
-    emu_lib.emu_compositor_rows_runs.restype = C.c_int
-    before = emu_lib.emu_compositor_rows_runs()
+    emu_lib.emu_compositor_strip_runs.restype = emu_lib.emu_compositor_rows_runs.restype = C.c_int
+    before = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs())
     emu_lib.emu_compositor_run(C.byref(p), got.ctypes.data, dw * 4, 0, 0, dw, dh)
-    assert emu_lib.emu_compositor_rows_runs() == before + 1        # the several-rows-per-wave form (k_aggregate_rows)
+    after = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs())
+    assert (after[0] - before[0], after[1] - before[1]) == (1, 0)      # k_aggregate_strip is the path of all-opaque-blend frames
     assert (exp == got).all()
 
 
-@pytest.mark.parametrize("rows,n_pads,dw", [(1, 5, 300), (7, 30, 530), (16, 9, 257)])
-def test_aggregate_rows_per_wave_list_on_host_matches_reference(emu_lib, ref, rows, n_pads, dw, monkeypatch):
-    """k_aggregate_rows' entry list: more x-hits than one pass holds (30 pads x 7 rows > AGG_LIST_MAX -> several passes), rows no
+@pytest.mark.parametrize("kind", ["strip", "rows"])
+@pytest.mark.parametrize("rows,n_pads,dw", [(1, 5, 300), (7, 30, 530), (16, 9, 257), (2, 32, 1030)])
+def test_aggregate_rows_per_wave_list_on_host_matches_reference(emu_lib, ref, rows, n_pads, dw, kind, monkeypatch):
+    """k_aggregate_rows (a measured variant kept in tuning builds, compositor_kernels.hip) - its entry list: more x-hits than one pass holds (30 pads x 7 rows > AGG_LIST_MAX -> several passes), rows no
     pad touches (skip entries), several strips of 256 columns with a ragged last lane, rows per wave not dividing the height."""
     emu_lib.emu_compositor_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
-    monkeypatch.setenv("EMU_AGG_ROWS", str(rows))
+    # "strip": k_aggregate_strip, the product path (pad walk on the scalar unit); "rows": k_aggregate_rows, the tuning-only variant
+    monkeypatch.setenv("EMU_AGG_STRIP_ROWS" if kind == "strip" else "EMU_AGG_ROWS", str(rows))
     fmt, dh, pw, ph = "BGRA", 61, 170, 23
     pads_np = [cases.frame_bytes(pw * ph * 4, "random", 7300 + i) for i in range(n_pads)]
     geo = [((i * 37) % (dw - 20) - 9, (i * 5) % 30 + (8 if i % 2 else -6), min(1.0, 0.2 + 0.03 * i), 1) for i in range(n_pads)]
@@ -170,7 +173,11 @@ def test_aggregate_rows_per_wave_list_on_host_matches_reference(emu_lib, ref, ro
         pd.data, pd.width, pd.height, pd.stride, pd.xpos, pd.ypos, pd.s_alpha, pd.mode = pads_np[k].ctypes.data, pw, ph, pw * 4, xpos, ypos, int(alpha * 255), mode
     p.n_pads = n_pads
     got = np.zeros(dw * dh * 4, np.uint8)
+    emu_lib.emu_compositor_strip_runs.restype = emu_lib.emu_compositor_rows_runs.restype = C.c_int
+    before = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs())
     emu_lib.emu_compositor_run(C.byref(p), got.ctypes.data, dw * 4, 0, 0, dw, dh)
+    after = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs())
+    assert (after[0] - before[0], after[1] - before[1]) == ((1, 0) if kind == "strip" else (0, 1))
     assert (exp == got).all()
 
 

@@ -146,6 +146,28 @@ def test_hip_bilinear420_rows_shapes_match_reference_bytewise(native_lib, gpu, r
     assert (out == exp).all(), int((out != exp).sum())
 
 
+@pytest.mark.parametrize("shape", [("NV12", 1920, 1080, "BGRA", 960, 540, 5), ("I420", 1280, 720, "RGBA", 854, 480, 3), ("NV12", 3840, 2160, "BGRA", 1920, 1080, 34)],
+                         ids=lambda s: "%s_%dx%d_x%d" % (s[0], s[1], s[2], s[5]))
+def test_hip_bilinear_frame_list_is_one_launch_and_matches_reference(native_lib, gpu, ref, shape):
+    """gstamd_video_converter_frames on a bilinear 4:2:0 plan: the list goes to the GPU as one grid (k_bilinear420_rows_frames; lists
+    longer than 32 frames in chunks) and every frame equals the reference's."""
+    import torch
+    ifmt, w, h, ofmt, ow, oh, n = shape
+    ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)
+    conv = V.VideoConverter(ii, oi, V.converter_config(**cases.LIN))
+    rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, cases.LIN))
+    srcs = [cases.frame_bytes(int(ii.size), "random", 9100 + 7 * i + w) for i in range(min(n, 4))]
+    d_src = [torch.from_numpy(s).to(gpu) for s in srcs]
+    d_dst = [torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu) for _ in range(n)]
+    conv.frames([d_src[i % len(d_src)] for i in range(n)], d_dst)
+    torch.cuda.synchronize()
+    exp = [rc.frame(s) for s in srcs]
+    for i in range(n):
+        out = d_dst[i].cpu().numpy()
+        assert (out == exp[i % len(exp)]).all(), (i, int((out != exp[i % len(exp)]).sum()))
+    conv.free()
+
+
 H420_SHAPES = [("NV12", 1280, 720, "BGRA", 320, 180, "lanczos"), ("NV21", 1920, 1080, "RGBA", 480, 270, "lanczos"),
                ("I420", 2048, 856, "ARGB", 512, 214, "lanczos"), ("YV12", 640, 359, "BGRA", 160, 90, "lanczos"),
                ("NV12", 1920, 1080, "BGRA", 640, 360, "lanczos"), ("I420", 1280, 720, "RGBA", 640, 360, "lanczos"),

@@ -657,6 +657,7 @@ GSTAMD_CD void aggs_advance (const AggregateParams &p, const AggsLanePad &lp, Ag
 }
 
 // the entry of pad k on row y (k < 0: a dummy that reads pad 0's first row, which exists on this path)
+template <int NPX>
 GSTAMD_CD AggsEntry aggs_entry (const PadDev &pad, int k, int ctl, int y)
 {
   AggsEntry e;
@@ -664,7 +665,7 @@ GSTAMD_CD AggsEntry aggs_entry (const PadDev &pad, int k, int ctl, int y)
   if (k < 0) {
     e.row = pad.data;
     e.xpos = 0;
-    e.width = 4;
+    e.width = NPX;              /* the fetch reads NPX pixels from the row's start: every pad is at least that wide on this path */
     e.alpha8081 = 0;
   } else {
     e.row = pad.data + (ptrdiff_t) (y - pad.ypos) * pad.stride;
@@ -675,17 +676,22 @@ GSTAMD_CD AggsEntry aggs_entry (const PadDev &pad, int k, int ctl, int y)
   return e;
 }
 
-GSTAMD_CD Px4Words aggs_fetch (const AggsEntry &e, int x)
+// NPX / 4 16-byte pieces of the entry's row under destination pixels x .. x + NPX - 1 (clamped into the row: width >= NPX here)
+template <int NPX>
+GSTAMD_CD void aggs_fetch (const AggsEntry &e, int x, Px4Words *out)
 {
   int sx = x - e.xpos;
-  const int hi = e.width - 4;
+  const int hi = e.width - NPX;
   sx = sx < 0 ? 0 : (sx > hi ? hi : sx);
-  return load_px4 (e.row + 4u * (uint32_t) sx);
+#pragma unroll
+  for (int q = 0; q < NPX / 4; q++)
+    out[q] = load_px4 (e.row + 4u * (uint32_t) sx + 16u * q);
 }
 
-// pixels x .. x+3 (the first nv inside the rectangle) of rows y0 .. y1-1.  Opaque blends only (p.fast), checker or colour background.
-template <int ASH, int DEPTH>
-GSTAMD_CD void aggregate_strip4 (const AggregateParams &p, const AggsLanePad &lp, uint32_t xmask, uint8_t *dst, int dstride, int x, int y0, int y1, int nv)
+// pixels x .. x + NPX - 1 (the first nv inside the rectangle) of rows y0 .. y1-1.  Opaque blends only (p.fast), checker or colour
+// background.  NPX = 4 or 8 pixels per lane (a wave covers 256 or 512 columns).
+template <int ASH, int DEPTH, int NPX>
+GSTAMD_CD void aggregate_strip (const AggregateParams &p, const AggsLanePad &lp, uint32_t xmask, uint8_t *dst, int dstride, int x, int y0, int y1, int nv)
 {
   AggsCursor c;
   c.xmask = xmask;
@@ -697,53 +703,70 @@ GSTAMD_CD void aggregate_strip4 (const AggregateParams &p, const AggsLanePad &lp
   aggs_advance (p, lp, c, &pk, &pctl, &py);
   PadDev pend = p.pads[pk < 0 ? 0 : pk];
   AggsEntry ring[DEPTH];
-  Px4Words buf[DEPTH];
+  Px4Words buf[DEPTH][NPX / 4];
 #pragma unroll
   for (int j = 0; j < DEPTH; j++) {
-    ring[j] = aggs_entry (pend, pk, pctl, py);
+    ring[j] = aggs_entry<NPX> (pend, pk, pctl, py);
     aggs_advance (p, lp, c, &pk, &pctl, &py);
     pend = p.pads[pk < 0 ? 0 : pk];
-    buf[j] = aggs_fetch (ring[j], x);
+    aggs_fetch<NPX> (ring[j], x, buf[j]);
     issue_order_fence ();
   }
-  Px2 acc[4];
+  Px2 acc[NPX];
   int y = y0;
-  agg_background4 (p, acc, x, y);
+#pragma unroll
+  for (int q = 0; q < NPX / 4; q++)
+    agg_background4 (p, acc + 4 * q, x + 4 * q, y);
   for (;;) {
 #pragma unroll
     for (int j = 0; j < DEPTH; j++) {
       const AggsEntry e = ring[j];
-      const Px4Words cur = buf[j];
-      ring[j] = aggs_entry (pend, pk, pctl, py);
+      Px4Words cur[NPX / 4];
+#pragma unroll
+      for (int q = 0; q < NPX / 4; q++)
+        cur[q] = buf[j][q];
+      ring[j] = aggs_entry<NPX> (pend, pk, pctl, py);
       aggs_advance (p, lp, c, &pk, &pctl, &py);
       pend = p.pads[pk < 0 ? 0 : pk];
-      buf[j] = aggs_fetch (ring[j], x);
+      aggs_fetch<NPX> (ring[j], x, buf[j]);
       if (e.ctl & AGGS_NONE)
         return;
       if (!(e.ctl & AGGS_SKIP)) {
         const int sx = x - e.xpos, w = e.width;
-        if ((unsigned) sx <= (unsigned) (w - 4)) {
+        if ((unsigned) sx <= (unsigned) (w - NPX)) {
 #pragma unroll
-          for (int i = 0; i < 4; i++)
-            px2_blend_lazy<ASH> (acc[i], cur.v[i], e.alpha8081);
-        } else if ((unsigned) (sx + 3) < (unsigned) (w + 3)) {           // lane straddles a pad edge
+          for (int i = 0; i < NPX; i++)
+            px2_blend_lazy<ASH> (acc[i], cur[i >> 2].v[i & 3], e.alpha8081);
+        } else if ((unsigned) (sx + NPX - 1) < (unsigned) (w + NPX - 1)) {       // lane straddles a pad edge
 #pragma unroll
-          for (int i = 0; i < 4; i++)
+          for (int i = 0; i < NPX; i++)
             if (sx + i >= 0 && sx + i < w)
               px2_blend_lazy<ASH> (acc[i], load_px1 (e.row + 4 * (ptrdiff_t) (sx + i)), e.alpha8081);
         }
       }
       if (e.ctl & AGGS_END) {
-        uint32_t d[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          d[i] = px2_pack (acc[i]) | (0xffu << ASH);
-        agg_store4 (dst + (ptrdiff_t) y * dstride + 4 * (ptrdiff_t) x, d, nv);
+        for (int q = 0; q < NPX / 4; q++) {
+          uint32_t d[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            d[i] = px2_pack (acc[4 * q + i]) | (0xffu << ASH);
+          const int nq = nv - 4 * q;
+          agg_store4 (dst + (ptrdiff_t) y * dstride + 4 * (ptrdiff_t) (x + 4 * q), d, nq < 0 ? 0 : (nq > 4 ? 4 : nq));
+        }
         y++;
-        agg_background4 (p, acc, x, y);
+#pragma unroll
+        for (int q = 0; q < NPX / 4; q++)
+          agg_background4 (p, acc + 4 * q, x + 4 * q, y);
       }
     }
   }
+}
+
+template <int ASH, int DEPTH>
+GSTAMD_CD void aggregate_strip4 (const AggregateParams &p, const AggsLanePad &lp, uint32_t xmask, uint8_t *dst, int dstride, int x, int y0, int y1, int nv)
+{
+  aggregate_strip<ASH, DEPTH, 4> (p, lp, xmask, dst, dstride, x, y0, y1, nv);
 }
 
 }  // namespace gstamd

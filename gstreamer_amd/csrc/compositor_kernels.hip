@@ -135,18 +135,22 @@ __global__ __launch_bounds__ (64) void k_aggregate_rows (AggregateParams p, uint
 }
 #endif
 
-// Strip form with the pad walk on the scalar unit (compositor_device.h, "k_aggregate_strip"): workgroup = one wave = 256 columns
-// x `rows` rows.
-template <int ASH, int DEPTH>
+#ifdef GSTAMD_TUNING
+// Strip form with the pad walk on the scalar unit (compositor_device.h, "k_aggregate_strip"): workgroup = one wave = 64 NPX columns
+// x `rows` rows.  Measured on C4 and NOT used by the product library: 17 % fewer vector instructions than k_aggregate (15.1 M against
+// 18.1 M per frame) and the same 37 us - with the blend arithmetic taken out altogether k_aggregate still takes 33 us, the kernel
+// is bound by its memory path (166 MB in 16-byte pieces from nine pad rows per wave), not by instruction issue; 8 pixels per lane:
+// 49 us (profiles/r02_c4_strip_variants.log, r02_c4_ablation.log, r02_c4_sq_*.json).
+template <int ASH, int DEPTH, int NPX>
 __global__ __launch_bounds__ (64) void k_aggregate_strip (AggregateParams p, uint8_t *__restrict__ dst, int dstride, int rx0, int ry0, int rw,
     int rh, int rows, int strips)
 {
   const int lane = (int) threadIdx.x;
   const int strip = (int) blockIdx.x % strips, rg = (int) blockIdx.x / strips;
-  const int wx0 = rx0 + strip * 256, wx1 = wx0 + 256 < rx0 + rw ? wx0 + 256 : rx0 + rw;
-  const int x = wx0 + 4 * lane;
+  const int wx0 = rx0 + strip * 64 * NPX, wx1 = wx0 + 64 * NPX < rx0 + rw ? wx0 + 64 * NPX : rx0 + rw;
+  const int x = wx0 + NPX * lane;
   int nv = rx0 + rw - x;
-  nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+  nv = nv < 0 ? 0 : (nv > NPX ? NPX : nv);
   const int y0 = ry0 + rg * rows, y1 = y0 + rows < ry0 + rh ? y0 + rows : ry0 + rh;
   const PadDev pad = p.pads[lane < p.n_pads ? lane : 0];
   AggsLanePad lp;
@@ -154,8 +158,9 @@ __global__ __launch_bounds__ (64) void k_aggregate_strip (AggregateParams p, uin
   lp.ypos = pad.ypos;
   lp.height = pad.height;
   const uint32_t xmask = (uint32_t) __ballot (lp.xhit);
-  aggregate_strip4<ASH, DEPTH> (p, lp, xmask, dst, dstride, x, y0, y1, nv);
+  aggregate_strip<ASH, DEPTH, NPX> (p, lp, xmask, dst, dstride, x, y0, y1, nv);
 }
+#endif
 
 static thread_local std::string g_comp_error;
 extern "C" const char *gstamd_last_error (void);
@@ -210,22 +215,27 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
     return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
   }
 #endif
-  {
-    int srows = 2;
 #ifdef GSTAMD_TUNING
-    if (getenv ("GSTAMD_AGG_STRIP_ROWS"))
-      srows = atoi (getenv ("GSTAMD_AGG_STRIP_ROWS"));
-#endif
+  {
+    int srows = getenv ("GSTAMD_AGG_STRIP_ROWS") ? atoi (getenv ("GSTAMD_AGG_STRIP_ROWS")) : 0;
+    int spx = getenv ("GSTAMD_AGG_STRIP_PX") ? atoi (getenv ("GSTAMD_AGG_STRIP_PX")) : 4;
+    for (int i = 0; i < q.n_pads; i++)
+      if (q.pads[i].width < 8)
+        spx = 4;
     if (srows > 0 && q.fast && q.n_pads > 0 && q.bg_kind != 2 && abl == 0) {
-      const int strips = (rw + 255) / 256;
+      const int strips = (rw + 64 * spx - 1) / (64 * spx);
       dim3 sgrid (strips * ((rh + srows - 1) / srows)), sblock (64);
-      if (q.ashift == 0)
-        hipLaunchKernelGGL ((k_aggregate_strip<0, 4>), sgrid, sblock, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh, srows, strips);
-      else
-        hipLaunchKernelGGL ((k_aggregate_strip<24, 4>), sgrid, sblock, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh, srows, strips);
+#define STRIP_LAUNCH(S, N) hipLaunchKernelGGL ((k_aggregate_strip<S, 4, N>), sgrid, sblock, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh, srows, strips)
+      if (q.ashift == 0) {
+        if (spx == 8) STRIP_LAUNCH (0, 8); else STRIP_LAUNCH (0, 4);
+      } else {
+        if (spx == 8) STRIP_LAUNCH (24, 8); else STRIP_LAUNCH (24, 4);
+      }
+#undef STRIP_LAUNCH
       return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
     }
   }
+#endif
   dim3 grid ((lanes + bx - 1) / bx, rh), block (bx);
 #define AGG_LAUNCH(A, S) hipLaunchKernelGGL ((k_aggregate<A, S>), grid, block, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh)
   if (q.ashift == 0) {

@@ -46,25 +46,33 @@ extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int 
       }
     return;
   }
-  if (q.fast && q.n_pads > 0 && q.bg_kind != 2 && !getenv ("EMU_AGG_SINGLE_ROW")) {
-    /* k_aggregate_strip: strips of 256 columns x `rows` rows, the pad walk of aggregate_strip4 */
-    const int rows = getenv ("EMU_AGG_STRIP_ROWS") ? atoi (getenv ("EMU_AGG_STRIP_ROWS")) : 2;
+  if (q.fast && q.n_pads > 0 && q.bg_kind != 2 && getenv ("EMU_AGG_STRIP_ROWS")) {
+    /* k_aggregate_strip: strips of 64 * npx columns x `rows` rows, the pad walk of aggregate_strip */
+    const int rows = atoi (getenv ("EMU_AGG_STRIP_ROWS"));
+    int npx = getenv ("EMU_AGG_STRIP_PX") ? atoi (getenv ("EMU_AGG_STRIP_PX")) : 4;
+    for (int k = 0; k < q.n_pads; k++)
+      if (q.pads[k].width < 8)
+        npx = 4;
     emu_strip_runs++;
     for (int y0 = ry0; y0 < ry0 + rh; y0 += rows)
-      for (int wx0 = rx0; wx0 < rx0 + rw; wx0 += 256) {
-        const int wx1 = wx0 + 256 < rx0 + rw ? wx0 + 256 : rx0 + rw, y1 = y0 + rows < ry0 + rh ? y0 + rows : ry0 + rh;
+      for (int wx0 = rx0; wx0 < rx0 + rw; wx0 += 64 * npx) {
+        const int wx1 = wx0 + 64 * npx < rx0 + rw ? wx0 + 64 * npx : rx0 + rw, y1 = y0 + rows < ry0 + rh ? y0 + rows : ry0 + rh;
         uint32_t xmask = 0;
         for (int k = 0; k < q.n_pads; k++)
           xmask |= pad_xhit (q.pads[k], wx0, wx1) ? 1u << k : 0u;
         AggsLanePad lp = {0, 0, 0};
         for (int lane = 0; lane < 64; lane++) {
-          const int x = wx0 + 4 * lane;
+          const int x = wx0 + npx * lane;
           int nv = rx0 + rw - x;
-          nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
-          if (q.ashift == 0)
-            aggregate_strip4<0, 4> (q, lp, xmask, dst, dstride, x, y0, y1, nv);
+          nv = nv < 0 ? 0 : (nv > npx ? npx : nv);
+          if (q.ashift == 0 && npx == 4)
+            aggregate_strip<0, 4, 4> (q, lp, xmask, dst, dstride, x, y0, y1, nv);
+          else if (q.ashift == 0)
+            aggregate_strip<0, 4, 8> (q, lp, xmask, dst, dstride, x, y0, y1, nv);
+          else if (npx == 4)
+            aggregate_strip<24, 4, 4> (q, lp, xmask, dst, dstride, x, y0, y1, nv);
           else
-            aggregate_strip4<24, 4> (q, lp, xmask, dst, dstride, x, y0, y1, nv);
+            aggregate_strip<24, 4, 8> (q, lp, xmask, dst, dstride, x, y0, y1, nv);
         }
       }
     return;

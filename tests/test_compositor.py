@@ -150,18 +150,21 @@ def test_aggregate_packed_path_on_host_matches_reference(emu_lib, ref, fmt, back
     before = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs())
     emu_lib.emu_compositor_run(C.byref(p), got.ctypes.data, dw * 4, 0, 0, dw, dh)
     after = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs())
-    assert (after[0] - before[0], after[1] - before[1]) == (1, 0)      # k_aggregate_strip is the path of all-opaque-blend frames
+    assert (after[0] - before[0], after[1] - before[1]) == (0, 0)      # k_aggregate's body: the strip / rows forms are tuning-build variants
     assert (exp == got).all()
 
 
-@pytest.mark.parametrize("kind", ["strip", "rows"])
+@pytest.mark.parametrize("kind", ["strip", "strip8", "rows"])
 @pytest.mark.parametrize("rows,n_pads,dw", [(1, 5, 300), (7, 30, 530), (16, 9, 257), (2, 32, 1030)])
 def test_aggregate_rows_per_wave_list_on_host_matches_reference(emu_lib, ref, rows, n_pads, dw, kind, monkeypatch):
     """k_aggregate_rows (a measured variant kept in tuning builds, compositor_kernels.hip) - its entry list: more x-hits than one pass holds (30 pads x 7 rows > AGG_LIST_MAX -> several passes), rows no
     pad touches (skip entries), several strips of 256 columns with a ragged last lane, rows per wave not dividing the height."""
     emu_lib.emu_compositor_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
-    # "strip": k_aggregate_strip, the product path (pad walk on the scalar unit); "rows": k_aggregate_rows, the tuning-only variant
-    monkeypatch.setenv("EMU_AGG_STRIP_ROWS" if kind == "strip" else "EMU_AGG_ROWS", str(rows))
+    # measured variants kept in tuning builds: "strip" k_aggregate_strip (pad walk on the scalar unit), "strip8" the same with 8
+    # pixels per lane, "rows" k_aggregate_rows (entry list in LDS)
+    monkeypatch.setenv("EMU_AGG_ROWS" if kind == "rows" else "EMU_AGG_STRIP_ROWS", str(rows))
+    if kind == "strip8":
+        monkeypatch.setenv("EMU_AGG_STRIP_PX", "8")            # eight pixels per lane, 512 columns per wave
     fmt, dh, pw, ph = "BGRA", 61, 170, 23
     pads_np = [cases.frame_bytes(pw * ph * 4, "random", 7300 + i) for i in range(n_pads)]
     geo = [((i * 37) % (dw - 20) - 9, (i * 5) % 30 + (8 if i % 2 else -6), min(1.0, 0.2 + 0.03 * i), 1) for i in range(n_pads)]
@@ -177,7 +180,7 @@ def test_aggregate_rows_per_wave_list_on_host_matches_reference(emu_lib, ref, ro
     before = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs())
     emu_lib.emu_compositor_run(C.byref(p), got.ctypes.data, dw * 4, 0, 0, dw, dh)
     after = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs())
-    assert (after[0] - before[0], after[1] - before[1]) == ((1, 0) if kind == "strip" else (0, 1))
+    assert (after[0] - before[0], after[1] - before[1]) == ((0, 1) if kind == "rows" else (1, 0))
     assert (exp == got).all()
 
 

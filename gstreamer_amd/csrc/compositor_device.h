@@ -281,10 +281,16 @@ GSTAMD_CD Px4Words load_px4 (const uint8_t *p)
 #else
   const uint32_t *g = (const uint32_t *) p;
 #endif
+#if defined(__HIPCC__) && defined(GSTAMD_AGG_NT_LOADS)
+  typedef unsigned int u32x4_a4l __attribute__ ((ext_vector_type (4), aligned (4)));
+  const u32x4_a4l v = __builtin_nontemporal_load ((const __attribute__ ((address_space (1))) u32x4_a4l *) g);
+  r.v[0] = v.x, r.v[1] = v.y, r.v[2] = v.z, r.v[3] = v.w;
+#else
   r.v[0] = g[0];
   r.v[1] = g[1];
   r.v[2] = g[2];
   r.v[3] = g[3];
+#endif
   return r;
 }
 
@@ -389,7 +395,7 @@ GSTAMD_CD void aggregate_span4 (const AggregateParams &p, const PadHit *hits, in
 #pragma unroll
       for (int i = 0; i < 4; i++)
         if (sx + i >= 0 && sx + i < h.width)
-          d[i] = apply_pad (d[i], *(const uint32_t *) (h.row + 4 * (size_t) (sx + i)), h.s_alpha, h.mode, p.ashift, p.overlay);
+          d[i] = apply_pad (d[i], load_px1 (h.row + 4 * (size_t) (sx + i)), h.s_alpha, h.mode, p.ashift, p.overlay);
     }
     return;
   }

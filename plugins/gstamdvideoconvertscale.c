@@ -16,7 +16,7 @@
  * (GSTAMD_ERR_UNSUPPORTED) make set_caps fail -> not-negotiated, like the reference's "no_convert" :1111-1120.
  *
  * fixate_caps follows the reference's format scoring and display-aspect-ratio rules (:1098-1975, restated below).  Not
- * implemented: the converter-config property, interlaced content (such caps are refused) and overlay composition metas.
+ * implemented: interlaced content (such caps are refused) and overlay composition metas.
  */
 #include <gst/base/gstbasetransform.h>
 #include <gst/gst.h>
@@ -81,6 +81,7 @@ typedef struct {
   gint alpha_mode, chroma_mode, matrix_mode;
   gdouble alpha_value, envelope, sharpness, sharpen;
   guint dither_quantization;
+  GstStructure *converter_config;      /* converter-config (:378): when set, the ONLY options the converter gets (:962-967) */
   gboolean add_borders;        /* add-borders (:312): letterbox / pillarbox instead of stretching when the DAR changes */
   gint borders_w, borders_h;
   /* negotiated */
@@ -111,7 +112,7 @@ typedef struct {
 } GstAmdVideoConvertScaleClass;
 
 enum { PROP_0, PROP_METHOD, PROP_ADD_BORDERS, PROP_N_THREADS, PROP_ALPHA_MODE, PROP_ALPHA_VALUE, PROP_CHROMA_MODE, PROP_MATRIX_MODE,
-  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION, PROP_DEVICE_ID, PROP_HIP_STREAMS };
+  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION, PROP_DEVICE_ID, PROP_HIP_STREAMS, PROP_CONVERTER_CONFIG };
 
 G_DEFINE_TYPE (GstAmdVideoConvertScale, gst_amd_vcs, GST_TYPE_BASE_TRANSFORM);
 #define AMD_VCS(o) ((GstAmdVideoConvertScale *) (o))
@@ -121,6 +122,7 @@ static void
 amd_vcs_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
 {
   GstAmdVideoConvertScale *s = AMD_VCS (object);
+  gboolean reconfigure = FALSE;
   GST_OBJECT_LOCK (s);
   switch (id) {
     case PROP_METHOD: s->method = g_value_get_enum (value); break;
@@ -136,9 +138,19 @@ amd_vcs_set_property (GObject * object, guint id, const GValue * value, GParamSp
     case PROP_DITHER_QUANTIZATION: s->dither_quantization = g_value_get_uint (value); break;
     case PROP_DEVICE_ID: s->device_id = g_value_get_int (value); break;
     case PROP_HIP_STREAMS: s->hip_streams = g_value_get_uint (value); break;
+    case PROP_CONVERTER_CONFIG:
+      if (s->converter_config)
+        gst_structure_free (s->converter_config);
+      s->converter_config = g_value_dup_boxed (value);
+      reconfigure = TRUE;
+      break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (s);
+  /* the reference applies a changed converter-config to the running converter before the next frame (:1989-2000); here the next
+   * buffer renegotiates, which builds the converter anew from the structure */
+  if (reconfigure)
+    gst_base_transform_reconfigure_src (GST_BASE_TRANSFORM (s));
 }
 
 static void
@@ -160,9 +172,83 @@ amd_vcs_get_property (GObject * object, guint id, GValue * value, GParamSpec * p
     case PROP_DITHER_QUANTIZATION: g_value_set_uint (value, s->dither_quantization); break;
     case PROP_DEVICE_ID: g_value_set_int (value, s->device_id); break;
     case PROP_HIP_STREAMS: g_value_set_uint (value, s->hip_streams); break;
+    case PROP_CONVERTER_CONFIG: g_value_set_boxed (value, s->converter_config); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (s);
+}
+
+static void
+amd_vcs_finalize (GObject * object)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (object);
+  if (s->converter_config)
+    gst_structure_free (s->converter_config);
+  s->converter_config = NULL;
+  G_OBJECT_CLASS (gst_amd_vcs_parent_class)->finalize (object);
+}
+
+/* One GstVideoConverter / GstVideoResampler option of a converter-config structure as a number: enums, ints, uints, doubles and
+ * booleans as the reference's get_opt_* read them (video-converter.c:2163-2210) */
+static gboolean
+amd_cfg_number (const GstStructure * st, const gchar * key, gdouble * out)
+{
+  const GValue *v = gst_structure_get_value (st, key);
+  if (!v)
+    return FALSE;
+  if (G_VALUE_HOLDS_ENUM (v))
+    *out = g_value_get_enum (v);
+  else if (G_VALUE_HOLDS_INT (v))
+    *out = g_value_get_int (v);
+  else if (G_VALUE_HOLDS_UINT (v))
+    *out = g_value_get_uint (v);
+  else if (G_VALUE_HOLDS_DOUBLE (v))
+    *out = g_value_get_double (v);
+  else if (G_VALUE_HOLDS_BOOLEAN (v))
+    *out = g_value_get_boolean (v);
+  else if (G_VALUE_HOLDS_STRING (v) && g_value_get_string (v))
+    *out = g_ascii_strtod (g_value_get_string (v), NULL);       /* gst-launch hands every field over as a string */
+  else
+    return FALSE;
+  return TRUE;
+}
+
+/* converter-config -> the C ABI's config: library defaults for whatever the structure does not name, exactly what
+ * gst_video_converter_new does with it */
+static void
+amd_cfg_from_structure (const GstStructure * st, GstAmdVideoConverterConfig * cfg)
+{
+  gdouble d;
+#define OPT_I(key, field) if (amd_cfg_number (st, key, &d)) cfg->field = (gint) d
+#define OPT_U(key, field) if (amd_cfg_number (st, key, &d)) cfg->field = (guint) d
+#define OPT_D(key, field) if (amd_cfg_number (st, key, &d)) cfg->field = d
+  OPT_I ("GstVideoConverter.resampler-method", resampler_method);
+  OPT_I ("GstVideoConverter.chroma-resampler-method", chroma_resampler_method);
+  OPT_U ("GstVideoConverter.resampler-taps", resampler_taps);
+  OPT_U ("GstVideoConverter.dither-quantization", dither_quantization);
+  OPT_I ("GstVideoConverter.src-x", src_x);
+  OPT_I ("GstVideoConverter.src-y", src_y);
+  OPT_I ("GstVideoConverter.src-width", src_width);
+  OPT_I ("GstVideoConverter.src-height", src_height);
+  OPT_I ("GstVideoConverter.dest-x", dest_x);
+  OPT_I ("GstVideoConverter.dest-y", dest_y);
+  OPT_I ("GstVideoConverter.dest-width", dest_width);
+  OPT_I ("GstVideoConverter.dest-height", dest_height);
+  OPT_I ("GstVideoConverter.fill-border", fill_border);
+  OPT_U ("GstVideoConverter.border-argb", border_argb);
+  OPT_D ("GstVideoConverter.alpha-value", alpha_value);
+  OPT_I ("GstVideoConverter.alpha-mode", alpha_mode);
+  OPT_I ("GstVideoConverter.chroma-mode", chroma_mode);
+  OPT_I ("GstVideoConverter.matrix-mode", matrix_mode);
+  OPT_I ("GstVideoResampler.max-taps", max_taps);
+  OPT_D ("GstVideoResampler.cubic-b", cubic_b);
+  OPT_D ("GstVideoResampler.cubic-c", cubic_c);
+  OPT_D ("GstVideoResampler.envelope", envelope);
+  OPT_D ("GstVideoResampler.sharpness", sharpness);
+  OPT_D ("GstVideoResampler.sharpen", sharpen);
+#undef OPT_I
+#undef OPT_U
+#undef OPT_D
 }
 
 static gboolean
@@ -731,6 +817,13 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   cfg.matrix_mode = s->matrix_mode;
   cfg.dither_quantization = s->dither_quantization;
 
+  if (s->converter_config) {
+    /* a user-provided converter-config replaces the element's own options altogether (gstvideoconvertscale.c:962-967): method,
+     * borders, alpha / chroma / matrix modes then come from the structure or are the library's defaults */
+    gstamd_video_converter_config_init (&cfg);
+    amd_cfg_from_structure (s->converter_config, &cfg);
+    GST_DEBUG_OBJECT (s, "using the user-provided converter-config %" GST_PTR_FORMAT, s->converter_config);
+  }
   if (s->convert)
     gstamd_video_converter_free (s->convert);
   s->convert = gstamd_video_converter_new (&ai, &ao, &cfg, &status);
@@ -1160,6 +1253,7 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
   GST_DEBUG_CATEGORY_GET (CAT_PERFORMANCE, "GST_PERFORMANCE");
   oc->set_property = amd_vcs_set_property;
   oc->get_property = amd_vcs_get_property;
+  oc->finalize = amd_vcs_finalize;
   g_object_class_install_property (oc, PROP_METHOD, g_param_spec_enum ("method", "method", "method",
           amd_scale_method_get_type (), AMD_SCALE_BILINEAR, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_ADD_BORDERS, g_param_spec_boolean ("add-borders", "Add Borders",
@@ -1189,6 +1283,9 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
   g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
           "HIP device this instance runs on (-1 = the process's current device)", -1, G_MAXINT, -1,
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_CONVERTER_CONFIG, g_param_spec_boxed ("converter-config", "Converter configuration",
+          "A GstStructure describing the configuration that should be used. This configuration, if set, takes precedence over the "
+          "other similar conversion properties.", GST_TYPE_STRUCTURE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_HIP_STREAMS, g_param_spec_uint ("hip-streams", "HIP streams",
           "HIP streams the instance rotates its frames over (the launch ramp of one frame overlaps the tail of the previous one)",
           1, AMD_MAX_STREAMS, 3, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));

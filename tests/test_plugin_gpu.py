@@ -55,6 +55,37 @@ def test_videoconvertscale_element_matches_reference(gst_env, ref):
         assert (rc.frame(src[i]) == out[i]).all(), i
 
 
+def test_videoconvertscale_converter_config_replaces_the_element_options(gst_env, ref):
+    """converter-config (gstvideoconvertscale.c:378-396, 962-967): the structure is the ONLY configuration the converter gets - here
+    Lanczos with a destination rectangle and a border colour although `method` stays bilinear - and a structure that names nothing
+    gives the library defaults (cubic), not the element's bilinear."""
+    env, tmp = gst_env
+    w, h, ow, oh, n = 640, 360, 400, 300, 2
+    fin, fout, fout2 = tmp / "cc_in.nv12", tmp / "cc_out.bgra", tmp / "cc_out2.bgra"
+    src_desc = ("videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=%d,height=%d,colorimetry=bt601,chroma-site=jpeg "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! " % (n, w, h, fin))
+    cc = ("cfg,GstVideoConverter.resampler-method=4,GstVideoConverter.dest-x=40,GstVideoConverter.dest-y=30,GstVideoConverter.dest-width=320,"
+          "GstVideoConverter.dest-height=240,GstVideoConverter.border-argb=(uint)4280303680")
+    r = subprocess.run([GST, "-q"] + src_desc.split() + ["videoconvertscale", "converter-config=" + cc, "!"] +
+                       ("video/x-raw,format=BGRA,width=%d,height=%d,pixel-aspect-ratio=1/1 ! filesink location=%s" % (ow, oh, fout)).split(),
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    cfg = dict(resampler_method="lanczos", dest_x=40, dest_y=30, dest_width=320, dest_height=240, border_argb=4280303680)
+    rc = ref.VideoConverter("NV12", w, h, "BGRA", ow, oh, config=cases.ref_config_string(ref, cfg), in_colorimetry="bt601", in_chroma_site="jpeg")
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), (i, int((rc.frame(src[i]) != out[i]).sum()))
+    r = subprocess.run([GST, "-q"] + src_desc.split() + ["videoconvertscale", "converter-config=cfg", "!"] +
+                       ("video/x-raw,format=BGRA,width=%d,height=%d,pixel-aspect-ratio=1/1 ! filesink location=%s" % (ow, oh, fout2)).split(),
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    out = np.fromfile(fout2, np.uint8).reshape(n, -1)
+    rc = ref.VideoConverter("NV12", w, h, "BGRA", ow, oh, in_colorimetry="bt601", in_chroma_site="jpeg")
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), (i, int((rc.frame(src[i]) != out[i]).sum()))
+
+
 def test_chained_elements_keep_frames_in_hbm_and_scale(gst_env, ref):
     """NV12 -> BGRA in HBM (memory:AMDHIPMemory between the two elements) -> RGBA; then a Lanczos downscale."""
     env, tmp = gst_env

@@ -66,6 +66,8 @@ struct GstAmdVideoConverter {
   Mfma420Tables mfma;
   uint32_t *btab_dev = nullptr;
   int mfma_waves = 0, mfma_rpc = 0, mfma_ring = 0, mfma_tile_w = 0;
+  uint8_t *deep_a = nullptr, *deep_b = nullptr;        /* scratch images of a scaled 10-bit conversion (convert_deep_scaled) */
+  size_t deep_a_size = 0, deep_b_size = 0;
 };
 
 namespace gstamd {
@@ -563,6 +565,88 @@ static bool bilinear420_params (GstAmdVideoConverter *c, BilParams *out)
   return true;
 }
 
+// 10-bit source with scaling (video_deep.h).  The picture shrinks: front -> AYUV64 image, the passes on 16-bit lines, the last one
+// fused with the convert stage.  It grows: the convert stage first (8-bit unpack-order image), then the 8-bit scalers.  The images
+// between the stages live in HBM (two scratch images per converter).
+static int convert_deep_scaled (GstAmdVideoConverter *c, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
+{
+  const VideoPlan &p = c->plan;
+  const int in_w = p.front.width, in_h = p.front.height, out_w = p.out_info.width, out_h = p.out_info.height;
+  const size_t n = p.passes.size ();
+  const size_t bpp = p.matrix_before_scale ? 4 : 8;
+  const int mid_w = p.passes[0].horizontal ? p.passes[0].out_size : in_w, mid_h = p.passes[0].horizontal ? in_h : p.passes[0].out_size;
+  const size_t need_a = (size_t) in_w * in_h * bpp, need_b = n == 2 ? (size_t) mid_w * mid_h * bpp : 0;
+  hipError_t e;
+  if (c->deep_a_size < need_a) {
+    if (c->deep_a)
+      (void) hipFree (c->deep_a);
+    c->deep_a = nullptr;
+    if ((e = hipMalloc ((void **) &c->deep_a, need_a)) != hipSuccess)
+      return hip_fail (e, "hipMalloc(16-bit scratch)");
+    c->deep_a_size = need_a;
+  }
+  if (c->deep_b_size < need_b) {
+    if (c->deep_b)
+      (void) hipFree (c->deep_b);
+    c->deep_b = nullptr;
+    if ((e = hipMalloc ((void **) &c->deep_b, need_b)) != hipSuccess)
+      return hip_fail (e, "hipMalloc(16-bit scratch)");
+    c->deep_b_size = need_b;
+  }
+  ScaleDev sd[2];
+  for (size_t i = 0; i < n; i++) {
+    memset (&sd[i], 0, sizeof (sd[i]));
+    sd[i].kind = p.passes[i].kind;
+    sd[i].n_taps = p.passes[i].n_taps;
+    sd[i].inc = p.passes[i].inc;
+    sd[i].offset = c->pass_dev[i].offset;
+    sd[i].taps = c->pass_dev[i].taps;
+    sd[i].tapw = c->pass_dev[i].tapw;
+    sd[i].nw = p.passes[i].nw;
+    sd[i].nw4 = p.passes[i].nw4;
+  }
+  if (!p.matrix_before_scale) {
+    if ((e = launch_front16 (p.front, pl, c->vpair_dev, c->deep_a, in_w * 8, stream)) != hipSuccess)
+      return hip_fail (e, "k_front16");
+    Deep16Image cur = {c->deep_a, in_w * 8, in_w, in_h};
+    for (size_t i = 0; i < n; i++) {
+      const bool hz = p.passes[i].horizontal, last = i + 1 == n;
+      const int ow = hz ? p.passes[i].out_size : cur.width, oh = hz ? cur.height : p.passes[i].out_size;
+      if (last)
+        e = launch_scale16 (cur, sd[i], hz, dst, dstride, ow, oh, &p.deep, &p.post, stream);
+      else
+        e = launch_scale16 (cur, sd[i], hz, c->deep_b, ow * 8, ow, oh, nullptr, nullptr, stream);
+      if (e != hipSuccess)
+        return hip_fail (e, "k_scale16");
+      cur.p = c->deep_b, cur.stride = ow * 8, cur.width = ow, cur.height = oh;
+    }
+    return GSTAMD_OK;
+  }
+  PostParams mid = p.post;
+  for (int i = 0; i < 4; i++)
+    mid.pack_pos[i] = i;
+  if ((e = launch_convert16 (p.front, pl, c->vpair_dev, p.deep, mid, c->deep_a, in_w * 4, stream)) != hipSuccess)
+    return hip_fail (e, "k_convert16");
+  ColorParams none;
+  memset (&none, 0, sizeof (none));
+  PostFast pf_none;
+  memset (&pf_none, 0, sizeof (pf_none));
+  const uint8_t *src = c->deep_a;
+  int sw = in_w, sh = in_h;
+  for (size_t i = 0; i < n; i++) {
+    const bool hz = p.passes[i].horizontal, last = i + 1 == n;
+    const int ow = hz ? p.passes[i].out_size : sw, oh = hz ? sh : p.passes[i].out_size;
+    e = launch_scale_from_image (hz, src, sw * 4, sd[i], last ? dst : c->deep_b, last ? dstride : ow * 4, last, none, p.post.pack_pos, ow, oh,
+        p.passes[i].max_span, sw, c->geom[i], pf_none, stream);
+    if (e != hipSuccess)
+      return hip_fail (e, "scale pass (8-bit lines of a 10-bit source)");
+    src = c->deep_b, sw = ow, sh = oh;
+  }
+  (void) out_w;
+  (void) out_h;
+  return GSTAMD_OK;
+}
+
 static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
 {
   const VideoPlan &p = c->plan;
@@ -604,8 +688,11 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     if (((uintptr_t) dst % 4) != 0 || (dstride % 4) != 0 || ((uintptr_t) pl.p[0] % 2) != 0 || (pl.stride[0] % 2) != 0 || ((uintptr_t) pl.p[1] % 2) != 0 ||
         (pl.stride[1] % 2) != 0 || (p.front.kind == UNPACK_PLANAR && (((uintptr_t) pl.p[2] % 2) != 0 || (pl.stride[2] % 2) != 0)))
       return set_error (GSTAMD_ERR_UNSUPPORTED, "10-bit frames need 2-byte aligned planes and pitches, the destination 4-byte aligned ones");
-    e = launch_convert16 (p.front, pl, c->vpair_dev, p.deep, p.post, dst, dstride, stream);
-    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert16");
+    if (p.passes.empty ()) {
+      e = launch_convert16 (p.front, pl, c->vpair_dev, p.deep, p.post, dst, dstride, stream);
+      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert16");
+    }
+    return convert_deep_scaled (c, pl, dst, dstride, stream);
   }
   if (p.passes.empty ()) {
     e = launch_convert (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, stream);
@@ -857,6 +944,12 @@ static void release_tables (GstAmdVideoConverter *c)
   }
   if (c->tmp)
     (void) hipFree (c->tmp);
+  if (c->deep_a)
+    (void) hipFree (c->deep_a);
+  if (c->deep_b)
+    (void) hipFree (c->deep_b);
+  c->deep_a = c->deep_b = nullptr;
+  c->deep_a_size = c->deep_b_size = 0;
   if (c->vgroup_dev)
     (void) hipFree (c->vgroup_dev);
   if (c->vtapw_dev)
@@ -1108,8 +1201,8 @@ int gstamd_video_converter_is_reentrant (GstAmdVideoConverter *c)
   if (!c || ensure_tables (c) != GSTAMD_OK)
     return 0;
   const VideoPlan &p = c->plan;
-  if (p.plane_mode || p.out_planar)
-    return 0;                   /* plane_tmp / pk_img: one scratch image per converter */
+  if (p.plane_mode || p.out_planar || (p.deep16 && !p.passes.empty ()))
+    return 0;                   /* plane_tmp / pk_img / the 16-bit scratch images: one set per converter */
   if (p.passes.size () == 2) {
     const auto small_kind = [](int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; };
     if (!(small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)))

@@ -571,7 +571,7 @@ static void convert_coeff (const double *src, int16_t *dest, int n, int precisio
 /* One gst_video_scaler_new + the function the reference would pick in get_functions
  * (video-scaler.c:1202-1342) for 4x8-bit pixels. */
 bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverterConfig &cfg, int in_size,
-    int out_size, bool horizontal, ScalePass *pass, bool h2_as_ntap)
+    int out_size, bool horizontal, ScalePass *pass, bool h2_as_ntap, bool deep16)
 {
   std::vector<double> dtaps;
   int max_taps = resampler_init (method, n_taps_opt, cfg, in_size, out_size, pass->offset, dtaps);
@@ -587,6 +587,16 @@ bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverte
   pass->tapw.clear ();
   if (max_taps == 1) {
     pass->kind = SCALE_NEAREST;               /* h_near_u32 / v_near: copies s[offset[i]] */
+    return true;
+  }
+  if (deep16) {
+    /* 16-bit lines (get_functions, video-scaler.c:1314-1340): h_ntap_u16 (its 2-tap branch rounds with + 4096, the others with
+     * + 4095), v_2tap_u16, v_ntap_u16 - all with taps at SCALE_U16 = 12 fractional bits */
+    pass->kind = max_taps == 2 ? SCALE_2TAP : SCALE_NTAP;
+    pass->precision = 12;
+    pass->taps.assign ((size_t) out_size * max_taps, 0);
+    for (int i = 0; i < out_size; i++)
+      convert_coeff (&dtaps[(size_t) i * max_taps], &pass->taps[(size_t) i * max_taps], max_taps, pass->precision);
     return true;
   }
   if (max_taps == 2 && horizontal && !h2_as_ntap) {
@@ -1192,18 +1202,18 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
 
   const bool same_matrix = cfg.matrix_mode == GSTAMD_MATRIX_MODE_NONE ? true : in_matrix == out_matrix;
   /* 10-bit sources: the reference unpacks them to AYUV64 and runs the chain on 16-bit lines until the convert stage narrows to
-   * the 8-bit pack format.  Built so far: the unscaled chain into a 4-byte 8-bit destination (decoder output -> display). */
+   * the 8-bit pack format.  Built so far: the chain into a 4-byte 8-bit destination (decoder output -> display), unscaled, shrunk
+   * (scaled on the 16-bit lines, then converted) or enlarged (converted, then scaled on 8-bit lines). */
   plan->deep16 = plan->fin->hi_depth != 0;
   if (plan->fout->hi_depth)
     return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destinations are not implemented on the GPU path");
   if (plan->deep16) {
     if (plan->out_planar)
       return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit source to a planar / 3-byte destination is not implemented on the GPU path");
-    if (in->width != out->width || in->height != out->height || plan->rect.in_x || plan->rect.in_y || plan->rect.out_x || plan->rect.out_y ||
+    if (plan->rect.in_x || plan->rect.in_y || plan->rect.out_x || plan->rect.out_y ||
         plan->rect.fill || (plan->rect.in_maxw && (plan->rect.in_maxw != in->width || plan->rect.in_maxh != in->height)) ||
         (plan->rect.out_maxw && (plan->rect.out_maxw != out->width || plan->rect.out_maxh != out->height)))
-      return fail (GSTAMD_ERR_UNSUPPORTED, "scaling / cropping / borders of a 10-bit source (u16 scalers, video-scaler.c:763-1106) are not "
-          "implemented on the GPU path");
+      return fail (GSTAMD_ERR_UNSUPPORTED, "cropping / borders of a 10-bit source are not implemented on the GPU path");
   }
   /* Fastpaths of the reference that are the generic chain with two decisions forced, reproduced by forcing them here:
    *  - convert_I420_BGRA / _ARGB / _pack_ARGB (:6772-6990) and convert_I420_AYUV / Y42B_AYUV / Y444_AYUV (:3563, ..):
@@ -1306,7 +1316,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       if (isz == osz)
         continue;
       ScalePass pass;
-      make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, isz, osz, horizontal, &pass);
+      make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, isz, osz, horizontal, &pass, false, plan->deep16 && !plan->matrix_before_scale);
       pass.max_span = 1 << 30;
       if (horizontal) {
         int worst = 0;

@@ -234,6 +234,6 @@ void converter_config_init (GstAmdVideoConverterConfig *config);
 void compute_convert_matrix (const VideoPlan &plan_inputs, int in_range, int in_matrix, int out_range,
     int out_matrix, bool in_yuv, bool out_yuv, int matrix_mode, double dm[4][4]);
 bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverterConfig &cfg, int in_size,
-    int out_size, bool horizontal, ScalePass *pass, bool h2_as_ntap = false);
+    int out_size, bool horizontal, ScalePass *pass, bool h2_as_ntap = false, bool deep16 = false);
 
 }  // namespace gstamd

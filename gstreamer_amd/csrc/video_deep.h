@@ -1,4 +1,4 @@
-// video_deep.h - the 16-bit chain of GstVideoConverter for 10-bit sources, unscaled, into an 8-bit 4-byte destination:
+// video_deep.h - the 16-bit chain of GstVideoConverter for 10-bit sources into an 8-bit 4-byte destination (scaled or not):
 //   unpack_I420_10LE / unpack_P010_10LE  -> AYUV64   (video-format.c:3836-3873, 5331-5400: 10 bits widened to 16 by bit replication)
 //   video_chroma_up_h2_u16 / _h2_cs_u16 / _v2_u16    (video-chroma.c:277-327, 687-699, instantiated for guint16 at :469-471, 796:
 //                                                     the same (3a+b+2)>>2 and (a+b+1)>>1 on 16-bit values, same line pairing)
@@ -62,10 +62,10 @@ GSTAMD_HD UV deep_chroma_h_at (const FrontParams &f, const Planes &pl, int crow,
   return c;
 }
 
-// pixel (x, y) through the whole chain: the 8-bit unpack-order word A | c1 << 8 | c2 << 16 | c3 << 24
-GSTAMD_HD uint32_t deep_pixel (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, const Deep16Params &d, int x, int y)
+// pixel (x, y) after unpack + chroma upsampling: the AYUV64 pixel as two words, {A | c1 << 16, c2 | c3 << 16} (memory order A, c1, c2, c3)
+GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x, int y)
 {
-  int c1 = deep_widen (f.hi_depth, ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
+  const int c1 = deep_widen (f.hi_depth, ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
   UV c;
   if (f.chroma_v2) {
     const int e0 = vpair[2 * y], rb = vpair[2 * y + 1];
@@ -86,14 +86,87 @@ GSTAMD_HD uint32_t deep_pixel (const FrontParams &f, const Planes &pl, const int
   } else {
     c = deep_chroma_h_at (f, pl, y >> f.h_sub, x);
   }
-  int c2 = c.u, c3 = c.v;
+  uint2 r;
+  r.x = 0xffffu | ((uint32_t) c1 << 16);
+  r.y = (uint32_t) c.u | ((uint32_t) c.v << 16);
+  return r;
+}
+
+// an AYUV64 pixel through video_converter_matrix16 and video_orc_convert_u16_to_u8: the 8-bit unpack-order word
+GSTAMD_HD uint32_t deep_finish_px (const Deep16Params &d, uint2 px)
+{
+  const int a = (int) (px.x & 0xffffu);
+  int c1 = (int) (px.x >> 16), c2 = (int) (px.y & 0xffffu), c3 = (int) (px.y >> 16);
   if (d.has_matrix) {
     const int r = c1, g = c2, b = c3;
     c1 = clampi ((d.im[0][0] * r + d.im[0][1] * g + d.im[0][2] * b + d.im[0][3]) >> 8, 0, 65535);
     c2 = clampi ((d.im[1][0] * r + d.im[1][1] * g + d.im[1][2] * b + d.im[1][3]) >> 8, 0, 65535);
     c3 = clampi ((d.im[2][0] * r + d.im[2][1] * g + d.im[2][2] * b + d.im[2][3]) >> 8, 0, 65535);
   }
-  return 0xffu | ((uint32_t) (c1 >> 8) << 8) | ((uint32_t) (c2 >> 8) << 16) | ((uint32_t) (c3 >> 8) << 24);
+  return (uint32_t) (a >> 8) | ((uint32_t) (c1 >> 8) << 8) | ((uint32_t) (c2 >> 8) << 16) | ((uint32_t) (c3 >> 8) << 24);
+}
+
+// pixel (x, y) through the whole unscaled chain
+GSTAMD_HD uint32_t deep_pixel (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, const Deep16Params &d, int x, int y)
+{
+  return deep_finish_px (d, deep_front_px (f, pl, vpair, x, y));
+}
+
+// ---- scaling on 16-bit lines (the source is scaled BEFORE the convert stage when the picture shrinks, chain_scale
+// video-converter.c:1685-1717, i.e. by the u16 scalers on AYUV64 lines) -------------------------------------------------------
+// (Deep16Image, an AYUV64 image in HBM at 8 bytes per pixel: video_types.h)
+GSTAMD_HD uint2 deep_img_at (const Deep16Image &im, int x, int y)
+{
+  x = x < 0 ? 0 : (x >= im.width ? im.width - 1 : x);
+  y = y < 0 ? 0 : (y >= im.height ? im.height - 1 : y);
+  return *(const uint2 *) (im.p + (ptrdiff_t) y * im.stride + 8 * (ptrdiff_t) x);
+}
+
+GSTAMD_HD int deep_comp (uint2 px, int c) { return (int) (((c & 2) ? px.y : px.x) >> (16 * (c & 1))) & 0xffff; }
+
+GSTAMD_HD uint2 deep_pack4 (const int *v)
+{
+  uint2 r;
+  r.x = (uint32_t) v[0] | ((uint32_t) v[1] << 16);
+  r.y = (uint32_t) v[2] | ((uint32_t) v[3] << 16);
+  return r;
+}
+
+// video_orc_resample_scaletaps_u16 (video-orc.orc:2507): (sum + 4095) >> 12, saturated to 16 unsigned bits
+GSTAMD_HD int deep_scaletaps (int acc) { return clampi ((acc + 4095) >> 12, 0, 65535); }
+
+// one output pixel of a pass: video_scale_h_near_u64 / h_ntap_u16 (2 taps: video_orc_resample_h_2tap_u16, + 4096) and
+// video_scale_v_near_u16 / v_2tap_u16 / v_ntap_u16 (video-scaler.c:546-606, 762-826, 1040-1106); taps at 12 fractional bits
+GSTAMD_HD uint2 deep_scale_px (const Deep16Image &im, const ScaleDev &sd, bool horizontal, int x, int y)
+{
+  const int o = horizontal ? x : y;
+  const int off = (int) sd.offset[o];
+  if (sd.kind == SCALE_NEAREST)
+    return horizontal ? deep_img_at (im, off, y) : deep_img_at (im, x, off);
+  const int16_t *t = sd.taps + (size_t) o * sd.n_taps;
+  int v[4];
+  if (sd.kind == SCALE_2TAP) {
+    const uint2 a = horizontal ? deep_img_at (im, off, y) : deep_img_at (im, x, off);
+    const uint2 b = horizontal ? deep_img_at (im, off + 1, y) : deep_img_at (im, x, off + 1);
+    for (int c = 0; c < 4; c++) {
+      const int s1 = deep_comp (a, c), s2 = deep_comp (b, c);
+      if (horizontal)
+        v[c] = clampi ((int) ((uint32_t) s1 * (uint32_t) (int) t[0] + (uint32_t) s2 * (uint32_t) (int) t[1] + 4096u) >> 12, 0, 65535);
+      else                      /* l1 + (((l2 - l1) * p1 + 4096) >> 12), p1 read as an unsigned 16-bit parameter */
+        v[c] = clampi (s1 + ((int) ((uint32_t) (s2 - s1) * (uint32_t) (uint16_t) t[1] + 4096u) >> 12), 0, 65535);
+    }
+    return deep_pack4 (v);
+  }
+  uint32_t acc[4] = {0, 0, 0, 0};       /* mulll / addl: 32-bit wrapping sums */
+  for (int l = 0; l < sd.n_taps; l++) {
+    const uint2 p = horizontal ? deep_img_at (im, off + l, y) : deep_img_at (im, x, off + l);
+    const uint32_t tp = (uint32_t) (int) t[l];
+    for (int c = 0; c < 4; c++)
+      acc[c] += (uint32_t) deep_comp (p, c) * tp;
+  }
+  for (int c = 0; c < 4; c++)
+    v[c] = deep_scaletaps ((int) acc[c]);
+  return deep_pack4 (v);
 }
 
 // pixels x0 .. x0+3 of row y
@@ -107,6 +180,34 @@ GSTAMD_HD void convert16_lane4 (const FrontParams &f, const Planes &pl, const in
     const uint32_t px = apply_alpha (post.alpha_kind, (unsigned) post.alpha_value, deep_pixel (f, pl, vpair, d, x0 + i, y));
     out[i] = pack_px (post.pack_pos, px);
   }
+}
+
+// front only: pixels x0 .. x0+3 of row y into an AYUV64 image
+GSTAMD_HD void front16_lane4 (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, uint8_t *img, int istride, int x0, int y)
+{
+  if (x0 >= f.width || y >= f.height)
+    return;
+  uint2 *out = (uint2 *) (img + (size_t) y * istride + 8 * (size_t) x0);
+  for (int i = 0; i < 4 && x0 + i < f.width; i++)
+    out[i] = deep_front_px (f, pl, vpair, x0 + i, y);
+}
+
+// one pass AYUV64 image -> AYUV64 image
+GSTAMD_HD void scale16_lane (const Deep16Image &im, const ScaleDev &sd, bool horizontal, uint8_t *dst, int dstride, int ow, int oh, int x, int y)
+{
+  if (x >= ow || y >= oh)
+    return;
+  *(uint2 *) (dst + (size_t) y * dstride + 8 * (size_t) x) = deep_scale_px (im, sd, horizontal, x, y);
+}
+
+// last pass fused with the convert stage: scaled AYUV64 pixel -> matrix16 -> 8 bits -> alpha -> pack
+GSTAMD_HD void scale16_final_lane (const Deep16Image &im, const ScaleDev &sd, bool horizontal, const Deep16Params &d, const PostParams &post, uint8_t *dst,
+    int dstride, int ow, int oh, int x, int y)
+{
+  if (x >= ow || y >= oh)
+    return;
+  const uint32_t px = apply_alpha (post.alpha_kind, (unsigned) post.alpha_value, deep_finish_px (d, deep_scale_px (im, sd, horizontal, x, y)));
+  *(uint32_t *) (dst + (size_t) y * dstride + 4 * (size_t) x) = pack_px (post.pack_pos, px);
 }
 
 }  // namespace gstamd

@@ -19,6 +19,12 @@ hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vp
 hipError_t launch_convert16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const Deep16Params &d, const PostParams &post, uint8_t *dst,
     int dstride, hipStream_t stream);
 
+struct Deep16Image;
+hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, uint8_t *img, int istride, hipStream_t stream);
+// d / post non-NULL: the last pass, fused with matrix16 + narrowing + alpha + pack into the 4-byte destination
+hipError_t launch_scale16 (const Deep16Image &im, const ScaleDev &sd, bool horizontal, uint8_t *dst, int dstride, int ow, int oh, const Deep16Params *d,
+    const PostParams *post, hipStream_t stream);
+
 struct FastParams;
 hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames, const uint8_t *const *y, const uint8_t *const *uv,
     uint8_t *const *dst, int ystride, int uvstride, int dstride, hipStream_t stream);

@@ -48,6 +48,42 @@ hipError_t launch_convert16 (const FrontParams &f, const Planes &pl, const int *
   return hipGetLastError ();
 }
 
+// 10-bit source, scaled in 16 bits (video_deep.h): front into an AYUV64 image, u16 passes, the last one fused with the convert stage.
+// Plain one-lane-per-pixel kernels with the AYUV64 images in HBM: correctness and coverage first.
+__global__ __launch_bounds__ (256) void k_front16 (FrontParams f, Planes pl, const int *__restrict__ vpair, uint8_t *__restrict__ img, int istride)
+{
+  front16_lane4 (f, pl, vpair, img, istride, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
+}
+
+__global__ __launch_bounds__ (256) void k_scale16 (Deep16Image im, ScaleDev sd, int horizontal, uint8_t *__restrict__ dst, int dstride, int ow, int oh)
+{
+  scale16_lane (im, sd, horizontal != 0, dst, dstride, ow, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+__global__ __launch_bounds__ (256) void k_scale16_final (Deep16Image im, ScaleDev sd, int horizontal, Deep16Params d, PostParams post,
+    uint8_t *__restrict__ dst, int dstride, int ow, int oh)
+{
+  scale16_final_lane (im, sd, horizontal != 0, d, post, dst, dstride, ow, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, uint8_t *img, int istride, hipStream_t stream)
+{
+  dim3 grid ((f.width / 4 + 256) / 256, f.height);
+  hipLaunchKernelGGL (k_front16, grid, dim3 (256), 0, stream, f, pl, vpair_dev, img, istride);
+  return hipGetLastError ();
+}
+
+hipError_t launch_scale16 (const Deep16Image &im, const ScaleDev &sd, bool horizontal, uint8_t *dst, int dstride, int ow, int oh, const Deep16Params *d,
+    const PostParams *post, hipStream_t stream)
+{
+  dim3 grid ((ow + 255) / 256, oh);
+  if (d)
+    hipLaunchKernelGGL (k_scale16_final, grid, dim3 (256), 0, stream, im, sd, horizontal ? 1 : 0, *d, *post, dst, dstride, ow, oh);
+  else
+    hipLaunchKernelGGL (k_scale16, grid, dim3 (256), 0, stream, im, sd, horizontal ? 1 : 0, dst, dstride, ow, oh);
+  return hipGetLastError ();
+}
+
 // up to 16 independent frames of one format per launch (blockIdx.z = frame): amortises launch ramp/tail
 #define GSTAMD_MAX_BATCH 32
 struct FrameBatch {

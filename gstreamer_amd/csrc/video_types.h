@@ -27,4 +27,11 @@ struct ScaleDev {         // one scaler pass, tables resident in HBM
   int nw, nw4;
 };
 
+// an AYUV64 image in HBM (the 16-bit chain's lines, video_deep.h): 8 bytes per pixel, memory order A, c1, c2, c3
+struct Deep16Image {
+  const uint8_t *p;
+  int stride;
+  int width, height;
+};
+
 }  // namespace gstamd

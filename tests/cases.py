@@ -318,6 +318,21 @@ VIDEO_CASES = [
     ("i42010_abgr_720p", "I420_10LE", 1280, 720, "ABGR", 1280, 720, {}, None, None, "random"),
     ("i42010_rgbx_cosited_odd", "I420_10LE", 35, 19, "RGBx", 35, 19, {}, "bt709", "cosited", "random"),
     ("i42010_ayuv_none_site", "I420_10LE", 66, 34, "AYUV", 66, 34, {}, "bt601", "none", "checker"),
+    # 10-bit sources with scaling: shrinking on the 16-bit lines (u16 scalers, then the convert stage), growing after the convert stage
+    ("p010_bgra_half_bilinear", "P010_10LE", 640, 360, "BGRA", 320, 180, LIN, None, None, "random"),
+    ("p010_rgba_quarter_lanczos", "P010_10LE", 640, 360, "RGBA", 160, 90, LAN, None, None, "random"),
+    ("p010_argb_down_nearest", "P010_10LE", 322, 242, "ARGB", 100, 77, NEAR, "bt2020", None, "random"),
+    ("p010_bgra_down_cubic_default", "P010_10LE", 1280, 720, "BGRA", 852, 480, {}, None, None, "random"),
+    ("p010_bgrx_hdown_only_lanczos", "P010_10LE", 640, 360, "BGRx", 213, 360, LAN, None, None, "random"),
+    ("p010_abgr_vdown_only_bilinear", "P010_10LE", 320, 240, "ABGR", 320, 100, LIN, "bt601", "jpeg", "random"),
+    ("i42010_bgra_down_bilinear2", "I420_10LE", 642, 362, "BGRA", 300, 171, dict(resampler_method="linear"), None, None, "random"),
+    ("i42010_rgba_1080p_to_720p_lanczos", "I420_10LE", 1920, 1080, "RGBA", 1280, 720, LAN, None, None, "random"),
+    ("i42010_ayuv_down_sinc_same_matrix", "I420_10LE", 400, 300, "AYUV", 133, 100, dict(resampler_method="sinc"), None, None, "random"),
+    ("p010_bgra_up2_bilinear", "P010_10LE", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
+    ("p010_rgba_up_lanczos", "P010_10LE", 160, 90, "RGBA", 400, 225, LAN, None, None, "random"),
+    ("i42010_argb_up_cubic_alpha_mult", "I420_10LE", 100, 60, "ARGB", 333, 200, dict(alpha_mode="mult", alpha_value=0.7), None, None, "random"),
+    ("p010_bgra_wider_shorter_bilinear", "P010_10LE", 320, 240, "BGRA", 400, 200, LIN, None, None, "random"),
+    ("p010_bgra_narrower_taller_bilinear", "P010_10LE", 320, 240, "BGRA", 200, 300, LIN, None, None, "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd

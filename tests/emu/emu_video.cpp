@@ -847,10 +847,39 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
         convert422_lane8_any (q, pl.p[0] + (size_t) y * pl.stride[0], d0 + (size_t) y * dstride, x0);
     return GSTAMD_OK;
   }
-  if (p.deep16) {                          /* k_convert16 */
+  if (p.deep16 && p.passes.empty ()) {     /* k_convert16 */
     for (int y = 0; y < p.front.height; y++)
       for (int x0 = 0; x0 < p.front.width; x0 += 4)
         convert16_lane4 (p.front, pl, vpair, p.deep, p.post, d0, dstride, x0, y);
+    return GSTAMD_OK;
+  }
+  if (p.deep16 && !p.matrix_before_scale) {        /* convert_deep_scaled: k_front16, k_scale16 ..., k_scale16_final */
+    const int in_w = p.front.width, in_h = p.front.height;
+    std::vector<uint8_t> a ((size_t) in_w * in_h * 8), b;
+    for (int y = 0; y < in_h; y++)
+      for (int x0 = 0; x0 < in_w; x0 += 4)
+        front16_lane4 (p.front, pl, vpair, a.data (), in_w * 8, x0, y);
+    Deep16Image cur = {a.data (), in_w * 8, in_w, in_h};
+    for (size_t i = 0; i < p.passes.size (); i++) {
+      const bool hz = p.passes[i].horizontal, last = i + 1 == p.passes.size ();
+      const int ow = hz ? p.passes[i].out_size : cur.width, oh = hz ? cur.height : p.passes[i].out_size;
+      ScaleDev sd16;
+      memset (&sd16, 0, sizeof (sd16));
+      sd16.kind = p.passes[i].kind;
+      sd16.n_taps = p.passes[i].n_taps;
+      sd16.offset = p.passes[i].offset.data ();
+      sd16.taps = p.passes[i].taps.data ();
+      if (!last)
+        b.assign ((size_t) ow * oh * 8, 0);
+      for (int y = 0; y < oh; y++)
+        for (int x = 0; x < ow; x++) {
+          if (last)
+            scale16_final_lane (cur, sd16, hz, p.deep, p.post, d0, dstride, ow, oh, x, y);
+          else
+            scale16_lane (cur, sd16, hz, b.data (), ow * 8, ow, oh, x, y);
+        }
+      cur.p = b.data (), cur.stride = ow * 8, cur.width = ow, cur.height = oh;
+    }
     return GSTAMD_OK;
   }
   if (p.passes.empty ()) {
@@ -904,6 +933,35 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
   memset (&pf_none, 0, sizeof (pf_none));
   pf.use = p.fast_post ? 1 : 0;
   pf.fp = emu_fast_params (p);
+  if (p.deep16) {
+    /* convert_deep_scaled, the picture grows: the convert stage first (k_convert16 into an 8-bit unpack-order image), then the
+     * 8-bit scalers from that image */
+    const int in_w = p.front.width, in_h = p.front.height;
+    std::vector<uint8_t> a ((size_t) in_w * in_h * 4), b;
+    PostParams mid = p.post;
+    for (int i = 0; i < 4; i++)
+      mid.pack_pos[i] = i;
+    for (int y = 0; y < in_h; y++)
+      for (int x0 = 0; x0 < in_w; x0 += 4)
+        convert16_lane4 (p.front, pl, vpair, p.deep, mid, a.data (), in_w * 4, x0, y);
+    SrcImage si;
+    si.p = a.data ();
+    si.stride = in_w * 4;
+    si.width = in_w;
+    int sh = in_h;
+    Dst fin = mk (d0, dstride, true);
+    fin.post = none;
+    for (size_t i = 0; i < p.passes.size (); i++) {
+      const bool hz = p.passes[i].horizontal, last = i + 1 == p.passes.size ();
+      const int ow = hz ? p.passes[i].out_size : si.width, oh = hz ? sh : p.passes[i].out_size;
+      if (!last)
+        b.assign ((size_t) ow * oh * 4, 0);
+      run_scale (hz, si, sd[i], last ? fin : mk (b.data (), ow * 4, false), ow, oh, p.passes[i].max_span, hz ? pass_tile_geom (p.passes[i]) : TileGeom {0, 0},
+          pf_none);
+      si.p = b.data (), si.stride = ow * 4, si.width = ow, sh = oh;
+    }
+    return GSTAMD_OK;
+  }
   const auto small_kind = [](int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; };
   if (p.passes.size () == 2 && small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)) {
     const bool h_first = p.passes[0].horizontal;

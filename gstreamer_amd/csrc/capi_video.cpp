@@ -414,7 +414,14 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
     if (be != hipSuccess)
       return hip_fail (be, "k_fill_border");
   }
-  return convert_rect (c, pl, dest_rect, dest_rect_stride, stream);
+  r = convert_rect (c, pl, dest_rect, dest_rect_stride, stream);
+  if (r == GSTAMD_OK && p.dither.on) {
+    /* the dither stage (video_dither.h) over the converted rectangle of the packed destination */
+    hipError_t de = launch_dither4 (p.dither, (uint8_t *) dest_rect[0], dest_rect_stride[0], p.out_info.width, p.out_info.height, stream);
+    if (de != hipSuccess)
+      return hip_fail (de, "k_dither4");
+  }
+  return r;
 }
 
 // the conversion proper: source planes already at the crop origin, destination planes at the rectangle origin
@@ -895,6 +902,8 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     const FastParams fp = make_fast_params (p, p.fout->kind == UNPACK_PACKED3);
     hipError_t e = launch_convert_pair (fp, p.front.chroma_h, n_frames, y.data (), uv.data (), d.data (), p.in_info.stride[0],
         p.in_info.stride[1], p.out_info.stride[0], (hipStream_t) stream_);
+    for (int i = 0; i < n_frames && e == hipSuccess && p.dither.on; i++)
+      e = launch_dither4 (p.dither, d[i], p.out_info.stride[0], p.out_info.width, p.out_info.height, (hipStream_t) stream_);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair(batch)");
   }
   /* one launch for the whole list through the bilinear 4:2:0 kernel as well (k_bilinear420_rows takes the frames as one grid) */
@@ -915,6 +924,8 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     }
     if (ok && (p.out_info.stride[0] % 4) == 0) {
       hipError_t e = launch_bilinear420_frames (bp, p.front.chroma_h, n_frames, pls.data (), d.data (), p.out_info.stride[0], (hipStream_t) stream_);
+      for (int i = 0; i < n_frames && e == hipSuccess && p.dither.on; i++)
+        e = launch_dither4 (p.dither, d[i], p.out_info.stride[0], p.out_info.width, p.out_info.height, (hipStream_t) stream_);
       if (e != hipErrorNotSupported)
         return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420(batch)");
     }

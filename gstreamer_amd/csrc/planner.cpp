@@ -175,6 +175,7 @@ void converter_config_init (GstAmdVideoConverterConfig *c)
   c->chroma_mode = GSTAMD_CHROMA_MODE_FULL;
   c->matrix_mode = GSTAMD_MATRIX_MODE_FULL;
   c->dither_quantization = 1;
+  c->dither_method = GSTAMD_DITHER_BAYER;                            /* DEFAULT_OPT_DITHER_METHOD */
   c->chroma_resampler_method = GSTAMD_RESAMPLER_METHOD_LINEAR;
   c->fill_border = 1;                                                /* DEFAULT_OPT_FILL_BORDER */
   c->border_argb = 0xff000000u;                                      /* DEFAULT_OPT_BORDER_ARGB */
@@ -1171,8 +1172,27 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     return fail (GSTAMD_ERR_INVALID, "bad frame size");
   plan->out_planar = plan->fout->kind != UNPACK_PACKED4;
   plan->plane_mode = false;
-  if (cfg.dither_quantization != 1)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "dither-quantization != 1 not implemented");
+  /* chain_dither (:2035-2100) on an 8-bit chain: a stage exists when dither-quantization asks for a coarser quantiser than the
+   * format's own (1 at 8 bits) and the method is not NONE - NONE returns before anything is set up, quantisation included.  Every
+   * component the destination has (depth > 0) gets the quantiser, rounded down to a power of two (count_power). */
+  memset (&plan->dither, 0, sizeof (plan->dither));
+  if (cfg.dither_quantization > 1 && cfg.dither_method != GSTAMD_DITHER_NONE) {
+    if (cfg.dither_method != GSTAMD_DITHER_BAYER)
+      return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods (verterr, floyd-steinberg, sierra-lite: video-dither.c:75-225) carry "
+          "errors from pixel to pixel and line to line; only bayer and none are implemented on the GPU path");
+    if (plan->out_planar)
+      return fail (GSTAMD_ERR_UNSUPPORTED, "dither-quantization > 1 into planar / 3-byte destinations (the stage sits between chroma downsampling "
+          "and packing) is not implemented on the GPU path");
+    int shift = 0;
+    for (unsigned q = cfg.dither_quantization; q > 1; q >>= 1)
+      shift++;
+    if (shift > 8)
+      shift = 8;
+    plan->dither.on = 1;
+    plan->dither.method = cfg.dither_method;
+    for (int comp = 0; comp < 4; comp++)
+      plan->dither.shift[plan->fout->pos[comp]] = (comp == 0 && !plan->fout->alpha) ? 0 : shift;
+  }
 
   const bool unpack_rgb = !plan->fin->yuv, pack_rgb = !plan->fout->yuv;
   /* gst_video_converter_init_from_config (:2380-2404): RGB formats force the RGB matrix */

@@ -72,6 +72,15 @@ struct FrontParams {    // unpack + chroma upsample of the source frame (functio
 
 // the 16-bit chain (unpack to AYUV64 -> chroma upsample on u16 -> video_converter_matrix16 -> video_orc_convert_u16_to_u8):
 // what a 10-bit source takes on its way to an 8-bit destination (video-converter.c:1719-1868, 3096-3145)
+// The dither stage (chain_dither video-converter.c:2035-2100, video-dither.c) as a pass over the packed 4-byte destination: it works per
+// component and the pack stage after it only permutes bytes, so dithering byte b of the packed pixel with the shift of the component
+// stored there is the same thing.  method: GSTAMD_DITHER_NONE (quantise only) or GSTAMD_DITHER_BAYER.
+struct DitherParams {
+  int on;
+  int method;
+  int shift[4];         // per BYTE of the packed pixel: log2 of the quantiser of the component stored there (0: untouched)
+};
+
 struct Deep16Params {
   int has_matrix;       // 0: same matrix on both sides, the stage only narrows 16 -> 8 bits
   int im[3][4];         // video_converter_matrix16's integer matrix (8 fractional bits; im[k][3] the offset)
@@ -189,6 +198,7 @@ struct VideoPlan {
   bool fast_post;             // scaled plans: the post stage may run fast_pixel (matrix provably wrap-free, alpha stays 0xff)
   bool deep16;                // 10-bit source, unscaled, 8-bit 4-byte destination: k_convert16 (video_deep.h)
   Deep16Params deep;
+  DitherParams dither;
   int im_raw[3][4];           // the rint()ed 8-bit matrix before the per-kind adjustments
   std::string ref_fastpath;   // name of the reference fastpath this plan reproduces (empty: generic chain)
   std::string description;

@@ -19,6 +19,7 @@ hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vp
 hipError_t launch_convert16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const Deep16Params &d, const PostParams &post, uint8_t *dst,
     int dstride, hipStream_t stream);
 
+hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream);
 struct Deep16Image;
 hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, uint8_t *img, int istride, hipStream_t stream);
 // d / post non-NULL: the last pass, fused with matrix16 + narrowing + alpha + pack into the 4-byte destination

@@ -22,6 +22,7 @@
 #include "video_encode_fast.h"
 #include "video_planes.h"
 #include "video_deep.h"
+#include "video_dither.h"
 
 namespace gstamd {
 
@@ -81,6 +82,19 @@ hipError_t launch_scale16 (const Deep16Image &im, const ScaleDev &sd, bool horiz
     hipLaunchKernelGGL (k_scale16_final, grid, dim3 (256), 0, stream, im, sd, horizontal ? 1 : 0, *d, *post, dst, dstride, ow, oh);
   else
     hipLaunchKernelGGL (k_scale16, grid, dim3 (256), 0, stream, im, sd, horizontal ? 1 : 0, dst, dstride, ow, oh);
+  return hipGetLastError ();
+}
+
+// the dither stage as a pass over the packed destination rectangle (video_dither.h)
+__global__ __launch_bounds__ (256) void k_dither4 (DitherParams d, uint8_t *__restrict__ img, int stride, int w, int h)
+{
+  dither_lane4 (d, img, stride, w, h, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
+}
+
+hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream)
+{
+  dim3 grid ((w / 4 + 256) / 256, h);
+  hipLaunchKernelGGL (k_dither4, grid, dim3 (256), 0, stream, d, img, stride, w, h);
   return hipGetLastError ();
 }
 

@@ -45,7 +45,7 @@ class ConverterConfig(C.Structure):
                 ("envelope", C.c_double), ("sharpness", C.c_double), ("sharpen", C.c_double),
                 ("cubic_b", C.c_double), ("cubic_c", C.c_double), ("alpha_mode", C.c_int32),
                 ("alpha_value", C.c_double), ("chroma_mode", C.c_int32), ("matrix_mode", C.c_int32),
-                ("dither_quantization", C.c_uint32), ("chroma_resampler_method", C.c_int32), ("reserved", C.c_int32 * 7),
+                ("dither_quantization", C.c_uint32), ("chroma_resampler_method", C.c_int32), ("dither_method", C.c_int32), ("reserved", C.c_int32 * 6),
                 ("src_x", C.c_int32), ("src_y", C.c_int32), ("src_width", C.c_int32), ("src_height", C.c_int32),
                 ("dest_x", C.c_int32), ("dest_y", C.c_int32), ("dest_width", C.c_int32), ("dest_height", C.c_int32),
                 ("fill_border", C.c_int32), ("border_argb", C.c_uint32)]
@@ -150,12 +150,15 @@ def video_info(fmt, width, height, colorimetry=None, chroma_site=None, stride=No
     return info
 
 
+DITHER_METHOD = {"none": 0, "verterr": 1, "floyd-steinberg": 2, "sierra-lite": 3, "bayer": 4}
+
+
 def converter_config(**kw):
     """Library defaults of video-converter.c:778-796; keyword overrides use the field names."""
     cfg = ConverterConfig()
     lib().gstamd_video_converter_config_init(C.byref(cfg))
     enums = {"resampler_method": RESAMPLER_METHOD, "alpha_mode": ALPHA_MODE, "chroma_mode": CHROMA_MODE,
-             "matrix_mode": MATRIX_MODE}
+             "matrix_mode": MATRIX_MODE, "dither_method": DITHER_METHOD}
     for k, v in kw.items():
         if k in enums and isinstance(v, str):
             v = enums[k][v]

@@ -118,6 +118,13 @@ typedef struct GstAmdVideoInfo {
  * implementation honours; gstamd_video_converter_config_init() sets the library defaults of
  * video-converter.c:778-796 (NB: resampler-method CUBIC; the videoconvertscale element itself
  * defaults to LINEAR with max-taps 2, gstvideoconvertscale.c:1000-1005). */
+/* GstVideoDitherMethod (video-dither.h:44-50) */
+#define GSTAMD_DITHER_NONE 0
+#define GSTAMD_DITHER_VERTERR 1
+#define GSTAMD_DITHER_FLOYD_STEINBERG 2
+#define GSTAMD_DITHER_SIERRA_LITE 3
+#define GSTAMD_DITHER_BAYER 4
+
 typedef struct GstAmdVideoConverterConfig {
   int32_t resampler_method;      /* GstVideoConverter.resampler-method */
   uint32_t resampler_taps;       /* GstVideoConverter.resampler-taps (0 = auto) */
@@ -132,7 +139,8 @@ typedef struct GstAmdVideoConverterConfig {
   int32_t matrix_mode;           /* GstVideoConverter.matrix-mode */
   uint32_t dither_quantization;  /* GstVideoConverter.dither-quantization (1) */
   int32_t chroma_resampler_method; /* GstVideoConverter.chroma-resampler-method (LINEAR): chroma planes of the plane scaler */
-  int32_t reserved[7];
+  int32_t dither_method;         /* GstVideoConverter.dither-method (BAYER); only matters with dither-quantization > 1 on this path */
+  int32_t reserved[6];
   /* source crop and destination rectangle (GstVideoConverter.src-x/-y/-width/-height, dest-x/-y/-width/-height,
    * video-converter.h:64-131); width / height 0 = "to the frame's edge" (the option absent) */
   int32_t src_x, src_y, src_width, src_height;

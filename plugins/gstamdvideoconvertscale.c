@@ -81,6 +81,7 @@ typedef struct {
   gint alpha_mode, chroma_mode, matrix_mode;
   gdouble alpha_value, envelope, sharpness, sharpen;
   guint dither_quantization;
+  gint dither;                 /* dither (:329): GstVideoDitherMethod, default bayer; only matters with dither-quantization > 1 here */
   GstStructure *converter_config;      /* converter-config (:378): when set, the ONLY options the converter gets (:962-967) */
   gboolean add_borders;        /* add-borders (:312): letterbox / pillarbox instead of stretching when the DAR changes */
   gint borders_w, borders_h;
@@ -112,7 +113,7 @@ typedef struct {
 } GstAmdVideoConvertScaleClass;
 
 enum { PROP_0, PROP_METHOD, PROP_ADD_BORDERS, PROP_N_THREADS, PROP_ALPHA_MODE, PROP_ALPHA_VALUE, PROP_CHROMA_MODE, PROP_MATRIX_MODE,
-  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION, PROP_DEVICE_ID, PROP_HIP_STREAMS, PROP_CONVERTER_CONFIG };
+  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION, PROP_DEVICE_ID, PROP_HIP_STREAMS, PROP_CONVERTER_CONFIG, PROP_DITHER };
 
 G_DEFINE_TYPE (GstAmdVideoConvertScale, gst_amd_vcs, GST_TYPE_BASE_TRANSFORM);
 #define AMD_VCS(o) ((GstAmdVideoConvertScale *) (o))
@@ -136,6 +137,7 @@ amd_vcs_set_property (GObject * object, guint id, const GValue * value, GParamSp
     case PROP_SHARPNESS: s->sharpness = g_value_get_double (value); break;
     case PROP_SHARPEN: s->sharpen = g_value_get_double (value); break;
     case PROP_DITHER_QUANTIZATION: s->dither_quantization = g_value_get_uint (value); break;
+    case PROP_DITHER: s->dither = g_value_get_enum (value); break;
     case PROP_DEVICE_ID: s->device_id = g_value_get_int (value); break;
     case PROP_HIP_STREAMS: s->hip_streams = g_value_get_uint (value); break;
     case PROP_CONVERTER_CONFIG:
@@ -170,6 +172,7 @@ amd_vcs_get_property (GObject * object, guint id, GValue * value, GParamSpec * p
     case PROP_SHARPNESS: g_value_set_double (value, s->sharpness); break;
     case PROP_SHARPEN: g_value_set_double (value, s->sharpen); break;
     case PROP_DITHER_QUANTIZATION: g_value_set_uint (value, s->dither_quantization); break;
+    case PROP_DITHER: g_value_set_enum (value, s->dither); break;
     case PROP_DEVICE_ID: g_value_set_int (value, s->device_id); break;
     case PROP_HIP_STREAMS: g_value_set_uint (value, s->hip_streams); break;
     case PROP_CONVERTER_CONFIG: g_value_set_boxed (value, s->converter_config); break;
@@ -226,6 +229,7 @@ amd_cfg_from_structure (const GstStructure * st, GstAmdVideoConverterConfig * cf
   OPT_I ("GstVideoConverter.chroma-resampler-method", chroma_resampler_method);
   OPT_U ("GstVideoConverter.resampler-taps", resampler_taps);
   OPT_U ("GstVideoConverter.dither-quantization", dither_quantization);
+  OPT_I ("GstVideoConverter.dither-method", dither_method);
   OPT_I ("GstVideoConverter.src-x", src_x);
   OPT_I ("GstVideoConverter.src-y", src_y);
   OPT_I ("GstVideoConverter.src-width", src_width);
@@ -816,6 +820,7 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   cfg.chroma_mode = s->chroma_mode;
   cfg.matrix_mode = s->matrix_mode;
   cfg.dither_quantization = s->dither_quantization;
+  cfg.dither_method = s->dither;
 
   if (s->converter_config) {
     /* a user-provided converter-config replaces the element's own options altogether (gstvideoconvertscale.c:962-967): method,
@@ -1283,6 +1288,8 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
   g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
           "HIP device this instance runs on (-1 = the process's current device)", -1, G_MAXINT, -1,
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_DITHER, g_param_spec_enum ("dither", "Dither", "Apply dithering while converting",
+          GST_TYPE_VIDEO_DITHER_METHOD, GST_VIDEO_DITHER_BAYER, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_CONVERTER_CONFIG, g_param_spec_boxed ("converter-config", "Converter configuration",
           "A GstStructure describing the configuration that should be used. This configuration, if set, takes precedence over the "
           "other similar conversion properties.", GST_TYPE_STRUCTURE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
@@ -1323,6 +1330,7 @@ gst_amd_vcs_init (GstAmdVideoConvertScale * s)
   s->sharpness = 1.0;
   s->sharpen = 0.0;
   s->dither_quantization = 1;
+  s->dither = GST_VIDEO_DITHER_BAYER;
   s->device_id = -1;
   s->hip_streams = 3;
   s->stats = g_getenv ("GSTAMD_ELEMENT_STATS") != NULL;

@@ -318,6 +318,18 @@ VIDEO_CASES = [
     ("i42010_abgr_720p", "I420_10LE", 1280, 720, "ABGR", 1280, 720, {}, None, None, "random"),
     ("i42010_rgbx_cosited_odd", "I420_10LE", 35, 19, "RGBx", 35, 19, {}, "bt709", "cosited", "random"),
     ("i42010_ayuv_none_site", "I420_10LE", 66, 34, "AYUV", 66, 34, {}, "bt601", "none", "checker"),
+    # the dither stage (bayer + quantisation; method none is no stage at all): same-size fused kernels, scalers, 10-bit chain, borders
+    ("nv12_bgra_dither_q4", "NV12", 64, 36, "BGRA", 64, 36, dict(dither_quantization=4), None, None, "random"),
+    ("nv12_bgrx_dither_q16_1080p", "NV12", 1920, 1080, "BGRx", 1920, 1080, dict(dither_quantization=16), None, None, "ramp"),
+    ("nv12_argb_dither_q2_odd", "NV12", 35, 19, "ARGB", 35, 19, dict(dither_quantization=2), None, None, "random"),
+    ("nv12_rgba_dither_q5_floor_pow2", "NV12", 64, 36, "RGBA", 64, 36, dict(dither_quantization=5), None, None, "random"),
+    ("nv12_bgra_dither_none_is_no_stage", "NV12", 64, 36, "BGRA", 64, 36, dict(dither_quantization=8, dither_method="none"), None, None, "random"),
+    ("nv12_bgra_dither_q8_half_bilinear", "NV12", 640, 360, "BGRA", 320, 180, dict(LIN, dither_quantization=8), None, None, "random"),
+    ("i420_rgba_dither_q4_lanczos_down", "I420", 640, 360, "RGBA", 213, 120, dict(LAN, dither_quantization=4), None, None, "random"),
+    ("bgra_ayuv_dither_q4", "BGRA", 64, 36, "AYUV", 64, 36, dict(dither_quantization=4), None, None, "random"),
+    ("yuy2_bgra_dither_q64", "YUY2", 64, 36, "BGRA", 64, 36, dict(dither_quantization=64), None, None, "random"),
+    ("p010_bgra_dither_q4", "P010_10LE", 64, 36, "BGRA", 64, 36, dict(dither_quantization=4), None, None, "random"),
+    ("nv12_bgra_dither_q4_letterbox", "NV12", 640, 360, "BGRA", 400, 400, dict(LIN, dither_quantization=4, dest_x=0, dest_y=88, dest_width=400, dest_height=225, border_argb=0xff203040), None, None, "random"),
     # 10-bit sources with scaling: shrinking on the 16-bit lines (u16 scalers, then the convert stage), growing after the convert stage
     ("p010_bgra_half_bilinear", "P010_10LE", 640, 360, "BGRA", 320, 180, LIN, None, None, "random"),
     ("p010_rgba_quarter_lanczos", "P010_10LE", 640, 360, "RGBA", 160, 90, LAN, None, None, "random"),
@@ -343,7 +355,8 @@ VISIBLE_ONLY = {"uyvy_yv12_33x17_fastpath", "uyvy_y444_33x18_fastpath", "uyvy_yu
 # conversions the reference runs through code this library has no kernel for -> must be REFUSED
 VIDEO_REFUSED = [
     ("NV12", 320, 180, "BGRA", 640, 100, LAN),           # reference temp-line aliasing (see planner.cpp)
-    ("NV12", 64, 64, "BGRA", 64, 64, dict(dither_quantization=4)),      # dither stage (video-dither.c) not built
+    ("NV12", 64, 64, "BGRA", 64, 64, dict(dither_quantization=4, dither_method="floyd-steinberg")),   # error diffusion: sequential
+    ("NV12", 64, 64, "I420", 64, 64, dict(dither_quantization=4)),      # dither between chroma downsampling and pack: not built
 ]
 
 

@@ -22,6 +22,7 @@
 #include "../../gstreamer_amd/csrc/video_planes.h"
 #include "../../gstreamer_amd/csrc/video_encode_fast.h"
 #include "../../gstreamer_amd/csrc/video_deep.h"
+#include "../../gstreamer_amd/csrc/video_dither.h"
 
 using namespace gstamd;
 
@@ -744,7 +745,12 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         pack_planar_body (p.pack, img.data (), p.out_info.width * 4, d, x0, yb);
     return GSTAMD_OK;
   }
-  return emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok, false);
+  r = emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok, false);
+  if (r == GSTAMD_OK && p.dither.on)               /* k_dither4 over the converted rectangle */
+    for (int y = 0; y < p.out_info.height; y++)
+      for (int x0 = 0; x0 < p.out_info.width; x0 += 4)
+        dither_lane4 (p.dither, dst + out->offset[0], out->stride[0], p.out_info.width, p.out_info.height, x0, y);
+  return r;
 }
 
 static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok, bool rgb24)

@@ -124,3 +124,109 @@ class AudioResampler:
             self.free()
         except Exception:
             pass
+
+
+# ---- GstAudioConverter (include/gstamd_audio.h) -------------------------------------------------------------------------------
+AFMT = {"S8": 2, "U8": 3, "S16LE": 4, "S24_32LE": 8, "S32LE": 12, "S24LE": 16, "F32LE": 28, "F64LE": 30}
+AFMT_BYTES = {"S8": 1, "U8": 1, "S16LE": 2, "S24LE": 3, "S24_32LE": 4, "S32LE": 4, "F32LE": 4, "F64LE": 8}
+DITHER = {"none": 0, "rpdf": 1, "tpdf": 2, "tpdf-hf": 3}
+NOISE_SHAPING = {"none": 0, "error-feedback": 1, "simple": 2, "medium": 3, "high": 4}
+MAX_CHANNELS = 8
+# default positions of gst_audio_info_set_format (audio-info.c: gst_audio_channel_positions ... default_channel_order) for 1 / 2 channels
+DEFAULT_POSITIONS = {1: [-1], 2: [0, 1]}
+
+
+class AudioInfo(C.Structure):
+    _fields_ = [("format", C.c_int32), ("rate", C.c_int32), ("channels", C.c_int32), ("layout", C.c_int32), ("unpositioned", C.c_int32),
+                ("position", C.c_int32 * MAX_CHANNELS)]
+
+
+class AudioConverterConfig(C.Structure):
+    _fields_ = [("dither_method", C.c_int32), ("noise_shaping", C.c_int32), ("dither_threshold", C.c_uint32), ("resampler_method", C.c_int32),
+                ("has_resampler_options", C.c_int32), ("resampler_options", ResamplerOptions), ("has_mix_matrix", C.c_int32),
+                ("mix_matrix", (C.c_float * MAX_CHANNELS) * MAX_CHANNELS)]
+
+
+def audio_info(fmt, rate, channels, positions=None, unpositioned=False):
+    ai = AudioInfo()
+    ai.format, ai.rate, ai.channels, ai.layout, ai.unpositioned = AFMT[fmt], rate, channels, 0, int(unpositioned)
+    pos = positions if positions is not None else DEFAULT_POSITIONS.get(channels)
+    if pos is None:
+        pos = list(range(channels))
+        ai.unpositioned = 1 if positions is None else ai.unpositioned
+    for i, v in enumerate(pos):
+        ai.position[i] = v
+    return ai
+
+
+_conv_ready = False
+
+
+def _conv_lib():
+    global _conv_ready
+    L = lib()
+    if not _conv_ready:
+        L.gstamd_audio_converter_config_init.argtypes = [C.POINTER(AudioConverterConfig)]
+        L.gstamd_audio_converter_new.restype = C.c_void_p
+        L.gstamd_audio_converter_new.argtypes = [C.c_int, C.POINTER(AudioInfo), C.POINTER(AudioInfo), C.POINTER(AudioConverterConfig), C.POINTER(C.c_int)]
+        L.gstamd_audio_converter_free.argtypes = [C.c_void_p]
+        L.gstamd_audio_converter_reset.argtypes = [C.c_void_p]
+        for n in ("get_out_frames", "get_in_frames"):
+            f = getattr(L, "gstamd_audio_converter_" + n)
+            f.restype, f.argtypes = C.c_size_t, [C.c_void_p, C.c_size_t]
+        L.gstamd_audio_converter_get_max_latency.restype = C.c_size_t
+        L.gstamd_audio_converter_get_max_latency.argtypes = [C.c_void_p]
+        L.gstamd_audio_converter_is_passthrough.argtypes = [C.c_void_p]
+        L.gstamd_audio_converter_samples.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gstamd_audio_converter_get_mix_matrix.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+        _conv_ready = True
+    return L
+
+
+def audio_converter_config(dither_method=None, noise_shaping=None, dither_threshold=None, mix_matrix=None, resampler_method=None):
+    cfg = AudioConverterConfig()
+    _conv_lib().gstamd_audio_converter_config_init(C.byref(cfg))
+    if dither_method is not None:
+        cfg.dither_method = DITHER[dither_method] if isinstance(dither_method, str) else dither_method
+    if noise_shaping is not None:
+        cfg.noise_shaping = NOISE_SHAPING[noise_shaping] if isinstance(noise_shaping, str) else noise_shaping
+    if dither_threshold is not None:
+        cfg.dither_threshold = dither_threshold
+    if resampler_method is not None:
+        cfg.resampler_method = METHODS[resampler_method] if isinstance(resampler_method, str) else resampler_method
+    if mix_matrix is not None:                  # [out][in], as the GstAudioConverter.mix-matrix option
+        cfg.has_mix_matrix = 1
+        for j, row in enumerate(mix_matrix):
+            for i, v in enumerate(row):
+                cfg.mix_matrix[j][i] = v
+    return cfg
+
+
+class AudioConverter:
+    """gst_audio_converter_new (flags, in_info, out_info, config) -> .samples (in, in_frames, out, out_frames) on device buffers."""
+
+    def __init__(self, in_info, out_info, config=None, flags=0):
+        st = C.c_int(0)
+        self._h = _conv_lib().gstamd_audio_converter_new(flags, C.byref(in_info), C.byref(out_info),
+                                                         C.byref(config) if config is not None else None, C.byref(st))
+        if not self._h:
+            raise _v.GstAmdError(st.value, _v.last_error())
+
+    def get_out_frames(self, in_frames):
+        return _conv_lib().gstamd_audio_converter_get_out_frames(self._h, in_frames)
+
+    def is_passthrough(self):
+        return bool(_conv_lib().gstamd_audio_converter_is_passthrough(self._h))
+
+    def samples(self, src, in_frames, dst, out_frames, stream=None):
+        _v._check(_conv_lib().gstamd_audio_converter_samples(self._h, 0, _v._ptr(src), in_frames, _v._ptr(dst), out_frames, stream))
+
+    def mix_matrix(self, in_ch, out_ch):
+        buf = (C.c_float * (in_ch * out_ch))()
+        _conv_lib().gstamd_audio_converter_get_mix_matrix(self._h, buf, in_ch * out_ch)
+        return [[buf[i * out_ch + j] for j in range(out_ch)] for i in range(in_ch)]
+
+    def free(self):
+        if self._h:
+            _conv_lib().gstamd_audio_converter_free(self._h)
+            self._h = None

@@ -1,0 +1,317 @@
+// audio_convert_device.h - GstAudioConverter's per-sample stages as device code (bodies only; tests/emu runs the same bodies on the host).
+//
+// Reference (paths under /root/reference/subprojects/gst-plugins-base/gst-libs/gst/audio/):
+//   chain_unpack / _convert_in / _mix / _resample / _convert_out / _quantize / _pack      audio-converter.c:708-1090
+//   unpack_* / pack_* of the formats                                                      audio-format.c:117-260, gstaudiopack.orc
+//   audio_orc_s32_to_double / audio_orc_double_to_s32                                     gstaudiopack.orc:412-426
+//   gst_audio_channel_mixer_mix_{int16,int32,float,double}                                audio-channel-mixer.c:961-1015
+//   gst_audio_quantize_quantize_int_none_none / _int_dither_none, setup_dither_buf        audio-quantize.c:83-180
+//   gst_fast_random_uint32 (32-bit xorshift)                                              audio-quantize.c:92-100
+//
+// The plan (AConvPlan) is made on the host by the decision code of audio_convert.hip, which restates gst_audio_converter_new.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/gstamd_audio.h"
+
+#ifdef __HIPCC__
+#define GSTAMD_AC __host__ __device__ __forceinline__
+#else
+#define GSTAMD_AC inline
+#endif
+
+namespace gstamd {
+
+// the format the samples are in between the stages (audio-converter.c is_intermediate_format)
+enum AMid : int { AMID_S16 = 0, AMID_S32 = 1, AMID_F32 = 2, AMID_F64 = 3 };
+
+struct AConvPlan {
+  int in_fmt, out_fmt;          // GSTAMD_AFMT_*
+  int in_ch, out_ch;
+  int mid_in;                   // AMid after unpack (+ convert_in): what the mixer and the resampler work on
+  int convert_in;               // S32 -> F64 after unpack
+  int mix;                      // 0: the mixer is a passthrough
+  int convert_out;              // F64 -> S32 after the resampler
+  int mid_out;                  // AMid after convert_out: what quantize / pack see
+  int quant_shift;              // 0: no quantize stage
+  int dither;                   // GSTAMD_AUDIO_DITHER_* of the quantize stage
+  float m[GSTAMD_AUDIO_MAX_CHANNELS][GSTAMD_AUDIO_MAX_CHANNELS];        // [in][out]
+  int mi[GSTAMD_AUDIO_MAX_CHANNELS][GSTAMD_AUDIO_MAX_CHANNELS];         // (gint) (m * 1024)
+};
+
+GSTAMD_AC int amid_bytes (int mid) { return mid == AMID_S16 ? 2 : mid == AMID_F64 ? 8 : 4; }
+GSTAMD_AC int afmt_bytes (int fmt)
+{
+  switch (fmt) {
+    case GSTAMD_AFMT_S8: case GSTAMD_AFMT_U8: return 1;
+    case GSTAMD_AFMT_S16LE: return 2;
+    case GSTAMD_AFMT_S24LE: return 3;
+    case GSTAMD_AFMT_F64LE: return 8;
+    default: return 4;
+  }
+}
+
+// ORC's C backups flush denormals around float operations (ORC_DENORMAL / ORC_DENORMAL_DOUBLE, orc/orcprogram-c.c): a value whose
+// exponent field is zero keeps only its sign
+GSTAMD_AC uint32_t orc_denormal_f (uint32_t x) { return (x & 0x7f800000u) == 0 ? (x & 0xff800000u) : x; }
+GSTAMD_AC uint64_t orc_denormal_d (uint64_t x) { return (x & 0x7ff0000000000000ull) == 0 ? (x & 0xfff0000000000000ull) : x; }
+GSTAMD_AC double bits_d (uint64_t b) { double d; memcpy (&d, &b, 8); return d; }
+GSTAMD_AC uint64_t d_bits (double d) { uint64_t b; memcpy (&b, &d, 8); return b; }
+GSTAMD_AC float bits_f (uint32_t b) { float f; memcpy (&f, &b, 4); return f; }
+GSTAMD_AC uint32_t f_bits (float f) { uint32_t b; memcpy (&b, &f, 4); return b; }
+
+// sample i of a buffer in `fmt`, unpacked to S32 (integer formats)
+GSTAMD_AC int32_t aconv_unpack_int (const uint8_t *p, int fmt, size_t i)
+{
+  switch (fmt) {
+    /* do_unpack passes GST_AUDIO_PACK_FLAG_TRUNCATE_RANGE (audio-converter.c:477): the *_trunc programs, plain shifts */
+    case GSTAMD_AFMT_S8: return (int32_t) ((uint32_t) p[i] << 24);                                  // splatbl, shll 24
+    case GSTAMD_AFMT_U8: return (int32_t) (((uint32_t) p[i] << 24) ^ 0x80000000u);
+    case GSTAMD_AFMT_S16LE: {
+      const uint32_t s = (uint32_t) p[2 * i] | ((uint32_t) p[2 * i + 1] << 8);
+      return (int32_t) (s << 16);                                                                   // convuwl, shll 16
+    }
+    case GSTAMD_AFMT_S24LE:
+      return (int32_t) (((uint32_t) p[3 * i] | ((uint32_t) p[3 * i + 1] << 8) | ((uint32_t) p[3 * i + 2] << 16)) << 8);
+    case GSTAMD_AFMT_S24_32LE: {
+      uint32_t v; memcpy (&v, p + 4 * i, 4);
+      return (int32_t) (v << 8);
+    }
+    default: {
+      int32_t v; memcpy (&v, p + 4 * i, 4);
+      return v;
+    }
+  }
+}
+
+// sample i of a float buffer, unpacked to F64 (audio_orc_unpack_f32: convfd with the denormal flush; f64: a copy)
+GSTAMD_AC double aconv_unpack_flt (const uint8_t *p, int fmt, size_t i)
+{
+  if (fmt == GSTAMD_AFMT_F32LE) {
+    uint32_t b; memcpy (&b, p + 4 * i, 4);
+    return (double) bits_f (orc_denormal_f (b));
+  }
+  double d; memcpy (&d, p + 8 * i, 8);
+  return d;
+}
+
+GSTAMD_AC void aconv_pack_int (uint8_t *p, int fmt, size_t i, int32_t v)
+{
+  switch (fmt) {
+    case GSTAMD_AFMT_S8: p[i] = (uint8_t) ((uint32_t) v >> 24); break;
+    case GSTAMD_AFMT_U8: p[i] = (uint8_t) (((uint32_t) v ^ 0x80000000u) >> 24); break;
+    case GSTAMD_AFMT_S16LE: { const uint16_t h = (uint16_t) ((uint32_t) v >> 16); memcpy (p + 2 * i, &h, 2); break; }
+    case GSTAMD_AFMT_S24LE: { const uint32_t t = (uint32_t) (v >> 8); p[3 * i] = (uint8_t) t; p[3 * i + 1] = (uint8_t) (t >> 8); p[3 * i + 2] = (uint8_t) (t >> 16); break; }
+    case GSTAMD_AFMT_S24_32LE: { const int32_t t = v >> 8; memcpy (p + 4 * i, &t, 4); break; }
+    default: memcpy (p + 4 * i, &v, 4); break;
+  }
+}
+
+GSTAMD_AC void aconv_pack_flt (uint8_t *p, int fmt, size_t i, double v)
+{
+  if (fmt == GSTAMD_AFMT_F32LE) {               // audio_orc_pack_f32: convdf, denormals flushed on both sides
+    const float f = (float) bits_d (orc_denormal_d (d_bits (v)));
+    const uint32_t b = orc_denormal_f (f_bits (f));
+    memcpy (p + 4 * i, &b, 4);
+  } else {
+    memcpy (p + 8 * i, &v, 8);
+  }
+}
+
+// audio_orc_s32_to_double: convld, divd 2147483648.0
+GSTAMD_AC double aconv_s32_to_double (int32_t s)
+{
+  return bits_d (orc_denormal_d (d_bits ((double) s / 2147483648.0)));
+}
+
+// audio_orc_double_to_s32: muld 2147483648.0, convdl (the C backup: (int) x, and 0x80000000 from a non-negative x becomes 0x7fffffff)
+GSTAMD_AC int32_t aconv_double_to_s32 (double x)
+{
+  const double a = bits_d (orc_denormal_d (d_bits (x)));
+  const double t = bits_d (orc_denormal_d (d_bits (a * 2147483648.0)));
+  if (!(t == t))                                /* NaN: the conversion gives 0x80000000, the fix-up looks at the sign bit */
+    return (d_bits (t) >> 63) ? (int32_t) 0x80000000u : 0x7fffffff;
+  if (t >= 2147483648.0)
+    return 0x7fffffff;
+  if (t <= -2147483649.0)
+    return (int32_t) 0x80000000u;
+  return (int32_t) t;
+}
+
+GSTAMD_AC int32_t aconv_addssl (int32_t a, int32_t b)
+{
+  const int64_t s = (int64_t) a + (int64_t) b;
+  return s > 2147483647ll ? 2147483647 : (s < -2147483648ll ? (int32_t) 0x80000000u : (int32_t) s);
+}
+
+// ---- the 32-bit xorshift of audio-quantize.c and jumping ahead in it -----------------------------------------------------------------
+GSTAMD_AC uint32_t aconv_rand_step (uint32_t s)
+{
+  uint64_t x = s;
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  return (uint32_t) x;
+}
+
+// The step is linear over GF(2); jump[j] holds the images of the 32 unit vectors under 2^j steps, so k steps are at most 32
+// matrix-vector products.  (Filled on the host by aconv_make_jump.)
+struct AConvJump {
+  uint32_t col[32][32];
+};
+
+GSTAMD_AC uint32_t aconv_rand_jump (const AConvJump &j, uint32_t s, uint64_t k)
+{
+  for (int b = 0; b < 32 && (k >> b); b++) {
+    if (!((k >> b) & 1))
+      continue;
+    uint32_t r = 0;
+    for (int i = 0; i < 32; i++)
+      if ((s >> i) & 1)
+        r ^= j.col[b][i];
+    s = r;
+  }
+  return s;
+}
+
+inline void aconv_make_jump (AConvJump *j)
+{
+  for (int i = 0; i < 32; i++)
+    j->col[0][i] = aconv_rand_step (1u << i);
+  for (int b = 1; b < 32; b++)
+    for (int i = 0; i < 32; i++) {
+      uint32_t s = j->col[b - 1][i], r = 0;     /* apply the 2^(b-1) map twice */
+      for (int q = 0; q < 32; q++)
+        if ((s >> q) & 1)
+          r ^= j->col[b - 1][q];
+      j->col[b][i] = r;
+    }
+}
+
+// RANDOM_INT_DITHER (state, dither): -dither + (next () & (2 dither - 1))
+GSTAMD_AC int32_t aconv_random_dither (uint32_t *state, int32_t dither)
+{
+  *state = aconv_rand_step (*state);
+  return -dither + (int32_t) (*state & (uint32_t) ((dither << 1) - 1));
+}
+
+// quantize stage for sample index i of the call (interleaved order); `state0` is the generator's state before the call
+GSTAMD_AC int32_t aconv_quantize (const AConvPlan &p, const AConvJump &jump, uint32_t state0, size_t i, int32_t v)
+{
+  const int shift = p.quant_shift;
+  const uint32_t mask = ~((1u << shift) - 1u);
+  const uint32_t bias = 1u << (shift - 1);
+  int32_t d;
+  if (p.dither == GSTAMD_AUDIO_DITHER_RPDF) {
+    uint32_t st = aconv_rand_jump (jump, state0, (uint64_t) i);
+    d = (int32_t) (bias + (uint32_t) aconv_random_dither (&st, 1 << shift));
+  } else if (p.dither == GSTAMD_AUDIO_DITHER_TPDF) {
+    uint32_t st = aconv_rand_jump (jump, state0, 2 * (uint64_t) i);
+    const int32_t r1 = aconv_random_dither (&st, 1 << (shift - 1));
+    const int32_t r2 = aconv_random_dither (&st, 1 << (shift - 1));
+    d = (int32_t) (bias + (uint32_t) r1 + (uint32_t) r2);
+  } else {
+    d = (int32_t) bias;                         /* audio_orc_int_bias */
+  }
+  return (int32_t) ((uint32_t) aconv_addssl (v, d) & mask);
+}
+
+// ---- stage 1: input frame n, output channel co -> one sample in the mid_in format ------------------------------------------------
+GSTAMD_AC void aconv_pre_sample (const AConvPlan &p, const uint8_t *in, uint8_t *mid, size_t n, int co)
+{
+  const size_t o = n * (size_t) p.out_ch + (size_t) co;
+  const size_t ibase = n * (size_t) p.in_ch;
+  switch (p.mid_in) {
+    case AMID_S16: {            // same 16-bit format in and out: the samples themselves
+      int32_t res;
+      if (!p.mix) {
+        int16_t v; memcpy (&v, in + 2 * (ibase + co), 2);
+        res = v;
+      } else {
+        res = 0;
+        for (int ci = 0; ci < p.in_ch; ci++) {
+          int16_t v; memcpy (&v, in + 2 * (ibase + ci), 2);
+          res += (int32_t) v * p.mi[ci][co];
+        }
+        res = (res + 512) >> 10;
+        res = res > 32767 ? 32767 : (res < -32768 ? -32768 : res);
+      }
+      const int16_t r = (int16_t) res;
+      memcpy (mid + 2 * o, &r, 2);
+      break;
+    }
+    case AMID_S32: {
+      int32_t r;
+      if (!p.mix) {
+        r = aconv_unpack_int (in, p.in_fmt, ibase + co);
+      } else {
+        int64_t res = 0;
+        for (int ci = 0; ci < p.in_ch; ci++)
+          res += (int64_t) aconv_unpack_int (in, p.in_fmt, ibase + ci) * (int64_t) p.mi[ci][co];
+        res = (res + 512) >> 10;
+        r = res > 2147483647ll ? 2147483647 : (res < -2147483648ll ? (int32_t) 0x80000000u : (int32_t) res);
+      }
+      memcpy (mid + 4 * o, &r, 4);
+      break;
+    }
+    case AMID_F32: {            // F32 in and out: the mixer works in single precision
+      float r;
+      if (!p.mix) {
+        memcpy (&r, in + 4 * (ibase + co), 4);
+      } else {
+        r = 0.0f;
+        for (int ci = 0; ci < p.in_ch; ci++) {
+          float v; memcpy (&v, in + 4 * (ibase + ci), 4);
+          r += v * p.m[ci][co];
+        }
+      }
+      memcpy (mid + 4 * o, &r, 4);
+      break;
+    }
+    default: {
+      double r;
+      if (!p.mix) {
+        r = p.convert_in ? aconv_s32_to_double (aconv_unpack_int (in, p.in_fmt, ibase + co)) : aconv_unpack_flt (in, p.in_fmt, ibase + co);
+      } else {
+        r = 0.0;
+        for (int ci = 0; ci < p.in_ch; ci++) {
+          const double v = p.convert_in ? aconv_s32_to_double (aconv_unpack_int (in, p.in_fmt, ibase + ci)) : aconv_unpack_flt (in, p.in_fmt, ibase + ci);
+          r += v * p.m[ci][co];
+        }
+      }
+      memcpy (mid + 8 * o, &r, 8);
+      break;
+    }
+  }
+}
+
+// ---- stage 2: sample i (interleaved index) of the mid buffer after the resampler -> the output format -----------------------------
+GSTAMD_AC void aconv_post_sample (const AConvPlan &p, const AConvJump &jump, uint32_t state0, const uint8_t *mid, uint8_t *out, size_t i)
+{
+  if (p.mid_in == AMID_S16) {
+    memcpy (out + 2 * i, mid + 2 * i, 2);
+    return;
+  }
+  if (p.mid_in == AMID_F32) {
+    memcpy (out + 4 * i, mid + 4 * i, 4);
+    return;
+  }
+  if (p.mid_out == AMID_F64) {
+    double v; memcpy (&v, mid + 8 * i, 8);
+    aconv_pack_flt (out, p.out_fmt, i, v);
+    return;
+  }
+  int32_t v;
+  if (p.convert_out) {
+    double d; memcpy (&d, mid + 8 * i, 8);
+    v = aconv_double_to_s32 (d);
+  } else {
+    memcpy (&v, mid + 4 * i, 4);
+  }
+  if (p.quant_shift > 0)
+    v = aconv_quantize (p, jump, state0, i, v);
+  aconv_pack_int (out, p.out_fmt, i, v);
+}
+
+}  // namespace gstamd

@@ -100,6 +100,57 @@ int gstamd_audio_resampler_debug_get (GstAmdAudioResampler *resampler, int32_t *
 /* copies the [n_phases][n_taps] taps table (as doubles) out; returns number of values or < 0 */
 long gstamd_audio_resampler_debug_taps (GstAmdAudioResampler *resampler, double *out, long max_out);
 
+/* ---- GstAudioConverter (gst-libs/gst/audio/audio-converter.h:85-140, audio-converter.c) ------------------------------------------
+ * The stages of gst_audio_converter_new's chain (audio-converter.c:708-1090) on the device: unpack -> S32 / F64, S32 -> F64
+ * (convert_in), channel mix, resample, F64 -> S32 (convert_out), quantize (dither), pack.  Formats are GstAudioFormat values
+ * (audio-format.h:80-130, little-endian ones): */
+enum {
+  GSTAMD_AFMT_S8 = 2, GSTAMD_AFMT_U8 = 3, GSTAMD_AFMT_S16LE = 4, GSTAMD_AFMT_S24_32LE = 8, GSTAMD_AFMT_S32LE = 12, GSTAMD_AFMT_S24LE = 16,
+  GSTAMD_AFMT_F32LE = 28, GSTAMD_AFMT_F64LE = 30
+};
+/* GstAudioDitherMethod / GstAudioNoiseShapingMethod (audio-quantize.h:45-72) */
+enum { GSTAMD_AUDIO_DITHER_NONE = 0, GSTAMD_AUDIO_DITHER_RPDF = 1, GSTAMD_AUDIO_DITHER_TPDF = 2, GSTAMD_AUDIO_DITHER_TPDF_HF = 3 };
+#define GSTAMD_AUDIO_MAX_CHANNELS 8
+
+typedef struct GstAmdAudioInfo {
+  int32_t format;               /* GSTAMD_AFMT_* */
+  int32_t rate, channels;
+  int32_t layout;               /* 0 interleaved (the only layout of the converter so far) */
+  int32_t unpositioned;         /* GST_AUDIO_FLAG_UNPOSITIONED */
+  int32_t position[GSTAMD_AUDIO_MAX_CHANNELS];  /* GstAudioChannelPosition (audio-channels.h:60-110): MONO -1, FRONT_LEFT 0, FRONT_RIGHT 1, ... */
+} GstAmdAudioInfo;
+
+typedef struct GstAmdAudioConverterConfig {
+  int32_t dither_method;        /* GstAudioConverter.dither-method (library default: none) */
+  int32_t noise_shaping;        /* GstAudioConverter.noise-shaping-method (NONE; the error-feedback methods are sequential per channel) */
+  uint32_t dither_threshold;    /* GstAudioConverter.dither-threshold (20) */
+  int32_t resampler_method;     /* GstAudioConverter.resampler-method (BLACKMAN_NUTTALL = 3) */
+  int32_t has_resampler_options;
+  GstAmdAudioResamplerOptions resampler_options;
+  int32_t has_mix_matrix;       /* GstAudioConverter.mix-matrix: mix_matrix[out][in] as in the option (audio-converter.c:797-845) */
+  float mix_matrix[GSTAMD_AUDIO_MAX_CHANNELS][GSTAMD_AUDIO_MAX_CHANNELS];
+} GstAmdAudioConverterConfig;
+
+typedef struct GstAmdAudioConverter GstAmdAudioConverter;
+
+void gstamd_audio_converter_config_init (GstAmdAudioConverterConfig *config);
+/* flags: GstAudioConverterFlags (audio-converter.h:99-103; 2 = VARIABLE_RATE).  NULL + *status on failure
+ * (GSTAMD_ERR_UNSUPPORTED: the reference converts this, the GPU path does not yet - never a CPU fallback). */
+GstAmdAudioConverter *gstamd_audio_converter_new (int flags, const GstAmdAudioInfo *in_info, const GstAmdAudioInfo *out_info,
+    const GstAmdAudioConverterConfig *config, int *status);
+void gstamd_audio_converter_free (GstAmdAudioConverter *convert);
+void gstamd_audio_converter_reset (GstAmdAudioConverter *convert);
+size_t gstamd_audio_converter_get_out_frames (GstAmdAudioConverter *convert, size_t in_frames);
+size_t gstamd_audio_converter_get_in_frames (GstAmdAudioConverter *convert, size_t out_frames);
+size_t gstamd_audio_converter_get_max_latency (GstAmdAudioConverter *convert);
+int gstamd_audio_converter_is_passthrough (GstAmdAudioConverter *convert);
+/* gst_audio_converter_samples (audio-converter.c:1545): in / out are device pointers to interleaved frames; in == NULL feeds
+ * silence into the resampler (drain) */
+int gstamd_audio_converter_samples (GstAmdAudioConverter *convert, int flags, const void *in, size_t in_frames, void *out, size_t out_frames,
+    void *stream);
+/* the mix matrix the converter uses, matrix[in][out] as GstAudioChannelMixer holds it; returns in_channels * out_channels */
+int gstamd_audio_converter_get_mix_matrix (GstAmdAudioConverter *convert, float *matrix, int max);
+
 #ifdef __cplusplus
 }
 #endif

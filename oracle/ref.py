@@ -42,6 +42,13 @@ def lib():
         L.ref_compositor_fill.restype = C.c_int
         L.ref_compositor_fill.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_audio_converter_new.restype = C.c_void_p
+        L.ref_audio_converter_new.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
+        L.ref_audio_converter_get_out_frames.restype = C.c_size_t
+        L.ref_audio_converter_get_out_frames.argtypes = [C.c_void_p, C.c_size_t]
+        L.ref_audio_converter_is_passthrough.argtypes = [C.c_void_p]
+        L.ref_audio_converter_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ref_audio_converter_free.argtypes = [C.c_void_p]
         L.ref_audio_resampler_new.restype = C.c_void_p
         L.ref_audio_resampler_new.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
         for n in ("get_out_frames", "get_in_frames"):
@@ -231,3 +238,43 @@ class AudioResampler:
 
     def __del__(self):
         self.close()
+
+
+AUDIO_BYTES = {"S8": 1, "U8": 1, "S16LE": 2, "S24LE": 3, "S24_32LE": 4, "S32LE": 4, "F32LE": 4, "F64LE": 8}
+
+
+class AudioConverter:
+    """gst_audio_converter_new / _samples of the reference on host numpy byte buffers (interleaved frames)."""
+
+    def __init__(self, in_fmt, in_rate, in_ch, out_fmt, out_rate, out_ch, config=None, mix=None, flags=0):
+        import numpy as np
+        m = None
+        if mix is not None:
+            m = np.ascontiguousarray(np.asarray(mix, np.float32))
+            assert m.shape == (out_ch, in_ch)
+        self.h = lib().ref_audio_converter_new(flags, in_fmt.encode(), in_rate, in_ch, out_fmt.encode(), out_rate, out_ch, _b(config),
+                                               m.ctypes.data if m is not None else None)
+        if not self.h:
+            raise ValueError("reference could not create the audio converter")
+        self.in_bpf, self.out_bpf = AUDIO_BYTES[in_fmt] * in_ch, AUDIO_BYTES[out_fmt] * out_ch
+
+    def get_out_frames(self, in_frames):
+        return lib().ref_audio_converter_get_out_frames(self.h, in_frames)
+
+    def is_passthrough(self):
+        return bool(lib().ref_audio_converter_is_passthrough(self.h))
+
+    def samples(self, src, in_frames=None):
+        """src: uint8 array of whole frames, or None with in_frames (silence into the resampler)."""
+        import numpy as np
+        n = in_frames if src is None else src.size // self.in_bpf
+        out_frames = self.get_out_frames(n)
+        out = np.zeros(out_frames * self.out_bpf, np.uint8)
+        ok = lib().ref_audio_converter_samples(self.h, src.ctypes.data if src is not None else None, n, out.ctypes.data, out_frames)
+        assert ok
+        return out
+
+    def free(self):
+        if self.h:
+            lib().ref_audio_converter_free(self.h)
+            self.h = None

@@ -31,6 +31,8 @@ ref_init (void)
     g_type_class_ref (gst_video_gamma_mode_get_type ());
     g_type_class_ref (gst_video_primaries_mode_get_type ());
     g_type_class_ref (gst_audio_resampler_filter_mode_get_type ());
+    g_type_class_ref (gst_audio_dither_method_get_type ());
+    g_type_class_ref (gst_audio_noise_shaping_method_get_type ());
     g_type_class_ref (gst_audio_resampler_filter_interpolation_get_type ());
     gst_compositor_init_blend ();
     g_once_init_leave (&ref_inited, 1);
@@ -481,4 +483,65 @@ void
 ref_audio_resampler_free (void *r)
 {
   gst_audio_resampler_free (r);
+}
+
+/* ---- audio converter (gst-libs/gst/audio/audio-converter.h) ------------------------------------------------------------------- */
+/* in / out: format string ("S16LE" ...), rate, channels (default positions of gst_audio_info_set_format: mono, stereo, ...).
+ * config: a GstStructure string or NULL; mix: NULL or out_ch * in_ch floats ([out][in]) for GstAudioConverter.mix-matrix */
+void *
+ref_audio_converter_new (int flags, const char *in_fmt, int in_rate, int in_ch, const char *out_fmt, int out_rate, int out_ch,
+    const char *config, const float *mix)
+{
+  GstAudioInfo in, out;
+  GstStructure *s = NULL;
+  ref_init ();
+  gst_audio_info_set_format (&in, gst_audio_format_from_string (in_fmt), in_rate, in_ch, NULL);
+  gst_audio_info_set_format (&out, gst_audio_format_from_string (out_fmt), out_rate, out_ch, NULL);
+  if (config)
+    s = gst_structure_from_string (config, NULL);
+  if (mix) {
+    GValue m = G_VALUE_INIT;
+    int i, j;
+    if (!s)
+      s = gst_structure_new_empty ("GstAudioConverter");
+    g_value_init (&m, GST_TYPE_ARRAY);
+    for (j = 0; j < out_ch; j++) {
+      GValue row = G_VALUE_INIT;
+      g_value_init (&row, GST_TYPE_ARRAY);
+      for (i = 0; i < in_ch; i++) {
+        GValue v = G_VALUE_INIT;
+        g_value_init (&v, G_TYPE_FLOAT);
+        g_value_set_float (&v, mix[j * in_ch + i]);
+        gst_value_array_append_and_take_value (&row, &v);
+      }
+      gst_value_array_append_and_take_value (&m, &row);
+    }
+    gst_structure_take_value (s, GST_AUDIO_CONVERTER_OPT_MIX_MATRIX, &m);
+  }
+  return gst_audio_converter_new ((GstAudioConverterFlags) flags, &in, &out, s);
+}
+
+gsize
+ref_audio_converter_get_out_frames (void *c, gsize in_frames)
+{
+  return gst_audio_converter_get_out_frames (c, in_frames);
+}
+
+int
+ref_audio_converter_is_passthrough (void *c)
+{
+  return gst_audio_converter_is_passthrough (c);
+}
+
+int
+ref_audio_converter_samples (void *c, const void *in, gsize in_frames, void *out, gsize out_frames)
+{
+  gpointer ina[1] = { (gpointer) in }, outa[1] = { out };
+  return gst_audio_converter_samples (c, 0, in ? ina : NULL, in_frames, outa, out_frames);
+}
+
+void
+ref_audio_converter_free (void *c)
+{
+  gst_audio_converter_free (c);
 }

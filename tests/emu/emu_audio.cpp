@@ -155,3 +155,89 @@ void emu_audio_resample (void *h, const void *in, size_t in_frames, void *out, s
 }
 
 }  // extern "C"
+
+// ---- audio converter (audio_convert_plan.h + audio_convert_device.h): the two kernels' bodies around the emulated resampler ------
+#include "../../gstreamer_amd/csrc/audio_convert_plan.h"
+
+struct EmuAConv {
+  AConvPlan plan;
+  bool resample = false, passthrough = false;
+  void *resampler = nullptr;
+  uint32_t random_state = 0xc2d6038fu;
+  AConvJump jump;
+};
+
+extern "C" {
+
+void *emu_aconv_new (int flags, const GstAmdAudioInfo *in, const GstAmdAudioInfo *out, const GstAmdAudioConverterConfig *cfg, char *err, int err_len)
+{
+  EmuAConv *c = new EmuAConv ();
+  std::string e;
+  if (aconv_make_plan (flags, in, out, *cfg, &c->plan, &c->resample, &c->passthrough, &e) != GSTAMD_OK) {
+    if (err)
+      strncpy (err, e.c_str (), err_len - 1);
+    delete c;
+    return nullptr;
+  }
+  if (c->resample) {
+    GstAmdAudioResamplerOptions ro;
+    if (cfg->has_resampler_options)
+      ro = cfg->resampler_options;
+    else
+      audio_options_init (&ro);
+    int st = 0;
+    c->resampler = emu_audio_new (cfg->resampler_method, (flags & 2) ? 4 : 0, c->plan.mid_in, out->channels, in->rate, out->rate, &ro, &st, err, err_len);
+    if (!c->resampler) {
+      delete c;
+      return nullptr;
+    }
+  }
+  aconv_make_jump (&c->jump);
+  return c;
+}
+
+void emu_aconv_free (void *h)
+{
+  EmuAConv *c = (EmuAConv *) h;
+  if (c && c->resampler)
+    emu_audio_free (c->resampler);
+  delete c;
+}
+
+size_t emu_aconv_get_out_frames (void *h, size_t in_frames)
+{
+  EmuAConv *c = (EmuAConv *) h;
+  return c->resampler ? emu_audio_get_out_frames (c->resampler, in_frames) : in_frames;
+}
+
+int emu_aconv_is_passthrough (void *h) { return ((EmuAConv *) h)->passthrough ? 1 : 0; }
+
+void emu_aconv_samples (void *h, const uint8_t *in, size_t in_frames, uint8_t *out, size_t out_frames)
+{
+  EmuAConv *c = (EmuAConv *) h;
+  const AConvPlan &p = c->plan;
+  if (in_frames == 0)
+    return;
+  if (c->passthrough) {
+    memcpy (out, in, out_frames * (size_t) p.out_ch * (size_t) afmt_bytes (p.out_fmt));
+    return;
+  }
+  const size_t mb = (size_t) amid_bytes (p.mid_in) * (size_t) p.out_ch;
+  std::vector<uint8_t> a ((in_frames ? in_frames : 1) * mb), b ((out_frames ? out_frames : 1) * mb);
+  if (in)
+    for (size_t n = 0; n < in_frames; n++)
+      for (int co = 0; co < p.out_ch; co++)
+        aconv_pre_sample (p, in, a.data (), n, co);
+  const uint8_t *after = a.data ();
+  if (c->resampler) {
+    emu_audio_resample (c->resampler, in ? a.data () : nullptr, in_frames, b.data (), out_frames);
+    after = b.data ();
+  }
+  const size_t samples = out_frames * (size_t) p.out_ch;
+  for (size_t i = 0; i < samples; i++)
+    aconv_post_sample (p, c->jump, c->random_state, after, out, i);
+  if (samples && p.quant_shift > 0 && p.dither != GSTAMD_AUDIO_DITHER_NONE)
+    c->random_state = aconv_rand_jump (c->jump, c->random_state, (uint64_t) samples * (p.dither == GSTAMD_AUDIO_DITHER_TPDF ? 2u : 1u));
+}
+
+}  // extern "C"

@@ -133,7 +133,10 @@ DITHER = {"none": 0, "rpdf": 1, "tpdf": 2, "tpdf-hf": 3}
 NOISE_SHAPING = {"none": 0, "error-feedback": 1, "simple": 2, "medium": 3, "high": 4}
 MAX_CHANNELS = 8
 # default positions of gst_audio_info_set_format (audio-info.c: gst_audio_channel_positions ... default_channel_order) for 1 / 2 channels
-DEFAULT_POSITIONS = {1: [-1], 2: [0, 1]}
+DEFAULT_POSITIONS = {1: [-2], 2: [0, 1]}
+# GstAudioChannelPosition (audio-channels.h:101-133)
+POSITION = {"none": -3, "mono": -2, "invalid": -1, "front-left": 0, "front-right": 1, "front-center": 2, "lfe1": 3, "rear-left": 4, "rear-right": 5,
+            "front-left-of-center": 6, "front-right-of-center": 7, "rear-center": 8, "lfe2": 9, "side-left": 10, "side-right": 11}
 
 
 class AudioInfo(C.Structure):
@@ -151,11 +154,11 @@ def audio_info(fmt, rate, channels, positions=None, unpositioned=False):
     ai = AudioInfo()
     ai.format, ai.rate, ai.channels, ai.layout, ai.unpositioned = AFMT[fmt], rate, channels, 0, int(unpositioned)
     pos = positions if positions is not None else DEFAULT_POSITIONS.get(channels)
-    if pos is None:
-        pos = list(range(channels))
-        ai.unpositioned = 1 if positions is None else ai.unpositioned
+    if pos is None:                             # gst_audio_info_set_format without positions beyond stereo: unpositioned, NONE everywhere
+        pos = [POSITION["none"]] * channels
+        ai.unpositioned = 1
     for i, v in enumerate(pos):
-        ai.position[i] = v
+        ai.position[i] = POSITION[v] if isinstance(v, str) else v
     return ai
 
 
@@ -220,6 +223,9 @@ class AudioConverter:
 
     def samples(self, src, in_frames, dst, out_frames, stream=None):
         _v._check(_conv_lib().gstamd_audio_converter_samples(self._h, 0, _v._ptr(src), in_frames, _v._ptr(dst), out_frames, stream))
+
+    def reset(self):
+        _conv_lib().gstamd_audio_converter_reset(self._h)
 
     def mix_matrix(self, in_ch, out_ch):
         buf = (C.c_float * (in_ch * out_ch))()

@@ -31,13 +31,23 @@ __global__ __launch_bounds__ (256) void k_aconv_pre (AConvPlan p, const uint8_t 
   aconv_pre_sample (p, in, mid, i / (size_t) p.out_ch, (int) (i % (size_t) p.out_ch));
 }
 
-__global__ __launch_bounds__ (256) void k_aconv_post (AConvPlan p, const AConvJump *__restrict__ jump, uint32_t state0, const uint8_t *__restrict__ mid,
-    uint8_t *__restrict__ out, size_t samples)
+__global__ __launch_bounds__ (256) void k_aconv_post (AConvPlan p, const AConvJump *__restrict__ jump, AConvDitherState ds, const uint8_t *__restrict__ mid,
+    uint8_t *__restrict__ out, int32_t *__restrict__ qv, int32_t *__restrict__ qd, size_t samples)
 {
   const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= samples)
     return;
-  aconv_post_sample (p, *jump, state0, mid, out, i);
+  aconv_post_sample (p, *jump, ds, mid, out, qv, qd, i);
+}
+
+// noise shaping: the error recurrence of a channel is sequential in time, so one lane walks one channel's frames (the samples and
+// dither words were prepared in parallel by k_aconv_post)
+__global__ __launch_bounds__ (64) void k_aconv_shape (AConvPlan p, const int32_t *__restrict__ qv, const int32_t *__restrict__ qd, int32_t *__restrict__ hist,
+    uint8_t *__restrict__ out, size_t frames)
+{
+  const int c = (int) threadIdx.x;
+  if (c < p.out_ch)
+    aconv_shape_channel (p, qv, qd, hist, out, frames, c);
 }
 
 struct GstAmdAudioConverter {
@@ -47,7 +57,10 @@ struct GstAmdAudioConverter {
   AConvPlan plan;
   bool passthrough = false;
   GstAmdAudioResampler *resampler = nullptr;
-  uint32_t random_state = 0xc2d6038fu;                  /* gst_audio_quantize_setup_dither */
+  AConvDitherState dither = { 0xc2d6038fu, 0u, 0 };     /* gst_audio_quantize_setup_dither */
+  int32_t *hist = nullptr;                              /* [8][channels] noise shaping error history */
+  uint8_t *q_v = nullptr, *q_d = nullptr;               /* S32 samples / dither words of a call with noise shaping */
+  size_t q_v_size = 0, q_d_size = 0;
   AConvJump jump_host;
   AConvJump *jump_dev = nullptr;
   uint8_t *mid_a = nullptr, *mid_b = nullptr;           /* before / after the resampler */
@@ -118,6 +131,13 @@ GstAmdAudioConverter *gstamd_audio_converter_new (int flags, const GstAmdAudioIn
     gstamd_audio_converter_free (c);
     return fail (GSTAMD_ERR_HIP, "jump table upload");
   }
+  if (c->plan.ns) {
+    const size_t hb = sizeof (int32_t) * 8 * GSTAMD_AUDIO_MAX_CHANNELS;
+    if (hipMalloc ((void **) &c->hist, hb) != hipSuccess || hipMemset (c->hist, 0, hb) != hipSuccess) {
+      gstamd_audio_converter_free (c);
+      return fail (GSTAMD_ERR_HIP, "error history");
+    }
+  }
   if (status)
     *status = GSTAMD_OK;
   return c;
@@ -135,14 +155,23 @@ void gstamd_audio_converter_free (GstAmdAudioConverter *c)
     (void) hipFree (c->mid_a);
   if (c->mid_b)
     (void) hipFree (c->mid_b);
+  if (c->hist)
+    (void) hipFree (c->hist);
+  if (c->q_v)
+    (void) hipFree (c->q_v);
+  if (c->q_d)
+    (void) hipFree (c->q_d);
   delete c;
 }
 
 void gstamd_audio_converter_reset (GstAmdAudioConverter *c)
 {
-  /* gst_audio_converter_reset (:1520-1530): the resampler and the quantizer (whose reset does not touch the random state) */
+  /* gst_audio_converter_reset (:1520-1530): the resampler and the quantizer, whose reset (audio-quantize.c:503-509) drops the error
+     history and touches neither the random state nor last_random */
   if (c && c->resampler)
     gstamd_audio_resampler_reset (c->resampler);
+  if (c && c->hist)
+    (void) hipMemset (c->hist, 0, sizeof (int32_t) * 8 * GSTAMD_AUDIO_MAX_CHANNELS);
 }
 
 size_t gstamd_audio_converter_get_out_frames (GstAmdAudioConverter *c, size_t in_frames)
@@ -231,13 +260,18 @@ int gstamd_audio_converter_samples (GstAmdAudioConverter *c, int flags, const vo
   const size_t samples = out_frames * (size_t) p.out_ch;
   if (samples == 0)                             /* the resampler only took input into its history */
     return GSTAMD_OK;
-  hipLaunchKernelGGL (k_aconv_post, dim3 ((unsigned) ((samples + 255) / 256)), dim3 (256), 0, stream, p, c->jump_dev, c->random_state, after, (uint8_t *) out,
-      samples);
+  if (p.ns && p.quant_shift > 0) {
+    if ((r = ensure (&c->q_v, &c->q_v_size, samples * 4)) != GSTAMD_OK || (r = ensure (&c->q_d, &c->q_d_size, samples * 4)) != GSTAMD_OK)
+      return r;
+  }
+  hipLaunchKernelGGL (k_aconv_post, dim3 ((unsigned) ((samples + 255) / 256)), dim3 (256), 0, stream, p, c->jump_dev, c->dither, after, (uint8_t *) out,
+      (int32_t *) c->q_v, (int32_t *) c->q_d, samples);
+  if (p.ns && p.quant_shift > 0)
+    hipLaunchKernelGGL (k_aconv_shape, dim3 (1), dim3 (64), 0, stream, p, (const int32_t *) c->q_v, (const int32_t *) c->q_d, c->hist, (uint8_t *) out, out_frames);
   if (hipGetLastError () != hipSuccess)
     return aconv_fail (GSTAMD_ERR_HIP, "kernel launch");
   /* the generator moves on by the draws of this call (setup_dither_buf draws for every sample of the block) */
-  if (p.quant_shift > 0 && p.dither != GSTAMD_AUDIO_DITHER_NONE)
-    c->random_state = aconv_rand_jump (c->jump_host, c->random_state, (uint64_t) samples * (p.dither == GSTAMD_AUDIO_DITHER_TPDF ? 2u : 1u));
+  aconv_dither_advance (p, c->jump_host, &c->dither, samples);
   return GSTAMD_OK;
 }
 

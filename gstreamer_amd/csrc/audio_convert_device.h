@@ -36,8 +36,13 @@ struct AConvPlan {
   int mid_out;                  // AMid after convert_out: what quantize / pack see
   int quant_shift;              // 0: no quantize stage
   int dither;                   // GSTAMD_AUDIO_DITHER_* of the quantize stage
+  int ns;                       // GSTAMD noise shaping of the quantize stage: 0 none, 1 error feedback, 2.. the filters (n_coeffs taps)
+  int n_coeffs;
+  int32_t coeffs[8];            // floor (c * 1024 + 0.5), audio-quantize.c:344-373
   float m[GSTAMD_AUDIO_MAX_CHANNELS][GSTAMD_AUDIO_MAX_CHANNELS];        // [in][out]
   int mi[GSTAMD_AUDIO_MAX_CHANNELS][GSTAMD_AUDIO_MAX_CHANNELS];         // (gint) (m * 1024)
+  int sparse;                   // the mixer's sparse form: only the coefficients of use[] are summed
+  uint32_t use[GSTAMD_AUDIO_MAX_CHANNELS];                              // [out]: bit ci = input channel ci takes part
 };
 
 GSTAMD_AC int amid_bytes (int mid) { return mid == AMID_S16 ? 2 : mid == AMID_F64 ? 8 : 4; }
@@ -196,25 +201,121 @@ GSTAMD_AC int32_t aconv_random_dither (uint32_t *state, int32_t dither)
   return -dither + (int32_t) (*state & (uint32_t) ((dither << 1) - 1));
 }
 
-// quantize stage for sample index i of the call (interleaved order); `state0` is the generator's state before the call
-GSTAMD_AC int32_t aconv_quantize (const AConvPlan &p, const AConvJump &jump, uint32_t state0, size_t i, int32_t v)
+// the generator across calls: its state before this call's draws, and - for tpdf-hf, whose value at a sample is the difference to the
+// draw of the previous frame's sample of the same channel (last_random) - the state before the draws of the previous call's last frame
+struct AConvDitherState {
+  uint32_t state0;
+  uint32_t prev_state;
+  int has_prev;                 // 0: last_random is still the zeros of gst_audio_quantize_setup_dither
+};
+
+// setup_dither_buf (audio-quantize.c:117-170): the dither word of sample index i of the call (interleaved order, draws in that order)
+GSTAMD_AC int32_t aconv_dither_value (const AConvPlan &p, const AConvJump &jump, const AConvDitherState &ds, size_t i)
 {
   const int shift = p.quant_shift;
-  const uint32_t mask = ~((1u << shift) - 1u);
   const uint32_t bias = 1u << (shift - 1);
-  int32_t d;
-  if (p.dither == GSTAMD_AUDIO_DITHER_RPDF) {
-    uint32_t st = aconv_rand_jump (jump, state0, (uint64_t) i);
-    d = (int32_t) (bias + (uint32_t) aconv_random_dither (&st, 1 << shift));
-  } else if (p.dither == GSTAMD_AUDIO_DITHER_TPDF) {
-    uint32_t st = aconv_rand_jump (jump, state0, 2 * (uint64_t) i);
-    const int32_t r1 = aconv_random_dither (&st, 1 << (shift - 1));
-    const int32_t r2 = aconv_random_dither (&st, 1 << (shift - 1));
-    d = (int32_t) (bias + (uint32_t) r1 + (uint32_t) r2);
-  } else {
-    d = (int32_t) bias;                         /* audio_orc_int_bias */
+  switch (p.dither) {
+    case GSTAMD_AUDIO_DITHER_RPDF: {
+      uint32_t st = aconv_rand_jump (jump, ds.state0, (uint64_t) i);
+      return (int32_t) (bias + (uint32_t) aconv_random_dither (&st, 1 << shift));
+    }
+    case GSTAMD_AUDIO_DITHER_TPDF: {
+      uint32_t st = aconv_rand_jump (jump, ds.state0, 2 * (uint64_t) i);
+      const int32_t r1 = aconv_random_dither (&st, 1 << (shift - 1));
+      const int32_t r2 = aconv_random_dither (&st, 1 << (shift - 1));
+      return (int32_t) (bias + (uint32_t) r1 + (uint32_t) r2);
+    }
+    case GSTAMD_AUDIO_DITHER_TPDF_HF: {
+      const size_t stride = (size_t) p.out_ch;
+      uint32_t st = aconv_rand_jump (jump, ds.state0, (uint64_t) i);
+      const int32_t tmp = aconv_random_dither (&st, 1 << (shift - 1));
+      int32_t last = 0;
+      if (i >= stride) {
+        uint32_t s2 = aconv_rand_jump (jump, ds.state0, (uint64_t) (i - stride));
+        last = aconv_random_dither (&s2, 1 << (shift - 1));
+      } else if (ds.has_prev) {
+        uint32_t s2 = aconv_rand_jump (jump, ds.prev_state, (uint64_t) i);
+        last = aconv_random_dither (&s2, 1 << (shift - 1));
+      }
+      return (int32_t) (bias + (uint32_t) tmp - (uint32_t) last);
+    }
+    default:
+      /* no dither: audio_orc_int_bias adds the bias; with noise shaping the quantizer reads a dither buffer of zeros instead */
+      return p.ns ? 0 : (int32_t) bias;
   }
+}
+
+// draws of a call over `samples` samples
+GSTAMD_AC uint64_t aconv_dither_draws (const AConvPlan &p, size_t samples)
+{
+  if (p.quant_shift <= 0 || p.dither == GSTAMD_AUDIO_DITHER_NONE)
+    return 0;
+  return (uint64_t) samples * (p.dither == GSTAMD_AUDIO_DITHER_TPDF ? 2u : 1u);
+}
+
+// after a call: the generator has moved on by the call's draws (host side)
+inline void aconv_dither_advance (const AConvPlan &p, const AConvJump &jump, AConvDitherState *ds, size_t samples)
+{
+  if (samples == 0 || aconv_dither_draws (p, samples) == 0)
+    return;
+  if (p.dither == GSTAMD_AUDIO_DITHER_TPDF_HF) {
+    ds->prev_state = aconv_rand_jump (jump, ds->state0, (uint64_t) (samples - (size_t) p.out_ch));
+    ds->has_prev = 1;
+  }
+  ds->state0 = aconv_rand_jump (jump, ds->state0, aconv_dither_draws (p, samples));
+}
+
+// quantize stage without noise shaping: gst_audio_quantize_quantize_int_none_none / _int_dither_none
+GSTAMD_AC int32_t aconv_quantize (const AConvPlan &p, int32_t d, int32_t v)
+{
+  const uint32_t mask = ~((1u << p.quant_shift) - 1u);
   return (int32_t) ((uint32_t) aconv_addssl (v, d) & mask);
+}
+
+GSTAMD_AC void aconv_pack_int (uint8_t *p, int fmt, size_t i, int32_t v);
+
+// quantize stage with noise shaping for channel c of a call: the error recurrence runs down the frames (one lane per channel).
+// v / d: the call's S32 samples and dither words; hist: [8][channels] error history carried between calls (zeros after new / reset).
+//   gst_audio_quantize_quantize_int_dither_feedback      audio-quantize.c:199-231
+//   gst_audio_quantize_quantize_int_dither_noise_shape   audio-quantize.c:239-278
+GSTAMD_AC void aconv_shape_channel (const AConvPlan &p, const int32_t *v, const int32_t *d, int32_t *hist, uint8_t *out, size_t frames, int c)
+{
+  const size_t ch = (size_t) p.out_ch;
+  const uint32_t mask = ~((1u << p.quant_shift) - 1u);
+  if (p.ns == 1) {
+    uint32_t e = (uint32_t) hist[c];
+    for (size_t n = 0; n < frames; n++) {
+      const size_t i = n * ch + (size_t) c;
+      const int32_t o = v[i];
+      const int32_t err = (int32_t) ((uint32_t) d[i] - e);
+      const int32_t x = (int32_t) ((uint32_t) aconv_addssl (o, err) & mask);
+      e += (uint32_t) x - (uint32_t) o;
+      aconv_pack_int (out, p.out_fmt, i, x);
+    }
+    hist[c] = (int32_t) e;
+    return;
+  }
+  uint32_t h[8];
+  for (int j = 0; j < 8; j++)
+    h[j] = j < p.n_coeffs ? (uint32_t) hist[(size_t) j * ch + (size_t) c] : 0u;
+  for (size_t n = 0; n < frames; n++) {
+    const size_t i = n * ch + (size_t) c;
+    uint32_t acc = 0;
+    for (int j = 0; j < 8; j++)
+      if (j < p.n_coeffs)
+        acc -= h[j] * (uint32_t) p.coeffs[j];
+    const int32_t err = (int32_t) (acc + 2u) >> 2;              /* (err + SROUND) >> SREDUCE */
+    const int32_t o = aconv_addssl (v[i], err);
+    const int32_t x = (int32_t) ((uint32_t) aconv_addssl (o, d[i]) & mask);
+    const int32_t ne = (int32_t) ((uint32_t) x - (uint32_t) o + 128u) >> 8;      /* (v - o + RROUND) >> REDUCE */
+    for (int j = 0; j < 7; j++)
+      if (j + 1 < p.n_coeffs)
+        h[j] = h[j + 1];
+    h[p.n_coeffs - 1] = (uint32_t) ne;
+    aconv_pack_int (out, p.out_fmt, i, x);
+  }
+  for (int j = 0; j < p.n_coeffs; j++)
+    hist[(size_t) j * ch + (size_t) c] = (int32_t) h[j];
 }
 
 // ---- stage 1: input frame n, output channel co -> one sample in the mid_in format ------------------------------------------------
@@ -231,6 +332,8 @@ GSTAMD_AC void aconv_pre_sample (const AConvPlan &p, const uint8_t *in, uint8_t 
       } else {
         res = 0;
         for (int ci = 0; ci < p.in_ch; ci++) {
+          if (!((p.use[co] >> ci) & 1u))
+            continue;
           int16_t v; memcpy (&v, in + 2 * (ibase + ci), 2);
           res += (int32_t) v * p.mi[ci][co];
         }
@@ -248,7 +351,8 @@ GSTAMD_AC void aconv_pre_sample (const AConvPlan &p, const uint8_t *in, uint8_t 
       } else {
         int64_t res = 0;
         for (int ci = 0; ci < p.in_ch; ci++)
-          res += (int64_t) aconv_unpack_int (in, p.in_fmt, ibase + ci) * (int64_t) p.mi[ci][co];
+          if ((p.use[co] >> ci) & 1u)
+            res += (int64_t) aconv_unpack_int (in, p.in_fmt, ibase + ci) * (int64_t) p.mi[ci][co];
         res = (res + 512) >> 10;
         r = res > 2147483647ll ? 2147483647 : (res < -2147483648ll ? (int32_t) 0x80000000u : (int32_t) res);
       }
@@ -262,6 +366,8 @@ GSTAMD_AC void aconv_pre_sample (const AConvPlan &p, const uint8_t *in, uint8_t 
       } else {
         r = 0.0f;
         for (int ci = 0; ci < p.in_ch; ci++) {
+          if (!((p.use[co] >> ci) & 1u))
+            continue;
           float v; memcpy (&v, in + 4 * (ibase + ci), 4);
           r += v * p.m[ci][co];
         }
@@ -276,6 +382,8 @@ GSTAMD_AC void aconv_pre_sample (const AConvPlan &p, const uint8_t *in, uint8_t 
       } else {
         r = 0.0;
         for (int ci = 0; ci < p.in_ch; ci++) {
+          if (!((p.use[co] >> ci) & 1u))
+            continue;
           const double v = p.convert_in ? aconv_s32_to_double (aconv_unpack_int (in, p.in_fmt, ibase + ci)) : aconv_unpack_flt (in, p.in_fmt, ibase + ci);
           r += v * p.m[ci][co];
         }
@@ -287,7 +395,9 @@ GSTAMD_AC void aconv_pre_sample (const AConvPlan &p, const uint8_t *in, uint8_t 
 }
 
 // ---- stage 2: sample i (interleaved index) of the mid buffer after the resampler -> the output format -----------------------------
-GSTAMD_AC void aconv_post_sample (const AConvPlan &p, const AConvJump &jump, uint32_t state0, const uint8_t *mid, uint8_t *out, size_t i)
+// With noise shaping (p.ns) the sample and its dither word go to qv / qd for aconv_shape_channel instead.
+GSTAMD_AC void aconv_post_sample (const AConvPlan &p, const AConvJump &jump, const AConvDitherState &ds, const uint8_t *mid, uint8_t *out, int32_t *qv, int32_t *qd,
+    size_t i)
 {
   if (p.mid_in == AMID_S16) {
     memcpy (out + 2 * i, mid + 2 * i, 2);
@@ -309,8 +419,15 @@ GSTAMD_AC void aconv_post_sample (const AConvPlan &p, const AConvJump &jump, uin
   } else {
     memcpy (&v, mid + 4 * i, 4);
   }
-  if (p.quant_shift > 0)
-    v = aconv_quantize (p, jump, state0, i, v);
+  if (p.quant_shift > 0) {
+    const int32_t d = aconv_dither_value (p, jump, ds, i);
+    if (p.ns) {
+      qv[i] = v;
+      qd[i] = d;
+      return;
+    }
+    v = aconv_quantize (p, d, v);
+  }
   aconv_pack_int (out, p.out_fmt, i, v);
 }
 

@@ -1,6 +1,7 @@
 // audio_convert_plan.h - the decision code of gst_audio_converter_new (audio-converter.c:1346-1470) restated: which stages a conversion
 // has and on which intermediate format they run.  Host only; shared by audio_convert.hip and the host emulation of tests/emu.
 #pragma once
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -38,62 +39,213 @@ static int afmt_mid (int fmt)
   return fmt == GSTAMD_AFMT_S16LE ? AMID_S16 : fmt == GSTAMD_AFMT_S32LE ? AMID_S32 : fmt == GSTAMD_AFMT_F32LE ? AMID_F32 : AMID_F64;
 }
 
-// the mixing matrix (gst_audio_channel_mixer_fill_matrix, audio-channel-mixer.c:731-805), as far as built: the mono <-> stereo
-// special cases, unpositioned input (identity), and layouts whose output positions all exist in the input (fill_identical; nothing
-// left for fill_compatible / fill_others to add, fill_normalize a no-op).  Everything else wants an explicit mix-matrix.
-static bool default_mix_matrix (const GstAmdAudioInfo &in, const GstAmdAudioInfo &out, float m[GSTAMD_AUDIO_MAX_CHANNELS][GSTAMD_AUDIO_MAX_CHANNELS], std::string *why)
+// ---- the default mixing matrix: gst_audio_channel_mixer_fill_matrix (audio-channel-mixer.c:731-805) restated --------------------------
+// Positions are GstAudioChannelPosition values (audio-channels.h:101-133).
+enum APos : int {
+  APOS_NONE = -3, APOS_MONO = -2, APOS_INVALID = -1, APOS_FL = 0, APOS_FR = 1, APOS_FC = 2, APOS_LFE1 = 3, APOS_RL = 4, APOS_RR = 5, APOS_FLOC = 6, APOS_FROC = 7,
+  APOS_RC = 8, APOS_LFE2 = 9, APOS_SL = 10, APOS_SR = 11
+};
+
+typedef float AMixMatrix[GSTAMD_AUDIO_MAX_CHANNELS][GSTAMD_AUDIO_MAX_CHANNELS];
+
+// fill_compatible (:163-253): mono <-> stereo pairs of the front, the centre pair and the rear
+static void amix_fill_compatible (AMixMatrix m, int in_ch, const int *ip, int out_ch, const int *op)
 {
-  const int FL = 0, FR = 1, MONO = -1;
-  memset (m, 0, sizeof (float) * GSTAMD_AUDIO_MAX_CHANNELS * GSTAMD_AUDIO_MAX_CHANNELS);
-  if (in.channels == 2 && out.channels == 1 && !in.unpositioned && !out.unpositioned &&
-      ((in.position[0] == FL && in.position[1] == FR) || (in.position[0] == FR && in.position[1] == FL)) && out.position[0] == MONO) {
-    m[0][0] = m[1][0] = 0.5f;
-    return true;
-  }
-  if (in.channels == 1 && out.channels == 2 && !in.unpositioned && !out.unpositioned &&
-      ((out.position[0] == FL && out.position[1] == FR) || (out.position[0] == FR && out.position[1] == FL)) && in.position[0] == MONO) {
-    m[0][0] = m[0][1] = 1.0f;
-    return true;
-  }
-  if (in.unpositioned) {
-    for (int co = 0; co < out.channels; co++)
-      for (int ci = 0; ci < in.channels; ci++)
-        m[ci][co] = ci == co ? 1.0f : 0.0f;
-    return true;
-  }
-  if (out.unpositioned) {
-    *why = "positioned input into unpositioned output";
-    return false;
-  }
-  /* all-mono or alternating left / right inputs of more than one / two channels are "virtual inputs" (:684-729): not built */
-  bool all_mono = in.channels >= 2, alternate = in.channels > 2;
-  for (int i = 0; i < in.channels; i++) {
-    all_mono = all_mono && in.position[i] == MONO;
-    alternate = alternate && in.position[i] == (i & 1);
-  }
-  if (all_mono || alternate) {
-    *why = "virtual mono / stereo input layouts";
-    return false;
-  }
-  if (in.channels != out.channels) {
-    *why = "channel layouts other than mono <-> stereo need the position-based down / up-mix rules (fill_compatible / fill_others)";
-    return false;
-  }
-  for (int co = 0; co < out.channels; co++) {
-    int found = 0;
-    for (int ci = 0; ci < in.channels; ci++)
-      if (in.position[ci] == out.position[co]) {
-        m[ci][co] = 1.0f;
-        found++;
-      }
-    if (found != 1) {
-      *why = "output channel positions that the input does not have";
-      return false;
+  static const int conv[3][3] = { {APOS_FL, APOS_FR, APOS_MONO}, {APOS_FLOC, APOS_FROC, APOS_FC}, {APOS_RL, APOS_RR, APOS_RC} };
+  for (int c = 0; c < 3; c++) {
+    int a0 = -1, a1 = -1, a2 = -1, b0 = -1, b1 = -1, b2 = -1;
+    for (int n = 0; n < in_ch; n++) {
+      if (ip[n] == conv[c][0]) a0 = n;
+      else if (ip[n] == conv[c][1]) a1 = n;
+      else if (ip[n] == conv[c][2]) a2 = n;
     }
+    for (int n = 0; n < out_ch; n++) {
+      if (op[n] == conv[c][0]) b0 = n;
+      else if (op[n] == conv[c][1]) b1 = n;
+      else if (op[n] == conv[c][2]) b2 = n;
+    }
+    /* left -> centre, right -> centre */
+    if (a0 != -1 && a2 == -1 && b0 == -1 && b2 != -1) m[a0][b2] = 1.0f;
+    else if (a0 != -1 && a2 != -1 && b0 == -1 && b2 != -1) m[a0][b2] = 0.5f;
+    else if (a0 != -1 && a2 == -1 && b0 != -1 && b2 != -1) m[a0][b2] = 1.0f;
+    if (a1 != -1 && a2 == -1 && b1 == -1 && b2 != -1) m[a1][b2] = 1.0f;
+    else if (a1 != -1 && a2 != -1 && b1 == -1 && b2 != -1) m[a1][b2] = 0.5f;
+    else if (a1 != -1 && a2 == -1 && b1 != -1 && b2 != -1) m[a1][b2] = 1.0f;
+    /* centre -> left, centre -> right */
+    if (a2 != -1 && a0 == -1 && b2 == -1 && b0 != -1) m[a2][b0] = 1.0f;
+    else if (a2 != -1 && a0 != -1 && b2 == -1 && b0 != -1) m[a2][b0] = 0.5f;
+    else if (a2 != -1 && a0 == -1 && b2 != -1 && b0 != -1) m[a2][b0] = 1.0f;
+    if (a2 != -1 && a1 == -1 && b2 == -1 && b1 != -1) m[a2][b1] = 1.0f;
+    else if (a2 != -1 && a1 != -1 && b2 == -1 && b1 != -1) m[a2][b1] = 0.5f;
+    else if (a2 != -1 && a1 == -1 && b2 != -1 && b1 != -1) m[a2][b1] = 1.0f;
   }
-  return true;
 }
 
+struct AMixGroups {             // detect_pos (:264-327): [0] left, [1] centre-ish, [2] right of the five families
+  int f[3] = { -1, -1, -1 }, c[3] = { -1, -1, -1 }, r[3] = { -1, -1, -1 }, s[3] = { -1, -1, -1 }, b[3] = { -1, -1, -1 };
+  bool has_f = false, has_c = false, has_r = false, has_s = false, has_b = false;
+};
+
+static void amix_detect (int ch, const int *pos, AMixGroups &g)
+{
+  for (int n = 0; n < ch; n++)
+    switch (pos[n]) {
+      case APOS_MONO: g.f[1] = n; g.has_f = true; break;
+      case APOS_FL: g.f[0] = n; g.has_f = true; break;
+      case APOS_FR: g.f[2] = n; g.has_f = true; break;
+      case APOS_FC: g.c[1] = n; g.has_c = true; break;
+      case APOS_FLOC: g.c[0] = n; g.has_c = true; break;
+      case APOS_FROC: g.c[2] = n; g.has_c = true; break;
+      case APOS_RC: g.r[1] = n; g.has_r = true; break;
+      case APOS_RL: g.r[0] = n; g.has_r = true; break;
+      case APOS_RR: g.r[2] = n; g.has_r = true; break;
+      case APOS_SL: g.s[0] = n; g.has_s = true; break;
+      case APOS_SR: g.s[2] = n; g.has_s = true; break;
+      case APOS_LFE1: g.b[1] = n; g.has_b = true; break;
+      default: break;
+    }
+}
+
+// fill_one_other (:329-378); `ratio` is a gfloat there and 0.5 * ratio is rounded to float on the store
+static void amix_one_other (AMixMatrix m, const int *from, const int *to, float ratio)
+{
+  const float half = (float) (0.5 * (double) ratio);
+  if (from[1] != -1 && to[1] != -1) m[from[1]][to[1]] = ratio;
+  if (from[0] != -1 && to[0] != -1) m[from[0]][to[0]] = ratio;
+  if (from[2] != -1 && to[2] != -1) m[from[2]][to[2]] = ratio;
+  if (from[0] != -1 && to[1] != -1) m[from[0]][to[1]] = from[1] != -1 ? half : ratio;
+  if (from[2] != -1 && to[1] != -1) m[from[2]][to[1]] = from[1] != -1 ? half : ratio;
+  if (from[1] != -1 && to[0] != -1) m[from[1]][to[0]] = from[0] != -1 ? half : ratio;
+  if (from[1] != -1 && to[2] != -1) m[from[1]][to[2]] = from[2] != -1 ? half : ratio;
+}
+
+// fill_others (:398-590): a family one side lacks goes to / comes from the nearest family the other side has
+static void amix_fill_others (AMixMatrix m, int in_ch, const int *ip, int out_ch, const int *op)
+{
+  AMixGroups i, o;
+  amix_detect (in_ch, ip, i);
+  amix_detect (out_ch, op, o);
+  const double R2 = 1.0 / sqrt (2.0), R8 = 1.0 / sqrt (8.0);
+  const double CENTER_FRONT = R2, CENTER_SIDE = 0.5, CENTER_REAR = R8, FRONT_SIDE = R2, FRONT_REAR = 0.5, SIDE_REAR = R2;
+  const double CENTER_BASS = R2, FRONT_BASS = 1.0, SIDE_BASS = R2, REAR_BASS = R2;
+  auto go = [&](const int *from, const int *to, double ratio) { amix_one_other (m, from, to, (float) ratio); };
+  /* centre <-> front / side / rear */
+  if (!i.has_c && i.has_f && o.has_c) go (i.f, o.c, CENTER_FRONT);
+  else if (!i.has_c && !i.has_f && i.has_s && o.has_c) go (i.s, o.c, CENTER_SIDE);
+  else if (!i.has_c && !i.has_f && !i.has_s && i.has_r && o.has_c) go (i.r, o.c, CENTER_REAR);
+  else if (i.has_c && !o.has_c && o.has_f) go (i.c, o.f, CENTER_FRONT);
+  else if (i.has_c && !o.has_c && !o.has_f && o.has_s) go (i.c, o.s, CENTER_SIDE);
+  else if (i.has_c && !o.has_c && !o.has_f && !o.has_s && o.has_r) go (i.c, o.r, CENTER_REAR);
+  /* front <-> centre / side / rear */
+  if (!i.has_f && i.has_c && !i.has_s && o.has_f) go (i.c, o.f, CENTER_FRONT);
+  else if (!i.has_f && !i.has_c && i.has_s && o.has_f) go (i.s, o.f, FRONT_SIDE);
+  else if (!i.has_f && i.has_c && i.has_s && o.has_f) { go (i.c, o.f, 0.5 * CENTER_FRONT); go (i.s, o.f, 0.5 * FRONT_SIDE); }
+  else if (!i.has_f && !i.has_c && !i.has_s && i.has_r && o.has_f) go (i.r, o.f, FRONT_REAR);
+  else if (i.has_f && o.has_c && !o.has_s && !o.has_f) go (i.f, o.c, CENTER_FRONT);
+  else if (i.has_f && !o.has_c && o.has_s && !o.has_f) go (i.f, o.s, FRONT_SIDE);
+  else if (i.has_f && o.has_c && o.has_s && !o.has_f) { go (i.f, o.c, 0.5 * CENTER_FRONT); go (i.f, o.s, 0.5 * FRONT_SIDE); }
+  else if (i.has_f && !o.has_c && !o.has_s && !o.has_f && o.has_r) go (i.f, o.r, FRONT_REAR);
+  /* side <-> centre / front / rear */
+  if (!i.has_s && i.has_f && !i.has_r && o.has_s) go (i.f, o.s, FRONT_SIDE);
+  else if (!i.has_s && !i.has_f && i.has_r && o.has_s) go (i.r, o.s, SIDE_REAR);
+  else if (!i.has_s && i.has_f && i.has_r && o.has_s) { go (i.f, o.s, 0.5 * FRONT_SIDE); go (i.r, o.s, 0.5 * SIDE_REAR); }
+  else if (!i.has_s && !i.has_f && !i.has_r && i.has_c && o.has_s) go (i.c, o.s, CENTER_SIDE);
+  else if (i.has_s && o.has_f && !o.has_r && !o.has_s) go (i.s, o.f, FRONT_SIDE);
+  else if (i.has_s && !o.has_f && o.has_r && !o.has_s) go (i.s, o.r, SIDE_REAR);
+  else if (i.has_s && o.has_f && o.has_r && !o.has_s) { go (i.s, o.f, 0.5 * FRONT_SIDE); go (i.s, o.r, 0.5 * SIDE_REAR); }
+  else if (i.has_s && !o.has_f && !o.has_r && o.has_c && !o.has_s) go (i.s, o.c, CENTER_SIDE);
+  /* rear <-> centre / front / side */
+  if (!i.has_r && i.has_s && o.has_r) go (i.s, o.r, SIDE_REAR);
+  else if (!i.has_r && !i.has_s && i.has_f && o.has_r) go (i.f, o.r, FRONT_REAR);
+  else if (!i.has_r && !i.has_s && !i.has_f && i.has_c && o.has_r) go (i.c, o.r, CENTER_REAR);
+  else if (i.has_r && !o.has_r && o.has_s) go (i.r, o.s, SIDE_REAR);
+  else if (i.has_r && !o.has_r && !o.has_s && o.has_f) go (i.r, o.f, FRONT_REAR);
+  else if (i.has_r && !o.has_r && !o.has_s && !o.has_f && o.has_c) go (i.r, o.c, CENTER_REAR);
+  /* bass <-> any */
+  if (i.has_b && !o.has_b) {
+    if (o.has_c) go (i.b, o.c, CENTER_BASS);
+    if (o.has_f) go (i.b, o.f, FRONT_BASS);
+    if (o.has_s) go (i.b, o.s, SIDE_BASS);
+    if (o.has_r) go (i.b, o.r, REAR_BASS);
+  } else if (!i.has_b && o.has_b) {
+    if (i.has_c) go (i.c, o.b, CENTER_BASS);
+    if (i.has_f) go (i.f, o.b, FRONT_BASS);
+    if (i.has_s) go (i.s, o.b, REAR_BASS);              /* the reference uses the rear ratio for the sides here (:581) */
+    if (i.has_r) go (i.r, o.b, REAR_BASS);
+  }
+}
+
+// fill_normalize (:596-626): float sums of |m| per output channel, every entry divided by the largest
+static void amix_normalize (AMixMatrix m, int in_ch, int out_ch)
+{
+  float top = 0;
+  for (int j = 0; j < out_ch; j++) {
+    float sum = 0.0f;
+    for (int i = 0; i < in_ch; i++)
+      sum = (float) ((double) sum + fabs ((double) m[i][j]));
+    if (sum > top)
+      top = sum;
+  }
+  if (top == 0.0f)
+    return;
+  for (int j = 0; j < out_ch; j++)
+    for (int i = 0; i < in_ch; i++)
+      m[i][j] /= top;
+}
+
+static void default_mix_matrix (const GstAmdAudioInfo &in, const GstAmdAudioInfo &out, AMixMatrix m)
+{
+  memset (m, 0, sizeof (AMixMatrix));
+  const int *ip = in.position, *op = out.position;
+  const int in_ch = in.channels, out_ch = out.channels;
+  /* fill_special (:628-656) */
+  if (in_ch == 2 && out_ch == 1 && ((ip[0] == APOS_FL && ip[1] == APOS_FR) || (ip[0] == APOS_FR && ip[1] == APOS_FL)) && op[0] == APOS_MONO) {
+    m[0][0] = m[1][0] = 0.5f;
+    return;
+  }
+  if (in_ch == 1 && out_ch == 2 && ((op[0] == APOS_FL && op[1] == APOS_FR) || (op[0] == APOS_FR && op[1] == APOS_FL)) && ip[0] == APOS_MONO) {
+    m[0][0] = m[0][1] = 1.0f;
+    return;
+  }
+  /* virtual inputs (:684-729): all-mono inputs count as one mono channel, alternating left / right ones as one stereo pair */
+  int in_size = in_ch, virt = 0;
+  if (in_ch >= 2) {
+    bool mono = true, alt = true;
+    for (int i = 0; i < in_ch; i++) {
+      mono = mono && ip[i] == APOS_MONO;
+      alt = alt && ip[i] == (i & 1 ? APOS_FR : APOS_FL);
+    }
+    if (mono) { virt = 1; in_size = 1; }
+    else if (alt && in_ch > 2) { virt = 2; in_size = 2; }
+  }
+  /* fill_identical (:130-155) */
+  for (int co = 0; co < out_ch; co++)
+    for (int ci = 0; ci < in_size; ci++) {
+      if (in.unpositioned)
+        m[ci][co] = ci == co ? 1.0f : 0.0f;
+      else if (ip[ci] == op[co])
+        m[ci][co] = 1.0f;
+    }
+  if (!in.unpositioned) {
+    amix_fill_compatible (m, in_size, ip, out_ch, op);
+    amix_fill_others (m, in_size, ip, out_ch, op);
+    amix_normalize (m, in_size, out_ch);
+  }
+  if (virt == 1) {
+    for (int o = 0; o < out_ch; o++)
+      m[0][o] /= (float) in_ch;
+    for (int i = 1; i < in_ch; i++)
+      memcpy (m[i], m[0], sizeof (float) * (size_t) out_ch);
+  } else if (virt == 2) {
+    const int right = in_ch >> 1, left = right + (in_ch % 2);
+    for (int o = 0; o < out_ch; o++) {
+      m[0][o] /= (float) left;
+      m[1][o] /= (float) right;
+    }
+    for (int i = 2; i < in_ch; i++)
+      memcpy (m[i], m[i % 2], sizeof (float) * (size_t) out_ch);
+  }
+}
 
 // The whole plan.  *resample: a resampler (on p->mid_in, out->channels) sits between the two kernels; *passthrough: the bytes
 // themselves.  Returns GSTAMD_OK or an error code with *err set.
@@ -143,10 +295,22 @@ inline int aconv_make_plan (int flags, const GstAmdAudioInfo *in, const GstAmdAu
       for (int co = 0; co < out->channels; co++)
         p.m[ci][co] = cfg.mix_matrix[co][ci];           /* mix_matrix_from_g_value: the option is [out][in] */
   } else {
-    std::string why;
-    if (!default_mix_matrix (*in, *out, p.m, &why)) {
-      *err = "no GPU-side rule for this channel conversion (" + why + "); pass a mix-matrix";
-      return GSTAMD_ERR_UNSUPPORTED;
+    default_mix_matrix (*in, *out, p.m);
+  }
+  /* gst_audio_channel_mixer_build_sparse_matrix (:1063-1122): with fewer than half of the coefficients above 1e-6 the mixer walks a
+     list of those only - the others are not summed at all (which matters for float samples: inf * 0) */
+  {
+    int pairs = 0;
+    for (int ci = 0; ci < in->channels; ci++)
+      for (int co = 0; co < out->channels; co++)
+        if (fabsf (p.m[ci][co]) > 1e-6f)
+          pairs++;
+    p.sparse = (double) pairs / (double) (in->channels * out->channels) < 0.5 ? 1 : 0;
+    for (int co = 0; co < out->channels; co++) {
+      p.use[co] = 0;
+      for (int ci = 0; ci < in->channels; ci++)
+        if (!p.sparse || fabsf (p.m[ci][co]) > 1e-6f)
+          p.use[co] |= 1u << ci;
     }
   }
   for (int ci = 0; ci < in->channels; ci++)
@@ -179,13 +343,18 @@ inline int aconv_make_plan (int flags, const GstAmdAudioInfo *in, const GstAmdAu
       ns = 1;
     }
     if (fo.integer && fo.depth < 32 && cur == AMID_S32) {
-      if (ns != 0) {
-        *err = "noise shaping (error feedback per channel, audio-quantize.c:200-290) is sequential; not built on the GPU path";
-        return GSTAMD_ERR_UNSUPPORTED;
-      }
-      if (dither == GSTAMD_AUDIO_DITHER_TPDF_HF) {
-        *err = "tpdf-hf dither (depends on the previous sample's random value) is not built on the GPU path";
-        return GSTAMD_ERR_UNSUPPORTED;
+      /* gst_audio_quantize_setup_noise_shaping :344-373 */
+      static const double ns_simple[] = { -0.5, 1.0 };
+      static const double ns_medium[] = { 0.6149, -1.590, 1.959, -2.165, 2.033 };
+      static const double ns_high[] = { -0.340122, 0.876066, -1.72008, 2.61339, -3.31399, 3.27918, -2.92975, 2.08484 };
+      const double *cf = ns == 2 ? ns_simple : ns == 3 ? ns_medium : ns_high;
+      p.ns = ns;
+      p.n_coeffs = ns == 2 ? 2 : ns == 3 ? 5 : ns == 4 ? 8 : 0;
+      for (int i = 0; i < p.n_coeffs; i++)
+        p.coeffs[i] = (int32_t) floor (cf[i] * 1024.0 + 0.5);
+      if (ns < 0 || ns > 4 || dither < 0 || dither > 3) {
+        *err = "unknown dither / noise shaping method";
+        return GSTAMD_ERR_INVALID;
       }
       p.quant_shift = 32 - fo.depth;                    /* quantizer 1 << (32 - depth): count_power */
       p.dither = dither;

@@ -117,7 +117,7 @@ typedef struct GstAmdAudioInfo {
   int32_t rate, channels;
   int32_t layout;               /* 0 interleaved (the only layout of the converter so far) */
   int32_t unpositioned;         /* GST_AUDIO_FLAG_UNPOSITIONED */
-  int32_t position[GSTAMD_AUDIO_MAX_CHANNELS];  /* GstAudioChannelPosition (audio-channels.h:60-110): MONO -1, FRONT_LEFT 0, FRONT_RIGHT 1, ... */
+  int32_t position[GSTAMD_AUDIO_MAX_CHANNELS];  /* GstAudioChannelPosition values (audio-channels.h:101-133): NONE -3, MONO -2, FRONT_LEFT 0, FRONT_RIGHT 1, FRONT_CENTER 2, LFE1 3, REAR_LEFT 4, ... */
 } GstAmdAudioInfo;
 
 typedef struct GstAmdAudioConverterConfig {

@@ -44,11 +44,15 @@ def lib():
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ref_audio_converter_new.restype = C.c_void_p
         L.ref_audio_converter_new.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
+        L.ref_audio_converter_new_positions.restype = C.c_void_p
+        L.ref_audio_converter_new_positions.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p,
+                                                        C.c_char_p, C.c_void_p]
         L.ref_audio_converter_get_out_frames.restype = C.c_size_t
         L.ref_audio_converter_get_out_frames.argtypes = [C.c_void_p, C.c_size_t]
         L.ref_audio_converter_is_passthrough.argtypes = [C.c_void_p]
         L.ref_audio_converter_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.ref_audio_converter_free.argtypes = [C.c_void_p]
+        L.ref_audio_converter_reset.argtypes = [C.c_void_p]
         L.ref_audio_resampler_new.restype = C.c_void_p
         L.ref_audio_resampler_new.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
         for n in ("get_out_frames", "get_in_frames"):
@@ -246,14 +250,17 @@ AUDIO_BYTES = {"S8": 1, "U8": 1, "S16LE": 2, "S24LE": 3, "S24_32LE": 4, "S32LE":
 class AudioConverter:
     """gst_audio_converter_new / _samples of the reference on host numpy byte buffers (interleaved frames)."""
 
-    def __init__(self, in_fmt, in_rate, in_ch, out_fmt, out_rate, out_ch, config=None, mix=None, flags=0):
+    def __init__(self, in_fmt, in_rate, in_ch, out_fmt, out_rate, out_ch, config=None, mix=None, flags=0, in_pos=None, out_pos=None):
         import numpy as np
         m = None
         if mix is not None:
             m = np.ascontiguousarray(np.asarray(mix, np.float32))
             assert m.shape == (out_ch, in_ch)
-        self.h = lib().ref_audio_converter_new(flags, in_fmt.encode(), in_rate, in_ch, out_fmt.encode(), out_rate, out_ch, _b(config),
-                                               m.ctypes.data if m is not None else None)
+        ip = np.asarray(in_pos, np.int32) if in_pos is not None else None
+        op = np.asarray(out_pos, np.int32) if out_pos is not None else None
+        self.h = lib().ref_audio_converter_new_positions(flags, in_fmt.encode(), in_rate, in_ch, ip.ctypes.data if ip is not None else None,
+                                                         out_fmt.encode(), out_rate, out_ch, op.ctypes.data if op is not None else None, _b(config),
+                                                         m.ctypes.data if m is not None else None)
         if not self.h:
             raise ValueError("reference could not create the audio converter")
         self.in_bpf, self.out_bpf = AUDIO_BYTES[in_fmt] * in_ch, AUDIO_BYTES[out_fmt] * out_ch
@@ -273,6 +280,9 @@ class AudioConverter:
         ok = lib().ref_audio_converter_samples(self.h, src.ctypes.data if src is not None else None, n, out.ctypes.data, out_frames)
         assert ok
         return out
+
+    def reset(self):
+        lib().ref_audio_converter_reset(self.h)
 
     def free(self):
         if self.h:

@@ -486,17 +486,47 @@ ref_audio_resampler_free (void *r)
 }
 
 /* ---- audio converter (gst-libs/gst/audio/audio-converter.h) ------------------------------------------------------------------- */
-/* in / out: format string ("S16LE" ...), rate, channels (default positions of gst_audio_info_set_format: mono, stereo, ...).
+/* in / out: format string ("S16LE" ...), rate, channels, positions (GstAudioChannelPosition values, or NULL for the defaults of
+ * gst_audio_info_set_format: mono, stereo, unpositioned beyond).
  * config: a GstStructure string or NULL; mix: NULL or out_ch * in_ch floats ([out][in]) for GstAudioConverter.mix-matrix */
+void *
+ref_audio_converter_new_positions (int flags, const char *in_fmt, int in_rate, int in_ch, const int *in_pos, const char *out_fmt, int out_rate, int out_ch,
+    const int *out_pos, const char *config, const float *mix);
+
 void *
 ref_audio_converter_new (int flags, const char *in_fmt, int in_rate, int in_ch, const char *out_fmt, int out_rate, int out_ch,
     const char *config, const float *mix)
 {
+  return ref_audio_converter_new_positions (flags, in_fmt, in_rate, in_ch, NULL, out_fmt, out_rate, out_ch, NULL, config, mix);
+}
+
+void *
+ref_audio_converter_new_positions (int flags, const char *in_fmt, int in_rate, int in_ch, const int *in_pos, const char *out_fmt, int out_rate, int out_ch,
+    const int *out_pos, const char *config, const float *mix)
+{
   GstAudioInfo in, out;
   GstStructure *s = NULL;
+  GstAudioChannelPosition ip[64], op[64];
+  int k;
   ref_init ();
+  for (k = 0; k < in_ch && in_pos; k++)
+    ip[k] = (GstAudioChannelPosition) in_pos[k];
+  for (k = 0; k < out_ch && out_pos; k++)
+    op[k] = (GstAudioChannelPosition) out_pos[k];
+  /* positions are written into the info the way the audioconvert element does for layouts gst_audio_info_set_format would not take
+     (several mono channels, reordered channels) */
   gst_audio_info_set_format (&in, gst_audio_format_from_string (in_fmt), in_rate, in_ch, NULL);
   gst_audio_info_set_format (&out, gst_audio_format_from_string (out_fmt), out_rate, out_ch, NULL);
+  if (in_pos) {
+    memcpy (in.position, ip, sizeof (ip[0]) * in_ch);
+    if (ip[0] != GST_AUDIO_CHANNEL_POSITION_NONE)
+      in.flags &= ~GST_AUDIO_FLAG_UNPOSITIONED;
+  }
+  if (out_pos) {
+    memcpy (out.position, op, sizeof (op[0]) * out_ch);
+    if (op[0] != GST_AUDIO_CHANNEL_POSITION_NONE)
+      out.flags &= ~GST_AUDIO_FLAG_UNPOSITIONED;
+  }
   if (config)
     s = gst_structure_from_string (config, NULL);
   if (mix) {
@@ -538,6 +568,12 @@ ref_audio_converter_samples (void *c, const void *in, gsize in_frames, void *out
 {
   gpointer ina[1] = { (gpointer) in }, outa[1] = { out };
   return gst_audio_converter_samples (c, 0, in ? ina : NULL, in_frames, outa, out_frames);
+}
+
+void
+ref_audio_converter_reset (void *c)
+{
+  gst_audio_converter_reset ((GstAudioConverter *) c);
 }
 
 void

@@ -11,7 +11,7 @@ OUT = os.path.join(HERE, "libgstamdhipdsp.so")
 
 
 def build():
-    srcs = [os.path.join(HERE, f) for f in ("gstamdplugin.c", "gstamdhipmemory.c", "gstamdhipbufferpool.c", "gstamdvideoconvertscale.c", "gstamdaudioresample.c", "gstamdcompositor.c", "gstamdhiptransfer.c")]
+    srcs = [os.path.join(HERE, f) for f in ("gstamdplugin.c", "gstamdhipmemory.c", "gstamdhipbufferpool.c", "gstamdvideoconvertscale.c", "gstamdaudioresample.c", "gstamdaudioconvert.c", "gstamdcompositor.c", "gstamdhiptransfer.c")]
     inc = ["-I%s/include/gstreamer-1.0" % CONDA, "-I%s/lib/gstreamer-1.0/include" % CONDA, "-I%s/include/glib-2.0" % CONDA,
            "-I%s/lib/glib-2.0/include" % CONDA]
     libdir = os.path.join(ROOT, "gstreamer_amd", "lib")

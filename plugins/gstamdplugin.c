@@ -1,7 +1,7 @@
 /* gstamdplugin.c - plugin entry: registers the MI355X elements under the REFERENCE's factory names and ranks
  * (subprojects/gst-plugins-base/gst/videoconvertscale/gstvideoconvertscaleplugin.c:33-53: `videoscale`, `videoconvert` rank
  * MARGINAL, `videoconvertscale` rank SECONDARY - gstvideoconvert.c:46, gstvideoscale.c:58, gstvideoconvertscale.c:121;
- * gst/audioresample/gstaudioresample.c:139 `audioresample` rank PRIMARY; gst/compositor/compositor.c `compositor` PRIMARY + 1),
+ * gst/audioresample/gstaudioresample.c:139 `audioresample` rank PRIMARY; gst/audioconvert/gstaudioconvert.c `audioconvert` PRIMARY; gst/compositor/compositor.c `compositor` PRIMARY + 1),
  * one rank step above the stock elements so that autopluggers prefer them when both plugins are visible.  A registry keeps ONE
  * feature per name: with this plugin scanned after gst-plugins-base (or in a GST_PLUGIN_PATH of its own) the names resolve to these
  * elements.  `amd`-prefixed aliases are always there, so both implementations can be addressed side by side in one registry;
@@ -13,6 +13,7 @@ GType gst_amd_video_convert_scale_get_type (void);
 GType gst_amd_video_convert_element_get_type (void);
 GType gst_amd_video_scale_element_get_type (void);
 GType gst_amd_audio_resample_get_type (void);
+GType gst_amd_audio_convert_get_type (void);
 GType gst_amd_compositor_get_type (void);
 GType gst_amd_hip_upload_element_get_type (void);
 GType gst_amd_hip_download_element_get_type (void);
@@ -59,11 +60,13 @@ plugin_init (GstPlugin * plugin)
     ok &= claim (plugin, "videoconvert", GST_RANK_MARGINAL + 1, gst_amd_video_convert_element_get_type ());
     ok &= claim (plugin, "videoscale", GST_RANK_MARGINAL + 1, gst_amd_video_scale_element_get_type ());
     ok &= claim (plugin, "audioresample", GST_RANK_PRIMARY + 1, gst_amd_audio_resample_get_type ());
+    ok &= claim (plugin, "audioconvert", GST_RANK_PRIMARY + 1, gst_amd_audio_convert_get_type ());
   }
   ok &= gst_element_register (plugin, "amdvideoconvertscale", GST_RANK_NONE, gst_amd_video_convert_scale_get_type ());
   ok &= gst_element_register (plugin, "amdvideoconvert", GST_RANK_NONE, gst_amd_video_convert_element_get_type ());
   ok &= gst_element_register (plugin, "amdvideoscale", GST_RANK_NONE, gst_amd_video_scale_element_get_type ());
   ok &= gst_element_register (plugin, "amdaudioresample", GST_RANK_NONE, gst_amd_audio_resample_get_type ());
+  ok &= gst_element_register (plugin, "amdaudioconvert", GST_RANK_NONE, gst_amd_audio_convert_get_type ());
   ok &= gst_element_register (plugin, "amdcompositor", GST_RANK_NONE, gst_amd_compositor_get_type ());
   ok &= gst_element_register (plugin, "amdhipupload", GST_RANK_NONE, gst_amd_hip_upload_element_get_type ());
   ok &= gst_element_register (plugin, "amdhipdownload", GST_RANK_NONE, gst_amd_hip_download_element_get_type ());

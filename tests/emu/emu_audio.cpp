@@ -163,8 +163,9 @@ struct EmuAConv {
   AConvPlan plan;
   bool resample = false, passthrough = false;
   void *resampler = nullptr;
-  uint32_t random_state = 0xc2d6038fu;
+  AConvDitherState dither = { 0xc2d6038fu, 0u, 0 };
   AConvJump jump;
+  std::vector<int32_t> hist = std::vector<int32_t> (8 * GSTAMD_AUDIO_MAX_CHANNELS, 0);
 };
 
 extern "C" {
@@ -210,6 +211,12 @@ size_t emu_aconv_get_out_frames (void *h, size_t in_frames)
   return c->resampler ? emu_audio_get_out_frames (c->resampler, in_frames) : in_frames;
 }
 
+void emu_aconv_reset (void *h)
+{
+  EmuAConv *c = (EmuAConv *) h;          /* converters without a resampler only (the emulated resampler has no reset) */
+  std::fill (c->hist.begin (), c->hist.end (), 0);
+}
+
 int emu_aconv_is_passthrough (void *h) { return ((EmuAConv *) h)->passthrough ? 1 : 0; }
 
 void emu_aconv_samples (void *h, const uint8_t *in, size_t in_frames, uint8_t *out, size_t out_frames)
@@ -234,10 +241,13 @@ void emu_aconv_samples (void *h, const uint8_t *in, size_t in_frames, uint8_t *o
     after = b.data ();
   }
   const size_t samples = out_frames * (size_t) p.out_ch;
+  std::vector<int32_t> qv (samples + 1), qd (samples + 1);
   for (size_t i = 0; i < samples; i++)
-    aconv_post_sample (p, c->jump, c->random_state, after, out, i);
-  if (samples && p.quant_shift > 0 && p.dither != GSTAMD_AUDIO_DITHER_NONE)
-    c->random_state = aconv_rand_jump (c->jump, c->random_state, (uint64_t) samples * (p.dither == GSTAMD_AUDIO_DITHER_TPDF ? 2u : 1u));
+    aconv_post_sample (p, c->jump, c->dither, after, out, qv.data (), qd.data (), i);
+  if (p.ns && p.quant_shift > 0)
+    for (int ch = 0; ch < p.out_ch; ch++)
+      aconv_shape_channel (p, qv.data (), qd.data (), c->hist.data (), out, out_frames, ch);
+  aconv_dither_advance (p, c->jump, &c->dither, samples);
 }
 
 }  // extern "C"

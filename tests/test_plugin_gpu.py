@@ -564,3 +564,75 @@ def test_p010_decoder_output_to_bgra_through_the_element(gst_env, ref):
     rc = ref.VideoConverter("P010_10LE", w, h, "BGRA", w, h, in_colorimetry="bt709", in_chroma_site="mpeg2")
     for i in range(n):
         assert (rc.frame(src[i]) == out[i]).all(), i
+
+
+def _ref_convert_blocks(rc, src_bytes, in_bpf, blk):
+    out = []
+    for off in range(0, src_bytes.size, blk * in_bpf):
+        out.append(rc.samples(src_bytes[off:off + blk * in_bpf]))
+    return np.concatenate(out)
+
+
+def test_audioconvert_element_matches_reference(gst_env, ref):
+    """`audioconvert` (plugins/gstamdaudioconvert.c): F32 -> S16 with the element's default triangular dither, then S16 stereo -> S32
+    mono, against the reference's converter fed buffer by buffer (the dither generator runs on across buffers)."""
+    env, tmp = gst_env
+    fin, fout, fmono = tmp / "ac_in.f32", tmp / "ac_out.s16", tmp / "ac_mono.s32"
+    launch(env, "audiotestsrc num-buffers=12 wave=white-noise volume=1.0 samplesperbuffer=1024 ! audio/x-raw,format=F32LE,rate=48000,channels=2 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! amdaudioconvert ! audio/x-raw,format=S16LE ! filesink location=%s" % (fin, fout))
+    src = np.fromfile(fin, np.uint8)
+    out = np.fromfile(fout, np.uint8)
+    rc = ref.AudioConverter("F32LE", 48000, 2, "S16LE", 48000, 2, config="GstAudioConverter, GstAudioConverter.dither-method=(GstAudioDitherMethod)tpdf")
+    exp = _ref_convert_blocks(rc, src, 8, 1024)
+    rc.free()
+    assert out.shape == exp.shape and (out == exp).all(), int((out != exp).sum())
+    launch(env, "filesrc location=%s blocksize=4096 ! audio/x-raw,format=S16LE,rate=48000,channels=2,layout=interleaved ! amdaudioconvert dithering=none "
+                "! audio/x-raw,format=S32LE,channels=1 ! filesink location=%s" % (fout, fmono))
+    mono = np.fromfile(fmono, np.uint8)
+    rc = ref.AudioConverter("S16LE", 48000, 2, "S32LE", 48000, 1)
+    exp = _ref_convert_blocks(rc, out, 4, 1024)
+    rc.free()
+    assert mono.shape == exp.shape and (mono == exp).all()
+
+
+def test_audioconvert_element_noise_shaping_downmix_and_resample_chain(gst_env, ref):
+    """5.1 (channel-mask 0x3f) F32 -> stereo S16 with noise shaping through the position-based down-mix rules, followed by audioresample."""
+    env, tmp = gst_env
+    fin, fout = tmp / "ac51_in.f32", tmp / "ac51_out.s16"
+    launch(env, "audiotestsrc num-buffers=10 wave=pink-noise samplesperbuffer=1024 ! audio/x-raw,format=F32LE,rate=48000,channels=6,channel-mask=(bitmask)0x3f "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! amdaudioconvert dithering=rpdf noise-shaping=medium "
+                "! audio/x-raw,format=S16LE,channels=2 ! amdaudioresample quality=4 ! audio/x-raw,rate=44100 ! filesink location=%s" % (fin, fout))
+    src = np.fromfile(fin, np.uint8)
+    out = np.fromfile(fout, np.int16).reshape(-1, 2)
+    pos = [0, 1, 2, 3, 4, 5]
+    rc = ref.AudioConverter("F32LE", 48000, 6, "S16LE", 48000, 2, in_pos=pos,
+                            config="GstAudioConverter, GstAudioConverter.dither-method=(GstAudioDitherMethod)rpdf, "
+                                   "GstAudioConverter.noise-shaping-method=(GstAudioNoiseShapingMethod)medium")
+    mid = _ref_convert_blocks(rc, src, 24, 1024).view(np.int16).reshape(-1, 2)
+    rc.free()
+    rr = ref.AudioResampler("S16LE", 2, 48000, 44100, quality=4)
+    exp = []
+    for off in range(0, len(mid), 1024):
+        blk = mid[off:off + 1024]
+        exp.append(rr.resample(blk, in_frames=len(blk), out_frames=rr.get_out_frames(len(blk))))
+    lat = rr.get_max_latency()
+    exp.append(rr.resample(None, in_frames=lat, out_frames=rr.get_out_frames(lat)))
+    exp = np.concatenate(exp)
+    assert out.shape == exp.shape and (out == exp).all()
+
+
+def test_audioconvert_element_mix_matrix_property(gst_env, ref):
+    env, tmp = gst_env
+    fin, fout = tmp / "acm_in.s16", tmp / "acm_out.s16"
+    r = subprocess.run([GST, "-q"] + ("audiotestsrc num-buffers=6 wave=white-noise samplesperbuffer=1024 ! audio/x-raw,format=S16LE,rate=44100,channels=2 "
+                                      "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! amdaudioconvert" % fin).split() +
+                       ["mix-matrix=<<(float)0.25,(float)0.75>,<(float)1.0,(float)0.0>,<(float)0.0,(float)-1.0>>", "!"] +
+                       ("audio/x-raw,format=S16LE,channels=3,channel-mask=(bitmask)0x0 ! filesink location=%s" % fout).split(),
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    src = np.fromfile(fin, np.uint8)
+    out = np.fromfile(fout, np.uint8)
+    rc = ref.AudioConverter("S16LE", 44100, 2, "S16LE", 44100, 3, mix=[[0.25, 0.75], [1.0, 0.0], [0.0, -1.0]])
+    exp = _ref_convert_blocks(rc, src, 4, 1024)
+    rc.free()
+    assert out.shape == exp.shape and (out == exp).all()

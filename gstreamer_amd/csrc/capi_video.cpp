@@ -68,6 +68,11 @@ struct GstAmdVideoConverter {
   int mfma_waves = 0, mfma_rpc = 0, mfma_ring = 0, mfma_tile_w = 0;
   uint8_t *deep_a = nullptr, *deep_b = nullptr;        /* scratch images of a scaled 10-bit conversion (convert_deep_scaled) */
   size_t deep_a_size = 0, deep_b_size = 0;
+  /* gamma-mode = remap (GammaPlan): the two sub-conversions, the tables and the 8-bit images either side of the 16-bit part */
+  GstAmdVideoConverter *sub_in = nullptr, *sub_out = nullptr;
+  uint16_t *gamma_dec_dev = nullptr;
+  uint8_t *gamma_enc_dev = nullptr;
+  uint8_t *gamma_mid_a = nullptr, *gamma_mid_b = nullptr;
 };
 
 namespace gstamd {
@@ -242,6 +247,22 @@ GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info
     delete c;
     return nullptr;
   }
+  if (c->plan.gamma.on) {
+    const GammaPlan &g = c->plan.gamma;
+    int st = GSTAMD_OK;
+    c->sub_in = gstamd_video_converter_new (&g.sub_in_info, &g.mid_in, &g.cfg_in, &st);
+    if (c->sub_in)
+      c->sub_out = gstamd_video_converter_new (&g.mid_out, &g.sub_out_info, &g.cfg_out, &st);
+    if (!c->sub_in || !c->sub_out) {
+      const std::string why = g_last_error;
+      if (status)
+        *status = st;
+      gstamd_video_converter_free (c);
+      set_error (st, "gamma-mode = remap: " + why);
+      return nullptr;
+    }
+    c->plan.description += " <- " + c->sub_in->plan.description + " -> " + c->sub_out->plan.description;
+  }
   return c;
 }
 
@@ -269,6 +290,24 @@ static int build_tables (GstAmdVideoConverter *c)
   VideoPlan &p = c->plan;
   if ((e = hipGetDevice (&c->device)) != hipSuccess)
     return hip_fail (e, "hipGetDevice");
+  if (p.gamma.on) {
+    const GammaPlan &g = p.gamma;
+    const size_t in_px = (size_t) g.mid_in.width * g.mid_in.height, out_px = (size_t) g.mid_out.width * g.mid_out.height;
+    if ((e = hipMalloc ((void **) &c->gamma_dec_dev, 256 * sizeof (uint16_t))) != hipSuccess ||
+        (e = hipMemcpy (c->gamma_dec_dev, g.dec.data (), 256 * sizeof (uint16_t), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMalloc ((void **) &c->gamma_enc_dev, 65536)) != hipSuccess ||
+        (e = hipMemcpy (c->gamma_enc_dev, g.enc.data (), 65536, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMalloc ((void **) &c->gamma_mid_a, in_px * 4)) != hipSuccess || (e = hipMalloc ((void **) &c->gamma_mid_b, out_px * 4)) != hipSuccess)
+      return hip_fail (e, "gamma tables / images");
+    if (!p.passes.empty ()) {
+      const ScalePass &s0 = p.passes[0];
+      const size_t mid_px = (size_t) (s0.horizontal ? s0.out_size : g.mid_in.width) * (s0.horizontal ? g.mid_in.height : s0.out_size);
+      c->deep_a_size = std::max (in_px, out_px) * 8;
+      c->deep_b_size = std::max (mid_px, out_px) * 8;
+      if ((e = hipMalloc ((void **) &c->deep_a, c->deep_a_size)) != hipSuccess || (e = hipMalloc ((void **) &c->deep_b, c->deep_b_size)) != hipSuccess)
+        return hip_fail (e, "hipMalloc(16-bit scratch)");
+    }
+  }
   if (!p.vpair.empty ()) {
     if ((e = hipMalloc ((void **) &c->vpair_dev, p.vpair.size () * sizeof (int32_t))) != hipSuccess)
       return hip_fail (e, "hipMalloc(vpair)");
@@ -379,6 +418,65 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
 static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
     const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES], hipStream_t stream);
 
+// gamma-mode = remap (GammaPlan, video_gamma.h): in -> 8-bit unpack-format image -> [decode | scalers on ARGB64 | primaries, alpha |
+// encode] -> 8-bit unpack-format image -> out.  The images live in HBM (correctness and coverage first).
+static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[GSTAMD_VIDEO_MAX_PLANES], const int32_t src_stride[GSTAMD_VIDEO_MAX_PLANES],
+    void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES], const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES], hipStream_t stream)
+{
+  const VideoPlan &p = c->plan;
+  const GammaPlan &g = p.gamma;
+  const int in_w = g.mid_in.width, in_h = g.mid_in.height, out_w = g.mid_out.width, out_h = g.mid_out.height;
+  void *ma[GSTAMD_VIDEO_MAX_PLANES] = {c->gamma_mid_a, nullptr, nullptr, nullptr};
+  const int32_t mas[GSTAMD_VIDEO_MAX_PLANES] = {in_w * 4, 0, 0, 0};
+  int r = gstamd_video_converter_frame_planes (c->sub_in, src_planes, src_stride, ma, mas, stream);
+  if (r != GSTAMD_OK)
+    return r;
+  GammaDev gd;
+  gd.to_rgb = g.to_rgb;
+  gd.to_yuv = g.to_yuv;
+  gd.prim = g.prim;
+  gd.alpha_kind = g.alpha_kind;
+  gd.alpha_value = g.alpha_value;
+  gd.dec = c->gamma_dec_dev;
+  gd.enc = c->gamma_enc_dev;
+  hipError_t e;
+  const size_t n = p.passes.size ();
+  if (n == 0) {
+    e = launch_gamma_stage (gd, GAMMA_STAGE_DEC | GAMMA_STAGE_MID | GAMMA_STAGE_ENC, c->gamma_mid_a, in_w * 4, c->gamma_mid_b, out_w * 4, out_w, out_h, stream);
+    if (e != hipSuccess)
+      return hip_fail (e, "k_gamma_stage");
+  } else {
+    if ((e = launch_gamma_stage (gd, GAMMA_STAGE_DEC | (g.shrink ? 0 : GAMMA_STAGE_MID), c->gamma_mid_a, in_w * 4, c->deep_a, in_w * 8, in_w, in_h, stream)) !=
+        hipSuccess)
+      return hip_fail (e, "k_gamma_stage(decode)");
+    Deep16Image cur = {c->deep_a, in_w * 8, in_w, in_h};
+    for (size_t i = 0; i < n; i++) {
+      ScaleDev sd;
+      memset (&sd, 0, sizeof (sd));
+      sd.kind = p.passes[i].kind;
+      sd.n_taps = p.passes[i].n_taps;
+      sd.inc = p.passes[i].inc;
+      sd.offset = c->pass_dev[i].offset;
+      sd.taps = c->pass_dev[i].taps;
+      sd.tapw = c->pass_dev[i].tapw;
+      sd.nw = p.passes[i].nw;
+      sd.nw4 = p.passes[i].nw4;
+      const bool hz = p.passes[i].horizontal;
+      const int ow = hz ? p.passes[i].out_size : cur.width, oh = hz ? cur.height : p.passes[i].out_size;
+      uint8_t *dst = cur.p == c->deep_a ? c->deep_b : c->deep_a;
+      if ((e = launch_scale16 (cur, sd, hz, dst, ow * 8, ow, oh, nullptr, nullptr, stream)) != hipSuccess)
+        return hip_fail (e, "k_scale16");
+      cur.p = dst, cur.stride = ow * 8, cur.width = ow, cur.height = oh;
+    }
+    if ((e = launch_gamma_stage (gd, (g.shrink ? GAMMA_STAGE_MID : 0) | GAMMA_STAGE_ENC, cur.p, cur.stride, c->gamma_mid_b, out_w * 4, out_w, out_h, stream)) !=
+        hipSuccess)
+      return hip_fail (e, "k_gamma_stage(encode)");
+  }
+  const void *mb[GSTAMD_VIDEO_MAX_PLANES] = {c->gamma_mid_b, nullptr, nullptr, nullptr};
+  const int32_t mbs[GSTAMD_VIDEO_MAX_PLANES] = {out_w * 4, 0, 0, 0};
+  return gstamd_video_converter_frame_planes (c->sub_out, mb, mbs, dest_planes, dest_stride, stream);
+}
+
 int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *const src_planes[GSTAMD_VIDEO_MAX_PLANES],
     const int32_t src_stride[GSTAMD_VIDEO_MAX_PLANES], void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
     const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES], void *stream_)
@@ -390,6 +488,8 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
     return r;
   hipStream_t stream = (hipStream_t) stream_;
   const VideoPlan &p = c->plan;
+  if (p.gamma.on)
+    return convert_gamma (c, src_planes, src_stride, dest_planes, dest_stride, stream);
   Planes pl;
   memset (&pl, 0, sizeof (pl));
   for (int i = 0; i < p.in_info.n_planes; i++) {
@@ -878,6 +978,12 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
   int r = ensure_tables (c);
   if (r != GSTAMD_OK)
     return r;
+  if (p.gamma.on) {
+    for (int i = 0; i < n_frames; i++)
+      if ((r = gstamd_video_converter_frame (c, src[i], dest[i], stream_)) != GSTAMD_OK)
+        return r;
+    return GSTAMD_OK;
+  }
   /* one launch for the whole list when the line-pair kernel applies to every frame */
   bool all_fast = true;
   std::vector<const uint8_t *> y (n_frames), uv (n_frames);
@@ -959,6 +1065,17 @@ static void release_tables (GstAmdVideoConverter *c)
     (void) hipFree (c->deep_a);
   if (c->deep_b)
     (void) hipFree (c->deep_b);
+  if (c->gamma_dec_dev)
+    (void) hipFree (c->gamma_dec_dev);
+  if (c->gamma_enc_dev)
+    (void) hipFree (c->gamma_enc_dev);
+  if (c->gamma_mid_a)
+    (void) hipFree (c->gamma_mid_a);
+  if (c->gamma_mid_b)
+    (void) hipFree (c->gamma_mid_b);
+  c->gamma_dec_dev = nullptr;
+  c->gamma_enc_dev = nullptr;
+  c->gamma_mid_a = c->gamma_mid_b = nullptr;
   c->deep_a = c->deep_b = nullptr;
   c->deep_a_size = c->deep_b_size = 0;
   if (c->vgroup_dev)
@@ -994,6 +1111,8 @@ void gstamd_video_converter_free (GstAmdVideoConverter *c)
   if (!c)
     return;
   release_tables (c);
+  gstamd_video_converter_free (c->sub_in);
+  gstamd_video_converter_free (c->sub_out);
   delete c;
 }
 
@@ -1003,7 +1122,7 @@ int gstamd_video_converter_set_config (GstAmdVideoConverter *c, const GstAmdVide
     return set_error (GSTAMD_ERR_INVALID, "NULL converter or config");
   VideoPlan np;
   std::string err;
-  const GstAmdVideoInfo in = c->plan.in_info, out = c->plan.out_info;
+  const GstAmdVideoInfo in = c->plan.orig_in, out = c->plan.orig_out;
   int r = plan_video_converter (&in, &out, config, &np, &err);
   if (r != GSTAMD_OK)
     return set_error (r, err);          /* the old plan stays, like a failed gst_video_converter_set_config leaves the converter usable */
@@ -1212,7 +1331,7 @@ int gstamd_video_converter_is_reentrant (GstAmdVideoConverter *c)
   if (!c || ensure_tables (c) != GSTAMD_OK)
     return 0;
   const VideoPlan &p = c->plan;
-  if (p.plane_mode || p.out_planar || (p.deep16 && !p.passes.empty ()))
+  if (p.gamma.on || p.plane_mode || p.out_planar || (p.deep16 && !p.passes.empty ()))
     return 0;                   /* plane_tmp / pk_img / the 16-bit scratch images: one set per converter */
   if (p.passes.size () == 2) {
     const auto small_kind = [](int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; };

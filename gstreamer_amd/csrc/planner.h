@@ -173,8 +173,28 @@ struct RectPlan {
   uint8_t border[4];            // border pixel in unpack order: A, R, G, B or A, Y, U, V
 };
 
+// gamma-mode = remap (video-converter.c chain_convert_to_RGB :1566-1610, chain_convert :1719-1868, chain_alpha, chain_convert_to_YUV
+// :1955-2015): the chain runs on linear-light ARGB64 lines between the chroma upsampler and the chroma downsampler.  The plan is a
+// composite: sub-conversion `in -> mid_in` (unpack + upsample into the 8-bit unpack format AYUV / ARGB, the source crop), the stages
+// of video_gamma.h and the 16-bit scalers on images in HBM, sub-conversion `mid_out -> out` (downsample, dither, pack, destination
+// rectangle and borders).
+struct GammaPlan {
+  bool on = false;
+  GstAmdVideoInfo sub_in_info, mid_in, mid_out, sub_out_info;
+  GstAmdVideoConverterConfig cfg_in, cfg_out;
+  MatrixParams to_rgb, to_yuv;  // 8-bit matrices around the tables (kind NONE: RGB on that side)
+  Deep16Params prim;            // primaries matrix on 16-bit values (video_converter_matrix16)
+  int alpha_kind;               // ALPHA_* on 16-bit alpha (convert_set_alpha_u16 / convert_mult_alpha_u16)
+  unsigned alpha_value;
+  bool shrink;                  // the scalers run before the primaries / alpha stages (chain_scale's first call)
+  std::vector<uint16_t> dec;    // [256] gamma_convert_u8_u16's table
+  std::vector<uint8_t> enc;     // [65536] gamma_convert_u16_u8's table
+};
+
 struct VideoPlan {
   GstAmdVideoInfo in_info, out_info;
+  GstAmdVideoInfo orig_in, orig_out;   // the frames as given (in_info / out_info are the crop / the destination rectangle)
+  GammaPlan gamma;
   GstAmdVideoConverterConfig config;
   const FormatDesc *fin, *fout;
   FrontParams front;

@@ -1,0 +1,80 @@
+// video_gamma.h - the linear-light part of GstVideoConverter with gamma-mode = remap, per pixel (bodies shared with tests/emu):
+//   do_convert_to_RGB_lines  video-converter.c:3070-3093   8-bit matrix to R'G'B' (prepare_matrix's table / matrix8 / AYUV_ARGB forms),
+//                                                          then gamma_convert_u8_u16 (:1444-1460): table[component], alpha a << 8 | a
+//   do_convert_lines         :3095-3140                    video_converter_matrix16 with the primaries matrix (:1296-1320)
+//   do_alpha_lines           :3142-3160                    convert_set_alpha_u16 / convert_mult_alpha_u16 (:1882-1908)
+//   do_convert_to_YUV_lines  :3162-3190                    gamma_convert_u16_u8 (:1462-1478): table[component], alpha >> 8; then the 8-bit
+//                                                          matrix to Y'CbCr
+// An ARGB64 pixel is two words as in video_deep.h: {A | c1 << 16, c2 | c3 << 16}.
+#pragma once
+#include "video_deep.h"
+
+namespace gstamd {
+
+enum { GAMMA_STAGE_DEC = 1, GAMMA_STAGE_MID = 2, GAMMA_STAGE_ENC = 4 };
+
+struct GammaDev {
+  MatrixParams to_rgb, to_yuv;
+  Deep16Params prim;
+  int alpha_kind;
+  unsigned alpha_value;
+  const uint16_t *dec;          // [256]
+  const uint8_t *enc;           // [65536]
+};
+
+GSTAMD_HD uint2 gamma_dec_px (const GammaDev &g, uint32_t px)
+{
+  px = apply_matrix (g.to_rgb, px);
+  const uint32_t a = px & 0xff;
+  uint2 r;
+  r.x = ((a << 8) | a) | ((uint32_t) g.dec[(px >> 8) & 0xff] << 16);
+  r.y = (uint32_t) g.dec[(px >> 16) & 0xff] | ((uint32_t) g.dec[px >> 24] << 16);
+  return r;
+}
+
+GSTAMD_HD uint2 gamma_mid_px (const GammaDev &g, uint2 px)
+{
+  int a = (int) (px.x & 0xffffu), c1 = (int) (px.x >> 16), c2 = (int) (px.y & 0xffffu), c3 = (int) (px.y >> 16);
+  if (g.prim.has_matrix) {
+    const int r = c1, gg = c2, b = c3;
+    c1 = clampi ((g.prim.im[0][0] * r + g.prim.im[0][1] * gg + g.prim.im[0][2] * b + g.prim.im[0][3]) >> 8, 0, 65535);
+    c2 = clampi ((g.prim.im[1][0] * r + g.prim.im[1][1] * gg + g.prim.im[1][2] * b + g.prim.im[1][3]) >> 8, 0, 65535);
+    c3 = clampi ((g.prim.im[2][0] * r + g.prim.im[2][1] * gg + g.prim.im[2][2] * b + g.prim.im[2][3]) >> 8, 0, 65535);
+  }
+  if (g.alpha_kind == ALPHA_SET) {
+    const unsigned v = g.alpha_value < 255u ? g.alpha_value : 255u;
+    a = (int) ((v | (v << 8)) & 0xffffu);
+  } else if (g.alpha_kind == ALPHA_MULT) {
+    a = clampi ((int) (((unsigned) a * g.alpha_value) / 255u), 0, 65535);
+  }
+  uint2 r;
+  r.x = (uint32_t) a | ((uint32_t) c1 << 16);
+  r.y = (uint32_t) c2 | ((uint32_t) c3 << 16);
+  return r;
+}
+
+GSTAMD_HD uint32_t gamma_enc_px (const GammaDev &g, uint2 px)
+{
+  const uint32_t p = ((px.x & 0xffffu) >> 8) | ((uint32_t) g.enc[px.x >> 16] << 8) | ((uint32_t) g.enc[px.y & 0xffffu] << 16) |
+      ((uint32_t) g.enc[px.y >> 16] << 24);
+  return apply_matrix (g.to_yuv, p);
+}
+
+// one pixel of a stage launch: the stages of `mask` in order; the source is an 8-bit image when the mask starts with the decode, the
+// destination an 8-bit image when it ends with the encode
+GSTAMD_HD void gamma_stage_px (const GammaDev &g, int mask, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int x, int y)
+{
+  uint2 v;
+  if (mask & GAMMA_STAGE_DEC)
+    v = gamma_dec_px (g, *(const uint32_t *) (src + (ptrdiff_t) y * sstride + 4 * (ptrdiff_t) x));
+  else
+    v = *(const uint2 *) (src + (ptrdiff_t) y * sstride + 8 * (ptrdiff_t) x);
+  if (mask & GAMMA_STAGE_MID)
+    v = gamma_mid_px (g, v);
+  if (mask & GAMMA_STAGE_ENC)
+    *(uint32_t *) (dst + (ptrdiff_t) y * dstride + 4 * (ptrdiff_t) x) = gamma_enc_px (g, v);
+  else
+    *(uint2 *) (dst + (ptrdiff_t) y * dstride + 8 * (ptrdiff_t) x) = v;
+}
+
+}  // namespace gstamd

@@ -10,6 +10,7 @@
 #include "video_hscale420.h"
 #include "video_bilinear_rows.h"
 #include "video_422_fast.h"
+#include "video_gamma.h"
 
 namespace gstamd {
 
@@ -19,6 +20,7 @@ hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vp
 hipError_t launch_convert16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const Deep16Params &d, const PostParams &post, uint8_t *dst,
     int dstride, hipStream_t stream);
 
+hipError_t launch_gamma_stage (const GammaDev &g, int mask, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int w, int h, hipStream_t stream);
 hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream);
 struct Deep16Image;
 hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, uint8_t *img, int istride, hipStream_t stream);

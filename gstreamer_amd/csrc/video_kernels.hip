@@ -85,6 +85,22 @@ hipError_t launch_scale16 (const Deep16Image &im, const ScaleDev &sd, bool horiz
   return hipGetLastError ();
 }
 
+// gamma-mode = remap: the per-pixel stages of video_gamma.h over an image (one lane per pixel; the tables are gathers from HBM / L2)
+__global__ __launch_bounds__ (256) void k_gamma_stage (GammaDev g, int mask, const uint8_t *__restrict__ src, int sstride, uint8_t *__restrict__ dst, int dstride,
+    int w, int h)
+{
+  const int x = (int) (blockIdx.x * blockDim.x + threadIdx.x), y = (int) blockIdx.y;
+  if (x < w && y < h)
+    gamma_stage_px (g, mask, src, sstride, dst, dstride, x, y);
+}
+
+hipError_t launch_gamma_stage (const GammaDev &g, int mask, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int w, int h, hipStream_t stream)
+{
+  dim3 grid ((w + 255) / 256, h);
+  hipLaunchKernelGGL (k_gamma_stage, grid, dim3 (256), 0, stream, g, mask, src, sstride, dst, dstride, w, h);
+  return hipGetLastError ();
+}
+
 // the dither stage as a pass over the packed destination rectangle (video_dither.h)
 __global__ __launch_bounds__ (256) void k_dither4 (DitherParams d, uint8_t *__restrict__ img, int stride, int w, int h)
 {

@@ -26,9 +26,18 @@ RESAMPLER_METHOD = {"nearest": 0, "linear": 1, "cubic": 2, "sinc": 3, "lanczos":
 ALPHA_MODE = {"copy": 0, "set": 1, "mult": 2}
 CHROMA_MODE = {"full": 0, "upsample-only": 1, "downsample-only": 2, "none": 3}
 MATRIX_MODE = {"full": 0, "input-only": 1, "output-only": 2, "none": 3}
-# colorimetry strings of video-color.c:72-86 -> (range, matrix)
-COLORIMETRY = {"bt601": ("16-235", "bt601"), "bt709": ("16-235", "bt709"), "smpte240m": ("16-235", "smpte240m"),
-               "sRGB": ("0-255", "rgb"), "bt2020": ("16-235", "bt2020")}
+# GstVideoTransferFunction / GstVideoColorPrimaries (video-color.h:132-148, 197-209)
+TRANSFER = {"unknown": 0, "gamma10": 1, "gamma18": 2, "gamma20": 3, "gamma22": 4, "bt709": 5, "smpte240m": 6, "srgb": 7, "gamma28": 8, "log100": 9,
+            "log316": 10, "bt2020-12": 11, "adobergb": 12, "bt2020-10": 13, "smpte2084": 14, "arib-std-b67": 15, "bt601": 16}
+PRIMARIES = {"unknown": 0, "bt709": 1, "bt470m": 2, "bt470bg": 3, "smpte170m": 4, "smpte240m": 5, "film": 6, "bt2020": 7, "adobergb": 8,
+             "smptest428": 9, "smpterp431": 10, "smpteeg432": 11, "ebu3213": 12}
+GAMMA_MODE = {"none": 0, "remap": 1}
+PRIMARIES_MODE = {"none": 0, "merge-only": 1, "fast": 2}
+# colorimetry strings of video-color.c:72-86 -> (range, matrix, transfer, primaries); "r:m:t:p" with the numbers of the enums also works
+COLORIMETRY = {"bt601": ("16-235", "bt601", "bt601", "smpte170m"), "bt709": ("16-235", "bt709", "bt709", "bt709"),
+               "smpte240m": ("16-235", "smpte240m", "smpte240m", "smpte240m"), "sRGB": ("0-255", "rgb", "srgb", "bt709"),
+               "bt2020": ("16-235", "bt2020", "bt2020-12", "bt2020"), "bt2020-10": ("16-235", "bt2020", "bt2020-10", "bt2020"),
+               "bt2100-pq": ("16-235", "bt2020", "smpte2084", "bt2020"), "bt2100-hlg": ("16-235", "bt2020", "arib-std-b67", "bt2020")}
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP = 0, -1, -2, -3
 
@@ -37,7 +46,7 @@ class VideoInfo(C.Structure):
     _fields_ = [("format", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("n_planes", C.c_int32),
                 ("stride", C.c_int32 * 4), ("offset", C.c_uint64 * 4), ("size", C.c_uint64),
                 ("color_range", C.c_int32), ("color_matrix", C.c_int32), ("chroma_site", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("color_transfer", C.c_int32), ("color_primaries", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class ConverterConfig(C.Structure):
@@ -45,7 +54,8 @@ class ConverterConfig(C.Structure):
                 ("envelope", C.c_double), ("sharpness", C.c_double), ("sharpen", C.c_double),
                 ("cubic_b", C.c_double), ("cubic_c", C.c_double), ("alpha_mode", C.c_int32),
                 ("alpha_value", C.c_double), ("chroma_mode", C.c_int32), ("matrix_mode", C.c_int32),
-                ("dither_quantization", C.c_uint32), ("chroma_resampler_method", C.c_int32), ("dither_method", C.c_int32), ("reserved", C.c_int32 * 6),
+                ("dither_quantization", C.c_uint32), ("chroma_resampler_method", C.c_int32), ("dither_method", C.c_int32),
+                ("gamma_mode", C.c_int32), ("primaries_mode", C.c_int32), ("internal_flags", C.c_int32), ("reserved", C.c_int32 * 3),
                 ("src_x", C.c_int32), ("src_y", C.c_int32), ("src_width", C.c_int32), ("src_height", C.c_int32),
                 ("dest_x", C.c_int32), ("dest_y", C.c_int32), ("dest_width", C.c_int32), ("dest_height", C.c_int32),
                 ("fill_border", C.c_int32), ("border_argb", C.c_uint32)]
@@ -136,9 +146,12 @@ def video_info(fmt, width, height, colorimetry=None, chroma_site=None, stride=No
     info = VideoInfo()
     _check(lib().gstamd_video_info_set_format(C.byref(info), FORMATS[fmt], width, height))
     if colorimetry:
-        rng, mtx = COLORIMETRY[colorimetry]
-        info.color_range = COLOR_RANGE[rng]
-        info.color_matrix = COLOR_MATRIX[mtx]
+        if colorimetry in COLORIMETRY:
+            rng, mtx, trc, prim = COLORIMETRY[colorimetry]
+            info.color_range, info.color_matrix = COLOR_RANGE[rng], COLOR_MATRIX[mtx]
+            info.color_transfer, info.color_primaries = TRANSFER[trc], PRIMARIES[prim]
+        else:                                   # "range:matrix:transfer:primaries" (gst_video_colorimetry_from_string's numeric form)
+            info.color_range, info.color_matrix, info.color_transfer, info.color_primaries = [int(v) for v in colorimetry.split(":")]
     if chroma_site:
         info.chroma_site = CHROMA_SITE[chroma_site]
     if stride is not None:
@@ -158,7 +171,7 @@ def converter_config(**kw):
     cfg = ConverterConfig()
     lib().gstamd_video_converter_config_init(C.byref(cfg))
     enums = {"resampler_method": RESAMPLER_METHOD, "alpha_mode": ALPHA_MODE, "chroma_mode": CHROMA_MODE,
-             "matrix_mode": MATRIX_MODE, "dither_method": DITHER_METHOD}
+             "matrix_mode": MATRIX_MODE, "dither_method": DITHER_METHOD, "gamma_mode": GAMMA_MODE, "primaries_mode": PRIMARIES_MODE}
     for k, v in kw.items():
         if k in enums and isinstance(v, str):
             v = enums[k][v]

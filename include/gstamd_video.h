@@ -90,6 +90,12 @@ enum {
   GSTAMD_MATRIX_MODE_OUTPUT_ONLY = 2, GSTAMD_MATRIX_MODE_NONE = 3
 };
 
+enum { GSTAMD_GAMMA_MODE_NONE = 0, GSTAMD_GAMMA_MODE_REMAP = 1 };
+enum { GSTAMD_PRIMARIES_MODE_NONE = 0, GSTAMD_PRIMARIES_MODE_MERGE_ONLY = 1, GSTAMD_PRIMARIES_MODE_FAST = 2 };
+/* GstVideoTransferFunction / GstVideoColorPrimaries values used by the defaults (the fields take any value of the reference's enums) */
+enum { GSTAMD_TRANSFER_UNKNOWN = 0, GSTAMD_TRANSFER_BT709 = 5, GSTAMD_TRANSFER_SRGB = 7, GSTAMD_TRANSFER_BT601 = 16 };
+enum { GSTAMD_PRIMARIES_UNKNOWN = 0, GSTAMD_PRIMARIES_BT709 = 1, GSTAMD_PRIMARIES_SMPTE170M = 4 };
+
 /* status codes (0 = ok).  The library never falls back to a CPU path: a conversion it does not
  * implement on the GPU is refused with GSTAMD_ERR_UNSUPPORTED, mirroring the reference returning
  * NULL from gst_video_converter_new for an impossible conversion (video-converter.c:2543-2562). */
@@ -111,7 +117,9 @@ typedef struct GstAmdVideoInfo {
   int32_t color_range;                          /* GstVideoColorRange */
   int32_t color_matrix;                         /* GstVideoColorMatrix */
   int32_t chroma_site;                          /* GstVideoChromaSite flags */
-  int32_t reserved[5];
+  int32_t color_transfer;                       /* GstVideoTransferFunction (video-color.h:132-148); read with gamma-mode = remap */
+  int32_t color_primaries;                      /* GstVideoColorPrimaries (video-color.h:197-209); read with primaries-mode != none */
+  int32_t reserved[3];
 } GstAmdVideoInfo;
 
 /* Mirror of the GstVideoConverter option keys (video-converter.h:34-286) that this
@@ -140,7 +148,10 @@ typedef struct GstAmdVideoConverterConfig {
   uint32_t dither_quantization;  /* GstVideoConverter.dither-quantization (1) */
   int32_t chroma_resampler_method; /* GstVideoConverter.chroma-resampler-method (LINEAR): chroma planes of the plane scaler */
   int32_t dither_method;         /* GstVideoConverter.dither-method (BAYER); only matters with dither-quantization > 1 on this path */
-  int32_t reserved[6];
+  int32_t gamma_mode;            /* GstVideoConverter.gamma-mode: GSTAMD_GAMMA_MODE_NONE (default) / _REMAP */
+  int32_t primaries_mode;        /* GstVideoConverter.primaries-mode: GSTAMD_PRIMARIES_MODE_NONE (default) / _MERGE_ONLY / _FAST */
+  int32_t internal_flags;        /* 0 for callers; the library's own sub-conversions of the gamma chain set bit 0 (generic chain only) */
+  int32_t reserved[3];
   /* source crop and destination rectangle (GstVideoConverter.src-x/-y/-width/-height, dest-x/-y/-width/-height,
    * video-converter.h:64-131); width / height 0 = "to the frame's edge" (the option absent) */
   int32_t src_x, src_y, src_width, src_height;

@@ -78,7 +78,7 @@ typedef struct {
   /* properties (reference names) */
   gint method;
   guint n_threads;             /* accepted for compatibility; the GPU grid replaces the thread slices */
-  gint alpha_mode, chroma_mode, matrix_mode;
+  gint alpha_mode, chroma_mode, matrix_mode, gamma_mode, primaries_mode;
   gdouble alpha_value, envelope, sharpness, sharpen;
   guint dither_quantization;
   gint dither;                 /* dither (:329): GstVideoDitherMethod, default bayer; only matters with dither-quantization > 1 here */
@@ -113,7 +113,8 @@ typedef struct {
 } GstAmdVideoConvertScaleClass;
 
 enum { PROP_0, PROP_METHOD, PROP_ADD_BORDERS, PROP_N_THREADS, PROP_ALPHA_MODE, PROP_ALPHA_VALUE, PROP_CHROMA_MODE, PROP_MATRIX_MODE,
-  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION, PROP_DEVICE_ID, PROP_HIP_STREAMS, PROP_CONVERTER_CONFIG, PROP_DITHER };
+  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION, PROP_DEVICE_ID, PROP_HIP_STREAMS, PROP_CONVERTER_CONFIG, PROP_DITHER,
+  PROP_GAMMA_MODE, PROP_PRIMARIES_MODE };
 
 G_DEFINE_TYPE (GstAmdVideoConvertScale, gst_amd_vcs, GST_TYPE_BASE_TRANSFORM);
 #define AMD_VCS(o) ((GstAmdVideoConvertScale *) (o))
@@ -133,6 +134,8 @@ amd_vcs_set_property (GObject * object, guint id, const GValue * value, GParamSp
     case PROP_ALPHA_VALUE: s->alpha_value = g_value_get_double (value); break;
     case PROP_CHROMA_MODE: s->chroma_mode = g_value_get_enum (value); break;
     case PROP_MATRIX_MODE: s->matrix_mode = g_value_get_enum (value); break;
+    case PROP_GAMMA_MODE: s->gamma_mode = g_value_get_enum (value); break;
+    case PROP_PRIMARIES_MODE: s->primaries_mode = g_value_get_enum (value); break;
     case PROP_ENVELOPE: s->envelope = g_value_get_double (value); break;
     case PROP_SHARPNESS: s->sharpness = g_value_get_double (value); break;
     case PROP_SHARPEN: s->sharpen = g_value_get_double (value); break;
@@ -168,6 +171,8 @@ amd_vcs_get_property (GObject * object, guint id, GValue * value, GParamSpec * p
     case PROP_ALPHA_VALUE: g_value_set_double (value, s->alpha_value); break;
     case PROP_CHROMA_MODE: g_value_set_enum (value, s->chroma_mode); break;
     case PROP_MATRIX_MODE: g_value_set_enum (value, s->matrix_mode); break;
+    case PROP_GAMMA_MODE: g_value_set_enum (value, s->gamma_mode); break;
+    case PROP_PRIMARIES_MODE: g_value_set_enum (value, s->primaries_mode); break;
     case PROP_ENVELOPE: g_value_set_double (value, s->envelope); break;
     case PROP_SHARPNESS: g_value_set_double (value, s->sharpness); break;
     case PROP_SHARPEN: g_value_set_double (value, s->sharpen); break;
@@ -244,6 +249,8 @@ amd_cfg_from_structure (const GstStructure * st, GstAmdVideoConverterConfig * cf
   OPT_I ("GstVideoConverter.alpha-mode", alpha_mode);
   OPT_I ("GstVideoConverter.chroma-mode", chroma_mode);
   OPT_I ("GstVideoConverter.matrix-mode", matrix_mode);
+  OPT_I ("GstVideoConverter.gamma-mode", gamma_mode);
+  OPT_I ("GstVideoConverter.primaries-mode", primaries_mode);
   OPT_I ("GstVideoResampler.max-taps", max_taps);
   OPT_D ("GstVideoResampler.cubic-b", cubic_b);
   OPT_D ("GstVideoResampler.cubic-c", cubic_c);
@@ -733,6 +740,9 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
   ai->color_range = vi->colorimetry.range;
   ai->color_matrix = vi->colorimetry.matrix;
   ai->chroma_site = vi->chroma_site;
+  /* GstVideoTransferFunction / GstVideoColorPrimaries as they are (the enums only ever grew at the end) */
+  ai->color_transfer = vi->colorimetry.transfer;
+  ai->color_primaries = vi->colorimetry.primaries;
   return TRUE;
 }
 
@@ -819,6 +829,8 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   cfg.alpha_value = s->alpha_value;
   cfg.chroma_mode = s->chroma_mode;
   cfg.matrix_mode = s->matrix_mode;
+  cfg.gamma_mode = s->gamma_mode;
+  cfg.primaries_mode = s->primaries_mode;
   cfg.dither_quantization = s->dither_quantization;
   cfg.dither_method = s->dither;
 
@@ -1253,6 +1265,11 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
     {2, "downsample-only", "downsample-only"}, {3, "none", "none"}, {0, NULL, NULL}};
   static const GEnumValue matrix_v[] = {{0, "full", "full"}, {1, "input-only", "input-only"},
     {2, "output-only", "output-only"}, {3, "none", "none"}, {0, NULL, NULL}};
+  /* GstVideoGammaMode / GstVideoPrimariesMode (video-converter.h:176-206) */
+  static const GEnumValue gamma_v[] = {{0, "disable gamma handling", "none"}, {1, "convert between input and output gamma", "remap"}, {0, NULL, NULL}};
+  static const GEnumValue primaries_v[] = {{0, "disable conversion between primaries", "none"},
+    {1, "do conversion between primaries only when it can be merged with color matrix conversion", "merge-only"},
+    {2, "fast conversion between primaries", "fast"}, {0, NULL, NULL}};
 
   GST_DEBUG_CATEGORY_INIT (amd_vcs_debug, "amdvideoconvertscale", 0, "MI355X videoconvertscale");
   GST_DEBUG_CATEGORY_GET (CAT_PERFORMANCE, "GST_PERFORMANCE");
@@ -1274,6 +1291,10 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
           "Chroma Resampling Mode", amd_enum_type ("GstAmdVideoChromaMode", chroma_v), 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_MATRIX_MODE, g_param_spec_enum ("matrix-mode", "Matrix Mode",
           "Matrix Conversion Mode", amd_enum_type ("GstAmdVideoMatrixMode", matrix_v), 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_GAMMA_MODE, g_param_spec_enum ("gamma-mode", "Gamma Mode",
+          "Gamma Conversion Mode", amd_enum_type ("GstAmdVideoGammaMode", gamma_v), 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_PRIMARIES_MODE, g_param_spec_enum ("primaries-mode", "Primaries Mode",
+          "Primaries Conversion Mode", amd_enum_type ("GstAmdVideoPrimariesMode", primaries_v), 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_ENVELOPE, g_param_spec_double ("envelope", "Envelope",
           "Size of filter envelope", 1.0, 5.0, 2.0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_SHARPNESS, g_param_spec_double ("sharpness", "Sharpness",

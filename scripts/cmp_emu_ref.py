@@ -14,8 +14,9 @@ emu.emu_video_convert.argtypes = [C.POINTER(V.VideoInfo), C.POINTER(V.VideoInfo)
 
 
 def run(ifmt, w, h, ofmt, ow, oh, cfg={}, col=None, site=None, seed=1):
+    col, ocol = cases.split_colorimetry(col)
     ii = V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site)
-    oi = V.video_info(ofmt, ow, oh)
+    oi = V.video_info(ofmt, ow, oh, colorimetry=ocol)
     src = cases.frame_bytes(ii.size, "random", seed, w)
     c = V.converter_config(**cfg)
     dst = np.zeros(oi.size, np.uint8)
@@ -25,7 +26,8 @@ def run(ifmt, w, h, ofmt, ow, oh, cfg={}, col=None, site=None, seed=1):
     if r != 0:
         print("%s: REFUSED %s" % (tag, desc.value.decode()))
         return
-    want = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site, config=cases.ref_config_string(ref, cfg)).frame(src)
+    want = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site, out_colorimetry=ocol,
+                               config=cases.ref_config_string(ref, cfg)).frame(src)
     bad = int((dst != want).sum())
     if bad:
         vb = lambda b: cases.visible_bytes(ofmt, ow, oh, list(oi.stride), list(oi.offset), b)

@@ -76,6 +76,14 @@ def visible_bytes(fmt, w, h, strides, offsets, buf):
     return np.concatenate(out)
 
 
+def split_colorimetry(col):
+    """a case's colorimetry field: None, "in" or "in>out" (gamma / primaries cases say what the destination is)"""
+    if col and ">" in col:
+        a, b = col.split(">")
+        return a or None, b or None
+    return col, None
+
+
 LIN = dict(resampler_method="linear", max_taps=2)          # what the videoconvertscale element sets by default
 LAN = dict(resampler_method="lanczos")
 NEAR = dict(resampler_method="nearest")
@@ -345,6 +353,34 @@ VIDEO_CASES = [
     ("i42010_argb_up_cubic_alpha_mult", "I420_10LE", 100, 60, "ARGB", 333, 200, dict(alpha_mode="mult", alpha_value=0.7), None, None, "random"),
     ("p010_bgra_wider_shorter_bilinear", "P010_10LE", 320, 240, "BGRA", 400, 200, LIN, None, None, "random"),
     ("p010_bgra_narrower_taller_bilinear", "P010_10LE", 320, 240, "BGRA", 200, 300, LIN, None, None, "random"),
+    # primaries-mode (video-converter.c:1735-1800: RGB_in -> XYZ -> RGB_out folded into the convert matrix); colorimetry "in>out",
+    # numeric form range:matrix:transfer:primaries where no name has the combination
+    ("prim_nv12_bgra_bt601_to_bt2020_primaries", "NV12", 322, 241, "BGRA", 322, 241, dict(primaries_mode="fast"), "bt601>1:1:7:7", None, "random"),
+    ("prim_i420_i420_bt601_to_bt2020", "I420", 64, 48, "I420", 64, 48, dict(primaries_mode="fast"), "bt601>bt2020", None, "random"),
+    ("prim_bgra_rgba_same_matrix_adobergb", "BGRA", 65, 33, "RGBA", 65, 33, dict(primaries_mode="fast"), "sRGB>1:1:7:8", None, "random"),
+    ("prim_bgra_rgba_merge_only", "BGRA", 65, 33, "RGBA", 65, 33, dict(primaries_mode="merge-only"), "sRGB>1:1:7:8", None, "random"),
+    ("prim_nv12_bgra_half_lanczos", "NV12", 640, 360, "BGRA", 320, 180, dict(primaries_mode="fast", resampler_method="lanczos"), "bt709>1:1:7:7", None, "random"),
+    ("prim_p010_bgra_bt2020_to_srgb", "P010_10LE", 64, 48, "BGRA", 64, 48, dict(primaries_mode="fast"), "bt2020-10>sRGB", None, "random"),
+    # gamma-mode = remap (video_gamma.h): decode table -> linear ARGB64 -> [scalers, primaries, alpha] -> encode table
+    ("gamma_nv12_bgra_322x241", "NV12", 322, 241, "BGRA", 322, 241, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"),
+    ("gamma_bgra_nv12_322x241", "BGRA", 322, 241, "NV12", 322, 241, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"),
+    ("gamma_i420_i420_bt601_bt709_no_chroma_resampler", "I420", 64, 48, "I420", 64, 48, dict(gamma_mode="remap"), "bt601>bt709", None, "random"),
+    ("gamma_primaries_nv12_bgra", "NV12", 322, 241, "BGRA", 322, 241, dict(gamma_mode="remap", primaries_mode="fast"), "bt709>1:1:7:7", None, "random"),
+    ("gamma_nv12_bgra_half_lanczos", "NV12", 640, 360, "BGRA", 320, 180, dict(gamma_mode="remap", resampler_method="lanczos"), "bt709>sRGB", None, "random"),
+    ("gamma_bgra_rgba_up_bilinear_same_transfer", "BGRA", 160, 90, "RGBA", 333, 200, dict(gamma_mode="remap", resampler_method="linear", max_taps=2), "sRGB>sRGB", None, "random"),
+    ("gamma_ayuv_argb_alpha_set", "AYUV", 64, 48, "ARGB", 64, 48, dict(gamma_mode="remap", alpha_mode="set", alpha_value=0.5), "bt709>sRGB", None, "random"),
+    ("gamma_ayuv_argb_alpha_mult", "AYUV", 64, 48, "ARGB", 64, 48, dict(gamma_mode="remap", alpha_mode="mult", alpha_value=0.5), "bt709>sRGB", None, "random"),
+    ("gamma_i420_yuy2_fastpath_kept", "I420", 64, 48, "YUY2", 64, 48, dict(gamma_mode="remap"), "bt601>bt601", None, "random"),
+    ("gamma_bgra_bgra_copy_kept", "BGRA", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap"), "sRGB>sRGB", None, "random"),
+    ("gamma_bgra_nv12_border", "BGRA", 200, 100, "NV12", 320, 240, dict(gamma_mode="remap", dest_x=40, dest_y=20, dest_width=200, dest_height=100, border_argb=0xff204060), "sRGB>bt709", None, "random"),
+    ("gamma_nv12_bgra_pq", "NV12", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap"), "2:6:14:7>sRGB", None, "random"),
+    ("gamma_nv12_bgra_hlg", "NV12", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap"), "2:6:15:7>sRGB", None, "random"),
+    ("gamma_nv12_rgb24_gamma28_to_gamma22", "NV12", 64, 48, "RGB", 64, 48, dict(gamma_mode="remap"), "2:4:8:3>1:1:4:1", None, "random"),
+    ("gamma_nv12_bgra_dither", "NV12", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap", dither_quantization=16), "bt709>sRGB", None, "random"),
+    ("gamma_ayuv_argb_matrix_none", "AYUV", 64, 48, "ARGB", 64, 48, dict(gamma_mode="remap", matrix_mode="none"), "bt709>sRGB", None, "random"),
+    ("gamma_nv12_i420_double_cubic", "NV12", 320, 180, "I420", 640, 360, dict(gamma_mode="remap", resampler_method="cubic"), "bt709>bt601", None, "random"),
+    ("gamma_i420_bgra_crop_shrink", "I420", 640, 480, "BGRA", 320, 100, dict(gamma_mode="remap", src_x=32, src_y=16, src_width=512, src_height=400), "bt601>sRGB", None, "random"),
+    ("gamma_nv12_bgra_1080p", "NV12", 1920, 1080, "BGRA", 1920, 1080, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd

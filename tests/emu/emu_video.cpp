@@ -22,6 +22,7 @@
 #include "../../gstreamer_amd/csrc/video_planes.h"
 #include "../../gstreamer_amd/csrc/video_encode_fast.h"
 #include "../../gstreamer_amd/csrc/video_deep.h"
+#include "../../gstreamer_amd/csrc/video_gamma.h"
 #include "../../gstreamer_amd/csrc/video_dither.h"
 
 using namespace gstamd;
@@ -627,6 +628,54 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   }
   if (desc)
     strncpy (desc, p.description.c_str (), desc_len - 1);
+  if (p.gamma.on) {
+    /* convert_gamma of capi_video.cpp: sub-conversion, the stage kernels' bodies over their grids, the u16 scalers, sub-conversion */
+    const GammaPlan &g = p.gamma;
+    const int in_w = g.mid_in.width, in_h = g.mid_in.height, out_w = g.mid_out.width, out_h = g.mid_out.height;
+    std::vector<uint8_t> mid_a ((size_t) in_w * in_h * 4), mid_b ((size_t) out_w * out_h * 4);
+    if ((r = emu_video_convert (&g.sub_in_info, &g.mid_in, &g.cfg_in, src, mid_a.data (), vec_ok, nullptr, 0)) != GSTAMD_OK)
+      return r;
+    GammaDev gd;
+    gd.to_rgb = g.to_rgb;
+    gd.to_yuv = g.to_yuv;
+    gd.prim = g.prim;
+    gd.alpha_kind = g.alpha_kind;
+    gd.alpha_value = g.alpha_value;
+    gd.dec = g.dec.data ();
+    gd.enc = g.enc.data ();
+    auto stage = [&](int mask, const uint8_t *s8, int ss, uint8_t *d8, int ds, int w, int h) {
+      for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+          gamma_stage_px (gd, mask, s8, ss, d8, ds, x, y);
+    };
+    if (p.passes.empty ()) {
+      stage (GAMMA_STAGE_DEC | GAMMA_STAGE_MID | GAMMA_STAGE_ENC, mid_a.data (), in_w * 4, mid_b.data (), out_w * 4, out_w, out_h);
+    } else {
+      std::vector<uint8_t> a ((size_t) in_w * in_h * 8), b;
+      stage (GAMMA_STAGE_DEC | (g.shrink ? 0 : GAMMA_STAGE_MID), mid_a.data (), in_w * 4, a.data (), in_w * 8, in_w, in_h);
+      Deep16Image cur = {a.data (), in_w * 8, in_w, in_h};
+      for (size_t i = 0; i < p.passes.size (); i++) {
+        ScaleDev sd;
+        memset (&sd, 0, sizeof (sd));
+        sd.kind = p.passes[i].kind;
+        sd.n_taps = p.passes[i].n_taps;
+        sd.inc = p.passes[i].inc;
+        sd.offset = p.passes[i].offset.data ();
+        sd.taps = p.passes[i].taps.data ();
+        const bool hz = p.passes[i].horizontal;
+        const int ow = hz ? p.passes[i].out_size : cur.width, oh = hz ? cur.height : p.passes[i].out_size;
+        std::vector<uint8_t> next ((size_t) ow * oh * 8);
+        for (int y = 0; y < oh; y++)
+          for (int x = 0; x < (ow + 255) / 256 * 256; x++)
+            scale16_lane (cur, sd, hz, next.data (), ow * 8, ow, oh, x, y);
+        b.swap (next);
+        a.swap (b);
+        cur.p = a.data (), cur.stride = ow * 8, cur.width = ow, cur.height = oh;
+      }
+      stage ((g.shrink ? GAMMA_STAGE_MID : 0) | GAMMA_STAGE_ENC, cur.p, cur.stride, mid_b.data (), out_w * 4, out_w, out_h);
+    }
+    return emu_video_convert (&g.mid_out, &g.sub_out_info, &g.cfg_out, mid_b.data (), dst, vec_ok, nullptr, 0);
+  }
   Planes pl;
   memset (&pl, 0, sizeof (pl));
   for (int i = 0; i < in->n_planes; i++) {

@@ -22,7 +22,8 @@ def main():
     for i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) in enumerate(cases.VIDEO_CASES):
         ii = ref.video_info(ifmt, w, h)
         src = cases.frame_bytes(ii["size"], pattern, cases.case_seed(name), w)
-        rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site,
+        col, ocol = cases.split_colorimetry(col)
+        rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site, out_colorimetry=ocol,
                                 config=cases.ref_config_string(ref, cfg))
         dst = rc.frame(src)
         out[name] = dict(sha256=cases.video_digest(name, dst), head=[int(x) for x in dst[:64]], in_sha256=cases.sha(src), size=int(dst.size))

@@ -636,3 +636,28 @@ def test_audioconvert_element_mix_matrix_property(gst_env, ref):
     exp = _ref_convert_blocks(rc, src, 4, 1024)
     rc.free()
     assert out.shape == exp.shape and (out == exp).all()
+
+
+def test_videoconvertscale_gamma_and_primaries_modes(gst_env, ref):
+    """gamma-mode=remap with a downscale, and primaries-mode=fast into bt2020 primaries, through the element (the colorimetry of the
+    caps reaches the converter: transfer function and primaries included)."""
+    env, tmp = gst_env
+    w, h, n = 640, 360, 2
+    fin, fout, fprim = tmp / "gm_in.nv12", tmp / "gm_out.bgra", tmp / "gm_prim.bgra"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=%d,height=%d,colorimetry=bt709,chroma-site=mpeg2 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale gamma-mode=remap method=lanczos "
+                "! video/x-raw,format=BGRA,width=320,height=180,colorimetry=sRGB ! filesink location=%s" % (n, w, h, fin, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    rc = ref.VideoConverter("NV12", w, h, "BGRA", 320, 180, in_colorimetry="bt709", in_chroma_site="mpeg2", out_colorimetry="sRGB",
+                            config=cases.ref_config_string(ref, dict(cases.LAN, gamma_mode="remap")))
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), (i, int((rc.frame(src[i]) != out[i]).sum()))
+    launch(env, "filesrc location=%s blocksize=%d ! video/x-raw,format=NV12,width=%d,height=%d,framerate=30/1,colorimetry=bt709,chroma-site=mpeg2 "
+                "! videoconvertscale primaries-mode=fast ! video/x-raw,format=BGRA,colorimetry=1:1:7:7 ! filesink location=%s"
+           % (fin, src.shape[1], w, h, fprim))
+    out = np.fromfile(fprim, np.uint8).reshape(n, -1)
+    rc = ref.VideoConverter("NV12", w, h, "BGRA", w, h, in_colorimetry="bt709", in_chroma_site="mpeg2", out_colorimetry="1:1:7:7",
+                            config=cases.ref_config_string(ref, dict(cases.LIN, primaries_mode="fast")))
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), (i, int((rc.frame(src[i]) != out[i]).sum()))

@@ -17,8 +17,9 @@ GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "video_golden.json
 
 def gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src, in_stride=None, in_offset=None, src_pad=0):
     import torch
+    col, ocol = cases.split_colorimetry(col)
     ii = V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site, stride=in_stride, offset=in_offset)
-    oi = V.video_info(ofmt, ow, oh)
+    oi = V.video_info(ofmt, ow, oh, colorimetry=ocol)
     conv = V.VideoConverter(ii, oi, V.converter_config(**cfg))
     d_src = torch.from_numpy(src).to(gpu)
     d_dst = torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu)

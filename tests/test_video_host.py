@@ -97,8 +97,9 @@ def test_unsupported_paths_are_refused_not_approximated(native_lib, case):
 def _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src, vec=1):
     emu_lib.emu_video_convert.argtypes = [C.POINTER(V.VideoInfo), C.POINTER(V.VideoInfo), C.POINTER(V.ConverterConfig),
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    col, ocol = cases.split_colorimetry(col)
     ii = V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site)
-    oi = V.video_info(ofmt, ow, oh)
+    oi = V.video_info(ofmt, ow, oh, colorimetry=ocol)
     c = V.converter_config(**cfg)
     dst = np.zeros(oi.size, np.uint8)
     desc = C.create_string_buffer(256)
@@ -325,7 +326,8 @@ def test_golden_vectors_are_the_references_output(ref, idx_case):
     """Pins the committed golden hashes to the reference implementation itself (oracle/_ref)."""
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     src = cases.frame_bytes(ref.video_info(ifmt, w, h)["size"], pattern, cases.case_seed(name), w)
-    rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site,
+    col, ocol = cases.split_colorimetry(col)
+    rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site, out_colorimetry=ocol,
                             config=cases.ref_config_string(ref, cfg))
     assert cases.video_digest(name, rc.frame(src)) == GOLDEN[name]["sha256"]
 

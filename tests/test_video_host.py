@@ -43,8 +43,9 @@ def test_video_info_matches_reference_layout(native_lib, ref):
             assert list(mine.stride)[:n] == r["stride"][:n], (fmt, w, h)
             assert list(mine.offset)[:n] == r["offset"][:n], (fmt, w, h)
             assert mine.size == r["size"]
-            rng, mtx = V.COLORIMETRY[r["colorimetry"]]
+            rng, mtx, trc, prim = V.COLORIMETRY[r["colorimetry"]]
             assert mine.color_range == V.COLOR_RANGE[rng] and mine.color_matrix == V.COLOR_MATRIX[mtx]
+            assert mine.color_transfer == V.TRANSFER[trc] and mine.color_primaries == V.PRIMARIES[prim], (fmt, w, h)
             assert mine.chroma_site == V.CHROMA_SITE[r["chroma_site"] or "unknown"]
 
 

@@ -250,18 +250,23 @@ GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info
   if (c->plan.gamma.on) {
     const GammaPlan &g = c->plan.gamma;
     int st = GSTAMD_OK;
-    c->sub_in = gstamd_video_converter_new (&g.sub_in_info, &g.mid_in, &g.cfg_in, &st);
-    if (c->sub_in)
-      c->sub_out = gstamd_video_converter_new (&g.mid_out, &g.sub_out_info, &g.cfg_out, &st);
-    if (!c->sub_in || !c->sub_out) {
+    bool ok = true;
+    if (!g.src16)
+      ok = (c->sub_in = gstamd_video_converter_new (&g.sub_in_info, &g.mid_in, &g.cfg_in, &st)) != nullptr;
+    if (ok && !g.pack16)
+      ok = (c->sub_out = gstamd_video_converter_new (&g.mid_out, &g.sub_out_info, &g.cfg_out, &st)) != nullptr;
+    if (!ok) {
       const std::string why = g_last_error;
       if (status)
         *status = st;
       gstamd_video_converter_free (c);
-      set_error (st, "gamma-mode = remap: " + why);
+      set_error (st, "16-bit chain: " + why);
       return nullptr;
     }
-    c->plan.description += " <- " + c->sub_in->plan.description + " -> " + c->sub_out->plan.description;
+    if (c->sub_in)
+      c->plan.description += " <- " + c->sub_in->plan.description;
+    if (c->sub_out)
+      c->plan.description += " -> " + c->sub_out->plan.description;
   }
   return c;
 }
@@ -293,18 +298,26 @@ static int build_tables (GstAmdVideoConverter *c)
   if (p.gamma.on) {
     const GammaPlan &g = p.gamma;
     const size_t in_px = (size_t) g.mid_in.width * g.mid_in.height, out_px = (size_t) g.mid_out.width * g.mid_out.height;
-    if ((e = hipMalloc ((void **) &c->gamma_dec_dev, 256 * sizeof (uint16_t))) != hipSuccess ||
-        (e = hipMemcpy (c->gamma_dec_dev, g.dec.data (), 256 * sizeof (uint16_t), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMalloc ((void **) &c->gamma_enc_dev, 65536)) != hipSuccess ||
-        (e = hipMemcpy (c->gamma_enc_dev, g.enc.data (), 65536, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMalloc ((void **) &c->gamma_mid_a, in_px * 4)) != hipSuccess || (e = hipMalloc ((void **) &c->gamma_mid_b, out_px * 4)) != hipSuccess)
-      return hip_fail (e, "gamma tables / images");
-    if (!p.passes.empty ()) {
-      const ScalePass &s0 = p.passes[0];
-      const size_t mid_px = (size_t) (s0.horizontal ? s0.out_size : g.mid_in.width) * (s0.horizontal ? g.mid_in.height : s0.out_size);
+    if (!g.dec.empty () && ((e = hipMalloc ((void **) &c->gamma_dec_dev, 256 * sizeof (uint16_t))) != hipSuccess ||
+            (e = hipMemcpy (c->gamma_dec_dev, g.dec.data (), 256 * sizeof (uint16_t), hipMemcpyHostToDevice)) != hipSuccess))
+      return hip_fail (e, "decode table");
+    if (!g.enc.empty () && ((e = hipMalloc ((void **) &c->gamma_enc_dev, 65536)) != hipSuccess ||
+            (e = hipMemcpy (c->gamma_enc_dev, g.enc.data (), 65536, hipMemcpyHostToDevice)) != hipSuccess))
+      return hip_fail (e, "encode table");
+    if (!g.src16 && (e = hipMalloc ((void **) &c->gamma_mid_a, in_px * 4)) != hipSuccess)
+      return hip_fail (e, "hipMalloc(8-bit image)");
+    if (!g.pack16 && (e = hipMalloc ((void **) &c->gamma_mid_b, out_px * 4)) != hipSuccess)
+      return hip_fail (e, "hipMalloc(8-bit image)");
+    if (!p.passes.empty () || g.pack16 || g.src16) {
+      size_t mid_px = 0;
+      if (!p.passes.empty ()) {
+        const ScalePass &s0 = p.passes[0];
+        mid_px = (size_t) (s0.horizontal ? s0.out_size : g.mid_in.width) * (s0.horizontal ? g.mid_in.height : s0.out_size);
+      }
       c->deep_a_size = std::max (in_px, out_px) * 8;
       c->deep_b_size = std::max (mid_px, out_px) * 8;
-      if ((e = hipMalloc ((void **) &c->deep_a, c->deep_a_size)) != hipSuccess || (e = hipMalloc ((void **) &c->deep_b, c->deep_b_size)) != hipSuccess)
+      if ((e = hipMalloc ((void **) &c->deep_a, c->deep_a_size)) != hipSuccess ||
+          (!p.passes.empty () && (e = hipMalloc ((void **) &c->deep_b, c->deep_b_size)) != hipSuccess))
         return hip_fail (e, "hipMalloc(16-bit scratch)");
     }
   }
@@ -426,11 +439,6 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   const VideoPlan &p = c->plan;
   const GammaPlan &g = p.gamma;
   const int in_w = g.mid_in.width, in_h = g.mid_in.height, out_w = g.mid_out.width, out_h = g.mid_out.height;
-  void *ma[GSTAMD_VIDEO_MAX_PLANES] = {c->gamma_mid_a, nullptr, nullptr, nullptr};
-  const int32_t mas[GSTAMD_VIDEO_MAX_PLANES] = {in_w * 4, 0, 0, 0};
-  int r = gstamd_video_converter_frame_planes (c->sub_in, src_planes, src_stride, ma, mas, stream);
-  if (r != GSTAMD_OK)
-    return r;
   GammaDev gd;
   gd.to_rgb = g.to_rgb;
   gd.to_yuv = g.to_yuv;
@@ -439,17 +447,51 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   gd.alpha_value = g.alpha_value;
   gd.dec = c->gamma_dec_dev;
   gd.enc = c->gamma_enc_dev;
-  hipError_t e;
+  const bool has_mid = g.prim.has_matrix || g.alpha_kind != ALPHA_NONE;
   const size_t n = p.passes.size ();
-  if (n == 0) {
-    e = launch_gamma_stage (gd, GAMMA_STAGE_DEC | GAMMA_STAGE_MID | GAMMA_STAGE_ENC, c->gamma_mid_a, in_w * 4, c->gamma_mid_b, out_w * 4, out_w, out_h, stream);
-    if (e != hipSuccess)
-      return hip_fail (e, "k_gamma_stage");
+  hipError_t e;
+  int r;
+  Deep16Image cur = {nullptr, 0, 0, 0};
+  bool mid_done = !has_mid;
+  if (g.src16) {
+    /* 10-bit source: the front of video_deep.h (unpack + chroma upsample) into an AYUV64 image */
+    Planes pl;
+    memset (&pl, 0, sizeof (pl));
+    for (int i = 0; i < p.in_info.n_planes; i++) {
+      pl.p[i] = (const uint8_t *) src_planes[i];
+      pl.stride[i] = src_stride ? src_stride[i] : p.in_info.stride[i];
+      if (!pl.p[i])
+        return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
+    }
+    if ((e = launch_front16 (p.front, pl, c->vpair_dev, c->deep_a, in_w * 8, stream)) != hipSuccess)
+      return hip_fail (e, "k_front16");
+    cur.p = c->deep_a, cur.stride = in_w * 8, cur.width = in_w, cur.height = in_h;
   } else {
-    if ((e = launch_gamma_stage (gd, GAMMA_STAGE_DEC | (g.shrink ? 0 : GAMMA_STAGE_MID), c->gamma_mid_a, in_w * 4, c->deep_a, in_w * 8, in_w, in_h, stream)) !=
-        hipSuccess)
-      return hip_fail (e, "k_gamma_stage(decode)");
-    Deep16Image cur = {c->deep_a, in_w * 8, in_w, in_h};
+    void *ma[GSTAMD_VIDEO_MAX_PLANES] = {c->gamma_mid_a, nullptr, nullptr, nullptr};
+    const int32_t mas[GSTAMD_VIDEO_MAX_PLANES] = {in_w * 4, 0, 0, 0};
+    if ((r = gstamd_video_converter_frame_planes (c->sub_in, src_planes, src_stride, ma, mas, stream)) != GSTAMD_OK)
+      return r;
+    if (n == 0 && !g.pack16) {
+      /* nothing between the tables: one launch from image to image */
+      if ((e = launch_gamma_stage (gd, GAMMA_STAGE_DEC | GAMMA_STAGE_MID | GAMMA_STAGE_ENC, c->gamma_mid_a, in_w * 4, c->gamma_mid_b, out_w * 4, out_w, out_h,
+                  stream)) != hipSuccess)
+        return hip_fail (e, "k_gamma_stage");
+      cur.p = nullptr;
+    } else {
+      const bool mid_now = !mid_done && (n == 0 || !g.shrink);
+      if ((e = launch_gamma_stage (gd, GAMMA_STAGE_DEC | (mid_now ? GAMMA_STAGE_MID : 0), c->gamma_mid_a, in_w * 4, c->deep_a, in_w * 8, in_w, in_h, stream)) !=
+          hipSuccess)
+        return hip_fail (e, "k_gamma_stage(decode)");
+      mid_done = mid_done || mid_now;
+      cur.p = c->deep_a, cur.stride = in_w * 8, cur.width = in_w, cur.height = in_h;
+    }
+  }
+  if (cur.p) {
+    if (!mid_done && (n == 0 || !g.shrink)) {           /* the convert stage before the scalers (or no scalers): in place */
+      if ((e = launch_gamma_stage (gd, GAMMA_STAGE_MID, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height, stream)) != hipSuccess)
+        return hip_fail (e, "k_gamma_stage(convert)");
+      mid_done = true;
+    }
     for (size_t i = 0; i < n; i++) {
       ScaleDev sd;
       memset (&sd, 0, sizeof (sd));
@@ -468,9 +510,25 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
         return hip_fail (e, "k_scale16");
       cur.p = dst, cur.stride = ow * 8, cur.width = ow, cur.height = oh;
     }
-    if ((e = launch_gamma_stage (gd, (g.shrink ? GAMMA_STAGE_MID : 0) | GAMMA_STAGE_ENC, cur.p, cur.stride, c->gamma_mid_b, out_w * 4, out_w, out_h, stream)) !=
-        hipSuccess)
+    if (g.pack16) {
+      if (!mid_done && (e = launch_gamma_stage (gd, GAMMA_STAGE_MID, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height, stream)) != hipSuccess)
+        return hip_fail (e, "k_gamma_stage(convert)");
+    } else if ((e = launch_gamma_stage (gd, (mid_done ? 0 : GAMMA_STAGE_MID) | GAMMA_STAGE_ENC, cur.p, cur.stride, c->gamma_mid_b, out_w * 4, out_w, out_h,
+                    stream)) != hipSuccess) {
       return hip_fail (e, "k_gamma_stage(encode)");
+    }
+  }
+  if (g.pack16) {
+    uint8_t *planes[3] = {nullptr, nullptr, nullptr};
+    int strides[3] = {0, 0, 0};
+    for (int i = 0; i < p.out_info.n_planes && i < 3; i++) {
+      planes[i] = (uint8_t *) dest_planes[i];
+      strides[i] = dest_stride ? dest_stride[i] : p.out_info.stride[i];
+      if (!planes[i])
+        return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+    }
+    e = launch_pack16 (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, planes, strides, stream);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_pack16");
   }
   const void *mb[GSTAMD_VIDEO_MAX_PLANES] = {c->gamma_mid_b, nullptr, nullptr, nullptr};
   const int32_t mbs[GSTAMD_VIDEO_MAX_PLANES] = {out_w * 4, 0, 0, 0};

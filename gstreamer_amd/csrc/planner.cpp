@@ -305,7 +305,7 @@ static void range_offsets (int range, bool yuv, int offset[3], int scale[3], int
 }
 
 static void compute_convert_matrix_depth (int in_range, int in_matrix, int out_range, int out_matrix, bool in_yuv, bool out_yuv,
-    int matrix_mode, int in_depth, double dm[4][4], const double (*start)[4] = nullptr);
+    int matrix_mode, int in_depth, double dm[4][4], const double (*start)[4] = nullptr, int out_depth = 8);
 
 void compute_convert_matrix (const VideoPlan &, int in_range, int in_matrix, int out_range,
     int out_matrix, bool in_yuv, bool out_yuv, int matrix_mode, double dm[4][4])
@@ -317,7 +317,7 @@ void compute_convert_matrix (const VideoPlan &, int in_range, int in_matrix, int
  * bits and an 8-bit output: the input side's offsets / scales are those of the 16-bit unpack format, and with in_bits > out_bits the
  * whole matrix is scaled by 1 << (in_bits - out_bits) so that it produces 16-bit values again */
 static void compute_convert_matrix_depth (int in_range, int in_matrix, int out_range, int out_matrix, bool in_yuv, bool out_yuv,
-    int matrix_mode, int in_depth, double dm[4][4], const double (*start)[4])
+    int matrix_mode, int in_depth, double dm[4][4], const double (*start)[4], int out_depth)
 {
   int offset[3], scale[3];
   double Kr = 0, Kb = 0;
@@ -326,6 +326,10 @@ static void compute_convert_matrix_depth (int in_range, int in_matrix, int out_r
    * from the left (chain_convert :1750-1822) */
   if (start)
     memcpy (dm, start, sizeof (M44));
+  if (in_depth < out_depth) {           /* :1811-1815: the widened input counts as in_bits values with a fraction */
+    const int down = 1 << (out_depth - in_depth);
+    m_scale_components (dm, 1 / (float) down, 1 / (float) down, 1 / (float) down);
+  }
   /* compute_matrix_to_RGB (video-converter.c:1372-1402) */
   range_offsets (in_range, in_yuv, offset, scale, in_depth);
   m_offset_components (dm, -offset[0], -offset[1], -offset[2]);
@@ -341,11 +345,11 @@ static void compute_convert_matrix_depth (int in_range, int in_matrix, int out_r
     if (get_Kr_Kb (mtx, &Kr, &Kb))
       m_RGB_to_YCbCr (dm, Kr, Kb);
   }
-  range_offsets (out_range, out_yuv, offset, scale);
+  range_offsets (out_range, out_yuv, offset, scale, out_depth);
   m_scale_components (dm, (float) scale[0], (float) scale[1], (float) scale[2]);
   m_offset_components (dm, offset[0], offset[1], offset[2]);
-  if (in_depth > 8) {
-    const int up = 1 << (in_depth - 8);
+  if (in_depth > out_depth) {
+    const int up = 1 << (in_depth - out_depth);
     m_scale_components (dm, (float) up, (float) up, (float) up);
   }
 }
@@ -1467,6 +1471,115 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   return GSTAMD_OK;
 }
 
+
+// A 10-bit destination (GammaPlan with pack16): called at the end of plan_core, whose front / vpair / passes / pack it keeps where they
+// apply (10-bit source) and replaces by a sub-conversion into the 8-bit unpack format where they do not (8-bit source).
+static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, VideoPlan *plan, bool same_matrix, bool same_primaries, M44 prim_dm,
+    int in_matrix, int out_matrix, int alpha_bits, std::string *error)
+{
+  const GstAmdVideoConverterConfig &cfg = plan->config;
+  const FormatDesc *fi = plan->fin, *fo = plan->fout;
+  GammaPlan &g = plan->gamma;
+  if (!kind_has_planes (fo->kind)) {
+    if (error)
+      *error = "10-bit destination layout not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  g.on = true;
+  g.pack16 = true;
+  g.src16 = fi->hi_depth != 0;
+  g.pack = plan->pack;
+  g.pack_hi_depth = fo->hi_depth;
+  const int in_w = in->width, in_h = in->height, out_w = out->width, out_h = out->height;
+  g.shrink = (long) out_w * out_h <= (long) in_w * in_h;
+  memset (&g.to_rgb, 0, sizeof (g.to_rgb));
+  memset (&g.to_yuv, 0, sizeof (g.to_yuv));
+  /* chain_convert (:1803-1838) with out_bits 16: the matrix exists when the colour matrices or the primaries differ, on 16-bit values */
+  memset (&g.prim, 0, sizeof (g.prim));
+  if (!same_matrix || !same_primaries) {
+    M44 dm;
+    compute_convert_matrix_depth (in->color_range, in_matrix, out->color_range, out_matrix, fi->yuv, fo->yuv, cfg.matrix_mode, g.src16 ? 16 : 8, dm,
+        same_primaries ? nullptr : prim_dm, 16);
+    if (!m_is_identity (dm)) {
+      m_scale_components (dm, 256.0f, 256.0f, 256.0f);
+      g.prim.has_matrix = 1;
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++)
+          g.prim.im[i][j] = (int) rint (dm[i][j]);
+    }
+  }
+  g.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
+  g.alpha_value = (unsigned) (int) (255 * cfg.alpha_value);
+  /* chain_dither (:2035-2085) on 16-bit lines: quantiser 1 << (16 - depth), or the target quantiser when that is coarser */
+  memset (&g.dither16, 0, sizeof (g.dither16));
+  if (cfg.dither_method != GSTAMD_DITHER_NONE) {
+    const int depth = 10;
+    unsigned q = 1u << (16 - depth);
+    if (cfg.dither_quantization > q)
+      q = cfg.dither_quantization;
+    int shift = 0;
+    for (unsigned v = q; v > 1; v >>= 1)
+      shift++;
+    g.dither16.on = 1;
+    g.dither16.method = cfg.dither_method;
+    g.dither16.shift[0] = 0;            /* no alpha component in the destination: quantiser 0 */
+    g.dither16.shift[1] = g.dither16.shift[2] = g.dither16.shift[3] = shift;
+  }
+  g.dec.clear ();
+  g.enc.clear ();
+  video_info_set_format (&g.mid_out, fo->yuv ? GSTAMD_VIDEO_FORMAT_AYUV : GSTAMD_VIDEO_FORMAT_ARGB, out_w, out_h);      /* dimensions only */
+  if (g.src16) {
+    video_info_set_format (&g.mid_in, GSTAMD_VIDEO_FORMAT_AYUV, in_w, in_h);        /* dimensions of the front image */
+  } else {
+    /* the 8-bit part - unpack, chroma upsampler, the scalers when the picture shrinks (chain_scale's first call sits before the
+       convert stage) - is a sub-conversion into the 8-bit unpack format */
+    const int mw = g.shrink ? out_w : in_w, mh = g.shrink ? out_h : in_h;
+    if (video_info_set_format (&g.mid_in, fi->yuv ? GSTAMD_VIDEO_FORMAT_AYUV : GSTAMD_VIDEO_FORMAT_ARGB, mw, mh) != GSTAMD_OK)
+      return GSTAMD_ERR_INVALID;
+    g.mid_in.color_range = in->color_range;
+    g.mid_in.color_matrix = in->color_matrix;
+    g.mid_in.chroma_site = in->chroma_site;
+    g.sub_in_info = plan->orig_in;
+    const int full_in_w = plan->rect.in_maxw ? plan->rect.in_maxw : in_w, full_in_h = plan->rect.in_maxh ? plan->rect.in_maxh : in_h;
+    const bool differs = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site || full_in_w != out_w || full_in_h != out_h;
+    const bool up = differs && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY;
+    g.cfg_in = cfg;
+    g.cfg_in.gamma_mode = GSTAMD_GAMMA_MODE_NONE;
+    g.cfg_in.primaries_mode = GSTAMD_PRIMARIES_MODE_NONE;
+    g.cfg_in.matrix_mode = GSTAMD_MATRIX_MODE_NONE;
+    g.cfg_in.alpha_mode = GSTAMD_ALPHA_MODE_COPY;
+    g.cfg_in.alpha_value = 1.0;
+    g.cfg_in.internal_flags = 1;
+    g.cfg_in.dither_quantization = 1;
+    g.cfg_in.chroma_mode = up ? GSTAMD_CHROMA_MODE_FULL : GSTAMD_CHROMA_MODE_NONE;
+    g.cfg_in.dest_x = g.cfg_in.dest_y = g.cfg_in.dest_width = g.cfg_in.dest_height = 0;
+    g.dec.resize (256);
+    for (int i = 0; i < 256; i++)
+      g.dec[i] = (uint16_t) (i * 257);                  /* video_orc_convert_u8_to_u16: mergebw d, s, s */
+    /* the picture grows: the u16 scalers after the convert stage */
+    plan->passes.clear ();
+    if (!g.shrink && (in_w != out_w || in_h != out_h)) {
+      const long s1 = (long) out_w * in_h, s2 = (long) in_w * out_h;
+      const bool h_first = s1 <= s2;
+      for (int step = 0; step < 2; step++) {
+        const bool horizontal = (step == 0) == h_first;
+        const int isz = horizontal ? in_w : in_h, osz = horizontal ? out_w : out_h;
+        if (isz == osz)
+          continue;
+        ScalePass pass;
+        make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, isz, osz, horizontal, &pass, false, true);
+        pass.max_span = 1 << 30;
+        plan->passes.push_back (pass);
+      }
+    }
+    plan->vpair.clear ();
+  }
+  plan->description = std::string ("deep_out[") + fi->name + "->" + fo->name + (g.src16 ? ",front16" : ",widen") + (g.prim.has_matrix ? ",matrix16" : "") +
+      (plan->passes.empty () ? "" : g.shrink ? ",scale16(first)" : ",scale16(last)") + (g.dither16.on ? ",dither" : "") + ",pack16[h" +
+      std::to_string (g.pack.down_h) + ",v" + std::to_string (g.pack.down_v) + "]]";
+  return GSTAMD_OK;
+}
+
 static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *config, VideoPlan *plan, std::string *error)
 {
@@ -1496,7 +1609,13 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * format's own (1 at 8 bits) and the method is not NONE - NONE returns before anything is set up, quantisation included.  Every
    * component the destination has (depth > 0) gets the quantiser, rounded down to a power of two (count_power). */
   memset (&plan->dither, 0, sizeof (plan->dither));
-  if (cfg.dither_quantization > 1 && cfg.dither_method != GSTAMD_DITHER_NONE) {
+  if (plan->fout->hi_depth) {
+    /* a 10-bit destination always has a dither stage unless the method is none (16-bit lines into 10-bit samples: quantiser 64):
+       finalize_deep_out */
+    if (cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
+      return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path (10-bit destinations dither by default: "
+          "choose bayer or none)");
+  } else if (cfg.dither_quantization > 1 && cfg.dither_method != GSTAMD_DITHER_NONE) {
     if (cfg.dither_method != GSTAMD_DITHER_BAYER)
       return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods (verterr, floyd-steinberg, sierra-lite: video-dither.c:75-225) carry "
           "errors from pixel to pixel and line to line; only bayer and none are implemented on the GPU path");
@@ -1550,11 +1669,13 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * the 8-bit pack format.  Built so far: the chain into a 4-byte 8-bit destination (decoder output -> display), unscaled, shrunk
    * (scaled on the 16-bit lines, then converted) or enlarged (converted, then scaled on 8-bit lines). */
   plan->deep16 = plan->fin->hi_depth != 0;
-  if (plan->fout->hi_depth)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destinations are not implemented on the GPU path");
+  plan->deep_out = plan->fout->hi_depth != 0;
+  if (plan->deep_out && (plan->rect.out_x || plan->rect.out_y || plan->rect.fill ||
+          (plan->rect.out_maxw && (plan->rect.out_maxw != out->width || plan->rect.out_maxh != out->height))))
+    return fail (GSTAMD_ERR_UNSUPPORTED, "a destination rectangle / borders inside a 10-bit frame are not implemented on the GPU path");
   if (plan->deep16) {
-    if (plan->out_planar)
-      return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit source to a planar / 3-byte destination is not implemented on the GPU path");
+    if (plan->out_planar && !plan->deep_out)
+      return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit source to an 8-bit planar / 3-byte destination is not implemented on the GPU path");
     if (plan->rect.in_x || plan->rect.in_y || plan->rect.out_x || plan->rect.out_y ||
         plan->rect.fill || (plan->rect.in_maxw && (plan->rect.in_maxw != in->width || plan->rect.in_maxh != in->height)) ||
         (plan->rect.out_maxw && (plan->rect.out_maxw != out->width || plan->rect.out_maxh != out->height)))
@@ -1673,7 +1794,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       if (isz == osz)
         continue;
       ScalePass pass;
-      make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, isz, osz, horizontal, &pass, false, plan->deep16 && !plan->matrix_before_scale);
+      make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, isz, osz, horizontal, &pass, false,
+          plan->deep16 && (!plan->matrix_before_scale || plan->deep_out));
       pass.max_span = 1 << 30;
       if (horizontal) {
         int worst = 0;
@@ -1713,7 +1835,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     if (!same_matrix || !same_primaries) {
       M44 dm;
       compute_convert_matrix_depth (in->color_range, in_matrix, out->color_range, out_matrix, plan->fin->yuv, plan->fout->yuv, cfg.matrix_mode, 16, dm,
-          same_primaries ? nullptr : prim_dm);
+          same_primaries ? nullptr : prim_dm, plan->deep_out ? 16 : 8);
       bool identity = true;
       for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++)
@@ -1858,8 +1980,9 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         plan->fast_post = false;
     }
   }
-  if (plan->deep16)
+  if (plan->deep16 || plan->deep_out)
     plan->fast_pair = plan->fast_420p = plan->fast_422 = plan->fast_enc420 = plan->fast_post = false;
+
   std::string d = plan->passes.empty () ? (plan->deep16 ? "convert16" : plan->fast_pair ? "fused_convert_pair" : plan->fast_enc420 ? "fused_encode_420" : plan->fast_422 ? "fused_convert_422" : plan->fast_420p ? "fused_convert_420p" : "fused_convert") : "scale";
   d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;
   d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : "";
@@ -1873,6 +1996,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   if (plan->out_planar)
     d += std::string ("+pack_planar[h") + std::to_string (plan->pack.down_h) + ",v" + std::to_string (plan->pack.down_v) + "]";
   plan->description = d;
+  if (plan->deep_out)
+    return finalize_deep_out (in, out, plan, same_matrix, same_primaries, prim_dm, in_matrix, out_matrix, alpha_bits, error);
   return GSTAMD_OK;
 }
 

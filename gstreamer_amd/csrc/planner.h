@@ -178,8 +178,16 @@ struct RectPlan {
 // composite: sub-conversion `in -> mid_in` (unpack + upsample into the 8-bit unpack format AYUV / ARGB, the source crop), the stages
 // of video_gamma.h and the 16-bit scalers on images in HBM, sub-conversion `mid_out -> out` (downsample, dither, pack, destination
 // rectangle and borders).
+// The same composite serves 10-bit DESTINATIONS (I420_10LE / P010_10LE, pack16): there the first stage only widens (table i * 257 =
+// video_orc_convert_u8_to_u16) or is the 16-bit front of a 10-bit source (src16), the middle stage is the convert matrix on 16-bit
+// values, and the last stage is chroma downsample + dither + pack on 16-bit lines (video_deep.h pack16_body) instead of the encode table.
 struct GammaPlan {
   bool on = false;
+  bool src16 = false;           // the source is 10-bit: k_front16 of this plan's front / vpair makes the first ARGB64 / AYUV64 image
+  bool pack16 = false;          // the destination is 10-bit: pack16_body finishes
+  PackPlanarParams pack;        // pack16: geometry and chroma downsampler of the destination
+  int pack_hi_depth;            // FormatDesc::hi_depth of the destination
+  DitherParams dither16;        // pack16: shift[] in unpack order (A, Y, U, V) on 16-bit values
   GstAmdVideoInfo sub_in_info, mid_in, mid_out, sub_out_info;
   GstAmdVideoConverterConfig cfg_in, cfg_out;
   MatrixParams to_rgb, to_yuv;  // 8-bit matrices around the tables (kind NONE: RGB on that side)
@@ -216,6 +224,7 @@ struct VideoPlan {
   bool fast_420p;             // unscaled planar 4:2:0 -> 4-byte RGB with nearest chroma (the reference's convert_I420_BGRA family): video_422_fast.h
   bool fast_422;              // unscaled packed 4:2:2 -> 4-byte RGB through the no-wrap AYUV_ARGB matrix: video_422_fast.h applies
   bool fast_post;             // scaled plans: the post stage may run fast_pixel (matrix provably wrap-free, alpha stays 0xff)
+  bool deep_out;              // 10-bit destination: the composite of GammaPlan with pack16
   bool deep16;                // 10-bit source, unscaled, 8-bit 4-byte destination: k_convert16 (video_deep.h)
   Deep16Params deep;
   DitherParams dither;

@@ -8,6 +8,7 @@
 // First version: one lane = 4 pixels of one row, per-pixel loads (correctness and coverage first, like video_planes.h).
 #pragma once
 #include "video_device.h"
+#include "video_dither.h"
 
 namespace gstamd {
 
@@ -208,6 +209,101 @@ GSTAMD_HD void scale16_final_lane (const Deep16Image &im, const ScaleDev &sd, bo
     return;
   const uint32_t px = apply_alpha (post.alpha_kind, (unsigned) post.alpha_value, deep_finish_px (d, deep_scale_px (im, sd, horizontal, x, y)));
   *(uint32_t *) (dst + (size_t) y * dstride + 4 * (size_t) x) = pack_px (post.pack_pos, px);
+}
+
+// ---- 10-bit destinations: chroma downsample + dither + pack on the final AYUV64 image -------------------------------------------------
+//   video_orc_chroma_down_v2_u16 (video-orc.orc:2769-2780), video_orc_chroma_down_h2_u16, video_chroma_down_h2_cs_u16 (video-chroma.c:740-762
+//   instantiated for guint16 :796): the arithmetic of video_pack.h on 16-bit values
+//   dither_ordered_u16_mask (video-dither.c:272-280, video_orc_dither_ordered_4u16_mask video-orc.orc:2926-2935): addusw of
+//   bayer >> (8 - shift), then andnw with the mask - on every component of every pixel, after the downsampler, before the packer
+//   pack_I420_10LE (video-format.c:3876-3916): value >> 6;  pack_P010_10LE (:5402-5450): value & 0xffc0
+struct DstPlanes16 {
+  uint8_t *p[3];
+  int stride[3];
+};
+
+GSTAMD_HD int dither16_comp (const DitherParams &d, int comp, int v, int x, int y)
+{
+  if (!d.on)
+    return v;
+  const int sh = d.shift[comp];
+  const int b = dither_bayer_value (x, y);
+  const int e = sh < 8 ? b >> (8 - sh) : b;
+  int p = v + e;
+  p = p > 65535 ? 65535 : p;                            /* addusw */
+  return p & ~((1 << sh) - 1) & 0xffff;                 /* andnw */
+}
+
+GSTAMD_HD uint16_t pack16_sample (int hi_depth, int v) { return (uint16_t) (hi_depth == 1 ? v >> 6 : v & 0xffc0); }
+
+// per-lane block as pack_planar_body: pixels x0 .. x0+3 of the lines (yb << h_sub) ..; planar and semi-planar kinds
+GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride,
+    const DstPlanes16 &d, int x0, int yb)
+{
+  const int w = pk.width, h = pk.height;
+  const int y0 = yb << pk.h_sub;
+  if (x0 >= w || y0 >= h)
+    return;
+  const int nlines = 1 << pk.h_sub;
+  for (int r = 0; r < nlines; r++) {
+    const int y = y0 + r;
+    if (y >= h)
+      break;
+    const uint2 *row = (const uint2 *) (src + (size_t) y * sstride);
+    uint16_t *dy = (uint16_t *) (d.p[0] + (size_t) y * d.stride[0]) + x0;
+    for (int i = 0; i < 4 && x0 + i < w; i++)
+      dy[i] = pack16_sample (hi_depth, dither16_comp (dt, 1, (int) (row[x0 + i].x >> 16), x0 + i, y));
+  }
+  const uint2 *ra = (const uint2 *) (src + (size_t) y0 * sstride);
+  const uint2 *rb = (const uint2 *) (src + (size_t) (y0 + 1 < h ? y0 + 1 : h - 1) * sstride);
+  int cu[6], cv[6];                                     // U, V of pixels x0-1 .. x0+4, clamped into the row
+  for (int i = 0; i < 6; i++) {
+    int x = x0 - 1 + i;
+    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+    int u = (int) (ra[x].y & 0xffffu), v = (int) (ra[x].y >> 16);
+    if (pk.down_v) {
+      u = (u + (int) (rb[x].y & 0xffffu) + 1) >> 1;     /* avguw */
+      v = (v + (int) (rb[x].y >> 16) + 1) >> 1;
+    }
+    cu[i] = u;
+    cv[i] = v;
+  }
+  const int step = 1 << pk.w_sub;
+  for (int i = 0; i < 4; i += step) {
+    const int x = x0 + i;
+    if (x >= w)
+      break;
+    int u = cu[i + 1], v = cv[i + 1];
+    if (pk.w_sub == 1) {
+      if (pk.down_h == 1) {
+        if (x + 1 < w) {
+          u = (cu[i + 1] + cu[i + 2] + 1) >> 1;
+          v = (cv[i + 1] + cv[i + 2] + 1) >> 1;
+        }
+      } else if (pk.down_h == 2 && w >= 2) {
+        if (x == 0) {
+          u = (3 * cu[i + 1] + cu[i + 2] + 2) >> 2;
+          v = (3 * cv[i + 1] + cv[i + 2] + 2) >> 2;
+        } else if (x < w - 2) {
+          u = (cu[i] + 2 * cu[i + 1] + cu[i + 2] + 2) >> 2;
+          v = (cv[i] + 2 * cv[i + 1] + cv[i + 2] + 2) >> 2;
+        } else {
+          u = (cu[i] + 3 * cu[i + 1] + 2) >> 2;
+          v = (cv[i] + 3 * cv[i + 1] + 2) >> 2;
+        }
+      }
+    }
+    const uint16_t pu = pack16_sample (hi_depth, dither16_comp (dt, 2, u, x, y0)), pv = pack16_sample (hi_depth, dither16_comp (dt, 3, v, x, y0));
+    const int k = x >> pk.w_sub;
+    if (pk.kind == UNPACK_SEMI) {
+      uint16_t *duv = (uint16_t *) (d.p[1] + (size_t) yb * d.stride[1]) + 2 * k;
+      duv[0] = pk.u_plane ? pu : pv;
+      duv[1] = pk.u_plane ? pv : pu;
+    } else {
+      ((uint16_t *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane]))[k] = pu;
+      ((uint16_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane]))[k] = pv;
+    }
+  }
 }
 
 }  // namespace gstamd

@@ -86,8 +86,8 @@ hipError_t launch_scale16 (const Deep16Image &im, const ScaleDev &sd, bool horiz
 }
 
 // gamma-mode = remap: the per-pixel stages of video_gamma.h over an image (one lane per pixel; the tables are gathers from HBM / L2)
-__global__ __launch_bounds__ (256) void k_gamma_stage (GammaDev g, int mask, const uint8_t *__restrict__ src, int sstride, uint8_t *__restrict__ dst, int dstride,
-    int w, int h)
+// (src and dst may be the same 16-bit image: a stage that only has the middle part runs in place)
+__global__ __launch_bounds__ (256) void k_gamma_stage (GammaDev g, int mask, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int w, int h)
 {
   const int x = (int) (blockIdx.x * blockDim.x + threadIdx.x), y = (int) blockIdx.y;
   if (x < w && y < h)
@@ -98,6 +98,26 @@ hipError_t launch_gamma_stage (const GammaDev &g, int mask, const uint8_t *src, 
 {
   dim3 grid ((w + 255) / 256, h);
   hipLaunchKernelGGL (k_gamma_stage, grid, dim3 (256), 0, stream, g, mask, src, sstride, dst, dstride, w, h);
+  return hipGetLastError ();
+}
+
+// 10-bit destinations: chroma downsample + dither + pack of the final AYUV64 image (video_deep.h pack16_body), one lane per 4-pixel block
+__global__ __launch_bounds__ (256) void k_pack16 (PackPlanarParams pk, int hi_depth, DitherParams dt, const uint8_t *__restrict__ src, int sstride, DstPlanes16 d)
+{
+  pack16_body (pk, hi_depth, dt, src, sstride, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
+}
+
+hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *src, int sstride, uint8_t *const planes[3],
+    const int strides[3], hipStream_t stream)
+{
+  DstPlanes16 d;
+  for (int i = 0; i < 3; i++) {
+    d.p[i] = planes[i];
+    d.stride[i] = strides[i];
+  }
+  const int rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
+  dim3 grid ((pk.width / 4 + 256) / 256, rows);
+  hipLaunchKernelGGL (k_pack16, grid, dim3 (256), 0, stream, pk, hi_depth, dt, src, sstride, d);
   return hipGetLastError ();
 }
 

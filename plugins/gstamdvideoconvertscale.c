@@ -32,9 +32,10 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #define GST_CAT_DEFAULT amd_vcs_debug
 
 #define AMD_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR }"
-#define AMD_OUT_FORMATS AMD_FORMATS
-/* 10-bit sources (decoder output) run the reference's 16-bit chain (video_deep.h): unscaled, into an 8-bit 4-byte destination;
- * everything else about them makes set_caps fail (not-negotiated) */
+/* 10-bit formats run the reference's 16-bit chain (video_deep.h): as sources into 8-bit 4-byte destinations, as destinations from
+ * every source format (widen, matrix16, u16 scalers, u16 chroma downsample, dither, pack); the combinations the library has no
+ * kernel for make set_caps fail (not-negotiated) */
+#define AMD_OUT_FORMATS AMD_IN_FORMATS
 #define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE }"
 
 /* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path

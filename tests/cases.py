@@ -381,6 +381,27 @@ VIDEO_CASES = [
     ("gamma_nv12_i420_double_cubic", "NV12", 320, 180, "I420", 640, 360, dict(gamma_mode="remap", resampler_method="cubic"), "bt709>bt601", None, "random"),
     ("gamma_i420_bgra_crop_shrink", "I420", 640, 480, "BGRA", 320, 100, dict(gamma_mode="remap", src_x=32, src_y=16, src_width=512, src_height=400), "bt601>sRGB", None, "random"),
     ("gamma_nv12_bgra_1080p", "NV12", 1920, 1080, "BGRA", 1920, 1080, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"),
+    # 10-bit destinations (GammaPlan with pack16): widen / 16-bit front -> matrix16 -> u16 scalers -> u16 chroma downsample -> bayer dither
+    # (on by default: 16-bit lines into 10-bit samples) -> pack_I420_10LE / pack_P010_10LE
+    ("deepout_nv12_p010_64x48", "NV12", 64, 48, "P010_10LE", 64, 48, {}, None, None, "random"),
+    ("deepout_nv12_p010_322x241", "NV12", 322, 241, "P010_10LE", 322, 241, {}, None, None, "random"),
+    ("deepout_i420_i420_10_bt601_bt709", "I420", 64, 48, "I420_10LE", 64, 48, {}, "bt601>bt709", None, "random"),
+    ("deepout_bgra_p010_65x33", "BGRA", 65, 33, "P010_10LE", 65, 33, {}, None, None, "random"),
+    ("deepout_bgra_i420_10", "BGRA", 64, 48, "I420_10LE", 64, 48, {}, None, None, "random"),
+    ("deepout_p010_i420_10", "P010_10LE", 64, 48, "I420_10LE", 64, 48, {}, None, None, "random"),
+    ("deepout_i420_10_p010_bt2020_bt709", "I420_10LE", 64, 48, "P010_10LE", 64, 48, {}, "bt2020-10>bt709", None, "random"),
+    ("deepout_p010_p010_half_lanczos", "P010_10LE", 128, 96, "P010_10LE", 64, 48, LAN, None, None, "random"),
+    ("deepout_p010_p010_double_bilinear", "P010_10LE", 64, 48, "P010_10LE", 128, 96, LIN, None, None, "random"),
+    ("deepout_nv12_p010_half_lanczos", "NV12", 128, 96, "P010_10LE", 64, 48, LAN, None, None, "random"),
+    ("deepout_nv12_p010_grow_cubic", "NV12", 64, 48, "P010_10LE", 160, 100, {}, None, None, "random"),
+    ("deepout_nv12_p010_no_dither", "NV12", 64, 48, "P010_10LE", 64, 48, dict(dither_method="none"), None, None, "random"),
+    ("deepout_nv12_p010_quant256", "NV12", 64, 48, "P010_10LE", 64, 48, dict(dither_quantization=256), None, None, "random"),
+    ("deepout_yuy2_i420_10", "YUY2", 64, 48, "I420_10LE", 64, 48, {}, None, None, "random"),
+    ("deepout_nv12_i420_10_crop_shrink", "NV12", 640, 480, "I420_10LE", 200, 320, dict(src_x=32, src_y=16, src_width=512, src_height=400), None, None, "random"),
+    ("deepout_nv12_p010_mpeg2", "NV12", 64, 48, "P010_10LE", 64, 48, {}, None, "mpeg2", "random"),
+    ("deepout_bgra_p010_primaries", "BGRA", 64, 48, "P010_10LE", 64, 48, dict(primaries_mode="fast"), "sRGB>bt2020-10", None, "random"),
+    ("deepout_nv12_p010_1080p", "NV12", 1920, 1080, "P010_10LE", 1920, 1080, {}, None, None, "random"),
+    ("deepout_p010_i420_10_4k_to_1080p", "P010_10LE", 3840, 2160, "I420_10LE", 1920, 1080, LIN, None, None, "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd

@@ -629,12 +629,11 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   if (desc)
     strncpy (desc, p.description.c_str (), desc_len - 1);
   if (p.gamma.on) {
-    /* convert_gamma of capi_video.cpp: sub-conversion, the stage kernels' bodies over their grids, the u16 scalers, sub-conversion */
+    /* convert_gamma of capi_video.cpp: sub-conversion / 16-bit front, the stage kernels' bodies over their grids, the u16 scalers,
+       encode + sub-conversion or the 16-bit packer */
     const GammaPlan &g = p.gamma;
     const int in_w = g.mid_in.width, in_h = g.mid_in.height, out_w = g.mid_out.width, out_h = g.mid_out.height;
-    std::vector<uint8_t> mid_a ((size_t) in_w * in_h * 4), mid_b ((size_t) out_w * out_h * 4);
-    if ((r = emu_video_convert (&g.sub_in_info, &g.mid_in, &g.cfg_in, src, mid_a.data (), vec_ok, nullptr, 0)) != GSTAMD_OK)
-      return r;
+    std::vector<uint8_t> mid_a, mid_b, a, b;
     GammaDev gd;
     gd.to_rgb = g.to_rgb;
     gd.to_yuv = g.to_yuv;
@@ -648,13 +647,43 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         for (int x = 0; x < w; x++)
           gamma_stage_px (gd, mask, s8, ss, d8, ds, x, y);
     };
-    if (p.passes.empty ()) {
-      stage (GAMMA_STAGE_DEC | GAMMA_STAGE_MID | GAMMA_STAGE_ENC, mid_a.data (), in_w * 4, mid_b.data (), out_w * 4, out_w, out_h);
+    const bool has_mid = g.prim.has_matrix || g.alpha_kind != ALPHA_NONE;
+    const size_t n = p.passes.size ();
+    bool mid_done = !has_mid;
+    Deep16Image cur = {nullptr, 0, 0, 0};
+    if (g.src16) {
+      Planes pl;
+      memset (&pl, 0, sizeof (pl));
+      for (int i = 0; i < in->n_planes; i++) {
+        pl.p[i] = src + in->offset[i];
+        pl.stride[i] = in->stride[i];
+      }
+      a.resize ((size_t) in_w * in_h * 8);
+      for (int y = 0; y < in_h; y++)
+        for (int x0 = 0; x0 < (in_w / 4 + 256) / 256 * 1024; x0 += 4)
+          front16_lane4 (p.front, pl, p.vpair.data (), a.data (), in_w * 8, x0, y);
+      cur.p = a.data (), cur.stride = in_w * 8, cur.width = in_w, cur.height = in_h;
     } else {
-      std::vector<uint8_t> a ((size_t) in_w * in_h * 8), b;
-      stage (GAMMA_STAGE_DEC | (g.shrink ? 0 : GAMMA_STAGE_MID), mid_a.data (), in_w * 4, a.data (), in_w * 8, in_w, in_h);
-      Deep16Image cur = {a.data (), in_w * 8, in_w, in_h};
-      for (size_t i = 0; i < p.passes.size (); i++) {
+      mid_a.resize ((size_t) in_w * in_h * 4);
+      if ((r = emu_video_convert (&g.sub_in_info, &g.mid_in, &g.cfg_in, src, mid_a.data (), vec_ok, nullptr, 0)) != GSTAMD_OK)
+        return r;
+      if (n == 0 && !g.pack16) {
+        mid_b.resize ((size_t) out_w * out_h * 4);
+        stage (GAMMA_STAGE_DEC | GAMMA_STAGE_MID | GAMMA_STAGE_ENC, mid_a.data (), in_w * 4, mid_b.data (), out_w * 4, out_w, out_h);
+      } else {
+        const bool mid_now = !mid_done && (n == 0 || !g.shrink);
+        a.resize ((size_t) in_w * in_h * 8);
+        stage (GAMMA_STAGE_DEC | (mid_now ? GAMMA_STAGE_MID : 0), mid_a.data (), in_w * 4, a.data (), in_w * 8, in_w, in_h);
+        mid_done = mid_done || mid_now;
+        cur.p = a.data (), cur.stride = in_w * 8, cur.width = in_w, cur.height = in_h;
+      }
+    }
+    if (cur.p) {
+      if (!mid_done && (n == 0 || !g.shrink)) {
+        stage (GAMMA_STAGE_MID, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height);
+        mid_done = true;
+      }
+      for (size_t i = 0; i < n; i++) {
         ScaleDev sd;
         memset (&sd, 0, sizeof (sd));
         sd.kind = p.passes[i].kind;
@@ -672,7 +701,26 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         a.swap (b);
         cur.p = a.data (), cur.stride = ow * 8, cur.width = ow, cur.height = oh;
       }
-      stage ((g.shrink ? GAMMA_STAGE_MID : 0) | GAMMA_STAGE_ENC, cur.p, cur.stride, mid_b.data (), out_w * 4, out_w, out_h);
+      if (g.pack16) {
+        if (!mid_done)
+          stage (GAMMA_STAGE_MID, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height);
+      } else {
+        mid_b.resize ((size_t) out_w * out_h * 4);
+        stage ((mid_done ? 0 : GAMMA_STAGE_MID) | GAMMA_STAGE_ENC, cur.p, cur.stride, mid_b.data (), out_w * 4, out_w, out_h);
+      }
+    }
+    if (g.pack16) {
+      DstPlanes16 d;
+      memset (&d, 0, sizeof (d));
+      for (int i = 0; i < out->n_planes && i < 3; i++) {
+        d.p[i] = dst + out->offset[i];
+        d.stride[i] = out->stride[i];
+      }
+      const int rows = (g.pack.height + (1 << g.pack.h_sub) - 1) >> g.pack.h_sub;
+      for (int yb = 0; yb < rows; yb++)
+        for (int x0 = 0; x0 < (g.pack.width / 4 + 256) / 256 * 1024; x0 += 4)
+          pack16_body (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, d, x0, yb);
+      return GSTAMD_OK;
     }
     return emu_video_convert (&g.mid_out, &g.sub_out_info, &g.cfg_out, mid_b.data (), dst, vec_ok, nullptr, 0);
   }

@@ -661,3 +661,19 @@ def test_videoconvertscale_gamma_and_primaries_modes(gst_env, ref):
                             config=cases.ref_config_string(ref, dict(cases.LIN, primaries_mode="fast")))
     for i in range(n):
         assert (rc.frame(src[i]) == out[i]).all(), (i, int((rc.frame(src[i]) != out[i]).sum()))
+
+
+def test_videoconvertscale_p010_output(gst_env, ref):
+    """NV12 -> P010_10LE (the encoder-facing direction) through the element: widening, the default bayer dither of a 10-bit destination."""
+    env, tmp = gst_env
+    w, h, n = 640, 360, 2
+    fin, fout = tmp / "po_in.nv12", tmp / "po_out.p010"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=%d,height=%d,colorimetry=bt709,chroma-site=mpeg2 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale "
+                "! video/x-raw,format=P010_10LE,colorimetry=bt709,chroma-site=mpeg2 ! filesink location=%s" % (n, w, h, fin, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    rc = ref.VideoConverter("NV12", w, h, "P010_10LE", w, h, in_colorimetry="bt709", in_chroma_site="mpeg2", out_colorimetry="bt709",
+                            out_chroma_site="mpeg2", config=cases.ref_config_string(ref, cases.LIN))
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), (i, int((rc.frame(src[i]) != out[i]).sum()))

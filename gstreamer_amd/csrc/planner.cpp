@@ -1580,6 +1580,62 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   return GSTAMD_OK;
 }
 
+
+// A 10-bit source into an 8-bit planar / semi-planar / 3-byte destination: the 16-bit front and - when the picture shrinks - the u16
+// scalers of this plan, the convert stage (matrix16 of plan->deep, then video_orc_convert_u16_to_u8 = the encode stage with the table
+// v >> 8) into an 8-bit unpack-format image, and a sub-conversion for what the reference does on 8-bit lines afterwards: the scalers
+// when the picture grows, chroma downsampler, dither, pack, destination rectangle.
+static int finalize_deep_to_planar (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, VideoPlan *plan, int alpha_bits, std::string *error)
+{
+  (void) error;
+  const GstAmdVideoConverterConfig &cfg = plan->config;
+  const FormatDesc *fi = plan->fin, *fo = plan->fout;
+  GammaPlan &g = plan->gamma;
+  g.on = true;
+  g.src16 = true;
+  g.pack16 = false;
+  const int in_w = in->width, in_h = in->height, out_w = out->width, out_h = out->height;
+  g.shrink = (long) out_w * out_h <= (long) in_w * in_h;
+  memset (&g.to_rgb, 0, sizeof (g.to_rgb));
+  memset (&g.to_yuv, 0, sizeof (g.to_yuv));
+  g.prim = plan->deep;
+  g.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
+  g.alpha_value = (unsigned) (int) (255 * cfg.alpha_value);
+  /* chain_alpha comes after the convert stage, on 8-bit lines here: (a8 * alpha) / 255 and the high byte of the 16-bit form agree only
+     for set; mult is left to the sub-conversion */
+  GstAmdVideoConverterConfig sub = cfg;
+  sub.gamma_mode = GSTAMD_GAMMA_MODE_NONE;
+  sub.primaries_mode = GSTAMD_PRIMARIES_MODE_NONE;
+  sub.matrix_mode = GSTAMD_MATRIX_MODE_NONE;
+  sub.internal_flags = 1;
+  sub.src_x = sub.src_y = sub.src_width = sub.src_height = 0;
+  g.alpha_kind = ALPHA_NONE;                            /* the destination has no alpha channel (planar / 3-byte formats) */
+  const int full_in_w = plan->rect.in_maxw ? plan->rect.in_maxw : in_w, full_in_h = plan->rect.in_maxh ? plan->rect.in_maxh : in_h;
+  const int full_out_w = plan->rect.out_maxw ? plan->rect.out_maxw : out_w, full_out_h = plan->rect.out_maxh ? plan->rect.out_maxh : out_h;
+  const bool differs = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site || full_in_w != full_out_w ||
+      full_in_h != full_out_h;
+  const bool down = differs && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY;
+  sub.chroma_mode = down ? GSTAMD_CHROMA_MODE_FULL : GSTAMD_CHROMA_MODE_NONE;
+  g.cfg_out = sub;
+  video_info_set_format (&g.mid_in, GSTAMD_VIDEO_FORMAT_AYUV, in_w, in_h);
+  const int mw = g.shrink ? out_w : in_w, mh = g.shrink ? out_h : in_h;
+  if (video_info_set_format (&g.mid_out, fo->yuv ? GSTAMD_VIDEO_FORMAT_AYUV : GSTAMD_VIDEO_FORMAT_ARGB, mw, mh) != GSTAMD_OK)
+    return GSTAMD_ERR_INVALID;
+  g.mid_out.color_range = out->color_range;
+  g.mid_out.color_matrix = out->color_matrix;
+  g.mid_out.chroma_site = out->chroma_site;
+  g.sub_out_info = plan->orig_out;
+  g.dec.clear ();
+  g.enc.resize (65536);
+  for (int i = 0; i < 65536; i++)
+    g.enc[i] = (uint8_t) (i >> 8);                      /* video_orc_convert_u16_to_u8 */
+  if (!g.shrink)
+    plan->passes.clear ();                              /* the 8-bit scalers of the sub-conversion */
+  plan->description = std::string ("deep_in[") + fi->name + "->" + fo->name + ",front16" + (g.prim.has_matrix ? ",matrix16" : "") +
+      (plan->passes.empty () ? "" : ",scale16(first)") + ",narrow]";
+  return GSTAMD_OK;
+}
+
 static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *config, VideoPlan *plan, std::string *error)
 {
@@ -1674,8 +1730,6 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
           (plan->rect.out_maxw && (plan->rect.out_maxw != out->width || plan->rect.out_maxh != out->height))))
     return fail (GSTAMD_ERR_UNSUPPORTED, "a destination rectangle / borders inside a 10-bit frame are not implemented on the GPU path");
   if (plan->deep16) {
-    if (plan->out_planar && !plan->deep_out)
-      return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit source to an 8-bit planar / 3-byte destination is not implemented on the GPU path");
     if (plan->rect.in_x || plan->rect.in_y || plan->rect.out_x || plan->rect.out_y ||
         plan->rect.fill || (plan->rect.in_maxw && (plan->rect.in_maxw != in->width || plan->rect.in_maxh != in->height)) ||
         (plan->rect.out_maxw && (plan->rect.out_maxw != out->width || plan->rect.out_maxh != out->height)))
@@ -1998,6 +2052,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   plan->description = d;
   if (plan->deep_out)
     return finalize_deep_out (in, out, plan, same_matrix, same_primaries, prim_dm, in_matrix, out_matrix, alpha_bits, error);
+  if (plan->deep16 && plan->out_planar)
+    return finalize_deep_to_planar (in, out, plan, alpha_bits, error);
   return GSTAMD_OK;
 }
 

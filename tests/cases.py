@@ -402,6 +402,17 @@ VIDEO_CASES = [
     ("deepout_bgra_p010_primaries", "BGRA", 64, 48, "P010_10LE", 64, 48, dict(primaries_mode="fast"), "sRGB>bt2020-10", None, "random"),
     ("deepout_nv12_p010_1080p", "NV12", 1920, 1080, "P010_10LE", 1920, 1080, {}, None, None, "random"),
     ("deepout_p010_i420_10_4k_to_1080p", "P010_10LE", 3840, 2160, "I420_10LE", 1920, 1080, LIN, None, None, "random"),
+    # 10-bit sources into 8-bit planar / semi-planar / 3-byte destinations: 16-bit front, u16 scalers when shrinking, matrix16 + narrowing, then a
+    # sub-conversion for the 8-bit tail (scalers when growing, chroma downsampler, pack)
+    ("deepin_p010_nv12_64x48", "P010_10LE", 64, 48, "NV12", 64, 48, {}, None, None, "random"),
+    ("deepin_i420_10_i420_bt2020_bt709", "I420_10LE", 66, 34, "I420", 66, 34, {}, "bt2020-10>bt709", None, "random"),
+    ("deepin_p010_nv12_half_lanczos", "P010_10LE", 128, 96, "NV12", 64, 48, LAN, None, None, "random"),
+    ("deepin_p010_nv12_grow_cubic", "P010_10LE", 64, 48, "NV12", 160, 100, {}, None, None, "random"),
+    ("deepin_p010_rgb24_odd", "P010_10LE", 65, 33, "RGB", 65, 33, {}, None, None, "random"),
+    ("deepin_i420_10_yuy2", "I420_10LE", 64, 48, "YUY2", 64, 48, {}, None, None, "random"),
+    ("deepin_p010_y444_mpeg2", "P010_10LE", 64, 48, "Y444", 64, 48, {}, None, "mpeg2", "random"),
+    ("deepin_p010_i420_half_bilinear", "P010_10LE", 640, 360, "I420", 320, 180, LIN, None, None, "random"),
+    ("deepin_p010_nv12_4k", "P010_10LE", 3840, 2160, "NV12", 3840, 2160, {}, None, None, "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd

@@ -38,6 +38,13 @@ VIDEO_CONFIGS = {
     "c5": ("NV12", 7680, 4320, "BGRA", 3840, 2160, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
            "8K->4K frames/s (videoconvertscale NV12->BGRA, bilinear) per GPU; % HBM roofline",
            "k_bilinear420_rows_frames (--batch 1: k_bilinear420_rows)"),
+    # SURVEY 8(f) rows, measured the same way (composite plans: several launches per frame, the whole frame is what is timed)
+    "f2gamma": ("NV12", 3840, 2160, "BGRA", 3840, 2160, {"gamma_mode": "remap"}, 8, 1,
+                "4K frames/s (videoconvertscale NV12->BGRA, gamma-mode=remap) per GPU; % HBM roofline", "sub-conversion + k_gamma_stage + sub-conversion"),
+    "f2p010out": ("NV12", 3840, 2160, "P010_10LE", 3840, 2160, {}, 8, 1,
+                  "4K frames/s (videoconvertscale NV12->P010_10LE) per GPU; % HBM roofline", "sub-conversion + k_gamma_stage + k_pack16"),
+    "f2p010in": ("P010_10LE", 3840, 2160, "NV12", 3840, 2160, {}, 8, 1,
+                 "4K frames/s (videoconvertscale P010_10LE->NV12) per GPU; % HBM roofline", "k_front16 + k_gamma_stage + sub-conversion"),
 }
 CONFIG_TEXT = {
     "c2": "C2: 3840x2160 NV12 (bt709 limited, chroma-site mpeg2) -> BGRA, fused unpack + chroma upsample + matrix + pack",
@@ -45,6 +52,9 @@ CONFIG_TEXT = {
     "c3": "C3: 7680x4320 I420 -> 1920x1080 RGBA, Lanczos (16 x 16 taps), horizontal then vertical like chain_scale",
     "c5": "C5 (per GPU): 7680x4320 NV12 -> 3840x2160 BGRA, bilinear (element default method); frame lists "
           "(gstamd_video_converter_frames, what the element's chain_list calls) - `--batch 1` for one launch per frame",
+    "f2gamma": "SURVEY 8(f)2: 3840x2160 NV12 bt709 -> BGRA sRGB with gamma-mode=remap (decode table, linear ARGB64, encode table)",
+    "f2p010out": "SURVEY 8(f)2: 3840x2160 NV12 -> P010_10LE (widen, ordered dither, pack)",
+    "f2p010in": "SURVEY 8(f)2: 3840x2160 P010_10LE -> NV12 (16-bit front, narrowing, pack)",
     "c4": "C4: compositor, 16 x 1920x1080 BGRA pads (xpos 640*(i%4), ypos 360*(i/4), alpha 0.25+0.05i, random pixel alpha, "
           "operator over) on a checker background -> 3840x2160 BGRA, one fused launch per output frame",
     "c4audio": "C4 audio: audioresample 48000 -> 44100 Hz, F32 stereo interleaved, Kaiser quality 4 (72 taps x 147 phases)",
@@ -360,7 +370,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5")
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | f2gamma | f2p010out | f2p010in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed sustained load before the W warmup steps: from idle an MI355X needs 20-30 ms of load "
@@ -406,7 +416,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     wl = make_workload(args)
-    steps = args.steps if args.steps is not None else {"c2": 400, "c1": 800, "c3": 150, "c5": 150, "c4": 150, "c4audio": 20, "stub": 5}[args.config]
+    steps = args.steps if args.steps is not None else {"c2": 400, "c1": 800, "c3": 150, "c5": 150, "c4": 150, "c4audio": 20, "stub": 5}.get(args.config, 50)
     warmup = args.warmup if args.warmup is not None else {"c4audio": 2, "stub": 1}.get(args.config, 20)
     wl.setup(dev, rank)
 

@@ -251,6 +251,8 @@ GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info
     const GammaPlan &g = c->plan.gamma;
     int st = GSTAMD_OK;
     bool ok = true;
+    if (g.planes_fast)
+      return c;
     if (!g.src16)
       ok = (c->sub_in = gstamd_video_converter_new (&g.sub_in_info, &g.mid_in, &g.cfg_in, &st)) != nullptr;
     if (ok && !g.pack16)
@@ -295,7 +297,7 @@ static int build_tables (GstAmdVideoConverter *c)
   VideoPlan &p = c->plan;
   if ((e = hipGetDevice (&c->device)) != hipSuccess)
     return hip_fail (e, "hipGetDevice");
-  if (p.gamma.on) {
+  if (p.gamma.on && !p.gamma.planes_fast) {
     const GammaPlan &g = p.gamma;
     const size_t in_px = (size_t) g.mid_in.width * g.mid_in.height, out_px = (size_t) g.mid_out.width * g.mid_out.height;
     if (!g.dec.empty () && ((e = hipMalloc ((void **) &c->gamma_dec_dev, 256 * sizeof (uint16_t))) != hipSuccess ||
@@ -438,6 +440,28 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
 {
   const VideoPlan &p = c->plan;
   const GammaPlan &g = p.gamma;
+  if (g.planes_fast) {
+    DeepPlanesPtrs pp;
+    memset (&pp, 0, sizeof (pp));
+    for (int i = 0; i < p.in_info.n_planes && i < 3; i++) {
+      pp.in[i] = (const uint8_t *) src_planes[i];
+      pp.in_stride[i] = src_stride ? src_stride[i] : p.in_info.stride[i];
+    }
+    for (int i = 0; i < p.out_info.n_planes && i < 3; i++) {
+      pp.out[i] = (uint8_t *) dest_planes[i];
+      pp.out_stride[i] = dest_stride ? dest_stride[i] : p.out_info.stride[i];
+      if (!pp.out[i])
+        return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+    }
+    for (int i = 0; i < p.in_info.n_planes && i < 3; i++)
+      if (!pp.in[i])
+        return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
+    pp.vec = 1;
+    for (int i = 0; i < 3; i++)
+      pp.vec = pp.vec && ((uintptr_t) pp.in[i] % 16) == 0 && (pp.in_stride[i] % 16) == 0 && ((uintptr_t) pp.out[i] % 16) == 0 && (pp.out_stride[i] % 16) == 0;
+    const hipError_t pe = launch_deep_planes (g.planes, pp, stream);
+    return pe == hipSuccess ? GSTAMD_OK : hip_fail (pe, "k_deep_planes");
+  }
   const int in_w = g.mid_in.width, in_h = g.mid_in.height, out_w = g.mid_out.width, out_h = g.mid_out.height;
   GammaDev gd;
   gd.to_rgb = g.to_rgb;

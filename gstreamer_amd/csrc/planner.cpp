@@ -1329,6 +1329,19 @@ TileGeom pass_tile_geom (const ScalePass &pass)
 }
 
 
+
+// bytes of the picture's samples in a frame of format f (SURVEY.md 8d's accounting: every plane once)
+static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
+{
+  if (f->kind == UNPACK_PACKED4)
+    return (uint64_t) w * h * 4;
+  if (f->kind == UNPACK_PACKED3)
+    return (uint64_t) w * h * 3;
+  const uint64_t cw = ((uint64_t) w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) h + (1 << f->h_sub) - 1) >> f->h_sub;
+  const uint64_t n = (uint64_t) w * h + 2 * cw * ch;
+  return f->hi_depth ? 2 * n : n;
+}
+
 // gamma-mode = remap: the composite plan of GammaPlan (planner.h).  `in` / `out` are the crop / the destination rectangle.
 static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, VideoPlan *plan, int alpha_bits, bool same_primaries, M44 prim_dm,
     std::string *error)
@@ -1464,13 +1477,43 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
       plan->passes.push_back (pass);
     }
   }
-  plan->algorithmic_bytes = (uint64_t) in_w * in_h * (fi->kind == UNPACK_PACKED4 ? 4 : fi->kind == UNPACK_PACKED3 ? 3 : 2) +
-      (uint64_t) out_w * out_h * (fo->kind == UNPACK_PACKED4 ? 4 : fo->kind == UNPACK_PACKED3 ? 3 : 2);
+  plan->algorithmic_bytes = picture_bytes (fi, in_w, in_h) + picture_bytes (fo, out_w, out_h);
   plan->description = std::string ("gamma_remap[") + fi->name + "->" + fo->name + (g.to_rgb.kind ? ",to_rgb" : "") + (g.prim.has_matrix ? ",primaries" : "") +
       (g.to_yuv.kind ? ",to_yuv" : "") + (plan->passes.empty () ? "" : g.shrink ? ",scale16(first)" : ",scale16(last)") + "]";
   return GSTAMD_OK;
 }
 
+
+
+// GammaPlan::planes_fast: the chain degenerates to per-sample work when both formats are planar / semi-planar YUV on the same chroma
+// grid, the size stays, no chroma resampler exists, no matrix, no crop
+static void deep_planes_try (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, VideoPlan *plan, bool resampler)
+{
+  GammaPlan &g = plan->gamma;
+  const FormatDesc *fi = plan->fin, *fo = plan->fout;
+  g.planes_fast = false;
+  if (!fi->yuv || !fo->yuv || !kind_has_planes (fi->kind) || !kind_has_planes (fo->kind) || fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub ||
+      in->width != out->width || in->height != out->height || resampler || g.prim.has_matrix || g.alpha_kind != ALPHA_NONE || plan->rect.in_x ||
+      plan->rect.in_y || (plan->rect.in_maxw && (plan->rect.in_maxw != in->width || plan->rect.in_maxh != in->height)))
+    return;
+  DeepPlanesParams &d = g.planes;
+  memset (&d, 0, sizeof (d));
+  d.width = in->width;
+  d.height = in->height;
+  d.w_sub = fi->w_sub;
+  d.h_sub = fi->h_sub;
+  d.in_kind = fi->kind;
+  d.out_kind = fo->kind;
+  d.in_hi = fi->hi_depth;
+  d.out_hi = fo->hi_depth;
+  d.in_u = fi->u_plane;
+  d.in_v = fi->v_plane;
+  d.out_u = fo->u_plane;
+  d.out_v = fo->v_plane;
+  if (fo->hi_depth)
+    d.dither = g.dither16;
+  g.planes_fast = true;
+}
 
 // A 10-bit destination (GammaPlan with pack16): called at the end of plan_core, whose front / vpair / passes / pack it keeps where they
 // apply (10-bit source) and replaces by a sub-conversion into the 8-bit unpack format where they do not (8-bit source).
@@ -1574,6 +1617,12 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
     }
     plan->vpair.clear ();
   }
+  plan->algorithmic_bytes = picture_bytes (fi, in_w, in_h) + picture_bytes (fo, out_w, out_h);
+  deep_planes_try (in, out, plan, g.pack.down_h || g.pack.down_v || plan->front.chroma_h != CHROMA_H_NONE || plan->front.chroma_v2);
+  if (g.planes_fast) {
+    plan->description = std::string ("deep_planes[") + fi->name + "->" + fo->name + (g.dither16.on ? ",dither" : "") + "]";
+    return GSTAMD_OK;
+  }
   plan->description = std::string ("deep_out[") + fi->name + "->" + fo->name + (g.src16 ? ",front16" : ",widen") + (g.prim.has_matrix ? ",matrix16" : "") +
       (plan->passes.empty () ? "" : g.shrink ? ",scale16(first)" : ",scale16(last)") + (g.dither16.on ? ",dither" : "") + ",pack16[h" +
       std::to_string (g.pack.down_h) + ",v" + std::to_string (g.pack.down_v) + "]]";
@@ -1631,6 +1680,12 @@ static int finalize_deep_to_planar (const GstAmdVideoInfo *in, const GstAmdVideo
     g.enc[i] = (uint8_t) (i >> 8);                      /* video_orc_convert_u16_to_u8 */
   if (!g.shrink)
     plan->passes.clear ();                              /* the 8-bit scalers of the sub-conversion */
+  deep_planes_try (in, out, plan, down || plan->front.chroma_h != CHROMA_H_NONE || plan->front.chroma_v2);
+  if (g.planes_fast && !cfg.dest_x && !cfg.dest_y && !plan->rect.fill && !plan->dither.on) {
+    plan->description = std::string ("deep_planes[") + fi->name + "->" + fo->name + "]";
+    return GSTAMD_OK;
+  }
+  g.planes_fast = false;
   plan->description = std::string ("deep_in[") + fi->name + "->" + fo->name + ",front16" + (g.prim.has_matrix ? ",matrix16" : "") +
       (plan->passes.empty () ? "" : ",scale16(first)") + ",narrow]";
   return GSTAMD_OK;

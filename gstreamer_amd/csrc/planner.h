@@ -81,6 +81,16 @@ struct DitherParams {
   int shift[4];         // per BYTE of the packed pixel: log2 of the quantiser of the component stored there (0: untouched)
 };
 
+// plane-to-plane form of the 16-bit chain when nothing mixes samples (video_deep.h deep_planes_body)
+struct DeepPlanesParams {
+  int width, height;
+  int w_sub, h_sub;
+  int in_kind, out_kind;        // UNPACK_PLANAR / UNPACK_SEMI
+  int in_hi, out_hi;            // FormatDesc::hi_depth of the two formats
+  int in_u, in_v, out_u, out_v; // planar: plane index of U and V; semi: u_first (1) / v_first (0) in *_u
+  DitherParams dither;          // 16-bit dither of a 10-bit destination (shift[1..3] = Y, U, V)
+};
+
 struct Deep16Params {
   int has_matrix;       // 0: same matrix on both sides, the stage only narrows 16 -> 8 bits
   int im[3][4];         // video_converter_matrix16's integer matrix (8 fractional bits; im[k][3] the offset)
@@ -188,6 +198,9 @@ struct GammaPlan {
   PackPlanarParams pack;        // pack16: geometry and chroma downsampler of the destination
   int pack_hi_depth;            // FormatDesc::hi_depth of the destination
   DitherParams dither16;        // pack16: shift[] in unpack order (A, Y, U, V) on 16-bit values
+  bool planes_fast = false;     // same size, same chroma grid, no resampler, no matrix: every destination sample comes from ONE source
+                                // sample (widen / narrow, dither, pack) - k_deep_planes goes from the source planes to the destination planes
+  DeepPlanesParams planes;
   GstAmdVideoInfo sub_in_info, mid_in, mid_out, sub_out_info;
   GstAmdVideoConverterConfig cfg_in, cfg_out;
   MatrixParams to_rgb, to_yuv;  // 8-bit matrices around the tables (kind NONE: RGB on that side)

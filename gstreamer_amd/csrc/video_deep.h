@@ -234,6 +234,18 @@ GSTAMD_HD int dither16_comp (const DitherParams &d, int comp, int v, int x, int 
   return p & ~((1 << sh) - 1) & 0xffff;                 /* andnw */
 }
 
+// the same with the matrix value already at hand
+GSTAMD_HD int dither16_with (const DitherParams &d, int comp, int v, int b)
+{
+  if (!d.on)
+    return v;
+  const int sh = d.shift[comp];
+  const int e = sh < 8 ? b >> (8 - sh) : b;
+  int p = v + e;
+  p = p > 65535 ? 65535 : p;
+  return p & ~((1 << sh) - 1) & 0xffff;
+}
+
 GSTAMD_HD uint16_t pack16_sample (int hi_depth, int v) { return (uint16_t) (hi_depth == 1 ? v >> 6 : v & 0xffc0); }
 
 // per-lane block as pack_planar_body: pixels x0 .. x0+3 of the lines (yb << h_sub) ..; planar and semi-planar kinds
@@ -303,6 +315,161 @@ GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const Dith
       ((uint16_t *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane]))[k] = pu;
       ((uint16_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane]))[k] = pv;
     }
+  }
+}
+
+// ---- plane to plane (GammaPlan::planes_fast): every destination sample is one source sample widened to 16 bits (unpack), dithered when the
+// destination has 10 bits, packed / narrowed.  One lane = 8 consecutive samples of a luma row, or 4 chroma positions (U and V) of a chroma row.
+struct DeepPlanesPtrs {
+  const uint8_t *in[3];
+  int in_stride[3];
+  uint8_t *out[3];
+  int out_stride[3];
+  int vec;                      // every pointer and pitch is a multiple of 16: whole groups go through one vector access each
+};
+
+// N (4 or 8) consecutive samples from index idx0 of a row, widened to 16 bits (8-bit unpack into the 16-bit chain:
+// video_orc_convert_u8_to_u16; 10-bit: deep_widen)
+template <int N>
+GSTAMD_HD void deep_planes_load (int hi, const uint8_t *row, int idx0, int n, int vec, int *v)
+{
+  if (vec && n == N) {
+    if (!hi) {
+      uint32_t w[N / 4];
+      if (N == 8)
+        *(uint2 *) w = *(const uint2 *) (row + idx0);
+      else
+        w[0] = *(const uint32_t *) (row + idx0);
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        v[i] = (int) ((w[i >> 2] >> (8 * (i & 3))) & 0xffu) * 257;
+    } else {
+      uint32_t w[N / 2];
+      if (N == 8)
+        *(uint4 *) w = *(const uint4 *) (row + 2 * (size_t) idx0);
+      else
+        *(uint2 *) w = *(const uint2 *) (row + 2 * (size_t) idx0);
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        v[i] = deep_widen (hi, (int) ((w[i >> 1] >> (16 * (i & 1))) & 0xffffu));
+    }
+    return;
+  }
+  for (int i = 0; i < N; i++)
+    if (i < n)
+      v[i] = hi ? deep_widen (hi, ((const uint16_t *) row)[idx0 + i]) : (int) row[idx0 + i] * 257;
+}
+
+// N consecutive samples of component comp to index idx0 of a row; sample i sits at picture position (x0 + i * xstep, y) for the dither
+template <int N>
+GSTAMD_HD void deep_planes_store (const DeepPlanesParams &d, uint8_t *row, int idx0, int n, int vec, int comp, const int *v, int x0, int xstep, int y)
+{
+  if (d.out_hi) {
+    uint32_t w[N / 2];
+#pragma unroll
+    for (int i = 0; i < N / 2; i++)
+      w[i] = 0;
+    /* the lane's positions x0 + i * xstep stay inside one 8-column group of the matrix row (x0 is a multiple of 8 for luma rows,
+       of 4 * xstep for chroma rows with xstep 1 or 2) */
+    const uint2 brow = d.dither.on ? dither_bayer_row8 (x0 & ~7, y) : uint2{0, 0};
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int col = (x0 + i * xstep) & 7;
+      const int bv = (int) (((col & 4) ? brow.y : brow.x) >> (8 * (col & 3))) & 0xff;
+      const uint32_t o = pack16_sample (d.out_hi, dither16_with (d.dither, comp, v[i], bv));
+      w[i >> 1] |= o << (16 * (i & 1));
+    }
+    if (vec && n == N) {
+      if (N == 8)
+        *(uint4 *) (row + 2 * (size_t) idx0) = *(const uint4 *) w;
+      else
+        *(uint2 *) (row + 2 * (size_t) idx0) = *(const uint2 *) w;
+    } else {
+      for (int i = 0; i < N; i++)
+        if (i < n)
+          ((uint16_t *) row)[idx0 + i] = (uint16_t) (w[i >> 1] >> (16 * (i & 1)));
+    }
+    return;
+  }
+  uint32_t w[N / 4];
+#pragma unroll
+  for (int i = 0; i < N / 4; i++)
+    w[i] = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++)
+    w[i >> 2] |= (uint32_t) ((v[i] >> 8) & 0xff) << (8 * (i & 3));              /* video_orc_convert_u16_to_u8 */
+  if (vec && n == N) {
+    if (N == 8)
+      *(uint2 *) (row + idx0) = *(const uint2 *) w;
+    else
+      *(uint32_t *) (row + idx0) = w[0];
+  } else {
+    for (int i = 0; i < N; i++)
+      if (i < n)
+        row[idx0 + i] = (uint8_t) (w[i >> 2] >> (8 * (i & 3)));
+  }
+}
+
+// row < height: luma row `row`, 8 samples per lane; otherwise chroma row `row - height`, 4 chroma positions (U and V) per lane
+GSTAMD_HD void deep_planes_body (const DeepPlanesParams &d, const DeepPlanesPtrs &pp, int lane_x, int row)
+{
+  if (row < d.height) {
+    const int x0 = lane_x * 8;
+    if (x0 >= d.width)
+      return;
+    const int n = d.width - x0 < 8 ? d.width - x0 : 8;
+    int v[8];
+    deep_planes_load<8> (d.in_hi, pp.in[0] + (size_t) row * pp.in_stride[0], x0, n, pp.vec, v);
+    deep_planes_store<8> (d, pp.out[0] + (size_t) row * pp.out_stride[0], x0, n, pp.vec, 1, v, x0, 1, row);
+    return;
+  }
+  const int cr = row - d.height;
+  const int cw = (d.width + (1 << d.w_sub) - 1) >> d.w_sub, ch = (d.height + (1 << d.h_sub) - 1) >> d.h_sub;
+  const int k0 = lane_x * 4;
+  if (cr >= ch || k0 >= cw)
+    return;
+  const int n = cw - k0 < 4 ? cw - k0 : 4;
+  const int y = cr << d.h_sub, x0 = k0 << d.w_sub, xstep = 1 << d.w_sub;
+  int u[4], v[4];
+  if (d.in_kind == UNPACK_SEMI) {
+    int t[8];
+    deep_planes_load<8> (d.in_hi, pp.in[1] + (size_t) cr * pp.in_stride[1], 2 * k0, 2 * n, pp.vec, t);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      u[i] = d.in_u ? t[2 * i] : t[2 * i + 1];
+      v[i] = d.in_u ? t[2 * i + 1] : t[2 * i];
+    }
+  } else {
+    deep_planes_load<4> (d.in_hi, pp.in[d.in_u] + (size_t) cr * pp.in_stride[d.in_u], k0, n, pp.vec, u);
+    deep_planes_load<4> (d.in_hi, pp.in[d.in_v] + (size_t) cr * pp.in_stride[d.in_v], k0, n, pp.vec, v);
+  }
+  if (d.out_kind == UNPACK_SEMI) {
+    /* interleave after the per-component dither: U with component 2, V with component 3, both at the position of the chroma sample */
+    DeepPlanesParams du = d;
+    int t[8];
+    uint8_t *q = pp.out[1] + (size_t) cr * pp.out_stride[1];
+    if (d.out_hi) {
+      const uint2 brow = d.dither.on ? dither_bayer_row8 (x0 & ~7, y) : uint2{0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int col = (x0 + i * xstep) & 7;
+        const int bv = (int) (((col & 4) ? brow.y : brow.x) >> (8 * (col & 3))) & 0xff;
+        const int pu = dither16_with (d.dither, 2, u[i], bv), pv = dither16_with (d.dither, 3, v[i], bv);
+        t[2 * i] = d.out_u ? pu : pv;
+        t[2 * i + 1] = d.out_u ? pv : pu;
+      }
+      du.dither.on = 0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        t[2 * i] = d.out_u ? u[i] : v[i];
+        t[2 * i + 1] = d.out_u ? v[i] : u[i];
+      }
+    }
+    deep_planes_store<8> (du, q, 2 * k0, 2 * n, pp.vec, 2, t, 0, 0, 0);
+  } else {
+    deep_planes_store<4> (d, pp.out[d.out_u] + (size_t) cr * pp.out_stride[d.out_u], k0, n, pp.vec, 2, u, x0, xstep, y);
+    deep_planes_store<4> (d, pp.out[d.out_v] + (size_t) cr * pp.out_stride[d.out_v], k0, n, pp.vec, 3, v, x0, xstep, y);
   }
 }
 

@@ -101,6 +101,20 @@ hipError_t launch_gamma_stage (const GammaDev &g, int mask, const uint8_t *src, 
   return hipGetLastError ();
 }
 
+// plane to plane between 8- and 10-bit planar formats (video_deep.h deep_planes_body): grid.y = luma rows, then chroma rows
+__global__ __launch_bounds__ (256) void k_deep_planes (DeepPlanesParams d, DeepPlanesPtrs pp)
+{
+  deep_planes_body (d, pp, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+hipError_t launch_deep_planes (const DeepPlanesParams &d, const DeepPlanesPtrs &pp, hipStream_t stream)
+{
+  const int ch = (d.height + (1 << d.h_sub) - 1) >> d.h_sub;
+  dim3 grid (((d.width + 7) / 8 + 255) / 256, d.height + ch);
+  hipLaunchKernelGGL (k_deep_planes, grid, dim3 (256), 0, stream, d, pp);
+  return hipGetLastError ();
+}
+
 // 10-bit destinations: chroma downsample + dither + pack of the final AYUV64 image (video_deep.h pack16_body), one lane per 4-pixel block
 __global__ __launch_bounds__ (256) void k_pack16 (PackPlanarParams pk, int hi_depth, DitherParams dt, const uint8_t *__restrict__ src, int sstride, DstPlanes16 d)
 {

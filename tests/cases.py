@@ -413,6 +413,17 @@ VIDEO_CASES = [
     ("deepin_p010_y444_mpeg2", "P010_10LE", 64, 48, "Y444", 64, 48, {}, None, "mpeg2", "random"),
     ("deepin_p010_i420_half_bilinear", "P010_10LE", 640, 360, "I420", 320, 180, LIN, None, None, "random"),
     ("deepin_p010_nv12_4k", "P010_10LE", 3840, 2160, "NV12", 3840, 2160, {}, None, None, "random"),
+    # k_deep_planes: same size, same chroma grid, no resampler, no matrix - plane to plane (vector groups of 8 samples, scalar tails)
+    ("planes_nv12_p010_720p", "NV12", 1280, 720, "P010_10LE", 1280, 720, {}, None, None, "random"),
+    ("planes_nv12_i420_10_720p", "NV12", 1280, 720, "I420_10LE", 1280, 720, {}, None, None, "random"),
+    ("planes_i420_p010_720p", "I420", 1280, 720, "P010_10LE", 1280, 720, {}, None, None, "random"),
+    ("planes_nv21_i420_10_odd", "NV21", 642, 363, "I420_10LE", 642, 363, {}, None, None, "random"),
+    ("planes_p010_nv12_720p", "P010_10LE", 1280, 720, "NV12", 1280, 720, {}, None, None, "random"),
+    ("planes_p010_i420_720p", "P010_10LE", 1280, 720, "I420", 1280, 720, {}, None, None, "random"),
+    ("planes_i420_10_nv21_720p", "I420_10LE", 1280, 720, "NV21", 1280, 720, {}, None, None, "random"),
+    ("planes_i420_10_p010_720p", "I420_10LE", 1280, 720, "P010_10LE", 1280, 720, {}, None, None, "random"),
+    ("planes_p010_yv12_odd", "P010_10LE", 643, 361, "YV12", 643, 361, {}, None, None, "random"),
+    ("planes_nv12_p010_4k", "NV12", 3840, 2160, "P010_10LE", 3840, 2160, {}, None, None, "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd

@@ -632,6 +632,26 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     /* convert_gamma of capi_video.cpp: sub-conversion / 16-bit front, the stage kernels' bodies over their grids, the u16 scalers,
        encode + sub-conversion or the 16-bit packer */
     const GammaPlan &g = p.gamma;
+    if (g.planes_fast && getenv ("GSTAMD_NO_DEEP_PLANES") == nullptr) {        /* k_deep_planes over its grid */
+      DeepPlanesPtrs pp;
+      memset (&pp, 0, sizeof (pp));
+      for (int i = 0; i < in->n_planes && i < 3; i++) {
+        pp.in[i] = src + in->offset[i];
+        pp.in_stride[i] = in->stride[i];
+      }
+      for (int i = 0; i < out->n_planes && i < 3; i++) {
+        pp.out[i] = dst + out->offset[i];
+        pp.out_stride[i] = out->stride[i];
+      }
+      pp.vec = vec_ok ? 1 : 0;
+      for (int i = 0; i < 3; i++)
+        pp.vec = pp.vec && ((uintptr_t) pp.in[i] % 16) == 0 && (pp.in_stride[i] % 16) == 0 && ((uintptr_t) pp.out[i] % 16) == 0 && (pp.out_stride[i] % 16) == 0;
+      const int chh = (g.planes.height + (1 << g.planes.h_sub) - 1) >> g.planes.h_sub;
+      for (int row = 0; row < g.planes.height + chh; row++)
+        for (int lx = 0; lx < ((g.planes.width + 7) / 8 + 255) / 256 * 256; lx++)
+          deep_planes_body (g.planes, pp, lx, row);
+      return GSTAMD_OK;
+    }
     const int in_w = g.mid_in.width, in_h = g.mid_in.height, out_w = g.mid_out.width, out_h = g.mid_out.height;
     std::vector<uint8_t> mid_a, mid_b, a, b;
     GammaDev gd;

@@ -70,6 +70,8 @@ struct GstAmdVideoConverter {
   size_t deep_a_size = 0, deep_b_size = 0;
   /* gamma-mode = remap (GammaPlan): the two sub-conversions, the tables and the 8-bit images either side of the 16-bit part */
   GstAmdVideoConverter *sub_in = nullptr, *sub_out = nullptr;
+  bool hook_on = false;                 /* this converter is the direct conversion of a fused gamma plan: k_convert_gamma with `hook` */
+  GammaDev hook;
   uint16_t *gamma_dec_dev = nullptr;
   uint8_t *gamma_enc_dev = nullptr;
   uint8_t *gamma_mid_a = nullptr, *gamma_mid_b = nullptr;
@@ -255,7 +257,9 @@ GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info
       return c;
     if (!g.src16)
       ok = (c->sub_in = gstamd_video_converter_new (&g.sub_in_info, &g.mid_in, &g.cfg_in, &st)) != nullptr;
-    if (ok && !g.pack16)
+    if (ok && g.fused)
+      ok = c->sub_in->plan.passes.empty () && !c->sub_in->plan.out_planar && !c->sub_in->plan.plane_mode && !c->sub_in->plan.gamma.on;
+    if (ok && !g.pack16 && !g.fused)
       ok = (c->sub_out = gstamd_video_converter_new (&g.mid_out, &g.sub_out_info, &g.cfg_out, &st)) != nullptr;
     if (!ok) {
       const std::string why = g_last_error;
@@ -306,11 +310,11 @@ static int build_tables (GstAmdVideoConverter *c)
     if (!g.enc.empty () && ((e = hipMalloc ((void **) &c->gamma_enc_dev, 65536)) != hipSuccess ||
             (e = hipMemcpy (c->gamma_enc_dev, g.enc.data (), 65536, hipMemcpyHostToDevice)) != hipSuccess))
       return hip_fail (e, "encode table");
-    if (!g.src16 && (e = hipMalloc ((void **) &c->gamma_mid_a, in_px * 4)) != hipSuccess)
+    if (!g.fused && !g.src16 && (e = hipMalloc ((void **) &c->gamma_mid_a, in_px * 4)) != hipSuccess)
       return hip_fail (e, "hipMalloc(8-bit image)");
-    if (!g.pack16 && (e = hipMalloc ((void **) &c->gamma_mid_b, out_px * 4)) != hipSuccess)
+    if (!g.fused && !g.pack16 && (e = hipMalloc ((void **) &c->gamma_mid_b, out_px * 4)) != hipSuccess)
       return hip_fail (e, "hipMalloc(8-bit image)");
-    if (!p.passes.empty () || g.pack16 || g.src16) {
+    if (!g.fused && (!p.passes.empty () || g.pack16 || g.src16)) {
       size_t mid_px = 0;
       if (!p.passes.empty ()) {
         const ScalePass &s0 = p.passes[0];
@@ -471,6 +475,11 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   gd.alpha_value = g.alpha_value;
   gd.dec = c->gamma_dec_dev;
   gd.enc = c->gamma_enc_dev;
+  if (g.fused) {
+    c->sub_in->hook = gd;
+    c->sub_in->hook_on = true;
+    return gstamd_video_converter_frame_planes (c->sub_in, src_planes, src_stride, dest_planes, dest_stride, stream);
+  }
   const bool has_mid = g.prim.has_matrix || g.alpha_kind != ALPHA_NONE;
   const size_t n = p.passes.size ();
   hipError_t e;
@@ -884,6 +893,10 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     return convert_deep_scaled (c, pl, dst, dstride, stream);
   }
   if (p.passes.empty ()) {
+    if (c->hook_on) {
+      e = launch_convert_gamma (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, c->hook, stream);
+      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_gamma");
+    }
     e = launch_convert (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert");
   }

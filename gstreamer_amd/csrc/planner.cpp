@@ -1478,7 +1478,15 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     }
   }
   plan->algorithmic_bytes = picture_bytes (fi, in_w, in_h) + picture_bytes (fo, out_w, out_h);
-  plan->description = std::string ("gamma_remap[") + fi->name + "->" + fo->name + (g.to_rgb.kind ? ",to_rgb" : "") + (g.prim.has_matrix ? ",primaries" : "") +
+  g.fused = plan->passes.empty () && fo->kind == UNPACK_PACKED4;
+  if (g.fused) {
+    /* the direct conversion (crop, chroma upsampler as the real chain decides it, destination rectangle, borders, dither) minus matrix and
+       alpha, which are the gamma chain's */
+    g.cfg_in = base;
+    g.cfg_in.chroma_mode = cfg.chroma_mode;
+    g.mid_in = plan->orig_out;
+  }
+  plan->description = std::string (g.fused ? "gamma_fused[" : "gamma_remap[") + fi->name + "->" + fo->name + (g.to_rgb.kind ? ",to_rgb" : "") + (g.prim.has_matrix ? ",primaries" : "") +
       (g.to_yuv.kind ? ",to_yuv" : "") + (plan->passes.empty () ? "" : g.shrink ? ",scale16(first)" : ",scale16(last)") + "]";
   return GSTAMD_OK;
 }

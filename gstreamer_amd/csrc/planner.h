@@ -198,6 +198,8 @@ struct GammaPlan {
   PackPlanarParams pack;        // pack16: geometry and chroma downsampler of the destination
   int pack_hi_depth;            // FormatDesc::hi_depth of the destination
   DitherParams dither16;        // pack16: shift[] in unpack order (A, Y, U, V) on 16-bit values
+  bool fused = false;           // gamma remap, unscaled, 4-byte destination: ONE kernel (k_convert_gamma) - cfg_in describes the direct conversion
+                                // in -> out without a matrix, whose per-pixel step is the whole gamma chain with the tables in LDS
   bool planes_fast = false;     // same size, same chroma grid, no resampler, no matrix: every destination sample comes from ONE source
                                 // sample (widen / narrow, dither, pack) - k_deep_planes goes from the source planes to the destination planes
   DeepPlanesParams planes;

@@ -388,10 +388,15 @@ GSTAMD_HD void front_span8_any (const FrontParams &f, const Planes &pl, const in
     front_span8<CHROMA_H_NONE> (f, pl, vpair, x0, y, out);
 }
 
-template <int CH>
+// a per-pixel step between the colour stage and the packer (default: none; the fused gamma kernel passes video_gamma.h's chain)
+struct PxIdentity {
+  GSTAMD_HD uint32_t operator() (uint32_t px) const { return px; }
+};
+
+template <int CH, class PXF = PxIdentity>
 GSTAMD_HD void convert_body (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, const ColorParams &color,
     int pack0, int pack1, int pack2, int pack3, uint8_t *__restrict__ dst, int dstride, int spans_per_row, int vec_ok,
-    int span, int y)
+    int span, int y, const PXF &pxf = PXF ())
 {
   if (span >= spans_per_row)
     return;
@@ -403,7 +408,7 @@ GSTAMD_HD void convert_body (const FrontParams &f, const Planes &pl, const int *
     front_span8<CH> (f, pl, vpair, x0, y, px);
 #pragma unroll
     for (int i = 0; i < 8; i++)
-      out[i] = pack_px (pos, apply_color (color, px[i]));
+      out[i] = pack_px (pos, pxf (apply_color (color, px[i])));
     uint4 *d = (uint4 *) (drow + 4 * (size_t) x0);
     d[0] = gstamd_make_uint4 (out[0], out[1], out[2], out[3]);
     d[1] = gstamd_make_uint4 (out[4], out[5], out[6], out[7]);
@@ -412,7 +417,7 @@ GSTAMD_HD void convert_body (const FrontParams &f, const Planes &pl, const int *
   const int x1 = x0 + K1_PX < w ? x0 + K1_PX : w;
   for (int x = x0; x < x1; x++) {
     const uint32_t px = fetch_front (f, pl, vpair, x, y);
-    *(uint32_t *) (drow + 4 * (size_t) x) = pack_px (pos, apply_color (color, px));
+    *(uint32_t *) (drow + 4 * (size_t) x) = pack_px (pos, pxf (apply_color (color, px)));
   }
 }
 

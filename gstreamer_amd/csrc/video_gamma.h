@@ -60,6 +60,12 @@ GSTAMD_HD uint32_t gamma_enc_px (const GammaDev &g, uint2 px)
   return apply_matrix (g.to_yuv, p);
 }
 
+// the whole per-pixel chain as the step convert_body takes between its colour stage and its packer (k_convert_gamma)
+struct GammaChainFn {
+  GammaDev g;
+  GSTAMD_HD uint32_t operator() (uint32_t px) const { return gamma_enc_px (g, gamma_mid_px (g, gamma_dec_px (g, px))); }
+};
+
 // one pixel of a stage launch: the stages of `mask` in order; the source is an 8-bit image when the mask starts with the decode, the
 // destination an 8-bit image when it ends with the encode
 GSTAMD_HD void gamma_stage_px (const GammaDev &g, int mask, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int x, int y)

@@ -23,6 +23,7 @@
 #include "video_planes.h"
 #include "video_deep.h"
 #include "video_dither.h"
+#include "video_gamma.h"
 
 namespace gstamd {
 
@@ -32,6 +33,32 @@ __global__ __launch_bounds__ (256) void k_convert (FrontParams f, Planes pl, con
 {
   convert_body<CH> (f, pl, vpair, color, pack0, pack1, pack2, pack3, dst, dstride, spans_per_row, vec_ok,
       (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+// gamma-mode = remap, unscaled, into a 4-byte destination, in ONE kernel: k_convert's body with the gamma chain between the colour stage and
+// the packer, both tables in LDS (64 KB + 512 B: the encode table is a gather per component and pixel, which HBM / L2 serve badly - the
+// three-launch composite spends 50 us of its 109 on it at 4K).  A workgroup loads the tables once and walks `rows` rows.
+#define GSTAMD_GAMMA_LDS_BYTES (65536 + 512)
+template <int CH>
+__global__ __launch_bounds__ (512) void k_convert_gamma (FrontParams f, Planes pl, const int *__restrict__ vpair, ColorParams color,
+    int pack0, int pack1, int pack2, int pack3, uint8_t *__restrict__ dst, int dstride, int spans_per_row, int vec_ok, GammaDev g, int rows)
+{
+  extern __shared__ uint4 gamma_lds[];
+  uint8_t *enc = (uint8_t *) gamma_lds;
+  uint16_t *dec = (uint16_t *) (enc + 65536);
+  for (int i = (int) threadIdx.x; i < 4096; i += (int) blockDim.x)
+    gamma_lds[i] = ((const uint4 *) g.enc)[i];
+  if (threadIdx.x < 256)
+    dec[threadIdx.x] = g.dec[threadIdx.x];
+  __syncthreads ();
+  GammaChainFn fn;
+  fn.g = g;
+  fn.g.enc = enc;
+  fn.g.dec = dec;
+  const int span = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+  const int y0 = (int) blockIdx.y * rows, y1 = y0 + rows < f.height ? y0 + rows : f.height;
+  for (int y = y0; y < y1; y++)
+    convert_body<CH, GammaChainFn> (f, pl, vpair, color, pack0, pack1, pack2, pack3, dst, dstride, spans_per_row, vec_ok, span, y, fn);
 }
 
 // the 16-bit chain of a 10-bit source into an 8-bit 4-byte destination (video_deep.h): a lane = 4 pixels of one row
@@ -581,6 +608,47 @@ hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vp
       break;
   }
   return hipGetLastError ();
+}
+
+template <int CH>
+static hipError_t launch_convert_gamma_ch (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color, const int pack_pos[4],
+    uint8_t *dst, int dstride, int spans, int vec_ok, const GammaDev &g, hipStream_t stream)
+{
+  const void *fn = (const void *) k_convert_gamma<CH>;
+  hipError_t e = hipFuncSetAttribute (fn, hipFuncAttributeMaxDynamicSharedMemorySize, GSTAMD_GAMMA_LDS_BYTES);
+  if (e != hipSuccess)
+    return e;
+  /* two workgroups of 512 lanes per CU (LDS), every one of them resident at once: rows per workgroup from the device's CU count */
+  int n_cu = 256, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    n_cu = prop.multiProcessorCount;
+  const int gx = (spans + 511) / 512;
+  int rows = (f.height * gx + 2 * n_cu - 1) / (2 * n_cu);
+  rows = rows < 1 ? 1 : rows;
+  dim3 grid (gx, (f.height + rows - 1) / rows);
+  hipLaunchKernelGGL (k_convert_gamma<CH>, grid, dim3 (512), GSTAMD_GAMMA_LDS_BYTES, stream, f, pl, vpair_dev, color, pack_pos[0], pack_pos[1], pack_pos[2],
+      pack_pos[3], dst, dstride, spans, vec_ok, g, rows);
+  return hipGetLastError ();
+}
+
+hipError_t launch_convert_gamma (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color, const int pack_pos[4], uint8_t *dst,
+    int dstride, const GammaDev &g, hipStream_t stream)
+{
+  const int spans = (f.width + K1_PX - 1) / K1_PX;
+  int vec_ok = aligned (dst, 16) && (dstride % 16) == 0 && kind_has_planes (f.kind) && f.w_sub == 1;
+  if (vec_ok) {
+    vec_ok = aligned (pl.p[0], 8) && (pl.stride[0] % 8) == 0;
+    if (f.kind == UNPACK_SEMI)
+      vec_ok = vec_ok && aligned (pl.p[1], 8) && (pl.stride[1] % 8) == 0;
+    else
+      vec_ok = vec_ok && aligned (pl.p[1], 4) && aligned (pl.p[2], 4) && (pl.stride[1] % 4) == 0 && (pl.stride[2] % 4) == 0;
+  }
+  if (f.chroma_h == CHROMA_H_H2_CS)
+    return launch_convert_gamma_ch<CHROMA_H_H2_CS> (f, pl, vpair_dev, color, pack_pos, dst, dstride, spans, vec_ok, g, stream);
+  if (f.chroma_h == CHROMA_H_H2)
+    return launch_convert_gamma_ch<CHROMA_H_H2> (f, pl, vpair_dev, color, pack_pos, dst, dstride, spans, vec_ok, g, stream);
+  return launch_convert_gamma_ch<CHROMA_H_NONE> (f, pl, vpair_dev, color, pack_pos, dst, dstride, spans, vec_ok, g, stream);
 }
 
 // strip kernel: grid.x = 256-pixel columns, grid.y = strips of K line pairs, grid.z = frame; one wave per workgroup

@@ -611,6 +611,9 @@ static int g_fast420p_runs = 0;
 extern "C" int emu_fast420p_runs (void) { return g_fast420p_runs; }
 extern "C" int emu_fast422_runs (void) { return g_fast422_runs; }
 static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok, bool rgb24);
+static const GammaDev *g_gamma_hook = nullptr;          /* set while the direct conversion of a fused gamma plan runs (k_convert_gamma) */
+static int g_gamma_fused_runs = 0;
+extern "C" int emu_gamma_fused_runs (void) { return g_gamma_fused_runs; }
 
 extern "C" int emu_h420_runs (void) { return g_h420_runs; }
 extern "C" int emu_h420_reg_runs (void) { return g_h420_reg_runs; }
@@ -667,6 +670,12 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         for (int x = 0; x < w; x++)
           gamma_stage_px (gd, mask, s8, ss, d8, ds, x, y);
     };
+    if (g.fused && getenv ("GSTAMD_NO_GAMMA_FUSED") == nullptr) {
+      g_gamma_hook = &gd;
+      r = emu_video_convert (&g.sub_in_info, &g.mid_in, &g.cfg_in, src, dst, vec_ok, nullptr, 0);
+      g_gamma_hook = nullptr;
+      return r;
+    }
     const bool has_mid = g.prim.has_matrix || g.alpha_kind != ALPHA_NONE;
     const size_t n = p.passes.size ();
     bool mid_done = !has_mid;
@@ -1003,6 +1012,28 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
         }
       cur.p = b.data (), cur.stride = ow * 8, cur.width = ow, cur.height = oh;
     }
+    return GSTAMD_OK;
+  }
+  if (p.passes.empty () && g_gamma_hook) {                /* k_convert_gamma: the same body with the gamma chain as its per-pixel step */
+    const int spans = (p.front.width + K1_PX - 1) / K1_PX;
+    GammaChainFn fn;
+    fn.g = *g_gamma_hook;
+    g_gamma_fused_runs++;
+    for (int y = 0; y < p.front.height; y++)
+      for (int s = 0; s < spans; s++) {
+        const int *pp = p.post.pack_pos;
+        switch (p.front.chroma_h) {
+          case CHROMA_H_H2_CS:
+            convert_body<CHROMA_H_H2_CS, GammaChainFn> (p.front, pl, vpair, color, pp[0], pp[1], pp[2], pp[3], d0, dstride, spans, vec_ok, s, y, fn);
+            break;
+          case CHROMA_H_H2:
+            convert_body<CHROMA_H_H2, GammaChainFn> (p.front, pl, vpair, color, pp[0], pp[1], pp[2], pp[3], d0, dstride, spans, vec_ok, s, y, fn);
+            break;
+          default:
+            convert_body<CHROMA_H_NONE, GammaChainFn> (p.front, pl, vpair, color, pp[0], pp[1], pp[2], pp[3], d0, dstride, spans, vec_ok, s, y, fn);
+            break;
+        }
+      }
     return GSTAMD_OK;
   }
   if (p.passes.empty ()) {

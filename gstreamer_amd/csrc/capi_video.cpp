@@ -60,7 +60,7 @@ struct GstAmdVideoConverter {
   Fused420Tables fused;
   int32_t *vgroup_dev = nullptr;
   uint32_t *vtapw_dev = nullptr;
-  int fused_waves = 0, fused_rpc = 0, fused_ring = 0, fused_first = 0;
+  int fused_waves = 0, fused_rpc = 0, fused_ring = 0, fused_first = 0, fused_sched = 1;
   // k_scale420_mfma (video_scale420_mfma.h): the same with the horizontal pass on the matrix cores (64 source pixels per 16 outputs)
   bool mfma_ok = false;
   Mfma420Tables mfma;
@@ -78,8 +78,8 @@ struct GstAmdVideoConverter {
 };
 
 namespace gstamd {
-size_t fused420_lds_bytes (int ring, int nwaves);
-int fused420_blocks_per_cu (int nwaves, size_t lds);
+size_t fused420_lds_bytes (int ring, int nwaves, int sched);
+int fused420_blocks_per_cu (int nwaves, size_t lds, int sched);
 hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
     const int pack_pos[4], const PostFast &pf, hipStream_t stream);
 size_t mfma420_lds_bytes (int ring);
@@ -136,29 +136,38 @@ static bool fused_pick_geometry (GstAmdVideoConverter *c, int tiles)
   hipDeviceProp_t prop;
   if (hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     n_cu = prop.multiProcessorCount;
-  for (int nwaves = first; nwaves >= 2; nwaves /= 2) {
-    if (nwaves > 16)
-      continue;
-    const int first = getenv ("GSTAMD_FUSED_FIRST") ? std::max (1, atoi (getenv ("GSTAMD_FUSED_FIRST"))) : fused420_first_rows (c->fused, nwaves);
-    int ring = fused420_ring_groups (c->fused, out_h, nwaves, first);
-    size_t lds = fused420_lds_bytes (ring, nwaves);
-    if (lds > 160 * 1024)
-      continue;
-    const int per_cu = fused420_blocks_per_cu (nwaves, lds);
-    if (per_cu <= 0)
-      continue;
-    const int chunks = std::max (1, per_cu * n_cu / std::max (1, tiles));
-    int rpc = er && atoi (er) > 0 ? atoi (er) : (out_h + chunks - 1) / chunks;
-    rpc = std::max (rpc, nwaves);
-    ring = fused420_ring_groups (c->fused, rpc, nwaves, first);
-    if (fused420_lds_bytes (ring, nwaves) > lds)
-      continue;
-    c->fused_first = std::min (first, nwaves);
-    c->fused_waves = nwaves;
-    c->fused_rpc = rpc;
-    c->fused_ring = ring;
-    return true;
-  }
+  /* schedule 2 (one barrier per round, the longer ring; Fused420Params::sched) where its LDS fits, schedule 1 otherwise;
+     GSTAMD_FUSED_SCHED pins one for tuning sessions and tests */
+  const char *es = getenv ("GSTAMD_FUSED_SCHED");
+  for (int sched = es && atoi (es) == 1 ? 1 : 2; sched >= (es && atoi (es) == 2 ? 2 : 1); sched--)
+    for (int nwaves = first; nwaves >= 2; nwaves /= 2) {
+      if (nwaves > 16)
+        continue;
+      const int first = getenv ("GSTAMD_FUSED_FIRST") ? std::max (1, atoi (getenv ("GSTAMD_FUSED_FIRST"))) : fused420_first_rows (c->fused, nwaves);
+      auto ring_of = [&](int rows) { return sched == 2 ? fused420_ring_groups2 (c->fused, rows, nwaves, first) : fused420_ring_groups (c->fused, rows, nwaves, first); };
+      int ring = ring_of (out_h);
+      size_t lds = fused420_lds_bytes (ring, nwaves, sched);
+      if (lds > 160 * 1024)
+        continue;
+      const int per_cu = fused420_blocks_per_cu (nwaves, lds, sched);
+      if (per_cu <= 0)
+        continue;
+      const int chunks = std::max (1, per_cu * n_cu / std::max (1, tiles));
+      int rpc = er && atoi (er) > 0 ? atoi (er) : (out_h + chunks - 1) / chunks;
+      rpc = std::max (rpc, nwaves);
+      ring = ring_of (rpc);
+      if (fused420_lds_bytes (ring, nwaves, sched) > lds)
+        continue;
+      c->fused_first = std::min (first, nwaves);
+      c->fused_waves = nwaves;
+      c->fused_rpc = rpc;
+      c->fused_ring = ring;
+      c->fused_sched = sched;
+      if (getenv ("GSTAMD_FUSED_DEBUG"))
+        fprintf (stderr, "fused geometry: sched %d waves %d rows/chunk %d first %d ring %d lds %zu per_cu %d tiles %d\n", sched, nwaves, rpc, c->fused_first, ring,
+            fused420_lds_bytes (ring, nwaves, sched), per_cu, tiles);
+      return true;
+    }
   return false;
 }
 
@@ -970,6 +979,7 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     fq.rows_per_chunk = c->fused_rpc;
     fq.first_rows = c->fused_first;
     fq.ring = c->fused_ring;
+    fq.sched = c->fused_sched;
     fq.n_groups = c->fused.n_groups;
 #ifdef GSTAMD_TUNING
     /* profiling builds: GSTAMD_FUSED_TRACE=<file> dumps the per-wave stage stamps of every launch (the last one stays) */

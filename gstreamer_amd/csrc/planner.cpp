@@ -918,6 +918,26 @@ int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwave
   return worst;
 }
 
+// schedule 2 (one barrier per round): the ring holds a round's window AND the groups of the next round
+int fused420_ring_groups2 (const Fused420Tables &t, int rows_per_chunk, int nwaves, int first_rows)
+{
+  const int out_h = (int) t.vgroup.size ();
+  int worst = 0;
+  if (first_rows <= 0)
+    first_rows = nwaves;
+  for (int j0 = 0; j0 < out_h; j0 += rows_per_chunk) {
+    const int j1 = std::min (j0 + rows_per_chunk, out_h);
+    int rows = first_rows;
+    for (int jr = j0; jr < j1; jr += rows, rows = nwaves) {
+      const int jr2 = jr + rows;
+      const int jl = std::min (jr2 < j1 ? jr2 + nwaves : jr2, j1) - 1;        /* last row of the next round (or of this one) */
+      const int gh = std::min (t.vgroup[jl] + t.ngv - 1, t.n_groups - 1);
+      worst = std::max (worst, gh - t.vgroup[jr] + 1);
+    }
+  }
+  return worst;
+}
+
 int fused420_first_rows (const Fused420Tables &t, int nwaves)
 {
   const int out_h = (int) t.vgroup.size ();

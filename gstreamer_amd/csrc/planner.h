@@ -149,6 +149,7 @@ bool make_fused420_tables (const ScalePass &vpass, int height, Fused420Tables *t
 // most groups any round of any chunk needs in the ring at once (rounds of `nwaves` rows inside chunks of rows_per_chunk rows)
 int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwaves, int first_rows = 0);
 // rows for a chunk's first round: the most (<= nwaves) whose windows span no more than nwaves groups
+int fused420_ring_groups2 (const Fused420Tables &t, int rows_per_chunk, int nwaves, int first_rows);
 int fused420_first_rows (const Fused420Tables &t, int nwaves);
 
 // B operands of the matrix-core horizontal pass (video_scale420_mfma.h): for every block of 16 outputs and each of its three

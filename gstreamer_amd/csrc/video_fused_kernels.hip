@@ -90,6 +90,98 @@ __global__ __launch_bounds__ (1024) void k_scale420_fused (Fused420Params p, Dst
   }
 }
 
+#ifndef GSTAMD_FUSED2_PARITY
+#define GSTAMD_FUSED2_PARITY 1
+#endif
+// schedule 2 (Fused420Params::sched): see there.  LDS: [ring slots][12][64] words, then per wave ONE staged line of three byte planes.
+template <int NW, int CH, int SEMI, int NGV>
+__global__ __launch_bounds__ (1024) void k_scale420_fused2 (Fused420Params p, Dst dst, PostFast pf)
+{
+  extern __shared__ uint32_t lds_w[];
+  const int nwaves = (int) (blockDim.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6)), lane = (int) (threadIdx.x & 63);
+  uint32_t *ring = lds_w;
+  uint32_t *stage = lds_w + (size_t) p.ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) wave * GSTAMD_H420_LINE_WORDS;
+  const int t0 = (int) blockIdx.x * p.h.tile_w;
+  const int t1 = t0 + p.h.tile_w < p.h.out_w ? t0 + p.h.tile_w : p.h.out_w;
+  const int j0 = (int) blockIdx.y * p.rows_per_chunk;
+  const int j1 = j0 + p.rows_per_chunk < p.out_h ? j0 + p.rows_per_chunk : p.out_h;
+  int x_lo, x_hi;
+  h420r_span (p.h, p.n_taps_h, t0, t1, &x_lo, &x_hi);
+  const int xa = x_lo & ~15;
+  Fused420Lane<NW> s;
+  s.x0 = xa + 16 * lane;
+  if (s.x0 + 16 > p.h.width)
+    s.x0 = p.h.width - 16;
+  h420r_fetch_taps<NW> (p.h, xa, t0, t1, lane, s.ft);
+  int gl, g_last;
+  fused_round_groups (p, j0, j1 - 1, &gl, &g_last);
+  int g = gl + wave;
+  fused_request_group<NW, SEMI> (p.h, g < g_last ? g : g_last, s);
+  /* this wave's groups up to gh */
+  auto produce = [&](int gh) {
+    while (g <= gh) {
+      const int gn = g + nwaves < g_last ? g + nwaves : g_last;
+      uint32_t *slot = ring + (size_t) (g % p.ring) * GSTAMD_FUSED_GROUP_WORDS;
+      fused2_stage<NW, CH, SEMI, 0> (p.h, s, stage, g, gn, lane);
+      fused_wave_sync ();
+      fused2_filter<NW, 0> (s, stage, slot, lane);
+      fused_wave_sync ();
+      fused2_stage<NW, CH, SEMI, 1> (p.h, s, stage, g, gn, lane);
+      fused_wave_sync ();
+      fused2_filter<NW, 1> (s, stage, slot, lane);
+      fused_wave_sync ();
+      fused2_stage<NW, CH, SEMI, 2> (p.h, s, stage, g, gn, lane);
+      fused_wave_sync ();
+      fused2_filter<NW, 2> (s, stage, slot, lane);
+      fused_wave_sync ();
+      fused2_stage<NW, CH, SEMI, 3> (p.h, s, stage, g, gn, lane);
+      fused_wave_sync ();
+      fused2_filter<NW, 3> (s, stage, slot, lane);
+      fused_wave_sync ();
+      g += nwaves;
+    }
+  };
+  /* round m of the chunk: rows [j0 + (m ? first_rows + (m - 1) nwaves : 0), ...) */
+  const int n_rounds = j1 - j0 <= p.first_rows ? 1 : 1 + (j1 - j0 - p.first_rows + nwaves - 1) / nwaves;
+  auto round_rows = [&](int m, int *jr, int *jl) {
+    const int a = m == 0 ? j0 : j0 + p.first_rows + (m - 1) * nwaves;
+    const int e = m == 0 ? j0 + p.first_rows : a + nwaves;
+    *jr = a;
+    *jl = (e < j1 ? e : j1) - 1;
+  };
+  /* One loop for every wave, one copy of each body in it.  An even wave's interval is [row of round k, groups of round k + 1, barrier];
+     an odd wave runs its horizontal work half an interval ahead: [row of round k, barrier, groups of round k + 2] - so between two
+     barriers half of the waves are in the (vector-ALU-bound) horizontal part while the other half sit in the (LDS / memory-latency-bound)
+     vertical part.  Both kinds pass the same number of barriers; the ring holds a round's window and the next round's groups, and an
+     odd wave's groups of round k + 2 are only written after the barrier that ends every read of round k. */
+#if GSTAMD_FUSED2_PARITY
+  const bool ahead = (wave & 1) != 0;
+#else
+  const bool ahead = false;
+#endif
+  for (int k = ahead ? -2 : -1; k < n_rounds; k++) {
+    if (k >= 0) {
+      int jr, jl;
+      round_rows (k, &jr, &jl);
+      const int j = jr + wave;
+      if (j <= jl)
+        fused_vrow<NGV> (p, ring, dst, pf, j, t0, t1, lane);
+    }
+    if (ahead && k >= -1 && k < n_rounds - 1)
+      __syncthreads ();
+    const int m = k + (ahead ? 2 : 1);
+    if (m < n_rounds) {
+      int jr, jl, gl_r, gh;
+      round_rows (m, &jr, &jl);
+      fused_round_groups (p, jr, jl, &gl_r, &gh);
+      produce (gh);
+    }
+    if (!ahead && k < n_rounds - 1)
+      __syncthreads ();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_scale420_mfma (video_scale420_mfma.h): the horizontal pass on v_mfma_i32_16x16x64_i8, the vertical pass and the ring as above
 // ------------------------------------------------------------------------------------------------
@@ -270,11 +362,15 @@ template <int NW, int CH, int SEMI>
 static hipError_t launch_fused_ngv (const Fused420Params &p, const Dst &d, const PostFast &pf, int nwaves, size_t lds, dim3 grid, hipStream_t stream)
 {
 #define GO(NGV) do { \
+    const void *fn = p.sched == 2 ? (const void *) k_scale420_fused2<NW, CH, SEMI, NGV> : (const void *) k_scale420_fused<NW, CH, SEMI, NGV>; \
     if (lds > 65536) { \
-      hipError_t e = hipFuncSetAttribute ((const void *) k_scale420_fused<NW, CH, SEMI, NGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+      hipError_t e = hipFuncSetAttribute (fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
       if (e != hipSuccess) return e; \
     } \
-    hipLaunchKernelGGL ((k_scale420_fused<NW, CH, SEMI, NGV>), grid, dim3 (64 * nwaves), lds, stream, p, d, pf); \
+    if (p.sched == 2) \
+      hipLaunchKernelGGL ((k_scale420_fused2<NW, CH, SEMI, NGV>), grid, dim3 (64 * nwaves), lds, stream, p, d, pf); \
+    else \
+      hipLaunchKernelGGL ((k_scale420_fused<NW, CH, SEMI, NGV>), grid, dim3 (64 * nwaves), lds, stream, p, d, pf); \
   } while (0)
   if (p.ngv == 5)
     GO (5);
@@ -295,9 +391,9 @@ static hipError_t launch_fused_ch (const Fused420Params &p, int chroma_h, const 
   return launch_fused_ngv<NW, CHROMA_H_NONE, SEMI> (p, d, pf, nwaves, lds, grid, stream);
 }
 
-size_t fused420_lds_bytes (int ring, int nwaves)
+size_t fused420_lds_bytes (int ring, int nwaves, int sched)
 {
-  return ((size_t) ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) nwaves * 2 * GSTAMD_H420_LINE_WORDS) * 4;
+  return ((size_t) ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) nwaves * (sched == 2 ? 1 : 2) * GSTAMD_H420_LINE_WORDS) * 4;
 }
 
 // hipErrorNotSupported: the caller takes the two-pass form
@@ -309,7 +405,7 @@ hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw,
     ok = ok && aligned (p.h.c0, 16) && (p.h.cstride % 16) == 0;
   else
     ok = ok && aligned (p.h.c0, 8) && aligned (p.h.c1, 8) && (p.h.cstride % 8) == 0;
-  const size_t lds = fused420_lds_bytes (p.ring, nwaves);
+  const size_t lds = fused420_lds_bytes (p.ring, nwaves, p.sched);
   if (!ok || nw < 3 || nw > 5 || nwaves < 1 || nwaves > 16 || lds > 160 * 1024)
     return hipErrorNotSupported;
   Dst d;
@@ -329,10 +425,10 @@ hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw,
 }
 
 // workgroups of this kernel one CU holds (occupancy API on a representative instantiation), 0 on failure
-int fused420_blocks_per_cu (int nwaves, size_t lds)
+int fused420_blocks_per_cu (int nwaves, size_t lds, int sched)
 {
   int per_cu = 0;
-  const void *fn = (const void *) k_scale420_fused<5, CHROMA_H_H2_CS, 0, 5>;
+  const void *fn = sched == 2 ? (const void *) k_scale420_fused2<5, CHROMA_H_H2_CS, 0, 5> : (const void *) k_scale420_fused<5, CHROMA_H_H2_CS, 0, 5>;
   if (lds > 65536 && hipFuncSetAttribute (fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess)
     return 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, fn, 64 * nwaves, lds) != hipSuccess)

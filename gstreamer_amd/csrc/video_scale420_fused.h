@@ -34,6 +34,10 @@ struct Fused420Params {
   int first_rows;               // rows of a chunk's first round (later rounds: one row per wave): chosen so that the first round, which
                                 // also fills the ring's run-in, has one group per wave like the others (no wave waits for a second)
   int ring;                     // ring slots (groups) in LDS
+  int sched;                    // 1: two barriers per round, a staged line PAIR per wave.  2: one barrier per round - the ring also holds the
+                                // NEXT round's groups, so between two barriers a wave filters its row of round k and produces its groups of
+                                // round k + 1, odd waves in the other order (the vector ALU work of one half overlaps the LDS / memory waits
+                                // of the other); the stage area of a wave is ONE line (the LDS that pays for the longer ring)
   int n_groups;                 // line groups of the picture: (height / 2 + 2) / 2
 #ifdef GSTAMD_TUNING
   unsigned long long *trace;    // profiling builds: [workgroup][wave][32] s_memtime stamps of the kernel's stages, or NULL
@@ -137,6 +141,46 @@ GSTAMD_HD void fused_phase_d (Fused420Lane<NW> &s, const uint32_t *stage, uint32
 #pragma unroll
   for (int k = 0; k < 12; k++)
     slot[64 * k + lane] = s.gw[k] ^ 0x80808080u;
+}
+
+// ---- schedule 2: the same arithmetic line by line (one staged line per wave) ---------------------------------------------------------
+// line B of group g (B = 0 .. 3 = lines 4g-1 .. 4g+2): stage it.  B 0 / 1 are pair 2g (chroma: P older, Q fresh), 2 / 3 pair 2g+1 (Q older,
+// P fresh).  After the pair's second line its registers are free: the next pair / the next group of this wave is requested there.
+template <int NW, int CH, int SEMI, int B>
+GSTAMD_HD void fused2_stage (const H420RegParams &p, Fused420Lane<NW> &s, uint32_t *stage, int g, int g_next, int lane)
+{
+  const int pw = GSTAMD_H420_PLANE_BYTES / 4, w0 = 4 * lane;
+  if (B == 0) {
+    h420_filter_raw2<CH> (SEMI != 0, p.u_first != 0, s.pre, s.P);
+    h420_filter_raw2<CH> (SEMI != 0, p.u_first != 0, s.pr.raw, s.Q);
+    h420r_stage_luma (s.pr.la, stage + w0);
+    h420_blend_store (s.P, s.Q, stage + pw + w0, stage + 2 * pw + w0);
+  } else if (B == 1) {
+    h420r_stage_luma (s.pr.lb, stage + w0);
+    h420_blend_store (s.Q, s.P, stage + pw + w0, stage + 2 * pw + w0);
+    const int last = p.height / 2;
+    h420r_request<SEMI> (p, 2 * g + 1 < last ? 2 * g + 1 : last, s.x0, s.pr);
+  } else if (B == 2) {
+    h420_filter_raw2<CH> (SEMI != 0, p.u_first != 0, s.pr.raw, s.P);
+    h420r_stage_luma (s.pr.la, stage + w0);
+    h420_blend_store (s.Q, s.P, stage + pw + w0, stage + 2 * pw + w0);
+  } else {
+    h420r_stage_luma (s.pr.lb, stage + w0);
+    h420_blend_store (s.P, s.Q, stage + pw + w0, stage + 2 * pw + w0);
+    fused_request_group<NW, SEMI> (p, g_next, s);
+  }
+}
+
+// filter the staged line into byte B of the group words; after the fourth line the words go to the ring slot
+template <int NW, int B>
+GSTAMD_HD void fused2_filter (Fused420Lane<NW> &s, const uint32_t *stage, uint32_t *slot, int lane)
+{
+  fused_filter_line<NW, B> (stage, s.ft, s.gw);
+  if (B == 3) {
+#pragma unroll
+    for (int k = 0; k < 12; k++)
+      slot[64 * k + lane] = s.gw[k] ^ 0x80808080u;
+  }
 }
 
 // one window word of the vertical pass: the lane's 12 (channel, slot) words of ring slot `slot` against tap word t

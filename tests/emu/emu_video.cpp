@@ -305,13 +305,14 @@ template <int NW, int CH, int SEMI>
 static void run_fused420 (const Fused420Params &p, const Dst &dst, const PostFast &pf, int nwaves)
 {
   const int tiles = (p.h.out_w + p.h.tile_w - 1) / p.h.tile_w, chunks = (p.out_h + p.rows_per_chunk - 1) / p.rows_per_chunk;
-  std::vector<uint32_t> lds ((size_t) p.ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) nwaves * 2 * GSTAMD_H420_LINE_WORDS + 4);
+  const int stage_lines = p.sched == 2 ? 1 : 2;
+  std::vector<uint32_t> lds ((size_t) p.ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) nwaves * stage_lines * GSTAMD_H420_LINE_WORDS + 4);
   uint32_t *base = (uint32_t *) (((uintptr_t) lds.data () + 15) & ~(uintptr_t) 15);
   std::vector<Fused420Lane<NW>> L ((size_t) nwaves * 64);
   std::vector<int> gnext (nwaves);
   for (int by = 0; by < chunks; by++)
     for (int bx = 0; bx < tiles; bx++) {
-      memset (base, 0xAB, ((size_t) p.ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) nwaves * 2 * GSTAMD_H420_LINE_WORDS) * 4);    /* LDS starts as garbage */
+      memset (base, 0xAB, ((size_t) p.ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) nwaves * stage_lines * GSTAMD_H420_LINE_WORDS) * 4);    /* LDS starts as garbage */
       uint32_t *ring = base;
       const int t0 = bx * p.h.tile_w, t1 = std::min (t0 + p.h.tile_w, p.h.out_w);
       const int j0 = by * p.rows_per_chunk, j1 = std::min (j0 + p.rows_per_chunk, p.out_h);
@@ -330,6 +331,76 @@ static void run_fused420 (const Fused420Params &p, const Dst &dst, const PostFas
           h420r_fetch_taps<NW> (p.h, xa, t0, t1, lane, s.ft);
           fused_request_group<NW, SEMI> (p.h, std::min (gnext[w], g_last), s);
         }
+      }
+      if (p.sched == 2) {
+        /* k_scale420_fused2: between two barriers every wave filters its row of round k and produces its groups of round k + 1 (odd
+           waves the other way round); the waves run one after the other here, which is the worst order for a ring that is too short */
+        auto produce = [&](int w, int gh) {
+          uint32_t *stage = base + (size_t) p.ring * GSTAMD_FUSED_GROUP_WORDS + (size_t) w * GSTAMD_H420_LINE_WORDS;
+          Fused420Lane<NW> *Lw = &L[(size_t) w * 64];
+          int &g = gnext[w];
+          while (g <= gh) {
+            const int gn = std::min (g + nwaves, g_last);
+            uint32_t *slot = ring + (size_t) (g % p.ring) * GSTAMD_FUSED_GROUP_WORDS;
+            for (int lane = 0; lane < 64; lane++) fused2_stage<NW, CH, SEMI, 0> (p.h, Lw[lane], stage, g, gn, lane);
+            for (int lane = 0; lane < 64; lane++) fused2_filter<NW, 0> (Lw[lane], stage, slot, lane);
+            for (int lane = 0; lane < 64; lane++) fused2_stage<NW, CH, SEMI, 1> (p.h, Lw[lane], stage, g, gn, lane);
+            for (int lane = 0; lane < 64; lane++) fused2_filter<NW, 1> (Lw[lane], stage, slot, lane);
+            for (int lane = 0; lane < 64; lane++) fused2_stage<NW, CH, SEMI, 2> (p.h, Lw[lane], stage, g, gn, lane);
+            for (int lane = 0; lane < 64; lane++) fused2_filter<NW, 2> (Lw[lane], stage, slot, lane);
+            for (int lane = 0; lane < 64; lane++) fused2_stage<NW, CH, SEMI, 3> (p.h, Lw[lane], stage, g, gn, lane);
+            for (int lane = 0; lane < 64; lane++) fused2_filter<NW, 3> (Lw[lane], stage, slot, lane);
+            g += nwaves;
+          }
+        };
+        auto vrow = [&](int j) {
+          for (int lane = 0; lane < 64; lane++) {
+            if (p.ngv == 5)
+              fused_vrow<5> (p, ring, dst, pf, j, t0, t1, lane);
+            else
+              fused_vrow<0> (p, ring, dst, pf, j, t0, t1, lane);
+          }
+        };
+        int jr = j0, rows = p.first_rows;
+        int jl = std::min (jr + rows, j1) - 1;
+        {
+          int gl_r, gh;
+          fused_round_groups (p, jr, jl, &gl_r, &gh);
+          for (int w = 0; w < nwaves; w++)
+            produce (w, gh);
+        }
+        for (;;) {
+          const int jr2 = jr + rows;
+          const bool more = jr2 < j1;
+          const int jl2 = std::min (jr2 + nwaves, j1) - 1;
+          int gh2 = -1;
+          if (more) {
+            int gl_r;
+            fused_round_groups (p, jr2, jl2, &gl_r, &gh2);
+          }
+          /* odd waves first: they produce before the even waves have read the round's window */
+          for (int pass = 0; pass < 2; pass++)
+            for (int w = 0; w < nwaves; w++) {
+              if ((w & 1) != (pass == 0 ? 1 : 0))
+                continue;
+              const int j = jr + w;
+              if (w & 1) {
+                produce (w, gh2);
+                if (j <= jl)
+                  vrow (j);
+              } else {
+                if (j <= jl)
+                  vrow (j);
+                produce (w, gh2);
+              }
+            }
+          if (!more)
+            break;
+          jr = jr2;
+          rows = nwaves;
+          jl = jl2;
+        }
+        continue;
       }
       int rows = p.first_rows;
       for (int jr = j0; jr < j1; jr += rows, rows = nwaves) {
@@ -519,7 +590,10 @@ static bool emu_scale420_fused (const VideoPlan &p, H420RegParams hp, int nw, in
   q.out_h = p.out_info.height;
   q.rows_per_chunk = rpc;
   q.first_rows = std::min (nwaves, getenv ("GSTAMD_FUSED_FIRST") ? std::max (1, atoi (getenv ("GSTAMD_FUSED_FIRST"))) : fused420_first_rows (t, nwaves));
-  q.ring = fused420_ring_groups (t, rpc, nwaves, q.first_rows);
+  q.sched = getenv ("GSTAMD_FUSED_SCHED") && atoi (getenv ("GSTAMD_FUSED_SCHED")) == 1 ? 1 : 2;
+  q.ring = q.sched == 2 ? fused420_ring_groups2 (t, rpc, nwaves, q.first_rows) : fused420_ring_groups (t, rpc, nwaves, q.first_rows);
+  if (getenv ("GSTAMD_FUSED_RING_SHORT"))        /* tests: a ring one slot too short must break the picture (the emulator's wave order shows it) */
+    q.ring -= 1;
   q.n_groups = t.n_groups;
   if (((uintptr_t) dst.p % 4) != 0 || (dst.stride % 4) != 0)
     return false;

@@ -90,6 +90,27 @@ __global__ __launch_bounds__ (1024) void k_scale420_fused (Fused420Params p, Dst
   }
 }
 
+// the row's entries of the two vertical tables through the scalar unit: the row is wave-uniform, but the compiler keeps such reads on the
+// vector memory path (the kernel also stores, so it cannot prove the tables unchanged), where they cost a full memory latency at the start
+// of every vertical row; s_load_* takes ~1/4 of that and no vector registers.  Waits for its own results (and the wave's LDS traffic).
+template <int NGV>
+static __device__ __forceinline__ void fused_row_tables (const Fused420Params &p, int j, int *group, uint32_t *tw)
+{
+  static_assert (NGV == 5, "window of five groups");
+  const int32_t *vg = p.vgroup;
+  const uint32_t *vt = p.vtapw;
+  typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+  const int og = j * 4, ot = j * 4 * NGV, ot4 = ot + 16;
+  int g;
+  u32x4 t;
+  uint32_t t4;
+  asm volatile ("s_load_dword %0, %3, %5\n\ts_load_dwordx4 %1, %4, %6\n\ts_load_dword %2, %4, %7\n\ts_waitcnt lgkmcnt(0)"
+      : "=&s" (g), "=&s" (t), "=&s" (t4)
+      : "s" (vg), "s" (vt), "s" (og), "s" (ot), "s" (ot4) : "memory");
+  *group = g;
+  tw[0] = t.x, tw[1] = t.y, tw[2] = t.z, tw[3] = t.w, tw[4] = t4;
+}
+
 #ifndef GSTAMD_FUSED2_PARITY
 #define GSTAMD_FUSED2_PARITY 1
 #endif
@@ -164,9 +185,17 @@ __global__ __launch_bounds__ (1024) void k_scale420_fused2 (Fused420Params p, Ds
     if (k >= 0) {
       int jr, jl;
       round_rows (k, &jr, &jl);
-      const int j = jr + wave;
-      if (j <= jl)
-        fused_vrow<NGV> (p, ring, dst, pf, j, t0, t1, lane);
+      const int j = __builtin_amdgcn_readfirstlane (jr + wave);
+      if (j <= jl) {
+        if (NGV == 5) {
+          int grp;
+          uint32_t tw[5];
+          fused_row_tables<5> (p, j, &grp, tw);
+          fused_vrow_words<5> (p, ring, dst, pf, j, t0, t1, lane, grp % p.ring, tw);
+        } else {
+          fused_vrow<NGV> (p, ring, dst, pf, j, t0, t1, lane);
+        }
+      }
     }
     if (ahead && k >= -1 && k < n_rounds - 1)
       __syncthreads ();

@@ -196,27 +196,50 @@ GSTAMD_HD void fused_vstep (const uint32_t *ring, int slot, int lane, uint32_t t
     acc[k] = dot4_i8 (v[k], t, acc[k]);
 }
 
-// vertical pass of output row j for the lane's four outputs, post stage, store.  NGV > 0: window words known at compile time.
+// vertical pass of output row j for the lane's four outputs, post stage, store: the row's first ring slot and its NGV window words given
+template <int NGV>
+GSTAMD_HD void fused_vrow_words (const Fused420Params &p, const uint32_t *ring, const Dst &dst, const PostFast &pf, int j, int t0, int t1, int lane, int slot,
+    const uint32_t *tw)
+{
+  int acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++)
+    acc[k] = 128 * 64 + 32;
+#pragma unroll
+  for (int r = 0; r < NGV; r++) {
+    fused_vstep (ring, slot, lane, tw[r], acc);
+    slot = slot + 1 == p.ring ? 0 : slot + 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = t0 + lane + 64 * i;
+    const uint32_t px = 0xffu | (h420r_finish (acc[i]) << 8) | (h420r_finish (acc[4 + i]) << 16) | (h420r_finish (acc[8 + i]) << 24);
+    if (x < t1)
+      store_px (dst, x, j, post_px (dst, pf, px));
+  }
+}
+
+// the same with the tables read here.  NGV > 0: window words known at compile time.
 template <int NGV>
 GSTAMD_HD void fused_vrow (const Fused420Params &p, const uint32_t *ring, const Dst &dst, const PostFast &pf, int j, int t0, int t1, int lane)
 {
   const uint32_t *tw = p.vtapw + (size_t) j * p.ngv;
+  if (NGV > 0) {
+    uint32_t w[NGV > 0 ? NGV : 1];
+#pragma unroll
+    for (int r = 0; r < NGV; r++)
+      w[r] = tw[r];
+    fused_vrow_words<NGV> (p, ring, dst, pf, j, t0, t1, lane, p.vgroup[j] % p.ring, w);
+    return;
+  }
   int acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++)
     acc[k] = 128 * 64 + 32;
   int slot = p.vgroup[j] % p.ring;
-  if (NGV > 0) {
-#pragma unroll
-    for (int r = 0; r < NGV; r++) {
-      fused_vstep (ring, slot, lane, tw[r], acc);
-      slot = slot + 1 == p.ring ? 0 : slot + 1;
-    }
-  } else {
-    for (int r = 0; r < p.ngv; r++) {
-      fused_vstep (ring, slot, lane, tw[r], acc);
-      slot = slot + 1 == p.ring ? 0 : slot + 1;
-    }
+  for (int r = 0; r < p.ngv; r++) {
+    fused_vstep (ring, slot, lane, tw[r], acc);
+    slot = slot + 1 == p.ring ? 0 : slot + 1;
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) {

@@ -278,6 +278,65 @@ class AudioWorkload:
                           "order parity is defined on)"}
 
 
+class AudioConvertWorkload:
+    """audioconvert ! audioresample on the device.  A step = 10 s of stereo F32 48 kHz -> S16 44.1 kHz with the element's default
+    triangular dither, in `block`-frame buffers: unpack / resample / quantize + dither / pack per buffer (three launches)."""
+    name, unit, dtype = "f4audioconv", "input frames/s", "f64"
+    metric = "audio input frames/s (audioconvert F32->S16 tpdf + audioresample 48k->44.1k, stereo) per GPU"
+    kernel = "k_aconv_pre + k_fir<double> + k_aconv_post"
+    CH, N = 2, 48000 * 10
+
+    def __init__(self, block=1024):
+        self.block = block
+
+    def setup(self, dev, rank):
+        import torch
+
+        import cases
+        from gstreamer_amd import audio as A
+        self.A = A
+        self.sig = torch.from_numpy(cases.audio_buffer("F32LE", self.CH, self.N, 4242 + rank)).to(dev)
+        self.c = A.AudioConverter(A.audio_info("F32LE", 48000, self.CH), A.audio_info("S16LE", 44100, self.CH),
+                                  A.audio_converter_config(dither_method="tpdf", resampler_method="kaiser"))
+        self.out = torch.zeros((self.N + 4096, self.CH), dtype=torch.int16, device=dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.blocks = [(o, min(self.block, self.N - o)) for o in range(0, self.N, self.block)]
+        self.launches_per_step = len(self.blocks)
+        self.units_per_step = self.N
+        no = self.N * 147 // 160
+        self.alg_bytes = self.N * self.CH * 4 + no * self.CH * 2
+        self.alg_bytes_per_launch = self.alg_bytes / len(self.blocks)
+
+    def step(self, s):
+        po = 0
+        for o, n in self.blocks:
+            m = self.c.get_out_frames(n)
+            self.c.samples(self.sig.data_ptr() + o * self.CH * 4, n, self.out.data_ptr() + po * self.CH * 2, m, self.stream)
+            po += m
+
+    def config(self, world):
+        return {"workload": "SURVEY 8(f)4: audioconvert F32LE 48000 Hz -> S16LE 44100 Hz stereo (tpdf dither, Kaiser resampler inside the converter), "
+                            "a step = 10 s of audio in buffers of %d frames (%d converter calls)" % (self.block, len(self.blocks)),
+                "block_frames": self.block, "parallelism": "stream-per-gpu x%d" % world}
+
+    def cpu_baseline(self):
+        import cases
+        from oracle import ref
+        if not ref.available():
+            return None
+        rc = ref.AudioConverter("F32LE", 48000, self.CH, "S16LE", 44100, self.CH,
+                                config="GstAudioConverter, GstAudioConverter.dither-method=(GstAudioDitherMethod)tpdf, "
+                                       "GstAudioConverter.resampler-method=(GstAudioResamplerMethod)kaiser")
+        n = 48000 * 30
+        data = cases.audio_buffer("F32LE", self.CH, n, 4242).view("uint8").reshape(-1)
+        t0 = time.perf_counter()
+        rc.samples(data)
+        secs = time.perf_counter() - t0
+        rc.free()
+        return {"value": round(n / secs, 1), "unit": "input frames/s", "cores": 1, "kind": "reference",
+                "sample": "30 s of stereo F32 48k -> S16 44.1k in one gst_audio_converter_samples call (ORC C backups, C inner product)"}
+
+
 class StubWorkload:
     """CPU stand-in used by tests/test_bench_dist.py to run THIS file's N>1 control flow under gloo: no converter, a step just takes
     a rank-dependent time.  Never part of a measurement."""
@@ -308,6 +367,8 @@ def make_workload(args):
         return CompositorWorkload()
     if args.config == "c4audio":
         return AudioWorkload(args.audio_block)
+    if args.config == "f4audioconv":
+        return AudioConvertWorkload(args.audio_block)
     if args.config == "stub":
         return StubWorkload()
     raise SystemExit("unknown --config %r" % args.config)
@@ -370,7 +431,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | f2gamma | f2p010out | f2p010in")
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | f2gamma | f2p010out | f2p010in | f4audioconv")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed sustained load before the W warmup steps: from idle an MI355X needs 20-30 ms of load "
@@ -416,8 +477,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     wl = make_workload(args)
-    steps = args.steps if args.steps is not None else {"c2": 400, "c1": 800, "c3": 150, "c5": 150, "c4": 150, "c4audio": 20, "stub": 5}.get(args.config, 50)
-    warmup = args.warmup if args.warmup is not None else {"c4audio": 2, "stub": 1}.get(args.config, 20)
+    steps = args.steps if args.steps is not None else {"c2": 400, "c1": 800, "c3": 150, "c5": 150, "c4": 150, "c4audio": 20, "f4audioconv": 10, "stub": 5}.get(args.config, 50)
+    warmup = args.warmup if args.warmup is not None else {"c4audio": 2, "f4audioconv": 2, "stub": 1}.get(args.config, 20)
     wl.setup(dev, rank)
 
     def sync():

@@ -414,6 +414,24 @@ GSTAMD_HD void convert_body (const FrontParams &f, const Planes &pl, const int *
     d[1] = gstamd_make_uint4 (out[4], out[5], out[6], out[7]);
     return;
   }
+  if (vec_ok == 2 && f.kind == UNPACK_PACKED4 && x0 + K1_PX <= w) {
+    /* 4-byte packed source (swizzles, RGB <-> AYUV): eight pixels through two 16-byte loads and two 16-byte stores per lane */
+    const uint4 *sp = (const uint4 *) (pl.p[0] + (size_t) y * pl.stride[0] + 4 * (size_t) x0);
+    const uint4 a = sp[0], b = sp[1];
+    const uint32_t raw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t out[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint32_t r = raw[i];
+      const uint32_t px = ((r >> (8 * f.pos[0])) & 0xff) | (((r >> (8 * f.pos[1])) & 0xff) << 8) | (((r >> (8 * f.pos[2])) & 0xff) << 16) |
+          (((r >> (8 * f.pos[3])) & 0xff) << 24);
+      out[i] = pack_px (pos, pxf (apply_color (color, px)));
+    }
+    uint4 *d = (uint4 *) (drow + 4 * (size_t) x0);
+    d[0] = gstamd_make_uint4 (out[0], out[1], out[2], out[3]);
+    d[1] = gstamd_make_uint4 (out[4], out[5], out[6], out[7]);
+    return;
+  }
   const int x1 = x0 + K1_PX < w ? x0 + K1_PX : w;
   for (int x = x0; x < x1; x++) {
     const uint32_t px = fetch_front (f, pl, vpair, x, y);

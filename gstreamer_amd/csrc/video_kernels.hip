@@ -591,6 +591,8 @@ hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vp
     else
       vec_ok = vec_ok && aligned (pl.p[1], 4) && aligned (pl.p[2], 4) && (pl.stride[1] % 4) == 0 && (pl.stride[2] % 4) == 0;
   }
+  if (f.kind == UNPACK_PACKED4 && aligned (dst, 16) && (dstride % 16) == 0 && aligned (pl.p[0], 16) && (pl.stride[0] % 16) == 0)
+    vec_ok = 2;                         /* convert_body's 16-byte path for 4-byte packed sources */
   const int bx = spans >= 256 ? 256 : (spans > 64 ? 128 : 64);
   dim3 grid ((spans + bx - 1) / bx, f.height), block (bx);
   switch (f.chroma_h) {
@@ -644,6 +646,8 @@ hipError_t launch_convert_gamma (const FrontParams &f, const Planes &pl, const i
     else
       vec_ok = vec_ok && aligned (pl.p[1], 4) && aligned (pl.p[2], 4) && (pl.stride[1] % 4) == 0 && (pl.stride[2] % 4) == 0;
   }
+  if (f.kind == UNPACK_PACKED4 && aligned (dst, 16) && (dstride % 16) == 0 && aligned (pl.p[0], 16) && (pl.stride[0] % 16) == 0)
+    vec_ok = 2;                         /* convert_body's 16-byte path for 4-byte packed sources */
   if (f.chroma_h == CHROMA_H_H2_CS)
     return launch_convert_gamma_ch<CHROMA_H_H2_CS> (f, pl, vpair_dev, color, pack_pos, dst, dstride, spans, vec_ok, g, stream);
   if (f.chroma_h == CHROMA_H_H2)

@@ -1088,6 +1088,12 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     }
     return GSTAMD_OK;
   }
+  /* launch_convert's 16-byte path for 4-byte packed sources */
+  if (p.passes.empty () && vec_ok && p.front.kind == UNPACK_PACKED4 && ((uintptr_t) d0 % 16) == 0 && (dstride % 16) == 0 && ((uintptr_t) pl.p[0] % 16) == 0 &&
+      (pl.stride[0] % 16) == 0)
+    vec_ok = 2;
+  else if (p.passes.empty () && p.front.kind == UNPACK_PACKED4 && vec_ok == 2)
+    vec_ok = 1;
   if (p.passes.empty () && g_gamma_hook) {                /* k_convert_gamma: the same body with the gamma chain as its per-pixel step */
     const int spans = (p.front.width + K1_PX - 1) / K1_PX;
     GammaChainFn fn;

@@ -222,6 +222,69 @@ class CompositorWorkload:
                           "one thread (max-threads default)" % n_frames}
 
 
+class CompositorScaledWorkload(CompositorWorkload):
+    """SURVEY 8d's C4 variant A ("next"): a 4 x 4 grid of non-overlapping pads, each 1080p BGRA frame scaled to 960x540 by a per-pad
+    converter with the library defaults (cubic) - what GstVideoAggregatorConvertPad does - then one aggregate launch."""
+    name = "c4a"
+    metric = "4K output frames/s (compositor, 16 x 1080p BGRA pads each scaled to 960x540, 4x4 grid) per GPU; % HBM roofline"
+    kernel = "16 x per-pad converter (plane scaler) + k_aggregate"
+    SW, SH = 960, 540
+
+    def pad_geometry(self, i):
+        return (i % 4) * 960, (i // 4) * 540, 1.0
+
+    def setup(self, dev, rank):
+        import torch
+        CompositorWorkload.setup(self, dev, rank)
+        V = self.V
+        self.convs = [V.VideoConverter(V.video_info("BGRA", self.PW, self.PH), V.video_info("BGRA", self.SW, self.SH)) for _ in range(self.N)]
+        self.scaled = [torch.zeros(self.SW * self.SH * 4, dtype=torch.uint8, device=dev) for _ in range(self.N)]
+        self.sarr = (V.CompositorPad * self.N)()
+        for i in range(self.N):
+            x, y, a = self.pad_geometry(i)
+            self.sarr[i].data, self.sarr[i].width, self.sarr[i].height, self.sarr[i].stride = self.scaled[i].data_ptr(), self.SW, self.SH, self.SW * 4
+            self.sarr[i].xpos, self.sarr[i].ypos, self.sarr[i].alpha, self.sarr[i].blend_mode = x, y, a, 1
+        self.launches_per_step = self.frames_per_step
+        self.plan = self.convs[0].describe()
+
+    def step(self, s):
+        for f in range(self.frames_per_step):
+            k = s * self.frames_per_step + f
+            for i in range(self.N):
+                self.convs[i].frame(self.pads[(k % self.SETS) * self.N + i].data_ptr(), self.scaled[i].data_ptr(), self.stream)
+            r = self.L.gstamd_compositor_aggregate(self.V.FORMATS["BGRA"], 0, self.sarr, self.N,
+                                                   self.outs[k % self.pool_out].data_ptr(), self.DW, self.DH, self.DW * 4, self.stream)
+            assert r == 0, self.V.last_error()
+
+    def config(self, world):
+        c = CompositorWorkload.config(self, world)
+        c["workload"] = ("C4 variant A: compositor, 16 x 1920x1080 BGRA pads each scaled to 960x540 (per-pad converter, cubic: %s), 4 x 4 grid, operator over, "
+                         "-> 3840x2160 BGRA; %d output frames/step" % (self.plan, self.frames_per_step))
+        return c
+
+    def cpu_baseline(self):
+        import numpy as np
+
+        import cases
+        from oracle import ref
+        if not ref.available():
+            return None
+        pad_np = cases.frame_bytes(self.PW * self.PH * 4, "random", 31)
+        canvas = np.zeros(self.DW * self.DH * 4, np.uint8)
+        rc = ref.VideoConverter("BGRA", self.PW, self.PH, "BGRA", self.SW, self.SH)
+        n_frames = 3
+        t0 = time.perf_counter()
+        for _ in range(n_frames):
+            ref.compositor_fill(0, "bgra", "BGRA", canvas, self.DW, self.DH, 0, self.DH)
+            for i in range(self.N):
+                x, y, a = self.pad_geometry(i)
+                small = rc.frame(pad_np)
+                ref.compositor_blend("blend_bgra", "BGRA", small, self.SW, self.SH, x, y, a, canvas, self.DW, self.DH, 0, self.DH, 1)
+        secs = time.perf_counter() - t0
+        return {"value": round(n_frames / secs, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+                "sample": "%d output frames: fill_checker + 16 x (gst_video_converter_frame 1080p -> 540p cubic + blend_bgra) of the reference, one thread" % n_frames}
+
+
 class AudioWorkload:
     """BASELINE C4, audio half.  A step = 10 s of stereo F32 handed over in `block`-frame buffers (1024 = what the element sees)."""
     name, unit, dtype = "c4audio", "input frames/s", "f32"
@@ -365,6 +428,8 @@ def make_workload(args):
         return VideoWorkload(args.config, args.batch, size)
     if args.config == "c4":
         return CompositorWorkload()
+    if args.config == "c4a":
+        return CompositorScaledWorkload()
     if args.config == "c4audio":
         return AudioWorkload(args.audio_block)
     if args.config == "f4audioconv":
@@ -431,7 +496,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | f2gamma | f2p010out | f2p010in | f4audioconv")
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed sustained load before the W warmup steps: from idle an MI355X needs 20-30 ms of load "

@@ -943,7 +943,16 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
         out_w, out_h, p.passes[h_first ? 0 : 1].max_span, c->geom[h_first ? 0 : 1], pf, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_scale2x2");
   }
+  /* a 4-byte packed source whose unpack is the identity (ARGB, AYUV, and every 4-byte format in plane scaling, where the bytes go through
+     raw) with no colour step before the scaler IS an image in the scalers' own layout: the image kernels (wave tiles, k_vscale_pk) take it
+     directly instead of the one-lane-per-pixel front kernels */
+  const bool raw4 = p.front.kind == UNPACK_PACKED4 && p.front.pos[0] == 0 && p.front.pos[1] == 1 && p.front.pos[2] == 2 && p.front.pos[3] == 3 &&
+      pre.matrix.kind == MATRIX_NONE && pre.alpha_kind == ALPHA_NONE && ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0;
   if (p.passes.size () == 1) {
+    if (raw4)
+      e = launch_scale_from_image (p.passes[0].horizontal, pl.p[0], pl.stride[0], sd[0], dst, dstride, true, post, p.post.pack_pos, out_w, out_h,
+          p.passes[0].max_span, p.front.width, c->geom[0], pf, stream);
+    else
     e = launch_scale_from_front (p.passes[0].horizontal, p.front, pl, c->vpair_dev, pre, sd[0], dst, dstride, true,
         post, p.post.pack_pos, out_w, out_h, p.passes[0].max_span, c->geom[0], pf, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "scale pass");
@@ -1050,7 +1059,10 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     if (e != hipSuccess && e != hipErrorNotSupported)
       return hip_fail (e, "k_hscale420_reg");
   }
-  if (e == hipErrorNotSupported)
+  if (e == hipErrorNotSupported && raw4)
+    e = launch_scale_from_image (p.passes[0].horizontal, pl.p[0], pl.stride[0], sd[0], c->tmp, c->tmp_w * 4, false, none, p.post.pack_pos, c->tmp_w,
+        c->tmp_h, p.passes[0].max_span, p.front.width, c->geom[0], pf_none, stream);
+  else if (e == hipErrorNotSupported)
   e = launch_scale_from_front (p.passes[0].horizontal, p.front, pl, c->vpair_dev, pre, sd[0], c->tmp, c->tmp_w * 4,
       false, none, p.post.pack_pos, c->tmp_w, c->tmp_h, p.passes[0].max_span, c->geom[0], pf_none, stream);
   if (e != hipSuccess)

@@ -1371,7 +1371,18 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
         scale2x2_body<SrcFront> (sf, sh, sv, h_first ? 1 : 0, d, p.out_info.width, p.out_info.height, x, y);
     return GSTAMD_OK;
   }
+  /* convert_to_packed's raw4: an identity-unpack 4-byte source without a colour step before the scaler goes to the image kernels */
+  const bool raw4 = p.front.kind == UNPACK_PACKED4 && p.front.pos[0] == 0 && p.front.pos[1] == 1 && p.front.pos[2] == 2 && p.front.pos[3] == 3 &&
+      sf.pre.matrix.kind == MATRIX_NONE && sf.pre.alpha_kind == ALPHA_NONE && ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0;
+  SrcImage raw_img;
+  raw_img.p = pl.p[0];
+  raw_img.stride = pl.stride[0];
+  raw_img.width = p.front.width;
   if (p.passes.size () == 1) {
+    if (raw4)
+      run_scale (p.passes[0].horizontal, raw_img, sd[0], mk (d0, dstride, true), p.out_info.width, p.out_info.height, p.passes[0].max_span,
+          p.passes[0].horizontal ? pass_tile_geom (p.passes[0]) : TileGeom {0, 0}, pf);
+    else
     run_scale (p.passes[0].horizontal, sf, sd[0], mk (d0, dstride, true), p.out_info.width, p.out_info.height, p.passes[0].max_span,
         p.passes[0].horizontal ? pass_tile_geom (p.passes[0]) : TileGeom {0, 0}, pf);
     return GSTAMD_OK;
@@ -1383,7 +1394,9 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
   const int reg = emu_hscale420_reg (p, sf, sd[0], tmp.data (), tw, &final_dst, &pf);
   if (reg == 2)
     return GSTAMD_OK;
-  if (!reg)
+  if (!reg && raw4)
+    run_scale (s0.horizontal, raw_img, sd[0], mk (tmp.data (), tw * 4, false), tw, th, s0.max_span, s0.horizontal ? pass_tile_geom (s0) : TileGeom {0, 0}, pf_none);
+  else if (!reg)
   run_scale (s0.horizontal, sf, sd[0], mk (tmp.data (), tw * 4, false), tw, th, s0.max_span,
       s0.horizontal ? pass_tile_geom (s0) : TileGeom {0, 0}, pf_none);
   SrcImage si;

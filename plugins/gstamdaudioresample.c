@@ -6,7 +6,8 @@
  * interleaved with the rate made a range by transform_caps, output sizes from
  * gst_audio_resampler_get_out_frames, one resample() per buffer (:745-860), drain of the filter history at EOS.
  * Samples are staged to HBM per buffer (audio buffers are tiny; a HIP-memory audio path would not change
- * throughput).  Not implemented: sinc-filter-* properties, gap/discont resets, latency query.
+ * throughput).  DISCONT buffers and timestamp jumps drain + reset the filter (gstaudioresample.c:705-739, 898-940).  Not implemented: GAP-buffer
+ * accounting, latency query.
  */
 #include <gst/audio/audio.h>
 #include <gst/base/gstbasetransform.h>
@@ -38,7 +39,9 @@ typedef struct {
   gsize d_in_size, d_out_size;
   gpointer stream;             /* this instance's HIP stream */
   gint device_id;              /* device-id property: -1 = the process's current device */
-  guint64 samples_out;
+  guint64 samples_in, samples_out;
+  guint64 in_offset0, out_offset0;
+  gboolean need_discont;
   GstClockTime t0;
 } GstAmdAudioResample;
 typedef struct { GstBaseTransformClass parent_class; } GstAmdAudioResampleClass;
@@ -154,8 +157,9 @@ amd_ar_set_caps (GstBaseTransform * t, GstCaps * incaps, GstCaps * outcaps)
   if (s->r && (!gst_audio_info_is_equal (&in, &s->in) || !gst_audio_info_is_equal (&out, &s->out))) {
     amd_ar_drain (s);
     gstamd_audio_resampler_reset (s->r);
-    s->samples_out = 0;
+    s->samples_in = s->samples_out = 0;
     s->t0 = GST_CLOCK_TIME_NONE;
+    s->need_discont = TRUE;
   }
   s->in = in;
   s->out = out;
@@ -186,8 +190,9 @@ amd_ar_set_caps (GstBaseTransform * t, GstCaps * incaps, GstCaps * outcaps)
     return FALSE;
   }
   s->r_method = s->method;
-  s->samples_out = 0;
+  s->samples_in = s->samples_out = 0;
   s->t0 = GST_CLOCK_TIME_NONE;
+  s->need_discont = TRUE;
   return TRUE;
 }
 
@@ -281,9 +286,32 @@ amd_ar_stamp (GstAmdAudioResample * s, GstBuffer * buf, gsize frames)
     GST_BUFFER_PTS (buf) = s->t0 + gst_util_uint64_scale_int_round (s->samples_out, GST_SECOND, rate);
     GST_BUFFER_DURATION (buf) = s->t0 + gst_util_uint64_scale_int_round (s->samples_out + frames, GST_SECOND, rate) - GST_BUFFER_PTS (buf);
   }
-  GST_BUFFER_OFFSET (buf) = s->samples_out;
-  GST_BUFFER_OFFSET_END (buf) = s->samples_out + frames;
+  if (s->out_offset0 != GST_BUFFER_OFFSET_NONE) {
+    GST_BUFFER_OFFSET (buf) = s->out_offset0 + s->samples_out;
+    GST_BUFFER_OFFSET_END (buf) = s->out_offset0 + s->samples_out + frames;
+  } else {
+    GST_BUFFER_OFFSET (buf) = GST_BUFFER_OFFSET_NONE;
+    GST_BUFFER_OFFSET_END (buf) = GST_BUFFER_OFFSET_NONE;
+  }
   s->samples_out += frames;
+}
+
+/* gst_audio_resample_check_discont (gstaudioresample.c:705-739): the DISCONT flag, or a timestamp that is more than rate / 32 samples away from
+ * where the stream should be */
+static gboolean
+amd_ar_check_discont (GstAmdAudioResample * s, GstBuffer * buf)
+{
+  guint64 offset, delta;
+  if (GST_BUFFER_IS_DISCONT (buf))
+    return TRUE;
+  if (!(GST_BUFFER_PTS_IS_VALID (buf) && GST_CLOCK_TIME_IS_VALID (s->t0)) || GST_BUFFER_PTS (buf) < s->t0)
+    return FALSE;
+  offset = gst_util_uint64_scale_int_round (GST_BUFFER_PTS (buf) - s->t0, GST_AUDIO_INFO_RATE (&s->in), GST_SECOND);
+  delta = offset > s->samples_in ? offset - s->samples_in : s->samples_in - offset;
+  if (delta <= (guint64) (GST_AUDIO_INFO_RATE (&s->in) >> 5))
+    return FALSE;
+  GST_WARNING_OBJECT (s, "encountered timestamp discontinuity of %" G_GUINT64_FORMAT " samples", delta);
+  return TRUE;
 }
 
 static GstFlowReturn
@@ -295,6 +323,24 @@ amd_ar_transform (GstBaseTransform * t, GstBuffer * inbuf, GstBuffer * outbuf)
 
   if (!s->r)
     return GST_FLOW_NOT_NEGOTIATED;
+  /* transform (:898-940): drain what the filter still holds with the old timing, reset it, restart the counters at this buffer */
+  if (s->samples_in > 0 && amd_ar_check_discont (s, inbuf)) {
+    amd_ar_drain (s);
+    gstamd_audio_resampler_reset (s->r);
+    s->need_discont = TRUE;
+  }
+  if (s->need_discont) {
+    s->samples_in = s->samples_out = 0;
+    s->t0 = GST_BUFFER_PTS_IS_VALID (inbuf) ? GST_BUFFER_PTS (inbuf) : GST_CLOCK_TIME_NONE;
+    if (GST_BUFFER_OFFSET_IS_VALID (inbuf)) {
+      s->in_offset0 = GST_BUFFER_OFFSET (inbuf);
+      s->out_offset0 = gst_util_uint64_scale_int_round (s->in_offset0, GST_AUDIO_INFO_RATE (&s->out), GST_AUDIO_INFO_RATE (&s->in));
+    } else {
+      s->in_offset0 = s->out_offset0 = GST_BUFFER_OFFSET_NONE;
+    }
+    GST_BUFFER_FLAG_SET (outbuf, GST_BUFFER_FLAG_DISCONT);
+    s->need_discont = FALSE;
+  }
   if (!GST_CLOCK_TIME_IS_VALID (s->t0))
     s->t0 = GST_BUFFER_PTS_IS_VALID (inbuf) ? GST_BUFFER_PTS (inbuf) : 0;
   if (!gst_buffer_map (inbuf, &im, GST_MAP_READ))
@@ -319,6 +365,7 @@ amd_ar_transform (GstBaseTransform * t, GstBuffer * inbuf, GstBuffer * outbuf)
     }
 #endif
     n = amd_ar_process (s, im.data, planes, in_frames, om.data, om.size / GST_AUDIO_INFO_BPF (&s->out));
+    s->samples_in += in_frames;
   }
   gst_buffer_unmap (outbuf, &om);
   gst_buffer_unmap (inbuf, &im);
@@ -369,8 +416,9 @@ amd_ar_sink_event (GstBaseTransform * t, GstEvent * event)
     amd_ar_drain (s);
   else if (GST_EVENT_TYPE (event) == GST_EVENT_FLUSH_STOP && s->r) {
     gstamd_audio_resampler_reset (s->r);
-    s->samples_out = 0;
+    s->samples_in = s->samples_out = 0;
     s->t0 = GST_CLOCK_TIME_NONE;
+    s->need_discont = TRUE;
   }
   return GST_BASE_TRANSFORM_CLASS (gst_amd_ar_parent_class)->sink_event (t, event);
 }
@@ -461,6 +509,8 @@ gst_amd_ar_init (GstAmdAudioResample * s)
   s->sinc_filter_auto_threshold = 1048576;
   s->t0 = GST_CLOCK_TIME_NONE;
   s->device_id = -1;
+  s->need_discont = TRUE;
+  s->in_offset0 = s->out_offset0 = GST_BUFFER_OFFSET_NONE;
 }
 
 GType

@@ -677,3 +677,27 @@ def test_videoconvertscale_p010_output(gst_env, ref):
                             out_chroma_site="mpeg2", config=cases.ref_config_string(ref, cases.LIN))
     for i in range(n):
         assert (rc.frame(src[i]) == out[i]).all(), (i, int((rc.frame(src[i]) != out[i]).sum()))
+
+
+def test_audioresample_element_discont_drains_and_resets(gst_env, ref):
+    """Two streams through `concat`: the second one starts with a DISCONT buffer, so the element drains the filter's history with the old
+    stream's timing, resets, and starts afresh (gstaudioresample.c:898-940) - the output is two independently resampled streams."""
+    env, tmp = gst_env
+    fin, fout = tmp / "ard_in.f32", tmp / "ard_out.f32"
+    launch(env, "concat name=c ! tee name=t t. ! queue ! filesink location=%s t. ! queue ! amdaudioresample quality=4 ! audio/x-raw,rate=44100 "
+                "! filesink location=%s audiotestsrc num-buffers=10 wave=white-noise samplesperbuffer=1024 ! audio/x-raw,format=F32LE,rate=48000,channels=2 ! c. "
+                "audiotestsrc num-buffers=7 wave=pink-noise samplesperbuffer=1024 ! audio/x-raw,format=F32LE,rate=48000,channels=2 ! c." % (fin, fout))
+    src = np.fromfile(fin, np.float32).reshape(-1, 2)
+    out = np.fromfile(fout, np.float32).reshape(-1, 2)
+    assert len(src) == 17 * 1024
+    exp = []
+    for part in (src[:10 * 1024], src[10 * 1024:]):
+        rr = ref.AudioResampler("F32LE", 2, 48000, 44100, quality=4)
+        for off in range(0, len(part), 1024):
+            blk = part[off:off + 1024]
+            exp.append(rr.resample(blk, in_frames=len(blk), out_frames=rr.get_out_frames(len(blk))))
+        lat = rr.get_max_latency()
+        exp.append(rr.resample(None, in_frames=lat, out_frames=rr.get_out_frames(lat)))
+    exp = np.concatenate(exp)
+    assert out.shape == exp.shape, (out.shape, exp.shape)
+    assert (out == exp).all()

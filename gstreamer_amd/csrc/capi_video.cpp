@@ -652,6 +652,7 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
           sd[k].inc = pp.passes[k].inc;
           sd[k].offset = c->plane_dev[i][k].offset;
           sd[k].taps = c->plane_dev[i][k].taps;
+          sd[k].merged = pp.passes[k].merged;
         }
         if (pp.passes.size () == 1) {
           e = launch_plane_pass (pp.passes[0].horizontal, sd[0], sp, ss, dp, ds, pp.n_elems, pp.ow, pp.oh, stream);

@@ -1219,8 +1219,9 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
     if (fo->kind == UNPACK_PACKED3) {
       pp.n_elems = 3;          /* get_functions (video-scaler.c:1222): RGB / BGR are 3 x u8 pixels */
     } else if (fo->kind == UNPACK_PACKED422) {
-      /* get_functions (:1215): the line is ROUND_UP_4 (width * 2) single bytes; only the vertical scaler can exist here */
-      pp.iw = pp.ow = round_up (out.width * 2, 4);
+      /* get_functions (:1215): the line is ROUND_UP_4 (width * 2) single bytes */
+      pp.iw = round_up (in.width * 2, 4);
+      pp.ow = round_up (out.width * 2, 4);
     }
     const int rm = i == 0 ? method : cr_method;
     /* the halve / double shortcuts exist for the planes of multi-plane formats only (setup_scale :8092-8180) */
@@ -1255,7 +1256,34 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
       ScalePass hp, vp;
       /* get_functions (video-scaler.c:1202-1342): a 2-tap horizontal pass is ldreslin only for 1- and 4-byte pixels;
        * the 2-byte UV pixels and the 3-byte RGB pixels take video_scale_h_ntap_u8 with two 6-bit taps */
-      if (need_h)
+      if (need_h && fo->kind == UNPACK_PACKED422) {
+        /* setup_scale (:8020-8046) + gst_video_scaler_combine_packed_YUV (video-scaler.c:1134-1199): a luma scaler over the pixels and a
+           chroma scaler over the pixel pairs with the SAME tap count, merged into one scaler over the line's bytes - output byte i is luma
+           i / 2 (source byte offset * 2 + the format's luma position) or chroma byte i & 3 of macropixel i / 4 (offset * 4 + (i & 3)) */
+        ScalePass yp, cp;
+        make_scale_pass (rm, cfg.resampler_taps, cfg, in.width, out.width, true, &yp, true);
+        make_scale_pass (rm, (unsigned) yp.n_taps, cfg, (in.width + 1) / 2, (out.width + 1) / 2, true, &cp, true);
+        if (cp.n_taps != yp.n_taps)
+          return GSTAMD_ERR_UNSUPPORTED;        /* g_return_val_if_fail (uv max_taps == y max_taps) */
+        const int y_off = (in.format == GSTAMD_VIDEO_FORMAT_YUY2 || in.format == GSTAMD_VIDEO_FORMAT_YVYU) ? 0 : 1;        /* get_y_offset */
+        hp = yp;
+        hp.in_size = pp.iw;
+        hp.out_size = pp.ow;
+        hp.merged = 1 + y_off;
+        hp.dot4_ok = false;
+        hp.tapw.clear ();
+        hp.offset.assign ((size_t) pp.ow, 0);
+        if (yp.n_taps > 1)
+          hp.taps.assign ((size_t) pp.ow * yp.n_taps, 0);
+        for (int b = 0; b < pp.ow; b++) {
+          const bool luma = (b & 1) == y_off;
+          const ScalePass &src = luma ? yp : cp;
+          const int ic = luma ? std::min (b / 2, yp.out_size - 1) : std::min (b / 4, cp.out_size - 1);
+          hp.offset[(size_t) b] = luma ? src.offset[(size_t) ic] * 2 + (uint32_t) y_off : src.offset[(size_t) ic] * 4 + (uint32_t) (b & 3);
+          for (int l = 0; l < yp.n_taps && yp.n_taps > 1; l++)
+            hp.taps[(size_t) b * yp.n_taps + l] = src.taps[(size_t) ic * yp.n_taps + l];
+        }
+      } else if (need_h)
         make_scale_pass (rm, cfg.resampler_taps, cfg, pp.iw, pp.ow, true, &hp, pp.n_elems != 1);
       if (need_v)
         make_scale_pass (rm, cfg.resampler_taps, cfg, pp.ih, pp.oh, false, &vp, false);
@@ -1861,9 +1889,6 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       force_nearest = force_avg_down = true;
     else if (name == "convert_scale_planes" && ki == UNPACK_PACKED4)
       plane_scale = true;
-    else if (name == "convert_scale_planes" && ki == UNPACK_PACKED422 && in->width != out->width)
-      return fail (GSTAMD_ERR_UNSUPPORTED, "horizontal scaling of packed 4:2:2 in its own format (gst_video_scaler_combine_packed_YUV) "
-          "is not implemented on the GPU path");
     else if (name == "convert_scale_planes" && (ki == ko || (kind_has_planes (ki) && kind_has_planes (ko))))
       return plan_planes (plan, fp);
     else

@@ -126,6 +126,7 @@ struct ScalePass {
   int nw, nw4;                    // tap words per output that are used / allocated (row stride of tapw)
   std::vector<uint32_t> tapw;     // [out_size][nw4]: 4 int8 taps per word, shifted by (offset & 3), zero padded
   int max_span;        // horizontal passes: largest source span under any 256-output tile (LDS staging)
+  int merged = 0;      // ScaleDev::merged
 };
 
 // wave-tile geometry of a horizontal pass (video_scale_fast.h): outputs per wave and LDS words per staged row

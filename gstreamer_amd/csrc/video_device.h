@@ -482,9 +482,10 @@ GSTAMD_HD uint32_t hscale_px (const ROW &row, const ScaleDev &sd, int x)
   }
   const int off = (int) sd.offset[x];
   const int16_t *t = sd.taps + (size_t) x * sd.n_taps;
+  const int st = sd.merged == 0 ? 1 : (((x & 1) == sd.merged - 1) ? 2 : 4);         /* realize_taps (video-scaler.c:431-436) */
   int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   for (int l = 0; l < sd.n_taps; l++) {
-    const uint32_t p = row.at (off + l);
+    const uint32_t p = row.at (off + l * st);
     const int tp = t[l];
     a0 += (int) (p & 0xff) * tp;                     // mullw/addw: only the low 16 bits survive
     a1 += (int) ((p >> 8) & 0xff) * tp;

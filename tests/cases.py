@@ -424,6 +424,14 @@ VIDEO_CASES = [
     ("planes_i420_10_p010_720p", "I420_10LE", 1280, 720, "P010_10LE", 1280, 720, {}, None, None, "random"),
     ("planes_p010_yv12_odd", "P010_10LE", 643, 361, "YV12", 643, 361, {}, None, None, "random"),
     ("planes_nv12_p010_4k", "NV12", 3840, 2160, "P010_10LE", 3840, 2160, {}, None, None, "random"),
+    # packed 4:2:2 scaled in its own format: the merged luma / chroma scaler over the line's bytes (gst_video_scaler_combine_packed_YUV)
+    ("yuy2_yuy2_half_bilinear_merged", "YUY2", 640, 480, "YUY2", 320, 240, LIN, None, None, "random"),
+    ("yuy2_yuy2_half_cubic_merged", "YUY2", 640, 480, "YUY2", 320, 240, {}, None, None, "random"),
+    ("uyvy_uyvy_odd_lanczos_merged", "UYVY", 322, 241, "UYVY", 160, 120, LAN, None, None, "random"),
+    ("yvyu_yvyu_grow_bilinear_merged", "YVYU", 160, 90, "YVYU", 333, 200, LIN, None, None, "random"),
+    ("yuy2_yuy2_mixed_lanczos_merged", "YUY2", 200, 100, "YUY2", 300, 50, LAN, None, None, "random"),
+    ("yuy2_yuy2_honly_odd_merged", "YUY2", 201, 100, "YUY2", 99, 100, LIN, None, None, "random"),
+    ("vyuy_vyuy_honly_cubic_merged", "VYUY", 320, 100, "VYUY", 200, 100, {}, None, None, "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd

@@ -886,6 +886,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         sd[k].inc = pp.passes[k].inc;
         sd[k].offset = pp.passes[k].offset.data ();
         sd[k].taps = pp.passes[k].taps.data ();
+        sd[k].merged = pp.passes[k].merged;
       }
       auto run = [&](bool horizontal, const ScaleDev &s1, const SrcPlane &a, const DstPlane &b, int w, int h) {
         for (int y = 0; y < h; y++)

@@ -264,11 +264,11 @@ GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info
     bool ok = true;
     if (g.planes_fast)
       return c;
-    if (!g.src16)
+    if (!g.src16 && !g.src64)
       ok = (c->sub_in = gstamd_video_converter_new (&g.sub_in_info, &g.mid_in, &g.cfg_in, &st)) != nullptr;
     if (ok && g.fused)
       ok = c->sub_in->plan.passes.empty () && !c->sub_in->plan.out_planar && !c->sub_in->plan.plane_mode && !c->sub_in->plan.gamma.on;
-    if (ok && !g.pack16 && !g.fused)
+    if (ok && !g.pack16 && !g.store64 && !g.fused)
       ok = (c->sub_out = gstamd_video_converter_new (&g.mid_out, &g.sub_out_info, &g.cfg_out, &st)) != nullptr;
     if (!ok) {
       const std::string why = g_last_error;
@@ -319,11 +319,11 @@ static int build_tables (GstAmdVideoConverter *c)
     if (!g.enc.empty () && ((e = hipMalloc ((void **) &c->gamma_enc_dev, 65536)) != hipSuccess ||
             (e = hipMemcpy (c->gamma_enc_dev, g.enc.data (), 65536, hipMemcpyHostToDevice)) != hipSuccess))
       return hip_fail (e, "encode table");
-    if (!g.fused && !g.src16 && (e = hipMalloc ((void **) &c->gamma_mid_a, in_px * 4)) != hipSuccess)
+    if (!g.fused && !g.src16 && !g.src64 && (e = hipMalloc ((void **) &c->gamma_mid_a, in_px * 4)) != hipSuccess)
       return hip_fail (e, "hipMalloc(8-bit image)");
-    if (!g.fused && !g.pack16 && (e = hipMalloc ((void **) &c->gamma_mid_b, out_px * 4)) != hipSuccess)
+    if (!g.fused && !g.pack16 && !g.store64 && (e = hipMalloc ((void **) &c->gamma_mid_b, out_px * 4)) != hipSuccess)
       return hip_fail (e, "hipMalloc(8-bit image)");
-    if (!g.fused && (!p.passes.empty () || g.pack16 || g.src16)) {
+    if (!g.fused && (!p.passes.empty () || g.pack16 || g.src16 || g.src64 || g.store64)) {
       size_t mid_px = 0;
       if (!p.passes.empty ()) {
         const ScalePass &s0 = p.passes[0];
@@ -495,7 +495,13 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   int r;
   Deep16Image cur = {nullptr, 0, 0, 0};
   bool mid_done = !has_mid;
-  if (g.src16) {
+  bool cur_is_source = false;           /* an ARGB64 / AYUV64 source frame is the first image: stages must not run in place on it */
+  if (g.src64) {
+    if (!src_planes[0])
+      return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
+    cur.p = (const uint8_t *) src_planes[0], cur.stride = src_stride ? src_stride[0] : p.in_info.stride[0], cur.width = in_w, cur.height = in_h;
+    cur_is_source = true;
+  } else if (g.src16) {
     /* 10-bit source: the front of video_deep.h (unpack + chroma upsample) into an AYUV64 image */
     Planes pl;
     memset (&pl, 0, sizeof (pl));
@@ -513,7 +519,7 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
     const int32_t mas[GSTAMD_VIDEO_MAX_PLANES] = {in_w * 4, 0, 0, 0};
     if ((r = gstamd_video_converter_frame_planes (c->sub_in, src_planes, src_stride, ma, mas, stream)) != GSTAMD_OK)
       return r;
-    if (n == 0 && !g.pack16) {
+    if (n == 0 && !g.pack16 && !g.store64) {
       /* nothing between the tables: one launch from image to image */
       if ((e = launch_gamma_stage (gd, GAMMA_STAGE_DEC | GAMMA_STAGE_MID | GAMMA_STAGE_ENC, c->gamma_mid_a, in_w * 4, c->gamma_mid_b, out_w * 4, out_w, out_h,
                   stream)) != hipSuccess)
@@ -530,8 +536,12 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   }
   if (cur.p) {
     if (!mid_done && (n == 0 || !g.shrink)) {           /* the convert stage before the scalers (or no scalers): in place */
-      if ((e = launch_gamma_stage (gd, GAMMA_STAGE_MID, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height, stream)) != hipSuccess)
+      uint8_t *md = cur_is_source ? c->deep_a : (uint8_t *) cur.p;
+      const int ms = cur_is_source ? cur.width * 8 : cur.stride;
+      if ((e = launch_gamma_stage (gd, GAMMA_STAGE_MID, cur.p, cur.stride, md, ms, cur.width, cur.height, stream)) != hipSuccess)
         return hip_fail (e, "k_gamma_stage(convert)");
+      cur.p = md, cur.stride = ms;
+      cur_is_source = false;
       mid_done = true;
     }
     for (size_t i = 0; i < n; i++) {
@@ -551,14 +561,28 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       if ((e = launch_scale16 (cur, sd, hz, dst, ow * 8, ow, oh, nullptr, nullptr, stream)) != hipSuccess)
         return hip_fail (e, "k_scale16");
       cur.p = dst, cur.stride = ow * 8, cur.width = ow, cur.height = oh;
+      cur_is_source = false;
     }
-    if (g.pack16) {
-      if (!mid_done && (e = launch_gamma_stage (gd, GAMMA_STAGE_MID, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height, stream)) != hipSuccess)
-        return hip_fail (e, "k_gamma_stage(convert)");
+    if (g.pack16 || g.store64) {
+      if (!mid_done) {
+        uint8_t *md = cur_is_source ? c->deep_a : (uint8_t *) cur.p;
+        const int ms = cur_is_source ? cur.width * 8 : cur.stride;
+        if ((e = launch_gamma_stage (gd, GAMMA_STAGE_MID, cur.p, cur.stride, md, ms, cur.width, cur.height, stream)) != hipSuccess)
+          return hip_fail (e, "k_gamma_stage(convert)");
+        cur.p = md, cur.stride = ms;
+      }
     } else if ((e = launch_gamma_stage (gd, (mid_done ? 0 : GAMMA_STAGE_MID) | GAMMA_STAGE_ENC, cur.p, cur.stride, c->gamma_mid_b, out_w * 4, out_w, out_h,
                     stream)) != hipSuccess) {
       return hip_fail (e, "k_gamma_stage(encode)");
     }
+  }
+  if (g.store64) {
+    /* the last 16-bit image is the frame (pack_ARGB64 / pack_AYUV64 are copies at native endianness) */
+    if (!dest_planes[0])
+      return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+    const int ds = dest_stride ? dest_stride[0] : p.out_info.stride[0];
+    e = hipMemcpy2DAsync (dest_planes[0], (size_t) ds, cur.p, (size_t) cur.stride, (size_t) out_w * 8, (size_t) out_h, hipMemcpyDeviceToDevice, stream);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "copy of the 16-bit image");
   }
   if (g.pack16) {
     uint8_t *planes[3] = {nullptr, nullptr, nullptr};

@@ -42,6 +42,9 @@ static const FormatDesc g_formats[] = {
   // 10 bits per sample in 16-bit little-endian words (video-format.c:3834-3873, 5329-5400); sources of the 16-bit chain
   {GSTAMD_VIDEO_FORMAT_I420_10LE, "I420_10LE", true, false, 3, UNPACK_PLANAR, 1, 1, 1, 2, {0, 0, 0, 0}, 1},
   {GSTAMD_VIDEO_FORMAT_P010_10LE, "P010_10LE", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}, 2},
+  // 16 bits per component, packed, native endianness (video-format.c:2426-2473, 2523-2570): the unpack formats of the 16-bit chain themselves
+  {GSTAMD_VIDEO_FORMAT_ARGB64, "ARGB64", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}, 3},
+  {GSTAMD_VIDEO_FORMAT_AYUV64, "AYUV64", true, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}, 3},
 };
 
 const FormatDesc *format_desc (int format)
@@ -140,6 +143,11 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
     case GSTAMD_VIDEO_FORMAT_BGR:
       info->stride[0] = round_up (width * 3, 4);
       info->size = (uint64_t) info->stride[0] * h;
+      break;
+    case GSTAMD_VIDEO_FORMAT_ARGB64:
+    case GSTAMD_VIDEO_FORMAT_AYUV64:
+      info->stride[0] = width * 8;
+      info->size = w * 8 * h;
       break;
     default:                   /* 4-byte packed */
       info->stride[0] = width * 4;
@@ -1147,7 +1155,7 @@ const FastRow g_fast_rows[] = {
   {F_YUY2, F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
   {F_UYVY, F_YUY2, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
   /* convert_scale_planes: every same-format pair, planar <-> planar and the NV12 / NV16 / NV24 family */
-  {F_RGB4A | F_AYUV, ~0ull, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
+  {F_RGB4A | F_AYUV | fbit (GSTAMD_VIDEO_FORMAT_ARGB64) | fbit (GSTAMD_VIDEO_FORMAT_AYUV64), ~0ull, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
   {F_RGB4X | F_RGB3 | F_420 | F_Y42B | F_Y444 | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
         F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_YVYU), ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_420 | F_Y42B | F_Y444, F_420 | F_Y42B | F_Y444, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
@@ -1382,7 +1390,7 @@ TileGeom pass_tile_geom (const ScalePass &pass)
 static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
 {
   if (f->kind == UNPACK_PACKED4)
-    return (uint64_t) w * h * 4;
+    return (uint64_t) w * h * (f->hi_depth == 3 ? 8 : 4);
   if (f->kind == UNPACK_PACKED3)
     return (uint64_t) w * h * 3;
   const uint64_t cw = ((uint64_t) w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) h + (1 << f->h_sub) - 1) >> f->h_sub;
@@ -1571,6 +1579,171 @@ static void deep_planes_try (const GstAmdVideoInfo *in, const GstAmdVideoInfo *o
   g.planes_fast = true;
 }
 
+
+// chain_downsample's decision + the geometry of a planar / semi-planar / 3-byte / packed 4:2:2 destination (the block plan_core fills
+// plan->pack with), for plans that do not run through plan_core's tail
+static void fill_pack_params (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, const FormatDesc *fi, const FormatDesc *fo, const GstAmdVideoConverterConfig &cfg,
+    int full_in_w, int full_in_h, int full_out_w, int full_out_h, PackPlanarParams *pkp)
+{
+  PackPlanarParams &pk = *pkp;
+  memset (&pk, 0, sizeof (pk));
+  pk.width = out->width;
+  pk.height = out->height;
+  pk.kind = fo->kind;
+  memcpy (pk.pos, fo->pos, sizeof (pk.pos));
+  pk.tail_swap = (out->format == GSTAMD_VIDEO_FORMAT_VYUY || out->format == GSTAMD_VIDEO_FORMAT_NV61) && (out->width & 1);
+  pk.w_sub = fo->w_sub;
+  pk.h_sub = fo->h_sub;
+  pk.u_plane = fo->u_plane;
+  pk.v_plane = fo->v_plane;
+  const bool differs = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site || full_in_w != full_out_w ||
+      full_in_h != full_out_h;
+  if (differs && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY) {
+    if (fo->w_sub == 1)
+      pk.down_h = (out->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? 2 : 1;
+    if (fo->h_sub == 1 && !(out->chroma_site & GSTAMD_CHROMA_SITE_V_COSITED))
+      pk.down_v = 1;
+  }
+}
+
+// An ARGB64 / AYUV64 SOURCE (GammaPlan::src64): the frame is the first 16-bit image of the chain; what follows is the composite of the
+// other 16-bit plans - u16 scalers, the convert matrix on 16-bit values, then by destination: the frame itself (store64), the 10-bit packer
+// (pack16), or narrowing + a sub-conversion for the 8-bit tail.  plane_scale: the reference's convert_scale_planes fastpath (same format, no
+// matrix): the 2-D scaler's own pass order.
+static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, VideoPlan *plan, int alpha_bits, bool same_matrix, bool same_primaries, M44 prim_dm,
+    int in_matrix, int out_matrix, bool plane_scale, std::string *error)
+{
+  auto fail = [&](int code, const std::string &msg) {
+    if (error)
+      *error = msg;
+    return code;
+  };
+  const GstAmdVideoConverterConfig &cfg = plan->config;
+  const FormatDesc *fi = plan->fin, *fo = plan->fout;
+  GammaPlan &g = plan->gamma;
+  if (cfg.gamma_mode == GSTAMD_GAMMA_MODE_REMAP && !plane_scale)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "gamma-mode = remap with a 16-bit unpack format is not implemented on the GPU path");
+  if (plan->rect.in_x || plan->rect.in_y || (plan->rect.in_maxw && (plan->rect.in_maxw != in->width || plan->rect.in_maxh != in->height)))
+    return fail (GSTAMD_ERR_UNSUPPORTED, "cropping a 16-bit source is not implemented on the GPU path");
+  if (fo->hi_depth && (plan->rect.out_x || plan->rect.out_y || plan->rect.fill ||
+          (plan->rect.out_maxw && (plan->rect.out_maxw != out->width || plan->rect.out_maxh != out->height))))
+    return fail (GSTAMD_ERR_UNSUPPORTED, "a destination rectangle / borders inside a 16-bit frame are not implemented on the GPU path");
+  if (fo->hi_depth && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path");
+  if (fo->hi_depth == 3 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_quantization > 1)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "dither-quantization > 1 into a 16-bit destination is not implemented on the GPU path");
+  g.on = true;
+  g.src64 = true;
+  g.src16 = false;
+  g.store64 = fo->hi_depth == 3;
+  g.pack16 = fo->hi_depth == 1 || fo->hi_depth == 2;
+  g.fused = g.planes_fast = false;
+  plan->plane_mode = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_post = false;
+  plan->deep16 = plan->deep_out = false;
+  plan->matrix_before_scale = false;
+  plan->vpair.clear ();
+  plan->planes.clear ();
+  memset (&plan->front, 0, sizeof (plan->front));
+  memset (&plan->matrix, 0, sizeof (plan->matrix));
+  memset (&plan->post, 0, sizeof (plan->post));
+  memset (&plan->pack, 0, sizeof (plan->pack));
+  memset (&plan->deep, 0, sizeof (plan->deep));
+  memset (&g.to_rgb, 0, sizeof (g.to_rgb));
+  memset (&g.to_yuv, 0, sizeof (g.to_yuv));
+  memset (&g.prim, 0, sizeof (g.prim));
+  memset (&g.dither16, 0, sizeof (g.dither16));
+  g.dec.clear ();
+  g.enc.clear ();
+  const int in_w = in->width, in_h = in->height, out_w = out->width, out_h = out->height;
+  g.shrink = (long) out_w * out_h <= (long) in_w * in_h;
+  /* the convert stage on 16-bit values (chain_convert with in_bits 16) */
+  if (!plane_scale && (!same_matrix || !same_primaries)) {
+    M44 dm;
+    compute_convert_matrix_depth (in->color_range, in_matrix, out->color_range, out_matrix, fi->yuv, fo->yuv, cfg.matrix_mode, 16, dm,
+        same_primaries ? nullptr : prim_dm, fo->hi_depth ? 16 : 8);
+    if (!m_is_identity (dm)) {
+      m_scale_components (dm, 256.0f, 256.0f, 256.0f);
+      g.prim.has_matrix = 1;
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++)
+          g.prim.im[i][j] = (int) rint (dm[i][j]);
+    }
+  }
+  /* the alpha stage works on the lines the convert stage leaves: 16-bit ones for a 16-bit destination (here), 8-bit ones otherwise (the
+     sub-conversion's) */
+  g.alpha_kind = ALPHA_NONE;
+  g.alpha_value = (unsigned) (int) (255 * cfg.alpha_value);
+  if (fo->hi_depth == 3 && !plane_scale)
+    g.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
+  /* scalers on the 16-bit lines: all of them for a 16-bit destination, the shrinking ones otherwise (an 8-bit tail scales what grows) */
+  plan->passes.clear ();
+  const bool scale_here = (in_w != out_w || in_h != out_h) && (fo->hi_depth != 0 || g.shrink);
+  if (scale_here) {
+    const long s1 = (long) out_w * in_h, s2 = (long) in_w * out_h;
+    bool h_first = s1 <= s2;
+    ScalePass hp, vp;
+    if (in_w != out_w)
+      make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, in_w, out_w, true, &hp, false, true);
+    if (in_h != out_h)
+      make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, in_h, out_h, false, &vp, false, true);
+    hp.max_span = vp.max_span = 1 << 30;
+    if (plane_scale && in_w != out_w && in_h != out_h)
+      h_first = (long) out_w * (long) vp.offset[out_h - 1] <= (long) out_w * out_h;      /* gst_video_scaler_2d */
+    for (int step = 0; step < 2; step++) {
+      const bool horizontal = (step == 0) == h_first;
+      if (horizontal ? in_w != out_w : in_h != out_h)
+        plan->passes.push_back (horizontal ? hp : vp);
+    }
+  }
+  video_info_set_format (&g.mid_in, GSTAMD_VIDEO_FORMAT_AYUV, in_w, in_h);      /* dimensions of the source image */
+  const int full_out_w = plan->rect.out_maxw ? plan->rect.out_maxw : out_w, full_out_h = plan->rect.out_maxh ? plan->rect.out_maxh : out_h;
+  if (fo->hi_depth == 0) {
+    /* narrowing (video_orc_convert_u16_to_u8) into the 8-bit unpack format, then the sub-conversion */
+    const int mw = scale_here || (in_w == out_w && in_h == out_h) ? out_w : in_w, mh = scale_here || (in_w == out_w && in_h == out_h) ? out_h : in_h;
+    if (video_info_set_format (&g.mid_out, fo->yuv ? GSTAMD_VIDEO_FORMAT_AYUV : GSTAMD_VIDEO_FORMAT_ARGB, mw, mh) != GSTAMD_OK)
+      return GSTAMD_ERR_INVALID;
+    g.mid_out.color_range = out->color_range;
+    g.mid_out.color_matrix = out->color_matrix;
+    g.mid_out.chroma_site = out->chroma_site;
+    g.sub_out_info = plan->orig_out;
+    GstAmdVideoConverterConfig sub = cfg;
+    sub.gamma_mode = GSTAMD_GAMMA_MODE_NONE;
+    sub.primaries_mode = GSTAMD_PRIMARIES_MODE_NONE;
+    sub.matrix_mode = GSTAMD_MATRIX_MODE_NONE;
+    sub.internal_flags = 1;
+    sub.src_x = sub.src_y = sub.src_width = sub.src_height = 0;
+    const bool differs = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site || in_w != full_out_w || in_h != full_out_h;
+    const bool down = differs && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY;
+    sub.chroma_mode = down ? GSTAMD_CHROMA_MODE_FULL : GSTAMD_CHROMA_MODE_NONE;
+    g.cfg_out = sub;
+    g.enc.resize (65536);
+    for (int i = 0; i < 65536; i++)
+      g.enc[i] = (uint8_t) (i >> 8);
+  } else {
+    video_info_set_format (&g.mid_out, GSTAMD_VIDEO_FORMAT_AYUV, out_w, out_h);     /* dimensions only */
+    if (g.pack16) {
+      fill_pack_params (in, out, fi, fo, cfg, in_w, in_h, full_out_w, full_out_h, &g.pack);
+      g.pack_hi_depth = fo->hi_depth;
+      if (cfg.dither_method != GSTAMD_DITHER_NONE) {
+        unsigned q = 1u << 6;
+        if (cfg.dither_quantization > q)
+          q = cfg.dither_quantization;
+        int shift = 0;
+        for (unsigned v = q; v > 1; v >>= 1)
+          shift++;
+        g.dither16.on = 1;
+        g.dither16.method = cfg.dither_method;
+        g.dither16.shift[1] = g.dither16.shift[2] = g.dither16.shift[3] = shift;
+      }
+    }
+  }
+  plan->algorithmic_bytes = picture_bytes (fi, in_w, in_h) + picture_bytes (fo, out_w, out_h);
+  plan->description = std::string ("deep64[") + fi->name + "->" + fo->name + (g.prim.has_matrix ? ",matrix16" : "") +
+      (plan->passes.empty () ? "" : g.shrink ? ",scale16(first)" : ",scale16(last)") +
+      (g.store64 ? ",store64" : g.pack16 ? ",pack16" : ",narrow") + (plane_scale ? "]{as convert_scale_planes}" : "]");
+  return GSTAMD_OK;
+}
+
 // A 10-bit destination (GammaPlan with pack16): called at the end of plan_core, whose front / vpair / passes / pack it keeps where they
 // apply (10-bit source) and replaces by a sub-conversion into the 8-bit unpack format where they do not (8-bit source).
 static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, VideoPlan *plan, bool same_matrix, bool same_primaries, M44 prim_dm,
@@ -1579,14 +1752,20 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   const GstAmdVideoConverterConfig &cfg = plan->config;
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
-  if (!kind_has_planes (fo->kind)) {
+  if (!kind_has_planes (fo->kind) && fo->hi_depth != 3) {
     if (error)
       *error = "10-bit destination layout not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
   }
   g.on = true;
-  g.pack16 = true;
+  g.store64 = fo->hi_depth == 3;
+  g.pack16 = !g.store64;
   g.src16 = fi->hi_depth != 0;
+  if (g.store64 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_quantization > 1) {
+    if (error)
+      *error = "dither-quantization > 1 into a 16-bit destination is not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
   g.pack = plan->pack;
   g.pack_hi_depth = fo->hi_depth;
   const int in_w = in->width, in_h = in->height, out_w = out->width, out_h = out->height;
@@ -1611,7 +1790,7 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   g.alpha_value = (unsigned) (int) (255 * cfg.alpha_value);
   /* chain_dither (:2035-2085) on 16-bit lines: quantiser 1 << (16 - depth), or the target quantiser when that is coarser */
   memset (&g.dither16, 0, sizeof (g.dither16));
-  if (cfg.dither_method != GSTAMD_DITHER_NONE) {
+  if (cfg.dither_method != GSTAMD_DITHER_NONE && !g.store64) {
     const int depth = 10;
     unsigned q = 1u << (16 - depth);
     if (cfg.dither_quantization > q)
@@ -1677,6 +1856,11 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   deep_planes_try (in, out, plan, g.pack.down_h || g.pack.down_v || plan->front.chroma_h != CHROMA_H_NONE || plan->front.chroma_v2);
   if (g.planes_fast) {
     plan->description = std::string ("deep_planes[") + fi->name + "->" + fo->name + (g.dither16.on ? ",dither" : "") + "]";
+    return GSTAMD_OK;
+  }
+  if (g.store64) {
+    plan->description = std::string ("deep_out[") + fi->name + "->" + fo->name + (g.src16 ? ",front16" : ",widen") + (g.prim.has_matrix ? ",matrix16" : "") +
+        (plan->passes.empty () ? "" : g.shrink ? ",scale16(first)" : ",scale16(last)") + ",store64]";
     return GSTAMD_OK;
   }
   plan->description = std::string ("deep_out[") + fi->name + "->" + fo->name + (g.src16 ? ",front16" : ",widen") + (g.prim.has_matrix ? ",matrix16" : "") +
@@ -1870,6 +2054,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     if (!fp)
       return plan_gamma (in, out, plan, alpha_bits, same_primaries, prim_dm, error);
   }
+  if (plan->fin->hi_depth == 3)
+    return plan_src64 (in, out, plan, alpha_bits, same_matrix, same_primaries, prim_dm, in_matrix, out_matrix, fp != nullptr, error);
   if (fp) {
     const std::string name = fp;
     const int ki = plan->fin->kind, ko = plan->fout->kind;

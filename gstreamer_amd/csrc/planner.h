@@ -34,7 +34,8 @@ struct FormatDesc {
   int u_plane, v_plane; // planar: plane index of U and V; semi: u_first (1) / v_first (0) in u_plane
   int pos[4];           // packed4 / packed3: memory byte index of unpacked component 0..3 (A,R,G,B / A,Y,U,V; packed3 has no A);
                         // packed422: byte of Y0, U, V inside the macropixel in pos[1..3] (Y1 is at pos[1] + 2)
-  int hi_depth;         // 0: 8-bit samples.  1 / 2: 10-bit samples in little-endian 16-bit words, in the low bits (I420_10LE) / the
+  int hi_depth;         // 0: 8-bit samples.  3: 4 x 16-bit components per pixel (ARGB64 / AYUV64; kind UNPACK_PACKED4 with 8-byte pixels).
+                        // 1 / 2: 10-bit samples in little-endian 16-bit words, in the low bits (I420_10LE) / the
                         // high bits (P010_10LE); such formats unpack to AYUV64 in the reference (video-format.c:3836, 5331)
 };
 const FormatDesc *format_desc (int format);
@@ -196,6 +197,8 @@ struct RectPlan {
 struct GammaPlan {
   bool on = false;
   bool src16 = false;           // the source is 10-bit: k_front16 of this plan's front / vpair makes the first ARGB64 / AYUV64 image
+  bool src64 = false;           // the source is ARGB64 / AYUV64: the frame itself is the first 16-bit image
+  bool store64 = false;         // the destination is ARGB64 / AYUV64: the last 16-bit image is the frame
   bool pack16 = false;          // the destination is 10-bit: pack16_body finishes
   PackPlanarParams pack;        // pack16: geometry and chroma downsampler of the destination
   int pack_hi_depth;            // FormatDesc::hi_depth of the destination
@@ -255,7 +258,7 @@ struct VideoPlan {
 inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int stride)
 {
   if (f->kind == UNPACK_PACKED4)
-    return (size_t) y * stride + (size_t) x * 4;
+    return (size_t) y * stride + (size_t) x * (f->hi_depth == 3 ? 8 : 4);
   if (f->kind == UNPACK_PACKED3)
     return (size_t) y * stride + (size_t) x * 3;
   if (f->kind == UNPACK_PACKED422)

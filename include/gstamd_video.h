@@ -59,6 +59,8 @@ enum {
   GSTAMD_VIDEO_FORMAT_NV21 = 24,
   GSTAMD_VIDEO_FORMAT_NV16 = 51,
   GSTAMD_VIDEO_FORMAT_NV24 = 52,
+  GSTAMD_VIDEO_FORMAT_ARGB64 = 39,      /* 16 bits per component, native endianness (little endian here), memory order A R G B */
+  GSTAMD_VIDEO_FORMAT_AYUV64 = 40,      /* the same with A Y U V */
   GSTAMD_VIDEO_FORMAT_I420_10LE = 43,   /* 10 bits in the low bits of little-endian 16-bit words; see DESIGN.md 3.6 / 3.7 for the combinations */
   GSTAMD_VIDEO_FORMAT_NV61 = 60,
   GSTAMD_VIDEO_FORMAT_P010_10LE = 62,   /* 10 bits in the high bits of little-endian 16-bit words */

@@ -432,6 +432,32 @@ VIDEO_CASES = [
     ("yuy2_yuy2_mixed_lanczos_merged", "YUY2", 200, 100, "YUY2", 300, 50, LAN, None, None, "random"),
     ("yuy2_yuy2_honly_odd_merged", "YUY2", 201, 100, "YUY2", 99, 100, LIN, None, None, "random"),
     ("vyuy_vyuy_honly_cubic_merged", "VYUY", 320, 100, "VYUY", 200, 100, {}, None, None, "random"),
+    # ARGB64 / AYUV64 (16 bits per component, packed): sources (the frame is the first image of the 16-bit chain), destinations (the last
+    # image is the frame), the same-format plane scaler with the 2-D scaler's pass order, 16-bit alpha modes
+    ("w64_argb64_copy", "ARGB64", 64, 48, "ARGB64", 64, 48, {}, None, None, "random"),
+    ("w64_ayuv64_argb64", "AYUV64", 65, 33, "ARGB64", 65, 33, {}, None, None, "random"),
+    ("w64_argb64_ayuv64_bt709", "ARGB64", 64, 48, "AYUV64", 64, 48, {}, "sRGB>bt709", None, "random"),
+    ("w64_argb64_bgra", "ARGB64", 64, 48, "BGRA", 64, 48, {}, None, None, "random"),
+    ("w64_ayuv64_nv12", "AYUV64", 64, 48, "NV12", 64, 48, {}, None, None, "random"),
+    ("w64_ayuv64_p010", "AYUV64", 64, 48, "P010_10LE", 64, 48, {}, None, None, "random"),
+    ("w64_argb64_i420_10", "ARGB64", 64, 48, "I420_10LE", 64, 48, {}, None, None, "random"),
+    ("w64_nv12_ayuv64", "NV12", 64, 48, "AYUV64", 64, 48, {}, None, None, "random"),
+    ("w64_bgra_argb64_odd", "BGRA", 65, 33, "ARGB64", 65, 33, {}, None, None, "random"),
+    ("w64_p010_ayuv64", "P010_10LE", 64, 48, "AYUV64", 64, 48, {}, None, None, "random"),
+    ("w64_i420_10_argb64", "I420_10LE", 64, 48, "ARGB64", 64, 48, {}, None, None, "random"),
+    ("w64_argb64_half_lanczos_planes", "ARGB64", 128, 96, "ARGB64", 64, 48, LAN, None, None, "random"),
+    ("w64_argb64_grow_bilinear_planes", "ARGB64", 64, 48, "ARGB64", 160, 100, LIN, None, None, "random"),
+    ("w64_ayuv64_mixed_cubic_planes", "AYUV64", 200, 100, "AYUV64", 120, 260, {}, None, None, "random"),
+    ("w64_argb64_bgra_half_lanczos", "ARGB64", 128, 96, "BGRA", 64, 48, LAN, None, None, "random"),
+    ("w64_argb64_rgba_grow_cubic", "ARGB64", 64, 48, "RGBA", 160, 100, {}, None, None, "random"),
+    ("w64_nv12_ayuv64_half_lanczos", "NV12", 128, 96, "AYUV64", 64, 48, LAN, None, None, "random"),
+    ("w64_bgra_argb64_grow_cubic", "BGRA", 64, 48, "ARGB64", 160, 100, {}, None, None, "random"),
+    ("w64_argb64_alpha_set", "ARGB64", 64, 48, "ARGB64", 64, 48, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+    ("w64_bgra_argb64_alpha_mult", "BGRA", 64, 48, "ARGB64", 64, 48, dict(alpha_mode="mult", alpha_value=0.5), None, None, "random"),
+    ("w64_argb64_abgr_alpha_mult", "ARGB64", 64, 48, "ABGR", 64, 48, dict(alpha_mode="mult", alpha_value=0.5), None, None, "random"),
+    ("w64_ayuv64_i420_half_bilinear", "AYUV64", 64, 48, "I420", 32, 24, LIN, None, None, "random"),
+    ("w64_bgra_ayuv64_alpha_set_matrix", "BGRA", 64, 48, "AYUV64", 64, 48, dict(alpha_mode="set", alpha_value=0.25), None, None, "random"),
+    ("w64_argb64_1080p_to_720p", "ARGB64", 1920, 1080, "ARGB64", 1280, 720, LIN, None, None, "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd

@@ -754,7 +754,11 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     const size_t n = p.passes.size ();
     bool mid_done = !has_mid;
     Deep16Image cur = {nullptr, 0, 0, 0};
-    if (g.src16) {
+    bool cur_is_source = false;
+    if (g.src64) {
+      cur.p = src + in->offset[0], cur.stride = in->stride[0], cur.width = in_w, cur.height = in_h;
+      cur_is_source = true;
+    } else if (g.src16) {
       Planes pl;
       memset (&pl, 0, sizeof (pl));
       for (int i = 0; i < in->n_planes; i++) {
@@ -770,7 +774,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       mid_a.resize ((size_t) in_w * in_h * 4);
       if ((r = emu_video_convert (&g.sub_in_info, &g.mid_in, &g.cfg_in, src, mid_a.data (), vec_ok, nullptr, 0)) != GSTAMD_OK)
         return r;
-      if (n == 0 && !g.pack16) {
+      if (n == 0 && !g.pack16 && !g.store64) {
         mid_b.resize ((size_t) out_w * out_h * 4);
         stage (GAMMA_STAGE_DEC | GAMMA_STAGE_MID | GAMMA_STAGE_ENC, mid_a.data (), in_w * 4, mid_b.data (), out_w * 4, out_w, out_h);
       } else {
@@ -783,7 +787,14 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     }
     if (cur.p) {
       if (!mid_done && (n == 0 || !g.shrink)) {
-        stage (GAMMA_STAGE_MID, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height);
+        if (cur_is_source) {
+          a.resize ((size_t) cur.width * cur.height * 8);
+          stage (GAMMA_STAGE_MID, cur.p, cur.stride, a.data (), cur.width * 8, cur.width, cur.height);
+          cur.p = a.data (), cur.stride = cur.width * 8;
+          cur_is_source = false;
+        } else {
+          stage (GAMMA_STAGE_MID, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height);
+        }
         mid_done = true;
       }
       for (size_t i = 0; i < n; i++) {
@@ -803,14 +814,25 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         b.swap (next);
         a.swap (b);
         cur.p = a.data (), cur.stride = ow * 8, cur.width = ow, cur.height = oh;
+        cur_is_source = false;
       }
-      if (g.pack16) {
-        if (!mid_done)
+      if (g.pack16 || g.store64) {
+        if (!mid_done && cur_is_source) {
+          a.resize ((size_t) cur.width * cur.height * 8);
+          stage (GAMMA_STAGE_MID, cur.p, cur.stride, a.data (), cur.width * 8, cur.width, cur.height);
+          cur.p = a.data (), cur.stride = cur.width * 8;
+        } else if (!mid_done) {
           stage (GAMMA_STAGE_MID, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height);
+        }
       } else {
         mid_b.resize ((size_t) out_w * out_h * 4);
         stage ((mid_done ? 0 : GAMMA_STAGE_MID) | GAMMA_STAGE_ENC, cur.p, cur.stride, mid_b.data (), out_w * 4, out_w, out_h);
       }
+    }
+    if (g.store64) {
+      for (int y = 0; y < out_h; y++)
+        memcpy (dst + out->offset[0] + (size_t) y * out->stride[0], cur.p + (size_t) y * cur.stride, (size_t) out_w * 8);
+      return GSTAMD_OK;
     }
     if (g.pack16) {
       DstPlanes16 d;

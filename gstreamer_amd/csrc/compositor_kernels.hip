@@ -14,6 +14,7 @@
 #include "../../include/gstamd_video.h"
 #include "compositor_device.h"
 #include "compositor_planes.h"
+#include "compositor_wide.h"
 
 using namespace gstamd;
 
@@ -162,6 +163,14 @@ __global__ __launch_bounds__ (64) void k_aggregate_strip (AggregateParams p, uin
 }
 #endif
 
+/* ARGB64 / AYUV64 canvases: one lane per destination pixel (compositor_wide.h) */
+__global__ __launch_bounds__ (64) void k_aggregate64 (Wide64Params p, uint8_t *dst, int dstride, int rx0, int ry0, int rw)
+{
+  const int x = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+  if (x < rw)
+    wide64_px (p, dst, dstride, rx0 + x, ry0 + (int) blockIdx.y);
+}
+
 static thread_local std::string g_comp_error;
 extern "C" const char *gstamd_last_error (void);
 
@@ -263,6 +272,31 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
   return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
 }
 
+static bool is_wide64 (int format)
+{
+  return format == GSTAMD_VIDEO_FORMAT_ARGB64 || format == GSTAMD_VIDEO_FORMAT_AYUV64;
+}
+
+static int wide64_alpha (double a)
+{
+  /* s_alpha = CLAMP ((gint) (src_alpha * G_MAXUINT16), 0, G_MAXUINT16) (blend.c:1202) */
+  const int s = (int) (a * 65535);
+  return s < 0 ? 0 : (s > 65535 ? 65535 : s);
+}
+
+static int launch64 (const Wide64Params &p, void *dest, int dstride, int rx0, int ry0, int rw, int rh, void *stream)
+{
+  if (rw <= 0 || rh <= 0)
+    return GSTAMD_OK;
+  hipLaunchKernelGGL (k_aggregate64, dim3 ((rw + 63) / 64, rh), dim3 (64), 0, (hipStream_t) stream, p, (uint8_t *) dest, dstride, rx0, ry0, rw);
+  return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
+}
+
+static uint64_t wide64_color (int c1, int c2, int c3)
+{
+  return 0xffffull | ((uint64_t) (c1 & 0xffff) << 16) | ((uint64_t) (c2 & 0xffff) << 32) | ((uint64_t) (c3 & 0xffff) << 48);
+}
+
 /* fill_color_* word (blend.c:218-240): GUINT32_FROM_BE ((0xff << A) | (c1 << C1) | (c2 << C2) | (c3 << C3)) */
 static bool color_word (int format, int c1, int c2, int c3, uint32_t *out)
 {
@@ -289,6 +323,31 @@ extern "C" {
 int gstamd_compositor_blend (int format, int overlay, const void *src, int sw, int sh, int sstride, int xpos, int ypos,
     double src_alpha, void *dest, int dw, int dh, int dstride, int dst_y_start, int dst_y_end, int mode, void *stream)
 {
+  if (is_wide64 (format)) {
+    if (!src || !dest)
+      return GSTAMD_ERR_INVALID;
+    const int a64 = wide64_alpha (src_alpha);
+    if (a64 == 0)
+      return GSTAMD_OK;
+    if (dst_y_end > dh)
+      dst_y_end = dh;
+    const int wx0 = xpos < 0 ? 0 : xpos, wy0 = ypos < dst_y_start ? dst_y_start : ypos;
+    const int wx1 = xpos + sw > dw ? dw : xpos + sw, wy1 = ypos + sh > dst_y_end ? dst_y_end : ypos + sh;
+    Wide64Params w;
+    memset (&w, 0, sizeof (w));
+    w.overlay = overlay ? 1 : 0;
+    w.bg_kind = 2;
+    w.n_pads = 1;
+    w.pads[0].data = (const uint8_t *) src;
+    w.pads[0].width = sw;
+    w.pads[0].height = sh;
+    w.pads[0].stride = sstride;
+    w.pads[0].xpos = xpos;
+    w.pads[0].ypos = ypos;
+    w.pads[0].s_alpha = a64;
+    w.pads[0].mode = mode;
+    return launch64 (w, dest, dstride, wx0, wy0, wx1 - wx0, wy1 - wy0, stream);
+  }
   const int ashift = family_ashift (format);
   if (ashift < 0 || !src || !dest)
     return GSTAMD_ERR_INVALID;
@@ -320,6 +379,13 @@ int gstamd_compositor_blend (int format, int overlay, const void *src, int sw, i
 
 int gstamd_compositor_fill_checker (int format, void *dest, int dw, int dh, int dstride, int y_start, int y_end, void *stream)
 {
+  if (is_wide64 (format) && dest) {
+    Wide64Params w;
+    memset (&w, 0, sizeof (w));
+    w.bg_kind = 0;
+    w.checker_yuv = format == GSTAMD_VIDEO_FORMAT_AYUV64;
+    return launch64 (w, dest, dstride, 0, y_start, dw, y_end - y_start, stream);
+  }
   const int ashift = family_ashift (format);
   if (ashift < 0 || !dest)
     return GSTAMD_ERR_INVALID;
@@ -334,6 +400,14 @@ int gstamd_compositor_fill_checker (int format, void *dest, int dw, int dh, int 
 int gstamd_compositor_fill_color (int format, void *dest, int dw, int dh, int dstride, int y_start, int y_end, int c1,
     int c2, int c3, void *stream)
 {
+  if (is_wide64 (format) && dest) {
+    /* fill_color_argb64 (blend.c:1354-1384): the picture's pixels, 16-bit components */
+    Wide64Params w;
+    memset (&w, 0, sizeof (w));
+    w.bg_kind = 1;
+    w.bg_px = wide64_color (c1, c2, c3);
+    return launch64 (w, dest, dstride, 0, y_start, dw, y_end - y_start, stream);
+  }
   AggregateParams p;
   memset (&p, 0, sizeof (p));
   if (!dest || !color_word (format, c1, c2, c3, &p.bg_word))
@@ -347,6 +421,60 @@ int gstamd_compositor_fill_color (int format, void *dest, int dw, int dh, int ds
 int gstamd_compositor_aggregate (int format, int background, const GstAmdCompositorPad *pads, int n_pads, void *dest,
     int dw, int dh, int dstride, void *stream)
 {
+  if (is_wide64 (format)) {
+    if (!dest || (n_pads > 0 && !pads))
+      return GSTAMD_ERR_INVALID;
+    Wide64Params w;
+    memset (&w, 0, sizeof (w));
+    w.overlay = background == GSTAMD_COMPOSITOR_BACKGROUND_TRANSPARENT;
+    const bool yuv64 = format == GSTAMD_VIDEO_FORMAT_AYUV64;
+    switch (background) {
+      case GSTAMD_COMPOSITOR_BACKGROUND_CHECKER:
+        w.bg_kind = 0;
+        w.checker_yuv = yuv64;
+        break;
+      case GSTAMD_COMPOSITOR_BACKGROUND_BLACK:    /* gst_video_color_range_offsets on 16 bits (compositor.c:1131-1149) */
+        w.bg_kind = 1;
+        w.bg_px = yuv64 ? wide64_color (16 << 8, 128 << 8, 128 << 8) : wide64_color (0, 0, 0);
+        break;
+      case GSTAMD_COMPOSITOR_BACKGROUND_WHITE:
+        w.bg_kind = 1;
+        w.bg_px = yuv64 ? wide64_color (235 << 8, 128 << 8, 128 << 8) : wide64_color (65535, 65535, 65535);
+        break;
+      case GSTAMD_COMPOSITOR_BACKGROUND_TRANSPARENT:
+        w.bg_kind = 1;
+        w.bg_px = 0;
+        break;
+      default:
+        return GSTAMD_ERR_INVALID;
+    }
+    int wdone = 0;
+    bool wfirst = true;
+    while (wfirst || wdone < n_pads) {
+      w.n_pads = 0;
+      while (wdone < n_pads && w.n_pads < GSTAMD_MAX_FUSED_PADS) {
+        const GstAmdCompositorPad &in = pads[wdone++];
+        const int a64 = wide64_alpha (in.alpha);
+        if (a64 == 0 || !in.data)
+          continue;
+        PadDev &pd = w.pads[w.n_pads++];
+        pd.data = (const uint8_t *) in.data;
+        pd.width = in.width;
+        pd.height = in.height;
+        pd.stride = in.stride;
+        pd.xpos = in.xpos;
+        pd.ypos = in.ypos;
+        pd.s_alpha = a64;
+        pd.mode = in.blend_mode;
+      }
+      const int r = launch64 (w, dest, dstride, 0, 0, dw, dh, stream);
+      if (r != GSTAMD_OK)
+        return r;
+      w.bg_kind = 2;
+      wfirst = false;
+    }
+    return GSTAMD_OK;
+  }
   const int ashift = family_ashift (format);
   if (ashift < 0 || !dest || (n_pads > 0 && !pads))
     return GSTAMD_ERR_INVALID;

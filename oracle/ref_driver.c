@@ -263,6 +263,10 @@ ref_compositor_blend (const char *func, const char *format, const guint8 * src, 
     fn = gst_compositor_blend_xrgb;
   else if (!strcmp (func, "blend_rgb"))
     fn = gst_compositor_blend_rgb;
+  else if (!strcmp (func, "blend_argb64"))
+    fn = gst_compositor_blend_argb64;
+  else if (!strcmp (func, "overlay_argb64"))
+    fn = gst_compositor_overlay_argb64;
   if (!fn)
     return -1;
   if (!map_simple (&sf, &si, &sb, format, sw, sh, (guint8 *) src, src_size, FALSE))
@@ -312,6 +316,10 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
       fn = gst_compositor_fill_checker_rgb;
     else if (!strcmp (fmt_func, "bgr"))
       fn = gst_compositor_fill_checker_bgr;
+    else if (!strcmp (fmt_func, "argb64"))
+      fn = gst_compositor_fill_checker_argb64;
+    else if (!strcmp (fmt_func, "ayuv64"))
+      fn = gst_compositor_fill_checker_ayuv64;
     if (!fn)
       return -1;
     fn (&df, y0, y1);
@@ -343,6 +351,8 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
       fn = gst_compositor_fill_color_rgb;
     else if (!strcmp (fmt_func, "bgr"))
       fn = gst_compositor_fill_color_bgr;
+    else if (!strcmp (fmt_func, "argb64"))
+      fn = gst_compositor_fill_color_argb64;
     if (!fn)
       return -1;
     fn (&df, y0, y1, c1, c2, c3);

@@ -35,10 +35,10 @@
 GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
 #define GST_CAT_DEFAULT amd_comp_debug
 
-#define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR }"
+#define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR }"
 /* what a pad may carry: anything the converter takes; it is brought to the output format / the pad's width x height by a
  * per-pad GstAmdVideoConverter (the reference's GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) */
-#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY }"
+#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY }"
 #define AMD_COMP_MAX_PADS 64
 
 static GstStaticPadTemplate comp_sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
@@ -297,6 +297,9 @@ amd_format_of (GstVideoFormat f)
     case GST_VIDEO_FORMAT_ARGB: return GSTAMD_VIDEO_FORMAT_ARGB;
     case GST_VIDEO_FORMAT_ABGR: return GSTAMD_VIDEO_FORMAT_ABGR;
     case GST_VIDEO_FORMAT_AYUV: return GSTAMD_VIDEO_FORMAT_AYUV;
+    /* 16 bits per component: blend_argb64 / overlay_argb64 (compositor.c:1048-1059) */
+    case GST_VIDEO_FORMAT_ARGB64: return GSTAMD_VIDEO_FORMAT_ARGB64;
+    case GST_VIDEO_FORMAT_AYUV64: return GSTAMD_VIDEO_FORMAT_AYUV64;
     /* outputs without per-pixel alpha: pads are blended plane by plane (gstamd_compositor_aggregate_frame) */
     case GST_VIDEO_FORMAT_I420: return GSTAMD_VIDEO_FORMAT_I420;
     case GST_VIDEO_FORMAT_YV12: return GSTAMD_VIDEO_FORMAT_YV12;

@@ -161,3 +161,15 @@ extern "C" int emu_compositor_aggregate_frame (int format, int background, const
   }
   return 0;
 }
+
+// ---- ARGB64 / AYUV64 canvases (compositor_wide.h): k_aggregate64's grid
+#include "../../gstreamer_amd/csrc/compositor_wide.h"
+
+extern "C" int emu_sizeof_wide64 (void) { return (int) sizeof (Wide64Params); }
+
+extern "C" void emu_compositor_wide64 (const Wide64Params *p, uint8_t *dst, int dstride, int rx0, int ry0, int rw, int rh)
+{
+  for (int y = 0; y < rh; y++)
+    for (int x = 0; x < rw; x++)
+      wide64_px (*p, dst, dstride, rx0 + x, ry0 + y);
+}

@@ -387,3 +387,143 @@ def test_hip_aggregate_frame_matches_reference(native_lib, gpu, ref, fmt, backgr
     torch.cuda.synchronize()
     exp = _frame_expected(ref, fmt, background)
     assert (_visible(fmt, d.cpu().numpy()) == _visible(fmt, exp)).all()
+
+
+# ---- ARGB64 / AYUV64 canvases (compositor_wide.h) against blend_argb64 / overlay_argb64 / fill_*_argb64 ---------------------------------
+class Wide64Params(C.Structure):
+    _fields_ = [("overlay", C.c_int), ("bg_kind", C.c_int), ("checker_yuv", C.c_int), ("bg_px", C.c_uint64), ("n_pads", C.c_int),
+                ("pads", PadDev * 32)]
+
+
+WIDE_CASES = []
+for fmt in ("ARGB64", "AYUV64"):
+    for overlay in (0, 1):
+        for mode in (0, 1, 2):
+            for alpha in (1.0, 0.5, 0.3, 0.00002, 0.0):
+                WIDE_CASES.append((fmt, overlay, 37, 21, 64, 48, 5 if overlay else -9, 7 if overlay else -4, alpha, mode, 0, 48))
+WIDE_CASES += [("ARGB64", 0, 100, 80, 64, 48, 40, 30, 0.7, 1, 10, 40), ("ARGB64", 1, 100, 80, 64, 48, -20, -30, 0.7, 2, 10, 40),
+               ("AYUV64", 0, 10, 10, 64, 48, 70, 30, 0.7, 1, 0, 48), ("AYUV64", 0, 64, 48, 64, 48, 0, 0, 1.0, 0, 0, 60)]
+
+
+def wide_inputs(case, i):
+    fmt, overlay, sw, sh, dw, dh = case[:6]
+    src, dst = cases.frame_bytes(sw * sh * 8, "random", 1500 + i), cases.frame_bytes(dw * dh * 8, "random", 1900 + i)
+    if i % 4 == 1:      # fully transparent / opaque alphas: the "final alpha 0" branch of the overlay functions
+        src.view(np.uint16)[::4][::3] = 0
+        dst.view(np.uint16)[::4][::2] = 0
+        src.view(np.uint16)[::4][1::3] = 65535
+    return src, dst
+
+
+def ref_wide_blend(ref, case, src, dst):
+    fmt, overlay, sw, sh, dw, dh, xpos, ypos, alpha, mode, y0, y1 = case
+    return ref.compositor_blend("overlay_argb64" if overlay else "blend_argb64", fmt, src, sw, sh, xpos, ypos, alpha, dst, dw, dh, y0, y1, mode)
+
+
+def wide_id(c):
+    return "%s_%d_%s_m%d" % (c[1][0], c[1][1], c[1][8], c[1][9])
+
+
+@pytest.mark.parametrize("i_case", list(enumerate(WIDE_CASES)), ids=wide_id)
+def test_wide64_body_on_host_matches_reference(emu_lib, ref, i_case):
+    i, case = i_case
+    fmt, overlay, sw, sh, dw, dh, xpos, ypos, alpha, mode, y0, y1 = case
+    emu_lib.emu_compositor_wide64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    assert C.sizeof(Wide64Params) == emu_lib.emu_sizeof_wide64()
+    src, dst = wide_inputs(case, i)
+    exp = ref_wide_blend(ref, case, src, dst.copy())
+    got = dst.copy()
+    sa = max(0, min(65535, int(alpha * 65535)))
+    if sa:
+        p = Wide64Params()
+        p.overlay, p.bg_kind, p.n_pads = overlay, 2, 1
+        pd = p.pads[0]
+        pd.data, pd.width, pd.height, pd.stride, pd.xpos, pd.ypos, pd.s_alpha, pd.mode = src.ctypes.data, sw, sh, sw * 8, xpos, ypos, sa, mode
+        x0, r0, x1, r1 = max(xpos, 0), max(ypos, y0), min(xpos + sw, dw), min(ypos + sh, min(y1, dh))
+        if x1 > x0 and r1 > r0:
+            emu_lib.emu_compositor_wide64(C.byref(p), got.ctypes.data, dw * 8, x0, r0, x1 - x0, r1 - r0)
+    assert (exp == got).all()
+
+
+def test_wide64_fills_on_host_match_reference(emu_lib, ref):
+    emu_lib.emu_compositor_wide64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    w, h = 70, 33
+    for fmt in ("ARGB64", "AYUV64"):
+        exp, got = np.zeros(w * h * 8, np.uint8), np.zeros(w * h * 8, np.uint8)
+        ref.compositor_fill(0, fmt.lower(), fmt, exp, w, h, 3, 30)
+        p = Wide64Params()
+        p.bg_kind, p.checker_yuv = 0, int(fmt == "AYUV64")
+        emu_lib.emu_compositor_wide64(C.byref(p), got.ctypes.data, w * 8, 0, 3, w, 27)
+        assert (exp == got).all()
+        exp[:] = 0
+        got[:] = 0
+        ref.compositor_fill(1, "argb64", fmt, exp, w, h, 2, 31, 4096, 51234, 777)
+        p = Wide64Params()
+        p.bg_kind, p.bg_px = 1, 0xffff | (4096 << 16) | (51234 << 32) | (777 << 48)
+        emu_lib.emu_compositor_wide64(C.byref(p), got.ctypes.data, w * 8, 0, 2, w, 29)
+        assert (exp == got).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i_case", list(enumerate(WIDE_CASES)), ids=wide_id)
+def test_hip_wide64_blend_matches_reference(native_lib, gpu, ref, i_case):
+    import torch
+    i, case = i_case
+    fmt, overlay, sw, sh, dw, dh, xpos, ypos, alpha, mode, y0, y1 = case
+    src, dst = wide_inputs(case, i)
+    exp = ref_wide_blend(ref, case, src, dst.copy())
+    d_src, d_dst = torch.from_numpy(src).to(gpu), torch.from_numpy(dst).to(gpu)
+    r = V.lib().gstamd_compositor_blend(V.FORMATS[fmt], overlay, d_src.data_ptr(), sw, sh, sw * 8, xpos, ypos, alpha,
+                                        d_dst.data_ptr(), dw, dh, dw * 8, y0, y1, mode, None)
+    assert r == 0
+    torch.cuda.synchronize()
+    assert (d_dst.cpu().numpy() == exp).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["ARGB64", "AYUV64"])
+def test_hip_wide64_fills_match_reference(native_lib, gpu, ref, fmt):
+    import torch
+    w, h = 70, 33
+    exp = np.zeros(w * h * 8, np.uint8)
+    d = torch.zeros(w * h * 8, dtype=torch.uint8, device=gpu)
+    ref.compositor_fill(0, fmt.lower(), fmt, exp, w, h, 3, 30)
+    assert V.lib().gstamd_compositor_fill_checker(V.FORMATS[fmt], d.data_ptr(), w, h, w * 8, 3, 30, None) == 0
+    torch.cuda.synchronize()
+    assert (d.cpu().numpy() == exp).all()
+    exp[:] = 0
+    d.zero_()
+    ref.compositor_fill(1, "argb64", fmt, exp, w, h, 2, 31, 4096, 51234, 777)
+    assert V.lib().gstamd_compositor_fill_color(V.FORMATS[fmt], d.data_ptr(), w, h, w * 8, 2, 31, 4096, 51234, 777, None) == 0
+    torch.cuda.synchronize()
+    assert (d.cpu().numpy() == exp).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,background", [("ARGB64", 0), ("AYUV64", 0), ("ARGB64", 1), ("AYUV64", 2), ("ARGB64", 3), ("AYUV64", 3)])
+def test_hip_wide64_aggregate_matches_reference_loop(native_lib, gpu, ref, fmt, background):
+    """the whole blend_pads loop (compositor.c:1641-1697) on a 64-bit canvas: background, then 40 pads in order (two chunks of the pad table)"""
+    import torch
+    dw, dh, pw, ph, n_pads = 200, 120, 48, 30, 40
+    yuv = fmt == "AYUV64"
+    geo = [((i % 7) * 29 - 11, (i // 7) * 21 - 7, min(1.0, 0.2 + 0.03 * i), i % 3) for i in range(n_pads)]
+    pads_np = [cases.frame_bytes(pw * ph * 8, "random", 3100 + i) for i in range(n_pads)]
+    exp = np.zeros(dw * dh * 8, np.uint8)
+    if background == 0:
+        ref.compositor_fill(0, fmt.lower(), fmt, exp, dw, dh, 0, dh)
+    elif background == 1:
+        ref.compositor_fill(1, "argb64", fmt, exp, dw, dh, 0, dh, *((4096, 32768, 32768) if yuv else (0, 0, 0)))
+    elif background == 2:
+        ref.compositor_fill(1, "argb64", fmt, exp, dw, dh, 0, dh, *((60160, 32768, 32768) if yuv else (65535, 65535, 65535)))
+    func = "overlay_argb64" if background == 3 else "blend_argb64"
+    for i, (xpos, ypos, alpha, mode) in enumerate(geo):
+        ref.compositor_blend(func, fmt, pads_np[i], pw, ph, xpos, ypos, alpha, exp, dw, dh, 0, dh, mode)
+    d_pads = [torch.from_numpy(p).to(gpu) for p in pads_np]
+    arr = (V.CompositorPad * n_pads)()
+    for i, (xpos, ypos, alpha, mode) in enumerate(geo):
+        arr[i].data, arr[i].width, arr[i].height, arr[i].stride = d_pads[i].data_ptr(), pw, ph, pw * 8
+        arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = xpos, ypos, alpha, mode
+    d = torch.empty(dw * dh * 8, dtype=torch.uint8, device=gpu)
+    assert V.lib().gstamd_compositor_aggregate(V.FORMATS[fmt], background, arr, n_pads, d.data_ptr(), dw, dh, dw * 8, None) == 0
+    torch.cuda.synchronize()
+    assert (d.cpu().numpy() == exp).all()

@@ -241,6 +241,32 @@ def test_compositor_element_scales_and_converts_pads(gst_env, ref):
         assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
 
 
+def test_compositor_element_on_a_64_bit_canvas(gst_env, ref):
+    """ARGB64 output (compositor.c:1048-1053: blend_argb64 / overlay_argb64, 16-bit fills): an ARGB64 pad as it is and a BGRA
+    pad brought to ARGB64 by the pad's converter, over the checker and over the transparent background."""
+    env, tmp = gst_env
+    n, dw, dh = 2, 320, 240
+    f0, f1 = tmp / "w0.argb64", tmp / "w1.bgra"
+    for background, func in (("checker", "blend_argb64"), ("transparent", "overlay_argb64")):
+        fout = tmp / ("w_out_%s.argb64" % background)
+        launch(env, "compositor name=c background=%s sink_1::xpos=100 sink_1::ypos=80 sink_1::alpha=0.6 sink_0::alpha=0.9 "
+                    "! video/x-raw,format=ARGB64,width=%d,height=%d ! filesink location=%s "
+                    "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=ARGB64,width=320,height=240,framerate=30/1 ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
+                    "videotestsrc num-buffers=%d pattern=ball foreground-color=0x80ff4020 ! video/x-raw,format=BGRA,width=160,height=120,framerate=30/1 ! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1"
+               % (background, dw, dh, fout, n, f0, n, f1))
+        out = np.fromfile(fout, np.uint8).reshape(n, -1)
+        s0 = np.fromfile(f0, np.uint8).reshape(n, -1)
+        s1 = np.fromfile(f1, np.uint8).reshape(n, -1)
+        c1 = ref.VideoConverter("BGRA", 160, 120, "ARGB64", 160, 120)
+        for f in range(n):
+            canvas = np.zeros(dw * dh * 8, np.uint8)
+            if background == "checker":
+                ref.compositor_fill(0, "argb64", "ARGB64", canvas, dw, dh, 0, dh)
+            ref.compositor_blend(func, "ARGB64", s0[f], 320, 240, 0, 0, 0.9, canvas, dw, dh, 0, dh, 1)
+            ref.compositor_blend(func, "ARGB64", c1.frame(s1[f]), 160, 120, 100, 80, 0.6, canvas, dw, dh, 0, dh, 1)
+            assert (canvas == out[f]).all(), (background, f, int((canvas != out[f]).sum()))
+
+
 def test_compositor_element_selects_frames_by_time_and_repeats_a_slower_pad(gst_env, ref):
     """GstVideoAggregator's frame selection (gstvideoaggregator.c:1753-2000): a 15 fps pad under a 30 fps pad - the output runs at
     30 fps (the best framerate) and every frame of the slower pad is shown twice."""

@@ -227,8 +227,9 @@ class CompositorScaledWorkload(CompositorWorkload):
     converter with the library defaults (cubic) - what GstVideoAggregatorConvertPad does - then one aggregate launch."""
     name = "c4a"
     metric = "4K output frames/s (compositor, 16 x 1080p BGRA pads each scaled to 960x540, 4x4 grid) per GPU; % HBM roofline"
-    kernel = "16 x per-pad converter (plane scaler) + k_aggregate"
+    kernel = "k_aggregate_scaled"
     SW, SH = 960, 540
+    FUSED = os.environ.get("GSTAMD_BENCH_C4A_CONVERTERS") is None      # set: the round-2 form, 16 x per-pad converter launches + k_aggregate
 
     def pad_geometry(self, i):
         return (i % 4) * 960, (i // 4) * 540, 1.0
@@ -244,12 +245,28 @@ class CompositorScaledWorkload(CompositorWorkload):
             x, y, a = self.pad_geometry(i)
             self.sarr[i].data, self.sarr[i].width, self.sarr[i].height, self.sarr[i].stride = self.scaled[i].data_ptr(), self.SW, self.SH, self.SW * 4
             self.sarr[i].xpos, self.sarr[i].ypos, self.sarr[i].alpha, self.sarr[i].blend_mode = x, y, a, 1
+        self.farr = [(V.CompositorScaledPad * self.N)() for _ in range(self.SETS)]
+        for st in range(self.SETS):
+            for i in range(self.N):
+                x, y, a = self.pad_geometry(i)
+                e = self.farr[st][i]
+                e.data, e.width, e.height, e.stride = self.pads[st * self.N + i].data_ptr(), self.PW, self.PH, self.PW * 4
+                e.xpos, e.ypos, e.alpha, e.blend_mode, e.scaler = x, y, a, 1, self.convs[i]._h
+        if self.FUSED:
+            assert self.L.gstamd_compositor_pad_scaler_usable(self.convs[0]._h) == 1
+        else:
+            self.kernel = "16 x per-pad converter (plane scaler) + k_aggregate"
         self.launches_per_step = self.frames_per_step
         self.plan = self.convs[0].describe()
 
     def step(self, s):
         for f in range(self.frames_per_step):
             k = s * self.frames_per_step + f
+            if self.FUSED:
+                r = self.L.gstamd_compositor_aggregate_scaled(self.V.FORMATS["BGRA"], 0, self.farr[k % self.SETS], self.N,
+                                                              self.outs[k % self.pool_out].data_ptr(), self.DW, self.DH, self.DW * 4, self.stream)
+                assert r == 0, self.V.last_error()
+                continue
             for i in range(self.N):
                 self.convs[i].frame(self.pads[(k % self.SETS) * self.N + i].data_ptr(), self.scaled[i].data_ptr(), self.stream)
             r = self.L.gstamd_compositor_aggregate(self.V.FORMATS["BGRA"], 0, self.sarr, self.N,
@@ -258,8 +275,9 @@ class CompositorScaledWorkload(CompositorWorkload):
 
     def config(self, world):
         c = CompositorWorkload.config(self, world)
-        c["workload"] = ("C4 variant A: compositor, 16 x 1920x1080 BGRA pads each scaled to 960x540 (per-pad converter, cubic: %s), 4 x 4 grid, operator over, "
-                         "-> 3840x2160 BGRA; %d output frames/step" % (self.plan, self.frames_per_step))
+        c["workload"] = ("C4 variant A: compositor, 16 x 1920x1080 BGRA pads each scaled to 960x540 (%s, cubic: %s), 4 x 4 grid, operator over, "
+                         "-> 3840x2160 BGRA; %d output frames/step" % ("scaled inside the blend kernel" if self.FUSED else "per-pad converter launches", self.plan,
+                                                                      self.frames_per_step))
         return c
 
     def cpu_baseline(self):

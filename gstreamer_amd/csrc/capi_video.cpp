@@ -1275,6 +1275,42 @@ int gstamd_video_converter_set_config (GstAmdVideoConverter *c, const GstAmdVide
   return GSTAMD_OK;
 }
 
+int gstamd_internal_pad_scaler_tile_rows (GstAmdVideoConverter *c)
+{
+  return c ? scaled_tile_rows_for (c->plan) : 16;
+}
+
+/* internal (compositor_kernels.hip): the scaler passes of a pad converter as device tables; 0 when the plan is more than that */
+int gstamd_internal_pad_scaler (GstAmdVideoConverter *c, gstamd::ScaleDev *sh, gstamd::ScaleDev *sv, int *h_first, int *in_w, int *in_h,
+    int *out_w, int *out_h, int *format)
+{
+  int hi = -1, vi = -1;
+  if (!c || !plan_is_pad_scaler (c->plan, &hi, &vi) || ensure_tables (c) != GSTAMD_OK)
+    return 0;
+  const VideoPlan &p = c->plan;
+  ScaleDev *out[2] = {sh, sv};
+  const int idx[2] = {hi, vi};
+  for (int k = 0; k < 2; k++) {
+    ScaleDev sd;
+    if (idx[k] >= 0) {
+      const ScalePass &sp = p.passes[idx[k]];
+      sd.kind = sp.kind;
+      sd.n_taps = sp.n_taps;
+      sd.inc = sp.inc;
+      sd.offset = c->pass_dev[idx[k]].offset;
+      sd.taps = c->pass_dev[idx[k]].taps;
+    }
+    *out[k] = sd;
+  }
+  *h_first = hi >= 0 && vi >= 0 && hi < vi;
+  *in_w = p.in_info.width;
+  *in_h = p.in_info.height;
+  *out_w = p.out_info.width;
+  *out_h = p.out_info.height;
+  *format = p.in_info.format;
+  return 1;
+}
+
 const char *gstamd_video_converter_describe (const GstAmdVideoConverter *c)
 {
   return c ? c->plan.description.c_str () : "";

@@ -10,11 +10,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/gstamd_video.h"
 #include "compositor_device.h"
 #include "compositor_planes.h"
 #include "compositor_wide.h"
+#include "compositor_scaled.h"
 
 using namespace gstamd;
 
@@ -169,6 +171,52 @@ __global__ __launch_bounds__ (64) void k_aggregate64 (Wide64Params p, uint8_t *d
   const int x = (int) (blockIdx.x * blockDim.x + threadIdx.x);
   if (x < rw)
     wide64_px (p, dst, dstride, rx0 + x, ry0 + (int) blockIdx.y);
+}
+
+/* pads scaled inside the blend pass (compositor_scaled.h): a 64 x 16 tile per workgroup, four rows per lane, first passes through LDS */
+__global__ __launch_bounds__ (256) void k_aggregate_scaled (ScaledAggParams p, uint8_t *dst, int dstride, int dw, int dh, int th)
+{
+  __shared__ uint32_t lds[SCALED_LDS_PX];
+  const int tid = (int) threadIdx.x;
+  const int tx0 = (int) blockIdx.x * SCALED_TILE_W, ty0 = (int) blockIdx.y * th;          /* th <= SCALED_TILE_H rows per tile */
+  const int tx1 = tx0 + SCALED_TILE_W < dw ? tx0 + SCALED_TILE_W : dw, ty1 = ty0 + th < dh ? ty0 + th : dh;
+  const int x = tx0 + (tid & 63), yb = ty0 + (tid >> 6);
+  const bool xin = x < dw;
+  uint32_t d[SCALED_TILE_H / 4];
+#pragma unroll
+  for (int k = 0; k < SCALED_TILE_H / 4; k++) {
+    const int y = yb + 4 * k;
+    d[k] = 0;
+    if (xin && y < ty1)
+      d[k] = p.bg_kind == 0 ? checker_px (x, y, p.ashift, p.checker_yuv) : (p.bg_kind == 1 ? p.bg_word : *((const uint32_t *) (dst + (size_t) y * dstride) + x));
+  }
+  for (int i = 0; i < p.n_pads; i++) {
+    const ScaledPadDev &sp = p.pads[i];
+    const ScaledTileGeom g = scaled_tile_geom (sp, tx0, ty0, tx1, ty1);
+    if (g.mode == 0)
+      continue;
+    if (g.mode >= 2) {
+      scaled_tile_stage (sp, g, lds, tid, 256, sp.src_w);
+      __syncthreads ();
+    }
+    const int sx = x - sp.pad.xpos;
+#pragma unroll
+    for (int k = 0; k < SCALED_TILE_H / 4; k++) {
+      const int sy = yb + 4 * k - sp.pad.ypos;
+      if (sx >= g.sx0 && sx < g.sx1 && sy >= g.sy0 && sy < g.sy1) {
+        const uint32_t s = g.mode >= 2 ? scaled_tile_px (sp, g, lds, sx, sy) : scaled_pad_px (sp, sx, sy);
+        d[k] = apply_pad (d[k], s, sp.pad.s_alpha, sp.pad.mode, p.ashift, p.overlay);
+      }
+    }
+    if (g.mode >= 2)
+      __syncthreads ();
+  }
+#pragma unroll
+  for (int k = 0; k < SCALED_TILE_H / 4; k++) {
+    const int y = yb + 4 * k;
+    if (xin && y < ty1)
+      *((uint32_t *) (dst + (size_t) y * dstride) + x) = d[k];
+  }
 }
 
 static thread_local std::string g_comp_error;
@@ -527,6 +575,122 @@ int gstamd_compositor_aggregate (int format, int background, const GstAmdComposi
     if (r != GSTAMD_OK)
       return r;
     p.bg_kind = 2;                                /* further chunks continue on the canvas */
+    first = false;
+  }
+  return GSTAMD_OK;
+}
+
+int gstamd_internal_pad_scaler (GstAmdVideoConverter *c, gstamd::ScaleDev *sh, gstamd::ScaleDev *sv, int *h_first, int *in_w, int *in_h,
+    int *out_w, int *out_h, int *format);
+
+int gstamd_internal_pad_scaler_tile_rows (GstAmdVideoConverter *c);
+
+/* rows per tile: the first scaled pad decides (the pads of one canvas usually share a ratio) - see scaled_tile_rows_for */
+static int scaled_tile_rows (GstAmdVideoConverter *c)
+{
+  const char *e = getenv ("GSTAMD_SCALED_TILE_ROWS");
+  if (e && atoi (e) >= 4 && atoi (e) <= SCALED_TILE_H)
+    return atoi (e);
+  return gstamd_internal_pad_scaler_tile_rows (c);
+}
+
+int gstamd_compositor_pad_scaler_usable (GstAmdVideoConverter *convert)
+{
+  ScaleDev sh, sv;
+  int hf, iw, ih, ow, oh, fmt;
+  return gstamd_internal_pad_scaler (convert, &sh, &sv, &hf, &iw, &ih, &ow, &oh, &fmt) && family_ashift (fmt) >= 0;
+}
+
+int gstamd_compositor_aggregate_scaled (int format, int background, const GstAmdCompositorScaledPad *pads, int n_pads, void *dest,
+    int dw, int dh, int dstride, void *stream)
+{
+  const int ashift = family_ashift (format);
+  if (ashift < 0 || !dest || (n_pads > 0 && !pads) || dw <= 0 || dh <= 0)
+    return GSTAMD_ERR_INVALID;
+  bool any = false;
+  for (int i = 0; i < n_pads; i++)
+    any = any || pads[i].scaler != nullptr;
+  if (!any) {                                     /* nothing to scale: the packed 4-pixel kernel */
+    std::vector<GstAmdCompositorPad> plain ((size_t) n_pads);
+    for (int i = 0; i < n_pads; i++) {
+      plain[i].data = pads[i].data;
+      plain[i].width = pads[i].width;
+      plain[i].height = pads[i].height;
+      plain[i].stride = pads[i].stride;
+      plain[i].xpos = pads[i].xpos;
+      plain[i].ypos = pads[i].ypos;
+      plain[i].alpha = pads[i].alpha;
+      plain[i].blend_mode = pads[i].blend_mode;
+    }
+    return gstamd_compositor_aggregate (format, background, plain.data (), n_pads, dest, dw, dh, dstride, stream);
+  }
+  ScaledAggParams p;
+  memset ((void *) &p, 0, sizeof (p));
+  p.ashift = ashift;
+  p.overlay = background == GSTAMD_COMPOSITOR_BACKGROUND_TRANSPARENT;
+  const bool yuv = format == GSTAMD_VIDEO_FORMAT_AYUV;
+  switch (background) {
+    case GSTAMD_COMPOSITOR_BACKGROUND_CHECKER:
+      p.bg_kind = 0;
+      p.checker_yuv = yuv;
+      break;
+    case GSTAMD_COMPOSITOR_BACKGROUND_BLACK:
+      p.bg_kind = 1;
+      color_word (format, yuv ? 16 : 0, yuv ? 128 : 0, yuv ? 128 : 0, &p.bg_word);
+      break;
+    case GSTAMD_COMPOSITOR_BACKGROUND_WHITE:
+      p.bg_kind = 1;
+      color_word (format, yuv ? 235 : 255, yuv ? 128 : 255, yuv ? 128 : 255, &p.bg_word);
+      break;
+    case GSTAMD_COMPOSITOR_BACKGROUND_TRANSPARENT:
+      p.bg_kind = 1;
+      p.bg_word = 0;
+      break;
+    default:
+      return GSTAMD_ERR_INVALID;
+  }
+  int done = 0, th = SCALED_TILE_H;
+  bool first = true, th_set = false;
+  while (first || done < n_pads) {
+    p.n_pads = 0;
+    while (done < n_pads && p.n_pads < GSTAMD_MAX_SCALED_PADS) {
+      const GstAmdCompositorScaledPad &in = pads[done++];
+      int s_alpha = (int) (in.alpha * 255);
+      s_alpha = s_alpha < 0 ? 0 : (s_alpha > 255 ? 255 : s_alpha);
+      if (s_alpha == 0 || !in.data)
+        continue;
+      ScaledPadDev &sp = p.pads[p.n_pads];
+      sp = ScaledPadDev ();
+      sp.pad.data = (const uint8_t *) in.data;
+      sp.pad.width = in.width;
+      sp.pad.height = in.height;
+      sp.pad.stride = in.stride;
+      sp.pad.xpos = in.xpos;
+      sp.pad.ypos = in.ypos;
+      sp.pad.s_alpha = s_alpha;
+      sp.pad.mode = in.blend_mode;
+      sp.src_w = in.width;
+      if (in.scaler) {
+        int hf, iw, ih, ow, oh, fmt;
+        if (!gstamd_internal_pad_scaler (in.scaler, &sp.sh, &sp.sv, &hf, &iw, &ih, &ow, &oh, &fmt) || fmt != format || iw != in.width ||
+            ih != in.height || ((uintptr_t) in.data % 4) != 0 || (in.stride % 4) != 0)
+          return GSTAMD_ERR_UNSUPPORTED;
+        sp.h_first = hf;
+        sp.n_pass = (sp.sh.kind != SCALE_NONE) + (sp.sv.kind != SCALE_NONE);
+        sp.pad.width = ow;
+        sp.pad.height = oh;
+        if (!th_set) {
+          th = scaled_tile_rows (in.scaler);
+          th_set = true;
+        }
+      }
+      p.n_pads++;
+    }
+    hipLaunchKernelGGL (k_aggregate_scaled, dim3 ((dw + SCALED_TILE_W - 1) / SCALED_TILE_W, (dh + th - 1) / th), dim3 (256), 0,
+        (hipStream_t) stream, p, (uint8_t *) dest, dstride, dw, dh, th);
+    if (hipGetLastError () != hipSuccess)
+      return GSTAMD_ERR_HIP;
+    p.bg_kind = 2;
     first = false;
   }
   return GSTAMD_OK;

@@ -2456,4 +2456,60 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   return plan_core (&ein, &eout, &cfg, plan, error);
 }
 
+bool plan_is_pad_scaler (const VideoPlan &p, int *h, int *v)
+{
+  *h = *v = -1;
+  if (p.gamma.on || p.plane_mode || p.out_planar || p.deep_out || p.deep16 || p.dither.on || p.passes.empty () || p.passes.size () > 2)
+    return false;
+  if (!p.fin || p.fin != p.fout || p.fin->kind != UNPACK_PACKED4 || p.fin->hi_depth != 0)
+    return false;
+  if (p.front.kind != UNPACK_PACKED4 || p.matrix.kind != MATRIX_NONE || p.post.matrix.kind != MATRIX_NONE || p.post.alpha_kind != ALPHA_NONE)
+    return false;
+  for (int k = 0; k < 4; k++)
+    if (p.front.pos[k] != k || p.post.pack_pos[k] != k)
+      return false;
+  const RectPlan &r = p.rect;
+  if (r.in_x || r.in_y || r.out_x || r.out_y || r.fill || r.in_maxw != p.in_info.width || r.in_maxh != p.in_info.height ||
+      r.out_maxw != p.out_info.width || r.out_maxh != p.out_info.height)
+    return false;
+  for (size_t i = 0; i < p.passes.size (); i++) {
+    const ScalePass &sp = p.passes[i];
+    if (sp.merged || sp.kind == SCALE_NONE || (sp.horizontal ? *h : *v) >= 0)
+      return false;
+    (sp.horizontal ? *h : *v) = (int) i;
+  }
+  return true;
+}
+
+int scaled_tile_rows_for (const VideoPlan &p)
+{
+  int h = -1, v = -1;
+  if (!plan_is_pad_scaler (p, &h, &v) || h < 0 || v < 0)
+    return 16;
+  const ScalePass &ph = p.passes[h], &pv = p.passes[v];
+  const int cols = std::min (64, ph.out_size);
+  const int ntap_h = ph.kind == SCALE_NTAP ? ph.n_taps : (ph.kind == SCALE_2TAP ? 2 : 1), ntap_v = pv.kind == SCALE_NTAP ? pv.n_taps : (pv.kind == SCALE_2TAP ? 2 : 1);
+  int best = 16;
+  double best_eff = -1.0;
+  for (int th = 16; th >= 12; th--) {
+    const int rows = std::min (th, pv.out_size);
+    int items;
+    if (h < v) {                /* horizontal first: the vertical source span of the rows x the tile's columns */
+      const int c0 = pv.out_size / 2 >= rows ? pv.out_size / 2 - rows / 2 : 0;
+      items = ((int) pv.offset[c0 + rows - 1] + ntap_v - (int) pv.offset[c0]) * cols;
+    } else {
+      const int c0 = ph.out_size / 2 >= cols ? ph.out_size / 2 - cols / 2 : 0;
+      const int span = ph.kind == SCALE_2TAP ? (((c0 + cols - 1) * ph.inc) >> 16) + 2 - ((c0 * ph.inc) >> 16)
+          : (int) ph.offset[c0 + cols - 1] + ntap_h - (int) ph.offset[c0];
+      items = ((span + 3) / 4) * rows;
+    }
+    const double eff = (double) items / (double) ((items + 255) / 256 * 256);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best = th;
+    }
+  }
+  return best;
+}
+
 }  // namespace gstamd

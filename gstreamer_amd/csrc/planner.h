@@ -286,6 +286,16 @@ GSTAMD_VP int vpair_pack (int row, int role) { return (int) (((uint32_t) row & 0
 int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *config, VideoPlan *plan, std::string *error);
 
+// A plan that is nothing but the scaler passes on the raw 4-byte pixels of one format (same 8-bit 4-byte packed format on both sides,
+// whole frames, no colour step, no dither): what a compositor pad's converter is when only the pad's size differs from its frames'
+// (GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513).  Such a plan can be sampled per destination pixel inside the blend
+// kernel (compositor_scaled.h).  *h / *v: index into plan.passes of the horizontal / vertical pass, -1: none.
+bool plan_is_pad_scaler (const VideoPlan &plan, int *h, int *v);
+// rows per 64-column canvas tile (12..16) of k_aggregate_scaled for pads scaled by this plan: the first pass under a tile is
+// rows x quads items (vertical first) or rows x 64 (horizontal first) spread over 256 lanes; the height that leaves the fewest idle
+// lanes in the last round wins (2:1 with 8 taps: 34 quads x 15 rows = 510 items = two full rounds, 16 rows would need a third)
+int scaled_tile_rows_for (const VideoPlan &plan);
+
 int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int height);
 void converter_config_init (GstAmdVideoConverterConfig *config);
 

@@ -67,6 +67,13 @@ class CompositorPad(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class CompositorScaledPad(C.Structure):
+    """GstAmdCompositorScaledPad: a pad's frame as it arrives + the converter that scales it (None: blended as it is)"""
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
+                ("xpos", C.c_int32), ("ypos", C.c_int32), ("alpha", C.c_double), ("blend_mode", C.c_int32),
+                ("reserved", C.c_int32), ("scaler", C.c_void_p)]
+
+
 class CompositorFramePad(C.Structure):
     _fields_ = [("data", C.c_void_p * 3), ("stride", C.c_int32 * 3), ("width", C.c_int32), ("height", C.c_int32),
                 ("xpos", C.c_int32), ("ypos", C.c_int32), ("alpha", C.c_double), ("blend_mode", C.c_int32), ("reserved", C.c_int32)]
@@ -119,6 +126,9 @@ def lib():
                                                        C.c_int, C.c_int, C.c_int, C.c_void_p]
             L.gstamd_compositor_aggregate.argtypes = [C.c_int, C.c_int, C.POINTER(CompositorPad), C.c_int, C.c_void_p,
                                                       C.c_int, C.c_int, C.c_int, C.c_void_p]
+            L.gstamd_compositor_aggregate_scaled.argtypes = [C.c_int, C.c_int, C.POINTER(CompositorScaledPad), C.c_int, C.c_void_p,
+                                                             C.c_int, C.c_int, C.c_int, C.c_void_p]
+            L.gstamd_compositor_pad_scaler_usable.argtypes = [C.c_void_p]
             L.gstamd_compositor_aggregate_frame.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                             C.POINTER(CompositorFramePad), C.c_int, C.POINTER(C.c_void_p),
                                                             C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p]

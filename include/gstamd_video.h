@@ -239,6 +239,27 @@ typedef struct GstAmdCompositorPad {
 int gstamd_compositor_aggregate (int format, int background, const GstAmdCompositorPad *pads,
     int n_pads, void *dest, int dw, int dh, int dstride, void *stream);
 
+/* Pads that are SCALED into the canvas (BASELINE C4 variant A): the reference gives each such pad a converter
+ * (GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) and blends the converted frame.  Here the pad hands over its frame as
+ * it arrived plus its converter, and the scaled pixels are evaluated inside the blend pass - no scaled frame in HBM, one launch per
+ * output frame.  `scaler` must be a converter for which gstamd_compositor_pad_scaler_usable () returns 1: the same 4-byte 8-bit
+ * format as the canvas on both sides, whole frames, any resampler method / taps (the result is the converter's own output, bit for
+ * bit); the pad then covers the converter's OUTPUT size on the canvas and data / stride describe a frame of its INPUT size.
+ * scaler == NULL: the frame is blended as it is (width x height).  Other pads (format conversions, crops, borders) are converted by
+ * the caller first, as before.  Formats: BGRA, RGBA, ARGB, ABGR, AYUV. */
+typedef struct GstAmdCompositorScaledPad {
+  const void *data;
+  int32_t width, height, stride;        /* the frame in `data` */
+  int32_t xpos, ypos;
+  double alpha;
+  int32_t blend_mode;
+  int32_t reserved;
+  GstAmdVideoConverter *scaler;
+} GstAmdCompositorScaledPad;
+int gstamd_compositor_pad_scaler_usable (GstAmdVideoConverter *convert);
+int gstamd_compositor_aggregate_scaled (int format, int background, const GstAmdCompositorScaledPad *pads,
+    int n_pads, void *dest, int dw, int dh, int dstride, void *stream);
+
 /* Outputs WITHOUT per-pixel alpha - I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR: the reference converts every pad to the
  * output format and blends plane by plane with the pad alpha only (blend.c PLANAR_YUV_BLEND / NV_YUV_BLEND / RGB_BLEND,
  * fill_checker_* / fill_color_*; compositor.c:1619-1697).  One pass per destination plane, pads applied in array order.

@@ -67,6 +67,7 @@ typedef struct {
   gsize staging_size;
   /* per-pad conversion (format and / or size): converter, its key, its device output frame */
   GstAmdVideoConverter *conv;
+  gboolean conv_inline;         /* conv only scales the canvas format: it is sampled inside the blend kernel (gstamd_compositor_aggregate_scaled) */
   gint conv_key[6];            /* in format, in w, in h, out format, out w, out h */
   gpointer conv_buf;
   gsize conv_buf_size;
@@ -230,6 +231,7 @@ typedef struct {
   gboolean zero_size_is_unscaled;      /* compositor.c:2131: width / height 0 mean "unscaled" (TRUE) or "invisible" (FALSE) */
   gboolean ignore_inactive_pads;       /* accepted (GstAggregator's inactive-pad tracking does not exist in this runtime) */
   guint max_threads;                   /* accepted; the GPU grid replaces the blend thread pool */
+  guint64 n_inline_scaled;             /* pad frames scaled inside the blend kernel instead of by a converter launch (GSTAMD_ELEMENT_STATS) */
   guint64 n_culled;                    /* pad frames left out because nothing of them can be seen (culled-frames, read-only) */
 } GstAmdCompositor;
 
@@ -747,6 +749,8 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
   const int fmt = amd_format_of (GST_VIDEO_INFO_FORMAT (&c->out_info));
   const gboolean by_planes = !GST_VIDEO_INFO_HAS_ALPHA (&c->out_info);
   GstAmdCompositorFramePad fdesc[AMD_COMP_MAX_PADS];
+  GstAmdVideoConverter *inline_conv[AMD_COMP_MAX_PADS];
+  gboolean any_inline = FALSE;
   gint pad_w[AMD_COMP_MAX_PADS], pad_h[AMD_COMP_MAX_PADS], pad_x[AMD_COMP_MAX_PADS], pad_y[AMD_COMP_MAX_PADS];
   guint n_culled = 0;
   int r;
@@ -894,7 +898,22 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
             goto done_inputs;
           }
           memcpy (p->conv_key, key, sizeof (key));
+          p->conv_inline = !by_planes && ifmt == fmt && GST_VIDEO_INFO_COMP_DEPTH (&c->out_info, 0) == 8 &&
+              g_getenv ("GSTAMD_COMPOSITOR_NO_INLINE_SCALE") == NULL && gstamd_compositor_pad_scaler_usable (p->conv) == 1;
         }
+        inline_conv[n_desc] = NULL;
+        if (p->conv_inline) {
+          /* the frame as it arrived + its scaler: no scaled frame in HBM, no extra launch */
+          vmeta = gst_buffer_get_video_meta (bufs[i]);
+          desc[n_desc].data = base + (vmeta ? vmeta->offset[0] : GST_VIDEO_INFO_PLANE_OFFSET (&p->info, 0));
+          desc[n_desc].width = GST_VIDEO_INFO_WIDTH (&p->info);
+          desc[n_desc].height = GST_VIDEO_INFO_HEIGHT (&p->info);
+          desc[n_desc].stride = vmeta ? vmeta->stride[0] : GST_VIDEO_INFO_PLANE_STRIDE (&p->info, 0);
+          memset (&fdesc[n_desc], 0, sizeof (fdesc[n_desc]));
+          inline_conv[n_desc] = p->conv;
+          any_inline = TRUE;
+          c->n_inline_scaled++;
+        } else {
         if (!ensure_device (&p->conv_buf, &p->conv_buf_size, (gsize) p->conv_out.size) ||
             gstamd_video_converter_frame (p->conv, base, p->conv_buf, c->stream) != GSTAMD_OK) {
           flow = GST_FLOW_ERROR;
@@ -909,7 +928,9 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
           fdesc[n_desc].data[k] = (const guint8 *) p->conv_buf + p->conv_out.offset[k];
           fdesc[n_desc].stride[k] = p->conv_out.stride[k];
         }
+        }
       } else {
+        inline_conv[n_desc] = NULL;
         vmeta = gst_buffer_get_video_meta (bufs[i]);
         desc[n_desc].data = base + (vmeta ? vmeta->offset[0] : GST_VIDEO_INFO_PLANE_OFFSET (&p->info, 0));
         desc[n_desc].width = GST_VIDEO_INFO_WIDTH (&p->info);
@@ -969,6 +990,23 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
     }
     r = gstamd_compositor_aggregate_frame (fmt, c->background, black, white, fdesc, (int) n_desc, dplanes, dstrides,
         GST_VIDEO_INFO_WIDTH (&c->out_info), GST_VIDEO_INFO_HEIGHT (&c->out_info), c->stream);
+  } else if (any_inline) {
+    GstAmdCompositorScaledPad sdesc[AMD_COMP_MAX_PADS];
+    guint k;
+    for (k = 0; k < n_desc; k++) {
+      sdesc[k].data = desc[k].data;
+      sdesc[k].width = desc[k].width;
+      sdesc[k].height = desc[k].height;
+      sdesc[k].stride = desc[k].stride;
+      sdesc[k].xpos = desc[k].xpos;
+      sdesc[k].ypos = desc[k].ypos;
+      sdesc[k].alpha = desc[k].alpha;
+      sdesc[k].blend_mode = desc[k].blend_mode;
+      sdesc[k].reserved = 0;
+      sdesc[k].scaler = inline_conv[k];
+    }
+    r = gstamd_compositor_aggregate_scaled (fmt, c->background, sdesc, (int) n_desc, canvas, GST_VIDEO_INFO_WIDTH (&c->out_info),
+        GST_VIDEO_INFO_HEIGHT (&c->out_info), GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, 0), c->stream);
   } else {
     r = gstamd_compositor_aggregate (fmt, c->background, desc, (int) n_desc, canvas, GST_VIDEO_INFO_WIDTH (&c->out_info),
         GST_VIDEO_INFO_HEIGHT (&c->out_info), GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, 0), c->stream);
@@ -1050,7 +1088,8 @@ amd_comp_stop (GstAggregator * agg)
   c->d_out_size = 0;
   c->have_out = FALSE;
   if (g_getenv ("GSTAMD_ELEMENT_STATS"))
-    g_printerr ("amdcompositor %s: frames %" G_GUINT64_FORMAT " culled-frames %" G_GUINT64_FORMAT "\n", GST_OBJECT_NAME (c), c->n_frames, c->n_culled);
+    g_printerr ("amdcompositor %s: frames %" G_GUINT64_FORMAT " culled-frames %" G_GUINT64_FORMAT " inline-scaled %" G_GUINT64_FORMAT "\n", GST_OBJECT_NAME (c),
+        c->n_frames, c->n_culled, c->n_inline_scaled);
   c->n_frames = 0;
   {
     GList *l;

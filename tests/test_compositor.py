@@ -527,3 +527,128 @@ def test_hip_wide64_aggregate_matches_reference_loop(native_lib, gpu, ref, fmt, 
     assert V.lib().gstamd_compositor_aggregate(V.FORMATS[fmt], background, arr, n_pads, d.data_ptr(), dw, dh, dw * 8, None) == 0
     torch.cuda.synchronize()
     assert (d.cpu().numpy() == exp).all()
+
+
+# ---- pads scaled inside the blend pass (compositor_scaled.h) against the reference's per-pad converter + blend -------------------------
+class EmuScaledPad(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("stride", C.c_int), ("xpos", C.c_int), ("ypos", C.c_int),
+                ("alpha", C.c_double), ("mode", C.c_int), ("out_w", C.c_int), ("out_h", C.c_int), ("method", C.c_int)]
+
+
+# (w, h, out_w, out_h, method, xpos, ypos, alpha, mode); out_w 0: not scaled
+SCALED_LAYOUTS = {
+    "cubic_down": [(96, 54, 48, 27, "cubic", 3, 2, 1.0, 1), (96, 54, 48, 27, "cubic", 40, 20, 0.6, 1), (64, 40, 37, 23, "cubic", -9, 30, 0.8, 1)],
+    "mixed_methods": [(60, 40, 90, 60, "cubic", 0, 0, 1.0, 1), (60, 40, 31, 40, "lanczos", 50, 10, 0.7, 1), (60, 40, 60, 17, "sinc", 20, 40, 0.9, 2),
+                      (60, 40, 0, 0, "cubic", 70, 30, 0.5, 1), (33, 21, 64, 50, "linear", 5, 25, 0.75, 0), (33, 21, 70, 9, "nearest", 30, 5, 0.4, 1)],
+    "extreme": [(400, 60, 16, 40, "cubic", 10, 5, 0.9, 1), (24, 200, 60, 14, "linear", 40, 30, 0.8, 1), (16, 12, 110, 70, "lanczos", 3, 4, 0.5, 1)],
+    "many": [(40 + (i % 3) * 8, 30, 20 + (i % 5) * 9, 12 + (i % 4) * 7, ("cubic", "linear", "lanczos")[i % 3], (i % 6) * 17 - 5, (i // 6) * 19 - 4,
+              min(1.0, 0.3 + 0.04 * i), i % 3) for i in range(20)],
+}
+METHODS = {"nearest": 0, "linear": 1, "cubic": 2, "sinc": 3, "lanczos": 4}
+
+
+def scaled_expected(ref, fmt, background, layout, frames, dw, dh):
+    fam = FAM[fmt]
+    exp = np.zeros(dw * dh * 4, np.uint8)
+    yuv = fmt == "AYUV"
+    if background == 0:
+        ref.compositor_fill(0, "ayuv" if yuv else fam, fmt, exp, dw, dh, 0, dh)
+    elif background == 1:
+        ref.compositor_fill(1, fmt.lower(), fmt, exp, dw, dh, 0, dh, *((16, 128, 128) if yuv else (0, 0, 0)))
+    elif background == 2:
+        ref.compositor_fill(1, fmt.lower(), fmt, exp, dw, dh, 0, dh, *((235, 128, 128) if yuv else (255, 255, 255)))
+    func = ("overlay_" if background == 3 else "blend_") + fam
+    for (w, h, ow, oh, method, xpos, ypos, alpha, mode), frame in zip(layout, frames):
+        if ow:
+            rc = ref.VideoConverter(fmt, w, h, fmt, ow, oh, config=cases.ref_config_string(ref, dict(resampler_method=method)))
+            frame, w, h = rc.frame(frame), ow, oh
+        ref.compositor_blend(func, fmt, frame, w, h, xpos, ypos, alpha, exp, dw, dh, 0, dh, mode)
+    return exp
+
+
+def scaled_frames(layout, seed):
+    return [cases.frame_bytes(p[0] * p[1] * 4, "random", seed + i) for i, p in enumerate(layout)]
+
+
+SCALED_CASES = [("BGRA", 0, "cubic_down"), ("BGRA", 1, "extreme"), ("ARGB", 1, "mixed_methods"), ("AYUV", 2, "mixed_methods"), ("RGBA", 3, "mixed_methods"),
+                ("BGRA", 3, "many"), ("ABGR", 0, "many")]
+
+
+@pytest.mark.parametrize("tile_rows", [0, 13])
+@pytest.mark.parametrize("fmt,background,name", SCALED_CASES)
+def test_scaled_pads_on_host_match_reference(emu_lib, ref, fmt, background, name, tile_rows):
+    layout = SCALED_LAYOUTS[name]
+    dw, dh = 120, 80
+    frames = scaled_frames(layout, 4200)
+    exp = scaled_expected(ref, fmt, background, layout, frames, dw, dh)
+    arr = (EmuScaledPad * len(layout))()
+    for i, (w, h, ow, oh, method, xpos, ypos, alpha, mode) in enumerate(layout):
+        arr[i].data, arr[i].width, arr[i].height, arr[i].stride = frames[i].ctypes.data, w, h, w * 4
+        arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].mode = xpos, ypos, alpha, mode
+        arr[i].out_w, arr[i].out_h, arr[i].method = ow, oh, METHODS[method]
+    yuv = fmt == "AYUV"
+    words = []
+    for c in ((16, 128, 128) if yuv else (0, 0, 0)), ((235, 128, 128) if yuv else (255, 255, 255)):
+        one = np.zeros(4, np.uint8)
+        ref.compositor_fill(1, fmt.lower(), fmt, one, 1, 1, 0, 1, *c)
+        words.append(int(one.view(np.uint32)[0]))
+    got = np.zeros(dw * dh * 4, np.uint8)
+    emu_lib.emu_compositor_aggregate_scaled.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                        C.c_uint32, C.c_uint32, C.c_int]
+    r = emu_lib.emu_compositor_aggregate_scaled(V.FORMATS[fmt], 0 if FAM[fmt] == "argb" else 24, background, arr, len(layout),
+                                                got.ctypes.data, dw, dh, dw * 4, words[0], words[1], tile_rows)
+    assert r == 0
+    assert (exp == got).all(), int((exp != got).sum())
+    assert emu_lib.emu_scaled_tile_stages() > 0           # the LDS form ran (and the per-pixel form for what does not fit: "extreme")
+
+
+def hip_scaled(gpu, fmt, background, layout, frames, dw, dh):
+    import torch
+    d_frames = [torch.from_numpy(f).to(gpu) for f in frames]
+    arr = (V.CompositorScaledPad * len(layout))()
+    convs = []
+    for i, (w, h, ow, oh, method, xpos, ypos, alpha, mode) in enumerate(layout):
+        arr[i].data, arr[i].width, arr[i].height, arr[i].stride = d_frames[i].data_ptr(), w, h, w * 4
+        arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = xpos, ypos, alpha, mode
+        if ow:
+            c = V.VideoConverter(V.video_info(fmt, w, h), V.video_info(fmt, ow, oh), V.converter_config(resampler_method=method))
+            assert V.lib().gstamd_compositor_pad_scaler_usable(c._h) == 1
+            convs.append(c)
+            arr[i].scaler = c._h
+    d = torch.empty(dw * dh * 4, dtype=torch.uint8, device=gpu)
+    assert V.lib().gstamd_compositor_aggregate_scaled(V.FORMATS[fmt], background, arr, len(layout), d.data_ptr(), dw, dh, dw * 4, None) == 0
+    torch.cuda.synchronize()
+    return d.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,background,name", SCALED_CASES)
+def test_hip_scaled_pads_match_reference(native_lib, gpu, ref, fmt, background, name):
+    layout = SCALED_LAYOUTS[name]
+    dw, dh = 120, 80
+    frames = scaled_frames(layout, 4200)
+    exp = scaled_expected(ref, fmt, background, layout, frames, dw, dh)
+    got = hip_scaled(gpu, fmt, background, layout, frames, dw, dh)
+    assert (exp == got).all(), int((exp != got).sum())
+
+
+@pytest.mark.gpu
+def test_hip_scaled_pads_c4_variant_a_full_size(native_lib, gpu, ref):
+    """BASELINE C4 variant A at its own size: 16 x 1080p BGRA pads, each cubic-downscaled to 960 x 540 by the pad's converter, in a
+    4 x 4 grid on the 4K canvas with pad alphas - against the reference's converter + blend per pad."""
+    dw, dh = 3840, 2160
+    layout = [(1920, 1080, 960, 540, "cubic", (i % 4) * 960, (i // 4) * 540, 1.0 if i % 2 else 0.8, 1) for i in range(16)]
+    frames = [cases.frame_bytes(1920 * 1080 * 4, "random", 5100 + i) for i in range(16)]
+    exp = scaled_expected(ref, "BGRA", 1, layout, frames, dw, dh)
+    got = hip_scaled(gpu, "BGRA", 1, layout, frames, dw, dh)
+    assert (exp == got).all(), int((exp != got).sum())
+
+
+@pytest.mark.gpu
+def test_hip_pad_scaler_usable_only_for_plain_scalers(native_lib, gpu):
+    usable = V.lib().gstamd_compositor_pad_scaler_usable
+    assert usable(V.VideoConverter(V.video_info("BGRA", 64, 48), V.video_info("BGRA", 32, 24))._h) == 1
+    assert usable(V.VideoConverter(V.video_info("NV12", 64, 48), V.video_info("BGRA", 32, 24))._h) == 0
+    assert usable(V.VideoConverter(V.video_info("BGRA", 64, 48), V.video_info("RGBA", 32, 24))._h) == 0
+    assert usable(V.VideoConverter(V.video_info("BGRA", 64, 48), V.video_info("BGRA", 64, 48))._h) == 0
+    assert usable(V.VideoConverter(V.video_info("BGRA", 64, 48), V.video_info("BGRA", 32, 24), V.converter_config(dest_x=4, dest_width=20))._h) == 0

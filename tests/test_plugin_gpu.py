@@ -222,7 +222,7 @@ def test_compositor_element_scales_and_converts_pads(gst_env, ref):
     env, tmp = gst_env
     n, dw, dh = 2, 320, 240
     f0, f1, fout = tmp / "s0.bgra", tmp / "s1.nv12", tmp / "s_out.bgra"
-    launch(env, "compositor name=c background=black sink_0::width=160 sink_0::height=120 sink_0::xpos=10 sink_0::ypos=20 "
+    log = launch(dict(env, GSTAMD_ELEMENT_STATS="1"), "compositor name=c background=black sink_0::width=160 sink_0::height=120 sink_0::xpos=10 sink_0::ypos=20 "
                 "sink_1::xpos=150 sink_1::ypos=100 sink_1::alpha=0.7 sink_1::width=128 sink_1::height=96 "
                 "! video/x-raw,format=BGRA,width=%d,height=%d ! filesink location=%s "
                 "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=320,height=240,framerate=30/1 ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
@@ -239,6 +239,8 @@ def test_compositor_element_scales_and_converts_pads(gst_env, ref):
         ref.compositor_blend("blend_bgra", "BGRA", c0.frame(s0[f]), 160, 120, 10, 20, 1.0, canvas, dw, dh, 0, dh, 1)
         ref.compositor_blend("blend_bgra", "BGRA", c1.frame(s1[f]), 128, 96, 150, 100, 0.7, canvas, dw, dh, 0, dh, 1)
         assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
+    # the BGRA pad only changes size: it is sampled inside the blend kernel; the NV12 pad goes through its converter first
+    assert "inline-scaled %d" % n in log, log[-500:]
 
 
 def test_compositor_element_on_a_64_bit_canvas(gst_env, ref):

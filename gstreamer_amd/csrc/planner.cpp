@@ -30,6 +30,10 @@ static const FormatDesc g_formats[] = {
   // 3 bytes per pixel (video-format.c:1519-1593)
   {GSTAMD_VIDEO_FORMAT_RGB, "RGB", false, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 0, 1, 2}},
   {GSTAMD_VIDEO_FORMAT_BGR, "BGR", false, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 2, 1, 0}},
+  // packed 4:4:4 YUV in 3 bytes (video-format.c:461-495 v308, :498-532 IYU2) and VUYA (:6186-6215)
+  {GSTAMD_VIDEO_FORMAT_v308, "v308", true, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 0, 1, 2}},
+  {GSTAMD_VIDEO_FORMAT_IYU2, "IYU2", true, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 1, 0, 2}},
+  {GSTAMD_VIDEO_FORMAT_VUYA, "VUYA", true, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {3, 2, 1, 0}},
   {GSTAMD_VIDEO_FORMAT_AYUV, "AYUV", true, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}},
   {GSTAMD_VIDEO_FORMAT_ARGB, "ARGB", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}},
   {GSTAMD_VIDEO_FORMAT_xRGB, "xRGB", false, false, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}},
@@ -141,6 +145,8 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       break;
     case GSTAMD_VIDEO_FORMAT_RGB:
     case GSTAMD_VIDEO_FORMAT_BGR:
+    case GSTAMD_VIDEO_FORMAT_v308:
+    case GSTAMD_VIDEO_FORMAT_IYU2:
       info->stride[0] = round_up (width * 3, 4);
       info->size = (uint64_t) info->stride[0] * h;
       break;
@@ -1121,13 +1127,15 @@ enum : unsigned {
   FP_ACOPY = 16, FP_ASET = 32, FP_AMULT = 64,
   FP_WEVEN = 128, FP_HEVEN = 256,   /* width_align / height_align == 1 */
 };
-constexpr uint64_t fbit (int f) { return 1ull << f; }
+/* one bit per format: the enum value below 64, the two bits no format owns (UNKNOWN, ENCODED) for VYUY (64) and VUYA (84) */
+constexpr uint64_t fbit (int f) { return f < 64 ? 1ull << f : (f == GSTAMD_VIDEO_FORMAT_VYUY ? 1ull : (f == GSTAMD_VIDEO_FORMAT_VUYA ? 2ull : 0ull)); }
 constexpr uint64_t F_I420 = fbit (GSTAMD_VIDEO_FORMAT_I420), F_YV12 = fbit (GSTAMD_VIDEO_FORMAT_YV12), F_420 = F_I420 | F_YV12;
 constexpr uint64_t F_Y42B = fbit (GSTAMD_VIDEO_FORMAT_Y42B), F_Y444 = fbit (GSTAMD_VIDEO_FORMAT_Y444);
 constexpr uint64_t F_AYUV = fbit (GSTAMD_VIDEO_FORMAT_AYUV), F_YUY2 = fbit (GSTAMD_VIDEO_FORMAT_YUY2), F_UYVY = fbit (GSTAMD_VIDEO_FORMAT_UYVY);
 constexpr uint64_t F_RGB4X = fbit (GSTAMD_VIDEO_FORMAT_RGBx) | fbit (GSTAMD_VIDEO_FORMAT_BGRx) | fbit (GSTAMD_VIDEO_FORMAT_xRGB) | fbit (GSTAMD_VIDEO_FORMAT_xBGR);
 constexpr uint64_t F_RGB4A = fbit (GSTAMD_VIDEO_FORMAT_RGBA) | fbit (GSTAMD_VIDEO_FORMAT_BGRA) | fbit (GSTAMD_VIDEO_FORMAT_ARGB) | fbit (GSTAMD_VIDEO_FORMAT_ABGR);
 constexpr uint64_t F_RGB3 = fbit (GSTAMD_VIDEO_FORMAT_RGB) | fbit (GSTAMD_VIDEO_FORMAT_BGR);
+constexpr uint64_t F_YUV3 = fbit (GSTAMD_VIDEO_FORMAT_v308) | fbit (GSTAMD_VIDEO_FORMAT_IYU2);
 constexpr uint64_t F_NV12 = fbit (GSTAMD_VIDEO_FORMAT_NV12), F_NV16 = fbit (GSTAMD_VIDEO_FORMAT_NV16), F_NV24 = fbit (GSTAMD_VIDEO_FORMAT_NV24);
 struct FastRow {
   uint64_t in, out;     /* format sets; `same` rows need in == out on top */
@@ -1156,7 +1164,7 @@ const FastRow g_fast_rows[] = {
   {F_UYVY, F_YUY2, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
   /* convert_scale_planes: every same-format pair, planar <-> planar and the NV12 / NV16 / NV24 family */
   {F_RGB4A | F_AYUV | fbit (GSTAMD_VIDEO_FORMAT_ARGB64) | fbit (GSTAMD_VIDEO_FORMAT_AYUV64), ~0ull, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
-  {F_RGB4X | F_RGB3 | F_420 | F_Y42B | F_Y444 | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
+  {F_RGB4X | F_RGB3 | F_YUV3 | F_420 | F_Y42B | F_Y444 | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
         F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_YVYU), ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_420 | F_Y42B | F_Y444, F_420 | F_Y42B | F_Y444, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_NV12 | F_NV16 | F_NV24, F_NV12 | F_NV16 | F_NV24, false, FP_CROP | FP_BORDER, "convert_scale_planes"},

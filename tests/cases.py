@@ -58,7 +58,7 @@ def visible_planes(fmt, w, h):
         return [(w, h), (2 * w, h)]
     if fmt in ("YUY2", "UYVY", "YVYU", "VYUY"):
         return [(4 * up2(w), h)]         # whole macropixels; visible_bytes blanks the unused luma slot of an odd last pixel
-    if fmt in ("RGB", "BGR"):
+    if fmt in ("RGB", "BGR", "v308", "IYU2"):
         return [(3 * w, h)]
     return [(4 * w, h)]
 
@@ -375,6 +375,33 @@ VIDEO_CASES = [
     ("gamma_bgra_nv12_border", "BGRA", 200, 100, "NV12", 320, 240, dict(gamma_mode="remap", dest_x=40, dest_y=20, dest_width=200, dest_height=100, border_argb=0xff204060), "sRGB>bt709", None, "random"),
     ("gamma_nv12_bgra_pq", "NV12", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap"), "2:6:14:7>sRGB", None, "random"),
     ("gamma_nv12_bgra_hlg", "NV12", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap"), "2:6:15:7>sRGB", None, "random"),
+    # packed 4:4:4 YUV in 3 bytes (v308, IYU2) and VUYA: the PACKED3 / PACKED4 kernels with other component positions
+    ("v308_bgra_64x48", "v308", 64, 48, "BGRA", 64, 48, {}, None, None, "random"),
+    ("nv12_v308_322x241", "NV12", 322, 241, "v308", 322, 241, {}, None, None, "random"),
+    ("v308_i420_161x91", "v308", 161, 91, "I420", 161, 91, {}, None, None, "random"),
+    ("v308_v308_down_bilinear_planes", "v308", 320, 180, "v308", 200, 100, LIN, None, None, "random"),
+    ("v308_rgba_down_lanczos", "v308", 320, 180, "RGBA", 120, 68, LAN, "bt709", None, "random"),
+    ("bgra_v308_up_cubic", "BGRA", 64, 48, "v308", 100, 75, {}, None, None, "random"),
+    ("iyu2_rgba_33x17", "IYU2", 33, 17, "RGBA", 33, 17, {}, None, None, "random"),
+    ("iyu2_nv12_161x91", "IYU2", 161, 91, "NV12", 161, 91, {}, None, None, "random"),
+    ("bgra_iyu2_64x48", "BGRA", 64, 48, "IYU2", 64, 48, {}, None, None, "random"),
+    ("iyu2_v308_33x17", "IYU2", 33, 17, "v308", 33, 17, {}, None, None, "random"),
+    ("yuy2_iyu2_66x20", "YUY2", 66, 20, "IYU2", 66, 20, {}, None, None, "random"),
+    ("vuya_bgra_64x48", "VUYA", 64, 48, "BGRA", 64, 48, {}, None, None, "random"),
+    ("nv12_vuya_322x241", "NV12", 322, 241, "VUYA", 322, 241, {}, None, None, "random"),
+    ("vuya_vuya_down_cubic_planes", "VUYA", 320, 180, "VUYA", 200, 100, {}, None, None, "random"),
+    ("vuya_ayuv_33x17", "VUYA", 33, 17, "AYUV", 33, 17, {}, None, None, "random"),
+    ("argb_vuya_alpha_64x48", "ARGB", 64, 48, "VUYA", 64, 48, dict(alpha_value=0.5, alpha_mode="mult"), None, None, "random"),
+    ("vuya_i420_down_bilinear", "VUYA", 320, 180, "I420", 160, 90, LIN, None, None, "random"),
+    ("iyu2_iyu2_up_cubic_planes", "IYU2", 320, 180, "IYU2", 480, 270, {}, None, None, "random"),
+    ("v308_v308_crop_planes", "v308", 320, 180, "v308", 160, 90, dict(src_x=33, src_y=20, src_width=160, src_height=90), None, None, "random"),
+    ("vuya_vuya_alpha_set", "VUYA", 64, 48, "VUYA", 64, 48, dict(alpha_value=0.5, alpha_mode="set"), None, None, "random"),
+    ("vuya_nv12_down_lanczos", "VUYA", 320, 180, "NV12", 160, 90, LAN, None, None, "random"),
+    ("i420_vuya_up_bilinear", "I420", 64, 48, "VUYA", 128, 96, LIN, None, None, "random"),
+    ("deepout_v308_i42010", "v308", 64, 48, "I420_10LE", 64, 48, {}, None, None, "random"),
+    ("deepin_p010_vuya", "P010_10LE", 64, 48, "VUYA", 64, 48, {}, None, None, "random"),
+    ("w64_vuya_ayuv64", "VUYA", 64, 48, "AYUV64", 64, 48, {}, None, None, "random"),
+    ("gamma_v308_bgra", "v308", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap"), None, None, "random"),
     ("gamma_nv12_rgb24_gamma28_to_gamma22", "NV12", 64, 48, "RGB", 64, 48, dict(gamma_mode="remap"), "2:4:8:3>1:1:4:1", None, "random"),
     ("gamma_nv12_bgra_dither", "NV12", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap", dither_quantization=16), "bt709>sRGB", None, "random"),
     ("gamma_ayuv_argb_matrix_none", "AYUV", 64, 48, "ARGB", 64, 48, dict(gamma_mode="remap", matrix_mode="none"), "bt709>sRGB", None, "random"),

@@ -129,6 +129,26 @@ def test_audioresample_element_matches_reference(gst_env, ref):
     assert out.shape == exp.shape and (out == exp).all()
 
 
+def test_videoconvertscale_element_packed_444_formats(gst_env, ref):
+    """v308 and IYU2 (3-byte packed 4:4:4 YUV) on either side of the element"""
+    env, tmp = gst_env
+    w, h, n = 322, 242, 2
+    fin, fmid, fout = tmp / "p.nv12", tmp / "p.v308", tmp / "p.iyu2"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=%d,height=%d,colorimetry=bt601,chroma-site=jpeg "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw,format=v308 ! tee name=u "
+                "u. ! queue ! filesink location=%s u. ! queue ! videoconvertscale ! video/x-raw,format=IYU2,width=160,height=120 ! filesink location=%s"
+           % (n, w, h, fin, fmid, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    mid = np.fromfile(fmid, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    c0 = ref.VideoConverter("NV12", w, h, "v308", w, h, in_colorimetry="bt601", in_chroma_site="jpeg", out_colorimetry="bt601")
+    c1 = ref.VideoConverter("v308", w, h, "IYU2", 160, 120, in_colorimetry="bt601", out_colorimetry="bt601",
+                            config=cases.ref_config_string(ref, cases.LIN))
+    for f in range(n):
+        assert (c0.frame(src[f]) == mid[f]).all()
+        assert (c1.frame(mid[f]) == out[f]).all()
+
+
 def test_compositor_element_matches_reference(gst_env, ref):
     """`compositor` element (GstAggregator subclass, plugins/gstamdcompositor.c): three BGRA pads with positions, pad
     alpha, zorder and the `source` operator over the checker background, then a transparent background whose first pad

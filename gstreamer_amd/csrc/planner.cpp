@@ -46,6 +46,15 @@ static const FormatDesc g_formats[] = {
   // 10 bits per sample in 16-bit little-endian words (video-format.c:3834-3873, 5329-5400); sources of the 16-bit chain
   {GSTAMD_VIDEO_FORMAT_I420_10LE, "I420_10LE", true, false, 3, UNPACK_PLANAR, 1, 1, 1, 2, {0, 0, 0, 0}, 1},
   {GSTAMD_VIDEO_FORMAT_P010_10LE, "P010_10LE", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}, 2},
+  // 12 bits and 16 bits in the same layouts (video-format.c: unpack_I420_12LE ... pack_P016_LE, pack_Y444_16LE)
+  {GSTAMD_VIDEO_FORMAT_I420_12LE, "I420_12LE", true, false, 3, UNPACK_PLANAR, 1, 1, 1, 2, {0, 0, 0, 0}, 4},
+  {GSTAMD_VIDEO_FORMAT_I422_12LE, "I422_12LE", true, false, 3, UNPACK_PLANAR, 1, 0, 1, 2, {0, 0, 0, 0}, 4},
+  {GSTAMD_VIDEO_FORMAT_Y444_12LE, "Y444_12LE", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 4},
+  {GSTAMD_VIDEO_FORMAT_P012_LE, "P012_LE", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}, 5},
+  {GSTAMD_VIDEO_FORMAT_P016_LE, "P016_LE", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}, 6},
+  {GSTAMD_VIDEO_FORMAT_Y444_16LE, "Y444_16LE", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 6},
+  {GSTAMD_VIDEO_FORMAT_I422_10LE, "I422_10LE", true, false, 3, UNPACK_PLANAR, 1, 0, 1, 2, {0, 0, 0, 0}, 1},
+  {GSTAMD_VIDEO_FORMAT_Y444_10LE, "Y444_10LE", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 1},
   // 16 bits per component, packed, native endianness (video-format.c:2426-2473, 2523-2570): the unpack formats of the 16-bit chain themselves
   {GSTAMD_VIDEO_FORMAT_ARGB64, "ARGB64", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}, 3},
   {GSTAMD_VIDEO_FORMAT_AYUV64, "AYUV64", true, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}, 3},
@@ -109,6 +118,7 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = info->offset[1] + info->stride[0] * cr_h;
       break;
     }
+    case GSTAMD_VIDEO_FORMAT_I420_12LE:
     case GSTAMD_VIDEO_FORMAT_I420_10LE: {       /* video-info.c:1142-1156 */
       info->stride[0] = round_up (width * 2, 4);
       info->stride[1] = info->stride[2] = round_up (width, 4);
@@ -118,6 +128,24 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = info->offset[2] + info->stride[2] * cr_h;
       break;
     }
+    case GSTAMD_VIDEO_FORMAT_I422_12LE:
+    case GSTAMD_VIDEO_FORMAT_I422_10LE:         /* video-info.c:1157-1169 */
+      info->stride[0] = round_up (width * 2, 4);
+      info->stride[1] = info->stride[2] = round_up (width, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
+      info->offset[2] = info->offset[1] + (uint64_t) info->stride[1] * round_up (height, 2);
+      info->size = info->offset[2] + (uint64_t) info->stride[2] * round_up (height, 2);
+      break;
+    case GSTAMD_VIDEO_FORMAT_Y444_12LE:
+    case GSTAMD_VIDEO_FORMAT_Y444_16LE:
+    case GSTAMD_VIDEO_FORMAT_Y444_10LE:         /* video-info.c:1170-1188 */
+      info->stride[0] = info->stride[1] = info->stride[2] = round_up (width * 2, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * h;
+      info->offset[2] = info->offset[1] * 2;
+      info->size = (uint64_t) info->stride[0] * h * 3;
+      break;
+    case GSTAMD_VIDEO_FORMAT_P012_LE:
+    case GSTAMD_VIDEO_FORMAT_P016_LE:
     case GSTAMD_VIDEO_FORMAT_P010_10LE: {       /* video-info.c:1309-1321 */
       info->stride[0] = info->stride[1] = round_up (width * 2, 4);
       info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
@@ -1644,7 +1672,7 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   g.src64 = true;
   g.src16 = false;
   g.store64 = fo->hi_depth == 3;
-  g.pack16 = fo->hi_depth == 1 || fo->hi_depth == 2;
+  g.pack16 = hi_depth_words (fo->hi_depth);
   g.fused = g.planes_fast = false;
   plan->plane_mode = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_post = false;
   plan->deep16 = plan->deep_out = false;
@@ -1733,13 +1761,13 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
       fill_pack_params (in, out, fi, fo, cfg, in_w, in_h, full_out_w, full_out_h, &g.pack);
       g.pack_hi_depth = fo->hi_depth;
       if (cfg.dither_method != GSTAMD_DITHER_NONE) {
-        unsigned q = 1u << 6;
+        unsigned q = 1u << (16 - hi_depth_bits (fo->hi_depth));     /* chain_dither :2035-2085: 1 << (current_bits - depth) */
         if (cfg.dither_quantization > q)
           q = cfg.dither_quantization;
         int shift = 0;
         for (unsigned v = q; v > 1; v >>= 1)
           shift++;
-        g.dither16.on = 1;
+        g.dither16.on = shift > 0;
         g.dither16.method = cfg.dither_method;
         g.dither16.shift[1] = g.dither16.shift[2] = g.dither16.shift[3] = shift;
       }
@@ -1799,14 +1827,14 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   /* chain_dither (:2035-2085) on 16-bit lines: quantiser 1 << (16 - depth), or the target quantiser when that is coarser */
   memset (&g.dither16, 0, sizeof (g.dither16));
   if (cfg.dither_method != GSTAMD_DITHER_NONE && !g.store64) {
-    const int depth = 10;
+    const int depth = hi_depth_bits (fo->hi_depth);
     unsigned q = 1u << (16 - depth);
     if (cfg.dither_quantization > q)
       q = cfg.dither_quantization;
     int shift = 0;
     for (unsigned v = q; v > 1; v >>= 1)
       shift++;
-    g.dither16.on = 1;
+    g.dither16.on = shift > 0;
     g.dither16.method = cfg.dither_method;
     g.dither16.shift[0] = 0;            /* no alpha component in the destination: quantiser 0 */
     g.dither16.shift[1] = g.dither16.shift[2] = g.dither16.shift[3] = shift;
@@ -2056,7 +2084,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     /* video_converter_lookup_fastpath :8940-8944: "fastpaths don't do gamma" - they are only looked at for a same-size conversion
      * between equivalent transfer functions, and when one matches it runs (without any gamma step); everything else takes the chain
      * with the decode / encode tables */
-    const bool eq = transfer_equivalent (in->color_transfer, plan->fin->hi_depth ? 10 : 8, out->color_transfer, plan->fout->hi_depth ? 10 : 8);
+    const bool eq = transfer_equivalent (in->color_transfer, hi_depth_bits (plan->fin->hi_depth), out->color_transfer, hi_depth_bits (plan->fout->hi_depth));
     if (!(plan->ref_same_size && eq))
       fp = nullptr;
     if (!fp)

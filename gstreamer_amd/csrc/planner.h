@@ -37,7 +37,16 @@ struct FormatDesc {
   int hi_depth;         // 0: 8-bit samples.  3: 4 x 16-bit components per pixel (ARGB64 / AYUV64; kind UNPACK_PACKED4 with 8-byte pixels).
                         // 1 / 2: 10-bit samples in little-endian 16-bit words, in the low bits (I420_10LE) / the
                         // high bits (P010_10LE); such formats unpack to AYUV64 in the reference (video-format.c:3836, 5331)
+                        // 4 / 5: the same with 12 bits (I420_12LE ... / P012_LE), 6: all 16 bits (P016_LE, Y444_16LE)
 };
+#if defined(__HIPCC__)
+#define GSTAMD_VP __host__ __device__ inline
+#else
+#define GSTAMD_VP inline
+#endif
+// significant bits of a sample for a FormatDesc::hi_depth code, and whether the format keeps its samples in 16-bit words in planes
+GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 ? 10 : (hi == 4 || hi == 5 ? 12 : (hi == 3 || hi == 6 ? 16 : 8)); }
+GSTAMD_VP bool hi_depth_words (int hi) { return hi == 1 || hi == 2 || hi >= 4; }
 const FormatDesc *format_desc (int format);
 
 // ---- device-consumable plan pieces (POD, passed to kernels by value) --------------------------
@@ -271,11 +280,6 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
 
 // vpair table entry 0: chroma row of the pair's first line (signed 30 bits: with a source crop the row above the crop
 // origin is -1) | role << 30; entry 1: row of the second line
-#if defined(__HIPCC__)
-#define GSTAMD_VP __host__ __device__ inline
-#else
-#define GSTAMD_VP inline
-#endif
 GSTAMD_VP bool kind_has_planes (int kind) { return kind == UNPACK_PLANAR || kind == UNPACK_SEMI; }
 GSTAMD_VP int vpair_row (int e0) { return (int) ((uint32_t) e0 << 2) >> 2; }
 GSTAMD_VP int vpair_role (int e0) { return (e0 >> 30) & 1; }

@@ -12,14 +12,18 @@
 
 namespace gstamd {
 
-// a stored 16-bit little-endian word -> the unpacked 16-bit value
+// a stored 16-bit little-endian word -> the unpacked 16-bit value (FormatDesc::hi_depth: 1 / 4 = 10 / 12 bits in the low bits,
+// 2 / 5 = in the high bits, 6 = all 16)
 GSTAMD_HD int deep_widen (int hi_depth, int v)
 {
-  if (hi_depth == 1) {                  // I420_10LE: value in the low 10 bits: Y = v << 6 (as guint16), Y |= Y >> 10
-    const int t = (v << 6) & 0xffff;
-    return t | (t >> 10);
+  if (hi_depth == 6)
+    return v;                           // P016_LE, Y444_16LE
+  const int bits = hi_depth_bits (hi_depth);
+  if (hi_depth == 1 || hi_depth == 4) { // I420_10LE: Y = v << 6 (as guint16), Y |= Y >> 10; I420_12LE: << 4, >> 12
+    const int t = (v << (16 - bits)) & 0xffff;
+    return t | (t >> bits);
   }
-  return v | (v >> 10);                 // P010_10LE: value in the high 10 bits
+  return v | (v >> bits);               // P010_10LE / P012_LE: value in the high bits
 }
 
 GSTAMD_HD UV deep_load_uv (const FrontParams &f, const Planes &pl, int crow, int k)
@@ -246,7 +250,13 @@ GSTAMD_HD int dither16_with (const DitherParams &d, int comp, int v, int b)
   return p & ~((1 << sh) - 1) & 0xffff;
 }
 
-GSTAMD_HD uint16_t pack16_sample (int hi_depth, int v) { return (uint16_t) (hi_depth == 1 ? v >> 6 : v & 0xffc0); }
+GSTAMD_HD uint16_t pack16_sample (int hi_depth, int v)
+{
+  if (hi_depth == 6)
+    return (uint16_t) v;
+  const int drop = 16 - hi_depth_bits (hi_depth);
+  return (uint16_t) (hi_depth == 1 || hi_depth == 4 ? v >> drop : v & ~((1 << drop) - 1));      /* pack_I420_10LE >> 6, pack_P010_10LE & 0xffc0, ... */
+}
 
 // per-lane block as pack_planar_body: pixels x0 .. x0+3 of the lines (yb << h_sub) ..; planar and semi-planar kinds
 GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride,

@@ -65,6 +65,14 @@ enum {
   GSTAMD_VIDEO_FORMAT_ARGB64 = 39,      /* 16 bits per component, native endianness (little endian here), memory order A R G B */
   GSTAMD_VIDEO_FORMAT_AYUV64 = 40,      /* the same with A Y U V */
   GSTAMD_VIDEO_FORMAT_I420_10LE = 43,   /* 10 bits in the low bits of little-endian 16-bit words; see DESIGN.md 3.6 / 3.7 for the combinations */
+  GSTAMD_VIDEO_FORMAT_I422_10LE = 45,   /* planar 4:2:2 and 4:4:4 with the same 10-bit samples */
+  GSTAMD_VIDEO_FORMAT_Y444_10LE = 47,
+  GSTAMD_VIDEO_FORMAT_I420_12LE = 73,   /* 12 bits in the low bits */
+  GSTAMD_VIDEO_FORMAT_I422_12LE = 75,
+  GSTAMD_VIDEO_FORMAT_Y444_12LE = 77,
+  GSTAMD_VIDEO_FORMAT_Y444_16LE = 88,   /* all 16 bits */
+  GSTAMD_VIDEO_FORMAT_P016_LE = 90,
+  GSTAMD_VIDEO_FORMAT_P012_LE = 92,     /* 12 bits in the high bits */
   GSTAMD_VIDEO_FORMAT_NV61 = 60,
   GSTAMD_VIDEO_FORMAT_P010_10LE = 62,   /* 10 bits in the high bits of little-endian 16-bit words */
   GSTAMD_VIDEO_FORMAT_VYUY = 64

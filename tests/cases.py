@@ -402,6 +402,52 @@ VIDEO_CASES = [
     ("deepin_p010_vuya", "P010_10LE", 64, 48, "VUYA", 64, 48, {}, None, None, "random"),
     ("w64_vuya_ayuv64", "VUYA", 64, 48, "AYUV64", 64, 48, {}, None, None, "random"),
     ("gamma_v308_bgra", "v308", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap"), None, None, "random"),
+    # 10-bit 4:2:2 / 4:4:4 planar, 12-bit and 16-bit samples (FormatDesc::hi_depth 1 / 4 / 5 / 6) through every 16-bit path
+    ("hd_i422_10le_bgra_64x36", "I422_10LE", 64, 36, "BGRA", 64, 36, {}, None, None, "random"),
+    ("hd_i422_10le_argb_33x17_col", "I422_10LE", 33, 17, "ARGB", 33, 17, {}, 'bt709', 'mpeg2', "random"),
+    ("hd_y444_10le_bgra_64x36", "Y444_10LE", 64, 36, "BGRA", 64, 36, {}, None, None, "random"),
+    ("hd_y444_10le_ayuv_33x17", "Y444_10LE", 33, 17, "AYUV", 33, 17, {}, None, None, "random"),
+    ("hd_i422_10le_rgba_160x120_bilinear", "I422_10LE", 322, 242, "RGBA", 160, 120, LIN, None, None, "random"),
+    ("hd_y444_10le_rgba_160x120_lanczos", "Y444_10LE", 322, 242, "RGBA", 160, 120, LAN, None, None, "random"),
+    ("hd_i422_10le_bgra_128x96", "I422_10LE", 64, 48, "BGRA", 128, 96, {}, None, None, "random"),
+    ("hd_bgra_i422_10le_64x36", "BGRA", 64, 36, "I422_10LE", 64, 36, {}, None, None, "random"),
+    ("hd_bgra_y444_10le_33x17", "BGRA", 33, 17, "Y444_10LE", 33, 17, {}, None, None, "random"),
+    ("hd_nv12_i422_10le_64x36", "NV12", 64, 36, "I422_10LE", 64, 36, {}, None, None, "random"),
+    ("hd_i420_10le_i422_10le_64x36", "I420_10LE", 64, 36, "I422_10LE", 64, 36, {}, None, None, "random"),
+    ("hd_i422_10le_i420_10le_64x36", "I422_10LE", 64, 36, "I420_10LE", 64, 36, {}, None, None, "random"),
+    ("hd_y444_10le_p010_10le_64x36", "Y444_10LE", 64, 36, "P010_10LE", 64, 36, {}, None, None, "random"),
+    ("hd_i422_10le_i422_10le_64x36", "I422_10LE", 64, 36, "I422_10LE", 64, 36, {}, None, None, "random"),
+    ("hd_y444_10le_y444_10le_32x18", "Y444_10LE", 64, 36, "Y444_10LE", 32, 18, {}, None, None, "random"),
+    ("hd_i422_10le_nv12_64x36", "I422_10LE", 64, 36, "NV12", 64, 36, {}, None, None, "random"),
+    ("hd_y444_10le_ayuv64_64x36", "Y444_10LE", 64, 36, "AYUV64", 64, 36, {}, None, None, "random"),
+    ("hd_ayuv64_i422_10le_64x36", "AYUV64", 64, 36, "I422_10LE", 64, 36, {}, None, None, "random"),
+    ("hd_bgra_y444_10le_100x60_bilinear", "BGRA", 64, 36, "Y444_10LE", 100, 60, LIN, None, None, "random"),
+    ("hd_i422_10le_y42b_65x37", "I422_10LE", 65, 37, "Y42B", 65, 37, {}, None, None, "random"),
+    ("hd_y42b_i422_10le_65x37", "Y42B", 65, 37, "I422_10LE", 65, 37, {}, None, None, "random"),
+    ("hd_i420_12le_bgra_64x36", "I420_12LE", 64, 36, "BGRA", 64, 36, {}, None, None, "random"),
+    ("hd_p012_le_argb_33x17_col", "P012_LE", 33, 17, "ARGB", 33, 17, {}, 'bt709', 'mpeg2', "random"),
+    ("hd_p016_le_bgra_64x36", "P016_LE", 64, 36, "BGRA", 64, 36, {}, None, None, "random"),
+    ("hd_y444_16le_ayuv_33x17", "Y444_16LE", 33, 17, "AYUV", 33, 17, {}, None, None, "random"),
+    ("hd_i422_12le_rgba_160x120_bilinear", "I422_12LE", 322, 242, "RGBA", 160, 120, LIN, None, None, "random"),
+    ("hd_y444_12le_rgba_160x120_lanczos", "Y444_12LE", 322, 242, "RGBA", 160, 120, LAN, None, None, "random"),
+    ("hd_bgra_i420_12le_64x36", "BGRA", 64, 36, "I420_12LE", 64, 36, {}, None, None, "random"),
+    ("hd_bgra_p012_le_33x17", "BGRA", 33, 17, "P012_LE", 33, 17, {}, None, None, "random"),
+    ("hd_bgra_p016_le_33x17", "BGRA", 33, 17, "P016_LE", 33, 17, {}, None, None, "random"),
+    ("hd_bgra_p016_le_33x17_q64", "BGRA", 33, 17, "P016_LE", 33, 17, dict(dither_quantization=64), None, None, "random"),
+    ("hd_nv12_y444_16le_64x36", "NV12", 64, 36, "Y444_16LE", 64, 36, {}, None, None, "random"),
+    ("hd_i420_10le_i420_12le_64x36", "I420_10LE", 64, 36, "I420_12LE", 64, 36, {}, None, None, "random"),
+    ("hd_i420_12le_i420_10le_64x36", "I420_12LE", 64, 36, "I420_10LE", 64, 36, {}, None, None, "random"),
+    ("hd_p016_le_p010_10le_64x36", "P016_LE", 64, 36, "P010_10LE", 64, 36, {}, None, None, "random"),
+    ("hd_p012_le_p012_le_64x36", "P012_LE", 64, 36, "P012_LE", 64, 36, {}, None, None, "random"),
+    ("hd_y444_16le_y444_16le_32x18", "Y444_16LE", 64, 36, "Y444_16LE", 32, 18, {}, None, None, "random"),
+    ("hd_i422_12le_nv12_64x36", "I422_12LE", 64, 36, "NV12", 64, 36, {}, None, None, "random"),
+    ("hd_p016_le_ayuv64_64x36", "P016_LE", 64, 36, "AYUV64", 64, 36, {}, None, None, "random"),
+    ("hd_ayuv64_p016_le_64x36", "AYUV64", 64, 36, "P016_LE", 64, 36, {}, None, None, "random"),
+    ("hd_bgra_y444_12le_100x60_bilinear", "BGRA", 64, 36, "Y444_12LE", 100, 60, LIN, None, None, "random"),
+    ("hd_i420_12le_i420_65x37", "I420_12LE", 65, 37, "I420", 65, 37, {}, None, None, "random"),
+    ("hd_i420_i420_12le_65x37", "I420", 65, 37, "I420_12LE", 65, 37, {}, None, None, "random"),
+    ("hd_p012_le_p016_le_65x37", "P012_LE", 65, 37, "P016_LE", 65, 37, {}, None, None, "random"),
+    ("hd_i420_12le_bgra_64x36_col", "I420_12LE", 64, 36, "BGRA", 64, 36, {}, '2:4:14:1', None, "random"),
     ("gamma_nv12_rgb24_gamma28_to_gamma22", "NV12", 64, 48, "RGB", 64, 48, dict(gamma_mode="remap"), "2:4:8:3>1:1:4:1", None, "random"),
     ("gamma_nv12_bgra_dither", "NV12", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap", dither_quantization=16), "bt709>sRGB", None, "random"),
     ("gamma_ayuv_argb_matrix_none", "AYUV", 64, 48, "ARGB", 64, 48, dict(gamma_mode="remap", matrix_mode="none"), "bt709>sRGB", None, "random"),

@@ -149,6 +149,28 @@ def test_videoconvertscale_element_packed_444_formats(gst_env, ref):
         assert (c1.frame(mid[f]) == out[f]).all()
 
 
+def test_videoconvertscale_element_12_bit_formats(gst_env, ref):
+    """I420_12LE out of the element and back into it as Y444_10LE -> BGRA"""
+    env, tmp = gst_env
+    w, h, n = 320, 240, 2
+    fin, fmid, fout = tmp / "d.nv12", tmp / "d.i42012", tmp / "d.bgra"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=%d,height=%d,colorimetry=bt601,chroma-site=jpeg "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw,format=I420_12LE ! tee name=u "
+                "u. ! queue ! filesink location=%s u. ! queue ! videoconvertscale ! video/x-raw,format=Y444_10LE ! videoconvertscale ! video/x-raw,format=BGRA "
+                "! filesink location=%s" % (n, w, h, fin, fmid, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    mid = np.fromfile(fmid, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    kw = dict(in_colorimetry="bt601", in_chroma_site="jpeg", out_colorimetry="bt601")
+    c0 = ref.VideoConverter("NV12", w, h, "I420_12LE", w, h, out_chroma_site="jpeg", **kw)
+    c1 = ref.VideoConverter("I420_12LE", w, h, "Y444_10LE", w, h, out_chroma_site="jpeg", **kw)
+    c2 = ref.VideoConverter("Y444_10LE", w, h, "BGRA", w, h, in_colorimetry="bt601", in_chroma_site="jpeg")
+    for f in range(n):
+        m = c0.frame(src[f])
+        assert (m == mid[f]).all()
+        assert (c2.frame(c1.frame(m)) == out[f]).all()
+
+
 def test_compositor_element_matches_reference(gst_env, ref):
     """`compositor` element (GstAggregator subclass, plugins/gstamdcompositor.c): three BGRA pads with positions, pad
     alpha, zorder and the `source` operator over the checker background, then a transparent background whose first pad

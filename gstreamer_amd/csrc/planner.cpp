@@ -1296,6 +1296,12 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
       else
         need_h = need_v = true;
     }
+    /* a packed 4:2:2 line: setup_scale compares the PIXEL widths (:8020); 63 and 64 pixels are the same 32 macropixels and still
+       go through the merged scaler */
+    if (fo->kind == UNPACK_PACKED422 && in.width != out.width && !need_h) {
+      need_h = true;
+      pp.kind = PLANE_SCALE;
+    }
     if (pp.kind == PLANE_SCALE) {
       ScalePass hp, vp;
       /* get_functions (video-scaler.c:1202-1342): a 2-tap horizontal pass is ldreslin only for 1- and 4-byte pixels;
@@ -1595,6 +1601,10 @@ static void deep_planes_try (const GstAmdVideoInfo *in, const GstAmdVideoInfo *o
   if (!fi->yuv || !fo->yuv || !kind_has_planes (fi->kind) || !kind_has_planes (fo->kind) || fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub ||
       in->width != out->width || in->height != out->height || resampler || g.prim.has_matrix || g.alpha_kind != ALPHA_NONE || plan->rect.in_x ||
       plan->rect.in_y || (plan->rect.in_maxw && (plan->rect.in_maxw != in->width || plan->rect.in_maxh != in->height)))
+    return;
+  /* pack_NV61 writes the last chroma pair of an odd-width line in NV16 order (video-format.c:2005-2011; PackPlanarParams::tail_swap):
+     the general packer knows, this per-sample form does not */
+  if (fo->format == GSTAMD_VIDEO_FORMAT_NV61 && (out->width & 1))
     return;
   DeepPlanesParams &d = g.planes;
   memset (&d, 0, sizeof (d));
@@ -2489,7 +2499,99 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       *error = "borders on a packed 4:2:2 destination (the macropixel border of convert_fill_border) are not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
   }
-  return plan_core (&ein, &eout, &cfg, plan, error);
+  const int r = plan_core (&ein, &eout, &cfg, plan, error);
+  if (r != GSTAMD_OK || !fi || !fo)
+    return r;
+  /* Two places where the reference's generic chain reads lines it has not (or has already) converted; its output there is
+   * uninitialised memory or a matrix applied twice, so there is nothing to reproduce - such plans are refused:
+   *  (a) do_convert_lines converts MIN (in_width, out_width) pixels (:3112) into a FRESH line when the bit depth changes (:3117-3136).
+   *      When the line is wider than that at this point - the horizontal pass already enlarged it (scaling first, the picture
+   *      shrinks overall) or will only shrink it afterwards (scaling last) - the scaler / packer reads the rest uninitialised.
+   *  (b) the nearest vertical scaler hands out the SAME line for every output row it repeats (video_scale_v_near), and the
+   *      convert / alpha stages after it work in place (:3127-3141, do_alpha_lines): a repeated row gets the matrix once more
+   *      per repetition. */
+  const VideoPlan &pl = *plan;
+  const bool chain = !pl.plane_mode && pl.ref_fastpath.empty ();
+  const int iw = ein.width, ih = ein.height, ow = eout.width, oh = eout.height;
+  const bool scale_first = (long) ow * oh <= (long) iw * ih;
+  const bool remap = pl.gamma.on && cfg.gamma_mode == GSTAMD_GAMMA_MODE_REMAP;
+  if (chain && (iw != ow || ih != oh)) {
+    const int in_bits = fi->hi_depth ? 16 : 8, out_bits = fo->hi_depth ? 16 : 8;
+    if (in_bits != out_bits && !remap && (scale_first ? ow : iw) > std::min (iw, ow)) {
+      if (error)
+        *error = "the reference converts only MIN (in_width, out_width) pixels of a line when the bit depth changes (do_convert_lines); with the "
+            "horizontal pass on the other side of that step its output is uninitialised memory; not reproduced";
+      return GSTAMD_ERR_UNSUPPORTED;
+    }
+    bool v_near_up = false;
+    for (const ScalePass &sp : pl.passes)
+      v_near_up = v_near_up || (!sp.horizontal && sp.kind == SCALE_NEAREST && sp.out_size > sp.in_size);
+    const GammaPlan &g = pl.gamma;
+    const bool in_place_op = pl.post.matrix.kind != MATRIX_NONE || pl.matrix.kind != MATRIX_NONE || pl.post.alpha_kind == ALPHA_MULT || pl.deep.has_matrix ||
+        (g.on && (g.prim.has_matrix || g.to_rgb.kind != MATRIX_NONE || g.to_yuv.kind != MATRIX_NONE || g.alpha_kind == ALPHA_MULT || remap));
+    /* the stages after the scalers that write into their input line: chroma downsampling (video_chroma_down_h2 / v2 work on the
+     * lines they are given) and the dither stage (do_dither_lines, write_input) */
+    const bool late_in_place = pl.dither.on || (g.on && g.dither16.on) || ((pl.out_planar || fo->kind == UNPACK_PACKED422) && (pl.pack.down_h || pl.pack.down_v)) ||
+        (g.on && g.pack16 && (g.pack.down_h || g.pack.down_v));
+    /* (the colour / alpha stage only shows it when the lines are the destination frame's own rows - a destination in its unpack
+     * format, identity_pack :2105, get_dest_line; with temporary lines the repeated row is converted from a fresh copy) */
+    const bool identity_pack = fo->format == GSTAMD_VIDEO_FORMAT_AYUV || fo->format == GSTAMD_VIDEO_FORMAT_ARGB ||
+        fo->format == GSTAMD_VIDEO_FORMAT_AYUV64 || fo->format == GSTAMD_VIDEO_FORMAT_ARGB64;
+    /* with temporary lines it shows once a row is repeated more than twice (the ring hands the converted line out again:
+       7 -> 14 rows match, 7 -> 49 do not) */
+    bool many_repeats = false;
+    for (const ScalePass &sp : pl.passes)
+      many_repeats = many_repeats || (!sp.horizontal && sp.kind == SCALE_NEAREST && sp.out_size > 2 * sp.in_size);
+    if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats)) || late_in_place)) {
+      if (error)
+        *error = "nearest vertical enlargement ahead of a stage that works in place (colour / alpha, chroma downsampling, dither): the reference "
+            "processes a repeated line once per repetition (line aliasing); not reproduced";
+      return GSTAMD_ERR_UNSUPPORTED;
+    }
+  }
+  /* the composite plans (8-bit source into the 16-bit part of the chain) unpack and upsample the whole frame in line order before
+   * anything else; the reference's vertical chroma upsampler pairs lines in the order the nearest vertical scaler asks for them
+   * (it skips / repeats lines), which the pair-table simulation of the direct plans follows and the composite does not */
+  if (chain && pl.gamma.on && !pl.gamma.src16 && !pl.gamma.src64 && fi->h_sub == 1 && kind_has_planes (fi->kind)) {
+    for (const ScalePass &sp : pl.passes)
+      if (!sp.horizontal && sp.kind == SCALE_NEAREST) {
+        if (error)
+          *error = "nearest vertical scaling of a 4:2:0 source through the 16-bit part of the chain (line pairing of the chroma upsampler follows the scaler's requests) is not implemented";
+        return GSTAMD_ERR_UNSUPPORTED;
+      }
+  }
+  /* do_alpha_lines sets / multiplies MIN (in_width, out_width) pixels (video-converter.c do_alpha_lines); when the line is wider at
+   * that point (the horizontal pass on the other side of the alpha stage) the rest keeps the alpha it had.  Well defined, but not
+   * built here: refused rather than silently different */
+  {
+    const bool alpha_op = pl.post.alpha_kind != ALPHA_NONE || (pl.gamma.on && pl.gamma.alpha_kind != ALPHA_NONE);
+    if (chain && alpha_op && (scale_first ? ow : iw) > std::min (iw, ow)) {
+      if (error)
+        *error = "alpha-mode set / mult with the horizontal pass on the other side of the alpha stage (the reference touches MIN (in_width, out_width) "
+            "pixels of a wider line) is not implemented";
+      return GSTAMD_ERR_UNSUPPORTED;
+    }
+  }
+  /* a 4:2:0 source into a 4:2:0 destination of odd height through the composite plans: the reference's last chroma row averages the
+   * last line with a line past the picture, which its upsampler makes from the clamped last rows (do_unpack_lines clamps :2966); the
+   * composite's sub-conversions end at the last line - and the direct plans' pair table has no entry for that line either */
+  const bool both_v = !pl.gamma.on && pl.front.chroma_v2 && pl.out_planar && pl.pack.down_v;       /* direct plans: both vertical chroma resamplers run */
+  if (chain && ((pl.gamma.on && !pl.gamma.planes_fast) || both_v) && fi->h_sub == 1 && fo->h_sub == 1 && (oh & 1)) {
+    if (error)
+      *error = "4:2:0 -> 4:2:0 of odd height through the generic chain (chroma of the line past the picture) is not implemented";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  /* unpack_VYUY (video-format.c:310-352) falls back to a C loop with U and V the other way round when the line it writes is not
+   * 8-byte aligned; with an unpack-format destination the lines are the destination frame's own (get_dest_line), so on frames whose
+   * rows are not all 8-byte aligned (odd widths) every other row comes out with swapped chroma */
+  if (chain && fi->format == GSTAMD_VIDEO_FORMAT_VYUY && iw == ow && ih == oh && fo->kind == UNPACK_PACKED4 && fo->hi_depth == 0 &&
+      fo->pos[0] == 0 && fo->pos[1] == 1 && fo->pos[2] == 2 && fo->pos[3] == 3 && (fo->alpha) &&
+      ((out->stride[0] % 8) != 0 || (out->offset[0] % 8) != 0)) {
+    if (error)
+      *error = "VYUY unpacked straight into destination rows that are not 8-byte aligned: the reference's fallback loop swaps U and V there; not reproduced";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  return r;
 }
 
 bool plan_is_pad_scaler (const VideoPlan &p, int *h, int *v)

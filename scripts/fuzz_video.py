@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the converter: kernel bodies on the host emulator (tests/emu) against the reference (oracle/_ref) over
+random format pairs, sizes and options.  A plan is either refused or must match the reference byte for byte (bytes outside the picture -
+stride padding - excepted).  python scripts/fuzz_video.py <seed> <count> [-v]; tests/test_video_fuzz.py runs a fixed slice of it."""
+import ctypes as C
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+from gstreamer_amd import video as V  # noqa: E402
+
+
+def random_case(rnd):
+    fm = sorted(V.FORMATS)
+    ifmt, ofmt = rnd.choice(fm), rnd.choice(fm)
+    w, h = rnd.randint(1, 70), rnd.randint(1, 40)
+    ow, oh = (w, h) if rnd.random() < 0.5 else (rnd.randint(1, 90), rnd.randint(1, 50))
+    cfg = {}
+    if rnd.random() < 0.5:
+        cfg["resampler_method"] = rnd.choice(["nearest", "linear", "cubic", "sinc", "lanczos"])
+    if rnd.random() < 0.2:
+        cfg["max_taps"] = rnd.choice([2, 4, 8])
+    if rnd.random() < 0.2:
+        cfg["alpha_mode"] = rnd.choice(["copy", "set", "mult"])
+        cfg["alpha_value"] = rnd.choice([0.25, 0.5, 1.0])
+    if rnd.random() < 0.15:
+        cfg["chroma_mode"] = rnd.choice(["full", "upsample-only", "downsample-only", "none"])
+    if rnd.random() < 0.1:
+        cfg["dither_quantization"] = rnd.choice([2, 8, 16])
+    if rnd.random() < 0.1:
+        cfg["matrix_mode"] = rnd.choice(["full", "input-only", "output-only", "none"])
+    col = rnd.choice([None, None, "bt601", "bt709"])
+    site = rnd.choice([None, None, "jpeg", "mpeg2", "cosited"])
+    return ifmt, w, h, ofmt, ow, oh, cfg, col, site
+
+
+def run_case(emu, ref, case, seed):
+    """-> ("ok" | "refused" | "bad", description)"""
+    ifmt, w, h, ofmt, ow, oh, cfg, col, site = case
+    ii = V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site)
+    oi = V.video_info(ofmt, ow, oh)
+    src = cases.frame_bytes(ii.size, "random", seed, w)
+    c = V.converter_config(**cfg)
+    dst = np.zeros(oi.size, np.uint8)
+    desc = C.create_string_buffer(256)
+    r = emu.emu_video_convert(C.byref(ii), C.byref(oi), C.byref(c), src.ctypes.data, dst.ctypes.data, 1, desc, 256)
+    if r != 0:
+        return "refused", desc.value.decode()
+    want = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site, config=cases.ref_config_string(ref, cfg)).frame(src)
+    if (dst == want).all():
+        return "ok", desc.value.decode()
+    vb = lambda b: cases.visible_bytes(ofmt, ow, oh, list(oi.stride), list(oi.offset), b)
+    try:
+        if (vb(dst) == vb(want)).all():
+            return "ok", desc.value.decode()
+    except Exception:
+        pass
+    return "bad", "%s: %d of %d bytes differ" % (desc.value.decode(), int((dst != want).sum()), dst.size)
+
+
+def load_emu():
+    emu = C.CDLL(os.path.join(ROOT, "tests", "emu", "libgstamdemu.so"))
+    emu.emu_video_convert.argtypes = [C.POINTER(V.VideoInfo), C.POINTER(V.VideoInfo), C.POINTER(V.ConverterConfig), C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_char_p, C.c_int]
+    return emu
+
+
+def main():
+    from oracle import ref
+    seed, n = int(sys.argv[1]), int(sys.argv[2])
+    rnd = random.Random(seed)
+    emu = load_emu()
+    count = {"ok": 0, "refused": 0, "bad": 0}
+    for it in range(n):
+        case = random_case(rnd)
+        verdict, text = run_case(emu, ref, case, seed * 1000 + it)
+        count[verdict] += 1
+        if verdict == "bad" or "-v" in sys.argv:
+            print(verdict.upper(), case, text)
+    print("seed %d: %s" % (seed, count))
+    return 1 if count["bad"] else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

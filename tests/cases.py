@@ -543,6 +543,19 @@ VIDEO_REFUSED = [
     ("NV12", 320, 180, "BGRA", 640, 100, LAN),           # reference temp-line aliasing (see planner.cpp)
     ("NV12", 64, 64, "BGRA", 64, 64, dict(dither_quantization=4, dither_method="floyd-steinberg")),   # error diffusion: sequential
     ("NV12", 64, 64, "I420", 64, 64, dict(dither_quantization=4)),      # dither between chroma downsampling and pack: not built
+    # places where the reference's own output is uninitialised memory or depends on line aliasing (found by scripts/fuzz_video.py; planner.cpp
+    # plan_video_converter explains each): refused rather than silently different
+    ("AYUV64", 58, 18, "AYUV", 30, 38, {}),              # bit depth changes with the line wider than MIN (in_width, out_width): do_convert_lines
+    ("P010_10LE", 30, 38, "BGRA", 58, 18, {}),           # the same with the horizontal pass ahead of the convert stage
+    ("AYUV", 58, 18, "ARGB", 30, 20, NEAR),              # nearest vertical enlargement ahead of the in-place matrix, destination rows as lines
+    ("BGRA", 29, 7, "Y444", 4, 49, NEAR),                # the same through temporary lines once rows repeat more than twice
+    ("RGBx", 28, 1, "BGRx", 55, 47, dict(dither_quantization=2)),   # ... ahead of the dither stage
+    ("IYU2", 11, 3, "Y42B", 15, 39, NEAR),               # ... ahead of the chroma downsampler
+    ("BGRA", 67, 36, "AYUV", 76, 21, dict(alpha_mode="mult", alpha_value=0.5)),    # alpha stage on MIN (in_width, out_width) pixels of a wider line
+    ("YV12", 11, 21, "Y444_16LE", 85, 12, NEAR),         # nearest vertical scaling of 4:2:0 through the composite plans
+    ("NV12", 67, 3, "I420", 67, 3, {}, "bt601", "mpeg2"),           # chroma of the line past an odd-height picture (generic chain)
+    ("P010_10LE", 31, 13, "NV12", 23, 13, {}),           # the same through the composite plans
+    ("VYUY", 59, 11, "AYUV", 59, 11, {}),                # unpack_VYUY's fallback loop on rows that are not 8-byte aligned swaps U and V
 ]
 
 

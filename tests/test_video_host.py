@@ -85,13 +85,14 @@ def test_c3_plan(native_lib):
 
 @pytest.mark.parametrize("case", cases.VIDEO_REFUSED, ids=lambda c: "%s_%dx%d_%s_%dx%d" % tuple(c[:6]))
 def test_unsupported_paths_are_refused_not_approximated(native_lib, case):
-    ifmt, w, h, ofmt, ow, oh, cfg = case
+    ifmt, w, h, ofmt, ow, oh, cfg = case[:7]
+    col, site = (case[7], case[8]) if len(case) > 7 else (None, None)
     try:
         oi = V.video_info(ofmt, ow, oh)
     except KeyError:
         return
     with pytest.raises(V.GstAmdError) as e:
-        V.VideoConverter(V.video_info(ifmt, w, h), oi, V.converter_config(**cfg))
+        V.VideoConverter(V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site), oi, V.converter_config(**cfg))
     assert e.value.code == V.ERR_UNSUPPORTED
 
 

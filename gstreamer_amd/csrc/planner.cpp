@@ -2542,7 +2542,9 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     bool many_repeats = false;
     for (const ScalePass &sp : pl.passes)
       many_repeats = many_repeats || (!sp.horizontal && sp.kind == SCALE_NEAREST && sp.out_size > 2 * sp.in_size);
-    if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats)) || late_in_place)) {
+    /* and when the bit depth changes the matrix runs on the SOURCE line before it is narrowed into a fresh one (:3127-3136): the
+       repeated row's source line has already been through it */
+    if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place)) {
       if (error)
         *error = "nearest vertical enlargement ahead of a stage that works in place (colour / alpha, chroma downsampling, dither): the reference "
             "processes a repeated line once per repetition (line aliasing); not reproduced";

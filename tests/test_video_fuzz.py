@@ -24,3 +24,44 @@ def test_random_conversions_match_reference_or_are_refused(emu_lib, ref, seed):
             bad.append((case, text))
     assert not bad, bad[:5]
     assert count["ok"] >= 80, count
+
+
+GPU_SEEDS = [int(x) for x in os.environ.get("GSTAMD_FUZZ_SEEDS", "101,404,505").split(",")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", GPU_SEEDS)
+def test_hip_random_conversions_match_reference_or_are_refused(native_lib, gpu, ref, seed):
+    """the same draws (and two more seeds) through the HIP library on the device"""
+    import numpy as np
+    import torch
+
+    import cases
+    from gstreamer_amd import video as V
+    rnd = random.Random(seed)
+    ok, bad = 0, []
+    for it in range(150):
+        case = fuzz_video.random_case(rnd)
+        ifmt, w, h, ofmt, ow, oh, cfg, col, site = case
+        ii = V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site)
+        oi = V.video_info(ofmt, ow, oh)
+        try:
+            conv = V.VideoConverter(ii, oi, V.converter_config(**cfg))
+        except V.GstAmdError as e:
+            assert e.code == V.ERR_UNSUPPORTED
+            continue
+        src = cases.frame_bytes(int(ii.size), "random", seed * 1000 + it, w)
+        d_src = torch.from_numpy(src).to(gpu)
+        d_dst = torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu)
+        conv.frame(d_src, d_dst)
+        torch.cuda.synchronize()
+        got = d_dst.cpu().numpy()
+        conv.free()
+        want = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site, config=cases.ref_config_string(ref, cfg)).frame(src)
+        vb = lambda b: cases.visible_bytes(ofmt, ow, oh, list(oi.stride), list(oi.offset), b)
+        if (got == want).all() or (vb(got) == vb(want)).all():
+            ok += 1
+        else:
+            bad.append((case, int((got != want).sum())))
+    assert not bad, bad[:5]
+    assert ok >= 100

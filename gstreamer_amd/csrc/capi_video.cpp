@@ -245,43 +245,62 @@ void gstamd_video_converter_config_init (GstAmdVideoConverterConfig *config)
     converter_config_init (config);
 }
 
+/* the sub-conversions of a composite plan (gamma remap / the 16-bit part of the chain: GammaPlan) - made for `plan`, handed back
+ * through sub_in / sub_out; the description and the divergence note of the plan take theirs on.  Used by _new and by _set_config,
+ * which must not keep sub-converters planned with the old options (a new resampler method, rectangle or gamma mode changes them) */
+static int build_sub_converters (VideoPlan &plan, GstAmdVideoConverter **sub_in, GstAmdVideoConverter **sub_out)
+{
+  *sub_in = *sub_out = nullptr;
+  if (!plan.gamma.on || plan.gamma.planes_fast)
+    return GSTAMD_OK;
+  const GammaPlan &g = plan.gamma;
+  int st = GSTAMD_OK;
+  bool ok = true;
+  if (!g.src16 && !g.src64)
+    ok = (*sub_in = gstamd_video_converter_new (&g.sub_in_info, &g.mid_in, &g.cfg_in, &st)) != nullptr;
+  if (ok && g.fused) {
+    ok = (*sub_in)->plan.passes.empty () && !(*sub_in)->plan.out_planar && !(*sub_in)->plan.plane_mode && !(*sub_in)->plan.gamma.on;
+    if (!ok) {
+      st = GSTAMD_ERR_UNSUPPORTED;
+      g_last_error = "the direct conversion of a fused gamma plan is not a one-kernel plan";
+    }
+  }
+  if (ok && !g.pack16 && !g.store64 && !g.fused)
+    ok = (*sub_out = gstamd_video_converter_new (&g.mid_out, &g.sub_out_info, &g.cfg_out, &st)) != nullptr;
+  if (!ok) {
+    const std::string why = g_last_error;
+    gstamd_video_converter_free (*sub_in);
+    gstamd_video_converter_free (*sub_out);
+    *sub_in = *sub_out = nullptr;
+    set_error (st, "16-bit chain: " + why);
+    return st;
+  }
+  if (*sub_in) {
+    plan.description += " <- " + (*sub_in)->plan.description;
+    plan.divergence += (*sub_in)->plan.divergence;
+  }
+  if (*sub_out) {
+    plan.description += " -> " + (*sub_out)->plan.description;
+    plan.divergence += (*sub_out)->plan.divergence;
+  }
+  return GSTAMD_OK;
+}
+
 GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info, const GstAmdVideoInfo *out_info,
     const GstAmdVideoConverterConfig *config, int *status)
 {
   GstAmdVideoConverter *c = new GstAmdVideoConverter ();
   std::string err;
   int r = plan_video_converter (in_info, out_info, config, &c->plan, &err);
+  if (r == GSTAMD_OK)
+    r = build_sub_converters (c->plan, &c->sub_in, &c->sub_out);
+  else
+    set_error (r, err);
   if (status)
     *status = r;
   if (r != GSTAMD_OK) {
-    set_error (r, err);
     delete c;
     return nullptr;
-  }
-  if (c->plan.gamma.on) {
-    const GammaPlan &g = c->plan.gamma;
-    int st = GSTAMD_OK;
-    bool ok = true;
-    if (g.planes_fast)
-      return c;
-    if (!g.src16 && !g.src64)
-      ok = (c->sub_in = gstamd_video_converter_new (&g.sub_in_info, &g.mid_in, &g.cfg_in, &st)) != nullptr;
-    if (ok && g.fused)
-      ok = c->sub_in->plan.passes.empty () && !c->sub_in->plan.out_planar && !c->sub_in->plan.plane_mode && !c->sub_in->plan.gamma.on;
-    if (ok && !g.pack16 && !g.store64 && !g.fused)
-      ok = (c->sub_out = gstamd_video_converter_new (&g.mid_out, &g.sub_out_info, &g.cfg_out, &st)) != nullptr;
-    if (!ok) {
-      const std::string why = g_last_error;
-      if (status)
-        *status = st;
-      gstamd_video_converter_free (c);
-      set_error (st, "16-bit chain: " + why);
-      return nullptr;
-    }
-    if (c->sub_in)
-      c->plan.description += " <- " + c->sub_in->plan.description;
-    if (c->sub_out)
-      c->plan.description += " -> " + c->sub_out->plan.description;
   }
   return c;
 }
@@ -1268,10 +1287,24 @@ int gstamd_video_converter_set_config (GstAmdVideoConverter *c, const GstAmdVide
   int r = plan_video_converter (&in, &out, config, &np, &err);
   if (r != GSTAMD_OK)
     return set_error (r, err);          /* the old plan stays, like a failed gst_video_converter_set_config leaves the converter usable */
-  std::lock_guard<std::mutex> g (c->lock);
-  (void) hipDeviceSynchronize ();       /* frames in flight still read the old tables */
-  release_tables (c);
-  c->plan = std::move (np);
+  /* the new plan's sub-conversions first; on failure the old plan and the old sub-converters stay */
+  GstAmdVideoConverter *nin = nullptr, *nout = nullptr;
+  if ((r = build_sub_converters (np, &nin, &nout)) != GSTAMD_OK)
+    return r;
+  GstAmdVideoConverter *oin, *oout;
+  {
+    std::lock_guard<std::mutex> g (c->lock);
+    (void) hipDeviceSynchronize ();       /* frames in flight still read the old tables */
+    release_tables (c);
+    c->plan = std::move (np);
+    oin = c->sub_in;
+    oout = c->sub_out;
+    c->sub_in = nin;
+    c->sub_out = nout;
+    c->hook_on = false;
+  }
+  gstamd_video_converter_free (oin);
+  gstamd_video_converter_free (oout);
   return GSTAMD_OK;
 }
 
@@ -1314,6 +1347,11 @@ int gstamd_internal_pad_scaler (GstAmdVideoConverter *c, gstamd::ScaleDev *sh, g
 const char *gstamd_video_converter_describe (const GstAmdVideoConverter *c)
 {
   return c ? c->plan.description.c_str () : "";
+}
+
+const char *gstamd_video_converter_divergence (const GstAmdVideoConverter *c)
+{
+  return c ? c->plan.divergence.c_str () : "";
 }
 
 uint64_t gstamd_video_converter_algorithmic_bytes (const GstAmdVideoConverter *c)

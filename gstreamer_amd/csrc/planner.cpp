@@ -2215,10 +2215,11 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * upsampler, the unpack temp-line ring (setup_allocators :2115-2187, sized MAX(n_taps, 5)) is one
    * line short: the pair mate of the window's last line overwrites the window's first line, so the
    * reference output depends on buffer reuse (verified against oracle/_ref: >15 % of bytes differ
-   * from the intended filter).  We refuse such plans instead of silently diverging. */
+   * from the intended filter).  There is nothing to reproduce: the plan computes the intended filter (what the reference gives when
+   * the same chain is run as two conversions, in -> AYUV at the source size and AYUV -> out) and says so in plan->divergence. */
   if (!plan->passes.empty () && !plan->passes[0].horizontal && fr.chroma_v2 && plan->passes[0].n_taps >= 5)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "vertical-first N-tap scaling fed by the 4:2:0 chroma upsampler hits a "
-        "temp-line aliasing bug in the reference; not reproduced");
+    plan->divergence += "vertical-first N-tap scaling fed by the 4:2:0 chroma upsampler: the reference's unpack ring is one line short "
+        "(temp-line aliasing, its output depends on buffer reuse); this library applies the filter to the lines the chain intends. ";
 
   // ---- colour matrix (chain_convert :1719-1868) --------------------------------------------------
   memset (&plan->matrix, 0, sizeof (plan->matrix));
@@ -2518,10 +2519,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   if (chain && (iw != ow || ih != oh)) {
     const int in_bits = fi->hi_depth ? 16 : 8, out_bits = fo->hi_depth ? 16 : 8;
     if (in_bits != out_bits && !remap && (scale_first ? ow : iw) > std::min (iw, ow)) {
-      if (error)
-        *error = "the reference converts only MIN (in_width, out_width) pixels of a line when the bit depth changes (do_convert_lines); with the "
-            "horizontal pass on the other side of that step its output is uninitialised memory; not reproduced";
-      return GSTAMD_ERR_UNSUPPORTED;
+      plan->divergence += "the reference converts only MIN (in_width, out_width) pixels of a line when the bit depth changes (do_convert_lines); with the "
+          "horizontal pass on the other side of that step the rest of its line is uninitialised memory; this library converts the whole line. ";
     }
     bool v_near_up = false;
     for (const ScalePass &sp : pl.passes)
@@ -2545,10 +2544,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     /* and when the bit depth changes the matrix runs on the SOURCE line before it is narrowed into a fresh one (:3127-3136): the
        repeated row's source line has already been through it */
     if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place)) {
-      if (error)
-        *error = "nearest vertical enlargement ahead of a stage that works in place (colour / alpha, chroma downsampling, dither): the reference "
-            "processes a repeated line once per repetition (line aliasing); not reproduced";
-      return GSTAMD_ERR_UNSUPPORTED;
+      plan->divergence += "nearest vertical enlargement ahead of a stage that works in place (colour / alpha, chroma downsampling, dither): the reference "
+          "processes a repeated line once more per repetition (line aliasing); this library applies every stage once per output row. ";
     }
   }
   /* the composite plans (8-bit source into the 16-bit part of the chain) unpack and upsample the whole frame in line order before
@@ -2589,9 +2586,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   if (chain && fi->format == GSTAMD_VIDEO_FORMAT_VYUY && iw == ow && ih == oh && fo->kind == UNPACK_PACKED4 && fo->hi_depth == 0 &&
       fo->pos[0] == 0 && fo->pos[1] == 1 && fo->pos[2] == 2 && fo->pos[3] == 3 && (fo->alpha) &&
       ((out->stride[0] % 8) != 0 || (out->offset[0] % 8) != 0)) {
-    if (error)
-      *error = "VYUY unpacked straight into destination rows that are not 8-byte aligned: the reference's fallback loop swaps U and V there; not reproduced";
-    return GSTAMD_ERR_UNSUPPORTED;
+    plan->divergence += "VYUY unpacked straight into destination rows that are not 8-byte aligned: the reference's fallback loop (video-format.c:337-352) "
+        "swaps U and V on those rows; this library unpacks every row the same way. ";
   }
   return r;
 }

@@ -260,6 +260,7 @@ struct VideoPlan {
   int im_raw[3][4];           // the rint()ed 8-bit matrix before the per-kind adjustments
   std::string ref_fastpath;   // name of the reference fastpath this plan reproduces (empty: generic chain)
   std::string description;
+  std::string divergence;     // where the reference's own output is undefined (uninitialised lines, line aliasing) and this plan computes the chain's intended result instead: why
   uint64_t algorithmic_bytes;
 };
 

@@ -108,6 +108,10 @@ def lib():
         L.gstamd_video_converter_free.argtypes = [C.c_void_p]
         L.gstamd_video_converter_describe.restype = C.c_char_p
         L.gstamd_video_converter_describe.argtypes = [C.c_void_p]
+        L.gstamd_video_converter_divergence.restype = C.c_char_p
+        L.gstamd_video_converter_divergence.argtypes = [C.c_void_p]
+        L.gstamd_video_converter_set_config.argtypes = [C.c_void_p, C.POINTER(ConverterConfig)]
+        L.gstamd_video_converter_get_config.argtypes = [C.c_void_p, C.POINTER(ConverterConfig)]
         L.gstamd_video_converter_algorithmic_bytes.restype = C.c_uint64
         L.gstamd_video_converter_algorithmic_bytes.argtypes = [C.c_void_p]
         L.gstamd_video_converter_debug_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int]
@@ -226,6 +230,14 @@ class VideoConverter:
 
     def describe(self):
         return lib().gstamd_video_converter_describe(self._h).decode()
+
+    def divergence(self):
+        """"" when the plan reproduces the reference bit for bit; else why not (the reference's own output is undefined there)"""
+        return lib().gstamd_video_converter_divergence(self._h).decode()
+
+    def set_config(self, config):
+        """gst_video_converter_set_config: re-plan with new options; a refused config leaves the converter as it was"""
+        _check(lib().gstamd_video_converter_set_config(self._h, C.byref(config)))
 
     def algorithmic_bytes(self):
         return lib().gstamd_video_converter_algorithmic_bytes(self._h)

@@ -210,6 +210,12 @@ void gstamd_video_converter_free (GstAmdVideoConverter *convert);
  * "front+hscale+vscale_back", ...) and algorithmic bytes per frame (source planes read once +
  * destination written once). */
 const char *gstamd_video_converter_describe (const GstAmdVideoConverter *convert);
+/* "" when the plan reproduces gst_video_converter_frame bit for bit.  Otherwise: why it does not - the conversions for which the
+ * reference's own output is undefined (it reads lines it has not converted, or converts a repeated line twice: video-converter.c
+ * do_convert_lines :3112, video_scale_v_near + the in-place stages, the unpack ring of setup_allocators :2115-2187, unpack_VYUY's
+ * fallback loop).  There this library computes what the chain's stages mean - the reference's result when the same stages are run
+ * as separate conversions - instead of refusing the caps. */
+const char *gstamd_video_converter_divergence (const GstAmdVideoConverter *convert);
 uint64_t gstamd_video_converter_algorithmic_bytes (const GstAmdVideoConverter *convert);
 
 /* ---- compositor ----------------------------------------------------------------------- */

@@ -775,4 +775,185 @@ GSTAMD_CD void aggregate_strip4 (const AggregateParams &p, const AggsLanePad &lp
   aggregate_strip<ASH, DEPTH, 4> (p, lp, xmask, dst, dstride, x, y0, y1, nv);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_aggregate_direct (round 3): the opaque-blend path with NO hit list in LDS and every request of a wave in flight before its
+// first blend.  Lane k tests pad k (one vector pass over all pads, as k_aggregate does) and keeps the pad's row pointer, position,
+// width and alpha factor; the ballot of the tests is a scalar bit mask.  The wave then walks the set bits on the scalar unit
+// (s_ff1 + clear), fetches the hit's values with v_readlane (lane index in an SGPR) and requests its 16 bytes into register set j -
+// j is the position among the HITS, so AGG_DIRECT_SLOTS sets serve any number of pads (more hits than sets: another round) - and
+// only then waits and blends, again walking the mask.  Against k_aggregate: no LDS round trip and no wave barrier between the pad
+// test and the first request, no 64-bit vector address arithmetic (row pointer in SGPRs + 32-bit lane offset), no clamped duplicate
+// requests past the last hit, no ring moves; up to 12 KB requested per wave ahead of the arithmetic instead of 4.
+// scripts/c4_probe.hip measured this request structure (its "skeleton", depth 0) at 30.1-30.4 us per C4 frame against 34.1 us with
+// one request in flight per lane; k_aggregate with its arithmetic removed took 33.3 us, and its SQ counters showed 18.1 M vector
+// instructions per frame of which 8.3 M are blend arithmetic.
+#define AGG_DIRECT_SLOTS 12
+
+// The requests are inline assembly on the device: written as plain loads the compiler sinks every conditional load to its use (one
+// request in flight: the 34 us of the probe's depth-1 form) or, with the loads kept in place, waits for the previous one before
+// each request.  So: `agg_request` issues global_load_dwordx4 with the uniform row pointer in SGPRs and a 32-bit lane offset - the
+// compiler does not know a load is outstanding - and `agg_arrived` is the one s_waitcnt vmcnt(0) ahead of the blends, tied to all
+// register sets so that nothing that reads them can be scheduled above it.  The sets stay 128-bit tuples until after the wait (a
+// tuple split would be a register copy of data that has not arrived).  In-order return makes the compiler's own counted waits for
+// its own (younger) loads conservative, never too short; a compiler-visible memory operation that is only POSSIBLY outstanding when
+// the requests start makes it put counted waits between them, hence no such operation in k_aggregate_direct ahead of this code.
+#ifdef __HIPCC__
+typedef unsigned int AggVec __attribute__ ((ext_vector_type (4)));
+GSTAMD_CD void agg_request (AggVec &b, const uint8_t *row, uint32_t byte_off)
+{
+  /* s_nop 4: the row pointer usually arrives in its SGPRs by v_readlane immediately before; a VMEM instruction reading an SGPR that a
+   * VALU instruction wrote needs 5 wait states on gfx9 hardware, and the compiler's hazard recognizer does not look into inline
+   * assembly (without it the load used the stale high half: memory access fault on the first MI355X run) */
+  asm volatile ("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v" (b) : "v" (byte_off), "s" (row));
+}
+GSTAMD_CD void agg_arrived (AggVec *b)
+{
+  asm volatile ("s_waitcnt vmcnt(0)" : "+v" (b[0]), "+v" (b[1]), "+v" (b[2]), "+v" (b[3]), "+v" (b[4]), "+v" (b[5]), "+v" (b[6]), "+v" (b[7]),
+      "+v" (b[8]), "+v" (b[9]), "+v" (b[10]), "+v" (b[11]));
+}
+#define AGGV(b, i) ((b)[i])
+#else
+struct AggVec {
+  uint32_t v[4];
+};
+GSTAMD_CD void agg_request (AggVec &b, const uint8_t *row, uint32_t byte_off)
+{
+  const Px4Words w = load_px4 (row + (size_t) byte_off);
+  for (int i = 0; i < 4; i++)
+    b.v[i] = w.v[i];
+}
+GSTAMD_CD void agg_arrived (AggVec *) {}
+#define AGGV(b, i) ((b).v[i])
+#endif
+
+// what the wave knows about the pads under its strip and row: bit k of `mask` = pad k is hit; on the device lane k holds pad k's
+// values and at () is four v_readlane, on the host they are computed from the pad table
+struct DirectPads {
+  unsigned long long mask;
+#ifdef __HIPCC__
+  uint32_t row_lo, row_hi, alpha8081;
+  int xpos, width;
+#else
+  const AggregateParams *p;
+  int y;
+#endif
+};
+
+struct DirectHit {
+  const uint8_t *row;
+  int xpos, width;
+  uint32_t alpha8081;
+};
+
+GSTAMD_CD DirectHit direct_hit (const DirectPads &dp, int k)
+{
+  DirectHit h;
+#ifdef __HIPCC__
+  const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane ((int) dp.row_lo, k), hi = (uint32_t) __builtin_amdgcn_readlane ((int) dp.row_hi, k);
+  h.row = (const uint8_t *) (uintptr_t) (((uint64_t) hi << 32) | lo);
+  h.xpos = __builtin_amdgcn_readlane (dp.xpos, k);
+  h.width = __builtin_amdgcn_readlane (dp.width, k);
+  h.alpha8081 = (uint32_t) __builtin_amdgcn_readlane ((int) dp.alpha8081, k);
+#else
+  const PadDev &pad = dp.p->pads[k];
+  h.row = pad.data + (ptrdiff_t) (dp.y - pad.ypos) * pad.stride;
+  h.xpos = pad.xpos;
+  h.width = pad.width;
+  h.alpha8081 = (uint32_t) pad.s_alpha * 0x8081u;
+#endif
+  return h;
+}
+
+GSTAMD_CD int mask_first (unsigned long long m) { return __builtin_ctzll (m); }
+
+GSTAMD_CD bool pad_hits_strip (const PadDev &pad, int wx0, int wx1, int y)
+{
+  const int sy = y - pad.ypos;
+  return (sy >= 0) & (sy < pad.height) & (pad.xpos < wx1) & (pad.xpos + pad.width > wx0);
+}
+
+#ifndef __HIPCC__
+GSTAMD_CD DirectPads direct_pads_host (const AggregateParams &p, int wx0, int wx1, int y)
+{
+  DirectPads dp;
+  dp.mask = 0;
+  dp.p = &p;
+  dp.y = y;
+  for (int k = 0; k < p.n_pads; k++)
+    if (pad_hits_strip (p.pads[k], wx0, wx1, y))
+      dp.mask |= 1ull << k;
+  return dp;
+}
+#endif
+
+// the four background pixels of a lane (checker: tab[((y & 8) >> 3) + ((x & 8) >> 3)] = 160 where exactly one of the bits is set)
+GSTAMD_CD void background4 (const AggregateParams &p, uint32_t *d, int x, int y)
+{
+  if (p.bg_kind == 1) {
+    d[0] = d[1] = d[2] = d[3] = p.bg_word;
+  } else if (p.bg_kind == 0) {
+    if ((x & 3) == 0) {          /* the four pixels share one 8-pixel square */
+      d[0] = d[1] = d[2] = d[3] = checker_px (x, y, p.ashift, p.checker_yuv);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        d[i] = checker_px (x + i, y, p.ashift, p.checker_yuv);
+    }
+  }
+}
+
+template <int ASH>
+GSTAMD_CD void aggregate_direct4 (const AggregateParams &p, const DirectPads &dp, uint32_t *d, int x, int y)
+{
+  background4 (p, d, x, y);
+  /* (unpacked before the requests: on a continuation chunk d is the canvas, a load the compiler waits for - ahead of the requests
+   * it is a wait for that load alone, after them it would drain them) */
+  Px2 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    acc[i] = px2_unpack (d[i]);
+  unsigned long long m = dp.mask;
+  uint32_t touched = 0;
+  while (m) {
+    AggVec buf[AGG_DIRECT_SLOTS];
+    // requests: one 16-byte load per hit (clamped into the pad row like span4_fetch), all of them ahead of the first use
+    unsigned long long mr = m;
+#pragma unroll
+    for (int j = 0; j < AGG_DIRECT_SLOTS; j++)
+      if (mr) {
+        const DirectHit h = direct_hit (dp, mask_first (mr));
+        mr &= mr - 1;
+        agg_request (buf[j], h.row, 4u * (uint32_t) span4_clamp (x - h.xpos, h.width));
+      }
+    agg_arrived (buf);
+#pragma unroll
+    for (int j = 0; j < AGG_DIRECT_SLOTS; j++)
+      if (m) {
+        const DirectHit h = direct_hit (dp, mask_first (m));
+        m &= m - 1;
+        const int sx = x - h.xpos, w = h.width;
+        if ((unsigned) sx <= (unsigned) (w - 4)) {
+          touched = 0xf;
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            px2_blend_lazy<ASH> (acc[i], AGGV (buf[j], i), h.alpha8081);
+        } else if ((unsigned) (sx + 3) < (unsigned) (w + 3)) {           // lane straddles a pad edge
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (sx + i >= 0 && sx + i < w) {
+              touched |= 1u << i;
+              px2_blend_lazy<ASH> (acc[i], load_px1 (h.row + 4 * (size_t) (sx + i)), h.alpha8081);
+            }
+        }
+      }
+  }
+  /* alpha forced once after the last pad, as in aggregate_span4: the opaque blend leaves 0xff, and so do the backgrounds of this path.
+   * A continuation chunk starts from the canvas, whose alpha an earlier chunk's SOURCE pads may have lowered: there only the pixels a
+   * pad of this chunk touched are forced */
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (p.bg_kind != 2 || ((touched >> i) & 1))
+      d[i] = px2_pack (acc[i]) | (0xffu << ASH);
+}
+
 }  // namespace gstamd

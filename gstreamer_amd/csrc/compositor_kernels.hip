@@ -77,6 +77,46 @@ __global__ __launch_bounds__ (256) void k_aggregate (AggregateParams p, uint8_t 
   }
 }
 
+// The opaque-blend path for <= AGG_DIRECT_PADS pads (compositor_device.h: aggregate_direct4): one wave = 256 destination pixels of
+// one row, pad descriptors and hit tests on the scalar unit, every pad row's 16 bytes requested before the first blend.
+// KEEP: a continuation chunk (bg_kind 2) starts from the canvas - a compile-time variant, because a canvas load that is only
+// *possibly* outstanding makes the compiler put a full s_waitcnt vmcnt(0) in front of every request of aggregate_direct4.
+// No scalar tail: the lanes past the rectangle leave, a lane with fewer than four pixels left moves back onto the rectangle's last
+// four (it and its neighbour compute the same values for the pixels they share; with KEEP the launcher requires rw % 4 == 0) - any
+// compiler-visible memory operation ahead of the requests would put counted waits between them.
+template <int ASH, int KEEP>
+__global__ __launch_bounds__ (64) void k_aggregate_direct (AggregateParams p, uint8_t *__restrict__ dst, int dstride, int rx0, int ry0, int rw)
+{
+  const int lane = (int) threadIdx.x;
+  const int y = ry0 + (int) blockIdx.y;
+  const int last = rx0 + rw - 4;
+  int wx0 = rx0 + (int) blockIdx.x * 256;
+  const int wx1 = wx0 + 256 < rx0 + rw ? wx0 + 256 : rx0 + rw;
+  int x = wx0 + 4 * lane;
+  if (x >= rx0 + rw)
+    return;
+  x = x < last ? x : last;
+  wx0 = wx0 < last ? wx0 : last;
+  // lane k tests pad k and keeps what a hit needs
+  const PadDev pad = p.pads[lane < p.n_pads ? lane : 0];
+  DirectPads dp;
+  dp.mask = __ballot ((lane < p.n_pads) & pad_hits_strip (pad, wx0, wx1, y));
+  const uint64_t prow = (uint64_t) (uintptr_t) (pad.data + (ptrdiff_t) (y - pad.ypos) * pad.stride);
+  dp.row_lo = (uint32_t) prow;
+  dp.row_hi = (uint32_t) (prow >> 32);
+  dp.alpha8081 = (uint32_t) pad.s_alpha * 0x8081u;
+  dp.xpos = pad.xpos;
+  dp.width = pad.width;
+  uint8_t *row = dst + (size_t) y * dstride;
+  px4 d;
+  if (KEEP)
+    d = *(const px4 *) (row + 4 * (size_t) x);
+  else
+    d.v[0] = d.v[1] = d.v[2] = d.v[3] = 0;
+  aggregate_direct4<ASH> (p, dp, d.v, x, y);
+  store_px4_stream (row + 4 * (size_t) x, d);
+}
+
 #ifdef GSTAMD_TUNING
 // Several rows per wave (compositor_device.h, "Several rows per wave"): workgroup = one wave = 256 columns x `rows` rows.  Measured
 // on C4 and NOT used by the product library: 1 row 38.5 us, 2 rows 37.1, 4 rows 40.5, 8 rows 53 (k_aggregate: 36.1) - the
@@ -293,6 +333,17 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
     }
   }
 #endif
+  if (q.fast && q.n_pads > 0 && abl == 0 && bx == 64 && rw >= 4 && (q.bg_kind != 2 || (rw & 3) == 0)) {
+    dim3 dgrid ((rw + 255) / 256, rh);
+#define AGG_DIRECT_LAUNCH(S, K) hipLaunchKernelGGL ((k_aggregate_direct<S, K>), dgrid, dim3 (64), 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw)
+    if (q.ashift == 0) {
+      if (q.bg_kind == 2) AGG_DIRECT_LAUNCH (0, 1); else AGG_DIRECT_LAUNCH (0, 0);
+    } else {
+      if (q.bg_kind == 2) AGG_DIRECT_LAUNCH (24, 1); else AGG_DIRECT_LAUNCH (24, 0);
+    }
+#undef AGG_DIRECT_LAUNCH
+    return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
+  }
   dim3 grid ((lanes + bx - 1) / bx, rh), block (bx);
 #define AGG_LAUNCH(A, S) hipLaunchKernelGGL ((k_aggregate<A, S>), grid, block, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh)
   if (q.ashift == 0) {

@@ -41,7 +41,9 @@ def random_case(rnd):
 
 
 def run_case(emu, ref, case, seed):
-    """-> ("ok" | "refused" | "bad", description)"""
+    """-> ("ok" | "refused" | "defined" | "bad", description).  "defined": the plan says the reference's own output is undefined for this
+    conversion (gstamd_video_converter_divergence) - there is nothing to compare with here; tests/cases.py VIDEO_DEFINED pins those
+    classes against the reference run stage by stage."""
     ifmt, w, h, ofmt, ow, oh, cfg, col, site = case
     ii = V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site)
     oi = V.video_info(ofmt, ow, oh)
@@ -52,6 +54,9 @@ def run_case(emu, ref, case, seed):
     r = emu.emu_video_convert(C.byref(ii), C.byref(oi), C.byref(c), src.ctypes.data, dst.ctypes.data, 1, desc, 256)
     if r != 0:
         return "refused", desc.value.decode()
+    div = emu.emu_video_last_divergence().decode()
+    if div:
+        return "defined", desc.value.decode() + " | " + div
     want = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site, config=cases.ref_config_string(ref, cfg)).frame(src)
     if (dst == want).all():
         return "ok", desc.value.decode()
@@ -68,6 +73,7 @@ def load_emu():
     emu = C.CDLL(os.path.join(ROOT, "tests", "emu", "libgstamdemu.so"))
     emu.emu_video_convert.argtypes = [C.POINTER(V.VideoInfo), C.POINTER(V.VideoInfo), C.POINTER(V.ConverterConfig), C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_char_p, C.c_int]
+    emu.emu_video_last_divergence.restype = C.c_char_p
     return emu
 
 
@@ -76,7 +82,7 @@ def main():
     seed, n = int(sys.argv[1]), int(sys.argv[2])
     rnd = random.Random(seed)
     emu = load_emu()
-    count = {"ok": 0, "refused": 0, "bad": 0}
+    count = {"ok": 0, "refused": 0, "defined": 0, "bad": 0}
     for it in range(n):
         case = random_case(rnd)
         verdict, text = run_case(emu, ref, case, seed * 1000 + it)

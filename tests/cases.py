@@ -538,25 +538,64 @@ VIDEO_CASES = [
 # this library writes picture bytes only.
 VISIBLE_ONLY = {"uyvy_yv12_33x17_fastpath", "uyvy_y444_33x18_fastpath", "uyvy_yuy2_33x17_fastpath"}
 
-# conversions the reference runs through code this library has no kernel for -> must be REFUSED
+# conversions the reference runs through code this library has no kernel for -> must be REFUSED ("not built", never approximated)
 VIDEO_REFUSED = [
-    ("NV12", 320, 180, "BGRA", 640, 100, LAN),           # reference temp-line aliasing (see planner.cpp)
     ("NV12", 64, 64, "BGRA", 64, 64, dict(dither_quantization=4, dither_method="floyd-steinberg")),   # error diffusion: sequential
     ("NV12", 64, 64, "I420", 64, 64, dict(dither_quantization=4)),      # dither between chroma downsampling and pack: not built
-    # places where the reference's own output is uninitialised memory or depends on line aliasing (found by scripts/fuzz_video.py; planner.cpp
-    # plan_video_converter explains each): refused rather than silently different
-    ("AYUV64", 58, 18, "AYUV", 30, 38, {}),              # bit depth changes with the line wider than MIN (in_width, out_width): do_convert_lines
-    ("P010_10LE", 30, 38, "BGRA", 58, 18, {}),           # the same with the horizontal pass ahead of the convert stage
-    ("AYUV", 58, 18, "ARGB", 30, 20, NEAR),              # nearest vertical enlargement ahead of the in-place matrix, destination rows as lines
-    ("BGRA", 29, 7, "Y444", 4, 49, NEAR),                # the same through temporary lines once rows repeat more than twice
-    ("RGBx", 28, 1, "BGRx", 55, 47, dict(dither_quantization=2)),   # ... ahead of the dither stage
-    ("IYU2", 11, 3, "Y42B", 15, 39, NEAR),               # ... ahead of the chroma downsampler
     ("BGRA", 67, 36, "AYUV", 76, 21, dict(alpha_mode="mult", alpha_value=0.5)),    # alpha stage on MIN (in_width, out_width) pixels of a wider line
     ("YV12", 11, 21, "Y444_16LE", 85, 12, NEAR),         # nearest vertical scaling of 4:2:0 through the composite plans
     ("NV12", 67, 3, "I420", 67, 3, {}, "bt601", "mpeg2"),           # chroma of the line past an odd-height picture (generic chain)
     ("P010_10LE", 31, 13, "NV12", 23, 13, {}),           # the same through the composite plans
-    ("VYUY", 59, 11, "AYUV", 59, 11, {}),                # unpack_VYUY's fallback loop on rows that are not 8-byte aligned swaps U and V
 ]
+
+# Conversions for which the REFERENCE's own output is undefined - it reads lines it has not converted, converts a repeated line once per
+# repetition, or (VYUY) depends on the alignment of a temporary line - found by scripts/fuzz_video.py in round 2 and refused then.  A drop-in
+# cannot answer caps the CPU element accepts with not-negotiated, so since round 3 the plan computes what the chain's stages MEAN and says
+# so in gstamd_video_converter_divergence ().  The expectation is the reference itself, run as the SEPARATE conversions the chain consists
+# of (each of them well defined): (name, conversion, [steps], mask) - a step is (in format, w, h, out format, w, h, config).
+# mask "vyuy": compared with the one-step reference after swapping U and V back on the rows its fallback loop handled, except the two
+# last columns (the tail pixel of an odd line is read in UYVY order on every row - reproduced - and the chroma filter spreads it).
+VIDEO_DEFINED = [
+    ("ub_templine_nv12_bgra_lanczos", ("NV12", 320, 180, "BGRA", 640, 100, LAN),      # unpack ring one line short (setup_allocators :2115-2187)
+     [("NV12", 320, 180, "AYUV", 320, 180, {}), ("AYUV", 320, 180, "BGRA", 640, 100, LAN)], None),
+    ("ub_templine_nv21_rgba_sinc", ("NV21", 64, 48, "RGBA", 100, 30, dict(resampler_method="sinc")),
+     [("NV21", 64, 48, "AYUV", 64, 48, {}), ("AYUV", 64, 48, "RGBA", 100, 30, dict(resampler_method="sinc"))], None),
+    ("ub_depth_ayuv64_vuya", ("AYUV64", 58, 18, "VUYA", 30, 38, {}),                 # do_convert_lines on MIN (in_width, out_width) pixels (:3112)
+     [("AYUV64", 58, 18, "AYUV", 58, 18, {}), ("AYUV", 58, 18, "AYUV", 30, 18, {}), ("AYUV", 30, 18, "AYUV", 30, 38, {}), ("AYUV", 30, 38, "VUYA", 30, 38, {})], None),
+    ("ub_depth_ayuv64_ayuv", ("AYUV64", 58, 18, "AYUV", 30, 38, {}),
+     [("AYUV64", 58, 18, "AYUV", 58, 18, {}), ("AYUV", 58, 18, "AYUV", 30, 18, {}), ("AYUV", 30, 18, "AYUV", 30, 38, {})], None),
+    ("ub_depth_p010_bgra", ("P010_10LE", 30, 38, "BGRA", 58, 18, {}),                # the same with the scalers ahead of the convert stage
+     [("P010_10LE", 30, 38, "AYUV64", 30, 38, {}), ("AYUV64", 30, 38, "AYUV64", 30, 18, {}), ("AYUV64", 30, 18, "AYUV64", 58, 18, {}),
+      ("AYUV64", 58, 18, "BGRA", 58, 18, {})], None),
+    ("ub_vnear_ayuv_argb", ("AYUV", 58, 18, "ARGB", 30, 20, NEAR),                   # video_scale_v_near hands out one line for repeated rows; matrix in place
+     [("AYUV", 58, 18, "AYUV", 30, 20, NEAR), ("AYUV", 30, 20, "ARGB", 30, 20, {})], None),
+    ("ub_vnear_bgra_y444", ("BGRA", 29, 7, "Y444", 4, 49, NEAR),                     # ... through temporary lines once rows repeat more than twice
+     [("BGRA", 29, 7, "BGRA", 4, 49, NEAR), ("BGRA", 4, 49, "Y444", 4, 49, {})], None),
+    ("ub_vnear_dither", ("RGBx", 28, 1, "BGRx", 55, 47, dict(dither_quantization=2)),             # ... ahead of the dither stage
+     [("RGBx", 28, 1, "RGBx", 55, 47, {}), ("RGBx", 55, 47, "BGRx", 55, 47, dict(dither_quantization=2))], None),
+    ("ub_vnear_chroma_down", ("IYU2", 11, 3, "Y42B", 15, 39, NEAR),                  # ... ahead of the chroma downsampler
+     [("IYU2", 11, 3, "IYU2", 15, 39, NEAR), ("IYU2", 15, 39, "Y42B", 15, 39, {})], None),
+    ("ub_vyuy_unaligned_rows", ("VYUY", 59, 11, "AYUV", 59, 11, {}),                # unpack_VYUY's fallback loop (video-format.c:337-352)
+     [("VYUY", 59, 11, "AYUV", 59, 11, {})], "vyuy"),
+]
+
+
+def video_defined_expected(ref, case):
+    """the reference run as the separate conversions of VIDEO_DEFINED's step list; returns (source frame, expected frame, compare mask or None)"""
+    import numpy as np
+    name, (ifmt, w, h, ofmt, ow, oh, cfg), steps, mask = case
+    src = frame_bytes(int(ref.video_info(ifmt, w, h)["size"]), "random", case_seed(name), w)
+    cur = src
+    for (sf, sw, sh, df, dw, dh, scfg) in steps:
+        cur = ref.VideoConverter(sf, sw, sh, df, dw, dh, config=ref_config_string(ref, scfg)).frame(cur)
+    keep = None
+    if mask == "vyuy":
+        px = cur.reshape(oh, ow, 4)
+        px[1::2, :, [2, 3]] = px[1::2, :, [3, 2]]
+        keep = np.ones((oh, ow, 4), bool)
+        keep[1::2, ow - 2:, :] = False
+        keep = keep.reshape(-1)
+    return src, cur, keep
 
 
 def default_layout(fmt, w, h):

@@ -6,7 +6,8 @@
 
 using namespace gstamd;
 
-static int emu_rows_runs = 0, emu_strip_runs = 0;
+static int emu_rows_runs = 0, emu_strip_runs = 0, emu_direct_runs = 0;
+extern "C" int emu_compositor_direct_runs (void) { return emu_direct_runs; }
 extern "C" int emu_compositor_rows_runs (void) { return emu_rows_runs; }
 extern "C" int emu_compositor_strip_runs (void) { return emu_strip_runs; }
 
@@ -74,6 +75,37 @@ extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int 
           else
             aggregate_strip<24, 4, 8> (q, lp, xmask, dst, dstride, x, y0, y1, nv);
         }
+      }
+    return;
+  }
+  if (q.fast && q.n_pads > 0 && rw >= 4 && (q.bg_kind != 2 || (rw & 3) == 0) && !getenv ("EMU_AGG_NO_DIRECT")) {
+    /* k_aggregate_direct: one wave = a strip of 256 columns of one row; the lanes past the rectangle leave, a lane with fewer than
+     * four pixels left moves back onto the last four */
+    emu_direct_runs++;
+    const int last = rx0 + rw - 4;
+    for (int y = ry0; y < ry0 + rh; y++)
+      for (int s0 = rx0; s0 < rx0 + rw; s0 += 256) {
+        const int wx1 = s0 + 256 < rx0 + rw ? s0 + 256 : rx0 + rw, wx0 = s0 < last ? s0 : last;
+        const DirectPads dp = direct_pads_host (q, wx0, wx1, y);
+        uint32_t out[64][4];
+        int xs[64], nl = 0;
+        /* all lanes of the wave read (KEEP) before any of them stores, like the SIMD does */
+        for (int lane = 0; lane < 64; lane++) {
+          int x = s0 + 4 * lane;
+          if (x >= rx0 + rw)
+            break;
+          x = x < last ? x : last;
+          const uint32_t *dp32 = (const uint32_t *) (dst + (size_t) y * dstride + 4 * (size_t) x);
+          for (int i = 0; i < 4; i++)
+            out[nl][i] = q.bg_kind == 2 ? dp32[i] : 0u;
+          if (q.ashift == 0)
+            aggregate_direct4<0> (q, dp, out[nl], x, y);
+          else
+            aggregate_direct4<24> (q, dp, out[nl], x, y);
+          xs[nl++] = x;
+        }
+        for (int l = 0; l < nl; l++)
+          memcpy (dst + (size_t) y * dstride + 4 * (size_t) xs[l], out[l], 16);
       }
     return;
   }

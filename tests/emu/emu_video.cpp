@@ -692,17 +692,24 @@ extern "C" int emu_gamma_fused_runs (void) { return g_gamma_fused_runs; }
 extern "C" int emu_h420_runs (void) { return g_h420_runs; }
 extern "C" int emu_h420_reg_runs (void) { return g_h420_reg_runs; }
 
+/* gstamd_video_converter_divergence of the last top-level emu_video_convert (the plan's note + those of its sub-conversions) */
+static std::string g_emu_divergence;
+extern "C" const char *emu_video_last_divergence (void) { return g_emu_divergence.c_str (); }
+
 extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *cfg, const uint8_t *src, uint8_t *dst, int vec_ok, char *desc, int desc_len)
 {
   VideoPlan p;
   std::string err;
+  if (desc)
+    g_emu_divergence.clear ();          /* a top-level call (the sub-conversions of a composite plan pass no buffer) */
   int r = plan_video_converter (in, out, cfg, &p, &err);
   if (r != GSTAMD_OK) {
     if (desc)
       strncpy (desc, err.c_str (), desc_len - 1);
     return r;
   }
+  g_emu_divergence += p.divergence;
   if (desc)
     strncpy (desc, p.description.c_str (), desc_len - 1);
   if (p.gamma.on) {

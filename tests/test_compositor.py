@@ -122,12 +122,20 @@ def _over_geometry(n_pads):
     return [((i % 4) * 43 - 11, (i // 4) * 29 - 7, min(1.0, 0.25 + 0.05 * i), 1 if i % 3 else 2) for i in range(n_pads)]
 
 
+@pytest.mark.parametrize("direct,dw,n_pads", [(1, 203, 12), (1, 204, 32), (1, 517, 29), (0, 203, 12)])
 @pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("ARGB", 1), ("AYUV", 0), ("RGBA", 2)])
-def test_aggregate_packed_path_on_host_matches_reference(emu_lib, ref, fmt, background):
+def test_aggregate_packed_path_on_host_matches_reference(emu_lib, ref, fmt, background, direct, dw, n_pads, monkeypatch):
+    """the opaque-blend path: k_aggregate_direct's body (mask walk over the hits, 12 request slots per round: 29 / 32 pads piled on
+    each other need three rounds; a width of 203 moves the last lane back onto the last four pixels) and k_aggregate's (hit list),
+    which still serves rectangles narrower than four pixels"""
     emu_lib.emu_compositor_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
-    dw, dh, pw, ph, n_pads = 203, 97, 90, 41, 12
+    if not direct:
+        monkeypatch.setenv("EMU_AGG_NO_DIRECT", "1")
+    dh, pw, ph = 97, 90, 41
     pads_np = [cases.frame_bytes(pw * ph * 4, "random", 7100 + i) for i in range(n_pads)]
     geo = _over_geometry(n_pads)
+    if n_pads == 29:            # piled up: more than 12 hits under one strip and row
+        geo = [(3 * i - 5, i - 3, min(1.0, 0.25 + 0.02 * i), 1 if i % 3 else 2) for i in range(n_pads)]
     exp = _aggregate_expected(ref, fmt, background, geo, pads_np, pw, ph, dw, dh)
     p = AggParams()
     p.ashift = 0 if FAM[fmt] == "argb" else 24
@@ -147,11 +155,43 @@ def test_aggregate_packed_path_on_host_matches_reference(emu_lib, ref, fmt, back
     p.n_pads = k
     got = np.zeros(dw * dh * 4, np.uint8)
     emu_lib.emu_compositor_strip_runs.restype = emu_lib.emu_compositor_rows_runs.restype = C.c_int
-    before = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs())
+    emu_lib.emu_compositor_direct_runs.restype = C.c_int
+    before = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs(), emu_lib.emu_compositor_direct_runs())
     emu_lib.emu_compositor_run(C.byref(p), got.ctypes.data, dw * 4, 0, 0, dw, dh)
-    after = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs())
-    assert (after[0] - before[0], after[1] - before[1]) == (0, 0)      # k_aggregate's body: the strip / rows forms are tuning-build variants
+    after = (emu_lib.emu_compositor_strip_runs(), emu_lib.emu_compositor_rows_runs(), emu_lib.emu_compositor_direct_runs())
+    assert tuple(a - b for a, b in zip(after, before)) == (0, 0, direct)      # the strip / rows forms are tuning-build variants
     assert (exp == got).all()
+
+
+def test_aggregate_continuation_chunk_on_host_matches_reference(emu_lib, ref):
+    """35 pads = two launches: the first 32 (with SOURCE pads that lower the canvas alpha: the general per-pixel path), then three OVER
+    pads that continue on the canvas (bg_kind 2) through k_aggregate_direct's body - which may force alpha only where its pads are"""
+    emu_lib.emu_compositor_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    dw, dh, pw, ph, n_pads = 480, 270, 240, 136, 35
+    pads_np = [cases.frame_bytes(pw * ph * 4, "random", 7000 + i) for i in range(n_pads)]
+    exp = np.zeros(dw * dh * 4, np.uint8)
+    ref.compositor_fill(0, "bgra", "BGRA", exp, dw, dh, 0, dh)
+    geo = []
+    for i in range(n_pads):
+        xpos, ypos, alpha = (i % 4) * 80 - 10, (i // 4) * 45 - 5, min(1.0, 0.25 + 0.05 * i)
+        mode = 1 if i % 5 else (0 if i % 2 else 2)
+        geo.append((xpos, ypos, alpha, mode))
+        ref.compositor_blend("blend_bgra", "BGRA", pads_np[i], pw, ph, xpos, ypos, alpha, exp, dw, dh, 0, dh, mode)
+    got = np.zeros(dw * dh * 4, np.uint8)
+    emu_lib.emu_compositor_direct_runs.restype = C.c_int
+    runs = []
+    for lo, hi, bg in ((0, 32, 0), (32, 35, 2)):
+        p = AggParams()
+        p.ashift, p.overlay, p.bg_kind, p.n_pads = 24, 0, bg, hi - lo
+        for k in range(lo, hi):
+            pd = p.pads[k - lo]
+            xpos, ypos, alpha, mode = geo[k]
+            pd.data, pd.width, pd.height, pd.stride, pd.xpos, pd.ypos, pd.s_alpha, pd.mode = pads_np[k].ctypes.data, pw, ph, pw * 4, xpos, ypos, int(alpha * 255), mode
+        before = emu_lib.emu_compositor_direct_runs()
+        emu_lib.emu_compositor_run(C.byref(p), got.ctypes.data, dw * 4, 0, 0, dw, dh)
+        runs.append(emu_lib.emu_compositor_direct_runs() - before)
+    assert runs == [0, 1]
+    assert (got == exp).all()
 
 
 @pytest.mark.parametrize("kind", ["strip", "strip8", "rows"])
@@ -185,12 +225,19 @@ def test_aggregate_rows_per_wave_list_on_host_matches_reference(emu_lib, ref, ro
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dw,n_pads", [(203, 12), (204, 32), (517, 29), (1300, 40)])
 @pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("ARGB", 1), ("AYUV", 0), ("RGBA", 2)])
-def test_hip_aggregate_packed_path_matches_reference(native_lib, gpu, ref, fmt, background):
+def test_hip_aggregate_packed_path_matches_reference(native_lib, gpu, ref, fmt, background, dw, n_pads):
+    """k_aggregate_direct: several strips per row, more hits than request slots (29 piled pads), more pads than one launch takes
+    (40: a continuation chunk on the canvas), a last lane moved back (203)"""
     import torch
-    dw, dh, pw, ph, n_pads = 203, 97, 90, 41, 12
+    dh, pw, ph = 97, 90, 41
     pads_np = [cases.frame_bytes(pw * ph * 4, "random", 7100 + i) for i in range(n_pads)]
     geo = _over_geometry(n_pads)
+    if n_pads == 29:
+        geo = [(3 * i - 5, i - 3, min(1.0, 0.25 + 0.02 * i), 1 if i % 3 else 2) for i in range(n_pads)]
+    if n_pads == 40:
+        geo = [((i % 10) * 120 - 11, (i // 10) * 19 - 7, min(1.0, 0.25 + 0.015 * i), 1 if i % 3 else 2) for i in range(n_pads)]
     exp = _aggregate_expected(ref, fmt, background, geo, pads_np, pw, ph, dw, dh)
     d_pads = [torch.from_numpy(p).to(gpu) for p in pads_np]
     arr = (V.CompositorPad * n_pads)()

@@ -39,6 +39,43 @@ def test_hip_matches_reference_golden(native_lib, gpu, idx_case):
     assert cases.video_digest(name, out) == GOLDEN[name]["sha256"], (name, list(out[:16]), GOLDEN[name]["head"][:16])
 
 
+@pytest.mark.parametrize("case", cases.VIDEO_DEFINED, ids=lambda c: c[0])
+def test_hip_reference_undefined_plans_compute_the_stage_by_stage_result(native_lib, gpu, ref, case):
+    """the conversions whose one-step reference output is undefined (cases.VIDEO_DEFINED): the HIP path against the reference run as the
+    separate conversions the chain consists of"""
+    name, (ifmt, w, h, ofmt, ow, oh, cfg), steps, mask = case
+    src, exp, keep = cases.video_defined_expected(ref, case)
+    got = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cfg, None, None, src)
+    if keep is not None:
+        assert (got[keep] == exp[keep]).all()
+    else:
+        assert (got == exp).all(), int((got != exp).sum())
+
+
+def test_hip_set_config_gives_the_frames_of_a_fresh_converter(native_lib, gpu, ref):
+    """gst_video_converter_set_config on a live converter, incl. the composite plans whose sub-conversions have to be re-planned"""
+    import torch
+    for (ifmt, ofmt, w, h, ow, oh) in (("NV12", "BGRA", 64, 48, 64, 48), ("P010_10LE", "NV12", 64, 48, 32, 24), ("NV12", "BGRA", 64, 48, 100, 70)):
+        ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)
+        src = cases.frame_bytes(int(ii.size), "random", 77, w)
+        d_src = torch.from_numpy(src).to(gpu)
+        c = V.VideoConverter(ii, oi)
+        for new in (dict(gamma_mode="remap"), dict(resampler_method="lanczos"), {}, dict(gamma_mode="remap", resampler_method="nearest")):
+            try:
+                c.set_config(V.converter_config(**new))
+            except V.GstAmdError as e:
+                assert e.code == V.ERR_UNSUPPORTED
+                continue
+            if c.divergence():
+                continue
+            d_dst = torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu)
+            c.frame(d_src, d_dst)
+            torch.cuda.synchronize()
+            exp = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, new)).frame(src)
+            assert (d_dst.cpu().numpy() == exp).all(), (ifmt, ofmt, new)
+        c.free()
+
+
 H420_GENERAL = [c for c in enumerate(cases.VIDEO_CASES) if "_h420_" in c[1][0] or c[1][0] in ("nv12_bgra_quarter_lanczos", "i420_rgba_1080p_to_270p_lanczos")]
 
 

@@ -110,6 +110,61 @@ def _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src, vec=1):
     return dst
 
 
+@pytest.mark.parametrize("case", cases.VIDEO_DEFINED, ids=lambda c: c[0])
+def test_reference_undefined_plans_compute_the_stage_by_stage_result_on_host(native_lib, emu_lib, ref, case):
+    """Where the reference's ONE-step output is undefined (see cases.VIDEO_DEFINED) the plan is no longer refused: it announces the
+    divergence and its bytes equal the reference run as the separate, well-defined conversions the chain consists of.  The one-step
+    reference output is shown to differ - if it stops differing the class has left the undefined territory and belongs in the goldens."""
+    name, (ifmt, w, h, ofmt, ow, oh, cfg), steps, mask = case
+    conv = V.VideoConverter(V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh), V.converter_config(**cfg))
+    assert conv.divergence() != "", name
+    conv.free()
+    src, exp, keep = cases.video_defined_expected(ref, case)
+    got = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, None, None, src)
+    emu_lib.emu_video_last_divergence.restype = C.c_char_p
+    assert emu_lib.emu_video_last_divergence() != b""
+    if keep is not None:
+        assert (got[keep] == exp[keep]).all()
+    else:
+        assert (got == exp).all(), int((got != exp).sum())
+    one_step = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, cfg)).frame(src)
+    assert (one_step != got).any()
+
+
+def test_plans_that_reproduce_the_reference_carry_no_divergence_note(native_lib):
+    for (ifmt, w, h, ofmt, ow, oh, cfg) in (("NV12", 3840, 2160, "BGRA", 3840, 2160, {}), ("I420", 7680, 4320, "RGBA", 1920, 1080, cases.LAN),
+                                            ("AYUV", 58, 18, "ARGB", 30, 20, cases.LIN), ("P010_10LE", 64, 48, "NV12", 64, 48, {})):
+        conv = V.VideoConverter(V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh), V.converter_config(**cfg))
+        assert conv.divergence() == "", (ifmt, ofmt, conv.divergence())
+        conv.free()
+
+
+def test_set_config_replans_the_sub_converters(native_lib):
+    """gst_video_converter_set_config (video-converter.c:2759): a converter re-configured in place ends up with the plan - and, for the
+    composite plans, the sub-conversions - of a converter created with the new options (round 2 kept sub-converters planned with the old
+    ones and dereferenced a missing one when gamma-mode = remap was switched on afterwards)"""
+    for (ifmt, ofmt, w, h, ow, oh) in (("NV12", "BGRA", 64, 48, 64, 48), ("P010_10LE", "NV12", 64, 48, 32, 24), ("NV12", "I420", 64, 48, 96, 64)):
+        for new in (dict(gamma_mode="remap"), dict(resampler_method="lanczos"), dict(gamma_mode="remap", resampler_method="nearest")):
+            ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)
+            try:
+                fresh = V.VideoConverter(ii, oi, V.converter_config(**new))
+            except V.GstAmdError:
+                fresh = None
+            c = V.VideoConverter(ii, oi)
+            before = c.describe()
+            if fresh is None:
+                with pytest.raises(V.GstAmdError):
+                    c.set_config(V.converter_config(**new))
+                assert c.describe() == before            # a refused config leaves the converter as it was
+            else:
+                c.set_config(V.converter_config(**new))
+                assert c.describe() == fresh.describe(), (ifmt, ofmt, new)
+                c.set_config(V.converter_config())
+                assert c.describe() == before
+                fresh.free()
+            c.free()
+
+
 SMALL = [c for c in enumerate(cases.VIDEO_CASES) if c[1][2] * c[1][3] <= 1280 * 720]
 
 

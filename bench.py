@@ -154,7 +154,7 @@ class CompositorWorkload:
     """BASELINE C4, video half: SURVEY.md 8d's primary layout."""
     name, unit, dtype = "c4", "frames/s", "u8"
     metric = "4K output frames/s (compositor, 16 x 1080p BGRA pads alpha-blended) per GPU; % HBM roofline"
-    kernel = "k_aggregate"
+    kernel = "k_aggregate_direct"
     DW, DH, PW, PH, N = 3840, 2160, 1920, 1080, 16
     frames_per_step = 8
     SETS = 5                # 5 x 16 pad frames of 8.3 MB = 663 MB of distinct pad pixels

@@ -244,14 +244,28 @@ GSTAMD_CD uint32_t cbperm (uint32_t hi, uint32_t lo, uint32_t sel)
 // and div255 finishes as (t + (t >> 8)) >> 8.  The destination's alpha lane is NOT forced to 0xff here: it never feeds another
 // lane, every blend recomputes it from bytes <= 255, and aggregate_span4 sets it once after the last pad (16 VALU per
 // pixel-blend instead of 24).
+// 0x00010001 in a register the compiler cannot see through: as a literal it splits `d * ias + 1` into v_pk_mul_lo_u16 and a
+// v_pk_add_u16 with an inline 1 (VOP3P takes no 32-bit literal) - 18 instructions per pixel-blend instead of 16
+GSTAMD_CD uint32_t pk_one ()
+{
+#ifdef __HIPCC__
+  uint32_t r;
+  asm ("v_mov_b32 %0, 0x10001" : "=v" (r));
+  return r;
+#else
+  return 0x00010001u;
+#endif
+}
+
 template <int ASH>
 GSTAMD_CD void px2_blend_lazy (Px2 &d, uint32_t s, uint32_t alpha8081)
 {
   const uint32_t a = mul24_alpha_byte<ASH> (s, alpha8081) >> 23;
   const uint32_t as = a | (a << 16), ias = 0x00ff00ffu - as;
   const uint32_t se = cbperm (0, s, 0x0c020c00u), so = cbperm (0, s, 0x0c030c01u);
-  const uint32_t te = cpk_mad16 (se, as, cpk_mad16 (d.e, ias, 0x00010001u));
-  const uint32_t to = cpk_mad16 (so, as, cpk_mad16 (d.o, ias, 0x00010001u));
+  const uint32_t one = pk_one ();
+  const uint32_t te = cpk_mad16 (se, as, cpk_mad16 (d.e, ias, one));
+  const uint32_t to = cpk_mad16 (so, as, cpk_mad16 (d.o, ias, one));
   d.e = pk16_shr8 (te + pk16_shr8 (te));
   d.o = pk16_shr8 (to + pk16_shr8 (to));
 }
@@ -799,12 +813,16 @@ GSTAMD_CD void aggregate_strip4 (const AggregateParams &p, const AggsLanePad &lp
 // the requests start makes it put counted waits between them, hence no such operation in k_aggregate_direct ahead of this code.
 #ifdef __HIPCC__
 typedef unsigned int AggVec __attribute__ ((ext_vector_type (4)));
+template <int NT>
 GSTAMD_CD void agg_request (AggVec &b, const uint8_t *row, uint32_t byte_off)
 {
   /* s_nop 4: the row pointer usually arrives in its SGPRs by v_readlane immediately before; a VMEM instruction reading an SGPR that a
    * VALU instruction wrote needs 5 wait states on gfx9 hardware, and the compiler's hazard recognizer does not look into inline
    * assembly (without it the load used the stale high half: memory access fault on the first MI355X run) */
-  asm volatile ("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v" (b) : "v" (byte_off), "s" (row));
+  if (NT)       /* streaming: every source pixel is read once */
+    asm volatile ("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=v" (b) : "v" (byte_off), "s" (row));
+  else
+    asm volatile ("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v" (b) : "v" (byte_off), "s" (row));
 }
 GSTAMD_CD void agg_arrived (AggVec *b)
 {
@@ -816,6 +834,7 @@ GSTAMD_CD void agg_arrived (AggVec *b)
 struct AggVec {
   uint32_t v[4];
 };
+template <int NT>
 GSTAMD_CD void agg_request (AggVec &b, const uint8_t *row, uint32_t byte_off)
 {
   const Px4Words w = load_px4 (row + (size_t) byte_off);
@@ -902,7 +921,7 @@ GSTAMD_CD void background4 (const AggregateParams &p, uint32_t *d, int x, int y)
   }
 }
 
-template <int ASH>
+template <int ASH, int NT, int KEEP>
 GSTAMD_CD void aggregate_direct4 (const AggregateParams &p, const DirectPads &dp, uint32_t *d, int x, int y)
 {
   background4 (p, d, x, y);
@@ -923,7 +942,7 @@ GSTAMD_CD void aggregate_direct4 (const AggregateParams &p, const DirectPads &dp
       if (mr) {
         const DirectHit h = direct_hit (dp, mask_first (mr));
         mr &= mr - 1;
-        agg_request (buf[j], h.row, 4u * (uint32_t) span4_clamp (x - h.xpos, h.width));
+        agg_request<NT> (buf[j], h.row, 4u * (uint32_t) span4_clamp (x - h.xpos, h.width));
       }
     agg_arrived (buf);
 #pragma unroll
@@ -933,7 +952,8 @@ GSTAMD_CD void aggregate_direct4 (const AggregateParams &p, const DirectPads &dp
         m &= m - 1;
         const int sx = x - h.xpos, w = h.width;
         if ((unsigned) sx <= (unsigned) (w - 4)) {
-          touched = 0xf;
+          if (KEEP)
+            touched = 0xf;
 #pragma unroll
           for (int i = 0; i < 4; i++)
             px2_blend_lazy<ASH> (acc[i], AGGV (buf[j], i), h.alpha8081);
@@ -941,18 +961,19 @@ GSTAMD_CD void aggregate_direct4 (const AggregateParams &p, const DirectPads &dp
 #pragma unroll
           for (int i = 0; i < 4; i++)
             if (sx + i >= 0 && sx + i < w) {
-              touched |= 1u << i;
+              if (KEEP)
+                touched |= 1u << i;
               px2_blend_lazy<ASH> (acc[i], load_px1 (h.row + 4 * (size_t) (sx + i)), h.alpha8081);
             }
         }
       }
   }
   /* alpha forced once after the last pad, as in aggregate_span4: the opaque blend leaves 0xff, and so do the backgrounds of this path.
-   * A continuation chunk starts from the canvas, whose alpha an earlier chunk's SOURCE pads may have lowered: there only the pixels a
+   * A continuation chunk (KEEP = bg_kind 2) starts from the canvas, whose alpha an earlier chunk's SOURCE pads may have lowered: there only the pixels a
    * pad of this chunk touched are forced */
 #pragma unroll
   for (int i = 0; i < 4; i++)
-    if (p.bg_kind != 2 || ((touched >> i) & 1))
+    if (!KEEP || ((touched >> i) & 1))
       d[i] = px2_pack (acc[i]) | (0xffu << ASH);
 }
 

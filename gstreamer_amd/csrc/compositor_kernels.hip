@@ -20,6 +20,8 @@
 
 using namespace gstamd;
 
+#define AGG_DIRECT_NT 1      /* cache policy of k_aggregate_direct's pad requests (1: nt); the tuning build reads GSTAMD_AGG_NT */
+
 struct __attribute__ ((aligned (4))) px4 { uint32_t v[4]; };
 
 // the canvas is written once and not read again by this kernel: streaming (nontemporal) 16-byte store at a
@@ -84,7 +86,7 @@ __global__ __launch_bounds__ (256) void k_aggregate (AggregateParams p, uint8_t 
 // No scalar tail: the lanes past the rectangle leave, a lane with fewer than four pixels left moves back onto the rectangle's last
 // four (it and its neighbour compute the same values for the pixels they share; with KEEP the launcher requires rw % 4 == 0) - any
 // compiler-visible memory operation ahead of the requests would put counted waits between them.
-template <int ASH, int KEEP>
+template <int ASH, int KEEP, int NT>
 __global__ __launch_bounds__ (64) void k_aggregate_direct (AggregateParams p, uint8_t *__restrict__ dst, int dstride, int rx0, int ry0, int rw)
 {
   const int lane = (int) threadIdx.x;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__ (64) void k_aggregate_direct (AggregateParams p, ui
     d = *(const px4 *) (row + 4 * (size_t) x);
   else
     d.v[0] = d.v[1] = d.v[2] = d.v[3] = 0;
-  aggregate_direct4<ASH> (p, dp, d.v, x, y);
+  aggregate_direct4<ASH, NT, KEEP> (p, dp, d.v, x, y);
   store_px4_stream (row + 4 * (size_t) x, d);
 }
 
@@ -335,7 +337,13 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
 #endif
   if (q.fast && q.n_pads > 0 && abl == 0 && bx == 64 && rw >= 4 && (q.bg_kind != 2 || (rw & 3) == 0)) {
     dim3 dgrid ((rw + 255) / 256, rh);
-#define AGG_DIRECT_LAUNCH(S, K) hipLaunchKernelGGL ((k_aggregate_direct<S, K>), dgrid, dim3 (64), 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw)
+#ifdef GSTAMD_TUNING
+    const int nt = getenv ("GSTAMD_AGG_NT") ? atoi (getenv ("GSTAMD_AGG_NT")) : AGG_DIRECT_NT;
+#else
+    const int nt = AGG_DIRECT_NT;
+#endif
+#define AGG_DIRECT_LAUNCH(S, K) do { if (nt) hipLaunchKernelGGL ((k_aggregate_direct<S, K, 1>), dgrid, dim3 (64), 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw); \
+      else hipLaunchKernelGGL ((k_aggregate_direct<S, K, 0>), dgrid, dim3 (64), 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw); } while (0)
     if (q.ashift == 0) {
       if (q.bg_kind == 2) AGG_DIRECT_LAUNCH (0, 1); else AGG_DIRECT_LAUNCH (0, 0);
     } else {

@@ -98,10 +98,14 @@ extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int 
           const uint32_t *dp32 = (const uint32_t *) (dst + (size_t) y * dstride + 4 * (size_t) x);
           for (int i = 0; i < 4; i++)
             out[nl][i] = q.bg_kind == 2 ? dp32[i] : 0u;
-          if (q.ashift == 0)
-            aggregate_direct4<0> (q, dp, out[nl], x, y);
+          if (q.ashift == 0 && q.bg_kind == 2)
+            aggregate_direct4<0, 0, 1> (q, dp, out[nl], x, y);
+          else if (q.ashift == 0)
+            aggregate_direct4<0, 0, 0> (q, dp, out[nl], x, y);
+          else if (q.bg_kind == 2)
+            aggregate_direct4<24, 0, 1> (q, dp, out[nl], x, y);
           else
-            aggregate_direct4<24> (q, dp, out[nl], x, y);
+            aggregate_direct4<24, 0, 0> (q, dp, out[nl], x, y);
           xs[nl++] = x;
         }
         for (int l = 0; l < nl; l++)

@@ -950,6 +950,10 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
       e = launch_convert_gamma (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, c->hook, stream);
       return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_gamma");
     }
+    if (swizzle4_usable (p.front, pl, color, dst, dstride)) {
+      e = launch_swizzle4 (p.front, pl, p.post.pack_pos, dst, dstride, stream);
+      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_swizzle4");
+    }
     e = launch_convert (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert");
   }
@@ -1532,6 +1536,23 @@ int gstamd_device_download_async (void *dst_host, const void *src_device, size_t
 {
   hipError_t e = hipMemcpyAsync (dst_host, src_device, size, hipMemcpyDeviceToHost, (hipStream_t) stream);
   return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "download");
+}
+
+/* pitched copies (one plane of a frame whose host rows and device rows have different strides): hipMemcpy2DAsync */
+int gstamd_device_upload_2d_async (void *dst_device, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t row_bytes, size_t rows, void *stream)
+{
+  if (!row_bytes || !rows)
+    return GSTAMD_OK;
+  hipError_t e = hipMemcpy2DAsync (dst_device, dst_pitch, src_host, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, (hipStream_t) stream);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "2-D upload");
+}
+
+int gstamd_device_download_2d_async (void *dst_host, size_t dst_pitch, const void *src_device, size_t src_pitch, size_t row_bytes, size_t rows, void *stream)
+{
+  if (!row_bytes || !rows)
+    return GSTAMD_OK;
+  hipError_t e = hipMemcpy2DAsync (dst_host, dst_pitch, src_device, src_pitch, row_bytes, rows, hipMemcpyDeviceToHost, (hipStream_t) stream);
+  return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "2-D download");
 }
 
 int gstamd_get_device (void)

@@ -440,6 +440,30 @@ GSTAMD_HD void convert_body (const FrontParams &f, const Planes &pl, const int *
 }
 
 // ------------------------------------------------------------------------------------------------
+// 4-byte packed -> 4-byte packed with neither a matrix nor an alpha operation (BGRA -> RGBA, ARGB -> BGRx ...: the unpack and the pack are
+// both byte permutations, video-format.c pack / unpack_<4-byte formats>): ONE selector word, v_perm_b32 per pixel.  Destination byte
+// pack_pos[i] takes component i, which the source keeps at byte pos[i].
+inline uint32_t swizzle4_selector (const int *src_pos, const int *pack_pos)     /* host */
+{
+  uint32_t sel = 0;
+  for (int i = 0; i < 4; i++)
+    sel |= (uint32_t) src_pos[i] << (8 * pack_pos[i]);
+  return sel;
+}
+
+GSTAMD_HD uint32_t swizzle4_px (uint32_t raw, uint32_t sel)
+{
+#ifdef __HIPCC__
+  return __builtin_amdgcn_perm (0u, raw, sel);
+#else
+  uint32_t r = 0;
+  for (int j = 0; j < 4; j++)
+    r |= ((raw >> (8 * ((sel >> (8 * j)) & 3))) & 0xffu) << (8 * j);
+  return r;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // scaler kernels: one lane per output pixel, x fastest
 // ------------------------------------------------------------------------------------------------
 // (acc + 32) as int16, arithmetic >> 6, unsigned saturate to a byte.

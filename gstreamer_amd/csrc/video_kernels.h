@@ -17,6 +17,10 @@ namespace gstamd {
 hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color,
     const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream);
 
+// 4-byte packed -> 4-byte packed, no matrix, no alpha operation: the copy-shaped permutation kernel
+bool swizzle4_usable (const FrontParams &f, const Planes &pl, const ColorParams &color, const uint8_t *dst, int dstride);
+hipError_t launch_swizzle4 (const FrontParams &f, const Planes &pl, const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream);
+
 hipError_t launch_convert16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const Deep16Params &d, const PostParams &post, uint8_t *dst,
     int dstride, hipStream_t stream);
 

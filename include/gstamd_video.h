@@ -324,6 +324,9 @@ void gstamd_host_free (void *ptr);
 int gstamd_device_copy (void *dst_device, const void *src_device, size_t size, void *stream);
 int gstamd_device_upload_async (void *dst_device, const void *src_host, size_t size, void *stream);
 int gstamd_device_download_async (void *dst_host, const void *src_device, size_t size, void *stream);
+/* one plane whose host rows and device rows have different pitches (a GstVideoMeta with padded strides, gstvideometa.h:55-77) */
+int gstamd_device_upload_2d_async (void *dst_device, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t row_bytes, size_t rows, void *stream);
+int gstamd_device_download_2d_async (void *dst_host, size_t dst_pitch, const void *src_device, size_t src_pitch, size_t row_bytes, size_t rows, void *stream);
 
 /* 1: frames of this converter may be in flight on several streams at once (the plan keeps no scratch image between its kernels);
  * 0: one stream at a time (two-pass scalers and planar packers own one intermediate image per converter). */

@@ -30,14 +30,14 @@ def build():
 def build_tools(inc):
     """Measurement / test programs that drive the elements through GstHarness (plugins/tests/)."""
     tdir = os.path.join(HERE, "tests")
-    for name in ("bench_element",):
+    for name in ("bench_element", "live_props"):
         src = os.path.join(tdir, name + ".c")
         if not os.path.exists(src):
             continue
         cmd = ["gcc", "-O2", "-Wall", "-Wno-deprecated-declarations", "-Wl,--allow-shlib-undefined", "-o", os.path.join(tdir, name), src] + inc + [
             "-L%s/lib" % CONDA, "-Wl,-rpath,%s/lib" % CONDA, "-L" + HERE, "-Wl,-rpath,$ORIGIN/..", "-lgstamdhipdsp",
             "-L" + os.path.join(ROOT, "gstreamer_amd", "lib"), "-Wl,-rpath,$ORIGIN/../../gstreamer_amd/lib", "-lgstamddsp",
-            "-lgstcheck-1.0", "-lgstvideo-1.0", "-lgstbase-1.0", "-lgstreamer-1.0", "-lgobject-2.0", "-lglib-2.0"]
+            "-lgstcheck-1.0", "-lgstvideo-1.0", "-lgstaudio-1.0", "-lgstbase-1.0", "-lgstreamer-1.0", "-lgobject-2.0", "-lglib-2.0"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("tool build failed:\n" + r.stdout)

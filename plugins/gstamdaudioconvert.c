@@ -33,6 +33,8 @@ typedef struct {
   guint dither_threshold;
   GValue mix_matrix;            /* GST_TYPE_ARRAY of rows ([out][in]) */
   gboolean mix_matrix_is_set;
+  gboolean conv_dirty;          /* options changed: the streaming thread re-makes the converter (object lock) */
+  gboolean have_caps;
   GstAudioInfo in, out;
   GstAmdAudioConverter *conv;
   gpointer d_in, d_out;
@@ -76,8 +78,13 @@ amd_ac_set_mix_matrix (GstAmdAudioConvert * s, const GValue * value)
       g_warning ("Invalid mix-matrix: rows of different lengths");
   }
   s->mix_matrix_is_set = ok;
-  amd_ac_drop_converter (s);
+  /* the converter is NOT freed here: this runs on the application's (or, for GstRequestAudioMixMatrix, an upstream) thread while the
+   * streaming thread may be inside gstamd_audio_converter_samples.  It is flagged and re-made by the streaming thread at the top of the
+   * next transform - the reference re-creates it lazily there too (gstaudioconvert.c:1700 gst_audio_convert_ensure_converter) - and the
+   * element leaves passthrough so that transform is called at all (gstaudioconvert.c:1883-1886) */
+  s->conv_dirty = TRUE;
   GST_OBJECT_UNLOCK (s);
+  gst_base_transform_set_passthrough (GST_BASE_TRANSFORM (s), FALSE);
   if (ok)
     gst_base_transform_reconfigure_sink (GST_BASE_TRANSFORM (s));
 }
@@ -278,20 +285,28 @@ amd_ac_info (const GstAudioInfo * i, GstAmdAudioInfo * a)
   return TRUE;
 }
 
-/* gst_audio_convert_set_caps + _ensure_converter (gstaudioconvert.c:1548-1684) */
+/* gst_audio_convert_ensure_converter (gstaudioconvert.c:1590-1684): (re)make the converter for s->in / s->out with the element's current
+ * options; streaming thread (set_caps, transform) */
 static gboolean
-amd_ac_set_caps (GstBaseTransform * t, GstCaps * incaps, GstCaps * outcaps)
+amd_ac_ensure_converter (GstAmdAudioConvert * s)
 {
-  GstAmdAudioConvert *s = AMD_AC (t);
-  GstAudioInfo in, out;
+  GstBaseTransform *t = GST_BASE_TRANSFORM (s);
   GstAmdAudioInfo ai, ao;
   GstAmdAudioConverterConfig cfg;
   int status = 0;
 
-  amd_ac_drop_converter (s);
-  if (!gst_audio_info_from_caps (&in, incaps) || !gst_audio_info_from_caps (&out, outcaps))
+  GST_OBJECT_LOCK (s);
+  if (s->conv && !s->conv_dirty) {
+    GST_OBJECT_UNLOCK (s);
+    return TRUE;
+  }
+  s->conv_dirty = FALSE;
+  GST_OBJECT_UNLOCK (s);
+  if (!s->have_caps)
     return FALSE;
-  if (!amd_ac_info (&in, &ai) || !amd_ac_info (&out, &ao)) {
+  gst_amd_hip_select_device (s->device_id);
+  amd_ac_drop_converter (s);
+  if (!amd_ac_info (&s->in, &ai) || !amd_ac_info (&s->out, &ao)) {
     GST_ERROR_OBJECT (s, "caps outside the device converter's formats / channel counts");
     return FALSE;
   }
@@ -324,16 +339,31 @@ amd_ac_set_caps (GstBaseTransform * t, GstCaps * incaps, GstCaps * outcaps)
     }
   }
   GST_OBJECT_UNLOCK (s);
-  gst_amd_hip_select_device (s->device_id);
   s->conv = gstamd_audio_converter_new (0, &ai, &ao, &cfg, &status);
   if (!s->conv) {
     GST_ERROR_OBJECT (s, "Failed to make converter (status %d): %s", status, gstamd_last_error ());
     return FALSE;
   }
-  s->in = in;
-  s->out = out;
   gst_base_transform_set_passthrough (t, gstamd_audio_converter_is_passthrough (s->conv));
   return TRUE;
+}
+
+/* gst_audio_convert_set_caps (gstaudioconvert.c:1548-1588) */
+static gboolean
+amd_ac_set_caps (GstBaseTransform * t, GstCaps * incaps, GstCaps * outcaps)
+{
+  GstAmdAudioConvert *s = AMD_AC (t);
+  GstAudioInfo in, out;
+
+  if (!gst_audio_info_from_caps (&in, incaps) || !gst_audio_info_from_caps (&out, outcaps))
+    return FALSE;
+  s->in = in;
+  s->out = out;
+  s->have_caps = TRUE;
+  GST_OBJECT_LOCK (s);
+  s->conv_dirty = TRUE;
+  GST_OBJECT_UNLOCK (s);
+  return amd_ac_ensure_converter (s);
 }
 
 static gboolean
@@ -365,8 +395,17 @@ amd_ac_transform (GstBaseTransform * t, GstBuffer * inbuf, GstBuffer * outbuf)
   gsize frames;
   gboolean ok = TRUE;
 
-  if (!s->conv)
+  if (!amd_ac_ensure_converter (s))
     return GST_FLOW_NOT_NEGOTIATED;
+  if (gstamd_audio_converter_is_passthrough (s->conv) && inbuf != outbuf && gst_buffer_get_size (inbuf) <= gst_buffer_get_size (outbuf)) {
+    /* the new options made the conversion an identity while the base class was not in passthrough for this buffer yet */
+    if (!gst_buffer_map (inbuf, &im, GST_MAP_READ))
+      return GST_FLOW_ERROR;
+    gst_buffer_fill (outbuf, 0, im.data, im.size);
+    gst_buffer_set_size (outbuf, im.size);
+    gst_buffer_unmap (inbuf, &im);
+    return GST_FLOW_OK;
+  }
   if (!gst_buffer_map (inbuf, &im, GST_MAP_READ))
     return GST_FLOW_ERROR;
   if (!gst_buffer_map (outbuf, &om, GST_MAP_WRITE)) {
@@ -431,6 +470,7 @@ amd_ac_stop (GstBaseTransform * t)
   GstAmdAudioConvert *s = AMD_AC (t);
   gst_amd_hip_select_device (s->device_id);
   amd_ac_drop_converter (s);
+  s->have_caps = FALSE;
   if (s->stream) {
     gstamd_stream_synchronize (s->stream);
     gstamd_stream_free (s->stream);

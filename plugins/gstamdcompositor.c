@@ -58,8 +58,10 @@ typedef struct {
   gint sizing_policy;          /* GstCompositorSizingPolicy: 0 none, 1 keep-aspect-ratio (compositor.c:207-232) */
   gboolean repeat_after_eos;   /* GstVideoAggregatorPad: keep showing the last frame after EOS (gstvideoaggregator.c:166-176) */
   guint64 max_last_buffer_repeat;
-  GstVideoInfo info;
+  GstVideoInfo info;            /* layout of `current` (and of the buffers taken since the last promoted CAPS event) */
   gboolean have_info;
+  GstVideoInfo pending_info;    /* caps that arrived while a frame of the old caps is still shown (object lock) */
+  gboolean have_pending;
   /* frame selection by running time (gst_video_aggregator_fill_queues, gstvideoaggregator.c:1753-2000) */
   GstBuffer *current;          /* the frame this pad shows now */
   GstClockTime cur_start, cur_end;     /* its running-time interval (end NONE: until replaced) */
@@ -493,17 +495,29 @@ amd_comp_sink_event (GstAggregator * agg, GstAggregatorPad * apad, GstEvent * ev
     GstAmdCompositorPadObj *p = AMD_COMP_PAD (apad);
     GstCaps *caps;
     gst_event_parse_caps (event, &caps);
-    GST_OBJECT_LOCK (p);
+    GstVideoInfo vi;
     /* progressive frames only: neither the blend nor the per-pad converter has a field-aware path (an interlaced pad would be
      * composited as if progressive), so such caps are refused like any other unsupported format */
-    p->have_info = gst_video_info_from_caps (&p->info, caps) && amd_pad_format_of (GST_VIDEO_INFO_FORMAT (&p->info)) != 0 &&
-        !GST_VIDEO_INFO_IS_INTERLACED (&p->info);
-    GST_OBJECT_UNLOCK (p);
-    if (!p->have_info) {
+    const gboolean ok = gst_video_info_from_caps (&vi, caps) && amd_pad_format_of (GST_VIDEO_INFO_FORMAT (&vi)) != 0 &&
+        !GST_VIDEO_INFO_IS_INTERLACED (&vi);
+    if (!ok) {
       GST_ERROR_OBJECT (apad, "unsupported caps %" GST_PTR_FORMAT, caps);
       gst_event_unref (event);
       return FALSE;
     }
+    /* The pad may still show a frame of the OLD caps (p->current, repeated until a frame of the new caps starts): the new layout is
+     * kept pending and becomes p->info at the moment a buffer queued after this event becomes the pad's current frame
+     * (amd_comp_pad_select) - gst_video_aggregator keeps pending_vinfo / pending_caps the same way (gstvideoaggregator.c:1825-1831,
+     * 1931-1937).  Describing the old buffer with the new width / height / stride made the blend kernels read past it. */
+    GST_OBJECT_LOCK (p);
+    p->pending_info = vi;
+    p->have_pending = TRUE;
+    if (!p->have_info) {          /* first caps: nothing is shown yet */
+      p->info = vi;
+      p->have_info = TRUE;
+      p->have_pending = FALSE;
+    }
+    GST_OBJECT_UNLOCK (p);
     gst_pad_mark_reconfigure (agg->srcpad);
   }
   return GST_AGGREGATOR_CLASS (gst_amd_compositor_parent_class)->sink_event (agg, apad, event);
@@ -661,6 +675,27 @@ ensure_device (gpointer * p, gsize * have, gsize need)
  * current frame and stays that until replaced - a 15 fps pad under a 30 fps output is shown twice.  After EOS the last frame stays
  * only with repeat-after-eos.  FALSE: the pad has nothing queued, is not EOS and its current frame does not reach out_end -
  * the aggregator has to wait for data. */
+/* a buffer queued after the pad's last CAPS event is about to become its current frame: the pending layout is now the frame's */
+static void
+amd_comp_pad_promote_caps (GstAmdCompositorPadObj * p)
+{
+  gboolean promoted = FALSE;
+  GST_OBJECT_LOCK (p);
+  if (p->have_pending) {
+    p->info = p->pending_info;
+    p->have_pending = FALSE;
+    promoted = TRUE;
+  }
+  GST_OBJECT_UNLOCK (p);
+  if (promoted) {               /* the canvas size / format follow the pads' layouts: renegotiate before the next output frame */
+    GstObject *agg = gst_object_get_parent (GST_OBJECT (p));
+    if (agg) {
+      gst_pad_mark_reconfigure (GST_AGGREGATOR (agg)->srcpad);
+      gst_object_unref (agg);
+    }
+  }
+}
+
 static gboolean
 amd_comp_pad_select (GstAmdCompositorPadObj * p, GstClockTime out_start, GstClockTime out_end, gboolean * is_eos)
 {
@@ -685,6 +720,7 @@ amd_comp_pad_select (GstAmdCompositorPadObj * p, GstClockTime out_start, GstCloc
       return p->current && GST_CLOCK_TIME_IS_VALID (p->cur_end) && p->cur_end >= out_end;
     }
     if (!GST_BUFFER_PTS_IS_VALID (b)) {         /* untimed: shown as it comes */
+      amd_comp_pad_promote_caps (p);
       gst_buffer_replace (&p->current, b);
       p->cur_start = p->cur_end = GST_CLOCK_TIME_NONE;
       gst_buffer_unref (b);
@@ -708,6 +744,7 @@ amd_comp_pad_select (GstAmdCompositorPadObj * p, GstClockTime out_start, GstCloc
       gst_buffer_unref (b);
       return p->current != NULL || start >= out_end;
     }
+    amd_comp_pad_promote_caps (p);
     gst_buffer_replace (&p->current, b);
     p->cur_start = start;
     p->cur_end = end;
@@ -959,11 +996,13 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
 
   /* canvas */
   if (c->out_hip) {
-    if (!c->out_pool || gst_buffer_pool_acquire_buffer (c->out_pool, &outbuf, NULL) != GST_FLOW_OK)
+    GstFlowReturn pool_flow = c->out_pool ? gst_buffer_pool_acquire_buffer (c->out_pool, &outbuf, NULL) : GST_FLOW_ERROR;
+    if (pool_flow != GST_FLOW_OK)
       outbuf = NULL;
     omem = outbuf ? gst_buffer_peek_memory (outbuf, 0) : NULL;
     if (!omem || !gst_memory_map (omem, &omap, GST_MAP_WRITE | GST_MAP_AMDHIP)) {
-      flow = GST_FLOW_ERROR;
+      /* a flushing pool (seek, state change) is passed on as it is; only a real failure posts an error below */
+      flow = pool_flow != GST_FLOW_OK ? pool_flow : GST_FLOW_ERROR;
       goto done_inputs;
     }
     gst_amd_hip_memory_wait_idle (omem, c->stream);           /* a recycled canvas may still be read downstream */

@@ -132,10 +132,83 @@ tr_prepare_output_buffer (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer
   if (!s->pool)
     return GST_BASE_TRANSFORM_CLASS (gst_amd_hip_transfer_parent_class)->prepare_output_buffer (trans, inbuf, outbuf);
   gst_amd_hip_select_device (s->device_id);
-  if (gst_buffer_pool_acquire_buffer (s->pool, outbuf, NULL) != GST_FLOW_OK)
-    return GST_FLOW_ERROR;
+  {
+    const GstFlowReturn fr = gst_buffer_pool_acquire_buffer (s->pool, outbuf, NULL);
+    if (fr != GST_FLOW_OK)
+      return fr;                /* FLUSHING is the pool's answer during a seek / shutdown, not an error */
+  }
   gst_buffer_copy_into (*outbuf, inbuf, GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS, 0, -1);
   return GST_FLOW_OK;
+}
+
+/* the metas of the input travel with the frame (GstBaseTransform's default copy_metadata runs for pool buffers too); the GstVideoMeta
+ * does not: it describes the INPUT's plane layout, the output frame has the pool's */
+static gboolean
+tr_transform_meta (GstBaseTransform * trans, GstBuffer * outbuf, GstMeta * meta, GstBuffer * inbuf)
+{
+  if (meta->info->api == GST_VIDEO_META_API_TYPE)
+    return FALSE;
+  return GST_BASE_TRANSFORM_CLASS (gst_amd_hip_transfer_parent_class)->transform_meta (trans, outbuf, meta, inbuf);
+}
+
+/* rows x bytes of plane k of a frame (gst_video_format_info component geometry; the packed formats have one plane of whole pixels) */
+static void
+tr_plane_geometry (const GstVideoInfo * info, guint k, gsize * row_bytes, gsize * rows)
+{
+  const GstVideoFormatInfo *f = info->finfo;
+  gint comp[GST_VIDEO_MAX_COMPONENTS];
+  guint c, n = 0;
+  gsize bytes = 0;
+  /* the components stored in plane k (gst_video_format_info_component exists from 1.18 on only) */
+  for (c = 0; c < GST_VIDEO_FORMAT_INFO_N_COMPONENTS (f); c++)
+    if (GST_VIDEO_FORMAT_INFO_PLANE (f, c) == k)
+      comp[n++] = (gint) c;
+  /* the widest extent a component of this plane reaches: offset of its last sample + its size */
+  for (c = 0; c < n; c++) {
+    const gint cw = GST_VIDEO_FORMAT_INFO_SCALE_WIDTH (f, comp[c], GST_VIDEO_INFO_WIDTH (info));
+    const gsize end = (gsize) GST_VIDEO_FORMAT_INFO_POFFSET (f, comp[c]) + (gsize) (cw - 1) * GST_VIDEO_FORMAT_INFO_PSTRIDE (f, comp[c]) +
+        (GST_VIDEO_FORMAT_INFO_DEPTH (f, comp[c]) + 7) / 8;
+    bytes = MAX (bytes, end);
+  }
+  *row_bytes = bytes;
+  *rows = n ? GST_VIDEO_FORMAT_INFO_SCALE_HEIGHT (f, comp[0], GST_VIDEO_INFO_HEIGHT (info)) : 0;
+}
+
+/* TRUE: the buffer's planes lie where `info` (the layout of the pool's frames: default strides) puts them - one flat copy serves */
+static gboolean
+tr_layout_is_default (GstBuffer * buf, const GstVideoInfo * info)
+{
+  const GstVideoMeta *m = gst_buffer_get_video_meta (buf);
+  guint k;
+  if (!m)
+    return TRUE;
+  if (m->n_planes != GST_VIDEO_INFO_N_PLANES (info))
+    return FALSE;
+  for (k = 0; k < m->n_planes; k++)
+    if (m->offset[k] != GST_VIDEO_INFO_PLANE_OFFSET (info, k) || m->stride[k] != GST_VIDEO_INFO_PLANE_STRIDE (info, k))
+      return FALSE;
+  return TRUE;
+}
+
+/* plane-by-plane pitched copy between a system-memory frame described by its GstVideoMeta and a frame in the default layout */
+static int
+tr_copy_planes (GstAmdHipTransfer * s, gboolean upload, guint8 * dev, guint8 * host, gsize host_size, const GstVideoMeta * m)
+{
+  guint k;
+  int r = GSTAMD_OK;
+  for (k = 0; k < GST_VIDEO_INFO_N_PLANES (&s->info) && r == GSTAMD_OK; k++) {
+    gsize row_bytes, rows;
+    tr_plane_geometry (&s->info, k, &row_bytes, &rows);
+    if (rows && m->offset[k] + (rows - 1) * (gsize) m->stride[k] + row_bytes > host_size)
+      return GSTAMD_ERR_INVALID;
+    if (upload)
+      r = gstamd_device_upload_2d_async (dev + GST_VIDEO_INFO_PLANE_OFFSET (&s->info, k), GST_VIDEO_INFO_PLANE_STRIDE (&s->info, k),
+          host + m->offset[k], m->stride[k], row_bytes, rows, s->stream);
+    else
+      r = gstamd_device_download_2d_async (host + m->offset[k], m->stride[k], dev + GST_VIDEO_INFO_PLANE_OFFSET (&s->info, k),
+          GST_VIDEO_INFO_PLANE_STRIDE (&s->info, k), row_bytes, rows, s->stream);
+  }
+  return r;
 }
 
 static GstFlowReturn
@@ -154,8 +227,13 @@ tr_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
       return GST_FLOW_ERROR;
     if (gst_memory_map (omem, &om, GST_MAP_WRITE | GST_MAP_AMDHIP)) {
       gst_amd_hip_memory_wait_idle (omem, s->stream);
-      /* pageable source: the call returns once the bytes have been staged, the input may be unmapped right away */
-      r = gstamd_device_upload_async (om.data, im.data, MIN (im.size, om.size), s->stream);
+      /* pageable source: the call returns once the bytes have been staged, the input may be unmapped right away.  A source with its
+       * own strides / plane offsets (GstVideoMeta of a decoder or an aligned pool) is copied plane by plane into the pool frame's
+       * default layout - a flat copy would shear every row after the first */
+      if (tr_layout_is_default (inbuf, &s->info))
+        r = gstamd_device_upload_async (om.data, im.data, MIN (im.size, om.size), s->stream);
+      else
+        r = tr_copy_planes (s, TRUE, om.data, im.data, im.size, gst_buffer_get_video_meta (inbuf));
       if (r == GSTAMD_OK)
         gst_amd_hip_memory_mark_written (omem, s->stream);
       gst_memory_unmap (omem, &om);
@@ -166,7 +244,10 @@ tr_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
       return GST_FLOW_ERROR;
     if (gst_buffer_map (outbuf, &om, GST_MAP_WRITE)) {
       gst_amd_hip_memory_wait_written (imem, s->stream);
-      r = gstamd_device_download_async (om.data, im.data, MIN (im.size, om.size), s->stream);
+      if (tr_layout_is_default (outbuf, &s->info))
+        r = gstamd_device_download_async (om.data, im.data, MIN (im.size, om.size), s->stream);
+      else
+        r = tr_copy_planes (s, FALSE, im.data, om.data, om.size, gst_buffer_get_video_meta (outbuf));
       if (r == GSTAMD_OK)
         r = gstamd_stream_synchronize (s->stream);
       gst_buffer_unmap (outbuf, &om);
@@ -228,6 +309,7 @@ gst_amd_hip_transfer_class_init (GstAmdHipTransferClass * klass)
   tc->get_unit_size = GST_DEBUG_FUNCPTR (tr_get_unit_size);
   tc->prepare_output_buffer = GST_DEBUG_FUNCPTR (tr_prepare_output_buffer);
   tc->transform = GST_DEBUG_FUNCPTR (tr_transform);
+  tc->transform_meta = GST_DEBUG_FUNCPTR (tr_transform_meta);
   tc->stop = GST_DEBUG_FUNCPTR (tr_stop);
   klass->upload = TRUE;
 }

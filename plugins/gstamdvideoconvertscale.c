@@ -939,14 +939,17 @@ amd_vcs_prepare_output_buffer (GstBaseTransform * trans, GstBuffer * inbuf, GstB
     const gint64 t0 = s->stats ? g_get_monotonic_time () : 0;
     const GstFlowReturn fr = s->out_pool ? gst_buffer_pool_acquire_buffer (s->out_pool, outbuf, NULL) : GST_FLOW_ERROR;
     if (fr != GST_FLOW_OK)
-      return GST_FLOW_ERROR;
+      return fr;                /* FLUSHING during a seek / shutdown is the pool's answer, not an error of this element */
     gst_buffer_copy_into (*outbuf, inbuf, GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS, 0, -1);
     if (s->stats)
       s->t_prepare += g_get_monotonic_time () - t0;
     return GST_FLOW_OK;
   }
-  if (!s->out_pool || gst_buffer_pool_acquire_buffer (s->out_pool, outbuf, NULL) != GST_FLOW_OK)
-    return GST_FLOW_ERROR;
+  {
+    const GstFlowReturn fr = s->out_pool ? gst_buffer_pool_acquire_buffer (s->out_pool, outbuf, NULL) : GST_FLOW_ERROR;
+    if (fr != GST_FLOW_OK)
+      return fr;
+  }
   gst_buffer_copy_into (*outbuf, inbuf, GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS, 0, -1);
   return GST_FLOW_OK;
 }
@@ -1159,11 +1162,12 @@ amd_vcs_chain_list (GstPad * pad, GstObject * parent, GstBufferList * list)
       gpointer stream;
       guint got = 0, mapped = 0;
       int r = GSTAMD_OK;
+      GstFlowReturn pool_flow = GST_FLOW_OK;
 
       gst_amd_hip_select_device (s->device_id);
       stream = s->streams[s->next_stream++ % s->n_streams];
       for (k = 0; k < cnt; k++) {
-        if (gst_buffer_pool_acquire_buffer (s->out_pool, &outs[k], NULL) != GST_FLOW_OK)
+        if ((pool_flow = gst_buffer_pool_acquire_buffer (s->out_pool, &outs[k], NULL)) != GST_FLOW_OK)
           break;
         got++;
         gst_buffer_copy_into (outs[k], gst_buffer_list_get (list, i + k), GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS, 0, -1);
@@ -1201,6 +1205,10 @@ amd_vcs_chain_list (GstPad * pad, GstObject * parent, GstBufferList * list)
       if (r != GSTAMD_OK) {
         for (k = 0; k < got; k++)
           gst_buffer_unref (outs[k]);
+        if (pool_flow != GST_FLOW_OK && pool_flow != GST_FLOW_ERROR) {
+          ret = pool_flow;      /* the pool is flushing (seek, state change): pass that on, nothing failed */
+          break;
+        }
         GST_ELEMENT_ERROR (s, LIBRARY, FAILED, ("HIP conversion of a buffer list failed"), ("%s", gstamd_last_error ()));
         ret = GST_FLOW_ERROR;
         break;

@@ -692,6 +692,9 @@ extern "C" int emu_gamma_fused_runs (void) { return g_gamma_fused_runs; }
 extern "C" int emu_h420_runs (void) { return g_h420_runs; }
 extern "C" int emu_h420_reg_runs (void) { return g_h420_reg_runs; }
 
+static int g_swizzle4_runs = 0;
+extern "C" int emu_swizzle4_runs (void) { return g_swizzle4_runs; }
+
 /* gstamd_video_converter_divergence of the last top-level emu_video_convert (the plan's note + those of its sub-conversions) */
 static std::string g_emu_divergence;
 extern "C" const char *emu_video_last_divergence (void) { return g_emu_divergence.c_str (); }
@@ -1144,6 +1147,18 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
             break;
         }
       }
+    return GSTAMD_OK;
+  }
+  if (p.passes.empty () && vec_ok == 2 && p.front.hi_depth == 0 && color.matrix.kind == MATRIX_NONE && color.alpha_kind == ALPHA_NONE) {
+    /* k_swizzle4: a byte permutation per pixel, four pixels per lane */
+    const uint32_t sel = swizzle4_selector (p.front.pos, p.post.pack_pos);
+    g_swizzle4_runs++;
+    for (int y = 0; y < p.front.height; y++) {
+      const uint32_t *sp = (const uint32_t *) (pl.p[0] + (size_t) y * pl.stride[0]);
+      uint32_t *dp = (uint32_t *) (d0 + (size_t) y * dstride);
+      for (int x = 0; x < p.front.width; x++)
+        dp[x] = swizzle4_px (sp[x], sel);
+    }
     return GSTAMD_OK;
   }
   if (p.passes.empty ()) {

@@ -691,6 +691,25 @@ def test_audioconvert_element_noise_shaping_downmix_and_resample_chain(gst_env, 
     assert out.shape == exp.shape and (out == exp).all()
 
 
+def test_upload_honours_the_video_meta_of_the_source(gst_env):
+    """amdhipupload with a system-memory frame whose GstVideoMeta has padded strides and a gap between the planes
+    (plugins/tests/live_props.c): plane-by-plane pitched copies into the pool frame's default layout"""
+    env, tmp = gst_env
+    exe = os.path.join(ROOT, "plugins", "tests", "live_props")
+    r = subprocess.run([exe, "upload-meta"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_audioconvert_mix_matrix_changed_while_running(gst_env):
+    """`mix-matrix` set between two buffers with unchanged caps (plugins/tests/live_props.c): the converter is re-made by the streaming
+    thread at the next transform, as gst_audio_convert_ensure_converter does (gstaudioconvert.c:1700), and the element leaves passthrough"""
+    env, tmp = gst_env
+    exe = os.path.join(ROOT, "plugins", "tests", "live_props")
+    assert os.path.exists(exe), "plugins/build.py builds it"
+    r = subprocess.run([exe, "mix-matrix"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_audioconvert_element_mix_matrix_property(gst_env, ref):
     env, tmp = gst_env
     fin, fout = tmp / "acm_in.s16", tmp / "acm_out.s16"

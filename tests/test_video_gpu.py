@@ -52,6 +52,17 @@ def test_hip_reference_undefined_plans_compute_the_stage_by_stage_result(native_
         assert (got == exp).all(), int((got != exp).sum())
 
 
+@pytest.mark.parametrize("pair", [("BGRA", "RGBA"), ("ARGB", "BGRx"), ("RGBx", "xBGR"), ("ABGR", "ARGB"), ("AYUV", "VUYA")])
+@pytest.mark.parametrize("size", [(3840, 2160), (1022, 33), (3, 5)])
+def test_hip_byte_permutations_match_reference(native_lib, gpu, ref, pair, size):
+    """k_swizzle4 (4-byte packed -> 4-byte packed, no colour step) at 4K, with a scalar tail, and narrower than one lane"""
+    (a, b), (w, h) = pair, size
+    src = cases.frame_bytes(w * h * 4, "random", 98, w)
+    got = gpu_convert(gpu, a, w, h, b, w, h, {}, None, None, src)
+    exp = ref.VideoConverter(a, w, h, b, w, h).frame(src)
+    assert (got == exp).all()
+
+
 def test_hip_set_config_gives_the_frames_of_a_fresh_converter(native_lib, gpu, ref):
     """gst_video_converter_set_config on a live converter, incl. the composite plans whose sub-conversions have to be re-planned"""
     import torch

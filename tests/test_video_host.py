@@ -131,6 +131,22 @@ def test_reference_undefined_plans_compute_the_stage_by_stage_result_on_host(nat
     assert (one_step != got).any()
 
 
+@pytest.mark.parametrize("pair", [("BGRA", "RGBA"), ("ARGB", "BGRx"), ("RGBx", "xBGR"), ("ABGR", "ARGB"), ("AYUV", "VUYA"), ("BGRA", "BGRA")])
+@pytest.mark.parametrize("w", [100, 64, 3])
+def test_byte_permutations_take_the_copy_shaped_kernel_on_host(native_lib, emu_lib, ref, pair, w):
+    """4-byte packed -> 4-byte packed with no colour step: k_swizzle4's body (one v_perm_b32 selector) against the reference"""
+    a, b = pair
+    if a == b:
+        return          # the same format is the reference's plane copy, not this kernel
+    h = 7
+    src = cases.frame_bytes(w * h * 4, "random", 99, w)
+    before = emu_lib.emu_swizzle4_runs()
+    got = _emu_convert(emu_lib, a, w, h, b, w, h, {}, None, None, src)
+    assert emu_lib.emu_swizzle4_runs() == before + (1 if (4 * w) % 16 == 0 else 0)       # rows that are not 16-byte aligned: the generic kernel
+    exp = ref.VideoConverter(a, w, h, b, w, h).frame(src)
+    assert (got == exp).all()
+
+
 def test_plans_that_reproduce_the_reference_carry_no_divergence_note(native_lib):
     for (ifmt, w, h, ofmt, ow, oh, cfg) in (("NV12", 3840, 2160, "BGRA", 3840, 2160, {}), ("I420", 7680, 4320, "RGBA", 1920, 1080, cases.LAN),
                                             ("AYUV", 58, 18, "ARGB", 30, 20, cases.LIN), ("P010_10LE", 64, 48, "NV12", 64, 48, {})):

@@ -73,6 +73,7 @@ struct GstAmdVideoConverter {
   bool hook_on = false;                 /* this converter is the direct conversion of a fused gamma plan: k_convert_gamma with `hook` */
   GammaDev hook;
   uint16_t *gamma_dec_dev = nullptr;
+  uint16_t *gamma_dec16_dev = nullptr, *gamma_enc16_dev = nullptr;          /* the 65536-entry tables of a remap with 16-bit ends */
   uint8_t *gamma_enc_dev = nullptr;
   uint8_t *gamma_mid_a = nullptr, *gamma_mid_b = nullptr;
 };
@@ -338,6 +339,12 @@ static int build_tables (GstAmdVideoConverter *c)
     if (!g.enc.empty () && ((e = hipMalloc ((void **) &c->gamma_enc_dev, 65536)) != hipSuccess ||
             (e = hipMemcpy (c->gamma_enc_dev, g.enc.data (), 65536, hipMemcpyHostToDevice)) != hipSuccess))
       return hip_fail (e, "encode table");
+    if (!g.dec16.empty () && ((e = hipMalloc ((void **) &c->gamma_dec16_dev, 65536 * sizeof (uint16_t))) != hipSuccess ||
+            (e = hipMemcpy (c->gamma_dec16_dev, g.dec16.data (), 65536 * sizeof (uint16_t), hipMemcpyHostToDevice)) != hipSuccess))
+      return hip_fail (e, "16-bit decode table");
+    if (!g.enc16.empty () && ((e = hipMalloc ((void **) &c->gamma_enc16_dev, 65536 * sizeof (uint16_t))) != hipSuccess ||
+            (e = hipMemcpy (c->gamma_enc16_dev, g.enc16.data (), 65536 * sizeof (uint16_t), hipMemcpyHostToDevice)) != hipSuccess))
+      return hip_fail (e, "16-bit encode table");
     if (!g.fused && !g.src16 && !g.src64 && (e = hipMalloc ((void **) &c->gamma_mid_a, in_px * 4)) != hipSuccess)
       return hip_fail (e, "hipMalloc(8-bit image)");
     if (!g.fused && !g.pack16 && !g.store64 && (e = hipMalloc ((void **) &c->gamma_mid_b, out_px * 4)) != hipSuccess)
@@ -503,6 +510,11 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   gd.alpha_value = g.alpha_value;
   gd.dec = c->gamma_dec_dev;
   gd.enc = c->gamma_enc_dev;
+  gd.to_rgb16 = g.to_rgb16;
+  gd.to_yuv16 = g.to_yuv16;
+  gd.dec16 = c->gamma_dec16_dev;
+  gd.enc16 = c->gamma_enc16_dev;
+  const bool dec16 = !g.dec16.empty (), enc16 = !g.enc16.empty ();          /* gamma remap with a 16-bit source / destination */
   if (g.fused) {
     c->sub_in->hook = gd;
     c->sub_in->hook_on = true;
@@ -553,6 +565,18 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       cur.p = c->deep_a, cur.stride = in_w * 8, cur.width = in_w, cur.height = in_h;
     }
   }
+  if (cur.p && dec16) {
+    /* 16-bit source: the matrix to R'G'B' + the 16 -> 16 decode table on the first image (never in place on the caller's frame), with the
+       convert stage where it comes before the scalers */
+    const bool mid_now = !mid_done && (n == 0 || !g.shrink);
+    uint8_t *md = cur_is_source ? c->deep_a : (uint8_t *) cur.p;
+    const int ms = cur_is_source ? cur.width * 8 : cur.stride;
+    if ((e = launch_gamma_stage (gd, GAMMA_STAGE_DEC16 | (mid_now ? GAMMA_STAGE_MID : 0), cur.p, cur.stride, md, ms, cur.width, cur.height, stream)) != hipSuccess)
+      return hip_fail (e, "k_gamma_stage(decode16)");
+    cur.p = md, cur.stride = ms;
+    cur_is_source = false;
+    mid_done = mid_done || mid_now;
+  }
   if (cur.p) {
     if (!mid_done && (n == 0 || !g.shrink)) {           /* the convert stage before the scalers (or no scalers): in place */
       uint8_t *md = cur_is_source ? c->deep_a : (uint8_t *) cur.p;
@@ -583,11 +607,12 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       cur_is_source = false;
     }
     if (g.pack16 || g.store64) {
-      if (!mid_done) {
+      if (!mid_done || enc16) {
         uint8_t *md = cur_is_source ? c->deep_a : (uint8_t *) cur.p;
         const int ms = cur_is_source ? cur.width * 8 : cur.stride;
-        if ((e = launch_gamma_stage (gd, GAMMA_STAGE_MID, cur.p, cur.stride, md, ms, cur.width, cur.height, stream)) != hipSuccess)
-          return hip_fail (e, "k_gamma_stage(convert)");
+        if ((e = launch_gamma_stage (gd, (mid_done ? 0 : GAMMA_STAGE_MID) | (enc16 ? GAMMA_STAGE_ENC16 : 0), cur.p, cur.stride, md, ms, cur.width, cur.height,
+                    stream)) != hipSuccess)
+          return hip_fail (e, "k_gamma_stage(convert / encode16)");
         cur.p = md, cur.stride = ms;
       }
     } else if ((e = launch_gamma_stage (gd, (mid_done ? 0 : GAMMA_STAGE_MID) | GAMMA_STAGE_ENC, cur.p, cur.stride, c->gamma_mid_b, out_w * 4, out_w, out_h,
@@ -1230,6 +1255,11 @@ static void release_tables (GstAmdVideoConverter *c)
     (void) hipFree (c->deep_a);
   if (c->deep_b)
     (void) hipFree (c->deep_b);
+  if (c->gamma_dec16_dev)
+    (void) hipFree (c->gamma_dec16_dev);
+  if (c->gamma_enc16_dev)
+    (void) hipFree (c->gamma_enc16_dev);
+  c->gamma_dec16_dev = c->gamma_enc16_dev = nullptr;
   if (c->gamma_dec_dev)
     (void) hipFree (c->gamma_dec_dev);
   if (c->gamma_enc_dev)

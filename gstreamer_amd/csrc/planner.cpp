@@ -1440,6 +1440,30 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
   return f->hi_depth ? 2 * n : n;
 }
 
+static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, const GstAmdVideoConverterConfig *config, VideoPlan *plan, std::string *error);
+static void fill_pack_params (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, const FormatDesc *fi, const FormatDesc *fo, const GstAmdVideoConverterConfig &cfg,
+    int full_in_w, int full_in_h, int full_out_w, int full_out_h, PackPlanarParams *pkp);
+
+/* chain_dither (:2035-2085) on 16-bit lines ahead of a 10 / 12 / 16-bit planar pack: quantiser 1 << (16 - depth), or the target
+ * quantiser when that is coarser; shift[] in unpack order (A, Y, U, V) */
+static void setup_dither16 (const GstAmdVideoConverterConfig &cfg, const FormatDesc *fo, DitherParams *d)
+{
+  memset (d, 0, sizeof (*d));
+  if (cfg.dither_method == GSTAMD_DITHER_NONE || fo->hi_depth == 3)
+    return;
+  const int depth = hi_depth_bits (fo->hi_depth);
+  unsigned q = 1u << (16 - depth);
+  if (cfg.dither_quantization > q)
+    q = cfg.dither_quantization;
+  int shift = 0;
+  for (unsigned v = q; v > 1; v >>= 1)
+    shift++;
+  d->on = shift > 0;
+  d->method = cfg.dither_method;
+  d->shift[0] = 0;              /* no alpha component in the destination: quantiser 0 */
+  d->shift[1] = d->shift[2] = d->shift[3] = shift;
+}
+
 // gamma-mode = remap: the composite plan of GammaPlan (planner.h).  `in` / `out` are the crop / the destination rectangle.
 static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, VideoPlan *plan, int alpha_bits, bool same_primaries, M44 prim_dm,
     std::string *error)
@@ -1451,10 +1475,61 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   };
   const GstAmdVideoConverterConfig &cfg = plan->config;
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
-  if (fi->hi_depth || fo->hi_depth)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "gamma-mode = remap with a 16-bit unpack format (the 65536-entry decode table) is not implemented on the GPU path");
   GammaPlan &g = plan->gamma;
+  const bool in16 = fi->hi_depth != 0, out16 = fo->hi_depth != 0;
+  if (out16 && !kind_has_planes (fo->kind) && fo->hi_depth != 3)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destination layout not implemented on the GPU path");
+  if (out16 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path");
+  if (fo->hi_depth == 3 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_quantization > 1)
+    return fail (GSTAMD_ERR_UNSUPPORTED, "dither-quantization > 1 into a 16-bit destination is not implemented on the GPU path");
+  /* a 10 / 12 / 16-bit planar SOURCE: the 16-bit front (unpack + chroma upsampler, k_front16) of the conversion into an AYUV64 frame of
+   * the same size - planned like any other conversion, its front / pair table taken over */
+  FrontParams front16;
+  std::vector<int32_t> vpair16;
+  memset (&front16, 0, sizeof (front16));
+  if (in16 && fi->hi_depth != 3) {
+    const int fw = plan->rect.in_maxw ? plan->rect.in_maxw : in->width, fh = plan->rect.in_maxh ? plan->rect.in_maxh : in->height;
+    const int ow_full = plan->rect.out_maxw ? plan->rect.out_maxw : out->width, oh_full = plan->rect.out_maxh ? plan->rect.out_maxh : out->height;
+    const bool differs16 = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site || fw != ow_full || fh != oh_full;
+    const bool up16 = differs16 && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY;
+    GstAmdVideoInfo a64;
+    if (video_info_set_format (&a64, GSTAMD_VIDEO_FORMAT_AYUV64, in->width, in->height) != GSTAMD_OK)
+      return fail (GSTAMD_ERR_INVALID, "bad frame size");
+    a64.color_range = in->color_range;
+    a64.color_matrix = in->color_matrix;
+    a64.color_transfer = in->color_transfer;
+    a64.color_primaries = in->color_primaries;
+    a64.chroma_site = in->chroma_site;
+    GstAmdVideoConverterConfig fc;
+    converter_config_init (&fc);
+    fc.chroma_mode = up16 ? GSTAMD_CHROMA_MODE_FULL : GSTAMD_CHROMA_MODE_NONE;
+    fc.matrix_mode = GSTAMD_MATRIX_MODE_NONE;
+    fc.dither_method = GSTAMD_DITHER_NONE;
+    fc.internal_flags = 1;
+    VideoPlan tmp;
+    std::string terr;
+    memset (&tmp.rect, 0, sizeof (tmp.rect));
+    tmp.rect.in_maxw = tmp.rect.out_maxw = in->width;
+    tmp.rect.in_maxh = tmp.rect.out_maxh = in->height;
+    tmp.orig_in = *in;
+    tmp.orig_out = a64;
+    const int tr = plan_core (in, &a64, &fc, &tmp, &terr);
+    if (tr != GSTAMD_OK)
+      return fail (tr, "16-bit front of a gamma remap: " + terr);
+    if (tmp.gamma.planes_fast || !tmp.gamma.src16)
+      return fail (GSTAMD_ERR_UNSUPPORTED, "16-bit front of a gamma remap: unexpected plan for the front");
+    front16 = tmp.front;
+    vpair16 = tmp.vpair;
+  }
   g.on = true;
+  g.in16 = in16;
+  g.out16 = out16;
+  g.src64 = fi->hi_depth == 3;
+  g.src16 = in16 && !g.src64;
+  g.store64 = fo->hi_depth == 3;
+  g.pack16 = out16 && !g.store64;
+  g.planes_fast = false;
   /* nothing of the single-converter plan is used by a composite */
   plan->plane_mode = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_post = plan->deep16 = false;
   plan->matrix_before_scale = false;
@@ -1466,6 +1541,17 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   memset (&plan->pack, 0, sizeof (plan->pack));
   memset (&plan->deep, 0, sizeof (plan->deep));
   memset (&plan->dither, 0, sizeof (plan->dither));
+  if (g.src16) {
+    plan->front = front16;
+    plan->vpair = vpair16;
+  }
+  memset (&g.to_rgb16, 0, sizeof (g.to_rgb16));
+  memset (&g.to_yuv16, 0, sizeof (g.to_yuv16));
+  memset (&g.dither16, 0, sizeof (g.dither16));
+  memset (&g.pack, 0, sizeof (g.pack));
+  g.pack_hi_depth = fo->hi_depth;
+  g.dec16.clear ();
+  g.enc16.clear ();
   const bool unpack_rgb = !fi->yuv, pack_rgb = !fo->yuv;
   const int in_matrix = unpack_rgb ? GSTAMD_COLOR_MATRIX_RGB : in->color_matrix, out_matrix = pack_rgb ? GSTAMD_COLOR_MATRIX_RGB : out->color_matrix;
   /* the two 8-bit unpack-format images around the 16-bit part */
@@ -1516,13 +1602,40 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     if (cfg.matrix_mode != GSTAMD_MATRIX_MODE_NONE && get_Kr_Kb (cfg.matrix_mode == GSTAMD_MATRIX_MODE_OUTPUT_ONLY ? out_matrix : in_matrix, &Kr, &Kb))
       m_YCbCr_to_RGB (dm, Kr, Kb);
     m_scale_components (dm, (float) 256, (float) 256, (float) 256);
-    if (!m_is_identity (dm))
+    if (!in16 && !m_is_identity (dm))
       prepare_matrix8 (dm, unpack_rgb, pack_rgb, &g.to_rgb, scratch);
   }
-  /* setup_gamma_decode (:1495-1530), 8 -> 16 bits */
-  g.dec.resize (256);
-  for (int i = 0; i < 256; i++)
-    g.dec[i] = (uint16_t) rint (transfer_decode (in->color_transfer, i / 255.0) * 65535.0);
+  if (in16 && !unpack_rgb) {
+    /* the same at current_bits 16: the unpack format's 16-bit range offsets, scaled to 1 << 16, prepare_matrix -> video_converter_matrix16 */
+    M44 dm;
+    int offset[3], scale[3];
+    double Kr = 0, Kb = 0;
+    m_identity (dm);
+    range_offsets (in->color_range, true, offset, scale, 16);
+    m_offset_components (dm, -offset[0], -offset[1], -offset[2]);
+    m_scale_components (dm, 1 / ((float) scale[0]), 1 / ((float) scale[1]), 1 / ((float) scale[2]));
+    if (cfg.matrix_mode != GSTAMD_MATRIX_MODE_NONE && get_Kr_Kb (cfg.matrix_mode == GSTAMD_MATRIX_MODE_OUTPUT_ONLY ? out_matrix : in_matrix, &Kr, &Kb))
+      m_YCbCr_to_RGB (dm, Kr, Kb);
+    m_scale_components (dm, (float) 65536, (float) 65536, (float) 65536);
+    if (!m_is_identity (dm)) {
+      m_scale_components (dm, 256.0f, 256.0f, 256.0f);
+      g.to_rgb16.has_matrix = 1;
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++)
+          g.to_rgb16.im[i][j] = (int) rint (dm[i][j]);
+    }
+  }
+  /* setup_gamma_decode (:1495-1530), 8 -> 16 bits, or 16 -> 16 */
+  g.dec.clear ();
+  if (in16) {
+    g.dec16.resize (65536);
+    for (int i = 0; i < 65536; i++)
+      g.dec16[i] = (uint16_t) rint (transfer_decode (in->color_transfer, i / 65535.0) * 65535.0);
+  } else {
+    g.dec.resize (256);
+    for (int i = 0; i < 256; i++)
+      g.dec[i] = (uint16_t) rint (transfer_decode (in->color_transfer, i / 255.0) * 65535.0);
+  }
   /* chain_convert with gamma (:1845-1854): only the primaries, on 16-bit values */
   memset (&g.prim, 0, sizeof (g.prim));
   if (!same_primaries && !m_is_identity (prim_dm)) {
@@ -1537,12 +1650,43 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   /* chain_alpha on 16-bit lines (:1870-1953) */
   g.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
   g.alpha_value = (unsigned) (int) (255 * cfg.alpha_value);
-  /* setup_gamma_encode (:1532-1565), 16 -> 8 bits */
-  g.enc.resize (65536);
-  for (int i = 0; i < 65536; i++)
-    g.enc[i] = (uint8_t) rint (transfer_encode (out->color_transfer, i / 65535.0) * 255.0);
+  /* setup_gamma_encode (:1532-1565), 16 -> pack_bits */
+  g.enc.clear ();
+  if (out16) {
+    g.enc16.resize (65536);
+    for (int i = 0; i < 65536; i++)
+      g.enc16[i] = (uint16_t) rint (transfer_encode (out->color_transfer, i / 65535.0) * 65535.0);
+  } else {
+    g.enc.resize (65536);
+    for (int i = 0; i < 65536; i++)
+      g.enc[i] = (uint8_t) rint (transfer_encode (out->color_transfer, i / 65535.0) * 255.0);
+  }
+  if (out16 && !pack_rgb) {
+    /* chain_convert_to_YUV at pack_bits 16: identity / (1 << 16), the matrix to Y'CbCr, the pack format's 16-bit range */
+    M44 dm;
+    int offset[3], scale[3];
+    double Kr = 0, Kb = 0;
+    m_identity (dm);
+    m_scale_components (dm, 1 / (float) 65536, 1 / (float) 65536, 1 / (float) 65536);
+    if (cfg.matrix_mode != GSTAMD_MATRIX_MODE_NONE && get_Kr_Kb (cfg.matrix_mode == GSTAMD_MATRIX_MODE_INPUT_ONLY ? in_matrix : out_matrix, &Kr, &Kb))
+      m_RGB_to_YCbCr (dm, Kr, Kb);
+    range_offsets (out->color_range, true, offset, scale, 16);
+    m_scale_components (dm, (float) scale[0], (float) scale[1], (float) scale[2]);
+    m_offset_components (dm, offset[0], offset[1], offset[2]);
+    if (!m_is_identity (dm)) {
+      m_scale_components (dm, 256.0f, 256.0f, 256.0f);
+      g.to_yuv16.has_matrix = 1;
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++)
+          g.to_yuv16.im[i][j] = (int) rint (dm[i][j]);
+    }
+  }
+  if (g.pack16) {
+    fill_pack_params (in, out, fi, fo, cfg, full_in_w, full_in_h, full_out_w, full_out_h, &g.pack);
+    setup_dither16 (cfg, fo, &g.dither16);
+  }
   /* chain_convert_to_YUV (:1955-2015): identity / (1 << 8), then the matrix to Y'CbCr and the output range */
-  if (!pack_rgb) {
+  if (!pack_rgb && !out16) {
     M44 dm;
     int offset[3], scale[3];
     double Kr = 0, Kb = 0;
@@ -1576,7 +1720,7 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     }
   }
   plan->algorithmic_bytes = picture_bytes (fi, in_w, in_h) + picture_bytes (fo, out_w, out_h);
-  g.fused = plan->passes.empty () && fo->kind == UNPACK_PACKED4;
+  g.fused = plan->passes.empty () && fo->kind == UNPACK_PACKED4 && !in16 && !out16;
   if (g.fused) {
     /* the direct conversion (crop, chroma upsampler as the real chain decides it, destination rectangle, borders, dither) minus matrix and
        alpha, which are the gamma chain's */
@@ -1584,8 +1728,9 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     g.cfg_in.chroma_mode = cfg.chroma_mode;
     g.mid_in = plan->orig_out;
   }
-  plan->description = std::string (g.fused ? "gamma_fused[" : "gamma_remap[") + fi->name + "->" + fo->name + (g.to_rgb.kind ? ",to_rgb" : "") + (g.prim.has_matrix ? ",primaries" : "") +
-      (g.to_yuv.kind ? ",to_yuv" : "") + (plan->passes.empty () ? "" : g.shrink ? ",scale16(first)" : ",scale16(last)") + "]";
+  plan->description = std::string (g.fused ? "gamma_fused[" : "gamma_remap[") + fi->name + "->" + fo->name + (g.src16 ? ",front16" : "") + (in16 ? ",dec16" : "") +
+      (g.to_rgb.kind || g.to_rgb16.has_matrix ? ",to_rgb" : "") + (g.prim.has_matrix ? ",primaries" : "") +
+      (g.to_yuv.kind || g.to_yuv16.has_matrix ? ",to_yuv" : "") + (out16 ? ",enc16" : "") + (g.pack16 ? ",pack16" : g.store64 ? ",store64" : "") + (plan->passes.empty () ? "" : g.shrink ? ",scale16(first)" : ",scale16(last)") + "]";
   return GSTAMD_OK;
 }
 

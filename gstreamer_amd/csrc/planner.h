@@ -226,6 +226,12 @@ struct GammaPlan {
   bool shrink;                  // the scalers run before the primaries / alpha stages (chain_scale's first call)
   std::vector<uint16_t> dec;    // [256] gamma_convert_u8_u16's table
   std::vector<uint8_t> enc;     // [65536] gamma_convert_u16_u8's table
+  /* gamma-mode = remap with a 16-bit unpack / pack format (setup_gamma_decode / _encode's 16 -> 16 tables, video-converter.c:1497-1564,
+   * and the to-RGB / to-YUV matrices of chain_convert_to_RGB :1567 / _to_YUV :1956 prepared for 16 bits = video_converter_matrix16) */
+  bool in16 = false, out16 = false;
+  Deep16Params to_rgb16, to_yuv16;
+  std::vector<uint16_t> dec16;  // [65536] gamma_convert_u16_u16 on the decode side
+  std::vector<uint16_t> enc16;  // [65536] ... on the encode side
 };
 
 struct VideoPlan {

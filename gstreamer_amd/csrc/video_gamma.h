@@ -11,7 +11,10 @@
 
 namespace gstamd {
 
-enum { GAMMA_STAGE_DEC = 1, GAMMA_STAGE_MID = 2, GAMMA_STAGE_ENC = 4 };
+// GAMMA_STAGE_DEC16 / _ENC16: the same stages when the unpack / pack format is a 16-bit one (round 3): video_converter_matrix16 with the
+// to-R'G'B' matrix prepared for 16 bits, then gamma_convert_u16_u16 (:1480-1494: table[component] on 65536 entries, alpha copied) - and on
+// the way out the 16 -> 16 encode table followed by matrix16 to Y'CbCr; source / destination are AYUV64 / ARGB64 images then.
+enum { GAMMA_STAGE_DEC = 1, GAMMA_STAGE_MID = 2, GAMMA_STAGE_ENC = 4, GAMMA_STAGE_DEC16 = 8, GAMMA_STAGE_ENC16 = 16 };
 
 struct GammaDev {
   MatrixParams to_rgb, to_yuv;
@@ -20,7 +23,33 @@ struct GammaDev {
   unsigned alpha_value;
   const uint16_t *dec;          // [256]
   const uint8_t *enc;           // [65536]
+  Deep16Params to_rgb16, to_yuv16;
+  const uint16_t *dec16;        // [65536]
+  const uint16_t *enc16;        // [65536]
 };
+
+// video_converter_matrix16 (video-converter.c:1296-1320) on the colour components of an ARGB64 pixel
+GSTAMD_HD uint2 gamma_matrix16 (const Deep16Params &m, uint2 px)
+{
+  if (!m.has_matrix)
+    return px;
+  const int r = (int) (px.x >> 16), gg = (int) (px.y & 0xffffu), b = (int) (px.y >> 16);
+  const int c1 = clampi ((m.im[0][0] * r + m.im[0][1] * gg + m.im[0][2] * b + m.im[0][3]) >> 8, 0, 65535);
+  const int c2 = clampi ((m.im[1][0] * r + m.im[1][1] * gg + m.im[1][2] * b + m.im[1][3]) >> 8, 0, 65535);
+  const int c3 = clampi ((m.im[2][0] * r + m.im[2][1] * gg + m.im[2][2] * b + m.im[2][3]) >> 8, 0, 65535);
+  uint2 o;
+  o.x = (px.x & 0xffffu) | ((uint32_t) c1 << 16);
+  o.y = (uint32_t) c2 | ((uint32_t) c3 << 16);
+  return o;
+}
+
+GSTAMD_HD uint2 gamma_lut16 (const uint16_t *t, uint2 px)
+{
+  uint2 o;
+  o.x = (px.x & 0xffffu) | ((uint32_t) t[px.x >> 16] << 16);
+  o.y = (uint32_t) t[px.y & 0xffffu] | ((uint32_t) t[px.y >> 16] << 16);
+  return o;
+}
 
 GSTAMD_HD uint2 gamma_dec_px (const GammaDev &g, uint32_t px)
 {
@@ -75,8 +104,12 @@ GSTAMD_HD void gamma_stage_px (const GammaDev &g, int mask, const uint8_t *src, 
     v = gamma_dec_px (g, *(const uint32_t *) (src + (ptrdiff_t) y * sstride + 4 * (ptrdiff_t) x));
   else
     v = *(const uint2 *) (src + (ptrdiff_t) y * sstride + 8 * (ptrdiff_t) x);
+  if (mask & GAMMA_STAGE_DEC16)
+    v = gamma_lut16 (g.dec16, gamma_matrix16 (g.to_rgb16, v));
   if (mask & GAMMA_STAGE_MID)
     v = gamma_mid_px (g, v);
+  if (mask & GAMMA_STAGE_ENC16)
+    v = gamma_matrix16 (g.to_yuv16, gamma_lut16 (g.enc16, v));
   if (mask & GAMMA_STAGE_ENC)
     *(uint32_t *) (dst + (ptrdiff_t) y * dstride + 4 * (ptrdiff_t) x) = gamma_enc_px (g, v);
   else

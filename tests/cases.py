@@ -531,6 +531,20 @@ VIDEO_CASES = [
     ("w64_ayuv64_i420_half_bilinear", "AYUV64", 64, 48, "I420", 32, 24, LIN, None, None, "random"),
     ("w64_bgra_ayuv64_alpha_set_matrix", "BGRA", 64, 48, "AYUV64", 64, 48, dict(alpha_mode="set", alpha_value=0.25), None, None, "random"),
     ("w64_argb64_1080p_to_720p", "ARGB64", 1920, 1080, "ARGB64", 1280, 720, LIN, None, None, "random"),
+    # gamma-mode = remap with a 16-bit unpack and / or pack format (round 3): 65536-entry decode / encode tables, the to-RGB / to-YUV
+    # matrices on 16-bit values (video-converter.c:1497-1564 setup_gamma_decode / _encode, :1567 chain_convert_to_RGB, :1956 _to_YUV)
+    ("gamma16_p010_bgra_pq", "P010_10LE", 64, 48, "BGRA", 64, 48, dict(gamma_mode="remap"), "bt2100-pq>sRGB", None, "random"),
+    ("gamma16_p010_p010_pq_to_bt2020", "P010_10LE", 64, 48, "P010_10LE", 64, 48, dict(gamma_mode="remap"), "bt2100-pq>bt2020", None, "random"),
+    ("gamma16_nv12_p010_to_pq", "NV12", 64, 48, "P010_10LE", 64, 48, dict(gamma_mode="remap"), "bt709>bt2100-pq", None, "random"),
+    ("gamma16_argb64_argb64_half", "ARGB64", 64, 48, "ARGB64", 32, 24, dict(gamma_mode="remap"), "1:0:5:1>1:0:7:1", None, "random"),
+    ("gamma16_i420_10_nv12_hlg_grow", "I420_10LE", 64, 48, "NV12", 96, 64, dict(gamma_mode="remap"), "bt2100-hlg>bt709", None, "random"),
+    ("gamma16_p010_bgra_half_primaries", "P010_10LE", 64, 48, "BGRA", 32, 24, dict(gamma_mode="remap", primaries_mode="fast"), "bt2100-pq>sRGB", None, "random"),
+    ("gamma16_ayuv64_i420_10_grow", "AYUV64", 40, 30, "I420_10LE", 60, 44, dict(gamma_mode="remap"), "bt2020>bt709", None, "random"),
+    ("gamma16_bgra_argb64_alpha_mult", "BGRA", 40, 30, "ARGB64", 40, 30, dict(gamma_mode="remap", alpha_mode="mult", alpha_value=0.5), "sRGB>1:0:8:1", None, "random"),
+    ("gamma16_y444_12_i422_10", "Y444_12LE", 33, 17, "I422_10LE", 33, 17, dict(gamma_mode="remap"), "bt2100-pq>bt709", None, "random"),
+    ("gamma16_p010_ayuv64", "P010_10LE", 64, 48, "AYUV64", 64, 48, dict(gamma_mode="remap"), "bt2100-pq>bt709", None, "random"),
+    ("gamma16_p010_nv12_720p_to_360p_lanczos", "P010_10LE", 1280, 720, "NV12", 640, 360, dict(gamma_mode="remap", resampler_method="lanczos"), "bt2100-pq>bt709", None, "random"),
+    ("gamma16_p016_i420_12_odd", "P016_LE", 45, 32, "I420_12LE", 45, 32, dict(gamma_mode="remap", primaries_mode="fast"), "bt2100-hlg>bt2020", None, "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd

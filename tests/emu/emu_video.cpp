@@ -749,6 +749,11 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     gd.alpha_value = g.alpha_value;
     gd.dec = g.dec.data ();
     gd.enc = g.enc.data ();
+    gd.to_rgb16 = g.to_rgb16;
+    gd.to_yuv16 = g.to_yuv16;
+    gd.dec16 = g.dec16.data ();
+    gd.enc16 = g.enc16.data ();
+    const bool dec16 = !g.dec16.empty (), enc16 = !g.enc16.empty ();
     auto stage = [&](int mask, const uint8_t *s8, int ss, uint8_t *d8, int ds, int w, int h) {
       for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++)
@@ -795,6 +800,18 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         cur.p = a.data (), cur.stride = in_w * 8, cur.width = in_w, cur.height = in_h;
       }
     }
+    if (cur.p && dec16) {           /* convert_gamma: the 16-bit decode (+ the convert stage where it comes before the scalers) on the first image */
+      const bool mid_now = !mid_done && (n == 0 || !g.shrink);
+      if (cur_is_source) {
+        a.resize ((size_t) cur.width * cur.height * 8);
+        stage (GAMMA_STAGE_DEC16 | (mid_now ? GAMMA_STAGE_MID : 0), cur.p, cur.stride, a.data (), cur.width * 8, cur.width, cur.height);
+        cur.p = a.data (), cur.stride = cur.width * 8;
+        cur_is_source = false;
+      } else {
+        stage (GAMMA_STAGE_DEC16 | (mid_now ? GAMMA_STAGE_MID : 0), cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height);
+      }
+      mid_done = mid_done || mid_now;
+    }
     if (cur.p) {
       if (!mid_done && (n == 0 || !g.shrink)) {
         if (cur_is_source) {
@@ -827,12 +844,13 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         cur_is_source = false;
       }
       if (g.pack16 || g.store64) {
-        if (!mid_done && cur_is_source) {
+        const int m16 = (mid_done ? 0 : GAMMA_STAGE_MID) | (enc16 ? GAMMA_STAGE_ENC16 : 0);
+        if (m16 && cur_is_source) {
           a.resize ((size_t) cur.width * cur.height * 8);
-          stage (GAMMA_STAGE_MID, cur.p, cur.stride, a.data (), cur.width * 8, cur.width, cur.height);
+          stage (m16, cur.p, cur.stride, a.data (), cur.width * 8, cur.width, cur.height);
           cur.p = a.data (), cur.stride = cur.width * 8;
-        } else if (!mid_done) {
-          stage (GAMMA_STAGE_MID, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height);
+        } else if (m16) {
+          stage (m16, cur.p, cur.stride, (uint8_t *) cur.p, cur.stride, cur.width, cur.height);
         }
       } else {
         mid_b.resize ((size_t) out_w * out_h * 4);

@@ -2112,7 +2112,7 @@ static int finalize_deep_to_planar (const GstAmdVideoInfo *in, const GstAmdVideo
   if (!g.shrink)
     plan->passes.clear ();                              /* the 8-bit scalers of the sub-conversion */
   deep_planes_try (in, out, plan, down || plan->front.chroma_h != CHROMA_H_NONE || plan->front.chroma_v2);
-  if (g.planes_fast && !cfg.dest_x && !cfg.dest_y && !plan->rect.fill && !plan->dither.on) {
+  if (g.planes_fast && !cfg.dest_x && !cfg.dest_y && !plan->rect.fill && !plan->dither.on && !plan->pack.dither.on) {
     plan->description = std::string ("deep_planes[") + fi->name + "->" + fo->name + "]";
     return GSTAMD_OK;
   }
@@ -2151,6 +2151,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * format's own (1 at 8 bits) and the method is not NONE - NONE returns before anything is set up, quantisation included.  Every
    * component the destination has (depth > 0) gets the quantiser, rounded down to a power of two (count_power). */
   memset (&plan->dither, 0, sizeof (plan->dither));
+  DitherParams planar_dither;
+  memset (&planar_dither, 0, sizeof (planar_dither));
   if (plan->fout->hi_depth) {
     /* a 10-bit destination always has a dither stage unless the method is none (16-bit lines into 10-bit samples: quantiser 64):
        finalize_deep_out */
@@ -2161,18 +2163,26 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     if (cfg.dither_method != GSTAMD_DITHER_BAYER)
       return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods (verterr, floyd-steinberg, sierra-lite: video-dither.c:75-225) carry "
           "errors from pixel to pixel and line to line; only bayer and none are implemented on the GPU path");
-    if (plan->out_planar)
-      return fail (GSTAMD_ERR_UNSUPPORTED, "dither-quantization > 1 into planar / 3-byte destinations (the stage sits between chroma downsampling "
-          "and packing) is not implemented on the GPU path");
     int shift = 0;
     for (unsigned q = cfg.dither_quantization; q > 1; q >>= 1)
       shift++;
     if (shift > 8)
       shift = 8;
-    plan->dither.on = 1;
-    plan->dither.method = cfg.dither_method;
-    for (int comp = 0; comp < 4; comp++)
-      plan->dither.shift[plan->fout->pos[comp]] = (comp == 0 && !plan->fout->alpha) ? 0 : shift;
+    if (plan->out_planar) {
+      /* planar / semi-planar / 3-byte / packed 4:2:2 destinations: the stage sits between chroma downsampling and packing - it is
+         part of the pack kernel (PackPlanarParams::dither, shift[] in unpack order); none of these formats has an alpha component */
+      planar_dither.on = 1;
+      planar_dither.y0 = plan->rect.out_y;
+      planar_dither.method = cfg.dither_method;
+      planar_dither.shift[0] = 0;
+      planar_dither.shift[1] = planar_dither.shift[2] = planar_dither.shift[3] = shift;
+    } else {
+      plan->dither.on = 1;
+      plan->dither.y0 = plan->rect.out_y;
+      plan->dither.method = cfg.dither_method;
+      for (int comp = 0; comp < 4; comp++)
+        plan->dither.shift[plan->fout->pos[comp]] = (comp == 0 && !plan->fout->alpha) ? 0 : shift;
+    }
   }
 
   const bool unpack_rgb = !plan->fin->yuv, pack_rgb = !plan->fout->yuv;
@@ -2441,6 +2451,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     }
     for (int i = 0; i < 4; i++)
       post.pack_pos[i] = i;
+    pk.dither = planar_dither;
   }
   if (plane_scale) {                   /* raw bytes in, raw bytes out */
     for (int i = 0; i < 4; i++)
@@ -2522,6 +2533,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   }
   if (plan->deep16 || plan->deep_out)
     plan->fast_pair = plan->fast_420p = plan->fast_422 = plan->fast_enc420 = plan->fast_post = false;
+  if (plan->pack.dither.on)             /* the dither stage lives in the pack kernel: the fused kernels that write planes / 3-byte pixels themselves have none */
+    plan->fast_pair = plan->fast_enc420 = false;
 
   std::string d = plan->passes.empty () ? (plan->deep16 ? "convert16" : plan->fast_pair ? "fused_convert_pair" : plan->fast_enc420 ? "fused_encode_420" : plan->fast_422 ? "fused_convert_422" : plan->fast_420p ? "fused_convert_420p" : "fused_convert") : "scale";
   d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;
@@ -2534,7 +2547,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   if (!plan->ref_fastpath.empty ())
     d += "{as " + plan->ref_fastpath + "}";
   if (plan->out_planar)
-    d += std::string ("+pack_planar[h") + std::to_string (plan->pack.down_h) + ",v" + std::to_string (plan->pack.down_v) + "]";
+    d += std::string ("+pack_planar[h") + std::to_string (plan->pack.down_h) + ",v" + std::to_string (plan->pack.down_v) + (plan->pack.dither.on ? ",dither" : "") + "]";
   plan->description = d;
   if (plan->deep_out)
     return finalize_deep_out (in, out, plan, same_matrix, same_primaries, prim_dm, in_matrix, out_matrix, alpha_bits, error);
@@ -2675,7 +2688,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         (g.on && (g.prim.has_matrix || g.to_rgb.kind != MATRIX_NONE || g.to_yuv.kind != MATRIX_NONE || g.alpha_kind == ALPHA_MULT || remap));
     /* the stages after the scalers that write into their input line: chroma downsampling (video_chroma_down_h2 / v2 work on the
      * lines they are given) and the dither stage (do_dither_lines, write_input) */
-    const bool late_in_place = pl.dither.on || (g.on && g.dither16.on) || ((pl.out_planar || fo->kind == UNPACK_PACKED422) && (pl.pack.down_h || pl.pack.down_v)) ||
+    const bool late_in_place = pl.dither.on || pl.pack.dither.on || (g.on && g.dither16.on) || ((pl.out_planar || fo->kind == UNPACK_PACKED422) && (pl.pack.down_h || pl.pack.down_v)) ||
         (g.on && g.pack16 && (g.pack.down_h || g.pack.down_v));
     /* (the colour / alpha stage only shows it when the lines are the destination frame's own rows - a destination in its unpack
      * format, identity_pack :2105, get_dest_line; with temporary lines the repeated row is converted from a fresh copy) */

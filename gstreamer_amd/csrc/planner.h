@@ -89,6 +89,8 @@ struct DitherParams {
   int on;
   int method;
   int shift[4];         // per BYTE of the packed pixel: log2 of the quantiser of the component stored there (0: untouched)
+  int y0;               // row of the destination FRAME the converted rectangle starts at: do_dither_lines hands gst_video_dither_line the
+                        // frame's line number (out_line = i + out_y, video-converter.c:3236, 3390), x counts from the rectangle's left edge
 };
 
 // plane-to-plane form of the 16-bit chain when nothing mixes samples (video_deep.h deep_planes_body)
@@ -118,6 +120,7 @@ struct PackPlanarParams {
   int down_v;           // 0: the even line's chroma as it is, 1: video_orc_chroma_down_v2_u8 over lines (2r, 2r+1)
   int tail_swap;        // 1: the last pixel of an odd-width line stores U and V the other way round - pack_VYUY writes it in UYVY
                         // order (video-format.c:374-380), pack_NV61 in NV16 order (:2005-2011)
+  DitherParams dither;  // chain_dither ahead of the pack (between chroma downsampling and packing): shift[] in unpack order (A, Y, U, V)
 };
 
 enum ScaleKind : int { SCALE_NONE = 0, SCALE_NEAREST = 1, SCALE_2TAP = 2, SCALE_NTAP = 3 };

@@ -1,7 +1,8 @@
 // video_dither.h - the dither stage of GstVideoConverter (chain_dither video-converter.c:2035-2100, do_dither_lines :3155-3175) for
 // 8-bit chains: GST_VIDEO_DITHER_BAYER with GST_VIDEO_DITHER_FLAG_QUANTIZE (video-dither.c dither_ordered_u8_mask :262-270,
 // video_orc_dither_ordered_4u8_mask video-orc.orc:2913-2924): per component  p = c + (bayer[y & 15][x & 15] >> (8 - shift));
-// p &= ~((1 << shift) - 1);  c = min (p, 255)  - x, y counted from the origin of the converted rectangle.
+// p &= ~((1 << shift) - 1);  c = min (p, 255)  - x counted from the left edge of the converted rectangle, y the line of the destination FRAME
+// (DitherParams::y0: do_dither_lines passes out_line = i + out_y).
 // Run as a pass over the packed 4-byte destination (planner.h DitherParams: why that is the same thing).
 #pragma once
 #include <stdint.h>
@@ -67,7 +68,7 @@ GSTAMD_HD uint2 dither_bayer_row8 (int x8, int y)
 
 GSTAMD_HD uint32_t dither_px (const DitherParams &d, uint32_t px, int x, int y)
 {
-  const int b = dither_bayer_value (x, y);
+  const int b = dither_bayer_value (x, y + d.y0);
   uint32_t r = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {

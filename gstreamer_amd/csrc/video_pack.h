@@ -9,6 +9,7 @@
 // lines.  All of it is per-pixel selection of a few neighbours, so one lane produces a 4-pixel-wide block directly.
 #pragma once
 #include "video_device.h"
+#include "video_dither.h"
 
 namespace gstamd {
 
@@ -16,6 +17,20 @@ struct DstPlanes {
   uint8_t *p[3];
   int stride[3];
 };
+
+// chain_dither between the chroma downsampler and the packer (do_dither_lines on the AYUV line, video-converter.c:3155): component k of
+// the pixel at (x, y) of the converted rectangle - for the chroma of a subsampled destination that is the even pixel of the even
+// line, where the downsamplers left their result
+GSTAMD_HD int pack_dither (const DitherParams &d, int k, int v, int x, int y)
+{
+  if (!d.on)
+    return v;
+  const int sh = d.shift[k];
+  const int b = d.method == GSTAMD_DITHER_NONE ? 0 : dither_bayer_value (x, y + d.y0);
+  int p = v + (sh < 8 ? b >> (8 - sh) : b);
+  p &= ~((1 << sh) - 1) & 0xffff;
+  return p > 255 ? 255 : p;
+}
 
 // U | V << 16 of AYUV word px (bytes A, Y, U, V)
 GSTAMD_HD uint32_t ayuv_uv (uint32_t px) { return ((px >> 16) & 0xffu) | ((px >> 24) << 16); }
@@ -32,9 +47,9 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__re
     uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 3 * (size_t) x0;
     for (int i = 0; i < 4 && x0 + i < w; i++) {
       const uint32_t px = row[x0 + i];
-      q[3 * i + pk.pos[1]] = (uint8_t) (px >> 8);
-      q[3 * i + pk.pos[2]] = (uint8_t) (px >> 16);
-      q[3 * i + pk.pos[3]] = (uint8_t) (px >> 24);
+      q[3 * i + pk.pos[1]] = (uint8_t) pack_dither (pk.dither, 1, (int) ((px >> 8) & 0xff), x0 + i, y0);
+      q[3 * i + pk.pos[2]] = (uint8_t) pack_dither (pk.dither, 2, (int) ((px >> 16) & 0xff), x0 + i, y0);
+      q[3 * i + pk.pos[3]] = (uint8_t) pack_dither (pk.dither, 3, (int) (px >> 24), x0 + i, y0);
     }
     return;
   }
@@ -43,7 +58,7 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__re
     const uint32_t *row = (const uint32_t *) (src + (size_t) y0 * sstride);
     uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 2 * (size_t) x0;
     for (int i = 0; i < 4 && x0 + i < w; i++)
-      q[4 * (i >> 1) + pk.pos[1] + 2 * (i & 1)] = (uint8_t) (row[x0 + i] >> 8);
+      q[4 * (i >> 1) + pk.pos[1] + 2 * (i & 1)] = (uint8_t) pack_dither (pk.dither, 1, (int) ((row[x0 + i] >> 8) & 0xff), x0 + i, y0);
   }
   // ---- luma of every line of the block
   for (int r = 0; r < nlines && pk.kind != UNPACK_PACKED422; r++) {
@@ -53,7 +68,7 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__re
     const uint32_t *row = (const uint32_t *) (src + (size_t) y * sstride);
     uint8_t *dy = d.p[0] + (size_t) y * d.stride[0] + x0;
     for (int i = 0; i < 4 && x0 + i < w; i++)
-      dy[i] = (uint8_t) (row[x0 + i] >> 8);
+      dy[i] = (uint8_t) pack_dither (pk.dither, 1, (int) ((row[x0 + i] >> 8) & 0xff), x0 + i, y);
   }
   // ---- chroma of the block's first line (the "chroma line"), vertically averaged with the next one
   const uint32_t *ra = (const uint32_t *) (src + (size_t) y0 * sstride);
@@ -87,7 +102,7 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__re
           c = ((cm + 3u * c0 + 0x00020002u) >> 2) & 0x00ff00ffu;
       }
     }
-    uint8_t cu = (uint8_t) c, cv = (uint8_t) (c >> 16);
+    uint8_t cu = (uint8_t) pack_dither (pk.dither, 2, (int) (c & 0xff), x, y0), cv = (uint8_t) pack_dither (pk.dither, 3, (int) ((c >> 16) & 0xff), x, y0);
     if (pk.tail_swap && x == w - 1) {
       const uint8_t t = cu;
       cu = cv;

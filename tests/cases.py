@@ -545,6 +545,20 @@ VIDEO_CASES = [
     ("gamma16_p010_ayuv64", "P010_10LE", 64, 48, "AYUV64", 64, 48, dict(gamma_mode="remap"), "bt2100-pq>bt709", None, "random"),
     ("gamma16_p010_nv12_720p_to_360p_lanczos", "P010_10LE", 1280, 720, "NV12", 640, 360, dict(gamma_mode="remap", resampler_method="lanczos"), "bt2100-pq>bt709", None, "random"),
     ("gamma16_p016_i420_12_odd", "P016_LE", 45, 32, "I420_12LE", 45, 32, dict(gamma_mode="remap", primaries_mode="fast"), "bt2100-hlg>bt2020", None, "random"),
+    # the dither stage ahead of a planar / semi-planar / 3-byte / packed 4:2:2 pack (round 3: between chroma downsampling and packing, inside
+    # the pack kernel), and its line counter: do_dither_lines passes the destination FRAME's line (out_line = i + out_y)
+    ("dither_nv12_i420_q4", "NV12", 64, 64, "I420", 64, 64, dict(dither_quantization=4), None, None, "random"),
+    ("dither_bgra_nv12_q8_odd", "BGRA", 66, 35, "NV12", 66, 35, dict(dither_quantization=8), None, None, "random"),
+    ("dither_bgra_nv12_q4_no_fused_encode", "BGRA", 64, 48, "NV12", 64, 48, dict(dither_quantization=4), None, None, "random"),
+    ("dither_nv12_rgb_q16_no_pair_kernel", "NV12", 64, 48, "RGB", 64, 48, dict(dither_quantization=16), None, None, "random"),
+    ("dither_bgra_yuy2_q4", "BGRA", 64, 48, "YUY2", 64, 48, dict(dither_quantization=4), None, None, "random"),
+    ("dither_ayuv_y444_q2", "AYUV", 33, 17, "Y444", 33, 17, dict(dither_quantization=2), None, None, "random"),
+    ("dither_nv12_y42b_half_lanczos_q4", "NV12", 128, 96, "Y42B", 64, 48, dict(dither_quantization=4, resampler_method="lanczos"), None, None, "random"),
+    ("dither_p010_nv12_q4_not_plane_copy", "P010_10LE", 64, 48, "NV12", 64, 48, dict(dither_quantization=4), None, None, "random"),
+    ("dither_nv12_i420_gamma_q4", "NV12", 64, 48, "I420", 64, 48, dict(dither_quantization=4, gamma_mode="remap"), "bt709>bt601", None, "random"),
+    ("dither_nv12_bgra_q4_dest_y3_frame_line", "NV12", 64, 48, "BGRA", 70, 54, dict(dither_quantization=4, dest_x=2, dest_y=3, dest_width=64, dest_height=48), None, None, "random"),
+    ("dither_nv12_nv12_q4_dest_y6_frame_line", "NV12", 64, 48, "NV12", 70, 60, dict(dither_quantization=4, dest_x=2, dest_y=6, dest_width=64, dest_height=48), None, None, "random"),
+    ("dither_nv12_rgb_q4_dest_y5_nearest", "NV12", 66, 34, "RGB", 90, 50, dict(dither_quantization=4, dest_x=3, dest_y=5, dest_width=66, dest_height=34, resampler_method="nearest"), None, None, "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd
@@ -555,7 +569,6 @@ VISIBLE_ONLY = {"uyvy_yv12_33x17_fastpath", "uyvy_y444_33x18_fastpath", "uyvy_yu
 # conversions the reference runs through code this library has no kernel for -> must be REFUSED ("not built", never approximated)
 VIDEO_REFUSED = [
     ("NV12", 64, 64, "BGRA", 64, 64, dict(dither_quantization=4, dither_method="floyd-steinberg")),   # error diffusion: sequential
-    ("NV12", 64, 64, "I420", 64, 64, dict(dither_quantization=4)),      # dither between chroma downsampling and pack: not built
     ("BGRA", 67, 36, "AYUV", 76, 21, dict(alpha_mode="mult", alpha_value=0.5)),    # alpha stage on MIN (in_width, out_width) pixels of a wider line
     ("YV12", 11, 21, "Y444_16LE", 85, 12, NEAR),         # nearest vertical scaling of 4:2:0 through the composite plans
     ("NV12", 67, 3, "I420", 67, 3, {}, "bt601", "mpeg2"),           # chroma of the line past an odd-height picture (generic chain)

@@ -460,7 +460,7 @@ static int build_tables (GstAmdVideoConverter *c)
     return GSTAMD_OK;
   }
   if (p.out_planar) {
-    if ((e = hipMalloc ((void **) &c->pk_img, (size_t) p.out_info.width * 4 * p.out_info.height)) != hipSuccess)
+    if ((e = hipMalloc ((void **) &c->pk_img, (size_t) p.out_info.width * 4 * (p.out_info.height + 1))) != hipSuccess)      /* + the line past the picture */
       return hip_fail (e, "hipMalloc(pack image)");
   }
   c->tables_ready = true;
@@ -979,7 +979,7 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
       e = launch_swizzle4 (p.front, pl, p.post.pack_pos, dst, dstride, stream);
       return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_swizzle4");
     }
-    e = launch_convert (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, stream);
+    e = launch_convert (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, stream, p.out_planar && dst == c->pk_img ? p.pack.virtual_line : 0);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert");
   }
   /* downscale: scale, then matrix+alpha in the post stage; upscale: matrix+alpha first */

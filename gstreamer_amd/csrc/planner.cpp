@@ -1097,12 +1097,14 @@ struct Sim {
 };
 }  // namespace
 
-static void simulate_vpairs (VideoPlan *plan, int out_height)
+/* extra: the chain is also asked for the line PAST the picture (the vertical chroma downsampler's last pair of an odd-height 4:2:0
+ * destination, do_downsample_lines :3192): one more table entry, for source line H */
+static void simulate_vpairs (VideoPlan *plan, int out_height, bool extra = false)
 {
-  const int H = plan->front.height;
-  plan->vpair.assign ((size_t) H * 2, 0);
-  for (int y = 0; y < H; y++) {
-    int r = y >> plan->front.h_sub;
+  const int H = plan->front.height, HT = H + (extra ? 1 : 0);
+  plan->vpair.assign ((size_t) HT * 2, 0);
+  for (int y = 0; y < HT; y++) {
+    int r = (y < H ? y : H - 1) >> plan->front.h_sub;
     plan->vpair[2 * y] = r;
     plan->vpair[2 * y + 1] = r;
   }
@@ -1110,7 +1112,7 @@ static void simulate_vpairs (VideoPlan *plan, int out_height)
     return;
   Sim sim;
   sim.vpair = &plan->vpair;
-  sim.in_height = H;
+  sim.in_height = HT;
   sim.line_lo = -plan->rect.in_y;
   sim.line_hi = plan->rect.in_maxh - 1 - plan->rect.in_y;
   sim.h_sub = plan->front.h_sub;
@@ -1138,6 +1140,8 @@ static void simulate_vpairs (VideoPlan *plan, int out_height)
   /* convert_generic_task: one thread, lines 0 .. out_height-1, one at a time */
   for (int i = 0; i < out_height; i++)
     sim.get_lines (prev, i, i, 1);
+  if (extra)
+    sim.get_lines (prev, out_height, out_height, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2304,6 +2308,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   fr.chroma_v2 = 0;
   fr.swap_k = in->format == GSTAMD_VIDEO_FORMAT_VYUY && (in->width & 1) ? (in->width - 1) >> 1 : -1;
   fr.hi_depth = plan->fin->hi_depth;
+  fr.luma_last = (plan->rect.in_maxh ? plan->rect.in_maxh : in->height) - 1 - plan->rect.in_y;
   /* video_converter_compute_resample (:2850-2895) + gst_video_chroma_resample_new (video-chroma.c:1041-1109) */
   if (cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY
       && plan->fin->yuv) {
@@ -2460,7 +2465,13 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     plan->matrix_before_scale = false;
   }
 
-  simulate_vpairs (plan, out_h);
+  /* an odd-height 4:2:0 destination fed by the vertical chroma upsampler at the same size: video_orc_chroma_down_v2 averages the last
+     line with the line PAST the picture, which the chain makes like any other - do_unpack_lines clamps it to the last line (:2966), the
+     upsampler pairs it with the (clamped) line after it - so its chroma is the last chroma row unblended.  The AYUV image gets that line
+     as one more row (k_convert's grid is one row taller), the pack kernel reads it (PackPlanarParams::virtual_line). */
+  plan->pack.virtual_line = plan->out_planar && plan->passes.empty () && fr.chroma_v2 && plan->pack.down_v && plan->pack.h_sub == 1 && (out_h & 1) &&
+      in_h == out_h && !plan->deep16 && !plan->deep_out ? 1 : 0;
+  simulate_vpairs (plan, out_h, plan->pack.virtual_line != 0);
 
   plan->algorithmic_bytes = 0;
   {
@@ -2733,6 +2744,19 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * last line with a line past the picture, which its upsampler makes from the clamped last rows (do_unpack_lines clamps :2966); the
    * composite's sub-conversions end at the last line - and the direct plans' pair table has no entry for that line either */
   const bool both_v = !pl.gamma.on && pl.front.chroma_v2 && pl.out_planar && pl.pack.down_v;       /* direct plans: both vertical chroma resamplers run */
+  bool has_vpass = false;
+  for (const ScalePass &sp : pl.passes)
+    has_vpass = has_vpass || !sp.horizontal;
+  if (chain && both_v && has_vpass && fi->h_sub == 1 && fo->h_sub == 1 && (oh & 1)) {
+    /* with a vertical scaler in the chain the line past the picture is the scaler's last line once more (do_vscale_lines clamps the
+       output line, :3074) - but it asks its window from the chroma upsampler a second time, lines that cache has already let go are
+       unpacked and paired anew, and what comes back differs from what the last line was made of (luma included): the reference's
+       last line pair depends on which lines happened to survive.  Here the last pair is (last line, last line). */
+    plan->divergence += "4:2:0 -> 4:2:0 of odd height with a vertical scaler between the chroma resamplers: the reference asks the scaler for the line past the "
+        "picture, whose window is unpacked and paired anew (line aliasing); this library pairs the last line with itself. ";
+  } else if (chain && both_v && pl.pack.virtual_line) {
+    /* same size: the line past the picture is made and used (PackPlanarParams::virtual_line) */
+  } else
   if (chain && ((pl.gamma.on && !pl.gamma.planes_fast) || both_v) && fi->h_sub == 1 && fo->h_sub == 1 && (oh & 1)) {
     if (error)
       *error = "4:2:0 -> 4:2:0 of odd height through the generic chain (chroma of the line past the picture) is not implemented";

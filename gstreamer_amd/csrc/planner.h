@@ -78,6 +78,8 @@ struct FrontParams {    // unpack + chroma upsample of the source frame (functio
   int swap_k;           // chroma sample whose U and V trade places, -1: none.  unpack_VYUY (video-format.c:346-352) reads the last
                         // pixel of an odd-width line in UYVY order
   int hi_depth;         // FormatDesc::hi_depth: samples are 16-bit words widened to 16 significant bits (v << 6 | v >> 4, or v | v >> 10)
+  int luma_last;        // last luma row the unpacker can deliver, relative to the crop origin (do_unpack_lines clamps to the FRAME, :2966): only a
+                        // line past the picture (PackPlanarParams::virtual_line) ever reaches it
 };
 
 // the 16-bit chain (unpack to AYUV64 -> chroma upsample on u16 -> video_converter_matrix16 -> video_orc_convert_u16_to_u8):
@@ -120,6 +122,8 @@ struct PackPlanarParams {
   int down_v;           // 0: the even line's chroma as it is, 1: video_orc_chroma_down_v2_u8 over lines (2r, 2r+1)
   int tail_swap;        // 1: the last pixel of an odd-width line stores U and V the other way round - pack_VYUY writes it in UYVY
                         // order (video-format.c:374-380), pack_NV61 in NV16 order (:2005-2011)
+  int virtual_line;     // 1: row `height` of the AYUV image holds the line past an odd-height picture as the chain delivers it (unpack clamped to the
+                        // last line, chroma upsampler pairing it anew) - the last 4:2:0 chroma row averages the last line with THAT line
   DitherParams dither;  // chain_dither ahead of the pack (between chroma downsampling and packing): shift[] in unpack order (A, Y, U, V)
 };
 

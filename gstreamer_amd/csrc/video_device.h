@@ -170,8 +170,9 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
     const uint8_t *q = pl.p[0] + (size_t) y * pl.stride[0] + 3 * (size_t) x;
     return 0xffu | ((uint32_t) q[f.pos[1]] << 8) | ((uint32_t) q[f.pos[2]] << 16) | ((uint32_t) q[f.pos[3]] << 24);
   }
-  const int Y = f.kind == UNPACK_PACKED422 ? pl.p[0][(size_t) y * pl.stride[0] + 4 * (size_t) (x >> 1) + f.pos[1] + 2 * (x & 1)]
-      : pl.p[0][(size_t) y * pl.stride[0] + x];
+  const int yl = y < f.luma_last ? y : f.luma_last;          /* a no-op for the picture's own lines; the line past it clamps like do_unpack_lines */
+  const int Y = f.kind == UNPACK_PACKED422 ? pl.p[0][(size_t) yl * pl.stride[0] + 4 * (size_t) (x >> 1) + f.pos[1] + 2 * (x & 1)]
+      : pl.p[0][(size_t) yl * pl.stride[0] + x];
   UV c;
   if (f.chroma_v2) {
     const int e0 = vpair[2 * y], rb = vpair[2 * y + 1];
@@ -341,7 +342,7 @@ template <int CH>
 GSTAMD_HD void front_span8 (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint32_t *out)
 {
   const int w = f.width;
-  const uint2 yy = *(const uint2 *) (pl.p[0] + (size_t) y * pl.stride[0] + x0);
+  const uint2 yy = *(const uint2 *) (pl.p[0] + (size_t) (y < f.luma_last ? y : f.luma_last) * pl.stride[0] + x0);
   const int cw = (w + 1) >> 1, k0 = x0 >> 1;
   int ra, rb, role = 0;
   if (f.chroma_v2) {

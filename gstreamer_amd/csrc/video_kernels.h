@@ -15,7 +15,7 @@
 namespace gstamd {
 
 hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color,
-    const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream);
+    const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream, int extra_rows = 0);
 
 // 4-byte packed -> 4-byte packed, no matrix, no alpha operation: the copy-shaped permutation kernel
 bool swizzle4_usable (const FrontParams &f, const Planes &pl, const ColorParams &color, const uint8_t *dst, int dstride);

@@ -615,7 +615,7 @@ hipError_t launch_swizzle4 (const FrontParams &f, const Planes &pl, const int pa
 }
 
 hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color,
-    const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream)
+    const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream, int extra_rows)
 {
   const int spans = (f.width + K1_PX - 1) / K1_PX;
   int vec_ok = aligned (dst, 16) && (dstride % 16) == 0 && kind_has_planes (f.kind) && f.w_sub == 1;
@@ -629,7 +629,7 @@ hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vp
   if (f.kind == UNPACK_PACKED4 && aligned (dst, 16) && (dstride % 16) == 0 && aligned (pl.p[0], 16) && (pl.stride[0] % 16) == 0)
     vec_ok = 2;                         /* convert_body's 16-byte path for 4-byte packed sources */
   const int bx = spans >= 256 ? 256 : (spans > 64 ? 128 : 64);
-  dim3 grid ((spans + bx - 1) / bx, f.height), block (bx);
+  dim3 grid ((spans + bx - 1) / bx, f.height + extra_rows), block (bx);       /* extra_rows: the line past the picture (PackPlanarParams::virtual_line) */
   switch (f.chroma_h) {
     case CHROMA_H_H2_CS:
       hipLaunchKernelGGL (k_convert<CHROMA_H_H2_CS>, grid, block, 0, stream, f, pl, vpair_dev, color, pack_pos[0],

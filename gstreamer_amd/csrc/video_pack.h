@@ -72,7 +72,7 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__re
   }
   // ---- chroma of the block's first line (the "chroma line"), vertically averaged with the next one
   const uint32_t *ra = (const uint32_t *) (src + (size_t) y0 * sstride);
-  const uint32_t *rb = (const uint32_t *) (src + (size_t) (y0 + 1 < h ? y0 + 1 : h - 1) * sstride);
+  const uint32_t *rb = (const uint32_t *) (src + (size_t) (y0 + 1 < h ? y0 + 1 : (pk.virtual_line ? h : h - 1)) * sstride);
   uint32_t v[6];                            // packed {U, V} of pixels x0-1 .. x0+4, clamped into the row
   for (int i = 0; i < 6; i++) {
     int x = x0 - 1 + i;

@@ -559,6 +559,11 @@ VIDEO_CASES = [
     ("dither_nv12_bgra_q4_dest_y3_frame_line", "NV12", 64, 48, "BGRA", 70, 54, dict(dither_quantization=4, dest_x=2, dest_y=3, dest_width=64, dest_height=48), None, None, "random"),
     ("dither_nv12_nv12_q4_dest_y6_frame_line", "NV12", 64, 48, "NV12", 70, 60, dict(dither_quantization=4, dest_x=2, dest_y=6, dest_width=64, dest_height=48), None, None, "random"),
     ("dither_nv12_rgb_q4_dest_y5_nearest", "NV12", 66, 34, "RGB", 90, 50, dict(dither_quantization=4, dest_x=3, dest_y=5, dest_width=66, dest_height=34, resampler_method="nearest"), None, None, "random"),
+    # odd-height 4:2:0 -> 4:2:0 through the generic chain at the same size (round 3): the vertical chroma downsampler's last pair is (last line,
+    # the line PAST the picture), which the chain makes from the clamped last source line with a chroma pairing of its own
+    ("nv12_i420_67x3_line_past_picture", "NV12", 67, 3, "I420", 67, 3, {}, "bt601", "mpeg2", "random"),
+    ("i420_nv21_45x31_bt601_bt709_line_past_picture", "I420", 45, 31, "NV21", 45, 31, {}, "bt601>bt709", None, "random"),
+    ("nv21_yv12_64x47_cosited_dither_line_past_picture", "NV21", 64, 47, "YV12", 64, 47, dict(dither_quantization=4), "bt709>bt601", "cosited", "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd
@@ -571,7 +576,6 @@ VIDEO_REFUSED = [
     ("NV12", 64, 64, "BGRA", 64, 64, dict(dither_quantization=4, dither_method="floyd-steinberg")),   # error diffusion: sequential
     ("BGRA", 67, 36, "AYUV", 76, 21, dict(alpha_mode="mult", alpha_value=0.5)),    # alpha stage on MIN (in_width, out_width) pixels of a wider line
     ("YV12", 11, 21, "Y444_16LE", 85, 12, NEAR),         # nearest vertical scaling of 4:2:0 through the composite plans
-    ("NV12", 67, 3, "I420", 67, 3, {}, "bt601", "mpeg2"),           # chroma of the line past an odd-height picture (generic chain)
     ("P010_10LE", 31, 13, "NV12", 23, 13, {}),           # the same through the composite plans
 ]
 
@@ -602,6 +606,10 @@ VIDEO_DEFINED = [
      [("RGBx", 28, 1, "RGBx", 55, 47, {}), ("RGBx", 55, 47, "BGRx", 55, 47, dict(dither_quantization=2))], None),
     ("ub_vnear_chroma_down", ("IYU2", 11, 3, "Y42B", 15, 39, NEAR),                  # ... ahead of the chroma downsampler
      [("IYU2", 11, 3, "IYU2", 15, 39, NEAR), ("IYU2", 15, 39, "Y42B", 15, 39, {})], None),
+    ("ub_odd_420_shrink_lanczos", ("NV12", 30, 22, "YV12", 38, 15, LAN),            # odd-height 4:2:0 -> 4:2:0 with a vertical scaler: the line past the picture
+     [("NV12", 30, 22, "AYUV", 30, 22, {}), ("AYUV", 30, 22, "VUYA", 38, 15, LAN), ("VUYA", 38, 15, "YV12", 38, 15, {})], None),
+    ("ub_odd_420_shrink_bilinear", ("NV12", 18, 40, "I420", 18, 19, dict(resampler_method="linear")),
+     [("NV12", 18, 40, "AYUV", 18, 40, {}), ("AYUV", 18, 40, "VUYA", 18, 19, dict(resampler_method="linear")), ("VUYA", 18, 19, "I420", 18, 19, {})], None),
     ("ub_vyuy_unaligned_rows", ("VYUY", 59, 11, "AYUV", 59, 11, {}),                # unpack_VYUY's fallback loop (video-format.c:337-352)
      [("VYUY", 59, 11, "AYUV", 59, 11, {})], "vyuy"),
 ]

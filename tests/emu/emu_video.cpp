@@ -693,6 +693,7 @@ extern "C" int emu_h420_runs (void) { return g_h420_runs; }
 extern "C" int emu_h420_reg_runs (void) { return g_h420_reg_runs; }
 
 static int g_swizzle4_runs = 0;
+static int g_extra_rows = 0;          /* the AYUV image of a planar destination is being rendered with the line past the picture */
 extern "C" int emu_swizzle4_runs (void) { return g_swizzle4_runs; }
 
 /* gstamd_video_converter_divergence of the last top-level emu_video_convert (the plan's note + those of its sub-conversions) */
@@ -980,8 +981,10 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     return GSTAMD_OK;
   }
   if (p.out_planar) {                     /* chain -> AYUV image, then the pack kernel body over its grid */
-    std::vector<uint8_t> img ((size_t) p.out_info.width * 4 * p.out_info.height);
+    std::vector<uint8_t> img ((size_t) p.out_info.width * 4 * (p.out_info.height + 1));          /* + the line past the picture */
+    g_extra_rows = p.pack.virtual_line;
     r = emu_convert_packed (p, in, pl, img.data (), p.out_info.width * 4, vec_ok, false);
+    g_extra_rows = 0;
     if (r != GSTAMD_OK)
       return r;
     DstPlanes d;
@@ -1181,7 +1184,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
   }
   if (p.passes.empty ()) {
     const int spans = (p.front.width + K1_PX - 1) / K1_PX;
-    for (int y = 0; y < p.front.height; y++)
+    for (int y = 0; y < p.front.height + g_extra_rows; y++)         /* launch_convert's extra_rows */
       for (int s = 0; s < spans; s++) {
         const int *pp = p.post.pack_pos;
         switch (p.front.chroma_h) {

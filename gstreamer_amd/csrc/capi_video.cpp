@@ -626,6 +626,8 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
     const int ds = dest_stride ? dest_stride[0] : p.out_info.stride[0];
     e = hipMemcpy2DAsync (dest_planes[0], (size_t) ds, cur.p, (size_t) cur.stride, (size_t) out_w * 8, (size_t) out_h, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess && g.dither16.on)
+      e = launch_dither16_image (g.dither16, (uint8_t *) dest_planes[0], ds, out_w, out_h, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "copy of the 16-bit image");
   }
   if (g.pack16) {

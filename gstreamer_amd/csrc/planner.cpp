@@ -1453,7 +1453,7 @@ static void fill_pack_params (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
 static void setup_dither16 (const GstAmdVideoConverterConfig &cfg, const FormatDesc *fo, DitherParams *d)
 {
   memset (d, 0, sizeof (*d));
-  if (cfg.dither_method == GSTAMD_DITHER_NONE || fo->hi_depth == 3)
+  if (cfg.dither_method == GSTAMD_DITHER_NONE)
     return;
   const int depth = hi_depth_bits (fo->hi_depth);
   unsigned q = 1u << (16 - depth);
@@ -1464,7 +1464,9 @@ static void setup_dither16 (const GstAmdVideoConverterConfig &cfg, const FormatD
     shift++;
   d->on = shift > 0;
   d->method = cfg.dither_method;
-  d->shift[0] = 0;              /* no alpha component in the destination: quantiser 0 */
+  /* the planar formats have no alpha component (depth 0: quantiser 0); ARGB64 / AYUV64 carry 16 bits of it like the other three - their own
+     quantiser is 1, so a stage only exists for dither-quantization > 1, run as a pass over the finished frame (k_dither16_image) */
+  d->shift[0] = fo->hi_depth == 3 ? shift : 0;
   d->shift[1] = d->shift[2] = d->shift[3] = shift;
 }
 
@@ -1485,8 +1487,6 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destination layout not implemented on the GPU path");
   if (out16 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
     return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path");
-  if (fo->hi_depth == 3 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_quantization > 1)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "dither-quantization > 1 into a 16-bit destination is not implemented on the GPU path");
   /* a 10 / 12 / 16-bit planar SOURCE: the 16-bit front (unpack + chroma upsampler, k_front16) of the conversion into an AYUV64 frame of
    * the same size - planned like any other conversion, its front / pair table taken over */
   FrontParams front16;
@@ -1685,10 +1685,10 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
           g.to_yuv16.im[i][j] = (int) rint (dm[i][j]);
     }
   }
-  if (g.pack16) {
+  if (g.pack16)
     fill_pack_params (in, out, fi, fo, cfg, full_in_w, full_in_h, full_out_w, full_out_h, &g.pack);
+  if (out16)
     setup_dither16 (cfg, fo, &g.dither16);
-  }
   /* chain_convert_to_YUV (:1955-2015): identity / (1 << 8), then the matrix to Y'CbCr and the output range */
   if (!pack_rgb && !out16) {
     M44 dm;
@@ -1825,8 +1825,6 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     return fail (GSTAMD_ERR_UNSUPPORTED, "a destination rectangle / borders inside a 16-bit frame are not implemented on the GPU path");
   if (fo->hi_depth && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
     return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path");
-  if (fo->hi_depth == 3 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_quantization > 1)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "dither-quantization > 1 into a 16-bit destination is not implemented on the GPU path");
   g.on = true;
   g.src64 = true;
   g.src16 = false;
@@ -1919,18 +1917,9 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     if (g.pack16) {
       fill_pack_params (in, out, fi, fo, cfg, in_w, in_h, full_out_w, full_out_h, &g.pack);
       g.pack_hi_depth = fo->hi_depth;
-      if (cfg.dither_method != GSTAMD_DITHER_NONE) {
-        unsigned q = 1u << (16 - hi_depth_bits (fo->hi_depth));     /* chain_dither :2035-2085: 1 << (current_bits - depth) */
-        if (cfg.dither_quantization > q)
-          q = cfg.dither_quantization;
-        int shift = 0;
-        for (unsigned v = q; v > 1; v >>= 1)
-          shift++;
-        g.dither16.on = shift > 0;
-        g.dither16.method = cfg.dither_method;
-        g.dither16.shift[1] = g.dither16.shift[2] = g.dither16.shift[3] = shift;
-      }
     }
+    if (!plane_scale)
+      setup_dither16 (cfg, fo, &g.dither16);          /* chain_dither :2035-2085 (the plane-scaling fastpath has no chain) */
   }
   plan->algorithmic_bytes = picture_bytes (fi, in_w, in_h) + picture_bytes (fo, out_w, out_h);
   plan->description = std::string ("deep64[") + fi->name + "->" + fo->name + (g.prim.has_matrix ? ",matrix16" : "") +
@@ -1956,11 +1945,6 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   g.store64 = fo->hi_depth == 3;
   g.pack16 = !g.store64;
   g.src16 = fi->hi_depth != 0;
-  if (g.store64 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_quantization > 1) {
-    if (error)
-      *error = "dither-quantization > 1 into a 16-bit destination is not implemented on the GPU path";
-    return GSTAMD_ERR_UNSUPPORTED;
-  }
   g.pack = plan->pack;
   g.pack_hi_depth = fo->hi_depth;
   const int in_w = in->width, in_h = in->height, out_w = out->width, out_h = out->height;
@@ -1984,20 +1968,7 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   g.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
   g.alpha_value = (unsigned) (int) (255 * cfg.alpha_value);
   /* chain_dither (:2035-2085) on 16-bit lines: quantiser 1 << (16 - depth), or the target quantiser when that is coarser */
-  memset (&g.dither16, 0, sizeof (g.dither16));
-  if (cfg.dither_method != GSTAMD_DITHER_NONE && !g.store64) {
-    const int depth = hi_depth_bits (fo->hi_depth);
-    unsigned q = 1u << (16 - depth);
-    if (cfg.dither_quantization > q)
-      q = cfg.dither_quantization;
-    int shift = 0;
-    for (unsigned v = q; v > 1; v >>= 1)
-      shift++;
-    g.dither16.on = shift > 0;
-    g.dither16.method = cfg.dither_method;
-    g.dither16.shift[0] = 0;            /* no alpha component in the destination: quantiser 0 */
-    g.dither16.shift[1] = g.dither16.shift[2] = g.dither16.shift[3] = shift;
-  }
+  setup_dither16 (cfg, fo, &g.dither16);
   g.dec.clear ();
   g.enc.clear ();
   video_info_set_format (&g.mid_out, fo->yuv ? GSTAMD_VIDEO_FORMAT_AYUV : GSTAMD_VIDEO_FORMAT_ARGB, out_w, out_h);      /* dimensions only */

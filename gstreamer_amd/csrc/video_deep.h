@@ -238,6 +238,19 @@ GSTAMD_HD int dither16_comp (const DitherParams &d, int comp, int v, int x, int 
   return p & ~((1 << sh) - 1) & 0xffff;                 /* andnw */
 }
 
+// the dither stage ahead of pack_ARGB64 / pack_AYUV64 (copies): every component of pixel (x, y) of a finished 16-bit frame, in place
+GSTAMD_HD void dither16_image_px (const DitherParams &d, uint8_t *img, int stride, int w, int h, int x, int y)
+{
+  if (x >= w || y >= h)
+    return;
+  uint2 *p = (uint2 *) (img + (size_t) y * stride + 8 * (size_t) x);
+  const uint2 v = *p;
+  uint2 o;
+  o.x = (uint32_t) dither16_comp (d, 0, (int) (v.x & 0xffffu), x, y) | ((uint32_t) dither16_comp (d, 1, (int) (v.x >> 16), x, y) << 16);
+  o.y = (uint32_t) dither16_comp (d, 2, (int) (v.y & 0xffffu), x, y) | ((uint32_t) dither16_comp (d, 3, (int) (v.y >> 16), x, y) << 16);
+  *p = o;
+}
+
 // the same with the matrix value already at hand
 GSTAMD_HD int dither16_with (const DitherParams &d, int comp, int v, int b)
 {

@@ -31,6 +31,7 @@ hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const Dither
     const int strides[3], hipStream_t stream);
 hipError_t launch_gamma_stage (const GammaDev &g, int mask, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int w, int h, hipStream_t stream);
 hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream);
+hipError_t launch_dither16_image (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream);
 struct Deep16Image;
 hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, uint8_t *img, int istride, hipStream_t stream);
 // d / post non-NULL: the last pass, fused with matrix16 + narrowing + alpha + pack into the 4-byte destination

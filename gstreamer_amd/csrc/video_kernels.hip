@@ -128,6 +128,18 @@ hipError_t launch_gamma_stage (const GammaDev &g, int mask, const uint8_t *src, 
   return hipGetLastError ();
 }
 
+// dither-quantization > 1 into an ARGB64 / AYUV64 frame: the stage ahead of the (copying) packer as a pass over the finished frame
+__global__ __launch_bounds__ (256) void k_dither16_image (DitherParams d, uint8_t *img, int stride, int w, int h)
+{
+  dither16_image_px (d, img, stride, w, h, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+hipError_t launch_dither16_image (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream)
+{
+  hipLaunchKernelGGL (k_dither16_image, dim3 ((w + 255) / 256, h), dim3 (256), 0, stream, d, img, stride, w, h);
+  return hipGetLastError ();
+}
+
 // plane to plane between 8- and 10-bit planar formats (video_deep.h deep_planes_body): grid.y = luma rows, then chroma rows
 __global__ __launch_bounds__ (256) void k_deep_planes (DeepPlanesParams d, DeepPlanesPtrs pp)
 {

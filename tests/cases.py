@@ -564,6 +564,12 @@ VIDEO_CASES = [
     ("nv12_i420_67x3_line_past_picture", "NV12", 67, 3, "I420", 67, 3, {}, "bt601", "mpeg2", "random"),
     ("i420_nv21_45x31_bt601_bt709_line_past_picture", "I420", 45, 31, "NV21", 45, 31, {}, "bt601>bt709", None, "random"),
     ("nv21_yv12_64x47_cosited_dither_line_past_picture", "NV21", 64, 47, "YV12", 64, 47, dict(dither_quantization=4), "bt709>bt601", "cosited", "random"),
+    # dither-quantization > 1 into ARGB64 / AYUV64 (round 3): the stage ahead of the copying packer, alpha included (depth 16 like the rest)
+    ("dither64_vuya_ayuv64_shrink_q2", "VUYA", 33, 40, "AYUV64", 8, 18, dict(dither_quantization=2), None, None, "random"),
+    ("dither64_bgra_argb64_q16", "BGRA", 64, 48, "ARGB64", 64, 48, dict(dither_quantization=16), None, None, "random"),
+    ("dither64_p010_ayuv64_q512", "P010_10LE", 64, 48, "AYUV64", 64, 48, dict(dither_quantization=512), None, None, "random"),
+    ("dither64_ayuv64_argb64_mixed_q8", "AYUV64", 40, 30, "ARGB64", 60, 20, dict(dither_quantization=8), None, None, "random"),
+    ("dither64_nv12_argb64_gamma_q4", "NV12", 64, 48, "ARGB64", 64, 48, dict(dither_quantization=4, gamma_mode="remap"), "bt709>1:0:8:1", None, "random"),
 ]
 
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd

@@ -861,6 +861,10 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     if (g.store64) {
       for (int y = 0; y < out_h; y++)
         memcpy (dst + out->offset[0] + (size_t) y * out->stride[0], cur.p + (size_t) y * cur.stride, (size_t) out_w * 8);
+      if (g.dither16.on)                /* k_dither16_image over the finished frame */
+        for (int y = 0; y < out_h; y++)
+          for (int x = 0; x < out_w; x++)
+            dither16_image_px (g.dither16, dst + out->offset[0], out->stride[0], out_w, out_h, x, y);
       return GSTAMD_OK;
     }
     if (g.pack16) {

@@ -126,7 +126,8 @@ class VideoWorkload:
         from oracle import ref
         if not ref.available():
             return None
-        n = {"c2": 40, "c1": 150, "c3": 12, "c5": 20}.get(self.name, 10)
+        # at least 100 frames or 5 s of the reference's work on one core (C3 / C5 run 4-8 frames/s: the 5 s rule)
+        n = {"c2": 100, "c1": 400, "c3": 24, "c5": 40}.get(self.name, 10)
         src = cases.frame_bytes(ref.video_info(self.ifmt, self.w, self.h)["size"], "random", 1)
 
         def conv(threads):
@@ -209,7 +210,7 @@ class CompositorWorkload:
             return None
         pad_np = cases.frame_bytes(self.PW * self.PH * 4, "random", 31)
         canvas = np.zeros(self.DW * self.DH * 4, np.uint8)
-        n_frames = 6
+        n_frames = 40             # 7.4 frames/s on one core: >= 5 s of the reference
         t0 = time.perf_counter()
         for _ in range(n_frames):
             ref.compositor_fill(0, "bgra", "BGRA", canvas, self.DW, self.DH, 0, self.DH)
@@ -290,7 +291,7 @@ class CompositorScaledWorkload(CompositorWorkload):
         pad_np = cases.frame_bytes(self.PW * self.PH * 4, "random", 31)
         canvas = np.zeros(self.DW * self.DH * 4, np.uint8)
         rc = ref.VideoConverter("BGRA", self.PW, self.PH, "BGRA", self.SW, self.SH)
-        n_frames = 3
+        n_frames = 18            # 3.4 frames/s on one core: >= 5 s
         t0 = time.perf_counter()
         for _ in range(n_frames):
             ref.compositor_fill(0, "bgra", "BGRA", canvas, self.DW, self.DH, 0, self.DH)

@@ -18,6 +18,27 @@ gst_amd_hip_select_device (gint device_id)
     gstamd_set_device (device_id);
 }
 
+/* the allocator's own transfer stream, one per device: CPU maps of HBM buffers copy on it and wait for IT alone - the NULL stream
+ * would order the copy against (and its synchronisation wait for) every blocking stream of the process */
+#define AMD_XFER_DEVICES 16
+static GMutex xfer_lock;
+static gpointer xfer_streams[AMD_XFER_DEVICES];
+
+static gpointer
+amd_hip_xfer_stream (gint device_id)
+{
+  gint d = device_id >= 0 ? device_id : gstamd_get_device ();
+  gpointer st;
+  if (d < 0 || d >= AMD_XFER_DEVICES)
+    return NULL;                /* the NULL stream still works, only less politely */
+  g_mutex_lock (&xfer_lock);
+  if (!xfer_streams[d])
+    xfer_streams[d] = gstamd_stream_new ();
+  st = xfer_streams[d];
+  g_mutex_unlock (&xfer_lock);
+  return st;
+}
+
 /* ---- tickets ----------------------------------------------------------------------------------------------------------- */
 static GMutex ticket_lock;
 static GSList *free_events = NULL;      /* recycled gstamd events (creating one costs more than recording it) */
@@ -210,7 +231,7 @@ amd_hip_map_full (GstMemory * mem, GstMapInfo * info, gsize maxsize)
      * would clobber the bytes the caller did not write */
     if (!m->host_valid) {
       host_wait (m, FALSE);
-      if (gstamd_device_download (m->host_staging, m->device_ptr, mem->maxsize, NULL) != GSTAMD_OK) {
+      if (gstamd_device_download (m->host_staging, m->device_ptr, mem->maxsize, amd_hip_xfer_stream (m->device_id)) != GSTAMD_OK) {
         g_mutex_unlock (&m->lock);
         return NULL;
       }
@@ -233,8 +254,11 @@ amd_hip_unmap_full (GstMemory * mem, GstMapInfo * info)
   if (!(info->flags & GST_MAP_AMDHIP) && (info->flags & GST_MAP_WRITE) && m->device_dirty_from_host) {
     gst_amd_hip_select_device (m->device_id);
     host_wait (m, TRUE);                /* kernels still reading the old contents */
-    gstamd_device_upload (m->device_ptr, m->host_staging, mem->maxsize, NULL);
-    gstamd_stream_synchronize (NULL);
+    {
+      gpointer xs = amd_hip_xfer_stream (m->device_id);
+      gstamd_device_upload (m->device_ptr, m->host_staging, mem->maxsize, xs);
+      gstamd_stream_synchronize (xs);     /* this stream only: other pipelines' streams keep running */
+    }
     m->device_dirty_from_host = FALSE;
     m->host_valid = TRUE;
   }

@@ -82,6 +82,7 @@ typedef struct {
   gint alpha_mode, chroma_mode, matrix_mode, gamma_mode, primaries_mode;
   gdouble alpha_value, envelope, sharpness, sharpen;
   guint dither_quantization;
+  gint chroma_resampler;       /* chroma-resampler (:137, :345): GstVideoResamplerMethod for the chroma planes of the plane scaler, default linear */
   gint dither;                 /* dither (:329): GstVideoDitherMethod, default bayer; only matters with dither-quantization > 1 here */
   GstStructure *converter_config;      /* converter-config (:378): when set, the ONLY options the converter gets (:962-967) */
   gboolean add_borders;        /* add-borders (:312): letterbox / pillarbox instead of stretching when the DAR changes */
@@ -115,7 +116,7 @@ typedef struct {
 
 enum { PROP_0, PROP_METHOD, PROP_ADD_BORDERS, PROP_N_THREADS, PROP_ALPHA_MODE, PROP_ALPHA_VALUE, PROP_CHROMA_MODE, PROP_MATRIX_MODE,
   PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION, PROP_DEVICE_ID, PROP_HIP_STREAMS, PROP_CONVERTER_CONFIG, PROP_DITHER,
-  PROP_GAMMA_MODE, PROP_PRIMARIES_MODE };
+  PROP_GAMMA_MODE, PROP_PRIMARIES_MODE, PROP_CHROMA_RESAMPLER };
 
 G_DEFINE_TYPE (GstAmdVideoConvertScale, gst_amd_vcs, GST_TYPE_BASE_TRANSFORM);
 #define AMD_VCS(o) ((GstAmdVideoConvertScale *) (o))
@@ -142,6 +143,7 @@ amd_vcs_set_property (GObject * object, guint id, const GValue * value, GParamSp
     case PROP_SHARPEN: s->sharpen = g_value_get_double (value); break;
     case PROP_DITHER_QUANTIZATION: s->dither_quantization = g_value_get_uint (value); break;
     case PROP_DITHER: s->dither = g_value_get_enum (value); break;
+    case PROP_CHROMA_RESAMPLER: s->chroma_resampler = g_value_get_enum (value); break;
     case PROP_DEVICE_ID: s->device_id = g_value_get_int (value); break;
     case PROP_HIP_STREAMS: s->hip_streams = g_value_get_uint (value); break;
     case PROP_CONVERTER_CONFIG:
@@ -179,6 +181,7 @@ amd_vcs_get_property (GObject * object, guint id, GValue * value, GParamSpec * p
     case PROP_SHARPEN: g_value_set_double (value, s->sharpen); break;
     case PROP_DITHER_QUANTIZATION: g_value_set_uint (value, s->dither_quantization); break;
     case PROP_DITHER: g_value_set_enum (value, s->dither); break;
+    case PROP_CHROMA_RESAMPLER: g_value_set_enum (value, s->chroma_resampler); break;
     case PROP_DEVICE_ID: g_value_set_int (value, s->device_id); break;
     case PROP_HIP_STREAMS: g_value_set_uint (value, s->hip_streams); break;
     case PROP_CONVERTER_CONFIG: g_value_set_boxed (value, s->converter_config); break;
@@ -840,6 +843,7 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   cfg.primaries_mode = s->primaries_mode;
   cfg.dither_quantization = s->dither_quantization;
   cfg.dither_method = s->dither;
+  cfg.chroma_resampler_method = s->chroma_resampler;       /* GST_VIDEO_CONVERTER_OPT_CHROMA_RESAMPLER_METHOD (:1076) */
 
   if (s->converter_config) {
     /* a user-provided converter-config replaces the element's own options altogether (gstvideoconvertscale.c:962-967): method,
@@ -1326,6 +1330,20 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_DITHER, g_param_spec_enum ("dither", "Dither", "Apply dithering while converting",
           GST_TYPE_VIDEO_DITHER_METHOD, GST_VIDEO_DITHER_BAYER, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  {
+    static GType rm_type = 0;
+    static const GEnumValue rm_values[] = {
+      {GSTAMD_RESAMPLER_METHOD_NEAREST, "Duplicates the samples when upsampling and drops when downsampling", "nearest"},
+      {GSTAMD_RESAMPLER_METHOD_LINEAR, "Uses linear interpolation to reconstruct missing samples and averaging to downsample", "linear"},
+      {GSTAMD_RESAMPLER_METHOD_CUBIC, "Uses cubic interpolation", "cubic"},
+      {GSTAMD_RESAMPLER_METHOD_SINC, "Uses sinc interpolation", "sinc"},
+      {GSTAMD_RESAMPLER_METHOD_LANCZOS, "Uses lanczos interpolation", "lanczos"}, {0, NULL, NULL}};
+    /* the library's own GstVideoResamplerMethod type where the runtime has it registered (same nicks and values) */
+    if (!rm_type && !(rm_type = g_type_from_name ("GstVideoResamplerMethod")))
+      rm_type = g_enum_register_static ("GstAmdVideoResamplerMethod", rm_values);
+    g_object_class_install_property (oc, PROP_CHROMA_RESAMPLER, g_param_spec_enum ("chroma-resampler", "Chroma resampler", "Chroma resampler method",
+            rm_type, GSTAMD_RESAMPLER_METHOD_LINEAR, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  }
   g_object_class_install_property (oc, PROP_CONVERTER_CONFIG, g_param_spec_boxed ("converter-config", "Converter configuration",
           "A GstStructure describing the configuration that should be used. This configuration, if set, takes precedence over the "
           "other similar conversion properties.", GST_TYPE_STRUCTURE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
@@ -1356,6 +1374,7 @@ static void
 gst_amd_vcs_init (GstAmdVideoConvertScale * s)
 {
   s->method = AMD_SCALE_BILINEAR;          /* DEFAULT_PROP_METHOD (:130) */
+  s->chroma_resampler = GSTAMD_RESAMPLER_METHOD_LINEAR;        /* DEFAULT_PROP_CHROMA_RESAMPLER (:137) */
   s->add_borders = TRUE;                   /* DEFAULT_PROP_ADD_BORDERS (:131) */
   s->n_threads = 1;
   s->alpha_mode = GSTAMD_ALPHA_MODE_COPY;

@@ -149,6 +149,31 @@ def test_videoconvertscale_element_packed_444_formats(gst_env, ref):
         assert (c1.frame(mid[f]) == out[f]).all()
 
 
+def test_videoconvertscale_chroma_resampler_property(gst_env, ref):
+    """`chroma-resampler` (gstvideoconvertscale.c:137, 345, 1076): the method of the chroma planes when a planar frame is scaled in its
+    own format (convert_scale_planes) - cubic luma with nearest / lanczos chroma against the reference's chroma-resampler-method"""
+    env, tmp = gst_env
+    w, h, ow, oh, n = 320, 240, 200, 136, 2
+    fin = tmp / "cr.nv12"
+    outs = {m: tmp / ("cr_%s.nv12" % m) for m in ("linear", "nearest", "lanczos")}
+    branches = " ".join("t. ! queue ! videoconvertscale method=catrom chroma-resampler=%s ! video/x-raw,format=NV12,width=%d,height=%d ! filesink location=%s"
+                        % (m, ow, oh, f) for m, f in outs.items())
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=%d,height=%d,colorimetry=bt601,chroma-site=jpeg "
+                "! tee name=t t. ! queue ! filesink location=%s %s" % (n, w, h, fin, branches))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    results = {}
+    for m, f in outs.items():
+        out = np.fromfile(f, np.uint8).reshape(n, -1)
+        cfg = ref.config_string(GstVideoConverter__resampler_method="cubic", GstVideoResampler__cubic_b=0.0, GstVideoResampler__cubic_c=0.5,
+                                GstVideoConverter__chroma_resampler_method=m)
+        c = ref.VideoConverter("NV12", w, h, "NV12", ow, oh, in_colorimetry="bt601", in_chroma_site="jpeg", out_colorimetry="bt601", out_chroma_site="jpeg",
+                               config=cfg)
+        for k in range(n):
+            assert (c.frame(src[k]) == out[k]).all(), m
+        results[m] = out
+    assert (results["linear"] != results["nearest"]).any() and (results["linear"] != results["lanczos"]).any()
+
+
 def test_videoconvertscale_element_12_bit_formats(gst_env, ref):
     """I420_12LE out of the element and back into it as Y444_10LE -> BGRA"""
     env, tmp = gst_env

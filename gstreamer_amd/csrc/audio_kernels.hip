@@ -18,6 +18,7 @@
 #include "../../include/gstamd_audio.h"
 #include "audio_device.h"
 #include "audio_taps.h"
+#include "tuning.h"
 
 using namespace gstamd;
 
@@ -174,7 +175,7 @@ static int run_resample (GstAmdAudioResampler *r, const void *in, size_t in_fram
   const FirParams p = make_fir_params (pl, s, in == nullptr, in_stride, out_stride);
   const int cur = r->cur, nxt = cur ^ 1;
   /* FULL mode: one launch of the LDS-staged kernel does the FIR and the history hand-over */
-  if (s.run_fir && !p.nearest && !p.interp && getenv ("GSTAMD_NO_FIR_LDS") == nullptr) {
+  if (s.run_fir && !p.nearest && !p.interp && !tuning_on ("GSTAMD_NO_FIR_LDS")) {
     FirLdsGeom g;
     g.row_stride = p.n_taps_padded + 4;
     const int span_max = FIR_LDS_FRAMES * (p.samp_inc + 1) + p.n_taps_padded + 2;

@@ -13,6 +13,7 @@
 
 #include "../../include/gstamd_video.h"
 #include "planner.h"
+#include "tuning.h"
 #include "video_kernels.h"
 #include "video_fast.h"
 #include "video_encode_fast.h"
@@ -94,13 +95,13 @@ hipError_t launch_scale420_mfma (const Mfma420Params &p, int chroma_h, int nwave
 static bool mfma_pick_geometry (GstAmdVideoConverter *c)
 {
   const int out_h = c->plan.out_info.height;
-  const char *ew = getenv ("GSTAMD_MFMA_WAVES"), *er = getenv ("GSTAMD_MFMA_ROWS");
+  const int ew = tuning_int ("GSTAMD_MFMA_WAVES", 0), er = tuning_int ("GSTAMD_MFMA_ROWS", 0);
   const int tiles = (c->mfma.n_blocks + 15) / 16, tile_blocks = (c->mfma.n_blocks + tiles - 1) / tiles;
   int n_cu = 256, dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     n_cu = prop.multiProcessorCount;
-  for (int nwaves = ew && atoi (ew) > 0 ? atoi (ew) : 4; nwaves >= 1; nwaves /= 2) {
+  for (int nwaves = ew > 0 ? ew : 4; nwaves >= 1; nwaves /= 2) {
     if (nwaves > 4)
       continue;
     const int rpr = 4 * nwaves;
@@ -112,7 +113,7 @@ static bool mfma_pick_geometry (GstAmdVideoConverter *c)
     if (per_cu <= 0)
       continue;
     const int chunks = std::max (1, per_cu * n_cu / std::max (1, tiles));
-    int rpc = er && atoi (er) > 0 ? atoi (er) : (out_h + chunks - 1) / chunks;
+    int rpc = er > 0 ? er : (out_h + chunks - 1) / chunks;
     rpc = std::max (rpc, rpr);
     ring = mfma420_ring_groups (c->fused, rpc, rpr);
     if (mfma420_lds_bytes (ring) > lds)
@@ -131,20 +132,20 @@ static bool mfma_pick_geometry (GstAmdVideoConverter *c)
 static bool fused_pick_geometry (GstAmdVideoConverter *c, int tiles)
 {
   const int out_h = c->plan.out_info.height;
-  const char *ew = getenv ("GSTAMD_FUSED_WAVES"), *er = getenv ("GSTAMD_FUSED_ROWS");
-  const int first = ew && atoi (ew) > 0 ? atoi (ew) : 16;      /* MI355X, C3: 16 waves 30.8 us, 8: 34.5, 4: 32.7, two-pass 33.7 (profiles/r02_c3_variants.log) */
+  const int ew = tuning_int ("GSTAMD_FUSED_WAVES", 0), er = tuning_int ("GSTAMD_FUSED_ROWS", 0);
+  const int first = ew > 0 ? ew : 16;      /* MI355X, C3: 16 waves 30.8 us, 8: 34.5, 4: 32.7, two-pass 33.7 (profiles/r02_c3_variants.log) */
   int n_cu = 256, dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     n_cu = prop.multiProcessorCount;
   /* schedule 2 (one barrier per round, the longer ring; Fused420Params::sched) where its LDS fits, schedule 1 otherwise;
      GSTAMD_FUSED_SCHED pins one for tuning sessions and tests */
-  const char *es = getenv ("GSTAMD_FUSED_SCHED");
-  for (int sched = es && atoi (es) == 1 ? 1 : 2; sched >= (es && atoi (es) == 2 ? 2 : 1); sched--)
+  const int es = tuning_int ("GSTAMD_FUSED_SCHED", 0);
+  for (int sched = es == 1 ? 1 : 2; sched >= (es == 2 ? 2 : 1); sched--)
     for (int nwaves = first; nwaves >= 2; nwaves /= 2) {
       if (nwaves > 16)
         continue;
-      const int first = getenv ("GSTAMD_FUSED_FIRST") ? std::max (1, atoi (getenv ("GSTAMD_FUSED_FIRST"))) : fused420_first_rows (c->fused, nwaves);
+      const int first = tuning_on ("GSTAMD_FUSED_FIRST") ? std::max (1, tuning_int ("GSTAMD_FUSED_FIRST", 1)) : fused420_first_rows (c->fused, nwaves);
       auto ring_of = [&](int rows) { return sched == 2 ? fused420_ring_groups2 (c->fused, rows, nwaves, first) : fused420_ring_groups (c->fused, rows, nwaves, first); };
       int ring = ring_of (out_h);
       size_t lds = fused420_lds_bytes (ring, nwaves, sched);
@@ -154,7 +155,7 @@ static bool fused_pick_geometry (GstAmdVideoConverter *c, int tiles)
       if (per_cu <= 0)
         continue;
       const int chunks = std::max (1, per_cu * n_cu / std::max (1, tiles));
-      int rpc = er && atoi (er) > 0 ? atoi (er) : (out_h + chunks - 1) / chunks;
+      int rpc = er > 0 ? er : (out_h + chunks - 1) / chunks;
       rpc = std::max (rpc, nwaves);
       ring = ring_of (rpc);
       if (fused420_lds_bytes (ring, nwaves, sched) > lds)
@@ -164,7 +165,7 @@ static bool fused_pick_geometry (GstAmdVideoConverter *c, int tiles)
       c->fused_rpc = rpc;
       c->fused_ring = ring;
       c->fused_sched = sched;
-      if (getenv ("GSTAMD_FUSED_DEBUG"))
+      if (tuning_on ("GSTAMD_FUSED_DEBUG"))
         fprintf (stderr, "fused geometry: sched %d waves %d rows/chunk %d first %d ring %d lds %zu per_cu %d tiles %d\n", sched, nwaves, rpc, c->fused_first, ring,
             fused420_lds_bytes (ring, nwaves, sched), per_cu, tiles);
       return true;
@@ -406,7 +407,7 @@ static int build_tables (GstAmdVideoConverter *c)
     }
     c->reg420 = regular;
     if (regular && !p.passes[1].horizontal && p.passes[1].kind == SCALE_NTAP && p.passes[0].nw >= 3 && p.passes[0].nw <= 5 &&
-        getenv ("GSTAMD_NO_FUSED420") == nullptr && make_fused420_tables (p.passes[1], p.front.height, &c->fused) &&
+        !tuning_on ("GSTAMD_NO_FUSED420") && make_fused420_tables (p.passes[1], p.front.height, &c->fused) &&
         fused_pick_geometry (c, (p.passes[0].out_size + c->geom[0].tile16_w - 1) / c->geom[0].tile16_w)) {
       if ((e = hipMalloc ((void **) &c->vgroup_dev, c->fused.vgroup.size () * sizeof (int32_t))) != hipSuccess ||
           (e = hipMemcpy (c->vgroup_dev, c->fused.vgroup.data (), c->fused.vgroup.size () * sizeof (int32_t), hipMemcpyHostToDevice)) != hipSuccess ||
@@ -418,7 +419,7 @@ static int build_tables (GstAmdVideoConverter *c)
        * lines in 16 neighbouring lanes, every load instruction then touches 16+ cache lines and costs ~64 texture-addresser
        * cycles whatever its width - the kernel is bound by its 16 loads per block (70.8 us at C3 against 30.8 for the
        * vector-ALU form; profiles/r02_c3_mfma_variants.log).  GSTAMD_MFMA420=1 selects it (tests, further work). */
-      if (getenv ("GSTAMD_MFMA420") != nullptr && make_mfma420_tables (p.passes[0], &c->mfma) && mfma_pick_geometry (c)) {
+      if (tuning_on ("GSTAMD_MFMA420") && make_mfma420_tables (p.passes[0], &c->mfma) && mfma_pick_geometry (c)) {
         if ((e = hipMalloc ((void **) &c->btab_dev, c->mfma.btab.size () * sizeof (uint32_t))) != hipSuccess ||
             (e = hipMemcpy (c->btab_dev, c->mfma.btab.data (), c->mfma.btab.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
           return hip_fail (e, "matrix-core scaler tables");
@@ -779,14 +780,14 @@ static bool bilinear420_params (GstAmdVideoConverter *c, BilParams *out)
     return false;
   /* semi-planar / planar 4:2:0 source, horizontal-first 2-tap x 2-tap, fast matrix */
   if (!(p.passes[0].horizontal && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && kind_has_planes (p.front.kind) && p.front.w_sub == 1 &&
-        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && getenv ("GSTAMD_NO_BILINEAR420") == nullptr))
+        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && !tuning_on ("GSTAMD_NO_BILINEAR420")))
     return false;
   const int out_w = p.out_info.width, out_h = p.out_info.height;
   BilParams bp;
   memset (&bp, 0, sizeof (bp));
   bp.tile_w = bil_pick_tile (out_w, p.passes[0].inc, &bp.ylen);
-  if (const char *e_tw = getenv ("GSTAMD_BIL_TILE")) {      /* tuning knob for profiling sessions */
-    bp.tile_w = atoi (e_tw);
+  if (tuning_on ("GSTAMD_BIL_TILE")) {      /* tuning knob for profiling sessions */
+    bp.tile_w = tuning_int ("GSTAMD_BIL_TILE", 0);
     bp.ylen = bil_ylen (out_w, p.passes[0].inc, bp.tile_w);
   }
   if (bp.tile_w <= 0 || bp.ylen <= 0)
@@ -802,7 +803,7 @@ static bool bilinear420_params (GstAmdVideoConverter *c, BilParams *out)
   bp.planar = p.front.kind == UNPACK_PLANAR;
   bp.u_plane = p.front.u_plane;
   bp.v_plane = p.front.v_plane;
-  if (p.front.chroma_v2 && getenv ("GSTAMD_BIL_TABLE") == nullptr) {
+  if (p.front.chroma_v2 && !tuning_on ("GSTAMD_BIL_TABLE")) {
     /* are the pairs of every source line the kernel will touch the closed form of bil_rows? */
     bool regular = true;
     BilParams probe = bp;
@@ -819,15 +820,15 @@ static bool bilinear420_params (GstAmdVideoConverter *c, BilParams *out)
   }
   /* rows per wave of k_bilinear420_rows: every source line pair has to sit in the three-row window of video_bilinear_rows.h */
   bp.rows = 0;
-  if (bp.regular_pairs && (p.front.width % 16) == 0 && getenv ("GSTAMD_NO_BILINEAR_ROWS") == nullptr) {
+  if (bp.regular_pairs && (p.front.width % 16) == 0 && !tuning_on ("GSTAMD_NO_BILINEAR_ROWS")) {
     bool fits = true;
     for (int y = 0; y < out_h && fits; y++)
       fits = bilr_window_matches (bp, (int) p.passes[1].offset[y]);
     int rows_ylen = 0;
     bp.rows_tile_w = bilr_pick_tile (out_w, p.passes[0].inc, &rows_ylen);
 #ifdef GSTAMD_TUNING
-    if (getenv ("GSTAMD_BIL_ROWS_TILE")) {
-      bp.rows_tile_w = atoi (getenv ("GSTAMD_BIL_ROWS_TILE"));
+    if (tuning_on ("GSTAMD_BIL_ROWS_TILE")) {
+      bp.rows_tile_w = tuning_int ("GSTAMD_BIL_ROWS_TILE", 0);
       rows_ylen = bil_ylen (out_w, p.passes[0].inc, bp.rows_tile_w);
     }
 #endif
@@ -835,8 +836,8 @@ static bool bilinear420_params (GstAmdVideoConverter *c, BilParams *out)
     if (fits)
       bp.rows = -1;
 #ifdef GSTAMD_TUNING
-    if (fits && getenv ("GSTAMD_BIL_ROWS"))
-      bp.rows = atoi (getenv ("GSTAMD_BIL_ROWS"));
+    if (fits && tuning_on ("GSTAMD_BIL_ROWS"))
+      bp.rows = tuning_int ("GSTAMD_BIL_ROWS", 0);
 #endif
   }
   *out = bp;
@@ -942,7 +943,7 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
   }
   if (p.fast_420p && ((uintptr_t) pl.p[0] % 8) == 0 && (pl.stride[0] % 8) == 0 && ((uintptr_t) pl.p[1] % 4) == 0 && ((uintptr_t) pl.p[2] % 4) == 0 &&
       (pl.stride[1] % 4) == 0 && pl.stride[1] == pl.stride[2] && ((uintptr_t) dst % 16) == 0 && (dstride % 16) == 0 &&
-      getenv ("GSTAMD_NO_FAST420P") == nullptr) {
+      !tuning_on ("GSTAMD_NO_FAST420P")) {
     Fast420pParams q;
     q.fp = make_fast_params (p);
     q.y = pl.p[0];
@@ -954,7 +955,7 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert420p");
   }
   if (p.fast_422 && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && ((uintptr_t) dst % 16) == 0 && (dstride % 16) == 0 &&
-      getenv ("GSTAMD_NO_FAST422") == nullptr) {
+      !tuning_on ("GSTAMD_NO_FAST422")) {
     Fast422Params q;
     q.fp = make_fast_params (p);
     q.chroma_h = p.front.chroma_h;
@@ -1067,7 +1068,7 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     fq.n_groups = c->fused.n_groups;
 #ifdef GSTAMD_TUNING
     /* profiling builds: GSTAMD_FUSED_TRACE=<file> dumps the per-wave stage stamps of every launch (the last one stays) */
-    const char *trace_path = getenv ("GSTAMD_FUSED_TRACE");
+    const char *trace_path = tuning_text ("GSTAMD_FUSED_TRACE");
     const size_t trace_n = (size_t) ((hp.out_w + hp.tile_w - 1) / hp.tile_w) * ((out_h + fq.rows_per_chunk - 1) / fq.rows_per_chunk) * 16 * 32;
     if (trace_path && hipMalloc ((void **) &fq.trace, trace_n * 8) == hipSuccess)
       (void) hipMemset (fq.trace, 0, trace_n * 8);

@@ -14,6 +14,7 @@
 
 #include "../../include/gstamd_video.h"
 #include "compositor_device.h"
+#include "tuning.h"
 #include "compositor_planes.h"
 #include "compositor_wide.h"
 #include "compositor_scaled.h"
@@ -292,15 +293,15 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
   /* development knobs (not a product interface): ablation of the blend (1), the pad loads (2), the hit loop (3),
    * both (4); workgroup width */
 #ifdef GSTAMD_TUNING
-  const int abl = getenv ("GSTAMD_AGG_ABLATE") ? atoi (getenv ("GSTAMD_AGG_ABLATE")) : 0;
-  if (getenv ("GSTAMD_AGG_BX"))
-    bx = atoi (getenv ("GSTAMD_AGG_BX"));
+  const int abl = tuning_int ("GSTAMD_AGG_ABLATE", 0);
+  if (tuning_on ("GSTAMD_AGG_BX"))
+    bx = tuning_int ("GSTAMD_AGG_BX", bx);
 #else
   const int abl = 0;
 #endif
 #ifdef GSTAMD_TUNING
-  const int rows = getenv ("GSTAMD_AGG_ROWS") ? atoi (getenv ("GSTAMD_AGG_ROWS")) : 0;
-  const int depth = getenv ("GSTAMD_AGG_DEPTH") ? atoi (getenv ("GSTAMD_AGG_DEPTH")) : 4;
+  const int rows = tuning_int ("GSTAMD_AGG_ROWS", 0);
+  const int depth = tuning_int ("GSTAMD_AGG_DEPTH", 4);
   if (rows > 0 && q.fast && q.n_pads > 0 && q.bg_kind != 2 && abl == 0) {
     const int strips = (rw + 255) / 256;
     dim3 rgrid (strips * ((rh + rows - 1) / rows)), rblock (64);
@@ -316,8 +317,8 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
 #endif
 #ifdef GSTAMD_TUNING
   {
-    int srows = getenv ("GSTAMD_AGG_STRIP_ROWS") ? atoi (getenv ("GSTAMD_AGG_STRIP_ROWS")) : 0;
-    int spx = getenv ("GSTAMD_AGG_STRIP_PX") ? atoi (getenv ("GSTAMD_AGG_STRIP_PX")) : 4;
+    int srows = tuning_int ("GSTAMD_AGG_STRIP_ROWS", 0);
+    int spx = tuning_int ("GSTAMD_AGG_STRIP_PX", 4);
     for (int i = 0; i < q.n_pads; i++)
       if (q.pads[i].width < 8)
         spx = 4;
@@ -338,7 +339,7 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
   if (q.fast && q.n_pads > 0 && abl == 0 && bx == 64 && rw >= 4 && (q.bg_kind != 2 || (rw & 3) == 0)) {
     dim3 dgrid ((rw + 255) / 256, rh);
 #ifdef GSTAMD_TUNING
-    const int nt = getenv ("GSTAMD_AGG_NT") ? atoi (getenv ("GSTAMD_AGG_NT")) : AGG_DIRECT_NT;
+    const int nt = tuning_int ("GSTAMD_AGG_NT", AGG_DIRECT_NT);
 #else
     const int nt = AGG_DIRECT_NT;
 #endif
@@ -647,9 +648,9 @@ int gstamd_internal_pad_scaler_tile_rows (GstAmdVideoConverter *c);
 /* rows per tile: the first scaled pad decides (the pads of one canvas usually share a ratio) - see scaled_tile_rows_for */
 static int scaled_tile_rows (GstAmdVideoConverter *c)
 {
-  const char *e = getenv ("GSTAMD_SCALED_TILE_ROWS");
-  if (e && atoi (e) >= 4 && atoi (e) <= SCALED_TILE_H)
-    return atoi (e);
+  const int e = tuning_int ("GSTAMD_SCALED_TILE_ROWS", 0);
+  if (e >= 4 && e <= SCALED_TILE_H)
+    return e;
   return gstamd_internal_pad_scaler_tile_rows (c);
 }
 

@@ -1,0 +1,101 @@
+// tuning.cpp - see tuning.h
+#include "tuning.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+namespace {
+
+struct Knob {
+  const char *name;
+  bool text;
+  int value;            /* -1: unset */
+  std::string str;
+  bool has_str;
+};
+
+Knob g_knobs[] = {
+  {"GSTAMD_NO_FUSED420", false, -1, "", false}, {"GSTAMD_NO_H420_REG", false, -1, "", false}, {"GSTAMD_H420_ROWS", false, -1, "", false},
+  {"GSTAMD_VSCALE_ROWS", false, -1, "", false}, {"GSTAMD_NO_FAST420P", false, -1, "", false}, {"GSTAMD_NO_FAST422", false, -1, "", false},
+  {"GSTAMD_NO_BILINEAR420", false, -1, "", false}, {"GSTAMD_NO_BILINEAR_ROWS", false, -1, "", false}, {"GSTAMD_BIL_TILE", false, -1, "", false},
+  {"GSTAMD_BIL_TABLE", false, -1, "", false}, {"GSTAMD_BIL_ROWS", false, -1, "", false}, {"GSTAMD_BIL_ROWS_TILE", false, -1, "", false},
+  {"GSTAMD_BIL_SLOTS", false, -1, "", false}, {"GSTAMD_BIL_WG", false, -1, "", false}, {"GSTAMD_BIL_VERBOSE", false, -1, "", false},
+  {"GSTAMD_FUSED_WAVES", false, -1, "", false}, {"GSTAMD_FUSED_ROWS", false, -1, "", false}, {"GSTAMD_FUSED_SCHED", false, -1, "", false},
+  {"GSTAMD_FUSED_FIRST", false, -1, "", false}, {"GSTAMD_FUSED_DEBUG", false, -1, "", false}, {"GSTAMD_MFMA420", false, -1, "", false},
+  {"GSTAMD_MFMA_WAVES", false, -1, "", false}, {"GSTAMD_MFMA_ROWS", false, -1, "", false}, {"GSTAMD_NO_FIR_LDS", false, -1, "", false},
+  {"GSTAMD_SCALED_TILE_ROWS", false, -1, "", false}, {"GSTAMD_AGG_BX", false, -1, "", false},
+  /* tuning builds */
+  {"GSTAMD_ABLATE", false, -1, "", false}, {"GSTAMD_AGG_ABLATE", false, -1, "", false}, {"GSTAMD_AGG_ROWS", false, -1, "", false},
+  {"GSTAMD_AGG_DEPTH", false, -1, "", false}, {"GSTAMD_AGG_STRIP_ROWS", false, -1, "", false}, {"GSTAMD_AGG_STRIP_PX", false, -1, "", false},
+  {"GSTAMD_AGG_NT", false, -1, "", false}, {"GSTAMD_FAST_VARIANT", true, -1, "", false}, {"GSTAMD_FUSED_TRACE", true, -1, "", false},
+};
+
+std::once_flag g_once;
+std::mutex g_lock;
+
+void read_environment ()
+{
+  for (Knob &k : g_knobs) {
+    const char *e = getenv (k.name);
+    if (!e)
+      continue;
+    if (k.text) {
+      k.str = e;
+      k.has_str = true;
+    } else {
+      const int v = atoi (e);
+      k.value = v < 0 ? 0 : v;          /* "set" with a value that is no number counts as 0 */
+    }
+  }
+}
+
+Knob *find (const char *name)
+{
+  std::call_once (g_once, read_environment);
+  for (Knob &k : g_knobs)
+    if (strcmp (k.name, name) == 0)
+      return &k;
+  return nullptr;
+}
+
+}  // namespace
+
+namespace gstamd {
+
+int tuning_int (const char *name, int unset)
+{
+  Knob *k = find (name);
+  if (!k)
+    return unset;
+  std::lock_guard<std::mutex> g (g_lock);
+  return k->value < 0 ? unset : k->value;
+}
+
+const char *tuning_text (const char *name)
+{
+  Knob *k = find (name);
+  return k && k->has_str ? k->str.c_str () : nullptr;
+}
+
+}  // namespace gstamd
+
+extern "C" {
+
+int gstamd_tuning_set (const char *name, int value)
+{
+  Knob *k = name ? find (name) : nullptr;
+  if (!k || k->text)
+    return -1;
+  std::lock_guard<std::mutex> g (g_lock);
+  k->value = value < 0 ? -1 : value;
+  return 0;
+}
+
+int gstamd_tuning_get (const char *name)
+{
+  return name ? gstamd::tuning_int (name, -1) : -1;
+}
+
+}

@@ -1,0 +1,44 @@
+// tuning.h - every development / support knob of the library in ONE table.
+//
+// The library's kernel choice does not depend on the process environment at the time of a call: the knobs below are read from the
+// environment once, when the library first looks at one of them, and afterwards change only through gstamd_tuning_set () (the tests
+// switch fast paths off with it to reach the general kernels).  A knob that is not set means "the library's own choice"; none of
+// them changes a result - every path they select is held to the same byte-exact tests.
+//
+//   name                     meaning (value)
+//   GSTAMD_NO_FUSED420       two-pass form instead of the fused 4:2:0 N-tap scaler (set)
+//   GSTAMD_NO_H420_REG       general horizontal 4:2:0 kernel (pair table) instead of the regular-pairs one (set)
+//   GSTAMD_H420_ROWS         lines per wave of the horizontal 4:2:0 kernels (n; 0: kernel off)
+//   GSTAMD_VSCALE_ROWS       output rows per lane group of the vertical N-tap pass (n)
+//   GSTAMD_NO_FAST420P       generic kernel instead of the I420 / YV12 -> RGB fastpath kernel (set)
+//   GSTAMD_NO_FAST422        generic kernel instead of the packed 4:2:2 -> RGB kernel (set)
+//   GSTAMD_NO_BILINEAR420    wave-tile scaler instead of the 4:2:0 bilinear kernels (set)
+//   GSTAMD_NO_BILINEAR_ROWS  k_bilinear420 instead of k_bilinear420_rows (set)
+//   GSTAMD_BIL_TILE, GSTAMD_BIL_TABLE, GSTAMD_BIL_ROWS, GSTAMD_BIL_ROWS_TILE, GSTAMD_BIL_SLOTS, GSTAMD_BIL_WG, GSTAMD_BIL_VERBOSE
+//                            geometry of the bilinear kernels (n)
+//   GSTAMD_FUSED_WAVES, GSTAMD_FUSED_ROWS, GSTAMD_FUSED_SCHED, GSTAMD_FUSED_FIRST, GSTAMD_FUSED_DEBUG
+//                            geometry / schedule of the fused scaler (n)
+//   GSTAMD_MFMA420, GSTAMD_MFMA_WAVES, GSTAMD_MFMA_ROWS
+//                            the matrix-core form of the fused scaler's horizontal pass (opt-in) and its geometry
+//   GSTAMD_NO_FIR_LDS        one-lane-per-sample FIR instead of the LDS-staged one (set)
+//   GSTAMD_SCALED_TILE_ROWS  rows per tile of k_aggregate_scaled (4 .. 16)
+//   GSTAMD_AGG_BX            workgroup width of k_aggregate (n)
+// -DGSTAMD_TUNING builds only (profiling sessions): GSTAMD_ABLATE, GSTAMD_AGG_ABLATE, GSTAMD_AGG_ROWS, GSTAMD_AGG_DEPTH,
+//   GSTAMD_AGG_STRIP_ROWS, GSTAMD_AGG_STRIP_PX, GSTAMD_AGG_NT, GSTAMD_FAST_VARIANT (text), GSTAMD_FUSED_TRACE (a path).
+#pragma once
+
+namespace gstamd {
+
+// value of a knob, or `unset` (default -1) when neither the environment at first use nor gstamd_tuning_set gave it one
+int tuning_int (const char *name, int unset = -1);
+inline bool tuning_on (const char *name) { return tuning_int (name, -1) >= 0; }
+// text-valued knobs of tuning builds (read from the environment once, too); NULL when unset
+const char *tuning_text (const char *name);
+
+}  // namespace gstamd
+
+extern "C" {
+/* value < 0 removes the knob (back to the library's own choice).  Returns 0, or -1 for a name the table does not have. */
+int gstamd_tuning_set (const char *name, int value);
+int gstamd_tuning_get (const char *name);
+}

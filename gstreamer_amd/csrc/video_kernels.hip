@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include "planner.h"
+#include "tuning.h"
 #include "video_kernels.h"
 #include "video_device.h"
 #include "video_fast.h"
@@ -818,7 +819,7 @@ static const FastVariant &fast_variant ()
 {
   static FastVariant v = {-1, 0, 0, 0, 0};
   if (v.set < 0) {
-    const char *e = getenv ("GSTAMD_FAST_VARIANT");
+    const char *e = tuning_text ("GSTAMD_FAST_VARIANT");
     v.set = e && sscanf (e, "%d,%d,%d,%d", &v.shape, &v.abl, &v.K, &v.order) >= 1;
   }
   return v;
@@ -939,11 +940,11 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
   Dst d = make_dst (dst, dstride, final, post, pack_pos);
   dim3 block (256), grid ((out_w + 255) / 256, out_h);
 #ifdef GSTAMD_TUNING
-  static const int ablate = getenv ("GSTAMD_ABLATE") ? atoi (getenv ("GSTAMD_ABLATE")) : 0;
+  const int ablate = tuning_int ("GSTAMD_ABLATE", 0);
 #else
   const int ablate = 0;         /* the stage-skipping switches of k_hscale420_dot4 are dead code in the product build */
 #endif
-  static const int h420_rows_env = getenv ("GSTAMD_H420_ROWS") ? atoi (getenv ("GSTAMD_H420_ROWS")) : -1;      /* 0: kernel off */
+  const int h420_rows_env = tuning_int ("GSTAMD_H420_ROWS", -1);      /* 0: kernel off */
   if (horizontal && geom.tile16_w > 0 && sd.tapw && dot4_source_ok (src) && h420_source_ok (src) && h420_rows_env != 0) {
     /* lines per wave: the waves of the launch should all be resident at once (one round, no tail of late waves), each walking
      * down as many lines as that takes - but at least 4, for the chroma rows and the taps a wave keeps between lines */
@@ -998,7 +999,7 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
 template <int NW, int SEMI>
 static hipError_t launch_h420_reg_nw (H420RegParams p, int chroma_h, int n_taps, hipStream_t stream)
 {
-  static const int lpw_env = getenv ("GSTAMD_H420_ROWS") ? atoi (getenv ("GSTAMD_H420_ROWS")) : -1;
+  const int lpw_env = tuning_int ("GSTAMD_H420_ROWS", -1);
   const size_t lds = (size_t) GSTAMD_H420_LINE_WORDS * 4 * 2;
   const void *fn = chroma_h == CHROMA_H_H2_CS ? (const void *) k_hscale420_reg<NW, CHROMA_H_H2_CS, SEMI> :
       (chroma_h == CHROMA_H_H2 ? (const void *) k_hscale420_reg<NW, CHROMA_H_H2, SEMI> : (const void *) k_hscale420_reg<NW, CHROMA_H_NONE, SEMI>);
@@ -1033,7 +1034,7 @@ static hipError_t launch_h420_reg_nw (H420RegParams p, int chroma_h, int n_taps,
 // regular 4:2:0 horizontal pass into the AYUV intermediate; hipErrorNotSupported: the caller takes the general kernels
 hipError_t launch_hscale420_reg (const H420RegParams &p, int chroma_h, int nw, int n_taps, hipStream_t stream)
 {
-  if (getenv ("GSTAMD_NO_H420_REG"))
+  if (tuning_on ("GSTAMD_NO_H420_REG"))
     return hipErrorNotSupported;
   int ok = (p.width % 16) == 0 && aligned (p.y, 16) && (p.ystride % 16) == 0 && aligned (p.dst, 4) && (p.dstride % 4) == 0;
   if (p.semi)
@@ -1084,7 +1085,7 @@ hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int ss
     hipLaunchKernelGGL (k_hscale<SrcImage>, grid, block, 0, stream, src, sd, d, out_w, out_h);
   else if (sd.kind == SCALE_NTAP) {
     /* the packed kernel runs the generic post stage too (post_px), so it serves every N-tap vertical pass */
-    static const int vrows = getenv ("GSTAMD_VSCALE_ROWS") ? atoi (getenv ("GSTAMD_VSCALE_ROWS")) : 1;
+    const int vrows = tuning_int ("GSTAMD_VSCALE_ROWS", 1);
     /* neighbouring output rows of an N-tap filter always share source rows (the window is 2a steps wide) */
     if (vrows == 4) {
       dim3 vgrid ((out_w + 255) / 256, (out_h + 3) / 4);
@@ -1158,17 +1159,17 @@ static hipError_t launch_bilinear420_rows (const BilParams &bp, int chroma_h, in
   BilParams rp = bp;
   int slots = bilr_wave_slots ();
 #ifdef GSTAMD_TUNING
-  if (getenv ("GSTAMD_BIL_SLOTS"))
-    slots = atoi (getenv ("GSTAMD_BIL_SLOTS"));
+  if (tuning_on ("GSTAMD_BIL_SLOTS"))
+    slots = tuning_int ("GSTAMD_BIL_SLOTS", slots);
 #endif
   /* one frame: as many strips as make one resident round (a round that tips over into a second one costs 20 %: keep a margin);
    * several frames: the rounds follow each other anyway, strips of six rows */
   rp.strips = n > 1 && bp.rows < 0 ? bilr_strips (bp.out_h, 6, rtiles, 0) : bilr_strips (bp.out_h, bp.rows, rtiles, slots - slots / 16);
   int wg = 1;
 #ifdef GSTAMD_TUNING
-  if (getenv ("GSTAMD_BIL_WG"))
-    wg = atoi (getenv ("GSTAMD_BIL_WG"));
-  if (getenv ("GSTAMD_BIL_VERBOSE"))
+  if (tuning_on ("GSTAMD_BIL_WG"))
+    wg = tuning_int ("GSTAMD_BIL_WG", wg);
+  if (tuning_on ("GSTAMD_BIL_VERBOSE"))
     fprintf (stderr, "k_bilinear420_rows: %d frame(s), slots %d, tiles %d, strips %d\n", n, slots, rtiles, rp.strips);
 #endif
   const int blocks_per_frame = wide_grid_blocks (rtiles, rp.strips) / wg;         /* a multiple of 256 / wg */

@@ -141,6 +141,27 @@ def lib():
     return _lib
 
 
+class tuning:
+    """with V.tuning(GSTAMD_NO_H420_REG=1): ...   - sets knobs of the library's tuning table (gstamd_tuning_set) for the block"""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        L = lib()
+        L.gstamd_tuning_set.argtypes = [C.c_char_p, C.c_int]
+        L.gstamd_tuning_get.argtypes = [C.c_char_p]
+        self.old = {k: L.gstamd_tuning_get(k.encode()) for k in self.knobs}
+        for k, v in self.knobs.items():
+            assert L.gstamd_tuning_set(k.encode(), int(v)) == 0, k
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            lib().gstamd_tuning_set(k.encode(), v)
+        return False
+
+
 def last_error():
     return lib().gstamd_last_error().decode()
 

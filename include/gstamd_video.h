@@ -332,6 +332,12 @@ int gstamd_device_download_2d_async (void *dst_host, size_t dst_pitch, const voi
  * 0: one stream at a time (two-pass scalers and planar packers own one intermediate image per converter). */
 int gstamd_video_converter_is_reentrant (GstAmdVideoConverter *convert);
 
+/* Development / support knobs (gstreamer_amd/csrc/tuning.h holds the table): the library reads them from the environment ONCE, at its
+ * first look at any of them; afterwards only this call changes one.  value < 0 unsets it (the library's own choice).  None of them
+ * changes a result: they choose between kernels that are held to the same byte-exact tests.  -1: unknown name. */
+int gstamd_tuning_set (const char *name, int value);
+int gstamd_tuning_get (const char *name);
+
 /* gst_video_converter_get_config / _set_config (video-converter.c:2736-2790) for the options this library reads: the config the
  * converter was planned with; set_config re-plans with the new options applied on top (unknown conversions: GSTAMD_ERR_UNSUPPORTED,
  * the converter keeps its old plan). */

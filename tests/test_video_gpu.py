@@ -91,12 +91,12 @@ H420_GENERAL = [c for c in enumerate(cases.VIDEO_CASES) if "_h420_" in c[1][0] o
 
 
 @pytest.mark.parametrize("idx_case", H420_GENERAL, ids=lambda c: c[1][0])
-def test_hip_general_hscale420_kernel_matches_golden(native_lib, gpu, idx_case, monkeypatch):
+def test_hip_general_hscale420_kernel_matches_golden(native_lib, gpu, idx_case):
     """The 4:2:0 cases again with k_hscale420_reg switched off: k_hscale420_dot4 (pair table, chroma-row cache) serves them."""
-    monkeypatch.setenv("GSTAMD_NO_H420_REG", "1")
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     src = cases.frame_bytes(int(V.video_info(ifmt, w, h).size), pattern, cases.case_seed(name), w)
-    out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    with V.tuning(GSTAMD_NO_H420_REG=1):
+        out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
     assert cases.video_digest(name, out) == GOLDEN[name]["sha256"]
 
 
@@ -164,14 +164,14 @@ MFMA_SHAPES = [("I420", 7680, 4320, "RGBA", 1920, 1080), ("NV12", 1280, 720, "BG
 
 
 @pytest.mark.parametrize("shape", MFMA_SHAPES, ids=lambda s: "%s_%dx%d" % (s[0], s[1], s[2]))
-def test_hip_scale420_mfma_matches_reference_bytewise(native_lib, gpu, ref, shape, monkeypatch):
+def test_hip_scale420_mfma_matches_reference_bytewise(native_lib, gpu, ref, shape):
     """k_scale420_mfma (4:1 horizontal pass on v_mfma_i32_16x16x64_i8; opt-in, see capi_video.cpp) memcmp'd against the reference:
     C3 at its own size, both plane layouts, odd height, several tiles."""
-    monkeypatch.setenv("GSTAMD_MFMA420", "1")
     ifmt, w, h, ofmt, ow, oh = shape
     src = cases.frame_bytes(ref.video_info(ifmt, w, h)["size"], "random", 31 + w)
     exp = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, cases.LAN)).frame(src)
-    out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LAN, None, None, src)
+    with V.tuning(GSTAMD_MFMA420=1):
+        out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LAN, None, None, src)
     assert (out == exp).all(), int((out != exp).sum())
 
 
@@ -180,7 +180,7 @@ BILR_SHAPES = [("NV12", 3840, 2160, "BGRA", 1920, 1080, None), ("NV12", 1920, 10
 
 
 @pytest.mark.parametrize("shape", BILR_SHAPES, ids=lambda s: "%s_%dx%d_%dx%d" % (s[0], s[1], s[2], s[4], s[5]))
-def test_hip_bilinear420_rows_shapes_match_reference_bytewise(native_lib, gpu, ref, shape, monkeypatch):
+def test_hip_bilinear420_rows_shapes_match_reference_bytewise(native_lib, gpu, ref, shape):
     """k_bilinear420_rows (chroma once per source pixel in byte lanes, balanced row strips): 2:1, 1.5:1, non-integer and upscaling
     ratios, both plane layouts, tiles of 384 and fewer outputs, memcmp'd against the reference run on this host - and the older
     k_bilinear420 on the same frames (GSTAMD_NO_BILINEAR_ROWS), which stays the path for sources the rows kernel does not take."""
@@ -190,8 +190,8 @@ def test_hip_bilinear420_rows_shapes_match_reference_bytewise(native_lib, gpu, r
     for _ in range(2):
         out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LIN, None, site, src)
         assert (out == exp).all(), int((out != exp).sum())
-    monkeypatch.setenv("GSTAMD_NO_BILINEAR_ROWS", "1")
-    out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LIN, None, site, src)
+    with V.tuning(GSTAMD_NO_BILINEAR_ROWS=1):
+        out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LIN, None, site, src)
     assert (out == exp).all(), int((out != exp).sum())
 
 

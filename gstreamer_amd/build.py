@@ -27,21 +27,24 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=True, tuning=False):
+def build(force=False, verbose=True, tuning=False, defines=(), suffix=None):
     """tuning=True adds -DGSTAMD_TUNING: the ablation switches (kernels that skip arithmetic on purpose, for profiling sessions)
     exist only in such a build - never commit / ship one; rebuild without it afterwards."""
     os.makedirs(LIBDIR, exist_ok=True)
-    if not force and not tuning and up_to_date():
+    if not force and not tuning and not suffix and up_to_date():
         return LIB
     lib = os.path.join(LIBDIR, "libgstamddsp_tuning.so") if tuning else LIB      # a tuning build never replaces the product library
     objdir = os.path.join(LIBDIR, "tuning") if tuning else LIBDIR
+    if suffix:                  # profiling variants with extra -D switches: libgstamddsp_<suffix>.so (select with GSTAMD_LIB_PATH)
+        lib = os.path.join(LIBDIR, "libgstamddsp_%s.so" % suffix)
+        objdir = os.path.join(LIBDIR, suffix)
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [HIPCC] + FLAGS + (["-DGSTAMD_TUNING"] if tuning else []) + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + (["-DGSTAMD_TUNING"] if tuning else []) + ["-D" + d for d in defines] + ["-x", "hip", "-c", src, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for src, p in procs:
         out, _ = p.communicate()
@@ -57,4 +60,6 @@ def build(force=False, verbose=True, tuning=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, tuning="--tuning" in sys.argv))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    sfx = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--suffix=")]
+    print(build(force="--force" in sys.argv, tuning="--tuning" in sys.argv, defines=defs, suffix=sfx[0] if sfx else None))

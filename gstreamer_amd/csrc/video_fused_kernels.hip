@@ -114,6 +114,10 @@ static __device__ __forceinline__ void fused_row_tables (const Fused420Params &p
 #ifndef GSTAMD_FUSED2_PARITY
 #define GSTAMD_FUSED2_PARITY 1
 #endif
+#if defined(GSTAMD_FUSED_ABL) && GSTAMD_FUSED_ABL == 5
+template <int NW, int CH, int SEMI, int B>
+static __device__ __forceinline__ void fused2_stage_skip (const H420RegParams &, Fused420Lane<NW> &, uint32_t *, int, int, int) {}
+#endif
 // schedule 2 (Fused420Params::sched): see there.  LDS: [ring slots][12][64] words, then per wave ONE staged line of three byte planes.
 template <int NW, int CH, int SEMI, int NGV>
 __global__ __launch_bounds__ (1024) void k_scale420_fused2 (Fused420Params p, Dst dst, PostFast pf)
@@ -140,10 +144,22 @@ __global__ __launch_bounds__ (1024) void k_scale420_fused2 (Fused420Params p, Ds
   int g = gl + wave;
   fused_request_group<NW, SEMI> (p.h, g < g_last ? g : g_last, s);
   /* this wave's groups up to gh */
+#if defined(GSTAMD_FUSED_ABL) && GSTAMD_FUSED_ABL == 1
+  const int g_shared = j1 < p.out_h ? p.vgroup[j1] : (1 << 30);        /* profiling build: groups the next chunk makes as well are not made */
+#endif
+#if defined(GSTAMD_FUSED_ABL) && GSTAMD_FUSED_ABL == 5
+#define fused2_stage fused2_stage_skip                               /* profiling build: no source loads, no chroma upsampling */
+#endif
   auto produce = [&](int gh) {
     while (g <= gh) {
       const int gn = g + nwaves < g_last ? g + nwaves : g_last;
       uint32_t *slot = ring + (size_t) (g % p.ring) * GSTAMD_FUSED_GROUP_WORDS;
+#if defined(GSTAMD_FUSED_ABL) && GSTAMD_FUSED_ABL == 1
+      if (g >= g_shared) {
+        g += nwaves;
+        continue;
+      }
+#endif
       fused2_stage<NW, CH, SEMI, 0> (p.h, s, stage, g, gn, lane);
       fused_wave_sync ();
       fused2_filter<NW, 0> (s, stage, slot, lane);
@@ -186,7 +202,11 @@ __global__ __launch_bounds__ (1024) void k_scale420_fused2 (Fused420Params p, Ds
       int jr, jl;
       round_rows (k, &jr, &jl);
       const int j = __builtin_amdgcn_readfirstlane (jr + wave);
+#if defined(GSTAMD_FUSED_ABL) && GSTAMD_FUSED_ABL == 4
+      if (false) {                      /* profiling build: no vertical pass, nothing stored */
+#else
       if (j <= jl) {
+#endif
         if (NGV == 5) {
           int grp;
           uint32_t tw[5];

@@ -68,9 +68,14 @@ GSTAMD_HD void fused_filter_line (const uint32_t *line, const Dot4Taps<NW> &ft, 
       const uint32_t *b = line + ft.w0[i0 + j];
 #pragma unroll
       for (int k = 0; k < NW; k++) {
+#if defined(GSTAMD_FUSED_ABL) && (GSTAMD_FUSED_ABL == 2 || GSTAMD_FUSED_ABL == 3)
+        /* profiling builds only (-DGSTAMD_FUSED_ABL=n, results WRONG): 2 = no LDS reads in the horizontal filter, 3 = no arithmetic either */
+        wy[j][k] = (uint32_t) ft.w0[i0 + j] + k, wu[j][k] = wy[j][k] * 3u, wv[j][k] = wy[j][k] * 5u;
+#else
         wy[j][k] = h420r_lds (b + k);
         wu[j][k] = h420r_lds (b + pw + k);
         wv[j][k] = h420r_lds (b + 2 * pw + k);
+#endif
       }
     }
 #pragma unroll
@@ -80,9 +85,13 @@ GSTAMD_HD void fused_filter_line (const uint32_t *line, const Dot4Taps<NW> &ft, 
 #pragma unroll
       for (int k = 0; k < NW; k++) {
         const uint32_t t = ft.t[i][k];
+#if defined(GSTAMD_FUSED_ABL) && GSTAMD_FUSED_ABL == 3
+        ay ^= (int) wy[j][k], au ^= (int) wu[j][k], av ^= (int) (wv[j][k] + t);
+#else
         ay = dot4_i8 (wy[j][k], t, ay);
         au = dot4_i8 (wu[j][k], t, au);
         av = dot4_i8 (wv[j][k], t, av);
+#endif
       }
       if (B == 0) {
         gw[i] = h420r_finish (ay);

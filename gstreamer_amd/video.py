@@ -11,7 +11,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgstamddsp.so")
-if os.environ.get("GSTAMD_TUNING_LIB") == "1":         # profiling sessions only: the -DGSTAMD_TUNING build (python -m gstreamer_amd.build --tuning)
+if os.environ.get("GSTAMD_LIB_PATH"):               # profiling sessions only: a variant built with python -m gstreamer_amd.build -DX=n --suffix=name
+    LIB_PATH = os.environ["GSTAMD_LIB_PATH"]
+elif os.environ.get("GSTAMD_TUNING_LIB") == "1":         # profiling sessions only: the -DGSTAMD_TUNING build (python -m gstreamer_amd.build --tuning)
     LIB_PATH = os.path.join(HERE, "lib", "libgstamddsp_tuning.so")
 
 FORMATS = {"I420": 2, "YV12": 3, "AYUV": 6, "RGBx": 7, "BGRx": 8, "xRGB": 9, "xBGR": 10, "RGBA": 11, "BGRA": 12,

@@ -19,8 +19,9 @@
  * _mixer_pad_get_output_size (compositor.c:290-412), and the visibility rules of prepare_frame_start (compositor.c:464-601):
  * frames with alpha 0, off the canvas or fully under an opaque pad never reach the GPU.  Pads of another format or size are
  * converted / scaled by a per-pad GstAmdVideoConverter with the library's default config (GstVideoAggregatorConvertPad).
- * Not here: converter-config, QoS and the latency bookkeeping of the base class; max-threads, ignore-inactive-pads and
- * max-last-buffer-repeat are accepted and have no effect.
+ * Not here: QoS and the latency bookkeeping of the base class.  max-threads is accepted and means nothing (the blend is one kernel launch
+ * per output frame), ignore-inactive-pads needs the 1.20 aggregator (gst_aggregator_pad_is_inactive) and is accepted without effect on
+ * the 1.14 runtime this image has.
  */
 #include <gst/base/gstaggregator.h>
 #include <gst/gst.h>
@@ -57,7 +58,9 @@ typedef struct {
   guint zorder;
   gint sizing_policy;          /* GstCompositorSizingPolicy: 0 none, 1 keep-aspect-ratio (compositor.c:207-232) */
   gboolean repeat_after_eos;   /* GstVideoAggregatorPad: keep showing the last frame after EOS (gstvideoaggregator.c:166-176) */
-  guint64 max_last_buffer_repeat;
+  guint64 max_last_buffer_repeat;   /* GstVideoAggregatorPad (gstvideoaggregator.c:282-303): ns past its end a frame is still shown without a successor */
+  GstStructure *converter_config;     /* GstVideoAggregatorConvertPad::converter-config (gstvideoaggregator.c:444-488), object lock */
+  gboolean converter_config_changed;
   GstVideoInfo info;            /* layout of `current` (and of the buffers taken since the last promoted CAPS event) */
   gboolean have_info;
   GstVideoInfo pending_info;    /* caps that arrived while a frame of the old caps is still shown (object lock) */
@@ -79,7 +82,7 @@ typedef struct {
 typedef struct { GstAggregatorPadClass parent_class; } GstAmdCompositorPadObjClass;
 
 enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_ZORDER,
-  PAD_PROP_SIZING_POLICY, PAD_PROP_REPEAT_AFTER_EOS, PAD_PROP_MAX_LAST_BUFFER_REPEAT };
+  PAD_PROP_SIZING_POLICY, PAD_PROP_REPEAT_AFTER_EOS, PAD_PROP_MAX_LAST_BUFFER_REPEAT, PAD_PROP_CONVERTER_CONFIG };
 
 G_DEFINE_TYPE (GstAmdCompositorPadObj, gst_amd_compositor_pad, GST_TYPE_AGGREGATOR_PAD);
 #define AMD_COMP_PAD(o) ((GstAmdCompositorPadObj *) (o))
@@ -121,6 +124,12 @@ amd_comp_pad_set_property (GObject * object, guint id, const GValue * value, GPa
     case PAD_PROP_SIZING_POLICY: p->sizing_policy = g_value_get_enum (value); break;
     case PAD_PROP_REPEAT_AFTER_EOS: p->repeat_after_eos = g_value_get_boolean (value); break;
     case PAD_PROP_MAX_LAST_BUFFER_REPEAT: p->max_last_buffer_repeat = g_value_get_uint64 (value); break;
+    case PAD_PROP_CONVERTER_CONFIG:
+      if (p->converter_config)
+        gst_structure_free (p->converter_config);
+      p->converter_config = g_value_dup_boxed (value);
+      p->converter_config_changed = TRUE;       /* the aggregate thread re-makes the pad's converter (gstvideoaggregator.c:468-476) */
+      break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (p);
@@ -142,6 +151,7 @@ amd_comp_pad_get_property (GObject * object, guint id, GValue * value, GParamSpe
     case PAD_PROP_SIZING_POLICY: g_value_set_enum (value, p->sizing_policy); break;
     case PAD_PROP_REPEAT_AFTER_EOS: g_value_set_boolean (value, p->repeat_after_eos); break;
     case PAD_PROP_MAX_LAST_BUFFER_REPEAT: g_value_set_uint64 (value, p->max_last_buffer_repeat); break;
+    case PAD_PROP_CONVERTER_CONFIG: g_value_set_boxed (value, p->converter_config); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (p);
@@ -156,6 +166,8 @@ amd_comp_pad_finalize (GObject * object)
   if (p->conv)
     gstamd_video_converter_free (p->conv);
   gst_buffer_replace (&p->current, NULL);
+  if (p->converter_config)
+    gst_structure_free (p->converter_config);
   G_OBJECT_CLASS (gst_amd_compositor_pad_parent_class)->finalize (object);
 }
 
@@ -199,6 +211,10 @@ gst_amd_compositor_pad_class_init (GstAmdCompositorPadObjClass * klass)
           "Repeat the last frame after EOS until all pads are EOS", FALSE, f));
   g_object_class_install_property (oc, PAD_PROP_MAX_LAST_BUFFER_REPEAT, g_param_spec_uint64 ("max-last-buffer-repeat", "Max Last Buffer Repeat",
           "Repeat last buffer for time (in ns, -1=until EOS), behaviour on EOS is not affected", 0, G_MAXUINT64, G_MAXUINT64, f));
+  /* GstVideoAggregatorConvertPad::converter-config (gstvideoaggregator.c:560-570) */
+  g_object_class_install_property (oc, PAD_PROP_CONVERTER_CONFIG, g_param_spec_boxed ("converter-config", "Converter configuration",
+          "A GstStructure describing the configuration that should be used when scaling and converting this pad's video frames", GST_TYPE_STRUCTURE,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
 }
 
 static void
@@ -716,6 +732,14 @@ amd_comp_pad_select (GstAmdCompositorPadObj * p, GstClockTime out_start, GstCloc
           gst_buffer_replace (&p->current, NULL);
         return TRUE;
       }
+      /* max-last-buffer-repeat (gstvideoaggregator.c:1984-2027): a frame that is over and has no successor yet goes on being shown -
+       * unless the output frame starts more than that many ns after its end (its start, for a frame without a duration): then the pad
+       * shows nothing until data arrives (a stalled network source falls back to the pads below it) */
+      if (p->current && GST_CLOCK_TIME_IS_VALID (p->max_last_buffer_repeat)) {
+        const GstClockTime ref_t = GST_CLOCK_TIME_IS_VALID (p->cur_end) ? p->cur_end : p->cur_start;
+        if (GST_CLOCK_TIME_IS_VALID (ref_t) && ref_t <= out_start && out_start - ref_t > p->max_last_buffer_repeat)
+          gst_buffer_replace (&p->current, NULL);
+      }
       /* an untimed frame is used once; a frame without a duration ends where the next one starts, which is not known yet */
       return p->current && GST_CLOCK_TIME_IS_VALID (p->cur_end) && p->cur_end >= out_end;
     }
@@ -912,10 +936,23 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
       const int ifmt = amd_pad_format_of (GST_VIDEO_INFO_FORMAT (&p->info));
       tw = pad_w[i];
       th = pad_h[i];
-      if (ifmt != fmt || tw != GST_VIDEO_INFO_WIDTH (&p->info) || th != GST_VIDEO_INFO_HEIGHT (&p->info)) {
-        /* GstVideoAggregatorConvertPad: library-default converter config (cubic), pad format / size -> canvas format / target size */
+      GstAmdVideoConverterConfig pcfg;
+      gboolean have_cfg, cfg_changed;
+      GST_OBJECT_LOCK (p);
+      have_cfg = p->converter_config != NULL;
+      cfg_changed = p->converter_config_changed;
+      p->converter_config_changed = FALSE;
+      if (have_cfg) {
+        gstamd_video_converter_config_init (&pcfg);
+        gst_amd_converter_config_from_structure (p->converter_config, &pcfg);
+      }
+      GST_OBJECT_UNLOCK (p);
+      /* GstVideoAggregatorConvertPad (gstvideoaggregator.c:479-513): a converter exists when the pad's frames differ from what the canvas
+       * wants - or when the pad has a converter-config, whose options (resampler method, alpha / chroma / matrix modes, dither ...) are the
+       * converter's; without one the library defaults apply (cubic) */
+      if (ifmt != fmt || tw != GST_VIDEO_INFO_WIDTH (&p->info) || th != GST_VIDEO_INFO_HEIGHT (&p->info) || have_cfg) {
         const gint key[6] = { ifmt, GST_VIDEO_INFO_WIDTH (&p->info), GST_VIDEO_INFO_HEIGHT (&p->info), fmt, tw, th };
-        if (!p->conv || memcmp (key, p->conv_key, sizeof (key)) != 0) {
+        if (!p->conv || cfg_changed || memcmp (key, p->conv_key, sizeof (key)) != 0) {
           GstAmdVideoInfo ai, ao;
           int status = 0;
           if (p->conv)
@@ -926,7 +963,7 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
               ao.color_range = c->out_info.colorimetry.range;
               ao.color_matrix = c->out_info.colorimetry.matrix;
             }
-            p->conv = gstamd_video_converter_new (&ai, &ao, NULL, &status);
+            p->conv = gstamd_video_converter_new (&ai, &ao, have_cfg ? &pcfg : NULL, &status);
             p->conv_out = ao;
           }
           if (!p->conv) {

@@ -75,4 +75,9 @@ void gst_amd_hip_memory_host_wait (GstMemory * mem);
 void gst_amd_hip_select_device (gint device_id);
 
 G_END_DECLS
+/* converter-config (a GstStructure of GstVideoConverter.* / GstVideoResampler.* options) -> the C ABI's config: library defaults for whatever
+ * the structure does not name (gstamdvideoconvertscale.c); shared with the compositor's per-pad converters */
+struct GstAmdVideoConverterConfig;
+void gst_amd_converter_config_from_structure (const GstStructure * st, struct GstAmdVideoConverterConfig * cfg);
+
 #endif

@@ -227,8 +227,8 @@ amd_cfg_number (const GstStructure * st, const gchar * key, gdouble * out)
 
 /* converter-config -> the C ABI's config: library defaults for whatever the structure does not name, exactly what
  * gst_video_converter_new does with it */
-static void
-amd_cfg_from_structure (const GstStructure * st, GstAmdVideoConverterConfig * cfg)
+void
+gst_amd_converter_config_from_structure (const GstStructure * st, GstAmdVideoConverterConfig * cfg)
 {
   gdouble d;
 #define OPT_I(key, field) if (amd_cfg_number (st, key, &d)) cfg->field = (gint) d
@@ -849,7 +849,7 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
     /* a user-provided converter-config replaces the element's own options altogether (gstvideoconvertscale.c:962-967): method,
      * borders, alpha / chroma / matrix modes then come from the structure or are the library's defaults */
     gstamd_video_converter_config_init (&cfg);
-    amd_cfg_from_structure (s->converter_config, &cfg);
+    gst_amd_converter_config_from_structure (s->converter_config, &cfg);
     GST_DEBUG_OBJECT (s, "using the user-provided converter-config %" GST_PTR_FORMAT, s->converter_config);
   }
   if (s->convert)

@@ -310,6 +310,36 @@ def test_compositor_element_scales_and_converts_pads(gst_env, ref):
     assert "inline-scaled %d" % n in log, log[-500:]
 
 
+def test_compositor_pad_converter_config(gst_env, ref):
+    """GstVideoAggregatorConvertPad::converter-config (gstvideoaggregator.c:444-488): the pad's converter takes its options from the
+    structure - nearest scaling on one pad, lanczos + alpha-mode=set on a converted NV12 pad - instead of the library defaults"""
+    env, tmp = gst_env
+    n, dw, dh = 2, 320, 240
+    f0, f1, fout = tmp / "cc0.bgra", tmp / "cc1.nv12", tmp / "cc_out.bgra"
+    cc0 = "GstVideoConverter,GstVideoConverter.resampler-method=(GstVideoResamplerMethod)nearest"
+    cc1 = "GstVideoConverter,GstVideoConverter.resampler-method=(GstVideoResamplerMethod)lanczos,GstVideoConverter.alpha-mode=(GstVideoAlphaMode)set,GstVideoConverter.alpha-value=(double)0.5"
+    r = subprocess.run([GST, "-q", "compositor", "name=c", "background=black", "sink_0::width=160", "sink_0::height=120", "sink_0::xpos=10", "sink_0::ypos=20",
+                        "sink_0::converter-config=" + cc0, "sink_1::xpos=150", "sink_1::ypos=100", "sink_1::width=128", "sink_1::height=96",
+                        "sink_1::converter-config=" + cc1, "!", "video/x-raw,format=BGRA,width=%d,height=%d" % (dw, dh), "!", "filesink", "location=%s" % fout]
+                       + ("videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=320,height=240,framerate=30/1 ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
+                          "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=NV12,width=256,height=192,framerate=30/1,colorimetry=bt601,chroma-site=jpeg ! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1"
+                          % (n, f0, n, f1)).split(), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    s0 = np.fromfile(f0, np.uint8).reshape(n, -1)
+    s1 = np.fromfile(f1, np.uint8).reshape(n, -1)
+    c0 = ref.VideoConverter("BGRA", 320, 240, "BGRA", 160, 120, config=ref.config_string(GstVideoConverter__resampler_method="nearest"))
+    c1 = ref.VideoConverter("NV12", 256, 192, "BGRA", 128, 96, in_colorimetry="bt601", in_chroma_site="jpeg",
+                            config=ref.config_string(GstVideoConverter__resampler_method="lanczos", GstVideoConverter__alpha_mode="set",
+                                                     GstVideoConverter__alpha_value=0.5))
+    for f in range(n):
+        canvas = np.zeros(dw * dh * 4, np.uint8)
+        ref.compositor_fill(1, "bgra", "BGRA", canvas, dw, dh, 0, dh, 0, 0, 0)
+        ref.compositor_blend("blend_bgra", "BGRA", c0.frame(s0[f]), 160, 120, 10, 20, 1.0, canvas, dw, dh, 0, dh, 1)
+        ref.compositor_blend("blend_bgra", "BGRA", c1.frame(s1[f]), 128, 96, 150, 100, 1.0, canvas, dw, dh, 0, dh, 1)
+        assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
+
+
 def test_compositor_element_on_a_64_bit_canvas(gst_env, ref):
     """ARGB64 output (compositor.c:1048-1053: blend_argb64 / overlay_argb64, 16-bit fills): an ARGB64 pad as it is and a BGRA
     pad brought to ARGB64 by the pad's converter, over the checker and over the transparent background."""

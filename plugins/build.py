@@ -24,7 +24,30 @@ def build():
     if r.stdout.strip():
         print(r.stdout)
     build_tools(inc)
+    check_against_reference_headers()
     return OUT
+
+
+def check_against_reference_headers():
+    """Second build target: every element source compiled (syntax / type check, -Werror=implicit-function-declaration) against the headers of
+    the reference's OWN version (1.29: /root/reference + the generated gstconfig.h / enumtypes headers of oracle/ref_build.py) - the API
+    subset the elements use must exist there with the same signatures.  Only where the reference tree is present (the build container)."""
+    ref = "/root/reference/subprojects"
+    gen = os.path.join(ROOT, "oracle", "_ref", "gen")
+    if not os.path.isdir(ref) or not os.path.isdir(os.path.join(gen, "gst")):
+        return None
+    inc = ["-DHAVE_CONFIG_H", "-I" + gen, "-I%s/gstreamer" % ref, "-I%s/gstreamer/libs" % ref, "-I%s/gst-plugins-base/gst-libs" % ref,
+           "-I%s/include/glib-2.0" % CONDA, "-I%s/lib/glib-2.0/include" % CONDA]
+    checked = []
+    for f in sorted(os.listdir(HERE)):
+        if not f.endswith(".c"):
+            continue
+        r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wno-deprecated-declarations", "-Werror=implicit-function-declaration",
+                            "-Werror=incompatible-pointer-types", os.path.join(HERE, f)] + inc, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("%s does not compile against the reference's 1.29 headers:\n%s" % (f, r.stdout[-3000:]))
+        checked.append(f)
+    return checked
 
 
 def build_tools(inc):

@@ -36,7 +36,14 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
  * every source format (widen, matrix16, u16 scalers, u16 chroma downsample, dither, pack); the combinations the library has no
  * kernel for make set_caps fail (not-negotiated) */
 #define AMD_OUT_FORMATS AMD_IN_FORMATS
-#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2 }"
+#if GST_CHECK_VERSION (1, 18, 0)
+#define AMD_NEWER_FORMATS ", VUYA, P012_LE, P016_LE, Y444_16LE"
+#elif GST_CHECK_VERSION (1, 16, 0)
+#define AMD_NEWER_FORMATS ", VUYA"
+#else
+#define AMD_NEWER_FORMATS ""
+#endif
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2" AMD_NEWER_FORMATS " }"
 
 /* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path
  * (video-converter.c:3304, 3383-3463), so interlaced caps are not negotiated rather than converted as if progressive
@@ -733,7 +740,15 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_I422_10LE, GSTAMD_VIDEO_FORMAT_I422_10LE}, {GST_VIDEO_FORMAT_Y444_10LE, GSTAMD_VIDEO_FORMAT_Y444_10LE},
     {GST_VIDEO_FORMAT_I420_12LE, GSTAMD_VIDEO_FORMAT_I420_12LE}, {GST_VIDEO_FORMAT_I422_12LE, GSTAMD_VIDEO_FORMAT_I422_12LE},
     {GST_VIDEO_FORMAT_Y444_12LE, GSTAMD_VIDEO_FORMAT_Y444_12LE},
-    /* VUYA, P012_LE, P016_LE, Y444_16LE (in the library) joined the format enum after 1.14, whose headers this builds against */
+    /* VUYA (1.16), P012_LE, P016_LE, Y444_16LE (1.18) joined the format enum after 1.14: there when the headers this is compiled
+     * against have them (plugins/build.py also type-checks every element against the reference's own 1.29 headers) */
+#if GST_CHECK_VERSION (1, 16, 0)
+    {GST_VIDEO_FORMAT_VUYA, GSTAMD_VIDEO_FORMAT_VUYA},
+#endif
+#if GST_CHECK_VERSION (1, 18, 0)
+    {GST_VIDEO_FORMAT_P012_LE, GSTAMD_VIDEO_FORMAT_P012_LE}, {GST_VIDEO_FORMAT_P016_LE, GSTAMD_VIDEO_FORMAT_P016_LE},
+    {GST_VIDEO_FORMAT_Y444_16LE, GSTAMD_VIDEO_FORMAT_Y444_16LE},
+#endif
   };
   int fmt = 0;
   for (i = 0; i < G_N_ELEMENTS (map); i++)

@@ -486,7 +486,7 @@ def gather_ranks(values, device, distributed, world):
 
 def stored_traffic(name):
     """HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    runs of this same command; scripts/gpu_round.sh).  A stored figure, not a per-run measurement: the source says so."""
+    runs of this same command; scripts/gpu_profiles.sh).  A stored figure, not a per-run measurement: the source says so."""
     for path in (os.path.join(ROOT, "profiles", "traffic_%s.json" % name),):
         if os.path.exists(path):
             try:

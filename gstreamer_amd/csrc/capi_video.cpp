@@ -52,6 +52,7 @@ struct GstAmdVideoConverter {
   struct PlaneDev { uint32_t *offset = nullptr; int16_t *taps = nullptr; };
   std::vector<std::vector<PlaneDev>> plane_dev;      // plane mode: tables of every pass of every plane
   uint8_t *plane_tmp = nullptr;           // plane mode: intermediate plane of a two-pass scale
+  void *ed_carry = nullptr;                // error-diffusion dither on rectangles taller than one band: the band's last line of errors (video_dither_ed.h)
   uint8_t *pk_img = nullptr;              // planar destinations: the chain's AYUV image before chroma downsample + pack
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
   bool reg420 = false;                    // first pass horizontal from a 4:2:0 source whose chroma pairing is the closed form of h420r_rows
@@ -464,6 +465,12 @@ static int build_tables (GstAmdVideoConverter *c)
     if ((e = hipMalloc ((void **) &c->pk_img, (size_t) p.out_info.width * 4 * (p.out_info.height + 1))) != hipSuccess)      /* + the line past the picture */
       return hip_fail (e, "hipMalloc(pack image)");
   }
+  {
+    const DitherParams &dp = p.out_planar ? p.pack.dither : p.dither;
+    if (dp.on && (dp.method == GSTAMD_DITHER_FLOYD_STEINBERG || dp.method == GSTAMD_DITHER_SIERRA_LITE) &&
+        (e = hipMalloc (&c->ed_carry, (size_t) (p.out_info.width + 4) * 8)) != hipSuccess)
+      return hip_fail (e, "hipMalloc(dither carry)");
+  }
   c->tables_ready = true;
   return GSTAMD_OK;
 }
@@ -688,7 +695,7 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
   r = convert_rect (c, pl, dest_rect, dest_rect_stride, stream);
   if (r == GSTAMD_OK && p.dither.on) {
     /* the dither stage (video_dither.h) over the converted rectangle of the packed destination */
-    hipError_t de = launch_dither4 (p.dither, (uint8_t *) dest_rect[0], dest_rect_stride[0], p.out_info.width, p.out_info.height, stream);
+    hipError_t de = launch_dither4 (p.dither, (uint8_t *) dest_rect[0], dest_rect_stride[0], p.out_info.width, p.out_info.height, stream, c->ed_carry);
     if (de != hipSuccess)
       return hip_fail (de, "k_dither4");
   }
@@ -764,7 +771,9 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
     r = convert_to_packed (c, pl, c->pk_img, p.out_info.width * 4, stream);
     if (r != GSTAMD_OK)
       return r;
-    hipError_t e = launch_pack_planar (p.pack, c->pk_img, p.out_info.width * 4, planes, strides, stream);
+    const bool diffusion = p.pack.dither.on && p.pack.dither.method != GSTAMD_DITHER_NONE && p.pack.dither.method != GSTAMD_DITHER_BAYER;
+    hipError_t e = diffusion ? launch_pack_planar_ed (p.pack, c->pk_img, p.out_info.width * 4, planes, strides, stream, c->ed_carry)
+        : launch_pack_planar (p.pack, c->pk_img, p.out_info.width * 4, planes, strides, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_pack_planar");
   }
   return convert_to_packed (c, pl, (uint8_t *) dest_planes[0], dest_stride ? dest_stride[0] : p.out_info.stride[0], stream);
@@ -1202,7 +1211,7 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     hipError_t e = launch_convert_pair (fp, p.front.chroma_h, n_frames, y.data (), uv.data (), d.data (), p.in_info.stride[0],
         p.in_info.stride[1], p.out_info.stride[0], (hipStream_t) stream_);
     for (int i = 0; i < n_frames && e == hipSuccess && p.dither.on; i++)
-      e = launch_dither4 (p.dither, d[i], p.out_info.stride[0], p.out_info.width, p.out_info.height, (hipStream_t) stream_);
+      e = launch_dither4 (p.dither, d[i], p.out_info.stride[0], p.out_info.width, p.out_info.height, (hipStream_t) stream_, c->ed_carry);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair(batch)");
   }
   /* one launch for the whole list through the bilinear 4:2:0 kernel as well (k_bilinear420_rows takes the frames as one grid) */
@@ -1224,7 +1233,7 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     if (ok && (p.out_info.stride[0] % 4) == 0) {
       hipError_t e = launch_bilinear420_frames (bp, p.front.chroma_h, n_frames, pls.data (), d.data (), p.out_info.stride[0], (hipStream_t) stream_);
       for (int i = 0; i < n_frames && e == hipSuccess && p.dither.on; i++)
-        e = launch_dither4 (p.dither, d[i], p.out_info.stride[0], p.out_info.width, p.out_info.height, (hipStream_t) stream_);
+        e = launch_dither4 (p.dither, d[i], p.out_info.stride[0], p.out_info.width, p.out_info.height, (hipStream_t) stream_, c->ed_carry);
       if (e != hipErrorNotSupported)
         return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420(batch)");
     }
@@ -1286,6 +1295,9 @@ static void release_tables (GstAmdVideoConverter *c)
   c->mfma_ok = false;
   if (c->pk_img)
     (void) hipFree (c->pk_img);
+  if (c->ed_carry)
+    (void) hipFree (c->ed_carry);
+  c->ed_carry = nullptr;
   if (c->plane_tmp)
     (void) hipFree (c->plane_tmp);
   c->tmp = c->pk_img = c->plane_tmp = nullptr;
@@ -1603,6 +1615,8 @@ int gstamd_video_converter_is_reentrant (GstAmdVideoConverter *c)
   const VideoPlan &p = c->plan;
   if (p.gamma.on || p.plane_mode || p.out_planar || (p.deep16 && !p.passes.empty ()))
     return 0;                   /* plane_tmp / pk_img / the 16-bit scratch images: one set per converter */
+  if (c->ed_carry)
+    return 0;                   /* the error-diffusion carry line */
   if (p.passes.size () == 2) {
     const auto small_kind = [](int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; };
     if (!(small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)))

@@ -2135,14 +2135,18 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path (10-bit destinations dither by default: "
           "choose bayer or none)");
   } else if (cfg.dither_quantization > 1 && cfg.dither_method != GSTAMD_DITHER_NONE) {
-    if (cfg.dither_method != GSTAMD_DITHER_BAYER)
-      return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods (verterr, floyd-steinberg, sierra-lite: video-dither.c:75-225) carry "
-          "errors from pixel to pixel and line to line; only bayer and none are implemented on the GPU path");
+    /* verterr / floyd-steinberg / sierra-lite (video_dither_ed.h) clear their error line when the FRAME's line 0 comes by (video-dither.c:82,
+       124, 192: y == 0, and y counts from the frame's top): with a destination rectangle that starts lower the errors of one frame's last
+       line run into the next frame's first - the output would depend on the frames converted before */
+    if (cfg.dither_method != GSTAMD_DITHER_BAYER && plan->rect.out_y != 0)
+      return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither into a destination rectangle below the frame's first line: the reference never clears the "
+          "error line there (y == 0 is the frame's line 0), so every frame depends on the one before");
     int shift = 0;
     for (unsigned q = cfg.dither_quantization; q > 1; q >>= 1)
       shift++;
-    if (shift > 8)
-      shift = 8;
+    const bool diffusion = cfg.dither_method != GSTAMD_DITHER_BAYER;
+    if (shift > (diffusion ? 16 : 8))             /* the error methods mask a guint16 (GstVideoDither::mask), the ordered one adds a byte-sized matrix value */
+      shift = diffusion ? 16 : 8;
     if (plan->out_planar) {
       /* planar / semi-planar / 3-byte / packed 4:2:2 destinations: the stage sits between chroma downsampling and packing - it is
          part of the pack kernel (PackPlanarParams::dither, shift[] in unpack order); none of these formats has an alpha component */

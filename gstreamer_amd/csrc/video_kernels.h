@@ -30,7 +30,11 @@ hipError_t launch_deep_planes (const DeepPlanesParams &d, const DeepPlanesPtrs &
 hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *src, int sstride, uint8_t *const planes[3],
     const int strides[3], hipStream_t stream);
 hipError_t launch_gamma_stage (const GammaDev &g, int mask, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int w, int h, hipStream_t stream);
-hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream);
+// method bayer / none: k_dither4; verterr: k_dither_verterr; floyd-steinberg / sierra-lite: k_dither_ed, which wants `ed_carry` (w x 8 bytes of
+// device memory) for rectangles taller than 1024 lines
+hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream, void *ed_carry = nullptr);
+hipError_t launch_pack_planar_ed (const PackPlanarParams &pk, uint8_t *img, int sstride, uint8_t *const planes[3], const int strides[3],
+    hipStream_t stream, void *ed_carry);
 hipError_t launch_dither16_image (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream);
 struct Deep16Image;
 hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, uint8_t *img, int istride, hipStream_t stream);

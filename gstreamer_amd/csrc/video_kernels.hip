@@ -24,6 +24,7 @@
 #include "video_planes.h"
 #include "video_deep.h"
 #include "video_dither.h"
+#include "video_dither_ed.h"
 #include "video_gamma.h"
 
 namespace gstamd {
@@ -181,8 +182,98 @@ __global__ __launch_bounds__ (256) void k_dither4 (DitherParams d, uint8_t *__re
   dither_lane4 (d, img, stride, w, h, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
 }
 
-hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream)
+// vertical error carry (dither_verterr_u8): a lane per column walks down the rectangle, the error in registers; the loads of a column do
+// not depend on the recurrence, so they run ahead
+__global__ __launch_bounds__ (256) void k_dither_verterr (DitherParams d, uint8_t *__restrict__ img, int stride, int w, int h)
 {
+  const int x = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+  if (x >= w)
+    return;
+  Err4 e = err4_zero ();
+  uint32_t *p = (uint32_t *) img + x;
+#pragma unroll 8
+  for (int y = 0; y < h; y++) {
+    uint32_t *q = (uint32_t *) ((uint8_t *) p + (size_t) y * stride);
+    *q = ed_verterr_px (d, *q, e);
+  }
+}
+
+// Floyd-Steinberg / Sierra Lite (video_dither_ed.h): lane r = line band + r, three pixels behind lane r - 1; the errors a line leaves for
+// the next sit in a 4-slot LDS ring per line (slot (x + 1) & 3 = pixel x: the line below reads pixels x' .. x' + 2 one to three steps after
+// they were written and the slot is rewritten at the fourth); the last line of a 1024-line band hands its errors to the next band through
+// `carry` (w entries in HBM).  One workgroup: the recurrence is serial in x and y, the wavefront is all the parallelism there is.
+#define GSTAMD_ED_LINES 1024
+template <int METHOD>
+__global__ __launch_bounds__ (GSTAMD_ED_LINES) void k_dither_ed (DitherParams d, uint8_t *__restrict__ img, int stride, int w, int h, Err4 *__restrict__ carry)
+{
+  __shared__ Err4 ring[GSTAMD_ED_LINES][4];
+  __shared__ Err4 a0s[GSTAMD_ED_LINES];
+  __shared__ Err4 a0_carry;
+  const int r = (int) threadIdx.x;
+  for (int band = 0; band < h; band += GSTAMD_ED_LINES) {
+    const int rows = h - band < GSTAMD_ED_LINES ? h - band : GSTAMD_ED_LINES;
+    const int y = band + r;
+    const bool active = r < rows, to_carry = r == rows - 1 && band + rows < h;
+    uint32_t *row = (uint32_t *) (img + (size_t) (active ? y : band) * stride);
+    Err4 left = err4_zero ();
+    const int nsteps = w + 3 * (rows - 1);
+    uint32_t next_px = active && r == 0 ? row[0] : 0u;
+    for (int s = 0; s < nsteps; s++) {
+      const int x = s - 3 * r;
+      const uint32_t px = next_px;
+      if (active && x + 1 >= 0 && x + 1 < w)
+        next_px = row[x + 1];                     /* in flight across the barrier */
+      if (active && x >= 0 && x < w) {
+        Err4 p[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int j = x + k;
+          if (y == 0 || j >= w)
+            p[k] = err4_zero ();
+          else if (r == 0)
+            p[k] = carry[j];
+          else
+            p[k] = ring[r - 1][(j + 1) & 3];
+        }
+        uint32_t out;
+        if (METHOD == GSTAMD_DITHER_FLOYD_STEINBERG) {
+          Err4 a0 = err4_zero ();
+          if (x == 0)
+            left = y == 0 ? err4_zero () : (r == 0 ? a0_carry : a0s[r - 1]);
+          out = ed_floyd_px (d, px, left, p[0], p[1], p[2], x == 0, x == w - 1, &a0);
+          if (x == 0) {
+            a0s[r] = a0;
+            if (to_carry)
+              a0_carry = a0;
+          }
+        } else {
+          out = ed_sierra_px (d, px, left, p[1], p[2]);
+        }
+        row[x] = out;
+        ring[r][(x + 1) & 3] = left;
+        if (to_carry)
+          carry[x] = left;
+      }
+      __syncthreads ();
+    }
+  }
+}
+
+hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream, void *ed_carry)
+{
+  if (d.method == GSTAMD_DITHER_VERTERR) {
+    hipLaunchKernelGGL (k_dither_verterr, dim3 ((w + 255) / 256), dim3 (256), 0, stream, d, img, stride, w, h);
+    return hipGetLastError ();
+  }
+  if (d.method == GSTAMD_DITHER_FLOYD_STEINBERG || d.method == GSTAMD_DITHER_SIERRA_LITE) {
+    if (h > GSTAMD_ED_LINES && !ed_carry)
+      return hipErrorInvalidValue;
+    if (d.method == GSTAMD_DITHER_FLOYD_STEINBERG)
+      hipLaunchKernelGGL (k_dither_ed<GSTAMD_DITHER_FLOYD_STEINBERG>, dim3 (1), dim3 (GSTAMD_ED_LINES), 0, stream, d, img, stride, w, h, (Err4 *) ed_carry);
+    else
+      hipLaunchKernelGGL (k_dither_ed<GSTAMD_DITHER_SIERRA_LITE>, dim3 (1), dim3 (GSTAMD_ED_LINES), 0, stream, d, img, stride, w, h, (Err4 *) ed_carry);
+    return hipGetLastError ();
+  }
   dim3 grid ((w / 4 + 256) / 256, h);
   hipLaunchKernelGGL (k_dither4, grid, dim3 (256), 0, stream, d, img, stride, w, h);
   return hipGetLastError ();
@@ -1296,6 +1387,36 @@ hipError_t launch_encode420 (const Enc420Params &ep, bool semi, const uint8_t *s
   else
     hipLaunchKernelGGL (k_encode420<0>, grid, dim3 (64), 0, stream, ep, src, sstride, d);
   return hipGetLastError ();
+}
+
+__global__ __launch_bounds__ (256) void k_pack_down_v (PackPlanarParams pk, uint8_t *__restrict__ img, int stride)
+{
+  pack_down_v_px (pk, img, stride, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+__global__ __launch_bounds__ (256) void k_pack_down_h (PackPlanarParams pk, uint8_t *__restrict__ img, int stride)
+{
+  pack_down_h_px (pk, img, stride, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+// error-diffusion dither ahead of a planar / 3-byte / packed 4:2:2 pack: the chroma downsamplers in place on the AYUV image, the dither
+// pass over every pixel of it, then the pack kernel as a pure selection (video_pack.h pack_select_only)
+hipError_t launch_pack_planar_ed (const PackPlanarParams &pk, uint8_t *img, int sstride, uint8_t *const planes[3], const int strides[3],
+    hipStream_t stream, void *ed_carry)
+{
+  const int rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
+  const dim3 grid ((pk.width + 255) / 256, rows);
+  if (pk.down_v)
+    hipLaunchKernelGGL (k_pack_down_v, grid, dim3 (256), 0, stream, pk, img, sstride);
+  if (pk.down_h && pk.w_sub == 1)
+    hipLaunchKernelGGL (k_pack_down_h, grid, dim3 (256), 0, stream, pk, img, sstride);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return e;
+  DitherParams d = pk.dither;
+  if ((e = launch_dither4 (d, img, sstride, pk.width, pk.height, stream, ed_carry)) != hipSuccess)
+    return e;
+  return launch_pack_planar (pack_select_only (pk), img, sstride, planes, strides, stream);
 }
 
 hipError_t launch_pack_planar (const PackPlanarParams &pk, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],

@@ -124,4 +124,49 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__re
   }
 }
 
+// The chroma downsamplers alone, on the AYUV image in place, exactly as the reference's line caches leave the lines (the error-diffusion
+// dither methods read every pixel of every line afterwards, also the chroma the packers never store): first the vertical pass - U, V of
+// every pixel of the pair's first line become the average - then, on that line (every line without vertical subsampling), the
+// horizontal pass rewrites the even pixels from their unchanged odd neighbours.  Two launches: each is free of read-after-write overlap.
+GSTAMD_HD void pack_down_v_px (const PackPlanarParams &pk, uint8_t *img, int stride, int x, int yb)
+{
+  const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
+  if (x >= w || y0 >= h || !pk.down_v)
+    return;
+  uint32_t *ra = (uint32_t *) (img + (size_t) y0 * stride);
+  const uint32_t *rb = (const uint32_t *) (img + (size_t) (y0 + 1 < h ? y0 + 1 : (pk.virtual_line ? h : h - 1)) * stride);
+  const uint32_t c = ((ayuv_uv (ra[x]) + ayuv_uv (rb[x]) + 0x00010001u) >> 1) & 0x00ff00ffu;
+  ra[x] = (ra[x] & 0xffffu) | ((c & 0xffu) << 16) | ((c >> 16) << 24);
+}
+
+GSTAMD_HD void pack_down_h_px (const PackPlanarParams &pk, uint8_t *img, int stride, int x, int yb)
+{
+  const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
+  if (x >= w || y0 >= h || pk.w_sub != 1 || !pk.down_h || (x & 1))
+    return;
+  uint32_t *ra = (uint32_t *) (img + (size_t) y0 * stride);
+  const uint32_t c0 = ayuv_uv (ra[x]), cm = ayuv_uv (ra[x > 0 ? x - 1 : 0]), cp = ayuv_uv (ra[x + 1 < w ? x + 1 : w - 1]);
+  uint32_t c = c0;
+  if (pk.down_h == 1) {
+    if (x + 1 < w)
+      c = ((c0 + cp + 0x00010001u) >> 1) & 0x00ff00ffu;
+  } else if (pk.down_h == 2 && w >= 2) {
+    if (x == 0)
+      c = ((3u * c0 + cp + 0x00020002u) >> 2) & 0x00ff00ffu;
+    else if (x < w - 2)
+      c = ((cm + 2u * c0 + cp + 0x00020002u) >> 2) & 0x00ff00ffu;
+    else
+      c = ((cm + 3u * c0 + 0x00020002u) >> 2) & 0x00ff00ffu;
+  }
+  ra[x] = (ra[x] & 0xffffu) | ((c & 0xffu) << 16) | ((c >> 16) << 24);
+}
+
+// the packer's view of the image once the downsamplers and the dither stage have run over it: selection only
+inline PackPlanarParams pack_select_only (PackPlanarParams pk)     /* host */
+{
+  pk.down_h = pk.down_v = 0;
+  pk.dither.on = 0;
+  return pk;
+}
+
 }  // namespace gstamd

@@ -1185,6 +1185,7 @@ gst_amd_compositor_class_init (GstAmdCompositorClass * klass)
   GstAggregatorClass *ac = (GstAggregatorClass *) klass;
 
   GST_DEBUG_CATEGORY_INIT (amd_comp_debug, "amdcompositor", 0, "MI355X compositor");
+  gst_amd_converter_config_register_types ();
   oc->set_property = amd_comp_set_property;
   oc->get_property = amd_comp_get_property;
   g_object_class_install_property (oc, PROP_BACKGROUND, g_param_spec_enum ("background", "Background", "Background type",

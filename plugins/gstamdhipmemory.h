@@ -79,5 +79,6 @@ G_END_DECLS
  * the structure does not name (gstamdvideoconvertscale.c); shared with the compositor's per-pad converters */
 struct GstAmdVideoConverterConfig;
 void gst_amd_converter_config_from_structure (const GstStructure * st, struct GstAmdVideoConverterConfig * cfg);
+void gst_amd_converter_config_register_types (void);
 
 #endif

@@ -232,6 +232,21 @@ amd_cfg_number (const GstStructure * st, const gchar * key, gdouble * out)
   return TRUE;
 }
 
+/* A converter-config written on a command line names its enum fields by type - GstVideoConverter.resampler-method=(GstVideoResamplerMethod)lanczos -
+ * and gst_structure_from_string only finds types that are registered by then: the elements that take such a structure register them
+ * with their class */
+void
+gst_amd_converter_config_register_types (void)
+{
+  g_type_class_unref (g_type_class_ref (gst_video_resampler_method_get_type ()));
+  g_type_class_unref (g_type_class_ref (gst_video_dither_method_get_type ()));
+  g_type_class_unref (g_type_class_ref (gst_video_alpha_mode_get_type ()));
+  g_type_class_unref (g_type_class_ref (gst_video_chroma_mode_get_type ()));
+  g_type_class_unref (g_type_class_ref (gst_video_matrix_mode_get_type ()));
+  g_type_class_unref (g_type_class_ref (gst_video_gamma_mode_get_type ()));
+  g_type_class_unref (g_type_class_ref (gst_video_primaries_mode_get_type ()));
+}
+
 /* converter-config -> the C ABI's config: library defaults for whatever the structure does not name, exactly what
  * gst_video_converter_new does with it */
 void
@@ -1304,6 +1319,8 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
   static const GEnumValue primaries_v[] = {{0, "disable conversion between primaries", "none"},
     {1, "do conversion between primaries only when it can be merged with color matrix conversion", "merge-only"},
     {2, "fast conversion between primaries", "fast"}, {0, NULL, NULL}};
+
+  gst_amd_converter_config_register_types ();
 
   GST_DEBUG_CATEGORY_INIT (amd_vcs_debug, "amdvideoconvertscale", 0, "MI355X videoconvertscale");
   GST_DEBUG_CATEGORY_GET (CAT_PERFORMANCE, "GST_PERFORMANCE");

@@ -564,6 +564,24 @@ VIDEO_CASES = [
     ("nv12_i420_67x3_line_past_picture", "NV12", 67, 3, "I420", 67, 3, {}, "bt601", "mpeg2", "random"),
     ("i420_nv21_45x31_bt601_bt709_line_past_picture", "I420", 45, 31, "NV21", 45, 31, {}, "bt601>bt709", None, "random"),
     ("nv21_yv12_64x47_cosited_dither_line_past_picture", "NV21", 64, 47, "YV12", 64, 47, dict(dither_quantization=4), "bt709>bt601", "cosited", "random"),
+    # the error-diffusion methods on 8-bit lines (round 3, video_dither_ed.h): packed destinations in place, planar ones between the
+    # chroma downsamplers and a selecting pack; more than 1024 lines = more than one band of the wavefront kernel
+    ("ed_nv12_bgra_floyd_q4", "NV12", 64, 64, "BGRA", 64, 64, dict(dither_quantization=4, dither_method="floyd-steinberg"), None, None, "random"),
+    ("ed_nv12_bgrx_sierra_q16", "NV12", 64, 36, "BGRx", 64, 36, dict(dither_quantization=16, dither_method="sierra-lite"), None, None, "random"),
+    ("ed_nv12_argb_verterr_q8_odd", "NV12", 35, 19, "ARGB", 35, 19, dict(dither_quantization=8, dither_method="verterr"), None, None, "random"),
+    ("ed_bgra_ayuv_floyd_q64_alpha", "BGRA", 33, 21, "AYUV", 33, 21, dict(dither_quantization=64, dither_method="floyd-steinberg"), None, None, "random"),
+    ("ed_bgra_rgba_floyd_q256_1px_wide", "BGRA", 1, 9, "RGBA", 1, 9, dict(dither_quantization=256, dither_method="floyd-steinberg"), None, None, "random"),
+    ("ed_bgra_rgba_sierra_q4_2px_wide", "BGRA", 2, 9, "RGBA", 2, 9, dict(dither_quantization=4, dither_method="sierra-lite"), None, None, "random"),
+    ("ed_nv12_bgra_floyd_q2_two_bands", "NV12", 48, 1100, "BGRA", 48, 1100, dict(dither_quantization=2, dither_method="floyd-steinberg"), None, None, "random"),
+    ("ed_nv12_bgra_sierra_q8_three_bands", "NV12", 20, 2060, "BGRA", 20, 2060, dict(dither_quantization=8, dither_method="sierra-lite"), None, None, "ramp"),
+    ("ed_i420_rgba_floyd_q4_lanczos_down_dest_x", "I420", 640, 360, "RGBA", 220, 120, dict(LAN, dither_quantization=4, dither_method="floyd-steinberg", dest_x=7, dest_y=0, dest_width=213, dest_height=120), None, None, "random"),
+    ("ed_nv12_i420_floyd_q4", "NV12", 64, 64, "I420", 64, 64, dict(dither_quantization=4, dither_method="floyd-steinberg"), None, None, "random"),
+    ("ed_bgra_nv12_sierra_q8_odd", "BGRA", 67, 35, "NV12", 67, 35, dict(dither_quantization=8, dither_method="sierra-lite"), None, None, "random"),
+    ("ed_bgra_yuy2_verterr_q4", "BGRA", 64, 48, "YUY2", 64, 48, dict(dither_quantization=4, dither_method="verterr"), None, None, "random"),
+    ("ed_nv12_rgb_floyd_q16", "NV12", 64, 48, "RGB", 64, 48, dict(dither_quantization=16, dither_method="floyd-steinberg"), None, None, "random"),
+    ("ed_bgra_y42b_floyd_q4_cosited", "BGRA", 66, 30, "Y42B", 66, 30, dict(dither_quantization=4, dither_method="floyd-steinberg"), None, "cosited", "random"),
+    ("ed_nv21_yv12_64x47_sierra_line_past_picture", "NV21", 64, 47, "YV12", 64, 47, dict(dither_quantization=4, dither_method="sierra-lite"), "bt709>bt601", "cosited", "random"),
+    ("ed_ayuv_y444_verterr_q2", "AYUV", 33, 17, "Y444", 33, 17, dict(dither_quantization=2, dither_method="verterr"), None, None, "random"),
     # dither-quantization > 1 into ARGB64 / AYUV64 (round 3): the stage ahead of the copying packer, alpha included (depth 16 like the rest)
     ("dither64_vuya_ayuv64_shrink_q2", "VUYA", 33, 40, "AYUV64", 8, 18, dict(dither_quantization=2), None, None, "random"),
     ("dither64_bgra_argb64_q16", "BGRA", 64, 48, "ARGB64", 64, 48, dict(dither_quantization=16), None, None, "random"),
@@ -579,7 +597,9 @@ VISIBLE_ONLY = {"uyvy_yv12_33x17_fastpath", "uyvy_y444_33x18_fastpath", "uyvy_yu
 
 # conversions the reference runs through code this library has no kernel for -> must be REFUSED ("not built", never approximated)
 VIDEO_REFUSED = [
-    ("NV12", 64, 64, "BGRA", 64, 64, dict(dither_quantization=4, dither_method="floyd-steinberg")),   # error diffusion: sequential
+    # error diffusion below the frame's first line: the reference's error line is never cleared there, frames depend on each other
+    ("NV12", 64, 64, "BGRA", 64, 70, dict(dither_quantization=4, dither_method="floyd-steinberg", dest_x=0, dest_y=3, dest_width=64, dest_height=64)),
+    ("NV12", 64, 64, "P010_10LE", 64, 64, dict(dither_method="sierra-lite")),           # error diffusion on 16-bit lines
     ("BGRA", 67, 36, "AYUV", 76, 21, dict(alpha_mode="mult", alpha_value=0.5)),    # alpha stage on MIN (in_width, out_width) pixels of a wider line
     ("YV12", 11, 21, "Y444_16LE", 85, 12, NEAR),         # nearest vertical scaling of 4:2:0 through the composite plans
     ("P010_10LE", 31, 13, "NV12", 23, 13, {}),           # the same through the composite plans

@@ -24,6 +24,7 @@
 #include "../../gstreamer_amd/csrc/video_deep.h"
 #include "../../gstreamer_amd/csrc/video_gamma.h"
 #include "../../gstreamer_amd/csrc/video_dither.h"
+#include "../../gstreamer_amd/csrc/video_dither_ed.h"
 
 using namespace gstamd;
 
@@ -998,13 +999,28 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       d.stride[i] = out->stride[i];
     }
     const int rows = (p.out_info.height + (1 << p.pack.h_sub) - 1) >> p.pack.h_sub;
+    PackPlanarParams pk = p.pack;
+    if (pk.dither.on && pk.dither.method != GSTAMD_DITHER_NONE && pk.dither.method != GSTAMD_DITHER_BAYER) {
+      /* launch_pack_planar_ed: k_pack_down_v, k_pack_down_h, the dither pass, then selection only */
+      for (int pass = 0; pass < 2; pass++)
+        for (int yb = 0; yb < rows; yb++)
+          for (int x = 0; x < p.out_info.width; x++)
+            if (pass == 0)
+              pack_down_v_px (pk, img.data (), p.out_info.width * 4, x, yb);
+            else
+              pack_down_h_px (pk, img.data (), p.out_info.width * 4, x, yb);
+      ed_image_host (pk.dither, img.data (), p.out_info.width * 4, p.out_info.width, p.out_info.height);
+      pk = pack_select_only (pk);
+    }
     for (int yb = 0; yb < rows; yb++)
       for (int x0 = 0; x0 < p.out_info.width; x0 += 4)
-        pack_planar_body (p.pack, img.data (), p.out_info.width * 4, d, x0, yb);
+        pack_planar_body (pk, img.data (), p.out_info.width * 4, d, x0, yb);
     return GSTAMD_OK;
   }
   r = emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok, false);
-  if (r == GSTAMD_OK && p.dither.on)               /* k_dither4 over the converted rectangle */
+  if (r == GSTAMD_OK && p.dither.on && p.dither.method != GSTAMD_DITHER_NONE && p.dither.method != GSTAMD_DITHER_BAYER)
+    ed_image_host (p.dither, dst + out->offset[0], out->stride[0], p.out_info.width, p.out_info.height);          /* k_dither_verterr / k_dither_ed */
+  else if (r == GSTAMD_OK && p.dither.on)               /* k_dither4 over the converted rectangle */
     for (int y = 0; y < p.out_info.height; y++)
       for (int x0 = 0; x0 < p.out_info.width; x0 += 4)
         dither_lane4 (p.dither, dst + out->offset[0], out->stride[0], p.out_info.width, p.out_info.height, x0, y);

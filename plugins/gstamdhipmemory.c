@@ -64,10 +64,10 @@ stream_slot_locked (gpointer stream)
   return free_slot;             /* -1: table full, the ticket falls back to plain event queries */
 }
 
-GstAmdHipTicket *
-gst_amd_hip_ticket_new (gpointer stream)
+/* record an event for `t` on `stream` (the free list first: creating an event costs more than recording it) */
+static gboolean
+ticket_record (GstAmdHipTicket * t, gpointer stream)
 {
-  GstAmdHipTicket *t;
   gpointer ev = NULL;
 
   g_mutex_lock (&ticket_lock);
@@ -81,17 +81,147 @@ gst_amd_hip_ticket_new (gpointer stream)
   if (!ev || gstamd_event_record (ev, stream) != GSTAMD_OK) {
     gstamd_event_free (ev);
     gstamd_stream_synchronize (stream);       /* no event: fall back to a host wait, nothing is pending afterwards */
-    return NULL;
+    return FALSE;
   }
-  t = g_new0 (GstAmdHipTicket, 1);
   t->event = ev;
-  t->refcount = 1;
+  t->stream = stream;
   g_mutex_lock (&ticket_lock);
   t->stream_slot = stream_slot_locked (stream);
   if (t->stream_slot >= 0)
     t->seq = stream_table[t->stream_slot].next_seq++;
   g_mutex_unlock (&ticket_lock);
+  return TRUE;
+}
+
+/* a place in the stream's order, no event; FALSE when the stream table is full (the caller records an event instead) */
+static gboolean
+ticket_make_lazy (GstAmdHipTicket * t, gpointer stream)
+{
+  g_mutex_lock (&ticket_lock);
+  t->stream_slot = stream_slot_locked (stream);
+  if (t->stream_slot >= 0)
+    t->seq = stream_table[t->stream_slot].next_seq++;
+  g_mutex_unlock (&ticket_lock);
+  if (t->stream_slot < 0)
+    return FALSE;
+  t->stream = stream;
+  g_atomic_int_set (&t->lazy, 1);
+  return TRUE;
+}
+
+/* the event of a lazy ticket, recorded now unless its stream has been retired or seen past it; the table lock keeps the stream alive */
+static void
+ticket_unlazy (GstAmdHipTicket * t)
+{
+  if (!t || !g_atomic_int_get (&t->lazy))
+    return;
+  g_mutex_lock (&ticket_lock);
+  if (g_atomic_int_get (&t->lazy)) {
+    if (t->seq > stream_table[t->stream_slot].done_seq) {
+      gpointer ev = NULL;
+      if (free_events) {
+        ev = free_events->data;
+        free_events = g_slist_delete_link (free_events, free_events);
+      }
+      if (!ev)
+        ev = gstamd_event_new ();
+      if (ev && gstamd_event_record (ev, t->stream) == GSTAMD_OK) {
+        t->event = ev;
+      } else {
+        gstamd_event_free (ev);
+        gstamd_stream_synchronize (t->stream);
+      }
+    }
+    g_atomic_int_set (&t->lazy, 0);
+  }
+  g_mutex_unlock (&ticket_lock);
+}
+
+void
+gst_amd_hip_stream_retire (gpointer stream)
+{
+  gint i;
+
+  if (!stream)
+    return;
+  gstamd_stream_synchronize (stream);
+  g_mutex_lock (&ticket_lock);
+  for (i = 0; i < AMD_STREAM_SLOTS; i++)
+    if (stream_table[i].next_seq && stream_table[i].stream == stream)
+      stream_table[i].done_seq = stream_table[i].next_seq - 1;
+  g_mutex_unlock (&ticket_lock);
+}
+
+GstAmdHipTicket *
+gst_amd_hip_ticket_new_lazy (gpointer stream)
+{
+  GstAmdHipTicket *t = g_new0 (GstAmdHipTicket, 1);
+
+  t->refcount = 1;
+  t->stream_slot = -1;
+  if (!ticket_make_lazy (t, stream) && !ticket_record (t, stream)) {
+    g_free (t);
+    return NULL;
+  }
   return t;
+}
+
+GstAmdHipTicket *
+gst_amd_hip_ticket_new (gpointer stream)
+{
+  GstAmdHipTicket *t = g_new0 (GstAmdHipTicket, 1);
+
+  t->refcount = 1;
+  t->stream_slot = -1;
+  if (!ticket_record (t, stream)) {
+    g_free (t);
+    return NULL;
+  }
+  return t;
+}
+
+GstAmdHipTicket *
+gst_amd_hip_ticket_new_deferred (void (*launch) (gpointer owner), gpointer owner, GDestroyNotify owner_unref)
+{
+  GstAmdHipTicket *t = g_new0 (GstAmdHipTicket, 1);
+
+  t->refcount = 1;
+  t->stream_slot = -1;
+  t->launch = launch;
+  t->owner = owner;
+  t->owner_unref = owner_unref;
+  t->deferred = 1;
+  return t;
+}
+
+void
+gst_amd_hip_ticket_resolve (GstAmdHipTicket * t, gpointer stream, gboolean lazy)
+{
+  if (!t || !g_atomic_int_get (&t->deferred))
+    return;
+  if (stream && !(lazy && ticket_make_lazy (t, stream)))
+    ticket_record (t, stream);          /* no event (failure or none to be had): the ticket counts as done */
+  g_atomic_int_set (&t->deferred, 0);
+}
+
+/* before anybody looks at the ticket's event: have deferred work launched (the owner serialises concurrent callers and resolves the
+ * ticket before launch returns) */
+static void
+ticket_settle (GstAmdHipTicket * t)
+{
+  if (t && g_atomic_int_get (&t->deferred))
+    t->launch (t->owner);
+}
+
+static void
+ticket_host_wait (GstAmdHipTicket * t)
+{
+  if (!t)
+    return;
+  ticket_settle (t);
+  ticket_unlazy (t);
+  if (t->event)
+    gstamd_event_synchronize (t->event);
 }
 
 gboolean
@@ -100,6 +230,16 @@ gst_amd_hip_ticket_is_done (GstAmdHipTicket * t)
   gboolean done = FALSE;
 
   if (!t)
+    return TRUE;
+  if (g_atomic_int_get (&t->deferred))
+    return FALSE;               /* not even launched; a mere completion check does not force the launch */
+  if (g_atomic_int_get (&t->lazy)) {
+    g_mutex_lock (&ticket_lock);
+    done = t->seq <= stream_table[t->stream_slot].done_seq;
+    g_mutex_unlock (&ticket_lock);
+    return done;                /* no event to ask; a later ticket of the stream (or its retirement) will tell */
+  }
+  if (!t->event)
     return TRUE;
   g_mutex_lock (&ticket_lock);
   if (t->stream_slot >= 0 && t->seq <= stream_table[t->stream_slot].done_seq)
@@ -129,9 +269,13 @@ gst_amd_hip_ticket_unref (GstAmdHipTicket * t)
 {
   if (!t || !g_atomic_int_dec_and_test (&t->refcount))
     return;
-  g_mutex_lock (&ticket_lock);
-  free_events = g_slist_prepend (free_events, t->event);
-  g_mutex_unlock (&ticket_lock);
+  if (t->event) {
+    g_mutex_lock (&ticket_lock);
+    free_events = g_slist_prepend (free_events, t->event);
+    g_mutex_unlock (&ticket_lock);
+  }
+  if (t->owner && t->owner_unref)
+    t->owner_unref (t->owner);
   g_free (t);
 }
 
@@ -160,14 +304,12 @@ amd_hip_free (GstAllocator * allocator, GstMemory * mem)
   GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
 
   /* work that still reads or writes the allocation must finish before it goes back to the driver */
-  if (m->written)
-    gstamd_event_synchronize (m->written->event);
+  ticket_host_wait (m->written);
   gst_amd_hip_ticket_unref (m->written);
   {
     guint i;
     for (i = 0; i < GST_AMD_HIP_MAX_READERS; i++) {
-      if (m->read[i])
-        gstamd_event_synchronize (m->read[i]->event);
+      ticket_host_wait (m->read[i]);
       gst_amd_hip_ticket_unref (m->read[i]);
     }
   }
@@ -181,7 +323,7 @@ static void
 host_wait (GstAmdHipMemory * m, gboolean also_reads)
 {
   if (m->written) {
-    gstamd_event_synchronize (m->written->event);
+    ticket_host_wait (m->written);
     gst_amd_hip_ticket_unref (m->written);
     m->written = NULL;
   }
@@ -189,7 +331,7 @@ host_wait (GstAmdHipMemory * m, gboolean also_reads)
     guint i;
     for (i = 0; i < GST_AMD_HIP_MAX_READERS; i++)
       if (m->read[i]) {
-        gstamd_event_synchronize (m->read[i]->event);
+        ticket_host_wait (m->read[i]);
         gst_amd_hip_ticket_unref (m->read[i]);
         m->read[i] = NULL;
       }
@@ -271,7 +413,16 @@ stream_wait_ticket (GstAmdHipTicket ** t, gpointer stream)
 {
   if (!*t)
     return;
+  ticket_settle (*t);
+  if ((*t)->stream == stream && !g_atomic_int_get (&(*t)->deferred))
+    return;                     /* the same stream: what it is given now runs after the ticket's work anyway - no wait, not even a query */
   if (gst_amd_hip_ticket_is_done (*t)) {
+    gst_amd_hip_ticket_unref (*t);
+    *t = NULL;
+    return;
+  }
+  ticket_unlazy (*t);
+  if (!(*t)->event) {           /* became done (or synchronised) while the event was being made */
     gst_amd_hip_ticket_unref (*t);
     *t = NULL;
   } else if ((*t)->waited_stream != stream) {
@@ -327,6 +478,20 @@ gst_amd_hip_memory_set_read (GstMemory * mem, GstAmdHipTicket * t)
    * (finished ones leave their slot); only when every slot holds a running reader does the host wait for the oldest */
   {
     guint i, slot = GST_AMD_HIP_MAX_READERS;
+    for (i = 0; t && i < GST_AMD_HIP_MAX_READERS; i++) {
+      /* the launch is in already, or an earlier one of the same stream is: the later ticket stands for both */
+      if (m->read[i] == t) {
+        g_mutex_unlock (&m->lock);
+        return;
+      }
+      if (m->read[i] && t->stream && m->read[i]->stream == t->stream && !g_atomic_int_get (&m->read[i]->deferred) &&
+          !g_atomic_int_get (&t->deferred) && m->read[i]->stream_slot >= 0 && m->read[i]->stream_slot == t->stream_slot && m->read[i]->seq < t->seq) {
+        gst_amd_hip_ticket_unref (m->read[i]);
+        m->read[i] = gst_amd_hip_ticket_ref (t);
+        g_mutex_unlock (&m->lock);
+        return;
+      }
+    }
     for (i = 0; i < GST_AMD_HIP_MAX_READERS; i++) {
       if (m->read[i] && gst_amd_hip_ticket_is_done (m->read[i])) {
         gst_amd_hip_ticket_unref (m->read[i]);
@@ -336,7 +501,7 @@ gst_amd_hip_memory_set_read (GstMemory * mem, GstAmdHipTicket * t)
         slot = i;
     }
     if (slot == GST_AMD_HIP_MAX_READERS) {
-      gstamd_event_synchronize (m->read[0]->event);
+      ticket_host_wait (m->read[0]);
       gst_amd_hip_ticket_unref (m->read[0]);
       slot = 0;
     }

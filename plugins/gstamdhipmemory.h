@@ -46,9 +46,28 @@ typedef struct _GstAmdHipTicket {
                              * ticket is known to be done as soon as any later one of its stream has been seen done - most
                              * completion checks then cost no HIP call (hipEventQuery is ~1.5 us on this stack) */
   gpointer waited_stream;   /* last stream that was made to wait on this ticket (a second wait would be redundant) */
+  /* a DEFERRED ticket stands for work its owner has collected but not launched yet (an element batching the buffers of several
+   * transform calls into one kernel launch): whoever needs the work - a stream about to read the memory, a CPU map, the free of
+   * the allocation - first calls launch (owner), which enqueues the work and resolves the ticket; nothing else changes for them */
+  /* a LAZY ticket knows its stream and its place in that stream's order but has no event yet: work enqueued later on the same stream
+   * needs none, and an element with a single stream then never records one; the first stream or host that does have to wait records
+   * it at that point (it then covers whatever the stream was given in between, which only makes the wait longer) */
+  gpointer stream;
+  volatile gint lazy;
+  volatile gint deferred;
+  void (*launch) (gpointer owner);
+  gpointer owner;           /* the ticket holds a reference (owner_unref) */
+  GDestroyNotify owner_unref;
 } GstAmdHipTicket;
 gboolean gst_amd_hip_ticket_is_done (GstAmdHipTicket * t);
 GstAmdHipTicket *gst_amd_hip_ticket_new (gpointer stream);    /* records on `stream`; NULL when no event could be had (the stream was synchronised instead) */
+/* a ticket for work that `launch (owner)` will enqueue on demand; the owner calls _resolve once it has (stream NULL: the work failed,
+ * the ticket then counts as done) */
+GstAmdHipTicket *gst_amd_hip_ticket_new_lazy (gpointer stream);
+/* before a stream that tickets were made for is destroyed: waits for it and marks everything it was given as done */
+void gst_amd_hip_stream_retire (gpointer stream);
+GstAmdHipTicket *gst_amd_hip_ticket_new_deferred (void (*launch) (gpointer owner), gpointer owner, GDestroyNotify owner_unref);
+void gst_amd_hip_ticket_resolve (GstAmdHipTicket * t, gpointer stream, gboolean lazy);
 GstAmdHipTicket *gst_amd_hip_ticket_ref (GstAmdHipTicket * t);
 void gst_amd_hip_ticket_unref (GstAmdHipTicket * t);
 

@@ -57,6 +57,8 @@ static GstStaticPadTemplate src_tmpl = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_S
         GST_VIDEO_CAPS_MAKE (AMD_OUT_FORMATS) AMD_PROGRESSIVE));
 
 #define AMD_MAX_STREAMS 4
+#define AMD_BATCH_MAX 8
+#define AMD_BATCH_MAX_AGE_US 2000
 
 /* GstVideoScaleMethod of the reference (gstvideoconvertscale.h) */
 typedef enum {
@@ -109,6 +111,11 @@ typedef struct {
   /* device staging for system-memory pads, one per stream */
   gpointer d_in[AMD_MAX_STREAMS], d_out[AMD_MAX_STREAMS];
   gsize d_in_size[AMD_MAX_STREAMS], d_out_size[AMD_MAX_STREAMS];
+  /* batch-buffers: HBM -> HBM frames of consecutive transform calls collected into ONE launch (AmdVcsBatch below) */
+  guint batch_buffers;         /* property: 0 = automatic (4 when upstream is not live, 1 = no batching when it is) */
+  guint batch_limit;           /* what applies to the negotiated stream */
+  struct _AmdVcsBatch *batch;
+  GThread *batch_watch;        /* launches a batch that has been sitting for AMD_BATCH_MAX_AGE_US without filling up */
   GstPadChainFunction base_chain;       /* GstBaseTransform's chain function (the sink pad's, before chain_list was installed) */
   /* GSTAMD_ELEMENT_STATS=1: host time spent in transform(), printed at stop (where does a buffer's CPU time go?) */
   gboolean stats;
@@ -121,8 +128,13 @@ typedef struct {
   gboolean converts, scales;
 } GstAmdVideoConvertScaleClass;
 
+static void amd_vcs_batch_flush (struct _AmdVcsBatch * b, gboolean on_demand);
+static void amd_vcs_batch_start (GstAmdVideoConvertScale * s);
+static void amd_vcs_batch_stop (GstAmdVideoConvertScale * s);
+static void amd_vcs_batch_set_converter (GstAmdVideoConvertScale * s);
+
 enum { PROP_0, PROP_METHOD, PROP_ADD_BORDERS, PROP_N_THREADS, PROP_ALPHA_MODE, PROP_ALPHA_VALUE, PROP_CHROMA_MODE, PROP_MATRIX_MODE,
-  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION, PROP_DEVICE_ID, PROP_HIP_STREAMS, PROP_CONVERTER_CONFIG, PROP_DITHER,
+  PROP_ENVELOPE, PROP_SHARPNESS, PROP_SHARPEN, PROP_DITHER_QUANTIZATION, PROP_DEVICE_ID, PROP_HIP_STREAMS, PROP_BATCH_BUFFERS, PROP_CONVERTER_CONFIG, PROP_DITHER,
   PROP_GAMMA_MODE, PROP_PRIMARIES_MODE, PROP_CHROMA_RESAMPLER };
 
 G_DEFINE_TYPE (GstAmdVideoConvertScale, gst_amd_vcs, GST_TYPE_BASE_TRANSFORM);
@@ -153,6 +165,7 @@ amd_vcs_set_property (GObject * object, guint id, const GValue * value, GParamSp
     case PROP_CHROMA_RESAMPLER: s->chroma_resampler = g_value_get_enum (value); break;
     case PROP_DEVICE_ID: s->device_id = g_value_get_int (value); break;
     case PROP_HIP_STREAMS: s->hip_streams = g_value_get_uint (value); break;
+    case PROP_BATCH_BUFFERS: s->batch_buffers = g_value_get_uint (value); break;
     case PROP_CONVERTER_CONFIG:
       if (s->converter_config)
         gst_structure_free (s->converter_config);
@@ -191,6 +204,7 @@ amd_vcs_get_property (GObject * object, guint id, GValue * value, GParamSpec * p
     case PROP_CHROMA_RESAMPLER: g_value_set_enum (value, s->chroma_resampler); break;
     case PROP_DEVICE_ID: g_value_set_int (value, s->device_id); break;
     case PROP_HIP_STREAMS: g_value_set_uint (value, s->hip_streams); break;
+    case PROP_BATCH_BUFFERS: g_value_set_uint (value, s->batch_buffers); break;
     case PROP_CONVERTER_CONFIG: g_value_set_boxed (value, s->converter_config); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
@@ -882,6 +896,8 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
     gst_amd_converter_config_from_structure (s->converter_config, &cfg);
     GST_DEBUG_OBJECT (s, "using the user-provided converter-config %" GST_PTR_FORMAT, s->converter_config);
   }
+  s->batch_limit = 1;
+  amd_vcs_batch_set_converter (s);      /* launches what is pending and detaches the old converter */
   if (s->convert)
     gstamd_video_converter_free (s->convert);
   s->convert = gstamd_video_converter_new (&ai, &ao, &cfg, &status);
@@ -902,6 +918,24 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
       return FALSE;
     }
     s->n_streams = i;
+  }
+  /* deferred launches (batch-buffers): HBM on both sides and a plan without per-converter scratch; automatic = only when upstream is
+   * not live - a live pipeline would have to report the frames it holds back as latency */
+  if (s->in_hip && s->out_hip && gstamd_video_converter_is_reentrant (s->convert)) {
+    guint want = s->batch_buffers;
+    if (want == 0) {
+      GstQuery *q = gst_query_new_latency ();
+      gboolean live = TRUE;
+      if (gst_pad_peer_query (GST_BASE_TRANSFORM_SINK_PAD (trans), q))
+        gst_query_parse_latency (q, &live, NULL, NULL);
+      gst_query_unref (q);
+      want = live ? 1 : 4;
+    }
+    s->batch_limit = MIN (want, AMD_BATCH_MAX);
+    if (s->batch_limit > 1) {
+      amd_vcs_batch_start (s);
+      amd_vcs_batch_set_converter (s);
+    }
   }
   return TRUE;
 }
@@ -1023,6 +1057,279 @@ frame_planes (GstBuffer * buf, const GstVideoInfo * info, guint8 * base, gpointe
   }
 }
 
+/* ---- deferred launches ------------------------------------------------------------------------------------------------------
+ * Two dependent kernels on one HIP stream are ~4 us apart on this stack however little the host does (scripts/launch_cost.cpp: 11.3 us
+ * per 4K frame back to back against 7.1 in a list of 32; 6.0 against 2.1 at 1080p), and an event record per buffer adds ~3 more.  With
+ * batch-buffers > 1 transform () does not launch: it files the (input, output) pair in the open batch and hangs a DEFERRED ticket
+ * (gstamdhipmemory.h) on both memories.  The batch becomes one gstamd_video_converter_frames call - one launch, one event - when it is
+ * full, when anybody needs one of its frames (a stream about to read it, a CPU map: the ticket's launch hook), at EOS / flush / caps
+ * change / stop, or when it has been sitting for AMD_BATCH_MAX_AGE_US.  The buffers are referenced until then, so neither side's pool
+ * can recycle them under the pending launch.  The object outlives the element for as long as a ticket points at it. */
+typedef struct _AmdVcsBatch {
+  gint refcount;
+  GMutex lock;
+  GCond cond;                   /* wakes the watcher */
+  GstAmdVideoConverter *convert;        /* the element's; cleared (after a flush) before the element frees it */
+  gint device_id;
+  gboolean lazy;                /* the element has one stream: its tickets need no event until another stream or the host asks */
+  gpointer stream;              /* of the open batch */
+  guint n;
+  GstBuffer *in[AMD_BATCH_MAX], *out[AMD_BATCH_MAX];
+  const void *src[AMD_BATCH_MAX];
+  void *dst[AMD_BATCH_MAX];
+  GstAmdHipTicket *ticket;      /* deferred, shared by the frames of the open batch */
+  gint64 opened_at;             /* monotonic us */
+  gboolean quit;
+  guint64 n_launches, n_frames, n_on_demand, n_aged;
+} AmdVcsBatch;
+
+static AmdVcsBatch *
+amd_vcs_batch_ref (AmdVcsBatch * b)
+{
+  g_atomic_int_inc (&b->refcount);
+  return b;
+}
+
+static void
+amd_vcs_batch_unref (gpointer p)
+{
+  AmdVcsBatch *b = p;
+  if (!g_atomic_int_dec_and_test (&b->refcount))
+    return;
+  g_mutex_clear (&b->lock);
+  g_cond_clear (&b->cond);
+  g_free (b);
+}
+
+/* lock held.  The buffers to release are handed back: dropping the last reference of a memory waits for its tickets on the host,
+ * which is nothing to do under the lock. */
+static guint
+amd_vcs_batch_launch_locked (AmdVcsBatch * b, GstBuffer ** drop)
+{
+  guint i, n_drop = 0;
+  int r = GSTAMD_ERR_INVALID;
+
+  if (!b->n)
+    return 0;
+  gst_amd_hip_select_device (b->device_id);
+  if (b->convert)
+    r = gstamd_video_converter_frames (b->convert, (int) b->n, b->src, b->dst, b->stream);
+  if (r != GSTAMD_OK)
+    GST_ERROR ("deferred HIP conversion of %u frames failed: %s", b->n, gstamd_last_error ());
+  gst_amd_hip_ticket_resolve (b->ticket, r == GSTAMD_OK ? b->stream : NULL, b->lazy);
+  gst_amd_hip_ticket_unref (b->ticket);
+  b->ticket = NULL;
+  for (i = 0; i < b->n; i++) {
+    drop[n_drop++] = b->in[i];
+    drop[n_drop++] = b->out[i];
+  }
+  b->n_launches++;
+  b->n_frames += b->n;
+  b->n = 0;
+  return n_drop;
+}
+
+static void
+amd_vcs_batch_flush (AmdVcsBatch * b, gboolean on_demand)
+{
+  GstBuffer *drop[2 * AMD_BATCH_MAX];
+  guint n, i;
+
+  if (!b)
+    return;
+  g_mutex_lock (&b->lock);
+  if (b->n && on_demand)
+    b->n_on_demand++;
+  n = amd_vcs_batch_launch_locked (b, drop);
+  g_mutex_unlock (&b->lock);
+  for (i = 0; i < n; i++)
+    gst_buffer_unref (drop[i]);
+}
+
+/* the deferred ticket's hook: somebody needs a frame of the open batch */
+static void
+amd_vcs_batch_launch_hook (gpointer owner)
+{
+  amd_vcs_batch_flush (owner, TRUE);
+}
+
+static gpointer
+amd_vcs_batch_watch (gpointer data)
+{
+  AmdVcsBatch *b = data;
+
+  g_mutex_lock (&b->lock);
+  while (!b->quit) {
+    if (!b->n) {
+      g_cond_wait (&b->cond, &b->lock);
+      continue;
+    }
+    {
+      const gint64 due = b->opened_at + AMD_BATCH_MAX_AGE_US;
+      if (g_get_monotonic_time () < due) {
+        g_cond_wait_until (&b->cond, &b->lock, due);
+        continue;
+      }
+    }
+    {
+      GstBuffer *drop[2 * AMD_BATCH_MAX];
+      guint n, i;
+      b->n_aged++;
+      n = amd_vcs_batch_launch_locked (b, drop);
+      g_mutex_unlock (&b->lock);
+      for (i = 0; i < n; i++)
+        gst_buffer_unref (drop[i]);
+      g_mutex_lock (&b->lock);
+    }
+  }
+  g_mutex_unlock (&b->lock);
+  amd_vcs_batch_unref (b);
+  return NULL;
+}
+
+static gboolean buffer_is_plain_hip_frame (GstBuffer * buf, const GstVideoInfo * info);
+
+/* transform () for one HBM -> HBM pair while batching is on: TRUE when the pair has been filed (or launched with the batch it filled) */
+static gboolean
+amd_vcs_batch_add (GstAmdVideoConvertScale * s, GstBuffer * inbuf, GstBuffer * outbuf)
+{
+  AmdVcsBatch *b = s->batch;
+  GstMemory *imem = gst_buffer_peek_memory (inbuf, 0), *omem = gst_buffer_peek_memory (outbuf, 0);
+  GstMapInfo imap, omap;
+  GstBuffer *drop[2 * AMD_BATCH_MAX + 2];
+  GstAmdHipTicket *t;
+  gpointer stream;
+  guint n_drop = 0, i;
+
+  gint64 ta = 0, tb = 0, tc = 0;
+
+  if (s->stats)
+    ta = g_get_monotonic_time ();
+  g_mutex_lock (&b->lock);
+  if (!b->n)
+    b->stream = s->streams[s->next_stream++ % s->n_streams];
+  stream = b->stream;
+  g_mutex_unlock (&b->lock);
+  /* device pointers (a device map also uploads what a CPU write left in the staging copy) and the stream's waits, outside the lock:
+   * they may run the launch hooks of other elements' tickets */
+  if (!gst_memory_map (imem, &imap, GST_MAP_READ | GST_MAP_AMDHIP))
+    return FALSE;
+  if (!gst_memory_map (omem, &omap, GST_MAP_WRITE | GST_MAP_AMDHIP)) {
+    gst_memory_unmap (imem, &imap);
+    return FALSE;
+  }
+  gst_amd_hip_memory_wait_written (imem, stream);
+  gst_amd_hip_memory_wait_idle (omem, stream);
+  if (s->stats)
+    tb = g_get_monotonic_time ();
+  g_mutex_lock (&b->lock);
+  if (b->n && b->stream != stream) {
+    /* cannot happen with one streaming thread; keep the waits and the launch on one stream whatever happened */
+    n_drop = amd_vcs_batch_launch_locked (b, drop);
+  }
+  if (!b->n) {
+    b->stream = stream;         /* a hook may have launched the batch meanwhile: a new one opens on the stream the waits went to */
+    b->opened_at = g_get_monotonic_time ();
+  }
+  if (!b->ticket)
+    b->ticket = gst_amd_hip_ticket_new_deferred (amd_vcs_batch_launch_hook, amd_vcs_batch_ref (b), amd_vcs_batch_unref);
+  t = gst_amd_hip_ticket_ref (b->ticket);
+  b->in[b->n] = gst_buffer_ref (inbuf);
+  b->out[b->n] = gst_buffer_ref (outbuf);
+  b->src[b->n] = imap.data;
+  b->dst[b->n] = omap.data;
+  b->n++;
+  if (b->n >= s->batch_limit)
+    n_drop += amd_vcs_batch_launch_locked (b, drop + n_drop);
+  else if (b->n == 1)
+    g_cond_signal (&b->cond);
+  g_mutex_unlock (&b->lock);
+  if (s->stats)
+    tc = g_get_monotonic_time ();
+  /* deferred or resolved by now, the ticket is the frame's either way */
+  gst_amd_hip_memory_set_read (imem, t);
+  gst_amd_hip_memory_set_written (omem, t);
+  gst_amd_hip_ticket_unref (t);
+  gst_memory_unmap (omem, &omap);
+  gst_memory_unmap (imem, &imap);
+  for (i = 0; i < n_drop; i++)
+    gst_buffer_unref (drop[i]);
+  if (s->stats) {
+    s->t_wait += tb - ta;
+    s->t_convert += tc - tb;
+    s->t_mark += g_get_monotonic_time () - tc;
+  }
+  return TRUE;
+}
+
+static void
+amd_vcs_batch_start (GstAmdVideoConvertScale * s)
+{
+  AmdVcsBatch *b;
+
+  if (s->batch)
+    return;
+  b = g_new0 (AmdVcsBatch, 1);
+  b->refcount = 1;
+  g_mutex_init (&b->lock);
+  g_cond_init (&b->cond);
+  b->device_id = s->device_id;
+  s->batch = b;
+  s->batch_watch = g_thread_new ("amdvcs-batch", amd_vcs_batch_watch, amd_vcs_batch_ref (b));
+}
+
+/* flush, detach from the element's converter, stop the watcher; tickets may keep the (empty) object alive */
+static void
+amd_vcs_batch_stop (GstAmdVideoConvertScale * s)
+{
+  AmdVcsBatch *b = s->batch;
+
+  if (!b)
+    return;
+  amd_vcs_batch_flush (b, FALSE);
+  g_mutex_lock (&b->lock);
+  b->convert = NULL;
+  b->quit = TRUE;
+  g_cond_signal (&b->cond);
+  g_mutex_unlock (&b->lock);
+  if (s->batch_watch)
+    g_thread_join (s->batch_watch);
+  s->batch_watch = NULL;
+  if (s->stats && b->n_launches)
+    g_printerr ("videoconvertscale deferred launches: %" G_GUINT64_FORMAT " frames in %" G_GUINT64_FORMAT " launches (%" G_GUINT64_FORMAT
+        " on demand, %" G_GUINT64_FORMAT " aged)\n", b->n_frames, b->n_launches, b->n_on_demand, b->n_aged);
+  s->batch = NULL;
+  amd_vcs_batch_unref (b);
+}
+
+/* after the element's converter changed (or is about to be freed): pending frames go out with the one they were filed for */
+static void
+amd_vcs_batch_set_converter (GstAmdVideoConvertScale * s)
+{
+  AmdVcsBatch *b = s->batch;
+
+  if (!b)
+    return;
+  amd_vcs_batch_flush (b, FALSE);
+  g_mutex_lock (&b->lock);
+  b->convert = s->batch_limit > 1 ? s->convert : NULL;
+  b->device_id = s->device_id;
+  b->lazy = s->n_streams == 1;
+  g_mutex_unlock (&b->lock);
+}
+
+/* serialized events must not overtake the frames filed before them */
+static gboolean
+amd_vcs_sink_event (GstBaseTransform * trans, GstEvent * event)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (trans);
+
+  if (s->batch && (GST_EVENT_IS_SERIALIZED (event) || GST_EVENT_TYPE (event) == GST_EVENT_FLUSH_START))
+    amd_vcs_batch_flush (s->batch, FALSE);
+  return GST_BASE_TRANSFORM_CLASS (gst_amd_vcs_parent_class)->sink_event (trans, event);
+}
+
+
 static GstFlowReturn
 amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
 {
@@ -1043,6 +1350,19 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
   if (s->stats)
     ta = g_get_monotonic_time ();
   gst_amd_hip_select_device (s->device_id);       /* the streaming thread's current device */
+  if (s->batch && s->batch_limit > 1) {
+    if (in_dev && out_dev && buffer_is_plain_hip_frame (inbuf, &s->in_info) && buffer_is_plain_hip_frame (outbuf, &s->out_info)) {
+      if (amd_vcs_batch_add (s, inbuf, outbuf)) {
+        if (s->stats) {
+          s->t_total += g_get_monotonic_time () - ta;
+          s->n_frames++;
+        }
+        return GST_FLOW_OK;
+      }
+      return GST_FLOW_ERROR;
+    }
+    amd_vcs_batch_flush (s->batch, FALSE);        /* a frame that takes the direct path: keep the order of the launches */
+  }
   k = s->next_stream++ % s->n_streams;
   stream = s->streams[k];
   /* source */
@@ -1087,7 +1407,7 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
   if (s->stats)
     tc = g_get_monotonic_time ();
   if (r == GSTAMD_OK && (out_dev || in_dev)) {
-    GstAmdHipTicket *t = gst_amd_hip_ticket_new (stream);       /* one event for the launch, shared by both buffers */
+    GstAmdHipTicket *t = s->n_streams == 1 ? gst_amd_hip_ticket_new_lazy (stream) : gst_amd_hip_ticket_new (stream);       /* one event for the launch, shared by both buffers */
     if (out_dev)
       gst_amd_hip_memory_set_written (omem, t);
     if (in_dev)
@@ -1170,6 +1490,8 @@ amd_vcs_chain_list (GstPad * pad, GstObject * parent, GstBufferList * list)
     gst_buffer_list_unref (list);
     return GST_FLOW_OK;
   }
+  if (s->batch)
+    amd_vcs_batch_flush (s->batch, FALSE);
   /* a negotiated, stable element (caps events are handled before the buffers that follow them; a pending downstream
    * reconfigure shows on the src pad) converts the whole list at once; otherwise the first buffer takes the regular path and
    * settles the negotiation */
@@ -1225,7 +1547,7 @@ amd_vcs_chain_list (GstPad * pad, GstObject * parent, GstBufferList * list)
       else
         r = GSTAMD_ERR_INVALID;
       if (r == GSTAMD_OK) {
-        GstAmdHipTicket *t = gst_amd_hip_ticket_new (stream);
+        GstAmdHipTicket *t = s->n_streams == 1 ? gst_amd_hip_ticket_new_lazy (stream) : gst_amd_hip_ticket_new (stream);
         for (k = 0; k < cnt; k++) {
           gst_amd_hip_memory_set_read (gst_buffer_peek_memory (gst_buffer_list_get (list, i + k), 0), t);
           gst_amd_hip_memory_set_written (gst_buffer_peek_memory (outs[k], 0), t);
@@ -1264,6 +1586,8 @@ static gboolean
 amd_vcs_stop (GstBaseTransform * trans)
 {
   GstAmdVideoConvertScale *s = AMD_VCS (trans);
+  gst_amd_hip_select_device (s->device_id);
+  amd_vcs_batch_stop (s);
   if (s->convert)
     gstamd_video_converter_free (s->convert);
   s->convert = NULL;
@@ -1282,7 +1606,7 @@ amd_vcs_stop (GstBaseTransform * trans)
     guint i;
     for (i = 0; i < AMD_MAX_STREAMS; i++) {
       if (s->streams[i]) {
-        gstamd_stream_synchronize (s->streams[i]);
+        gst_amd_hip_stream_retire (s->streams[i]);      /* waits for it; lazy tickets of the stream count as done from here on */
         gstamd_stream_free (s->streams[i]);
       }
       s->streams[i] = NULL;
@@ -1383,6 +1707,11 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
           "HIP streams the instance rotates its frames over (the launch ramp of one frame overlaps the tail of the previous one)",
           1, AMD_MAX_STREAMS, 3, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
 
+  g_object_class_install_property (oc, PROP_BATCH_BUFFERS, g_param_spec_uint ("batch-buffers", "Buffers per launch",
+          "HBM frames of consecutive buffers converted by one kernel launch (the launch is deferred until that many have arrived, "
+          "somebody needs one of them, or 2 ms have passed); 0 = 4 when upstream is not live, 1 otherwise; 1 = one launch per buffer",
+          0, AMD_BATCH_MAX, 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+
   gst_element_class_set_static_metadata (ec, "Video colorspace converter and scaler (MI355X/HIP)",
       "Filter/Converter/Video/Scaler/Colorspace",
       "Converts and resizes raw video on an AMD Instinct GPU with kernels bit-exact to GstVideoConverter", "gstreamer_amd");
@@ -1398,6 +1727,7 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
   tc->propose_allocation = GST_DEBUG_FUNCPTR (amd_vcs_propose_allocation);
   tc->transform = GST_DEBUG_FUNCPTR (amd_vcs_transform);
   tc->stop = GST_DEBUG_FUNCPTR (amd_vcs_stop);
+  tc->sink_event = GST_DEBUG_FUNCPTR (amd_vcs_sink_event);
   klass->converts = TRUE;
   klass->scales = TRUE;
 }

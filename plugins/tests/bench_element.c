@@ -5,7 +5,7 @@
  * into the sink pad, the converted HBM buffers are pulled from the src pad and released back to the element's pool.  No host
  * synchronisation happens inside the timed loop; the clock stops after a CPU map of the last output (which waits for it).
  *
- *   bench_element <in_fmt> <w> <h> <out_fmt> <ow> <oh> <frames> <hip-streams> [method] [list]
+ *   bench_element <in_fmt> <w> <h> <out_fmt> <ow> <oh> <frames> <hip-streams> [method] [list] [batch-buffers]
  * list > 1: the frames are pushed as GstBufferLists of that many buffers (gst_pad_push_list), the element's chain_list path
  * prints one JSON line. */
 #include <gst/check/gstharness.h>
@@ -33,6 +33,7 @@ main (int argc, char **argv)
   }
   const char *ifmt = argv[1], *ofmt = argv[4], *method = argc > 9 ? argv[9] : "bilinear";
   const int list_n = argc > 10 ? atoi (argv[10]) : 1;
+  const int batch_n = argc > 11 ? atoi (argv[11]) : 1;          /* the harness answers latency queries as a live source: say it */
   const int w = atoi (argv[2]), h = atoi (argv[3]), ow = atoi (argv[5]), oh = atoi (argv[6]), streams = atoi (argv[8]);
   int frames = atoi (argv[7]);
   frames = (frames + list_n - 1) / list_n * list_n;
@@ -43,7 +44,7 @@ main (int argc, char **argv)
     return 1;
   }
   gst_util_set_object_arg (G_OBJECT (hn->element), "method", method);
-  g_object_set (hn->element, "hip-streams", (guint) streams, NULL);
+  g_object_set (hn->element, "hip-streams", (guint) streams, "batch-buffers", (guint) batch_n, NULL);
   gchar *in_caps = g_strdup_printf ("video/x-raw(memory:AMDHIPMemory),format=%s,width=%d,height=%d,framerate=30/1", ifmt, w, h);
   gchar *out_caps = g_strdup_printf ("video/x-raw(memory:AMDHIPMemory),format=%s,width=%d,height=%d,framerate=30/1", ofmt, ow, oh);
   gst_harness_set_caps_str (hn, in_caps, out_caps);
@@ -120,8 +121,8 @@ main (int argc, char **argv)
   }
   const double in_bytes = (double) GST_VIDEO_INFO_SIZE (&ii), out_bytes = (double) gst_buffer_get_size (last);
   printf ("{\"element\": \"videoconvertscale\", \"in\": \"%s %dx%d\", \"out\": \"%s %dx%d\", \"method\": \"%s\", \"hip_streams\": %d, "
-      "\"buffers_per_list\": %d, \"frames\": %d, \"frames_per_s\": %.1f, \"us_per_frame\": %.3f, \"algorithmic_gb_per_s\": %.1f, \"input_pool_frames\": %d, \"last_frame_sum\": %" G_GUINT64_FORMAT "}\n",
-      ifmt, w, h, ofmt, ow, oh, method, streams, list_n, frames, frames / secs, secs * 1e6 / frames, (in_bytes + out_bytes) * frames / secs / 1e9,
+      "\"buffers_per_list\": %d, \"batch_buffers\": %d, \"frames\": %d, \"frames_per_s\": %.1f, \"us_per_frame\": %.3f, \"algorithmic_gb_per_s\": %.1f, \"input_pool_frames\": %d, \"last_frame_sum\": %" G_GUINT64_FORMAT "}\n",
+      ifmt, w, h, ofmt, ow, oh, method, streams, list_n, batch_n, frames, frames / secs, secs * 1e6 / frames, (in_bytes + out_bytes) * frames / secs / 1e9,
       n_in, sum);
   gst_buffer_unref (last);
   for (int i = 0; i < n_in; i++)

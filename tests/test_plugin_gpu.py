@@ -609,6 +609,50 @@ def test_upload_download_elements_bracket_an_hbm_pipeline(gst_env, ref):
         assert (b.frame(a.frame(src[i])) == out[i]).all(), i
 
 
+@pytest.mark.parametrize("b1,b2,queue", [(4, 3, True), (4, 4, False), (8, 1, True), (0, 0, True)])
+def test_deferred_launches_give_the_same_frames(gst_env, ref, b1, b2, queue):
+    """batch-buffers: HBM -> HBM frames of consecutive buffers filed and launched together (one gstamd_video_converter_frames call), the
+    launch forced by whoever needs a frame first (the next element's stream, the download's map), by EOS (11 frames: the last batch is
+    short) or by the 2 ms watcher.  Two batching converters in a row, with and without a thread boundary; 0 = automatic (videotestsrc is
+    not live: 4).  Bytes equal the reference's two conversions."""
+    env, tmp = gst_env
+    w, h, n = 640, 360, 11
+    fin, fout = tmp / "bb_in.nv12", tmp / "bb_out.rgba"
+    log = launch(dict(env, GSTAMD_ELEMENT_STATS="1"),
+                 "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=NV12,width=%d,height=%d,colorimetry=bt709,chroma-site=mpeg2 "
+                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! amdhipupload ! video/x-raw(memory:AMDHIPMemory),format=NV12 "
+                 "! videoconvertscale batch-buffers=%d ! video/x-raw(memory:AMDHIPMemory),format=BGRA %s! videoconvertscale batch-buffers=%d "
+                 "! video/x-raw(memory:AMDHIPMemory),format=RGBA ! amdhipdownload ! video/x-raw,format=RGBA ! filesink location=%s"
+                 % (n, w, h, fin, b1, "! queue " if queue else "", b2, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    a = ref.VideoConverter("NV12", w, h, "BGRA", w, h, in_colorimetry="bt709", in_chroma_site="mpeg2")
+    b = ref.VideoConverter("BGRA", w, h, "RGBA", w, h)
+    for i in range(n):
+        assert (b.frame(a.frame(src[i])) == out[i]).all(), i
+    assert "deferred launches: %d frames" % n in log, log[-800:]
+
+
+def test_deferred_launches_through_the_harness(gst_env):
+    """The element alone on HBM buffers (plugins/tests/bench_element): the last output frame of a per-buffer run with batch-buffers=4
+    equals the one without, and the per-buffer rates with deferred launches go to gpurun_out/element_bench.jsonl."""
+    env, tmp = gst_env
+    a = _bench_element(dict(env, GSTAMD_BENCH_SUM="1"), ["NV12", 1280, 720, "BGRA", 1280, 720, 66, 1, "bilinear", 1, 1])
+    b = _bench_element(dict(env, GSTAMD_BENCH_SUM="1"), ["NV12", 1280, 720, "BGRA", 1280, 720, 66, 1, "bilinear", 1, 4])
+    assert a["last_frame_sum"] == b["last_frame_sum"] and a["last_frame_sum"] != 0
+    out = []
+    for (w, h, n) in ((3840, 2160, 600), (1920, 1080, 1500)):
+        for streams, batch in ((1, 4), (2, 4), (1, 8)):
+            res = _bench_element(env, ["NV12", w, h, "BGRA", w, h, n, streams, "bilinear", 1, batch])
+            out.append(res)
+            print(res)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "element_bench.jsonl"), "a") as f:
+        for res in out:
+            f.write(__import__("json").dumps(res) + "\n")
+    assert max(r["frames_per_s"] for r in out[:3]) > 90000, out
+
+
 def test_reference_factory_names_are_ours_in_a_registry_without_the_stock_elements(gst_env, ref):
     """north_star: "register under the same factory names".  A registry keeps one feature per name, so the drop-in deployment is a
     plugin directory that ships this plugin INSTEAD of gst-plugins-base's videoconvert / videoscale / audioresample plugins: there

@@ -52,6 +52,7 @@ struct GstAmdVideoConverter {
   struct PlaneDev { uint32_t *offset = nullptr; int16_t *taps = nullptr; };
   std::vector<std::vector<PlaneDev>> plane_dev;      // plane mode: tables of every pass of every plane
   uint8_t *plane_tmp = nullptr;           // plane mode: intermediate plane of a two-pass scale
+  size_t plane_tmp_bytes = 0;
   void *ed_carry = nullptr;                // error-diffusion dither on rectangles taller than one band: the band's last line of errors (video_dither_ed.h)
   uint8_t *pk_img = nullptr;              // planar destinations: the chain's AYUV image before chroma downsample + pack
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
@@ -78,6 +79,17 @@ struct GstAmdVideoConverter {
   uint16_t *gamma_dec16_dev = nullptr, *gamma_enc16_dev = nullptr;          /* the 65536-entry tables of a remap with 16-bit ends */
   uint8_t *gamma_enc_dev = nullptr;
   uint8_t *gamma_mid_a = nullptr, *gamma_mid_b = nullptr;
+  /* The scratch images above (tmp, plane_tmp, pk_img, ed_carry, deep_a / deep_b, gamma_mid_a / gamma_mid_b) belong to the frames of ONE
+   * stream: a second stream's frames would run over them while the first one's kernels are still reading.  Every stream a frame is sent
+   * on gets a set of its own (bind_scratch): the members hold the set of `bound_stream`, the others wait in `parked`. */
+  struct ScratchSet {
+    uint8_t *tmp, *plane_tmp, *pk_img, *deep_a, *deep_b, *gamma_mid_a, *gamma_mid_b;
+    void *ed_carry;
+    size_t deep_a_size, deep_b_size;
+  };
+  bool bound = false;
+  void *bound_stream = nullptr;
+  std::vector<std::pair<void *, ScratchSet>> parked;
 };
 
 namespace gstamd {
@@ -310,6 +322,7 @@ GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info
 
 static void release_tables (GstAmdVideoConverter *c);
 static int build_tables (GstAmdVideoConverter *c);
+static int alloc_scratch (GstAmdVideoConverter *c);
 
 // device tables on first use; a failure part-way releases what was allocated (a retry starts from nothing)
 static int ensure_tables (GstAmdVideoConverter *c)
@@ -334,7 +347,6 @@ static int build_tables (GstAmdVideoConverter *c)
     return hip_fail (e, "hipGetDevice");
   if (p.gamma.on && !p.gamma.planes_fast) {
     const GammaPlan &g = p.gamma;
-    const size_t in_px = (size_t) g.mid_in.width * g.mid_in.height, out_px = (size_t) g.mid_out.width * g.mid_out.height;
     if (!g.dec.empty () && ((e = hipMalloc ((void **) &c->gamma_dec_dev, 256 * sizeof (uint16_t))) != hipSuccess ||
             (e = hipMemcpy (c->gamma_dec_dev, g.dec.data (), 256 * sizeof (uint16_t), hipMemcpyHostToDevice)) != hipSuccess))
       return hip_fail (e, "decode table");
@@ -347,22 +359,6 @@ static int build_tables (GstAmdVideoConverter *c)
     if (!g.enc16.empty () && ((e = hipMalloc ((void **) &c->gamma_enc16_dev, 65536 * sizeof (uint16_t))) != hipSuccess ||
             (e = hipMemcpy (c->gamma_enc16_dev, g.enc16.data (), 65536 * sizeof (uint16_t), hipMemcpyHostToDevice)) != hipSuccess))
       return hip_fail (e, "16-bit encode table");
-    if (!g.fused && !g.src16 && !g.src64 && (e = hipMalloc ((void **) &c->gamma_mid_a, in_px * 4)) != hipSuccess)
-      return hip_fail (e, "hipMalloc(8-bit image)");
-    if (!g.fused && !g.pack16 && !g.store64 && (e = hipMalloc ((void **) &c->gamma_mid_b, out_px * 4)) != hipSuccess)
-      return hip_fail (e, "hipMalloc(8-bit image)");
-    if (!g.fused && (!p.passes.empty () || g.pack16 || g.src16 || g.src64 || g.store64)) {
-      size_t mid_px = 0;
-      if (!p.passes.empty ()) {
-        const ScalePass &s0 = p.passes[0];
-        mid_px = (size_t) (s0.horizontal ? s0.out_size : g.mid_in.width) * (s0.horizontal ? g.mid_in.height : s0.out_size);
-      }
-      c->deep_a_size = std::max (in_px, out_px) * 8;
-      c->deep_b_size = std::max (mid_px, out_px) * 8;
-      if ((e = hipMalloc ((void **) &c->deep_a, c->deep_a_size)) != hipSuccess ||
-          (!p.passes.empty () && (e = hipMalloc ((void **) &c->deep_b, c->deep_b_size)) != hipSuccess))
-        return hip_fail (e, "hipMalloc(16-bit scratch)");
-    }
   }
   if (!p.vpair.empty ()) {
     if ((e = hipMalloc ((void **) &c->vpair_dev, p.vpair.size () * sizeof (int32_t))) != hipSuccess)
@@ -456,9 +452,44 @@ static int build_tables (GstAmdVideoConverter *c)
         tmp_bytes = std::max (tmp_bytes, tw * th * (size_t) pp.n_elems);
       }
     }
-    if (tmp_bytes && (e = hipMalloc ((void **) &c->plane_tmp, tmp_bytes)) != hipSuccess)
+    c->plane_tmp_bytes = tmp_bytes;
+  }
+  const int r = alloc_scratch (c);
+  if (r != GSTAMD_OK)
+    return r;
+  c->tables_ready = true;
+  return GSTAMD_OK;
+}
+
+// the images one stream's frames pass through on their way (the members are empty on entry); `tmp` and growth of deep_a / deep_b happen on
+// first use (convert_two_pass, convert_deep_scaled)
+static int alloc_scratch (GstAmdVideoConverter *c)
+{
+  hipError_t e;
+  const VideoPlan &p = c->plan;
+  if (p.gamma.on && !p.gamma.planes_fast) {
+    const GammaPlan &g = p.gamma;
+    const size_t in_px = (size_t) g.mid_in.width * g.mid_in.height, out_px = (size_t) g.mid_out.width * g.mid_out.height;
+    if (!g.fused && !g.src16 && !g.src64 && (e = hipMalloc ((void **) &c->gamma_mid_a, in_px * 4)) != hipSuccess)
+      return hip_fail (e, "hipMalloc(8-bit image)");
+    if (!g.fused && !g.pack16 && !g.store64 && (e = hipMalloc ((void **) &c->gamma_mid_b, out_px * 4)) != hipSuccess)
+      return hip_fail (e, "hipMalloc(8-bit image)");
+    if (!g.fused && (!p.passes.empty () || g.pack16 || g.src16 || g.src64 || g.store64)) {
+      size_t mid_px = 0;
+      if (!p.passes.empty ()) {
+        const ScalePass &s0 = p.passes[0];
+        mid_px = (size_t) (s0.horizontal ? s0.out_size : g.mid_in.width) * (s0.horizontal ? g.mid_in.height : s0.out_size);
+      }
+      c->deep_a_size = std::max (in_px, out_px) * 8;
+      c->deep_b_size = std::max (mid_px, out_px) * 8;
+      if ((e = hipMalloc ((void **) &c->deep_a, c->deep_a_size)) != hipSuccess ||
+          (!p.passes.empty () && (e = hipMalloc ((void **) &c->deep_b, c->deep_b_size)) != hipSuccess))
+        return hip_fail (e, "hipMalloc(16-bit scratch)");
+    }
+  }
+  if (p.plane_mode) {
+    if (c->plane_tmp_bytes && (e = hipMalloc ((void **) &c->plane_tmp, c->plane_tmp_bytes)) != hipSuccess)
       return hip_fail (e, "hipMalloc(plane tmp)");
-    c->tables_ready = true;
     return GSTAMD_OK;
   }
   if (p.out_planar) {
@@ -471,8 +502,56 @@ static int build_tables (GstAmdVideoConverter *c)
         (e = hipMalloc (&c->ed_carry, (size_t) (p.out_info.width + 4) * 8)) != hipSuccess)
       return hip_fail (e, "hipMalloc(dither carry)");
   }
-  c->tables_ready = true;
   return GSTAMD_OK;
+}
+
+static GstAmdVideoConverter::ScratchSet take_scratch (GstAmdVideoConverter *c)
+{
+  GstAmdVideoConverter::ScratchSet s = {c->tmp, c->plane_tmp, c->pk_img, c->deep_a, c->deep_b, c->gamma_mid_a, c->gamma_mid_b, c->ed_carry,
+    c->deep_a_size, c->deep_b_size};
+  c->tmp = c->plane_tmp = c->pk_img = c->deep_a = c->deep_b = c->gamma_mid_a = c->gamma_mid_b = nullptr;
+  c->ed_carry = nullptr;
+  c->deep_a_size = c->deep_b_size = 0;
+  return s;
+}
+
+static void put_scratch (GstAmdVideoConverter *c, const GstAmdVideoConverter::ScratchSet &s)
+{
+  c->tmp = s.tmp, c->plane_tmp = s.plane_tmp, c->pk_img = s.pk_img, c->deep_a = s.deep_a, c->deep_b = s.deep_b;
+  c->gamma_mid_a = s.gamma_mid_a, c->gamma_mid_b = s.gamma_mid_b, c->ed_carry = s.ed_carry;
+  c->deep_a_size = s.deep_a_size, c->deep_b_size = s.deep_b_size;
+}
+
+static void free_scratch (GstAmdVideoConverter::ScratchSet &s)
+{
+  void *all[] = {s.tmp, s.plane_tmp, s.pk_img, s.deep_a, s.deep_b, s.gamma_mid_a, s.gamma_mid_b, s.ed_carry};
+  for (void *q : all)
+    if (q)
+      (void) hipFree (q);
+  memset (&s, 0, sizeof (s));
+}
+
+// The frame about to be enqueued goes to `stream`: make the scratch members that stream's set (tables are built by now).  Calls into one
+// converter are the caller's to serialise (one streaming thread per element); what may overlap is the work on the streams.
+static int bind_scratch (GstAmdVideoConverter *c, void *stream)
+{
+  std::lock_guard<std::mutex> g (c->lock);
+  if (!c->bound) {
+    c->bound = true;
+    c->bound_stream = stream;
+    return GSTAMD_OK;
+  }
+  if (c->bound_stream == stream)
+    return GSTAMD_OK;
+  c->parked.emplace_back (c->bound_stream, take_scratch (c));
+  c->bound_stream = stream;
+  for (size_t i = 0; i < c->parked.size (); i++)
+    if (c->parked[i].first == stream) {
+      put_scratch (c, c->parked[i].second);
+      c->parked.erase (c->parked.begin () + (long) i);
+      return GSTAMD_OK;
+    }
+  return alloc_scratch (c);
 }
 
 // the chain up to a packed 4-byte image: unpack, chroma upsample, scale, matrix, alpha, byte order
@@ -662,7 +741,7 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
   if (!c || !src_planes || !dest_planes || !src_planes[0] || !dest_planes[0])
     return set_error (GSTAMD_ERR_INVALID, "NULL converter or frame");
   int r = ensure_tables (c);
-  if (r != GSTAMD_OK)
+  if (r != GSTAMD_OK || (r = bind_scratch (c, stream_)) != GSTAMD_OK)
     return r;
   hipStream_t stream = (hipStream_t) stream_;
   const VideoPlan &p = c->plan;
@@ -1178,7 +1257,7 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     return GSTAMD_OK;
   const VideoPlan &p = c->plan;
   int r = ensure_tables (c);
-  if (r != GSTAMD_OK)
+  if (r != GSTAMD_OK || (r = bind_scratch (c, stream_)) != GSTAMD_OK)
     return r;
   if (p.gamma.on) {
     for (int i = 0; i < n_frames; i++)
@@ -1249,6 +1328,11 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
 // every device table / scratch image of the converter; the plan stays
 static void release_tables (GstAmdVideoConverter *c)
 {
+  for (auto &ps : c->parked)
+    free_scratch (ps.second);
+  c->parked.clear ();
+  c->bound = false;
+  c->bound_stream = nullptr;
   if (c->vpair_dev)
     (void) hipFree (c->vpair_dev);
   c->vpair_dev = nullptr;
@@ -1610,20 +1694,9 @@ int gstamd_get_device (void)
 
 int gstamd_video_converter_is_reentrant (GstAmdVideoConverter *c)
 {
-  if (!c || ensure_tables (c) != GSTAMD_OK)
-    return 0;
-  const VideoPlan &p = c->plan;
-  if (p.gamma.on || p.plane_mode || p.out_planar || (p.deep16 && !p.passes.empty ()))
-    return 0;                   /* plane_tmp / pk_img / the 16-bit scratch images: one set per converter */
-  if (c->ed_carry)
-    return 0;                   /* the error-diffusion carry line */
-  if (p.passes.size () == 2) {
-    const auto small_kind = [](int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; };
-    if (!(small_kind (p.passes[0].kind) && small_kind (p.passes[1].kind)))
-      return 0;                 /* N-tap in both directions: the fused scaler needs no scratch, but a frame whose planes miss its
-                                 * alignment takes the two-pass form with the AYUV image in between */
-  }
-  return 1;
+  /* every stream a frame is sent on has a scratch set of its own (bind_scratch): plans with intermediate images - gamma remap, plane
+   * scalers, planar packers, two-pass and 16-bit scalers - overlap across streams like the single-kernel ones */
+  return c && ensure_tables (c) == GSTAMD_OK ? 1 : 0;
 }
 
 int gstamd_video_converter_get_config (const GstAmdVideoConverter *c, GstAmdVideoConverterConfig *config)

@@ -328,8 +328,9 @@ int gstamd_device_download_async (void *dst_host, const void *src_device, size_t
 int gstamd_device_upload_2d_async (void *dst_device, size_t dst_pitch, const void *src_host, size_t src_pitch, size_t row_bytes, size_t rows, void *stream);
 int gstamd_device_download_2d_async (void *dst_host, size_t dst_pitch, const void *src_device, size_t src_pitch, size_t row_bytes, size_t rows, void *stream);
 
-/* 1: frames of this converter may be in flight on several streams at once (the plan keeps no scratch image between its kernels);
- * 0: one stream at a time (two-pass scalers and planar packers own one intermediate image per converter). */
+/* 1: frames of this converter may be in flight on several streams at once.  Since round 3 that is every plan: the intermediate images
+ * of multi-kernel plans (two-pass and 16-bit scalers, planar packers, plane scalers, gamma remap) exist once per stream a frame has
+ * been sent on.  Calls into one converter remain the caller's to serialise (one streaming thread per element). */
 int gstamd_video_converter_is_reentrant (GstAmdVideoConverter *convert);
 
 /* Development / support knobs (gstreamer_amd/csrc/tuning.h holds the table): the library reads them from the environment ONCE, at its

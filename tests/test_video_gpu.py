@@ -1,6 +1,7 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the reference's golden
 hashes (tests/golden, generated from oracle/_ref) and - when loadable on the box - against the
 reference itself byte for byte.  Bit-exact is the bar for this integer path."""
+import ctypes as C
 import json
 import os
 
@@ -327,3 +328,54 @@ def test_frame_without_gpu_library_fails_loudly(native_lib):
     with pytest.raises(V.GstAmdError):
         c = V.VideoConverter(V.video_info("NV12", 64, 64), V.video_info("BGRA", 64, 64))
         c.frame(0, 0)
+
+
+SCRATCH_PLANS = [   # plans that keep intermediate images between their kernels: one set per stream since round 3
+    ("planar_pack", "BGRA", 1280, 720, "YUY2", 1280, 720, {}),
+    ("two_pass_lanczos", "BGRA", 1280, 720, "RGBA", 900, 500, dict(resampler_method="lanczos")),
+    ("plane_scaler", "I420", 1280, 720, "I420", 640, 360, dict(resampler_method="lanczos")),
+    ("chain_scaler_planar_out", "I420", 1280, 720, "I420", 640, 480, dict(resampler_method="lanczos")),
+    ("gamma_remap_scaled", "NV12", 1280, 720, "BGRA", 960, 540, dict(gamma_mode="remap")),
+    ("gamma_remap_scaled_p010", "NV12", 1280, 720, "P010_10LE", 960, 540, dict(gamma_mode="remap", resampler_method="cubic")),
+    ("deep_scaled", "P010_10LE", 1280, 720, "BGRA", 640, 360, dict(resampler_method="cubic")),
+    ("floyd_steinberg_planar", "BGRA", 640, 1200, "NV12", 640, 1200, dict(dither_quantization=8, dither_method="floyd-steinberg")),
+]
+
+
+@pytest.mark.parametrize("case", SCRATCH_PLANS, ids=lambda c: c[0])
+def test_hip_frames_in_flight_on_several_streams_keep_their_own_scratch(native_lib, gpu, case):
+    """gstamd_video_converter_is_reentrant is 1 for every plan: 12 different frames sent round robin to 3 streams with nothing between
+    them but the streams' own order - every stream's frames pass through that stream's intermediate images, so each output equals the
+    one the same converter gives for that frame alone."""
+    import torch
+    name, ifmt, w, h, ofmt, ow, oh, cfg = case
+    ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)
+    conv = V.VideoConverter(ii, oi, V.converter_config(**cfg))
+    L = V.lib()
+    L.gstamd_video_converter_is_reentrant.argtypes = [C.c_void_p]
+    L.gstamd_stream_new.restype = C.c_void_p
+    L.gstamd_stream_free.argtypes = [C.c_void_p]
+    L.gstamd_stream_synchronize.argtypes = [C.c_void_p]
+    assert L.gstamd_video_converter_is_reentrant(conv._h) == 1
+    n = 12
+    srcs = [torch.from_numpy(cases.frame_bytes(int(ii.size), "random", 7000 + i, w)).to(gpu) for i in range(n)]
+    alone = []
+    for i in range(n):
+        d = torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu)
+        conv.frame(srcs[i], d)
+        torch.cuda.synchronize()
+        alone.append(d.cpu().numpy())
+    streams = [C.c_void_p(L.gstamd_stream_new()) for _ in range(3)]
+    assert all(st.value for st in streams)
+    for rep in range(3):
+        outs = [torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu) for _ in range(n)]
+        torch.cuda.synchronize()
+        for i in range(n):
+            conv.frame(srcs[i], outs[i], stream=streams[i % 3])
+        for st in streams:
+            assert L.gstamd_stream_synchronize(st) == 0
+        for i in range(n):
+            assert (outs[i].cpu().numpy() == alone[i]).all(), (name, rep, i)
+    for st in streams:
+        L.gstamd_stream_free(st)
+    conv.free()

@@ -45,8 +45,18 @@ VIDEO_CONFIGS = {
                   "4K frames/s (videoconvertscale NV12->P010_10LE) per GPU; % HBM roofline", "sub-conversion + k_gamma_stage + k_pack16"),
     "f2p010in": ("P010_10LE", 3840, 2160, "NV12", 3840, 2160, {}, 8, 1,
                  "4K frames/s (videoconvertscale P010_10LE->NV12) per GPU; % HBM roofline", "k_front16 + k_gamma_stage + sub-conversion"),
+    # SURVEY 8(f) generic paths: the plane scaler behind `videoscale` on NV12, a planar 4:2:0 pack, a byte swizzle
+    "f8scale": ("NV12", 3840, 2160, "NV12", 1920, 1080, {"resampler_method": "linear"}, 8, 1,
+                "4K->1080p frames/s (videoscale NV12->NV12, bilinear) per GPU; % HBM roofline", "k_plane_scale2 (one launch per frame: all planes, both passes)"),
+    "f8pack": ("YUY2", 3840, 2160, "I420", 3840, 2160, {}, 8, 1,
+               "4K frames/s (videoconvert YUY2->I420) per GPU; % HBM roofline", "k_convert + k_pack_planar"),
+    "f8swizzle": ("BGRA", 3840, 2160, "RGBA", 3840, 2160, {}, 8, 1,
+                  "4K frames/s (videoconvert BGRA->RGBA) per GPU; % HBM roofline", "k_swizzle4"),
 }
 CONFIG_TEXT = {
+    "f8scale": "SURVEY 8(f): 3840x2160 NV12 -> 1920x1080 NV12, bilinear, plane by plane (convert_scale_planes)",
+    "f8pack": "SURVEY 8(f): 3840x2160 YUY2 -> I420 (unpack, chroma downsample, planar pack)",
+    "f8swizzle": "SURVEY 8(f): 3840x2160 BGRA -> RGBA (a byte permutation)",
     "c2": "C2: 3840x2160 NV12 (bt709 limited, chroma-site mpeg2) -> BGRA, fused unpack + chroma upsample + matrix + pack",
     "c1": "C1 size on the GPU: 1920x1080 NV12 -> BGRA (the reference's CPU-runnable case)",
     "c3": "C3: 7680x4320 I420 -> 1920x1080 RGBA, Lanczos (16 x 16 taps), horizontal then vertical like chain_scale",
@@ -515,7 +525,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv")
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f8scale | f8pack | f8swizzle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed sustained load before the W warmup steps: from idle an MI355X needs 20-30 ms of load "

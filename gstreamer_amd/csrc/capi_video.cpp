@@ -847,6 +847,18 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
       hipError_t e = launch_encode420 (make_enc420_params (p), p.fout->kind == UNPACK_SEMI, pl.p[0], pl.stride[0], planes, strides, stream);
       return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_encode420");
     }
+    const bool diffusion_first = p.pack.dither.on && p.pack.dither.method != GSTAMD_DITHER_NONE && p.pack.dither.method != GSTAMD_DITHER_BAYER;
+    ColorParams color;
+    color.matrix = p.matrix;
+    color.alpha_kind = p.post.alpha_kind;
+    color.alpha_value = p.post.alpha_value;
+    if (p.passes.empty () && !p.deep16 && !c->hook_on && !diffusion_first && p.post.pack_pos[0] == 0 && p.post.pack_pos[1] == 1 &&
+        p.post.pack_pos[2] == 2 && p.post.pack_pos[3] == 3 && convert_pack_usable (p.front, pl, color) && !tuning_on ("GSTAMD_NO_CONVERT_PACK")) {
+      /* an unscaled 8-bit chain with a cheap pixel source: the packer takes its pixels from the chain itself, nothing goes through HBM
+         in between */
+      hipError_t ce = launch_convert_pack (p.pack, p.front, pl, c->vpair_dev, color, planes, strides, stream);
+      return ce == hipSuccess ? GSTAMD_OK : hip_fail (ce, "k_convert_pack");
+    }
     r = convert_to_packed (c, pl, c->pk_img, p.out_info.width * 4, stream);
     if (r != GSTAMD_OK)
       return r;

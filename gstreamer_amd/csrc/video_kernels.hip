@@ -666,9 +666,25 @@ __global__ __launch_bounds__ (256) void k_fill_border (uint8_t *__restrict__ p, 
     *q = (uint8_t) value;
 }
 
-__global__ __launch_bounds__ (256) void k_pack_planar (PackPlanarParams pk, const uint8_t *__restrict__ src, int sstride, DstPlanes d)
+__global__ __launch_bounds__ (256) void k_pack_planar (PackPlanarParams pk, const uint8_t *__restrict__ src, int sstride, DstPlanes d, int wide)
 {
-  pack_planar_body (pk, src, sstride, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
+  const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (wide && pack_planar_block4 (pk, src, sstride, d, x0, (int) blockIdx.y))
+    return;
+  const SrcImage img = {src, sstride, pk.width};
+  pack_planar_body (pk, img, d, x0, (int) blockIdx.y);
+}
+
+// the same with the unscaled 8-bit chain as its pixel source: YUY2 -> I420, AYUV -> NV12, I420 -> Y42B ... in one launch, no AYUV image
+__global__ __launch_bounds__ (64) void k_convert_pack (PackPlanarParams pk, FrontParams f, Planes pl, const int *__restrict__ vpair, ColorParams color, DstPlanes d)
+{
+  SrcFront src;
+  src.f = f;
+  src.pl = pl;
+  src.vpair = vpair;
+  src.pre = color;
+  src.vec_ok = 0;
+  pack_planar_body (pk, src, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
 }
 
 // 4-byte RGB -> 4:2:0 (video_encode_fast.h): one lane = a 4 x 2 pixel block, one wave per workgroup
@@ -1419,6 +1435,48 @@ hipError_t launch_pack_planar_ed (const PackPlanarParams &pk, uint8_t *img, int 
   return launch_pack_planar (pack_select_only (pk), img, sstride, planes, strides, stream);
 }
 
+__global__ __launch_bounds__ (256) void k_convert_pack_422 (PackPlanarParams pk, Src422Dup src, DstPlanes d, int wide)
+{
+  const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (x0 >= pk.width)
+    return;
+  if (wide && (pk.kind == UNPACK_PLANAR || pk.kind == UNPACK_SEMI) && pack_422dup_block8 (pk, src, d, x0, (int) blockIdx.y))
+    return;
+  pack_planar_body (pk, src, d, x0, (int) blockIdx.y);
+  pack_planar_body (pk, src, d, x0 + 4, (int) blockIdx.y);
+}
+
+// which unscaled chains the fused form pays for: the pixel source must be cheap per pixel, a lane evaluates up to 20 of them for its 4 x 2 block
+bool convert_pack_usable (const FrontParams &f, const Planes &pl, const ColorParams &color)
+{
+  if (f.kind == UNPACK_PACKED4)
+    return ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0;
+  return f.kind == UNPACK_PACKED422 && f.chroma_h == CHROMA_H_NONE && !f.chroma_v2 && color.matrix.kind == MATRIX_NONE && color.alpha_kind == ALPHA_NONE &&
+      ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0;
+}
+
+hipError_t launch_convert_pack (const PackPlanarParams &pk, const FrontParams &f, const Planes &pl, const int *vpair, const ColorParams &color,
+    uint8_t *const planes[3], const int strides[3], hipStream_t stream)
+{
+  DstPlanes d;
+  for (int i = 0; i < 3; i++) {
+    d.p[i] = planes[i];
+    d.stride[i] = strides[i];
+  }
+  const int lanes = (pk.width + 3) / 4, rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
+  if (f.kind == UNPACK_PACKED422) {
+    const Src422Dup src = {pl.p[0], pl.stride[0], 8 * f.pos[1], 8 * f.pos[2], 8 * f.pos[3], f.swap_k};
+    /* pack_422dup_block8: source rows on 16 bytes, plane rows on 8 */
+    int wide = ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0;
+    for (int i = 0; wide && i < (pk.kind == UNPACK_SEMI ? 2 : 3); i++)
+      wide = ((uintptr_t) planes[i] % 8) == 0 && (strides[i] % 8) == 0;
+    hipLaunchKernelGGL (k_convert_pack_422, dim3 (((pk.width + 7) / 8 + 255) / 256, rows), dim3 (256), 0, stream, pk, src, d, wide);
+  } else {
+    hipLaunchKernelGGL (k_convert_pack, dim3 ((lanes + 63) / 64, rows), dim3 (64), 0, stream, pk, f, pl, vpair, color, d);
+  }
+  return hipGetLastError ();
+}
+
 hipError_t launch_pack_planar (const PackPlanarParams &pk, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],
     hipStream_t stream)
 {
@@ -1428,7 +1486,11 @@ hipError_t launch_pack_planar (const PackPlanarParams &pk, const uint8_t *src, i
     d.stride[i] = strides[i];
   }
   const int lanes = (pk.width + 3) / 4, rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
-  hipLaunchKernelGGL (k_pack_planar, dim3 ((lanes + 255) / 256, rows), dim3 (256), 0, stream, pk, src, sstride, d);
+  /* pack_planar_block4: planar / semi-planar YUV without a dither stage, image rows on 16 bytes, plane rows on 4 */
+  int wide = !pk.dither.on && (pk.kind == UNPACK_PLANAR || pk.kind == UNPACK_SEMI) && ((uintptr_t) src % 16) == 0 && (sstride % 16) == 0;
+  for (int i = 0; wide && i < (pk.kind == UNPACK_SEMI ? 2 : 3); i++)
+    wide = ((uintptr_t) planes[i] % 4) == 0 && (strides[i] % 4) == 0;
+  hipLaunchKernelGGL (k_pack_planar, dim3 ((lanes + 255) / 256, rows), dim3 (256), 0, stream, pk, src, sstride, d, wide);
   return hipGetLastError ();
 }
 

@@ -36,17 +36,19 @@ GSTAMD_HD int pack_dither (const DitherParams &d, int k, int v, int x, int y)
 GSTAMD_HD uint32_t ayuv_uv (uint32_t px) { return ((px >> 16) & 0xffu) | ((px >> 24) << 16); }
 
 // per-lane block: pixels x0 .. x0+3 of the lines (yb << h_sub) .. ; x0 % 4 == 0
-GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__restrict__ src, int sstride, const DstPlanes &d, int x0, int yb)
+// SRC: where the AYUV pixel (x, y) of the converted picture comes from - the image a scaled / gamma / dithering chain left in HBM (SrcImage) or,
+// for an unscaled 8-bit chain, the chain itself (SrcFront: unpack + chroma upsample + matrix + alpha per pixel, nothing in between in HBM)
+template <class SRC>
+GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, const DstPlanes &d, int x0, int yb)
 {
   const int w = pk.width, h = pk.height;
   const int y0 = yb << pk.h_sub;
   if (x0 >= w || y0 >= h)
     return;
   if (pk.kind == UNPACK_PACKED3) {          // pack_RGB / pack_BGR (video-format.c:1540, 1577): 4 pixels = 12 bytes
-    const uint32_t *row = (const uint32_t *) (src + (size_t) y0 * sstride);
     uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 3 * (size_t) x0;
     for (int i = 0; i < 4 && x0 + i < w; i++) {
-      const uint32_t px = row[x0 + i];
+      const uint32_t px = src.at (x0 + i, y0);
       q[3 * i + pk.pos[1]] = (uint8_t) pack_dither (pk.dither, 1, (int) ((px >> 8) & 0xff), x0 + i, y0);
       q[3 * i + pk.pos[2]] = (uint8_t) pack_dither (pk.dither, 2, (int) ((px >> 16) & 0xff), x0 + i, y0);
       q[3 * i + pk.pos[3]] = (uint8_t) pack_dither (pk.dither, 3, (int) (px >> 24), x0 + i, y0);
@@ -55,31 +57,28 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__re
   }
   const int nlines = 1 << pk.h_sub;
   if (pk.kind == UNPACK_PACKED422) {       // luma into the macropixels (pack_YUY2 & co, video-format.c:201-460)
-    const uint32_t *row = (const uint32_t *) (src + (size_t) y0 * sstride);
     uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 2 * (size_t) x0;
     for (int i = 0; i < 4 && x0 + i < w; i++)
-      q[4 * (i >> 1) + pk.pos[1] + 2 * (i & 1)] = (uint8_t) pack_dither (pk.dither, 1, (int) ((row[x0 + i] >> 8) & 0xff), x0 + i, y0);
+      q[4 * (i >> 1) + pk.pos[1] + 2 * (i & 1)] = (uint8_t) pack_dither (pk.dither, 1, (int) ((src.at (x0 + i, y0) >> 8) & 0xff), x0 + i, y0);
   }
   // ---- luma of every line of the block
   for (int r = 0; r < nlines && pk.kind != UNPACK_PACKED422; r++) {
     const int y = y0 + r;
     if (y >= h)
       break;
-    const uint32_t *row = (const uint32_t *) (src + (size_t) y * sstride);
     uint8_t *dy = d.p[0] + (size_t) y * d.stride[0] + x0;
     for (int i = 0; i < 4 && x0 + i < w; i++)
-      dy[i] = (uint8_t) pack_dither (pk.dither, 1, (int) ((row[x0 + i] >> 8) & 0xff), x0 + i, y);
+      dy[i] = (uint8_t) pack_dither (pk.dither, 1, (int) ((src.at (x0 + i, y) >> 8) & 0xff), x0 + i, y);
   }
   // ---- chroma of the block's first line (the "chroma line"), vertically averaged with the next one
-  const uint32_t *ra = (const uint32_t *) (src + (size_t) y0 * sstride);
-  const uint32_t *rb = (const uint32_t *) (src + (size_t) (y0 + 1 < h ? y0 + 1 : (pk.virtual_line ? h : h - 1)) * sstride);
+  const int yb1 = y0 + 1 < h ? y0 + 1 : (pk.virtual_line ? h : h - 1);
   uint32_t v[6];                            // packed {U, V} of pixels x0-1 .. x0+4, clamped into the row
   for (int i = 0; i < 6; i++) {
     int x = x0 - 1 + i;
     x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-    uint32_t c = ayuv_uv (ra[x]);
+    uint32_t c = ayuv_uv (src.at (x, y0));
     if (pk.down_v)
-      c = ((c + ayuv_uv (rb[x]) + 0x00010001u) >> 1) & 0x00ff00ffu;      // avgub on both components
+      c = ((c + ayuv_uv (src.at (x, yb1)) + 0x00010001u) >> 1) & 0x00ff00ffu;      // avgub on both components
     v[i] = c;
   }
   const int step = 1 << pk.w_sub;
@@ -122,6 +121,180 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const uint8_t *__re
       d.p[pk.v_plane][(size_t) yb * d.stride[pk.v_plane] + k] = cv;
     }
   }
+}
+
+// pixel source of k_convert_pack for a packed 4:2:2 frame whose chroma is duplicated sideways and taken line by line (the reference's
+// YUY2 / UYVY -> planar fastpaths, video_orc_convert_YUY2_I420 & co; chroma_h NONE, no vertical pairing), no matrix, no alpha stage: the
+// macropixel word, three byte picks
+struct Src422Dup {
+  const uint8_t *p;
+  int stride;
+  int ysh, ush, vsh;    // bit offsets of Y0, U, V inside the macropixel word (Y1 = Y0 + 16)
+  int swap_k;           // FrontParams::swap_k
+  GSTAMD_HD uint32_t at (int x, int y) const
+  {
+    const int k = x >> 1;
+    const uint32_t m = *(const uint32_t *) (p + (size_t) y * stride + 4 * (size_t) k);
+    const uint32_t Y = (m >> (ysh + 16 * (x & 1))) & 0xffu;
+    const bool sw = k == swap_k;
+    const uint32_t U = (m >> (sw ? vsh : ush)) & 0xffu, V = (m >> (sw ? ush : vsh)) & 0xffu;
+    return 0xffu | (Y << 8) | (U << 16) | (V << 24);
+  }
+};
+
+GSTAMD_HD uint32_t avgub4 (uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }          /* (a + b + 1) >> 1 on four bytes */
+
+// Src422Dup -> planar / semi-planar YUV in wide accesses: 8 pixels (four macropixels, one 16-byte load) of one or two lines per lane - the
+// shape of video_orc_convert_YUY2_I420 / _Y42B / _Y444 and their UYVY twins (video-orc.orc:1452-1620): luma copied, chroma copied
+// (4:2:2), averaged over the line pair (4:2:0) or doubled (4:4:4).  False for what it leaves to pack_planar_body (picture edge, the swapped
+// tail macropixel, a cosited horizontal filter, dither, the line past the picture).
+GSTAMD_HD bool pack_422dup_block8 (const PackPlanarParams &pk, const Src422Dup &s, const DstPlanes &d, int x0, int yb)
+{
+  const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
+  if (y0 >= h)
+    return true;
+  if (x0 + 8 > w || pk.down_h > 1 || pk.dither.on || pk.virtual_line || (s.swap_k >= 0 && s.swap_k >= (x0 >> 1) && s.swap_k < (x0 >> 1) + 4))
+    return false;
+  const int y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+  const uint4 a = *(const uint4 *) (s.p + (size_t) y0 * s.stride + 2 * (size_t) x0);
+  uint4 b = a;
+  if (pk.h_sub || pk.down_v)
+    b = *(const uint4 *) (s.p + (size_t) y1 * s.stride + 2 * (size_t) x0);
+#define GSTAMD_LUM2(m) ((((m) >> s.ysh) & 0xffu) | ((((m) >> (s.ysh + 16)) & 0xffu) << 8))
+#define GSTAMD_PICK4(q, sh) ((((q).x >> (sh)) & 0xffu) | ((((q).y >> (sh)) & 0xffu) << 8) | ((((q).z >> (sh)) & 0xffu) << 16) | ((((q).w >> (sh)) & 0xffu) << 24))
+  uint2 ya;
+  ya.x = GSTAMD_LUM2 (a.x) | (GSTAMD_LUM2 (a.y) << 16), ya.y = GSTAMD_LUM2 (a.z) | (GSTAMD_LUM2 (a.w) << 16);
+  *(uint2 *) (d.p[0] + (size_t) y0 * d.stride[0] + x0) = ya;
+  if (pk.h_sub && y0 + 1 < h) {
+    uint2 yb2;
+    yb2.x = GSTAMD_LUM2 (b.x) | (GSTAMD_LUM2 (b.y) << 16), yb2.y = GSTAMD_LUM2 (b.z) | (GSTAMD_LUM2 (b.w) << 16);
+    *(uint2 *) (d.p[0] + (size_t) (y0 + 1) * d.stride[0] + x0) = yb2;
+  }
+  uint32_t u = GSTAMD_PICK4 (a, s.ush), v = GSTAMD_PICK4 (a, s.vsh);
+  if (pk.down_v) {
+    u = avgub4 (u, GSTAMD_PICK4 (b, s.ush));
+    v = avgub4 (v, GSTAMD_PICK4 (b, s.vsh));
+  }
+#undef GSTAMD_LUM2
+#undef GSTAMD_PICK4
+  if (pk.w_sub == 1) {
+    const int k = x0 >> 1;
+    if (pk.kind == UNPACK_SEMI) {
+      const uint32_t f = pk.u_plane ? u : v, g = pk.u_plane ? v : u;
+      uint2 o;
+      o.x = (f & 0xffu) | ((g & 0xffu) << 8) | ((f & 0xff00u) << 8) | ((g & 0xff00u) << 16);
+      o.y = ((f >> 16) & 0xffu) | (((g >> 16) & 0xffu) << 8) | ((f >> 24) << 16) | ((g >> 24) << 24);
+      *(uint2 *) (d.p[1] + (size_t) yb * d.stride[1] + 2 * k) = o;
+    } else {
+      *(uint32_t *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane] + k) = u;
+      *(uint32_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane] + k) = v;
+    }
+    return true;
+  }
+  /* 4:4:4: every pixel its macropixel's chroma */
+  uint2 uu, vv;
+  uu.x = (u & 0xffu) * 0x0101u | (((u >> 8) & 0xffu) * 0x0101u) << 16, uu.y = ((u >> 16) & 0xffu) * 0x0101u | ((u >> 24) * 0x0101u) << 16;
+  vv.x = (v & 0xffu) * 0x0101u | (((v >> 8) & 0xffu) * 0x0101u) << 16, vv.y = ((v >> 16) & 0xffu) * 0x0101u | ((v >> 24) * 0x0101u) << 16;
+  if (pk.kind == UNPACK_SEMI) {
+    uint8_t *q = d.p[1] + (size_t) yb * d.stride[1] + 2 * (size_t) x0;
+    for (int i = 0; i < 8; i++) {
+      const uint32_t cu = ((i < 4 ? uu.x : uu.y) >> (8 * (i & 3))) & 0xffu, cv = ((i < 4 ? vv.x : vv.y) >> (8 * (i & 3))) & 0xffu;
+      q[2 * i] = (uint8_t) (pk.u_plane ? cu : cv);
+      q[2 * i + 1] = (uint8_t) (pk.u_plane ? cv : cu);
+    }
+  } else {
+    *(uint2 *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane] + x0) = uu;
+    *(uint2 *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane] + x0) = vv;
+  }
+  return true;
+}
+
+// The common shape of the pack in wide accesses: AYUV image -> planar / semi-planar YUV, a block of 4 pixels wholly inside the picture, no
+// dither stage: 16-byte loads of the block's pixels (the image rows are 16-byte aligned: the caller checks), the luma of a line as one
+// 32-bit store, the chroma as 16-bit (4:2:x planar), 32-bit (semi-planar, 4:4:4) stores; the arithmetic is pack_planar_body's on the same
+// packed {U, V} words.  Returns false for the blocks it leaves to the general body (picture edge, tail_swap pixel).
+GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const uint8_t *__restrict__ img, int sstride, const DstPlanes &d, int x0, int yb)
+{
+  const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
+  if (x0 + 4 > w || y0 >= h || (pk.tail_swap && x0 + 4 == w && (w & 1)))
+    return false;
+  const int yb1 = y0 + 1 < h ? y0 + 1 : (pk.virtual_line ? h : h - 1);
+  const uint4 a = *(const uint4 *) (img + (size_t) y0 * sstride + 4 * (size_t) x0);
+  uint4 b = a;
+  if (pk.h_sub || pk.down_v)
+    b = *(const uint4 *) (img + (size_t) yb1 * sstride + 4 * (size_t) x0);
+  // luma
+  *(uint32_t *) (d.p[0] + (size_t) y0 * d.stride[0] + x0) = ((a.x >> 8) & 0xffu) | (a.y & 0xff00u) | ((a.z << 8) & 0xff0000u) | ((a.w << 16) & 0xff000000u);
+  if (pk.h_sub && y0 + 1 < h)
+    *(uint32_t *) (d.p[0] + (size_t) (y0 + 1) * d.stride[0] + x0) = ((b.x >> 8) & 0xffu) | (b.y & 0xff00u) | ((b.z << 8) & 0xff0000u) | ((b.w << 16) & 0xff000000u);
+  // chroma of pixels x0 - 1 .. x0 + 4 of the chroma line
+  uint32_t v[6];
+  v[1] = ayuv_uv (a.x), v[2] = ayuv_uv (a.y), v[3] = ayuv_uv (a.z), v[4] = ayuv_uv (a.w);
+  const bool edges = pk.w_sub == 1 && pk.down_h == 2;
+  uint32_t em = 0, ep = 0, fm = 0, fp = 0;
+  const int xm = x0 > 0 ? x0 - 1 : 0, xp = x0 + 4 < w ? x0 + 4 : w - 1;
+  if (edges) {
+    em = *(const uint32_t *) (img + (size_t) y0 * sstride + 4 * (size_t) xm);
+    ep = *(const uint32_t *) (img + (size_t) y0 * sstride + 4 * (size_t) xp);
+    if (pk.down_v) {
+      fm = *(const uint32_t *) (img + (size_t) yb1 * sstride + 4 * (size_t) xm);
+      fp = *(const uint32_t *) (img + (size_t) yb1 * sstride + 4 * (size_t) xp);
+    }
+  }
+  v[0] = ayuv_uv (em), v[5] = ayuv_uv (ep);
+  if (pk.down_v) {
+    v[1] = ((v[1] + ayuv_uv (b.x) + 0x00010001u) >> 1) & 0x00ff00ffu;
+    v[2] = ((v[2] + ayuv_uv (b.y) + 0x00010001u) >> 1) & 0x00ff00ffu;
+    v[3] = ((v[3] + ayuv_uv (b.z) + 0x00010001u) >> 1) & 0x00ff00ffu;
+    v[4] = ((v[4] + ayuv_uv (b.w) + 0x00010001u) >> 1) & 0x00ff00ffu;
+    v[0] = ((v[0] + ayuv_uv (fm) + 0x00010001u) >> 1) & 0x00ff00ffu;
+    v[5] = ((v[5] + ayuv_uv (fp) + 0x00010001u) >> 1) & 0x00ff00ffu;
+  }
+  uint32_t c[4];                            // what is stored: all four (w_sub == 0) or c[0], c[2]
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = x0 + i;
+    const uint32_t cm = v[i], c0 = v[i + 1], cp = v[i + 2];
+    uint32_t r = c0;
+    if (pk.w_sub == 1 && !(i & 1)) {
+      if (pk.down_h == 1) {
+        r = ((c0 + cp + 0x00010001u) >> 1) & 0x00ff00ffu;              /* x + 1 < w: the block is inside the picture */
+      } else if (pk.down_h == 2 && w >= 2) {
+        if (x == 0)
+          r = ((3u * c0 + cp + 0x00020002u) >> 2) & 0x00ff00ffu;
+        else if (x < w - 2)
+          r = ((cm + 2u * c0 + cp + 0x00020002u) >> 2) & 0x00ff00ffu;
+        else
+          r = ((cm + 3u * c0 + 0x00020002u) >> 2) & 0x00ff00ffu;
+      }
+    }
+    c[i] = r;
+  }
+  if (pk.w_sub == 1) {
+    const uint32_t u2 = (c[0] & 0xffu) | ((c[2] & 0xffu) << 8), v2 = (c[0] >> 16) | ((c[2] >> 16) << 8);
+    const int k = x0 >> 1;
+    if (pk.kind == UNPACK_SEMI) {
+      const uint32_t first = pk.u_plane ? u2 : v2, second = pk.u_plane ? v2 : u2;
+      *(uint32_t *) (d.p[1] + (size_t) yb * d.stride[1] + 2 * k) = (first & 0xffu) | ((second & 0xffu) << 8) | ((first & 0xff00u) << 8) | ((second & 0xff00u) << 16);
+    } else {
+      *(uint16_t *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane] + k) = (uint16_t) u2;
+      *(uint16_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane] + k) = (uint16_t) v2;
+    }
+  } else {
+    const uint32_t u4 = (c[0] & 0xffu) | ((c[1] & 0xffu) << 8) | ((c[2] & 0xffu) << 16) | ((c[3] & 0xffu) << 24);
+    const uint32_t v4 = (c[0] >> 16) | ((c[1] >> 16) << 8) | ((c[2] >> 16) << 16) | ((c[3] >> 16) << 24);
+    if (pk.kind == UNPACK_SEMI) {           /* NV24 family: 8 interleaved bytes */
+      uint8_t *q = d.p[1] + (size_t) yb * d.stride[1] + 2 * (size_t) x0;
+      for (int i = 0; i < 4; i++) {
+        q[2 * i] = (uint8_t) (pk.u_plane ? c[i] : c[i] >> 16);
+        q[2 * i + 1] = (uint8_t) (pk.u_plane ? c[i] >> 16 : c[i]);
+      }
+    } else {
+      *(uint32_t *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane] + x0) = u4;
+      *(uint32_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane] + x0) = v4;
+    }
+  }
+  return true;
 }
 
 // The chroma downsamplers alone, on the AYUV image in place, exactly as the reference's line caches leave the lines (the error-diffusion

@@ -281,6 +281,19 @@ VIDEO_CASES = [
     ("y444_yuy2_33x17_generic_odd_w", "Y444", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
     ("yuy2_ayuv_64x48_fastpath_alpha", "YUY2", 64, 48, "AYUV", 64, 48, dict(alpha_mode="set", alpha_value=0.25), None, None, "random"),
     ("ayuv_uyvy_64x48_fastpath", "AYUV", 64, 48, "UYVY", 64, 48, {}, None, None, "random"),
+    # the same family on frames whose rows sit on 16 bytes: the 8-pixel block form (video_pack.h pack_422dup_block8) and the wide AYUV-image pack
+    ("yuy2_i420_640x49_block8_odd_h", "YUY2", 640, 49, "I420", 640, 49, {}, None, None, "random"),
+    ("uyvy_nv12_64x34_block8", "UYVY", 64, 34, "NV12", 64, 34, {}, None, None, "random"),
+    ("yvyu_nv21_72x10_block8", "YVYU", 72, 10, "NV21", 72, 10, {}, None, None, "random"),
+    ("vyuy_y42b_64x17_block8", "VYUY", 64, 17, "Y42B", 64, 17, {}, None, None, "random"),
+    ("yuy2_y444_64x16_block8", "YUY2", 64, 16, "Y444", 64, 16, {}, None, None, "random"),
+    ("uyvy_yv12_136x24_block8_tail_lane", "UYVY", 136, 24, "YV12", 136, 24, {}, None, None, "random"),
+    ("yuy2_nv16_64x9_block8", "YUY2", 64, 9, "NV16", 64, 9, {}, None, None, "random"),
+    ("bgra_y42b_64x18_chain_fed_pack", "BGRA", 64, 18, "Y42B", 64, 18, {}, None, None, "random"),
+    ("ayuv_nv12_64x18_chain_fed_pack", "AYUV", 64, 18, "NV12", 64, 18, {}, None, None, "random"),
+    ("argb_y444_33x9_chain_fed_pack", "ARGB", 33, 9, "Y444", 33, 9, {}, None, None, "random"),
+    ("nv12_i420_half_lanczos_wide_pack", "NV12", 256, 96, "I420", 128, 48, dict(LAN), "bt709>bt601", None, "random"),
+    ("bgra_nv12_third_cubic_wide_pack_cosited", "BGRA", 384, 96, "NV12", 128, 32, dict(resampler_method="cubic"), None, "cosited", "random"),
     ("yuy2_uyvy_322x241_fastpath", "YUY2", 322, 241, "UYVY", 322, 241, {}, None, None, "random"),
     ("uyvy_yuy2_33x17_fastpath", "UYVY", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
     ("yuy2_yuy2_copy_33x17_planes", "YUY2", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),

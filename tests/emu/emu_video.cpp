@@ -985,6 +985,44 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       }
     return GSTAMD_OK;
   }
+  if (p.out_planar && p.passes.empty () && !p.deep16 && !(p.pack.dither.on && p.pack.dither.method != GSTAMD_DITHER_NONE && p.pack.dither.method != GSTAMD_DITHER_BAYER) &&
+      p.post.pack_pos[0] == 0 && p.post.pack_pos[1] == 1 && p.post.pack_pos[2] == 2 && p.post.pack_pos[3] == 3 && !getenv ("EMU_NO_CONVERT_PACK") &&
+      (p.front.kind == UNPACK_PACKED4 || (p.front.kind == UNPACK_PACKED422 && p.front.chroma_h == CHROMA_H_NONE && !p.front.chroma_v2 &&
+              p.matrix.kind == MATRIX_NONE && p.post.alpha_kind == ALPHA_NONE))) {          /* convert_pack_usable, alignment aside */
+    /* k_convert_pack: the pack body with the chain itself as its pixel source */
+    DstPlanes d;
+    memset (&d, 0, sizeof (d));
+    for (int i = 0; i < out->n_planes && i < 3; i++) {
+      d.p[i] = dst + out->offset[i];
+      d.stride[i] = out->stride[i];
+    }
+    SrcFront sf;
+    sf.f = p.front;
+    sf.pl = pl;
+    sf.vpair = p.vpair.empty () ? nullptr : p.vpair.data ();
+    memset (&sf.pre, 0, sizeof (sf.pre));
+    sf.pre.matrix = p.matrix;
+    sf.pre.alpha_kind = p.post.alpha_kind;
+    sf.pre.alpha_value = p.post.alpha_value;
+    sf.vec_ok = 0;
+    const int rows = (p.out_info.height + (1 << p.pack.h_sub) - 1) >> p.pack.h_sub;
+    const Src422Dup s422 = {pl.p[0], pl.stride[0], 8 * p.front.pos[1], 8 * p.front.pos[2], 8 * p.front.pos[3], p.front.swap_k};
+    for (int yb = 0; yb < rows; yb++)
+      for (int x0 = 0; x0 < p.out_info.width; x0 += 4)
+        if (p.front.kind == UNPACK_PACKED422) {               /* k_convert_pack_422: 8 pixels per lane */
+          if (x0 & 4)
+            continue;
+          bool wide = ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && (p.pack.kind == UNPACK_PLANAR || p.pack.kind == UNPACK_SEMI);
+          for (int i = 0; wide && i < (p.pack.kind == UNPACK_SEMI ? 2 : 3); i++)
+            wide = ((uintptr_t) d.p[i] % 8) == 0 && (d.stride[i] % 8) == 0;
+          if (wide && pack_422dup_block8 (p.pack, s422, d, x0, yb))
+            continue;
+          pack_planar_body (p.pack, s422, d, x0, yb);
+          pack_planar_body (p.pack, s422, d, x0 + 4, yb);
+        } else
+          pack_planar_body (p.pack, sf, d, x0, yb);
+    return GSTAMD_OK;
+  }
   if (p.out_planar) {                     /* chain -> AYUV image, then the pack kernel body over its grid */
     std::vector<uint8_t> img ((size_t) p.out_info.width * 4 * (p.out_info.height + 1));          /* + the line past the picture */
     g_extra_rows = p.pack.virtual_line;
@@ -1014,7 +1052,16 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     }
     for (int yb = 0; yb < rows; yb++)
       for (int x0 = 0; x0 < p.out_info.width; x0 += 4)
-        pack_planar_body (pk, img.data (), p.out_info.width * 4, d, x0, yb);
+      {
+        /* k_pack_planar: the wide block form where launch_pack_planar allows it (the emulator's buffers: image rows on 16 bytes when the
+           width is a multiple of 4; plane rows judged like the launcher does) */
+        bool wide = !pk.dither.on && (pk.kind == UNPACK_PLANAR || pk.kind == UNPACK_SEMI) && ((uintptr_t) img.data () % 16) == 0 && ((p.out_info.width * 4) % 16) == 0;
+        for (int i = 0; wide && i < (pk.kind == UNPACK_SEMI ? 2 : 3); i++)
+          wide = ((uintptr_t) d.p[i] % 4) == 0 && (d.stride[i] % 4) == 0;
+        if (wide && pack_planar_block4 (pk, img.data (), p.out_info.width * 4, d, x0, yb))
+          continue;
+        pack_planar_body (pk, SrcImage {img.data (), p.out_info.width * 4, p.out_info.width}, d, x0, yb);
+      }
     return GSTAMD_OK;
   }
   r = emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok, false);

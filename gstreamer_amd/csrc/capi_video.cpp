@@ -53,6 +53,8 @@ struct GstAmdVideoConverter {
   std::vector<std::vector<PlaneDev>> plane_dev;      // plane mode: tables of every pass of every plane
   uint8_t *plane_tmp = nullptr;           // plane mode: intermediate plane of a two-pass scale
   size_t plane_tmp_bytes = 0;
+  size_t plane_lds_bytes = 0;
+  bool plane_frame_ok = false;            // the frame's planes go through k_plane_frame (one launch)
   void *ed_carry = nullptr;                // error-diffusion dither on rectangles taller than one band: the band's last line of errors (video_dither_ed.h)
   uint8_t *pk_img = nullptr;              // planar destinations: the chain's AYUV image before chroma downsample + pack
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
@@ -453,6 +455,14 @@ static int build_tables (GstAmdVideoConverter *c)
       }
     }
     c->plane_tmp_bytes = tmp_bytes;
+    /* k_plane_frame: up to three planes, no merged packed-4:2:2 scaler, every tile's first pass inside its LDS */
+    c->plane_frame_ok = p.planes.size () <= PLN_MAX_JOBS;
+    for (const PlanePlan &pp : p.planes) {
+      for (const ScalePass &sp : pp.passes)
+        c->plane_frame_ok = c->plane_frame_ok && sp.merged == 0;
+      c->plane_lds_bytes = std::max (c->plane_lds_bytes, plane_job_lds_bytes (pp));
+      c->plane_frame_ok = c->plane_frame_ok && plane_job_lds_bytes (pp) <= PLN_LDS_BYTES;
+    }
   }
   const int r = alloc_scratch (c);
   if (r != GSTAMD_OK)
@@ -487,11 +497,8 @@ static int alloc_scratch (GstAmdVideoConverter *c)
         return hip_fail (e, "hipMalloc(16-bit scratch)");
     }
   }
-  if (p.plane_mode) {
-    if (c->plane_tmp_bytes && (e = hipMalloc ((void **) &c->plane_tmp, c->plane_tmp_bytes)) != hipSuccess)
-      return hip_fail (e, "hipMalloc(plane tmp)");
-    return GSTAMD_OK;
-  }
+  if (p.plane_mode)
+    return GSTAMD_OK;           /* plane_tmp: by the first frame that takes the pass-by-pass form (k_plane_frame needs none) */
   if (p.out_planar) {
     if ((e = hipMalloc ((void **) &c->pk_img, (size_t) p.out_info.width * 4 * (p.out_info.height + 1))) != hipSuccess)      /* + the line past the picture */
       return hip_fail (e, "hipMalloc(pack image)");
@@ -787,6 +794,47 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
 {
   const VideoPlan &p = c->plan;
   int r = GSTAMD_OK;
+  if (p.plane_mode && c->plane_frame_ok && !tuning_on ("GSTAMD_NO_PLANE_FRAME")) {
+    /* convert_scale_planes in one launch: the tiles of every plane, the first pass of a tile in LDS (video_planes.h) */
+    PlaneJobs jobs;
+    memset ((void *) &jobs, 0, sizeof (jobs));
+    int tiles = 0;
+    /* planes with two passes first: their tiles are the long ones, the pass-free planes' tiles fill in around them */
+    size_t order[PLN_MAX_JOBS], n_order = 0;
+    for (int two = 1; two >= 0; two--)
+      for (size_t i = 0; i < p.planes.size (); i++)
+        if ((p.planes[i].kind == PLANE_SCALE && p.planes[i].passes.size () == 2) == (two == 1))
+          order[n_order++] = i;
+    for (size_t k = 0; k < n_order; k++) {
+      const size_t i = order[k];
+      const PlanePlan &pp = p.planes[i];
+      PlaneJob &J = jobs.job[k];
+      J.kind = pp.kind;
+      J.s.p = pl.p[pp.src_plane], J.s.stride = pl.stride[pp.src_plane], J.s.n = pp.n_elems;
+      J.d.p = (uint8_t *) dest_planes[pp.dst_plane], J.d.stride = dest_stride ? dest_stride[pp.dst_plane] : p.out_info.stride[pp.dst_plane], J.d.n = pp.n_elems;
+      if (!J.s.p || !J.d.p)
+        return set_error (GSTAMD_ERR_INVALID, "NULL plane");
+      J.iw = pp.iw, J.ih = pp.ih, J.ow = pp.ow, J.oh = pp.oh;
+      J.n_pass = (int) pp.passes.size ();
+      J.h_first = J.n_pass ? pp.passes[0].horizontal : 0;
+      for (size_t q = 0; q < pp.passes.size (); q++) {
+        J.pass[q].kind = pp.passes[q].kind;
+        J.pass[q].n_taps = pp.passes[q].n_taps;
+        J.pass[q].inc = pp.passes[q].inc;
+        J.pass[q].offset = c->plane_dev[i][q].offset;
+        J.pass[q].taps = c->plane_dev[i][q].taps;
+      }
+      const int unit = 4 * pp.n_elems;
+      J.wide = pp.n_elems <= 2 && ((uintptr_t) J.d.p % unit) == 0 && (J.d.stride % unit) == 0;
+      J.wide_src = ((uintptr_t) J.s.p % 8) == 0 && (J.s.stride % 8) == 0;
+      J.tile0 = tiles;
+      J.tiles_x = (pp.ow + PLN_TW - 1) / PLN_TW;
+      tiles += J.tiles_x * ((pp.oh + PLN_TH - 1) / PLN_TH);
+    }
+    jobs.n = (int) p.planes.size ();
+    hipError_t e = launch_plane_frame (jobs, tiles, c->plane_lds_bytes, stream);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_plane_frame");
+  }
   if (p.plane_mode) {
     /* convert_scale_planes: every destination plane from one source plane */
     for (size_t i = 0; i < p.planes.size (); i++) {
@@ -815,6 +863,8 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
           e = launch_plane_pass (pp.passes[0].horizontal, sd[0], sp, ss, dp, ds, pp.n_elems, pp.ow, pp.oh, stream);
         } else {
           const int tw = pp.passes[0].horizontal ? pp.ow : pp.iw, th = pp.passes[0].horizontal ? pp.ih : pp.oh;
+          if (!c->plane_tmp && (e = hipMalloc ((void **) &c->plane_tmp, c->plane_tmp_bytes)) != hipSuccess)
+            return hip_fail (e, "hipMalloc(plane tmp)");
           e = launch_plane_pass (pp.passes[0].horizontal, sd[0], sp, ss, c->plane_tmp, tw * pp.n_elems, pp.n_elems, tw, th, stream);
           if (e == hipSuccess)
             e = launch_plane_pass (pp.passes[1].horizontal, sd[1], c->plane_tmp, tw * pp.n_elems, dp, ds, pp.n_elems, pp.ow, pp.oh, stream);

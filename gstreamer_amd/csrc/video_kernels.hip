@@ -645,6 +645,39 @@ __global__ __launch_bounds__ (256) void k_plane_vscale (SrcPlane s, ScaleDev sd,
   plane_vscale_body (s, sd, d, width, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
 }
 
+// the frame's planes in one launch (video_planes.h plane_tile_body): blockIdx.x runs over the tiles of all planes
+template <int K>
+__device__ __forceinline__ void plane_frame_job (const PlaneJobs &jobs, uint8_t *lds)
+{
+  const int tile = (int) blockIdx.x - jobs.job[K].tile0;
+#pragma unroll
+  for (int phase = 0; phase < PLN_PHASES; phase++) {
+    plane_tile_body (jobs.job[K], lds, tile, (int) threadIdx.x, phase);
+    if (phase + 1 < PLN_PHASES)
+      __syncthreads ();
+  }
+}
+
+__global__ __launch_bounds__ (PLN_THREADS) void k_plane_frame (PlaneJobs jobs)
+{
+  extern __shared__ uint32_t plane_lds[];         /* the largest tile's needs (plane_job_lds_bytes), not PLN_LDS_BYTES: workgroups per CU */
+  uint8_t *lds = (uint8_t *) plane_lds;
+  /* an if-chain over the jobs, not jobs.job[j]: indexing the by-value argument with a run-time index sends the whole struct through scratch */
+  const int b = (int) blockIdx.x;
+  if (jobs.n > 2 && b >= jobs.job[2].tile0)
+    plane_frame_job<2> (jobs, lds);
+  else if (jobs.n > 1 && b >= jobs.job[1].tile0)
+    plane_frame_job<1> (jobs, lds);
+  else
+    plane_frame_job<0> (jobs, lds);
+}
+
+hipError_t launch_plane_frame (const PlaneJobs &jobs, int n_tiles, size_t lds_bytes, hipStream_t stream)
+{
+  hipLaunchKernelGGL (k_plane_frame, dim3 (n_tiles), dim3 (PLN_THREADS), lds_bytes ? lds_bytes : 4, stream, jobs);
+  return hipGetLastError ();
+}
+
 // borders (convert_fill_border, video-converter.c:7190): every pixel of a destination plane outside the picture rectangle
 // gets the plane's border value; es = bytes per pixel of the plane (1, 2, 3 or 4)
 __global__ __launch_bounds__ (256) void k_fill_border (uint8_t *__restrict__ p, int stride, int es, uint32_t value, int maxw, int maxh,

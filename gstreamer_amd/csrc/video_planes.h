@@ -5,6 +5,7 @@
 // vertically as plain bytes.  The scaler arithmetic is the 4 x u8 one of video_device.h
 // applied to the bytes the plane has (hscale_px / vscale_px on words whose upper bytes are zero).
 #pragma once
+#include <algorithm>
 #include "video_device.h"
 
 namespace gstamd {
@@ -87,6 +88,342 @@ GSTAMD_HD void plane_vscale_body (const SrcPlane &s, const ScaleDev &sd, const D
   if (x >= width || y >= oh)
     return;
   d.put (x, y, vscale_px (s, sd, x, y));
+}
+
+// ---- one launch per frame: every plane, both passes ---------------------------------------------------------------------------
+// The passes above are one lane per output byte with the first pass's plane going through HBM, a frame is 2 .. 6 launches, and every lane
+// walks a chain of dependent loads (offset table -> tap table -> pixels) - the kernels are latency-bound at full occupancy.
+// k_plane_frame covers the frame with 64 x 16 output tiles of all its planes (PlaneJobs: where each plane's tiles start) and gives every
+// tile ONE round of global loads: the source rectangle the tile's outputs depend on and the table rows of its output rows / columns go
+// to LDS with plain coalesced copies (phase 0); the first pass runs from LDS into LDS (phase 1: the source rows the vertical pass
+// needs, horizontally scaled - or the columns the horizontal pass needs, vertically scaled; the order and the per-pass rounding are the
+// plan's, hscale_px / vscale_px the functions), the second from LDS to the plane (phase 2).  Plans whose tiles do not fit
+// PLN_LDS_BYTES, and the merged packed-4:2:2 scalers, keep the passes above.
+#define PLN_TW 64
+#define PLN_TH 16
+#define PLN_THREADS 256
+#define PLN_LDS_BYTES 61440
+#define PLN_MAX_JOBS 3
+#define PLN_PHASES 3
+#define PLN_STAGE_ILP 6
+
+struct PlaneJob {
+  int kind;             // PlaneKind
+  SrcPlane s;
+  DstPlane d;
+  int iw, ih, ow, oh;
+  int n_pass, h_first;
+  ScaleDev pass[2];
+  int tile0, tiles_x;   // first tile of the plane in the launch's grid, tiles per tile row
+  int wide;             // destination rows and the tile's 4-pixel groups sit on whole words: 4 outputs per store
+  int wide_src;         // source rows on 8 bytes: the pass-free kinds read 4 / 8 source bytes per lane (plane_simple4)
+};
+
+struct PlaneJobs {
+  PlaneJob job[PLN_MAX_JOBS];
+  int n;
+};
+
+// source indices [lo, hi) a pass reads for its outputs [o0, o1)
+GSTAMD_HD void plane_pass_span (const ScaleDev &sd, bool horizontal, int o0, int o1, int *lo, int *hi)
+{
+  if (sd.kind == SCALE_2TAP && horizontal) {
+    *lo = (o0 * sd.inc) >> 16;
+    *hi = (((o1 - 1) * sd.inc) >> 16) + 2;
+    return;
+  }
+  const int n = sd.kind == SCALE_NEAREST ? 1 : (sd.kind == SCALE_2TAP ? 2 : sd.n_taps);
+  *lo = (int) sd.offset[o0];
+  *hi = (int) sd.offset[o1 - 1] + n;
+}
+
+// the tile's source rectangle in LDS, bytes as they are in the plane
+struct LdsBytes {
+  const uint8_t *b;
+  int x0, y0, pitch, n;
+  GSTAMD_HD uint32_t at (int x, int y) const
+  {
+    const uint8_t *q = b + (y - y0) * pitch + (x - x0) * n;
+    uint32_t v = q[0];
+    if (n >= 2)
+      v |= (uint32_t) q[1] << 8;
+    if (n >= 3)
+      v |= (uint32_t) q[2] << 16;
+    return v;
+  }
+};
+
+// the first pass's result in LDS, one word per pixel
+struct LdsPlane {
+  const uint32_t *w;
+  int x0, y0, pitch;
+  GSTAMD_HD uint32_t at (int x, int y) const { return w[(y - y0) * pitch + (x - x0)]; }
+};
+
+// what a tile keeps in LDS and where
+struct PlaneTile {
+  int x0, y0, x1, y1;           // outputs
+  int sx0, sx1, sy0, sy1;       // source rectangle
+  int pitch;                    // bytes per staged source row (a multiple of 4)
+  int skew;                     // bytes of a staged row in front of pixel sx0 (the rows are staged from a 4-byte boundary when the plane allows)
+  int raw_off, mid_off, tab_off[2];     // byte offsets: source bytes, first-pass words, the passes' table rows (offset words, then taps)
+  int mid_pitch;                // words per row of the first pass's result
+};
+
+// Where pass k's table rows sit: [n offsets as words][n x n_taps taps as int16], for the pass's outputs [o0, o1)
+GSTAMD_HD int plane_tab_bytes (const ScaleDev &sd, int n_out)
+{
+  const int taps = sd.kind == SCALE_NTAP ? sd.n_taps : (sd.kind == SCALE_2TAP ? 2 : 0);
+  return (4 * n_out + 2 * n_out * taps + 3) & ~3;
+}
+
+GSTAMD_HD void plane_tile_geometry (const PlaneJob &J, int tile, PlaneTile &T)
+{
+  const int tx = tile % J.tiles_x, ty = tile / J.tiles_x;
+  T.x0 = tx * PLN_TW, T.y0 = ty * PLN_TH;
+  T.x1 = T.x0 + PLN_TW < J.ow ? T.x0 + PLN_TW : J.ow;
+  T.y1 = T.y0 + PLN_TH < J.oh ? T.y0 + PLN_TH : J.oh;
+  const ScaleDev &ph = J.pass[J.h_first ? 0 : 1], &pv = J.pass[J.h_first ? 1 : 0];
+  plane_pass_span (ph, true, T.x0, T.x1, &T.sx0, &T.sx1);
+  plane_pass_span (pv, false, T.y0, T.y1, &T.sy0, &T.sy1);
+  T.sx1 = T.sx1 < J.iw ? T.sx1 : J.iw;                  /* a tap of weight 0 may point past the plane: staged as 0 */
+  T.sy1 = T.sy1 < J.ih ? T.sy1 : J.ih;
+  T.skew = J.wide_src ? (T.sx0 * J.s.n) & 3 : 0;
+  T.pitch = (T.skew + (T.sx1 - T.sx0) * J.s.n + 7) & ~3;          /* + room for the one pixel past the row the 2-tap form reads */
+  T.raw_off = 0;
+  const int raw_rows = T.sy1 - T.sy0 + 1;               /* + one zero row for the same reason */
+  T.mid_off = T.raw_off + raw_rows * T.pitch;
+  T.mid_pitch = J.h_first ? PLN_TW : T.sx1 - T.sx0 + 1;
+  const int mid_rows = J.h_first ? T.sy1 - T.sy0 + 1 : PLN_TH;
+  T.tab_off[0] = T.mid_off + 4 * mid_rows * T.mid_pitch;
+  const int n0 = J.h_first ? T.x1 - T.x0 : T.y1 - T.y0;
+  T.tab_off[1] = T.tab_off[0] + plane_tab_bytes (J.pass[0], n0);
+}
+
+// pass k of the tile with its tables in LDS: the ScaleDev's pointers rebased so that the pass's own output indices keep working
+GSTAMD_HD ScaleDev plane_lds_pass (const PlaneJob &J, const PlaneTile &T, const uint8_t *lds, int k)
+{
+  ScaleDev sd = J.pass[k];
+  const bool horizontal = (k == 0) == (J.h_first != 0);
+  const int o0 = horizontal ? T.x0 : T.y0, n_out = horizontal ? T.x1 - T.x0 : T.y1 - T.y0;
+  const int taps = sd.kind == SCALE_NTAP ? sd.n_taps : (sd.kind == SCALE_2TAP ? 2 : 0);
+  const uint32_t *off = (const uint32_t *) (lds + T.tab_off[k]);
+  sd.offset = off - o0;
+  sd.taps = (const int16_t *) (off + n_out) - (ptrdiff_t) o0 * taps;
+  return sd;
+}
+
+GSTAMD_HD uint32_t avgub_w (uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }        /* avgub on four bytes */
+GSTAMD_HD uint32_t even_bytes (uint32_t lo, uint32_t hi) { return (lo & 0xffu) | ((lo >> 8) & 0xff00u) | ((hi & 0xffu) << 16) | ((hi << 8) & 0xff000000u); }
+GSTAMD_HD uint32_t odd_bytes (uint32_t lo, uint32_t hi) { return ((lo >> 8) & 0xffu) | ((lo >> 16) & 0xff00u) | ((hi << 8) & 0xff0000u) | (hi & 0xff000000u); }
+
+// the pass-free plane kinds on four outputs of a 1-byte plane at once (x a multiple of 4, rows of both planes on 8 / 4 bytes): the same
+// averages (video_orc_planar_chroma_*: avgub) on packed bytes
+GSTAMD_HD bool plane_simple4 (const PlaneJob &J, int x, int y)
+{
+  if (J.s.n != 1)
+    return false;
+  const uint8_t *sp = J.s.p;
+  const size_t st = (size_t) J.s.stride;
+  uint32_t v;
+  switch (J.kind) {
+    case PLANE_COPY:
+      v = *(const uint32_t *) (sp + (size_t) y * st + x);
+      break;
+    case PLANE_V_HALVE:
+      v = avgub_w (*(const uint32_t *) (sp + (size_t) (2 * y) * st + x), *(const uint32_t *) (sp + (size_t) (2 * y + 1) * st + x));
+      break;
+    case PLANE_H_HALVE: {
+      const uint2 a = *(const uint2 *) (sp + (size_t) y * st + 2 * x);
+      v = avgub_w (even_bytes (a.x, a.y), odd_bytes (a.x, a.y));
+      break;
+    }
+    case PLANE_HV_HALVE: {
+      const uint2 a = *(const uint2 *) (sp + (size_t) (2 * y) * st + 2 * x), b = *(const uint2 *) (sp + (size_t) (2 * y + 1) * st + 2 * x);
+      const uint32_t lo = avgub_w (a.x, b.x), hi = avgub_w (a.y, b.y);
+      v = avgub_w (even_bytes (lo, hi), odd_bytes (lo, hi));
+      break;
+    }
+    case PLANE_V_DOUBLE:
+      v = *(const uint32_t *) (sp + (size_t) (y >> 1) * st + x);
+      break;
+    case PLANE_H_DOUBLE:
+    case PLANE_HV_DOUBLE: {
+      const uint32_t h = *(const uint16_t *) (sp + (size_t) (J.kind == PLANE_HV_DOUBLE ? y >> 1 : y) * st + (x >> 1));
+      v = (h & 0xffu) * 0x0101u | ((h >> 8) * 0x0101u) << 16;
+      break;
+    }
+    default:
+      return false;
+  }
+  *(uint32_t *) (J.d.p + (size_t) y * J.d.stride + x) = v;
+  return true;
+}
+
+// four outputs of a row (or what is left of the row) to the plane
+GSTAMD_HD void plane_put4 (const PlaneJob &J, int x, int y, int x1, const uint32_t *px)
+{
+  if (J.wide && x + 4 <= x1) {
+    uint8_t *q = J.d.p + (size_t) y * J.d.stride + (size_t) x * J.d.n;
+    if (J.d.n == 1) {
+      *(uint32_t *) q = (px[0] & 0xffu) | ((px[1] & 0xffu) << 8) | ((px[2] & 0xffu) << 16) | (px[3] << 24);
+      return;
+    }
+    if (J.d.n == 2) {
+      uint2 o;
+      o.x = (px[0] & 0xffffu) | (px[1] << 16), o.y = (px[2] & 0xffffu) | (px[3] << 16);
+      *(uint2 *) q = o;
+      return;
+    }
+  }
+  for (int i = 0; i < 4 && x + i < x1; i++)
+    J.d.put (x + i, y, px[i]);
+}
+
+// phase 0: source rectangle + table rows -> LDS; 1: first pass, LDS -> LDS; 2: second pass (or the only one, or a pass-free kind) -> plane.
+// A barrier separates the phases.
+GSTAMD_HD void plane_tile_body (const PlaneJob &J, uint8_t *lds, int tile, int tid, int phase)
+{
+  const bool two = J.kind == PLANE_SCALE && J.n_pass == 2;
+  if (!two) {
+    if (phase != PLN_PHASES - 1)
+      return;
+    const int tx = tile % J.tiles_x, ty = tile / J.tiles_x;
+    const int x0 = tx * PLN_TW, y0 = ty * PLN_TH;
+    const int x1 = x0 + PLN_TW < J.ow ? x0 + PLN_TW : J.ow, y1 = y0 + PLN_TH < J.oh ? y0 + PLN_TH : J.oh;
+    const int x = x0 + 4 * (tid % (PLN_TW / 4)), y = y0 + tid / (PLN_TW / 4);
+    if (y >= y1 || x >= x1)
+      return;
+    if (J.kind != PLANE_SCALE) {
+      if (J.wide && J.wide_src && x + 4 <= x1 && plane_simple4 (J, x, y))
+        return;
+      for (int i = 0; i < 4 && x + i < x1; i++)
+        plane_simple_body (J.kind, J.s, J.d, J.ow, J.oh, x + i, y);
+      return;
+    }
+    uint32_t px[4] = {0, 0, 0, 0};
+    const RowOfSrc<SrcPlane> row = {J.s, y};
+    for (int i = 0; i < 4 && x + i < x1; i++)
+      px[i] = J.h_first ? hscale_px (row, J.pass[0], x + i) : vscale_px (J.s, J.pass[0], x + i, y);
+    plane_put4 (J, x, y, x1, px);
+    return;
+  }
+  PlaneTile T;
+  plane_tile_geometry (J, tile, T);
+  if (phase == 0) {
+    /* the source rectangle, row by row, as aligned words (T.skew: the bytes in front of the rectangle's first pixel that come along); the
+       loads of a lane all leave before the first of them is stored (each is a full memory round trip otherwise); the row past the
+       rectangle is zero, what lies past a row's end or the plane's is never weighted */
+    const int rows = T.sy1 - T.sy0, wpr = T.pitch / 4, total = (rows + 1) * wpr;
+    const size_t plane_bytes = (size_t) J.s.stride * (size_t) (J.ih - 1) + (size_t) J.iw * J.s.n;          /* up to the picture's last byte */
+    for (int i0 = tid; i0 < total; i0 += PLN_STAGE_ILP * PLN_THREADS) {
+      uint32_t v[PLN_STAGE_ILP];
+#pragma unroll
+      for (int k = 0; k < PLN_STAGE_ILP; k++) {
+        const int i = i0 + k * PLN_THREADS;
+        const int rr = i / wpr, w4 = 4 * (i % wpr);
+        v[k] = 0;
+        if (i < total && rr < rows) {
+          const size_t at = (size_t) (T.sy0 + rr) * J.s.stride + (size_t) T.sx0 * J.s.n - T.skew + w4;
+          if (J.wide_src && at + 4 <= plane_bytes)
+            v[k] = *(const uint32_t *) (J.s.p + at);
+          else
+            for (int b = 0; b < 4 && at + b < plane_bytes; b++)
+              v[k] |= (uint32_t) J.s.p[at + b] << (8 * b);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < PLN_STAGE_ILP; k++) {
+        const int i = i0 + k * PLN_THREADS;
+        if (i < total)
+          *(uint32_t *) (lds + T.raw_off + 4 * i) = v[k];
+      }
+    }
+    for (int k = 0; k < 2; k++) {
+      const ScaleDev &sd = J.pass[k];
+      const bool horizontal = (k == 0) == (J.h_first != 0);
+      const int o0 = horizontal ? T.x0 : T.y0, n_out = horizontal ? T.x1 - T.x0 : T.y1 - T.y0;
+      const int taps = sd.kind == SCALE_NTAP ? sd.n_taps : (sd.kind == SCALE_2TAP ? 2 : 0);
+      uint32_t *off = (uint32_t *) (lds + T.tab_off[k]);
+      int16_t *tp = (int16_t *) (off + n_out);
+      if (!(sd.kind == SCALE_2TAP && horizontal))       /* the horizontal 2-tap form has no tables (ldreslinl) */
+        for (int i = tid; i < n_out; i += PLN_THREADS)
+          off[i] = sd.offset[o0 + i];
+      if (taps && sd.taps)
+        for (int i = tid; i < n_out * taps; i += PLN_THREADS)
+          tp[i] = sd.taps[(size_t) o0 * taps + i];
+    }
+    return;
+  }
+  const LdsBytes raw = {lds + T.raw_off + T.skew, T.sx0, T.sy0, T.pitch, J.s.n};
+  uint32_t *mid = (uint32_t *) (lds + T.mid_off);
+  if (phase == 1) {
+    const ScaleDev p0 = plane_lds_pass (J, T, lds, 0);
+    if (J.h_first) {
+      const int rows = T.sy1 - T.sy0;
+      for (int i = tid; i < rows * PLN_TW; i += PLN_THREADS) {
+        const int rr = i / PLN_TW, c = i % PLN_TW;
+        uint32_t v = 0;
+        if (T.x0 + c < T.x1) {
+          const RowOfSrc<LdsBytes> row = {raw, T.sy0 + rr};
+          v = hscale_px (row, p0, T.x0 + c);
+        }
+        mid[i] = v;
+      }
+      for (int i = tid; i < PLN_TW; i += PLN_THREADS)          /* the row a zero-weight tap may point at */
+        mid[rows * PLN_TW + i] = 0;
+    } else {
+      const int cols = T.sx1 - T.sx0;
+      for (int i = tid; i < PLN_TH * (cols + 1); i += PLN_THREADS) {
+        const int rr = i / (cols + 1), c = i % (cols + 1);
+        mid[i] = (c < cols && T.y0 + rr < T.y1) ? vscale_px (raw, p0, T.sx0 + c, T.y0 + rr) : 0u;
+      }
+    }
+    return;
+  }
+  const int r = tid / (PLN_TW / 4), x = T.x0 + 4 * (tid % (PLN_TW / 4)), y = T.y0 + r;
+  if (y >= T.y1 || x >= T.x1)
+    return;
+  const ScaleDev p1 = plane_lds_pass (J, T, lds, 1);
+  uint32_t px[4] = {0, 0, 0, 0};
+  if (J.h_first) {
+    const LdsPlane lp = {mid, T.x0, T.sy0, PLN_TW};
+    for (int i = 0; i < 4 && x + i < T.x1; i++)
+      px[i] = vscale_px (lp, p1, x + i, y);
+  } else {
+    const RowOfLds row = {mid + r * T.mid_pitch, T.sx0};
+    for (int i = 0; i < 4 && x + i < T.x1; i++)
+      px[i] = hscale_px (row, p1, x + i);
+  }
+  plane_put4 (J, x, y, T.x1, px);
+}
+
+// LDS bytes the plane's largest tile needs (host, from the pass tables); 0 for planes without a second pass
+inline size_t plane_job_lds_bytes (const PlanePlan &pp)
+{
+  if (pp.kind != PLANE_SCALE || pp.passes.size () != 2)
+    return 0;
+  const bool h_first = pp.passes[0].horizontal;
+  const ScalePass &ph = pp.passes[h_first ? 0 : 1], &pv = pp.passes[h_first ? 1 : 0];
+  const auto span = [](const ScalePass &p, bool horizontal, int o0, int o1) {
+    if (p.kind == SCALE_2TAP && horizontal)
+      return ((((o1 - 1) * p.inc) >> 16) + 2) - ((o0 * p.inc) >> 16);
+    const int n = p.kind == SCALE_NEAREST ? 1 : (p.kind == SCALE_2TAP ? 2 : p.n_taps);
+    return (int) p.offset[o1 - 1] + n - (int) p.offset[o0];
+  };
+  const auto tabs = [](const ScalePass &p, int n_out) {
+    const int taps = p.kind == SCALE_NTAP ? p.n_taps : (p.kind == SCALE_2TAP ? 2 : 0);
+    return (size_t) ((4 * n_out + 2 * n_out * taps + 3) & ~3);
+  };
+  int cols = 0, rows = 0;
+  for (int o0 = 0; o0 < pp.ow; o0 += PLN_TW)
+    cols = std::max (cols, span (ph, true, o0, std::min (o0 + PLN_TW, pp.ow)));
+  for (int o0 = 0; o0 < pp.oh; o0 += PLN_TH)
+    rows = std::max (rows, span (pv, false, o0, std::min (o0 + PLN_TH, pp.oh)));
+  const size_t pitch = (size_t) ((3 + cols * pp.n_elems + 7) & ~3);
+  const size_t raw = (size_t) (rows + 1) * pitch;
+  const size_t mid = 4 * (h_first ? (size_t) (rows + 1) * PLN_TW : (size_t) PLN_TH * (cols + 1));
+  return raw + mid + tabs (pp.passes[0], h_first ? PLN_TW : PLN_TH) + tabs (pp.passes[1], h_first ? PLN_TH : PLN_TW);
 }
 
 }  // namespace gstamd

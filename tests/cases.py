@@ -294,6 +294,12 @@ VIDEO_CASES = [
     ("argb_y444_33x9_chain_fed_pack", "ARGB", 33, 9, "Y444", 33, 9, {}, None, None, "random"),
     ("nv12_i420_half_lanczos_wide_pack", "NV12", 256, 96, "I420", 128, 48, dict(LAN), "bt709>bt601", None, "random"),
     ("bgra_nv12_third_cubic_wide_pack_cosited", "BGRA", 384, 96, "NV12", 128, 32, dict(resampler_method="cubic"), None, "cosited", "random"),
+    ("y444_y42b_planes_h_halve_64x18", "Y444", 64, 18, "Y42B", 64, 18, {}, None, None, "random"),
+    ("y42b_y444_planes_h_double_64x18", "Y42B", 64, 18, "Y444", 64, 18, NEAR, None, None, "random"),
+    ("y444_i420_planes_hv_halve_72x34", "Y444", 72, 34, "I420", 72, 34, {}, None, None, "random"),
+    ("i420_y444_planes_hv_double_72x34", "I420", 72, 34, "Y444", 72, 34, NEAR, None, None, "random"),
+    ("nv12_nv12_third_lanczos_planes_tiles", "NV12", 768, 216, "NV12", 256, 72, dict(LAN), None, None, "random"),
+    ("i420_i420_two_thirds_cubic_planes_tiles", "I420", 384, 120, "I420", 256, 80, dict(resampler_method="cubic"), None, None, "random"),
     ("yuy2_uyvy_322x241_fastpath", "YUY2", 322, 241, "UYVY", 322, 241, {}, None, None, "random"),
     ("uyvy_yuy2_33x17_fastpath", "UYVY", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
     ("yuy2_yuy2_copy_33x17_planes", "YUY2", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),

@@ -924,6 +924,42 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   for (int i = 0; i < out->n_planes; i++)
     orect.offset[i] = out->offset[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]);
   out = &orect;
+  bool plane_frame = p.plane_mode && p.planes.size () <= PLN_MAX_JOBS && !getenv ("EMU_NO_PLANE_FRAME");
+  for (const PlanePlan &pp : p.planes) {
+    for (const ScalePass &sp : pp.passes)
+      plane_frame = plane_frame && sp.merged == 0;
+    plane_frame = plane_frame && plane_job_lds_bytes (pp) <= PLN_LDS_BYTES;
+  }
+  if (plane_frame) {                      /* k_plane_frame: tile by tile, the two phases either side of the barrier */
+    std::vector<uint32_t> lds (PLN_LDS_BYTES / 4);
+    for (const PlanePlan &pp : p.planes) {
+      PlaneJob J;
+      memset ((void *) &J, 0, sizeof (J));
+      J.kind = pp.kind;
+      J.s = {pl.p[pp.src_plane], pl.stride[pp.src_plane], pp.n_elems};
+      J.d = {dst + out->offset[pp.dst_plane], out->stride[pp.dst_plane], pp.n_elems};
+      J.iw = pp.iw, J.ih = pp.ih, J.ow = pp.ow, J.oh = pp.oh;
+      J.n_pass = (int) pp.passes.size ();
+      J.h_first = J.n_pass ? pp.passes[0].horizontal : 0;
+      for (size_t k = 0; k < pp.passes.size (); k++) {
+        J.pass[k].kind = pp.passes[k].kind;
+        J.pass[k].n_taps = pp.passes[k].n_taps;
+        J.pass[k].inc = pp.passes[k].inc;
+        J.pass[k].offset = pp.passes[k].offset.data ();
+        J.pass[k].taps = pp.passes[k].taps.data ();
+      }
+      const int unit = 4 * pp.n_elems;
+      J.wide = pp.n_elems <= 2 && ((uintptr_t) J.d.p % unit) == 0 && (J.d.stride % unit) == 0;
+      J.wide_src = ((uintptr_t) J.s.p % 8) == 0 && (J.s.stride % 8) == 0;
+      J.tiles_x = (pp.ow + PLN_TW - 1) / PLN_TW;
+      const int tiles = J.tiles_x * ((pp.oh + PLN_TH - 1) / PLN_TH);
+      for (int t = 0; t < tiles; t++)
+        for (int phase = 0; phase < PLN_PHASES; phase++)
+          for (int tid = 0; tid < PLN_THREADS; tid++)
+            plane_tile_body (J, (uint8_t *) lds.data (), t, tid, phase);
+    }
+    return GSTAMD_OK;
+  }
   if (p.plane_mode) {                     /* convert_scale_planes: the plane kernels' bodies over their grids */
     for (const PlanePlan &pp : p.planes) {
       const SrcPlane sp = {pl.p[pp.src_plane], pl.stride[pp.src_plane], pp.n_elems};

@@ -6,7 +6,7 @@ import ctypes as C
 from . import video as _v
 
 METHODS = {"nearest": 0, "linear": 1, "cubic": 2, "blackman-nuttall": 3, "kaiser": 4}
-FORMATS = {"S16LE": 0, "S32LE": 1, "F32LE": 2, "F64LE": 3}
+FORMATS = {"S16LE": 4, "S32LE": 12, "F32LE": 28, "F64LE": 30}      # GstAudioFormat values, as gst_audio_resampler_new takes them
 FILTER_MODE = {"interpolated": 0, "full": 1, "auto": 2}
 FILTER_INTERPOLATION = {"none": 0, "linear": 1, "cubic": 2}
 

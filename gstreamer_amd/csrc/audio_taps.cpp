@@ -475,6 +475,15 @@ int plan_audio_resampler (int method, int flags, int format, int channels, int i
       *error = msg;
     return code;
   };
+  /* `format` is a GstAudioFormat as gst_audio_resampler_new takes it (audio-resampler.h:218): the four native-endian ones the
+     resampler accepts (audio-resampler.c:1358-1360); the library's own 0 .. 3 of earlier releases mean the same four */
+  switch (format) {
+    case GSTAMD_AFMT_S16LE: format = GSTAMD_AUDIO_FORMAT_S16; break;
+    case GSTAMD_AFMT_S32LE: format = GSTAMD_AUDIO_FORMAT_S32; break;
+    case GSTAMD_AFMT_F32LE: format = GSTAMD_AUDIO_FORMAT_F32; break;
+    case GSTAMD_AFMT_F64LE: format = GSTAMD_AUDIO_FORMAT_F64; break;
+    default: break;
+  }
   if (method < 0 || method > 4 || format < 0 || format > 3 || channels <= 0 || in_rate <= 0 || out_rate <= 0)
     return fail (GSTAMD_ERR_INVALID, "bad resampler arguments");
   GstAmdAudioResamplerOptions o;

@@ -39,7 +39,9 @@ enum {
 enum { GSTAMD_AUDIO_FILTER_MODE_INTERPOLATED = 0, GSTAMD_AUDIO_FILTER_MODE_FULL = 1, GSTAMD_AUDIO_FILTER_MODE_AUTO = 2 };
 enum { GSTAMD_AUDIO_FILTER_INTERPOLATION_NONE = 0, GSTAMD_AUDIO_FILTER_INTERPOLATION_LINEAR = 1,
   GSTAMD_AUDIO_FILTER_INTERPOLATION_CUBIC = 2 };
-/* sample formats (native endian): the four GstAudioResampler accepts (audio-resampler.c:1358-1360) */
+/* gstamd_audio_resampler_new's `format` is a GstAudioFormat like gst_audio_resampler_new's (audio-resampler.h:218) - GSTAMD_AFMT_S16LE,
+ * _S32LE, _F32LE, _F64LE below, whose values are GstAudioFormat's: a binding passes GST_AUDIO_INFO_FORMAT through.  The private
+ * values 0 .. 3 of the first two releases stay understood (they collide with no GstAudioFormat the resampler accepts). */
 enum { GSTAMD_AUDIO_FORMAT_S16 = 0, GSTAMD_AUDIO_FORMAT_S32 = 1, GSTAMD_AUDIO_FORMAT_F32 = 2, GSTAMD_AUDIO_FORMAT_F64 = 3 };
 
 /* Mirror of the GstAudioResampler.* option keys (audio-resampler.h:42-165).  A field left at its

@@ -121,11 +121,13 @@ amd_ar_fixate_caps (GstBaseTransform * t, GstPadDirection d, GstCaps * caps, Gst
 static int
 amd_format (const GstAudioInfo * i)
 {
+  /* the ABI takes the GstAudioFormat itself (gst_audio_resampler_new, audio-resampler.h:218); these four are what the resampler accepts */
   switch (GST_AUDIO_INFO_FORMAT (i)) {
-    case GST_AUDIO_FORMAT_S16LE: return GSTAMD_AUDIO_FORMAT_S16;
-    case GST_AUDIO_FORMAT_S32LE: return GSTAMD_AUDIO_FORMAT_S32;
-    case GST_AUDIO_FORMAT_F32LE: return GSTAMD_AUDIO_FORMAT_F32;
-    case GST_AUDIO_FORMAT_F64LE: return GSTAMD_AUDIO_FORMAT_F64;
+    case GST_AUDIO_FORMAT_S16LE:
+    case GST_AUDIO_FORMAT_S32LE:
+    case GST_AUDIO_FORMAT_F32LE:
+    case GST_AUDIO_FORMAT_F64LE:
+      return (int) GST_AUDIO_INFO_FORMAT (i);
     default: return -1;
   }
 }

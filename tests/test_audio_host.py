@@ -146,6 +146,29 @@ def test_c4_plan_48k_to_44k1(native_lib):
         x.free()
 
 
+def test_resampler_abi_takes_gst_audio_format_values(native_lib):
+    """gst_audio_resampler_new's `format` is a GstAudioFormat (audio-resampler.h:218): the ABI takes those values (S16LE 4, S32LE 12,
+    F32LE 28, F64LE 30), still understands the private 0 .. 3 of the first releases, and refuses the formats the resampler does not
+    accept (audio-resampler.c:1358-1360)."""
+    import ctypes as C
+    L = A.lib()
+    for gst_value, old_value in ((4, 0), (12, 1), (28, 2), (30, 3)):
+        taps = []
+        for v in (gst_value, old_value):
+            st = C.c_int(0)
+            h = L.gstamd_audio_resampler_new(4, 0, v, 2, 48000, 44100, None, C.byref(st))
+            assert h and st.value == 0, (v, st.value)
+            L.gstamd_audio_resampler_get_out_frames.argtypes = [C.c_void_p, C.c_size_t]
+            L.gstamd_audio_resampler_get_out_frames.restype = C.c_size_t
+            taps.append(L.gstamd_audio_resampler_get_out_frames(C.c_void_p(h), 1024))
+            L.gstamd_audio_resampler_free.argtypes = [C.c_void_p]
+            L.gstamd_audio_resampler_free(C.c_void_p(h))
+        assert taps[0] == taps[1]
+    for bad in (5, 8, 16, 29, 31, 40):           # S16BE, S24_32LE, S24LE, F32BE, F64BE, nothing (2 and 3 - S8, U8 - are the old F32 and F64)
+        st = C.c_int(0)
+        assert not L.gstamd_audio_resampler_new(4, 0, bad, 2, 48000, 44100, None, C.byref(st)) and st.value != 0, bad
+
+
 def test_filter_mode_auto_picks_interpolated_for_big_tables(native_lib):
     """audio-resampler.c:1110-1130: 48000 -> 44101 would need 44101 phases x 72 taps x 4 B > the 1 MiB threshold, so
     mode AUTO resolves to INTERPOLATED (cubic, 8x oversampled table of 8 + 4 rows)."""

@@ -17,6 +17,10 @@ GType gst_amd_hip_buffer_pool_get_type (void);
 #define GST_TYPE_AMD_HIP_BUFFER_POOL (gst_amd_hip_buffer_pool_get_type ())
 
 GstBufferPool *gst_amd_hip_buffer_pool_new (void);
+/* the same pool class handing out PAGE-LOCKED HOST memory (hipHostMalloc) as ordinary system memory: what an element at the edge of the
+ * HBM part of a pipeline offers its system-memory neighbours, so that the copies to and from the device are DMA transfers at the
+ * link's rate instead of staged copies of pageable memory */
+GstBufferPool *gst_amd_hip_buffer_pool_new_pinned_host (void);
 /* configured and activated pool for frames of `caps` (video/x-raw; size from the caps), or NULL */
 GstBufferPool *gst_amd_hip_buffer_pool_new_for_caps (GstCaps * caps, guint min_buffers);
 

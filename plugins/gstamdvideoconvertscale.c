@@ -112,6 +112,7 @@ typedef struct {
   gpointer d_in[AMD_MAX_STREAMS], d_out[AMD_MAX_STREAMS];
   gsize d_in_size[AMD_MAX_STREAMS], d_out_size[AMD_MAX_STREAMS];
   /* batch-buffers: HBM -> HBM frames of consecutive transform calls collected into ONE launch (AmdVcsBatch below) */
+  gboolean pinned_pools;       /* GSTAMD_NO_PINNED_POOLS unset: offer / use page-locked host buffers at the system-memory edges */
   guint batch_buffers;         /* property: 0 = automatic (4 when upstream is not live, 1 = no batching when it is) */
   guint batch_limit;           /* what applies to the negotiated stream */
   struct _AmdVcsBatch *batch;
@@ -976,8 +977,50 @@ amd_vcs_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query, G
       gst_query_add_allocation_pool (query, NULL, GST_VIDEO_INFO_SIZE (&info), 2, 0);
     }
   }
+  else if (caps && need_pool && s->pinned_pools) {
+    /* system-memory frames that are about to be uploaded: offer page-locked host buffers, the upload is then a DMA transfer at the
+       link's rate (pageable memory is staged by the runtime at a fraction of it) */
+    GstVideoInfo info;
+    if (gst_video_info_from_caps (&info, caps)) {
+      GstBufferPool *pool = gst_amd_hip_buffer_pool_new_pinned_host ();
+      GstStructure *config = gst_buffer_pool_get_config (pool);
+      gst_amd_hip_select_device (s->device_id);
+      gst_buffer_pool_config_set_params (config, caps, GST_VIDEO_INFO_SIZE (&info), 2, 0);
+      if (gst_buffer_pool_set_config (pool, config))
+        gst_query_add_allocation_pool (query, pool, GST_VIDEO_INFO_SIZE (&info), 2, 0);
+      gst_object_unref (pool);
+    }
+  }
   gst_query_add_allocation_meta (query, GST_VIDEO_META_API_TYPE, NULL);
   return TRUE;
+}
+
+/* system-memory output that downstream has no pool for: page-locked host buffers of our own (the download is a DMA transfer) */
+static gboolean
+amd_vcs_decide_allocation (GstBaseTransform * trans, GstQuery * query)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (trans);
+  GstCaps *caps = NULL;
+
+  gst_query_parse_allocation (query, &caps, NULL);
+  if (caps && !caps_are_hip (caps) && s->pinned_pools) {
+    GstBufferPool *theirs = NULL;
+    GstVideoInfo info;
+    if (gst_query_get_n_allocation_pools (query) > 0)
+      gst_query_parse_nth_allocation_pool (query, 0, &theirs, NULL, NULL, NULL);
+    if (!theirs && gst_video_info_from_caps (&info, caps)) {
+      GstBufferPool *pool = gst_amd_hip_buffer_pool_new_pinned_host ();
+      gst_amd_hip_select_device (s->device_id);
+      if (gst_query_get_n_allocation_pools (query) > 0)
+        gst_query_set_nth_allocation_pool (query, 0, pool, GST_VIDEO_INFO_SIZE (&info), 2, 0);
+      else
+        gst_query_add_allocation_pool (query, pool, GST_VIDEO_INFO_SIZE (&info), 2, 0);
+      gst_object_unref (pool);
+    }
+    if (theirs)
+      gst_object_unref (theirs);
+  }
+  return GST_BASE_TRANSFORM_CLASS (gst_amd_vcs_parent_class)->decide_allocation (trans, query);
 }
 
 static gboolean
@@ -1725,6 +1768,7 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
   tc->get_unit_size = GST_DEBUG_FUNCPTR (amd_vcs_get_unit_size);
   tc->prepare_output_buffer = GST_DEBUG_FUNCPTR (amd_vcs_prepare_output_buffer);
   tc->propose_allocation = GST_DEBUG_FUNCPTR (amd_vcs_propose_allocation);
+  tc->decide_allocation = GST_DEBUG_FUNCPTR (amd_vcs_decide_allocation);
   tc->transform = GST_DEBUG_FUNCPTR (amd_vcs_transform);
   tc->stop = GST_DEBUG_FUNCPTR (amd_vcs_stop);
   tc->sink_event = GST_DEBUG_FUNCPTR (amd_vcs_sink_event);
@@ -1751,6 +1795,7 @@ gst_amd_vcs_init (GstAmdVideoConvertScale * s)
   s->device_id = -1;
   s->hip_streams = 3;
   s->stats = g_getenv ("GSTAMD_ELEMENT_STATS") != NULL;
+  s->pinned_pools = g_getenv ("GSTAMD_NO_PINNED_POOLS") == NULL;
   s->base_chain = GST_PAD_CHAINFUNC (GST_BASE_TRANSFORM_SINK_PAD (s));
   gst_pad_set_chain_list_function (GST_BASE_TRANSFORM_SINK_PAD (s), GST_DEBUG_FUNCPTR (amd_vcs_chain_list));
   gst_amd_hip_allocator_get ();

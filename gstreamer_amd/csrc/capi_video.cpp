@@ -897,6 +897,22 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
       hipError_t e = launch_encode420 (make_enc420_params (p), p.fout->kind == UNPACK_SEMI, pl.p[0], pl.stride[0], planes, strides, stream);
       return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_encode420");
     }
+    if (p.relayout && !tuning_on ("GSTAMD_NO_RELAYOUT")) {
+      RelayoutParams rp;
+      memset ((void *) &rp, 0, sizeof (rp));
+      rp.width = p.out_info.width, rp.height = p.out_info.height;
+      rp.cw = (rp.width + (1 << p.fout->w_sub) - 1) >> p.fout->w_sub, rp.ch = (rp.height + (1 << p.fout->h_sub) - 1) >> p.fout->h_sub;
+      rp.in_semi = p.fin->kind == UNPACK_SEMI, rp.out_semi = p.fout->kind == UNPACK_SEMI;
+      rp.in_u = p.fin->u_plane, rp.in_v = p.fin->v_plane, rp.out_u = p.fout->u_plane, rp.out_v = p.fout->v_plane;
+      for (int i = 0; i < p.in_info.n_planes && i < 3; i++)
+        rp.in[i] = pl.p[i], rp.in_stride[i] = pl.stride[i];
+      for (int i = 0; i < p.out_info.n_planes && i < 3; i++)
+        rp.out[i] = planes[i], rp.out_stride[i] = strides[i];
+      if (relayout_usable (rp)) {
+        hipError_t re = launch_planes_relayout (rp, stream);
+        return re == hipSuccess ? GSTAMD_OK : hip_fail (re, "k_planes_relayout");
+      }
+    }
     const bool diffusion_first = p.pack.dither.on && p.pack.dither.method != GSTAMD_DITHER_NONE && p.pack.dither.method != GSTAMD_DITHER_BAYER;
     ColorParams color;
     color.matrix = p.matrix;

@@ -1535,7 +1535,7 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   g.pack16 = out16 && !g.store64;
   g.planes_fast = false;
   /* nothing of the single-converter plan is used by a composite */
-  plan->plane_mode = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_post = plan->deep16 = false;
+  plan->plane_mode = plan->relayout = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_post = plan->deep16 = false;
   plan->matrix_before_scale = false;
   plan->vpair.clear ();
   plan->planes.clear ();
@@ -1831,7 +1831,7 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   g.store64 = fo->hi_depth == 3;
   g.pack16 = hi_depth_words (fo->hi_depth);
   g.fused = g.planes_fast = false;
-  plan->plane_mode = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_post = false;
+  plan->plane_mode = plan->relayout = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_post = false;
   plan->deep16 = plan->deep_out = false;
   plan->matrix_before_scale = false;
   plan->vpair.clear ();
@@ -2122,6 +2122,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     return fail (GSTAMD_ERR_INVALID, "bad frame size");
   plan->out_planar = plan->fout->kind != UNPACK_PACKED4;
   plan->plane_mode = false;
+  plan->relayout = false;
   /* chain_dither (:2035-2100) on an 8-bit chain: a stage exists when dither-quantization asks for a coarser quantiser than the
    * format's own (1 at 8 bits) and the method is not NONE - NONE returns before anything is set up, quantisation included.  Every
    * component the destination has (depth > 0) gets the quantiser, rounded down to a power of two (count_power). */
@@ -2521,8 +2522,16 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     plan->fast_pair = plan->fast_420p = plan->fast_422 = plan->fast_enc420 = plan->fast_post = false;
   if (plan->pack.dither.on)             /* the dither stage lives in the pack kernel: the fused kernels that write planes / 3-byte pixels themselves have none */
     plan->fast_pair = plan->fast_enc420 = false;
+  /* planar / semi-planar 8-bit YUV on both sides with the same subsampling, and a chain that neither filters nor mixes: the front hands
+     every pixel the chroma sample of its own position (no upsampling filter, no vertical pairing), the pack takes it back as it is or as
+     the average of equal values - decoder output to encoder input (I420 -> NV12) is a re-arrangement of the planes */
+  plan->relayout = plan->passes.empty () && plan->out_planar && !plan->deep16 && !plan->deep_out && kind_has_planes (fr.kind) && kind_has_planes (plan->fout->kind) &&
+      plan->fin->hi_depth == 0 && plan->fout->hi_depth == 0 && plan->fin->w_sub == plan->fout->w_sub && plan->fin->h_sub == plan->fout->h_sub &&
+      fr.chroma_h == CHROMA_H_NONE && !fr.chroma_v2 && plan->pack.down_h != 2 && !plan->pack.virtual_line && !plan->pack.tail_swap &&
+      !plan->pack.dither.on && plan->matrix.kind == MATRIX_NONE && post.alpha_kind == ALPHA_NONE && in_w == out->width && in_h == out->height &&
+      !plan->rect.in_x && !plan->rect.in_y && !plan->rect.out_x && !plan->rect.out_y;
 
-  std::string d = plan->passes.empty () ? (plan->deep16 ? "convert16" : plan->fast_pair ? "fused_convert_pair" : plan->fast_enc420 ? "fused_encode_420" : plan->fast_422 ? "fused_convert_422" : plan->fast_420p ? "fused_convert_420p" : "fused_convert") : "scale";
+  std::string d = plan->passes.empty () ? (plan->deep16 ? "convert16" : plan->fast_pair ? "fused_convert_pair" : plan->relayout ? "planes_relayout" : plan->fast_enc420 ? "fused_encode_420" : plan->fast_422 ? "fused_convert_422" : plan->fast_420p ? "fused_convert_420p" : "fused_convert") : "scale";
   d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;
   d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : "";
   d += fr.chroma_v2 ? ",v2" : "";

@@ -12,6 +12,7 @@
 #include "video_422_fast.h"
 #include "video_gamma.h"
 #include "video_planes.h"
+#include "video_relayout.h"
 
 namespace gstamd {
 
@@ -74,6 +75,8 @@ struct Enc420Params;
 hipError_t launch_encode420 (const Enc420Params &ep, bool semi, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],
     hipStream_t stream);
 hipError_t launch_plane_frame (const PlaneJobs &jobs, int n_tiles, size_t lds_bytes, hipStream_t stream);
+bool relayout_usable (const RelayoutParams &p);
+hipError_t launch_planes_relayout (const RelayoutParams &p, hipStream_t stream);
 bool convert_pack_usable (const FrontParams &f, const Planes &pl, const ColorParams &color);
 hipError_t launch_convert_pack (const PackPlanarParams &pk, const FrontParams &f, const Planes &pl, const int *vpair, const ColorParams &color,
     uint8_t *const planes[3], const int strides[3], hipStream_t stream);

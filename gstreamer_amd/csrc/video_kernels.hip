@@ -25,6 +25,7 @@
 #include "video_deep.h"
 #include "video_dither.h"
 #include "video_dither_ed.h"
+#include "video_relayout.h"
 #include "video_gamma.h"
 
 namespace gstamd {
@@ -643,6 +644,30 @@ __global__ __launch_bounds__ (256) void k_plane_hscale (SrcPlane s, ScaleDev sd,
 __global__ __launch_bounds__ (256) void k_plane_vscale (SrcPlane s, ScaleDev sd, DstPlane d, int width, int oh)
 {
   plane_vscale_body (s, sd, d, width, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+// plane re-arrangement (video_relayout.h): 16 output bytes per lane, grid.y = luma rows, then the chroma rows of the destination's planes
+__global__ __launch_bounds__ (256) void k_planes_relayout (RelayoutParams p)
+{
+  relayout_body (p, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+bool relayout_usable (const RelayoutParams &p)
+{
+  for (int i = 0; i < 3; i++) {
+    if (p.in[i] && (((uintptr_t) p.in[i] % 16) != 0 || (p.in_stride[i] % 16) != 0))
+      return false;
+    if (p.out[i] && (((uintptr_t) p.out[i] % 16) != 0 || (p.out_stride[i] % 16) != 0))
+      return false;
+  }
+  return true;
+}
+
+hipError_t launch_planes_relayout (const RelayoutParams &p, hipStream_t stream)
+{
+  const int lanes = relayout_lanes (p);
+  hipLaunchKernelGGL (k_planes_relayout, dim3 ((lanes + 255) / 256, relayout_rows (p)), dim3 (256), 0, stream, p);
+  return hipGetLastError ();
 }
 
 // the frame's planes in one launch (video_planes.h plane_tile_body): blockIdx.x runs over the tiles of all planes

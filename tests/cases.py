@@ -300,6 +300,19 @@ VIDEO_CASES = [
     ("i420_y444_planes_hv_double_72x34", "I420", 72, 34, "Y444", 72, 34, NEAR, None, None, "random"),
     ("nv12_nv12_third_lanczos_planes_tiles", "NV12", 768, 216, "NV12", 256, 72, dict(LAN), None, None, "random"),
     ("i420_i420_two_thirds_cubic_planes_tiles", "I420", 384, 120, "I420", 256, 80, dict(resampler_method="cubic"), None, None, "random"),
+    # planes re-arranged (video_relayout.h): same subsampling, no filter in the chain; rows on 16 bytes take the kernel, the others the chain
+    ("i420_nv12_relayout_640x48", "I420", 640, 48, "NV12", 640, 48, {}, None, None, "random"),
+    ("nv12_i420_relayout_640x49_odd_h", "NV12", 640, 49, "I420", 640, 49, {}, None, None, "random"),
+    ("yv12_nv21_relayout_96x34", "YV12", 96, 34, "NV21", 96, 34, {}, None, None, "random"),
+    ("nv21_yv12_relayout_96x34", "NV21", 96, 34, "YV12", 96, 34, {}, None, None, "random"),
+    ("nv12_nv21_relayout_128x18", "NV12", 128, 18, "NV21", 128, 18, {}, None, None, "random"),
+    ("i420_nv21_relayout_131x37_unaligned", "I420", 131, 37, "NV21", 131, 37, {}, None, None, "random"),
+    ("y42b_nv16_relayout_64x10", "Y42B", 64, 10, "NV16", 64, 10, {}, None, None, "random"),
+    ("nv16_y42b_relayout_160x9", "NV16", 160, 9, "Y42B", 160, 9, {}, None, None, "random"),
+    ("y444_nv24_relayout_48x7", "Y444", 48, 7, "NV24", 48, 7, {}, None, None, "random"),
+    ("nv24_y444_relayout_80x5", "NV24", 80, 5, "Y444", 80, 5, {}, None, None, "random"),
+    ("nv61_y42b_relayout_64x6", "NV61", 64, 6, "Y42B", 64, 6, {}, None, None, "random"),
+    ("i420_nv12_relayout_bt601_to_bt709_is_a_matrix", "I420", 64, 16, "NV12", 64, 16, {}, "bt601>bt709", None, "random"),
     ("yuy2_uyvy_322x241_fastpath", "YUY2", 322, 241, "UYVY", 322, 241, {}, None, None, "random"),
     ("uyvy_yuy2_33x17_fastpath", "UYVY", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
     ("yuy2_yuy2_copy_33x17_planes", "YUY2", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),

@@ -25,6 +25,7 @@
 #include "../../gstreamer_amd/csrc/video_gamma.h"
 #include "../../gstreamer_amd/csrc/video_dither.h"
 #include "../../gstreamer_amd/csrc/video_dither_ed.h"
+#include "../../gstreamer_amd/csrc/video_relayout.h"
 
 using namespace gstamd;
 
@@ -1020,6 +1021,29 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
           enc420_block<0> (ep, pl.p[0], pl.stride[0], d, x0, r2);
       }
     return GSTAMD_OK;
+  }
+  if (p.out_planar && p.relayout && !getenv ("EMU_NO_RELAYOUT")) {         /* k_planes_relayout when relayout_usable says so */
+    RelayoutParams rp;
+    memset ((void *) &rp, 0, sizeof (rp));
+    rp.width = p.out_info.width, rp.height = p.out_info.height;
+    rp.cw = (rp.width + (1 << p.fout->w_sub) - 1) >> p.fout->w_sub, rp.ch = (rp.height + (1 << p.fout->h_sub) - 1) >> p.fout->h_sub;
+    rp.in_semi = p.fin->kind == UNPACK_SEMI, rp.out_semi = p.fout->kind == UNPACK_SEMI;
+    rp.in_u = p.fin->u_plane, rp.in_v = p.fin->v_plane, rp.out_u = p.fout->u_plane, rp.out_v = p.fout->v_plane;
+    bool ok = true;
+    for (int i = 0; i < p.in_info.n_planes && i < 3; i++) {
+      rp.in[i] = pl.p[i], rp.in_stride[i] = pl.stride[i];
+      ok = ok && ((uintptr_t) rp.in[i] % 16) == 0 && (rp.in_stride[i] % 16) == 0;
+    }
+    for (int i = 0; i < out->n_planes && i < 3; i++) {
+      rp.out[i] = dst + out->offset[i], rp.out_stride[i] = out->stride[i];
+      ok = ok && ((uintptr_t) rp.out[i] % 16) == 0 && (rp.out_stride[i] % 16) == 0;
+    }
+    if (ok) {
+      for (int row = 0; row < relayout_rows (rp); row++)
+        for (int lane = 0; lane < (relayout_lanes (rp) + 255) / 256 * 256; lane++)
+          relayout_body (rp, lane, row);
+      return GSTAMD_OK;
+    }
   }
   if (p.out_planar && p.passes.empty () && !p.deep16 && !(p.pack.dither.on && p.pack.dither.method != GSTAMD_DITHER_NONE && p.pack.dither.method != GSTAMD_DITHER_BAYER) &&
       p.post.pack_pos[0] == 0 && p.post.pack_pos[1] == 1 && p.post.pack_pos[2] == 2 && p.post.pack_pos[3] == 3 && !getenv ("EMU_NO_CONVERT_PACK") &&

@@ -897,6 +897,16 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
       hipError_t e = launch_encode420 (make_enc420_params (p), p.fout->kind == UNPACK_SEMI, pl.p[0], pl.stride[0], planes, strides, stream);
       return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_encode420");
     }
+    if (p.fout->kind == UNPACK_PACKED3 && p.passes.empty () && !p.deep16 && !c->hook_on && !p.pack.dither.on && p.matrix.kind == MATRIX_NONE &&
+        p.post.alpha_kind == ALPHA_NONE && p.front.hi_depth == 0 && (p.front.kind == UNPACK_PACKED4 || p.front.kind == UNPACK_PACKED3) &&
+        p.post.pack_pos[0] == 0 && p.post.pack_pos[1] == 1 && p.post.pack_pos[2] == 2 && p.post.pack_pos[3] == 3 && !tuning_on ("GSTAMD_NO_SWIZZLE34")) {
+      Swz34Params sp;
+      const int sb = p.front.kind == UNPACK_PACKED4 ? 4 : 3;
+      if (swizzle34_setup (sb, p.front.pos, 3, p.pack.pos, pl.p[0], pl.stride[0], planes[0], strides[0], p.out_info.width, &sp)) {
+        hipError_t se = launch_swizzle34 (sp, sb, 3, p.out_info.height, stream);
+        return se == hipSuccess ? GSTAMD_OK : hip_fail (se, "k_swizzle34");
+      }
+    }
     if (p.relayout && !tuning_on ("GSTAMD_NO_RELAYOUT")) {
       RelayoutParams rp;
       memset ((void *) &rp, 0, sizeof (rp));
@@ -1143,6 +1153,14 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     if (c->hook_on) {
       e = launch_convert_gamma (p.front, pl, c->vpair_dev, color, p.post.pack_pos, dst, dstride, c->hook, stream);
       return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_gamma");
+    }
+    if (p.front.kind == UNPACK_PACKED3 && p.front.hi_depth == 0 && color.matrix.kind == MATRIX_NONE && color.alpha_kind == ALPHA_NONE &&
+        !tuning_on ("GSTAMD_NO_SWIZZLE34")) {
+      Swz34Params sp;
+      if (swizzle34_setup (3, p.front.pos, 4, p.post.pack_pos, pl.p[0], pl.stride[0], dst, dstride, p.front.width, &sp)) {
+        e = launch_swizzle34 (sp, 3, 4, p.front.height, stream);
+        return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_swizzle34");
+      }
     }
     if (swizzle4_usable (p.front, pl, color, dst, dstride)) {
       e = launch_swizzle4 (p.front, pl, p.post.pack_pos, dst, dstride, stream);

@@ -26,6 +26,7 @@
 #include "video_dither.h"
 #include "video_dither_ed.h"
 #include "video_relayout.h"
+#include "video_swizzle34.h"
 #include "video_gamma.h"
 
 namespace gstamd {
@@ -644,6 +645,46 @@ __global__ __launch_bounds__ (256) void k_plane_hscale (SrcPlane s, ScaleDev sd,
 __global__ __launch_bounds__ (256) void k_plane_vscale (SrcPlane s, ScaleDev sd, DstPlane d, int width, int oh)
 {
   plane_vscale_body (s, sd, d, width, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+// 3- / 4-byte pixel permutations (video_swizzle34.h)
+template <int SB, int DB>
+__global__ __launch_bounds__ (256) void k_swizzle34 (Swz34Params p)
+{
+  swizzle34_body<SB, DB> (p, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+// map[j]: which source byte of a pixel lands in destination byte j.  src_pos / dst_pos: byte of component c (A, c1, c2, c3) in the
+// source / destination pixel; a 3-byte pixel has no component 0.
+bool swizzle34_setup (int src_bytes, const int *src_pos, int dst_bytes, const int *dst_pos, const uint8_t *src, int sstride, uint8_t *dst, int dstride,
+    int width, Swz34Params *p)
+{
+  if (((uintptr_t) src % 4) != 0 || (sstride % 4) != 0 || ((uintptr_t) dst % 4) != 0 || (dstride % 4) != 0 || (src_bytes == 4 && dst_bytes == 4))
+    return false;
+  uint8_t map[4] = {0, 0, 0, 0};
+  for (int c = dst_bytes == 4 ? 0 : 1; c < 4; c++)
+    map[dst_pos[c]] = c == 0 && src_bytes == 3 ? 0xff : (uint8_t) src_pos[c];
+  memset ((void *) p, 0, sizeof (*p));
+  if (src_bytes == 3 && dst_bytes == 4)
+    swz34_selectors<3, 4> (map, p);
+  else if (src_bytes == 4 && dst_bytes == 3)
+    swz34_selectors<4, 3> (map, p);
+  else
+    swz34_selectors<3, 3> (map, p);
+  p->src = src, p->sstride = sstride, p->dst = dst, p->dstride = dstride, p->width = width;
+  return true;
+}
+
+hipError_t launch_swizzle34 (const Swz34Params &p, int src_bytes, int dst_bytes, int height, hipStream_t stream)
+{
+  const dim3 grid (((p.width + 3) / 4 + 255) / 256, height);
+  if (src_bytes == 3 && dst_bytes == 4)
+    hipLaunchKernelGGL ((k_swizzle34<3, 4>), grid, dim3 (256), 0, stream, p);
+  else if (src_bytes == 4 && dst_bytes == 3)
+    hipLaunchKernelGGL ((k_swizzle34<4, 3>), grid, dim3 (256), 0, stream, p);
+  else
+    hipLaunchKernelGGL ((k_swizzle34<3, 3>), grid, dim3 (256), 0, stream, p);
+  return hipGetLastError ();
 }
 
 // plane re-arrangement (video_relayout.h): 16 output bytes per lane, grid.y = luma rows, then the chroma rows of the destination's planes

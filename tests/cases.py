@@ -313,6 +313,19 @@ VIDEO_CASES = [
     ("nv24_y444_relayout_80x5", "NV24", 80, 5, "Y444", 80, 5, {}, None, None, "random"),
     ("nv61_y42b_relayout_64x6", "NV61", 64, 6, "Y42B", 64, 6, {}, None, None, "random"),
     ("i420_nv12_relayout_bt601_to_bt709_is_a_matrix", "I420", 64, 16, "NV12", 64, 16, {}, "bt601>bt709", None, "random"),
+    # 3- / 4-byte pixel permutations (video_swizzle34.h): four pixels per lane, the tail pixel by pixel
+    ("rgb_bgra_swizzle34_64x9", "RGB", 64, 9, "BGRA", 64, 9, {}, None, None, "random"),
+    ("bgr_xrgb_swizzle34_67x5_tail", "BGR", 67, 5, "xRGB", 67, 5, {}, None, None, "random"),
+    ("rgb_argb_swizzle34_1x3", "RGB", 1, 3, "ARGB", 1, 3, {}, None, None, "random"),
+    ("bgra_rgb_swizzle43_64x9", "BGRA", 64, 9, "RGB", 64, 9, {}, None, None, "random"),
+    ("argb_bgr_swizzle43_70x4_tail", "ARGB", 70, 4, "BGR", 70, 4, {}, None, None, "random"),
+    ("rgbx_rgb_swizzle43_5x5", "RGBx", 5, 5, "RGB", 5, 5, {}, None, None, "random"),
+    ("rgb_bgr_swizzle33_64x7", "RGB", 64, 7, "BGR", 64, 7, {}, None, None, "random"),
+    ("bgr_rgb_swizzle33_71x3_tail", "BGR", 71, 3, "RGB", 71, 3, {}, None, None, "random"),
+    ("v308_ayuv_swizzle34_64x6", "v308", 64, 6, "AYUV", 64, 6, {}, None, None, "random"),
+    ("ayuv_iyu2_swizzle43_36x6", "AYUV", 36, 6, "IYU2", 36, 6, {}, None, None, "random"),
+    ("vuya_v308_swizzle43_40x4", "VUYA", 40, 4, "v308", 40, 4, {}, None, None, "random"),
+    ("iyu2_v308_swizzle33_44x4", "IYU2", 44, 4, "v308", 44, 4, {}, None, None, "random"),
     ("yuy2_uyvy_322x241_fastpath", "YUY2", 322, 241, "UYVY", 322, 241, {}, None, None, "random"),
     ("uyvy_yuy2_33x17_fastpath", "UYVY", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
     ("yuy2_yuy2_copy_33x17_planes", "YUY2", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),

@@ -26,6 +26,7 @@
 #include "../../gstreamer_amd/csrc/video_dither.h"
 #include "../../gstreamer_amd/csrc/video_dither_ed.h"
 #include "../../gstreamer_amd/csrc/video_relayout.h"
+#include "../../gstreamer_amd/csrc/video_swizzle34.h"
 
 using namespace gstamd;
 
@@ -694,6 +695,35 @@ extern "C" int emu_gamma_fused_runs (void) { return g_gamma_fused_runs; }
 extern "C" int emu_h420_runs (void) { return g_h420_runs; }
 extern "C" int emu_h420_reg_runs (void) { return g_h420_reg_runs; }
 
+// k_swizzle34 (video_kernels.hip swizzle34_setup + the kernel's grid)
+static bool emu_swizzle34 (int sb, const int *src_pos, int db, const int *dst_pos, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int width, int height)
+{
+  if (((uintptr_t) src % 4) != 0 || (sstride % 4) != 0 || ((uintptr_t) dst % 4) != 0 || (dstride % 4) != 0 || getenv ("EMU_NO_SWIZZLE34"))
+    return false;
+  uint8_t map[4] = {0, 0, 0, 0};
+  for (int c = db == 4 ? 0 : 1; c < 4; c++)
+    map[dst_pos[c]] = c == 0 && sb == 3 ? 0xff : (uint8_t) src_pos[c];
+  Swz34Params sp;
+  memset ((void *) &sp, 0, sizeof (sp));
+  if (sb == 3 && db == 4)
+    swz34_selectors<3, 4> (map, &sp);
+  else if (sb == 4 && db == 3)
+    swz34_selectors<4, 3> (map, &sp);
+  else
+    swz34_selectors<3, 3> (map, &sp);
+  sp.src = src, sp.sstride = sstride, sp.dst = dst, sp.dstride = dstride, sp.width = width;
+  for (int y = 0; y < height; y++)
+    for (int lane = 0; lane < ((width + 3) / 4 + 255) / 256 * 256; lane++) {
+      if (sb == 3 && db == 4)
+        swizzle34_body<3, 4> (sp, lane, y);
+      else if (sb == 4 && db == 3)
+        swizzle34_body<4, 3> (sp, lane, y);
+      else
+        swizzle34_body<3, 3> (sp, lane, y);
+    }
+  return true;
+}
+
 static int g_swizzle4_runs = 0;
 static int g_extra_rows = 0;          /* the AYUV image of a planar destination is being rendered with the line past the picture */
 extern "C" int emu_swizzle4_runs (void) { return g_swizzle4_runs; }
@@ -1003,6 +1033,12 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     }
     return GSTAMD_OK;
   }
+  if (p.out_planar && p.fout->kind == UNPACK_PACKED3 && p.passes.empty () && !p.deep16 && !p.pack.dither.on && p.matrix.kind == MATRIX_NONE &&
+      p.post.alpha_kind == ALPHA_NONE && p.front.hi_depth == 0 && (p.front.kind == UNPACK_PACKED4 || p.front.kind == UNPACK_PACKED3) &&
+      p.post.pack_pos[0] == 0 && p.post.pack_pos[1] == 1 && p.post.pack_pos[2] == 2 && p.post.pack_pos[3] == 3 &&
+      emu_swizzle34 (p.front.kind == UNPACK_PACKED4 ? 4 : 3, p.front.pos, 3, p.pack.pos, pl.p[0], pl.stride[0], dst + out->offset[0], out->stride[0],
+          p.out_info.width, p.out_info.height))
+    return GSTAMD_OK;
   if (p.out_planar && p.fout->kind == UNPACK_PACKED3 && p.passes.empty () && p.fast_pair && vec_ok)
     return emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok >= 200 ? 1 : vec_ok, true);     /* the line-pair kernel stores 3-byte pixels itself */
   if (p.out_planar && p.fast_enc420 && vec_ok) {      /* k_encode420's grid: 4 x 2 pixel blocks */
@@ -1297,6 +1333,9 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
       }
     return GSTAMD_OK;
   }
+  if (p.passes.empty () && p.front.kind == UNPACK_PACKED3 && p.front.hi_depth == 0 && color.matrix.kind == MATRIX_NONE && color.alpha_kind == ALPHA_NONE &&
+      !rgb24 && emu_swizzle34 (3, p.front.pos, 4, p.post.pack_pos, pl.p[0], pl.stride[0], d0, dstride, p.front.width, p.front.height))
+    return GSTAMD_OK;
   if (p.passes.empty () && vec_ok == 2 && p.front.hi_depth == 0 && color.matrix.kind == MATRIX_NONE && color.alpha_kind == ALPHA_NONE) {
     /* k_swizzle4: a byte permutation per pixel, four pixels per lane */
     const uint32_t sel = swizzle4_selector (p.front.pos, p.post.pack_pos);

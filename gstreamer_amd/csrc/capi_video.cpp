@@ -1139,6 +1139,17 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     e = launch_convert422 (q, pl.p[0], pl.stride[0], dst, dstride, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert422");
   }
+  if (p.fast_422_ayuv && !c->hook_on && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && ((uintptr_t) dst % 16) == 0 && (dstride % 16) == 0 &&
+      !tuning_on ("GSTAMD_NO_FAST422")) {
+    Fast422Params q;
+    memset ((void *) &q, 0, sizeof (q));
+    q.fp.width = p.front.width;
+    q.fp.height = p.front.height;
+    q.chroma_h = p.front.chroma_h;
+    fast422_selectors (p.front.pos[1], p.front.pos[2], p.front.pos[3], &q);
+    e = launch_convert422 (q, pl.p[0], pl.stride[0], dst, dstride, stream, true);
+    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert422_ayuv");
+  }
   if (p.deep16) {
     if (((uintptr_t) dst % 4) != 0 || (dstride % 4) != 0 || ((uintptr_t) pl.p[0] % 2) != 0 || (pl.stride[0] % 2) != 0 || ((uintptr_t) pl.p[1] % 2) != 0 ||
         (pl.stride[1] % 2) != 0 || (p.front.kind == UNPACK_PLANAR && (((uintptr_t) pl.p[2] % 2) != 0 || (pl.stride[2] % 2) != 0)))

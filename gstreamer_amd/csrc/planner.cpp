@@ -1535,7 +1535,7 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   g.pack16 = out16 && !g.store64;
   g.planes_fast = false;
   /* nothing of the single-converter plan is used by a composite */
-  plan->plane_mode = plan->relayout = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_post = plan->deep16 = false;
+  plan->plane_mode = plan->relayout = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_422_ayuv = plan->fast_post = plan->deep16 = false;
   plan->matrix_before_scale = false;
   plan->vpair.clear ();
   plan->planes.clear ();
@@ -1831,7 +1831,7 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   g.store64 = fo->hi_depth == 3;
   g.pack16 = hi_depth_words (fo->hi_depth);
   g.fused = g.planes_fast = false;
-  plan->plane_mode = plan->relayout = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_post = false;
+  plan->plane_mode = plan->relayout = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_422_ayuv = plan->fast_post = false;
   plan->deep16 = plan->deep_out = false;
   plan->matrix_before_scale = false;
   plan->vpair.clear ();
@@ -2123,6 +2123,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   plan->out_planar = plan->fout->kind != UNPACK_PACKED4;
   plan->plane_mode = false;
   plan->relayout = false;
+  plan->fast_422_ayuv = false;
   /* chain_dither (:2035-2100) on an 8-bit chain: a stage exists when dither-quantization asks for a coarser quantiser than the
    * format's own (1 at 8 bits) and the method is not NONE - NONE returns before anything is set up, quantisation included.  Every
    * component the destination has (depth > 0) gets the quantiser, rounded down to a power of two (count_power). */
@@ -2490,6 +2491,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   /* capture direction (video_422_fast.h): unscaled packed 4:2:2 -> 4-byte RGB, whole 8-pixel groups, no odd-width tail quirk */
   plan->fast_422 = plan->passes.empty () && fr.kind == UNPACK_PACKED422 && !plan->out_planar && matrix_no_wrap && (in_w % 8) == 0 &&
       fr.swap_k < 0 && !fr.chroma_v2;
+  plan->fast_422_ayuv = plan->passes.empty () && fr.kind == UNPACK_PACKED422 && plan->matrix.kind == MATRIX_NONE && post.alpha_kind == ALPHA_NONE &&
+      (in_w % 8) == 0 && fr.swap_k < 0 && !fr.chroma_v2 && post.pack_pos[0] == 0 && post.pack_pos[1] == 1 && post.pack_pos[2] == 2 && post.pack_pos[3] == 3;
   /* decoder-output direction: the reference's I420 / YV12 -> RGB same-size fastpaths (nearest chroma), whole 8-pixel groups */
   plan->fast_420p = plan->passes.empty () && fr.kind == UNPACK_PLANAR && fr.w_sub == 1 && fr.h_sub == 1 && fr.chroma_h == CHROMA_H_NONE &&
       !fr.chroma_v2 && !plan->out_planar && matrix_no_wrap && (in_w % 8) == 0;
@@ -2519,7 +2522,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     }
   }
   if (plan->deep16 || plan->deep_out)
-    plan->fast_pair = plan->fast_420p = plan->fast_422 = plan->fast_enc420 = plan->fast_post = false;
+    plan->fast_pair = plan->fast_420p = plan->fast_422 = plan->fast_422_ayuv = plan->fast_enc420 = plan->fast_post = false;
   if (plan->pack.dither.on)             /* the dither stage lives in the pack kernel: the fused kernels that write planes / 3-byte pixels themselves have none */
     plan->fast_pair = plan->fast_enc420 = false;
   /* planar / semi-planar 8-bit YUV on both sides with the same subsampling, and a chain that neither filters nor mixes: the front hands

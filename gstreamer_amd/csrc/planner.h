@@ -265,6 +265,7 @@ struct VideoPlan {
   bool relayout;              // the chain changes nothing but where the samples sit (I420 <-> NV12 <-> NV21 <-> YV12, Y42B <-> NV16, Y444 <-> NV24): video_relayout.h
   bool fast_enc420;           // unscaled 4-byte RGB -> 4:2:0 YUV through the table matrix: the block kernel of video_encode_fast.h applies
   bool fast_420p;             // unscaled planar 4:2:0 -> 4-byte RGB with nearest chroma (the reference's convert_I420_BGRA family): video_422_fast.h
+  bool fast_422_ayuv;         // unscaled packed 4:2:2 with neither matrix nor alpha stage: the same kernel leaving A, Y, U, V bytes (AYUV destinations, the image ahead of a planar pack)
   bool fast_422;              // unscaled packed 4:2:2 -> 4-byte RGB through the no-wrap AYUV_ARGB matrix: video_422_fast.h applies
   bool fast_post;             // scaled plans: the post stage may run fast_pixel (matrix provably wrap-free, alpha stays 0xff)
   bool deep_out;              // 10-bit destination: the composite of GammaPlan with pack16

@@ -41,8 +41,9 @@ GSTAMD_HD uint32_t fast_pixel_uv (const FastParams &fp, uint32_t yx, uint32_t ys
   return bperm ((uint32_t) b, ((uint32_t) g << 8) | (uint32_t) r, fp.pack_sel);
 }
 
-// pixels x0 .. x0+7 (x0 % 8 == 0, x0 + 8 <= width) of one line; srow / drow 16-byte aligned
-template <int CH>
+// pixels x0 .. x0+7 (x0 % 8 == 0, x0 + 8 <= width) of one line; srow / drow 16-byte aligned.  AYUV = 1: no matrix, the pixels leave as
+// A = 0xff, Y, U, V bytes (the chain's AYUV image ahead of a planar pack, or an AYUV destination)
+template <int CH, int AYUV = 0>
 GSTAMD_HD void convert422_lane8 (const Fast422Params &p, const uint8_t *__restrict__ srow, uint8_t *__restrict__ drow, int x0)
 {
   const int w = p.fp.width;
@@ -50,7 +51,8 @@ GSTAMD_HD void convert422_lane8 (const Fast422Params &p, const uint8_t *__restri
   // neighbour macropixels, clamped into the line (the reference repeats the edge sample)
   const uint32_t mn = x0 + 8 < w ? *(const uint32_t *) (srow + 2 * (size_t) (x0 + 8)) : m.w;
   const uint32_t mp = (CH == CHROMA_H_H2 && x0 > 0) ? *(const uint32_t *) (srow + 2 * (size_t) (x0 - 2)) : m.x;
-  const uint32_t y03 = bperm (m.y, m.x, p.sel_y) ^ 0x80808080u, y47 = bperm (m.w, m.z, p.sel_y) ^ 0x80808080u;
+  const uint32_t flip = AYUV ? 0u : 0x80808080u;
+  const uint32_t y03 = bperm (m.y, m.x, p.sel_y) ^ flip, y47 = bperm (m.w, m.z, p.sel_y) ^ flip;
   const uint32_t u4 = bperm (bperm (m.w, m.z, p.sel_c2), bperm (m.y, m.x, p.sel_c2), 0x05040100u);       // U of macropixels 0..3
   const uint32_t v4 = bperm (bperm (m.w, m.z, p.sel_c2v), bperm (m.y, m.x, p.sel_c2v), 0x05040100u);
   const uint32_t un = bperm (0, mn, p.sel_c2) & 0xffu, vn = bperm (0, mn, p.sel_c2v) & 0xffu;
@@ -65,10 +67,19 @@ GSTAMD_HD void convert422_lane8 (const Fast422Params &p, const uint8_t *__restri
     uo = blend31_u8 (u4, align_bytes (un, u4, 1));
     vo = blend31_u8 (v4, align_bytes (vn, v4, 1));
   }
-  ue ^= 0x80808080u, ve ^= 0x80808080u, uo ^= 0x80808080u, vo ^= 0x80808080u;
+  ue ^= flip, ve ^= flip, uo ^= flip, vo ^= flip;
   uint32_t o[8];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
+    if (AYUV) {
+      const uint32_t yw = j < 2 ? y03 : y47;
+      const uint32_t s0 = 0x0000000du | ((uint32_t) (2 * (j & 1)) << 8) | ((uint32_t) (4 + j) << 16) | 0x0c000000u;
+      const uint32_t s1 = 0x0000000du | ((uint32_t) (2 * (j & 1) + 1) << 8) | ((uint32_t) (4 + j) << 16) | 0x0c000000u;
+      const uint32_t sv = 0x00020100u | ((uint32_t) (4 + j) << 24);
+      o[2 * j] = bperm (ve, bperm (ue, yw, s0), sv);
+      o[2 * j + 1] = bperm (vo, bperm (uo, yw, s1), sv);
+      continue;
+    }
     const uint32_t csel = 0x0c00000cu | ((uint32_t) j << 8) | ((uint32_t) j << 16);
     const uint32_t yw = j < 2 ? y03 : y47;
     const uint32_t ys0 = 0x0c00000cu | ((uint32_t) (2 * (j & 1)) << 8) | ((uint32_t) (2 * (j & 1)) << 16);
@@ -86,6 +97,16 @@ GSTAMD_HD void convert422_lane8 (const Fast422Params &p, const uint8_t *__restri
   for (int i = 0; i < 8; i++)
     ((uint32_t *) d)[i] = o[i];
 #endif
+}
+
+GSTAMD_HD void convert422_lane8_ayuv (const Fast422Params &p, const uint8_t *srow, uint8_t *drow, int x0)
+{
+  if (p.chroma_h == CHROMA_H_H2_CS)
+    convert422_lane8<CHROMA_H_H2_CS, 1> (p, srow, drow, x0);
+  else if (p.chroma_h == CHROMA_H_H2)
+    convert422_lane8<CHROMA_H_H2, 1> (p, srow, drow, x0);
+  else
+    convert422_lane8<CHROMA_H_NONE, 1> (p, srow, drow, x0);
 }
 
 GSTAMD_HD void convert422_lane8_any (const Fast422Params &p, const uint8_t *srow, uint8_t *drow, int x0)

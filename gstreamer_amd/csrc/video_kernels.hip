@@ -503,6 +503,13 @@ __global__ __launch_bounds__ (256) void k_convert422 (Fast422Params p, const uin
     convert422_lane8_any (p, src + (size_t) y * sstride, dst + (size_t) y * dstride, x0);
 }
 
+__global__ __launch_bounds__ (256) void k_convert422_ayuv (Fast422Params p, const uint8_t *src, int sstride, uint8_t *dst, int dstride)
+{
+  const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 8, y = (int) blockIdx.y;
+  if (x0 < p.fp.width)
+    convert422_lane8_ayuv (p, src + (size_t) y * sstride, dst + (size_t) y * dstride, x0);
+}
+
 // unscaled planar 4:2:0 -> 4-byte RGB, nearest chroma (video_422_fast.h): a lane = 8 pixels of a line pair
 __global__ __launch_bounds__ (256) void k_convert420p (Fast420pParams p, uint8_t *dst, int dstride)
 {
@@ -1264,10 +1271,13 @@ hipError_t launch_convert420p (const Fast420pParams &p, uint8_t *dst, int dstrid
   return hipGetLastError ();
 }
 
-hipError_t launch_convert422 (const Fast422Params &p, const uint8_t *src, int sstride, uint8_t *dst, int dstride, hipStream_t stream)
+hipError_t launch_convert422 (const Fast422Params &p, const uint8_t *src, int sstride, uint8_t *dst, int dstride, hipStream_t stream, bool ayuv)
 {
   dim3 grid ((p.fp.width / 8 + 255) / 256, p.fp.height);
-  hipLaunchKernelGGL (k_convert422, grid, dim3 (256), 0, stream, p, src, sstride, dst, dstride);
+  if (ayuv)
+    hipLaunchKernelGGL (k_convert422_ayuv, grid, dim3 (256), 0, stream, p, src, sstride, dst, dstride);
+  else
+    hipLaunchKernelGGL (k_convert422, grid, dim3 (256), 0, stream, p, src, sstride, dst, dstride);
   return hipGetLastError ();
 }
 

@@ -326,6 +326,12 @@ VIDEO_CASES = [
     ("ayuv_iyu2_swizzle43_36x6", "AYUV", 36, 6, "IYU2", 36, 6, {}, None, None, "random"),
     ("vuya_v308_swizzle43_40x4", "VUYA", 40, 4, "v308", 40, 4, {}, None, None, "random"),
     ("iyu2_v308_swizzle33_44x4", "IYU2", 44, 4, "v308", 44, 4, {}, None, None, "random"),
+    # packed 4:2:2 through the full chain (chroma upsampler, then the pack's downsampler) with the wide front (k_convert422_ayuv)
+    ("yuy2_nv12_chain_wide_front_640x18", "YUY2", 640, 18, "NV12", 640, 18, {}, None, None, "random"),
+    ("uyvy_nv21_chain_wide_front_cosited_64x10", "UYVY", 64, 10, "NV21", 64, 10, {}, None, "cosited", "random"),
+    ("yvyu_y444_chain_wide_front_64x6", "YVYU", 64, 6, "Y444", 64, 6, {}, None, None, "random"),
+    ("yuy2_ayuv_wide_front_64x6", "YUY2", 64, 6, "AYUV", 64, 6, {}, None, None, "random"),
+    ("uyvy_ayuv_wide_front_chroma_none_72x5", "UYVY", 72, 5, "AYUV", 72, 5, dict(chroma_mode="none"), None, None, "random"),
     ("yuy2_uyvy_322x241_fastpath", "YUY2", 322, 241, "UYVY", 322, 241, {}, None, None, "random"),
     ("uyvy_yuy2_33x17_fastpath", "UYVY", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
     ("yuy2_yuy2_copy_33x17_planes", "YUY2", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),

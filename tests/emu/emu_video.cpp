@@ -1270,6 +1270,19 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
         convert422_lane8_any (q, pl.p[0] + (size_t) y * pl.stride[0], d0 + (size_t) y * dstride, x0);
     return GSTAMD_OK;
   }
+  if (p.fast_422_ayuv && !rgb24 && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && ((uintptr_t) d0 % 16) == 0 && (dstride % 16) == 0 &&
+      getenv ("GSTAMD_NO_FAST422") == nullptr) {        /* k_convert422_ayuv */
+    Fast422Params q;
+    memset ((void *) &q, 0, sizeof (q));
+    q.fp.width = p.front.width;
+    q.fp.height = p.front.height;
+    q.chroma_h = p.front.chroma_h;
+    fast422_selectors (p.front.pos[1], p.front.pos[2], p.front.pos[3], &q);
+    for (int y = 0; y < p.front.height; y++)
+      for (int x0 = 0; x0 < p.front.width; x0 += 8)
+        convert422_lane8_ayuv (q, pl.p[0] + (size_t) y * pl.stride[0], d0 + (size_t) y * dstride, x0);
+    return GSTAMD_OK;
+  }
   if (p.deep16 && p.passes.empty ()) {     /* k_convert16 */
     for (int y = 0; y < p.front.height; y++)
       for (int x0 = 0; x0 < p.front.width; x0 += 4)

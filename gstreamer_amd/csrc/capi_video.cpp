@@ -75,11 +75,16 @@ struct GstAmdVideoConverter {
   size_t deep_a_size = 0, deep_b_size = 0;
   /* gamma-mode = remap (GammaPlan): the two sub-conversions, the tables and the 8-bit images either side of the 16-bit part */
   GstAmdVideoConverter *sub_in = nullptr, *sub_out = nullptr;
+  const uint8_t *post_lut = nullptr;    /* this converter is the direct conversion of a GammaPlan::lut_direct plan: the composed table (device) the parent wants on
+                                         * the colour bytes; a kernel that applies it itself says so in post_lut_done, otherwise the parent runs k_lut3 */
+  int post_lut_keep = 0;
+  bool post_lut_done = false;
   bool hook_on = false;                 /* this converter is the direct conversion of a fused gamma plan: k_convert_gamma with `hook` */
   GammaDev hook;
   uint16_t *gamma_dec_dev = nullptr;
   uint16_t *gamma_dec16_dev = nullptr, *gamma_enc16_dev = nullptr;          /* the 65536-entry tables of a remap with 16-bit ends */
   uint8_t *gamma_enc_dev = nullptr;
+  uint8_t *gamma_comp_dev = nullptr;      /* GammaPlan::comp */
   uint8_t *gamma_mid_a = nullptr, *gamma_mid_b = nullptr;
   /* The scratch images above (tmp, plane_tmp, pk_img, ed_carry, deep_a / deep_b, gamma_mid_a / gamma_mid_b) belong to the frames of ONE
    * stream: a second stream's frames would run over them while the first one's kernels are still reading.  Every stream a frame is sent
@@ -273,8 +278,12 @@ static int build_sub_converters (VideoPlan &plan, GstAmdVideoConverter **sub_in,
   const GammaPlan &g = plan.gamma;
   int st = GSTAMD_OK;
   bool ok = true;
-  if (!g.src16 && !g.src64)
+  if (!g.src16 && !g.src64) {
+    if (g.lut_direct)
+      plan_set_matrix_override (&g.to_rgb);
     ok = (*sub_in = gstamd_video_converter_new (&g.sub_in_info, &g.mid_in, &g.cfg_in, &st)) != nullptr;
+    plan_set_matrix_override (nullptr);
+  }
   if (ok && g.fused) {
     ok = (*sub_in)->plan.passes.empty () && !(*sub_in)->plan.out_planar && !(*sub_in)->plan.plane_mode && !(*sub_in)->plan.gamma.on;
     if (!ok) {
@@ -355,6 +364,9 @@ static int build_tables (GstAmdVideoConverter *c)
     if (!g.enc.empty () && ((e = hipMalloc ((void **) &c->gamma_enc_dev, 65536)) != hipSuccess ||
             (e = hipMemcpy (c->gamma_enc_dev, g.enc.data (), 65536, hipMemcpyHostToDevice)) != hipSuccess))
       return hip_fail (e, "encode table");
+    if (!g.comp.empty () && ((e = hipMalloc ((void **) &c->gamma_comp_dev, 256)) != hipSuccess ||
+            (e = hipMemcpy (c->gamma_comp_dev, g.comp.data (), 256, hipMemcpyHostToDevice)) != hipSuccess))
+      return hip_fail (e, "composed gamma table");
     if (!g.dec16.empty () && ((e = hipMalloc ((void **) &c->gamma_dec16_dev, 65536 * sizeof (uint16_t))) != hipSuccess ||
             (e = hipMemcpy (c->gamma_dec16_dev, g.dec16.data (), 65536 * sizeof (uint16_t), hipMemcpyHostToDevice)) != hipSuccess))
       return hip_fail (e, "16-bit decode table");
@@ -604,11 +616,26 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   gd.alpha_value = g.alpha_value;
   gd.dec = c->gamma_dec_dev;
   gd.enc = c->gamma_enc_dev;
+  gd.comp = tuning_on ("GSTAMD_NO_GAMMA_COMP") ? nullptr : c->gamma_comp_dev;
   gd.to_rgb16 = g.to_rgb16;
   gd.to_yuv16 = g.to_yuv16;
   gd.dec16 = c->gamma_dec16_dev;
   gd.enc16 = c->gamma_enc16_dev;
   const bool dec16 = !g.dec16.empty (), enc16 = !g.enc16.empty ();          /* gamma remap with a 16-bit source / destination */
+  if (g.fused && g.lut_direct) {
+    /* the direct conversion with its own kernels, then the composed table over the converted rectangle */
+    c->sub_in->hook_on = false;
+    c->sub_in->post_lut = c->gamma_comp_dev;
+    c->sub_in->post_lut_keep = p.fout->pos[0];
+    c->sub_in->post_lut_done = false;
+    const int dr = gstamd_video_converter_frame_planes (c->sub_in, src_planes, src_stride, dest_planes, dest_stride, stream);
+    if (dr != GSTAMD_OK || c->sub_in->post_lut_done)
+      return dr;
+    const int ds = dest_stride ? dest_stride[0] : p.out_info.stride[0];
+    uint8_t *rect = (uint8_t *) dest_planes[0] + plane_origin (p.fout, 0, p.rect.out_x, p.rect.out_y, ds);
+    const hipError_t le = launch_lut3 (rect, ds, p.out_info.width, p.out_info.height, c->gamma_comp_dev, p.fout->pos[0], stream);
+    return le == hipSuccess ? GSTAMD_OK : hip_fail (le, "k_lut3");
+  }
   if (g.fused) {
     c->sub_in->hook = gd;
     c->sub_in->hook_on = true;
@@ -1112,7 +1139,12 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
   color.alpha_value = p.post.alpha_value;
   hipError_t e;
   if (fast_pair_usable (p, pl, dst, dstride)) {
-    const FastParams fp = make_fast_params (p);
+    FastParams fp = make_fast_params (p);
+    if (c->post_lut) {
+      fp.lut = c->post_lut;
+      fp.lut_keep = c->post_lut_keep;
+      c->post_lut_done = true;
+    }
     const uint8_t *y = pl.p[0], *uv = pl.p[1];
     e = launch_convert_pair (fp, p.front.chroma_h, 1, &y, &uv, &dst, pl.stride[0], pl.stride[1], dstride, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair");
@@ -1467,6 +1499,9 @@ static void release_tables (GstAmdVideoConverter *c)
     (void) hipFree (c->gamma_dec_dev);
   if (c->gamma_enc_dev)
     (void) hipFree (c->gamma_enc_dev);
+  if (c->gamma_comp_dev)
+    (void) hipFree (c->gamma_comp_dev);
+  c->gamma_comp_dev = nullptr;
   if (c->gamma_mid_a)
     (void) hipFree (c->gamma_mid_a);
   if (c->gamma_mid_b)

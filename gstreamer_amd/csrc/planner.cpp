@@ -8,6 +8,10 @@
 
 namespace gstamd {
 
+// capi_video.cpp sets this around the planning of a fused gamma plan's direct conversion (config.internal_flags & 2)
+static thread_local const MatrixParams *g_matrix_override = nullptr;
+void plan_set_matrix_override (const MatrixParams *m) { g_matrix_override = m; }
+
 // ------------------------------------------------------------------------------------------------
 // format table (facts: video-format.c:8190-8235; byte orders: video-orc.orc:334-411)
 // ------------------------------------------------------------------------------------------------
@@ -1725,6 +1729,13 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   }
   plan->algorithmic_bytes = picture_bytes (fi, in_w, in_h) + picture_bytes (fo, out_w, out_h);
   g.fused = plan->passes.empty () && fo->kind == UNPACK_PACKED4 && !in16 && !out16;
+  g.comp.clear ();
+  if (g.fused && !g.prim.has_matrix && g.alpha_kind == ALPHA_NONE && g.dec.size () == 256 && g.enc.size () == 65536) {
+    g.comp.resize (256);
+    for (int i = 0; i < 256; i++)
+      g.comp[i] = g.enc[g.dec[i]];
+  }
+  g.lut_direct = false;
   if (g.fused) {
     /* the direct conversion (crop, chroma upsampler as the real chain decides it, destination rectangle, borders, dither) minus matrix and
        alpha, which are the gamma chain's */
@@ -1732,7 +1743,44 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     g.cfg_in.chroma_mode = cfg.chroma_mode;
     g.mid_in = plan->orig_out;
   }
-  plan->description = std::string (g.fused ? "gamma_fused[" : "gamma_remap[") + fi->name + "->" + fo->name + (g.src16 ? ",front16" : "") + (in16 ? ",dec16" : "") +
+  if (g.fused && !g.comp.empty () && g.to_yuv.kind == MATRIX_NONE && !plan->rect.fill) {
+    /* an RGB destination, nothing between the two tables: if the chain's own one-step plan for these frames (same options, no gamma, the
+       chain rather than a transforms[] fastpath) has exactly to_rgb as its matrix and no dither stage, the remap is that conversion followed
+       by the composed table on the colour bytes */
+    GstAmdVideoConverterConfig direct = cfg;
+    direct.gamma_mode = GSTAMD_GAMMA_MODE_NONE;
+    direct.primaries_mode = GSTAMD_PRIMARIES_MODE_NONE;
+    direct.internal_flags = 1;
+    direct.src_x = direct.src_y = direct.src_width = direct.src_height = 0;
+    direct.dest_x = direct.dest_y = direct.dest_width = direct.dest_height = 0;
+    VideoPlan tmp;
+    std::string terr;
+    memset (&tmp.rect, 0, sizeof (tmp.rect));
+    tmp.rect.in_maxw = in->width, tmp.rect.in_maxh = in->height;
+    tmp.rect.out_maxw = out->width, tmp.rect.out_maxh = out->height;
+    tmp.orig_in = *in;
+    tmp.orig_out = *out;
+    const int dbg_r = plan_core (in, out, &direct, &tmp, &terr);
+    if (getenv ("GSTAMD_PLAN_DEBUG")) {
+      fprintf (stderr, "lut_direct probe: r=%d (%s) gamma %d dither %d planar %d plane %d passes %zu alpha %d | kind %d/%d p %d %d %d %d %d / %d %d %d %d %d\n", dbg_r, terr.c_str (), tmp.gamma.on,
+          tmp.dither.on, tmp.out_planar, tmp.plane_mode, tmp.passes.size (), tmp.post.alpha_kind, tmp.matrix.kind, g.to_rgb.kind, tmp.matrix.p[0], tmp.matrix.p[1], tmp.matrix.p[2],
+          tmp.matrix.p[3], tmp.matrix.p[4], g.to_rgb.p[0], g.to_rgb.p[1], g.to_rgb.p[2], g.to_rgb.p[3], g.to_rgb.p[4]);
+      for (int i = 0; i < 3; i++)
+        fprintf (stderr, "  im %d %d %d %d / %d %d %d %d\n", tmp.matrix.im[i][0], tmp.matrix.im[i][1], tmp.matrix.im[i][2], tmp.matrix.im[i][3], g.to_rgb.im[i][0], g.to_rgb.im[i][1],
+            g.to_rgb.im[i][2], g.to_rgb.im[i][3]);
+    }
+    if (dbg_r == GSTAMD_OK && !tmp.gamma.on && !tmp.dither.on && !tmp.out_planar && !tmp.plane_mode &&
+        tmp.passes.empty () && tmp.post.alpha_kind == ALPHA_NONE && tmp.matrix.kind == g.to_rgb.kind && g.to_rgb.kind != MATRIX_NONE) {
+      /* the chain's to_RGB matrix maps to 0 .. 256, the one-step conversion's to 0 .. 255: same form (kind), other coefficients - the
+         direct plan is made with to_rgb in place of its own matrix (internal_flags & 2) */
+      g.lut_direct = true;
+      g.cfg_in = cfg;
+      g.cfg_in.gamma_mode = GSTAMD_GAMMA_MODE_NONE;
+      g.cfg_in.primaries_mode = GSTAMD_PRIMARIES_MODE_NONE;
+      g.cfg_in.internal_flags = 3;
+    }
+  }
+  plan->description = std::string (g.lut_direct ? "gamma_lut[" : g.fused ? "gamma_fused[" : "gamma_remap[") + fi->name + "->" + fo->name + (g.src16 ? ",front16" : "") + (in16 ? ",dec16" : "") +
       (g.to_rgb.kind || g.to_rgb16.has_matrix ? ",to_rgb" : "") + (g.prim.has_matrix ? ",primaries" : "") +
       (g.to_yuv.kind || g.to_yuv16.has_matrix ? ",to_yuv" : "") + (out16 ? ",enc16" : "") + (g.pack16 ? ",pack16" : g.store64 ? ",store64" : "") + (plan->passes.empty () ? "" : g.shrink ? ",scale16(first)" : ",scale16(last)") + "]";
   return GSTAMD_OK;
@@ -2399,6 +2447,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   // ---- alpha + pack ------------------------------------------------------------------------------
   PostParams &post = plan->post;
   memset (&post, 0, sizeof (post));
+  if ((cfg.internal_flags & 2) && g_matrix_override)
+    plan->matrix = *g_matrix_override;          /* GammaPlan::lut_direct: the direct plan with the gamma chain's to_RGB matrix in place of its own */
   post.matrix = plan->matrix;
   post.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
   post.alpha_value = (int) (255 * cfg.alpha_value);

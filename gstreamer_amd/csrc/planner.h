@@ -233,6 +233,11 @@ struct GammaPlan {
   bool shrink;                  // the scalers run before the primaries / alpha stages (chain_scale's first call)
   std::vector<uint16_t> dec;    // [256] gamma_convert_u8_u16's table
   std::vector<uint8_t> enc;     // [65536] gamma_convert_u16_u8's table
+  bool lut_direct = false;      // the fused form collapses further: to_rgb IS the direct conversion's matrix and `comp` is all the gamma chain does, so the
+                                // frame is the DIRECT conversion (cfg_in then carries the matrix: every fast kernel applies) followed by `comp` on the
+                                // colour bytes of the destination rectangle (k_lut3)
+  std::vector<uint8_t> comp;    // [256] enc[dec[v]]: the fused kernel's whole gamma part when nothing sits between the two tables (no primaries
+                                // matrix, no alpha operation) - both lookups are per component and exact, so is their composition
   /* gamma-mode = remap with a 16-bit unpack / pack format (setup_gamma_decode / _encode's 16 -> 16 tables, video-converter.c:1497-1564,
    * and the to-RGB / to-YUV matrices of chain_convert_to_RGB :1567 / _to_YUV :1956 prepared for 16 bits = video_converter_matrix16) */
   bool in16 = false, out16 = false;
@@ -310,6 +315,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
 // whole frames, no colour step, no dither): what a compositor pad's converter is when only the pad's size differs from its frames'
 // (GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513).  Such a plan can be sampled per destination pixel inside the blend
 // kernel (compositor_scaled.h).  *h / *v: index into plan.passes of the horizontal / vertical pass, -1: none.
+void plan_set_matrix_override (const MatrixParams *m);
 bool plan_is_pad_scaler (const VideoPlan &plan, int *h, int *v);
 // rows per 64-column canvas tile (12..16) of k_aggregate_scaled for pads scaled by this plan: the first pass under a tile is
 // rows x quads items (vertical first) or rows x 64 (horizontal first) spread over 256 lanes; the height that leaves the fewest idle

@@ -31,7 +31,29 @@ struct FastParams {
   int crow_lo, crow_hi; // chroma rows that exist, relative to the plane pointer (0 .. rows - 1; a source crop widens it)
   int pack_pos[4];      // destination byte of A, R, G, B
   int px_bytes;         // 4; 3: RGB / BGR destination - the pixel is formed as RGBx / BGRx and its three colour bytes are stored
+  const uint8_t *lut;   // NULL, or a 256-byte table in device memory every colour byte of the finished pixel goes through (GammaPlan::lut_direct:
+  int lut_keep;         // decode table . encode table); lut_keep: the destination byte that is alpha / filler and stays
 };
+
+// the table's copy in LDS while a kernel of the ABL == 2 ("table after the pack") variants runs: 64 words, filled by the kernel's one wave
+#ifdef __HIPCC__
+extern __shared__ uint32_t fast_lut_lds[];
+#else
+static uint32_t fast_lut_lds[64];
+#endif
+#define GSTAMD_FAST_LUT 2
+
+GSTAMD_HD uint32_t fast_lut3_px (uint32_t px, int keep)
+{
+  const uint8_t *t = (const uint8_t *) fast_lut_lds;
+  uint32_t r = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const uint32_t v = (px >> (8 * b)) & 0xffu;
+    r |= (b == keep ? v : (uint32_t) t[v]) << (8 * b);
+  }
+  return r;
+}
 
 inline void fast_params_finish (FastParams &fp, const int p[5], const int pack_pos[4], int u_first)
 {
@@ -46,6 +68,8 @@ inline void fast_params_finish (FastParams &fp, const int p[5], const int pack_p
   for (int i = 0; i < 4; i++)
     fp.pack_pos[i] = pack_pos[i];
   fp.px_bytes = 4;
+  fp.lut = nullptr;
+  fp.lut_keep = 0;
 }
 
 // RGB / BGR destination: the kernel forms RGBx / BGRx pixels (alpha in byte 3) and stores their three colour bytes
@@ -356,6 +380,11 @@ GSTAMD_HD void fast_emit4_l (const FastParams &fp, uint8_t *__restrict__ d, bool
 #pragma unroll
     for (int j = 0; j < 4; j++)
       sat_pk_u8_hi (o[j], q[j][1]);
+  }
+  if (ABL == GSTAMD_FAST_LUT) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      o[j] = fast_lut3_px (o[j], fp.lut_keep);
   }
   if (store) {
     if (fp.px_bytes == 3)                   // wave-uniform

@@ -23,6 +23,7 @@ struct GammaDev {
   unsigned alpha_value;
   const uint16_t *dec;          // [256]
   const uint8_t *enc;           // [65536]
+  const uint8_t *comp;          // [256] enc[dec[v]] or NULL (GammaPlan::comp)
   Deep16Params to_rgb16, to_yuv16;
   const uint16_t *dec16;        // [65536]
   const uint16_t *enc16;        // [65536]
@@ -89,10 +90,30 @@ GSTAMD_HD uint32_t gamma_enc_px (const GammaDev &g, uint2 px)
   return apply_matrix (g.to_yuv, p);
 }
 
+// GammaPlan::lut_direct: the composed table on the colour bytes of a finished 4-byte RGB pixel (`keep`: the byte that is alpha / filler)
+GSTAMD_HD uint32_t gamma_lut3_px (const uint8_t *comp, uint32_t px, int keep)
+{
+  uint32_t r = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const uint32_t v = (px >> (8 * b)) & 0xffu;
+    r |= (b == keep ? v : (uint32_t) comp[v]) << (8 * b);
+  }
+  return r;
+}
+
 // the whole per-pixel chain as the step convert_body takes between its colour stage and its packer (k_convert_gamma)
 struct GammaChainFn {
   GammaDev g;
-  GSTAMD_HD uint32_t operator() (uint32_t px) const { return gamma_enc_px (g, gamma_mid_px (g, gamma_dec_px (g, px))); }
+  GSTAMD_HD uint32_t operator() (uint32_t px) const
+  {
+    if (g.comp) {               /* decode table, nothing, encode table: one 256-entry table per component; alpha (a << 8 | a) >> 8 = a */
+      px = apply_matrix (g.to_rgb, px);
+      px = (px & 0xffu) | ((uint32_t) g.comp[(px >> 8) & 0xff] << 8) | ((uint32_t) g.comp[(px >> 16) & 0xff] << 16) | ((uint32_t) g.comp[px >> 24] << 24);
+      return apply_matrix (g.to_yuv, px);
+    }
+    return gamma_enc_px (g, gamma_mid_px (g, gamma_dec_px (g, px)));
+  }
 };
 
 // one pixel of a stage launch: the stages of `mask` in order; the source is an 8-bit image when the mask starts with the decode, the

@@ -79,6 +79,7 @@ hipError_t launch_plane_frame (const PlaneJobs &jobs, int n_tiles, size_t lds_by
 bool swizzle34_setup (int src_bytes, const int *src_pos, int dst_bytes, const int *dst_pos, const uint8_t *src, int sstride, uint8_t *dst, int dstride,
     int width, Swz34Params *p);
 hipError_t launch_swizzle34 (const Swz34Params &p, int src_bytes, int dst_bytes, int height, hipStream_t stream);
+hipError_t launch_lut3 (uint8_t *img, int stride, int w, int h, const uint8_t *comp_dev, int keep, hipStream_t stream);
 bool relayout_usable (const RelayoutParams &p);
 hipError_t launch_planes_relayout (const RelayoutParams &p, hipStream_t stream);
 bool convert_pack_usable (const FrontParams &f, const Planes &pl, const ColorParams &color);

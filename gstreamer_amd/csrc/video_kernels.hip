@@ -50,19 +50,54 @@ __global__ __launch_bounds__ (512) void k_convert_gamma (FrontParams f, Planes p
   extern __shared__ uint4 gamma_lds[];
   uint8_t *enc = (uint8_t *) gamma_lds;
   uint16_t *dec = (uint16_t *) (enc + 65536);
-  for (int i = (int) threadIdx.x; i < 4096; i += (int) blockDim.x)
-    gamma_lds[i] = ((const uint4 *) g.enc)[i];
-  if (threadIdx.x < 256)
-    dec[threadIdx.x] = g.dec[threadIdx.x];
-  __syncthreads ();
   GammaChainFn fn;
   fn.g = g;
-  fn.g.enc = enc;
-  fn.g.dec = dec;
+  if (g.comp) {                 /* the composed table: 256 bytes of LDS, not 64.5 KB */
+    if (threadIdx.x < 64)
+      ((uint32_t *) gamma_lds)[threadIdx.x] = ((const uint32_t *) g.comp)[threadIdx.x];
+    fn.g.comp = (const uint8_t *) gamma_lds;
+  } else {
+    for (int i = (int) threadIdx.x; i < 4096; i += (int) blockDim.x)
+      gamma_lds[i] = ((const uint4 *) g.enc)[i];
+    if (threadIdx.x < 256)
+      dec[threadIdx.x] = g.dec[threadIdx.x];
+    fn.g.enc = enc;
+    fn.g.dec = dec;
+  }
+  __syncthreads ();
   const int span = (int) (blockIdx.x * blockDim.x + threadIdx.x);
   const int y0 = (int) blockIdx.y * rows, y1 = y0 + rows < f.height ? y0 + rows : f.height;
   for (int y = y0; y < y1; y++)
     convert_body<CH, GammaChainFn> (f, pl, vpair, color, pack0, pack1, pack2, pack3, dst, dstride, spans_per_row, vec_ok, span, y, fn);
+}
+
+// GammaPlan::lut_direct: the composed gamma table over the converted rectangle of a 4-byte RGB destination, in place; four pixels per
+// lane, the table in LDS
+__global__ __launch_bounds__ (256) void k_lut3 (uint8_t *__restrict__ img, int stride, int w, int h, const uint8_t *__restrict__ comp, int keep)
+{
+  __shared__ uint32_t tab[64];
+  if (threadIdx.x < 64)
+    tab[threadIdx.x] = ((const uint32_t *) comp)[threadIdx.x];
+  __syncthreads ();
+  const uint8_t *t = (const uint8_t *) tab;
+  const int x = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = (int) blockIdx.y;
+  if (x >= w)
+    return;
+  uint32_t *p = (uint32_t *) (img + (size_t) y * stride) + x;
+  if (x + 4 <= w && (((uintptr_t) p) & 15) == 0) {
+    uint4 v = *(uint4 *) p;
+    v.x = gamma_lut3_px (t, v.x, keep), v.y = gamma_lut3_px (t, v.y, keep), v.z = gamma_lut3_px (t, v.z, keep), v.w = gamma_lut3_px (t, v.w, keep);
+    *(uint4 *) p = v;
+  } else {
+    for (int i = 0; i < 4 && x + i < w; i++)
+      p[i] = gamma_lut3_px (t, p[i], keep);
+  }
+}
+
+hipError_t launch_lut3 (uint8_t *img, int stride, int w, int h, const uint8_t *comp_dev, int keep, hipStream_t stream)
+{
+  hipLaunchKernelGGL (k_lut3, dim3 (((w + 3) / 4 + 255) / 256, h), dim3 (256), 0, stream, img, stride, w, h, comp_dev, keep);
+  return hipGetLastError ();
 }
 
 // the 16-bit chain of a 10-bit source into an 8-bit 4-byte destination (video_deep.h): a lane = 4 pixels of one row
@@ -881,16 +916,19 @@ static hipError_t launch_convert_gamma_ch (const FrontParams &f, const Planes &p
   hipError_t e = hipFuncSetAttribute (fn, hipFuncAttributeMaxDynamicSharedMemorySize, GSTAMD_GAMMA_LDS_BYTES);
   if (e != hipSuccess)
     return e;
-  /* two workgroups of 512 lanes per CU (LDS), every one of them resident at once: rows per workgroup from the device's CU count */
-  int n_cu = 256, dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    n_cu = prop.multiProcessorCount;
+  /* two workgroups of 512 lanes per CU (LDS), every one of them resident at once: rows per workgroup from the device's CU count; with the
+     composed 256-byte table LDS is no limit and a workgroup takes two rows */
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
   const int gx = (spans + 511) / 512;
-  int rows = (f.height * gx + 2 * n_cu - 1) / (2 * n_cu);
+  int rows = g.comp ? 2 : (f.height * gx + 2 * n_cu - 1) / (2 * n_cu);
   rows = rows < 1 ? 1 : rows;
   dim3 grid (gx, (f.height + rows - 1) / rows);
-  hipLaunchKernelGGL (k_convert_gamma<CH>, grid, dim3 (512), GSTAMD_GAMMA_LDS_BYTES, stream, f, pl, vpair_dev, color, pack_pos[0], pack_pos[1], pack_pos[2],
+  hipLaunchKernelGGL (k_convert_gamma<CH>, grid, dim3 (512), g.comp ? 256 : GSTAMD_GAMMA_LDS_BYTES, stream, f, pl, vpair_dev, color, pack_pos[0], pack_pos[1], pack_pos[2],
       pack_pos[3], dst, dstride, spans, vec_ok, g, rows);
   return hipGetLastError ();
 }
@@ -920,6 +958,10 @@ hipError_t launch_convert_gamma (const FrontParams &f, const Planes &pl, const i
 template <int CH, int L, int ABL>
 __global__ __launch_bounds__ (64) void k_convert_strip (FastParams fp, FrameBatch batch, int pairs, int K)
 {
+  if (ABL == GSTAMD_FAST_LUT) {
+    fast_lut_lds[threadIdx.x] = ((const uint32_t *) fp.lut)[threadIdx.x];
+    __syncthreads ();
+  }
   const Planes pl = batch_planes (batch, blockIdx.z);
   const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
   const int p0 = blockIdx.y * K;
@@ -931,6 +973,10 @@ __global__ __launch_bounds__ (64) void k_convert_strip (FastParams fp, FrameBatc
 template <int CH, int L, int ABL>
 __global__ __launch_bounds__ (64) void k_convert_strip_xcd (FastParams fp, FrameBatch batch, int ncol, int pairs, int K, int strips, int total_strips)
 {
+  if (ABL == GSTAMD_FAST_LUT) {
+    fast_lut_lds[threadIdx.x] = ((const uint32_t *) fp.lut)[threadIdx.x];
+    __syncthreads ();
+  }
   int col, S;
   if (!wide_block_map (blockIdx.x, ncol, total_strips, &col, &S))
     return;
@@ -959,10 +1005,10 @@ static bool launch_strip_variant (const FastParams &fp, const FrameBatch &batch,
   const int pairs = fp.height / 2 + 1, strips = (pairs + K - 1) / K, ncol = (fp.width + 255) / 256;
 #define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \
     if (xcd_order) \
-      hipLaunchKernelGGL ((k_convert_strip_xcd<CH, GSTAMD_LAYOUT (pr, pg, pb), ABL>), dim3 (wide_grid_blocks (ncol, strips * n)), dim3 (64), 0, stream, \
+      hipLaunchKernelGGL ((k_convert_strip_xcd<CH, GSTAMD_LAYOUT (pr, pg, pb), ABL>), dim3 (wide_grid_blocks (ncol, strips * n)), dim3 (64), ABL == GSTAMD_FAST_LUT ? 256 : 0, stream, \
           fp, batch, ncol, pairs, K, strips, strips * n); \
     else \
-      hipLaunchKernelGGL ((k_convert_strip<CH, GSTAMD_LAYOUT (pr, pg, pb), ABL>), dim3 (ncol, strips, n), dim3 (64), 0, stream, fp, batch, pairs, K); \
+      hipLaunchKernelGGL ((k_convert_strip<CH, GSTAMD_LAYOUT (pr, pg, pb), ABL>), dim3 (ncol, strips, n), dim3 (64), ABL == GSTAMD_FAST_LUT ? 256 : 0, stream, fp, batch, pairs, K); \
     return true;
   switch (fast_layout (fp)) {
     GSTAMD_FOR_LAYOUTS (W)
@@ -1050,6 +1096,8 @@ static bool launch_fast (const FastParams &fp, const FrameBatch &batch, int n, h
     return shape == 1 ? launch_wide_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, K, stream) :
         launch_strip_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, K, v.order != 0, stream);
 #endif
+  if (fp.lut)                   /* GammaPlan::lut_direct: the composed gamma table between the pack and the store */
+    return launch_strip_variant<CH, GSTAMD_FAST_LUT> (fp, batch, n, K, v.set && v.order != 0, stream);
   if (shape == 1 && fp.width >= GSTAMD_WIDE_PX / 2 && fp.px_bytes == 4)
     return launch_wide_variant<CH, 0> (fp, batch, n, K, stream);
   return launch_strip_variant<CH, 0> (fp, batch, n, K, v.set && v.order != 0, stream);

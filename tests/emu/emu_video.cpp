@@ -724,6 +724,9 @@ static bool emu_swizzle34 (int sb, const int *src_pos, int db, const int *dst_po
   return true;
 }
 
+static const uint8_t *g_post_lut = nullptr;      /* GammaPlan::lut_direct: set around the direct conversion (GstAmdVideoConverter::post_lut) */
+static int g_post_lut_keep = 0;
+static bool g_post_lut_done = false;
 static int g_swizzle4_runs = 0;
 static int g_extra_rows = 0;          /* the AYUV image of a planar destination is being rendered with the line past the picture */
 extern "C" int emu_swizzle4_runs (void) { return g_swizzle4_runs; }
@@ -782,6 +785,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     gd.alpha_value = g.alpha_value;
     gd.dec = g.dec.data ();
     gd.enc = g.enc.data ();
+    gd.comp = g.comp.empty () || getenv ("EMU_NO_GAMMA_COMP") ? nullptr : g.comp.data ();
     gd.to_rgb16 = g.to_rgb16;
     gd.to_yuv16 = g.to_yuv16;
     gd.dec16 = g.dec16.data ();
@@ -792,6 +796,25 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         for (int x = 0; x < w; x++)
           gamma_stage_px (gd, mask, s8, ss, d8, ds, x, y);
     };
+    if (g.fused && g.lut_direct) {          /* the direct conversion (planned with the chain's to_RGB matrix), then k_lut3 over the converted rectangle */
+      plan_set_matrix_override (&g.to_rgb);
+      g_post_lut = g.comp.data ();
+      g_post_lut_keep = p.fout->pos[0];
+      g_post_lut_done = false;
+      r = emu_video_convert (&g.sub_in_info, &g.mid_in, &g.cfg_in, src, dst, vec_ok, nullptr, 0);
+      g_post_lut = nullptr;
+      plan_set_matrix_override (nullptr);
+      if (r != GSTAMD_OK || g_post_lut_done)
+        return r;
+      const int ds = p.orig_out.stride[0];
+      uint8_t *rect = dst + p.orig_out.offset[0] + plane_origin (p.fout, 0, p.rect.out_x, p.rect.out_y, ds);
+      for (int y = 0; y < p.out_info.height; y++)
+        for (int x = 0; x < p.out_info.width; x++) {
+          uint32_t *q = (uint32_t *) (rect + (size_t) y * ds) + x;
+          *q = gamma_lut3_px (g.comp.data (), *q, p.fout->pos[0]);
+        }
+      return GSTAMD_OK;
+    }
     if (g.fused && getenv ("GSTAMD_NO_GAMMA_FUSED") == nullptr) {
       g_gamma_hook = &gd;
       r = emu_video_convert (&g.sub_in_info, &g.mid_in, &g.cfg_in, src, dst, vec_ok, nullptr, 0);
@@ -1181,7 +1204,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
   if (p.passes.empty () && p.fast_pair && vec_ok) {
     /* vec_ok: 1 = shipped configuration (strip kernel, 3 line pairs per lane); 100 + K = strip kernel with K pairs;
      * 200 + K = wide kernel (LDS-staged 1024-px runs) with K pairs per wave */
-    const FastParams fp = emu_fast_params (p, rgb24);
+    FastParams fp = emu_fast_params (p, rgb24);
     const int pairs = fp.height / 2 + 1;
     const int lay = GSTAMD_LAYOUT (fp.pack_pos[1], fp.pack_pos[2], fp.pack_pos[3]);
 #define FOR_LAYOUT(CH, CALL) \
@@ -1231,12 +1254,25 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     }
     {
       const int K = vec_ok >= 100 && vec_ok < 200 && vec_ok - 100 > 0 ? vec_ok - 100 : 3;
+      if (g_post_lut && !rgb24) {           /* launch_strip_variant<CH, GSTAMD_FAST_LUT>: the composed gamma table between pack and store */
+        memcpy (fast_lut_lds, g_post_lut, 256);
+        fp.lut = g_post_lut;
+        fp.lut_keep = g_post_lut_keep;
+        g_post_lut_done = true;
+#define STRIP(CH, LAY) \
+      for (int p0 = 0; p0 < pairs; p0 += K) \
+        for (int x0 = 0; x0 + 4 <= fp.width; x0 += 4) \
+          fast_strip<CH, LAY, GSTAMD_FAST_LUT> (fp, pl, d0, dstride, x0, p0, p0 + K < pairs ? p0 + K : pairs);
+        FOR_CH (STRIP)
+#undef STRIP
+      } else {
 #define STRIP(CH, LAY) \
       for (int p0 = 0; p0 < pairs; p0 += K) \
         for (int x0 = 0; x0 + 4 <= fp.width; x0 += 4) \
           fast_strip<CH, LAY, 0> (fp, pl, d0, dstride, x0, p0, p0 + K < pairs ? p0 + K : pairs);
       FOR_CH (STRIP)
 #undef STRIP
+      }
     }
 #undef FOR_CH
 #undef FOR_LAYOUT

@@ -56,6 +56,8 @@ struct GstAmdVideoConverter {
   size_t plane_lds_bytes = 0;
   bool plane_frame_ok = false;            // the frame's planes go through k_plane_frame (one launch)
   void *ed_carry = nullptr;                // error-diffusion dither on rectangles taller than one band: the band's last line of errors (video_dither_ed.h)
+  uint8_t *pre_img = nullptr;             // enlarging from a planar / packed 4:2:2 source: the source frame after front + colour stage, at its own size
+  size_t pre_img_size = 0;
   uint8_t *pk_img = nullptr;              // planar destinations: the chain's AYUV image before chroma downsample + pack
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
   bool reg420 = false;                    // first pass horizontal from a 4:2:0 source whose chroma pairing is the closed form of h420r_rows
@@ -90,9 +92,9 @@ struct GstAmdVideoConverter {
    * stream: a second stream's frames would run over them while the first one's kernels are still reading.  Every stream a frame is sent
    * on gets a set of its own (bind_scratch): the members hold the set of `bound_stream`, the others wait in `parked`. */
   struct ScratchSet {
-    uint8_t *tmp, *plane_tmp, *pk_img, *deep_a, *deep_b, *gamma_mid_a, *gamma_mid_b;
+    uint8_t *tmp, *plane_tmp, *pk_img, *deep_a, *deep_b, *gamma_mid_a, *gamma_mid_b, *pre_img;
     void *ed_carry;
-    size_t deep_a_size, deep_b_size;
+    size_t deep_a_size, deep_b_size, pre_img_size;
   };
   bool bound = false;
   void *bound_stream = nullptr;
@@ -526,24 +528,24 @@ static int alloc_scratch (GstAmdVideoConverter *c)
 
 static GstAmdVideoConverter::ScratchSet take_scratch (GstAmdVideoConverter *c)
 {
-  GstAmdVideoConverter::ScratchSet s = {c->tmp, c->plane_tmp, c->pk_img, c->deep_a, c->deep_b, c->gamma_mid_a, c->gamma_mid_b, c->ed_carry,
-    c->deep_a_size, c->deep_b_size};
-  c->tmp = c->plane_tmp = c->pk_img = c->deep_a = c->deep_b = c->gamma_mid_a = c->gamma_mid_b = nullptr;
+  GstAmdVideoConverter::ScratchSet s = {c->tmp, c->plane_tmp, c->pk_img, c->deep_a, c->deep_b, c->gamma_mid_a, c->gamma_mid_b, c->pre_img, c->ed_carry,
+    c->deep_a_size, c->deep_b_size, c->pre_img_size};
+  c->tmp = c->plane_tmp = c->pk_img = c->deep_a = c->deep_b = c->gamma_mid_a = c->gamma_mid_b = c->pre_img = nullptr;
   c->ed_carry = nullptr;
-  c->deep_a_size = c->deep_b_size = 0;
+  c->deep_a_size = c->deep_b_size = c->pre_img_size = 0;
   return s;
 }
 
 static void put_scratch (GstAmdVideoConverter *c, const GstAmdVideoConverter::ScratchSet &s)
 {
   c->tmp = s.tmp, c->plane_tmp = s.plane_tmp, c->pk_img = s.pk_img, c->deep_a = s.deep_a, c->deep_b = s.deep_b;
-  c->gamma_mid_a = s.gamma_mid_a, c->gamma_mid_b = s.gamma_mid_b, c->ed_carry = s.ed_carry;
-  c->deep_a_size = s.deep_a_size, c->deep_b_size = s.deep_b_size;
+  c->gamma_mid_a = s.gamma_mid_a, c->gamma_mid_b = s.gamma_mid_b, c->ed_carry = s.ed_carry, c->pre_img = s.pre_img;
+  c->deep_a_size = s.deep_a_size, c->deep_b_size = s.deep_b_size, c->pre_img_size = s.pre_img_size;
 }
 
 static void free_scratch (GstAmdVideoConverter::ScratchSet &s)
 {
-  void *all[] = {s.tmp, s.plane_tmp, s.pk_img, s.deep_a, s.deep_b, s.gamma_mid_a, s.gamma_mid_b, s.ed_carry};
+  void *all[] = {s.tmp, s.plane_tmp, s.pk_img, s.deep_a, s.deep_b, s.gamma_mid_a, s.gamma_mid_b, s.pre_img, s.ed_carry};
   for (void *q : all)
     if (q)
       (void) hipFree (q);
@@ -1242,6 +1244,39 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
         return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420");
     }
     const ScaleDev &sh = h_first ? sd[0] : sd[1], &sv = h_first ? sd[1] : sd[0];
+    if (p.matrix_before_scale && p.front.kind != UNPACK_PACKED4 && p.front.hi_depth == 0 && ((uintptr_t) dst % 4) == 0 && (dstride % 4) == 0 &&
+        !tuning_on ("GSTAMD_NO_BILINEAR4")) {
+      /* enlarging (the matrix runs on the source's pixels, chain_convert ahead of chain_scale): the source frame through the front and the
+         colour stage into an A, c1, c2, c3 image of ITS size - one of the unscaled kernels, a quarter of the destination's pixels at 1080p
+         -> 4K - and the four-outputs-per-lane scaler from that image; the scaler works per byte, so this is the chain's own order */
+      const int in_w = p.front.width, in_h = p.front.height;
+      const size_t need = (size_t) in_w * 4 * in_h;
+      if (c->pre_img_size < need) {
+        if (c->pre_img)
+          (void) hipFree (c->pre_img);
+        c->pre_img = nullptr;
+        c->pre_img_size = 0;
+        if ((e = hipMalloc ((void **) &c->pre_img, need)) != hipSuccess)
+          return hip_fail (e, "hipMalloc(converted source)");
+        c->pre_img_size = need;
+      }
+      const int ident[4] = {0, 1, 2, 3};
+      if ((e = launch_convert (p.front, pl, c->vpair_dev, pre, ident, c->pre_img, in_w * 4, stream, 0)) != hipSuccess)
+        return hip_fail (e, "k_convert(source size)");
+      FrontParams f4;
+      memset ((void *) &f4, 0, sizeof (f4));
+      f4.kind = UNPACK_PACKED4;
+      f4.width = in_w, f4.height = in_h;
+      for (int i = 0; i < 4; i++)
+        f4.pos[i] = i;
+      f4.swap_k = -1;
+      Planes p4;
+      memset ((void *) &p4, 0, sizeof (p4));
+      p4.p[0] = c->pre_img, p4.stride[0] = in_w * 4;
+      e = launch_scale2x2_from_front (f4, p4, nullptr, none, sh, sv, h_first, dst, dstride, post, p.post.pack_pos, out_w, out_h,
+          p.passes[h_first ? 0 : 1].max_span, c->geom[h_first ? 0 : 1], pf_none, stream);
+      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear4_rows");
+    }
     e = launch_scale2x2_from_front (p.front, pl, c->vpair_dev, pre, sh, sv, h_first, dst, dstride, post, p.post.pack_pos,
         out_w, out_h, p.passes[h_first ? 0 : 1].max_span, c->geom[h_first ? 0 : 1], pf, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_scale2x2");
@@ -1524,6 +1559,10 @@ static void release_tables (GstAmdVideoConverter *c)
   if (c->ed_carry)
     (void) hipFree (c->ed_carry);
   c->ed_carry = nullptr;
+  if (c->pre_img)
+    (void) hipFree (c->pre_img);
+  c->pre_img = nullptr;
+  c->pre_img_size = 0;
   if (c->plane_tmp)
     (void) hipFree (c->plane_tmp);
   c->tmp = c->pk_img = c->plane_tmp = nullptr;

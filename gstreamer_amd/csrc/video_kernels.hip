@@ -1366,6 +1366,11 @@ hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int ss
   return hipGetLastError ();
 }
 
+__global__ __launch_bounds__ (256) void k_bilinear4_rows (Bil4Params b, Dst dst, PostFast pf)
+{
+  bilinear4_rows_lane (b, dst, pf, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y * b.rows);
+}
+
 hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &pre,
     const ScaleDev &sh, const ScaleDev &sv, bool h_first, uint8_t *dst, int dstride, const ColorParams &post,
     const int pack_pos[4], int out_w, int out_h, int h_span, TileGeom geom, const PostFast &pf, hipStream_t stream)
@@ -1378,6 +1383,18 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
   src.vec_ok = front_vec_ok (f, pl);
   Dst d = make_dst (dst, dstride, true, post, pack_pos);
   dim3 block (256), grid ((out_w + 255) / 256, out_h);
+  if (f.kind == UNPACK_PACKED4 && f.hi_depth == 0 && pre.matrix.kind == MATRIX_NONE && pre.alpha_kind == ALPHA_NONE && aligned (pl.p[0], 4) &&
+      (pl.stride[0] % 4) == 0 && aligned (dst, 4) && (dstride % 4) == 0 && !tuning_on ("GSTAMD_NO_BILINEAR4")) {
+    /* 4-byte packed source, nothing in front of the scaler: four outputs per lane, straight from memory (video_scale_fast.h) */
+    Bil4Params b;
+    memset ((void *) &b, 0, sizeof (b));
+    b.src = pl.p[0], b.sstride = pl.stride[0], b.src_w = f.width, b.src_h = f.height;
+    b.sel_in = (uint32_t) f.pos[0] | ((uint32_t) f.pos[1] << 8) | ((uint32_t) f.pos[2] << 16) | ((uint32_t) f.pos[3] << 24);
+    b.sh = sh, b.sv = sv, b.h_first = h_first ? 1 : 0;
+    b.out_w = out_w, b.out_h = out_h, b.rows = 4;
+    hipLaunchKernelGGL (k_bilinear4_rows, dim3 (((out_w + 3) / 4 + 255) / 256, (out_h + b.rows - 1) / b.rows), dim3 (256), 0, stream, b, d, pf);
+    return hipGetLastError ();
+  }
   if (geom.tile_w > 0 && geom.lds_px * 8 <= WAVE_TILE_LDS_BYTES) {
     dim3 wgrid ((out_w + geom.tile_w - 1) / geom.tile_w, out_h);
     hipLaunchKernelGGL (k_scale2x2_wave<SrcFront>, wgrid, dim3 (64), (size_t) geom.lds_px * 8, stream, src, sh, sv, h_first ? 1 : 0, d,

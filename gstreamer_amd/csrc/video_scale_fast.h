@@ -326,6 +326,105 @@ GSTAMD_HD void scale2x2_tile_lane (const uint32_t *la, const uint32_t *lb, int x
 }
 
 // ------------------------------------------------------------------------------------------------
+// The fused nearest / 2-tap scaler for 4-byte packed sources without a colour step in front of it (BGRA -> BGRA `videoscale`, the
+// scaler of a converted frame on its way to a display size): a lane owns FOUR neighbouring outputs of `rows` consecutive rows, reads
+// the source pixels it needs straight from memory (neighbouring lanes share them through L1; at 1080p -> 4K a lane's 4 outputs sit on
+// 3 source pixels) and leaves one 16-byte streaming store per row.  The wave-tile form above spends a workgroup and two staged source
+// rows on 256 outputs of ONE row - 70 us for a 4K destination; this one is bound by the destination's bytes.  Same integers: the
+// arithmetic is scale2x2_tile_lane's, line by line.
+// ------------------------------------------------------------------------------------------------
+struct Bil4Params {
+  const uint8_t *src;
+  int sstride, src_w, src_h;
+  uint32_t sel_in;              // v_perm selector: memory bytes -> A, c1, c2, c3 (the unpack of the 4-byte format)
+  ScaleDev sh, sv;
+  int h_first;
+  int out_w, out_h, rows;
+};
+
+GSTAMD_HD uint32_t bil4_fetch (const Bil4Params &b, const uint8_t *row, int x)
+{
+  x = x < b.src_w - 1 ? x : b.src_w - 1;
+  return swizzle4_px (*(const uint32_t *) (row + 4 * (size_t) x), b.sel_in);
+}
+
+GSTAMD_HD void bilinear4_rows_lane (const Bil4Params &b, const Dst &dst, const PostFast &pf, int x0, int y0)
+{
+  if (x0 >= b.out_w)
+    return;
+  const bool v2 = b.sv.kind == SCALE_2TAP, h2 = b.sh.kind == SCALE_2TAP;
+  int idx[4];
+  uint32_t fr[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = x0 + i < b.out_w ? x0 + i : b.out_w - 1;
+    if (h2) {
+      const int tmp = x * b.sh.inc;
+      idx[i] = tmp >> 16;
+      fr[i] = (uint32_t) (tmp >> 8) & 0xffu;
+    } else {
+      idx[i] = (int) b.sh.offset[x];
+      fr[i] = 0;
+    }
+  }
+  const int y1 = y0 + b.rows < b.out_h ? y0 + b.rows : b.out_h;
+  for (int y = y0; y < y1; y++) {
+    const int ya = (int) b.sv.offset[y];
+    const uint32_t p1s = v2 ? ((uint32_t) (uint16_t) b.sv.taps[(size_t) y * 2 + 1]) * 0x00010001u : 0u;
+    const uint8_t *ra = b.src + (size_t) ya * b.sstride;
+    const uint8_t *rb = b.src + (size_t) (ya + 1 < b.src_h ? ya + 1 : b.src_h - 1) * b.sstride;
+    uint32_t out[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t e, o;
+      if (h2) {
+        if (!v2) {
+          h2tap_eo (bil4_fetch (b, ra, idx[i]), bil4_fetch (b, ra, idx[i] + 1), fr[i], e, o);
+        } else if (b.h_first) {
+          uint32_t e2, o2;
+          h2tap_eo (bil4_fetch (b, ra, idx[i]), bil4_fetch (b, ra, idx[i] + 1), fr[i], e, o);
+          h2tap_eo (bil4_fetch (b, rb, idx[i]), bil4_fetch (b, rb, idx[i] + 1), fr[i], e2, o2);
+          e = v2tap_pk (e, e2, p1s);
+          o = v2tap_pk (o, o2, p1s);
+        } else {
+          const uint32_t a1 = bil4_fetch (b, ra, idx[i]), a2 = bil4_fetch (b, rb, idx[i]);
+          const uint32_t b1 = bil4_fetch (b, ra, idx[i] + 1), b2 = bil4_fetch (b, rb, idx[i] + 1);
+          const uint32_t ae = v2tap_pk (a1 & 0x00ff00ffu, a2 & 0x00ff00ffu, p1s), ao = v2tap_pk (pk_shr<8> (a1), pk_shr<8> (a2), p1s);
+          const uint32_t be = v2tap_pk (b1 & 0x00ff00ffu, b2 & 0x00ff00ffu, p1s), bo = v2tap_pk (pk_shr<8> (b1), pk_shr<8> (b2), p1s);
+          const uint32_t nf = 256u - fr[i];
+          e = pk_shr<8> (umul24 (ae, nf) + umul24 (be, fr[i]));
+          o = pk_shr<8> (umul24 (ao, nf) + umul24 (bo, fr[i]));
+        }
+      } else {
+        const uint32_t a1 = bil4_fetch (b, ra, idx[i]);
+        e = a1 & 0x00ff00ffu;
+        o = pk_shr<8> (a1);
+        if (v2) {
+          const uint32_t a2 = bil4_fetch (b, rb, idx[i]);
+          e = v2tap_pk (e, a2 & 0x00ff00ffu, p1s);
+          o = v2tap_pk (o, pk_shr<8> (a2), p1s);
+        }
+      }
+      out[i] = post_px (dst, pf, e | (o << 8));
+    }
+    uint8_t *d = dst.p + (size_t) y * dst.stride + 4 * (size_t) x0;
+    if (x0 + 4 <= b.out_w && (((uintptr_t) d) & 15) == 0) {
+#ifdef __HIPCC__
+      typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
+      const u32x4 v = {out[0], out[1], out[2], out[3]};
+      __builtin_nontemporal_store (v, (u32x4 *) d);
+#else
+      for (int i = 0; i < 4; i++)
+        ((uint32_t *) d)[i] = out[i];
+#endif
+    } else {
+      for (int i = 0; i < 4 && x0 + i < b.out_w; i++)
+        ((uint32_t *) d)[i] = out[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // N-tap horizontal pass as byte dot products (v_dot4_i32_i8).  The wave stages Y, U, V of the source span as three
 // byte planes, each byte XOR 0x80 (= value - 128 as int8); one output channel is
 //     sum (px * tap) = sum ((px - 128) * tap) + 128 * sum (tap),      sum (tap) = 64 (checked by the planner)

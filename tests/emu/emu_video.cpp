@@ -1611,6 +1611,41 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
 #undef BIL_L
       return GSTAMD_OK;
     }
+    if (p.matrix_before_scale && p.front.kind != UNPACK_PACKED4 && p.front.hi_depth == 0 && ((uintptr_t) d0 % 4) == 0 && (dstride % 4) == 0 &&
+        !getenv ("EMU_NO_BILINEAR4")) {
+      /* enlarging from planes / packed 4:2:2: k_convert at the source's size into an A, c1, c2, c3 image, then k_bilinear4_rows from it */
+      const int in_w = p.front.width, in_h = p.front.height;
+      std::vector<uint32_t> img ((size_t) in_w * in_h);
+      for (int y = 0; y < in_h; y++)
+        for (int x = 0; x < in_w; x++)
+          img[(size_t) y * in_w + x] = sf.at (x, y);
+      Bil4Params b;
+      memset ((void *) &b, 0, sizeof (b));
+      b.src = (const uint8_t *) img.data (), b.sstride = in_w * 4, b.src_w = in_w, b.src_h = in_h;
+      b.sel_in = 0x03020100u;
+      b.sh = sh, b.sv = sv, b.h_first = h_first ? 1 : 0;
+      b.out_w = p.out_info.width, b.out_h = p.out_info.height, b.rows = 4;
+      PostFast pf_none;
+      memset ((void *) &pf_none, 0, sizeof (pf_none));
+      for (int y0 = 0; y0 < b.out_h; y0 += b.rows)
+        for (int x0 = 0; x0 < b.out_w; x0 += 4)
+          bilinear4_rows_lane (b, d, pf_none, x0, y0);
+      return GSTAMD_OK;
+    }
+    if (p.front.kind == UNPACK_PACKED4 && p.front.hi_depth == 0 && sf.pre.matrix.kind == MATRIX_NONE && sf.pre.alpha_kind == ALPHA_NONE &&
+        ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0 && ((uintptr_t) d0 % 4) == 0 && (dstride % 4) == 0 && !getenv ("EMU_NO_BILINEAR4")) {
+      /* k_bilinear4_rows: four outputs per lane, four rows per lane */
+      Bil4Params b;
+      memset ((void *) &b, 0, sizeof (b));
+      b.src = pl.p[0], b.sstride = pl.stride[0], b.src_w = p.front.width, b.src_h = p.front.height;
+      b.sel_in = (uint32_t) p.front.pos[0] | ((uint32_t) p.front.pos[1] << 8) | ((uint32_t) p.front.pos[2] << 16) | ((uint32_t) p.front.pos[3] << 24);
+      b.sh = sh, b.sv = sv, b.h_first = h_first ? 1 : 0;
+      b.out_w = p.out_info.width, b.out_h = p.out_info.height, b.rows = 4;
+      for (int y0 = 0; y0 < b.out_h; y0 += b.rows)
+        for (int x0 = 0; x0 < b.out_w; x0 += 4)
+          bilinear4_rows_lane (b, d, pf, x0, y0);
+      return GSTAMD_OK;
+    }
     if (g.tile_w > 0 && g.lds_px * 8 <= 16384) {      /* k_scale2x2_wave */
       std::vector<uint32_t> la (g.lds_px), lb (g.lds_px);
       for (int y = 0; y < p.out_info.height; y++)

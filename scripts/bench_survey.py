@@ -10,8 +10,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch                              # noqa: E402
 from gstreamer_amd import video as V      # noqa: E402
 
-LIN, CUB, LAN = dict(resampler_method="linear"), dict(resampler_method="cubic"), dict(resampler_method="lanczos")
-CASES = [("BGRA", 3840, 2160, "BGRA", 1920, 1080, LIN), ("BGRA", 3840, 2160, "BGRA", 1920, 1080, CUB), ("BGRA", 3840, 2160, "BGRA", 1280, 720, LAN),
+# BIL = the elements' default method (bilinear: linear with max-taps 2); LIN = the library's linear (taps grow with the ratio)
+BIL, LIN, CUB, LAN = dict(resampler_method="linear", max_taps=2), dict(resampler_method="linear"), dict(resampler_method="cubic"), dict(resampler_method="lanczos")
+CASES = [("BGRA", 3840, 2160, "BGRA", 1920, 1080, BIL), ("NV12", 3840, 2160, "BGRA", 1920, 1080, BIL), ("NV12", 3840, 2160, "NV12", 1920, 1080, BIL),
+         ("BGRA", 3840, 2160, "NV12", 1920, 1080, BIL), ("NV12", 1920, 1080, "BGRA", 3840, 2160, BIL), ("I420", 1920, 1080, "I420", 1280, 720, BIL),
+         ("BGRA", 3840, 2160, "BGRA", 1920, 1080, LIN), ("BGRA", 3840, 2160, "BGRA", 1920, 1080, CUB), ("BGRA", 3840, 2160, "BGRA", 1280, 720, LAN),
          ("BGRA", 1920, 1080, "BGRA", 3840, 2160, LIN), ("BGRA", 3840, 2160, "NV12", 3840, 2160, {}), ("BGRA", 3840, 2160, "NV12", 1920, 1080, LIN),
          ("BGRA", 3840, 2160, "I420", 1920, 1080, CUB), ("NV12", 3840, 2160, "BGRA", 1920, 1080, LIN), ("NV12", 3840, 2160, "BGRA", 1920, 1080, LAN),
          ("NV12", 1920, 1080, "BGRA", 3840, 2160, LIN), ("I420", 3840, 2160, "BGRA", 3840, 2160, {}), ("I420", 3840, 2160, "NV12", 3840, 2160, {}),
@@ -41,6 +44,6 @@ for ifmt, w, h, ofmt, ow, oh, cfg in CASES:
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / n * 1e6
     alg = conv.algorithmic_bytes()
-    print("%-10s %4dx%-4d -> %-10s %4dx%-4d %-8s %7.1f us  %6.1f MB  frac %.3f  %s" % (ifmt, w, h, ofmt, ow, oh, cfg.get("resampler_method", ""), us, alg / 1e6,
+    print("%-10s %4dx%-4d -> %-10s %4dx%-4d %-8s %7.1f us  %6.1f MB  frac %.3f  %s" % (ifmt, w, h, ofmt, ow, oh, ("bilinear" if cfg.get("max_taps") == 2 else cfg.get("resampler_method", "")), us, alg / 1e6,
                                                                                  alg / (us * 1e-6) / 8e12, conv.describe()))
     conv.free()

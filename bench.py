@@ -35,7 +35,7 @@ VIDEO_CONFIGS = {
            "1080p frames/s (videoconvertscale NV12->BGRA) per GPU; % HBM roofline", "k_convert_strip<CHROMA_H_H2_CS, layout BGRA>"),
     "c3": ("I420", 7680, 4320, "RGBA", 1920, 1080, {"resampler_method": "lanczos"}, 8, 1,
            "8K->1080p frames/s (videoconvertscale I420->RGBA, Lanczos) per GPU; % HBM roofline", "k_scale420_fused / k_hscale420_reg + k_vscale_pk"),
-    "c5": ("NV12", 7680, 4320, "BGRA", 3840, 2160, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
+    "c5": ("NV12", 7680, 4320, "BGRA", 3840, 2160, {"resampler_method": "linear", "max_taps": 2}, 16, 16,
            "8K->4K frames/s (videoconvertscale NV12->BGRA, bilinear) per GPU; % HBM roofline",
            "k_bilinear420_rows_frames (--batch 1: k_bilinear420_rows)"),
     # SURVEY 8(f) rows, measured the same way (composite plans: several launches per frame, the whole frame is what is timed)
@@ -46,7 +46,7 @@ VIDEO_CONFIGS = {
     "f2p010in": ("P010_10LE", 3840, 2160, "NV12", 3840, 2160, {}, 8, 1,
                  "4K frames/s (videoconvertscale P010_10LE->NV12) per GPU; % HBM roofline", "k_front16 + k_gamma_stage + sub-conversion"),
     # SURVEY 8(f) generic paths: the plane scaler behind `videoscale` on NV12, a planar 4:2:0 pack, a byte swizzle
-    "f8scale": ("NV12", 3840, 2160, "NV12", 1920, 1080, {"resampler_method": "linear"}, 8, 1,
+    "f8scale": ("NV12", 3840, 2160, "NV12", 1920, 1080, {"resampler_method": "linear", "max_taps": 2}, 8, 1,
                 "4K->1080p frames/s (videoscale NV12->NV12, bilinear) per GPU; % HBM roofline", "k_plane_scale2 (one launch per frame: all planes, both passes)"),
     "f8pack": ("YUY2", 3840, 2160, "I420", 3840, 2160, {}, 8, 1,
                "4K frames/s (videoconvert YUY2->I420) per GPU; % HBM roofline", "k_convert + k_pack_planar"),
@@ -54,7 +54,7 @@ VIDEO_CONFIGS = {
                   "4K frames/s (videoconvert BGRA->RGBA) per GPU; % HBM roofline", "k_swizzle4"),
 }
 CONFIG_TEXT = {
-    "f8scale": "SURVEY 8(f): 3840x2160 NV12 -> 1920x1080 NV12, bilinear, plane by plane (convert_scale_planes)",
+    "f8scale": "SURVEY 8(f): 3840x2160 NV12 -> 1920x1080 NV12, bilinear (the elements' default method: linear, max-taps 2), plane by plane (convert_scale_planes)",
     "f8pack": "SURVEY 8(f): 3840x2160 YUY2 -> I420 (unpack, chroma downsample, planar pack)",
     "f8swizzle": "SURVEY 8(f): 3840x2160 BGRA -> RGBA (a byte permutation)",
     "c2": "C2: 3840x2160 NV12 (bt709 limited, chroma-site mpeg2) -> BGRA, fused unpack + chroma upsample + matrix + pack",

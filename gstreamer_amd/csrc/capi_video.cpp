@@ -840,6 +840,7 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
       PlaneJob &J = jobs.job[k];
       J.kind = pp.kind;
       J.s.p = pl.p[pp.src_plane], J.s.stride = pl.stride[pp.src_plane], J.s.n = pp.n_elems;
+      J.s.pairs = pp.n_elems == 2 && ((uintptr_t) J.s.p % 2) == 0 && (J.s.stride % 2) == 0;
       J.d.p = (uint8_t *) dest_planes[pp.dst_plane], J.d.stride = dest_stride ? dest_stride[pp.dst_plane] : p.out_info.stride[pp.dst_plane], J.d.n = pp.n_elems;
       if (!J.s.p || !J.d.p)
         return set_error (GSTAMD_ERR_INVALID, "NULL plane");
@@ -861,7 +862,7 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
       tiles += J.tiles_x * ((pp.oh + PLN_TH - 1) / PLN_TH);
     }
     jobs.n = (int) p.planes.size ();
-    hipError_t e = launch_plane_frame (jobs, tiles, c->plane_lds_bytes, stream);
+    hipError_t e = launch_plane_frame (jobs, c->plane_lds_bytes, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_plane_frame");
   }
   if (p.plane_mode) {

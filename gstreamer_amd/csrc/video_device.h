@@ -626,6 +626,24 @@ GSTAMD_HD void hscale_from_lds (const uint32_t *lds, int x_lo, const ScaleDev &s
 // Fused 2x2 scaler: both passes are nearest or 2-tap ("bilinear", the element default): one lane = one output
 // pixel computed straight from <= 4 source pixels, pass order as planned (h_first), no intermediate image.
 template <class SRC>
+GSTAMD_HD uint32_t scale2x2_px (const SRC &src, const ScaleDev &sh, const ScaleDev &sv, int h_first, int x, int y)
+{
+  const int ya = (int) sv.offset[y];
+  const bool v2 = sv.kind == SCALE_2TAP;
+  const int p1 = v2 ? (int) sv.taps[(size_t) y * 2 + 1] : 0;
+  if (h_first) {
+    const RowOfSrc<SRC> ra = {src, ya};
+    const uint32_t ha = hscale_px (ra, sh, x);
+    if (!v2)
+      return ha;
+    const RowOfSrc<SRC> rb = {src, ya + 1};
+    return v2tap_px (ha, hscale_px (rb, sh, x), p1);
+  }
+  const RowVFiltered<SRC> vr = {src, ya, p1, v2};
+  return hscale_px (vr, sh, x);
+}
+
+template <class SRC>
 GSTAMD_HD void scale2x2_body (const SRC &src, const ScaleDev &sh, const ScaleDev &sv, int h_first, const Dst &dst, int out_w,
     int out_h, int x, int y)
 {

@@ -75,7 +75,7 @@ hipError_t launch_fill_border (uint8_t *p, int stride, int es, uint32_t value, i
 struct Enc420Params;
 hipError_t launch_encode420 (const Enc420Params &ep, bool semi, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],
     hipStream_t stream);
-hipError_t launch_plane_frame (const PlaneJobs &jobs, int n_tiles, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_plane_frame (const PlaneJobs &jobs, size_t lds_bytes, hipStream_t stream);
 bool swizzle34_setup (int src_bytes, const int *src_pos, int dst_bytes, const int *dst_pos, const uint8_t *src, int sstride, uint8_t *dst, int dstride,
     int width, Swz34Params *p);
 hipError_t launch_swizzle34 (const Swz34Params &p, int src_bytes, int dst_bytes, int height, hipStream_t stream);

@@ -753,9 +753,12 @@ hipError_t launch_planes_relayout (const RelayoutParams &p, hipStream_t stream)
   return hipGetLastError ();
 }
 
-// the frame's planes in one launch (video_planes.h plane_tile_body): blockIdx.x runs over the tiles of all planes
+// the frame's planes (video_planes.h): blockIdx.x runs over the 64 x 16 output tiles of the planes of `jobs`.  An if-chain over the jobs, not
+// jobs.job[j] (indexing the by-value argument with a run-time index sends the whole struct through scratch) and not one body after
+// uniform selects of every field (all three jobs live in SGPRs at once: 170 spilled).  Two kernels - the planes that stage nothing, and
+// the two-pass N-tap tiles with their LDS and barriers - because one body with both cost 185 VGPRs.
 template <int K>
-__device__ __forceinline__ void plane_frame_job (const PlaneJobs &jobs, uint8_t *lds)
+__device__ __forceinline__ void plane_tiles_job (const PlaneJobs &jobs, uint8_t *lds)
 {
   const int tile = (int) blockIdx.x - jobs.job[K].tile0;
 #pragma unroll
@@ -766,23 +769,52 @@ __device__ __forceinline__ void plane_frame_job (const PlaneJobs &jobs, uint8_t 
   }
 }
 
-__global__ __launch_bounds__ (PLN_THREADS) void k_plane_frame (PlaneJobs jobs)
+__global__ __launch_bounds__ (PLN_THREADS) void k_plane_tiles (PlaneJobs jobs)
 {
   extern __shared__ uint32_t plane_lds[];         /* the largest tile's needs (plane_job_lds_bytes), not PLN_LDS_BYTES: workgroups per CU */
   uint8_t *lds = (uint8_t *) plane_lds;
-  /* an if-chain over the jobs, not jobs.job[j]: indexing the by-value argument with a run-time index sends the whole struct through scratch */
   const int b = (int) blockIdx.x;
   if (jobs.n > 2 && b >= jobs.job[2].tile0)
-    plane_frame_job<2> (jobs, lds);
+    plane_tiles_job<2> (jobs, lds);
   else if (jobs.n > 1 && b >= jobs.job[1].tile0)
-    plane_frame_job<1> (jobs, lds);
+    plane_tiles_job<1> (jobs, lds);
   else
-    plane_frame_job<0> (jobs, lds);
+    plane_tiles_job<0> (jobs, lds);
 }
 
-hipError_t launch_plane_frame (const PlaneJobs &jobs, int n_tiles, size_t lds_bytes, hipStream_t stream)
+__global__ __launch_bounds__ (PLN_THREADS) void k_plane_direct (PlaneJobs jobs)
 {
-  hipLaunchKernelGGL (k_plane_frame, dim3 (n_tiles), dim3 (PLN_THREADS), lds_bytes ? lds_bytes : 4, stream, jobs);
+  const int b = (int) blockIdx.x;
+  if (jobs.n > 2 && b >= jobs.job[2].tile0)
+    plane_direct_body (jobs.job[2], b - jobs.job[2].tile0, (int) threadIdx.x);
+  else if (jobs.n > 1 && b >= jobs.job[1].tile0)
+    plane_direct_body (jobs.job[1], b - jobs.job[1].tile0, (int) threadIdx.x);
+  else
+    plane_direct_body (jobs.job[0], b, (int) threadIdx.x);
+}
+
+// `jobs`: the frame's planes in any order; they are split by kind of body and each kind gets a launch of its own
+hipError_t launch_plane_frame (const PlaneJobs &jobs, size_t lds_bytes, hipStream_t stream)
+{
+  for (int direct = 0; direct < 2; direct++) {
+    PlaneJobs part;
+    memset ((void *) &part, 0, sizeof (part));
+    int tiles = 0;
+    for (int i = 0; i < jobs.n; i++) {
+      if (plane_job_is_direct (jobs.job[i]) != (direct == 1))
+        continue;
+      PlaneJob &J = part.job[part.n++];
+      J = jobs.job[i];
+      J.tile0 = tiles;
+      tiles += J.tiles_x * ((J.oh + PLN_TH - 1) / PLN_TH);
+    }
+    if (!part.n)
+      continue;
+    if (direct)
+      hipLaunchKernelGGL (k_plane_direct, dim3 (tiles), dim3 (PLN_THREADS), 0, stream, part);
+    else
+      hipLaunchKernelGGL (k_plane_tiles, dim3 (tiles), dim3 (PLN_THREADS), lds_bytes ? lds_bytes : 4, stream, part);
+  }
   return hipGetLastError ();
 }
 
@@ -1538,7 +1570,7 @@ hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &
 
 hipError_t launch_plane_simple (int kind, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems, int ow, int oh, hipStream_t stream)
 {
-  const SrcPlane s = {src, sstride, n_elems};
+  const SrcPlane s = {src, sstride, n_elems, 0};
   const DstPlane d = {dst, dstride, n_elems};
   hipLaunchKernelGGL (k_plane_simple, dim3 ((ow + 255) / 256, oh), dim3 (256), 0, stream, kind, s, d, ow, oh);
   return hipGetLastError ();
@@ -1547,7 +1579,7 @@ hipError_t launch_plane_simple (int kind, const uint8_t *src, int sstride, uint8
 hipError_t launch_plane_pass (bool horizontal, const ScaleDev &sd, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems,
     int ow, int oh, hipStream_t stream)
 {
-  const SrcPlane s = {src, sstride, n_elems};
+  const SrcPlane s = {src, sstride, n_elems, 0};
   const DstPlane d = {dst, dstride, n_elems};
   if (horizontal)
     hipLaunchKernelGGL (k_plane_hscale, dim3 ((ow + 255) / 256, oh), dim3 (256), 0, stream, s, sd, d, ow, oh);

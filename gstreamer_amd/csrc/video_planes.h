@@ -7,6 +7,7 @@
 #pragma once
 #include <algorithm>
 #include "video_device.h"
+#include "video_scale_fast.h"
 
 namespace gstamd {
 
@@ -14,9 +15,12 @@ struct SrcPlane {
   const uint8_t *p;
   int stride;
   int n;                // bytes per pixel: 1, 2 or 3 (RGB / BGR)
+  int pairs;            // n == 2 and every pixel sits on an even address: one 16-bit load per pixel
   GSTAMD_HD uint32_t at (int x, int y) const
   {
     const uint8_t *q = p + (size_t) y * stride + (size_t) x * n;
+    if (pairs)
+      return *(const uint16_t *) q;
     uint32_t v = q[0];
     if (n >= 2)
       v |= (uint32_t) q[1] << 8;
@@ -280,34 +284,91 @@ GSTAMD_HD void plane_put4 (const PlaneJob &J, int x, int y, int x1, const uint32
     J.d.put (x + i, y, px[i]);
 }
 
-// phase 0: source rectangle + table rows -> LDS; 1: first pass, LDS -> LDS; 2: second pass (or the only one, or a pass-free kind) -> plane.
-// A barrier separates the phases.
-GSTAMD_HD void plane_tile_body (const PlaneJob &J, uint8_t *lds, int tile, int tid, int phase)
+GSTAMD_VP bool plane_small_kind (int k) { return k == SCALE_NEAREST || k == SCALE_2TAP; }
+
+// scale2x2_px in the packed 16-bit lane arithmetic of the 4-byte scalers (h2tap_eo / v2tap_pk, video_scale_fast.h: the same integers as
+// hscale_px / v2tap_px - scale2x2_tile_lane is held to them by the packed-format tests); a plane's pixel is 1 .. 3 bytes in a zero-extended word
+GSTAMD_HD uint32_t plane_scale2x2_pk (const SrcPlane &s, const ScaleDev &sh, const ScaleDev &sv, int h_first, int x, int y)
 {
-  const bool two = J.kind == PLANE_SCALE && J.n_pass == 2;
-  if (!two) {
-    if (phase != PLN_PHASES - 1)
-      return;
-    const int tx = tile % J.tiles_x, ty = tile / J.tiles_x;
-    const int x0 = tx * PLN_TW, y0 = ty * PLN_TH;
-    const int x1 = x0 + PLN_TW < J.ow ? x0 + PLN_TW : J.ow, y1 = y0 + PLN_TH < J.oh ? y0 + PLN_TH : J.oh;
-    const int x = x0 + 4 * (tid % (PLN_TW / 4)), y = y0 + tid / (PLN_TW / 4);
-    if (y >= y1 || x >= x1)
-      return;
-    if (J.kind != PLANE_SCALE) {
-      if (J.wide && J.wide_src && x + 4 <= x1 && plane_simple4 (J, x, y))
-        return;
-      for (int i = 0; i < 4 && x + i < x1; i++)
-        plane_simple_body (J.kind, J.s, J.d, J.ow, J.oh, x + i, y);
-      return;
+  const bool v2 = sv.kind == SCALE_2TAP, h2 = sh.kind == SCALE_2TAP;
+  const int ya = (int) sv.offset[y];
+  const uint32_t p1s = v2 ? ((uint32_t) (uint16_t) sv.taps[(size_t) y * 2 + 1]) * 0x00010001u : 0u;
+  uint32_t e, o;
+  if (h2) {
+    const int tmp = x * sh.inc;
+    const int idx = tmp >> 16;
+    const uint32_t fr = (uint32_t) (tmp >> 8) & 0xffu;
+    if (!v2) {
+      h2tap_eo (s.at (idx, ya), s.at (idx + 1, ya), fr, e, o);
+    } else if (h_first) {
+      uint32_t e2, o2;
+      h2tap_eo (s.at (idx, ya), s.at (idx + 1, ya), fr, e, o);
+      h2tap_eo (s.at (idx, ya + 1), s.at (idx + 1, ya + 1), fr, e2, o2);
+      e = v2tap_pk (e, e2, p1s);
+      o = v2tap_pk (o, o2, p1s);
+    } else {
+      const uint32_t a1 = s.at (idx, ya), a2 = s.at (idx, ya + 1), b1 = s.at (idx + 1, ya), b2 = s.at (idx + 1, ya + 1);
+      const uint32_t ae = v2tap_pk (a1 & 0x00ff00ffu, a2 & 0x00ff00ffu, p1s), ao = v2tap_pk (pk_shr<8> (a1), pk_shr<8> (a2), p1s);
+      const uint32_t be = v2tap_pk (b1 & 0x00ff00ffu, b2 & 0x00ff00ffu, p1s), bo = v2tap_pk (pk_shr<8> (b1), pk_shr<8> (b2), p1s);
+      const uint32_t nf = 256u - fr;
+      e = pk_shr<8> (umul24 (ae, nf) + umul24 (be, fr));
+      o = pk_shr<8> (umul24 (ao, nf) + umul24 (bo, fr));
     }
-    uint32_t px[4] = {0, 0, 0, 0};
+  } else {
+    const uint32_t a1 = s.at ((int) sh.offset[x], ya);
+    e = a1 & 0x00ff00ffu;
+    o = pk_shr<8> (a1);
+    if (v2) {
+      const uint32_t a2 = s.at ((int) sh.offset[x], ya + 1);
+      e = v2tap_pk (e, a2 & 0x00ff00ffu, p1s);
+      o = v2tap_pk (o, pk_shr<8> (a2), p1s);
+    }
+  }
+  return e | (o << 8);
+}
+
+// planes that need nothing staged: pass-free kinds, one pass, or nearest / 2-tap in both directions.  One call per lane: outputs
+// x .. x + 3 of a row of the tile.
+GSTAMD_HD void plane_direct_body (const PlaneJob &J, int tile, int tid)
+{
+  const int tx = tile % J.tiles_x, ty = tile / J.tiles_x;
+  const int x0 = tx * PLN_TW, y0 = ty * PLN_TH;
+  const int x1 = x0 + PLN_TW < J.ow ? x0 + PLN_TW : J.ow, y1 = y0 + PLN_TH < J.oh ? y0 + PLN_TH : J.oh;
+  const int x = x0 + 4 * (tid % (PLN_TW / 4)), y = y0 + tid / (PLN_TW / 4);
+  if (y >= y1 || x >= x1)
+    return;
+  if (J.kind != PLANE_SCALE) {
+    if (J.wide && J.wide_src && x + 4 <= x1 && plane_simple4 (J, x, y))
+      return;
+    for (int i = 0; i < 4 && x + i < x1; i++)
+      plane_simple_body (J.kind, J.s, J.d, J.ow, J.oh, x + i, y);
+    return;
+  }
+  uint32_t px[4] = {0, 0, 0, 0};
+  if (J.n_pass == 2) {
+    /* nearest / 2-tap in both directions (the elements' default method): an output is a function of at most four source pixels - straight
+       from memory, no staging, no barrier (scale2x2_px: the two passes with the first one's rounding in between, in the plan's order) */
+    const ScaleDev &sh = J.pass[J.h_first ? 0 : 1], &sv = J.pass[J.h_first ? 1 : 0];
+    for (int i = 0; i < 4 && x + i < x1; i++)
+      px[i] = plane_scale2x2_pk (J.s, sh, sv, J.h_first, x + i, y);
+  } else {
     const RowOfSrc<SrcPlane> row = {J.s, y};
     for (int i = 0; i < 4 && x + i < x1; i++)
       px[i] = J.h_first ? hscale_px (row, J.pass[0], x + i) : vscale_px (J.s, J.pass[0], x + i, y);
-    plane_put4 (J, x, y, x1, px);
-    return;
   }
+  plane_put4 (J, x, y, x1, px);
+}
+
+// does the plane go through plane_direct_body (host and device)
+GSTAMD_VP bool plane_job_is_direct (const PlaneJob &J)
+{
+  return J.kind != PLANE_SCALE || J.n_pass < 2 || (plane_small_kind (J.pass[0].kind) && plane_small_kind (J.pass[1].kind));
+}
+
+// two N-tap passes.  phase 0: source rectangle + table rows -> LDS; 1: first pass, LDS -> LDS; 2: second pass -> plane.  A barrier separates
+// the phases.
+GSTAMD_HD void plane_tile_body (const PlaneJob &J, uint8_t *lds, int tile, int tid, int phase)
+{
   PlaneTile T;
   plane_tile_geometry (J, tile, T);
   if (phase == 0) {
@@ -403,6 +464,8 @@ inline size_t plane_job_lds_bytes (const PlanePlan &pp)
 {
   if (pp.kind != PLANE_SCALE || pp.passes.size () != 2)
     return 0;
+  if ((pp.passes[0].kind == SCALE_NEAREST || pp.passes[0].kind == SCALE_2TAP) && (pp.passes[1].kind == SCALE_NEAREST || pp.passes[1].kind == SCALE_2TAP))
+    return 0;                   /* the direct form: nothing staged */
   const bool h_first = pp.passes[0].horizontal;
   const ScalePass &ph = pp.passes[h_first ? 0 : 1], &pv = pp.passes[h_first ? 1 : 0];
   const auto span = [](const ScalePass &p, bool horizontal, int o0, int o1) {

@@ -990,7 +990,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       PlaneJob J;
       memset ((void *) &J, 0, sizeof (J));
       J.kind = pp.kind;
-      J.s = {pl.p[pp.src_plane], pl.stride[pp.src_plane], pp.n_elems};
+      J.s = {pl.p[pp.src_plane], pl.stride[pp.src_plane], pp.n_elems, pp.n_elems == 2 && ((uintptr_t) pl.p[pp.src_plane] % 2) == 0 && (pl.stride[pp.src_plane] % 2) == 0};
       J.d = {dst + out->offset[pp.dst_plane], out->stride[pp.dst_plane], pp.n_elems};
       J.iw = pp.iw, J.ih = pp.ih, J.ow = pp.ow, J.oh = pp.oh;
       J.n_pass = (int) pp.passes.size ();
@@ -1007,16 +1007,22 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       J.wide_src = ((uintptr_t) J.s.p % 8) == 0 && (J.s.stride % 8) == 0;
       J.tiles_x = (pp.ow + PLN_TW - 1) / PLN_TW;
       const int tiles = J.tiles_x * ((pp.oh + PLN_TH - 1) / PLN_TH);
-      for (int t = 0; t < tiles; t++)
-        for (int phase = 0; phase < PLN_PHASES; phase++)
+      for (int t = 0; t < tiles; t++) {
+        if (plane_job_is_direct (J)) {        /* k_plane_direct */
+          for (int tid = 0; tid < PLN_THREADS; tid++)
+            plane_direct_body (J, t, tid);
+          continue;
+        }
+        for (int phase = 0; phase < PLN_PHASES; phase++)          /* k_plane_tiles */
           for (int tid = 0; tid < PLN_THREADS; tid++)
             plane_tile_body (J, (uint8_t *) lds.data (), t, tid, phase);
+      }
     }
     return GSTAMD_OK;
   }
   if (p.plane_mode) {                     /* convert_scale_planes: the plane kernels' bodies over their grids */
     for (const PlanePlan &pp : p.planes) {
-      const SrcPlane sp = {pl.p[pp.src_plane], pl.stride[pp.src_plane], pp.n_elems};
+      const SrcPlane sp = {pl.p[pp.src_plane], pl.stride[pp.src_plane], pp.n_elems, 0};
       const DstPlane dp = {dst + out->offset[pp.dst_plane], out->stride[pp.dst_plane], pp.n_elems};
       if (pp.kind != PLANE_SCALE) {
         for (int y = 0; y < pp.oh; y++)
@@ -1049,7 +1055,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         const int tw = pp.passes[0].horizontal ? pp.ow : pp.iw, th = pp.passes[0].horizontal ? pp.ih : pp.oh;
         std::vector<uint8_t> tmp ((size_t) tw * th * pp.n_elems);
         const DstPlane td = {tmp.data (), tw * pp.n_elems, pp.n_elems};
-        const SrcPlane ts = {tmp.data (), tw * pp.n_elems, pp.n_elems};
+        const SrcPlane ts = {tmp.data (), tw * pp.n_elems, pp.n_elems, 0};
         run (pp.passes[0].horizontal, sd[0], sp, td, tw, th);
         run (pp.passes[1].horizontal, sd[1], ts, dp, pp.ow, pp.oh);
       }

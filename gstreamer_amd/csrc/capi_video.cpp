@@ -236,6 +236,8 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[3], co
     return launch_fill_border (planes[0], strides[0], 3, v, rc.out_maxw, rc.out_maxh, rc.out_x, rc.out_y, w, h, stream);
   }
   e = launch_fill_border (planes[0], strides[0], 1, rc.border[1], rc.out_maxw, rc.out_maxh, rc.out_x, rc.out_y, w, h, stream);
+  if (f->kind == UNPACK_GRAY)
+    return e;
   const int cmw = up (rc.out_maxw, f->w_sub), cmh = up (rc.out_maxh, f->h_sub), cx = rc.out_x >> f->w_sub, cy = rc.out_y >> f->h_sub;
   const int cw = up (w, f->w_sub), ch = up (h, f->h_sub);
   if (e == hipSuccess && f->kind == UNPACK_SEMI) {

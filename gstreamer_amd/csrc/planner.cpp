@@ -31,6 +31,8 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_UYVY, "UYVY", true, false, 1, UNPACK_PACKED422, 1, 0, 0, 0, {0, 1, 0, 2}},
   {GSTAMD_VIDEO_FORMAT_YVYU, "YVYU", true, false, 1, UNPACK_PACKED422, 1, 0, 0, 0, {0, 0, 3, 1}},
   {GSTAMD_VIDEO_FORMAT_VYUY, "VYUY", true, false, 1, UNPACK_PACKED422, 1, 0, 0, 0, {0, 1, 2, 0}},
+  // luma only (video-format.c:1207-1229)
+  {GSTAMD_VIDEO_FORMAT_GRAY8, "GRAY8", true, false, 1, UNPACK_GRAY, 0, 0, 0, 0, {0, 0, 0, 0}},
   // 3 bytes per pixel (video-format.c:1519-1593)
   {GSTAMD_VIDEO_FORMAT_RGB, "RGB", false, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 0, 1, 2}},
   {GSTAMD_VIDEO_FORMAT_BGR, "BGR", false, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 2, 1, 0}},
@@ -175,6 +177,10 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->stride[0] = round_up (width * 2, 4);
       info->size = (uint64_t) info->stride[0] * h;
       break;
+    case GSTAMD_VIDEO_FORMAT_GRAY8:             /* video-info.c:942-946 */
+      info->stride[0] = round_up (width, 4);
+      info->size = (uint64_t) info->stride[0] * h;
+      break;
     case GSTAMD_VIDEO_FORMAT_RGB:
     case GSTAMD_VIDEO_FORMAT_BGR:
     case GSTAMD_VIDEO_FORMAT_v308:
@@ -192,7 +198,13 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = w * 4 * h;
       break;
   }
-  if (f->yuv) {
+  if (f->kind == UNPACK_GRAY) {         /* set_default_colorimetry (video-info.c:175-176): DEFAULT_GRAY = 0 .. 255, bt601, unknown, unknown */
+    info->color_range = GSTAMD_COLOR_RANGE_0_255;
+    info->color_matrix = GSTAMD_COLOR_MATRIX_BT601;
+    info->chroma_site = GSTAMD_CHROMA_SITE_UNKNOWN;
+    info->color_transfer = GSTAMD_TRANSFER_UNKNOWN;
+    info->color_primaries = GSTAMD_PRIMARIES_UNKNOWN;
+  } else if (f->yuv) {
     info->color_range = GSTAMD_COLOR_RANGE_16_235;
     info->color_matrix = height > 576 ? GSTAMD_COLOR_MATRIX_BT709 : GSTAMD_COLOR_MATRIX_BT601;
     info->chroma_site = height > 576 ? GSTAMD_CHROMA_SITE_H_COSITED : GSTAMD_CHROMA_SITE_NONE;
@@ -1172,6 +1184,7 @@ constexpr uint64_t F_RGB4X = fbit (GSTAMD_VIDEO_FORMAT_RGBx) | fbit (GSTAMD_VIDE
 constexpr uint64_t F_RGB4A = fbit (GSTAMD_VIDEO_FORMAT_RGBA) | fbit (GSTAMD_VIDEO_FORMAT_BGRA) | fbit (GSTAMD_VIDEO_FORMAT_ARGB) | fbit (GSTAMD_VIDEO_FORMAT_ABGR);
 constexpr uint64_t F_RGB3 = fbit (GSTAMD_VIDEO_FORMAT_RGB) | fbit (GSTAMD_VIDEO_FORMAT_BGR);
 constexpr uint64_t F_YUV3 = fbit (GSTAMD_VIDEO_FORMAT_v308) | fbit (GSTAMD_VIDEO_FORMAT_IYU2);
+constexpr uint64_t F_GRAY8 = fbit (GSTAMD_VIDEO_FORMAT_GRAY8);
 constexpr uint64_t F_NV12 = fbit (GSTAMD_VIDEO_FORMAT_NV12), F_NV16 = fbit (GSTAMD_VIDEO_FORMAT_NV16), F_NV24 = fbit (GSTAMD_VIDEO_FORMAT_NV24);
 struct FastRow {
   uint64_t in, out;     /* format sets; `same` rows need in == out on top */
@@ -1203,6 +1216,9 @@ const FastRow g_fast_rows[] = {
   {F_RGB4X | F_RGB3 | F_YUV3 | F_420 | F_Y42B | F_Y444 | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
         F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_YVYU), ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_420 | F_Y42B | F_Y444, F_420 | F_Y42B | F_Y444, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  /* the GRAY8 rows (:8560-8661): the luma plane from / to the planar formats, chroma planes filled with 0x80; GRAY8 -> GRAY8 */
+  {F_420 | F_Y42B | F_Y444, F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {F_GRAY8, F_420 | F_Y42B | F_Y444 | F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_NV12 | F_NV16 | F_NV24, F_NV12 | F_NV16 | F_NV24, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
 };
 }  // namespace
@@ -1252,8 +1268,14 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
     pp.dst_plane = i;
     pp.n_elems = 1;
     int isub_w = 0, isub_h = 0, osub_w = 0, osub_h = 0;
+    bool fill = false;
     if (i == 0) {
       pp.src_plane = 0;
+    } else if (fi->kind == UNPACK_GRAY) {
+      /* the source has no such component (setup_scale :8108-8149): convert_plane_fill with 0x80 */
+      fill = true;
+      pp.src_plane = 0;
+      osub_w = fo->w_sub, osub_h = fo->h_sub;
     } else if (fo->kind == UNPACK_SEMI) {
       pp.src_plane = 1;
       pp.n_elems = 2;
@@ -1277,7 +1299,14 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
     }
     const int rm = i == 0 ? method : cr_method;
     /* the halve / double shortcuts exist for the planes of multi-plane formats only (setup_scale :8092-8180) */
-    const bool p1 = pp.n_elems == 1 && fo->n_planes > 1, lin = rm == GSTAMD_RESAMPLER_METHOD_LINEAR, near = rm == GSTAMD_RESAMPLER_METHOD_NEAREST;
+    if (fill) {
+      pp.iw = pp.ih = 0;
+      pp.kind = PLANE_FILL;
+      bytes += (uint64_t) pp.ow * pp.oh;
+      plan->planes.push_back (pp);
+      continue;
+    }
+    const bool p1 = pp.n_elems == 1 && (fo->n_planes > 1 || fo->kind == UNPACK_GRAY), lin = rm == GSTAMD_RESAMPLER_METHOD_LINEAR, near = rm == GSTAMD_RESAMPLER_METHOD_NEAREST;
     bool need_h = false, need_v = false;
     pp.kind = PLANE_SCALE;
     if (pp.iw == pp.ow) {
@@ -1365,7 +1394,7 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
   }
   plan->algorithmic_bytes = bytes;
   std::string d = std::string ("scale_planes[") + fi->name + "->" + fo->name;
-  static const char *kn[] = {"copy", "h/2", "hx2", "v/2", "vx2", "hv/2", "hvx2", "scale"};
+  static const char *kn[] = {"copy", "h/2", "hx2", "v/2", "vx2", "hv/2", "hvx2", "scale", "fill"};
   for (const PlanePlan &pp : plan->planes) {
     d += std::string (",") + kn[pp.kind];
     for (const ScalePass &ps : pp.passes)
@@ -1443,6 +1472,8 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
     return (uint64_t) w * h * (f->hi_depth == 3 ? 8 : 4);
   if (f->kind == UNPACK_PACKED3)
     return (uint64_t) w * h * 3;
+  if (f->kind == UNPACK_GRAY)
+    return (uint64_t) w * h;
   const uint64_t cw = ((uint64_t) w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) h + (1 << f->h_sub) - 1) >> f->h_sub;
   const uint64_t n = (uint64_t) w * h + 2 * cw * ch;
   return f->hi_depth ? 2 * n : n;
@@ -2305,7 +2336,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       force_nearest = force_avg_down = true;
     else if (name == "convert_scale_planes" && ki == UNPACK_PACKED4)
       plane_scale = true;
-    else if (name == "convert_scale_planes" && (ki == ko || (kind_has_planes (ki) && kind_has_planes (ko))))
+    else if (name == "convert_scale_planes" && (ki == ko || (kind_has_planes (ki) && kind_has_planes (ko)) || (ki == UNPACK_GRAY && ko == UNPACK_PLANAR) ||
+            (ki == UNPACK_PLANAR && ko == UNPACK_GRAY)))
       return plan_planes (plan, fp);
     else
       return fail (GSTAMD_ERR_UNSUPPORTED, std::string ("reference takes fastpath ") + fp +
@@ -2509,6 +2541,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       rd = (uint64_t) in_w * in_h * 4;
     else if (f->kind == UNPACK_PACKED3)
       rd = (uint64_t) in_w * in_h * 3;
+    else if (f->kind == UNPACK_GRAY)
+      rd = (uint64_t) in_w * in_h;
     else {
       uint64_t cw = ((uint64_t) in_w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) in_h + (1 << f->h_sub) - 1) >> f->h_sub;
       rd = (uint64_t) in_w * in_h + 2 * cw * ch;
@@ -2519,7 +2553,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     if (plan->out_planar) {
       const FormatDesc *fo = plan->fout;
       uint64_t cw = ((uint64_t) out_w + (1 << fo->w_sub) - 1) >> fo->w_sub, ch = ((uint64_t) out_h + (1 << fo->h_sub) - 1) >> fo->h_sub;
-      wr = fo->kind == UNPACK_PACKED3 ? (uint64_t) out_w * out_h * 3 : (uint64_t) out_w * out_h + 2 * cw * ch;
+      wr = fo->kind == UNPACK_PACKED3 ? (uint64_t) out_w * out_h * 3 : fo->kind == UNPACK_GRAY ? (uint64_t) out_w * out_h : (uint64_t) out_w * out_h + 2 * cw * ch;
     }
     plan->algorithmic_bytes = rd + wr;
   }
@@ -2670,7 +2704,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     rc.border[1] = (uint8_t) r;
     rc.border[2] = (uint8_t) g;
     rc.border[3] = (uint8_t) b;
-    if (fo->yuv) {
+    if (fo->yuv && fo->kind != UNPACK_GRAY) {          /* GST_VIDEO_INFO_IS_YUV: a GRAY8 frame keeps the ARGB bytes, pack_GRAY8 then stores R */
       /* identity -> compute_matrix_to_YUV (force) -> rint; then 16 / 128 / 128 are added whatever the range */
       M44 dm;
       m_identity (dm);

@@ -21,6 +21,7 @@ enum UnpackKind : int {
   UNPACK_SEMI = 2,      // Y plane + interleaved UV plane (NV12, NV21, NV16, NV61, NV24)
   UNPACK_PACKED3 = 3,   // one plane, 3 bytes / pixel (RGB, BGR)
   UNPACK_PACKED422 = 4, // one plane, 4-byte macropixels of two pixels (YUY2, UYVY, YVYU, VYUY)
+  UNPACK_GRAY = 5,      // one plane of luma (GRAY8): a YUV format as far as the chain goes (unpack format AYUV), U = V = 0x80
 };
 
 struct FormatDesc {
@@ -183,7 +184,8 @@ bool make_mfma420_tables (const ScalePass &hpass, Mfma420Tables *t);
 int mfma420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int rows_per_round);
 
 // one destination plane of convert_scale_planes on a planar / semi-planar format
-enum PlaneKind : int { PLANE_COPY = 0, PLANE_H_HALVE, PLANE_H_DOUBLE, PLANE_V_HALVE, PLANE_V_DOUBLE, PLANE_HV_HALVE, PLANE_HV_DOUBLE, PLANE_SCALE };
+enum PlaneKind : int { PLANE_COPY = 0, PLANE_H_HALVE, PLANE_H_DOUBLE, PLANE_V_HALVE, PLANE_V_DOUBLE, PLANE_HV_HALVE, PLANE_HV_DOUBLE, PLANE_SCALE,
+  PLANE_FILL /* a destination plane whose component the source does not have: convert_plane_fill (video-converter.c:7310), 0x80 for chroma */ };
 struct PlanePlan {
   int kind;                       // PlaneKind
   int src_plane, dst_plane;

@@ -170,6 +170,8 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
     const uint8_t *q = pl.p[0] + (size_t) y * pl.stride[0] + 3 * (size_t) x;
     return 0xffu | ((uint32_t) q[f.pos[1]] << 8) | ((uint32_t) q[f.pos[2]] << 16) | ((uint32_t) q[f.pos[3]] << 24);
   }
+  if (f.kind == UNPACK_GRAY)             // unpack_GRAY8 (video-format.c:1209, video_orc_unpack_GRAY8): A = 0xff, Y, U = V = 0x80
+    return 0x808000ffu | ((uint32_t) pl.p[0][(size_t) y * pl.stride[0] + x] << 8);
   const int yl = y < f.luma_last ? y : f.luma_last;          /* a no-op for the picture's own lines; the line past it clamps like do_unpack_lines */
   const int Y = f.kind == UNPACK_PACKED422 ? pl.p[0][(size_t) yl * pl.stride[0] + 4 * (size_t) (x >> 1) + f.pos[1] + 2 * (x & 1)]
       : pl.p[0][(size_t) yl * pl.stride[0] + x];

@@ -55,6 +55,12 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
     }
     return;
   }
+  if (pk.kind == UNPACK_GRAY) {            // pack_GRAY8 (video-format.c:1221): the luma byte of every pixel
+    uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + x0;
+    for (int i = 0; i < 4 && x0 + i < w; i++)
+      q[i] = (uint8_t) pack_dither (pk.dither, 1, (int) ((src.at (x0 + i, y0) >> 8) & 0xff), x0 + i, y0);
+    return;
+  }
   const int nlines = 1 << pk.h_sub;
   if (pk.kind == UNPACK_PACKED422) {       // luma into the macropixels (pack_YUY2 & co, video-format.c:201-460)
     uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 2 * (size_t) x0;

@@ -72,6 +72,9 @@ GSTAMD_HD void plane_simple_body (int kind, const SrcPlane &s, const DstPlane &d
     case PLANE_HV_DOUBLE:    /* video_orc_planar_chroma_420_444 */
       v = s.at (x >> 1, y >> 1);
       break;
+    case PLANE_FILL:         /* convert_plane_fill: the chroma plane of a destination whose source has none */
+      v = 0x80;
+      break;
     default:                 /* PLANE_COPY */
       v = s.at (x, y);
       break;
@@ -231,6 +234,9 @@ GSTAMD_HD bool plane_simple4 (const PlaneJob &J, int x, int y)
   const size_t st = (size_t) J.s.stride;
   uint32_t v;
   switch (J.kind) {
+    case PLANE_FILL:
+      v = 0x80808080u;
+      break;
     case PLANE_COPY:
       v = *(const uint32_t *) (sp + (size_t) y * st + x);
       break;

@@ -56,6 +56,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_YVYU = 19,
   GSTAMD_VIDEO_FORMAT_Y444 = 20,
   GSTAMD_VIDEO_FORMAT_NV12 = 23,
+  GSTAMD_VIDEO_FORMAT_GRAY8 = 25,       /* one plane of luma; unpacks to A = 0xff, Y, U = V = 0x80 (video-format.c:1207-1229) */
   GSTAMD_VIDEO_FORMAT_v308 = 28,        /* packed 4:4:4, 3 bytes per pixel: Y U V */
   GSTAMD_VIDEO_FORMAT_IYU2 = 63,        /* the same in the order U Y V */
   GSTAMD_VIDEO_FORMAT_VUYA = 84,        /* packed 4:4:4:4, 4 bytes per pixel: V U Y A */

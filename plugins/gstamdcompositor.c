@@ -39,7 +39,7 @@ GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
 #define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR }"
 /* what a pad may carry: anything the converter takes; it is brought to the output format / the pad's width x height by a
  * per-pad GstAmdVideoConverter (the reference's GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) */
-#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY }"
+#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, GRAY8 }"
 #define AMD_COMP_MAX_PADS 64
 
 static GstStaticPadTemplate comp_sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
@@ -356,6 +356,7 @@ amd_pad_format_of (GstVideoFormat f)
     case GST_VIDEO_FORMAT_VYUY: return GSTAMD_VIDEO_FORMAT_VYUY;
     case GST_VIDEO_FORMAT_RGB: return GSTAMD_VIDEO_FORMAT_RGB;
     case GST_VIDEO_FORMAT_BGR: return GSTAMD_VIDEO_FORMAT_BGR;
+    case GST_VIDEO_FORMAT_GRAY8: return GSTAMD_VIDEO_FORMAT_GRAY8;
     default: return amd_format_of (f);
   }
 }

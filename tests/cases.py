@@ -332,6 +332,24 @@ VIDEO_CASES = [
     ("yvyu_y444_chain_wide_front_64x6", "YVYU", 64, 6, "Y444", 64, 6, {}, None, None, "random"),
     ("yuy2_ayuv_wide_front_64x6", "YUY2", 64, 6, "AYUV", 64, 6, {}, None, None, "random"),
     ("uyvy_ayuv_wide_front_chroma_none_72x5", "UYVY", 72, 5, "AYUV", 72, 5, dict(chroma_mode="none"), None, None, "random"),
+    # ---- GRAY8 (pack_GRAY8 / unpack_GRAY8 video-format.c; DEFAULT_GRAY colorimetry video-info.c:175-176; fastpath rows video-converter.c
+    # :7190-7206 planar YUV <-> GRAY8 with the chroma planes filled with 0x80)
+    ("gray8_bgra_66x9", "GRAY8", 66, 9, "BGRA", 66, 9, {}, None, None, "random"),
+    ("bgra_gray8_67x9", "BGRA", 67, 9, "GRAY8", 67, 9, {}, None, None, "random"),
+    ("rgb_gray8_33x5", "RGB", 33, 5, "GRAY8", 33, 5, {}, None, None, "random"),
+    ("gray8_i420_fill_planes_66x11", "GRAY8", 66, 11, "I420", 66, 11, {}, None, None, "random"),
+    ("i420_gray8_planes_66x11", "I420", 66, 11, "GRAY8", 66, 11, {}, None, None, "random"),
+    ("y444_gray8_scaled_planes_lanczos", "Y444", 64, 48, "GRAY8", 40, 30, LAN, None, None, "random"),
+    ("gray8_gray8_scaled_bilinear", "GRAY8", 64, 48, "GRAY8", 100, 70, LIN, None, None, "random"),
+    ("gray8_y42b_scaled_fill", "GRAY8", 64, 48, "Y42B", 33, 17, {}, None, None, "random"),
+    ("gray8_nv12_generic_70x10", "GRAY8", 70, 10, "NV12", 70, 10, {}, None, None, "random"),
+    ("nv12_gray8_bt709_generic_70x10", "NV12", 70, 10, "GRAY8", 70, 10, {}, "bt709", None, "random"),
+    ("yuy2_gray8_64x6", "YUY2", 64, 6, "GRAY8", 64, 6, {}, None, None, "random"),
+    ("gray8_ayuv_scaled_cubic", "GRAY8", 64, 48, "AYUV", 90, 50, dict(resampler_method="cubic"), None, None, "random"),
+    ("p010_gray8_64x8", "P010_10LE", 64, 8, "GRAY8", 64, 8, {}, None, None, "random"),
+    ("gray8_argb64_33x4", "GRAY8", 33, 4, "ARGB64", 33, 4, {}, None, None, "random"),
+    ("gray8_i420_border", "GRAY8", 64, 48, "I420", 80, 60, dict(dest_x=8, dest_y=4, dest_width=64, dest_height=48, border_argb=0xff336699), None, None, "random"),
+    ("bgra_gray8_border_dither", "BGRA", 64, 48, "GRAY8", 80, 60, dict(dest_x=8, dest_y=6, dest_width=64, dest_height=48, border_argb=0xffc08040), None, None, "random"),
     ("yuy2_uyvy_322x241_fastpath", "YUY2", 322, 241, "UYVY", 322, 241, {}, None, None, "random"),
     ("uyvy_yuy2_33x17_fastpath", "UYVY", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
     ("yuy2_yuy2_copy_33x17_planes", "YUY2", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),

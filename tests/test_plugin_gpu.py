@@ -149,6 +149,25 @@ def test_videoconvertscale_element_packed_444_formats(gst_env, ref):
         assert (c1.frame(mid[f]) == out[f]).all()
 
 
+def test_videoconvertscale_element_gray8(gst_env, ref):
+    """GRAY8 on either side: NV12 -> GRAY8 half size (the luma plane scaled alone), GRAY8 -> BGRA"""
+    env, tmp = gst_env
+    w, h, n = 322, 242, 2
+    fin, fmid, fout = tmp / "g.nv12", tmp / "g.gray", tmp / "g.bgra"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=%d,height=%d,colorimetry=bt601,chroma-site=jpeg "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw,format=GRAY8,width=160,height=120 ! tee name=u "
+                "u. ! queue ! filesink location=%s u. ! queue ! videoconvertscale ! video/x-raw,format=BGRA,width=160,height=120 ! filesink location=%s"
+           % (n, w, h, fin, fmid, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    mid = np.fromfile(fmid, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    c0 = ref.VideoConverter("NV12", w, h, "GRAY8", 160, 120, in_colorimetry="bt601", in_chroma_site="jpeg", config=cases.ref_config_string(ref, cases.LIN))
+    c1 = ref.VideoConverter("GRAY8", 160, 120, "BGRA", 160, 120)
+    for f in range(n):
+        assert (c0.frame(src[f]) == mid[f]).all()
+        assert (c1.frame(mid[f]) == out[f]).all()
+
+
 def test_videoconvertscale_chroma_resampler_property(gst_env, ref):
     """`chroma-resampler` (gstvideoconvertscale.c:137, 345, 1076): the method of the chroma planes when a planar frame is scaled in its
     own format (convert_scale_planes) - cubic luma with nearest / lanczos chroma against the reference's chroma-resampler-method"""

@@ -223,30 +223,21 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[3], co
   const int w = p.out_info.width, h = p.out_info.height;
   auto up = [](int v, int sub) { return -((-v) >> sub); };
   hipError_t e = hipSuccess;
-  if (f->kind == UNPACK_PACKED4) {
-    uint32_t v = 0;
-    for (int c = 0; c < 4; c++)
-      v |= (uint32_t) rc.border[c] << (8 * f->pos[c]);
-    return launch_fill_border (planes[0], strides[0], 4, v, rc.out_maxw, rc.out_maxh, rc.out_x, rc.out_y, w, h, stream);
-  }
-  if (f->kind == UNPACK_PACKED3) {
-    uint32_t v = 0;
-    for (int c = 1; c < 4; c++)
-      v |= (uint32_t) rc.border[c] << (8 * f->pos[c]);
-    return launch_fill_border (planes[0], strides[0], 3, v, rc.out_maxw, rc.out_maxh, rc.out_x, rc.out_y, w, h, stream);
-  }
-  e = launch_fill_border (planes[0], strides[0], 1, rc.border[1], rc.out_maxw, rc.out_maxh, rc.out_x, rc.out_y, w, h, stream);
-  if (f->kind == UNPACK_GRAY)
-    return e;
-  const int cmw = up (rc.out_maxw, f->w_sub), cmh = up (rc.out_maxh, f->h_sub), cx = rc.out_x >> f->w_sub, cy = rc.out_y >> f->h_sub;
-  const int cw = up (w, f->w_sub), ch = up (h, f->h_sub);
-  if (e == hipSuccess && f->kind == UNPACK_SEMI) {
-    const uint32_t uv = f->u_plane ? (uint32_t) rc.border[2] | ((uint32_t) rc.border[3] << 8) : (uint32_t) rc.border[3] | ((uint32_t) rc.border[2] << 8);
-    e = launch_fill_border (planes[1], strides[1], 2, uv, cmw, cmh, cx, cy, cw, ch, stream);
-  } else if (e == hipSuccess) {
-    e = launch_fill_border (planes[f->u_plane], strides[f->u_plane], 1, rc.border[2], cmw, cmh, cx, cy, cw, ch, stream);
-    if (e == hipSuccess)
-      e = launch_fill_border (planes[f->v_plane], strides[f->v_plane], 1, rc.border[3], cmw, cmh, cx, cy, cw, ch, stream);
+  const int n_planes = kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
+  for (int i = 0; i < n_planes && e == hipSuccess; i++) {
+    int es;
+    uint32_t lo, hi;
+    border_plane_value (f, rc.border, i, &es, &lo, &hi);
+    const int ws = i ? f->w_sub : 0, hs = i ? f->h_sub : 0;
+    const int mw = up (rc.out_maxw, ws), mh = up (rc.out_maxh, hs);
+    e = launch_fill_border (planes[i], strides[i], es, lo, hi, mw, mh, rc.out_x >> ws, rc.out_y >> hs, up (w, ws), up (h, hs), stream);
+    if (e == hipSuccess && i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && (rc.out_maxw & 1)) {
+      /* pack_NV61's odd-width tail (video-format.c:2005-2011) stores the last pair of every border line in NV16 order; the picture's rows
+         are the packer's (tail_swap) when the rectangle reaches that column */
+      const bool reaches = rc.out_x + w == rc.out_maxw;
+      e = launch_fill_border (planes[1] + (size_t) (mw - 1) * 2, strides[1], 2, (lo >> 8) | ((lo & 0xff) << 8), 0, 1, mh, 0, rc.out_y >> hs, reaches ? 1 : 0,
+          reaches ? up (h, hs) : 0, stream);
+    }
   }
   return e;
 }
@@ -655,7 +646,8 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   if (g.src64) {
     if (!src_planes[0])
       return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
-    cur.p = (const uint8_t *) src_planes[0], cur.stride = src_stride ? src_stride[0] : p.in_info.stride[0], cur.width = in_w, cur.height = in_h;
+    cur.stride = src_stride ? src_stride[0] : p.in_info.stride[0], cur.width = in_w, cur.height = in_h;
+    cur.p = (const uint8_t *) src_planes[0] + plane_origin (p.fin, 0, p.rect.in_x, p.rect.in_y, cur.stride);          /* the source crop */
     cur_is_source = true;
   } else if (g.src16) {
     /* 10-bit source: the front of video_deep.h (unpack + chroma upsample) into an AYUV64 image */
@@ -666,6 +658,7 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       pl.stride[i] = src_stride ? src_stride[i] : p.in_info.stride[i];
       if (!pl.p[i])
         return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
+      pl.p[i] += plane_origin (p.fin, i, p.rect.in_x, p.rect.in_y, pl.stride[i]);          /* the source crop (the vpair table knows the frame's rows) */
     }
     if ((e = launch_front16 (p.front, pl, c->vpair_dev, c->deep_a, in_w * 8, stream)) != hipSuccess)
       return hip_fail (e, "k_front16");
@@ -745,17 +738,8 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       return hip_fail (e, "k_gamma_stage(encode)");
     }
   }
-  if (g.store64) {
-    /* the last 16-bit image is the frame (pack_ARGB64 / pack_AYUV64 are copies at native endianness) */
-    if (!dest_planes[0])
-      return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
-    const int ds = dest_stride ? dest_stride[0] : p.out_info.stride[0];
-    e = hipMemcpy2DAsync (dest_planes[0], (size_t) ds, cur.p, (size_t) cur.stride, (size_t) out_w * 8, (size_t) out_h, hipMemcpyDeviceToDevice, stream);
-    if (e == hipSuccess && g.dither16.on)
-      e = launch_dither16_image (g.dither16, (uint8_t *) dest_planes[0], ds, out_w, out_h, stream);
-    return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "copy of the 16-bit image");
-  }
-  if (g.pack16) {
+  if (g.store64 || g.pack16) {
+    /* a 16-bit destination frame: borders around the rectangle first (the border pixel packed like any other, border_plane_value) */
     uint8_t *planes[3] = {nullptr, nullptr, nullptr};
     int strides[3] = {0, 0, 0};
     for (int i = 0; i < p.out_info.n_planes && i < 3; i++) {
@@ -763,6 +747,17 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       strides[i] = dest_stride ? dest_stride[i] : p.out_info.stride[i];
       if (!planes[i])
         return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+    }
+    if (p.rect.fill && (e = fill_borders (p, planes, strides, stream)) != hipSuccess)
+      return hip_fail (e, "k_fill_border");
+    for (int i = 0; i < p.out_info.n_planes && i < 3; i++)
+      planes[i] += plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, strides[i]);
+    if (g.store64) {
+      /* the last 16-bit image is the picture (pack_ARGB64 / pack_AYUV64 are copies at native endianness) */
+      e = hipMemcpy2DAsync (planes[0], (size_t) strides[0], cur.p, (size_t) cur.stride, (size_t) out_w * 8, (size_t) out_h, hipMemcpyDeviceToDevice, stream);
+      if (e == hipSuccess && g.dither16.on)
+        e = launch_dither16_image (g.dither16, planes[0], strides[0], out_w, out_h, stream);
+      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "copy of the 16-bit image");
     }
     e = launch_pack16 (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, planes, strides, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_pack16");

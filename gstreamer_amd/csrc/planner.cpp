@@ -1897,11 +1897,6 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   GammaPlan &g = plan->gamma;
   if (cfg.gamma_mode == GSTAMD_GAMMA_MODE_REMAP && !plane_scale)
     return fail (GSTAMD_ERR_UNSUPPORTED, "gamma-mode = remap with a 16-bit unpack format is not implemented on the GPU path");
-  if (plan->rect.in_x || plan->rect.in_y || (plan->rect.in_maxw && (plan->rect.in_maxw != in->width || plan->rect.in_maxh != in->height)))
-    return fail (GSTAMD_ERR_UNSUPPORTED, "cropping a 16-bit source is not implemented on the GPU path");
-  if (fo->hi_depth && (plan->rect.out_x || plan->rect.out_y || plan->rect.fill ||
-          (plan->rect.out_maxw && (plan->rect.out_maxw != out->width || plan->rect.out_maxh != out->height))))
-    return fail (GSTAMD_ERR_UNSUPPORTED, "a destination rectangle / borders inside a 16-bit frame are not implemented on the GPU path");
   if (fo->hi_depth && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
     return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path");
   g.on = true;
@@ -2282,15 +2277,6 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * (scaled on the 16-bit lines, then converted) or enlarged (converted, then scaled on 8-bit lines). */
   plan->deep16 = plan->fin->hi_depth != 0;
   plan->deep_out = plan->fout->hi_depth != 0;
-  if (plan->deep_out && (plan->rect.out_x || plan->rect.out_y || plan->rect.fill ||
-          (plan->rect.out_maxw && (plan->rect.out_maxw != out->width || plan->rect.out_maxh != out->height))))
-    return fail (GSTAMD_ERR_UNSUPPORTED, "a destination rectangle / borders inside a 10-bit frame are not implemented on the GPU path");
-  if (plan->deep16) {
-    if (plan->rect.in_x || plan->rect.in_y || plan->rect.out_x || plan->rect.out_y ||
-        plan->rect.fill || (plan->rect.in_maxw && (plan->rect.in_maxw != in->width || plan->rect.in_maxh != in->height)) ||
-        (plan->rect.out_maxw && (plan->rect.out_maxw != out->width || plan->rect.out_maxh != out->height)))
-      return fail (GSTAMD_ERR_UNSUPPORTED, "cropping / borders of a 10-bit source are not implemented on the GPU path");
-  }
   /* Fastpaths of the reference that are the generic chain with two decisions forced, reproduced by forcing them here:
    *  - convert_I420_BGRA / _ARGB / _pack_ARGB (:6772-6990) and convert_I420_AYUV / Y42B_AYUV / Y444_AYUV (:3563, ..):
    *    chroma is sampled nearest (row y >> 1, loadupdb), no interpolation;
@@ -2713,7 +2699,9 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       if (get_Kr_Kb (mtx, &Kr, &Kb))
         m_RGB_to_YCbCr (dm, Kr, Kb);
       int offset[4], scale[4];
-      range_offsets (out->color_range, true, offset, scale);
+      /* the range of the PACK format (compute_matrix_to_YUV :1430-1438): 16-bit scales for a 10 / 12 / 16-bit destination, which the 8-bit
+         formula below then clamps to 0 or 255 for most colours - the reference's border in such frames */
+      range_offsets (out->color_range, true, offset, scale, fo->hi_depth ? 16 : 8);
       m_scale_components (dm, (float) scale[0], (float) scale[1], (float) scale[2]);
       m_offset_components (dm, offset[0], offset[1], offset[2]);
       int im[3][3];
@@ -2751,6 +2739,11 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    *  (b) the nearest vertical scaler hands out the SAME line for every output row it repeats (video_scale_v_near), and the
    *      convert / alpha stages after it work in place (:3127-3141, do_alpha_lines): a repeated row gets the matrix once more
    *      per repetition. */
+  /* the odd-width tail of pack_VYUY / pack_NV61 is the FRAME line's (the reference packs out_maxwidth pixels a line, borders included): a
+     rectangle that ends before the frame's right edge packs its last pixel the ordinary way */
+  if (!(plan->rect.out_x + eout.width == plan->rect.out_maxw && (plan->rect.out_maxw & 1)))
+    plan->pack.tail_swap = plan->gamma.pack.tail_swap = 0;
+  plan->gamma.dither16.y0 = plan->rect.out_y;          /* the 16-bit dither stage counts frame lines (do_dither_lines: out_line = i + out_y) */
   const VideoPlan &pl = *plan;
   const bool chain = !pl.plane_mode && pl.ref_fastpath.empty ();
   const int iw = ein.width, ih = ein.height, ow = eout.width, oh = eout.height;

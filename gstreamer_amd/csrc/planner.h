@@ -295,10 +295,51 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
     return (size_t) y * stride + (size_t) x * 3;
   if (f->kind == UNPACK_PACKED422)
     return (size_t) y * stride + (size_t) x * 2;
+  const size_t bps = f->hi_depth ? 2 : 1;          /* planes of 10 / 12 / 16-bit formats hold 16-bit samples */
   if (plane == 0)
-    return (size_t) y * stride + (size_t) x;
+    return (size_t) y * stride + (size_t) x * bps;
   const size_t row = (size_t) (y >> f->h_sub) * stride;
-  return f->kind == UNPACK_SEMI ? row + (size_t) (x >> f->w_sub) * 2 : row + (size_t) (x >> f->w_sub);
+  return f->kind == UNPACK_SEMI ? row + (size_t) (x >> f->w_sub) * 2 * bps : row + (size_t) (x >> f->w_sub) * bps;
+}
+
+// The border sample(s) of plane `plane` of the destination (setup_borderline :2189-2262 packs one border pixel with the format's own pack
+// function): *es = bytes a plane position takes, lo / hi = its value (hi: the upper half of an 8-byte pixel).  16-bit formats pack the
+// border widened by video_orc_splat2_u64 (v * 257).  swap: the position is the odd-width tail of an NV61 line (see fill_borders).
+inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], int plane, int *es, uint32_t *lo, uint32_t *hi)
+{
+  *hi = 0;
+  auto s16 = [&](int c) -> uint32_t {
+    const uint32_t v = (uint32_t) border[c] * 257u;
+    if (f->hi_depth == 3 || f->hi_depth == 6)
+      return v;
+    const int drop = 16 - hi_depth_bits (f->hi_depth);
+    return f->hi_depth == 1 || f->hi_depth == 4 ? v >> drop : v & ~((1u << drop) - 1u);
+  };
+  if (f->kind == UNPACK_PACKED4 && f->hi_depth == 3) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int c = 0; c < 4; c++)
+      w[f->pos[c]] = s16 (c);
+    *es = 8, *lo = w[0] | (w[1] << 16), *hi = w[2] | (w[3] << 16);
+  } else if (f->kind == UNPACK_PACKED4 || f->kind == UNPACK_PACKED3) {
+    uint32_t v = 0;
+    for (int c = f->kind == UNPACK_PACKED4 ? 0 : 1; c < 4; c++)
+      v |= (uint32_t) border[c] << (8 * f->pos[c]);
+    *es = f->kind == UNPACK_PACKED4 ? 4 : 3, *lo = v;
+  } else if (f->hi_depth) {
+    if (plane == 0)
+      *es = 2, *lo = s16 (1);
+    else if (f->kind == UNPACK_SEMI)
+      *es = 4, *lo = f->u_plane ? s16 (2) | (s16 (3) << 16) : s16 (3) | (s16 (2) << 16);
+    else
+      *es = 2, *lo = s16 (plane == f->u_plane ? 2 : 3);
+  } else {
+    if (plane == 0)
+      *es = 1, *lo = border[1];
+    else if (f->kind == UNPACK_SEMI)
+      *es = 2, *lo = f->u_plane ? (uint32_t) border[2] | ((uint32_t) border[3] << 8) : (uint32_t) border[3] | ((uint32_t) border[2] << 8);
+    else
+      *es = 1, *lo = border[plane == f->u_plane ? 2 : 3];
+  }
 }
 
 // vpair table entry 0: chroma row of the pair's first line (signed 30 bits: with a source crop the row above the crop

@@ -231,7 +231,7 @@ GSTAMD_HD int dither16_comp (const DitherParams &d, int comp, int v, int x, int 
   if (!d.on)
     return v;
   const int sh = d.shift[comp];
-  const int b = dither_bayer_value (x, y);
+  const int b = dither_bayer_value (x, y + d.y0);          /* do_dither_lines passes out_line = i + out_y */
   const int e = sh < 8 ? b >> (8 - sh) : b;
   int p = v + e;
   p = p > 65535 ? 65535 : p;                            /* addusw */

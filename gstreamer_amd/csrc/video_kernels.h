@@ -70,7 +70,7 @@ hipError_t launch_bilinear420_frames (const BilParams &bp, int chroma_h, int n, 
 hipError_t launch_plane_simple (int kind, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems, int ow, int oh, hipStream_t stream);
 hipError_t launch_plane_pass (bool horizontal, const ScaleDev &sd, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems,
     int ow, int oh, hipStream_t stream);
-hipError_t launch_fill_border (uint8_t *p, int stride, int es, uint32_t value, int maxw, int maxh, int x0, int y0, int w, int h,
+hipError_t launch_fill_border (uint8_t *p, int stride, int es, uint32_t value, uint32_t value_hi, int maxw, int maxh, int x0, int y0, int w, int h,
     hipStream_t stream);
 struct Enc420Params;
 hipError_t launch_encode420 (const Enc420Params &ep, bool semi, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],

@@ -819,15 +819,17 @@ hipError_t launch_plane_frame (const PlaneJobs &jobs, size_t lds_bytes, hipStrea
 }
 
 // borders (convert_fill_border, video-converter.c:7190): every pixel of a destination plane outside the picture rectangle
-// gets the plane's border value; es = bytes per pixel of the plane (1, 2, 3 or 4)
-__global__ __launch_bounds__ (256) void k_fill_border (uint8_t *__restrict__ p, int stride, int es, uint32_t value, int maxw, int maxh,
+// gets the plane's border value; es = bytes per pixel of the plane (1, 2, 3, 4 or 8: value_hi is the upper word)
+__global__ __launch_bounds__ (256) void k_fill_border (uint8_t *__restrict__ p, int stride, int es, uint32_t value, uint32_t value_hi, int maxw, int maxh,
     int x0, int y0, int w, int h)
 {
   const int x = (int) (blockIdx.x * blockDim.x + threadIdx.x), y = (int) blockIdx.y;
   if (x >= maxw || y >= maxh || (x >= x0 && x < x0 + w && y >= y0 && y < y0 + h))
     return;
   uint8_t *q = p + (size_t) y * stride + (size_t) x * es;
-  if (es == 4)
+  if (es == 8)
+    *(uint2 *) q = make_uint2 (value, value_hi);
+  else if (es == 4)
     *(uint32_t *) q = value;
   else if (es == 2)
     *(uint16_t *) q = (uint16_t) value;
@@ -1588,10 +1590,10 @@ hipError_t launch_plane_pass (bool horizontal, const ScaleDev &sd, const uint8_t
   return hipGetLastError ();
 }
 
-hipError_t launch_fill_border (uint8_t *p, int stride, int es, uint32_t value, int maxw, int maxh, int x0, int y0, int w, int h,
+hipError_t launch_fill_border (uint8_t *p, int stride, int es, uint32_t value, uint32_t value_hi, int maxw, int maxh, int x0, int y0, int w, int h,
     hipStream_t stream)
 {
-  hipLaunchKernelGGL (k_fill_border, dim3 ((maxw + 255) / 256, maxh), dim3 (256), 0, stream, p, stride, es, value, maxw, maxh, x0, y0, w, h);
+  hipLaunchKernelGGL (k_fill_border, dim3 ((maxw + 255) / 256, maxh), dim3 (256), 0, stream, p, stride, es, value, value_hi, maxw, maxh, x0, y0, w, h);
   return hipGetLastError ();
 }
 

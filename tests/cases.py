@@ -350,6 +350,23 @@ VIDEO_CASES = [
     ("gray8_argb64_33x4", "GRAY8", 33, 4, "ARGB64", 33, 4, {}, None, None, "random"),
     ("gray8_i420_border", "GRAY8", 64, 48, "I420", 80, 60, dict(dest_x=8, dest_y=4, dest_width=64, dest_height=48, border_argb=0xff336699), None, None, "random"),
     ("bgra_gray8_border_dither", "BGRA", 64, 48, "GRAY8", 80, 60, dict(dest_x=8, dest_y=6, dest_width=64, dest_height=48, border_argb=0xffc08040), None, None, "random"),
+    # ---- crops / destination rectangles / borders in 10-, 12- and 16-bit frames (border_plane_value: the border pixel widened by
+    # video_orc_splat2_u64 and packed by the format's own pack function; its Y'CbCr value comes out of the 8-bit formula of setup_borderline
+    # :2206-2232 fed with the 16-bit scales of the pack format, i.e. clamped)
+    ("p010_bgra_crop_dest_border", "P010_10LE", 128, 72, "BGRA", 100, 60, dict(src_x=32, src_y=10, src_width=64, src_height=36, dest_x=20, dest_y=12, dest_width=64, dest_height=36), None, None, "random"),
+    ("p010_nv12_crop_scaled", "P010_10LE", 128, 72, "NV12", 48, 30, dict(LIN, src_x=16, src_y=6, src_width=96, src_height=60), None, None, "random"),
+    ("i420_10le_i420_crop_odd_rows", "I420_10LE", 66, 38, "I420", 66, 38, dict(src_x=2, src_y=6, src_width=40, src_height=21), None, "mpeg2", "random"),
+    ("nv12_p010_letterbox_border", "NV12", 64, 36, "P010_10LE", 80, 80, dict(LIN, dest_x=0, dest_y=18, dest_width=80, dest_height=44, border_argb=0xff203040), None, None, "random"),
+    ("bgra_i420_10le_pillarbox_odd", "BGRA", 33, 40, "I420_10LE", 81, 41, dict(dest_x=24, dest_y=0, dest_width=33, dest_height=41, border_argb=0xffc08040), None, None, "random"),
+    ("y444_12le_p012_crop_dest", "Y444_12LE", 64, 40, "P012_LE", 70, 50, dict(LAN, src_x=9, src_y=7, src_width=40, src_height=25, dest_x=6, dest_y=4, dest_width=52, dest_height=40, border_argb=0x80112233), None, None, "random"),
+    ("ayuv64_argb64_crop_dest_border", "AYUV64", 48, 30, "ARGB64", 60, 40, dict(src_x=5, src_y=3, src_width=30, src_height=20, dest_x=7, dest_y=9, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+    ("bgra_ayuv64_dest_border_dither", "BGRA", 40, 24, "AYUV64", 64, 36, dict(LIN, dither_quantization=16, dest_x=10, dest_y=5, dest_width=44, dest_height=26, border_argb=0xffe01020), None, None, "random"),
+    ("argb64_nv12_crop_border", "ARGB64", 50, 30, "NV12", 50, 30, dict(src_x=10, src_y=4, src_width=30, src_height=20, dest_x=8, dest_y=6, dest_width=30, dest_height=20), None, None, "random"),
+    ("p016_y444_16le_dest_border", "P016_LE", 40, 24, "Y444_16LE", 60, 30, dict(dest_x=12, dest_y=3, dest_width=40, dest_height=24, border_argb=0xff101010), None, None, "random"),
+    ("i422_10le_y42b_crop_gamma_free", "I422_10LE", 48, 20, "Y42B", 24, 10, dict(src_x=8, src_y=5, src_width=36, src_height=11), "bt709", None, "random"),
+    # pack_NV61's odd-width tail is the frame line's, not the rectangle's (video-format.c:2005-2011)
+    ("rgb_nv61_odd_frame_rect_inside", "RGB", 51, 25, "NV61", 51, 25, dict(LIN, dest_x=2, dest_y=6, dest_width=9, dest_height=3, border_argb=0x01e255e2), "bt709", "jpeg", "random"),
+    ("rgb_nv61_odd_frame_rect_to_edge", "RGB", 51, 25, "NV61", 51, 25, dict(LIN, dest_x=42, dest_y=6, dest_width=9, dest_height=3, border_argb=0x01e255e2), "bt709", "jpeg", "random"),
     ("yuy2_uyvy_322x241_fastpath", "YUY2", 322, 241, "UYVY", 322, 241, {}, None, None, "random"),
     ("uyvy_yuy2_33x17_fastpath", "UYVY", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),
     ("yuy2_yuy2_copy_33x17_planes", "YUY2", 33, 17, "YUY2", 33, 17, {}, None, None, "random"),

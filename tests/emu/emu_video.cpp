@@ -735,6 +735,36 @@ extern "C" int emu_swizzle4_runs (void) { return g_swizzle4_runs; }
 static std::string g_emu_divergence;
 extern "C" const char *emu_video_last_divergence (void) { return g_emu_divergence.c_str (); }
 
+// fill_borders of capi_video.cpp: k_fill_border's rule plane by plane, values from border_plane_value
+static void emu_fill_borders (const VideoPlan &p, const GstAmdVideoInfo *out, uint8_t *dst)
+{
+  const FormatDesc *f = p.fout;
+  auto up = [](int v, int sub) { return -((-v) >> sub); };
+  const int n_planes = kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
+  for (int i = 0; i < n_planes; i++) {
+    int es;
+    uint32_t lo, hi;
+    border_plane_value (f, p.rect.border, i, &es, &lo, &hi);
+    uint8_t v[8];
+    memcpy (v, &lo, 4);
+    memcpy (v + 4, &hi, 4);
+    const int ws = i ? f->w_sub : 0, hs = i ? f->h_sub : 0;
+    const int mw = up (p.rect.out_maxw, ws), mh = up (p.rect.out_maxh, hs), x0 = p.rect.out_x >> ws, y0 = p.rect.out_y >> hs;
+    const int w = up (p.out_info.width, ws), h = up (p.out_info.height, hs);
+    for (int y = 0; y < mh; y++)
+      for (int x = 0; x < mw; x++)
+        if (!(x >= x0 && x < x0 + w && y >= y0 && y < y0 + h))
+          memcpy (dst + out->offset[i] + (size_t) y * out->stride[i] + (size_t) x * es, v, es);
+    if (i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && (p.rect.out_maxw & 1)) {          /* the second k_fill_border launch of fill_borders */
+      const uint8_t sw[2] = {v[1], v[0]};
+      const bool reaches = p.rect.out_x + p.out_info.width == p.rect.out_maxw;
+      for (int y = 0; y < mh; y++)
+        if (!(reaches && y >= y0 && y < y0 + h))
+          memcpy (dst + out->offset[i] + (size_t) y * out->stride[i] + (size_t) (mw - 1) * 2, sw, 2);
+    }
+  }
+}
+
 extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *cfg, const uint8_t *src, uint8_t *dst, int vec_ok, char *desc, int desc_len)
 {
@@ -827,13 +857,13 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     Deep16Image cur = {nullptr, 0, 0, 0};
     bool cur_is_source = false;
     if (g.src64) {
-      cur.p = src + in->offset[0], cur.stride = in->stride[0], cur.width = in_w, cur.height = in_h;
+      cur.p = src + in->offset[0] + plane_origin (p.fin, 0, p.rect.in_x, p.rect.in_y, in->stride[0]), cur.stride = in->stride[0], cur.width = in_w, cur.height = in_h;
       cur_is_source = true;
     } else if (g.src16) {
       Planes pl;
       memset (&pl, 0, sizeof (pl));
       for (int i = 0; i < in->n_planes; i++) {
-        pl.p[i] = src + in->offset[i];
+        pl.p[i] = src + in->offset[i] + plane_origin (p.fin, i, p.rect.in_x, p.rect.in_y, in->stride[i]);
         pl.stride[i] = in->stride[i];
       }
       a.resize ((size_t) in_w * in_h * 8);
@@ -913,20 +943,23 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         stage ((mid_done ? 0 : GAMMA_STAGE_MID) | GAMMA_STAGE_ENC, cur.p, cur.stride, mid_b.data (), out_w * 4, out_w, out_h);
       }
     }
+    if ((g.store64 || g.pack16) && p.rect.fill)
+      emu_fill_borders (p, out, dst);
     if (g.store64) {
+      uint8_t *rect = dst + out->offset[0] + plane_origin (p.fout, 0, p.rect.out_x, p.rect.out_y, out->stride[0]);
       for (int y = 0; y < out_h; y++)
-        memcpy (dst + out->offset[0] + (size_t) y * out->stride[0], cur.p + (size_t) y * cur.stride, (size_t) out_w * 8);
-      if (g.dither16.on)                /* k_dither16_image over the finished frame */
+        memcpy (rect + (size_t) y * out->stride[0], cur.p + (size_t) y * cur.stride, (size_t) out_w * 8);
+      if (g.dither16.on)                /* k_dither16_image over the finished picture */
         for (int y = 0; y < out_h; y++)
           for (int x = 0; x < out_w; x++)
-            dither16_image_px (g.dither16, dst + out->offset[0], out->stride[0], out_w, out_h, x, y);
+            dither16_image_px (g.dither16, rect, out->stride[0], out_w, out_h, x, y);
       return GSTAMD_OK;
     }
     if (g.pack16) {
       DstPlanes16 d;
       memset (&d, 0, sizeof (d));
       for (int i = 0; i < out->n_planes && i < 3; i++) {
-        d.p[i] = dst + out->offset[i];
+        d.p[i] = dst + out->offset[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]);
         d.stride[i] = out->stride[i];
       }
       const int rows = (g.pack.height + (1 << g.pack.h_sub) - 1) >> g.pack.h_sub;
@@ -945,36 +978,8 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   }
   /* destination rectangle + borders (k_fill_border's rule, plane by plane) */
   GstAmdVideoInfo orect = *out;
-  if (p.rect.fill) {
-    const FormatDesc *f = p.fout;
-    auto up = [](int v, int sub) { return -((-v) >> sub); };
-    for (int i = 0; i < out->n_planes; i++) {
-      const bool chroma = kind_has_planes (f->kind) && i > 0;
-      const int es = f->kind == UNPACK_PACKED4 ? 4 : f->kind == UNPACK_PACKED3 ? 3 : (chroma && f->kind == UNPACK_SEMI ? 2 : 1);
-      const int ws = chroma ? f->w_sub : 0, hs = chroma ? f->h_sub : 0;
-      const int mw = up (p.rect.out_maxw, ws), mh = up (p.rect.out_maxh, hs), x0 = p.rect.out_x >> ws, y0 = p.rect.out_y >> hs;
-      const int w = up (p.out_info.width, ws), h = up (p.out_info.height, hs);
-      uint8_t v[4] = {0, 0, 0, 0};
-      if (f->kind == UNPACK_PACKED4) {
-        for (int c = 0; c < 4; c++)
-          v[f->pos[c]] = p.rect.border[c];
-      } else if (f->kind == UNPACK_PACKED3) {
-        for (int c = 1; c < 4; c++)
-          v[f->pos[c]] = p.rect.border[c];
-      } else if (!chroma) {
-        v[0] = p.rect.border[1];
-      } else if (f->kind == UNPACK_SEMI) {
-        v[0] = f->u_plane ? p.rect.border[2] : p.rect.border[3];
-        v[1] = f->u_plane ? p.rect.border[3] : p.rect.border[2];
-      } else {
-        v[0] = i == f->u_plane ? p.rect.border[2] : p.rect.border[3];
-      }
-      for (int y = 0; y < mh; y++)
-        for (int x = 0; x < mw; x++)
-          if (!(x >= x0 && x < x0 + w && y >= y0 && y < y0 + h))
-            memcpy (dst + out->offset[i] + (size_t) y * out->stride[i] + (size_t) x * es, v, es);
-    }
-  }
+  if (p.rect.fill)
+    emu_fill_borders (p, out, dst);
   for (int i = 0; i < out->n_planes; i++)
     orect.offset[i] = out->offset[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]);
   out = &orect;

@@ -12,14 +12,16 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import fuzz_video  # noqa: E402
 
 
-@pytest.mark.parametrize("seed", [101, 202, 303])
+# seeds from 700 on also draw source crops, destination rectangles and border colours (fuzz_video.random_case's second generator)
+@pytest.mark.parametrize("seed", [101, 202, 303, 707, 808])
 def test_random_conversions_match_reference_or_are_refused(emu_lib, ref, seed):
     emu = fuzz_video.load_emu()
     rnd = random.Random(seed)
+    rects = random.Random(seed + 77) if seed >= 700 else None
     count = {"ok": 0, "refused": 0, "defined": 0, "bad": 0}
     bad = []
     for it in range(120):
-        case = fuzz_video.random_case(rnd)
+        case = fuzz_video.random_case(rnd, rects)
         verdict, text = fuzz_video.run_case(emu, ref, case, seed * 1000 + it)
         count[verdict] += 1
         if verdict == "bad":
@@ -28,7 +30,7 @@ def test_random_conversions_match_reference_or_are_refused(emu_lib, ref, seed):
     assert count["ok"] >= 80, count
 
 
-GPU_SEEDS = [int(x) for x in os.environ.get("GSTAMD_FUZZ_SEEDS", "101,404,505").split(",")]
+GPU_SEEDS = [int(x) for x in os.environ.get("GSTAMD_FUZZ_SEEDS", "101,404,505,707,909").split(",")]
 
 
 @pytest.mark.gpu
@@ -41,9 +43,10 @@ def test_hip_random_conversions_match_reference_or_are_refused(native_lib, gpu, 
     import cases
     from gstreamer_amd import video as V
     rnd = random.Random(seed)
+    rects = random.Random(seed + 77) if seed >= 700 else None
     ok, bad = 0, []
     for it in range(150):
-        case = fuzz_video.random_case(rnd)
+        case = fuzz_video.random_case(rnd, rects)
         ifmt, w, h, ofmt, ow, oh, cfg, col, site = case
         ii = V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site)
         oi = V.video_info(ofmt, ow, oh)
@@ -62,11 +65,10 @@ def test_hip_random_conversions_match_reference_or_are_refused(native_lib, gpu, 
         conv.free()
         if diverges:
             continue
-        want = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site, config=cases.ref_config_string(ref, cfg)).frame(src)
-        vb = lambda b: cases.visible_bytes(ofmt, ow, oh, list(oi.stride), list(oi.offset), b)
-        if (got == want).all() or (vb(got) == vb(want)).all():
+        same, text = fuzz_video.matches_reference(ref, case, src, got, oi)
+        if same:
             ok += 1
         else:
-            bad.append((case, int((got != want).sum())))
+            bad.append((case, text))
     assert not bad, bad[:5]
     assert ok >= 100

@@ -273,6 +273,7 @@ static int build_sub_converters (VideoPlan &plan, GstAmdVideoConverter **sub_in,
   const GammaPlan &g = plan.gamma;
   int st = GSTAMD_OK;
   bool ok = true;
+  plan_set_border_override (plan.rect.border);          /* the sub-conversion that fills the borders fills them with THIS plan's border pixel */
   if (!g.src16 && !g.src64) {
     if (g.lut_direct)
       plan_set_matrix_override (&g.to_rgb);
@@ -288,6 +289,7 @@ static int build_sub_converters (VideoPlan &plan, GstAmdVideoConverter **sub_in,
   }
   if (ok && !g.pack16 && !g.store64 && !g.fused)
     ok = (*sub_out = gstamd_video_converter_new (&g.mid_out, &g.sub_out_info, &g.cfg_out, &st)) != nullptr;
+  plan_set_border_override (nullptr);
   if (!ok) {
     const std::string why = g_last_error;
     gstamd_video_converter_free (*sub_in);

@@ -11,6 +11,10 @@ namespace gstamd {
 // capi_video.cpp sets this around the planning of a fused gamma plan's direct conversion (config.internal_flags & 2)
 static thread_local const MatrixParams *g_matrix_override = nullptr;
 void plan_set_matrix_override (const MatrixParams *m) { g_matrix_override = m; }
+// the border pixel of a composite plan's sub-conversion is the composite's (computed from the caller's matrix-mode and source colorimetry, which
+// the sub-conversion's own config no longer has): set around the planning of the sub-converters (config.internal_flags & 1)
+static thread_local const uint8_t *g_border_override = nullptr;
+void plan_set_border_override (const uint8_t *border) { g_border_override = border; }
 
 // ------------------------------------------------------------------------------------------------
 // format table (facts: video-format.c:8190-8235; byte orders: video-orc.orc:334-411)
@@ -31,6 +35,11 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_UYVY, "UYVY", true, false, 1, UNPACK_PACKED422, 1, 0, 0, 0, {0, 1, 0, 2}},
   {GSTAMD_VIDEO_FORMAT_YVYU, "YVYU", true, false, 1, UNPACK_PACKED422, 1, 0, 0, 0, {0, 0, 3, 1}},
   {GSTAMD_VIDEO_FORMAT_VYUY, "VYUY", true, false, 1, UNPACK_PACKED422, 1, 0, 0, 0, {0, 1, 2, 0}},
+  // packed 10 / 12-bit formats of the 16-bit chain (video-format.c:760-861 Y210, :863-921 Y410, :6995-7092 Y212_LE): pos[1..3] = WORD of Y0, U, V.
+  // Y410 stores two bits of alpha but is declared without GST_VIDEO_FORMAT_FLAG_ALPHA (MAKE_YUV_FORMAT :8380): the alpha options pass it by
+  {GSTAMD_VIDEO_FORMAT_Y210, "Y210", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 2},
+  {GSTAMD_VIDEO_FORMAT_Y212_LE, "Y212_LE", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 5},
+  {GSTAMD_VIDEO_FORMAT_Y410, "Y410", true, false, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 0, 0, 0}, 7},
   // luma only (video-format.c:1207-1229)
   {GSTAMD_VIDEO_FORMAT_GRAY8, "GRAY8", true, false, 1, UNPACK_GRAY, 0, 0, 0, 0, {0, 0, 0, 0}},
   // 3 bytes per pixel (video-format.c:1519-1593)
@@ -175,6 +184,11 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
     case GSTAMD_VIDEO_FORMAT_YVYU:
     case GSTAMD_VIDEO_FORMAT_VYUY:
       info->stride[0] = round_up (width * 2, 4);
+      info->size = (uint64_t) info->stride[0] * h;
+      break;
+    case GSTAMD_VIDEO_FORMAT_Y210:
+    case GSTAMD_VIDEO_FORMAT_Y212_LE:           /* video-info.c:932-941 */
+      info->stride[0] = round_up (width * 4, 8);
       info->size = (uint64_t) info->stride[0] * h;
       break;
     case GSTAMD_VIDEO_FORMAT_GRAY8:             /* video-info.c:942-946 */
@@ -1474,6 +1488,10 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
     return (uint64_t) w * h * 3;
   if (f->kind == UNPACK_GRAY)
     return (uint64_t) w * h;
+  if (f->kind == UNPACK_Y410)
+    return (uint64_t) w * h * 4;
+  if (f->kind == UNPACK_P422_16)
+    return (uint64_t) ((w + 1) / 2) * 8 * h;
   const uint64_t cw = ((uint64_t) w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) h + (1 << f->h_sub) - 1) >> f->h_sub;
   const uint64_t n = (uint64_t) w * h + 2 * cw * ch;
   return f->hi_depth ? 2 * n : n;
@@ -1502,6 +1520,15 @@ static void setup_dither16 (const GstAmdVideoConverterConfig &cfg, const FormatD
   /* the planar formats have no alpha component (depth 0: quantiser 0); ARGB64 / AYUV64 carry 16 bits of it like the other three - their own
      quantiser is 1, so a stage only exists for dither-quantization > 1, run as a pass over the finished frame (k_dither16_image) */
   d->shift[0] = fo->hi_depth == 3 ? shift : 0;
+  if (fo->kind == UNPACK_Y410) {          /* 2 bits of alpha: quantiser 1 << 14 (chain_dither :2060-2075 per component depth) */
+    unsigned qa = 1u << 14;
+    if (cfg.dither_quantization > qa)
+      qa = cfg.dither_quantization;
+    int sa = 0;
+    for (unsigned v = qa; v > 1; v >>= 1)
+      sa++;
+    d->shift[0] = sa;
+  }
   d->shift[1] = d->shift[2] = d->shift[3] = shift;
 }
 
@@ -1518,7 +1545,7 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
   const bool in16 = fi->hi_depth != 0, out16 = fo->hi_depth != 0;
-  if (out16 && !kind_has_planes (fo->kind) && fo->hi_depth != 3)
+  if (out16 && !kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && fo->kind != UNPACK_Y410)
     return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destination layout not implemented on the GPU path");
   if (out16 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
     return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path");
@@ -1903,7 +1930,7 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   g.src64 = true;
   g.src16 = false;
   g.store64 = fo->hi_depth == 3;
-  g.pack16 = hi_depth_words (fo->hi_depth);
+  g.pack16 = fo->hi_depth != 0 && !g.store64;
   g.fused = g.planes_fast = false;
   plan->plane_mode = plan->relayout = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_422_ayuv = plan->fast_post = false;
   plan->deep16 = plan->deep_out = false;
@@ -1979,7 +2006,8 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     sub.matrix_mode = GSTAMD_MATRIX_MODE_NONE;
     sub.internal_flags = 1;
     sub.src_x = sub.src_y = sub.src_width = sub.src_height = 0;
-    const bool differs = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site || in_w != full_out_w || in_h != full_out_h;
+    const bool differs = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site ||
+        (plan->rect.in_maxw ? plan->rect.in_maxw : in_w) != full_out_w || (plan->rect.in_maxh ? plan->rect.in_maxh : in_h) != full_out_h;
     const bool down = differs && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY;
     sub.chroma_mode = down ? GSTAMD_CHROMA_MODE_FULL : GSTAMD_CHROMA_MODE_NONE;
     g.cfg_out = sub;
@@ -2010,7 +2038,7 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   const GstAmdVideoConverterConfig &cfg = plan->config;
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
-  if (!kind_has_planes (fo->kind) && fo->hi_depth != 3) {
+  if (!kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && fo->kind != UNPACK_Y410) {
     if (error)
       *error = "10-bit destination layout not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
@@ -2059,7 +2087,8 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
     g.mid_in.chroma_site = in->chroma_site;
     g.sub_in_info = plan->orig_in;
     const int full_in_w = plan->rect.in_maxw ? plan->rect.in_maxw : in_w, full_in_h = plan->rect.in_maxh ? plan->rect.in_maxh : in_h;
-    const bool differs = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site || full_in_w != out_w || full_in_h != out_h;
+    const bool differs = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site ||
+        full_in_w != (plan->rect.out_maxw ? plan->rect.out_maxw : out_w) || full_in_h != (plan->rect.out_maxh ? plan->rect.out_maxh : out_h);          /* FRAME sizes (video_converter_compute_resample :2866-2870) */
     const bool up = differs && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY;
     g.cfg_in = cfg;
     g.cfg_in.gamma_mode = GSTAMD_GAMMA_MODE_NONE;
@@ -2514,8 +2543,10 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
      line with the line PAST the picture, which the chain makes like any other - do_unpack_lines clamps it to the last line (:2966), the
      upsampler pairs it with the (clamped) line after it - so its chroma is the last chroma row unblended.  The AYUV image gets that line
      as one more row (k_convert's grid is one row taller), the pack kernel reads it (PackPlanarParams::virtual_line). */
-  plan->pack.virtual_line = plan->out_planar && plan->passes.empty () && fr.chroma_v2 && plan->pack.down_v && plan->pack.h_sub == 1 && (out_h & 1) &&
-      in_h == out_h && !plan->deep16 && !plan->deep_out ? 1 : 0;
+  /* With a source crop that ends above the frame's last line the line past the picture is a real one (do_unpack_lines clamps to the FRAME),
+     whatever the source format: the same extra row then. */
+  plan->pack.virtual_line = plan->out_planar && plan->passes.empty () && (fr.chroma_v2 || fr.luma_last >= in_h) && plan->pack.down_v && plan->pack.h_sub == 1 &&
+      (out_h & 1) && in_h == out_h && !plan->deep16 && !plan->deep_out ? 1 : 0;
   simulate_vpairs (plan, out_h, plan->pack.virtual_line != 0);
 
   plan->algorithmic_bytes = 0;
@@ -2570,7 +2601,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * matrix (which the reference only picks when no pixel can clip, so every row sum stays inside 16 bits) with byte coefficients */
   plan->fast_enc420 = false;
   if (plan->passes.empty () && plan->out_planar && kind_has_planes (plan->fout->kind) && plan->fout->w_sub == 1 && plan->fout->h_sub == 1 &&
-      fr.kind == UNPACK_PACKED4 && !plan->fin->yuv && plan->matrix.kind == MATRIX_TABLE && (in_w % 4) == 0) {
+      fr.kind == UNPACK_PACKED4 && !plan->fin->yuv && plan->matrix.kind == MATRIX_TABLE && (in_w % 4) == 0 && !plan->pack.virtual_line) {
     bool fits = true;
     for (int k = 0; k < 3; k++)
       for (int j = 0; j < 3; j++)
@@ -2713,6 +2744,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       rc.border[2] = (uint8_t) clamp8 (128 + ((r * im[1][0] + g * im[1][1] + b * im[1][2]) >> 8));
       rc.border[3] = (uint8_t) clamp8 (128 + ((r * im[2][0] + g * im[2][1] + b * im[2][2]) >> 8));
     }
+    if (g_border_override && (cfg.internal_flags & 1))
+      memcpy (rc.border, g_border_override, 4);
   } else {
     plan->ref_same_size = in->width == out->width && in->height == out->height;
   }
@@ -2723,7 +2756,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   plan->rect = rc;
   plan->orig_in = *in;
   plan->orig_out = *out;
-  if (rc.fill && fo && fo->kind == UNPACK_PACKED422) {
+  if (rc.fill && fo && (fo->kind == UNPACK_PACKED422 || fo->kind == UNPACK_P422_16)) {
     if (error)
       *error = "borders on a packed 4:2:2 destination (the macropixel border of convert_fill_border) are not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
@@ -2776,6 +2809,17 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       many_repeats = many_repeats || (!sp.horizontal && sp.kind == SCALE_NEAREST && sp.out_size > 2 * sp.in_size);
     /* and when the bit depth changes the matrix runs on the SOURCE line before it is narrowed into a fresh one (:3127-3136): the
        repeated row's source line has already been through it */
+    /* any nearest vertical pass into an odd-height 4:2:0 destination: the line past the picture (the vertical chroma downsampler's last pair) is the
+       scaler's last line handed out AGAIN - the in-place stages have been through it once already */
+    bool v_near = false;
+    for (const ScalePass &sp : pl.passes)
+      v_near = v_near || (!sp.horizontal && sp.kind == SCALE_NEAREST);
+    if (v_near && !v_near_up && fo->h_sub == 1 && (oh & 1) && (in_place_op || late_in_place) && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE &&
+        cfg.chroma_mode != GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY) {
+      plan->divergence += "nearest vertical scaling into an odd-height 4:2:0 destination: the line past the picture is the scaler's last line handed out a second "
+          "time, after the in-place stages (colour, dither, chroma downsampling) have already changed it (line aliasing); this library pairs the last line "
+          "with itself. ";
+    }
     if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place)) {
       plan->divergence += "nearest vertical enlargement ahead of a stage that works in place (colour / alpha, chroma downsampling, dither): the reference "
           "processes a repeated line once more per repetition (line aliasing); this library applies every stage once per output row. ";
@@ -2801,6 +2845,21 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       if (error)
         *error = "alpha-mode set / mult with the horizontal pass on the other side of the alpha stage (the reference touches MIN (in_width, out_width) "
             "pixels of a wider line) is not implemented";
+      return GSTAMD_ERR_UNSUPPORTED;
+    }
+  }
+  /* an odd-height 4:2:0 destination, no vertical scaler, and a source crop that ends above the frame's last line: the line past the picture the
+   * vertical chroma downsampler averages the last line with is a REAL source line then (do_unpack_lines clamps to the frame, :2966).  The
+   * unscaled direct plans make it (PackPlanarParams::virtual_line); behind a horizontal scaler or inside the composite plans it is not built */
+  {
+    const bool line_below = plan->rect.in_maxh && plan->rect.in_y + ih < plan->rect.in_maxh;
+    const bool down_v = (pl.out_planar && pl.pack.down_v) || (pl.gamma.on && pl.gamma.pack16 && pl.gamma.pack.down_v) ||
+        (pl.gamma.on && !pl.gamma.pack16 && !pl.gamma.store64 && !pl.gamma.fused && !pl.gamma.planes_fast &&
+            cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY);
+    if (chain && line_below && fo->h_sub == 1 && (oh & 1) && ih == oh && down_v && !pl.pack.virtual_line) {
+      if (error)
+        *error = "an odd-height 4:2:0 destination from a source crop with frame lines below it (the chroma downsampler's line past the picture is a real "
+            "line there) is only implemented for unscaled 8-bit conversions";
       return GSTAMD_ERR_UNSUPPORTED;
     }
   }

@@ -22,6 +22,8 @@ enum UnpackKind : int {
   UNPACK_PACKED3 = 3,   // one plane, 3 bytes / pixel (RGB, BGR)
   UNPACK_PACKED422 = 4, // one plane, 4-byte macropixels of two pixels (YUY2, UYVY, YVYU, VYUY)
   UNPACK_GRAY = 5,      // one plane of luma (GRAY8): a YUV format as far as the chain goes (unpack format AYUV), U = V = 0x80
+  UNPACK_P422_16 = 6,   // one plane, macropixels of four 16-bit little-endian words Y0 U Y1 V (Y210, Y212_LE): a source / destination of the 16-bit chain
+  UNPACK_Y410 = 7,      // one plane, a little-endian 32-bit word per pixel: U, Y, V at 10 bits, A at 2 (Y410); hi_depth code 7
 };
 
 struct FormatDesc {
@@ -39,6 +41,7 @@ struct FormatDesc {
                         // 1 / 2: 10-bit samples in little-endian 16-bit words, in the low bits (I420_10LE) / the
                         // high bits (P010_10LE); such formats unpack to AYUV64 in the reference (video-format.c:3836, 5331)
                         // 4 / 5: the same with 12 bits (I420_12LE ... / P012_LE), 6: all 16 bits (P016_LE, Y444_16LE)
+                        // 7: Y410's 10 + 10 + 10 + 2 bits in a 32-bit word
 };
 #if defined(__HIPCC__)
 #define GSTAMD_VP __host__ __device__ inline
@@ -46,8 +49,8 @@ struct FormatDesc {
 #define GSTAMD_VP inline
 #endif
 // significant bits of a sample for a FormatDesc::hi_depth code, and whether the format keeps its samples in 16-bit words in planes
-GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 ? 10 : (hi == 4 || hi == 5 ? 12 : (hi == 3 || hi == 6 ? 16 : 8)); }
-GSTAMD_VP bool hi_depth_words (int hi) { return hi == 1 || hi == 2 || hi >= 4; }
+GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 || hi == 7 ? 10 : (hi == 4 || hi == 5 ? 12 : (hi == 3 || hi == 6 ? 16 : 8)); }
+GSTAMD_VP bool hi_depth_words (int hi) { return hi == 1 || hi == 2 || (hi >= 4 && hi <= 6); }
 const FormatDesc *format_desc (int format);
 
 // ---- device-consumable plan pieces (POD, passed to kernels by value) --------------------------
@@ -295,6 +298,8 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
     return (size_t) y * stride + (size_t) x * 3;
   if (f->kind == UNPACK_PACKED422)
     return (size_t) y * stride + (size_t) x * 2;
+  if (f->kind == UNPACK_P422_16 || f->kind == UNPACK_Y410)          /* 8 bytes per pair of pixels / 4 bytes per pixel */
+    return (size_t) y * stride + (size_t) x * 4;
   const size_t bps = f->hi_depth ? 2 : 1;          /* planes of 10 / 12 / 16-bit formats hold 16-bit samples */
   if (plane == 0)
     return (size_t) y * stride + (size_t) x * bps;
@@ -315,7 +320,10 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
     const int drop = 16 - hi_depth_bits (f->hi_depth);
     return f->hi_depth == 1 || f->hi_depth == 4 ? v >> drop : v & ~((1u << drop) - 1u);
   };
-  if (f->kind == UNPACK_PACKED4 && f->hi_depth == 3) {
+  if (f->kind == UNPACK_Y410) {            /* pack_Y410 (video-format.c:898-921) of the widened border */
+    const uint32_t a = (uint32_t) border[0] * 257u, y = (uint32_t) border[1] * 257u, u = (uint32_t) border[2] * 257u, v = (uint32_t) border[3] * 257u;
+    *es = 4, *lo = ((u & 0xffc0u) >> 6) | ((y & 0xffc0u) << 4) | ((v & 0xffc0u) << 14) | ((a & 0xc000u) << 16);
+  } else if (f->kind == UNPACK_PACKED4 && f->hi_depth == 3) {
     uint32_t w[4] = {0, 0, 0, 0};
     for (int c = 0; c < 4; c++)
       w[f->pos[c]] = s16 (c);
@@ -359,6 +367,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
 // (GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513).  Such a plan can be sampled per destination pixel inside the blend
 // kernel (compositor_scaled.h).  *h / *v: index into plan.passes of the horizontal / vertical pass, -1: none.
 void plan_set_matrix_override (const MatrixParams *m);
+void plan_set_border_override (const uint8_t *border);
 bool plan_is_pad_scaler (const VideoPlan &plan, int *h, int *v);
 // rows per 64-column canvas tile (12..16) of k_aggregate_scaled for pads scaled by this plan: the first pass under a tile is
 // rows x quads items (vertical first) or rows x 64 (horizontal first) spread over 256 lanes; the height that leaves the fewest idle

@@ -26,10 +26,25 @@ GSTAMD_HD int deep_widen (int hi_depth, int v)
   return v | (v >> bits);               // P010_10LE / P012_LE: value in the high bits
 }
 
+// one 10-bit field of a Y410 word (unpack_Y410 video-format.c:863-896): (field << 6) | (field >> 4)
+GSTAMD_HD int y410_field (uint32_t w, int shift)
+{
+  const int t = (int) ((w >> shift) & 0x3ffu) << 6;
+  return t | (t >> 10);
+}
+
 GSTAMD_HD UV deep_load_uv (const FrontParams &f, const Planes &pl, int crow, int k)
 {
   UV r;
-  if (f.kind == UNPACK_SEMI) {
+  if (f.kind == UNPACK_P422_16) {        // unpack_Y210 / _Y212_LE: U, V of macropixel k, widened like P010's samples
+    const uint16_t *p = (const uint16_t *) (pl.p[0] + (ptrdiff_t) crow * pl.stride[0]) + 4 * k;
+    r.u = deep_widen (f.hi_depth, p[f.pos[2]]);
+    r.v = deep_widen (f.hi_depth, p[f.pos[3]]);
+  } else if (f.kind == UNPACK_Y410) {
+    const uint32_t w = ((const uint32_t *) (pl.p[0] + (ptrdiff_t) crow * pl.stride[0]))[k];
+    r.u = y410_field (w, 0);
+    r.v = y410_field (w, 20);
+  } else if (f.kind == UNPACK_SEMI) {
     const uint16_t *p = (const uint16_t *) (pl.p[1] + (ptrdiff_t) crow * pl.stride[1]) + 2 * k;
     r.u = deep_widen (f.hi_depth, p[f.u_plane ? 0 : 1]);
     r.v = deep_widen (f.hi_depth, p[f.u_plane ? 1 : 0]);
@@ -70,7 +85,20 @@ GSTAMD_HD UV deep_chroma_h_at (const FrontParams &f, const Planes &pl, int crow,
 // pixel (x, y) after unpack + chroma upsampling: the AYUV64 pixel as two words, {A | c1 << 16, c2 | c3 << 16} (memory order A, c1, c2, c3)
 GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x, int y)
 {
-  const int c1 = deep_widen (f.hi_depth, ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
+  int c1, a = 0xffff;
+  if (f.kind == UNPACK_P422_16) {
+    /* unpack_Y210 (video-format.c:783-806): the pair loop widens Y0, U and V - not Y1, which keeps its low bits clear; the last pixel of an
+       odd-width line is a Y0 */
+    const int raw = ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[4 * (x >> 1) + f.pos[1] + 2 * (x & 1)];
+    c1 = (x & 1) ? raw : deep_widen (f.hi_depth, raw);
+  } else if (f.kind == UNPACK_Y410) {
+    const uint32_t w = ((const uint32_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x];
+    c1 = y410_field (w, 10);
+    const int t = (int) (w >> 30) << 14;                /* A: two bits, A |= A >> 10 */
+    a = t | (t >> 10);
+  } else {
+    c1 = deep_widen (f.hi_depth, ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
+  }
   UV c;
   if (f.chroma_v2) {
     const int e0 = vpair[2 * y], rb = vpair[2 * y + 1];
@@ -92,7 +120,7 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
     c = deep_chroma_h_at (f, pl, y >> f.h_sub, x);
   }
   uint2 r;
-  r.x = 0xffffu | ((uint32_t) c1 << 16);
+  r.x = (uint32_t) a | ((uint32_t) c1 << 16);
   r.y = (uint32_t) c.u | ((uint32_t) c.v << 16);
   return r;
 }
@@ -339,6 +367,66 @@ GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const Dith
       ((uint16_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane]))[k] = pv;
     }
   }
+}
+
+// ---- packed 10 / 12-bit destinations (Y210, Y212_LE, Y410): one lane per stored unit - a macropixel of two pixels / a pixel.  The stages are
+// the planar packer's: chroma downsampled on the line (h only, these formats have no vertical subsampling), every component of every pixel
+// dithered at its own position, then pack_Y210 (video-format.c:835-861: & 0xffc0, Y1 of an odd-width line's last macropixel = its Y0) /
+// pack_Y410 (:898-921)
+GSTAMD_HD void pack16_chroma_h (const PackPlanarParams &pk, const uint2 *row, int w, int x, int *u, int *v)
+{
+  auto cu = [&](int i) { return (int) (row[i < 0 ? 0 : (i > w - 1 ? w - 1 : i)].y & 0xffffu); };
+  auto cv = [&](int i) { return (int) (row[i < 0 ? 0 : (i > w - 1 ? w - 1 : i)].y >> 16); };
+  *u = cu (x), *v = cv (x);
+  if (pk.w_sub != 1)
+    return;
+  if (pk.down_h == 1) {
+    if (x + 1 < w) {
+      *u = (cu (x) + cu (x + 1) + 1) >> 1;
+      *v = (cv (x) + cv (x + 1) + 1) >> 1;
+    }
+  } else if (pk.down_h == 2 && w >= 2) {
+    if (x == 0) {
+      *u = (3 * cu (x) + cu (x + 1) + 2) >> 2;
+      *v = (3 * cv (x) + cv (x + 1) + 2) >> 2;
+    } else if (x < w - 2) {
+      *u = (cu (x - 1) + 2 * cu (x) + cu (x + 1) + 2) >> 2;
+      *v = (cv (x - 1) + 2 * cv (x) + cv (x + 1) + 2) >> 2;
+    } else {
+      *u = (cu (x - 1) + 3 * cu (x) + 2) >> 2;
+      *v = (cv (x - 1) + 3 * cv (x) + 2) >> 2;
+    }
+  }
+}
+
+GSTAMD_VP int pack16_units (const PackPlanarParams &pk) { return pk.kind == UNPACK_P422_16 ? (pk.width + 1) / 2 : pk.width; }
+
+GSTAMD_HD void pack16_packed_body (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride,
+    uint8_t *__restrict__ dst, int dstride, int unit, int y)
+{
+  const int w = pk.width;
+  if (y >= pk.height || unit >= pack16_units (pk))
+    return;
+  const uint2 *row = (const uint2 *) (src + (size_t) y * sstride);
+  if (pk.kind == UNPACK_Y410) {
+    const uint2 px = row[unit];
+    const uint32_t a = (uint32_t) dither16_comp (dt, 0, (int) (px.x & 0xffffu), unit, y) & 0xc000u;
+    const uint32_t yy = (uint32_t) dither16_comp (dt, 1, (int) (px.x >> 16), unit, y) & 0xffc0u;
+    const uint32_t u = (uint32_t) dither16_comp (dt, 2, (int) (px.y & 0xffffu), unit, y) & 0xffc0u;
+    const uint32_t v = (uint32_t) dither16_comp (dt, 3, (int) (px.y >> 16), unit, y) & 0xffc0u;
+    ((uint32_t *) (dst + (size_t) y * dstride))[unit] = (u >> 6) | (yy << 4) | (v << 14) | (a << 16);
+    return;
+  }
+  const int x = 2 * unit;
+  int u, v;
+  pack16_chroma_h (pk, row, w, x, &u, &v);
+  const uint16_t y0 = pack16_sample (hi_depth, dither16_comp (dt, 1, (int) (row[x].x >> 16), x, y));
+  const uint16_t y1 = x + 1 < w ? pack16_sample (hi_depth, dither16_comp (dt, 1, (int) (row[x + 1].x >> 16), x + 1, y)) : y0;
+  uint16_t *d = (uint16_t *) (dst + (size_t) y * dstride) + 4 * unit;
+  d[pk.pos[1]] = y0;
+  d[pk.pos[1] + 2] = y1;
+  d[pk.pos[2]] = pack16_sample (hi_depth, dither16_comp (dt, 2, u, x, y));
+  d[pk.pos[3]] = pack16_sample (hi_depth, dither16_comp (dt, 3, v, x, y));
 }
 
 // ---- plane to plane (GammaPlan::planes_fast): every destination sample is one source sample widened to 16 bits (unpack), dithered when the

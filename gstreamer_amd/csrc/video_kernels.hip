@@ -199,9 +199,19 @@ __global__ __launch_bounds__ (256) void k_pack16 (PackPlanarParams pk, int hi_de
   pack16_body (pk, hi_depth, dt, src, sstride, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
 }
 
+__global__ __launch_bounds__ (256) void k_pack16_packed (PackPlanarParams pk, int hi_depth, DitherParams dt, const uint8_t *__restrict__ src, int sstride,
+    uint8_t *__restrict__ dst, int dstride)
+{
+  pack16_packed_body (pk, hi_depth, dt, src, sstride, dst, dstride, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
 hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *src, int sstride, uint8_t *const planes[3],
     const int strides[3], hipStream_t stream)
 {
+  if (pk.kind == UNPACK_P422_16 || pk.kind == UNPACK_Y410) {          /* Y210, Y212_LE, Y410: a lane per macropixel / pixel */
+    hipLaunchKernelGGL (k_pack16_packed, dim3 ((pack16_units (pk) + 255) / 256, pk.height), dim3 (256), 0, stream, pk, hi_depth, dt, src, sstride, planes[0], strides[0]);
+    return hipGetLastError ();
+  }
   DstPlanes16 d;
   for (int i = 0; i < 3; i++) {
     d.p[i] = planes[i];

@@ -135,10 +135,14 @@ class VideoConverter:
     def frame(self, src):
         src = np.ascontiguousarray(src, dtype=np.uint8)
         assert src.size == self.in_info["size"], (src.size, self.in_info["size"])
-        dst = np.zeros(self.out_info["size"], dtype=np.uint8)
-        r = lib().ref_video_converter_frame(self.h, src.ctypes.data, src.size, dst.ctypes.data, dst.size)
+        # slack behind the frame: some of the reference's fastpaths store whole pixel pairs (convert_UYVY_AYUV on an odd width writes one
+        # pixel past every line, the last one past the frame) - without it that store lands in the allocator's bookkeeping
+        size = self.out_info["size"]
+        buf = np.zeros(size + 256, dtype=np.uint8)
+        dst = buf[:size]
+        r = lib().ref_video_converter_frame(self.h, src.ctypes.data, src.size, dst.ctypes.data, size)
         assert r == 0
-        return dst
+        return dst.copy()
 
     def bench(self, src, n_frames):
         src = np.ascontiguousarray(src, dtype=np.uint8)

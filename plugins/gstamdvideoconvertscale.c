@@ -37,9 +37,9 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
  * kernel for make set_caps fail (not-negotiated) */
 #define AMD_OUT_FORMATS AMD_IN_FORMATS
 #if GST_CHECK_VERSION (1, 18, 0)
-#define AMD_NEWER_FORMATS ", VUYA, P012_LE, P016_LE, Y444_16LE"
+#define AMD_NEWER_FORMATS ", VUYA, Y210, Y410, P012_LE, P016_LE, Y444_16LE, Y212_LE"
 #elif GST_CHECK_VERSION (1, 16, 0)
-#define AMD_NEWER_FORMATS ", VUYA"
+#define AMD_NEWER_FORMATS ", VUYA, Y210, Y410"
 #else
 #define AMD_NEWER_FORMATS ""
 #endif
@@ -771,14 +771,14 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_I422_10LE, GSTAMD_VIDEO_FORMAT_I422_10LE}, {GST_VIDEO_FORMAT_Y444_10LE, GSTAMD_VIDEO_FORMAT_Y444_10LE},
     {GST_VIDEO_FORMAT_I420_12LE, GSTAMD_VIDEO_FORMAT_I420_12LE}, {GST_VIDEO_FORMAT_I422_12LE, GSTAMD_VIDEO_FORMAT_I422_12LE},
     {GST_VIDEO_FORMAT_Y444_12LE, GSTAMD_VIDEO_FORMAT_Y444_12LE},
-    /* VUYA (1.16), P012_LE, P016_LE, Y444_16LE (1.18) joined the format enum after 1.14: there when the headers this is compiled
+    /* VUYA, Y210, Y410 (1.16), P012_LE, P016_LE, Y444_16LE, Y212_LE (1.18) joined the format enum after 1.14: there when the headers this is compiled
      * against have them (plugins/build.py also type-checks every element against the reference's own 1.29 headers) */
 #if GST_CHECK_VERSION (1, 16, 0)
-    {GST_VIDEO_FORMAT_VUYA, GSTAMD_VIDEO_FORMAT_VUYA},
+    {GST_VIDEO_FORMAT_VUYA, GSTAMD_VIDEO_FORMAT_VUYA}, {GST_VIDEO_FORMAT_Y210, GSTAMD_VIDEO_FORMAT_Y210}, {GST_VIDEO_FORMAT_Y410, GSTAMD_VIDEO_FORMAT_Y410},
 #endif
 #if GST_CHECK_VERSION (1, 18, 0)
     {GST_VIDEO_FORMAT_P012_LE, GSTAMD_VIDEO_FORMAT_P012_LE}, {GST_VIDEO_FORMAT_P016_LE, GSTAMD_VIDEO_FORMAT_P016_LE},
-    {GST_VIDEO_FORMAT_Y444_16LE, GSTAMD_VIDEO_FORMAT_Y444_16LE},
+    {GST_VIDEO_FORMAT_Y444_16LE, GSTAMD_VIDEO_FORMAT_Y444_16LE}, {GST_VIDEO_FORMAT_Y212_LE, GSTAMD_VIDEO_FORMAT_Y212_LE},
 #endif
   };
   int fmt = 0;

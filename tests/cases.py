@@ -364,6 +364,26 @@ VIDEO_CASES = [
     ("argb64_nv12_crop_border", "ARGB64", 50, 30, "NV12", 50, 30, dict(src_x=10, src_y=4, src_width=30, src_height=20, dest_x=8, dest_y=6, dest_width=30, dest_height=20), None, None, "random"),
     ("p016_y444_16le_dest_border", "P016_LE", 40, 24, "Y444_16LE", 60, 30, dict(dest_x=12, dest_y=3, dest_width=40, dest_height=24, border_argb=0xff101010), None, None, "random"),
     ("i422_10le_y42b_crop_gamma_free", "I422_10LE", 48, 20, "Y42B", 24, 10, dict(src_x=8, src_y=5, src_width=36, src_height=11), "bt709", None, "random"),
+    # ---- Y210 / Y212_LE / Y410 on either side of the 16-bit chain (unpack_Y210 video-format.c:760-833: Y1 of a pair is not widened; pack_Y210
+    # :835-861; unpack_Y410 / pack_Y410 :863-921: two bits of alpha that the format flags do not declare)
+    ("y210_bgra_66x9", "Y210", 66, 9, "BGRA", 66, 9, {}, None, None, "random"),
+    ("y210_nv12_odd_67x8", "Y210", 67, 8, "NV12", 67, 8, {}, None, "mpeg2", "random"),
+    ("y210_y210_scaled_lanczos", "Y210", 64, 36, "Y210", 40, 30, LAN, None, None, "random"),
+    ("yuy2_y210_64x6", "YUY2", 64, 6, "Y210", 64, 6, {}, None, None, "random"),
+    ("bgra_y210_cosited_33x5", "BGRA", 33, 5, "Y210", 33, 5, {}, None, "cosited", "random"),
+    ("p010_y210_crop_scaled", "P010_10LE", 64, 36, "Y210", 48, 20, dict(LIN, src_x=8, src_y=4, src_width=48, src_height=28), None, None, "random"),
+    ("y212_i422_12le_40x7", "Y212_LE", 40, 7, "I422_12LE", 40, 7, {}, None, None, "random"),
+    ("i420_y212_dither_q16", "I420", 40, 8, "Y212_LE", 40, 8, dict(dither_quantization=16), None, None, "random"),
+    ("y410_bgra_37x6", "Y410", 37, 6, "BGRA", 37, 6, {}, None, None, "random"),
+    ("y410_ayuv64_33x4", "Y410", 33, 4, "AYUV64", 33, 4, {}, None, None, "random"),
+    ("ayuv_y410_alpha_bits_40x5", "AYUV", 40, 5, "Y410", 40, 5, {}, None, None, "random"),
+    ("ayuv_y410_alpha_set_ignored", "AYUV", 40, 5, "Y410", 40, 5, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+    ("nv12_y410_scaled_bilinear", "NV12", 64, 36, "Y410", 100, 50, LIN, None, None, "random"),
+    ("y410_y444_10le_crop_dest_border", "Y410", 48, 30, "Y444_10LE", 60, 40, dict(src_x=5, src_y=3, src_width=30, src_height=20, dest_x=7, dest_y=9, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+    ("argb64_y410_dest_border", "ARGB64", 30, 20, "Y410", 50, 30, dict(dest_x=7, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+    # the line past an odd-height 4:2:0 picture is a real source line when the crop ends above the frame's last line
+    ("nv61_i420_crop_line_below_odd_h", "NV61", 22, 27, "I420", 8, 13, dict(src_x=6, src_y=12, src_width=8, src_height=13), "bt709", "cosited", "random"),
+    ("bgra_nv12_crop_line_below_odd_h", "BGRA", 22, 27, "NV12", 8, 13, dict(src_x=6, src_y=12, src_width=8, src_height=13), None, None, "random"),
     # pack_NV61's odd-width tail is the frame line's, not the rectangle's (video-format.c:2005-2011)
     ("rgb_nv61_odd_frame_rect_inside", "RGB", 51, 25, "NV61", 51, 25, dict(LIN, dest_x=2, dest_y=6, dest_width=9, dest_height=3, border_argb=0x01e255e2), "bt709", "jpeg", "random"),
     ("rgb_nv61_odd_frame_rect_to_edge", "RGB", 51, 25, "NV61", 51, 25, dict(LIN, dest_x=42, dest_y=6, dest_width=9, dest_height=3, border_argb=0x01e255e2), "bt709", "jpeg", "random"),

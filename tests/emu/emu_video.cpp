@@ -831,7 +831,9 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       g_post_lut = g.comp.data ();
       g_post_lut_keep = p.fout->pos[0];
       g_post_lut_done = false;
+      plan_set_border_override (p.rect.border);
       r = emu_video_convert (&g.sub_in_info, &g.mid_in, &g.cfg_in, src, dst, vec_ok, nullptr, 0);
+      plan_set_border_override (nullptr);
       g_post_lut = nullptr;
       plan_set_matrix_override (nullptr);
       if (r != GSTAMD_OK || g_post_lut_done)
@@ -847,7 +849,9 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     }
     if (g.fused && getenv ("GSTAMD_NO_GAMMA_FUSED") == nullptr) {
       g_gamma_hook = &gd;
+      plan_set_border_override (p.rect.border);
       r = emu_video_convert (&g.sub_in_info, &g.mid_in, &g.cfg_in, src, dst, vec_ok, nullptr, 0);
+      plan_set_border_override (nullptr);
       g_gamma_hook = nullptr;
       return r;
     }
@@ -962,13 +966,22 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         d.p[i] = dst + out->offset[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]);
         d.stride[i] = out->stride[i];
       }
+      if (g.pack.kind == UNPACK_P422_16 || g.pack.kind == UNPACK_Y410) {          /* k_pack16_packed */
+        for (int y = 0; y < g.pack.height; y++)
+          for (int un = 0; un < (pack16_units (g.pack) + 255) / 256 * 256; un++)
+            pack16_packed_body (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, d.p[0], d.stride[0], un, y);
+        return GSTAMD_OK;
+      }
       const int rows = (g.pack.height + (1 << g.pack.h_sub) - 1) >> g.pack.h_sub;
       for (int yb = 0; yb < rows; yb++)
         for (int x0 = 0; x0 < (g.pack.width / 4 + 256) / 256 * 1024; x0 += 4)
           pack16_body (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, d, x0, yb);
       return GSTAMD_OK;
     }
-    return emu_video_convert (&g.mid_out, &g.sub_out_info, &g.cfg_out, mid_b.data (), dst, vec_ok, nullptr, 0);
+    plan_set_border_override (p.rect.border);
+    r = emu_video_convert (&g.mid_out, &g.sub_out_info, &g.cfg_out, mid_b.data (), dst, vec_ok, nullptr, 0);
+    plan_set_border_override (nullptr);
+    return r;
   }
   Planes pl;
   memset (&pl, 0, sizeof (pl));

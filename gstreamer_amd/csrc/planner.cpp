@@ -40,6 +40,7 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_Y210, "Y210", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 2},
   {GSTAMD_VIDEO_FORMAT_Y212_LE, "Y212_LE", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 5},
   {GSTAMD_VIDEO_FORMAT_Y410, "Y410", true, false, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 0, 0, 0}, 7},
+  {GSTAMD_VIDEO_FORMAT_v210, "v210", true, false, 1, UNPACK_V210, 1, 0, 0, 0, {0, 0, 0, 0}, 8},          /* video-format.c:558-757 */
   // luma only (video-format.c:1207-1229)
   {GSTAMD_VIDEO_FORMAT_GRAY8, "GRAY8", true, false, 1, UNPACK_GRAY, 0, 0, 0, 0, {0, 0, 0, 0}},
   // 3 bytes per pixel (video-format.c:1519-1593)
@@ -184,6 +185,10 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
     case GSTAMD_VIDEO_FORMAT_YVYU:
     case GSTAMD_VIDEO_FORMAT_VYUY:
       info->stride[0] = round_up (width * 2, 4);
+      info->size = (uint64_t) info->stride[0] * h;
+      break;
+    case GSTAMD_VIDEO_FORMAT_v210:              /* video-info.c:927-931 */
+      info->stride[0] = ((width + 47) / 48) * 128;
       info->size = (uint64_t) info->stride[0] * h;
       break;
     case GSTAMD_VIDEO_FORMAT_Y210:
@@ -1224,7 +1229,15 @@ const FastRow g_fast_rows[] = {
   {F_Y444, F_YUY2 | F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER | FP_WEVEN, "convert_Y444_YUY2"},
   {F_YUY2 | F_UYVY, F_Y42B | F_Y444, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_YUY2_planar"},
   {F_YUY2, F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
+  {F_UYVY, F_GRAY8, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_GRAY8"},          /* :8501 */
   {F_UYVY, F_YUY2, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
+  /* the v210 rows (:8433-8543; convert_I420_v210, convert_v210_I420_10 ...: their own arithmetic - 8-bit samples shifted by two, no widening):
+     not built, such pairs are refused at their own size (every one of these rows wants keeps_size and the same colour matrix; crop / border /
+     alpha flags are matched generously - refusing a conversion the reference would run through the chain costs nothing but coverage) */
+  {F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), fbit (GSTAMD_VIDEO_FORMAT_v210), false,
+        FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY | FP_ASET | FP_AMULT, "convert_to_v210"},
+  {fbit (GSTAMD_VIDEO_FORMAT_v210), F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), false,
+        FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY | FP_ASET | FP_AMULT, "convert_from_v210"},
   /* convert_scale_planes: every same-format pair, planar <-> planar and the NV12 / NV16 / NV24 family */
   {F_RGB4A | F_AYUV | fbit (GSTAMD_VIDEO_FORMAT_ARGB64) | fbit (GSTAMD_VIDEO_FORMAT_AYUV64), ~0ull, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
   {F_RGB4X | F_RGB3 | F_YUV3 | F_420 | F_Y42B | F_Y444 | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
@@ -1492,6 +1505,8 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
     return (uint64_t) w * h * 4;
   if (f->kind == UNPACK_P422_16)
     return (uint64_t) ((w + 1) / 2) * 8 * h;
+  if (f->kind == UNPACK_V210)
+    return (uint64_t) ((w + 5) / 6) * 16 * h;
   const uint64_t cw = ((uint64_t) w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) h + (1 << f->h_sub) - 1) >> f->h_sub;
   const uint64_t n = (uint64_t) w * h + 2 * cw * ch;
   return f->hi_depth ? 2 * n : n;
@@ -1545,7 +1560,7 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
   const bool in16 = fi->hi_depth != 0, out16 = fo->hi_depth != 0;
-  if (out16 && !kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && fo->kind != UNPACK_Y410)
+  if (out16 && !kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && fo->kind != UNPACK_Y410 && fo->kind != UNPACK_V210)
     return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destination layout not implemented on the GPU path");
   if (out16 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
     return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path");
@@ -2038,7 +2053,7 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   const GstAmdVideoConverterConfig &cfg = plan->config;
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
-  if (!kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && fo->kind != UNPACK_Y410) {
+  if (!kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && fo->kind != UNPACK_Y410 && fo->kind != UNPACK_V210) {
     if (error)
       *error = "10-bit destination layout not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
@@ -2295,8 +2310,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       alpha_bits = cfg.alpha_value == 1.0 ? 0 : 2;
   }
 
-  const bool same_matrix = cfg.matrix_mode == GSTAMD_MATRIX_MODE_NONE ? true : in_matrix == out_matrix;
-  const bool same_primaries = cfg.primaries_mode == GSTAMD_PRIMARIES_MODE_NONE ? true : primaries_equivalent (in->color_primaries, out->color_primaries);
+  bool same_matrix = cfg.matrix_mode == GSTAMD_MATRIX_MODE_NONE ? true : in_matrix == out_matrix;
+  bool same_primaries = cfg.primaries_mode == GSTAMD_PRIMARIES_MODE_NONE ? true : primaries_equivalent (in->color_primaries, out->color_primaries);
   M44 prim_dm;
   m_identity (prim_dm);
   if (!same_primaries)
@@ -2349,7 +2364,16 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       /* video_orc_convert_{I420,Y42B,Y444}_{YUY2,UYVY}, _{YUY2,UYVY}_{I420,Y42B,Y444}, _UYVY_YUY2 (video-orc.orc:1193-1620): chroma is
        * duplicated where the destination has more of it and avgub'ed (lines, then pixel pairs) where it has less */
       force_nearest = force_avg_down = true;
-    else if (name == "convert_scale_planes" && ki == UNPACK_PACKED4)
+    else if (name == "convert_UYVY_GRAY8") {
+      /* video_orc_convert_UYVY_GRAY8 (video-orc.orc:2937-2946; :5565-5606): the luma bytes as they are, whatever the two colour matrices say
+         (needs_color_matrix is set on the row).  The function starts at the two FRAMES' first pixels - crop and rectangle origins are not
+         applied - and then fills the border around the rectangle over part of what it wrote: only the uncropped form is reproduced */
+      const RectPlan &rc = plan->rect;
+      if (rc.in_x || rc.in_y || rc.out_x || rc.out_y || rc.fill || (rc.in_maxw && (rc.in_maxw != in->width || rc.in_maxh != in->height)) ||
+          (rc.out_maxw && (rc.out_maxw != out->width || rc.out_maxh != out->height)))
+        return fail (GSTAMD_ERR_UNSUPPORTED, "the reference's convert_UYVY_GRAY8 ignores the crop and rectangle origins; not reproduced");
+      same_matrix = same_primaries = true;
+    } else if (name == "convert_scale_planes" && ki == UNPACK_PACKED4)
       plane_scale = true;
     else if (name == "convert_scale_planes" && (ki == ko || (kind_has_planes (ki) && kind_has_planes (ko)) || (ki == UNPACK_GRAY && ko == UNPACK_PLANAR) ||
             (ki == UNPACK_PLANAR && ko == UNPACK_GRAY)))
@@ -2756,6 +2780,16 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   plan->rect = rc;
   plan->orig_in = *in;
   plan->orig_out = *out;
+  if (fi && fi->kind == UNPACK_V210 && rc.in_x) {
+    if (error)
+      *error = "a horizontal source offset into v210 (unpack_v210 ignores it: 'Horizontal offsets are not supported for v210') is not reproduced";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  if (fo && fo->kind == UNPACK_V210 && (rc.out_x || rc.out_y || rc.fill || (rc.out_maxw && (rc.out_maxw != eout.width || rc.out_maxh != eout.height)))) {
+    if (error)
+      *error = "a destination rectangle inside a v210 frame (6-pixel groups shared with the border) is not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
   if (rc.fill && fo && (fo->kind == UNPACK_PACKED422 || fo->kind == UNPACK_P422_16)) {
     if (error)
       *error = "borders on a packed 4:2:2 destination (the macropixel border of convert_fill_border) are not implemented on the GPU path";

@@ -24,6 +24,7 @@ enum UnpackKind : int {
   UNPACK_GRAY = 5,      // one plane of luma (GRAY8): a YUV format as far as the chain goes (unpack format AYUV), U = V = 0x80
   UNPACK_P422_16 = 6,   // one plane, macropixels of four 16-bit little-endian words Y0 U Y1 V (Y210, Y212_LE): a source / destination of the 16-bit chain
   UNPACK_Y410 = 7,      // one plane, a little-endian 32-bit word per pixel: U, Y, V at 10 bits, A at 2 (Y410); hi_depth code 7
+  UNPACK_V210 = 8,      // one plane, groups of six pixels in 16 bytes: three 10-bit samples per little-endian 32-bit word (v210); hi_depth code 8
 };
 
 struct FormatDesc {
@@ -41,7 +42,7 @@ struct FormatDesc {
                         // 1 / 2: 10-bit samples in little-endian 16-bit words, in the low bits (I420_10LE) / the
                         // high bits (P010_10LE); such formats unpack to AYUV64 in the reference (video-format.c:3836, 5331)
                         // 4 / 5: the same with 12 bits (I420_12LE ... / P012_LE), 6: all 16 bits (P016_LE, Y444_16LE)
-                        // 7: Y410's 10 + 10 + 10 + 2 bits in a 32-bit word
+                        // 7: Y410's 10 + 10 + 10 + 2 bits in a 32-bit word, 8: v210's three 10-bit samples per 32-bit word
 };
 #if defined(__HIPCC__)
 #define GSTAMD_VP __host__ __device__ inline
@@ -49,7 +50,7 @@ struct FormatDesc {
 #define GSTAMD_VP inline
 #endif
 // significant bits of a sample for a FormatDesc::hi_depth code, and whether the format keeps its samples in 16-bit words in planes
-GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 || hi == 7 ? 10 : (hi == 4 || hi == 5 ? 12 : (hi == 3 || hi == 6 ? 16 : 8)); }
+GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 ? 10 : (hi == 4 || hi == 5 ? 12 : (hi == 3 || hi == 6 ? 16 : 8)); }
 GSTAMD_VP bool hi_depth_words (int hi) { return hi == 1 || hi == 2 || (hi >= 4 && hi <= 6); }
 const FormatDesc *format_desc (int format);
 
@@ -300,6 +301,8 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
     return (size_t) y * stride + (size_t) x * 2;
   if (f->kind == UNPACK_P422_16 || f->kind == UNPACK_Y410)          /* 8 bytes per pair of pixels / 4 bytes per pixel */
     return (size_t) y * stride + (size_t) x * 4;
+  if (f->kind == UNPACK_V210)            /* rows only: a horizontal offset inside the 6-pixel groups is refused by the planner */
+    return (size_t) y * stride;
   const size_t bps = f->hi_depth ? 2 : 1;          /* planes of 10 / 12 / 16-bit formats hold 16-bit samples */
   if (plane == 0)
     return (size_t) y * stride + (size_t) x * bps;

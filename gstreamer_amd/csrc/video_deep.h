@@ -44,6 +44,11 @@ GSTAMD_HD UV deep_load_uv (const FrontParams &f, const Planes &pl, int crow, int
     const uint32_t w = ((const uint32_t *) (pl.p[0] + (ptrdiff_t) crow * pl.stride[0]))[k];
     r.u = y410_field (w, 0);
     r.v = y410_field (w, 20);
+  } else if (f.kind == UNPACK_V210) {     // unpack_v210 (video-format.c:560-649): chroma pair k of the line, pair k % 3 of group k / 3
+    const uint32_t *g = (const uint32_t *) (pl.p[0] + (ptrdiff_t) crow * pl.stride[0]) + 4 * (k / 3);
+    const int j = k % 3;
+    r.u = j == 0 ? y410_field (g[0], 0) : (j == 1 ? y410_field (g[1], 10) : y410_field (g[2], 20));
+    r.v = j == 0 ? y410_field (g[0], 20) : (j == 1 ? y410_field (g[2], 0) : y410_field (g[3], 10));
   } else if (f.kind == UNPACK_SEMI) {
     const uint16_t *p = (const uint16_t *) (pl.p[1] + (ptrdiff_t) crow * pl.stride[1]) + 2 * k;
     r.u = deep_widen (f.hi_depth, p[f.u_plane ? 0 : 1]);
@@ -96,6 +101,10 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
     c1 = y410_field (w, 10);
     const int t = (int) (w >> 30) << 14;                /* A: two bits, A |= A >> 10 */
     a = t | (t >> 10);
+  } else if (f.kind == UNPACK_V210) {   // luma j of the group: words 0 1 1 2 3 3 at bit 10 0 20 10 0 20
+    const uint32_t *g = (const uint32_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]) + 4 * (x / 6);
+    const int j = x % 6;
+    c1 = y410_field (g[j < 1 ? 0 : (j < 3 ? 1 : (j < 4 ? 2 : 3))], j == 0 || j == 3 ? 10 : (j == 1 || j == 4 ? 0 : 20));
   } else {
     c1 = deep_widen (f.hi_depth, ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
   }
@@ -399,7 +408,7 @@ GSTAMD_HD void pack16_chroma_h (const PackPlanarParams &pk, const uint2 *row, in
   }
 }
 
-GSTAMD_VP int pack16_units (const PackPlanarParams &pk) { return pk.kind == UNPACK_P422_16 ? (pk.width + 1) / 2 : pk.width; }
+GSTAMD_VP int pack16_units (const PackPlanarParams &pk) { return pk.kind == UNPACK_P422_16 ? (pk.width + 1) / 2 : (pk.kind == UNPACK_V210 ? (pk.width + 5) / 6 : pk.width); }
 
 GSTAMD_HD void pack16_packed_body (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride,
     uint8_t *__restrict__ dst, int dstride, int unit, int y)
@@ -415,6 +424,29 @@ GSTAMD_HD void pack16_packed_body (const PackPlanarParams &pk, int hi_depth, con
     const uint32_t u = (uint32_t) dither16_comp (dt, 2, (int) (px.y & 0xffffu), unit, y) & 0xffc0u;
     const uint32_t v = (uint32_t) dither16_comp (dt, 3, (int) (px.y >> 16), unit, y) & 0xffc0u;
     ((uint32_t *) (dst + (size_t) y * dstride))[unit] = (u >> 6) | (yy << 4) | (v << 14) | (a << 16);
+    return;
+  }
+  if (pk.kind == UNPACK_V210) {
+    /* pack_v210 (video-format.c:651-708): the group's six lumas and the chroma of its even pixels at 10 bits (>> 6), samples past the line's end 0 */
+    uint32_t yy[6], uu[3], vv[3];
+    for (int j = 0; j < 6; j++) {
+      const int x = 6 * unit + j;
+      yy[j] = x < w ? (uint32_t) dither16_comp (dt, 1, (int) (row[x].x >> 16), x, y) >> 6 : 0u;
+      if (!(j & 1)) {
+        uu[j >> 1] = vv[j >> 1] = 0;
+        if (x < w) {
+          int u, v;
+          pack16_chroma_h (pk, row, w, x, &u, &v);
+          uu[j >> 1] = (uint32_t) dither16_comp (dt, 2, u, x, y) >> 6;
+          vv[j >> 1] = (uint32_t) dither16_comp (dt, 3, v, x, y) >> 6;
+        }
+      }
+    }
+    uint32_t *d = (uint32_t *) (dst + (size_t) y * dstride) + 4 * unit;
+    d[0] = uu[0] | (yy[0] << 10) | (vv[0] << 20);
+    d[1] = yy[1] | (uu[1] << 10) | (yy[2] << 20);
+    d[2] = vv[1] | (yy[3] << 10) | (uu[2] << 20);
+    d[3] = yy[4] | (vv[2] << 10) | (yy[5] << 20);
     return;
   }
   const int x = 2 * unit;

@@ -208,7 +208,7 @@ __global__ __launch_bounds__ (256) void k_pack16_packed (PackPlanarParams pk, in
 hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *src, int sstride, uint8_t *const planes[3],
     const int strides[3], hipStream_t stream)
 {
-  if (pk.kind == UNPACK_P422_16 || pk.kind == UNPACK_Y410) {          /* Y210, Y212_LE, Y410: a lane per macropixel / pixel */
+  if (pk.kind == UNPACK_P422_16 || pk.kind == UNPACK_Y410 || pk.kind == UNPACK_V210) {          /* Y210, Y212_LE, Y410: a lane per macropixel / pixel */
     hipLaunchKernelGGL (k_pack16_packed, dim3 ((pack16_units (pk) + 255) / 256, pk.height), dim3 (256), 0, stream, pk, hi_depth, dt, src, sstride, planes[0], strides[0]);
     return hipGetLastError ();
   }

@@ -74,6 +74,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_Y444_16LE = 88,   /* all 16 bits */
   GSTAMD_VIDEO_FORMAT_P016_LE = 90,
   GSTAMD_VIDEO_FORMAT_P012_LE = 92,     /* 12 bits in the high bits */
+  GSTAMD_VIDEO_FORMAT_v210 = 21,      /* packed 4:2:2, 10 bits: six pixels in four little-endian 32-bit words (three samples a word) */
   GSTAMD_VIDEO_FORMAT_Y210 = 82,      /* packed 4:2:2, 16-bit little-endian words Y0 U Y1 V, 10 bits in the high bits */
   GSTAMD_VIDEO_FORMAT_Y410 = 83,      /* packed 4:4:4 in one little-endian 32-bit word: U 10, Y 10, V 10, A 2 (from the low bits) */
   GSTAMD_VIDEO_FORMAT_Y212_LE = 94,   /* Y210's layout with 12 bits */

@@ -381,6 +381,17 @@ VIDEO_CASES = [
     ("nv12_y410_scaled_bilinear", "NV12", 64, 36, "Y410", 100, 50, LIN, None, None, "random"),
     ("y410_y444_10le_crop_dest_border", "Y410", 48, 30, "Y444_10LE", 60, 40, dict(src_x=5, src_y=3, src_width=30, src_height=20, dest_x=7, dest_y=9, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
     ("argb64_y410_dest_border", "ARGB64", 30, 20, "Y410", 50, 30, dict(dest_x=7, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+    # ---- v210 through the generic chain (unpack_v210 / pack_v210 video-format.c:558-708: six pixels in four 32-bit words); the reference's own
+    # v210 fastpaths (I420 / YUY2 / ... <-> v210 at the same size) are not built - refused, see VIDEO_REFUSED
+    ("v210_bgra_50x7", "v210", 50, 7, "BGRA", 50, 7, {}, None, None, "random"),
+    ("v210_nv12_scaled_bilinear", "v210", 96, 40, "NV12", 64, 30, LIN, None, None, "random"),
+    ("bgra_v210_49x5_cosited", "BGRA", 49, 5, "v210", 49, 5, {}, None, "cosited", "random"),
+    ("nv12_v210_scaled_lanczos", "NV12", 64, 36, "v210", 100, 50, LAN, None, None, "random"),
+    ("v210_v210_scaled_cubic", "v210", 60, 20, "v210", 31, 13, dict(resampler_method="cubic"), None, None, "random"),
+    ("v210_p010_crop_rows", "v210", 48, 30, "P010_10LE", 48, 20, dict(src_y=6, src_height=20), None, None, "random"),
+    ("ayuv64_v210_dither_q8", "AYUV64", 40, 6, "v210", 40, 6, dict(dither_quantization=128), None, None, "random"),
+    # convert_UYVY_GRAY8 (video-converter.c:5565, row :8501 with needs_color_matrix): the luma bytes whatever the colour matrices
+    ("uyvy_gray8_bt709_fastpath_copy", "UYVY", 66, 9, "GRAY8", 66, 9, {}, "bt709", None, "random"),
     # the line past an odd-height 4:2:0 picture is a real source line when the crop ends above the frame's last line
     ("nv61_i420_crop_line_below_odd_h", "NV61", 22, 27, "I420", 8, 13, dict(src_x=6, src_y=12, src_width=8, src_height=13), "bt709", "cosited", "random"),
     ("bgra_nv12_crop_line_below_odd_h", "BGRA", 22, 27, "NV12", 8, 13, dict(src_x=6, src_y=12, src_width=8, src_height=13), None, None, "random"),
@@ -706,6 +717,12 @@ VIDEO_REFUSED = [
     # error diffusion below the frame's first line: the reference's error line is never cleared there, frames depend on each other
     ("NV12", 64, 64, "BGRA", 64, 70, dict(dither_quantization=4, dither_method="floyd-steinberg", dest_x=0, dest_y=3, dest_width=64, dest_height=64)),
     ("NV12", 64, 64, "P010_10LE", 64, 64, dict(dither_method="sierra-lite")),           # error diffusion on 16-bit lines
+    ("I420", 48, 16, "v210", 48, 16, {}),                # the reference's own v210 fastpaths (convert_I420_v210 ...: samples shifted, not widened) are not built
+    ("v210", 48, 16, "UYVY", 48, 16, {}),
+    ("v210", 48, 16, "BGRA", 40, 16, dict(src_x=6, src_width=40)),          # unpack_v210 ignores the horizontal offset
+    ("BGRA", 40, 16, "v210", 48, 16, dict(dest_x=6, dest_width=40)),        # a rectangle inside 6-pixel groups
+    ("UYVY", 64, 16, "GRAY8", 64, 16, dict(src_y=4, src_height=8)),         # convert_UYVY_GRAY8 ignores crop origins
+    ("NV24", 13, 29, "NV21", 7, 49, dict(src_x=6, src_y=3, src_width=6, src_height=15, dest_x=2, dest_y=18, dest_width=4, dest_height=15)),   # line past an odd-height 4:2:0 picture behind a horizontal scaler
     ("BGRA", 67, 36, "AYUV", 76, 21, dict(alpha_mode="mult", alpha_value=0.5)),    # alpha stage on MIN (in_width, out_width) pixels of a wider line
     ("YV12", 11, 21, "Y444_16LE", 85, 12, NEAR),         # nearest vertical scaling of 4:2:0 through the composite plans
     ("P010_10LE", 31, 13, "NV12", 23, 13, {}),           # the same through the composite plans

@@ -966,7 +966,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         d.p[i] = dst + out->offset[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]);
         d.stride[i] = out->stride[i];
       }
-      if (g.pack.kind == UNPACK_P422_16 || g.pack.kind == UNPACK_Y410) {          /* k_pack16_packed */
+      if (g.pack.kind == UNPACK_P422_16 || g.pack.kind == UNPACK_Y410 || g.pack.kind == UNPACK_V210) {          /* k_pack16_packed */
         for (int y = 0; y < g.pack.height; y++)
           for (int un = 0; un < (pack16_units (g.pack) + 255) / 256 * 256; un++)
             pack16_packed_body (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, d.p[0], d.stride[0], un, y);

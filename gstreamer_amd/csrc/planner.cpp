@@ -2854,6 +2854,15 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
           "time, after the in-place stages (colour, dither, chroma downsampling) have already changed it (line aliasing); this library pairs the last line "
           "with itself. ";
     }
+    /* observed with the reference (scripts/fuzz_video.py, a sweep of 8 -> 9 .. 69 rows): a 4:2:0 source enlarged by the nearest vertical scaler ALONE
+       (no horizontal pass between the in-place stages and the scaler) comes out with other chroma on the first line of a pair once the enlargement
+       exceeds five - 8 -> 42 rows match, 8 -> 43 do not, with a horizontal pass anywhere in the chain every ratio matches: its temporary lines are
+       reused before the repetitions have been served.  Announced, not reproduced */
+    if (pl.front.chroma_v2 && pl.passes.size () == 1 && !pl.passes[0].horizontal && pl.passes[0].kind == SCALE_NEAREST && pl.passes[0].out_size > 5 * pl.passes[0].in_size &&
+        !(v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place))) {
+      plan->divergence += "nearest vertical enlargement by more than five of a 4:2:0 source with no horizontal pass: the reference's temporary lines are reused before "
+          "every repetition of a line has been served (line aliasing: the first line of a chroma pair changes); this library serves every repetition from the same line. ";
+    }
     if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place)) {
       plan->divergence += "nearest vertical enlargement ahead of a stage that works in place (colour / alpha, chroma downsampling, dither): the reference "
           "processes a repeated line once more per repetition (line aliasing); this library applies every stage once per output row. ";
@@ -2927,6 +2936,21 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       ((out->stride[0] % 8) != 0 || (out->offset[0] % 8) != 0)) {
     plan->divergence += "VYUY unpacked straight into destination rows that are not 8-byte aligned: the reference's fallback loop (video-format.c:337-352) "
         "swaps U and V on those rows; this library unpacks every row the same way. ";
+  }
+  /* a ONE-line 4:2:0 source enlarged into a rectangle below the first row of a frame in its unpack format (ARGB / AYUV: the chain's lines are the
+   * destination's own rows, get_dest_line): the chroma upsampler makes its line pair (-1, 0) in the rows (out_y - 1, out_y) and the row above the
+   * rectangle keeps what it wrote there */
+  if (chain && pl.front.chroma_v2 && ih == 1 && oh > 1 && plan->rect.out_y > 0 &&
+      (fo->format == GSTAMD_VIDEO_FORMAT_AYUV || fo->format == GSTAMD_VIDEO_FORMAT_ARGB)) {
+    plan->divergence += "a one-line 4:2:0 source enlarged into a rectangle of an ARGB / AYUV frame: the reference's chroma upsampler writes the line before the "
+        "picture into the frame row above the rectangle; this library leaves that row to the border. ";
+  }
+  /* convert_scale_planes on packed 4:2:2 with the vertical pass first: that pass moves `width` pixels = 2 * width bytes of a line (video-converter.c
+   * convert_plane_v / _hv), which on an odd width leaves out the V sample of the last, half macropixel; the horizontal pass then reads it from a
+   * temporary line nobody wrote */
+  if (pl.plane_mode && fi->kind == UNPACK_PACKED422 && (iw & 1) && !pl.planes.empty () && pl.planes[0].passes.size () == 2 && !pl.planes[0].passes[0].horizontal) {
+    plan->divergence += "packed 4:2:2 of odd width scaled vertically, then horizontally: the reference's vertical pass copies 2 * width bytes of a line, the V sample of the "
+        "last half macropixel stays uninitialised in its temporary line and the horizontal pass reads it; this library takes that sample from the source row. ";
   }
   return r;
 }

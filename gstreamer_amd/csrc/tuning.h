@@ -14,6 +14,7 @@
 //   GSTAMD_NO_FAST422        generic kernel instead of the packed 4:2:2 -> RGB kernel (set)
 //   GSTAMD_NO_PLANE_FRAME    one kernel per plane and pass (intermediate plane in HBM) instead of k_plane_frame (set)
 //   GSTAMD_NO_BILINEAR4      wave-tile scaler instead of the four-outputs-per-lane nearest / 2-tap scaler of 4-byte sources (set)
+//   GSTAMD_NO_CONVERT16_FAST the general 16-bit convert kernel instead of the ones specialised by plane layout and chroma filter (set)
 //   GSTAMD_NO_GAMMA_COMP     decode and encode tables separately in the fused gamma kernel, not their composition (set)
 //   GSTAMD_NO_SWIZZLE34      the chain's kernels instead of the 3- / 4-byte pixel permutation kernel (set)
 //   GSTAMD_NO_RELAYOUT       the chain's kernels instead of the plane re-arrangement kernel for I420 <-> NV12 & co (set)

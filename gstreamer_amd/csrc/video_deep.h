@@ -134,6 +134,120 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
   return r;
 }
 
+// ---- the same for four neighbouring pixels x0 .. x0+3 of one row with the loads shared (planar / semi-planar sources with horizontally subsampled
+// chroma, x0 a multiple of 4, x0 + 4 <= width): the four lumas in one 8-byte load, the chroma samples k0-1 .. k0+2 of a chroma row once for all four
+// pixels.  Same arithmetic as deep_front_px / deep_chroma_h_at, value for value.
+// deep_widen with the format decoded once: t = (v << sh) & 0xffff; t | t >> bits  (sh = 16 - bits for samples in the low bits, 0 otherwise; the 16-bit
+// formats come out unchanged)
+struct Widen { int sh, bits; };
+GSTAMD_HD Widen deep_widen_params (int hi_depth)
+{
+  Widen w;
+  w.bits = hi_depth_bits (hi_depth);
+  w.sh = hi_depth == 1 || hi_depth == 4 ? 16 - w.bits : 0;
+  return w;
+}
+GSTAMD_HD int deep_widen_w (const Widen &w, int v)
+{
+  const int t = (v << w.sh) & 0xffff;
+  return t | (t >> w.bits);
+}
+
+// a * b on 24-bit operands (the matrix coefficients checked by the caller, samples have 16 bits): v_mul_i32_i24 / v_mad_i32_i24 at full rate, the low
+// 32 bits of the product - what the 32-bit multiply of video_converter_matrix16 keeps
+GSTAMD_HD int mul24s (int a, int b)
+{
+#ifdef __HIPCC__
+  return __mul24 (a, b);
+#else
+  return (int) ((uint32_t) a * (uint32_t) b);
+#endif
+}
+
+struct UV4 { int u[4], v[4]; };         // samples k0-1, k0, k0+1, k0+2 of a chroma row (indices clamped into the row: the formulas never use a clamped one)
+
+GSTAMD_HD UV4 deep_load_uv4 (const FrontParams &f, const Planes &pl, const Widen &wd, int crow, int k0, int cw)
+{
+  UV4 r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int k = k0 - 1 + i;
+    k = k < 0 ? 0 : (k > cw - 1 ? cw - 1 : k);
+    if (f.kind == UNPACK_SEMI) {
+      const uint32_t w = ((const uint32_t *) (pl.p[1] + (ptrdiff_t) crow * pl.stride[1]))[k];
+      const int lo = (int) (w & 0xffffu), hi = (int) (w >> 16);
+      r.u[i] = deep_widen_w (wd, f.u_plane ? lo : hi);
+      r.v[i] = deep_widen_w (wd, f.u_plane ? hi : lo);
+    } else {
+      r.u[i] = deep_widen_w (wd, ((const uint16_t *) (pl.p[f.u_plane] + (ptrdiff_t) crow * pl.stride[f.u_plane]))[k]);
+      r.v[i] = deep_widen_w (wd, ((const uint16_t *) (pl.p[f.v_plane] + (ptrdiff_t) crow * pl.stride[f.v_plane]))[k]);
+    }
+  }
+  return r;
+}
+
+// deep_chroma_h_at for pixel x0 + i (i = 0 .. 3) from the row's four samples
+GSTAMD_HD UV deep_chroma_h4 (const FrontParams &f, const UV4 &s, int x0, int i)
+{
+  const int x = x0 + i, j = 1 + (i >> 1), w = f.width;           /* s.u[j] is sample k = x >> 1 */
+  UV c;
+  c.u = s.u[j], c.v = s.v[j];
+  if (f.chroma_h == CHROMA_H_H2_CS) {
+    if ((x & 1) && x < w - 1) {
+      c.u = (s.u[j] + s.u[j + 1] + 1) >> 1;
+      c.v = (s.v[j] + s.v[j + 1] + 1) >> 1;
+    }
+  } else if (f.chroma_h == CHROMA_H_H2) {
+    if ((x & 1) && x < w - 1) {
+      c.u = (3 * s.u[j] + s.u[j + 1] + 2) >> 2;
+      c.v = (3 * s.v[j] + s.v[j + 1] + 2) >> 2;
+    } else if (!(x & 1) && x >= 2) {
+      c.u = (s.u[j - 1] + 3 * s.u[j] + 2) >> 2;
+      c.v = (s.v[j - 1] + 3 * s.v[j] + 2) >> 2;
+    }
+  }
+  return c;
+}
+
+GSTAMD_HD bool deep_front4_usable (const FrontParams &f, int x0)
+{
+  return kind_has_planes (f.kind) && f.w_sub == 1 && (x0 & 3) == 0 && x0 + 4 <= f.width;
+}
+
+GSTAMD_HD void deep_front4 (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint2 *out)
+{
+  struct __attribute__ ((aligned (4))) L4 { uint16_t v[4]; };
+  const L4 l = *(const L4 *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0] + 2 * (ptrdiff_t) x0);
+  const int cw = (f.width + 1) >> 1, k0 = x0 >> 1;
+  int ra = y >> f.h_sub, rb = ra, role = 0;
+  if (f.chroma_v2) {
+    const int e0 = vpair[2 * y];
+    rb = vpair[2 * y + 1];
+    ra = vpair_row (e0), role = vpair_role (e0);
+  }
+  const Widen wd = deep_widen_params (f.hi_depth);
+  const UV4 a = deep_load_uv4 (f, pl, wd, ra, k0, cw);
+  UV4 b = a;
+  if (ra != rb)
+    b = deep_load_uv4 (f, pl, wd, rb, k0, cw);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    UV c = deep_chroma_h4 (f, a, x0, i);
+    if (ra != rb) {
+      const UV d = deep_chroma_h4 (f, b, x0, i);
+      if (role == 0) {
+        c.u = (3 * c.u + d.u + 2) >> 2;
+        c.v = (3 * c.v + d.v + 2) >> 2;
+      } else {
+        c.u = (c.u + 3 * d.u + 2) >> 2;
+        c.v = (c.v + 3 * d.v + 2) >> 2;
+      }
+    }
+    out[i].x = 0xffffu | ((uint32_t) deep_widen_w (wd, l.v[i]) << 16);
+    out[i].y = (uint32_t) c.u | ((uint32_t) c.v << 16);
+  }
+}
+
 // an AYUV64 pixel through video_converter_matrix16 and video_orc_convert_u16_to_u8: the 8-bit unpack-order word
 GSTAMD_HD uint32_t deep_finish_px (const Deep16Params &d, uint2 px)
 {
@@ -211,6 +325,140 @@ GSTAMD_HD uint2 deep_scale_px (const Deep16Image &im, const ScaleDev &sd, bool h
   return deep_pack4 (v);
 }
 
+// ---- deep_front4 with the layout (SEMI: interleaved UV plane / separate planes) and the horizontal chroma filter (CH) fixed at compile time, every
+// other decision arithmetic: no wave-uniform branch trees (the general kernel's listing is 20 000 instructions of them - it was bound by its SCALAR
+// unit).  x0 a multiple of 4, x0 + 4 <= width.  Value for value deep_front_px: the vertical blend as (wa a + wb b + 2) >> 2 with (3, 1) / (1, 3)
+// by the pair's role ((4 a + 2) >> 2 = a when both rows are the same), the edge rules of deep_chroma_h_at as selects.
+template <int SEMI, int CH>
+GSTAMD_HD void deep_front4_t (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint2 *out)
+{
+  struct __attribute__ ((aligned (4))) L4 { uint16_t v[4]; };
+  const L4 l = *(const L4 *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0] + 2 * (ptrdiff_t) x0);
+  const Widen wd = deep_widen_params (f.hi_depth);
+  const int w = f.width, cw = (w + 1) >> 1, k0 = x0 >> 1;
+  int ra = y >> f.h_sub, rb = ra, wa = 3;
+  if (f.chroma_v2) {
+    const int e0 = vpair[2 * y];
+    rb = vpair[2 * y + 1];
+    ra = vpair_row (e0);
+    wa = vpair_role (e0) ? 1 : 3;
+  }
+  const int wb = 4 - wa;
+  int u[2][4], v[2][4];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int crow = r ? rb : ra;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int k = k0 - 1 + i;
+      k = k < 0 ? 0 : (k > cw - 1 ? cw - 1 : k);
+      int su, sv;
+      if (SEMI) {
+        const uint32_t t = ((const uint32_t *) (pl.p[1] + (ptrdiff_t) crow * pl.stride[1]))[k];
+        const int lo = (int) (t & 0xffffu), hi = (int) (t >> 16);
+        su = f.u_plane ? lo : hi;
+        sv = f.u_plane ? hi : lo;
+      } else {
+        su = ((const uint16_t *) (pl.p[f.u_plane] + (ptrdiff_t) crow * pl.stride[f.u_plane]))[k];
+        sv = ((const uint16_t *) (pl.p[f.v_plane] + (ptrdiff_t) crow * pl.stride[f.v_plane]))[k];
+      }
+      u[r][i] = deep_widen_w (wd, su);
+      v[r][i] = deep_widen_w (wd, sv);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = x0 + i, j = 1 + (i >> 1);
+    int cu[2], cv[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      int a = u[r][j], b = v[r][j];
+      if (CH == CHROMA_H_H2_CS) {
+        if (i & 1) {
+          const bool in = x < w - 1;
+          a = in ? (u[r][j] + u[r][j + 1] + 1) >> 1 : a;
+          b = in ? (v[r][j] + v[r][j + 1] + 1) >> 1 : b;
+        }
+      } else if (CH == CHROMA_H_H2) {
+        if (i & 1) {
+          const bool in = x < w - 1;
+          a = in ? (3 * u[r][j] + u[r][j + 1] + 2) >> 2 : a;
+          b = in ? (3 * v[r][j] + v[r][j + 1] + 2) >> 2 : b;
+        } else {
+          const bool in = x >= 2;
+          a = in ? (u[r][j - 1] + 3 * u[r][j] + 2) >> 2 : a;
+          b = in ? (v[r][j - 1] + 3 * v[r][j] + 2) >> 2 : b;
+        }
+      }
+      cu[r] = a, cv[r] = b;
+    }
+    const int fu = (wa * cu[0] + wb * cu[1] + 2) >> 2, fv = (wa * cv[0] + wb * cv[1] + 2) >> 2;
+    out[i].x = 0xffffu | ((uint32_t) deep_widen_w (wd, l.v[i]) << 16);
+    out[i].y = (uint32_t) fu | ((uint32_t) fv << 16);
+  }
+}
+
+// which instantiation serves a front (-1: none): planes with horizontally subsampled chroma, one of the three filters
+GSTAMD_VP int deep_front4_variant (const FrontParams &f)
+{
+  if (!kind_has_planes (f.kind) || f.w_sub != 1)
+    return -1;
+  const int ch = f.chroma_h == CHROMA_H_NONE ? 0 : (f.chroma_h == CHROMA_H_H2 ? 1 : (f.chroma_h == CHROMA_H_H2_CS ? 2 : -1));
+  return ch < 0 ? -1 : (f.kind == UNPACK_SEMI ? 3 : 0) + ch;
+}
+
+GSTAMD_HD void deep_front4_any (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint2 *out)
+{
+  switch (deep_front4_variant (f)) {
+    case 0: deep_front4_t<0, CHROMA_H_NONE> (f, pl, vpair, x0, y, out); break;
+    case 1: deep_front4_t<0, CHROMA_H_H2> (f, pl, vpair, x0, y, out); break;
+    case 2: deep_front4_t<0, CHROMA_H_H2_CS> (f, pl, vpair, x0, y, out); break;
+    case 3: deep_front4_t<1, CHROMA_H_NONE> (f, pl, vpair, x0, y, out); break;
+    case 4: deep_front4_t<1, CHROMA_H_H2> (f, pl, vpair, x0, y, out); break;
+    case 5: deep_front4_t<1, CHROMA_H_H2_CS> (f, pl, vpair, x0, y, out); break;
+    default: deep_front4 (f, pl, vpair, x0, y, out); break;
+  }
+}
+
+// four unpacked pixels through the convert stage (matrix16 on 24-bit operands when the coefficients allow), narrowing, alpha and pack, stored as a row piece
+GSTAMD_HD void deep_finish_store4 (const Deep16Params &d, const PostParams &post, const uint2 *px, uint32_t *out)
+{
+  uint32_t o[4];
+  bool fits24 = true;                 /* every coefficient a 24-bit operand (wave-uniform; the offsets im[k][3] are addends) */
+  for (int k = 0; k < 3; k++)
+    for (int j = 0; j < 3; j++)
+      fits24 = fits24 && d.im[k][j] > -(1 << 23) && d.im[k][j] < (1 << 23);
+  uint32_t sel = 0;                   /* destination byte pos[c] <- component c, as a v_perm_b32 selector */
+  for (int c = 0; c < 4; c++)
+    sel |= (uint32_t) c << (8 * post.pack_pos[c]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t w8;
+    if (d.has_matrix && fits24) {
+      const int a = (int) (px[i].x & 0xffffu), r = (int) (px[i].x >> 16), g = (int) (px[i].y & 0xffffu), b = (int) (px[i].y >> 16);
+      const int c1 = clampi ((mul24s (d.im[0][0], r) + mul24s (d.im[0][1], g) + mul24s (d.im[0][2], b) + d.im[0][3]) >> 8, 0, 65535);
+      const int c2 = clampi ((mul24s (d.im[1][0], r) + mul24s (d.im[1][1], g) + mul24s (d.im[1][2], b) + d.im[1][3]) >> 8, 0, 65535);
+      const int c3 = clampi ((mul24s (d.im[2][0], r) + mul24s (d.im[2][1], g) + mul24s (d.im[2][2], b) + d.im[2][3]) >> 8, 0, 65535);
+      w8 = (uint32_t) (a >> 8) | ((uint32_t) (c1 >> 8) << 8) | ((uint32_t) (c2 >> 8) << 16) | ((uint32_t) (c3 >> 8) << 24);
+    } else {
+      w8 = deep_finish_px (d, px[i]);
+    }
+    w8 = apply_alpha (post.alpha_kind, (unsigned) post.alpha_value, w8);
+#ifdef __HIPCC__
+    o[i] = __builtin_amdgcn_perm (0u, w8, sel);
+#else
+    o[i] = pack_px (post.pack_pos, w8);
+#endif
+  }
+  if ((((uintptr_t) out) & 15) == 0) {
+    *(uint4 *) out = gstamd_make_uint4 (o[0], o[1], o[2], o[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      out[i] = o[i];
+  }
+}
+
 // pixels x0 .. x0+3 of row y
 GSTAMD_HD void convert16_lane4 (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, const Deep16Params &d, const PostParams &post,
     uint8_t *dst, int dstride, int x0, int y)
@@ -218,10 +466,61 @@ GSTAMD_HD void convert16_lane4 (const FrontParams &f, const Planes &pl, const in
   if (x0 >= f.width || y >= f.height)
     return;
   uint32_t *out = (uint32_t *) (dst + (size_t) y * dstride + 4 * (size_t) x0);
+  if (deep_front4_usable (f, x0)) {
+    uint2 px[4];
+    deep_front4_any (f, pl, vpair, x0, y, px);
+    deep_finish_store4 (d, post, px, out);
+    return;
+  }
   for (int i = 0; i < 4 && x0 + i < f.width; i++) {
     const uint32_t px = apply_alpha (post.alpha_kind, (unsigned) post.alpha_value, deep_pixel (f, pl, vpair, d, x0 + i, y));
     out[i] = pack_px (post.pack_pos, px);
   }
+}
+
+// the same for rows y0 and y0 + 1: both rows' loads go out before either row's arithmetic (twice the memory parallelism per lane, half the waves)
+GSTAMD_HD void convert16_rows2 (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, const Deep16Params &d, const PostParams &post,
+    uint8_t *dst, int dstride, int x0, int y0)
+{
+  if (x0 < f.width && y0 + 1 < f.height && deep_front4_usable (f, x0)) {
+    uint2 pa[4], pb[4];
+    deep_front4_any (f, pl, vpair, x0, y0, pa);
+    deep_front4_any (f, pl, vpair, x0, y0 + 1, pb);
+    deep_finish_store4 (d, post, pa, (uint32_t *) (dst + (size_t) y0 * dstride + 4 * (size_t) x0));
+    deep_finish_store4 (d, post, pb, (uint32_t *) (dst + (size_t) (y0 + 1) * dstride + 4 * (size_t) x0));
+    return;
+  }
+  convert16_lane4 (f, pl, vpair, d, post, dst, dstride, x0, y0);
+  convert16_lane4 (f, pl, vpair, d, post, dst, dstride, x0, y0 + 1);
+}
+
+// the specialised kernels' lane: rows y0, y0 + 1 of a frame whose width is a multiple of 4
+template <int SEMI, int CH>
+GSTAMD_HD void convert16_fast_rows2 (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, const Deep16Params &d, const PostParams &post,
+    uint8_t *dst, int dstride, int x0, int y0)
+{
+  if (x0 + 4 > f.width || y0 >= f.height)
+    return;
+  uint2 pa[4], pb[4];
+  const int y1 = y0 + 1 < f.height ? y0 + 1 : y0;
+  deep_front4_t<SEMI, CH> (f, pl, vpair, x0, y0, pa);
+  deep_front4_t<SEMI, CH> (f, pl, vpair, x0, y1, pb);
+  deep_finish_store4 (d, post, pa, (uint32_t *) (dst + (size_t) y0 * dstride + 4 * (size_t) x0));
+  if (y1 != y0)
+    deep_finish_store4 (d, post, pb, (uint32_t *) (dst + (size_t) y1 * dstride + 4 * (size_t) x0));
+}
+
+// the specialised front kernels' lane: pixels x0 .. x0+3 of row y into an AYUV64 image (width a multiple of 4, the image rows 16-byte aligned)
+template <int SEMI, int CH>
+GSTAMD_HD void front16_fast_lane4 (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, uint8_t *img, int istride, int x0, int y)
+{
+  if (x0 + 4 > f.width || y >= f.height)
+    return;
+  uint2 px[4];
+  deep_front4_t<SEMI, CH> (f, pl, vpair, x0, y, px);
+  uint4 *out = (uint4 *) (img + (size_t) y * istride + 8 * (size_t) x0);
+  out[0] = gstamd_make_uint4 (px[0].x, px[0].y, px[1].x, px[1].y);
+  out[1] = gstamd_make_uint4 (px[2].x, px[2].y, px[3].x, px[3].y);
 }
 
 // front only: pixels x0 .. x0+3 of row y into an AYUV64 image
@@ -230,6 +529,19 @@ GSTAMD_HD void front16_lane4 (const FrontParams &f, const Planes &pl, const int 
   if (x0 >= f.width || y >= f.height)
     return;
   uint2 *out = (uint2 *) (img + (size_t) y * istride + 8 * (size_t) x0);
+  if (deep_front4_usable (f, x0)) {
+    uint2 px[4];
+    deep_front4_any (f, pl, vpair, x0, y, px);
+    if ((((uintptr_t) out) & 15) == 0) {
+      ((uint4 *) out)[0] = gstamd_make_uint4 (px[0].x, px[0].y, px[1].x, px[1].y);
+      ((uint4 *) out)[1] = gstamd_make_uint4 (px[2].x, px[2].y, px[3].x, px[3].y);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        out[i] = px[i];
+    }
+    return;
+  }
   for (int i = 0; i < 4 && x0 + i < f.width; i++)
     out[i] = deep_front_px (f, pl, vpair, x0 + i, y);
 }

@@ -100,17 +100,38 @@ hipError_t launch_lut3 (uint8_t *img, int stride, int w, int h, const uint8_t *c
   return hipGetLastError ();
 }
 
-// the 16-bit chain of a 10-bit source into an 8-bit 4-byte destination (video_deep.h): a lane = 4 pixels of one row
+// the 16-bit chain of a 10-bit source into an 8-bit 4-byte destination (video_deep.h): a lane = 4 pixels of two rows
 __global__ __launch_bounds__ (256) void k_convert16 (FrontParams f, Planes pl, const int *__restrict__ vpair, Deep16Params d, PostParams post,
     uint8_t *__restrict__ dst, int dstride)
 {
-  convert16_lane4 (f, pl, vpair, d, post, dst, dstride, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
+  convert16_rows2 (f, pl, vpair, d, post, dst, dstride, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, 2 * (int) blockIdx.y);
+}
+
+template <int SEMI, int CH>
+__global__ __launch_bounds__ (256) void k_convert16_fast (FrontParams f, Planes pl, const int *__restrict__ vpair, Deep16Params d, PostParams post,
+    uint8_t *__restrict__ dst, int dstride)
+{
+  convert16_fast_rows2<SEMI, CH> (f, pl, vpair, d, post, dst, dstride, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, 2 * (int) blockIdx.y);
 }
 
 hipError_t launch_convert16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const Deep16Params &d, const PostParams &post, uint8_t *dst,
     int dstride, hipStream_t stream)
 {
-  dim3 grid ((f.width / 4 + 256) / 256, f.height);
+  const int variant = (f.width % 4) == 0 && !tuning_on ("GSTAMD_NO_CONVERT16_FAST") ? deep_front4_variant (f) : -1;
+  if (variant >= 0) {
+    /* planes with horizontally subsampled chroma, widths in whole 4-pixel blocks: layout and chroma filter are template parameters */
+    const dim3 fgrid ((f.width / 4 + 255) / 256, (f.height + 1) / 2);
+    switch (variant) {
+      case 0: hipLaunchKernelGGL ((k_convert16_fast<0, CHROMA_H_NONE>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, d, post, dst, dstride); break;
+      case 1: hipLaunchKernelGGL ((k_convert16_fast<0, CHROMA_H_H2>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, d, post, dst, dstride); break;
+      case 2: hipLaunchKernelGGL ((k_convert16_fast<0, CHROMA_H_H2_CS>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, d, post, dst, dstride); break;
+      case 3: hipLaunchKernelGGL ((k_convert16_fast<1, CHROMA_H_NONE>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, d, post, dst, dstride); break;
+      case 4: hipLaunchKernelGGL ((k_convert16_fast<1, CHROMA_H_H2>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, d, post, dst, dstride); break;
+      default: hipLaunchKernelGGL ((k_convert16_fast<1, CHROMA_H_H2_CS>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, d, post, dst, dstride); break;
+    }
+    return hipGetLastError ();
+  }
+  dim3 grid ((f.width / 4 + 256) / 256, (f.height + 1) / 2);
   hipLaunchKernelGGL (k_convert16, grid, dim3 (256), 0, stream, f, pl, vpair_dev, d, post, dst, dstride);
   return hipGetLastError ();
 }
@@ -133,8 +154,27 @@ __global__ __launch_bounds__ (256) void k_scale16_final (Deep16Image im, ScaleDe
   scale16_final_lane (im, sd, horizontal != 0, d, post, dst, dstride, ow, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
 }
 
+template <int SEMI, int CH>
+__global__ __launch_bounds__ (256) void k_front16_fast (FrontParams f, Planes pl, const int *__restrict__ vpair, uint8_t *__restrict__ img, int istride)
+{
+  front16_fast_lane4<SEMI, CH> (f, pl, vpair, img, istride, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
+}
+
 hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, uint8_t *img, int istride, hipStream_t stream)
 {
+  const int variant = (f.width % 4) == 0 && ((uintptr_t) img % 16) == 0 && (istride % 16) == 0 && !tuning_on ("GSTAMD_NO_CONVERT16_FAST") ? deep_front4_variant (f) : -1;
+  if (variant >= 0) {
+    const dim3 fgrid ((f.width / 4 + 255) / 256, f.height);
+    switch (variant) {
+      case 0: hipLaunchKernelGGL ((k_front16_fast<0, CHROMA_H_NONE>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, img, istride); break;
+      case 1: hipLaunchKernelGGL ((k_front16_fast<0, CHROMA_H_H2>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, img, istride); break;
+      case 2: hipLaunchKernelGGL ((k_front16_fast<0, CHROMA_H_H2_CS>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, img, istride); break;
+      case 3: hipLaunchKernelGGL ((k_front16_fast<1, CHROMA_H_NONE>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, img, istride); break;
+      case 4: hipLaunchKernelGGL ((k_front16_fast<1, CHROMA_H_H2>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, img, istride); break;
+      default: hipLaunchKernelGGL ((k_front16_fast<1, CHROMA_H_H2_CS>), fgrid, dim3 (256), 0, stream, f, pl, vpair_dev, img, istride); break;
+    }
+    return hipGetLastError ();
+  }
   dim3 grid ((f.width / 4 + 256) / 256, f.height);
   hipLaunchKernelGGL (k_front16, grid, dim3 (256), 0, stream, f, pl, vpair_dev, img, istride);
   return hipGetLastError ();

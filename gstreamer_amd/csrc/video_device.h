@@ -237,6 +237,41 @@ struct SrcFront {
   }
 };
 
+// a 4-byte packed source through unpack (a byte permutation) and the colour stage - the pixel source of k_convert_pack.  SrcFront does the same
+// through fetch_front, whose switch over every source layout a packer body inlines twenty times: 25 000 instructions of wave-uniform branches
+struct SrcPacked4 {
+  const uint8_t *p;
+  int stride;
+  int pos[4];
+  uint32_t sel;         // v_perm_b32 selector: unpacked byte c <- memory byte pos[c]
+  ColorParams pre;
+  GSTAMD_HD uint32_t at (int x, int y) const
+  {
+    const uint32_t raw = *(const uint32_t *) (p + (size_t) y * stride + 4 * (size_t) x);
+#ifdef __HIPCC__
+    const uint32_t px = __builtin_amdgcn_perm (0u, raw, sel);
+#else
+    const uint32_t px = ((raw >> (8 * pos[0])) & 0xff) | (((raw >> (8 * pos[1])) & 0xff) << 8) | (((raw >> (8 * pos[2])) & 0xff) << 16) |
+        (((raw >> (8 * pos[3])) & 0xff) << 24);
+#endif
+    return apply_color (pre, px);
+  }
+};
+
+inline SrcPacked4 make_src_packed4 (const FrontParams &f, const Planes &pl, const ColorParams &color)
+{
+  SrcPacked4 s;
+  s.p = pl.p[0];
+  s.stride = pl.stride[0];
+  s.sel = 0;
+  for (int c = 0; c < 4; c++) {
+    s.pos[c] = f.pos[c];
+    s.sel |= (uint32_t) f.pos[c] << (8 * c);
+  }
+  s.pre = color;
+  return s;
+}
+
 struct SrcImage {
   const uint8_t *p;
   int stride;

@@ -901,14 +901,8 @@ __global__ __launch_bounds__ (256) void k_pack_planar (PackPlanarParams pk, cons
 }
 
 // the same with the unscaled 8-bit chain as its pixel source: YUY2 -> I420, AYUV -> NV12, I420 -> Y42B ... in one launch, no AYUV image
-__global__ __launch_bounds__ (64) void k_convert_pack (PackPlanarParams pk, FrontParams f, Planes pl, const int *__restrict__ vpair, ColorParams color, DstPlanes d)
+__global__ __launch_bounds__ (64) void k_convert_pack (PackPlanarParams pk, SrcPacked4 src, DstPlanes d)
 {
-  SrcFront src;
-  src.f = f;
-  src.pl = pl;
-  src.vpair = vpair;
-  src.pre = color;
-  src.vec_ok = 0;
   pack_planar_body (pk, src, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
 }
 
@@ -1730,7 +1724,8 @@ hipError_t launch_convert_pack (const PackPlanarParams &pk, const FrontParams &f
       wide = ((uintptr_t) planes[i] % 8) == 0 && (strides[i] % 8) == 0;
     hipLaunchKernelGGL (k_convert_pack_422, dim3 (((pk.width + 7) / 8 + 255) / 256, rows), dim3 (256), 0, stream, pk, src, d, wide);
   } else {
-    hipLaunchKernelGGL (k_convert_pack, dim3 ((lanes + 63) / 64, rows), dim3 (64), 0, stream, pk, f, pl, vpair, color, d);
+    (void) vpair;
+    hipLaunchKernelGGL (k_convert_pack, dim3 ((lanes + 63) / 64, rows), dim3 (64), 0, stream, pk, make_src_packed4 (f, pl, color), d);
   }
   return hipGetLastError ();
 }

@@ -25,7 +25,8 @@ CASES = [("BGRA", 3840, 2160, "BGRA", 1920, 1080, BIL), ("NV12", 3840, 2160, "BG
 if len(sys.argv) > 1:          # python scripts/bench_survey.py P010 I420_10LE ...: only the cases naming one of these formats
     CASES = [c for c in CASES if c[0] in sys.argv[1:] or c[3] in sys.argv[1:]]
     CASES += [("I420_10LE", 3840, 2160, "BGRA", 3840, 2160, {}), ("P010_10LE", 3840, 2160, "NV12", 1920, 1080, BIL), ("NV12", 3840, 2160, "P010_10LE", 3840, 2160, {}),
-              ("P010_10LE", 3840, 2160, "BGRA", 1920, 1080, BIL), ("P010_10LE", 1920, 1080, "BGRA", 3840, 2160, BIL)] if "P010_10LE" in sys.argv[1:] else []
+              ("P010_10LE", 3840, 2160, "BGRA", 1920, 1080, BIL), ("P010_10LE", 1920, 1080, "BGRA", 3840, 2160, BIL),
+              ("AYUV", 3840, 2160, "NV12", 3840, 2160, {}), ("BGRA", 3840, 2160, "Y444", 3840, 2160, {}), ("BGRA", 3840, 2160, "I420", 3840, 2160, dict(matrix_mode="none"))] if "P010_10LE" in sys.argv[1:] else []
 dev = torch.device("cuda:0")
 for ifmt, w, h, ofmt, ow, oh, cfg in CASES:
     ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)

@@ -1163,7 +1163,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
           pack_planar_body (p.pack, s422, d, x0, yb);
           pack_planar_body (p.pack, s422, d, x0 + 4, yb);
         } else
-          pack_planar_body (p.pack, sf, d, x0, yb);
+          pack_planar_body (p.pack, make_src_packed4 (p.front, pl, sf.pre), d, x0, yb);
     return GSTAMD_OK;
   }
   if (p.out_planar) {                     /* chain -> AYUV image, then the pack kernel body over its grid */

@@ -2859,11 +2859,12 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
        exceeds five - 8 -> 42 rows match, 8 -> 43 do not, with a horizontal pass anywhere in the chain every ratio matches: its temporary lines are
        reused before the repetitions have been served.  Announced, not reproduced */
     if (pl.front.chroma_v2 && pl.passes.size () == 1 && !pl.passes[0].horizontal && pl.passes[0].kind == SCALE_NEAREST && pl.passes[0].out_size > 5 * pl.passes[0].in_size &&
-        !(v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place))) {
+        !(v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place || (identity_pack && pl.front.chroma_v2)))) {
       plan->divergence += "nearest vertical enlargement by more than five of a 4:2:0 source with no horizontal pass: the reference's temporary lines are reused before "
           "every repetition of a line has been served (line aliasing: the first line of a chroma pair changes); this library serves every repetition from the same line. ";
     }
-    if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place)) {
+    /* (a 4:2:0 source into a frame in its unpack format: the chroma upsampler itself works in the destination's rows, which the scaler hands out again) */
+    if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place || (identity_pack && pl.front.chroma_v2))) {
       plan->divergence += "nearest vertical enlargement ahead of a stage that works in place (colour / alpha, chroma downsampling, dither): the reference "
           "processes a repeated line once more per repetition (line aliasing); this library applies every stage once per output row. ";
     }

@@ -629,25 +629,50 @@ GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const Dith
   if (x0 >= w || y0 >= h)
     return;
   const int nlines = 1 << pk.h_sub;
+  const uint2 *ra = (const uint2 *) (src + (size_t) y0 * sstride);
+  const uint2 *rb = (const uint2 *) (src + (size_t) (y0 + 1 < h ? y0 + 1 : h - 1) * sstride);
+  /* a whole block inside the row, image rows on 16 bytes: the block's four pixels of a row in two 16-byte loads (a lane's pixels are 32 contiguous
+     bytes; pixel by pixel every load instruction of a wave touched 2 KB for 256 useful bytes), the two neighbours the cosited filter reaches singly */
+  uint2 pa[6], pb[6];                                   // pixels x0-1 .. x0+4 of the two rows, clamped into the row
+  const bool whole = x0 + 4 <= w && (((uintptr_t) src | (uintptr_t) sstride) & 15) == 0;
+  if (whole) {
+    const uint4 a0 = *(const uint4 *) (ra + x0), a1 = *(const uint4 *) (ra + x0 + 2), b0 = *(const uint4 *) (rb + x0), b1 = *(const uint4 *) (rb + x0 + 2);
+    pa[1].x = a0.x, pa[1].y = a0.y, pa[2].x = a0.z, pa[2].y = a0.w, pa[3].x = a1.x, pa[3].y = a1.y, pa[4].x = a1.z, pa[4].y = a1.w;
+    pb[1].x = b0.x, pb[1].y = b0.y, pb[2].x = b0.z, pb[2].y = b0.w, pb[3].x = b1.x, pb[3].y = b1.y, pb[4].x = b1.z, pb[4].y = b1.w;
+    const int xl = x0 > 0 ? x0 - 1 : 0, xr = x0 + 4 < w ? x0 + 4 : w - 1;
+    pa[0] = ra[xl], pb[0] = rb[xl], pa[5] = ra[xr], pb[5] = rb[xr];
+  } else {
+    for (int i = 0; i < 6; i++) {
+      int x = x0 - 1 + i;
+      x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+      pa[i] = ra[x], pb[i] = rb[x];
+    }
+  }
   for (int r = 0; r < nlines; r++) {
     const int y = y0 + r;
     if (y >= h)
       break;
-    const uint2 *row = (const uint2 *) (src + (size_t) y * sstride);
+    const uint2 *pr = r ? pb : pa;
     uint16_t *dy = (uint16_t *) (d.p[0] + (size_t) y * d.stride[0]) + x0;
+    uint16_t o[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4 && x0 + i < w; i++)
-      dy[i] = pack16_sample (hi_depth, dither16_comp (dt, 1, (int) (row[x0 + i].x >> 16), x0 + i, y));
+      o[i] = pack16_sample (hi_depth, dither16_comp (dt, 1, (int) (pr[i + 1].x >> 16), x0 + i, y));
+    if (whole && (((uintptr_t) dy) & 7) == 0) {
+      uint2 st;
+      st.x = (uint32_t) o[0] | ((uint32_t) o[1] << 16);
+      st.y = (uint32_t) o[2] | ((uint32_t) o[3] << 16);
+      *(uint2 *) dy = st;
+    } else {
+      for (int i = 0; i < 4 && x0 + i < w; i++)
+        dy[i] = o[i];
+    }
   }
-  const uint2 *ra = (const uint2 *) (src + (size_t) y0 * sstride);
-  const uint2 *rb = (const uint2 *) (src + (size_t) (y0 + 1 < h ? y0 + 1 : h - 1) * sstride);
-  int cu[6], cv[6];                                     // U, V of pixels x0-1 .. x0+4, clamped into the row
+  int cu[6], cv[6];                                     // U, V of pixels x0-1 .. x0+4
   for (int i = 0; i < 6; i++) {
-    int x = x0 - 1 + i;
-    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-    int u = (int) (ra[x].y & 0xffffu), v = (int) (ra[x].y >> 16);
+    int u = (int) (pa[i].y & 0xffffu), v = (int) (pa[i].y >> 16);
     if (pk.down_v) {
-      u = (u + (int) (rb[x].y & 0xffffu) + 1) >> 1;     /* avguw */
-      v = (v + (int) (rb[x].y >> 16) + 1) >> 1;
+      u = (u + (int) (pb[i].y & 0xffffu) + 1) >> 1;     /* avguw */
+      v = (v + (int) (pb[i].y >> 16) + 1) >> 1;
     }
     cu[i] = u;
     cv[i] = v;
@@ -681,8 +706,13 @@ GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const Dith
     const int k = x >> pk.w_sub;
     if (pk.kind == UNPACK_SEMI) {
       uint16_t *duv = (uint16_t *) (d.p[1] + (size_t) yb * d.stride[1]) + 2 * k;
-      duv[0] = pk.u_plane ? pu : pv;
-      duv[1] = pk.u_plane ? pv : pu;
+      const uint16_t c0 = pk.u_plane ? pu : pv, c1 = pk.u_plane ? pv : pu;
+      if ((((uintptr_t) duv) & 3) == 0) {
+        *(uint32_t *) duv = (uint32_t) c0 | ((uint32_t) c1 << 16);
+      } else {
+        duv[0] = c0;
+        duv[1] = c1;
+      }
     } else {
       ((uint16_t *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane]))[k] = pu;
       ((uint16_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane]))[k] = pv;

@@ -1090,10 +1090,18 @@ static int convert_deep_scaled (GstAmdVideoConverter *c, const Planes &pl, uint8
     sd[i].nw4 = p.passes[i].nw4;
   }
   if (!p.matrix_before_scale) {
-    if ((e = launch_front16 (p.front, pl, c->vpair_dev, c->deep_a, in_w * 8, stream)) != hipSuccess)
-      return hip_fail (e, "k_front16");
     Deep16Image cur = {c->deep_a, in_w * 8, in_w, in_h};
-    for (size_t i = 0; i < n; i++) {
+    size_t first = 0;
+    if (n == 2 && p.passes[0].horizontal && front_hscale16_usable (p.front)) {
+      /* the front inside the first, horizontal pass: no full-size AYUV64 image */
+      if ((e = launch_front_hscale16 (p.front, pl, c->vpair_dev, sd[0], c->deep_b, mid_w * 8, mid_w, stream)) != hipSuccess)
+        return hip_fail (e, "k_front_hscale16");
+      cur.p = c->deep_b, cur.stride = mid_w * 8, cur.width = mid_w, cur.height = in_h;
+      first = 1;
+    } else if ((e = launch_front16 (p.front, pl, c->vpair_dev, c->deep_a, in_w * 8, stream)) != hipSuccess) {
+      return hip_fail (e, "k_front16");
+    }
+    for (size_t i = first; i < n; i++) {
       const bool hz = p.passes[i].horizontal, last = i + 1 == n;
       const int ow = hz ? p.passes[i].out_size : cur.width, oh = hz ? cur.height : p.passes[i].out_size;
       if (last)

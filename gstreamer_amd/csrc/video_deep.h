@@ -510,6 +510,123 @@ GSTAMD_HD void convert16_fast_rows2 (const FrontParams &f, const Planes &pl, con
     deep_finish_store4 (d, post, pb, (uint32_t *) (dst + (size_t) y1 * dstride + 4 * (size_t) x0));
 }
 
+// ---- the front fused into the FIRST, horizontal u16 pass (a 10-bit source that shrinks: chain_scale ahead of the convert stage): the pass evaluates the
+// source pixels under its taps itself - no full-size AYUV64 image is written and read back (66 MB each way for a 4K frame).  One output pixel per lane;
+// deep_front_px's value for a single pixel with layout and filter fixed at compile time, deep_scale_px's horizontal arithmetic on it.
+struct FrontRow {       // what every pixel of a row shares
+  Widen wd;
+  int ra, rb, wa, wb, cw;
+};
+
+GSTAMD_HD FrontRow deep_front_row (const FrontParams &f, const int *__restrict__ vpair, int y)
+{
+  FrontRow r;
+  r.wd = deep_widen_params (f.hi_depth);
+  r.cw = (f.width + 1) >> 1;
+  r.ra = y >> f.h_sub, r.rb = r.ra, r.wa = 3;
+  if (f.chroma_v2) {
+    const int e0 = vpair[2 * y];
+    r.rb = vpair[2 * y + 1];
+    r.ra = vpair_row (e0);
+    r.wa = vpair_role (e0) ? 1 : 3;
+  }
+  r.wb = 4 - r.wa;
+  return r;
+}
+
+template <int SEMI, int CH>
+GSTAMD_HD uint2 deep_front1_t (const FrontParams &f, const Planes &pl, const FrontRow &fr, int x, int y)
+{
+  const int w = f.width, k = x >> 1, odd = x & 1;
+  int kn = odd ? k + 1 : k - 1;                         /* the neighbour sample the filter of this pixel may reach */
+  kn = kn < 0 ? 0 : (kn > fr.cw - 1 ? fr.cw - 1 : kn);
+  const bool in = odd ? x < w - 1 : x >= 2;
+  int cu[2], cv[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int crow = r ? fr.rb : fr.ra;
+    int su, sv, nu, nv;
+    if (SEMI) {
+      const uint32_t *q = (const uint32_t *) (pl.p[1] + (ptrdiff_t) crow * pl.stride[1]);
+      const uint32_t t = q[k], tn = CH == CHROMA_H_NONE ? t : q[kn];
+      su = (int) (f.u_plane ? t & 0xffffu : t >> 16), sv = (int) (f.u_plane ? t >> 16 : t & 0xffffu);
+      nu = (int) (f.u_plane ? tn & 0xffffu : tn >> 16), nv = (int) (f.u_plane ? tn >> 16 : tn & 0xffffu);
+    } else {
+      const uint16_t *qu = (const uint16_t *) (pl.p[f.u_plane] + (ptrdiff_t) crow * pl.stride[f.u_plane]);
+      const uint16_t *qv = (const uint16_t *) (pl.p[f.v_plane] + (ptrdiff_t) crow * pl.stride[f.v_plane]);
+      su = qu[k], sv = qv[k];
+      nu = CH == CHROMA_H_NONE ? su : qu[kn], nv = CH == CHROMA_H_NONE ? sv : qv[kn];
+    }
+    su = deep_widen_w (fr.wd, su), sv = deep_widen_w (fr.wd, sv), nu = deep_widen_w (fr.wd, nu), nv = deep_widen_w (fr.wd, nv);
+    int a = su, b = sv;
+    if (CH == CHROMA_H_H2_CS) {
+      if (odd && in)
+        a = (su + nu + 1) >> 1, b = (sv + nv + 1) >> 1;
+    } else if (CH == CHROMA_H_H2) {
+      if (in) {
+        a = odd ? (3 * su + nu + 2) >> 2 : (nu + 3 * su + 2) >> 2;
+        b = odd ? (3 * sv + nv + 2) >> 2 : (nv + 3 * sv + 2) >> 2;
+      }
+    }
+    cu[r] = a, cv[r] = b;
+  }
+  const int fu = (fr.wa * cu[0] + fr.wb * cu[1] + 2) >> 2, fv = (fr.wa * cv[0] + fr.wb * cv[1] + 2) >> 2;
+  const int c1 = deep_widen_w (fr.wd, ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
+  uint2 px;
+  px.x = 0xffffu | ((uint32_t) c1 << 16);
+  px.y = (uint32_t) fu | ((uint32_t) fv << 16);
+  return px;
+}
+
+template <int SEMI, int CH>
+GSTAMD_HD void front_hscale16_lane (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, const ScaleDev &sd, uint8_t *dst, int dstride, int ow,
+    int x, int y)
+{
+  if (x >= ow || y >= f.height)
+    return;
+  const FrontRow fr = deep_front_row (f, vpair, y);
+  const int w = f.width, off = (int) sd.offset[x];
+  auto at = [&](int sx) { return deep_front1_t<SEMI, CH> (f, pl, fr, sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx), y); };          /* deep_img_at's clamp */
+  uint2 o;
+  if (sd.kind == SCALE_NEAREST) {
+    o = at (off);
+  } else {
+    const int16_t *t = sd.taps + (size_t) x * sd.n_taps;
+    int v[4];
+    if (sd.kind == SCALE_2TAP) {
+      const uint2 a = at (off), b = at (off + 1);
+      for (int c = 0; c < 4; c++)
+        v[c] = clampi ((int) ((uint32_t) deep_comp (a, c) * (uint32_t) (int) t[0] + (uint32_t) deep_comp (b, c) * (uint32_t) (int) t[1] + 4096u) >> 12, 0, 65535);
+    } else {
+      uint32_t acc[4] = {0, 0, 0, 0};
+      for (int l = 0; l < sd.n_taps; l++) {
+        const uint2 p = at (off + l);
+        const uint32_t tp = (uint32_t) (int) t[l];
+        for (int c = 0; c < 4; c++)
+          acc[c] += (uint32_t) deep_comp (p, c) * tp;
+      }
+      for (int c = 0; c < 4; c++)
+        v[c] = deep_scaletaps ((int) acc[c]);
+    }
+    o = deep_pack4 (v);
+  }
+  *(uint2 *) (dst + (size_t) y * dstride + 8 * (size_t) x) = o;
+}
+
+// front_hscale16_lane of the variant deep_front4_variant names (host emulator; the device launcher instantiates the kernels)
+GSTAMD_HD void front_hscale16_any (int variant, const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, const ScaleDev &sd, uint8_t *dst, int dstride,
+    int ow, int x, int y)
+{
+  switch (variant) {
+    case 0: front_hscale16_lane<0, CHROMA_H_NONE> (f, pl, vpair, sd, dst, dstride, ow, x, y); break;
+    case 1: front_hscale16_lane<0, CHROMA_H_H2> (f, pl, vpair, sd, dst, dstride, ow, x, y); break;
+    case 2: front_hscale16_lane<0, CHROMA_H_H2_CS> (f, pl, vpair, sd, dst, dstride, ow, x, y); break;
+    case 3: front_hscale16_lane<1, CHROMA_H_NONE> (f, pl, vpair, sd, dst, dstride, ow, x, y); break;
+    case 4: front_hscale16_lane<1, CHROMA_H_H2> (f, pl, vpair, sd, dst, dstride, ow, x, y); break;
+    default: front_hscale16_lane<1, CHROMA_H_H2_CS> (f, pl, vpair, sd, dst, dstride, ow, x, y); break;
+  }
+}
+
 // the specialised front kernels' lane: pixels x0 .. x0+3 of row y into an AYUV64 image (width a multiple of 4, the image rows 16-byte aligned)
 template <int SEMI, int CH>
 GSTAMD_HD void front16_fast_lane4 (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, uint8_t *img, int istride, int x0, int y)

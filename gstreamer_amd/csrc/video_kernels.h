@@ -41,6 +41,8 @@ hipError_t launch_pack_planar_ed (const PackPlanarParams &pk, uint8_t *img, int 
 hipError_t launch_dither16_image (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream);
 struct Deep16Image;
 hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, uint8_t *img, int istride, hipStream_t stream);
+bool front_hscale16_usable (const FrontParams &f);
+hipError_t launch_front_hscale16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ScaleDev &sd, uint8_t *dst, int dstride, int ow, hipStream_t stream);
 // d / post non-NULL: the last pass, fused with matrix16 + narrowing + alpha + pack into the 4-byte destination
 hipError_t launch_scale16 (const Deep16Image &im, const ScaleDev &sd, bool horizontal, uint8_t *dst, int dstride, int ow, int oh, const Deep16Params *d,
     const PostParams *post, hipStream_t stream);

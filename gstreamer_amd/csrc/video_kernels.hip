@@ -155,6 +155,32 @@ __global__ __launch_bounds__ (256) void k_scale16_final (Deep16Image im, ScaleDe
 }
 
 template <int SEMI, int CH>
+__global__ __launch_bounds__ (256) void k_front_hscale16 (FrontParams f, Planes pl, const int *__restrict__ vpair, ScaleDev sd, uint8_t *__restrict__ dst, int dstride, int ow)
+{
+  front_hscale16_lane<SEMI, CH> (f, pl, vpair, sd, dst, dstride, ow, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+// the 16-bit front inside the first, horizontal u16 pass; false: this front has no specialised form (the caller runs k_front16 + k_scale16)
+bool front_hscale16_usable (const FrontParams &f)
+{
+  return deep_front4_variant (f) >= 0 && !tuning_on ("GSTAMD_NO_CONVERT16_FAST");
+}
+
+hipError_t launch_front_hscale16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ScaleDev &sd, uint8_t *dst, int dstride, int ow, hipStream_t stream)
+{
+  const dim3 grid ((ow + 255) / 256, f.height);
+  switch (deep_front4_variant (f)) {
+    case 0: hipLaunchKernelGGL ((k_front_hscale16<0, CHROMA_H_NONE>), grid, dim3 (256), 0, stream, f, pl, vpair_dev, sd, dst, dstride, ow); break;
+    case 1: hipLaunchKernelGGL ((k_front_hscale16<0, CHROMA_H_H2>), grid, dim3 (256), 0, stream, f, pl, vpair_dev, sd, dst, dstride, ow); break;
+    case 2: hipLaunchKernelGGL ((k_front_hscale16<0, CHROMA_H_H2_CS>), grid, dim3 (256), 0, stream, f, pl, vpair_dev, sd, dst, dstride, ow); break;
+    case 3: hipLaunchKernelGGL ((k_front_hscale16<1, CHROMA_H_NONE>), grid, dim3 (256), 0, stream, f, pl, vpair_dev, sd, dst, dstride, ow); break;
+    case 4: hipLaunchKernelGGL ((k_front_hscale16<1, CHROMA_H_H2>), grid, dim3 (256), 0, stream, f, pl, vpair_dev, sd, dst, dstride, ow); break;
+    default: hipLaunchKernelGGL ((k_front_hscale16<1, CHROMA_H_H2_CS>), grid, dim3 (256), 0, stream, f, pl, vpair_dev, sd, dst, dstride, ow); break;
+  }
+  return hipGetLastError ();
+}
+
+template <int SEMI, int CH>
 __global__ __launch_bounds__ (256) void k_front16_fast (FrontParams f, Planes pl, const int *__restrict__ vpair, uint8_t *__restrict__ img, int istride)
 {
   front16_fast_lane4<SEMI, CH> (f, pl, vpair, img, istride, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);

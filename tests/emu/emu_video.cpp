@@ -1356,7 +1356,25 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
       for (int x0 = 0; x0 < in_w; x0 += 4)
         front16_lane4 (p.front, pl, vpair, a.data (), in_w * 8, x0, y);
     Deep16Image cur = {a.data (), in_w * 8, in_w, in_h};
-    for (size_t i = 0; i < p.passes.size (); i++) {
+    size_t first = 0;
+    if (p.passes.size () == 2 && p.passes[0].horizontal && deep_front4_variant (p.front) >= 0 && !getenv ("EMU_NO_CONVERT16_FAST")) {
+      /* k_front_hscale16: the front inside the first, horizontal pass */
+      ScaleDev sd16;
+      memset (&sd16, 0, sizeof (sd16));
+      sd16.kind = p.passes[0].kind;
+      sd16.n_taps = p.passes[0].n_taps;
+      sd16.offset = p.passes[0].offset.data ();
+      sd16.taps = p.passes[0].taps.data ();
+      const int ow = p.passes[0].out_size;
+      b.assign ((size_t) ow * in_h * 8, 0);
+      for (int y = 0; y < in_h; y++)
+        for (int x = 0; x < (ow + 255) / 256 * 256; x++)
+          front_hscale16_any (deep_front4_variant (p.front), p.front, pl, vpair, sd16, b.data (), ow * 8, ow, x, y);
+      a.swap (b);
+      cur.p = a.data (), cur.stride = ow * 8, cur.width = ow, cur.height = in_h;
+      first = 1;
+    }
+    for (size_t i = first; i < p.passes.size (); i++) {
       const bool hz = p.passes[i].horizontal, last = i + 1 == p.passes.size ();
       const int ow = hz ? p.passes[i].out_size : cur.width, oh = hz ? cur.height : p.passes[i].out_size;
       ScaleDev sd16;

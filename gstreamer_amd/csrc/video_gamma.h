@@ -30,14 +30,30 @@ struct GammaDev {
 };
 
 // video_converter_matrix16 (video-converter.c:1296-1320) on the colour components of an ARGB64 pixel
+// rows of video_converter_matrix16 on 16-bit samples: v_mad_i32_i24 when every coefficient is a 24-bit operand (wave-uniform test), the 32-bit multiply
+// otherwise - the same low 32 bits either way
+GSTAMD_HD bool matrix16_fits24 (const Deep16Params &m)
+{
+  bool fits = true;
+  for (int k = 0; k < 3; k++)
+    for (int j = 0; j < 3; j++)
+      fits = fits && m.im[k][j] > -(1 << 23) && m.im[k][j] < (1 << 23);
+  return fits;
+}
+
+GSTAMD_HD int matrix16_row (const Deep16Params &m, bool fits24, int k, int r, int g, int b)
+{
+  const int s = fits24 ? mul24s (m.im[k][0], r) + mul24s (m.im[k][1], g) + mul24s (m.im[k][2], b) : m.im[k][0] * r + m.im[k][1] * g + m.im[k][2] * b;
+  return clampi ((s + m.im[k][3]) >> 8, 0, 65535);
+}
+
 GSTAMD_HD uint2 gamma_matrix16 (const Deep16Params &m, uint2 px)
 {
   if (!m.has_matrix)
     return px;
   const int r = (int) (px.x >> 16), gg = (int) (px.y & 0xffffu), b = (int) (px.y >> 16);
-  const int c1 = clampi ((m.im[0][0] * r + m.im[0][1] * gg + m.im[0][2] * b + m.im[0][3]) >> 8, 0, 65535);
-  const int c2 = clampi ((m.im[1][0] * r + m.im[1][1] * gg + m.im[1][2] * b + m.im[1][3]) >> 8, 0, 65535);
-  const int c3 = clampi ((m.im[2][0] * r + m.im[2][1] * gg + m.im[2][2] * b + m.im[2][3]) >> 8, 0, 65535);
+  const bool f24 = matrix16_fits24 (m);
+  const int c1 = matrix16_row (m, f24, 0, r, gg, b), c2 = matrix16_row (m, f24, 1, r, gg, b), c3 = matrix16_row (m, f24, 2, r, gg, b);
   uint2 o;
   o.x = (px.x & 0xffffu) | ((uint32_t) c1 << 16);
   o.y = (uint32_t) c2 | ((uint32_t) c3 << 16);
@@ -67,9 +83,10 @@ GSTAMD_HD uint2 gamma_mid_px (const GammaDev &g, uint2 px)
   int a = (int) (px.x & 0xffffu), c1 = (int) (px.x >> 16), c2 = (int) (px.y & 0xffffu), c3 = (int) (px.y >> 16);
   if (g.prim.has_matrix) {
     const int r = c1, gg = c2, b = c3;
-    c1 = clampi ((g.prim.im[0][0] * r + g.prim.im[0][1] * gg + g.prim.im[0][2] * b + g.prim.im[0][3]) >> 8, 0, 65535);
-    c2 = clampi ((g.prim.im[1][0] * r + g.prim.im[1][1] * gg + g.prim.im[1][2] * b + g.prim.im[1][3]) >> 8, 0, 65535);
-    c3 = clampi ((g.prim.im[2][0] * r + g.prim.im[2][1] * gg + g.prim.im[2][2] * b + g.prim.im[2][3]) >> 8, 0, 65535);
+    const bool f24 = matrix16_fits24 (g.prim);
+    c1 = matrix16_row (g.prim, f24, 0, r, gg, b);
+    c2 = matrix16_row (g.prim, f24, 1, r, gg, b);
+    c3 = matrix16_row (g.prim, f24, 2, r, gg, b);
   }
   if (g.alpha_kind == ALPHA_SET) {
     const unsigned v = g.alpha_value < 255u ? g.alpha_value : 255u;

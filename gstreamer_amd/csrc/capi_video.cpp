@@ -645,6 +645,7 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   Deep16Image cur = {nullptr, 0, 0, 0};
   bool mid_done = !has_mid;
   bool cur_is_source = false;           /* an ARGB64 / AYUV64 source frame is the first image: stages must not run in place on it */
+  size_t first_pass = 0;                /* 1: the first pass already ran, fused with the 16-bit front */
   if (g.src64) {
     if (!src_planes[0])
       return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
@@ -662,9 +663,25 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
         return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
       pl.p[i] += plane_origin (p.fin, i, p.rect.in_x, p.rect.in_y, pl.stride[i]);          /* the source crop (the vpair table knows the frame's rows) */
     }
-    if ((e = launch_front16 (p.front, pl, c->vpair_dev, c->deep_a, in_w * 8, stream)) != hipSuccess)
-      return hip_fail (e, "k_front16");
-    cur.p = c->deep_a, cur.stride = in_w * 8, cur.width = in_w, cur.height = in_h;
+    if (n >= 1 && p.passes[0].horizontal && !dec16 && (mid_done || g.shrink) && front_hscale16_usable (p.front)) {
+      /* nothing between the front and a first, horizontal pass: the front runs inside it (k_front_hscale16), no full-size AYUV64 image */
+      ScaleDev sd;
+      memset (&sd, 0, sizeof (sd));
+      sd.kind = p.passes[0].kind;
+      sd.n_taps = p.passes[0].n_taps;
+      sd.inc = p.passes[0].inc;
+      sd.offset = c->pass_dev[0].offset;
+      sd.taps = c->pass_dev[0].taps;
+      const int ow = p.passes[0].out_size;
+      if ((e = launch_front_hscale16 (p.front, pl, c->vpair_dev, sd, c->deep_b, ow * 8, ow, stream)) != hipSuccess)
+        return hip_fail (e, "k_front_hscale16");
+      cur.p = c->deep_b, cur.stride = ow * 8, cur.width = ow, cur.height = in_h;
+      first_pass = 1;
+    } else {
+      if ((e = launch_front16 (p.front, pl, c->vpair_dev, c->deep_a, in_w * 8, stream)) != hipSuccess)
+        return hip_fail (e, "k_front16");
+      cur.p = c->deep_a, cur.stride = in_w * 8, cur.width = in_w, cur.height = in_h;
+    }
   } else {
     void *ma[GSTAMD_VIDEO_MAX_PLANES] = {c->gamma_mid_a, nullptr, nullptr, nullptr};
     const int32_t mas[GSTAMD_VIDEO_MAX_PLANES] = {in_w * 4, 0, 0, 0};
@@ -707,7 +724,7 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       cur_is_source = false;
       mid_done = true;
     }
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = first_pass; i < n; i++) {
       ScaleDev sd;
       memset (&sd, 0, sizeof (sd));
       sd.kind = p.passes[i].kind;

@@ -168,6 +168,25 @@ def test_videoconvertscale_element_gray8(gst_env, ref):
         assert (c1.frame(mid[f]) == out[f]).all()
 
 
+def test_videoconvertscale_element_v210(gst_env, ref):
+    """v210 (SDI capture / playout) on either side through the generic 16-bit chain: BGRA -> v210 at another size, v210 -> BGRA"""
+    env, tmp = gst_env
+    w, h, n = 322, 242, 2
+    fin, fmid, fout = tmp / "v.bgra", tmp / "v.v210", tmp / "v.out"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=%d,height=%d "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw,format=v210,width=192,height=120,colorimetry=bt709 ! tee name=u "
+                "u. ! queue ! filesink location=%s u. ! queue ! videoconvertscale ! video/x-raw,format=BGRA,width=192,height=120 ! filesink location=%s"
+           % (n, w, h, fin, fmid, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    mid = np.fromfile(fmid, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    c0 = ref.VideoConverter("BGRA", w, h, "v210", 192, 120, out_colorimetry="bt709", config=cases.ref_config_string(ref, cases.LIN))
+    c1 = ref.VideoConverter("v210", 192, 120, "BGRA", 192, 120, in_colorimetry="bt709")
+    for f in range(n):
+        assert (c0.frame(src[f]) == mid[f]).all()
+        assert (c1.frame(mid[f]) == out[f]).all()
+
+
 def test_videoconvertscale_chroma_resampler_property(gst_env, ref):
     """`chroma-resampler` (gstvideoconvertscale.c:137, 345, 1076): the method of the chroma planes when a planar frame is scaled in its
     own format (convert_scale_planes) - cubic luma with nearest / lanczos chroma against the reference's chroma-resampler-method"""

@@ -1495,9 +1495,9 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
     b.src = pl.p[0], b.sstride = pl.stride[0], b.src_w = f.width, b.src_h = f.height;
     b.sel_in = (uint32_t) f.pos[0] | ((uint32_t) f.pos[1] << 8) | ((uint32_t) f.pos[2] << 16) | ((uint32_t) f.pos[3] << 24);
     b.sh = sh, b.sv = sv, b.h_first = h_first ? 1 : 0;
-    /* rows per lane: four amortise the per-column work when the destination is large; a small destination (4K -> 1080p: 130 000 lanes at four rows, two
-       waves per SIMD) needs the lanes more than the amortisation - every row of a lane starts with two dependent table reads */
-    b.out_w = out_w, b.out_h = out_h, b.rows = (long) out_w * out_h >= 6000000 ? 4 : ((long) out_w * out_h >= 3000000 ? 2 : 1);
+    /* rows per lane, measured: two for a 4K destination (BGRA 1080p -> 4K 31.0 us at four rows, 27.2 at two, 29.1 at one), one for smaller ones (4K ->
+       1080p: 130 000 lanes at four rows, two waves per SIMD - 29.2 us against 23.8): every row of a lane starts with two dependent table reads */
+    b.out_w = out_w, b.out_h = out_h, b.rows = (long) out_w * out_h >= 6000000 ? 2 : 1;
     hipLaunchKernelGGL (k_bilinear4_rows, dim3 (((out_w + 3) / 4 + 255) / 256, (out_h + b.rows - 1) / b.rows), dim3 (256), 0, stream, b, d, pf);
     return hipGetLastError ();
   }

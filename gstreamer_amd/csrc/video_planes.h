@@ -335,6 +335,33 @@ GSTAMD_HD uint32_t plane_scale2x2_pk (const SrcPlane &s, const ScaleDev &sh, con
 
 // planes that need nothing staged: pass-free kinds, one pass, or nearest / 2-tap in both directions.  One call per lane: outputs
 // x .. x + 3 of a row of the tile.
+// a pass that reads at most two source pixels per output: nearest, the 2-tap functions, or an N-tap filter of two taps (what `linear` with max-taps 2
+// gives the planes the reference's 2-tap functions do not serve - the UV plane of NV12)
+GSTAMD_VP bool plane_short_pass (const PlaneJob &J, int q) { return plane_small_kind (J.pass[q].kind) || (J.pass[q].kind == SCALE_NTAP && J.pass[q].n_taps <= 2); }
+
+GSTAMD_VP bool plane_job_is_direct (const PlaneJob &J)
+{
+  return J.kind != PLANE_SCALE || J.n_pass < 2 || (plane_short_pass (J, 0) && plane_short_pass (J, 1));
+}
+
+// the two passes composed per pixel on the plane itself (first pass's result = the clamped byte the reference keeps in its temporary line)
+struct PlaneHRows {
+  SrcPlane s;
+  const ScaleDev *sh;
+  GSTAMD_HD uint32_t at (int x, int y) const
+  {
+    const RowOfSrc<SrcPlane> row = {s, y};
+    return hscale_px (row, *sh, x);
+  }
+};
+
+struct PlaneVRow {
+  SrcPlane s;
+  const ScaleDev *sv;
+  int y;
+  GSTAMD_HD uint32_t at (int x) const { return vscale_px (s, *sv, x, y); }
+};
+
 GSTAMD_HD void plane_direct_body (const PlaneJob &J, int tile, int tid)
 {
   const int tx = tile % J.tiles_x, ty = tile / J.tiles_x;
@@ -355,8 +382,18 @@ GSTAMD_HD void plane_direct_body (const PlaneJob &J, int tile, int tid)
     /* nearest / 2-tap in both directions (the elements' default method): an output is a function of at most four source pixels - straight
        from memory, no staging, no barrier (scale2x2_px: the two passes with the first one's rounding in between, in the plan's order) */
     const ScaleDev &sh = J.pass[J.h_first ? 0 : 1], &sv = J.pass[J.h_first ? 1 : 0];
-    for (int i = 0; i < 4 && x + i < x1; i++)
-      px[i] = plane_scale2x2_pk (J.s, sh, sv, J.h_first, x + i, y);
+    if (plane_small_kind (sh.kind) && plane_small_kind (sv.kind)) {
+      for (int i = 0; i < 4 && x + i < x1; i++)
+        px[i] = plane_scale2x2_pk (J.s, sh, sv, J.h_first, x + i, y);
+    } else if (J.h_first) {          /* two-tap N-tap passes: V (H (plane)) or H (V (plane)) per pixel, at most four source pixels each */
+      const PlaneHRows rows = {J.s, &sh};
+      for (int i = 0; i < 4 && x + i < x1; i++)
+        px[i] = vscale_px (rows, sv, x + i, y);
+    } else {
+      const PlaneVRow row = {J.s, &sv, y};
+      for (int i = 0; i < 4 && x + i < x1; i++)
+        px[i] = hscale_px (row, sh, x + i);
+    }
   } else {
     const RowOfSrc<SrcPlane> row = {J.s, y};
     for (int i = 0; i < 4 && x + i < x1; i++)
@@ -366,11 +403,6 @@ GSTAMD_HD void plane_direct_body (const PlaneJob &J, int tile, int tid)
 }
 
 // does the plane go through plane_direct_body (host and device)
-GSTAMD_VP bool plane_job_is_direct (const PlaneJob &J)
-{
-  return J.kind != PLANE_SCALE || J.n_pass < 2 || (plane_small_kind (J.pass[0].kind) && plane_small_kind (J.pass[1].kind));
-}
-
 // two N-tap passes.  phase 0: source rectangle + table rows -> LDS; 1: first pass, LDS -> LDS; 2: second pass -> plane.  A barrier separates
 // the phases.
 GSTAMD_HD void plane_tile_body (const PlaneJob &J, uint8_t *lds, int tile, int tid, int phase)

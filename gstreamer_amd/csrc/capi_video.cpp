@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/gstamd_video.h"
@@ -18,7 +19,7 @@
 #include "video_fast.h"
 #include "video_encode_fast.h"
 #include "video_scale420_fused.h"
-#include "video_scale420_mfma.h"
+#include "video_scale_col.h"
 
 using namespace gstamd;
 
@@ -62,17 +63,19 @@ struct GstAmdVideoConverter {
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
   bool reg420 = false;                    // first pass horizontal from a 4:2:0 source whose chroma pairing is the closed form of h420r_rows
   int reg_lo = 0, reg_hi = 0;
+  // k_scale_col (video_scale_col.h): both N-tap passes of a regular 4:2:0 source in one kernel, a wave per column tile
+  bool col_ok = false;
+  ColTables col;
+  ColForm col_form;
+  int32_t *col_tiles_dev = nullptr;
+  uint32_t *col_hout_dev = nullptr, *col_vrow_dev = nullptr;
+  int col_waves = 0, col_per_cu = 0, col_cus = 0;
   // k_scale420_fused (video_scale420_fused.h): both N-tap passes of a regular 4:2:0 source in one kernel
   bool fused_ok = false;
   Fused420Tables fused;
   int32_t *vgroup_dev = nullptr;
   uint32_t *vtapw_dev = nullptr;
   int fused_waves = 0, fused_rpc = 0, fused_ring = 0, fused_first = 0, fused_sched = 1;
-  // k_scale420_mfma (video_scale420_mfma.h): the same with the horizontal pass on the matrix cores (64 source pixels per 16 outputs)
-  bool mfma_ok = false;
-  Mfma420Tables mfma;
-  uint32_t *btab_dev = nullptr;
-  int mfma_waves = 0, mfma_rpc = 0, mfma_ring = 0, mfma_tile_w = 0;
   uint8_t *deep_a = nullptr, *deep_b = nullptr;        /* scratch images of a scaled 10-bit conversion (convert_deep_scaled) */
   size_t deep_a_size = 0, deep_b_size = 0;
   /* gamma-mode = remap (GammaPlan): the two sub-conversions, the tables and the 8-bit images either side of the 16-bit part */
@@ -106,47 +109,10 @@ size_t fused420_lds_bytes (int ring, int nwaves, int sched);
 int fused420_blocks_per_cu (int nwaves, size_t lds, int sched);
 hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
     const int pack_pos[4], const PostFast &pf, hipStream_t stream);
-size_t mfma420_lds_bytes (int ring);
-int mfma420_blocks_per_cu (int nwaves, size_t lds);
-hipError_t launch_scale420_mfma (const Mfma420Params &p, int chroma_h, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
-    const int pack_pos[4], const PostFast &pf, hipStream_t stream);
-}
-
-// geometry of the matrix-core scaler: column tiles of whole 16-output blocks (as even as possible, <= 256 outputs), waves per
-// workgroup (each takes a 16-line block per round, a round finishes 4 x waves output rows at 4:1), rows per workgroup
-static bool mfma_pick_geometry (GstAmdVideoConverter *c)
-{
-  const int out_h = c->plan.out_info.height;
-  const int ew = tuning_int ("GSTAMD_MFMA_WAVES", 0), er = tuning_int ("GSTAMD_MFMA_ROWS", 0);
-  const int tiles = (c->mfma.n_blocks + 15) / 16, tile_blocks = (c->mfma.n_blocks + tiles - 1) / tiles;
-  int n_cu = 256, dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    n_cu = prop.multiProcessorCount;
-  for (int nwaves = ew > 0 ? ew : 4; nwaves >= 1; nwaves /= 2) {
-    if (nwaves > 4)
-      continue;
-    const int rpr = 4 * nwaves;
-    int ring = mfma420_ring_groups (c->fused, out_h, rpr);
-    const size_t lds = mfma420_lds_bytes (ring);
-    if (lds > 160 * 1024)
-      continue;
-    const int per_cu = mfma420_blocks_per_cu (nwaves, lds);
-    if (per_cu <= 0)
-      continue;
-    const int chunks = std::max (1, per_cu * n_cu / std::max (1, tiles));
-    int rpc = er > 0 ? er : (out_h + chunks - 1) / chunks;
-    rpc = std::max (rpc, rpr);
-    ring = mfma420_ring_groups (c->fused, rpc, rpr);
-    if (mfma420_lds_bytes (ring) > lds)
-      continue;
-    c->mfma_waves = nwaves;
-    c->mfma_rpc = rpc;
-    c->mfma_ring = ring;
-    c->mfma_tile_w = 16 * tile_blocks;
-    return true;
-  }
-  return false;
+size_t col_lds_bytes (const ColForm &f, int pubn, int nwaves);
+int col_blocks_per_cu (const ColForm &f, int chroma_h, int semi, int pubn, int nwaves);
+hipError_t launch_scale_col (const ColParams &p, const ColForm &f, int chroma_h, int semi, int nwaves, const ColFrames &fr, int n_frames, int dstride,
+    const ColorParams &post, const int pack_pos[4], const PostFast &pf, hipStream_t stream);
 }
 
 // geometry of the fused scaler: waves per workgroup, output rows per workgroup (every workgroup of the launch resident at once where
@@ -193,6 +159,51 @@ static bool fused_pick_geometry (GstAmdVideoConverter *c, int tiles)
       return true;
     }
   return false;
+}
+
+// waves per workgroup of the column-walk scaler: the most for which a CU still holds its full share of waves (occupancy query), so that
+// the workgroups' row runs are long and few groups are filtered twice at their seams.  GSTAMD_COL_WAVES pins it.
+static bool col_pick_waves (GstAmdVideoConverter *c)
+{
+  const VideoPlan &p = c->plan;
+  const int semi = p.front.kind == UNPACK_SEMI ? 1 : 0;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  c->col_cus = 256;
+  if (hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    c->col_cus = prop.multiProcessorCount;
+  const int pin = tuning_int ("GSTAMD_COL_WAVES", 0);
+  int best_waves = 0, best_cu_waves = 0, best_per_cu = 0;
+  for (int nwaves = GSTAMD_COL_MAX_WAVES; nwaves >= 1; nwaves--) {
+    if (pin > 0 && nwaves != pin)
+      continue;
+    const int per_cu = col_blocks_per_cu (c->col_form, p.front.chroma_h, semi, c->col.pubn, nwaves);
+    if (per_cu <= 0)
+      continue;
+    if (per_cu * nwaves > best_cu_waves) {
+      best_cu_waves = per_cu * nwaves;
+      best_waves = nwaves;
+      best_per_cu = per_cu;
+    }
+  }
+  c->col_waves = best_waves;
+  c->col_per_cu = best_per_cu;
+  return best_waves > 0;
+}
+
+// rows per wave / workgroup for a launch of n_frames frames: every workgroup of the launch resident at once where the picture allows it
+static void col_geometry (const GstAmdVideoConverter *c, int n_frames, ColParams *q)
+{
+  const int out_h = c->plan.out_info.height, tiles = (int) c->col.tiles.size () / 4;
+  const int pin = tuning_int ("GSTAMD_COL_CHUNKS", 0);
+  const int capacity = std::max (1, c->col_per_cu * c->col_cus);
+  int chunks = pin > 0 ? pin : std::max (1, capacity / std::max (1, tiles * n_frames));
+  int rpw = (out_h + chunks * c->col_waves - 1) / (chunks * c->col_waves);
+  rpw = std::max (rpw, c->col.min_rows_per_wave);
+  q->rows_per_wave = rpw;
+  q->rows_per_wg = rpw * c->col_waves;
+  q->n_chunks = (out_h + q->rows_per_wg - 1) / q->rows_per_wg;
+  q->n_tiles = tiles;
 }
 
 static bool fast_pair_usable (const VideoPlan &p, const Planes &pl, const uint8_t *dst, int dstride, int dalign = 16)
@@ -399,6 +410,30 @@ static int build_tables (GstAmdVideoConverter *c)
   for (size_t i = 0; i < p.passes.size (); i++)
     if (p.passes[i].horizontal)
       c->geom[i] = pass_tile_geom (p.passes[i]);
+  {
+    int lo, hi;
+    if (!tuning_on ("GSTAMD_NO_COL") && col_plan_regular (p, &lo, &hi) &&
+        col_choose (p.passes[0], p.passes[1], p.front.width, p.front.height, std::max (0, tuning_int ("GSTAMD_COL_OPL", 0)), tuning_int ("GSTAMD_COL_SHARE", 1) != 0,
+            &c->col, &c->col_form)) {
+      c->reg_lo = lo;
+      c->reg_hi = hi;
+      if (col_pick_waves (c)) {
+        if ((e = hipMalloc ((void **) &c->col_tiles_dev, (c->col.tiles.size () + 8) * sizeof (int32_t))) != hipSuccess ||
+            (e = hipMemset (c->col_tiles_dev, 0, (c->col.tiles.size () + 8) * sizeof (int32_t))) != hipSuccess ||
+            (e = hipMemcpy (c->col_tiles_dev, c->col.tiles.data (), c->col.tiles.size () * sizeof (int32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMalloc ((void **) &c->col_hout_dev, c->col.hout.size () * sizeof (uint32_t))) != hipSuccess ||
+            (e = hipMemcpy (c->col_hout_dev, c->col.hout.data (), c->col.hout.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMalloc ((void **) &c->col_vrow_dev, c->col.vrow.size () * sizeof (uint32_t))) != hipSuccess ||
+            (e = hipMemcpy (c->col_vrow_dev, c->col.vrow.data (), c->col.vrow.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
+          return hip_fail (e, "column scaler tables");
+        c->col_ok = true;
+        if (tuning_on ("GSTAMD_COL_DEBUG"))
+          fprintf (stderr, "k_scale_col: opl %d nw %d ngv %d wstep %d a8 %d (form %d %d %d %d) tiles %zu waves %d per_cu %d lds %zu pubn %d\n", c->col.opl, c->col.nw,
+              c->col.ngv, c->col.wstep, c->col.a8, c->col_form.nw, c->col_form.ngv, c->col_form.wstep, c->col_form.a8, c->col.tiles.size () / 4, c->col_waves,
+              c->col_per_cu, col_lds_bytes (c->col_form, c->col.pubn, c->col_waves), c->col.pubn);
+      }
+    }
+  }
   if (p.passes.size () == 2 && p.passes[0].horizontal && p.passes[0].kind == SCALE_NTAP && p.passes[0].dot4_ok && c->geom[0].tile16_w > 0 &&
       p.front.chroma_v2 && kind_has_planes (p.front.kind) && p.front.w_sub == 1 && p.front.h_sub == 1 && !p.matrix_before_scale &&
       (int) p.vpair.size () >= 2 * p.front.height) {
@@ -423,16 +458,6 @@ static int build_tables (GstAmdVideoConverter *c)
           (e = hipMemcpy (c->vtapw_dev, c->fused.vtapw.data (), c->fused.vtapw.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
         return hip_fail (e, "fused scaler tables");
       c->fused_ok = true;
-      /* the matrix-core form of the horizontal pass is parity-green but NOT the default: the MFMA operand layout puts 16 different
-       * lines in 16 neighbouring lanes, every load instruction then touches 16+ cache lines and costs ~64 texture-addresser
-       * cycles whatever its width - the kernel is bound by its 16 loads per block (70.8 us at C3 against 30.8 for the
-       * vector-ALU form; profiles/r02_c3_mfma_variants.log).  GSTAMD_MFMA420=1 selects it (tests, further work). */
-      if (tuning_on ("GSTAMD_MFMA420") && make_mfma420_tables (p.passes[0], &c->mfma) && mfma_pick_geometry (c)) {
-        if ((e = hipMalloc ((void **) &c->btab_dev, c->mfma.btab.size () * sizeof (uint32_t))) != hipSuccess ||
-            (e = hipMemcpy (c->btab_dev, c->mfma.btab.data (), c->mfma.btab.size () * sizeof (uint32_t), hipMemcpyHostToDevice)) != hipSuccess)
-          return hip_fail (e, "matrix-core scaler tables");
-        c->mfma_ok = true;
-      }
     }
   }
   if (p.passes.size () == 2) {
@@ -994,6 +1019,53 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
 
 // Does the plan take the direct 4:2:0 bilinear kernels (video_bilinear_fast.h / video_bilinear_rows.h)?  Fills everything of
 // BilParams that does not depend on a particular frame's pointers.
+// k_scale_col applies to these planes: the plan's tables exist, no colour step ahead of the scaler, U and V planes of one pitch
+static bool col_usable (const GstAmdVideoConverter *c, const Planes &pl, const ColorParams &pre)
+{
+  const VideoPlan &p = c->plan;
+  return c->col_ok && pre.matrix.kind == MATRIX_NONE && pre.alpha_kind == ALPHA_NONE &&
+      (p.front.kind == UNPACK_SEMI || pl.stride[p.front.u_plane] == pl.stride[p.front.v_plane]);
+}
+
+// n frames (source plane pointers src[f][0 .. 2], destinations dst[f]) of the strides of `pl`: launches of up to GSTAMD_COL_MAX_FRAMES frames
+static hipError_t col_launch (GstAmdVideoConverter *c, int n, const void *const (*src)[3], uint8_t *const *dst, const Planes &pl, int dstride, const ColorParams &post,
+    const PostFast &pf, hipStream_t stream)
+{
+  const VideoPlan &p = c->plan;
+  const bool semi = p.front.kind == UNPACK_SEMI;
+  ColParams q;
+  memset ((void *) &q, 0, sizeof (q));
+  q.ystride = pl.stride[0];
+  q.cstride = semi ? pl.stride[1] : pl.stride[p.front.u_plane];
+  q.width = p.front.width;
+  q.height = p.front.height;
+  q.u_first = p.front.u_plane != 0;
+  q.crow_lo = c->reg_lo;
+  q.crow_hi = c->reg_hi;
+  q.tiles = c->col_tiles_dev;
+  q.hout = c->col_hout_dev;
+  q.vrow = c->col_vrow_dev;
+  q.out_w = p.passes[0].out_size;
+  q.out_h = p.passes[1].out_size;
+  q.pubn = c->col.pubn;
+  for (int base = 0; base < n; base += GSTAMD_COL_MAX_FRAMES) {
+    const int nb = std::min (n - base, GSTAMD_COL_MAX_FRAMES);
+    col_geometry (c, nb, &q);
+    ColFrames fr;
+    memset ((void *) &fr, 0, sizeof (fr));
+    for (int f = 0; f < nb; f++) {
+      fr.y[f] = (const uint8_t *) src[base + f][0];
+      fr.c0[f] = (const uint8_t *) (semi ? src[base + f][1] : src[base + f][p.front.u_plane]);
+      fr.c1[f] = (const uint8_t *) (semi ? src[base + f][1] : src[base + f][p.front.v_plane]);
+      fr.dst[f] = dst[base + f];
+    }
+    const hipError_t e = launch_scale_col (q, c->col_form, p.front.chroma_h, semi ? 1 : 0, c->col_waves, fr, nb, dstride, post, p.post.pack_pos, pf, stream);
+    if (e != hipSuccess)
+      return e;           /* hipErrorNotSupported can only come from the first launch (alignment): nothing has run yet */
+  }
+  return hipSuccess;
+}
+
 static bool bilinear420_params (GstAmdVideoConverter *c, BilParams *out)
 {
   const VideoPlan &p = c->plan;
@@ -1320,6 +1392,14 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
         post, p.post.pack_pos, out_w, out_h, p.passes[0].max_span, c->geom[0], pf, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "scale pass");
   }
+  if (col_usable (c, pl, pre)) {
+    const void *sp[3] = {pl.p[0], pl.p[1], pl.p[2]};
+    e = col_launch (c, 1, &sp, &dst, pl, dstride, post, pf, stream);
+    if (e == hipSuccess)
+      return GSTAMD_OK;
+    if (e != hipErrorNotSupported)
+      return hip_fail (e, "k_scale_col");
+  }
   e = hipErrorNotSupported;
   const bool reg_usable = c->reg420 && pre.matrix.kind == MATRIX_NONE && pre.alpha_kind == ALPHA_NONE &&
       (p.front.kind == UNPACK_SEMI || pl.stride[p.front.u_plane] == pl.stride[p.front.v_plane]);
@@ -1361,21 +1441,6 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
       (void) hipMemset (fq.trace, 0, trace_n * 8);
 #endif
     e = hipErrorNotSupported;
-    if (c->mfma_ok) {
-      Mfma420Params mq;
-      mq.f = fq;
-      mq.f.h.tile_w = c->mfma_tile_w;
-      mq.f.rows_per_chunk = c->mfma_rpc;
-      mq.f.ring = c->mfma_ring;
-      mq.btab = (const uint4 *) c->btab_dev;
-      mq.d0 = c->mfma.d0;
-      mq.n_blocks = c->mfma.n_blocks;
-      e = launch_scale420_mfma (mq, p.front.chroma_h, c->mfma_waves, dst, dstride, post, p.post.pack_pos, pf, stream);
-      if (e == hipSuccess)
-        return GSTAMD_OK;
-      if (e != hipErrorNotSupported)
-        return hip_fail (e, "k_scale420_mfma");
-    }
     e = launch_scale420_fused (fq, p.front.chroma_h, sd[0].nw, c->fused_waves, dst, dstride, post, p.post.pack_pos, pf, stream);
 #ifdef GSTAMD_TUNING
     if (fq.trace) {
@@ -1516,6 +1581,37 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
         return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420(batch)");
     }
   }
+  /* ... and through the column-walk scaler (k_scale_col takes the frames as the grid's third dimension) */
+  if (c->col_ok && !p.rect.fill && p.rect.in_x == 0 && p.rect.in_y == 0 && p.rect.out_x == 0 && p.rect.out_y == 0 && !p.out_planar && !p.plane_mode &&
+      p.fout->kind == UNPACK_PACKED4 && p.fout->hi_depth == 0 && !p.matrix_before_scale) {
+    Planes pl0;
+    memset (&pl0, 0, sizeof (pl0));
+    for (int k = 0; k < p.in_info.n_planes && k < 3; k++)
+      pl0.stride[k] = p.in_info.stride[k];
+    ColorParams none_c, color;
+    memset (&none_c, 0, sizeof (none_c));
+    color.matrix = p.matrix;
+    color.alpha_kind = p.post.alpha_kind;
+    color.alpha_value = p.post.alpha_value;
+    if (col_usable (c, pl0, none_c)) {
+      std::vector<std::array<const void *, 3>> sp (n_frames);
+      for (int i = 0; i < n_frames; i++) {
+        if (!src[i] || !dest[i])
+          return set_error (GSTAMD_ERR_INVALID, "NULL frame in list");
+        for (int k = 0; k < 3; k++)
+          sp[i][k] = k < p.in_info.n_planes ? (const uint8_t *) src[i] + p.in_info.offset[k] : nullptr;
+        d[i] = (uint8_t *) dest[i] + p.out_info.offset[0];
+      }
+      PostFast pf;
+      pf.use = p.fast_post ? 1 : 0;
+      pf.fp = make_fast_params (p);
+      hipError_t e = col_launch (c, n_frames, (const void *const (*)[3]) sp.data (), d.data (), pl0, p.out_info.stride[0], color, pf, (hipStream_t) stream_);
+      for (int i = 0; i < n_frames && e == hipSuccess && p.dither.on; i++)
+        e = launch_dither4 (p.dither, d[i], p.out_info.stride[0], p.out_info.width, p.out_info.height, (hipStream_t) stream_, c->ed_carry);
+      if (e != hipErrorNotSupported)
+        return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_scale_col(batch)");
+    }
+  }
   for (int i = 0; i < n_frames; i++) {
     r = gstamd_video_converter_frame (c, src[i], dest[i], stream_);
     if (r != GSTAMD_OK)
@@ -1575,10 +1671,6 @@ static void release_tables (GstAmdVideoConverter *c)
     (void) hipFree (c->vgroup_dev);
   if (c->vtapw_dev)
     (void) hipFree (c->vtapw_dev);
-  if (c->btab_dev)
-    (void) hipFree (c->btab_dev);
-  c->btab_dev = nullptr;
-  c->mfma_ok = false;
   if (c->pk_img)
     (void) hipFree (c->pk_img);
   if (c->ed_carry)
@@ -1602,6 +1694,15 @@ static void release_tables (GstAmdVideoConverter *c)
     }
   c->plane_dev.clear ();
   c->fused_ok = false;
+  if (c->col_tiles_dev)
+    (void) hipFree (c->col_tiles_dev);
+  if (c->col_hout_dev)
+    (void) hipFree (c->col_hout_dev);
+  if (c->col_vrow_dev)
+    (void) hipFree (c->col_vrow_dev);
+  c->col_tiles_dev = nullptr;
+  c->col_hout_dev = c->col_vrow_dev = nullptr;
+  c->col_ok = false;
   c->reg420 = false;
   c->tables_ready = false;
 }

@@ -934,47 +934,234 @@ bool make_fused420_tables (const ScalePass &v, int height, Fused420Tables *t)
   return true;
 }
 
-bool make_mfma420_tables (const ScalePass &hp, Mfma420Tables *t)
+// ---- column-walk scaler (video_scale_col.h) ------------------------------------------------------------------------------------------
+namespace {
+struct ColWin { int lo, hi, sum; };         // first / last source index with a nonzero tap, sum of the taps
+
+// nonzero extent of every output's window; false: a tap outside int8, a sum outside [64, 128] (below 64 the alpha byte 0xff would
+// not survive the pass: (255 s + 32) >> 6 < 255; above 128 the 16-bit sum of the reference wraps for alpha), an extent that runs backwards
+bool col_windows (const ScalePass &p, int in_size, std::vector<ColWin> *w)
 {
-  if (!hp.horizontal || hp.kind != SCALE_NTAP || !hp.dot4_ok)
-    return false;
-  const int out_w = hp.out_size, n = hp.n_taps;
-  t->n_blocks = (out_w + 15) / 16;
-  /* d0 from a block in the middle of the line, then every block is checked against it */
-  const int mid = t->n_blocks / 2;
-  t->d0 = (int) (hp.offset[std::min (16 * mid, out_w - 1)] / 64) - mid;
-  t->btab.assign ((size_t) t->n_blocks * 3 * 64 * 4, 0);
-  for (int bg = 0; bg < t->n_blocks; bg++)
-    for (int col = 0; col < 16; col++) {
-      const int x = 16 * bg + col;
-      if (x >= out_w)
-        continue;
-      const int off = (int) hp.offset[x], lo = 64 * (bg + t->d0);
-      if (off < lo || off + n > lo + 64 * 3)
+  const int n = p.n_taps, out = p.out_size;
+  w->assign ((size_t) out, ColWin ());
+  for (int i = 0; i < out; i++) {
+    int f = -1, l = -1, sum = 0;
+    for (int k = 0; k < n; k++) {
+      const int t = p.taps[(size_t) i * n + k];
+      if (t < -128 || t > 127)
         return false;
-      for (int l = 0; l < n; l++) {
-        const int rel = off + l - lo, chunk = rel / 64, kg = (rel % 64) / 16, j = rel % 16, lane = 16 * kg + col;
-        const uint32_t b = (uint32_t) (uint8_t) (int8_t) hp.taps[(size_t) x * n + l];
-        t->btab[(((size_t) bg * 3 + chunk) * 64 + lane) * 4 + (j >> 2)] |= b << (8 * (j & 3));
+      sum += t;
+      if (t != 0) {
+        if (f < 0)
+          f = k;
+        l = k;
       }
     }
+    if (f < 0 || sum < 64 || sum > 128)
+      return false;
+    ColWin &cw = (*w)[(size_t) i];
+    cw.lo = (int) p.offset[(size_t) i] + f;
+    cw.hi = (int) p.offset[(size_t) i] + l;
+    cw.sum = sum;
+    if (cw.lo < 0 || cw.hi >= in_size || (i > 0 && (cw.lo < (*w)[(size_t) i - 1].lo || cw.hi < (*w)[(size_t) i - 1].hi)))
+      return false;
+  }
   return true;
 }
 
-int mfma420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int rows_per_round)
+int col_mod (int a, int m) { const int r = a % m; return r < 0 ? r + m : r; }
+
+struct ColHTry {
+  bool ok = false;
+  int nw = 0, wstep = -1, a8 = 0, words = 0;
+  std::vector<int32_t> tiles;
+  std::vector<int> wbase;         // per output (shared mode: the even output's base for both)
+};
+
+// greedy tiling for one alignment phase; share: the two outputs of a lane read one window (opl = 2)
+ColHTry col_try_h (const std::vector<ColWin> &hw, int width, int opl, int ph, int wstep, int cap = 0)
 {
-  const int out_h = (int) t.vgroup.size ();
-  int worst = 0;
-  for (int j0 = 0; j0 < out_h; j0 += rows_per_chunk) {
-    const int j1 = std::min (j0 + rows_per_chunk, out_h);
-    for (int jr = j0; jr < j1; jr += rows_per_round) {
-      const int jl = std::min (jr + rows_per_round, j1) - 1;
-      const int gh = std::min (t.vgroup[jl] + t.ngv - 1, t.n_groups - 1);
-      /* whole line blocks are written: from the block holding the round's first group to the block holding gh */
-      worst = std::max (worst, 4 * (gh >> 2) + 3 - 4 * (t.vgroup[jr] >> 2) + 1);
+  ColHTry r;
+  const int out_w = (int) hw.size (), pxl = 4 * opl, span = 64 * pxl, align = opl == 2 ? 8 : 4;
+  const bool share = wstep >= 0;
+  r.wbase.assign ((size_t) out_w, 0);
+  r.wstep = wstep;
+  r.a8 = share ? 1 : 0;
+  int x = 0;
+  while (x < out_w) {
+    int s0 = hw[(size_t) x].lo - col_mod (hw[(size_t) x].lo - ph, align);
+    if (share && x + 1 < out_w) {
+      /* the odd output's words start wstep words after the even one's: room for that in front of the tile's first pair */
+      const int b1 = (hw[(size_t) x + 1].lo - s0) & ~3;
+      if (b1 - 4 * wstep < 0)
+        s0 -= align;
+    }
+    int p0 = s0 > 0 ? s0 : 0;
+    if (p0 + span > width && col_mod (width - p0, pxl) != 0) {
+      /* the tile reaches the picture's right edge: its lanes load whole groups of pxl pixels, so the loads start a multiple of pxl from
+         the edge (the staged bytes then sit off their natural alignment in LDS, like the first tile's) */
+      s0 -= align;
+      p0 = s0 + col_mod (width - s0, pxl);
+      if (p0 < 0)
+        return r;
+    }
+    if (p0 - s0 > 16)            /* a staged plane is the span + 16 bytes */
+      return r;
+    int n = 0;
+    while (x + n < out_w && n < 64 * opl && (cap <= 0 || n < cap) && hw[(size_t) (x + n)].hi < p0 + span)
+      n++;
+    if (opl == 2 && x + n < out_w)
+      n &= ~1;
+    if (n <= 0)
+      return r;
+    for (int i = 0; i < n; i += share ? 2 : 1) {
+      const ColWin &w0 = hw[(size_t) (x + i)];
+      const int b0 = (w0.lo - s0) & ~3, e0 = (w0.hi - s0) & ~3;
+      if (!share) {
+        r.wbase[(size_t) (x + i)] = b0;
+        r.nw = std::max (r.nw, (e0 - b0) / 4 + 1);
+        continue;
+      }
+      int ub = b0, top = e0;
+      if (x + i + 1 < out_w && i + 1 < n) {
+        const ColWin &w1 = hw[(size_t) (x + i + 1)];
+        const int b1 = (w1.lo - s0) & ~3, e1 = (w1.hi - s0) & ~3;
+        ub = std::min (b0, b1 - 4 * wstep);
+        top = std::max (e0, e1 - 4 * wstep);
+        r.wbase[(size_t) (x + i + 1)] = ub;
+      }
+      if (ub < 0)
+        return r;
+      if (ub & 7)
+        r.a8 = 0;
+      r.wbase[(size_t) (x + i)] = ub;
+      r.nw = std::max (r.nw, (top - ub) / 4 + 1);
+    }
+    r.tiles.push_back (x);
+    r.tiles.push_back (n);
+    r.tiles.push_back (s0);
+    r.tiles.push_back (p0);
+    x += n;
+  }
+  r.words = share ? r.nw + wstep : opl * r.nw;      /* LDS words a lane reads per line and plane */
+  r.ok = r.nw <= 6;
+  return r;
+}
+}  // namespace
+
+bool make_col_tables (const ScalePass &h, const ScalePass &v, int width, int height, int opl, bool share, ColTables *t)
+{
+  if (!h.horizontal || v.horizontal || h.kind != SCALE_NTAP || v.kind != SCALE_NTAP || h.precision != 6 || v.precision != 6)
+    return false;
+  if ((opl != 1 && opl != 2) || (width % 4) != 0 || width < 16 * opl || height < 2 || h.in_size != width || v.in_size != height)
+    return false;
+  const int out_w = h.out_size, out_h = v.out_size;
+  if (opl == 2 && (out_w & 1))
+    return false;
+  std::vector<ColWin> hw, vw;
+  if (!col_windows (h, width, &hw) || !col_windows (v, height, &vw))
+    return false;
+  /* horizontal: the alignment phase and the window form with the fewest dot products per output, then the fewest LDS words, then tiles */
+  ColHTry best;
+  for (int ph = 0; ph < (opl == 2 ? 8 : 4); ph += 2)
+    for (int ws = -1; ws <= (opl == 2 && share ? 2 : -1); ws++) {
+      ColHTry c = col_try_h (hw, width, opl, ph, ws);
+      if (!c.ok)
+        continue;
+      /* the same number of tiles, evenly wide (the last tile of the greedy run is a stub, and every tile costs a wave column) */
+      const int nt = (int) c.tiles.size () / 4, even = ((out_w + nt - 1) / nt + opl - 1) / opl * opl;
+      ColHTry b = col_try_h (hw, width, opl, ph, ws, even);
+      if (b.ok && b.tiles.size () == c.tiles.size () && b.nw <= c.nw)
+        c = b;
+      const auto key = [](const ColHTry &a) { return std::make_tuple (a.nw, a.words - (a.a8 ? 1 : 0), (int) a.tiles.size ()); };
+      if (!best.ok || key (c) < key (best))
+        best = c;
+    }
+  if (!best.ok)
+    return false;
+  t->opl = opl;
+  t->nw = best.nw;
+  t->wstep = best.wstep;
+  t->a8 = best.a8;
+  t->tiles = best.tiles;
+  t->hout.assign ((size_t) out_w * 8, 0);
+  for (size_t ti = 0; ti < best.tiles.size (); ti += 4) {
+    const int o0 = best.tiles[ti], n = best.tiles[ti + 1], s0 = best.tiles[ti + 2];
+    for (int x = o0; x < o0 + n; x++) {
+      uint32_t *e = &t->hout[(size_t) x * 8];
+      int base = best.wbase[(size_t) x];
+      if (best.wstep >= 0 && ((x - o0) & 1))
+        base += 4 * best.wstep;           /* the odd output's own first word; the kernel reads from the even one's */
+      e[0] = (uint32_t) best.wbase[(size_t) x];
+      e[1] = (uint32_t) (128 * hw[(size_t) x].sum + 32);
+      for (int l = 0; l < h.n_taps; l++) {
+        const int tap = h.taps[(size_t) x * h.n_taps + l];
+        if (tap == 0)
+          continue;
+        const int b = (int) h.offset[(size_t) x] + l - s0 - base;
+        if (b < 0 || b >= 4 * best.nw)
+          return false;
+        e[2 + (b >> 2)] |= (uint32_t) (uint8_t) (int8_t) tap << (8 * (b & 3));
+      }
     }
   }
-  return worst;
+  /* vertical: line y sits in byte (y + 1) & 3 of group (y + 1) >> 2 */
+  t->n_groups = (height >> 2) + 1;
+  t->ngv = 0;
+  t->vrow.assign ((size_t) out_h * 8, 0);
+  for (int j = 0; j < out_h; j++) {
+    const int gf = (vw[(size_t) j].lo + 1) >> 2, gl = (vw[(size_t) j].hi + 1) >> 2;
+    t->ngv = std::max (t->ngv, gl - gf + 1);
+    if (gl - gf + 1 > 5)
+      return false;
+    uint32_t *e = &t->vrow[(size_t) j * 8];
+    e[0] = (uint32_t) gf;
+    e[1] = (uint32_t) gl;
+    e[2] = (uint32_t) (128 * vw[(size_t) j].sum + 32);
+    for (int l = 0; l < v.n_taps; l++) {
+      const int tap = v.taps[(size_t) j * v.n_taps + l];
+      if (tap == 0)
+        continue;
+      const int b = (int) v.offset[(size_t) j] + l + 1 - 4 * gf;
+      e[3 + (b >> 2)] |= (uint32_t) (uint8_t) (int8_t) tap << (8 * (b & 3));
+    }
+  }
+  t->pubn = 0;
+  for (int j = 1; j < out_h; j++)
+    t->pubn = std::max (t->pubn, (int) t->vrow[(size_t) (j - 1) * 8 + 1] - (int) t->vrow[(size_t) j * 8] + 1);
+  /* a wave owning rows [a, a + m) makes the groups [gfirst (a), gfirst (a + m)) and publishes [gfirst (a), glast (a - 1)] */
+  int m = 1;
+  for (; m < out_h; m++) {
+    bool ok = true;
+    for (int j = 1; j + m < out_h && ok; j++)
+      ok = (int) t->vrow[(size_t) (j + m) * 8] > (int) t->vrow[(size_t) (j - 1) * 8 + 1];
+    if (ok)
+      break;
+  }
+  t->min_rows_per_wave = m;
+  return true;
+}
+
+bool col_plan_regular (const VideoPlan &p, int *crow_lo, int *crow_hi)
+{
+  if (p.passes.size () != 2 || !p.passes[0].horizontal || p.passes[0].kind != SCALE_NTAP || p.passes[1].horizontal || p.passes[1].kind != SCALE_NTAP)
+    return false;
+  if (!kind_has_planes (p.front.kind) || p.front.w_sub != 1 || p.front.h_sub != 1 || !p.front.chroma_v2 || p.front.hi_depth != 0 || p.matrix_before_scale ||
+      p.front.swap_k >= 0 || (int) p.vpair.size () < 2 * p.front.height)
+    return false;
+  const int lo = -(p.rect.in_y >> 1), hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
+  for (int y = 0; y < p.front.height; y++) {
+    const int u = (y + 1) >> 1;
+    const int ra = std::min (std::max (u - 1, lo), hi), rb = std::min (std::max (u, lo), hi);
+    const int heavy = (y & 1) ? ra : rb, light = (y & 1) ? rb : ra;
+    const int e0 = p.vpair[(size_t) 2 * y], ta = vpair_row (e0), tb = p.vpair[(size_t) 2 * y + 1];
+    const int th = vpair_role (e0) == 0 ? ta : tb, tl = vpair_role (e0) == 0 ? tb : ta;
+    if (th != heavy || tl != light)
+      return false;
+  }
+  *crow_lo = lo;
+  *crow_hi = hi;
+  return true;
 }
 
 int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwaves, int first_rows)

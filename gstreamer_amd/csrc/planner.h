@@ -175,17 +175,35 @@ int fused420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int nwave
 int fused420_ring_groups2 (const Fused420Tables &t, int rows_per_chunk, int nwaves, int first_rows);
 int fused420_first_rows (const Fused420Tables &t, int nwaves);
 
-// B operands of the matrix-core horizontal pass (video_scale420_mfma.h): for every block of 16 outputs and each of its three
-// 64-pixel chunks, per lane (output n = lane & 15, pixels 64 c + 16 (lane >> 4) + j) the int8 taps, zero outside the window
-struct Mfma420Tables {
-  int d0;                         // block bg reads the chunks bg + d0 .. bg + d0 + 2
-  int n_blocks;
-  std::vector<uint32_t> btab;     // [n_blocks][3][64][4]
+// tables of the column-walk scaler (video_scale_col.h): both N-tap passes (horizontal first) of a 2x horizontally subsampled planar /
+// semi-planar source in one kernel, one WAVE per column tile walking down its rows.
+//   tiles[t] = {o0, n, s0, p0}: outputs [o0, o0 + n) of every row; the staged source span is the pixels [p0, p0 + 256 opl) and source
+//              pixel q sits at byte q - s0 of a staged byte plane (s0 <= p0, s0 < 0 only for the first tile: p0 = 0 then)
+//   hout[x]  = {wbase, init, tw[0 .. 5]}: byte offset (word aligned) of output x's first window word inside a staged plane, the accumulator's
+//              start value 128 * sum (taps) + 32, the int8 x 4 tap words (zero padded); with `wstep` >= 0 (opl = 2) the two outputs of a lane
+//              share ONE window of nw + wstep words from the even output's wbase, the odd output's words start wstep words in
+//   vrow[j]  = {gfirst, glast, init, 0, tw[0 .. 3]}: the line groups (lines 4g-1 .. 4g+2, byte = line) of row j's window with their tap words
+struct ColTables {
+  int opl;                        // outputs per lane: 1 (4 staged pixels per lane) or 2 (8)
+  int nw, ngv;                    // tap words per output (horizontal, <= 6) and per row (vertical, <= 4)
+  int wstep;                      // -1: every output reads its own nw words
+  int a8;                         // the shared window starts on an 8-byte boundary everywhere (two ds_read_b64 + ...)
+  int n_groups;
+  int pubn;                       // most groups the last row of a wave shares with the first row of the wave below
+  int min_rows_per_wave;          // fewest rows a wave may own for the hand-over of those groups to work (a wave publishes only groups it makes)
+  std::vector<int32_t> tiles;     // [n_tiles][4]
+  std::vector<uint32_t> hout;     // [out_w][8]
+  std::vector<uint32_t> vrow;     // [out_h][8]
 };
-// false: some block's windows do not fit its three chunks (not 64 source pixels per 16 outputs), or the pass has no int8 form
-bool make_mfma420_tables (const ScalePass &hpass, Mfma420Tables *t);
-// ring slots the matrix-core kernel needs: whole line blocks of four groups are produced, rounds of rows_per_round rows
-int mfma420_ring_groups (const Fused420Tables &t, int rows_per_chunk, int rows_per_round);
+// false: no byte form (a tap outside int8, a phase whose taps sum to less than 64 - the alpha byte would not stay 0xff -, windows too long)
+// share: let the two outputs of a lane read one window where that saves LDS traffic (opl = 2)
+bool make_col_tables (const ScalePass &hpass, const ScalePass &vpass, int width, int height, int opl, bool share, ColTables *t);
+
+// does the column-walk scaler apply to this plan?  Two N-tap passes, horizontal first, ahead of the convert stage, from an 8-bit planar /
+// semi-planar 4:2:0 source whose chroma line pairing is the closed form (lines 2u-1, 2u blend rows u-1 and u, clamped into
+// [*crow_lo, *crow_hi] = the frame's rows around a crop): what do_upsample_lines produces when every line is consumed in order
+struct VideoPlan;
+bool col_plan_regular (const VideoPlan &plan, int *crow_lo, int *crow_hi);
 
 // one destination plane of convert_scale_planes on a planar / semi-planar format
 enum PlaneKind : int { PLANE_COPY = 0, PLANE_H_HALVE, PLANE_H_DOUBLE, PLANE_V_HALVE, PLANE_V_DOUBLE, PLANE_HV_HALVE, PLANE_HV_DOUBLE, PLANE_SCALE,

@@ -6,6 +6,10 @@
 // them changes a result - every path they select is held to the same byte-exact tests.
 //
 //   name                     meaning (value)
+//   GSTAMD_NO_COL            the older fused / two-pass kernels instead of the column-walk scaler k_scale_col (set)
+//   GSTAMD_COL_OPL, GSTAMD_COL_SHARE, GSTAMD_COL_WAVES, GSTAMD_COL_CHUNKS, GSTAMD_COL_DEBUG
+//                            form and geometry of the column-walk scaler: outputs per lane (1 / 2), shared windows (0: off), waves per
+//                            workgroup, workgroups down a frame; DEBUG prints the choice
 //   GSTAMD_NO_FUSED420       two-pass form instead of the fused 4:2:0 N-tap scaler (set)
 //   GSTAMD_NO_H420_REG       general horizontal 4:2:0 kernel (pair table) instead of the regular-pairs one (set)
 //   GSTAMD_H420_ROWS         lines per wave of the horizontal 4:2:0 kernels (n; 0: kernel off)
@@ -25,8 +29,6 @@
 //                            geometry of the bilinear kernels (n)
 //   GSTAMD_FUSED_WAVES, GSTAMD_FUSED_ROWS, GSTAMD_FUSED_SCHED, GSTAMD_FUSED_FIRST, GSTAMD_FUSED_DEBUG
 //                            geometry / schedule of the fused scaler (n)
-//   GSTAMD_MFMA420, GSTAMD_MFMA_WAVES, GSTAMD_MFMA_ROWS
-//                            the matrix-core form of the fused scaler's horizontal pass (opt-in) and its geometry
 //   GSTAMD_NO_FIR_LDS        one-lane-per-sample FIR instead of the LDS-staged one (set)
 //   GSTAMD_SCALED_TILE_ROWS  rows per tile of k_aggregate_scaled (4 .. 16)
 //   GSTAMD_AGG_BX            workgroup width of k_aggregate (n)

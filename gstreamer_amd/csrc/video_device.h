@@ -27,6 +27,7 @@
 #ifdef __HIPCC__
 #define GSTAMD_HD __device__ __forceinline__
 #define gstamd_make_uint4 make_uint4
+#define gstamd_make_uint2 make_uint2
 #else
 #define GSTAMD_HD inline
 #ifndef __restrict__
@@ -35,6 +36,7 @@
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 gstamd_make_uint4 (uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 r = {x, y, z, w}; return r; }
+static inline uint2 gstamd_make_uint2 (uint32_t x, uint32_t y) { uint2 r = {x, y}; return r; }
 #endif
 
 namespace gstamd {

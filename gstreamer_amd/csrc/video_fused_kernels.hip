@@ -12,7 +12,6 @@
 #include "video_scale_fast.h"
 #include "video_hscale420.h"
 #include "video_scale420_fused.h"
-#include "video_scale420_mfma.h"
 
 namespace gstamd {
 
@@ -229,180 +228,6 @@ __global__ __launch_bounds__ (1024) void k_scale420_fused2 (Fused420Params p, Ds
     if (!ahead && k < n_rounds - 1)
       __syncthreads ();
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_scale420_mfma (video_scale420_mfma.h): the horizontal pass on v_mfma_i32_16x16x64_i8, the vertical pass and the ring as above
-// ------------------------------------------------------------------------------------------------
-typedef int mfma_v4i __attribute__ ((ext_vector_type (4)));
-
-static __device__ __forceinline__ mfma_v4i mfma_i8 (const uint4 &a, const uint4 &b, mfma_v4i c)
-{
-  const mfma_v4i va = {(int) a.x, (int) a.y, (int) a.z, (int) a.w}, vb = {(int) b.x, (int) b.y, (int) b.z, (int) b.w};
-  return __builtin_amdgcn_mfma_i32_16x16x64_i8 (va, vb, c, 0, 0, 0);
-}
-
-// one block of 16 outputs x 16 lines: three chunks against the block's taps, results into the ring
-static __device__ __forceinline__ void mfma_block (const Mfma420A &a0, const Mfma420A &a1, const Mfma420A &a2, const uint4 *b, uint32_t *ring_word)
-{
-  const mfma_v4i init = {128 * 64 + 32, 128 * 64 + 32, 128 * 64 + 32, 128 * 64 + 32};
-  mfma_v4i cy = mfma_i8 (a0.y, b[0], init), cu = mfma_i8 (a0.u, b[0], init), cv = mfma_i8 (a0.v, b[0], init);
-  cy = mfma_i8 (a1.y, b[1], cy), cu = mfma_i8 (a1.u, b[1], cu), cv = mfma_i8 (a1.v, b[1], cv);
-  cy = mfma_i8 (a2.y, b[2], cy), cu = mfma_i8 (a2.u, b[2], cu), cv = mfma_i8 (a2.v, b[2], cv);
-  ring_word[0] = mfma_group_word (cy.x, cy.y, cy.z, cy.w);
-  ring_word[256] = mfma_group_word (cu.x, cu.y, cu.z, cu.w);
-  ring_word[512] = mfma_group_word (cv.x, cv.y, cv.z, cv.w);
-}
-
-template <int CH, int SEMI, int NGV>
-__global__ __launch_bounds__ (256) void k_scale420_mfma (Mfma420Params p, Dst dst, PostFast pf)
-{
-  extern __shared__ uint32_t lds_w[];
-  uint32_t *ring = lds_w;
-  const int nwaves = (int) (blockDim.x >> 6);
-  const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6)), lane = (int) (threadIdx.x & 63);
-  const int col = lane & 15, kg = lane >> 4;
-  const int tile_blocks = p.f.h.tile_w >> 4;
-  const int B0 = (int) blockIdx.x * tile_blocks, B1 = B0 + tile_blocks < p.n_blocks ? B0 + tile_blocks : p.n_blocks;
-  const int t0 = 16 * B0, t1 = t0 + p.f.h.tile_w < p.f.h.out_w ? t0 + p.f.h.tile_w : p.f.h.out_w;
-  const int j0 = (int) blockIdx.y * p.f.rows_per_chunk;
-  const int j1 = j0 + p.f.rows_per_chunk < p.f.out_h ? j0 + p.f.rows_per_chunk : p.f.out_h;
-  const int rows_per_round = 4 * nwaves;
-  int gl, g_last;
-  fused_round_groups (p.f, j0, j1 - 1, &gl, &g_last);
-  int kb = (gl >> 2) + wave;              // this wave's next line block (lines 16 kb - 1 .. 16 kb + 14 = groups 4 kb .. 4 kb + 3)
-  for (int jr = j0; jr < j1; jr += rows_per_round) {
-    const int jl = (jr + rows_per_round < j1 ? jr + rows_per_round : j1) - 1;
-    int gl_r, gh;
-    fused_round_groups (p.f, jr, jl, &gl_r, &gh);
-    while (kb <= (gh >> 2)) {
-      Mfma420Rows rows;
-      mfma_rows (p.f.h, 16 * kb - 1 + col, rows);
-      int slot = (4 * kb) % p.f.ring + kg;
-      slot = slot >= p.f.ring ? slot - p.f.ring : slot;
-      uint32_t *rw = ring + (size_t) slot * GSTAMD_FUSED_GROUP_WORDS + col;
-      const uint4 *bt = p.btab + (size_t) B0 * (GSTAMD_MFMA_CHUNKS * 64) + lane;
-      Mfma420Loads qa, qb, q0, q1, q2;
-      Mfma420A a0, a1, a2;
-      uint4 bc[3], bn[3];
-      int c = B0 + p.d0;
-      // chunks c .. c + 4 on their way; the window slides one chunk per block, loads run three blocks ahead
-      mfma_request<SEMI> (p.f.h, rows, c, kg, qa);
-      mfma_request<SEMI> (p.f.h, rows, c + 1, kg, qb);
-      mfma_request<SEMI> (p.f.h, rows, c + 2, kg, q0);
-      mfma_request<SEMI> (p.f.h, rows, c + 3, kg, q1);
-      mfma_request<SEMI> (p.f.h, rows, c + 4, kg, q2);
-      bc[0] = bt[0], bc[1] = bt[64], bc[2] = bt[128];
-      mfma_make_a<CH, SEMI> (p.f.h, qa, a0);
-      mfma_make_a<CH, SEMI> (p.f.h, qb, a1);
-      // three blocks per turn: chunk registers, load buffers and tap registers keep fixed roles while the window slides
-#define MFMA_PIN_LOADS() do { asm volatile ("" ::: "memory"); __builtin_amdgcn_sched_barrier (0); } while (0)
-      MFMA_PIN_LOADS ();
-#define MFMA_STEP(k, A0, A1, A2, Q, BC, BN) \
-      { \
-        const int nb = bg + (k) + 1 < B1 ? (k) + 1 : (k);                /* next block's taps (the last block reloads its own) */ \
-        BN[0] = bt[(size_t) nb * (GSTAMD_MFMA_CHUNKS * 64)], BN[1] = bt[(size_t) nb * (GSTAMD_MFMA_CHUNKS * 64) + 64], \
-            BN[2] = bt[(size_t) nb * (GSTAMD_MFMA_CHUNKS * 64) + 128]; \
-        MFMA_PIN_LOADS ();              /* issued HERE: the scheduler otherwise sinks them to their use, a block later, and waits there */ \
-        mfma_make_a<CH, SEMI> (p.f.h, Q, A2); \
-        mfma_request<SEMI> (p.f.h, rows, c + 5 + (k), kg, Q); \
-        MFMA_PIN_LOADS (); \
-        mfma_block (A0, A1, A2, BC, rw + 16 * (k)); \
-      }
-      for (int bg = B0; bg < B1; bg += 3) {
-        MFMA_STEP (0, a0, a1, a2, q0, bc, bn)
-        if (bg + 1 >= B1)
-          break;
-        MFMA_STEP (1, a1, a2, a0, q1, bn, bc)
-        if (bg + 2 >= B1)
-          break;
-        MFMA_STEP (2, a2, a0, a1, q2, bc, bn)
-        // an odd number of steps per turn: the tap registers swap roles, put the next block's back into bc
-        bc[0] = bn[0], bc[1] = bn[1], bc[2] = bn[2];
-        c += 3;
-        bt += 3 * GSTAMD_MFMA_CHUNKS * 64;
-        rw += 48;
-      }
-#undef MFMA_STEP
-#undef MFMA_PIN_LOADS
-      kb += nwaves;
-    }
-    __syncthreads ();
-    for (int j = jr + wave; j <= jl; j += nwaves)
-      fused_vrow<NGV> (p.f, ring, dst, pf, j, t0, t1, lane);
-    __syncthreads ();
-  }
-}
-
-size_t mfma420_lds_bytes (int ring)
-{
-  return (size_t) ring * GSTAMD_FUSED_GROUP_WORDS * 4;
-}
-
-template <int CH, int SEMI>
-static hipError_t launch_mfma_ngv (const Mfma420Params &p, const Dst &d, const PostFast &pf, int nwaves, size_t lds, dim3 grid, hipStream_t stream)
-{
-#define GO(NGV) do { \
-    if (lds > 65536) { \
-      hipError_t e = hipFuncSetAttribute ((const void *) k_scale420_mfma<CH, SEMI, NGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-      if (e != hipSuccess) return e; \
-    } \
-    hipLaunchKernelGGL ((k_scale420_mfma<CH, SEMI, NGV>), grid, dim3 (64 * nwaves), lds, stream, p, d, pf); \
-  } while (0)
-  if (p.f.ngv == 5)
-    GO (5);
-  else
-    GO (0);
-#undef GO
-  return hipGetLastError ();
-}
-
-int mfma420_blocks_per_cu (int nwaves, size_t lds)
-{
-  int per_cu = 0;
-  const void *fn = (const void *) k_scale420_mfma<CHROMA_H_H2_CS, 0, 5>;
-  if (lds > 65536 && hipFuncSetAttribute (fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess)
-    return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, fn, 64 * nwaves, lds) != hipSuccess)
-    return 0;
-  return per_cu;
-}
-
-// hipErrorNotSupported: the caller takes k_scale420_fused
-hipError_t launch_scale420_mfma (const Mfma420Params &p, int chroma_h, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
-    const int pack_pos[4], const PostFast &pf, hipStream_t stream)
-{
-  const H420RegParams &h = p.f.h;
-  int ok = (h.width % 16) == 0 && ((uintptr_t) h.y % 16) == 0 && (h.ystride % 16) == 0 && ((uintptr_t) dst % 4) == 0 && (dstride % 4) == 0 &&
-      (h.tile_w % 16) == 0 && h.tile_w <= 256;
-  if (h.semi)
-    ok = ok && ((uintptr_t) h.c0 % 16) == 0 && (h.cstride % 16) == 0;
-  else
-    ok = ok && ((uintptr_t) h.c0 % 8) == 0 && ((uintptr_t) h.c1 % 8) == 0 && (h.cstride % 8) == 0;
-  const size_t lds = mfma420_lds_bytes (p.f.ring);
-  if (!ok || nwaves < 1 || nwaves > 8 || lds > 160 * 1024)
-    return hipErrorNotSupported;
-  Dst d;
-  d.p = dst;
-  d.stride = dstride;
-  d.final = 1;
-  d.post = post;
-  for (int i = 0; i < 4; i++)
-    d.pack_pos[i] = pack_pos[i];
-  const int tile_blocks = h.tile_w / 16, tiles = (p.n_blocks + tile_blocks - 1) / tile_blocks;
-  dim3 grid (tiles, (p.f.out_h + p.f.rows_per_chunk - 1) / p.f.rows_per_chunk);
-  if (h.semi) {
-    if (chroma_h == CHROMA_H_H2_CS)
-      return launch_mfma_ngv<CHROMA_H_H2_CS, 1> (p, d, pf, nwaves, lds, grid, stream);
-    if (chroma_h == CHROMA_H_H2)
-      return launch_mfma_ngv<CHROMA_H_H2, 1> (p, d, pf, nwaves, lds, grid, stream);
-    return launch_mfma_ngv<CHROMA_H_NONE, 1> (p, d, pf, nwaves, lds, grid, stream);
-  }
-  if (chroma_h == CHROMA_H_H2_CS)
-    return launch_mfma_ngv<CHROMA_H_H2_CS, 0> (p, d, pf, nwaves, lds, grid, stream);
-  if (chroma_h == CHROMA_H_H2)
-    return launch_mfma_ngv<CHROMA_H_H2, 0> (p, d, pf, nwaves, lds, grid, stream);
-  return launch_mfma_ngv<CHROMA_H_NONE, 0> (p, d, pf, nwaves, lds, grid, stream);
 }
 
 static inline bool aligned (const void *p, size_t a) { return ((uintptr_t) p & (a - 1)) == 0; }

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <memory>
 
 #include "../../gstreamer_amd/csrc/planner.h"
 #include "../../gstreamer_amd/csrc/video_device.h"
@@ -12,7 +13,7 @@
 #include "../../gstreamer_amd/csrc/video_scale_fast.h"
 #include "../../gstreamer_amd/csrc/video_hscale420.h"
 #include "../../gstreamer_amd/csrc/video_scale420_fused.h"
-#include "../../gstreamer_amd/csrc/video_scale420_mfma.h"
+#include "../../gstreamer_amd/csrc/video_scale_col.h"
 #include "../../gstreamer_amd/csrc/video_422_fast.h"
 #include <cstdlib>
 #include <algorithm>
@@ -236,6 +237,112 @@ static void run_h420_reg_ch (const H420RegParams &p, int chroma_h, int n_taps)
     run_h420_reg_ch2<NW, 0> (p, chroma_h, n_taps);
 }
 
+// ---- k_scale_col (video_col_kernels.hip): video_scale_col.h's col_wave with the 64 lanes of a wave run one after the other, the waves of a
+// workgroup from the bottom one up (a wave's hand-over copy exists before the wave above asks for it - on the device a flag says so) ----
+static int g_col_runs = 0;
+extern "C" int emu_col_runs (void) { return g_col_runs; }
+
+template <int OPL, int NW>
+struct ColExecEmu {
+  ColLane<OPL, NW> L[64];
+  ColRaw<OPL> ra[64], rb[64];
+  template <class F> void each (F f) { for (int lane = 0; lane < 64; lane++) f (lane, L[lane], ra[lane], rb[lane]); }
+  void sync () {}
+  void publish (uint32_t *flags, int wave) { flags[wave] = 1u; }
+  void wait_flag (uint32_t *flags, int wave)
+  {
+    if (!flags[wave]) {
+      fprintf (stderr, "emu k_scale_col: wave %d asks for a hand-over copy that was never published\n", wave);
+      abort ();
+    }
+  }
+};
+
+template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8>
+static void run_scale_col (const ColParams &p, const ColSrc &src, const Dst &dst, const PostFast &pf, int nwaves)
+{
+  const size_t wave_bytes = col_wave_bytes (OPL, NGV, p.pubn);
+  std::vector<uint32_t> lds_words ((GSTAMD_COL_FLAG_BYTES + (size_t) (nwaves + 1) * wave_bytes) / 4 + 16);
+  uint8_t *lds = (uint8_t *) lds_words.data ();
+  for (int chunk = 0; chunk < p.n_chunks; chunk++)
+    for (int ti = 0; ti < p.n_tiles; ti++) {
+      memset (lds, 0xa5, lds_words.size () * 4);          /* LDS holds whatever the last workgroup left: no result may depend on it */
+      uint32_t *flags = (uint32_t *) lds;
+      for (int w = 0; w < nwaves; w++)
+        flags[w] = 0;
+      for (int wave = nwaves - 1; wave >= 0; wave--) {
+        ColWavePlan wp;
+        if (!col_wave_plan (p, chunk, wave, &wp))
+          continue;
+        uint8_t *mine = lds + GSTAMD_COL_FLAG_BYTES + (size_t) wave * wave_bytes;
+        auto x = std::make_unique<ColExecEmu<OPL, NW>> ();
+        col_wave<OPL, NW, NGV, CH, SEMI, WSTEP, A8> (*x, p, src, p.tiles + 4 * ti, wp, mine, mine + wave_bytes, flags, wave, dst, pf);
+      }
+    }
+}
+
+template <int OPL, int NW, int NGV, int WSTEP, int A8>
+static void run_scale_col_src (const ColParams &p, int chroma_h, int semi, const ColSrc &src, const Dst &dst, const PostFast &pf, int nwaves)
+{
+  if (chroma_h == CHROMA_H_H2) {
+    if (semi) run_scale_col<OPL, NW, NGV, CHROMA_H_H2, 1, WSTEP, A8> (p, src, dst, pf, nwaves);
+    else run_scale_col<OPL, NW, NGV, CHROMA_H_H2, 0, WSTEP, A8> (p, src, dst, pf, nwaves);
+  } else {
+    if (semi) run_scale_col<OPL, NW, NGV, CHROMA_H_H2_CS, 1, WSTEP, A8> (p, src, dst, pf, nwaves);
+    else run_scale_col<OPL, NW, NGV, CHROMA_H_H2_CS, 0, WSTEP, A8> (p, src, dst, pf, nwaves);
+  }
+}
+
+// the decision of capi_video.cpp (build_tables + convert_to_packed) for k_scale_col
+static bool emu_scale_col (const VideoPlan &p, const SrcFront &sf, const Dst &dst, const PostFast &pf)
+{
+  int lo, hi;
+  if (getenv ("GSTAMD_NO_COL") || !col_plan_regular (p, &lo, &hi) || sf.pre.matrix.kind != MATRIX_NONE || sf.pre.alpha_kind != ALPHA_NONE)
+    return false;
+  const Planes &pl = sf.pl;
+  const bool semi = p.front.kind == UNPACK_SEMI;
+  if (!semi && pl.stride[p.front.u_plane] != pl.stride[p.front.v_plane])
+    return false;
+  ColTables t;
+  ColForm f;
+  const char *eo = getenv ("GSTAMD_COL_OPL"), *es = getenv ("GSTAMD_COL_SHARE");
+  if (!col_choose (p.passes[0], p.passes[1], p.front.width, p.front.height, eo ? atoi (eo) : 0, !(es && atoi (es) == 0), &t, &f))
+    return false;
+  if (((uintptr_t) dst.p % (4 * f.opl)) != 0 || (dst.stride % (4 * f.opl)) != 0)
+    return false;
+  const char *ew = getenv ("GSTAMD_COL_WAVES"), *er = getenv ("GSTAMD_COL_ROWS");
+  const int nwaves = ew && atoi (ew) > 0 ? std::min (atoi (ew), GSTAMD_COL_MAX_WAVES) : 3;
+  ColParams q;
+  memset ((void *) &q, 0, sizeof (q));
+  q.ystride = pl.stride[0];
+  q.cstride = semi ? pl.stride[1] : pl.stride[p.front.u_plane];
+  q.width = p.front.width;
+  q.height = p.front.height;
+  q.u_first = p.front.u_plane != 0;
+  q.crow_lo = lo;
+  q.crow_hi = hi;
+  q.tiles = t.tiles.data ();
+  q.hout = t.hout.data ();
+  q.vrow = t.vrow.data ();
+  q.out_w = p.passes[0].out_size;
+  q.out_h = p.passes[1].out_size;
+  q.n_tiles = (int) t.tiles.size () / 4;
+  q.rows_per_wave = std::max (t.min_rows_per_wave, er && atoi (er) > 0 ? atoi (er) : 5);
+  q.rows_per_wg = q.rows_per_wave * nwaves;
+  q.n_chunks = (q.out_h + q.rows_per_wg - 1) / q.rows_per_wg;
+  q.pubn = t.pubn;
+  ColSrc src;
+  src.y = pl.p[0];
+  src.c0 = semi ? pl.p[1] : pl.p[p.front.u_plane];
+  src.c1 = semi ? pl.p[1] : pl.p[p.front.v_plane];
+  g_col_runs++;
+#define V(o, n, g, w, a) if (f.opl == o && f.nw == n && f.ngv == g && f.wstep == w && f.a8 == a) { run_scale_col_src<o, n, g, w, a> (q, p.front.chroma_h, semi, src, dst, pf, nwaves); return true; }
+  GSTAMD_COL_FORMS (V)
+#undef V
+  g_col_runs--;
+  return false;
+}
+
 static bool emu_scale420_fused (const VideoPlan &p, H420RegParams hp, int nw, int n_taps_h, const Dst &dst, const PostFast &pf);
 // returns 1: the horizontal pass went to tmp, 2: the fused kernel rendered the final image, 0: not applicable
 static int emu_hscale420_reg (const VideoPlan &p, const SrcFront &sf, const ScaleDev &sd0, uint8_t *tmp, int tmp_w, const Dst *final_dst, const PostFast *pf)
@@ -452,124 +559,6 @@ static void run_fused420_ch (const Fused420Params &p, int chroma_h, const Dst &d
     run_fused420<NW, CHROMA_H_NONE, SEMI> (p, dst, pf, nwaves);
 }
 
-// k_scale420_mfma: v_mfma_i32_16x16x64_i8 restated (A: lane = row + 16 kgroup, B: lane = col + 16 kgroup, 16 int8 each;
-// C: lane = col + 16 (row / 4), reg = row % 4), then the kernel's loop structure wave by wave
-static int g_mfma_runs = 0;
-extern "C" int emu_mfma_runs (void) { return g_mfma_runs; }
-
-static void emu_mfma_i8 (const uint4 *a, const uint4 *b, int (*c)[4])
-{
-  for (int row = 0; row < 16; row++)
-    for (int col = 0; col < 16; col++) {
-      int sum = 0;
-      for (int kg = 0; kg < 4; kg++) {
-        const uint32_t *wa = &a[row + 16 * kg].x, *wb = &b[col + 16 * kg].x;
-        for (int j = 0; j < 16; j++)
-          sum += (int) (int8_t) (wa[j >> 2] >> (8 * (j & 3))) * (int) (int8_t) (wb[j >> 2] >> (8 * (j & 3)));
-      }
-      c[col + 16 * (row / 4)][row % 4] += sum;
-    }
-}
-
-template <int CH, int SEMI>
-static void run_mfma420 (const Mfma420Params &p, const Dst &dst, const PostFast &pf, int nwaves)
-{
-  const int tile_blocks = p.f.h.tile_w >> 4, tiles = (p.n_blocks + tile_blocks - 1) / tile_blocks;
-  const int chunks = (p.f.out_h + p.f.rows_per_chunk - 1) / p.f.rows_per_chunk, rpr = 4 * nwaves;
-  std::vector<uint32_t> ring ((size_t) p.f.ring * GSTAMD_FUSED_GROUP_WORDS);
-  for (int by = 0; by < chunks; by++)
-    for (int bx = 0; bx < tiles; bx++) {
-      memset (ring.data (), 0xAB, ring.size () * 4);
-      const int B0 = bx * tile_blocks, B1 = std::min (B0 + tile_blocks, p.n_blocks);
-      const int t0 = 16 * B0, t1 = std::min (t0 + p.f.h.tile_w, p.f.h.out_w);
-      const int j0 = by * p.f.rows_per_chunk, j1 = std::min (j0 + p.f.rows_per_chunk, p.f.out_h);
-      int gl, g_last;
-      fused_round_groups (p.f, j0, j1 - 1, &gl, &g_last);
-      std::vector<int> kbw (nwaves);
-      for (int w = 0; w < nwaves; w++)
-        kbw[w] = (gl >> 2) + w;
-      for (int jr = j0; jr < j1; jr += rpr) {
-        const int jl = std::min (jr + rpr, j1) - 1;
-        int gl_r, gh;
-        fused_round_groups (p.f, jr, jl, &gl_r, &gh);
-        for (int w = 0; w < nwaves; w++)
-          for (int &kb = kbw[w]; kb <= (gh >> 2); kb += nwaves)
-            for (int bg = B0; bg < B1; bg++) {
-              uint4 a[3][3][64], b[3][64];         /* [chunk][plane][lane] */
-              for (int i = 0; i < 3; i++)
-                for (int lane = 0; lane < 64; lane++) {
-                  Mfma420Rows rows;
-                  Mfma420Loads q;
-                  Mfma420A aa;
-                  mfma_rows (p.f.h, 16 * kb - 1 + (lane & 15), rows);
-                  mfma_request<SEMI> (p.f.h, rows, bg + p.d0 + i, lane >> 4, q);
-                  mfma_make_a<CH, SEMI> (p.f.h, q, aa);
-                  a[i][0][lane] = aa.y, a[i][1][lane] = aa.u, a[i][2][lane] = aa.v;
-                  b[i][lane] = p.btab[((size_t) bg * 3 + i) * 64 + lane];
-                }
-              for (int pl = 0; pl < 3; pl++) {
-                int c[64][4];
-                for (int lane = 0; lane < 64; lane++)
-                  c[lane][0] = c[lane][1] = c[lane][2] = c[lane][3] = 128 * 64 + 32;
-                for (int i = 0; i < 3; i++)
-                  emu_mfma_i8 (a[i][pl], b[i], c);
-                for (int lane = 0; lane < 64; lane++) {
-                  int slot = (4 * kb) % p.f.ring + (lane >> 4);
-                  slot = slot >= p.f.ring ? slot - p.f.ring : slot;
-                  ring[(size_t) slot * GSTAMD_FUSED_GROUP_WORDS + 256 * pl + 16 * (bg - B0) + (lane & 15)] =
-                      mfma_group_word (c[lane][0], c[lane][1], c[lane][2], c[lane][3]);
-                }
-              }
-            }
-        for (int j = jr; j <= jl; j++)
-          for (int lane = 0; lane < 64; lane++) {
-            if (p.f.ngv == 5)
-              fused_vrow<5> (p.f, ring.data (), dst, pf, j, t0, t1, lane);
-            else
-              fused_vrow<0> (p.f, ring.data (), dst, pf, j, t0, t1, lane);
-          }
-      }
-    }
-}
-
-static bool emu_scale420_mfma (const VideoPlan &p, const H420RegParams &hp, int n_taps_h, const Fused420Tables &t, const Dst &dst, const PostFast &pf)
-{
-  Mfma420Tables m;
-  if (!getenv ("GSTAMD_MFMA420") || !make_mfma420_tables (p.passes[0], &m))
-    return false;
-  const char *ew = getenv ("GSTAMD_MFMA_WAVES"), *er = getenv ("GSTAMD_MFMA_ROWS");
-  const int nwaves = ew && atoi (ew) > 0 ? atoi (ew) : 4, rpr = 4 * nwaves;
-  const int tiles = (m.n_blocks + 15) / 16, tile_blocks = (m.n_blocks + tiles - 1) / tiles;
-  Mfma420Params q;
-  memset (&q, 0, sizeof (q));
-  q.f.h = hp;
-  q.f.h.tile_w = 16 * tile_blocks;
-  q.f.n_taps_h = n_taps_h;
-  q.f.vgroup = t.vgroup.data ();
-  q.f.vtapw = t.vtapw.data ();
-  q.f.ngv = t.ngv;
-  q.f.out_h = p.out_info.height;
-  q.f.rows_per_chunk = std::max (rpr, er && atoi (er) > 0 ? atoi (er) : 37);
-  q.f.ring = mfma420_ring_groups (t, q.f.rows_per_chunk, rpr);
-  q.f.n_groups = t.n_groups;
-  q.btab = (const uint4 *) m.btab.data ();
-  q.d0 = m.d0;
-  q.n_blocks = m.n_blocks;
-  if (((uintptr_t) m.btab.data () % 16) != 0)
-    return false;
-  g_mfma_runs++;
-  if (hp.semi) {
-    if (p.front.chroma_h == CHROMA_H_H2_CS) run_mfma420<CHROMA_H_H2_CS, 1> (q, dst, pf, nwaves);
-    else if (p.front.chroma_h == CHROMA_H_H2) run_mfma420<CHROMA_H_H2, 1> (q, dst, pf, nwaves);
-    else run_mfma420<CHROMA_H_NONE, 1> (q, dst, pf, nwaves);
-  } else {
-    if (p.front.chroma_h == CHROMA_H_H2_CS) run_mfma420<CHROMA_H_H2_CS, 0> (q, dst, pf, nwaves);
-    else if (p.front.chroma_h == CHROMA_H_H2) run_mfma420<CHROMA_H_H2, 0> (q, dst, pf, nwaves);
-    else run_mfma420<CHROMA_H_NONE, 0> (q, dst, pf, nwaves);
-  }
-  return true;
-}
-
 // the decision of capi_video.cpp (ensure_tables + convert_to_packed) for k_scale420_fused; hp = the k_hscale420_reg parameters
 static bool emu_scale420_fused (const VideoPlan &p, H420RegParams hp, int nw, int n_taps_h, const Dst &dst, const PostFast &pf)
 {
@@ -578,8 +567,6 @@ static bool emu_scale420_fused (const VideoPlan &p, H420RegParams hp, int nw, in
   Fused420Tables t;
   if (!make_fused420_tables (p.passes[1], p.front.height, &t))
     return false;
-  if (((uintptr_t) dst.p % 4) == 0 && (dst.stride % 4) == 0 && emu_scale420_mfma (p, hp, n_taps_h, t, dst, pf))
-    return true;
   const char *ew = getenv ("GSTAMD_FUSED_WAVES"), *er = getenv ("GSTAMD_FUSED_ROWS");
   const int nwaves = ew && atoi (ew) > 0 ? atoi (ew) : 8;
   const int rpc = std::max (nwaves, er && atoi (er) > 0 ? atoi (er) : 17);
@@ -1749,6 +1736,8 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
   const int tw = s0.horizontal ? s0.out_size : p.in_info.width, th = s0.horizontal ? p.in_info.height : s0.out_size;
   std::vector<uint8_t> tmp ((size_t) tw * 4 * (th + 1));
   const Dst final_dst = mk (d0, dstride, true);
+  if (emu_scale_col (p, sf, final_dst, pf))
+    return GSTAMD_OK;
   const int reg = emu_hscale420_reg (p, sf, sd[0], tmp.data (), tw, &final_dst, &pf);
   if (reg == 2)
     return GSTAMD_OK;

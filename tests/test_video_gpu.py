@@ -160,20 +160,53 @@ def test_hip_frame_list_32x4k_matches_reference(native_lib, gpu, ref):
     conv.free()
 
 
-MFMA_SHAPES = [("I420", 7680, 4320, "RGBA", 1920, 1080), ("NV12", 1280, 720, "BGRA", 320, 180), ("NV21", 1920, 1080, "RGBA", 480, 270),
-               ("YV12", 640, 359, "BGRA", 160, 90), ("I420", 2048, 856, "ARGB", 512, 214)]
+COL_SHAPES = [("I420", 7680, 4320, "RGBA", 1920, 1080), ("NV12", 1280, 720, "BGRA", 320, 180), ("NV21", 1920, 1080, "RGBA", 480, 270),
+              ("YV12", 640, 359, "BGRA", 160, 90), ("I420", 2048, 856, "ARGB", 512, 214), ("NV12", 3840, 2160, "BGRA", 1920, 1080),
+              ("NV12", 3840, 2160, "BGRA", 1280, 720), ("I420", 1920, 1080, "BGRx", 1280, 720)]
+# (outputs per lane, shared windows, waves per workgroup, workgroups down the frame): 0 = the library's own choice
+COL_KNOBS = [(0, 1, 0, 0), (1, 1, 8, 0), (1, 1, 1, 0), (2, 1, 4, 0), (2, 0, 2, 3), (2, 1, 8, 1)]
 
 
-@pytest.mark.parametrize("shape", MFMA_SHAPES, ids=lambda s: "%s_%dx%d" % (s[0], s[1], s[2]))
-def test_hip_scale420_mfma_matches_reference_bytewise(native_lib, gpu, ref, shape):
-    """k_scale420_mfma (4:1 horizontal pass on v_mfma_i32_16x16x64_i8; opt-in, see capi_video.cpp) memcmp'd against the reference:
-    C3 at its own size, both plane layouts, odd height, several tiles."""
+@pytest.mark.parametrize("knobs", COL_KNOBS, ids=lambda k: "opl%d_share%d_waves%d_chunks%d" % k)
+@pytest.mark.parametrize("shape", COL_SHAPES, ids=lambda s: "%s_%dx%d_%dx%d" % (s[0], s[1], s[2], s[4], s[5]))
+def test_hip_scale_col_matches_reference_bytewise(native_lib, gpu, ref, shape, knobs):
+    """k_scale_col (video_scale_col.h) memcmp'd against the reference: C3 at its own size, both plane layouts, odd height, several tiles,
+    2:1 / 3:1 / 1.5:1, either number of outputs per lane, shared and private windows, one-wave and eight-wave workgroups (the hand-over
+    of line groups between the waves of a workgroup through LDS flags is what only the device can show), one workgroup per column."""
     ifmt, w, h, ofmt, ow, oh = shape
     src = cases.frame_bytes(ref.video_info(ifmt, w, h)["size"], "random", 31 + w)
     exp = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, cases.LAN)).frame(src)
-    with V.tuning(GSTAMD_MFMA420=1):
+    kw = {}
+    if knobs[0]:
+        kw["GSTAMD_COL_OPL"] = knobs[0]
+    kw["GSTAMD_COL_SHARE"] = knobs[1]
+    if knobs[2]:
+        kw["GSTAMD_COL_WAVES"] = knobs[2]
+    if knobs[3]:
+        kw["GSTAMD_COL_CHUNKS"] = knobs[3]
+    with V.tuning(**kw):
         out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LAN, None, None, src)
     assert (out == exp).all(), int((out != exp).sum())
+
+
+def test_hip_scale_col_frame_list_is_one_grid(native_lib, gpu, ref):
+    """a list of frames through k_scale_col (the frames are the grid's third dimension; 18 frames: two launches) == the reference frame by frame"""
+    ifmt, w, h, ofmt, ow, oh = "NV12", 1920, 1080, "BGRA", 960, 540
+    n = 18
+    ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)
+    conv = V.VideoConverter(ii, oi, V.converter_config(**cases.LAN))
+    rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, cases.LAN))
+    srcs, outs, exp = [], [], []
+    for i in range(n):
+        b = cases.frame_bytes(ii.size, "random", 900 + i)
+        exp.append(cases.sha(rc.frame(b)))
+        srcs.append(torch.from_numpy(b).to(gpu))
+        outs.append(torch.zeros(oi.size, dtype=torch.uint8, device=gpu))
+    conv.frames(srcs, outs)
+    torch.cuda.synchronize()
+    got = [cases.sha(o.cpu().numpy()) for o in outs]
+    assert got == exp, [i for i in range(n) if got[i] != exp[i]]
+    conv.free()
 
 
 BILR_SHAPES = [("NV12", 3840, 2160, "BGRA", 1920, 1080, None), ("NV12", 1920, 1080, "RGBA", 1280, 720, None), ("I420", 2048, 858, "ARGB", 1024, 429, "jpeg"),

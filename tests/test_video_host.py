@@ -209,6 +209,7 @@ def test_hscale420_bodies_any_rows_per_wave(native_lib, emu_lib, idx_case, rows,
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     monkeypatch.setenv("GSTAMD_H420_ROWS", str(rows))
     monkeypatch.setenv("GSTAMD_NO_H420_REG", "1")
+    monkeypatch.setenv("GSTAMD_NO_COL", "1")
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     before = emu_lib.emu_h420_runs()
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
@@ -226,7 +227,8 @@ def test_hscale420_reg_bodies_any_lines_per_wave(native_lib, emu_lib, idx_case, 
     chroma site included; the path must be the one taken for these 4:2:0 cases."""
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     monkeypatch.setenv("GSTAMD_H420_ROWS", str(rows))
-    monkeypatch.setenv("GSTAMD_NO_FUSED420", "1")           # the two-pass form (the fused scaler is tested below)
+    monkeypatch.setenv("GSTAMD_NO_FUSED420", "1")           # the two-pass form (the fused scalers are tested below)
+    monkeypatch.setenv("GSTAMD_NO_COL", "1")
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     before = emu_lib.emu_h420_reg_runs()
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
@@ -243,6 +245,7 @@ def test_scale420_fused_bodies_any_geometry(native_lib, emu_lib, idx_case, geom,
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     monkeypatch.setenv("GSTAMD_FUSED_WAVES", str(geom[0]))
     monkeypatch.setenv("GSTAMD_FUSED_ROWS", str(geom[1]))
+    monkeypatch.setenv("GSTAMD_NO_COL", "1")
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     emu_lib.emu_fused_runs.restype = C.c_int
     before, before_reg = emu_lib.emu_fused_runs(), emu_lib.emu_h420_reg_runs()
@@ -253,6 +256,7 @@ def test_scale420_fused_bodies_any_geometry(native_lib, emu_lib, idx_case, geom,
 
 def test_scale420_fused_is_taken_for_the_c3_shape(native_lib, emu_lib, monkeypatch):
     name = "i420_rgba_quarter_lanczos"
+    monkeypatch.setenv("GSTAMD_NO_COL", "1")
     _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     before = emu_lib.emu_fused_runs()
@@ -261,24 +265,40 @@ def test_scale420_fused_is_taken_for_the_c3_shape(native_lib, emu_lib, monkeypat
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
 
 
-MFMA_CASES = [c for c in SMALL if c[1][0] in ("nv12_bgra_quarter_lanczos", "i420_rgba_quarter_lanczos")]
+# (outputs per lane, shared windows, waves per workgroup, rows per wave): one-wave workgroups (no hand-over), the smallest runs the
+# hand-over allows, long runs (one workgroup for the picture)
+COL_GEOMS = [(0, 1, 3, 5), (1, 1, 1, 4), (1, 1, 8, 1), (2, 1, 4, 3), (2, 0, 2, 7), (2, 1, 1, 1000), (1, 1, 5, 1000), (2, 1, 8, 2)]
 
 
-@pytest.mark.parametrize("geom", [(4, 37), (1, 4), (2, 8), (4, 1000), (3, 13)], ids=lambda g: "waves%d_rows%d" % g)
-@pytest.mark.parametrize("idx_case", MFMA_CASES, ids=lambda c: c[1][0])
-def test_scale420_mfma_bodies_any_geometry(native_lib, emu_lib, idx_case, geom, monkeypatch):
-    """k_scale420_mfma (video_scale420_mfma.h): the 4:1 horizontal pass as v_mfma_i32_16x16x64_i8 over 64-pixel chunks (restated
-    on the host with the instruction's lane maps), ring + vertical pass of the fused scaler - the reference's bytes for any
-    waves / rows split, both plane layouts; with GSTAMD_MFMA420=1 it must be the path taken at 4:1."""
+@pytest.mark.parametrize("geom", COL_GEOMS, ids=lambda g: "opl%d_share%d_waves%d_rows%d" % g)
+@pytest.mark.parametrize("idx_case", H420_REG, ids=lambda c: c[1][0])
+def test_scale_col_bodies_any_geometry(native_lib, emu_lib, idx_case, geom, monkeypatch):
+    """k_scale_col (video_scale_col.h: a wave per column tile walks down the source in groups of four lines, horizontal pass from byte
+    planes in LDS, vertical pass down the lane's own ring words, the groups at the seam of two waves handed over through LDS) gives the
+    reference's bytes for either number of outputs per lane, shared and private windows, any waves-per-workgroup / rows-per-wave split,
+    crop and chroma sites included; where both passes are N-tap it must be the path taken."""
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
-    monkeypatch.setenv("GSTAMD_MFMA420", "1")               # opt-in: the vector-ALU form is the default (see capi_video.cpp)
-    monkeypatch.setenv("GSTAMD_MFMA_WAVES", str(geom[0]))
-    monkeypatch.setenv("GSTAMD_MFMA_ROWS", str(geom[1]))
+    monkeypatch.setenv("GSTAMD_COL_OPL", str(geom[0]))
+    monkeypatch.setenv("GSTAMD_COL_SHARE", str(geom[1]))
+    monkeypatch.setenv("GSTAMD_COL_WAVES", str(geom[2]))
+    monkeypatch.setenv("GSTAMD_COL_ROWS", str(geom[3]))
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
-    emu_lib.emu_mfma_runs.restype = C.c_int
-    before = emu_lib.emu_mfma_runs()
+    emu_lib.emu_col_runs.restype = C.c_int
+    before = emu_lib.emu_col_runs()
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
-    assert emu_lib.emu_mfma_runs() == before + 1
+    ran = emu_lib.emu_col_runs() - before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+    if name in ("nv12_bgra_quarter_lanczos", "i420_rgba_quarter_lanczos", "nv12_bgra_h420_cubic_down"):
+        assert ran == 1, name
+
+
+def test_scale_col_is_taken_for_the_c3_shape(native_lib, emu_lib):
+    name = "i420_rgba_quarter_lanczos"
+    _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    before = emu_lib.emu_col_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_col_runs() == before + 1
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
 
 

@@ -354,18 +354,28 @@ GSTAMD_HD void col_first_row (const ColParams &p, const ColSrc &s, ColLane<OPL, 
   col_hup<OPL, NW, CH, SEMI> (L, c, L.hu, L.hv);
 }
 
+// Two gfx950 hazards the compiler does not see inside inline asm (both found on the device: bytes off by a few units in rows whose last
+// tap word is not zero): (1) a VALU instruction that writes PART of a register (SDWA dst_sel other than DWORD) needs one wait state before
+// a VALU instruction reads that register; (2) the result of a dot-product instruction (v_dot4c_i32_i8) may be read by a VALU instruction
+// of another kind only three wait states later - an earlier read sees the accumulator WITHOUT the last product.  The sequences below are
+// single asm blocks that start with s_nop 2 (their inputs come straight from dot products), keep an independent instruction between every
+// pair of the first kind, and end in s_nop 0 for whatever reads the result next.
+//
 // four 16-bit wrapping sums -> ((int16) sum >> 6) clamped to a byte each, byte k = sum k, XOR 0x80: a ring word
 GSTAMD_HD uint32_t col_fin4 (int a0, int a1, int a2, int a3)
 {
 #ifdef __HIPCC__
   uint32_t t01, t23, w;
   const int six = 6;
-  asm ("v_ashrrev_i16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v" (t01) : "s" (six), "v" (a0));
-  asm ("v_ashrrev_i16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0" : "+v" (t01) : "s" (six), "v" (a1));
-  asm ("v_ashrrev_i16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v" (t23) : "s" (six), "v" (a2));
-  asm ("v_ashrrev_i16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0" : "+v" (t23) : "s" (six), "v" (a3));
-  asm ("v_sat_pk_u8_i16 %0, %1" : "=v" (w) : "v" (t01));
-  asm ("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v" (w) : "v" (t23));
+  asm ("s_nop 2\n\t"
+       "v_ashrrev_i16_sdwa %1, %3, %4 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+       "v_ashrrev_i16_sdwa %2, %3, %6 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+       "v_ashrrev_i16_sdwa %1, %3, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0\n\t"
+       "v_ashrrev_i16_sdwa %2, %3, %7 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0\n\t"
+       "v_sat_pk_u8_i16 %0, %1\n\t"
+       "v_sat_pk_u8_i16_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+       "s_nop 0"
+       : "=&v" (w), "=&v" (t01), "=&v" (t23) : "s" (six), "v" (a0), "v" (a1), "v" (a2), "v" (a3));
   return w ^ 0x80808080u;
 #else
   const int a[4] = {a0, a1, a2, a3};
@@ -384,11 +394,14 @@ GSTAMD_HD uint32_t col_fin_px (int ay, int au, int av)
 #ifdef __HIPCC__
   uint32_t t01 = 0xffu, t23, w;
   const int six = 6;
-  asm ("v_ashrrev_i16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0" : "+v" (t01) : "s" (six), "v" (ay));
-  asm ("v_ashrrev_i16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v" (t23) : "s" (six), "v" (au));
-  asm ("v_ashrrev_i16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0" : "+v" (t23) : "s" (six), "v" (av));
-  asm ("v_sat_pk_u8_i16 %0, %1" : "=v" (w) : "v" (t01));
-  asm ("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v" (w) : "v" (t23));
+  asm ("s_nop 2\n\t"
+       "v_ashrrev_i16_sdwa %2, %3, %5 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+       "v_ashrrev_i16_sdwa %1, %3, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0\n\t"
+       "v_ashrrev_i16_sdwa %2, %3, %6 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0\n\t"
+       "v_sat_pk_u8_i16 %0, %1\n\t"
+       "v_sat_pk_u8_i16_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+       "s_nop 0"
+       : "=&v" (w), "+v" (t01), "=&v" (t23) : "s" (six), "v" (ay), "v" (au), "v" (av));
   return w;
 #else
   return 0xffu | (h420r_finish (ay) << 8) | (h420r_finish (au) << 16) | (h420r_finish (av) << 24);

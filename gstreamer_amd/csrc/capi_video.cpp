@@ -198,10 +198,18 @@ static void col_geometry (const GstAmdVideoConverter *c, int n_frames, ColParams
   const int pin = tuning_int ("GSTAMD_COL_CHUNKS", 0);
   const int capacity = std::max (1, c->col_per_cu * c->col_cus);
   int chunks = pin > 0 ? pin : std::max (1, capacity / std::max (1, tiles * n_frames));
-  int rpw = (out_h + chunks * c->col_waves - 1) / (chunks * c->col_waves);
-  rpw = std::max (rpw, c->col.min_rows_per_wave);
+  /* a workgroup's rows: (waves - 1) runs of rpw rows and the last wave's shorter run (col_rows_last) */
+  int rpw = std::max (1, (out_h + chunks * c->col_waves - 1) / (chunks * c->col_waves));
+  for (;; rpw++) {
+    rpw = std::max (rpw, c->col.min_rows_per_wave);
+    const int per_wg = rpw * (c->col_waves - 1) + col_rows_last (c->col, rpw, out_h);
+    if ((long long) per_wg * chunks >= out_h)
+      break;
+  }
   q->rows_per_wave = rpw;
-  q->rows_per_wg = rpw * c->col_waves;
+  q->nwaves = c->col_waves;
+  q->rows_last = col_rows_last (c->col, rpw, out_h);
+  q->rows_per_wg = rpw * (c->col_waves - 1) + q->rows_last;
   q->n_chunks = (out_h + q->rows_per_wg - 1) / q->rows_per_wg;
   q->n_tiles = tiles;
 }
@@ -1048,6 +1056,7 @@ static hipError_t col_launch (GstAmdVideoConverter *c, int n, const void *const 
   q.out_w = p.passes[0].out_size;
   q.out_h = p.passes[1].out_size;
   q.pubn = c->col.pubn;
+  q.dstride = dstride;
   for (int base = 0; base < n; base += GSTAMD_COL_MAX_FRAMES) {
     const int nb = std::min (n - base, GSTAMD_COL_MAX_FRAMES);
     col_geometry (c, nb, &q);
@@ -1059,7 +1068,35 @@ static hipError_t col_launch (GstAmdVideoConverter *c, int n, const void *const 
       fr.c1[f] = (const uint8_t *) (semi ? src[base + f][1] : src[base + f][p.front.v_plane]);
       fr.dst[f] = dst[base + f];
     }
+#ifdef GSTAMD_COL_TRACE
+    /* profiling builds: cycles per phase of the walk, averaged over the waves of the launch (stderr) */
+    const size_t trace_n = (size_t) q.n_tiles * q.n_chunks * nb * GSTAMD_COL_MAX_WAVES * 8;
+    q.trace = nullptr;
+    static int trace_left = 3;
+    if (trace_left > 0 && hipMalloc ((void **) &q.trace, trace_n * 8) == hipSuccess)
+      (void) hipMemsetAsync (q.trace, 0, trace_n * 8, stream);
+#endif
     const hipError_t e = launch_scale_col (q, c->col_form, p.front.chroma_h, semi ? 1 : 0, c->col_waves, fr, nb, dstride, post, p.post.pack_pos, pf, stream);
+#ifdef GSTAMD_COL_TRACE
+    if (q.trace) {
+      std::vector<unsigned long long> h (trace_n);
+      (void) hipStreamSynchronize (stream);
+      (void) hipMemcpy (h.data (), q.trace, trace_n * 8, hipMemcpyDeviceToHost);
+      (void) hipFree (q.trace);
+      double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      size_t waves = 0;
+      for (size_t i = 0; i < trace_n; i += 8)
+        if (h[i + 7]) {
+          waves++;
+          for (int k = 0; k < 7; k++)
+            sum[k] += (double) h[i + k];
+        }
+      if (waves)
+        fprintf (stderr, "k_scale_col trace: %zu waves, %.1f groups each; cycles per wave: prologue %.0f, per group: load wait %.0f stage %.0f horizontal %.0f rows %.0f; hand-over %.0f\n",
+            waves, sum[6] / waves, sum[0] / waves, sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6], sum[4] / sum[6], sum[5] / waves);
+      trace_left--;
+    }
+#endif
     if (e != hipSuccess)
       return e;           /* hipErrorNotSupported can only come from the first launch (alignment): nothing has run yet */
   }

@@ -1126,6 +1126,7 @@ bool make_col_tables (const ScalePass &h, const ScalePass &v, int width, int hei
       e[3 + (b >> 2)] |= (uint32_t) (uint8_t) (int8_t) tap << (8 * (b & 3));
     }
   }
+  t->ngv_aligned = 0;               /* tw[k] <-> group gfirst + k until col_align_rows */
   t->pubn = 0;
   for (int j = 1; j < out_h; j++)
     t->pubn = std::max (t->pubn, (int) t->vrow[(size_t) (j - 1) * 8 + 1] - (int) t->vrow[(size_t) j * 8] + 1);
@@ -1140,6 +1141,21 @@ bool make_col_tables (const ScalePass &h, const ScalePass &v, int width, int hei
   }
   t->min_rows_per_wave = m;
   return true;
+}
+
+void col_align_rows (ColTables *t, int ngv_form)
+{
+  const size_t out_h = t->vrow.size () / 8;
+  for (size_t j = 0; j < out_h; j++) {
+    uint32_t *e = &t->vrow[j * 8];
+    const int n = (int) e[1] - (int) e[0] + 1, first_now = t->ngv_aligned ? t->ngv_aligned - n : 0, first_new = ngv_form - n;
+    uint32_t w[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < n; k++)
+      w[first_new + k] = e[3 + first_now + k];
+    for (int k = 0; k < 5; k++)
+      e[3 + k] = w[k];
+  }
+  t->ngv_aligned = ngv_form;
 }
 
 bool col_plan_regular (const VideoPlan &p, int *crow_lo, int *crow_hi)

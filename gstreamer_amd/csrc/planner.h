@@ -182,7 +182,8 @@ int fused420_first_rows (const Fused420Tables &t, int nwaves);
 //   hout[x]  = {wbase, init, tw[0 .. 5]}: byte offset (word aligned) of output x's first window word inside a staged plane, the accumulator's
 //              start value 128 * sum (taps) + 32, the int8 x 4 tap words (zero padded); with `wstep` >= 0 (opl = 2) the two outputs of a lane
 //              share ONE window of nw + wstep words from the even output's wbase, the odd output's words start wstep words in
-//   vrow[j]  = {gfirst, glast, init, 0, tw[0 .. 3]}: the line groups (lines 4g-1 .. 4g+2, byte = line) of row j's window with their tap words
+//   vrow[j]  = {gfirst, glast, init, tw[0 .. 4]}: the line groups (lines 4g-1 .. 4g+2, byte = line) of row j's window with their tap words;
+//              tw[k] belongs to group glast - ngv_aligned + 1 + k (col_align_rows: the kernel keeps the LAST ngv groups, oldest first)
 struct ColTables {
   int opl;                        // outputs per lane: 1 (4 staged pixels per lane) or 2 (8)
   int nw, ngv;                    // tap words per output (horizontal, <= 6) and per row (vertical, <= 4)
@@ -190,6 +191,7 @@ struct ColTables {
   int a8;                         // the shared window starts on an 8-byte boundary everywhere (two ds_read_b64 + ...)
   int n_groups;
   int pubn;                       // most groups the last row of a wave shares with the first row of the wave below
+  int ngv_aligned;                // window groups per row the tap words of vrow are laid out for (>= ngv: the kernel form's)
   int min_rows_per_wave;          // fewest rows a wave may own for the hand-over of those groups to work (a wave publishes only groups it makes)
   std::vector<int32_t> tiles;     // [n_tiles][4]
   std::vector<uint32_t> hout;     // [out_w][8]
@@ -198,6 +200,8 @@ struct ColTables {
 // false: no byte form (a tap outside int8, a phase whose taps sum to less than 64 - the alpha byte would not stay 0xff -, windows too long)
 // share: let the two outputs of a lane read one window where that saves LDS traffic (opl = 2)
 bool make_col_tables (const ScalePass &hpass, const ScalePass &vpass, int width, int height, int opl, bool share, ColTables *t);
+// lay the rows' tap words out for a kernel that keeps ngv_form >= t->ngv groups per row (leading zero words for shorter windows)
+void col_align_rows (ColTables *t, int ngv_form);
 
 // does the column-walk scaler apply to this plan?  Two N-tap passes, horizontal first, ahead of the convert stage, from an 8-bit planar /
 // semi-planar 4:2:0 source whose chroma line pairing is the closed form (lines 2u-1, 2u blend rows u-1 and u, clamped into

@@ -16,12 +16,13 @@
 namespace gstamd {
 
 // the lanes of a wave on the device: the thread's own registers
-template <int OPL, int NW>
+template <int OPL, int NW, int NGV>
 struct ColExecDev {
   int lane;
   ColLane<OPL, NW> L;
-  ColRaw<OPL> ra, rb;
-  template <class F> __device__ __forceinline__ void each (F f) { f (lane, L, ra, rb); }
+  ColRaw<OPL> ra;
+  ColRingRegs<OPL, NGV> rg;
+  template <class F> __device__ __forceinline__ void each (F f) { f (lane, L, ra, rg); }
   __device__ __forceinline__ void sync ()
   {
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
@@ -32,6 +33,21 @@ struct ColExecDev {
   {
     __hip_atomic_store (flags + wave, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
+#ifdef GSTAMD_COL_TRACE
+  __device__ __forceinline__ unsigned long long now () { return __builtin_readcyclecounter (); }
+  __device__ __forceinline__ void wait_loads () { asm volatile ("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __device__ __forceinline__ void trace_out (unsigned long long *trace, const unsigned long long *acc, int groups)
+  {
+    if (!trace || lane != 0)
+      return;
+    const size_t wg = ((size_t) blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    unsigned long long *d = trace + (wg * GSTAMD_COL_MAX_WAVES + (threadIdx.x >> 6)) * 8;
+    for (int k = 0; k < 6; k++)
+      d[k] = acc[k];
+    d[6] = (unsigned long long) groups;
+    d[7] = 1;
+  }
+#endif
   __device__ __forceinline__ void wait_flag (uint32_t *flags, int wave)
   {
     while (__hip_atomic_load (flags + wave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u)
@@ -40,7 +56,7 @@ struct ColExecDev {
 };
 
 // LDS: [flags: one word per wave][per wave: staged group | ring | hand-over slots]
-template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8>
+template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8, int POST>
 __global__ __launch_bounds__ (64 * GSTAMD_COL_MAX_WAVES) void k_scale_col (ColParams p, ColFrames fr, Dst dst, PostFast pf)
 {
   extern __shared__ __attribute__ ((aligned (16))) uint8_t col_lds[];
@@ -62,46 +78,47 @@ __global__ __launch_bounds__ (64 * GSTAMD_COL_MAX_WAVES) void k_scale_col (ColPa
   uint32_t te[8];
   col_entry8 ((const uint32_t *) p.tiles, ti >> 1, te);          /* two 4-word tile entries per 8-word read */
   const int32_t tile[4] = {(int32_t) te[4 * (ti & 1)], (int32_t) te[4 * (ti & 1) + 1], (int32_t) te[4 * (ti & 1) + 2], (int32_t) te[4 * (ti & 1) + 3]};
-  typedef const __attribute__ ((address_space (1))) uint8_t *gptr_t;
   const int frame = (int) blockIdx.z;
+  const uint32_t crow_bytes = (uint32_t) (p.cstride * (p.crow_hi - p.crow_lo) + (SEMI ? p.width : p.width / 2));
   ColSrc s;
-  s.y = (const uint8_t *) (gptr_t) fr.y[frame];
-  s.c0 = (const uint8_t *) (gptr_t) fr.c0[frame];
-  s.c1 = (const uint8_t *) (gptr_t) fr.c1[frame];
-  Dst d = dst;
-  d.p = (uint8_t *) (__attribute__ ((address_space (1))) uint8_t *) fr.dst[frame];
+  s.y = col_plane (fr.y[frame], 0, (uint32_t) (p.ystride * (p.height - 1) + p.width));
+  s.c0 = col_plane (fr.c0[frame], (long long) p.crow_lo * p.cstride, crow_bytes);
+  s.c1 = col_plane (fr.c1[frame], (long long) p.crow_lo * p.cstride, crow_bytes);
+  s.out = col_plane (fr.dst[frame], 0, (uint32_t) (p.dstride * (p.out_h - 1) + 4 * p.out_w));
+  const Dst &d = dst;
   const size_t wave_bytes = col_wave_bytes (OPL, NGV, p.pubn);
   uint8_t *mine = col_lds + GSTAMD_COL_FLAG_BYTES + (size_t) wave * wave_bytes;
-  ColExecDev<OPL, NW> x;
+  ColExecDev<OPL, NW, NGV> x;
   x.lane = lane;
-  col_wave<OPL, NW, NGV, CH, SEMI, WSTEP, A8> (x, p, s, tile, wp, mine, mine + wave_bytes, flags, wave, d, pf);
+  col_wave<OPL, NW, NGV, CH, SEMI, WSTEP, A8, POST> (x, p, s, tile, wp, mine, mine + wave_bytes, flags, wave, d, pf);
 }
 
 struct ColVariant {
-  int opl, nw, ngv, ch, semi, wstep, a8;
+  int opl, nw, ngv, ch, semi, wstep, a8, post;
   const void *fn;
   void (*launch) (const ColParams &, const ColFrames &, const Dst &, const PostFast &, dim3, int, size_t, hipStream_t);
 };
 
-template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8>
+template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8, int POST>
 static void col_launch_one (const ColParams &p, const ColFrames &fr, const Dst &d, const PostFast &pf, dim3 grid, int nwaves, size_t lds, hipStream_t stream)
 {
-  hipLaunchKernelGGL ((k_scale_col<OPL, NW, NGV, CH, SEMI, WSTEP, A8>), grid, dim3 (64 * nwaves), lds, stream, p, fr, d, pf);
+  hipLaunchKernelGGL ((k_scale_col<OPL, NW, NGV, CH, SEMI, WSTEP, A8, POST>), grid, dim3 (64 * nwaves), lds, stream, p, fr, d, pf);
 }
 
-#define COL_V(OPL, NW, NGV, CH, SEMI, WSTEP, A8) \
-  {OPL, NW, NGV, CH, SEMI, WSTEP, A8, (const void *) k_scale_col<OPL, NW, NGV, CH, SEMI, WSTEP, A8>, col_launch_one<OPL, NW, NGV, CH, SEMI, WSTEP, A8>},
+#define COL_V1(OPL, NW, NGV, CH, SEMI, WSTEP, A8, POST) \
+  {OPL, NW, NGV, CH, SEMI, WSTEP, A8, POST, (const void *) k_scale_col<OPL, NW, NGV, CH, SEMI, WSTEP, A8, POST>, col_launch_one<OPL, NW, NGV, CH, SEMI, WSTEP, A8, POST>},
+#define COL_V(OPL, NW, NGV, CH, SEMI, WSTEP, A8) COL_V1 (OPL, NW, NGV, CH, SEMI, WSTEP, A8, 1) COL_V1 (OPL, NW, NGV, CH, SEMI, WSTEP, A8, 0)
 #define COL_F(o, n, g, w, a) COL_V (o, n, g, CHROMA_H_H2_CS, 0, w, a) COL_V (o, n, g, CHROMA_H_H2_CS, 1, w, a) COL_V (o, n, g, CHROMA_H_H2, 0, w, a) COL_V (o, n, g, CHROMA_H_H2, 1, w, a)
 static const ColVariant g_col_variants[] = {
   GSTAMD_COL_FORMS (COL_F)
 };
 
 // the kernel of a form (col_form_for); CHROMA_H_NONE runs as the co-sited filter with both selectors equal
-static const ColVariant *col_find (const ColForm &f, int chroma_h, int semi)
+static const ColVariant *col_find (const ColForm &f, int chroma_h, int semi, int post = 1)
 {
   const int ch = chroma_h == CHROMA_H_H2 ? CHROMA_H_H2 : CHROMA_H_H2_CS;
   for (const ColVariant &v : g_col_variants)
-    if (v.opl == f.opl && v.nw == f.nw && v.ngv == f.ngv && v.wstep == f.wstep && v.a8 == f.a8 && v.ch == ch && v.semi == semi)
+    if (v.opl == f.opl && v.nw == f.nw && v.ngv == f.ngv && v.wstep == f.wstep && v.a8 == f.a8 && v.ch == ch && v.semi == semi && v.post == post)
       return &v;
   return nullptr;
 }
@@ -125,7 +142,7 @@ int col_blocks_per_cu (const ColForm &f, int chroma_h, int semi, int pubn, int n
 hipError_t launch_scale_col (const ColParams &p, const ColForm &f, int chroma_h, int semi, int nwaves, const ColFrames &fr, int n_frames, int dstride,
     const ColorParams &post, const int pack_pos[4], const PostFast &pf, hipStream_t stream)
 {
-  const ColVariant *v = col_find (f, chroma_h, semi);
+  const ColVariant *v = col_find (f, chroma_h, semi, pf.use ? 1 : 0);
   if (!v || nwaves < 1 || nwaves > GSTAMD_COL_MAX_WAVES || n_frames < 1 || n_frames > GSTAMD_COL_MAX_FRAMES || (dstride % (4 * f.opl)) != 0)
     return hipErrorNotSupported;
   for (int k = 0; k < n_frames; k++)

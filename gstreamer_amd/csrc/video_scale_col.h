@@ -35,9 +35,56 @@ struct ColFrames {
   uint8_t *dst[GSTAMD_COL_MAX_FRAMES];
 };
 
+// a source plane as the kernel reads it: a raw buffer (base, bytes) - loads take a 32-bit lane offset plus a scalar row offset, and reads
+// past the end return zero (lanes right of the picture and lines below it only ever meet zero taps)
+#ifdef __HIPCC__
+typedef __amdgpu_buffer_rsrc_t colplane_t;
+#else
+struct colplane_t { const uint8_t *p; uint32_t bytes; };
+#endif
 struct ColSrc {
-  const uint8_t *y, *c0, *c1;
+  colplane_t y, c0, c1;         // c0 / c1: based at chroma row ColParams::crow_lo (rows above a crop origin have negative numbers)
+  colplane_t out;               // the destination frame
 };
+
+GSTAMD_HD colplane_t col_plane (const uint8_t *base, long long first_byte, uint32_t bytes)
+{
+#ifdef __HIPCC__
+  return __builtin_amdgcn_make_buffer_rsrc ((void *) (base + first_byte), (short) 0, (int) bytes, 0x00020000);
+#else
+  colplane_t pl = {base + first_byte, bytes};
+  return pl;
+#endif
+}
+
+GSTAMD_HD void col_store32 (colplane_t pl, uint32_t lane_off, uint32_t row_off, const uint32_t *v, int n)
+{
+#ifdef __HIPCC__
+  typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
+  if (n == 2) {
+    const u32x2 d = {v[0], v[1]};
+    __builtin_amdgcn_raw_buffer_store_b64 (d, pl, (int) lane_off, (int) row_off, 0);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b32 (v[0], pl, (int) lane_off, (int) row_off, 0);
+  }
+#else
+  if ((unsigned long long) lane_off + row_off + 4 * n <= pl.bytes)
+    __builtin_memcpy (const_cast<uint8_t *> (pl.p) + lane_off + row_off, v, 4 * (size_t) n);
+#endif
+}
+
+// dwords at byte lane_off + row_off (+ 4) of the plane; row_off is wave-uniform (the instruction's scalar offset)
+GSTAMD_HD uint32_t col_load32 (colplane_t pl, uint32_t lane_off, uint32_t row_off)
+{
+#ifdef __HIPCC__
+  return (uint32_t) __builtin_amdgcn_raw_buffer_load_b32 (pl, (int) lane_off, (int) row_off, 0);
+#else
+  uint32_t v = 0;
+  if ((unsigned long long) lane_off + row_off + 4 <= pl.bytes)
+    __builtin_memcpy (&v, pl.p + lane_off + row_off, 4);
+  return v;
+#endif
+}
 
 struct ColParams {
   int ystride, cstride;
@@ -49,7 +96,13 @@ struct ColParams {
   int out_w, out_h;
   int n_tiles, n_chunks;        // grid: n_tiles x n_chunks workgroups per frame
   int rows_per_wg, rows_per_wave;
+  int rows_last, nwaves;        // a workgroup's last wave owns rows_last <= rows_per_wave rows (it also makes the groups past its last row that the
+                                // other waves get from the wave below them): rows_per_wg = rows_per_wave * (nwaves - 1) + rows_last
+  int dstride;
   int pubn;                     // ring slots of a wave's hand-over area
+#ifdef GSTAMD_COL_TRACE
+  unsigned long long *trace;    // profiling builds: [workgroup][wave][8] cycles per phase of the walk
+#endif
 };
 
 // the instantiated forms (outputs per lane, tap words per output, window groups per row, window form, 8-byte aligned shared window); each exists
@@ -85,10 +138,20 @@ inline bool col_choose (const ScalePass &h, const ScalePass &v, int width, int h
     if (opl_pref && opl != opl_pref)
       continue;
     for (int sh = share ? 1 : 0; sh >= 0; sh--)
-      if (make_col_tables (h, v, width, height, opl, sh != 0, t) && col_form_for (opl, t->nw, t->ngv, t->wstep, t->a8, form))
+      if (make_col_tables (h, v, width, height, opl, sh != 0, t) && col_form_for (opl, t->nw, t->ngv, t->wstep, t->a8, form)) {
+        col_align_rows (t, form->ngv);
         return true;
+      }
   }
   return false;
+}
+
+// rows of a workgroup's last wave: it makes the groups its rows share with the rows BELOW the workgroup itself (the other waves get
+// theirs from the wave below), so it owns that many rows fewer - the waves of a workgroup then finish together
+inline int col_rows_last (const ColTables &t, int rows_per_wave, int out_h)
+{
+  const int extra = (int) (((long long) t.pubn * out_h + t.n_groups / 2) / (t.n_groups > 0 ? t.n_groups : 1));
+  return rows_per_wave - extra > 1 ? rows_per_wave - extra : (rows_per_wave > 1 ? 1 : rows_per_wave);
 }
 
 template <int OPL>
@@ -100,13 +163,13 @@ struct ColGeom {
   static constexpr int STAGEB = 4 * LINEB + 32;         // + room for the zero-tap words a window may read past the last plane
   static constexpr int SLOTW = 3 * OPL * 64;            // words of a ring slot: [channel][lane][output of the lane]
 };
-template <int V> struct ColSel { static constexpr int value = V; };
-template <int NGV> struct ColRing { static constexpr int SLOTS = NGV <= 4 ? 4 : 8; };
 
+// LDS of a wave: the staged group, then the hand-over slots (the ring of line groups itself lives in registers)
 GSTAMD_H420_HOSTDEV size_t col_wave_bytes (int opl, int ngv, int pubn)
 {
-  const int slotw = 3 * opl * 64, stage = 4 * 3 * (256 * opl + 16) + 32, ring = (ngv <= 4 ? 4 : 8) * slotw * 4;
-  return (size_t) ((stage + ring + pubn * slotw * 4 + 15) & ~15);
+  const int slotw = 3 * opl * 64, stage = 4 * 3 * (256 * opl + 16) + 32;
+  (void) ngv;
+  return (size_t) ((stage + pubn * slotw * 4 + 15) & ~15);
 }
 
 // per-lane constants of a wave
@@ -115,6 +178,7 @@ struct ColLane {
   uint32_t tw[OPL][NW];
   int hinit[OPL];
   int wb[OPL];                  // byte offset of the output's first window word inside a staged plane (shared windows: wb[0] for both)
+  int lb[4][OPL];               // wb + line * LINEB, kept apart (see col_setup)
   int st;                       // byte offset of the lane's staged pixels inside a plane
   int xl;                       // first source pixel the lane loads
   int xo;                       // first output column of the lane
@@ -124,6 +188,12 @@ struct ColLane {
   uint32_t hu[OPL], hv[OPL];    // h-filtered chroma row 2g-1 (carried from the previous group)
 };
 
+// the lane's ring: the words of the last NGV line groups of its output column(s), oldest first - registers, moved down one place per group
+template <int OPL, int NGV>
+struct ColRingRegs {
+  uint32_t w[NGV][3][OPL];
+};
+
 // one group's loads
 template <int OPL>
 struct ColRaw {
@@ -131,39 +201,56 @@ struct ColRaw {
   uint32_t c[2][2 * OPL];       // chroma rows 2g, 2g+1.  planar: [0, OPL) U, [OPL, 2 OPL) V; semi-planar: OPL x 8 interleaved bytes
 };
 
-GSTAMD_HD uint32_t col_load32 (const uint8_t *p)
-{
-  uint32_t v;
-  __builtin_memcpy (&v, p, 4);          // any alignment: global_load_dword (unaligned access mode)
-  return v;
-}
-
 GSTAMD_HD int col_clamp (int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// row `row` of a plane; everything here is wave-uniform and stays on the scalar unit
-GSTAMD_HD const uint8_t *col_row_ptr (const uint8_t *base, int row, int stride)
+// byte offset of row `row` of a plane: wave-uniform, stays on the scalar unit
+GSTAMD_HD uint32_t col_row_off (int row, int stride)
 {
 #ifdef __HIPCC__
-  const long long off = (long long) __builtin_amdgcn_readfirstlane (row) * (long long) stride;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane ((uint32_t) off), hi = __builtin_amdgcn_readfirstlane ((uint32_t) ((unsigned long long) off >> 32));
-  return base + (ptrdiff_t) (((unsigned long long) hi << 32) | lo);
+  return (uint32_t) __builtin_amdgcn_readfirstlane (row * stride);
 #else
-  return base + (ptrdiff_t) row * stride;
+  return (uint32_t) (row * stride);
 #endif
 }
 
-// tile entry / row entry through the scalar unit (wave-uniform index)
+// tile entry / row entry (wave-uniform index): read through the constant address space, so that the compiler issues scalar loads
+// (s_load_dwordx8) and places their waits itself - a row's entry is requested a whole group ahead of its use
 GSTAMD_HD void col_entry8 (const uint32_t *table, int idx, uint32_t *e)
 {
 #ifdef __HIPCC__
-  typedef uint32_t u32x8 __attribute__ ((ext_vector_type (8)));
-  u32x8 v;
-  const int off = idx * 32;
-  asm volatile ("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s" (v) : "s" (table), "s" (off) : "memory");
-  e[0] = v.s0, e[1] = v.s1, e[2] = v.s2, e[3] = v.s3, e[4] = v.s4, e[5] = v.s5, e[6] = v.s6, e[7] = v.s7;
+  typedef const __attribute__ ((address_space (4))) uint32_t *cptr_t;
+  cptr_t t = (cptr_t) (uintptr_t) table + (size_t) __builtin_amdgcn_readfirstlane (idx) * 8;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    e[k] = t[k];
 #else
   for (int k = 0; k < 8; k++)
     e[k] = table[(size_t) idx * 8 + k];
+#endif
+}
+
+// byte dot product with accumulator, ALWAYS this one opcode (never the compiler's own choice between v_dot4_i32_i8 and v_dot4c_i32_i8): a dot
+// product's result may be read back-to-back only as the accumulator of the SAME opcode (every other reader needs three wait states,
+// which the compiler cannot add around instructions it does not see - col_fin4 / col_fin_px start with them).  b_is_uniform: the taps
+// sit in a scalar register.
+GSTAMD_HD int col_dot4 (uint32_t a, uint32_t b, int c)
+{
+#ifdef __HIPCC__
+  int r;
+  asm ("v_dot4_i32_i8 %0, %1, %2, %3" : "=v" (r) : "v" (a), "v" (b), "v" (c));
+  return r;
+#else
+  return dot4_i8 (a, b, c);
+#endif
+}
+GSTAMD_HD int col_dot4s (uint32_t a, uint32_t b_uniform, int c)
+{
+#ifdef __HIPCC__
+  int r;
+  asm ("v_dot4_i32_i8 %0, %1, %2, %3" : "=v" (r) : "v" (a), "s" (b_uniform), "v" (c));
+  return r;
+#else
+  return dot4_i8 (a, b_uniform, c);
 #endif
 }
 
@@ -216,6 +303,15 @@ GSTAMD_HD void col_setup (const ColParams &p, const int32_t *tile, int lane, Col
     L.wb[i] = (int) e[0];
     L.hinit[i] = (int) e[1];
 #pragma unroll
+    for (int k = 0; k < 4; k++) {
+      // one address register per staged line: all three planes of a line are within reach of its LDS instructions' immediate offsets
+      // (8 bits of dwords for the paired reads).  Opaque, or the compiler folds the lines back onto one base and adds a constant per read.
+      L.lb[k][i] = L.wb[i] + k * ColGeom<OPL>::LINEB;
+#ifdef __HIPCC__
+      asm volatile ("" : "+v" (L.lb[k][i]));
+#endif
+    }
+#pragma unroll
     for (int k = 0; k < NW; k++)
       L.tw[i][k] = e[2 + k];
   }
@@ -224,20 +320,18 @@ GSTAMD_HD void col_setup (const ColParams &p, const int32_t *tile, int lane, Col
 template <int OPL, int SEMI>
 GSTAMD_HD void col_load_crow (const ColParams &p, const ColSrc &s, const int *ca, int row, uint32_t *c)
 {
-  const int r = col_clamp (row, p.crow_lo, p.crow_hi);
+  const uint32_t ro = col_row_off (col_clamp (row, p.crow_lo, p.crow_hi) - p.crow_lo, p.cstride);
   if (SEMI) {
-    const uint8_t *b = col_row_ptr (s.c0, r, p.cstride);
 #pragma unroll
     for (int j = 0; j < OPL; j++) {
-      c[2 * j] = col_load32 (b + (uint32_t) (2 * ca[j]));
-      c[2 * j + 1] = col_load32 (b + (uint32_t) (2 * ca[j] + 4));
+      c[2 * j] = col_load32 (s.c0, (uint32_t) (2 * ca[j]), ro);
+      c[2 * j + 1] = col_load32 (s.c0, (uint32_t) (2 * ca[j] + 4), ro);
     }
   } else {
-    const uint8_t *bu = col_row_ptr (s.c0, r, p.cstride), *bv = col_row_ptr (s.c1, r, p.cstride);
 #pragma unroll
     for (int j = 0; j < OPL; j++) {
-      c[j] = col_load32 (bu + (uint32_t) ca[j]);
-      c[OPL + j] = col_load32 (bv + (uint32_t) ca[j]);
+      c[j] = col_load32 (s.c0, (uint32_t) ca[j], ro);
+      c[OPL + j] = col_load32 (s.c1, (uint32_t) ca[j], ro);
     }
   }
 }
@@ -246,13 +340,16 @@ GSTAMD_HD void col_load_crow (const ColParams &p, const ColSrc &s, const int *ca
 template <int OPL, int NW, int SEMI>
 GSTAMD_HD void col_request (const ColParams &p, const ColSrc &s, const ColLane<OPL, NW> &L, int g, ColRaw<OPL> &r)
 {
+#if defined(GSTAMD_COL_ABL) && GSTAMD_COL_ABL == 1      /* profiling builds only (results WRONG): no source loads after a wave's first */
+  if (g != -12345)
+    return;
+#endif
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int y = col_clamp (4 * g - 1 + k, 0, p.height - 1);
-    const uint8_t *b = col_row_ptr (s.y, y, p.ystride);         /* wave-uniform: a scalar base, the lane's pixel as the 32-bit offset */
+    const uint32_t ro = col_row_off (col_clamp (4 * g - 1 + k, 0, p.height - 1), p.ystride);
 #pragma unroll
     for (int j = 0; j < OPL; j++)
-      r.y[k][j] = col_load32 (b + (uint32_t) (L.xl + 4 * j));
+      r.y[k][j] = col_load32 (s.y, (uint32_t) (L.xl + 4 * j), ro);
   }
   col_load_crow<OPL, SEMI> (p, s, L.ca, 2 * g, r.c[0]);
   col_load_crow<OPL, SEMI> (p, s, L.ca, 2 * g + 1, r.c[1]);
@@ -412,19 +509,27 @@ GSTAMD_HD uint32_t col_fin_px (int ay, int au, int av)
 template <int N, int A8>
 GSTAMD_HD void col_lds_words (const uint8_t *p, uint32_t *o)
 {
+#ifdef __HIPCC__
+  typedef const __attribute__ ((address_space (3))) uint32_t *lptr_t;
+  typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
+  typedef const __attribute__ ((address_space (3))) u32x2 *lptr2_t;
   if (A8) {
 #pragma unroll
     for (int k = 0; k + 1 < N; k += 2) {
-      const uint2 v = *(const uint2 *) (p + 4 * k);
+      const u32x2 v = *(lptr2_t) (p + 4 * k);
       o[k] = v.x, o[k + 1] = v.y;
     }
     if (N & 1)
-      o[N - 1] = *(const uint32_t *) (p + 4 * (N - 1));
+      o[N - 1] = *(lptr_t) (p + 4 * (N - 1));
   } else {
 #pragma unroll
     for (int k = 0; k < N; k++)
-      o[k] = h420r_lds ((const uint32_t *) (p + 4 * k));
+      o[k] = *(lptr_t) (p + 4 * k);
   }
+#else
+  for (int k = 0; k < N; k++)
+    o[k] = *(const uint32_t *) (p + 4 * k);
+#endif
 }
 
 // horizontal pass of the staged group: the lane's outputs on the four lines, packed into the group's ring words gw[channel][output]
@@ -432,44 +537,47 @@ template <int OPL, int NW, int WSTEP, int A8>
 GSTAMD_HD void col_hfilter (const ColLane<OPL, NW> &L, const uint8_t *stage, uint32_t gw[3][OPL])
 {
   typedef ColGeom<OPL> G;
+  constexpr int SH = WSTEP >= 0 ? WSTEP : 0;
+  constexpr int NWIN = WSTEP >= 0 ? 1 : OPL;            /* windows a lane reads per line and plane */
+  constexpr int NWORDS = NW + SH;
   int acc[4][3][OPL];
+  uint32_t w[2][3][NWIN][NWORDS];
+  // the windows of line k + 1 are requested before the dot products of line k start
+  auto fetch = [&](int k, uint32_t (*d)[NWIN][NWORDS]) {
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int i = 0; i < NWIN; i++) {
+#if defined(GSTAMD_COL_ABL) && GSTAMD_COL_ABL == 2      /* no window reads */
+        for (int q = 0; q < NWORDS; q++)
+          d[c][i][q] = (uint32_t) L.lb[k][i] * 3u + q + c;
+#else
+        col_lds_words<NWORDS, A8> (stage + L.lb[k][i] + c * G::PP, d[c][i]);
+#endif
+      }
+  };
+  fetch (0, w[0]);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const uint8_t *line = stage + k * G::LINEB;
-    if (WSTEP >= 0) {
-      // the two outputs of the lane read one window: words [0, NW) for the even output, [WSTEP, WSTEP + NW) for the odd one
-      uint32_t w[3][NW + (WSTEP >= 0 ? WSTEP : 0)];
+    if (k < 3)
+      fetch (k + 1, w[(k + 1) & 1]);
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-        col_lds_words<NW + (WSTEP >= 0 ? WSTEP : 0), A8> (line + c * G::PP + L.wb[0], w[c]);
+    for (int c = 0; c < 3; c++)
 #pragma unroll
-      for (int c = 0; c < 3; c++)
+      for (int i = 0; i < OPL; i++) {
+        // shared windows: words [0, NW) for the even output, [WSTEP, WSTEP + NW) for the odd one
+        const uint32_t *ww = w[k & 1][c][WSTEP >= 0 ? 0 : i] + (WSTEP >= 0 && i ? SH : 0);
+        int a = L.hinit[i];
 #pragma unroll
-        for (int i = 0; i < OPL; i++) {
-          int a = L.hinit[i];
-#pragma unroll
-          for (int q = 0; q < NW; q++)
-            a = dot4_i8 (w[c][q + (i ? (WSTEP >= 0 ? WSTEP : 0) : 0)], L.tw[i][q], a);
-          acc[k][c][i] = a;
+        for (int q = 0; q < NW; q++) {
+#if defined(GSTAMD_COL_ABL) && GSTAMD_COL_ABL == 5      /* no horizontal dot products */
+          a ^= (int) ww[q];
+#else
+          a = col_dot4 (ww[q], L.tw[i][q], a);
+#endif
         }
-    } else {
-      uint32_t w[3][OPL][NW];
-#pragma unroll
-      for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int i = 0; i < OPL; i++)
-          col_lds_words<NW, 0> (line + c * G::PP + L.wb[i], w[c][i]);
-#pragma unroll
-      for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int i = 0; i < OPL; i++) {
-          int a = L.hinit[i];
-#pragma unroll
-          for (int q = 0; q < NW; q++)
-            a = dot4_i8 (w[c][i][q], L.tw[i][q], a);
-          acc[k][c][i] = a;
-        }
-    }
+        acc[k][c][i] = a;
+      }
   }
 #pragma unroll
   for (int c = 0; c < 3; c++)
@@ -502,50 +610,64 @@ GSTAMD_HD void col_slot_load (const uint32_t *slot, int lane, uint32_t gw[3][OPL
       const uint2 v = *(const uint2 *) d;
       gw[c][0] = v.x, gw[c][1] = v.y;
     } else {
-      gw[c][0] = h420r_lds (d);
+#ifdef __HIPCC__
+      gw[c][0] = *(const __attribute__ ((address_space (3))) uint32_t *) d;
+#else
+      gw[c][0] = *d;
+#endif
     }
   }
 }
 
-// one output row: vertical pass down the lane's ring words, post stage, store.  e = the row's entry of ColParams::vrow
+// the newest group's words into the ring: the older ones move down one place (registers: an array indexed at run time would live in
+// scratch memory - 5 x the kernel's time, as tried)
 template <int OPL, int NGV>
-GSTAMD_HD void col_vrow (const uint32_t *ring, int lane, const uint32_t *e, const Dst &dst, const PostFast &pf, int x, int j)
+GSTAMD_HD void col_ring_put (ColRingRegs<OPL, NGV> &rg, const uint32_t gw[3][OPL])
 {
-  typedef ColGeom<OPL> G;
-  const int mask = ColRing<NGV>::SLOTS - 1;
+#pragma unroll
+  for (int k = 0; k + 1 < NGV; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int i = 0; i < OPL; i++)
+        rg.w[k][c][i] = rg.w[k + 1][c][i];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int i = 0; i < OPL; i++)
+      rg.w[NGV - 1][c][i] = gw[c][i];
+}
+
+// one output row (its window ends with the newest group in the ring): vertical pass down the lane's ring words - e[3 + k] is the tap
+// word of the k-th oldest of the last NGV groups (ColTables::ngv_aligned) -, post stage, store.  e = the row's entry of ColParams::vrow
+template <int OPL, int NGV, int POST>
+GSTAMD_HD void col_vrow (const ColRingRegs<OPL, NGV> &rg, const uint32_t *e, const ColParams &p, const ColSrc &s, const Dst &dst, const PostFast &pf, int x, int j)
+{
   int acc[3][OPL];
 #pragma unroll
   for (int c = 0; c < 3; c++)
 #pragma unroll
     for (int i = 0; i < OPL; i++)
       acc[c][i] = (int) e[2];
-  uint32_t w[NGV][3][OPL];
-#pragma unroll
-  for (int k = 0; k < NGV; k++)
-    col_slot_load<OPL> (ring + (size_t) (((int) e[0] + k) & mask) * G::SLOTW, lane, w[k]);
 #pragma unroll
   for (int k = 0; k < NGV; k++)
 #pragma unroll
     for (int c = 0; c < 3; c++)
 #pragma unroll
       for (int i = 0; i < OPL; i++)
-        acc[c][i] = dot4_i8 (w[k][c][i], e[3 + k], acc[c][i]);
+        acc[c][i] = col_dot4s (rg.w[k][c][i], e[3 + k], acc[c][i]);
   uint32_t px[OPL];
 #pragma unroll
-  for (int i = 0; i < OPL; i++)
-    px[i] = post_px (dst, pf, col_fin_px (acc[0][i], acc[1][i], acc[2][i]));
-  uint8_t *d = dst.p + (size_t) j * dst.stride + 4 * (size_t) x;
-  if constexpr (OPL == 2) {
-#ifdef __HIPCC__
-    typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
-    const u32x2 v = {px[0], px[1]};
-    __builtin_nontemporal_store (v, (u32x2 *) d);
-#else
-    ((uint32_t *) d)[0] = px[0], ((uint32_t *) d)[1] = px[1];
-#endif
-  } else {
-    store_px (dst, x, j, px[0]);
+  for (int i = 0; i < OPL; i++) {
+    const uint32_t q = col_fin_px (acc[0][i], acc[1][i], acc[2][i]);
+    if constexpr (POST) {               /* VideoPlan::fast_post: the no-wrap AYUV -> ARGB matrix, alpha stays 0xff */
+      const uint32_t z = q ^ 0x80808080u;
+      px[i] = fast_pixel (pf.fp, z, 0x0c01010cu, z, 0x0c02020cu, 0x0c03030cu);
+    } else {
+      px[i] = dst.final ? pack_px (dst.pack_pos, apply_color (dst.post, q)) : q;
+    }
   }
+  col_store32 (s.out, (uint32_t) (4 * x), col_row_off (j, p.dstride), px, OPL);
 }
 
 // what a wave does: its rows [r0, r1), the groups it makes [ga, ge), the groups it takes from the wave below (ge .. gl), the groups it
@@ -561,7 +683,8 @@ GSTAMD_HD bool col_wave_plan (const ColParams &p, int chunk, int wave, ColWavePl
   w->r0 = ra + wave * p.rows_per_wave;
   if (w->r0 >= rb)
     return false;
-  w->r1 = w->r0 + p.rows_per_wave < rb ? w->r0 + p.rows_per_wave : rb;
+  const int mine = wave == p.nwaves - 1 ? p.rows_last : p.rows_per_wave;
+  w->r1 = w->r0 + mine < rb ? w->r0 + mine : rb;
   uint32_t e[8];
   col_entry8 (p.vrow, w->r0, e);
   w->ga = (int) e[0];
@@ -588,20 +711,19 @@ GSTAMD_HD bool col_wave_plan (const ColParams &p, int chunk, int wave, ColWavePl
 // X supplies the lanes: on the device `each (f)` calls f once with the thread's own registers, in the host emulator (tests/emu) it
 // loops over 64 lane states - ONE control flow for both.  sync (): the wave's LDS traffic is ordered (in-order LDS queue; a compiler
 // fence on the device).  publish / wait_flag: the hand-over flag of a wave (workgroup-scope release / acquire).
-template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8, class X>
+template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8, int POST, class X>
 GSTAMD_HD void col_wave (X &x, const ColParams &p, const ColSrc &s, const int32_t *tile, const ColWavePlan &wp, uint8_t *wave_lds, uint8_t *below_lds,
     uint32_t *flags, int wave, const Dst &dst, const PostFast &pf)
 {
   typedef ColGeom<OPL> G;
   typedef ColLane<OPL, NW> Lane;
   typedef ColRaw<OPL> Raw;
-  const int mask = ColRing<NGV>::SLOTS - 1;
+  typedef ColRingRegs<OPL, NGV> Ring;
   uint8_t *stage = wave_lds;
-  uint32_t *ring = (uint32_t *) (wave_lds + G::STAGEB);
-  uint32_t *pub = ring + (size_t) ColRing<NGV>::SLOTS * G::SLOTW;
-  const uint32_t *pub_below = (const uint32_t *) (below_lds + G::STAGEB) + (size_t) ColRing<NGV>::SLOTS * G::SLOTW;
+  uint32_t *pub = (uint32_t *) (wave_lds + G::STAGEB);
+  const uint32_t *pub_below = (const uint32_t *) (below_lds + G::STAGEB);
   const bool aligned = ((tile[3] - tile[2]) % G::PXL) == 0;
-  x.each ([&](int lane, Lane &L, Raw &ra, Raw &) {
+  x.each ([&](int lane, Lane &L, Raw &ra, Ring &) {
     col_setup<OPL, NW, CH, SEMI> (p, tile, lane, L);
     col_request<OPL, NW, SEMI> (p, s, L, wp.ga, ra);
     col_first_row<OPL, NW, CH, SEMI> (p, s, L, wp.ga);
@@ -609,65 +731,86 @@ GSTAMD_HD void col_wave (X &x, const ColParams &p, const ColSrc &s, const int32_
   int r = wp.r0;
   uint32_t e[8];
   col_entry8 (p.vrow, r, e);
+#ifdef GSTAMD_COL_TRACE
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = x.now ();
+#define COL_STAMP(k) do { const unsigned long long t_ = x.now (); tacc[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define COL_STAMP(k) do { } while (0)
+#endif
   // the rows whose window ends with group g
   auto rows = [&](int g) {
     while (r < wp.r1 && (int) e[1] == g) {
-      x.each ([&](int lane, Lane &L, Raw &, Raw &) { col_vrow<OPL, NGV> (ring, lane, e, dst, pf, L.xo, r); });
+#if !(defined(GSTAMD_COL_ABL) && GSTAMD_COL_ABL == 3)   /* 3: no rows */
+      x.each ([&](int, Lane &L, Raw &, Ring &rg) { col_vrow<OPL, NGV, POST> (rg, e, p, s, dst, pf, L.xo, r); });
+#endif
       r++;
       if (r < wp.r1)
         col_entry8 (p.vrow, r, e);
     }
   };
   int g = wp.ga;
-  // group g from the loads in `cur`, the next group's loads into `nxt`
-  auto step = [&](auto sel) {
+  // group g: staged from its loads, whose registers then take the next group's requests - those have the horizontal pass, the rows
+  // and the other waves' turns to arrive (one register set: a second one bought nothing but a wave of occupancy less)
+  COL_STAMP (0);                        /* prologue: tables, first loads */
+  while (g < wp.ge) {
     const int gn = g + 1 < wp.ge ? g + 1 : wp.ge - 1;
+#ifdef GSTAMD_COL_TRACE
+    x.wait_loads ();
+    COL_STAMP (1);                      /* waiting for the group's source loads */
+#endif
+#if defined(GSTAMD_COL_ABL) && GSTAMD_COL_ABL == 4      /* no staging */
+    if (g == -12345)
+#else
     if (aligned)
-      x.each ([&](int, Lane &L, Raw &ra, Raw &rb) {
-        Raw &cur = decltype (sel)::value ? rb : ra, &nxt = decltype (sel)::value ? ra : rb;
-        col_request<OPL, NW, SEMI> (p, s, L, gn, nxt);
-        col_stage<OPL, NW, CH, SEMI, 1> (L, cur, stage);
+#endif
+      x.each ([&](int, Lane &L, Raw &ra, Ring &) {
+        col_stage<OPL, NW, CH, SEMI, 1> (L, ra, stage);
+        col_request<OPL, NW, SEMI> (p, s, L, gn, ra);
       });
+#if defined(GSTAMD_COL_ABL) && GSTAMD_COL_ABL == 4
+    else if (g == -12346)
+#else
     else
-      x.each ([&](int, Lane &L, Raw &ra, Raw &rb) {
-        Raw &cur = decltype (sel)::value ? rb : ra, &nxt = decltype (sel)::value ? ra : rb;
-        col_request<OPL, NW, SEMI> (p, s, L, gn, nxt);
-        col_stage<OPL, NW, CH, SEMI, 0> (L, cur, stage);
+#endif
+      x.each ([&](int, Lane &L, Raw &ra, Ring &) {
+        col_stage<OPL, NW, CH, SEMI, 0> (L, ra, stage);
+        col_request<OPL, NW, SEMI> (p, s, L, gn, ra);
       });
     x.sync ();
-    x.each ([&](int lane, Lane &L, Raw &, Raw &) {
+    COL_STAMP (2);                      /* staging */
+    x.each ([&](int lane, Lane &L, Raw &, Ring &rg) {
       uint32_t gw[3][OPL];
       col_hfilter<OPL, NW, WSTEP, A8> (L, stage, gw);
-      col_slot_store<OPL> (ring + (size_t) (g & mask) * G::SLOTW, lane, gw);
+      col_ring_put<OPL, NGV> (rg, gw);
       if (g <= wp.gp)
         col_slot_store<OPL> (pub + (size_t) (g - wp.ga) * G::SLOTW, lane, gw);
     });
     x.sync ();
     if (g == wp.gp)
       x.publish (flags, wave);
+    COL_STAMP (3);                      /* horizontal pass */
     rows (g);
+    COL_STAMP (4);                      /* rows */
     g++;
-  };
-  while (g < wp.ge) {
-    step (ColSel<0> ());
-    if (g >= wp.ge)
-      break;
-    step (ColSel<1> ());
   }
   if (wp.gp >= wp.ga)
     x.publish (flags, wave);            // (already done inside the loop whenever rows_per_wave >= ColTables::min_rows_per_wave: never leave the wave above waiting)
   if (wp.gl >= wp.ge) {
     x.wait_flag (flags, wave + 1);
     for (; g <= wp.gl; g++) {
-      x.each ([&](int lane, Lane &, Raw &, Raw &) {
+      x.each ([&](int lane, Lane &, Raw &, Ring &rg) {
         uint32_t gw[3][OPL];
         col_slot_load<OPL> (pub_below + (size_t) (g - wp.ge) * G::SLOTW, lane, gw);
-        col_slot_store<OPL> (ring + (size_t) (g & mask) * G::SLOTW, lane, gw);
+        col_ring_put<OPL, NGV> (rg, gw);
       });
-      x.sync ();
       rows (g);
     }
   }
+  COL_STAMP (5);                        /* hand-over */
+#ifdef GSTAMD_COL_TRACE
+  x.trace_out (p.trace, tacc, wp.ge - wp.ga);
+#endif
+#undef COL_STAMP
 }
 
 }  // namespace gstamd

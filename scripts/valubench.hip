@@ -42,12 +42,19 @@
 #define OP_SAD(x) asm volatile ("v_sad_u8 %0, %0, %1, %2" : "+v" (x) : "v" (b), "v" (c));
 #define OP_FMA(x) asm volatile ("v_fma_f32 %0, %0, %1, %2" : "+v" (x) : "v" (b), "v" (c));
 #define OP_ASHRPK(x) asm volatile ("v_lshrrev_b32 %0, 3, %0" : "+v" (x));
+#define OP_LERP(x) asm volatile ("v_lerp_u8 %0, %0, %1, %2" : "+v" (x) : "v" (b), "v" (c));
+#define OP_DOT4I(x) asm volatile ("v_dot4_i32_i8 %0, %1, %2, %0" : "+v" (x) : "v" (b), "v" (c));
+#define OP_SATPK(x) asm volatile ("v_sat_pk_u8_i16 %0, %0" : "+v" (x));
+#define OP_ASHR16S(x) asm volatile ("v_ashrrev_i16_sdwa %0, %1, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:WORD_0" : "+v" (x) : "v" (b));
+#define OP_XOR(x) asm volatile ("v_xor_b32 %0, %0, %1" : "+v" (x) : "v" (b));
+#define OP_MOV(x) asm volatile ("v_mov_b32 %0, %1" : "+v" (x) : "v" (b));
 
 KERNEL (k_add, OP_ADD) KERNEL (k_mul24, OP_MUL24) KERNEL (k_mad24, OP_MAD24) KERNEL (k_mullo, OP_MULLO)
 KERNEL (k_mulhi24, OP_MULHI24) KERNEL (k_add3, OP_ADD3) KERNEL (k_pkshr, OP_PKSHR) KERNEL (k_pkmul, OP_PKMUL)
 KERNEL (k_pkmad, OP_PKMAD) KERNEL (k_pkadd, OP_PKADD) KERNEL (k_perm, OP_PERM) KERNEL (k_and, OP_AND) KERNEL (k_bfe, OP_BFE)
 KERNEL (k_lshlor, OP_LSHLOR) KERNEL (k_med3, OP_MED3) KERNEL (k_cndmask, OP_CNDMASK) KERNEL (k_sdwa, OP_SDWA)
 KERNEL (k_dot4, OP_DOT4) KERNEL (k_sad, OP_SAD) KERNEL (k_fma, OP_FMA) KERNEL (k_shr, OP_ASHRPK)
+KERNEL (k_lerp, OP_LERP) KERNEL (k_dot4i, OP_DOT4I) KERNEL (k_satpk, OP_SATPK) KERNEL (k_ashr16s, OP_ASHR16S) KERNEL (k_xor, OP_XOR) KERNEL (k_mov, OP_MOV)
 
 typedef void (*kern_t) (uint32_t *, uint32_t);
 
@@ -77,5 +84,6 @@ int main ()
 #define R(n) run (#n, n, out);
   R (k_add) R (k_mul24) R (k_mad24) R (k_mullo) R (k_mulhi24) R (k_add3) R (k_pkshr) R (k_pkmul) R (k_pkmad) R (k_pkadd)
   R (k_perm) R (k_and) R (k_bfe) R (k_lshlor) R (k_med3) R (k_cndmask) R (k_sdwa) R (k_dot4) R (k_sad) R (k_fma) R (k_shr)
+  R (k_lerp) R (k_dot4i) R (k_satpk) R (k_ashr16s) R (k_xor) R (k_mov)
   return 0;
 }

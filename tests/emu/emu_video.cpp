@@ -242,11 +242,12 @@ static void run_h420_reg_ch (const H420RegParams &p, int chroma_h, int n_taps)
 static int g_col_runs = 0;
 extern "C" int emu_col_runs (void) { return g_col_runs; }
 
-template <int OPL, int NW>
+template <int OPL, int NW, int NGV>
 struct ColExecEmu {
   ColLane<OPL, NW> L[64];
-  ColRaw<OPL> ra[64], rb[64];
-  template <class F> void each (F f) { for (int lane = 0; lane < 64; lane++) f (lane, L[lane], ra[lane], rb[lane]); }
+  ColRaw<OPL> ra[64];
+  ColRingRegs<OPL, NGV> rg[64];
+  template <class F> void each (F f) { for (int lane = 0; lane < 64; lane++) f (lane, L[lane], ra[lane], rg[lane]); }
   void sync () {}
   void publish (uint32_t *flags, int wave) { flags[wave] = 1u; }
   void wait_flag (uint32_t *flags, int wave)
@@ -258,7 +259,7 @@ struct ColExecEmu {
   }
 };
 
-template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8>
+template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8, int POST>
 static void run_scale_col (const ColParams &p, const ColSrc &src, const Dst &dst, const PostFast &pf, int nwaves)
 {
   const size_t wave_bytes = col_wave_bytes (OPL, NGV, p.pubn);
@@ -275,22 +276,32 @@ static void run_scale_col (const ColParams &p, const ColSrc &src, const Dst &dst
         if (!col_wave_plan (p, chunk, wave, &wp))
           continue;
         uint8_t *mine = lds + GSTAMD_COL_FLAG_BYTES + (size_t) wave * wave_bytes;
-        auto x = std::make_unique<ColExecEmu<OPL, NW>> ();
-        col_wave<OPL, NW, NGV, CH, SEMI, WSTEP, A8> (*x, p, src, p.tiles + 4 * ti, wp, mine, mine + wave_bytes, flags, wave, dst, pf);
+        auto x = std::make_unique<ColExecEmu<OPL, NW, NGV>> ();
+        memset ((void *) x->rg, 0x5a, sizeof (x->rg));
+        col_wave<OPL, NW, NGV, CH, SEMI, WSTEP, A8, POST> (*x, p, src, p.tiles + 4 * ti, wp, mine, mine + wave_bytes, flags, wave, dst, pf);
       }
     }
+}
+
+template <int OPL, int NW, int NGV, int WSTEP, int A8, int POST>
+static void run_scale_col_post (const ColParams &p, int chroma_h, int semi, const ColSrc &src, const Dst &dst, const PostFast &pf, int nwaves)
+{
+  if (chroma_h == CHROMA_H_H2) {
+    if (semi) run_scale_col<OPL, NW, NGV, CHROMA_H_H2, 1, WSTEP, A8, POST> (p, src, dst, pf, nwaves);
+    else run_scale_col<OPL, NW, NGV, CHROMA_H_H2, 0, WSTEP, A8, POST> (p, src, dst, pf, nwaves);
+  } else {
+    if (semi) run_scale_col<OPL, NW, NGV, CHROMA_H_H2_CS, 1, WSTEP, A8, POST> (p, src, dst, pf, nwaves);
+    else run_scale_col<OPL, NW, NGV, CHROMA_H_H2_CS, 0, WSTEP, A8, POST> (p, src, dst, pf, nwaves);
+  }
 }
 
 template <int OPL, int NW, int NGV, int WSTEP, int A8>
 static void run_scale_col_src (const ColParams &p, int chroma_h, int semi, const ColSrc &src, const Dst &dst, const PostFast &pf, int nwaves)
 {
-  if (chroma_h == CHROMA_H_H2) {
-    if (semi) run_scale_col<OPL, NW, NGV, CHROMA_H_H2, 1, WSTEP, A8> (p, src, dst, pf, nwaves);
-    else run_scale_col<OPL, NW, NGV, CHROMA_H_H2, 0, WSTEP, A8> (p, src, dst, pf, nwaves);
-  } else {
-    if (semi) run_scale_col<OPL, NW, NGV, CHROMA_H_H2_CS, 1, WSTEP, A8> (p, src, dst, pf, nwaves);
-    else run_scale_col<OPL, NW, NGV, CHROMA_H_H2_CS, 0, WSTEP, A8> (p, src, dst, pf, nwaves);
-  }
+  if (pf.use)
+    run_scale_col_post<OPL, NW, NGV, WSTEP, A8, 1> (p, chroma_h, semi, src, dst, pf, nwaves);
+  else
+    run_scale_col_post<OPL, NW, NGV, WSTEP, A8, 0> (p, chroma_h, semi, src, dst, pf, nwaves);
 }
 
 // the decision of capi_video.cpp (build_tables + convert_to_packed) for k_scale_col
@@ -328,13 +339,18 @@ static bool emu_scale_col (const VideoPlan &p, const SrcFront &sf, const Dst &ds
   q.out_h = p.passes[1].out_size;
   q.n_tiles = (int) t.tiles.size () / 4;
   q.rows_per_wave = std::max (t.min_rows_per_wave, er && atoi (er) > 0 ? atoi (er) : 5);
-  q.rows_per_wg = q.rows_per_wave * nwaves;
+  q.nwaves = nwaves;
+  q.rows_last = col_rows_last (t, q.rows_per_wave, q.out_h);
+  q.rows_per_wg = q.rows_per_wave * (nwaves - 1) + q.rows_last;
   q.n_chunks = (q.out_h + q.rows_per_wg - 1) / q.rows_per_wg;
   q.pubn = t.pubn;
+  q.dstride = dst.stride;
+  const long long crow_bytes = (long long) q.cstride * (hi - lo) + (semi ? q.width : q.width / 2);
   ColSrc src;
-  src.y = pl.p[0];
-  src.c0 = semi ? pl.p[1] : pl.p[p.front.u_plane];
-  src.c1 = semi ? pl.p[1] : pl.p[p.front.v_plane];
+  src.y = col_plane (pl.p[0], 0, (uint32_t) (q.ystride * (q.height - 1) + q.width));
+  src.c0 = col_plane (semi ? pl.p[1] : pl.p[p.front.u_plane], (long long) lo * q.cstride, (uint32_t) crow_bytes);
+  src.c1 = col_plane (semi ? pl.p[1] : pl.p[p.front.v_plane], (long long) lo * q.cstride, (uint32_t) crow_bytes);
+  src.out = col_plane (dst.p, 0, (uint32_t) (dst.stride * (q.out_h - 1) + 4 * q.out_w));
   g_col_runs++;
 #define V(o, n, g, w, a) if (f.opl == o && f.nw == n && f.ngv == g && f.wstep == w && f.a8 == a) { run_scale_col_src<o, n, g, w, a> (q, p.front.chroma_h, semi, src, dst, pf, nwaves); return true; }
   GSTAMD_COL_FORMS (V)

@@ -191,6 +191,7 @@ def test_hip_scale_col_matches_reference_bytewise(native_lib, gpu, ref, shape, k
 
 def test_hip_scale_col_frame_list_is_one_grid(native_lib, gpu, ref):
     """a list of frames through k_scale_col (the frames are the grid's third dimension; 18 frames: two launches) == the reference frame by frame"""
+    import torch
     ifmt, w, h, ofmt, ow, oh = "NV12", 1920, 1080, "BGRA", 960, 540
     n = 18
     ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)

@@ -172,9 +172,11 @@ static bool col_pick_waves (GstAmdVideoConverter *c)
   c->col_cus = 256;
   if (hipGetDevice (&dev) == hipSuccess && hipGetDeviceProperties (&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     c->col_cus = prop.multiProcessorCount;
+  /* MI355X, C3 (profiles/r04/col_sweep.log): four-wave workgroups of the two-outputs-per-lane form 16.4 us per 8K frame in lists of 8, 17.7 in
+     lists of 4 (eight waves: 18.8 / 20.1, two: 18.8 / 20.8); single frames 25-27 us whatever the form */
   const int pin = tuning_int ("GSTAMD_COL_WAVES", 0);
   int best_waves = 0, best_cu_waves = 0, best_per_cu = 0;
-  for (int nwaves = GSTAMD_COL_MAX_WAVES; nwaves >= 1; nwaves--) {
+  for (int nwaves = pin > 0 ? GSTAMD_COL_MAX_WAVES : 4; nwaves >= 1; nwaves--) {
     if (pin > 0 && nwaves != pin)
       continue;
     const int per_cu = col_blocks_per_cu (c->col_form, p.front.chroma_h, semi, c->col.pubn, nwaves);
@@ -497,6 +499,7 @@ static int build_tables (GstAmdVideoConverter *c)
       }
     }
     c->plane_tmp_bytes = tmp_bytes;
+    c->plane_lds_bytes = 0;           /* of THIS plan (set_config re-plans in place: a size left over from the old plan is not this one's) */
     /* k_plane_frame: up to three planes, no merged packed-4:2:2 scaler, every tile's first pass inside its LDS */
     c->plane_frame_ok = p.planes.size () <= PLN_MAX_JOBS;
     for (const PlanePlan &pp : p.planes) {

@@ -84,7 +84,7 @@ __global__ __launch_bounds__ (256) void k_aggregate (AggregateParams p, uint8_t 
 // one row, pad descriptors and hit tests on the scalar unit, every pad row's 16 bytes requested before the first blend.
 // KEEP: a continuation chunk (bg_kind 2) starts from the canvas - a compile-time variant, because a canvas load that is only
 // *possibly* outstanding makes the compiler put a full s_waitcnt vmcnt(0) in front of every request of aggregate_direct4.
-// No scalar tail: the lanes past the rectangle leave, a lane with fewer than four pixels left moves back onto the rectangle's last
+// No scalar tail: the lanes past the rectangle and a lane with fewer than four pixels left move back onto the rectangle's last
 // four (it and its neighbour compute the same values for the pixels they share; with KEEP the launcher requires rw % 4 == 0) - any
 // compiler-visible memory operation ahead of the requests would put counted waits between them.
 template <int ASH, int KEEP, int NT>
@@ -96,8 +96,9 @@ __global__ __launch_bounds__ (64) void k_aggregate_direct (AggregateParams p, ui
   int wx0 = rx0 + (int) blockIdx.x * 256;
   const int wx1 = wx0 + 256 < rx0 + rw ? wx0 + 256 : rx0 + rw;
   int x = wx0 + 4 * lane;
-  if (x >= rx0 + rw)
-    return;
+  /* every lane stays: lane k tests pad k below (a lane that left before the ballot took its pad with it - in a short last strip the pads
+     from index ceil (rem / 4) up were never blended), and pad k's fields are read back from lane k.  Lanes past the rectangle move
+     onto its last four pixels like the one lane that straddles the edge: the same values to the same address. */
   x = x < last ? x : last;
   wx0 = wx0 < last ? wx0 : last;
   // lane k tests pad k and keeps what a hit needs

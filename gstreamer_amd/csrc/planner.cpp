@@ -997,11 +997,12 @@ ColHTry col_try_h (const std::vector<ColWin> &hw, int width, int opl, int ph, in
         s0 -= align;
     }
     int p0 = s0 > 0 ? s0 : 0;
-    if (p0 + span > width && col_mod (width - p0, pxl) != 0) {
-      /* the tile reaches the picture's right edge: its lanes load whole groups of pxl pixels, so the loads start a multiple of pxl from
-         the edge (the staged bytes then sit off their natural alignment in LDS, like the first tile's) */
+    if (p0 + span > width && col_mod (width - p0, 4) != 0) {
+      /* the tile reaches the picture's right edge: reads past the last row's end are range-checked per dword, so the loads start a
+         multiple of 4 pixels from the edge - no dword straddles it (the staged bytes then sit off their natural alignment in LDS, like
+         the first tile's) */
       s0 -= align;
-      p0 = s0 + col_mod (width - s0, pxl);
+      p0 = s0 + col_mod (width - s0, 4);
       if (p0 < 0)
         return r;
     }
@@ -1053,7 +1054,7 @@ bool make_col_tables (const ScalePass &h, const ScalePass &v, int width, int hei
 {
   if (!h.horizontal || v.horizontal || h.kind != SCALE_NTAP || v.kind != SCALE_NTAP || h.precision != 6 || v.precision != 6)
     return false;
-  if ((opl != 1 && opl != 2) || (width % 4) != 0 || width < 16 * opl || height < 2 || h.in_size != width || v.in_size != height)
+  if ((opl != 1 && opl != 2) || (width % 8) != 0 || width < 16 * opl || height < 2 || h.in_size != width || v.in_size != height)
     return false;
   const int out_w = h.out_size, out_h = v.out_size;
   if (opl == 2 && (out_w & 1))

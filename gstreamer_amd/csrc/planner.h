@@ -178,7 +178,8 @@ int fused420_first_rows (const Fused420Tables &t, int nwaves);
 // tables of the column-walk scaler (video_scale_col.h): both N-tap passes (horizontal first) of a 2x horizontally subsampled planar /
 // semi-planar source in one kernel, one WAVE per column tile walking down its rows.
 //   tiles[t] = {o0, n, s0, p0}: outputs [o0, o0 + n) of every row; the staged source span is the pixels [p0, p0 + 256 opl) and source
-//              pixel q sits at byte q - s0 of a staged byte plane (s0 <= p0, s0 < 0 only for the first tile: p0 = 0 then)
+//              pixel q sits at byte q - s0 of a staged byte plane (p0 = s0 except for the first tile when its s0 < 0: p0 = 0 then; loads past
+//              the picture's right edge read row padding or, out of the plane, zeros - such bytes only ever meet zero taps)
 //   hout[x]  = {wbase, init, tw[0 .. 5]}: byte offset (word aligned) of output x's first window word inside a staged plane, the accumulator's
 //              start value 128 * sum (taps) + 32, the int8 x 4 tap words (zero padded); with `wstep` >= 0 (opl = 2) the two outputs of a lane
 //              share ONE window of nw + wstep words from the even output's wbase, the odd output's words start wstep words in

@@ -73,16 +73,34 @@ GSTAMD_HD void col_store32 (colplane_t pl, uint32_t lane_off, uint32_t row_off, 
 #endif
 }
 
-// dwords at byte lane_off + row_off (+ 4) of the plane; row_off is wave-uniform (the instruction's scalar offset)
-GSTAMD_HD uint32_t col_load32 (colplane_t pl, uint32_t lane_off, uint32_t row_off)
+// 16 / 12 bytes at byte `off` of the plane (any alignment; out of range: zeros, no fault)
+GSTAMD_HD void col_load128 (colplane_t pl, uint32_t off, uint32_t *v)
 {
 #ifdef __HIPCC__
-  return (uint32_t) __builtin_amdgcn_raw_buffer_load_b32 (pl, (int) lane_off, (int) row_off, 0);
+  typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+  const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128 (pl, (int) off, 0, 0);
+  v[0] = d.x, v[1] = d.y, v[2] = d.z, v[3] = d.w;
 #else
-  uint32_t v = 0;
-  if ((unsigned long long) lane_off + row_off + 4 <= pl.bytes)
-    __builtin_memcpy (&v, pl.p + lane_off + row_off, 4);
-  return v;
+  v[0] = v[1] = v[2] = v[3] = 0;
+  if ((unsigned long long) off + 16 <= pl.bytes)
+    __builtin_memcpy (v, pl.p + off, 16);
+  else if (off < pl.bytes)
+    __builtin_memcpy (v, pl.p + off, (pl.bytes - off) & ~3u);       /* range checking is per dword */
+#endif
+}
+
+GSTAMD_HD void col_load96 (colplane_t pl, uint32_t off, uint32_t *v)
+{
+#ifdef __HIPCC__
+  typedef uint32_t u32x3 __attribute__ ((ext_vector_type (3)));
+  const u32x3 d = __builtin_amdgcn_raw_buffer_load_b96 (pl, (int) off, 0, 0);
+  v[0] = d.x, v[1] = d.y, v[2] = d.z;
+#else
+  v[0] = v[1] = v[2] = 0;
+  if ((unsigned long long) off + 12 <= pl.bytes)
+    __builtin_memcpy (v, pl.p + off, 12);
+  else if (off < pl.bytes)
+    __builtin_memcpy (v, pl.p + off, (pl.bytes - off) & ~3u);
 #endif
 }
 
@@ -156,20 +174,37 @@ inline int col_rows_last (const ColTables &t, int rows_per_wave, int out_h)
 
 template <int OPL>
 struct ColGeom {
-  static constexpr int PXL = 4 * OPL;                   // source pixels per lane and line
+  static constexpr int PXL = 4 * OPL;                   // source pixels per lane and line (the lane's share of a staged line)
   static constexpr int SPAN = 64 * PXL;
   static constexpr int PP = SPAN + 16;                  // bytes of a staged plane
   static constexpr int LINEB = 3 * PP;
   static constexpr int STAGEB = 4 * LINEB + 32;         // + room for the zero-tap words a window may read past the last plane
-  static constexpr int SLOTW = 3 * OPL * 64;            // words of a ring slot: [channel][lane][output of the lane]
+  static constexpr int SLOTW = 3 * OPL * 64;            // words of a hand-over slot: [channel][lane][output of the lane]
+  // loads.  Vector memory instructions cost the same whatever they carry per lane (~14 G wave-instructions / s on the chip: one per ~37
+  // cycles and CU), so a group's 1 KB x OPL of luma is OPL instructions of 16 bytes a lane (16 OPL lanes per line, 4 / OPL lines per
+  // instruction) and its raw chroma rows go through a small LDS area: lanes 8 bytes apart read 12 bytes each (the 4 extra bytes carry the
+  // neighbour samples of the row's last lane).  Planar: one instruction per plane, lanes [0, 16 OPL) row 2g, [16 OPL, 32 OPL) row 2g + 1;
+  // semi-planar: 32 OPL lanes per row, OPL instructions.
+  static constexpr int YI = OPL;
+  static constexpr int YLPL = 16 * OPL;                 // lanes per line
+  static constexpr int YLINES = 4 / OPL;                // lines per instruction
 };
+template <int OPL, int SEMI>
+struct ColChroma {
+  static constexpr int CB = SEMI ? 2 : 1;               // bytes per chroma sample position
+  static constexpr int CI = SEMI ? OPL : 2;             // load instructions per group
+  static constexpr int CLPR = 16 * OPL * CB;            // lanes per raw row
+  static constexpr int CROWB = 128 * OPL * CB + 16;     // bytes of a raw row in LDS
+  static constexpr int CROWS = SEMI ? 2 : 4;            // semi-planar: rows 2g, 2g+1; planar: U 2g, U 2g+1, V 2g, V 2g+1
+};
+#define GSTAMD_COL_CRAW_BYTES(opl) (4 * (128 * (opl) + 16) + 32)
 
-// LDS of a wave: the staged group, then the hand-over slots (the ring of line groups itself lives in registers)
+// LDS of a wave: the staged group, the raw chroma rows, then the hand-over slots (the ring of line groups itself lives in registers)
 GSTAMD_H420_HOSTDEV size_t col_wave_bytes (int opl, int ngv, int pubn)
 {
   const int slotw = 3 * opl * 64, stage = 4 * 3 * (256 * opl + 16) + 32;
   (void) ngv;
-  return (size_t) ((stage + pubn * slotw * 4 + 15) & ~15);
+  return (size_t) ((stage + GSTAMD_COL_CRAW_BYTES (opl) + pubn * slotw * 4 + 15) & ~15);
 }
 
 // per-lane constants of a wave
@@ -179,10 +214,14 @@ struct ColLane {
   int hinit[OPL];
   int wb[OPL];                  // byte offset of the output's first window word inside a staged plane (shared windows: wb[0] for both)
   int lb[4][OPL];               // wb + line * LINEB, kept apart (see col_setup)
-  int st;                       // byte offset of the lane's staged pixels inside a plane
-  int xl;                       // first source pixel the lane loads
   int xo;                       // first output column of the lane
-  int ca[OPL];                  // first chroma sample of the lane's chroma load(s)
+  // loads (the lane as one of 16 OPL per luma line / as one of the lanes of a raw chroma row)
+  int yvo, ykl;                 // luma: byte offset inside the row, line of the group (first instruction; + YLINES per instruction)
+  int yst;                      // luma: LDS byte of the lane's 16 pixels (first instruction; + YLINES * LINEB per instruction)
+  int cvo[2], crow[2], cst[2];  // chroma instruction t: byte offset inside the row (idle lanes: out of range), row of the pair, LDS byte in the raw area
+  // staging (the lane as the owner of 4 OPL pixels of every line)
+  int st;                       // byte offset of the lane's staged pixels inside a plane
+  int cr[OPL];                  // byte offset inside a raw chroma row of the 8 bytes the lane's chroma of pixels 4j .. 4j+3 comes from
   uint32_t sx[OPL], sy[OPL];    // v_perm selectors of the horizontal chroma filter (U; planar: both planes)
   uint32_t sxv[OPL], syv[OPL];  // semi-planar: the V bytes
   uint32_t hu[OPL], hv[OPL];    // h-filtered chroma row 2g-1 (carried from the previous group)
@@ -197,8 +236,8 @@ struct ColRingRegs {
 // one group's loads
 template <int OPL>
 struct ColRaw {
-  uint32_t y[4][OPL];
-  uint32_t c[2][2 * OPL];       // chroma rows 2g, 2g+1.  planar: [0, OPL) U, [OPL, 2 OPL) V; semi-planar: OPL x 8 interleaved bytes
+  uint32_t y[OPL][4];
+  uint32_t c[2][3];
 };
 
 GSTAMD_HD int col_clamp (int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -254,10 +293,43 @@ GSTAMD_HD int col_dot4s (uint32_t a, uint32_t b_uniform, int c)
 #endif
 }
 
-// selector byte of chroma sample s for a lane whose load starts at sample a: planar byte s - a, semi-planar byte 2 (s - a) + comp
-GSTAMD_HD uint32_t col_sel_byte (int s, int a, int cw, int semi, int comp)
+// N words of LDS from p; A8: p is 8-byte aligned (ds_read_b64 at 256 B / clk; off that alignment such a read is replayed for 64 cycles);
+// A8 < 0: p may be only 2-byte aligned
+template <int N, int A8>
+GSTAMD_HD void col_lds_words (const uint8_t *p, uint32_t *o)
 {
-  const int pos = col_clamp (s, 0, cw - 1) - a;
+#ifdef __HIPCC__
+  typedef const __attribute__ ((address_space (3))) uint32_t *lptr_t;
+  typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
+  typedef const __attribute__ ((address_space (3))) u32x2 *lptr2_t;
+  if (A8) {
+#pragma unroll
+    for (int k = 0; k + 1 < N; k += 2) {
+      const u32x2 v = *(lptr2_t) (p + 4 * k);
+      o[k] = v.x, o[k + 1] = v.y;
+    }
+    if (N & 1)
+      o[N - 1] = *(lptr_t) (p + 4 * (N - 1));
+  } else if (A8 < 0) {
+    typedef uint32_t __attribute__ ((aligned (2))) u32_a2;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      o[k] = *(const __attribute__ ((address_space (3))) u32_a2 *) (p + 4 * k);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      o[k] = *(lptr_t) (p + 4 * k);
+  }
+#else
+  for (int k = 0; k < N; k++)
+    __builtin_memcpy (&o[k], p + 4 * k, 4);
+#endif
+}
+
+// selector byte of chroma sample s among the 8 bytes that start at sample sb of a raw row: planar byte s - sb, semi-planar 2 (s - sb) + comp
+GSTAMD_HD uint32_t col_sel_byte (int s, int sb, int cw, int semi, int comp)
+{
+  const int pos = col_clamp (col_clamp (s, 0, cw - 1) - sb, 0, semi ? 3 : 7);
   return (uint32_t) (semi ? 2 * pos + comp : pos);
 }
 
@@ -265,23 +337,42 @@ template <int OPL, int NW, int CH, int SEMI>
 GSTAMD_HD void col_setup (const ColParams &p, const int32_t *tile, int lane, ColLane<OPL, NW> &L)
 {
   typedef ColGeom<OPL> G;
+  typedef ColChroma<OPL, SEMI> C;
   const int o0 = tile[0], n = tile[1], s0 = tile[2], p0 = tile[3];
-  const int cw = p.width >> 1;
-  int xl = p0 + G::PXL * lane;
-  if (xl + G::PXL > p.width)
-    xl = p.width - G::PXL;              // lanes past the picture: harmless loads, their staged bytes meet zero taps only
-  L.xl = xl;
-  L.st = (p0 - s0) + G::PXL * lane;
+  const int cw = p.width >> 1, delta = p0 - s0;
+  // ---- the lane as a loader
+  L.ykl = lane / G::YLPL;
+  L.yvo = p0 + 16 * (lane % G::YLPL);
+  L.yst = L.ykl * G::LINEB + delta + 16 * (lane % G::YLPL);
+  int rawbase = p0 / 2 - 1 > 0 ? p0 / 2 - 1 : 0;                /* first sample of a raw row: one left of the span's first (the non-co-sited filter's neighbour) */
+  if (p0 + G::SPAN > p.width)                                   /* a tile at the right edge: whole dwords up to the row's end (width % 8 == 0), see ColTables */
+    rawbase -= (rawbase - cw) & (4 / C::CB - 1);
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int u = SEMI ? t * 64 + lane : lane;                  /* planar: instruction t is plane t */
+    const int row = u / C::CLPR, j = u % C::CLPR;
+    const bool live = t < C::CI && row < 2;
+    L.crow[t] = live ? row : 0;
+    L.cvo[t] = live ? rawbase * C::CB + 8 * j : 0x40000000;     /* idle lanes: out of range, no memory request */
+    L.cst[t] = live ? ((SEMI ? row : 2 * t + row) * C::CROWB + 8 * j) : C::CROWS * C::CROWB;
+  }
+  // ---- the lane as the owner of 4 OPL pixels per line
+  L.st = delta + G::PXL * lane;
   const int uo = SEMI ? (p.u_first ? 0 : 1) : 0;
 #pragma unroll
   for (int j = 0; j < OPL; j++) {
-    const int k = (xl + 4 * j) >> 1;
-    const int a = col_clamp (CH == CHROMA_H_H2 ? k - 1 : k, 0, cw - 4);
-    L.ca[j] = a;
+    const int k = (p0 + G::PXL * lane + 4 * j) >> 1;
+    // planar: the aligned dword pair around sample k - 1; semi-planar: the pairs k - 1 .. k + 2 themselves (8 bytes: no slack to align in -
+    // the first tile, whose raw rows start at sample 0 instead of -1, reads them off a 2-byte boundary)
+    int cr = SEMI ? (k - 1 - rawbase) * 2 : ((k - 1 - rawbase) & ~3);
+    if (cr < 0)
+      cr = 0;
+    L.cr[j] = cr;
+    const int sb = rawbase + cr / C::CB;
     // pixels 4j .. 4j+3 of the lane: X = {c[k], c[k], c[k+1], c[k+1]}; co-sited Y = {c[k], c[k+1], c[k+1], c[k+2]} (even pixel: the sample, odd:
     // (c[j] + c[j+1] + 1) >> 1), else Y = {c[k-1], c[k+1], c[k], c[k+2]} ((3 X + Y + 2) >> 2); samples clamp at the picture's edges
-    const uint32_t k0 = col_sel_byte (k, a, cw, SEMI, uo), k1 = col_sel_byte (k + 1, a, cw, SEMI, uo), k2 = col_sel_byte (k + 2, a, cw, SEMI, uo),
-        km = col_sel_byte (k - 1, a, cw, SEMI, uo);
+    const uint32_t k0 = col_sel_byte (k, sb, cw, SEMI, uo), k1 = col_sel_byte (k + 1, sb, cw, SEMI, uo), k2 = col_sel_byte (k + 2, sb, cw, SEMI, uo),
+        km = col_sel_byte (k - 1, sb, cw, SEMI, uo);
     L.sx[j] = k0 | (k0 << 8) | (k1 << 16) | (k1 << 24);
     if (CH == CHROMA_H_H2)
       L.sy[j] = km | (k1 << 8) | (k0 << 16) | (k2 << 24);
@@ -317,22 +408,15 @@ GSTAMD_HD void col_setup (const ColParams &p, const int32_t *tile, int lane, Col
   }
 }
 
-template <int OPL, int SEMI>
-GSTAMD_HD void col_load_crow (const ColParams &p, const ColSrc &s, const int *ca, int row, uint32_t *c)
+// chroma rows crow0, crow0 + 1 (a group's: 2g, 2g + 1), clamped into the rows the upsampler may touch
+template <int OPL, int NW, int SEMI>
+GSTAMD_HD void col_request_chroma (const ColParams &p, const ColSrc &s, const ColLane<OPL, NW> &L, int crow0, ColRaw<OPL> &r)
 {
-  const uint32_t ro = col_row_off (col_clamp (row, p.crow_lo, p.crow_hi) - p.crow_lo, p.cstride);
-  if (SEMI) {
+  typedef ColChroma<OPL, SEMI> C;
 #pragma unroll
-    for (int j = 0; j < OPL; j++) {
-      c[2 * j] = col_load32 (s.c0, (uint32_t) (2 * ca[j]), ro);
-      c[2 * j + 1] = col_load32 (s.c0, (uint32_t) (2 * ca[j] + 4), ro);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < OPL; j++) {
-      c[j] = col_load32 (s.c0, (uint32_t) ca[j], ro);
-      c[OPL + j] = col_load32 (s.c1, (uint32_t) ca[j], ro);
-    }
+  for (int t = 0; t < C::CI; t++) {
+    const int row = col_clamp (crow0 + L.crow[t], p.crow_lo, p.crow_hi) - p.crow_lo;
+    col_load96 (SEMI || t == 0 ? s.c0 : s.c1, (uint32_t) (row * p.cstride + L.cvo[t]), r.c[t]);
   }
 }
 
@@ -340,63 +424,34 @@ GSTAMD_HD void col_load_crow (const ColParams &p, const ColSrc &s, const int *ca
 template <int OPL, int NW, int SEMI>
 GSTAMD_HD void col_request (const ColParams &p, const ColSrc &s, const ColLane<OPL, NW> &L, int g, ColRaw<OPL> &r)
 {
+  typedef ColGeom<OPL> G;
 #if defined(GSTAMD_COL_ABL) && GSTAMD_COL_ABL == 1      /* profiling builds only (results WRONG): no source loads after a wave's first */
   if (g != -12345)
     return;
 #endif
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t ro = col_row_off (col_clamp (4 * g - 1 + k, 0, p.height - 1), p.ystride);
-#pragma unroll
-    for (int j = 0; j < OPL; j++)
-      r.y[k][j] = col_load32 (s.y, (uint32_t) (L.xl + 4 * j), ro);
+  for (int t = 0; t < G::YI; t++) {
+    const int y = col_clamp (4 * g - 1 + L.ykl + t * G::YLINES, 0, p.height - 1);
+    col_load128 (s.y, (uint32_t) (y * p.ystride + L.yvo), r.y[t]);
   }
-  col_load_crow<OPL, SEMI> (p, s, L.ca, 2 * g, r.c[0]);
-  col_load_crow<OPL, SEMI> (p, s, L.ca, 2 * g + 1, r.c[1]);
+  col_request_chroma<OPL, NW, SEMI> (p, s, L, 2 * g, r);
 }
 
-// horizontal chroma filter of one raw row: 4 OPL pixels of U and of V in byte lanes
-template <int OPL, int NW, int CH, int SEMI>
-GSTAMD_HD void col_hup (const ColLane<OPL, NW> &L, const uint32_t *c, uint32_t *u, uint32_t *v)
-{
-#pragma unroll
-  for (int j = 0; j < OPL; j++) {
-    uint32_t xu, yu, xv, yv;
-    if (SEMI) {
-      xu = bperm (c[2 * j + 1], c[2 * j], L.sx[j]), xv = bperm (c[2 * j + 1], c[2 * j], L.sxv[j]);
-      if (CH != CHROMA_H_NONE)
-        yu = bperm (c[2 * j + 1], c[2 * j], L.sy[j]), yv = bperm (c[2 * j + 1], c[2 * j], L.syv[j]);
-      else
-        yu = xu, yv = xv;
-    } else {
-      xu = bperm (c[j], c[j], L.sx[j]), xv = bperm (c[OPL + j], c[OPL + j], L.sx[j]);
-      if (CH != CHROMA_H_NONE)
-        yu = bperm (c[j], c[j], L.sy[j]), yv = bperm (c[OPL + j], c[OPL + j], L.sy[j]);
-      else
-        yu = xu, yv = xv;
-    }
-    if (CH == CHROMA_H_H2_CS)
-      u[j] = lerp_u8 (xu, yu, 0x01010101u), v[j] = lerp_u8 (xv, yv, 0x01010101u);
-    else if (CH == CHROMA_H_H2)
-      u[j] = blend31_u8 (xu, yu), v[j] = blend31_u8 (xv, yv);
-    else
-      u[j] = xu, v[j] = xv;
-  }
-}
-
-// the lane's 4 OPL bytes of one staged plane line.  Tiles whose LDS placement is not a multiple of the lane's width (the first tile:
-// s0 < 0) store 16-bit halves - an 8-byte store off its alignment is replayed for 64 cycles.
-template <int OPL, int ALIGNED>
+// n dwords at LDS byte d; tiles whose LDS placement is off the natural alignment (the first tile: s0 < 0) store 16-bit halves - a wide
+// store off its alignment is replayed for 64 cycles
+template <int N, int ALIGNED>
 GSTAMD_HD void col_lds_store (uint8_t *d, const uint32_t *w)
 {
   if constexpr (ALIGNED) {
-    if constexpr (OPL == 2)
+    if constexpr (N == 4)
+      *(uint4 *) d = gstamd_make_uint4 (w[0], w[1], w[2], w[3]);
+    else if constexpr (N == 2)
       *(uint2 *) d = gstamd_make_uint2 (w[0], w[1]);
     else
       *(uint32_t *) d = w[0];
   } else {
 #pragma unroll
-    for (int j = 0; j < OPL; j++) {
+    for (int j = 0; j < N; j++) {
 #ifdef __HIPCC__
       typedef volatile __attribute__ ((address_space (3))) uint16_t *lds16_t;       /* volatile: not to be merged back into one misaligned store */
       *(lds16_t) (d + 4 * j) = (uint16_t) w[j];
@@ -409,17 +464,64 @@ GSTAMD_HD void col_lds_store (uint8_t *d, const uint32_t *w)
   }
 }
 
-// stage group g from its loads: Y, U, V byte planes of the four lines.  Chroma rows: A = 2g-1 (carried, h-filtered), B = 2g, C = 2g+1;
-// line 4g-1 = (3 A + B + 2) >> 2, 4g = (A + 3 B + 2) >> 2, 4g+1 = (3 B + C + 2) >> 2, 4g+2 = (B + 3 C + 2) >> 2 per byte, each as
-// lerp (heavy, (heavy + light) >> 1) - the inner average is the same for the two lines of a pair.
+// first half of the staging, the lane as a loader: the luma bytes (XOR 0x80) straight into their plane, the raw chroma rows into the raw area
+template <int OPL, int NW, int SEMI, int ALIGNED>
+GSTAMD_HD void col_stage_loads (const ColLane<OPL, NW> &L, const ColRaw<OPL> &r, uint8_t *stage, uint8_t *craw, bool with_luma)
+{
+  typedef ColGeom<OPL> G;
+  typedef ColChroma<OPL, SEMI> C;
+  if (with_luma) {
+#pragma unroll
+    for (int t = 0; t < G::YI; t++) {
+      const uint32_t w[4] = {r.y[t][0] ^ 0x80808080u, r.y[t][1] ^ 0x80808080u, r.y[t][2] ^ 0x80808080u, r.y[t][3] ^ 0x80808080u};
+      col_lds_store<4, ALIGNED> (stage + L.yst + t * G::YLINES * G::LINEB, w);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < C::CI; t++) {
+    // 12 bytes, the last four the same as the next lane's first four
+    col_lds_store<2, 1> (craw + L.cst[t], r.c[t]);
+    col_lds_store<1, 1> (craw + L.cst[t] + 8, r.c[t] + 2);
+  }
+}
+
+// horizontal chroma filter of one raw row (in the raw area): 4 OPL pixels of U and of V in byte lanes
 template <int OPL, int NW, int CH, int SEMI, int ALIGNED>
-GSTAMD_HD void col_stage (ColLane<OPL, NW> &L, const ColRaw<OPL> &r, uint8_t *stage)
+GSTAMD_HD void col_hup (const ColLane<OPL, NW> &L, const uint8_t *craw, int row, uint32_t *u, uint32_t *v)
+{
+  typedef ColChroma<OPL, SEMI> C;
+#pragma unroll
+  for (int j = 0; j < OPL; j++) {
+    uint32_t cu[2], cv[2];
+    col_lds_words<2, (SEMI && !ALIGNED) ? -1 : 0> (craw + row * C::CROWB + L.cr[j], cu);
+    if (SEMI)
+      cv[0] = cu[0], cv[1] = cu[1];
+    else
+      col_lds_words<2, 0> (craw + (2 + row) * C::CROWB + L.cr[j], cv);
+    const uint32_t xu = bperm (cu[1], cu[0], L.sx[j]), xv = bperm (cv[1], cv[0], SEMI ? L.sxv[j] : L.sx[j]);
+    uint32_t yu = xu, yv = xv;
+    if (CH != CHROMA_H_NONE)
+      yu = bperm (cu[1], cu[0], L.sy[j]), yv = bperm (cv[1], cv[0], SEMI ? L.syv[j] : L.sy[j]);
+    if (CH == CHROMA_H_H2_CS)
+      u[j] = lerp_u8 (xu, yu, 0x01010101u), v[j] = lerp_u8 (xv, yv, 0x01010101u);
+    else if (CH == CHROMA_H_H2)
+      u[j] = blend31_u8 (xu, yu), v[j] = blend31_u8 (xv, yv);
+    else
+      u[j] = xu, v[j] = xv;
+  }
+}
+
+// second half of the staging, the lane as the owner of 4 OPL pixels of every line: U and V byte planes of the four lines.  Chroma rows:
+// A = 2g-1 (carried, h-filtered), B = 2g, C = 2g+1; line 4g-1 = (3 A + B + 2) >> 2, 4g = (A + 3 B + 2) >> 2, 4g+1 = (3 B + C + 2) >> 2,
+// 4g+2 = (B + 3 C + 2) >> 2 per byte, each as lerp (heavy, (heavy + light) >> 1) - the inner average is the same for the two lines of a pair.
+template <int OPL, int NW, int CH, int SEMI, int ALIGNED>
+GSTAMD_HD void col_stage_chroma (ColLane<OPL, NW> &L, const uint8_t *craw, uint8_t *stage)
 {
   typedef ColGeom<OPL> G;
   uint32_t bu[OPL], bv[OPL], cu[OPL], cv[OPL];
-  col_hup<OPL, NW, CH, SEMI> (L, r.c[0], bu, bv);
-  col_hup<OPL, NW, CH, SEMI> (L, r.c[1], cu, cv);
-  uint32_t lu[4][OPL], lv[4][OPL], ly[4][OPL];
+  col_hup<OPL, NW, CH, SEMI, ALIGNED> (L, craw, 0, bu, bv);
+  col_hup<OPL, NW, CH, SEMI, ALIGNED> (L, craw, 1, cu, cv);
+  uint32_t lu[4][OPL], lv[4][OPL];
 #pragma unroll
   for (int j = 0; j < OPL; j++) {
     const uint32_t mu = lerp_u8 (L.hu[j], bu[j], 0u), mv = lerp_u8 (L.hv[j], bv[j], 0u);
@@ -429,26 +531,21 @@ GSTAMD_HD void col_stage (ColLane<OPL, NW> &L, const ColRaw<OPL> &r, uint8_t *st
     lu[2][j] = lerp_u8 (bu[j], nu, 0x01010101u) ^ 0x80808080u, lv[2][j] = lerp_u8 (bv[j], nv, 0x01010101u) ^ 0x80808080u;
     lu[3][j] = lerp_u8 (cu[j], nu, 0x01010101u) ^ 0x80808080u, lv[3][j] = lerp_u8 (cv[j], nv, 0x01010101u) ^ 0x80808080u;
     L.hu[j] = cu[j], L.hv[j] = cv[j];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      ly[k][j] = r.y[k][j] ^ 0x80808080u;
   }
   uint8_t *d = stage + L.st;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    col_lds_store<OPL, ALIGNED> (d + k * G::LINEB, ly[k]);
     col_lds_store<OPL, ALIGNED> (d + k * G::LINEB + G::PP, lu[k]);
     col_lds_store<OPL, ALIGNED> (d + k * G::LINEB + 2 * G::PP, lv[k]);
   }
 }
 
-// chroma row 2g-1 of a wave's first group: loaded and h-filtered on the spot
-template <int OPL, int NW, int CH, int SEMI>
-GSTAMD_HD void col_first_row (const ColParams &p, const ColSrc &s, ColLane<OPL, NW> &L, int g)
+// chroma row 2g-1 of a wave's first group, h-filtered: what the staging of group g - 1 would have left in hu / hv.  After col_stage_loads
+// of the rows (2g-2, 2g-1) and a sync.
+template <int OPL, int NW, int CH, int SEMI, int ALIGNED>
+GSTAMD_HD void col_first_row (ColLane<OPL, NW> &L, const uint8_t *craw)
 {
-  uint32_t c[2 * OPL];
-  col_load_crow<OPL, SEMI> (p, s, L.ca, 2 * g - 1, c);
-  col_hup<OPL, NW, CH, SEMI> (L, c, L.hu, L.hv);
+  col_hup<OPL, NW, CH, SEMI, ALIGNED> (L, craw, 1, L.hu, L.hv);
 }
 
 // Two gfx950 hazards the compiler does not see inside inline asm (both found on the device: bytes off by a few units in rows whose last
@@ -502,33 +599,6 @@ GSTAMD_HD uint32_t col_fin_px (int ay, int au, int av)
   return w;
 #else
   return 0xffu | (h420r_finish (ay) << 8) | (h420r_finish (au) << 16) | (h420r_finish (av) << 24);
-#endif
-}
-
-// N words of LDS from p; A8: p is 8-byte aligned (ds_read_b64 at 256 B / clk; off that alignment such a read is replayed for 64 cycles)
-template <int N, int A8>
-GSTAMD_HD void col_lds_words (const uint8_t *p, uint32_t *o)
-{
-#ifdef __HIPCC__
-  typedef const __attribute__ ((address_space (3))) uint32_t *lptr_t;
-  typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
-  typedef const __attribute__ ((address_space (3))) u32x2 *lptr2_t;
-  if (A8) {
-#pragma unroll
-    for (int k = 0; k + 1 < N; k += 2) {
-      const u32x2 v = *(lptr2_t) (p + 4 * k);
-      o[k] = v.x, o[k + 1] = v.y;
-    }
-    if (N & 1)
-      o[N - 1] = *(lptr_t) (p + 4 * (N - 1));
-  } else {
-#pragma unroll
-    for (int k = 0; k < N; k++)
-      o[k] = *(lptr_t) (p + 4 * k);
-  }
-#else
-  for (int k = 0; k < N; k++)
-    o[k] = *(const uint32_t *) (p + 4 * k);
 #endif
 }
 
@@ -719,15 +789,28 @@ GSTAMD_HD void col_wave (X &x, const ColParams &p, const ColSrc &s, const int32_
   typedef ColLane<OPL, NW> Lane;
   typedef ColRaw<OPL> Raw;
   typedef ColRingRegs<OPL, NGV> Ring;
-  uint8_t *stage = wave_lds;
-  uint32_t *pub = (uint32_t *) (wave_lds + G::STAGEB);
-  const uint32_t *pub_below = (const uint32_t *) (below_lds + G::STAGEB);
-  const bool aligned = ((tile[3] - tile[2]) % G::PXL) == 0;
+  uint8_t *stage = wave_lds, *craw = wave_lds + G::STAGEB;
+  uint32_t *pub = (uint32_t *) (wave_lds + G::STAGEB + GSTAMD_COL_CRAW_BYTES (OPL));
+  const uint32_t *pub_below = (const uint32_t *) (below_lds + G::STAGEB + GSTAMD_COL_CRAW_BYTES (OPL));
+  const bool aligned = ((tile[3] - tile[2]) % 16) == 0 && tile[3] > 0 && tile[3] + G::SPAN <= p.width;
+  // chroma row 2 ga - 1 the way the staging of group ga - 1 would have left it, then the first group's loads
   x.each ([&](int lane, Lane &L, Raw &ra, Ring &) {
     col_setup<OPL, NW, CH, SEMI> (p, tile, lane, L);
+    col_request_chroma<OPL, NW, SEMI> (p, s, L, 2 * wp.ga - 2, ra);
+    if (aligned)
+      col_stage_loads<OPL, NW, SEMI, 1> (L, ra, stage, craw, false);
+    else
+      col_stage_loads<OPL, NW, SEMI, 0> (L, ra, stage, craw, false);
     col_request<OPL, NW, SEMI> (p, s, L, wp.ga, ra);
-    col_first_row<OPL, NW, CH, SEMI> (p, s, L, wp.ga);
   });
+  x.sync ();
+  x.each ([&](int, Lane &L, Raw &, Ring &) {
+    if (aligned)
+      col_first_row<OPL, NW, CH, SEMI, 1> (L, craw);
+    else
+      col_first_row<OPL, NW, CH, SEMI, 0> (L, craw);
+  });
+  x.sync ();
   int r = wp.r0;
   uint32_t e[8];
   col_entry8 (p.vrow, r, e);
@@ -758,24 +841,23 @@ GSTAMD_HD void col_wave (X &x, const ColParams &p, const ColSrc &s, const int32_
     x.wait_loads ();
     COL_STAMP (1);                      /* waiting for the group's source loads */
 #endif
-#if defined(GSTAMD_COL_ABL) && GSTAMD_COL_ABL == 4      /* no staging */
-    if (g == -12345)
-#else
+    // the loads' registers go to LDS (luma: final; chroma: raw rows) and take the next group's requests - those have the horizontal pass, the
+    // rows and the other waves' turns to arrive
     if (aligned)
-#endif
       x.each ([&](int, Lane &L, Raw &ra, Ring &) {
-        col_stage<OPL, NW, CH, SEMI, 1> (L, ra, stage);
+        col_stage_loads<OPL, NW, SEMI, 1> (L, ra, stage, craw, true);
         col_request<OPL, NW, SEMI> (p, s, L, gn, ra);
       });
-#if defined(GSTAMD_COL_ABL) && GSTAMD_COL_ABL == 4
-    else if (g == -12346)
-#else
     else
-#endif
       x.each ([&](int, Lane &L, Raw &ra, Ring &) {
-        col_stage<OPL, NW, CH, SEMI, 0> (L, ra, stage);
+        col_stage_loads<OPL, NW, SEMI, 0> (L, ra, stage, craw, true);
         col_request<OPL, NW, SEMI> (p, s, L, gn, ra);
       });
+    x.sync ();
+    if (aligned)
+      x.each ([&](int, Lane &L, Raw &, Ring &) { col_stage_chroma<OPL, NW, CH, SEMI, 1> (L, craw, stage); });
+    else
+      x.each ([&](int, Lane &L, Raw &, Ring &) { col_stage_chroma<OPL, NW, CH, SEMI, 0> (L, craw, stage); });
     x.sync ();
     COL_STAMP (2);                      /* staging */
     x.each ([&](int lane, Lane &L, Raw &, Ring &rg) {

@@ -592,3 +592,85 @@ gst_amd_hip_buffer_new_video (const GstVideoInfo * info)
         (gsize *) info->offset, (gint *) info->stride);
   return buf;
 }
+
+/* ---- host buffers under a queued transfer ------------------------------------------------------------------------------------------- */
+typedef struct
+{
+  gpointer event;
+  GstBuffer *buf;
+} AmdPendingRead;
+
+struct _GstAmdHipPendingReads
+{
+  GMutex lock;
+  GQueue items;
+};
+
+GstAmdHipPendingReads *
+gst_amd_hip_pending_reads_new (void)
+{
+  GstAmdHipPendingReads *p = g_new0 (GstAmdHipPendingReads, 1);
+  g_mutex_init (&p->lock);
+  g_queue_init (&p->items);
+  return p;
+}
+
+/* drop the references of the transfers that are over (all of them when `wait`); events fire in stream order but the element may use
+ * several streams, so the whole queue is looked at */
+static void
+amd_pending_reads_retire (GstAmdHipPendingReads * p, gboolean wait)
+{
+  GList *l = p->items.head;
+  while (l) {
+    GList *next = l->next;
+    AmdPendingRead *r = l->data;
+    if (wait)
+      gstamd_event_synchronize (r->event);
+    if (wait || gstamd_event_query (r->event) != 0) {
+      gstamd_event_free (r->event);
+      gst_buffer_unref (r->buf);
+      g_free (r);
+      g_queue_delete_link (&p->items, l);
+    }
+    l = next;
+  }
+}
+
+void
+gst_amd_hip_pending_reads_hold (GstAmdHipPendingReads * p, GstBuffer * buf, gpointer stream)
+{
+  AmdPendingRead *r;
+  gpointer ev = gstamd_event_new ();
+  if (!ev || gstamd_event_record (ev, stream) != GSTAMD_OK) {
+    /* no event: the safe answer is to wait for the stream here */
+    if (ev)
+      gstamd_event_free (ev);
+    gstamd_stream_synchronize (stream);
+    return;
+  }
+  r = g_new0 (AmdPendingRead, 1);
+  r->event = ev;
+  r->buf = gst_buffer_ref (buf);
+  g_mutex_lock (&p->lock);
+  g_queue_push_tail (&p->items, r);
+  amd_pending_reads_retire (p, FALSE);
+  g_mutex_unlock (&p->lock);
+}
+
+void
+gst_amd_hip_pending_reads_drain (GstAmdHipPendingReads * p)
+{
+  g_mutex_lock (&p->lock);
+  amd_pending_reads_retire (p, TRUE);
+  g_mutex_unlock (&p->lock);
+}
+
+void
+gst_amd_hip_pending_reads_free (GstAmdHipPendingReads * p)
+{
+  if (!p)
+    return;
+  gst_amd_hip_pending_reads_drain (p);
+  g_mutex_clear (&p->lock);
+  g_free (p);
+}

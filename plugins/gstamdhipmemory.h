@@ -93,6 +93,15 @@ void gst_amd_hip_memory_host_wait (GstMemory * mem);
 /* device every thread of this process should select before touching HIP for an element: -1 = leave the current one */
 void gst_amd_hip_select_device (gint device_id);
 
+/* Host buffers a queued host -> HBM transfer still reads.  From page-locked memory (our own pinned pools, or anybody's) the copy call
+ * returns before a byte has moved, so the buffer must not go back to its pool - and be overwritten upstream - when transform () returns:
+ * it stays referenced until an event recorded behind the copy has fired. */
+typedef struct _GstAmdHipPendingReads GstAmdHipPendingReads;
+GstAmdHipPendingReads *gst_amd_hip_pending_reads_new (void);
+void gst_amd_hip_pending_reads_hold (GstAmdHipPendingReads * p, GstBuffer * buf, gpointer stream);     /* right after queueing the copy */
+void gst_amd_hip_pending_reads_drain (GstAmdHipPendingReads * p);        /* wait for every transfer, drop the references (stop, flush) */
+void gst_amd_hip_pending_reads_free (GstAmdHipPendingReads * p);
+
 G_END_DECLS
 /* converter-config (a GstStructure of GstVideoConverter.* / GstVideoResampler.* options) -> the C ABI's config: library defaults for whatever
  * the structure does not name (gstamdvideoconvertscale.c); shared with the compositor's per-pad converters */

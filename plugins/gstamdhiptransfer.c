@@ -24,6 +24,7 @@ typedef struct {
   gpointer stream;
   GstBufferPool *pool;          /* upload: HBM output frames */
   GstVideoInfo info;
+  GstAmdHipPendingReads *reads; /* upload: input buffers whose transfer is still queued */
 } GstAmdHipTransfer;
 
 typedef struct {
@@ -163,12 +164,24 @@ tr_plane_geometry (const GstVideoInfo * info, guint k, gsize * row_bytes, gsize 
   for (c = 0; c < GST_VIDEO_FORMAT_INFO_N_COMPONENTS (f); c++)
     if (GST_VIDEO_FORMAT_INFO_PLANE (f, c) == k)
       comp[n++] = (gint) c;
-  /* the widest extent a component of this plane reaches: offset of its last sample + its size */
-  for (c = 0; c < n; c++) {
-    const gint cw = GST_VIDEO_FORMAT_INFO_SCALE_WIDTH (f, comp[c], GST_VIDEO_INFO_WIDTH (info));
-    const gsize end = (gsize) GST_VIDEO_FORMAT_INFO_POFFSET (f, comp[c]) + (gsize) (cw - 1) * GST_VIDEO_FORMAT_INFO_PSTRIDE (f, comp[c]) +
-        (GST_VIDEO_FORMAT_INFO_DEPTH (f, comp[c]) + 7) / 8;
-    bytes = MAX (bytes, end);
+  /* whole pixels: width x pixel stride of the widest component of the plane (the last sample's own bytes are too few where a pixel is
+   * wider than its last component: RGB16 / RGB15, Y410, r210).  Formats whose samples do not sit at a fixed stride (pixel stride 0 /
+   * GST_VIDEO_FORMAT_FLAG_COMPLEX: v210, UYVP ...) copy the rows of the format's default layout. */
+  {
+    gboolean fixed = !(GST_VIDEO_FORMAT_INFO_FLAGS (f) & GST_VIDEO_FORMAT_FLAG_COMPLEX);
+    for (c = 0; c < n && fixed; c++)
+      fixed = GST_VIDEO_FORMAT_INFO_PSTRIDE (f, comp[c]) > 0;
+    if (fixed) {
+      for (c = 0; c < n; c++) {
+        const gint cw = GST_VIDEO_FORMAT_INFO_SCALE_WIDTH (f, comp[c], GST_VIDEO_INFO_WIDTH (info));
+        bytes = MAX (bytes, (gsize) cw * (gsize) GST_VIDEO_FORMAT_INFO_PSTRIDE (f, comp[c]));
+      }
+    } else if (n) {
+      GstVideoInfo def;
+      gst_video_info_init (&def);
+      if (gst_video_info_set_format (&def, GST_VIDEO_INFO_FORMAT (info), GST_VIDEO_INFO_WIDTH (info), GST_VIDEO_INFO_HEIGHT (info)))
+        bytes = (gsize) GST_VIDEO_INFO_PLANE_STRIDE (&def, k);
+    }
   }
   *row_bytes = bytes;
   *rows = n ? GST_VIDEO_FORMAT_INFO_SCALE_HEIGHT (f, comp[0], GST_VIDEO_INFO_HEIGHT (info)) : 0;
@@ -227,15 +240,21 @@ tr_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
       return GST_FLOW_ERROR;
     if (gst_memory_map (omem, &om, GST_MAP_WRITE | GST_MAP_AMDHIP)) {
       gst_amd_hip_memory_wait_idle (omem, s->stream);
-      /* pageable source: the call returns once the bytes have been staged, the input may be unmapped right away.  A source with its
+      /* A source with its
        * own strides / plane offsets (GstVideoMeta of a decoder or an aligned pool) is copied plane by plane into the pool frame's
        * default layout - a flat copy would shear every row after the first */
       if (tr_layout_is_default (inbuf, &s->info))
         r = gstamd_device_upload_async (om.data, im.data, MIN (im.size, om.size), s->stream);
       else
         r = tr_copy_planes (s, TRUE, om.data, im.data, im.size, gst_buffer_get_video_meta (inbuf));
-      if (r == GSTAMD_OK)
+      if (r == GSTAMD_OK) {
         gst_amd_hip_memory_mark_written (omem, s->stream);
+        /* from page-locked memory (an upstream element's pinned pool) the copy is only QUEUED when the call returns: the input stays
+         * referenced - out of its pool - until the transfer is over */
+        if (!s->reads)
+          s->reads = gst_amd_hip_pending_reads_new ();
+        gst_amd_hip_pending_reads_hold (s->reads, inbuf, s->stream);
+      }
       gst_memory_unmap (omem, &om);
     }
     gst_buffer_unmap (inbuf, &im);
@@ -280,6 +299,10 @@ tr_stop (GstBaseTransform * trans)
     gst_buffer_pool_set_active (s->pool, FALSE);
     gst_object_unref (s->pool);
     s->pool = NULL;
+  }
+  if (s->reads) {
+    gst_amd_hip_pending_reads_free (s->reads);
+    s->reads = NULL;
   }
   if (s->stream) {
     gstamd_stream_synchronize (s->stream);

@@ -113,6 +113,7 @@ typedef struct {
   gsize d_in_size[AMD_MAX_STREAMS], d_out_size[AMD_MAX_STREAMS];
   /* batch-buffers: HBM -> HBM frames of consecutive transform calls collected into ONE launch (AmdVcsBatch below) */
   gboolean pinned_pools;       /* GSTAMD_NO_PINNED_POOLS unset: offer / use page-locked host buffers at the system-memory edges */
+  GstAmdHipPendingReads *reads;        /* system-memory inputs whose upload is still queued */
   guint batch_buffers;         /* property: 0 = automatic (4 when upstream is not live, 1 = no batching when it is) */
   guint batch_limit;           /* what applies to the negotiated stream */
   struct _AmdVcsBatch *batch;
@@ -240,9 +241,41 @@ amd_cfg_number (const GstStructure * st, const gchar * key, gdouble * out)
     *out = g_value_get_double (v);
   else if (G_VALUE_HOLDS_BOOLEAN (v))
     *out = g_value_get_boolean (v);
-  else if (G_VALUE_HOLDS_STRING (v) && g_value_get_string (v))
-    *out = g_ascii_strtod (g_value_get_string (v), NULL);       /* gst-launch hands every field over as a string */
-  else
+  else if (G_VALUE_HOLDS_STRING (v) && g_value_get_string (v)) {
+    /* gst-launch hands an untyped field over as a string: a number, or for the enum options the value's nick ("lanczos").  Anything
+     * else is a wrongly typed field - the reference ignores such a field and keeps its default, so do we (with a warning) */
+    const gchar *txt = g_value_get_string (v);
+    gchar *end = NULL;
+    const gdouble num = g_ascii_strtod (txt, &end);
+    if (end != txt && *end == '\0') {
+      *out = num;
+      return TRUE;
+    }
+    {
+      static const struct { const gchar *key; GType (*type) (void); } enums[] = {
+        {"GstVideoConverter.resampler-method", gst_video_resampler_method_get_type},
+        {"GstVideoConverter.chroma-resampler-method", gst_video_resampler_method_get_type},
+        {"GstVideoConverter.dither-method", gst_video_dither_method_get_type}, {"GstVideoConverter.alpha-mode", gst_video_alpha_mode_get_type},
+        {"GstVideoConverter.chroma-mode", gst_video_chroma_mode_get_type}, {"GstVideoConverter.matrix-mode", gst_video_matrix_mode_get_type},
+        {"GstVideoConverter.gamma-mode", gst_video_gamma_mode_get_type}, {"GstVideoConverter.primaries-mode", gst_video_primaries_mode_get_type},
+      };
+      guint i;
+      for (i = 0; i < G_N_ELEMENTS (enums); i++)
+        if (g_strcmp0 (key, enums[i].key) == 0) {
+          GEnumClass *klass = g_type_class_ref (enums[i].type ());
+          const GEnumValue *ev = g_enum_get_value_by_nick (klass, txt);
+          if (!ev)
+            ev = g_enum_get_value_by_name (klass, txt);
+          if (ev)
+            *out = ev->value;
+          g_type_class_unref (klass);
+          if (ev)
+            return TRUE;
+        }
+    }
+    GST_WARNING ("converter-config: field %s has the value \"%s\", which is neither a number nor a value of the option's type - ignored", key, txt);
+    return FALSE;
+  } else
     return FALSE;
   return TRUE;
 }
@@ -1418,12 +1451,16 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
   } else {
     if (!gst_buffer_map (inbuf, &imap, GST_MAP_READ))
       return GST_FLOW_ERROR;
-    /* pageable host memory: the copy call returns once the source has been staged, so the buffer may be unmapped after it */
     if (!ensure_staging (&s->d_in[k], &s->d_in_size[k], imap.size) ||
         gstamd_device_upload_async (s->d_in[k], imap.data, imap.size, stream) != GSTAMD_OK) {
       gst_buffer_unmap (inbuf, &imap);
       return GST_FLOW_ERROR;
     }
+    /* from pageable memory the copy call returns once the source has been staged; from page-locked memory - the pool this element offers
+     * upstream (propose_allocation) - it is only QUEUED: the input stays referenced, out of its pool, until the transfer is over */
+    if (!s->reads)
+      s->reads = gst_amd_hip_pending_reads_new ();
+    gst_amd_hip_pending_reads_hold (s->reads, inbuf, stream);
     src = s->d_in[k];
   }
   /* destination */
@@ -1646,6 +1683,10 @@ amd_vcs_stop (GstBaseTransform * trans)
         "(map + stream waits %.2f, converter call %.2f, event records %.2f)\n", s->n_frames, (double) s->t_prepare / s->n_frames,
         (double) s->t_total / s->n_frames, (double) s->t_wait / s->n_frames, (double) s->t_convert / s->n_frames,
         (double) s->t_mark / s->n_frames);
+  if (s->reads) {
+    gst_amd_hip_pending_reads_free (s->reads);          /* waits for the queued uploads, gives their input buffers back */
+    s->reads = NULL;
+  }
   {
     guint i;
     for (i = 0; i < AMD_MAX_STREAMS; i++) {

@@ -9,12 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 SETS = []
 for opl in (1, 2):
-    for waves in (1, 2, 4, 8):
+    for waves in (2, 4, 8):
         SETS.append({"GSTAMD_COL_OPL": opl, "GSTAMD_COL_WAVES": waves})
-SETS += [{"GSTAMD_COL_OPL": 2, "GSTAMD_COL_SHARE": 0, "GSTAMD_COL_WAVES": 4}, {"GSTAMD_NO_COL": 1},
-         {"GSTAMD_COL_OPL": 1, "GSTAMD_COL_WAVES": 4, "GSTAMD_COL_CHUNKS": 8}, {"GSTAMD_COL_OPL": 1, "GSTAMD_COL_WAVES": 4, "GSTAMD_COL_CHUNKS": 24},
-         {"GSTAMD_COL_OPL": 2, "GSTAMD_COL_WAVES": 4, "GSTAMD_COL_CHUNKS": 16}, {"GSTAMD_COL_OPL": 2, "GSTAMD_COL_WAVES": 8, "GSTAMD_COL_CHUNKS": 8}]
-for batch in (1, 4):
+SETS += [{"GSTAMD_NO_COL": 1}]
+BATCHES = [int(b) for b in os.environ.get("COL_SWEEP_BATCHES", "1,4").split(",")]
+for batch in BATCHES:
     for kn in SETS:
         env = dict(os.environ)
         env.update({k: str(v) for k, v in kn.items()})

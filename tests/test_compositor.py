@@ -251,6 +251,28 @@ def test_hip_aggregate_packed_path_matches_reference(native_lib, gpu, ref, fmt, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dw,n_pads", [(800, 24), (264, 32), (1366, 30), (40, 12)])
+@pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("RGBA", 2)])
+def test_hip_aggregate_high_index_pads_in_a_short_last_strip(native_lib, gpu, ref, fmt, background, dw, n_pads):
+    """k_aggregate_direct tests pad k on lane k: in a short last strip (800 = 3 x 256 + 32: 8 lanes' worth of pixels) every lane still has to
+    take part in the hit test, or the pads with an index past the strip's lanes are never blended there (round-3 advisor finding)"""
+    import torch
+    dh, pw, ph = 61, 70, 33
+    pads_np = [cases.frame_bytes(pw * ph * 4, "random", 7300 + i) for i in range(n_pads)]
+    geo = [(dw - 50 + (i % 5) * 6 - 9, (i // 5) * 9 - 4, min(1.0, 0.3 + 0.02 * i), 1 if i % 3 else 2) for i in range(n_pads)]
+    exp = _aggregate_expected(ref, fmt, background, geo, pads_np, pw, ph, dw, dh)
+    d_pads = [torch.from_numpy(p).to(gpu) for p in pads_np]
+    arr = (V.CompositorPad * n_pads)()
+    for i, (xpos, ypos, alpha, mode) in enumerate(geo):
+        arr[i].data, arr[i].width, arr[i].height, arr[i].stride = d_pads[i].data_ptr(), pw, ph, pw * 4
+        arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = xpos, ypos, alpha, mode
+    d_out = torch.zeros(dw * dh * 4, dtype=torch.uint8, device=gpu)
+    assert V.lib().gstamd_compositor_aggregate(V.FORMATS[fmt], background, arr, n_pads, d_out.data_ptr(), dw, dh, dw * 4, None) == 0
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy() == exp).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("background", [0, 1, 2, 3])
 def test_hip_aggregate_equals_reference_pad_by_pad(native_lib, gpu, ref, background):
     """Fused aggregate (one pass) == the reference's _draw_background + blend_pads loop

@@ -39,18 +39,18 @@ VIDEO_CONFIGS = {
            "8K->4K frames/s (videoconvertscale NV12->BGRA, bilinear) per GPU; % HBM roofline",
            "k_bilinear420_rows_frames (--batch 1: k_bilinear420_rows)"),
     # SURVEY 8(f) rows, measured the same way (composite plans: several launches per frame, the whole frame is what is timed)
-    "f2gamma": ("NV12", 3840, 2160, "BGRA", 3840, 2160, {"gamma_mode": "remap"}, 8, 1,
+    "f2gamma": ("NV12", 3840, 2160, "BGRA", 3840, 2160, {"gamma_mode": "remap"}, 8, 8,
                 "4K frames/s (videoconvertscale NV12->BGRA, gamma-mode=remap) per GPU; % HBM roofline", "k_convert_strip<.., GSTAMD_FAST_LUT> (the direct conversion made with the gamma chain's to_RGB matrix, the composed decode/encode table ahead of the store)"),
-    "f2p010out": ("NV12", 3840, 2160, "P010_10LE", 3840, 2160, {}, 8, 1,
+    "f2p010out": ("NV12", 3840, 2160, "P010_10LE", 3840, 2160, {}, 8, 8,
                   "4K frames/s (videoconvertscale NV12->P010_10LE) per GPU; % HBM roofline", "sub-conversion + k_gamma_stage + k_pack16"),
-    "f2p010in": ("P010_10LE", 3840, 2160, "NV12", 3840, 2160, {}, 8, 1,
+    "f2p010in": ("P010_10LE", 3840, 2160, "NV12", 3840, 2160, {}, 8, 8,
                  "4K frames/s (videoconvertscale P010_10LE->NV12) per GPU; % HBM roofline", "k_front16 + k_gamma_stage + sub-conversion"),
     # SURVEY 8(f) generic paths: the plane scaler behind `videoscale` on NV12, a planar 4:2:0 pack, a byte swizzle
-    "f8scale": ("NV12", 3840, 2160, "NV12", 1920, 1080, {"resampler_method": "linear", "max_taps": 2}, 8, 1,
+    "f8scale": ("NV12", 3840, 2160, "NV12", 1920, 1080, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
                 "4K->1080p frames/s (videoscale NV12->NV12, bilinear) per GPU; % HBM roofline", "k_plane_direct (one frame, every plane straight from memory: nearest / 2-tap / two-tap N-tap passes composed per pixel; k_plane_tiles serves longer filters)"),
-    "f8pack": ("YUY2", 3840, 2160, "I420", 3840, 2160, {}, 8, 1,
+    "f8pack": ("YUY2", 3840, 2160, "I420", 3840, 2160, {}, 8, 8,
                "4K frames/s (videoconvert YUY2->I420) per GPU; % HBM roofline", "k_convert_pack_422 (the planar packer fed by the unscaled chain, no AYUV image)"),
-    "f8swizzle": ("BGRA", 3840, 2160, "RGBA", 3840, 2160, {}, 8, 1,
+    "f8swizzle": ("BGRA", 3840, 2160, "RGBA", 3840, 2160, {}, 8, 8,
                   "4K frames/s (videoconvert BGRA->RGBA) per GPU; % HBM roofline", "k_swizzle4"),
 }
 CONFIG_TEXT = {

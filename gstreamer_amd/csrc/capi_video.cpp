@@ -84,6 +84,7 @@ struct GstAmdVideoConverter {
                                          * the colour bytes; a kernel that applies it itself says so in post_lut_done, otherwise the parent runs k_lut3 */
   int post_lut_keep = 0;
   bool post_lut_done = false;
+  int list_launches = 0;                /* launches of the last _frames call that each served a whole (chunk of the) list; 0: frame by frame */
   bool hook_on = false;                 /* this converter is the direct conversion of a fused gamma plan: k_convert_gamma with `hook` */
   GammaDev hook;
   uint16_t *gamma_dec_dev = nullptr;
@@ -175,18 +176,15 @@ static bool col_pick_waves (GstAmdVideoConverter *c)
   /* MI355X, C3 (profiles/r04/col_sweep.log): four-wave workgroups of the two-outputs-per-lane form 16.4 us per 8K frame in lists of 8, 17.7 in
      lists of 4 (eight waves: 18.8 / 20.1, two: 18.8 / 20.8); single frames 25-27 us whatever the form */
   const int pin = tuning_int ("GSTAMD_COL_WAVES", 0);
-  int best_waves = 0, best_cu_waves = 0, best_per_cu = 0;
-  for (int nwaves = pin > 0 ? GSTAMD_COL_MAX_WAVES : 4; nwaves >= 1; nwaves--) {
+  int best_waves = 0, best_per_cu = 0;
+  /* four waves where a CU takes such a workgroup at all (MI355X, C3 in lists of 8, profiles/r04/col_waves.log: one wave 173 us per launch, two 149,
+     three 143, four 137, five 154, six 155), fewer only where it does not */
+  for (int nwaves = pin > 0 ? GSTAMD_COL_MAX_WAVES : 4; nwaves >= 1 && !best_waves; nwaves--) {
     if (pin > 0 && nwaves != pin)
       continue;
     const int per_cu = col_blocks_per_cu (c->col_form, p.front.chroma_h, semi, c->col.pubn, nwaves);
-    if (per_cu <= 0)
-      continue;
-    if (per_cu * nwaves > best_cu_waves) {
-      best_cu_waves = per_cu * nwaves;
-      best_waves = nwaves;
-      best_per_cu = per_cu;
-    }
+    if (per_cu > 0)
+      best_waves = nwaves, best_per_cu = per_cu;
   }
   c->col_waves = best_waves;
   c->col_per_cu = best_per_cu;
@@ -1560,10 +1558,31 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
   if (n_frames == 0)
     return GSTAMD_OK;
   const VideoPlan &p = c->plan;
+  c->list_launches = 0;
   int r = ensure_tables (c);
   if (r != GSTAMD_OK || (r = bind_scratch (c, stream_)) != GSTAMD_OK)
     return r;
-  if (p.gamma.on) {
+  if (p.gamma.on && p.gamma.fused && p.gamma.lut_direct && !p.rect.fill && c->sub_in && n_frames > 1) {
+    /* gamma remap collapsed into the direct conversion + one composed table: the direct conversion's frame list, the table inside its
+       kernel where that kernel applies it (the line-pair kernel) */
+    c->sub_in->hook_on = false;
+    c->sub_in->post_lut = c->gamma_comp_dev;
+    c->sub_in->post_lut_keep = p.fout->pos[0];
+    c->sub_in->post_lut_done = false;
+    r = gstamd_video_converter_frames (c->sub_in, n_frames, src, dest, stream_);
+    c->list_launches = c->sub_in->post_lut_done ? c->sub_in->list_launches : 0;
+    if (r != GSTAMD_OK || c->sub_in->post_lut_done)
+      return r;
+    for (int i = 0; i < n_frames; i++) {
+      const int ds = p.out_info.stride[0];
+      uint8_t *rect = (uint8_t *) dest[i] + p.out_info.offset[0] + plane_origin (p.fout, 0, p.rect.out_x, p.rect.out_y, ds);
+      const hipError_t le = launch_lut3 (rect, ds, p.out_info.width, p.out_info.height, c->gamma_comp_dev, p.fout->pos[0], (hipStream_t) stream_);
+      if (le != hipSuccess)
+        return hip_fail (le, "k_lut3");
+    }
+    return GSTAMD_OK;
+  }
+  if (p.gamma.on && !p.gamma.planes_fast) {
     for (int i = 0; i < n_frames; i++)
       if ((r = gstamd_video_converter_frame (c, src[i], dest[i], stream_)) != GSTAMD_OK)
         return r;
@@ -1590,11 +1609,17 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     uv[i] = pl.p[1];
   }
   if (all_fast) {
-    const FastParams fp = make_fast_params (p, p.fout->kind == UNPACK_PACKED3);
+    FastParams fp = make_fast_params (p, p.fout->kind == UNPACK_PACKED3);
+    if (c->post_lut) {          /* this converter is the direct conversion of a collapsed gamma remap (see above) */
+      fp.lut = c->post_lut;
+      fp.lut_keep = c->post_lut_keep;
+      c->post_lut_done = true;
+    }
     hipError_t e = launch_convert_pair (fp, p.front.chroma_h, n_frames, y.data (), uv.data (), d.data (), p.in_info.stride[0],
         p.in_info.stride[1], p.out_info.stride[0], (hipStream_t) stream_);
     for (int i = 0; i < n_frames && e == hipSuccess && p.dither.on; i++)
       e = launch_dither4 (p.dither, d[i], p.out_info.stride[0], p.out_info.width, p.out_info.height, (hipStream_t) stream_, c->ed_carry);
+    c->list_launches = p.dither.on ? 0 : (n_frames + 31) / 32;
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert_pair(batch)");
   }
   /* one launch for the whole list through the bilinear 4:2:0 kernel as well (k_bilinear420_rows takes the frames as one grid) */
@@ -1617,8 +1642,10 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
       hipError_t e = launch_bilinear420_frames (bp, p.front.chroma_h, n_frames, pls.data (), d.data (), p.out_info.stride[0], (hipStream_t) stream_);
       for (int i = 0; i < n_frames && e == hipSuccess && p.dither.on; i++)
         e = launch_dither4 (p.dither, d[i], p.out_info.stride[0], p.out_info.width, p.out_info.height, (hipStream_t) stream_, c->ed_carry);
-      if (e != hipErrorNotSupported)
+      if (e != hipErrorNotSupported) {
+        c->list_launches = p.dither.on ? 0 : 1;
         return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420(batch)");
+      }
     }
   }
   /* ... and through the column-walk scaler (k_scale_col takes the frames as the grid's third dimension) */
@@ -1648,16 +1675,45 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
       hipError_t e = col_launch (c, n_frames, (const void *const (*)[3]) sp.data (), d.data (), pl0, p.out_info.stride[0], color, pf, (hipStream_t) stream_);
       for (int i = 0; i < n_frames && e == hipSuccess && p.dither.on; i++)
         e = launch_dither4 (p.dither, d[i], p.out_info.stride[0], p.out_info.width, p.out_info.height, (hipStream_t) stream_, c->ed_carry);
-      if (e != hipErrorNotSupported)
+      if (e != hipErrorNotSupported) {
+        c->list_launches = p.dither.on ? 0 : (n_frames + GSTAMD_COL_MAX_FRAMES - 1) / GSTAMD_COL_MAX_FRAMES;
         return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_scale_col(batch)");
+      }
     }
   }
-  for (int i = 0; i < n_frames; i++) {
+  /* plans that convert a frame in ONE launch of a kernel that takes frame lists (video_kernels.hip: the list is the grid's third
+     dimension): frame `base` is converted with the list of up to 32 frames behind it armed; the launcher says whether it took the list */
+  int base = 0;
+  if (!p.rect.fill && !p.dither.on && (!p.gamma.on || p.gamma.planes_fast)) {
+    while (n_frames - base >= 2) {
+      const int nb = std::min (n_frames - base, 32);
+      for (int i = 0; i < nb; i++)
+        if (!src[base + i] || !dest[base + i])
+          return set_error (GSTAMD_ERR_INVALID, "NULL frame in list");
+      video_frame_list_begin (nb, src + base, dest + base, p.in_info.size, p.out_info.size);
+      r = gstamd_video_converter_frame (c, src[base], dest[base], stream_);
+      const int used = video_frame_list_end ();
+      if (r != GSTAMD_OK)
+        return r;
+      if (!used) {
+        base++;                 /* this plan's kernels do not take lists: frame by frame from here */
+        break;
+      }
+      c->list_launches += used;
+      base += nb;
+    }
+  }
+  for (int i = base; i < n_frames; i++) {
     r = gstamd_video_converter_frame (c, src[i], dest[i], stream_);
     if (r != GSTAMD_OK)
       return r;
   }
   return GSTAMD_OK;
+}
+
+int gstamd_video_converter_list_launches (GstAmdVideoConverter *c)
+{
+  return c ? c->list_launches : 0;
 }
 
 // every device table / scratch image of the converter; the plan stays

@@ -142,6 +142,7 @@ int col_blocks_per_cu (const ColForm &f, int chroma_h, int semi, int pubn, int n
 hipError_t launch_scale_col (const ColParams &p, const ColForm &f, int chroma_h, int semi, int nwaves, const ColFrames &fr, int n_frames, int dstride,
     const ColorParams &post, const int pack_pos[4], const PostFast &pf, hipStream_t stream)
 {
+  video_frame_list_touch (fr.dst[0]);
   const ColVariant *v = col_find (f, chroma_h, semi, pf.use ? 1 : 0);
   if (!v || nwaves < 1 || nwaves > GSTAMD_COL_MAX_WAVES || n_frames < 1 || n_frames > GSTAMD_COL_MAX_FRAMES || (dstride % (4 * f.opl)) != 0)
     return hipErrorNotSupported;

@@ -1013,7 +1013,7 @@ GSTAMD_HD void deep_planes_store (const DeepPlanesParams &d, uint8_t *row, int i
 }
 
 // row < height: luma row `row`, 8 samples per lane; otherwise chroma row `row - height`, 4 chroma positions (U and V) per lane
-GSTAMD_HD void deep_planes_body (const DeepPlanesParams &d, const DeepPlanesPtrs &pp, int lane_x, int row)
+GSTAMD_HD void deep_planes_body (const DeepPlanesParams &d, const DeepPlanesPtrs &pp, int lane_x, int row, long long ds = 0, long long dd = 0)
 {
   if (row < d.height) {
     const int x0 = lane_x * 8;
@@ -1021,8 +1021,8 @@ GSTAMD_HD void deep_planes_body (const DeepPlanesParams &d, const DeepPlanesPtrs
       return;
     const int n = d.width - x0 < 8 ? d.width - x0 : 8;
     int v[8];
-    deep_planes_load<8> (d.in_hi, pp.in[0] + (size_t) row * pp.in_stride[0], x0, n, pp.vec, v);
-    deep_planes_store<8> (d, pp.out[0] + (size_t) row * pp.out_stride[0], x0, n, pp.vec, 1, v, x0, 1, row);
+    deep_planes_load<8> (d.in_hi, pp.in[0] + ds + (size_t) row * pp.in_stride[0], x0, n, pp.vec, v);
+    deep_planes_store<8> (d, pp.out[0] + dd + (size_t) row * pp.out_stride[0], x0, n, pp.vec, 1, v, x0, 1, row);
     return;
   }
   const int cr = row - d.height;
@@ -1035,21 +1035,21 @@ GSTAMD_HD void deep_planes_body (const DeepPlanesParams &d, const DeepPlanesPtrs
   int u[4], v[4];
   if (d.in_kind == UNPACK_SEMI) {
     int t[8];
-    deep_planes_load<8> (d.in_hi, pp.in[1] + (size_t) cr * pp.in_stride[1], 2 * k0, 2 * n, pp.vec, t);
+    deep_planes_load<8> (d.in_hi, pp.in[1] + ds + (size_t) cr * pp.in_stride[1], 2 * k0, 2 * n, pp.vec, t);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       u[i] = d.in_u ? t[2 * i] : t[2 * i + 1];
       v[i] = d.in_u ? t[2 * i + 1] : t[2 * i];
     }
   } else {
-    deep_planes_load<4> (d.in_hi, pp.in[d.in_u] + (size_t) cr * pp.in_stride[d.in_u], k0, n, pp.vec, u);
-    deep_planes_load<4> (d.in_hi, pp.in[d.in_v] + (size_t) cr * pp.in_stride[d.in_v], k0, n, pp.vec, v);
+    deep_planes_load<4> (d.in_hi, pp.in[d.in_u] + ds + (size_t) cr * pp.in_stride[d.in_u], k0, n, pp.vec, u);
+    deep_planes_load<4> (d.in_hi, pp.in[d.in_v] + ds + (size_t) cr * pp.in_stride[d.in_v], k0, n, pp.vec, v);
   }
   if (d.out_kind == UNPACK_SEMI) {
     /* interleave after the per-component dither: U with component 2, V with component 3, both at the position of the chroma sample */
     DeepPlanesParams du = d;
     int t[8];
-    uint8_t *q = pp.out[1] + (size_t) cr * pp.out_stride[1];
+    uint8_t *q = pp.out[1] + dd + (size_t) cr * pp.out_stride[1];
     if (d.out_hi) {
       const uint2 brow = d.dither.on ? dither_bayer_row8 (x0 & ~7, y) : uint2{0, 0};
 #pragma unroll
@@ -1070,8 +1070,8 @@ GSTAMD_HD void deep_planes_body (const DeepPlanesParams &d, const DeepPlanesPtrs
     }
     deep_planes_store<8> (du, q, 2 * k0, 2 * n, pp.vec, 2, t, 0, 0, 0);
   } else {
-    deep_planes_store<4> (d, pp.out[d.out_u] + (size_t) cr * pp.out_stride[d.out_u], k0, n, pp.vec, 2, u, x0, xstep, y);
-    deep_planes_store<4> (d, pp.out[d.out_v] + (size_t) cr * pp.out_stride[d.out_v], k0, n, pp.vec, 3, v, x0, xstep, y);
+    deep_planes_store<4> (d, pp.out[d.out_u] + dd + (size_t) cr * pp.out_stride[d.out_u], k0, n, pp.vec, 2, u, x0, xstep, y);
+    deep_planes_store<4> (d, pp.out[d.out_v] + dd + (size_t) cr * pp.out_stride[d.out_v], k0, n, pp.vec, 3, v, x0, xstep, y);
   }
 }
 

@@ -115,7 +115,7 @@ GSTAMD_HD uint32_t pk_avg (uint32_t a, uint32_t b) { return pk_shr<1> (a + b + 0
 
 // one lane: pixels x0 .. x0+3 of the lines 2r, 2r+1 (x0 % 4 == 0, x0 < width)
 template <int SEMI>
-GSTAMD_HD void enc420_block (const Enc420Params &ep, const uint8_t *__restrict__ src, int sstride, const DstPlanes &d, int x0, int r)
+GSTAMD_HD void enc420_block (const Enc420Params &ep, const uint8_t *__restrict__ src, int sstride, const DstPlanes &d, int x0, int r, long long dd = 0)
 {
   const int w = ep.width, h = ep.height;
   const int y0 = 2 * r, y1 = y0 + 1 < h ? y0 + 1 : y0;
@@ -130,9 +130,9 @@ GSTAMD_HD void enc420_block (const Enc420Params &ep, const uint8_t *__restrict__
     bm = *(const uint32_t *) (row1 + 4 * (size_t) xm);
   }
   // ---- luma
-  enc_store32 (d.p[0] + (size_t) y0 * d.stride[0] + x0, enc_luma4 (ep, a));
+  enc_store32 ((d.p[0] + dd) + (size_t) y0 * d.stride[0] + x0, enc_luma4 (ep, a));
   if (y1 != y0)
-    enc_store32 (d.p[0] + (size_t) y1 * d.stride[0] + x0, enc_luma4 (ep, b));
+    enc_store32 ((d.p[0] + dd) + (size_t) y1 * d.stride[0] + x0, enc_luma4 (ep, b));
   // ---- chroma columns x0 .. x0+3 (and x0-1 for the cosited filter), lines averaged first
   uint32_t c[4], cm = 0;
   c[0] = enc_chroma (ep, a.x);
@@ -164,10 +164,10 @@ GSTAMD_HD void enc420_block (const Enc420Params &ep, const uint8_t *__restrict__
     o1 = x0 + 2 < w - 2 ? pk_shr<2> (c[1] + 2u * c[2] + c[3] + 0x00020002u) : pk_shr<2> (c[1] + 3u * c[2] + 0x00020002u);
   }
   if (SEMI) {
-    enc_store32 (d.p[1] + (size_t) r * d.stride[1] + x0, bperm (o1, o0, ep.u_first ? 0x06040200u : 0x04060002u));
+    enc_store32 ((d.p[1] + dd) + (size_t) r * d.stride[1] + x0, bperm (o1, o0, ep.u_first ? 0x06040200u : 0x04060002u));
   } else {
-    *(uint16_t *) (d.p[ep.u_plane] + (size_t) r * d.stride[ep.u_plane] + (x0 >> 1)) = (uint16_t) bperm (o1, o0, 0x0c0c0400u);
-    *(uint16_t *) (d.p[ep.v_plane] + (size_t) r * d.stride[ep.v_plane] + (x0 >> 1)) = (uint16_t) bperm (o1, o0, 0x0c0c0602u);
+    *(uint16_t *) ((d.p[ep.u_plane] + dd) + (size_t) r * d.stride[ep.u_plane] + (x0 >> 1)) = (uint16_t) bperm (o1, o0, 0x0c0c0400u);
+    *(uint16_t *) ((d.p[ep.v_plane] + dd) + (size_t) r * d.stride[ep.v_plane] + (x0 >> 1)) = (uint16_t) bperm (o1, o0, 0x0c0c0602u);
   }
 }
 

@@ -274,6 +274,7 @@ size_t fused420_lds_bytes (int ring, int nwaves, int sched)
 hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
     const int pack_pos[4], const PostFast &pf, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   int ok = (p.h.width % 16) == 0 && aligned (p.h.y, 16) && (p.h.ystride % 16) == 0 && aligned (dst, 4) && (dstride % 4) == 0;
   if (p.h.semi)
     ok = ok && aligned (p.h.c0, 16) && (p.h.cstride % 16) == 0;

@@ -81,6 +81,10 @@ hipError_t launch_plane_frame (const PlaneJobs &jobs, size_t lds_bytes, hipStrea
 bool swizzle34_setup (int src_bytes, const int *src_pos, int dst_bytes, const int *dst_pos, const uint8_t *src, int sstride, uint8_t *dst, int dstride,
     int width, Swz34Params *p);
 hipError_t launch_swizzle34 (const Swz34Params &p, int src_bytes, int dst_bytes, int height, hipStream_t stream);
+/* frame lists for single-kernel plans (video_kernels.hip) */
+void video_frame_list_begin (int n, const void *const *src, void *const *dst, size_t src_size, size_t dst_size);
+int video_frame_list_end ();
+void video_frame_list_touch (const void *dp);
 hipError_t launch_lut3 (uint8_t *img, int stride, int w, int h, const uint8_t *comp_dev, int keep, hipStream_t stream);
 bool relayout_usable (const RelayoutParams &p);
 hipError_t launch_planes_relayout (const RelayoutParams &p, hipStream_t stream);

@@ -31,6 +31,78 @@
 
 namespace gstamd {
 
+// ---- frame lists for the single-kernel plans ------------------------------------------------------------------------------------------
+// gstamd_video_converter_frames hands a list of frames of ONE layout over: frame i's planes sit at frame 0's plus a constant.  A kernel
+// that converts a frame in one launch takes the list as the grid's third dimension: its arguments are frame 0's, workgroup z adds
+// list.s[z] to every source pointer and list.d[z] to every destination pointer (pointer + offset stays a global pointer for the
+// compiler; pointers read out of an array argument would be generic ones - FLAT loads).  The list travels from capi_video.cpp to the
+// launchers through a thread-local context: a launcher uses it only when ITS source and destination pointers lie inside frame 0 of
+// the list (a kernel that reads or writes a scratch image must not be rebased), and says so; the caller converts the remaining
+// frames one by one when nobody did.
+#define GSTAMD_MAX_BATCH 32
+struct FrameDeltas {
+  long long s[GSTAMD_MAX_BATCH], d[GSTAMD_MAX_BATCH];
+};
+namespace {
+struct FrameListCtx {
+  bool armed = false;
+  int n = 0, used = 0;
+  bool mixed = false;
+  const uint8_t *src0 = nullptr, *dst0 = nullptr;
+  size_t src_size = 0, dst_size = 0;
+  FrameDeltas fd;
+};
+thread_local FrameListCtx g_frame_list;
+}
+void video_frame_list_begin (int n, const void *const *src, void *const *dst, size_t src_size, size_t dst_size)
+{
+  FrameListCtx &c = g_frame_list;
+  c.armed = n > 1 && n <= GSTAMD_MAX_BATCH;
+  c.n = n;
+  c.used = 0;
+  c.mixed = false;
+  c.src0 = (const uint8_t *) src[0], c.dst0 = (const uint8_t *) dst[0];
+  c.src_size = src_size, c.dst_size = dst_size;
+  memset (&c.fd, 0, sizeof (c.fd));
+  for (int i = 0; c.armed && i < n; i++) {
+    c.fd.s[i] = (long long) ((const uint8_t *) src[i] - c.src0);
+    c.fd.d[i] = (long long) ((const uint8_t *) dst[i] - c.dst0);
+  }
+}
+int video_frame_list_end ()
+{
+  g_frame_list.armed = false;
+  if (tuning_on ("GSTAMD_LIST_DEBUG"))
+    fprintf (stderr, "frame list of %d: %d list launches%s\n", g_frame_list.n, g_frame_list.used, g_frame_list.mixed ? ", and kernels that take no lists" : "");
+  return g_frame_list.mixed ? 0 : g_frame_list.used;
+}
+// a launcher whose kernel does NOT take frame lists writes dp: when that is inside frame 0 of an armed list the plan is not one the
+// list may serve on its own (a patched kernel before or after it would have converted every frame, this one only frame 0): the
+// caller then converts the other frames one by one (conversions are pure functions of the source frame, doing one twice is harmless)
+void video_frame_list_touch (const void *dp)
+{
+  FrameListCtx &c = g_frame_list;
+  const uint8_t *d8 = (const uint8_t *) dp;
+  if (c.armed && d8 >= c.dst0 && d8 < c.dst0 + c.dst_size)
+    c.mixed = true;
+}
+// the list for a launch whose source / destination pointers are sp / dp (NULL: not a frame's plane, or no list): *nz = frames
+static const FrameDeltas &frame_list_for (const void *sp, const void *dp, int *nz)
+{
+  static const FrameDeltas none = {};
+  FrameListCtx &c = g_frame_list;
+  *nz = 1;
+  if (!c.armed)
+    return none;
+  const uint8_t *s8 = (const uint8_t *) sp, *d8 = (const uint8_t *) dp;
+  if (s8 < c.src0 || s8 >= c.src0 + c.src_size || d8 < c.dst0 || d8 >= c.dst0 + c.dst_size)
+    return none;
+  c.used++;
+  *nz = c.n;
+  return c.fd;
+}
+#define GSTAMD_FRAME_Z const long long fls_ = fl.s[blockIdx.z], fld_ = fl.d[blockIdx.z]
+
 template <int CH>
 __global__ __launch_bounds__ (256) void k_convert (FrontParams f, Planes pl, const int *__restrict__ vpair, ColorParams color,
     int pack0, int pack1, int pack2, int pack3, uint8_t *__restrict__ dst, int dstride, int spans_per_row, int vec_ok)
@@ -96,6 +168,7 @@ __global__ __launch_bounds__ (256) void k_lut3 (uint8_t *__restrict__ img, int s
 
 hipError_t launch_lut3 (uint8_t *img, int stride, int w, int h, const uint8_t *comp_dev, int keep, hipStream_t stream)
 {
+  video_frame_list_touch (img);
   hipLaunchKernelGGL (k_lut3, dim3 (((w + 3) / 4 + 255) / 256, h), dim3 (256), 0, stream, img, stride, w, h, comp_dev, keep);
   return hipGetLastError ();
 }
@@ -117,6 +190,7 @@ __global__ __launch_bounds__ (256) void k_convert16_fast (FrontParams f, Planes 
 hipError_t launch_convert16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const Deep16Params &d, const PostParams &post, uint8_t *dst,
     int dstride, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   const int variant = (f.width % 4) == 0 && !tuning_on ("GSTAMD_NO_CONVERT16_FAST") ? deep_front4_variant (f) : -1;
   if (variant >= 0) {
     /* planes with horizontally subsampled chroma, widths in whole 4-pixel blocks: layout and chroma filter are template parameters */
@@ -241,21 +315,25 @@ __global__ __launch_bounds__ (256) void k_dither16_image (DitherParams d, uint8_
 
 hipError_t launch_dither16_image (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream)
 {
+  video_frame_list_touch (img);
   hipLaunchKernelGGL (k_dither16_image, dim3 ((w + 255) / 256, h), dim3 (256), 0, stream, d, img, stride, w, h);
   return hipGetLastError ();
 }
 
 // plane to plane between 8- and 10-bit planar formats (video_deep.h deep_planes_body): grid.y = luma rows, then chroma rows
-__global__ __launch_bounds__ (256) void k_deep_planes (DeepPlanesParams d, DeepPlanesPtrs pp)
+__global__ __launch_bounds__ (256) void k_deep_planes (DeepPlanesParams d, DeepPlanesPtrs pp, FrameDeltas fl)
 {
-  deep_planes_body (d, pp, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+  GSTAMD_FRAME_Z;
+  deep_planes_body (d, pp, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y, fls_, fld_);
 }
 
 hipError_t launch_deep_planes (const DeepPlanesParams &d, const DeepPlanesPtrs &pp, hipStream_t stream)
 {
   const int ch = (d.height + (1 << d.h_sub) - 1) >> d.h_sub;
-  dim3 grid (((d.width + 7) / 8 + 255) / 256, d.height + ch);
-  hipLaunchKernelGGL (k_deep_planes, grid, dim3 (256), 0, stream, d, pp);
+  int nz;
+  const FrameDeltas &fl = frame_list_for (pp.in[0], pp.out[0], &nz);
+  dim3 grid (((d.width + 7) / 8 + 255) / 256, d.height + ch, nz);
+  hipLaunchKernelGGL (k_deep_planes, grid, dim3 (256), 0, stream, d, pp, fl);
   return hipGetLastError ();
 }
 
@@ -274,6 +352,7 @@ __global__ __launch_bounds__ (256) void k_pack16_packed (PackPlanarParams pk, in
 hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *src, int sstride, uint8_t *const planes[3],
     const int strides[3], hipStream_t stream)
 {
+  video_frame_list_touch (planes[0]);
   if (pk.kind == UNPACK_P422_16 || pk.kind == UNPACK_Y410 || pk.kind == UNPACK_V210) {          /* Y210, Y212_LE, Y410: a lane per macropixel / pixel */
     hipLaunchKernelGGL (k_pack16_packed, dim3 ((pack16_units (pk) + 255) / 256, pk.height), dim3 (256), 0, stream, pk, hi_depth, dt, src, sstride, planes[0], strides[0]);
     return hipGetLastError ();
@@ -374,6 +453,7 @@ __global__ __launch_bounds__ (GSTAMD_ED_LINES) void k_dither_ed (DitherParams d,
 
 hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream, void *ed_carry)
 {
+  video_frame_list_touch (img);
   if (d.method == GSTAMD_DITHER_VERTERR) {
     hipLaunchKernelGGL (k_dither_verterr, dim3 ((w + 255) / 256), dim3 (256), 0, stream, d, img, stride, w, h);
     return hipGetLastError ();
@@ -392,8 +472,7 @@ hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int 
   return hipGetLastError ();
 }
 
-// up to 16 independent frames of one format per launch (blockIdx.z = frame): amortises launch ramp/tail
-#define GSTAMD_MAX_BATCH 32
+// up to 32 independent frames of one format per launch (blockIdx.z = frame): amortises launch ramp/tail
 struct FrameBatch {
   const uint8_t *y[GSTAMD_MAX_BATCH];
   const uint8_t *uv[GSTAMD_MAX_BATCH];
@@ -607,23 +686,29 @@ __global__ __launch_bounds__ (64) void k_hscale420_reg (H420RegParams p, int n_t
 }
 
 // unscaled packed 4:2:2 -> 4-byte RGB (video_422_fast.h): a lane = 8 pixels of one line
-__global__ __launch_bounds__ (256) void k_convert422 (Fast422Params p, const uint8_t *src, int sstride, uint8_t *dst, int dstride)
+__global__ __launch_bounds__ (256) void k_convert422 (Fast422Params p, const uint8_t *src, int sstride, uint8_t *dst, int dstride, FrameDeltas fl)
 {
+  GSTAMD_FRAME_Z;
+  src += fls_, dst += fld_;
   const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 8, y = (int) blockIdx.y;
   if (x0 < p.fp.width)
     convert422_lane8_any (p, src + (size_t) y * sstride, dst + (size_t) y * dstride, x0);
 }
 
-__global__ __launch_bounds__ (256) void k_convert422_ayuv (Fast422Params p, const uint8_t *src, int sstride, uint8_t *dst, int dstride)
+__global__ __launch_bounds__ (256) void k_convert422_ayuv (Fast422Params p, const uint8_t *src, int sstride, uint8_t *dst, int dstride, FrameDeltas fl)
 {
+  GSTAMD_FRAME_Z;
+  src += fls_, dst += fld_;
   const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 8, y = (int) blockIdx.y;
   if (x0 < p.fp.width)
     convert422_lane8_ayuv (p, src + (size_t) y * sstride, dst + (size_t) y * dstride, x0);
 }
 
 // unscaled planar 4:2:0 -> 4-byte RGB, nearest chroma (video_422_fast.h): a lane = 8 pixels of a line pair
-__global__ __launch_bounds__ (256) void k_convert420p (Fast420pParams p, uint8_t *dst, int dstride)
+__global__ __launch_bounds__ (256) void k_convert420p (Fast420pParams p, uint8_t *dst, int dstride, FrameDeltas fl)
 {
+  GSTAMD_FRAME_Z;
+  p.y += fls_, p.u += fls_, p.v += fls_, dst += fld_;
   const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 8, r = (int) blockIdx.y;
   if (x0 < p.fp.width)
     convert420p_lane8x2 (p, dst, dstride, x0, r);
@@ -767,8 +852,10 @@ __global__ __launch_bounds__ (256) void k_plane_vscale (SrcPlane s, ScaleDev sd,
 
 // 3- / 4-byte pixel permutations (video_swizzle34.h)
 template <int SB, int DB>
-__global__ __launch_bounds__ (256) void k_swizzle34 (Swz34Params p)
+__global__ __launch_bounds__ (256) void k_swizzle34 (Swz34Params p, FrameDeltas fl)
 {
+  GSTAMD_FRAME_Z;
+  p.src += fls_, p.dst += fld_;
   swizzle34_body<SB, DB> (p, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
 }
 
@@ -795,20 +882,23 @@ bool swizzle34_setup (int src_bytes, const int *src_pos, int dst_bytes, const in
 
 hipError_t launch_swizzle34 (const Swz34Params &p, int src_bytes, int dst_bytes, int height, hipStream_t stream)
 {
-  const dim3 grid (((p.width + 3) / 4 + 255) / 256, height);
+  int nz;
+  const FrameDeltas &fl = frame_list_for (p.src, p.dst, &nz);
+  const dim3 grid (((p.width + 3) / 4 + 255) / 256, height, nz);
   if (src_bytes == 3 && dst_bytes == 4)
-    hipLaunchKernelGGL ((k_swizzle34<3, 4>), grid, dim3 (256), 0, stream, p);
+    hipLaunchKernelGGL ((k_swizzle34<3, 4>), grid, dim3 (256), 0, stream, p, fl);
   else if (src_bytes == 4 && dst_bytes == 3)
-    hipLaunchKernelGGL ((k_swizzle34<4, 3>), grid, dim3 (256), 0, stream, p);
+    hipLaunchKernelGGL ((k_swizzle34<4, 3>), grid, dim3 (256), 0, stream, p, fl);
   else
-    hipLaunchKernelGGL ((k_swizzle34<3, 3>), grid, dim3 (256), 0, stream, p);
+    hipLaunchKernelGGL ((k_swizzle34<3, 3>), grid, dim3 (256), 0, stream, p, fl);
   return hipGetLastError ();
 }
 
 // plane re-arrangement (video_relayout.h): 16 output bytes per lane, grid.y = luma rows, then the chroma rows of the destination's planes
-__global__ __launch_bounds__ (256) void k_planes_relayout (RelayoutParams p)
+__global__ __launch_bounds__ (256) void k_planes_relayout (RelayoutParams p, FrameDeltas fl)
 {
-  relayout_body (p, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+  GSTAMD_FRAME_Z;
+  relayout_body (p, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y, fls_, fld_);
 }
 
 bool relayout_usable (const RelayoutParams &p)
@@ -825,7 +915,9 @@ bool relayout_usable (const RelayoutParams &p)
 hipError_t launch_planes_relayout (const RelayoutParams &p, hipStream_t stream)
 {
   const int lanes = relayout_lanes (p);
-  hipLaunchKernelGGL (k_planes_relayout, dim3 ((lanes + 255) / 256, relayout_rows (p)), dim3 (256), 0, stream, p);
+  int nz;
+  const FrameDeltas &fl = frame_list_for (p.in[0], p.out[0], &nz);
+  hipLaunchKernelGGL (k_planes_relayout, dim3 ((lanes + 255) / 256, relayout_rows (p), nz), dim3 (256), 0, stream, p, fl);
   return hipGetLastError ();
 }
 
@@ -845,8 +937,17 @@ __device__ __forceinline__ void plane_tiles_job (const PlaneJobs &jobs, uint8_t 
   }
 }
 
-__global__ __launch_bounds__ (PLN_THREADS) void k_plane_tiles (PlaneJobs jobs)
+static __device__ __forceinline__ void plane_jobs_rebase (PlaneJobs &jobs, long long ds, long long dd)
 {
+#pragma unroll
+  for (int k = 0; k < PLN_MAX_JOBS; k++)
+    jobs.job[k].s.p += ds, jobs.job[k].d.p += dd;
+}
+
+__global__ __launch_bounds__ (PLN_THREADS) void k_plane_tiles (PlaneJobs jobs, FrameDeltas fl)
+{
+  GSTAMD_FRAME_Z;
+  plane_jobs_rebase (jobs, fls_, fld_);
   extern __shared__ uint32_t plane_lds[];         /* the largest tile's needs (plane_job_lds_bytes), not PLN_LDS_BYTES: workgroups per CU */
   uint8_t *lds = (uint8_t *) plane_lds;
   const int b = (int) blockIdx.x;
@@ -858,8 +959,10 @@ __global__ __launch_bounds__ (PLN_THREADS) void k_plane_tiles (PlaneJobs jobs)
     plane_tiles_job<0> (jobs, lds);
 }
 
-__global__ __launch_bounds__ (PLN_THREADS) void k_plane_direct (PlaneJobs jobs)
+__global__ __launch_bounds__ (PLN_THREADS) void k_plane_direct (PlaneJobs jobs, FrameDeltas fl)
 {
+  GSTAMD_FRAME_Z;
+  plane_jobs_rebase (jobs, fls_, fld_);
   const int b = (int) blockIdx.x;
   if (jobs.n > 2 && b >= jobs.job[2].tile0)
     plane_direct_body (jobs.job[2], b - jobs.job[2].tile0, (int) threadIdx.x);
@@ -872,6 +975,8 @@ __global__ __launch_bounds__ (PLN_THREADS) void k_plane_direct (PlaneJobs jobs)
 // `jobs`: the frame's planes in any order; they are split by kind of body and each kind gets a launch of its own
 hipError_t launch_plane_frame (const PlaneJobs &jobs, size_t lds_bytes, hipStream_t stream)
 {
+  int nz;
+  const FrameDeltas &fl = frame_list_for (jobs.job[0].s.p, jobs.job[0].d.p, &nz);
   for (int direct = 0; direct < 2; direct++) {
     PlaneJobs part;
     memset ((void *) &part, 0, sizeof (part));
@@ -887,9 +992,9 @@ hipError_t launch_plane_frame (const PlaneJobs &jobs, size_t lds_bytes, hipStrea
     if (!part.n)
       continue;
     if (direct)
-      hipLaunchKernelGGL (k_plane_direct, dim3 (tiles), dim3 (PLN_THREADS), 0, stream, part);
+      hipLaunchKernelGGL (k_plane_direct, dim3 (tiles, 1, nz), dim3 (PLN_THREADS), 0, stream, part, fl);
     else
-      hipLaunchKernelGGL (k_plane_tiles, dim3 (tiles), dim3 (PLN_THREADS), lds_bytes ? lds_bytes : 4, stream, part);
+      hipLaunchKernelGGL (k_plane_tiles, dim3 (tiles, 1, nz), dim3 (PLN_THREADS), lds_bytes ? lds_bytes : 4, stream, part, fl);
   }
   return hipGetLastError ();
 }
@@ -927,23 +1032,30 @@ __global__ __launch_bounds__ (256) void k_pack_planar (PackPlanarParams pk, cons
 }
 
 // the same with the unscaled 8-bit chain as its pixel source: YUY2 -> I420, AYUV -> NV12, I420 -> Y42B ... in one launch, no AYUV image
-__global__ __launch_bounds__ (64) void k_convert_pack (PackPlanarParams pk, SrcPacked4 src, DstPlanes d)
+__global__ __launch_bounds__ (64) void k_convert_pack (PackPlanarParams pk, SrcPacked4 src, DstPlanes d, FrameDeltas fl)
 {
-  pack_planar_body (pk, src, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y);
+  GSTAMD_FRAME_Z;
+  src.p += fls_;
+  pack_planar_body (pk, src, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y, fld_);
 }
 
 // 4-byte RGB -> 4:2:0 (video_encode_fast.h): one lane = a 4 x 2 pixel block, one wave per workgroup
 template <int SEMI>
-__global__ __launch_bounds__ (64) void k_encode420 (Enc420Params ep, const uint8_t *__restrict__ src, int sstride, DstPlanes d)
+__global__ __launch_bounds__ (64) void k_encode420 (Enc420Params ep, const uint8_t *__restrict__ src, int sstride, DstPlanes d, FrameDeltas fl)
 {
-  enc420_block<SEMI> (ep, src, sstride, d, (int) (blockIdx.x * 64 + threadIdx.x) * 4, (int) blockIdx.y);
+  GSTAMD_FRAME_Z;
+  src += fls_;
+  enc420_block<SEMI> (ep, src, sstride, d, (int) (blockIdx.x * 64 + threadIdx.x) * 4, (int) blockIdx.y, fld_);
 }
 
 // k_swizzle4: a pure byte permutation of 4-byte pixels is a copy as far as the memory system goes, and is laid out like the copy that
 // measures best on this chip (scripts/c4_probe.hip: one 16-byte element per lane, no grid-stride loop, nontemporal load and store:
 // 6.4-6.6 TB/s against 4.7-5.3 for the grid-stride forms): one lane = 4 pixels, one wave = 1 KB of a row, every byte touched once.
-__global__ __launch_bounds__ (256) void k_swizzle4 (const uint8_t *__restrict__ src, int sstride, uint8_t *__restrict__ dst, int dstride, int width, uint32_t sel)
+__global__ __launch_bounds__ (256) void k_swizzle4 (const uint8_t *__restrict__ src, int sstride, uint8_t *__restrict__ dst, int dstride, int width, uint32_t sel,
+    FrameDeltas fl)
 {
+  GSTAMD_FRAME_Z;
+  src += fls_, dst += fld_;
   const int x = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = (int) blockIdx.y;
   if (x >= width)
     return;
@@ -974,14 +1086,17 @@ bool swizzle4_usable (const FrontParams &f, const Planes &pl, const ColorParams 
 hipError_t launch_swizzle4 (const FrontParams &f, const Planes &pl, const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream)
 {
   const int lanes = (f.width + 3) / 4;
-  hipLaunchKernelGGL (k_swizzle4, dim3 ((lanes + 255) / 256, f.height), dim3 (256), 0, stream, pl.p[0], pl.stride[0], dst, dstride, f.width,
-      swizzle4_selector (f.pos, pack_pos));
+  int nz;
+  const FrameDeltas &fl = frame_list_for (pl.p[0], dst, &nz);
+  hipLaunchKernelGGL (k_swizzle4, dim3 ((lanes + 255) / 256, f.height, nz), dim3 (256), 0, stream, pl.p[0], pl.stride[0], dst, dstride, f.width,
+      swizzle4_selector (f.pos, pack_pos), fl);
   return hipGetLastError ();
 }
 
 hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color,
     const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream, int extra_rows)
 {
+  video_frame_list_touch (dst);
   const int spans = (f.width + K1_PX - 1) / K1_PX;
   int vec_ok = aligned (dst, 16) && (dstride % 16) == 0 && kind_has_planes (f.kind) && f.w_sub == 1;
   if (vec_ok) {
@@ -1040,6 +1155,7 @@ static hipError_t launch_convert_gamma_ch (const FrontParams &f, const Planes &p
 hipError_t launch_convert_gamma (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color, const int pack_pos[4], uint8_t *dst,
     int dstride, const GammaDev &g, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   const int spans = (f.width + K1_PX - 1) / K1_PX;
   int vec_ok = aligned (dst, 16) && (dstride % 16) == 0 && kind_has_planes (f.kind) && f.w_sub == 1;
   if (vec_ok) {
@@ -1210,6 +1326,7 @@ static bool launch_fast (const FastParams &fp, const FrameBatch &batch, int n, h
 hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames, const uint8_t *const *y, const uint8_t *const *uv,
     uint8_t *const *dst, int ystride, int uvstride, int dstride, hipStream_t stream)
 {
+  video_frame_list_touch (dst[0]);
   for (int base = 0; base < n_frames; base += GSTAMD_MAX_BATCH) {
     const int n = n_frames - base < GSTAMD_MAX_BATCH ? n_frames - base : GSTAMD_MAX_BATCH;
     FrameBatch batch;
@@ -1296,6 +1413,7 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
     const ColorParams &pre, const ScaleDev &sd, uint8_t *dst, int dstride, bool final, const ColorParams &post,
     const int pack_pos[4], int out_w, int out_h, int max_span, TileGeom geom, const PostFast &pf, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   SrcFront src;
   src.f = f;
   src.pl = pl;
@@ -1399,6 +1517,7 @@ static hipError_t launch_h420_reg_nw (H420RegParams p, int chroma_h, int n_taps,
 // regular 4:2:0 horizontal pass into the AYUV intermediate; hipErrorNotSupported: the caller takes the general kernels
 hipError_t launch_hscale420_reg (const H420RegParams &p, int chroma_h, int nw, int n_taps, hipStream_t stream)
 {
+  video_frame_list_touch (p.dst);
   if (tuning_on ("GSTAMD_NO_H420_REG"))
     return hipErrorNotSupported;
   int ok = (p.width % 16) == 0 && aligned (p.y, 16) && (p.ystride % 16) == 0 && aligned (p.dst, 4) && (p.dstride % 4) == 0;
@@ -1418,18 +1537,22 @@ hipError_t launch_hscale420_reg (const H420RegParams &p, int chroma_h, int nw, i
 
 hipError_t launch_convert420p (const Fast420pParams &p, uint8_t *dst, int dstride, hipStream_t stream)
 {
-  dim3 grid ((p.fp.width / 8 + 255) / 256, (p.fp.height + 1) / 2);
-  hipLaunchKernelGGL (k_convert420p, grid, dim3 (256), 0, stream, p, dst, dstride);
+  int nz;
+  const FrameDeltas &fl = frame_list_for (p.y, dst, &nz);
+  dim3 grid ((p.fp.width / 8 + 255) / 256, (p.fp.height + 1) / 2, nz);
+  hipLaunchKernelGGL (k_convert420p, grid, dim3 (256), 0, stream, p, dst, dstride, fl);
   return hipGetLastError ();
 }
 
 hipError_t launch_convert422 (const Fast422Params &p, const uint8_t *src, int sstride, uint8_t *dst, int dstride, hipStream_t stream, bool ayuv)
 {
-  dim3 grid ((p.fp.width / 8 + 255) / 256, p.fp.height);
+  int nz;
+  const FrameDeltas &fl = frame_list_for (src, dst, &nz);
+  dim3 grid ((p.fp.width / 8 + 255) / 256, p.fp.height, nz);
   if (ayuv)
-    hipLaunchKernelGGL (k_convert422_ayuv, grid, dim3 (256), 0, stream, p, src, sstride, dst, dstride);
+    hipLaunchKernelGGL (k_convert422_ayuv, grid, dim3 (256), 0, stream, p, src, sstride, dst, dstride, fl);
   else
-    hipLaunchKernelGGL (k_convert422, grid, dim3 (256), 0, stream, p, src, sstride, dst, dstride);
+    hipLaunchKernelGGL (k_convert422, grid, dim3 (256), 0, stream, p, src, sstride, dst, dstride, fl);
   return hipGetLastError ();
 }
 
@@ -1437,6 +1560,7 @@ hipError_t launch_scale_from_image (bool horizontal, const uint8_t *simg, int ss
     int dstride, bool final, const ColorParams &post, const int pack_pos[4], int out_w, int out_h, int max_span, int src_w,
     TileGeom geom, const PostFast &pf, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   SrcImage src;
   src.p = simg;
   src.stride = sstride;
@@ -1479,6 +1603,7 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
     const ScaleDev &sh, const ScaleDev &sv, bool h_first, uint8_t *dst, int dstride, const ColorParams &post,
     const int pack_pos[4], int out_w, int out_h, int h_span, TileGeom geom, const PostFast &pf, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   SrcFront src;
   src.f = f;
   src.pl = pl;
@@ -1604,6 +1729,7 @@ static hipError_t launch_bilinear420_rows (const BilParams &bp, int chroma_h, in
 
 hipError_t launch_bilinear420_frames (const BilParams &bp, int chroma_h, int n, const Planes *pl, uint8_t *const *dst, int dstride, hipStream_t stream)
 {
+  video_frame_list_touch (dst[0]);
   bool rows_ok = bp.rows != 0 && (bp.fp.width % 16) == 0 && bp.regular_pairs;
   for (int f = 0; f < n && rows_ok; f++)
     rows_ok = bil_vec_ok (bp, pl[f]) && pl[f].stride[0] == pl[0].stride[0] && pl[f].stride[1] == pl[0].stride[1] && pl[f].stride[2] == pl[0].stride[2];
@@ -1619,6 +1745,7 @@ hipError_t launch_bilinear420_frames (const BilParams &bp, int chroma_h, int n, 
 
 hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   const int vec = bil_vec_ok (bp, pl);
   if (bp.planar && !vec)
     return hipErrorNotSupported;
@@ -1644,6 +1771,7 @@ hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &
 
 hipError_t launch_plane_simple (int kind, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems, int ow, int oh, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   const SrcPlane s = {src, sstride, n_elems, 0};
   const DstPlane d = {dst, dstride, n_elems};
   hipLaunchKernelGGL (k_plane_simple, dim3 ((ow + 255) / 256, oh), dim3 (256), 0, stream, kind, s, d, ow, oh);
@@ -1653,6 +1781,7 @@ hipError_t launch_plane_simple (int kind, const uint8_t *src, int sstride, uint8
 hipError_t launch_plane_pass (bool horizontal, const ScaleDev &sd, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems,
     int ow, int oh, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   const SrcPlane s = {src, sstride, n_elems, 0};
   const DstPlane d = {dst, dstride, n_elems};
   if (horizontal)
@@ -1665,6 +1794,7 @@ hipError_t launch_plane_pass (bool horizontal, const ScaleDev &sd, const uint8_t
 hipError_t launch_fill_border (uint8_t *p, int stride, int es, uint32_t value, uint32_t value_hi, int maxw, int maxh, int x0, int y0, int w, int h,
     hipStream_t stream)
 {
+  video_frame_list_touch (p);
   hipLaunchKernelGGL (k_fill_border, dim3 ((maxw + 255) / 256, maxh), dim3 (256), 0, stream, p, stride, es, value, value_hi, maxw, maxh, x0, y0, w, h);
   return hipGetLastError ();
 }
@@ -1677,11 +1807,13 @@ hipError_t launch_encode420 (const Enc420Params &ep, bool semi, const uint8_t *s
     d.p[i] = planes[i];
     d.stride[i] = strides[i];
   }
-  const dim3 grid ((ep.width / 4 + 63) / 64, (ep.height + 1) / 2);
+  int nz;
+  const FrameDeltas &fl = frame_list_for (src, planes[0], &nz);
+  const dim3 grid ((ep.width / 4 + 63) / 64, (ep.height + 1) / 2, nz);
   if (semi)
-    hipLaunchKernelGGL (k_encode420<1>, grid, dim3 (64), 0, stream, ep, src, sstride, d);
+    hipLaunchKernelGGL (k_encode420<1>, grid, dim3 (64), 0, stream, ep, src, sstride, d, fl);
   else
-    hipLaunchKernelGGL (k_encode420<0>, grid, dim3 (64), 0, stream, ep, src, sstride, d);
+    hipLaunchKernelGGL (k_encode420<0>, grid, dim3 (64), 0, stream, ep, src, sstride, d, fl);
   return hipGetLastError ();
 }
 
@@ -1700,6 +1832,7 @@ __global__ __launch_bounds__ (256) void k_pack_down_h (PackPlanarParams pk, uint
 hipError_t launch_pack_planar_ed (const PackPlanarParams &pk, uint8_t *img, int sstride, uint8_t *const planes[3], const int strides[3],
     hipStream_t stream, void *ed_carry)
 {
+  video_frame_list_touch (planes[0]);
   const int rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
   const dim3 grid ((pk.width + 255) / 256, rows);
   if (pk.down_v)
@@ -1715,15 +1848,17 @@ hipError_t launch_pack_planar_ed (const PackPlanarParams &pk, uint8_t *img, int 
   return launch_pack_planar (pack_select_only (pk), img, sstride, planes, strides, stream);
 }
 
-__global__ __launch_bounds__ (256) void k_convert_pack_422 (PackPlanarParams pk, Src422Dup src, DstPlanes d, int wide)
+__global__ __launch_bounds__ (256) void k_convert_pack_422 (PackPlanarParams pk, Src422Dup src, DstPlanes d, int wide, FrameDeltas fl)
 {
+  GSTAMD_FRAME_Z;
+  src.p += fls_;
   const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (x0 >= pk.width)
     return;
-  if (wide && (pk.kind == UNPACK_PLANAR || pk.kind == UNPACK_SEMI) && pack_422dup_block8 (pk, src, d, x0, (int) blockIdx.y))
+  if (wide && (pk.kind == UNPACK_PLANAR || pk.kind == UNPACK_SEMI) && pack_422dup_block8 (pk, src, d, x0, (int) blockIdx.y, fld_))
     return;
-  pack_planar_body (pk, src, d, x0, (int) blockIdx.y);
-  pack_planar_body (pk, src, d, x0 + 4, (int) blockIdx.y);
+  pack_planar_body (pk, src, d, x0, (int) blockIdx.y, fld_);
+  pack_planar_body (pk, src, d, x0 + 4, (int) blockIdx.y, fld_);
 }
 
 // which unscaled chains the fused form pays for: the pixel source must be cheap per pixel, a lane evaluates up to 20 of them for its 4 x 2 block
@@ -1744,16 +1879,18 @@ hipError_t launch_convert_pack (const PackPlanarParams &pk, const FrontParams &f
     d.stride[i] = strides[i];
   }
   const int lanes = (pk.width + 3) / 4, rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
+  int nz;
+  const FrameDeltas &fl = frame_list_for (pl.p[0], planes[0], &nz);
   if (f.kind == UNPACK_PACKED422) {
     const Src422Dup src = {pl.p[0], pl.stride[0], 8 * f.pos[1], 8 * f.pos[2], 8 * f.pos[3], f.swap_k};
     /* pack_422dup_block8: source rows on 16 bytes, plane rows on 8 */
     int wide = ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0;
     for (int i = 0; wide && i < (pk.kind == UNPACK_SEMI ? 2 : 3); i++)
       wide = ((uintptr_t) planes[i] % 8) == 0 && (strides[i] % 8) == 0;
-    hipLaunchKernelGGL (k_convert_pack_422, dim3 (((pk.width + 7) / 8 + 255) / 256, rows), dim3 (256), 0, stream, pk, src, d, wide);
+    hipLaunchKernelGGL (k_convert_pack_422, dim3 (((pk.width + 7) / 8 + 255) / 256, rows, nz), dim3 (256), 0, stream, pk, src, d, wide, fl);
   } else {
     (void) vpair;
-    hipLaunchKernelGGL (k_convert_pack, dim3 ((lanes + 63) / 64, rows), dim3 (64), 0, stream, pk, make_src_packed4 (f, pl, color), d);
+    hipLaunchKernelGGL (k_convert_pack, dim3 ((lanes + 63) / 64, rows, nz), dim3 (64), 0, stream, pk, make_src_packed4 (f, pl, color), d, fl);
   }
   return hipGetLastError ();
 }
@@ -1761,6 +1898,7 @@ hipError_t launch_convert_pack (const PackPlanarParams &pk, const FrontParams &f
 hipError_t launch_pack_planar (const PackPlanarParams &pk, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3],
     hipStream_t stream)
 {
+  video_frame_list_touch (planes[0]);
   DstPlanes d;
   for (int i = 0; i < 3; i++) {
     d.p[i] = planes[i];

@@ -13,6 +13,8 @@
 
 namespace gstamd {
 
+// (dd, the bodies' last argument: the byte distance of the frame a workgroup of a frame-list launch writes from frame 0's planes, which
+// are what p[] holds - added where a plane pointer is formed: a kernel that rebased p[] itself would hold the struct in LDS)
 struct DstPlanes {
   uint8_t *p[3];
   int stride[3];
@@ -39,14 +41,14 @@ GSTAMD_HD uint32_t ayuv_uv (uint32_t px) { return ((px >> 16) & 0xffu) | ((px >>
 // SRC: where the AYUV pixel (x, y) of the converted picture comes from - the image a scaled / gamma / dithering chain left in HBM (SrcImage) or,
 // for an unscaled 8-bit chain, the chain itself (SrcFront: unpack + chroma upsample + matrix + alpha per pixel, nothing in between in HBM)
 template <class SRC>
-GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, const DstPlanes &d, int x0, int yb)
+GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, const DstPlanes &d, int x0, int yb, long long dd = 0)
 {
   const int w = pk.width, h = pk.height;
   const int y0 = yb << pk.h_sub;
   if (x0 >= w || y0 >= h)
     return;
   if (pk.kind == UNPACK_PACKED3) {          // pack_RGB / pack_BGR (video-format.c:1540, 1577): 4 pixels = 12 bytes
-    uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 3 * (size_t) x0;
+    uint8_t *q = (d.p[0] + dd) + (size_t) y0 * d.stride[0] + 3 * (size_t) x0;
     for (int i = 0; i < 4 && x0 + i < w; i++) {
       const uint32_t px = src.at (x0 + i, y0);
       q[3 * i + pk.pos[1]] = (uint8_t) pack_dither (pk.dither, 1, (int) ((px >> 8) & 0xff), x0 + i, y0);
@@ -56,14 +58,14 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
     return;
   }
   if (pk.kind == UNPACK_GRAY) {            // pack_GRAY8 (video-format.c:1221): the luma byte of every pixel
-    uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + x0;
+    uint8_t *q = (d.p[0] + dd) + (size_t) y0 * d.stride[0] + x0;
     for (int i = 0; i < 4 && x0 + i < w; i++)
       q[i] = (uint8_t) pack_dither (pk.dither, 1, (int) ((src.at (x0 + i, y0) >> 8) & 0xff), x0 + i, y0);
     return;
   }
   const int nlines = 1 << pk.h_sub;
   if (pk.kind == UNPACK_PACKED422) {       // luma into the macropixels (pack_YUY2 & co, video-format.c:201-460)
-    uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 2 * (size_t) x0;
+    uint8_t *q = (d.p[0] + dd) + (size_t) y0 * d.stride[0] + 2 * (size_t) x0;
     for (int i = 0; i < 4 && x0 + i < w; i++)
       q[4 * (i >> 1) + pk.pos[1] + 2 * (i & 1)] = (uint8_t) pack_dither (pk.dither, 1, (int) ((src.at (x0 + i, y0) >> 8) & 0xff), x0 + i, y0);
   }
@@ -72,7 +74,7 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
     const int y = y0 + r;
     if (y >= h)
       break;
-    uint8_t *dy = d.p[0] + (size_t) y * d.stride[0] + x0;
+    uint8_t *dy = (d.p[0] + dd) + (size_t) y * d.stride[0] + x0;
     for (int i = 0; i < 4 && x0 + i < w; i++)
       dy[i] = (uint8_t) pack_dither (pk.dither, 1, (int) ((src.at (x0 + i, y) >> 8) & 0xff), x0 + i, y);
   }
@@ -115,16 +117,16 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
     }
     const int k = x >> pk.w_sub;
     if (pk.kind == UNPACK_PACKED422) {
-      uint8_t *q = d.p[0] + (size_t) y0 * d.stride[0] + 4 * (size_t) k;
+      uint8_t *q = (d.p[0] + dd) + (size_t) y0 * d.stride[0] + 4 * (size_t) k;
       q[pk.pos[2]] = cu;
       q[pk.pos[3]] = cv;
     } else if (pk.kind == UNPACK_SEMI) {
-      uint8_t *duv = d.p[1] + (size_t) yb * d.stride[1] + 2 * k;
+      uint8_t *duv = (d.p[1] + dd) + (size_t) yb * d.stride[1] + 2 * k;
       duv[0] = pk.u_plane ? cu : cv;
       duv[1] = pk.u_plane ? cv : cu;
     } else {
-      d.p[pk.u_plane][(size_t) yb * d.stride[pk.u_plane] + k] = cu;
-      d.p[pk.v_plane][(size_t) yb * d.stride[pk.v_plane] + k] = cv;
+      (d.p[pk.u_plane] + dd)[(size_t) yb * d.stride[pk.u_plane] + k] = cu;
+      (d.p[pk.v_plane] + dd)[(size_t) yb * d.stride[pk.v_plane] + k] = cv;
     }
   }
 }
@@ -154,7 +156,7 @@ GSTAMD_HD uint32_t avgub4 (uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) 
 // shape of video_orc_convert_YUY2_I420 / _Y42B / _Y444 and their UYVY twins (video-orc.orc:1452-1620): luma copied, chroma copied
 // (4:2:2), averaged over the line pair (4:2:0) or doubled (4:4:4).  False for what it leaves to pack_planar_body (picture edge, the swapped
 // tail macropixel, a cosited horizontal filter, dither, the line past the picture).
-GSTAMD_HD bool pack_422dup_block8 (const PackPlanarParams &pk, const Src422Dup &s, const DstPlanes &d, int x0, int yb)
+GSTAMD_HD bool pack_422dup_block8 (const PackPlanarParams &pk, const Src422Dup &s, const DstPlanes &d, int x0, int yb, long long dd = 0)
 {
   const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
   if (y0 >= h)
@@ -170,11 +172,11 @@ GSTAMD_HD bool pack_422dup_block8 (const PackPlanarParams &pk, const Src422Dup &
 #define GSTAMD_PICK4(q, sh) ((((q).x >> (sh)) & 0xffu) | ((((q).y >> (sh)) & 0xffu) << 8) | ((((q).z >> (sh)) & 0xffu) << 16) | ((((q).w >> (sh)) & 0xffu) << 24))
   uint2 ya;
   ya.x = GSTAMD_LUM2 (a.x) | (GSTAMD_LUM2 (a.y) << 16), ya.y = GSTAMD_LUM2 (a.z) | (GSTAMD_LUM2 (a.w) << 16);
-  *(uint2 *) (d.p[0] + (size_t) y0 * d.stride[0] + x0) = ya;
+  *(uint2 *) ((d.p[0] + dd) + (size_t) y0 * d.stride[0] + x0) = ya;
   if (pk.h_sub && y0 + 1 < h) {
     uint2 yb2;
     yb2.x = GSTAMD_LUM2 (b.x) | (GSTAMD_LUM2 (b.y) << 16), yb2.y = GSTAMD_LUM2 (b.z) | (GSTAMD_LUM2 (b.w) << 16);
-    *(uint2 *) (d.p[0] + (size_t) (y0 + 1) * d.stride[0] + x0) = yb2;
+    *(uint2 *) ((d.p[0] + dd) + (size_t) (y0 + 1) * d.stride[0] + x0) = yb2;
   }
   uint32_t u = GSTAMD_PICK4 (a, s.ush), v = GSTAMD_PICK4 (a, s.vsh);
   if (pk.down_v) {
@@ -190,10 +192,10 @@ GSTAMD_HD bool pack_422dup_block8 (const PackPlanarParams &pk, const Src422Dup &
       uint2 o;
       o.x = (f & 0xffu) | ((g & 0xffu) << 8) | ((f & 0xff00u) << 8) | ((g & 0xff00u) << 16);
       o.y = ((f >> 16) & 0xffu) | (((g >> 16) & 0xffu) << 8) | ((f >> 24) << 16) | ((g >> 24) << 24);
-      *(uint2 *) (d.p[1] + (size_t) yb * d.stride[1] + 2 * k) = o;
+      *(uint2 *) ((d.p[1] + dd) + (size_t) yb * d.stride[1] + 2 * k) = o;
     } else {
-      *(uint32_t *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane] + k) = u;
-      *(uint32_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane] + k) = v;
+      *(uint32_t *) ((d.p[pk.u_plane] + dd) + (size_t) yb * d.stride[pk.u_plane] + k) = u;
+      *(uint32_t *) ((d.p[pk.v_plane] + dd) + (size_t) yb * d.stride[pk.v_plane] + k) = v;
     }
     return true;
   }
@@ -202,15 +204,15 @@ GSTAMD_HD bool pack_422dup_block8 (const PackPlanarParams &pk, const Src422Dup &
   uu.x = (u & 0xffu) * 0x0101u | (((u >> 8) & 0xffu) * 0x0101u) << 16, uu.y = ((u >> 16) & 0xffu) * 0x0101u | ((u >> 24) * 0x0101u) << 16;
   vv.x = (v & 0xffu) * 0x0101u | (((v >> 8) & 0xffu) * 0x0101u) << 16, vv.y = ((v >> 16) & 0xffu) * 0x0101u | ((v >> 24) * 0x0101u) << 16;
   if (pk.kind == UNPACK_SEMI) {
-    uint8_t *q = d.p[1] + (size_t) yb * d.stride[1] + 2 * (size_t) x0;
+    uint8_t *q = (d.p[1] + dd) + (size_t) yb * d.stride[1] + 2 * (size_t) x0;
     for (int i = 0; i < 8; i++) {
       const uint32_t cu = ((i < 4 ? uu.x : uu.y) >> (8 * (i & 3))) & 0xffu, cv = ((i < 4 ? vv.x : vv.y) >> (8 * (i & 3))) & 0xffu;
       q[2 * i] = (uint8_t) (pk.u_plane ? cu : cv);
       q[2 * i + 1] = (uint8_t) (pk.u_plane ? cv : cu);
     }
   } else {
-    *(uint2 *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane] + x0) = uu;
-    *(uint2 *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane] + x0) = vv;
+    *(uint2 *) ((d.p[pk.u_plane] + dd) + (size_t) yb * d.stride[pk.u_plane] + x0) = uu;
+    *(uint2 *) ((d.p[pk.v_plane] + dd) + (size_t) yb * d.stride[pk.v_plane] + x0) = vv;
   }
   return true;
 }
@@ -219,7 +221,7 @@ GSTAMD_HD bool pack_422dup_block8 (const PackPlanarParams &pk, const Src422Dup &
 // dither stage: 16-byte loads of the block's pixels (the image rows are 16-byte aligned: the caller checks), the luma of a line as one
 // 32-bit store, the chroma as 16-bit (4:2:x planar), 32-bit (semi-planar, 4:4:4) stores; the arithmetic is pack_planar_body's on the same
 // packed {U, V} words.  Returns false for the blocks it leaves to the general body (picture edge, tail_swap pixel).
-GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const uint8_t *__restrict__ img, int sstride, const DstPlanes &d, int x0, int yb)
+GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const uint8_t *__restrict__ img, int sstride, const DstPlanes &d, int x0, int yb, long long dd = 0)
 {
   const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
   if (x0 + 4 > w || y0 >= h || (pk.tail_swap && x0 + 4 == w && (w & 1)))
@@ -230,9 +232,9 @@ GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const uint8_t *__
   if (pk.h_sub || pk.down_v)
     b = *(const uint4 *) (img + (size_t) yb1 * sstride + 4 * (size_t) x0);
   // luma
-  *(uint32_t *) (d.p[0] + (size_t) y0 * d.stride[0] + x0) = ((a.x >> 8) & 0xffu) | (a.y & 0xff00u) | ((a.z << 8) & 0xff0000u) | ((a.w << 16) & 0xff000000u);
+  *(uint32_t *) ((d.p[0] + dd) + (size_t) y0 * d.stride[0] + x0) = ((a.x >> 8) & 0xffu) | (a.y & 0xff00u) | ((a.z << 8) & 0xff0000u) | ((a.w << 16) & 0xff000000u);
   if (pk.h_sub && y0 + 1 < h)
-    *(uint32_t *) (d.p[0] + (size_t) (y0 + 1) * d.stride[0] + x0) = ((b.x >> 8) & 0xffu) | (b.y & 0xff00u) | ((b.z << 8) & 0xff0000u) | ((b.w << 16) & 0xff000000u);
+    *(uint32_t *) ((d.p[0] + dd) + (size_t) (y0 + 1) * d.stride[0] + x0) = ((b.x >> 8) & 0xffu) | (b.y & 0xff00u) | ((b.z << 8) & 0xff0000u) | ((b.w << 16) & 0xff000000u);
   // chroma of pixels x0 - 1 .. x0 + 4 of the chroma line
   uint32_t v[6];
   v[1] = ayuv_uv (a.x), v[2] = ayuv_uv (a.y), v[3] = ayuv_uv (a.z), v[4] = ayuv_uv (a.w);
@@ -281,23 +283,23 @@ GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const uint8_t *__
     const int k = x0 >> 1;
     if (pk.kind == UNPACK_SEMI) {
       const uint32_t first = pk.u_plane ? u2 : v2, second = pk.u_plane ? v2 : u2;
-      *(uint32_t *) (d.p[1] + (size_t) yb * d.stride[1] + 2 * k) = (first & 0xffu) | ((second & 0xffu) << 8) | ((first & 0xff00u) << 8) | ((second & 0xff00u) << 16);
+      *(uint32_t *) ((d.p[1] + dd) + (size_t) yb * d.stride[1] + 2 * k) = (first & 0xffu) | ((second & 0xffu) << 8) | ((first & 0xff00u) << 8) | ((second & 0xff00u) << 16);
     } else {
-      *(uint16_t *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane] + k) = (uint16_t) u2;
-      *(uint16_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane] + k) = (uint16_t) v2;
+      *(uint16_t *) ((d.p[pk.u_plane] + dd) + (size_t) yb * d.stride[pk.u_plane] + k) = (uint16_t) u2;
+      *(uint16_t *) ((d.p[pk.v_plane] + dd) + (size_t) yb * d.stride[pk.v_plane] + k) = (uint16_t) v2;
     }
   } else {
     const uint32_t u4 = (c[0] & 0xffu) | ((c[1] & 0xffu) << 8) | ((c[2] & 0xffu) << 16) | ((c[3] & 0xffu) << 24);
     const uint32_t v4 = (c[0] >> 16) | ((c[1] >> 16) << 8) | ((c[2] >> 16) << 16) | ((c[3] >> 16) << 24);
     if (pk.kind == UNPACK_SEMI) {           /* NV24 family: 8 interleaved bytes */
-      uint8_t *q = d.p[1] + (size_t) yb * d.stride[1] + 2 * (size_t) x0;
+      uint8_t *q = (d.p[1] + dd) + (size_t) yb * d.stride[1] + 2 * (size_t) x0;
       for (int i = 0; i < 4; i++) {
         q[2 * i] = (uint8_t) (pk.u_plane ? c[i] : c[i] >> 16);
         q[2 * i + 1] = (uint8_t) (pk.u_plane ? c[i] >> 16 : c[i]);
       }
     } else {
-      *(uint32_t *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane] + x0) = u4;
-      *(uint32_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane] + x0) = v4;
+      *(uint32_t *) ((d.p[pk.u_plane] + dd) + (size_t) yb * d.stride[pk.u_plane] + x0) = u4;
+      *(uint32_t *) ((d.p[pk.v_plane] + dd) + (size_t) yb * d.stride[pk.v_plane] + x0) = v4;
     }
   }
   return true;

@@ -38,14 +38,14 @@ GSTAMD_HD void rl_copy_bytes (uint8_t *d, const uint8_t *s, int n)
 
 // row < height: 16 luma bytes of row `row` from byte 16 * lane.  Then the chroma rows: for a semi-planar destination `ch` rows of 16
 // interleaved bytes (8 samples of each component); for a planar one `ch` rows of U and `ch` rows of V, 16 samples each.
-GSTAMD_HD void relayout_body (const RelayoutParams &p, int lane, int row)
+GSTAMD_HD void relayout_body (const RelayoutParams &p, int lane, int row, long long ds = 0, long long dd = 0)
 {
   const int b0 = 16 * lane;
   if (row < p.height) {
     if (b0 >= p.width)
       return;
-    const uint8_t *s = p.in[0] + (size_t) row * p.in_stride[0] + b0;
-    uint8_t *d = p.out[0] + (size_t) row * p.out_stride[0] + b0;
+    const uint8_t *s = (p.in[0] + ds) + (size_t) row * p.in_stride[0] + b0;
+    uint8_t *d = (p.out[0] + dd) + (size_t) row * p.out_stride[0] + b0;
     if (b0 + 16 <= p.width)
       *(uint4 *) d = *(const uint4 *) s;
     else
@@ -57,11 +57,11 @@ GSTAMD_HD void relayout_body (const RelayoutParams &p, int lane, int row)
     if (row >= p.ch || b0 >= 2 * p.cw)
       return;
     const int k0 = b0 / 2;              /* first chroma sample of the lane, 8 of them */
-    uint8_t *d = p.out[1] + (size_t) row * p.out_stride[1] + b0;
+    uint8_t *d = (p.out[1] + dd) + (size_t) row * p.out_stride[1] + b0;
     if (b0 + 16 <= 2 * p.cw) {
       uint4 o;
       if (p.in_semi) {
-        const uint4 a = *(const uint4 *) (p.in[1] + (size_t) row * p.in_stride[1] + b0);
+        const uint4 a = *(const uint4 *) ((p.in[1] + ds) + (size_t) row * p.in_stride[1] + b0);
         if (p.in_u == p.out_u) {
           o = a;
         } else {                        /* NV12 <-> NV21: the bytes of every pair trade places */
@@ -69,8 +69,8 @@ GSTAMD_HD void relayout_body (const RelayoutParams &p, int lane, int row)
           o.z = ((a.z >> 8) & 0x00ff00ffu) | ((a.z << 8) & 0xff00ff00u), o.w = ((a.w >> 8) & 0x00ff00ffu) | ((a.w << 8) & 0xff00ff00u);
         }
       } else {
-        const uint2 u = *(const uint2 *) (p.in[p.in_u] + (size_t) row * p.in_stride[p.in_u] + k0);
-        const uint2 v = *(const uint2 *) (p.in[p.in_v] + (size_t) row * p.in_stride[p.in_v] + k0);
+        const uint2 u = *(const uint2 *) ((p.in[p.in_u] + ds) + (size_t) row * p.in_stride[p.in_u] + k0);
+        const uint2 v = *(const uint2 *) ((p.in[p.in_v] + ds) + (size_t) row * p.in_stride[p.in_v] + k0);
         const uint2 f = p.out_u ? u : v, g = p.out_u ? v : u;
         o.x = rl_zip (f.x, g.x, 0), o.y = rl_zip (f.x, g.x, 1), o.z = rl_zip (f.y, g.y, 0), o.w = rl_zip (f.y, g.y, 1);
       }
@@ -80,10 +80,10 @@ GSTAMD_HD void relayout_body (const RelayoutParams &p, int lane, int row)
     for (int k = k0; k < p.cw; k++) {
       uint8_t cu, cv;
       if (p.in_semi) {
-        const uint8_t *s = p.in[1] + (size_t) row * p.in_stride[1] + 2 * k;
+        const uint8_t *s = (p.in[1] + ds) + (size_t) row * p.in_stride[1] + 2 * k;
         cu = p.in_u ? s[0] : s[1], cv = p.in_u ? s[1] : s[0];
       } else {
-        cu = p.in[p.in_u][(size_t) row * p.in_stride[p.in_u] + k], cv = p.in[p.in_v][(size_t) row * p.in_stride[p.in_v] + k];
+        cu = (p.in[p.in_u] + ds)[(size_t) row * p.in_stride[p.in_u] + k], cv = (p.in[p.in_v] + ds)[(size_t) row * p.in_stride[p.in_v] + k];
       }
       d[2 * (k - k0)] = p.out_u ? cu : cv;
       d[2 * (k - k0) + 1] = p.out_u ? cv : cu;
@@ -97,10 +97,10 @@ GSTAMD_HD void relayout_body (const RelayoutParams &p, int lane, int row)
   if (row >= p.ch || b0 >= p.cw)
     return;
   const int want_u = !second;         /* first the U plane's rows */
-  uint8_t *d = p.out[want_u ? p.out_u : p.out_v] + (size_t) row * p.out_stride[want_u ? p.out_u : p.out_v] + b0;
+  uint8_t *d = (p.out[want_u ? p.out_u : p.out_v] + dd) + (size_t) row * p.out_stride[want_u ? p.out_u : p.out_v] + b0;
   if (!p.in_semi) {
     const int sp = want_u ? p.in_u : p.in_v;
-    const uint8_t *s = p.in[sp] + (size_t) row * p.in_stride[sp] + b0;
+    const uint8_t *s = (p.in[sp] + ds) + (size_t) row * p.in_stride[sp] + b0;
     if (b0 + 16 <= p.cw)
       *(uint4 *) d = *(const uint4 *) s;
     else
@@ -108,7 +108,7 @@ GSTAMD_HD void relayout_body (const RelayoutParams &p, int lane, int row)
     return;
   }
   const int first_byte = (want_u ? 1 : 0) == (p.in_u ? 1 : 0);          /* is the wanted component the first byte of a pair? */
-  const uint8_t *s = p.in[1] + (size_t) row * p.in_stride[1] + 2 * b0;
+  const uint8_t *s = (p.in[1] + ds) + (size_t) row * p.in_stride[1] + 2 * b0;
   if (b0 + 16 <= p.cw) {
     const uint4 a = *(const uint4 *) s, b = *(const uint4 *) (s + 16);
     uint4 o;

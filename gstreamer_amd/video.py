@@ -107,6 +107,7 @@ def lib():
                                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_void_p]
         L.gstamd_video_converter_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                     C.c_void_p]
+        L.gstamd_video_converter_list_launches.argtypes = [C.c_void_p]
         L.gstamd_video_converter_free.argtypes = [C.c_void_p]
         L.gstamd_video_converter_describe.restype = C.c_char_p
         L.gstamd_video_converter_describe.argtypes = [C.c_void_p]
@@ -250,6 +251,10 @@ class VideoConverter:
         sp = (C.c_void_p * n)(*[_ptr(x) for x in srcs])
         dp = (C.c_void_p * n)(*[_ptr(x) for x in dests])
         _check(lib().gstamd_video_converter_frames(self._h, n, sp, dp, stream))
+
+    def list_launches(self):
+        """launches of the last frames() call that each served a whole list (0: the frames went one by one)"""
+        return int(lib().gstamd_video_converter_list_launches(self._h))
 
     def describe(self):
         return lib().gstamd_video_converter_describe(self._h).decode()

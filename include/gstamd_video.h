@@ -209,6 +209,12 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *convert,
 int gstamd_video_converter_frames (GstAmdVideoConverter *convert, int n_frames, const void *const *src,
     void *const *dest, void *stream);
 
+/* How the last _frames call on this converter ran: the number of kernel launches that each served a whole list (or a
+ * chunk of up to 32 / 16 frames of it) - 0 when the plan's kernels took the frames one by one.  What tests and the
+ * element's statistics read; no reference counterpart (the reference converts buffer lists buffer by buffer,
+ * gstbasetransform.c default chain_list). */
+int gstamd_video_converter_list_launches (GstAmdVideoConverter *convert);
+
 void gstamd_video_converter_free (GstAmdVideoConverter *convert);
 
 /* Introspection used by tests / bench: name of the kernel plan chosen ("fused_convert",

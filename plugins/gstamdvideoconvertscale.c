@@ -121,6 +121,7 @@ typedef struct {
   GstPadChainFunction base_chain;       /* GstBaseTransform's chain function (the sink pad's, before chain_list was installed) */
   /* GSTAMD_ELEMENT_STATS=1: host time spent in transform(), printed at stop (where does a buffer's CPU time go?) */
   gboolean stats;
+  guint64 n_list_calls, n_list_launches;        /* buffer lists: converter calls, and the launches of them that each served a whole list */
   gint64 t_wait, t_convert, t_mark, t_total, t_prepare;
   guint64 n_frames;
 } GstAmdVideoConvertScale;
@@ -1623,9 +1624,11 @@ amd_vcs_chain_list (GstPad * pad, GstObject * parent, GstBufferList * list)
         dsts[k] = omaps[k].data;
         mapped++;
       }
-      if (mapped == cnt)
+      if (mapped == cnt) {
         r = gstamd_video_converter_frames (s->convert, (int) cnt, srcs, dsts, stream);
-      else
+        s->n_list_calls++;
+        s->n_list_launches += (guint64) gstamd_video_converter_list_launches (s->convert);
+      } else
         r = GSTAMD_ERR_INVALID;
       if (r == GSTAMD_OK) {
         GstAmdHipTicket *t = s->n_streams == 1 ? gst_amd_hip_ticket_new_lazy (stream) : gst_amd_hip_ticket_new (stream);
@@ -1683,6 +1686,10 @@ amd_vcs_stop (GstBaseTransform * trans)
         "(map + stream waits %.2f, converter call %.2f, event records %.2f)\n", s->n_frames, (double) s->t_prepare / s->n_frames,
         (double) s->t_total / s->n_frames, (double) s->t_wait / s->n_frames, (double) s->t_convert / s->n_frames,
         (double) s->t_mark / s->n_frames);
+  if (s->stats && s->n_list_calls)
+    g_printerr ("videoconvertscale buffer lists: %" G_GUINT64_FORMAT " converter calls, %" G_GUINT64_FORMAT " list launches\n", s->n_list_calls,
+        s->n_list_launches);
+  s->n_list_calls = s->n_list_launches = 0;
   if (s->reads) {
     gst_amd_hip_pending_reads_free (s->reads);          /* waits for the queued uploads, gives their input buffers back */
     s->reads = NULL;

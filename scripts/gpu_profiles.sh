@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-config evidence for profiles/: the bench line (roofline + cpu_baseline), rocprofv3 kernel-trace stats and the PMC HBM traffic
 # (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes) of the SAME bench command; plus the FETCH_SIZE /
-# WRITE_SIZE calibration on known byte counts (scripts/fetchcal.hip).   usage: gpu_profiles.sh [configs...]
+# WRITE_SIZE calibration on known byte counts (scripts/fetchcal.hip).   usage: gpu_profiles.sh [configs...]   (GSTAMD_PROF_NO_PMC=1: bench line + kernel stats only)
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/prof; R=$GRAFT_REPO_ROOT/gpurun_out/prof
 CONFIGS="${@:-c2 c3 c4 c5 c4audio c1}"
@@ -10,7 +10,9 @@ for c in $CONFIGS; do
   BENCH="python $GRAFT_REPO_ROOT/bench.py --config $c --no-cpu-baseline"
   ( cd /tmp; rm -rf /tmp/p_$c
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$c/trace -o t -- $BENCH > /tmp/p_$c.log 2>&1
+    [ -n "$GSTAMD_PROF_NO_PMC" ] ||
     timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_$c/fetch -o t -- $BENCH >> /tmp/p_$c.log 2>&1
+    [ -n "$GSTAMD_PROF_NO_PMC" ] ||
     timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_$c/write -o t -- $BENCH >> /tmp/p_$c.log 2>&1 )
   f=$(find /tmp/p_$c/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/${c}_kernel_stats.csv
   python3 - $c /tmp/p_$c $R <<'PY'
@@ -35,6 +37,7 @@ json.dump(res, open("%s/pmc_%s.json" % (out, c), "w"), indent=1)
 print(json.dumps(res)[:1500])
 PY
 done
+[ -n "$GSTAMD_PROF_NO_PMC" ] && exit 0
 ( cd /tmp; rm -rf /tmp/p_cal
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_cal/fetch -o t -- $GRAFT_REPO_ROOT/scripts/fetchcal > /tmp/p_cal.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_cal/write -o t -- $GRAFT_REPO_ROOT/scripts/fetchcal >> /tmp/p_cal.log 2>&1 )

@@ -574,7 +574,7 @@ def test_compositor_element_i420_and_nv12_output(gst_env, ref):
             assert (canvas == out[f]).all(), (ofmt, f, int((canvas != out[f]).sum()))
 
 
-def _bench_element(env, args):
+def _bench_element(env, args, keep_stderr=False):
     exe = os.path.join(ROOT, "plugins", "tests", "bench_element")
     assert os.path.exists(exe), "plugins/build.py builds it"
     r = subprocess.run([exe] + [str(a) for a in args], env=dict(env, GSTAMD_ELEMENT_STATS="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -583,22 +583,58 @@ def _bench_element(env, args):
     print(r.stderr.strip()[-600:])
     import json
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    return json.loads(line)
+    return dict(json.loads(line), stderr=r.stderr) if keep_stderr else json.loads(line)
+
+
+def _list_stats(res):
+    import re
+    m = re.search(r"buffer lists: (\d+) converter calls, (\d+) list launches", res["stderr"])
+    assert m, res["stderr"][-600:]
+    return int(m.group(1)), int(m.group(2))
 
 
 @pytest.mark.parametrize("list_n", [4, 32])
 def test_element_buffer_lists_take_one_launch(gst_env, list_n):
-    """GstBufferLists through the element's chain_list path (one converter call per list): frames/s at 4K and 1080p."""
+    """GstBufferLists through the element's chain_list path (one converter call per list): frames/s at 4K and 1080p, and the
+    element's own count of converter calls against the launches that each served a whole list (one per call)."""
     env, tmp = gst_env
     out = []
     for (w, h, n) in ((3840, 2160, 640), (1920, 1080, 1600)):
-        res = _bench_element(env, ["NV12", w, h, "BGRA", w, h, n, 3, "bilinear", list_n])
+        res = _bench_element(env, ["NV12", w, h, "BGRA", w, h, n, 3, "bilinear", list_n], keep_stderr=True)
+        calls, launches = _list_stats(res)
+        assert calls > 0 and launches == calls, (calls, launches)
+        res.pop("stderr")
         out.append(res)
         print(res)
     with open(os.path.join(ROOT, "gpurun_out", "element_bench.jsonl"), "a") as f:
         for res in out:
             f.write(__import__("json").dumps(res) + "\n")
     assert out[0]["frames_per_s"] > 40000, out
+
+
+LIST_ELEMENT_PLANS = [      # single-kernel plans whose kernels take the list as the grid's third dimension (video_kernels.hip: frame lists)
+    ("plane_scaler", "NV12", 3840, 2160, "NV12", 1920, 1080, 1),
+    ("p010_out", "NV12", 3840, 2160, "P010_10LE", 3840, 2160, 1),
+    ("p010_in", "P010_10LE", 3840, 2160, "NV12", 3840, 2160, 1),
+    ("planar_pack", "YUY2", 3840, 2160, "I420", 3840, 2160, 1),
+    ("swizzle", "BGRA", 3840, 2160, "RGBA", 3840, 2160, 1),
+    ("column_scaler", "I420", 3840, 2160, "RGBA", 1920, 1080, 1),
+]
+
+
+@pytest.mark.parametrize("plan", LIST_ELEMENT_PLANS, ids=lambda p: p[0])
+def test_element_buffer_lists_of_single_kernel_plans_take_one_launch(gst_env, plan):
+    """the plane scaler, the P010 plans, the planar packer, the swizzle and the column scaler behind chain_list: every converter call
+    of a list is served by launches that take the whole list (the plane scaler: one per kernel form of its planes)"""
+    env, tmp = gst_env
+    _, ifmt, w, h, ofmt, ow, oh, per_call = plan
+    res = _bench_element(env, [ifmt, w, h, ofmt, ow, oh, 256, 1, "lanczos" if plan[0] == "column_scaler" else "bilinear", 8], keep_stderr=True)
+    calls, launches = _list_stats(res)
+    res.pop("stderr")
+    print(res)
+    assert calls == 256 // 8 and launches >= calls * per_call and launches <= calls * 3, (calls, launches)
+    with open(os.path.join(ROOT, "gpurun_out", "element_bench.jsonl"), "a") as f:
+        f.write(__import__("json").dumps(dict(res, plan=plan[0])) + "\n")
 
 
 def test_buffer_list_output_equals_single_buffers(gst_env, ref):

@@ -210,6 +210,70 @@ def test_hip_scale_col_frame_list_is_one_grid(native_lib, gpu, ref):
     conv.free()
 
 
+LIST_PLANS = [      # (id, in, w, h, out, ow, oh, config, list launches expected per chunk: 0 = the plan goes frame by frame)
+    ("plane_direct", "NV12", 1920, 1080, "NV12", 960, 540, cases.LIN, 1),
+    ("plane_tiles", "I420", 1280, 720, "I420", 640, 360, cases.LAN, 1),
+    ("plane_y444", "Y444", 640, 480, "Y444", 800, 600, cases.LIN, 1),
+    ("pack_422", "YUY2", 1920, 1080, "I420", 1920, 1080, {}, 1),
+    ("pack_422_nv12", "UYVY", 1280, 720, "NV12", 1280, 720, {}, 1),
+    ("convert_pack", "BGRA", 1280, 720, "I420", 1280, 720, {}, 1),
+    ("encode420", "BGRA", 1920, 1080, "NV12", 1920, 1080, {}, 1),
+    ("swizzle4", "BGRA", 1920, 1080, "RGBA", 1920, 1080, {}, 1),
+    ("swizzle34", "RGB", 1280, 720, "BGRA", 1280, 720, {}, 1),
+    ("swizzle43", "BGRx", 1280, 720, "BGR", 1280, 720, {}, 1),
+    ("relayout", "I420", 1280, 720, "NV12", 1280, 720, {}, 1),
+    ("convert422", "YUY2", 1280, 720, "BGRA", 1280, 720, {}, 1),
+    ("convert422_ayuv", "UYVY", 1280, 720, "AYUV", 1280, 720, {}, 1),
+    ("convert420p", "I420", 1280, 720, "RGB", 1280, 720, {}, 1),
+    ("p010_out", "NV12", 1920, 1080, "P010_10LE", 1920, 1080, {}, 1),
+    ("p010_in", "P010_10LE", 1920, 1080, "NV12", 1920, 1080, {}, 1),
+    ("i420_10_in", "I420_10LE", 1280, 720, "I420", 1280, 720, {}, 1),
+    ("gamma_remap", "NV12", 1920, 1080, "BGRA", 1920, 1080, dict(gamma_mode="remap"), 1),
+    ("odd_size", "YUY2", 322, 242, "I420", 322, 242, {}, -1),
+    ("two_pass_lanczos", "BGRA", 640, 360, "RGBA", 500, 300, cases.LAN, 0),
+    ("dithered", "BGRA", 640, 360, "NV12", 640, 360, dict(dither_quantization=8), 0),
+    ("gamma_remap_scaled", "NV12", 640, 360, "BGRA", 480, 270, dict(gamma_mode="remap"), 0),
+    ("borders", "BGRA", 640, 360, "RGBA", 640, 360, dict(dest_x=16, dest_y=8, dest_width=600, dest_height=340), 0),
+]
+
+
+@pytest.mark.parametrize("plan", LIST_PLANS, ids=lambda p: p[0])
+def test_hip_single_kernel_plans_take_frame_lists(native_lib, gpu, ref, plan):
+    """gstamd_video_converter_frames on the single-kernel plans: the list is the grid's third dimension (one launch per chunk of 32
+    frames and kernel), every frame memcmp'd against the reference; plans of several kernels go frame by frame with the same bytes.
+    35 frames: a chunk of 32 and one of 3; frames of the list lie in scattered allocations (different distances between them)."""
+    import torch
+    _, ifmt, w, h, ofmt, ow, oh, cfg, expect = plan
+    n = 35 if w * h <= 1280 * 720 else 5
+    ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)
+    conv = V.VideoConverter(ii, oi, V.converter_config(**cfg))
+    rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, cfg))
+    srcs, outs, exp, pad = [], [], [], []
+    for i in range(n):
+        b = cases.frame_bytes(ii.size, "random", 7100 + i)
+        exp.append(rc.frame(b))
+        pad.append(torch.empty(4096 * (1 + (i * 7) % 5), dtype=torch.uint8, device=gpu))         # uneven gaps between the frames
+        srcs.append(torch.from_numpy(b).to(gpu))
+        outs.append(torch.full((int(oi.size),), 0x5A, dtype=torch.uint8, device=gpu))
+    order = list(range(n))
+    order[1], order[-1] = order[-1], order[1]                                                     # and a list that is not in address order
+    conv.frames([srcs[i] for i in order], [outs[i] for i in order])
+    torch.cuda.synchronize()
+    launches = conv.list_launches()
+    bad = [i for i in range(n) if not (outs[i].cpu().numpy()[: len(exp[i])] == exp[i]).all()]
+    assert not bad, (bad, launches)
+    chunks = (n + 31) // 32
+    if expect > 0:
+        assert chunks * expect <= launches <= chunks * 3, launches
+    elif expect == 0:
+        assert launches == 0, launches
+    # ... and frame by frame again on the same converter (the list context must not outlive the call)
+    conv.frame(srcs[0], outs[1])
+    torch.cuda.synchronize()
+    assert (outs[1].cpu().numpy()[: len(exp[0])] == exp[0]).all()
+    conv.free()
+
+
 BILR_SHAPES = [("NV12", 3840, 2160, "BGRA", 1920, 1080, None), ("NV12", 1920, 1080, "RGBA", 1280, 720, None), ("I420", 2048, 858, "ARGB", 1024, 429, "jpeg"),
                ("NV21", 1280, 720, "BGRx", 1000, 562, None), ("YV12", 640, 480, "BGRA", 1280, 960, None), ("NV12", 4096, 2160, "BGRA", 2730, 1440, "mpeg2")]
 

@@ -1075,4 +1075,131 @@ GSTAMD_HD void deep_planes_body (const DeepPlanesParams &d, const DeepPlanesPtrs
   }
 }
 
+// ---- k_deep_planes16: the plain depth changes, sixteen samples of a plane row per lane ---------------------------------------------------
+// deep_planes_body is written per sample with every format switch at run time (some 200 VALU instructions for a lane's 8 samples: P010 ->
+// NV12 at 4K ran 11 us, NV12 -> P010 15 us, against 4.7 us of HBM traffic).  When both formats have the same plane layout and exactly one of
+// them is deep, a plane row is a row of samples in and a row of samples out, and the per-sample chain collapses:
+//   deep -> 8 bits: widen to 16 (bit replication below the stored bits), keep the high byte (video_orc_convert_u16_to_u8) = the high byte
+//     of the stored word for the formats that keep their bits on top (P010, P012, P016), (word >> (bits - 8)) & 0xff for the others;
+//   8 bits -> deep: byte * 257 (video_orc_convert_u8_to_u16) = the byte in both halves of the word, + the dither matrix value of the
+//     sample's picture position >> (8 - shift), saturated, & ~((1 << shift) - 1) (gst_video_dither_line, ordered dither on 16-bit lines),
+//     then the packer's & ~((1 << drop) - 1) or >> drop.  The matrix is 16 columns wide and a lane starts at a multiple of 16 samples:
+//     the eight pairs of dither values are the same for every lane of a row.
+// A lane loads 32 / 16 bytes and stores 16 / 32; two samples per register in the packed 16-bit instructions.
+GSTAMD_VP bool deep_planes16_ok (const DeepPlanesParams &d)
+{
+  if (d.in_kind != d.out_kind || (d.in_kind != UNPACK_PLANAR && d.in_kind != UNPACK_SEMI) || (d.in_hi != 0) == (d.out_hi != 0) || d.w_sub > 1)
+    return false;
+  const int deep = d.in_hi ? d.in_hi : d.out_hi;
+  if (deep != 1 && deep != 2 && deep != 4 && deep != 5 && deep != 6)
+    return false;
+  const int cw = (d.width + (1 << d.w_sub) - 1) >> d.w_sub;
+  if ((d.width % 16) != 0 || ((d.in_kind == UNPACK_SEMI ? 2 * cw : cw) % 16) != 0)
+    return false;
+  if (d.in_kind == UNPACK_SEMI && (d.in_u != d.out_u || d.w_sub != 1))
+    return false;
+  if (d.out_hi && d.dither.on && (d.dither.shift[1] != d.dither.shift[2] || d.dither.shift[1] != d.dither.shift[3] || d.dither.shift[1] > 8 || d.dither.shift[1] < 0))
+    return false;
+  return true;
+}
+
+GSTAMD_HD uint32_t pk_adds16 (uint32_t a, uint32_t b)            // v_pk_add_u16 clamp: per 16-bit lane, saturating
+{
+#ifdef __HIPCC__
+  typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
+  return __builtin_bit_cast (uint32_t, __builtin_elementwise_add_sat (__builtin_bit_cast (us2, a), __builtin_bit_cast (us2, b)));
+#else
+  const uint32_t lo = (a & 0xffffu) + (b & 0xffffu), hi = (a >> 16) + (b >> 16);
+  return (lo > 0xffffu ? 0xffffu : lo) | ((hi > 0xffffu ? 0xffffu : hi) << 16);
+#endif
+}
+
+GSTAMD_VP int deep_planes16_rows (const DeepPlanesParams &d)
+{
+  const int ch = (d.height + (1 << d.h_sub) - 1) >> d.h_sub;
+  return d.height + (d.in_kind == UNPACK_SEMI ? ch : 2 * ch);
+}
+
+// lane: samples 16 * lane .. + 15 of plane row `row` (luma rows, then the chroma rows: of the interleaved plane, or of U and then of V)
+template <int TO_HI>
+GSTAMD_HD void deep_planes16_body (const DeepPlanesParams &d, const DeepPlanesPtrs &pp, int lane, int row, long long ds = 0, long long dd = 0)
+{
+  const int ch = (d.height + (1 << d.h_sub) - 1) >> d.h_sub, cw = (d.width + (1 << d.w_sub) - 1) >> d.w_sub;
+  int ip = 0, op = 0, r = row, n = d.width, mode = 0, y = row;
+  if (row >= d.height) {
+    r = row - d.height;
+    if (d.in_kind == UNPACK_SEMI) {
+      ip = op = 1, n = 2 * cw, mode = 1;
+    } else {
+      const int second = r >= ch ? 1 : 0;
+      r -= second * ch;
+      ip = second ? d.in_v : d.in_u, op = second ? d.out_v : d.out_u;
+      n = cw, mode = d.w_sub ? 2 : 0;
+    }
+    if (r >= ch)
+      return;
+    y = r << d.h_sub;
+  }
+  const int s0 = 16 * lane;
+  if (s0 >= n)
+    return;
+  const uint8_t *src = pp.in[ip] + ds + (size_t) r * pp.in_stride[ip];
+  uint8_t *dst = pp.out[op] + dd + (size_t) r * pp.out_stride[op];
+  if (!TO_HI) {
+    const uint4 a = *(const uint4 *) (src + 2 * (size_t) s0), b = *(const uint4 *) (src + 2 * (size_t) s0 + 16);
+    uint4 o;
+    if (d.in_hi == 1 || d.in_hi == 4) {           /* the value in the low bits: (word >> (bits - 8)) & 0xff */
+      const int sh = hi_depth_bits (d.in_hi) - 8;
+      o.x = bperm (a.y >> sh, a.x >> sh, 0x06040200u), o.y = bperm (a.w >> sh, a.z >> sh, 0x06040200u);
+      o.z = bperm (b.y >> sh, b.x >> sh, 0x06040200u), o.w = bperm (b.w >> sh, b.z >> sh, 0x06040200u);
+    } else {
+      o.x = bperm (a.y, a.x, 0x07050301u), o.y = bperm (a.w, a.z, 0x07050301u);
+      o.z = bperm (b.y, b.x, 0x07050301u), o.w = bperm (b.w, b.z, 0x07050301u);
+    }
+    *(uint4 *) (dst + s0) = o;
+    return;
+  }
+  /* the row's sixteen dither values, as the eight pairs the lane's sample pairs meet */
+  uint32_t e[8];
+  const int sh = d.dither.on ? d.dither.shift[1] : 0;
+  if (d.dither.on && sh > 0) {
+    const uint2 lo = dither_bayer_row8 (0, y), hi = dither_bayer_row8 (8, y);
+    uint32_t eb[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      eb[i] = (eb[i] >> (8 - sh)) & ((0xffu >> (8 - sh)) * 0x01010101u);
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+      if (mode == 0)            /* sample j at column j */
+        e[p] = bperm (0u, eb[p / 2], (p & 1) ? 0x0c030c02u : 0x0c010c00u);
+      else if (mode == 1)       /* U and V of chroma position k (samples 2k, 2k + 1) at column 2k */
+        e[p] = bperm (0u, eb[p / 2], (p & 1) ? 0x0c020c02u : 0x0c000c00u);
+      else                      /* chroma sample j at column 2j (mod 16) */
+        e[p] = bperm (0u, eb[p & 3], 0x0c020c00u);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+      e[p] = 0;
+  }
+  const uint32_t keep = (0xffffu & ~((1u << sh) - 1u)) * 0x00010001u;
+  const int drop = d.out_hi == 6 ? 0 : 16 - hi_depth_bits (d.out_hi);
+  const bool low = d.out_hi == 1 || d.out_hi == 4;
+  const uint32_t keep2 = low ? 0xffffffffu : (0xffffu & ~((1u << drop) - 1u)) * 0x00010001u;
+  const uint4 w = *(const uint4 *) (src + s0);
+  const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+  uint32_t o[8];
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    const uint32_t v2 = bperm (0u, wv[p / 2], (p & 1) ? 0x03030202u : 0x01010000u);           /* byte * 257, two samples */
+    uint32_t q = pk_adds16 (v2, e[p]) & keep & keep2;
+    if (low)
+      q = (q >> drop) & ((0xffffu >> drop) * 0x00010001u);
+    o[p] = q;
+  }
+  uint4 *dq = (uint4 *) (dst + 2 * (size_t) s0);
+  dq[0] = gstamd_make_uint4 (o[0], o[1], o[2], o[3]);
+  dq[1] = gstamd_make_uint4 (o[4], o[5], o[6], o[7]);
+}
+
 }  // namespace gstamd

@@ -327,11 +327,28 @@ __global__ __launch_bounds__ (256) void k_deep_planes (DeepPlanesParams d, DeepP
   deep_planes_body (d, pp, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y, fls_, fld_);
 }
 
+// ... sixteen samples per lane where a row of samples goes in and a row comes out (video_deep.h: k_deep_planes16); one wave per workgroup: a
+// 1080p row is 120 lanes
+template <int TO_HI>
+__global__ __launch_bounds__ (64) void k_deep_planes16 (DeepPlanesParams d, DeepPlanesPtrs pp, FrameDeltas fl)
+{
+  GSTAMD_FRAME_Z;
+  deep_planes16_body<TO_HI> (d, pp, (int) (blockIdx.x * 64 + threadIdx.x), (int) blockIdx.y, fls_, fld_);
+}
+
 hipError_t launch_deep_planes (const DeepPlanesParams &d, const DeepPlanesPtrs &pp, hipStream_t stream)
 {
   const int ch = (d.height + (1 << d.h_sub) - 1) >> d.h_sub;
   int nz;
   const FrameDeltas &fl = frame_list_for (pp.in[0], pp.out[0], &nz);
+  if (pp.vec && deep_planes16_ok (d) && !tuning_on ("GSTAMD_NO_DEEP_PLANES16")) {
+    const dim3 grid16 ((d.width / 16 + 63) / 64, deep_planes16_rows (d), nz);
+    if (d.out_hi)
+      hipLaunchKernelGGL (k_deep_planes16<1>, grid16, dim3 (64), 0, stream, d, pp, fl);
+    else
+      hipLaunchKernelGGL (k_deep_planes16<0>, grid16, dim3 (64), 0, stream, d, pp, fl);
+    return hipGetLastError ();
+  }
   dim3 grid (((d.width + 7) / 8 + 255) / 256, d.height + ch, nz);
   hipLaunchKernelGGL (k_deep_planes, grid, dim3 (256), 0, stream, d, pp, fl);
   return hipGetLastError ();
@@ -972,17 +989,60 @@ __global__ __launch_bounds__ (PLN_THREADS) void k_plane_direct (PlaneJobs jobs, 
     plane_direct_body (jobs.job[0], b, (int) threadIdx.x);
 }
 
+// the planes of two short passes (video_planes.h: k_plane_quad): a workgroup = 64 lanes x 4 output rows, one row per wave
+template <int K>
+__device__ __forceinline__ void plane_quad_job (const PlaneJobs &jobs, const QuadGrid &g)
+{
+  const int local = (int) blockIdx.x - g.block0[K];
+  const int bxi = local % g.bx[K], byi = local / g.bx[K];
+  const int y = __builtin_amdgcn_readfirstlane (byi * 4 + (int) (threadIdx.x >> 6));
+  plane_quad_body (jobs.job[K], bxi * 64 + (int) (threadIdx.x & 63), y);
+}
+
+__global__ __launch_bounds__ (256) void k_plane_quad (PlaneJobs jobs, QuadGrid g, FrameDeltas fl)
+{
+  GSTAMD_FRAME_Z;
+  plane_jobs_rebase (jobs, fls_, fld_);
+  const int b = (int) blockIdx.x;
+  if (jobs.n > 2 && g.block0[2] >= 0 && b >= g.block0[2])
+    plane_quad_job<2> (jobs, g);
+  else if (jobs.n > 1 && g.block0[1] >= 0 && b >= g.block0[1])
+    plane_quad_job<1> (jobs, g);
+  else
+    plane_quad_job<0> (jobs, g);
+}
+
 // `jobs`: the frame's planes in any order; they are split by kind of body and each kind gets a launch of its own
 hipError_t launch_plane_frame (const PlaneJobs &jobs, size_t lds_bytes, hipStream_t stream)
 {
   int nz;
   const FrameDeltas &fl = frame_list_for (jobs.job[0].s.p, jobs.job[0].d.p, &nz);
+  const bool quads = !tuning_on ("GSTAMD_NO_PLANE_QUAD");
+  {
+    PlaneJobs part;
+    QuadGrid g;
+    memset ((void *) &part, 0, sizeof (part));
+    int blocks = 0;
+    for (int i = 0; i < jobs.n; i++) {
+      if (!quads || !jobs.job[i].quad)
+        continue;
+      const PlaneJob &J = jobs.job[i];
+      g.block0[part.n] = blocks;
+      g.bx[part.n] = ((J.ow * J.s.n + 3) / 4 + 63) / 64;
+      blocks += g.bx[part.n] * ((J.oh + 3) / 4);
+      part.job[part.n++] = J;
+    }
+    for (int i = part.n; i < PLN_MAX_JOBS; i++)
+      g.block0[i] = -1, g.bx[i] = 1;
+    if (part.n)
+      hipLaunchKernelGGL (k_plane_quad, dim3 (blocks, 1, nz), dim3 (256), 0, stream, part, g, fl);
+  }
   for (int direct = 0; direct < 2; direct++) {
     PlaneJobs part;
     memset ((void *) &part, 0, sizeof (part));
     int tiles = 0;
     for (int i = 0; i < jobs.n; i++) {
-      if (plane_job_is_direct (jobs.job[i]) != (direct == 1))
+      if ((quads && jobs.job[i].quad) || plane_job_is_direct (jobs.job[i]) != (direct == 1))
         continue;
       PlaneJob &J = part.job[part.n++];
       J = jobs.job[i];

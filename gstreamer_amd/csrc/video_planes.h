@@ -124,6 +124,7 @@ struct PlaneJob {
   int tile0, tiles_x;   // first tile of the plane in the launch's grid, tiles per tile row
   int wide;             // destination rows and the tile's 4-pixel groups sit on whole words: 4 outputs per store
   int wide_src;         // source rows on 8 bytes: the pass-free kinds read 4 / 8 source bytes per lane (plane_simple4)
+  int quad;             // plane_quad_ok and destination rows on whole words - or a pass-free one-byte plane with wide and wide_src: k_plane_quad
 };
 
 struct PlaneJobs {
@@ -400,6 +401,206 @@ GSTAMD_HD void plane_direct_body (const PlaneJob &J, int tile, int tid)
       px[i] = J.h_first ? hscale_px (row, J.pass[0], x + i) : vscale_px (J.s, J.pass[0], x + i, y);
   }
   plane_put4 (J, x, y, x1, px);
+}
+
+// ---- k_plane_quad: two short passes, four output bytes per lane from two 8-byte loads --------------------------------------------------
+// plane_direct_body asks memory for every source byte on its own (4 outputs x 4 source pixels = 16 byte loads per lane, plus the table
+// rows): at 4K -> 1080p the kernel issues ~20 load instructions per wave and the chip's vector-memory issue rate (one wave instruction
+// per ~37 clocks and CU, profiles/r04) bounds it at 6.5 us per NV12 frame against 1.9 us of traffic.  When both passes read at most two
+// source pixels per output and four consecutive output BYTES of a row (four pixels of a one-byte plane, two of a two-byte one) depend
+// on at most 8 source bytes per row - any ratio up to 2:1 shrinking, every enlargement - a lane loads those 8 bytes of its two source
+// rows with one (unaligned) load each, picks an output's two taps with v_perm_b32 into the halves of a register, and a pass is a
+// v_dot2 on it: H = (a * w0 + b * w1 + rnd) >> shift with (256 - f, f, 0, 8) for the 2-tap function (ldreslinl), (256, 0, 0, 8) for
+// nearest, (t0, t1, 32, 6) and a clamp for a two-tap N-tap filter; V likewise (the 2-tap V keeps its own rounding: v2tap_px).  The
+// passes run in the plan's order with the first one's result as the byte the reference keeps in its temporary line.  A wave works on
+// one output row (the vertical pass's table row is wave-uniform: scalar loads); lanes whose four bytes cross the row's end take
+// plane_direct_body's per-pixel route.
+struct QuadGrid {
+  int block0[PLN_MAX_JOBS];      // first workgroup of each job (jobs in PlaneJobs order), -1: the job is not in this launch
+  int bx[PLN_MAX_JOBS];          // workgroups per row of workgroups (64 lanes x 4 rows each)
+};
+
+// host: may the plane go this way?  (table contents: spans of four output bytes, tap magnitudes)
+inline bool plane_quad_ok (const PlanePlan &pp)
+{
+  if (pp.kind != PLANE_SCALE || pp.passes.size () != 2 || (pp.n_elems != 1 && pp.n_elems != 2) || pp.iw * pp.n_elems < 8 || pp.ih < 1)
+    return false;
+  const ScalePass *ph = pp.passes[0].horizontal ? &pp.passes[0] : &pp.passes[1], *pv = pp.passes[0].horizontal ? &pp.passes[1] : &pp.passes[0];
+  if (!ph->horizontal || pv->horizontal)
+    return false;
+  for (const ScalePass *q : {ph, pv}) {
+    if (q->merged != 0)
+      return false;
+    if (q->kind == SCALE_NTAP) {
+      if (q->n_taps != 2)
+        return false;
+      for (size_t i = 0; i + 1 < q->taps.size (); i += 2)
+        if (abs ((int) q->taps[i]) + abs ((int) q->taps[i + 1]) > 128)          /* no 16-bit wrap in a * t0 + b * t1 + 32 */
+          return false;
+    } else if (q->kind != SCALE_NEAREST && q->kind != SCALE_2TAP) {
+      return false;
+    }
+  }
+  /* the source pixels of every group of 4 / n_elems consecutive outputs: first tap of the first .. second tap of the last, within 8 bytes */
+  const int per = 4 / pp.n_elems;
+  for (int x = 0; x + per <= pp.ow; x += per) {
+    int lo, hi;
+    if (ph->kind == SCALE_2TAP) {
+      lo = (x * ph->inc) >> 16, hi = (((x + per - 1) * ph->inc) >> 16) + 1;
+    } else {
+      lo = (int) ph->offset[x], hi = (int) ph->offset[x + per - 1] + 1;
+      for (int k = 1; k < per; k++)
+        if ((int) ph->offset[x + k] < lo)
+          return false;
+    }
+    if ((hi - lo + 1) * pp.n_elems > 8)
+      return false;
+  }
+  return true;
+}
+
+GSTAMD_HD int quad_dot2 (uint32_t pair, uint32_t w, int acc)     // lo(pair) * lo(w) + hi(pair) * hi(w) + acc, 16-bit signed halves
+{
+#ifdef __HIPCC__
+  typedef short s2 __attribute__ ((ext_vector_type (2)));
+  return __builtin_amdgcn_sdot2 (__builtin_bit_cast (s2, pair), __builtin_bit_cast (s2, w), acc, false);
+#else
+  return (int) (int16_t) (pair & 0xffffu) * (int) (int16_t) (w & 0xffffu) + (int) (int16_t) (pair >> 16) * (int) (int16_t) (w >> 16) + acc;
+#endif
+}
+
+GSTAMD_HD int quad_clamp255 (int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// (s1 * t0 + s2 * t1 + 32) >> 6, clamped, per 16-bit half (taps splat over both halves)
+GSTAMD_HD uint32_t quad_vntap_pk (uint32_t s1, uint32_t s2, uint32_t t0s, uint32_t t1s)
+{
+#ifdef __HIPCC__
+  typedef short s2v __attribute__ ((ext_vector_type (2)));
+  s2v m = __builtin_bit_cast (s2v, pk_mad16 (s1, t0s, pk_mad16 (s2, t1s, 0x00200020u)));
+  m = m >> (short) 6;
+  m = __builtin_elementwise_min (__builtin_elementwise_max (m, (s2v) (short) 0), (s2v) (short) 255);
+  return __builtin_bit_cast (uint32_t, m);
+#else
+  uint32_t r = 0;
+  for (int h = 0; h < 2; h++) {
+    const int a = (int) ((s1 >> (16 * h)) & 0xffffu), b = (int) ((s2 >> (16 * h)) & 0xffffu);
+    const int acc = (int) (int16_t) (uint16_t) (a * (int) (int16_t) (t0s & 0xffffu) + b * (int) (int16_t) (t1s & 0xffffu) + 32);
+    r |= (uint32_t) quad_clamp255 (acc >> 6) << (16 * h);
+  }
+  return r;
+#endif
+}
+
+// 8 bytes from byte `off` of a plane row (the lane's window of source bytes), any alignment
+GSTAMD_HD uint2 quad_load8 (const uint8_t *row, int off)
+{
+#ifdef __HIPCC__
+  typedef unsigned long long __attribute__ ((aligned (1))) u64_u;
+  const unsigned long long v = *(const u64_u *) (row + off);
+  uint2 r;
+  r.x = (uint32_t) v, r.y = (uint32_t) (v >> 32);
+  return r;
+#else
+  uint2 r;
+  memcpy (&r, row + off, 8);
+  return r;
+#endif
+}
+
+// `lane`: output bytes 4 * lane .. 4 * lane + 3 of output row y
+GSTAMD_HD void plane_quad_body (const PlaneJob &J, int lane, int y)
+{
+  const int n = J.s.n, per = 4 / n;
+  const int x = lane * per;
+  if (y >= J.oh || x >= J.ow)
+    return;
+  if (J.kind != PLANE_SCALE) {          /* a pass-free plane of the same frame (the 2:1 luma next to a scaled UV plane): plane_direct_body's route */
+    if (x + 4 <= J.ow && plane_simple4 (J, x, y))
+      return;
+    for (int i = 0; i < 4 && x + i < J.ow; i++)
+      plane_simple_body (J.kind, J.s, J.d, J.ow, J.oh, x + i, y);
+    return;
+  }
+  const ScaleDev &sh = J.pass[J.h_first ? 0 : 1], &sv = J.pass[J.h_first ? 1 : 0];
+  if (x + per > J.ow) {                 /* the row's last, partial group: pixel by pixel (plane_direct_body's arithmetic) */
+    for (int i = 0; x + i < J.ow; i++) {
+      uint32_t px;
+      if (plane_small_kind (sh.kind) && plane_small_kind (sv.kind)) {
+        px = plane_scale2x2_pk (J.s, sh, sv, J.h_first, x + i, y);
+      } else if (J.h_first) {
+        const PlaneHRows rows = {J.s, &sh};
+        px = vscale_px (rows, sv, x + i, y);
+      } else {
+        const PlaneVRow row = {J.s, &sv, y};
+        px = hscale_px (row, sh, x + i);
+      }
+      J.d.put (x + i, y, px);
+    }
+    return;
+  }
+  /* horizontal: source index and weight pair of the lane's outputs */
+  int idx[4];
+  uint32_t w[4];
+  const bool h_ntap = sh.kind == SCALE_NTAP;
+  if (sh.kind == SCALE_2TAP) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int tmp = (x + (k < per ? k : 0)) * sh.inc;
+      idx[k] = tmp >> 16;
+      w[k] = ((uint32_t) (tmp >> 8) & 0xffu) * 0xffffu + 256u;           /* (256 - f) | f << 16 */
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int xk = x + (k < per ? k : 0);
+      idx[k] = (int) sh.offset[xk];
+      w[k] = h_ntap ? ((const uint32_t *) sh.taps)[xk] : 256u;           /* the output's two taps as they lie in the table / nearest: a * 256 >> 8 */
+    }
+  }
+  const int h_rnd = h_ntap ? 32 : 0, h_shift = h_ntap ? 6 : 8;
+  /* vertical: the two source rows and their weights */
+  const int ya = (int) sv.offset[y], yb = sv.kind == SCALE_NEAREST ? ya : (ya + 1 < J.ih ? ya + 1 : J.ih - 1);
+  const int vt0 = sv.kind == SCALE_NTAP ? (int) sv.taps[(size_t) y * 2] : 0, vt1 = sv.kind == SCALE_NEAREST ? 0 : (int) sv.taps[(size_t) y * 2 + 1];
+  /* the window: 8 bytes from the first output's first tap; pulled back where it would leave the plane's last row */
+  const int row_bytes = J.iw * n;
+  int off = idx[0] * n, back = 0;
+  if (off + 8 > row_bytes)
+    back = off + 8 - row_bytes, off = row_bytes - 8;
+  const uint2 ra = quad_load8 (J.s.p + (size_t) ya * J.s.stride, off);
+  const uint2 rb = sv.kind == SCALE_NEAREST ? ra : quad_load8 (J.s.p + (size_t) yb * J.s.stride, off);
+  uint32_t o[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {         /* output byte c: pixel c (n == 1) or component c & 1 of pixel c >> 1 (n == 2) */
+    const int k = n == 1 ? c : c >> 1;
+    const int d = (idx[k] - idx[0]) * n + (n == 2 ? (c & 1) : 0) + back;
+    const uint32_t sel = (n == 1 ? 0x0c010c00u : 0x0c020c00u) + (uint32_t) d * 0x00010001u;
+    const uint32_t pa = bperm (ra.y, ra.x, sel), pb = bperm (rb.y, rb.x, sel);             /* tap a | tap b << 16, rows ya and yb */
+    int r;
+    if (J.h_first) {
+      int ha = (quad_dot2 (pa, w[k], h_rnd)) >> h_shift, hb = (quad_dot2 (pb, w[k], h_rnd)) >> h_shift;
+      if (h_ntap)
+        ha = quad_clamp255 (ha), hb = quad_clamp255 (hb);
+      if (sv.kind == SCALE_NEAREST)
+        r = ha;
+      else if (sv.kind == SCALE_2TAP)
+        r = (((((hb - ha) * vt1 + 128) >> 8) & 0xff) + ha) & 0xff;                        /* v2tap_px */
+      else
+        r = quad_clamp255 ((int) (int16_t) (uint16_t) (ha * vt0 + hb * vt1 + 32) >> 6);
+    } else {
+      uint32_t v;
+      if (sv.kind == SCALE_NEAREST)
+        v = pa;
+      else if (sv.kind == SCALE_2TAP)
+        v = v2tap_pk (pa, pb, (uint32_t) (uint16_t) vt1 * 0x00010001u);
+      else
+        v = quad_vntap_pk (pa, pb, (uint32_t) (uint16_t) vt0 * 0x00010001u, (uint32_t) (uint16_t) vt1 * 0x00010001u);
+      r = quad_dot2 (v, w[k], h_rnd) >> h_shift;
+      if (h_ntap)
+        r = quad_clamp255 (r);
+    }
+    o[c] = (uint32_t) r;
+  }
+  *(uint32_t *) (J.d.p + (size_t) y * J.d.stride + 4 * (size_t) lane) = (o[0] | (o[1] << 8)) | ((o[2] | (o[3] << 8)) << 16);
 }
 
 // does the plane go through plane_direct_body (host and device)

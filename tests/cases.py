@@ -614,6 +614,40 @@ VIDEO_CASES = [
     ("planes_i420_10_p010_720p", "I420_10LE", 1280, 720, "P010_10LE", 1280, 720, {}, None, None, "random"),
     ("planes_p010_yv12_odd", "P010_10LE", 643, 361, "YV12", 643, 361, {}, None, None, "random"),
     ("planes_nv12_p010_4k", "NV12", 3840, 2160, "P010_10LE", 3840, 2160, {}, None, None, "random"),
+    # k_plane_quad: both passes of a plane read at most two source pixels per output and four output bytes depend on at most 8 source bytes
+    ("quad_i420_4_3_down_bilinear", "I420", 640, 480, "I420", 480, 360, LIN, None, None, "random"),
+    ("quad_i420_3_2_down_bilinear", "I420", 640, 480, "I420", 426, 320, LIN, None, None, "random"),
+    ("quad_nv12_odd_half_bilinear", "NV12", 322, 242, "NV12", 161, 121, LIN, None, None, "random"),
+    ("quad_nv12_up_bilinear", "NV12", 320, 240, "NV12", 480, 400, LIN, None, None, "random"),
+    ("quad_nv21_up_3x_bilinear", "NV21", 160, 90, "NV21", 480, 270, LIN, None, None, "random"),
+    ("quad_i420_too_steep_bilinear", "I420", 640, 480, "I420", 200, 150, LIN, None, None, "random"),
+    ("quad_gray8_odd_bilinear", "GRAY8", 333, 111, "GRAY8", 200, 77, LIN, None, None, "random"),
+    ("quad_nv12_nearest_down", "NV12", 640, 480, "NV12", 400, 300, dict(resampler_method="nearest"), None, None, "random"),
+    ("quad_i420_nearest_up", "I420", 200, 120, "I420", 333, 201, dict(resampler_method="nearest"), None, None, "random"),
+    ("quad_y444_mixed_bilinear", "Y444", 100, 100, "Y444", 150, 50, LIN, None, None, "random"),
+    ("quad_y42b_mixed_bilinear", "Y42B", 200, 60, "Y42B", 120, 90, LIN, None, None, "random"),
+    ("quad_nv16_down_bilinear_ones", "NV16", 320, 240, "NV16", 240, 180, LIN, None, None, "ones"),
+    ("quad_nv12_crop_dest_bilinear", "NV12", 640, 480, "NV12", 480, 360, dict(LIN, src_x=32, src_y=16, src_width=400, src_height=300, dest_x=20, dest_y=10, dest_width=300, dest_height=226), None, None, "random"),
+    ("quad_nv12_1080p_to_720p", "NV12", 1920, 1080, "NV12", 1280, 720, LIN, None, None, "random"),
+    ("quad_i420_720p_to_1080p", "I420", 1280, 720, "I420", 1920, 1080, LIN, None, None, "random"),
+    ("quad_nv12_4k_to_1080p", "NV12", 3840, 2160, "NV12", 1920, 1080, LIN, None, None, "random"),
+    # k_deep_planes16: the same plane layout on both sides, one side deep, rows a multiple of 16 samples - sixteen samples per lane
+    ("planes16_i420_i420_10", "I420", 640, 360, "I420_10LE", 640, 360, {}, None, None, "random"),
+    ("planes16_i420_10_i420", "I420_10LE", 640, 360, "I420", 640, 360, {}, None, None, "random"),
+    ("planes16_i420_12_yv12", "I420_12LE", 320, 240, "YV12", 320, 240, {}, None, None, "random"),
+    ("planes16_yv12_i420_12", "YV12", 320, 240, "I420_12LE", 320, 240, {}, None, None, "random"),
+    ("planes16_nv12_p012", "NV12", 320, 240, "P012_LE", 320, 240, {}, None, None, "random"),
+    ("planes16_p012_nv12", "P012_LE", 320, 240, "NV12", 320, 240, {}, None, None, "random"),
+    ("planes16_nv12_p016", "NV12", 320, 240, "P016_LE", 320, 240, {}, None, None, "random"),
+    ("planes16_p016_nv12", "P016_LE", 320, 240, "NV12", 320, 240, {}, None, None, "random"),
+    ("planes16_y444_y444_10", "Y444", 320, 240, "Y444_10LE", 320, 240, {}, None, None, "random"),
+    ("planes16_y444_12_y444", "Y444_12LE", 320, 240, "Y444", 320, 240, {}, None, None, "random"),
+    ("planes16_y444_y444_16", "Y444", 320, 240, "Y444_16LE", 320, 240, {}, None, None, "random"),
+    ("planes16_y42b_i422_10", "Y42B", 320, 240, "I422_10LE", 320, 240, {}, None, None, "random"),
+    ("planes16_i422_12_y42b", "I422_12LE", 320, 240, "Y42B", 320, 240, {}, None, None, "random"),
+    ("planes16_nv12_p010_ones", "NV12", 320, 240, "P010_10LE", 320, 240, {}, None, None, "ones"),
+    ("planes16_nv12_p010_nodither", "NV12", 320, 240, "P010_10LE", 320, 240, dict(dither_method="none"), None, None, "random"),
+    ("planes16_nv12_p010_row_not_16", "NV12", 328, 240, "P010_10LE", 328, 240, {}, None, None, "random"),
     # packed 4:2:2 scaled in its own format: the merged luma / chroma scaler over the line's bytes (gst_video_scaler_combine_packed_YUV)
     ("yuy2_yuy2_half_bilinear_merged", "YUY2", 640, 480, "YUY2", 320, 240, LIN, None, None, "random"),
     ("yuy2_yuy2_half_cubic_merged", "YUY2", 640, 480, "YUY2", 320, 240, {}, None, None, "random"),

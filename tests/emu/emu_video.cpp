@@ -241,6 +241,10 @@ static void run_h420_reg_ch (const H420RegParams &p, int chroma_h, int n_taps)
 // workgroup from the bottom one up (a wave's hand-over copy exists before the wave above asks for it - on the device a flag says so) ----
 static int g_col_runs = 0;
 extern "C" int emu_col_runs (void) { return g_col_runs; }
+static int g_emu_deep16_runs = 0;
+static int g_emu_quad_runs = 0;
+extern "C" int emu_quad_runs (void) { return g_emu_quad_runs; }
+extern "C" int emu_deep16_runs (void) { return g_emu_deep16_runs; }
 
 template <int OPL, int NW, int NGV>
 struct ColExecEmu {
@@ -802,6 +806,17 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       pp.vec = vec_ok ? 1 : 0;
       for (int i = 0; i < 3; i++)
         pp.vec = pp.vec && ((uintptr_t) pp.in[i] % 16) == 0 && (pp.in_stride[i] % 16) == 0 && ((uintptr_t) pp.out[i] % 16) == 0 && (pp.out_stride[i] % 16) == 0;
+      if (pp.vec && deep_planes16_ok (g.planes) && getenv ("GSTAMD_NO_DEEP_PLANES16") == nullptr) {   /* k_deep_planes16 over its grid */
+        g_emu_deep16_runs++;
+        for (int row = 0; row < deep_planes16_rows (g.planes); row++)
+          for (int lx = 0; lx < (g.planes.width / 16 + 63) / 64 * 64; lx++) {
+            if (g.planes.out_hi)
+              deep_planes16_body<1> (g.planes, pp, lx, row);
+            else
+              deep_planes16_body<0> (g.planes, pp, lx, row);
+          }
+        return GSTAMD_OK;
+      }
       const int chh = (g.planes.height + (1 << g.planes.h_sub) - 1) >> g.planes.h_sub;
       for (int row = 0; row < g.planes.height + chh; row++)
         for (int lx = 0; lx < ((g.planes.width + 7) / 8 + 255) / 256 * 256; lx++)
@@ -1027,6 +1042,16 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       J.wide = pp.n_elems <= 2 && ((uintptr_t) J.d.p % unit) == 0 && (J.d.stride % unit) == 0;
       J.wide_src = ((uintptr_t) J.s.p % 8) == 0 && (J.s.stride % 8) == 0;
       J.tiles_x = (pp.ow + PLN_TW - 1) / PLN_TW;
+      J.quad = ((plane_quad_ok (pp) && ((uintptr_t) J.d.p % 4) == 0 && (J.d.stride % 4) == 0) || (pp.kind != PLANE_SCALE && pp.n_elems == 1 && J.wide && J.wide_src)) &&
+          getenv ("GSTAMD_NO_PLANE_QUAD") == nullptr;
+      if (J.quad) {                           /* k_plane_quad over its grid */
+        g_emu_quad_runs++;
+        const int lanes = (((J.ow * J.s.n + 3) / 4 + 63) / 64) * 64;
+        for (int y = 0; y < (J.oh + 3) / 4 * 4; y++)
+          for (int lane = 0; lane < lanes; lane++)
+            plane_quad_body (J, lane, y);
+        continue;
+      }
       const int tiles = J.tiles_x * ((pp.oh + PLN_TH - 1) / PLN_TH);
       for (int t = 0; t < tiles; t++) {
         if (plane_job_is_direct (J)) {        /* k_plane_direct */

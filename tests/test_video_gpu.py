@@ -211,9 +211,9 @@ def test_hip_scale_col_frame_list_is_one_grid(native_lib, gpu, ref):
 
 
 LIST_PLANS = [      # (id, in, w, h, out, ow, oh, config, list launches expected per chunk: 0 = the plan goes frame by frame)
-    ("plane_direct", "NV12", 1920, 1080, "NV12", 960, 540, cases.LIN, 1),
-    ("plane_tiles", "I420", 1280, 720, "I420", 640, 360, cases.LAN, 1),
-    ("plane_y444", "Y444", 640, 480, "Y444", 800, 600, cases.LIN, 1),
+    ("plane_direct", "NV12", 1920, 1080, "NV12", 1280, 720, cases.LIN, 1),            # (a 540-line output would be bt601: a matrix, not the plane scaler)
+    ("plane_tiles", "I420", 1920, 1080, "I420", 1280, 720, cases.LAN, 1),
+    ("plane_quad", "I420", 640, 480, "I420", 480, 360, cases.LIN, 1),
     ("pack_422", "YUY2", 1920, 1080, "I420", 1920, 1080, {}, 1),
     ("pack_422_nv12", "UYVY", 1280, 720, "NV12", 1280, 720, {}, 1),
     ("convert_pack", "BGRA", 1280, 720, "I420", 1280, 720, {}, 1),

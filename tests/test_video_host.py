@@ -448,3 +448,40 @@ def test_reference_output_depends_on_thread_slicing_for_420(ref):
         rc = ref.VideoConverter("ARGB", 640, 800, "AYUV", 640, 800, config=ref.config_string(GstVideoConverter__threads=t))
         outs.append(rc.frame(src))
     assert (outs[0] == outs[1]).all()
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("planes16_")])
+def test_deep_planes16_body_is_the_one_that_runs(native_lib, emu_lib, name, monkeypatch):
+    """the planes16_* cases go through deep_planes16_body (sixteen samples per lane) - all but the one whose rows are no multiple of 16
+    samples - and through deep_planes_body with GSTAMD_NO_DEEP_PLANES16, with the reference's bytes either way"""
+    _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    emu_lib.emu_deep16_runs.restype = C.c_int
+    before = emu_lib.emu_deep16_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_deep16_runs() - before == (0 if name.endswith("row_not_16") else 1)
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+    monkeypatch.setenv("GSTAMD_NO_DEEP_PLANES16", "1")
+    before = emu_lib.emu_deep16_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_deep16_runs() == before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("quad_") and c[2] * c[3] <= 1280 * 720])
+def test_plane_quad_body_is_the_one_that_runs(native_lib, emu_lib, name, monkeypatch):
+    """the quad_* cases go through plane_quad_body (four output bytes per lane from two 8-byte windows) - all but the one that shrinks by
+    more than 2:1 - and through the per-pixel bodies with GSTAMD_NO_PLANE_QUAD, with the reference's bytes either way"""
+    _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    emu_lib.emu_quad_runs.restype = C.c_int
+    before = emu_lib.emu_quad_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    ran = emu_lib.emu_quad_runs() - before
+    assert (ran == 0) == ("too_steep" in name), ran
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+    monkeypatch.setenv("GSTAMD_NO_PLANE_QUAD", "1")
+    before = emu_lib.emu_quad_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_quad_runs() == before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]

@@ -4,6 +4,7 @@
 // every source byte is read once (chroma rows are shared through L2) and every destination
 // byte written once with 16-byte stores per lane.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <stdint.h>
@@ -989,14 +990,15 @@ __global__ __launch_bounds__ (PLN_THREADS) void k_plane_direct (PlaneJobs jobs, 
     plane_direct_body (jobs.job[0], b, (int) threadIdx.x);
 }
 
-// the planes of two short passes (video_planes.h: k_plane_quad): a workgroup = 64 lanes x 4 output rows, one row per wave
+// the planes of two short passes and the pass-free ones next to them (video_planes.h: k_plane_quad): a workgroup = 64 lanes x 4 waves, a wave
+// walks g.rows output rows
 template <int K>
 __device__ __forceinline__ void plane_quad_job (const PlaneJobs &jobs, const QuadGrid &g)
 {
   const int local = (int) blockIdx.x - g.block0[K];
   const int bxi = local % g.bx[K], byi = local / g.bx[K];
-  const int y = __builtin_amdgcn_readfirstlane (byi * 4 + (int) (threadIdx.x >> 6));
-  plane_quad_body (jobs.job[K], bxi * 64 + (int) (threadIdx.x & 63), y);
+  const int y0 = __builtin_amdgcn_readfirstlane ((byi * 4 + (int) (threadIdx.x >> 6)) * g.rows);
+  plane_rows_body (jobs.job[K], g.mode[K], bxi * 64 + (int) (threadIdx.x & 63), y0, g.rows);
 }
 
 __global__ __launch_bounds__ (256) void k_plane_quad (PlaneJobs jobs, QuadGrid g, FrameDeltas fl)
@@ -1022,18 +1024,28 @@ hipError_t launch_plane_frame (const PlaneJobs &jobs, size_t lds_bytes, hipStrea
     PlaneJobs part;
     QuadGrid g;
     memset ((void *) &part, 0, sizeof (part));
-    int blocks = 0;
+    long long wave_rows = 0;
     for (int i = 0; i < jobs.n; i++) {
       if (!quads || !jobs.job[i].quad)
         continue;
       const PlaneJob &J = jobs.job[i];
-      g.block0[part.n] = blocks;
-      g.bx[part.n] = ((J.ow * J.s.n + 3) / 4 + 63) / 64;
-      blocks += g.bx[part.n] * ((J.oh + 3) / 4);
+      g.mode[part.n] = J.quad - 1;
+      const int bytes = 4 << g.mode[part.n];
+      g.bx[part.n] = ((J.ow * J.s.n + bytes - 1) / bytes + 63) / 64;
+      wave_rows += (long long) g.bx[part.n] * J.oh;
       part.job[part.n++] = J;
     }
+    /* rows per wave: what is set up per column serves more rows the longer a wave walks, but the launch should still hold some eight
+       waves per SIMD (1024 of them): a single 4K -> 1080p NV12 frame is 4300 wave-rows, a list of eight 35000 */
+    const int rows_pin = tuning_int ("GSTAMD_PLANE_QUAD_ROWS", 0);
+    g.rows = rows_pin > 0 ? rows_pin : (int) std::min<long long> (8, std::max<long long> (1, wave_rows * nz / 8192));
+    int blocks = 0;
+    for (int k = 0; k < part.n; k++) {
+      g.block0[k] = blocks;
+      blocks += g.bx[k] * ((part.job[k].oh + 4 * g.rows - 1) / (4 * g.rows));
+    }
     for (int i = part.n; i < PLN_MAX_JOBS; i++)
-      g.block0[i] = -1, g.bx[i] = 1;
+      g.block0[i] = -1, g.bx[i] = 1, g.mode[i] = 0;
     if (part.n)
       hipLaunchKernelGGL (k_plane_quad, dim3 (blocks, 1, nz), dim3 (256), 0, stream, part, g, fl);
   }

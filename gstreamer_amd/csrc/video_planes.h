@@ -124,7 +124,8 @@ struct PlaneJob {
   int tile0, tiles_x;   // first tile of the plane in the launch's grid, tiles per tile row
   int wide;             // destination rows and the tile's 4-pixel groups sit on whole words: 4 outputs per store
   int wide_src;         // source rows on 8 bytes: the pass-free kinds read 4 / 8 source bytes per lane (plane_simple4)
-  int quad;             // plane_quad_ok and destination rows on whole words - or a pass-free one-byte plane with wide and wide_src: k_plane_quad
+  int quad;             // 0: not for k_plane_quad; 1 + QUAD_4 / QUAD_8 / QUAD_16: how (plane_quad_ok / plane_oct_ok / a pass-free one-byte plane, and the
+                        // destination rows on 4 / 8 / 16 bytes)
 };
 
 struct PlaneJobs {
@@ -417,7 +418,9 @@ GSTAMD_HD void plane_direct_body (const PlaneJob &J, int tile, int tid)
 // plane_direct_body's per-pixel route.
 struct QuadGrid {
   int block0[PLN_MAX_JOBS];      // first workgroup of each job (jobs in PlaneJobs order), -1: the job is not in this launch
-  int bx[PLN_MAX_JOBS];          // workgroups per row of workgroups (64 lanes x 4 rows each)
+  int bx[PLN_MAX_JOBS];          // workgroups per row of workgroups (64 lanes x 4 waves each)
+  int mode[PLN_MAX_JOBS];        // QUAD_4 / QUAD_8 / QUAD_16: output bytes per lane and row
+  int rows;                      // rows a wave walks
 };
 
 // host: may the plane go this way?  (table contents: spans of four output bytes, tap magnitudes)
@@ -601,6 +604,225 @@ GSTAMD_HD void plane_quad_body (const PlaneJob &J, int lane, int y)
     o[c] = (uint32_t) r;
   }
   *(uint32_t *) (J.d.p + (size_t) y * J.d.stride + 4 * (size_t) lane) = (o[0] | (o[1] << 8)) | ((o[2] | (o[3] << 8)) << 16);
+}
+
+// ---- the same with eight output bytes per lane and a lane that walks several rows -----------------------------------------------------
+// k_plane_quad's loads are 8 bytes, its stores 4: three memory instructions per four output bytes (five with the table rows of an N-tap
+// pass), and the vector-memory issue rate still bounds a 4K -> 1080p NV12 frame at ~6 us.  plane_oct_body gives a lane eight output bytes
+// of a row from a 16-byte window of each source row, and `rows` consecutive rows: what depends on the column only - source indices,
+// weight pairs, and the two v_perm selectors that pull an output's taps out of the window's low and high halves (a | b << 16 = perm
+// (w1, w0, selA) | perm (w3, w2, selB): selector 0x0c yields zero for the half a byte is not in) - is set up once per lane.
+// plane_simple16 is the pass-free kinds' form of the same idea: 16 output bytes per lane.
+inline bool plane_oct_ok (const PlanePlan &pp)
+{
+  if (!plane_quad_ok (pp) || pp.iw * pp.n_elems < 16)
+    return false;
+  const ScalePass *ph = pp.passes[0].horizontal ? &pp.passes[0] : &pp.passes[1];
+  const int per = 8 / pp.n_elems;
+  for (int x = 0; x + per <= pp.ow; x += per) {
+    int lo, hi;
+    if (ph->kind == SCALE_2TAP) {
+      lo = (x * ph->inc) >> 16, hi = (((x + per - 1) * ph->inc) >> 16) + 1;
+    } else {
+      lo = (int) ph->offset[x], hi = (int) ph->offset[x + per - 1] + 1;
+      for (int k = 1; k < per; k++)
+        if ((int) ph->offset[x + k] < lo)
+          return false;
+    }
+    if ((hi - lo + 1) * pp.n_elems > 16)
+      return false;
+  }
+  return true;
+}
+
+GSTAMD_HD uint4 oct_load16 (const uint8_t *row, int off)
+{
+#ifdef __HIPCC__
+  typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4), aligned (1)));
+  const u32x4 v = *(const u32x4 *) (row + off);
+  return gstamd_make_uint4 (v.x, v.y, v.z, v.w);
+#else
+  uint4 r;
+  memcpy (&r, row + off, 16);
+  return r;
+#endif
+}
+
+// selector for one half of the window (bytes base .. base + 7): tap a (window byte da) into byte 0, tap b (db) into byte 2, zero elsewhere
+GSTAMD_HD uint32_t oct_sel (int da, int db, int base)
+{
+  const uint32_t a = da >= base && da < base + 8 ? (uint32_t) (da - base) : 0x0cu;
+  const uint32_t b = db >= base && db < base + 8 ? (uint32_t) (db - base) : 0x0cu;
+  return 0x0c000c00u | a | (b << 16);
+}
+
+// N = bytes per pixel (1, 2).  lane: output bytes 8 * lane .. + 7 of rows y0 .. y0 + rows - 1
+template <int N>
+GSTAMD_HD void plane_oct_body (const PlaneJob &J, int lane, int y0, int rows)
+{
+  const int PER = 8 / N;
+  const int x = lane * PER;
+  if (x >= J.ow)
+    return;
+  if (x + PER > J.ow) {                 /* the rows' last, partial group */
+    for (int r = 0; r < rows && y0 + r < J.oh; r++) {
+      plane_quad_body (J, 2 * lane, y0 + r);
+      plane_quad_body (J, 2 * lane + 1, y0 + r);
+    }
+    return;
+  }
+  const ScaleDev &sh = J.pass[J.h_first ? 0 : 1], &sv = J.pass[J.h_first ? 1 : 0];
+  int idx[PER];
+  uint32_t w[PER];
+  const bool h_ntap = sh.kind == SCALE_NTAP;
+  if (sh.kind == SCALE_2TAP) {
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const int tmp = (x + k) * sh.inc;
+      idx[k] = tmp >> 16;
+      w[k] = ((uint32_t) (tmp >> 8) & 0xffu) * 0xffffu + 256u;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      idx[k] = (int) sh.offset[x + k];
+      w[k] = h_ntap ? ((const uint32_t *) sh.taps)[x + k] : 256u;
+    }
+  }
+  const int h_rnd = h_ntap ? 32 : 0, h_shift = h_ntap ? 6 : 8;
+  const int row_bytes = J.iw * N;
+  int off = idx[0] * N, back = 0;
+  if (off + 16 > row_bytes)
+    back = off + 16 - row_bytes, off = row_bytes - 16;
+  uint32_t sel_a[8], sel_b[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const int d = (idx[c / N] - idx[0]) * N + (c % N) + back;
+    sel_a[c] = oct_sel (d, d + N, 0);
+    sel_b[c] = oct_sel (d, d + N, 8);
+  }
+  for (int r = 0; r < rows; r++) {
+    const int y = y0 + r;
+    if (y >= J.oh)
+      break;
+    const int ya = (int) sv.offset[y], yb = sv.kind == SCALE_NEAREST ? ya : (ya + 1 < J.ih ? ya + 1 : J.ih - 1);
+    const int vt0 = sv.kind == SCALE_NTAP ? (int) sv.taps[(size_t) y * 2] : 0, vt1 = sv.kind == SCALE_NEAREST ? 0 : (int) sv.taps[(size_t) y * 2 + 1];
+    const uint4 ra = oct_load16 (J.s.p + (size_t) ya * J.s.stride, off);
+    const uint4 rb = sv.kind == SCALE_NEAREST ? ra : oct_load16 (J.s.p + (size_t) yb * J.s.stride, off);
+    uint32_t o[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int k = c / N;
+      const uint32_t pa = bperm (ra.y, ra.x, sel_a[c]) | bperm (ra.w, ra.z, sel_b[c]);
+      const uint32_t pb = bperm (rb.y, rb.x, sel_a[c]) | bperm (rb.w, rb.z, sel_b[c]);
+      int q;
+      if (J.h_first) {
+        int ha = (quad_dot2 (pa, w[k], h_rnd)) >> h_shift, hb = (quad_dot2 (pb, w[k], h_rnd)) >> h_shift;
+        if (h_ntap)
+          ha = quad_clamp255 (ha), hb = quad_clamp255 (hb);
+        if (sv.kind == SCALE_NEAREST)
+          q = ha;
+        else if (sv.kind == SCALE_2TAP)
+          q = (((((hb - ha) * vt1 + 128) >> 8) & 0xff) + ha) & 0xff;
+        else
+          q = quad_clamp255 ((int) (int16_t) (uint16_t) (ha * vt0 + hb * vt1 + 32) >> 6);
+      } else {
+        uint32_t v;
+        if (sv.kind == SCALE_NEAREST)
+          v = pa;
+        else if (sv.kind == SCALE_2TAP)
+          v = v2tap_pk (pa, pb, (uint32_t) (uint16_t) vt1 * 0x00010001u);
+        else
+          v = quad_vntap_pk (pa, pb, (uint32_t) (uint16_t) vt0 * 0x00010001u, (uint32_t) (uint16_t) vt1 * 0x00010001u);
+        q = quad_dot2 (v, w[k], h_rnd) >> h_shift;
+        if (h_ntap)
+          q = quad_clamp255 (q);
+      }
+      o[c] = (uint32_t) q;
+    }
+    uint2 st;
+    st.x = (o[0] | (o[1] << 8)) | ((o[2] | (o[3] << 8)) << 16);
+    st.y = (o[4] | (o[5] << 8)) | ((o[6] | (o[7] << 8)) << 16);
+    *(uint2 *) (J.d.p + (size_t) y * J.d.stride + 8 * (size_t) lane) = st;
+  }
+}
+
+// the pass-free kinds of a one-byte plane on sixteen outputs (x a multiple of 16, destination rows on 16 bytes); false: not this kind
+GSTAMD_HD bool plane_simple16 (const PlaneJob &J, int x, int y)
+{
+  const uint8_t *sp = J.s.p;
+  const size_t st = (size_t) J.s.stride;
+  uint4 v;
+  switch (J.kind) {
+    case PLANE_COPY:
+      v = oct_load16 (sp + (size_t) y * st, x);
+      break;
+    case PLANE_V_HALVE: {
+      const uint4 a = oct_load16 (sp + (size_t) (2 * y) * st, x), b = oct_load16 (sp + (size_t) (2 * y + 1) * st, x);
+      v = gstamd_make_uint4 (avgub_w (a.x, b.x), avgub_w (a.y, b.y), avgub_w (a.z, b.z), avgub_w (a.w, b.w));
+      break;
+    }
+    case PLANE_H_HALVE: {
+      const uint4 a = oct_load16 (sp + (size_t) y * st, 2 * x), b = oct_load16 (sp + (size_t) y * st, 2 * x + 16);
+      v = gstamd_make_uint4 (avgub_w (bperm (a.y, a.x, 0x06040200u), bperm (a.y, a.x, 0x07050301u)), avgub_w (bperm (a.w, a.z, 0x06040200u), bperm (a.w, a.z, 0x07050301u)),
+          avgub_w (bperm (b.y, b.x, 0x06040200u), bperm (b.y, b.x, 0x07050301u)), avgub_w (bperm (b.w, b.z, 0x06040200u), bperm (b.w, b.z, 0x07050301u)));
+      break;
+    }
+    case PLANE_HV_HALVE: {
+      const uint8_t *r0 = sp + (size_t) (2 * y) * st, *r1 = r0 + st;
+      const uint4 a0 = oct_load16 (r0, 2 * x), a1 = oct_load16 (r0, 2 * x + 16), b0 = oct_load16 (r1, 2 * x), b1 = oct_load16 (r1, 2 * x + 16);
+      const uint32_t m[8] = {avgub_w (a0.x, b0.x), avgub_w (a0.y, b0.y), avgub_w (a0.z, b0.z), avgub_w (a0.w, b0.w),
+                             avgub_w (a1.x, b1.x), avgub_w (a1.y, b1.y), avgub_w (a1.z, b1.z), avgub_w (a1.w, b1.w)};
+      v = gstamd_make_uint4 (avgub_w (bperm (m[1], m[0], 0x06040200u), bperm (m[1], m[0], 0x07050301u)), avgub_w (bperm (m[3], m[2], 0x06040200u), bperm (m[3], m[2], 0x07050301u)),
+          avgub_w (bperm (m[5], m[4], 0x06040200u), bperm (m[5], m[4], 0x07050301u)), avgub_w (bperm (m[7], m[6], 0x06040200u), bperm (m[7], m[6], 0x07050301u)));
+      break;
+    }
+    default:
+      return false;
+  }
+  *(uint4 *) (J.d.p + (size_t) y * J.d.stride + x) = v;
+  return true;
+}
+
+// host: PlaneJob::quad of a job whose pointers are set (quad_ok / oct_ok: plane_quad_ok / plane_oct_ok of its plan); max_mode caps the form
+inline int plane_job_quad (const PlaneJob &J, bool quad_ok, bool oct_ok, int max_mode = 2)
+{
+  const uintptr_t d = (uintptr_t) J.d.p;
+  if (J.kind != PLANE_SCALE) {
+    if (J.s.n != 1 || !J.wide || !J.wide_src)
+      return 0;
+    return 1 + ((d % 16) == 0 && (J.d.stride % 16) == 0 && max_mode >= 2 ? 2 : 0);
+  }
+  if (oct_ok && (d % 8) == 0 && (J.d.stride % 8) == 0 && max_mode >= 1)
+    return 1 + 1;
+  return quad_ok && (d % 4) == 0 && (J.d.stride % 4) == 0 ? 1 : 0;
+}
+
+// what a lane of k_plane_quad does for a job: QUAD_4 plane_quad_body, QUAD_8 plane_oct_body, QUAD_16 plane_simple16 (pass-free kinds)
+enum { QUAD_4 = 0, QUAD_8 = 1, QUAD_16 = 2 };
+
+GSTAMD_HD void plane_rows_body (const PlaneJob &J, int mode, int lane, int y0, int rows)
+{
+  if (mode == QUAD_8) {
+    if (J.s.n == 1)
+      plane_oct_body<1> (J, lane, y0, rows);
+    else
+      plane_oct_body<2> (J, lane, y0, rows);
+    return;
+  }
+  for (int r = 0; r < rows && y0 + r < J.oh; r++) {
+    if (mode == QUAD_16) {
+      const int x = 16 * lane;
+      if (x >= J.ow)
+        return;
+      if (x + 16 <= J.ow && plane_simple16 (J, x, y0 + r))
+        continue;
+      for (int q = 0; q < 4; q++)
+        plane_quad_body (J, 4 * lane + q, y0 + r);
+    } else {
+      plane_quad_body (J, lane, y0 + r);
+    }
+  }
 }
 
 // does the plane go through plane_direct_body (host and device)

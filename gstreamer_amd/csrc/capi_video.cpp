@@ -56,6 +56,7 @@ struct GstAmdVideoConverter {
   size_t plane_tmp_bytes = 0;
   size_t plane_lds_bytes = 0;
   bool plane_frame_ok = false;            // the frame's planes go through k_plane_frame (one launch)
+  std::vector<int> plane_dstep;
   std::vector<bool> plane_quad, plane_oct;        // per plane of the plan: plane_quad_ok / plane_oct_ok (k_plane_quad takes it where the destination rows allow)
   void *ed_carry = nullptr;                // error-diffusion dither on rectangles taller than one band: the band's last line of errors (video_dither_ed.h)
   uint8_t *pre_img = nullptr;             // enlarging from a planar / packed 4:2:2 source: the source frame after front + colour stage, at its own size
@@ -503,9 +504,11 @@ static int build_tables (GstAmdVideoConverter *c)
     c->plane_frame_ok = p.planes.size () <= PLN_MAX_JOBS;
     c->plane_quad.clear ();
     c->plane_oct.clear ();
+    c->plane_dstep.clear ();
     for (const PlanePlan &pp : p.planes) {
+      c->plane_dstep.push_back (plane_quad_dstep (pp));
       c->plane_quad.push_back (plane_quad_ok (pp));
-      c->plane_oct.push_back (plane_oct_ok (pp));
+      c->plane_oct.push_back (plane_quad_ok (pp, 8));
     }
     for (const PlanePlan &pp : p.planes) {
       for (const ScalePass &sp : pp.passes)
@@ -914,6 +917,7 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
       const int unit = 4 * pp.n_elems;
       J.wide = pp.n_elems <= 2 && ((uintptr_t) J.d.p % unit) == 0 && (J.d.stride % unit) == 0;
       J.wide_src = ((uintptr_t) J.s.p % 8) == 0 && (J.s.stride % 8) == 0;
+      J.dstep = i < c->plane_dstep.size () && !tuning_on ("GSTAMD_PLANE_QUAD_NO_DSTEP") ? c->plane_dstep[i] : 0;
       J.quad = plane_job_quad (J, i < c->plane_quad.size () && c->plane_quad[i], i < c->plane_oct.size () && c->plane_oct[i], tuning_int ("GSTAMD_PLANE_QUAD_MODE", 2));
       J.tile0 = tiles;
       J.tiles_x = (pp.ow + PLN_TW - 1) / PLN_TW;

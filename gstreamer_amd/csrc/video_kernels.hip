@@ -991,27 +991,27 @@ __global__ __launch_bounds__ (PLN_THREADS) void k_plane_direct (PlaneJobs jobs, 
 }
 
 // the planes of two short passes and the pass-free ones next to them (video_planes.h: k_plane_quad): a workgroup = 64 lanes x 4 waves, a wave
-// walks g.rows output rows
+// walks g.rows output rows.  An if-chain over the jobs (see k_plane_tiles); the argument is not written to - a frame list's rebase happens
+// where the body forms a pointer
 template <int K>
-__device__ __forceinline__ void plane_quad_job (const PlaneJobs &jobs, const QuadGrid &g)
+__device__ __forceinline__ void plane_quad_job (const PlaneJobs &jobs, const QuadGrid &g, int local, long long ds, long long dd)
 {
-  const int local = (int) blockIdx.x - g.block0[K];
   const int bxi = local % g.bx[K], byi = local / g.bx[K];
-  const int y0 = __builtin_amdgcn_readfirstlane ((byi * 4 + (int) (threadIdx.x >> 6)) * g.rows);
-  plane_rows_body (jobs.job[K], g.mode[K], bxi * 64 + (int) (threadIdx.x & 63), y0, g.rows);
+  const int y0 = __builtin_amdgcn_readfirstlane ((byi * 4 + (int) (threadIdx.x >> 6)) * g.rows[K]);
+  plane_rows_body (jobs.job[K], bxi * 64 + (int) (threadIdx.x & 63), y0, g.rows[K], ds, dd, g.nt);
 }
 
 __global__ __launch_bounds__ (256) void k_plane_quad (PlaneJobs jobs, QuadGrid g, FrameDeltas fl)
 {
   GSTAMD_FRAME_Z;
-  plane_jobs_rebase (jobs, fls_, fld_);
-  const int b = (int) blockIdx.x;
-  if (jobs.n > 2 && g.block0[2] >= 0 && b >= g.block0[2])
-    plane_quad_job<2> (jobs, g);
-  else if (jobs.n > 1 && g.block0[1] >= 0 && b >= g.block0[1])
-    plane_quad_job<1> (jobs, g);
+  int k, local;
+  quad_grid_find (g, (int) blockIdx.x, &k, &local);
+  if (k == 2)
+    plane_quad_job<2> (jobs, g, local, fls_, fld_);
+  else if (k == 1)
+    plane_quad_job<1> (jobs, g, local, fls_, fld_);
   else
-    plane_quad_job<0> (jobs, g);
+    plane_quad_job<0> (jobs, g, local, fls_, fld_);
 }
 
 // `jobs`: the frame's planes in any order; they are split by kind of body and each kind gets a launch of its own
@@ -1028,24 +1028,28 @@ hipError_t launch_plane_frame (const PlaneJobs &jobs, size_t lds_bytes, hipStrea
     for (int i = 0; i < jobs.n; i++) {
       if (!quads || !jobs.job[i].quad)
         continue;
+      if (tuning_int ("GSTAMD_PLANE_QUAD_ONLY", -1) >= 0 && tuning_int ("GSTAMD_PLANE_QUAD_ONLY", -1) != i)          /* timing one plane of the frame on its own (the others are not converted) */
+        continue;
       const PlaneJob &J = jobs.job[i];
-      g.mode[part.n] = J.quad - 1;
-      const int bytes = 4 << g.mode[part.n];
+      const int bytes = quad_mode_bytes (J.quad - 1);
       g.bx[part.n] = ((J.ow * J.s.n + bytes - 1) / bytes + 63) / 64;
       wave_rows += (long long) g.bx[part.n] * J.oh;
       part.job[part.n++] = J;
     }
-    /* rows per wave: what is set up per column serves more rows the longer a wave walks, but the launch should still hold some eight
-       waves per SIMD (1024 of them): a single 4K -> 1080p NV12 frame is 4300 wave-rows, a list of eight 35000 */
+    /* rows per wave: what a two-pass plane sets up per column (indices, weights, selectors) serves more rows the longer a wave walks, but
+       the launch wants many waves more than it wants that (MI355X, NV12 4K -> 1080p in lists of 8, profiles/r04/f8scale_variants.log: 30.2 /
+       29.6 / 33.6 us per launch at 1 / 2 / 4 rows; single frames 7.7 / 9.0 / 12.6); a pass-free plane has nothing to set up */
     const int rows_pin = tuning_int ("GSTAMD_PLANE_QUAD_ROWS", 0);
-    g.rows = rows_pin > 0 ? rows_pin : (int) std::min<long long> (8, std::max<long long> (1, wave_rows * nz / 8192));
+    g.nt = tuning_int ("GSTAMD_PLANE_QUAD_NT", 0);
     int blocks = 0;
     for (int k = 0; k < part.n; k++) {
-      g.block0[k] = blocks;
-      blocks += g.bx[k] * ((part.job[k].oh + 4 * g.rows - 1) / (4 * g.rows));
+      const bool two_pass = part.job[k].kind == PLANE_SCALE;
+      g.rows[k] = !two_pass ? 1 : (rows_pin > 0 ? rows_pin : (wave_rows * nz >= 16384 ? 2 : 1));
+      g.n[k] = g.bx[k] * ((part.job[k].oh + 4 * g.rows[k] - 1) / (4 * g.rows[k]));
+      blocks += g.n[k];
     }
     for (int i = part.n; i < PLN_MAX_JOBS; i++)
-      g.block0[i] = -1, g.bx[i] = 1, g.mode[i] = 0;
+      g.n[i] = 0, g.bx[i] = 1, g.rows[i] = 1;
     if (part.n)
       hipLaunchKernelGGL (k_plane_quad, dim3 (blocks, 1, nz), dim3 (256), 0, stream, part, g, fl);
   }

@@ -124,8 +124,8 @@ struct PlaneJob {
   int tile0, tiles_x;   // first tile of the plane in the launch's grid, tiles per tile row
   int wide;             // destination rows and the tile's 4-pixel groups sit on whole words: 4 outputs per store
   int wide_src;         // source rows on 8 bytes: the pass-free kinds read 4 / 8 source bytes per lane (plane_simple4)
-  int quad;             // 0: not for k_plane_quad; 1 + QUAD_4 / QUAD_8 / QUAD_16: how (plane_quad_ok / plane_oct_ok / a pass-free one-byte plane, and the
-                        // destination rows on 4 / 8 / 16 bytes)
+  int quad;             // 0: not for k_plane_quad; 1 + QUAD_4 / QUAD_8 / QUAD_16 / QUAD_S8: how (plane_job_quad)
+  int dstep;            // plane_quad_dstep of the plan (k_plane_quad's eight-byte form only)
 };
 
 struct PlaneJobs {
@@ -404,29 +404,51 @@ GSTAMD_HD void plane_direct_body (const PlaneJob &J, int tile, int tid)
   plane_put4 (J, x, y, x1, px);
 }
 
-// ---- k_plane_quad: two short passes, four output bytes per lane from two 8-byte loads --------------------------------------------------
+// ---- k_plane_quad: planes of two short passes, 4 or 8 output bytes per lane from 8- / 16-byte windows; pass-free planes 16 per lane ---------
 // plane_direct_body asks memory for every source byte on its own (4 outputs x 4 source pixels = 16 byte loads per lane, plus the table
 // rows): at 4K -> 1080p the kernel issues ~20 load instructions per wave and the chip's vector-memory issue rate (one wave instruction
 // per ~37 clocks and CU, profiles/r04) bounds it at 6.5 us per NV12 frame against 1.9 us of traffic.  When both passes read at most two
-// source pixels per output and four consecutive output BYTES of a row (four pixels of a one-byte plane, two of a two-byte one) depend
-// on at most 8 source bytes per row - any ratio up to 2:1 shrinking, every enlargement - a lane loads those 8 bytes of its two source
-// rows with one (unaligned) load each, picks an output's two taps with v_perm_b32 into the halves of a register, and a pass is a
-// v_dot2 on it: H = (a * w0 + b * w1 + rnd) >> shift with (256 - f, f, 0, 8) for the 2-tap function (ldreslinl), (256, 0, 0, 8) for
-// nearest, (t0, t1, 32, 6) and a clamp for a two-tap N-tap filter; V likewise (the 2-tap V keeps its own rounding: v2tap_px).  The
-// passes run in the plan's order with the first one's result as the byte the reference keeps in its temporary line.  A wave works on
-// one output row (the vertical pass's table row is wave-uniform: scalar loads); lanes whose four bytes cross the row's end take
-// plane_direct_body's per-pixel route.
+// source pixels per output and B consecutive output BYTES of a row (B = 4 or 8: pixels of a one-byte plane, half as many of a two-byte
+// one) depend on at most 2 B source bytes per row - any ratio up to 2:1 shrinking, every enlargement - a lane loads that window of its
+// two source rows with one (unaligned) load each, picks an output's two taps with v_perm_b32 into the halves of a register, and a pass
+// is a v_dot2 on it: H = (a * w0 + b * w1 + rnd) >> shift with (256 - f, f, 0, 8) for the 2-tap function (ldreslinl), (256, 0, 0, 8)
+// for nearest, (t0, t1, 32, 6) and a clamp for a two-tap N-tap filter; V likewise (the 2-tap V keeps its own rounding: v2tap_px).  The
+// passes run in the plan's order with the first one's result as the byte the reference keeps in its temporary line.
+// A wave works on `rows` consecutive output rows of its 64 lanes' columns: what depends on the column only - source indices, weight
+// pairs, the v_perm selectors (for the 16-byte window two per output: a | b << 16 = perm (w1, w0, selA) | perm (w3, w2, selB), selector
+// 0x0c yields zero for the half a tap is not in) - is set up once; the vertical pass's table row is wave-uniform (scalar loads).  The
+// last lane of a row whose group would cross the row's end moves back to end with it (it recomputes bytes of its neighbour: same
+// values).  The pass-free kinds (the 2:1 luma next to a scaled UV plane) go 16 output bytes per lane.  A frame list rebases the planes
+// where a pointer is formed (ds, dd).
 struct QuadGrid {
-  int block0[PLN_MAX_JOBS];      // first workgroup of each job (jobs in PlaneJobs order), -1: the job is not in this launch
+  int n[PLN_MAX_JOBS];           // workgroups of each job (jobs in PlaneJobs order), 0: none
   int bx[PLN_MAX_JOBS];          // workgroups per row of workgroups (64 lanes x 4 waves each)
-  int mode[PLN_MAX_JOBS];        // QUAD_4 / QUAD_8 / QUAD_16: output bytes per lane and row
-  int rows;                      // rows a wave walks
+  int rows[PLN_MAX_JOBS];        // rows a wave walks
+  int nt;                        // bit 0: nontemporal loads, bit 1: nontemporal stores
 };
 
-// host: may the plane go this way?  (table contents: spans of four output bytes, tap magnitudes)
-inline bool plane_quad_ok (const PlanePlan &pp)
+// workgroup b of the launch -> job and workgroup within the job: plane after plane.  (Alternating the planes' workgroups along the grid in
+// proportion to their counts - a plane that waits on dependent loads next to one that streams - measured the same or worse: 30.5 against
+// 29.6 us per list of eight 4K NV12 frames, profiles/r04/f8scale_variants.log.)
+GSTAMD_HD void quad_grid_find (const QuadGrid &g, int b, int *job, int *local)
 {
-  if (pp.kind != PLANE_SCALE || pp.passes.size () != 2 || (pp.n_elems != 1 && pp.n_elems != 2) || pp.iw * pp.n_elems < 8 || pp.ih < 1)
+  for (int k = 0; k < PLN_MAX_JOBS - 1; k++) {
+    if (b < g.n[k]) {
+      *job = k, *local = b;
+      return;
+    }
+    b -= g.n[k];
+  }
+  *job = PLN_MAX_JOBS - 1, *local = b;
+}
+
+enum { QUAD_4 = 0, QUAD_8 = 1, QUAD_16 = 2, QUAD_S8 = 3 };           // PlaneJob::quad - 1: two-pass planes 4 / 8 output bytes per lane and row, pass-free ones 16 / 8
+GSTAMD_VP int quad_mode_bytes (int mode) { return mode == QUAD_S8 ? 8 : 4 << mode; }
+
+// host: may the plane go this way with B = `bytes` output bytes per lane?  (table contents: spans of the groups, tap magnitudes)
+inline bool plane_quad_ok (const PlanePlan &pp, int bytes = 4)
+{
+  if (pp.kind != PLANE_SCALE || pp.passes.size () != 2 || (pp.n_elems != 1 && pp.n_elems != 2) || pp.iw * pp.n_elems < 2 * bytes || pp.ow * pp.n_elems < bytes || pp.ih < 1)
     return false;
   const ScalePass *ph = pp.passes[0].horizontal ? &pp.passes[0] : &pp.passes[1], *pv = pp.passes[0].horizontal ? &pp.passes[1] : &pp.passes[0];
   if (!ph->horizontal || pv->horizontal)
@@ -444,9 +466,10 @@ inline bool plane_quad_ok (const PlanePlan &pp)
       return false;
     }
   }
-  /* the source pixels of every group of 4 / n_elems consecutive outputs: first tap of the first .. second tap of the last, within 8 bytes */
-  const int per = 4 / pp.n_elems;
-  for (int x = 0; x + per <= pp.ow; x += per) {
+  /* the source pixels of every group of `per` consecutive outputs - a group starts at ANY pixel (the row's last one is moved back): first
+     tap of the first .. second tap of the last, within 2 * bytes */
+  const int per = bytes / pp.n_elems;
+  for (int x = 0; x + per <= pp.ow; x++) {
     int lo, hi;
     if (ph->kind == SCALE_2TAP) {
       lo = (x * ph->inc) >> 16, hi = (((x + per - 1) * ph->inc) >> 16) + 1;
@@ -456,7 +479,7 @@ inline bool plane_quad_ok (const PlanePlan &pp)
         if ((int) ph->offset[x + k] < lo)
           return false;
     }
-    if ((hi - lo + 1) * pp.n_elems > 8)
+    if ((hi - lo + 1) * pp.n_elems > 2 * bytes)
       return false;
   }
   return true;
@@ -494,183 +517,119 @@ GSTAMD_HD uint32_t quad_vntap_pk (uint32_t s1, uint32_t s2, uint32_t t0s, uint32
 #endif
 }
 
-// 8 bytes from byte `off` of a plane row (the lane's window of source bytes), any alignment
-GSTAMD_HD uint2 quad_load8 (const uint8_t *row, int off)
+// W dwords from byte `off` of a plane row / to byte `off` of one, any alignment
+template <int W>
+struct QuadWords { uint32_t w[W]; };
+
+template <int W>
+GSTAMD_HD QuadWords<W> quad_load (const uint8_t *row, int off, int nt = 0)
+{
+  QuadWords<W> r;
+#ifdef __HIPCC__
+  typedef unsigned int uv __attribute__ ((ext_vector_type (W), aligned (1)));
+  const uv v = nt ? __builtin_nontemporal_load ((const uv *) (row + off)) : *(const uv *) (row + off);
+#pragma unroll
+  for (int i = 0; i < W; i++)
+    r.w[i] = v[i];
+#else
+  memcpy (r.w, row + off, 4 * W);
+#endif
+  return r;
+}
+
+template <int W>
+GSTAMD_HD void quad_store (uint8_t *row, int off, const uint32_t *w, int nt = 0)
 {
 #ifdef __HIPCC__
-  typedef unsigned long long __attribute__ ((aligned (1))) u64_u;
-  const unsigned long long v = *(const u64_u *) (row + off);
-  uint2 r;
-  r.x = (uint32_t) v, r.y = (uint32_t) (v >> 32);
-  return r;
+  typedef unsigned int uv __attribute__ ((ext_vector_type (W), aligned (1)));
+  uv v;
+#pragma unroll
+  for (int i = 0; i < W; i++)
+    v[i] = w[i];
+  if (nt)
+    __builtin_nontemporal_store (v, (uv *) (row + off));
+  else
+    *(uv *) (row + off) = v;
 #else
-  uint2 r;
-  memcpy (&r, row + off, 8);
-  return r;
+  memcpy (row + off, w, 4 * W);
 #endif
 }
 
-// `lane`: output bytes 4 * lane .. 4 * lane + 3 of output row y
-GSTAMD_HD void plane_quad_body (const PlaneJob &J, int lane, int y)
+// a source plane as a raw buffer (base, bytes): a window load takes a wave-uniform row offset plus the lane's byte offset, any alignment,
+// and what lies past the plane's end reads as zero (per dword) - the row's last lane needs no special case
+#ifdef __HIPCC__
+typedef __amdgpu_buffer_rsrc_t quadplane_t;
+#else
+struct quadplane_t { const uint8_t *p; uint32_t bytes; };
+#endif
+GSTAMD_HD quadplane_t quad_plane (const uint8_t *base, uint32_t bytes)
 {
-  const int n = J.s.n, per = 4 / n;
-  const int x = lane * per;
-  if (y >= J.oh || x >= J.ow)
-    return;
-  if (J.kind != PLANE_SCALE) {          /* a pass-free plane of the same frame (the 2:1 luma next to a scaled UV plane): plane_direct_body's route */
-    if (x + 4 <= J.ow && plane_simple4 (J, x, y))
-      return;
-    for (int i = 0; i < 4 && x + i < J.ow; i++)
-      plane_simple_body (J.kind, J.s, J.d, J.ow, J.oh, x + i, y);
-    return;
-  }
-  const ScaleDev &sh = J.pass[J.h_first ? 0 : 1], &sv = J.pass[J.h_first ? 1 : 0];
-  if (x + per > J.ow) {                 /* the row's last, partial group: pixel by pixel (plane_direct_body's arithmetic) */
-    for (int i = 0; x + i < J.ow; i++) {
-      uint32_t px;
-      if (plane_small_kind (sh.kind) && plane_small_kind (sv.kind)) {
-        px = plane_scale2x2_pk (J.s, sh, sv, J.h_first, x + i, y);
-      } else if (J.h_first) {
-        const PlaneHRows rows = {J.s, &sh};
-        px = vscale_px (rows, sv, x + i, y);
-      } else {
-        const PlaneVRow row = {J.s, &sv, y};
-        px = hscale_px (row, sh, x + i);
-      }
-      J.d.put (x + i, y, px);
-    }
-    return;
-  }
-  /* horizontal: source index and weight pair of the lane's outputs */
-  int idx[4];
-  uint32_t w[4];
-  const bool h_ntap = sh.kind == SCALE_NTAP;
-  if (sh.kind == SCALE_2TAP) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int tmp = (x + (k < per ? k : 0)) * sh.inc;
-      idx[k] = tmp >> 16;
-      w[k] = ((uint32_t) (tmp >> 8) & 0xffu) * 0xffffu + 256u;           /* (256 - f) | f << 16 */
-    }
+#ifdef __HIPCC__
+  return __builtin_amdgcn_make_buffer_rsrc ((void *) base, (short) 0, (int) bytes, 0x00020000);
+#else
+  quadplane_t pl = {base, bytes};
+  return pl;
+#endif
+}
+template <int W>
+GSTAMD_HD QuadWords<W> quad_window (quadplane_t pl, uint32_t row_off, uint32_t off)
+{
+  QuadWords<W> r;
+#ifdef __HIPCC__
+  if constexpr (W == 4) {
+    typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128 (pl, (int) off, (int) row_off, 0);
+    r.w[0] = d.x, r.w[1] = d.y, r.w[2] = d.z, r.w[3] = d.w;
   } else {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int xk = x + (k < per ? k : 0);
-      idx[k] = (int) sh.offset[xk];
-      w[k] = h_ntap ? ((const uint32_t *) sh.taps)[xk] : 256u;           /* the output's two taps as they lie in the table / nearest: a * 256 >> 8 */
-    }
+    typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
+    const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64 (pl, (int) off, (int) row_off, 0);
+    r.w[0] = d.x, r.w[1] = d.y;
   }
-  const int h_rnd = h_ntap ? 32 : 0, h_shift = h_ntap ? 6 : 8;
-  /* vertical: the two source rows and their weights */
-  const int ya = (int) sv.offset[y], yb = sv.kind == SCALE_NEAREST ? ya : (ya + 1 < J.ih ? ya + 1 : J.ih - 1);
-  const int vt0 = sv.kind == SCALE_NTAP ? (int) sv.taps[(size_t) y * 2] : 0, vt1 = sv.kind == SCALE_NEAREST ? 0 : (int) sv.taps[(size_t) y * 2 + 1];
-  /* the window: 8 bytes from the first output's first tap; pulled back where it would leave the plane's last row */
-  const int row_bytes = J.iw * n;
-  int off = idx[0] * n, back = 0;
-  if (off + 8 > row_bytes)
-    back = off + 8 - row_bytes, off = row_bytes - 8;
-  const uint2 ra = quad_load8 (J.s.p + (size_t) ya * J.s.stride, off);
-  const uint2 rb = sv.kind == SCALE_NEAREST ? ra : quad_load8 (J.s.p + (size_t) yb * J.s.stride, off);
-  uint32_t o[4];
-#pragma unroll
-  for (int c = 0; c < 4; c++) {         /* output byte c: pixel c (n == 1) or component c & 1 of pixel c >> 1 (n == 2) */
-    const int k = n == 1 ? c : c >> 1;
-    const int d = (idx[k] - idx[0]) * n + (n == 2 ? (c & 1) : 0) + back;
-    const uint32_t sel = (n == 1 ? 0x0c010c00u : 0x0c020c00u) + (uint32_t) d * 0x00010001u;
-    const uint32_t pa = bperm (ra.y, ra.x, sel), pb = bperm (rb.y, rb.x, sel);             /* tap a | tap b << 16, rows ya and yb */
-    int r;
-    if (J.h_first) {
-      int ha = (quad_dot2 (pa, w[k], h_rnd)) >> h_shift, hb = (quad_dot2 (pb, w[k], h_rnd)) >> h_shift;
-      if (h_ntap)
-        ha = quad_clamp255 (ha), hb = quad_clamp255 (hb);
-      if (sv.kind == SCALE_NEAREST)
-        r = ha;
-      else if (sv.kind == SCALE_2TAP)
-        r = (((((hb - ha) * vt1 + 128) >> 8) & 0xff) + ha) & 0xff;                        /* v2tap_px */
-      else
-        r = quad_clamp255 ((int) (int16_t) (uint16_t) (ha * vt0 + hb * vt1 + 32) >> 6);
-    } else {
-      uint32_t v;
-      if (sv.kind == SCALE_NEAREST)
-        v = pa;
-      else if (sv.kind == SCALE_2TAP)
-        v = v2tap_pk (pa, pb, (uint32_t) (uint16_t) vt1 * 0x00010001u);
-      else
-        v = quad_vntap_pk (pa, pb, (uint32_t) (uint16_t) vt0 * 0x00010001u, (uint32_t) (uint16_t) vt1 * 0x00010001u);
-      r = quad_dot2 (v, w[k], h_rnd) >> h_shift;
-      if (h_ntap)
-        r = quad_clamp255 (r);
-    }
-    o[c] = (uint32_t) r;
+#else
+  const unsigned long long at = (unsigned long long) row_off + off;
+  for (int i = 0; i < W; i++) {
+    r.w[i] = 0;
+    if (at + 4 * i + 4 <= pl.bytes)
+      memcpy (&r.w[i], pl.p + at + 4 * i, 4);
   }
-  *(uint32_t *) (J.d.p + (size_t) y * J.d.stride + 4 * (size_t) lane) = (o[0] | (o[1] << 8)) | ((o[2] | (o[3] << 8)) << 16);
+#endif
+  return r;
 }
 
-// ---- the same with eight output bytes per lane and a lane that walks several rows -----------------------------------------------------
-// k_plane_quad's loads are 8 bytes, its stores 4: three memory instructions per four output bytes (five with the table rows of an N-tap
-// pass), and the vector-memory issue rate still bounds a 4K -> 1080p NV12 frame at ~6 us.  plane_oct_body gives a lane eight output bytes
-// of a row from a 16-byte window of each source row, and `rows` consecutive rows: what depends on the column only - source indices,
-// weight pairs, and the two v_perm selectors that pull an output's taps out of the window's low and high halves (a | b << 16 = perm
-// (w1, w0, selA) | perm (w3, w2, selB): selector 0x0c yields zero for the half a byte is not in) - is set up once per lane.
-// plane_simple16 is the pass-free kinds' form of the same idea: 16 output bytes per lane.
-inline bool plane_oct_ok (const PlanePlan &pp)
-{
-  if (!plane_quad_ok (pp) || pp.iw * pp.n_elems < 16)
-    return false;
-  const ScalePass *ph = pp.passes[0].horizontal ? &pp.passes[0] : &pp.passes[1];
-  const int per = 8 / pp.n_elems;
-  for (int x = 0; x + per <= pp.ow; x += per) {
-    int lo, hi;
-    if (ph->kind == SCALE_2TAP) {
-      lo = (x * ph->inc) >> 16, hi = (((x + per - 1) * ph->inc) >> 16) + 1;
-    } else {
-      lo = (int) ph->offset[x], hi = (int) ph->offset[x + per - 1] + 1;
-      for (int k = 1; k < per; k++)
-        if ((int) ph->offset[x + k] < lo)
-          return false;
-    }
-    if ((hi - lo + 1) * pp.n_elems > 16)
-      return false;
-  }
-  return true;
-}
-
-GSTAMD_HD uint4 oct_load16 (const uint8_t *row, int off)
+// selector for the window's bytes base .. base + 7: tap a (window byte da) into byte 0, tap b (db) into byte 2, zero elsewhere.  dd = da | db << 16;
+// per half: t = d - base (wrapping), u = min (t, 8), selector byte = u + 4 * (u >> 3): 0 .. 7 stay, everything else becomes 0x0c - packed
+// 16-bit instructions, no compares (v_cndmask behind a v_cmp runs at a fifth of the rate of plain VALU here, scripts/valubench.hip)
+GSTAMD_HD uint32_t pk_min16 (uint32_t a, uint32_t b)
 {
 #ifdef __HIPCC__
-  typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4), aligned (1)));
-  const u32x4 v = *(const u32x4 *) (row + off);
-  return gstamd_make_uint4 (v.x, v.y, v.z, v.w);
+  typedef unsigned short us2 __attribute__ ((ext_vector_type (2)));
+  return __builtin_bit_cast (uint32_t, __builtin_elementwise_min (__builtin_bit_cast (us2, a), __builtin_bit_cast (us2, b)));
 #else
-  uint4 r;
-  memcpy (&r, row + off, 16);
-  return r;
+  const uint32_t lo = (a & 0xffffu) < (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu), hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+  return lo | (hi << 16);
 #endif
 }
 
-// selector for one half of the window (bytes base .. base + 7): tap a (window byte da) into byte 0, tap b (db) into byte 2, zero elsewhere
-GSTAMD_HD uint32_t oct_sel (int da, int db, int base)
+GSTAMD_HD uint32_t quad_sel (uint32_t dd, int base)
 {
-  const uint32_t a = da >= base && da < base + 8 ? (uint32_t) (da - base) : 0x0cu;
-  const uint32_t b = db >= base && db < base + 8 ? (uint32_t) (db - base) : 0x0cu;
-  return 0x0c000c00u | a | (b << 16);
+  const uint32_t u = pk_min16 (pk_sub16 (dd, (uint32_t) base * 0x00010001u), 0x00080008u);
+  return pk_mad16 (pk_shr<3> (u), 0x00040004u, u) | 0x0c000c00u;
 }
 
-// N = bytes per pixel (1, 2).  lane: output bytes 8 * lane .. + 7 of rows y0 .. y0 + rows - 1
-template <int N>
-GSTAMD_HD void plane_oct_body (const PlaneJob &J, int lane, int y0, int rows)
+#ifndef QUAD_CH
+#define QUAD_CH 2               // rows whose loads leave together
+#endif
+// N = bytes per pixel (1, 2), B = output bytes per lane and row (4, 8), DS = 0, or the plane's uniform distance in pixels between the first
+// taps of neighbouring outputs (PlaneJob::dstep: 2 = a 2:1 reduction - the window bytes of an output are then known at compile time, no
+// selectors to set up and one v_perm per tap pair).  lane: output bytes B * lane .. of rows y0 .. y0 + rows - 1
+template <int N, int B, int DS>
+GSTAMD_HD void plane_quad_body (const PlaneJob &J, int lane, int y0, int rows, long long ds, long long dd, int nt)
 {
-  const int PER = 8 / N;
-  const int x = lane * PER;
+  const int PER = B / N, HALVES = B / 4;          /* pixels per lane; 8-byte halves of the window */
+  int x = lane * PER;
   if (x >= J.ow)
     return;
-  if (x + PER > J.ow) {                 /* the rows' last, partial group */
-    for (int r = 0; r < rows && y0 + r < J.oh; r++) {
-      plane_quad_body (J, 2 * lane, y0 + r);
-      plane_quad_body (J, 2 * lane + 1, y0 + r);
-    }
-    return;
-  }
+  x = x + PER > J.ow ? J.ow - PER : x;          /* the row's last group ends with the row */
   const ScaleDev &sh = J.pass[J.h_first ? 0 : 1], &sv = J.pass[J.h_first ? 1 : 0];
   int idx[PER];
   uint32_t w[PER];
@@ -680,149 +639,250 @@ GSTAMD_HD void plane_oct_body (const PlaneJob &J, int lane, int y0, int rows)
     for (int k = 0; k < PER; k++) {
       const int tmp = (x + k) * sh.inc;
       idx[k] = tmp >> 16;
-      w[k] = ((uint32_t) (tmp >> 8) & 0xffu) * 0xffffu + 256u;
+      w[k] = ((uint32_t) (tmp >> 8) & 0xffu) * 0xffffu + 256u;           /* (256 - f) | f << 16 */
     }
   } else {
+    /* the lane's table rows with one load each (PER consecutive words; the compiler leaves indexed loads one word at a time) */
+    if (DS == 0) {
+      const QuadWords<PER> to = quad_load<PER> ((const uint8_t *) sh.offset, 4 * x);
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-      idx[k] = (int) sh.offset[x + k];
-      w[k] = h_ntap ? ((const uint32_t *) sh.taps)[x + k] : 256u;
+      for (int k = 0; k < PER; k++)
+        idx[k] = (int) to.w[k];
+    } else {
+      idx[0] = (int) sh.offset[x];
     }
+    QuadWords<PER> tw;
+    if (h_ntap)
+      tw = quad_load<PER> ((const uint8_t *) sh.taps, 4 * x);           /* an output's two taps as they lie in the table */
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+      w[k] = h_ntap ? tw.w[k] : 256u;                                   /* nearest: a * 256 >> 8 */
   }
   const int h_rnd = h_ntap ? 32 : 0, h_shift = h_ntap ? 6 : 8;
-  const int row_bytes = J.iw * N;
-  int off = idx[0] * N, back = 0;
-  if (off + 16 > row_bytes)
-    back = off + 16 - row_bytes, off = row_bytes - 16;
-  uint32_t sel_a[8], sel_b[8];
+  /* the window: 2 B bytes from the first output's first tap; pulled back where it would leave the row (a word that straddles the plane's
+     end reads as zero as a whole: the row's own bytes must not depend on what follows it) - a 2:1 plane's windows end with the row */
+  uint32_t off = (uint32_t) idx[0] * N;
+  int back = 0;
+  if (DS == 0 && (int) off + 2 * B > J.iw * N)
+    back = (int) off + 2 * B - J.iw * N, off = (uint32_t) (J.iw * N - 2 * B);
+  uint32_t sel[HALVES][B];
+  if (DS == 0) {
 #pragma unroll
-  for (int c = 0; c < 8; c++) {
-    const int d = (idx[c / N] - idx[0]) * N + (c % N) + back;
-    sel_a[c] = oct_sel (d, d + N, 0);
-    sel_b[c] = oct_sel (d, d + N, 8);
+    for (int c = 0; c < B; c++) {         /* output byte c: component c % N of pixel c / N */
+      const uint32_t d = (uint32_t) ((idx[c / N] - idx[0]) * N + (c % N) + back) * 0x00010001u + ((uint32_t) N << 16);
+#pragma unroll
+      for (int h = 0; h < HALVES; h++)
+        sel[h][c] = quad_sel (d, 8 * h);
+    }
   }
-  for (int r = 0; r < rows; r++) {
-    const int y = y0 + r;
-    if (y >= J.oh)
-      break;
-    const int ya = (int) sv.offset[y], yb = sv.kind == SCALE_NEAREST ? ya : (ya + 1 < J.ih ? ya + 1 : J.ih - 1);
-    const int vt0 = sv.kind == SCALE_NTAP ? (int) sv.taps[(size_t) y * 2] : 0, vt1 = sv.kind == SCALE_NEAREST ? 0 : (int) sv.taps[(size_t) y * 2 + 1];
-    const uint4 ra = oct_load16 (J.s.p + (size_t) ya * J.s.stride, off);
-    const uint4 rb = sv.kind == SCALE_NEAREST ? ra : oct_load16 (J.s.p + (size_t) yb * J.s.stride, off);
-    uint32_t o[8];
+  const quadplane_t src = quad_plane (J.s.p + ds, (uint32_t) ((size_t) J.s.stride * (size_t) J.ih));
+  uint8_t *dp = J.d.p + dd;
+  for (int r0 = 0; r0 < rows && y0 + r0 < J.oh; r0 += QUAD_CH) {
+    /* every load of the chunk's rows leaves before the first result is needed (the stores of a row and the loads of the next may
+       alias as far as the compiler knows: it would not move them itself) */
+    QuadWords<2 * HALVES> ra[QUAD_CH], rb[QUAD_CH];
+    int vt0[QUAD_CH], vt1[QUAD_CH];
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const int k = c / N;
-      const uint32_t pa = bperm (ra.y, ra.x, sel_a[c]) | bperm (ra.w, ra.z, sel_b[c]);
-      const uint32_t pb = bperm (rb.y, rb.x, sel_a[c]) | bperm (rb.w, rb.z, sel_b[c]);
-      int q;
-      if (J.h_first) {
-        int ha = (quad_dot2 (pa, w[k], h_rnd)) >> h_shift, hb = (quad_dot2 (pb, w[k], h_rnd)) >> h_shift;
-        if (h_ntap)
-          ha = quad_clamp255 (ha), hb = quad_clamp255 (hb);
-        if (sv.kind == SCALE_NEAREST)
-          q = ha;
-        else if (sv.kind == SCALE_2TAP)
-          q = (((((hb - ha) * vt1 + 128) >> 8) & 0xff) + ha) & 0xff;
-        else
-          q = quad_clamp255 ((int) (int16_t) (uint16_t) (ha * vt0 + hb * vt1 + 32) >> 6);
-      } else {
-        uint32_t v;
-        if (sv.kind == SCALE_NEAREST)
-          v = pa;
-        else if (sv.kind == SCALE_2TAP)
-          v = v2tap_pk (pa, pb, (uint32_t) (uint16_t) vt1 * 0x00010001u);
-        else
-          v = quad_vntap_pk (pa, pb, (uint32_t) (uint16_t) vt0 * 0x00010001u, (uint32_t) (uint16_t) vt1 * 0x00010001u);
-        q = quad_dot2 (v, w[k], h_rnd) >> h_shift;
-        if (h_ntap)
-          q = quad_clamp255 (q);
+    for (int j = 0; j < QUAD_CH; j++) {
+      const int y = y0 + r0 + j;
+      if (r0 + j < rows && y < J.oh) {
+        const int ya = (int) sv.offset[y], yb = sv.kind == SCALE_NEAREST ? ya : (ya + 1 < J.ih ? ya + 1 : J.ih - 1);
+        vt0[j] = sv.kind == SCALE_NTAP ? (int) sv.taps[(size_t) y * 2] : 0, vt1[j] = sv.kind == SCALE_NEAREST ? 0 : (int) sv.taps[(size_t) y * 2 + 1];
+        ra[j] = quad_window<2 * HALVES> (src, (uint32_t) ya * (uint32_t) J.s.stride, off);
+        rb[j] = sv.kind == SCALE_NEAREST ? ra[j] : quad_window<2 * HALVES> (src, (uint32_t) yb * (uint32_t) J.s.stride, off);
       }
-      o[c] = (uint32_t) q;
     }
-    uint2 st;
-    st.x = (o[0] | (o[1] << 8)) | ((o[2] | (o[3] << 8)) << 16);
-    st.y = (o[4] | (o[5] << 8)) | ((o[6] | (o[7] << 8)) << 16);
-    *(uint2 *) (J.d.p + (size_t) y * J.d.stride + 8 * (size_t) lane) = st;
+#pragma unroll
+    for (int j = 0; j < QUAD_CH; j++) {
+      const int y = y0 + r0 + j;
+      if (r0 + j < rows && y < J.oh) {
+        uint32_t o[B];
+#pragma unroll
+        for (int c = 0; c < B; c++) {
+          const int k = c / N;
+          uint32_t pa, pb;                /* tap a | tap b << 16, rows ya and yb */
+          if (DS == 0) {
+            pa = bperm (ra[j].w[1], ra[j].w[0], sel[0][c]), pb = bperm (rb[j].w[1], rb[j].w[0], sel[0][c]);
+            if (HALVES == 2) {
+              pa |= bperm (ra[j].w[2 * HALVES - 1], ra[j].w[2 * HALVES - 2], sel[HALVES - 1][c]);
+              pb |= bperm (rb[j].w[2 * HALVES - 1], rb[j].w[2 * HALVES - 2], sel[HALVES - 1][c]);
+            }
+          } else {
+            /* taps at window bytes d and d + N, d = k DS N + c % N: both in the word pair (d / 4, d / 4 + 1) - or in one word */
+            const int d = k * DS * N + (c % N), wi = d / 4 < 2 * HALVES - 1 ? d / 4 : 2 * HALVES - 2, dl = d - 4 * wi;
+            const uint32_t cs = 0x0c000c00u | (uint32_t) dl | ((uint32_t) (dl + N) << 16);
+            pa = bperm (ra[j].w[wi + 1], ra[j].w[wi], cs), pb = bperm (rb[j].w[wi + 1], rb[j].w[wi], cs);
+          }
+          int q;
+          if (J.h_first) {
+            int ha = (quad_dot2 (pa, w[k], h_rnd)) >> h_shift, hb = (quad_dot2 (pb, w[k], h_rnd)) >> h_shift;
+            if (h_ntap)
+              ha = quad_clamp255 (ha), hb = quad_clamp255 (hb);
+            if (sv.kind == SCALE_NEAREST)
+              q = ha;
+            else if (sv.kind == SCALE_2TAP)
+              q = (((((hb - ha) * vt1[j] + 128) >> 8) & 0xff) + ha) & 0xff;                        /* v2tap_px */
+            else
+              q = quad_clamp255 ((int) (int16_t) (uint16_t) (ha * vt0[j] + hb * vt1[j] + 32) >> 6);
+          } else {
+            uint32_t v;
+            if (sv.kind == SCALE_NEAREST)
+              v = pa;
+            else if (sv.kind == SCALE_2TAP)
+              v = v2tap_pk (pa, pb, (uint32_t) (uint16_t) vt1[j] * 0x00010001u);
+            else
+              v = quad_vntap_pk (pa, pb, (uint32_t) (uint16_t) vt0[j] * 0x00010001u, (uint32_t) (uint16_t) vt1[j] * 0x00010001u);
+            q = quad_dot2 (v, w[k], h_rnd) >> h_shift;
+            if (h_ntap)
+              q = quad_clamp255 (q);
+          }
+          o[c] = (uint32_t) q;
+        }
+        uint32_t st[HALVES];
+#pragma unroll
+        for (int h = 0; h < HALVES; h++)
+          st[h] = (o[4 * h] | (o[4 * h + 1] << 8)) | ((o[4 * h + 2] | (o[4 * h + 3] << 8)) << 16);
+        quad_store<HALVES> (dp + (size_t) y * J.d.stride, x * N, st, nt & 2);
+      }
+    }
   }
 }
 
-// the pass-free kinds of a one-byte plane on sixteen outputs (x a multiple of 16, destination rows on 16 bytes); false: not this kind
-GSTAMD_HD bool plane_simple16 (const PlaneJob &J, int x, int y)
+// host: PlaneJob::dstep of a plane that goes through plane_quad_body - 2 when every output's first horizontal tap lies two pixels after its
+// left neighbour's (a 2:1 reduction), else 0
+inline int plane_quad_dstep (const PlanePlan &pp)
 {
-  const uint8_t *sp = J.s.p;
-  const size_t st = (size_t) J.s.stride;
-  uint4 v;
-  switch (J.kind) {
-    case PLANE_COPY:
-      v = oct_load16 (sp + (size_t) y * st, x);
-      break;
-    case PLANE_V_HALVE: {
-      const uint4 a = oct_load16 (sp + (size_t) (2 * y) * st, x), b = oct_load16 (sp + (size_t) (2 * y + 1) * st, x);
-      v = gstamd_make_uint4 (avgub_w (a.x, b.x), avgub_w (a.y, b.y), avgub_w (a.z, b.z), avgub_w (a.w, b.w));
-      break;
-    }
-    case PLANE_H_HALVE: {
-      const uint4 a = oct_load16 (sp + (size_t) y * st, 2 * x), b = oct_load16 (sp + (size_t) y * st, 2 * x + 16);
-      v = gstamd_make_uint4 (avgub_w (bperm (a.y, a.x, 0x06040200u), bperm (a.y, a.x, 0x07050301u)), avgub_w (bperm (a.w, a.z, 0x06040200u), bperm (a.w, a.z, 0x07050301u)),
-          avgub_w (bperm (b.y, b.x, 0x06040200u), bperm (b.y, b.x, 0x07050301u)), avgub_w (bperm (b.w, b.z, 0x06040200u), bperm (b.w, b.z, 0x07050301u)));
-      break;
-    }
-    case PLANE_HV_HALVE: {
-      const uint8_t *r0 = sp + (size_t) (2 * y) * st, *r1 = r0 + st;
-      const uint4 a0 = oct_load16 (r0, 2 * x), a1 = oct_load16 (r0, 2 * x + 16), b0 = oct_load16 (r1, 2 * x), b1 = oct_load16 (r1, 2 * x + 16);
-      const uint32_t m[8] = {avgub_w (a0.x, b0.x), avgub_w (a0.y, b0.y), avgub_w (a0.z, b0.z), avgub_w (a0.w, b0.w),
-                             avgub_w (a1.x, b1.x), avgub_w (a1.y, b1.y), avgub_w (a1.z, b1.z), avgub_w (a1.w, b1.w)};
-      v = gstamd_make_uint4 (avgub_w (bperm (m[1], m[0], 0x06040200u), bperm (m[1], m[0], 0x07050301u)), avgub_w (bperm (m[3], m[2], 0x06040200u), bperm (m[3], m[2], 0x07050301u)),
-          avgub_w (bperm (m[5], m[4], 0x06040200u), bperm (m[5], m[4], 0x07050301u)), avgub_w (bperm (m[7], m[6], 0x06040200u), bperm (m[7], m[6], 0x07050301u)));
-      break;
-    }
-    default:
-      return false;
+  if (pp.kind != PLANE_SCALE || pp.passes.size () != 2)
+    return 0;
+  const ScalePass *ph = pp.passes[0].horizontal ? &pp.passes[0] : &pp.passes[1];
+  for (int x = 0; x + 1 < pp.ow; x++) {
+    const int a = ph->kind == SCALE_2TAP ? (x * ph->inc) >> 16 : (int) ph->offset[x], b = ph->kind == SCALE_2TAP ? ((x + 1) * ph->inc) >> 16 : (int) ph->offset[x + 1];
+    if (b - a != 2)
+      return 0;
   }
-  *(uint4 *) (J.d.p + (size_t) y * J.d.stride + x) = v;
-  return true;
+  const int last = ph->kind == SCALE_2TAP ? ((pp.ow - 1) * ph->inc) >> 16 : (int) ph->offset[pp.ow - 1];
+  return last + 2 <= pp.iw ? 2 : 0;           /* the last output's window ends inside the row */
 }
 
-// host: PlaneJob::quad of a job whose pointers are set (quad_ok / oct_ok: plane_quad_ok / plane_oct_ok of its plan); max_mode caps the form
+// the pass-free kinds of a one-byte plane on sixteen outputs: copy, and the 2:1 averages in one or both directions (video_orc_planar_chroma_*:
+// avgub).  hs / vs: the kind halves horizontally / vertically.  The source bytes of a row first (s16_load: up to four 16-byte loads), then
+// the averages and the store (s16_put).  Plain locals and uniform branches, no switch writing into a struct (that ends in scratch).
+GSTAMD_VP bool plane_simple16_kind (int kind) { return kind == PLANE_COPY || kind == PLANE_V_HALVE || kind == PLANE_H_HALVE || kind == PLANE_HV_HALVE; }
+
+struct S16Row { QuadWords<4> a0, a1, b0, b1; };
+
+GSTAMD_HD void s16_load (const uint8_t *sp, size_t st, int hs, int vs, int x, int y, S16Row &q, int nt)
+{
+  const uint8_t *r0 = sp + (size_t) (y << vs) * st;
+  q.a0 = quad_load<4> (r0, x << hs, nt);
+  q.a1 = hs ? quad_load<4> (r0, 2 * x + 16, nt) : q.a0;
+  q.b0 = vs ? quad_load<4> (r0 + st, x << hs, nt) : q.a0;
+  q.b1 = hs && vs ? quad_load<4> (r0 + st, 2 * x + 16, nt) : q.a0;
+}
+
+GSTAMD_HD uint32_t avg_pairs (uint32_t lo, uint32_t hi) { return avgub_w (bperm (hi, lo, 0x06040200u), bperm (hi, lo, 0x07050301u)); }     /* avgub of the byte pairs of 8 bytes */
+
+GSTAMD_HD void s16_put (uint8_t *dp, size_t dst, int hs, int vs, int x, int y, const S16Row &q, int nt)
+{
+  uint32_t m0[4], m1[4], v[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    m0[i] = vs ? avgub_w (q.a0.w[i], q.b0.w[i]) : q.a0.w[i];
+    m1[i] = vs ? avgub_w (q.a1.w[i], q.b1.w[i]) : q.a1.w[i];
+  }
+  v[0] = hs ? avg_pairs (m0[0], m0[1]) : m0[0];
+  v[1] = hs ? avg_pairs (m0[2], m0[3]) : m0[1];
+  v[2] = hs ? avg_pairs (m1[0], m1[1]) : m0[2];
+  v[3] = hs ? avg_pairs (m1[2], m1[3]) : m0[3];
+  quad_store<4> (dp + (size_t) y * dst, x, v, nt);
+}
+
+GSTAMD_HD void plane_simple16_body (const PlaneJob &J, int lane, int y0, int rows, long long ds, long long dd, int nt)
+{
+  int x = 16 * lane;
+  if (x >= J.ow)
+    return;
+  x = x + 16 > J.ow ? J.ow - 16 : x;
+  const uint8_t *sp = J.s.p + ds;
+  uint8_t *dp = J.d.p + dd;
+  const int hs = J.kind == PLANE_H_HALVE || J.kind == PLANE_HV_HALVE ? 1 : 0, vs = J.kind == PLANE_V_HALVE || J.kind == PLANE_HV_HALVE ? 1 : 0;
+  const size_t st = (size_t) J.s.stride, dst = (size_t) J.d.stride;
+  for (int r0 = 0; r0 < rows && y0 + r0 < J.oh; r0 += 2) {          /* two rows' loads, then their averages and stores */
+    S16Row qa, qb;
+    const bool two = r0 + 1 < rows && y0 + r0 + 1 < J.oh;
+    s16_load (sp, st, hs, vs, x, y0 + r0, qa, nt & 1);
+    if (two)
+      s16_load (sp, st, hs, vs, x, y0 + r0 + 1, qb, nt & 1);
+    s16_put (dp, dst, hs, vs, x, y0 + r0, qa, nt & 2);
+    if (two)
+      s16_put (dp, dst, hs, vs, x, y0 + r0 + 1, qb, nt & 2);
+  }
+}
+
+// the same on eight outputs per lane: a horizontally halving kind then reads 16 bytes per lane and row, lane after lane without gaps
+GSTAMD_HD void plane_simple8_body (const PlaneJob &J, int lane, int y0, int rows, long long ds, long long dd, int nt)
+{
+  int x = 8 * lane;
+  if (x >= J.ow)
+    return;
+  x = x + 8 > J.ow ? J.ow - 8 : x;
+  const uint8_t *sp = J.s.p + ds;
+  uint8_t *dp = J.d.p + dd;
+  const int hs = J.kind == PLANE_H_HALVE || J.kind == PLANE_HV_HALVE ? 1 : 0, vs = J.kind == PLANE_V_HALVE || J.kind == PLANE_HV_HALVE ? 1 : 0;
+  const size_t st = (size_t) J.s.stride;
+  for (int r = 0; r < rows && y0 + r < J.oh; r++) {
+    const int y = y0 + r;
+    const uint8_t *r0 = sp + (size_t) (y << vs) * st;
+    uint32_t a[4], b[4], v[2];
+    if (hs) {
+      const QuadWords<4> qa = quad_load<4> (r0, 2 * x, nt & 1), qb = vs ? quad_load<4> (r0 + st, 2 * x, nt & 1) : qa;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        a[i] = qa.w[i], b[i] = qb.w[i];
+    } else {
+      const QuadWords<2> qa = quad_load<2> (r0, x, nt & 1), qb = vs ? quad_load<2> (r0 + st, x, nt & 1) : qa;
+      a[0] = qa.w[0], a[1] = qa.w[1], b[0] = qb.w[0], b[1] = qb.w[1];
+      a[2] = a[3] = b[2] = b[3] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      a[i] = vs ? avgub_w (a[i], b[i]) : a[i];
+    v[0] = hs ? avg_pairs (a[0], a[1]) : a[0];
+    v[1] = hs ? avg_pairs (a[2], a[3]) : a[1];
+    quad_store<2> (dp + (size_t) y * J.d.stride, x, v, nt & 2);
+  }
+}
+
+// host: PlaneJob::quad of a job whose pointers are set (quad_ok / oct_ok: plane_quad_ok (pp, 4) / (pp, 8) of its plan); max_mode caps the form
 inline int plane_job_quad (const PlaneJob &J, bool quad_ok, bool oct_ok, int max_mode = 2)
 {
-  const uintptr_t d = (uintptr_t) J.d.p;
-  if (J.kind != PLANE_SCALE) {
-    if (J.s.n != 1 || !J.wide || !J.wide_src)
-      return 0;
-    return 1 + ((d % 16) == 0 && (J.d.stride % 16) == 0 && max_mode >= 2 ? 2 : 0);
-  }
-  if (oct_ok && (d % 8) == 0 && (J.d.stride % 8) == 0 && max_mode >= 1)
-    return 1 + 1;
-  return quad_ok && (d % 4) == 0 && (J.d.stride % 4) == 0 ? 1 : 0;
+  if (J.kind != PLANE_SCALE)
+    return J.s.n == 1 && plane_simple16_kind (J.kind) && J.ow >= 16 && max_mode >= 2 ? 1 + (max_mode >= 3 ? QUAD_S8 : QUAD_16) : 0;
+  if (oct_ok && max_mode >= 1)
+    return 1 + QUAD_8;
+  return quad_ok ? 1 + QUAD_4 : 0;
 }
 
-// what a lane of k_plane_quad does for a job: QUAD_4 plane_quad_body, QUAD_8 plane_oct_body, QUAD_16 plane_simple16 (pass-free kinds)
-enum { QUAD_4 = 0, QUAD_8 = 1, QUAD_16 = 2 };
-
-GSTAMD_HD void plane_rows_body (const PlaneJob &J, int mode, int lane, int y0, int rows)
+// what a lane of k_plane_quad does for a job
+GSTAMD_HD void plane_rows_body (const PlaneJob &J, int lane, int y0, int rows, long long ds = 0, long long dd = 0, int nt = 0)
 {
-  if (mode == QUAD_8) {
-    if (J.s.n == 1)
-      plane_oct_body<1> (J, lane, y0, rows);
-    else
-      plane_oct_body<2> (J, lane, y0, rows);
-    return;
-  }
-  for (int r = 0; r < rows && y0 + r < J.oh; r++) {
-    if (mode == QUAD_16) {
-      const int x = 16 * lane;
-      if (x >= J.ow)
-        return;
-      if (x + 16 <= J.ow && plane_simple16 (J, x, y0 + r))
-        continue;
-      for (int q = 0; q < 4; q++)
-        plane_quad_body (J, 4 * lane + q, y0 + r);
-    } else {
-      plane_quad_body (J, lane, y0 + r);
-    }
-  }
+  const int mode = J.quad - 1;
+  if (mode == QUAD_16)
+    plane_simple16_body (J, lane, y0, rows, ds, dd, nt);
+  else if (mode == QUAD_S8)
+    plane_simple8_body (J, lane, y0, rows, ds, dd, nt);
+  else if (mode == QUAD_8 && J.s.n == 1 && J.dstep == 2)
+    plane_quad_body<1, 8, 2> (J, lane, y0, rows, ds, dd, nt);
+  else if (mode == QUAD_8 && J.s.n == 1)
+    plane_quad_body<1, 8, 0> (J, lane, y0, rows, ds, dd, nt);
+  else if (mode == QUAD_8 && J.dstep == 2)
+    plane_quad_body<2, 8, 2> (J, lane, y0, rows, ds, dd, nt);
+  else if (mode == QUAD_8)
+    plane_quad_body<2, 8, 0> (J, lane, y0, rows, ds, dd, nt);
+  else if (J.s.n == 1)
+    plane_quad_body<1, 4, 0> (J, lane, y0, rows, ds, dd, nt);
+  else
+    plane_quad_body<2, 4, 0> (J, lane, y0, rows, ds, dd, nt);
 }
 
 // does the plane go through plane_direct_body (host and device)

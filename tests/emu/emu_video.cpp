@@ -241,6 +241,21 @@ static void run_h420_reg_ch (const H420RegParams &p, int chroma_h, int n_taps)
 // workgroup from the bottom one up (a wave's hand-over copy exists before the wave above asks for it - on the device a flag says so) ----
 static int g_col_runs = 0;
 extern "C" int emu_col_runs (void) { return g_col_runs; }
+// quad_grid_find over a whole grid: 1 when every (job, workgroup) pair comes up exactly once
+extern "C" int emu_quad_grid_check (int n0, int n1, int n2)
+{
+  QuadGrid g;
+  memset (&g, 0, sizeof (g));
+  g.n[0] = n0, g.n[1] = n1, g.n[2] = n2;
+  std::vector<int> seen[3] = {std::vector<int> (n0, 0), std::vector<int> (n1, 0), std::vector<int> (n2, 0)};
+  for (int b = 0; b < n0 + n1 + n2; b++) {
+    int k = -1, local = -1;
+    quad_grid_find (g, b, &k, &local);
+    if (k < 0 || k > 2 || local < 0 || local >= g.n[k] || seen[k][local]++)
+      return 0;
+  }
+  return 1;
+}
 static int g_emu_deep16_runs = 0;
 static int g_emu_quad_runs = 0, g_emu_quad_modes = 0;
 extern "C" int emu_quad_modes (void) { const int m = g_emu_quad_modes; g_emu_quad_modes = 0; return m; }
@@ -1043,15 +1058,16 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       J.wide = pp.n_elems <= 2 && ((uintptr_t) J.d.p % unit) == 0 && (J.d.stride % unit) == 0;
       J.wide_src = ((uintptr_t) J.s.p % 8) == 0 && (J.s.stride % 8) == 0;
       J.tiles_x = (pp.ow + PLN_TW - 1) / PLN_TW;
-      J.quad = getenv ("GSTAMD_NO_PLANE_QUAD") ? 0 : plane_job_quad (J, plane_quad_ok (pp), plane_oct_ok (pp), getenv ("GSTAMD_PLANE_QUAD_MODE") ? atoi (getenv ("GSTAMD_PLANE_QUAD_MODE")) : 2);
+      J.dstep = getenv ("GSTAMD_PLANE_QUAD_NO_DSTEP") ? 0 : plane_quad_dstep (pp);
+      J.quad = getenv ("GSTAMD_NO_PLANE_QUAD") ? 0 : plane_job_quad (J, plane_quad_ok (pp), plane_quad_ok (pp, 8), getenv ("GSTAMD_PLANE_QUAD_MODE") ? atoi (getenv ("GSTAMD_PLANE_QUAD_MODE")) : 2);
       if (J.quad) {                           /* k_plane_quad over its grid: 64-lane waves, `rows` rows each */
         g_emu_quad_runs++;
         g_emu_quad_modes |= 1 << (J.quad - 1);
-        const int bytes = 4 << (J.quad - 1), rows = getenv ("GSTAMD_PLANE_QUAD_ROWS") ? atoi (getenv ("GSTAMD_PLANE_QUAD_ROWS")) : 3;
+        const int bytes = quad_mode_bytes (J.quad - 1), rows = getenv ("GSTAMD_PLANE_QUAD_ROWS") ? atoi (getenv ("GSTAMD_PLANE_QUAD_ROWS")) : 3;
         const int lanes = (((J.ow * J.s.n + bytes - 1) / bytes + 63) / 64) * 64;
         for (int y0 = 0; y0 < J.oh; y0 += rows)
           for (int lane = 0; lane < lanes; lane++)
-            plane_rows_body (J, J.quad - 1, lane, y0, rows);
+            plane_rows_body (J, lane, y0, rows);
         continue;
       }
       const int tiles = J.tiles_x * ((pp.oh + PLN_TH - 1) / PLN_TH);

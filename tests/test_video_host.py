@@ -485,3 +485,9 @@ def test_plane_quad_body_is_the_one_that_runs(native_lib, emu_lib, name, monkeyp
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
     assert emu_lib.emu_quad_runs() == before
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
+@pytest.mark.parametrize("counts", [(540, 540, 0), (540, 0, 0), (1, 1, 1), (7, 1000, 3), (1000, 7, 0), (0, 5, 9), (136, 34, 34), (3, 0, 8), (4097, 129, 77)])
+def test_plane_quad_grid_mapping_is_a_bijection(emu_lib, counts):
+    """k_plane_quad's workgroup -> (plane, workgroup of the plane) mapping: every pair exactly once"""
+    assert emu_lib.emu_quad_grid_check(counts[0], counts[1], counts[2]) == 1, counts

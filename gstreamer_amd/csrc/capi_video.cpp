@@ -682,6 +682,34 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
     c->sub_in->hook_on = true;
     return gstamd_video_converter_frame_planes (c->sub_in, src_planes, src_stride, dest_planes, dest_stride, stream);
   }
+  Enc16Params ep16;
+  if (enc16_params (p, &ep16) && !tuning_on ("GSTAMD_NO_ENCODE16") && src_planes[0]) {
+    /* unscaled, 4-byte 8-bit source, deep planar destination: one kernel from the frame to the frame (k_encode16) where the rows sit on the
+       words it moves */
+    const int ss = src_stride ? src_stride[0] : p.in_info.stride[0];
+    const uint8_t *sp = (const uint8_t *) src_planes[0] + plane_origin (p.fin, 0, p.rect.in_x, p.rect.in_y, ss);
+    uint8_t *planes[3] = {nullptr, nullptr, nullptr};
+    int strides[3] = {0, 0, 0};
+    bool ok = ((uintptr_t) sp % 16) == 0 && (ss % 16) == 0;
+    for (int i = 0; i < p.out_info.n_planes && i < 3; i++) {
+      planes[i] = (uint8_t *) dest_planes[i];
+      strides[i] = dest_stride ? dest_stride[i] : p.out_info.stride[i];
+      if (!planes[i])
+        return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+    }
+    uint8_t *rect[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < p.out_info.n_planes && i < 3; i++) {
+      rect[i] = planes[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, strides[i]);
+      ok = ok && ((uintptr_t) rect[i] % 8) == 0 && (strides[i] % 8) == 0;
+    }
+    if (ok) {
+      hipError_t e16;
+      if (p.rect.fill && (e16 = fill_borders (p, planes, strides, stream)) != hipSuccess)
+        return hip_fail (e16, "k_fill_border");
+      e16 = launch_encode16 (ep16, sp, ss, rect, strides, stream);
+      return e16 == hipSuccess ? GSTAMD_OK : hip_fail (e16, "k_encode16");
+    }
+  }
   const bool has_mid = g.prim.has_matrix || g.alpha_kind != ALPHA_NONE;
   const size_t n = p.passes.size ();
   hipError_t e;

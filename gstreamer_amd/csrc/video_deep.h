@@ -1202,4 +1202,164 @@ GSTAMD_HD void deep_planes16_body (const DeepPlanesParams &d, const DeepPlanesPt
   dq[1] = gstamd_make_uint4 (o[4], o[5], o[6], o[7]);
 }
 
+// ---- k_encode16: 4-byte 8-bit pixels -> 10 / 12 / 16-bit planar or semi-planar 4:2:0 / 4:2:2 YUV in one kernel ----------------------------
+// The composite plan (deep_out) makes three images in HBM on the way: the 8-bit unpack-order image of the sub-conversion, the AYUV64 image
+// of k_gamma_stage (widen + matrix16), and k_pack16 reads that one (BGRA 4K -> P010: 87 us for 58 MB of frame bytes).  When nothing scales,
+// the same integers come from the source pixels directly, a 4 x 2 (4 x 1 for 4:2:2) pixel block per lane as in video_encode_fast.h:
+//   unpack: byte positions (FormatDesc::pos); widen: byte * 257 (video_orc_convert_u8_to_u16), folded into the coefficients (im * (257 c)
+//   = (257 im) * c); video_converter_matrix16 (:1296-1320): (row . px + offset) >> 8, clamped to 0 .. 65535; chroma downsampling on the
+//   16-bit values (video_orc_chroma_down_v2_u16 = avguw of the line pair, then _h2_u16 / video_chroma_down_h2_cs_u16: pack16_body's
+//   rules); ordered dither per stored sample at its picture position (dither16_comp); pack (pack16_sample).
+struct Enc16Params {
+  int width, height;
+  int sh[3];                    // bit position of the source byte of unpacked components 1, 2, 3 (R G B / Y U V)
+  int has_matrix;
+  int cf[3][3], off[3];         // 257 * im[k][j] (24-bit operands), im[k][3]
+  int hi_depth;
+  PackPlanarParams pk;
+  DitherParams dt;
+};
+
+// host: does the plan go this way?  (`p` is a deep_out plan whose pack16 finishes it)
+inline bool enc16_params (const VideoPlan &p, Enc16Params *ep)
+{
+  const GammaPlan &g = p.gamma;
+  if (!g.on || !g.pack16 || g.src16 || g.src64 || g.store64 || g.planes_fast || g.fused || !p.passes.empty () || !g.dec16.empty () || !g.enc16.empty ())
+    return false;
+  if (p.fin->kind != UNPACK_PACKED4 || p.fin->hi_depth != 0 || g.to_rgb.kind != 0 || g.to_yuv.kind != 0)
+    return false;
+  if (g.mid_in.width != g.mid_out.width || g.mid_in.height != g.mid_out.height || p.in_info.width != p.out_info.width || p.in_info.height != p.out_info.height)
+    return false;
+  if ((g.pack.kind != UNPACK_PLANAR && g.pack.kind != UNPACK_SEMI) || g.pack.w_sub != 1 || (g.pack.width % 4) != 0 || g.pack.width < 4 || g.pack.virtual_line)
+    return false;
+  if (g.dither16.on && (g.dither16.method != GSTAMD_DITHER_BAYER || g.dither16.shift[1] != g.dither16.shift[2] || g.dither16.shift[1] != g.dither16.shift[3]))
+    return false;
+  memset (ep, 0, sizeof (*ep));
+  ep->width = g.pack.width, ep->height = g.pack.height;
+  for (int j = 0; j < 3; j++)
+    ep->sh[j] = 8 * p.fin->pos[j + 1];
+  ep->has_matrix = g.prim.has_matrix;
+  for (int k = 0; k < 3; k++) {
+    for (int j = 0; j < 3; j++) {
+      const long long c = 257ll * g.prim.im[k][j];
+      if (c <= -(1 << 23) || c >= (1 << 23))
+        return false;
+      ep->cf[k][j] = (int) c;
+    }
+    ep->off[k] = g.prim.im[k][3];
+  }
+  ep->hi_depth = g.pack_hi_depth;
+  ep->pk = g.pack;
+  ep->dt = g.dither16;
+  return true;
+}
+
+// unpacked component K (0, 1, 2 = Y U V / what the matrix makes of R G B) of a source pixel, 16 bits
+template <int K>
+GSTAMD_HD int enc16_comp (const Enc16Params &ep, uint32_t px)
+{
+  const int c0 = (int) ((px >> ep.sh[0]) & 0xffu), c1 = (int) ((px >> ep.sh[1]) & 0xffu), c2 = (int) ((px >> ep.sh[2]) & 0xffu);
+  if (!ep.has_matrix)
+    return (K == 0 ? c0 : K == 1 ? c1 : c2) * 257;
+  const int v = (mul24s (ep.cf[K][0], c0) + mul24s (ep.cf[K][1], c1) + mul24s (ep.cf[K][2], c2) + ep.off[K]) >> 8;
+  return v < 0 ? 0 : (v > 65535 ? 65535 : v);
+}
+
+GSTAMD_HD uint32_t enc16_sample (const Enc16Params &ep, int v, int bayer)
+{
+  return pack16_sample (ep.hi_depth, dither16_with (ep.dt, 1, v, bayer));
+}
+
+// one lane: pixels x0 .. x0 + 3 (x0 % 4 == 0) of the lines (yb << h_sub) ..; source rows on 16 bytes, luma rows on 8, chroma rows on 8 (semi) / 4
+template <int SEMI>
+GSTAMD_HD void enc16_block (const Enc16Params &ep, const uint8_t *__restrict__ src, int sstride, const DstPlanes16 &d, int x0, int yb, long long ds = 0, long long dd = 0)
+{
+  const int w = ep.width, h = ep.height, h_sub = ep.pk.h_sub;
+  const int y0 = yb << h_sub;
+  if (x0 >= w || y0 >= h)
+    return;
+  const int y1 = h_sub && y0 + 1 < h ? y0 + 1 : y0;
+  const uint8_t *row0 = src + ds + (size_t) y0 * sstride, *row1 = src + ds + (size_t) y1 * sstride;
+  const uint4 a = *(const uint4 *) (row0 + 4 * (size_t) x0);
+  uint4 b = a;
+  if (h_sub)
+    b = *(const uint4 *) (row1 + 4 * (size_t) x0);
+  uint32_t am = a.x, bm = b.x;
+  if (ep.pk.down_h == 2 && x0 > 0) {
+    am = *(const uint32_t *) (row0 + 4 * (size_t) (x0 - 1));
+    bm = *(const uint32_t *) (row1 + 4 * (size_t) (x0 - 1));
+  }
+  const uint32_t pa[5] = {am, a.x, a.y, a.z, a.w}, pb[5] = {bm, b.x, b.y, b.z, b.w};            /* pixels x0 - 1 .. x0 + 3 */
+  /* luma */
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int y = r ? y1 : y0;
+    if (r && y1 == y0)
+      break;
+    const uint2 brow = ep.dt.on ? dither_bayer_row8 (x0 & ~7, y + ep.dt.y0) : gstamd_make_uint2 (0, 0);
+    const uint32_t bw = (x0 & 4) ? brow.y : brow.x;
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      o[i] = enc16_sample (ep, enc16_comp<0> (ep, r ? pb[i + 1] : pa[i + 1]), (int) ((bw >> (8 * i)) & 0xffu));
+    uint2 st;
+    st.x = o[0] | (o[1] << 16), st.y = o[2] | (o[3] << 16);
+    *(uint2 *) (d.p[0] + dd + (size_t) y * d.stride[0] + 2 * (size_t) x0) = st;
+  }
+  /* chroma of pixels x0 - 1 .. x0 + 3, the line pair averaged first */
+  int cu[5], cv[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    if (i == 0 && ep.pk.down_h != 2) {
+      cu[i] = cv[i] = 0;
+      continue;
+    }
+    if ((i == 2 || i == 4) && ep.pk.down_h == 0) {
+      cu[i] = cv[i] = 0;
+      continue;
+    }
+    int u = enc16_comp<1> (ep, pa[i]), v = enc16_comp<2> (ep, pa[i]);
+    if (ep.pk.down_v) {
+      u = (u + enc16_comp<1> (ep, pb[i]) + 1) >> 1;          /* avguw */
+      v = (v + enc16_comp<2> (ep, pb[i]) + 1) >> 1;
+    }
+    cu[i] = u, cv[i] = v;
+  }
+  const uint2 crow = ep.dt.on ? dither_bayer_row8 (x0 & ~7, y0 + ep.dt.y0) : gstamd_make_uint2 (0, 0);
+  const uint32_t cw = (x0 & 4) ? crow.y : crow.x;
+  uint32_t pu[2], pv[2];
+#pragma unroll
+  for (int i = 0; i < 4; i += 2) {
+    const int x = x0 + i;
+    int u = cu[i + 1], v = cv[i + 1];
+    if (ep.pk.down_h == 1) {
+      u = (cu[i + 1] + cu[i + 2] + 1) >> 1;
+      v = (cv[i + 1] + cv[i + 2] + 1) >> 1;
+    } else if (ep.pk.down_h == 2) {
+      if (x == 0) {
+        u = (3 * cu[i + 1] + cu[i + 2] + 2) >> 2;
+        v = (3 * cv[i + 1] + cv[i + 2] + 2) >> 2;
+      } else if (x < w - 2) {
+        u = (cu[i] + 2 * cu[i + 1] + cu[i + 2] + 2) >> 2;
+        v = (cv[i] + 2 * cv[i + 1] + cv[i + 2] + 2) >> 2;
+      } else {
+        u = (cu[i] + 3 * cu[i + 1] + 2) >> 2;
+        v = (cv[i] + 3 * cv[i + 1] + 2) >> 2;
+      }
+    }
+    const int bv = (int) ((cw >> (8 * i)) & 0xffu);
+    pu[i >> 1] = enc16_sample (ep, u, bv);
+    pv[i >> 1] = enc16_sample (ep, v, bv);
+  }
+  if (SEMI) {
+    uint2 st;
+    st.x = ep.pk.u_plane ? pu[0] | (pv[0] << 16) : pv[0] | (pu[0] << 16);
+    st.y = ep.pk.u_plane ? pu[1] | (pv[1] << 16) : pv[1] | (pu[1] << 16);
+    *(uint2 *) (d.p[1] + dd + (size_t) yb * d.stride[1] + 2 * (size_t) x0) = st;
+  } else {
+    *(uint32_t *) (d.p[ep.pk.u_plane] + dd + (size_t) yb * d.stride[ep.pk.u_plane] + (size_t) x0) = pu[0] | (pu[1] << 16);
+    *(uint32_t *) (d.p[ep.pk.v_plane] + dd + (size_t) yb * d.stride[ep.pk.v_plane] + (size_t) x0) = pv[0] | (pv[1] << 16);
+  }
+}
+
 }  // namespace gstamd

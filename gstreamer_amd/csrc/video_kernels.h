@@ -30,6 +30,7 @@ hipError_t launch_convert16 (const FrontParams &f, const Planes &pl, const int *
 hipError_t launch_convert_gamma (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color, const int pack_pos[4], uint8_t *dst,
     int dstride, const GammaDev &g, hipStream_t stream);
 hipError_t launch_deep_planes (const DeepPlanesParams &d, const DeepPlanesPtrs &pp, hipStream_t stream);
+hipError_t launch_encode16 (const Enc16Params &ep, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3], hipStream_t stream);
 hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *src, int sstride, uint8_t *const planes[3],
     const int strides[3], hipStream_t stream);
 hipError_t launch_gamma_stage (const GammaDev &g, int mask, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int w, int h, hipStream_t stream);

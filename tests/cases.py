@@ -614,6 +614,24 @@ VIDEO_CASES = [
     ("planes_i420_10_p010_720p", "I420_10LE", 1280, 720, "P010_10LE", 1280, 720, {}, None, None, "random"),
     ("planes_p010_yv12_odd", "P010_10LE", 643, 361, "YV12", 643, 361, {}, None, None, "random"),
     ("planes_nv12_p010_4k", "NV12", 3840, 2160, "P010_10LE", 3840, 2160, {}, None, None, "random"),
+    # k_encode16: 4-byte 8-bit pixels straight into deep planar / semi-planar 4:2:0 / 4:2:2 YUV (widen, matrix16, chroma down, dither, pack in one kernel)
+    ("enc16_bgra_p010_cosited", "BGRA", 64, 36, "P010_10LE", 64, 36, {}, None, "cosited", "random"),
+    ("enc16_rgba_p010_odd_height", "RGBA", 64, 37, "P010_10LE", 64, 37, {}, None, None, "random"),
+    ("enc16_argb_p012", "ARGB", 128, 20, "P012_LE", 128, 20, {}, None, None, "random"),
+    ("enc16_xrgb_p016", "xRGB", 64, 36, "P016_LE", 64, 36, {}, None, None, "random"),
+    ("enc16_bgrx_i422_12_cosited", "BGRx", 64, 19, "I422_12LE", 64, 19, {}, None, "cosited", "random"),
+    ("enc16_ayuv_p010_no_matrix", "AYUV", 64, 36, "P010_10LE", 64, 36, {}, None, None, "random"),
+    ("enc16_vuya_i420_10", "VUYA", 64, 36, "I420_10LE", 64, 36, {}, None, None, "random"),
+    ("enc16_ayuv_p010_bt601_to_bt2020", "AYUV", 64, 36, "P010_10LE", 64, 36, {}, "bt601>bt2020-10", None, "random"),
+    ("enc16_bgra_p010_ones", "BGRA", 64, 36, "P010_10LE", 64, 36, {}, None, None, "ones"),
+    ("enc16_bgra_p010_zeros", "BGRA", 64, 36, "P010_10LE", 64, 36, {}, None, None, "zeros"),
+    ("enc16_bgra_p010_no_dither", "BGRA", 64, 36, "P010_10LE", 64, 36, dict(dither_method="none"), None, None, "random"),
+    ("enc16_bgra_p010_q256", "BGRA", 64, 36, "P010_10LE", 64, 36, dict(dither_quantization=256), None, None, "random"),
+    ("enc16_bgra_p010_q2048", "BGRA", 64, 36, "P010_10LE", 64, 36, dict(dither_quantization=2048), None, None, "random"),
+    ("enc16_bgra_p010_crop_dest", "BGRA", 128, 96, "P010_10LE", 160, 120, dict(src_x=16, src_y=8, src_width=96, src_height=64, dest_x=24, dest_y=16, dest_width=96, dest_height=64), None, None, "random"),
+    ("enc16_bgra_p010_width_not_4", "BGRA", 66, 36, "P010_10LE", 66, 36, {}, None, None, "random"),
+    ("enc16_bgra_p010_1080p", "BGRA", 1920, 1080, "P010_10LE", 1920, 1080, {}, None, None, "random"),
+    ("enc16_bgra_i420_10_4k", "BGRA", 3840, 2160, "I420_10LE", 3840, 2160, {}, None, None, "random"),
     # k_plane_quad: both passes of a plane read at most two source pixels per output and four output bytes depend on at most 8 source bytes
     ("quad_i420_4_3_down_bilinear", "I420", 640, 480, "I420", 480, 360, LIN, None, None, "random"),
     ("quad_i420_3_2_down_bilinear", "I420", 640, 480, "I420", 426, 320, LIN, None, None, "random"),

@@ -257,6 +257,8 @@ extern "C" int emu_quad_grid_check (int n0, int n1, int n2)
   return 1;
 }
 static int g_emu_deep16_runs = 0;
+static int g_emu_enc16_runs = 0;
+extern "C" int emu_enc16_runs (void) { return g_emu_enc16_runs; }
 static int g_emu_quad_runs = 0, g_emu_quad_modes = 0;
 extern "C" int emu_quad_modes (void) { const int m = g_emu_quad_modes; g_emu_quad_modes = 0; return m; }
 extern "C" int emu_quad_runs (void) { return g_emu_quad_runs; }
@@ -888,6 +890,32 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       plan_set_border_override (nullptr);
       g_gamma_hook = nullptr;
       return r;
+    }
+    Enc16Params ep16;
+    if (enc16_params (p, &ep16) && getenv ("GSTAMD_NO_ENCODE16") == nullptr) {          /* k_encode16 over its grid */
+      const uint8_t *sp = src + in->offset[0] + plane_origin (p.fin, 0, p.rect.in_x, p.rect.in_y, in->stride[0]);
+      DstPlanes16 d;
+      memset (&d, 0, sizeof (d));
+      bool ok = vec_ok && ((uintptr_t) sp % 16) == 0 && (in->stride[0] % 16) == 0;
+      for (int i = 0; i < out->n_planes && i < 3; i++) {
+        d.p[i] = dst + out->offset[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]);
+        d.stride[i] = out->stride[i];
+        ok = ok && ((uintptr_t) d.p[i] % 8) == 0 && (d.stride[i] % 8) == 0;
+      }
+      if (ok) {
+        g_emu_enc16_runs++;
+        if (p.rect.fill)
+          emu_fill_borders (p, out, dst);
+        const int rows = (ep16.height + (1 << ep16.pk.h_sub) - 1) >> ep16.pk.h_sub;
+        for (int yb = 0; yb < rows; yb++)
+          for (int x0 = 0; x0 < (ep16.width / 4 + 63) / 64 * 256; x0 += 4) {
+            if (ep16.pk.kind == UNPACK_SEMI)
+              enc16_block<1> (ep16, sp, in->stride[0], d, x0, yb);
+            else
+              enc16_block<0> (ep16, sp, in->stride[0], d, x0, yb);
+          }
+        return GSTAMD_OK;
+      }
     }
     const bool has_mid = g.prim.has_matrix || g.alpha_kind != ALPHA_NONE;
     const size_t n = p.passes.size ();

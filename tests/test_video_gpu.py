@@ -228,6 +228,7 @@ LIST_PLANS = [      # (id, in, w, h, out, ow, oh, config, list launches expected
     ("p010_out", "NV12", 1920, 1080, "P010_10LE", 1920, 1080, {}, 1),
     ("p010_in", "P010_10LE", 1920, 1080, "NV12", 1920, 1080, {}, 1),
     ("i420_10_in", "I420_10LE", 1280, 720, "I420", 1280, 720, {}, 1),
+    ("encode16", "BGRA", 1280, 720, "P010_10LE", 1280, 720, {}, 1),
     ("gamma_remap", "NV12", 1920, 1080, "BGRA", 1920, 1080, dict(gamma_mode="remap"), 1),
     ("odd_size", "YUY2", 322, 242, "I420", 322, 242, {}, -1),
     ("two_pass_lanczos", "BGRA", 640, 360, "RGBA", 500, 300, cases.LAN, 0),

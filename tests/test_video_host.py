@@ -491,3 +491,21 @@ def test_plane_quad_body_is_the_one_that_runs(native_lib, emu_lib, name, monkeyp
 def test_plane_quad_grid_mapping_is_a_bijection(emu_lib, counts):
     """k_plane_quad's workgroup -> (plane, workgroup of the plane) mapping: every pair exactly once"""
     assert emu_lib.emu_quad_grid_check(counts[0], counts[1], counts[2]) == 1, counts
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("enc16_") and c[2] * c[3] <= 1280 * 720])
+def test_encode16_body_is_the_one_that_runs(native_lib, emu_lib, name, monkeypatch):
+    """the enc16_* cases go through enc16_block (frame to frame in one kernel) - all but the one whose width is no multiple of 4 - and through
+    the three-stage composite with GSTAMD_NO_ENCODE16, with the reference's bytes either way"""
+    _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    emu_lib.emu_enc16_runs.restype = C.c_int
+    before = emu_lib.emu_enc16_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_enc16_runs() - before == (0 if "width_not_4" in name else 1)
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+    monkeypatch.setenv("GSTAMD_NO_ENCODE16", "1")
+    before = emu_lib.emu_enc16_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_enc16_runs() == before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]

@@ -1622,7 +1622,9 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     }
     return GSTAMD_OK;
   }
-  if (p.gamma.on && !p.gamma.planes_fast) {
+  Enc16Params ep16_list;
+  const bool enc16_list = p.gamma.on && enc16_params (p, &ep16_list) && !tuning_on ("GSTAMD_NO_ENCODE16");         /* k_encode16: one kernel, takes lists */
+  if (p.gamma.on && !p.gamma.planes_fast && !enc16_list) {
     for (int i = 0; i < n_frames; i++)
       if ((r = gstamd_video_converter_frame (c, src[i], dest[i], stream_)) != GSTAMD_OK)
         return r;
@@ -1724,7 +1726,7 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
   /* plans that convert a frame in ONE launch of a kernel that takes frame lists (video_kernels.hip: the list is the grid's third
      dimension): frame `base` is converted with the list of up to 32 frames behind it armed; the launcher says whether it took the list */
   int base = 0;
-  if (!p.rect.fill && !p.dither.on && (!p.gamma.on || p.gamma.planes_fast)) {
+  if (!p.rect.fill && !p.dither.on && (!p.gamma.on || p.gamma.planes_fast || enc16_list)) {
     while (n_frames - base >= 2) {
       const int nb = std::min (n_frames - base, 32);
       for (int i = 0; i < nb; i++)

@@ -1215,6 +1215,9 @@ struct Enc16Params {
   int sh[3];                    // bit position of the source byte of unpacked components 1, 2, 3 (R G B / Y U V)
   int has_matrix;
   int cf[3][3], off[3];         // 257 * im[k][j] (24-bit operands), im[k][3]
+  int dot;                      // every |im[k][j]| <= 255: the rows as byte dot products on the pixel word
+  uint32_t cpos[3], cneg[3];    // |im[k][j]| of the positive / negative entries at the source byte of component j
+  int neg_mask;                 // bit k: row k has negative entries
   int hi_depth;
   PackPlanarParams pk;
   DitherParams dt;
@@ -1248,48 +1251,111 @@ inline bool enc16_params (const VideoPlan &p, Enc16Params *ep)
     }
     ep->off[k] = g.prim.im[k][3];
   }
+  ep->dot = 1;
+  for (int k = 0; k < 3; k++)
+    for (int j = 0; j < 3; j++) {
+      const int cf = g.prim.im[k][j];
+      ep->dot = ep->dot && cf >= -255 && cf <= 255;
+      if (cf >= 0)
+        ep->cpos[k] |= ((uint32_t) cf & 0xffu) << ep->sh[j];
+      else {
+        ep->cneg[k] |= ((uint32_t) (-cf) & 0xffu) << ep->sh[j];
+        ep->neg_mask |= 1 << k;
+      }
+    }
   ep->hi_depth = g.pack_hi_depth;
   ep->pk = g.pack;
   ep->dt = g.dither16;
   return true;
 }
 
-// unpacked component K (0, 1, 2 = Y U V / what the matrix makes of R G B) of a source pixel, 16 bits
+GSTAMD_HD uint32_t dot4_u8_16 (uint32_t a, uint32_t b, uint32_t c)         // sum of the four byte products + c: v_dot4_u32_u8
+{
+#ifdef __HIPCC__
+  return __builtin_amdgcn_udot4 (a, b, c, false);
+#else
+  uint32_t r = c;
+  for (int i = 0; i < 4; i++)
+    r += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
+  return r;
+#endif
+}
+
+// unpacked component K (0, 1, 2 = Y U V / what the matrix makes of R G B) of a source pixel, 16 bits.  Coefficients of at most 8 bits
+// (every Y'CbCr matrix between the usual ranges): the row is two byte dot products on the pixel word, positive and negative entries apart
+// (video_encode_fast.h), then (257 s + offset) >> 8; larger ones: three 24-bit multiplies on the unpacked bytes
 template <int K>
 GSTAMD_HD int enc16_comp (const Enc16Params &ep, uint32_t px)
 {
-  const int c0 = (int) ((px >> ep.sh[0]) & 0xffu), c1 = (int) ((px >> ep.sh[1]) & 0xffu), c2 = (int) ((px >> ep.sh[2]) & 0xffu);
   if (!ep.has_matrix)
-    return (K == 0 ? c0 : K == 1 ? c1 : c2) * 257;
-  const int v = (mul24s (ep.cf[K][0], c0) + mul24s (ep.cf[K][1], c1) + mul24s (ep.cf[K][2], c2) + ep.off[K]) >> 8;
+    return (int) ((px >> ep.sh[K]) & 0xffu) * 257;
+  int s;
+  if (ep.dot) {
+    s = (int) dot4_u8_16 (px, ep.cpos[K], 0u) - (ep.neg_mask & (1 << K) ? (int) dot4_u8_16 (px, ep.cneg[K], 0u) : 0);
+    s = mul24s (s, 257) + ep.off[K];
+  } else {
+    const int c0 = (int) ((px >> ep.sh[0]) & 0xffu), c1 = (int) ((px >> ep.sh[1]) & 0xffu), c2 = (int) ((px >> ep.sh[2]) & 0xffu);
+    s = mul24s (ep.cf[K][0], c0) + mul24s (ep.cf[K][1], c1) + mul24s (ep.cf[K][2], c2) + ep.off[K];
+  }
+  const int v = s >> 8;
   return v < 0 ? 0 : (v > 65535 ? 65535 : v);
 }
 
-GSTAMD_HD uint32_t enc16_sample (const Enc16Params &ep, int v, int bayer)
+// the dither values of columns c0, c1 of a matrix row's word, as the 16-bit pair a sample pair takes (>> (8 - shift), dither16_with)
+GSTAMD_HD uint32_t enc16_dither_pair (const Enc16Params &ep, uint32_t bw, uint32_t sel)
 {
-  return pack16_sample (ep.hi_depth, dither16_with (ep.dt, 1, v, bayer));
+  if (!ep.dt.on)
+    return 0u;
+  const int sh = ep.dt.shift[1];
+  const uint32_t eb = sh < 8 ? (bw >> (8 - sh)) & ((0xffu >> (8 - sh)) * 0x01010101u) : bw;
+  return bperm (0u, eb, sel);
 }
 
-// one lane: pixels x0 .. x0 + 3 (x0 % 4 == 0) of the lines (yb << h_sub) ..; source rows on 16 bytes, luma rows on 8, chroma rows on 8 (semi) / 4
-template <int SEMI>
+// two samples (v0 | v1 << 16) through the dither (saturating add, & ~(quantiser - 1)) and the packer (& ~((1 << drop) - 1), or >> drop)
+GSTAMD_HD uint32_t enc16_finish_pair (const Enc16Params &ep, uint32_t v2, uint32_t e2)
+{
+  uint32_t q = v2;
+  if (ep.dt.on)
+    q = pk_adds16 (v2, e2) & ((0xffffu & ~((1u << ep.dt.shift[1]) - 1u)) * 0x00010001u);
+  if (ep.hi_depth == 6)
+    return q;
+  const int drop = 16 - hi_depth_bits (ep.hi_depth);
+  if (ep.hi_depth == 1 || ep.hi_depth == 4)
+    return (q >> drop) & ((0xffffu >> drop) * 0x00010001u);
+  return q & ((0xffffu & ~((1u << drop) - 1u)) * 0x00010001u);
+}
+
+// one lane: pixels x0 .. x0 + 4 NB - 1 (x0 % (4 NB) == 0) of the lines (yb << h_sub) ..; source rows on 16 bytes, destination rows on 8 NB
+template <int SEMI, int NB>
 GSTAMD_HD void enc16_block (const Enc16Params &ep, const uint8_t *__restrict__ src, int sstride, const DstPlanes16 &d, int x0, int yb, long long ds = 0, long long dd = 0)
 {
+  const int NPX = 4 * NB;
   const int w = ep.width, h = ep.height, h_sub = ep.pk.h_sub;
   const int y0 = yb << h_sub;
   if (x0 >= w || y0 >= h)
     return;
   const int y1 = h_sub && y0 + 1 < h ? y0 + 1 : y0;
   const uint8_t *row0 = src + ds + (size_t) y0 * sstride, *row1 = src + ds + (size_t) y1 * sstride;
-  const uint4 a = *(const uint4 *) (row0 + 4 * (size_t) x0);
-  uint4 b = a;
-  if (h_sub)
-    b = *(const uint4 *) (row1 + 4 * (size_t) x0);
-  uint32_t am = a.x, bm = b.x;
-  if (ep.pk.down_h == 2 && x0 > 0) {
-    am = *(const uint32_t *) (row0 + 4 * (size_t) (x0 - 1));
-    bm = *(const uint32_t *) (row1 + 4 * (size_t) (x0 - 1));
+  uint32_t pa[NPX + 1], pb[NPX + 1];                  /* pixels x0 - 1 .. x0 + NPX - 1 of the two lines */
+#pragma unroll
+  for (int g = 0; g < NB; g++) {
+    const uint4 a = *(const uint4 *) (row0 + 4 * (size_t) (x0 + 4 * g));
+    pa[4 * g + 1] = a.x, pa[4 * g + 2] = a.y, pa[4 * g + 3] = a.z, pa[4 * g + 4] = a.w;
   }
-  const uint32_t pa[5] = {am, a.x, a.y, a.z, a.w}, pb[5] = {bm, b.x, b.y, b.z, b.w};            /* pixels x0 - 1 .. x0 + 3 */
+#pragma unroll
+  for (int g = 0; g < NB; g++) {
+    if (h_sub) {
+      const uint4 b = *(const uint4 *) (row1 + 4 * (size_t) (x0 + 4 * g));
+      pb[4 * g + 1] = b.x, pb[4 * g + 2] = b.y, pb[4 * g + 3] = b.z, pb[4 * g + 4] = b.w;
+    } else {
+      pb[4 * g + 1] = pa[4 * g + 1], pb[4 * g + 2] = pa[4 * g + 2], pb[4 * g + 3] = pa[4 * g + 3], pb[4 * g + 4] = pa[4 * g + 4];
+    }
+  }
+  pa[0] = pa[1], pb[0] = pb[1];
+  if (ep.pk.down_h == 2 && x0 > 0) {
+    pa[0] = *(const uint32_t *) (row0 + 4 * (size_t) (x0 - 1));
+    pb[0] = *(const uint32_t *) (row1 + 4 * (size_t) (x0 - 1));
+  }
   /* luma */
 #pragma unroll
   for (int r = 0; r < 2; r++) {
@@ -1297,24 +1363,28 @@ GSTAMD_HD void enc16_block (const Enc16Params &ep, const uint8_t *__restrict__ s
     if (r && y1 == y0)
       break;
     const uint2 brow = ep.dt.on ? dither_bayer_row8 (x0 & ~7, y + ep.dt.y0) : gstamd_make_uint2 (0, 0);
-    const uint32_t bw = (x0 & 4) ? brow.y : brow.x;
-    uint32_t o[4];
+    uint32_t st[2 * NB];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      o[i] = enc16_sample (ep, enc16_comp<0> (ep, r ? pb[i + 1] : pa[i + 1]), (int) ((bw >> (8 * i)) & 0xffu));
-    uint2 st;
-    st.x = o[0] | (o[1] << 16), st.y = o[2] | (o[3] << 16);
-    *(uint2 *) (d.p[0] + dd + (size_t) y * d.stride[0] + 2 * (size_t) x0) = st;
-  }
-  /* chroma of pixels x0 - 1 .. x0 + 3, the line pair averaged first */
-  int cu[5], cv[5];
-#pragma unroll
-  for (int i = 0; i < 5; i++) {
-    if (i == 0 && ep.pk.down_h != 2) {
-      cu[i] = cv[i] = 0;
-      continue;
+    for (int g = 0; g < NB; g++) {
+      const uint32_t bw = NB == 2 ? (g ? brow.y : brow.x) : ((x0 & 4) ? brow.y : brow.x);
+      const uint32_t *px = (r ? pb : pa) + 4 * g + 1;
+      const uint32_t v01 = (uint32_t) enc16_comp<0> (ep, px[0]) | ((uint32_t) enc16_comp<0> (ep, px[1]) << 16);
+      const uint32_t v23 = (uint32_t) enc16_comp<0> (ep, px[2]) | ((uint32_t) enc16_comp<0> (ep, px[3]) << 16);
+      st[2 * g] = enc16_finish_pair (ep, v01, enc16_dither_pair (ep, bw, 0x0c010c00u));
+      st[2 * g + 1] = enc16_finish_pair (ep, v23, enc16_dither_pair (ep, bw, 0x0c030c02u));
     }
-    if ((i == 2 || i == 4) && ep.pk.down_h == 0) {
+    uint8_t *q = d.p[0] + dd + (size_t) y * d.stride[0] + 2 * (size_t) x0;
+    if (NB == 2)
+      *(uint4 *) q = gstamd_make_uint4 (st[0], st[1], st[2], st[2 * NB - 1]);
+    else
+      *(uint2 *) q = gstamd_make_uint2 (st[0], st[1]);
+  }
+  /* chroma of pixels x0 - 1 .. x0 + NPX - 1, the line pair averaged first */
+  int cu[NPX + 1], cv[NPX + 1];
+#pragma unroll
+  for (int i = 0; i < NPX + 1; i++) {
+    const bool needed = ep.pk.down_h == 2 ? true : (ep.pk.down_h == 1 ? i >= 1 : (i & 1) == 1);
+    if (!needed) {
       cu[i] = cv[i] = 0;
       continue;
     }
@@ -1326,39 +1396,58 @@ GSTAMD_HD void enc16_block (const Enc16Params &ep, const uint8_t *__restrict__ s
     cu[i] = u, cv[i] = v;
   }
   const uint2 crow = ep.dt.on ? dither_bayer_row8 (x0 & ~7, y0 + ep.dt.y0) : gstamd_make_uint2 (0, 0);
-  const uint32_t cw = (x0 & 4) ? crow.y : crow.x;
-  uint32_t pu[2], pv[2];
+  uint32_t pu[NB], pv[NB];                            /* the group's two chroma positions as a pair */
 #pragma unroll
-  for (int i = 0; i < 4; i += 2) {
-    const int x = x0 + i;
-    int u = cu[i + 1], v = cv[i + 1];
-    if (ep.pk.down_h == 1) {
-      u = (cu[i + 1] + cu[i + 2] + 1) >> 1;
-      v = (cv[i + 1] + cv[i + 2] + 1) >> 1;
-    } else if (ep.pk.down_h == 2) {
-      if (x == 0) {
-        u = (3 * cu[i + 1] + cu[i + 2] + 2) >> 2;
-        v = (3 * cv[i + 1] + cv[i + 2] + 2) >> 2;
-      } else if (x < w - 2) {
-        u = (cu[i] + 2 * cu[i + 1] + cu[i + 2] + 2) >> 2;
-        v = (cv[i] + 2 * cv[i + 1] + cv[i + 2] + 2) >> 2;
-      } else {
-        u = (cu[i] + 3 * cu[i + 1] + 2) >> 2;
-        v = (cv[i] + 3 * cv[i + 1] + 2) >> 2;
+  for (int g = 0; g < NB; g++) {
+    int uu[2], vv[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int i = 4 * g + 2 * t, x = x0 + i;
+      int u = cu[i + 1], v = cv[i + 1];
+      if (ep.pk.down_h == 1) {
+        u = (cu[i + 1] + cu[i + 2] + 1) >> 1;
+        v = (cv[i + 1] + cv[i + 2] + 1) >> 1;
+      } else if (ep.pk.down_h == 2) {
+        if (x == 0) {
+          u = (3 * cu[i + 1] + cu[i + 2] + 2) >> 2;
+          v = (3 * cv[i + 1] + cv[i + 2] + 2) >> 2;
+        } else if (x < w - 2) {
+          u = (cu[i] + 2 * cu[i + 1] + cu[i + 2] + 2) >> 2;
+          v = (cv[i] + 2 * cv[i + 1] + cv[i + 2] + 2) >> 2;
+        } else {
+          u = (cu[i] + 3 * cu[i + 1] + 2) >> 2;
+          v = (cv[i] + 3 * cv[i + 1] + 2) >> 2;
+        }
       }
+      uu[t] = u, vv[t] = v;
     }
-    const int bv = (int) ((cw >> (8 * i)) & 0xffu);
-    pu[i >> 1] = enc16_sample (ep, u, bv);
-    pv[i >> 1] = enc16_sample (ep, v, bv);
+    const uint32_t bw = NB == 2 ? (g ? crow.y : crow.x) : ((x0 & 4) ? crow.y : crow.x);
+    const uint32_t e = enc16_dither_pair (ep, bw, 0x0c020c00u);
+    pu[g] = enc16_finish_pair (ep, (uint32_t) uu[0] | ((uint32_t) uu[1] << 16), e);
+    pv[g] = enc16_finish_pair (ep, (uint32_t) vv[0] | ((uint32_t) vv[1] << 16), e);
   }
   if (SEMI) {
-    uint2 st;
-    st.x = ep.pk.u_plane ? pu[0] | (pv[0] << 16) : pv[0] | (pu[0] << 16);
-    st.y = ep.pk.u_plane ? pu[1] | (pv[1] << 16) : pv[1] | (pu[1] << 16);
-    *(uint2 *) (d.p[1] + dd + (size_t) yb * d.stride[1] + 2 * (size_t) x0) = st;
+    uint32_t st[2 * NB];
+#pragma unroll
+    for (int g = 0; g < NB; g++) {
+      const uint32_t c0 = ep.pk.u_plane ? pu[g] : pv[g], c1 = ep.pk.u_plane ? pv[g] : pu[g];
+      st[2 * g] = bperm (c1, c0, 0x05040100u), st[2 * g + 1] = bperm (c1, c0, 0x07060302u);
+    }
+    uint8_t *q = d.p[1] + dd + (size_t) yb * d.stride[1] + 2 * (size_t) x0;
+    if (NB == 2)
+      *(uint4 *) q = gstamd_make_uint4 (st[0], st[1], st[2], st[2 * NB - 1]);
+    else
+      *(uint2 *) q = gstamd_make_uint2 (st[0], st[1]);
   } else {
-    *(uint32_t *) (d.p[ep.pk.u_plane] + dd + (size_t) yb * d.stride[ep.pk.u_plane] + (size_t) x0) = pu[0] | (pu[1] << 16);
-    *(uint32_t *) (d.p[ep.pk.v_plane] + dd + (size_t) yb * d.stride[ep.pk.v_plane] + (size_t) x0) = pv[0] | (pv[1] << 16);
+    uint8_t *qu = d.p[ep.pk.u_plane] + dd + (size_t) yb * d.stride[ep.pk.u_plane] + (size_t) x0;
+    uint8_t *qv = d.p[ep.pk.v_plane] + dd + (size_t) yb * d.stride[ep.pk.v_plane] + (size_t) x0;
+    if (NB == 2) {
+      *(uint2 *) qu = gstamd_make_uint2 (pu[0], pu[NB - 1]);
+      *(uint2 *) qv = gstamd_make_uint2 (pv[0], pv[NB - 1]);
+    } else {
+      *(uint32_t *) qu = pu[0];
+      *(uint32_t *) qv = pv[0];
+    }
   }
 }
 

@@ -387,27 +387,40 @@ hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const Dither
 }
 
 // 4-byte 8-bit pixels -> deep planar / semi-planar YUV in one kernel (video_deep.h: k_encode16), one wave per workgroup like k_encode420
-template <int SEMI>
+template <int SEMI, int NB>
 __global__ __launch_bounds__ (64) void k_encode16 (Enc16Params ep, const uint8_t *__restrict__ src, int sstride, DstPlanes16 d, FrameDeltas fl)
 {
   GSTAMD_FRAME_Z;
-  enc16_block<SEMI> (ep, src, sstride, d, (int) (blockIdx.x * 64 + threadIdx.x) * 4, (int) blockIdx.y, fls_, fld_);
+  enc16_block<SEMI, NB> (ep, src, sstride, d, (int) (blockIdx.x * 64 + threadIdx.x) * 4 * NB, (int) blockIdx.y, fls_, fld_);
 }
 
+// eight pixels of a line per lane where the rows allow (width % 8, destination rows on 16 bytes): the kernel is bound by the number of
+// memory instructions it issues, not by their bytes
 hipError_t launch_encode16 (const Enc16Params &ep, const uint8_t *src, int sstride, uint8_t *const planes[3], const int strides[3], hipStream_t stream)
 {
   DstPlanes16 d;
+  bool wide = (ep.width % 8) == 0 && !tuning_on ("GSTAMD_ENCODE16_NARROW");
   for (int i = 0; i < 3; i++) {
     d.p[i] = planes[i];
     d.stride[i] = strides[i];
+    if (planes[i])
+      wide = wide && ((uintptr_t) planes[i] % 16) == 0 && (strides[i] % 16) == 0;
   }
   int nz;
   const FrameDeltas &fl = frame_list_for (src, planes[0], &nz);
-  const dim3 grid ((ep.width / 4 + 63) / 64, (ep.height + (1 << ep.pk.h_sub) - 1) >> ep.pk.h_sub, nz);
-  if (ep.pk.kind == UNPACK_SEMI)
-    hipLaunchKernelGGL (k_encode16<1>, grid, dim3 (64), 0, stream, ep, src, sstride, d, fl);
-  else
-    hipLaunchKernelGGL (k_encode16<0>, grid, dim3 (64), 0, stream, ep, src, sstride, d, fl);
+  const int nb = wide ? 2 : 1;
+  const dim3 grid ((ep.width / (4 * nb) + 63) / 64, (ep.height + (1 << ep.pk.h_sub) - 1) >> ep.pk.h_sub, nz);
+  if (ep.pk.kind == UNPACK_SEMI) {
+    if (wide)
+      hipLaunchKernelGGL ((k_encode16<1, 2>), grid, dim3 (64), 0, stream, ep, src, sstride, d, fl);
+    else
+      hipLaunchKernelGGL ((k_encode16<1, 1>), grid, dim3 (64), 0, stream, ep, src, sstride, d, fl);
+  } else {
+    if (wide)
+      hipLaunchKernelGGL ((k_encode16<0, 2>), grid, dim3 (64), 0, stream, ep, src, sstride, d, fl);
+    else
+      hipLaunchKernelGGL ((k_encode16<0, 1>), grid, dim3 (64), 0, stream, ep, src, sstride, d, fl);
+  }
   return hipGetLastError ();
 }
 

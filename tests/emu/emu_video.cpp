@@ -907,12 +907,23 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         if (p.rect.fill)
           emu_fill_borders (p, out, dst);
         const int rows = (ep16.height + (1 << ep16.pk.h_sub) - 1) >> ep16.pk.h_sub;
+        bool wide = (ep16.width % 8) == 0 && getenv ("GSTAMD_ENCODE16_NARROW") == nullptr;
+        for (int i = 0; i < out->n_planes && i < 3; i++)
+          wide = wide && ((uintptr_t) d.p[i] % 16) == 0 && (d.stride[i] % 16) == 0;
+        const int npx = wide ? 8 : 4;
         for (int yb = 0; yb < rows; yb++)
-          for (int x0 = 0; x0 < (ep16.width / 4 + 63) / 64 * 256; x0 += 4) {
-            if (ep16.pk.kind == UNPACK_SEMI)
-              enc16_block<1> (ep16, sp, in->stride[0], d, x0, yb);
-            else
-              enc16_block<0> (ep16, sp, in->stride[0], d, x0, yb);
+          for (int x0 = 0; x0 < (ep16.width / npx + 63) / 64 * 64 * npx; x0 += npx) {
+            if (ep16.pk.kind == UNPACK_SEMI) {
+              if (wide)
+                enc16_block<1, 2> (ep16, sp, in->stride[0], d, x0, yb);
+              else
+                enc16_block<1, 1> (ep16, sp, in->stride[0], d, x0, yb);
+            } else {
+              if (wide)
+                enc16_block<0, 2> (ep16, sp, in->stride[0], d, x0, yb);
+              else
+                enc16_block<0, 1> (ep16, sp, in->stride[0], d, x0, yb);
+            }
           }
         return GSTAMD_OK;
       }

@@ -50,6 +50,8 @@ VIDEO_CONFIGS = {
                 "4K->1080p frames/s (videoscale NV12->NV12, bilinear) per GPU; % HBM roofline", "k_plane_direct (one frame, every plane straight from memory: nearest / 2-tap / two-tap N-tap passes composed per pixel; k_plane_tiles serves longer filters)"),
     "f8pack": ("YUY2", 3840, 2160, "I420", 3840, 2160, {}, 8, 8,
                "4K frames/s (videoconvert YUY2->I420) per GPU; % HBM roofline", "k_convert_pack_422 (the planar packer fed by the unscaled chain, no AYUV image)"),
+    "f5encode16": ("BGRA", 3840, 2160, "P010_10LE", 3840, 2160, {}, 8, 8,
+                   "4K frames/s (videoconvertscale BGRA->P010_10LE) per GPU; % HBM roofline", "k_encode16 (widen, matrix16, chroma down, ordered dither, pack in one kernel)"),
     "f8swizzle": ("BGRA", 3840, 2160, "RGBA", 3840, 2160, {}, 8, 8,
                   "4K frames/s (videoconvert BGRA->RGBA) per GPU; % HBM roofline", "k_swizzle4"),
 }
@@ -57,6 +59,7 @@ CONFIG_TEXT = {
     "f8scale": "SURVEY 8(f): 3840x2160 NV12 -> 1920x1080 NV12, bilinear (the elements' default method: linear, max-taps 2), plane by plane (convert_scale_planes)",
     "f8pack": "SURVEY 8(f): 3840x2160 YUY2 -> I420 (unpack, chroma downsample, planar pack)",
     "f8swizzle": "SURVEY 8(f): 3840x2160 BGRA -> RGBA (a byte permutation)",
+    "f5encode16": "SURVEY 8(f)2 / VERDICT r03 item 5: 3840x2160 BGRA -> P010_10LE (widen, matrix16, cosited chroma down, ordered dither, pack)",
     "c2": "C2: 3840x2160 NV12 (bt709 limited, chroma-site mpeg2) -> BGRA, fused unpack + chroma upsample + matrix + pack",
     "c1": "C1 size on the GPU: 1920x1080 NV12 -> BGRA (the reference's CPU-runnable case)",
     "c3": "C3: 7680x4320 I420 -> 1920x1080 RGBA, Lanczos (16 x 16 taps), horizontal then vertical like chain_scale",
@@ -525,7 +528,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f8scale | f8pack | f8swizzle")
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f5encode16 | f8scale | f8pack | f8swizzle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed sustained load before the W warmup steps: from idle an MI355X needs 20-30 ms of load "

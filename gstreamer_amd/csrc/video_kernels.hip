@@ -408,6 +408,9 @@ hipError_t launch_encode16 (const Enc16Params &ep, const uint8_t *src, int sstri
   }
   int nz;
   const FrameDeltas &fl = frame_list_for (src, planes[0], &nz);
+  /* (a single 4K frame is one round of waves either way - 8640 or 17280 of them for 8192 places - and runs as a load phase, a compute phase and
+     a store phase; the narrow form's second half-round overlaps a little: 23.9 against 25.7 us.  Lists of 8: 17.4 against 13.9 us per frame) */
+  wide = wide && (nz > 1 || tuning_on ("GSTAMD_ENCODE16_WIDE"));
   const int nb = wide ? 2 : 1;
   const dim3 grid ((ep.width / (4 * nb) + 63) / 64, (ep.height + (1 << ep.pk.h_sub) - 1) >> ep.pk.h_sub, nz);
   if (ep.pk.kind == UNPACK_SEMI) {

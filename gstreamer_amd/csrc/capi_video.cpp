@@ -249,7 +249,8 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[3], co
     int es;
     uint32_t lo, hi;
     border_plane_value (f, rc.border, i, &es, &lo, &hi);
-    const int ws = i ? f->w_sub : 0, hs = i ? f->h_sub : 0;
+    const bool pairs = f->kind == UNPACK_PACKED422 || f->kind == UNPACK_P422_16;          /* the plane's unit is the macropixel */
+    const int ws = i || pairs ? f->w_sub : 0, hs = i ? f->h_sub : 0;
     const int mw = up (rc.out_maxw, ws), mh = up (rc.out_maxh, hs);
     e = launch_fill_border (planes[i], strides[i], es, lo, hi, mw, mh, rc.out_x >> ws, rc.out_y >> hs, up (w, ws), up (h, hs), stream);
     if (e == hipSuccess && i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && (rc.out_maxw & 1)) {

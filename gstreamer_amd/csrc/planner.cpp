@@ -2994,9 +2994,10 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       *error = "a destination rectangle inside a v210 frame (6-pixel groups shared with the border) is not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
   }
-  if (rc.fill && fo && (fo->kind == UNPACK_PACKED422 || fo->kind == UNPACK_P422_16)) {
+  if (rc.fill && fo && (fo->kind == UNPACK_PACKED422 || fo->kind == UNPACK_P422_16) && ((rc.out_x | eout.width | rc.out_maxw) & 1)) {
+    /* (rectangles on whole macropixels are filled: border_plane_value) */
     if (error)
-      *error = "borders on a packed 4:2:2 destination (the macropixel border of convert_fill_border) are not implemented on the GPU path";
+      *error = "borders on a packed 4:2:2 destination whose rectangle or frame ends inside a macropixel (pixel pairs shared between border and picture) are not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
   }
   const int r = plan_core (&ein, &eout, &cfg, plan, error);

@@ -346,7 +346,16 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
     const int drop = 16 - hi_depth_bits (f->hi_depth);
     return f->hi_depth == 1 || f->hi_depth == 4 ? v >> drop : v & ~((1u << drop) - 1u);
   };
-  if (f->kind == UNPACK_Y410) {            /* pack_Y410 (video-format.c:898-921) of the widened border */
+  if (f->kind == UNPACK_PACKED422) {
+    /* the unit is the macropixel (the planner admits borders on these formats only where no macropixel holds border and picture: even offsets, widths
+       and frame width - every path of the reference, the generic chain's packed border line and convert_fill_border's group 42 alike, then lays the
+       border pair from an even pixel on): two border pixels packed, 4 bytes */
+    uint8_t m[4];
+    m[f->pos[1]] = m[f->pos[1] + 2] = border[1], m[f->pos[2]] = border[2], m[f->pos[3]] = border[3];
+    *es = 4, *lo = (uint32_t) m[0] | ((uint32_t) m[1] << 8) | ((uint32_t) m[2] << 16) | ((uint32_t) m[3] << 24);
+  } else if (f->kind == UNPACK_P422_16) {
+    *es = 8, *lo = s16 (1) | (s16 (2) << 16), *hi = s16 (1) | (s16 (3) << 16);          /* pack_Y210: Y0 U Y1 V, 16 bits each */
+  } else if (f->kind == UNPACK_Y410) {            /* pack_Y410 (video-format.c:898-921) of the widened border */
     const uint32_t a = (uint32_t) border[0] * 257u, y = (uint32_t) border[1] * 257u, u = (uint32_t) border[2] * 257u, v = (uint32_t) border[3] * 257u;
     *es = 4, *lo = ((u & 0xffc0u) >> 6) | ((y & 0xffc0u) << 4) | ((v & 0xffc0u) << 14) | ((a & 0xc000u) << 16);
   } else if (f->kind == UNPACK_PACKED4 && f->hi_depth == 3) {

@@ -773,7 +773,8 @@ static void emu_fill_borders (const VideoPlan &p, const GstAmdVideoInfo *out, ui
     uint8_t v[8];
     memcpy (v, &lo, 4);
     memcpy (v + 4, &hi, 4);
-    const int ws = i ? f->w_sub : 0, hs = i ? f->h_sub : 0;
+    const bool pairs = f->kind == UNPACK_PACKED422 || f->kind == UNPACK_P422_16;
+    const int ws = i || pairs ? f->w_sub : 0, hs = i ? f->h_sub : 0;
     const int mw = up (p.rect.out_maxw, ws), mh = up (p.rect.out_maxh, hs), x0 = p.rect.out_x >> ws, y0 = p.rect.out_y >> hs;
     const int w = up (p.out_info.width, ws), h = up (p.out_info.height, hs);
     for (int y = 0; y < mh; y++)

@@ -497,14 +497,21 @@ def gather_ranks(values, device, distributed, world):
     return [list(map(float, o.tolist())) for o in out]
 
 
-def stored_traffic(name):
+def stored_traffic(name, frames_per_launch=None):
     """HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    runs of this same command; scripts/gpu_profiles.sh).  A stored figure, not a per-run measurement: the source says so."""
+    runs of this same command; scripts/gpu_profiles.sh).  A stored figure, not a per-run measurement: the source says so.  The
+    passes were taken at some number of frames per launch: the figure is scaled to this run's (traffic per frame does not
+    depend on the list length for these kernels - every frame of a list is read and written once)."""
     for path in (os.path.join(ROOT, "profiles", "traffic_%s.json" % name),):
         if os.path.exists(path):
             try:
                 d = json.load(open(path))
-                return int(d["hbm_bytes_per_launch"]), "stored PMC figure: profiles/%s (%s)" % (os.path.basename(path), d.get("measured", "round 1"))
+                b, at = int(d["hbm_bytes_per_launch"]), int(d.get("frames_per_launch", 0) or 0)
+                note = ""
+                if frames_per_launch and at and at != frames_per_launch:
+                    b = int(round(b * frames_per_launch / at))
+                    note = "; taken at %d frame(s) per launch, scaled to %d" % (at, frames_per_launch)
+                return b, "stored PMC figure: profiles/%s (%s%s)" % (os.path.basename(path), d.get("measured", "round 1"), note)
             except Exception:
                 pass
     return None, None
@@ -620,7 +627,7 @@ def main():
 
     if rank == 0:
         assert total_units == steps * wl.units_per_step * world
-        traffic, traffic_src = stored_traffic(args.config)
+        traffic, traffic_src = stored_traffic(args.config, wl.config(world).get("frames_per_launch"))
         line = {
             "metric": wl.metric,
             "value": round(total_units / wall_max, 1),

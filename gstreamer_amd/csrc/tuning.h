@@ -10,6 +10,16 @@
 //   GSTAMD_COL_OPL, GSTAMD_COL_SHARE, GSTAMD_COL_WAVES, GSTAMD_COL_CHUNKS, GSTAMD_COL_DEBUG
 //                            form and geometry of the column-walk scaler: outputs per lane (1 / 2), shared windows (0: off), waves per
 //                            workgroup, workgroups down a frame; DEBUG prints the choice
+//   GSTAMD_NO_PLANE_QUAD     k_plane_direct / k_plane_tiles instead of k_plane_quad for planes of two short passes and the pass-free planes next to them (set)
+//   GSTAMD_PLANE_QUAD_MODE, GSTAMD_PLANE_QUAD_ROWS, GSTAMD_PLANE_QUAD_NT, GSTAMD_PLANE_QUAD_ONLY, GSTAMD_PLANE_QUAD_NO_DSTEP
+//                            k_plane_quad: widest form allowed (0: 4 output bytes per lane, 1: 8, 2: + 16 for pass-free planes, 3: 8 for those), rows a
+//                            wave walks, nontemporal loads (bit 0) / stores (bit 1), one plane of the frame only (timing; the others are NOT
+//                            converted), the general selectors for 2:1 planes too
+//   GSTAMD_NO_DEEP_PLANES16  k_deep_planes (8 samples per lane, every format switch at run time) instead of k_deep_planes16 (set)
+//   GSTAMD_NO_ENCODE16       the three-stage composite instead of k_encode16 for 4-byte pixels -> deep planar YUV (set)
+//   GSTAMD_ENCODE16_NARROW, GSTAMD_ENCODE16_WIDE
+//                            k_encode16 with four / eight pixels per lane whatever the launch (default: eight in frame lists)
+//   GSTAMD_LIST_DEBUG        print, per frame list, how many launches took the list (set)
 //   GSTAMD_NO_FUSED420       two-pass form instead of the fused 4:2:0 N-tap scaler (set)
 //   GSTAMD_NO_H420_REG       general horizontal 4:2:0 kernel (pair table) instead of the regular-pairs one (set)
 //   GSTAMD_H420_ROWS         lines per wave of the horizontal 4:2:0 kernels (n; 0: kernel off)

@@ -57,6 +57,8 @@ struct GstAmdVideoConverter {
   size_t plane_lds_bytes = 0;
   bool plane_frame_ok = false;            // the frame's planes go through k_plane_frame (one launch)
   std::vector<int> plane_dstep;
+  bool raw4_quad = false;                 // plane_raw4_plan: the 4-byte plane scaler goes through k_plane_quad
+  int raw4_dstep = 0;
   std::vector<bool> plane_quad, plane_oct;        // per plane of the plan: plane_quad_ok / plane_oct_ok (k_plane_quad takes it where the destination rows allow)
   void *ed_carry = nullptr;                // error-diffusion dither on rectangles taller than one band: the band's last line of errors (video_dither_ed.h)
   uint8_t *pre_img = nullptr;             // enlarging from a planar / packed 4:2:2 source: the source frame after front + colour stage, at its own size
@@ -477,6 +479,11 @@ static int build_tables (GstAmdVideoConverter *c)
     c->tmp_h = s0.horizontal ? p.in_info.height : s0.out_size;
     c->tmp_size = (size_t) c->tmp_w * 4 * (c->tmp_h + 1);      /* + the spare row k_hscale420_reg sends its out-of-picture lines to */
     /* allocated by the first frame that takes the two-pass form (ensure_tmp): the fused scaler needs no intermediate image */
+  }
+  {
+    PlanePlan raw4;
+    c->raw4_quad = plane_raw4_plan (p, &raw4);
+    c->raw4_dstep = c->raw4_quad ? plane_quad_dstep (raw4) : 0;
   }
   if (p.plane_mode) {
     size_t tmp_bytes = 0;
@@ -1420,6 +1427,25 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
         return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_bilinear420");
     }
     const ScaleDev &sh = h_first ? sd[0] : sd[1], &sv = h_first ? sd[1] : sd[0];
+    if (c->raw4_quad && pl.p[0] && !tuning_on ("GSTAMD_NO_PLANE_QUAD")) {
+      /* the plane scaler on 4-byte pixels, both passes short: k_plane_quad with a pixel of four one-byte components (video_planes.h) */
+      PlaneJobs jobs;
+      memset ((void *) &jobs, 0, sizeof (jobs));
+      PlaneJob &J = jobs.job[0];
+      J.kind = PLANE_SCALE;
+      J.s.p = pl.p[0], J.s.stride = pl.stride[0], J.s.n = 4;
+      J.d.p = dst, J.d.stride = dstride, J.d.n = 4;
+      J.iw = p.front.width, J.ih = p.front.height, J.ow = out_w, J.oh = out_h;
+      J.n_pass = 2;
+      J.h_first = h_first ? 1 : 0;
+      J.pass[0] = sd[0], J.pass[1] = sd[1];
+      J.dstep = tuning_on ("GSTAMD_PLANE_QUAD_NO_DSTEP") ? 0 : c->raw4_dstep;
+      J.quad = 1 + QUAD_8;
+      J.tiles_x = 1;
+      jobs.n = 1;
+      e = launch_plane_frame (jobs, 0, stream);
+      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_plane_quad(4-byte pixels)");
+    }
     if (p.matrix_before_scale && p.front.kind != UNPACK_PACKED4 && p.front.hi_depth == 0 && ((uintptr_t) dst % 4) == 0 && (dstride % 4) == 0 &&
         !tuning_on ("GSTAMD_NO_BILINEAR4")) {
       /* enlarging (the matrix runs on the source's pixels, chain_convert ahead of chain_scale): the source frame through the front and the

@@ -448,7 +448,8 @@ GSTAMD_VP int quad_mode_bytes (int mode) { return mode == QUAD_S8 ? 8 : 4 << mod
 // host: may the plane go this way with B = `bytes` output bytes per lane?  (table contents: spans of the groups, tap magnitudes)
 inline bool plane_quad_ok (const PlanePlan &pp, int bytes = 4)
 {
-  if (pp.kind != PLANE_SCALE || pp.passes.size () != 2 || (pp.n_elems != 1 && pp.n_elems != 2) || pp.iw * pp.n_elems < 2 * bytes || pp.ow * pp.n_elems < bytes || pp.ih < 1)
+  if (pp.kind != PLANE_SCALE || pp.passes.size () != 2 || (pp.n_elems != 1 && pp.n_elems != 2 && !(pp.n_elems == 4 && bytes == 8)) || pp.iw * pp.n_elems < 2 * bytes ||
+      pp.ow * pp.n_elems < bytes || pp.ih < 1)
     return false;
   const ScalePass *ph = pp.passes[0].horizontal ? &pp.passes[0] : &pp.passes[1], *pv = pp.passes[0].horizontal ? &pp.passes[1] : &pp.passes[0];
   if (!ph->horizontal || pv->horizontal)
@@ -858,9 +859,24 @@ inline int plane_job_quad (const PlaneJob &J, bool quad_ok, bool oct_ok, int max
 {
   if (J.kind != PLANE_SCALE)
     return J.s.n == 1 && plane_simple16_kind (J.kind) && J.ow >= 16 && max_mode >= 2 ? 1 + (max_mode >= 3 ? QUAD_S8 : QUAD_16) : 0;
-  if (oct_ok && max_mode >= 1)
+  if (oct_ok && (max_mode >= 1 || J.s.n == 4))
     return 1 + QUAD_8;
-  return quad_ok ? 1 + QUAD_4 : 0;
+  return quad_ok && J.s.n != 4 ? 1 + QUAD_4 : 0;
+}
+
+// host: the reference's plane scaler on a 4-byte packed format (convert_scale_planes: the same 8-bit format on both sides, no colour step - the
+// bytes go through raw) with two short passes is one plane of four-byte pixels to k_plane_quad: *pp = that plane's plan
+inline bool plane_raw4_plan (const VideoPlan &p, PlanePlan *pp)
+{
+  if (p.ref_fastpath != "convert_scale_planes" || p.plane_mode || p.gamma.on || p.front.kind != UNPACK_PACKED4 || p.front.hi_depth != 0 || p.passes.size () != 2 ||
+      p.dither.on || p.out_planar || p.matrix.kind != MATRIX_NONE || p.post.matrix.kind != MATRIX_NONE || p.post.alpha_kind != ALPHA_NONE)
+    return false;
+  pp->kind = PLANE_SCALE;
+  pp->src_plane = pp->dst_plane = 0;
+  pp->n_elems = 4;
+  pp->iw = p.front.width, pp->ih = p.front.height, pp->ow = p.out_info.width, pp->oh = p.out_info.height;
+  pp->passes = p.passes;
+  return plane_quad_ok (*pp, 8);
 }
 
 // what a lane of k_plane_quad does for a job
@@ -871,6 +887,10 @@ GSTAMD_HD void plane_rows_body (const PlaneJob &J, int lane, int y0, int rows, l
     plane_simple16_body (J, lane, y0, rows, ds, dd, nt);
   else if (mode == QUAD_S8)
     plane_simple8_body (J, lane, y0, rows, ds, dd, nt);
+  else if (mode == QUAD_8 && J.s.n == 4 && J.dstep == 2)
+    plane_quad_body<4, 8, 2> (J, lane, y0, rows, ds, dd, nt);
+  else if (mode == QUAD_8 && J.s.n == 4)
+    plane_quad_body<4, 8, 0> (J, lane, y0, rows, ds, dd, nt);
   else if (mode == QUAD_8 && J.s.n == 1 && J.dstep == 2)
     plane_quad_body<1, 8, 2> (J, lane, y0, rows, ds, dd, nt);
   else if (mode == QUAD_8 && J.s.n == 1)

@@ -614,6 +614,16 @@ VIDEO_CASES = [
     ("planes_i420_10_p010_720p", "I420_10LE", 1280, 720, "P010_10LE", 1280, 720, {}, None, None, "random"),
     ("planes_p010_yv12_odd", "P010_10LE", 643, 361, "YV12", 643, 361, {}, None, None, "random"),
     ("planes_nv12_p010_4k", "NV12", 3840, 2160, "P010_10LE", 3840, 2160, {}, None, None, "random"),
+    # k_plane_quad on 4-byte pixels: the reference's plane scaler (convert_scale_planes) on a packed 4-byte format, both passes short
+    ("quad4_bgra_half_bilinear", "BGRA", 640, 360, "BGRA", 320, 180, LIN, None, None, "random"),
+    ("quad4_rgba_3_2_down_bilinear", "RGBA", 640, 360, "RGBA", 426, 240, LIN, None, None, "random"),
+    ("quad4_argb_up_bilinear_odd", "ARGB", 161, 91, "ARGB", 333, 200, LIN, None, None, "random"),
+    ("quad4_xrgb_nearest_down", "xRGB", 320, 240, "xRGB", 200, 150, NEAR, None, None, "random"),
+    ("quad4_ayuv_mixed_bilinear", "AYUV", 200, 60, "AYUV", 120, 90, LIN, None, None, "random"),
+    ("quad4_bgra_too_steep_bilinear", "BGRA", 640, 360, "BGRA", 200, 112, LIN, None, None, "random"),
+    ("quad4_bgra_crop_dest_bilinear", "BGRA", 640, 480, "BGRA", 480, 360, dict(LIN, src_x=32, src_y=16, src_width=400, src_height=300, dest_x=20, dest_y=10, dest_width=300, dest_height=226), None, None, "random"),
+    ("quad4_bgra_4k_to_1080p", "BGRA", 3840, 2160, "BGRA", 1920, 1080, LIN, None, None, "random"),
+    ("quad4_bgra_1080p_to_4k", "BGRA", 1920, 1080, "BGRA", 3840, 2160, LIN, None, None, "random"),
     # k_encode16: 4-byte 8-bit pixels straight into deep planar / semi-planar 4:2:0 / 4:2:2 YUV (widen, matrix16, chroma down, dither, pack in one kernel)
     ("enc16_bgra_p010_cosited", "BGRA", 64, 36, "P010_10LE", 64, 36, {}, None, "cosited", "random"),
     ("enc16_rgba_p010_odd_height", "RGBA", 64, 37, "P010_10LE", 64, 37, {}, None, None, "random"),

@@ -1760,6 +1760,27 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
           bilinear4_rows_lane (b, d, pf_none, x0, y0);
       return GSTAMD_OK;
     }
+    PlanePlan raw4;
+    if (plane_raw4_plan (p, &raw4) && getenv ("GSTAMD_NO_PLANE_QUAD") == nullptr) {          /* k_plane_quad on 4-byte pixels */
+      PlaneJob J;
+      memset ((void *) &J, 0, sizeof (J));
+      J.kind = PLANE_SCALE;
+      J.s = {pl.p[0], pl.stride[0], 4, 0};
+      J.d = {d0, dstride, 4};
+      J.iw = raw4.iw, J.ih = raw4.ih, J.ow = raw4.ow, J.oh = raw4.oh;
+      J.n_pass = 2;
+      J.h_first = h_first ? 1 : 0;
+      J.pass[h_first ? 0 : 1] = sh, J.pass[h_first ? 1 : 0] = sv;
+      J.dstep = getenv ("GSTAMD_PLANE_QUAD_NO_DSTEP") ? 0 : plane_quad_dstep (raw4);
+      J.quad = 1 + QUAD_8;
+      g_emu_quad_runs++;
+      const int rows = getenv ("GSTAMD_PLANE_QUAD_ROWS") ? atoi (getenv ("GSTAMD_PLANE_QUAD_ROWS")) : 3;
+      const int lanes = (((J.ow * 4 + 7) / 8 + 63) / 64) * 64;
+      for (int y0 = 0; y0 < J.oh; y0 += rows)
+        for (int lane = 0; lane < lanes; lane++)
+          plane_rows_body (J, lane, y0, rows);
+      return GSTAMD_OK;
+    }
     if (p.front.kind == UNPACK_PACKED4 && p.front.hi_depth == 0 && sf.pre.matrix.kind == MATRIX_NONE && sf.pre.alpha_kind == ALPHA_NONE &&
         ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0 && ((uintptr_t) d0 % 4) == 0 && (dstride % 4) == 0 && !getenv ("EMU_NO_BILINEAR4")) {
       /* k_bilinear4_rows: four outputs per lane, four rows per lane */

@@ -774,7 +774,9 @@ int gstamd_compositor_aggregate_frame (int format, int background, const int32_t
   if (!n_planes || !dest || !dstride || dw <= 0 || dh <= 0 || (n_pads > 0 && !pads) || background < 0 || background > 3)
     return GSTAMD_ERR_INVALID;
   const int yuv = f->yuv ? 1 : 0;
-  const int dblack[3] = {yuv ? 16 : 0, yuv ? 128 : 0, yuv ? 128 : 0}, dwhite[3] = {yuv ? 235 : 255, yuv ? 128 : 255, yuv ? 128 : 255};
+  const int up = f->hi_depth ? hi_depth_bits (f->hi_depth) - 8 : 0;          /* deeper samples: the 8-bit defaults shifted up (limited range) */
+  const int dblack[3] = {(yuv ? 16 : 0) << up, (yuv ? 128 : 0) << up, (yuv ? 128 : 0) << up};
+  const int dwhite[3] = {(yuv ? 235 : 255) << up, (yuv ? 128 : 255) << up, (yuv ? 128 : 255) << up};
   const int bk[3] = {black ? black[0] : dblack[0], black ? black[1] : dblack[1], black ? black[2] : dblack[2]};
   const int wh[3] = {white ? white[0] : dwhite[0], white ? white[1] : dwhite[1], white ? white[2] : dwhite[2]};
   for (int pl = 0; pl < n_planes; pl++) {

@@ -40,6 +40,8 @@ struct PlaneJob {
   int wbytes, rows;       // plane size
   int bg_kind;            // 0: checker, 1: constant bytes, 2: keep the canvas (follow-up chunk)
   int px_bytes;           // bytes per pixel of the plane (checker squares are 8 PIXELS wide; constants repeat per pixel)
+  int bits;               // 8, or 10 / 12 / 16: the plane holds 16-bit little-endian samples of that depth (compositor_orc_blend_u10 / u12 / u16,
+                          // compositororc.orc:38-88: d = (d << bits + (s - d) * alpha) >> bits in 32 bits, saturated to 16; alpha = (int) (a * (2^bits - 1)))
   uint8_t bg[4];          // constant background: byte k of every pixel
   int n;
   PlaneRect r[GSTAMD_PLANE_MAX_PADS];
@@ -65,12 +67,52 @@ GSTAMD_CP uint32_t plane_byte (const PlaneJob &j, int x, int y, uint32_t canvas)
   return d;
 }
 
+// one 16-bit sample (x = its first byte, even)
+GSTAMD_CP uint32_t plane_sample16 (const PlaneJob &j, int x, int y, uint32_t canvas)
+{
+  uint32_t d;
+  if (j.bg_kind == 2)
+    d = canvas;
+  else if (j.bg_kind == 0)          /* PLANAR_YUV_HIGH_FILL_CHECKER (blend.c:503-551): 80 / 160 << (bits - 8) in 8 x 8 pixel squares */
+    d = (((((unsigned) y & 8u) >> 3) + ((((unsigned) (x / j.px_bytes)) & 8u) >> 3)) & 1u ? 160u : 80u) << (j.bits - 8);
+  else
+    d = (uint32_t) j.bg[0] | ((uint32_t) j.bg[1] << 8);
+  for (int k = 0; k < j.n; k++) {
+    const PlaneRect &r = j.r[k];
+    if (x < r.x || x >= r.x + r.w || y < r.y || y >= r.y + r.h)
+      continue;
+    const uint8_t *sp = r.src + (size_t) (y - r.y) * r.sstride + (x - r.x);
+    const uint32_t s = (uint32_t) sp[0] | ((uint32_t) sp[1] << 8);
+    if (r.mode == 1) {
+      d = s;
+    } else {
+      const uint32_t t = ((d << j.bits) + (uint32_t) (((int) s - (int) d) * r.alpha)) >> j.bits;       /* subl, mulll, shll, addl, shrul: 32-bit wrap */
+      d = (int32_t) t < 0 ? 0u : (t > 65535u ? 65535u : t);                                             /* convsuslw */
+    }
+  }
+  return d;
+}
+
 // one lane: bytes x0 .. x0+3 of row y
 GSTAMD_CP void plane_word_body (const PlaneJob &j, int x0, int y)
 {
   if (x0 >= j.wbytes || y >= j.rows)
     return;
   uint8_t *q = j.dst + (size_t) y * j.dstride + x0;
+  if (j.bits > 8) {                     /* two 16-bit samples (plane rows are whole samples: wbytes is even) */
+    const uint16_t *q16 = (const uint16_t *) q;
+    const uint32_t a = plane_sample16 (j, x0, y, j.bg_kind == 2 ? q16[0] : 0);
+    if (x0 + 2 < j.wbytes) {
+      const uint32_t b = plane_sample16 (j, x0 + 2, y, j.bg_kind == 2 ? q16[1] : 0);
+      if ((((uintptr_t) q) & 3) == 0)
+        *(uint32_t *) q = a | (b << 16);
+      else
+        ((uint16_t *) q)[0] = (uint16_t) a, ((uint16_t *) q)[1] = (uint16_t) b;
+    } else {
+      *(uint16_t *) q = (uint16_t) a;
+    }
+    return;
+  }
   const int n = j.wbytes - x0 < 4 ? j.wbytes - x0 : 4;
   uint32_t v[4];
   for (int i = 0; i < n; i++)
@@ -101,11 +143,15 @@ inline int compositor_plane_geometry (const FormatDesc *f, PlaneGeom g[3])
 {
   if (!f)
     return 0;
-  if (f->kind == UNPACK_PLANAR) {
-    g[0] = {0, 0, 1};
-    g[1] = g[2] = {f->w_sub, f->h_sub, 1};
+  if (f->kind == UNPACK_PLANAR && (f->hi_depth == 0 || f->hi_depth == 1 || f->hi_depth == 4 || f->hi_depth == 6)) {
+    /* 8-bit planes, or 16-bit little-endian samples with the value in the low bits (I420_10LE ... Y444_16LE: blend.c:609-681) */
+    const int sb = f->hi_depth ? 2 : 1;
+    g[0] = {0, 0, sb};
+    g[1] = g[2] = {f->w_sub, f->h_sub, sb};
     return 3;
   }
+  if (f->hi_depth)
+    return 0;
   if (f->kind == UNPACK_SEMI && f->w_sub == 1 && f->h_sub == 1) {
     g[0] = {0, 0, 1};
     g[1] = {1, 1, 2};
@@ -163,13 +209,14 @@ inline bool compositor_pad_rect (const FormatDesc *f, const PlaneGeom &g, int pl
   out->y = cy;
   out->w = cw * g.px_bytes;
   out->h = ch;
+  const int range = (1 << (f->hi_depth ? hi_depth_bits (f->hi_depth) : 8)) - 1;          /* PLANAR_YUV_BLEND: range = (1 << n_bits) - 1 (blend.c:280-281) */
   if (alpha == 1.0) {
     out->mode = 1;
-    out->alpha = 255;
+    out->alpha = range;
   } else {
-    int a = (int) (alpha * 255);
+    int a = (int) (alpha * range);
     out->mode = 2;
-    out->alpha = a < 0 ? 0 : (a > 255 ? 255 : a);
+    out->alpha = a < 0 ? 0 : (a > range ? range : a);
   }
   return true;
 }
@@ -179,7 +226,25 @@ inline void compositor_plane_background (const FormatDesc *f, const PlaneGeom &g
     PlaneJob *job)
 {
   job->px_bytes = g.px_bytes;
+  job->bits = f->hi_depth ? hi_depth_bits (f->hi_depth) : 8;
   memset (job->bg, 0, sizeof (job->bg));
+  if (job->bits > 8) {
+    /* PLANAR_YUV_HIGH_FILL_CHECKER / _FILL_COLOR (blend.c:503-607): luma checker, chroma 1 << (bits - 1); colours as 16-bit values */
+    const bool luma = pl == 0;
+    int v = 0;
+    if (background == 3) {
+      job->bg_kind = 1;
+    } else if (background == 0) {
+      job->bg_kind = luma ? 0 : 1;
+      v = 1 << (job->bits - 1);
+    } else {
+      const int *c = background == 1 ? black : white;
+      job->bg_kind = 1;
+      v = luma ? c[0] : (pl == f->u_plane ? c[1] : c[2]);
+    }
+    job->bg[0] = (uint8_t) (v & 0xff), job->bg[1] = (uint8_t) ((v >> 8) & 0xff);
+    return;
+  }
   if (background == 3) {                  /* transparent: memset 0 */
     job->bg_kind = 1;
     return;

@@ -267,6 +267,21 @@ ref_compositor_blend (const char *func, const char *format, const guint8 * src, 
     fn = gst_compositor_blend_argb64;
   else if (!strcmp (func, "overlay_argb64"))
     fn = gst_compositor_overlay_argb64;
+  /* the planar canvases of more than 8 bits (blend.c:609-681: PLANAR_YUV_BLEND with compositor_orc_blend_u10 / u12 / u16) */
+  else if (!strcmp (func, "blend_i420_10le"))
+    fn = gst_compositor_blend_i420_10le;
+  else if (!strcmp (func, "blend_i420_12le"))
+    fn = gst_compositor_blend_i420_12le;
+  else if (!strcmp (func, "blend_i422_10le"))
+    fn = gst_compositor_blend_i422_10le;
+  else if (!strcmp (func, "blend_i422_12le"))
+    fn = gst_compositor_blend_i422_12le;
+  else if (!strcmp (func, "blend_y444_10le"))
+    fn = gst_compositor_blend_y444_10le;
+  else if (!strcmp (func, "blend_y444_12le"))
+    fn = gst_compositor_blend_y444_12le;
+  else if (!strcmp (func, "blend_y444_16le"))
+    fn = gst_compositor_blend_y444_16le;
   if (!fn)
     return -1;
   if (!map_simple (&sf, &si, &sb, format, sw, sh, (guint8 *) src, src_size, FALSE))
@@ -320,6 +335,12 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
       fn = gst_compositor_fill_checker_argb64;
     else if (!strcmp (fmt_func, "ayuv64"))
       fn = gst_compositor_fill_checker_ayuv64;
+    else if (!strcmp (fmt_func, "i420_10le") || !strcmp (fmt_func, "i422_10le") || !strcmp (fmt_func, "y444_10le"))
+      fn = gst_compositor_fill_checker_i420_10le;          /* blend.h:127-129: one function for the three layouts */
+    else if (!strcmp (fmt_func, "i420_12le") || !strcmp (fmt_func, "i422_12le") || !strcmp (fmt_func, "y444_12le"))
+      fn = gst_compositor_fill_checker_i420_12le;
+    else if (!strcmp (fmt_func, "y444_16le"))
+      fn = gst_compositor_fill_checker_y444_16le;
     if (!fn)
       return -1;
     fn (&df, y0, y1);
@@ -353,6 +374,12 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
       fn = gst_compositor_fill_color_bgr;
     else if (!strcmp (fmt_func, "argb64"))
       fn = gst_compositor_fill_color_argb64;
+    else if (!strcmp (fmt_func, "i420_10le") || !strcmp (fmt_func, "i422_10le") || !strcmp (fmt_func, "y444_10le"))
+      fn = gst_compositor_fill_color_i420_10le;
+    else if (!strcmp (fmt_func, "i420_12le") || !strcmp (fmt_func, "i422_12le") || !strcmp (fmt_func, "y444_12le"))
+      fn = gst_compositor_fill_color_i420_12le;
+    else if (!strcmp (fmt_func, "y444_16le"))
+      fn = gst_compositor_fill_color_y444_16le;
     if (!fn)
       return -1;
     fn (&df, y0, y1, c1, c2, c3);

@@ -36,10 +36,20 @@
 GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
 #define GST_CAT_DEFAULT amd_comp_debug
 
-#define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR }"
+/* Y444_16LE, P012_LE and P016_LE joined the format enum in 1.18: there when the headers this is compiled against have them */
+#if GST_CHECK_VERSION (1, 18, 0)
+#define AMD_COMP_NEWER_CANVAS ", Y444_16LE"
+#define AMD_COMP_NEWER_PADS ", Y444_16LE, P012_LE, P016_LE"
+#else
+#define AMD_COMP_NEWER_CANVAS ""
+#define AMD_COMP_NEWER_PADS ""
+#endif
+#define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR, " \
+    "I420_10LE, I420_12LE, I422_10LE, I422_12LE, Y444_10LE, Y444_12LE" AMD_COMP_NEWER_CANVAS " }"
 /* what a pad may carry: anything the converter takes; it is brought to the output format / the pad's width x height by a
  * per-pad GstAmdVideoConverter (the reference's GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) */
-#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, GRAY8 }"
+#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, GRAY8, " \
+    "I420_10LE, I420_12LE, I422_10LE, I422_12LE, Y444_10LE, Y444_12LE, P010_10LE" AMD_COMP_NEWER_PADS " }"
 #define AMD_COMP_MAX_PADS 64
 
 static GstStaticPadTemplate comp_sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
@@ -329,6 +339,16 @@ amd_format_of (GstVideoFormat f)
     case GST_VIDEO_FORMAT_NV21: return GSTAMD_VIDEO_FORMAT_NV21;
     case GST_VIDEO_FORMAT_RGB: return GSTAMD_VIDEO_FORMAT_RGB;
     case GST_VIDEO_FORMAT_BGR: return GSTAMD_VIDEO_FORMAT_BGR;
+    /* ... and the planar canvases of 10 / 12 / 16 bits (blend.c:609-697: compositor_orc_blend_u10 / u12 / u16) */
+    case GST_VIDEO_FORMAT_I420_10LE: return GSTAMD_VIDEO_FORMAT_I420_10LE;
+    case GST_VIDEO_FORMAT_I420_12LE: return GSTAMD_VIDEO_FORMAT_I420_12LE;
+    case GST_VIDEO_FORMAT_I422_10LE: return GSTAMD_VIDEO_FORMAT_I422_10LE;
+    case GST_VIDEO_FORMAT_I422_12LE: return GSTAMD_VIDEO_FORMAT_I422_12LE;
+    case GST_VIDEO_FORMAT_Y444_10LE: return GSTAMD_VIDEO_FORMAT_Y444_10LE;
+    case GST_VIDEO_FORMAT_Y444_12LE: return GSTAMD_VIDEO_FORMAT_Y444_12LE;
+#if GST_CHECK_VERSION (1, 18, 0)
+    case GST_VIDEO_FORMAT_Y444_16LE: return GSTAMD_VIDEO_FORMAT_Y444_16LE;
+#endif
     default: return 0;
   }
 }
@@ -357,6 +377,11 @@ amd_pad_format_of (GstVideoFormat f)
     case GST_VIDEO_FORMAT_RGB: return GSTAMD_VIDEO_FORMAT_RGB;
     case GST_VIDEO_FORMAT_BGR: return GSTAMD_VIDEO_FORMAT_BGR;
     case GST_VIDEO_FORMAT_GRAY8: return GSTAMD_VIDEO_FORMAT_GRAY8;
+    case GST_VIDEO_FORMAT_P010_10LE: return GSTAMD_VIDEO_FORMAT_P010_10LE;
+#if GST_CHECK_VERSION (1, 18, 0)
+    case GST_VIDEO_FORMAT_P012_LE: return GSTAMD_VIDEO_FORMAT_P012_LE;
+    case GST_VIDEO_FORMAT_P016_LE: return GSTAMD_VIDEO_FORMAT_P016_LE;
+#endif
     default: return amd_format_of (f);
   }
 }
@@ -1055,9 +1080,13 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
   }
   if (by_planes) {
     /* black_color / white_color of the element (compositor.c:1131-1149): the range's offset and offset + scale */
-    const gboolean yuv = GST_VIDEO_INFO_IS_YUV (&c->out_info), full = c->out_info.colorimetry.range == GST_VIDEO_COLOR_RANGE_0_255;
-    const int32_t black[3] = { yuv && !full ? 16 : 0, yuv ? 128 : 0, yuv ? 128 : 0 };
-    const int32_t white[3] = { yuv && !full ? 235 : 255, yuv ? 128 : 255, yuv ? 128 : 255 };
+    const gboolean yuv = GST_VIDEO_INFO_IS_YUV (&c->out_info);
+    gint offset[GST_VIDEO_MAX_COMPONENTS], scale[GST_VIDEO_MAX_COMPONENTS];
+    int32_t black[3], white[3];
+    gst_video_color_range_offsets (c->out_info.colorimetry.range, c->out_info.finfo, offset, scale);          /* at the format's own depth */
+    black[0] = offset[0], white[0] = scale[0] + offset[0];
+    black[1] = offset[1], white[1] = yuv ? offset[1] : scale[1] + offset[1];
+    black[2] = offset[2], white[2] = yuv ? offset[2] : scale[2] + offset[2];
     void *dplanes[3] = { NULL, NULL, NULL };
     int32_t dstrides[3] = { 0, 0, 0 };
     gint k;

@@ -363,7 +363,37 @@ def test_div255_identity_used_by_packed_blend():
 
 
 # ---- outputs without per-pixel alpha: plane-by-plane aggregation (compositor_planes.h) ---------------------------------------
-FRAME_FMTS = ["I420", "YV12", "Y42B", "Y444", "NV12", "NV21", "RGB", "BGR"]
+FRAME_FMTS = ["I420", "YV12", "Y42B", "Y444", "NV12", "NV21", "RGB", "BGR",
+              # planar canvases of 10 / 12 / 16 bits (blend.c:609-697: compositor_orc_blend_u10 / u12 / u16, PLANAR_YUV_HIGH_FILL_*)
+              "I420_10LE", "I420_12LE", "I422_10LE", "I422_12LE", "Y444_10LE", "Y444_12LE", "Y444_16LE"]
+
+
+def _frame_depth_shift(fmt):
+    return 2 if "_10" in fmt else 4 if "_12" in fmt else 8 if "_16" in fmt else 0
+
+
+def _frame_layout(fmt, w, h):
+    """(strides, offsets): cases.default_layout for the 8-bit formats, the library's video_info (pinned against the reference's
+    gst_video_info_set_format elsewhere) for the deep planar ones"""
+    if not _frame_depth_shift(fmt):
+        return cases.default_layout(fmt, w, h)
+    vi = V.video_info(fmt, w, h)
+    return [int(vi.stride[i]) for i in range(3)], [int(vi.offset[i]) for i in range(3)]
+
+
+def _frame_visible(fmt, w, h, buf):
+    if not _frame_depth_shift(fmt):
+        strides, offsets = cases.default_layout(fmt, w, h)
+        return cases.visible_bytes(fmt, w, h, strides, offsets, buf)
+    strides, offsets = _frame_layout(fmt, w, h)
+    ws = 1 if ("I420" in fmt or "I422" in fmt) else 0
+    hs = 1 if "I420" in fmt else 0
+    out = []
+    for i in range(3):
+        cw, ch = (w, h) if i == 0 else (-((-w) >> ws), -((-h) >> hs))
+        plane = buf[offsets[i]:offsets[i] + strides[i] * ch].reshape(ch, strides[i])
+        out.append(plane[:, :2 * cw].reshape(-1))
+    return np.concatenate(out)
 # (width, height, xpos, ypos, alpha, mode) per pad: odd positions (rounded up to even where the format subsamples), negative
 # offsets, a pad hanging over the right / bottom edge, opaque, `source`, transparent and tiny-alpha pads
 FRAME_PADS = [(64, 48, 5, 7, 0.5, 1), (37, 21, -9, -3, 0.3, 1), (40, 30, 70, 40, 1.0, 1), (33, 17, 20, 10, 0.7, 0),
@@ -390,6 +420,8 @@ def _frame_expected(ref, fmt, background):
     low = fmt.lower()
     if background == 0:
         ref.compositor_fill(0, low, fmt, dst, FDW, FDH, 0, FDH)
+    elif background == 3 and _frame_depth_shift(fmt):
+        dst[:] = 0          # (padding is not compared)
     elif background == 3:
         strides, offsets = cases.default_layout(fmt, FDW, FDH)
         for i, (rb, rows) in enumerate(cases.visible_planes(fmt, FDW, FDH)):
@@ -398,6 +430,7 @@ def _frame_expected(ref, fmt, background):
     else:
         yuv = fmt not in ("RGB", "BGR")
         c = ((16, 128, 128) if yuv else (0, 0, 0)) if background == 1 else ((235, 128, 128) if yuv else (255, 255, 255))
+        c = tuple(v << _frame_depth_shift(fmt) for v in c)
         ref.compositor_fill(1, low, fmt, dst, FDW, FDH, 0, FDH, *c)
     func = {"YV12": "blend_i420", "BGR": "blend_rgb"}.get(fmt, "blend_" + low)
     for src, (w, h, x, y, alpha, mode) in zip(_frame_inputs(fmt), FRAME_PADS):
@@ -406,8 +439,7 @@ def _frame_expected(ref, fmt, background):
 
 
 def _visible(fmt, buf):
-    strides, offsets = cases.default_layout(fmt, FDW, FDH)
-    return cases.visible_bytes(fmt, FDW, FDH, strides, offsets, buf)
+    return _frame_visible(fmt, FDW, FDH, buf)
 
 
 @pytest.mark.parametrize("background", [0, 1, 2, 3])
@@ -416,18 +448,19 @@ def test_aggregate_frame_on_host_matches_reference(emu_lib, ref, fmt, background
     srcs = _frame_inputs(fmt)
     pads = (EmuFramePad * len(FRAME_PADS))()
     for k, (w, h, x, y, alpha, mode) in enumerate(FRAME_PADS):
-        strides, offsets = cases.default_layout(fmt, w, h)
+        strides, offsets = _frame_layout(fmt, w, h)
         for i in range(len(strides)):
             pads[k].data[i] = srcs[k].ctypes.data + offsets[i]
             pads[k].stride[i] = strides[i]
         pads[k].width, pads[k].height, pads[k].xpos, pads[k].ypos, pads[k].alpha, pads[k].mode = w, h, x, y, alpha, mode
     dst = cases.frame_bytes(_frame_size(fmt, FDW, FDH), "random", 6999)
-    strides, offsets = cases.default_layout(fmt, FDW, FDH)
+    strides, offsets = _frame_layout(fmt, FDW, FDH)
     dp = (C.c_void_p * 3)(*[dst.ctypes.data + o for o in offsets] + [None] * (3 - len(offsets)))
     ds = (C.c_int * 3)(*strides + [0] * (3 - len(strides)))
     yuv = fmt not in ("RGB", "BGR")
-    black = (C.c_int * 3)(*((16, 128, 128) if yuv else (0, 0, 0)))
-    white = (C.c_int * 3)(*((235, 128, 128) if yuv else (255, 255, 255)))
+    sh = _frame_depth_shift(fmt)
+    black = (C.c_int * 3)(*[v << sh for v in ((16, 128, 128) if yuv else (0, 0, 0))])
+    white = (C.c_int * 3)(*[v << sh for v in ((235, 128, 128) if yuv else (255, 255, 255))])
     emu_lib.emu_compositor_aggregate_frame.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                        C.c_int, C.c_int]
     assert emu_lib.emu_compositor_aggregate_frame(V.FORMATS[fmt], background, black, white, pads, len(FRAME_PADS), dp, ds, FDW, FDH) == 0
@@ -443,13 +476,13 @@ def test_hip_aggregate_frame_matches_reference(native_lib, gpu, ref, fmt, backgr
     srcs = [torch.from_numpy(s).to(gpu) for s in _frame_inputs(fmt)]
     pads = (V.CompositorFramePad * len(FRAME_PADS))()
     for k, (w, h, x, y, alpha, mode) in enumerate(FRAME_PADS):
-        strides, offsets = cases.default_layout(fmt, w, h)
+        strides, offsets = _frame_layout(fmt, w, h)
         for i in range(len(strides)):
             pads[k].data[i] = srcs[k].data_ptr() + offsets[i]
             pads[k].stride[i] = strides[i]
         pads[k].width, pads[k].height, pads[k].xpos, pads[k].ypos, pads[k].alpha, pads[k].blend_mode = w, h, x, y, alpha, mode
     d = torch.from_numpy(cases.frame_bytes(_frame_size(fmt, FDW, FDH), "random", 6999)).to(gpu)
-    strides, offsets = cases.default_layout(fmt, FDW, FDH)
+    strides, offsets = _frame_layout(fmt, FDW, FDH)
     dp = (C.c_void_p * 3)(*[d.data_ptr() + o for o in offsets] + [None] * (3 - len(offsets)))
     ds = (C.c_int32 * 3)(*strides + [0] * (3 - len(strides)))
     V._check(V.lib().gstamd_compositor_aggregate_frame(V.FORMATS[fmt], background, None, None, pads, len(FRAME_PADS), dp, ds, FDW, FDH, None))

@@ -574,6 +574,35 @@ def test_compositor_element_i420_and_nv12_output(gst_env, ref):
             assert (canvas == out[f]).all(), (ofmt, f, int((canvas != out[f]).sum()))
 
 
+def test_compositor_element_10_and_12_bit_planar_canvases(gst_env, ref):
+    """Planar canvases of more than 8 bits (blend.c:609-697): an I420_10LE canvas over black from an I420_10LE pad and a BGRA pad (its pad
+    converter goes through k_encode16), an I422_12LE canvas over the checker; the reference's blend_i420_10le / blend_i422_12le and
+    fill functions pad by pad, black = the limited range's offsets at the format's depth (compositor.c:1131-1149)."""
+    env, tmp = gst_env
+    n, dw, dh = 2, 320, 240
+    for ofmt, bits, bg, bgkind in (("I420_10LE", 10, "black", 1), ("I422_12LE", 12, "checker", 0)):
+        f0, f1, fout = tmp / ("q0_%s.yuv" % ofmt), tmp / ("q1_%s.bgra" % ofmt), tmp / ("qout_%s.yuv" % ofmt)
+        launch(env, "compositor name=c background=%s sink_0::xpos=11 sink_0::ypos=21 sink_0::alpha=0.6 sink_1::xpos=150 sink_1::ypos=100 sink_1::alpha=0.7 "
+                    "! video/x-raw,format=%s,width=%d,height=%d,colorimetry=bt601,chroma-site=jpeg ! filesink location=%s "
+                    "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=%s,width=160,height=120,framerate=30/1,colorimetry=bt601,chroma-site=jpeg ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
+                    "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=BGRA,width=128,height=96,framerate=30/1 ! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1"
+               % (bg, ofmt, dw, dh, fout, n, ofmt, f0, n, f1))
+        out = np.fromfile(fout, np.uint8).reshape(n, -1)
+        s0 = np.fromfile(f0, np.uint8).reshape(n, -1)
+        s1 = np.fromfile(f1, np.uint8).reshape(n, -1)
+        c1 = ref.VideoConverter("BGRA", 128, 96, ofmt, 128, 96, out_colorimetry="bt601", out_chroma_site="jpeg")
+        low = ofmt.lower()
+        for f in range(n):
+            canvas = np.zeros(out.shape[1], np.uint8)
+            if bgkind == 0:
+                ref.compositor_fill(0, low, ofmt, canvas, dw, dh, 0, dh)
+            else:
+                ref.compositor_fill(1, low, ofmt, canvas, dw, dh, 0, dh, 16 << (bits - 8), 128 << (bits - 8), 128 << (bits - 8))
+            ref.compositor_blend("blend_" + low, ofmt, s0[f], 160, 120, 11, 21, 0.6, canvas, dw, dh, 0, dh, 1)
+            ref.compositor_blend("blend_" + low, ofmt, c1.frame(s1[f]), 128, 96, 150, 100, 0.7, canvas, dw, dh, 0, dh, 1)
+            assert (canvas == out[f]).all(), (ofmt, f, int((canvas != out[f]).sum()))
+
+
 def _bench_element(env, args, keep_stderr=False):
     exe = os.path.join(ROOT, "plugins", "tests", "bench_element")
     assert os.path.exists(exe), "plugins/build.py builds it"

@@ -496,7 +496,15 @@ GSTAMD_HD int quad_dot2 (uint32_t pair, uint32_t w, int acc)     // lo(pair) * l
 #endif
 }
 
-GSTAMD_HD int quad_clamp255 (int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+// (the opaque register barrier keeps a preceding shift and this clamp apart: fused into v_ashr_pk_u8_i32 the second lane of a pair came back
+// wrong on gfx950 - video_device.h lq_round)
+GSTAMD_HD int quad_clamp255 (int v)
+{
+#ifdef __HIPCC__
+  asm volatile ("" : "+v" (v));
+#endif
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
 
 // (s1 * t0 + s2 * t1 + 32) >> 6, clamped, per 16-bit half (taps splat over both halves)
 GSTAMD_HD uint32_t quad_vntap_pk (uint32_t s1, uint32_t s2, uint32_t t0s, uint32_t t1s)
@@ -623,7 +631,7 @@ GSTAMD_HD uint32_t quad_sel (uint32_t dd, int base)
 // N = bytes per pixel (1, 2), B = output bytes per lane and row (4, 8), DS = 0, or the plane's uniform distance in pixels between the first
 // taps of neighbouring outputs (PlaneJob::dstep: 2 = a 2:1 reduction - the window bytes of an output are then known at compile time, no
 // selectors to set up and one v_perm per tap pair).  lane: output bytes B * lane .. of rows y0 .. y0 + rows - 1
-template <int N, int B, int DS>
+template <int N, int B, int DS, int MODE>
 GSTAMD_HD void plane_quad_body (const PlaneJob &J, int lane, int y0, int rows, long long ds, long long dd, int nt)
 {
   const int PER = B / N, HALVES = B / 4;          /* pixels per lane; 8-byte halves of the window */
@@ -631,11 +639,15 @@ GSTAMD_HD void plane_quad_body (const PlaneJob &J, int lane, int y0, int rows, l
   if (x >= J.ow)
     return;
   x = x + PER > J.ow ? J.ow - PER : x;          /* the row's last group ends with the row */
-  const ScaleDev &sh = J.pass[J.h_first ? 0 : 1], &sv = J.pass[J.h_first ? 1 : 0];
+  /* MODE >= 0: the passes' order and kinds as compile-time constants (quad_mode_of) - with run-time kinds every output byte of every row
+     went through four wave-uniform branches, ~50 taken branches per wave and row: more clocks than the arithmetic */
+  const bool hfirst = MODE < 0 ? J.h_first != 0 : (MODE & 1) != 0;
+  const ScaleDev &sh = J.pass[hfirst ? 0 : 1], &sv = J.pass[hfirst ? 1 : 0];
+  const int vkind = MODE < 0 ? sv.kind : ((MODE >> 1) & 3) == 0 ? (int) SCALE_NEAREST : ((MODE >> 1) & 3) == 1 ? (int) SCALE_2TAP : (int) SCALE_NTAP;
   int idx[PER];
   uint32_t w[PER];
-  const bool h_ntap = sh.kind == SCALE_NTAP;
-  if (sh.kind == SCALE_2TAP) {
+  const bool h_ntap = MODE < 0 ? sh.kind == SCALE_NTAP : (MODE & 8) != 0;
+  if (!h_ntap && sh.kind == SCALE_2TAP) {
 #pragma unroll
     for (int k = 0; k < PER; k++) {
       const int tmp = (x + k) * sh.inc;
@@ -687,10 +699,18 @@ GSTAMD_HD void plane_quad_body (const PlaneJob &J, int lane, int y0, int rows, l
     for (int j = 0; j < QUAD_CH; j++) {
       const int y = y0 + r0 + j;
       if (r0 + j < rows && y < J.oh) {
-        const int ya = (int) sv.offset[y], yb = sv.kind == SCALE_NEAREST ? ya : (ya + 1 < J.ih ? ya + 1 : J.ih - 1);
-        vt0[j] = sv.kind == SCALE_NTAP ? (int) sv.taps[(size_t) y * 2] : 0, vt1[j] = sv.kind == SCALE_NEAREST ? 0 : (int) sv.taps[(size_t) y * 2 + 1];
+        const int ya = (int) sv.offset[y], yb = vkind == SCALE_NEAREST ? ya : (ya + 1 < J.ih ? ya + 1 : J.ih - 1);
+        vt0[j] = vkind == SCALE_NTAP ? (int) sv.taps[(size_t) y * 2] : 0, vt1[j] = vkind == SCALE_NEAREST ? 0 : (int) sv.taps[(size_t) y * 2 + 1];
+#ifdef GSTAMD_TUNING
+        if (nt & 4) {                   /* profiling builds (results WRONG): no window loads */
+#pragma unroll
+          for (int i = 0; i < 2 * HALVES; i++)
+            ra[j].w[i] = rb[j].w[i] = (uint32_t) (lane + i);
+          continue;
+        }
+#endif
         ra[j] = quad_window<2 * HALVES> (src, (uint32_t) ya * (uint32_t) J.s.stride, off);
-        rb[j] = sv.kind == SCALE_NEAREST ? ra[j] : quad_window<2 * HALVES> (src, (uint32_t) yb * (uint32_t) J.s.stride, off);
+        rb[j] = vkind == SCALE_NEAREST ? ra[j] : quad_window<2 * HALVES> (src, (uint32_t) yb * (uint32_t) J.s.stride, off);
       }
     }
 #pragma unroll
@@ -715,21 +735,21 @@ GSTAMD_HD void plane_quad_body (const PlaneJob &J, int lane, int y0, int rows, l
             pa = bperm (ra[j].w[wi + 1], ra[j].w[wi], cs), pb = bperm (rb[j].w[wi + 1], rb[j].w[wi], cs);
           }
           int q;
-          if (J.h_first) {
+          if (hfirst) {
             int ha = (quad_dot2 (pa, w[k], h_rnd)) >> h_shift, hb = (quad_dot2 (pb, w[k], h_rnd)) >> h_shift;
             if (h_ntap)
               ha = quad_clamp255 (ha), hb = quad_clamp255 (hb);
-            if (sv.kind == SCALE_NEAREST)
+            if (vkind == SCALE_NEAREST)
               q = ha;
-            else if (sv.kind == SCALE_2TAP)
+            else if (vkind == SCALE_2TAP)
               q = (((((hb - ha) * vt1[j] + 128) >> 8) & 0xff) + ha) & 0xff;                        /* v2tap_px */
             else
               q = quad_clamp255 ((int) (int16_t) (uint16_t) (ha * vt0[j] + hb * vt1[j] + 32) >> 6);
           } else {
             uint32_t v;
-            if (sv.kind == SCALE_NEAREST)
+            if (vkind == SCALE_NEAREST)
               v = pa;
-            else if (sv.kind == SCALE_2TAP)
+            else if (vkind == SCALE_2TAP)
               v = v2tap_pk (pa, pb, (uint32_t) (uint16_t) vt1[j] * 0x00010001u);
             else
               v = quad_vntap_pk (pa, pb, (uint32_t) (uint16_t) vt0[j] * 0x00010001u, (uint32_t) (uint16_t) vt1[j] * 0x00010001u);
@@ -743,6 +763,10 @@ GSTAMD_HD void plane_quad_body (const PlaneJob &J, int lane, int y0, int rows, l
 #pragma unroll
         for (int h = 0; h < HALVES; h++)
           st[h] = (o[4 * h] | (o[4 * h + 1] << 8)) | ((o[4 * h + 2] | (o[4 * h + 3] << 8)) << 16);
+#ifdef GSTAMD_TUNING
+        if ((nt & 8) && st[0] != 0x12345678u)          /* profiling builds (results WRONG): no stores */
+          continue;
+#endif
         quad_store<HALVES> (dp + (size_t) y * J.d.stride, x * N, st, nt & 2);
       }
     }
@@ -883,6 +907,38 @@ inline bool plane_raw4_plan (const VideoPlan &p, PlanePlan *pp)
   return plane_quad_ok (*pp, 8);
 }
 
+GSTAMD_HD bool sh_is_2tap (const PlaneJob &J) { return J.pass[J.h_first ? 0 : 1].kind == SCALE_2TAP; }
+
+// the compile-time form of a job's passes for plane_quad_body: bit 0 horizontal first, bits 1-2 the vertical kind (0 nearest, 1 the 2-tap
+// function, 2 a two-tap N-tap filter), bit 3 the horizontal pass is an N-tap filter.  The forms the elements' methods produce are
+// instantiated (bilinear: both orders with the 2-tap functions or with N-tap pairs); anything else runs the generic body (-1).
+GSTAMD_HD int quad_mode_of (const PlaneJob &J)
+{
+  const ScaleDev &sh = J.pass[J.h_first ? 0 : 1], &sv = J.pass[J.h_first ? 1 : 0];
+  const int vk = sv.kind == SCALE_NEAREST ? 0 : sv.kind == SCALE_2TAP ? 1 : 2;
+  return (J.h_first ? 1 : 0) | (vk << 1) | (sh.kind == SCALE_NTAP ? 8 : 0);
+}
+
+template <int N, int B, int DS>
+GSTAMD_HD void plane_quad_modes (const PlaneJob &J, int lane, int y0, int rows, long long ds, long long dd, int nt)
+{
+  const int mode = quad_mode_of (J);
+  if (B == 8 && mode == (0 | (2 << 1) | 8))                 /* V then H, N-tap pairs */
+    plane_quad_body<N, B, DS, (0 | (2 << 1) | 8)> (J, lane, y0, rows, ds, dd, nt);
+  else if (B == 8 && mode == (1 | (2 << 1) | 8))            /* H then V, N-tap pairs */
+    plane_quad_body<N, B, DS, (1 | (2 << 1) | 8)> (J, lane, y0, rows, ds, dd, nt);
+  else if (B == 8 && mode == (0 | (1 << 1) | 8))            /* V 2-tap function then H N-tap pair: the UV plane of NV12 under `bilinear` */
+    plane_quad_body<N, B, DS, (0 | (1 << 1) | 8)> (J, lane, y0, rows, ds, dd, nt);
+  else if (B == 8 && mode == (1 | (1 << 1) | 8))            /* H N-tap pair then V 2-tap function */
+    plane_quad_body<N, B, DS, (1 | (1 << 1) | 8)> (J, lane, y0, rows, ds, dd, nt);
+  else if (B == 8 && mode == (0 | (1 << 1) | 0) && sh_is_2tap (J))          /* V then H, the 2-tap functions */
+    plane_quad_body<N, B, DS, (0 | (1 << 1) | 0)> (J, lane, y0, rows, ds, dd, nt);
+  else if (B == 8 && mode == (1 | (1 << 1) | 0) && sh_is_2tap (J))          /* H then V, the 2-tap functions */
+    plane_quad_body<N, B, DS, (1 | (1 << 1) | 0)> (J, lane, y0, rows, ds, dd, nt);
+  else
+    plane_quad_body<N, B, DS, -1> (J, lane, y0, rows, ds, dd, nt);
+}
+
 // what a lane of k_plane_quad does for a job
 GSTAMD_HD void plane_rows_body (const PlaneJob &J, int lane, int y0, int rows, long long ds = 0, long long dd = 0, int nt = 0)
 {
@@ -892,21 +948,21 @@ GSTAMD_HD void plane_rows_body (const PlaneJob &J, int lane, int y0, int rows, l
   else if (mode == QUAD_S8)
     plane_simple8_body (J, lane, y0, rows, ds, dd, nt);
   else if (mode == QUAD_8 && J.s.n == 4 && J.dstep == 2)
-    plane_quad_body<4, 8, 2> (J, lane, y0, rows, ds, dd, nt);
+    plane_quad_modes<4, 8, 2> (J, lane, y0, rows, ds, dd, nt);
   else if (mode == QUAD_8 && J.s.n == 4)
-    plane_quad_body<4, 8, 0> (J, lane, y0, rows, ds, dd, nt);
+    plane_quad_modes<4, 8, 0> (J, lane, y0, rows, ds, dd, nt);
   else if (mode == QUAD_8 && J.s.n == 1 && J.dstep == 2)
-    plane_quad_body<1, 8, 2> (J, lane, y0, rows, ds, dd, nt);
+    plane_quad_modes<1, 8, 2> (J, lane, y0, rows, ds, dd, nt);
   else if (mode == QUAD_8 && J.s.n == 1)
-    plane_quad_body<1, 8, 0> (J, lane, y0, rows, ds, dd, nt);
+    plane_quad_modes<1, 8, 0> (J, lane, y0, rows, ds, dd, nt);
   else if (mode == QUAD_8 && J.dstep == 2)
-    plane_quad_body<2, 8, 2> (J, lane, y0, rows, ds, dd, nt);
+    plane_quad_modes<2, 8, 2> (J, lane, y0, rows, ds, dd, nt);
   else if (mode == QUAD_8)
-    plane_quad_body<2, 8, 0> (J, lane, y0, rows, ds, dd, nt);
+    plane_quad_modes<2, 8, 0> (J, lane, y0, rows, ds, dd, nt);
   else if (J.s.n == 1)
-    plane_quad_body<1, 4, 0> (J, lane, y0, rows, ds, dd, nt);
+    plane_quad_body<1, 4, 0, -1> (J, lane, y0, rows, ds, dd, nt);
   else
-    plane_quad_body<2, 4, 0> (J, lane, y0, rows, ds, dd, nt);
+    plane_quad_body<2, 4, 0, -1> (J, lane, y0, rows, ds, dd, nt);
 }
 
 // does the plane go through plane_direct_body (host and device)

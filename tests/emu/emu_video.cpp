@@ -1100,6 +1100,9 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       J.tiles_x = (pp.ow + PLN_TW - 1) / PLN_TW;
       J.dstep = getenv ("GSTAMD_PLANE_QUAD_NO_DSTEP") ? 0 : plane_quad_dstep (pp);
       J.quad = getenv ("GSTAMD_NO_PLANE_QUAD") ? 0 : plane_job_quad (J, plane_quad_ok (pp), plane_quad_ok (pp, 8), getenv ("GSTAMD_PLANE_QUAD_MODE") ? atoi (getenv ("GSTAMD_PLANE_QUAD_MODE")) : 2);
+      if (J.quad && getenv ("EMU_QUAD_DEBUG"))
+        fprintf (stderr, "plane %d: n %d quad %d dstep %d h_first %d kinds %d %d mode %d\n", (int) (&pp - &p.planes[0]), J.s.n, J.quad, J.dstep, J.h_first, J.pass[0].kind, J.pass[1].kind,
+            J.kind == PLANE_SCALE ? quad_mode_of (J) : -1);
       if (J.quad) {                           /* k_plane_quad over its grid: 64-lane waves, `rows` rows each */
         g_emu_quad_runs++;
         g_emu_quad_modes |= 1 << (J.quad - 1);

@@ -258,6 +258,23 @@ struct SrcPacked4 {
 #endif
     return apply_color (pre, px);
   }
+  /* pack_planar_block4's row source: four pixels with one 16-byte load (frame rows on 16 bytes: the kernel's `wide` switch) */
+  GSTAMD_HD uint32_t conv (uint32_t raw) const
+  {
+#ifdef __HIPCC__
+    const uint32_t px = __builtin_amdgcn_perm (0u, raw, sel);
+#else
+    const uint32_t px = ((raw >> (8 * pos[0])) & 0xff) | (((raw >> (8 * pos[1])) & 0xff) << 8) | (((raw >> (8 * pos[2])) & 0xff) << 16) |
+        (((raw >> (8 * pos[3])) & 0xff) << 24);
+#endif
+    return apply_color (pre, px);
+  }
+  GSTAMD_HD uint4 row4 (int x0, int y) const
+  {
+    const uint4 r = *(const uint4 *) (p + (size_t) y * stride + 4 * (size_t) x0);
+    return gstamd_make_uint4 (conv (r.x), conv (r.y), conv (r.z), conv (r.w));
+  }
+  GSTAMD_HD uint32_t px (int x, int y) const { return at (x, y); }
 };
 
 inline SrcPacked4 make_src_packed4 (const FrontParams &f, const Planes &pl, const ColorParams &color)

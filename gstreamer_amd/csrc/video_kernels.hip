@@ -1149,11 +1149,16 @@ __global__ __launch_bounds__ (256) void k_pack_planar (PackPlanarParams pk, cons
 }
 
 // the same with the unscaled 8-bit chain as its pixel source: YUY2 -> I420, AYUV -> NV12, I420 -> Y42B ... in one launch, no AYUV image
-__global__ __launch_bounds__ (64) void k_convert_pack (PackPlanarParams pk, SrcPacked4 src, DstPlanes d, FrameDeltas fl)
+__global__ __launch_bounds__ (64) void k_convert_pack (PackPlanarParams pk, SrcPacked4 src, DstPlanes d, int wide, FrameDeltas fl)
 {
   GSTAMD_FRAME_Z;
   src.p += fls_;
-  pack_planar_body (pk, src, d, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y, fld_);
+  const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  /* whole blocks inside the picture in wide accesses (pack_planar_block4 with the frame as its row source: one 16-byte load per line, word /
+     half-word stores); the picture's edge, dither and the 3-byte / packed 4:2:2 packs through the general body */
+  if (wide && pack_planar_block4 (pk, src, d, x0, (int) blockIdx.y, fld_))
+    return;
+  pack_planar_body (pk, src, d, x0, (int) blockIdx.y, fld_);
 }
 
 // 4-byte RGB -> 4:2:0 (video_encode_fast.h): one lane = a 4 x 2 pixel block, one wave per workgroup
@@ -2007,7 +2012,11 @@ hipError_t launch_convert_pack (const PackPlanarParams &pk, const FrontParams &f
     hipLaunchKernelGGL (k_convert_pack_422, dim3 (((pk.width + 7) / 8 + 255) / 256, rows, nz), dim3 (256), 0, stream, pk, src, d, wide, fl);
   } else {
     (void) vpair;
-    hipLaunchKernelGGL (k_convert_pack, dim3 ((lanes + 63) / 64, rows, nz), dim3 (64), 0, stream, pk, make_src_packed4 (f, pl, color), d, fl);
+    int wide = !pk.dither.on && (pk.kind == UNPACK_PLANAR || pk.kind == UNPACK_SEMI) && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 &&
+        !tuning_on ("GSTAMD_NO_CONVERT_PACK_WIDE");
+    for (int i = 0; wide && i < (pk.kind == UNPACK_SEMI ? 2 : 3); i++)
+      wide = ((uintptr_t) planes[i] % 4) == 0 && (strides[i] % 4) == 0;
+    hipLaunchKernelGGL (k_convert_pack, dim3 ((lanes + 63) / 64, rows, nz), dim3 (64), 0, stream, pk, make_src_packed4 (f, pl, color), d, wide, fl);
   }
   return hipGetLastError ();
 }

@@ -221,16 +221,26 @@ GSTAMD_HD bool pack_422dup_block8 (const PackPlanarParams &pk, const Src422Dup &
 // dither stage: 16-byte loads of the block's pixels (the image rows are 16-byte aligned: the caller checks), the luma of a line as one
 // 32-bit store, the chroma as 16-bit (4:2:x planar), 32-bit (semi-planar, 4:4:4) stores; the arithmetic is pack_planar_body's on the same
 // packed {U, V} words.  Returns false for the blocks it leaves to the general body (picture edge, tail_swap pixel).
-GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const uint8_t *__restrict__ img, int sstride, const DstPlanes &d, int x0, int yb, long long dd = 0)
+// ROWS: where four / one AYUV pixels of a row come from - the AYUV image (ImgRows), or a 4-byte source frame through its unpack permutation and
+// colour stage (SrcPacked4: k_convert_pack's block form)
+struct ImgRows {
+  const uint8_t *img;
+  int sstride;
+  GSTAMD_HD uint4 row4 (int x0, int y) const { return *(const uint4 *) (img + (size_t) y * sstride + 4 * (size_t) x0); }
+  GSTAMD_HD uint32_t px (int x, int y) const { return *(const uint32_t *) (img + (size_t) y * sstride + 4 * (size_t) x); }
+};
+
+template <class ROWS>
+GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const ROWS &rows, const DstPlanes &d, int x0, int yb, long long dd = 0)
 {
   const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
   if (x0 + 4 > w || y0 >= h || (pk.tail_swap && x0 + 4 == w && (w & 1)))
     return false;
   const int yb1 = y0 + 1 < h ? y0 + 1 : (pk.virtual_line ? h : h - 1);
-  const uint4 a = *(const uint4 *) (img + (size_t) y0 * sstride + 4 * (size_t) x0);
+  const uint4 a = rows.row4 (x0, y0);
   uint4 b = a;
   if (pk.h_sub || pk.down_v)
-    b = *(const uint4 *) (img + (size_t) yb1 * sstride + 4 * (size_t) x0);
+    b = rows.row4 (x0, yb1);
   // luma
   *(uint32_t *) ((d.p[0] + dd) + (size_t) y0 * d.stride[0] + x0) = ((a.x >> 8) & 0xffu) | (a.y & 0xff00u) | ((a.z << 8) & 0xff0000u) | ((a.w << 16) & 0xff000000u);
   if (pk.h_sub && y0 + 1 < h)
@@ -242,11 +252,11 @@ GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const uint8_t *__
   uint32_t em = 0, ep = 0, fm = 0, fp = 0;
   const int xm = x0 > 0 ? x0 - 1 : 0, xp = x0 + 4 < w ? x0 + 4 : w - 1;
   if (edges) {
-    em = *(const uint32_t *) (img + (size_t) y0 * sstride + 4 * (size_t) xm);
-    ep = *(const uint32_t *) (img + (size_t) y0 * sstride + 4 * (size_t) xp);
+    em = rows.px (xm, y0);
+    ep = rows.px (xp, y0);
     if (pk.down_v) {
-      fm = *(const uint32_t *) (img + (size_t) yb1 * sstride + 4 * (size_t) xm);
-      fp = *(const uint32_t *) (img + (size_t) yb1 * sstride + 4 * (size_t) xp);
+      fm = rows.px (xm, yb1);
+      fp = rows.px (xp, yb1);
     }
   }
   v[0] = ayuv_uv (em), v[5] = ayuv_uv (ep);
@@ -303,6 +313,12 @@ GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const uint8_t *__
     }
   }
   return true;
+}
+
+GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const uint8_t *__restrict__ img, int sstride, const DstPlanes &d, int x0, int yb, long long dd = 0)
+{
+  const ImgRows rows = {img, sstride};
+  return pack_planar_block4 (pk, rows, d, x0, yb, dd);
 }
 
 // The chroma downsamplers alone, on the AYUV image in place, exactly as the reference's line caches leave the lines (the error-diffusion

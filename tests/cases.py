@@ -624,6 +624,17 @@ VIDEO_CASES = [
     ("quad4_bgra_crop_dest_bilinear", "BGRA", 640, 480, "BGRA", 480, 360, dict(LIN, src_x=32, src_y=16, src_width=400, src_height=300, dest_x=20, dest_y=10, dest_width=300, dest_height=226), None, None, "random"),
     ("quad4_bgra_4k_to_1080p", "BGRA", 3840, 2160, "BGRA", 1920, 1080, LIN, None, None, "random"),
     ("quad4_bgra_1080p_to_4k", "BGRA", 1920, 1080, "BGRA", 3840, 2160, LIN, None, None, "random"),
+    # k_convert_pack's block form (pack_planar_block4 with the frame as its row source): 4-byte sources into planar / semi-planar YUV, one 16-byte load per line
+    ("pack4_bgra_y444_matrix", "BGRA", 128, 36, "Y444", 128, 36, {}, None, None, "random"),
+    ("pack4_rgba_i420_cosited", "RGBA", 128, 37, "I420", 128, 37, dict(matrix_mode="none"), None, "cosited", "random"),
+    ("pack4_ayuv_nv12", "AYUV", 128, 36, "NV12", 128, 36, {}, None, None, "random"),
+    ("pack4_vuya_nv21_mpeg2", "VUYA", 64, 35, "NV21", 64, 35, {}, None, "mpeg2", "random"),
+    ("pack4_xbgr_y42b_cosited", "xBGR", 64, 19, "Y42B", 64, 19, {}, None, "cosited", "random"),
+    ("pack4_argb_yv12_alpha_set", "ARGB", 64, 36, "YV12", 64, 36, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+    ("pack4_bgra_nv24", "BGRA", 68, 20, "NV24", 68, 20, {}, None, None, "random"),
+    ("pack4_bgra_y444_width_not_4", "BGRA", 66, 20, "Y444", 66, 20, {}, None, None, "random"),
+    ("pack4_bgra_y444_4k", "BGRA", 3840, 2160, "Y444", 3840, 2160, {}, None, None, "random"),
+    ("pack4_ayuv_nv12_4k", "AYUV", 3840, 2160, "NV12", 3840, 2160, {}, None, None, "random"),
     # k_encode16: 4-byte 8-bit pixels straight into deep planar / semi-planar 4:2:0 / 4:2:2 YUV (widen, matrix16, chroma down, dither, pack in one kernel)
     ("enc16_bgra_p010_cosited", "BGRA", 64, 36, "P010_10LE", 64, 36, {}, None, "cosited", "random"),
     ("enc16_rgba_p010_odd_height", "RGBA", 64, 37, "P010_10LE", 64, 37, {}, None, None, "random"),

@@ -257,6 +257,8 @@ extern "C" int emu_quad_grid_check (int n0, int n1, int n2)
   return 1;
 }
 static int g_emu_deep16_runs = 0;
+static int g_emu_pack4_runs = 0;
+extern "C" int emu_pack4_runs (void) { return g_emu_pack4_runs; }
 static int g_emu_enc16_runs = 0;
 extern "C" int emu_enc16_runs (void) { return g_emu_enc16_runs; }
 static int g_emu_quad_runs = 0, g_emu_quad_modes = 0;
@@ -1251,8 +1253,18 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
             continue;
           pack_planar_body (p.pack, s422, d, x0, yb);
           pack_planar_body (p.pack, s422, d, x0 + 4, yb);
-        } else
-          pack_planar_body (p.pack, make_src_packed4 (p.front, pl, sf.pre), d, x0, yb);
+        } else {
+          const SrcPacked4 s4 = make_src_packed4 (p.front, pl, sf.pre);
+          bool wide = vec_ok && !p.pack.dither.on && (p.pack.kind == UNPACK_PLANAR || p.pack.kind == UNPACK_SEMI) && ((uintptr_t) pl.p[0] % 16) == 0 &&
+              (pl.stride[0] % 16) == 0 && getenv ("GSTAMD_NO_CONVERT_PACK_WIDE") == nullptr;
+          for (int i = 0; wide && i < (p.pack.kind == UNPACK_SEMI ? 2 : 3); i++)
+            wide = ((uintptr_t) d.p[i] % 4) == 0 && (d.stride[i] % 4) == 0;
+          if (wide && pack_planar_block4 (p.pack, s4, d, x0, yb)) {
+            g_emu_pack4_runs++;
+            continue;
+          }
+          pack_planar_body (p.pack, s4, d, x0, yb);
+        }
     return GSTAMD_OK;
   }
   if (p.out_planar) {                     /* chain -> AYUV image, then the pack kernel body over its grid */

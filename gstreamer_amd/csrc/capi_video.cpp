@@ -59,6 +59,8 @@ struct GstAmdVideoConverter {
   std::vector<int> plane_dstep;
   bool raw4_quad = false;                 // plane_raw4_plan: the 4-byte plane scaler goes through k_plane_quad
   int raw4_dstep = 0;
+  bool raw4_pack = false, raw4_pack_enc420 = false;          // plane_raw4_pack_plan
+  int raw4_pack_dstep = 0;
   std::vector<bool> plane_quad, plane_oct;        // per plane of the plan: plane_quad_ok / plane_oct_ok (k_plane_quad takes it where the destination rows allow)
   void *ed_carry = nullptr;                // error-diffusion dither on rectangles taller than one band: the band's last line of errors (video_dither_ed.h)
   uint8_t *pre_img = nullptr;             // enlarging from a planar / packed 4:2:2 source: the source frame after front + colour stage, at its own size
@@ -484,6 +486,8 @@ static int build_tables (GstAmdVideoConverter *c)
     PlanePlan raw4;
     c->raw4_quad = plane_raw4_plan (p, &raw4);
     c->raw4_dstep = c->raw4_quad ? plane_quad_dstep (raw4) : 0;
+    c->raw4_pack = plane_raw4_pack_plan (p, &raw4, &c->raw4_pack_enc420);
+    c->raw4_pack_dstep = c->raw4_pack ? plane_quad_dstep (raw4) : 0;
   }
   if (p.plane_mode) {
     size_t tmp_bytes = 0;
@@ -1062,6 +1066,46 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
          in between */
       hipError_t ce = launch_convert_pack (p.pack, p.front, pl, c->vpair_dev, color, planes, strides, stream);
       return ce == hipSuccess ? GSTAMD_OK : hip_fail (ce, "k_convert_pack");
+    }
+    if (c->raw4_pack && pl.p[0] && !c->hook_on && !tuning_on ("GSTAMD_NO_PLANE_QUAD")) {
+      /* plane_raw4_pack_plan: the scaler on the raw 4-byte pixels into the image, then the unscaled block kernels from it */
+      const int ow = p.out_info.width, oh = p.out_info.height;
+      PlaneJobs jobs;
+      memset ((void *) &jobs, 0, sizeof (jobs));
+      PlaneJob &J = jobs.job[0];
+      J.kind = PLANE_SCALE;
+      J.s.p = pl.p[0], J.s.stride = pl.stride[0], J.s.n = 4;
+      J.d.p = c->pk_img, J.d.stride = ow * 4, J.d.n = 4;
+      J.iw = p.front.width, J.ih = p.front.height, J.ow = ow, J.oh = oh;
+      J.n_pass = 2;
+      J.h_first = p.passes[0].horizontal ? 1 : 0;
+      for (int q = 0; q < 2; q++) {
+        J.pass[q].kind = p.passes[q].kind;
+        J.pass[q].n_taps = p.passes[q].n_taps;
+        J.pass[q].inc = p.passes[q].inc;
+        J.pass[q].offset = c->pass_dev[q].offset;
+        J.pass[q].taps = c->pass_dev[q].taps;
+      }
+      J.dstep = tuning_on ("GSTAMD_PLANE_QUAD_NO_DSTEP") ? 0 : c->raw4_pack_dstep;
+      J.quad = 1 + QUAD_8;
+      J.tiles_x = 1;
+      jobs.n = 1;
+      hipError_t qe = launch_plane_frame (jobs, 0, stream);
+      if (qe != hipSuccess)
+        return hip_fail (qe, "k_plane_quad(4-byte pixels)");
+      bool enc = c->raw4_pack_enc420 && ((uintptr_t) planes[0] % 4) == 0 && (strides[0] % 4) == 0 && ((uintptr_t) planes[1] % 4) == 0 && (strides[1] % 4) == 0 &&
+          (p.fout->kind == UNPACK_SEMI || (((uintptr_t) planes[2] % 4) == 0 && (strides[2] % 4) == 0));
+      if (enc) {
+        qe = launch_encode420 (make_enc420_params (p), p.fout->kind == UNPACK_SEMI, c->pk_img, ow * 4, planes, strides, stream);
+        return qe == hipSuccess ? GSTAMD_OK : hip_fail (qe, "k_encode420");
+      }
+      FrontParams f2 = p.front;
+      f2.width = ow, f2.height = oh;
+      Planes pl2;
+      memset ((void *) &pl2, 0, sizeof (pl2));
+      pl2.p[0] = c->pk_img, pl2.stride[0] = ow * 4;
+      qe = launch_convert_pack (p.pack, f2, pl2, nullptr, color, planes, strides, stream);
+      return qe == hipSuccess ? GSTAMD_OK : hip_fail (qe, "k_convert_pack");
     }
     r = convert_to_packed (c, pl, c->pk_img, p.out_info.width * 4, stream);
     if (r != GSTAMD_OK)

@@ -907,6 +907,35 @@ inline bool plane_raw4_plan (const VideoPlan &p, PlanePlan *pp)
   return plane_quad_ok (*pp, 8);
 }
 
+// host: a 4-byte 8-bit packed source shrunk by two short passes into a planar / semi-planar 8-bit destination (BGRA 4K -> NV12 1080p: screen
+// capture into an encoder).  The chain is unpack (a byte permutation) -> scale -> matrix -> chroma down -> pack; the scaler works per byte, so
+// it runs on the RAW pixels (k_plane_quad, four-byte pixels) into the plan's AYUV-sized image and the UNSCALED kernels - k_encode420 or
+// k_convert_pack, with the source format at the destination's size - finish from there: two launches, 12 + 4 us instead of the one-lane-per-pixel
+// scaler's 20 + the packer's 9.  *pp = the scaler's plane; *enc420 = the block encoder applies (planner.cpp's fast_enc420 test without the
+// "no scaler" clause).
+inline bool plane_raw4_pack_plan (const VideoPlan &p, PlanePlan *pp, bool *enc420)
+{
+  if (!p.out_planar || p.plane_mode || p.gamma.on || p.deep16 || p.deep_out || p.front.kind != UNPACK_PACKED4 || p.front.hi_depth != 0 || p.passes.size () != 2 ||
+      p.matrix_before_scale || p.pack.virtual_line || p.dither.on || p.post.pack_pos[0] != 0 || p.post.pack_pos[1] != 1 || p.post.pack_pos[2] != 2 || p.post.pack_pos[3] != 3)
+    return false;
+  if (p.pack.dither.on && p.pack.dither.method != GSTAMD_DITHER_NONE && p.pack.dither.method != GSTAMD_DITHER_BAYER)
+    return false;
+  pp->kind = PLANE_SCALE;
+  pp->src_plane = pp->dst_plane = 0;
+  pp->n_elems = 4;
+  pp->iw = p.front.width, pp->ih = p.front.height, pp->ow = p.out_info.width, pp->oh = p.out_info.height;
+  pp->passes = p.passes;
+  if ((long long) pp->ow * pp->oh > (long long) pp->iw * pp->ih || !plane_quad_ok (*pp, 8))
+    return false;
+  bool fits = kind_has_planes (p.fout->kind) && p.fout->w_sub == 1 && p.fout->h_sub == 1 && !p.fin->yuv && p.matrix.kind == MATRIX_TABLE && (pp->ow % 4) == 0 &&
+      !p.pack.dither.on;
+  for (int k = 0; k < 3; k++)
+    for (int j = 0; j < 3; j++)
+      fits = fits && abs (p.matrix.im[k][j]) <= 255;
+  *enc420 = fits;
+  return true;
+}
+
 GSTAMD_HD bool sh_is_2tap (const PlaneJob &J) { return J.pass[J.h_first ? 0 : 1].kind == SCALE_2TAP; }
 
 // the compile-time form of a job's passes for plane_quad_body: bit 0 horizontal first, bits 1-2 the vertical kind (0 nearest, 1 the 2-tap

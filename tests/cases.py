@@ -635,6 +635,15 @@ VIDEO_CASES = [
     ("pack4_bgra_y444_width_not_4", "BGRA", 66, 20, "Y444", 66, 20, {}, None, None, "random"),
     ("pack4_bgra_y444_4k", "BGRA", 3840, 2160, "Y444", 3840, 2160, {}, None, None, "random"),
     ("pack4_ayuv_nv12_4k", "AYUV", 3840, 2160, "NV12", 3840, 2160, {}, None, None, "random"),
+    # 4-byte sources shrunk by two short passes into planar destinations: k_plane_quad on the raw pixels, then k_encode420 / k_convert_pack (plane_raw4_pack_plan)
+    ("rawpack_bgra_nv12_half_bilinear", "BGRA", 640, 360, "NV12", 320, 180, LIN, None, None, "random"),
+    ("rawpack_rgba_i420_3_2_cosited", "RGBA", 640, 360, "I420", 428, 240, LIN, None, "cosited", "random"),
+    ("rawpack_bgrx_y444_half_nearest", "BGRx", 320, 240, "Y444", 160, 120, NEAR, None, None, "random"),
+    ("rawpack_argb_y42b_down_odd", "ARGB", 333, 111, "Y42B", 200, 77, LIN, None, None, "random"),
+    ("rawpack_ayuv_nv21_half", "AYUV", 320, 240, "NV21", 160, 120, LIN, None, None, "random"),
+    ("rawpack_bgra_nv12_odd_height", "BGRA", 320, 242, "NV12", 160, 121, LIN, None, None, "random"),
+    ("rawpack_bgra_nv12_dither", "BGRA", 320, 240, "NV12", 160, 120, dict(LIN, dither_quantization=8), None, None, "random"),
+    ("rawpack_bgra_nv12_4k_to_1080p", "BGRA", 3840, 2160, "NV12", 1920, 1080, LIN, None, None, "random"),
     # k_encode16: 4-byte 8-bit pixels straight into deep planar / semi-planar 4:2:0 / 4:2:2 YUV (widen, matrix16, chroma down, dither, pack in one kernel)
     ("enc16_bgra_p010_cosited", "BGRA", 64, 36, "P010_10LE", 64, 36, {}, None, "cosited", "random"),
     ("enc16_rgba_p010_odd_height", "RGBA", 64, 37, "P010_10LE", 64, 37, {}, None, None, "random"),

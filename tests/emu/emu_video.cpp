@@ -1267,6 +1267,80 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         }
     return GSTAMD_OK;
   }
+  {
+    PlanePlan raw4;
+    bool enc420 = false;
+    if (plane_raw4_pack_plan (p, &raw4, &enc420) && getenv ("GSTAMD_NO_PLANE_QUAD") == nullptr && vec_ok) {
+      /* k_plane_quad on the raw 4-byte pixels into the image, then k_encode420 / k_convert_pack from it (capi_video.cpp: raw4_pack) */
+      const int ow = p.out_info.width, oh = p.out_info.height;
+      std::vector<uint32_t> img ((size_t) ow * (oh + 1) + 4);
+      PlaneJob J;
+      memset ((void *) &J, 0, sizeof (J));
+      J.kind = PLANE_SCALE;
+      J.s = {pl.p[0], pl.stride[0], 4, 0};
+      J.d = {(uint8_t *) img.data (), ow * 4, 4};
+      J.iw = raw4.iw, J.ih = raw4.ih, J.ow = ow, J.oh = oh;
+      J.n_pass = 2;
+      J.h_first = p.passes[0].horizontal ? 1 : 0;
+      for (int q = 0; q < 2; q++) {
+        J.pass[q].kind = p.passes[q].kind;
+        J.pass[q].n_taps = p.passes[q].n_taps;
+        J.pass[q].inc = p.passes[q].inc;
+        J.pass[q].offset = p.passes[q].offset.data ();
+        J.pass[q].taps = p.passes[q].taps.data ();
+      }
+      J.dstep = getenv ("GSTAMD_PLANE_QUAD_NO_DSTEP") ? 0 : plane_quad_dstep (raw4);
+      J.quad = 1 + QUAD_8;
+      g_emu_quad_runs++;
+      const int qrows = getenv ("GSTAMD_PLANE_QUAD_ROWS") ? atoi (getenv ("GSTAMD_PLANE_QUAD_ROWS")) : 3;
+      const int lanes = (((ow * 4 + 7) / 8 + 63) / 64) * 64;
+      for (int y0 = 0; y0 < oh; y0 += qrows)
+        for (int lane = 0; lane < lanes; lane++)
+          plane_rows_body (J, lane, y0, qrows);
+      DstPlanes d;
+      memset (&d, 0, sizeof (d));
+      bool enc = enc420;
+      for (int i = 0; i < out->n_planes && i < 3; i++) {
+        d.p[i] = dst + out->offset[i];
+        d.stride[i] = out->stride[i];
+        enc = enc && ((uintptr_t) d.p[i] % 4) == 0 && (d.stride[i] % 4) == 0;
+      }
+      if (enc) {
+        const Enc420Params ep = make_enc420_params (p);
+        for (int r2 = 0; r2 < (ep.height + 1) / 2; r2++)
+          for (int x0 = 0; x0 < (ep.width / 4 + 63) / 64 * 256; x0 += 4) {
+            if (p.fout->kind == UNPACK_SEMI)
+              enc420_block<1> (ep, (const uint8_t *) img.data (), ow * 4, d, x0, r2);
+            else
+              enc420_block<0> (ep, (const uint8_t *) img.data (), ow * 4, d, x0, r2);
+          }
+        return GSTAMD_OK;
+      }
+      FrontParams f2 = p.front;
+      f2.width = ow, f2.height = oh;
+      Planes pl2;
+      memset ((void *) &pl2, 0, sizeof (pl2));
+      pl2.p[0] = (const uint8_t *) img.data (), pl2.stride[0] = ow * 4;
+      ColorParams color;
+      memset (&color, 0, sizeof (color));
+      color.matrix = p.matrix;
+      color.alpha_kind = p.post.alpha_kind;
+      color.alpha_value = p.post.alpha_value;
+      const SrcPacked4 s4 = make_src_packed4 (f2, pl2, color);
+      bool wide = !p.pack.dither.on && (p.pack.kind == UNPACK_PLANAR || p.pack.kind == UNPACK_SEMI) && getenv ("GSTAMD_NO_CONVERT_PACK_WIDE") == nullptr;
+      for (int i = 0; wide && i < (p.pack.kind == UNPACK_SEMI ? 2 : 3); i++)
+        wide = ((uintptr_t) d.p[i] % 4) == 0 && (d.stride[i] % 4) == 0;
+      wide = wide && ((uintptr_t) img.data () % 16) == 0 && ((ow * 4) % 16) == 0;
+      const int prow = (oh + (1 << p.pack.h_sub) - 1) >> p.pack.h_sub;
+      for (int yb = 0; yb < prow; yb++)
+        for (int x0 = 0; x0 < ow; x0 += 4) {
+          if (wide && pack_planar_block4 (p.pack, s4, d, x0, yb))
+            continue;
+          pack_planar_body (p.pack, s4, d, x0, yb);
+        }
+      return GSTAMD_OK;
+    }
+  }
   if (p.out_planar) {                     /* chain -> AYUV image, then the pack kernel body over its grid */
     std::vector<uint8_t> img ((size_t) p.out_info.width * 4 * (p.out_info.height + 1));          /* + the line past the picture */
     g_extra_rows = p.pack.virtual_line;

@@ -345,25 +345,54 @@ GSTAMD_HD void deep_front4_t (const FrontParams &f, const Planes &pl, const int 
   }
   const int wb = 4 - wa;
   int u[2][4], v[2][4];
+  /* the chroma positions k0 - 1 .. k0 + 2 (clamped into the row) of a chroma row with ONE load per plane where the row has four positions:
+     position by position the kernel issued eight loads per line and lane and sat on the vector-memory issue rate (P010 4K -> BGRA 25 us).  The
+     window starts at k0 - 1; the row's first lane starts it at 0, the last at cw - 4, and both take their clamped positions by selects */
+  const bool left = k0 == 0, right = k0 + 2 > cw - 1, wide_c = cw >= 4;
+  const int cbase = left ? 0 : (right ? cw - 4 : k0 - 1);
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const int crow = r ? rb : ra;
+    int su[4], sv[4];
+    if (wide_c) {
+      uint32_t e[4];                  /* {U | V << 16} of the four positions */
+      if (SEMI) {
+        struct __attribute__ ((aligned (4))) C4 { uint32_t w[4]; };
+        const C4 c = *(const C4 *) (pl.p[1] + (ptrdiff_t) crow * pl.stride[1] + 4 * (ptrdiff_t) cbase);
+        const uint32_t w0 = f.u_plane ? c.w[0] : (c.w[0] >> 16) | (c.w[0] << 16), w1 = f.u_plane ? c.w[1] : (c.w[1] >> 16) | (c.w[1] << 16);
+        const uint32_t w2 = f.u_plane ? c.w[2] : (c.w[2] >> 16) | (c.w[2] << 16), w3 = f.u_plane ? c.w[3] : (c.w[3] >> 16) | (c.w[3] << 16);
+        e[0] = right ? w1 : w0, e[1] = left ? w0 : (right ? w2 : w1), e[2] = left ? w1 : (right ? w3 : w2), e[3] = left ? w2 : w3;
+      } else {
+        struct __attribute__ ((aligned (2))) C4 { uint16_t h[4]; };
+        const C4 cu = *(const C4 *) (pl.p[f.u_plane] + (ptrdiff_t) crow * pl.stride[f.u_plane] + 2 * (ptrdiff_t) cbase);
+        const C4 cv = *(const C4 *) (pl.p[f.v_plane] + (ptrdiff_t) crow * pl.stride[f.v_plane] + 2 * (ptrdiff_t) cbase);
+        const uint32_t w0 = (uint32_t) cu.h[0] | ((uint32_t) cv.h[0] << 16), w1 = (uint32_t) cu.h[1] | ((uint32_t) cv.h[1] << 16);
+        const uint32_t w2 = (uint32_t) cu.h[2] | ((uint32_t) cv.h[2] << 16), w3 = (uint32_t) cu.h[3] | ((uint32_t) cv.h[3] << 16);
+        e[0] = right ? w1 : w0, e[1] = left ? w0 : (right ? w2 : w1), e[2] = left ? w1 : (right ? w3 : w2), e[3] = left ? w2 : w3;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        su[i] = (int) (e[i] & 0xffffu), sv[i] = (int) (e[i] >> 16);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        int k = k0 - 1 + i;
+        k = k < 0 ? 0 : (k > cw - 1 ? cw - 1 : k);
+        if (SEMI) {
+          const uint32_t t = ((const uint32_t *) (pl.p[1] + (ptrdiff_t) crow * pl.stride[1]))[k];
+          const int lo = (int) (t & 0xffffu), hi = (int) (t >> 16);
+          su[i] = f.u_plane ? lo : hi;
+          sv[i] = f.u_plane ? hi : lo;
+        } else {
+          su[i] = ((const uint16_t *) (pl.p[f.u_plane] + (ptrdiff_t) crow * pl.stride[f.u_plane]))[k];
+          sv[i] = ((const uint16_t *) (pl.p[f.v_plane] + (ptrdiff_t) crow * pl.stride[f.v_plane]))[k];
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      int k = k0 - 1 + i;
-      k = k < 0 ? 0 : (k > cw - 1 ? cw - 1 : k);
-      int su, sv;
-      if (SEMI) {
-        const uint32_t t = ((const uint32_t *) (pl.p[1] + (ptrdiff_t) crow * pl.stride[1]))[k];
-        const int lo = (int) (t & 0xffffu), hi = (int) (t >> 16);
-        su = f.u_plane ? lo : hi;
-        sv = f.u_plane ? hi : lo;
-      } else {
-        su = ((const uint16_t *) (pl.p[f.u_plane] + (ptrdiff_t) crow * pl.stride[f.u_plane]))[k];
-        sv = ((const uint16_t *) (pl.p[f.v_plane] + (ptrdiff_t) crow * pl.stride[f.v_plane]))[k];
-      }
-      u[r][i] = deep_widen_w (wd, su);
-      v[r][i] = deep_widen_w (wd, sv);
+      u[r][i] = deep_widen_w (wd, su[i]);
+      v[r][i] = deep_widen_w (wd, sv[i]);
     }
   }
 #pragma unroll
@@ -450,13 +479,17 @@ GSTAMD_HD void deep_finish_store4 (const Deep16Params &d, const PostParams &post
     o[i] = pack_px (post.pack_pos, w8);
 #endif
   }
-  if ((((uintptr_t) out) & 15) == 0) {
-    *(uint4 *) out = gstamd_make_uint4 (o[0], o[1], o[2], o[3]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      out[i] = o[i];
-  }
+  /* one 16-byte store whatever the row's alignment (a dword-aligned vector type: the hardware takes it; the two-way form "aligned ? one store :
+     four" came out of the compiler as four stores on both sides) */
+#ifdef __HIPCC__
+  typedef uint32_t u32x4_a4 __attribute__ ((ext_vector_type (4), aligned (4)));
+  u32x4_a4 v;
+  v.x = o[0], v.y = o[1], v.z = o[2], v.w = o[3];
+  *(u32x4_a4 *) out = v;
+#else
+  for (int i = 0; i < 4; i++)
+    out[i] = o[i];
+#endif
 }
 
 // pixels x0 .. x0+3 of row y

@@ -120,6 +120,20 @@ struct PkAcc {
 
 GSTAMD_HD uint32_t tap_splat (int16_t t) { return (uint32_t) (uint16_t) t * 0x00010001u; }
 
+// the eight taps of an output as four words with ONE load (a row of the tap table: 16 bytes on a 16-byte boundary), tap l in both halves of a
+// register with one v_perm - tap by tap the kernel issued a 2-byte load per tap and lane, ~10 per canvas pixel, and sat on the vector-memory
+// issue rate (C4-A: 103 us)
+struct Taps8 { uint32_t w[4]; };
+GSTAMD_HD Taps8 taps8_load (const int16_t *t)
+{
+  Taps8 r;
+  const uint4 v = *(const uint4 *) t;
+  r.w[0] = v.x, r.w[1] = v.y, r.w[2] = v.z, r.w[3] = v.w;
+  return r;
+}
+template <int L>
+GSTAMD_HD uint32_t taps8_splat (const Taps8 &t) { return bperm (0u, t.w[L >> 1], (L & 1) ? 0x03020302u : 0x01000100u); }
+
 GSTAMD_HD void vscale_span (const ScaleDev &sd, int t0, int t1, int *y_lo, int *y_hi)
 {
   const int n = sd.kind == SCALE_NEAREST ? 1 : (sd.kind == SCALE_2TAP ? 2 : sd.n_taps);
@@ -169,7 +183,21 @@ GSTAMD_HD void scaled_tile_stage (const ScaledPadDev &sp, const ScaledTileGeom &
     for (int i = tid; i < n; i += nthreads) {
       const int r = i / nq, c = (i - r * nq) * 4, sy = g.sy0 + r;
       uint32_t *out = lds + r * g.pitch + c;
-      if (sp.sv.kind == SCALE_NTAP && g.lo + c + 4 <= src_w) {
+      if (sp.sv.kind == SCALE_NTAP && sp.sv.n_taps == 8 && g.lo + c + 4 <= src_w) {
+        const Taps8 t8 = taps8_load (sp.sv.taps + (size_t) sy * 8);
+        const uint8_t *q = img.p + (size_t) sp.sv.offset[sy] * img.stride + 4 * (size_t) (g.lo + c);
+        PkAcc a[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        W4 w[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++)
+          w[l] = *(const W4 *) (q + (size_t) l * img.stride);
+#define GSTAMD_V8(L) { const uint32_t ts = taps8_splat<L> (t8); for (int k = 0; k < 4; k++) a[k].mad (w[L].v[k], ts); }
+        GSTAMD_V8 (0) GSTAMD_V8 (1) GSTAMD_V8 (2) GSTAMD_V8 (3) GSTAMD_V8 (4) GSTAMD_V8 (5) GSTAMD_V8 (6) GSTAMD_V8 (7)
+#undef GSTAMD_V8
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          out[k] = a[k].finish ();
+      } else if (sp.sv.kind == SCALE_NTAP && g.lo + c + 4 <= src_w) {
         const int16_t *t = sp.sv.taps + (size_t) sy * sp.sv.n_taps;
         const uint8_t *q = img.p + (size_t) sp.sv.offset[sy] * img.stride + 4 * (size_t) (g.lo + c);
         PkAcc a[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -194,7 +222,16 @@ GSTAMD_HD void scaled_tile_stage (const ScaledPadDev &sp, const ScaledTileGeom &
   const int n = g.w * g.rows;
   for (int i = tid; i < n; i += nthreads) {
     const int r = i / g.w, c = i - r * g.w, sx = g.sx0 + c;
-    if (sp.sh.kind == SCALE_NTAP) {
+    if (sp.sh.kind == SCALE_NTAP && sp.sh.n_taps == 8) {
+      struct __attribute__ ((aligned (4))) W4 { uint32_t v[4]; };
+      const Taps8 t8 = taps8_load (sp.sh.taps + (size_t) sx * 8);
+      const uint32_t *q = (const uint32_t *) (img.p + (size_t) (g.lo + r) * img.stride) + sp.sh.offset[sx];
+      const W4 qa = *(const W4 *) q, qb = *(const W4 *) (q + 4);
+      PkAcc a = {0, 0};
+      a.mad (qa.v[0], taps8_splat<0> (t8)), a.mad (qa.v[1], taps8_splat<1> (t8)), a.mad (qa.v[2], taps8_splat<2> (t8)), a.mad (qa.v[3], taps8_splat<3> (t8));
+      a.mad (qb.v[0], taps8_splat<4> (t8)), a.mad (qb.v[1], taps8_splat<5> (t8)), a.mad (qb.v[2], taps8_splat<6> (t8)), a.mad (qb.v[3], taps8_splat<7> (t8));
+      lds[i] = a.finish ();
+    } else if (sp.sh.kind == SCALE_NTAP) {
       const int16_t *t = sp.sh.taps + (size_t) sx * sp.sh.n_taps;
       const uint32_t *q = (const uint32_t *) (img.p + (size_t) (g.lo + r) * img.stride) + sp.sh.offset[sx];
       PkAcc a = {0, 0};
@@ -220,6 +257,14 @@ GSTAMD_HD uint32_t scaled_tile_px (const ScaledPadDev &sp, const ScaledTileGeom 
 {
   if (g.mode == 2) {
     const uint32_t *rowp = lds + (sy - g.sy0) * g.pitch;
+    if (sp.sh.kind == SCALE_NTAP && sp.sh.n_taps == 8) {
+      const Taps8 t8 = taps8_load (sp.sh.taps + (size_t) sx * 8);
+      const uint32_t *q = rowp + ((int) sp.sh.offset[sx] - g.lo);
+      PkAcc a = {0, 0};
+      a.mad (q[0], taps8_splat<0> (t8)), a.mad (q[1], taps8_splat<1> (t8)), a.mad (q[2], taps8_splat<2> (t8)), a.mad (q[3], taps8_splat<3> (t8));
+      a.mad (q[4], taps8_splat<4> (t8)), a.mad (q[5], taps8_splat<5> (t8)), a.mad (q[6], taps8_splat<6> (t8)), a.mad (q[7], taps8_splat<7> (t8));
+      return a.finish ();
+    }
     if (sp.sh.kind == SCALE_NTAP) {
       const int16_t *t = sp.sh.taps + (size_t) sx * sp.sh.n_taps;
       const uint32_t *q = rowp + ((int) sp.sh.offset[sx] - g.lo);
@@ -231,6 +276,14 @@ GSTAMD_HD uint32_t scaled_tile_px (const ScaledPadDev &sp, const ScaledTileGeom 
     }
     const RowOfLds row = {rowp, g.lo};
     return hscale_px (row, sp.sh, sx);
+  }
+  if (sp.sv.kind == SCALE_NTAP && sp.sv.n_taps == 8) {
+    const Taps8 t8 = taps8_load (sp.sv.taps + (size_t) sy * 8);
+    const uint32_t *q = lds + ((int) sp.sv.offset[sy] - g.lo) * g.w + (sx - g.sx0);
+    PkAcc a = {0, 0};
+    a.mad (q[0], taps8_splat<0> (t8)), a.mad (q[g.w], taps8_splat<1> (t8)), a.mad (q[2 * g.w], taps8_splat<2> (t8)), a.mad (q[3 * g.w], taps8_splat<3> (t8));
+    a.mad (q[4 * g.w], taps8_splat<4> (t8)), a.mad (q[5 * g.w], taps8_splat<5> (t8)), a.mad (q[6 * g.w], taps8_splat<6> (t8)), a.mad (q[7 * g.w], taps8_splat<7> (t8));
+    return a.finish ();
   }
   if (sp.sv.kind == SCALE_NTAP) {
     const int16_t *t = sp.sv.taps + (size_t) sy * sp.sv.n_taps;

@@ -271,7 +271,7 @@ static int family_ashift (int format)
   switch (format) {
     case GSTAMD_VIDEO_FORMAT_ARGB: case GSTAMD_VIDEO_FORMAT_ABGR: case GSTAMD_VIDEO_FORMAT_AYUV:
       return 0;
-    case GSTAMD_VIDEO_FORMAT_BGRA: case GSTAMD_VIDEO_FORMAT_RGBA:
+    case GSTAMD_VIDEO_FORMAT_BGRA: case GSTAMD_VIDEO_FORMAT_RGBA: case GSTAMD_VIDEO_FORMAT_VUYA:     /* blend.h:58-65: VUYA takes BGRA's functions */
       return 24;
     default:
       return -1;
@@ -412,7 +412,7 @@ static bool color_word (int format, int c1, int c2, int c3, uint32_t *out)
   int A, C1, C2, C3;
   switch (format) {
     case GSTAMD_VIDEO_FORMAT_ARGB: case GSTAMD_VIDEO_FORMAT_AYUV: A = 24; C1 = 16; C2 = 8; C3 = 0; break;
-    case GSTAMD_VIDEO_FORMAT_BGRA: A = 0; C1 = 8; C2 = 16; C3 = 24; break;
+    case GSTAMD_VIDEO_FORMAT_BGRA: case GSTAMD_VIDEO_FORMAT_VUYA: A = 0; C1 = 8; C2 = 16; C3 = 24; break;     /* A32_COLOR (vuya, 0, 8, 16, 24) */
     case GSTAMD_VIDEO_FORMAT_ABGR: A = 24; C1 = 0; C2 = 8; C3 = 16; break;
     case GSTAMD_VIDEO_FORMAT_RGBA: A = 0; C1 = 24; C2 = 16; C3 = 8; break;
     default: return false;
@@ -502,7 +502,7 @@ int gstamd_compositor_fill_checker (int format, void *dest, int dw, int dh, int 
   memset (&p, 0, sizeof (p));
   p.ashift = ashift;
   p.bg_kind = 0;
-  p.checker_yuv = format == GSTAMD_VIDEO_FORMAT_AYUV;
+  p.checker_yuv = format == GSTAMD_VIDEO_FORMAT_AYUV || format == GSTAMD_VIDEO_FORMAT_VUYA;
   return launch (p, dest, dstride, 0, y_start, dw, y_end - y_start, stream);
 }
 
@@ -591,7 +591,7 @@ int gstamd_compositor_aggregate (int format, int background, const GstAmdComposi
   memset (&p, 0, sizeof (p));
   p.ashift = ashift;
   p.overlay = background == GSTAMD_COMPOSITOR_BACKGROUND_TRANSPARENT;
-  const bool yuv = format == GSTAMD_VIDEO_FORMAT_AYUV;
+  const bool yuv = format == GSTAMD_VIDEO_FORMAT_AYUV || format == GSTAMD_VIDEO_FORMAT_VUYA;
   switch (background) {
     case GSTAMD_COMPOSITOR_BACKGROUND_CHECKER:
       p.bg_kind = 0;
@@ -689,7 +689,7 @@ int gstamd_compositor_aggregate_scaled (int format, int background, const GstAmd
   memset ((void *) &p, 0, sizeof (p));
   p.ashift = ashift;
   p.overlay = background == GSTAMD_COMPOSITOR_BACKGROUND_TRANSPARENT;
-  const bool yuv = format == GSTAMD_VIDEO_FORMAT_AYUV;
+  const bool yuv = format == GSTAMD_VIDEO_FORMAT_AYUV || format == GSTAMD_VIDEO_FORMAT_VUYA;
   switch (background) {
     case GSTAMD_COMPOSITOR_BACKGROUND_CHECKER:
       p.bg_kind = 0;
@@ -786,7 +786,7 @@ int gstamd_compositor_aggregate_frame (int format, int background, const int32_t
     memset (&job, 0, sizeof (job));
     job.dst = (uint8_t *) dest[pl];
     job.dstride = dstride[pl];
-    job.wbytes = sub_scale (dw, geom[pl].w_sub) * geom[pl].px_bytes;
+    job.wbytes = compositor_plane_row_bytes (f, geom[pl], dw, background);
     job.rows = sub_scale (dh, geom[pl].h_sub);
     compositor_plane_background (f, geom[pl], pl, background, bk, wh, &job);
     int done = 0;

@@ -1,5 +1,6 @@
-// compositor_planes.h - compositor output in the formats that have no per-pixel alpha: planar YUV (I420, YV12, Y42B, Y444),
-// semi-planar (NV12, NV21) and 24-bit RGB / BGR.  The reference converts every pad to the output format first and then
+// compositor_planes.h - compositor output in the formats that have no per-pixel alpha: planar YUV (I420, YV12, Y42B, Y444 and their
+// 10 / 12 / 16-bit forms), semi-planar (NV12, NV21), 24-bit RGB / BGR, the 32-bit xRGB / xBGR / RGBx / BGRx (RGB_BLEND with bpp 4,
+// blend.c:1768-1783) and packed 4:2:2 YUY2 / UYVY / YVYU (PACKED_422_BLEND :1785-1925).  The reference converts every pad to the output format first and then
 // blends PLANE BY PLANE with the pad alpha only (gst/compositor/blend.c: PLANAR_YUV_BLEND :247-405, NV_YUV_BLEND :1387-1500,
 // RGB_BLEND :1610-1684): a plane rectangle is copied (alpha 1.0 or operator `source`), left alone (alpha 0.0) or run
 // through compositor_orc_blend_u8 (compositororc.orc:20-36: d = (d * 256 + (s - d) * alpha) >> 8 in 16 bits, alpha =
@@ -39,7 +40,10 @@ struct PlaneJob {
   int dstride;
   int wbytes, rows;       // plane size
   int bg_kind;            // 0: checker, 1: constant bytes, 2: keep the canvas (follow-up chunk)
-  int px_bytes;           // bytes per pixel of the plane (checker squares are 8 PIXELS wide; constants repeat per pixel)
+  int px_bytes;           // bytes per pixel of the plane (checker squares are 8 PIXELS wide)
+  int bg_period;          // constants repeat every bg_period bytes (= px_bytes; 4 for packed 4:2:2, whose U and V differ)
+  int keep_mask;          // checker only: bit k = byte k of a pixel is NOT written (the x byte of xRGB ...: RGB_FILL_CHECKER_C writes r, g, b)
+  int const_mask;         // checker only: bit k = byte k of a pixel is bg[k] (the chroma bytes of packed 4:2:2: 128)
   int bits;               // 8, or 10 / 12 / 16: the plane holds 16-bit little-endian samples of that depth (compositor_orc_blend_u10 / u12 / u16,
                           // compositororc.orc:38-88: d = (d << bits + (s - d) * alpha) >> bits in 32 bits, saturated to 16; alpha = (int) (a * (2^bits - 1)))
   uint8_t bg[4];          // constant background: byte k of every pixel
@@ -53,10 +57,16 @@ GSTAMD_CP uint32_t plane_byte (const PlaneJob &j, int x, int y, uint32_t canvas)
   uint32_t d;
   if (j.bg_kind == 2)
     d = canvas;
-  else if (j.bg_kind == 0)
-    d = ((((unsigned) y & 8u) >> 3) + ((((unsigned) (x / j.px_bytes)) & 8u) >> 3)) & 1u ? 160u : 80u;
-  else
-    d = j.bg[x % j.px_bytes];
+  else if (j.bg_kind == 0) {
+    const int k = x % j.px_bytes;
+    if ((j.keep_mask >> k) & 1)
+      d = canvas;
+    else if ((j.const_mask >> k) & 1)
+      d = j.bg[k];
+    else
+      d = ((((unsigned) y & 8u) >> 3) + ((((unsigned) (x / j.px_bytes)) & 8u) >> 3)) & 1u ? 160u : 80u;
+  } else
+    d = j.bg[x % j.bg_period];
   for (int k = 0; k < j.n; k++) {
     const PlaneRect &r = j.r[k];
     if (x < r.x || x >= r.x + r.w || y < r.y || y >= r.y + r.h)
@@ -116,7 +126,7 @@ GSTAMD_CP void plane_word_body (const PlaneJob &j, int x0, int y)
   const int n = j.wbytes - x0 < 4 ? j.wbytes - x0 : 4;
   uint32_t v[4];
   for (int i = 0; i < n; i++)
-    v[i] = plane_byte (j, x0 + i, y, j.bg_kind == 2 ? q[i] : 0);
+    v[i] = plane_byte (j, x0 + i, y, (j.bg_kind == 2 || j.keep_mask) ? q[i] : 0);
   if (n == 4 && (((uintptr_t) q) & 3) == 0)
     *(uint32_t *) q = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
   else
@@ -132,6 +142,8 @@ struct FramePad {           // one pad, already in the output format
   double alpha;
   int mode;                 // GstCompositorBlendMode
 };
+
+inline int sub_scale (int v, int sub) { return -((-v) >> sub); }     /* GST_VIDEO_SUB_SCALE */
 
 struct PlaneGeom {          // plane i of a format: which bytes it holds
   int w_sub, h_sub;         // subsampling of the plane's component(s)
@@ -161,10 +173,25 @@ inline int compositor_plane_geometry (const FormatDesc *f, PlaneGeom g[3])
     g[0] = {0, 0, 3};
     return 1;
   }
+  if (f->kind == UNPACK_PACKED4 && !f->alpha) {         /* xRGB, xBGR, RGBx, BGRx: blend_xrgb on 4 bytes per pixel, the x byte included */
+    g[0] = {0, 0, 4};
+    return 1;
+  }
+  if (f->kind == UNPACK_PACKED422 && f->format != GSTAMD_VIDEO_FORMAT_VYUY) {
+    g[0] = {0, 0, 2};                                   /* YUY2, UYVY, YVYU: rows of 2 bytes per pixel, xpos on even pixels */
+    return 1;
+  }
   return 0;
 }
 
-inline int sub_scale (int v, int sub) { return -((-v) >> sub); }     /* GST_VIDEO_SUB_SCALE */
+// bytes of a row of plane `pl` the background writes (PACKED_422_FILL_*: whole macropixels; the transparent memset: 2 * width, compositor.c:1657)
+inline int compositor_plane_row_bytes (const FormatDesc *f, const PlaneGeom &g, int dw, int background)
+{
+  if (f->kind == UNPACK_PACKED422)
+    return (background == 3 ? dw : ((dw + 1) & ~1)) * 2;
+  return sub_scale (dw, g.w_sub) * g.px_bytes;
+}
+
 
 // the rectangle of plane `pl` one pad contributes (blend_<format> of blend.c); false: nothing to do
 inline bool compositor_pad_rect (const FormatDesc *f, const PlaneGeom &g, int pl, const FramePad &pad, int dest_w, int dest_h, PlaneRect *out)
@@ -226,6 +253,8 @@ inline void compositor_plane_background (const FormatDesc *f, const PlaneGeom &g
     PlaneJob *job)
 {
   job->px_bytes = g.px_bytes;
+  job->bg_period = g.px_bytes;
+  job->keep_mask = job->const_mask = 0;
   job->bits = f->hi_depth ? hi_depth_bits (f->hi_depth) : 8;
   memset (job->bg, 0, sizeof (job->bg));
   if (job->bits > 8) {
@@ -250,10 +279,29 @@ inline void compositor_plane_background (const FormatDesc *f, const PlaneGeom &g
     return;
   }
   const bool luma_like = pl == 0;         /* the Y plane, or the single RGB plane */
-  if (background == 0) {                  /* checker */
-    if (luma_like)
+  if (f->kind == UNPACK_PACKED422) {
+    /* PACKED_422_FILL_CHECKER_C (blend.c:1847-1876: Y = 80 / 160 by pixel, U = V = 128; YVYU takes YUY2's) and _FILL_COLOR (:1878-1917) */
+    const int ybyte = f->pos[1] & 1;
+    if (background == 0) {
       job->bg_kind = 0;
-    else {
+      job->const_mask = 1 << (ybyte ^ 1);
+      job->bg[ybyte ^ 1] = 128;
+    } else {
+      const int *c = background == 1 ? black : white;
+      job->bg_kind = 1;
+      job->bg_period = 4;
+      job->bg[f->pos[1]] = job->bg[f->pos[1] + 2] = (uint8_t) c[0];
+      job->bg[f->pos[2]] = (uint8_t) c[1];
+      job->bg[f->pos[3]] = (uint8_t) c[2];
+    }
+    return;
+  }
+  if (background == 0) {                  /* checker */
+    if (luma_like) {
+      job->bg_kind = 0;
+      if (f->kind == UNPACK_PACKED4)      /* RGB_FILL_CHECKER_C (xrgb / rgbx, :1693-1717) leaves the x byte alone */
+        job->keep_mask = 1 << f->pos[0];
+    } else {
       job->bg_kind = 1;
       job->bg[0] = job->bg[1] = 0x80;
     }
@@ -261,7 +309,14 @@ inline void compositor_plane_background (const FormatDesc *f, const PlaneGeom &g
   }
   const int *c = background == 1 ? black : white;
   job->bg_kind = 1;
-  if (f->kind == UNPACK_PACKED3) {
+  if (f->kind == UNPACK_PACKED4 && f->pos[0] == 0) {
+    /* MEMSET_XRGB (xrgb, 24, 16, 0) / (xbgr, 0, 16, 24) (blend.c:1770, 1773): the word's shifts put the three colours into bytes 0, 1 and 3 -
+     * R G 0 B for xRGB, B G 0 R for xBGR - not into the format's own byte order; followed as is */
+    const bool rgb_order = f->pos[1] == 1;
+    job->bg[0] = (uint8_t) c[rgb_order ? 0 : 2];
+    job->bg[1] = (uint8_t) c[1];
+    job->bg[3] = (uint8_t) c[rgb_order ? 2 : 0];
+  } else if (f->kind == UNPACK_PACKED3 || f->kind == UNPACK_PACKED4) {       /* MEMSET_XRGB (rgbx / bgrx): the x byte is 0 */
     for (int k = 1; k < 4; k++)
       job->bg[f->pos[k]] = (uint8_t) c[k - 1];
   } else if (pl == 0) {

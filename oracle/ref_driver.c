@@ -263,6 +263,8 @@ ref_compositor_blend (const char *func, const char *format, const guint8 * src, 
     fn = gst_compositor_blend_xrgb;
   else if (!strcmp (func, "blend_rgb"))
     fn = gst_compositor_blend_rgb;
+  else if (!strcmp (func, "blend_yuy2"))        /* blend.h: YVYU and UYVY take the same function */
+    fn = gst_compositor_blend_yuy2;
   else if (!strcmp (func, "blend_argb64"))
     fn = gst_compositor_blend_argb64;
   else if (!strcmp (func, "overlay_argb64"))
@@ -331,6 +333,16 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
       fn = gst_compositor_fill_checker_rgb;
     else if (!strcmp (fmt_func, "bgr"))
       fn = gst_compositor_fill_checker_bgr;
+    else if (!strcmp (fmt_func, "vuya"))
+      fn = gst_compositor_fill_checker_vuya;
+    else if (!strcmp (fmt_func, "xrgb") || !strcmp (fmt_func, "xbgr"))
+      fn = gst_compositor_fill_checker_xrgb;
+    else if (!strcmp (fmt_func, "rgbx") || !strcmp (fmt_func, "bgrx"))
+      fn = gst_compositor_fill_checker_rgbx;
+    else if (!strcmp (fmt_func, "yuy2") || !strcmp (fmt_func, "yvyu"))
+      fn = gst_compositor_fill_checker_yuy2;
+    else if (!strcmp (fmt_func, "uyvy"))
+      fn = gst_compositor_fill_checker_uyvy;
     else if (!strcmp (fmt_func, "argb64"))
       fn = gst_compositor_fill_checker_argb64;
     else if (!strcmp (fmt_func, "ayuv64"))
@@ -372,6 +384,22 @@ ref_compositor_fill (int kind, const char *fmt_func, const char *format, guint8 
       fn = gst_compositor_fill_color_rgb;
     else if (!strcmp (fmt_func, "bgr"))
       fn = gst_compositor_fill_color_bgr;
+    else if (!strcmp (fmt_func, "vuya"))
+      fn = gst_compositor_fill_color_vuya;
+    else if (!strcmp (fmt_func, "xrgb"))
+      fn = gst_compositor_fill_color_xrgb;
+    else if (!strcmp (fmt_func, "xbgr"))
+      fn = gst_compositor_fill_color_xbgr;
+    else if (!strcmp (fmt_func, "rgbx"))
+      fn = gst_compositor_fill_color_rgbx;
+    else if (!strcmp (fmt_func, "bgrx"))
+      fn = gst_compositor_fill_color_bgrx;
+    else if (!strcmp (fmt_func, "yuy2"))
+      fn = gst_compositor_fill_color_yuy2;
+    else if (!strcmp (fmt_func, "yvyu"))
+      fn = gst_compositor_fill_color_yvyu;
+    else if (!strcmp (fmt_func, "uyvy"))
+      fn = gst_compositor_fill_color_uyvy;
     else if (!strcmp (fmt_func, "argb64"))
       fn = gst_compositor_fill_color_argb64;
     else if (!strcmp (fmt_func, "i420_10le") || !strcmp (fmt_func, "i422_10le") || !strcmp (fmt_func, "y444_10le"))

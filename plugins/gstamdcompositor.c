@@ -38,13 +38,16 @@ GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
 
 /* Y444_16LE, P012_LE and P016_LE joined the format enum in 1.18: there when the headers this is compiled against have them */
 #if GST_CHECK_VERSION (1, 18, 0)
-#define AMD_COMP_NEWER_CANVAS ", Y444_16LE"
-#define AMD_COMP_NEWER_PADS ", Y444_16LE, P012_LE, P016_LE"
+#define AMD_COMP_NEWER_CANVAS ", VUYA, Y444_16LE"
+#define AMD_COMP_NEWER_PADS ", VUYA, Y444_16LE, P012_LE, P016_LE"
+#elif GST_CHECK_VERSION (1, 16, 0)
+#define AMD_COMP_NEWER_CANVAS ", VUYA"
+#define AMD_COMP_NEWER_PADS ", VUYA"
 #else
 #define AMD_COMP_NEWER_CANVAS ""
 #define AMD_COMP_NEWER_PADS ""
 #endif
-#define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR, " \
+#define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR, RGBx, BGRx, xRGB, xBGR, YUY2, UYVY, YVYU, " \
     "I420_10LE, I420_12LE, I422_10LE, I422_12LE, Y444_10LE, Y444_12LE" AMD_COMP_NEWER_CANVAS " }"
 /* what a pad may carry: anything the converter takes; it is brought to the output format / the pad's width x height by a
  * per-pad GstAmdVideoConverter (the reference's GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) */
@@ -339,6 +342,17 @@ amd_format_of (GstVideoFormat f)
     case GST_VIDEO_FORMAT_NV21: return GSTAMD_VIDEO_FORMAT_NV21;
     case GST_VIDEO_FORMAT_RGB: return GSTAMD_VIDEO_FORMAT_RGB;
     case GST_VIDEO_FORMAT_BGR: return GSTAMD_VIDEO_FORMAT_BGR;
+    /* RGB_BLEND with four bytes per pixel and PACKED_422_BLEND (blend.c:1768-1925) */
+    case GST_VIDEO_FORMAT_RGBx: return GSTAMD_VIDEO_FORMAT_RGBx;
+    case GST_VIDEO_FORMAT_BGRx: return GSTAMD_VIDEO_FORMAT_BGRx;
+    case GST_VIDEO_FORMAT_xRGB: return GSTAMD_VIDEO_FORMAT_xRGB;
+    case GST_VIDEO_FORMAT_xBGR: return GSTAMD_VIDEO_FORMAT_xBGR;
+    case GST_VIDEO_FORMAT_YUY2: return GSTAMD_VIDEO_FORMAT_YUY2;
+    case GST_VIDEO_FORMAT_UYVY: return GSTAMD_VIDEO_FORMAT_UYVY;
+    case GST_VIDEO_FORMAT_YVYU: return GSTAMD_VIDEO_FORMAT_YVYU;
+#if GST_CHECK_VERSION (1, 16, 0)
+    case GST_VIDEO_FORMAT_VUYA: return GSTAMD_VIDEO_FORMAT_VUYA;          /* BGRA's blend / overlay, its own fills (blend.h:58-65) */
+#endif
     /* ... and the planar canvases of 10 / 12 / 16 bits (blend.c:609-697: compositor_orc_blend_u10 / u12 / u16) */
     case GST_VIDEO_FORMAT_I420_10LE: return GSTAMD_VIDEO_FORMAT_I420_10LE;
     case GST_VIDEO_FORMAT_I420_12LE: return GSTAMD_VIDEO_FORMAT_I420_12LE;
@@ -357,25 +371,10 @@ static int
 amd_pad_format_of (GstVideoFormat f)
 {
   switch (f) {
-    case GST_VIDEO_FORMAT_RGBx: return GSTAMD_VIDEO_FORMAT_RGBx;
-    case GST_VIDEO_FORMAT_BGRx: return GSTAMD_VIDEO_FORMAT_BGRx;
-    case GST_VIDEO_FORMAT_xRGB: return GSTAMD_VIDEO_FORMAT_xRGB;
-    case GST_VIDEO_FORMAT_xBGR: return GSTAMD_VIDEO_FORMAT_xBGR;
-    case GST_VIDEO_FORMAT_NV12: return GSTAMD_VIDEO_FORMAT_NV12;
-    case GST_VIDEO_FORMAT_NV21: return GSTAMD_VIDEO_FORMAT_NV21;
-    case GST_VIDEO_FORMAT_I420: return GSTAMD_VIDEO_FORMAT_I420;
-    case GST_VIDEO_FORMAT_YV12: return GSTAMD_VIDEO_FORMAT_YV12;
-    case GST_VIDEO_FORMAT_Y42B: return GSTAMD_VIDEO_FORMAT_Y42B;
-    case GST_VIDEO_FORMAT_Y444: return GSTAMD_VIDEO_FORMAT_Y444;
     case GST_VIDEO_FORMAT_NV16: return GSTAMD_VIDEO_FORMAT_NV16;
     case GST_VIDEO_FORMAT_NV61: return GSTAMD_VIDEO_FORMAT_NV61;
     case GST_VIDEO_FORMAT_NV24: return GSTAMD_VIDEO_FORMAT_NV24;
-    case GST_VIDEO_FORMAT_YUY2: return GSTAMD_VIDEO_FORMAT_YUY2;
-    case GST_VIDEO_FORMAT_UYVY: return GSTAMD_VIDEO_FORMAT_UYVY;
-    case GST_VIDEO_FORMAT_YVYU: return GSTAMD_VIDEO_FORMAT_YVYU;
     case GST_VIDEO_FORMAT_VYUY: return GSTAMD_VIDEO_FORMAT_VYUY;
-    case GST_VIDEO_FORMAT_RGB: return GSTAMD_VIDEO_FORMAT_RGB;
-    case GST_VIDEO_FORMAT_BGR: return GSTAMD_VIDEO_FORMAT_BGR;
     case GST_VIDEO_FORMAT_GRAY8: return GSTAMD_VIDEO_FORMAT_GRAY8;
     case GST_VIDEO_FORMAT_P010_10LE: return GSTAMD_VIDEO_FORMAT_P010_10LE;
 #if GST_CHECK_VERSION (1, 18, 0)

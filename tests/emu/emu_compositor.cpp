@@ -165,7 +165,7 @@ extern "C" int emu_compositor_aggregate_frame (int format, int background, const
     memset (&job, 0, sizeof (job));
     job.dst = dest[pl];
     job.dstride = dstride[pl];
-    job.wbytes = sub_scale (dw, geom[pl].w_sub) * geom[pl].px_bytes;
+    job.wbytes = compositor_plane_row_bytes (f, geom[pl], dw, background);
     job.rows = sub_scale (dh, geom[pl].h_sub);
     compositor_plane_background (f, geom[pl], pl, background, black, white, &job);
     int done = 0;

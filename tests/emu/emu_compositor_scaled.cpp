@@ -30,7 +30,7 @@ extern "C" int emu_compositor_aggregate_scaled (int format, int ashift, int back
   p.ashift = ashift;
   p.overlay = background == GSTAMD_COMPOSITOR_BACKGROUND_TRANSPARENT;
   p.bg_kind = background == GSTAMD_COMPOSITOR_BACKGROUND_CHECKER ? 0 : 1;
-  p.checker_yuv = format == GSTAMD_VIDEO_FORMAT_AYUV;
+  p.checker_yuv = format == GSTAMD_VIDEO_FORMAT_AYUV || format == GSTAMD_VIDEO_FORMAT_VUYA;
   p.bg_word = background == GSTAMD_COMPOSITOR_BACKGROUND_BLACK ? black_word : (background == GSTAMD_COMPOSITOR_BACKGROUND_WHITE ? white_word : 0);
   int done = 0;
   bool first = true;

@@ -8,10 +8,11 @@ import pytest
 import cases
 from gstreamer_amd import video as V
 
-FAM = {"BGRA": "bgra", "RGBA": "bgra", "ARGB": "argb", "ABGR": "argb", "AYUV": "argb"}
+FAM = {"BGRA": "bgra", "RGBA": "bgra", "ARGB": "argb", "ABGR": "argb", "AYUV": "argb", "VUYA": "bgra"}       # blend.h:55-65
+CHECKER_FN = {"AYUV": "ayuv", "VUYA": "vuya"}
 
 BLEND_CASES = []
-for fmt in ("BGRA", "ARGB", "RGBA", "AYUV"):
+for fmt in ("BGRA", "ARGB", "RGBA", "AYUV", "VUYA"):
     for mode in (0, 1, 2):
         for alpha in (1.0, 0.5, 0.3, 0.004, 0.0):
             BLEND_CASES.append((fmt, 0, 37, 21, 64, 48, 5, 7, alpha, mode, 0, 48))
@@ -81,19 +82,19 @@ def test_hip_blend_matches_reference(native_lib, gpu, ref, i_case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fmt", ["BGRA", "ARGB", "RGBA", "ABGR", "AYUV"])
+@pytest.mark.parametrize("fmt", ["BGRA", "ARGB", "RGBA", "ABGR", "AYUV", "VUYA"])
 def test_hip_fills_match_reference(native_lib, gpu, ref, fmt):
     import torch
     w, h = 70, 33
     exp = np.zeros(w * h * 4, np.uint8)
-    checker_fn = {"BGRA": "bgra", "RGBA": "bgra", "ARGB": "argb", "ABGR": "argb", "AYUV": "ayuv"}.get(fmt)
+    checker_fn = CHECKER_FN.get(fmt, FAM[fmt])
     d = torch.zeros(w * h * 4, dtype=torch.uint8, device=gpu)
     if checker_fn:
         ref.compositor_fill(0, checker_fn, fmt, exp, w, h, 3, 30)
         assert V.lib().gstamd_compositor_fill_checker(V.FORMATS[fmt], d.data_ptr(), w, h, w * 4, 3, 30, None) == 0
         torch.cuda.synchronize()
         assert (d.cpu().numpy() == exp).all()
-    if fmt != "AYUV":
+    if True:
         exp[:] = 0
         d.zero_()
         ref.compositor_fill(1, fmt.lower(), fmt, exp, w, h, 2, 31, 10, 200, 77)
@@ -102,15 +103,20 @@ def test_hip_fills_match_reference(native_lib, gpu, ref, fmt):
         assert (d.cpu().numpy() == exp).all()
 
 
+def _black_white(fmt, background):
+    """compositor.c:1131-1149: the colours of gst_video_color_range_offsets for the format's default range"""
+    if fmt in CHECKER_FN:
+        return (16, 128, 128) if background == 1 else (235, 128, 128)
+    return (0, 0, 0) if background == 1 else (255, 255, 255)
+
+
 def _aggregate_expected(ref, fmt, background, geo, pads_np, pw, ph, dw, dh):
     fam = FAM[fmt]
     exp = np.zeros(dw * dh * 4, np.uint8)
     if background == 0:
-        ref.compositor_fill(0, "ayuv" if fmt == "AYUV" else fam, fmt, exp, dw, dh, 0, dh)
-    elif background == 1:
-        ref.compositor_fill(1, fmt.lower(), fmt, exp, dw, dh, 0, dh, 0, 0, 0)
-    elif background == 2:
-        ref.compositor_fill(1, fmt.lower(), fmt, exp, dw, dh, 0, dh, 255, 255, 255)
+        ref.compositor_fill(0, CHECKER_FN.get(fmt, fam), fmt, exp, dw, dh, 0, dh)
+    elif background in (1, 2):
+        ref.compositor_fill(1, fmt.lower(), fmt, exp, dw, dh, 0, dh, *_black_white(fmt, background))
     func = ("overlay_" if background == 3 else "blend_") + fam
     for i, (xpos, ypos, alpha, mode) in enumerate(geo):
         ref.compositor_blend(func, fmt, pads_np[i], pw, ph, xpos, ypos, alpha, exp, dw, dh, 0, dh, mode)
@@ -123,7 +129,7 @@ def _over_geometry(n_pads):
 
 
 @pytest.mark.parametrize("direct,dw,n_pads", [(1, 203, 12), (1, 204, 32), (1, 517, 29), (0, 203, 12)])
-@pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("ARGB", 1), ("AYUV", 0), ("RGBA", 2)])
+@pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("ARGB", 1), ("AYUV", 0), ("RGBA", 2), ("VUYA", 0), ("VUYA", 1)])
 def test_aggregate_packed_path_on_host_matches_reference(emu_lib, ref, fmt, background, direct, dw, n_pads, monkeypatch):
     """the opaque-blend path: k_aggregate_direct's body (mask walk over the hits, 12 request slots per round: 29 / 32 pads piled on
     each other need three rounds; a width of 203 moves the last lane back onto the last four pixels) and k_aggregate's (hit list),
@@ -139,10 +145,10 @@ def test_aggregate_packed_path_on_host_matches_reference(emu_lib, ref, fmt, back
     exp = _aggregate_expected(ref, fmt, background, geo, pads_np, pw, ph, dw, dh)
     p = AggParams()
     p.ashift = 0 if FAM[fmt] == "argb" else 24
-    p.overlay, p.bg_kind, p.checker_yuv = 0, (0 if background == 0 else 1), int(fmt == "AYUV")
+    p.overlay, p.bg_kind, p.checker_yuv = 0, (0 if background == 0 else 1), int(fmt in CHECKER_FN)
     if background:
         word = np.zeros(4, np.uint8)
-        ref.compositor_fill(1, fmt.lower(), fmt, word, 1, 1, 0, 1, *((0, 0, 0) if background == 1 else (255, 255, 255)))
+        ref.compositor_fill(1, fmt.lower(), fmt, word, 1, 1, 0, 1, *_black_white(fmt, background))
         p.bg_word = int(word.view(np.uint32)[0])
     k = 0
     for i, (xpos, ypos, alpha, mode) in enumerate(geo):
@@ -226,7 +232,7 @@ def test_aggregate_rows_per_wave_list_on_host_matches_reference(emu_lib, ref, ro
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dw,n_pads", [(203, 12), (204, 32), (517, 29), (1300, 40)])
-@pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("ARGB", 1), ("AYUV", 0), ("RGBA", 2)])
+@pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("ARGB", 1), ("AYUV", 0), ("RGBA", 2), ("VUYA", 0), ("VUYA", 1)])
 def test_hip_aggregate_packed_path_matches_reference(native_lib, gpu, ref, fmt, background, dw, n_pads):
     """k_aggregate_direct: several strips per row, more hits than request slots (29 piled pads), more pads than one launch takes
     (40: a continuation chunk on the canvas), a last lane moved back (203)"""
@@ -365,7 +371,12 @@ def test_div255_identity_used_by_packed_blend():
 # ---- outputs without per-pixel alpha: plane-by-plane aggregation (compositor_planes.h) ---------------------------------------
 FRAME_FMTS = ["I420", "YV12", "Y42B", "Y444", "NV12", "NV21", "RGB", "BGR",
               # planar canvases of 10 / 12 / 16 bits (blend.c:609-697: compositor_orc_blend_u10 / u12 / u16, PLANAR_YUV_HIGH_FILL_*)
-              "I420_10LE", "I420_12LE", "I422_10LE", "I422_12LE", "Y444_10LE", "Y444_12LE", "Y444_16LE"]
+              "I420_10LE", "I420_12LE", "I422_10LE", "I422_12LE", "Y444_10LE", "Y444_12LE", "Y444_16LE",
+              # 32-bit RGB without alpha (RGB_BLEND with bpp 4) and packed 4:2:2 (PACKED_422_BLEND): one plane of bytes, compared WHOLE
+              # (the reference's fills write whole macropixels / leave the x byte, its transparent memset stops at 2 * width)
+              "xRGB", "xBGR", "RGBx", "BGRx", "YUY2", "UYVY", "YVYU"]
+FRAME_RGB = ("RGB", "BGR", "xRGB", "xBGR", "RGBx", "BGRx")
+FRAME_WHOLE = ("xRGB", "xBGR", "RGBx", "BGRx", "YUY2", "UYVY", "YVYU")
 
 
 def _frame_depth_shift(fmt):
@@ -382,6 +393,8 @@ def _frame_layout(fmt, w, h):
 
 
 def _frame_visible(fmt, w, h, buf):
+    if fmt in FRAME_WHOLE:
+        return np.asarray(buf)
     if not _frame_depth_shift(fmt):
         strides, offsets = cases.default_layout(fmt, w, h)
         return cases.visible_bytes(fmt, w, h, strides, offsets, buf)
@@ -422,17 +435,21 @@ def _frame_expected(ref, fmt, background):
         ref.compositor_fill(0, low, fmt, dst, FDW, FDH, 0, FDH)
     elif background == 3 and _frame_depth_shift(fmt):
         dst[:] = 0          # (padding is not compared)
+    elif background == 3 and fmt in FRAME_WHOLE:
+        (stride,), _o = cases.default_layout(fmt, FDW, FDH)
+        dst.reshape(FDH, stride)[:, :FDW * (2 if "Y" in fmt else 4)] = 0          # compositor.c:1657: comp width x pixel stride
     elif background == 3:
         strides, offsets = cases.default_layout(fmt, FDW, FDH)
         for i, (rb, rows) in enumerate(cases.visible_planes(fmt, FDW, FDH)):
             plane = dst[offsets[i]:offsets[i] + strides[i] * rows].reshape(rows, strides[i])
             plane[:, :rb] = 0
     else:
-        yuv = fmt not in ("RGB", "BGR")
+        yuv = fmt not in FRAME_RGB
         c = ((16, 128, 128) if yuv else (0, 0, 0)) if background == 1 else ((235, 128, 128) if yuv else (255, 255, 255))
         c = tuple(v << _frame_depth_shift(fmt) for v in c)
         ref.compositor_fill(1, low, fmt, dst, FDW, FDH, 0, FDH, *c)
-    func = {"YV12": "blend_i420", "BGR": "blend_rgb"}.get(fmt, "blend_" + low)
+    func = {"YV12": "blend_i420", "BGR": "blend_rgb", "xBGR": "blend_xrgb", "RGBx": "blend_xrgb", "BGRx": "blend_xrgb", "UYVY": "blend_yuy2",
+            "YVYU": "blend_yuy2"}.get(fmt, "blend_" + low)
     for src, (w, h, x, y, alpha, mode) in zip(_frame_inputs(fmt), FRAME_PADS):
         ref.compositor_blend(func, fmt, src, w, h, x, y, alpha, dst, FDW, FDH, 0, FDH, mode)
     return dst
@@ -457,7 +474,7 @@ def test_aggregate_frame_on_host_matches_reference(emu_lib, ref, fmt, background
     strides, offsets = _frame_layout(fmt, FDW, FDH)
     dp = (C.c_void_p * 3)(*[dst.ctypes.data + o for o in offsets] + [None] * (3 - len(offsets)))
     ds = (C.c_int * 3)(*strides + [0] * (3 - len(strides)))
-    yuv = fmt not in ("RGB", "BGR")
+    yuv = fmt not in FRAME_RGB
     sh = _frame_depth_shift(fmt)
     black = (C.c_int * 3)(*[v << sh for v in ((16, 128, 128) if yuv else (0, 0, 0))])
     white = (C.c_int * 3)(*[v << sh for v in ((235, 128, 128) if yuv else (255, 255, 255))])
@@ -466,6 +483,23 @@ def test_aggregate_frame_on_host_matches_reference(emu_lib, ref, fmt, background
     assert emu_lib.emu_compositor_aggregate_frame(V.FORMATS[fmt], background, black, white, pads, len(FRAME_PADS), dp, ds, FDW, FDH) == 0
     exp = _frame_expected(ref, fmt, background)
     assert (_visible(fmt, dst) == _visible(fmt, exp)).all()
+
+
+@pytest.mark.parametrize("fmt", FRAME_WHOLE)
+def test_aggregate_frame_background_colours_land_where_the_reference_puts_them(emu_lib, ref, fmt):
+    """three different colour values: MEMSET_XRGB's shifts for xRGB / xBGR (R G 0 B / B G 0 R), U and V of the packed 4:2:2 word"""
+    col = (10, 200, 77)
+    dst = cases.frame_bytes(_frame_size(fmt, FDW, FDH), "random", 6999)
+    exp = dst.copy()
+    ref.compositor_fill(1, fmt.lower(), fmt, exp, FDW, FDH, 0, FDH, *col)
+    strides, offsets = _frame_layout(fmt, FDW, FDH)
+    dp = (C.c_void_p * 3)(dst.ctypes.data, None, None)
+    ds = (C.c_int * 3)(strides[0], 0, 0)
+    c3 = (C.c_int * 3)(*col)
+    emu_lib.emu_compositor_aggregate_frame.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                       C.c_int, C.c_int]
+    assert emu_lib.emu_compositor_aggregate_frame(V.FORMATS[fmt], 1, c3, c3, None, 0, dp, ds, FDW, FDH) == 0
+    assert (dst == exp).all()
 
 
 @pytest.mark.gpu
@@ -652,9 +686,9 @@ METHODS = {"nearest": 0, "linear": 1, "cubic": 2, "sinc": 3, "lanczos": 4}
 def scaled_expected(ref, fmt, background, layout, frames, dw, dh):
     fam = FAM[fmt]
     exp = np.zeros(dw * dh * 4, np.uint8)
-    yuv = fmt == "AYUV"
+    yuv = fmt in CHECKER_FN
     if background == 0:
-        ref.compositor_fill(0, "ayuv" if yuv else fam, fmt, exp, dw, dh, 0, dh)
+        ref.compositor_fill(0, CHECKER_FN.get(fmt, fam), fmt, exp, dw, dh, 0, dh)
     elif background == 1:
         ref.compositor_fill(1, fmt.lower(), fmt, exp, dw, dh, 0, dh, *((16, 128, 128) if yuv else (0, 0, 0)))
     elif background == 2:
@@ -688,7 +722,7 @@ def test_scaled_pads_on_host_match_reference(emu_lib, ref, fmt, background, name
         arr[i].data, arr[i].width, arr[i].height, arr[i].stride = frames[i].ctypes.data, w, h, w * 4
         arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].mode = xpos, ypos, alpha, mode
         arr[i].out_w, arr[i].out_h, arr[i].method = ow, oh, METHODS[method]
-    yuv = fmt == "AYUV"
+    yuv = fmt in CHECKER_FN
     words = []
     for c in ((16, 128, 128) if yuv else (0, 0, 0)), ((235, 128, 128) if yuv else (255, 255, 255)):
         one = np.zeros(4, np.uint8)

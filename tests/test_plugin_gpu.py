@@ -603,6 +603,39 @@ def test_compositor_element_10_and_12_bit_planar_canvases(gst_env, ref):
             assert (canvas == out[f]).all(), (ofmt, f, int((canvas != out[f]).sum()))
 
 
+def test_compositor_element_packed_canvases_without_alpha(gst_env, ref):
+    """xRGB / BGRx (RGB_BLEND with four bytes per pixel) and YUY2 / UYVY (PACKED_422_BLEND) canvases: a pad of the canvas format at an odd
+    xpos (rounded up to an even pixel on 4:2:2) and a BGRA pad through its converter, over white (MEMSET_XRGB's byte order for xRGB), black
+    and the 4:2:2 checker - whole output buffers against the reference's functions"""
+    env, tmp = gst_env
+    n, dw, dh = 2, 322, 240
+    for ofmt, bg, bgkind in (("xRGB", "white", 2), ("BGRx", "black", 1), ("YUY2", "checker", 0), ("UYVY", "white", 2)):
+        yuv = ofmt in ("YUY2", "UYVY")
+        extra = ",colorimetry=bt601,chroma-site=jpeg" if yuv else ""
+        f0, f1, fout = tmp / ("k0_%s.raw" % ofmt), tmp / ("k1_%s.bgra" % ofmt), tmp / ("kout_%s.raw" % ofmt)
+        launch(env, "compositor name=c background=%s sink_0::xpos=11 sink_0::ypos=21 sink_0::alpha=0.6 sink_1::xpos=150 sink_1::ypos=100 sink_1::alpha=0.7 "
+                    "! video/x-raw,format=%s,width=%d,height=%d%s ! filesink location=%s "
+                    "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=%s,width=160,height=120,framerate=30/1%s ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
+                    "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=BGRA,width=128,height=96,framerate=30/1 ! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1"
+               % (bg, ofmt, dw, dh, extra, fout, n, ofmt, extra, f0, n, f1))
+        out = np.fromfile(fout, np.uint8).reshape(n, -1)
+        s0 = np.fromfile(f0, np.uint8).reshape(n, -1)
+        s1 = np.fromfile(f1, np.uint8).reshape(n, -1)
+        c1 = ref.VideoConverter("BGRA", 128, 96, ofmt, 128, 96, **(dict(out_colorimetry="bt601", out_chroma_site="jpeg") if yuv else {}))
+        low = ofmt.lower()
+        func = "blend_yuy2" if yuv else "blend_xrgb"
+        for f in range(n):
+            canvas = np.zeros(out.shape[1], np.uint8)
+            if bgkind == 0:
+                ref.compositor_fill(0, low, ofmt, canvas, dw, dh, 0, dh)
+            else:
+                c = ((16, 128, 128) if bgkind == 1 else (235, 128, 128)) if yuv else ((0, 0, 0) if bgkind == 1 else (255, 255, 255))
+                ref.compositor_fill(1, low, ofmt, canvas, dw, dh, 0, dh, *c)
+            ref.compositor_blend(func, ofmt, s0[f], 160, 120, 11, 21, 0.6, canvas, dw, dh, 0, dh, 1)
+            ref.compositor_blend(func, ofmt, c1.frame(s1[f]), 128, 96, 150, 100, 0.7, canvas, dw, dh, 0, dh, 1)
+            assert (canvas == out[f]).all(), (ofmt, f, int((canvas != out[f]).sum()))
+
+
 def _bench_element(env, args, keep_stderr=False):
     exe = os.path.join(ROOT, "plugins", "tests", "bench_element")
     assert os.path.exists(exe), "plugins/build.py builds it"

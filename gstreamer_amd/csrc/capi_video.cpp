@@ -1264,6 +1264,7 @@ static bool bilinear420_params (GstAmdVideoConverter *c, BilParams *out)
       bp.rows = tuning_int ("GSTAMD_BIL_ROWS", 0);
 #endif
   }
+  bp.half = !tuning_on ("GSTAMD_NO_BILINEAR_HALF") && bilh_plan_ok (bp, p.passes[1].offset.data (), p.passes[1].taps.data ());
   *out = bp;
   return true;
 }

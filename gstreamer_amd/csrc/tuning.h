@@ -35,6 +35,9 @@
 //   GSTAMD_NO_CONVERT_PACK   AYUV image + k_pack_planar instead of the packer fed by the chain itself, k_convert_pack (set)
 //   GSTAMD_NO_BILINEAR420    wave-tile scaler instead of the 4:2:0 bilinear kernels (set)
 //   GSTAMD_NO_BILINEAR_ROWS  k_bilinear420 instead of k_bilinear420_rows (set)
+//   GSTAMD_NO_BILINEAR_HALF  k_bilinear420_rows instead of k_bilinear420_half where the picture shrinks by exactly two (set)
+//   GSTAMD_BIL_HALF_ROWS     output rows per wave of k_bilinear420_half (n; default: one resident round for a frame, 8 in lists)
+//   GSTAMD_NO_CONVERT_PACK_WIDE  the byte-store form of k_convert_pack instead of its whole-block form (set)
 //   GSTAMD_BIL_TILE, GSTAMD_BIL_TABLE, GSTAMD_BIL_ROWS, GSTAMD_BIL_ROWS_TILE, GSTAMD_BIL_SLOTS, GSTAMD_BIL_WG, GSTAMD_BIL_VERBOSE
 //                            geometry of the bilinear kernels (n)
 //   GSTAMD_FUSED_WAVES, GSTAMD_FUSED_ROWS, GSTAMD_FUSED_SCHED, GSTAMD_FUSED_FIRST, GSTAMD_FUSED_DEBUG

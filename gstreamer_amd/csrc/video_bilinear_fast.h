@@ -61,6 +61,7 @@ struct BilParams {
   int rows;                  // > 0: k_bilinear420_rows (video_bilinear_rows.h) with this many output rows per wave; < 0: as many
                              // waves as the chip holds at once; 0: k_bilinear420
   int strips;                // row strips per tile column of k_bilinear420_rows: strip g covers rows [g h / strips, (g + 1) h / strips)
+  int half;                  // the picture shrinks by exactly two in both directions: k_bilinear420_half (video_bilinear_half.h)
 };
 
 GSTAMD_HOSTDEV void bil_rows (const BilParams &bp, int line, int *ra, int *rb, int *role)

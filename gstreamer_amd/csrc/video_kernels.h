@@ -9,6 +9,7 @@
 #include "video_bilinear_fast.h"
 #include "video_hscale420.h"
 #include "video_bilinear_rows.h"
+#include "video_bilinear_half.h"
 #include "video_422_fast.h"
 #include "video_gamma.h"
 #include "video_planes.h"
@@ -69,6 +70,9 @@ hipError_t launch_convert422 (const Fast422Params &p, const uint8_t *src, int ss
 hipError_t launch_convert420p (const Fast420pParams &p, uint8_t *dst, int dstride, hipStream_t stream);
 hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream);
 // n frames of the same geometry in as few launches as the kernel allows (one, when k_bilinear420_rows takes them)
+// the exact halving (BilParams::half) on frames whose rows are 16-byte aligned: video_bilinear_half.hip
+bool bilinear420_half_usable (const BilParams &bp, int n, const Planes *pl, uint8_t *const *dst, int dstride);
+hipError_t launch_bilinear420_half (const BilParams &bp, int chroma_h, int n, const Planes *pl, uint8_t *const *dst, int dstride, hipStream_t stream);
 hipError_t launch_bilinear420_frames (const BilParams &bp, int chroma_h, int n, const Planes *pl, uint8_t *const *dst, int dstride, hipStream_t stream);
 hipError_t launch_plane_simple (int kind, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems, int ow, int oh, hipStream_t stream);
 hipError_t launch_plane_pass (bool horizontal, const ScaleDev &sd, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int n_elems,

@@ -1852,6 +1852,8 @@ static hipError_t launch_bilinear420_rows (const BilParams &bp, int chroma_h, in
 hipError_t launch_bilinear420_frames (const BilParams &bp, int chroma_h, int n, const Planes *pl, uint8_t *const *dst, int dstride, hipStream_t stream)
 {
   video_frame_list_touch (dst[0]);
+  if (bilinear420_half_usable (bp, n, pl, dst, dstride))
+    return launch_bilinear420_half (bp, chroma_h, n, pl, dst, dstride, stream);
   bool rows_ok = bp.rows != 0 && (bp.fp.width % 16) == 0 && bp.regular_pairs;
   for (int f = 0; f < n && rows_ok; f++)
     rows_ok = bil_vec_ok (bp, pl[f]) && pl[f].stride[0] == pl[0].stride[0] && pl[f].stride[1] == pl[0].stride[1] && pl[f].stride[2] == pl[0].stride[2];
@@ -1868,6 +1870,8 @@ hipError_t launch_bilinear420_frames (const BilParams &bp, int chroma_h, int n, 
 hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream)
 {
   video_frame_list_touch (dst);
+  if (bilinear420_half_usable (bp, 1, &pl, &dst, dstride))
+    return launch_bilinear420_half (bp, chroma_h, 1, &pl, &dst, dstride, stream);
   const int vec = bil_vec_ok (bp, pl);
   if (bp.planar && !vec)
     return hipErrorNotSupported;

@@ -225,6 +225,16 @@ VIDEO_CASES = [
     ("i420_bgra_bil420_half", "I420", 1280, 720, "BGRA", 640, 360, LIN, None, None, "random"),
     ("yv12_argb_bil420_nonint_jpeg", "YV12", 1024, 600, "ARGB", 600, 352, LIN, None, "jpeg", "random"),
     ("i420_rgba_bil420_third_none", "I420", 960, 540, "RGBA", 320, 180, LIN, None, "none", "random"),
+    # k_bilinear420_half (video_bilinear_half.h): exact halvings - two full 1024-pixel columns and a short third one, every layout,
+    # the three horizontal chroma filters, planar sources, a full-range matrix, a height that does not divide into the strips
+    ("half_nv12_bgra_2080x360", "NV12", 2080, 360, "BGRA", 1040, 180, LIN, None, None, "random"),
+    ("half_nv21_rgba_jpeg", "NV21", 1056, 250, "RGBA", 528, 125, LIN, None, "jpeg", "random"),
+    ("half_nv12_argb_none", "NV12", 1024, 128, "ARGB", 512, 64, LIN, None, "none", "random"),
+    ("half_yv12_abgr_jpeg", "YV12", 1040, 180, "ABGR", 520, 90, LIN, None, "jpeg", "random"),
+    ("half_i420_rgbx_mpeg2", "I420", 640, 364, "RGBx", 320, 182, LIN, None, "mpeg2", "random"),
+    ("half_nv12_bgrx_fullrange", "NV12", 48, 44, "BGRx", 24, 22, LIN, "1:4:0:0", None, "random"),
+    ("half_nv12_xrgb_checker", "NV12", 128, 64, "xRGB", 64, 32, LIN, None, None, "checker"),
+    ("half_nv12_bgra_width_not_16", "NV12", 136, 64, "BGRA", 68, 32, LIN, None, None, "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),

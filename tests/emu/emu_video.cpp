@@ -20,6 +20,7 @@
 #include "../../gstreamer_amd/csrc/video_pack.h"
 #include "../../gstreamer_amd/csrc/video_bilinear_fast.h"
 #include "../../gstreamer_amd/csrc/video_bilinear_rows.h"
+#include "../../gstreamer_amd/csrc/video_bilinear_half.h"
 #include "../../gstreamer_amd/csrc/video_planes.h"
 #include "../../gstreamer_amd/csrc/video_encode_fast.h"
 #include "../../gstreamer_amd/csrc/video_deep.h"
@@ -708,7 +709,8 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
 }
 
 static int g_fast422_runs = 0;
-static int g_bil_runs = 0, g_bilr_runs = 0;
+static int g_bil_runs = 0, g_bilr_runs = 0, g_bilh_runs = 0;
+extern "C" int emu_bilh_runs (void) { return g_bilh_runs; }
 extern "C" int emu_bil_runs (void) { return g_bil_runs; }
 extern "C" int emu_bilr_runs (void) { return g_bilr_runs; }
 static int g_fast420p_runs = 0;
@@ -1757,6 +1759,46 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
         fits = fits && bp.rows_tile_w > 0 && rows_ylen > 0;
         if (fits)
           bp.rows = getenv ("EMU_BIL_ROWS") ? atoi (getenv ("EMU_BIL_ROWS")) : 4;
+      }
+      if (bp.rows != 0 && p.front.chroma_v2 && getenv ("EMU_NO_BILINEAR_HALF") == nullptr) {
+        /* k_bilinear420_half (video_bilinear_half.h): capi_video.cpp's gate - the pairing table is the closed form, the halving exact - and
+         * bilinear420_half_usable's alignment rules */
+        BilParams hp = bp;
+        hp.regular_pairs = 1;
+        bool regular = true;
+        for (int y = 0; y < bp.out_h && regular; y++)
+          for (int l = 0; l < 2 && regular; l++) {
+            const int line = (int) bp.voffset[y] + l;
+            int ra, rb, role;
+            bil_rows (hp, line, &ra, &rb, &role);
+            const int e0 = vpair[2 * line], ta = vpair_row (e0), trole = vpair_role (e0), tb = vpair[2 * line + 1];
+            regular = ta == ra && tb == rb && (ra == rb || trole == role);
+          }
+        const bool al = ((uintptr_t) pl.p[0] % 16) == 0 && pl.stride[0] % 16 == 0 && ((uintptr_t) d0 % 16) == 0 && dstride % 16 == 0 &&
+            (bil_planar ? bil_planar_ok : (((uintptr_t) pl.p[1] % 16) == 0 && pl.stride[1] % 16 == 0));
+        if (regular && al && bilh_plan_ok (hp, bp.voffset, bp.vtaps)) {
+          g_bilh_runs++;
+          const int tiles = (hp.fp.width + BILH_TILE_SRC - 1) / BILH_TILE_SRC;
+          const int rows = getenv ("EMU_BIL_HALF_ROWS") ? atoi (getenv ("EMU_BIL_HALF_ROWS")) : 5;
+          hp.strips = bilh_strips (hp.out_h, rows, tiles, rows < 0 ? -rows : 0);
+          const auto p1_of = [&] (int y) { return (int) hp.vtaps[(size_t) y * 2 + 1]; };
+#define BILH_L(CH, pr, pg, pb) if (lay == GSTAMD_LAYOUT (pr, pg, pb)) bilh_strip<CH, GSTAMD_LAYOUT (pr, pg, pb)> (hp, pl, d0, dstride, x0, y0, y1, p1_of);
+#define BILH(CH) { BILH_L (CH, 2, 1, 0) BILH_L (CH, 0, 1, 2) BILH_L (CH, 1, 2, 3) BILH_L (CH, 3, 2, 1) }
+          for (int g = 0; g < hp.strips; g++) {
+            const int y0 = (int) ((unsigned) g * (unsigned) hp.out_h / (unsigned) hp.strips);
+            const int y1 = (int) ((unsigned) (g + 1) * (unsigned) hp.out_h / (unsigned) hp.strips);
+            for (int tile = 0; tile < tiles; tile++)
+              for (int lane = 0; lane < 64; lane++) {
+                const int x0 = tile * BILH_TILE_SRC + BILH_SRC_PER_LANE * lane;
+                if (p.front.chroma_h == CHROMA_H_H2_CS) BILH (CHROMA_H_H2_CS)
+                else if (p.front.chroma_h == CHROMA_H_H2) BILH (CHROMA_H_H2)
+                else BILH (CHROMA_H_NONE)
+              }
+          }
+#undef BILH
+#undef BILH_L
+          return GSTAMD_OK;
+        }
       }
       if (bp.rows != 0) {
         g_bilr_runs++;

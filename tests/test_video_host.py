@@ -404,6 +404,7 @@ def test_bilinear_rows_kernel_body_any_rows_per_wave(native_lib, emu_lib, idx_ca
     i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     monkeypatch.setenv("EMU_BIL_ROWS", str(rows))
+    monkeypatch.setenv("EMU_NO_BILINEAR_HALF", "1")           # exact halvings have their own kernel (test below)
     if tile:
         monkeypatch.setenv("EMU_BIL_ROWS_TILE", str(tile))     # default: 384 outputs per wave where the span fits, else 256 ...
     emu_lib.emu_bilr_runs.restype = C.c_int
@@ -415,6 +416,26 @@ def test_bilinear_rows_kernel_body_any_rows_per_wave(native_lib, emu_lib, idx_ca
         print(name, "rows kernel" if took else "older kernel")
     if name in ("nv12_bgra_2to1_bilinear_1280x720", "i420_bgra_bil420_half", "nv12_bgra_half_bilinear"):
         assert took == 1, name
+
+
+HALF = [c for c in SMALL if c[1][0].startswith("half_") or c[1][0] in ("nv12_bgra_2to1_bilinear_1280x720", "i420_bgra_bil420_half", "nv12_bgra_half_bilinear")]
+
+
+@pytest.mark.parametrize("rows", [5, 1, 4, 64, -100, -7, 100])
+@pytest.mark.parametrize("idx_case", HALF, ids=lambda c: c[1][0])
+def test_bilinear_half_kernel_body_any_rows_per_wave(native_lib, emu_lib, idx_case, rows, monkeypatch):
+    """k_bilinear420_half (video_bilinear_half.h): pictures that shrink by exactly two - a lane turns the 16 source pixels of one load into eight
+    consecutive outputs, both passes as v_dot2 on {even | odd} pixel pairs, no LDS.  Rows per wave are a tuning knob (negative: balanced strips);
+    a width that is no multiple of 16 stays with the rows kernel's predecessors."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    monkeypatch.setenv("EMU_BIL_HALF_ROWS", str(rows))
+    emu_lib.emu_bilh_runs.restype = C.c_int
+    before = emu_lib.emu_bilh_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    took = emu_lib.emu_bilh_runs() - before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
+    assert took == (0 if name == "half_nv12_bgra_width_not_16" else 1), name
 
 
 @pytest.mark.parametrize("idx_case", SMALL[::4], ids=lambda c: c[1][0])

@@ -102,9 +102,10 @@ GSTAMD_HD uint32_t bilh_pixel (const FastParams &fp, uint32_t ys, uint32_t cs, u
 
 // eight outputs of one row.  ya / yb: the 16 luma bytes of lines 2 y, 2 y + 1; c0 / c1: the upsampled chroma of those lines in the split
 // form of h420_filter_raw2 ([0..1] U of the even pixels, [2..3] U of the odd pixels, [4..7] the same for V); vw = {256 - p1 | p1 << 16}
-template <int L>
+// ST: void (int half, four pixels): outputs 4 half .. 4 half + 3 of the lane
+template <int L, class ST>
 GSTAMD_HD void bilh_emit_row (const FastParams &fp, const BilhLane &c, const uint32_t *ya, const uint32_t *yb, const uint32_t *c0, const uint32_t *c1,
-    uint32_t vw, uint8_t *__restrict__ d, bool store, uint32_t (&q)[4][2])
+    uint32_t vw, ST st, uint32_t (&q)[4][2])
 {
 #pragma unroll
   for (int half = 0; half < 2; half++) {
@@ -119,8 +120,7 @@ GSTAMD_HD void bilh_emit_row (const FastParams &fp, const BilhLane &c, const uin
       const uint32_t rv = bilh_value (bperm (c0[6 + half], c0[4 + half], sel_c), bperm (c1[6 + half], c1[4 + half], sel_c), c.w[j], vw);
       o[k] = bilh_pixel<L> (fp, bperm (0u, ry, 0x0c0c0101u), bperm (rv, ru, 0x05050101u), q[k]);
     }
-    if (store)
-      store16_stream (d + 16 * half, o[0], o[1], o[2], o[3]);
+    st (half, o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -155,9 +155,10 @@ GSTAMD_HD void bilh_request (const BilParams &bp, const Planes &pl, int y, int x
 }
 
 // one lane's share of a strip: outputs [o0, o0 + 8) of rows [y0, y1).  P1: int (int row) -> the second vertical tap of a row (the
-// kernel reads it out of a lane table with v_readlane, the emulator from the plan's table)
-template <int CH, int L, class P1>
-GSTAMD_HD void bilh_strip (const BilParams &bp, const Planes &pl, uint8_t *__restrict__ dst, int dstride, int x0, int y0, int y1, P1 p1_of)
+// kernel reads it out of a lane table with v_readlane, the emulator from the plan's table); ST: void (row pointer of the lane's first
+// output, lane stores?, half, four pixels) - the emulator stores them where they belong, the kernel trades them between lanes first
+template <int CH, int L, class P1, class ST>
+GSTAMD_HD void bilh_strip (const BilParams &bp, const Planes &pl, uint8_t *__restrict__ dst, int dstride, int x0, int y0, int y1, P1 p1_of, ST st)
 {
   const bool active = x0 < bp.fp.width;
   const int xc = active ? x0 : 0;             /* lanes right of the picture work on the first piece and store nothing */
@@ -188,7 +189,8 @@ GSTAMD_HD void bilh_strip (const BilParams &bp, const Planes &pl, uint8_t *__res
     bilh_blend (s[1], s[0], c0);                            /* line 2 y: 3 B + A; line 2 y + 1: 3 B + C (bilr_window, r0 even) */
     bilh_blend (s[1], s[2], c1);
     const uint32_t p1 = (uint32_t) p1_of (y);
-    bilh_emit_row<L> (bp.fp, c, ya, yb, c0, c1, (256u - p1) | (p1 << 16), d, active, q);
+    bilh_emit_row<L> (bp.fp, c, ya, yb, c0, c1, (256u - p1) | (p1 << 16),
+        [&] (int half, uint32_t a, uint32_t b, uint32_t e, uint32_t f) { st (d, active, half, a, b, e, f); }, q);
     d += dstride;
 #pragma unroll
     for (int i = 0; i < 8; i++)

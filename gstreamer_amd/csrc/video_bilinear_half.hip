@@ -39,8 +39,45 @@ __global__ __launch_bounds__ (256) void k_bilinear420_half (BilParams bp, BilBat
    * which also waits for the prefetch and the stores of the row before */
   const int yl = y0 + lane < bp.out_h ? y0 + lane : bp.out_h - 1;
   const int tab_p1 = (int) bp.vtaps[(size_t) yl * 2 + 1];
-  bilh_strip<CH, L> (bp, pl, dst, dstride, tile * BILH_TILE_SRC + BILH_SRC_PER_LANE * lane, y0, y1,
-      [&] (int y) { return __builtin_amdgcn_readlane (tab_p1, y - y0); });
+  /* a lane's eight pixels are 32 consecutive bytes: stored as they are, each 16-byte store instruction would write every other 16 bytes of a
+   * 2 KB run - half-written 32-byte sectors that the memory system has to merge.  The wave trades the halves through 2 KB of LDS instead
+   * (two 16-byte writes, two 16-byte reads per lane and row, no barrier: one wave) and stores two whole 1 KB runs. */
+  extern __shared__ __attribute__ ((aligned (16))) uint8_t lds_all[];
+  uint8_t *lds = lds_all + wave * 2048;
+  const int x0 = tile * BILH_TILE_SRC + BILH_SRC_PER_LANE * lane;
+  const int mode = bp.half;             /* 1: through LDS; 2: plain direct stores; 3: streaming direct stores (tuning builds) */
+  const bool src_a = tile * BILH_TILE_SRC + BILH_SRC_PER_LANE * (lane >> 1) < bp.fp.width;
+  const bool src_b = tile * BILH_TILE_SRC + BILH_SRC_PER_LANE * (32 + (lane >> 1)) < bp.fp.width;
+  bilh_strip<CH, L> (bp, pl, dst, dstride, x0, y0, y1,
+      [&] (int y) { return __builtin_amdgcn_readlane (tab_p1, y - y0); },
+      [&] (uint8_t *d, bool active, int half, uint32_t a, uint32_t b, uint32_t e, uint32_t f) {
+        if (mode == 2) {
+          if (active)
+            *(uint4 *) (d + 16 * half) = make_uint4 (a, b, e, f);
+          return;
+        }
+        if (mode == 3) {
+          if (active)
+            store16_stream (d + 16 * half, a, b, e, f);
+          return;
+        }
+        *(uint4 *) (lds + 32 * lane + 16 * half) = make_uint4 (a, b, e, f);
+        if (half == 0)
+          return;
+        __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier ();
+        __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+        const uint4 va = *(const uint4 *) (lds + 16 * lane), vb = *(const uint4 *) (lds + 1024 + 16 * lane);
+        /* d = the row's pointer at THIS lane's first output (at the ROW's first for lanes right of the picture): to the tile's start */
+        uint8_t *row = active ? d - 32 * lane : d + 2 * BILH_TILE_SRC * tile;
+        if (src_a)
+          store16_stream (row + 16 * lane, va.x, va.y, va.z, va.w);
+        if (src_b)
+          store16_stream (row + 1024 + 16 * lane, vb.x, vb.y, vb.z, vb.w);
+        __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier ();
+        __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+      });
 }
 
 static inline bool aligned (const void *p, size_t a) { return ((uintptr_t) p & (a - 1)) == 0; }
@@ -69,7 +106,7 @@ static int bilh_wave_slots ()
     if (hipGetDevice (&dev) != hipSuccess || hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;
     const void *fn = (const void *) k_bilinear420_half<CHROMA_H_H2_CS, GSTAMD_LAYOUT (2, 1, 0)>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, fn, 64, 0) != hipSuccess || per_cu <= 0)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, fn, 64, 2048) != hipSuccess || per_cu <= 0)
       per_cu = 16;
     (void) hipGetLastError ();
     slots = cus * per_cu;
@@ -89,6 +126,8 @@ hipError_t launch_bilinear420_half (const BilParams &bp, int chroma_h, int n, co
     rows = tuning_int ("GSTAMD_BIL_HALF_ROWS", rows);
   if (tuning_on ("GSTAMD_BIL_WG"))
     wg = tuning_int ("GSTAMD_BIL_WG", wg);
+  if (tuning_on ("GSTAMD_BIL_HALF_STORE"))
+    rp.half = tuning_int ("GSTAMD_BIL_HALF_STORE", 1);
 #endif
   /* one frame: as many strips as make one resident round (with a margin: a round that tips over into a second one costs 20 %);
    * several frames: the rounds follow each other anyway, strips of eight rows */
@@ -112,11 +151,11 @@ hipError_t launch_bilinear420_half (const BilParams &bp, int chroma_h, int n, co
     dim3 grid ((unsigned) blocks_per_frame * (unsigned) nb), block (64 * wg);
 #define W(pr, pg, pb) case GSTAMD_LAYOUT (pr, pg, pb): \
     if (chroma_h == CHROMA_H_H2_CS) \
-      hipLaunchKernelGGL ((k_bilinear420_half<CHROMA_H_H2_CS, GSTAMD_LAYOUT (pr, pg, pb)>), grid, block, 0, stream, rp, fb, dstride, tiles, blocks_per_frame); \
+      hipLaunchKernelGGL ((k_bilinear420_half<CHROMA_H_H2_CS, GSTAMD_LAYOUT (pr, pg, pb)>), grid, block, (size_t) wg * 2048, stream, rp, fb, dstride, tiles, blocks_per_frame); \
     else if (chroma_h == CHROMA_H_H2) \
-      hipLaunchKernelGGL ((k_bilinear420_half<CHROMA_H_H2, GSTAMD_LAYOUT (pr, pg, pb)>), grid, block, 0, stream, rp, fb, dstride, tiles, blocks_per_frame); \
+      hipLaunchKernelGGL ((k_bilinear420_half<CHROMA_H_H2, GSTAMD_LAYOUT (pr, pg, pb)>), grid, block, (size_t) wg * 2048, stream, rp, fb, dstride, tiles, blocks_per_frame); \
     else \
-      hipLaunchKernelGGL ((k_bilinear420_half<CHROMA_H_NONE, GSTAMD_LAYOUT (pr, pg, pb)>), grid, block, 0, stream, rp, fb, dstride, tiles, blocks_per_frame); \
+      hipLaunchKernelGGL ((k_bilinear420_half<CHROMA_H_NONE, GSTAMD_LAYOUT (pr, pg, pb)>), grid, block, (size_t) wg * 2048, stream, rp, fb, dstride, tiles, blocks_per_frame); \
     break;
     switch (GSTAMD_LAYOUT (bp.fp.pack_pos[1], bp.fp.pack_pos[2], bp.fp.pack_pos[3])) {
       W (2, 1, 0)      /* BGRA, BGRx */

@@ -490,7 +490,9 @@ GSTAMD_HD int quad_dot2 (uint32_t pair, uint32_t w, int acc)     // lo(pair) * l
 {
 #ifdef __HIPCC__
   typedef short s2 __attribute__ ((ext_vector_type (2)));
-  return __builtin_amdgcn_sdot2 (__builtin_bit_cast (s2, pair), __builtin_bit_cast (s2, w), acc, false);
+  /* clamp = true keeps the three-operand v_dot2_i32_i16 (its accumulator may be a scalar register); without it the compiler picks v_dot2c, whose
+   * accumulator is the destination, and loads it with a v_mov in front of every dot product.  The sums here are far from 2^31: it never acts. */
+  return __builtin_amdgcn_sdot2 (__builtin_bit_cast (s2, pair), __builtin_bit_cast (s2, w), acc, true);
 #else
   return (int) (int16_t) (pair & 0xffffu) * (int) (int16_t) (w & 0xffffu) + (int) (int16_t) (pair >> 16) * (int) (int16_t) (w >> 16) + acc;
 #endif

@@ -1782,7 +1782,11 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
           const int rows = getenv ("EMU_BIL_HALF_ROWS") ? atoi (getenv ("EMU_BIL_HALF_ROWS")) : 5;
           hp.strips = bilh_strips (hp.out_h, rows, tiles, rows < 0 ? -rows : 0);
           const auto p1_of = [&] (int y) { return (int) hp.vtaps[(size_t) y * 2 + 1]; };
-#define BILH_L(CH, pr, pg, pb) if (lay == GSTAMD_LAYOUT (pr, pg, pb)) bilh_strip<CH, GSTAMD_LAYOUT (pr, pg, pb)> (hp, pl, d0, dstride, x0, y0, y1, p1_of);
+          const auto put = [&] (uint8_t *d, bool active, int half, uint32_t a, uint32_t b, uint32_t e, uint32_t f) {
+            if (active)
+              store16_stream (d + 16 * half, a, b, e, f);
+          };
+#define BILH_L(CH, pr, pg, pb) if (lay == GSTAMD_LAYOUT (pr, pg, pb)) bilh_strip<CH, GSTAMD_LAYOUT (pr, pg, pb)> (hp, pl, d0, dstride, x0, y0, y1, p1_of, put);
 #define BILH(CH) { BILH_L (CH, 2, 1, 0) BILH_L (CH, 0, 1, 2) BILH_L (CH, 1, 2, 3) BILH_L (CH, 3, 2, 1) }
           for (int g = 0; g < hp.strips; g++) {
             const int y0 = (int) ((unsigned) g * (unsigned) hp.out_h / (unsigned) hp.strips);

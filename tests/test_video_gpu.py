@@ -276,7 +276,7 @@ def test_hip_single_kernel_plans_take_frame_lists(native_lib, gpu, ref, plan):
     conv.free()
 
 
-BILR_SHAPES = [("NV12", 3840, 2160, "BGRA", 1920, 1080, None), ("NV12", 1920, 1080, "RGBA", 1280, 720, None), ("I420", 2048, 858, "ARGB", 1024, 429, "jpeg"),
+BILR_SHAPES = [("NV12", 3840, 2160, "BGRA", 1920, 1080, None), ("NV21", 7680, 4320, "xRGB", 3840, 2160, "jpeg"), ("YV12", 1040, 362, "RGBA", 520, 181, "none"), ("NV12", 1920, 1080, "RGBA", 1280, 720, None), ("I420", 2048, 858, "ARGB", 1024, 429, "jpeg"),
                ("NV21", 1280, 720, "BGRx", 1000, 562, None), ("YV12", 640, 480, "BGRA", 1280, 960, None), ("NV12", 4096, 2160, "BGRA", 2730, 1440, "mpeg2")]
 
 
@@ -294,6 +294,12 @@ def test_hip_bilinear420_rows_shapes_match_reference_bytewise(native_lib, gpu, r
     with V.tuning(GSTAMD_NO_BILINEAR_ROWS=1):
         out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LIN, None, site, src)
     assert (out == exp).all(), int((out != exp).sum())
+    if (w, h) == (2 * ow, 2 * oh):
+        # exact halvings go through k_bilinear420_half: the rows kernel on the same frames, and the direct stores instead of the trade through LDS
+        for knobs in (dict(GSTAMD_NO_BILINEAR_HALF=1), dict(GSTAMD_BIL_HALF_STORE=2), dict(GSTAMD_BIL_HALF_STORE=3), dict(GSTAMD_BIL_HALF_ROWS=3)):
+            with V.tuning(**knobs):
+                out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LIN, None, site, src)
+            assert (out == exp).all(), (knobs, int((out != exp).sum()))
 
 
 @pytest.mark.parametrize("shape", [("NV12", 1920, 1080, "BGRA", 960, 540, 5), ("I420", 1280, 720, "RGBA", 854, 480, 3), ("NV12", 3840, 2160, "BGRA", 1920, 1080, 34)],

@@ -33,11 +33,11 @@ VIDEO_CONFIGS = {
     "c2": ("NV12", 3840, 2160, "BGRA", 3840, 2160, {}, 32, 32, HEADLINE, "k_convert_strip<CHROMA_H_H2_CS, layout BGRA>"),
     "c1": ("NV12", 1920, 1080, "BGRA", 1920, 1080, {}, 32, 32,
            "1080p frames/s (videoconvertscale NV12->BGRA) per GPU; % HBM roofline", "k_convert_strip<CHROMA_H_H2_CS, layout BGRA>"),
-    "c3": ("I420", 7680, 4320, "RGBA", 1920, 1080, {"resampler_method": "lanczos"}, 8, 8,
+    "c3": ("I420", 7680, 4320, "RGBA", 1920, 1080, {"resampler_method": "lanczos"}, 16, 16,
            "8K->1080p frames/s (videoconvertscale I420->RGBA, Lanczos) per GPU; % HBM roofline", "k_scale_col (--batch 1: one frame per launch)"),
     "c5": ("NV12", 7680, 4320, "BGRA", 3840, 2160, {"resampler_method": "linear", "max_taps": 2}, 16, 16,
            "8K->4K frames/s (videoconvertscale NV12->BGRA, bilinear) per GPU; % HBM roofline",
-           "k_bilinear420_rows_frames (--batch 1: k_bilinear420_rows)"),
+           "k_bilinear420_half (an exact halving; other ratios: k_bilinear420_rows)"),
     # SURVEY 8(f) rows, measured the same way (composite plans: several launches per frame, the whole frame is what is timed)
     "f2gamma": ("NV12", 3840, 2160, "BGRA", 3840, 2160, {"gamma_mode": "remap"}, 8, 8,
                 "4K frames/s (videoconvertscale NV12->BGRA, gamma-mode=remap) per GPU; % HBM roofline", "k_convert_strip<.., GSTAMD_FAST_LUT> (the direct conversion made with the gamma chain's to_RGB matrix, the composed decode/encode table ahead of the store)"),

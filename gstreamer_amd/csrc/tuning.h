@@ -27,6 +27,8 @@
 //   GSTAMD_NO_FAST420P       generic kernel instead of the I420 / YV12 -> RGB fastpath kernel (set)
 //   GSTAMD_NO_FAST422        generic kernel instead of the packed 4:2:2 -> RGB kernel (set)
 //   GSTAMD_NO_PLANE_FRAME    one kernel per plane and pass (intermediate plane in HBM) instead of k_plane_frame (set)
+//   GSTAMD_NO_BILINEAR4_UP   k_bilinear4_rows instead of k_bilinear4_up for horizontal-first 2-tap x 2-tap plans of 4-byte pixels (set)
+//   GSTAMD_BIL4_UP_ROWS      output rows per wave of k_bilinear4_up (n, default 8)
 //   GSTAMD_NO_BILINEAR4      wave-tile scaler instead of the four-outputs-per-lane nearest / 2-tap scaler of 4-byte sources (set)
 //   GSTAMD_NO_CONVERT16_FAST the general 16-bit convert kernel instead of the ones specialised by plane layout and chroma filter (set)
 //   GSTAMD_NO_GAMMA_COMP     decode and encode tables separately in the fused gamma kernel, not their composition (set)

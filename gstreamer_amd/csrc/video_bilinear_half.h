@@ -189,6 +189,19 @@ GSTAMD_HD void bilh_strip (const BilParams &bp, const Planes &pl, uint8_t *__res
     bilh_blend (s[1], s[0], c0);                            /* line 2 y: 3 B + A; line 2 y + 1: 3 B + C (bilr_window, r0 even) */
     bilh_blend (s[1], s[2], c1);
     const uint32_t p1 = (uint32_t) p1_of (y);
+#if defined (GSTAMD_TUNING) && defined (__HIPCC__)
+    if (bp.half >= 5) {                 /* ablations (wrong bytes): 5 = loads, chroma filter + blend, stores; 6 = loads and stores only */
+      if (bp.half == 5) {
+        st (d, active, 0, ya[0] ^ c0[0] ^ c1[0], ya[1] ^ c0[1] ^ c1[1], ya[2] ^ c0[2] ^ c1[2], ya[3] ^ c0[3] ^ c1[3]);
+        st (d, active, 1, yb[0] ^ c0[4] ^ c1[4], yb[1] ^ c0[5] ^ c1[5], yb[2] ^ c0[6] ^ c1[6], yb[3] ^ c0[7] ^ c1[7]);
+      } else {
+        st (d, active, 0, ya[0] ^ s[2][0], ya[1] ^ s[2][1], ya[2] ^ s[2][2], ya[3] ^ s[2][3]);
+        st (d, active, 1, yb[0] ^ s[2][4], yb[1] ^ s[2][5], yb[2] ^ s[2][6], yb[3] ^ s[2][7]);
+      }
+      d += dstride;
+      continue;
+    }
+#endif
     bilh_emit_row<L> (bp.fp, c, ya, yb, c0, c1, (256u - p1) | (p1 << 16),
         [&] (int half, uint32_t a, uint32_t b, uint32_t e, uint32_t f) { st (d, active, half, a, b, e, f); }, q);
     d += dstride;

@@ -1721,6 +1721,22 @@ __global__ __launch_bounds__ (256) void k_bilinear4_rows (Bil4Params b, Dst dst,
   bilinear4_rows_lane (b, dst, pf, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y * b.rows);
 }
 
+// bilinear4_up_lane: a wave = 256 outputs x a strip of b.rows output rows (<= 64: one lane per row holds the row's table entries)
+template <int PLAIN>
+__global__ __launch_bounds__ (256) void k_bilinear4_up (Bil4Params b, Dst dst, PostFast pf, uint32_t plain_sel)
+{
+  const int lane = (int) threadIdx.x & 63;
+  const int y0 = (int) blockIdx.y * b.rows, y1 = y0 + b.rows < b.out_h ? y0 + b.rows : b.out_h;
+  /* table reads inside the row loop would be vector loads followed by s_waitcnt vmcnt(0) - which also waits for the line just requested */
+  const int yl = y0 + lane < b.out_h ? y0 + lane : b.out_h - 1;
+  const int tab_ya = (int) b.sv.offset[yl], tab_p1 = (int) b.sv.taps[(size_t) yl * 2 + 1];
+  bilinear4_up_lane<PLAIN> (b, dst, pf, plain_sel, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, y0, y1,
+      [&] (int y, int *ya, uint32_t *p1) {
+        *ya = __builtin_amdgcn_readlane (tab_ya, y - y0);
+        *p1 = (uint32_t) __builtin_amdgcn_readlane (tab_p1, y - y0);
+      });
+}
+
 hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &pre,
     const ScaleDev &sh, const ScaleDev &sv, bool h_first, uint8_t *dst, int dstride, const ColorParams &post,
     const int pack_pos[4], int out_w, int out_h, int h_span, TileGeom geom, const PostFast &pf, hipStream_t stream)
@@ -1745,6 +1761,22 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
     /* rows per lane, measured: two for a 4K destination (BGRA 1080p -> 4K 31.0 us at four rows, 27.2 at two, 29.1 at one), one for smaller ones (4K ->
        1080p: 130 000 lanes at four rows, two waves per SIMD - 29.2 us against 23.8): every row of a lane starts with two dependent table reads */
     b.out_w = out_w, b.out_h = out_h, b.rows = (long) out_w * out_h >= 6000000 ? 2 : 1;
+    if (bilinear4_up_ok (b) && !tuning_on ("GSTAMD_NO_BILINEAR4_UP")) {
+      /* horizontal first, two taps both ways: source lines carried down strips of rows */
+      b.rows = 8;
+#ifdef GSTAMD_TUNING
+      if (tuning_on ("GSTAMD_BIL4_UP_ROWS"))
+        b.rows = tuning_int ("GSTAMD_BIL4_UP_ROWS", b.rows);
+#endif
+      b.rows = b.rows < 1 ? 1 : (b.rows > 64 ? 64 : b.rows);
+      uint32_t sel = 0;
+      const dim3 ugrid (((out_w + 3) / 4 + 255) / 256, (out_h + b.rows - 1) / b.rows);
+      if (bilinear4_plain_sel (d, pf, &sel))
+        hipLaunchKernelGGL (k_bilinear4_up<1>, ugrid, dim3 (256), 0, stream, b, d, pf, sel);
+      else
+        hipLaunchKernelGGL (k_bilinear4_up<0>, ugrid, dim3 (256), 0, stream, b, d, pf, sel);
+      return hipGetLastError ();
+    }
     hipLaunchKernelGGL (k_bilinear4_rows, dim3 (((out_w + 3) / 4 + 255) / 256, (out_h + b.rows - 1) / b.rows), dim3 (256), 0, stream, b, d, pf);
     return hipGetLastError ();
   }

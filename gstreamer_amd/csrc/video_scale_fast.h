@@ -425,6 +425,156 @@ GSTAMD_HD void bilinear4_rows_lane (const Bil4Params &b, const Dst &dst, const P
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same scaler for plans that filter horizontally first with two taps both ways (what an enlargement of 4-byte pixels is: BGRA 1080p -> 4K,
+// the second stage of NV12 1080p -> BGRA 4K), with the source lines CARRIED DOWN the rows: bilinear4_rows_lane fetched 16 separate pixels per
+// output row (17 vector-memory instructions per four outputs - the chip issues one per ~37 clocks and CU whatever its width, so a 4K destination
+// could not go below ~38 us) and filtered both source lines again for every output row.  Here a lane walks a strip of rows with the ldreslinl
+// results of source lines ya and ya + 1 of its four outputs in registers: a source line is fetched once (one 8-byte load per output: the pixel
+// pair idx, idx + 1) and filtered once, however many output rows blend it - at 2x that is two loads and one 16-byte store per output row.
+// The line the NEXT row will need is requested before this row's vertical pass.  Run-time forms of the post stage are decided once per lane,
+// not per pixel.  Same integers: h2tap_eo, v2tap_pk, post_px.
+// ------------------------------------------------------------------------------------------------
+struct Bil4Line {
+  uint32_t e[4], o[4];          // h2tap_eo of the lane's four outputs on one source line
+};
+
+GSTAMD_HD uint2 bil4_pair (const uint8_t *__restrict__ row, uint32_t off)
+{
+#ifdef __HIPCC__
+  typedef unsigned int u32x2a __attribute__ ((ext_vector_type (2), aligned (4)));
+  const u32x2a v = *(const u32x2a *) (row + off);
+  return make_uint2 (v.x, v.y);
+#else
+  uint2 v;
+  __builtin_memcpy (&v, row + off, 8);
+  return v;
+#endif
+}
+
+// can the plan take bilinear4_up_lane?  (host)
+inline bool bilinear4_up_ok (const Bil4Params &b)
+{
+  return b.sh.kind == SCALE_2TAP && b.sv.kind == SCALE_2TAP && b.h_first && b.src_w >= 2;
+}
+
+// the post stage as one byte permutation, when it is nothing else: an intermediate image, or a final pack without matrix / alpha stage
+inline bool bilinear4_plain_sel (const Dst &dst, const PostFast &pf, uint32_t *sel)
+{
+  if (pf.use || (dst.final && (dst.post.matrix.kind != MATRIX_NONE || dst.post.alpha_kind != ALPHA_NONE)))
+    return false;
+  *sel = 0x03020100u;
+  if (dst.final) {
+    *sel = 0;
+    for (int j = 0; j < 4; j++)
+      *sel |= (uint32_t) j << (8 * dst.pack_pos[j]);
+  }
+  return true;
+}
+
+// TAB: void (int y, int *ya, uint32_t *p1) -> first source line and second tap of output row y (the kernel keeps a strip's entries in a lane
+// table and reads them with v_readlane, the emulator takes them from the plan)
+template <int PLAIN, class TAB>
+GSTAMD_HD void bilinear4_up_lane (const Bil4Params &b, const Dst &dst, const PostFast &pf, uint32_t plain_sel, int x0, int y0, int y1, TAB tab)
+{
+  if (x0 >= b.out_w)
+    return;
+  uint32_t off[4], fr[4], sa[4];
+  const uint32_t sb = b.sel_in + 0x04040404u;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = x0 + i < b.out_w ? x0 + i : b.out_w - 1;
+    const int tmp = x * b.sh.inc;
+    const int idx = tmp >> 16;
+    fr[i] = (uint32_t) (tmp >> 8) & 0xffu;
+    /* the pair (idx, idx + 1); on the row's last pixel the pair before it, read as (second, second): the clamp of bil4_fetch */
+    const bool edge = idx >= b.src_w - 1;
+    off[i] = 4u * (uint32_t) (edge ? b.src_w - 2 : idx);
+    sa[i] = edge ? sb : b.sel_in;
+  }
+  Bil4Line A, B;
+  uint2 P[4];
+  int id_a = -1, id_b = -1, id_p = -1;
+  const auto fetch = [&] (int line, uint2 *p) {
+    const uint8_t *__restrict__ row = b.src + (size_t) line * b.sstride;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      p[i] = bil4_pair (row, off[i]);
+  };
+  const auto hline = [&] (const uint2 *p, Bil4Line &l) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      h2tap_eo (bperm (p[i].y, p[i].x, sa[i]), bperm (p[i].y, p[i].x, sb), fr[i], l.e[i], l.o[i]);
+  };
+  for (int y = y0; y < y1; y++) {
+    int ya;
+    uint32_t p1;
+    tab (y, &ya, &p1);
+    const int yb = ya + 1 < b.src_h ? ya + 1 : b.src_h - 1;
+    /* wave-uniform from here to the vertical pass: line numbers only */
+    if (id_a != ya) {
+      if (id_b == ya) {
+        A = B;
+      } else if (id_p == ya) {
+        hline (P, A);
+      } else {
+        uint2 t[4];
+        fetch (ya, t);
+        hline (t, A);
+      }
+      id_a = ya;
+    }
+    if (id_b != yb) {
+      if (id_a == yb) {
+        B = A;
+      } else if (id_p == yb) {
+        hline (P, B);
+      } else {
+        uint2 t[4];
+        fetch (yb, t);
+        hline (t, B);
+      }
+      id_b = yb;
+    }
+    if (y + 1 < y1) {
+      int yn;
+      uint32_t pn;
+      tab (y + 1, &yn, &pn);
+      const int ynb = yn + 1 < b.src_h ? yn + 1 : b.src_h - 1;
+      const int want = (yn != id_a && yn != id_b) ? yn : ynb;
+      if (want != id_a && want != id_b && want != id_p) {
+        fetch (want, P);                /* in flight during this row's vertical pass and store */
+        id_p = want;
+      }
+    }
+    const uint32_t p1s = (p1 & 0xffffu) * 0x00010001u;
+    uint32_t out[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t e = v2tap_pk (A.e[i], B.e[i], p1s), o = v2tap_pk (A.o[i], B.o[i], p1s);
+      const uint32_t px = e | (o << 8);
+      out[i] = PLAIN ? bperm (0u, px, plain_sel) : post_px (dst, pf, px);
+    }
+    uint8_t *d = dst.p + (size_t) y * dst.stride + 4 * (size_t) x0;
+    if (x0 + 4 <= b.out_w && (((uintptr_t) d) & 15) == 0) {
+#ifdef __HIPCC__
+      typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
+      const u32x4 v = {out[0], out[1], out[2], out[3]};
+      if (dst.final)
+        __builtin_nontemporal_store (v, (u32x4 *) d);
+      else
+        *(u32x4 *) d = v;
+#else
+      for (int i = 0; i < 4; i++)
+        ((uint32_t *) d)[i] = out[i];
+#endif
+    } else {
+      for (int i = 0; i < 4 && x0 + i < b.out_w; i++)
+        ((uint32_t *) d)[i] = out[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // N-tap horizontal pass as byte dot products (v_dot4_i32_i8).  The wave stages Y, U, V of the source span as three
 // byte planes, each byte XOR 0x80 (= value - 128 as int8); one output channel is
 //     sum (px * tap) = sum ((px - 128) * tap) + 128 * sum (tap),      sum (tap) = 64 (checked by the planner)

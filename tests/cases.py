@@ -235,6 +235,16 @@ VIDEO_CASES = [
     ("half_nv12_bgrx_fullrange", "NV12", 48, 44, "BGRx", 24, 22, LIN, "1:4:0:0", None, "random"),
     ("half_nv12_xrgb_checker", "NV12", 128, 64, "xRGB", 64, 32, LIN, None, None, "checker"),
     ("half_nv12_bgra_width_not_16", "NV12", 136, 64, "BGRA", 68, 32, LIN, None, None, "random"),
+    # k_bilinear4_up (video_scale_fast.h: bilinear4_up_lane): horizontal-first 2-tap x 2-tap on 4-byte pixels with the source lines carried down the
+    # rows - 2x, non-integer, a one-pixel enlargement, a two-pixel-wide source, a converted source (YUY2), a width that is no multiple of four,
+    # mixed enlarge / shrink with the matrix behind the scaler
+    ("up4_bgra_bgra_2x", "BGRA", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
+    ("up4_rgba_argb_nonint", "RGBA", 100, 60, "ARGB", 333, 211, LIN, None, None, "random"),
+    ("up4_argb_argb_plus_one", "ARGB", 64, 48, "ARGB", 65, 49, LIN, None, None, "random"),
+    ("up4_xrgb_bgrx_tiny_source", "xRGB", 2, 2, "BGRx", 9, 7, LIN, None, None, "random"),
+    ("up4_yuy2_bgra_converted_source", "YUY2", 160, 90, "BGRA", 322, 200, LIN, None, None, "random"),
+    ("up4_ayuv_bgra_mixed", "AYUV", 100, 100, "BGRA", 150, 80, LIN, None, None, "random"),
+    ("up4_vuya_vuya_3x", "VUYA", 61, 33, "VUYA", 183, 99, LIN, None, None, "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),

@@ -709,6 +709,32 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
 }
 
 static int g_fast422_runs = 0;
+
+static int g_bil4_up_runs = 0;
+extern "C" int emu_bil4_up_runs (void) { return g_bil4_up_runs; }
+// k_bilinear4_up's grid: a lane per four outputs, strips of EMU_BIL4_UP_ROWS rows (launch_scale2x2_from_front's gate)
+static bool emu_bilinear4_up (Bil4Params b, const Dst &d, const PostFast &pf)
+{
+  if (!bilinear4_up_ok (b) || getenv ("EMU_NO_BILINEAR4_UP"))
+    return false;
+  g_bil4_up_runs++;
+  b.rows = getenv ("EMU_BIL4_UP_ROWS") ? atoi (getenv ("EMU_BIL4_UP_ROWS")) : 5;
+  uint32_t sel = 0;
+  const bool plain = bilinear4_plain_sel (d, pf, &sel);
+  const auto tab = [&] (int y, int *ya, uint32_t *p1) {
+    *ya = (int) b.sv.offset[y];
+    *p1 = (uint32_t) (int) b.sv.taps[(size_t) y * 2 + 1];
+  };
+  for (int y0 = 0; y0 < b.out_h; y0 += b.rows)
+    for (int x0 = 0; x0 < b.out_w; x0 += 4) {
+      const int y1 = y0 + b.rows < b.out_h ? y0 + b.rows : b.out_h;
+      if (plain)
+        bilinear4_up_lane<1> (b, d, pf, sel, x0, y0, y1, tab);
+      else
+        bilinear4_up_lane<0> (b, d, pf, sel, x0, y0, y1, tab);
+    }
+  return true;
+}
 static int g_bil_runs = 0, g_bilr_runs = 0, g_bilh_runs = 0;
 extern "C" int emu_bilh_runs (void) { return g_bilh_runs; }
 extern "C" int emu_bil_runs (void) { return g_bil_runs; }
@@ -1890,6 +1916,8 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
       b.out_w = p.out_info.width, b.out_h = p.out_info.height, b.rows = 4;
       PostFast pf_none;
       memset ((void *) &pf_none, 0, sizeof (pf_none));
+      if (emu_bilinear4_up (b, d, pf_none))
+        return GSTAMD_OK;
       for (int y0 = 0; y0 < b.out_h; y0 += b.rows)
         for (int x0 = 0; x0 < b.out_w; x0 += 4)
           bilinear4_rows_lane (b, d, pf_none, x0, y0);
@@ -1925,6 +1953,8 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
       b.sel_in = (uint32_t) p.front.pos[0] | ((uint32_t) p.front.pos[1] << 8) | ((uint32_t) p.front.pos[2] << 16) | ((uint32_t) p.front.pos[3] << 24);
       b.sh = sh, b.sv = sv, b.h_first = h_first ? 1 : 0;
       b.out_w = p.out_info.width, b.out_h = p.out_info.height, b.rows = 4;
+      if (emu_bilinear4_up (b, d, pf))
+        return GSTAMD_OK;
       for (int y0 = 0; y0 < b.out_h; y0 += b.rows)
         for (int x0 = 0; x0 < b.out_w; x0 += 4)
           bilinear4_rows_lane (b, d, pf, x0, y0);

@@ -438,6 +438,31 @@ def test_bilinear_half_kernel_body_any_rows_per_wave(native_lib, emu_lib, idx_ca
     assert took == (0 if name == "half_nv12_bgra_width_not_16" else 1), name
 
 
+UP4 = [c for c in SMALL if c[1][0].startswith("up4_") or c[1][0] in ("bgrx_bgrx_up_bilinear_planes", "nv12_bgra_up2_bilinear", "i420_vuya_up_bilinear",
+                                                                     "quad4_argb_up_bilinear_odd")]
+
+
+@pytest.mark.parametrize("rows", [5, 1, 2, 64])
+@pytest.mark.parametrize("idx_case", UP4, ids=lambda c: c[1][0])
+def test_bilinear4_up_kernel_body_any_rows_per_wave(native_lib, emu_lib, idx_case, rows, monkeypatch):
+    """k_bilinear4_up (bilinear4_up_lane): enlargements of 4-byte pixels with the filtered source lines carried down a strip of rows; the strip
+    height is a tuning knob.  Plans it does not take (vertical first, a colour stage ahead of the scaler) stay with the older kernels."""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    monkeypatch.setenv("EMU_BIL4_UP_ROWS", str(rows))
+    emu_lib.emu_bil4_up_runs.restype = C.c_int
+    before = emu_lib.emu_bil4_up_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    took = emu_lib.emu_bil4_up_runs() - before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
+    if rows == 5:
+        print(name, "up kernel" if took else "older kernel")
+    assert took == (0 if name in ("up4_ayuv_bgra_mixed", "up4_xrgb_bgrx_tiny_source") else 1), name
+    monkeypatch.setenv("EMU_NO_BILINEAR4_UP", "1")
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
+
+
 @pytest.mark.parametrize("idx_case", SMALL[::4], ids=lambda c: c[1][0])
 def test_golden_vectors_are_the_references_output(ref, idx_case):
     """Pins the committed golden hashes to the reference implementation itself (oracle/_ref)."""

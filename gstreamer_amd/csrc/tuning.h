@@ -38,6 +38,8 @@
 //   GSTAMD_NO_BILINEAR420    wave-tile scaler instead of the 4:2:0 bilinear kernels (set)
 //   GSTAMD_NO_BILINEAR_ROWS  k_bilinear420 instead of k_bilinear420_rows (set)
 //   GSTAMD_NO_BILINEAR_HALF  k_bilinear420_rows instead of k_bilinear420_half where the picture shrinks by exactly two (set)
+//   GSTAMD_BIL_HALF_SMALL    k_bilinear420_half also for single frames of less than 4 M outputs (set)
+//   GSTAMD_BIL_HALF_STORE    tuning builds: 1 the halves traded through LDS (default), 2 plain direct stores, 3 streaming direct stores, 5 / 6 ablations (n)
 //   GSTAMD_BIL_HALF_ROWS     output rows per wave of k_bilinear420_half (n; default: one resident round for a frame, 8 in lists)
 //   GSTAMD_NO_CONVERT_PACK_WIDE  the byte-store form of k_convert_pack instead of its whole-block form (set)
 //   GSTAMD_BIL_TILE, GSTAMD_BIL_TABLE, GSTAMD_BIL_ROWS, GSTAMD_BIL_ROWS_TILE, GSTAMD_BIL_SLOTS, GSTAMD_BIL_WG, GSTAMD_BIL_VERBOSE

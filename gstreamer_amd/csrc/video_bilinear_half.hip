@@ -86,6 +86,10 @@ bool bilinear420_half_usable (const BilParams &bp, int n, const Planes *pl, uint
 {
   if (!bp.half || (dstride % 16) != 0)
     return false;
+  /* a wave needs a 1024-pixel source column to itself: one frame of less than ~4 M outputs is a few hundred waves with long serial walks, and the
+   * rows kernel's narrower tiles win (4K -> 1080p, one frame: 12.6 us against 15.2; 8K -> 4K: 24.2 against 22.8; in lists this kernel, 14.3 against 18) */
+  if (n == 1 && (long) bp.out_w * bp.out_h < 4000000 && !tuning_on ("GSTAMD_BIL_HALF_SMALL"))
+    return false;
   for (int f = 0; f < n; f++) {
     const Planes &q = pl[f];
     if (!aligned (q.p[0], 16) || (q.stride[0] % 16) != 0 || !aligned (dst[f], 16) || q.stride[0] != pl[0].stride[0] || q.stride[1] != pl[0].stride[1] ||

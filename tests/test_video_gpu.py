@@ -88,6 +88,32 @@ def test_hip_set_config_gives_the_frames_of_a_fresh_converter(native_lib, gpu, r
         c.free()
 
 
+HALF_CASES = [c for c in enumerate(cases.VIDEO_CASES) if c[1][0].startswith("half_") or c[1][0] in ("nv12_bgra_2to1_bilinear_1280x720", "i420_bgra_bil420_half",
+                                                                                                   "nv12_bgra_half_bilinear")]
+
+
+@pytest.mark.parametrize("idx_case", HALF_CASES, ids=lambda c: c[1][0])
+def test_hip_bilinear_half_kernel_matches_golden(native_lib, gpu, idx_case):
+    """The exact halvings through k_bilinear420_half: single frames of this size stay with the rows kernel by default (GSTAMD_BIL_HALF_SMALL lifts
+    that), in a list they take it - both against the golden vectors"""
+    import torch
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(int(V.video_info(ifmt, w, h).size), pattern, cases.case_seed(name), w)
+    with V.tuning(GSTAMD_BIL_HALF_SMALL=1):
+        out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert cases.video_digest(name, out) == GOLDEN[name]["sha256"]
+    col_i, col_o = cases.split_colorimetry(col)
+    ii, oi = V.video_info(ifmt, w, h, colorimetry=col_i, chroma_site=site), V.video_info(ofmt, ow, oh, colorimetry=col_o)
+    conv = V.VideoConverter(ii, oi, V.converter_config(**cfg))
+    d_src = torch.from_numpy(src).to(gpu)
+    outs = [torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu) for _ in range(3)]
+    conv.frames([d_src] * 3, outs)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert cases.video_digest(name, o.cpu().numpy()) == GOLDEN[name]["sha256"]
+    conv.free()
+
+
 H420_GENERAL = [c for c in enumerate(cases.VIDEO_CASES) if "_h420_" in c[1][0] or c[1][0] in ("nv12_bgra_quarter_lanczos", "i420_rgba_1080p_to_270p_lanczos")]
 
 
@@ -296,7 +322,8 @@ def test_hip_bilinear420_rows_shapes_match_reference_bytewise(native_lib, gpu, r
     assert (out == exp).all(), int((out != exp).sum())
     if (w, h) == (2 * ow, 2 * oh):
         # exact halvings go through k_bilinear420_half: the rows kernel on the same frames, and the direct stores instead of the trade through LDS
-        for knobs in (dict(GSTAMD_NO_BILINEAR_HALF=1), dict(GSTAMD_BIL_HALF_STORE=2), dict(GSTAMD_BIL_HALF_STORE=3), dict(GSTAMD_BIL_HALF_ROWS=3)):
+        for knobs in (dict(GSTAMD_NO_BILINEAR_HALF=1), dict(GSTAMD_BIL_HALF_SMALL=1), dict(GSTAMD_BIL_HALF_SMALL=1, GSTAMD_BIL_HALF_STORE=2),
+                      dict(GSTAMD_BIL_HALF_SMALL=1, GSTAMD_BIL_HALF_STORE=3), dict(GSTAMD_BIL_HALF_SMALL=1, GSTAMD_BIL_HALF_ROWS=3)):
             with V.tuning(**knobs):
                 out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LIN, None, site, src)
             assert (out == exp).all(), (knobs, int((out != exp).sum()))

@@ -438,6 +438,9 @@ struct Bil4Line {
   uint32_t e[4], o[4];          // h2tap_eo of the lane's four outputs on one source line
 };
 
+#ifdef GSTAMD_EMU_BOUNDS
+static const uint8_t *g_bil4_lo, *g_bil4_hi;     // the emulator's bounds check of the pair loads (tests/emu)
+#endif
 GSTAMD_HD uint2 bil4_pair (const uint8_t *__restrict__ row, uint32_t off)
 {
 #ifdef __HIPCC__
@@ -445,6 +448,12 @@ GSTAMD_HD uint2 bil4_pair (const uint8_t *__restrict__ row, uint32_t off)
   const u32x2a v = *(const u32x2a *) (row + off);
   return make_uint2 (v.x, v.y);
 #else
+#ifdef GSTAMD_EMU_BOUNDS
+  if (row + off < g_bil4_lo || row + off + 8 > g_bil4_hi) {
+    fprintf (stderr, "bil4_pair: read of 8 bytes at %+ld, frame of %ld bytes\n", (long) (row + off - g_bil4_lo), (long) (g_bil4_hi - g_bil4_lo));
+    abort ();
+  }
+#endif
   uint2 v;
   __builtin_memcpy (&v, row + off, 8);
   return v;
@@ -476,8 +485,11 @@ inline bool bilinear4_plain_sel (const Dst &dst, const PostFast &pf, uint32_t *s
 template <int PLAIN, class TAB>
 GSTAMD_HD void bilinear4_up_lane (const Bil4Params &b, const Dst &dst, const PostFast &pf, uint32_t plain_sel, int x0, int y0, int y1, TAB tab)
 {
-  if (x0 >= b.out_w)
-    return;
+  /* lanes right of the picture stay (on the first four outputs, storing nothing): the kernel's row table lives in the LANES of the wave and is read
+   * with v_readlane - with an early exit here the compiler sinks the table loads below it, lanes that left never load their entry, and a picture
+   * narrower than 4 x (rows per strip) outputs reads garbage line numbers (found by the device fuzz: a 25-pixel-wide frame) */
+  const bool active = x0 < b.out_w;
+  x0 = active ? x0 : 0;
   uint32_t off[4], fr[4], sa[4];
   const uint32_t sb = b.sel_in + 0x04040404u;
 #pragma unroll
@@ -555,6 +567,8 @@ GSTAMD_HD void bilinear4_up_lane (const Bil4Params &b, const Dst &dst, const Pos
       out[i] = PLAIN ? bperm (0u, px, plain_sel) : post_px (dst, pf, px);
     }
     uint8_t *d = dst.p + (size_t) y * dst.stride + 4 * (size_t) x0;
+    if (!active)
+      continue;
     if (x0 + 4 <= b.out_w && (((uintptr_t) d) & 15) == 0) {
 #ifdef __HIPCC__
       typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));

@@ -245,6 +245,9 @@ VIDEO_CASES = [
     ("up4_yuy2_bgra_converted_source", "YUY2", 160, 90, "BGRA", 322, 200, LIN, None, None, "random"),
     ("up4_ayuv_bgra_mixed", "AYUV", 100, 100, "BGRA", 150, 80, LIN, None, None, "random"),
     ("up4_vuya_vuya_3x", "VUYA", 61, 33, "VUYA", 183, 99, LIN, None, None, "random"),
+    # fewer lanes with outputs than rows in a strip (the kernel's row table lives in the lanes of the wave: found by the device fuzz)
+    ("up4_bgra_bgra_narrower_than_a_strip", "BGRA", 11, 9, "BGRA", 18, 32, LIN, None, None, "random"),
+    ("up4_argb_rgba_three_outputs_wide", "ARGB", 2, 20, "RGBA", 3, 50, LIN, None, None, "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),

@@ -2,6 +2,8 @@
 // (gstreamer_amd/csrc/video_device.h) over the launch grid on the host CPU, so the kernel logic and
 // the planner can be checked against the oracle in this GPU-less container.  Not linked into the
 // product, never used as a fallback.
+#define GSTAMD_EMU_BOUNDS 1
+#include <stdio.h>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -718,6 +720,7 @@ static bool emu_bilinear4_up (Bil4Params b, const Dst &d, const PostFast &pf)
   if (!bilinear4_up_ok (b) || getenv ("EMU_NO_BILINEAR4_UP"))
     return false;
   g_bil4_up_runs++;
+  g_bil4_lo = b.src, g_bil4_hi = b.src + (size_t) b.sstride * b.src_h;
   b.rows = getenv ("EMU_BIL4_UP_ROWS") ? atoi (getenv ("EMU_BIL4_UP_ROWS")) : 5;
   uint32_t sel = 0;
   const bool plain = bilinear4_plain_sel (d, pf, &sel);

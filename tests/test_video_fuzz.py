@@ -48,6 +48,8 @@ def test_hip_random_conversions_match_reference_or_are_refused(native_lib, gpu, 
     for it in range(150):
         case = fuzz_video.random_case(rnd, rects)
         ifmt, w, h, ofmt, ow, oh, cfg, col, site = case
+        if os.environ.get("GSTAMD_FUZZ_VERBOSE"):          # a device fault ends the process: say what was running
+            print(seed, it, case, flush=True)
         ii = V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site)
         oi = V.video_info(ofmt, ow, oh)
         try:

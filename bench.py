@@ -47,7 +47,7 @@ VIDEO_CONFIGS = {
                  "4K frames/s (videoconvertscale P010_10LE->NV12) per GPU; % HBM roofline", "k_front16 + k_gamma_stage + sub-conversion"),
     # SURVEY 8(f) generic paths: the plane scaler behind `videoscale` on NV12, a planar 4:2:0 pack, a byte swizzle
     "f8scale": ("NV12", 3840, 2160, "NV12", 1920, 1080, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
-                "4K->1080p frames/s (videoscale NV12->NV12, bilinear) per GPU; % HBM roofline", "k_plane_direct (one frame, every plane straight from memory: nearest / 2-tap / two-tap N-tap passes composed per pixel; k_plane_tiles serves longer filters)"),
+                "4K->1080p frames/s (videoscale NV12->NV12, bilinear) per GPU; % HBM roofline", "k_plane_quad (every plane of the list in one grid: eight output bytes per lane from one 16-byte window per source row, passes as v_dot2; k_plane_tiles serves longer filters)"),
     "f8pack": ("YUY2", 3840, 2160, "I420", 3840, 2160, {}, 8, 8,
                "4K frames/s (videoconvert YUY2->I420) per GPU; % HBM roofline", "k_convert_pack_422 (the planar packer fed by the unscaled chain, no AYUV image)"),
     "f5encode16": ("BGRA", 3840, 2160, "P010_10LE", 3840, 2160, {}, 8, 8,

@@ -41,6 +41,7 @@
 //   GSTAMD_BIL_HALF_SMALL    k_bilinear420_half also for single frames of less than 4 M outputs (set)
 //   GSTAMD_BIL_HALF_STORE    tuning builds: 1 the halves traded through LDS (default), 2 plain direct stores, 3 streaming direct stores, 5 / 6 ablations (n)
 //   GSTAMD_BIL_HALF_ROWS     output rows per wave of k_bilinear420_half (n; default: one resident round for a frame, 8 in lists)
+//   GSTAMD_NO_CONVERT_PACK_422UP  AYUV image + k_pack_planar for packed 4:2:2 sources whose chain upsamples the chroma horizontally (set)
 //   GSTAMD_NO_CONVERT_PACK_WIDE  the byte-store form of k_convert_pack instead of its whole-block form (set)
 //   GSTAMD_BIL_TILE, GSTAMD_BIL_TABLE, GSTAMD_BIL_ROWS, GSTAMD_BIL_ROWS_TILE, GSTAMD_BIL_SLOTS, GSTAMD_BIL_WG, GSTAMD_BIL_VERBOSE
 //                            geometry of the bilinear kernels (n)

@@ -269,6 +269,7 @@ struct SrcPacked4 {
 #endif
     return apply_color (pre, px);
   }
+  GSTAMD_HD bool ok4 (int, int) const { return true; }
   GSTAMD_HD uint4 row4 (int x0, int y) const
   {
     const uint4 r = *(const uint4 *) (p + (size_t) y * stride + 4 * (size_t) x0);

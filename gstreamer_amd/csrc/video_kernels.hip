@@ -2019,12 +2019,26 @@ __global__ __launch_bounds__ (256) void k_convert_pack_422 (PackPlanarParams pk,
   pack_planar_body (pk, src, d, x0 + 4, (int) blockIdx.y, fld_);
 }
 
+// the same for packed 4:2:2 frames whose chain upsamples the chroma horizontally (YUY2 / UYVY -> NV12 & co): pack_planar_block4 on Src422Up's
+// rows inside the picture, the general body on its pixels along the edges
+__global__ __launch_bounds__ (64) void k_convert_pack_422up (PackPlanarParams pk, Src422Up src, DstPlanes d, int wide, FrameDeltas fl)
+{
+  GSTAMD_FRAME_Z;
+  src.p += fls_;
+  const int x0 = (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (wide && pack_planar_block4 (pk, src, d, x0, (int) blockIdx.y, fld_))
+    return;
+  pack_planar_body (pk, src, d, x0, (int) blockIdx.y, fld_);
+}
+
 // which unscaled chains the fused form pays for: the pixel source must be cheap per pixel, a lane evaluates up to 20 of them for its 4 x 2 block
 bool convert_pack_usable (const FrontParams &f, const Planes &pl, const ColorParams &color)
 {
   if (f.kind == UNPACK_PACKED4)
     return ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0;
-  return f.kind == UNPACK_PACKED422 && f.chroma_h == CHROMA_H_NONE && !f.chroma_v2 && color.matrix.kind == MATRIX_NONE && color.alpha_kind == ALPHA_NONE &&
+  if (f.kind == UNPACK_PACKED422 && f.chroma_h != CHROMA_H_NONE && tuning_on ("GSTAMD_NO_CONVERT_PACK_422UP"))
+    return false;
+  return f.kind == UNPACK_PACKED422 && !f.chroma_v2 && color.matrix.kind == MATRIX_NONE && color.alpha_kind == ALPHA_NONE &&
       ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0;
 }
 
@@ -2039,7 +2053,14 @@ hipError_t launch_convert_pack (const PackPlanarParams &pk, const FrontParams &f
   const int lanes = (pk.width + 3) / 4, rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
   int nz;
   const FrameDeltas &fl = frame_list_for (pl.p[0], planes[0], &nz);
-  if (f.kind == UNPACK_PACKED422) {
+  if (f.kind == UNPACK_PACKED422 && f.chroma_h != CHROMA_H_NONE) {
+    const Src422Up src = {pl.p[0], pl.stride[0], 8 * f.pos[1], 8 * f.pos[2], 8 * f.pos[3], f.swap_k, f.chroma_h, f.width, f.luma_last};
+    /* pack_planar_block4 on Src422Up's rows: macropixels on 4 bytes (any 16-byte phase), plane rows on 4 */
+    int wide = !pk.dither.on && (pk.kind == UNPACK_PLANAR || pk.kind == UNPACK_SEMI);
+    for (int i = 0; wide && i < (pk.kind == UNPACK_SEMI ? 2 : 3); i++)
+      wide = ((uintptr_t) planes[i] % 4) == 0 && (strides[i] % 4) == 0;
+    hipLaunchKernelGGL (k_convert_pack_422up, dim3 ((lanes + 63) / 64, rows, nz), dim3 (64), 0, stream, pk, src, d, wide, fl);
+  } else if (f.kind == UNPACK_PACKED422) {
     const Src422Dup src = {pl.p[0], pl.stride[0], 8 * f.pos[1], 8 * f.pos[2], 8 * f.pos[3], f.swap_k};
     /* pack_422dup_block8: source rows on 16 bytes, plane rows on 8 */
     int wide = ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0;

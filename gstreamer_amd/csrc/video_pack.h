@@ -226,6 +226,7 @@ GSTAMD_HD bool pack_422dup_block8 (const PackPlanarParams &pk, const Src422Dup &
 struct ImgRows {
   const uint8_t *img;
   int sstride;
+  GSTAMD_HD bool ok4 (int, int) const { return true; }
   GSTAMD_HD uint4 row4 (int x0, int y) const { return *(const uint4 *) (img + (size_t) y * sstride + 4 * (size_t) x0); }
   GSTAMD_HD uint32_t px (int x, int y) const { return *(const uint32_t *) (img + (size_t) y * sstride + 4 * (size_t) x); }
 };
@@ -237,6 +238,8 @@ GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const ROWS &rows,
   if (x0 + 4 > w || y0 >= h || (pk.tail_swap && x0 + 4 == w && (w & 1)))
     return false;
   const int yb1 = y0 + 1 < h ? y0 + 1 : (pk.virtual_line ? h : h - 1);
+  if (!rows.ok4 (x0, y0) || !rows.ok4 (x0, yb1))
+    return false;
   const uint4 a = rows.row4 (x0, y0);
   uint4 b = a;
   if (pk.h_sub || pk.down_v)
@@ -314,6 +317,73 @@ GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const ROWS &rows,
   }
   return true;
 }
+
+// pixel source of k_convert_pack_422up: a packed 4:2:2 frame through unpack and the HORIZONTAL chroma upsampler of the generic chain
+// (chroma_h_at of video_device.h: video_chroma_up_h2 / _h2_cs on the macropixels' chroma), no vertical pairing, no matrix, no alpha stage -
+// what YUY2 / UYVY -> NV12 / NV21 and the 4:2:2 -> 4:4:4 packs run through (the reference has fastpaths for the PLANAR destinations only:
+// those are Src422Dup's).  at (): any pixel, with the edge rules; row4 (): four pixels of a block whose neighbours exist (ok4), from one
+// 16-byte load of the macropixels k0 - 1 .. k0 + 2 and packed {U | V << 16} arithmetic.
+struct Src422Up {
+  const uint8_t *p;
+  int stride;
+  int ysh, ush, vsh;    // bit offsets of Y0, U, V inside the macropixel word (Y1 = Y0 + 16)
+  int swap_k;           // FrontParams::swap_k
+  int chroma_h;         // CHROMA_H_H2 or CHROMA_H_H2_CS
+  int width, luma_last;
+  GSTAMD_HD uint32_t uv_of (uint32_t m, bool sw) const
+  {
+    const uint32_t u = (m >> (sw ? vsh : ush)) & 0xffu, v = (m >> (sw ? ush : vsh)) & 0xffu;
+    return u | (v << 16);
+  }
+  GSTAMD_HD uint32_t at (int x, int y) const
+  {
+    const int k = x >> 1;
+    const uint8_t *row = p + (size_t) y * stride;
+    const uint8_t *lrow = p + (size_t) (y < luma_last ? y : luma_last) * stride;
+    const uint32_t Y = (*(const uint32_t *) (lrow + 4 * (size_t) k) >> (ysh + 16 * (x & 1))) & 0xffu;
+    uint32_t c = uv_of (*(const uint32_t *) (row + 4 * (size_t) k), k == swap_k);
+    if ((x & 1) && x < width - 1) {
+      const uint32_t n = uv_of (*(const uint32_t *) (row + 4 * (size_t) (k + 1)), k + 1 == swap_k);
+      c = chroma_h == CHROMA_H_H2_CS ? ((c + n + 0x00010001u) >> 1) & 0x00ff00ffu : ((3u * c + n + 0x00020002u) >> 2) & 0x00ff00ffu;
+    } else if (!(x & 1) && x >= 2 && chroma_h == CHROMA_H_H2) {
+      const uint32_t pv = uv_of (*(const uint32_t *) (row + 4 * (size_t) (k - 1)), false);
+      c = ((pv + 3u * c + 0x00020002u) >> 2) & 0x00ff00ffu;
+    }
+    return 0xffu | (Y << 8) | ((c & 0xffu) << 16) | ((c >> 16) << 24);
+  }
+  GSTAMD_HD uint32_t px (int x, int y) const { return at (x, y); }
+  /* blocks whose four macropixels k0 - 1 .. k0 + 2 exist, none of them the swapped tail, no pixel on an edge rule */
+  GSTAMD_HD bool ok4 (int x0, int y) const { return x0 >= 2 && x0 + 6 <= width && (swap_k < 0 || swap_k > (x0 >> 1) + 2) && y <= luma_last; }
+  GSTAMD_HD uint4 row4 (int x0, int y) const
+  {
+    const uint8_t *q = p + (size_t) y * stride + 2 * (size_t) x0 - 4;
+#ifdef __HIPCC__
+    typedef unsigned int u32x4a __attribute__ ((ext_vector_type (4), aligned (4)));
+    const u32x4a m = *(const u32x4a *) q;
+    const uint32_t m0 = m.x, m1 = m.y, m2 = m.z, m3 = m.w;
+#else
+    uint32_t mm[4];
+    __builtin_memcpy (mm, q, 16);
+    const uint32_t m0 = mm[0], m1 = mm[1], m2 = mm[2], m3 = mm[3];
+#endif
+    const uint32_t c0 = uv_of (m0, false), c1 = uv_of (m1, false), c2 = uv_of (m2, false), c3 = uv_of (m3, false);
+    uint32_t e1, o1, e2, o2;          /* pixels x0 (even, macropixel 1), x0 + 1, x0 + 2 (macropixel 2), x0 + 3 */
+    if (chroma_h == CHROMA_H_H2_CS) {
+      e1 = c1, e2 = c2;
+      o1 = ((c1 + c2 + 0x00010001u) >> 1) & 0x00ff00ffu;
+      o2 = ((c2 + c3 + 0x00010001u) >> 1) & 0x00ff00ffu;
+    } else {
+      e1 = ((c0 + 3u * c1 + 0x00020002u) >> 2) & 0x00ff00ffu;
+      o1 = ((3u * c1 + c2 + 0x00020002u) >> 2) & 0x00ff00ffu;
+      e2 = ((c1 + 3u * c2 + 0x00020002u) >> 2) & 0x00ff00ffu;
+      o2 = ((3u * c2 + c3 + 0x00020002u) >> 2) & 0x00ff00ffu;
+    }
+#define GSTAMD_AYUV(m, odd, c) (0xffu | ((((m) >> (ysh + 16 * (odd))) & 0xffu) << 8) | (((c) & 0xffu) << 16) | (((c) >> 16) << 24))
+    const uint4 r = gstamd_make_uint4 (GSTAMD_AYUV (m1, 0, e1), GSTAMD_AYUV (m1, 1, o1), GSTAMD_AYUV (m2, 0, e2), GSTAMD_AYUV (m2, 1, o2));
+#undef GSTAMD_AYUV
+    return r;
+  }
+};
 
 GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const uint8_t *__restrict__ img, int sstride, const DstPlanes &d, int x0, int yb, long long dd = 0)
 {

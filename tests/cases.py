@@ -248,6 +248,18 @@ VIDEO_CASES = [
     # fewer lanes with outputs than rows in a strip (the kernel's row table lives in the lanes of the wave: found by the device fuzz)
     ("up4_bgra_bgra_narrower_than_a_strip", "BGRA", 11, 9, "BGRA", 18, 32, LIN, None, None, "random"),
     ("up4_argb_rgba_three_outputs_wide", "ARGB", 2, 20, "RGBA", 3, 50, LIN, None, None, "random"),
+    # k_convert_pack_422up (Src422Up, video_pack.h): packed 4:2:2 through the chain's horizontal chroma upsampler into semi-planar 4:2:0 and the
+    # 4:4:4 layouts (the reference has fastpaths for the PLANAR 4:2:x destinations only) - both filters, odd widths (the swapped tail
+    # macropixel), the narrowest frames with and without an inner block, odd heights
+    ("pack422up_yuy2_nv12", "YUY2", 64, 48, "NV12", 64, 48, {}, None, None, "random"),
+    ("pack422up_uyvy_nv21_odd", "UYVY", 35, 21, "NV21", 35, 21, {}, None, None, "random"),
+    ("pack422up_yvyu_nv12_jpeg", "YVYU", 70, 10, "NV12", 70, 10, {}, None, "jpeg", "random"),
+    ("pack422up_vyuy_nv12_mpeg2", "VYUY", 128, 7, "NV12", 128, 7, {}, None, "mpeg2", "random"),
+    ("pack422up_uyvy_nv24_jpeg_odd", "UYVY", 35, 21, "NV24", 35, 21, {}, None, "jpeg", "random"),
+    ("pack422up_uyvy_nv24_mpeg2", "UYVY", 48, 9, "NV24", 48, 9, {}, None, "mpeg2", "random"),
+    ("pack422up_yuy2_nv12_w8", "YUY2", 8, 6, "NV12", 8, 6, {}, None, None, "random"),
+    ("pack422up_yuy2_nv12_w6", "YUY2", 6, 4, "NV12", 6, 4, {}, None, "jpeg", "random"),
+    ("pack422up_yuy2_nv12_720p", "YUY2", 1280, 720, "NV12", 1280, 720, {}, None, None, "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),

@@ -712,7 +712,8 @@ static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, cons
 
 static int g_fast422_runs = 0;
 
-static int g_bil4_up_runs = 0;
+static int g_bil4_up_runs = 0, g_emu_pack422up_runs = 0;
+extern "C" int emu_pack422up_runs (void) { return g_emu_pack422up_runs; }
 extern "C" int emu_bil4_up_runs (void) { return g_bil4_up_runs; }
 // k_bilinear4_up's grid: a lane per four outputs, strips of EMU_BIL4_UP_ROWS rows (launch_scale2x2_from_front's gate)
 static bool emu_bilinear4_up (Bil4Params b, const Dst &d, const PostFast &pf)
@@ -1252,8 +1253,8 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   }
   if (p.out_planar && p.passes.empty () && !p.deep16 && !(p.pack.dither.on && p.pack.dither.method != GSTAMD_DITHER_NONE && p.pack.dither.method != GSTAMD_DITHER_BAYER) &&
       p.post.pack_pos[0] == 0 && p.post.pack_pos[1] == 1 && p.post.pack_pos[2] == 2 && p.post.pack_pos[3] == 3 && !getenv ("EMU_NO_CONVERT_PACK") &&
-      (p.front.kind == UNPACK_PACKED4 || (p.front.kind == UNPACK_PACKED422 && p.front.chroma_h == CHROMA_H_NONE && !p.front.chroma_v2 &&
-              p.matrix.kind == MATRIX_NONE && p.post.alpha_kind == ALPHA_NONE))) {          /* convert_pack_usable, alignment aside */
+      (p.front.kind == UNPACK_PACKED4 || (p.front.kind == UNPACK_PACKED422 && (p.front.chroma_h == CHROMA_H_NONE || !getenv ("GSTAMD_NO_CONVERT_PACK_422UP")) &&
+              !p.front.chroma_v2 && p.matrix.kind == MATRIX_NONE && p.post.alpha_kind == ALPHA_NONE))) {          /* convert_pack_usable, alignment aside */
     /* k_convert_pack: the pack body with the chain itself as its pixel source */
     DstPlanes d;
     memset (&d, 0, sizeof (d));
@@ -1274,7 +1275,18 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     const Src422Dup s422 = {pl.p[0], pl.stride[0], 8 * p.front.pos[1], 8 * p.front.pos[2], 8 * p.front.pos[3], p.front.swap_k};
     for (int yb = 0; yb < rows; yb++)
       for (int x0 = 0; x0 < p.out_info.width; x0 += 4)
-        if (p.front.kind == UNPACK_PACKED422) {               /* k_convert_pack_422: 8 pixels per lane */
+        if (p.front.kind == UNPACK_PACKED422 && p.front.chroma_h != CHROMA_H_NONE) {          /* k_convert_pack_422up */
+          const Src422Up sup = {pl.p[0], pl.stride[0], 8 * p.front.pos[1], 8 * p.front.pos[2], 8 * p.front.pos[3], p.front.swap_k, p.front.chroma_h,
+            p.front.width, p.front.luma_last};
+          bool wide = vec_ok && !p.pack.dither.on && (p.pack.kind == UNPACK_PLANAR || p.pack.kind == UNPACK_SEMI);
+          for (int i = 0; wide && i < (p.pack.kind == UNPACK_SEMI ? 2 : 3); i++)
+            wide = ((uintptr_t) d.p[i] % 4) == 0 && (d.stride[i] % 4) == 0;
+          if (wide && pack_planar_block4 (p.pack, sup, d, x0, yb)) {
+            g_emu_pack422up_runs++;
+            continue;
+          }
+          pack_planar_body (p.pack, sup, d, x0, yb);
+        } else if (p.front.kind == UNPACK_PACKED422) {               /* k_convert_pack_422: 8 pixels per lane */
           if (x0 & 4)
             continue;
           bool wide = ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && (p.pack.kind == UNPACK_PLANAR || p.pack.kind == UNPACK_SEMI);

@@ -463,6 +463,25 @@ def test_bilinear4_up_kernel_body_any_rows_per_wave(native_lib, emu_lib, idx_cas
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
 
 
+@pytest.mark.parametrize("idx_case", [c for c in SMALL if c[1][0].startswith("pack422up_")], ids=lambda c: c[1][0])
+def test_convert_pack_422up_is_the_body_that_runs(native_lib, emu_lib, idx_case, monkeypatch):
+    """packed 4:2:2 -> semi-planar 4:2:0 / 4:4:4 through k_convert_pack_422up (the chain's horizontal chroma upsampler inside the packer's row source),
+    through the AYUV image + k_pack_planar with it switched off: the reference's bytes either way"""
+    i, (name, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern) = idx_case
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    emu_lib.emu_pack422up_runs.restype = C.c_int
+    before = emu_lib.emu_pack422up_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    took = emu_lib.emu_pack422up_runs() - before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
+    assert (took > 0) == (w >= 10), (name, took)        # blocks of four pixels with a macropixel to spare on either side: x0 = 4 at the earliest
+    monkeypatch.setenv("GSTAMD_NO_CONVERT_PACK_422UP", "1")
+    before = emu_lib.emu_pack422up_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_pack422up_runs() == before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
+
+
 @pytest.mark.parametrize("idx_case", SMALL[::4], ids=lambda c: c[1][0])
 def test_golden_vectors_are_the_references_output(ref, idx_case):
     """Pins the committed golden hashes to the reference implementation itself (oracle/_ref)."""

@@ -275,6 +275,12 @@ struct SrcPacked4 {
     const uint4 r = *(const uint4 *) (p + (size_t) y * stride + 4 * (size_t) x0);
     return gstamd_make_uint4 (conv (r.x), conv (r.y), conv (r.z), conv (r.w));
   }
+  GSTAMD_HD uint4 row4n (int x0, int y, bool edges, int xm, int xp, uint32_t &em, uint32_t &ep) const
+  {
+    if (edges)
+      em = px (xm, y), ep = px (xp, y);
+    return row4 (x0, y);
+  }
   GSTAMD_HD uint32_t px (int x, int y) const { return at (x, y); }
 };
 

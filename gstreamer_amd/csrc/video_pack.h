@@ -229,6 +229,12 @@ struct ImgRows {
   GSTAMD_HD bool ok4 (int, int) const { return true; }
   GSTAMD_HD uint4 row4 (int x0, int y) const { return *(const uint4 *) (img + (size_t) y * sstride + 4 * (size_t) x0); }
   GSTAMD_HD uint32_t px (int x, int y) const { return *(const uint32_t *) (img + (size_t) y * sstride + 4 * (size_t) x); }
+  GSTAMD_HD uint4 row4n (int x0, int y, bool edges, int xm, int xp, uint32_t &em, uint32_t &ep) const
+  {
+    if (edges)
+      em = px (xm, y), ep = px (xp, y);
+    return row4 (x0, y);
+  }
 };
 
 template <class ROWS>
@@ -240,10 +246,15 @@ GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const ROWS &rows,
   const int yb1 = y0 + 1 < h ? y0 + 1 : (pk.virtual_line ? h : h - 1);
   if (!rows.ok4 (x0, y0) || !rows.ok4 (x0, yb1))
     return false;
-  const uint4 a = rows.row4 (x0, y0);
+  /* the cosited horizontal downsampler also reads the pixels left and right of the block (their chroma): handed over by the row source together
+   * with the block where that is cheaper than two more pixel fetches per line (Src422Up has them in the macropixels it loaded anyway) */
+  const bool edges = pk.w_sub == 1 && pk.down_h == 2;
+  uint32_t em = 0, ep = 0, fm = 0, fp = 0;
+  const int xm = x0 > 0 ? x0 - 1 : 0, xp = x0 + 4 < w ? x0 + 4 : w - 1;
+  const uint4 a = rows.row4n (x0, y0, edges, xm, xp, em, ep);
   uint4 b = a;
   if (pk.h_sub || pk.down_v)
-    b = rows.row4 (x0, yb1);
+    b = rows.row4n (x0, yb1, edges && pk.down_v, xm, xp, fm, fp);
   // luma
   *(uint32_t *) ((d.p[0] + dd) + (size_t) y0 * d.stride[0] + x0) = ((a.x >> 8) & 0xffu) | (a.y & 0xff00u) | ((a.z << 8) & 0xff0000u) | ((a.w << 16) & 0xff000000u);
   if (pk.h_sub && y0 + 1 < h)
@@ -251,17 +262,6 @@ GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const ROWS &rows,
   // chroma of pixels x0 - 1 .. x0 + 4 of the chroma line
   uint32_t v[6];
   v[1] = ayuv_uv (a.x), v[2] = ayuv_uv (a.y), v[3] = ayuv_uv (a.z), v[4] = ayuv_uv (a.w);
-  const bool edges = pk.w_sub == 1 && pk.down_h == 2;
-  uint32_t em = 0, ep = 0, fm = 0, fp = 0;
-  const int xm = x0 > 0 ? x0 - 1 : 0, xp = x0 + 4 < w ? x0 + 4 : w - 1;
-  if (edges) {
-    em = rows.px (xm, y0);
-    ep = rows.px (xp, y0);
-    if (pk.down_v) {
-      fm = rows.px (xm, yb1);
-      fp = rows.px (xp, yb1);
-    }
-  }
   v[0] = ayuv_uv (em), v[5] = ayuv_uv (ep);
   if (pk.down_v) {
     v[1] = ((v[1] + ayuv_uv (b.x) + 0x00010001u) >> 1) & 0x00ff00ffu;
@@ -352,20 +352,31 @@ struct Src422Up {
     return 0xffu | (Y << 8) | ((c & 0xffu) << 16) | ((c >> 16) << 24);
   }
   GSTAMD_HD uint32_t px (int x, int y) const { return at (x, y); }
-  /* blocks whose four macropixels k0 - 1 .. k0 + 2 exist, none of them the swapped tail, no pixel on an edge rule */
-  GSTAMD_HD bool ok4 (int x0, int y) const { return x0 >= 2 && x0 + 6 <= width && (swap_k < 0 || swap_k > (x0 >> 1) + 2) && y <= luma_last; }
-  GSTAMD_HD uint4 row4 (int x0, int y) const
+  /* whole blocks of a picture at least eight pixels wide, none of their macropixels the swapped tail.  (The picture's first and last block come out of
+   * the same formulas on a clamped neighbour - (c + c + 1) >> 1 == (3 c + c + 2) >> 2 == c are the edge rules of chroma_h_at - so only a partial
+   * last block and the tail of an odd width go through the general body: with a lane of every row in it, its waves set the kernel's time.) */
+  GSTAMD_HD bool ok4 (int x0, int y) const { return x0 + 4 <= width && width >= 8 && (swap_k < 0 || swap_k > (x0 >> 1) + 2) && y <= luma_last; }
+  /* + the pixels x0 - 1 and x0 + 4 (clamped into the line: xm, xp): the odd pixel of macropixel k0 - 1, the even one of k0 + 2 */
+  GSTAMD_HD uint4 row4n (int x0, int y, bool edges, int, int, uint32_t &em, uint32_t &ep) const
   {
-    const uint8_t *q = p + (size_t) y * stride + 2 * (size_t) x0 - 4;
+    /* macropixels k0 - 1 .. k0 + 2; at the picture's left edge k0 .. k0 + 3 with the first one standing in for its missing neighbour, at the right
+     * edge k0 - 2 .. k0 + 1 with the last one doing so */
+    const bool left = x0 == 0, right = x0 + 4 >= width;
+    const uint8_t *q = p + (size_t) y * stride + 2 * (size_t) x0 - (left ? 0 : (right ? 8 : 4));
 #ifdef __HIPCC__
     typedef unsigned int u32x4a __attribute__ ((ext_vector_type (4), aligned (4)));
     const u32x4a m = *(const u32x4a *) q;
-    const uint32_t m0 = m.x, m1 = m.y, m2 = m.z, m3 = m.w;
+    const uint32_t l0 = m.x, l1 = m.y, l2 = m.z, l3 = m.w;
 #else
     uint32_t mm[4];
     __builtin_memcpy (mm, q, 16);
-    const uint32_t m0 = mm[0], m1 = mm[1], m2 = mm[2], m3 = mm[3];
+    const uint32_t l0 = mm[0], l1 = mm[1], l2 = mm[2], l3 = mm[3];
 #endif
+    uint32_t m0 = l0, m1 = l1, m2 = l2, m3 = l3;
+    if (left)
+      m1 = l0, m2 = l1, m3 = l2;
+    else if (right)
+      m0 = l1, m1 = l2, m2 = l3;
     const uint32_t c0 = uv_of (m0, false), c1 = uv_of (m1, false), c2 = uv_of (m2, false), c3 = uv_of (m3, false);
     uint32_t e1, o1, e2, o2;          /* pixels x0 (even, macropixel 1), x0 + 1, x0 + 2 (macropixel 2), x0 + 3 */
     if (chroma_h == CHROMA_H_H2_CS) {
@@ -379,6 +390,11 @@ struct Src422Up {
       o2 = ((3u * c2 + c3 + 0x00020002u) >> 2) & 0x00ff00ffu;
     }
 #define GSTAMD_AYUV(m, odd, c) (0xffu | ((((m) >> (ysh + 16 * (odd))) & 0xffu) << 8) | (((c) & 0xffu) << 16) | (((c) >> 16) << 24))
+    if (edges) {
+      const uint32_t om = chroma_h == CHROMA_H_H2_CS ? ((c0 + c1 + 0x00010001u) >> 1) & 0x00ff00ffu : ((3u * c0 + c1 + 0x00020002u) >> 2) & 0x00ff00ffu;
+      const uint32_t e3 = chroma_h == CHROMA_H_H2_CS ? c3 : ((c2 + 3u * c3 + 0x00020002u) >> 2) & 0x00ff00ffu;
+      em = GSTAMD_AYUV (m0, 1, om), ep = GSTAMD_AYUV (m3, 0, e3);
+    }
     const uint4 r = gstamd_make_uint4 (GSTAMD_AYUV (m1, 0, e1), GSTAMD_AYUV (m1, 1, o1), GSTAMD_AYUV (m2, 0, e2), GSTAMD_AYUV (m2, 1, o2));
 #undef GSTAMD_AYUV
     return r;

@@ -474,7 +474,7 @@ def test_convert_pack_422up_is_the_body_that_runs(native_lib, emu_lib, idx_case,
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
     took = emu_lib.emu_pack422up_runs() - before
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"], name
-    assert (took > 0) == (w >= 10), (name, took)        # blocks of four pixels with a macropixel to spare on either side: x0 = 4 at the earliest
+    assert (took > 0) == (w >= 8), (name, took)         # whole blocks of pictures at least eight pixels wide
     monkeypatch.setenv("GSTAMD_NO_CONVERT_PACK_422UP", "1")
     before = emu_lib.emu_pack422up_runs()
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)

@@ -253,11 +253,16 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[3], co
     int es;
     uint32_t lo, hi;
     border_plane_value (f, rc.border, i, &es, &lo, &hi);
+    /* the reference's fastpaths fill with convert_fill_border, whose per-plane values come from packing ONE border pixel (setup_borderline :2256: width
+       1 << w_sub = 1 for multi-plane formats) - for NV61 that is pack_NV61's odd-width tail, which stores U before V: every border pair of the plane */
+    const bool nv61_fastpath = i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && !p.ref_fastpath.empty ();
+    if (nv61_fastpath)
+      lo = (lo >> 8) | ((lo & 0xffu) << 8);
     const bool pairs = f->kind == UNPACK_PACKED422 || f->kind == UNPACK_P422_16;          /* the plane's unit is the macropixel */
     const int ws = i || pairs ? f->w_sub : 0, hs = i ? f->h_sub : 0;
     const int mw = up (rc.out_maxw, ws), mh = up (rc.out_maxh, hs);
     e = launch_fill_border (planes[i], strides[i], es, lo, hi, mw, mh, rc.out_x >> ws, rc.out_y >> hs, up (w, ws), up (h, hs), stream);
-    if (e == hipSuccess && i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && (rc.out_maxw & 1)) {
+    if (e == hipSuccess && i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && (rc.out_maxw & 1) && !nv61_fastpath) {
       /* pack_NV61's odd-width tail (video-format.c:2005-2011) stores the last pair of every border line in NV16 order; the picture's rows
          are the packer's (tail_swap) when the rectangle reaches that column */
       const bool reaches = rc.out_x + w == rc.out_maxw;

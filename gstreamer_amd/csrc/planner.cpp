@@ -25,6 +25,8 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_YV12, "YV12", true, false, 3, UNPACK_PLANAR, 1, 1, 2, 1, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_Y42B, "Y42B", true, false, 3, UNPACK_PLANAR, 1, 0, 1, 2, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_Y444, "Y444", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}},
+  // planar RGB (video-format.c:1119-1147: the Y444 unpack / pack on the R, G, B lines); planes R, G, B inside a plan (format_plan_planes)
+  {GSTAMD_VIDEO_FORMAT_GBR, "GBR", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV12, "NV12", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV21, "NV21", true, false, 2, UNPACK_SEMI, 1, 1, 0, 1, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV16, "NV16", true, false, 2, UNPACK_SEMI, 1, 0, 1, 0, {0, 0, 0, 0}},
@@ -120,6 +122,7 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = info->offset[2] + info->stride[2] * h;
       break;
     case GSTAMD_VIDEO_FORMAT_Y444:
+    case GSTAMD_VIDEO_FORMAT_GBR:             /* video-info.c:1030-1041 */
       info->stride[0] = info->stride[1] = info->stride[2] = round_up (width, 4);
       info->offset[1] = (uint64_t) info->stride[0] * h;
       info->offset[2] = info->offset[1] * 2;
@@ -1444,7 +1447,7 @@ const FastRow g_fast_rows[] = {
         FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY | FP_ASET | FP_AMULT, "convert_from_v210"},
   /* convert_scale_planes: every same-format pair, planar <-> planar and the NV12 / NV16 / NV24 family */
   {F_RGB4A | F_AYUV | fbit (GSTAMD_VIDEO_FORMAT_ARGB64) | fbit (GSTAMD_VIDEO_FORMAT_AYUV64), ~0ull, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
-  {F_RGB4X | F_RGB3 | F_YUV3 | F_420 | F_Y42B | F_Y444 | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
+  {F_RGB4X | F_RGB3 | F_YUV3 | F_420 | F_Y42B | F_Y444 | fbit (GSTAMD_VIDEO_FORMAT_GBR) | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
         F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_YVYU), ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_420 | F_Y42B | F_Y444, F_420 | F_Y42B | F_Y444, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   /* the GRAY8 rows (:8560-8661): the luma plane from / to the planar formats, chroma planes filled with 0x80; GRAY8 -> GRAY8 */
@@ -1528,7 +1531,9 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
       pp.iw = round_up (in.width * 2, 4);
       pp.ow = round_up (out.width * 2, 4);
     }
-    const int rm = i == 0 ? method : cr_method;
+    /* setup_scale (:8165): resample_method = (i == 0 ? method : cr_method) on the FRAME's plane order - GBR's first plane is G, plane 1 of a plan */
+    const int first_plane = fo->format == GSTAMD_VIDEO_FORMAT_GBR ? 1 : 0;
+    const int rm = i == first_plane ? method : cr_method;
     /* the halve / double shortcuts exist for the planes of multi-plane formats only (setup_scale :8092-8180) */
     if (fill) {
       pp.iw = pp.ih = 0;
@@ -2438,6 +2443,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   const GstAmdVideoConverterConfig &cfg = plan->config;
   plan->fin = format_desc (in->format);
   plan->fout = format_desc (out->format);
+  format_plan_planes (plan->fin, &plan->in_info);
+  format_plan_planes (plan->fout, &plan->out_info);
   if (!plan->fin || !plan->fout)
     return fail (GSTAMD_ERR_UNSUPPORTED, "format not implemented on the GPU path");
   if (in->width <= 0 || in->height <= 0 || out->width <= 0 || out->height <= 0)

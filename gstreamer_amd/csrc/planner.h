@@ -44,6 +44,19 @@ struct FormatDesc {
                         // 4 / 5: the same with 12 bits (I420_12LE ... / P012_LE), 6: all 16 bits (P016_LE, Y444_16LE)
                         // 7: Y410's 10 + 10 + 10 + 2 bits in a 32-bit word, 8: v210's three 10-bit samples per 32-bit word
 };
+// GBR keeps its planes in the order G, B, R; inside a plan (VideoPlan::in_info / out_info, the copies every launcher takes plane pointers from)
+// they are R, G, B - component order, what the planar 4:4:4 code expects (unpack_GBR is video_orc_unpack_Y444 on the R, G, B lines,
+// video-format.c:1121-1147).  Callers keep the frame's own layout: only the plan's copies are permuted.
+inline void format_plan_planes (const FormatDesc *f, GstAmdVideoInfo *info)
+{
+  if (f && f->format == GSTAMD_VIDEO_FORMAT_GBR) {
+    const uint64_t og = info->offset[0], ob = info->offset[1], orr = info->offset[2];
+    const int32_t sg = info->stride[0], sb = info->stride[1], sr = info->stride[2];
+    info->offset[0] = orr, info->offset[1] = og, info->offset[2] = ob;
+    info->stride[0] = sr, info->stride[1] = sg, info->stride[2] = sb;
+  }
+}
+
 #if defined(__HIPCC__)
 #define GSTAMD_VP __host__ __device__ inline
 #else

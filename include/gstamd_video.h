@@ -61,6 +61,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_IYU2 = 63,        /* the same in the order U Y V */
   GSTAMD_VIDEO_FORMAT_VUYA = 84,        /* packed 4:4:4:4, 4 bytes per pixel: V U Y A */
   GSTAMD_VIDEO_FORMAT_NV21 = 24,
+  GSTAMD_VIDEO_FORMAT_GBR = 48,         /* planar 8-bit RGB, planes in the order G, B, R */
   GSTAMD_VIDEO_FORMAT_NV16 = 51,
   GSTAMD_VIDEO_FORMAT_NV24 = 52,
   GSTAMD_VIDEO_FORMAT_ARGB64 = 39,      /* 16 bits per component, native endianness (little endian here), memory order A R G B */

@@ -51,7 +51,7 @@ GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
     "I420_10LE, I420_12LE, I422_10LE, I422_12LE, Y444_10LE, Y444_12LE" AMD_COMP_NEWER_CANVAS " }"
 /* what a pad may carry: anything the converter takes; it is brought to the output format / the pad's width x height by a
  * per-pad GstAmdVideoConverter (the reference's GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) */
-#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, GRAY8, " \
+#define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, GRAY8, GBR, " \
     "I420_10LE, I420_12LE, I422_10LE, I422_12LE, Y444_10LE, Y444_12LE, P010_10LE" AMD_COMP_NEWER_PADS " }"
 #define AMD_COMP_MAX_PADS 64
 
@@ -376,6 +376,7 @@ amd_pad_format_of (GstVideoFormat f)
     case GST_VIDEO_FORMAT_NV24: return GSTAMD_VIDEO_FORMAT_NV24;
     case GST_VIDEO_FORMAT_VYUY: return GSTAMD_VIDEO_FORMAT_VYUY;
     case GST_VIDEO_FORMAT_GRAY8: return GSTAMD_VIDEO_FORMAT_GRAY8;
+    case GST_VIDEO_FORMAT_GBR: return GSTAMD_VIDEO_FORMAT_GBR;
     case GST_VIDEO_FORMAT_P010_10LE: return GSTAMD_VIDEO_FORMAT_P010_10LE;
 #if GST_CHECK_VERSION (1, 18, 0)
     case GST_VIDEO_FORMAT_P012_LE: return GSTAMD_VIDEO_FORMAT_P012_LE;

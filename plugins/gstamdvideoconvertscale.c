@@ -43,7 +43,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #else
 #define AMD_NEWER_FORMATS ""
 #endif
-#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, v210" AMD_NEWER_FORMATS " }"
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GBR, v210" AMD_NEWER_FORMATS " }"
 
 /* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path
  * (video-converter.c:3304, 3383-3463), so interlaced caps are not negotiated rather than converted as if progressive
@@ -801,7 +801,7 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_P010_10LE, GSTAMD_VIDEO_FORMAT_P010_10LE}, {GST_VIDEO_FORMAT_I420_10LE, GSTAMD_VIDEO_FORMAT_I420_10LE},
     {GST_VIDEO_FORMAT_ARGB64, GSTAMD_VIDEO_FORMAT_ARGB64}, {GST_VIDEO_FORMAT_AYUV64, GSTAMD_VIDEO_FORMAT_AYUV64},
     {GST_VIDEO_FORMAT_v308, GSTAMD_VIDEO_FORMAT_v308}, {GST_VIDEO_FORMAT_IYU2, GSTAMD_VIDEO_FORMAT_IYU2},
-    {GST_VIDEO_FORMAT_GRAY8, GSTAMD_VIDEO_FORMAT_GRAY8}, {GST_VIDEO_FORMAT_v210, GSTAMD_VIDEO_FORMAT_v210},
+    {GST_VIDEO_FORMAT_GRAY8, GSTAMD_VIDEO_FORMAT_GRAY8}, {GST_VIDEO_FORMAT_GBR, GSTAMD_VIDEO_FORMAT_GBR}, {GST_VIDEO_FORMAT_v210, GSTAMD_VIDEO_FORMAT_v210},
     {GST_VIDEO_FORMAT_I422_10LE, GSTAMD_VIDEO_FORMAT_I422_10LE}, {GST_VIDEO_FORMAT_Y444_10LE, GSTAMD_VIDEO_FORMAT_Y444_10LE},
     {GST_VIDEO_FORMAT_I420_12LE, GSTAMD_VIDEO_FORMAT_I420_12LE}, {GST_VIDEO_FORMAT_I422_12LE, GSTAMD_VIDEO_FORMAT_I422_12LE},
     {GST_VIDEO_FORMAT_Y444_12LE, GSTAMD_VIDEO_FORMAT_Y444_12LE},

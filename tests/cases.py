@@ -48,7 +48,7 @@ def visible_planes(fmt, w, h):
         return [(w, h), (up2(w), up2(h)), (up2(w), up2(h))]
     if fmt == "Y42B":
         return [(w, h), (up2(w), h), (up2(w), h)]
-    if fmt == "Y444":
+    if fmt in ("Y444", "GBR"):
         return [(w, h)] * 3
     if fmt in ("NV12", "NV21"):
         return [(w, h), (2 * up2(w), up2(h))]
@@ -260,6 +260,25 @@ VIDEO_CASES = [
     ("pack422up_yuy2_nv12_w8", "YUY2", 8, 6, "NV12", 8, 6, {}, None, None, "random"),
     ("pack422up_yuy2_nv12_w6", "YUY2", 6, 4, "NV12", 6, 4, {}, None, "jpeg", "random"),
     ("pack422up_yuy2_nv12_720p", "YUY2", 1280, 720, "NV12", 1280, 720, {}, None, None, "random"),
+    # GBR (planar RGB, planes G, B, R; unpack_GBR / pack_GBR are the Y444 functions on the R, G, B lines): the chain on both sides, the
+    # reference's GBR -> GBR plane scaler, a crop and a border
+    ("gbr_bgra", "GBR", 66, 21, "BGRA", 66, 21, {}, None, None, "random"),
+    ("bgra_gbr", "BGRA", 35, 18, "GBR", 35, 18, {}, None, None, "random"),
+    ("gbr_i420_bt709", "GBR", 64, 32, "I420", 64, 32, {}, None, None, "random"),
+    ("nv12_gbr", "NV12", 48, 26, "GBR", 48, 26, {}, None, None, "random"),
+    ("gbr_rgb", "GBR", 33, 9, "RGB", 33, 9, {}, None, None, "random"),
+    ("y444_gbr_fullrange", "Y444", 40, 12, "GBR", 40, 12, {}, "1:4:0:0", None, "random"),
+    ("gbr_gbr_copy", "GBR", 50, 20, "GBR", 50, 20, {}, None, None, "random"),
+    ("gbr_gbr_scale_planes_bilinear", "GBR", 64, 48, "GBR", 40, 30, LIN, None, None, "random"),
+    ("gbr_gbr_scale_planes_lanczos_up", "GBR", 31, 17, "GBR", 52, 40, LAN, None, None, "random"),
+    ("gbr_bgra_cubic_down", "GBR", 96, 64, "BGRA", 40, 30, {}, None, None, "random"),
+    ("i420_gbr_lanczos_up", "I420", 32, 24, "GBR", 64, 50, LAN, None, None, "random"),
+    ("gbr_gbr_crop_border", "GBR", 48, 32, "GBR", 64, 40, dict(src_x=5, src_y=3, src_width=30, src_height=20, dest_x=9, dest_y=7, dest_width=40, dest_height=25, border_argb=0x80aa5533), None, None, "random"),
+    ("p010_gbr", "P010_10LE", 32, 16, "GBR", 32, 16, {}, None, None, "random"),
+    ("gbr_ayuv64", "GBR", 24, 10, "AYUV64", 24, 10, {}, None, None, "random"),
+    # the fastpaths' border pairs of an NV61 frame are U, V (convert_fill_border's values come from packing ONE pixel: pack_NV61's odd-width tail)
+    ("nv61_nv61_planes_border_pairs", "NV61", 16, 9, "NV61", 24, 48, dict(dest_x=2, dest_y=9, dest_width=8, dest_height=38, border_argb=0x3754a1c0), None, None, "random"),
+    ("nv61_nv61_planes_border_pairs_odd", "NV61", 16, 9, "NV61", 23, 48, dict(dest_x=0, dest_y=9, dest_width=4, dest_height=38, border_argb=0x3754a1c0), None, None, "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),
@@ -910,7 +929,7 @@ def default_layout(fmt, w, h):
     if fmt == "Y42B":
         s0, s1 = r4(w), (w + 7) // 8 * 8 // 2
         return [s0, s1, s1], [0, s0 * h, s0 * h + s1 * h]
-    if fmt == "Y444":
+    if fmt in ("Y444", "GBR"):
         return [r4(w)] * 3, [0, r4(w) * h, 2 * r4(w) * h]
     if fmt in ("NV12", "NV21"):
         return [r4(w), r4(w)], [0, r4(w) * r2(h)]

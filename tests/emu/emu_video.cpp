@@ -804,6 +804,9 @@ static void emu_fill_borders (const VideoPlan &p, const GstAmdVideoInfo *out, ui
     int es;
     uint32_t lo, hi;
     border_plane_value (f, p.rect.border, i, &es, &lo, &hi);
+    const bool nv61_fastpath = i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && !p.ref_fastpath.empty ();
+    if (nv61_fastpath)
+      lo = (lo >> 8) | ((lo & 0xffu) << 8);
     uint8_t v[8];
     memcpy (v, &lo, 4);
     memcpy (v + 4, &hi, 4);
@@ -815,7 +818,7 @@ static void emu_fill_borders (const VideoPlan &p, const GstAmdVideoInfo *out, ui
       for (int x = 0; x < mw; x++)
         if (!(x >= x0 && x < x0 + w && y >= y0 && y < y0 + h))
           memcpy (dst + out->offset[i] + (size_t) y * out->stride[i] + (size_t) x * es, v, es);
-    if (i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && (p.rect.out_maxw & 1)) {          /* the second k_fill_border launch of fill_borders */
+    if (i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && (p.rect.out_maxw & 1) && !nv61_fastpath) {          /* the second k_fill_border launch of fill_borders */
       const uint8_t sw[2] = {v[1], v[0]};
       const bool reaches = p.rect.out_x + p.out_info.width == p.rect.out_maxw;
       for (int y = 0; y < mh; y++)
@@ -841,6 +844,11 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   g_emu_divergence += p.divergence;
   if (desc)
     strncpy (desc, p.description.c_str (), desc_len - 1);
+  /* plane pointers come from the plan's view of the two frames (GBR: planes R, G, B - format_plan_planes), as in capi_video.cpp */
+  GstAmdVideoInfo in_planes = *in, out_planes = *out;
+  format_plan_planes (p.fin, &in_planes);
+  format_plan_planes (p.fout, &out_planes);
+  in = &in_planes, out = &out_planes;
   if (p.gamma.on) {
     /* convert_gamma of capi_video.cpp: sub-conversion / 16-bit front, the stage kernels' bodies over their grids, the u16 scalers,
        encode + sub-conversion or the 16-bit packer */

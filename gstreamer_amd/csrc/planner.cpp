@@ -3091,6 +3091,23 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
           *error = "nearest vertical scaling of a 4:2:0 source through the 16-bit part of the chain (line pairing of the chroma upsampler follows the scaler's requests) is not implemented";
         return GSTAMD_ERR_UNSUPPORTED;
       }
+    /* ... and the same for a filter whose windows leave source lines out (a shrink by more than its taps: 12 -> 2 rows with two taps asks for lines
+     * 2, 3, 8, 9): do_upsample_lines pairs (L, L + 1) from the line it is ASKED for (:2991-3021, start_line = in_line), so a window that starts on
+     * an even line after a gap flips the pairing against the in-order (odd, even) pairs the composite's front makes.  Found by the device fuzz once
+     * the comparison of 16-bit frames covered their chroma planes (tests/cases.py visible_planes); windows that cover every line from the top
+     * keep the in-order pairs */
+    for (const ScalePass &sp : pl.passes)
+      if (!sp.horizontal && sp.kind != SCALE_NONE && !sp.offset.empty ()) {
+        const int taps = sp.kind == SCALE_NTAP ? sp.n_taps : (sp.kind == SCALE_2TAP ? 2 : 1);
+        bool gaps = (int) sp.offset[0] > 1;
+        for (size_t y = 0; y + 1 < sp.offset.size () && !gaps; y++)
+          gaps = (int) sp.offset[y + 1] > (int) sp.offset[y] + taps;
+        if (gaps) {
+          if (error)
+            *error = "vertical scaling that leaves source lines out, of a 4:2:0 source through the 16-bit part of the chain (line pairing of the chroma upsampler follows the scaler's requests), is not implemented";
+          return GSTAMD_ERR_UNSUPPORTED;
+        }
+      }
   }
   /* do_alpha_lines sets / multiplies MIN (in_width, out_width) pixels (video-converter.c do_alpha_lines); when the line is wider at
    * that point (the horizontal pass on the other side of the alpha stage) the rest keeps the alpha it had.  Well defined, but not

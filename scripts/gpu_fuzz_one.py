@@ -33,3 +33,10 @@ for it in range(target + 1):
     torch.cuda.synchronize()
     got = d_dst.cpu().numpy()
     print(fuzz_video.matches_reference(ref, case, src, got, oi), flush=True)
+    want = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, in_colorimetry=col, in_chroma_site=site, config=cases.ref_config_string(ref, cfg)).frame(src)
+    import numpy as np
+    d = np.nonzero(got != want)[0]
+    if len(d):
+        st = int(oi.stride[0])
+        print("stride", st, "first differing bytes (row, byte, got, want):", [(int(i) // st, int(i) % st, int(got[i]), int(want[i])) for i in d[:24]])
+        rows = sorted(set(int(i) // st for i in d)); print("rows", rows[:40], "cols", sorted(set(int(i) % st for i in d))[:60])

@@ -560,8 +560,12 @@ static int alloc_scratch (GstAmdVideoConverter *c)
         const ScalePass &s0 = p.passes[0];
         mid_px = (size_t) (s0.horizontal ? s0.out_size : g.mid_in.width) * (s0.horizontal ? g.mid_in.height : s0.out_size);
       }
-      c->deep_a_size = std::max (in_px, out_px) * 8;
-      c->deep_b_size = std::max (mid_px, out_px) * 8;
+      /* the passes alternate between the two images, starting with deep_a when the first image is the caller's own 16-bit frame (ARGB64 / AYUV64
+         sources): either may hold the first pass's result, which a horizontal-first enlargement makes LARGER than both frames (26 x 20 between
+         25 x 20 and 26 x 14: deep_a was 160 bytes short and the pass wrote into whatever the allocator had put behind it - the device fuzz's
+         seed 863, wrong bytes in some processes only) */
+      c->deep_a_size = std::max (std::max (in_px, out_px), mid_px) * 8;
+      c->deep_b_size = std::max (std::max (in_px, out_px), mid_px) * 8;
       if ((e = hipMalloc ((void **) &c->deep_a, c->deep_a_size)) != hipSuccess ||
           (!p.passes.empty () && (e = hipMalloc ((void **) &c->deep_b, c->deep_b_size)) != hipSuccess))
         return hip_fail (e, "hipMalloc(16-bit scratch)");
@@ -827,8 +831,27 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       const bool hz = p.passes[i].horizontal;
       const int ow = hz ? p.passes[i].out_size : cur.width, oh = hz ? cur.height : p.passes[i].out_size;
       uint8_t *dst = cur.p == c->deep_a ? c->deep_b : c->deep_a;
+      if ((size_t) ow * 8 * oh > (dst == c->deep_a ? c->deep_a_size : c->deep_b_size))
+        return set_error (GSTAMD_ERR_INVALID, "16-bit scratch image smaller than a pass's result");
       if ((e = launch_scale16 (cur, sd, hz, dst, ow * 8, ow, oh, nullptr, nullptr, stream)) != hipSuccess)
         return hip_fail (e, "k_scale16");
+      if (tuning_on ("GSTAMD_DEEP_DEBUG")) {          /* what each 16-bit pass read and wrote: sums of its tables, its source rows and its result */
+        (void) hipStreamSynchronize (stream);
+        std::vector<uint8_t> hb ((size_t) ow * 8 * oh), ht (p.passes[i].taps.size () * 2), ho (p.passes[i].offset.size () * 4);
+        (void) hipMemcpy (hb.data (), dst, hb.size (), hipMemcpyDeviceToHost);
+        (void) hipMemcpy (ht.data (), sd.taps, ht.size (), hipMemcpyDeviceToHost);
+        (void) hipMemcpy (ho.data (), sd.offset, ho.size (), hipMemcpyDeviceToHost);
+        unsigned long long sb = 0, st = 0, so = 0, stp = 0, sop = 0;
+        for (size_t k = 0; k < hb.size (); k++) sb = sb * 31 + hb[k];
+        for (size_t k = 0; k < ht.size (); k++) st = st * 31 + ht[k];
+        for (size_t k = 0; k < ho.size (); k++) so = so * 31 + ho[k];
+        const uint8_t *pt = (const uint8_t *) p.passes[i].taps.data (), *po = (const uint8_t *) p.passes[i].offset.data ();
+        for (size_t k = 0; k < ht.size (); k++) stp = stp * 31 + pt[k];
+        for (size_t k = 0; k < ho.size (); k++) sop = sop * 31 + po[k];
+        fprintf (stderr, "deep pass %zu (%s, kind %d, %d taps) %dx%d <- %dx%d stride %d src %p%s: result %016llx, taps dev %016llx plan %016llx, offsets dev %016llx plan %016llx, dst %p taps %p offsets %p\n",
+            i, hz ? "h" : "v", sd.kind, sd.n_taps, ow, oh, cur.width, cur.height, cur.stride, (const void *) cur.p, cur_is_source ? " (source)" : "", sb, st, stp, so, sop,
+            (void *) dst, (const void *) sd.taps, (const void *) sd.offset);
+      }
       cur.p = dst, cur.stride = ow * 8, cur.width = ow, cur.height = oh;
       cur_is_source = false;
     }

@@ -36,7 +36,12 @@ def run(case, it, poison=None):
         del junk
     d_src = torch.from_numpy(src).to(gpu)
     d_dst = torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu)
-    conv.frame(d_src, d_dst)
+    if os.environ.get("DEBUG_DRAW") and it == int(os.environ["DEBUG_DRAW"]):
+        os.environ["GSTAMD_DEEP_DEBUG"] = "1"
+        with V.tuning(GSTAMD_DEEP_DEBUG=1):
+            conv.frame(d_src, d_dst)
+    else:
+        conv.frame(d_src, d_dst)
     torch.cuda.synchronize()
     got = d_dst.cpu().numpy()
     desc = conv.describe()

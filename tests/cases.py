@@ -297,6 +297,10 @@ VIDEO_CASES = [
     # the fastpaths' border pairs of an NV61 frame are U, V (convert_fill_border's values come from packing ONE pixel: pack_NV61's odd-width tail)
     ("nv61_nv61_planes_border_pairs", "NV61", 16, 9, "NV61", 24, 48, dict(dest_x=2, dest_y=9, dest_width=8, dest_height=38, border_argb=0x3754a1c0), None, None, "random"),
     ("nv61_nv61_planes_border_pairs_odd", "NV61", 16, 9, "NV61", 23, 48, dict(dest_x=0, dest_y=9, dest_width=4, dest_height=38, border_argb=0x3754a1c0), None, None, "random"),
+    # a horizontal-first pass whose result is larger than both frames, from a 16-bit frame of the caller (the first pass writes scratch image A:
+    # it was sized for the two frames only - the device fuzz's seed 863)
+    ("deep64_argb64_hfirst_mid_larger_than_both_frames", "ARGB64", 25, 20, "ARGB64", 26, 14, dict(resampler_method="lanczos", max_taps=8), None, None, "random"),
+    ("deep64_ayuv64_hfirst_mid_larger_crop_rect", "AYUV64", 48, 31, "AYUV64", 44, 41, dict(resampler_method="lanczos", max_taps=8, src_x=18, src_y=11, src_width=25, src_height=20, dest_x=3, dest_y=20, dest_width=26, dest_height=14), None, None, "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),

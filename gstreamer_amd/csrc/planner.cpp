@@ -3075,6 +3075,25 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       plan->divergence += "nearest vertical enlargement by more than five of a 4:2:0 source with no horizontal pass: the reference's temporary lines are reused before "
           "every repetition of a line has been served (line aliasing: the first line of a chroma pair changes); this library serves every repetition from the same line. ";
     }
+    /* observed the same way (150 000 device fuzz draws late in round 4, then sweeps of small crops of NV12 / I420 into VUYA / BGRA): the nearest scaler in
+       both directions, the VERTICAL one first (the order chain_scale picks when in_width x out_height < out_width x in_height) - once the FIRST line of an
+       upsampler pair (lines 1, 3, ... of the crop) has been handed out MORE THAN FOUR times, the pair's second line comes out with other content, luma
+       included: a temporary line reused, not a pairing rule (4 -> 16 rows match, 4 -> 18 do not; 3 -> 14 matches - its line 1 is repeated four times -
+       3 -> 13 and 3 -> 15 do not; two source lines never show it; horizontal first every ratio matches; a 4:2:2 source is exact).  Announced, not reproduced */
+    if (pl.front.chroma_v2 && pl.passes.size () == 2 && !pl.passes[0].horizontal && pl.passes[0].kind == SCALE_NEAREST && pl.passes[1].horizontal &&
+        pl.passes[1].kind == SCALE_NEAREST) {
+      const ScalePass &pv = pl.passes[0];
+      std::vector<int> repeats ((size_t) pv.in_size + 1, 0);
+      for (uint32_t o : pv.offset)
+        if ((int) o <= pv.in_size)
+          repeats[o]++;
+      bool reused = false;
+      for (int l = 1; l + 1 < pv.in_size; l += 2)          /* the pair (l, l + 1): its first line asked for more than four times, its second comes out wrong */
+        reused = reused || repeats[(size_t) l] > 4;
+      if (reused)
+        plan->divergence += "nearest enlargement of a 4:2:0 source, vertical pass first, with the first line of a chroma pair handed out more than four times: the "
+            "reference delivers the pair's second line with the content of another line (a temporary line reused; line aliasing); this library replicates the source's pixels. ";
+    }
     /* (a 4:2:0 source into a frame in its unpack format: the chroma upsampler itself works in the destination's rows, which the scaler hands out again) */
     if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place || (identity_pack && pl.front.chroma_v2))) {
       plan->divergence += "nearest vertical enlargement ahead of a stage that works in place (colour / alpha, chroma downsampling, dither): the reference "

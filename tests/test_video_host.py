@@ -158,6 +158,26 @@ def test_plans_that_reproduce_the_reference_carry_no_divergence_note(native_lib)
         conv.free()
 
 
+@pytest.mark.parametrize("ow,oh,inside", [(28, 16, False), (30, 16, False), (16, 18, False), (18, 18, False), (20, 18, True), (30, 18, True), (83, 28, True),
+                                          (40, 40, False), (60, 40, True)])
+def test_nearest_enlargement_aliasing_class_has_its_boundary_where_the_reference_has_it(emu_lib, ref, ow, oh, inside):
+    """the nearest scaler both ways on a 4 x 4 crop of NV12: exact while no source line is handed out more than four times or the horizontal pass runs
+    first (out_width <= out_height for a square crop), announced as reference line aliasing otherwise - plans on both sides of both edges of the class"""
+    import ctypes
+    w, h = 16, 6
+    cfg = dict(resampler_method="nearest", src_x=6, src_y=2, src_width=4, src_height=4)
+    src = cases.frame_bytes(int(V.video_info("NV12", w, h).size), "random", 99, w)
+    dst = _emu_convert(emu_lib, "NV12", w, h, "VUYA", ow, oh, cfg, None, None, src)
+    emu_lib.emu_video_last_divergence.restype = ctypes.c_char_p
+    note = emu_lib.emu_video_last_divergence().decode()
+    exp = ref.VideoConverter("NV12", w, h, "VUYA", ow, oh, config=cases.ref_config_string(ref, cfg)).frame(src)
+    if inside:
+        assert "handed out more than four times" in note, note
+        assert (dst != exp).any()           # the reference really differs there (every second source line's rows)
+    else:
+        assert note == "" and (dst == exp).all()
+
+
 def test_set_config_replans_the_sub_converters(native_lib):
     """gst_video_converter_set_config (video-converter.c:2759): a converter re-configured in place ends up with the plan - and, for the
     composite plans, the sub-conversions - of a converter created with the new options (round 2 kept sub-converters planned with the old

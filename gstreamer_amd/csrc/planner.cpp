@@ -2678,6 +2678,21 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     }
   }
 
+  /* unpack_VYUY hands lines that are not 8-byte aligned to a C loop (video-format.c: `if (IS_ALIGNED (d, 8)) video_orc_unpack_VYUY ... else`) which
+     stores V where U belongs and U where V does - on EVERY macropixel, like the odd-width tail does on the last one.  With a border to fill the
+     destination-side lines start out_x pixels into their allocation (get_border_temp_line :717-730: out_x * pack_pstride, 4 bytes a pixel on an 8-bit
+     pack), and setup_allocators hands that allocator back through every stage that works in place - up to the unpacker unless a scaler that makes
+     new lines sits in between (every filter; the nearest VERTICAL scaler hands its input line on).  An odd out_x is then such a line: unscaled
+     chains and chains with only a nearest vertical pass.  (Found by the device fuzz, seed 4832; the boundary from sweeps over the pass kinds.) */
+  {
+    bool new_lines = false;
+    for (const ScalePass &sp : plan->passes)
+      new_lines = new_lines || sp.horizontal || sp.kind != SCALE_NEAREST;
+    if (in->format == GSTAMD_VIDEO_FORMAT_VYUY && plan->rect.fill && (plan->rect.out_x & 1) && plan->fout->hi_depth == 0 && !new_lines) {
+      std::swap (fr.pos[2], fr.pos[3]);
+      fr.swap_k = -1;
+    }
+  }
   /* Reference quirk: when the vertical scaler comes first and pulls straight from the 2-line chroma
    * upsampler, the unpack temp-line ring (setup_allocators :2115-2187, sized MAX(n_taps, 5)) is one
    * line short: the pair mate of the window's last line overwrites the window's first line, so the

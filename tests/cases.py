@@ -301,6 +301,12 @@ VIDEO_CASES = [
     # it was sized for the two frames only - the device fuzz's seed 863)
     ("deep64_argb64_hfirst_mid_larger_than_both_frames", "ARGB64", 25, 20, "ARGB64", 26, 14, dict(resampler_method="lanczos", max_taps=8), None, None, "random"),
     ("deep64_ayuv64_hfirst_mid_larger_crop_rect", "AYUV64", 48, 31, "AYUV64", 44, 41, dict(resampler_method="lanczos", max_taps=8, src_x=18, src_y=11, src_width=25, src_height=20, dest_x=3, dest_y=20, dest_width=26, dest_height=14), None, None, "random"),
+    # unpack_VYUY's loop for lines that are not 8-byte aligned swaps U and V on every macropixel: a border to fill and an odd dest-x put the
+    # unpacker's line there when no scaler that makes new lines sits in between (device fuzz seed 4832)
+    ("vyuy_xrgb_odd_dest_x_border_unscaled", "VYUY", 24, 39, "xRGB", 24, 39, dict(src_x=12, src_y=17, src_width=6, src_height=13, dest_x=3, dest_y=10, dest_width=6, dest_height=13, border_argb=0x773e3b05), None, "mpeg2", "random"),
+    ("vyuy_bgra_odd_dest_x_border_v_nearest", "VYUY", 24, 39, "BGRA", 24, 39, dict(NEAR, src_x=12, src_y=17, src_width=6, src_height=13, dest_x=3, dest_y=10, dest_width=6, dest_height=11, border_argb=0x773e3b05), None, "mpeg2", "random"),
+    ("vyuy_xrgb_odd_dest_x_border_v_linear", "VYUY", 24, 39, "xRGB", 24, 39, dict(resampler_method="linear", src_x=12, src_y=17, src_width=6, src_height=13, dest_x=3, dest_y=10, dest_width=6, dest_height=11, border_argb=0x773e3b05), None, "mpeg2", "random"),
+    ("vyuy_nv12_odd_dest_x_border_unscaled", "VYUY", 24, 40, "NV12", 24, 40, dict(src_x=12, src_y=16, src_width=6, src_height=12, dest_x=3, dest_y=10, dest_width=6, dest_height=12, border_argb=0x773e3b05), None, None, "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),

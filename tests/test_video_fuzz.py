@@ -64,6 +64,18 @@ def test_hip_random_conversions_match_reference_or_are_refused(native_lib, gpu, 
         conv.frame(d_src, d_dst)
         torch.cuda.synchronize()
         got = d_dst.cpu().numpy()
+        if it % 3 == 0:
+            # every third draw also as a buffer list (three frames, two different sources): whatever the plan - one grid for the list, or frame by
+            # frame - each frame of the list equals the frame converted on its own
+            src2 = cases.frame_bytes(int(ii.size), "random", seed * 1000 + it + 500000, w)
+            d_src2 = torch.from_numpy(src2).to(gpu)
+            outs = [torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu) for _ in range(3)]
+            conv.frames([d_src, d_src2, d_src], outs)
+            d_one = torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu)
+            conv.frame(d_src2, d_one)
+            torch.cuda.synchronize()
+            assert (outs[0].cpu().numpy() == got).all() and (outs[2].cpu().numpy() == got).all(), ("list frame differs from the single frame", case)
+            assert (outs[1].cpu().numpy() == d_one.cpu().numpy()).all(), ("list frame differs from the single frame", case)
         conv.free()
         if diverges:
             continue

@@ -2688,7 +2688,11 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     bool new_lines = false;
     for (const ScalePass &sp : plan->passes)
       new_lines = new_lines || sp.horizontal || sp.kind != SCALE_NEAREST;
-    if (in->format == GSTAMD_VIDEO_FORMAT_VYUY && plan->rect.fill && (plan->rect.out_x & 1) && plan->fout->hi_depth == 0 && !new_lines) {
+    /* a destination in its unpack format (ARGB / AYUV: identity_pack) lends its OWN rows instead (get_dest_line: row + out_x * 4, border or not); with
+       rows on 8 bytes that is the same rule, otherwise the alignment changes from row to row (announced below) */
+    const bool own_rows = plan->fout->format == GSTAMD_VIDEO_FORMAT_ARGB || plan->fout->format == GSTAMD_VIDEO_FORMAT_AYUV;
+    const bool rows_on_8 = (out->stride[0] % 8) == 0 && (out->offset[0] % 8) == 0;
+    if (in->format == GSTAMD_VIDEO_FORMAT_VYUY && (plan->rect.out_x & 1) && plan->fout->hi_depth == 0 && !new_lines && (own_rows ? rows_on_8 : plan->rect.fill)) {
       std::swap (fr.pos[2], fr.pos[3]);
       fr.swap_k = -1;
     }
@@ -3195,7 +3199,10 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   /* unpack_VYUY (video-format.c:310-352) falls back to a C loop with U and V the other way round when the line it writes is not
    * 8-byte aligned; with an unpack-format destination the lines are the destination frame's own (get_dest_line), so on frames whose
    * rows are not all 8-byte aligned (odd widths) every other row comes out with swapped chroma */
-  if (chain && fi->format == GSTAMD_VIDEO_FORMAT_VYUY && iw == ow && ih == oh && fo->kind == UNPACK_PACKED4 && fo->hi_depth == 0 &&
+  bool vyuy_new_lines = false;          /* a scaler that makes new lines between the unpacker and the destination's rows (not the nearest vertical one) */
+  for (const ScalePass &sp : pl.passes)
+    vyuy_new_lines = vyuy_new_lines || sp.horizontal || sp.kind != SCALE_NEAREST;
+  if (chain && fi->format == GSTAMD_VIDEO_FORMAT_VYUY && !vyuy_new_lines && fo->kind == UNPACK_PACKED4 && fo->hi_depth == 0 &&
       fo->pos[0] == 0 && fo->pos[1] == 1 && fo->pos[2] == 2 && fo->pos[3] == 3 && (fo->alpha) &&
       ((out->stride[0] % 8) != 0 || (out->offset[0] % 8) != 0)) {
     plan->divergence += "VYUY unpacked straight into destination rows that are not 8-byte aligned: the reference's fallback loop (video-format.c:337-352) "
@@ -3204,10 +3211,21 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   /* a ONE-line 4:2:0 source enlarged into a rectangle below the first row of a frame in its unpack format (ARGB / AYUV: the chain's lines are the
    * destination's own rows, get_dest_line): the chroma upsampler makes its line pair (-1, 0) in the rows (out_y - 1, out_y) and the row above the
    * rectangle keeps what it wrote there */
-  if (chain && pl.front.chroma_v2 && ih == 1 && oh > 1 && plan->rect.out_y > 0 &&
-      (fo->format == GSTAMD_VIDEO_FORMAT_AYUV || fo->format == GSTAMD_VIDEO_FORMAT_ARGB)) {
-    plan->divergence += "a one-line 4:2:0 source enlarged into a rectangle of an ARGB / AYUV frame: the reference's chroma upsampler writes the line before the "
-        "picture into the frame row above the rectangle; this library leaves that row to the border. ";
+  /* (the device fuzz's seed 5484 widened it: the same with one output row, and with the 16-bit unpack formats as destinations - the pair's other line
+   * still lands in a frame row, or in front of the frame when the rectangle starts at row 0, and the picture's own row differs) */
+  const bool one_line_420 = pl.front.chroma_v2 || (pl.gamma.on && fi->h_sub == 1 && kind_has_planes (fi->kind) && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE &&
+      cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY);
+  /* ... and every chain whose unpacker works in the destination's rows (no scaler that makes new lines in between) does it to the row above a rectangle
+   * that starts below row 0: a crop copied unscaled into a rectangle of an ARGB frame keeps picture-derived pixels in that border row */
+  /* ... and so does a source CROP (frame lines above or below it: the pair mates of the crop's first / last line are real lines, unpacked into the rows
+   * next to the picture - or past the frame's last row) */
+  const bool cropped_v = plan->rect.in_y > 0 || (plan->rect.in_maxh && plan->rect.in_y + ih < plan->rect.in_maxh);
+  if (chain && one_line_420 && (ih == 1 || (!vyuy_new_lines && (plan->rect.out_y > 0 || cropped_v))) &&
+      (fo->format == GSTAMD_VIDEO_FORMAT_AYUV || fo->format == GSTAMD_VIDEO_FORMAT_ARGB || fo->format == GSTAMD_VIDEO_FORMAT_AYUV64 ||
+          fo->format == GSTAMD_VIDEO_FORMAT_ARGB64)) {
+    plan->divergence += "a 4:2:0 source whose chroma upsampler works in the rows of an ARGB / AYUV (or ARGB64 / AYUV64) frame - one source line, a rectangle below row 0, "
+        "or a crop with frame lines above / below it: the reference unpacks the pair mates of the picture's first / last line into the frame rows next to the picture "
+        "(or past the frame); this library leaves those rows to the border and pairs inside the crop. ";
   }
   /* convert_scale_planes on packed 4:2:2 with the vertical pass first: that pass moves `width` pixels = 2 * width bytes of a line (video-converter.c
    * convert_plane_v / _hv), which on an odd width leaves out the V sample of the last, half macropixel; the horizontal pass then reads it from a

@@ -30,7 +30,16 @@ def test_random_conversions_match_reference_or_are_refused(emu_lib, ref, seed):
     assert count["ok"] >= 80, count
 
 
-GPU_SEEDS = [int(x) for x in os.environ.get("GSTAMD_FUZZ_SEEDS", "101,404,505,707,909").split(",")]
+def _seed_list(spec):
+    """"101,404,700-720": single seeds and inclusive ranges"""
+    out = []
+    for part in spec.split(","):
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+GPU_SEEDS = _seed_list(os.environ.get("GSTAMD_FUZZ_SEEDS", "101,404,505,707,909"))
 
 
 @pytest.mark.gpu

@@ -261,13 +261,20 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[3], co
     const bool pairs = f->kind == UNPACK_PACKED422 || f->kind == UNPACK_P422_16;          /* the plane's unit is the macropixel */
     const int ws = i || pairs ? f->w_sub : 0, hs = i ? f->h_sub : 0;
     const int mw = up (rc.out_maxw, ws), mh = up (rc.out_maxh, hs);
-    e = launch_fill_border (planes[i], strides[i], es, lo, hi, mw, mh, rc.out_x >> ws, rc.out_y >> hs, up (w, ws), up (h, hs), stream);
+    e = launch_fill_border (planes[i], strides[i], es, lo, hi, mw, mh, rc.out_x >> ws, rc.out_y >> hs, border_picture_positions (f, rc, w, ws), up (h, hs), stream);
     if (e == hipSuccess && i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && (rc.out_maxw & 1) && !nv61_fastpath) {
       /* pack_NV61's odd-width tail (video-format.c:2005-2011) stores the last pair of every border line in NV16 order; the picture's rows
          are the packer's (tail_swap) when the rectangle reaches that column */
       const bool reaches = rc.out_x + w == rc.out_maxw;
       e = launch_fill_border (planes[1] + (size_t) (mw - 1) * 2, strides[1], 2, (lo >> 8) | ((lo & 0xff) << 8), 0, 1, mh, 0, rc.out_y >> hs, reaches ? 1 : 0,
           reaches ? up (h, hs) : 0, stream);
+    }
+    if (e == hipSuccess && f->format == GSTAMD_VIDEO_FORMAT_VYUY && (rc.out_maxw & 1) && p.ref_fastpath.empty () && !p.plane_mode) {
+      /* pack_VYUY's odd-width tail (video-format.c:374-380) stores the frame line's last pixel in UYVY order: the last macropixel of every border
+         line, and of the picture's lines too when the rectangle ends left of it */
+      const bool reaches = rc.out_x + w == rc.out_maxw;
+      e = launch_fill_border (planes[0] + (size_t) (mw - 1) * 4, strides[0], 4, ((lo >> 16) & 0xffffu) | (lo << 16), 0, 1, mh, 0, rc.out_y, reaches ? 1 : 0,
+          reaches ? h : 0, stream);
     }
   }
   return e;

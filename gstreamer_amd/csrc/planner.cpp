@@ -3020,15 +3020,18 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       *error = "a destination rectangle inside a v210 frame (6-pixel groups shared with the border) is not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
   }
-  if (rc.fill && fo && (fo->kind == UNPACK_PACKED422 || fo->kind == UNPACK_P422_16) && ((rc.out_x | eout.width | rc.out_maxw) & 1)) {
-    /* (rectangles on whole macropixels are filled: border_plane_value) */
-    if (error)
-      *error = "borders on a packed 4:2:2 destination whose rectangle or frame ends inside a macropixel (pixel pairs shared between border and picture) are not implemented on the GPU path";
-    return GSTAMD_ERR_UNSUPPORTED;
-  }
   const int r = plan_core (&ein, &eout, &cfg, plan, error);
   if (r != GSTAMD_OK || !fi || !fo)
     return r;
+  if (rc.fill && (fo->kind == UNPACK_PACKED422 || fo->kind == UNPACK_P422_16) && ((rc.out_x | eout.width | rc.out_maxw) & 1) &&
+      (plan->plane_mode || !plan->ref_fastpath.empty ())) {
+    /* (the generic chain packs frame lines pair by pair: border_picture_positions; rectangles on whole macropixels are filled by every path.
+       convert_fill_border's group 42 (:7277-7285) writes 2-byte units from the rectangle's odd right edge on and swaps its U and V for EVERY border
+       line then, and each fastpath / plane scaler has its own tail rule: not built) */
+    if (error)
+      *error = "borders of the reference's fastpaths and plane scaler (convert_fill_border, group 42) on a packed 4:2:2 destination whose rectangle or frame ends inside a macropixel are not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
   /* Two places where the reference's generic chain reads lines it has not (or has already) converted; its output there is
    * uninitialised memory or a matrix applied twice, so there is nothing to reproduce - such plans are refused:
    *  (a) do_convert_lines converts MIN (in_width, out_width) pixels (:3112) into a FRESH line when the bit depth changes (:3117-3136).
@@ -3041,6 +3044,10 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
      rectangle that ends before the frame's right edge packs its last pixel the ordinary way */
   if (!(plan->rect.out_x + eout.width == plan->rect.out_maxw && (plan->rect.out_maxw & 1)))
     plan->pack.tail_swap = plan->gamma.pack.tail_swap = 0;
+  /* pack_Y210 / pack_Y212_LE repeat the first luma of an odd-width line's last macropixel as its second (video-format.c:849-850) - of the FRAME line: a
+     rectangle of odd width that ends before the frame's right edge has the border's luma there (border_picture_positions); 2 = the packer leaves it */
+  if (fo->kind == UNPACK_P422_16 && rc.fill && (eout.width & 1) && rc.out_x + eout.width < rc.out_maxw)
+    plan->gamma.pack.tail_swap = 2;
   plan->gamma.dither16.y0 = plan->rect.out_y;          /* the 16-bit dither stage counts frame lines (do_dither_lines: out_line = i + out_y) */
   const VideoPlan &pl = *plan;
   const bool chain = !pl.plane_mode && pl.ref_fastpath.empty ();

@@ -139,7 +139,8 @@ struct PackPlanarParams {
   int down_h;           // 0: the even pixel's chroma as it is, 1: video_orc_chroma_down_h2_u8, 2: video_chroma_down_h2_cs_u8
   int down_v;           // 0: the even line's chroma as it is, 1: video_orc_chroma_down_v2_u8 over lines (2r, 2r+1)
   int tail_swap;        // 1: the last pixel of an odd-width line stores U and V the other way round - pack_VYUY writes it in UYVY
-                        // order (video-format.c:374-380), pack_NV61 in NV16 order (:2005-2011)
+                        // order (video-format.c:374-380), pack_NV61 in NV16 order (:2005-2011); 2 (Y210 / Y212): the second luma of an odd-width line's
+                        // last macropixel is not the packer's to write (it is the border's luma: border_picture_positions)
   int virtual_line;     // 1: row `height` of the AYUV image holds the line past an odd-height picture as the chain delivers it (unpack clamped to the
                         // last line, chroma upsampler pairing it anew) - the last 4:2:0 chroma row averages the last line with THAT line
   DitherParams dither;  // chain_dither ahead of the pack (between chroma downsampling and packing): shift[] in unpack order (A, Y, U, V)
@@ -344,6 +345,20 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
     return (size_t) y * stride + (size_t) x * bps;
   const size_t row = (size_t) (y >> f->h_sub) * stride;
   return f->kind == UNPACK_SEMI ? row + (size_t) (x >> f->w_sub) * 2 * bps : row + (size_t) (x >> f->w_sub) * bps;
+}
+
+// Width, in plane positions, of the part of a destination plane's rows the border fill leaves to the picture.  Planes of whole pixels and
+// subsampled chroma planes: every position the picture touches.  Packed 4:2:2 (positions = macropixels; out_x is even, gst_video_converter_new
+// clears the subsampling bits :2330): a picture of odd width that ends left of the frame's right edge shares its last macropixel with the border -
+// the generic chain packs the frame line pair by pair (pack_YUY2 & co over out_maxwidth pixels, video-converter.c:3274), so that macropixel is
+// {picture luma, picture chroma of the last pixel, BORDER luma}: the fill lays the border pair there first and the packer's odd tail (luma,
+// U, V of pixel width - 1; it never writes the second luma) goes over it on the same stream.
+inline int border_picture_positions (const FormatDesc *f, const RectPlan &rc, int width, int ws)
+{
+  const bool pairs = f->kind == UNPACK_PACKED422 || f->kind == UNPACK_P422_16;
+  if (pairs && (width & 1) && rc.out_x + width < rc.out_maxw)
+    return width >> 1;
+  return -((-width) >> ws);
 }
 
 // The border sample(s) of plane `plane` of the destination (setup_borderline :2189-2262 packs one border pixel with the format's own pack

@@ -948,7 +948,8 @@ GSTAMD_HD void pack16_packed_body (const PackPlanarParams &pk, int hi_depth, con
   const uint16_t y1 = x + 1 < w ? pack16_sample (hi_depth, dither16_comp (dt, 1, (int) (row[x + 1].x >> 16), x + 1, y)) : y0;
   uint16_t *d = (uint16_t *) (dst + (size_t) y * dstride) + 4 * unit;
   d[pk.pos[1]] = y0;
-  d[pk.pos[1] + 2] = y1;
+  if (x + 1 < w || pk.tail_swap != 2)          /* (2: the second luma of the picture's last macropixel is the border's - planner.cpp, border_picture_positions) */
+    d[pk.pos[1] + 2] = y1;
   d[pk.pos[2]] = pack16_sample (hi_depth, dither16_comp (dt, 2, u, x, y));
   d[pk.pos[3]] = pack16_sample (hi_depth, dither16_comp (dt, 3, v, x, y));
 }

@@ -307,6 +307,20 @@ VIDEO_CASES = [
     ("vyuy_bgra_odd_dest_x_border_v_nearest", "VYUY", 24, 39, "BGRA", 24, 39, dict(NEAR, src_x=12, src_y=17, src_width=6, src_height=13, dest_x=3, dest_y=10, dest_width=6, dest_height=11, border_argb=0x773e3b05), None, "mpeg2", "random"),
     ("vyuy_xrgb_odd_dest_x_border_v_linear", "VYUY", 24, 39, "xRGB", 24, 39, dict(resampler_method="linear", src_x=12, src_y=17, src_width=6, src_height=13, dest_x=3, dest_y=10, dest_width=6, dest_height=11, border_argb=0x773e3b05), None, "mpeg2", "random"),
     ("vyuy_nv12_odd_dest_x_border_unscaled", "VYUY", 24, 40, "NV12", 24, 40, dict(src_x=12, src_y=16, src_width=6, src_height=12, dest_x=3, dest_y=10, dest_width=6, dest_height=12, border_argb=0x773e3b05), None, None, "random"),
+    # packed 4:2:2 destinations whose picture ends inside a macropixel (odd width left of the frame's right edge: the generic chain packs the FRAME
+    # line pair by pair, so that macropixel is {picture luma, the last pixel's chroma, border luma}: border_picture_positions), odd frame widths (the
+    # border's tail macropixel; pack_VYUY's tail in UYVY order), Y210 / Y212_LE (pack_Y210 repeats the luma only at the frame line's end)
+    ("ayuv_yuy2_border_shared_macropixel", "AYUV", 16, 6, "YUY2", 16, 6, dict(dest_x=3, dest_y=1, dest_width=9, dest_height=4), None, None, "random"),
+    ("i420_yuy2_border_odd_frame_width", "I420", 21, 11, "YUY2", 21, 11, dict(dest_x=6, dest_y=4, dest_width=6, dest_height=7), None, None, "random"),
+    ("bgrx_vyuy_border_shared_dither_linear", "BGRx", 65, 18, "VYUY", 65, 18, dict(resampler_method="linear", dither_quantization=8, dest_x=5, dest_y=3, dest_width=23, dest_height=8), None, "jpeg", "random"),
+    ("bgrx_vyuy_border_rect_reaches_odd_frame_edge", "BGRx", 65, 18, "VYUY", 65, 18, dict(dest_x=4, dest_y=3, dest_width=61, dest_height=8, border_argb=0x9749f0c7), None, "jpeg", "random"),
+    ("bgrx_vyuy_border_tail_uyvy_order", "BGRx", 65, 18, "VYUY", 65, 18, dict(dest_x=4, dest_y=3, dest_width=60, dest_height=8, border_argb=0x9749f0c7), None, "jpeg", "random"),
+    ("rgbx_uyvy_border_shared_sinc", "RGBx", 24, 20, "UYVY", 79, 11, dict(resampler_method="sinc", dest_x=29, dest_y=1, dest_width=33, dest_height=10, border_argb=0x974a3d07), None, None, "random"),
+    ("nv16_uyvy_border_shared_cosited_lanczos", "NV16", 57, 10, "UYVY", 83, 24, dict(LAN, dest_x=30, dest_y=8, dest_width=19, dest_height=12), "bt601", "mpeg2", "random"),
+    ("nv12_yvyu_letterbox_odd_width_4k_shape", "NV12", 320, 180, "YVYU", 401, 300, dict(LIN, dest_x=40, dest_y=38, dest_width=321, dest_height=224, border_argb=0xff203040), None, None, "random"),
+    ("i422_12_y212_border_shared_macropixel", "I422_12LE", 45, 28, "Y212_LE", 65, 20, dict(dest_x=30, dest_y=7, dest_width=25, dest_height=7), None, "jpeg", "random"),
+    ("bgrx_y210_border_shared_odd_frame", "BGRx", 65, 18, "Y210", 65, 18, dict(dest_x=4, dest_y=3, dest_width=59, dest_height=8, border_argb=0x9749f0c7), None, "jpeg", "random"),
+    ("bgrx_y210_border_rect_reaches_odd_frame_edge", "BGRx", 65, 18, "Y210", 65, 18, dict(dest_x=4, dest_y=3, dest_width=61, dest_height=8, border_argb=0x9749f0c7), None, "jpeg", "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),
@@ -874,7 +888,11 @@ VIDEO_CASES = [
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd
 # width they copy one byte of source row padding into the destination row padding (video-converter.c:3409-3560, 3954-4030, ..);
 # this library writes picture bytes only.
-VISIBLE_ONLY = {"uyvy_yv12_33x17_fastpath", "uyvy_y444_33x18_fastpath", "uyvy_yuy2_33x17_fastpath"}
+VISIBLE_ONLY = {"uyvy_yv12_33x17_fastpath", "uyvy_y444_33x18_fastpath", "uyvy_yuy2_33x17_fastpath",
+                # frames of odd width with borders: the fill lays whole border macropixels, the reference's odd tail leaves the byte past the frame line alone
+                "i420_yuy2_border_odd_frame_width", "bgrx_vyuy_border_shared_dither_linear", "bgrx_vyuy_border_rect_reaches_odd_frame_edge",
+                "bgrx_vyuy_border_tail_uyvy_order", "rgbx_uyvy_border_shared_sinc", "nv16_uyvy_border_shared_cosited_lanczos",
+                "nv12_yvyu_letterbox_odd_width_4k_shape"}
 
 # conversions the reference runs through code this library has no kernel for -> must be REFUSED ("not built", never approximated)
 VIDEO_REFUSED = [
@@ -885,6 +903,8 @@ VIDEO_REFUSED = [
     ("v210", 48, 16, "UYVY", 48, 16, {}),
     ("v210", 48, 16, "BGRA", 40, 16, dict(src_x=6, src_width=40)),          # unpack_v210 ignores the horizontal offset
     ("BGRA", 40, 16, "v210", 48, 16, dict(dest_x=6, dest_width=40)),        # a rectangle inside 6-pixel groups
+    ("UYVY", 24, 11, "UYVY", 81, 29, dict(resampler_method="sinc", dest_x=37, dest_y=3, dest_width=40, dest_height=23)),   # convert_fill_border's group 42 with an odd frame width (plane scaler)
+    ("Y42B", 31, 16, "UYVY", 40, 20, dict(dest_x=4, dest_y=2, dest_width=31, dest_height=16)),            # ... with the picture ending inside a macropixel (fastpath convert_Y42B_UYVY)
     ("UYVY", 64, 16, "GRAY8", 64, 16, dict(src_y=4, src_height=8)),         # convert_UYVY_GRAY8 ignores crop origins
     ("NV24", 13, 29, "NV21", 7, 49, dict(src_x=6, src_y=3, src_width=6, src_height=15, dest_x=2, dest_y=18, dest_width=4, dest_height=15)),   # line past an odd-height 4:2:0 picture behind a horizontal scaler
     ("BGRA", 67, 36, "AYUV", 76, 21, dict(alpha_mode="mult", alpha_value=0.5)),    # alpha stage on MIN (in_width, out_width) pixels of a wider line

@@ -813,7 +813,7 @@ static void emu_fill_borders (const VideoPlan &p, const GstAmdVideoInfo *out, ui
     const bool pairs = f->kind == UNPACK_PACKED422 || f->kind == UNPACK_P422_16;
     const int ws = i || pairs ? f->w_sub : 0, hs = i ? f->h_sub : 0;
     const int mw = up (p.rect.out_maxw, ws), mh = up (p.rect.out_maxh, hs), x0 = p.rect.out_x >> ws, y0 = p.rect.out_y >> hs;
-    const int w = up (p.out_info.width, ws), h = up (p.out_info.height, hs);
+    const int w = border_picture_positions (f, p.rect, p.out_info.width, ws), h = up (p.out_info.height, hs);
     for (int y = 0; y < mh; y++)
       for (int x = 0; x < mw; x++)
         if (!(x >= x0 && x < x0 + w && y >= y0 && y < y0 + h))
@@ -824,6 +824,13 @@ static void emu_fill_borders (const VideoPlan &p, const GstAmdVideoInfo *out, ui
       for (int y = 0; y < mh; y++)
         if (!(reaches && y >= y0 && y < y0 + h))
           memcpy (dst + out->offset[i] + (size_t) y * out->stride[i] + (size_t) (mw - 1) * 2, sw, 2);
+    }
+    if (f->format == GSTAMD_VIDEO_FORMAT_VYUY && (p.rect.out_maxw & 1) && p.ref_fastpath.empty () && !p.plane_mode) {          /* the VYUY launch of fill_borders */
+      const uint8_t sw[4] = {v[2], v[3], v[0], v[1]};
+      const bool reaches = p.rect.out_x + p.out_info.width == p.rect.out_maxw;
+      for (int y = 0; y < mh; y++)
+        if (!(reaches && y >= y0 && y < y0 + h))
+          memcpy (dst + out->offset[i] + (size_t) y * out->stride[i] + (size_t) (mw - 1) * 4, sw, 4);
     }
   }
 }

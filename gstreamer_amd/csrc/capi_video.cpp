@@ -886,9 +886,11 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       if (!planes[i])
         return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
     }
-    if (p.rect.fill && (e = fill_borders (p, planes, strides, stream)) != hipSuccess)
+    /* (a v210 frame's borders are its packer's own: groups of six pixels hold border and picture - PackPlanarParams::frame_on) */
+    const bool frame_pack = g.pack16 && g.pack.kind == UNPACK_V210 && g.pack.frame_on == 2;
+    if (p.rect.fill && !frame_pack && (e = fill_borders (p, planes, strides, stream)) != hipSuccess)
       return hip_fail (e, "k_fill_border");
-    for (int i = 0; i < p.out_info.n_planes && i < 3; i++)
+    for (int i = 0; i < p.out_info.n_planes && i < 3 && !frame_pack; i++)
       planes[i] += plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, strides[i]);
     if (g.store64) {
       /* the last 16-bit image is the picture (pack_ARGB64 / pack_AYUV64 are copies at native endianness) */

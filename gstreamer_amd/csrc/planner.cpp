@@ -3007,19 +3007,13 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     rc.in_maxw = in->width;
     rc.in_maxh = in->height;
   }
+  /* unpack_v210 takes no horizontal offset ("Horizontal offsets are not supported for v210", video-format.c:570-573): the generic chain's crop of a v210
+     source is src_width pixels from the line's FIRST pixel on, whatever src-x says (do_unpack_lines :2966 passes in_x, the unpacker drops it) */
+  if (fi && fi->kind == UNPACK_V210)
+    rc.in_x = 0;
   plan->rect = rc;
   plan->orig_in = *in;
   plan->orig_out = *out;
-  if (fi && fi->kind == UNPACK_V210 && rc.in_x) {
-    if (error)
-      *error = "a horizontal source offset into v210 (unpack_v210 ignores it: 'Horizontal offsets are not supported for v210') is not reproduced";
-    return GSTAMD_ERR_UNSUPPORTED;
-  }
-  if (fo && fo->kind == UNPACK_V210 && (rc.out_x || rc.out_y || rc.fill || (rc.out_maxw && (rc.out_maxw != eout.width || rc.out_maxh != eout.height)))) {
-    if (error)
-      *error = "a destination rectangle inside a v210 frame (6-pixel groups shared with the border) is not implemented on the GPU path";
-    return GSTAMD_ERR_UNSUPPORTED;
-  }
   const int r = plan_core (&ein, &eout, &cfg, plan, error);
   if (r != GSTAMD_OK || !fi || !fo)
     return r;
@@ -3044,6 +3038,19 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
      rectangle that ends before the frame's right edge packs its last pixel the ordinary way */
   if (!(plan->rect.out_x + eout.width == plan->rect.out_maxw && (plan->rect.out_maxw & 1)))
     plan->pack.tail_swap = plan->gamma.pack.tail_swap = 0;
+  /* a rectangle inside a v210 frame: the packer works on the frame line's groups (PackPlanarParams::frame_on) */
+  if (fo->kind == UNPACK_V210 && (rc.out_x || rc.out_y || rc.fill || (rc.out_maxw && (rc.out_maxw != eout.width || rc.out_maxh != eout.height)))) {
+    if (!plan->gamma.on || !plan->gamma.pack16 || !rc.out_maxw) {
+      if (error)
+        *error = "a destination rectangle inside a v210 frame is only implemented for the 16-bit chain's packer";
+      return GSTAMD_ERR_UNSUPPORTED;
+    }
+    PackPlanarParams &pk = plan->gamma.pack;
+    pk.frame_on = rc.fill ? 2 : 1;
+    pk.frame_x = rc.out_x, pk.frame_y = rc.out_y, pk.frame_w = rc.out_maxw, pk.frame_h = rc.out_maxh;
+    for (int k = 0; k < 3; k++)
+      pk.border10[k] = ((uint32_t) rc.border[k + 1] * 257u) >> 6;          /* setup_borderline's video_orc_splat2_u64 of the 8-bit border, then pack_v210's >> 6 */
+  }
   /* pack_Y210 / pack_Y212_LE repeat the first luma of an odd-width line's last macropixel as its second (video-format.c:849-850) - of the FRAME line: a
      rectangle of odd width that ends before the frame's right edge has the border's luma there (border_picture_positions); 2 = the packer leaves it */
   if (fo->kind == UNPACK_P422_16 && rc.fill && (eout.width & 1) && rc.out_x + eout.width < rc.out_maxw)

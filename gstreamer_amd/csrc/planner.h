@@ -144,6 +144,12 @@ struct PackPlanarParams {
   int virtual_line;     // 1: row `height` of the AYUV image holds the line past an odd-height picture as the chain delivers it (unpack clamped to the
                         // last line, chroma upsampler pairing it anew) - the last 4:2:0 chroma row averages the last line with THAT line
   DitherParams dither;  // chain_dither ahead of the pack (between chroma downsampling and packing): shift[] in unpack order (A, Y, U, V)
+  // v210 destinations with a rectangle: pack_v210 packs the FRAME line in groups of six pixels (video_converter_generic packs out_maxwidth pixels a
+  // line, :3274), so a group can hold border and picture pixels.  frame_on 1: the rectangle's rows only (fill-border off: groups that touch the
+  // picture), 2: every row of the frame, borders included (no k_fill_border for this format); the picture's first pixel sits at (frame_x, frame_y)
+  // of a frame_w x frame_h frame; border10: the border's Y, U, V as pack_v210 stores them ((v * 257) >> 6)
+  int frame_on, frame_x, frame_y, frame_w, frame_h;
+  uint32_t border10[3];
 };
 
 enum ScaleKind : int { SCALE_NONE = 0, SCALE_NEAREST = 1, SCALE_2TAP = 2, SCALE_NTAP = 3 };

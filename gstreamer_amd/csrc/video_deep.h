@@ -900,14 +900,52 @@ GSTAMD_HD void pack16_chroma_h (const PackPlanarParams &pk, const uint2 *row, in
   }
 }
 
-GSTAMD_VP int pack16_units (const PackPlanarParams &pk) { return pk.kind == UNPACK_P422_16 ? (pk.width + 1) / 2 : (pk.kind == UNPACK_V210 ? (pk.width + 5) / 6 : pk.width); }
+GSTAMD_VP int pack16_units (const PackPlanarParams &pk)
+{
+  if (pk.kind == UNPACK_V210)
+    return ((pk.frame_on ? pk.frame_w : pk.width) + 5) / 6;          /* groups of the frame line */
+  return pk.kind == UNPACK_P422_16 ? (pk.width + 1) / 2 : pk.width;
+}
+// rows of k_pack16_packed's grid (PackPlanarParams::frame_on 2: the frame's)
+GSTAMD_VP int pack16_rows (const PackPlanarParams &pk) { return pk.kind == UNPACK_V210 && pk.frame_on == 2 ? pk.frame_h : pk.height; }
 
 GSTAMD_HD void pack16_packed_body (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride,
     uint8_t *__restrict__ dst, int dstride, int unit, int y)
 {
   const int w = pk.width;
-  if (y >= pk.height || unit >= pack16_units (pk))
+  if (y >= pack16_rows (pk) || unit >= pack16_units (pk))
     return;
+  if (pk.kind == UNPACK_V210 && pk.frame_on) {
+    /* the frame line's group `unit` (PackPlanarParams::frame_on): pixels left and right of the picture - and every pixel of the rows above and below
+       it - are the border's; dst is the frame's first row (2) or the rectangle's (1) */
+    const int yp = pk.frame_on == 2 ? y - pk.frame_y : y;
+    const bool in_row = yp >= 0 && yp < pk.height;
+    const int x_lo = 6 * unit - pk.frame_x;                 /* picture pixel of the group's first sample */
+    if (pk.frame_on == 1 && (x_lo + 6 <= 0 || x_lo >= w))
+      return;
+    const uint2 *prow = (const uint2 *) (src + (size_t) (in_row ? yp : 0) * sstride);
+    uint32_t yy[6], uu[3], vv[3];
+    for (int j = 0; j < 6; j++) {
+      const int x = x_lo + j;
+      const bool in_frame = 6 * unit + j < pk.frame_w, in_pic = in_row && x >= 0 && x < w;
+      yy[j] = !in_frame ? 0u : (in_pic ? (uint32_t) dither16_comp (dt, 1, (int) (prow[x].x >> 16), x, yp) >> 6 : pk.border10[0]);
+      if (!(j & 1)) {
+        uu[j >> 1] = in_frame ? pk.border10[1] : 0u, vv[j >> 1] = in_frame ? pk.border10[2] : 0u;
+        if (in_frame && in_pic) {
+          int u, v;
+          pack16_chroma_h (pk, prow, w, x, &u, &v);
+          uu[j >> 1] = (uint32_t) dither16_comp (dt, 2, u, x, yp) >> 6;
+          vv[j >> 1] = (uint32_t) dither16_comp (dt, 3, v, x, yp) >> 6;
+        }
+      }
+    }
+    uint32_t *d = (uint32_t *) (dst + (size_t) y * dstride) + 4 * unit;
+    d[0] = uu[0] | (yy[0] << 10) | (vv[0] << 20);
+    d[1] = yy[1] | (uu[1] << 10) | (yy[2] << 20);
+    d[2] = vv[1] | (yy[3] << 10) | (uu[2] << 20);
+    d[3] = yy[4] | (vv[2] << 10) | (yy[5] << 20);
+    return;
+  }
   const uint2 *row = (const uint2 *) (src + (size_t) y * sstride);
   if (pk.kind == UNPACK_Y410) {
     const uint2 px = row[unit];

@@ -321,6 +321,16 @@ VIDEO_CASES = [
     ("i422_12_y212_border_shared_macropixel", "I422_12LE", 45, 28, "Y212_LE", 65, 20, dict(dest_x=30, dest_y=7, dest_width=25, dest_height=7), None, "jpeg", "random"),
     ("bgrx_y210_border_shared_odd_frame", "BGRx", 65, 18, "Y210", 65, 18, dict(dest_x=4, dest_y=3, dest_width=59, dest_height=8, border_argb=0x9749f0c7), None, "jpeg", "random"),
     ("bgrx_y210_border_rect_reaches_odd_frame_edge", "BGRx", 65, 18, "Y210", 65, 18, dict(dest_x=4, dest_y=3, dest_width=61, dest_height=8, border_argb=0x9749f0c7), None, "jpeg", "random"),
+    # v210: unpack_v210 takes no horizontal offset (a crop of a v210 source starts at the line's first pixel whatever src-x says); pack_v210 packs the
+    # frame line in groups of six pixels - rectangles inside a v210 frame share groups with the border (PackPlanarParams::frame_on)
+    ("v210_bgra_src_x_ignored", "v210", 48, 16, "BGRA", 40, 16, dict(src_x=6, src_width=40), None, None, "random"),
+    ("v210_bgra_crop_src_x_ignored_lanczos", "v210", 48, 16, "BGRA", 40, 16, dict(LAN, src_x=5, src_y=3, src_width=31, src_height=9), None, None, "random"),
+    ("v210_i420_crop_src_x_ignored_scaled", "v210", 48, 16, "I420", 30, 10, dict(src_x=8, src_y=2, src_width=33, src_height=11), None, None, "random"),
+    ("bgra_v210_rect_in_groups", "BGRA", 40, 16, "v210", 48, 16, dict(dest_x=6, dest_width=40), None, None, "random"),
+    ("bgra_v210_rect_border_colour", "BGRA", 40, 16, "v210", 50, 20, dict(dest_x=4, dest_y=3, dest_width=31, dest_height=11, border_argb=0x9749f0c7), None, None, "random"),
+    ("p010_v210_rect_lanczos_dither", "P010_10LE", 40, 16, "v210", 61, 20, dict(LAN, dest_x=9, dest_y=0, dest_width=52, dest_height=19, border_argb=0x1749f0c7, dither_quantization=8), None, None, "random"),
+    ("y444_v210_rect_bottom_border", "Y444", 44, 6, "v210", 44, 6, dict(dest_x=10, dest_y=0, dest_width=20, dest_height=5), None, None, "random"),
+    ("v210_v210_crop_rect_scaled", "v210", 41, 17, "v210", 38, 26, dict(src_x=4, src_y=2, src_width=30, src_height=12, dest_x=8, dest_y=5, dest_width=21, dest_height=17, border_argb=0x80aa5533), None, None, "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),
@@ -901,8 +911,6 @@ VIDEO_REFUSED = [
     ("NV12", 64, 64, "P010_10LE", 64, 64, dict(dither_method="sierra-lite")),           # error diffusion on 16-bit lines
     ("I420", 48, 16, "v210", 48, 16, {}),                # the reference's own v210 fastpaths (convert_I420_v210 ...: samples shifted, not widened) are not built
     ("v210", 48, 16, "UYVY", 48, 16, {}),
-    ("v210", 48, 16, "BGRA", 40, 16, dict(src_x=6, src_width=40)),          # unpack_v210 ignores the horizontal offset
-    ("BGRA", 40, 16, "v210", 48, 16, dict(dest_x=6, dest_width=40)),        # a rectangle inside 6-pixel groups
     ("UYVY", 24, 11, "UYVY", 81, 29, dict(resampler_method="sinc", dest_x=37, dest_y=3, dest_width=40, dest_height=23)),   # convert_fill_border's group 42 with an odd frame width (plane scaler)
     ("Y42B", 31, 16, "UYVY", 40, 20, dict(dest_x=4, dest_y=2, dest_width=31, dest_height=16)),            # ... with the picture ending inside a macropixel (fastpath convert_Y42B_UYVY)
     ("UYVY", 64, 16, "GRAY8", 64, 16, dict(src_y=4, src_height=8)),         # convert_UYVY_GRAY8 ignores crop origins

@@ -1070,7 +1070,8 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         stage ((mid_done ? 0 : GAMMA_STAGE_MID) | GAMMA_STAGE_ENC, cur.p, cur.stride, mid_b.data (), out_w * 4, out_w, out_h);
       }
     }
-    if ((g.store64 || g.pack16) && p.rect.fill)
+    const bool frame_pack = g.pack16 && g.pack.kind == UNPACK_V210 && g.pack.frame_on == 2;          /* as convert_gamma of capi_video.cpp */
+    if ((g.store64 || g.pack16) && p.rect.fill && !frame_pack)
       emu_fill_borders (p, out, dst);
     if (g.store64) {
       uint8_t *rect = dst + out->offset[0] + plane_origin (p.fout, 0, p.rect.out_x, p.rect.out_y, out->stride[0]);
@@ -1086,11 +1087,11 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       DstPlanes16 d;
       memset (&d, 0, sizeof (d));
       for (int i = 0; i < out->n_planes && i < 3; i++) {
-        d.p[i] = dst + out->offset[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]);
+        d.p[i] = dst + out->offset[i] + (frame_pack ? 0 : plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]));
         d.stride[i] = out->stride[i];
       }
       if (g.pack.kind == UNPACK_P422_16 || g.pack.kind == UNPACK_Y410 || g.pack.kind == UNPACK_V210) {          /* k_pack16_packed */
-        for (int y = 0; y < g.pack.height; y++)
+        for (int y = 0; y < pack16_rows (g.pack); y++)
           for (int un = 0; un < (pack16_units (g.pack) + 255) / 256 * 256; un++)
             pack16_packed_body (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, d.p[0], d.stride[0], un, y);
         return GSTAMD_OK;

@@ -331,6 +331,14 @@ VIDEO_CASES = [
     ("p010_v210_rect_lanczos_dither", "P010_10LE", 40, 16, "v210", 61, 20, dict(LAN, dest_x=9, dest_y=0, dest_width=52, dest_height=19, border_argb=0x1749f0c7, dither_quantization=8), None, None, "random"),
     ("y444_v210_rect_bottom_border", "Y444", 44, 6, "v210", 44, 6, dict(dest_x=10, dest_y=0, dest_width=20, dest_height=5), None, None, "random"),
     ("v210_v210_crop_rect_scaled", "v210", 41, 17, "v210", 38, 26, dict(src_x=4, src_y=2, src_width=30, src_height=12, dest_x=8, dest_y=5, dest_width=21, dest_height=17, border_argb=0x80aa5533), None, None, "random"),
+    # odd-height 4:2:0 -> 4:2:0 through the composite plans (10 / 12-bit ends): exact where the line past the picture is not consumed (no vertical
+    # downsampler / upsampler in the chain) or a vertical size change puts the scaler's clamped last line there
+    ("oddh_i420_12_p016_downsample_only", "I420_12LE", 37, 7, "P016_LE", 37, 7, dict(LAN, chroma_mode="downsample-only"), None, "cosited", "random"),
+    ("oddh_p012_i420_10_crop_grow_lanczos", "P012_LE", 36, 17, "I420_10LE", 88, 27, dict(LAN, src_x=15, src_y=2, src_width=20, src_height=7), None, None, "random"),
+    ("oddh_i420_10_nv12_rect_matrix", "I420_10LE", 6, 34, "NV12", 6, 34, dict(LAN, matrix_mode="input-only", dest_x=1, dest_y=2, dest_width=1, dest_height=13), "bt709", "cosited", "random"),
+    ("oddh_i420_p012_rect_grow_cubic", "I420", 13, 5, "P012_LE", 68, 15, dict(resampler_method="cubic", chroma_mode="full", dest_x=6, dest_y=6, dest_width=18, dest_height=7), None, None, "random"),
+    ("oddh_i420_12_i420_10_grow_alpha", "I420_12LE", 43, 4, "I420_10LE", 73, 49, dict(max_taps=4, alpha_mode="mult", alpha_value=0.25), "bt601", "jpeg", "random"),
+    ("oddh_p016_nv12_upsample_only", "P016_LE", 55, 35, "NV12", 55, 35, dict(alpha_mode="mult", alpha_value=0.25, chroma_mode="upsample-only"), "bt709", "mpeg2", "random"),
     ("nv12_bgra_up2_bilinear", "NV12", 320, 180, "BGRA", 640, 360, LIN, None, None, "random"),
     ("nv12_bgra_up2_cubic", "NV12", 320, 180, "BGRA", 640, 360, {}, None, None, "random"),
     ("nv12_bgra_anamorphic_lanczos", "NV12", 321, 181, "BGRA", 100, 300, LAN, None, None, "random"),

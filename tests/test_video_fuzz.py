@@ -100,7 +100,7 @@ def test_hip_random_conversions_match_reference_or_are_refused(native_lib, gpu, 
 @pytest.mark.parametrize("seed,rects", [(9101, False), (9102, True)])
 def test_share_of_defined_and_refused_draws_stays_bounded(emu_lib, ref, seed, rects):
     """1500 draws: no bad ones, and the plans that step aside - refused, or announced as "the reference's own output is undefined here" -
-    stay a bounded share (measured at the end of round 4: defined 9.7-11.7 %, refused 2-9 %); a planner change that widens one of those
+    stay a bounded share (measured at the end of round 4: defined 9.5-12 %, refused 1-2.2 %); a planner change that widens one of those
     classes by accident shows up here"""
     emu = fuzz_video.load_emu()
     rnd = random.Random(seed)
@@ -111,5 +111,5 @@ def test_share_of_defined_and_refused_draws_stays_bounded(emu_lib, ref, seed, re
         count[verdict] += 1
     assert count["bad"] == 0, count
     assert count["defined"] <= 0.13 * 1500, count
-    assert count["refused"] <= 0.10 * 1500, count
+    assert count["refused"] <= 0.05 * 1500, count
     assert count["ok"] >= 0.78 * 1500, count

@@ -642,6 +642,9 @@ static int bind_scratch (GstAmdVideoConverter *c, void *stream)
   return alloc_scratch (c);
 }
 
+static int frame_planes_plan_order (GstAmdVideoConverter *c, const void *const src_planes[GSTAMD_VIDEO_MAX_PLANES],
+    const int32_t src_stride[GSTAMD_VIDEO_MAX_PLANES], void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
+    const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES], void *stream_);
 // the chain up to a packed 4-byte image: unpack, chroma upsample, scale, matrix, alpha, byte order
 static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t *dst, int dstride, hipStream_t stream);
 static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
@@ -697,7 +700,7 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
     c->sub_in->post_lut = c->gamma_comp_dev;
     c->sub_in->post_lut_keep = p.fout->pos[0];
     c->sub_in->post_lut_done = false;
-    const int dr = gstamd_video_converter_frame_planes (c->sub_in, src_planes, src_stride, dest_planes, dest_stride, stream);
+    const int dr = frame_planes_plan_order (c->sub_in, src_planes, src_stride, dest_planes, dest_stride, stream);
     if (dr != GSTAMD_OK || c->sub_in->post_lut_done)
       return dr;
     const int ds = dest_stride ? dest_stride[0] : p.out_info.stride[0];
@@ -708,7 +711,7 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   if (g.fused) {
     c->sub_in->hook = gd;
     c->sub_in->hook_on = true;
-    return gstamd_video_converter_frame_planes (c->sub_in, src_planes, src_stride, dest_planes, dest_stride, stream);
+    return frame_planes_plan_order (c->sub_in, src_planes, src_stride, dest_planes, dest_stride, stream);
   }
   Enc16Params ep16;
   if (enc16_params (p, &ep16) && !tuning_on ("GSTAMD_NO_ENCODE16") && src_planes[0]) {
@@ -785,7 +788,7 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   } else {
     void *ma[GSTAMD_VIDEO_MAX_PLANES] = {c->gamma_mid_a, nullptr, nullptr, nullptr};
     const int32_t mas[GSTAMD_VIDEO_MAX_PLANES] = {in_w * 4, 0, 0, 0};
-    if ((r = gstamd_video_converter_frame_planes (c->sub_in, src_planes, src_stride, ma, mas, stream)) != GSTAMD_OK)
+    if ((r = frame_planes_plan_order (c->sub_in, src_planes, src_stride, ma, mas, stream)) != GSTAMD_OK)
       return r;
     if (n == 0 && !g.pack16 && !g.store64) {
       /* nothing between the tables: one launch from image to image */
@@ -904,10 +907,38 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   }
   const void *mb[GSTAMD_VIDEO_MAX_PLANES] = {c->gamma_mid_b, nullptr, nullptr, nullptr};
   const int32_t mbs[GSTAMD_VIDEO_MAX_PLANES] = {out_w * 4, 0, 0, 0};
-  return gstamd_video_converter_frame_planes (c->sub_out, mb, mbs, dest_planes, dest_stride, stream);
+  return frame_planes_plan_order (c->sub_out, mb, mbs, dest_planes, dest_stride, stream);
 }
 
+// The public entry takes the planes as a GstVideoFrame carries them in data[] / GstVideoMeta: GBR's are G, B, R.  Inside a plan they are
+// R, G, B (format_plan_planes) - what _frame / _frames derive from the plan's own offsets and what every launcher expects.
 int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *const src_planes[GSTAMD_VIDEO_MAX_PLANES],
+    const int32_t src_stride[GSTAMD_VIDEO_MAX_PLANES], void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
+    const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES], void *stream)
+{
+  if (!c || !src_planes || !dest_planes)
+    return set_error (GSTAMD_ERR_INVALID, "NULL converter or frame");
+  const bool in_gbr = c->plan.fin && c->plan.fin->format == GSTAMD_VIDEO_FORMAT_GBR;
+  const bool out_gbr = c->plan.fout && c->plan.fout->format == GSTAMD_VIDEO_FORMAT_GBR;
+  if (!in_gbr && !out_gbr)
+    return frame_planes_plan_order (c, src_planes, src_stride, dest_planes, dest_stride, stream);
+  const void *sp[GSTAMD_VIDEO_MAX_PLANES];
+  void *dp[GSTAMD_VIDEO_MAX_PLANES];
+  int32_t ss[GSTAMD_VIDEO_MAX_PLANES], ds[GSTAMD_VIDEO_MAX_PLANES];
+  static const int gbr_of_rgb[GSTAMD_VIDEO_MAX_PLANES] = {2, 0, 1, 3};          /* plan plane R, G, B <- frame plane 2, 0, 1 */
+  for (int i = 0; i < GSTAMD_VIDEO_MAX_PLANES; i++) {
+    const int si = in_gbr ? gbr_of_rgb[i] : i, di = out_gbr ? gbr_of_rgb[i] : i;
+    sp[i] = src_planes[si];
+    dp[i] = dest_planes[di];
+    if (src_stride)
+      ss[i] = src_stride[si];
+    if (dest_stride)
+      ds[i] = dest_stride[di];
+  }
+  return frame_planes_plan_order (c, sp, src_stride ? ss : nullptr, dp, dest_stride ? ds : nullptr, stream);
+}
+
+static int frame_planes_plan_order (GstAmdVideoConverter *c, const void *const src_planes[GSTAMD_VIDEO_MAX_PLANES],
     const int32_t src_stride[GSTAMD_VIDEO_MAX_PLANES], void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
     const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES], void *stream_)
 {
@@ -1697,7 +1728,7 @@ int gstamd_video_converter_frame (GstAmdVideoConverter *c, const void *src, void
     sp[i] = (const uint8_t *) src + c->plan.in_info.offset[i];
   for (int i = 0; i < c->plan.out_info.n_planes; i++)
     dp[i] = (uint8_t *) dest + c->plan.out_info.offset[i];
-  return gstamd_video_converter_frame_planes (c, sp, nullptr, dp, nullptr, stream);
+  return frame_planes_plan_order (c, sp, nullptr, dp, nullptr, stream);
 }
 
 int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const void *const *src, void *const *dest, void *stream_)
@@ -2201,6 +2232,20 @@ void gstamd_host_free (void *ptr)
 {
   if (ptr)
     (void) hipHostFree (ptr);
+}
+
+int gstamd_host_is_pinned (const void *ptr)
+{
+  if (!ptr)
+    return 0;
+  hipPointerAttribute_t attr;
+  memset (&attr, 0, sizeof (attr));
+  const hipError_t e = hipPointerGetAttributes (&attr, ptr);
+  if (e != hipSuccess) {
+    (void) hipGetLastError ();          /* pageable memory: "invalid value" is the answer, not a failure */
+    return 0;
+  }
+  return attr.type == hipMemoryTypeHost ? 1 : 0;
 }
 
 int gstamd_device_copy (void *dst_device, const void *src_device, size_t size, void *stream)

@@ -2347,10 +2347,15 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   }
   plan->algorithmic_bytes = picture_bytes (fi, in_w, in_h) + picture_bytes (fo, out_w, out_h);
   deep_planes_try (in, out, plan, g.pack.down_h || g.pack.down_v || plan->front.chroma_h != CHROMA_H_NONE || plan->front.chroma_v2);
-  if (g.planes_fast) {
+  /* k_deep_planes writes whole planes from (0, 0) and knows no border: a destination rectangle (an origin, a frame wider / taller than the
+     picture, borders to fill) goes through the pack16 tail below, which places the picture and fills convert_fill_border's lines */
+  const bool out_rect = cfg.dest_x || cfg.dest_y || plan->rect.fill || plan->rect.out_x || plan->rect.out_y ||
+      (plan->rect.out_maxw && (plan->rect.out_maxw != out_w || plan->rect.out_maxh != out_h));
+  if (g.planes_fast && !out_rect) {
     plan->description = std::string ("deep_planes[") + fi->name + "->" + fo->name + (g.dither16.on ? ",dither" : "") + "]";
     return GSTAMD_OK;
   }
+  g.planes_fast = false;
   if (g.store64) {
     plan->description = std::string ("deep_out[") + fi->name + "->" + fo->name + (g.src16 ? ",front16" : ",widen") + (g.prim.has_matrix ? ",matrix16" : "") +
         (plan->passes.empty () ? "" : g.shrink ? ",scale16(first)" : ",scale16(last)") + ",store64]";

@@ -243,6 +243,7 @@ bool front_hscale16_usable (const FrontParams &f)
 
 hipError_t launch_front_hscale16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ScaleDev &sd, uint8_t *dst, int dstride, int ow, hipStream_t stream)
 {
+  video_frame_list_touch (dst);          /* takes no frame list: says so should it ever write a frame (today: scratch images only) */
   const dim3 grid ((ow + 255) / 256, f.height);
   switch (deep_front4_variant (f)) {
     case 0: hipLaunchKernelGGL ((k_front_hscale16<0, CHROMA_H_NONE>), grid, dim3 (256), 0, stream, f, pl, vpair_dev, sd, dst, dstride, ow); break;
@@ -263,6 +264,7 @@ __global__ __launch_bounds__ (256) void k_front16_fast (FrontParams f, Planes pl
 
 hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, uint8_t *img, int istride, hipStream_t stream)
 {
+  video_frame_list_touch (img);
   const int variant = (f.width % 4) == 0 && ((uintptr_t) img % 16) == 0 && (istride % 16) == 0 && !tuning_on ("GSTAMD_NO_CONVERT16_FAST") ? deep_front4_variant (f) : -1;
   if (variant >= 0) {
     const dim3 fgrid ((f.width / 4 + 255) / 256, f.height);
@@ -284,6 +286,7 @@ hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vp
 hipError_t launch_scale16 (const Deep16Image &im, const ScaleDev &sd, bool horizontal, uint8_t *dst, int dstride, int ow, int oh, const Deep16Params *d,
     const PostParams *post, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   dim3 grid ((ow + 255) / 256, oh);
   if (d)
     hipLaunchKernelGGL (k_scale16_final, grid, dim3 (256), 0, stream, im, sd, horizontal ? 1 : 0, *d, *post, dst, dstride, ow, oh);
@@ -303,6 +306,7 @@ __global__ __launch_bounds__ (256) void k_gamma_stage (GammaDev g, int mask, con
 
 hipError_t launch_gamma_stage (const GammaDev &g, int mask, const uint8_t *src, int sstride, uint8_t *dst, int dstride, int w, int h, hipStream_t stream)
 {
+  video_frame_list_touch (dst);
   dim3 grid ((w + 255) / 256, h);
   hipLaunchKernelGGL (k_gamma_stage, grid, dim3 (256), 0, stream, g, mask, src, sstride, dst, dstride, w, h);
   return hipGetLastError ();

@@ -244,6 +244,17 @@ class VideoConverter:
     def frame(self, src, dest, stream=None):
         _check(lib().gstamd_video_converter_frame(self._h, _ptr(src), _ptr(dest), stream))
 
+    def frame_planes(self, src_planes, src_strides, dest_planes, dest_strides, stream=None):
+        """One device pointer and pitch per plane, in the FRAME's plane order (GstVideoFrame.data[]: GBR's planes are G, B, R)."""
+        def arr(t, xs):
+            xs = list(xs) + [0] * (4 - len(xs))
+            return (t * 4)(*xs)
+        sp = arr(C.c_void_p, [_ptr(x) for x in src_planes])
+        dp = arr(C.c_void_p, [_ptr(x) for x in dest_planes])
+        ss = arr(C.c_int32, src_strides) if src_strides is not None else None
+        ds = arr(C.c_int32, dest_strides) if dest_strides is not None else None
+        _check(lib().gstamd_video_converter_frame_planes(self._h, sp, ss, dp, ds, stream))
+
     def frames(self, srcs, dests, stream=None):
         """Convert a list of frames (GstBufferList analogue) - one launch when the plan allows."""
         n = len(srcs)

@@ -333,6 +333,9 @@ int gstamd_event_query (void *event);            /* 1: reached, 0: not yet, < 0:
 /* page-locked host memory for system-memory pads (pageable memory makes hipMemcpyAsync synchronous and slow) */
 void *gstamd_host_alloc (size_t size);
 void gstamd_host_free (void *ptr);
+/* 1 when `ptr` lies in page-locked host memory known to HIP (hipHostMalloc / hipHostRegister) - a hipMemcpyAsync from it is only QUEUED
+ * when the call returns; 0 for pageable memory, where the call returns once the source has been staged */
+int gstamd_host_is_pinned (const void *ptr);
 int gstamd_device_copy (void *dst_device, const void *src_device, size_t size, void *stream);
 int gstamd_device_upload_async (void *dst_device, const void *src_host, size_t size, void *stream);
 int gstamd_device_download_async (void *dst_host, const void *src_device, size_t size, void *stream);

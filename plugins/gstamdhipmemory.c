@@ -636,16 +636,45 @@ amd_pending_reads_retire (GstAmdHipPendingReads * p, gboolean wait)
   }
 }
 
+/* at most this many transfers stay un-waited-for: a source that runs ahead does not pile its buffers up here */
+#define AMD_PENDING_READS_MAX 4
+
+static gboolean
+amd_buffer_pool_is_tight (GstBuffer * buf)
+{
+  GstBufferPool *pool = buf->pool;
+  GstStructure *config;
+  guint size = 0, min = 0, max = 0;
+  gboolean tight = FALSE;
+
+  if (!pool)
+    return FALSE;
+  config = gst_buffer_pool_get_config (pool);
+  if (config) {
+    if (gst_buffer_pool_config_get_params (config, NULL, &size, &min, &max))
+      tight = max != 0 && max <= 3;
+    gst_structure_free (config);
+  }
+  return tight;
+}
+
 void
-gst_amd_hip_pending_reads_hold (GstAmdHipPendingReads * p, GstBuffer * buf, gpointer stream)
+gst_amd_hip_pending_reads_hold (GstAmdHipPendingReads * p, GstBuffer * buf, gconstpointer host, gpointer stream)
 {
   AmdPendingRead *r;
-  gpointer ev = gstamd_event_new ();
-  if (!ev || gstamd_event_record (ev, stream) != GSTAMD_OK) {
-    /* no event: the safe answer is to wait for the stream here */
-    if (ev)
+  gpointer ev;
+
+  gst_amd_hip_pending_reads_retire (p);
+  if (!gstamd_host_is_pinned (host))
+    return;                     /* pageable: hipMemcpyAsync returned with the source staged */
+  ev = gstamd_event_new ();
+  if (!ev || gstamd_event_record (ev, stream) != GSTAMD_OK || amd_buffer_pool_is_tight (buf)) {
+    /* no event, or a pool that cannot spare the buffer: the safe answer is to wait for the transfer here */
+    if (ev) {
+      gstamd_event_synchronize (ev);
       gstamd_event_free (ev);
-    gstamd_stream_synchronize (stream);
+    } else
+      gstamd_stream_synchronize (stream);
     return;
   }
   r = g_new0 (AmdPendingRead, 1);
@@ -653,6 +682,22 @@ gst_amd_hip_pending_reads_hold (GstAmdHipPendingReads * p, GstBuffer * buf, gpoi
   r->buf = gst_buffer_ref (buf);
   g_mutex_lock (&p->lock);
   g_queue_push_tail (&p->items, r);
+  while (g_queue_get_length (&p->items) > AMD_PENDING_READS_MAX) {
+    AmdPendingRead *o = g_queue_pop_head (&p->items);
+    gstamd_event_synchronize (o->event);
+    gstamd_event_free (o->event);
+    gst_buffer_unref (o->buf);
+    g_free (o);
+  }
+  g_mutex_unlock (&p->lock);
+}
+
+void
+gst_amd_hip_pending_reads_retire (GstAmdHipPendingReads * p)
+{
+  if (!p)
+    return;
+  g_mutex_lock (&p->lock);
   amd_pending_reads_retire (p, FALSE);
   g_mutex_unlock (&p->lock);
 }
@@ -660,6 +705,8 @@ gst_amd_hip_pending_reads_hold (GstAmdHipPendingReads * p, GstBuffer * buf, gpoi
 void
 gst_amd_hip_pending_reads_drain (GstAmdHipPendingReads * p)
 {
+  if (!p)
+    return;
   g_mutex_lock (&p->lock);
   amd_pending_reads_retire (p, TRUE);
   g_mutex_unlock (&p->lock);

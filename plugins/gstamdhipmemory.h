@@ -98,7 +98,11 @@ void gst_amd_hip_select_device (gint device_id);
  * it stays referenced until an event recorded behind the copy has fired. */
 typedef struct _GstAmdHipPendingReads GstAmdHipPendingReads;
 GstAmdHipPendingReads *gst_amd_hip_pending_reads_new (void);
-void gst_amd_hip_pending_reads_hold (GstAmdHipPendingReads * p, GstBuffer * buf, gpointer stream);     /* right after queueing the copy */
+/* right after queueing the copy from `host` (the mapped bytes of `buf`).  Pageable memory is not held (the copy call has staged it).  A
+ * buffer of a bounded pool (max-buffers <= 3: v4l2-style fixed pools) is waited for here instead of held: upstream would block in
+ * acquire_buffer while this element waits for the next buffer before letting go of the last. */
+void gst_amd_hip_pending_reads_hold (GstAmdHipPendingReads * p, GstBuffer * buf, gconstpointer host, gpointer stream);
+void gst_amd_hip_pending_reads_retire (GstAmdHipPendingReads * p);      /* drop the references of the transfers that are over; never waits */
 void gst_amd_hip_pending_reads_drain (GstAmdHipPendingReads * p);        /* wait for every transfer, drop the references (stop, flush) */
 void gst_amd_hip_pending_reads_free (GstAmdHipPendingReads * p);
 

@@ -212,6 +212,9 @@ tr_copy_planes (GstAmdHipTransfer * s, gboolean upload, guint8 * dev, guint8 * h
   for (k = 0; k < GST_VIDEO_INFO_N_PLANES (&s->info) && r == GSTAMD_OK; k++) {
     gsize row_bytes, rows;
     tr_plane_geometry (&s->info, k, &row_bytes, &rows);
+    /* a complex format's row is its default layout's row, padding included: a tightly packed producer's own pitch may be smaller */
+    if (m->stride[k] > 0 && row_bytes > (gsize) m->stride[k])
+      row_bytes = (gsize) m->stride[k];
     if (rows && m->offset[k] + (rows - 1) * (gsize) m->stride[k] + row_bytes > host_size)
       return GSTAMD_ERR_INVALID;
     if (upload)
@@ -253,7 +256,7 @@ tr_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
          * referenced - out of its pool - until the transfer is over */
         if (!s->reads)
           s->reads = gst_amd_hip_pending_reads_new ();
-        gst_amd_hip_pending_reads_hold (s->reads, inbuf, s->stream);
+        gst_amd_hip_pending_reads_hold (s->reads, inbuf, im.data, s->stream);
       }
       gst_memory_unmap (omem, &om);
     }
@@ -287,6 +290,19 @@ tr_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
     return GST_FLOW_ERROR;
   }
   return GST_FLOW_OK;
+}
+
+/* input buffers a queued upload still reads are not kept across a flush or the end of the stream */
+static gboolean
+tr_sink_event (GstBaseTransform * trans, GstEvent * event)
+{
+  GstAmdHipTransfer *s = AMD_TR (trans);
+
+  if (GST_EVENT_TYPE (event) == GST_EVENT_FLUSH_STOP || GST_EVENT_TYPE (event) == GST_EVENT_EOS || GST_EVENT_TYPE (event) == GST_EVENT_GAP) {
+    gst_amd_hip_select_device (s->device_id);
+    gst_amd_hip_pending_reads_drain (s->reads);
+  }
+  return GST_BASE_TRANSFORM_CLASS (gst_amd_hip_transfer_parent_class)->sink_event (trans, event);
 }
 
 static gboolean
@@ -334,6 +350,7 @@ gst_amd_hip_transfer_class_init (GstAmdHipTransferClass * klass)
   tc->transform = GST_DEBUG_FUNCPTR (tr_transform);
   tc->transform_meta = GST_DEBUG_FUNCPTR (tr_transform_meta);
   tc->stop = GST_DEBUG_FUNCPTR (tr_stop);
+  tc->sink_event = GST_DEBUG_FUNCPTR (tr_sink_event);
   klass->upload = TRUE;
 }
 

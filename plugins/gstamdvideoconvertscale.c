@@ -1404,6 +1404,11 @@ amd_vcs_sink_event (GstBaseTransform * trans, GstEvent * event)
 
   if (s->batch && (GST_EVENT_IS_SERIALIZED (event) || GST_EVENT_TYPE (event) == GST_EVENT_FLUSH_START))
     amd_vcs_batch_flush (s->batch, FALSE);
+  /* input buffers a queued upload still reads are not kept across a flush or the end of the stream */
+  if (GST_EVENT_TYPE (event) == GST_EVENT_FLUSH_STOP || GST_EVENT_TYPE (event) == GST_EVENT_EOS || GST_EVENT_TYPE (event) == GST_EVENT_GAP) {
+    gst_amd_hip_select_device (s->device_id);
+    gst_amd_hip_pending_reads_drain (s->reads);
+  }
   return GST_BASE_TRANSFORM_CLASS (gst_amd_vcs_parent_class)->sink_event (trans, event);
 }
 
@@ -1428,6 +1433,7 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
   if (s->stats)
     ta = g_get_monotonic_time ();
   gst_amd_hip_select_device (s->device_id);       /* the streaming thread's current device */
+  gst_amd_hip_pending_reads_retire (s->reads);
   if (s->batch && s->batch_limit > 1) {
     if (in_dev && out_dev && buffer_is_plain_hip_frame (inbuf, &s->in_info) && buffer_is_plain_hip_frame (outbuf, &s->out_info)) {
       if (amd_vcs_batch_add (s, inbuf, outbuf)) {
@@ -1461,7 +1467,7 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
      * upstream (propose_allocation) - it is only QUEUED: the input stays referenced, out of its pool, until the transfer is over */
     if (!s->reads)
       s->reads = gst_amd_hip_pending_reads_new ();
-    gst_amd_hip_pending_reads_hold (s->reads, inbuf, stream);
+    gst_amd_hip_pending_reads_hold (s->reads, inbuf, imap.data, stream);
     src = s->d_in[k];
   }
   /* destination */
@@ -1502,6 +1508,7 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
     r = gstamd_device_download_async (omap.data, s->d_out[k], omap.size, stream);
     if (r == GSTAMD_OK)
       r = gstamd_stream_synchronize (stream);         /* the CPU is about to look at outbuf */
+    gst_amd_hip_pending_reads_retire (s->reads);      /* ... and this stream's upload is over: its input goes back to its pool now */
   }
 
   if (out_dev)

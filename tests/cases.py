@@ -903,6 +903,47 @@ VIDEO_CASES = [
     ("dither64_nv12_argb64_gamma_q4", "NV12", 64, 48, "ARGB64", 64, 48, dict(dither_quantization=4, gamma_mode="remap"), "bt709>1:0:8:1", None, "random"),
 ]
 
+# Round 5: the plane-to-plane copies between 10 / 12 / 16-bit planar formats (deep_planes) know no destination rectangle: with an origin,
+# a larger frame or borders the plan takes the pack16 tail (round 4 shipped these un-refused and wrong: the picture landed at (0, 0) and
+# the borders were never written - fuzz seed 61030 draw 47).  Every depth pair x {whole frame, rectangle with borders, rectangle without
+# fill} x {dither off / on} x picture widths {1, 2, 17}.  (fill-border = FALSE: the reference's generic chain packs whatever its line buffers
+# held beside the rectangle, its frames differ from run to run - tests/test_video_host.py compares the bytes the picture decides.)
+def _deep_plane_sweep():
+    out = []
+    fam = [("Y444_10LE", 10), ("Y444_12LE", 12), ("Y444_16LE", 16)]
+    for fi, bi in fam:
+        for fo, bo in fam:
+            for w in (1, 2, 17):
+                for rect in ("whole", "border"):
+                    for dq in (1, 2):
+                        cfg = {}
+                        ow, oh = w, 11
+                        if rect != "whole":
+                            ow, oh = w + 13, 27
+                            cfg.update(dest_x=4, dest_y=5, dest_width=w, dest_height=11)
+                            if w == 2:
+                                cfg["border_argb"] = 0x80c03577
+                        if dq > 1:
+                            cfg["dither_quantization"] = dq
+                        out.append(("deepplanes_%d_%d_w%d_%s_q%d" % (bi, bo, w, rect, dq), fi, w, 11, fo, ow, oh, cfg, None, None, "random"))
+    # the 4:2:0 / 4:2:2 / semi-planar members of the same plan, with a rectangle
+    for fi, fo, w, h in (("I420_10LE", "I420_12LE", 18, 10), ("I422_12LE", "I422_10LE", 17, 9), ("P010_10LE", "I420_10LE", 16, 12),
+                         ("I420_10LE", "P010_10LE", 9, 8), ("P016_LE", "P012_LE", 20, 8), ("Y444_10LE", "Y444_12LE", 8, 8)):
+        for dq in (1, 4):
+            cfg = dict(dest_x=4, dest_y=6 if fo != "Y444_12LE" else 5, dest_width=w, dest_height=h)
+            if dq > 1:
+                cfg["dither_quantization"] = dq
+            out.append(("deepplanes_rect_%s_%s_q%d" % (fi.lower(), fo.lower(), dq), fi, w, h, fo, w + 24, h + 12, cfg, None, None, "random"))
+    return out
+
+
+VIDEO_CASES += _deep_plane_sweep()
+
+
+# fill-border = FALSE over the same plans: compared on the bytes the picture decides (scripts/fuzz_video.py matches_reference)
+DEEP_NOFILL = [(fi, w, 11, fo, w + 13, 27, dict(dest_x=4, dest_y=5, dest_width=w, dest_height=11, fill_border=0, **({"dither_quantization": dq} if dq > 1 else {})))
+               for fi in ("Y444_10LE", "Y444_12LE", "Y444_16LE") for fo in ("Y444_10LE", "Y444_12LE", "Y444_16LE") for w in (1, 2, 17) for dq in (1, 2)]
+
 # Cases compared on the bytes of the PICTURE only.  The reference's 4:2:2 fastpaths convert (width + 1) / 2 macropixels, so with an odd
 # width they copy one byte of source row padding into the destination row padding (video-converter.c:3409-3560, 3954-4030, ..);
 # this library writes picture bytes only.
@@ -1030,6 +1071,8 @@ def ref_config_string(ref, cfg):
             m["GstVideoResampler__max_taps"] = v
         elif k in ("envelope", "sharpness", "sharpen"):
             m["GstVideoResampler__" + k] = float(v)
+        elif k == "fill_border":
+            m["GstVideoConverter__" + k] = bool(v)          # get_opt_bool (video-converter.c:798) ignores an (int) and takes the default TRUE
         else:
             m["GstVideoConverter__" + k] = v
     return ref.config_string(**m) if m else None

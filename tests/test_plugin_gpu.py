@@ -1025,3 +1025,24 @@ def test_audioresample_element_discont_drains_and_resets(gst_env, ref):
     exp = np.concatenate(exp)
     assert out.shape == exp.shape, (out.shape, exp.shape)
     assert (out == exp).all()
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_videoconvertscale_element_gbr_planes_in_frame_order(gst_env, ref, batch):
+    """GBR through the element with system memory on both sides: the single-buffer path (batch-buffers=1) hands GstVideoFrame's planes
+    - G, B, R - to gstamd_video_converter_frame_planes; round 4 rotated the channels there while the batched path was right"""
+    env, tmp = gst_env
+    w, h, n = 322, 180, 4
+    fin, fmid, fout = tmp / ("gbr_in_%d.bgra" % batch), tmp / ("gbr_mid_%d.gbr" % batch), tmp / ("gbr_out_%d.rgba" % batch)
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=%d,height=%d ! tee name=t "
+                "t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale batch-buffers=%d ! video/x-raw,format=GBR ! tee name=u "
+                "u. ! queue ! filesink location=%s u. ! queue ! videoconvertscale batch-buffers=%d ! video/x-raw,format=RGBA,width=%d,height=%d ! filesink location=%s"
+           % (n, w, h, fin, batch, fmid, batch, w // 2, h // 2, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    mid = np.fromfile(fmid, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    a = ref.VideoConverter("BGRA", w, h, "GBR", w, h)
+    b = ref.VideoConverter("GBR", w, h, "RGBA", w // 2, h // 2, config=cases.ref_config_string(ref, cases.LIN))
+    for i in range(n):
+        assert (a.frame(src[i]) == mid[i]).all(), i
+        assert (b.frame(mid[i]) == out[i]).all(), i

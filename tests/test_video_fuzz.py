@@ -39,7 +39,7 @@ def _seed_list(spec):
     return out
 
 
-GPU_SEEDS = _seed_list(os.environ.get("GSTAMD_FUZZ_SEEDS", "101,404,505,707,909"))
+GPU_SEEDS = _seed_list(os.environ.get("GSTAMD_FUZZ_SEEDS", "101,404,505,707,909,61030"))
 
 
 @pytest.mark.gpu

@@ -512,3 +512,60 @@ def test_hip_frames_in_flight_on_several_streams_keep_their_own_scratch(native_l
     for st in streams:
         L.gstamd_stream_free(st)
     conv.free()
+
+
+@pytest.mark.parametrize("case", cases.DEEP_NOFILL, ids=lambda c: "%s_%s_w%d_q%d" % (c[0], c[3], c[1], c[6].get("dither_quantization", 1)))
+def test_hip_deep_plane_copies_without_border_fill(native_lib, gpu, ref, case):
+    """the device side of test_deep_plane_copies_without_border_fill_on_host"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_video
+    ifmt, w, h, ofmt, ow, oh, cfg = case
+    src = cases.frame_bytes(int(V.video_info(ifmt, w, h).size), "random", 4242 + w, w)
+    dst = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cfg, None, None, src)
+    ok, text = fuzz_video.matches_reference(ref, (ifmt, w, h, ofmt, ow, oh, cfg, None, None), src, dst, V.video_info(ofmt, ow, oh))
+    assert ok, text
+    assert not dst[:cfg["dest_y"] * V.video_info(ofmt, ow, oh).stride[0]].any()
+
+
+@pytest.mark.parametrize("pair", [("GBR", "BGRA"), ("BGRA", "GBR"), ("GBR", "GBR"), ("GBR", "I420"), ("NV12", "GBR"), ("GBR", "ARGB64")])
+def test_hip_frame_planes_takes_gbr_planes_in_frame_order(native_lib, gpu, ref, pair):
+    """gstamd_video_converter_frame_planes gets the planes as GstVideoFrame.data[] holds them - G, B, R for GBR (video-info.c:1030-1041) -
+    with pitches of the caller's choosing; inside a plan they are R, G, B.  (Round 4's element converted GBR with rotated channels on its
+    single-buffer path: _frame / _frames were right, _frame_planes took the caller's order for the plan's.)"""
+    import torch
+    ifmt, ofmt = pair
+    w, h, ow, oh = 70, 33, (70, 33) if ofmt != "GBR" or ifmt != "GBR" else (96, 40)
+    ow, oh = (ow, oh) if isinstance(ow, int) else ow
+    ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)
+    src = cases.frame_bytes(int(ii.size), "random", 515, w)
+    exp = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh).frame(src)
+    conv = V.VideoConverter(ii, oi)
+    # every plane in its own allocation with a wider pitch than the default layout
+    def scatter(info, fmt, data):
+        planes, strides = [], []
+        for i in range(info.n_planes):
+            rows = (int(info.size) - int(info.offset[i])) // int(info.stride[i]) if i == info.n_planes - 1 else (int(info.offset[i + 1]) - int(info.offset[i])) // int(info.stride[i])
+            pitch = int(info.stride[i]) + 64
+            t = torch.zeros(rows * pitch, dtype=torch.uint8, device=gpu)
+            if data is not None:
+                a = torch.from_numpy(data[int(info.offset[i]):int(info.offset[i]) + rows * int(info.stride[i])].reshape(rows, int(info.stride[i]))).to(gpu)
+                t.view(rows, pitch)[:, :int(info.stride[i])] = a
+            planes.append(t)
+            strides.append(pitch)
+        return planes, strides
+    sp, ss = scatter(ii, ifmt, src)
+    dp, ds = scatter(oi, ofmt, None)
+    conv.frame_planes(sp, ss, dp, ds)
+    torch.cuda.synchronize()
+    got = np.zeros(int(oi.size), np.uint8)
+    for i in range(oi.n_planes):
+        rows = dp[i].numel() // ds[i]
+        got[int(oi.offset[i]):int(oi.offset[i]) + rows * int(oi.stride[i])] = dp[i].view(rows, ds[i])[:, :int(oi.stride[i])].cpu().numpy().reshape(-1)
+    assert (got == exp).all(), int((got != exp).sum())
+    # and the frame-base entry agrees
+    d_dst = torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu)
+    conv.frame(torch.from_numpy(src).to(gpu), d_dst)
+    torch.cuda.synchronize()
+    assert (d_dst.cpu().numpy() == exp).all()
+    conv.free()

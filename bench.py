@@ -241,7 +241,7 @@ class CompositorScaledWorkload(CompositorWorkload):
     converter with the library defaults (cubic) - what GstVideoAggregatorConvertPad does - then one aggregate launch."""
     name = "c4a"
     metric = "4K output frames/s (compositor, 16 x 1080p BGRA pads each scaled to 960x540, 4x4 grid) per GPU; % HBM roofline"
-    kernel = "k_aggregate_scaled"
+    kernel = "k_aggregate_walk (exact halvings with 8-tap passes, scaled pads side by side; other pad sets: k_aggregate_scaled)"
     SW, SH = 960, 540
     FUSED = os.environ.get("GSTAMD_BENCH_C4A_CONVERTERS") is None      # set: the round-2 form, 16 x per-pad converter launches + k_aggregate
 
@@ -517,6 +517,63 @@ def stored_traffic(name, frames_per_launch=None):
     return None, None
 
 
+def element_env():
+    """Environment in which plugins/tests/bench_element finds the elements of plugins/ (the GStreamer runtime of this image: conda 1.14)."""
+    env = dict(os.environ)
+    env.update(GST_PLUGIN_PATH=os.path.join(ROOT, "plugins") + ":/opt/conda/lib/gstreamer-1.0", GST_PLUGIN_SYSTEM_PATH="/nonexistent",
+               GST_REGISTRY="/tmp/gstamd_bench_registry.bin", GST_REGISTRY_FORK="no", GSTAMD_ELEMENT_STATS="0",
+               LD_LIBRARY_PATH=os.path.join(ROOT, "gstreamer_amd", "lib") + ":" + env.get("LD_LIBRARY_PATH", ""))
+    if os.path.exists("/usr/lib/x86_64-linux-gnu/libstdc++.so.6"):
+        env["LD_PRELOAD"] = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    return env
+
+
+def secondary_c2(wl, sync):
+    """What the headline does NOT say: the same C2 conversion with ONE frame per launch at the C ABI, and through the
+    `videoconvertscale` element (GstHarness, HBM buffers; plugins/tests/bench_element.c) per buffer, in buffer lists of 4 and with
+    batch-buffers=8.  Same accounting (45,619,200 algorithmic bytes per 4K frame over the 8 TB/s peak), measured after the headline's timed
+    region, never part of `value`."""
+    import torch
+    out = {"note": "same workload and accounting as the headline; measured after it, not part of `value`"}
+    # one launch per frame at the C ABI
+    n = 1600
+    for i in range(200):
+        wl.conv.frame(wl.in_ptrs[i % wl.pool_in], wl.out_ptrs[i % wl.pool_out], wl.stream)
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for i in range(n):
+        wl.conv.frame(wl.in_ptrs[i % wl.pool_in], wl.out_ptrs[i % wl.pool_out], wl.stream)
+    ev1.record()
+    sync()
+    us = ev0.elapsed_time(ev1) * 1e3 / n
+    out["c_abi_one_frame_per_launch"] = {"us_per_frame": round(us, 3), "frames_per_s": round(1e6 / us, 1),
+                                         "frac": round(wl.alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "frames": n}
+    exe = os.path.join(ROOT, "plugins", "tests", "bench_element")
+    if not os.path.exists(exe):
+        out["element"] = "unavailable: plugins/tests/bench_element not built"
+        return out
+    rows = []
+    # (label, hip-streams, buffers per list, batch-buffers)
+    for label, streams, list_n, batch in (("per buffer, 1 stream", 1, 1, 1), ("per buffer, hip-streams=3 (the element default)", 3, 1, 1),
+                                          ("buffer lists of 4", 1, 4, 1), ("batch-buffers=8", 1, 1, 8)):
+        try:
+            argv = [exe, wl.ifmt, str(wl.w), str(wl.h), wl.ofmt, str(wl.ow), str(wl.oh), "640", str(streams), "bilinear", str(list_n), str(batch)]
+            r = subprocess.run(argv, env=element_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+            js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not js:
+                rows.append({"case": label, "error": (r.stderr or r.stdout)[-200:]})
+                continue
+            d = json.loads(js[-1])
+            rows.append({"case": label, "hip_streams": d.get("hip_streams"), "buffers_per_list": list_n, "batch_buffers": batch,
+                         "us_per_frame": d["us_per_frame"], "frames_per_s": d["frames_per_s"],
+                         "frac": round(d["algorithmic_gb_per_s"] / HBM_PEAK_GBS, 4), "frames": d["frames"]})
+        except Exception as e:      # a report, never a reason to fail the bench
+            rows.append({"case": label, "error": repr(e)[:200]})
+    out["element"] = rows
+    return out
+
+
 def spawn_ranks(args):
     """`--gpus N` given without a torchrun environment: run N ranks of this file under torch.distributed.run."""
     import socket
@@ -537,6 +594,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f5encode16 | f8scale | f8pack | f8swizzle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="c2: skip the batch-1 / element numbers reported beside the headline")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed sustained load before the W warmup steps: from idle an MI355X needs 20-30 ms of load "
                          "to reach its steady rate (scripts/clock_ramp.py, profiles/r01_clock_ramp.log)")
@@ -650,6 +708,8 @@ def main():
         }
         if hasattr(wl, "flops_per_step"):
             line["roofline"]["gflops"] = round(wl.flops_per_step * steps / (ev_ms * 1e-3) / 1e9, 1)
+        if world == 1 and args.config == "c2" and not args.no_secondary and not cpu_mode and not args.size and not args.batch:
+            line["secondary"] = secondary_c2(wl, sync)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = wl.cpu_baseline()

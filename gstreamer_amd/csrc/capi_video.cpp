@@ -75,6 +75,10 @@ struct GstAmdVideoConverter {
   ColForm col_form;
   int32_t *col_tiles_dev = nullptr;
   uint32_t *col_hout_dev = nullptr, *col_vrow_dev = nullptr;
+  // compositor_walk.h: a pad converter's two 8-tap passes remapped onto rings that advance two source lines / columns per output
+  int walk_state = 0;                   // 0: not looked at, 1: tables on the device, -1: the plan does not fit the walk
+  uint32_t *walk_vt_dev = nullptr, *walk_ht_dev = nullptr;
+  int walk_vbase = 0, walk_hbase = 0;
   int col_waves = 0, col_per_cu = 0, col_cus = 0;
   // k_scale420_fused (video_scale420_fused.h): both N-tap passes of a regular 4:2:0 source in one kernel
   bool fused_ok = false;
@@ -1972,6 +1976,12 @@ static void release_tables (GstAmdVideoConverter *c)
     }
   c->plane_dev.clear ();
   c->fused_ok = false;
+  if (c->walk_vt_dev)
+    (void) hipFree (c->walk_vt_dev);
+  if (c->walk_ht_dev)
+    (void) hipFree (c->walk_ht_dev);
+  c->walk_vt_dev = c->walk_ht_dev = nullptr;
+  c->walk_state = 0;
   if (c->col_tiles_dev)
     (void) hipFree (c->col_tiles_dev);
   if (c->col_hout_dev)
@@ -2059,6 +2069,67 @@ int gstamd_internal_pad_scaler (GstAmdVideoConverter *c, gstamd::ScaleDev *sh, g
   *out_w = p.out_info.width;
   *out_h = p.out_info.height;
   *format = p.in_info.format;
+  return 1;
+}
+
+// One 8-tap pass onto a ring that advances two source positions per output: output i reads positions 2 i + base .. 2 i + base + 7.
+// words: four per output (two s16 taps per word, even ring position in the low half).  false: some non-zero tap falls outside the ring.
+static bool walk_remap (const ScalePass &sp, std::vector<uint32_t> *words, int *base)
+{
+  if (sp.kind != SCALE_NTAP || sp.n_taps != 8 || sp.merged || sp.out_size < 1 || (int) sp.offset.size () < sp.out_size ||
+      (int) sp.taps.size () < sp.out_size * 8)
+    return false;
+  const int mid = sp.out_size / 2;
+  const int b = (int) sp.offset[mid] - 2 * mid;
+  words->assign ((size_t) sp.out_size * 4, 0u);
+  for (int i = 0; i < sp.out_size; i++) {
+    int16_t ring[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 8; k++) {
+      const int16_t t = sp.taps[(size_t) i * 8 + k];
+      if (!t)
+        continue;
+      const int pos = (int) sp.offset[i] + k - (2 * i + b);
+      if (pos < 0 || pos > 7 || (int) sp.offset[i] + k >= sp.in_size)
+        return false;
+      ring[pos] = (int16_t) (ring[pos] + t);
+    }
+    for (int k = 0; k < 4; k++)
+      (*words)[(size_t) i * 4 + k] = (uint32_t) (uint16_t) ring[2 * k] | ((uint32_t) (uint16_t) ring[2 * k + 1] << 16);
+  }
+  *base = b;
+  return true;
+}
+
+/* internal (compositor_kernels.hip): the walk tables of a pad converter (compositor_walk.h); 0 when the plan does not fit - a pad
+ * scaler whose vertical 8-tap pass runs first and whose passes both halve */
+int gstamd_internal_pad_walk (GstAmdVideoConverter *c, const uint32_t **vt, const uint32_t **ht, int *vbase, int *hbase)
+{
+  int hi = -1, vi = -1;
+  if (!c || !plan_is_pad_scaler (c->plan, &hi, &vi) || hi < 0 || vi < 0 || vi > hi)
+    return 0;
+  std::lock_guard<std::mutex> guard (c->lock);
+  if (c->walk_state == 0) {
+    c->walk_state = -1;
+    std::vector<uint32_t> wv, wh;
+    int bv = 0, bh = 0;
+    if (walk_remap (c->plan.passes[vi], &wv, &bv) && walk_remap (c->plan.passes[hi], &wh, &bh)) {
+      if (hipMalloc ((void **) &c->walk_vt_dev, wv.size () * 4) == hipSuccess && hipMalloc ((void **) &c->walk_ht_dev, wh.size () * 4) == hipSuccess &&
+          hipMemcpy (c->walk_vt_dev, wv.data (), wv.size () * 4, hipMemcpyHostToDevice) == hipSuccess &&
+          hipMemcpy (c->walk_ht_dev, wh.data (), wh.size () * 4, hipMemcpyHostToDevice) == hipSuccess) {
+        c->walk_vbase = bv;
+        c->walk_hbase = bh;
+        c->walk_state = 1;
+      } else {
+        (void) hipGetLastError ();
+      }
+    }
+  }
+  if (c->walk_state != 1)
+    return 0;
+  *vt = c->walk_vt_dev;
+  *ht = c->walk_ht_dev;
+  *vbase = c->walk_vbase;
+  *hbase = c->walk_hbase;
   return 1;
 }
 

@@ -18,6 +18,7 @@
 #include "compositor_planes.h"
 #include "compositor_wide.h"
 #include "compositor_scaled.h"
+#include "compositor_walk.h"
 
 using namespace gstamd;
 
@@ -261,6 +262,31 @@ __global__ __launch_bounds__ (256) void k_aggregate_scaled (ScaledAggParams p, u
     if (xin && y < ty1)
       *((uint32_t *) (dst + (size_t) y * dstride) + x) = d[k];
   }
+}
+
+/* scaled pads as column walks (compositor_walk.h): one wave per workgroup; blocks [0, n_blocks) walk, the rest fill what no scaled pad covers */
+/* eight waves per SIMD for the form a mosaic takes (opaque blends, no unscaled pads: 63 registers, nothing spilled; C4-A 45.9 us against 50.4
+ * with six), six for the forms that carry the general blend */
+template <int ASH, int FAST, int PLAIN>
+__global__ __launch_bounds__ (64) __attribute__ ((amdgpu_waves_per_eu ((FAST && !PLAIN) ? 8 : 6, (FAST && !PLAIN) ? 8 : 6))) void k_aggregate_walk (WalkParams p, uint8_t *dst, int dstride, int dw, int dh)
+{
+  __shared__ uint4 lds4[64];
+  int b = (int) blockIdx.x;
+  if (p.xcd_span && b < 8 * p.xcd_span) {      /* workgroups go round the eight XCDs: give each a contiguous run of strips (neighbours share halo columns and canvas lines in its L2) */
+    b = (b & 7) * p.xcd_span + (b >> 3);
+    if (b >= p.n_blocks)
+      return;
+  }
+  if (b >= p.n_blocks) {
+    walk_fill<ASH> (p, b - (p.xcd_span ? 8 * p.xcd_span : p.n_blocks), dst, dstride, dw, dh);
+    return;
+  }
+  int pi = 0;
+  while (pi + 1 < p.n_walk && b >= p.walk[pi + 1].first_block)
+    pi++;
+  const WalkPad &wp = p.walk[pi];
+  b -= wp.first_block;
+  walk_wave<ASH, FAST, PLAIN> (p, wp, b % wp.tiles, b / wp.tiles, dst, dstride, dw, dh, (uint32_t *) lds4);
 }
 
 static thread_local std::string g_comp_error;
@@ -662,6 +688,135 @@ int gstamd_compositor_pad_scaler_usable (GstAmdVideoConverter *convert)
   return gstamd_internal_pad_scaler (convert, &sh, &sv, &hf, &iw, &ih, &ow, &oh, &fmt) && family_ashift (fmt) >= 0;
 }
 
+int gstamd_internal_pad_walk (GstAmdVideoConverter *c, const uint32_t **vt, const uint32_t **ht, int *vbase, int *hbase);
+
+static thread_local int g_last_scaled_kernel = 0;       /* 1: k_aggregate_walk, 2: k_aggregate_scaled, 3: no scaled pad (k_aggregate) */
+extern "C" int gstamd_internal_last_scaled_kernel (void) { return g_last_scaled_kernel; }
+
+/* The column walk (compositor_walk.h) when the pad set fits it: every scaled pad an exact halving with 8-tap passes, vertical first, no two
+ * scaled pads overlapping on the canvas, at most 16 scaled and 16 unscaled pads.  1: launched, 0: not eligible, < 0: error */
+static int try_walk (int format, int ashift, int background, const GstAmdCompositorScaledPad *pads, int n_pads, void *dest, int dw, int dh,
+    int dstride, void *stream)
+{
+  if (tuning_on ("GSTAMD_NO_AGG_WALK"))
+    return 0;
+  WalkParams p;
+  memset ((void *) &p, 0, sizeof (p));
+  p.ashift = ashift;
+  p.overlay = background == GSTAMD_COMPOSITOR_BACKGROUND_TRANSPARENT;
+  const bool yuv = format == GSTAMD_VIDEO_FORMAT_AYUV || format == GSTAMD_VIDEO_FORMAT_VUYA;
+  switch (background) {
+    case GSTAMD_COMPOSITOR_BACKGROUND_CHECKER: p.bg_kind = 0; p.checker_yuv = yuv; break;
+    case GSTAMD_COMPOSITOR_BACKGROUND_BLACK: p.bg_kind = 1; color_word (format, yuv ? 16 : 0, yuv ? 128 : 0, yuv ? 128 : 0, &p.bg_word); break;
+    case GSTAMD_COMPOSITOR_BACKGROUND_WHITE: p.bg_kind = 1; color_word (format, yuv ? 235 : 255, yuv ? 128 : 255, yuv ? 128 : 255, &p.bg_word); break;
+    case GSTAMD_COMPOSITOR_BACKGROUND_TRANSPARENT: p.bg_kind = 1; p.bg_word = 0; break;
+    default: return GSTAMD_ERR_INVALID;
+  }
+  bool fast = !p.overlay;
+  int rows_pref = tuning_int ("GSTAMD_WALK_ROWS", 0);
+  /* rows a wave walks.  One resident round is the aim (8 waves per SIMD x 1024 SIMDs when every blend is the opaque one, else 6): the strips of
+     all scaled pads x the chunks of their rows should come to that many waves; a walk shorter than ~12 rows spends itself on priming its ring */
+  int strips = 0, total_rows = 0, n_scaled = 0;
+  for (int i = 0; i < n_pads; i++)
+    if (pads[i].scaler && pads[i].data && pads[i].alpha * 255 >= 1) {
+      ScaleDev sh, sv;
+      int hf, iw, ih, ow = 0, oh = 0, fmt;
+      if (gstamd_internal_pad_scaler (pads[i].scaler, &sh, &sv, &hf, &iw, &ih, &ow, &oh, &fmt)) {
+        strips += (ow + GSTAMD_WALK_TILE - 1) / GSTAMD_WALK_TILE;
+        total_rows += oh;
+        n_scaled++;
+      }
+    }
+  int walk_rows = 17;
+  if (n_scaled > 0 && strips > 0) {
+    const long long slots = 8192;
+    const long long strip_rows = (long long) strips * (total_rows / n_scaled);          /* rows x strips to hand out */
+    walk_rows = (int) ((strip_rows + slots - 1) / slots);
+    walk_rows = walk_rows < 12 ? 12 : (walk_rows > 64 ? 64 : walk_rows);
+  }
+  long long covered = 0;
+  for (int i = 0; i < n_pads; i++) {
+    const GstAmdCompositorScaledPad &in = pads[i];
+    int s_alpha = (int) (in.alpha * 255);
+    s_alpha = s_alpha < 0 ? 0 : (s_alpha > 255 ? 255 : s_alpha);
+    if (s_alpha == 0 || !in.data)
+      continue;
+    if (((uintptr_t) in.data % 4) != 0 || (in.stride % 4) != 0)
+      return 0;
+    if (!in.scaler) {
+      if (p.n_plain >= GSTAMD_WALK_MAX_PADS)
+        return 0;
+      PadDev &q = p.plain[p.n_plain++];
+      q.data = (const uint8_t *) in.data;
+      q.width = in.width, q.height = in.height, q.stride = in.stride;
+      q.xpos = in.xpos, q.ypos = in.ypos, q.s_alpha = s_alpha, q.mode = in.blend_mode;
+      continue;
+    }
+    if (p.n_walk >= GSTAMD_WALK_MAX_PADS)
+      return 0;
+    ScaleDev sh, sv;
+    int hf, iw, ih, ow, oh, fmt;
+    if (!gstamd_internal_pad_scaler (in.scaler, &sh, &sv, &hf, &iw, &ih, &ow, &oh, &fmt) || fmt != format || iw != in.width || ih != in.height)
+      return 0;
+    WalkPad &w = p.walk[p.n_walk];
+    if (!gstamd_internal_pad_walk (in.scaler, &w.vt, &w.ht, &w.vbase, &w.hbase))
+      return 0;
+    w.src = (const uint8_t *) in.data;
+    w.sstride = in.stride, w.src_w = iw, w.src_h = ih;
+    if ((unsigned long long) w.sstride * (unsigned long long) ih >= 0x7fffffffull)
+      return 0;
+    w.xpos = in.xpos, w.ypos = in.ypos, w.ow = ow, w.oh = oh;
+    w.s_alpha = s_alpha, w.mode = in.blend_mode;
+    w.n_below = p.n_plain;
+    if (in.blend_mode == GSTAMD_COMPOSITOR_BLEND_MODE_SOURCE)
+      fast = false;
+    for (int k = 0; k < p.n_walk; k++) {          /* no two scaled pads on one canvas pixel */
+      const WalkPad &o = p.walk[k];
+      if (o.xpos < w.xpos + w.ow && w.xpos < o.xpos + o.ow && o.ypos < w.ypos + w.oh && w.ypos < o.ypos + o.oh)
+        return 0;
+    }
+    w.tiles = (ow + GSTAMD_WALK_TILE - 1) / GSTAMD_WALK_TILE;
+    w.tile_w = (ow + w.tiles - 1) / w.tiles;
+    w.chunk_rows = rows_pref > 0 ? rows_pref : walk_rows;
+    w.chunks = (oh + w.chunk_rows - 1) / w.chunk_rows;
+    w.chunk_rows = (oh + w.chunks - 1) / w.chunks;
+    w.first_block = p.n_blocks;
+    p.n_blocks += w.tiles * w.chunks;
+    const int cx0 = w.xpos > 0 ? w.xpos : 0, cy0 = w.ypos > 0 ? w.ypos : 0;
+    const int cx1 = w.xpos + ow < dw ? w.xpos + ow : dw, cy1 = w.ypos + oh < dh ? w.ypos + oh : dh;
+    if (cx1 > cx0 && cy1 > cy0)
+      covered += (long long) (cx1 - cx0) * (cy1 - cy0);
+    p.n_walk++;
+  }
+  if (!p.n_walk)
+    return 0;
+  if (covered < (long long) dw * dh) {
+    p.fill_tiles_x = (dw + 63) / 64;
+    p.fill_tiles_y = (dh + 15) / 16;
+  }
+  int walk_grid = p.n_blocks;
+  if (tuning_int ("GSTAMD_WALK_XCD", 0) > 0) {          /* measured: no difference on C4-A (47.7 us either way) - off */
+    p.xcd_span = (p.n_blocks + 7) / 8;
+    walk_grid = 8 * p.xcd_span;
+  }
+  const dim3 grid ((unsigned) (walk_grid + p.fill_tiles_x * p.fill_tiles_y)), block (64);
+  uint8_t *d8 = (uint8_t *) dest;
+#define WALK_LAUNCH(A, F, P) hipLaunchKernelGGL ((k_aggregate_walk<A, F, P>), grid, block, 0, (hipStream_t) stream, p, d8, dstride, dw, dh)
+  const int variant = (ashift ? 4 : 0) | (fast ? 2 : 0) | (p.n_plain ? 1 : 0);
+  switch (variant) {
+    case 0: WALK_LAUNCH (0, 0, 0); break;
+    case 1: WALK_LAUNCH (0, 0, 1); break;
+    case 2: WALK_LAUNCH (0, 1, 0); break;
+    case 3: WALK_LAUNCH (0, 1, 1); break;
+    case 4: WALK_LAUNCH (24, 0, 0); break;
+    case 5: WALK_LAUNCH (24, 0, 1); break;
+    case 6: WALK_LAUNCH (24, 1, 0); break;
+    default: WALK_LAUNCH (24, 1, 1); break;
+  }
+#undef WALK_LAUNCH
+  return hipGetLastError () == hipSuccess ? 1 : GSTAMD_ERR_HIP;
+}
+
 int gstamd_compositor_aggregate_scaled (int format, int background, const GstAmdCompositorScaledPad *pads, int n_pads, void *dest,
     int dw, int dh, int dstride, void *stream)
 {
@@ -671,6 +826,16 @@ int gstamd_compositor_aggregate_scaled (int format, int background, const GstAmd
   bool any = false;
   for (int i = 0; i < n_pads; i++)
     any = any || pads[i].scaler != nullptr;
+  g_last_scaled_kernel = any ? 2 : 3;
+  if (any) {
+    const int wr = try_walk (format, ashift, background, pads, n_pads, dest, dw, dh, dstride, stream);
+    if (wr < 0)
+      return wr;
+    if (wr == 1) {
+      g_last_scaled_kernel = 1;
+      return GSTAMD_OK;
+    }
+  }
   if (!any) {                                     /* nothing to scale: the packed 4-pixel kernel */
     std::vector<GstAmdCompositorPad> plain ((size_t) n_pads);
     for (int i = 0; i < n_pads; i++) {

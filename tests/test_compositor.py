@@ -788,3 +788,55 @@ def test_hip_pad_scaler_usable_only_for_plain_scalers(native_lib, gpu):
     assert usable(V.VideoConverter(V.video_info("BGRA", 64, 48), V.video_info("RGBA", 32, 24))._h) == 0
     assert usable(V.VideoConverter(V.video_info("BGRA", 64, 48), V.video_info("BGRA", 64, 48))._h) == 0
     assert usable(V.VideoConverter(V.video_info("BGRA", 64, 48), V.video_info("BGRA", 32, 24), V.converter_config(dest_x=4, dest_width=20))._h) == 0
+
+
+# ---- the column walk (compositor_walk.h): exact halvings with 8-tap passes, scaled pads that do not overlap each other ----------------------
+# (w, h, ow, oh, method, xpos, ypos, alpha, mode)
+WALK_LAYOUTS = {
+    # a 2 x 2 mosaic that covers the canvas: no filler
+    "mosaic": [(128, 96, 64, 48, "cubic", 0, 0, 1.0, 1), (128, 96, 64, 48, "cubic", 64, 0, 0.8, 1), (128, 96, 64, 48, "cubic", 0, 48, 0.5, 1),
+               (128, 96, 64, 48, "cubic", 64, 48, 1.0, 1)],
+    # strips wider than one wave's 61 outputs, an odd number of rows, gaps the filler has to write
+    "wide": [(400, 66, 200, 33, "cubic", 10, 3, 0.9, 1), (300, 70, 150, 35, "cubic", 40, 40, 1.0, 1)],
+    # pads hanging over every canvas edge
+    "clipped": [(128, 96, 64, 48, "cubic", -20, -10, 1.0, 1), (128, 96, 64, 48, "cubic", 150, 50, 0.7, 1), (256, 64, 128, 32, "cubic", 0, 60, 1.0, 1)],
+    # unscaled pads under, between and over the scaled ones (z order = list order)
+    "layers": [(200, 80, 0, 0, None, 0, 0, 1.0, 1), (128, 96, 64, 48, "cubic", 8, 4, 0.8, 1), (60, 40, 0, 0, None, 50, 30, 0.6, 1),
+               (128, 96, 64, 48, "cubic", 100, 20, 1.0, 1), (30, 70, 0, 0, None, 90, 5, 0.5, 1)],
+    # the SOURCE and ADD operators
+    "operators": [(128, 96, 64, 48, "cubic", 0, 0, 0.7, 0), (128, 96, 64, 48, "cubic", 70, 10, 0.9, 2), (40, 40, 0, 0, None, 40, 30, 0.5, 0)],
+    # a small pad: fewer rows than the ring is deep
+    "tiny": [(32, 24, 16, 12, "cubic", 3, 3, 1.0, 1), (24, 32, 12, 16, "cubic", 30, 3, 1.0, 1)],
+    # the other 8-tap filters of a halving
+    "filters": [(128, 96, 64, 48, "lanczos", 0, 0, 1.0, 1), (128, 96, 64, 48, "sinc", 70, 10, 0.9, 1)],
+}
+WALK_CASES = [("BGRA", 0, "mosaic"), ("ARGB", 1, "mosaic"), ("BGRA", 1, "wide"), ("AYUV", 0, "wide"), ("RGBA", 2, "clipped"), ("BGRA", 3, "clipped"),
+              ("BGRA", 0, "layers"), ("ABGR", 3, "layers"), ("BGRA", 1, "operators"), ("ARGB", 3, "operators"), ("BGRA", 0, "tiny"), ("BGRA", 1, "filters")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,background,name", WALK_CASES)
+def test_hip_column_walk_of_halved_pads_matches_reference(native_lib, gpu, ref, fmt, background, name, monkeypatch):
+    """k_aggregate_walk against the reference's converter + blend per pad, and against k_aggregate_scaled on the same pads"""
+    layout = WALK_LAYOUTS[name]
+    dw, dh = 200, 100
+    frames = scaled_frames(layout, 7300)
+    exp = scaled_expected(ref, fmt, background, layout, frames, dw, dh)
+    got = hip_scaled(gpu, fmt, background, layout, frames, dw, dh)
+    V.lib().gstamd_internal_last_scaled_kernel.restype = C.c_int
+    assert V.lib().gstamd_internal_last_scaled_kernel() == 1, "the pad set did not take the column walk"
+    assert (exp == got).all(), (int((exp != got).sum()), np.flatnonzero(exp != got)[:8])
+
+
+@pytest.mark.gpu
+def test_hip_column_walk_is_not_taken_by_pad_sets_it_cannot_serve(native_lib, gpu, ref):
+    """overlapping scaled pads, other ratios and other filters stay with k_aggregate_scaled - same bytes as the reference either way"""
+    V.lib().gstamd_internal_last_scaled_kernel.restype = C.c_int
+    for layout in ([(128, 96, 64, 48, "cubic", 0, 0, 1.0, 1), (128, 96, 64, 48, "cubic", 30, 20, 0.5, 1)],          # overlap
+                   [(150, 96, 50, 48, "cubic", 0, 0, 1.0, 1)],                                                          # 3 : 1 horizontally
+                   [(128, 96, 64, 48, "linear", 0, 0, 1.0, 1)]):
+        frames = scaled_frames(layout, 7400)
+        exp = scaled_expected(ref, "BGRA", 0, layout, frames, 120, 80)
+        got = hip_scaled(gpu, "BGRA", 0, layout, frames, 120, 80)
+        assert V.lib().gstamd_internal_last_scaled_kernel() == 2, layout
+        assert (exp == got).all(), layout

@@ -535,8 +535,8 @@ def test_hip_frame_planes_takes_gbr_planes_in_frame_order(native_lib, gpu, ref, 
     single-buffer path: _frame / _frames were right, _frame_planes took the caller's order for the plan's.)"""
     import torch
     ifmt, ofmt = pair
-    w, h, ow, oh = 70, 33, (70, 33) if ofmt != "GBR" or ifmt != "GBR" else (96, 40)
-    ow, oh = (ow, oh) if isinstance(ow, int) else ow
+    w, h = 70, 33
+    ow, oh = (96, 40) if ifmt == ofmt else (70, 33)
     ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)
     src = cases.frame_bytes(int(ii.size), "random", 515, w)
     exp = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh).frame(src)

@@ -80,6 +80,7 @@ struct GstAmdVideoConverter {
   uint32_t *walk_vt_dev = nullptr, *walk_ht_dev = nullptr;
   int walk_vbase = 0, walk_hbase = 0;
   int col_waves = 0, col_per_cu = 0, col_cus = 0;
+  int col_per_cu_solo = 0;              // the same without the hand-over area (every wave makes all the groups its rows need)
   // k_scale420_fused (video_scale420_fused.h): both N-tap passes of a regular 4:2:0 source in one kernel
   bool fused_ok = false;
   Fused420Tables fused;
@@ -196,8 +197,13 @@ static bool col_pick_waves (GstAmdVideoConverter *c)
     if (per_cu > 0)
       best_waves = nwaves, best_per_cu = per_cu;
   }
+  /* (the register-window form fits five four-wave workgroups a CU by the occupancy query's count - a launch sized for five ran 15.7 us per frame
+     against 14.3-14.5 for every other geometry, profiles/r05: sized for four) */
+  if (best_waves * best_per_cu > 16)
+    best_per_cu = std::max (1, 16 / best_waves);
   c->col_waves = best_waves;
   c->col_per_cu = best_per_cu;
+  c->col_per_cu_solo = best_waves > 0 ? col_blocks_per_cu (c->col_form, p.front.chroma_h, semi, 0, best_waves) : 0;
   return best_waves > 0;
 }
 
@@ -206,22 +212,39 @@ static void col_geometry (const GstAmdVideoConverter *c, int n_frames, ColParams
 {
   const int out_h = c->plan.out_info.height, tiles = (int) c->col.tiles.size () / 4;
   const int pin = tuning_int ("GSTAMD_COL_CHUNKS", 0);
-  const int capacity = std::max (1, c->col_per_cu * c->col_cus);
+  /* solo: no hand-over between the waves of a workgroup - each makes every group its rows need (the groups at a seam twice), and the LDS the
+     hand-over slots took buys resident waves.  Worth it when a wave's run of rows is long against the groups a seam shares. */
+  const int solo_pin = tuning_int ("GSTAMD_COL_SOLO", -1);
+  bool solo = false;
+  if (c->col_per_cu_solo > c->col_per_cu && solo_pin != 0) {
+    const int cap_solo = std::max (1, c->col_per_cu_solo * c->col_cus);
+    const int chunks_solo = std::max (1, cap_solo / std::max (1, tiles * n_frames));
+    const int rpw_solo = std::max (1, (out_h + chunks_solo * c->col_waves - 1) / (chunks_solo * c->col_waves));
+    /* groups a run of rpw rows needs against the ones a seam adds */
+    const double groups_per_row = (double) c->col.n_groups / std::max (1, out_h);
+    solo = solo_pin > 0;                /* measured (C3, lists of 16): 16.5 us against 15.5 with the hand-over - the kernel is bound by its LDS and VALU
+                                           work, not by resident waves; kept as a knob */
+    (void) groups_per_row;
+    (void) rpw_solo;
+  }
+  const int capacity = std::max (1, (solo ? c->col_per_cu_solo : c->col_per_cu) * c->col_cus);
   int chunks = pin > 0 ? pin : std::max (1, capacity / std::max (1, tiles * n_frames));
   /* a workgroup's rows: (waves - 1) runs of rpw rows and the last wave's shorter run (col_rows_last) */
   int rpw = std::max (1, (out_h + chunks * c->col_waves - 1) / (chunks * c->col_waves));
   for (;; rpw++) {
-    rpw = std::max (rpw, c->col.min_rows_per_wave);
-    const int per_wg = rpw * (c->col_waves - 1) + col_rows_last (c->col, rpw, out_h);
+    if (!solo)
+      rpw = std::max (rpw, c->col.min_rows_per_wave);
+    const int per_wg = rpw * (c->col_waves - 1) + (solo ? rpw : col_rows_last (c->col, rpw, out_h));
     if ((long long) per_wg * chunks >= out_h)
       break;
   }
   q->rows_per_wave = rpw;
   q->nwaves = c->col_waves;
-  q->rows_last = col_rows_last (c->col, rpw, out_h);
+  q->rows_last = solo ? rpw : col_rows_last (c->col, rpw, out_h);
   q->rows_per_wg = rpw * (c->col_waves - 1) + q->rows_last;
   q->n_chunks = (out_h + q->rows_per_wg - 1) / q->rows_per_wg;
   q->n_tiles = tiles;
+  q->pubn = solo ? 0 : c->col.pubn;
 }
 
 static bool fast_pair_usable (const VideoPlan &p, const Planes &pl, const uint8_t *dst, int dstride, int dalign = 16)
@@ -445,7 +468,7 @@ static int build_tables (GstAmdVideoConverter *c)
     int lo, hi;
     if (!tuning_on ("GSTAMD_NO_COL") && col_plan_regular (p, &lo, &hi) &&
         col_choose (p.passes[0], p.passes[1], p.front.width, p.front.height, std::max (0, tuning_int ("GSTAMD_COL_OPL", 0)), tuning_int ("GSTAMD_COL_SHARE", 1) != 0,
-            &c->col, &c->col_form)) {
+            &c->col, &c->col_form, !tuning_on ("GSTAMD_COL_NO_REGWIN"))) {
       c->reg_lo = lo;
       c->reg_hi = hi;
       if (col_pick_waves (c)) {
@@ -1220,7 +1243,6 @@ static hipError_t col_launch (GstAmdVideoConverter *c, int n, const void *const 
   q.vrow = c->col_vrow_dev;
   q.out_w = p.passes[0].out_size;
   q.out_h = p.passes[1].out_size;
-  q.pubn = c->col.pubn;
   q.dstride = dstride;
   for (int base = 0; base < n; base += GSTAMD_COL_MAX_FRAMES) {
     const int nb = std::min (n - base, GSTAMD_COL_MAX_FRAMES);

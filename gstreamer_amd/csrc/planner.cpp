@@ -1088,6 +1088,20 @@ bool make_col_tables (const ScalePass &h, const ScalePass &v, int width, int hei
   t->wstep = best.wstep;
   t->a8 = best.a8;
   t->tiles = best.tiles;
+  /* register windows (video_scale_col.h col_hfilter_regs): in every tile unit u's shared window starts 8 u bytes after unit 0's, and that one at
+     byte 0 or 8 of the tile's window space - then lane u's window begins with the two words lane u itself holds, and the rest comes over the lanes */
+  if (opl == 2 && best.wstep == 1 && best.a8 && best.nw <= 4) {
+    bool rw = true;
+    for (size_t ti = 0; ti < best.tiles.size () && rw; ti += 4) {
+      const int o0 = best.tiles[ti], n = best.tiles[ti + 1];
+      const int w0 = best.wbase[(size_t) o0];
+      rw = (w0 == 0 || w0 == 8) && (n % 2) == 0;
+      for (int u = 0; u < n / 2 && rw; u++)
+        rw = best.wbase[(size_t) (o0 + 2 * u)] == w0 + 8 * u;
+    }
+    if (rw)
+      t->a8 = 2;
+  }
   t->hout.assign ((size_t) out_w * 8, 0);
   for (size_t ti = 0; ti < best.tiles.size (); ti += 4) {
     const int o0 = best.tiles[ti], n = best.tiles[ti + 1], s0 = best.tiles[ti + 2];

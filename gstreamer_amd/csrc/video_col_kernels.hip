@@ -23,6 +23,12 @@ struct ColExecDev {
   ColRaw<OPL> ra;
   ColRingRegs<OPL, NGV> rg;
   template <class F> __device__ __forceinline__ void each (F f) { f (lane, L, ra, rg); }
+  // word of the lane `dist` places up: a DPP wave shift of `v` (the lane's own word for dist 1, the dist-1 result for dist 2); the last lane reads 0
+  struct Nb {
+    __device__ __forceinline__ uint32_t operator() (uint32_t v, int, int, int, int) const { return (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x130, 0xf, 0xf, true); }
+  };
+  template <class F> __device__ __forceinline__ void each_nb (F f) { Nb nb; f (lane, L, ra, rg, nb); }
+  template <class F> __device__ __forceinline__ bool all (F pred) { return __ballot (pred (lane, L)) == ~0ull; }
   __device__ __forceinline__ void sync ()
   {
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
@@ -56,8 +62,12 @@ struct ColExecDev {
 };
 
 // LDS: [flags: one word per wave][per wave: staged group | ring | hand-over slots]
+#ifndef GSTAMD_COL_RW_WAVES
+#define GSTAMD_COL_RW_WAVES 4
+#endif
 template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8, int POST>
-__global__ __launch_bounds__ (64 * GSTAMD_COL_MAX_WAVES) void k_scale_col (ColParams p, ColFrames fr, Dst dst, PostFast pf)
+__global__ __launch_bounds__ (64 * GSTAMD_COL_MAX_WAVES) __attribute__ ((amdgpu_waves_per_eu ((OPL == 2 && A8 == 2) ? GSTAMD_COL_RW_WAVES : 1, (OPL == 2 && A8 == 2) ? GSTAMD_COL_RW_WAVES : 8)))
+void k_scale_col (ColParams p, ColFrames fr, Dst dst, PostFast pf)
 {
   extern __shared__ __attribute__ ((aligned (16))) uint8_t col_lds[];
   const int wave = __builtin_amdgcn_readfirstlane ((int) (threadIdx.x >> 6)), lane = (int) (threadIdx.x & 63);
@@ -86,7 +96,7 @@ __global__ __launch_bounds__ (64 * GSTAMD_COL_MAX_WAVES) void k_scale_col (ColPa
   s.c1 = col_plane (fr.c1[frame], (long long) p.crow_lo * p.cstride, crow_bytes);
   s.out = col_plane (fr.dst[frame], 0, (uint32_t) (p.dstride * (p.out_h - 1) + 4 * p.out_w));
   const Dst &d = dst;
-  const size_t wave_bytes = col_wave_bytes (OPL, NGV, p.pubn);
+  const size_t wave_bytes = col_wave_bytes (OPL, NGV, p.pubn, OPL == 2 && WSTEP == 1 && A8 == 2);
   uint8_t *mine = col_lds + GSTAMD_COL_FLAG_BYTES + (size_t) wave * wave_bytes;
   ColExecDev<OPL, NW, NGV> x;
   x.lane = lane;
@@ -123,7 +133,7 @@ static const ColVariant *col_find (const ColForm &f, int chroma_h, int semi, int
   return nullptr;
 }
 
-size_t col_lds_bytes (const ColForm &f, int pubn, int nwaves) { return GSTAMD_COL_FLAG_BYTES + (size_t) nwaves * col_wave_bytes (f.opl, f.ngv, pubn); }
+size_t col_lds_bytes (const ColForm &f, int pubn, int nwaves) { return GSTAMD_COL_FLAG_BYTES + (size_t) nwaves * col_wave_bytes (f.opl, f.ngv, pubn, f.a8 == 2); }
 
 // workgroups of `nwaves` waves one CU holds, 0 on failure
 int col_blocks_per_cu (const ColForm &f, int chroma_h, int semi, int pubn, int nwaves)

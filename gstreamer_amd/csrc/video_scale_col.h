@@ -123,12 +123,13 @@ struct ColParams {
 #endif
 };
 
-// the instantiated forms (outputs per lane, tap words per output, window groups per row, window form, 8-byte aligned shared window); each exists
+// the instantiated forms (outputs per lane, tap words per output, window groups per row, window form, 8-byte aligned shared window - 2: and
+// every lane's window starts with the lane's own staged words, the REGISTER-WINDOW form, see col_hfilter_regs); each exists
 // for the co-sited and the non-co-sited horizontal chroma filter and for planar and semi-planar sources.  A plan runs on the smallest form
 // that holds it: tap words and groups beyond its own are zero.
 #define GSTAMD_COL_FORMS(V) \
-  V (1, 3, 3, -1, 0) V (2, 3, 3, -1, 0) V (2, 3, 3, 1, 1) V (2, 3, 3, 0, 0) \
-  V (1, 4, 4, -1, 0) V (2, 4, 4, -1, 0) V (2, 4, 4, 1, 1) V (2, 4, 4, 0, 0)
+  V (1, 3, 3, -1, 0) V (2, 3, 3, -1, 0) V (2, 3, 3, 1, 1) V (2, 3, 3, 0, 0) V (2, 3, 3, 1, 2) \
+  V (1, 4, 4, -1, 0) V (2, 4, 4, -1, 0) V (2, 4, 4, 1, 1) V (2, 4, 4, 0, 0) V (2, 4, 4, 1, 2)
 
 struct ColForm { int opl, nw, ngv, wstep, a8; };
 // the form that serves (opl, nw, ngv, wstep, a8), false: none
@@ -150,13 +151,14 @@ inline bool col_form_for (int opl, int nw, int ngv, int wstep, int a8, ColForm *
 }
 
 // tables + form for a plan's two passes.  opl_pref: 0 = the default order (two outputs per lane first), else that many only
-inline bool col_choose (const ScalePass &h, const ScalePass &v, int width, int height, int opl_pref, bool share, ColTables *t, ColForm *form)
+inline bool col_choose (const ScalePass &h, const ScalePass &v, int width, int height, int opl_pref, bool share, ColTables *t, ColForm *form, bool regwin = true)
 {
   for (int opl = 2; opl >= 1; opl--) {
     if (opl_pref && opl != opl_pref)
       continue;
     for (int sh = share ? 1 : 0; sh >= 0; sh--)
-      if (make_col_tables (h, v, width, height, opl, sh != 0, t) && col_form_for (opl, t->nw, t->ngv, t->wstep, t->a8, form)) {
+      if (make_col_tables (h, v, width, height, opl, sh != 0, t) && (regwin || t->a8 < 2 || (t->a8 = 1)) &&
+          col_form_for (opl, t->nw, t->ngv, t->wstep, t->a8, form)) {
         col_align_rows (t, form->ngv);
         return true;
       }
@@ -172,12 +174,12 @@ inline int col_rows_last (const ColTables &t, int rows_per_wave, int out_h)
   return rows_per_wave - extra > 1 ? rows_per_wave - extra : (rows_per_wave > 1 ? 1 : rows_per_wave);
 }
 
-template <int OPL>
+template <int OPL, int RW = 0>
 struct ColGeom {
   static constexpr int PXL = 4 * OPL;                   // source pixels per lane and line (the lane's share of a staged line)
   static constexpr int SPAN = 64 * PXL;
   static constexpr int PP = SPAN + 16;                  // bytes of a staged plane
-  static constexpr int LINEB = 3 * PP;
+  static constexpr int LINEB = RW ? PP : 3 * PP;        // register windows: only the luma goes through LDS (loader lanes -> owner lanes)
   static constexpr int STAGEB = 4 * LINEB + 32;         // + room for the zero-tap words a window may read past the last plane
   static constexpr int SLOTW = 3 * OPL * 64;            // words of a hand-over slot: [channel][lane][output of the lane]
   // loads.  Vector memory instructions cost the same whatever they carry per lane (~14 G wave-instructions / s on the chip: one per ~37
@@ -200,9 +202,9 @@ struct ColChroma {
 #define GSTAMD_COL_CRAW_BYTES(opl) (4 * (128 * (opl) + 16) + 32)
 
 // LDS of a wave: the staged group, the raw chroma rows, then the hand-over slots (the ring of line groups itself lives in registers)
-GSTAMD_H420_HOSTDEV size_t col_wave_bytes (int opl, int ngv, int pubn)
+GSTAMD_H420_HOSTDEV size_t col_wave_bytes (int opl, int ngv, int pubn, int rw = 0)
 {
-  const int slotw = 3 * opl * 64, stage = 4 * 3 * (256 * opl + 16) + 32;
+  const int slotw = 3 * opl * 64, stage = 4 * (rw ? 1 : 3) * (256 * opl + 16) + 32;
   (void) ngv;
   return (size_t) ((stage + GSTAMD_COL_CRAW_BYTES (opl) + pubn * slotw * 4 + 15) & ~15);
 }
@@ -225,6 +227,7 @@ struct ColLane {
   uint32_t sx[OPL], sy[OPL];    // v_perm selectors of the horizontal chroma filter (U; planar: both planes)
   uint32_t sxv[OPL], syv[OPL];  // semi-planar: the V bytes
   uint32_t hu[OPL], hv[OPL];    // h-filtered chroma row 2g-1 (carried from the previous group)
+  uint32_t win[4][3][OPL];      // register windows (col_hfilter_regs): the lane's own words of the four lines' Y / U / V bytes
 };
 
 // the lane's ring: the words of the last NGV line groups of its output column(s), oldest first - registers, moved down one place per group
@@ -333,13 +336,17 @@ GSTAMD_HD uint32_t col_sel_byte (int s, int sb, int cw, int semi, int comp)
   return (uint32_t) (semi ? 2 * pos + comp : pos);
 }
 
-template <int OPL, int NW, int CH, int SEMI>
+template <int OPL, int NW, int CH, int SEMI, int RW = 0>
 GSTAMD_HD void col_setup (const ColParams &p, const int32_t *tile, int lane, ColLane<OPL, NW> &L)
 {
-  typedef ColGeom<OPL> G;
+  typedef ColGeom<OPL, RW> G;
   typedef ColChroma<OPL, SEMI> C;
   const int o0 = tile[0], n = tile[1], s0 = tile[2], p0 = tile[3];
   const int cw = p.width >> 1, delta = p0 - s0;
+  // the lane as the owner of 4 OPL pixels of a line: from the tile's first loaded pixel on - or (register windows) from the pixel its own
+  // window starts with: window space begins s0 - the tile's first window, which may lie left of the picture - and unit 0's window at byte wsh
+  const int wsh = RW ? (int) p.hout[(size_t) o0 * 8] : 0;
+  const int ob = RW ? s0 + wsh : p0;
   // ---- the lane as a loader
   L.ykl = lane / G::YLPL;
   L.yvo = p0 + 16 * (lane % G::YLPL);
@@ -357,11 +364,11 @@ GSTAMD_HD void col_setup (const ColParams &p, const int32_t *tile, int lane, Col
     L.cst[t] = live ? ((SEMI ? row : 2 * t + row) * C::CROWB + 8 * j) : C::CROWS * C::CROWB;
   }
   // ---- the lane as the owner of 4 OPL pixels per line
-  L.st = delta + G::PXL * lane;
+  L.st = (ob - s0) + G::PXL * lane;
   const int uo = SEMI ? (p.u_first ? 0 : 1) : 0;
 #pragma unroll
   for (int j = 0; j < OPL; j++) {
-    const int k = (p0 + G::PXL * lane + 4 * j) >> 1;
+    const int k = (ob + G::PXL * lane + 4 * j) >> 1;
     // planar: the aligned dword pair around sample k - 1; semi-planar: the pairs k - 1 .. k + 2 themselves (8 bytes: no slack to align in -
     // the first tile, whose raw rows start at sample 0 instead of -1, reads them off a 2-byte boundary)
     int cr = SEMI ? (k - 1 - rawbase) * 2 : ((k - 1 - rawbase) & ~3);
@@ -388,6 +395,8 @@ GSTAMD_HD void col_setup (const ColParams &p, const int32_t *tile, int lane, Col
   const int units = n / OPL;
   const int u = lane < units ? lane : units - 1;
   L.xo = o0 + OPL * u;
+  if (RW && lane >= units)
+    L.xo = 0x10000000;          /* register windows: such a lane would repeat the last output from OTHER words - its stores fall out of range (dropped) */
 #pragma unroll
   for (int i = 0; i < OPL; i++) {
     const uint32_t *e = p.hout + (size_t) (o0 + OPL * u + i) * 8;
@@ -397,7 +406,7 @@ GSTAMD_HD void col_setup (const ColParams &p, const int32_t *tile, int lane, Col
     for (int k = 0; k < 4; k++) {
       // one address register per staged line: all three planes of a line are within reach of its LDS instructions' immediate offsets
       // (8 bits of dwords for the paired reads).  Opaque, or the compiler folds the lines back onto one base and adds a constant per read.
-      L.lb[k][i] = L.wb[i] + k * ColGeom<OPL>::LINEB;
+      L.lb[k][i] = L.wb[i] + k * G::LINEB;
 #ifdef __HIPCC__
       asm volatile ("" : "+v" (L.lb[k][i]));
 #endif
@@ -424,7 +433,7 @@ GSTAMD_HD void col_request_chroma (const ColParams &p, const ColSrc &s, const Co
 template <int OPL, int NW, int SEMI>
 GSTAMD_HD void col_request (const ColParams &p, const ColSrc &s, const ColLane<OPL, NW> &L, int g, ColRaw<OPL> &r)
 {
-  typedef ColGeom<OPL> G;
+  typedef ColGeom<OPL> G;          /* (the members used here do not depend on the window form) */
 #if defined(GSTAMD_COL_ABL) && GSTAMD_COL_ABL == 1      /* profiling builds only (results WRONG): no source loads after a wave's first */
   if (g != -12345)
     return;
@@ -465,10 +474,10 @@ GSTAMD_HD void col_lds_store (uint8_t *d, const uint32_t *w)
 }
 
 // first half of the staging, the lane as a loader: the luma bytes (XOR 0x80) straight into their plane, the raw chroma rows into the raw area
-template <int OPL, int NW, int SEMI, int ALIGNED>
+template <int OPL, int NW, int SEMI, int ALIGNED, int RW = 0>
 GSTAMD_HD void col_stage_loads (const ColLane<OPL, NW> &L, const ColRaw<OPL> &r, uint8_t *stage, uint8_t *craw, bool with_luma)
 {
-  typedef ColGeom<OPL> G;
+  typedef ColGeom<OPL, RW> G;
   typedef ColChroma<OPL, SEMI> C;
   if (with_luma) {
 #pragma unroll
@@ -514,7 +523,7 @@ GSTAMD_HD void col_hup (const ColLane<OPL, NW> &L, const uint8_t *craw, int row,
 // second half of the staging, the lane as the owner of 4 OPL pixels of every line: U and V byte planes of the four lines.  Chroma rows:
 // A = 2g-1 (carried, h-filtered), B = 2g, C = 2g+1; line 4g-1 = (3 A + B + 2) >> 2, 4g = (A + 3 B + 2) >> 2, 4g+1 = (3 B + C + 2) >> 2,
 // 4g+2 = (B + 3 C + 2) >> 2 per byte, each as lerp (heavy, (heavy + light) >> 1) - the inner average is the same for the two lines of a pair.
-template <int OPL, int NW, int CH, int SEMI, int ALIGNED>
+template <int OPL, int NW, int CH, int SEMI, int ALIGNED, int RW = 0>
 GSTAMD_HD void col_stage_chroma (ColLane<OPL, NW> &L, const uint8_t *craw, uint8_t *stage)
 {
   typedef ColGeom<OPL> G;
@@ -531,6 +540,14 @@ GSTAMD_HD void col_stage_chroma (ColLane<OPL, NW> &L, const uint8_t *craw, uint8
     lu[2][j] = lerp_u8 (bu[j], nu, 0x01010101u) ^ 0x80808080u, lv[2][j] = lerp_u8 (bv[j], nv, 0x01010101u) ^ 0x80808080u;
     lu[3][j] = lerp_u8 (cu[j], nu, 0x01010101u) ^ 0x80808080u, lv[3][j] = lerp_u8 (cv[j], nv, 0x01010101u) ^ 0x80808080u;
     L.hu[j] = cu[j], L.hv[j] = cv[j];
+  }
+  if constexpr (RW) {           /* the words stay with the lane: they ARE its window's first words (col_hfilter_regs) */
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < OPL; j++)
+        L.win[k][1][j] = lu[k][j], L.win[k][2][j] = lv[k][j];
+    return;
   }
   uint8_t *d = stage + L.st;
 #pragma unroll
@@ -656,6 +673,44 @@ GSTAMD_HD void col_hfilter (const ColLane<OPL, NW> &L, const uint8_t *stage, uin
       gw[c][i] = col_fin4 (acc[0][c][i], acc[1][c][i], acc[2][c][i], acc[3][c][i]);
 }
 
+// The same pass with the windows in REGISTERS (two outputs per lane sharing a window one word apart, the tile's staged bytes at their
+// natural place: window word q of lane l is own word q for q < 2, else word (q - 2) & 1 of lane l + 1 + (q - 2) / 2).  The lane's own two
+// words of a line and plane it already holds (U / V: col_stage_chroma left them in L.win; Y: one 8-byte LDS read of what the loader lanes
+// staged); the neighbours' come over the lanes with DPP wave shifts (v_mov_b32_dpp wave_shl:1 - lane l reads lane l + 1, the last lane
+// zero: its window words there only meet zero taps) instead of the five-word LDS read per line and plane of col_hfilter: 424 -> 152 bytes
+// of LDS traffic per lane and group, 36 more VALU.  nb (v, k, c, j, dist): the word [k][c][j] of lane + dist; on the device that is the
+// shift of v (the caller hands over the lane's own word for dist 1 and the dist-1 result for dist 2), in the emulator a look at that lane.
+template <int OPL, int NW, class NB>
+GSTAMD_HD void col_hfilter_regs (const ColLane<OPL, NW> &L, NB &nb, uint32_t gw[3][OPL])
+{
+  static_assert (OPL == 2 && NW <= 4, "register windows: two outputs per lane, windows of up to five words");
+  constexpr int NWORDS = NW + 1;
+  int acc[4][3][OPL];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      uint32_t w[5];
+      w[0] = L.win[k][c][0], w[1] = L.win[k][c][1];
+      w[2] = nb (w[0], k, c, 0, 1);
+      w[3] = NWORDS > 3 ? nb (w[1], k, c, 1, 1) : 0u;
+      w[4] = NWORDS > 4 ? nb (w[2], k, c, 0, 2) : 0u;
+#pragma unroll
+      for (int i = 0; i < OPL; i++) {
+        int a = L.hinit[i];
+#pragma unroll
+        for (int q = 0; q < NW; q++)
+          a = col_dot4 (w[q + i], L.tw[i][q], a);
+        acc[k][c][i] = a;
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int i = 0; i < OPL; i++)
+      gw[c][i] = col_fin4 (acc[0][c][i], acc[1][c][i], acc[2][c][i], acc[3][c][i]);
+}
+
 // a ring slot (or a slot of the hand-over area): [channel][lane][output of the lane]
 template <int OPL>
 GSTAMD_HD void col_slot_store (uint32_t *slot, int lane, const uint32_t gw[3][OPL])
@@ -760,15 +815,15 @@ GSTAMD_HD bool col_wave_plan (const ColParams &p, int chunk, int wave, ColWavePl
   w->ga = (int) e[0];
   col_entry8 (p.vrow, w->r1 - 1, e);
   w->gl = (int) e[1];
-  if (w->r1 == rb) {
-    w->ge = w->gl + 1;                  // the workgroup's last wave makes every group its rows need
+  if (w->r1 == rb || p.pubn == 0) {
+    w->ge = w->gl + 1;                  // the workgroup's last wave makes every group its rows need (pubn == 0: every wave does - no hand-over area)
   } else {
     col_entry8 (p.vrow, w->r1, e);
     w->ge = (int) e[0];
     if (w->ge > w->gl + 1)
       w->ge = w->gl + 1;
   }
-  if (w->r0 == ra) {
+  if (w->r0 == ra || p.pubn == 0) {
     w->gp = w->ga - 1;
   } else {
     col_entry8 (p.vrow, w->r0 - 1, e);
@@ -785,7 +840,8 @@ template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8, int POS
 GSTAMD_HD void col_wave (X &x, const ColParams &p, const ColSrc &s, const int32_t *tile, const ColWavePlan &wp, uint8_t *wave_lds, uint8_t *below_lds,
     uint32_t *flags, int wave, const Dst &dst, const PostFast &pf)
 {
-  typedef ColGeom<OPL> G;
+  constexpr int RW = OPL == 2 && WSTEP == 1 && A8 == 2;
+  typedef ColGeom<OPL, RW> G;
   typedef ColLane<OPL, NW> Lane;
   typedef ColRaw<OPL> Raw;
   typedef ColRingRegs<OPL, NGV> Ring;
@@ -795,12 +851,12 @@ GSTAMD_HD void col_wave (X &x, const ColParams &p, const ColSrc &s, const int32_
   const bool aligned = ((tile[3] - tile[2]) % 16) == 0 && tile[3] > 0 && tile[3] + G::SPAN <= p.width;
   // chroma row 2 ga - 1 the way the staging of group ga - 1 would have left it, then the first group's loads
   x.each ([&](int lane, Lane &L, Raw &ra, Ring &) {
-    col_setup<OPL, NW, CH, SEMI> (p, tile, lane, L);
+    col_setup<OPL, NW, CH, SEMI, RW> (p, tile, lane, L);
     col_request_chroma<OPL, NW, SEMI> (p, s, L, 2 * wp.ga - 2, ra);
     if (aligned)
-      col_stage_loads<OPL, NW, SEMI, 1> (L, ra, stage, craw, false);
+      col_stage_loads<OPL, NW, SEMI, 1, RW> (L, ra, stage, craw, false);
     else
-      col_stage_loads<OPL, NW, SEMI, 0> (L, ra, stage, craw, false);
+      col_stage_loads<OPL, NW, SEMI, 0, RW> (L, ra, stage, craw, false);
     col_request<OPL, NW, SEMI> (p, s, L, wp.ga, ra);
   });
   x.sync ();
@@ -845,28 +901,44 @@ GSTAMD_HD void col_wave (X &x, const ColParams &p, const ColSrc &s, const int32_
     // rows and the other waves' turns to arrive
     if (aligned)
       x.each ([&](int, Lane &L, Raw &ra, Ring &) {
-        col_stage_loads<OPL, NW, SEMI, 1> (L, ra, stage, craw, true);
+        col_stage_loads<OPL, NW, SEMI, 1, RW> (L, ra, stage, craw, true);
         col_request<OPL, NW, SEMI> (p, s, L, gn, ra);
       });
     else
       x.each ([&](int, Lane &L, Raw &ra, Ring &) {
-        col_stage_loads<OPL, NW, SEMI, 0> (L, ra, stage, craw, true);
+        col_stage_loads<OPL, NW, SEMI, 0, RW> (L, ra, stage, craw, true);
         col_request<OPL, NW, SEMI> (p, s, L, gn, ra);
       });
     x.sync ();
     if (aligned)
-      x.each ([&](int, Lane &L, Raw &, Ring &) { col_stage_chroma<OPL, NW, CH, SEMI, 1> (L, craw, stage); });
+      x.each ([&](int, Lane &L, Raw &, Ring &) { col_stage_chroma<OPL, NW, CH, SEMI, 1, RW> (L, craw, stage); });
     else
-      x.each ([&](int, Lane &L, Raw &, Ring &) { col_stage_chroma<OPL, NW, CH, SEMI, 0> (L, craw, stage); });
+      x.each ([&](int, Lane &L, Raw &, Ring &) { col_stage_chroma<OPL, NW, CH, SEMI, 0, RW> (L, craw, stage); });
     x.sync ();
     COL_STAMP (2);                      /* staging */
-    x.each ([&](int lane, Lane &L, Raw &, Ring &rg) {
-      uint32_t gw[3][OPL];
-      col_hfilter<OPL, NW, WSTEP, A8> (L, stage, gw);
-      col_ring_put<OPL, NGV> (rg, gw);
-      if (g <= wp.gp)
-        col_slot_store<OPL> (pub + (size_t) (g - wp.ga) * G::SLOTW, lane, gw);
-    });
+    if constexpr (RW) {
+      // the lane's own luma words of the four lines (what the loader lanes staged), then the windows over the lanes
+      x.each ([&](int, Lane &L, Raw &, Ring &) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          col_lds_words<2, 1> (stage + L.st + k * G::LINEB, L.win[k][0]);
+      });
+      x.each_nb ([&](int lane, Lane &L, Raw &, Ring &rg, auto &nb) {
+        uint32_t gw[3][OPL];
+        col_hfilter_regs<OPL, NW> (L, nb, gw);
+        col_ring_put<OPL, NGV> (rg, gw);
+        if (g <= wp.gp)
+          col_slot_store<OPL> (pub + (size_t) (g - wp.ga) * G::SLOTW, lane, gw);
+      });
+    } else {
+      x.each ([&](int lane, Lane &L, Raw &, Ring &rg) {
+        uint32_t gw[3][OPL];
+        col_hfilter<OPL, NW, WSTEP, A8> (L, stage, gw);
+        col_ring_put<OPL, NGV> (rg, gw);
+        if (g <= wp.gp)
+          col_slot_store<OPL> (pub + (size_t) (g - wp.ga) * G::SLOTW, lane, gw);
+      });
+    }
     x.sync ();
     if (g == wp.gp)
       x.publish (flags, wave);

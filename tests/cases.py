@@ -938,6 +938,17 @@ def _deep_plane_sweep():
 
 
 VIDEO_CASES += _deep_plane_sweep()
+# k_scale_col's register windows (round 5, col_hfilter_regs): pictures wide enough to have column tiles between the first and the last one
+# (only those sit at their natural place in the window space): C3's 4:1 Lanczos shape on planar and semi-planar sources, both chroma
+# filters, a crop, and the 3-tap-word form of a 2:1 cubic
+VIDEO_CASES += [
+    ("regwin_i420_rgba_quarter_lanczos_wide", "I420", 2560, 96, "RGBA", 640, 24, dict(LAN), None, None, "random"),
+    ("regwin_nv12_bgra_quarter_lanczos_wide_jpeg", "NV12", 3072, 64, "BGRA", 768, 16, dict(LAN), None, "jpeg", "random"),
+    ("regwin_nv21_argb_quarter_lanczos_wide_cosited", "NV21", 2048, 80, "ARGB", 512, 20, dict(LAN), "bt601", "cosited", "random"),
+    ("regwin_yv12_rgba_half_cubic_wide", "YV12", 2560, 64, "RGBA", 1280, 32, dict(resampler_method="cubic"), None, None, "random"),
+    ("regwin_i420_rgba_quarter_lanczos_wide_crop", "I420", 2600, 100, "RGBA", 640, 24, dict(LAN, src_x=24, src_y=2, src_width=2560, src_height=96), None, None, "random"),
+    ("regwin_i420_bgra_quarter_lanczos_8k_line", "I420", 7680, 32, "BGRA", 1920, 8, dict(LAN), None, None, "ramp"),
+]
 
 
 # fill-border = FALSE over the same plans: compared on the bytes the picture decides (scripts/fuzz_video.py matches_reference)

@@ -242,8 +242,9 @@ static void run_h420_reg_ch (const H420RegParams &p, int chroma_h, int n_taps)
 
 // ---- k_scale_col (video_col_kernels.hip): video_scale_col.h's col_wave with the 64 lanes of a wave run one after the other, the waves of a
 // workgroup from the bottom one up (a wave's hand-over copy exists before the wave above asks for it - on the device a flag says so) ----
-static int g_col_runs = 0;
+static int g_col_runs = 0, g_col_regwin = 0;
 extern "C" int emu_col_runs (void) { return g_col_runs; }
+extern "C" int emu_col_regwin_groups (void) { return g_col_regwin; }          /* line groups filtered from register windows (col_hfilter_regs) */
 // quad_grid_find over a whole grid: 1 when every (job, workgroup) pair comes up exactly once
 extern "C" int emu_quad_grid_check (int n0, int n1, int n2)
 {
@@ -275,6 +276,14 @@ struct ColExecEmu {
   ColRaw<OPL> ra[64];
   ColRingRegs<OPL, NGV> rg[64];
   template <class F> void each (F f) { for (int lane = 0; lane < 64; lane++) f (lane, L[lane], ra[lane], rg[lane]); }
+  // register windows: the word [k][c][j] of the lane `dist` places up (the device shifts `v` across the lanes: v_mov_b32_dpp wave_shl:1, zero into the last lane)
+  struct Nb {
+    ColExecEmu *x;
+    int lane;
+    uint32_t operator() (uint32_t, int k, int c, int j, int dist) const { return lane + dist < 64 ? x->L[lane + dist].win[k][c][j] : 0u; }
+  };
+  template <class F> void each_nb (F f) { g_col_regwin++; for (int lane = 0; lane < 64; lane++) { Nb nb = {this, lane}; f (lane, L[lane], ra[lane], rg[lane], nb); } }
+  template <class F> bool all (F pred) { bool r = true; for (int lane = 0; lane < 64; lane++) r = pred (lane, L[lane]) && r; return r; }
   void sync () {}
   void publish (uint32_t *flags, int wave) { flags[wave] = 1u; }
   void wait_flag (uint32_t *flags, int wave)
@@ -289,7 +298,7 @@ struct ColExecEmu {
 template <int OPL, int NW, int NGV, int CH, int SEMI, int WSTEP, int A8, int POST>
 static void run_scale_col (const ColParams &p, const ColSrc &src, const Dst &dst, const PostFast &pf, int nwaves)
 {
-  const size_t wave_bytes = col_wave_bytes (OPL, NGV, p.pubn);
+  const size_t wave_bytes = col_wave_bytes (OPL, NGV, p.pubn, OPL == 2 && WSTEP == 1 && A8 == 2);
   std::vector<uint32_t> lds_words ((GSTAMD_COL_FLAG_BYTES + (size_t) (nwaves + 1) * wave_bytes) / 4 + 16);
   uint8_t *lds = (uint8_t *) lds_words.data ();
   for (int chunk = 0; chunk < p.n_chunks; chunk++)
@@ -344,7 +353,7 @@ static bool emu_scale_col (const VideoPlan &p, const SrcFront &sf, const Dst &ds
   ColTables t;
   ColForm f;
   const char *eo = getenv ("GSTAMD_COL_OPL"), *es = getenv ("GSTAMD_COL_SHARE");
-  if (!col_choose (p.passes[0], p.passes[1], p.front.width, p.front.height, eo ? atoi (eo) : 0, !(es && atoi (es) == 0), &t, &f))
+  if (!col_choose (p.passes[0], p.passes[1], p.front.width, p.front.height, eo ? atoi (eo) : 0, !(es && atoi (es) == 0), &t, &f, !getenv ("GSTAMD_COL_NO_REGWIN")))
     return false;
   if (((uintptr_t) dst.p % (4 * f.opl)) != 0 || (dst.stride % (4 * f.opl)) != 0)
     return false;

@@ -21,6 +21,10 @@ import subprocess
 import sys
 import time
 
+# kernel arguments in device memory (a HIP runtime switch read when the runtime initialises - PyTorch does that long before the library is
+# loaded, so the library's own load-time default comes too late here; gstreamer_amd/csrc/tuning.cpp says what it buys)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -64,6 +64,16 @@ Knob *find (const char *name)
 
 }  // namespace
 
+// Kernel arguments in device memory: the command processor fetches a launch's arguments from HBM instead of over PCIe from host memory.  On MI355X
+// that takes ~3.7 us off every launch (4K NV12 -> BGRA, one frame per launch: 15.2 -> 11.5 us; lists of 32: 245 -> 232 us; profiles/r04/
+// launch_kernarg.log) - a frame a launch is what a live pipeline runs.  It is a switch of the HIP runtime, read when the runtime initialises
+// (the first HIP call of the process): this library asks for it when it is loaded, unless the environment already says something.  A process
+// that has initialised HIP before loading the library (PyTorch) sets HIP_FORCE_DEV_KERNARG=1 itself - bench.py does.
+__attribute__ ((constructor)) static void gstamd_runtime_defaults ()
+{
+  setenv ("HIP_FORCE_DEV_KERNARG", "1", 0);
+}
+
 namespace gstamd {
 
 int tuning_int (const char *name, int unset)

@@ -20,6 +20,7 @@
 #include "video_encode_fast.h"
 #include "video_scale420_fused.h"
 #include "video_scale_col.h"
+#include "video_dither_ed.h"
 
 using namespace gstamd;
 
@@ -612,7 +613,7 @@ static int alloc_scratch (GstAmdVideoConverter *c)
       return hip_fail (e, "hipMalloc(pack image)");
   }
   {
-    const DitherParams &dp = p.out_planar ? p.pack.dither : p.dither;
+    const DitherParams &dp = p.gamma.on && (p.gamma.pack16 || p.gamma.store64) ? p.gamma.dither16 : (p.out_planar ? p.pack.dither : p.dither);
     if (dp.on && (dp.method == GSTAMD_DITHER_FLOYD_STEINBERG || dp.method == GSTAMD_DITHER_SIERRA_LITE) &&
         (e = hipMalloc (&c->ed_carry, (size_t) (p.out_info.width + 4) * 8)) != hipSuccess)
       return hip_fail (e, "hipMalloc(dither carry)");
@@ -926,8 +927,21 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       /* the last 16-bit image is the picture (pack_ARGB64 / pack_AYUV64 are copies at native endianness) */
       e = hipMemcpy2DAsync (planes[0], (size_t) strides[0], cur.p, (size_t) cur.stride, (size_t) out_w * 8, (size_t) out_h, hipMemcpyDeviceToDevice, stream);
       if (e == hipSuccess && g.dither16.on)
-        e = launch_dither16_image (g.dither16, planes[0], strides[0], out_w, out_h, stream);
+        e = launch_dither16_any (g.dither16, planes[0], strides[0], out_w, out_h, stream, c->ed_carry);
       return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "copy of the 16-bit image");
+    }
+    if (dither_is_diffusion (g.dither16)) {
+      /* error diffusion: chroma downsamplers, then the dither pass, in place on the image - never on the caller's frame */
+      if (cur_is_source) {
+        if ((size_t) out_w * 8 * out_h > c->deep_a_size)
+          return set_error (GSTAMD_ERR_INVALID, "16-bit scratch image smaller than the picture");
+        if ((e = hipMemcpy2DAsync (c->deep_a, (size_t) out_w * 8, cur.p, (size_t) cur.stride, (size_t) out_w * 8, (size_t) out_h, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
+          return hip_fail (e, "copy of the 16-bit source");
+        cur.p = c->deep_a, cur.stride = out_w * 8;
+        cur_is_source = false;
+      }
+      e = launch_pack16_ed (g.pack, g.pack_hi_depth, g.dither16, (uint8_t *) cur.p, cur.stride, planes, strides, stream, c->ed_carry);
+      return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_pack16 (error diffusion)");
     }
     e = launch_pack16 (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, planes, strides, stream);
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_pack16");

@@ -1753,6 +1753,8 @@ static void setup_dither16 (const GstAmdVideoConverterConfig &cfg, const FormatD
   int shift = 0;
   for (unsigned v = q; v > 1; v >>= 1)
     shift++;
+  if (shift > 16)
+    shift = 16;                 /* guint16 masks */
   d->on = shift > 0;
   d->method = cfg.dither_method;
   /* the planar formats have no alpha component (depth 0: quantiser 0); ARGB64 / AYUV64 carry 16 bits of it like the other three - their own
@@ -1765,7 +1767,7 @@ static void setup_dither16 (const GstAmdVideoConverterConfig &cfg, const FormatD
     int sa = 0;
     for (unsigned v = qa; v > 1; v >>= 1)
       sa++;
-    d->shift[0] = sa;
+    d->shift[0] = sa > 16 ? 16 : sa;
   }
   d->shift[1] = d->shift[2] = d->shift[3] = shift;
 }
@@ -1785,8 +1787,6 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   const bool in16 = fi->hi_depth != 0, out16 = fo->hi_depth != 0;
   if (out16 && !kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && fo->kind != UNPACK_Y410 && fo->kind != UNPACK_V210)
     return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destination layout not implemented on the GPU path");
-  if (out16 && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path");
   /* a 10 / 12 / 16-bit planar SOURCE: the 16-bit front (unpack + chroma upsampler, k_front16) of the conversion into an AYUV64 frame of
    * the same size - planned like any other conversion, its front / pair table taken over */
   FrontParams front16;
@@ -1814,9 +1814,12 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     VideoPlan tmp;
     std::string terr;
     memset (&tmp.rect, 0, sizeof (tmp.rect));
-    tmp.rect.in_maxw = tmp.rect.out_maxw = in->width;
-    tmp.rect.in_maxh = tmp.rect.out_maxh = in->height;
-    tmp.orig_in = *in;
+    /* the crop inside its frame: the chroma upsampler pairs the FRAME's rows (the rows above and below a crop are read, do_unpack_lines :2966) -
+       round 4 planned this front as if the crop were the frame (found by the round-5 fuzz draws of gamma-mode = remap with a vertical crop) */
+    tmp.rect.in_x = plan->rect.in_x, tmp.rect.in_y = plan->rect.in_y;
+    tmp.rect.in_maxw = fw, tmp.rect.in_maxh = fh;
+    tmp.rect.out_maxw = in->width, tmp.rect.out_maxh = in->height;
+    tmp.orig_in = plan->orig_in;
     tmp.orig_out = a64;
     const int tr = plan_core (in, &a64, &fc, &tmp, &terr);
     if (tr != GSTAMD_OK)
@@ -2115,6 +2118,8 @@ static void deep_planes_try (const GstAmdVideoInfo *in, const GstAmdVideoInfo *o
   d.out_v = fo->v_plane;
   if (fo->hi_depth)
     d.dither = g.dither16;
+  if (fo->hi_depth && g.dither16.on && g.dither16.method != GSTAMD_DITHER_BAYER)
+    return;                     /* error diffusion runs over whole AYUV64 lines (launch_pack16_ed), not sample by sample */
   g.planes_fast = true;
 }
 
@@ -2162,8 +2167,6 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   GammaPlan &g = plan->gamma;
   if (cfg.gamma_mode == GSTAMD_GAMMA_MODE_REMAP && !plane_scale)
     return fail (GSTAMD_ERR_UNSUPPORTED, "gamma-mode = remap with a 16-bit unpack format is not implemented on the GPU path");
-  if (fo->hi_depth && cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
-    return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path");
   g.on = true;
   g.src64 = true;
   g.src16 = false;
@@ -2481,9 +2484,10 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   if (plan->fout->hi_depth) {
     /* a 10-bit destination always has a dither stage unless the method is none (16-bit lines into 10-bit samples: quantiser 64):
        finalize_deep_out */
-    if (cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER)
-      return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither methods are not implemented on the GPU path (10-bit destinations dither by default: "
-          "choose bayer or none)");
+    /* the error-diffusion methods on 16-bit lines (video_dither_ed.h ed16_*): the same frame-line-0 rule as on 8-bit lines below */
+    if (cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER && plan->rect.out_y != 0)
+      return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither into a destination rectangle below the frame's first line: the reference never clears the "
+          "error line there (y == 0 is the frame's line 0), so every frame depends on the one before");
   } else if (cfg.dither_quantization > 1 && cfg.dither_method != GSTAMD_DITHER_NONE) {
     /* verterr / floyd-steinberg / sierra-lite (video_dither_ed.h) clear their error line when the FRAME's line 0 comes by (video-dither.c:82,
        124, 192: y == 0, and y counts from the frame's top): with a destination rectangle that starts lower the errors of one frame's last
@@ -2494,9 +2498,11 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     int shift = 0;
     for (unsigned q = cfg.dither_quantization; q > 1; q >>= 1)
       shift++;
-    const bool diffusion = cfg.dither_method != GSTAMD_DITHER_BAYER;
-    if (shift > (diffusion ? 16 : 8))             /* the error methods mask a guint16 (GstVideoDither::mask), the ordered one adds a byte-sized matrix value */
-      shift = diffusion ? 16 : 8;
+    /* every method masks with a guint16 (GstVideoDither::mask; the ordered one with FLAG_QUANTIZE runs on 16-bit sums of pixel + matrix value,
+       video_orc_dither_ordered_4u8_mask): a quantiser of 512 and more clears every component it applies to.  (Round 4 capped the ordered
+       method at 256 - found by the round-5 fuzz draws of dither-quantization 1024.) */
+    if (shift > 16)
+      shift = 16;
     if (plan->out_planar) {
       /* planar / semi-planar / 3-byte / packed 4:2:2 destinations: the stage sits between chroma downsampling and packing - it is
          part of the pack kernel (PackPlanarParams::dither, shift[] in unpack order); none of these formats has an alpha component */
@@ -3064,6 +3070,11 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         *error = "a destination rectangle inside a v210 frame is only implemented for the 16-bit chain's packer";
       return GSTAMD_ERR_UNSUPPORTED;
     }
+    if (plan->gamma.dither16.on && plan->gamma.dither16.method != GSTAMD_DITHER_BAYER) {
+      if (error)
+        *error = "error-diffusion dither into a rectangle inside a v210 frame is not implemented on the GPU path";
+      return GSTAMD_ERR_UNSUPPORTED;
+    }
     PackPlanarParams &pk = plan->gamma.pack;
     pk.frame_on = rc.fill ? 2 : 1;
     pk.frame_x = rc.out_x, pk.frame_y = rc.out_y, pk.frame_w = rc.out_maxw, pk.frame_h = rc.out_maxh;
@@ -3155,7 +3166,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   /* the composite plans (8-bit source into the 16-bit part of the chain) unpack and upsample the whole frame in line order before
    * anything else; the reference's vertical chroma upsampler pairs lines in the order the nearest vertical scaler asks for them
    * (it skips / repeats lines), which the pair-table simulation of the direct plans follows and the composite does not */
-  if (chain && pl.gamma.on && !pl.gamma.src16 && !pl.gamma.src64 && fi->h_sub == 1 && kind_has_planes (fi->kind)) {
+  /* (a 10 / 12 / 16-bit 4:2:0 source under gamma-mode = remap goes the same way: its 16-bit front is planned as an unscaled conversion, plan_gamma) */
+  if (chain && pl.gamma.on && (!pl.gamma.src16 || remap) && !pl.gamma.src64 && fi->h_sub == 1 && kind_has_planes (fi->kind)) {
     for (const ScalePass &sp : pl.passes)
       if (!sp.horizontal && sp.kind == SCALE_NEAREST) {
         if (error)

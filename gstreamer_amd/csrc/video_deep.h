@@ -770,6 +770,35 @@ GSTAMD_HD uint16_t pack16_sample (int hi_depth, int v)
   return (uint16_t) (hi_depth == 1 || hi_depth == 4 ? v >> drop : v & ~((1 << drop) - 1));      /* pack_I420_10LE >> 6, pack_P010_10LE & 0xffc0, ... */
 }
 
+GSTAMD_HD void pack16_chroma_h (const PackPlanarParams &pk, const uint2 *row, int w, int x, int *u, int *v);
+
+// The chroma downsamplers IN PLACE on the AYUV64 image, the way the reference's run on its lines (video_chroma_down_v2_u16 writes the
+// pair's first line, the horizontal ones the even pixels; everything else keeps its values): what an error-diffusion dither stage has to
+// see - it runs over every component of every pixel AFTER them, also the ones no packer picks up (video_pack.h pack_down_v_px / _h_px
+// are the 8-bit twins).  x = pixel, yb = line pair (h_sub) / line.
+GSTAMD_HD void pack16_down_v_px (const PackPlanarParams &pk, uint8_t *img, int stride, int x, int yb)
+{
+  const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
+  if (x >= w || y0 >= h || !pk.down_v)
+    return;
+  uint2 *ra = (uint2 *) (img + (size_t) y0 * stride);
+  const uint2 *rb = (const uint2 *) (img + (size_t) (y0 + 1 < h ? y0 + 1 : h - 1) * stride);
+  const uint32_t a = ra[x].y, b = rb[x].y;
+  const uint32_t u = ((a & 0xffffu) + (b & 0xffffu) + 1u) >> 1, v = ((a >> 16) + (b >> 16) + 1u) >> 1;          /* avguw */
+  ra[x].y = u | (v << 16);
+}
+
+GSTAMD_HD void pack16_down_h_px (const PackPlanarParams &pk, uint8_t *img, int stride, int x, int yb)
+{
+  const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
+  if (x >= w || y0 >= h || pk.w_sub != 1 || !pk.down_h || (x & 1))
+    return;
+  uint2 *ra = (uint2 *) (img + (size_t) y0 * stride);
+  int u, v;
+  pack16_chroma_h (pk, ra, w, x, &u, &v);          /* reads the odd neighbours only, which no lane writes */
+  ra[x].y = (uint32_t) u | ((uint32_t) v << 16);
+}
+
 // per-lane block as pack_planar_body: pixels x0 .. x0+3 of the lines (yb << h_sub) ..; planar and semi-planar kinds
 GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride,
     const DstPlanes16 &d, int x0, int yb)

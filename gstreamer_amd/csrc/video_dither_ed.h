@@ -94,6 +94,96 @@ GSTAMD_HD uint32_t ed_floyd_px (const DitherParams &d, uint32_t px, Err4 &left, 
   return r;
 }
 
+// ---- the same methods on 16-bit lines (round 5): dither_verterr_u16 (video-dither.c:89-115), dither_floyd_steinberg_u16 (:153-180),
+// dither_sierra_lite_u16 (:208-232) ahead of the 10 / 12 / 16-bit packers and of pack_ARGB64 / pack_AYUV64.  Plain C there, 32-bit sums:
+//   verterr      v = p + P(x)
+//   sierra-lite  v = p + ((2 L + P(x+1) + P(x+2)) >> 2)
+//   floyd-st.    v = p + ((7 L + P(x) + 5 P(x+1) + 3 P(x+2)) >> 4)     (one expression: no muladd pass, slot 0 stays 0 - L = 0 at x = 0)
+//   all          err = v & mask;  v &= ~mask;  p = min (v, 65535)
+// A pixel is 4 x u16 (A, Y, U, V / A, R, G, B in unpack order), DitherParams::shift[] per component.
+struct Px16 {
+  uint32_t lo, hi;              // components 0, 1 / 2, 3 (16 bits each, little-endian)
+};
+
+GSTAMD_HD uint32_t ed16_quantise (const DitherParams &d, int k, uint32_t v, uint16_t *err)
+{
+  const uint32_t mask = (1u << d.shift[k]) - 1u;
+  *err = (uint16_t) (v & mask);
+  v &= ~mask;
+  return v > 65535u ? 65535u : v;
+}
+
+GSTAMD_HD uint32_t ed16_comp (const Px16 &p, int k) { return k < 2 ? (p.lo >> (16 * k)) & 0xffffu : (p.hi >> (16 * (k - 2))) & 0xffffu; }
+
+GSTAMD_HD Px16 ed16_pack (const uint32_t *c)
+{
+  Px16 r;
+  r.lo = c[0] | (c[1] << 16);
+  r.hi = c[2] | (c[3] << 16);
+  return r;
+}
+
+GSTAMD_HD Px16 ed16_verterr_px (const DitherParams &d, const Px16 &px, Err4 &err)
+{
+  uint32_t c[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    c[k] = ed16_quantise (d, k, ed16_comp (px, k) + err.c[k], &err.c[k]);
+  return ed16_pack (c);
+}
+
+GSTAMD_HD Px16 ed16_sierra_px (const DitherParams &d, const Px16 &px, Err4 &left, const Err4 &p1, const Err4 &p2)
+{
+  uint32_t c[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    c[k] = ed16_quantise (d, k, ed16_comp (px, k) + ((2u * left.c[k] + p1.c[k] + p2.c[k]) >> 2), &left.c[k]);
+  return ed16_pack (c);
+}
+
+GSTAMD_HD Px16 ed16_floyd_px (const DitherParams &d, const Px16 &px, Err4 &left, const Err4 &p0, const Err4 &p1, const Err4 &p2)
+{
+  uint32_t c[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    c[k] = ed16_quantise (d, k, ed16_comp (px, k) + ((7u * left.c[k] + p0.c[k] + 5u * p1.c[k] + 3u * p2.c[k]) >> 4), &left.c[k]);
+  return ed16_pack (c);
+}
+
+#ifndef __HIPCC__
+// the whole 16-bit rectangle on the host (emulator and tests): prev / cur = errors of the previous / this line per pixel
+inline void ed16_image_host (const DitherParams &d, uint8_t *img, int stride, int w, int h)
+{
+  Err4 *a = new Err4[2 * (size_t) (w + 2)] (), *b = a + (w + 2);
+  Err4 *base = a;
+  for (int y = 0; y < h; y++) {
+    Px16 *row = (Px16 *) (img + (size_t) y * stride);
+    Err4 left = err4_zero ();
+    for (int x = 0; x < w; x++) {
+      if (d.method == GSTAMD_DITHER_VERTERR) {
+        left = a[x];
+        row[x] = ed16_verterr_px (d, row[x], left);
+      } else if (d.method == GSTAMD_DITHER_SIERRA_LITE) {
+        row[x] = ed16_sierra_px (d, row[x], left, a[x + 1], a[x + 2]);
+      } else {
+        row[x] = ed16_floyd_px (d, row[x], left, a[x], a[x + 1], a[x + 2]);
+      }
+      b[x] = left;
+    }
+    b[w] = b[w + 1] = err4_zero ();
+    Err4 *t = a;
+    a = b;
+    b = t;
+  }
+  delete[] base;
+}
+#endif
+
+GSTAMD_VP bool dither_is_diffusion (const DitherParams &d)
+{
+  return d.on && (d.method == GSTAMD_DITHER_VERTERR || d.method == GSTAMD_DITHER_FLOYD_STEINBERG || d.method == GSTAMD_DITHER_SIERRA_LITE);
+}
+
 #ifndef __HIPCC__
 // One line on the host (emulator and tests): prev / cur = errors of the previous / this line per pixel (w + 2 entries, the last two 0),
 // a0 = the Floyd-Steinberg slot-0 accumulator (in: previous line's, out: this line's)

@@ -40,6 +40,9 @@ hipError_t launch_gamma_stage (const GammaDev &g, int mask, const uint8_t *src, 
 hipError_t launch_dither4 (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream, void *ed_carry = nullptr);
 hipError_t launch_pack_planar_ed (const PackPlanarParams &pk, uint8_t *img, int sstride, uint8_t *const planes[3], const int strides[3],
     hipStream_t stream, void *ed_carry);
+hipError_t launch_dither16_any (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream, void *ed_carry);
+hipError_t launch_pack16_ed (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, uint8_t *img, int sstride, uint8_t *const planes[3],
+    const int strides[3], hipStream_t stream, void *ed_carry);
 hipError_t launch_dither16_image (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream);
 struct Deep16Image;
 hipError_t launch_front16 (const FrontParams &f, const Planes &pl, const int *vpair_dev, uint8_t *img, int istride, hipStream_t stream);

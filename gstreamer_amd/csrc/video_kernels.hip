@@ -390,6 +390,118 @@ hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const Dither
   return hipGetLastError ();
 }
 
+// ---- error diffusion on 16-bit lines (video_dither_ed.h, round 5) -------------------------------------------------------------------------
+#define GSTAMD_ED_LINES 1024
+__global__ __launch_bounds__ (256) void k_dither16_verterr (DitherParams d, uint8_t *__restrict__ img, int stride, int w, int h)
+{
+  const int x = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+  if (x >= w)
+    return;
+  Err4 e = err4_zero ();
+#pragma unroll 4
+  for (int y = 0; y < h; y++) {
+    Px16 *q = (Px16 *) (img + (size_t) y * stride) + x;
+    *q = ed16_verterr_px (d, *q, e);
+  }
+}
+
+// k_dither_ed's wavefront over 8-byte pixels: lane r = line band + r, three pixels behind lane r - 1, a line's errors in a 4-slot LDS ring
+template <int METHOD>
+__global__ __launch_bounds__ (GSTAMD_ED_LINES) void k_dither16_ed (DitherParams d, uint8_t *__restrict__ img, int stride, int w, int h, Err4 *__restrict__ carry)
+{
+  __shared__ Err4 ring[GSTAMD_ED_LINES][4];
+  const int r = (int) threadIdx.x;
+  for (int band = 0; band < h; band += GSTAMD_ED_LINES) {
+    const int rows = h - band < GSTAMD_ED_LINES ? h - band : GSTAMD_ED_LINES;
+    const int y = band + r;
+    const bool active = r < rows, to_carry = r == rows - 1 && band + rows < h;
+    Px16 *row = (Px16 *) (img + (size_t) (active ? y : band) * stride);
+    Err4 left = err4_zero ();
+    const int nsteps = w + 3 * (rows - 1);
+    Px16 next_px = {0u, 0u};
+    if (active && r == 0)
+      next_px = row[0];
+    for (int s = 0; s < nsteps; s++) {
+      const int x = s - 3 * r;
+      const Px16 px = next_px;
+      if (active && x + 1 >= 0 && x + 1 < w)
+        next_px = row[x + 1];                     /* in flight across the barrier */
+      if (active && x >= 0 && x < w) {
+        Err4 p[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int j = x + k;
+          if (y == 0 || j >= w)
+            p[k] = err4_zero ();
+          else if (r == 0)
+            p[k] = carry[j];
+          else
+            p[k] = ring[r - 1][(j + 1) & 3];
+        }
+        if (x == 0)
+          left = err4_zero ();
+        const Px16 out = METHOD == GSTAMD_DITHER_FLOYD_STEINBERG ? ed16_floyd_px (d, px, left, p[0], p[1], p[2]) : ed16_sierra_px (d, px, left, p[1], p[2]);
+        row[x] = out;
+        ring[r][(x + 1) & 3] = left;
+        if (to_carry)
+          carry[x] = left;
+      }
+      __syncthreads ();
+    }
+  }
+}
+
+// the dither stage over a 16-bit image in place: ordered (k_dither16_image) or one of the error-diffusion methods
+hipError_t launch_dither16_any (const DitherParams &d, uint8_t *img, int stride, int w, int h, hipStream_t stream, void *ed_carry)
+{
+  if (!dither_is_diffusion (d))
+    return launch_dither16_image (d, img, stride, w, h, stream);
+  video_frame_list_touch (img);
+  if (d.method == GSTAMD_DITHER_VERTERR) {
+    hipLaunchKernelGGL (k_dither16_verterr, dim3 ((w + 255) / 256), dim3 (256), 0, stream, d, img, stride, w, h);
+    return hipGetLastError ();
+  }
+  if (h > GSTAMD_ED_LINES && !ed_carry)
+    return hipErrorInvalidValue;
+  if (d.method == GSTAMD_DITHER_FLOYD_STEINBERG)
+    hipLaunchKernelGGL (k_dither16_ed<GSTAMD_DITHER_FLOYD_STEINBERG>, dim3 (1), dim3 (GSTAMD_ED_LINES), 0, stream, d, img, stride, w, h, (Err4 *) ed_carry);
+  else
+    hipLaunchKernelGGL (k_dither16_ed<GSTAMD_DITHER_SIERRA_LITE>, dim3 (1), dim3 (GSTAMD_ED_LINES), 0, stream, d, img, stride, w, h, (Err4 *) ed_carry);
+  return hipGetLastError ();
+}
+
+__global__ __launch_bounds__ (256) void k_pack16_down_v (PackPlanarParams pk, uint8_t *__restrict__ img, int stride)
+{
+  pack16_down_v_px (pk, img, stride, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+__global__ __launch_bounds__ (256) void k_pack16_down_h (PackPlanarParams pk, uint8_t *__restrict__ img, int stride)
+{
+  pack16_down_h_px (pk, img, stride, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+// error-diffusion dither ahead of a 10 / 12 / 16-bit packer: the chroma downsamplers in place on the AYUV64 image (which must not be the
+// caller's frame), the dither pass over every pixel of it, then the packer as a pure selection
+hipError_t launch_pack16_ed (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, uint8_t *img, int sstride, uint8_t *const planes[3],
+    const int strides[3], hipStream_t stream, void *ed_carry)
+{
+  video_frame_list_touch (planes[0]);
+  const int rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
+  const dim3 grid ((pk.width + 255) / 256, rows);
+  if (pk.down_v)
+    hipLaunchKernelGGL (k_pack16_down_v, grid, dim3 (256), 0, stream, pk, img, sstride);
+  if (pk.down_h && pk.w_sub == 1)
+    hipLaunchKernelGGL (k_pack16_down_h, grid, dim3 (256), 0, stream, pk, img, sstride);
+  hipError_t e = hipGetLastError ();
+  if (e != hipSuccess)
+    return e;
+  if ((e = launch_dither16_any (dt, img, sstride, pk.width, pk.height, stream, ed_carry)) != hipSuccess)
+    return e;
+  DitherParams off;
+  memset (&off, 0, sizeof (off));
+  return launch_pack16 (pack_select_only (pk), hi_depth, off, img, sstride, planes, strides, stream);
+}
+
 // 4-byte 8-bit pixels -> deep planar / semi-planar YUV in one kernel (video_deep.h: k_encode16), one wave per workgroup like k_encode420
 template <int SEMI, int NB>
 __global__ __launch_bounds__ (64) void k_encode16 (Enc16Params ep, const uint8_t *__restrict__ src, int sstride, DstPlanes16 d, FrameDeltas fl)
@@ -457,7 +569,6 @@ __global__ __launch_bounds__ (256) void k_dither_verterr (DitherParams d, uint8_
 // the next sit in a 4-slot LDS ring per line (slot (x + 1) & 3 = pixel x: the line below reads pixels x' .. x' + 2 one to three steps after
 // they were written and the slot is rewritten at the fourth); the last line of a 1024-line band hands its errors to the next band through
 // `carry` (w entries in HBM).  One workgroup: the recurrence is serial in x and y, the wavefront is all the parallelism there is.
-#define GSTAMD_ED_LINES 1024
 template <int METHOD>
 __global__ __launch_bounds__ (GSTAMD_ED_LINES) void k_dither_ed (DitherParams d, uint8_t *__restrict__ img, int stride, int w, int h, Err4 *__restrict__ carry)
 {

@@ -16,8 +16,10 @@ import cases  # noqa: E402
 from gstreamer_amd import video as V  # noqa: E402
 
 
-def random_case(rnd, rects=None):
-    """rects: a second generator; when given, 60 % of the cases also get a source crop and / or a destination rectangle with borders"""
+def random_case(rnd, rects=None, more=None):
+    """rects: a second generator; when given, 60 % of the cases also get a source crop and / or a destination rectangle with borders.
+    more: a third generator (round 5) for the options the first two never drew: dither methods (error diffusion on 8- and 16-bit lines),
+    gamma-mode = remap, primaries-mode"""
     fm = sorted(V.FORMATS)
     ifmt, ofmt = rnd.choice(fm), rnd.choice(fm)
     w, h = rnd.randint(1, 70), rnd.randint(1, 40)
@@ -50,6 +52,16 @@ def random_case(rnd, rects=None):
                 cfg["border_argb"] = r.randint(0, 0xffffffff)
             if r.random() < 0.2:
                 cfg["fill_border"] = 0
+    if more is not None:
+        m = more
+        if m.random() < 0.5:
+            cfg["dither_method"] = m.choice(["none", "verterr", "floyd-steinberg", "sierra-lite", "bayer"])
+            if m.random() < 0.5:
+                cfg["dither_quantization"] = m.choice([2, 4, 16, 64, 256, 1024])
+        if m.random() < 0.25:
+            cfg["gamma_mode"] = "remap"
+        if m.random() < 0.15:
+            cfg["primaries_mode"] = m.choice(["merge-only", "fast"])
     return ifmt, w, h, ofmt, ow, oh, cfg, col, site
 
 
@@ -113,9 +125,10 @@ def main():
     rnd = random.Random(seed)
     emu = load_emu()
     rects = random.Random(seed + 77) if "--rects" in sys.argv else None
+    more = random.Random(seed + 313) if "--more" in sys.argv else None
     count = {"ok": 0, "refused": 0, "defined": 0, "bad": 0}
     for it in range(n):
-        case = random_case(rnd, rects)
+        case = random_case(rnd, rects, more)
         verdict, text = run_case(emu, ref, case, seed * 1000 + it)
         count[verdict] += 1
         if verdict == "bad" or "-v" in sys.argv:

@@ -938,6 +938,39 @@ def _deep_plane_sweep():
 
 
 VIDEO_CASES += _deep_plane_sweep()
+# error diffusion on 16-bit lines (round 5, video_dither_ed.h ed16_*: dither_verterr_u16 / dither_floyd_steinberg_u16 / dither_sierra_lite_u16) ahead of
+# the 10 / 12 / 16-bit packers and of pack_ARGB64 / pack_AYUV64: the chroma downsamplers in place, the pass over every component of every pixel,
+# a selecting pack; more than 1024 lines = more than one band of the wavefront kernel
+VIDEO_CASES += [
+    ("ed16_nv12_p010_floyd", "NV12", 64, 48, "P010_10LE", 64, 48, dict(dither_method="floyd-steinberg"), None, None, "random"),
+    ("ed16_nv12_p010_sierra_odd", "NV12", 67, 35, "P010_10LE", 67, 35, dict(dither_method="sierra-lite"), None, None, "random"),
+    ("ed16_bgra_i420_10_verterr", "BGRA", 66, 34, "I420_10LE", 66, 34, dict(dither_method="verterr"), None, None, "random"),
+    ("ed16_bgra_i422_12_floyd_cosited_q64", "BGRA", 65, 33, "I422_12LE", 65, 33, dict(dither_method="floyd-steinberg", dither_quantization=64), None, "cosited", "random"),
+    ("ed16_p010_i420_10_sierra_q256", "P010_10LE", 64, 48, "I420_10LE", 64, 48, dict(dither_method="sierra-lite", dither_quantization=256), None, None, "random"),
+    ("ed16_y444_10_y444_12_floyd", "Y444_10LE", 33, 17, "Y444_12LE", 33, 17, dict(dither_method="floyd-steinberg", dither_quantization=32), None, None, "random"),
+    ("ed16_nv12_y210_floyd", "NV12", 66, 30, "Y210", 66, 30, dict(dither_method="floyd-steinberg"), None, None, "random"),
+    ("ed16_bgra_y410_sierra", "BGRA", 35, 19, "Y410", 35, 19, dict(dither_method="sierra-lite"), None, None, "random"),
+    ("ed16_nv12_v210_verterr", "NV12", 48, 16, "v210", 48, 16, dict(dither_method="verterr"), None, None, "random"),
+    ("ed16_bgra_argb64_floyd_q16", "BGRA", 64, 48, "ARGB64", 64, 48, dict(dither_method="floyd-steinberg", dither_quantization=16), None, None, "random"),
+    ("ed16_ayuv64_p010_sierra_source_untouched", "AYUV64", 40, 30, "P010_10LE", 40, 30, dict(dither_method="sierra-lite"), None, None, "random"),
+    ("ed16_ayuv64_ayuv64_lanczos_floyd_q512", "AYUV64", 40, 30, "AYUV64", 60, 20, dict(LAN, dither_method="floyd-steinberg", dither_quantization=512), None, None, "random"),
+    ("ed16_nv12_p010_lanczos_down_floyd_dest_x", "NV12", 640, 360, "P010_10LE", 326, 180, dict(LAN, dither_method="floyd-steinberg", dest_x=6, dest_y=0, dest_width=320, dest_height=180), None, None, "random"),
+    ("ed16_p010_p010_gamma_remap_sierra", "P010_10LE", 64, 48, "P010_10LE", 64, 48, dict(dither_method="sierra-lite", gamma_mode="remap"), "bt2100-pq>bt2020", None, "random"),
+    ("ed16_nv12_i420_10_floyd_two_bands", "NV12", 48, 1100, "I420_10LE", 48, 1100, dict(dither_method="floyd-steinberg"), None, None, "random"),
+    ("ed16_bgra_argb64_sierra_three_bands", "BGRA", 20, 2060, "ARGB64", 20, 2060, dict(dither_method="sierra-lite", dither_quantization=8), None, None, "ramp"),
+    # the ordered method with a quantiser of 512 and more (16-bit sums, a guint16 mask: everything it applies to becomes 0)
+    ("dither_nv12_abgr_bayer_q1024", "NV12", 34, 18, "ABGR", 34, 18, dict(dither_quantization=1024), None, None, "random"),
+    ("dither_p012_bgrx_bayer_q512_linear_up", "P012_LE", 13, 5, "BGRx", 70, 46, dict(LIN, dither_quantization=512), "bt601", None, "random"),
+]
+
+# gamma-mode = remap from a 10 / 12 / 16-bit 4:2:0 source with a vertical crop: the 16-bit front pairs the FRAME's chroma rows (round 4 planned
+# it as if the crop were the frame - found by the round-5 fuzz draws)
+VIDEO_CASES += [
+    ("gamma16_p010_bgra_vcrop", "P010_10LE", 64, 48, "BGRA", 64, 40, dict(gamma_mode="remap", src_y=4, src_height=40), None, None, "random"),
+    ("gamma16_i420_12_nv12_vcrop_odd_down", "I420_12LE", 64, 48, "NV12", 32, 20, dict(gamma_mode="remap", src_y=3, src_height=41), None, None, "random"),
+    ("gamma16_p016_p010_vcrop_up_floyd", "P016_LE", 64, 48, "P010_10LE", 96, 60, dict(gamma_mode="remap", src_y=0, src_height=40, src_x=4, src_width=56, dither_method="floyd-steinberg"), "bt2100-pq>bt2020", None, "random"),
+]
+
 # k_scale_col's register windows (round 5, col_hfilter_regs): pictures wide enough to have column tiles between the first and the last one
 # (only those sit at their natural place in the window space): C3's 4:1 Lanczos shape on planar and semi-planar sources, both chroma
 # filters, a crop, and the 3-tap-word form of a 2:1 cubic
@@ -968,7 +1001,7 @@ VISIBLE_ONLY = {"uyvy_yv12_33x17_fastpath", "uyvy_y444_33x18_fastpath", "uyvy_yu
 VIDEO_REFUSED = [
     # error diffusion below the frame's first line: the reference's error line is never cleared there, frames depend on each other
     ("NV12", 64, 64, "BGRA", 64, 70, dict(dither_quantization=4, dither_method="floyd-steinberg", dest_x=0, dest_y=3, dest_width=64, dest_height=64)),
-    ("NV12", 64, 64, "P010_10LE", 64, 64, dict(dither_method="sierra-lite")),           # error diffusion on 16-bit lines
+    ("NV12", 64, 64, "P010_10LE", 64, 70, dict(dither_method="sierra-lite", dest_x=0, dest_y=3, dest_width=64, dest_height=64)),   # the same on 16-bit lines
     ("I420", 48, 16, "v210", 48, 16, {}),                # the reference's own v210 fastpaths (convert_I420_v210 ...: samples shifted, not widened) are not built
     ("v210", 48, 16, "UYVY", 48, 16, {}),
     ("UYVY", 24, 11, "UYVY", 81, 29, dict(resampler_method="sinc", dest_x=37, dest_y=3, dest_width=40, dest_height=23)),   # convert_fill_border's group 42 with an odd frame width (plane scaler)
@@ -978,6 +1011,7 @@ VIDEO_REFUSED = [
     ("BGRA", 67, 36, "AYUV", 76, 21, dict(alpha_mode="mult", alpha_value=0.5)),    # alpha stage on MIN (in_width, out_width) pixels of a wider line
     ("YV12", 11, 21, "Y444_16LE", 85, 12, NEAR),         # nearest vertical scaling of 4:2:0 through the composite plans
     ("P010_10LE", 31, 13, "NV12", 23, 13, {}),           # the same through the composite plans
+    ("I420_12LE", 13, 33, "ARGB64", 43, 11, dict(resampler_method="nearest", gamma_mode="remap")),   # ... and under gamma-mode = remap, whose 16-bit front runs in line order
 ]
 
 # Conversions for which the REFERENCE's own output is undefined - it reads lines it has not converted, converts a repeated line once per

@@ -1086,7 +1086,9 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       uint8_t *rect = dst + out->offset[0] + plane_origin (p.fout, 0, p.rect.out_x, p.rect.out_y, out->stride[0]);
       for (int y = 0; y < out_h; y++)
         memcpy (rect + (size_t) y * out->stride[0], cur.p + (size_t) y * cur.stride, (size_t) out_w * 8);
-      if (g.dither16.on)                /* k_dither16_image over the finished picture */
+      if (dither_is_diffusion (g.dither16))          /* launch_dither16_any: k_dither16_verterr / k_dither16_ed */
+        ed16_image_host (g.dither16, rect, out->stride[0], out_w, out_h);
+      else if (g.dither16.on)           /* k_dither16_image over the finished picture */
         for (int y = 0; y < out_h; y++)
           for (int x = 0; x < out_w; x++)
             dither16_image_px (g.dither16, rect, out->stride[0], out_w, out_h, x, y);
@@ -1099,16 +1101,37 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         d.p[i] = dst + out->offset[i] + (frame_pack ? 0 : plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]));
         d.stride[i] = out->stride[i];
       }
+      PackPlanarParams pk16 = g.pack;
+      DitherParams dt16 = g.dither16;
+      std::vector<uint8_t> ed_img;
+      if (dither_is_diffusion (g.dither16)) {
+        /* launch_pack16_ed: the downsamplers in place on (a copy of) the image, the dither pass over all of it, then selection only */
+        ed_img.resize ((size_t) out_w * 8 * out_h);
+        for (int y = 0; y < out_h; y++)
+          memcpy (ed_img.data () + (size_t) y * out_w * 8, cur.p + (size_t) y * cur.stride, (size_t) out_w * 8);
+        const int prow = (pk16.height + (1 << pk16.h_sub) - 1) >> pk16.h_sub;
+        for (int pass = 0; pass < 2; pass++)
+          for (int yb = 0; yb < prow; yb++)
+            for (int x = 0; x < pk16.width; x++)
+              if (pass == 0)
+                pack16_down_v_px (pk16, ed_img.data (), out_w * 8, x, yb);
+              else
+                pack16_down_h_px (pk16, ed_img.data (), out_w * 8, x, yb);
+        ed16_image_host (g.dither16, ed_img.data (), out_w * 8, out_w, out_h);
+        cur.p = ed_img.data (), cur.stride = out_w * 8;
+        pk16 = pack_select_only (pk16);
+        memset (&dt16, 0, sizeof (dt16));
+      }
       if (g.pack.kind == UNPACK_P422_16 || g.pack.kind == UNPACK_Y410 || g.pack.kind == UNPACK_V210) {          /* k_pack16_packed */
         for (int y = 0; y < pack16_rows (g.pack); y++)
           for (int un = 0; un < (pack16_units (g.pack) + 255) / 256 * 256; un++)
-            pack16_packed_body (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, d.p[0], d.stride[0], un, y);
+            pack16_packed_body (pk16, g.pack_hi_depth, dt16, cur.p, cur.stride, d.p[0], d.stride[0], un, y);
         return GSTAMD_OK;
       }
       const int rows = (g.pack.height + (1 << g.pack.h_sub) - 1) >> g.pack.h_sub;
       for (int yb = 0; yb < rows; yb++)
         for (int x0 = 0; x0 < (g.pack.width / 4 + 256) / 256 * 1024; x0 += 4)
-          pack16_body (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, d, x0, yb);
+          pack16_body (pk16, g.pack_hi_depth, dt16, cur.p, cur.stride, d, x0, yb);
       return GSTAMD_OK;
     }
     plan_set_border_override (p.rect.border);

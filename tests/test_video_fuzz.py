@@ -12,16 +12,18 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import fuzz_video  # noqa: E402
 
 
-# seeds from 700 on also draw source crops, destination rectangles and border colours (fuzz_video.random_case's second generator)
-@pytest.mark.parametrize("seed", [101, 202, 303, 707, 808])
+# seeds from 700 on also draw source crops, destination rectangles and border colours (fuzz_video.random_case's second generator); seeds from
+# 5000 on (round 5) the dither methods - error diffusion on 8- and 16-bit lines -, gamma-mode = remap and primaries-mode as well (the third)
+@pytest.mark.parametrize("seed", [101, 202, 303, 707, 808, 5001, 6005])
 def test_random_conversions_match_reference_or_are_refused(emu_lib, ref, seed):
     emu = fuzz_video.load_emu()
     rnd = random.Random(seed)
     rects = random.Random(seed + 77) if seed >= 700 else None
+    more = random.Random(seed + 313) if seed >= 5000 else None
     count = {"ok": 0, "refused": 0, "defined": 0, "bad": 0}
     bad = []
     for it in range(120):
-        case = fuzz_video.random_case(rnd, rects)
+        case = fuzz_video.random_case(rnd, rects, more)
         verdict, text = fuzz_video.run_case(emu, ref, case, seed * 1000 + it)
         count[verdict] += 1
         if verdict == "bad":
@@ -39,7 +41,7 @@ def _seed_list(spec):
     return out
 
 
-GPU_SEEDS = _seed_list(os.environ.get("GSTAMD_FUZZ_SEEDS", "101,404,505,707,909,61030"))
+GPU_SEEDS = _seed_list(os.environ.get("GSTAMD_FUZZ_SEEDS", "101,404,505,707,909,61030,5001,6005"))
 
 
 @pytest.mark.gpu
@@ -53,9 +55,10 @@ def test_hip_random_conversions_match_reference_or_are_refused(native_lib, gpu, 
     from gstreamer_amd import video as V
     rnd = random.Random(seed)
     rects = random.Random(seed + 77) if seed >= 700 else None
+    more = random.Random(seed + 313) if 5000 <= seed < 60000 else None
     ok, bad = 0, []
     for it in range(150):
-        case = fuzz_video.random_case(rnd, rects)
+        case = fuzz_video.random_case(rnd, rects, more)
         ifmt, w, h, ofmt, ow, oh, cfg, col, site = case
         if os.environ.get("GSTAMD_FUZZ_VERBOSE"):          # a device fault ends the process: say what was running
             print(seed, it, case, flush=True)

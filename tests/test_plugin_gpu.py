@@ -15,18 +15,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GST = "/opt/conda/bin/gst-launch-1.0"
 
 
-@pytest.fixture(scope="module")
-def gst_env(native_lib, tmp_path_factory):
-    if not os.path.exists(GST):
-        pytest.skip("no GStreamer runtime in this image")
+RT129 = os.path.join(ROOT, "oracle", "_ref", "rt129")
+LAUNCH129 = os.path.join(ROOT, "plugins", "tests", "launch129")
+
+
+# Two runtimes: the GStreamer 1.14 of this image (conda: gst-launch-1.0, a registry, GstHarness tools) and - round 5 - the reference's OWN
+# version, 1.29, hand-built from /root/reference by oracle/rt129_build.py (core, libgstbase, libgstvideo with GstVideoAggregator, libgstaudio,
+# coreelements, videotestsrc, audiotestsrc; no gst_parse and no registry: plugins/tests/launch129 builds the pipelines and loads the plugins by
+# path) with the elements of plugins/ compiled and linked against it (plugins/rt129/libgstamdhipdsp.so).
+@pytest.fixture(scope="module", params=["1.14", "1.29"])
+def gst_env(request, native_lib, tmp_path_factory):
     sys.path.insert(0, os.path.join(ROOT, "plugins"))
     import build as plugin_build
+    env = dict(os.environ)
+    tmp = tmp_path_factory.mktemp("gst" + request.param.replace(".", ""))
+    if request.param == "1.29":
+        so = plugin_build.build129()
+        if not so or not os.path.exists(LAUNCH129) or not os.path.exists(os.path.join(RT129, "lib", "libgstvideo-1.0.so.0")):
+            pytest.skip("the 1.29 runtime is not built (oracle/rt129_build.py needs /root/reference)")
+        plugs = [os.path.join(RT129, "plugins", f) for f in ("libgstcoreelements.so", "libgstvideotestsrc.so", "libgstaudiotestsrc.so")] + [so]
+        env.update(GSTAMD_LAUNCH_PLUGINS=":".join(plugs), GSTAMD_RUNTIME="1.29", GSTAMD_LAUNCH_BIN=LAUNCH129,
+                   LD_LIBRARY_PATH=os.path.join(RT129, "lib") + ":" + os.path.join(ROOT, "gstreamer_amd", "lib") + ":" + env.get("LD_LIBRARY_PATH", ""))
+        return env, tmp
+    if not os.path.exists(GST):
+        pytest.skip("no GStreamer runtime in this image")
     so = plugin_build.build()
     assert os.path.exists(so)
-    tmp = tmp_path_factory.mktemp("gst")
-    env = dict(os.environ)
     env.update(GST_PLUGIN_PATH=os.path.join(ROOT, "plugins") + ":/opt/conda/lib/gstreamer-1.0", GST_PLUGIN_SYSTEM_PATH="/nonexistent",
-               GST_REGISTRY=str(tmp / "registry.bin"), GST_REGISTRY_FORK="no",
+               GST_REGISTRY=str(tmp / "registry.bin"), GST_REGISTRY_FORK="no", GSTAMD_RUNTIME="1.14", GSTAMD_LAUNCH_BIN=GST,
                LD_LIBRARY_PATH=os.path.join(ROOT, "gstreamer_amd", "lib") + ":" + env.get("LD_LIBRARY_PATH", ""))
     # the conda runtime ships an older libstdc++ than the one hipcc links against: load the system one first
     sys_stdcpp = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
@@ -35,8 +51,14 @@ def gst_env(native_lib, tmp_path_factory):
     return env, tmp
 
 
+def only_on_114(env, why):
+    """tools that exist for the conda runtime only (GstHarness programs need libgstcheck, gst-inspect a registry)"""
+    if env.get("GSTAMD_RUNTIME") != "1.14":
+        pytest.skip("1.29 runtime: " + why)
+
+
 def launch(env, pipeline):
-    r = subprocess.run([GST, "-q"] + pipeline.split(), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    r = subprocess.run([env["GSTAMD_LAUNCH_BIN"], "-q"] + pipeline.split(), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     return r.stdout
 
@@ -66,7 +88,7 @@ def test_videoconvertscale_converter_config_replaces_the_element_options(gst_env
                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! " % (n, w, h, fin))
     cc = ("cfg,GstVideoConverter.resampler-method=4,GstVideoConverter.dest-x=40,GstVideoConverter.dest-y=30,GstVideoConverter.dest-width=320,"
           "GstVideoConverter.dest-height=240,GstVideoConverter.border-argb=(uint)4280303680")
-    r = subprocess.run([GST, "-q"] + src_desc.split() + ["videoconvertscale", "converter-config=" + cc, "!"] +
+    r = subprocess.run([env["GSTAMD_LAUNCH_BIN"], "-q"] + src_desc.split() + ["videoconvertscale", "converter-config=" + cc, "!"] +
                        ("video/x-raw,format=BGRA,width=%d,height=%d,pixel-aspect-ratio=1/1 ! filesink location=%s" % (ow, oh, fout)).split(),
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
@@ -76,7 +98,7 @@ def test_videoconvertscale_converter_config_replaces_the_element_options(gst_env
     rc = ref.VideoConverter("NV12", w, h, "BGRA", ow, oh, config=cases.ref_config_string(ref, cfg), in_colorimetry="bt601", in_chroma_site="jpeg")
     for i in range(n):
         assert (rc.frame(src[i]) == out[i]).all(), (i, int((rc.frame(src[i]) != out[i]).sum()))
-    r = subprocess.run([GST, "-q"] + src_desc.split() + ["videoconvertscale", "converter-config=cfg", "!"] +
+    r = subprocess.run([env["GSTAMD_LAUNCH_BIN"], "-q"] + src_desc.split() + ["videoconvertscale", "converter-config=cfg", "!"] +
                        ("video/x-raw,format=BGRA,width=%d,height=%d,pixel-aspect-ratio=1/1 ! filesink location=%s" % (ow, oh, fout2)).split(),
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
@@ -356,7 +378,7 @@ def test_compositor_pad_converter_config(gst_env, ref):
     f0, f1, fout = tmp / "cc0.bgra", tmp / "cc1.nv12", tmp / "cc_out.bgra"
     cc0 = "GstVideoConverter,GstVideoConverter.resampler-method=(GstVideoResamplerMethod)nearest"
     cc1 = "GstVideoConverter,GstVideoConverter.resampler-method=(GstVideoResamplerMethod)lanczos,GstVideoConverter.alpha-mode=(GstVideoAlphaMode)set,GstVideoConverter.alpha-value=(double)0.5"
-    r = subprocess.run([GST, "-q", "compositor", "name=c", "background=black", "sink_0::width=160", "sink_0::height=120", "sink_0::xpos=10", "sink_0::ypos=20",
+    r = subprocess.run([env["GSTAMD_LAUNCH_BIN"], "-q", "compositor", "name=c", "background=black", "sink_0::width=160", "sink_0::height=120", "sink_0::xpos=10", "sink_0::ypos=20",
                         "sink_0::converter-config=" + cc0, "sink_1::xpos=150", "sink_1::ypos=100", "sink_1::width=128", "sink_1::height=96",
                         "sink_1::converter-config=" + cc1, "!", "video/x-raw,format=BGRA,width=%d,height=%d" % (dw, dh), "!", "filesink", "location=%s" % fout]
                        + ("videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=320,height=240,framerate=30/1 ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
@@ -637,6 +659,7 @@ def test_compositor_element_packed_canvases_without_alpha(gst_env, ref):
 
 
 def _bench_element(env, args, keep_stderr=False):
+    only_on_114(env, "plugins/tests/bench_element drives the element through GstHarness (libgstcheck)")
     exe = os.path.join(ROOT, "plugins", "tests", "bench_element")
     assert os.path.exists(exe), "plugins/build.py builds it"
     r = subprocess.run([exe] + [str(a) for a in args], env=dict(env, GSTAMD_ELEMENT_STATS="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -794,6 +817,7 @@ def test_reference_factory_names_are_ours_in_a_registry_without_the_stock_elemen
     plugin directory that ships this plugin INSTEAD of gst-plugins-base's videoconvert / videoscale / audioresample plugins: there
     `videoconvert`, `videoscale` and `audioresample` resolve to the MI355X elements and run unchanged pipelines."""
     env, tmp = gst_env
+    only_on_114(env, "no registry to resolve factory names in")
     pdir = tmp / "dropin_plugins"
     pdir.mkdir()
     stock = "/opt/conda/lib/gstreamer-1.0"
@@ -843,7 +867,7 @@ def test_fixate_caps_keeps_the_display_aspect_ratio_like_the_reference(gst_env, 
     import re
     env, tmp = gst_env
     in_caps, out_caps, w, h, par = case
-    r = subprocess.run([GST, "-v", "videotestsrc", "num-buffers=1", "!", "video/x-raw,format=AYUV,framerate=30/1," + in_caps, "!",
+    r = subprocess.run([env["GSTAMD_LAUNCH_BIN"], "-v", "videotestsrc", "num-buffers=1", "!", "video/x-raw,format=AYUV,framerate=30/1," + in_caps, "!",
                         "videoconvertscale", "!", "video/x-raw,format=AYUV," + out_caps, "!", "fakesink"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:]
@@ -930,6 +954,7 @@ def test_upload_honours_the_video_meta_of_the_source(gst_env):
     """amdhipupload with a system-memory frame whose GstVideoMeta has padded strides and a gap between the planes
     (plugins/tests/live_props.c): plane-by-plane pitched copies into the pool frame's default layout"""
     env, tmp = gst_env
+    only_on_114(env, "plugins/tests/live_props drives the element through GstHarness (libgstcheck)")
     exe = os.path.join(ROOT, "plugins", "tests", "live_props")
     r = subprocess.run([exe, "upload-meta"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
@@ -939,6 +964,7 @@ def test_audioconvert_mix_matrix_changed_while_running(gst_env):
     """`mix-matrix` set between two buffers with unchanged caps (plugins/tests/live_props.c): the converter is re-made by the streaming
     thread at the next transform, as gst_audio_convert_ensure_converter does (gstaudioconvert.c:1700), and the element leaves passthrough"""
     env, tmp = gst_env
+    only_on_114(env, "plugins/tests/live_props drives the element through GstHarness (libgstcheck)")
     exe = os.path.join(ROOT, "plugins", "tests", "live_props")
     assert os.path.exists(exe), "plugins/build.py builds it"
     r = subprocess.run([exe, "mix-matrix"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
@@ -948,7 +974,7 @@ def test_audioconvert_mix_matrix_changed_while_running(gst_env):
 def test_audioconvert_element_mix_matrix_property(gst_env, ref):
     env, tmp = gst_env
     fin, fout = tmp / "acm_in.s16", tmp / "acm_out.s16"
-    r = subprocess.run([GST, "-q"] + ("audiotestsrc num-buffers=6 wave=white-noise samplesperbuffer=1024 ! audio/x-raw,format=S16LE,rate=44100,channels=2 "
+    r = subprocess.run([env["GSTAMD_LAUNCH_BIN"], "-q"] + ("audiotestsrc num-buffers=6 wave=white-noise samplesperbuffer=1024 ! audio/x-raw,format=S16LE,rate=44100,channels=2 "
                                       "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! amdaudioconvert" % fin).split() +
                        ["mix-matrix=<<(float)0.25,(float)0.75>,<(float)1.0,(float)0.0>,<(float)0.0,(float)-1.0>>", "!"] +
                        ("audio/x-raw,format=S16LE,channels=3,channel-mask=(bitmask)0x0 ! filesink location=%s" % fout).split(),

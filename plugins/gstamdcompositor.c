@@ -8,10 +8,16 @@
  *   - element property background (checker / black / white / transparent)       compositor.c:2103-2120
  *   - output size = bounding box of the pads (xpos + width, ypos + height)       compositor.c:1060-1160 (_fixate_caps)
  *   - one output frame = background fill + pads blended in zorder               compositor.c:1619-1697, 1739-1870
- * The reference subclasses GstVideoAggregator; this element sits directly on GstAggregator (public in libgstbase
- * since 1.14, which is the runtime available here) and does the small part of GstVideoAggregator the blend path
- * needs.  All pads of one frame go to the GPU in ONE fused kernel launch (gstamd_compositor_aggregate): every canvas
- * pixel is written once, where the reference read-modify-writes the canvas once per pad.
+ * The reference subclasses GstVideoAggregator (compositor.c:808-809, aggregate_frames :1739 / :2098, pads derived from
+ * GstVideoAggregatorConvertPad gstvideoaggregator.c:656-678).  So does this element wherever that base class is public API - libgstvideo
+ * from 1.16 on, which includes the reference's own version (AMD_COMP_VAGG below): GstVideoAggregator does the frame selection, the QoS and
+ * latency bookkeeping, zorder / repeat-after-eos / max-last-buffer-repeat / converter-config and the child proxy; the element supplies
+ * create_output_buffer (HBM frames of its own pool) and aggregate_frames, the pads a prepare_frame that maps and converts NOTHING on the CPU
+ * (the frames stay where they are, per-pad conversions are GstAmdVideoConverters on the GPU).  On the 1.14 runtime of this image, where
+ * GstVideoAggregator still lived in gst-plugins-bad's unstable library, the same file compiles onto GstAggregator (public in libgstbase since
+ * 1.14) and does the part of GstVideoAggregator the blend path needs itself (described below).  Either way all pads of one frame go to the GPU
+ * in ONE fused kernel launch (gstamd_compositor_aggregate): every canvas pixel is written once, where the reference read-modify-writes the
+ * canvas once per pad.
  *
  * What of GstVideoAggregator is here: frame selection by running time (a pad shows the queued frame that overlaps the output
  * frame's interval, older ones are dropped, a slower pad's frame is repeated; gstvideoaggregator.c:1753-2000), repeat-after-eos,
@@ -19,13 +25,19 @@
  * _mixer_pad_get_output_size (compositor.c:290-412), and the visibility rules of prepare_frame_start (compositor.c:464-601):
  * frames with alpha 0, off the canvas or fully under an opaque pad never reach the GPU.  Pads of another format or size are
  * converted / scaled by a per-pad GstAmdVideoConverter with the library's default config (GstVideoAggregatorConvertPad).
- * Not here: QoS and the latency bookkeeping of the base class.  max-threads is accepted and means nothing (the blend is one kernel launch
- * per output frame), ignore-inactive-pads needs the 1.20 aggregator (gst_aggregator_pad_is_inactive) and is accepted without effect on
- * the 1.14 runtime this image has.
+ * Not there (1.14 form only): QoS and the latency bookkeeping of the base class.  max-threads is accepted and means nothing (the blend is one
+ * kernel launch per output frame), ignore-inactive-pads needs the 1.20 aggregator (gst_aggregator_set_ignore_inactive_pads) and is accepted
+ * without effect on the 1.14 runtime this image has.
  */
 #include <gst/base/gstaggregator.h>
 #include <gst/gst.h>
 #include <gst/video/video.h>
+#if GST_CHECK_VERSION (1, 16, 0)
+#define AMD_COMP_VAGG 1
+#include <gst/video/gstvideoaggregator.h>
+#else
+#define AMD_COMP_VAGG 0
+#endif
 #include <gst/video/gstvideosink.h>
 #include <string.h>
 
@@ -64,7 +76,11 @@ static GstStaticPadTemplate comp_src_tmpl = GST_STATIC_PAD_TEMPLATE ("src", GST_
 
 /* ---- pad ------------------------------------------------------------------------------------------------ */
 typedef struct {
+#if AMD_COMP_VAGG
+  GstVideoAggregatorConvertPad parent;
+#else
   GstAggregatorPad parent;
+#endif
   gint xpos, ypos, width, height;
   gdouble alpha;
   gint op;                     /* GstCompositorOperator: 0 source, 1 over, 2 add */
@@ -92,12 +108,18 @@ typedef struct {
   GstAmdVideoInfo conv_out;      /* layout of the converted frame in conv_buf */
 } GstAmdCompositorPadObj;
 
+#if AMD_COMP_VAGG
+typedef struct { GstVideoAggregatorConvertPadClass parent_class; } GstAmdCompositorPadObjClass;
+#define AMD_COMP_PAD_PARENT_TYPE GST_TYPE_VIDEO_AGGREGATOR_CONVERT_PAD
+#else
 typedef struct { GstAggregatorPadClass parent_class; } GstAmdCompositorPadObjClass;
+#define AMD_COMP_PAD_PARENT_TYPE GST_TYPE_AGGREGATOR_PAD
+#endif
 
 enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_ZORDER,
   PAD_PROP_SIZING_POLICY, PAD_PROP_REPEAT_AFTER_EOS, PAD_PROP_MAX_LAST_BUFFER_REPEAT, PAD_PROP_CONVERTER_CONFIG };
 
-G_DEFINE_TYPE (GstAmdCompositorPadObj, gst_amd_compositor_pad, GST_TYPE_AGGREGATOR_PAD);
+G_DEFINE_TYPE (GstAmdCompositorPadObj, gst_amd_compositor_pad, AMD_COMP_PAD_PARENT_TYPE);
 #define AMD_COMP_PAD(o) ((GstAmdCompositorPadObj *) (o))
 
 static GType
@@ -184,6 +206,7 @@ amd_comp_pad_finalize (GObject * object)
   G_OBJECT_CLASS (gst_amd_compositor_pad_parent_class)->finalize (object);
 }
 
+#if !AMD_COMP_VAGG
 static GstFlowReturn
 amd_comp_pad_flush (GstAggregatorPad * pad, GstAggregator * agg)
 {
@@ -191,12 +214,41 @@ amd_comp_pad_flush (GstAggregatorPad * pad, GstAggregator * agg)
   gst_buffer_replace (&AMD_COMP_PAD (pad)->current, NULL);
   return GST_FLOW_OK;
 }
+#else
+/* GstVideoAggregatorPadClass::prepare_frame / clean_frame: the base classes would map the buffer on the CPU (an HBM frame: a download) and
+ * GstVideoAggregatorConvertPad would run a CPU GstVideoConverter on it (gstvideoaggregator.c:479-569).  Nothing of that: aggregate_frames
+ * takes the pad's current buffer (gst_video_aggregator_pad_get_current_buffer) as it is */
+static gboolean
+amd_comp_pad_prepare_frame (GstVideoAggregatorPad * pad, GstVideoAggregator * vagg, GstBuffer * buffer, GstVideoFrame * prepared_frame)
+{
+  (void) pad;
+  (void) vagg;
+  (void) buffer;
+  (void) prepared_frame;
+  return TRUE;
+}
+
+static void
+amd_comp_pad_clean_frame (GstVideoAggregatorPad * pad, GstVideoAggregator * vagg, GstVideoFrame * prepared_frame)
+{
+  (void) pad;
+  (void) vagg;
+  (void) prepared_frame;
+}
+#endif
 
 static void
 gst_amd_compositor_pad_class_init (GstAmdCompositorPadObjClass * klass)
 {
   GObjectClass *oc = (GObjectClass *) klass;
+#if AMD_COMP_VAGG
+  ((GstVideoAggregatorPadClass *) klass)->prepare_frame = amd_comp_pad_prepare_frame;
+  ((GstVideoAggregatorPadClass *) klass)->clean_frame = amd_comp_pad_clean_frame;
+  ((GstVideoAggregatorPadClass *) klass)->prepare_frame_start = NULL;
+  ((GstVideoAggregatorPadClass *) klass)->prepare_frame_finish = NULL;
+#else
   ((GstAggregatorPadClass *) klass)->flush = amd_comp_pad_flush;
+#endif
   const GParamFlags f = G_PARAM_READWRITE | GST_PARAM_CONTROLLABLE | G_PARAM_STATIC_STRINGS;
   oc->set_property = amd_comp_pad_set_property;
   oc->get_property = amd_comp_pad_get_property;
@@ -209,7 +261,9 @@ gst_amd_compositor_pad_class_init (GstAmdCompositorPadObjClass * klass)
   g_object_class_install_property (oc, PAD_PROP_ALPHA, g_param_spec_double ("alpha", "Alpha", "Alpha of the picture", 0.0, 1.0, 1.0, f));
   g_object_class_install_property (oc, PAD_PROP_OPERATOR, g_param_spec_enum ("operator", "Operator",
           "Blending operator to use for blending this pad over the previous ones", amd_comp_operator_get_type (), 1, f));
+#if !AMD_COMP_VAGG              /* (GstVideoAggregatorPad's own, gstvideoaggregator.c:150-176, 282-303) */
   g_object_class_install_property (oc, PAD_PROP_ZORDER, g_param_spec_uint ("zorder", "Z-Order", "Z Order of the picture", 0, G_MAXUINT, 0, f));
+#endif
   {
     static const GEnumValue sp[] = { {0, "None: Image is scaled to fill configured destination rectangle without padding or keeping the aspect ratio", "none"},
       {1, "Keep Aspect Ratio: Image is scaled to fit destination rectangle specified by GstCompositorPad:{xpos, ypos, width, height} "
@@ -220,6 +274,7 @@ gst_amd_compositor_pad_class_init (GstAmdCompositorPadObjClass * klass)
     g_object_class_install_property (oc, PAD_PROP_SIZING_POLICY, g_param_spec_enum ("sizing-policy", "Sizing policy",
             "Sizing policy to use for image scaling", t, 0, f));
   }
+#if !AMD_COMP_VAGG
   g_object_class_install_property (oc, PAD_PROP_REPEAT_AFTER_EOS, g_param_spec_boolean ("repeat-after-eos", "Repeat After EOS",
           "Repeat the last frame after EOS until all pads are EOS", FALSE, f));
   g_object_class_install_property (oc, PAD_PROP_MAX_LAST_BUFFER_REPEAT, g_param_spec_uint64 ("max-last-buffer-repeat", "Max Last Buffer Repeat",
@@ -228,6 +283,7 @@ gst_amd_compositor_pad_class_init (GstAmdCompositorPadObjClass * klass)
   g_object_class_install_property (oc, PAD_PROP_CONVERTER_CONFIG, g_param_spec_boxed ("converter-config", "Converter configuration",
           "A GstStructure describing the configuration that should be used when scaling and converting this pad's video frames", GST_TYPE_STRUCTURE,
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+#endif
 }
 
 static void
@@ -248,7 +304,11 @@ gst_amd_compositor_pad_init (GstAmdCompositorPadObj * p)
 
 /* ---- element -------------------------------------------------------------------------------------------- */
 typedef struct {
+#if AMD_COMP_VAGG
+  GstVideoAggregator parent;
+#else
   GstAggregator parent;
+#endif
   gint background;
   GstVideoInfo out_info;
   gboolean have_out, out_hip;
@@ -266,11 +326,15 @@ typedef struct {
   guint64 n_culled;                    /* pad frames left out because nothing of them can be seen (culled-frames, read-only) */
 } GstAmdCompositor;
 
+#if AMD_COMP_VAGG
+typedef struct { GstVideoAggregatorClass parent_class; } GstAmdCompositorClass;
+#else
 typedef struct { GstAggregatorClass parent_class; } GstAmdCompositorClass;
+#endif
 
 enum { PROP_0, PROP_BACKGROUND, PROP_DEVICE_ID, PROP_ZERO_SIZE_IS_UNSCALED, PROP_MAX_THREADS, PROP_IGNORE_INACTIVE_PADS, PROP_CULLED_FRAMES };
 
-/* GstChildProxy (as gstvideoaggregator.c does): lets `sink_1::xpos=..` address pad properties from gst-launch */
+/* GstChildProxy (as compositor.c:2185-2220 does): lets `sink_1::xpos=..` address pad properties from gst-launch */
 static GObject *
 amd_comp_child_by_index (GstChildProxy * proxy, guint index)
 {
@@ -301,8 +365,13 @@ amd_comp_child_proxy_init (gpointer g_iface, gpointer iface_data)
   iface->get_children_count = amd_comp_children_count;
 }
 
+#if AMD_COMP_VAGG
+G_DEFINE_TYPE_WITH_CODE (GstAmdCompositor, gst_amd_compositor, GST_TYPE_VIDEO_AGGREGATOR,          /* compositor.c:808-810 */
+    G_IMPLEMENT_INTERFACE (GST_TYPE_CHILD_PROXY, amd_comp_child_proxy_init));
+#else
 G_DEFINE_TYPE_WITH_CODE (GstAmdCompositor, gst_amd_compositor, GST_TYPE_AGGREGATOR,
     G_IMPLEMENT_INTERFACE (GST_TYPE_CHILD_PROXY, amd_comp_child_proxy_init));
+#endif
 #define AMD_COMP(o) ((GstAmdCompositor *) (o))
 
 static GstPad *
@@ -479,9 +548,12 @@ amd_comp_set_property (GObject * object, guint id, const GValue * value, GParamS
     AMD_COMP (object)->zero_size_is_unscaled = g_value_get_boolean (value);
   else if (id == PROP_MAX_THREADS)
     AMD_COMP (object)->max_threads = g_value_get_uint (value);
-  else if (id == PROP_IGNORE_INACTIVE_PADS)
+  else if (id == PROP_IGNORE_INACTIVE_PADS) {
     AMD_COMP (object)->ignore_inactive_pads = g_value_get_boolean (value);
-  else
+#if GST_CHECK_VERSION (1, 20, 0)
+    gst_aggregator_set_ignore_inactive_pads (GST_AGGREGATOR (object), AMD_COMP (object)->ignore_inactive_pads);        /* compositor.c:2057 */
+#endif
+  } else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
 }
 
@@ -504,6 +576,7 @@ amd_comp_get_property (GObject * object, guint id, GValue * value, GParamSpec * 
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
 }
 
+#if !AMD_COMP_VAGG              /* GstVideoAggregator makes the pads, takes the CAPS events and answers the caps queries itself */
 static GstAggregatorPad *
 amd_comp_create_new_pad (GstAggregator * agg, GstPadTemplate * templ, const gchar * req_name, const GstCaps * caps)
 {
@@ -565,6 +638,11 @@ amd_comp_sink_event (GstAggregator * agg, GstAggregatorPad * apad, GstEvent * ev
   return GST_AGGREGATOR_CLASS (gst_amd_compositor_parent_class)->sink_event (agg, apad, event);
 }
 
+#endif
+
+/* (also on GstVideoAggregator: its own answer ties a sink pad to the memory type downstream negotiated and - when the output format has no
+ * alpha - to formats without alpha, gstvideoaggregator.c:1597-1665; here system-memory and HBM pads mix freely and every pad is converted
+ * to the canvas format on the GPU, so the pads accept what their template says) */
 static gboolean
 amd_comp_sink_query (GstAggregator * agg, GstAggregatorPad * apad, GstQuery * query)
 {
@@ -608,6 +686,10 @@ amd_comp_update_src_caps (GstAggregator * agg, GstCaps * caps, GstCaps ** ret)
     GstAmdCompositorPadObj *p = AMD_COMP_PAD (l->data);
     gint w, h;
     gdouble fps;
+#if AMD_COMP_VAGG
+    p->info = GST_VIDEO_AGGREGATOR_PAD (p)->info;         /* the base class keeps the pad's negotiated layout */
+    p->have_info = p->info.finfo != NULL && GST_VIDEO_INFO_FORMAT (&p->info) != GST_VIDEO_FORMAT_UNKNOWN;
+#endif
     if (!p->have_info) {
       all = FALSE;
       continue;
@@ -690,15 +772,22 @@ amd_comp_negotiated_src_caps (GstAggregator * agg, GstCaps * caps)
     return FALSE;
   c->have_out = TRUE;
   GST_INFO_OBJECT (c, "output %" GST_PTR_FORMAT, caps);
+#if AMD_COMP_VAGG
+  return GST_AGGREGATOR_CLASS (gst_amd_compositor_parent_class)->negotiated_src_caps (agg, caps);          /* GstVideoAggregator::info, the pads' conversion info, latency */
+#else
   return TRUE;
+#endif
 }
 
+#if !AMD_COMP_VAGG
 static gint
 pad_zorder_cmp (gconstpointer a, gconstpointer b)
 {
   const GstAmdCompositorPadObj *pa = *(GstAmdCompositorPadObj * const *) a, *pb = *(GstAmdCompositorPadObj * const *) b;
   return pa->zorder < pb->zorder ? -1 : (pa->zorder > pb->zorder ? 1 : 0);
 }
+
+#endif
 
 static gboolean
 ensure_device (gpointer * p, gsize * have, gsize need)
@@ -711,6 +800,7 @@ ensure_device (gpointer * p, gsize * have, gsize need)
   return *p != NULL;
 }
 
+#if !AMD_COMP_VAGG
 /* Which queued frame does the pad show during the output frame [out_start, out_end) (running time)?  The rule of
  * gst_video_aggregator_fill_queues (gstvideoaggregator.c:1753-2000): frames that ended before the output frame starts are dropped,
  * a frame that starts at or after its end stays queued (the pad keeps showing what it shows), anything else becomes the pad's
@@ -804,6 +894,8 @@ amd_comp_pad_select (GstAmdCompositorPadObj * p, GstClockTime out_start, GstCloc
   }
 }
 
+#endif
+
 /* rectangle (x, y, w, h) clamped to the canvas (clamp_rectangle, compositor.c:441-459) */
 static GstVideoRectangle
 amd_comp_clamp (gint x, gint y, gint w, gint h, gint cw, gint ch)
@@ -816,23 +908,20 @@ amd_comp_clamp (gint x, gint y, gint w, gint h, gint cw, gint ch)
   return r;
 }
 
+/* One output frame: the pads' current frames (bufs[i], NULL: the pad shows nothing; pads in z order) composited into the canvas.
+ * outbuf_in: the frame to fill (GstVideoAggregator's create_output_buffer made it), NULL: made here.  Consumes the references in pads[] / bufs[]. */
 static GstFlowReturn
-amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
+amd_comp_compose (GstAmdCompositor * c, GstAmdCompositorPadObj ** pads, GstBuffer ** bufs, guint n, GstBuffer * outbuf_in, GstBuffer ** outbuf_out)
 {
-  GstAmdCompositor *c = AMD_COMP (agg);
-  GstAmdCompositorPadObj *pads[AMD_COMP_MAX_PADS];
-  GstBuffer *bufs[AMD_COMP_MAX_PADS];
   GstMapInfo maps[AMD_COMP_MAX_PADS];
   gboolean mapped_dev[AMD_COMP_MAX_PADS];
   GstAmdCompositorPad desc[AMD_COMP_MAX_PADS];
-  GstBuffer *outbuf = NULL;
+  GstBuffer *outbuf = outbuf_in;
   GstMapInfo omap;
   GstMemory *omem = NULL;
   gpointer canvas;
   GstFlowReturn flow = GST_FLOW_OK;
-  GList *l;
-  guint n = 0, i, n_desc = 0;
-  gboolean all_eos = TRUE;
+  guint i, n_desc = 0;
   const int fmt = amd_format_of (GST_VIDEO_INFO_FORMAT (&c->out_info));
   const gboolean by_planes = !GST_VIDEO_INFO_HAS_ALPHA (&c->out_info);
   GstAmdCompositorFramePad fdesc[AMD_COMP_MAX_PADS];
@@ -842,50 +931,13 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
   guint n_culled = 0;
   int r;
 
-  if (!c->have_out)
-    return GST_FLOW_NOT_NEGOTIATED;
   memset (mapped_dev, 0, sizeof (mapped_dev));
+  *outbuf_out = NULL;
   gst_amd_hip_select_device (c->device_id);
   if (!c->stream && !(c->stream = gstamd_stream_new ())) {
     GST_ELEMENT_ERROR (c, LIBRARY, INIT, ("no HIP stream"), ("%s", gstamd_last_error ()));
-    return GST_FLOW_ERROR;
-  }
-
-  GST_OBJECT_LOCK (agg);
-  for (l = GST_ELEMENT (agg)->sinkpads; l && n < AMD_COMP_MAX_PADS; l = l->next)
-    pads[n++] = gst_object_ref (l->data);
-  GST_OBJECT_UNLOCK (agg);
-  qsort (pads, n, sizeof (pads[0]), pad_zorder_cmp);
-
-  {
-    /* the output frame's running-time interval: frame counter at the output framerate, from running time 0 */
-    const guint64 fn = GST_VIDEO_INFO_FPS_N (&c->out_info) > 0 ? GST_VIDEO_INFO_FPS_N (&c->out_info) : 25;
-    const guint64 fd = GST_VIDEO_INFO_FPS_N (&c->out_info) > 0 ? GST_VIDEO_INFO_FPS_D (&c->out_info) : 1;
-    const GstClockTime out_start = gst_util_uint64_scale (c->n_frames, fd * GST_SECOND, fn);
-    const GstClockTime out_end = gst_util_uint64_scale (c->n_frames + 1, fd * GST_SECOND, fn);
-    gboolean need_data = FALSE;
-    for (i = 0; i < n; i++) {
-      gboolean eos = FALSE;
-      if (!amd_comp_pad_select (pads[i], out_start, out_end, &eos) && !timeout)
-        need_data = TRUE;
-      if (!eos)
-        all_eos = FALSE;
-    }
-    if (need_data && !all_eos) {
-      for (i = 0; i < n; i++)
-        gst_object_unref (pads[i]);
-      return GST_AGGREGATOR_FLOW_NEED_DATA;
-    }
-    for (i = 0; i < n; i++)
-      bufs[i] = pads[i]->current ? gst_buffer_ref (pads[i]->current) : NULL;
-  }
-  GST_LOG_OBJECT (c, "aggregate: %u pads, all_eos %d, timeout %d", n, all_eos, timeout);
-  if (all_eos) {
-    for (i = 0; i < n; i++) {
-      gst_buffer_replace (&bufs[i], NULL);
-      gst_object_unref (pads[i]);
-    }
-    return GST_FLOW_EOS;
+    flow = GST_FLOW_ERROR;
+    goto done_inputs;
   }
 
   /* where each pad lands, and which pads cannot be seen at all (_should_draw_background / prepare_frame_start,
@@ -914,7 +966,7 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
         continue;
       }
       for (j = i + 1; j < n; j++) {
-        if (!pads[j]->current || !pads[j]->have_info || pads[j]->alpha != 1.0 || GST_VIDEO_INFO_HAS_ALPHA (&pads[j]->info))
+        if (!bufs[j] || !pads[j]->have_info || pads[j]->alpha != 1.0 || GST_VIDEO_INFO_HAS_ALPHA (&pads[j]->info))
           continue;
         if (pad_x[j] <= fr.x && pad_y[j] <= fr.y && pad_x[j] + pad_w[j] >= fr.x + fr.w && pad_y[j] + pad_h[j] >= fr.y + fr.h) {
           gst_buffer_replace (&bufs[i], NULL);
@@ -964,6 +1016,23 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
       th = pad_h[i];
       GstAmdVideoConverterConfig pcfg;
       gboolean have_cfg, cfg_changed;
+#if AMD_COMP_VAGG
+      {
+        /* GstVideoAggregatorConvertPad keeps converter-config privately: read it through the property, notice changes by comparing */
+        GstStructure *cc = NULL;
+        g_object_get (p, "converter-config", &cc, NULL);
+        GST_OBJECT_LOCK (p);
+        if ((cc == NULL) != (p->converter_config == NULL) || (cc && !gst_structure_is_equal (cc, p->converter_config))) {
+          if (p->converter_config)
+            gst_structure_free (p->converter_config);
+          p->converter_config = cc;
+          p->converter_config_changed = TRUE;
+        } else if (cc) {
+          gst_structure_free (cc);
+        }
+        GST_OBJECT_UNLOCK (p);
+      }
+#endif
       GST_OBJECT_LOCK (p);
       have_cfg = p->converter_config != NULL;
       cfg_changed = p->converter_config_changed;
@@ -1059,7 +1128,7 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
 
   /* canvas */
   if (c->out_hip) {
-    GstFlowReturn pool_flow = c->out_pool ? gst_buffer_pool_acquire_buffer (c->out_pool, &outbuf, NULL) : GST_FLOW_ERROR;
+    GstFlowReturn pool_flow = outbuf ? GST_FLOW_OK : (c->out_pool ? gst_buffer_pool_acquire_buffer (c->out_pool, &outbuf, NULL) : GST_FLOW_ERROR);
     if (pool_flow != GST_FLOW_OK)
       outbuf = NULL;
     omem = outbuf ? gst_buffer_peek_memory (outbuf, 0) : NULL;
@@ -1071,7 +1140,8 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
     gst_amd_hip_memory_wait_idle (omem, c->stream);           /* a recycled canvas may still be read downstream */
     canvas = omap.data;
   } else {
-    outbuf = gst_buffer_new_allocate (NULL, GST_VIDEO_INFO_SIZE (&c->out_info), NULL);
+    if (!outbuf)
+      outbuf = gst_buffer_new_allocate (NULL, GST_VIDEO_INFO_SIZE (&c->out_info), NULL);
     if (!outbuf || !ensure_device (&c->d_out, &c->d_out_size, GST_VIDEO_INFO_SIZE (&c->out_info))) {
       flow = GST_FLOW_ERROR;
       goto done_inputs;
@@ -1145,18 +1215,10 @@ amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
     flow = GST_FLOW_ERROR;
     goto done_inputs;
   }
-  /* timestamps: the running frame count at the output framerate (gst_video_aggregator_do_aggregate) */
-  if (GST_VIDEO_INFO_FPS_N (&c->out_info) > 0) {
-    const guint64 fn = GST_VIDEO_INFO_FPS_N (&c->out_info), fd = GST_VIDEO_INFO_FPS_D (&c->out_info);
-    GST_BUFFER_PTS (outbuf) = gst_util_uint64_scale (c->n_frames, fd * GST_SECOND, fn);
-    GST_BUFFER_DURATION (outbuf) = gst_util_uint64_scale (c->n_frames + 1, fd * GST_SECOND, fn) - GST_BUFFER_PTS (outbuf);
-  }
   c->n_frames++;
 
 done_inputs:
   for (i = 0; i < n; i++) {
-    if (pads[i]->current && !GST_CLOCK_TIME_IS_VALID (pads[i]->cur_start))
-      gst_buffer_replace (&pads[i]->current, NULL);             /* untimed frames are shown once */
     if (bufs[i]) {
       if (mapped_dev[i])
         gst_memory_unmap (gst_buffer_peek_memory (bufs[i], 0), &maps[i]);
@@ -1165,14 +1227,124 @@ done_inputs:
     gst_object_unref (pads[i]);
   }
   if (flow != GST_FLOW_OK) {
-    if (outbuf)
+    if (outbuf && !outbuf_in)
       gst_buffer_unref (outbuf);
     if (flow == GST_FLOW_ERROR)
       GST_ELEMENT_ERROR (c, LIBRARY, FAILED, ("HIP compositing failed"), ("%s", gstamd_last_error ()));
     return flow;
   }
+  *outbuf_out = outbuf;
+  return GST_FLOW_OK;
+}
+
+#if AMD_COMP_VAGG
+/* GstVideoAggregatorClass::create_output_buffer: an HBM frame of this element's pool when downstream negotiated memory:AMDHIPMemory */
+static GstFlowReturn
+amd_comp_create_output_buffer (GstVideoAggregator * vagg, GstBuffer ** outbuf)
+{
+  GstAmdCompositor *c = AMD_COMP (vagg);
+  if (!c->have_out)
+    return GST_FLOW_NOT_NEGOTIATED;
+  if (c->out_hip) {
+    gst_amd_hip_select_device (c->device_id);
+    return c->out_pool ? gst_buffer_pool_acquire_buffer (c->out_pool, outbuf, NULL) : GST_FLOW_ERROR;
+  }
+  *outbuf = gst_buffer_new_allocate (NULL, GST_VIDEO_INFO_SIZE (&c->out_info), NULL);
+  return *outbuf ? GST_FLOW_OK : GST_FLOW_ERROR;
+}
+
+/* GstVideoAggregatorClass::aggregate_frames (compositor.c:1739): the base class has chosen every pad's frame for this output frame */
+static GstFlowReturn
+amd_comp_aggregate_frames (GstVideoAggregator * vagg, GstBuffer * outbuf)
+{
+  GstAmdCompositor *c = AMD_COMP (vagg);
+  GstAmdCompositorPadObj *pads[AMD_COMP_MAX_PADS];
+  GstBuffer *bufs[AMD_COMP_MAX_PADS], *out = NULL;
+  guint n = 0, i;
+  GList *l;
+
+  if (!c->have_out)
+    return GST_FLOW_NOT_NEGOTIATED;
+  GST_OBJECT_LOCK (vagg);
+  for (l = GST_ELEMENT (vagg)->sinkpads; l && n < AMD_COMP_MAX_PADS; l = l->next)          /* kept in z order by the base class */
+    pads[n++] = gst_object_ref (l->data);
+  GST_OBJECT_UNLOCK (vagg);
+  for (i = 0; i < n; i++) {
+    GstVideoAggregatorPad *vp = GST_VIDEO_AGGREGATOR_PAD (pads[i]);
+    GstBuffer *b = gst_video_aggregator_pad_get_current_buffer (vp);
+    pads[i]->info = vp->info;
+    pads[i]->have_info = vp->info.finfo != NULL && GST_VIDEO_INFO_FORMAT (&vp->info) != GST_VIDEO_FORMAT_UNKNOWN;
+    bufs[i] = b ? gst_buffer_ref (b) : NULL;
+  }
+  return amd_comp_compose (c, pads, bufs, n, outbuf, &out);
+}
+#else
+static GstFlowReturn
+amd_comp_aggregate (GstAggregator * agg, gboolean timeout)
+{
+  GstAmdCompositor *c = AMD_COMP (agg);
+  GstAmdCompositorPadObj *pads[AMD_COMP_MAX_PADS];
+  GstBuffer *bufs[AMD_COMP_MAX_PADS], *outbuf = NULL;
+  GstFlowReturn flow;
+  GList *l;
+  guint n = 0, i;
+  gboolean all_eos = TRUE;
+
+  if (!c->have_out)
+    return GST_FLOW_NOT_NEGOTIATED;
+  GST_OBJECT_LOCK (agg);
+  for (l = GST_ELEMENT (agg)->sinkpads; l && n < AMD_COMP_MAX_PADS; l = l->next)
+    pads[n++] = gst_object_ref (l->data);
+  GST_OBJECT_UNLOCK (agg);
+  qsort (pads, n, sizeof (pads[0]), pad_zorder_cmp);
+  {
+    /* the output frame's running-time interval: frame counter at the output framerate, from running time 0 */
+    const guint64 fn = GST_VIDEO_INFO_FPS_N (&c->out_info) > 0 ? GST_VIDEO_INFO_FPS_N (&c->out_info) : 25;
+    const guint64 fd = GST_VIDEO_INFO_FPS_N (&c->out_info) > 0 ? GST_VIDEO_INFO_FPS_D (&c->out_info) : 1;
+    const GstClockTime out_start = gst_util_uint64_scale (c->n_frames, fd * GST_SECOND, fn);
+    const GstClockTime out_end = gst_util_uint64_scale (c->n_frames + 1, fd * GST_SECOND, fn);
+    gboolean need_data = FALSE;
+    for (i = 0; i < n; i++) {
+      gboolean eos = FALSE;
+      if (!amd_comp_pad_select (pads[i], out_start, out_end, &eos) && !timeout)
+        need_data = TRUE;
+      if (!eos)
+        all_eos = FALSE;
+    }
+    if (need_data && !all_eos) {
+      for (i = 0; i < n; i++)
+        gst_object_unref (pads[i]);
+      return GST_AGGREGATOR_FLOW_NEED_DATA;
+    }
+    for (i = 0; i < n; i++)
+      bufs[i] = pads[i]->current ? gst_buffer_ref (pads[i]->current) : NULL;
+  }
+  GST_LOG_OBJECT (c, "aggregate: %u pads, all_eos %d, timeout %d", n, all_eos, timeout);
+  if (all_eos) {
+    for (i = 0; i < n; i++) {
+      gst_buffer_replace (&bufs[i], NULL);
+      gst_object_unref (pads[i]);
+    }
+    return GST_FLOW_EOS;
+  }
+  for (i = 0; i < n; i++)
+    if (pads[i]->current && !GST_CLOCK_TIME_IS_VALID (pads[i]->cur_start))
+      gst_buffer_replace (&pads[i]->current, NULL);             /* untimed frames are shown once (bufs[] holds this frame's reference) */
+  {
+    const guint64 frame_no = c->n_frames;
+    flow = amd_comp_compose (c, pads, bufs, n, NULL, &outbuf);
+    if (flow != GST_FLOW_OK)
+      return flow;
+    /* timestamps: the running frame count at the output framerate (gst_video_aggregator_do_aggregate) */
+    if (GST_VIDEO_INFO_FPS_N (&c->out_info) > 0) {
+      const guint64 fn = GST_VIDEO_INFO_FPS_N (&c->out_info), fd = GST_VIDEO_INFO_FPS_D (&c->out_info);
+      GST_BUFFER_PTS (outbuf) = gst_util_uint64_scale (frame_no, fd * GST_SECOND, fn);
+      GST_BUFFER_DURATION (outbuf) = gst_util_uint64_scale (frame_no + 1, fd * GST_SECOND, fn) - GST_BUFFER_PTS (outbuf);
+    }
+  }
   return gst_aggregator_finish_buffer (agg, outbuf);
 }
+#endif
 
 static gboolean
 amd_comp_stop (GstAggregator * agg)
@@ -1204,7 +1376,11 @@ amd_comp_stop (GstAggregator * agg)
       gst_buffer_replace (&AMD_COMP_PAD (l->data)->current, NULL);
     GST_OBJECT_UNLOCK (agg);
   }
+#if AMD_COMP_VAGG
+  return GST_AGGREGATOR_CLASS (gst_amd_compositor_parent_class)->stop (agg);
+#else
   return TRUE;
+#endif
 }
 
 static void
@@ -1238,15 +1414,22 @@ gst_amd_compositor_class_init (GstAmdCompositorClass * klass)
   gst_element_class_add_static_pad_template_with_gtype (ec, &comp_src_tmpl, GST_TYPE_AGGREGATOR_PAD);
   gst_element_class_set_static_metadata (ec, "Compositor (MI355X/HIP)", "Filter/Editor/Video/Compositor",
       "Composite multiple video streams in one fused GPU pass", "gstreamer_amd");
-  ec->request_new_pad = amd_comp_request_new_pad;
-  ec->release_pad = amd_comp_release_pad;
+#if AMD_COMP_VAGG
+  /* GstVideoAggregator: pads, events, queries, frame selection, timestamps, QoS are the base class's; the canvas size / format rules and the
+   * output memory are this element's, and so is the frame (compositor.c:2098 aggregate_frames, :2096 fixate_src_caps) */
+  ((GstVideoAggregatorClass *) klass)->aggregate_frames = amd_comp_aggregate_frames;
+  ((GstVideoAggregatorClass *) klass)->create_output_buffer = amd_comp_create_output_buffer;
+#else
   ac->create_new_pad = amd_comp_create_new_pad;
   ac->sink_event = amd_comp_sink_event;
+  ac->aggregate = amd_comp_aggregate;
+#endif
   ac->sink_query = amd_comp_sink_query;
+  ec->request_new_pad = amd_comp_request_new_pad;           /* child-added / child-removed around the base class's (compositor.c:1887-1930) */
+  ec->release_pad = amd_comp_release_pad;
   ac->update_src_caps = amd_comp_update_src_caps;
   ac->fixate_src_caps = amd_comp_fixate_src_caps;
   ac->negotiated_src_caps = amd_comp_negotiated_src_caps;
-  ac->aggregate = amd_comp_aggregate;
   ac->stop = amd_comp_stop;
 }
 

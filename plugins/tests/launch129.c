@@ -81,6 +81,28 @@ main (int argc, char **argv)
     }
     g_strfreev (paths);
   }
+  if (argc == 3 && !strcmp (argv[1], "--types")) {
+    /* the type chain of an element and of its request sink pads: what `gst-inspect-1.0` shows under "GObject" */
+    GstElement *e = gst_element_factory_make (argv[2], NULL);
+    GType t;
+    GstPad *pad;
+    if (!e) {
+      fprintf (stderr, "launch129: no element '%s'\n", argv[2]);
+      return 2;
+    }
+    for (t = G_OBJECT_TYPE (e); t; t = g_type_parent (t))
+      printf ("%s%s", g_type_name (t), g_type_parent (t) ? " < " : "\n");
+    pad = gst_element_request_pad_simple (e, "sink_%u");
+    if (pad) {
+      printf ("pad: ");
+      for (t = G_OBJECT_TYPE (pad); t; t = g_type_parent (t))
+        printf ("%s%s", g_type_name (t), g_type_parent (t) ? " < " : "\n");
+      gst_element_release_request_pad (e, pad);
+      gst_object_unref (pad);
+    }
+    gst_object_unref (e);
+    return 0;
+  }
   pipeline = gst_pipeline_new ("pipeline");
   for (i = 1; i < argc; i++) {
     const gchar *t = argv[i];

@@ -1072,3 +1072,17 @@ def test_videoconvertscale_element_gbr_planes_in_frame_order(gst_env, ref, batch
     for i in range(n):
         assert (a.frame(src[i]) == mid[i]).all(), i
         assert (b.frame(mid[i]) == out[i]).all(), i
+
+
+def test_compositor_is_a_video_aggregator_on_the_references_own_version(gst_env):
+    """`compositor` is a GstVideoAggregator subclass (compositor.c:808-809) with pads derived from GstVideoAggregatorConvertPad
+    (gstvideoaggregator.c:656-678) - wherever that base class is public API, which includes the reference's own version.  The conda 1.14
+    runtime keeps the GstAggregator form (there GstVideoAggregator lived in gst-plugins-bad's unstable library)."""
+    env, tmp = gst_env
+    if env.get("GSTAMD_RUNTIME") != "1.29":
+        pytest.skip("the 1.14 runtime has no public GstVideoAggregator")
+    r = subprocess.run([env["GSTAMD_LAUNCH_BIN"], "--types", "compositor"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("GstAmdCompositor < GstVideoAggregator < GstAggregator < GstElement"), lines
+    assert lines[1].startswith("pad: GstAmdCompositorPadObj < GstVideoAggregatorConvertPad < GstVideoAggregatorPad < GstAggregatorPad < GstPad"), lines

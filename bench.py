@@ -377,6 +377,57 @@ class AudioWorkload:
                           "order parity is defined on)"}
 
 
+class AudioManyWorkload(AudioWorkload):
+    """The same buffers for STREAMS independent stereo streams at once (a mixer's inputs, the sessions of a transcoding farm): one
+    gstamd_audio_resampler_resample_many call - one launch - per round of 1024-frame buffers.  A step = 10 s of every stream."""
+    name = "c4audiomany"
+    metric = "audio input frames/s (audioresample 48k->44.1k F32 stereo, 64 independent streams per launch) per GPU"
+    kernel = "k_fir_lds_many<float> (blockIdx.y = stream)"
+    STREAMS = 64
+
+    def setup(self, dev, rank):
+        import torch
+
+        import cases
+        from gstreamer_amd import audio as A
+        self.A = A
+        self.sigs = [torch.from_numpy(cases.audio_buffer("F32LE", self.CH, self.N, 4242 + rank + 7 * i)).to(dev) for i in range(self.STREAMS)]
+        self.rs = [A.AudioResampler("F32LE", self.CH, 48000, 44100, "kaiser", None) for _ in range(self.STREAMS)]
+        self.outs = [torch.zeros((self.N + 4096, self.CH), dtype=torch.float32, device=dev) for _ in range(self.STREAMS)]
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.blocks = [(o, min(self.block, self.N - o)) for o in range(0, self.N, self.block)]
+        self.launches_per_step = len(self.blocks)
+        self.units_per_step = self.N * self.STREAMS
+        no = self.N * 147 // 160
+        self.alg_bytes = (self.N * self.CH * 4 + no * self.CH * 4) * self.STREAMS
+        self.alg_bytes_per_launch = self.alg_bytes / len(self.blocks)
+        self.flops_per_step = 2.0 * 72 * no * self.CH * self.STREAMS
+
+        # the argument arrays of every round, built once: the output frame counts of a stream follow from its input sizes alone
+        # (gst_audio_resampler_get_out_frames is a function of the phase, which a throw-away plan walks through here)
+        walker = A.AudioResampler("F32LE", self.CH, 48000, 44100, "kaiser", None)
+        tmp = torch.zeros((self.block + 64, self.CH), dtype=torch.float32, device=dev)
+        self.calls, po, fsz = [], 0, self.CH * 4
+        for o, n in self.blocks:
+            m = walker.get_out_frames(n)
+            walker.resample(self.sigs[0].data_ptr() + o * fsz, n, tmp, m, self.stream)
+            self.calls.append(A.ManyBuffers(self.rs, [x.data_ptr() + o * fsz for x in self.sigs], [n] * self.STREAMS,
+                                            [x.data_ptr() + po * fsz for x in self.outs], [m] * self.STREAMS))
+            po += m
+        torch.cuda.synchronize()
+
+    def step(self, s):
+        for r in self.rs:
+            r.reset()
+        for c in self.calls:
+            c.run(self.stream)
+
+    def config(self, world):
+        return {"workload": "%s, %d independent streams, a step = 10 s of each in buffers of %d frames (%d launches of %d streams)"
+                            % (CONFIG_TEXT["c4audio"], self.STREAMS, self.block, len(self.blocks), self.STREAMS),
+                "block_frames": self.block, "streams": self.STREAMS, "parallelism": "stream-per-gpu x%d" % world}
+
+
 class AudioConvertWorkload:
     """audioconvert ! audioresample on the device.  A step = 10 s of stereo F32 48 kHz -> S16 44.1 kHz with the element's default
     triangular dither, in `block`-frame buffers: unpack / resample / quantize + dither / pack per buffer (three launches)."""
@@ -468,6 +519,8 @@ def make_workload(args):
         return CompositorScaledWorkload()
     if args.config == "c4audio":
         return AudioWorkload(args.audio_block)
+    if args.config == "c4audiomany":
+        return AudioManyWorkload(args.audio_block)
     if args.config == "f4audioconv":
         return AudioConvertWorkload(args.audio_block)
     if args.config == "stub":
@@ -596,7 +649,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f5encode16 | f8scale | f8pack | f8swizzle")
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c4audiomany | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f5encode16 | f8scale | f8pack | f8swizzle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="c2: skip the batch-1 / element numbers reported beside the headline")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
@@ -643,8 +696,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     wl = make_workload(args)
-    steps = args.steps if args.steps is not None else {"c2": 400, "c1": 800, "c3": 150, "c5": 150, "c4": 150, "c4audio": 20, "f4audioconv": 10, "stub": 5}.get(args.config, 50)
-    warmup = args.warmup if args.warmup is not None else {"c4audio": 2, "f4audioconv": 2, "stub": 1}.get(args.config, 20)
+    steps = args.steps if args.steps is not None else {"c2": 400, "c1": 800, "c3": 150, "c5": 150, "c4": 150, "c4audio": 20, "c4audiomany": 4, "f4audioconv": 10, "stub": 5}.get(args.config, 50)
+    warmup = args.warmup if args.warmup is not None else {"c4audio": 2, "c4audiomany": 1, "f4audioconv": 2, "stub": 1}.get(args.config, 20)
     wl.setup(dev, rank)
 
     def sync():

@@ -41,6 +41,8 @@ def lib():
         L.gstamd_audio_resampler_get_max_latency.argtypes = [C.c_void_p]
         L.gstamd_audio_resampler_resample.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.gstamd_audio_resampler_resample_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gstamd_audio_resampler_resample_many.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                                                           C.POINTER(C.c_size_t), C.c_void_p]
         L.gstamd_audio_resampler_debug_get.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.gstamd_audio_resampler_debug_taps.restype = C.c_long
         L.gstamd_audio_resampler_debug_taps.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_long]
@@ -60,6 +62,34 @@ def options(method="kaiser", quality=None, in_rate=0, out_rate=0, **kw):
             v = enums[k][v]
         setattr(o, k, v)
     return o
+
+
+_ptr = _v._ptr
+
+
+class ManyBuffers:
+    """The argument arrays of one gstamd_audio_resampler_resample_many call, built once (a caller that cycles through a ring of buffers keeps
+    one of these per slot: building five ctypes arrays of 64 entries costs more than the launch)."""
+
+    def __init__(self, resamplers, srcs, in_frames, dsts, out_frames):
+        n = self.n = len(resamplers)
+        assert n == len(srcs) == len(in_frames) == len(dsts) == len(out_frames)
+        self.keep = (list(resamplers), list(srcs), list(dsts))
+        self.rs = (C.c_void_p * n)(*[r._h for r in resamplers])
+        self.ip = (C.c_void_p * n)(*[None if x is None else _ptr(x) for x in srcs])
+        self.op = (C.c_void_p * n)(*[_ptr(x) for x in dsts])
+        self.inf = (C.c_size_t * n)(*in_frames)
+        self.outf = (C.c_size_t * n)(*out_frames)
+
+    def run(self, stream=None):
+        r = lib().gstamd_audio_resampler_resample_many(self.n, self.rs, self.ip, self.inf, self.op, self.outf, stream)
+        if r != 0:
+            raise RuntimeError("gstamd_audio_resampler_resample_many: %d" % r)
+
+
+def resample_many(resamplers, srcs, in_frames, dsts, out_frames, stream=None):
+    """gstamd_audio_resampler_resample_many: one buffer per resampler, one launch where the resamplers share a filter"""
+    ManyBuffers(resamplers, srcs, in_frames, dsts, out_frames).run(stream)
 
 
 class AudioResampler:

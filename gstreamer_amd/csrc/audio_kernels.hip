@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -47,13 +48,13 @@ __global__ __launch_bounds__ (256) void k_history (FirParams p, const T *__restr
 // FULL-table mode through LDS (audio_device.h, second half): FIR_LDS_FRAMES output frames per 256-lane workgroup, four lanes per
 // frame.  The workgroups past the FIR ones write the history the next call needs (k_history's job, one launch instead of two).
 template <typename T>
-__global__ __launch_bounds__ (256) void k_fir_lds (FirParams p, FirLdsGeom g, const T *__restrict__ hist, const T *__restrict__ in,
+__device__ __forceinline__ void fir_lds_block (const FirParams &p, const FirLdsGeom &g, const T *__restrict__ hist, const T *__restrict__ in,
     const T *__restrict__ table, T *__restrict__ out, long long n_out, int fir_blocks, T *__restrict__ new_hist, long long src_start,
-    long long moved, long long keep)
+    long long moved, long long keep, int bx)
 {
   extern __shared__ __attribute__ ((aligned (16))) unsigned char fir_lds_raw[];
-  if ((int) blockIdx.x >= fir_blocks) {
-    const long long i = (long long) (blockIdx.x - fir_blocks) * blockDim.x + threadIdx.x;
+  if (bx >= fir_blocks) {
+    const long long i = (long long) (bx - fir_blocks) * blockDim.x + threadIdx.x;
     if (i < keep * p.channels)
       new_hist[i] = history_sample<T> (p, hist, in, src_start, moved, i / p.channels, (int) (i % p.channels));
     return;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__ (256) void k_fir_lds (FirParams p, FirLdsGeom g, co
   typedef typename Acc<T>::type A;
   T *rows = (T *) fir_lds_raw, *win = rows + FIR_LDS_FRAMES * g.row_stride;
   int *pos = (int *) (win + (size_t) p.channels * g.win_frames);
-  const long long jb = (long long) blockIdx.x * FIR_LDS_FRAMES;
+  const long long jb = (long long) bx * FIR_LDS_FRAMES;
   const int nj = n_out - jb < FIR_LDS_FRAMES ? (int) (n_out - jb) : FIR_LDS_FRAMES;
   fir_lds_positions (p, jb, nj, pos, (int) threadIdx.x, 256);
   __syncthreads ();
@@ -78,6 +79,67 @@ __global__ __launch_bounds__ (256) void k_fir_lds (FirParams p, FirLdsGeom g, co
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__ (256) void k_fir_lds (FirParams p, FirLdsGeom g, const T *__restrict__ hist, const T *__restrict__ in,
+    const T *__restrict__ table, T *__restrict__ out, long long n_out, int fir_blocks, T *__restrict__ new_hist, long long src_start,
+    long long moved, long long keep)
+{
+  fir_lds_block<T> (p, g, hist, in, table, out, n_out, fir_blocks, new_hist, src_start, moved, keep, (int) blockIdx.x);
+}
+
+// ---- many independent resamplers of one filter in ONE launch (round 5: gstamd_audio_resampler_resample_many) ---------------------------------
+// A buffer of 1024 frames is 5.7 us of launch for 0.2 us of work; "independent streams" is this path's parallelism, so the streams of a
+// mixer / a multi-channel capture / a transcoding farm go into one grid: blockIdx.y = stream.  What differs between the streams - the
+// buffers and where each stands in its own history - fits 56 bytes, 64 streams fit the kernel arguments; the filter (rates, taps table,
+// channel count, sample type) is the same for all.  Each stream's blocks do exactly what its own k_fir_lds launch would have done.
+#define GSTAMD_AUDIO_MANY_MAX 64
+struct FirManyStream {
+  const void *hist, *in;
+  void *out, *new_hist;
+  int samp_index0, samp_phase0, hist_frames, in_frames, n_out;
+  int pad;
+};
+struct FirMany {
+  FirManyStream s[GSTAMD_AUDIO_MANY_MAX];
+};
+
+template <typename T>
+__global__ __launch_bounds__ (256) void k_fir_lds_many (FirParams shared, FirLdsGeom g, const T *__restrict__ table, FirMany many)
+{
+  const FirManyStream &m = many.s[blockIdx.y];
+  FirParams p = shared;
+  p.samp_index0 = m.samp_index0;
+  p.samp_phase0 = m.samp_phase0;
+  p.hist_frames = m.hist_frames;
+  p.total_frames = (long long) m.hist_frames + m.in_frames;
+  p.in_is_null = m.in == nullptr;
+  if (p.in_plane_stride)
+    p.in_plane_stride = m.in_frames;            /* non-interleaved sides: the planes follow each other, as in _resample */
+  if (p.out_plane_stride)
+    p.out_plane_stride = m.n_out;
+  // the history hand-over of audio_step (audio_taps.cpp), from the same numbers
+  long long src_start = 0, moved = p.total_frames, keep = p.total_frames;
+  if (m.n_out > 0) {
+    const long long tot = (long long) m.samp_phase0 + (long long) m.n_out * p.samp_frac;
+    const long long end_index = (long long) m.samp_index0 + (long long) m.n_out * p.samp_inc + tot / p.out_rate;
+    const long long consumed = end_index - m.samp_index0;
+    if (p.total_frames > end_index) {
+      src_start = end_index;
+      moved = p.total_frames - end_index;
+    } else {
+      src_start = 0;
+      moved = 0;
+    }
+    keep = consumed > 0 ? (p.total_frames - consumed > 0 ? p.total_frames - consumed : 0) : p.total_frames;
+  }
+  const int fir_blocks = (int) ((m.n_out + FIR_LDS_FRAMES - 1) / FIR_LDS_FRAMES);
+  const int hist_blocks = keep > 0 ? (int) ((keep * p.channels + 255) / 256) : 0;
+  if ((int) blockIdx.x >= fir_blocks + hist_blocks)
+    return;
+  fir_lds_block<T> (p, g, (const T *) m.hist, (const T *) m.in, table, (T *) m.out, m.n_out, fir_blocks, (T *) m.new_hist, src_start, moved, keep,
+      (int) blockIdx.x);
+}
+
 struct GstAmdAudioResampler {
   AudioPlan plan;
   std::mutex lock;
@@ -88,6 +150,7 @@ struct GstAmdAudioResampler {
   void *hist[2] = {nullptr, nullptr};
   size_t hist_cap[2] = {0, 0};      // frames
   int cur = 0;
+  unsigned long long table_hash = 0;      // of plan.table: resamplers with the same hash, rates, taps and sample type share one launch (_resample_many)
 };
 
 extern "C" const char *gstamd_last_error (void);
@@ -131,6 +194,10 @@ static int ensure_device (GstAmdAudioResampler *r)
       return audio_hip_fail (__func__);
     if (hipMemcpy (r->table_dev, r->plan.table.data (), r->plan.table.size (), hipMemcpyHostToDevice) != hipSuccess)
       return audio_hip_fail (__func__);
+    unsigned long long h = 1469598103934665603ull;
+    for (unsigned char b : r->plan.table)
+      h = (h ^ b) * 1099511628211ull;
+    r->table_hash = h ^ r->plan.table.size ();
   }
   int e = ensure_hist (r, 0, (size_t) r->plan.n_taps + 64);
   if (e == GSTAMD_OK)
@@ -216,6 +283,53 @@ static int run_resample (GstAmdAudioResampler *r, const void *in, size_t in_fram
   }
   r->cur = nxt;
   return GSTAMD_OK;
+}
+
+template <typename T>
+static int run_many (int n, GstAmdAudioResampler *const *rs, const void *const *in, const size_t *in_frames, void *const *out, const size_t *out_frames,
+    hipStream_t stream)
+{
+  const AudioPlan &pl = rs[0]->plan;
+  FirMany many;
+  memset ((void *) &many, 0, sizeof (many));
+  AudioStep first;
+  memset (&first, 0, sizeof (first));
+  int max_blocks = 0, live = 0;
+  for (int i = 0; i < n; i++) {
+    GstAmdAudioResampler *r = rs[i];
+    const AudioStep s = audio_step (r->plan, &r->st, in_frames[i], out_frames[i]);
+    if (s.skipped_all)
+      continue;
+    if (s.keep > 0) {
+      const int e = ensure_hist (r, r->cur ^ 1, (size_t) s.keep + 64);
+      if (e != GSTAMD_OK)
+        return e;
+    }
+    FirManyStream &m = many.s[live++];
+    m.hist = r->hist[r->cur];
+    m.new_hist = r->hist[r->cur ^ 1];
+    m.in = in[i];
+    m.out = out[i];
+    m.samp_index0 = (int) s.samp_index0;
+    m.samp_phase0 = s.samp_phase0;
+    m.hist_frames = (int) s.hist_frames;
+    m.in_frames = (int) (s.total_frames - s.hist_frames);
+    m.n_out = s.run_fir ? (int) s.n_out : 0;
+    const int blocks = (int) ((m.n_out + FIR_LDS_FRAMES - 1) / FIR_LDS_FRAMES) + (s.keep > 0 ? (int) ((s.keep * pl.channels + 255) / 256) : 0);
+    max_blocks = blocks > max_blocks ? blocks : max_blocks;
+    r->cur ^= 1;
+    first = s;
+  }
+  if (!live || !max_blocks)
+    return GSTAMD_OK;
+  const FirParams p = make_fir_params (pl, first, false, 1, 1);          /* the per-stream fields are filled in by the kernel */
+  FirLdsGeom g;
+  g.row_stride = p.n_taps_padded + 4;
+  const int span_max = FIR_LDS_FRAMES * (p.samp_inc + 1) + p.n_taps_padded + 2;
+  g.win_frames = ((span_max + 31) & ~31) + 16;
+  const size_t lds = ((size_t) FIR_LDS_FRAMES * g.row_stride + (size_t) pl.channels * g.win_frames) * sizeof (T) + 2 * FIR_LDS_FRAMES * sizeof (int);
+  hipLaunchKernelGGL (k_fir_lds_many<T>, dim3 ((unsigned) max_blocks, (unsigned) live), dim3 (256), lds, stream, p, g, (const T *) rs[0]->table_dev, many);
+  return hipGetLastError () == hipSuccess ? GSTAMD_OK : audio_hip_fail (__func__);
 }
 
 extern "C" {
@@ -394,6 +508,89 @@ int gstamd_audio_resampler_resample_planes (GstAmdAudioResampler *r, const void 
   if (pl.out_planar && pl.channels < 2)
     os = (long long) out_frames;
   return resample_strided (r, in ? in[0] : nullptr, in_frames, out ? out[0] : nullptr, out_frames, is, os, stream);
+}
+
+/* N independent resamplers, one buffer each, in ONE kernel launch where they share a filter: the same sample type, channel count, layout flags,
+ * rates and taps table (resamplers made with the same arguments), full filter mode, at most 2^31 frames of state each.  Results and the
+ * resamplers' states are exactly those of n gstamd_audio_resampler_resample calls (which is also what happens, one by one, for a set that
+ * does not qualify).  No reference counterpart: gst_audio_resampler_resample (audio-resampler.c:1750) takes one stream. */
+int gstamd_audio_resampler_resample_many (int n, GstAmdAudioResampler *const *resamplers, const void *const *in, const size_t *in_frames, void *const *out,
+    const size_t *out_frames, void *stream)
+{
+  if (n < 0 || (n > 0 && (!resamplers || !in_frames || !out || !out_frames)))
+    return GSTAMD_ERR_INVALID;
+  for (int i = 0; i < n; i++)
+    if (!resamplers[i] || (out_frames[i] > 0 && !out[i]))
+      return GSTAMD_ERR_INVALID;
+  int done = 0;
+  while (done < n) {
+    /* the longest run from `done` on that one launch can serve */
+    GstAmdAudioResampler *r0 = resamplers[done];
+    int e = GSTAMD_OK;
+    {
+      std::lock_guard<std::mutex> g (r0->lock);
+      e = ensure_device (r0);
+    }
+    if (e != GSTAMD_OK)
+      return e;
+    const AudioPlan &p0 = r0->plan;
+    const bool full = p0.method != GSTAMD_AUDIO_RESAMPLER_METHOD_NEAREST && p0.in_rate != p0.out_rate && p0.filter_mode != GSTAMD_AUDIO_FILTER_MODE_INTERPOLATED &&
+        !tuning_on ("GSTAMD_NO_FIR_LDS") && !tuning_on ("GSTAMD_NO_FIR_MANY");
+    int run = 1;
+    while (full && done + run < n && run < GSTAMD_AUDIO_MANY_MAX) {
+      GstAmdAudioResampler *r = resamplers[done + run];
+      bool dup = false;
+      for (int k = 0; k < run; k++)
+        dup = dup || resamplers[done + k] == r;          /* the same resampler twice: its second buffer depends on the first */
+      if (dup)
+        break;
+      {
+        std::lock_guard<std::mutex> g (r->lock);
+        e = ensure_device (r);
+      }
+      if (e != GSTAMD_OK)
+        return e;
+      const AudioPlan &p = r->plan;
+      if (p.format != p0.format || p.channels != p0.channels || p.in_rate != p0.in_rate || p.out_rate != p0.out_rate || p.n_taps != p0.n_taps ||
+          p.taps_stride != p0.taps_stride || p.in_planar != p0.in_planar || p.out_planar != p0.out_planar || p.method != p0.method ||
+          p.filter_mode != p0.filter_mode || r->table_hash != r0->table_hash)
+        break;
+      run++;
+    }
+    bool fits = full && run > 1;
+    for (int k = 0; fits && k < run; k++)
+      fits = in_frames[done + k] < (1u << 30) && out_frames[done + k] < (1u << 30);
+    if (fits) {
+      const size_t fbytes = (size_t) p0.bps;
+      const size_t lds_need = ((size_t) FIR_LDS_FRAMES * (p0.taps_stride + 4) + (size_t) p0.channels * (((FIR_LDS_FRAMES * (p0.samp_inc + 1) + p0.taps_stride + 2 + 31) & ~31) + 16)) * fbytes +
+          2 * FIR_LDS_FRAMES * sizeof (int);
+      fits = lds_need <= 64 * 1024;
+    }
+    if (!fits) {
+      e = resample_strided (r0, in ? in[done] : nullptr, in_frames[done], out[done], out_frames[done], (long long) in_frames[done], (long long) out_frames[done], stream);
+      if (e != GSTAMD_OK)
+        return e;
+      done++;
+      continue;
+    }
+    /* every resampler of the run under its own lock for the duration (ascending addresses: no two callers can wait for each other) */
+    std::vector<GstAmdAudioResampler *> order (resamplers + done, resamplers + done + run);
+    std::sort (order.begin (), order.end ());
+    for (GstAmdAudioResampler *r : order)
+      r->lock.lock ();
+    switch (p0.format) {
+      case GSTAMD_AUDIO_FORMAT_S16: e = run_many<int16_t> (run, resamplers + done, in + done, in_frames + done, out + done, out_frames + done, (hipStream_t) stream); break;
+      case GSTAMD_AUDIO_FORMAT_S32: e = run_many<int32_t> (run, resamplers + done, in + done, in_frames + done, out + done, out_frames + done, (hipStream_t) stream); break;
+      case GSTAMD_AUDIO_FORMAT_F32: e = run_many<float> (run, resamplers + done, in + done, in_frames + done, out + done, out_frames + done, (hipStream_t) stream); break;
+      default: e = run_many<double> (run, resamplers + done, in + done, in_frames + done, out + done, out_frames + done, (hipStream_t) stream); break;
+    }
+    for (GstAmdAudioResampler *r : order)
+      r->lock.unlock ();
+    if (e != GSTAMD_OK)
+      return e;
+    done += run;
+  }
+  return GSTAMD_OK;
 }
 
 int gstamd_audio_resampler_debug_get (GstAmdAudioResampler *r, int32_t *out, int max_out)

@@ -25,7 +25,7 @@ Knob g_knobs[] = {
   {"GSTAMD_BIL_SLOTS", false, -1, "", false}, {"GSTAMD_BIL_WG", false, -1, "", false}, {"GSTAMD_BIL_VERBOSE", false, -1, "", false},
   {"GSTAMD_FUSED_WAVES", false, -1, "", false}, {"GSTAMD_FUSED_ROWS", false, -1, "", false}, {"GSTAMD_FUSED_SCHED", false, -1, "", false},
   {"GSTAMD_FUSED_FIRST", false, -1, "", false}, {"GSTAMD_FUSED_DEBUG", false, -1, "", false},
-  {"GSTAMD_NO_FIR_LDS", false, -1, "", false},
+  {"GSTAMD_NO_FIR_LDS", false, -1, "", false}, {"GSTAMD_NO_FIR_MANY", false, -1, "", false},
   {"GSTAMD_SCALED_TILE_ROWS", false, -1, "", false}, {"GSTAMD_AGG_BX", false, -1, "", false},
   {"GSTAMD_NO_AGG_WALK", false, -1, "", false}, {"GSTAMD_WALK_ROWS", false, -1, "", false}, {"GSTAMD_WALK_XCD", false, -1, "", false},
   /* tuning builds */

@@ -98,6 +98,14 @@ int gstamd_audio_resampler_resample_planes (GstAmdAudioResampler *resampler, con
     void *const out[], size_t out_frames, void *stream);
 
 /* introspection for tests: n_taps, n_phases (reduced out_rate), reduced in_rate, oversample, filter mode */
+/* `n` independent resamplers, one buffer each (in[i] / out[i] interleaved, or non-interleaved planes following each other as in _resample),
+ * in ONE kernel launch where they share a filter - resamplers made with the same arguments, full filter mode; up to 64 per launch, longer
+ * or mixed sets run as several launches / one by one.  Outputs and resampler states are exactly those of n _resample calls.  For what
+ * carries many streams at once: the channels of a non-interleaved capture, the inputs of a mixer, a buffer list.  No reference counterpart:
+ * gst_audio_resampler_resample (audio-resampler.h:253) takes one stream and the reference has no cross-stream batching. */
+int gstamd_audio_resampler_resample_many (int n, GstAmdAudioResampler *const *resamplers, const void *const *in, const size_t *in_frames,
+    void *const *out, const size_t *out_frames, void *stream);
+
 int gstamd_audio_resampler_debug_get (GstAmdAudioResampler *resampler, int32_t *out, int max_out);
 /* copies the [n_phases][n_taps] taps table (as doubles) out; returns number of values or < 0 */
 long gstamd_audio_resampler_debug_taps (GstAmdAudioResampler *resampler, double *out, long max_out);

@@ -170,3 +170,59 @@ def test_one_big_buffer_equals_many_small(native_lib, gpu):
 
     a, b, c = run(n_total), run(4096), run(1000)
     assert a.shape == b.shape == c.shape and torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("fmt,ch", [("F32LE", 2), ("S16LE", 1), ("F64LE", 3), ("S32LE", 2)])
+def test_hip_many_resamplers_in_one_launch_equal_one_by_one(native_lib, gpu, ref, fmt, ch):
+    """gstamd_audio_resampler_resample_many: 70 independent streams (more than one launch's 64) that joined at different times - every stream
+    stands somewhere else in its history and phase - against the reference stream by stream, 0 ULP, over buffers of uneven sizes incl. the
+    drain; a resampler of another filter in the middle of the set goes its own way and the rest still share launches."""
+    import torch
+    dt = cases.AUDIO_DTYPES[fmt]
+    tdt = {"F32LE": torch.float32, "S16LE": torch.int16, "F64LE": torch.float64, "S32LE": torch.int32}[fmt]
+    n_streams = 70
+    odd = 33                              # this one resamples to another rate: not part of anybody's launch
+    rates = [(48000, 32000) if i == odd else (48000, 44100) for i in range(n_streams)]
+    rs = [A.AudioResampler(fmt, ch, a, b, "kaiser", A.options("kaiser", 4, a, b)) for a, b in rates]
+    rrs = [ref.AudioResampler(fmt, ch, a, b, quality=4) for a, b in rates]
+    sigs = [cases.audio_buffer(fmt, ch, 6000, 9000 + i) for i in range(n_streams)]
+    d_sigs = [torch.from_numpy(x).to(gpu) for x in sigs]
+    pos = [0] * n_streams
+    # a head start of its own for every stream, one by one: different histories and phases
+    for i in range(n_streams):
+        n = 37 * (i % 9) + 5
+        no = rrs[i].get_out_frames(n)
+        assert rs[i].get_out_frames(n) == no
+        exp = rrs[i].resample(sigs[i][:n], in_frames=n, out_frames=no)
+        d_out = torch.zeros((max(no, 1), ch), dtype=tdt, device=gpu)
+        rs[i].resample(d_sigs[i][:n], n, d_out, no)
+        torch.cuda.synchronize()
+        assert (d_out[:no].cpu().numpy().reshape(-1) == np.asarray(exp).reshape(-1)).all()
+        pos[i] = n
+    for size in (1024, 1, 480, 1024, 0, 777):
+        ins, nin, outs, nout, exps = [], [], [], [], []
+        for i in range(n_streams):
+            n = size if size else None
+            if n is None:                  # drain: NULL input of get_max_latency frames
+                nn = rrs[i].get_max_latency()
+                no = rrs[i].get_out_frames(nn)
+                assert rs[i].get_out_frames(nn) == no
+                exps.append(rrs[i].resample(None, in_frames=nn, out_frames=no))
+                ins.append(None)
+                nin.append(nn)
+            else:
+                no = rrs[i].get_out_frames(n)
+                assert rs[i].get_out_frames(n) == no
+                exps.append(rrs[i].resample(sigs[i][pos[i]:pos[i] + n], in_frames=n, out_frames=no))
+                ins.append(d_sigs[i][pos[i]:pos[i] + n])
+                nin.append(n)
+                pos[i] += n
+            outs.append(torch.zeros((max(no, 1), ch), dtype=tdt, device=gpu))
+            nout.append(no)
+        A.resample_many(rs, ins, nin, outs, nout)
+        torch.cuda.synchronize()
+        for i in range(n_streams):
+            got = outs[i][:nout[i]].cpu().numpy().reshape(-1)
+            assert (got == np.asarray(exps[i]).reshape(-1)).all(), (size, i)
+    for r in rs:
+        r.free()

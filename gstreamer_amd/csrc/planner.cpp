@@ -2586,6 +2586,10 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   if (fp) {
     const std::string name = fp;
     const int ki = plan->fin->kind, ko = plan->fout->kind;
+    /* no fastpath converts primaries: the rows without needs_color_matrix are only taken when they are equivalent, and the others build
+     * their matrix with video_converter_compute_matrix (:2837-2847) - to RGB, to YUV, nothing between - whatever primaries-mode says */
+    same_primaries = true;
+    m_identity (prim_dm);
     if (name == "convert_I420_xRGB")
       force_nearest = force_ayuv_argb = true;
     else if (name == "convert_AYUV_xRGB")
@@ -3134,7 +3138,8 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
        exceeds five - 8 -> 42 rows match, 8 -> 43 do not, with a horizontal pass anywhere in the chain every ratio matches: its temporary lines are
        reused before the repetitions have been served.  Announced, not reproduced */
     if (pl.front.chroma_v2 && pl.passes.size () == 1 && !pl.passes[0].horizontal && pl.passes[0].kind == SCALE_NEAREST && pl.passes[0].out_size > 5 * pl.passes[0].in_size &&
-        !(v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place || (identity_pack && pl.front.chroma_v2)))) {
+        !(v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits || (remap && (pl.gamma.prim.has_matrix || pl.gamma.alpha_kind == ALPHA_MULT)))) ||
+                late_in_place || (identity_pack && pl.front.chroma_v2)))) {
       plan->divergence += "nearest vertical enlargement by more than five of a 4:2:0 source with no horizontal pass: the reference's temporary lines are reused before "
           "every repetition of a line has been served (line aliasing: the first line of a chroma pair changes); this library serves every repetition from the same line. ";
     }
@@ -3158,7 +3163,12 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
             "reference delivers the pair's second line with the content of another line (a temporary line reused; line aliasing); this library replicates the source's pixels. ";
     }
     /* (a 4:2:0 source into a frame in its unpack format: the chroma upsampler itself works in the destination's rows, which the scaler hands out again) */
-    if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits)) || late_in_place || (identity_pack && pl.front.chroma_v2))) {
+    /* under gamma-mode = remap the stages between the decode and encode tables (the primaries matrix, the alpha multiply) work in place on 16-bit
+       temporary lines whose allocator the two scalers share (pass_alloc, one line): the vertical scaler's output IS the horizontal scaler's cached
+       line, so the second hand-out of a line is already converted (observed: 20x1 -> 3x3 drifts row by row; two taps and two source lines are exact) */
+    const bool gamma_in_place16 = remap && (g.prim.has_matrix || g.alpha_kind == ALPHA_MULT);
+    if (v_near_up && ((scale_first && in_place_op && (identity_pack || many_repeats || in_bits != out_bits || gamma_in_place16)) || late_in_place ||
+            (identity_pack && pl.front.chroma_v2))) {
       plan->divergence += "nearest vertical enlargement ahead of a stage that works in place (colour / alpha, chroma downsampling, dither): the reference "
           "processes a repeated line once more per repetition (line aliasing); this library applies every stage once per output row. ";
     }

@@ -34,7 +34,9 @@ def run(ifmt, w, h, ofmt, ow, oh, cfg={}, col=None, site=None, seed=1):
         if (vb(dst) == vb(want)).all():
             print("%s: OK(visible) [%s]" % (tag, desc.value.decode()))
             return
-    print("%s: %s  [%s]" % (tag, "OK" if bad == 0 else "MISMATCH %d of %d, first at %d" % (bad, dst.size, int(np.argmax(dst != want))), desc.value.decode()))
+    emu.emu_video_last_divergence.restype = C.c_char_p
+    defined = " (DEFINED: the plan announces a divergence)" if emu.emu_video_last_divergence() else ""
+    print("%s: %s%s  [%s]" % (tag, "OK" if bad == 0 else "MISMATCH %d of %d, first at %d" % (bad, dst.size, int(np.argmax(dst != want))), defined, desc.value.decode()))
 
 
 if __name__ == "__main__":

@@ -592,11 +592,21 @@ VIDEO_CASES = [
     ("prim_bgra_rgba_merge_only", "BGRA", 65, 33, "RGBA", 65, 33, dict(primaries_mode="merge-only"), "sRGB>1:1:7:8", None, "random"),
     ("prim_nv12_bgra_half_lanczos", "NV12", 640, 360, "BGRA", 320, 180, dict(primaries_mode="fast", resampler_method="lanczos"), "bt709>1:1:7:7", None, "random"),
     ("prim_p010_bgra_bt2020_to_srgb", "P010_10LE", 64, 48, "BGRA", 64, 48, dict(primaries_mode="fast"), "bt2020-10>sRGB", None, "random"),
+    # the reference's fastpaths never convert primaries: their matrix is video_converter_compute_matrix's (to RGB, to YUV, :2837-2847), and the rows
+    # with needs_color_matrix are taken whatever primaries-mode says (:8989) - found by the device fuzz of round 5 (seeds 7066 ...)
+    ("prim_fastpath_i420_bgra_ignores_primaries", "I420", 64, 48, "BGRA", 64, 48, dict(primaries_mode="fast"), None, None, "random"),
+    ("prim_fastpath_yv12_bgr_13x7_merge_only", "YV12", 13, 7, "BGR", 13, 7, dict(primaries_mode="merge-only", matrix_mode="input-only"), None, "cosited", "random"),
+    ("prim_fastpath_ayuv_rgba_57x8", "AYUV", 57, 8, "RGBA", 57, 8, dict(primaries_mode="fast"), None, None, "random"),
+    ("prim_fastpath_i420_xbgr_1x20_verterr", "I420", 1, 20, "xBGR", 1, 20, dict(primaries_mode="fast", dither_method="verterr"), None, None, "random"),
+    ("prim_fastpath_i420_argb_gamma_same_transfer", "I420", 34, 11, "ARGB", 34, 11, dict(primaries_mode="fast", gamma_mode="remap"), "bt601>1:1:6:1", None, "random"),
+    ("prim_chain_nv12_bgra_default_colorimetry", "NV12", 34, 12, "BGRA", 34, 12, dict(primaries_mode="fast"), None, None, "random"),
     # gamma-mode = remap (video_gamma.h): decode table -> linear ARGB64 -> [scalers, primaries, alpha] -> encode table
     ("gamma_nv12_bgra_322x241", "NV12", 322, 241, "BGRA", 322, 241, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"),
     ("gamma_bgra_nv12_322x241", "BGRA", 322, 241, "NV12", 322, 241, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"),
     ("gamma_i420_i420_bt601_bt709_no_chroma_resampler", "I420", 64, 48, "I420", 64, 48, dict(gamma_mode="remap"), "bt601>bt709", None, "random"),
     ("gamma_primaries_nv12_bgra", "NV12", 322, 241, "BGRA", 322, 241, dict(gamma_mode="remap", primaries_mode="fast"), "bt709>1:1:7:7", None, "random"),
+    ("gamma_yuy2_argb_dither_q2", "YUY2", 16, 33, "ARGB", 16, 33, dict(gamma_mode="remap", dither_quantization=2), "bt709", None, "random"),
+    ("gamma_vyuy_ayuv_dither_q2_verterr", "VYUY", 24, 9, "AYUV", 24, 9, dict(gamma_mode="remap", dither_quantization=2, dither_method="verterr"), "bt709>bt601", None, "random"),
     ("gamma_nv12_bgra_half_lanczos", "NV12", 640, 360, "BGRA", 320, 180, dict(gamma_mode="remap", resampler_method="lanczos"), "bt709>sRGB", None, "random"),
     ("gamma_bgra_rgba_up_bilinear_same_transfer", "BGRA", 160, 90, "RGBA", 333, 200, dict(gamma_mode="remap", resampler_method="linear", max_taps=2), "sRGB>sRGB", None, "random"),
     ("gamma_ayuv_argb_alpha_set", "AYUV", 64, 48, "ARGB", 64, 48, dict(gamma_mode="remap", alpha_mode="set", alpha_value=0.5), "bt709>sRGB", None, "random"),

@@ -1596,7 +1596,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
         convert422_lane8_any (q, pl.p[0] + (size_t) y * pl.stride[0], d0 + (size_t) y * dstride, x0);
     return GSTAMD_OK;
   }
-  if (p.fast_422_ayuv && !rgb24 && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && ((uintptr_t) d0 % 16) == 0 && (dstride % 16) == 0 &&
+  if (p.fast_422_ayuv && !g_gamma_hook && !rgb24 && ((uintptr_t) pl.p[0] % 16) == 0 && (pl.stride[0] % 16) == 0 && ((uintptr_t) d0 % 16) == 0 && (dstride % 16) == 0 &&
       getenv ("GSTAMD_NO_FAST422") == nullptr) {        /* k_convert422_ayuv */
     Fast422Params q;
     memset ((void *) &q, 0, sizeof (q));

@@ -19,7 +19,7 @@ def test_random_conversions_match_reference_or_are_refused(emu_lib, ref, seed):
     emu = fuzz_video.load_emu()
     rnd = random.Random(seed)
     rects = random.Random(seed + 77) if seed >= 700 else None
-    more = random.Random(seed + 313) if seed >= 5000 else None
+    more = random.Random(seed + 313) if 5000 <= seed < 60000 else None
     count = {"ok": 0, "refused": 0, "defined": 0, "bad": 0}
     bad = []
     for it in range(120):

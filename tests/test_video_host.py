@@ -179,6 +179,37 @@ def test_nearest_enlargement_aliasing_class_has_its_boundary_where_the_reference
         assert note == "" and (dst == exp).all()
 
 
+@pytest.mark.parametrize("cfg,ow,oh,inside", [
+    (dict(resampler_method="nearest", gamma_mode="remap", primaries_mode="fast"), 3, 4, True),
+    (dict(resampler_method="nearest", gamma_mode="remap", primaries_mode="fast"), 3, 3, True),
+    (dict(resampler_method="nearest", gamma_mode="remap", alpha_mode="mult", alpha_value=0.5), 3, 4, True),
+    (dict(resampler_method="linear", gamma_mode="remap", primaries_mode="fast"), 3, 4, False),          # two taps, two source lines: exact
+    (dict(resampler_method="nearest", gamma_mode="remap", primaries_mode="fast"), 3, 2, False),         # no line handed out twice
+    (dict(resampler_method="nearest", gamma_mode="remap"), 3, 4, False),                                  # nothing in place between the tables
+    (dict(resampler_method="nearest", gamma_mode="remap", primaries_mode="fast"), 30, 4, False),        # enlarged overall: scaled after the encode table
+    (dict(resampler_method="nearest", primaries_mode="fast"), 3, 4, False)])                              # the 8-bit chain converts a fresh copy
+def test_gamma_chain_in_place_stage_after_a_repeating_vertical_scaler_is_announced(emu_lib, ref, cfg, ow, oh, inside):
+    """gamma-mode = remap, scaling first, a source line handed out twice, and the primaries matrix / alpha multiply between the decode and encode
+    tables: the reference converts the repeated line again (the two scalers share a one-line allocator there; found by the device fuzz of round 5,
+    seed 7596) - announced, every row computed once from the source; the neighbouring plans are exact"""
+    w, h = 20, 2
+    ifmt = "ARGB" if "alpha_mode" in cfg else "xRGB"
+    src = cases.frame_bytes(int(V.video_info(ifmt, w, h).size), "random", 5, w)
+    dst = _emu_convert(emu_lib, ifmt, w, h, ifmt, ow, oh, cfg, "bt601", None, src)
+    emu_lib.emu_video_last_divergence.restype = C.c_char_p
+    note = emu_lib.emu_video_last_divergence().decode()
+    exp = ref.VideoConverter(ifmt, w, h, ifmt, ow, oh, in_colorimetry="bt601", config=cases.ref_config_string(ref, cfg)).frame(src)
+    if inside:
+        assert "once more per repetition" in note, note
+        got, want = dst.reshape(oh, -1), exp.reshape(oh, -1)
+        assert (got != want).any()
+        assert (got[0] == want[0]).all()            # a line's first hand-out is converted once by both
+        if oh == 2 * h:
+            assert (got[1] == got[0]).all()         # and its repetition equals it here
+    else:
+        assert note == "" and (dst == exp).all()
+
+
 def test_set_config_replans_the_sub_converters(native_lib):
     """gst_video_converter_set_config (video-converter.c:2759): a converter re-configured in place ends up with the plan - and, for the
     composite plans, the sub-conversions - of a converter created with the new options (round 2 kept sub-converters planned with the old

@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/prof; R=$GRAFT_REPO_ROOT/gpurun_out/p
 CONFIGS="${@:-c2 c3 c4 c5 c4audio c1}"
 for c in $CONFIGS; do
   timeout 600 python bench.py --config $c > $R/bench_$c.json 2> $R/bench_$c.err
-  BENCH="python $GRAFT_REPO_ROOT/bench.py --config $c --no-cpu-baseline"
+  BENCH="python $GRAFT_REPO_ROOT/bench.py --config $c --no-cpu-baseline --no-secondary"   # (the secondary legs launch the same kernel on single frames: they would mix into its average)
   ( cd /tmp; rm -rf /tmp/p_$c
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$c/trace -o t -- $BENCH > /tmp/p_$c.log 2>&1
     [ -n "$GSTAMD_PROF_NO_PMC" ] ||

@@ -41,7 +41,10 @@ static const FormatDesc g_formats[] = {
   // Y410 stores two bits of alpha but is declared without GST_VIDEO_FORMAT_FLAG_ALPHA (MAKE_YUV_FORMAT :8380): the alpha options pass it by
   {GSTAMD_VIDEO_FORMAT_Y210, "Y210", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 2},
   {GSTAMD_VIDEO_FORMAT_Y212_LE, "Y212_LE", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 5},
-  {GSTAMD_VIDEO_FORMAT_Y410, "Y410", true, false, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 0, 0, 0}, 7},
+  {GSTAMD_VIDEO_FORMAT_Y410, "Y410", true, false, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 10, 0, 20}, 7},
+  /* unpack_rgb10a2_le / unpack_bgr10a2_le (video-format.c:6210-6330; format table :8384-8388): Y410's word with R, G, B fields, unpack format ARGB64 */
+  {GSTAMD_VIDEO_FORMAT_RGB10A2_LE, "RGB10A2_LE", false, true, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 0, 10, 20}, 7},
+  {GSTAMD_VIDEO_FORMAT_BGR10A2_LE, "BGR10A2_LE", false, true, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 20, 10, 0}, 7},
   {GSTAMD_VIDEO_FORMAT_v210, "v210", true, false, 1, UNPACK_V210, 1, 0, 0, 0, {0, 0, 0, 0}, 8},          /* video-format.c:558-757 */
   // luma only (video-format.c:1207-1229)
   {GSTAMD_VIDEO_FORMAT_GRAY8, "GRAY8", true, false, 1, UNPACK_GRAY, 0, 0, 0, 0, {0, 0, 0, 0}},
@@ -75,6 +78,19 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_Y444_10LE, "Y444_10LE", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 1},
   // 16 bits per component, packed, native endianness (video-format.c:2426-2473, 2523-2570): the unpack formats of the 16-bit chain themselves
   {GSTAMD_VIDEO_FORMAT_ARGB64, "ARGB64", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}, 3},
+  /* the endian-specific 64-bit formats (video-format.c:2467-2815, table :8421-8436): ARGB64_LE is ARGB64 on this host (unpack_copy8), the others
+     reorder and / or byte-swap the four words */
+  {GSTAMD_VIDEO_FORMAT_ARGB64_LE, "ARGB64_LE", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}, 3},
+  {GSTAMD_VIDEO_FORMAT_ARGB64_BE, "ARGB64_BE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {0, 1, 2, 3}, 10},
+  {GSTAMD_VIDEO_FORMAT_RGBA64_LE, "RGBA64_LE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 0, 1, 2}, 9},
+  {GSTAMD_VIDEO_FORMAT_RGBA64_BE, "RGBA64_BE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 0, 1, 2}, 10},
+  {GSTAMD_VIDEO_FORMAT_BGRA64_LE, "BGRA64_LE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 2, 1, 0}, 9},
+  {GSTAMD_VIDEO_FORMAT_BGRA64_BE, "BGRA64_BE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 2, 1, 0}, 10},
+  {GSTAMD_VIDEO_FORMAT_ABGR64_LE, "ABGR64_LE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {0, 3, 2, 1}, 9},
+  {GSTAMD_VIDEO_FORMAT_ABGR64_BE, "ABGR64_BE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {0, 3, 2, 1}, 10},
+  /* unpack_GRAY16_LE / _BE (video-format.c:1231-1299): A = 0xffff, Y, U = V = 0x8000 */
+  {GSTAMD_VIDEO_FORMAT_GRAY16_LE, "GRAY16_LE", true, false, 1, UNPACK_GRAY16, 0, 0, 0, 0, {0, 0, 0, 0}, 9},
+  {GSTAMD_VIDEO_FORMAT_GRAY16_BE, "GRAY16_BE", true, false, 1, UNPACK_GRAY16, 0, 0, 0, 0, {0, 0, 0, 0}, 10},
   {GSTAMD_VIDEO_FORMAT_AYUV64, "AYUV64", true, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}, 3},
 };
 
@@ -210,6 +226,19 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->stride[0] = round_up (width * 3, 4);
       info->size = (uint64_t) info->stride[0] * h;
       break;
+    case GSTAMD_VIDEO_FORMAT_GRAY16_LE:
+    case GSTAMD_VIDEO_FORMAT_GRAY16_BE:         /* video-info.c:947-952 */
+      info->stride[0] = round_up (width * 2, 4);
+      info->size = (uint64_t) info->stride[0] * h;
+      break;
+    case GSTAMD_VIDEO_FORMAT_ARGB64_LE:
+    case GSTAMD_VIDEO_FORMAT_ARGB64_BE:
+    case GSTAMD_VIDEO_FORMAT_RGBA64_LE:
+    case GSTAMD_VIDEO_FORMAT_RGBA64_BE:
+    case GSTAMD_VIDEO_FORMAT_BGRA64_LE:
+    case GSTAMD_VIDEO_FORMAT_BGRA64_BE:
+    case GSTAMD_VIDEO_FORMAT_ABGR64_LE:
+    case GSTAMD_VIDEO_FORMAT_ABGR64_BE:
     case GSTAMD_VIDEO_FORMAT_ARGB64:
     case GSTAMD_VIDEO_FORMAT_AYUV64:
       info->stride[0] = width * 8;
@@ -220,7 +249,7 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = w * 4 * h;
       break;
   }
-  if (f->kind == UNPACK_GRAY) {         /* set_default_colorimetry (video-info.c:175-176): DEFAULT_GRAY = 0 .. 255, bt601, unknown, unknown */
+  if (f->kind == UNPACK_GRAY || f->kind == UNPACK_GRAY16) {         /* set_default_colorimetry (video-info.c:175-176): DEFAULT_GRAY = 0 .. 255, bt601, unknown, unknown */
     info->color_range = GSTAMD_COLOR_RANGE_0_255;
     info->color_matrix = GSTAMD_COLOR_MATRIX_BT601;
     info->chroma_site = GSTAMD_CHROMA_SITE_UNKNOWN;
@@ -1468,6 +1497,8 @@ const FastRow g_fast_rows[] = {
   {F_420 | F_Y42B | F_Y444, F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_GRAY8, F_420 | F_Y42B | F_Y444 | F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_NV12 | F_NV16 | F_NV24, F_NV12 | F_NV16 | F_NV24, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  /* GRAY16_LE -> GRAY16_LE, GRAY16_BE -> GRAY16_BE (:8901-8904) */
+  {fbit (GSTAMD_VIDEO_FORMAT_GRAY16_LE) | fbit (GSTAMD_VIDEO_FORMAT_GRAY16_BE), ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
 };
 }  // namespace
 
@@ -1538,7 +1569,9 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
     pp.ih = up (in.height, isub_h);
     pp.ow = up (out.width, osub_w);
     pp.oh = up (out.height, osub_h);
-    if (fo->kind == UNPACK_PACKED3) {
+    if (fo->kind == UNPACK_GRAY16) {
+      pp.n_elems = 2;          /* copies and nearest passes only (plan_core): a 16-bit sample moves as two bytes */
+    } else if (fo->kind == UNPACK_PACKED3) {
       pp.n_elems = 3;          /* get_functions (video-scaler.c:1222): RGB / BGR are 3 x u8 pixels */
     } else if (fo->kind == UNPACK_PACKED422) {
       /* get_functions (:1215): the line is ROUND_UP_4 (width * 2) single bytes */
@@ -1726,6 +1759,10 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
     return (uint64_t) w * h;
   if (f->kind == UNPACK_Y410)
     return (uint64_t) w * h * 4;
+  if (f->kind == UNPACK_PACKED64)
+    return (uint64_t) w * h * 8;
+  if (f->kind == UNPACK_GRAY16)
+    return (uint64_t) w * h * 2;
   if (f->kind == UNPACK_P422_16)
     return (uint64_t) ((w + 1) / 2) * 8 * h;
   if (f->kind == UNPACK_V210)
@@ -1759,7 +1796,7 @@ static void setup_dither16 (const GstAmdVideoConverterConfig &cfg, const FormatD
   d->method = cfg.dither_method;
   /* the planar formats have no alpha component (depth 0: quantiser 0); ARGB64 / AYUV64 carry 16 bits of it like the other three - their own
      quantiser is 1, so a stage only exists for dither-quantization > 1, run as a pass over the finished frame (k_dither16_image) */
-  d->shift[0] = fo->hi_depth == 3 ? shift : 0;
+  d->shift[0] = fo->hi_depth == 3 || fo->kind == UNPACK_PACKED64 ? shift : 0;
   if (fo->kind == UNPACK_Y410) {          /* 2 bits of alpha: quantiser 1 << 14 (chain_dither :2060-2075 per component depth) */
     unsigned qa = 1u << 14;
     if (cfg.dither_quantization > qa)
@@ -1785,7 +1822,7 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
   const bool in16 = fi->hi_depth != 0, out16 = fo->hi_depth != 0;
-  if (out16 && !kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && fo->kind != UNPACK_Y410 && fo->kind != UNPACK_V210)
+  if (out16 && !kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && !GSTAMD_KIND_PX16 (fo->kind) && fo->kind != UNPACK_V210)
     return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destination layout not implemented on the GPU path");
   /* a 10 / 12 / 16-bit planar SOURCE: the 16-bit front (unpack + chroma upsampler, k_front16) of the conversion into an AYUV64 frame of
    * the same size - planned like any other conversion, its front / pair table taken over */
@@ -1798,7 +1835,8 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
     const bool differs16 = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site || fw != ow_full || fh != oh_full;
     const bool up16 = differs16 && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY;
     GstAmdVideoInfo a64;
-    if (video_info_set_format (&a64, GSTAMD_VIDEO_FORMAT_AYUV64, in->width, in->height) != GSTAMD_OK)
+    /* the unpack format of the source: AYUV64, or ARGB64 for the RGB formats of the 16-bit chain (RGB10A2_LE, BGR10A2_LE) */
+    if (video_info_set_format (&a64, fi->yuv ? GSTAMD_VIDEO_FORMAT_AYUV64 : GSTAMD_VIDEO_FORMAT_ARGB64, in->width, in->height) != GSTAMD_OK)
       return fail (GSTAMD_ERR_INVALID, "bad frame size");
     a64.color_range = in->color_range;
     a64.color_matrix = in->color_matrix;
@@ -2208,7 +2246,7 @@ static int plan_src64 (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
      sub-conversion's) */
   g.alpha_kind = ALPHA_NONE;
   g.alpha_value = (unsigned) (int) (255 * cfg.alpha_value);
-  if (fo->hi_depth == 3 && !plane_scale)
+  if (fo->hi_depth != 0 && !plane_scale)         /* (alpha_bits is 0 already where the destination declares no alpha: planes, Y410) */
     g.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
   /* scalers on the 16-bit lines: all of them for a 16-bit destination, the shrinking ones otherwise (an 8-bit tail scales what grows) */
   plan->passes.clear ();
@@ -2279,7 +2317,7 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   const GstAmdVideoConverterConfig &cfg = plan->config;
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
-  if (!kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && fo->kind != UNPACK_Y410 && fo->kind != UNPACK_V210) {
+  if (!kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && !GSTAMD_KIND_PX16 (fo->kind) && fo->kind != UNPACK_V210) {
     if (error)
       *error = "10-bit destination layout not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
@@ -2568,7 +2606,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    *  - convert_scale_planes on a one-plane 4-byte format (setup_scale :7958-8075, convert_plane_hv :7693): the plane
    *    goes through gst_video_scaler_2d as raw 4 x u8 pixels - no unpack / matrix / alpha / pack - and the order of the
    *    two passes is the 2-D scaler's own rule (video-scaler.c:1542-1545), not chain_scale's. */
-  bool force_nearest = false, force_ayuv_argb = false, plane_scale = false, force_avg_down = false;
+  bool force_nearest = false, force_ayuv_argb = false, plane_scale = false, force_avg_down = false, order_2d = false;
   const char *fp = (cfg.internal_flags & 1) ? nullptr : lookup_fastpath (*plan, alpha_bits, same_matrix && same_primaries);
   plan->gamma.on = false;
   if (cfg.gamma_mode == GSTAMD_GAMMA_MODE_REMAP) {
@@ -2580,6 +2618,14 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       fp = nullptr;
     if (!fp)
       return plan_gamma (in, out, plan, alpha_bits, same_primaries, prim_dm, error);
+  }
+  if (fp && plan->fin->kind == UNPACK_GRAY16 && (in->width != out->width || in->height != out->height) &&
+      cfg.resampler_method != GSTAMD_RESAMPLER_METHOD_NEAREST) {
+    /* setup_scale (:7985-8003): the plane scaler serves the foreign-endian GRAY16 format with nearest only (the fastpath is dropped and the
+       chain runs); native 16-bit samples go through the u16 plane scalers, which this library has not built */
+    if (plan->fin->hi_depth != 10)
+      order_2d = true;          /* the u16 plane scaler = the chain's u16 passes in gst_video_scaler_2d's order, nothing else between unpack and pack */
+    fp = nullptr;
   }
   if (plan->fin->hi_depth == 3)
     return plan_src64 (in, out, plan, alpha_bits, same_matrix, same_primaries, prim_dm, in_matrix, out_matrix, fp != nullptr, error);
@@ -2672,7 +2718,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   if (need_scale) {
     const long s1 = (long) out_w * in_h, s2 = (long) in_w * out_h;
     bool h_first = s1 <= s2;
-    if (plane_scale && in_w != out_w && in_h != out_h) {
+    if ((plane_scale || order_2d) && in_w != out_w && in_h != out_h) {
       /* gst_video_scaler_2d: horizontal first iff width * voffset[height - 1] <= width * height */
       ScalePass vp;
       make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, in_h, out_h, false, &vp);
@@ -3004,7 +3050,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     rc.border[1] = (uint8_t) r;
     rc.border[2] = (uint8_t) g;
     rc.border[3] = (uint8_t) b;
-    if (fo->yuv && fo->kind != UNPACK_GRAY) {          /* GST_VIDEO_INFO_IS_YUV: a GRAY8 frame keeps the ARGB bytes, pack_GRAY8 then stores R */
+    if (fo->yuv && fo->kind != UNPACK_GRAY && fo->kind != UNPACK_GRAY16) {          /* GST_VIDEO_INFO_IS_YUV: a GRAY8 frame keeps the ARGB bytes, pack_GRAY8 then stores R */
       /* identity -> compute_matrix_to_YUV (force) -> rint; then 16 / 128 / 128 are added whatever the range */
       M44 dm;
       m_identity (dm);
@@ -3040,6 +3086,16 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
      source is src_width pixels from the line's FIRST pixel on, whatever src-x says (do_unpack_lines :2966 passes in_x, the unpacker drops it) */
   if (fi && fi->kind == UNPACK_V210)
     rc.in_x = 0;
+  /* unpack_RGBA64_LE and its seven siblings advance a guint16 pointer by x * 8 (video-format.c:2483, 2532 ...): 16 bytes per pixel of a horizontal
+     crop offset - the picture starts at pixel 2 x (reproduced), and runs into the next row when that is too far right (refused) */
+  if (fi && fi->kind == UNPACK_PACKED64 && rc.in_x != 0) {
+    if (2 * rc.in_x + ein.width > rc.in_maxw) {
+      if (error)
+        *error = "the reference's 64-bit unpackers misplace a horizontal source crop (x * 8 on a 16-bit pointer) and read past the row here; not reproduced";
+      return GSTAMD_ERR_UNSUPPORTED;
+    }
+    rc.in_x *= 2;               /* inside the row: the crop simply starts twice as far right */
+  }
   plan->rect = rc;
   plan->orig_in = *in;
   plan->orig_out = *out;
@@ -3277,6 +3333,19 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       ((out->stride[0] % 8) != 0 || (out->offset[0] % 8) != 0)) {
     plan->divergence += "VYUY unpacked straight into destination rows that are not 8-byte aligned: the reference's fallback loop (video-format.c:337-352) "
         "swaps U and V on those rows; this library unpacks every row the same way. ";
+  }
+  /* pack_VYUY (video-format.c:354-384) has the same fallback for a SOURCE line that is not 8-byte aligned, and its loop stores U, Y, V, Y - UYVY
+   * order.  The packer's source line is the source frame's own row when nothing between unpack and pack makes a line of its own: an AYUV source
+   * (identity unpack), no scaler, no matrix, no chroma downsampler, no dither, no border - then rows of a frame of odd width (or every row behind an
+   * odd src-x) come out with U and V swapped.  (Found in round 5 when the new formats reshuffled the fuzz draws: seed 101.) */
+  {
+    const RectPlan &rcv = plan->rect;
+    const bool whole = !rcv.out_x && !rcv.out_y && !rcv.fill && (!rcv.out_maxw || (rcv.out_maxw == out->width && rcv.out_maxh == out->height));
+    if (chain && fi->format == GSTAMD_VIDEO_FORMAT_AYUV && fo->format == GSTAMD_VIDEO_FORMAT_VYUY && pl.passes.empty () && !pl.gamma.on &&
+        pl.matrix.kind == MATRIX_NONE && pl.post.matrix.kind == MATRIX_NONE && pl.out_planar && !pl.pack.down_h && !pl.pack.dither.on && whole &&
+        ((in->stride[0] % 8) != 0 || (in->offset[0] % 8) != 0 || (rcv.in_x & 1)))
+      plan->divergence += "AYUV rows that are not 8-byte aligned packed straight into VYUY: the reference's fallback loop (video-format.c:366-373) stores "
+          "UYVY order on those rows; this library packs every row the same way. ";
   }
   /* a ONE-line 4:2:0 source enlarged into a rectangle below the first row of a frame in its unpack format (ARGB / AYUV: the chain's lines are the
    * destination's own rows, get_dest_line): the chroma upsampler makes its line pair (-1, 0) in the rows (out_y - 1, out_y) and the row above the

@@ -23,9 +23,15 @@ enum UnpackKind : int {
   UNPACK_PACKED422 = 4, // one plane, 4-byte macropixels of two pixels (YUY2, UYVY, YVYU, VYUY)
   UNPACK_GRAY = 5,      // one plane of luma (GRAY8): a YUV format as far as the chain goes (unpack format AYUV), U = V = 0x80
   UNPACK_P422_16 = 6,   // one plane, macropixels of four 16-bit little-endian words Y0 U Y1 V (Y210, Y212_LE): a source / destination of the 16-bit chain
-  UNPACK_Y410 = 7,      // one plane, a little-endian 32-bit word per pixel: U, Y, V at 10 bits, A at 2 (Y410); hi_depth code 7
+  UNPACK_Y410 = 7,      // one plane, a little-endian 32-bit word per pixel: three 10-bit fields and 2 bits of alpha on top (Y410: U, Y, V from the low
+                        // bits; RGB10A2_LE: R, G, B; BGR10A2_LE: B, G, R); hi_depth code 7; FormatDesc::pos[1..3] = first bit of component c1, c2, c3
   UNPACK_V210 = 8,      // one plane, groups of six pixels in 16 bytes: three 10-bit samples per little-endian 32-bit word (v210); hi_depth code 8
+  UNPACK_PACKED64 = 9,  // one plane, four 16-bit words per pixel in an order of their own (RGBA64_LE / _BE, BGRA64, ABGR64, ARGB64_BE; unpack format
+                        // ARGB64): FormatDesc::pos[c] = word of component c (A, R, G, B); hi_depth code 9 (little endian) / 10 (big endian)
+  UNPACK_GRAY16 = 10,   // one plane of 16-bit luma (GRAY16_LE / _BE; unpack format AYUV64, U = V = 0x8000); hi_depth code 9 / 10
 };
+// one plane of whole pixels whose samples reach the 16-bit chain through deep_front_px and leave it through pack16_packed_body, a lane per pixel
+#define GSTAMD_KIND_PX16(k) ((k) == UNPACK_Y410 || (k) == UNPACK_PACKED64 || (k) == UNPACK_GRAY16)
 
 struct FormatDesc {
   int format;
@@ -63,7 +69,9 @@ inline void format_plan_planes (const FormatDesc *f, GstAmdVideoInfo *info)
 #define GSTAMD_VP inline
 #endif
 // significant bits of a sample for a FormatDesc::hi_depth code, and whether the format keeps its samples in 16-bit words in planes
-GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 ? 10 : (hi == 4 || hi == 5 ? 12 : (hi == 3 || hi == 6 ? 16 : 8)); }
+GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 ? 10 : (hi == 4 || hi == 5 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 ? 16 : 8)); }
+// a stored 16-bit word of a UNPACK_PACKED64 / UNPACK_GRAY16 format -> its value (GST_READ_UINT16_LE / _BE; the same function stores)
+GSTAMD_VP int px16_word (int hi, int v) { return hi == 10 ? ((v >> 8) | (v << 8)) & 0xffff : v; }
 GSTAMD_VP bool hi_depth_words (int hi) { return hi == 1 || hi == 2 || (hi >= 4 && hi <= 6); }
 const FormatDesc *format_desc (int format);
 
@@ -344,6 +352,10 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
     return (size_t) y * stride + (size_t) x * 2;
   if (f->kind == UNPACK_P422_16 || f->kind == UNPACK_Y410)          /* 8 bytes per pair of pixels / 4 bytes per pixel */
     return (size_t) y * stride + (size_t) x * 4;
+  if (f->kind == UNPACK_PACKED64)
+    return (size_t) y * stride + (size_t) x * 8;
+  if (f->kind == UNPACK_GRAY16)
+    return (size_t) y * stride + (size_t) x * 2;
   if (f->kind == UNPACK_V210)            /* rows only: a horizontal offset inside the 6-pixel groups is refused by the planner */
     return (size_t) y * stride;
   const size_t bps = f->hi_depth ? 2 : 1;          /* planes of 10 / 12 / 16-bit formats hold 16-bit samples */
@@ -375,8 +387,8 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
   *hi = 0;
   auto s16 = [&](int c) -> uint32_t {
     const uint32_t v = (uint32_t) border[c] * 257u;
-    if (f->hi_depth == 3 || f->hi_depth == 6)
-      return v;
+    if (f->hi_depth == 3 || f->hi_depth == 6 || f->hi_depth == 9 || f->hi_depth == 10)
+      return (uint32_t) px16_word (f->hi_depth, (int) v);
     const int drop = 16 - hi_depth_bits (f->hi_depth);
     return f->hi_depth == 1 || f->hi_depth == 4 ? v >> drop : v & ~((1u << drop) - 1u);
   };
@@ -391,8 +403,10 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
     *es = 8, *lo = s16 (1) | (s16 (2) << 16), *hi = s16 (1) | (s16 (3) << 16);          /* pack_Y210: Y0 U Y1 V, 16 bits each */
   } else if (f->kind == UNPACK_Y410) {            /* pack_Y410 (video-format.c:898-921) of the widened border */
     const uint32_t a = (uint32_t) border[0] * 257u, y = (uint32_t) border[1] * 257u, u = (uint32_t) border[2] * 257u, v = (uint32_t) border[3] * 257u;
-    *es = 4, *lo = ((u & 0xffc0u) >> 6) | ((y & 0xffc0u) << 4) | ((v & 0xffc0u) << 14) | ((a & 0xc000u) << 16);
-  } else if (f->kind == UNPACK_PACKED4 && f->hi_depth == 3) {
+    *es = 4, *lo = ((y >> 6) << f->pos[1]) | ((u >> 6) << f->pos[2]) | ((v >> 6) << f->pos[3]) | ((a & 0xc000u) << 16);
+  } else if (f->kind == UNPACK_GRAY16) {
+    *es = 2, *lo = s16 (1);
+  } else if ((f->kind == UNPACK_PACKED4 && f->hi_depth == 3) || f->kind == UNPACK_PACKED64) {
     uint32_t w[4] = {0, 0, 0, 0};
     for (int c = 0; c < 4; c++)
       w[f->pos[c]] = s16 (c);

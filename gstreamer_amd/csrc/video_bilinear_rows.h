@@ -256,13 +256,21 @@ GSTAMD_HD void issue_order_fence_v ()
 #endif
 }
 
-// bytes [o, o + 1] of an LDS plane (the source pixels idx and idx + 1): one unaligned 16-bit load
+// bytes [o, o + 1] of an LDS plane (the source pixels idx and idx + 1).  EVEN (every offset of the plan is even: increments that are multiples
+// of two pixels, the span starts on 16): one 16-bit load.  Otherwise two byte loads: a ds_read_u16 at an ODD address is legal and gives the right
+// bytes, but the LDS serialises such lanes - at 3:2 (every other lane odd) the kernel took 47.5 us per 1440p frame against 14.5 with the
+// offsets forced even and 15.7 with byte loads (profiles/r05/bilr_lds_align.log)
+template <bool EVEN>
 GSTAMD_HD uint32_t bilr_pair (const uint8_t *plane, uint32_t o)
 {
-  uint16_t v;
-  __builtin_memcpy (&v, plane + o, 2);
-  return v;
+  if (EVEN) {
+    uint16_t v;
+    __builtin_memcpy (&v, plane + o, 2);
+    return v;
+  }
+  return (uint32_t) plane[o] | ((uint32_t) plane[o + 1] << 8);
 }
+GSTAMD_HOSTDEV bool bilr_even_offsets (const BilParams &bp) { return (bp.inc & 0x1ffff) == 0; }
 
 // ldreslinl on two 16-bit lanes: (a * (256 - f) + b * f) >> 8
 GSTAMD_HD uint32_t bilr_h (uint32_t a, uint32_t b, uint32_t frs) { return pk_shr<8> (pk_mad16 (b, frs, pk_mad16 (a, 0x01000100u - frs, 0u))); }
@@ -273,16 +281,17 @@ struct BilrPairs {
   uint32_t u0[2], v0[2], u1[2], v1[2];
 };
 
+template <bool EVEN>
 GSTAMD_HD void bilr_read_pairs (const BilrLane &c, const uint8_t *lds, int j, BilrPairs &r)
 {
   constexpr int P = BILR_PLANE_BYTES;
   const uint32_t oa = c.off[2 * j], ob = c.off[2 * j + 1];
-  r.l0a = bilr_pair (lds, oa), r.l0b = bilr_pair (lds, ob);
-  r.l1a = bilr_pair (lds + P, oa), r.l1b = bilr_pair (lds + P, ob);
-  r.u0[0] = bilr_pair (lds + 2 * P, oa), r.v0[0] = bilr_pair (lds + 3 * P, oa);
-  r.u1[0] = bilr_pair (lds + 4 * P, oa), r.v1[0] = bilr_pair (lds + 5 * P, oa);
-  r.u0[1] = bilr_pair (lds + 2 * P, ob), r.v0[1] = bilr_pair (lds + 3 * P, ob);
-  r.u1[1] = bilr_pair (lds + 4 * P, ob), r.v1[1] = bilr_pair (lds + 5 * P, ob);
+  r.l0a = bilr_pair<EVEN> (lds, oa), r.l0b = bilr_pair<EVEN> (lds, ob);
+  r.l1a = bilr_pair<EVEN> (lds + P, oa), r.l1b = bilr_pair<EVEN> (lds + P, ob);
+  r.u0[0] = bilr_pair<EVEN> (lds + 2 * P, oa), r.v0[0] = bilr_pair<EVEN> (lds + 3 * P, oa);
+  r.u1[0] = bilr_pair<EVEN> (lds + 4 * P, oa), r.v1[0] = bilr_pair<EVEN> (lds + 5 * P, oa);
+  r.u0[1] = bilr_pair<EVEN> (lds + 2 * P, ob), r.v0[1] = bilr_pair<EVEN> (lds + 3 * P, ob);
+  r.u1[1] = bilr_pair<EVEN> (lds + 4 * P, ob), r.v1[1] = bilr_pair<EVEN> (lds + 5 * P, ob);
 }
 
 // v2tap_pk with 0x80 added to both results (mod 256), i.e. each XOR 0x80 - the form the AYUV -> ARGB matrix wants (value - 128 as
@@ -326,18 +335,18 @@ GSTAMD_HD void bilr_store (uint8_t *__restrict__ row, uint32_t xoff, uint32_t v)
 // the next pair of outputs are issued before the arithmetic of this pair starts (the compiler left to itself issues each read
 // right in front of its use and the wave sits out the LDS latency once per output).  Lanes past the tile computed the tile's last
 // pixel (bilr_lane_setup): they store it again, same value to the same address, which keeps the row one straight run of code.
-template <int L, int NP>
+template <int L, int NP, bool EVEN = false>
 GSTAMD_HD void bilr_emit_row (const BilParams &bp, const BilrLane &c, const uint8_t *lds, uint8_t *__restrict__ dst, int dstride, int y, int p1,
     uint32_t (&q)[2])
 {
   const uint32_t p1s = ((uint32_t) (uint16_t) p1) * 0x00010001u;         /* p1 = bp.vtaps[2 y + 1], handed in by the caller */
   uint8_t *__restrict__ row = dst + (ptrdiff_t) y * dstride;
   BilrPairs rp[2];
-  bilr_read_pairs (c, lds, 0, rp[0]);
+  bilr_read_pairs<EVEN> (c, lds, 0, rp[0]);
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     if (j + 1 < NP)
-      bilr_read_pairs (c, lds, j + 1, rp[(j + 1) & 1]);
+      bilr_read_pairs<EVEN> (c, lds, j + 1, rp[(j + 1) & 1]);
     issue_order_fence_v ();
     const BilrPairs &r = rp[j & 1];
     // luma of two outputs: {output 2 j | output 2 j + 1 << 16} on each source line, then the vertical 2-tap between the lines

@@ -375,7 +375,7 @@ hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const Dither
     const int strides[3], hipStream_t stream)
 {
   video_frame_list_touch (planes[0]);
-  if (pk.kind == UNPACK_P422_16 || pk.kind == UNPACK_Y410 || pk.kind == UNPACK_V210) {          /* Y210, Y212_LE, Y410: a lane per macropixel / pixel */
+  if (pk.kind == UNPACK_P422_16 || GSTAMD_KIND_PX16 (pk.kind) || pk.kind == UNPACK_V210) {          /* Y210, Y212_LE, Y410: a lane per macropixel / pixel */
     hipLaunchKernelGGL (k_pack16_packed, dim3 ((pack16_units (pk) + 255) / 256, pack16_rows (pk)), dim3 (256), 0, stream, pk, hi_depth, dt, src, sstride, planes[0], strides[0]);
     return hipGetLastError ();
   }
@@ -970,6 +970,7 @@ static __device__ __forceinline__ void bilinear420_rows_body (const BilParams &b
   const int tab_r0 = (int) bp.voffset[yl], tab_p1 = (int) bp.vtaps[(size_t) yl * 2 + 1];
   BilrReq rq;
   bilr_request (bp, pl, st, first_r0, xa, x_hi, lane, rq);
+  const bool even = bilr_even_offsets (bp);       /* wave-uniform: which form of the LDS pair reads (video_bilinear_rows.h bilr_pair) */
   for (int y = y0; y < y1; y++) {
     bilr_install<CH> (bp, pl, st, rq, __builtin_amdgcn_readlane (tab_r0, y - y0), xa, x_hi, lane, lds);
     if (y + 1 < y1)
@@ -977,7 +978,10 @@ static __device__ __forceinline__ void bilinear420_rows_body (const BilParams &b
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier ();
     __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
-    bilr_emit_row<L, NP> (bp, c, lds, dst, dstride, y, __builtin_amdgcn_readlane (tab_p1, y - y0), q);
+    if (even)
+      bilr_emit_row<L, NP, true> (bp, c, lds, dst, dstride, y, __builtin_amdgcn_readlane (tab_p1, y - y0), q);
+    else
+      bilr_emit_row<L, NP, false> (bp, c, lds, dst, dstride, y, __builtin_amdgcn_readlane (tab_p1, y - y0), q);
     __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier ();
     __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");

@@ -57,6 +57,8 @@ enum {
   GSTAMD_VIDEO_FORMAT_Y444 = 20,
   GSTAMD_VIDEO_FORMAT_NV12 = 23,
   GSTAMD_VIDEO_FORMAT_GRAY8 = 25,       /* one plane of luma; unpacks to A = 0xff, Y, U = V = 0x80 (video-format.c:1207-1229) */
+  GSTAMD_VIDEO_FORMAT_GRAY16_BE = 26,   /* one plane of 16-bit luma, big / little endian; unpacks to AYUV64 with U = V = 0x8000 */
+  GSTAMD_VIDEO_FORMAT_GRAY16_LE = 27,
   GSTAMD_VIDEO_FORMAT_v308 = 28,        /* packed 4:4:4, 3 bytes per pixel: Y U V */
   GSTAMD_VIDEO_FORMAT_IYU2 = 63,        /* the same in the order U Y V */
   GSTAMD_VIDEO_FORMAT_VUYA = 84,        /* packed 4:4:4:4, 4 bytes per pixel: V U Y A */
@@ -78,7 +80,17 @@ enum {
   GSTAMD_VIDEO_FORMAT_v210 = 21,      /* packed 4:2:2, 10 bits: six pixels in four little-endian 32-bit words (three samples a word) */
   GSTAMD_VIDEO_FORMAT_Y210 = 82,      /* packed 4:2:2, 16-bit little-endian words Y0 U Y1 V, 10 bits in the high bits */
   GSTAMD_VIDEO_FORMAT_Y410 = 83,      /* packed 4:4:4 in one little-endian 32-bit word: U 10, Y 10, V 10, A 2 (from the low bits) */
-  GSTAMD_VIDEO_FORMAT_Y212_LE = 94,   /* Y210's layout with 12 bits */
+  GSTAMD_VIDEO_FORMAT_BGR10A2_LE = 85,  /* one little-endian 32-bit word per pixel: B 10, G 10, R 10, A 2 (from the low bits) */
+  GSTAMD_VIDEO_FORMAT_RGB10A2_LE = 86,  /* the same with R 10, G 10, B 10, A 2 */
+  GSTAMD_VIDEO_FORMAT_Y212_LE = 94,
+  GSTAMD_VIDEO_FORMAT_ARGB64_LE = 102,  /* 16 bits per component in the named memory order and endianness (ARGB64 is ARGB64_LE on this host) */
+  GSTAMD_VIDEO_FORMAT_ARGB64_BE = 103,
+  GSTAMD_VIDEO_FORMAT_RGBA64_LE = 104,
+  GSTAMD_VIDEO_FORMAT_RGBA64_BE = 105,
+  GSTAMD_VIDEO_FORMAT_BGRA64_LE = 106,
+  GSTAMD_VIDEO_FORMAT_BGRA64_BE = 107,
+  GSTAMD_VIDEO_FORMAT_ABGR64_LE = 108,
+  GSTAMD_VIDEO_FORMAT_ABGR64_BE = 109,   /* Y210's layout with 12 bits */
   GSTAMD_VIDEO_FORMAT_NV61 = 60,
   GSTAMD_VIDEO_FORMAT_P010_10LE = 62,   /* 10 bits in the high bits of little-endian 16-bit words */
   GSTAMD_VIDEO_FORMAT_VYUY = 64

@@ -36,14 +36,16 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
  * every source format (widen, matrix16, u16 scalers, u16 chroma downsample, dither, pack); the combinations the library has no
  * kernel for make set_caps fail (not-negotiated) */
 #define AMD_OUT_FORMATS AMD_IN_FORMATS
-#if GST_CHECK_VERSION (1, 18, 0)
-#define AMD_NEWER_FORMATS ", VUYA, Y210, Y410, P012_LE, P016_LE, Y444_16LE, Y212_LE"
+#if GST_CHECK_VERSION (1, 20, 0)
+#define AMD_NEWER_FORMATS ", VUYA, Y210, Y410, BGR10A2_LE, P012_LE, P016_LE, Y444_16LE, Y212_LE, RGB10A2_LE, ARGB64_LE, ARGB64_BE, RGBA64_LE, RGBA64_BE, BGRA64_LE, BGRA64_BE, ABGR64_LE, ABGR64_BE"
+#elif GST_CHECK_VERSION (1, 18, 0)
+#define AMD_NEWER_FORMATS ", VUYA, Y210, Y410, BGR10A2_LE, P012_LE, P016_LE, Y444_16LE, Y212_LE, RGB10A2_LE"
 #elif GST_CHECK_VERSION (1, 16, 0)
-#define AMD_NEWER_FORMATS ", VUYA, Y210, Y410"
+#define AMD_NEWER_FORMATS ", VUYA, Y210, Y410, BGR10A2_LE"
 #else
 #define AMD_NEWER_FORMATS ""
 #endif
-#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GBR, v210" AMD_NEWER_FORMATS " }"
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GRAY16_LE, GRAY16_BE, GBR, v210" AMD_NEWER_FORMATS " }"
 
 /* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path
  * (video-converter.c:3304, 3383-3463), so interlaced caps are not negotiated rather than converted as if progressive
@@ -805,14 +807,23 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_I422_10LE, GSTAMD_VIDEO_FORMAT_I422_10LE}, {GST_VIDEO_FORMAT_Y444_10LE, GSTAMD_VIDEO_FORMAT_Y444_10LE},
     {GST_VIDEO_FORMAT_I420_12LE, GSTAMD_VIDEO_FORMAT_I420_12LE}, {GST_VIDEO_FORMAT_I422_12LE, GSTAMD_VIDEO_FORMAT_I422_12LE},
     {GST_VIDEO_FORMAT_Y444_12LE, GSTAMD_VIDEO_FORMAT_Y444_12LE},
+    {GST_VIDEO_FORMAT_GRAY16_LE, GSTAMD_VIDEO_FORMAT_GRAY16_LE}, {GST_VIDEO_FORMAT_GRAY16_BE, GSTAMD_VIDEO_FORMAT_GRAY16_BE},
     /* VUYA, Y210, Y410 (1.16), P012_LE, P016_LE, Y444_16LE, Y212_LE (1.18) joined the format enum after 1.14: there when the headers this is compiled
      * against have them (plugins/build.py also type-checks every element against the reference's own 1.29 headers) */
 #if GST_CHECK_VERSION (1, 16, 0)
     {GST_VIDEO_FORMAT_VUYA, GSTAMD_VIDEO_FORMAT_VUYA}, {GST_VIDEO_FORMAT_Y210, GSTAMD_VIDEO_FORMAT_Y210}, {GST_VIDEO_FORMAT_Y410, GSTAMD_VIDEO_FORMAT_Y410},
+    {GST_VIDEO_FORMAT_BGR10A2_LE, GSTAMD_VIDEO_FORMAT_BGR10A2_LE},
 #endif
 #if GST_CHECK_VERSION (1, 18, 0)
     {GST_VIDEO_FORMAT_P012_LE, GSTAMD_VIDEO_FORMAT_P012_LE}, {GST_VIDEO_FORMAT_P016_LE, GSTAMD_VIDEO_FORMAT_P016_LE},
     {GST_VIDEO_FORMAT_Y444_16LE, GSTAMD_VIDEO_FORMAT_Y444_16LE}, {GST_VIDEO_FORMAT_Y212_LE, GSTAMD_VIDEO_FORMAT_Y212_LE},
+    {GST_VIDEO_FORMAT_RGB10A2_LE, GSTAMD_VIDEO_FORMAT_RGB10A2_LE},
+#endif
+#if GST_CHECK_VERSION (1, 20, 0)
+    {GST_VIDEO_FORMAT_ARGB64_LE, GSTAMD_VIDEO_FORMAT_ARGB64_LE}, {GST_VIDEO_FORMAT_ARGB64_BE, GSTAMD_VIDEO_FORMAT_ARGB64_BE},
+    {GST_VIDEO_FORMAT_RGBA64_LE, GSTAMD_VIDEO_FORMAT_RGBA64_LE}, {GST_VIDEO_FORMAT_RGBA64_BE, GSTAMD_VIDEO_FORMAT_RGBA64_BE},
+    {GST_VIDEO_FORMAT_BGRA64_LE, GSTAMD_VIDEO_FORMAT_BGRA64_LE}, {GST_VIDEO_FORMAT_BGRA64_BE, GSTAMD_VIDEO_FORMAT_BGRA64_BE},
+    {GST_VIDEO_FORMAT_ABGR64_LE, GSTAMD_VIDEO_FORMAT_ABGR64_LE}, {GST_VIDEO_FORMAT_ABGR64_BE, GSTAMD_VIDEO_FORMAT_ABGR64_BE},
 #endif
   };
   int fmt = 0;

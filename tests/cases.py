@@ -72,8 +72,10 @@ def visible_planes(fmt, w, h):
         return [(2 * w, h), (4 * up2(w), up2(h))]
     if fmt in ("Y210", "Y212_LE"):
         return [(8 * up2(w), h)]
-    if fmt in ("ARGB64", "AYUV64"):
+    if fmt in ("ARGB64", "AYUV64") or fmt.endswith(("64_LE", "64_BE")):
         return [(8 * w, h)]
+    if fmt in ("GRAY16_LE", "GRAY16_BE"):
+        return [(2 * w, h)]
     if fmt == "GRAY8":
         return [(w, h)]
     if fmt == "v210":
@@ -994,6 +996,59 @@ VIDEO_CASES += [
 ]
 
 
+# Round 5 formats: RGB10A2_LE / BGR10A2_LE (Y410's word with R, G, B fields), the endian- and order-specific 64-bit formats (ARGB64_LE / _BE, RGBA64,
+# BGRA64, ABGR64), GRAY16_LE / _BE - each as a source and as a destination of the 16-bit chain: into / from 8-bit and 16-bit neighbours, scaled on
+# either side, a rectangle with borders, the alpha stage on 16-bit lines, dither, gamma remap; GRAY16's own plane scaler rows (:8901-8904)
+def _round5_format_sweep():
+    out = []
+    fams = ["RGB10A2_LE", "BGR10A2_LE", "ARGB64_LE", "ARGB64_BE", "RGBA64_LE", "RGBA64_BE", "BGRA64_LE", "BGRA64_BE", "ABGR64_LE", "ABGR64_BE",
+            "GRAY16_LE", "GRAY16_BE"]
+    for f in fams:
+        n = f.lower()
+        rgb = not f.startswith("GRAY")
+        out += [
+            ("r5f_%s_bgra_37x6" % n, f, 37, 6, "BGRA", 37, 6, {}, None, None, "random"),
+            ("r5f_bgra_%s_40x5" % n, "BGRA", 40, 5, f, 40, 5, {}, None, None, "random"),
+            ("r5f_%s_nv12_40x6" % n, f, 40, 6, "NV12", 40, 6, {}, None, None, "random"),
+            ("r5f_nv12_%s_up_bilinear" % n, "NV12", 64, 36, f, 100, 50, LIN, None, None, "random"),
+            ("r5f_%s_i420_10le_down_lanczos" % n, f, 64, 36, "I420_10LE", 32, 20, LAN, None, None, "random"),
+            ("r5f_%s_y410_33x7" % n, f, 33, 7, "Y410", 33, 7, {}, None, None, "random"),
+            ("r5f_argb64_%s_dest_border" % n, "ARGB64", 30, 20, f, 50, 30, dict(dest_x=7, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+            ("r5f_%s_y444_10le_vcrop_dest_border" % n, f, 48, 30, "Y444_10LE", 60, 40, dict(src_y=3, src_height=20, src_width=30, dest_x=7, dest_y=9, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+            ("r5f_bgra_%s_sierra_q64" % n, "BGRA", 35, 19, f, 35, 19, dict(dither_method="sierra-lite", dither_quantization=64), None, None, "random"),
+            ("r5f_%s_self_down_bilinear" % n, f, 64, 36, f, 32, 20, LIN, None, None, "random"),
+            ("r5f_%s_bgra_gamma_remap" % n, f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709" if rgb else "bt709>sRGB", None, "random"),
+            ("r5f_i420_%s_gamma_remap" % n, "I420", 40, 8, f, 40, 8, dict(gamma_mode="remap"), "bt709>sRGB" if rgb else "bt709>bt2020", None, "random"),
+        ]
+        if rgb:
+            out += [
+                ("r5f_ayuv64_%s_alpha_set" % n, "AYUV64", 26, 10, f, 26, 10, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+                ("r5f_argb64_%s_alpha_mult_up" % n, "ARGB64", 26, 10, f, 40, 20, dict(LIN, alpha_mode="mult", alpha_value=0.25), None, None, "random"),
+                ("r5f_%s_bgra_alpha_mult" % n, f, 40, 5, "BGRA", 40, 5, dict(alpha_mode="mult", alpha_value=0.5), None, None, "random"),
+            ]
+        else:
+            out += [
+                ("r5f_%s_self_copy" % n, f, 33, 17, f, 33, 17, {}, None, None, "random"),
+                ("r5f_%s_self_nearest_up" % n, f, 33, 17, f, 50, 40, NEAR, None, None, "random"),
+                ("r5f_%s_self_crop_border_lanczos" % n, f, 48, 30, f, 60, 40, dict(LAN, src_x=5, src_y=3, src_width=30, src_height=20, dest_x=7, dest_y=9, dest_width=20, dest_height=10, border_argb=0x40e0a060), None, None, "random"),
+                ("r5f_%s_gray8" % n, f, 30, 20, "GRAY8", 30, 20, {}, None, None, "random"),
+                ("r5f_gray8_%s" % n, "GRAY8", 30, 20, f, 30, 20, {}, None, None, "random"),
+            ]
+    out += [
+        ("r5f_rgb10a2_bgr10a2", "RGB10A2_LE", 30, 20, "BGR10A2_LE", 30, 20, {}, None, None, "random"),
+        ("r5f_rgba64_le_abgr64_be", "RGBA64_LE", 30, 20, "ABGR64_BE", 30, 20, {}, None, None, "random"),
+        ("r5f_gray16_be_gray16_le_lanczos", "GRAY16_BE", 48, 30, "GRAY16_LE", 20, 10, LAN, None, None, "random"),
+        ("r5f_argb64_le_crop_x_copy8", "ARGB64_LE", 48, 30, "BGRA", 30, 20, dict(src_x=5, src_y=3, src_width=30, src_height=20), None, None, "random"),
+        ("r5f_rgba64_le_crop_x_doubled", "RGBA64_LE", 48, 30, "BGRA", 30, 20, dict(src_x=5, src_y=3, src_width=30, src_height=20), None, None, "random"),
+        ("r5f_abgr64_be_crop_x_doubled_scaled", "ABGR64_BE", 60, 30, "RGB10A2_LE", 20, 12, dict(LIN, src_x=9, src_y=3, src_width=40, src_height=20), None, None, "random"),
+        ("r5f_p010_rgb10a2_1080_strip", "P010_10LE", 1920, 16, "RGB10A2_LE", 1920, 16, {}, None, None, "random"),
+    ]
+    return out
+
+
+VIDEO_CASES += _round5_format_sweep()
+
+
 # fill-border = FALSE over the same plans: compared on the bytes the picture decides (scripts/fuzz_video.py matches_reference)
 DEEP_NOFILL = [(fi, w, 11, fo, w + 13, 27, dict(dest_x=4, dest_y=5, dest_width=w, dest_height=11, fill_border=0, **({"dither_quantization": dq} if dq > 1 else {})))
                for fi in ("Y444_10LE", "Y444_12LE", "Y444_16LE") for fo in ("Y444_10LE", "Y444_12LE", "Y444_16LE") for w in (1, 2, 17) for dq in (1, 2)]
@@ -1022,6 +1077,9 @@ VIDEO_REFUSED = [
     ("YV12", 11, 21, "Y444_16LE", 85, 12, NEAR),         # nearest vertical scaling of 4:2:0 through the composite plans
     ("P010_10LE", 31, 13, "NV12", 23, 13, {}),           # the same through the composite plans
     ("I420_12LE", 13, 33, "ARGB64", 43, 11, dict(resampler_method="nearest", gamma_mode="remap")),   # ... and under gamma-mode = remap, whose 16-bit front runs in line order
+    # the reference's 64-bit unpackers step x * 8 on a guint16 pointer (video-format.c:2483 ...): a horizontal source crop starts at pixel 2 x
+    ("RGBA64_LE", 48, 30, "BGRA", 30, 20, dict(src_x=10, src_y=3, src_width=30, src_height=20)),         # ... and past the row's end from x = 10 on
+    ("ARGB64_BE", 48, 30, "ARGB64", 30, 20, dict(src_x=12, src_width=30, src_height=20)),
 ]
 
 # Conversions for which the REFERENCE's own output is undefined - it reads lines it has not converted, converts a repeated line once per
@@ -1055,6 +1113,10 @@ VIDEO_DEFINED = [
      [("NV12", 30, 22, "AYUV", 30, 22, {}), ("AYUV", 30, 22, "VUYA", 38, 15, LAN), ("VUYA", 38, 15, "YV12", 38, 15, {})], None),
     ("ub_odd_420_shrink_bilinear", ("NV12", 18, 40, "I420", 18, 19, dict(resampler_method="linear")),
      [("NV12", 18, 40, "AYUV", 18, 40, {}), ("AYUV", 18, 40, "VUYA", 18, 19, dict(resampler_method="linear")), ("VUYA", 18, 19, "I420", 18, 19, {})], None),
+    ("ub_vyuy_pack_unaligned_source_rows", ("AYUV", 43, 18, "VYUY", 43, 18, dict(chroma_mode="none")),     # pack_VYUY's fallback loop on the source frame's own rows
+     [("AYUV", 43, 18, "Y444", 43, 18, {}), ("Y444", 43, 18, "VYUY", 43, 18, dict(chroma_mode="none"))], None),
+    ("ub_vyuy_pack_odd_src_x", ("AYUV", 44, 18, "VYUY", 40, 18, dict(chroma_mode="upsample-only", src_x=1, src_width=40)),
+     [("AYUV", 44, 18, "Y444", 40, 18, dict(src_x=1, src_width=40)), ("Y444", 40, 18, "VYUY", 40, 18, dict(chroma_mode="none"))], None),
     ("ub_vyuy_unaligned_rows", ("VYUY", 59, 11, "AYUV", 59, 11, {}),                # unpack_VYUY's fallback loop (video-format.c:337-352)
      [("VYUY", 59, 11, "AYUV", 59, 11, {})], "vyuy"),
 ]

@@ -190,6 +190,28 @@ def test_videoconvertscale_element_gray8(gst_env, ref):
         assert (c1.frame(mid[f]) == out[f]).all()
 
 
+def test_videoconvertscale_element_round5_formats(gst_env, ref):
+    """the formats of round 5 through the element, as a destination and as a source: GRAY16_LE on both runtimes; RGB10A2_LE (1.18) and
+    RGBA64_BE (1.20) where the runtime knows them (the reference's own version)"""
+    env, tmp = gst_env
+    fmts = ["GRAY16_LE"] + (["RGB10A2_LE", "RGBA64_BE"] if env.get("GSTAMD_RUNTIME") == "1.29" else [])
+    w, h, n = 322, 242, 2
+    for fmt in fmts:
+        fin, fmid, fout = tmp / ("r5_%s.bgra" % fmt), tmp / ("r5_%s.mid" % fmt), tmp / ("r5_%s.out" % fmt)
+        launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=%d,height=%d "
+                    "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw,format=%s,width=192,height=120 ! tee name=u "
+                    "u. ! queue ! filesink location=%s u. ! queue ! videoconvertscale ! video/x-raw,format=BGRA,width=192,height=120 ! filesink location=%s"
+               % (n, w, h, fin, fmt, fmid, fout))
+        src = np.fromfile(fin, np.uint8).reshape(n, -1)
+        mid = np.fromfile(fmid, np.uint8).reshape(n, -1)
+        out = np.fromfile(fout, np.uint8).reshape(n, -1)
+        c0 = ref.VideoConverter("BGRA", w, h, fmt, 192, 120, config=cases.ref_config_string(ref, cases.LIN))
+        c1 = ref.VideoConverter(fmt, 192, 120, "BGRA", 192, 120)
+        for f in range(n):
+            assert (c0.frame(src[f]) == mid[f]).all(), fmt
+            assert (c1.frame(mid[f]) == out[f]).all(), fmt
+
+
 def test_videoconvertscale_element_v210(gst_env, ref):
     """v210 (SDI capture / playout) on either side through the generic 16-bit chain: BGRA -> v210 at another size, v210 -> BGRA"""
     env, tmp = gst_env

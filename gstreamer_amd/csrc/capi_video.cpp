@@ -1771,6 +1771,19 @@ int gstamd_video_converter_frame (GstAmdVideoConverter *c, const void *src, void
   return frame_planes_plan_order (c, sp, nullptr, dp, nullptr, stream);
 }
 
+// frames [0, n) of a list one by one on the caller's stream.  (Round 5 tried fanning them out over four internal streams, forked from and joined
+// into the caller's with events, a scratch set per stream: lists of 8 got SLOWER - BGRA 4K -> NV12 1080p bilinear 16.4 -> 23.5 us per frame, I420 4K ->
+// RGBA 720p 7.9 -> 15.4 - the cross-queue event waits cost more than the overlap of the short launches gives; profiles/r05/survey_fan_out_4_streams.log.)
+static int frames_one_by_one (GstAmdVideoConverter *c, int n_frames, const void *const *src, void *const *dest, void *stream_)
+{
+  for (int i = 0; i < n_frames; i++) {
+    const int r = gstamd_video_converter_frame (c, src[i], dest[i], stream_);
+    if (r != GSTAMD_OK)
+      return r;
+  }
+  return GSTAMD_OK;
+}
+
 int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const void *const *src, void *const *dest, void *stream_)
 {
   if (!c || n_frames < 0 || (n_frames > 0 && (!src || !dest)))
@@ -1804,12 +1817,8 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
   }
   Enc16Params ep16_list;
   const bool enc16_list = p.gamma.on && enc16_params (p, &ep16_list) && !tuning_on ("GSTAMD_NO_ENCODE16");         /* k_encode16: one kernel, takes lists */
-  if (p.gamma.on && !p.gamma.planes_fast && !enc16_list) {
-    for (int i = 0; i < n_frames; i++)
-      if ((r = gstamd_video_converter_frame (c, src[i], dest[i], stream_)) != GSTAMD_OK)
-        return r;
-    return GSTAMD_OK;
-  }
+  if (p.gamma.on && !p.gamma.planes_fast && !enc16_list)
+    return frames_one_by_one (c, n_frames, src, dest, stream_);
   /* one launch for the whole list when the line-pair kernel applies to every frame */
   bool all_fast = true;
   std::vector<const uint8_t *> y (n_frames), uv (n_frames);
@@ -1925,12 +1934,7 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
       base += nb;
     }
   }
-  for (int i = base; i < n_frames; i++) {
-    r = gstamd_video_converter_frame (c, src[i], dest[i], stream_);
-    if (r != GSTAMD_OK)
-      return r;
-  }
-  return GSTAMD_OK;
+  return frames_one_by_one (c, n_frames - base, src + base, dest + base, stream_);
 }
 
 int gstamd_video_converter_list_launches (GstAmdVideoConverter *c)

@@ -169,6 +169,61 @@ GSTAMD_HD void src_span8 (const SrcImage &s, int x0, int y, uint32_t *px)
     px[i] = v.v[i];
 }
 
+// a 4-byte packed 8-bit source (BGRA & co) whose rows are word aligned: eight pixels with word loads issued together, the unpack permutation
+// and the colour stage ahead of the scaler on each - instead of eight dependent trips through fetch_front's switch (the horizontal pass of a
+// BGRA 4K -> 1080p linear downscale spent 33 us there, profiles/r05/survey_item6_kernel_split_start.log)
+GSTAMD_HD bool src_p4 (const SrcFront &s)
+{
+  return s.f.kind == UNPACK_PACKED4 && s.f.hi_depth == 0 && (s.pl.stride[0] & 3) == 0 && ((size_t) s.pl.p[0] & 3) == 0;
+}
+GSTAMD_HD bool src_p4 (const SrcImage &) { return false; }
+GSTAMD_HD void src_span8_p4 (const SrcFront &s, int x0, int y, uint32_t *px)
+{
+  struct __attribute__ ((aligned (4))) W8 { uint32_t v[8]; };
+  const W8 v = *(const W8 *) (s.pl.p[0] + (size_t) y * s.pl.stride[0] + 4 * (size_t) x0);
+  const uint32_t sel = (uint32_t) s.f.pos[0] | ((uint32_t) s.f.pos[1] << 8) | ((uint32_t) s.f.pos[2] << 16) | ((uint32_t) s.f.pos[3] << 24);
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    px[i] = apply_color (s.pre, bperm (0u, v.v[i], sel));
+}
+GSTAMD_HD void src_span8_p4 (const SrcImage &, int, int, uint32_t *) {}
+
+// the same for a packed 4:2:2 source (YUY2 & co): pixels x0 .. x0 + 7 are macropixels k0 .. k0 + 3, the horizontal chroma upsampler also reads
+// k0 - 1 and k0 + 4 - six words loaded together, then fetch_front's arithmetic (load_uv, chroma_h_at) on registers.  Inside the picture only:
+// x0 >= 2, x0 + 9 <= width (every odd pixel has a right neighbour), no swapped tail macropixel in reach, rows the unpacker does not clamp.
+GSTAMD_HD bool src_p422 (const SrcFront &s) { return s.f.kind == UNPACK_PACKED422 && (s.pl.stride[0] & 3) == 0 && ((size_t) s.pl.p[0] & 3) == 0; }
+GSTAMD_HD bool src_p422 (const SrcImage &) { return false; }
+GSTAMD_HD bool src_span8_p422_ok (const SrcFront &s, int x0, int y)
+{
+  return x0 >= 2 && x0 + 9 <= s.f.width && y <= s.f.luma_last && (s.f.swap_k < 0 || (x0 >> 1) + 4 < s.f.swap_k);
+}
+GSTAMD_HD bool src_span8_p422_ok (const SrcImage &, int, int) { return false; }
+GSTAMD_HD void src_span8_p422 (const SrcFront &s, int x0, int y, uint32_t *px)
+{
+  struct __attribute__ ((aligned (4))) W6 { uint32_t v[6]; };
+  const W6 m = *(const W6 *) (s.pl.p[0] + (size_t) y * s.pl.stride[0] + 2 * (size_t) x0 - 4);
+  const int by = 8 * s.f.pos[1], bu = 8 * s.f.pos[2], bv = 8 * s.f.pos[3];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t cur = m.v[1 + (i >> 1)];
+    const int Y = (int) ((cur >> (by + 16 * (i & 1))) & 0xff);
+    int u = (int) ((cur >> bu) & 0xff), v = (int) ((cur >> bv) & 0xff);
+    if (s.f.chroma_h == CHROMA_H_H2_CS) {
+      if (i & 1) {
+        const uint32_t n = m.v[2 + (i >> 1)];
+        u = (u + (int) ((n >> bu) & 0xff) + 1) >> 1;
+        v = (v + (int) ((n >> bv) & 0xff) + 1) >> 1;
+      }
+    } else if (s.f.chroma_h == CHROMA_H_H2) {
+      const uint32_t n = m.v[(i & 1) ? 2 + (i >> 1) : (i >> 1)];
+      u = (3 * u + (int) ((n >> bu) & 0xff) + 2) >> 2;
+      v = (3 * v + (int) ((n >> bv) & 0xff) + 2) >> 2;
+    }
+    px[i] = apply_color (s.pre, 0xffu | ((uint32_t) Y << 8) | ((uint32_t) u << 16) | ((uint32_t) v << 24));
+  }
+}
+GSTAMD_HD void src_span8_p422 (const SrcImage &, int, int, uint32_t *) {}
+
 // ------------------------------------------------------------------------------------------------
 // wave tiles
 // ------------------------------------------------------------------------------------------------
@@ -180,7 +235,19 @@ template <class SRC>
 GSTAMD_HD void tile_stage_row (const SRC &src, uint32_t *lds, int xa, int x_hi, int y, int lane, int packed)
 {
   for (int x0 = xa + 8 * lane; x0 < x_hi; x0 += 8 * 64) {
-    if (packed && src_span8_ok (src, x0)) {
+    if (src_p4 (src) && x0 + 8 <= x_hi) {
+      uint32_t px[8];
+      src_span8_p4 (src, x0, y, px);
+      uint4 *d = (uint4 *) (lds + (x0 - xa));
+      d[0] = gstamd_make_uint4 (px[0], px[1], px[2], px[3]);
+      d[1] = gstamd_make_uint4 (px[4], px[5], px[6], px[7]);
+    } else if (src_p422 (src) && x0 + 8 <= x_hi && src_span8_p422_ok (src, x0, y)) {
+      uint32_t px[8];
+      src_span8_p422 (src, x0, y, px);
+      uint4 *d = (uint4 *) (lds + (x0 - xa));
+      d[0] = gstamd_make_uint4 (px[0], px[1], px[2], px[3]);
+      d[1] = gstamd_make_uint4 (px[4], px[5], px[6], px[7]);
+    } else if (packed && src_span8_ok (src, x0)) {
       uint32_t px[8];
       src_span8 (src, x0, y, px);
       uint4 *d = (uint4 *) (lds + (x0 - xa));

@@ -52,6 +52,11 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_RGB, "RGB", false, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 0, 1, 2}},
   {GSTAMD_VIDEO_FORMAT_BGR, "BGR", false, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 2, 1, 0}},
   // packed 4:4:4 YUV in 3 bytes (video-format.c:461-495 v308, :498-532 IYU2) and VUYA (:6186-6215)
+  /* unpack_RGB16 / _BGR16 / _RGB15 / _BGR15 (video-format.c:1301-1425; format table :8249-8256) */
+  {GSTAMD_VIDEO_FORMAT_RGB16, "RGB16", false, false, 1, UNPACK_RGB16, 0, 0, 0, 0, {6, 11, 5, 0}},
+  {GSTAMD_VIDEO_FORMAT_BGR16, "BGR16", false, false, 1, UNPACK_RGB16, 0, 0, 0, 0, {6, 0, 5, 11}},
+  {GSTAMD_VIDEO_FORMAT_RGB15, "RGB15", false, false, 1, UNPACK_RGB16, 0, 0, 0, 0, {5, 10, 5, 0}},
+  {GSTAMD_VIDEO_FORMAT_BGR15, "BGR15", false, false, 1, UNPACK_RGB16, 0, 0, 0, 0, {5, 0, 5, 10}},
   {GSTAMD_VIDEO_FORMAT_v308, "v308", true, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 0, 1, 2}},
   {GSTAMD_VIDEO_FORMAT_IYU2, "IYU2", true, false, 1, UNPACK_PACKED3, 0, 0, 0, 0, {0, 1, 0, 2}},
   {GSTAMD_VIDEO_FORMAT_VUYA, "VUYA", true, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {3, 2, 1, 0}},
@@ -226,6 +231,10 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->stride[0] = round_up (width * 3, 4);
       info->size = (uint64_t) info->stride[0] * h;
       break;
+    case GSTAMD_VIDEO_FORMAT_RGB16:
+    case GSTAMD_VIDEO_FORMAT_BGR16:
+    case GSTAMD_VIDEO_FORMAT_RGB15:
+    case GSTAMD_VIDEO_FORMAT_BGR15:             /* video-info.c:911-918 */
     case GSTAMD_VIDEO_FORMAT_GRAY16_LE:
     case GSTAMD_VIDEO_FORMAT_GRAY16_BE:         /* video-info.c:947-952 */
       info->stride[0] = round_up (width * 2, 4);
@@ -1455,6 +1464,7 @@ constexpr uint64_t F_RGB3 = fbit (GSTAMD_VIDEO_FORMAT_RGB) | fbit (GSTAMD_VIDEO_
 constexpr uint64_t F_YUV3 = fbit (GSTAMD_VIDEO_FORMAT_v308) | fbit (GSTAMD_VIDEO_FORMAT_IYU2);
 constexpr uint64_t F_GRAY8 = fbit (GSTAMD_VIDEO_FORMAT_GRAY8);
 constexpr uint64_t F_NV12 = fbit (GSTAMD_VIDEO_FORMAT_NV12), F_NV16 = fbit (GSTAMD_VIDEO_FORMAT_NV16), F_NV24 = fbit (GSTAMD_VIDEO_FORMAT_NV24);
+constexpr uint64_t F_RGB16S = fbit (GSTAMD_VIDEO_FORMAT_RGB16) | fbit (GSTAMD_VIDEO_FORMAT_BGR16) | fbit (GSTAMD_VIDEO_FORMAT_RGB15) | fbit (GSTAMD_VIDEO_FORMAT_BGR15);
 struct FastRow {
   uint64_t in, out;     /* format sets; `same` rows need in == out on top */
   bool same;
@@ -1462,7 +1472,7 @@ struct FastRow {
   const char *name;
 };
 const FastRow g_fast_rows[] = {
-  {F_420, F_RGB4X | F_RGB4A | F_RGB3, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_I420_xRGB"},
+  {F_420, F_RGB4X | F_RGB4A | F_RGB3 | F_RGB16S, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_I420_xRGB"},       /* (... _pack_ARGB into RGB15 / 16: :8797-8800, 8809-8812) */
   {F_AYUV, F_RGB4X, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_AYUV_xRGB"},
   {F_AYUV, F_RGB4A, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY, "convert_AYUV_xRGB"},
   {F_420, F_AYUV, false, FP_SIZE | FP_ASET, "convert_I420_AYUV"},
@@ -1497,6 +1507,8 @@ const FastRow g_fast_rows[] = {
   {F_420 | F_Y42B | F_Y444, F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_GRAY8, F_420 | F_Y42B | F_Y444 | F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_NV12 | F_NV16 | F_NV24, F_NV12 | F_NV16 | F_NV24, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  /* RGB15 / RGB16 / BGR15 / BGR16 onto themselves (:8879-8886; setup_scale serves them with nearest only, :7985-8003) */
+  {F_RGB16S, ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
   /* GRAY16_LE -> GRAY16_LE, GRAY16_BE -> GRAY16_BE (:8901-8904) */
   {fbit (GSTAMD_VIDEO_FORMAT_GRAY16_LE) | fbit (GSTAMD_VIDEO_FORMAT_GRAY16_BE), ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
 };
@@ -1569,7 +1581,7 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
     pp.ih = up (in.height, isub_h);
     pp.ow = up (out.width, osub_w);
     pp.oh = up (out.height, osub_h);
-    if (fo->kind == UNPACK_GRAY16) {
+    if (fo->kind == UNPACK_GRAY16 || fo->kind == UNPACK_RGB16) {
       pp.n_elems = 2;          /* copies and nearest passes only (plan_core): a 16-bit sample moves as two bytes */
     } else if (fo->kind == UNPACK_PACKED3) {
       pp.n_elems = 3;          /* get_functions (video-scaler.c:1222): RGB / BGR are 3 x u8 pixels */
@@ -1761,7 +1773,7 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
     return (uint64_t) w * h * 4;
   if (f->kind == UNPACK_PACKED64)
     return (uint64_t) w * h * 8;
-  if (f->kind == UNPACK_GRAY16)
+  if (f->kind == UNPACK_GRAY16 || f->kind == UNPACK_RGB16)
     return (uint64_t) w * h * 2;
   if (f->kind == UNPACK_P422_16)
     return (uint64_t) ((w + 1) / 2) * 8 * h;
@@ -2526,7 +2538,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     if (cfg.dither_method != GSTAMD_DITHER_NONE && cfg.dither_method != GSTAMD_DITHER_BAYER && plan->rect.out_y != 0)
       return fail (GSTAMD_ERR_UNSUPPORTED, "error-diffusion dither into a destination rectangle below the frame's first line: the reference never clears the "
           "error line there (y == 0 is the frame's line 0), so every frame depends on the one before");
-  } else if (cfg.dither_quantization > 1 && cfg.dither_method != GSTAMD_DITHER_NONE) {
+  } else if ((cfg.dither_quantization > 1 || plan->fout->kind == UNPACK_RGB16) && cfg.dither_method != GSTAMD_DITHER_NONE) {
     /* verterr / floyd-steinberg / sierra-lite (video_dither_ed.h) clear their error line when the FRAME's line 0 comes by (video-dither.c:82,
        124, 192: y == 0, and y counts from the frame's top): with a destination rectangle that starts lower the errors of one frame's last
        line run into the next frame's first - the output would depend on the frames converted before */
@@ -2549,6 +2561,12 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       planar_dither.method = cfg.dither_method;
       planar_dither.shift[0] = 0;
       planar_dither.shift[1] = planar_dither.shift[2] = planar_dither.shift[3] = shift;
+      if (plan->fout->kind == UNPACK_RGB16) {
+        /* components of 5 / 6 bits on 8-bit lines: their own quantiser 1 << (8 - depth) (:2070-2078) where the target is not coarser */
+        const int nat_g = 8 - plan->fout->pos[0];
+        planar_dither.shift[1] = planar_dither.shift[3] = std::max (shift, 3);
+        planar_dither.shift[2] = std::max (shift, nat_g);
+      }
     } else {
       plan->dither.on = 1;
       plan->dither.y0 = plan->rect.out_y;
@@ -2619,6 +2637,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     if (!fp)
       return plan_gamma (in, out, plan, alpha_bits, same_primaries, prim_dm, error);
   }
+  if (fp && plan->fin->kind == UNPACK_RGB16 && plan->fin == plan->fout && cfg.resampler_method != GSTAMD_RESAMPLER_METHOD_NEAREST)
+    fp = nullptr;               /* setup_scale: "only with nearest resampling", asked before it looks at the sizes - the chain runs (and dithers) even for a copy */
   if (fp && plan->fin->kind == UNPACK_GRAY16 && (in->width != out->width || in->height != out->height) &&
       cfg.resampler_method != GSTAMD_RESAMPLER_METHOD_NEAREST) {
     /* setup_scale (:7985-8003): the plane scaler serves the foreign-endian GRAY16 format with nearest only (the fastpath is dropped and the
@@ -2860,6 +2880,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     for (int i = 0; i < 4; i++)
       post.pack_pos[i] = i;
     pk.dither = planar_dither;
+    if (!plan->ref_fastpath.empty ())
+      memset (&pk.dither, 0, sizeof (pk.dither));          /* no fastpath has a dither stage (they are only looked up at dither-quantization 1, where RGB15 / 16 alone still have one in the chain) */
   }
   if (plane_scale) {                   /* raw bytes in, raw bytes out */
     for (int i = 0; i < 4; i++)

@@ -29,6 +29,8 @@ enum UnpackKind : int {
   UNPACK_PACKED64 = 9,  // one plane, four 16-bit words per pixel in an order of their own (RGBA64_LE / _BE, BGRA64, ABGR64, ARGB64_BE; unpack format
                         // ARGB64): FormatDesc::pos[c] = word of component c (A, R, G, B); hi_depth code 9 (little endian) / 10 (big endian)
   UNPACK_GRAY16 = 10,   // one plane of 16-bit luma (GRAY16_LE / _BE; unpack format AYUV64, U = V = 0x8000); hi_depth code 9 / 10
+  UNPACK_RGB16 = 11,    // one plane, a little-endian 16-bit word per pixel with 5-6-5 or 5-5-5 bit fields (RGB16, BGR16, RGB15, BGR15; unpack format ARGB,
+                        // 8-bit chain): FormatDesc::pos = {bits of G, first bit of R, of G, of B}
 };
 // one plane of whole pixels whose samples reach the 16-bit chain through deep_front_px and leave it through pack16_packed_body, a lane per pixel
 #define GSTAMD_KIND_PX16(k) ((k) == UNPACK_Y410 || (k) == UNPACK_PACKED64 || (k) == UNPACK_GRAY16)
@@ -70,6 +72,10 @@ inline void format_plan_planes (const FormatDesc *f, GstAmdVideoInfo *info)
 #endif
 // significant bits of a sample for a FormatDesc::hi_depth code, and whether the format keeps its samples in 16-bit words in planes
 GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 ? 10 : (hi == 4 || hi == 5 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 ? 16 : 8)); }
+// video_orc_unpack_RGB16 & co (video-orc.orc: mulhsw by 0x4200 / 0x2080 / 0x0210 = field * 8.25 or * 4.0625, floored): the field's bits replicated
+GSTAMD_VP int rgb16_field (int word, int shift, int bits) { const int f = (word >> shift) & ((1 << bits) - 1); return bits == 6 ? (f << 2) | (f >> 4) : (f << 3) | (f >> 2); }
+// video_orc_pack_RGB16_le & co: the top bits of every component at its field
+GSTAMD_VP int rgb16_pack (const int *pos, int r, int g, int b) { return ((r >> 3) << pos[1]) | ((g >> (8 - pos[0])) << pos[2]) | ((b >> 3) << pos[3]); }
 // a stored 16-bit word of a UNPACK_PACKED64 / UNPACK_GRAY16 format -> its value (GST_READ_UINT16_LE / _BE; the same function stores)
 GSTAMD_VP int px16_word (int hi, int v) { return hi == 10 ? ((v >> 8) | (v << 8)) & 0xffff : v; }
 GSTAMD_VP bool hi_depth_words (int hi) { return hi == 1 || hi == 2 || (hi >= 4 && hi <= 6); }
@@ -354,7 +360,7 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
     return (size_t) y * stride + (size_t) x * 4;
   if (f->kind == UNPACK_PACKED64)
     return (size_t) y * stride + (size_t) x * 8;
-  if (f->kind == UNPACK_GRAY16)
+  if (f->kind == UNPACK_GRAY16 || f->kind == UNPACK_RGB16)
     return (size_t) y * stride + (size_t) x * 2;
   if (f->kind == UNPACK_V210)            /* rows only: a horizontal offset inside the 6-pixel groups is refused by the planner */
     return (size_t) y * stride;
@@ -406,6 +412,8 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
     *es = 4, *lo = ((y >> 6) << f->pos[1]) | ((u >> 6) << f->pos[2]) | ((v >> 6) << f->pos[3]) | ((a & 0xc000u) << 16);
   } else if (f->kind == UNPACK_GRAY16) {
     *es = 2, *lo = s16 (1);
+  } else if (f->kind == UNPACK_RGB16) {
+    *es = 2, *lo = (uint32_t) rgb16_pack (f->pos, border[1], border[2], border[3]);
   } else if ((f->kind == UNPACK_PACKED4 && f->hi_depth == 3) || f->kind == UNPACK_PACKED64) {
     uint32_t w[4] = {0, 0, 0, 0};
     for (int c = 0; c < 4; c++)

@@ -172,6 +172,11 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
     const uint8_t *q = pl.p[0] + (size_t) y * pl.stride[0] + 3 * (size_t) x;
     return 0xffu | ((uint32_t) q[f.pos[1]] << 8) | ((uint32_t) q[f.pos[2]] << 16) | ((uint32_t) q[f.pos[3]] << 24);
   }
+  if (f.kind == UNPACK_RGB16) {          // unpack_RGB16 / _BGR16 / _RGB15 / _BGR15 (video-format.c:1301-1425)
+    const int wd = *(const uint16_t *) (pl.p[0] + (size_t) y * pl.stride[0] + 2 * (size_t) x);
+    return 0xffu | ((uint32_t) rgb16_field (wd, f.pos[1], 5) << 8) | ((uint32_t) rgb16_field (wd, f.pos[2], f.pos[0]) << 16) |
+        ((uint32_t) rgb16_field (wd, f.pos[3], 5) << 24);
+  }
   if (f.kind == UNPACK_GRAY)             // unpack_GRAY8 (video-format.c:1209, video_orc_unpack_GRAY8): A = 0xff, Y, U = V = 0x80
     return 0x808000ffu | ((uint32_t) pl.p[0][(size_t) y * pl.stride[0] + x] << 8);
   const int yl = y < f.luma_last ? y : f.luma_last;          /* a no-op for the picture's own lines; the line past it clamps like do_unpack_lines */

@@ -57,6 +57,15 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
     }
     return;
   }
+  if (pk.kind == UNPACK_RGB16) {           // pack_RGB16 / _BGR16 / _RGB15 / _BGR15 (video-format.c:1316-1425): the components' top bits in one word
+    uint16_t *q = (uint16_t *) ((d.p[0] + dd) + (size_t) y0 * d.stride[0]) + x0;
+    for (int i = 0; i < 4 && x0 + i < w; i++) {
+      const uint32_t px = src.at (x0 + i, y0);
+      q[i] = (uint16_t) rgb16_pack (pk.pos, pack_dither (pk.dither, 1, (int) ((px >> 8) & 0xff), x0 + i, y0),
+          pack_dither (pk.dither, 2, (int) ((px >> 16) & 0xff), x0 + i, y0), pack_dither (pk.dither, 3, (int) (px >> 24), x0 + i, y0));
+    }
+    return;
+  }
   if (pk.kind == UNPACK_GRAY) {            // pack_GRAY8 (video-format.c:1221): the luma byte of every pixel
     uint8_t *q = (d.p[0] + dd) + (size_t) y0 * d.stride[0] + x0;
     for (int i = 0; i < 4 && x0 + i < w; i++)

@@ -59,7 +59,11 @@ enum {
   GSTAMD_VIDEO_FORMAT_GRAY8 = 25,       /* one plane of luma; unpacks to A = 0xff, Y, U = V = 0x80 (video-format.c:1207-1229) */
   GSTAMD_VIDEO_FORMAT_GRAY16_BE = 26,   /* one plane of 16-bit luma, big / little endian; unpacks to AYUV64 with U = V = 0x8000 */
   GSTAMD_VIDEO_FORMAT_GRAY16_LE = 27,
-  GSTAMD_VIDEO_FORMAT_v308 = 28,        /* packed 4:4:4, 3 bytes per pixel: Y U V */
+  GSTAMD_VIDEO_FORMAT_v308 = 28,
+  GSTAMD_VIDEO_FORMAT_RGB16 = 29,       /* one little-endian 16-bit word per pixel: R 5, G 6, B 5 from the high bits; BGR16 the other way round */
+  GSTAMD_VIDEO_FORMAT_BGR16 = 30,
+  GSTAMD_VIDEO_FORMAT_RGB15 = 31,       /* x 1, R 5, G 5, B 5; BGR15 the other way round */
+  GSTAMD_VIDEO_FORMAT_BGR15 = 32,        /* packed 4:4:4, 3 bytes per pixel: Y U V */
   GSTAMD_VIDEO_FORMAT_IYU2 = 63,        /* the same in the order U Y V */
   GSTAMD_VIDEO_FORMAT_VUYA = 84,        /* packed 4:4:4:4, 4 bytes per pixel: V U Y A */
   GSTAMD_VIDEO_FORMAT_NV21 = 24,

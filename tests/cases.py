@@ -74,7 +74,7 @@ def visible_planes(fmt, w, h):
         return [(8 * up2(w), h)]
     if fmt in ("ARGB64", "AYUV64") or fmt.endswith(("64_LE", "64_BE")):
         return [(8 * w, h)]
-    if fmt in ("GRAY16_LE", "GRAY16_BE"):
+    if fmt in ("GRAY16_LE", "GRAY16_BE", "RGB16", "BGR16", "RGB15", "BGR15"):
         return [(2 * w, h)]
     if fmt == "GRAY8":
         return [(w, h)]
@@ -1049,6 +1049,49 @@ def _round5_format_sweep():
 VIDEO_CASES += _round5_format_sweep()
 
 
+# RGB16 / BGR16 / RGB15 / BGR15 (5-6-5 and 5-5-5 words on the 8-bit chain): the bit-replicating unpackers, the truncating packers, the chain's own
+# dither stage for components of fewer than 8 bits (ordered by default, error diffusion, none, a coarser target), the fastpaths that skip it
+# (convert_I420_pack_ARGB), the same-format plane scaler that only serves nearest
+def _round5_rgb16_sweep():
+    out = []
+    for f in ("RGB16", "BGR16", "RGB15", "BGR15"):
+        n = f.lower()
+        out += [
+            ("r5g_%s_bgra_37x6" % n, f, 37, 6, "BGRA", 37, 6, {}, None, None, "random"),
+            ("r5g_%s_rgb_ramp" % n, f, 128, 4, "RGB", 128, 4, {}, None, None, "ramp"),
+            ("r5g_bgra_%s_bayer" % n, "BGRA", 40, 21, f, 40, 21, {}, None, None, "random"),
+            ("r5g_bgra_%s_no_dither" % n, "BGRA", 40, 5, f, 40, 5, dict(dither_method="none"), None, None, "random"),
+            ("r5g_bgra_%s_q16" % n, "BGRA", 40, 5, f, 40, 5, dict(dither_quantization=16), None, None, "random"),
+            ("r5g_bgra_%s_q4_between_the_native_quantisers" % n, "BGRA", 40, 5, f, 40, 5, dict(dither_quantization=4), None, None, "random"),
+            ("r5g_bgra_%s_sierra" % n, "BGRA", 35, 19, f, 35, 19, dict(dither_method="sierra-lite"), None, None, "random"),
+            ("r5g_bgra_%s_floyd_q16" % n, "BGRA", 35, 19, f, 35, 19, dict(dither_method="floyd-steinberg", dither_quantization=16), None, None, "random"),
+            ("r5g_i420_%s_fastpath_no_dither" % n, "I420", 40, 6, f, 40, 6, {}, None, None, "random"),
+            ("r5g_yv12_%s_fastpath_odd" % n, "YV12", 41, 7, f, 41, 7, {}, None, None, "random"),
+            ("r5g_nv12_%s_chain" % n, "NV12", 40, 6, f, 40, 6, {}, None, None, "random"),
+            ("r5g_%s_nv12" % n, f, 40, 6, "NV12", 40, 6, {}, None, None, "random"),
+            ("r5g_nv12_%s_up_bilinear" % n, "NV12", 64, 36, f, 100, 50, LIN, None, None, "random"),
+            ("r5g_%s_i420_down_lanczos" % n, f, 64, 36, "I420", 32, 20, LAN, None, None, "random"),
+            ("r5g_%s_self_dithers" % n, f, 64, 36, f, 64, 36, {}, None, None, "random"),
+            ("r5g_%s_self_nearest_copy" % n, f, 64, 36, f, 64, 36, NEAR, None, None, "random"),
+            ("r5g_%s_self_nearest_down" % n, f, 64, 36, f, 32, 20, NEAR, None, None, "random"),
+            ("r5g_%s_self_bilinear_down" % n, f, 64, 36, f, 32, 20, LIN, None, None, "random"),
+            ("r5g_%s_self_nearest_crop_border" % n, f, 48, 30, f, 60, 40, dict(NEAR, src_x=5, src_y=3, src_width=30, src_height=20, dest_x=7, dest_y=9, dest_width=21, dest_height=11, border_argb=0x40e0a060), None, None, "random"),
+            ("r5g_%s_p010" % n, f, 30, 20, "P010_10LE", 30, 20, {}, None, None, "random"),
+            ("r5g_p010_%s" % n, "P010_10LE", 30, 20, f, 30, 20, {}, None, None, "random"),
+            ("r5g_argb64_%s" % n, "ARGB64", 30, 20, f, 30, 20, {}, None, None, "random"),
+            ("r5g_bgra_%s_dest_border" % n, "BGRA", 30, 20, f, 50, 30, dict(dest_x=7, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+            ("r5g_%s_bgrx_crop_border_lanczos" % n, f, 48, 30, "BGRx", 60, 40, dict(LAN, src_x=5, src_y=3, src_width=30, src_height=20, dest_x=7, dest_y=9, dest_width=20, dest_height=10, border_argb=0x40e0a060), None, None, "random"),
+            ("r5g_%s_bgra_gamma_remap" % n, f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"),
+            ("r5g_i420_%s_gamma_remap" % n, "I420", 40, 8, f, 40, 8, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"),
+        ]
+    out += [("r5g_rgb16_bgr15", "RGB16", 30, 20, "BGR15", 30, 20, {}, None, None, "random"),
+            ("r5g_nv12_rgb16_1080_strip", "NV12", 1920, 16, "RGB16", 1920, 16, {}, None, None, "random")]
+    return out
+
+
+VIDEO_CASES += _round5_rgb16_sweep()
+
+
 # fill-border = FALSE over the same plans: compared on the bytes the picture decides (scripts/fuzz_video.py matches_reference)
 DEEP_NOFILL = [(fi, w, 11, fo, w + 13, 27, dict(dest_x=4, dest_y=5, dest_width=w, dest_height=11, fill_border=0, **({"dither_quantization": dq} if dq > 1 else {})))
                for fi in ("Y444_10LE", "Y444_12LE", "Y444_16LE") for fo in ("Y444_10LE", "Y444_12LE", "Y444_16LE") for w in (1, 2, 17) for dq in (1, 2)]
@@ -1163,6 +1206,10 @@ def default_layout(fmt, w, h):
         return [r4(2 * w)], [0]
     if fmt in ("RGB", "BGR"):
         return [r4(3 * w)], [0]
+    if fmt in ("GRAY16_LE", "GRAY16_BE", "RGB16", "BGR16", "RGB15", "BGR15"):
+        return [r4(2 * w)], [0]
+    if fmt in ("ARGB64", "AYUV64") or fmt.endswith(("64_LE", "64_BE")):
+        return [8 * w], [0]
     return [4 * w], [0]
 
 

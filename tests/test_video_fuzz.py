@@ -113,6 +113,8 @@ def test_share_of_defined_and_refused_draws_stays_bounded(emu_lib, ref, seed, re
         verdict, _ = fuzz_video.run_case(emu, ref, fuzz_video.random_case(rnd, rr), seed * 1000 + it)
         count[verdict] += 1
     assert count["bad"] == 0, count
-    assert count["defined"] <= 0.13 * 1500, count
+    # (round 5: 16 more formats, 12 of them members of the 16-bit chain - draws that change the bit depth behind a horizontal scaler, the largest
+    # announced class (the reference converts MIN (in_width, out_width) pixels of such lines), went from 9.5-12 % to 12.3-13.7 % of all draws)
+    assert count["defined"] <= 0.16 * 1500, count
     assert count["refused"] <= 0.05 * 1500, count
     assert count["ok"] >= 0.78 * 1500, count

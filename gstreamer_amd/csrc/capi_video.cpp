@@ -992,6 +992,27 @@ static int frame_planes_plan_order (GstAmdVideoConverter *c, const void *const s
   const VideoPlan &p = c->plan;
   if (p.gamma.on)
     return convert_gamma (c, src_planes, src_stride, dest_planes, dest_stride, stream);
+  if (p.v210_fast) {
+    V210FastParams vp;
+    memset ((void *) &vp, 0, sizeof (vp));
+    const FormatDesc *f8 = p.fin->kind == UNPACK_V210 ? p.fout : p.fin;
+    vp.to_v210 = p.fout->kind == UNPACK_V210;
+    vp.kind = f8->kind, vp.h_sub = f8->h_sub, vp.u_plane = f8->u_plane, vp.v_plane = f8->v_plane;
+    memcpy (vp.pos, f8->pos, sizeof (vp.pos));
+    vp.width = p.in_info.width, vp.height = p.in_info.height;
+    for (int i = 0; i < p.in_info.n_planes && i < 3; i++) {
+      if (!src_planes[i])
+        return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
+      vp.s[i] = (const uint8_t *) src_planes[i], vp.sstride[i] = src_stride ? src_stride[i] : p.in_info.stride[i];
+    }
+    for (int i = 0; i < p.out_info.n_planes && i < 3; i++) {
+      if (!dest_planes[i])
+        return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+      vp.d[i] = (uint8_t *) dest_planes[i], vp.dstride[i] = dest_stride ? dest_stride[i] : p.out_info.stride[i];
+    }
+    const hipError_t ve = launch_v210_fast (vp, stream);
+    return ve == hipSuccess ? GSTAMD_OK : hip_fail (ve, "k_v210_fast");
+  }
   Planes pl;
   memset (&pl, 0, sizeof (pl));
   for (int i = 0; i < p.in_info.n_planes; i++) {

@@ -1494,6 +1494,9 @@ const FastRow g_fast_rows[] = {
   /* the v210 rows (:8433-8543; convert_I420_v210, convert_v210_I420_10 ...: their own arithmetic - 8-bit samples shifted by two, no widening):
      not built, such pairs are refused at their own size (every one of these rows wants keeps_size and the same colour matrix; crop / border /
      alpha flags are matched generously - refusing a conversion the reference would run through the chain costs nothing but coverage) */
+  /* round 5: the 8-bit ones on whole frames (video_v210_fast.h); with a crop or a rectangle the generous rows below still refuse */
+  {F_420 | F_Y42B | F_YUY2 | F_UYVY, fbit (GSTAMD_VIDEO_FORMAT_v210), false, FP_SIZE, "convert_8bit_v210"},
+  {fbit (GSTAMD_VIDEO_FORMAT_v210), F_420 | F_Y42B | F_YUY2 | F_UYVY, false, FP_SIZE, "convert_v210_8bit"},
   {F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), fbit (GSTAMD_VIDEO_FORMAT_v210), false,
         FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY | FP_ASET | FP_AMULT, "convert_to_v210"},
   {fbit (GSTAMD_VIDEO_FORMAT_v210), F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), false,
@@ -2656,6 +2659,24 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
      * their matrix with video_converter_compute_matrix (:2837-2847) - to RGB, to YUV, nothing between - whatever primaries-mode says */
     same_primaries = true;
     m_identity (prim_dm);
+    if (name == "convert_8bit_v210" || name == "convert_v210_8bit") {
+      plan->v210_fast = true;
+      plan->plane_mode = plan->relayout = plan->fast_pair = plan->fast_enc420 = plan->fast_420p = plan->fast_422 = plan->fast_422_ayuv = plan->fast_post = false;
+      plan->deep16 = plan->deep_out = plan->matrix_before_scale = false;
+      plan->planes.clear ();
+      memset (&plan->front, 0, sizeof (plan->front));
+      memset (&plan->matrix, 0, sizeof (plan->matrix));
+      memset (&plan->post, 0, sizeof (plan->post));
+      memset (&plan->pack, 0, sizeof (plan->pack));
+      memset (&plan->deep, 0, sizeof (plan->deep));
+      memset (&plan->dither, 0, sizeof (plan->dither));
+      plan->ref_fastpath = name == "convert_8bit_v210" ? std::string ("convert_") + plan->fin->name + "_v210" : std::string ("convert_v210_") + plan->fout->name;
+      plan->passes.clear ();
+      plan->vpair.clear ();
+      plan->algorithmic_bytes = picture_bytes (plan->fin, in->width, in->height) + picture_bytes (plan->fout, out->width, out->height);
+      plan->description = std::string ("v210_fast[") + plan->fin->name + "->" + plan->fout->name + "]{as " + plan->ref_fastpath + "}";
+      return GSTAMD_OK;
+    }
     if (name == "convert_I420_xRGB")
       force_nearest = force_ayuv_argb = true;
     else if (name == "convert_AYUV_xRGB")

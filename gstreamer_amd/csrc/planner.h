@@ -330,6 +330,7 @@ struct VideoPlan {
   bool out_planar;            // destination is planar / semi-planar: the chain renders AYUV, pack_planar finishes
   PackPlanarParams pack;
   bool fast_pair;             // BASELINE C2 shape: line-pair kernel of video_fast.h is applicable
+  bool v210_fast = false;     // the reference's own v210 <-> 8-bit 4:2:0 / 4:2:2 fastpaths (video_v210_fast.h); nothing else of the plan is used
   bool relayout;              // the chain changes nothing but where the samples sit (I420 <-> NV12 <-> NV21 <-> YV12, Y42B <-> NV16, Y444 <-> NV24): video_relayout.h
   bool fast_enc420;           // unscaled 4-byte RGB -> 4:2:0 YUV through the table matrix: the block kernel of video_encode_fast.h applies
   bool fast_420p;             // unscaled planar 4:2:0 -> 4-byte RGB with nearest chroma (the reference's convert_I420_BGRA family): video_422_fast.h

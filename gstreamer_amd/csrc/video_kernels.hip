@@ -1028,6 +1028,23 @@ __global__ __launch_bounds__ (256) void k_plane_vscale (SrcPlane s, ScaleDev sd,
   plane_vscale_body (s, sd, d, width, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
 }
 
+// the reference's v210 fastpaths (video_v210_fast.h): a lane per group of six pixels of a line / line pair; frame lists in blockIdx.z
+__global__ __launch_bounds__ (256) void k_v210_fast (V210FastParams p, FrameDeltas fl)
+{
+  GSTAMD_FRAME_Z;
+  for (int i = 0; i < 3; i++)
+    p.s[i] = p.s[i] ? p.s[i] + fls_ : nullptr, p.d[i] = p.d[i] ? p.d[i] + fld_ : nullptr;
+  v210_fast_body (p, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+hipError_t launch_v210_fast (const V210FastParams &p, hipStream_t stream)
+{
+  int nz;
+  const FrameDeltas &fl = frame_list_for (p.s[0], p.d[0], &nz);
+  hipLaunchKernelGGL (k_v210_fast, dim3 ((v210_fast_groups (p) + 255) / 256, v210_fast_rows (p), nz), dim3 (256), 0, stream, p, fl);
+  return hipGetLastError ();
+}
+
 // 3- / 4-byte pixel permutations (video_swizzle34.h)
 template <int SB, int DB>
 __global__ __launch_bounds__ (256) void k_swizzle34 (Swz34Params p, FrameDeltas fl)

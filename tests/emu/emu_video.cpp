@@ -31,6 +31,7 @@
 #include "../../gstreamer_amd/csrc/video_dither_ed.h"
 #include "../../gstreamer_amd/csrc/video_relayout.h"
 #include "../../gstreamer_amd/csrc/video_swizzle34.h"
+#include "../../gstreamer_amd/csrc/video_v210_fast.h"
 
 using namespace gstamd;
 
@@ -865,6 +866,23 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   format_plan_planes (p.fin, &in_planes);
   format_plan_planes (p.fout, &out_planes);
   in = &in_planes, out = &out_planes;
+  if (p.v210_fast) {            /* k_v210_fast */
+    V210FastParams vp;
+    memset ((void *) &vp, 0, sizeof (vp));
+    const FormatDesc *f8 = p.fin->kind == UNPACK_V210 ? p.fout : p.fin;
+    vp.to_v210 = p.fout->kind == UNPACK_V210;
+    vp.kind = f8->kind, vp.h_sub = f8->h_sub, vp.u_plane = f8->u_plane, vp.v_plane = f8->v_plane;
+    memcpy (vp.pos, f8->pos, sizeof (vp.pos));
+    vp.width = in->width, vp.height = in->height;
+    for (int i = 0; i < in->n_planes && i < 3; i++)
+      vp.s[i] = src + in->offset[i], vp.sstride[i] = in->stride[i];
+    for (int i = 0; i < out->n_planes && i < 3; i++)
+      vp.d[i] = dst + out->offset[i], vp.dstride[i] = out->stride[i];
+    for (int r0 = 0; r0 < v210_fast_rows (vp); r0++)
+      for (int g0 = 0; g0 < (v210_fast_groups (vp) + 255) / 256 * 256; g0++)
+        v210_fast_body (vp, g0, r0);
+    return GSTAMD_OK;
+  }
   if (p.gamma.on) {
     /* convert_gamma of capi_video.cpp: sub-conversion / 16-bit front, the stage kernels' bodies over their grids, the u16 scalers,
        encode + sub-conversion or the 16-bit packer */

@@ -269,14 +269,14 @@ static FastParams make_fast_params (const VideoPlan &p, bool rgb24 = false)
 }
 
 // rectangle complement of every destination plane <- the border pixel (convert_fill_border :7190-7290)
-static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[3], const int strides[3], hipStream_t stream)
+static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[4], const int strides[4], hipStream_t stream)
 {
   const FormatDesc *f = p.fout;
   const RectPlan &rc = p.rect;
   const int w = p.out_info.width, h = p.out_info.height;
   auto up = [](int v, int sub) { return -((-v) >> sub); };
   hipError_t e = hipSuccess;
-  const int n_planes = kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
+  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
   for (int i = 0; i < n_planes && e == hipSuccess; i++) {
     int es;
     uint32_t lo, hi;
@@ -287,7 +287,8 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[3], co
     if (nv61_fastpath)
       lo = (lo >> 8) | ((lo & 0xffu) << 8);
     const bool pairs = f->kind == UNPACK_PACKED422 || f->kind == UNPACK_P422_16;          /* the plane's unit is the macropixel */
-    const int ws = i || pairs ? f->w_sub : 0, hs = i ? f->h_sub : 0;
+    const bool full = i == 0 || (f->kind == UNPACK_PLANAR_A && i == 3);      /* a plane of one sample per pixel */
+    const int ws = !full || pairs ? f->w_sub : 0, hs = !full ? f->h_sub : 0;
     const int mw = up (rc.out_maxw, ws), mh = up (rc.out_maxh, hs);
     e = launch_fill_border (planes[i], strides[i], es, lo, hi, mw, mh, rc.out_x >> ws, rc.out_y >> hs, border_picture_positions (f, rc, w, ws), up (h, hs), stream);
     if (e == hipSuccess && i == 1 && f->format == GSTAMD_VIDEO_FORMAT_NV61 && (rc.out_maxw & 1) && !nv61_fastpath) {
@@ -1032,7 +1033,7 @@ static int frame_planes_plan_order (GstAmdVideoConverter *c, const void *const s
     dest_rect[i] = (uint8_t *) dest_planes[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, dest_rect_stride[i]);
   }
   if (p.rect.fill) {
-    uint8_t *bp[3] = {(uint8_t *) dest_planes[0], (uint8_t *) dest_planes[1], (uint8_t *) dest_planes[2]};
+    uint8_t *bp[4] = {(uint8_t *) dest_planes[0], (uint8_t *) dest_planes[1], (uint8_t *) dest_planes[2], (uint8_t *) dest_planes[3]};
     hipError_t be = fill_borders (p, bp, dest_rect_stride, stream);
     if (be != hipSuccess)
       return hip_fail (be, "k_fill_border");
@@ -1190,14 +1191,15 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
     color.matrix = p.matrix;
     color.alpha_kind = p.post.alpha_kind;
     color.alpha_value = p.post.alpha_value;
-    if (p.passes.empty () && !p.deep16 && !c->hook_on && !diffusion_first && p.post.pack_pos[0] == 0 && p.post.pack_pos[1] == 1 &&
+    const bool alpha_plane = p.fout->kind == UNPACK_PLANAR_A;      /* A420: the image path below, then the fourth plane from the image */
+    if (!alpha_plane && p.passes.empty () && !p.deep16 && !c->hook_on && !diffusion_first && p.post.pack_pos[0] == 0 && p.post.pack_pos[1] == 1 &&
         p.post.pack_pos[2] == 2 && p.post.pack_pos[3] == 3 && convert_pack_usable (p.front, pl, color) && !tuning_on ("GSTAMD_NO_CONVERT_PACK")) {
       /* an unscaled 8-bit chain with a cheap pixel source: the packer takes its pixels from the chain itself, nothing goes through HBM
          in between */
       hipError_t ce = launch_convert_pack (p.pack, p.front, pl, c->vpair_dev, color, planes, strides, stream);
       return ce == hipSuccess ? GSTAMD_OK : hip_fail (ce, "k_convert_pack");
     }
-    if (c->raw4_pack && pl.p[0] && !c->hook_on && !tuning_on ("GSTAMD_NO_PLANE_QUAD")) {
+    if (c->raw4_pack && !alpha_plane && pl.p[0] && !c->hook_on && !tuning_on ("GSTAMD_NO_PLANE_QUAD")) {
       /* plane_raw4_pack_plan: the scaler on the raw 4-byte pixels into the image, then the unscaled block kernels from it */
       const int ow = p.out_info.width, oh = p.out_info.height;
       PlaneJobs jobs;
@@ -1243,6 +1245,14 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
     const bool diffusion = p.pack.dither.on && p.pack.dither.method != GSTAMD_DITHER_NONE && p.pack.dither.method != GSTAMD_DITHER_BAYER;
     hipError_t e = diffusion ? launch_pack_planar_ed (p.pack, c->pk_img, p.out_info.width * 4, planes, strides, stream, c->ed_carry)
         : launch_pack_planar (p.pack, c->pk_img, p.out_info.width * 4, planes, strides, stream);
+    if (e == hipSuccess && alpha_plane) {
+      if (!dest_planes[3])
+        return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+      PackPlanarParams pa = p.pack;
+      if (diffusion)
+        memset (&pa.dither, 0, sizeof (pa.dither));         /* the error-diffusion pass ran over all four components of the image already */
+      e = launch_pack_alpha_plane (pa, c->pk_img, p.out_info.width * 4, (uint8_t *) dest_planes[3], dest_stride ? dest_stride[3] : p.out_info.stride[3], stream);
+    }
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_pack_planar");
   }
   return convert_to_packed (c, pl, (uint8_t *) dest_planes[0], dest_stride ? dest_stride[0] : p.out_info.stride[0], stream);

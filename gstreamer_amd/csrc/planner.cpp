@@ -23,6 +23,7 @@ static const FormatDesc g_formats[] = {
   // format, name, yuv, alpha, planes, kind, w_sub, h_sub, u_plane, v_plane, pos{A,c1,c2,c3}
   {GSTAMD_VIDEO_FORMAT_I420, "I420", true, false, 3, UNPACK_PLANAR, 1, 1, 1, 2, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_YV12, "YV12", true, false, 3, UNPACK_PLANAR, 1, 1, 2, 1, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_A420, "A420", true, true, 4, UNPACK_PLANAR_A, 1, 1, 1, 2, {0, 0, 0, 0}},          /* unpack_A420 / pack_A420 video-format.c:2118-2185 */
   {GSTAMD_VIDEO_FORMAT_Y42B, "Y42B", true, false, 3, UNPACK_PLANAR, 1, 0, 1, 2, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_Y444, "Y444", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}},
   // planar RGB (video-format.c:1119-1147: the Y444 unpack / pack on the R, G, B lines); planes R, G, B inside a plan (format_plan_planes)
@@ -132,6 +133,18 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       uint64_t cr_h = round_up (height, 2) / 2;
       info->offset[2] = info->offset[1] + info->stride[1] * cr_h;
       info->size = info->offset[2] + info->stride[2] * cr_h;
+      break;
+    }
+    case GSTAMD_VIDEO_FORMAT_A420: {            /* video-info.c:1089-1102 */
+      info->stride[0] = round_up (width, 4);
+      info->stride[1] = round_up (round_up (width, 2) / 2, 4);
+      info->stride[2] = info->stride[1];
+      info->stride[3] = info->stride[0];
+      const uint64_t h2 = (uint64_t) round_up (height, 2);
+      info->offset[1] = (uint64_t) info->stride[0] * h2;
+      info->offset[2] = info->offset[1] + (uint64_t) info->stride[1] * (h2 / 2);
+      info->offset[3] = info->offset[2] + (uint64_t) info->stride[2] * (h2 / 2);
+      info->size = info->offset[3] + (uint64_t) info->stride[0] * h2;
       break;
     }
     case GSTAMD_VIDEO_FORMAT_Y42B:
@@ -1464,6 +1477,7 @@ constexpr uint64_t F_RGB3 = fbit (GSTAMD_VIDEO_FORMAT_RGB) | fbit (GSTAMD_VIDEO_
 constexpr uint64_t F_YUV3 = fbit (GSTAMD_VIDEO_FORMAT_v308) | fbit (GSTAMD_VIDEO_FORMAT_IYU2);
 constexpr uint64_t F_GRAY8 = fbit (GSTAMD_VIDEO_FORMAT_GRAY8);
 constexpr uint64_t F_NV12 = fbit (GSTAMD_VIDEO_FORMAT_NV12), F_NV16 = fbit (GSTAMD_VIDEO_FORMAT_NV16), F_NV24 = fbit (GSTAMD_VIDEO_FORMAT_NV24);
+constexpr uint64_t F_A420 = fbit (GSTAMD_VIDEO_FORMAT_A420);
 constexpr uint64_t F_RGB16S = fbit (GSTAMD_VIDEO_FORMAT_RGB16) | fbit (GSTAMD_VIDEO_FORMAT_BGR16) | fbit (GSTAMD_VIDEO_FORMAT_RGB15) | fbit (GSTAMD_VIDEO_FORMAT_BGR15);
 struct FastRow {
   uint64_t in, out;     /* format sets; `same` rows need in == out on top */
@@ -1510,6 +1524,15 @@ const FastRow g_fast_rows[] = {
   {F_420 | F_Y42B | F_Y444, F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_GRAY8, F_420 | F_Y42B | F_Y444 | F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_NV12 | F_NV16 | F_NV24, F_NV12 | F_NV16 | F_NV24, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  /* the A420 rows (:8560-8700, 8820-8842): into 4-byte RGB with the alpha plane copied (convert_A420_pack_ARGB / _BGRA: ABGR, RGBA, BGRA only), into the
+     alpha-less RGB formats through the I420 functions (BGRx, xBGR, RGBx, RGB, BGR, RGB15, BGR16 - not xRGB, ARGB, RGB16, BGR15), the plane scaler */
+  {F_A420, fbit (GSTAMD_VIDEO_FORMAT_ABGR) | fbit (GSTAMD_VIDEO_FORMAT_RGBA) | fbit (GSTAMD_VIDEO_FORMAT_BGRA), false,
+        FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY, "convert_I420_xRGB"},
+  {F_A420, fbit (GSTAMD_VIDEO_FORMAT_BGRx) | fbit (GSTAMD_VIDEO_FORMAT_xBGR) | fbit (GSTAMD_VIDEO_FORMAT_RGBx) | F_RGB3 | fbit (GSTAMD_VIDEO_FORMAT_RGB15) |
+        fbit (GSTAMD_VIDEO_FORMAT_BGR16), false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_I420_xRGB(opaque)"},
+  {F_420 | F_Y42B | F_Y444 | F_GRAY8, F_A420, false, FP_CROP | FP_BORDER | FP_ASET, "convert_scale_planes"},
+  {F_A420, F_420 | F_Y42B | F_Y444 | F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {F_A420, F_A420, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
   /* RGB15 / RGB16 / BGR15 / BGR16 onto themselves (:8879-8886; setup_scale serves them with nearest only, :7985-8003) */
   {F_RGB16S, ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
   /* GRAY16_LE -> GRAY16_LE, GRAY16_BE -> GRAY16_BE (:8901-8904) */
@@ -1565,6 +1588,13 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
     bool fill = false;
     if (i == 0) {
       pp.src_plane = 0;
+    } else if (fo->kind == UNPACK_PLANAR_A && i == 3) {
+      /* A420's alpha plane: the source's when it has one, else convert_plane_fill - with 0x80, not the alpha value: setup_scale's
+         `if (i == 3) ffill = alpha_value; if (i == 0) ffill = 0; else ffill = 0x80;` lacks an else (:8141-8147) */
+      pp.src_plane = 3;
+      fill = fi->kind != UNPACK_PLANAR_A;
+      if (fill)
+        pp.src_plane = 0;
     } else if (fi->kind == UNPACK_GRAY) {
       /* the source has no such component (setup_scale :8108-8149): convert_plane_fill with 0x80 */
       fill = true;
@@ -1783,7 +1813,7 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
   if (f->kind == UNPACK_V210)
     return (uint64_t) ((w + 5) / 6) * 16 * h;
   const uint64_t cw = ((uint64_t) w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) h + (1 << f->h_sub) - 1) >> f->h_sub;
-  const uint64_t n = (uint64_t) w * h + 2 * cw * ch;
+  const uint64_t n = (uint64_t) w * h + 2 * cw * ch + (f->kind == UNPACK_PLANAR_A ? (uint64_t) w * h : 0);
   return f->hi_depth ? 2 * n : n;
 }
 
@@ -2466,7 +2496,12 @@ static int finalize_deep_to_planar (const GstAmdVideoInfo *in, const GstAmdVideo
   sub.matrix_mode = GSTAMD_MATRIX_MODE_NONE;
   sub.internal_flags = 1;
   sub.src_x = sub.src_y = sub.src_width = sub.src_height = 0;
-  g.alpha_kind = ALPHA_NONE;                            /* the destination has no alpha channel (planar / 3-byte formats) */
+  g.alpha_kind = ALPHA_NONE;                            /* the destination has no alpha channel (planar / 3-byte formats) - or it is A420: */
+  /* the alpha stage is the sub-conversion's then, which sees an AYUV / ARGB image where the real source may have no alpha: what
+     convert_get_alpha_mode decided for the real pair is handed on as the mode that decides the same on the image */
+  sub.alpha_mode = alpha_bits == 2 ? GSTAMD_ALPHA_MODE_SET : alpha_bits == 4 ? GSTAMD_ALPHA_MODE_MULT : GSTAMD_ALPHA_MODE_COPY;
+  if (alpha_bits == 0 || alpha_bits == 1)
+    sub.alpha_value = 1.0;
   const int full_in_w = plan->rect.in_maxw ? plan->rect.in_maxw : in_w, full_in_h = plan->rect.in_maxh ? plan->rect.in_maxh : in_h;
   const int full_out_w = plan->rect.out_maxw ? plan->rect.out_maxw : out_w, full_out_h = plan->rect.out_maxh ? plan->rect.out_maxh : out_h;
   const bool differs = fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub || in->chroma_site != out->chroma_site || full_in_w != full_out_w ||
@@ -2562,7 +2597,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       planar_dither.on = 1;
       planar_dither.y0 = plan->rect.out_y;
       planar_dither.method = cfg.dither_method;
-      planar_dither.shift[0] = 0;
+      planar_dither.shift[0] = plan->fout->kind == UNPACK_PLANAR_A ? shift : 0;          /* A420's alpha plane is a component of depth 8 like the others */
       planar_dither.shift[1] = planar_dither.shift[2] = planar_dither.shift[3] = shift;
       if (plan->fout->kind == UNPACK_RGB16) {
         /* components of 5 / 6 bits on 8-bit lines: their own quantiser 1 << (8 - depth) (:2070-2078) where the target is not coarser */
@@ -2627,7 +2662,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    *  - convert_scale_planes on a one-plane 4-byte format (setup_scale :7958-8075, convert_plane_hv :7693): the plane
    *    goes through gst_video_scaler_2d as raw 4 x u8 pixels - no unpack / matrix / alpha / pack - and the order of the
    *    two passes is the 2-D scaler's own rule (video-scaler.c:1542-1545), not chain_scale's. */
-  bool force_nearest = false, force_ayuv_argb = false, plane_scale = false, force_avg_down = false, order_2d = false;
+  bool force_nearest = false, force_ayuv_argb = false, plane_scale = false, force_avg_down = false, order_2d = false, force_opaque = false;
   const char *fp = (cfg.internal_flags & 1) ? nullptr : lookup_fastpath (*plan, alpha_bits, same_matrix && same_primaries);
   plan->gamma.on = false;
   if (cfg.gamma_mode == GSTAMD_GAMMA_MODE_REMAP) {
@@ -2679,6 +2714,11 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     }
     if (name == "convert_I420_xRGB")
       force_nearest = force_ayuv_argb = true;
+    else if (name == "convert_I420_xRGB(opaque)") {
+      /* video_orc_convert_I420_BGRA & co on A420's first three planes: the destination's fourth byte is 0xff, whatever the alpha plane holds */
+      force_nearest = force_ayuv_argb = force_opaque = true;
+      fp = "convert_I420_xRGB";
+    }
     else if (name == "convert_AYUV_xRGB")
       force_ayuv_argb = true;
     else if (name == "convert_I420_AYUV" || name == "convert_Y42B_AYUV" || name == "convert_Y444_AYUV" || name == "convert_YUY2_AYUV" ||
@@ -2703,7 +2743,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     } else if (name == "convert_scale_planes" && ki == UNPACK_PACKED4)
       plane_scale = true;
     else if (name == "convert_scale_planes" && (ki == ko || (kind_has_planes (ki) && kind_has_planes (ko)) || (ki == UNPACK_GRAY && ko == UNPACK_PLANAR) ||
-            (ki == UNPACK_PLANAR && ko == UNPACK_GRAY)))
+            (ki == UNPACK_PLANAR && ko == UNPACK_GRAY) || ki == UNPACK_PLANAR_A || ko == UNPACK_PLANAR_A))
       return plan_planes (plan, fp);
     else
       return fail (GSTAMD_ERR_UNSUPPORTED, std::string ("reference takes fastpath ") + fp +
@@ -2869,6 +2909,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   post.matrix = plan->matrix;
   post.alpha_kind = alpha_bits == 2 ? ALPHA_SET : alpha_bits == 4 ? ALPHA_MULT : ALPHA_NONE;
   post.alpha_value = (int) (255 * cfg.alpha_value);
+  if (force_opaque)
+    post.alpha_kind = ALPHA_SET, post.alpha_value = 255;
   memcpy (post.pack_pos, plan->fout->pos, sizeof (post.pack_pos));
   memset (&plan->pack, 0, sizeof (plan->pack));
   if (plan->out_planar) {

@@ -29,6 +29,7 @@ enum UnpackKind : int {
   UNPACK_PACKED64 = 9,  // one plane, four 16-bit words per pixel in an order of their own (RGBA64_LE / _BE, BGRA64, ABGR64, ARGB64_BE; unpack format
                         // ARGB64): FormatDesc::pos[c] = word of component c (A, R, G, B); hi_depth code 9 (little endian) / 10 (big endian)
   UNPACK_GRAY16 = 10,   // one plane of 16-bit luma (GRAY16_LE / _BE; unpack format AYUV64, U = V = 0x8000); hi_depth code 9 / 10
+  UNPACK_PLANAR_A = 12, // I420's planes plus a full-size alpha plane (A420: plane 3); generic per-pixel kernels only (kind_has_planes is false for it)
   UNPACK_RGB16 = 11,    // one plane, a little-endian 16-bit word per pixel with 5-6-5 or 5-5-5 bit fields (RGB16, BGR16, RGB15, BGR15; unpack format ARGB,
                         // 8-bit chain): FormatDesc::pos = {bits of G, first bit of R, of G, of B}
 };
@@ -366,7 +367,7 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
   if (f->kind == UNPACK_V210)            /* rows only: a horizontal offset inside the 6-pixel groups is refused by the planner */
     return (size_t) y * stride;
   const size_t bps = f->hi_depth ? 2 : 1;          /* planes of 10 / 12 / 16-bit formats hold 16-bit samples */
-  if (plane == 0)
+  if (plane == 0 || (f->kind == UNPACK_PLANAR_A && plane == 3))
     return (size_t) y * stride + (size_t) x * bps;
   const size_t row = (size_t) (y >> f->h_sub) * stride;
   return f->kind == UNPACK_SEMI ? row + (size_t) (x >> f->w_sub) * 2 * bps : row + (size_t) (x >> f->w_sub) * bps;
@@ -433,7 +434,9 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
     else
       *es = 2, *lo = s16 (plane == f->u_plane ? 2 : 3);
   } else {
-    if (plane == 0)
+    if (f->kind == UNPACK_PLANAR_A && plane == 3)
+      *es = 1, *lo = border[0];
+    else if (plane == 0)
       *es = 1, *lo = border[1];
     else if (f->kind == UNPACK_SEMI)
       *es = 2, *lo = f->u_plane ? (uint32_t) border[2] | ((uint32_t) border[3] << 8) : (uint32_t) border[3] | ((uint32_t) border[2] << 8);

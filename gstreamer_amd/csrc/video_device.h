@@ -202,7 +202,9 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
   } else {
     c = chroma_h_at (f, pl, y >> f.h_sub, x);
   }
-  return 0xffu | ((uint32_t) Y << 8) | ((uint32_t) c.u << 16) | ((uint32_t) c.v << 24);
+  /* unpack_A420 (video-format.c:2118-2146): the alpha plane's sample of the same line (clamped like the luma: do_unpack_lines) */
+  const uint32_t A = f.kind == UNPACK_PLANAR_A ? pl.p[3][(size_t) yl * pl.stride[3] + x] : 0xffu;
+  return A | ((uint32_t) Y << 8) | ((uint32_t) c.u << 16) | ((uint32_t) c.v << 24);
 }
 
 // ------------------------------------------------------------------------------------------------

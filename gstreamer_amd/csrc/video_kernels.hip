@@ -1028,6 +1028,19 @@ __global__ __launch_bounds__ (256) void k_plane_vscale (SrcPlane s, ScaleDev sd,
   plane_vscale_body (s, sd, d, width, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
 }
 
+// A420's alpha plane from the chain's AYUV image (video_pack.h pack_alpha_plane_body)
+__global__ __launch_bounds__ (256) void k_pack_alpha_plane (PackPlanarParams pk, const uint8_t *__restrict__ img, int istride, uint8_t *__restrict__ plane, int stride)
+{
+  pack_alpha_plane_body (pk, img, istride, plane, stride, 4 * (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+hipError_t launch_pack_alpha_plane (const PackPlanarParams &pk, const uint8_t *img, int istride, uint8_t *plane, int stride, hipStream_t stream)
+{
+  video_frame_list_touch (plane);
+  hipLaunchKernelGGL (k_pack_alpha_plane, dim3 (((pk.width + 3) / 4 + 255) / 256, pk.height), dim3 (256), 0, stream, pk, img, istride, plane, stride);
+  return hipGetLastError ();
+}
+
 // the reference's v210 fastpaths (video_v210_fast.h): a lane per group of six pixels of a line / line pair; frame lists in blockIdx.z
 __global__ __launch_bounds__ (256) void k_v210_fast (V210FastParams p, FrameDeltas fl)
 {

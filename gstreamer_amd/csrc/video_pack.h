@@ -140,6 +140,17 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
   }
 }
 
+// the fourth plane of an A420 destination (pack_A420 video-format.c:2148-2185: the alpha byte of every pixel of every line) from the chain's AYUV image:
+// pixels x0 .. x0 + 3 of line y
+GSTAMD_HD void pack_alpha_plane_body (const PackPlanarParams &pk, const uint8_t *img, int istride, uint8_t *da, int dstride, int x0, int y)
+{
+  if (x0 >= pk.width || y >= pk.height)
+    return;
+  const uint32_t *row = (const uint32_t *) (img + (size_t) y * istride);
+  for (int i = 0; i < 4 && x0 + i < pk.width; i++)
+    da[(size_t) y * dstride + x0 + i] = (uint8_t) pack_dither (pk.dither, 0, (int) (row[x0 + i] & 0xffu), x0 + i, y);
+}
+
 // pixel source of k_convert_pack for a packed 4:2:2 frame whose chroma is duplicated sideways and taken line by line (the reference's
 // YUY2 / UYVY -> planar fastpaths, video_orc_convert_YUY2_I420 & co; chroma_h NONE, no vertical pairing), no matrix, no alpha stage: the
 // macropixel word, three byte picks

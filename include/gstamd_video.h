@@ -70,6 +70,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_GBR = 48,         /* planar 8-bit RGB, planes in the order G, B, R */
   GSTAMD_VIDEO_FORMAT_NV16 = 51,
   GSTAMD_VIDEO_FORMAT_NV24 = 52,
+  GSTAMD_VIDEO_FORMAT_A420 = 34,        /* I420 with a fourth, full-size plane of alpha */
   GSTAMD_VIDEO_FORMAT_ARGB64 = 39,      /* 16 bits per component, native endianness (little endian here), memory order A R G B */
   GSTAMD_VIDEO_FORMAT_AYUV64 = 40,      /* the same with A Y U V */
   GSTAMD_VIDEO_FORMAT_I420_10LE = 43,   /* 10 bits in the low bits of little-endian 16-bit words; see DESIGN.md 3.6 / 3.7 for the combinations */

@@ -45,7 +45,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #else
 #define AMD_NEWER_FORMATS ""
 #endif
-#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, GBR, v210" AMD_NEWER_FORMATS " }"
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, GBR, v210" AMD_NEWER_FORMATS " }"
 
 /* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path
  * (video-converter.c:3304, 3383-3463), so interlaced caps are not negotiated rather than converted as if progressive
@@ -808,6 +808,7 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_I420_12LE, GSTAMD_VIDEO_FORMAT_I420_12LE}, {GST_VIDEO_FORMAT_I422_12LE, GSTAMD_VIDEO_FORMAT_I422_12LE},
     {GST_VIDEO_FORMAT_Y444_12LE, GSTAMD_VIDEO_FORMAT_Y444_12LE},
     {GST_VIDEO_FORMAT_GRAY16_LE, GSTAMD_VIDEO_FORMAT_GRAY16_LE}, {GST_VIDEO_FORMAT_GRAY16_BE, GSTAMD_VIDEO_FORMAT_GRAY16_BE},
+    {GST_VIDEO_FORMAT_A420, GSTAMD_VIDEO_FORMAT_A420},
     {GST_VIDEO_FORMAT_RGB16, GSTAMD_VIDEO_FORMAT_RGB16}, {GST_VIDEO_FORMAT_BGR16, GSTAMD_VIDEO_FORMAT_BGR16},
     {GST_VIDEO_FORMAT_RGB15, GSTAMD_VIDEO_FORMAT_RGB15}, {GST_VIDEO_FORMAT_BGR15, GSTAMD_VIDEO_FORMAT_BGR15},
     /* VUYA, Y210, Y410 (1.16), P012_LE, P016_LE, Y444_16LE, Y212_LE (1.18) joined the format enum after 1.14: there when the headers this is compiled

@@ -46,6 +46,8 @@ def visible_planes(fmt, w, h):
     up2 = lambda v: (v + 1) // 2
     if fmt in ("I420", "YV12"):
         return [(w, h), (up2(w), up2(h)), (up2(w), up2(h))]
+    if fmt == "A420":
+        return [(w, h), (up2(w), up2(h)), (up2(w), up2(h)), (w, h)]
     if fmt == "Y42B":
         return [(w, h), (up2(w), h), (up2(w), h)]
     if fmt in ("Y444", "GBR"):
@@ -1091,6 +1093,42 @@ def _round5_rgb16_sweep():
 
 VIDEO_CASES += _round5_rgb16_sweep()
 
+# A420 (I420 plus a full-size alpha plane): the chain on both sides (alpha copied, set, multiplied, dithered), the fastpaths into RGB (alpha plane copied
+# into ABGR / RGBA / BGRA; the I420 functions with an opaque fourth byte for BGRx & co; ARGB / xRGB / RGB16 take the chain), the plane scaler rows (the
+# alpha plane filled with 0x80 whatever alpha-value says - setup_scale's missing else), rectangles and borders on four planes
+def _round5_a420_sweep():
+    out = []
+    for o in ("ABGR", "RGBA", "BGRA", "ARGB", "BGRx", "xBGR", "RGBx", "xRGB", "RGB", "BGR", "RGB15", "BGR16", "RGB16", "AYUV", "I420", "YV12", "Y42B", "Y444",
+              "GRAY8", "A420", "NV12", "P010_10LE", "AYUV64"):
+        out.append(("a420_%s_37x7" % o.lower(), "A420", 37, 7, o, 37, 7, {}, None, None, "random"))
+    for i in ("I420", "YV12", "Y42B", "Y444", "GRAY8", "AYUV", "BGRA", "NV12", "ARGB64", "P010_10LE", "VUYA"):
+        out.append(("%s_a420_40x10" % i.lower(), i, 40, 10, "A420", 40, 10, {}, None, None, "random"))
+    out += [
+        ("a420_bgra_down_bilinear", "A420", 64, 36, "BGRA", 32, 20, LIN, None, None, "random"),
+        ("a420_a420_down_bilinear_planes", "A420", 64, 36, "A420", 32, 20, LIN, None, None, "random"),
+        ("a420_a420_up_lanczos_planes", "A420", 64, 36, "A420", 100, 50, LAN, None, None, "random"),
+        ("a420_i420_down_bilinear_planes", "A420", 64, 36, "I420", 32, 20, LIN, None, None, "random"),
+        ("i420_a420_down_bilinear_planes_alpha_0x80", "I420", 64, 36, "A420", 32, 20, LIN, None, None, "random"),
+        ("bgra_a420_down_lanczos", "BGRA", 64, 36, "A420", 32, 20, LAN, None, None, "random"),
+        ("i420_a420_alpha_set_still_0x80", "I420", 64, 36, "A420", 64, 36, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+        ("ayuv_a420_alpha_mult", "AYUV", 64, 36, "A420", 64, 36, dict(alpha_mode="mult", alpha_value=0.5), None, None, "random"),
+        ("a420_bgra_alpha_mult_chain", "A420", 64, 36, "BGRA", 64, 36, dict(alpha_mode="mult", alpha_value=0.5), None, None, "random"),
+        ("a420_bgra_alpha_set_chain", "A420", 64, 36, "BGRA", 64, 36, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+        ("bgra_a420_bayer_q8", "BGRA", 35, 19, "A420", 35, 19, dict(dither_quantization=8), None, None, "random"),
+        ("bgra_a420_sierra_q8", "BGRA", 35, 19, "A420", 35, 19, dict(dither_method="sierra-lite", dither_quantization=8), None, None, "random"),
+        ("a420_a420_crop_dest_border", "A420", 48, 30, "A420", 60, 40, dict(src_x=4, src_y=2, src_width=30, src_height=20, dest_x=8, dest_y=10, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+        ("bgra_a420_dest_border", "BGRA", 30, 20, "A420", 50, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+        ("i420_a420_dest_border_planes", "I420", 30, 20, "A420", 50, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+        ("a420_bgra_crop_fastpath", "A420", 48, 30, "BGRA", 30, 20, dict(src_x=5, src_y=3, src_width=30, src_height=20), None, None, "random"),
+        ("a420_bgra_gamma_remap", "A420", 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"),
+        ("bgra_a420_gamma_remap", "BGRA", 40, 8, "A420", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"),
+        ("a420_bgra_1080_strip", "A420", 1920, 16, "BGRA", 1920, 16, {}, None, None, "random"),
+    ]
+    return out
+
+
+VIDEO_CASES += _round5_a420_sweep()
+
 # the reference's own v210 fastpaths between v210 and the 8-bit 4:2:0 / 4:2:2 formats (video_v210_fast.h): samples shifted, not widened; group tails
 # (widths 6 k + 1 .. 5), the odd last line of a 4:2:0 frame, one-pixel frames
 VIDEO_CASES += [("v210fast_%s_%s_%dx%d" % (a.lower(), b.lower(), w, h), a, w, h, b, w, h, {}, None, None, "random")
@@ -1198,6 +1236,11 @@ def default_layout(fmt, w, h):
         s0, s1 = r4(w), r4(r2(w) // 2)
         o1 = s0 * r2(h)
         return [s0, s1, s1], [0, o1, o1 + s1 * (r2(h) // 2)]
+    if fmt == "A420":
+        s0, s1 = r4(w), r4(r2(w) // 2)
+        o1 = s0 * r2(h)
+        o2 = o1 + s1 * (r2(h) // 2)
+        return [s0, s1, s1, s0], [0, o1, o2, o2 + s1 * (r2(h) // 2)]
     if fmt == "Y42B":
         s0, s1 = r4(w), (w + 7) // 8 * 8 // 2
         return [s0, s1, s1], [0, s0 * h, s0 * h + s1 * h]

@@ -960,16 +960,16 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *c, const void *co
 {
   if (!c || !src_planes || !dest_planes)
     return set_error (GSTAMD_ERR_INVALID, "NULL converter or frame");
-  const bool in_gbr = c->plan.fin && c->plan.fin->format == GSTAMD_VIDEO_FORMAT_GBR;
-  const bool out_gbr = c->plan.fout && c->plan.fout->format == GSTAMD_VIDEO_FORMAT_GBR;
-  if (!in_gbr && !out_gbr)
+  int perm_i[4], perm_o[4];
+  const bool in_perm = c->plan.fin && format_plane_perm (c->plan.fin->format, perm_i);
+  const bool out_perm = c->plan.fout && format_plane_perm (c->plan.fout->format, perm_o);
+  if (!in_perm && !out_perm)
     return frame_planes_plan_order (c, src_planes, src_stride, dest_planes, dest_stride, stream);
   const void *sp[GSTAMD_VIDEO_MAX_PLANES];
   void *dp[GSTAMD_VIDEO_MAX_PLANES];
   int32_t ss[GSTAMD_VIDEO_MAX_PLANES], ds[GSTAMD_VIDEO_MAX_PLANES];
-  static const int gbr_of_rgb[GSTAMD_VIDEO_MAX_PLANES] = {2, 0, 1, 3};          /* plan plane R, G, B <- frame plane 2, 0, 1 */
   for (int i = 0; i < GSTAMD_VIDEO_MAX_PLANES; i++) {
-    const int si = in_gbr ? gbr_of_rgb[i] : i, di = out_gbr ? gbr_of_rgb[i] : i;
+    const int si = in_perm ? perm_i[i] : i, di = out_perm ? perm_o[i] : i;          /* plan plane i <- frame plane perm[i] */
     sp[i] = src_planes[si];
     dp[i] = dest_planes[di];
     if (src_stride)

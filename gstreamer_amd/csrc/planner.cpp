@@ -28,6 +28,17 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_Y444, "Y444", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}},
   // planar RGB (video-format.c:1119-1147: the Y444 unpack / pack on the R, G, B lines); planes R, G, B inside a plan (format_plan_planes)
   {GSTAMD_VIDEO_FORMAT_GBR, "GBR", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}},
+  /* the rest of the planar RGB family (format_plane_perm says which frame plane is which component): unpack_RGBP / _BGRP video-format.c:7480-7540,
+     unpack_GBRA :1151 (the fourth plane is alpha), unpack_GBR_10LE / _12LE / _16LE :3117, 3370, 3486 (Y444_10LE's arithmetic) */
+  {GSTAMD_VIDEO_FORMAT_RGBP, "RGBP", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_BGRP, "BGRP", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_GBRA, "GBRA", false, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_GBR_10LE, "GBR_10LE", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 1},
+  {GSTAMD_VIDEO_FORMAT_GBR_12LE, "GBR_12LE", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 4},
+  {GSTAMD_VIDEO_FORMAT_GBR_16LE, "GBR_16LE", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 6},
+  /* A422 / A444 (unpack_A422 :4859, unpack_A444 :4588): Y42B / Y444 plus the alpha plane */
+  {GSTAMD_VIDEO_FORMAT_A422, "A422", true, true, 4, UNPACK_PLANAR_A, 1, 0, 1, 2, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_A444, "A444", true, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV12, "NV12", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV21, "NV21", true, false, 2, UNPACK_SEMI, 1, 1, 0, 1, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV16, "NV16", true, false, 2, UNPACK_SEMI, 1, 0, 1, 0, {0, 0, 0, 0}},
@@ -42,6 +53,11 @@ static const FormatDesc g_formats[] = {
   // Y410 stores two bits of alpha but is declared without GST_VIDEO_FORMAT_FLAG_ALPHA (MAKE_YUV_FORMAT :8380): the alpha options pass it by
   {GSTAMD_VIDEO_FORMAT_Y210, "Y210", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 2},
   {GSTAMD_VIDEO_FORMAT_Y212_LE, "Y212_LE", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 5},
+  {GSTAMD_VIDEO_FORMAT_Y216_LE, "Y216_LE", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 6},          /* unpack_Y216_LE video-format.c:7181 */
+  /* unpack_Y412_LE :7323 (12 bits in the high bits, widened by v | v >> 12), unpack_Y416_LE :7430: words U Y V A; like Y410 their alpha word is a
+     component the format flags do not declare (MAKE_YUV_LE_FORMAT :8407, 8495) */
+  {GSTAMD_VIDEO_FORMAT_Y412_LE, "Y412_LE", true, false, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 1, 0, 2}, 11},
+  {GSTAMD_VIDEO_FORMAT_Y416_LE, "Y416_LE", true, false, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 1, 0, 2}, 9},
   {GSTAMD_VIDEO_FORMAT_Y410, "Y410", true, false, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 10, 0, 20}, 7},
   /* unpack_rgb10a2_le / unpack_bgr10a2_le (video-format.c:6210-6330; format table :8384-8388): Y410's word with R, G, B fields, unpack format ARGB64 */
   {GSTAMD_VIDEO_FORMAT_RGB10A2_LE, "RGB10A2_LE", false, true, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 0, 10, 20}, 7},
@@ -69,6 +85,7 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_RGBA, "RGBA", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {3, 0, 1, 2}},
   {GSTAMD_VIDEO_FORMAT_RGBx, "RGBx", false, false, 1, UNPACK_PACKED4, 0, 0, 0, 0, {3, 0, 1, 2}},
   {GSTAMD_VIDEO_FORMAT_ABGR, "ABGR", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 3, 2, 1}},
+  {GSTAMD_VIDEO_FORMAT_RBGA, "RBGA", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {3, 0, 2, 1}},          /* packed R B G A (unpack_RBGA video-format.c:7999) */
   {GSTAMD_VIDEO_FORMAT_xBGR, "xBGR", false, false, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 3, 2, 1}},
   // 10 bits per sample in 16-bit little-endian words (video-format.c:3834-3873, 5329-5400); sources of the 16-bit chain
   {GSTAMD_VIDEO_FORMAT_I420_10LE, "I420_10LE", true, false, 3, UNPACK_PLANAR, 1, 1, 1, 2, {0, 0, 0, 0}, 1},
@@ -155,6 +172,26 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->offset[2] = info->offset[1] + info->stride[1] * h;
       info->size = info->offset[2] + info->stride[2] * h;
       break;
+    case GSTAMD_VIDEO_FORMAT_GBRA:            /* video-info.c:1042-1052 */
+      info->stride[0] = info->stride[1] = info->stride[2] = info->stride[3] = round_up (width, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * h;
+      info->offset[2] = info->offset[1] * 2;
+      info->offset[3] = info->offset[1] * 3;
+      info->size = (uint64_t) info->stride[0] * h * 4;
+      break;
+    case GSTAMD_VIDEO_FORMAT_A422:
+    case GSTAMD_VIDEO_FORMAT_A444: {           /* video-info.c:1103-1128 */
+      const uint64_t h2 = (uint64_t) round_up (height, 2);
+      info->stride[0] = info->stride[3] = round_up (width, 4);
+      info->stride[1] = info->stride[2] = format == GSTAMD_VIDEO_FORMAT_A422 ? round_up (width, 8) / 2 : info->stride[0];
+      info->offset[1] = (uint64_t) info->stride[0] * h2;
+      info->offset[2] = info->offset[1] + (uint64_t) info->stride[1] * h2;
+      info->offset[3] = info->offset[2] + (uint64_t) info->stride[2] * h2;
+      info->size = info->offset[3] + (uint64_t) info->stride[0] * h2;
+      break;
+    }
+    case GSTAMD_VIDEO_FORMAT_RGBP:
+    case GSTAMD_VIDEO_FORMAT_BGRP:
     case GSTAMD_VIDEO_FORMAT_Y444:
     case GSTAMD_VIDEO_FORMAT_GBR:             /* video-info.c:1030-1041 */
       info->stride[0] = info->stride[1] = info->stride[2] = round_up (width, 4);
@@ -189,6 +226,9 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->offset[2] = info->offset[1] + (uint64_t) info->stride[1] * round_up (height, 2);
       info->size = info->offset[2] + (uint64_t) info->stride[2] * round_up (height, 2);
       break;
+    case GSTAMD_VIDEO_FORMAT_GBR_10LE:
+    case GSTAMD_VIDEO_FORMAT_GBR_12LE:
+    case GSTAMD_VIDEO_FORMAT_GBR_16LE:
     case GSTAMD_VIDEO_FORMAT_Y444_12LE:
     case GSTAMD_VIDEO_FORMAT_Y444_16LE:
     case GSTAMD_VIDEO_FORMAT_Y444_10LE:         /* video-info.c:1170-1188 */
@@ -229,6 +269,7 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = (uint64_t) info->stride[0] * h;
       break;
     case GSTAMD_VIDEO_FORMAT_Y210:
+    case GSTAMD_VIDEO_FORMAT_Y216_LE:
     case GSTAMD_VIDEO_FORMAT_Y212_LE:           /* video-info.c:932-941 */
       info->stride[0] = round_up (width * 4, 8);
       info->size = (uint64_t) info->stride[0] * h;
@@ -253,6 +294,8 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->stride[0] = round_up (width * 2, 4);
       info->size = (uint64_t) info->stride[0] * h;
       break;
+    case GSTAMD_VIDEO_FORMAT_Y412_LE:
+    case GSTAMD_VIDEO_FORMAT_Y416_LE:
     case GSTAMD_VIDEO_FORMAT_ARGB64_LE:
     case GSTAMD_VIDEO_FORMAT_ARGB64_BE:
     case GSTAMD_VIDEO_FORMAT_RGBA64_LE:
@@ -1466,21 +1509,23 @@ enum : unsigned {
   FP_ACOPY = 16, FP_ASET = 32, FP_AMULT = 64,
   FP_WEVEN = 128, FP_HEVEN = 256,   /* width_align / height_align == 1 */
 };
-/* one bit per format: the enum value below 64, the two bits no format owns (UNKNOWN, ENCODED) for VYUY (64) and VUYA (84) */
-constexpr uint64_t fbit (int f) { return f < 64 ? 1ull << f : (f == GSTAMD_VIDEO_FORMAT_VYUY ? 1ull : (f == GSTAMD_VIDEO_FORMAT_VUYA ? 2ull : 0ull)); }
-constexpr uint64_t F_I420 = fbit (GSTAMD_VIDEO_FORMAT_I420), F_YV12 = fbit (GSTAMD_VIDEO_FORMAT_YV12), F_420 = F_I420 | F_YV12;
-constexpr uint64_t F_Y42B = fbit (GSTAMD_VIDEO_FORMAT_Y42B), F_Y444 = fbit (GSTAMD_VIDEO_FORMAT_Y444);
-constexpr uint64_t F_AYUV = fbit (GSTAMD_VIDEO_FORMAT_AYUV), F_YUY2 = fbit (GSTAMD_VIDEO_FORMAT_YUY2), F_UYVY = fbit (GSTAMD_VIDEO_FORMAT_UYVY);
-constexpr uint64_t F_RGB4X = fbit (GSTAMD_VIDEO_FORMAT_RGBx) | fbit (GSTAMD_VIDEO_FORMAT_BGRx) | fbit (GSTAMD_VIDEO_FORMAT_xRGB) | fbit (GSTAMD_VIDEO_FORMAT_xBGR);
-constexpr uint64_t F_RGB4A = fbit (GSTAMD_VIDEO_FORMAT_RGBA) | fbit (GSTAMD_VIDEO_FORMAT_BGRA) | fbit (GSTAMD_VIDEO_FORMAT_ARGB) | fbit (GSTAMD_VIDEO_FORMAT_ABGR);
-constexpr uint64_t F_RGB3 = fbit (GSTAMD_VIDEO_FORMAT_RGB) | fbit (GSTAMD_VIDEO_FORMAT_BGR);
-constexpr uint64_t F_YUV3 = fbit (GSTAMD_VIDEO_FORMAT_v308) | fbit (GSTAMD_VIDEO_FORMAT_IYU2);
-constexpr uint64_t F_GRAY8 = fbit (GSTAMD_VIDEO_FORMAT_GRAY8);
-constexpr uint64_t F_NV12 = fbit (GSTAMD_VIDEO_FORMAT_NV12), F_NV16 = fbit (GSTAMD_VIDEO_FORMAT_NV16), F_NV24 = fbit (GSTAMD_VIDEO_FORMAT_NV24);
-constexpr uint64_t F_A420 = fbit (GSTAMD_VIDEO_FORMAT_A420);
-constexpr uint64_t F_RGB16S = fbit (GSTAMD_VIDEO_FORMAT_RGB16) | fbit (GSTAMD_VIDEO_FORMAT_BGR16) | fbit (GSTAMD_VIDEO_FORMAT_RGB15) | fbit (GSTAMD_VIDEO_FORMAT_BGR15);
+/* one bit per format, the enum value (128 bits: every format transforms[] names lies below 128; the later ones - GBR_16LE, RBGA, Y216_LE, Y416_LE -
+   have no rows and no bit) */
+typedef unsigned __int128 fmask;
+constexpr fmask fbit (int f) { return f >= 0 && f < 128 ? (fmask) 1 << f : (fmask) 0; }
+constexpr fmask F_I420 = fbit (GSTAMD_VIDEO_FORMAT_I420), F_YV12 = fbit (GSTAMD_VIDEO_FORMAT_YV12), F_420 = F_I420 | F_YV12;
+constexpr fmask F_Y42B = fbit (GSTAMD_VIDEO_FORMAT_Y42B), F_Y444 = fbit (GSTAMD_VIDEO_FORMAT_Y444);
+constexpr fmask F_AYUV = fbit (GSTAMD_VIDEO_FORMAT_AYUV), F_YUY2 = fbit (GSTAMD_VIDEO_FORMAT_YUY2), F_UYVY = fbit (GSTAMD_VIDEO_FORMAT_UYVY);
+constexpr fmask F_RGB4X = fbit (GSTAMD_VIDEO_FORMAT_RGBx) | fbit (GSTAMD_VIDEO_FORMAT_BGRx) | fbit (GSTAMD_VIDEO_FORMAT_xRGB) | fbit (GSTAMD_VIDEO_FORMAT_xBGR);
+constexpr fmask F_RGB4A = fbit (GSTAMD_VIDEO_FORMAT_RGBA) | fbit (GSTAMD_VIDEO_FORMAT_BGRA) | fbit (GSTAMD_VIDEO_FORMAT_ARGB) | fbit (GSTAMD_VIDEO_FORMAT_ABGR);
+constexpr fmask F_RGB3 = fbit (GSTAMD_VIDEO_FORMAT_RGB) | fbit (GSTAMD_VIDEO_FORMAT_BGR);
+constexpr fmask F_YUV3 = fbit (GSTAMD_VIDEO_FORMAT_v308) | fbit (GSTAMD_VIDEO_FORMAT_IYU2);
+constexpr fmask F_GRAY8 = fbit (GSTAMD_VIDEO_FORMAT_GRAY8);
+constexpr fmask F_NV12 = fbit (GSTAMD_VIDEO_FORMAT_NV12), F_NV16 = fbit (GSTAMD_VIDEO_FORMAT_NV16), F_NV24 = fbit (GSTAMD_VIDEO_FORMAT_NV24);
+constexpr fmask F_A420 = fbit (GSTAMD_VIDEO_FORMAT_A420);
+constexpr fmask F_RGB16S = fbit (GSTAMD_VIDEO_FORMAT_RGB16) | fbit (GSTAMD_VIDEO_FORMAT_BGR16) | fbit (GSTAMD_VIDEO_FORMAT_RGB15) | fbit (GSTAMD_VIDEO_FORMAT_BGR15);
 struct FastRow {
-  uint64_t in, out;     /* format sets; `same` rows need in == out on top */
+  fmask in, out;        /* format sets; `same` rows need in == out on top */
   bool same;
   unsigned flags;
   const char *name;
@@ -1516,9 +1561,9 @@ const FastRow g_fast_rows[] = {
   {fbit (GSTAMD_VIDEO_FORMAT_v210), F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), false,
         FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY | FP_ASET | FP_AMULT, "convert_from_v210"},
   /* convert_scale_planes: every same-format pair, planar <-> planar and the NV12 / NV16 / NV24 family */
-  {F_RGB4A | F_AYUV | fbit (GSTAMD_VIDEO_FORMAT_ARGB64) | fbit (GSTAMD_VIDEO_FORMAT_AYUV64), ~0ull, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
+  {F_RGB4A | F_AYUV | fbit (GSTAMD_VIDEO_FORMAT_ARGB64) | fbit (GSTAMD_VIDEO_FORMAT_AYUV64), ~(fmask) 0, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
   {F_RGB4X | F_RGB3 | F_YUV3 | F_420 | F_Y42B | F_Y444 | fbit (GSTAMD_VIDEO_FORMAT_GBR) | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
-        F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_YVYU), ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
+        F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_YVYU), ~(fmask) 0, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_420 | F_Y42B | F_Y444, F_420 | F_Y42B | F_Y444, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   /* the GRAY8 rows (:8560-8661): the luma plane from / to the planar formats, chroma planes filled with 0x80; GRAY8 -> GRAY8 */
   {F_420 | F_Y42B | F_Y444, F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
@@ -1533,10 +1578,13 @@ const FastRow g_fast_rows[] = {
   {F_420 | F_Y42B | F_Y444 | F_GRAY8, F_A420, false, FP_CROP | FP_BORDER | FP_ASET, "convert_scale_planes"},
   {F_A420, F_420 | F_Y42B | F_Y444 | F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_A420, F_A420, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
+  /* GBRA / RGBP / BGRP onto themselves (:8851-8856; GBR is in the long row above) */
+  {fbit (GSTAMD_VIDEO_FORMAT_RGBP) | fbit (GSTAMD_VIDEO_FORMAT_BGRP), ~(fmask) 0, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {fbit (GSTAMD_VIDEO_FORMAT_GBRA), ~(fmask) 0, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
   /* RGB15 / RGB16 / BGR15 / BGR16 onto themselves (:8879-8886; setup_scale serves them with nearest only, :7985-8003) */
-  {F_RGB16S, ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {F_RGB16S, ~(fmask) 0, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
   /* GRAY16_LE -> GRAY16_LE, GRAY16_BE -> GRAY16_BE (:8901-8904) */
-  {fbit (GSTAMD_VIDEO_FORMAT_GRAY16_LE) | fbit (GSTAMD_VIDEO_FORMAT_GRAY16_BE), ~0ull, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {fbit (GSTAMD_VIDEO_FORMAT_GRAY16_LE) | fbit (GSTAMD_VIDEO_FORMAT_GRAY16_BE), ~(fmask) 0, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
 };
 }  // namespace
 
@@ -1545,7 +1593,7 @@ static const char *lookup_fastpath (const VideoPlan &p, int alpha_mode_bits, boo
   const int in = p.in_info.format, out = p.out_info.format;
   const bool same_size = p.ref_same_size;
   const bool need_copy = alpha_mode_bits & 1, need_set = alpha_mode_bits & 2, need_mult = alpha_mode_bits & 4;
-  if (p.config.dither_quantization != 1 || in >= 64 || out >= 64)
+  if (p.config.dither_quantization != 1)
     return nullptr;
   const RectPlan &rc = p.rect;
   const bool crop = rc.in_x || rc.in_y || p.in_info.width < rc.in_maxw || p.in_info.height < rc.in_maxh;
@@ -1624,7 +1672,11 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
       pp.ow = round_up (out.width * 2, 4);
     }
     /* setup_scale (:8165): resample_method = (i == 0 ? method : cr_method) on the FRAME's plane order - GBR's first plane is G, plane 1 of a plan */
-    const int first_plane = fo->format == GSTAMD_VIDEO_FORMAT_GBR ? 1 : 0;
+    int perm_o[4], first_plane = 0;
+    format_plane_perm (fo->format, perm_o);
+    for (int q = 0; q < 4; q++)
+      if (perm_o[q] == 0)
+        first_plane = q;
     const int rm = i == first_plane ? method : cr_method;
     /* the halve / double shortcuts exist for the planes of multi-plane formats only (setup_scale :8092-8180) */
     if (fill) {
@@ -3001,6 +3053,13 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     }
     long worst = t[0] + std::max (std::max (t[1], t[2]), t[3] + t[4]);
     matrix_no_wrap = fits && worst < 32000;
+    /* ... and the kernels built on it are instantiated for the four byte orders with the colour bytes in sequence (BGRx, RGBx, xRGB, xBGR and
+       their alpha forms - GSTAMD_FOR_LAYOUTS in video_kernels.hip); RBGA goes through the generic kernels */
+    if (plan->fout->kind == UNPACK_PACKED4 && plan->fout->hi_depth == 0) {
+      const int pr = post.pack_pos[1], pg = post.pack_pos[2], pb = post.pack_pos[3];
+      const bool seq = (pr == 2 && pg == 1 && pb == 0) || (pr == 0 && pg == 1 && pb == 2) || (pr == 1 && pg == 2 && pb == 3) || (pr == 3 && pg == 2 && pb == 1);
+      matrix_no_wrap = matrix_no_wrap && seq;
+    }
   }
   plan->fast_pair = plan->passes.empty () && fr.kind == UNPACK_SEMI && fr.chroma_v2 && (in_w % 4) == 0 && in_h >= 2 && matrix_no_wrap;
   /* capture direction (video_422_fast.h): unscaled packed 4:2:2 -> 4-byte RGB, whole 8-pixel groups, no odd-width tail quirk */
@@ -3173,7 +3232,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     rc.in_x = 0;
   /* unpack_RGBA64_LE and its seven siblings advance a guint16 pointer by x * 8 (video-format.c:2483, 2532 ...): 16 bytes per pixel of a horizontal
      crop offset - the picture starts at pixel 2 x (reproduced), and runs into the next row when that is too far right (refused) */
-  if (fi && fi->kind == UNPACK_PACKED64 && rc.in_x != 0) {
+  if (fi && fi->kind == UNPACK_PACKED64 && !fi->yuv && rc.in_x != 0) {         /* (unpack_Y412_LE / _Y416_LE step x * 4: no quirk) */
     if (2 * rc.in_x + ein.width > rc.in_maxw) {
       if (error)
         *error = "the reference's 64-bit unpackers misplace a horizontal source crop (x * 8 on a 16-bit pointer) and read past the row here; not reproduced";

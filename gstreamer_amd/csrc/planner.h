@@ -56,13 +56,33 @@ struct FormatDesc {
 // GBR keeps its planes in the order G, B, R; inside a plan (VideoPlan::in_info / out_info, the copies every launcher takes plane pointers from)
 // they are R, G, B - component order, what the planar 4:4:4 code expects (unpack_GBR is video_orc_unpack_Y444 on the R, G, B lines,
 // video-format.c:1121-1147).  Callers keep the frame's own layout: only the plan's copies are permuted.
+// perm[i]: the FRAME plane that is plane i of a plan (component order R, G, B, A).  false: the frame's own order is the plan's.
+// (the planar RGB family of video-format.c: GBR & its 10 / 12 / 16-bit forms and GBRA keep G, B, R (A); BGRP B, G, R; RGBP R, G, B)
+inline bool format_plane_perm (int format, int perm[4])
+{
+  perm[0] = 0, perm[1] = 1, perm[2] = 2, perm[3] = 3;
+  switch (format) {
+    case GSTAMD_VIDEO_FORMAT_GBR:
+    case GSTAMD_VIDEO_FORMAT_GBRA:
+    case GSTAMD_VIDEO_FORMAT_GBR_10LE:
+    case GSTAMD_VIDEO_FORMAT_GBR_12LE:
+    case GSTAMD_VIDEO_FORMAT_GBR_16LE:
+      perm[0] = 2, perm[1] = 0, perm[2] = 1;
+      return true;
+    case GSTAMD_VIDEO_FORMAT_BGRP:
+      perm[0] = 2, perm[1] = 1, perm[2] = 0;
+      return true;
+    default:
+      return false;
+  }
+}
 inline void format_plan_planes (const FormatDesc *f, GstAmdVideoInfo *info)
 {
-  if (f && f->format == GSTAMD_VIDEO_FORMAT_GBR) {
-    const uint64_t og = info->offset[0], ob = info->offset[1], orr = info->offset[2];
-    const int32_t sg = info->stride[0], sb = info->stride[1], sr = info->stride[2];
-    info->offset[0] = orr, info->offset[1] = og, info->offset[2] = ob;
-    info->stride[0] = sr, info->stride[1] = sg, info->stride[2] = sb;
+  int perm[4];
+  if (f && format_plane_perm (f->format, perm)) {
+    const GstAmdVideoInfo o = *info;
+    for (int i = 0; i < 4; i++)
+      info->offset[i] = o.offset[perm[i]], info->stride[i] = o.stride[perm[i]];
   }
 }
 
@@ -72,13 +92,16 @@ inline void format_plan_planes (const FormatDesc *f, GstAmdVideoInfo *info)
 #define GSTAMD_VP inline
 #endif
 // significant bits of a sample for a FormatDesc::hi_depth code, and whether the format keeps its samples in 16-bit words in planes
-GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 ? 10 : (hi == 4 || hi == 5 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 ? 16 : 8)); }
+GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 ? 10 : (hi == 4 || hi == 5 || hi == 11 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 ? 16 : 8)); }
 // video_orc_unpack_RGB16 & co (video-orc.orc: mulhsw by 0x4200 / 0x2080 / 0x0210 = field * 8.25 or * 4.0625, floored): the field's bits replicated
 GSTAMD_VP int rgb16_field (int word, int shift, int bits) { const int f = (word >> shift) & ((1 << bits) - 1); return bits == 6 ? (f << 2) | (f >> 4) : (f << 3) | (f >> 2); }
 // video_orc_pack_RGB16_le & co: the top bits of every component at its field
 GSTAMD_VP int rgb16_pack (const int *pos, int r, int g, int b) { return ((r >> 3) << pos[1]) | ((g >> (8 - pos[0])) << pos[2]) | ((b >> 3) << pos[3]); }
 // a stored 16-bit word of a UNPACK_PACKED64 / UNPACK_GRAY16 format -> its value (GST_READ_UINT16_LE / _BE; the same function stores)
 GSTAMD_VP int px16_word (int hi, int v) { return hi == 10 ? ((v >> 8) | (v << 8)) & 0xffff : v; }
+// hi_depth code 11 (Y412_LE): 12 bits in the high bits of a little-endian word - read: masked and widened (v | v >> 12), stored: masked
+GSTAMD_VP int px16_load (int hi, int v) { return hi == 11 ? (v & 0xfff0) | ((v & 0xfff0) >> 12) : px16_word (hi, v); }
+GSTAMD_VP int px16_store (int hi, int v) { return hi == 11 ? v & 0xfff0 : px16_word (hi, v); }
 GSTAMD_VP bool hi_depth_words (int hi) { return hi == 1 || hi == 2 || (hi >= 4 && hi <= 6); }
 const FormatDesc *format_desc (int format);
 
@@ -395,8 +418,8 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
   *hi = 0;
   auto s16 = [&](int c) -> uint32_t {
     const uint32_t v = (uint32_t) border[c] * 257u;
-    if (f->hi_depth == 3 || f->hi_depth == 6 || f->hi_depth == 9 || f->hi_depth == 10)
-      return (uint32_t) px16_word (f->hi_depth, (int) v);
+    if (f->hi_depth == 3 || f->hi_depth == 6 || f->hi_depth == 9 || f->hi_depth == 10 || f->hi_depth == 11)
+      return (uint32_t) px16_store (f->hi_depth, (int) v);
     const int drop = 16 - hi_depth_bits (f->hi_depth);
     return f->hi_depth == 1 || f->hi_depth == 4 ? v >> drop : v & ~((1u << drop) - 1u);
   };

@@ -46,8 +46,8 @@ GSTAMD_HD UV deep_load_uv (const FrontParams &f, const Planes &pl, int crow, int
     r.v = y410_field (w, f.pos[3]);
   } else if (f.kind == UNPACK_PACKED64) { // unpack_RGBA64_LE & co (video-format.c:2470-2815): word pos[c] of the pixel, read little / big endian
     const uint16_t *p = (const uint16_t *) (pl.p[0] + (ptrdiff_t) crow * pl.stride[0]) + 4 * k;
-    r.u = px16_word (f.hi_depth, p[f.pos[2]]);
-    r.v = px16_word (f.hi_depth, p[f.pos[3]]);
+    r.u = px16_load (f.hi_depth, p[f.pos[2]]);
+    r.v = px16_load (f.hi_depth, p[f.pos[3]]);
   } else if (f.kind == UNPACK_GRAY16) {
     r.u = r.v = 0x8000;
   } else if (f.kind == UNPACK_V210) {     // unpack_v210 (video-format.c:560-649): chroma pair k of the line, pair k % 3 of group k / 3
@@ -109,8 +109,8 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
     a = t | (t >> 10);
   } else if (f.kind == UNPACK_PACKED64) {
     const uint16_t *p = (const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]) + 4 * x;
-    c1 = px16_word (f.hi_depth, p[f.pos[1]]);
-    a = px16_word (f.hi_depth, p[f.pos[0]]);
+    c1 = px16_load (f.hi_depth, p[f.pos[1]]);
+    a = px16_load (f.hi_depth, p[f.pos[0]]);
   } else if (f.kind == UNPACK_GRAY16) {
     c1 = px16_word (f.hi_depth, ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
   } else if (f.kind == UNPACK_V210) {   // luma j of the group: words 0 1 1 2 3 3 at bit 10 0 20 10 0 20
@@ -1002,16 +1002,16 @@ GSTAMD_HD void pack16_packed_body (const PackPlanarParams &pk, int hi_depth, con
     /* pack_RGBA64_LE & co (video-format.c:2548-2815), pack_GRAY16_LE / _BE (:1250-1299): the components' 16 bits at their words, in the format's
        byte order */
     const uint2 px = row[unit];
-    const int yy = px16_word (hi_depth, dither16_comp (dt, 1, (int) (px.x >> 16), unit, y));
+    const int yy = px16_store (hi_depth, dither16_comp (dt, 1, (int) (px.x >> 16), unit, y));
     if (pk.kind == UNPACK_GRAY16) {
       ((uint16_t *) (dst + (size_t) y * dstride))[unit] = (uint16_t) yy;
       return;
     }
     uint16_t *d = (uint16_t *) (dst + (size_t) y * dstride) + 4 * unit;
-    d[pk.pos[0]] = (uint16_t) px16_word (hi_depth, dither16_comp (dt, 0, (int) (px.x & 0xffffu), unit, y));
+    d[pk.pos[0]] = (uint16_t) px16_store (hi_depth, dither16_comp (dt, 0, (int) (px.x & 0xffffu), unit, y));
     d[pk.pos[1]] = (uint16_t) yy;
-    d[pk.pos[2]] = (uint16_t) px16_word (hi_depth, dither16_comp (dt, 2, (int) (px.y & 0xffffu), unit, y));
-    d[pk.pos[3]] = (uint16_t) px16_word (hi_depth, dither16_comp (dt, 3, (int) (px.y >> 16), unit, y));
+    d[pk.pos[2]] = (uint16_t) px16_store (hi_depth, dither16_comp (dt, 2, (int) (px.y & 0xffffu), unit, y));
+    d[pk.pos[3]] = (uint16_t) px16_store (hi_depth, dither16_comp (dt, 3, (int) (px.y >> 16), unit, y));
     return;
   }
   if (pk.kind == UNPACK_V210) {

@@ -23,7 +23,9 @@ FORMATS = {"I420": 2, "YV12": 3, "AYUV": 6, "RGBx": 7, "BGRx": 8, "xRGB": 9, "xB
            "I420_12LE": 73, "I422_12LE": 75, "Y444_12LE": 77, "Y444_16LE": 88, "P016_LE": 90, "P012_LE": 92, "GRAY8": 25, "v210": 21, "Y210": 82, "Y410": 83, "Y212_LE": 94,
            "BGR10A2_LE": 85, "RGB10A2_LE": 86, "GRAY16_BE": 26, "GRAY16_LE": 27, "ARGB64_LE": 102, "ARGB64_BE": 103,
            "RGBA64_LE": 104, "RGBA64_BE": 105, "BGRA64_LE": 106, "BGRA64_BE": 107, "ABGR64_LE": 108, "ABGR64_BE": 109,
-           "RGB16": 29, "BGR16": 30, "RGB15": 31, "BGR15": 32, "A420": 34}
+           "RGB16": 29, "BGR16": 30, "RGB15": 31, "BGR15": 32, "A420": 34,
+           "GBR_10LE": 50, "GBRA": 65, "GBR_12LE": 69, "Y412_LE": 96, "RGBP": 99, "BGRP": 100, "A422": 117, "A444": 118, "GBR_16LE": 131, "RBGA": 133,
+           "Y216_LE": 134, "Y416_LE": 136}
 COLOR_RANGE = {"unknown": 0, "0-255": 1, "16-235": 2}
 COLOR_MATRIX = {"unknown": 0, "rgb": 1, "fcc": 2, "bt709": 3, "bt601": 4, "smpte240m": 5, "bt2020": 6}
 CHROMA_SITE = {"unknown": 0, "none": 1, "jpeg": 1, "h-cosited": 2, "mpeg2": 2, "v-cosited": 4, "cosited": 6,

@@ -68,6 +68,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_VUYA = 84,        /* packed 4:4:4:4, 4 bytes per pixel: V U Y A */
   GSTAMD_VIDEO_FORMAT_NV21 = 24,
   GSTAMD_VIDEO_FORMAT_GBR = 48,         /* planar 8-bit RGB, planes in the order G, B, R */
+  GSTAMD_VIDEO_FORMAT_GBR_10LE = 50,    /* GBR with 10 / 12 / 16 bits in little-endian 16-bit words (GBR_12LE = 69, GBR_16LE = 131) */
   GSTAMD_VIDEO_FORMAT_NV16 = 51,
   GSTAMD_VIDEO_FORMAT_NV24 = 52,
   GSTAMD_VIDEO_FORMAT_A420 = 34,        /* I420 with a fourth, full-size plane of alpha */
@@ -88,6 +89,17 @@ enum {
   GSTAMD_VIDEO_FORMAT_BGR10A2_LE = 85,  /* one little-endian 32-bit word per pixel: B 10, G 10, R 10, A 2 (from the low bits) */
   GSTAMD_VIDEO_FORMAT_RGB10A2_LE = 86,  /* the same with R 10, G 10, B 10, A 2 */
   GSTAMD_VIDEO_FORMAT_Y212_LE = 94,
+  GSTAMD_VIDEO_FORMAT_GBRA = 65,        /* planar 8-bit RGB with alpha, planes G, B, R, A */
+  GSTAMD_VIDEO_FORMAT_GBR_12LE = 69,
+  GSTAMD_VIDEO_FORMAT_Y412_LE = 96,     /* packed 4:4:4:4, four little-endian 16-bit words U Y V A, 12 bits in the high bits */
+  GSTAMD_VIDEO_FORMAT_RGBP = 99,        /* planar 8-bit RGB, planes R, G, B / B, G, R */
+  GSTAMD_VIDEO_FORMAT_BGRP = 100,
+  GSTAMD_VIDEO_FORMAT_A422 = 117,       /* Y42B / Y444 with a fourth, full-size plane of alpha */
+  GSTAMD_VIDEO_FORMAT_A444 = 118,
+  GSTAMD_VIDEO_FORMAT_GBR_16LE = 131,
+  GSTAMD_VIDEO_FORMAT_RBGA = 133,       /* packed 4-byte RGB with alpha, bytes R, B, G, A */
+  GSTAMD_VIDEO_FORMAT_Y216_LE = 134,    /* Y210's layout with all 16 bits */
+  GSTAMD_VIDEO_FORMAT_Y416_LE = 136,    /* Y412_LE's layout with all 16 bits */
   GSTAMD_VIDEO_FORMAT_ARGB64_LE = 102,  /* 16 bits per component in the named memory order and endianness (ARGB64 is ARGB64_LE on this host) */
   GSTAMD_VIDEO_FORMAT_ARGB64_BE = 103,
   GSTAMD_VIDEO_FORMAT_RGBA64_LE = 104,

@@ -36,6 +36,12 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
  * every source format (widen, matrix16, u16 scalers, u16 chroma downsample, dither, pack); the combinations the library has no
  * kernel for make set_caps fail (not-negotiated) */
 #define AMD_OUT_FORMATS AMD_IN_FORMATS
+/* (RGBP / BGRP 1.20, RBGA / A422 / A444 / GBR_16LE / Y216_LE / Y416_LE later: taken together where the headers are the reference's own) */
+#if GST_CHECK_VERSION (1, 26, 0)
+#define AMD_NEWEST_FORMATS ", RGBP, BGRP, RBGA, A422, A444, GBR_16LE, Y216_LE, Y412_LE, Y416_LE"
+#else
+#define AMD_NEWEST_FORMATS ""
+#endif
 #if GST_CHECK_VERSION (1, 20, 0)
 #define AMD_NEWER_FORMATS ", VUYA, Y210, Y410, BGR10A2_LE, P012_LE, P016_LE, Y444_16LE, Y212_LE, RGB10A2_LE, ARGB64_LE, ARGB64_BE, RGBA64_LE, RGBA64_BE, BGRA64_LE, BGRA64_BE, ABGR64_LE, ABGR64_BE"
 #elif GST_CHECK_VERSION (1, 18, 0)
@@ -45,7 +51,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #else
 #define AMD_NEWER_FORMATS ""
 #endif
-#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, GBR, v210" AMD_NEWER_FORMATS " }"
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, GBR, GBRA, GBR_10LE, GBR_12LE, v210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
 
 /* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path
  * (video-converter.c:3304, 3383-3463), so interlaced caps are not negotiated rather than converted as if progressive
@@ -808,7 +814,13 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_I420_12LE, GSTAMD_VIDEO_FORMAT_I420_12LE}, {GST_VIDEO_FORMAT_I422_12LE, GSTAMD_VIDEO_FORMAT_I422_12LE},
     {GST_VIDEO_FORMAT_Y444_12LE, GSTAMD_VIDEO_FORMAT_Y444_12LE},
     {GST_VIDEO_FORMAT_GRAY16_LE, GSTAMD_VIDEO_FORMAT_GRAY16_LE}, {GST_VIDEO_FORMAT_GRAY16_BE, GSTAMD_VIDEO_FORMAT_GRAY16_BE},
-    {GST_VIDEO_FORMAT_A420, GSTAMD_VIDEO_FORMAT_A420},
+    {GST_VIDEO_FORMAT_A420, GSTAMD_VIDEO_FORMAT_A420}, {GST_VIDEO_FORMAT_GBRA, GSTAMD_VIDEO_FORMAT_GBRA},
+    {GST_VIDEO_FORMAT_GBR_10LE, GSTAMD_VIDEO_FORMAT_GBR_10LE}, {GST_VIDEO_FORMAT_GBR_12LE, GSTAMD_VIDEO_FORMAT_GBR_12LE},
+#if GST_CHECK_VERSION (1, 26, 0)
+    {GST_VIDEO_FORMAT_RGBP, GSTAMD_VIDEO_FORMAT_RGBP}, {GST_VIDEO_FORMAT_BGRP, GSTAMD_VIDEO_FORMAT_BGRP}, {GST_VIDEO_FORMAT_RBGA, GSTAMD_VIDEO_FORMAT_RBGA},
+    {GST_VIDEO_FORMAT_A422, GSTAMD_VIDEO_FORMAT_A422}, {GST_VIDEO_FORMAT_A444, GSTAMD_VIDEO_FORMAT_A444}, {GST_VIDEO_FORMAT_GBR_16LE, GSTAMD_VIDEO_FORMAT_GBR_16LE},
+    {GST_VIDEO_FORMAT_Y216_LE, GSTAMD_VIDEO_FORMAT_Y216_LE}, {GST_VIDEO_FORMAT_Y412_LE, GSTAMD_VIDEO_FORMAT_Y412_LE}, {GST_VIDEO_FORMAT_Y416_LE, GSTAMD_VIDEO_FORMAT_Y416_LE},
+#endif
     {GST_VIDEO_FORMAT_RGB16, GSTAMD_VIDEO_FORMAT_RGB16}, {GST_VIDEO_FORMAT_BGR16, GSTAMD_VIDEO_FORMAT_BGR16},
     {GST_VIDEO_FORMAT_RGB15, GSTAMD_VIDEO_FORMAT_RGB15}, {GST_VIDEO_FORMAT_BGR15, GSTAMD_VIDEO_FORMAT_BGR15},
     /* VUYA, Y210, Y410 (1.16), P012_LE, P016_LE, Y444_16LE, Y212_LE (1.18) joined the format enum after 1.14: there when the headers this is compiled

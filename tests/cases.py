@@ -50,8 +50,12 @@ def visible_planes(fmt, w, h):
         return [(w, h), (up2(w), up2(h)), (up2(w), up2(h)), (w, h)]
     if fmt == "Y42B":
         return [(w, h), (up2(w), h), (up2(w), h)]
-    if fmt in ("Y444", "GBR"):
+    if fmt in ("Y444", "GBR", "RGBP", "BGRP"):
         return [(w, h)] * 3
+    if fmt in ("GBRA", "A444"):
+        return [(w, h)] * 4
+    if fmt == "A422":
+        return [(w, h), (up2(w), h), (up2(w), h), (w, h)]
     if fmt in ("NV12", "NV21"):
         return [(w, h), (2 * up2(w), up2(h))]
     if fmt in ("NV16", "NV61"):
@@ -68,13 +72,13 @@ def visible_planes(fmt, w, h):
         return [(2 * w, h), (2 * up2(w), up2(h)), (2 * up2(w), up2(h))]
     if fmt in ("I422_10LE", "I422_12LE"):
         return [(2 * w, h), (2 * up2(w), h), (2 * up2(w), h)]
-    if fmt in ("Y444_10LE", "Y444_12LE", "Y444_16LE"):
+    if fmt in ("Y444_10LE", "Y444_12LE", "Y444_16LE", "GBR_10LE", "GBR_12LE", "GBR_16LE"):
         return [(2 * w, h)] * 3
     if fmt in ("P010_10LE", "P012_LE", "P016_LE"):
         return [(2 * w, h), (4 * up2(w), up2(h))]
-    if fmt in ("Y210", "Y212_LE"):
+    if fmt in ("Y210", "Y212_LE", "Y216_LE"):
         return [(8 * up2(w), h)]
-    if fmt in ("ARGB64", "AYUV64") or fmt.endswith(("64_LE", "64_BE")):
+    if fmt in ("ARGB64", "AYUV64", "Y412_LE", "Y416_LE") or fmt.endswith(("64_LE", "64_BE")):
         return [(8 * w, h)]
     if fmt in ("GRAY16_LE", "GRAY16_BE", "RGB16", "BGR16", "RGB15", "BGR15"):
         return [(2 * w, h)]
@@ -1129,6 +1133,52 @@ def _round5_a420_sweep():
 
 VIDEO_CASES += _round5_a420_sweep()
 
+
+# the planar RGB family beyond GBR (RGBP, BGRP, GBRA, GBR_10LE / _12LE / _16LE: which frame plane is which component - format_plane_perm), A422 / A444,
+# RBGA (a packed byte order the strip kernels are not instantiated for), Y216_LE, Y412_LE (12 bits masked and widened), Y416_LE
+def _round5_planar_rgb_sweep():
+    out = []
+    for f in ("RGBP", "BGRP", "GBRA", "RBGA", "GBR_10LE", "GBR_12LE", "GBR_16LE", "A422", "A444", "Y216_LE", "Y412_LE", "Y416_LE"):
+        n = f.lower()
+        rgb = f[0] in "RGB" and not f.startswith("GRAY")
+        out += [
+            ("r5p_%s_bgra_37x6" % n, f, 37, 6, "BGRA", 37, 6, {}, None, None, "random"),
+            ("r5p_bgra_%s_40x5" % n, "BGRA", 40, 5, f, 40, 5, {}, None, None, "random"),
+            ("r5p_%s_nv12_40x6" % n, f, 40, 6, "NV12", 40, 6, {}, None, None, "random"),
+            ("r5p_nv12_%s_64x36" % n, "NV12", 64, 36, f, 64, 36, {}, None, None, "random"),
+            ("r5p_nv12_%s_up_bilinear" % n, "NV12", 64, 36, f, 100, 50, LIN, None, None, "random"),
+            ("r5p_%s_i420_10le_down_lanczos" % n, f, 64, 36, "I420_10LE", 32, 20, LAN, None, None, "random"),
+            ("r5p_%s_self_copy" % n, f, 64, 36, f, 64, 36, {}, None, None, "random"),
+            ("r5p_%s_self_down_bilinear" % n, f, 64, 36, f, 32, 20, LIN, None, None, "random"),
+            ("r5p_%s_self_up_lanczos_odd" % n, f, 33, 17, f, 50, 40, LAN, None, None, "random"),
+            ("r5p_%s_ayuv64" % n, f, 33, 7, "AYUV64", 33, 7, {}, None, None, "random"),
+            ("r5p_argb64_%s_dest_border" % n, "ARGB64", 30, 20, f, 50, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+            ("r5p_%s_self_crop_dest_border" % n, f, 48, 30, f, 60, 40, dict(src_x=4, src_y=2, src_width=30, src_height=20, dest_x=8, dest_y=10, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+            ("r5p_bgra_%s_sierra_q64" % n, "BGRA", 35, 19, f, 35, 19, dict(dither_method="sierra-lite", dither_quantization=64), None, None, "random"),
+            ("r5p_bgra_%s_alpha_set" % n, "BGRA", 40, 5, f, 40, 5, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+            ("r5p_%s_bgra_alpha_mult" % n, f, 40, 5, "BGRA", 40, 5, dict(alpha_mode="mult", alpha_value=0.5), None, None, "random"),
+            ("r5p_%s_bgra_gamma_remap" % n, f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709" if rgb else "bt709>sRGB", None, "random"),
+        ]
+    out += [
+        ("r5p_gbr_rgbp", "GBR", 40, 8, "RGBP", 40, 8, {}, None, None, "random"),
+        ("r5p_rgbp_gbra", "RGBP", 40, 8, "GBRA", 40, 8, {}, None, None, "random"),
+        ("r5p_gbra_a444", "GBRA", 40, 8, "A444", 40, 8, {}, None, None, "random"),
+        ("r5p_a444_a420", "A444", 40, 8, "A420", 40, 8, {}, None, None, "random"),
+        ("r5p_a420_a422", "A420", 40, 8, "A422", 40, 8, {}, None, None, "random"),
+        ("r5p_y416_y412", "Y416_LE", 40, 8, "Y412_LE", 40, 8, {}, None, None, "random"),
+        ("r5p_y410_y416", "Y410", 40, 8, "Y416_LE", 40, 8, {}, None, None, "random"),
+        ("r5p_y216_y210", "Y216_LE", 40, 8, "Y210", 40, 8, {}, None, None, "random"),
+        ("r5p_nv12_rbga_generic_kernels_1080_strip", "NV12", 1920, 16, "RBGA", 1920, 16, {}, None, None, "random"),
+        ("r5p_i420_rbga_fastpath_shape", "I420", 64, 36, "RBGA", 64, 36, {}, None, None, "random"),
+        ("r5p_yuy2_rbga", "YUY2", 64, 36, "RBGA", 64, 36, {}, None, None, "random"),
+        ("r5p_nv12_rbga_down_lanczos", "NV12", 64, 36, "RBGA", 32, 18, LAN, None, None, "random"),
+        ("r5p_y416_crop_x_no_quirk", "Y416_LE", 48, 30, "BGRA", 30, 20, dict(src_x=5, src_y=3, src_width=30, src_height=20), None, None, "random"),
+    ]
+    return out
+
+
+VIDEO_CASES += _round5_planar_rgb_sweep()
+
 # the reference's own v210 fastpaths between v210 and the 8-bit 4:2:0 / 4:2:2 formats (video_v210_fast.h): samples shifted, not widened; group tails
 # (widths 6 k + 1 .. 5), the odd last line of a 4:2:0 frame, one-pixel frames
 VIDEO_CASES += [("v210fast_%s_%s_%dx%d" % (a.lower(), b.lower(), w, h), a, w, h, b, w, h, {}, None, None, "random")
@@ -1244,8 +1294,14 @@ def default_layout(fmt, w, h):
     if fmt == "Y42B":
         s0, s1 = r4(w), (w + 7) // 8 * 8 // 2
         return [s0, s1, s1], [0, s0 * h, s0 * h + s1 * h]
-    if fmt in ("Y444", "GBR"):
+    if fmt in ("Y444", "GBR", "RGBP", "BGRP"):
         return [r4(w)] * 3, [0, r4(w) * h, 2 * r4(w) * h]
+    if fmt == "GBRA":
+        return [r4(w)] * 4, [0, r4(w) * h, 2 * r4(w) * h, 3 * r4(w) * h]
+    if fmt in ("A422", "A444"):
+        s0 = r4(w)
+        s1 = (w + 7) // 8 * 8 // 2 if fmt == "A422" else s0
+        return [s0, s1, s1, s0], [0, s0 * r2(h), s0 * r2(h) + s1 * r2(h), s0 * r2(h) + 2 * s1 * r2(h)]
     if fmt in ("NV12", "NV21"):
         return [r4(w), r4(w)], [0, r4(w) * r2(h)]
     if fmt in ("NV16", "NV61"):
@@ -1258,7 +1314,7 @@ def default_layout(fmt, w, h):
         return [r4(3 * w)], [0]
     if fmt in ("GRAY16_LE", "GRAY16_BE", "RGB16", "BGR16", "RGB15", "BGR15"):
         return [r4(2 * w)], [0]
-    if fmt in ("ARGB64", "AYUV64") or fmt.endswith(("64_LE", "64_BE")):
+    if fmt in ("ARGB64", "AYUV64", "Y412_LE", "Y416_LE") or fmt.endswith(("64_LE", "64_BE")):
         return [8 * w], [0]
     return [4 * w], [0]
 

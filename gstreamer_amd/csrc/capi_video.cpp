@@ -910,9 +910,9 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
   }
   if (g.store64 || g.pack16) {
     /* a 16-bit destination frame: borders around the rectangle first (the border pixel packed like any other, border_plane_value) */
-    uint8_t *planes[3] = {nullptr, nullptr, nullptr};
-    int strides[3] = {0, 0, 0};
-    for (int i = 0; i < p.out_info.n_planes && i < 3; i++) {
+    uint8_t *planes[4] = {nullptr, nullptr, nullptr, nullptr};
+    int strides[4] = {0, 0, 0, 0};
+    for (int i = 0; i < p.out_info.n_planes && i < 4; i++) {
       planes[i] = (uint8_t *) dest_planes[i];
       strides[i] = dest_stride ? dest_stride[i] : p.out_info.stride[i];
       if (!planes[i])
@@ -942,9 +942,19 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
         cur_is_source = false;
       }
       e = launch_pack16_ed (g.pack, g.pack_hi_depth, g.dither16, (uint8_t *) cur.p, cur.stride, planes, strides, stream, c->ed_carry);
+      if (e == hipSuccess && p.fout->kind == UNPACK_PLANAR_A) {
+        DitherParams none;
+        memset (&none, 0, sizeof (none));           /* the error-diffusion pass ran over all four components of the image */
+        const int sa = dest_stride ? dest_stride[3] : p.out_info.stride[3];
+        e = launch_pack16_alpha_plane (g.pack, g.pack_hi_depth, none, cur.p, cur.stride, (uint8_t *) dest_planes[3] + plane_origin (p.fout, 3, p.rect.out_x, p.rect.out_y, sa), sa, stream);
+      }
       return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_pack16 (error diffusion)");
     }
     e = launch_pack16 (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, planes, strides, stream);
+    if (e == hipSuccess && p.fout->kind == UNPACK_PLANAR_A) {
+      const int sa = dest_stride ? dest_stride[3] : p.out_info.stride[3];
+      e = launch_pack16_alpha_plane (g.pack, g.pack_hi_depth, g.dither16, cur.p, cur.stride, (uint8_t *) dest_planes[3] + plane_origin (p.fout, 3, p.rect.out_x, p.rect.out_y, sa), sa, stream);
+    }
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_pack16");
   }
   const void *mb[GSTAMD_VIDEO_MAX_PLANES] = {c->gamma_mid_b, nullptr, nullptr, nullptr};

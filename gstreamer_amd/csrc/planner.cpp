@@ -36,6 +36,19 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_GBR_10LE, "GBR_10LE", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 1},
   {GSTAMD_VIDEO_FORMAT_GBR_12LE, "GBR_12LE", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 4},
   {GSTAMD_VIDEO_FORMAT_GBR_16LE, "GBR_16LE", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 6},
+  /* the 10 / 12 / 16-bit forms with an alpha plane (unpack_A420_16 / _A422_16 / _A444_16 :4645-5040: samples in the low bits, every plane widened the same
+     way; unpack_GBRA_10LE :3240, _12LE :3590) */
+  {GSTAMD_VIDEO_FORMAT_A420_10LE, "A420_10LE", true, true, 4, UNPACK_PLANAR_A, 1, 1, 1, 2, {0, 0, 0, 0}, 1},
+  {GSTAMD_VIDEO_FORMAT_A422_10LE, "A422_10LE", true, true, 4, UNPACK_PLANAR_A, 1, 0, 1, 2, {0, 0, 0, 0}, 1},
+  {GSTAMD_VIDEO_FORMAT_A444_10LE, "A444_10LE", true, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}, 1},
+  {GSTAMD_VIDEO_FORMAT_A420_12LE, "A420_12LE", true, true, 4, UNPACK_PLANAR_A, 1, 1, 1, 2, {0, 0, 0, 0}, 4},
+  {GSTAMD_VIDEO_FORMAT_A422_12LE, "A422_12LE", true, true, 4, UNPACK_PLANAR_A, 1, 0, 1, 2, {0, 0, 0, 0}, 4},
+  {GSTAMD_VIDEO_FORMAT_A444_12LE, "A444_12LE", true, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}, 4},
+  {GSTAMD_VIDEO_FORMAT_A420_16LE, "A420_16LE", true, true, 4, UNPACK_PLANAR_A, 1, 1, 1, 2, {0, 0, 0, 0}, 6},
+  {GSTAMD_VIDEO_FORMAT_A422_16LE, "A422_16LE", true, true, 4, UNPACK_PLANAR_A, 1, 0, 1, 2, {0, 0, 0, 0}, 6},
+  {GSTAMD_VIDEO_FORMAT_A444_16LE, "A444_16LE", true, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}, 6},
+  {GSTAMD_VIDEO_FORMAT_GBRA_10LE, "GBRA_10LE", false, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}, 1},
+  {GSTAMD_VIDEO_FORMAT_GBRA_12LE, "GBRA_12LE", false, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}, 4},
   /* A422 / A444 (unpack_A422 :4859, unpack_A444 :4588): Y42B / Y444 plus the alpha plane */
   {GSTAMD_VIDEO_FORMAT_A422, "A422", true, true, 4, UNPACK_PLANAR_A, 1, 0, 1, 2, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_A444, "A444", true, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}},
@@ -174,6 +187,33 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       break;
     case GSTAMD_VIDEO_FORMAT_GBRA:            /* video-info.c:1042-1052 */
       info->stride[0] = info->stride[1] = info->stride[2] = info->stride[3] = round_up (width, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * h;
+      info->offset[2] = info->offset[1] * 2;
+      info->offset[3] = info->offset[1] * 3;
+      info->size = (uint64_t) info->stride[0] * h * 4;
+      break;
+    case GSTAMD_VIDEO_FORMAT_A420_10LE:
+    case GSTAMD_VIDEO_FORMAT_A420_12LE:
+    case GSTAMD_VIDEO_FORMAT_A420_16LE:
+    case GSTAMD_VIDEO_FORMAT_A422_10LE:
+    case GSTAMD_VIDEO_FORMAT_A422_12LE:
+    case GSTAMD_VIDEO_FORMAT_A422_16LE: {      /* video-info.c:1256-1291 */
+      const bool v2 = format == GSTAMD_VIDEO_FORMAT_A420_10LE || format == GSTAMD_VIDEO_FORMAT_A420_12LE || format == GSTAMD_VIDEO_FORMAT_A420_16LE;
+      const uint64_t h2 = (uint64_t) round_up (height, 2), ch = v2 ? h2 / 2 : h2;
+      info->stride[0] = info->stride[3] = round_up (width * 2, 4);
+      info->stride[1] = info->stride[2] = round_up (width, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * h2;
+      info->offset[2] = info->offset[1] + (uint64_t) info->stride[1] * ch;
+      info->offset[3] = info->offset[2] + (uint64_t) info->stride[2] * ch;
+      info->size = info->offset[3] + (uint64_t) info->stride[0] * h2;
+      break;
+    }
+    case GSTAMD_VIDEO_FORMAT_A444_10LE:
+    case GSTAMD_VIDEO_FORMAT_A444_12LE:
+    case GSTAMD_VIDEO_FORMAT_A444_16LE:
+    case GSTAMD_VIDEO_FORMAT_GBRA_10LE:
+    case GSTAMD_VIDEO_FORMAT_GBRA_12LE:        /* video-info.c:1189-1203, 1292-1308 */
+      info->stride[0] = info->stride[1] = info->stride[2] = info->stride[3] = round_up (width * 2, 4);
       info->offset[1] = (uint64_t) info->stride[0] * h;
       info->offset[2] = info->offset[1] * 2;
       info->offset[3] = info->offset[1] * 3;
@@ -1893,7 +1933,7 @@ static void setup_dither16 (const GstAmdVideoConverterConfig &cfg, const FormatD
   d->method = cfg.dither_method;
   /* the planar formats have no alpha component (depth 0: quantiser 0); ARGB64 / AYUV64 carry 16 bits of it like the other three - their own
      quantiser is 1, so a stage only exists for dither-quantization > 1, run as a pass over the finished frame (k_dither16_image) */
-  d->shift[0] = fo->hi_depth == 3 || fo->kind == UNPACK_PACKED64 ? shift : 0;
+  d->shift[0] = fo->hi_depth == 3 || fo->kind == UNPACK_PACKED64 || fo->kind == UNPACK_PLANAR_A ? shift : 0;
   if (fo->kind == UNPACK_Y410) {          /* 2 bits of alpha: quantiser 1 << 14 (chain_dither :2060-2075 per component depth) */
     unsigned qa = 1u << 14;
     if (cfg.dither_quantization > qa)
@@ -1919,7 +1959,7 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
   const bool in16 = fi->hi_depth != 0, out16 = fo->hi_depth != 0;
-  if (out16 && !kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && !GSTAMD_KIND_PX16 (fo->kind) && fo->kind != UNPACK_V210)
+  if (out16 && !kind_has_planes (fo->kind) && fo->kind != UNPACK_PLANAR_A && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && !GSTAMD_KIND_PX16 (fo->kind) && fo->kind != UNPACK_V210)
     return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destination layout not implemented on the GPU path");
   /* a 10 / 12 / 16-bit planar SOURCE: the 16-bit front (unpack + chroma upsampler, k_front16) of the conversion into an AYUV64 frame of
    * the same size - planned like any other conversion, its front / pair table taken over */
@@ -2414,7 +2454,7 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   const GstAmdVideoConverterConfig &cfg = plan->config;
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
-  if (!kind_has_planes (fo->kind) && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && !GSTAMD_KIND_PX16 (fo->kind) && fo->kind != UNPACK_V210) {
+  if (!kind_has_planes (fo->kind) && fo->kind != UNPACK_PLANAR_A && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && !GSTAMD_KIND_PX16 (fo->kind) && fo->kind != UNPACK_V210) {
     if (error)
       *error = "10-bit destination layout not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;

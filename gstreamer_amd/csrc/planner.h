@@ -67,6 +67,8 @@ inline bool format_plane_perm (int format, int perm[4])
     case GSTAMD_VIDEO_FORMAT_GBR_10LE:
     case GSTAMD_VIDEO_FORMAT_GBR_12LE:
     case GSTAMD_VIDEO_FORMAT_GBR_16LE:
+    case GSTAMD_VIDEO_FORMAT_GBRA_10LE:
+    case GSTAMD_VIDEO_FORMAT_GBRA_12LE:
       perm[0] = 2, perm[1] = 0, perm[2] = 1;
       return true;
     case GSTAMD_VIDEO_FORMAT_BGRP:
@@ -450,7 +452,9 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
       v |= (uint32_t) border[c] << (8 * f->pos[c]);
     *es = f->kind == UNPACK_PACKED4 ? 4 : 3, *lo = v;
   } else if (f->hi_depth) {
-    if (plane == 0)
+    if (f->kind == UNPACK_PLANAR_A && plane == 3)
+      *es = 2, *lo = s16 (0);
+    else if (plane == 0)
       *es = 2, *lo = s16 (1);
     else if (f->kind == UNPACK_SEMI)
       *es = 4, *lo = f->u_plane ? s16 (2) | (s16 (3) << 16) : s16 (3) | (s16 (2) << 16);

@@ -119,6 +119,8 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
     c1 = y410_field (g[j < 1 ? 0 : (j < 3 ? 1 : (j < 4 ? 2 : 3))], j == 0 || j == 3 ? 10 : (j == 1 || j == 4 ? 0 : 20));
   } else {
     c1 = deep_widen (f.hi_depth, ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
+    if (f.kind == UNPACK_PLANAR_A)        /* unpack_A420_16 / _A422_16 / _A444_16 (video-format.c:4645-5040), unpack_GBRA_10LE :3240: the alpha plane widened like the others */
+      a = deep_widen (f.hi_depth, ((const uint16_t *) (pl.p[3] + (ptrdiff_t) y * pl.stride[3]))[x]);
   }
   UV c;
   if (f.chroma_v2) {
@@ -909,6 +911,18 @@ GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const Dith
       ((uint16_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane]))[k] = pv;
     }
   }
+}
+
+// the fourth plane of a 10 / 12 / 16-bit destination with an alpha plane (pack_A420_16 & co, pack_GBRA_10LE): pixels x0 .. x0 + 3 of line y
+GSTAMD_HD void pack16_alpha_plane_body (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride,
+    uint8_t *__restrict__ da, int dstride, int x0, int y)
+{
+  if (x0 >= pk.width || y >= pk.height)
+    return;
+  const uint2 *row = (const uint2 *) (src + (size_t) y * sstride);
+  uint16_t *d = (uint16_t *) (da + (size_t) y * dstride);
+  for (int i = 0; i < 4 && x0 + i < pk.width; i++)
+    d[x0 + i] = pack16_sample (hi_depth, dither16_comp (dt, 0, (int) (row[x0 + i].x & 0xffffu), x0 + i, y));
 }
 
 // ---- packed 10 / 12-bit destinations (Y210, Y212_LE, Y410): one lane per stored unit - a macropixel of two pixels / a pixel.  The stages are

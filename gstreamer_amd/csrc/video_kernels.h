@@ -94,6 +94,8 @@ hipError_t launch_swizzle34 (const Swz34Params &p, int src_bytes, int dst_bytes,
 void video_frame_list_begin (int n, const void *const *src, void *const *dst, size_t src_size, size_t dst_size);
 int video_frame_list_end ();
 void video_frame_list_touch (const void *dp);
+hipError_t launch_pack16_alpha_plane (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *src, int sstride, uint8_t *plane, int stride,
+    hipStream_t stream);
 hipError_t launch_pack_alpha_plane (const PackPlanarParams &pk, const uint8_t *img, int istride, uint8_t *plane, int stride, hipStream_t stream);
 hipError_t launch_v210_fast (const V210FastParams &p, hipStream_t stream);
 hipError_t launch_lut3 (uint8_t *img, int stride, int w, int h, const uint8_t *comp_dev, int keep, hipStream_t stream);

@@ -1028,6 +1028,21 @@ __global__ __launch_bounds__ (256) void k_plane_vscale (SrcPlane s, ScaleDev sd,
   plane_vscale_body (s, sd, d, width, oh, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
 }
 
+// ... and of its 10 / 12 / 16-bit relatives from the AYUV64 image (video_deep.h pack16_alpha_plane_body)
+__global__ __launch_bounds__ (256) void k_pack16_alpha_plane (PackPlanarParams pk, int hi_depth, DitherParams dt, const uint8_t *__restrict__ src, int sstride,
+    uint8_t *__restrict__ plane, int stride)
+{
+  pack16_alpha_plane_body (pk, hi_depth, dt, src, sstride, plane, stride, 4 * (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
+hipError_t launch_pack16_alpha_plane (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *src, int sstride, uint8_t *plane, int stride,
+    hipStream_t stream)
+{
+  video_frame_list_touch (plane);
+  hipLaunchKernelGGL (k_pack16_alpha_plane, dim3 (((pk.width + 3) / 4 + 255) / 256, pk.height), dim3 (256), 0, stream, pk, hi_depth, dt, src, sstride, plane, stride);
+  return hipGetLastError ();
+}
+
 // A420's alpha plane from the chain's AYUV image (video_pack.h pack_alpha_plane_body)
 __global__ __launch_bounds__ (256) void k_pack_alpha_plane (PackPlanarParams pk, const uint8_t *__restrict__ img, int istride, uint8_t *__restrict__ plane, int stride)
 {

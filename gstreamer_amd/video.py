@@ -25,7 +25,9 @@ FORMATS = {"I420": 2, "YV12": 3, "AYUV": 6, "RGBx": 7, "BGRx": 8, "xRGB": 9, "xB
            "RGBA64_LE": 104, "RGBA64_BE": 105, "BGRA64_LE": 106, "BGRA64_BE": 107, "ABGR64_LE": 108, "ABGR64_BE": 109,
            "RGB16": 29, "BGR16": 30, "RGB15": 31, "BGR15": 32, "A420": 34,
            "GBR_10LE": 50, "GBRA": 65, "GBR_12LE": 69, "Y412_LE": 96, "RGBP": 99, "BGRP": 100, "A422": 117, "A444": 118, "GBR_16LE": 131, "RBGA": 133,
-           "Y216_LE": 134, "Y416_LE": 136}
+           "Y216_LE": 134, "Y416_LE": 136,
+           "A420_10LE": 55, "A422_10LE": 57, "A444_10LE": 59, "GBRA_10LE": 67, "GBRA_12LE": 71, "A444_12LE": 119, "A422_12LE": 121, "A420_12LE": 123,
+           "A444_16LE": 125, "A422_16LE": 127, "A420_16LE": 129}
 COLOR_RANGE = {"unknown": 0, "0-255": 1, "16-235": 2}
 COLOR_MATRIX = {"unknown": 0, "rgb": 1, "fcc": 2, "bt709": 3, "bt601": 4, "smpte240m": 5, "bt2020": 6}
 CHROMA_SITE = {"unknown": 0, "none": 1, "jpeg": 1, "h-cosited": 2, "mpeg2": 2, "v-cosited": 4, "cosited": 6,

@@ -89,7 +89,18 @@ enum {
   GSTAMD_VIDEO_FORMAT_BGR10A2_LE = 85,  /* one little-endian 32-bit word per pixel: B 10, G 10, R 10, A 2 (from the low bits) */
   GSTAMD_VIDEO_FORMAT_RGB10A2_LE = 86,  /* the same with R 10, G 10, B 10, A 2 */
   GSTAMD_VIDEO_FORMAT_Y212_LE = 94,
-  GSTAMD_VIDEO_FORMAT_GBRA = 65,        /* planar 8-bit RGB with alpha, planes G, B, R, A */
+  GSTAMD_VIDEO_FORMAT_A420_10LE = 55,   /* A420 / A422 / A444 with 10, 12 (A444_12LE = 119, A422_12LE = 121, A420_12LE = 123) or 16 bits (125, 127, 129) in LE words */
+  GSTAMD_VIDEO_FORMAT_A422_10LE = 57,
+  GSTAMD_VIDEO_FORMAT_A444_10LE = 59,
+  GSTAMD_VIDEO_FORMAT_GBRA = 65,
+  GSTAMD_VIDEO_FORMAT_GBRA_10LE = 67,
+  GSTAMD_VIDEO_FORMAT_GBRA_12LE = 71,
+  GSTAMD_VIDEO_FORMAT_A444_12LE = 119,
+  GSTAMD_VIDEO_FORMAT_A422_12LE = 121,
+  GSTAMD_VIDEO_FORMAT_A420_12LE = 123,
+  GSTAMD_VIDEO_FORMAT_A444_16LE = 125,
+  GSTAMD_VIDEO_FORMAT_A422_16LE = 127,
+  GSTAMD_VIDEO_FORMAT_A420_16LE = 129,        /* planar 8-bit RGB with alpha, planes G, B, R, A */
   GSTAMD_VIDEO_FORMAT_GBR_12LE = 69,
   GSTAMD_VIDEO_FORMAT_Y412_LE = 96,     /* packed 4:4:4:4, four little-endian 16-bit words U Y V A, 12 bits in the high bits */
   GSTAMD_VIDEO_FORMAT_RGBP = 99,        /* planar 8-bit RGB, planes R, G, B / B, G, R */

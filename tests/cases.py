@@ -54,6 +54,12 @@ def visible_planes(fmt, w, h):
         return [(w, h)] * 3
     if fmt in ("GBRA", "A444"):
         return [(w, h)] * 4
+    if fmt in ("GBRA_10LE", "GBRA_12LE", "A444_10LE", "A444_12LE", "A444_16LE"):
+        return [(2 * w, h)] * 4
+    if fmt in ("A420_10LE", "A420_12LE", "A420_16LE"):
+        return [(2 * w, h), (2 * up2(w), up2(h)), (2 * up2(w), up2(h)), (2 * w, h)]
+    if fmt in ("A422_10LE", "A422_12LE", "A422_16LE"):
+        return [(2 * w, h), (2 * up2(w), h), (2 * up2(w), h), (2 * w, h)]
     if fmt == "A422":
         return [(w, h), (up2(w), h), (up2(w), h), (w, h)]
     if fmt in ("NV12", "NV21"):
@@ -1178,6 +1184,35 @@ def _round5_planar_rgb_sweep():
 
 
 VIDEO_CASES += _round5_planar_rgb_sweep()
+
+
+# the 10 / 12 / 16-bit formats with an alpha plane (A420 / A422 / A444 _10LE / _12LE / _16LE, GBRA_10LE / _12LE): the alpha plane widened in the 16-bit
+# front, dithered and packed by k_pack16_alpha_plane, bordered as a fourth plane
+def _round5_alpha16_sweep():
+    out = []
+    for f in ("A420_10LE", "A422_10LE", "A444_10LE", "GBRA_10LE", "GBRA_12LE", "A444_12LE", "A422_12LE", "A420_12LE", "A444_16LE", "A422_16LE", "A420_16LE"):
+        n = f.lower()
+        out += [
+            ("r5a_%s_bgra_37x7" % n, f, 37, 7, "BGRA", 37, 7, {}, None, None, "random"),
+            ("r5a_bgra_%s_40x6" % n, "BGRA", 40, 6, f, 40, 6, {}, None, None, "random"),
+            ("r5a_%s_nv12_40x6" % n, f, 40, 6, "NV12", 40, 6, {}, None, None, "random"),
+            ("r5a_nv12_%s_up_bilinear" % n, "NV12", 64, 36, f, 100, 50, LIN, None, None, "random"),
+            ("r5a_%s_i420_10le_down_lanczos" % n, f, 64, 36, "I420_10LE", 32, 20, LAN, None, None, "random"),
+            ("r5a_%s_self" % n, f, 64, 36, f, 64, 36, {}, None, None, "random"),
+            ("r5a_%s_self_down_bilinear" % n, f, 64, 36, f, 32, 20, LIN, None, None, "random"),
+            ("r5a_argb64_%s_dest_border" % n, "ARGB64", 30, 20, f, 50, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+            ("r5a_%s_self_crop_dest_border" % n, f, 48, 30, f, 60, 40, dict(src_x=4, src_y=2, src_width=30, src_height=20, dest_x=8, dest_y=10, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+            ("r5a_bgra_%s_sierra_q128" % n, "BGRA", 35, 19, f, 35, 19, dict(dither_method="sierra-lite", dither_quantization=128), None, None, "random"),
+            ("r5a_bgra_%s_alpha_set" % n, "BGRA", 40, 6, f, 40, 6, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+            ("r5a_%s_bgra_alpha_mult" % n, f, 40, 6, "BGRA", 40, 6, dict(alpha_mode="mult", alpha_value=0.5), None, None, "random"),
+            ("r5a_%s_a420" % n, f, 40, 6, "A420", 40, 6, {}, None, None, "random"),
+            ("r5a_a420_%s" % n, "A420", 40, 6, f, 40, 6, {}, None, None, "random"),
+            ("r5a_%s_bgra_gamma_remap" % n, f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709" if f[0] == "G" else "bt709>sRGB", None, "random"),
+        ]
+    return out
+
+
+VIDEO_CASES += _round5_alpha16_sweep()
 
 # the reference's own v210 fastpaths between v210 and the 8-bit 4:2:0 / 4:2:2 formats (video_v210_fast.h): samples shifted, not widened; group tails
 # (widths 6 k + 1 .. 5), the odd last line of a 4:2:0 frame, one-pixel frames

@@ -1151,6 +1151,11 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       for (int yb = 0; yb < rows; yb++)
         for (int x0 = 0; x0 < (g.pack.width / 4 + 256) / 256 * 1024; x0 += 4)
           pack16_body (pk16, g.pack_hi_depth, dt16, cur.p, cur.stride, d, x0, yb);
+      if (p.fout->kind == UNPACK_PLANAR_A)          /* k_pack16_alpha_plane */
+        for (int y = 0; y < g.pack.height; y++)
+          for (int x0 = 0; x0 < g.pack.width; x0 += 4)
+            pack16_alpha_plane_body (pk16, g.pack_hi_depth, dt16, cur.p, cur.stride,
+                dst + out->offset[3] + plane_origin (p.fout, 3, p.rect.out_x, p.rect.out_y, out->stride[3]), out->stride[3], x0, y);
       return GSTAMD_OK;
     }
     plan_set_border_override (p.rect.border);

@@ -1065,10 +1065,25 @@ __global__ __launch_bounds__ (256) void k_v210_fast (V210FastParams p, FrameDelt
   v210_fast_body (p, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
 }
 
+__global__ __launch_bounds__ (256) void k_v210_fast_vec (V210FastParams p, FrameDeltas fl)
+{
+  GSTAMD_FRAME_Z;
+  for (int i = 0; i < 3; i++)
+    p.s[i] = p.s[i] ? p.s[i] + fls_ : nullptr, p.d[i] = p.d[i] ? p.d[i] + fld_ : nullptr;
+  v210_fast_block (p, (int) (blockIdx.x * blockDim.x + threadIdx.x), (int) blockIdx.y);
+}
+
 hipError_t launch_v210_fast (const V210FastParams &p, hipStream_t stream)
 {
   int nz;
   const FrameDeltas &fl = frame_list_for (p.s[0], p.d[0], &nz);
+  bool vec = v210_fast_vec_ok (p);
+  for (int z = 1; z < nz && vec; z++)         /* every frame of a list on the same 16-byte phase */
+    vec = (fl.s[z] % 16) == 0 && (fl.d[z] % 16) == 0;
+  if (vec) {
+    hipLaunchKernelGGL (k_v210_fast_vec, dim3 ((v210_fast_blocks (p) + 63) / 64, v210_fast_rows (p), nz), dim3 (64), 0, stream, p, fl);
+    return hipGetLastError ();
+  }
   hipLaunchKernelGGL (k_v210_fast, dim3 ((v210_fast_groups (p) + 255) / 256, v210_fast_rows (p), nz), dim3 (256), 0, stream, p, fl);
   return hipGetLastError ();
 }

@@ -879,6 +879,12 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       vp.s[i] = src + in->offset[i], vp.sstride[i] = in->stride[i];
     for (int i = 0; i < out->n_planes && i < 3; i++)
       vp.d[i] = dst + out->offset[i], vp.dstride[i] = out->stride[i];
+    if (v210_fast_vec_ok (vp) && vec_ok) {          /* k_v210_fast_vec */
+      for (int r0 = 0; r0 < v210_fast_rows (vp); r0++)
+        for (int b0 = 0; b0 < (v210_fast_blocks (vp) + 63) / 64 * 64; b0++)
+          v210_fast_block (vp, b0, r0);
+      return GSTAMD_OK;
+    }
     for (int r0 = 0; r0 < v210_fast_rows (vp); r0++)
       for (int g0 = 0; g0 < (v210_fast_groups (vp) + 255) / 256 * 256; g0++)
         v210_fast_body (vp, g0, r0);

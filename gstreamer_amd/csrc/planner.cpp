@@ -113,6 +113,35 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_I422_10LE, "I422_10LE", true, false, 3, UNPACK_PLANAR, 1, 0, 1, 2, {0, 0, 0, 0}, 1},
   {GSTAMD_VIDEO_FORMAT_Y444_10LE, "Y444_10LE", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 1},
   // 16 bits per component, packed, native endianness (video-format.c:2426-2473, 2523-2570): the unpack formats of the 16-bit chain themselves
+  /* the big-endian forms of the word-plane formats (GST_READ_UINT16_BE / GST_WRITE_UINT16_BE around the same arithmetic): hi_depth code + 20 */
+  {GSTAMD_VIDEO_FORMAT_I420_10BE, "I420_10BE", true, false, 3, UNPACK_PLANAR, 1, 1, 1, 2, {0, 0, 0, 0}, 21},
+  {GSTAMD_VIDEO_FORMAT_I422_10BE, "I422_10BE", true, false, 3, UNPACK_PLANAR, 1, 0, 1, 2, {0, 0, 0, 0}, 21},
+  {GSTAMD_VIDEO_FORMAT_Y444_10BE, "Y444_10BE", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 21},
+  {GSTAMD_VIDEO_FORMAT_I420_12BE, "I420_12BE", true, false, 3, UNPACK_PLANAR, 1, 1, 1, 2, {0, 0, 0, 0}, 24},
+  {GSTAMD_VIDEO_FORMAT_I422_12BE, "I422_12BE", true, false, 3, UNPACK_PLANAR, 1, 0, 1, 2, {0, 0, 0, 0}, 24},
+  {GSTAMD_VIDEO_FORMAT_Y444_12BE, "Y444_12BE", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 24},
+  {GSTAMD_VIDEO_FORMAT_Y444_16BE, "Y444_16BE", true, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 26},
+  {GSTAMD_VIDEO_FORMAT_P010_10BE, "P010_10BE", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}, 22},
+  {GSTAMD_VIDEO_FORMAT_P012_BE, "P012_BE", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}, 25},
+  {GSTAMD_VIDEO_FORMAT_P016_BE, "P016_BE", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}, 26},
+  {GSTAMD_VIDEO_FORMAT_GBR_10BE, "GBR_10BE", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 21},
+  {GSTAMD_VIDEO_FORMAT_GBR_12BE, "GBR_12BE", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 24},
+  {GSTAMD_VIDEO_FORMAT_GBR_16BE, "GBR_16BE", false, false, 3, UNPACK_PLANAR, 0, 0, 1, 2, {0, 0, 0, 0}, 26},
+  {GSTAMD_VIDEO_FORMAT_GBRA_10BE, "GBRA_10BE", false, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}, 21},
+  {GSTAMD_VIDEO_FORMAT_GBRA_12BE, "GBRA_12BE", false, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}, 24},
+  {GSTAMD_VIDEO_FORMAT_A420_10BE, "A420_10BE", true, true, 4, UNPACK_PLANAR_A, 1, 1, 1, 2, {0, 0, 0, 0}, 21},
+  {GSTAMD_VIDEO_FORMAT_A422_10BE, "A422_10BE", true, true, 4, UNPACK_PLANAR_A, 1, 0, 1, 2, {0, 0, 0, 0}, 21},
+  {GSTAMD_VIDEO_FORMAT_A444_10BE, "A444_10BE", true, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}, 21},
+  {GSTAMD_VIDEO_FORMAT_A420_12BE, "A420_12BE", true, true, 4, UNPACK_PLANAR_A, 1, 1, 1, 2, {0, 0, 0, 0}, 24},
+  {GSTAMD_VIDEO_FORMAT_A422_12BE, "A422_12BE", true, true, 4, UNPACK_PLANAR_A, 1, 0, 1, 2, {0, 0, 0, 0}, 24},
+  {GSTAMD_VIDEO_FORMAT_A444_12BE, "A444_12BE", true, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}, 24},
+  {GSTAMD_VIDEO_FORMAT_A420_16BE, "A420_16BE", true, true, 4, UNPACK_PLANAR_A, 1, 1, 1, 2, {0, 0, 0, 0}, 26},
+  {GSTAMD_VIDEO_FORMAT_A422_16BE, "A422_16BE", true, true, 4, UNPACK_PLANAR_A, 1, 0, 1, 2, {0, 0, 0, 0}, 26},
+  {GSTAMD_VIDEO_FORMAT_A444_16BE, "A444_16BE", true, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}, 26},
+  {GSTAMD_VIDEO_FORMAT_Y212_BE, "Y212_BE", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 25},
+  {GSTAMD_VIDEO_FORMAT_Y216_BE, "Y216_BE", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 26},
+  {GSTAMD_VIDEO_FORMAT_Y412_BE, "Y412_BE", true, false, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 1, 0, 2}, 12},
+  {GSTAMD_VIDEO_FORMAT_Y416_BE, "Y416_BE", true, false, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 1, 0, 2}, 10},
   {GSTAMD_VIDEO_FORMAT_ARGB64, "ARGB64", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}, 3},
   /* the endian-specific 64-bit formats (video-format.c:2467-2815, table :8421-8436): ARGB64_LE is ARGB64 on this host (unpack_copy8), the others
      reorder and / or byte-swap the four words */
@@ -192,13 +221,20 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->offset[3] = info->offset[1] * 3;
       info->size = (uint64_t) info->stride[0] * h * 4;
       break;
+    case GSTAMD_VIDEO_FORMAT_A420_10BE:
     case GSTAMD_VIDEO_FORMAT_A420_10LE:
+    case GSTAMD_VIDEO_FORMAT_A420_12BE:
     case GSTAMD_VIDEO_FORMAT_A420_12LE:
+    case GSTAMD_VIDEO_FORMAT_A420_16BE:
     case GSTAMD_VIDEO_FORMAT_A420_16LE:
+    case GSTAMD_VIDEO_FORMAT_A422_10BE:
     case GSTAMD_VIDEO_FORMAT_A422_10LE:
+    case GSTAMD_VIDEO_FORMAT_A422_12BE:
     case GSTAMD_VIDEO_FORMAT_A422_12LE:
+    case GSTAMD_VIDEO_FORMAT_A422_16BE:
     case GSTAMD_VIDEO_FORMAT_A422_16LE: {      /* video-info.c:1256-1291 */
-      const bool v2 = format == GSTAMD_VIDEO_FORMAT_A420_10LE || format == GSTAMD_VIDEO_FORMAT_A420_12LE || format == GSTAMD_VIDEO_FORMAT_A420_16LE;
+      const bool v2 = format == GSTAMD_VIDEO_FORMAT_A420_10LE || format == GSTAMD_VIDEO_FORMAT_A420_12LE || format == GSTAMD_VIDEO_FORMAT_A420_16LE ||
+          format == GSTAMD_VIDEO_FORMAT_A420_10BE || format == GSTAMD_VIDEO_FORMAT_A420_12BE || format == GSTAMD_VIDEO_FORMAT_A420_16BE;
       const uint64_t h2 = (uint64_t) round_up (height, 2), ch = v2 ? h2 / 2 : h2;
       info->stride[0] = info->stride[3] = round_up (width * 2, 4);
       info->stride[1] = info->stride[2] = round_up (width, 4);
@@ -208,10 +244,15 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = info->offset[3] + (uint64_t) info->stride[0] * h2;
       break;
     }
+    case GSTAMD_VIDEO_FORMAT_A444_10BE:
     case GSTAMD_VIDEO_FORMAT_A444_10LE:
+    case GSTAMD_VIDEO_FORMAT_A444_12BE:
     case GSTAMD_VIDEO_FORMAT_A444_12LE:
+    case GSTAMD_VIDEO_FORMAT_A444_16BE:
     case GSTAMD_VIDEO_FORMAT_A444_16LE:
+    case GSTAMD_VIDEO_FORMAT_GBRA_10BE:
     case GSTAMD_VIDEO_FORMAT_GBRA_10LE:
+    case GSTAMD_VIDEO_FORMAT_GBRA_12BE:
     case GSTAMD_VIDEO_FORMAT_GBRA_12LE:        /* video-info.c:1189-1203, 1292-1308 */
       info->stride[0] = info->stride[1] = info->stride[2] = info->stride[3] = round_up (width * 2, 4);
       info->offset[1] = (uint64_t) info->stride[0] * h;
@@ -248,7 +289,9 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = info->offset[1] + info->stride[0] * cr_h;
       break;
     }
+    case GSTAMD_VIDEO_FORMAT_I420_12BE:
     case GSTAMD_VIDEO_FORMAT_I420_12LE:
+    case GSTAMD_VIDEO_FORMAT_I420_10BE:
     case GSTAMD_VIDEO_FORMAT_I420_10LE: {       /* video-info.c:1142-1156 */
       info->stride[0] = round_up (width * 2, 4);
       info->stride[1] = info->stride[2] = round_up (width, 4);
@@ -258,7 +301,9 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = info->offset[2] + info->stride[2] * cr_h;
       break;
     }
+    case GSTAMD_VIDEO_FORMAT_I422_12BE:
     case GSTAMD_VIDEO_FORMAT_I422_12LE:
+    case GSTAMD_VIDEO_FORMAT_I422_10BE:
     case GSTAMD_VIDEO_FORMAT_I422_10LE:         /* video-info.c:1157-1169 */
       info->stride[0] = round_up (width * 2, 4);
       info->stride[1] = info->stride[2] = round_up (width, 4);
@@ -266,19 +311,28 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->offset[2] = info->offset[1] + (uint64_t) info->stride[1] * round_up (height, 2);
       info->size = info->offset[2] + (uint64_t) info->stride[2] * round_up (height, 2);
       break;
+    case GSTAMD_VIDEO_FORMAT_GBR_10BE:
     case GSTAMD_VIDEO_FORMAT_GBR_10LE:
+    case GSTAMD_VIDEO_FORMAT_GBR_12BE:
     case GSTAMD_VIDEO_FORMAT_GBR_12LE:
+    case GSTAMD_VIDEO_FORMAT_GBR_16BE:
     case GSTAMD_VIDEO_FORMAT_GBR_16LE:
+    case GSTAMD_VIDEO_FORMAT_Y444_12BE:
     case GSTAMD_VIDEO_FORMAT_Y444_12LE:
+    case GSTAMD_VIDEO_FORMAT_Y444_16BE:
     case GSTAMD_VIDEO_FORMAT_Y444_16LE:
+    case GSTAMD_VIDEO_FORMAT_Y444_10BE:
     case GSTAMD_VIDEO_FORMAT_Y444_10LE:         /* video-info.c:1170-1188 */
       info->stride[0] = info->stride[1] = info->stride[2] = round_up (width * 2, 4);
       info->offset[1] = (uint64_t) info->stride[0] * h;
       info->offset[2] = info->offset[1] * 2;
       info->size = (uint64_t) info->stride[0] * h * 3;
       break;
+    case GSTAMD_VIDEO_FORMAT_P012_BE:
     case GSTAMD_VIDEO_FORMAT_P012_LE:
+    case GSTAMD_VIDEO_FORMAT_P016_BE:
     case GSTAMD_VIDEO_FORMAT_P016_LE:
+    case GSTAMD_VIDEO_FORMAT_P010_10BE:
     case GSTAMD_VIDEO_FORMAT_P010_10LE: {       /* video-info.c:1309-1321 */
       info->stride[0] = info->stride[1] = round_up (width * 2, 4);
       info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
@@ -309,7 +363,9 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = (uint64_t) info->stride[0] * h;
       break;
     case GSTAMD_VIDEO_FORMAT_Y210:
+    case GSTAMD_VIDEO_FORMAT_Y216_BE:
     case GSTAMD_VIDEO_FORMAT_Y216_LE:
+    case GSTAMD_VIDEO_FORMAT_Y212_BE:
     case GSTAMD_VIDEO_FORMAT_Y212_LE:           /* video-info.c:932-941 */
       info->stride[0] = round_up (width * 4, 8);
       info->size = (uint64_t) info->stride[0] * h;
@@ -334,7 +390,9 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->stride[0] = round_up (width * 2, 4);
       info->size = (uint64_t) info->stride[0] * h;
       break;
+    case GSTAMD_VIDEO_FORMAT_Y412_BE:
     case GSTAMD_VIDEO_FORMAT_Y412_LE:
+    case GSTAMD_VIDEO_FORMAT_Y416_BE:
     case GSTAMD_VIDEO_FORMAT_Y416_LE:
     case GSTAMD_VIDEO_FORMAT_ARGB64_LE:
     case GSTAMD_VIDEO_FORMAT_ARGB64_BE:
@@ -2269,7 +2327,8 @@ static void deep_planes_try (const GstAmdVideoInfo *in, const GstAmdVideoInfo *o
   GammaPlan &g = plan->gamma;
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   g.planes_fast = false;
-  if (!fi->yuv || !fo->yuv || !kind_has_planes (fi->kind) || !kind_has_planes (fo->kind) || fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub ||
+  if (!fi->yuv || !fo->yuv || !kind_has_planes (fi->kind) || !kind_has_planes (fo->kind) || hi_depth_be (fi->hi_depth) || hi_depth_be (fo->hi_depth) ||
+      fi->w_sub != fo->w_sub || fi->h_sub != fo->h_sub ||
       in->width != out->width || in->height != out->height || resampler || g.prim.has_matrix || g.alpha_kind != ALPHA_NONE || plan->rect.in_x ||
       plan->rect.in_y || (plan->rect.in_maxw && (plan->rect.in_maxw != in->width || plan->rect.in_maxh != in->height)))
     return;

@@ -69,6 +69,11 @@ inline bool format_plane_perm (int format, int perm[4])
     case GSTAMD_VIDEO_FORMAT_GBR_16LE:
     case GSTAMD_VIDEO_FORMAT_GBRA_10LE:
     case GSTAMD_VIDEO_FORMAT_GBRA_12LE:
+    case GSTAMD_VIDEO_FORMAT_GBR_10BE:
+    case GSTAMD_VIDEO_FORMAT_GBR_12BE:
+    case GSTAMD_VIDEO_FORMAT_GBR_16BE:
+    case GSTAMD_VIDEO_FORMAT_GBRA_10BE:
+    case GSTAMD_VIDEO_FORMAT_GBRA_12BE:
       perm[0] = 2, perm[1] = 0, perm[2] = 1;
       return true;
     case GSTAMD_VIDEO_FORMAT_BGRP:
@@ -94,7 +99,14 @@ inline void format_plan_planes (const FormatDesc *f, GstAmdVideoInfo *info)
 #define GSTAMD_VP inline
 #endif
 // significant bits of a sample for a FormatDesc::hi_depth code, and whether the format keeps its samples in 16-bit words in planes
-GSTAMD_VP int hi_depth_bits (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 ? 10 : (hi == 4 || hi == 5 || hi == 11 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 ? 16 : 8)); }
+// big-endian forms of the word-plane codes: code + 20 (21 / 24: 10 / 12 bits in the low bits, 22 / 25: in the high bits, 26: 16 bits); the 16-byte vector
+// kernels of the little-endian forms do not serve them (deep_front4_variant, planes_fast, k_encode16), the per-sample ones swap on the way
+GSTAMD_VP bool hi_depth_be (int hi) { return hi >= 20; }
+GSTAMD_VP int hi_depth_le (int hi) { return hi >= 20 ? hi - 20 : hi; }
+GSTAMD_VP int bswap16i (int v) { return ((v >> 8) | (v << 8)) & 0xffff; }
+GSTAMD_VP int hi_depth_bits_le (int hi);
+GSTAMD_VP int hi_depth_bits (int hi) { return hi_depth_bits_le (hi_depth_le (hi)); }
+GSTAMD_VP int hi_depth_bits_le (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 ? 10 : (hi == 4 || hi == 5 || hi == 11 || hi == 12 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 ? 16 : 8)); }
 // video_orc_unpack_RGB16 & co (video-orc.orc: mulhsw by 0x4200 / 0x2080 / 0x0210 = field * 8.25 or * 4.0625, floored): the field's bits replicated
 GSTAMD_VP int rgb16_field (int word, int shift, int bits) { const int f = (word >> shift) & ((1 << bits) - 1); return bits == 6 ? (f << 2) | (f >> 4) : (f << 3) | (f >> 2); }
 // video_orc_pack_RGB16_le & co: the top bits of every component at its field
@@ -102,9 +114,10 @@ GSTAMD_VP int rgb16_pack (const int *pos, int r, int g, int b) { return ((r >> 3
 // a stored 16-bit word of a UNPACK_PACKED64 / UNPACK_GRAY16 format -> its value (GST_READ_UINT16_LE / _BE; the same function stores)
 GSTAMD_VP int px16_word (int hi, int v) { return hi == 10 ? ((v >> 8) | (v << 8)) & 0xffff : v; }
 // hi_depth code 11 (Y412_LE): 12 bits in the high bits of a little-endian word - read: masked and widened (v | v >> 12), stored: masked
-GSTAMD_VP int px16_load (int hi, int v) { return hi == 11 ? (v & 0xfff0) | ((v & 0xfff0) >> 12) : px16_word (hi, v); }
-GSTAMD_VP int px16_store (int hi, int v) { return hi == 11 ? v & 0xfff0 : px16_word (hi, v); }
-GSTAMD_VP bool hi_depth_words (int hi) { return hi == 1 || hi == 2 || (hi >= 4 && hi <= 6); }
+// (code 12: the same big endian, Y412_BE)
+GSTAMD_VP int px16_load (int hi, int v) { if (hi == 12) v = bswap16i (v); return hi == 11 || hi == 12 ? (v & 0xfff0) | ((v & 0xfff0) >> 12) : px16_word (hi, v); }
+GSTAMD_VP int px16_store (int hi, int v) { return hi == 11 ? v & 0xfff0 : hi == 12 ? bswap16i (v & 0xfff0) : px16_word (hi, v); }
+GSTAMD_VP bool hi_depth_words (int hi) { hi = hi_depth_le (hi); return hi == 1 || hi == 2 || (hi >= 4 && hi <= 6); }
 const FormatDesc *format_desc (int format);
 
 // ---- device-consumable plan pieces (POD, passed to kernels by value) --------------------------
@@ -420,10 +433,11 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
   *hi = 0;
   auto s16 = [&](int c) -> uint32_t {
     const uint32_t v = (uint32_t) border[c] * 257u;
-    if (f->hi_depth == 3 || f->hi_depth == 6 || f->hi_depth == 9 || f->hi_depth == 10 || f->hi_depth == 11)
+    if (f->hi_depth == 3 || f->hi_depth == 6 || f->hi_depth == 9 || f->hi_depth == 10 || f->hi_depth == 11 || f->hi_depth == 12)
       return (uint32_t) px16_store (f->hi_depth, (int) v);
-    const int drop = 16 - hi_depth_bits (f->hi_depth);
-    return f->hi_depth == 1 || f->hi_depth == 4 ? v >> drop : v & ~((1u << drop) - 1u);
+    const int le = hi_depth_le (f->hi_depth), drop = 16 - hi_depth_bits (f->hi_depth);
+    const uint32_t w = le == 6 ? v : (le == 1 || le == 4 ? v >> drop : v & ~((1u << drop) - 1u));
+    return hi_depth_be (f->hi_depth) ? (uint32_t) bswap16i ((int) w) : w;
   };
   if (f->kind == UNPACK_PACKED422) {
     /* the unit is the macropixel (the planner admits borders on these formats only where no macropixel holds border and picture: even offsets, widths

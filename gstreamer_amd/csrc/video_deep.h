@@ -16,6 +16,10 @@ namespace gstamd {
 // 2 / 5 = in the high bits, 6 = all 16)
 GSTAMD_HD int deep_widen (int hi_depth, int v)
 {
+  if (hi_depth_be (hi_depth)) {           /* GST_READ_UINT16_BE, then the little-endian form's arithmetic */
+    v = bswap16i (v);
+    hi_depth = hi_depth_le (hi_depth);
+  }
   if (hi_depth == 6)
     return v;                           // P016_LE, Y444_16LE
   const int bits = hi_depth_bits (hi_depth);
@@ -101,7 +105,7 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
     /* unpack_Y210 (video-format.c:783-806): the pair loop widens Y0, U and V - not Y1, which keeps its low bits clear; the last pixel of an
        odd-width line is a Y0 */
     const int raw = ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[4 * (x >> 1) + f.pos[1] + 2 * (x & 1)];
-    c1 = (x & 1) ? raw : deep_widen (f.hi_depth, raw);
+    c1 = (x & 1) ? (hi_depth_be (f.hi_depth) ? bswap16i (raw) : raw) : deep_widen (f.hi_depth, raw);
   } else if (f.kind == UNPACK_Y410) {
     const uint32_t w = ((const uint32_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x];
     c1 = y410_field (w, f.pos[1]);
@@ -225,7 +229,7 @@ GSTAMD_HD UV deep_chroma_h4 (const FrontParams &f, const UV4 &s, int x0, int i)
 
 GSTAMD_HD bool deep_front4_usable (const FrontParams &f, int x0)
 {
-  return kind_has_planes (f.kind) && f.w_sub == 1 && (x0 & 3) == 0 && x0 + 4 <= f.width;
+  return kind_has_planes (f.kind) && !hi_depth_be (f.hi_depth) && f.w_sub == 1 && (x0 & 3) == 0 && x0 + 4 <= f.width;
 }
 
 GSTAMD_HD void deep_front4 (const FrontParams &f, const Planes &pl, const int *__restrict__ vpair, int x0, int y, uint2 *out)
@@ -444,7 +448,7 @@ GSTAMD_HD void deep_front4_t (const FrontParams &f, const Planes &pl, const int 
 // which instantiation serves a front (-1: none): planes with horizontally subsampled chroma, one of the three filters
 GSTAMD_VP int deep_front4_variant (const FrontParams &f)
 {
-  if (!kind_has_planes (f.kind) || f.w_sub != 1)
+  if (!kind_has_planes (f.kind) || f.w_sub != 1 || hi_depth_be (f.hi_depth))
     return -1;
   const int ch = f.chroma_h == CHROMA_H_NONE ? 0 : (f.chroma_h == CHROMA_H_H2 ? 1 : (f.chroma_h == CHROMA_H_H2_CS ? 2 : -1));
   return ch < 0 ? -1 : (f.kind == UNPACK_SEMI ? 3 : 0) + ch;
@@ -778,10 +782,15 @@ GSTAMD_HD int dither16_with (const DitherParams &d, int comp, int v, int b)
 
 GSTAMD_HD uint16_t pack16_sample (int hi_depth, int v)
 {
-  if (hi_depth == 6)
-    return (uint16_t) v;
-  const int drop = 16 - hi_depth_bits (hi_depth);
-  return (uint16_t) (hi_depth == 1 || hi_depth == 4 ? v >> drop : v & ~((1 << drop) - 1));      /* pack_I420_10LE >> 6, pack_P010_10LE & 0xffc0, ... */
+  const int le = hi_depth_le (hi_depth);
+  int w = v;
+  if (le != 6) {
+    const int drop = 16 - hi_depth_bits (hi_depth);
+    w = le == 1 || le == 4 ? v >> drop : v & ~((1 << drop) - 1);
+  }
+  if (hi_depth_be (hi_depth))
+    w = bswap16i (w);                     /* GST_WRITE_UINT16_BE */
+  return (uint16_t) w;      /* pack_I420_10LE >> 6, pack_P010_10LE & 0xffc0, ... */
 }
 
 GSTAMD_HD void pack16_chroma_h (const PackPlanarParams &pk, const uint2 *row, int w, int x, int *u, int *v);
@@ -1377,7 +1386,7 @@ inline bool enc16_params (const VideoPlan &p, Enc16Params *ep)
     return false;
   if (g.mid_in.width != g.mid_out.width || g.mid_in.height != g.mid_out.height || p.in_info.width != p.out_info.width || p.in_info.height != p.out_info.height)
     return false;
-  if ((g.pack.kind != UNPACK_PLANAR && g.pack.kind != UNPACK_SEMI) || g.pack.w_sub != 1 || (g.pack.width % 4) != 0 || g.pack.width < 4 || g.pack.virtual_line)
+  if ((g.pack.kind != UNPACK_PLANAR && g.pack.kind != UNPACK_SEMI) || hi_depth_be (g.pack_hi_depth) || g.pack.w_sub != 1 || (g.pack.width % 4) != 0 || g.pack.width < 4 || g.pack.virtual_line)
     return false;
   if (g.dither16.on && (g.dither16.method != GSTAMD_DITHER_BAYER || g.dither16.shift[1] != g.dither16.shift[2] || g.dither16.shift[1] != g.dither16.shift[3]))
     return false;

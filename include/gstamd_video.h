@@ -119,6 +119,35 @@ enum {
   GSTAMD_VIDEO_FORMAT_BGRA64_BE = 107,
   GSTAMD_VIDEO_FORMAT_ABGR64_LE = 108,
   GSTAMD_VIDEO_FORMAT_ABGR64_BE = 109,   /* Y210's layout with 12 bits */
+  /* big-endian forms of the 10 / 12 / 16-bit word formats (round 5) */
+  GSTAMD_VIDEO_FORMAT_I420_10BE = 42,
+  GSTAMD_VIDEO_FORMAT_I422_10BE = 44,
+  GSTAMD_VIDEO_FORMAT_Y444_10BE = 46,
+  GSTAMD_VIDEO_FORMAT_GBR_10BE = 49,
+  GSTAMD_VIDEO_FORMAT_A420_10BE = 54,
+  GSTAMD_VIDEO_FORMAT_A422_10BE = 56,
+  GSTAMD_VIDEO_FORMAT_A444_10BE = 58,
+  GSTAMD_VIDEO_FORMAT_P010_10BE = 61,
+  GSTAMD_VIDEO_FORMAT_GBRA_10BE = 66,
+  GSTAMD_VIDEO_FORMAT_GBR_12BE = 68,
+  GSTAMD_VIDEO_FORMAT_GBRA_12BE = 70,
+  GSTAMD_VIDEO_FORMAT_I420_12BE = 72,
+  GSTAMD_VIDEO_FORMAT_I422_12BE = 74,
+  GSTAMD_VIDEO_FORMAT_Y444_12BE = 76,
+  GSTAMD_VIDEO_FORMAT_Y444_16BE = 87,
+  GSTAMD_VIDEO_FORMAT_P016_BE = 89,
+  GSTAMD_VIDEO_FORMAT_P012_BE = 91,
+  GSTAMD_VIDEO_FORMAT_Y212_BE = 93,
+  GSTAMD_VIDEO_FORMAT_Y412_BE = 95,
+  GSTAMD_VIDEO_FORMAT_A444_12BE = 120,
+  GSTAMD_VIDEO_FORMAT_A422_12BE = 122,
+  GSTAMD_VIDEO_FORMAT_A420_12BE = 124,
+  GSTAMD_VIDEO_FORMAT_A444_16BE = 126,
+  GSTAMD_VIDEO_FORMAT_A422_16BE = 128,
+  GSTAMD_VIDEO_FORMAT_A420_16BE = 130,
+  GSTAMD_VIDEO_FORMAT_GBR_16BE = 132,
+  GSTAMD_VIDEO_FORMAT_Y216_BE = 135,
+  GSTAMD_VIDEO_FORMAT_Y416_BE = 137,
   GSTAMD_VIDEO_FORMAT_NV61 = 60,
   GSTAMD_VIDEO_FORMAT_P010_10LE = 62,   /* 10 bits in the high bits of little-endian 16-bit words */
   GSTAMD_VIDEO_FORMAT_VYUY = 64

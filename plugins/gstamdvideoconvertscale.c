@@ -38,7 +38,8 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #define AMD_OUT_FORMATS AMD_IN_FORMATS
 /* (RGBP / BGRP 1.20, RBGA / A422 / A444 / GBR_16LE / Y216_LE / Y416_LE later: taken together where the headers are the reference's own) */
 #if GST_CHECK_VERSION (1, 26, 0)
-#define AMD_NEWEST_FORMATS ", RGBP, BGRP, RBGA, A422, A444, GBR_16LE, Y216_LE, Y412_LE, Y416_LE, A420_12LE, A422_12LE, A444_12LE, A420_16LE, A422_16LE, A444_16LE"
+#define AMD_NEWEST_FORMATS ", RGBP, BGRP, RBGA, A422, A444, GBR_16LE, Y216_LE, Y412_LE, Y416_LE, A420_12LE, A422_12LE, A444_12LE, A420_16LE, A422_16LE, A444_16LE, " \
+    "I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE"
 #else
 #define AMD_NEWEST_FORMATS ""
 #endif
@@ -825,6 +826,34 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_Y216_LE, GSTAMD_VIDEO_FORMAT_Y216_LE}, {GST_VIDEO_FORMAT_Y412_LE, GSTAMD_VIDEO_FORMAT_Y412_LE}, {GST_VIDEO_FORMAT_Y416_LE, GSTAMD_VIDEO_FORMAT_Y416_LE},
     {GST_VIDEO_FORMAT_A420_12LE, GSTAMD_VIDEO_FORMAT_A420_12LE}, {GST_VIDEO_FORMAT_A422_12LE, GSTAMD_VIDEO_FORMAT_A422_12LE}, {GST_VIDEO_FORMAT_A444_12LE, GSTAMD_VIDEO_FORMAT_A444_12LE},
     {GST_VIDEO_FORMAT_A420_16LE, GSTAMD_VIDEO_FORMAT_A420_16LE}, {GST_VIDEO_FORMAT_A422_16LE, GSTAMD_VIDEO_FORMAT_A422_16LE}, {GST_VIDEO_FORMAT_A444_16LE, GSTAMD_VIDEO_FORMAT_A444_16LE},
+    {GST_VIDEO_FORMAT_I420_10BE, GSTAMD_VIDEO_FORMAT_I420_10BE},
+    {GST_VIDEO_FORMAT_I422_10BE, GSTAMD_VIDEO_FORMAT_I422_10BE},
+    {GST_VIDEO_FORMAT_Y444_10BE, GSTAMD_VIDEO_FORMAT_Y444_10BE},
+    {GST_VIDEO_FORMAT_I420_12BE, GSTAMD_VIDEO_FORMAT_I420_12BE},
+    {GST_VIDEO_FORMAT_I422_12BE, GSTAMD_VIDEO_FORMAT_I422_12BE},
+    {GST_VIDEO_FORMAT_Y444_12BE, GSTAMD_VIDEO_FORMAT_Y444_12BE},
+    {GST_VIDEO_FORMAT_Y444_16BE, GSTAMD_VIDEO_FORMAT_Y444_16BE},
+    {GST_VIDEO_FORMAT_P010_10BE, GSTAMD_VIDEO_FORMAT_P010_10BE},
+    {GST_VIDEO_FORMAT_P012_BE, GSTAMD_VIDEO_FORMAT_P012_BE},
+    {GST_VIDEO_FORMAT_P016_BE, GSTAMD_VIDEO_FORMAT_P016_BE},
+    {GST_VIDEO_FORMAT_GBR_10BE, GSTAMD_VIDEO_FORMAT_GBR_10BE},
+    {GST_VIDEO_FORMAT_GBR_12BE, GSTAMD_VIDEO_FORMAT_GBR_12BE},
+    {GST_VIDEO_FORMAT_GBR_16BE, GSTAMD_VIDEO_FORMAT_GBR_16BE},
+    {GST_VIDEO_FORMAT_GBRA_10BE, GSTAMD_VIDEO_FORMAT_GBRA_10BE},
+    {GST_VIDEO_FORMAT_GBRA_12BE, GSTAMD_VIDEO_FORMAT_GBRA_12BE},
+    {GST_VIDEO_FORMAT_A420_10BE, GSTAMD_VIDEO_FORMAT_A420_10BE},
+    {GST_VIDEO_FORMAT_A422_10BE, GSTAMD_VIDEO_FORMAT_A422_10BE},
+    {GST_VIDEO_FORMAT_A444_10BE, GSTAMD_VIDEO_FORMAT_A444_10BE},
+    {GST_VIDEO_FORMAT_A420_12BE, GSTAMD_VIDEO_FORMAT_A420_12BE},
+    {GST_VIDEO_FORMAT_A422_12BE, GSTAMD_VIDEO_FORMAT_A422_12BE},
+    {GST_VIDEO_FORMAT_A444_12BE, GSTAMD_VIDEO_FORMAT_A444_12BE},
+    {GST_VIDEO_FORMAT_A420_16BE, GSTAMD_VIDEO_FORMAT_A420_16BE},
+    {GST_VIDEO_FORMAT_A422_16BE, GSTAMD_VIDEO_FORMAT_A422_16BE},
+    {GST_VIDEO_FORMAT_A444_16BE, GSTAMD_VIDEO_FORMAT_A444_16BE},
+    {GST_VIDEO_FORMAT_Y212_BE, GSTAMD_VIDEO_FORMAT_Y212_BE},
+    {GST_VIDEO_FORMAT_Y216_BE, GSTAMD_VIDEO_FORMAT_Y216_BE},
+    {GST_VIDEO_FORMAT_Y412_BE, GSTAMD_VIDEO_FORMAT_Y412_BE},
+    {GST_VIDEO_FORMAT_Y416_BE, GSTAMD_VIDEO_FORMAT_Y416_BE},
 #endif
     {GST_VIDEO_FORMAT_RGB16, GSTAMD_VIDEO_FORMAT_RGB16}, {GST_VIDEO_FORMAT_BGR16, GSTAMD_VIDEO_FORMAT_BGR16},
     {GST_VIDEO_FORMAT_RGB15, GSTAMD_VIDEO_FORMAT_RGB15}, {GST_VIDEO_FORMAT_BGR15, GSTAMD_VIDEO_FORMAT_BGR15},

@@ -41,8 +41,13 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+_BE_OF = {"P010_10BE": "P010_10LE"}
+
+
 def visible_planes(fmt, w, h):
     """[(bytes per visible row, rows)] per plane of a frame (the bytes that belong to the picture, without stride padding)."""
+    if fmt.endswith("BE") and fmt not in ("GRAY16_BE",) and not fmt.endswith("64_BE"):        # a big-endian form has its little-endian form's planes
+        fmt = _BE_OF.get(fmt, fmt[:-2] + "LE")
     up2 = lambda v: (v + 1) // 2
     if fmt in ("I420", "YV12"):
         return [(w, h), (up2(w), up2(h)), (up2(w), up2(h))]
@@ -1213,6 +1218,33 @@ def _round5_alpha16_sweep():
 
 
 VIDEO_CASES += _round5_alpha16_sweep()
+
+
+# the big-endian forms of the word-plane formats (hi_depth code + 20: the per-sample kernels swap on the way, the 16-byte kernels of the little-endian
+# forms step aside) and Y412_BE / Y416_BE
+def _round5_be_sweep():
+    out = []
+    for f in ("I420_10BE", "I422_10BE", "Y444_10BE", "I420_12BE", "I422_12BE", "Y444_12BE", "Y444_16BE", "P010_10BE", "P012_BE", "P016_BE", "GBR_10BE", "GBR_12BE", "GBR_16BE",
+              "GBRA_10BE", "GBRA_12BE", "A420_10BE", "A422_10BE", "A444_10BE", "A420_12BE", "A422_12BE", "A444_12BE", "A420_16BE", "A422_16BE", "A444_16BE", "Y212_BE", "Y216_BE",
+              "Y412_BE", "Y416_BE"):
+        n = f.lower()
+        le = "P010_10LE" if f == "P010_10BE" else f[:-2] + "LE"
+        out += [
+            ("r5b_%s_bgra_38x8" % n, f, 38, 8, "BGRA", 38, 8, {}, None, None, "random"),
+            ("r5b_bgra_%s_40x6" % n, "BGRA", 40, 6, f, 40, 6, {}, None, None, "random"),
+            ("r5b_nv12_%s_up_bilinear" % n, "NV12", 64, 36, f, 100, 50, LIN, None, None, "random"),
+            ("r5b_%s_i420_10le_down_lanczos" % n, f, 64, 36, "I420_10LE", 32, 20, LAN, None, None, "random"),
+            ("r5b_%s_self" % n, f, 64, 36, f, 64, 36, {}, None, None, "random"),
+            ("r5b_%s_to_le" % n, f, 64, 36, le, 64, 36, {}, None, None, "random"),
+            ("r5b_le_to_%s" % n, le, 64, 36, f, 64, 36, {}, None, None, "random"),
+            ("r5b_%s_self_crop_dest_border" % n, f, 48, 30, f, 60, 40, dict(src_x=4, src_y=2, src_width=30, src_height=20, dest_x=8, dest_y=10, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+            ("r5b_bgra_%s_sierra_q128" % n, "BGRA", 36, 19, f, 36, 19, dict(dither_method="sierra-lite", dither_quantization=128), None, None, "random"),
+            ("r5b_%s_bgra_gamma_remap" % n, f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709" if f[0] == "G" else "bt709>sRGB", None, "random"),
+        ]
+    return out
+
+
+VIDEO_CASES += _round5_be_sweep()
 
 # the reference's own v210 fastpaths between v210 and the 8-bit 4:2:0 / 4:2:2 formats (video_v210_fast.h): samples shifted, not widened; group tails
 # (widths 6 k + 1 .. 5), the odd last line of a 4:2:0 frame, one-pixel frames

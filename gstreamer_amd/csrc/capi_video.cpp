@@ -67,6 +67,7 @@ struct GstAmdVideoConverter {
   uint8_t *pre_img = nullptr;             // enlarging from a planar / packed 4:2:2 source: the source frame after front + colour stage, at its own size
   size_t pre_img_size = 0;
   uint8_t *pk_img = nullptr;              // planar destinations: the chain's AYUV image before chroma downsample + pack
+  int pk_img_frames = 1;                  // ... as many of them, one behind the other, as a frame list may use at once (video_frame_list_scratch)
   TileGeom geom[2] = {{0, 0}, {0, 0}};   // wave-tile geometry of the horizontal passes
   bool reg420 = false;                    // first pass horizontal from a 4:2:0 source whose chroma pairing is the closed form of h420r_rows
   int reg_lo = 0, reg_hi = 0;
@@ -111,6 +112,7 @@ struct GstAmdVideoConverter {
     uint8_t *tmp, *plane_tmp, *pk_img, *deep_a, *deep_b, *gamma_mid_a, *gamma_mid_b, *pre_img;
     void *ed_carry;
     size_t deep_a_size, deep_b_size, pre_img_size;
+    int pk_img_frames;
   };
   bool bound = false;
   void *bound_stream = nullptr;
@@ -612,6 +614,7 @@ static int alloc_scratch (GstAmdVideoConverter *c)
   if (p.out_planar) {
     if ((e = hipMalloc ((void **) &c->pk_img, (size_t) p.out_info.width * 4 * (p.out_info.height + 1))) != hipSuccess)      /* + the line past the picture */
       return hip_fail (e, "hipMalloc(pack image)");
+    c->pk_img_frames = 1;
   }
   {
     const DitherParams &dp = p.gamma.on && (p.gamma.pack16 || p.gamma.store64) ? p.gamma.dither16 : (p.out_planar ? p.pack.dither : p.dither);
@@ -622,10 +625,14 @@ static int alloc_scratch (GstAmdVideoConverter *c)
   return GSTAMD_OK;
 }
 
+// bytes of one pack image inside a list of them: the image (+ the line past the picture), rounded so that every image starts on the alignment of the first
+static size_t pk_img_bytes (const VideoPlan &p) { return (((size_t) p.out_info.width * 4 * (size_t) (p.out_info.height + 1)) + 255) & ~(size_t) 255; }
+
 static GstAmdVideoConverter::ScratchSet take_scratch (GstAmdVideoConverter *c)
 {
   GstAmdVideoConverter::ScratchSet s = {c->tmp, c->plane_tmp, c->pk_img, c->deep_a, c->deep_b, c->gamma_mid_a, c->gamma_mid_b, c->pre_img, c->ed_carry,
-    c->deep_a_size, c->deep_b_size, c->pre_img_size};
+    c->deep_a_size, c->deep_b_size, c->pre_img_size, c->pk_img_frames};
+  c->pk_img_frames = 1;
   c->tmp = c->plane_tmp = c->pk_img = c->deep_a = c->deep_b = c->gamma_mid_a = c->gamma_mid_b = c->pre_img = nullptr;
   c->ed_carry = nullptr;
   c->deep_a_size = c->deep_b_size = c->pre_img_size = 0;
@@ -637,6 +644,7 @@ static void put_scratch (GstAmdVideoConverter *c, const GstAmdVideoConverter::Sc
   c->tmp = s.tmp, c->plane_tmp = s.plane_tmp, c->pk_img = s.pk_img, c->deep_a = s.deep_a, c->deep_b = s.deep_b;
   c->gamma_mid_a = s.gamma_mid_a, c->gamma_mid_b = s.gamma_mid_b, c->ed_carry = s.ed_carry, c->pre_img = s.pre_img;
   c->deep_a_size = s.deep_a_size, c->deep_b_size = s.deep_b_size, c->pre_img_size = s.pre_img_size;
+  c->pk_img_frames = s.pk_img_frames;
 }
 
 static void free_scratch (GstAmdVideoConverter::ScratchSet &s)
@@ -1957,12 +1965,32 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
      dimension): frame `base` is converted with the list of up to 32 frames behind it armed; the launcher says whether it took the list */
   int base = 0;
   if (!p.rect.fill && !p.dither.on && (!p.gamma.on || p.gamma.planes_fast || enc16_list)) {
+    /* a plan that scales into the pack image and packs from it with list-taking kernels (k_plane_quad + k_encode420 / k_convert_pack: raw4_pack) gets
+       one image per frame of the list - up to 1 GiB of them - so that both launches take the list */
+    if (c->raw4_pack && c->pk_img && !c->hook_on) {
+      const size_t per = pk_img_bytes (p);
+      const int want = (int) std::min<size_t> ((size_t) std::min (n_frames, 32), std::max<size_t> (1, ((size_t) 1 << 30) / per));
+      if (want > c->pk_img_frames) {
+        uint8_t *bigger = nullptr;
+        if (hipMalloc ((void **) &bigger, per * (size_t) want) == hipSuccess) {
+          (void) hipStreamSynchronize ((hipStream_t) stream_);          /* nothing of this stream reads the old image any more */
+          (void) hipFree (c->pk_img);
+          c->pk_img = bigger;
+          c->pk_img_frames = want;
+        } else
+          (void) hipGetLastError ();
+      }
+    }
     while (n_frames - base >= 2) {
-      const int nb = std::min (n_frames - base, 32);
+      int nb = std::min (n_frames - base, 32);
+      if (c->raw4_pack && c->pk_img && c->pk_img_frames > 1)
+        nb = std::min (nb, c->pk_img_frames);
       for (int i = 0; i < nb; i++)
         if (!src[base + i] || !dest[base + i])
           return set_error (GSTAMD_ERR_INVALID, "NULL frame in list");
       video_frame_list_begin (nb, src + base, dest + base, p.in_info.size, p.out_info.size);
+      if (c->pk_img && c->pk_img_frames >= nb)
+        video_frame_list_scratch (c->pk_img, pk_img_bytes (p));
       r = gstamd_video_converter_frame (c, src[base], dest[base], stream_);
       const int used = video_frame_list_end ();
       if (r != GSTAMD_OK)

@@ -92,6 +92,7 @@ bool swizzle34_setup (int src_bytes, const int *src_pos, int dst_bytes, const in
 hipError_t launch_swizzle34 (const Swz34Params &p, int src_bytes, int dst_bytes, int height, hipStream_t stream);
 /* frame lists for single-kernel plans (video_kernels.hip) */
 void video_frame_list_begin (int n, const void *const *src, void *const *dst, size_t src_size, size_t dst_size);
+void video_frame_list_scratch (const void *p, size_t per_frame);
 int video_frame_list_end ();
 void video_frame_list_touch (const void *dp);
 hipError_t launch_pack16_alpha_plane (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *src, int sstride, uint8_t *plane, int stride,

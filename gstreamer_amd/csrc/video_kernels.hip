@@ -52,6 +52,10 @@ struct FrameListCtx {
   const uint8_t *src0 = nullptr, *dst0 = nullptr;
   size_t src_size = 0, dst_size = 0;
   FrameDeltas fd;
+  /* a scratch image between two list-taking kernels of a plan (video_frame_list_scratch): frame i's copy sits i * scr_stride behind frame 0's */
+  const uint8_t *scr0 = nullptr;
+  size_t scr_stride = 0;
+  FrameDeltas tmp;
 };
 thread_local FrameListCtx g_frame_list;
 }
@@ -64,11 +68,20 @@ void video_frame_list_begin (int n, const void *const *src, void *const *dst, si
   c.mixed = false;
   c.src0 = (const uint8_t *) src[0], c.dst0 = (const uint8_t *) dst[0];
   c.src_size = src_size, c.dst_size = dst_size;
+  c.scr0 = nullptr, c.scr_stride = 0;
   memset (&c.fd, 0, sizeof (c.fd));
   for (int i = 0; c.armed && i < n; i++) {
     c.fd.s[i] = (long long) ((const uint8_t *) src[i] - c.src0);
     c.fd.d[i] = (long long) ((const uint8_t *) dst[i] - c.dst0);
   }
+}
+// The plan's scratch image `p` exists once per frame of the armed list, per_frame bytes apart: a list-taking kernel that writes it (or reads it) is
+// rebased frame by frame like one that touches the frames themselves - a two-kernel plan (scale into the image, pack from it) serves the list in two launches.
+void video_frame_list_scratch (const void *p, size_t per_frame)
+{
+  FrameListCtx &c = g_frame_list;
+  if (c.armed)
+    c.scr0 = (const uint8_t *) p, c.scr_stride = per_frame;
 }
 int video_frame_list_end ()
 {
@@ -84,7 +97,7 @@ void video_frame_list_touch (const void *dp)
 {
   FrameListCtx &c = g_frame_list;
   const uint8_t *d8 = (const uint8_t *) dp;
-  if (c.armed && d8 >= c.dst0 && d8 < c.dst0 + c.dst_size)
+  if (c.armed && ((d8 >= c.dst0 && d8 < c.dst0 + c.dst_size) || (c.scr0 && d8 >= c.scr0 && d8 < c.scr0 + c.scr_stride)))
     c.mixed = true;
 }
 // the list for a launch whose source / destination pointers are sp / dp (NULL: not a frame's plane, or no list): *nz = frames
@@ -96,11 +109,25 @@ static const FrameDeltas &frame_list_for (const void *sp, const void *dp, int *n
   if (!c.armed)
     return none;
   const uint8_t *s8 = (const uint8_t *) sp, *d8 = (const uint8_t *) dp;
-  if (s8 < c.src0 || s8 >= c.src0 + c.src_size || d8 < c.dst0 || d8 >= c.dst0 + c.dst_size)
-    return none;
-  c.used++;
-  *nz = c.n;
-  return c.fd;
+  const bool s_frame = s8 >= c.src0 && s8 < c.src0 + c.src_size, d_frame = d8 >= c.dst0 && d8 < c.dst0 + c.dst_size;
+  const bool s_scr = c.scr0 && s8 >= c.scr0 && s8 < c.scr0 + c.scr_stride, d_scr = c.scr0 && d8 >= c.scr0 && d8 < c.scr0 + c.scr_stride;
+  if (s_frame && d_frame) {
+    c.used++;
+    *nz = c.n;
+    return c.fd;
+  }
+  if ((s_frame && d_scr) || (s_scr && d_frame)) {          /* frame -> scratch image, scratch image -> frame */
+    for (int i = 0; i < c.n; i++) {
+      c.tmp.s[i] = s_frame ? c.fd.s[i] : (long long) (i * c.scr_stride);
+      c.tmp.d[i] = d_frame ? c.fd.d[i] : (long long) (i * c.scr_stride);
+    }
+    c.used++;
+    *nz = c.n;
+    return c.tmp;
+  }
+  if (d_scr || d_frame)
+    c.mixed = true;             /* a kernel that writes frame 0's picture or scratch image and cannot be rebased: the list is not served by launches alone */
+  return none;
 }
 #define GSTAMD_FRAME_Z const long long fls_ = fl.s[blockIdx.z], fld_ = fl.d[blockIdx.z]
 

@@ -66,7 +66,12 @@ static const FormatDesc g_formats[] = {
   // Y410 stores two bits of alpha but is declared without GST_VIDEO_FORMAT_FLAG_ALPHA (MAKE_YUV_FORMAT :8380): the alpha options pass it by
   {GSTAMD_VIDEO_FORMAT_Y210, "Y210", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 2},
   {GSTAMD_VIDEO_FORMAT_Y212_LE, "Y212_LE", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 5},
-  {GSTAMD_VIDEO_FORMAT_Y216_LE, "Y216_LE", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 6},          /* unpack_Y216_LE video-format.c:7181 */
+  {GSTAMD_VIDEO_FORMAT_Y216_LE, "Y216_LE", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 0, 1, 3}, 6},
+  {GSTAMD_VIDEO_FORMAT_v216, "v216", true, false, 1, UNPACK_P422_16, 1, 0, 0, 0, {0, 1, 0, 2}, 6},          /* unpack_v216 video-format.c: words U Y0 V Y1 */
+  /* unpack_r210: one BIG-endian 32-bit word per pixel, x 2, R 10, G 10, B 10 - Y410's kind with hi_depth code 27 (word swapped, no alpha bits) */
+  {GSTAMD_VIDEO_FORMAT_r210, "r210", false, false, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 20, 10, 0}, 27},
+  /* unpack_GRAY10_LE16: 10 bits in the low bits of little-endian words */
+  {GSTAMD_VIDEO_FORMAT_GRAY10_LE16, "GRAY10_LE16", true, false, 1, UNPACK_GRAY16, 0, 0, 0, 0, {0, 0, 0, 0}, 1},          /* unpack_Y216_LE video-format.c:7181 */
   /* unpack_Y412_LE :7323 (12 bits in the high bits, widened by v | v >> 12), unpack_Y416_LE :7430: words U Y V A; like Y410 their alpha word is a
      component the format flags do not declare (MAKE_YUV_LE_FORMAT :8407, 8495) */
   {GSTAMD_VIDEO_FORMAT_Y412_LE, "Y412_LE", true, false, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 1, 0, 2}, 11},
@@ -363,6 +368,7 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = (uint64_t) info->stride[0] * h;
       break;
     case GSTAMD_VIDEO_FORMAT_Y210:
+    case GSTAMD_VIDEO_FORMAT_v216:
     case GSTAMD_VIDEO_FORMAT_Y216_BE:
     case GSTAMD_VIDEO_FORMAT_Y216_LE:
     case GSTAMD_VIDEO_FORMAT_Y212_BE:
@@ -385,6 +391,7 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
     case GSTAMD_VIDEO_FORMAT_BGR16:
     case GSTAMD_VIDEO_FORMAT_RGB15:
     case GSTAMD_VIDEO_FORMAT_BGR15:             /* video-info.c:911-918 */
+    case GSTAMD_VIDEO_FORMAT_GRAY10_LE16:
     case GSTAMD_VIDEO_FORMAT_GRAY16_LE:
     case GSTAMD_VIDEO_FORMAT_GRAY16_BE:         /* video-info.c:947-952 */
       info->stride[0] = round_up (width * 2, 4);
@@ -1992,7 +1999,7 @@ static void setup_dither16 (const GstAmdVideoConverterConfig &cfg, const FormatD
   /* the planar formats have no alpha component (depth 0: quantiser 0); ARGB64 / AYUV64 carry 16 bits of it like the other three - their own
      quantiser is 1, so a stage only exists for dither-quantization > 1, run as a pass over the finished frame (k_dither16_image) */
   d->shift[0] = fo->hi_depth == 3 || fo->kind == UNPACK_PACKED64 || fo->kind == UNPACK_PLANAR_A ? shift : 0;
-  if (fo->kind == UNPACK_Y410) {          /* 2 bits of alpha: quantiser 1 << 14 (chain_dither :2060-2075 per component depth) */
+  if (fo->kind == UNPACK_Y410 && fo->hi_depth != 27) {          /* 2 bits of alpha: quantiser 1 << 14 (chain_dither :2060-2075 per component depth) */
     unsigned qa = 1u << 14;
     if (cfg.dither_quantization > qa)
       qa = cfg.dither_quantization;

@@ -447,10 +447,14 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
     m[f->pos[1]] = m[f->pos[1] + 2] = border[1], m[f->pos[2]] = border[2], m[f->pos[3]] = border[3];
     *es = 4, *lo = (uint32_t) m[0] | ((uint32_t) m[1] << 8) | ((uint32_t) m[2] << 16) | ((uint32_t) m[3] << 24);
   } else if (f->kind == UNPACK_P422_16) {
-    *es = 8, *lo = s16 (1) | (s16 (2) << 16), *hi = s16 (1) | (s16 (3) << 16);          /* pack_Y210: Y0 U Y1 V, 16 bits each */
+    uint32_t w[4] = {0, 0, 0, 0};               /* pack_Y210: words Y0 U Y1 V; pack_v216: U Y0 V Y1 */
+    w[f->pos[1]] = w[f->pos[1] + 2] = s16 (1), w[f->pos[2]] = s16 (2), w[f->pos[3]] = s16 (3);
+    *es = 8, *lo = w[0] | (w[1] << 16), *hi = w[2] | (w[3] << 16);
   } else if (f->kind == UNPACK_Y410) {            /* pack_Y410 (video-format.c:898-921) of the widened border */
     const uint32_t a = (uint32_t) border[0] * 257u, y = (uint32_t) border[1] * 257u, u = (uint32_t) border[2] * 257u, v = (uint32_t) border[3] * 257u;
-    *es = 4, *lo = ((y >> 6) << f->pos[1]) | ((u >> 6) << f->pos[2]) | ((v >> 6) << f->pos[3]) | ((a & 0xc000u) << 16);
+    *es = 4, *lo = ((y >> 6) << f->pos[1]) | ((u >> 6) << f->pos[2]) | ((v >> 6) << f->pos[3]) | (f->hi_depth == 27 ? 0u : (a & 0xc000u) << 16);
+    if (f->hi_depth == 27)        /* r210: the word big endian */
+      *lo = (*lo >> 24) | ((*lo >> 8) & 0xff00u) | ((*lo << 8) & 0xff0000u) | (*lo << 24);
   } else if (f->kind == UNPACK_GRAY16) {
     *es = 2, *lo = s16 (1);
   } else if (f->kind == UNPACK_RGB16) {

@@ -30,6 +30,12 @@ GSTAMD_HD int deep_widen (int hi_depth, int v)
   return v | (v >> bits);               // P010_10LE / P012_LE: value in the high bits
 }
 
+// the stored word of a UNPACK_Y410 format as the little-endian one the fields are cut from (hi_depth 27, r210: GST_READ_UINT32_BE)
+GSTAMD_HD uint32_t y410_word (int hi_depth, uint32_t w)
+{
+  return hi_depth == 27 ? (w >> 24) | ((w >> 8) & 0xff00u) | ((w << 8) & 0xff0000u) | (w << 24) : w;
+}
+
 // one 10-bit field of a Y410 word (unpack_Y410 video-format.c:863-896): (field << 6) | (field >> 4)
 GSTAMD_HD int y410_field (uint32_t w, int shift)
 {
@@ -45,7 +51,7 @@ GSTAMD_HD UV deep_load_uv (const FrontParams &f, const Planes &pl, int crow, int
     r.u = deep_widen (f.hi_depth, p[f.pos[2]]);
     r.v = deep_widen (f.hi_depth, p[f.pos[3]]);
   } else if (f.kind == UNPACK_Y410) {
-    const uint32_t w = ((const uint32_t *) (pl.p[0] + (ptrdiff_t) crow * pl.stride[0]))[k];
+    const uint32_t w = y410_word (f.hi_depth, ((const uint32_t *) (pl.p[0] + (ptrdiff_t) crow * pl.stride[0]))[k]);
     r.u = y410_field (w, f.pos[2]);          /* FormatDesc::pos of these formats: bit of the 10-bit field of component c1, c2, c3 */
     r.v = y410_field (w, f.pos[3]);
   } else if (f.kind == UNPACK_PACKED64) { // unpack_RGBA64_LE & co (video-format.c:2470-2815): word pos[c] of the pixel, read little / big endian
@@ -107,16 +113,17 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
     const int raw = ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[4 * (x >> 1) + f.pos[1] + 2 * (x & 1)];
     c1 = (x & 1) ? (hi_depth_be (f.hi_depth) ? bswap16i (raw) : raw) : deep_widen (f.hi_depth, raw);
   } else if (f.kind == UNPACK_Y410) {
-    const uint32_t w = ((const uint32_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x];
+    const uint32_t w = y410_word (f.hi_depth, ((const uint32_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
     c1 = y410_field (w, f.pos[1]);
     const int t = (int) (w >> 30) << 14;                /* A: two bits, A |= A >> 10 */
-    a = t | (t >> 10);
+    a = f.hi_depth == 27 ? 0xffff : t | (t >> 10);       /* (r210 has none) */
   } else if (f.kind == UNPACK_PACKED64) {
     const uint16_t *p = (const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]) + 4 * x;
     c1 = px16_load (f.hi_depth, p[f.pos[1]]);
     a = px16_load (f.hi_depth, p[f.pos[0]]);
   } else if (f.kind == UNPACK_GRAY16) {
-    c1 = px16_word (f.hi_depth, ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
+    const int raw = ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x];
+    c1 = f.hi_depth == 9 || f.hi_depth == 10 ? px16_word (f.hi_depth, raw) : deep_widen (f.hi_depth, raw);         /* GRAY16_LE / _BE, GRAY10_LE16 */
   } else if (f.kind == UNPACK_V210) {   // luma j of the group: words 0 1 1 2 3 3 at bit 10 0 20 10 0 20
     const uint32_t *g = (const uint32_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]) + 4 * (x / 6);
     const int j = x % 6;
@@ -1018,18 +1025,20 @@ GSTAMD_HD void pack16_packed_body (const PackPlanarParams &pk, int hi_depth, con
     const uint32_t u = (uint32_t) dither16_comp (dt, 2, (int) (px.y & 0xffffu), unit, y) & 0xffc0u;
     const uint32_t v = (uint32_t) dither16_comp (dt, 3, (int) (px.y >> 16), unit, y) & 0xffc0u;
     /* pack_Y410 / pack_rgb10a2_le / pack_bgr10a2_le (video-format.c:898-921, 6243-6330): the top ten bits of each component at its field */
-    ((uint32_t *) (dst + (size_t) y * dstride))[unit] = ((yy >> 6) << pk.pos[1]) | ((u >> 6) << pk.pos[2]) | ((v >> 6) << pk.pos[3]) | (a << 16);
+    const uint32_t word = ((yy >> 6) << pk.pos[1]) | ((u >> 6) << pk.pos[2]) | ((v >> 6) << pk.pos[3]) | (hi_depth == 27 ? 0u : a << 16);         /* (pack_r210 leaves the top two bits 0) */
+    ((uint32_t *) (dst + (size_t) y * dstride))[unit] = y410_word (hi_depth, word);
     return;
   }
   if (pk.kind == UNPACK_PACKED64 || pk.kind == UNPACK_GRAY16) {
     /* pack_RGBA64_LE & co (video-format.c:2548-2815), pack_GRAY16_LE / _BE (:1250-1299): the components' 16 bits at their words, in the format's
        byte order */
     const uint2 px = row[unit];
-    const int yy = px16_store (hi_depth, dither16_comp (dt, 1, (int) (px.x >> 16), unit, y));
     if (pk.kind == UNPACK_GRAY16) {
-      ((uint16_t *) (dst + (size_t) y * dstride))[unit] = (uint16_t) yy;
+      const int yd = dither16_comp (dt, 1, (int) (px.x >> 16), unit, y);
+      ((uint16_t *) (dst + (size_t) y * dstride))[unit] = hi_depth == 9 || hi_depth == 10 ? (uint16_t) px16_word (hi_depth, yd) : pack16_sample (hi_depth, yd);
       return;
     }
+    const int yy = px16_store (hi_depth, dither16_comp (dt, 1, (int) (px.x >> 16), unit, y));
     uint16_t *d = (uint16_t *) (dst + (size_t) y * dstride) + 4 * unit;
     d[pk.pos[0]] = (uint16_t) px16_store (hi_depth, dither16_comp (dt, 0, (int) (px.x & 0xffffu), unit, y));
     d[pk.pos[1]] = (uint16_t) yy;

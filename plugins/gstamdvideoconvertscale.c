@@ -39,7 +39,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 /* (RGBP / BGRP 1.20, RBGA / A422 / A444 / GBR_16LE / Y216_LE / Y416_LE later: taken together where the headers are the reference's own) */
 #if GST_CHECK_VERSION (1, 26, 0)
 #define AMD_NEWEST_FORMATS ", RGBP, BGRP, RBGA, A422, A444, GBR_16LE, Y216_LE, Y412_LE, Y416_LE, A420_12LE, A422_12LE, A444_12LE, A420_16LE, A422_16LE, A444_16LE, " \
-    "I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE"
+    "GRAY10_LE16, I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE"
 #else
 #define AMD_NEWEST_FORMATS ""
 #endif
@@ -52,7 +52,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #else
 #define AMD_NEWER_FORMATS ""
 #endif
-#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210, v216, r210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
 
 /* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path
  * (video-converter.c:3304, 3383-3463), so interlaced caps are not negotiated rather than converted as if progressive
@@ -818,6 +818,7 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_A420, GSTAMD_VIDEO_FORMAT_A420}, {GST_VIDEO_FORMAT_GBRA, GSTAMD_VIDEO_FORMAT_GBRA},
     {GST_VIDEO_FORMAT_GBR_10LE, GSTAMD_VIDEO_FORMAT_GBR_10LE}, {GST_VIDEO_FORMAT_GBR_12LE, GSTAMD_VIDEO_FORMAT_GBR_12LE},
     {GST_VIDEO_FORMAT_GBRA_10LE, GSTAMD_VIDEO_FORMAT_GBRA_10LE}, {GST_VIDEO_FORMAT_GBRA_12LE, GSTAMD_VIDEO_FORMAT_GBRA_12LE},
+    {GST_VIDEO_FORMAT_v216, GSTAMD_VIDEO_FORMAT_v216}, {GST_VIDEO_FORMAT_r210, GSTAMD_VIDEO_FORMAT_r210},
     {GST_VIDEO_FORMAT_A420_10LE, GSTAMD_VIDEO_FORMAT_A420_10LE}, {GST_VIDEO_FORMAT_A422_10LE, GSTAMD_VIDEO_FORMAT_A422_10LE},
     {GST_VIDEO_FORMAT_A444_10LE, GSTAMD_VIDEO_FORMAT_A444_10LE},
 #if GST_CHECK_VERSION (1, 26, 0)
@@ -826,6 +827,7 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_Y216_LE, GSTAMD_VIDEO_FORMAT_Y216_LE}, {GST_VIDEO_FORMAT_Y412_LE, GSTAMD_VIDEO_FORMAT_Y412_LE}, {GST_VIDEO_FORMAT_Y416_LE, GSTAMD_VIDEO_FORMAT_Y416_LE},
     {GST_VIDEO_FORMAT_A420_12LE, GSTAMD_VIDEO_FORMAT_A420_12LE}, {GST_VIDEO_FORMAT_A422_12LE, GSTAMD_VIDEO_FORMAT_A422_12LE}, {GST_VIDEO_FORMAT_A444_12LE, GSTAMD_VIDEO_FORMAT_A444_12LE},
     {GST_VIDEO_FORMAT_A420_16LE, GSTAMD_VIDEO_FORMAT_A420_16LE}, {GST_VIDEO_FORMAT_A422_16LE, GSTAMD_VIDEO_FORMAT_A422_16LE}, {GST_VIDEO_FORMAT_A444_16LE, GSTAMD_VIDEO_FORMAT_A444_16LE},
+    {GST_VIDEO_FORMAT_GRAY10_LE16, GSTAMD_VIDEO_FORMAT_GRAY10_LE16},
     {GST_VIDEO_FORMAT_I420_10BE, GSTAMD_VIDEO_FORMAT_I420_10BE},
     {GST_VIDEO_FORMAT_I422_10BE, GSTAMD_VIDEO_FORMAT_I422_10BE},
     {GST_VIDEO_FORMAT_Y444_10BE, GSTAMD_VIDEO_FORMAT_Y444_10BE},

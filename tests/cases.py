@@ -87,11 +87,11 @@ def visible_planes(fmt, w, h):
         return [(2 * w, h)] * 3
     if fmt in ("P010_10LE", "P012_LE", "P016_LE"):
         return [(2 * w, h), (4 * up2(w), up2(h))]
-    if fmt in ("Y210", "Y212_LE", "Y216_LE"):
+    if fmt in ("Y210", "Y212_LE", "Y216_LE", "v216"):
         return [(8 * up2(w), h)]
     if fmt in ("ARGB64", "AYUV64", "Y412_LE", "Y416_LE") or fmt.endswith(("64_LE", "64_BE")):
         return [(8 * w, h)]
-    if fmt in ("GRAY16_LE", "GRAY16_BE", "RGB16", "BGR16", "RGB15", "BGR15"):
+    if fmt in ("GRAY16_LE", "GRAY16_BE", "RGB16", "BGR16", "RGB15", "BGR15", "GRAY10_LE16"):
         return [(2 * w, h)]
     if fmt == "GRAY8":
         return [(w, h)]
@@ -1245,6 +1245,19 @@ def _round5_be_sweep():
 
 
 VIDEO_CASES += _round5_be_sweep()
+
+# v216 (Y216's samples in U Y0 V Y1 order), r210 (Y410's kind on a big-endian word without alpha bits), GRAY10_LE16
+VIDEO_CASES += [c for f, col in (("v216", "bt709>sRGB"), ("r210", "sRGB>bt709"), ("GRAY10_LE16", "bt709>sRGB")) for c in (
+    ("r5m_%s_bgra_37x7" % f.lower(), f, 37, 7, "BGRA", 37, 7, {}, None, None, "random"),
+    ("r5m_bgra_%s_41x7" % f.lower(), "BGRA", 41, 7, f, 41, 7, {}, None, None, "random"),
+    ("r5m_%s_nv12" % f.lower(), f, 40, 6, "NV12", 40, 6, {}, None, None, "random"),
+    ("r5m_nv12_%s_up_bilinear" % f.lower(), "NV12", 64, 36, f, 100, 50, LIN, None, None, "random"),
+    ("r5m_%s_i420_10le_down_lanczos" % f.lower(), f, 64, 36, "I420_10LE", 32, 20, LAN, None, None, "random"),
+    ("r5m_%s_self_down_bilinear" % f.lower(), f, 64, 36, f, 32, 20, LIN, None, None, "random"),
+    ("r5m_argb64_%s_dest_border" % f.lower(), "ARGB64", 30, 20, f, 50, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+    ("r5m_%s_self_crop_dest_border" % f.lower(), f, 48, 30, f, 60, 40, dict(src_x=4, src_y=2, src_width=30, src_height=20, dest_x=8, dest_y=10, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+    ("r5m_bgra_%s_sierra_q128" % f.lower(), "BGRA", 36, 19, f, 36, 19, dict(dither_method="sierra-lite", dither_quantization=128), None, None, "random"),
+    ("r5m_%s_bgra_gamma_remap" % f.lower(), f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), col, None, "random"))]
 
 # the reference's own v210 fastpaths between v210 and the 8-bit 4:2:0 / 4:2:2 formats (video_v210_fast.h): samples shifted, not widened; group tails
 # (widths 6 k + 1 .. 5), the odd last line of a 4:2:0 frame, one-pixel frames

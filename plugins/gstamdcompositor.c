@@ -64,7 +64,9 @@ GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
 /* what a pad may carry: anything the converter takes; it is brought to the output format / the pad's width x height by a
  * per-pad GstAmdVideoConverter (the reference's GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) */
 #define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, GRAY8, GBR, " \
-    "I420_10LE, I420_12LE, I422_10LE, I422_12LE, Y444_10LE, Y444_12LE, P010_10LE" AMD_COMP_NEWER_PADS " }"
+    "I420_10LE, I420_12LE, I422_10LE, I422_12LE, Y444_10LE, Y444_12LE, P010_10LE, " \
+    /* round 5: the converter's newer formats (those every supported runtime's headers know) - A420 first, the alpha-plane format WebM / VP8 alpha decodes to */ \
+    "A420, A420_10LE, A422_10LE, A444_10LE, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, v210, v216, r210, v308, IYU2" AMD_COMP_NEWER_PADS " }"
 #define AMD_COMP_MAX_PADS 64
 
 static GstStaticPadTemplate comp_sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
@@ -451,7 +453,15 @@ amd_pad_format_of (GstVideoFormat f)
     case GST_VIDEO_FORMAT_P012_LE: return GSTAMD_VIDEO_FORMAT_P012_LE;
     case GST_VIDEO_FORMAT_P016_LE: return GSTAMD_VIDEO_FORMAT_P016_LE;
 #endif
-    default: return amd_format_of (f);
+    default:
+      break;
+  }
+  if (amd_format_of (f))
+    return amd_format_of (f);
+  /* every other format the converter knows: the ABI's format numbers ARE GstVideoFormat's (include/gstamd_video.h), the library says whether it has this one */
+  {
+    GstAmdVideoInfo probe;
+    return gstamd_video_info_set_format (&probe, (int) f, 16, 16) == GSTAMD_OK ? (int) f : 0;
   }
 }
 

@@ -1017,6 +1017,7 @@ static int frame_planes_plan_order (GstAmdVideoConverter *c, const void *const s
     const FormatDesc *f8 = p.fin->kind == UNPACK_V210 ? p.fout : p.fin;
     vp.to_v210 = p.fout->kind == UNPACK_V210;
     vp.kind = f8->kind, vp.h_sub = f8->h_sub, vp.u_plane = f8->u_plane, vp.v_plane = f8->v_plane;
+    vp.bps = f8->hi_depth ? 2 : 1;
     memcpy (vp.pos, f8->pos, sizeof (vp.pos));
     vp.width = p.in_info.width, vp.height = p.in_info.height;
     for (int i = 0; i < p.in_info.n_planes && i < 3; i++) {

@@ -1659,8 +1659,8 @@ const FastRow g_fast_rows[] = {
      not built, such pairs are refused at their own size (every one of these rows wants keeps_size and the same colour matrix; crop / border /
      alpha flags are matched generously - refusing a conversion the reference would run through the chain costs nothing but coverage) */
   /* round 5: the 8-bit ones on whole frames (video_v210_fast.h); with a crop or a rectangle the generous rows below still refuse */
-  {F_420 | F_Y42B | F_YUY2 | F_UYVY, fbit (GSTAMD_VIDEO_FORMAT_v210), false, FP_SIZE, "convert_8bit_v210"},
-  {fbit (GSTAMD_VIDEO_FORMAT_v210), F_420 | F_Y42B | F_YUY2 | F_UYVY, false, FP_SIZE, "convert_v210_8bit"},
+  {F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), fbit (GSTAMD_VIDEO_FORMAT_v210), false, FP_SIZE, "convert_8bit_v210"},
+  {fbit (GSTAMD_VIDEO_FORMAT_v210), F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), false, FP_SIZE, "convert_v210_8bit"},
   {F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), fbit (GSTAMD_VIDEO_FORMAT_v210), false,
         FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY | FP_ASET | FP_AMULT, "convert_to_v210"},
   {fbit (GSTAMD_VIDEO_FORMAT_v210), F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), false,

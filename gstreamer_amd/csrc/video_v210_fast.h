@@ -14,6 +14,9 @@ namespace gstamd {
 
 struct V210FastParams {
   int to_v210;          // 1: 8-bit -> v210, 0: v210 -> 8-bit
+  int bps;              // bytes per sample of the other side: 1, or 2 for I420_10LE / I422_10LE (convert_I420_10_v210 :3803, _v210_I420_10 :4201,
+                        // _I422_10_v210 :6232, _v210_I422_10 :4789): the ten bits as they are - words carrying more than ten bits run into their neighbours'
+                        // fields exactly as `u0 | (y0 << 10) | (v0 << 20)` does, except on the odd last line of a 4:2:0 frame, which unpack + pack mask
   int kind;             // the 8-bit side: UNPACK_PLANAR or UNPACK_PACKED422
   int h_sub;            // 1: its chroma rows serve two lines (I420 / YV12)
   int pos[4];           // packed 4:2:2: byte of Y0, U, V in the macropixel (FormatDesc::pos[1..3])
@@ -42,18 +45,22 @@ GSTAMD_HD void v210_fast_body (const V210FastParams &p, int g, int r)
       const uint8_t *su = packed ? sy : p.s[p.u_plane] + (size_t) crow * p.sstride[p.u_plane];
       const uint8_t *sv = packed ? sy : p.s[p.v_plane] + (size_t) crow * p.sstride[p.v_plane];
       uint32_t y[6], u[3], v[3];
+      const bool wide = p.bps == 2;
+      /* (the odd last line of a 4:2:0 frame goes through unpack_I420_10LE + pack_v210: ten bits of every word) */
+      const uint32_t keep = wide && p.h_sub && nl == 1 ? 0x3ffu : 0xffffu;
       for (int k = 0; k < 6; k++)
-        y[k] = (k == 0 || j < w - k) ? (packed ? sy[4 * ((j + k) >> 1) + p.pos[1] + 2 * ((j + k) & 1)] : sy[j + k]) : 0u;
+        y[k] = (k == 0 || j < w - k) ? (packed ? sy[4 * ((j + k) >> 1) + p.pos[1] + 2 * ((j + k) & 1)] : wide ? ((const uint16_t *) sy)[j + k] & keep : sy[j + k]) : 0u;
       for (int k = 0; k < 3; k++) {
         const bool in = k == 0 || j < w - 2 * k;
-        u[k] = in ? (packed ? su[4 * (j / 2 + k) + p.pos[2]] : su[j / 2 + k]) : 0u;
-        v[k] = in ? (packed ? sv[4 * (j / 2 + k) + p.pos[3]] : sv[j / 2 + k]) : 0u;
+        u[k] = in ? (packed ? su[4 * (j / 2 + k) + p.pos[2]] : wide ? ((const uint16_t *) su)[j / 2 + k] & keep : su[j / 2 + k]) : 0u;
+        v[k] = in ? (packed ? sv[4 * (j / 2 + k) + p.pos[3]] : wide ? ((const uint16_t *) sv)[j / 2 + k] & keep : sv[j / 2 + k]) : 0u;
       }
       uint32_t *d = (uint32_t *) (p.d[0] + (size_t) l * p.dstride[0]) + 4 * g;
-      d[0] = (u[0] << 2) | (y[0] << 12) | (v[0] << 22);
-      d[1] = (y[1] << 2) | (u[1] << 12) | (y[2] << 22);
-      d[2] = (v[1] << 2) | (y[3] << 12) | (u[2] << 22);
-      d[3] = (y[4] << 2) | (v[2] << 12) | (y[5] << 22);
+      const int s0 = wide ? 0 : 2, s1 = s0 + 10, s2 = s0 + 20;
+      d[0] = (u[0] << s0) | (y[0] << s1) | (v[0] << s2);
+      d[1] = (y[1] << s0) | (u[1] << s1) | (y[2] << s2);
+      d[2] = (v[1] << s0) | (y[3] << s1) | (u[2] << s2);
+      d[3] = (y[4] << s0) | (v[2] << s1) | (y[5] << s2);
     }
     return;
   }
@@ -61,10 +68,11 @@ GSTAMD_HD void v210_fast_body (const V210FastParams &p, int g, int r)
   for (int t = 0; t < nl; t++) {
     const uint32_t *a = (const uint32_t *) (p.s[0] + (size_t) (l0 + t) * p.sstride[0]) + 4 * g;
     const uint32_t a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
-    u[t][0] = ((a0 >> 0) & 0x3ffu) >> 2, y[t][0] = ((a0 >> 10) & 0x3ffu) >> 2, v[t][0] = ((a0 >> 20) & 0x3ffu) >> 2;
-    y[t][1] = ((a1 >> 0) & 0x3ffu) >> 2, u[t][1] = ((a1 >> 10) & 0x3ffu) >> 2, y[t][2] = ((a1 >> 20) & 0x3ffu) >> 2;
-    v[t][1] = ((a2 >> 0) & 0x3ffu) >> 2, y[t][3] = ((a2 >> 10) & 0x3ffu) >> 2, u[t][2] = ((a2 >> 20) & 0x3ffu) >> 2;
-    y[t][4] = ((a3 >> 0) & 0x3ffu) >> 2, v[t][2] = ((a3 >> 10) & 0x3ffu) >> 2, y[t][5] = ((a3 >> 20) & 0x3ffu) >> 2;
+    const int dn = p.bps == 2 ? 0 : 2;
+    u[t][0] = ((a0 >> 0) & 0x3ffu) >> dn, y[t][0] = ((a0 >> 10) & 0x3ffu) >> dn, v[t][0] = ((a0 >> 20) & 0x3ffu) >> dn;
+    y[t][1] = ((a1 >> 0) & 0x3ffu) >> dn, u[t][1] = ((a1 >> 10) & 0x3ffu) >> dn, y[t][2] = ((a1 >> 20) & 0x3ffu) >> dn;
+    v[t][1] = ((a2 >> 0) & 0x3ffu) >> dn, y[t][3] = ((a2 >> 10) & 0x3ffu) >> dn, u[t][2] = ((a2 >> 20) & 0x3ffu) >> dn;
+    y[t][4] = ((a3 >> 0) & 0x3ffu) >> dn, v[t][2] = ((a3 >> 10) & 0x3ffu) >> dn, y[t][5] = ((a3 >> 20) & 0x3ffu) >> dn;
   }
   for (int t = 0; t < nl; t++) {
     uint8_t *dy = p.d[0] + (size_t) (l0 + t) * p.dstride[0];
@@ -72,6 +80,8 @@ GSTAMD_HD void v210_fast_body (const V210FastParams &p, int g, int r)
       if (k == 0 || j < w - k) {
         if (packed)
           dy[4 * ((j + k) >> 1) + p.pos[1] + 2 * ((j + k) & 1)] = (uint8_t) y[t][k];
+        else if (p.bps == 2)
+          ((uint16_t *) dy)[j + k] = (uint16_t) y[t][k];
         else
           dy[j + k] = (uint8_t) y[t][k];
       }
@@ -86,6 +96,8 @@ GSTAMD_HD void v210_fast_body (const V210FastParams &p, int g, int r)
       const uint32_t cu = p.h_sub && nl == 2 ? (u[0][k] + u[1][k]) / 2 : u[t][k], cv = p.h_sub && nl == 2 ? (v[0][k] + v[1][k]) / 2 : v[t][k];
       if (packed)
         du[4 * (j / 2 + k) + p.pos[2]] = (uint8_t) cu, dv[4 * (j / 2 + k) + p.pos[3]] = (uint8_t) cv;
+      else if (p.bps == 2)
+        ((uint16_t *) du)[j / 2 + k] = (uint16_t) cu, ((uint16_t *) dv)[j / 2 + k] = (uint16_t) cv;
       else
         du[j / 2 + k] = (uint8_t) cu, dv[j / 2 + k] = (uint8_t) cv;
     }
@@ -97,6 +109,8 @@ GSTAMD_HD void v210_fast_body (const V210FastParams &p, int g, int r)
 // aligned for those accesses (v210_fast_vec_ok); the blocks that hold the line's end take v210_fast_body group by group.
 GSTAMD_VP bool v210_fast_vec_ok (const V210FastParams &p)
 {
+  if (p.bps != 1)
+    return false;               /* the 10-bit forms: group by group */
   const bool packed = p.kind == UNPACK_PACKED422;
   const uint8_t *const *p8 = p.to_v210 ? p.s : (const uint8_t *const *) p.d;
   const int *s8 = p.to_v210 ? p.sstride : p.dstride;

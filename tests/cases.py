@@ -1262,7 +1262,7 @@ VIDEO_CASES += [c for f, col in (("v216", "bt709>sRGB"), ("r210", "sRGB>bt709"),
 # the reference's own v210 fastpaths between v210 and the 8-bit 4:2:0 / 4:2:2 formats (video_v210_fast.h): samples shifted, not widened; group tails
 # (widths 6 k + 1 .. 5), the odd last line of a 4:2:0 frame, one-pixel frames
 VIDEO_CASES += [("v210fast_%s_%s_%dx%d" % (a.lower(), b.lower(), w, h), a, w, h, b, w, h, {}, None, None, "random")
-                for f in ("I420", "YV12", "Y42B", "YUY2", "UYVY") for (a, b) in ((f, "v210"), ("v210", f))
+                for f in ("I420", "YV12", "Y42B", "YUY2", "UYVY", "I420_10LE", "I422_10LE") for (a, b) in ((f, "v210"), ("v210", f))
                 for (w, h) in ((48, 16), (50, 17), (7, 5), (13, 3), (1, 1), (5, 4), (1920, 4))]
 
 
@@ -1284,9 +1284,8 @@ VIDEO_REFUSED = [
     # error diffusion below the frame's first line: the reference's error line is never cleared there, frames depend on each other
     ("NV12", 64, 64, "BGRA", 64, 70, dict(dither_quantization=4, dither_method="floyd-steinberg", dest_x=0, dest_y=3, dest_width=64, dest_height=64)),
     ("NV12", 64, 64, "P010_10LE", 64, 70, dict(dither_method="sierra-lite", dest_x=0, dest_y=3, dest_width=64, dest_height=64)),   # the same on 16-bit lines
-    ("I420_10LE", 48, 16, "v210", 48, 16, {}),           # the reference's own 10-bit v210 fastpaths (convert_I420_10_v210 ...) are not built (the 8-bit ones are: video_v210_fast.h)
-    ("v210", 48, 16, "I422_10LE", 48, 16, {}),
-    ("Y42B", 48, 16, "v210", 60, 20, dict(dest_x=6, dest_y=2, dest_width=48, dest_height=16)),      # ... nor their crop / rectangle forms (rows offset by ROUND_UP_2 (x) * 2 bytes)
+    ("Y42B", 48, 16, "v210", 60, 20, dict(dest_x=6, dest_y=2, dest_width=48, dest_height=16)),      # the reference's own v210 fastpaths in their crop / rectangle forms (rows offset by ROUND_UP_2 (x) * 2 bytes) are not built
+    ("I422_10LE", 48, 16, "v210", 60, 20, dict(dest_x=6, dest_y=2, dest_width=48, dest_height=16)),
     ("UYVY", 24, 11, "UYVY", 81, 29, dict(resampler_method="sinc", dest_x=37, dest_y=3, dest_width=40, dest_height=23)),   # convert_fill_border's group 42 with an odd frame width (plane scaler)
     ("Y42B", 31, 16, "UYVY", 40, 20, dict(dest_x=4, dest_y=2, dest_width=31, dest_height=16)),            # ... with the picture ending inside a macropixel (fastpath convert_Y42B_UYVY)
     ("UYVY", 64, 16, "GRAY8", 64, 16, dict(src_y=4, src_height=8)),         # convert_UYVY_GRAY8 ignores crop origins

@@ -278,7 +278,7 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[4], co
   const int w = p.out_info.width, h = p.out_info.height;
   auto up = [](int v, int sub) { return -((-v) >> sub); };
   hipError_t e = hipSuccess;
-  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
+  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : f->kind == UNPACK_SEMI_A ? 3 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
   for (int i = 0; i < n_planes && e == hipSuccess; i++) {
     int es;
     uint32_t lo, hi;
@@ -289,7 +289,7 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[4], co
     if (nv61_fastpath)
       lo = (lo >> 8) | ((lo & 0xffu) << 8);
     const bool pairs = f->kind == UNPACK_PACKED422 || f->kind == UNPACK_P422_16;          /* the plane's unit is the macropixel */
-    const bool full = i == 0 || (f->kind == UNPACK_PLANAR_A && i == 3);      /* a plane of one sample per pixel */
+    const bool full = i == 0 || i == GSTAMD_KIND_ALPHA_PLANE (f->kind);      /* a plane of one sample per pixel */
     const int ws = !full || pairs ? f->w_sub : 0, hs = !full ? f->h_sub : 0;
     const int mw = up (rc.out_maxw, ws), mh = up (rc.out_maxh, hs);
     e = launch_fill_border (planes[i], strides[i], es, lo, hi, mw, mh, rc.out_x >> ws, rc.out_y >> hs, border_picture_positions (f, rc, w, ws), up (h, hs), stream);
@@ -1210,7 +1210,8 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
     color.matrix = p.matrix;
     color.alpha_kind = p.post.alpha_kind;
     color.alpha_value = p.post.alpha_value;
-    const bool alpha_plane = p.fout->kind == UNPACK_PLANAR_A;      /* A420: the image path below, then the fourth plane from the image */
+    const int alpha_idx = GSTAMD_KIND_ALPHA_PLANE (p.fout->kind);
+    const bool alpha_plane = alpha_idx >= 0;      /* A420: the image path below, then the fourth plane from the image */
     if (!alpha_plane && p.passes.empty () && !p.deep16 && !c->hook_on && !diffusion_first && p.post.pack_pos[0] == 0 && p.post.pack_pos[1] == 1 &&
         p.post.pack_pos[2] == 2 && p.post.pack_pos[3] == 3 && convert_pack_usable (p.front, pl, color) && !tuning_on ("GSTAMD_NO_CONVERT_PACK")) {
       /* an unscaled 8-bit chain with a cheap pixel source: the packer takes its pixels from the chain itself, nothing goes through HBM
@@ -1265,12 +1266,12 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
     hipError_t e = diffusion ? launch_pack_planar_ed (p.pack, c->pk_img, p.out_info.width * 4, planes, strides, stream, c->ed_carry)
         : launch_pack_planar (p.pack, c->pk_img, p.out_info.width * 4, planes, strides, stream);
     if (e == hipSuccess && alpha_plane) {
-      if (!dest_planes[3])
+      if (!dest_planes[alpha_idx])
         return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
       PackPlanarParams pa = p.pack;
       if (diffusion)
         memset (&pa.dither, 0, sizeof (pa.dither));         /* the error-diffusion pass ran over all four components of the image already */
-      e = launch_pack_alpha_plane (pa, c->pk_img, p.out_info.width * 4, (uint8_t *) dest_planes[3], dest_stride ? dest_stride[3] : p.out_info.stride[3], stream);
+      e = launch_pack_alpha_plane (pa, c->pk_img, p.out_info.width * 4, (uint8_t *) dest_planes[alpha_idx], dest_stride ? dest_stride[alpha_idx] : p.out_info.stride[alpha_idx], stream);
     }
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_pack_planar");
   }

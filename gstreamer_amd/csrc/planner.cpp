@@ -54,6 +54,7 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_A444, "A444", true, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV12, "NV12", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV21, "NV21", true, false, 2, UNPACK_SEMI, 1, 1, 0, 1, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_AV12, "AV12", true, true, 3, UNPACK_SEMI_A, 1, 1, 1, 0, {0, 0, 0, 0}},          /* unpack_AV12 / pack_AV12 video-format.c: NV12 + an alpha plane */
   {GSTAMD_VIDEO_FORMAT_NV16, "NV16", true, false, 2, UNPACK_SEMI, 1, 0, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV61, "NV61", true, false, 2, UNPACK_SEMI, 1, 0, 0, 1, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV24, "NV24", true, false, 2, UNPACK_SEMI, 0, 0, 1, 0, {0, 0, 0, 0}},
@@ -285,6 +286,14 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->offset[2] = info->offset[1] * 2;
       info->size = (uint64_t) info->stride[0] * h * 3;
       break;
+    case GSTAMD_VIDEO_FORMAT_AV12: {            /* video-info.c:1064-1073 */
+      const uint64_t h2 = (uint64_t) round_up (height, 2);
+      info->stride[0] = info->stride[1] = info->stride[2] = round_up (width, 4);
+      info->offset[1] = (uint64_t) info->stride[0] * h2;
+      info->offset[2] = info->offset[1] + (uint64_t) info->stride[1] * h2 / 2;
+      info->size = info->offset[2] + (uint64_t) info->stride[2] * h2;
+      break;
+    }
     case GSTAMD_VIDEO_FORMAT_NV12:
     case GSTAMD_VIDEO_FORMAT_NV21: {
       info->stride[0] = round_up (width, 4);
@@ -1970,7 +1979,7 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
   if (f->kind == UNPACK_V210)
     return (uint64_t) ((w + 5) / 6) * 16 * h;
   const uint64_t cw = ((uint64_t) w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) h + (1 << f->h_sub) - 1) >> f->h_sub;
-  const uint64_t n = (uint64_t) w * h + 2 * cw * ch + (f->kind == UNPACK_PLANAR_A ? (uint64_t) w * h : 0);
+  const uint64_t n = (uint64_t) w * h + 2 * cw * ch + (GSTAMD_KIND_ALPHA_PLANE (f->kind) >= 0 ? (uint64_t) w * h : 0);
   return f->hi_depth ? 2 * n : n;
 }
 
@@ -2755,7 +2764,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       planar_dither.on = 1;
       planar_dither.y0 = plan->rect.out_y;
       planar_dither.method = cfg.dither_method;
-      planar_dither.shift[0] = plan->fout->kind == UNPACK_PLANAR_A ? shift : 0;          /* A420's alpha plane is a component of depth 8 like the others */
+      planar_dither.shift[0] = GSTAMD_KIND_ALPHA_PLANE (plan->fout->kind) >= 0 ? shift : 0;          /* A420's alpha plane is a component of depth 8 like the others */
       planar_dither.shift[1] = planar_dither.shift[2] = planar_dither.shift[3] = shift;
       if (plan->fout->kind == UNPACK_RGB16) {
         /* components of 5 / 6 bits on 8-bit lines: their own quantiser 1 << (8 - depth) (:2070-2078) where the target is not coarser */
@@ -3483,7 +3492,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * anything else; the reference's vertical chroma upsampler pairs lines in the order the nearest vertical scaler asks for them
    * (it skips / repeats lines), which the pair-table simulation of the direct plans follows and the composite does not */
   /* (a 10 / 12 / 16-bit 4:2:0 source under gamma-mode = remap goes the same way: its 16-bit front is planned as an unscaled conversion, plan_gamma) */
-  if (chain && pl.gamma.on && (!pl.gamma.src16 || remap) && !pl.gamma.src64 && fi->h_sub == 1 && (kind_has_planes (fi->kind) || fi->kind == UNPACK_PLANAR_A)) {
+  if (chain && pl.gamma.on && (!pl.gamma.src16 || remap) && !pl.gamma.src64 && fi->h_sub == 1 && (kind_has_planes (fi->kind) || GSTAMD_KIND_ALPHA_PLANE (fi->kind) >= 0)) {
     for (const ScalePass &sp : pl.passes)
       if (!sp.horizontal && sp.kind == SCALE_NEAREST) {
         if (error)
@@ -3602,7 +3611,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * rectangle keeps what it wrote there */
   /* (the device fuzz's seed 5484 widened it: the same with one output row, and with the 16-bit unpack formats as destinations - the pair's other line
    * still lands in a frame row, or in front of the frame when the rectangle starts at row 0, and the picture's own row differs) */
-  const bool one_line_420 = pl.front.chroma_v2 || (pl.gamma.on && fi->h_sub == 1 && (kind_has_planes (fi->kind) || fi->kind == UNPACK_PLANAR_A) && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE &&
+  const bool one_line_420 = pl.front.chroma_v2 || (pl.gamma.on && fi->h_sub == 1 && (kind_has_planes (fi->kind) || GSTAMD_KIND_ALPHA_PLANE (fi->kind) >= 0) && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE &&
       cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY);
   /* ... and every chain whose unpacker works in the destination's rows (no scaler that makes new lines in between) does it to the row above a rectangle
    * that starts below row 0: a crop copied unscaled into a rectangle of an ARGB frame keeps picture-derived pixels in that border row */

@@ -30,10 +30,14 @@ enum UnpackKind : int {
                         // ARGB64): FormatDesc::pos[c] = word of component c (A, R, G, B); hi_depth code 9 (little endian) / 10 (big endian)
   UNPACK_GRAY16 = 10,   // one plane of 16-bit luma (GRAY16_LE / _BE; unpack format AYUV64, U = V = 0x8000); hi_depth code 9 / 10
   UNPACK_PLANAR_A = 12, // I420's planes plus a full-size alpha plane (A420: plane 3); generic per-pixel kernels only (kind_has_planes is false for it)
+  UNPACK_SEMI_A = 13,   // NV12's planes plus a full-size alpha plane (AV12: plane 2); generic per-pixel kernels only
   UNPACK_RGB16 = 11,    // one plane, a little-endian 16-bit word per pixel with 5-6-5 or 5-5-5 bit fields (RGB16, BGR16, RGB15, BGR15; unpack format ARGB,
                         // 8-bit chain): FormatDesc::pos = {bits of G, first bit of R, of G, of B}
 };
 // one plane of whole pixels whose samples reach the 16-bit chain through deep_front_px and leave it through pack16_packed_body, a lane per pixel
+// the full-size alpha plane of a kind that has one (A420 & co: 3, AV12: 2), else -1; interleaved U / V samples in plane 1
+#define GSTAMD_KIND_ALPHA_PLANE(k) ((k) == UNPACK_PLANAR_A ? 3 : ((k) == UNPACK_SEMI_A ? 2 : -1))
+#define GSTAMD_KIND_SEMI(k) ((k) == UNPACK_SEMI || (k) == UNPACK_SEMI_A)
 #define GSTAMD_KIND_PX16(k) ((k) == UNPACK_Y410 || (k) == UNPACK_PACKED64 || (k) == UNPACK_GRAY16)
 
 struct FormatDesc {
@@ -405,10 +409,10 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
   if (f->kind == UNPACK_V210)            /* rows only: a horizontal offset inside the 6-pixel groups is refused by the planner */
     return (size_t) y * stride;
   const size_t bps = f->hi_depth ? 2 : 1;          /* planes of 10 / 12 / 16-bit formats hold 16-bit samples */
-  if (plane == 0 || (f->kind == UNPACK_PLANAR_A && plane == 3))
+  if (plane == 0 || plane == GSTAMD_KIND_ALPHA_PLANE (f->kind))
     return (size_t) y * stride + (size_t) x * bps;
   const size_t row = (size_t) (y >> f->h_sub) * stride;
-  return f->kind == UNPACK_SEMI ? row + (size_t) (x >> f->w_sub) * 2 * bps : row + (size_t) (x >> f->w_sub) * bps;
+  return GSTAMD_KIND_SEMI (f->kind) ? row + (size_t) (x >> f->w_sub) * 2 * bps : row + (size_t) (x >> f->w_sub) * bps;
 }
 
 // Width, in plane positions, of the part of a destination plane's rows the border fill leaves to the picture.  Planes of whole pixels and
@@ -470,7 +474,7 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
       v |= (uint32_t) border[c] << (8 * f->pos[c]);
     *es = f->kind == UNPACK_PACKED4 ? 4 : 3, *lo = v;
   } else if (f->hi_depth) {
-    if (f->kind == UNPACK_PLANAR_A && plane == 3)
+    if (plane == GSTAMD_KIND_ALPHA_PLANE (f->kind))
       *es = 2, *lo = s16 (0);
     else if (plane == 0)
       *es = 2, *lo = s16 (1);
@@ -479,11 +483,11 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
     else
       *es = 2, *lo = s16 (plane == f->u_plane ? 2 : 3);
   } else {
-    if (f->kind == UNPACK_PLANAR_A && plane == 3)
+    if (plane == GSTAMD_KIND_ALPHA_PLANE (f->kind))
       *es = 1, *lo = border[0];
     else if (plane == 0)
       *es = 1, *lo = border[1];
-    else if (f->kind == UNPACK_SEMI)
+    else if (GSTAMD_KIND_SEMI (f->kind))
       *es = 2, *lo = f->u_plane ? (uint32_t) border[2] | ((uint32_t) border[3] << 8) : (uint32_t) border[3] | ((uint32_t) border[2] << 8);
     else
       *es = 1, *lo = border[plane == f->u_plane ? 2 : 3];

@@ -121,7 +121,7 @@ GSTAMD_HD UV load_uv (const FrontParams &f, const Planes &pl, int crow, int k)
     const bool swap = k == f.swap_k;
     r.u = p[f.pos[swap ? 3 : 2]];
     r.v = p[f.pos[swap ? 2 : 3]];
-  } else if (f.kind == UNPACK_SEMI) {
+  } else if (GSTAMD_KIND_SEMI (f.kind)) {
     const uint8_t *p = pl.p[1] + (ptrdiff_t) crow * pl.stride[1] + 2 * k;
     const int c0 = p[0], c1 = p[1];
     r.u = f.u_plane ? c0 : c1;           // NV12: U first; NV21: V first
@@ -203,7 +203,8 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
     c = chroma_h_at (f, pl, y >> f.h_sub, x);
   }
   /* unpack_A420 (video-format.c:2118-2146): the alpha plane's sample of the same line (clamped like the luma: do_unpack_lines) */
-  const uint32_t A = f.kind == UNPACK_PLANAR_A ? pl.p[3][(size_t) yl * pl.stride[3] + x] : 0xffu;
+  const int ap = GSTAMD_KIND_ALPHA_PLANE (f.kind);       /* ... unpack_AV12 :1655 */
+  const uint32_t A = ap == 3 ? pl.p[3][(size_t) yl * pl.stride[3] + x] : (ap == 2 ? pl.p[2][(size_t) yl * pl.stride[2] + x] : 0xffu);
   return A | ((uint32_t) Y << 8) | ((uint32_t) c.u << 16) | ((uint32_t) c.v << 24);
 }
 

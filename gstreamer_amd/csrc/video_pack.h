@@ -129,7 +129,7 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
       uint8_t *q = (d.p[0] + dd) + (size_t) y0 * d.stride[0] + 4 * (size_t) k;
       q[pk.pos[2]] = cu;
       q[pk.pos[3]] = cv;
-    } else if (pk.kind == UNPACK_SEMI) {
+    } else if (GSTAMD_KIND_SEMI (pk.kind)) {
       uint8_t *duv = (d.p[1] + dd) + (size_t) yb * d.stride[1] + 2 * k;
       duv[0] = pk.u_plane ? cu : cv;
       duv[1] = pk.u_plane ? cv : cu;

@@ -114,6 +114,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_RBGA = 133,       /* packed 4-byte RGB with alpha, bytes R, B, G, A */
   GSTAMD_VIDEO_FORMAT_Y216_LE = 134,    /* Y210's layout with all 16 bits */
   GSTAMD_VIDEO_FORMAT_Y416_LE = 136,    /* Y412_LE's layout with all 16 bits */
+  GSTAMD_VIDEO_FORMAT_AV12 = 101,       /* NV12 with a third, full-size plane of alpha */
   GSTAMD_VIDEO_FORMAT_ARGB64_LE = 102,  /* 16 bits per component in the named memory order and endianness (ARGB64 is ARGB64_LE on this host) */
   GSTAMD_VIDEO_FORMAT_ARGB64_BE = 103,
   GSTAMD_VIDEO_FORMAT_RGBA64_LE = 104,

@@ -39,7 +39,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 /* (RGBP / BGRP 1.20, RBGA / A422 / A444 / GBR_16LE / Y216_LE / Y416_LE later: taken together where the headers are the reference's own) */
 #if GST_CHECK_VERSION (1, 26, 0)
 #define AMD_NEWEST_FORMATS ", RGBP, BGRP, RBGA, A422, A444, GBR_16LE, Y216_LE, Y412_LE, Y416_LE, A420_12LE, A422_12LE, A444_12LE, A420_16LE, A422_16LE, A444_16LE, " \
-    "GRAY10_LE16, I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE"
+    "GRAY10_LE16, I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE, AV12"
 #else
 #define AMD_NEWEST_FORMATS ""
 #endif
@@ -849,7 +849,7 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_A420_12BE, GSTAMD_VIDEO_FORMAT_A420_12BE},
     {GST_VIDEO_FORMAT_A422_12BE, GSTAMD_VIDEO_FORMAT_A422_12BE},
     {GST_VIDEO_FORMAT_A444_12BE, GSTAMD_VIDEO_FORMAT_A444_12BE},
-    {GST_VIDEO_FORMAT_A420_16BE, GSTAMD_VIDEO_FORMAT_A420_16BE},
+    {GST_VIDEO_FORMAT_A420_16BE, GSTAMD_VIDEO_FORMAT_A420_16BE}, {GST_VIDEO_FORMAT_AV12, GSTAMD_VIDEO_FORMAT_AV12},
     {GST_VIDEO_FORMAT_A422_16BE, GSTAMD_VIDEO_FORMAT_A422_16BE},
     {GST_VIDEO_FORMAT_A444_16BE, GSTAMD_VIDEO_FORMAT_A444_16BE},
     {GST_VIDEO_FORMAT_Y212_BE, GSTAMD_VIDEO_FORMAT_Y212_BE},

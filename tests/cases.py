@@ -69,6 +69,8 @@ def visible_planes(fmt, w, h):
         return [(w, h), (up2(w), h), (up2(w), h), (w, h)]
     if fmt in ("NV12", "NV21"):
         return [(w, h), (2 * up2(w), up2(h))]
+    if fmt == "AV12":
+        return [(w, h), (2 * up2(w), up2(h)), (w, h)]
     if fmt in ("NV16", "NV61"):
         return [(w, h), (2 * up2(w), h)]
     if fmt == "NV24":
@@ -1246,6 +1248,48 @@ def _round5_be_sweep():
 
 VIDEO_CASES += _round5_be_sweep()
 
+
+# AV12 (NV12 + a full-size alpha plane in plane 2: UNPACK_SEMI_A): no fastpath row names it, so every conversion is the chain
+def _round5_av12_sweep():
+    out = []
+    for o in ("BGRA", "ARGB", "RGB", "RGB16", "AYUV", "I420", "NV12", "NV21", "A420", "AV12", "UYVY", "GRAY8", "ARGB64", "A420_10LE", "Y410", "P010_10LE", "GBRA"):
+        out.append(("av12_%s_37x7" % o.lower(), "AV12", 37, 7, o, 37, 7, {}, None, None, "random"))
+    for i in ("BGRA", "RGB", "RGB15", "AYUV", "I420", "NV12", "A420", "UYVY", "GRAY8", "ARGB64", "A444_16LE", "RGBA64_BE", "Y410", "VUYA", "GBRA_10LE"):
+        out.append(("%s_av12_40x10" % i.lower(), i, 40, 10, "AV12", 40, 10, {}, None, None, "random"))
+        out.append(("%s_av12_33x17" % i.lower(), i, 33, 17, "AV12", 33, 17, {}, None, None, "random"))
+    out += [
+        ("av12_bgra_down_bilinear", "AV12", 64, 36, "BGRA", 32, 20, LIN, None, None, "random"),
+        ("av12_av12_down_bilinear", "AV12", 64, 36, "AV12", 32, 20, LIN, None, None, "random"),
+        ("av12_av12_up_lanczos_odd", "AV12", 33, 17, "AV12", 50, 40, LAN, None, None, "random"),
+        ("av12_av12_cubic", "AV12", 64, 36, "AV12", 48, 30, dict(resampler_method="cubic"), None, None, "random"),
+        ("av12_av12_nearest", "AV12", 64, 36, "AV12", 100, 50, dict(resampler_method="nearest"), None, None, "random"),
+        ("bgra_av12_down_lanczos", "BGRA", 64, 36, "AV12", 32, 20, LAN, None, None, "random"),
+        ("nv12_av12_up_bilinear", "NV12", 64, 36, "AV12", 100, 50, LIN, None, None, "random"),
+        ("av12_a420_10le_down_lanczos", "AV12", 64, 36, "A420_10LE", 32, 20, LAN, None, None, "random"),
+        ("nv12_av12_alpha_set", "NV12", 64, 36, "AV12", 64, 36, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+        ("ayuv_av12_alpha_mult", "AYUV", 64, 36, "AV12", 64, 36, dict(alpha_mode="mult", alpha_value=0.5), None, None, "random"),
+        ("av12_bgra_alpha_mult", "AV12", 64, 36, "BGRA", 64, 36, dict(alpha_mode="mult", alpha_value=0.5), None, None, "random"),
+        ("av12_av12_alpha_set", "AV12", 64, 36, "AV12", 64, 36, dict(alpha_mode="set", alpha_value=0.25), None, None, "random"),
+        ("bgra_av12_bayer_q8", "BGRA", 35, 19, "AV12", 35, 19, dict(dither_quantization=8), None, None, "random"),
+        ("bgra_av12_sierra_q8", "BGRA", 35, 19, "AV12", 35, 19, dict(dither_method="sierra-lite", dither_quantization=8), None, None, "random"),
+        ("argb64_av12_floyd_q16", "ARGB64", 35, 19, "AV12", 35, 19, dict(dither_method="floyd-steinberg", dither_quantization=16), None, None, "random"),
+        ("av12_av12_crop_dest_border", "AV12", 48, 30, "AV12", 60, 40, dict(src_x=4, src_y=2, src_width=30, src_height=20, dest_x=8, dest_y=10, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+        ("bgra_av12_dest_border", "BGRA", 30, 20, "AV12", 50, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+        ("argb64_av12_dest_border_odd", "ARGB64", 30, 20, "AV12", 51, 31, dict(dest_x=7, dest_y=5, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+        ("av12_bgra_crop", "AV12", 48, 30, "BGRA", 30, 20, dict(src_x=5, src_y=3, src_width=30, src_height=20), None, None, "random"),
+        ("av12_bgra_gamma_remap", "AV12", 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"),
+        ("bgra_av12_gamma_remap", "BGRA", 40, 8, "AV12", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"),
+        ("av12_av12_primaries", "AV12", 40, 8, "AV12", 40, 8, dict(primaries_mode="fast"), "bt709>bt2020", None, "random"),
+        ("av12_bgra_1080_strip", "AV12", 1920, 16, "BGRA", 1920, 16, {}, None, None, "random"),
+        ("bgra_av12_1080_strip", "BGRA", 1920, 16, "AV12", 1920, 16, {}, None, None, "random"),
+        ("av12_nv12_cosited", "AV12", 64, 36, "NV12", 64, 36, {}, None, "cosited", "random"),
+        ("y444_av12_mpeg2", "Y444", 64, 36, "AV12", 64, 36, {}, None, "mpeg2", "random"),
+    ]
+    return out
+
+
+VIDEO_CASES += _round5_av12_sweep()
+
 # v216 (Y216's samples in U Y0 V Y1 order), r210 (Y410's kind on a big-endian word without alpha bits), GRAY10_LE16
 VIDEO_CASES += [c for f, col in (("v216", "bt709>sRGB"), ("r210", "sRGB>bt709"), ("GRAY10_LE16", "bt709>sRGB")) for c in (
     ("r5m_%s_bgra_37x7" % f.lower(), f, 37, 7, "BGRA", 37, 7, {}, None, None, "random"),
@@ -1383,6 +1427,8 @@ def default_layout(fmt, w, h):
         return [s0, s1, s1, s0], [0, s0 * r2(h), s0 * r2(h) + s1 * r2(h), s0 * r2(h) + 2 * s1 * r2(h)]
     if fmt in ("NV12", "NV21"):
         return [r4(w), r4(w)], [0, r4(w) * r2(h)]
+    if fmt == "AV12":
+        return [r4(w)] * 3, [0, r4(w) * r2(h), r4(w) * r2(h) + r4(w) * r2(h) // 2]
     if fmt in ("NV16", "NV61"):
         return [r4(w), r4(w)], [0, r4(w) * h]
     if fmt == "NV24":

@@ -809,7 +809,7 @@ static void emu_fill_borders (const VideoPlan &p, const GstAmdVideoInfo *out, ui
 {
   const FormatDesc *f = p.fout;
   auto up = [](int v, int sub) { return -((-v) >> sub); };
-  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
+  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : f->kind == UNPACK_SEMI_A ? 3 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
   for (int i = 0; i < n_planes; i++) {
     int es;
     uint32_t lo, hi;
@@ -821,7 +821,7 @@ static void emu_fill_borders (const VideoPlan &p, const GstAmdVideoInfo *out, ui
     memcpy (v, &lo, 4);
     memcpy (v + 4, &hi, 4);
     const bool pairs = f->kind == UNPACK_PACKED422 || f->kind == UNPACK_P422_16;
-    const bool full = i == 0 || (f->kind == UNPACK_PLANAR_A && i == 3);
+    const bool full = i == 0 || i == GSTAMD_KIND_ALPHA_PLANE (f->kind);
     const int ws = !full || pairs ? f->w_sub : 0, hs = !full ? f->h_sub : 0;
     const int mw = up (p.rect.out_maxw, ws), mh = up (p.rect.out_maxh, hs), x0 = p.rect.out_x >> ws, y0 = p.rect.out_y >> hs;
     const int w = border_picture_positions (f, p.rect, p.out_info.width, ws), h = up (p.out_info.height, hs);
@@ -1330,7 +1330,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       return GSTAMD_OK;
     }
   }
-  if (p.out_planar && p.fout->kind != UNPACK_PLANAR_A && p.passes.empty () && !p.deep16 && !(p.pack.dither.on && p.pack.dither.method != GSTAMD_DITHER_NONE && p.pack.dither.method != GSTAMD_DITHER_BAYER) &&
+  if (p.out_planar && GSTAMD_KIND_ALPHA_PLANE (p.fout->kind) < 0 && p.passes.empty () && !p.deep16 && !(p.pack.dither.on && p.pack.dither.method != GSTAMD_DITHER_NONE && p.pack.dither.method != GSTAMD_DITHER_BAYER) &&
       p.post.pack_pos[0] == 0 && p.post.pack_pos[1] == 1 && p.post.pack_pos[2] == 2 && p.post.pack_pos[3] == 3 && !getenv ("EMU_NO_CONVERT_PACK") &&
       (p.front.kind == UNPACK_PACKED4 || (p.front.kind == UNPACK_PACKED422 && (p.front.chroma_h == CHROMA_H_NONE || !getenv ("GSTAMD_NO_CONVERT_PACK_422UP")) &&
               !p.front.chroma_v2 && p.matrix.kind == MATRIX_NONE && p.post.alpha_kind == ALPHA_NONE))) {          /* convert_pack_usable, alignment aside */
@@ -1392,7 +1392,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   {
     PlanePlan raw4;
     bool enc420 = false;
-    if (p.fout->kind != UNPACK_PLANAR_A && plane_raw4_pack_plan (p, &raw4, &enc420) && getenv ("GSTAMD_NO_PLANE_QUAD") == nullptr && vec_ok) {
+    if (GSTAMD_KIND_ALPHA_PLANE (p.fout->kind) < 0 && plane_raw4_pack_plan (p, &raw4, &enc420) && getenv ("GSTAMD_NO_PLANE_QUAD") == nullptr && vec_ok) {
       /* k_plane_quad on the raw 4-byte pixels into the image, then k_encode420 / k_convert_pack from it (capi_video.cpp: raw4_pack) */
       const int ow = p.out_info.width, oh = p.out_info.height;
       std::vector<uint32_t> img ((size_t) ow * (oh + 1) + 4);
@@ -1502,10 +1502,12 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
           continue;
         pack_planar_body (pk, SrcImage {img.data (), p.out_info.width * 4, p.out_info.width}, d, x0, yb);
       }
-    if (p.fout->kind == UNPACK_PLANAR_A)          /* k_pack_alpha_plane (pk: the dither-free form after an error-diffusion pass) */
+    if (GSTAMD_KIND_ALPHA_PLANE (p.fout->kind) >= 0) {          /* k_pack_alpha_plane (pk: the dither-free form after an error-diffusion pass) */
+      const int ai = GSTAMD_KIND_ALPHA_PLANE (p.fout->kind);
       for (int y = 0; y < p.out_info.height; y++)
         for (int x0 = 0; x0 < p.out_info.width; x0 += 4)
-          pack_alpha_plane_body (pk, img.data (), p.out_info.width * 4, dst + out->offset[3], out->stride[3], x0, y);
+          pack_alpha_plane_body (pk, img.data (), p.out_info.width * 4, dst + out->offset[ai], out->stride[ai], x0, y);
+    }
     return GSTAMD_OK;
   }
   r = emu_convert_packed (p, in, pl, dst + out->offset[0], out->stride[0], vec_ok, false);

@@ -240,6 +240,63 @@ class CompositorWorkload:
                           "one thread (max-threads default)" % n_frames}
 
 
+class CompositorOpaqueWorkload(CompositorWorkload):
+    """C4's layout with opaque pads (pad alpha 1.0, pixel alpha 255) through gstamd_compositor_aggregate_opaque: blend_pads' canvas byte for byte, without
+    the reads under a strip that an opaque pad covers.  --opaque-hint map: per-pad opacity maps made once before the timed region (still pads / frames
+    composited more than once); all: the pads flagged all_opaque (frames converted from a format without alpha); none: no hints (the plain kernel)."""
+    name = "c4opaque"
+    metric = "4K output frames/s (compositor, 16 x 1080p opaque BGRA pads, C4's overlapping layout, strips under an opaque pad not read) per GPU"
+    kernel = "k_aggregate_direct_cull"
+    hint = "map"
+
+    def pad_geometry(self, i):
+        return (i % 4) * 640, (i // 4) * 360, 1.0
+
+    def setup(self, dev, rank):
+        import torch
+        super().setup(dev, rank)
+        V = self.V
+        for t in self.pads:
+            t.view(-1, 4)[:, 3] = 255
+        self.opas, self.maps = [], []
+        for s_ in range(self.SETS):
+            opa = (V.CompositorPadOpacity * self.N)()
+            for i in range(self.N):
+                if self.hint == "all":
+                    opa[i].all_opaque = 1
+                elif self.hint == "map":
+                    m = torch.zeros(self.PH, dtype=torch.int64, device=dev)
+                    r = self.L.gstamd_compositor_pad_opacity_map(V.FORMATS["BGRA"], self.pads[s_ * self.N + i].data_ptr(), self.PW, self.PH, self.PW * 4,
+                                                                 m.data_ptr(), self.stream)
+                    assert r == 0, V.last_error()
+                    self.maps.append(m)
+                    opa[i].map = m.data_ptr()
+            self.opas.append(opa)
+        torch.cuda.synchronize()
+        if self.hint == "none":
+            self.kernel = "k_aggregate_direct"
+        # what the culled pass has to move: the topmost pad's pixels of every canvas pixel + one canvas write (the 4 x 4 grid at 640 x 360 steps covers the canvas)
+        self.alg_bytes_ref = self.alg_bytes
+        self.alg_bytes = self.alg_bytes_per_launch = 2 * self.DW * self.DH * 4
+
+    def step(self, s):
+        for f in range(self.frames_per_step):
+            k = s * self.frames_per_step + f
+            r = self.L.gstamd_compositor_aggregate_opaque(self.V.FORMATS["BGRA"], 0, self.arrs[k % self.SETS], self.opas[k % self.SETS] if self.hint != "none" else None,
+                                                          self.N, self.outs[k % self.pool_out].data_ptr(), self.DW, self.DH, self.DW * 4, self.stream)
+            assert r == 0, self.V.last_error()
+
+    def config(self, world):
+        c = super().config(world)
+        c["workload"] = ("C4 opaque: compositor, 16 x 1920x1080 BGRA pads at xpos 640*(i%%4), ypos 360*(i/4), pad alpha 1.0, pixel alpha 255, checker background, "
+                         "opacity hint '%s'; bytes counted: the visible pad pixels + the canvas (%d MB; blend_pads reads %d MB), %d output frames/step"
+                         % (self.hint, self.alg_bytes // 1000000, self.alg_bytes_ref // 1000000, self.frames_per_step))
+        return c
+
+    def cpu_baseline(self):
+        return None
+
+
 class CompositorScaledWorkload(CompositorWorkload):
     """SURVEY 8d's C4 variant A ("next"): a 4 x 4 grid of non-overlapping pads, each 1080p BGRA frame scaled to 960x540 by a per-pad
     converter with the library defaults (cubic) - what GstVideoAggregatorConvertPad does - then one aggregate launch."""
@@ -515,6 +572,10 @@ def make_workload(args):
         return VideoWorkload(args.config, args.batch, size)
     if args.config == "c4":
         return CompositorWorkload()
+    if args.config == "c4opaque":
+        w = CompositorOpaqueWorkload()
+        w.hint = args.opaque_hint
+        return w
     if args.config == "c4a":
         return CompositorScaledWorkload()
     if args.config == "c4audio":
@@ -649,7 +710,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4audio | c4audiomany | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f5encode16 | f8scale | f8pack | f8swizzle")
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4opaque | c4audio | c4audiomany | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f5encode16 | f8scale | f8pack | f8swizzle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="c2: skip the batch-1 / element numbers reported beside the headline")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
@@ -657,6 +718,7 @@ def main():
                          "to reach its steady rate (scripts/clock_ramp.py, profiles/r01_clock_ramp.log)")
     ap.add_argument("--batch", type=int, default=None,
                     help="frames per kernel launch (gstamd_video_converter_frames, the GstBufferList analogue); 1 = one launch per frame")
+    ap.add_argument("--opaque-hint", default="map", choices=["map", "all", "none"], help="c4opaque: where the pads' opacity is known from")
     ap.add_argument("--audio-block", type=int, default=1024, help="c4audio: frames per resample call")
     ap.add_argument("--size", default=None, help="experiments only: frame size (the headline metric is 3840x2160)")
     ap.add_argument("--backend", default=None, help=argparse.SUPPRESS)      # tests: gloo + the stub workload on CPU

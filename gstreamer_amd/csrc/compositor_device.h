@@ -891,7 +891,66 @@ GSTAMD_CD bool pad_hits_strip (const PadDev &pad, int wx0, int wx1, int y)
   return (sy >= 0) & (sy < pad.height) & (pad.xpos < wx1) & (pad.xpos + pad.width > wx0);
 }
 
+// ---- opaque culling (gstamd_compositor_aggregate_opaque) --------------------------------------------------------------------------
+// The reference blends every pad over what is under it (blend_pads compositor.c:1678-1697) even where the result is the pad's own pixel:
+// OVER at pad alpha 1.0 on a pixel of alpha 255 is (s * 255 + d * 0) / 255 = s with the destination alpha forced to 0xff (BLEND_A32 blend.c:96-132,
+// compositor_orc_blend_argb / _bgra).  Where such pixels cover the whole 256-pixel strip of a row, nothing under that pad is read.
+struct OpacityMaps {
+  const unsigned long long *map[GSTAMD_MAX_FUSED_PADS];   // pad k: one word per pad row, bit b = the pixels [64 b, 64 b + 64) of the row all have alpha 255
+                                                          // (gstamd_compositor_pad_opacity_map); NULL: not known
+  uint32_t all;                                           // bit k: every pixel of pad k has alpha 255 (a pad converted from a format without alpha)
+};
+
+// bit b of a pad row's word (host form; k_opacity_map computes it with a ballot)
+GSTAMD_CD unsigned long long opacity_row_bits (const uint8_t *row, int w, int ashift)
+{
+  unsigned long long bits = 0;
+  for (int b = 0; 64 * b < w && b < 64; b++) {
+    bool ok = true;
+    for (int x = 64 * b; x < 64 * b + 64 && x < w; x++)
+      ok &= ((load_px1 (row + 4 * (size_t) x) >> ashift) & 0xffu) == 0xffu;
+    if (ok)
+      bits |= 1ull << b;
+  }
+  return bits;
+}
+
+// does this pad hide everything under the strip [wx0, wx1) of canvas row y?  (callers: the pad hits the strip and the launch is the fast form -
+// no SOURCE operator, where OVER and ADD are the same arithmetic)
+GSTAMD_CD bool pad_covers_strip (const PadDev &pad, const unsigned long long *map, bool all, int wx0, int wx1, int y)
+{
+  if (pad.s_alpha != 255 || pad.xpos > wx0 || pad.xpos + pad.width < wx1)
+    return false;
+  const int sy = y - pad.ypos;
+  if (sy < 0 || sy >= pad.height)
+    return false;
+  if (all)
+    return true;
+  if (!map)
+    return false;
+  const int b0 = (wx0 - pad.xpos) >> 6, b1 = (wx1 - 1 - pad.xpos) >> 6;
+  if (b1 > 63)
+    return false;
+  const unsigned long long need = (b1 - b0 == 63 ? ~0ull : ((1ull << (b1 - b0 + 1)) - 1ull)) << b0;
+  return (map[sy] & need) == need;
+}
+
+// the hit mask without the pads under the topmost covering one
+GSTAMD_CD unsigned long long cull_mask (unsigned long long hits, unsigned long long covers)
+{
+  return covers ? hits & ~((1ull << (63 - __builtin_clzll (covers))) - 1ull) : hits;
+}
+
 #ifndef __HIPCC__
+GSTAMD_CD unsigned long long direct_cover_mask_host (const AggregateParams &p, const OpacityMaps &om, int wx0, int wx1, int y)
+{
+  unsigned long long c = 0;
+  for (int k = 0; k < p.n_pads; k++)
+    if (pad_hits_strip (p.pads[k], wx0, wx1, y) && pad_covers_strip (p.pads[k], om.map[k], (om.all >> k) & 1u, wx0, wx1, y))
+      c |= 1ull << k;
+  return c;
+}
+
 GSTAMD_CD DirectPads direct_pads_host (const AggregateParams &p, int wx0, int wx1, int y)
 {
   DirectPads dp;

@@ -304,7 +304,66 @@ static int family_ashift (int format)
   }
 }
 
-static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, int ry0, int rw, int rh, void *stream)
+// k_aggregate_direct with the pads under an opaque strip left out of the mask (compositor_device.h "opaque culling"): lane k also asks whether pad k
+// covers the strip with opaque pixels - one 8-byte load of the pad row's opacity word - and the walk starts at the topmost such pad.  A kernel of its
+// own: the plain form's arguments and code stay as they were measured.
+template <int ASH, int KEEP, int NT>
+__global__ __launch_bounds__ (64) void k_aggregate_direct_cull (AggregateParams p, OpacityMaps om, uint8_t *__restrict__ dst, int dstride, int rx0, int ry0,
+    int rw)
+{
+  const int lane = (int) threadIdx.x;
+  const int y = ry0 + (int) blockIdx.y;
+  const int last = rx0 + rw - 4;
+  int wx0 = rx0 + (int) blockIdx.x * 256;
+  const int wx1 = wx0 + 256 < rx0 + rw ? wx0 + 256 : rx0 + rw;
+  int x = wx0 + 4 * lane;
+  x = x < last ? x : last;
+  wx0 = wx0 < last ? wx0 : last;
+  const int k = lane < p.n_pads ? lane : 0;
+  const PadDev pad = p.pads[k];
+  const bool hit = (lane < p.n_pads) & pad_hits_strip (pad, wx0, wx1, y);
+  DirectPads dp;
+  const unsigned long long hits = __ballot (hit);
+  const unsigned long long covers = __ballot (hit && pad_covers_strip (pad, om.map[k], (om.all >> k) & 1u, wx0, wx1, y));
+  dp.mask = cull_mask (hits, covers);
+  const uint64_t prow = (uint64_t) (uintptr_t) (pad.data + (ptrdiff_t) (y - pad.ypos) * pad.stride);
+  dp.row_lo = (uint32_t) prow;
+  dp.row_hi = (uint32_t) (prow >> 32);
+  dp.alpha8081 = (uint32_t) pad.s_alpha * 0x8081u;
+  dp.xpos = pad.xpos;
+  dp.width = pad.width;
+  uint8_t *row = dst + (size_t) y * dstride;
+  px4 d;
+  if (KEEP)
+    d = *(const px4 *) (row + 4 * (size_t) x);
+  else
+    d.v[0] = d.v[1] = d.v[2] = d.v[3] = 0;
+  aggregate_direct4<ASH, NT, KEEP> (p, dp, d.v, x, y);
+  store_px4_stream (row + 4 * (size_t) x, d);
+}
+
+// gstamd_compositor_pad_opacity_map: one wave = 256 pixels of one pad row, four per lane; 16 lanes = one bit of the row's word
+__global__ __launch_bounds__ (64) void k_opacity_map (const uint8_t *__restrict__ src, int w, int stride, int ashift, unsigned long long *__restrict__ map)
+{
+  const int lane = (int) threadIdx.x, y = (int) blockIdx.y;
+  const int x = ((int) blockIdx.x * 64 + lane) * 4;
+  const uint8_t *row = src + (size_t) y * stride;
+  bool ok = true;
+  for (int i = 0; i < 4; i++)
+    if (x + i < w)
+      ok &= ((load_px1 (row + 4 * (size_t) (x + i)) >> ashift) & 0xffu) == 0xffu;
+  const unsigned long long b = __ballot (ok);
+  if (lane == 0) {
+    unsigned long long bits = 0;
+    for (int j = 0; j < 4; j++)
+      if ((int) blockIdx.x * 256 + 64 * j < w && ((b >> (16 * j)) & 0xffffull) == 0xffffull)
+        bits |= 1ull << ((int) blockIdx.x * 4 + j);
+    if (bits)
+      atomicOr (&map[y], bits);
+  }
+}
+
+static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, int ry0, int rw, int rh, void *stream, const OpacityMaps *om = nullptr)
 {
   if (rw <= 0 || rh <= 0)
     return GSTAMD_OK;
@@ -370,6 +429,16 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
 #else
     const int nt = AGG_DIRECT_NT;
 #endif
+    if (om) {
+#define AGG_CULL_LAUNCH(S, K) hipLaunchKernelGGL ((k_aggregate_direct_cull<S, K, AGG_DIRECT_NT>), dgrid, dim3 (64), 0, (hipStream_t) stream, q, *om, (uint8_t *) dest, dstride, rx0, ry0, rw)
+      if (q.ashift == 0) {
+        if (q.bg_kind == 2) AGG_CULL_LAUNCH (0, 1); else AGG_CULL_LAUNCH (0, 0);
+      } else {
+        if (q.bg_kind == 2) AGG_CULL_LAUNCH (24, 1); else AGG_CULL_LAUNCH (24, 0);
+      }
+#undef AGG_CULL_LAUNCH
+      return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
+    }
 #define AGG_DIRECT_LAUNCH(S, K) do { if (nt) hipLaunchKernelGGL ((k_aggregate_direct<S, K, 1>), dgrid, dim3 (64), 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw); \
       else hipLaunchKernelGGL ((k_aggregate_direct<S, K, 0>), dgrid, dim3 (64), 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw); } while (0)
     if (q.ashift == 0) {
@@ -553,7 +622,34 @@ int gstamd_compositor_fill_color (int format, void *dest, int dw, int dh, int ds
   return launch (p, dest, dstride, 0, y_start, dstride / 4, y_end - y_start, stream);
 }
 
+static int aggregate_impl (int format, int background, const GstAmdCompositorPad *pads, const GstAmdCompositorPadOpacity *opacity, int n_pads, void *dest,
+    int dw, int dh, int dstride, void *stream);
+
 int gstamd_compositor_aggregate (int format, int background, const GstAmdCompositorPad *pads, int n_pads, void *dest,
+    int dw, int dh, int dstride, void *stream)
+{
+  return aggregate_impl (format, background, pads, nullptr, n_pads, dest, dw, dh, dstride, stream);
+}
+
+int gstamd_compositor_aggregate_opaque (int format, int background, const GstAmdCompositorPad *pads, const GstAmdCompositorPadOpacity *opacity, int n_pads,
+    void *dest, int dw, int dh, int dstride, void *stream)
+{
+  return aggregate_impl (format, background, pads, opacity, n_pads, dest, dw, dh, dstride, stream);
+}
+
+int gstamd_compositor_pad_opacity_map (int format, const void *data, int width, int height, int stride, uint64_t *map, void *stream)
+{
+  const int ashift = family_ashift (format);
+  if (ashift < 0 || !data || !map || width <= 0 || height <= 0 || width > 4096)
+    return GSTAMD_ERR_INVALID;
+  if (hipMemsetAsync (map, 0, (size_t) height * sizeof (uint64_t), (hipStream_t) stream) != hipSuccess)
+    return GSTAMD_ERR_HIP;
+  hipLaunchKernelGGL (k_opacity_map, dim3 ((width + 255) / 256, height), dim3 (64), 0, (hipStream_t) stream, (const uint8_t *) data, width, stride, ashift,
+      (unsigned long long *) map);
+  return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
+}
+
+static int aggregate_impl (int format, int background, const GstAmdCompositorPad *pads, const GstAmdCompositorPadOpacity *opacity, int n_pads, void *dest,
     int dw, int dh, int dstride, void *stream)
 {
   if (is_wide64 (format)) {
@@ -640,14 +736,25 @@ int gstamd_compositor_aggregate (int format, int background, const GstAmdComposi
   }
   int done = 0;
   bool first = true;
+  OpacityMaps om;
   while (first || done < n_pads) {
     p.n_pads = 0;
+    memset (&om, 0, sizeof (om));
+    bool any_opaque = false;
     while (done < n_pads && p.n_pads < GSTAMD_MAX_FUSED_PADS) {
-      const GstAmdCompositorPad &in = pads[done++];
+      const GstAmdCompositorPad &in = pads[done];
+      const GstAmdCompositorPadOpacity *op = opacity ? &opacity[done] : nullptr;
+      done++;
       int s_alpha = (int) (in.alpha * 255);
       s_alpha = s_alpha < 0 ? 0 : (s_alpha > 255 ? 255 : s_alpha);
       if (s_alpha == 0 || !in.data)
         continue;
+      if (op && s_alpha == 255 && (op->all_opaque || (op->map && in.width <= 4096))) {
+        om.map[p.n_pads] = (const unsigned long long *) op->map;
+        if (op->all_opaque)
+          om.all |= 1u << p.n_pads;
+        any_opaque = true;
+      }
       PadDev &pd = p.pads[p.n_pads++];
       pd.data = (const uint8_t *) in.data;
       pd.width = in.width;
@@ -658,7 +765,7 @@ int gstamd_compositor_aggregate (int format, int background, const GstAmdComposi
       pd.s_alpha = s_alpha;
       pd.mode = in.blend_mode;
     }
-    int r = launch (p, dest, dstride, 0, 0, dw, dh, stream);
+    int r = launch (p, dest, dstride, 0, 0, dw, dh, stream, any_opaque ? &om : nullptr);
     if (r != GSTAMD_OK)
       return r;
     p.bg_kind = 2;                                /* further chunks continue on the canvas */

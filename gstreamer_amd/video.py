@@ -78,6 +78,11 @@ class CompositorPad(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class CompositorPadOpacity(C.Structure):
+    """GstAmdCompositorPadOpacity: what is known about a pad's pixel alpha (gstamd_compositor_aggregate_opaque)"""
+    _fields_ = [("map", C.c_void_p), ("all_opaque", C.c_int32), ("reserved", C.c_int32)]
+
+
 class CompositorScaledPad(C.Structure):
     """GstAmdCompositorScaledPad: a pad's frame as it arrives + the converter that scales it (None: blended as it is)"""
     _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
@@ -142,6 +147,9 @@ def lib():
                                                        C.c_int, C.c_int, C.c_int, C.c_void_p]
             L.gstamd_compositor_aggregate.argtypes = [C.c_int, C.c_int, C.POINTER(CompositorPad), C.c_int, C.c_void_p,
                                                       C.c_int, C.c_int, C.c_int, C.c_void_p]
+            L.gstamd_compositor_aggregate_opaque.argtypes = [C.c_int, C.c_int, C.POINTER(CompositorPad), C.POINTER(CompositorPadOpacity), C.c_int,
+                                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+            L.gstamd_compositor_pad_opacity_map.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
             L.gstamd_compositor_aggregate_scaled.argtypes = [C.c_int, C.c_int, C.POINTER(CompositorScaledPad), C.c_int, C.c_void_p,
                                                              C.c_int, C.c_int, C.c_int, C.c_void_p]
             L.gstamd_compositor_pad_scaler_usable.argtypes = [C.c_void_p]

@@ -341,6 +341,22 @@ typedef struct GstAmdCompositorPad {
 int gstamd_compositor_aggregate (int format, int background, const GstAmdCompositorPad *pads,
     int n_pads, void *dest, int dw, int dh, int dstride, void *stream);
 
+/* gstamd_compositor_aggregate that reads fewer bytes than blend_pads (compositor.c:1678-1697) does: where a pad with alpha 1.0 covers a whole
+ * 256-pixel strip of a canvas row with pixels of alpha 255, OVER / ADD leave the pad's own pixel ((s * 255 + d * 0) / 255, BLEND_A32 blend.c:96-132)
+ * and nothing under that pad is read for the strip.  The output is the same byte for byte.  opacity[i] says what is known about pad i (NULL array:
+ * nothing, the plain aggregate): all_opaque for a pad whose frame was converted from a format without alpha, or a map made once per pad frame by
+ * gstamd_compositor_pad_opacity_map (a still image, a logo, a frame composited more than once).  Launches without the direct form (a SOURCE pad, a
+ * transparent background, pads narrower than 4 pixels) and 64-bit canvases ignore the hints. */
+typedef struct GstAmdCompositorPadOpacity {
+  const uint64_t *map;          /* device pointer: pad-height words, bit b of word r = pixels [64 b, 64 b + 64) of pad row r all have alpha 255; or NULL */
+  int32_t all_opaque;           /* 1: every pixel of the pad has alpha 255 */
+  int32_t reserved;
+} GstAmdCompositorPadOpacity;
+int gstamd_compositor_aggregate_opaque (int format, int background, const GstAmdCompositorPad *pads,
+    const GstAmdCompositorPadOpacity *opacity, int n_pads, void *dest, int dw, int dh, int dstride, void *stream);
+/* the map of one pad frame (width <= 4096): `map` is a device buffer of `height` words, written on `stream` */
+int gstamd_compositor_pad_opacity_map (int format, const void *data, int width, int height, int stride, uint64_t *map, void *stream);
+
 /* Pads that are SCALED into the canvas (BASELINE C4 variant A): the reference gives each such pad a converter
  * (GstVideoAggregatorConvertPad, gstvideoaggregator.c:479-513) and blends the converted frame.  Here the pad hands over its frame as
  * it arrived plus its converter, and the scaled pixels are evaluated inside the blend pass - no scaled frame in HBM, one launch per

@@ -935,6 +935,7 @@ amd_comp_compose (GstAmdCompositor * c, GstAmdCompositorPadObj ** pads, GstBuffe
   const int fmt = amd_format_of (GST_VIDEO_INFO_FORMAT (&c->out_info));
   const gboolean by_planes = !GST_VIDEO_INFO_HAS_ALPHA (&c->out_info);
   GstAmdCompositorFramePad fdesc[AMD_COMP_MAX_PADS];
+  GstAmdCompositorPadOpacity odesc[AMD_COMP_MAX_PADS];
   GstAmdVideoConverter *inline_conv[AMD_COMP_MAX_PADS];
   gboolean any_inline = FALSE;
   gint pad_w[AMD_COMP_MAX_PADS], pad_h[AMD_COMP_MAX_PADS], pad_x[AMD_COMP_MAX_PADS], pad_y[AMD_COMP_MAX_PADS];
@@ -1026,6 +1027,7 @@ amd_comp_compose (GstAmdCompositor * c, GstAmdCompositorPadObj ** pads, GstBuffe
       th = pad_h[i];
       GstAmdVideoConverterConfig pcfg;
       gboolean have_cfg, cfg_changed;
+      odesc[n_desc].all_opaque = 0;
 #if AMD_COMP_VAGG
       {
         /* GstVideoAggregatorConvertPad keeps converter-config privately: read it through the property, notice changes by comparing */
@@ -1099,6 +1101,7 @@ amd_comp_compose (GstAmdCompositor * c, GstAmdCompositorPadObj ** pads, GstBuffe
           goto done_inputs;
         }
         desc[n_desc].data = p->conv_buf;
+        odesc[n_desc].all_opaque = !have_cfg && !GST_VIDEO_INFO_HAS_ALPHA (&p->info);
         desc[n_desc].width = tw;
         desc[n_desc].height = th;
         desc[n_desc].stride = p->conv_out.stride[0];
@@ -1122,6 +1125,10 @@ amd_comp_compose (GstAmdCompositor * c, GstAmdCompositorPadObj ** pads, GstBuffe
         }
       }
     }
+    /* a frame a default converter made from a format without alpha has alpha 255 everywhere (the unpackers' 0xff, alpha-mode copy): strips of the
+     * canvas it covers at pad alpha 1.0 need nothing from the pads under it (gstamd_compositor_aggregate_opaque - blend_pads' bytes all the same) */
+    odesc[n_desc].map = NULL;
+    odesc[n_desc].reserved = 0;
     desc[n_desc].xpos = pad_x[i];
     desc[n_desc].ypos = pad_y[i];
     desc[n_desc].alpha = p->alpha;
@@ -1194,7 +1201,7 @@ amd_comp_compose (GstAmdCompositor * c, GstAmdCompositorPadObj ** pads, GstBuffe
     r = gstamd_compositor_aggregate_scaled (fmt, c->background, sdesc, (int) n_desc, canvas, GST_VIDEO_INFO_WIDTH (&c->out_info),
         GST_VIDEO_INFO_HEIGHT (&c->out_info), GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, 0), c->stream);
   } else {
-    r = gstamd_compositor_aggregate (fmt, c->background, desc, (int) n_desc, canvas, GST_VIDEO_INFO_WIDTH (&c->out_info),
+    r = gstamd_compositor_aggregate_opaque (fmt, c->background, desc, odesc, (int) n_desc, canvas, GST_VIDEO_INFO_WIDTH (&c->out_info),
         GST_VIDEO_INFO_HEIGHT (&c->out_info), GST_VIDEO_INFO_PLANE_STRIDE (&c->out_info, 0), c->stream);
   }
   if (r == GSTAMD_OK) {

@@ -11,7 +11,35 @@ extern "C" int emu_compositor_direct_runs (void) { return emu_direct_runs; }
 extern "C" int emu_compositor_rows_runs (void) { return emu_rows_runs; }
 extern "C" int emu_compositor_strip_runs (void) { return emu_strip_runs; }
 
+static long emu_culled = 0;
+extern "C" long emu_compositor_culled (void) { return emu_culled; }          /* pad-strip hits the culled form left out so far */
+static void run_impl (const AggregateParams *p, const OpacityMaps *om, uint8_t *dst, int dstride, int rx0, int ry0, int rw, int rh);
+
 extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int dstride, int rx0, int ry0, int rw, int rh)
+{
+  run_impl (p, nullptr, dst, dstride, rx0, ry0, rw, rh);
+}
+
+/* k_aggregate_direct_cull where launch () takes it (the direct form), the plain kernels elsewhere: maps[k] / all as OpacityMaps, indexed like p->pads */
+extern "C" void emu_compositor_run_cull (const AggregateParams *p, const unsigned long long *const *maps, unsigned all, uint8_t *dst, int dstride, int rx0,
+    int ry0, int rw, int rh)
+{
+  OpacityMaps om;
+  memset (&om, 0, sizeof (om));
+  for (int k = 0; k < p->n_pads; k++)
+    om.map[k] = maps[k];
+  om.all = all;
+  run_impl (p, &om, dst, dstride, rx0, ry0, rw, rh);
+}
+
+/* gstamd_compositor_pad_opacity_map's result (k_opacity_map computes the same bits with a ballot) */
+extern "C" void emu_compositor_opacity_map (const uint8_t *data, int w, int h, int stride, int ashift, unsigned long long *map)
+{
+  for (int y = 0; y < h; y++)
+    map[y] = opacity_row_bits (data + (size_t) y * stride, w, ashift);
+}
+
+static void run_impl (const AggregateParams *p, const OpacityMaps *om, uint8_t *dst, int dstride, int rx0, int ry0, int rw, int rh)
 {
   /* same lane decomposition as k_aggregate: 4 pixels per lane, scalar tail */
   AggregateParams q = *p;
@@ -86,7 +114,12 @@ extern "C" void emu_compositor_run (const AggregateParams *p, uint8_t *dst, int 
     for (int y = ry0; y < ry0 + rh; y++)
       for (int s0 = rx0; s0 < rx0 + rw; s0 += 256) {
         const int wx1 = s0 + 256 < rx0 + rw ? s0 + 256 : rx0 + rw, wx0 = s0 < last ? s0 : last;
-        const DirectPads dp = direct_pads_host (q, wx0, wx1, y);
+        DirectPads dp = direct_pads_host (q, wx0, wx1, y);
+        if (om) {
+          const unsigned long long kept = cull_mask (dp.mask, direct_cover_mask_host (q, *om, wx0, wx1, y));
+          emu_culled += __builtin_popcountll (dp.mask) - __builtin_popcountll (kept);
+          dp.mask = kept;
+        }
         uint32_t out[64][4];
         int xs[64], nl = 0;
         /* all lanes of the wave read (KEEP) before any of them stores, like the SIMD does */

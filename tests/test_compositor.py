@@ -840,3 +840,145 @@ def test_hip_column_walk_is_not_taken_by_pad_sets_it_cannot_serve(native_lib, gp
         got = hip_scaled(gpu, "BGRA", 0, layout, frames, 120, 80)
         assert V.lib().gstamd_internal_last_scaled_kernel() == 2, layout
         assert (exp == got).all(), layout
+
+
+# ---- opaque culling (gstamd_compositor_aggregate_opaque) ---------------------------------------------------------------------------
+CULL_PW, CULL_PH = 330, 41
+
+
+def _cull_pads(fmt, n_pads, seed):
+    """pad frames with known opacity: i % 4 == 0 alpha 255 everywhere (flagged all_opaque), 1: alpha 255 in the columns [64, 256) only, 2: alpha 255 but
+    for one pixel of row 7, 3: random alpha.  Returns the frames and what a caller may claim about each: "all", "map", "map", None"""
+    ash = 0 if FAM[fmt] == "argb" else 3
+    pads, kinds = [], []
+    for i in range(n_pads):
+        f = cases.frame_bytes(CULL_PW * CULL_PH * 4, "random", seed + i).copy().reshape(CULL_PH, CULL_PW, 4)
+        if i % 4 == 0:
+            f[:, :, ash] = 255
+        elif i % 4 == 1:
+            f[:, 64:256, ash] = 255
+            f[:, 63, ash] = 254
+        elif i % 4 == 2:
+            f[:, :, ash] = 255
+            f[7, 200, ash] = 3
+        pads.append(f.reshape(-1))
+        kinds.append(("all", "map", "map", None)[i % 4])
+    return pads, kinds
+
+
+def _cull_geometry(n_pads, dw):
+    """pads of 330 x 41 that cover whole 256-pixel strips of some rows, piled on each other; most at pad alpha 1.0"""
+    return [((i * 97) % max(1, dw - 200) - 40, (i * 13) % 50 - 6, 0.5 if i % 7 == 3 else 1.0, 1 if i % 5 else 2) for i in range(n_pads)]
+
+
+def _opacity_words(frame, w, h, ash):
+    a = frame.reshape(h, w, 4)[:, :, ash]
+    words = np.zeros(h, np.uint64)
+    for b in range((w + 63) // 64):
+        words |= (a[:, 64 * b:64 * b + 64] == 255).all(axis=1).astype(np.uint64) << np.uint64(b)
+    return words
+
+
+def test_opacity_map_body_on_host(emu_lib):
+    emu_lib.emu_compositor_opacity_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    for fmt in ("BGRA", "ARGB"):
+        pads, _ = _cull_pads(fmt, 4, 8100)
+        for f in pads:
+            got = np.zeros(CULL_PH, np.uint64)
+            emu_lib.emu_compositor_opacity_map(f.ctypes.data, CULL_PW, CULL_PH, CULL_PW * 4, 0 if FAM[fmt] == "argb" else 24, got.ctypes.data)
+            assert (got == _opacity_words(f, CULL_PW, CULL_PH, 0 if FAM[fmt] == "argb" else 3)).all()
+    assert int(_opacity_words(pads[1], CULL_PW, CULL_PH, 0)[0]) == 0b001110      # columns [64, 256): blocks 1, 2, 3; the last block is the partial one (330 - 320)
+
+
+@pytest.mark.parametrize("dw,n_pads", [(600, 12), (512, 31), (259, 9)])
+@pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("ARGB", 1), ("AYUV", 0), ("RGBA", 2)])
+def test_aggregate_opaque_culling_on_host_matches_reference(emu_lib, ref, fmt, background, dw, n_pads):
+    """k_aggregate_direct_cull's body: the pads under a strip that an opaque pad covers are left out of the walk, and the canvas is what blend_pads makes
+    of ALL the pads (compositor.c:1678-1697).  Opaque everywhere, opaque in some 64-pixel blocks, opaque but for one pixel, pad alpha below 1, a short last
+    strip (600 = 2 x 256 + 88; 259: the last lane moved back)"""
+    emu_lib.emu_compositor_run_cull.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    emu_lib.emu_compositor_culled.restype = C.c_long
+    dh = 97
+    pads_np, kinds = _cull_pads(fmt, n_pads, 8200)
+    geo = _cull_geometry(n_pads, dw)
+    exp = _aggregate_expected(ref, fmt, background, geo, pads_np, CULL_PW, CULL_PH, dw, dh)
+    ash = 0 if FAM[fmt] == "argb" else 3
+    p = AggParams()
+    p.ashift = 0 if FAM[fmt] == "argb" else 24
+    p.overlay, p.bg_kind, p.checker_yuv = 0, (0 if background == 0 else 1), int(fmt in CHECKER_FN)
+    if background:
+        word = np.zeros(4, np.uint8)
+        ref.compositor_fill(1, fmt.lower(), fmt, word, 1, 1, 0, 1, *_black_white(fmt, background))
+        p.bg_word = int(word.view(np.uint32)[0])
+    maps, keep, all_bits = (C.c_void_p * 32)(), [], 0
+    for i, (xpos, ypos, alpha, mode) in enumerate(geo):
+        pd = p.pads[i]
+        pd.data, pd.width, pd.height, pd.stride = pads_np[i].ctypes.data, CULL_PW, CULL_PH, CULL_PW * 4
+        pd.xpos, pd.ypos, pd.s_alpha, pd.mode = xpos, ypos, int(alpha * 255), mode
+        if kinds[i] == "all":
+            all_bits |= 1 << i
+        elif kinds[i] == "map":
+            keep.append(_opacity_words(pads_np[i], CULL_PW, CULL_PH, ash))
+            maps[i] = keep[-1].ctypes.data
+    p.n_pads = n_pads
+    got = np.zeros(dw * dh * 4, np.uint8)
+    before = emu_lib.emu_compositor_culled()
+    emu_lib.emu_compositor_run_cull(C.byref(p), maps, all_bits, got.ctypes.data, dw * 4, 0, 0, dw, dh)
+    assert emu_lib.emu_compositor_culled() > before          # something was left out
+    assert (exp == got).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dw,n_pads", [(600, 12), (512, 31), (259, 9), (800, 40)])
+@pytest.mark.parametrize("fmt,background", [("BGRA", 0), ("ARGB", 1), ("AYUV", 0), ("RGBA", 2), ("BGRA", 3)])
+def test_hip_aggregate_opaque_matches_reference(native_lib, gpu, ref, fmt, background, dw, n_pads):
+    """gstamd_compositor_aggregate_opaque: the maps from gstamd_compositor_pad_opacity_map (k_opacity_map against numpy), the culled canvas against
+    blend_pads over all the pads; 40 pads: a continuation chunk on the canvas; background 3 (transparent: the overlay functions) ignores the hints"""
+    import torch
+    dh = 97
+    pads_np, kinds = _cull_pads(fmt, n_pads, 8200)
+    geo = _cull_geometry(n_pads, dw)
+    exp = _aggregate_expected(ref, fmt, background, geo, pads_np, CULL_PW, CULL_PH, dw, dh)
+    ash = 0 if FAM[fmt] == "argb" else 3
+    d_pads = [torch.from_numpy(p).to(gpu) for p in pads_np]
+    arr = (V.CompositorPad * n_pads)()
+    opa = (V.CompositorPadOpacity * n_pads)()
+    d_maps = []
+    for i, (xpos, ypos, alpha, mode) in enumerate(geo):
+        arr[i].data, arr[i].width, arr[i].height, arr[i].stride = d_pads[i].data_ptr(), CULL_PW, CULL_PH, CULL_PW * 4
+        arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = xpos, ypos, alpha, mode
+        if kinds[i] == "all":
+            opa[i].all_opaque = 1
+        elif kinds[i] == "map":
+            m = torch.full((CULL_PH,), -1, dtype=torch.int64, device=gpu)
+            V._check(V.lib().gstamd_compositor_pad_opacity_map(V.FORMATS[fmt], d_pads[i].data_ptr(), CULL_PW, CULL_PH, CULL_PW * 4, m.data_ptr(), None))
+            torch.cuda.synchronize()
+            assert (m.cpu().numpy().view(np.uint64) == _opacity_words(pads_np[i], CULL_PW, CULL_PH, ash)).all()
+            d_maps.append(m)
+            opa[i].map = m.data_ptr()
+    d_out = torch.zeros(dw * dh * 4, dtype=torch.uint8, device=gpu)
+    V._check(V.lib().gstamd_compositor_aggregate_opaque(V.FORMATS[fmt], background, arr, opa, n_pads, d_out.data_ptr(), dw, dh, dw * 4, None))
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy() == exp).all()
+    d_out2 = torch.zeros(dw * dh * 4, dtype=torch.uint8, device=gpu)
+    V._check(V.lib().gstamd_compositor_aggregate_opaque(V.FORMATS[fmt], background, arr, None, n_pads, d_out2.data_ptr(), dw, dh, dw * 4, None))
+    torch.cuda.synchronize()
+    assert (d_out2.cpu().numpy() == exp).all()
+
+
+@pytest.mark.gpu
+def test_hip_opacity_map_wide_pad_and_refusals(native_lib, gpu):
+    """a 4096-pixel pad fills all 64 bits of a row's word; wider pads have no map"""
+    import torch
+    w, h = 4096, 3
+    f = np.full((h, w, 4), 255, np.uint8)
+    f[1, 4095, 3] = 0
+    f[2, 0, 3] = 0
+    d = torch.from_numpy(f.reshape(-1)).to(gpu)
+    m = torch.zeros(h, dtype=torch.int64, device=gpu)
+    V._check(V.lib().gstamd_compositor_pad_opacity_map(V.FORMATS["BGRA"], d.data_ptr(), w, h, w * 4, m.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = m.cpu().numpy().view(np.uint64)
+    assert [int(x) for x in got] == [2 ** 64 - 1, 2 ** 63 - 1, 2 ** 64 - 2]
+    assert V.lib().gstamd_compositor_pad_opacity_map(V.FORMATS["BGRA"], d.data_ptr(), 4097, 1, 4097 * 4, m.data_ptr(), None) != 0
+    assert V.lib().gstamd_compositor_pad_opacity_map(V.FORMATS["I420"], d.data_ptr(), 64, 1, 256, m.data_ptr(), None) != 0

@@ -392,6 +392,32 @@ def test_compositor_element_scales_and_converts_pads(gst_env, ref):
     assert "inline-scaled %d" % n in log, log[-500:]
 
 
+def test_compositor_element_picture_in_picture_of_opaque_pads(gst_env, ref):
+    """three I420 / NV12 pads at pad alpha 1.0 piled on a 640-wide BGRA canvas (whole 256-pixel strips of the lower pads hidden) and a translucent one on
+    top: the element hands the converted pads to gstamd_compositor_aggregate_opaque as all_opaque, the canvas is blend_pads' over every pad"""
+    env, tmp = gst_env
+    n, dw, dh = 2, 640, 360
+    f0, f1, f2, fout = tmp / "p0.i420", tmp / "p1.nv12", tmp / "p2.i420", tmp / "p_out.bgra"
+    launch(env, "compositor name=c background=checker sink_1::xpos=100 sink_1::ypos=40 sink_2::xpos=180 sink_2::ypos=90 sink_2::alpha=0.6 "
+                "! video/x-raw,format=BGRA,width=%d,height=%d ! filesink location=%s "
+                "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=I420,width=640,height=360,framerate=30/1,colorimetry=bt601,chroma-site=jpeg ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
+                "videotestsrc num-buffers=%d pattern=ball ! video/x-raw,format=NV12,width=480,height=270,framerate=30/1,colorimetry=bt601,chroma-site=jpeg ! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1 "
+                "videotestsrc num-buffers=%d pattern=snow ! video/x-raw,format=I420,width=320,height=200,framerate=30/1,colorimetry=bt601,chroma-site=jpeg ! tee name=t2 t2. ! queue ! filesink location=%s t2. ! queue ! c.sink_2"
+           % (dw, dh, fout, n, f0, n, f1, n, f2))
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    srcs = [np.fromfile(f, np.uint8).reshape(n, -1) for f in (f0, f1, f2)]
+    convs = [ref.VideoConverter("I420", 640, 360, "BGRA", 640, 360, in_colorimetry="bt601", in_chroma_site="jpeg"),
+             ref.VideoConverter("NV12", 480, 270, "BGRA", 480, 270, in_colorimetry="bt601", in_chroma_site="jpeg"),
+             ref.VideoConverter("I420", 320, 200, "BGRA", 320, 200, in_colorimetry="bt601", in_chroma_site="jpeg")]
+    geo = [(640, 360, 0, 0, 1.0), (480, 270, 100, 40, 1.0), (320, 200, 180, 90, 0.6)]
+    for f in range(n):
+        canvas = np.zeros(dw * dh * 4, np.uint8)
+        ref.compositor_fill(0, "bgra", "BGRA", canvas, dw, dh, 0, dh)
+        for k, (w, h, x, y, a) in enumerate(geo):
+            ref.compositor_blend("blend_bgra", "BGRA", convs[k].frame(srcs[k][f]), w, h, x, y, a, canvas, dw, dh, 0, dh, 1)
+        assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
+
+
 def test_compositor_element_takes_an_a420_pad(gst_env, ref):
     """a pad in A420 (round 5: I420 plus an alpha plane): its converter brings it to the BGRA canvas with the alpha plane copied - the reference's
     convert_A420_BGRA fastpath at the pad's own size - and the blend uses that alpha"""

@@ -54,6 +54,7 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_A444, "A444", true, true, 4, UNPACK_PLANAR_A, 0, 0, 1, 2, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV12, "NV12", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV21, "NV21", true, false, 2, UNPACK_SEMI, 1, 1, 0, 1, {0, 0, 0, 0}},
+  {GSTAMD_VIDEO_FORMAT_Y41B, "Y41B", true, false, 3, UNPACK_PLANAR_H4, 2, 0, 1, 2, {0, 0, 0, 0}},          /* unpack_Y41B / pack_Y41B video-format.c:923-1006 */
   {GSTAMD_VIDEO_FORMAT_AV12, "AV12", true, true, 3, UNPACK_SEMI_A, 1, 1, 1, 0, {0, 0, 0, 0}},          /* unpack_AV12 / pack_AV12 video-format.c: NV12 + an alpha plane */
   {GSTAMD_VIDEO_FORMAT_NV16, "NV16", true, false, 2, UNPACK_SEMI, 1, 0, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV61, "NV61", true, false, 2, UNPACK_SEMI, 1, 0, 0, 1, {0, 0, 0, 0}},
@@ -285,6 +286,13 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->offset[1] = (uint64_t) info->stride[0] * h;
       info->offset[2] = info->offset[1] * 2;
       info->size = (uint64_t) info->stride[0] * h * 3;
+      break;
+    case GSTAMD_VIDEO_FORMAT_Y41B:              /* video-info.c:1010-1019 */
+      info->stride[0] = round_up (width, 4);
+      info->stride[1] = info->stride[2] = round_up (width, 16) / 4;
+      info->offset[1] = (uint64_t) info->stride[0] * height;
+      info->offset[2] = info->offset[1] + (uint64_t) info->stride[1] * height;
+      info->size = ((uint64_t) info->stride[0] + round_up (width, 16) / 2) * height;
       break;
     case GSTAMD_VIDEO_FORMAT_AV12: {            /* video-info.c:1064-1073 */
       const uint64_t h2 = (uint64_t) round_up (height, 2);
@@ -1637,6 +1645,7 @@ constexpr fmask F_YUV3 = fbit (GSTAMD_VIDEO_FORMAT_v308) | fbit (GSTAMD_VIDEO_FO
 constexpr fmask F_GRAY8 = fbit (GSTAMD_VIDEO_FORMAT_GRAY8);
 constexpr fmask F_NV12 = fbit (GSTAMD_VIDEO_FORMAT_NV12), F_NV16 = fbit (GSTAMD_VIDEO_FORMAT_NV16), F_NV24 = fbit (GSTAMD_VIDEO_FORMAT_NV24);
 constexpr fmask F_A420 = fbit (GSTAMD_VIDEO_FORMAT_A420);
+constexpr fmask F_Y41B = fbit (GSTAMD_VIDEO_FORMAT_Y41B);
 constexpr fmask F_RGB16S = fbit (GSTAMD_VIDEO_FORMAT_RGB16) | fbit (GSTAMD_VIDEO_FORMAT_BGR16) | fbit (GSTAMD_VIDEO_FORMAT_RGB15) | fbit (GSTAMD_VIDEO_FORMAT_BGR15);
 struct FastRow {
   fmask in, out;        /* format sets; `same` rows need in == out on top */
@@ -1678,10 +1687,11 @@ const FastRow g_fast_rows[] = {
   {F_RGB4A | F_AYUV | fbit (GSTAMD_VIDEO_FORMAT_ARGB64) | fbit (GSTAMD_VIDEO_FORMAT_AYUV64), ~(fmask) 0, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
   {F_RGB4X | F_RGB3 | F_YUV3 | F_420 | F_Y42B | F_Y444 | fbit (GSTAMD_VIDEO_FORMAT_GBR) | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
         F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_YVYU), ~(fmask) 0, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
-  {F_420 | F_Y42B | F_Y444, F_420 | F_Y42B | F_Y444, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {F_420 | F_Y42B | F_Y444 | F_Y41B, F_420 | F_Y42B | F_Y444 | F_Y41B, false, FP_CROP | FP_BORDER, "convert_scale_planes"},          /* Y41B: :8554-8630 */
+  {F_Y41B, F_Y41B, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
   /* the GRAY8 rows (:8560-8661): the luma plane from / to the planar formats, chroma planes filled with 0x80; GRAY8 -> GRAY8 */
-  {F_420 | F_Y42B | F_Y444, F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
-  {F_GRAY8, F_420 | F_Y42B | F_Y444 | F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {F_420 | F_Y42B | F_Y444 | F_Y41B, F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {F_GRAY8, F_420 | F_Y42B | F_Y444 | F_Y41B | F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_NV12 | F_NV16 | F_NV24, F_NV12 | F_NV16 | F_NV24, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   /* the A420 rows (:8560-8700, 8820-8842): into 4-byte RGB with the alpha plane copied (convert_A420_pack_ARGB / _BGRA: ABGR, RGBA, BGRA only), into the
      alpha-less RGB formats through the I420 functions (BGRx, xBGR, RGBx, RGB, BGR, RGB15, BGR16 - not xRGB, ARGB, RGB16, BGR15), the plane scaler */
@@ -1689,8 +1699,8 @@ const FastRow g_fast_rows[] = {
         FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY, "convert_I420_xRGB"},
   {F_A420, fbit (GSTAMD_VIDEO_FORMAT_BGRx) | fbit (GSTAMD_VIDEO_FORMAT_xBGR) | fbit (GSTAMD_VIDEO_FORMAT_RGBx) | F_RGB3 | fbit (GSTAMD_VIDEO_FORMAT_RGB15) |
         fbit (GSTAMD_VIDEO_FORMAT_BGR16), false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_I420_xRGB(opaque)"},
-  {F_420 | F_Y42B | F_Y444 | F_GRAY8, F_A420, false, FP_CROP | FP_BORDER | FP_ASET, "convert_scale_planes"},
-  {F_A420, F_420 | F_Y42B | F_Y444 | F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
+  {F_420 | F_Y42B | F_Y444 | F_Y41B | F_GRAY8, F_A420, false, FP_CROP | FP_BORDER | FP_ASET, "convert_scale_planes"},
+  {F_A420, F_420 | F_Y42B | F_Y444 | F_Y41B | F_GRAY8, false, FP_CROP | FP_BORDER, "convert_scale_planes"},
   {F_A420, F_A420, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
   /* GBRA / RGBP / BGRP onto themselves (:8851-8856; GBR is in the long row above) */
   {fbit (GSTAMD_VIDEO_FORMAT_RGBP) | fbit (GSTAMD_VIDEO_FORMAT_BGRP), ~(fmask) 0, true, FP_CROP | FP_BORDER, "convert_scale_planes"},
@@ -2395,6 +2405,8 @@ static void fill_pack_params (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   if (differs && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY) {
     if (fo->w_sub == 1)
       pk.down_h = (out->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? 2 : 1;
+    if (fo->w_sub == 2)
+      pk.down_h = (out->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? 4 : 3;
     if (fo->h_sub == 1 && !(out->chroma_site & GSTAMD_CHROMA_SITE_V_COSITED))
       pk.down_v = 1;
   }
@@ -2910,7 +2922,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     } else if (name == "convert_scale_planes" && ki == UNPACK_PACKED4)
       plane_scale = true;
     else if (name == "convert_scale_planes" && (ki == ko || (kind_has_planes (ki) && kind_has_planes (ko)) || (ki == UNPACK_GRAY && ko == UNPACK_PLANAR) ||
-            (ki == UNPACK_PLANAR && ko == UNPACK_GRAY) || ki == UNPACK_PLANAR_A || ko == UNPACK_PLANAR_A))
+            (ki == UNPACK_PLANAR && ko == UNPACK_GRAY) || ki == UNPACK_PLANAR_A || ko == UNPACK_PLANAR_A || ki == UNPACK_PLANAR_H4 || ko == UNPACK_PLANAR_H4))
       return plan_planes (plan, fp);
     else
       return fail (GSTAMD_ERR_UNSUPPORTED, std::string ("reference takes fastpath ") + fp +
@@ -2948,6 +2960,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     if (differs && (fr.w_sub || fr.h_sub)) {
       if (fr.w_sub == 1)
         fr.chroma_h = (in->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? CHROMA_H_H2_CS : CHROMA_H_H2;
+      if (fr.w_sub == 2)
+        fr.chroma_h = (in->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? CHROMA_H_H4_CS : CHROMA_H_H4;
       if (fr.h_sub == 1 && !(in->chroma_site & GSTAMD_CHROMA_SITE_V_COSITED))
         fr.chroma_v2 = 1;      /* video_chroma_up_v2_u8; the cosited variant is an h-only stub */
     }
@@ -3100,6 +3114,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     if (differs && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE && cfg.chroma_mode != GSTAMD_CHROMA_MODE_UPSAMPLE_ONLY) {
       if (fo->w_sub == 1)
         pk.down_h = (out->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? 2 : 1;
+      if (fo->w_sub == 2)
+        pk.down_h = (out->chroma_site & GSTAMD_CHROMA_SITE_H_COSITED) ? 4 : 3;
       if (fo->h_sub == 1 && !(out->chroma_site & GSTAMD_CHROMA_SITE_V_COSITED))
         pk.down_v = 1;          /* the cosited vertical variant is an h-only stub (video-chroma.c:996) */
     }
@@ -3225,7 +3241,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
 
   std::string d = plan->passes.empty () ? (plan->deep16 ? "convert16" : plan->fast_pair ? "fused_convert_pair" : plan->relayout ? "planes_relayout" : plan->fast_enc420 ? "fused_encode_420" : plan->fast_422 ? "fused_convert_422" : plan->fast_420p ? "fused_convert_420p" : "fused_convert") : "scale";
   d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;
-  d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : "";
+  d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : fr.chroma_h == CHROMA_H_H4 ? ",h4" : fr.chroma_h == CHROMA_H_H4_CS ? ",h4cs" : "";
   d += fr.chroma_v2 ? ",v2" : "";
   for (const ScalePass &p : plan->passes)
     d += std::string (p.horizontal ? ",H" : ",V") + std::to_string (p.n_taps) + (p.dot4_ok ? "b" : "");    /* b: byte-dot-product taps */

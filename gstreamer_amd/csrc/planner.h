@@ -31,6 +31,7 @@ enum UnpackKind : int {
   UNPACK_GRAY16 = 10,   // one plane of 16-bit luma (GRAY16_LE / _BE; unpack format AYUV64, U = V = 0x8000); hi_depth code 9 / 10
   UNPACK_PLANAR_A = 12, // I420's planes plus a full-size alpha plane (A420: plane 3); generic per-pixel kernels only (kind_has_planes is false for it)
   UNPACK_SEMI_A = 13,   // NV12's planes plus a full-size alpha plane (AV12: plane 2); generic per-pixel kernels only
+  UNPACK_PLANAR_H4 = 14, // Y, U, V planes with one chroma sample per FOUR pixels of a line (Y41B); generic per-pixel kernels only (kind_has_planes is false)
   UNPACK_RGB16 = 11,    // one plane, a little-endian 16-bit word per pixel with 5-6-5 or 5-5-5 bit fields (RGB16, BGR16, RGB15, BGR15; unpack format ARGB,
                         // 8-bit chain): FormatDesc::pos = {bits of G, first bit of R, of G, of B}
 };
@@ -125,7 +126,8 @@ GSTAMD_VP bool hi_depth_words (int hi) { hi = hi_depth_le (hi); return hi == 1 |
 const FormatDesc *format_desc (int format);
 
 // ---- device-consumable plan pieces (POD, passed to kernels by value) --------------------------
-enum ChromaH : int { CHROMA_H_NONE = 0, CHROMA_H_H2 = 1, CHROMA_H_H2_CS = 2 };
+enum ChromaH : int { CHROMA_H_NONE = 0, CHROMA_H_H2 = 1, CHROMA_H_H2_CS = 2,
+  CHROMA_H_H4 = 3, CHROMA_H_H4_CS = 4 };        // 4:1:1 sources (video_chroma_up_h4_u8 / _h4_cs_u8 video-chroma.c:493-517, 819-838): chroma_h_at only
 enum MatrixKind : int { MATRIX_NONE = 0, MATRIX_AYUV_ARGB = 1, MATRIX_TABLE = 2, MATRIX_8 = 3 };
 enum AlphaKind : int { ALPHA_NONE = 0, ALPHA_SET = 1, ALPHA_MULT = 2 };
 
@@ -193,7 +195,8 @@ struct PackPlanarParams {
   int pos[4];           // FormatDesc::pos of the destination (packed3 / packed422)
   int w_sub, h_sub;
   int u_plane, v_plane; // planar: plane index of U and V; semi: u_first (1) / v_first (0) in u_plane
-  int down_h;           // 0: the even pixel's chroma as it is, 1: video_orc_chroma_down_h2_u8, 2: video_chroma_down_h2_cs_u8
+  int down_h;           // 0: the even pixel's chroma as it is, 1: video_orc_chroma_down_h2_u8, 2: video_chroma_down_h2_cs_u8; 4:1:1 destinations: 3
+                        // video_chroma_down_h4_u8, 4 video_chroma_down_h4_cs_u8 (video-chroma.c:595-612, 880-905)
   int down_v;           // 0: the even line's chroma as it is, 1: video_orc_chroma_down_v2_u8 over lines (2r, 2r+1)
   int tail_swap;        // 1: the last pixel of an odd-width line stores U and V the other way round - pack_VYUY writes it in UYVY
                         // order (video-format.c:374-380), pack_NV61 in NV16 order (:2005-2011); 2 (Y210 / Y212): the second luma of an odd-width line's

@@ -138,6 +138,34 @@ GSTAMD_HD UV chroma_h_at (const FrontParams &f, const Planes &pl, int crow, int 
 {
   if (f.w_sub == 0)
     return load_uv (f, pl, crow, x);
+  if (f.w_sub == 2) {                     // 4:1:1: the unpacker gave pixel x the sample x >> 2 (unpack_Y41B video-format.c:923-974)
+    const int w = f.width;
+    UV c = load_uv (f, pl, crow, x >> 2);
+    if (f.chroma_h == CHROMA_H_H4) {      // video_chroma_up_h4_u8: for (i = 2; i < width - 3; i += 4) pixels i .. i + 3 from samples PR (i - 2), PR (i + 2)
+      const int i = x >= 2 ? 2 + ((x - 2) & ~3) : -1;
+      if (i >= 0 && i < w - 3) {
+        const int g = (i - 2) >> 2, j = x - i;
+        const UV a = load_uv (f, pl, crow, g), b = load_uv (f, pl, crow, g + 1);
+        const int wa = 7 - 2 * j, wb = 1 + 2 * j;         // FILT_7_1, _5_3, _3_5, _1_7
+        c.u = (wa * a.u + wb * b.u + 4) >> 3;
+        c.v = (wa * a.v + wb * b.v + 4) >> 3;
+      }
+    } else if (f.chroma_h == CHROMA_H_H4_CS) {      // video_chroma_up_h4_cs_u8: for (i = 0; i < width - 4; i += 4) pixels i + 1 .. i + 3 from PR (i), PR (i + 4)
+      const int i = x & ~3, j = x & 3;
+      if (j && i < w - 4) {
+        const UV b = load_uv (f, pl, crow, (i >> 2) + 1);
+        if (j == 2) {
+          c.u = (c.u + b.u + 1) >> 1;
+          c.v = (c.v + b.v + 1) >> 1;
+        } else {
+          const int wa = j == 1 ? 3 : 1, wb = 4 - wa;
+          c.u = (wa * c.u + wb * b.u + 2) >> 2;
+          c.v = (wa * c.v + wb * b.v + 2) >> 2;
+        }
+      }
+    }
+    return c;
+  }
   const int k = x >> 1, w = f.width;
   UV c = load_uv (f, pl, crow, k);
   if (f.chroma_h == CHROMA_H_H2_CS) {

@@ -98,6 +98,32 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
       c = ((c + ayuv_uv (src.at (x, yb1)) + 0x00010001u) >> 1) & 0x00ff00ffu;      // avgub on both components
     v[i] = c;
   }
+  if (pk.w_sub == 2) {        // pack_Y41B (video-format.c:976-1006): the chroma of pixel x0 = 4 k after the 4:1:1 downsampler, which works in place on that pixel
+    const int x = x0, k = x0 >> 2;
+    uint32_t c = v[1];
+    auto at = [&] (int xx) {          // chroma pair of pixel xx of the chroma line (vertical average applied), xx inside the row
+      if (xx >= x0 - 1 && xx <= x0 + 4)
+        return v[xx - x0 + 1];
+      uint32_t cc = ayuv_uv (src.at (xx, y0));
+      if (pk.down_v)
+        cc = ((cc + ayuv_uv (src.at (xx, yb1)) + 0x00010001u) >> 1) & 0x00ff00ffu;
+      return cc;
+    };
+    if (pk.down_h == 3) {     // video_chroma_down_h4_u8: for (i = 0; i < width - 4; i += 4) PR (i) = FILT_1_3_3_1 (PR (i) .. PR (i + 3))
+      if (x < w - 4)
+        c = ((v[1] + 3u * (v[2] + v[3]) + v[4] + 0x00040004u) >> 3) & 0x00ff00ffu;
+    } else if (pk.down_h == 4 && w >= 4) {      // video_chroma_down_h4_cs_u8
+      if (x == 0)
+        c = ((10u * v[1] + 3u * v[2] + 2u * v[3] + v[4] + 0x00080008u) >> 4) & 0x00ff00ffu;
+      else if (x < w - 4)
+        c = ((at (x - 3) + 2u * (at (x - 2) + at (x + 2)) + 3u * (at (x - 1) + at (x + 1)) + 4u * at (x) + at (x + 3) + 0x00080008u) >> 4) & 0x00ff00ffu;
+      else
+        c = ((at (x - 3) + 2u * at (x - 2) + 3u * at (x - 1) + 10u * at (x) + 0x00080008u) >> 4) & 0x00ff00ffu;
+    }
+    (d.p[pk.u_plane] + dd)[(size_t) yb * d.stride[pk.u_plane] + k] = (uint8_t) pack_dither (pk.dither, 2, (int) (c & 0xff), x, y0);
+    (d.p[pk.v_plane] + dd)[(size_t) yb * d.stride[pk.v_plane] + k] = (uint8_t) pack_dither (pk.dither, 3, (int) ((c >> 16) & 0xff), x, y0);
+    return;
+  }
   const int step = 1 << pk.w_sub;
   for (int i = 0; i < 4; i += step) {
     const int x = x0 + i;                   // an even pixel when w_sub == 1
@@ -445,6 +471,26 @@ GSTAMD_HD void pack_down_v_px (const PackPlanarParams &pk, uint8_t *img, int str
 GSTAMD_HD void pack_down_h_px (const PackPlanarParams &pk, uint8_t *img, int stride, int x, int yb)
 {
   const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
+  if (pk.w_sub == 2) {          /* video_chroma_down_h4_u8 / _h4_cs_u8 in place: only the pixels 4 k are rewritten, from neighbours that are not */
+    if (x >= w || y0 >= h || !pk.down_h || (x & 3))
+      return;
+    uint32_t *r4 = (uint32_t *) (img + (size_t) y0 * stride);
+    auto at = [&] (int xx) { return ayuv_uv (r4[xx]); };
+    uint32_t c4 = at (x);
+    if (pk.down_h == 3) {
+      if (x < w - 4)
+        c4 = ((at (x) + 3u * (at (x + 1) + at (x + 2)) + at (x + 3) + 0x00040004u) >> 3) & 0x00ff00ffu;
+    } else if (pk.down_h == 4 && w >= 4) {
+      if (x == 0)
+        c4 = ((10u * at (0) + 3u * at (1) + 2u * at (2) + at (3) + 0x00080008u) >> 4) & 0x00ff00ffu;
+      else if (x < w - 4)
+        c4 = ((at (x - 3) + 2u * (at (x - 2) + at (x + 2)) + 3u * (at (x - 1) + at (x + 1)) + 4u * at (x) + at (x + 3) + 0x00080008u) >> 4) & 0x00ff00ffu;
+      else
+        c4 = ((at (x - 3) + 2u * at (x - 2) + 3u * at (x - 1) + 10u * at (x) + 0x00080008u) >> 4) & 0x00ff00ffu;
+    }
+    r4[x] = (r4[x] & 0xffffu) | ((c4 & 0xffu) << 16) | ((c4 >> 16) << 24);
+    return;
+  }
   if (x >= w || y0 >= h || pk.w_sub != 1 || !pk.down_h || (x & 1))
     return;
   uint32_t *ra = (uint32_t *) (img + (size_t) y0 * stride);

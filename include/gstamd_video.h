@@ -52,6 +52,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_ABGR = 14,
   GSTAMD_VIDEO_FORMAT_RGB = 15,
   GSTAMD_VIDEO_FORMAT_BGR = 16,
+  GSTAMD_VIDEO_FORMAT_Y41B = 17,       /* planar 4:1:1 */
   GSTAMD_VIDEO_FORMAT_Y42B = 18,
   GSTAMD_VIDEO_FORMAT_YVYU = 19,
   GSTAMD_VIDEO_FORMAT_Y444 = 20,

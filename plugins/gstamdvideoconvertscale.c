@@ -52,7 +52,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #else
 #define AMD_NEWER_FORMATS ""
 #endif
-#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210, v216, r210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y41B, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210, v216, r210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
 
 /* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path
  * (video-converter.c:3304, 3383-3463), so interlaced caps are not negotiated rather than converted as if progressive
@@ -799,7 +799,7 @@ fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_BGRx, GSTAMD_VIDEO_FORMAT_BGRx}, {GST_VIDEO_FORMAT_xRGB, GSTAMD_VIDEO_FORMAT_xRGB},
     {GST_VIDEO_FORMAT_xBGR, GSTAMD_VIDEO_FORMAT_xBGR}, {GST_VIDEO_FORMAT_RGBA, GSTAMD_VIDEO_FORMAT_RGBA},
     {GST_VIDEO_FORMAT_BGRA, GSTAMD_VIDEO_FORMAT_BGRA}, {GST_VIDEO_FORMAT_ARGB, GSTAMD_VIDEO_FORMAT_ARGB},
-    {GST_VIDEO_FORMAT_ABGR, GSTAMD_VIDEO_FORMAT_ABGR}, {GST_VIDEO_FORMAT_Y42B, GSTAMD_VIDEO_FORMAT_Y42B},
+    {GST_VIDEO_FORMAT_ABGR, GSTAMD_VIDEO_FORMAT_ABGR}, {GST_VIDEO_FORMAT_Y42B, GSTAMD_VIDEO_FORMAT_Y42B}, {GST_VIDEO_FORMAT_Y41B, GSTAMD_VIDEO_FORMAT_Y41B},
     {GST_VIDEO_FORMAT_Y444, GSTAMD_VIDEO_FORMAT_Y444}, {GST_VIDEO_FORMAT_NV12, GSTAMD_VIDEO_FORMAT_NV12},
     {GST_VIDEO_FORMAT_NV21, GSTAMD_VIDEO_FORMAT_NV21}, {GST_VIDEO_FORMAT_NV16, GSTAMD_VIDEO_FORMAT_NV16},
     {GST_VIDEO_FORMAT_NV61, GSTAMD_VIDEO_FORMAT_NV61}, {GST_VIDEO_FORMAT_NV24, GSTAMD_VIDEO_FORMAT_NV24},

@@ -71,6 +71,8 @@ def visible_planes(fmt, w, h):
         return [(w, h), (2 * up2(w), up2(h))]
     if fmt == "AV12":
         return [(w, h), (2 * up2(w), up2(h)), (w, h)]
+    if fmt == "Y41B":
+        return [(w, h), ((w + 3) // 4, h), ((w + 3) // 4, h)]
     if fmt in ("NV16", "NV61"):
         return [(w, h), (2 * up2(w), h)]
     if fmt == "NV24":
@@ -1290,6 +1292,63 @@ def _round5_av12_sweep():
 
 VIDEO_CASES += _round5_av12_sweep()
 
+
+# Y41B (planar 4:1:1, UNPACK_PLANAR_H4): the 4 x horizontal chroma resamplers (video_chroma_up_h4 / _h4_cs / down_h4 / _h4_cs), the plane scaler rows
+def _round5_y41b_sweep():
+    out = []
+    for site in (None, "cosited"):
+        t = "_cs" if site else ""
+        for o in ("BGRA", "RGB", "RGB16", "AYUV", "I420", "NV12", "Y42B", "Y444", "A420", "Y41B", "UYVY", "GRAY8", "ARGB64", "I420_10LE", "AV12"):
+            out.append(("y41b_%s_37x7%s" % (o.lower(), t), "Y41B", 37, 7, o, 37, 7, {}, None, site, "random"))
+        for i in ("BGRA", "RGB", "AYUV", "I420", "NV12", "Y42B", "Y444", "A420", "UYVY", "GRAY8", "ARGB64", "I420_10LE", "Y410"):
+            for (w, h) in ((40, 10), (33, 17), (30, 3), (5, 3)):
+                out.append(("%s_y41b_%dx%d%s" % (i.lower(), w, h, t), i, w, h, "Y41B", w, h, {}, None, site, "random"))
+        out += [
+            ("y41b_bgra_down_bilinear" + t, "Y41B", 64, 36, "BGRA", 40, 22, LIN, None, site, "random"),
+            ("y41b_nv12_up_lanczos" + t, "Y41B", 64, 36, "NV12", 100, 50, LAN, None, site, "random"),
+            ("y41b_i420_10le_cubic_odd" + t, "Y41B", 33, 17, "I420_10LE", 50, 40, {}, None, site, "random"),
+            ("bgra_y41b_down_bilinear" + t, "BGRA", 64, 36, "Y41B", 40, 22, LIN, None, site, "random"),
+            ("uyvy_y41b_up_lanczos_odd" + t, "UYVY", 64, 36, "Y41B", 101, 50, LAN, None, site, "random"),
+            ("argb64_y41b_cubic" + t, "ARGB64", 33, 17, "Y41B", 50, 40, {}, None, site, "random"),
+            ("bgra_y41b_floyd_q8" + t, "BGRA", 35, 19, "Y41B", 35, 19, dict(dither_method="floyd-steinberg", dither_quantization=8), None, site, "random"),
+            ("bgra_y41b_bayer_q8" + t, "BGRA", 35, 19, "Y41B", 35, 19, dict(dither_quantization=8), None, site, "random"),
+        ]
+    for w in (1, 2, 3, 4, 7, 8, 9, 12, 13):
+        out.append(("y444_y41b_w%d_cosited" % w, "Y444", w, 2, "Y41B", w, 2, {}, None, "cosited", "random"))
+        out.append(("y444_y41b_w%d" % w, "Y444", w, 2, "Y41B", w, 2, {}, None, None, "random"))
+        out.append(("y41b_y444_w%d_cosited_full" % w, "Y41B", w, 2, "Y444", w, 2, dict(chroma_mode="full"), None, "cosited", "random"))
+        out.append(("y41b_bgra_w%d" % w, "Y41B", w, 2, "BGRA", w, 2, {}, None, None, "random"))
+    out += [
+        ("y41b_y41b_planes_down_bilinear", "Y41B", 64, 36, "Y41B", 40, 22, LIN, None, None, "random"),
+        ("y41b_i420_planes_up_lanczos", "Y41B", 64, 36, "I420", 100, 50, LAN, None, None, "random"),
+        ("i420_y41b_planes_down", "I420", 64, 36, "Y41B", 40, 22, LIN, None, None, "random"),
+        ("y42b_y41b_planes_same_size", "Y42B", 64, 36, "Y41B", 64, 36, {}, None, None, "random"),
+        ("y444_y41b_planes_nearest", "Y444", 64, 36, "Y41B", 64, 50, dict(resampler_method="nearest"), None, None, "random"),
+        ("gray8_y41b_planes_fill", "GRAY8", 40, 10, "Y41B", 40, 10, {}, None, None, "random"),
+        ("y41b_gray8_planes", "Y41B", 40, 10, "GRAY8", 40, 10, {}, None, None, "random"),
+        ("a420_y41b_planes", "A420", 40, 10, "Y41B", 40, 10, {}, None, None, "random"),
+        ("y41b_a420_planes_alpha_0x80", "Y41B", 40, 10, "A420", 40, 10, {}, None, None, "random"),
+        ("y41b_y41b_crop_dest_border", "Y41B", 48, 30, "Y41B", 60, 40, dict(src_x=4, src_y=2, src_width=30, src_height=20, dest_x=8, dest_y=10, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+        ("y41b_y41b_crop_dest_border_unaligned", "Y41B", 48, 30, "Y41B", 61, 40, dict(src_x=6, src_y=3, src_width=30, src_height=20, dest_x=10, dest_y=11, dest_width=31, dest_height=21, border_argb=0x40e0a060), None, None, "random"),
+        ("bgra_y41b_crop_dest_border_odd", "BGRA", 48, 30, "Y41B", 61, 40, dict(src_x=5, src_y=3, src_width=30, src_height=20, dest_x=9, dest_y=11, dest_width=31, dest_height=21, border_argb=0x40e0a060), None, None, "random"),
+        ("y41b_bgra_crop_dest_border_odd", "Y41B", 48, 30, "BGRA", 61, 40, dict(src_x=5, src_y=3, src_width=30, src_height=20, dest_x=9, dest_y=11, dest_width=31, dest_height=21, border_argb=0x40e0a060), None, None, "random"),
+        ("i420_y41b_crop_dest_border_odd", "I420", 48, 30, "Y41B", 61, 40, dict(src_x=5, src_y=3, src_width=30, src_height=20, dest_x=9, dest_y=11, dest_width=31, dest_height=21, border_argb=0x40e0a060), None, None, "random"),
+        ("y41b_bgra_gamma_remap", "Y41B", 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"),
+        ("bgra_y41b_gamma_remap", "BGRA", 40, 8, "Y41B", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"),
+        ("y41b_y41b_primaries", "Y41B", 40, 8, "Y41B", 40, 8, dict(primaries_mode="fast"), "bt709>bt2020", None, "random"),
+        ("ayuv_y41b_alpha_mult", "AYUV", 40, 8, "Y41B", 40, 8, dict(alpha_mode="mult", alpha_value=0.5), None, None, "random"),
+        ("y41b_bgra_alpha_set", "Y41B", 40, 8, "BGRA", 40, 8, dict(alpha_mode="set", alpha_value=0.5), None, None, "random"),
+        ("y41b_i420_chroma_none", "Y41B", 64, 36, "I420", 64, 36, dict(chroma_mode="none"), None, None, "random"),
+        ("i420_y41b_upsample_only", "I420", 64, 36, "Y41B", 64, 36, dict(chroma_mode="upsample-only"), None, None, "random"),
+        ("i420_y41b_downsample_only", "I420", 64, 36, "Y41B", 64, 36, dict(chroma_mode="downsample-only"), None, None, "random"),
+        ("y41b_bgra_1080_strip", "Y41B", 1920, 8, "BGRA", 1920, 8, {}, None, None, "random"),
+        ("bgra_y41b_1080_strip", "BGRA", 1920, 8, "Y41B", 1920, 8, {}, None, None, "random"),
+    ]
+    return out
+
+
+VIDEO_CASES += _round5_y41b_sweep()
+
 # v216 (Y216's samples in U Y0 V Y1 order), r210 (Y410's kind on a big-endian word without alpha bits), GRAY10_LE16
 VIDEO_CASES += [c for f, col in (("v216", "bt709>sRGB"), ("r210", "sRGB>bt709"), ("GRAY10_LE16", "bt709>sRGB")) for c in (
     ("r5m_%s_bgra_37x7" % f.lower(), f, 37, 7, "BGRA", 37, 7, {}, None, None, "random"),
@@ -1427,6 +1486,9 @@ def default_layout(fmt, w, h):
         return [s0, s1, s1, s0], [0, s0 * r2(h), s0 * r2(h) + s1 * r2(h), s0 * r2(h) + 2 * s1 * r2(h)]
     if fmt in ("NV12", "NV21"):
         return [r4(w), r4(w)], [0, r4(w) * r2(h)]
+    if fmt == "Y41B":
+        c = ((w + 15) // 16) * 4
+        return [r4(w), c, c], [0, r4(w) * h, r4(w) * h + c * h]
     if fmt == "AV12":
         return [r4(w)] * 3, [0, r4(w) * r2(h), r4(w) * r2(h) + r4(w) * r2(h) // 2]
     if fmt in ("NV16", "NV61"):

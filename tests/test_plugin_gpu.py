@@ -194,7 +194,7 @@ def test_videoconvertscale_element_round5_formats(gst_env, ref):
     """the formats of round 5 through the element, as a destination and as a source: GRAY16_LE on both runtimes; RGB10A2_LE (1.18) and
     RGBA64_BE / AV12 (1.20) where the runtime knows them (the reference's own version)"""
     env, tmp = gst_env
-    fmts = ["GRAY16_LE", "RGB16", "A420"] + (["RGB10A2_LE", "RGBA64_BE", "AV12"] if env.get("GSTAMD_RUNTIME") == "1.29" else [])
+    fmts = ["GRAY16_LE", "RGB16", "A420", "Y41B"] + (["RGB10A2_LE", "RGBA64_BE", "AV12"] if env.get("GSTAMD_RUNTIME") == "1.29" else [])
     w, h, n = 322, 242, 2
     for fmt in fmts:
         fin, fmid, fout = tmp / ("r5_%s.bgra" % fmt), tmp / ("r5_%s.mid" % fmt), tmp / ("r5_%s.out" % fmt)

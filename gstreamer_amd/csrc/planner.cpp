@@ -2843,6 +2843,14 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    *    two passes is the 2-D scaler's own rule (video-scaler.c:1542-1545), not chain_scale's. */
   bool force_nearest = false, force_ayuv_argb = false, plane_scale = false, force_avg_down = false, order_2d = false, force_opaque = false;
   const char *fp = (cfg.internal_flags & 1) ? nullptr : lookup_fastpath (*plan, alpha_bits, same_matrix && same_primaries);
+  /* setup_scale (:7985-8003), called by the lookup for every row without keeps_size before it looks at the sizes: RGB15 / 16 and the foreign-endian
+     GRAY16 "only with nearest resampling" - the lookup fails and the whole chain runs (with its gamma / dither stages), even for a copy */
+  if (fp && cfg.resampler_method != GSTAMD_RESAMPLER_METHOD_NEAREST) {
+    if (plan->fin->kind == UNPACK_RGB16 && plan->fin == plan->fout)
+      fp = nullptr;
+    else if (plan->fin->kind == UNPACK_GRAY16 && plan->fin->hi_depth == 10)
+      fp = nullptr;
+  }
   plan->gamma.on = false;
   if (cfg.gamma_mode == GSTAMD_GAMMA_MODE_REMAP) {
     /* video_converter_lookup_fastpath :8940-8944: "fastpaths don't do gamma" - they are only looked at for a same-size conversion
@@ -2854,14 +2862,11 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     if (!fp)
       return plan_gamma (in, out, plan, alpha_bits, same_primaries, prim_dm, error);
   }
-  if (fp && plan->fin->kind == UNPACK_RGB16 && plan->fin == plan->fout && cfg.resampler_method != GSTAMD_RESAMPLER_METHOD_NEAREST)
-    fp = nullptr;               /* setup_scale: "only with nearest resampling", asked before it looks at the sizes - the chain runs (and dithers) even for a copy */
   if (fp && plan->fin->kind == UNPACK_GRAY16 && (in->width != out->width || in->height != out->height) &&
       cfg.resampler_method != GSTAMD_RESAMPLER_METHOD_NEAREST) {
-    /* setup_scale (:7985-8003): the plane scaler serves the foreign-endian GRAY16 format with nearest only (the fastpath is dropped and the
-       chain runs); native 16-bit samples go through the u16 plane scalers, which this library has not built */
-    if (plan->fin->hi_depth != 10)
-      order_2d = true;          /* the u16 plane scaler = the chain's u16 passes in gst_video_scaler_2d's order, nothing else between unpack and pack */
+    /* native 16-bit samples go through the u16 plane scalers, which this library has not built: the chain's u16 passes in gst_video_scaler_2d's
+       order, nothing else between unpack and pack */
+    order_2d = true;
     fp = nullptr;
   }
   if (plan->fin->hi_depth == 3)

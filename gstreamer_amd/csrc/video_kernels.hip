@@ -2201,7 +2201,7 @@ hipError_t launch_pack_planar_ed (const PackPlanarParams &pk, uint8_t *img, int 
   const dim3 grid ((pk.width + 255) / 256, rows);
   if (pk.down_v)
     hipLaunchKernelGGL (k_pack_down_v, grid, dim3 (256), 0, stream, pk, img, sstride);
-  if (pk.down_h && pk.w_sub == 1)
+  if (pk.down_h && pk.w_sub >= 1)
     hipLaunchKernelGGL (k_pack_down_h, grid, dim3 (256), 0, stream, pk, img, sstride);
   hipError_t e = hipGetLastError ();
   if (e != hipSuccess)

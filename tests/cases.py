@@ -1349,6 +1349,18 @@ def _round5_y41b_sweep():
 
 VIDEO_CASES += _round5_y41b_sweep()
 
+# setup_scale refuses RGB15 / 16 and GRAY16_BE unless the method is nearest BEFORE the lookup settles (video-converter.c:7985-8003): the whole chain runs
+# for such a same-format "copy", gamma tables and all (device fuzz seed 43003)
+VIDEO_CASES += [
+    ("gray16_be_self_gamma_remap_chain", "GRAY16_BE", 30, 5, "GRAY16_BE", 30, 5, dict(gamma_mode="remap"), None, None, "random"),
+    ("gray16_be_self_gamma_remap_nearest_copy", "GRAY16_BE", 30, 5, "GRAY16_BE", 30, 5, dict(gamma_mode="remap", resampler_method="nearest"), None, None, "random"),
+    ("gray16_le_self_gamma_remap_copy", "GRAY16_LE", 30, 5, "GRAY16_LE", 30, 5, dict(gamma_mode="remap"), None, None, "random"),
+    ("gray16_be_self_gamma_remap_scaled", "GRAY16_BE", 30, 5, "GRAY16_BE", 40, 9, dict(gamma_mode="remap"), None, None, "random"),
+    ("rgb16_self_gamma_remap_chain", "RGB16", 30, 5, "RGB16", 30, 5, dict(gamma_mode="remap"), None, None, "random"),
+    ("bgr15_self_gamma_remap_nearest_copy", "BGR15", 30, 5, "BGR15", 30, 5, dict(gamma_mode="remap", resampler_method="nearest"), None, None, "random"),
+    ("rgb16_self_primaries_chain", "RGB16", 30, 5, "RGB16", 30, 5, dict(primaries_mode="fast"), "sRGB>bt2020", None, "random"),
+]
+
 # v216 (Y216's samples in U Y0 V Y1 order), r210 (Y410's kind on a big-endian word without alpha bits), GRAY10_LE16
 VIDEO_CASES += [c for f, col in (("v216", "bt709>sRGB"), ("r210", "sRGB>bt709"), ("GRAY10_LE16", "bt709>sRGB")) for c in (
     ("r5m_%s_bgra_37x7" % f.lower(), f, 37, 7, "BGRA", 37, 7, {}, None, None, "random"),

@@ -852,6 +852,7 @@ struct DirectPads {
 #ifdef __HIPCC__
   uint32_t row_lo, row_hi, alpha8081;
   int xpos, width;
+  int stride;           // aggregate_direct4_rows only: the pad's pitch, for the rows after the first
 #else
   const AggregateParams *p;
   int y;
@@ -879,6 +880,18 @@ GSTAMD_CD DirectHit direct_hit (const DirectPads &dp, int k)
   h.xpos = pad.xpos;
   h.width = pad.width;
   h.alpha8081 = (uint32_t) pad.s_alpha * 0x8081u;
+#endif
+  return h;
+}
+
+// pad k's row under canvas row (first row of the wave) + r
+GSTAMD_CD DirectHit direct_hit_row (const DirectPads &dp, int k, int r)
+{
+  DirectHit h = direct_hit (dp, k);
+#ifdef __HIPCC__
+  h.row += (ptrdiff_t) r * __builtin_amdgcn_readlane (dp.stride, k);
+#else
+  h.row += (ptrdiff_t) r * dp.p->pads[k].stride;
 #endif
   return h;
 }
@@ -1034,6 +1047,79 @@ GSTAMD_CD void aggregate_direct4 (const AggregateParams &p, const DirectPads &dp
   for (int i = 0; i < 4; i++)
     if (!KEEP || ((touched >> i) & 1))
       d[i] = px2_pack (acc[i]) | (0xffu << ASH);
+}
+
+// R canvas rows per wave (k_aggregate_direct_cull): the culled walk is short - one or two pads a strip where opaque pads pile up - and a wave's life is
+// the three dependent trips to memory (descriptors, opacity words, pad pixels), so a wave takes R rows through them together: the request slots are
+// split R ways (a row with more hits than its share takes another round), masks[r] = hit mask of row y0 + r (0: a row past the rectangle).
+template <int ASH, int NT, int KEEP, int R>
+GSTAMD_CD void aggregate_direct4_rows (const AggregateParams &p, const DirectPads &dp, const unsigned long long *masks, uint32_t (*d)[4], int x, int y0)
+{
+  constexpr int S = AGG_DIRECT_SLOTS / R;
+  Px2 acc[R][4];
+  unsigned long long m[R];
+  uint32_t touched[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    background4 (p, d[r], x, y0 + r);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      acc[r][i] = px2_unpack (d[r][i]);
+    m[r] = masks[r];
+    touched[r] = 0;
+  }
+  for (;;) {
+    unsigned long long any = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      any |= m[r];
+    if (!any)
+      break;
+    AggVec buf[AGG_DIRECT_SLOTS];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      unsigned long long mr = m[r];
+#pragma unroll
+      for (int j = 0; j < S; j++)
+        if (mr) {
+          const DirectHit h = direct_hit_row (dp, mask_first (mr), r);
+          mr &= mr - 1;
+          agg_request<NT> (buf[r * S + j], h.row, 4u * (uint32_t) span4_clamp (x - h.xpos, h.width));
+        }
+    }
+    agg_arrived (buf);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+#pragma unroll
+      for (int j = 0; j < S; j++)
+        if (m[r]) {
+          const DirectHit h = direct_hit_row (dp, mask_first (m[r]), r);
+          m[r] &= m[r] - 1;
+          const int sx = x - h.xpos, w = h.width;
+          if ((unsigned) sx <= (unsigned) (w - 4)) {
+            if (KEEP)
+              touched[r] = 0xf;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              px2_blend_lazy<ASH> (acc[r][i], AGGV (buf[r * S + j], i), h.alpha8081);
+          } else if ((unsigned) (sx + 3) < (unsigned) (w + 3)) {           // lane straddles a pad edge
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              if (sx + i >= 0 && sx + i < w) {
+                if (KEEP)
+                  touched[r] |= 1u << i;
+                px2_blend_lazy<ASH> (acc[r][i], load_px1 (h.row + 4 * (size_t) (sx + i)), h.alpha8081);
+              }
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (!KEEP || ((touched[r] >> i) & 1))
+        d[r][i] = px2_pack (acc[r][i]) | (0xffu << ASH);
 }
 
 }  // namespace gstamd

@@ -22,6 +22,7 @@
 
 using namespace gstamd;
 
+#define AGG_CULL_ROWS 2       /* canvas rows per wave of k_aggregate_direct_cull (1, 2 or 4) */
 #define AGG_DIRECT_NT 1      /* cache policy of k_aggregate_direct's pad requests (1: nt); the tuning build reads GSTAMD_AGG_NT */
 
 struct __attribute__ ((aligned (4))) px4 { uint32_t v[4]; };
@@ -307,12 +308,12 @@ static int family_ashift (int format)
 // k_aggregate_direct with the pads under an opaque strip left out of the mask (compositor_device.h "opaque culling"): lane k also asks whether pad k
 // covers the strip with opaque pixels - one 8-byte load of the pad row's opacity word - and the walk starts at the topmost such pad.  A kernel of its
 // own: the plain form's arguments and code stay as they were measured.
-template <int ASH, int KEEP, int NT>
+template <int ASH, int KEEP, int NT, int R>
 __global__ __launch_bounds__ (64) void k_aggregate_direct_cull (AggregateParams p, OpacityMaps om, uint8_t *__restrict__ dst, int dstride, int rx0, int ry0,
-    int rw)
+    int rw, int rh)
 {
   const int lane = (int) threadIdx.x;
-  const int y = ry0 + (int) blockIdx.y;
+  const int y0 = ry0 + (int) blockIdx.y * R;
   const int last = rx0 + rw - 4;
   int wx0 = rx0 + (int) blockIdx.x * 256;
   const int wx1 = wx0 + 256 < rx0 + rw ? wx0 + 256 : rx0 + rw;
@@ -321,25 +322,49 @@ __global__ __launch_bounds__ (64) void k_aggregate_direct_cull (AggregateParams 
   wx0 = wx0 < last ? wx0 : last;
   const int k = lane < p.n_pads ? lane : 0;
   const PadDev pad = p.pads[k];
-  const bool hit = (lane < p.n_pads) & pad_hits_strip (pad, wx0, wx1, y);
+  const unsigned long long *map = om.map[k];
+  const bool all = (om.all >> k) & 1u;
+  unsigned long long masks[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int y = y0 + r;
+    const bool hit = (lane < p.n_pads) & (y < ry0 + rh) & pad_hits_strip (pad, wx0, wx1, y);
+    const unsigned long long hits = __ballot (hit);
+    const unsigned long long covers = __ballot (hit && pad_covers_strip (pad, map, all, wx0, wx1, y));
+    masks[r] = cull_mask (hits, covers);
+  }
   DirectPads dp;
-  const unsigned long long hits = __ballot (hit);
-  const unsigned long long covers = __ballot (hit && pad_covers_strip (pad, om.map[k], (om.all >> k) & 1u, wx0, wx1, y));
-  dp.mask = cull_mask (hits, covers);
-  const uint64_t prow = (uint64_t) (uintptr_t) (pad.data + (ptrdiff_t) (y - pad.ypos) * pad.stride);
+  dp.mask = 0;
+  const uint64_t prow = (uint64_t) (uintptr_t) (pad.data + (ptrdiff_t) (y0 - pad.ypos) * pad.stride);
   dp.row_lo = (uint32_t) prow;
   dp.row_hi = (uint32_t) (prow >> 32);
   dp.alpha8081 = (uint32_t) pad.s_alpha * 0x8081u;
   dp.xpos = pad.xpos;
   dp.width = pad.width;
-  uint8_t *row = dst + (size_t) y * dstride;
-  px4 d;
-  if (KEEP)
-    d = *(const px4 *) (row + 4 * (size_t) x);
-  else
-    d.v[0] = d.v[1] = d.v[2] = d.v[3] = 0;
-  aggregate_direct4<ASH, NT, KEEP> (p, dp, d.v, x, y);
-  store_px4_stream (row + 4 * (size_t) x, d);
+  dp.stride = pad.stride;
+  px4 d[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    if (KEEP && y0 + r < ry0 + rh)
+      d[r] = *(const px4 *) (dst + (size_t) (y0 + r) * dstride + 4 * (size_t) x);
+    else
+      d[r].v[0] = d[r].v[1] = d[r].v[2] = d[r].v[3] = 0;
+  }
+  uint32_t dv[R][4];
+#pragma unroll
+  for (int r = 0; r < R; r++)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      dv[r][i] = d[r].v[i];
+  aggregate_direct4_rows<ASH, NT, KEEP, R> (p, dp, masks, dv, x, y0);
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (y0 + r < ry0 + rh) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        d[r].v[i] = dv[r][i];
+      store_px4_stream (dst + (size_t) (y0 + r) * dstride + 4 * (size_t) x, d[r]);
+    }
 }
 
 // gstamd_compositor_pad_opacity_map: one wave = 256 pixels of one pad row, four per lane; 16 lanes = one bit of the row's word
@@ -430,13 +455,21 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
     const int nt = AGG_DIRECT_NT;
 #endif
     if (om) {
-#define AGG_CULL_LAUNCH(S, K) hipLaunchKernelGGL ((k_aggregate_direct_cull<S, K, AGG_DIRECT_NT>), dgrid, dim3 (64), 0, (hipStream_t) stream, q, *om, (uint8_t *) dest, dstride, rx0, ry0, rw)
+#ifdef GSTAMD_TUNING
+      const int cr = tuning_int ("GSTAMD_AGG_CULL_ROWS", AGG_CULL_ROWS);
+#else
+      const int cr = AGG_CULL_ROWS;     /* measured on C4's layout with opaque pads: 1 row 16.8 / 19.1 us (all_opaque / maps), 2 rows 16.5 / 19.05, 4 rows 17.25 / 18.7 */
+#endif
+      dim3 cgrid ((rw + 255) / 256, (rh + cr - 1) / cr);
+#define AGG_CULL_LAUNCH_R(S, K, R) hipLaunchKernelGGL ((k_aggregate_direct_cull<S, K, AGG_DIRECT_NT, R>), cgrid, dim3 (64), 0, (hipStream_t) stream, q, *om, (uint8_t *) dest, dstride, rx0, ry0, rw, rh)
+#define AGG_CULL_LAUNCH(S, K) do { if (cr == 1) AGG_CULL_LAUNCH_R (S, K, 1); else if (cr == 2) AGG_CULL_LAUNCH_R (S, K, 2); else AGG_CULL_LAUNCH_R (S, K, 4); } while (0)
       if (q.ashift == 0) {
         if (q.bg_kind == 2) AGG_CULL_LAUNCH (0, 1); else AGG_CULL_LAUNCH (0, 0);
       } else {
         if (q.bg_kind == 2) AGG_CULL_LAUNCH (24, 1); else AGG_CULL_LAUNCH (24, 0);
       }
 #undef AGG_CULL_LAUNCH
+#undef AGG_CULL_LAUNCH_R
       return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
     }
 #define AGG_DIRECT_LAUNCH(S, K) do { if (nt) hipLaunchKernelGGL ((k_aggregate_direct<S, K, 1>), dgrid, dim3 (64), 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw); \

@@ -29,7 +29,7 @@ Knob g_knobs[] = {
   {"GSTAMD_SCALED_TILE_ROWS", false, -1, "", false}, {"GSTAMD_AGG_BX", false, -1, "", false},
   {"GSTAMD_NO_AGG_WALK", false, -1, "", false}, {"GSTAMD_WALK_ROWS", false, -1, "", false}, {"GSTAMD_WALK_XCD", false, -1, "", false},
   /* tuning builds */
-  {"GSTAMD_ABLATE", false, -1, "", false}, {"GSTAMD_AGG_ABLATE", false, -1, "", false}, {"GSTAMD_AGG_ROWS", false, -1, "", false},
+  {"GSTAMD_ABLATE", false, -1, "", false}, {"GSTAMD_AGG_ABLATE", false, -1, "", false}, {"GSTAMD_AGG_ROWS", false, -1, "", false}, {"GSTAMD_AGG_CULL_ROWS", false, -1, "", false},
   {"GSTAMD_AGG_DEPTH", false, -1, "", false}, {"GSTAMD_AGG_STRIP_ROWS", false, -1, "", false}, {"GSTAMD_AGG_STRIP_PX", false, -1, "", false},
   {"GSTAMD_AGG_NT", false, -1, "", false}, {"GSTAMD_FAST_VARIANT", true, -1, "", false}, {"GSTAMD_FUSED_TRACE", true, -1, "", false},
 };

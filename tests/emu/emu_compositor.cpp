@@ -111,15 +111,50 @@ static void run_impl (const AggregateParams *p, const OpacityMaps *om, uint8_t *
      * four pixels left moves back onto the last four */
     emu_direct_runs++;
     const int last = rx0 + rw - 4;
+    if (om) {
+      /* k_aggregate_direct_cull: EMU_CULL_ROWS (default 2, as AGG_CULL_ROWS) canvas rows per wave */
+      const int R = getenv ("EMU_CULL_ROWS") ? atoi (getenv ("EMU_CULL_ROWS")) : 2;
+      for (int y0 = ry0; y0 < ry0 + rh; y0 += R)
+        for (int s0 = rx0; s0 < rx0 + rw; s0 += 256) {
+          const int wx1 = s0 + 256 < rx0 + rw ? s0 + 256 : rx0 + rw, wx0 = s0 < last ? s0 : last;
+          unsigned long long masks[4] = {0, 0, 0, 0};
+          for (int r = 0; r < R; r++) {
+            if (y0 + r >= ry0 + rh)
+              continue;
+            const unsigned long long hits = direct_pads_host (q, wx0, wx1, y0 + r).mask;
+            masks[r] = cull_mask (hits, direct_cover_mask_host (q, *om, wx0, wx1, y0 + r));
+            emu_culled += __builtin_popcountll (hits) - __builtin_popcountll (masks[r]);
+          }
+          DirectPads dp = direct_pads_host (q, wx0, wx1, y0);
+          uint32_t out[64][4][4];
+          int xs[64], nl = 0;
+          for (int lane = 0; lane < 64; lane++) {
+            int x = s0 + 4 * lane;
+            if (x >= rx0 + rw)
+              break;
+            x = x < last ? x : last;
+            for (int r = 0; r < R; r++)
+              for (int i = 0; i < 4; i++)
+                out[nl][r][i] = q.bg_kind == 2 && y0 + r < ry0 + rh ? ((const uint32_t *) (dst + (size_t) (y0 + r) * dstride + 4 * (size_t) x))[i] : 0u;
+#define CULL_CALL(S, K) do { if (R == 1) aggregate_direct4_rows<S, 0, K, 1> (q, dp, masks, out[nl], x, y0); else if (R == 2) aggregate_direct4_rows<S, 0, K, 2> (q, dp, masks, out[nl], x, y0); \
+              else aggregate_direct4_rows<S, 0, K, 4> (q, dp, masks, out[nl], x, y0); } while (0)
+            if (q.ashift == 0 && q.bg_kind == 2) CULL_CALL (0, 1);
+            else if (q.ashift == 0) CULL_CALL (0, 0);
+            else if (q.bg_kind == 2) CULL_CALL (24, 1);
+            else CULL_CALL (24, 0);
+#undef CULL_CALL
+            xs[nl++] = x;
+          }
+          for (int l = 0; l < nl; l++)
+            for (int r = 0; r < R && y0 + r < ry0 + rh; r++)
+              memcpy (dst + (size_t) (y0 + r) * dstride + 4 * (size_t) xs[l], out[l][r], 16);
+        }
+      return;
+    }
     for (int y = ry0; y < ry0 + rh; y++)
       for (int s0 = rx0; s0 < rx0 + rw; s0 += 256) {
         const int wx1 = s0 + 256 < rx0 + rw ? s0 + 256 : rx0 + rw, wx0 = s0 < last ? s0 : last;
-        DirectPads dp = direct_pads_host (q, wx0, wx1, y);
-        if (om) {
-          const unsigned long long kept = cull_mask (dp.mask, direct_cover_mask_host (q, *om, wx0, wx1, y));
-          emu_culled += __builtin_popcountll (dp.mask) - __builtin_popcountll (kept);
-          dp.mask = kept;
-        }
+        const DirectPads dp = direct_pads_host (q, wx0, wx1, y);
         uint32_t out[64][4];
         int xs[64], nl = 0;
         /* all lanes of the wave read (KEEP) before any of them stores, like the SIMD does */

@@ -113,14 +113,22 @@ GSTAMD_HD uint32_t pack_px (const int *pos, uint32_t px)
 // ------------------------------------------------------------------------------------------------
 struct UV { int u, v; };
 
+// the four bytes of a packed 4:2:2 macropixel as one load (rows are 4-byte multiples; a frame pointer of any alignment is fine for a global dword load)
+GSTAMD_HD uint32_t load_macropixel (const uint8_t *p)
+{
+  uint32_t m;
+  __builtin_memcpy (&m, p, 4);
+  return m;
+}
+
 GSTAMD_HD UV load_uv (const FrontParams &f, const Planes &pl, int crow, int k)
 {
   UV r;
   if (f.kind == UNPACK_PACKED422) {      // macropixel k of line crow: U and V at their bytes (unpack_YUY2 & co, video-format.c:155-460)
-    const uint8_t *p = pl.p[0] + (ptrdiff_t) crow * pl.stride[0] + 4 * k;
+    const uint32_t m = load_macropixel (pl.p[0] + (ptrdiff_t) crow * pl.stride[0] + 4 * k);          // one request, not two
     const bool swap = k == f.swap_k;
-    r.u = p[f.pos[swap ? 3 : 2]];
-    r.v = p[f.pos[swap ? 2 : 3]];
+    r.u = (int) ((m >> (8 * f.pos[swap ? 3 : 2])) & 0xffu);
+    r.v = (int) ((m >> (8 * f.pos[swap ? 2 : 3])) & 0xffu);
   } else if (GSTAMD_KIND_SEMI (f.kind)) {
     const uint8_t *p = pl.p[1] + (ptrdiff_t) crow * pl.stride[1] + 2 * k;
     const int c0 = p[0], c1 = p[1];
@@ -208,7 +216,7 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
   if (f.kind == UNPACK_GRAY)             // unpack_GRAY8 (video-format.c:1209, video_orc_unpack_GRAY8): A = 0xff, Y, U = V = 0x80
     return 0x808000ffu | ((uint32_t) pl.p[0][(size_t) y * pl.stride[0] + x] << 8);
   const int yl = y < f.luma_last ? y : f.luma_last;          /* a no-op for the picture's own lines; the line past it clamps like do_unpack_lines */
-  const int Y = f.kind == UNPACK_PACKED422 ? pl.p[0][(size_t) yl * pl.stride[0] + 4 * (size_t) (x >> 1) + f.pos[1] + 2 * (x & 1)]
+  const int Y = f.kind == UNPACK_PACKED422 ? (int) ((load_macropixel (pl.p[0] + (ptrdiff_t) yl * pl.stride[0] + 4 * (x >> 1)) >> (8 * (f.pos[1] + 2 * (x & 1)))) & 0xffu)
       : pl.p[0][(size_t) yl * pl.stride[0] + x];
   UV c;
   if (f.chroma_v2) {

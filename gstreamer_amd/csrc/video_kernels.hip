@@ -1927,6 +1927,13 @@ __global__ __launch_bounds__ (256) void k_bilinear4_rows (Bil4Params b, Dst dst,
   bilinear4_rows_lane (b, dst, pf, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y * b.rows);
 }
 
+// the same lane on a packed 4:2:2 frame: every fetch unpacks a pixel (luma byte, chroma of its macropixel and of the neighbour the upsampler asks for) -
+// two dword loads where k_scale2x2_wave staged the lines through LDS one wave per row and tile (YUY2 4K -> NV12 1080p: 50.7 us in that kernel)
+__global__ __launch_bounds__ (256) void k_bilinear422_rows (Bil4Params b, Dst dst, PostFast pf)
+{
+  bilinear4_rows_lane<1> (b, dst, pf, (int) (blockIdx.x * blockDim.x + threadIdx.x) * 4, (int) blockIdx.y * b.rows);
+}
+
 // bilinear4_up_lane: a wave = 256 outputs x a strip of b.rows output rows (<= 64: one lane per row holds the row's table entries)
 template <int PLAIN>
 __global__ __launch_bounds__ (256) void k_bilinear4_up (Bil4Params b, Dst dst, PostFast pf, uint32_t plain_sel)
@@ -1984,6 +1991,17 @@ hipError_t launch_scale2x2_from_front (const FrontParams &f, const Planes &pl, c
       return hipGetLastError ();
     }
     hipLaunchKernelGGL (k_bilinear4_rows, dim3 (((out_w + 3) / 4 + 255) / 256, (out_h + b.rows - 1) / b.rows), dim3 (256), 0, stream, b, d, pf);
+    return hipGetLastError ();
+  }
+  if (f.kind == UNPACK_PACKED422 && f.hi_depth == 0 && pre.matrix.kind == MATRIX_NONE && pre.alpha_kind == ALPHA_NONE && aligned (dst, 4) && (dstride % 4) == 0 &&
+      !tuning_on ("GSTAMD_NO_BILINEAR4")) {
+    Bil4Params b;
+    memset ((void *) &b, 0, sizeof (b));
+    b.src = pl.p[0], b.sstride = pl.stride[0], b.src_w = f.width, b.src_h = f.height;
+    b.pos1 = f.pos[1], b.pos2 = f.pos[2], b.pos3 = f.pos[3], b.chroma_h = f.chroma_h, b.swap_k = f.swap_k;
+    b.sh = sh, b.sv = sv, b.h_first = h_first ? 1 : 0;
+    b.out_w = out_w, b.out_h = out_h, b.rows = (long) out_w * out_h >= 6000000 ? 2 : 1;
+    hipLaunchKernelGGL (k_bilinear422_rows, dim3 (((out_w + 3) / 4 + 255) / 256, (out_h + b.rows - 1) / b.rows), dim3 (256), 0, stream, b, d, pf);
     return hipGetLastError ();
   }
   if (geom.tile_w > 0 && geom.lds_px * 8 <= WAVE_TILE_LDS_BYTES) {

@@ -407,14 +407,48 @@ struct Bil4Params {
   ScaleDev sh, sv;
   int h_first;
   int out_w, out_h, rows;
+  // the packed 4:2:2 form (bilinear4_rows_lane<1>): `src` is a YUY2 / UYVY / YVYU / VYUY frame, a fetch unpacks one pixel of it - fetch_front's
+  // A = 0xff, Y, and the horizontally upsampled U, V (chroma_h_at); byte positions, ChromaH and FrontParams::swap_k of the source
+  int pos1, pos2, pos3, chroma_h, swap_k;
 };
 
+template <int P422>
 GSTAMD_HD uint32_t bil4_fetch (const Bil4Params &b, const uint8_t *row, int x)
 {
   x = x < b.src_w - 1 ? x : b.src_w - 1;
-  return swizzle4_px (*(const uint32_t *) (row + 4 * (size_t) x), b.sel_in);
+  if (!P422)
+    return swizzle4_px (*(const uint32_t *) (row + 4 * (size_t) x), b.sel_in);
+  const int k = x >> 1;
+  const uint32_t m = load_macropixel (row + 4 * k);
+  const int su = 8 * (k == b.swap_k ? b.pos3 : b.pos2), sv = 8 * (k == b.swap_k ? b.pos2 : b.pos3);
+  const uint32_t Y = (m >> (8 * (b.pos1 + 2 * (x & 1)))) & 0xffu;
+  uint32_t u = (m >> su) & 0xffu, v = (m >> sv) & 0xffu;
+  /* chroma_h_at (video_device.h) */
+  int kn = -1, wa = 0;
+  if (b.chroma_h == CHROMA_H_H2_CS) {
+    if ((x & 1) && x < b.src_w - 1)
+      kn = k + 1, wa = 1;
+  } else if (b.chroma_h == CHROMA_H_H2) {
+    if ((x & 1) && x < b.src_w - 1)
+      kn = k + 1, wa = 3;
+    else if (!(x & 1) && x >= 2)
+      kn = k - 1, wa = 3;
+  }
+  if (kn >= 0) {
+    const uint32_t n = load_macropixel (row + 4 * kn);
+    const uint32_t un = (n >> (8 * (kn == b.swap_k ? b.pos3 : b.pos2))) & 0xffu, vn = (n >> (8 * (kn == b.swap_k ? b.pos2 : b.pos3))) & 0xffu;
+    if (wa == 1) {
+      u = (u + un + 1) >> 1;
+      v = (v + vn + 1) >> 1;
+    } else {
+      u = (3 * u + un + 2) >> 2;
+      v = (3 * v + vn + 2) >> 2;
+    }
+  }
+  return 0xffu | (Y << 8) | (u << 16) | (v << 24);
 }
 
+template <int P422 = 0>
 GSTAMD_HD void bilinear4_rows_lane (const Bil4Params &b, const Dst &dst, const PostFast &pf, int x0, int y0)
 {
   if (x0 >= b.out_w)
@@ -446,16 +480,16 @@ GSTAMD_HD void bilinear4_rows_lane (const Bil4Params &b, const Dst &dst, const P
       uint32_t e, o;
       if (h2) {
         if (!v2) {
-          h2tap_eo (bil4_fetch (b, ra, idx[i]), bil4_fetch (b, ra, idx[i] + 1), fr[i], e, o);
+          h2tap_eo (bil4_fetch<P422> (b, ra, idx[i]), bil4_fetch<P422> (b, ra, idx[i] + 1), fr[i], e, o);
         } else if (b.h_first) {
           uint32_t e2, o2;
-          h2tap_eo (bil4_fetch (b, ra, idx[i]), bil4_fetch (b, ra, idx[i] + 1), fr[i], e, o);
-          h2tap_eo (bil4_fetch (b, rb, idx[i]), bil4_fetch (b, rb, idx[i] + 1), fr[i], e2, o2);
+          h2tap_eo (bil4_fetch<P422> (b, ra, idx[i]), bil4_fetch<P422> (b, ra, idx[i] + 1), fr[i], e, o);
+          h2tap_eo (bil4_fetch<P422> (b, rb, idx[i]), bil4_fetch<P422> (b, rb, idx[i] + 1), fr[i], e2, o2);
           e = v2tap_pk (e, e2, p1s);
           o = v2tap_pk (o, o2, p1s);
         } else {
-          const uint32_t a1 = bil4_fetch (b, ra, idx[i]), a2 = bil4_fetch (b, rb, idx[i]);
-          const uint32_t b1 = bil4_fetch (b, ra, idx[i] + 1), b2 = bil4_fetch (b, rb, idx[i] + 1);
+          const uint32_t a1 = bil4_fetch<P422> (b, ra, idx[i]), a2 = bil4_fetch<P422> (b, rb, idx[i]);
+          const uint32_t b1 = bil4_fetch<P422> (b, ra, idx[i] + 1), b2 = bil4_fetch<P422> (b, rb, idx[i] + 1);
           const uint32_t ae = v2tap_pk (a1 & 0x00ff00ffu, a2 & 0x00ff00ffu, p1s), ao = v2tap_pk (pk_shr<8> (a1), pk_shr<8> (a2), p1s);
           const uint32_t be = v2tap_pk (b1 & 0x00ff00ffu, b2 & 0x00ff00ffu, p1s), bo = v2tap_pk (pk_shr<8> (b1), pk_shr<8> (b2), p1s);
           const uint32_t nf = 256u - fr[i];
@@ -463,11 +497,11 @@ GSTAMD_HD void bilinear4_rows_lane (const Bil4Params &b, const Dst &dst, const P
           o = pk_shr<8> (umul24 (ao, nf) + umul24 (bo, fr[i]));
         }
       } else {
-        const uint32_t a1 = bil4_fetch (b, ra, idx[i]);
+        const uint32_t a1 = bil4_fetch<P422> (b, ra, idx[i]);
         e = a1 & 0x00ff00ffu;
         o = pk_shr<8> (a1);
         if (v2) {
-          const uint32_t a2 = bil4_fetch (b, rb, idx[i]);
+          const uint32_t a2 = bil4_fetch<P422> (b, rb, idx[i]);
           e = v2tap_pk (e, a2 & 0x00ff00ffu, p1s);
           o = v2tap_pk (o, pk_shr<8> (a2), p1s);
         }

@@ -12,7 +12,7 @@ for cfg in "c4" "c4opaque --opaque-hint none" "c4opaque --opaque-hint map" "c4op
   timeout 300 python bench.py --config $cfg > $O/bench_$n.json 2> $O/bench_$n.err
 done
 R=$PWD
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c4opaque -o c4opaque -- python $R/bench.py --config c4opaque --steps 30 --warmup 5 > $R/$O/prof.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_c4opaque -o c4opaque -- python $R/bench.py --config c4opaque --steps 30 --warmup 5 > $R/$O/prof.log 2>&1)
 find $O/prof_c4opaque -name "*kernel_stats.csv" -exec cp {} $O/c4opaque_kernel_stats.csv \; ; rm -rf $O/prof_c4opaque
 for f in $O/pytest_*.log; do tail -n 3 $f; done; for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json,sys

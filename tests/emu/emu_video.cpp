@@ -2060,6 +2060,20 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
           bilinear4_rows_lane (b, d, pf, x0, y0);
       return GSTAMD_OK;
     }
+    if (p.front.kind == UNPACK_PACKED422 && p.front.hi_depth == 0 && sf.pre.matrix.kind == MATRIX_NONE && sf.pre.alpha_kind == ALPHA_NONE &&
+        ((uintptr_t) d0 % 4) == 0 && (dstride % 4) == 0 && !getenv ("EMU_NO_BILINEAR4")) {
+      /* k_bilinear422_rows */
+      Bil4Params b;
+      memset ((void *) &b, 0, sizeof (b));
+      b.src = pl.p[0], b.sstride = pl.stride[0], b.src_w = p.front.width, b.src_h = p.front.height;
+      b.pos1 = p.front.pos[1], b.pos2 = p.front.pos[2], b.pos3 = p.front.pos[3], b.chroma_h = p.front.chroma_h, b.swap_k = p.front.swap_k;
+      b.sh = sh, b.sv = sv, b.h_first = h_first ? 1 : 0;
+      b.out_w = p.out_info.width, b.out_h = p.out_info.height, b.rows = 2;
+      for (int y0 = 0; y0 < b.out_h; y0 += b.rows)
+        for (int x0 = 0; x0 < b.out_w; x0 += 4)
+          bilinear4_rows_lane<1> (b, d, pf, x0, y0);
+      return GSTAMD_OK;
+    }
     if (g.tile_w > 0 && g.lds_px * 8 <= 16384) {      /* k_scale2x2_wave */
       std::vector<uint32_t> la (g.lds_px), lb (g.lds_px);
       for (int y = 0; y < p.out_info.height; y++)

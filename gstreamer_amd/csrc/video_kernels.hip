@@ -1707,7 +1707,7 @@ static int front_packed_ok (const SrcFront &s)
 // byte-dot-product N-tap pass: opaque source (alpha 0xff in, 0xff out) and no colour step before the scaler
 static int dot4_source_ok (const SrcFront &s)
 {
-  return kind_has_planes (s.f.kind) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
+  return (kind_has_planes (s.f.kind) || (s.f.kind == UNPACK_PACKED422 && s.f.hi_depth == 0)) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
 }
 
 // 16-pixel staging of video_hscale420.h: planes with 2x horizontal subsampling, 16-byte luma / interleaved-chroma and 8-byte
@@ -1755,6 +1755,20 @@ hipError_t launch_scale_from_front (bool horizontal, const FrontParams &f, const
 #else
   const int ablate = 0;         /* the stage-skipping switches of k_hscale420_dot4 are dead code in the product build */
 #endif
+  /* a packed 8-bit frame with nothing ahead of the scaler: the lean source (video_scale_fast.h SrcLean) */
+  if (horizontal && geom.tile_w > 0 && geom.lds_px * 4 <= WAVE_TILE_LDS_BYTES && f.hi_depth == 0 && pre.matrix.kind == MATRIX_NONE &&
+      pre.alpha_kind == ALPHA_NONE && (f.kind == UNPACK_PACKED4 || f.kind == UNPACK_PACKED422) && aligned (pl.p[0], 4) && (pl.stride[0] % 4) == 0 &&
+      f.height - 1 <= f.luma_last) {
+    SrcLean ls;
+    memset ((void *) &ls, 0, sizeof (ls));
+    ls.p = pl.p[0], ls.stride = pl.stride[0], ls.width = f.width;
+    ls.p422 = f.kind == UNPACK_PACKED422;
+    ls.sel = (uint32_t) f.pos[0] | ((uint32_t) f.pos[1] << 8) | ((uint32_t) f.pos[2] << 16) | ((uint32_t) f.pos[3] << 24);
+    ls.pos1 = f.pos[1], ls.pos2 = f.pos[2], ls.pos3 = f.pos[3], ls.chroma_h = f.chroma_h, ls.swap_k = f.swap_k;
+    dim3 wgrid ((out_w + geom.tile_w - 1) / geom.tile_w, out_h);
+    hipLaunchKernelGGL (k_hscale_wave<SrcLean>, wgrid, dim3 (64), (size_t) geom.lds_px * 4, stream, ls, sd, d, pf, out_w, out_h, geom.tile_w, geom.lds_px, 0);
+    return hipGetLastError ();
+  }
   const int h420_rows_env = tuning_int ("GSTAMD_H420_ROWS", -1);      /* 0: kernel off */
   if (horizontal && geom.tile16_w > 0 && sd.tapw && dot4_source_ok (src) && h420_source_ok (src) && h420_rows_env != 0) {
     /* lines per wave: the waves of the launch should all be resident at once (one round, no tail of late waves), each walking

@@ -198,31 +198,113 @@ GSTAMD_HD bool src_span8_p422_ok (const SrcFront &s, int x0, int y)
   return x0 >= 2 && x0 + 9 <= s.f.width && y <= s.f.luma_last && (s.f.swap_k < 0 || (x0 >> 1) + 4 < s.f.swap_k);
 }
 GSTAMD_HD bool src_span8_p422_ok (const SrcImage &, int, int) { return false; }
-GSTAMD_HD void src_span8_p422 (const SrcFront &s, int x0, int y, uint32_t *px)
+// one pixel of a packed 4:2:2 line as fetch_front makes it (A = 0xff, Y, horizontally upsampled U, V: load_uv + chroma_h_at of video_device.h), x inside the line
+GSTAMD_HD uint32_t p422_px (const uint8_t *row, int x, int src_w, int pos1, int pos2, int pos3, int chroma_h, int swap_k)
+{
+  const int k = x >> 1;
+  const uint32_t m = load_macropixel (row + 4 * k);
+  const int su = 8 * (k == swap_k ? pos3 : pos2), sv = 8 * (k == swap_k ? pos2 : pos3);
+  const uint32_t Y = (m >> (8 * (pos1 + 2 * (x & 1)))) & 0xffu;
+  uint32_t u = (m >> su) & 0xffu, v = (m >> sv) & 0xffu;
+  /* chroma_h_at (video_device.h) */
+  int kn = -1, wa = 0;
+  if (chroma_h == CHROMA_H_H2_CS) {
+    if ((x & 1) && x < src_w - 1)
+      kn = k + 1, wa = 1;
+  } else if (chroma_h == CHROMA_H_H2) {
+    if ((x & 1) && x < src_w - 1)
+      kn = k + 1, wa = 3;
+    else if (!(x & 1) && x >= 2)
+      kn = k - 1, wa = 3;
+  }
+  if (kn >= 0) {
+    const uint32_t n = load_macropixel (row + 4 * kn);
+    const uint32_t un = (n >> (8 * (kn == swap_k ? pos3 : pos2))) & 0xffu, vn = (n >> (8 * (kn == swap_k ? pos2 : pos3))) & 0xffu;
+    if (wa == 1) {
+      u = (u + un + 1) >> 1;
+      v = (v + vn + 1) >> 1;
+    } else {
+      u = (3 * u + un + 2) >> 2;
+      v = (3 * v + vn + 2) >> 2;
+    }
+  }
+  return 0xffu | (Y << 8) | (u << 16) | (v << 24);
+}
+
+GSTAMD_HD void span8_p422_raw (const uint8_t *row, int x0, int pos1, int pos2, int pos3, int chroma_h, uint32_t *px)
 {
   struct __attribute__ ((aligned (4))) W6 { uint32_t v[6]; };
-  const W6 m = *(const W6 *) (s.pl.p[0] + (size_t) y * s.pl.stride[0] + 2 * (size_t) x0 - 4);
-  const int by = 8 * s.f.pos[1], bu = 8 * s.f.pos[2], bv = 8 * s.f.pos[3];
+  const W6 m = *(const W6 *) (row + 2 * (size_t) x0 - 4);
+  const int by = 8 * pos1, bu = 8 * pos2, bv = 8 * pos3;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const uint32_t cur = m.v[1 + (i >> 1)];
     const int Y = (int) ((cur >> (by + 16 * (i & 1))) & 0xff);
     int u = (int) ((cur >> bu) & 0xff), v = (int) ((cur >> bv) & 0xff);
-    if (s.f.chroma_h == CHROMA_H_H2_CS) {
+    if (chroma_h == CHROMA_H_H2_CS) {
       if (i & 1) {
         const uint32_t n = m.v[2 + (i >> 1)];
         u = (u + (int) ((n >> bu) & 0xff) + 1) >> 1;
         v = (v + (int) ((n >> bv) & 0xff) + 1) >> 1;
       }
-    } else if (s.f.chroma_h == CHROMA_H_H2) {
+    } else if (chroma_h == CHROMA_H_H2) {
       const uint32_t n = m.v[(i & 1) ? 2 + (i >> 1) : (i >> 1)];
       u = (3 * u + (int) ((n >> bu) & 0xff) + 2) >> 2;
       v = (3 * v + (int) ((n >> bv) & 0xff) + 2) >> 2;
     }
-    px[i] = apply_color (s.pre, 0xffu | ((uint32_t) Y << 8) | ((uint32_t) u << 16) | ((uint32_t) v << 24));
+    px[i] = 0xffu | ((uint32_t) Y << 8) | ((uint32_t) u << 16) | ((uint32_t) v << 24);
   }
 }
+GSTAMD_HD void src_span8_p422 (const SrcFront &s, int x0, int y, uint32_t *px)
+{
+  span8_p422_raw (s.pl.p[0] + (size_t) y * s.pl.stride[0], x0, s.f.pos[1], s.f.pos[2], s.f.pos[3], s.f.chroma_h, px);
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    px[i] = apply_color (s.pre, px[i]);
+}
 GSTAMD_HD void src_span8_p422 (const SrcImage &, int, int, uint32_t *) {}
+
+// ------------------------------------------------------------------------------------------------
+// SrcLean: a packed 8-bit frame (4-byte pixels in any byte order, or packed 4:2:2) with no colour step ahead of the scaler - what the wave-tile
+// kernels need of SrcFront in 48 bytes of kernel arguments.  A kernel instantiated on SrcFront carries the whole per-pixel front (every unpack kind,
+// the chroma pair table, two colour matrices: 330 spilled SGPRs in k_scale2x2_wave) and loads a kilobyte of arguments at the start of every one of
+// its ~17 000 short waves: the horizontal 4-tap pass of a 4K frame took 43.4 us from UYVY through SrcFront and 18.9 us from AYUV through SrcImage
+// (profiles/r05/item6_case11 / case16).
+// ------------------------------------------------------------------------------------------------
+struct SrcLean {
+  const uint8_t *p;
+  int stride, width;
+  int p422;             // 0: 4-byte pixels, `sel` the unpack permutation (memory bytes -> A, c1, c2, c3); 1: packed 4:2:2
+  uint32_t sel;
+  int pos1, pos2, pos3, chroma_h, swap_k;       // FormatDesc::pos, ChromaH, FrontParams::swap_k of a packed 4:2:2 source
+  GSTAMD_HD uint32_t at (int x, int y) const
+  {
+    const uint8_t *row = p + (size_t) y * stride;
+    if (!p422)
+      return bperm (0u, *(const uint32_t *) (row + 4 * (size_t) x), sel);
+    return p422_px (row, x, width, pos1, pos2, pos3, chroma_h, swap_k);
+  }
+};
+GSTAMD_HD bool src_span8_ok (const SrcLean &, int) { return false; }
+GSTAMD_HD void src_span8 (const SrcLean &, int, int, uint32_t *) {}
+GSTAMD_HD bool src_p4 (const SrcLean &s) { return !s.p422; }
+GSTAMD_HD void src_span8_p4 (const SrcLean &s, int x0, int y, uint32_t *px)
+{
+  struct __attribute__ ((aligned (4))) W8 { uint32_t v[8]; };
+  const W8 v = *(const W8 *) (s.p + (size_t) y * s.stride + 4 * (size_t) x0);
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    px[i] = bperm (0u, v.v[i], s.sel);
+}
+GSTAMD_HD bool src_p422 (const SrcLean &s) { return s.p422 != 0; }
+GSTAMD_HD bool src_span8_p422_ok (const SrcLean &s, int x0, int)
+{
+  return x0 >= 2 && x0 + 9 <= s.width && (s.swap_k < 0 || (x0 >> 1) + 4 < s.swap_k);
+}
+GSTAMD_HD void src_span8_p422 (const SrcLean &s, int x0, int y, uint32_t *px)
+{
+  span8_p422_raw (s.p + (size_t) y * s.stride, x0, s.pos1, s.pos2, s.pos3, s.chroma_h, px);
+}
 
 // ------------------------------------------------------------------------------------------------
 // wave tiles
@@ -418,34 +500,7 @@ GSTAMD_HD uint32_t bil4_fetch (const Bil4Params &b, const uint8_t *row, int x)
   x = x < b.src_w - 1 ? x : b.src_w - 1;
   if (!P422)
     return swizzle4_px (*(const uint32_t *) (row + 4 * (size_t) x), b.sel_in);
-  const int k = x >> 1;
-  const uint32_t m = load_macropixel (row + 4 * k);
-  const int su = 8 * (k == b.swap_k ? b.pos3 : b.pos2), sv = 8 * (k == b.swap_k ? b.pos2 : b.pos3);
-  const uint32_t Y = (m >> (8 * (b.pos1 + 2 * (x & 1)))) & 0xffu;
-  uint32_t u = (m >> su) & 0xffu, v = (m >> sv) & 0xffu;
-  /* chroma_h_at (video_device.h) */
-  int kn = -1, wa = 0;
-  if (b.chroma_h == CHROMA_H_H2_CS) {
-    if ((x & 1) && x < b.src_w - 1)
-      kn = k + 1, wa = 1;
-  } else if (b.chroma_h == CHROMA_H_H2) {
-    if ((x & 1) && x < b.src_w - 1)
-      kn = k + 1, wa = 3;
-    else if (!(x & 1) && x >= 2)
-      kn = k - 1, wa = 3;
-  }
-  if (kn >= 0) {
-    const uint32_t n = load_macropixel (row + 4 * kn);
-    const uint32_t un = (n >> (8 * (kn == b.swap_k ? b.pos3 : b.pos2))) & 0xffu, vn = (n >> (8 * (kn == b.swap_k ? b.pos2 : b.pos3))) & 0xffu;
-    if (wa == 1) {
-      u = (u + un + 1) >> 1;
-      v = (v + vn + 1) >> 1;
-    } else {
-      u = (3 * u + un + 2) >> 2;
-      v = (3 * v + vn + 2) >> 2;
-    }
-  }
-  return 0xffu | (Y << 8) | (u << 16) | (v << 24);
+  return p422_px (row, x, b.src_w, b.pos1, b.pos2, b.pos3, b.chroma_h, b.swap_k);
 }
 
 template <int P422 = 0>
@@ -714,7 +769,18 @@ GSTAMD_HD void tile_stage_row_planes (const SrcFront &src, uint32_t *py, uint32_
 {
   for (int x0 = xa + 8 * lane; x0 < x_hi; x0 += 8 * 64) {
     const int w0 = (x0 - xa) >> 2;
-    if (packed && src_span8_ok (src, x0)) {
+    if (src_p422 (src) && x0 + 8 <= x_hi && src_span8_p422_ok (src, x0, y)) {
+      /* packed 4:2:2 (alpha 0xff like the planar sources): the eight pixels of the span from its macropixel words, split into the three byte planes */
+      uint32_t px[8];
+      src_span8_p422 (src, x0, y, px);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t a = px[4 * h], b = px[4 * h + 1], c = px[4 * h + 2], d = px[4 * h + 3];
+        py[w0 + h] = (((a >> 8) & 0xffu) | (((b >> 8) & 0xffu) << 8) | (((c >> 8) & 0xffu) << 16) | (((d >> 8) & 0xffu) << 24)) ^ 0x80808080u;
+        pu[w0 + h] = (((a >> 16) & 0xffu) | (((b >> 16) & 0xffu) << 8) | (((c >> 16) & 0xffu) << 16) | (((d >> 16) & 0xffu) << 24)) ^ 0x80808080u;
+        pv[w0 + h] = ((a >> 24) | ((b >> 24) << 8) | ((c >> 24) << 16) | ((d >> 24) << 24)) ^ 0x80808080u;
+      }
+    } else if (packed && src_span8_ok (src, x0)) {
       uint2 yy;
       uint32_t ca[8];
       front_chroma8_packed_any (src.f, src.pl, src.vpair, x0, y, yy, ca);

@@ -4,7 +4,7 @@ set -u
 cd "$(dirname "$0")/.."
 R=$PWD; O=gpurun_out/r05split; mkdir -p $O
 export TMPDIR=/tmp
-for c in 12 8 11; do
+for c in ${CASES:-12 8 11}; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$c -o s -- python $R/scripts/survey_item6.py $c > $R/$O/run_$c.log 2>&1)
   f=$(find $O/prof_$c -name "*kernel_stats.csv" | head -1)
   echo "== case $c"; tail -n 1 $O/run_$c.log | cut -c1-230

@@ -10,7 +10,7 @@ LIN = dict(resampler_method="linear")
 dev = torch.device("cuda:0")
 CASES = [("BGRA", "NV12", BIL, None), ("AYUV", "NV12", BIL, None), ("YUY2", "NV12", BIL, None), ("YUY2", "NV12", dict(BIL, chroma_mode="none"), None),
          ("YUY2", "NV12", BIL, "mpeg2"), ("UYVY", "NV12", BIL, None), ("YUY2", "AYUV", BIL, None), ("YUY2", "BGRA", BIL, None), ("Y42B", "NV12", BIL, None),
-         ("UYVY", "I420", LIN, None), ("AYUV", "I420", LIN, None), ("YUY2", "NV12", {}, None), ("AYUV", "NV12", {}, None)]
+         ("UYVY", "I420", LIN, None), ("AYUV", "I420", LIN, None), ("BGRA", "NV12", LIN, None), ("BGRA", "I420", dict(resampler_method="cubic"), None), ("BGRA", "BGRA", LIN, None), ("YUY2", "NV12", {}, None), ("AYUV", "NV12", {}, None)]
 for ifmt, ofmt, cfg, site in CASES:
     ii, oi = V.video_info(ifmt, 3840, 2160, chroma_site=site), V.video_info(ofmt, 1920, 1080)
     conv = V.VideoConverter(ii, oi, V.converter_config(**cfg))

@@ -18,7 +18,8 @@ CASES = [("NV12", 3840, 2160, "BGRA", 1920, 1080, BIL), ("NV12", 3840, 2160, "BG
          ("BGRA", 1920, 1080, "NV12", 1280, 720, BIL),
          ("P010_10LE", 3840, 2160, "NV12", 1920, 1080, BIL), ("P010_10LE", 3840, 2160, "BGRA", 1920, 1080, BIL), ("P010_10LE", 3840, 2160, "BGRA", 1920, 1080, LIN),
          ("UYVY", 3840, 2160, "I420", 1920, 1080, LIN), ("YUY2", 3840, 2160, "NV12", 1920, 1080, BIL), ("YUY2", 3840, 2160, "NV12", 3840, 2160, {}),
-         ("BGRA", 3840, 2160, "BGRA", 1920, 1080, CUB), ("BGRA", 3840, 2160, "BGRA", 1920, 1080, LIN)]
+         ("BGRA", 3840, 2160, "BGRA", 1920, 1080, CUB), ("BGRA", 3840, 2160, "BGRA", 1920, 1080, LIN),
+         ("AYUV", 3840, 2160, "I420", 1920, 1080, LIN)]
 if len(sys.argv) > 1:
     CASES = [CASES[int(a)] for a in sys.argv[1:]]
 dev = torch.device("cuda:0")

@@ -70,6 +70,7 @@ static int emu_packed_ok (const SrcFront &s)           /* front_packed_ok of vid
   return s.vec_ok && s.f.w_sub == 1 && kind_has_planes (s.f.kind) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
 }
 static int emu_packed_ok (const SrcImage &) { return 1; }
+static int emu_packed_ok (const SrcLean &) { return 0; }
 
 // k_hscale_wave: one wave per tile, staging phase for all 64 lanes, then the filter phase
 template <class SRC>
@@ -652,7 +653,7 @@ static bool emu_scale420_fused (const VideoPlan &p, H420RegParams hp, int nw, in
 
 static bool emu_dot4_ok (const SrcFront &s, const ScaleDev &sd)
 {
-  return sd.tapw && kind_has_planes (s.f.kind) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
+  return sd.tapw && (kind_has_planes (s.f.kind) || (s.f.kind == UNPACK_PACKED422 && s.f.hi_depth == 0)) && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE;
 }
 static bool emu_dot4_ok (const SrcImage &, const ScaleDev &) { return false; }
 static void run_hscale_dot4 (const SrcImage &, const ScaleDev &, const Dst &, const PostFast &, int, int, TileGeom) {}
@@ -681,10 +682,31 @@ static void emu_vscale_pk_rows (const SrcImage &src, const ScaleDev &sd, const D
 }
 static void emu_vscale_pk_rows (const SrcFront &, const ScaleDev &, const Dst &, const PostFast &, int, int, int) {}
 
+/* launch_scale_from_front's first branch: k_hscale_wave<SrcLean> */
+static bool emu_lean_source (const SrcFront &s, SrcLean *ls)
+{
+  const FrontParams &f = s.f;
+  if (!(f.hi_depth == 0 && s.pre.matrix.kind == MATRIX_NONE && s.pre.alpha_kind == ALPHA_NONE && (f.kind == UNPACK_PACKED4 || f.kind == UNPACK_PACKED422) &&
+          ((uintptr_t) s.pl.p[0] % 4) == 0 && (s.pl.stride[0] % 4) == 0 && f.height - 1 <= f.luma_last))
+    return false;
+  memset ((void *) ls, 0, sizeof (*ls));
+  ls->p = s.pl.p[0], ls->stride = s.pl.stride[0], ls->width = f.width;
+  ls->p422 = f.kind == UNPACK_PACKED422;
+  ls->sel = (uint32_t) f.pos[0] | ((uint32_t) f.pos[1] << 8) | ((uint32_t) f.pos[2] << 16) | ((uint32_t) f.pos[3] << 24);
+  ls->pos1 = f.pos[1], ls->pos2 = f.pos[2], ls->pos3 = f.pos[3], ls->chroma_h = f.chroma_h, ls->swap_k = f.swap_k;
+  return true;
+}
+static bool emu_lean_source (const SrcImage &, SrcLean *) { return false; }
+
 template <class SRC>
 static void run_scale (bool horizontal, const SRC &src, const ScaleDev &sd, const Dst &d, int out_w, int out_h, int max_span, TileGeom g,
     const PostFast &pf)
 {
+  SrcLean lean;
+  if (horizontal && g.tile_w > 0 && g.lds_px * 4 <= 16384 && emu_lean_source (src, &lean)) {
+    run_hscale_wave (lean, sd, d, pf, out_w, out_h, g);
+    return;
+  }
   if (horizontal && g.tile16_w > 0 && emu_dot4_ok (src, sd) && emu_h420_ok (src)) {
     run_hscale420 (src, sd, d, pf, out_w, out_h, g);
     return;

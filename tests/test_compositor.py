@@ -982,3 +982,94 @@ def test_hip_opacity_map_wide_pad_and_refusals(native_lib, gpu):
     assert [int(x) for x in got] == [2 ** 64 - 1, 2 ** 63 - 1, 2 ** 64 - 2]
     assert V.lib().gstamd_compositor_pad_opacity_map(V.FORMATS["BGRA"], d.data_ptr(), 4097, 1, 4097 * 4, m.data_ptr(), None) != 0
     assert V.lib().gstamd_compositor_pad_opacity_map(V.FORMATS["I420"], d.data_ptr(), 64, 1, 256, m.data_ptr(), None) != 0
+
+
+def _cull_scene(seed):
+    """a random scene for the culling fuzz: 3..20 pads of random sizes (some wider than a 256-pixel strip) and positions, pad alpha mostly 1.0, OVER / ADD, pixel alpha
+    255 everywhere / in runs of 64-pixel blocks / random; what a caller may claim about each pad ("all", "map", None)"""
+    rng = np.random.default_rng(seed)
+    dw, dh = int(rng.integers(260, 900)), int(rng.integers(20, 70))
+    scene = []
+    for i in range(int(rng.integers(3, 21))):
+        pw, ph = int(rng.integers(4, 700)), int(rng.integers(3, 50))
+        f = rng.integers(0, 256, (ph, pw, 4), dtype=np.uint8)
+        kind = [None, "all", "map", "map"][int(rng.integers(0, 4))]
+        scene.append(dict(w=pw, h=ph, x=int(rng.integers(-pw // 2, dw)), y=int(rng.integers(-ph // 2, dh)), alpha=1.0 if rng.random() < 0.75 else float(rng.random()),
+                          mode=1 if rng.random() < 0.8 else 2, frame=f, kind=kind, rng_blocks=rng.random((ph, (pw + 63) // 64)) < 0.7))
+    return dw, dh, scene
+
+
+def _cull_scene_alpha(scene, ash):
+    for s in scene:
+        f = s["frame"]
+        if s["kind"] == "all":
+            f[:, :, ash] = 255
+        elif s["kind"] == "map":
+            for b in range((s["w"] + 63) // 64):
+                rows = s["rng_blocks"][:, b]
+                f[rows, 64 * b:64 * b + 64, ash] = 255
+        s["bytes"] = np.ascontiguousarray(f).reshape(-1)
+
+
+@pytest.mark.parametrize("seed", range(9100, 9140))
+def test_aggregate_opaque_culling_fuzz_on_host(emu_lib, seed):
+    """random scenes through k_aggregate_direct_cull's body and through the plain kernel's: the same canvas, byte for byte (the plain one is pinned to blend_pads elsewhere)"""
+    emu_lib.emu_compositor_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    emu_lib.emu_compositor_run_cull.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    dw, dh, scene = _cull_scene(seed)
+    fam_argb = seed % 2 == 0
+    ash = 0 if fam_argb else 3
+    _cull_scene_alpha(scene, ash)
+    p = AggParams()
+    p.ashift, p.overlay, p.bg_kind, p.checker_yuv = (0 if fam_argb else 24), 0, 0, 0
+    maps, keep, all_bits, k = (C.c_void_p * 32)(), [], 0, 0
+    for s in scene:
+        sa = max(0, min(255, int(s["alpha"] * 255)))
+        if not sa:
+            continue
+        pd = p.pads[k]
+        pd.data, pd.width, pd.height, pd.stride = s["bytes"].ctypes.data, s["w"], s["h"], s["w"] * 4
+        pd.xpos, pd.ypos, pd.s_alpha, pd.mode = s["x"], s["y"], sa, s["mode"]
+        if sa == 255 and s["kind"] == "all":
+            all_bits |= 1 << k
+        elif sa == 255 and s["kind"] == "map":
+            keep.append(_opacity_words(s["bytes"], s["w"], s["h"], ash))
+            maps[k] = keep[-1].ctypes.data
+        k += 1
+    p.n_pads = k
+    plain, culled = np.zeros(dw * dh * 4, np.uint8), np.zeros(dw * dh * 4, np.uint8)
+    emu_lib.emu_compositor_run(C.byref(p), plain.ctypes.data, dw * 4, 0, 0, dw, dh)
+    emu_lib.emu_compositor_run_cull(C.byref(p), maps, all_bits, culled.ctypes.data, dw * 4, 0, 0, dw, dh)
+    assert (plain == culled).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(9200, 9260))
+def test_hip_aggregate_opaque_fuzz(native_lib, gpu, seed):
+    """random scenes on the device: gstamd_compositor_aggregate_opaque with maps from k_opacity_map / all_opaque flags equals gstamd_compositor_aggregate"""
+    import torch
+    dw, dh, scene = _cull_scene(seed)
+    fmt = ["BGRA", "ARGB", "AYUV", "RGBA"][seed % 4]
+    ash = 0 if FAM[fmt] == "argb" else 3
+    _cull_scene_alpha(scene, ash)
+    n = len(scene)
+    arr, opa, hold = (V.CompositorPad * n)(), (V.CompositorPadOpacity * n)(), []
+    for i, s in enumerate(scene):
+        d = torch.from_numpy(s["bytes"]).to(gpu)
+        hold.append(d)
+        arr[i].data, arr[i].width, arr[i].height, arr[i].stride = d.data_ptr(), s["w"], s["h"], s["w"] * 4
+        arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = s["x"], s["y"], s["alpha"], s["mode"]
+        if s["kind"] == "all":
+            opa[i].all_opaque = 1
+        elif s["kind"] == "map":
+            m = torch.zeros(s["h"], dtype=torch.int64, device=gpu)
+            V._check(V.lib().gstamd_compositor_pad_opacity_map(V.FORMATS[fmt], d.data_ptr(), s["w"], s["h"], s["w"] * 4, m.data_ptr(), None))
+            hold.append(m)
+            opa[i].map = m.data_ptr()
+    background = seed % 3
+    a = torch.zeros(dw * dh * 4, dtype=torch.uint8, device=gpu)
+    b = torch.zeros(dw * dh * 4, dtype=torch.uint8, device=gpu)
+    V._check(V.lib().gstamd_compositor_aggregate(V.FORMATS[fmt], background, arr, n, a.data_ptr(), dw, dh, dw * 4, None))
+    V._check(V.lib().gstamd_compositor_aggregate_opaque(V.FORMATS[fmt], background, arr, opa, n, b.data_ptr(), dw, dh, dw * 4, None))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)

@@ -59,6 +59,11 @@ GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
 #define AMD_COMP_NEWER_CANVAS ""
 #define AMD_COMP_NEWER_PADS ""
 #endif
+#if GST_CHECK_VERSION (1, 20, 0)
+#define AMD_COMP_NEWEST_PADS ", AV12"
+#else
+#define AMD_COMP_NEWEST_PADS ""
+#endif
 #define AMD_COMP_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, I420, YV12, Y42B, Y444, NV12, NV21, RGB, BGR, RGBx, BGRx, xRGB, xBGR, YUY2, UYVY, YVYU, " \
     "I420_10LE, I420_12LE, I422_10LE, I422_12LE, Y444_10LE, Y444_12LE" AMD_COMP_NEWER_CANVAS " }"
 /* what a pad may carry: anything the converter takes; it is brought to the output format / the pad's width x height by a
@@ -66,7 +71,7 @@ GST_DEBUG_CATEGORY_STATIC (amd_comp_debug);
 #define AMD_COMP_PAD_FORMATS "{ BGRA, RGBA, ARGB, ABGR, AYUV, ARGB64, AYUV64, RGBx, BGRx, xRGB, xBGR, RGB, BGR, NV12, NV21, NV16, NV61, NV24, I420, YV12, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, GRAY8, GBR, " \
     "I420_10LE, I420_12LE, I422_10LE, I422_12LE, Y444_10LE, Y444_12LE, P010_10LE, " \
     /* round 5: the converter's newer formats (those every supported runtime's headers know) - A420 first, the alpha-plane format WebM / VP8 alpha decodes to */ \
-    "A420, A420_10LE, A422_10LE, A444_10LE, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, v210, v216, r210, v308, IYU2" AMD_COMP_NEWER_PADS " }"
+    "A420, A420_10LE, A422_10LE, A444_10LE, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, v210, v216, r210, v308, IYU2, Y41B" AMD_COMP_NEWER_PADS AMD_COMP_NEWEST_PADS " }"
 #define AMD_COMP_MAX_PADS 64
 
 static GstStaticPadTemplate comp_sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,

@@ -441,6 +441,31 @@ def test_compositor_element_takes_an_a420_pad(gst_env, ref):
         assert (canvas == out[f]).all(), (f, int((canvas != out[f]).sum()))
 
 
+def test_compositor_element_takes_y41b_and_av12_pads(gst_env, ref):
+    """pads in the last two formats of round 5: Y41B (4:1:1; its converter upsamples the chroma 4 x) and, where the runtime knows it, AV12 (NV12 + an alpha
+    plane: the blend uses that alpha)"""
+    env, tmp = gst_env
+    n, dw, dh = 2, 320, 240
+    fmts = ["Y41B"] + (["AV12"] if env.get("GSTAMD_RUNTIME") == "1.29" else [])
+    for fmt in fmts:
+        f0, f1, fout = tmp / ("q0_%s.bgra" % fmt), tmp / ("q1_%s.raw" % fmt), tmp / ("q_out_%s.bgra" % fmt)
+        launch(env, "compositor name=c background=black sink_1::xpos=40 sink_1::ypos=30 sink_1::alpha=0.8 "
+                    "! video/x-raw,format=BGRA,width=%d,height=%d ! filesink location=%s "
+                    "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=BGRA,width=320,height=240,framerate=30/1 ! tee name=t0 t0. ! queue ! filesink location=%s t0. ! queue ! c.sink_0 "
+                    "videotestsrc num-buffers=%d pattern=ball foreground-color=0x80ffffff ! video/x-raw,format=%s,width=256,height=192,framerate=30/1,colorimetry=bt601,chroma-site=jpeg ! tee name=t1 t1. ! queue ! filesink location=%s t1. ! queue ! c.sink_1"
+               % (dw, dh, fout, n, f0, n, fmt, f1))
+        out = np.fromfile(fout, np.uint8).reshape(n, -1)
+        s0 = np.fromfile(f0, np.uint8).reshape(n, -1)
+        s1 = np.fromfile(f1, np.uint8).reshape(n, -1)
+        c1 = ref.VideoConverter(fmt, 256, 192, "BGRA", 256, 192, in_colorimetry="bt601", in_chroma_site="jpeg")
+        for f in range(n):
+            canvas = np.zeros(dw * dh * 4, np.uint8)
+            ref.compositor_fill(1, "bgra", "BGRA", canvas, dw, dh, 0, dh, 0, 0, 0)
+            ref.compositor_blend("blend_bgra", "BGRA", s0[f], 320, 240, 0, 0, 1.0, canvas, dw, dh, 0, dh, 1)
+            ref.compositor_blend("blend_bgra", "BGRA", c1.frame(s1[f]), 256, 192, 40, 30, 0.8, canvas, dw, dh, 0, dh, 1)
+            assert (canvas == out[f]).all(), (fmt, f, int((canvas != out[f]).sum()))
+
+
 def test_compositor_pad_converter_config(gst_env, ref):
     """GstVideoAggregatorConvertPad::converter-config (gstvideoaggregator.c:444-488): the pad's converter takes its options from the
     structure - nearest scaling on one pad, lanczos + alpha-mode=set on a converted NV12 pad - instead of the library defaults"""

@@ -482,6 +482,12 @@ static int launch (const AggregateParams &p, void *dest, int dstride, int rx0, i
 #undef AGG_DIRECT_LAUNCH
     return hipGetLastError () == hipSuccess ? GSTAMD_OK : GSTAMD_ERR_HIP;
   }
+  /* k_aggregate's packed span (aggregate_span4) forces the alpha byte of every pixel of the span once after the last pad.  On a continuation chunk
+     (bg_kind 2: more pads than one launch takes) the canvas may hold alpha that a SOURCE pad of an earlier chunk lowered, on pixels no pad of this
+     chunk touches - k_aggregate_direct<KEEP> keeps track of the touched pixels, this kernel does not, so a continuation that ends up here (a width
+     that is not a multiple of four) takes the per-pixel form.  (Compositor fuzz, fresh seeds 7018 / 7022 / 7045 / 7085: 40 pads, only the alpha byte wrong.) */
+  if (q.bg_kind == 2)
+    q.fast = 0;
   dim3 grid ((lanes + bx - 1) / bx, rh), block (bx);
 #define AGG_LAUNCH(A, S) hipLaunchKernelGGL ((k_aggregate<A, S>), grid, block, 0, (hipStream_t) stream, q, (uint8_t *) dest, dstride, rx0, ry0, rw, rh)
   if (q.ashift == 0) {

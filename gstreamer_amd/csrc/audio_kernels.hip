@@ -295,16 +295,23 @@ static int run_many (int n, GstAmdAudioResampler *const *rs, const void *const *
   AudioStep first;
   memset (&first, 0, sizeof (first));
   int max_blocks = 0, live = 0;
+  /* every allocation first, on a COPY of each stream's state: a failure for stream i must not leave streams 0 .. i - 1 advanced (their input consumed,
+     r->cur pointing at a history buffer no kernel has written) with nothing launched */
+  for (int i = 0; i < n; i++) {
+    GstAmdAudioResampler *r = rs[i];
+    auto probe = r->st;
+    const AudioStep s = audio_step (r->plan, &probe, in_frames[i], out_frames[i]);
+    if (!s.skipped_all && s.keep > 0) {
+      const int e = ensure_hist (r, r->cur ^ 1, (size_t) s.keep + 64);
+      if (e != GSTAMD_OK)
+        return e;
+    }
+  }
   for (int i = 0; i < n; i++) {
     GstAmdAudioResampler *r = rs[i];
     const AudioStep s = audio_step (r->plan, &r->st, in_frames[i], out_frames[i]);
     if (s.skipped_all)
       continue;
-    if (s.keep > 0) {
-      const int e = ensure_hist (r, r->cur ^ 1, (size_t) s.keep + 64);
-      if (e != GSTAMD_OK)
-        return e;
-    }
     FirManyStream &m = many.s[live++];
     m.hist = r->hist[r->cur];
     m.new_hist = r->hist[r->cur ^ 1];
@@ -558,8 +565,9 @@ int gstamd_audio_resampler_resample_many (int n, GstAmdAudioResampler *const *re
       run++;
     }
     bool fits = full && run > 1;
+    /* (a NULL `in` array or a NULL in[i] means silence, as in gstamd_audio_resampler_resample: such sets go one by one - the batched kernel reads in[i]) */
     for (int k = 0; fits && k < run; k++)
-      fits = in_frames[done + k] < (1u << 30) && out_frames[done + k] < (1u << 30);
+      fits = in && in[done + k] && in_frames[done + k] < (1u << 30) && out_frames[done + k] < (1u << 30);
     if (fits) {
       const size_t fbytes = (size_t) p0.bps;
       const size_t lds_need = ((size_t) FIR_LDS_FRAMES * (p0.taps_stride + 4) + (size_t) p0.channels * (((FIR_LDS_FRAMES * (p0.samp_inc + 1) + p0.taps_stride + 2 + 31) & ~31) + 16)) * fbytes +

@@ -64,15 +64,12 @@ Knob *find (const char *name)
 
 }  // namespace
 
-// Kernel arguments in device memory: the command processor fetches a launch's arguments from HBM instead of over PCIe from host memory.  On MI355X
-// that takes ~3.7 us off every launch (4K NV12 -> BGRA, one frame per launch: 15.2 -> 11.5 us; lists of 32: 245 -> 232 us; profiles/r04/
-// launch_kernarg.log) - a frame a launch is what a live pipeline runs.  It is a switch of the HIP runtime, read when the runtime initialises
-// (the first HIP call of the process): this library asks for it when it is loaded, unless the environment already says something.  A process
-// that has initialised HIP before loading the library (PyTorch) sets HIP_FORCE_DEV_KERNARG=1 itself - bench.py does.
-__attribute__ ((constructor)) static void gstamd_runtime_defaults ()
-{
-  setenv ("HIP_FORCE_DEV_KERNARG", "1", 0);
-}
+// Kernel arguments in device memory (HIP_FORCE_DEV_KERNARG=1): the command processor fetches a launch's arguments from HBM instead of over PCIe
+// from host memory.  On MI355X that takes ~3.7 us off every launch (4K NV12 -> BGRA, one frame per launch: 15.2 -> 11.5 us; lists of 32:
+// 245 -> 232 us; profiles/r04/launch_kernarg.log) - a frame a launch is what a live pipeline runs.  It is a switch of the HIP runtime, read once
+// when the runtime initialises, and it belongs to the PROCESS: this library does not touch the environment (a setenv from a dlopen'ed plugin
+// races with getenv in the host's other threads and changes the runtime for every other HIP user).  The launcher sets it - bench.py,
+// plugins/tests/bench_element.c, plugins/tests/launch129.c and tests/conftest.py do; INTEGRATION.md says so for applications.
 
 namespace gstamd {
 

@@ -251,8 +251,10 @@ gst_amd_compositor_pad_class_init (GstAmdCompositorPadObjClass * klass)
 #if AMD_COMP_VAGG
   ((GstVideoAggregatorPadClass *) klass)->prepare_frame = amd_comp_pad_prepare_frame;
   ((GstVideoAggregatorPadClass *) klass)->clean_frame = amd_comp_pad_clean_frame;
+#if GST_CHECK_VERSION (1, 20, 0)          /* members since 1.20 (gstvideoaggregator.h) */
   ((GstVideoAggregatorPadClass *) klass)->prepare_frame_start = NULL;
   ((GstVideoAggregatorPadClass *) klass)->prepare_frame_finish = NULL;
+#endif
 #else
   ((GstAggregatorPadClass *) klass)->flush = amd_comp_pad_flush;
 #endif

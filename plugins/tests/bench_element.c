@@ -27,6 +27,7 @@ wait_for (GstBuffer * buf)
 int
 main (int argc, char **argv)
 {
+  setenv ("HIP_FORCE_DEV_KERNARG", "1", 0);     /* kernel arguments in HBM; the launcher's decision, single-threaded here (tuning.cpp) */
   if (argc < 9) {
     fprintf (stderr, "usage: %s in_fmt w h out_fmt ow oh frames hip-streams [method]\n", argv[0]);
     return 2;

@@ -61,6 +61,7 @@ main (int argc, char **argv)
   End prev = { NULL, NULL };
   gboolean link_pending = FALSE;
   GArray *deferred = g_array_new (FALSE, TRUE, sizeof (Deferred));
+  g_setenv ("HIP_FORCE_DEV_KERNARG", "1", FALSE);     /* kernel arguments in HBM; the launcher's decision, single-threaded here (tuning.cpp) */
   const gchar *plugins = g_getenv ("GSTAMD_LAUNCH_PLUGINS");
   int i, rc = 0;
 

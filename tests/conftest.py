@@ -7,6 +7,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# kernel arguments in HBM (a switch of the HIP runtime, read when it initialises): the launcher's decision - the product library does not
+# touch the environment (gstreamer_amd/csrc/tuning.cpp); inherited by the gst-launch / bench_element child processes of the plugin tests
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 
 def pytest_configure(config):

@@ -89,6 +89,34 @@ def video_info(fmt, w, h):
                 colorimetry=col.value.decode(), chroma_site=chroma.value.decode())
 
 
+_props = {}
+
+
+def format_props(fmt):
+    """the reference's format table entry: dict(flags, yuv, rgb, gray, alpha, unpack, bits, w_sub, h_sub)"""
+    if fmt not in _props:
+        L = lib()
+        flags, bits, ws, hs = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        name = C.create_string_buffer(32)
+        L.ref_video_format_props.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        if L.ref_video_format_props(fmt.encode(), C.byref(flags), name, 32, C.byref(bits), C.byref(ws), C.byref(hs)) != 0:
+            raise ValueError(fmt)
+        f = flags.value          # GstVideoFormatFlags (video-format.h): YUV 1, RGB 2, GRAY 4, ALPHA 8
+        _props[fmt] = dict(flags=f, yuv=bool(f & 1), rgb=bool(f & 2), gray=bool(f & 4), alpha=bool(f & 8), unpack=name.value.decode(), bits=bits.value,
+                           w_sub=ws.value, h_sub=hs.value)
+    return _props[fmt]
+
+
+def scaler_windows(config, in_size, out_size):
+    """(first source line of every output line, taps) of the scaler gst_video_converter_new would make under `config` (a config_string () or None)"""
+    L = lib()
+    L.ref_video_scaler_windows.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    offs = (C.c_int * out_size)()
+    n = C.c_int()
+    L.ref_video_scaler_windows(_b(config), in_size, out_size, offs, C.byref(n))
+    return list(offs), n.value
+
+
 def config_string(**opts):
     """Serialise converter options the way gst_structure_from_string wants them.
 

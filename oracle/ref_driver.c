@@ -102,6 +102,56 @@ ref_video_info (const char *format, int w, int h, int *stride, gsize * offset, g
   return GST_VIDEO_INFO_N_PLANES (&info);
 }
 
+/* The reference's own format table entry (video-format.c): flags (GstVideoFormatFlags), the unpack format's name, bits of the unpack
+ * format (8 or 16), the chroma subsampling shifts.  For tests that split a conversion into the chain's stages. */
+int
+ref_video_format_props (const char *format, int *flags, char *unpack_out, int unpack_len, int *unpack_bits, int *w_sub, int *h_sub)
+{
+  const GstVideoFormatInfo *fi, *ui;
+  GstVideoFormat f;
+  ref_init ();
+  f = gst_video_format_from_string (format);
+  if (f == GST_VIDEO_FORMAT_UNKNOWN)
+    return -1;
+  fi = gst_video_format_get_info (f);
+  ui = gst_video_format_get_info (fi->unpack_format);
+  *flags = (int) fi->flags;
+  g_strlcpy (unpack_out, ui->name, unpack_len);
+  *unpack_bits = ui->depth[0];
+  *w_sub = fi->n_components > 1 ? fi->w_sub[1] : 0;
+  *h_sub = fi->n_components > 1 ? fi->h_sub[1] : 0;
+  return 0;
+}
+
+/* The vertical (or horizontal) scaler gst_video_converter_new would make for in -> out lines under `config` (chain_vscale, video-converter.c:1653:
+ * method and taps from the config, which also carries the resampler options): the first source line and the number of taps of every output
+ * line (gst_video_scaler_get_coeff, video-scaler.c:300).  For tests that need the ORDER in which a scaler asks for lines. */
+int
+ref_video_scaler_windows (const char *config, int in_size, int out_size, int *offsets, int *n_taps)
+{
+  GstStructure *cfg = NULL;
+  GstVideoResamplerMethod method = GST_VIDEO_RESAMPLER_METHOD_CUBIC;
+  guint taps = 0, n = 0, off = 0;
+  GstVideoScaler *sc;
+  int j;
+  ref_init ();
+  if (config && *config)
+    cfg = gst_structure_from_string (config, NULL);
+  if (!cfg)
+    cfg = gst_structure_new_empty ("GstVideoConverter");
+  gst_structure_get_enum (cfg, GST_VIDEO_CONVERTER_OPT_RESAMPLER_METHOD, GST_TYPE_VIDEO_RESAMPLER_METHOD, (gint *) & method);
+  gst_structure_get_uint (cfg, GST_VIDEO_CONVERTER_OPT_RESAMPLER_TAPS, &taps);
+  sc = gst_video_scaler_new (method, GST_VIDEO_SCALER_FLAG_NONE, taps, in_size, out_size, cfg);
+  for (j = 0; j < out_size; j++) {
+    gst_video_scaler_get_coeff (sc, j, &off, &n);
+    offsets[j] = (int) off;
+  }
+  *n_taps = (int) n;
+  gst_video_scaler_free (sc);
+  gst_structure_free (cfg);
+  return 0;
+}
+
 static GstBuffer *
 wrap_frame (GstVideoInfo * info, guint8 * data, gsize size, gboolean writable)
 {

@@ -65,10 +65,48 @@ def random_case(rnd, rects=None, more=None):
     return ifmt, w, h, ofmt, ow, oh, cfg, col, site
 
 
+VERDICTS = ("ok", "refused", "bad", "defined-staged", "defined-masked", "defined-unchecked")
+
+
+def emu_diverges(emu):
+    """-> diverges (case): does the plan of that conversion announce a divergence (or refuse)?  Asked of the planner through the host emulator."""
+    def diverges(case):
+        ifmt, w, h, ofmt, ow, oh, cfg, col, site = case
+        ii = V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site)
+        oi = V.video_info(ofmt, ow, oh)
+        c = V.converter_config(**cfg)
+        src, dst = np.zeros(ii.size, np.uint8), np.zeros(oi.size, np.uint8)
+        desc = C.create_string_buffer(256)
+        r = emu.emu_video_convert(C.byref(ii), C.byref(oi), C.byref(c), src.ctypes.data, dst.ctypes.data, 1, desc, 256)
+        return r != 0 or emu.emu_video_last_divergence().decode() != ""
+    return diverges
+
+
+def check_defined(ref, case, src, got, divergence, diverges):
+    """A draw whose plan announces a divergence (the reference's own one-step output is undefined there): compared with the reference run STAGE BY
+    STAGE (tests/staged.py), or - where the split cannot express the draw - with the one-step reference on the bytes its undefined part cannot reach.
+    -> ("defined-staged" | "defined-masked" | "defined-unchecked" | "bad", text)"""
+    import staged
+    notes = [d.strip() for d in divergence.split(". ") if d.strip()]
+    # (the class whose one-step reference has no line order to follow: the plan pairs the chroma lines in frame order, which is what the split computes)
+    canonical = all(n.startswith("vertical-first N-tap scaling fed by the 4:2:0 chroma upsampler") for n in notes)
+    r = staged.staged_expected(ref, case, src, diverges, canonical)
+    if r is not None:
+        same, text = staged.compare(ref, case, got, r[0], r[1])
+        return ("defined-staged" if same else "bad"), text
+    checked, same, text = staged.masked_check(ref, case, src, got, divergence)
+    if not checked:
+        return "defined-unchecked", " (" + staged.stageable(ref, case, diverges, canonical)[1] + ")"
+    return ("defined-masked" if same else "bad"), text
+
+
+def divergence_class(divergence):
+    return " + ".join(sorted({d.strip()[:48] for d in divergence.split(". ") if d.strip()}))
+
+
 def run_case(emu, ref, case, seed):
-    """-> ("ok" | "refused" | "defined" | "bad", description).  "defined": the plan says the reference's own output is undefined for this
-    conversion (gstamd_video_converter_divergence) - there is nothing to compare with here; tests/cases.py VIDEO_DEFINED pins those
-    classes against the reference run stage by stage."""
+    """-> (one of VERDICTS, description).  A plan that announces a divergence (gstamd_video_converter_divergence: the reference's own output is
+    undefined for this conversion) is checked by check_defined."""
     ifmt, w, h, ofmt, ow, oh, cfg, col, site = case
     ii = V.video_info(ifmt, w, h, colorimetry=col, chroma_site=site)
     oi = V.video_info(ofmt, ow, oh)
@@ -81,7 +119,8 @@ def run_case(emu, ref, case, seed):
         return "refused", desc.value.decode()
     div = emu.emu_video_last_divergence().decode()
     if div:
-        return "defined", desc.value.decode() + " | " + div
+        verdict, text = check_defined(ref, case, src, dst, div, emu_diverges(emu))
+        return verdict, desc.value.decode() + text + " | " + divergence_class(div)
     ok, text = matches_reference(ref, case, src, dst, oi)
     return ("ok" if ok else "bad"), desc.value.decode() + text
 
@@ -126,14 +165,20 @@ def main():
     emu = load_emu()
     rects = random.Random(seed + 77) if "--rects" in sys.argv else None
     more = random.Random(seed + 313) if "--more" in sys.argv else None
-    count = {"ok": 0, "refused": 0, "defined": 0, "bad": 0}
+    count = {v: 0 for v in VERDICTS}
+    classes = {}
     for it in range(n):
         case = random_case(rnd, rects, more)
         verdict, text = run_case(emu, ref, case, seed * 1000 + it)
         count[verdict] += 1
+        if verdict.startswith("defined"):
+            k = (text.rsplit(" | ", 1)[1], verdict)
+            classes[k] = classes.get(k, 0) + 1
         if verdict == "bad" or "-v" in sys.argv:
             print(verdict.upper(), case, text)
     print("seed %d: %s" % (seed, count))
+    for k in sorted(classes):
+        print("   %5d  %-18s %s" % (classes[k], k[1], k[0]))
     return 1 if count["bad"] else 0
 
 

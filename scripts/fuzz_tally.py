@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Sums the per-seed lines tests/test_video_fuzz.py writes when GSTAMD_FUZZ_TALLY names a file: draws compared with the one-step reference,
-announced draws checked stage by stage / on the bytes the reference's undefined part cannot reach / compared with nothing, per class.
+"""Sums the per-seed lines the device fuzz tests (test_video_fuzz / test_compositor_fuzz / test_audio_fuzz) write when GSTAMD_FUZZ_TALLY names a
+file.  Video: draws compared with the one-step reference ("ok", 150 draws a seed), announced draws checked stage by stage / on the bytes the reference's
+undefined part cannot reach / compared with nothing, per class.  Compositor: scenes per entry and pad-count bracket.  Audio: streams and rounds.
 python scripts/fuzz_tally.py gpurun_out/fuzz_tally.jsonl"""
 import json
 import sys
@@ -15,6 +16,6 @@ for line in open(sys.argv[1]):
                 classes[c] = classes.get(c, 0) + n
         elif k != "seed":
             tot[k] = tot.get(k, 0) + v
-print("%d seeds x 150 draws: %s" % (seeds, tot))
+print("%d seeds: %s" % (seeds, tot))
 for c in sorted(classes):
     print("  %6d  %s" % (classes[c], c))

@@ -248,3 +248,158 @@ def test_hip_off_canvas_and_zero_area_pads_are_skipped(native_lib, gpu):
             torch.cuda.synchronize()
             return cases.visible_bytes(fmt, dw, dh, strides, offsets, d.cpu().numpy())
         assert (run(off) == run([])).all(), fmt
+
+
+# ---- second generator (round 6): every entry point, pad counts past 32 and past 64, opacity hints, wide canvases ---------------------------------
+# One scene = one draw of the entry (gstamd_compositor_aggregate / _aggregate_opaque with hints / _aggregate_scaled / _aggregate_frame), 1 .. 100 pads
+# (two launches past 32 pads, three past 64), canvas widths up to 600 (whole 256-pixel strips for the culling form) and any residue modulo 4, SOURCE / OVER /
+# ADD mixes, all four backgrounds.  Expectation: ALWAYS the reference's own fill + BlendFunction loop (blend_pads, compositor.c:1678-1697; BLEND_A32
+# blend.c:41-132), never another entry of this library.  GSTAMD_COMP_SEEDS="200000-201700" runs 1701 seeds x 12 scenes (scripts/gpu_fuzz_all.sh).
+def _seed_list(spec):
+    out = []
+    for part in spec.split(","):
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+SEEDS2 = _seed_list(os.environ.get("GSTAMD_COMP_SEEDS", "200000-200011"))
+ALPHA_BYTE = {"BGRA": 3, "RGBA": 3, "ARGB": 0, "ABGR": 0, "AYUV": 0}
+
+
+def _scene2(rnd, seed, it):
+    entry = rnd.choice(["plain", "plain", "opaque", "opaque", "scaled", "frame"])
+    n = rnd.choice([1, 2, 5, 17, 31, 32, 33, 40, 63, 64, 65, 70, 100])
+    background = rnd.randint(0, 3)
+    if entry == "frame":
+        fmt = rnd.choice(PLANE_FMTS)
+        dw, dh = rnd.randint(1, 200), rnd.randint(1, 100)
+        narrow = rnd.random() < 0.4
+        pads = [(rnd.randint(1, 6 if narrow else 90), rnd.randint(1, 50), rnd.randint(-40, dw + 6), rnd.randint(-30, dh + 6),
+                 rnd.choice([1.0, 1.0, 0.7, 0.5, 0.3, 0.004, 0.0]), rnd.randint(0, 2)) for _ in range(n)]
+        return dict(entry=entry, fmt=fmt, dw=dw, dh=dh, background=background, pads=pads)
+    fmt = rnd.choice(["BGRA", "RGBA", "ARGB", "ABGR", "AYUV"] + ([] if entry in ("scaled", "opaque") else ["ARGB64", "AYUV64"]))
+    wide_canvas = entry == "opaque" or rnd.random() < 0.25
+    dw, dh = (rnd.randint(200, 600), rnd.randint(8, 60)) if wide_canvas else (rnd.randint(8, 200), rnd.randint(8, 120))
+    pads = []
+    for i in range(n):
+        big = wide_canvas and rnd.random() < 0.5
+        w, h = (rnd.randint(200, 700), rnd.randint(3, 50)) if big else (rnd.randint(1, 90), rnd.randint(1, 60))
+        ow = oh = 0
+        if entry == "scaled" and rnd.random() < 0.4:
+            ow, oh = rnd.randint(1, 120), rnd.randint(1, 80)
+            if (ow, oh) == (w, h):
+                ow = oh = 0
+        x, y = rnd.randint(-60, dw + 10), rnd.randint(-40, dh + 10)
+        alpha = rnd.choice([1.0, 1.0, 1.0, 0.75, 0.5, 0.3, 0.004, 0.0])
+        mode = rnd.choice([1, 1, 1, 2, 0]) if entry == "opaque" else rnd.randint(0, 2)
+        hint = rnd.choice([None, "all", "map", "map"]) if entry == "opaque" else None
+        pads.append(dict(w=w, h=h, ow=ow, oh=oh, method=rnd.choice(METHODS), x=x, y=y, alpha=alpha, mode=mode, hint=hint))
+    return dict(entry=entry, fmt=fmt, dw=dw, dh=dh, background=background, pads=pads)
+
+
+def _scene2_frames(sc, seed, it):
+    fmt = sc["fmt"]
+    if sc["entry"] == "frame":
+        return _plane_frames(fmt, sc["pads"], seed, it)
+    bpp = 8 if fmt.endswith("64") else 4
+    frames = []
+    for i, p in enumerate(sc["pads"]):
+        f = cases.frame_bytes(p["w"] * p["h"] * bpp, "random", seed * 10000 + it * 100 + i).copy()
+        if p["hint"] == "all":          # a frame converted from a format without alpha: every pixel opaque
+            f.reshape(p["h"], p["w"], 4)[:, :, ALPHA_BYTE[fmt]] = 255
+        elif p["hint"] == "map":        # a logo: opaque in some 64-pixel blocks of some rows
+            px = f.reshape(p["h"], p["w"], 4)
+            blocks = np.random.default_rng(seed * 131 + it * 17 + i).random((p["h"], (p["w"] + 63) // 64)) < 0.7
+            for b in range(blocks.shape[1]):
+                px[blocks[:, b], 64 * b:64 * b + 64, ALPHA_BYTE[fmt]] = 255
+        frames.append(f)
+    return frames
+
+
+def _scene2_expected(ref, sc, frames):
+    if sc["entry"] == "frame":
+        return _plane_expected(ref, sc["fmt"], sc["dw"], sc["dh"], sc["background"], sc["pads"], frames)
+    pads = [(p["w"], p["h"], p["ow"], p["oh"], p["method"], p["x"], p["y"], p["alpha"], p["mode"]) for p in sc["pads"]]
+    return expected(ref, sc["fmt"], sc["background"], pads, frames, sc["dw"], sc["dh"])
+
+
+def _scene2_run(sc, frames, gpu):
+    import ctypes as C
+
+    import torch
+    fmt, dw, dh, background, n = sc["fmt"], sc["dw"], sc["dh"], sc["background"], len(sc["pads"])
+    srcs = [torch.from_numpy(f).to(gpu) for f in frames]
+    hold = []
+    if sc["entry"] == "frame":
+        arr = (V.CompositorFramePad * n)()
+        for k, (w, h, x, y, alpha, mode) in enumerate(sc["pads"]):
+            st, of = cases.default_layout(fmt, w, h)
+            for i in range(len(st)):
+                arr[k].data[i] = srcs[k].data_ptr() + of[i]
+                arr[k].stride[i] = st[i]
+            arr[k].width, arr[k].height, arr[k].xpos, arr[k].ypos, arr[k].alpha, arr[k].blend_mode = w, h, x, y, alpha, mode
+        d = torch.from_numpy(cases.frame_bytes(int(V.video_info(fmt, dw, dh).size), "random", 6999)).to(gpu)
+        strides, offsets = cases.default_layout(fmt, dw, dh)
+        dp = (C.c_void_p * 3)(*[d.data_ptr() + o for o in offsets] + [None] * (3 - len(offsets)))
+        ds = (C.c_int32 * 3)(*strides + [0] * (3 - len(strides)))
+        V._check(V.lib().gstamd_compositor_aggregate_frame(V.FORMATS[fmt], background, None, None, arr, n, dp, ds, dw, dh, None))
+        torch.cuda.synchronize()
+        return d.cpu().numpy()
+    bpp = 8 if fmt.endswith("64") else 4
+    d = torch.empty(dw * dh * bpp, dtype=torch.uint8, device=gpu)
+    if sc["entry"] == "scaled":
+        arr = (V.CompositorScaledPad * n)()
+        for i, p in enumerate(sc["pads"]):
+            arr[i].data, arr[i].width, arr[i].height, arr[i].stride = srcs[i].data_ptr(), p["w"], p["h"], p["w"] * bpp
+            arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = p["x"], p["y"], p["alpha"], p["mode"]
+            if p["ow"]:
+                c = V.VideoConverter(V.video_info(fmt, p["w"], p["h"]), V.video_info(fmt, p["ow"], p["oh"]), V.converter_config(resampler_method=p["method"]))
+                assert V.lib().gstamd_compositor_pad_scaler_usable(c._h) == 1
+                hold.append(c)
+                arr[i].scaler = c._h
+        V._check(V.lib().gstamd_compositor_aggregate_scaled(V.FORMATS[fmt], background, arr, n, d.data_ptr(), dw, dh, dw * bpp, None))
+        torch.cuda.synchronize()
+        for c in hold:
+            c.free()
+        return d.cpu().numpy()
+    arr = (V.CompositorPad * n)()
+    opa = (V.CompositorPadOpacity * n)()
+    for i, p in enumerate(sc["pads"]):
+        arr[i].data, arr[i].width, arr[i].height, arr[i].stride = srcs[i].data_ptr(), p["w"], p["h"], p["w"] * bpp
+        arr[i].xpos, arr[i].ypos, arr[i].alpha, arr[i].blend_mode = p["x"], p["y"], p["alpha"], p["mode"]
+        if p["hint"] == "all":
+            opa[i].all_opaque = 1
+        elif p["hint"] == "map" and p["w"] <= 4096:
+            m = torch.zeros(p["h"], dtype=torch.int64, device=gpu)
+            V._check(V.lib().gstamd_compositor_pad_opacity_map(V.FORMATS[fmt], srcs[i].data_ptr(), p["w"], p["h"], p["w"] * 4, m.data_ptr(), None))
+            hold.append(m)
+            opa[i].map = m.data_ptr()
+    if sc["entry"] == "opaque":
+        V._check(V.lib().gstamd_compositor_aggregate_opaque(V.FORMATS[fmt], background, arr, opa, n, d.data_ptr(), dw, dh, dw * bpp, None))
+    else:
+        V._check(V.lib().gstamd_compositor_aggregate(V.FORMATS[fmt], background, arr, n, d.data_ptr(), dw, dh, dw * bpp, None))
+    torch.cuda.synchronize()
+    return d.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS2)
+def test_hip_random_scenes_every_entry_match_reference(native_lib, gpu, ref, seed):
+    rnd = random.Random(seed)
+    tally = {}
+    for it in range(12):
+        sc = _scene2(rnd, seed, it)
+        frames = _scene2_frames(sc, seed, it)
+        exp = _scene2_expected(ref, sc, frames)
+        got = _scene2_run(sc, frames, gpu)
+        if sc["entry"] == "frame":
+            strides, offsets = cases.default_layout(sc["fmt"], sc["dw"], sc["dh"])
+            got, exp = (cases.visible_bytes(sc["fmt"], sc["dw"], sc["dh"], strides, offsets, b) for b in (got, exp))
+        assert (got == exp).all(), (seed, it, sc["entry"], sc["fmt"], sc["background"], len(sc["pads"]), sc["dw"], sc["dh"], int((got != exp).sum()), sc["pads"][:3])
+        k = "%s/%s" % (sc["entry"], "33+" if len(sc["pads"]) > 32 else "-32")
+        tally[k] = tally.get(k, 0) + 1
+    if os.environ.get("GSTAMD_FUZZ_TALLY"):
+        import json
+        with open(os.environ["GSTAMD_FUZZ_TALLY"], "a") as f:
+            f.write(json.dumps(dict(seed=seed, scenes=12, classes=tally)) + "\n")

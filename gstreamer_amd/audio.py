@@ -126,6 +126,12 @@ class AudioResampler:
         """gst_audio_resampler_update (resampler, in_rate, out_rate, options); opts None keeps the previous filter design."""
         _v._check(lib().gstamd_audio_resampler_update(self._h, in_rate, out_rate, C.byref(opts) if opts is not None else None))
 
+    def divergence(self):
+        """"" while the output is the reference's bit for bit (gstamd_audio_resampler_divergence)"""
+        f = lib().gstamd_audio_resampler_divergence
+        f.restype, f.argtypes = C.c_char_p, [C.c_void_p]
+        return f(self._h).decode()
+
     def reset(self):
         lib().gstamd_audio_resampler_reset(self._h)
 

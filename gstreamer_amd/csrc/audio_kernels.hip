@@ -151,6 +151,7 @@ struct GstAmdAudioResampler {
   size_t hist_cap[2] = {0, 0};      // frames
   int cur = 0;
   unsigned long long table_hash = 0;      // of plan.table: resamplers with the same hash, rates, taps and sample type share one launch (_resample_many)
+  std::string divergence;                 // gstamd_audio_resampler_divergence: set by an update that enlarges the filter past the history (audio_update)
 };
 
 extern "C" const char *gstamd_last_error (void);
@@ -415,6 +416,13 @@ int gstamd_audio_resampler_update (GstAmdAudioResampler *r, int in_rate, int out
   const bool new_table = plan.table != r->plan.table;
   r->plan = std::move (plan);
   r->st = st;
+  if (shift.stale > 0) {
+    char text[320];
+    snprintf (text, sizeof (text), "gst_audio_resampler_update enlarged the filter by more than the history held: the reference fills %lld frame(s) of the new "
+        "history with what its sample buffer held past the valid samples (input of earlier calls; audio-resampler.c:1587-1590, a FIXME there), this library "
+        "with silence; output equals the reference's again once those frames have left the filter window. ", shift.stale);
+    r->divergence = text;
+  }
   if (!r->device_ready)
     return GSTAMD_OK;
   if (hipDeviceSynchronize () != hipSuccess)
@@ -599,6 +607,16 @@ int gstamd_audio_resampler_resample_many (int n, GstAmdAudioResampler *const *re
     done += run;
   }
   return GSTAMD_OK;
+}
+
+/* "" while the output is the reference's bit for bit; otherwise what differs and why (set by gstamd_audio_resampler_update, see audio_taps.cpp
+ * audio_update; expires once the frames in question have left the filter window, and on reset) */
+const char *gstamd_audio_resampler_divergence (GstAmdAudioResampler *r)
+{
+  if (!r)
+    return "";
+  std::lock_guard<std::mutex> g (r->lock);
+  return r->st.stale_ahead > 0 ? r->divergence.c_str () : "";
 }
 
 int gstamd_audio_resampler_debug_get (GstAmdAudioResampler *r, int32_t *out, int max_out)

@@ -547,6 +547,17 @@ int audio_update (AudioPlan *p, AudioState *st, int in_rate, int out_rate, const
       shift->src_off = soff;
       shift->dst_off = doff;
       shift->frames = frames > 0 ? frames : 0;
+      /* "when we enlarge we just leave the old samples in there.  FIXME, probably do something better like mirror or fill with zeroes"
+       * (audio-resampler.c:1587-1590): the head of the enlarged history, [samp_index, samp_index + diff), keeps what the sample buffer held there.
+       * Up to samples_avail that is the old history's own head (reproduced by audio_history_shift); beyond it, it is whatever EARLIER calls
+       * left in the buffer past its valid samples - input of the previous gst_audio_resampler_resample calls that this library never kept.
+       * Those frames are silence here (the FIXME's second suggestion), and the resampler says so: gstamd_audio_resampler_divergence. */
+      if (diff > 0) {
+        const long long past = (long long) st->samp_index + diff - (long long) st->samples_avail;
+        shift->stale = past > 0 ? past : 0;
+        if (past > 0)
+          st->stale_ahead = (long long) st->samp_index + diff;
+      }
       st->samples_avail = (size_t) ((long long) st->samples_avail + diff > 0 ? (long long) st->samples_avail + diff : 0);
     }
   } else if (p->filter_mode == GSTAMD_AUDIO_FILTER_MODE_FULL) {
@@ -581,6 +592,7 @@ void audio_history_shift (const AudioHistoryShift &s, size_t frame_bytes, std::v
 /* gst_audio_resampler_reset (audio-resampler.c:1466-1488) */
 void audio_state_reset (const AudioPlan &plan, AudioState *st)
 {
+  st->stale_ahead = 0;
   st->samp_index = 0;
   st->samples_avail = (size_t) (plan.n_taps / 2 - 1);
 }
@@ -624,6 +636,8 @@ AudioStep audio_step (const AudioPlan &pl, AudioState *st, size_t in_frames, siz
   }
   st->samp_index = 0;
   st->samp_phase = tot % pl.out_rate;
+  if (consumed > 0)
+    st->stale_ahead = st->stale_ahead > consumed ? st->stale_ahead - consumed : 0;
   if (consumed > 0) {
     const long long left = (long long) samples_avail - consumed;
     if (left > 0) {

@@ -28,6 +28,7 @@ struct AudioPlan {
 struct AudioState {
   long long samp_index = 0, samp_phase = 0, skip = 0;
   size_t samples_avail = 0;
+  long long stale_ahead = 0;     // > 0: the first stale_ahead frames of the history still hold frames the reference fills otherwise (audio_update); counts down as input is consumed
 };
 
 // what one gst_audio_resampler_resample() call has to launch
@@ -47,6 +48,7 @@ struct AudioStep {
 struct AudioHistoryShift {
   bool changed;
   long long src_off, dst_off, frames;
+  long long stale;              // frames of the new history that the reference takes from beyond its valid samples (see audio_update)
 };
 
 void audio_state_reset (const AudioPlan &plan, AudioState *st);

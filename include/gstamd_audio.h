@@ -81,6 +81,12 @@ void gstamd_audio_resampler_reset (GstAmdAudioResampler *resampler);
  * error with the resampler left as it was. */
 int gstamd_audio_resampler_update (GstAmdAudioResampler *resampler, int in_rate, int out_rate,
     const GstAmdAudioResamplerOptions *options);
+/* Where the reference's own result is not a function of the stream: gst_audio_resampler_update with options that ENLARGE the filter by more than
+ * twice the history it holds leaves the head of the new history as it finds it in its sample buffer - input of earlier calls past the valid
+ * samples ("FIXME, probably do something better like mirror or fill with zeroes", audio-resampler.c:1587-1590).  This library fills those
+ * frames with silence and says so here: a text while such frames are inside the filter window, "" otherwise (and always for streams that
+ * never enlarge their filter that far).  Same contract as gstamd_video_converter_divergence. */
+const char *gstamd_audio_resampler_divergence (GstAmdAudioResampler *resampler);
 size_t gstamd_audio_resampler_get_out_frames (GstAmdAudioResampler *resampler, size_t in_frames);
 size_t gstamd_audio_resampler_get_in_frames (GstAmdAudioResampler *resampler, size_t out_frames);
 size_t gstamd_audio_resampler_get_max_latency (GstAmdAudioResampler *resampler);

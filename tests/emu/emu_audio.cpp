@@ -130,6 +130,7 @@ int emu_audio_update (void *h, int in_rate, int out_rate, const GstAmdAudioResam
   r->hist.resize (r->hist.size () + 8 * fbytes, 0);
   return st;
 }
+int emu_audio_stale_ahead (void *h) { return (int) ((EmuResampler *) h)->st.stale_ahead; }
 int emu_audio_state (void *h, int which)
 {
   EmuResampler *r = (EmuResampler *) h;

@@ -417,7 +417,7 @@ int gstamd_audio_resampler_update (GstAmdAudioResampler *r, int in_rate, int out
   r->plan = std::move (plan);
   r->st = st;
   if (shift.stale > 0) {
-    char text[320];
+    char text[512];
     snprintf (text, sizeof (text), "gst_audio_resampler_update enlarged the filter by more than the history held: the reference fills %lld frame(s) of the new "
         "history with what its sample buffer held past the valid samples (input of earlier calls; audio-resampler.c:1587-1590, a FIXME there), this library "
         "with silence; output equals the reference's again once those frames have left the filter window. ", shift.stale);

@@ -6,6 +6,9 @@
 // them changes a result - every path they select is held to the same byte-exact tests.
 //
 //   name                     meaning (value)
+//   GSTAMD_STORE_POLICY, GSTAMD_STORE_WT_BELOW
+//                            how k_convert_strip's pixels leave the CU (video_fast.h store16_policy: 0 streaming, 1 write-through sc0 sc1, 2 sc1, 3 sc0 sc1 nt,
+//                            4 plain; default: 1 for launches of fewer than GSTAMD_STORE_WT_BELOW = 9 frames, 3 for longer lists; profiles/r06/store_policy.md)
 //   GSTAMD_NO_COL            the older fused / two-pass kernels instead of the column-walk scaler k_scale_col (set)
 //   GSTAMD_COL_OPL, GSTAMD_COL_SHARE, GSTAMD_COL_WAVES, GSTAMD_COL_CHUNKS, GSTAMD_COL_DEBUG
 //                            form and geometry of the column-walk scaler: outputs per lane (1 / 2), shared windows (0: off), waves per

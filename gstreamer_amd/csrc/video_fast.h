@@ -33,6 +33,8 @@ struct FastParams {
   int px_bytes;         // 4; 3: RGB / BGR destination - the pixel is formed as RGBx / BGRx and its three colour bytes are stored
   const uint8_t *lut;   // NULL, or a 256-byte table in device memory every colour byte of the finished pixel goes through (GammaPlan::lut_direct:
   int lut_keep;         // decode table . encode table); lut_keep: the destination byte that is alpha / filler and stays
+  int store_policy;     // how the finished pixels leave the CU (store16_policy): 0 streaming (nt: the line stays in the XCD's L2 until evicted or flushed
+                        // at the end of the kernel), 1 write-through (sc0 sc1: nothing of the frame is dirty in L2 when the kernel ends)
 };
 
 // the table's copy in LDS while a kernel of the ABL == 2 ("table after the pack") variants runs: 64 words, filled by the kernel's one wave
@@ -68,6 +70,7 @@ inline void fast_params_finish (FastParams &fp, const int p[5], const int pack_p
   for (int i = 0; i < 4; i++)
     fp.pack_pos[i] = pack_pos[i];
   fp.px_bytes = 4;
+  fp.store_policy = 0;
   fp.lut = nullptr;
   fp.lut_keep = 0;
 }
@@ -144,6 +147,31 @@ GSTAMD_HD void store16_stream (uint8_t *p, uint32_t a, uint32_t b, uint32_t c, u
   u32x4 v = {a, b, c, d};
   __builtin_nontemporal_store (v, (u32x4 *) p);
 #else
+  *(uint4 *) p = gstamd_make_uint4 (a, b, c, d);
+#endif
+}
+
+// The same with the store policy of the launch (FastParams::store_policy, wave-uniform).  A kernel's end writes back what its stores left dirty in the
+// eight L2s - "+ B / 6 TB/s when the predecessor leaves B bytes dirty" (MI355X_MICROARCH.md, boundary row) - and for ONE 4K frame per launch that is
+// most of the 33 MB the frame wrote: a launch per frame (what a live pipeline runs) pays it every frame, a 32-frame list once.  Write-through stores
+// (sc0 sc1) leave nothing behind.
+GSTAMD_HD void store16_policy (uint8_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d, int policy)
+{
+#ifdef __HIPCC__
+  typedef unsigned int u32x4 __attribute__ ((ext_vector_type (4)));
+  u32x4 v = {a, b, c, d};
+  if (policy == 1)
+    asm volatile ("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v" (p), "v" (v) : "memory");
+  else if (policy == 2)
+    asm volatile ("global_store_dwordx4 %0, %1, off sc1" : : "v" (p), "v" (v) : "memory");
+  else if (policy == 3)
+    asm volatile ("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v" (p), "v" (v) : "memory");
+  else if (policy == 4)
+    *(u32x4 *) p = v;
+  else
+    __builtin_nontemporal_store (v, (u32x4 *) p);
+#else
+  (void) policy;
   *(uint4 *) p = gstamd_make_uint4 (a, b, c, d);
 #endif
 }
@@ -390,7 +418,7 @@ GSTAMD_HD void fast_emit4_l (const FastParams &fp, uint8_t *__restrict__ d, bool
     if (fp.px_bytes == 3)                   // wave-uniform
       store12_stream (d, o[0], o[1], o[2], o[3]);
     else
-      store16_stream (d, o[0], o[1], o[2], o[3]);
+      store16_policy (d, o[0], o[1], o[2], o[3], fp.store_policy);
   }
 }
 

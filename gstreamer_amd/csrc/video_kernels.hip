@@ -1651,10 +1651,20 @@ static bool launch_fast (const FastParams &fp, const FrameBatch &batch, int n, h
   return launch_strip_variant<CH, 0> (fp, batch, n, K, v.set && v.order != 0, stream);
 }
 
-hipError_t launch_convert_pair (const FastParams &fp, int chroma_h, int n_frames, const uint8_t *const *y, const uint8_t *const *uv,
+hipError_t launch_convert_pair (const FastParams &fp_in, int chroma_h, int n_frames, const uint8_t *const *y, const uint8_t *const *uv,
     uint8_t *const *dst, int ystride, int uvstride, int dstride, hipStream_t stream)
 {
   video_frame_list_touch (dst[0]);
+  /* store policy (video_fast.h store16_policy): write-through for launches of few frames - what such a launch leaves dirty in the L2s is written back
+     at its end, on the critical path of the next launch; a long list amortises that and takes the write-through streaming store (sc0 sc1 nt), the
+     fastest of the five at 32 frames (profiles/r06/store_policy.md).  GSTAMD_STORE_POLICY pins it. */
+  FastParams fpl = fp_in;
+  {
+    const int pin = tuning_int ("GSTAMD_STORE_POLICY", -1);
+    const int few = tuning_int ("GSTAMD_STORE_WT_BELOW", 9);
+    fpl.store_policy = pin >= 0 ? pin : (n_frames < few ? 1 : 3);
+  }
+  const FastParams &fp = fpl;
   for (int base = 0; base < n_frames; base += GSTAMD_MAX_BATCH) {
     const int n = n_frames - base < GSTAMD_MAX_BATCH ? n_frames - base : GSTAMD_MAX_BATCH;
     FrameBatch batch;

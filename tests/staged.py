@@ -209,10 +209,24 @@ def staged_expected(ref, case, src, diverges=None, canonical_pairs=False):
     return want, mask
 
 
+def picture_bytes(ref, fmt, w, h, size):
+    """bool mask of the frame's bytes that belong to the picture (stride padding and the unused second luma slot of an odd-width packed 4:2:2 line
+    excepted): an index image sent through cases.visible_bytes"""
+    oi = ref.video_info(fmt, w, h)
+    pic = np.zeros(size, bool)
+    try:
+        idx = cases.visible_bytes(fmt, w, h, list(oi["stride"]), list(oi["offset"]), np.arange(1, size + 1, dtype=np.int64))
+        pic[idx[idx > 0] - 1] = True
+    except Exception:
+        pic[:] = True
+    return pic
+
+
 def compare(ref, case, got, want, mask):
     """bytes of the picture (stride padding excepted) -> (equal, text)"""
     ifmt, w, h, ofmt, OW, OH, cfg, col, site = case
     if mask is not None:
+        mask = mask & picture_bytes(ref, ofmt, OW, OH, got.size)
         bad = int((got[mask] != want[mask]).sum())
         return bad == 0, "" if bad == 0 else ": %d of %d bytes inside the rectangle differ from the staged reference" % (bad, int(mask.sum()))
     if (got == want).all():
@@ -324,13 +338,6 @@ def masked_check(ref, case, src, got, divergence):
     if mask is None or not mask.any():
         return False, True, ""
     one = ref.VideoConverter(ifmt, w, h, ofmt, OW, OH, in_colorimetry=col, in_chroma_site=site, config=cases.ref_config_string(ref, cfg)).frame(src)
-    oi = ref.video_info(ofmt, OW, OH)
-    try:
-        pic = np.zeros(got.size, bool)          # the picture's bytes (stride padding excepted), found by sending an index image through visible_bytes
-        idx = cases.visible_bytes(ofmt, OW, OH, list(oi["stride"]), list(oi["offset"]), np.arange(got.size, dtype=np.int64))
-        pic[idx] = True
-        mask &= pic
-    except Exception:
-        pass
+    mask &= picture_bytes(ref, ofmt, OW, OH, got.size)
     bad = int((got[mask] != one[mask]).sum())
     return True, bad == 0, "" if bad == 0 else ": %d of %d bytes the reference's undefined part cannot reach differ from the one-step reference" % (bad, int(mask.sum()))

@@ -152,7 +152,7 @@ def test_hip_random_conversions_match_reference_or_are_refused(native_lib, gpu, 
     if os.environ.get("GSTAMD_FUZZ_TALLY"):          # one line per seed for scripts/fuzz_tally.py (the per-class counts of a long run)
         import json
         with open(os.environ["GSTAMD_FUZZ_TALLY"], "a") as f:
-            f.write(json.dumps(dict(seed=seed, ok=ok, bad=len(bad), classes=classes, **tally)) + "\n")
+            f.write(json.dumps(dict(dict(tally, bad=len(bad)), seed=seed, ok=ok, classes=classes)) + "\n")
     assert not bad, bad[:5]
     assert ok >= 100
 

@@ -93,6 +93,7 @@ struct GstAmdVideoConverter {
   size_t deep_a_size = 0, deep_b_size = 0;
   /* gamma-mode = remap (GammaPlan): the two sub-conversions, the tables and the 8-bit images either side of the 16-bit part */
   GstAmdVideoConverter *sub_in = nullptr, *sub_out = nullptr;
+  GstAmdVideoConverter *field[2] = {nullptr, nullptr};        // an interleaved frame's two field conversions (VideoPlan::interlaced): they do all the work
   const uint8_t *post_lut = nullptr;    /* this converter is the direct conversion of a GammaPlan::lut_direct plan: the composed table (device) the parent wants on
                                          * the colour bytes; a kernel that applies it itself says so in post_lut_done, otherwise the parent runs k_lut3 */
   int post_lut_keep = 0;
@@ -384,7 +385,18 @@ GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info
   GstAmdVideoConverter *c = new GstAmdVideoConverter ();
   std::string err;
   int r = plan_video_converter (in_info, out_info, config, &c->plan, &err);
-  if (r == GSTAMD_OK)
+  if (r == GSTAMD_OK && c->plan.interlaced) {
+    for (int f = 0; f < 2 && r == GSTAMD_OK; f++) {
+      GstAmdVideoInfo fin, fout;
+      plan_field_infos (in_info, out_info, f, &fin, &fout);
+      c->field[f] = gstamd_video_converter_new (&fin, &fout, config, &r);
+    }
+    if (r != GSTAMD_OK) {
+      gstamd_video_converter_free (c->field[0]);
+      gstamd_video_converter_free (c->field[1]);
+      c->field[0] = c->field[1] = nullptr;
+    }
+  } else if (r == GSTAMD_OK)
     r = build_sub_converters (c->plan, &c->sub_in, &c->sub_out);
   else
     set_error (r, err);
@@ -493,7 +505,7 @@ static int build_tables (GstAmdVideoConverter *c)
     }
   }
   if (p.passes.size () == 2 && p.passes[0].horizontal && p.passes[0].kind == SCALE_NTAP && p.passes[0].dot4_ok && c->geom[0].tile16_w > 0 &&
-      p.front.chroma_v2 && kind_has_planes (p.front.kind) && p.front.w_sub == 1 && p.front.h_sub == 1 && !p.matrix_before_scale &&
+      p.front.chroma_v2 == 1 && kind_has_planes (p.front.kind) && p.front.w_sub == 1 && p.front.h_sub == 1 && !p.matrix_before_scale &&
       (int) p.vpair.size () >= 2 * p.front.height) {
     /* k_hscale420_reg: is the planner's simulated pair table the closed form (every line consumed in order)? */
     c->reg_lo = -(p.rect.in_y >> 1);
@@ -1004,6 +1016,39 @@ static int frame_planes_plan_order (GstAmdVideoConverter *c, const void *const s
 {
   if (!c || !src_planes || !dest_planes || !src_planes[0] || !dest_planes[0])
     return set_error (GSTAMD_ERR_INVALID, "NULL converter or frame");
+  if (c->plan.interlaced) {
+    /* an interleaved frame: field f is lines f, f + 2, ... of every plane (plan_field_infos) - except the SOURCE chroma planes of a field plan whose
+       pair table names rows of the frame's chroma planes (VideoPlan::field_src_chroma_frame) */
+    const VideoPlan &fp = c->plan;
+    for (int f = 0; f < 2; f++) {
+      GstAmdVideoConverter *fc = c->field[f];
+      if (!fc)
+        return set_error (GSTAMD_ERR_INVALID, "interlaced converter without its field conversions");
+      const void *sp[GSTAMD_VIDEO_MAX_PLANES] = {nullptr, nullptr, nullptr, nullptr};
+      void *dp[GSTAMD_VIDEO_MAX_PLANES] = {nullptr, nullptr, nullptr, nullptr};
+      int32_t ss[GSTAMD_VIDEO_MAX_PLANES] = {0, 0, 0, 0}, ds[GSTAMD_VIDEO_MAX_PLANES] = {0, 0, 0, 0};
+      const int alpha_plane = GSTAMD_KIND_ALPHA_PLANE (fp.fin->kind);
+      for (int i = 0; i < fp.in_info.n_planes; i++) {
+        const int st = src_stride ? src_stride[i] : fp.in_info.stride[i];
+        const bool frame_rows = fc->plan.field_src_chroma_frame && i != 0 && i != alpha_plane;
+        if (!src_planes[i])
+          return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
+        sp[i] = frame_rows ? src_planes[i] : (const uint8_t *) src_planes[i] + (f ? st : 0);
+        ss[i] = frame_rows ? st : 2 * st;
+      }
+      for (int i = 0; i < fp.out_info.n_planes; i++) {
+        const int st = dest_stride ? dest_stride[i] : fp.out_info.stride[i];
+        if (!dest_planes[i])
+          return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+        dp[i] = (uint8_t *) dest_planes[i] + (f ? st : 0);
+        ds[i] = 2 * st;
+      }
+      const int fr = frame_planes_plan_order (fc, sp, ss, dp, ds, stream_);
+      if (fr != GSTAMD_OK)
+        return fr;
+    }
+    return GSTAMD_OK;
+  }
   int r = ensure_tables (c);
   if (r != GSTAMD_OK || (r = bind_scratch (c, stream_)) != GSTAMD_OK)
     return r;
@@ -1363,7 +1408,7 @@ static bool bilinear420_params (GstAmdVideoConverter *c, BilParams *out)
     return false;
   /* semi-planar / planar 4:2:0 source, horizontal-first 2-tap x 2-tap, fast matrix */
   if (!(p.passes[0].horizontal && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && kind_has_planes (p.front.kind) && p.front.w_sub == 1 &&
-        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && !tuning_on ("GSTAMD_NO_BILINEAR420")))
+        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && p.front.chroma_v2 != 2 && !tuning_on ("GSTAMD_NO_BILINEAR420")))
     return false;
   const int out_w = p.out_info.width, out_h = p.out_info.height;
   BilParams bp;
@@ -1843,6 +1888,8 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
     return GSTAMD_OK;
   const VideoPlan &p = c->plan;
   c->list_launches = 0;
+  if (p.interlaced)
+    return frames_one_by_one (c, n_frames, src, dest, stream_);
   int r = ensure_tables (c);
   if (r != GSTAMD_OK || (r = bind_scratch (c, stream_)) != GSTAMD_OK)
     return r;
@@ -2113,6 +2160,8 @@ void gstamd_video_converter_free (GstAmdVideoConverter *c)
   release_tables (c);
   gstamd_video_converter_free (c->sub_in);
   gstamd_video_converter_free (c->sub_out);
+  gstamd_video_converter_free (c->field[0]);
+  gstamd_video_converter_free (c->field[1]);
   delete c;
 }
 
@@ -2120,6 +2169,21 @@ int gstamd_video_converter_set_config (GstAmdVideoConverter *c, const GstAmdVide
 {
   if (!c || !config)
     return set_error (GSTAMD_ERR_INVALID, "NULL converter or config");
+  if (c->plan.interlaced) {
+    /* both field conversions take the new options, or neither does (the first one's failure leaves everything as it was; the second cannot fail where
+       the first did not - the two plans differ in their field's tables only) */
+    int fr = gstamd_video_converter_set_config (c->field[0], config);
+    if (fr == GSTAMD_OK)
+      fr = gstamd_video_converter_set_config (c->field[1], config);
+    if (fr == GSTAMD_OK) {
+      VideoPlan top;
+      std::string terr;
+      const GstAmdVideoInfo tin = c->plan.orig_in, tout = c->plan.orig_out;
+      if (plan_video_converter (&tin, &tout, config, &top, &terr) == GSTAMD_OK)
+        c->plan = std::move (top);
+    }
+    return fr;
+  }
   VideoPlan np;
   std::string err;
   const GstAmdVideoInfo in = c->plan.orig_in, out = c->plan.orig_out;
@@ -2477,6 +2541,8 @@ int gstamd_video_converter_is_reentrant (GstAmdVideoConverter *c)
 {
   /* every stream a frame is sent on has a scratch set of its own (bind_scratch): plans with intermediate images - gamma remap, plane
    * scalers, planar packers, two-pass and 16-bit scalers - overlap across streams like the single-kernel ones */
+  if (c && c->plan.interlaced)
+    return gstamd_video_converter_is_reentrant (c->field[0]) && gstamd_video_converter_is_reentrant (c->field[1]) ? 1 : 0;
   return c && ensure_tables (c) == GSTAMD_OK ? 1 : 0;
 }
 

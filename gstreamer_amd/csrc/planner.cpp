@@ -921,7 +921,7 @@ static double get_tap (const TapParams *p, int l, int xi, double x)
 
 /* gst_video_resampler_init + resampler_calculate_taps; returns max_taps, fills offset + double taps */
 static int resampler_init (int method, unsigned n_taps, const GstAmdVideoConverterConfig &cfg, int in_size,
-    int out_size, std::vector<uint32_t> &offset, std::vector<double> &taps)
+    int out_size, std::vector<uint32_t> &offset, std::vector<double> &taps, double shift_arg = 0.0, bool half_taps = false)
 {
   TapParams params;
   memset (&params, 0, sizeof (params));
@@ -965,6 +965,8 @@ static int resampler_init (int method, unsigned n_taps, const GstAmdVideoConvert
       v = max_taps_opt;
     n_taps = (unsigned) v;            /* CLAMP (params.dx, 0, max_taps) assigned to guint */
   }
+  if (half_taps && n_taps > 3)        /* GST_VIDEO_RESAMPLER_FLAG_HALF_TAPS (video-resampler.c:414): the top field's resampler of an interlaced scaler */
+    n_taps /= 2;
   params.fx = 2.0 * params.envelope / n_taps;
   params.ex = 2.0 / n_taps;
   if (n_taps > (unsigned) in_size)
@@ -973,7 +975,7 @@ static int resampler_init (int method, unsigned n_taps, const GstAmdVideoConvert
 
   int tap_offs = (max_taps - 1) / 2;
   double corr = (max_taps == 1 ? 0.0 : 0.5);
-  double shift = 0.0;
+  double shift = shift_arg;
   offset.assign (out_size, 0);
   taps.assign ((size_t) out_size * max_taps, 0.0);
   for (int j = 0; j < out_size; j++) {
@@ -1048,11 +1050,53 @@ static void convert_coeff (const double *src, int16_t *dest, int n, int precisio
 
 /* One gst_video_scaler_new + the function the reference would pick in get_functions
  * (video-scaler.c:1202-1342) for 4x8-bit pixels. */
+static bool finish_scale_pass (int max_taps, const std::vector<double> &dtaps, int in_size, int out_size, bool horizontal, ScalePass *pass, bool h2_as_ntap, bool deep16);
+
 bool make_scale_pass (int method, unsigned n_taps_opt, const GstAmdVideoConverterConfig &cfg, int in_size,
     int out_size, bool horizontal, ScalePass *pass, bool h2_as_ntap, bool deep16)
 {
   std::vector<double> dtaps;
   int max_taps = resampler_init (method, n_taps_opt, cfg, in_size, out_size, pass->offset, dtaps);
+  return finish_scale_pass (max_taps, dtaps, in_size, out_size, horizontal, pass, h2_as_ntap, deep16);
+}
+
+/* The vertical scaler of an INTERLACED frame (gst_video_scaler_new with GST_VIDEO_SCALER_FLAG_INTERLACED, video-scaler.c:229-249): one resampler per
+ * field - top: (in + 1) / 2 -> (out + 1) / 2 lines, shifted by 0.5 * out / in, HALF_TAPS; bottom: the rest, the top's tap count, shifted the other way -
+ * zipped line by line (resampler_zip :109-146: output i takes field i & 1, offset * 2 + (i & 1), taps over every OTHER line).  `field` 0 / 1: that
+ * field's resampler as a pass over the field's own lines.  *zip_last: the zipped scaler's offset of the frame's last output line (gst_video_scaler_2d's
+ * order rule); *zip_offsets (frame lines, for the line-cache simulation) when asked for.  false: the reference cannot make this scaler (a field
+ * without lines, or the two resamplers disagreeing on their tap count: g_return_if_fail (r1->max_taps == r2->max_taps)). */
+static bool make_field_vpass (int method, unsigned n_taps_opt, const GstAmdVideoConverterConfig &cfg, int frame_in, int frame_out, int field,
+    ScalePass *pass, bool deep16, int *zip_last, std::vector<uint32_t> *zip_offsets)
+{
+  const int tin = (frame_in + 1) / 2, tout = (frame_out + 1) / 2, bin = frame_in - tin, bout = frame_out - tout;
+  if (tin <= 0 || tout <= 0 || bin <= 0 || bout <= 0)
+    return false;
+  const double shift = (0.5 * frame_out) / frame_in;
+  std::vector<uint32_t> toff, boff;
+  std::vector<double> ttaps, btaps;
+  const int tmax = resampler_init (method, n_taps_opt, cfg, tin, tout, toff, ttaps, shift, true);
+  const int bmax = resampler_init (method, (unsigned) tmax, cfg, bin, bout, boff, btaps, -shift, false);
+  if (tmax != bmax)
+    return false;
+  if (zip_last) {
+    const int i = frame_out - 1;
+    *zip_last = (int) ((i & 1) ? boff[(size_t) (i / 2)] : toff[(size_t) (i / 2)]) * 2 + (i & 1);
+  }
+  if (zip_offsets) {
+    zip_offsets->assign ((size_t) frame_out, 0);
+    for (int i = 0; i < frame_out; i++)
+      (*zip_offsets)[(size_t) i] = ((i & 1) ? boff[(size_t) (i / 2)] : toff[(size_t) (i / 2)]) * 2 + (uint32_t) (i & 1);
+  }
+  if (pass) {
+    pass->offset = field ? boff : toff;
+    return finish_scale_pass (tmax, field ? btaps : ttaps, field ? bin : tin, field ? bout : tout, false, pass, false, deep16);
+  }
+  return true;
+}
+
+static bool finish_scale_pass (int max_taps, const std::vector<double> &dtaps, int in_size, int out_size, bool horizontal, ScalePass *pass, bool h2_as_ntap, bool deep16)
+{
   pass->horizontal = horizontal;
   pass->in_size = in_size;
   pass->out_size = out_size;
@@ -1396,7 +1440,7 @@ bool col_plan_regular (const VideoPlan &p, int *crow_lo, int *crow_hi)
 {
   if (p.passes.size () != 2 || !p.passes[0].horizontal || p.passes[0].kind != SCALE_NTAP || p.passes[1].horizontal || p.passes[1].kind != SCALE_NTAP)
     return false;
-  if (!kind_has_planes (p.front.kind) || p.front.w_sub != 1 || p.front.h_sub != 1 || !p.front.chroma_v2 || p.front.hi_depth != 0 || p.matrix_before_scale ||
+  if (!kind_has_planes (p.front.kind) || p.front.w_sub != 1 || p.front.h_sub != 1 || p.front.chroma_v2 != 1 || p.front.hi_depth != 0 || p.matrix_before_scale ||
       p.front.swap_k >= 0 || (int) p.vpair.size () < 2 * p.front.height)
     return false;
   const int lo = -(p.rect.in_y >> 1), hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
@@ -1477,6 +1521,8 @@ struct SimCache {
   int kind = 0;    // 0 unpack, 1 upsample, 2 passthrough (hscale/convert/alpha), 3 vscale
   const ScalePass *vpass = nullptr;
   int out_height = 0;
+  const std::vector<uint32_t> *zip = nullptr;      // interlaced frames: the zipped scaler's first line per output line; its windows are 2 * taps lines
+  int zip_lines = 0;
 };
 
 struct Sim {
@@ -1485,6 +1531,8 @@ struct Sim {
   int line_lo, line_hi;     // lines the unpacker can deliver, relative to the crop origin: do_unpack_lines (:2966) clamps to the FRAME
   int h_sub;
   int up_n_lines, up_offset;
+  bool ilace = false;       // an interlaced frame: 4:2:0 lines take the chroma row of their FIELD (GET_UV_420, video-format.c:1045), and the table's
+                            // second entries carry video_chroma_up_vi2's weights (vpair_pack_w8)
 
   void clear (SimCache *c) { c->len = 0; c->first = 0; }
   void add_line (SimCache *c, int idx)
@@ -1520,6 +1568,8 @@ struct Sim {
   int chroma_row (int line) const
   {
     int cl = std::min (std::max (line, line_lo), line_hi);
+    if (ilace && h_sub == 1)
+      return ((cl & ~2) >> 1) | (cl & 1);         /* GET_UV_420 with GST_VIDEO_PACK_FLAG_INTERLACED */
     return cl >> h_sub;                   /* arithmetic: line -1 -> row -1 */
   }
   bool need_line (SimCache *c, int out_line, int in_line)
@@ -1536,6 +1586,18 @@ struct Sim {
         }
         if (!get_lines (c->prev, out_line, start_line, n_lines))
           return false;
+        if (n_lines == 4) {
+          /* video_chroma_up_vi2_u8 (video-chroma.c:347-384) over lines[0 .. 3]: lines 0 and 2 blend the rows of lines 0 and 2 (5:3, 1:7), lines 1 and 3
+             those of lines 1 and 3 (7:1, 3:5) */
+          static const int wa[4] = {5, 7, 1, 3};
+          for (int i = 0; i < 4; i++) {
+            const int line = start_line + i;
+            if (line >= 0 && line < in_height) {
+              (*vpair)[2 * line + 0] = vpair_pack (chroma_row (start_line + (i & 1)), 0);
+              (*vpair)[2 * line + 1] = vpair_pack_w8 (chroma_row (start_line + (i & 1) + 2), wa[i]);
+            }
+          }
+        }
         if (n_lines == 2) {
           int ra = chroma_row (start_line), rb = chroma_row (start_line + 1);
           for (int i = 0; i < 2; i++) {
@@ -1557,7 +1619,7 @@ struct Sim {
         return true;
       case 3: {
         int cline = std::min (std::max (in_line, 0), c->out_height - 1);
-        int sline = (int) c->vpass->offset[cline], n = c->vpass->n_taps;
+        int sline = c->zip ? (int) (*c->zip)[(size_t) cline] : (int) c->vpass->offset[cline], n = c->zip ? c->zip_lines : c->vpass->n_taps;
         if (!get_lines (c->prev, out_line, sline, n))
           return false;
         add_line (c, in_line);
@@ -1616,6 +1678,78 @@ static void simulate_vpairs (VideoPlan *plan, int out_height, bool extra = false
     sim.get_lines (prev, out_height, out_height, 1);
 }
 
+/* The pair table of ONE FIELD of an interlaced frame: the frame's chain simulated as the reference runs it on a frame with
+ * GST_VIDEO_FRAME_FLAG_INTERLACED (video_converter_generic :3303-3312: upsample_i / v_scaler_i) - the chroma upsampler in groups of four lines from
+ * the line it is asked for (video_chroma_up_vi2: n_lines 4, offset -2; none when the site is vertically cosited or the upsampler is off), the
+ * vertical scaler asking for 2 * taps lines from its zipped offsets with that many lines of backlog (chain_vscale :1651-1660, 1673) - then the
+ * entries of the field's lines, in rows of the FRAME's chroma planes.  up_v: the vertical upsampler runs. */
+static void simulate_vpairs_field (VideoPlan *plan, int frame_in_h, int frame_out_h, int field, bool up_v, const std::vector<uint32_t> *zip, int zip_lines,
+    bool dest_rows)
+{
+  const int H = frame_in_h;
+  std::vector<int32_t> tab ((size_t) H * 2, 0);
+  Sim sim;
+  sim.vpair = &tab;
+  sim.in_height = H;
+  sim.line_lo = 0;
+  sim.line_hi = H - 1;
+  sim.h_sub = plan->front.h_sub;
+  sim.ilace = true;
+  sim.up_n_lines = up_v ? 4 : 1;
+  sim.up_offset = up_v ? -2 : 0;
+  for (int y = 0; y < H; y++) {
+    const int r = sim.chroma_row (y);
+    tab[(size_t) 2 * y] = vpair_pack (r, 0);
+    tab[(size_t) 2 * y + 1] = vpair_pack_w8 (r, 4);
+  }
+  if (up_v) {
+    std::vector<SimCache> caches (2 + plan->passes.size ());
+    caches[0].kind = 0;
+    caches[1].kind = 1;
+    caches[1].prev = &caches[0];
+    SimCache *prev = &caches[1];
+    size_t ci = 2;
+    for (const ScalePass &p : plan->passes) {
+      SimCache *c = &caches[ci++];
+      c->prev = prev;
+      if (p.horizontal) {
+        c->kind = 2;
+      } else {
+        c->kind = 3;
+        c->vpass = &p;
+        c->out_height = frame_out_h;
+        c->zip = zip;
+        c->zip_lines = zip_lines;
+        prev->backlog = zip_lines;          /* chain_vscale: prev->backlog = taps_i */
+      }
+      prev = c;
+    }
+    for (int i = 0; i < frame_out_h; i++)
+      sim.get_lines (prev, i, i, 1);
+  }
+  if (up_v && dest_rows) {
+    /* the chain's lines are the destination frame's own rows (a destination in its unpack format, nothing between the unpacker and the packer that makes
+       lines of its own: get_dest_line :2925 clamps the row): the lines above the picture of the first group (-2, -1) ARE row 0 and the lines below it of
+       the last group are the last row, and video_chroma_up_vi2 filters a group only `if (l0 != l1 && l2 != l3)` (video-chroma.c:368) - the two picture
+       lines of those groups keep the chroma row they were unpacked with */
+    for (int y = 0; y < H; y++) {
+      const int start = ((y + 2) & ~3) - 2;          /* the group (4 m - 2 .. 4 m + 1) of line y, lines asked for in order */
+      if (start < 0 || start + 3 > H - 1) {
+        const int r = sim.chroma_row (y);
+        tab[(size_t) 2 * y] = vpair_pack (r, 0);
+        tab[(size_t) 2 * y + 1] = vpair_pack_w8 (r, 4);
+      }
+    }
+  }
+  const int FH = plan->front.height;
+  plan->vpair.assign ((size_t) FH * 2, 0);
+  for (int k = 0; k < FH; k++) {
+    const int y = std::min (2 * k + field, H - 1);
+    plan->vpair[(size_t) 2 * k] = tab[(size_t) 2 * y];
+    plan->vpair[(size_t) 2 * k + 1] = tab[(size_t) 2 * y + 1];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // fastpath detection (video-converter.c:8907-9017 + transforms[] :8413-8905), restricted to the
 // formats this library knows.  Returns a short name of the reference fastpath or nullptr.
@@ -1630,6 +1764,7 @@ enum : unsigned {
   FP_BORDER = 8,      /* do_border */
   FP_ACOPY = 16, FP_ASET = 32, FP_AMULT = 64,
   FP_WEVEN = 128, FP_HEVEN = 256,   /* width_align / height_align == 1 */
+  FP_ILACE = 512,     /* keeps_interlaced: usable on interlaced infos (the convert_scale_planes rows: see lookup_fastpath) */
 };
 /* one bit per format, the enum value (128 bits: every format transforms[] names lies below 128; the later ones - GBR_16LE, RBGA, Y216_LE, Y416_LE -
    have no rows and no bit) */
@@ -1655,34 +1790,34 @@ struct FastRow {
 };
 const FastRow g_fast_rows[] = {
   {F_420, F_RGB4X | F_RGB4A | F_RGB3 | F_RGB16S, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_I420_xRGB"},       /* (... _pack_ARGB into RGB15 / 16: :8797-8800, 8809-8812) */
-  {F_AYUV, F_RGB4X, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_AYUV_xRGB"},
-  {F_AYUV, F_RGB4A, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY, "convert_AYUV_xRGB"},
-  {F_420, F_AYUV, false, FP_SIZE | FP_ASET, "convert_I420_AYUV"},
-  {F_Y42B, F_AYUV, false, FP_SIZE | FP_CROP | FP_BORDER | FP_ASET | FP_WEVEN, "convert_Y42B_AYUV"},
-  {F_Y444, F_AYUV, false, FP_SIZE | FP_CROP | FP_BORDER | FP_ASET, "convert_Y444_AYUV"},
-  {F_YUY2, F_AYUV, false, FP_SIZE | FP_CROP | FP_BORDER | FP_ASET | FP_WEVEN, "convert_YUY2_AYUV"},
-  {F_UYVY, F_AYUV, false, FP_SIZE | FP_CROP | FP_BORDER | FP_ASET, "convert_UYVY_AYUV"},
+  {F_AYUV, F_RGB4X, false, FP_ILACE | FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_AYUV_xRGB"},
+  {F_AYUV, F_RGB4A, false, FP_ILACE | FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY, "convert_AYUV_xRGB"},
+  {F_420, F_AYUV, false, FP_ILACE | FP_SIZE | FP_ASET, "convert_I420_AYUV"},
+  {F_Y42B, F_AYUV, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER | FP_ASET | FP_WEVEN, "convert_Y42B_AYUV"},
+  {F_Y444, F_AYUV, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER | FP_ASET, "convert_Y444_AYUV"},
+  {F_YUY2, F_AYUV, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER | FP_ASET | FP_WEVEN, "convert_YUY2_AYUV"},
+  {F_UYVY, F_AYUV, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER | FP_ASET, "convert_UYVY_AYUV"},
   {F_AYUV, F_420, false, FP_SIZE | FP_CROP | FP_BORDER | FP_WEVEN | FP_HEVEN, "convert_AYUV_I420"},
-  {F_AYUV, F_Y42B | F_YUY2 | F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER | FP_WEVEN, "convert_AYUV_422"},
-  {F_AYUV, F_Y444, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_AYUV_Y444"},
-  {F_420, F_YUY2 | F_UYVY, false, FP_SIZE, "convert_I420_YUY2"},
-  {F_YUY2 | F_UYVY, F_420, false, FP_SIZE, "convert_YUY2_I420"},
-  {F_Y42B, F_YUY2 | F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_Y42B_YUY2"},
-  {F_Y444, F_YUY2 | F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER | FP_WEVEN, "convert_Y444_YUY2"},
-  {F_YUY2 | F_UYVY, F_Y42B | F_Y444, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_YUY2_planar"},
-  {F_YUY2, F_UYVY, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
-  {F_UYVY, F_GRAY8, false, FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_GRAY8"},          /* :8501 */
-  {F_UYVY, F_YUY2, false, FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
+  {F_AYUV, F_Y42B | F_YUY2 | F_UYVY, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER | FP_WEVEN, "convert_AYUV_422"},
+  {F_AYUV, F_Y444, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER, "convert_AYUV_Y444"},
+  {F_420, F_YUY2 | F_UYVY, false, FP_ILACE | FP_SIZE, "convert_I420_YUY2"},
+  {F_YUY2 | F_UYVY, F_420, false, FP_ILACE | FP_SIZE, "convert_YUY2_I420"},
+  {F_Y42B, F_YUY2 | F_UYVY, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER, "convert_Y42B_YUY2"},
+  {F_Y444, F_YUY2 | F_UYVY, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER | FP_WEVEN, "convert_Y444_YUY2"},
+  {F_YUY2 | F_UYVY, F_Y42B | F_Y444, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER, "convert_YUY2_planar"},
+  {F_YUY2, F_UYVY, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
+  {F_UYVY, F_GRAY8, false, FP_ILACE | FP_MATRIX | FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_GRAY8"},          /* :8501 */
+  {F_UYVY, F_YUY2, false, FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER, "convert_UYVY_YUY2"},
   /* the v210 rows (:8433-8543; convert_I420_v210, convert_v210_I420_10 ...: their own arithmetic - 8-bit samples shifted by two, no widening):
      not built, such pairs are refused at their own size (every one of these rows wants keeps_size and the same colour matrix; crop / border /
      alpha flags are matched generously - refusing a conversion the reference would run through the chain costs nothing but coverage) */
   /* round 5: the 8-bit ones on whole frames (video_v210_fast.h); with a crop or a rectangle the generous rows below still refuse */
-  {F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), fbit (GSTAMD_VIDEO_FORMAT_v210), false, FP_SIZE, "convert_8bit_v210"},
-  {fbit (GSTAMD_VIDEO_FORMAT_v210), F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), false, FP_SIZE, "convert_v210_8bit"},
+  {F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), fbit (GSTAMD_VIDEO_FORMAT_v210), false, FP_ILACE | FP_SIZE, "convert_8bit_v210"},
+  {fbit (GSTAMD_VIDEO_FORMAT_v210), F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), false, FP_ILACE | FP_SIZE, "convert_v210_8bit"},
   {F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), fbit (GSTAMD_VIDEO_FORMAT_v210), false,
-        FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY | FP_ASET | FP_AMULT, "convert_to_v210"},
+        FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY | FP_ASET | FP_AMULT, "convert_to_v210"},
   {fbit (GSTAMD_VIDEO_FORMAT_v210), F_420 | F_Y42B | F_YUY2 | F_UYVY | fbit (GSTAMD_VIDEO_FORMAT_I420_10LE) | fbit (GSTAMD_VIDEO_FORMAT_I422_10LE), false,
-        FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY | FP_ASET | FP_AMULT, "convert_from_v210"},
+        FP_ILACE | FP_SIZE | FP_CROP | FP_BORDER | FP_ACOPY | FP_ASET | FP_AMULT, "convert_from_v210"},
   /* convert_scale_planes: every same-format pair, planar <-> planar and the NV12 / NV16 / NV24 family */
   {F_RGB4A | F_AYUV | fbit (GSTAMD_VIDEO_FORMAT_ARGB64) | fbit (GSTAMD_VIDEO_FORMAT_AYUV64), ~(fmask) 0, true, FP_CROP | FP_BORDER | FP_ACOPY, "convert_scale_planes"},
   {F_RGB4X | F_RGB3 | F_YUV3 | F_420 | F_Y42B | F_Y444 | fbit (GSTAMD_VIDEO_FORMAT_GBR) | F_NV12 | F_NV16 | F_NV24 | fbit (GSTAMD_VIDEO_FORMAT_NV21) | fbit (GSTAMD_VIDEO_FORMAT_NV61) |
@@ -1715,6 +1850,11 @@ const FastRow g_fast_rows[] = {
 static const char *lookup_fastpath (const VideoPlan &p, int alpha_mode_bits, bool same_matrix)
 {
   const int in = p.in_info.format, out = p.out_info.format;
+  /* interlaced infos: rows with keeps_interlaced only (:8985).  Of the convert_scale_planes rows those are every same-format pair, I420 <-> YV12 and the
+     pairs among NV12 / NV16 / NV24 (:8547-8904) */
+  const bool ilace = p.field != 0;
+  const fmask nv = F_NV12 | F_NV16 | F_NV24;
+  const bool planes_ilace_ok = in == out || ((fbit (in) & F_420) && (fbit (out) & F_420)) || ((fbit (in) & nv) && (fbit (out) & nv));
   const bool same_size = p.ref_same_size;
   const bool need_copy = alpha_mode_bits & 1, need_set = alpha_mode_bits & 2, need_mult = alpha_mode_bits & 4;
   if (p.config.dither_quantization != 1)
@@ -1722,11 +1862,13 @@ static const char *lookup_fastpath (const VideoPlan &p, int alpha_mode_bits, boo
   const RectPlan &rc = p.rect;
   const bool crop = rc.in_x || rc.in_y || p.in_info.width < rc.in_maxw || p.in_info.height < rc.in_maxh;
   const bool border = rc.out_x || rc.out_y || (rc.out_maxw && p.out_info.width < rc.out_maxw) || (rc.out_maxh && p.out_info.height < rc.out_maxh);
-  const int full_w = rc.in_maxw ? rc.in_maxw : p.in_info.width, full_h = rc.in_maxh ? rc.in_maxh : p.in_info.height;
+  const int full_w = rc.in_maxw ? rc.in_maxw : p.in_info.width, full_h = ilace ? p.in_info.frame_height : (rc.in_maxh ? rc.in_maxh : p.in_info.height);
   for (const FastRow &r : g_fast_rows) {
     if (!(r.in & fbit (in)) || !(r.out & fbit (out)) || (r.same && in != out))
       continue;
     const unsigned f = r.flags;
+    if (ilace && !(strcmp (r.name, "convert_scale_planes") == 0 ? planes_ilace_ok : (f & FP_ILACE) != 0))
+      continue;
     if (((f & FP_MATRIX) || same_matrix) && (!(f & FP_SIZE) || same_size) && (!(f & FP_WEVEN) || !(full_w & 1)) &&
         (!(f & FP_HEVEN) || !(full_h & 1)) && ((f & FP_CROP) || !crop) && ((f & FP_BORDER) || !border) &&
         ((f & FP_ACOPY) || !need_copy) && ((f & FP_ASET) || !need_set) && ((f & FP_AMULT) || !need_mult))
@@ -1752,6 +1894,10 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
   plan->ref_fastpath = fastpath;
   uint64_t bytes = 0;
   auto up = [](int v, int sub) { return -((-v) >> sub); };       /* GST_VIDEO_SUB_SCALE */
+  /* a field of an interlaced frame (setup_scale :7977, 8075, 8236): every decision is the FRAME plane's, the vertical scalers are interlaced ones
+     (this field's resampler over the field's lines), and none of the halve / double shortcuts applies (`!interlaced &&`, :8171-8206) */
+  const int field = plan->field;
+  const int frame_ih = field ? in.frame_height : in.height, frame_oh = field ? out.frame_height : out.height;
   for (int i = 0; i < fo->n_planes; i++) {
     PlanePlan pp;
     pp.dst_plane = i;
@@ -1786,6 +1932,13 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
     pp.ih = up (in.height, isub_h);
     pp.ow = up (out.width, osub_w);
     pp.oh = up (out.height, osub_h);
+    const int fpih = up (frame_ih, isub_h), fpoh = up (frame_oh, osub_h);          /* the frame's plane heights */
+    if (field) {
+      pp.ih = field == 1 ? (fpih + 1) / 2 : fpih - (fpih + 1) / 2;
+      pp.oh = field == 1 ? (fpoh + 1) / 2 : fpoh - (fpoh + 1) / 2;
+      if (pp.ih <= 0 || pp.oh <= 0)
+        return GSTAMD_ERR_UNSUPPORTED;
+    }
     if (fo->kind == UNPACK_GRAY16 || fo->kind == UNPACK_RGB16) {
       pp.n_elems = 2;          /* copies and nearest passes only (plan_core): a 16-bit sample moves as two bytes */
     } else if (fo->kind == UNPACK_PACKED3) {
@@ -1813,26 +1966,31 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
     const bool p1 = pp.n_elems == 1 && (fo->n_planes > 1 || fo->kind == UNPACK_GRAY), lin = rm == GSTAMD_RESAMPLER_METHOD_LINEAR, near = rm == GSTAMD_RESAMPLER_METHOD_NEAREST;
     bool need_h = false, need_v = false;
     pp.kind = PLANE_SCALE;
+    const int dih = field ? fpih : pp.ih, doh = field ? fpoh : pp.oh;          /* the heights the decisions look at */
+    /* the planes of multi-plane and GRAY formats (setup_scale's plane loop, :8088): `if (iw == ow) { if (!interlaced && ih == oh) copy ...  else
+       need_v_scaler }` - an interlaced plane of unchanged WIDTH always goes through the interlaced vertical scaler, which is no copy at equal heights
+       either (its two resamplers are shifted by half a line, video-scaler.c:233).  One-plane formats (:8016-8087) scale vertically iff the heights differ. */
+    const bool loop_plane = fo->n_planes > 1 || fo->kind == UNPACK_GRAY || fo->kind == UNPACK_GRAY16;
     if (pp.iw == pp.ow) {
-      if (pp.ih == pp.oh)
+      if (dih == doh && !(field && loop_plane))
         pp.kind = PLANE_COPY;
-      else if (pp.ih == 2 * pp.oh && p1 && lin)
+      else if (!field && dih == 2 * doh && p1 && lin)
         pp.kind = PLANE_V_HALVE;
-      else if (2 * pp.ih == pp.oh && p1 && near)
+      else if (!field && 2 * dih == doh && p1 && near)
         pp.kind = PLANE_V_DOUBLE;
       else
         need_v = true;
-    } else if (pp.ih == pp.oh) {
-      if (pp.iw == 2 * pp.ow && p1 && lin)
+    } else if (dih == doh) {
+      if (!field && pp.iw == 2 * pp.ow && p1 && lin)
         pp.kind = PLANE_H_HALVE;
-      else if (2 * pp.iw == pp.ow && p1 && near)
+      else if (!field && 2 * pp.iw == pp.ow && p1 && near)
         pp.kind = PLANE_H_DOUBLE;
       else
         need_h = true;
     } else {
-      if (pp.iw == 2 * pp.ow && pp.ih == 2 * pp.oh && p1 && lin)
+      if (!field && pp.iw == 2 * pp.ow && dih == 2 * doh && p1 && lin)
         pp.kind = PLANE_HV_HALVE;
-      else if (2 * pp.iw == pp.ow && 2 * pp.ih == pp.oh && p1 && near)
+      else if (!field && 2 * pp.iw == pp.ow && 2 * dih == doh && p1 && near)
         pp.kind = PLANE_HV_DOUBLE;
       else
         need_h = need_v = true;
@@ -1876,12 +2034,16 @@ static int plan_planes (VideoPlan *plan, const char *fastpath)
         }
       } else if (need_h)
         make_scale_pass (rm, cfg.resampler_taps, cfg, pp.iw, pp.ow, true, &hp, pp.n_elems != 1);
-      if (need_v)
+      int zip_last = 0;
+      if (need_v && field) {
+        if (!make_field_vpass (rm, cfg.resampler_taps, cfg, fpih, fpoh, field - 1, &vp, false, &zip_last, nullptr))
+          return GSTAMD_ERR_UNSUPPORTED;
+      } else if (need_v)
         make_scale_pass (rm, cfg.resampler_taps, cfg, pp.ih, pp.oh, false, &vp, false);
       hp.max_span = vp.max_span = 1 << 30;
       if (need_h && need_v) {
         /* gst_video_scaler_2d: horizontal first iff width * voffset[height - 1] <= width * height */
-        const bool h_first = (long) pp.ow * (long) vp.offset[pp.oh - 1] <= (long) pp.ow * pp.oh;
+        const bool h_first = field ? (long) pp.ow * (long) zip_last <= (long) pp.ow * fpoh : (long) pp.ow * (long) vp.offset[pp.oh - 1] <= (long) pp.ow * pp.oh;
         if (h_first) {
           pp.passes.push_back (hp);
           pp.passes.push_back (vp);
@@ -2742,6 +2904,27 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   plan->plane_mode = false;
   plan->relayout = false;
   plan->fast_422_ayuv = false;
+  /* one field of an interlaced frame (plan_field_infos): the frame's heights decide what the reference's converter is made of */
+  const int field = in->interlace_mode == GSTAMD_INTERLACE_FIELD_TOP ? 1 : (in->interlace_mode == GSTAMD_INTERLACE_FIELD_BOTTOM ? 2 : 0);
+  plan->field = field;
+  plan->interlaced = false;
+  plan->field_src_chroma_frame = false;
+  const int frame_in_h = field ? in->frame_height : in->height, frame_out_h = field ? out->frame_height : out->height;
+  if (field) {
+    if (out->interlace_mode != in->interlace_mode || frame_in_h < 2 || frame_out_h < 2)
+      return fail (GSTAMD_ERR_INVALID, "field conversion: both infos must name the same field of frames of two lines or more");
+    const RectPlan &rc = plan->rect;
+    if (rc.in_x || rc.in_y || rc.out_x || rc.out_y || rc.fill || (rc.in_maxw && (rc.in_maxw != in->width || rc.in_maxh != in->height)) ||
+        (rc.out_maxw && (rc.out_maxw != out->width || rc.out_maxh != out->height)))
+      return fail (GSTAMD_ERR_UNSUPPORTED, "interlaced frames with a source crop or a destination rectangle are not implemented on the GPU path");
+    /* GET_UV_420 / IS_CHROMA_LINE_420 with GST_VIDEO_PACK_FLAG_INTERLACED (video-format.c:1045-1052) address chroma row ((y & ~2) >> 1) | (y & 1): for a
+       frame height that is not a multiple of four the last lines of the bottom field read (unpack) and write (pack) a row past the chroma planes */
+    if ((plan->fin->h_sub == 1 && (frame_in_h & 3)) || (plan->fout->h_sub == 1 && (frame_out_h & 3)))
+      return fail (GSTAMD_ERR_UNSUPPORTED, "interlaced 4:2:0 frames whose height is not a multiple of four: the reference's unpack / pack functions address a "
+          "chroma row past the planes there; not reproduced");
+    if (cfg.gamma_mode == GSTAMD_GAMMA_MODE_REMAP)
+      return fail (GSTAMD_ERR_UNSUPPORTED, "gamma-mode = remap on interlaced frames is not implemented on the GPU path");
+  }
   /* chain_dither (:2035-2100) on an 8-bit chain: a stage exists when dither-quantization asks for a coarser quantiser than the
    * format's own (1 at 8 bits) and the method is not NONE - NONE returns before anything is set up, quantisation included.  Every
    * component the destination has (depth > 0) gets the quantiser, rounded down to a power of two (count_power). */
@@ -2793,6 +2976,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     }
   }
 
+  if (field && (plan->dither.on || planar_dither.on || (plan->fout->hi_depth && cfg.dither_method != GSTAMD_DITHER_NONE && plan->fin->format != plan->fout->format)))
+    return fail (GSTAMD_ERR_UNSUPPORTED, "a dither stage on interlaced frames (its pattern follows the frame's line numbers) is not implemented on the GPU path");
   const bool unpack_rgb = !plan->fin->yuv, pack_rgb = !plan->fout->yuv;
   /* gst_video_converter_init_from_config (:2380-2404): RGB formats force the RGB matrix */
   int in_matrix = unpack_rgb ? GSTAMD_COLOR_MATRIX_RGB : in->color_matrix;
@@ -2869,6 +3054,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     order_2d = true;
     fp = nullptr;
   }
+  if (field && plan->fin->hi_depth == 3 && !(fp && strcmp (fp, "convert_scale_planes") == 0 && in->width == out->width && frame_in_h == frame_out_h))
+    return fail (GSTAMD_ERR_UNSUPPORTED, "interlaced ARGB64 / AYUV64 sources are not implemented on the GPU path");
   if (plan->fin->hi_depth == 3)
     return plan_src64 (in, out, plan, alpha_bits, same_matrix, same_primaries, prim_dm, in_matrix, out_matrix, fp != nullptr, error);
   if (fp) {
@@ -2933,14 +3120,14 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       return fail (GSTAMD_ERR_UNSUPPORTED, std::string ("reference takes fastpath ") + fp +
           " for this conversion; no GPU kernel for it yet");
     plan->ref_fastpath = fp;
-    if ((force_nearest || force_ayuv_argb || force_avg_down) && (in->width != out->width || in->height != out->height))
+    if ((force_nearest || force_ayuv_argb || force_avg_down) && (in->width != out->width || frame_in_h != frame_out_h))
       return fail (GSTAMD_ERR_UNSUPPORTED, "the reference selects a same-size fastpath by the uncropped input size while the crop differs from the "
           "destination rectangle; not reproduced");
   }
 
   // ---- front: unpack + chroma upsample (chain_unpack_line, chain_upsample) ----------------------
-  const int full_in_w = plan->rect.in_maxw ? plan->rect.in_maxw : in->width, full_in_h = plan->rect.in_maxh ? plan->rect.in_maxh : in->height;
-  const int full_out_w = plan->rect.out_maxw ? plan->rect.out_maxw : out->width, full_out_h = plan->rect.out_maxh ? plan->rect.out_maxh : out->height;
+  const int full_in_w = plan->rect.in_maxw ? plan->rect.in_maxw : in->width, full_in_h = field ? frame_in_h : (plan->rect.in_maxh ? plan->rect.in_maxh : in->height);
+  const int full_out_w = plan->rect.out_maxw ? plan->rect.out_maxw : out->width, full_out_h = field ? frame_out_h : (plan->rect.out_maxh ? plan->rect.out_maxh : out->height);
   FrontParams &fr = plan->front;
   memset (&fr, 0, sizeof (fr));
   fr.kind = plan->fin->kind;
@@ -2975,28 +3162,50 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     fr.chroma_h = CHROMA_H_NONE;
     fr.chroma_v2 = 0;
   }
+  /* a field: video_chroma_up_vi2_u8 where the frame's chain has the v2 upsampler (v_index + 16, video-chroma.c:1087); the cosited one is a stub as well */
+  const bool field_up_v = field && fr.chroma_v2 != 0;
 
   // ---- scaling (chain_scale :1685-1717 decides WHERE and in which ORDER) -------------------------
   plan->passes.clear ();
   const int in_w = in->width, in_h = in->height, out_w = out->width, out_h = out->height;
-  const long s0 = (long) in_w * in_h, s3 = (long) out_w * out_h;
-  const bool need_scale = in_w != out_w || in_h != out_h;
+  /* (a field: the sizes chain_scale and gst_video_scaler_2d compare are the frame's) */
+  const int dec_in_h = field ? frame_in_h : in_h, dec_out_h = field ? frame_out_h : out_h;
+  const long s0 = (long) in_w * dec_in_h, s3 = (long) out_w * dec_out_h;
+  const bool need_scale = in_w != out_w || dec_in_h != dec_out_h;
   plan->matrix_before_scale = need_scale && !(s3 <= s0);
+  std::vector<uint32_t> field_zip;          /* the frame's zipped vertical scaler: first line of every output line */
+  int field_zip_lines = 0;
   if (need_scale) {
-    const long s1 = (long) out_w * in_h, s2 = (long) in_w * out_h;
+    const long s1 = (long) out_w * dec_in_h, s2 = (long) in_w * dec_out_h;
     bool h_first = s1 <= s2;
-    if ((plane_scale || order_2d) && in_w != out_w && in_h != out_h) {
+    if ((plane_scale || order_2d) && in_w != out_w && dec_in_h != dec_out_h) {
       /* gst_video_scaler_2d: horizontal first iff width * voffset[height - 1] <= width * height */
+      if (field) {
+        int zip_last = 0;
+        if (!make_field_vpass (cfg.resampler_method, cfg.resampler_taps, cfg, frame_in_h, frame_out_h, 0, nullptr, false, &zip_last, nullptr))
+          return fail (GSTAMD_ERR_UNSUPPORTED, "the reference cannot make an interlaced scaler for these heights");
+        h_first = (long) out_w * (long) zip_last <= (long) out_w * frame_out_h;
+      } else {
       ScalePass vp;
       make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, in_h, out_h, false, &vp);
       h_first = (long) out_w * (long) vp.offset[out_h - 1] <= (long) out_w * out_h;
+      }
     }
     for (int step = 0; step < 2; step++) {
       bool horizontal = (step == 0) == h_first;
-      int isz = horizontal ? in_w : in_h, osz = horizontal ? out_w : out_h;
+      int isz = horizontal ? in_w : dec_in_h, osz = horizontal ? out_w : dec_out_h;
       if (isz == osz)
         continue;
       ScalePass pass;
+      if (field && !horizontal) {
+        /* chain_vscale (:1651-1660) / setup_scale (:8075): GST_VIDEO_SCALER_FLAG_INTERLACED - this field's resampler over the field's lines */
+        if (!make_field_vpass (cfg.resampler_method, cfg.resampler_taps, cfg, frame_in_h, frame_out_h, field - 1, &pass,
+                plan->deep16 && (!plan->matrix_before_scale || plan->deep_out), nullptr, &field_zip))
+          return fail (GSTAMD_ERR_UNSUPPORTED, "the reference cannot make an interlaced scaler for these heights");
+        field_zip_lines = 2 * pass.n_taps;
+        if (pass.in_size != in_h || pass.out_size != out_h)
+          return fail (GSTAMD_ERR_INVALID, "field conversion: the infos' heights are not this field's");
+      } else
       make_scale_pass (cfg.resampler_method, cfg.resampler_taps, cfg, isz, osz, horizontal, &pass, false,
           plan->deep16 && (!plan->matrix_before_scale || plan->deep_out));
       pass.max_span = 1 << 30;
@@ -3045,7 +3254,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * reference output depends on buffer reuse (verified against oracle/_ref: >15 % of bytes differ
    * from the intended filter).  There is nothing to reproduce: the plan computes the intended filter (what the reference gives when
    * the same chain is run as two conversions, in -> AYUV at the source size and AYUV -> out) and says so in plan->divergence. */
-  if (!plan->passes.empty () && !plan->passes[0].horizontal && fr.chroma_v2 && plan->passes[0].n_taps >= 5)
+  if (!field && !plan->passes.empty () && !plan->passes[0].horizontal && fr.chroma_v2 && plan->passes[0].n_taps >= 5)
     plan->divergence += "vertical-first N-tap scaling fed by the 4:2:0 chroma upsampler: the reference's unpack ring is one line short "
         "(temp-line aliasing, its output depends on buffer reuse); this library applies the filter to the lines the chain intends. ";
 
@@ -3124,9 +3333,12 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       if (fo->h_sub == 1 && !(out->chroma_site & GSTAMD_CHROMA_SITE_V_COSITED))
         pk.down_v = 1;          /* the cosited vertical variant is an h-only stub (video-chroma.c:996) */
     }
+    if (field)
+      pk.down_v = 0;          /* video_chroma_down_vi2_u8 is a stub (video-chroma.c:461-470): every line keeps its chroma, pack_planar_420 & co take the field's
+                                 even lines' (IS_CHROMA_LINE_420 with the interlaced flag) - this field's lines 0, 2, ... into its chroma rows */
     if (force_avg_down) {
       pk.down_h = fo->w_sub == 1 ? 1 : 0;
-      pk.down_v = fo->h_sub == 1 ? 1 : 0;
+      pk.down_v = fo->h_sub == 1 ? 1 : 0;          /* (a field: GET_LINE_OFFSETS pairs lines l and l + 2, two consecutive lines of the field, :3383) */
     }
     for (int i = 0; i < 4; i++)
       post.pack_pos[i] = i;
@@ -3148,7 +3360,13 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   /* With a source crop that ends above the frame's last line the line past the picture is a real one (do_unpack_lines clamps to the FRAME),
      whatever the source format: the same extra row then. */
   plan->pack.virtual_line = plan->out_planar && plan->passes.empty () && (fr.chroma_v2 || fr.luma_last >= in_h) && plan->pack.down_v && plan->pack.h_sub == 1 &&
-      (out_h & 1) && in_h == out_h && !plan->deep16 && !plan->deep_out ? 1 : 0;
+      (out_h & 1) && in_h == out_h && !plan->deep16 && !plan->deep_out && !field ? 1 : 0;
+  if (field && fr.h_sub == 1 && (kind_has_planes (fr.kind) || GSTAMD_KIND_ALPHA_PLANE (fr.kind) >= 0)) {
+    const bool dest_rows = plan->passes.empty () && !plan->deep16 && (plan->fout->format == GSTAMD_VIDEO_FORMAT_ARGB || plan->fout->format == GSTAMD_VIDEO_FORMAT_AYUV);
+    simulate_vpairs_field (plan, frame_in_h, frame_out_h, field - 1, field_up_v, field_zip.empty () ? nullptr : &field_zip, field_zip_lines, dest_rows);
+    fr.chroma_v2 = 2;
+    plan->field_src_chroma_frame = true;
+  } else
   simulate_vpairs (plan, out_h, plan->pack.virtual_line != 0);
 
   plan->algorithmic_bytes = 0;
@@ -3197,7 +3415,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       matrix_no_wrap = matrix_no_wrap && seq;
     }
   }
-  plan->fast_pair = plan->passes.empty () && fr.kind == UNPACK_SEMI && fr.chroma_v2 && (in_w % 4) == 0 && in_h >= 2 && matrix_no_wrap;
+  plan->fast_pair = plan->passes.empty () && fr.kind == UNPACK_SEMI && fr.chroma_v2 == 1 && (in_w % 4) == 0 && in_h >= 2 && matrix_no_wrap;
   /* capture direction (video_422_fast.h): unscaled packed 4:2:2 -> 4-byte RGB, whole 8-pixel groups, no odd-width tail quirk */
   plan->fast_422 = plan->passes.empty () && fr.kind == UNPACK_PACKED422 && !plan->out_planar && matrix_no_wrap && (in_w % 8) == 0 &&
       fr.swap_k < 0 && !fr.chroma_v2;
@@ -3233,6 +3451,8 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   }
   if (plan->deep16 || plan->deep_out)
     plan->fast_pair = plan->fast_420p = plan->fast_422 = plan->fast_422_ayuv = plan->fast_enc420 = plan->fast_post = false;
+  if (field)            /* the generic kernels (their chroma rows and weights come from the field's pair table); the per-line 4:2:2 kernels stay */
+    plan->fast_pair = plan->fast_420p = plan->fast_enc420 = false;
   if (plan->pack.dither.on)             /* the dither stage lives in the pack kernel: the fused kernels that write planes / 3-byte pixels themselves have none */
     plan->fast_pair = plan->fast_enc420 = false;
   /* planar / semi-planar 8-bit YUV on both sides with the same subsampling, and a chain that neither filters nor mixes: the front hands
@@ -3244,10 +3464,14 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
       !plan->pack.dither.on && plan->matrix.kind == MATRIX_NONE && post.alpha_kind == ALPHA_NONE && in_w == out->width && in_h == out->height &&
       !plan->rect.in_x && !plan->rect.in_y && !plan->rect.out_x && !plan->rect.out_y;
 
+  if (field && (plan->deep_out || (plan->deep16 && plan->out_planar)))
+    return fail (GSTAMD_ERR_UNSUPPORTED, "interlaced frames through the 16-bit part of the chain into a planar or 10 / 12 / 16-bit destination are not implemented on the GPU path");
   std::string d = plan->passes.empty () ? (plan->deep16 ? "convert16" : plan->fast_pair ? "fused_convert_pair" : plan->relayout ? "planes_relayout" : plan->fast_enc420 ? "fused_encode_420" : plan->fast_422 ? "fused_convert_422" : plan->fast_420p ? "fused_convert_420p" : "fused_convert") : "scale";
   d += std::string ("[") + plan->fin->name + "->" + plan->fout->name;
   d += fr.chroma_h == CHROMA_H_H2_CS ? ",h2cs" : fr.chroma_h == CHROMA_H_H2 ? ",h2" : fr.chroma_h == CHROMA_H_H4 ? ",h4" : fr.chroma_h == CHROMA_H_H4_CS ? ",h4cs" : "";
-  d += fr.chroma_v2 ? ",v2" : "";
+  d += fr.chroma_v2 == 2 ? (field_up_v ? ",vi2" : ",vi") : fr.chroma_v2 ? ",v2" : "";
+  if (field)
+    d += field == 1 ? ",top" : ",bottom";
   for (const ScalePass &p : plan->passes)
     d += std::string (p.horizontal ? ",H" : ",V") + std::to_string (p.n_taps) + (p.dot4_ok ? "b" : "");    /* b: byte-dot-product taps */
   static const char *mk[] = {"none", "ayuv_argb", "table", "matrix8"};
@@ -3278,6 +3502,59 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     cfg = *config;
   else
     converter_config_init (&cfg);
+  /* interlaced frames.  gst_video_converter_new insists on one mode for both infos (:2435).  An interleaved frame (GST_VIDEO_FRAME_IS_INTERLACED) becomes
+     two field conversions; this plan only speaks for them. */
+  if (in->interlace_mode != out->interlace_mode) {
+    if (error)
+      *error = "the two infos carry different interlace modes (gst_video_converter_new refuses that: \"we won't ever do deinterlace\")";
+    return GSTAMD_ERR_INVALID;
+  }
+  if (in->interlace_mode != GSTAMD_INTERLACE_MODE_PROGRESSIVE && !info_is_interleaved (*in) && !info_is_field (*in)) {
+    if (error)
+      *error = "interlace-mode fields / alternate is not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  if (info_is_interleaved (*in)) {
+    VideoPlan fp[2];
+    for (int f = 0; f < 2; f++) {
+      GstAmdVideoInfo fin, fout;
+      plan_field_infos (in, out, f, &fin, &fout);
+      const int r = plan_video_converter (&fin, &fout, &cfg, &fp[f], error);
+      if (r != GSTAMD_OK)
+        return r;
+    }
+    *plan = VideoPlan ();
+    plan->in_info = plan->orig_in = *in;
+    plan->out_info = plan->orig_out = *out;
+    plan->config = cfg;
+    plan->fin = format_desc (in->format);
+    plan->fout = format_desc (out->format);
+    format_plan_planes (plan->fin, &plan->in_info);
+    format_plan_planes (plan->fout, &plan->out_info);
+    plan->interlaced = true;
+    plan->plane_mode = plan->out_planar = plan->fast_pair = plan->relayout = plan->fast_enc420 = plan->fast_420p = plan->fast_422_ayuv = plan->fast_422 = false;
+    plan->fast_post = plan->deep_out = plan->deep16 = plan->matrix_before_scale = plan->ref_same_size = false;
+    memset (&plan->rect, 0, sizeof (plan->rect));
+    memset (&plan->front, 0, sizeof (plan->front));
+    memset (&plan->matrix, 0, sizeof (plan->matrix));
+    memset (&plan->post, 0, sizeof (plan->post));
+    memset (&plan->pack, 0, sizeof (plan->pack));
+    memset (&plan->deep, 0, sizeof (plan->deep));
+    memset (&plan->dither, 0, sizeof (plan->dither));
+    plan->ref_fastpath = fp[0].ref_fastpath;
+    plan->description = "interlaced{" + fp[0].description + " | " + fp[1].description + "}";
+    plan->divergence = fp[0].divergence;
+    if (fp[1].divergence != fp[0].divergence)
+      plan->divergence += fp[1].divergence;
+    plan->algorithmic_bytes = fp[0].algorithmic_bytes + fp[1].algorithmic_bytes;
+    return GSTAMD_OK;
+  }
+  const bool is_field = info_is_field (*in);
+  if (is_field && (cfg.src_x || cfg.src_y || cfg.src_width || cfg.src_height || cfg.dest_x || cfg.dest_y || cfg.dest_width || cfg.dest_height)) {
+    if (error)
+      *error = "interlaced frames with a source crop or a destination rectangle are not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
   const FormatDesc *fi = format_desc (in->format), *fo = format_desc (out->format);
   RectPlan rc;
   memset (&rc, 0, sizeof (rc));
@@ -3376,12 +3653,42 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     }
     rc.in_x *= 2;               /* inside the row: the crop simply starts twice as far right */
   }
+  if (is_field)
+    plan->ref_same_size = in->width == out->width && in->frame_height == out->frame_height;          /* (the lookup's same_size: the frames') */
   plan->rect = rc;
   plan->orig_in = *in;
   plan->orig_out = *out;
   const int r = plan_core (&ein, &eout, &cfg, plan, error);
   if (r != GSTAMD_OK || !fi || !fo)
     return r;
+  if (is_field) {
+    /* (the notes below are what the reference's PROGRESSIVE chain does with lines it hands out twice; the interlaced chain's own cases of that kind
+       have not been mapped: the one stage known to alias - a nearest vertical scaler, which hands its input line on - is refused in the chain) */
+    if (!plan->plane_mode && plan->ref_fastpath.empty ())
+      for (const ScalePass &sp : plan->passes)
+        if (!sp.horizontal && sp.kind == SCALE_NEAREST) {
+          if (error)
+            *error = "nearest vertical scaling of interlaced frames through the generic chain (lines handed out more than once, in place stages behind them) is not implemented on the GPU path";
+          return GSTAMD_ERR_UNSUPPORTED;
+        }
+    /* Observed with the reference (scripts/ilace_probe.py; oracle/_ref): the generic chain's vertical scaler of an interlaced frame asks the line cache
+       for 2 * taps lines and keeps as many behind it (chain_vscale :1651-1675: backlog = taps_i), more lines than the temporary-line rings below it hold
+       (setup_allocators :2115-2187).  Whenever a window reaches back to a line whose buffer has been handed out again the scaler reads ANOTHER line's
+       pixels - luma included: every enlargement (22 x 12 -> 22 x 20: the top field's rows come from source lines four further down), reductions whose
+       windows overlap (32 -> 24 lines with three taps: five rows), every 4:2:0 source (its upsampler's groups of four sit in the same rings).  The same
+       frame through the reference's plane scaler (same scaler object, same taps: Y444 -> Y444) has none of it.  Nothing to reproduce: the field plans
+       apply the interlaced scaler's taps to the lines the chain intends - tests/test_video_interlaced.py pins that against the reference run stage by
+       stage, the vertical pass through its plane scaler. */
+    if (!plan->plane_mode && plan->ref_fastpath.empty ())
+      for (const ScalePass &sp : plan->passes)
+        if (!sp.horizontal) {
+          plan->divergence += "interlaced frames through the generic chain's vertical scaler: the reference keeps 2 * taps lines of backlog over temporary-line rings "
+              "that are shorter (line aliasing: its windows read other lines' pixels, luma included; its own plane scaler with the same taps does not); "
+              "this library applies the interlaced scaler's taps to the lines the chain intends. ";
+          break;
+        }
+    return r;
+  }
   if (rc.fill && (fo->kind == UNPACK_PACKED422 || fo->kind == UNPACK_P422_16) && ((rc.out_x | eout.width | rc.out_maxw) & 1) &&
       (plan->plane_mode || !plan->ref_fastpath.empty ())) {
     /* (the generic chain packs frame lines pair by pair: border_picture_positions; rectangles on whole macropixels are filled by every path.
@@ -3654,6 +3961,23 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         "last half macropixel stays uninitialised in its temporary line and the horizontal pass reads it; this library takes that sample from the source row. ";
   }
   return r;
+}
+
+void plan_field_infos (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, int f, GstAmdVideoInfo *fin, GstAmdVideoInfo *fout)
+{
+  const GstAmdVideoInfo *src[2] = {in, out};
+  GstAmdVideoInfo *dst[2] = {fin, fout};
+  for (int k = 0; k < 2; k++) {
+    GstAmdVideoInfo &d = *dst[k];
+    d = *src[k];
+    d.interlace_mode = f ? GSTAMD_INTERLACE_FIELD_BOTTOM : GSTAMD_INTERLACE_FIELD_TOP;
+    d.frame_height = src[k]->height;
+    d.height = f ? src[k]->height - (src[k]->height + 1) / 2 : (src[k]->height + 1) / 2;
+    for (int i = 0; i < GSTAMD_VIDEO_MAX_PLANES; i++) {
+      d.offset[i] = src[k]->offset[i] + (uint64_t) (f ? src[k]->stride[i] : 0);
+      d.stride[i] = src[k]->stride[i] * 2;
+    }
+  }
 }
 
 bool plan_is_pad_scaler (const VideoPlan &p, int *h, int *v)

@@ -151,7 +151,9 @@ struct FrontParams {    // unpack + chroma upsample of the source frame (functio
   int u_plane, v_plane; // see FormatDesc
   int pos[4];
   int chroma_h;         // ChromaH
-  int chroma_v2;        // 1: vertical 2x upsample through the pair table
+  int chroma_v2;        // 1: vertical 2x upsample through the pair table (weights 3:1 / 1:3 by the entry's role); 2: one FIELD of an interlaced frame -
+                        // every line's two chroma rows come from the table, in rows of the FRAME's chroma planes (which the field conversion is
+                        // handed unsplit), with the weight of the first over 8 in the entry (vpair_get)
   int swap_k;           // chroma sample whose U and V trade places, -1: none.  unpack_VYUY (video-format.c:346-352) reads the last
                         // pixel of an odd-width line in UYVY order
   int hi_depth;         // FormatDesc::hi_depth: samples are 16-bit words widened to 16 significant bits (v << 6 | v >> 4, or v | v >> 10)
@@ -371,6 +373,13 @@ struct VideoPlan {
   std::vector<int32_t> vpair;     // [in_height][2]: (row_a | role << 30), row_b
   RectPlan rect;
   bool ref_same_size;         // video_converter_lookup_fastpath's same_size: FULL input size == destination rectangle (:8942)
+  // An interleaved frame (GstAmdVideoInfo::interlace_mode) is converted as two FIELD conversions (plan_field_infos): `interlaced` marks the frame's
+  // plan, whose own kernels never run - it carries the description, the divergence notes and the algorithmic bytes of the two; `field` (1 top, 2 bottom)
+  // marks a field's plan: a progressive plan over the field's lines (pitches doubled) whose fastpath lookup, chroma line pairing, vertical taps and pass
+  // order are the FRAME's (video-converter.c:3303-3312, 1651-1660, 7977; video-scaler.c:229-249; video-chroma.c:347).
+  bool interlaced = false;
+  int field = 0;
+  bool field_src_chroma_frame = false;   // a field plan whose SOURCE chroma planes are addressed as the frame's (rows from the pair table), not as the field's
   bool plane_mode;            // convert_scale_planes on a planar / semi-planar format: `planes` is the whole plan
   std::vector<PlanePlan> planes;
   bool out_planar;            // destination is planar / semi-planar: the chain renders AYUV, pack_planar finishes
@@ -503,6 +512,25 @@ GSTAMD_VP bool kind_has_planes (int kind) { return kind == UNPACK_PLANAR || kind
 GSTAMD_VP int vpair_row (int e0) { return (int) ((uint32_t) e0 << 2) >> 2; }
 GSTAMD_VP int vpair_role (int e0) { return (e0 >> 30) & 1; }
 GSTAMD_VP int vpair_pack (int row, int role) { return (int) (((uint32_t) row & 0x3fffffffu) | ((uint32_t) role << 30)); }
+// One line's vertical chroma blend: c = (wa * C[ra] + (8 - wa) * C[rb] + 4) >> 3 (ra == rb: a copy).  Progressive tables (mode 1): video_chroma_up_v2's
+// (3 a + b + 2) >> 2 and (a + 3 b + 2) >> 2 = weights 6 / 2 over 8.  Field tables (mode 2): the second entry carries the weight in bits 28 .. 30 over a
+// 28-bit signed row - video_chroma_up_vi2's FILT_5_3, _7_1, _1_7, _3_5 (video-chroma.c:347-384).
+struct VPairW { int ra, rb, wa; };
+GSTAMD_VP int vpair_pack_w8 (int row, int wa) { return (int) (((uint32_t) row & 0x0fffffffu) | ((uint32_t) wa << 28)); }
+GSTAMD_VP VPairW vpair_get (const int *vpair, int y, int mode)
+{
+  VPairW r;
+  const int e0 = vpair[2 * y], e1 = vpair[2 * y + 1];
+  r.ra = vpair_row (e0);
+  if (mode == 2) {
+    r.rb = (int) ((uint32_t) e1 << 4) >> 4;
+    r.wa = (e1 >> 28) & 7;
+  } else {
+    r.rb = e1;
+    r.wa = vpair_role (e0) ? 2 : 6;
+  }
+  return r;
+}
 
 // Returns GSTAMD_OK and fills `plan`, or an error code (GSTAMD_ERR_UNSUPPORTED for conversions the
 // reference would run through a path this library has no kernel for yet).
@@ -522,6 +550,12 @@ bool plan_is_pad_scaler (const VideoPlan &plan, int *h, int *v);
 int scaled_tile_rows_for (const VideoPlan &plan);
 
 int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int height);
+// The two infos of field `f` (0 top, 1 bottom) of an interleaved frame pair: lines f, f + 2, ... of every plane (offset + f * pitch, pitch * 2, the field's
+// height), marked GSTAMD_INTERLACE_FIELD_* with the frame's height beside it.  Plane pointers for a field conversion follow the same rule, except the
+// source chroma planes of a plan with field_src_chroma_frame, which stay the frame's.
+void plan_field_infos (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, int f, GstAmdVideoInfo *fin, GstAmdVideoInfo *fout);
+inline bool info_is_field (const GstAmdVideoInfo &i) { return i.interlace_mode == GSTAMD_INTERLACE_FIELD_TOP || i.interlace_mode == GSTAMD_INTERLACE_FIELD_BOTTOM; }
+inline bool info_is_interleaved (const GstAmdVideoInfo &i) { return i.interlace_mode == GSTAMD_INTERLACE_MODE_INTERLEAVED || i.interlace_mode == GSTAMD_INTERLACE_MODE_MIXED; }
 void converter_config_init (GstAmdVideoConverterConfig *config);
 
 // building blocks exposed for tests

@@ -135,20 +135,15 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
   }
   UV c;
   if (f.chroma_v2) {
-    const int e0 = vpair[2 * y], rb = vpair[2 * y + 1];
-    const int ra = vpair_row (e0), role = vpair_role (e0);
+    const VPairW t = vpair_get (vpair, y, f.chroma_v2);
+    const int ra = t.ra, rb = t.rb;
     const UV a = deep_chroma_h_at (f, pl, ra, x);
     if (ra == rb) {
       c = a;
     } else {
-      const UV b = deep_chroma_h_at (f, pl, rb, x);
-      if (role == 0) {
-        c.u = (3 * a.u + b.u + 2) >> 2;
-        c.v = (3 * a.v + b.v + 2) >> 2;
-      } else {
-        c.u = (a.u + 3 * b.u + 2) >> 2;
-        c.v = (a.v + 3 * b.v + 2) >> 2;
-      }
+      const UV b = deep_chroma_h_at (f, pl, rb, x);          // (3 a + b + 2) >> 2 = (6 a + 2 b + 4) >> 3: vpair_get
+      c.u = (t.wa * a.u + (8 - t.wa) * b.u + 4) >> 3;
+      c.v = (t.wa * a.v + (8 - t.wa) * b.v + 4) >> 3;
     }
   } else {
     c = deep_chroma_h_at (f, pl, y >> f.h_sub, x);
@@ -244,11 +239,10 @@ GSTAMD_HD void deep_front4 (const FrontParams &f, const Planes &pl, const int *_
   struct __attribute__ ((aligned (4))) L4 { uint16_t v[4]; };
   const L4 l = *(const L4 *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0] + 2 * (ptrdiff_t) x0);
   const int cw = (f.width + 1) >> 1, k0 = x0 >> 1;
-  int ra = y >> f.h_sub, rb = ra, role = 0;
+  int ra = y >> f.h_sub, rb = ra, wa = 6;
   if (f.chroma_v2) {
-    const int e0 = vpair[2 * y];
-    rb = vpair[2 * y + 1];
-    ra = vpair_row (e0), role = vpair_role (e0);
+    const VPairW t = vpair_get (vpair, y, f.chroma_v2);
+    ra = t.ra, rb = t.rb, wa = t.wa;
   }
   const Widen wd = deep_widen_params (f.hi_depth);
   const UV4 a = deep_load_uv4 (f, pl, wd, ra, k0, cw);
@@ -260,13 +254,8 @@ GSTAMD_HD void deep_front4 (const FrontParams &f, const Planes &pl, const int *_
     UV c = deep_chroma_h4 (f, a, x0, i);
     if (ra != rb) {
       const UV d = deep_chroma_h4 (f, b, x0, i);
-      if (role == 0) {
-        c.u = (3 * c.u + d.u + 2) >> 2;
-        c.v = (3 * c.v + d.v + 2) >> 2;
-      } else {
-        c.u = (c.u + 3 * d.u + 2) >> 2;
-        c.v = (c.v + 3 * d.v + 2) >> 2;
-      }
+      c.u = (wa * c.u + (8 - wa) * d.u + 4) >> 3;
+      c.v = (wa * c.v + (8 - wa) * d.v + 4) >> 3;
     }
     out[i].x = 0xffffu | ((uint32_t) deep_widen_w (wd, l.v[i]) << 16);
     out[i].y = (uint32_t) c.u | ((uint32_t) c.v << 16);
@@ -361,14 +350,12 @@ GSTAMD_HD void deep_front4_t (const FrontParams &f, const Planes &pl, const int 
   const L4 l = *(const L4 *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0] + 2 * (ptrdiff_t) x0);
   const Widen wd = deep_widen_params (f.hi_depth);
   const int w = f.width, cw = (w + 1) >> 1, k0 = x0 >> 1;
-  int ra = y >> f.h_sub, rb = ra, wa = 3;
+  int ra = y >> f.h_sub, rb = ra, wa = 6;          /* weights over 8: vpair_get */
   if (f.chroma_v2) {
-    const int e0 = vpair[2 * y];
-    rb = vpair[2 * y + 1];
-    ra = vpair_row (e0);
-    wa = vpair_role (e0) ? 1 : 3;
+    const VPairW t = vpair_get (vpair, y, f.chroma_v2);
+    ra = t.ra, rb = t.rb, wa = t.wa;
   }
-  const int wb = 4 - wa;
+  const int wb = 8 - wa;
   int u[2][4], v[2][4];
   /* the chroma positions k0 - 1 .. k0 + 2 (clamped into the row) of a chroma row with ONE load per plane where the row has four positions:
      position by position the kernel issued eight loads per line and lane and sat on the vector-memory issue rate (P010 4K -> BGRA 25 us).  The
@@ -446,7 +433,7 @@ GSTAMD_HD void deep_front4_t (const FrontParams &f, const Planes &pl, const int 
       }
       cu[r] = a, cv[r] = b;
     }
-    const int fu = (wa * cu[0] + wb * cu[1] + 2) >> 2, fv = (wa * cv[0] + wb * cv[1] + 2) >> 2;
+    const int fu = (wa * cu[0] + wb * cu[1] + 4) >> 3, fv = (wa * cv[0] + wb * cv[1] + 4) >> 3;
     out[i].x = 0xffffu | ((uint32_t) deep_widen_w (wd, l.v[i]) << 16);
     out[i].y = (uint32_t) fu | ((uint32_t) fv << 16);
   }
@@ -581,14 +568,12 @@ GSTAMD_HD FrontRow deep_front_row (const FrontParams &f, const int *__restrict__
   FrontRow r;
   r.wd = deep_widen_params (f.hi_depth);
   r.cw = (f.width + 1) >> 1;
-  r.ra = y >> f.h_sub, r.rb = r.ra, r.wa = 3;
+  r.ra = y >> f.h_sub, r.rb = r.ra, r.wa = 6;          /* weights over 8: vpair_get */
   if (f.chroma_v2) {
-    const int e0 = vpair[2 * y];
-    r.rb = vpair[2 * y + 1];
-    r.ra = vpair_row (e0);
-    r.wa = vpair_role (e0) ? 1 : 3;
+    const VPairW t = vpair_get (vpair, y, f.chroma_v2);
+    r.ra = t.ra, r.rb = t.rb, r.wa = t.wa;
   }
-  r.wb = 4 - r.wa;
+  r.wb = 8 - r.wa;
   return r;
 }
 
@@ -628,7 +613,7 @@ GSTAMD_HD uint2 deep_front1_t (const FrontParams &f, const Planes &pl, const Fro
     }
     cu[r] = a, cv[r] = b;
   }
-  const int fu = (fr.wa * cu[0] + fr.wb * cu[1] + 2) >> 2, fv = (fr.wa * cv[0] + fr.wb * cv[1] + 2) >> 2;
+  const int fu = (fr.wa * cu[0] + fr.wb * cu[1] + 4) >> 3, fv = (fr.wa * cv[0] + fr.wb * cv[1] + 4) >> 3;
   const int c1 = deep_widen_w (fr.wd, ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x]);
   uint2 px;
   px.x = 0xffffu | ((uint32_t) c1 << 16);

@@ -220,20 +220,16 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
       : pl.p[0][(size_t) yl * pl.stride[0] + x];
   UV c;
   if (f.chroma_v2) {
-    const int e0 = vpair[2 * y], rb = vpair[2 * y + 1];
-    const int ra = vpair_row (e0), role = vpair_role (e0);
+    const VPairW t = vpair_get (vpair, y, f.chroma_v2);
+    const int ra = t.ra, rb = t.rb;
     const UV a = chroma_h_at (f, pl, ra, x);
     if (ra == rb) {
       c = a;
     } else {
       const UV b = chroma_h_at (f, pl, rb, x);
-      if (role == 0) {                    // d1 = (3*s1 + s2 + 2) >> 2
-        c.u = (3 * a.u + b.u + 2) >> 2;
-        c.v = (3 * a.v + b.v + 2) >> 2;
-      } else {                            // d2 = (s1 + 3*s2 + 2) >> 2
-        c.u = (a.u + 3 * b.u + 2) >> 2;
-        c.v = (a.v + 3 * b.v + 2) >> 2;
-      }
+      // video_chroma_up_v2: d1 = (3*s1 + s2 + 2) >> 2, d2 = (s1 + 3*s2 + 2) >> 2 - weights 6 / 2 over 8; a field's table: video_chroma_up_vi2's (vpair_get)
+      c.u = (t.wa * a.u + (8 - t.wa) * b.u + 4) >> 3;
+      c.v = (t.wa * a.v + (8 - t.wa) * b.v + 4) >> 3;
     }
   } else {
     c = chroma_h_at (f, pl, y >> f.h_sub, x);
@@ -451,12 +447,10 @@ GSTAMD_HD void front_span8 (const FrontParams &f, const Planes &pl, const int *_
   const int w = f.width;
   const uint2 yy = *(const uint2 *) (pl.p[0] + (size_t) (y < f.luma_last ? y : f.luma_last) * pl.stride[0] + x0);
   const int cw = (w + 1) >> 1, k0 = x0 >> 1;
-  int ra, rb, role = 0;
+  int ra, rb, wa = 6;
   if (f.chroma_v2) {
-    const int e0 = vpair[2 * y];
-    ra = vpair_row (e0);
-    role = vpair_role (e0);
-    rb = vpair[2 * y + 1];
+    const VPairW t = vpair_get (vpair, y, f.chroma_v2);
+    ra = t.ra, rb = t.rb, wa = t.wa;
   } else {
     ra = rb = y >> f.h_sub;
   }
@@ -471,11 +465,11 @@ GSTAMD_HD void front_span8 (const FrontParams &f, const Planes &pl, const int *_
     int u2[8], v2[8];
     load_chroma6 (f, pl, rb, k0, cw, c);
     hfilter8<CH> (c, x0, w, u2, v2);
-    const int wa = role == 0 ? 3 : 1, wb = 4 - wa;
+    const int wb = 8 - wa;          // over 8: vpair_get
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      u[i] = (wa * u[i] + wb * u2[i] + 2) >> 2;
-      v[i] = (wa * v[i] + wb * v2[i] + 2) >> 2;
+      u[i] = (wa * u[i] + wb * u2[i] + 4) >> 3;
+      v[i] = (wa * v[i] + wb * v2[i] + 4) >> 3;
     }
   }
   const uint32_t yw[2] = {yy.x, yy.y};

@@ -1725,7 +1725,7 @@ static int dot4_source_ok (const SrcFront &s)
 static int h420_source_ok (const SrcFront &s)
 {
   const FrontParams &f = s.f;
-  if (!kind_has_planes (f.kind) || f.w_sub != 1 || (f.width % 16) != 0)
+  if (!kind_has_planes (f.kind) || f.w_sub != 1 || (f.width % 16) != 0 || f.chroma_v2 == 2)          /* (a field's pair table: the per-pixel front) */
     return 0;
   int ok = aligned (s.pl.p[0], 16) && (s.pl.stride[0] % 16) == 0;
   if (f.kind == UNPACK_SEMI)

@@ -85,12 +85,10 @@ GSTAMD_HD void front_chroma8_packed (const FrontParams &f, const Planes &pl, con
   const int w = f.width;
   yy = *(const uint2 *) (pl.p[0] + (size_t) y * pl.stride[0] + x0);
   const int cw = (w + 1) >> 1, k0 = x0 >> 1;
-  int ra, rb, role = 0;
+  int ra, rb, wa = 6;
   if (f.chroma_v2) {
-    const int e0 = vpair[2 * y];
-    ra = vpair_row (e0);
-    role = vpair_role (e0);
-    rb = vpair[2 * y + 1];
+    const VPairW t = vpair_get (vpair, y, f.chroma_v2);
+    ra = t.ra, rb = t.rb, wa = t.wa;
   } else {
     ra = rb = y >> f.h_sub;
   }
@@ -104,15 +102,11 @@ GSTAMD_HD void front_chroma8_packed (const FrontParams &f, const Planes &pl, con
     uint32_t cb[8];
     load_chroma6_packed (f, pl, rb, k0, cw, c);
     hfilter8_packed<CH> (c, x0, w, cb);
-    if (role == 0) {
+    /* weights over 8 (vpair_get): (3 a + b + 2) >> 2 = (6 a + 2 b + 4) >> 3; 8 * 255 + 4 stays inside the 16-bit halves */
+    const uint32_t ua = (uint32_t) wa, ub = (uint32_t) (8 - wa);
 #pragma unroll
-      for (int i = 0; i < 8; i++)
-        ca[i] = pk_shr<2> (3u * ca[i] + cb[i] + 0x00020002u);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; i++)
-        ca[i] = pk_shr<2> (ca[i] + 3u * cb[i] + 0x00020002u);
-    }
+    for (int i = 0; i < 8; i++)
+      ca[i] = pk_shr<3> (ua * ca[i] + ub * cb[i] + 0x00040004u);
   }
 }
 

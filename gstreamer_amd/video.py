@@ -57,7 +57,8 @@ class VideoInfo(C.Structure):
     _fields_ = [("format", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("n_planes", C.c_int32),
                 ("stride", C.c_int32 * 4), ("offset", C.c_uint64 * 4), ("size", C.c_uint64),
                 ("color_range", C.c_int32), ("color_matrix", C.c_int32), ("chroma_site", C.c_int32),
-                ("color_transfer", C.c_int32), ("color_primaries", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("color_transfer", C.c_int32), ("color_primaries", C.c_int32), ("interlace_mode", C.c_int32), ("frame_height", C.c_int32),
+                ("reserved", C.c_int32 * 1)]
 
 
 class ConverterConfig(C.Structure):

@@ -212,8 +212,25 @@ typedef struct GstAmdVideoInfo {
   int32_t chroma_site;                          /* GstVideoChromaSite flags */
   int32_t color_transfer;                       /* GstVideoTransferFunction (video-color.h:132-148); read with gamma-mode = remap */
   int32_t color_primaries;                      /* GstVideoColorPrimaries (video-color.h:197-209); read with primaries-mode != none */
-  int32_t reserved[3];
+  int32_t interlace_mode;                       /* GSTAMD_INTERLACE_MODE_* (GstVideoInterlaceMode, video-info.h:38-58); 0 = progressive.  Both infos of a
+                                                 * converter carry the same mode (gst_video_converter_new, video-converter.c:2435).  With _INTERLEAVED every
+                                                 * frame is converted as two fields (GST_VIDEO_FRAME_IS_INTERLACED: field-aware 4:2:0 lines, chroma
+                                                 * resampling and vertical scaling, video-converter.c:3303, 3383, 1651, 7977) */
+  int32_t frame_height;                         /* 0 for callers (the library's own field conversions: height of the frame a field belongs to) */
+  int32_t reserved[1];
 } GstAmdVideoInfo;
+
+/* GstVideoInterlaceMode.  _MIXED streams flag each buffer (GST_VIDEO_BUFFER_FLAG_INTERLACED): the caller converts flagged frames with a converter
+ * made for _INTERLEAVED infos and the others with one made for progressive infos (what gst_video_frame_map + video_converter_generic :3303 do per
+ * frame); _FIELDS and _ALTERNATE are refused (GSTAMD_ERR_UNSUPPORTED). */
+#define GSTAMD_INTERLACE_MODE_PROGRESSIVE 0
+#define GSTAMD_INTERLACE_MODE_INTERLEAVED 1
+#define GSTAMD_INTERLACE_MODE_MIXED 2
+#define GSTAMD_INTERLACE_MODE_FIELDS 3
+#define GSTAMD_INTERLACE_MODE_ALTERNATE 4
+/* (internal: the two field conversions an interleaved frame is split into) */
+#define GSTAMD_INTERLACE_FIELD_TOP 16
+#define GSTAMD_INTERLACE_FIELD_BOTTOM 17
 
 /* Mirror of the GstVideoConverter option keys (video-converter.h:34-286) that this
  * implementation honours; gstamd_video_converter_config_init() sets the library defaults of

@@ -151,10 +151,15 @@ class VideoConverter:
     """gst_video_converter_new/frame of the reference on host numpy buffers."""
 
     def __init__(self, in_fmt, in_w, in_h, out_fmt, out_w, out_h, in_colorimetry=None, in_chroma_site=None,
-                 out_colorimetry=None, out_chroma_site=None, config=None):
-        self.h = lib().ref_video_converter_new(_b(in_fmt), in_w, in_h, _b(in_colorimetry), _b(in_chroma_site), None, None,
-                                               _b(out_fmt), out_w, out_h, _b(out_colorimetry), _b(out_chroma_site), None,
-                                               None, _b(config))
+                 out_colorimetry=None, out_chroma_site=None, config=None, interlaced=False):
+        """interlaced: both infos carry interlace-mode=interleaved, every frame is mapped with GST_VIDEO_FRAME_FLAG_INTERLACED"""
+        L = lib()
+        L.ref_video_converter_new_interlaced.restype = C.c_void_p
+        L.ref_video_converter_new_interlaced.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p,
+                                                         C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        self.h = L.ref_video_converter_new_interlaced(_b(in_fmt), in_w, in_h, _b(in_colorimetry), _b(in_chroma_site), None, None,
+                                                      _b(out_fmt), out_w, out_h, _b(out_colorimetry), _b(out_chroma_site), None,
+                                                      None, _b(config), 1 if interlaced else 0)
         if not self.h:
             raise ValueError("reference could not create converter")
         self.in_info = video_info(in_fmt, in_w, in_h)

@@ -171,12 +171,32 @@ typedef struct
 
 /* config: serialized GstStructure ("GstVideoConverter, GstVideoConverter.threads=(uint)1, ...")
  * or NULL for the library defaults (video-converter.c:778-796). */
+void *ref_video_converter_new_interlaced (const char *in_format, int in_w, int in_h, const char *in_colorimetry,
+    const char *in_chroma_site, const int *in_stride, const gsize * in_offset,
+    const char *out_format, int out_w, int out_h, const char *out_colorimetry,
+    const char *out_chroma_site, const int *out_stride, const gsize * out_offset,
+    const char *config, int interlace_mode);
+
 void *
 ref_video_converter_new (const char *in_format, int in_w, int in_h, const char *in_colorimetry,
     const char *in_chroma_site, const int *in_stride, const gsize * in_offset,
     const char *out_format, int out_w, int out_h, const char *out_colorimetry,
     const char *out_chroma_site, const int *out_stride, const gsize * out_offset,
     const char *config)
+{
+  return ref_video_converter_new_interlaced (in_format, in_w, in_h, in_colorimetry, in_chroma_site, in_stride, in_offset,
+      out_format, out_w, out_h, out_colorimetry, out_chroma_site, out_stride, out_offset, config, 0);
+}
+
+/* interlace_mode: GstVideoInterlaceMode of BOTH infos (gst_video_converter_new insists on equal modes, video-converter.c:2435); with
+ * 1 = interleaved gst_video_frame_map marks every frame GST_VIDEO_FRAME_FLAG_INTERLACED (video-frame.c), which is what the converter's
+ * field-aware paths look at (video_converter_generic :3303, GET_LINE_OFFSETS :3383, setup_scale :7977) */
+void *
+ref_video_converter_new_interlaced (const char *in_format, int in_w, int in_h, const char *in_colorimetry,
+    const char *in_chroma_site, const int *in_stride, const gsize * in_offset,
+    const char *out_format, int out_w, int out_h, const char *out_colorimetry,
+    const char *out_chroma_site, const int *out_stride, const gsize * out_offset,
+    const char *config, int interlace_mode)
 {
   RefConverter *rc;
   GstStructure *s = NULL;
@@ -196,6 +216,8 @@ ref_video_converter_new (const char *in_format, int in_w, int in_h, const char *
       return NULL;
     }
   }
+  GST_VIDEO_INFO_INTERLACE_MODE (&rc->in_info) = (GstVideoInterlaceMode) interlace_mode;
+  GST_VIDEO_INFO_INTERLACE_MODE (&rc->out_info) = (GstVideoInterlaceMode) interlace_mode;
   rc->conv = gst_video_converter_new (&rc->in_info, &rc->out_info, s);
   if (!rc->conv) {
     g_free (rc);

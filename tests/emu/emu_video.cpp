@@ -129,7 +129,7 @@ static bool emu_h420_ok (const SrcFront &s)
 {
   const FrontParams &f = s.f;
   auto al = [](const void *p, int a) { return ((uintptr_t) p % a) == 0; };
-  if (!kind_has_planes (f.kind) || f.w_sub != 1 || (f.width % 16) != 0 || emu_h420_rows () <= 0)
+  if (!kind_has_planes (f.kind) || f.w_sub != 1 || (f.width % 16) != 0 || f.chroma_v2 == 2 || emu_h420_rows () <= 0)
     return false;
   bool ok = al (s.pl.p[0], 16) && (s.pl.stride[0] % 16) == 0;
   if (f.kind == UNPACK_SEMI)
@@ -405,7 +405,7 @@ static int emu_hscale420_reg (const VideoPlan &p, const SrcFront &sf, const Scal
     return false;
   const TileGeom g = p.passes[0].horizontal ? pass_tile_geom (p.passes[0]) : TileGeom {0, 0, 0};
   if (!(p.passes.size () == 2 && p.passes[0].horizontal && p.passes[0].kind == SCALE_NTAP && p.passes[0].dot4_ok && g.tile16_w > 0 &&
-      p.front.chroma_v2 && kind_has_planes (p.front.kind) && p.front.w_sub == 1 && p.front.h_sub == 1 && !p.matrix_before_scale &&
+      p.front.chroma_v2 == 1 && kind_has_planes (p.front.kind) && p.front.w_sub == 1 && p.front.h_sub == 1 && !p.matrix_before_scale &&
       (int) p.vpair.size () >= 2 * p.front.height))
     return false;
   const int lo = -(p.rect.in_y >> 1), hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
@@ -884,6 +884,30 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
   g_emu_divergence += p.divergence;
   if (desc)
     strncpy (desc, p.description.c_str (), desc_len - 1);
+  if (p.interlaced) {
+    /* frame_planes_plan_order of capi_video.cpp: the two field conversions, field f over lines f, f + 2, ... of every plane - the source chroma planes of
+       a plan whose pair table names rows of the frame's chroma planes stay the frame's */
+    const std::string keep = g_emu_divergence;
+    for (int f = 0; f < 2; f++) {
+      GstAmdVideoInfo fin, fout;
+      plan_field_infos (in, out, f, &fin, &fout);
+      VideoPlan fp;
+      if ((r = plan_video_converter (&fin, &fout, cfg, &fp, &err)) != GSTAMD_OK)
+        return r;
+      if (fp.field_src_chroma_frame) {
+        int perm[4];
+        format_plane_perm (in->format, perm);
+        const int alpha_plane = GSTAMD_KIND_ALPHA_PLANE (fp.fin->kind);
+        for (int i = 1; i < in->n_planes; i++)
+          if (i != alpha_plane)
+            fin.offset[i] = in->offset[i], fin.stride[i] = in->stride[i];
+      }
+      if ((r = emu_video_convert (&fin, &fout, cfg, src, dst, vec_ok, nullptr, 0)) != GSTAMD_OK)
+        return r;
+    }
+    g_emu_divergence = keep;
+    return GSTAMD_OK;
+  }
   /* plane pointers come from the plan's view of the two frames (GBR: planes R, G, B - format_plan_planes), as in capi_video.cpp */
   GstAmdVideoInfo in_planes = *in, out_planes = *out;
   format_plan_planes (p.fin, &in_planes);
@@ -1859,7 +1883,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     const bool bil_planar_ok = bil_planar && ((uintptr_t) pl.p[0] % 16) == 0 && pl.stride[0] % 16 == 0 && ((uintptr_t) pl.p[1] % 8) == 0 &&
         ((uintptr_t) pl.p[2] % 8) == 0 && pl.stride[1] % 8 == 0 && pl.stride[2] % 8 == 0 && (p.front.width % 16) == 0;
     if (h_first && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && (p.front.kind == UNPACK_SEMI || bil_planar_ok) && p.front.w_sub == 1 &&
-        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && bil_tw > 0 && bil_yl > 0 && vec_ok != 300) {
+        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && p.front.chroma_v2 != 2 && bil_tw > 0 && bil_yl > 0 && vec_ok != 300) {
       /* k_bilinear420 (video_bilinear_fast.h); vec_ok == 300 selects the generic tile kernel below instead */
       BilParams bp;
       bp.fp = pf.fp;

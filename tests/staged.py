@@ -341,3 +341,45 @@ def masked_check(ref, case, src, got, divergence):
     mask &= picture_bytes(ref, ofmt, OW, OH, got.size)
     bad = int((got[mask] != one[mask]).sum())
     return True, bad == 0, "" if bad == 0 else ": %d of %d bytes the reference's undefined part cannot reach differ from the one-step reference" % (bad, int(mask.sum()))
+
+
+# ---- interlaced frames --------------------------------------------------------------------------------------------------------------------------------
+# The reference's generic chain is not a usable reference for a VERTICAL scaler pass on interlaced frames (planner.cpp, plan_video_converter: its line
+# cache keeps 2 * taps lines of backlog over shorter temporary-line rings - the windows read other lines' pixels).  Its plane scaler is: the same
+# gst_video_scaler_new (..., GST_VIDEO_SCALER_FLAG_INTERLACED, ...) object, the same 8-bit taps, applied by gst_video_scaler_2d straight from the frame
+# (convert_scale_planes on a 4-byte format scales whole pixels as 4 x u8: setup_scale :8016-8087).  So the split above with every stage run on
+# interlace-mode=interleaved infos and every scaler pass run as <4-byte unpack format> -> <same format> through that fastpath.
+PLANE_SCALED = {"VUYA": "AYUV", "ABGR": "ABGR"}          # 4-byte formats convert_scale_planes serves onto themselves (video-converter.c:8547-8904); VUYA is none
+
+
+def staged_expected_interlaced(ref, case, src):
+    """-> expected frame of an 8-bit interlaced conversion, or None (formats / options the split cannot express)"""
+    ifmt, w, h, ofmt, OW, OH, cfg, col, site = case
+    pi, po = ref.format_props(ifmt), ref.format_props(ofmt)
+    if pi["bits"] != 8 or po["bits"] != 8 or pi["gray"] or po["gray"] or cfg.get("gamma_mode") == "remap" or any(k in cfg for k in ("src_x", "dest_x")):
+        return None
+    if "VYUY" in (ifmt, ofmt):
+        return None
+    if (w, h) == (OW, OH) and pi["h_sub"] and ofmt in ("ARGB", "AYUV"):
+        return None          # the chain works in the destination's own rows there: the edge groups of video_chroma_up_vi2 stay unfiltered (planner.cpp simulate_vpairs_field), which no split shows
+    steps, _c = _steps(ref, case)
+    cur = src
+    for (sf, sw, sh, scol, ssite, df, dw, dh, dcol, dsite, scfg) in steps:
+        if (sf, sw, sh, scol) == (df, dw, dh, dcol) and scfg == NO_FAST:
+            continue
+        if sf == df and (sw, sh) != (dw, dh):
+            # a scaler pass: through the plane scaler, in a format it serves (a byte swizzle either side where needed; those are per-pixel and exact)
+            pf = PLANE_SCALED[sf]
+            scaler = {k: v for k, v in scfg.items() if k not in NO_FAST}
+            if "resampler_taps" in cfg:
+                scaler["resampler_taps"] = cfg["resampler_taps"]
+            if pf != sf:
+                cur = ref.VideoConverter(sf, sw, sh, pf, sw, sh, in_colorimetry=scol, out_colorimetry=scol, config=cases.ref_config_string(ref, NO_FAST), interlaced=True).frame(cur)
+            cur = ref.VideoConverter(pf, sw, sh, pf, dw, dh, in_colorimetry=scol, out_colorimetry=scol, config=cases.ref_config_string(ref, dict(scaler, threads=1)),
+                                     interlaced=True).frame(cur)
+            if pf != sf:
+                cur = ref.VideoConverter(pf, dw, dh, sf, dw, dh, in_colorimetry=scol, out_colorimetry=scol, config=cases.ref_config_string(ref, NO_FAST), interlaced=True).frame(cur)
+            continue
+        cur = ref.VideoConverter(sf, sw, sh, df, dw, dh, in_colorimetry=scol, in_chroma_site=ssite, out_colorimetry=dcol, out_chroma_site=dsite,
+                                 config=cases.ref_config_string(ref, scfg), interlaced=True).frame(cur)
+    return cur

@@ -386,10 +386,12 @@ GstAmdVideoConverter *gstamd_video_converter_new (const GstAmdVideoInfo *in_info
   std::string err;
   int r = plan_video_converter (in_info, out_info, config, &c->plan, &err);
   if (r == GSTAMD_OK && c->plan.interlaced) {
+    GstAmdVideoConverterConfig fcfg;
+    (void) plan_field_config (in_info, out_info, config, &fcfg);          /* (true: the frame's plan exists) */
     for (int f = 0; f < 2 && r == GSTAMD_OK; f++) {
       GstAmdVideoInfo fin, fout;
       plan_field_infos (in_info, out_info, f, &fin, &fout);
-      c->field[f] = gstamd_video_converter_new (&fin, &fout, config, &r);
+      c->field[f] = gstamd_video_converter_new (&fin, &fout, &fcfg, &r);
     }
     if (r != GSTAMD_OK) {
       gstamd_video_converter_free (c->field[0]);
@@ -2172,9 +2174,12 @@ int gstamd_video_converter_set_config (GstAmdVideoConverter *c, const GstAmdVide
   if (c->plan.interlaced) {
     /* both field conversions take the new options, or neither does (the first one's failure leaves everything as it was; the second cannot fail where
        the first did not - the two plans differ in their field's tables only) */
-    int fr = gstamd_video_converter_set_config (c->field[0], config);
+    GstAmdVideoConverterConfig fcfg;
+    if (!plan_field_config (&c->plan.orig_in, &c->plan.orig_out, config, &fcfg))
+      return set_error (GSTAMD_ERR_UNSUPPORTED, "interlaced frames with a source crop or a destination rectangle are not implemented on the GPU path");
+    int fr = gstamd_video_converter_set_config (c->field[0], &fcfg);
     if (fr == GSTAMD_OK)
-      fr = gstamd_video_converter_set_config (c->field[1], config);
+      fr = gstamd_video_converter_set_config (c->field[1], &fcfg);
     if (fr == GSTAMD_OK) {
       VideoPlan top;
       std::string terr;

@@ -3517,10 +3517,16 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   }
   if (info_is_interleaved (*in)) {
     VideoPlan fp[2];
+    GstAmdVideoConverterConfig fcfg;
+    if (!plan_field_config (in, out, &cfg, &fcfg)) {
+      if (error)
+        *error = "interlaced frames with a source crop or a destination rectangle are not implemented on the GPU path";
+      return GSTAMD_ERR_UNSUPPORTED;
+    }
     for (int f = 0; f < 2; f++) {
       GstAmdVideoInfo fin, fout;
       plan_field_infos (in, out, f, &fin, &fout);
-      const int r = plan_video_converter (&fin, &fout, &cfg, &fp[f], error);
+      const int r = plan_video_converter (&fin, &fout, &fcfg, &fp[f], error);
       if (r != GSTAMD_OK)
         return r;
     }
@@ -3966,6 +3972,22 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         "last half macropixel stays uninitialised in its temporary line and the horizontal pass reads it; this library takes that sample from the source row. ";
   }
   return r;
+}
+
+bool plan_field_config (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, const GstAmdVideoConverterConfig *cfg, GstAmdVideoConverterConfig *fcfg)
+{
+  if (cfg)
+    *fcfg = *cfg;
+  else
+    converter_config_init (fcfg);
+  const GstAmdVideoConverterConfig &c = *fcfg;
+  const bool whole_src = c.src_x == 0 && c.src_y == 0 && (c.src_width == 0 || c.src_width >= in->width) && (c.src_height == 0 || c.src_height >= in->height);
+  const bool whole_dst = c.dest_x == 0 && c.dest_y == 0 && (c.dest_width == 0 || c.dest_width >= out->width) && (c.dest_height == 0 || c.dest_height >= out->height);
+  if (!whole_src || !whole_dst)
+    return false;
+  fcfg->src_x = fcfg->src_y = fcfg->src_width = fcfg->src_height = 0;
+  fcfg->dest_x = fcfg->dest_y = fcfg->dest_width = fcfg->dest_height = 0;
+  return true;
 }
 
 void plan_field_infos (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, int f, GstAmdVideoInfo *fin, GstAmdVideoInfo *fout)

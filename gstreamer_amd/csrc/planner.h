@@ -554,6 +554,9 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
 // height), marked GSTAMD_INTERLACE_FIELD_* with the frame's height beside it.  Plane pointers for a field conversion follow the same rule, except the
 // source chroma planes of a plan with field_src_chroma_frame, which stay the frame's.
 void plan_field_infos (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, int f, GstAmdVideoInfo *fin, GstAmdVideoInfo *fout);
+// The options of the field conversions of an interleaved frame: the frame's, with rectangle options that name the whole frames (what the elements
+// always pass: dest-x 0, dest-width = the frame's ...) dropped.  false: an actual source crop or destination rectangle (not built for interlaced frames).
+bool plan_field_config (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, const GstAmdVideoConverterConfig *cfg, GstAmdVideoConverterConfig *fcfg);
 inline bool info_is_field (const GstAmdVideoInfo &i) { return i.interlace_mode == GSTAMD_INTERLACE_FIELD_TOP || i.interlace_mode == GSTAMD_INTERLACE_FIELD_BOTTOM; }
 inline bool info_is_interleaved (const GstAmdVideoInfo &i) { return i.interlace_mode == GSTAMD_INTERLACE_MODE_INTERLEAVED || i.interlace_mode == GSTAMD_INTERLACE_MODE_MIXED; }
 void converter_config_init (GstAmdVideoConverterConfig *config);

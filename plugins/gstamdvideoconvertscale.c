@@ -16,7 +16,8 @@
  * (GSTAMD_ERR_UNSUPPORTED) make set_caps fail -> not-negotiated, like the reference's "no_convert" :1111-1120.
  *
  * fixate_caps follows the reference's format scoring and display-aspect-ratio rules (:1098-1975, restated below).  Not
- * implemented: interlaced content (such caps are refused) and overlay composition metas.
+ * implemented: interlace-mode fields / alternate (such caps are refused; interleaved and mixed content is converted field-aware, see AMD_INTERLACE_MODES)
+ * and overlay composition metas.
  */
 #include <gst/base/gstbasetransform.h>
 #include <gst/gst.h>
@@ -54,10 +55,14 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #endif
 #define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y41B, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210, v216, r210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
 
-/* progressive content only: the converter has no field-aware chroma resampling / GST_VIDEO_SCALER_FLAG_INTERLACED path
- * (video-converter.c:3304, 3383-3463), so interlaced caps are not negotiated rather than converted as if progressive
- * (caps without the field are progressive by definition) */
-#define AMD_PROGRESSIVE ", interlace-mode=(string)progressive"
+/* progressive, interleaved and mixed content (caps without the field are progressive by definition).  An interleaved frame - every frame of
+ * interlace-mode=interleaved, the buffers flagged GST_VIDEO_BUFFER_FLAG_INTERLACED of interlace-mode=mixed, which is what gst_video_frame_map makes
+ * of the two modes - goes through a converter made for interlaced infos: field-aware 4:2:0 rows, video_chroma_up_vi2, the interlaced scaler
+ * (video-converter.c:3303-3312, 3383, 1651; gstamd_video.h GstAmdVideoInfo::interlace_mode).  fields / alternate are not negotiated. */
+/* (the templates carry no interlace-mode field, like the reference's (gstvideoconvertscale.c:100-118): a list there would leave the caps of an upstream
+ * capsfilter without the field unfixed.  interlace-mode=alternate needs the caps feature format:Interlaced, which the templates do not offer; fields is
+ * refused by set_caps) */
+#define AMD_PROGRESSIVE ""
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_AMD_HIP, AMD_IN_FORMATS) AMD_PROGRESSIVE ";"
         GST_VIDEO_CAPS_MAKE (AMD_IN_FORMATS) AMD_PROGRESSIVE));
@@ -109,6 +114,7 @@ typedef struct {
   GstVideoInfo in_info, out_info;
   gboolean in_hip, out_hip;
   GstAmdVideoConverter *convert;
+  GstAmdVideoConverter *convert_i;     /* interlace-mode=mixed: the converter of the buffers flagged GST_VIDEO_BUFFER_FLAG_INTERLACED (`convert` takes the others) */
   GstBufferPool *out_pool;     /* HBM output frames are recycled through a GstAmdHipBufferPool */
   /* one ring of HIP streams per element instance (SURVEY 8b Threading): frame k runs on stream k % n_streams, so the launch
    * ramp of one frame overlaps the tail of the previous one and two elements of a process never serialise on the NULL stream;
@@ -915,8 +921,11 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
 
   if (!gst_video_info_from_caps (&s->in_info, incaps) || !gst_video_info_from_caps (&s->out_info, outcaps))
     return FALSE;
-  if (GST_VIDEO_INFO_IS_INTERLACED (&s->in_info) || GST_VIDEO_INFO_INTERLACE_MODE (&s->in_info) != GST_VIDEO_INFO_INTERLACE_MODE (&s->out_info)) {
-    GST_ERROR_OBJECT (s, "interlaced content is not supported by the HIP converter");
+  if (GST_VIDEO_INFO_INTERLACE_MODE (&s->in_info) != GST_VIDEO_INFO_INTERLACE_MODE (&s->out_info) ||
+      (GST_VIDEO_INFO_IS_INTERLACED (&s->in_info) && GST_VIDEO_INFO_INTERLACE_MODE (&s->in_info) != GST_VIDEO_INTERLACE_MODE_INTERLEAVED &&
+          GST_VIDEO_INFO_INTERLACE_MODE (&s->in_info) != GST_VIDEO_INTERLACE_MODE_MIXED)) {
+    GST_ERROR_OBJECT (s, "interlace-mode %s is not supported by the HIP converter (the modes of both sides must be equal, as gst_video_converter_new wants them)",
+        gst_video_interlace_mode_to_string (GST_VIDEO_INFO_INTERLACE_MODE (&s->in_info)));
     return FALSE;
   }
   gst_amd_hip_select_device (s->device_id);
@@ -998,10 +1007,27 @@ amd_vcs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   amd_vcs_batch_set_converter (s);      /* launches what is pending and detaches the old converter */
   if (s->convert)
     gstamd_video_converter_free (s->convert);
+  if (s->convert_i)
+    gstamd_video_converter_free (s->convert_i);
+  s->convert_i = NULL;
+  /* interleaved: every frame is an interlaced one; mixed: the flagged buffers are (a second converter), the others are progressive frames */
+  ai.interlace_mode = ao.interlace_mode = GST_VIDEO_INFO_INTERLACE_MODE (&s->in_info) == GST_VIDEO_INTERLACE_MODE_INTERLEAVED ?
+      GSTAMD_INTERLACE_MODE_INTERLEAVED : GSTAMD_INTERLACE_MODE_PROGRESSIVE;
   s->convert = gstamd_video_converter_new (&ai, &ao, &cfg, &status);
   if (!s->convert) {
     GST_ERROR_OBJECT (s, "no HIP conversion for these caps: %s", gstamd_last_error ());
     return FALSE;
+  }
+  if (GST_VIDEO_INFO_INTERLACE_MODE (&s->in_info) == GST_VIDEO_INTERLACE_MODE_MIXED) {
+    ai.interlace_mode = ao.interlace_mode = GSTAMD_INTERLACE_MODE_INTERLEAVED;
+    s->convert_i = gstamd_video_converter_new (&ai, &ao, &cfg, &status);
+    if (!s->convert_i) {
+      GST_ERROR_OBJECT (s, "no HIP conversion for the interlaced frames of these caps: %s", gstamd_last_error ());
+      gstamd_video_converter_free (s->convert);
+      s->convert = NULL;
+      return FALSE;
+    }
+    GST_CAT_DEBUG_OBJECT (CAT_PERFORMANCE, s, "HIP plan of the flagged frames: %s", gstamd_video_converter_describe (s->convert_i));
   }
   GST_CAT_DEBUG_OBJECT (CAT_PERFORMANCE, s, "HIP plan: %s", gstamd_video_converter_describe (s->convert));
   {
@@ -1488,6 +1514,7 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
   guint8 *src, *dst;
   guint k;
   int r;
+  GstAmdVideoConverter *conv;
 
   gint64 ta = 0, tb = 0, tc = 0, td = 0;
   if (!s->convert || !s->n_streams)
@@ -1496,8 +1523,10 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
     ta = g_get_monotonic_time ();
   gst_amd_hip_select_device (s->device_id);       /* the streaming thread's current device */
   gst_amd_hip_pending_reads_retire (s->reads);
+  /* interlace-mode=mixed: gst_video_frame_map marks the frames of buffers with GST_VIDEO_BUFFER_FLAG_INTERLACED (video-frame.c) */
+  conv = s->convert_i && GST_BUFFER_FLAG_IS_SET (inbuf, GST_VIDEO_BUFFER_FLAG_INTERLACED) ? s->convert_i : s->convert;
   if (s->batch && s->batch_limit > 1) {
-    if (in_dev && out_dev && buffer_is_plain_hip_frame (inbuf, &s->in_info) && buffer_is_plain_hip_frame (outbuf, &s->out_info)) {
+    if (conv == s->convert && in_dev && out_dev && buffer_is_plain_hip_frame (inbuf, &s->in_info) && buffer_is_plain_hip_frame (outbuf, &s->out_info)) {
       if (amd_vcs_batch_add (s, inbuf, outbuf)) {
         if (s->stats) {
           s->t_total += g_get_monotonic_time () - ta;
@@ -1548,12 +1577,12 @@ amd_vcs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outb
     dst = s->d_out[k];
   }
 
-  GST_CAT_DEBUG_OBJECT (CAT_PERFORMANCE, s, "HIP convert %s on stream %u", gstamd_video_converter_describe (s->convert), k);
+  GST_CAT_DEBUG_OBJECT (CAT_PERFORMANCE, s, "HIP convert %s on stream %u", gstamd_video_converter_describe (conv), k);
   frame_planes (inbuf, &s->in_info, src, sp, ss);
   frame_planes (outbuf, &s->out_info, dst, dp, ds);
   if (s->stats)
     tb = g_get_monotonic_time ();
-  r = gstamd_video_converter_frame_planes (s->convert, (const void *const *) sp, ss, dp, ds, stream);
+  r = gstamd_video_converter_frame_planes (conv, (const void *const *) sp, ss, dp, ds, stream);
   if (s->stats)
     tc = g_get_monotonic_time ();
   if (r == GSTAMD_OK && (out_dev || in_dev)) {
@@ -1655,7 +1684,8 @@ amd_vcs_chain_list (GstPad * pad, GstObject * parent, GstBufferList * list)
         !gst_pad_needs_reconfigure (GST_BASE_TRANSFORM_SRC_PAD (trans));
     guint cnt = MIN (n - i, AMD_LIST_CHUNK), k;
     for (k = 0; batch && k < cnt; k++)
-      batch = buffer_is_plain_hip_frame (gst_buffer_list_get (list, i + k), &s->in_info);
+      batch = buffer_is_plain_hip_frame (gst_buffer_list_get (list, i + k), &s->in_info) &&
+          !(s->convert_i && GST_BUFFER_FLAG_IS_SET (gst_buffer_list_get (list, i + k), GST_VIDEO_BUFFER_FLAG_INTERLACED));
     if (!batch) {
       ret = s->base_chain (pad, parent, gst_buffer_ref (gst_buffer_list_get (list, i)));
       i++;
@@ -1744,6 +1774,9 @@ amd_vcs_stop (GstBaseTransform * trans)
   if (s->convert)
     gstamd_video_converter_free (s->convert);
   s->convert = NULL;
+  if (s->convert_i)
+    gstamd_video_converter_free (s->convert_i);
+  s->convert_i = NULL;
   if (s->out_pool) {
     gst_buffer_pool_set_active (s->out_pool, FALSE);
     gst_object_unref (s->out_pool);

@@ -888,6 +888,9 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
     /* frame_planes_plan_order of capi_video.cpp: the two field conversions, field f over lines f, f + 2, ... of every plane - the source chroma planes of
        a plan whose pair table names rows of the frame's chroma planes stay the frame's */
     const std::string keep = g_emu_divergence;
+    GstAmdVideoConverterConfig fcfg;
+    (void) plan_field_config (in, out, cfg, &fcfg);
+    cfg = &fcfg;
     for (int f = 0; f < 2; f++) {
       GstAmdVideoInfo fin, fout;
       plan_field_infos (in, out, f, &fin, &fout);

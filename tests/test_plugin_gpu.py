@@ -1182,3 +1182,41 @@ def test_compositor_is_a_video_aggregator_on_the_references_own_version(gst_env)
     lines = r.stdout.strip().splitlines()
     assert lines[0].startswith("GstAmdCompositor < GstVideoAggregator < GstAggregator < GstElement"), lines
     assert lines[1].startswith("pad: GstAmdCompositorPadObj < GstVideoAggregatorConvertPad < GstVideoAggregatorPad < GstAggregatorPad < GstPad"), lines
+
+
+def test_videoconvertscale_interlaced_caps_are_converted_field_aware(gst_env, ref):
+    """interlace-mode=interleaved on both sides (round 6; the round-5 element refused such caps): 576i NV12 -> BGRA through system memory, and 1080i I420
+    scaled to 576i in HBM (the interlaced plane scaler, element default method bilinear) - against the reference converter made for interlaced infos"""
+    env, tmp = gst_env
+    w, h, n = 720, 576, 3
+    fin, fout, fsc = tmp / "i_in.nv12", tmp / "i_out.bgra", tmp / "i_sc.i420"
+    launch(env, "videotestsrc num-buffers=%d pattern=smpte ! video/x-raw,format=NV12,width=%d,height=%d,interlace-mode=interleaved,colorimetry=bt601,chroma-site=mpeg2 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw,format=BGRA,interlace-mode=interleaved ! filesink location=%s"
+           % (n, w, h, fin, fout))
+    src = np.fromfile(fin, np.uint8).reshape(n, -1)
+    out = np.fromfile(fout, np.uint8).reshape(n, -1)
+    rc = ref.VideoConverter("NV12", w, h, "BGRA", w, h, in_colorimetry="bt601", in_chroma_site="mpeg2", interlaced=True)
+    rp = ref.VideoConverter("NV12", w, h, "BGRA", w, h, in_colorimetry="bt601", in_chroma_site="mpeg2")
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), i
+    assert (rp.frame(src[0]) != out[0]).any()          # ... which is not what the progressive converter makes of the same bytes
+    W, H, ow, oh = 1920, 1080, 720, 576
+    fin2 = tmp / "i_in.i420"
+    launch(env, "videotestsrc num-buffers=2 pattern=smpte ! video/x-raw,format=I420,width=%d,height=%d,interlace-mode=interleaved,colorimetry=bt709 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! amdhipupload ! videoconvertscale ! video/x-raw(memory:AMDHIPMemory),format=I420,width=%d,height=%d "
+                "! amdhipdownload ! filesink location=%s" % (W, H, fin2, ow, oh, fsc))
+    src = np.fromfile(fin2, np.uint8).reshape(2, -1)
+    out = np.fromfile(fsc, np.uint8).reshape(2, -1)
+    rs = ref.VideoConverter("I420", W, H, "I420", ow, oh, in_colorimetry="bt709", out_colorimetry="bt709", config=cases.ref_config_string(ref, cases.LIN), interlaced=True)
+    for i in range(2):
+        assert (rs.frame(src[i]) == out[i]).all(), i
+
+
+def test_videoconvertscale_refuses_alternate_and_mismatched_interlace_modes(gst_env):
+    """fields / alternate are not negotiated, and neither is a change of the mode (gst_video_converter_new: "we won't ever do deinterlace")"""
+    env, tmp = gst_env
+    for caps_in, caps_out in (("interlace-mode=interleaved", "interlace-mode=progressive"),):
+        r = subprocess.run([env["GSTAMD_LAUNCH_BIN"], "-q"] + ("videotestsrc num-buffers=1 ! video/x-raw,format=NV12,width=320,height=240,%s ! videoconvertscale ! "
+                                                              "video/x-raw,format=BGRA,%s ! fakesink" % (caps_in, caps_out)).split(),
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+        assert r.returncode != 0, r.stdout[-500:]

@@ -249,8 +249,17 @@ def test_interlaced_refusals_and_modes(native_lib):
 
 
 # ---- device ---------------------------------------------------------------------------------------------------------------------------------------
+def _seeds(default):
+    """GSTAMD_ILACE_SEEDS=a-b: a longer run (scripts/gpu_r06_interlaced.sh); one tally line per seed into GSTAMD_FUZZ_TALLY"""
+    e = os.environ.get("GSTAMD_ILACE_SEEDS")
+    if not e:
+        return default
+    a, b = e.split("-")
+    return list(range(int(a), int(b) + 1))
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("seed", _seeds([1, 2, 3, 4, 5, 6, 7, 8]))
 def test_hip_interlaced_random_conversions_match_reference_or_are_refused(native_lib, gpu, ref, seed):
     rnd = random.Random(9000 + seed)
     tally = {}
@@ -258,6 +267,10 @@ def test_hip_interlaced_random_conversions_match_reference_or_are_refused(native
         case = random_case(rnd)
         r = check(lambda c, s: _dev_run(gpu, c, s), ref, case, seed * 1000 + it)
         tally[r] = tally.get(r, 0) + 1
+    if os.environ.get("GSTAMD_FUZZ_TALLY"):
+        import json
+        with open(os.environ["GSTAMD_FUZZ_TALLY"], "a") as f:
+            f.write(json.dumps(dict(tally, seed=seed)) + "\n")
     assert tally.get("ok", 0) + tally.get("staged", 0) >= 45, tally
 
 

@@ -279,6 +279,16 @@ gst_amd_hip_ticket_unref (GstAmdHipTicket * t)
   g_free (t);
 }
 
+/* the allocation a memory stands for: a sub-memory made by mem_share has no state of its own - its device pointer, host mirror and tickets are its
+ * parent's (whatever touches part of an allocation is ordered against everything that touches the allocation) */
+static inline GstAmdHipMemory *
+amd_hip_root (GstMemory * mem)
+{
+  while (mem->parent)
+    mem = mem->parent;
+  return (GstAmdHipMemory *) mem;
+}
+
 static GstMemory *
 amd_hip_alloc (GstAllocator * allocator, gsize size, GstAllocationParams * params)
 {
@@ -293,8 +303,8 @@ amd_hip_alloc (GstAllocator * allocator, gsize size, GstAllocationParams * param
   }
   m->device_id = gstamd_get_device ();
   g_mutex_init (&m->lock);
-  /* NO_SHARE: there is no mem_share (a sub-memory would need its own events); gst_buffer_copy_region & co. then copy */
-  gst_memory_init (GST_MEMORY_CAST (m), GST_MEMORY_FLAG_NO_SHARE, allocator, NULL, maxsize, 255, params ? params->prefix : 0, size);
+  /* shareable (amd_hip_mem_share): gst_buffer_copy_region & co. then make sub-memories of the same HBM allocation instead of copying */
+  gst_memory_init (GST_MEMORY_CAST (m), 0, allocator, NULL, maxsize, 255, params ? params->prefix : 0, size);
   return GST_MEMORY_CAST (m);
 }
 
@@ -302,6 +312,12 @@ static void
 amd_hip_free (GstAllocator * allocator, GstMemory * mem)
 {
   GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+
+  if (mem->parent) {            /* a sub-memory: nothing of its own but the struct (the core drops its reference on the parent) */
+    g_mutex_clear (&m->lock);
+    g_free (m);
+    return;
+  }
 
   /* work that still reads or writes the allocation must finish before it goes back to the driver */
   ticket_host_wait (m->written);
@@ -341,7 +357,7 @@ host_wait (GstAmdHipMemory * m, gboolean also_reads)
 void
 gst_amd_hip_memory_host_wait (GstMemory * mem)
 {
-  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+  GstAmdHipMemory *m = amd_hip_root (mem);
 
   g_mutex_lock (&m->lock);
   host_wait (m, TRUE);
@@ -351,7 +367,7 @@ gst_amd_hip_memory_host_wait (GstMemory * mem)
 static gpointer
 amd_hip_map_full (GstMemory * mem, GstMapInfo * info, gsize maxsize)
 {
-  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+  GstAmdHipMemory *m = amd_hip_root (mem);
   gpointer ret;
 
   g_mutex_lock (&m->lock);
@@ -390,7 +406,7 @@ amd_hip_map_full (GstMemory * mem, GstMapInfo * info, gsize maxsize)
 static void
 amd_hip_unmap_full (GstMemory * mem, GstMapInfo * info)
 {
-  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+  GstAmdHipMemory *m = amd_hip_root (mem);
 
   g_mutex_lock (&m->lock);
   if (!(info->flags & GST_MAP_AMDHIP) && (info->flags & GST_MAP_WRITE) && m->device_dirty_from_host) {
@@ -434,7 +450,7 @@ stream_wait_ticket (GstAmdHipTicket ** t, gpointer stream)
 void
 gst_amd_hip_memory_wait_written (GstMemory * mem, gpointer stream)
 {
-  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+  GstAmdHipMemory *m = amd_hip_root (mem);
 
   g_mutex_lock (&m->lock);
   stream_wait_ticket (&m->written, stream);
@@ -444,7 +460,7 @@ gst_amd_hip_memory_wait_written (GstMemory * mem, gpointer stream)
 void
 gst_amd_hip_memory_wait_idle (GstMemory * mem, gpointer stream)
 {
-  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+  GstAmdHipMemory *m = amd_hip_root (mem);
 
   g_mutex_lock (&m->lock);
   stream_wait_ticket (&m->written, stream);
@@ -459,7 +475,7 @@ gst_amd_hip_memory_wait_idle (GstMemory * mem, gpointer stream)
 void
 gst_amd_hip_memory_set_written (GstMemory * mem, GstAmdHipTicket * t)
 {
-  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+  GstAmdHipMemory *m = amd_hip_root (mem);
 
   g_mutex_lock (&m->lock);
   gst_amd_hip_ticket_unref (m->written);        /* the writer waited for it (wait_idle) before it wrote */
@@ -471,7 +487,7 @@ gst_amd_hip_memory_set_written (GstMemory * mem, GstAmdHipTicket * t)
 void
 gst_amd_hip_memory_set_read (GstMemory * mem, GstAmdHipTicket * t)
 {
-  GstAmdHipMemory *m = (GstAmdHipMemory *) mem;
+  GstAmdHipMemory *m = amd_hip_root (mem);
 
   g_mutex_lock (&m->lock);
   /* readers do not wait for each other: the memory remembers up to GST_AMD_HIP_MAX_READERS launches that may still be reading it
@@ -526,6 +542,57 @@ gst_amd_hip_memory_mark_read (GstMemory * mem, gpointer stream)
   gst_amd_hip_ticket_unref (t);
 }
 
+/* GstAllocator::mem_copy in HBM (the default copies through a CPU map: a download and an upload over PCIe for every gst_buffer_copy_deep / tee with a
+ * writer behind it).  Precedent: gst-plugins-bad gst-libs/gst/hip/gsthipmemory.cpp hip_mem_copy.  The copy runs on the transfer stream behind the launch
+ * that wrote the source (its ticket; deferred work is launched), and the two memories carry the copy's ticket like any reader / writer. */
+static GstMemory *
+amd_hip_mem_copy (GstMemory * mem, gssize offset, gssize size)
+{
+  GstAmdHipMemory *m = amd_hip_root (mem), *c;
+  GstMemory *copy;
+  GstAmdHipTicket *t;
+  gpointer xs;
+
+  if (size == -1)
+    size = (gssize) mem->size > offset ? (gssize) mem->size - offset : 0;
+  gst_amd_hip_select_device (m->device_id);
+  copy = amd_hip_alloc (mem->allocator, (gsize) size, NULL);
+  if (!copy)
+    return NULL;
+  c = (GstAmdHipMemory *) copy;
+  xs = amd_hip_xfer_stream (m->device_id);
+  gst_amd_hip_memory_wait_written (mem, xs);
+  if (size > 0 && gstamd_device_copy (c->device_ptr, (const guint8 *) m->device_ptr + mem->offset + offset, (gsize) size, xs) != GSTAMD_OK) {
+    GST_ERROR ("HBM copy of %" G_GSSIZE_FORMAT " bytes failed: %s", size, gstamd_last_error ());
+    gst_memory_unref (copy);
+    return NULL;
+  }
+  t = gst_amd_hip_ticket_new (xs);
+  gst_amd_hip_memory_set_read (mem, t);
+  gst_amd_hip_memory_set_written (copy, t);
+  gst_amd_hip_ticket_unref (t);
+  return copy;
+}
+
+/* GstAllocator::mem_share: a window into the same HBM allocation (gst_memory_share: gst_buffer_copy_region, gst_buffer_resize on shared memory ...).
+ * The sub-memory keeps a reference on its parent and borrows everything from it (amd_hip_root). */
+static GstMemory *
+amd_hip_mem_share (GstMemory * mem, gssize offset, gssize size)
+{
+  GstMemory *parent = mem->parent ? mem->parent : mem;
+  GstAmdHipMemory *root = amd_hip_root (mem), *sub;
+
+  if (size == -1)
+    size = (gssize) mem->size - offset;
+  sub = g_new0 (GstAmdHipMemory, 1);
+  sub->device_ptr = root->device_ptr;
+  sub->device_id = root->device_id;
+  g_mutex_init (&sub->lock);
+  gst_memory_init (GST_MEMORY_CAST (sub), GST_MINI_OBJECT_FLAGS (parent) | GST_MINI_OBJECT_FLAG_LOCK_READONLY, mem->allocator, parent, mem->maxsize, mem->align,
+      mem->offset + offset, (gsize) size);
+  return GST_MEMORY_CAST (sub);
+}
+
 static void
 gst_amd_hip_allocator_class_init (GstAmdHipAllocatorClass * klass)
 {
@@ -543,7 +610,8 @@ gst_amd_hip_allocator_init (GstAmdHipAllocator * self)
   a->mem_type = GST_AMD_HIP_MEMORY_TYPE;
   a->mem_map_full = amd_hip_map_full;
   a->mem_unmap_full = amd_hip_unmap_full;
-  /* mem_copy: GstAllocator's default (through a CPU map); mem_share: none - memories are created NO_SHARE */
+  a->mem_copy = amd_hip_mem_copy;
+  a->mem_share = amd_hip_mem_share;
   GST_OBJECT_FLAG_SET (self, GST_ALLOCATOR_FLAG_CUSTOM_ALLOC);
 }
 

@@ -1765,6 +1765,66 @@ amd_vcs_chain_list (GstPad * pad, GstObject * parent, GstBufferList * list)
   return ret;
 }
 
+/* gst_video_convert_scale_src_event (gstvideoconvertscale.c:2008-2037): a navigation event travelling upstream names a point of the OUTPUT picture;
+ * upstream of a scaler it is the point of the input picture that lands there.  (The coordinates are the event structure's pointer_x / pointer_y
+ * fields on every GStreamer version; gst_navigation_event_set_coordinates, 1.22, writes the same two fields.) */
+static gboolean
+amd_vcs_src_event (GstBaseTransform * trans, GstEvent * event)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (trans);
+
+  if (GST_EVENT_TYPE (event) == GST_EVENT_NAVIGATION && s->convert &&
+      (s->in_info.width != s->out_info.width || s->in_info.height != s->out_info.height) && s->out_info.width > 0 && s->out_info.height > 0) {
+    GstStructure *st;
+    gdouble x, y;
+    event = gst_event_make_writable (event);
+    st = gst_event_writable_structure (event);
+    if (st && gst_structure_get_double (st, "pointer_x", &x) && gst_structure_get_double (st, "pointer_y", &y))
+      gst_structure_set (st, "pointer_x", G_TYPE_DOUBLE, x * s->in_info.width / s->out_info.width,
+          "pointer_y", G_TYPE_DOUBLE, y * s->in_info.height / s->out_info.height, NULL);
+  }
+  return GST_BASE_TRANSFORM_CLASS (gst_amd_vcs_parent_class)->src_event (trans, event);
+}
+
+/* gst_video_convert_scale_transform_meta (gstvideoconvertscale.c:773-829): metas whose tags are all of {video, orientation, size} survive the
+ * conversion - copied as they are, or, when they carry the size tag, through their own transform function (GstVideoMetaTransformMatrix on 1.28+ with
+ * the picture's place inside the borders, else the older "gst-video-scale" transform with the two infos: video crop, region-of-interest ...);
+ * colorspace-tagged and any other metas go to the base class's rule */
+static gboolean
+amd_vcs_transform_meta (GstBaseTransform * trans, GstBuffer * outbuf, GstMeta * meta, GstBuffer * inbuf)
+{
+  GstAmdVideoConvertScale *s = AMD_VCS (trans);
+  const GstMetaInfo *info = meta->info;
+  const gchar *const *tags = gst_meta_api_type_get_tags (info->api);
+  static const gchar *const valid[] = { GST_META_TAG_VIDEO_STR, GST_META_TAG_VIDEO_ORIENTATION_STR, GST_META_TAG_VIDEO_SIZE_STR, NULL };
+  guint i, k;
+
+  /* (gst_meta_api_type_tags_contain_only, 1.24: every tag of the API is one of the list; an API without tags qualifies) */
+  for (i = 0; tags && tags[i]; i++) {
+    for (k = 0; valid[k] && strcmp (tags[i], valid[k]) != 0; k++);
+    if (!valid[k])
+      return GST_BASE_TRANSFORM_CLASS (gst_amd_vcs_parent_class)->transform_meta (trans, outbuf, meta, inbuf);
+  }
+  if (gst_meta_api_type_has_tag (info->api, g_quark_from_static_string (GST_META_TAG_VIDEO_SIZE_STR))) {
+    if (info->transform_func) {
+      GstVideoMetaTransform sc = { &s->in_info, &s->out_info };
+#if GST_CHECK_VERSION (1, 27, 0)
+      GstVideoMetaTransformMatrix mx;
+      const GstVideoRectangle in_rect = { 0, 0, GST_VIDEO_INFO_WIDTH (&s->in_info), GST_VIDEO_INFO_HEIGHT (&s->in_info) };
+      const GstVideoRectangle out_rect = { s->borders_w / 2, s->borders_h / 2, GST_VIDEO_INFO_WIDTH (&s->out_info) - s->borders_w,
+        GST_VIDEO_INFO_HEIGHT (&s->out_info) - s->borders_h
+      };
+      gst_video_meta_transform_matrix_init (&mx, &s->in_info, &in_rect, &s->out_info, &out_rect);
+      if (info->transform_func (outbuf, meta, inbuf, gst_video_meta_transform_matrix_get_quark (), &mx))
+        return FALSE;
+#endif
+      info->transform_func (outbuf, meta, inbuf, gst_video_meta_transform_scale_get_quark (), &sc);
+    }
+    return FALSE;          /* transformed (or not transformable): never copied as it is */
+  }
+  return TRUE;
+}
+
 static gboolean
 amd_vcs_stop (GstBaseTransform * trans)
 {
@@ -1922,6 +1982,8 @@ gst_amd_vcs_class_init (GstAmdVideoConvertScaleClass * klass)
   tc->decide_allocation = GST_DEBUG_FUNCPTR (amd_vcs_decide_allocation);
   tc->transform = GST_DEBUG_FUNCPTR (amd_vcs_transform);
   tc->stop = GST_DEBUG_FUNCPTR (amd_vcs_stop);
+  tc->src_event = GST_DEBUG_FUNCPTR (amd_vcs_src_event);
+  tc->transform_meta = GST_DEBUG_FUNCPTR (amd_vcs_transform_meta);
   tc->sink_event = GST_DEBUG_FUNCPTR (amd_vcs_sink_event);
   klass->converts = TRUE;
   klass->scales = TRUE;

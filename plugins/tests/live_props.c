@@ -8,12 +8,16 @@
  *   live_props upload-meta     amdhipupload fed an NV12 frame whose GstVideoMeta has padded strides and a gap between the planes (what a
  *                              decoder or an aligned pool hands over): the HBM frame must hold the picture in the default layout.  Round
  *                              2's element copied the bytes flat and sheared every row after the first.
+ *   live_props nav-meta        videoconvertscale while scaling: navigation events travelling upstream get input coordinates, size-tagged metas
+ *                              (GstVideoCropMeta) are scaled onto the output buffer.
+ *   live_props hip-memory      the HIP allocator's mem_copy (device to device) and mem_share (windows into one allocation).
  * prints "ok" and exits 0 when every output buffer is what the options in force at that buffer say. */
 #include <gst/check/gstharness.h>
 #include <gst/gst.h>
 #include <gst/video/video.h>
 #include <stdio.h>
 #include <string.h>
+#include "../gstamdhipmemory.h"
 
 static GstBuffer *
 make_buffer (int frames, float base)
@@ -111,12 +115,164 @@ upload_meta (void)
   return 0;
 }
 
+/* videoconvertscale 320x240 -> 160x60: a navigation event sent upstream from the src pad arrives with its coordinates in INPUT pixels
+ * (gst_video_convert_scale_src_event, gstvideoconvertscale.c:2008), and a GstVideoCropMeta on the input buffer comes out scaled to the output size
+ * (gst_video_convert_scale_transform_meta :773: the meta's own "gst-video-scale" transform) */
+static int
+nav_meta (void)
+{
+  GstHarness *hn = gst_harness_new ("videoconvertscale");
+  if (!hn) {
+    fprintf (stderr, "no videoconvertscale element (GST_PLUGIN_PATH?)\n");
+    return 1;
+  }
+  gst_harness_set_caps_str (hn, "video/x-raw,format=BGRA,width=320,height=240,framerate=30/1", "video/x-raw,format=BGRA,width=160,height=60,framerate=30/1");
+  GstBuffer *b = gst_buffer_new_allocate (NULL, 320 * 240 * 4, NULL);
+  gst_buffer_memset (b, 0, 0x40, 320 * 240 * 4);
+  GstVideoCropMeta *cm = gst_buffer_add_video_crop_meta (b);
+  cm->x = 40, cm->y = 80, cm->width = 100, cm->height = 120;
+  if (gst_harness_push (hn, b) != GST_FLOW_OK) {
+    fprintf (stderr, "push failed\n");
+    return 1;
+  }
+  GstBuffer *out = gst_harness_try_pull (hn);
+  int bad = out == NULL;
+  if (out) {
+    GstVideoCropMeta *oc = gst_buffer_get_video_crop_meta (out);
+    if (!oc || oc->x != 20 || oc->y != 20 || oc->width != 50 || oc->height != 30) {
+      fprintf (stderr, "crop meta on the output: %s (%u, %u, %u x %u), expected (20, 20, 50 x 30)\n", oc ? "wrong" : "missing", oc ? oc->x : 0, oc ? oc->y : 0,
+          oc ? oc->width : 0, oc ? oc->height : 0);
+      bad = 1;
+    }
+    gst_buffer_unref (out);
+  }
+  /* the navigation event: structure fields pointer_x / pointer_y (what gst_navigation_event_new_mouse_move makes) */
+  GstStructure *st = gst_structure_new ("application/x-gst-navigation", "event", G_TYPE_STRING, "mouse-move", "pointer_x", G_TYPE_DOUBLE, 80.0,
+      "pointer_y", G_TYPE_DOUBLE, 30.0, NULL);
+  while (gst_harness_try_pull_upstream_event (hn));          /* (whatever the negotiation sent upstream) */
+  if (!gst_harness_push_upstream_event (hn, gst_event_new_navigation (st))) {
+    fprintf (stderr, "navigation event refused\n");
+    bad = 1;
+  }
+  GstEvent *ev;
+  int seen = 0;
+  while ((ev = gst_harness_try_pull_upstream_event (hn))) {
+    if (GST_EVENT_TYPE (ev) == GST_EVENT_NAVIGATION) {
+      gdouble x = 0, y = 0;
+      const GstStructure *es = gst_event_get_structure (ev);
+      seen = 1;
+      if (!gst_structure_get_double (es, "pointer_x", &x) || !gst_structure_get_double (es, "pointer_y", &y) || x != 160.0 || y != 120.0) {
+        fprintf (stderr, "navigation event upstream at (%g, %g), expected (160, 120)\n", x, y);
+        bad = 1;
+      }
+    }
+    gst_event_unref (ev);
+  }
+  if (!seen) {
+    fprintf (stderr, "no navigation event arrived upstream\n");
+    bad = 1;
+  }
+  gst_harness_teardown (hn);
+  if (!bad)
+    printf ("ok\n");
+  return bad;
+}
+
+/* GstAllocator::mem_copy / mem_share of the HIP allocator: a deep copy of an HBM buffer is another HBM allocation with the same bytes (made on the
+ * device: the source's host mirror is not touched), a shared window shows the parent's bytes at its offset and keeps the parent alive */
+static int
+hip_memory (void)
+{
+  const gsize size = 1 << 20;
+  int bad = 0;
+  GstBuffer *b = gst_amd_hip_buffer_new (size);
+  GstMapInfo m;
+  if (!b || !gst_buffer_map (b, &m, GST_MAP_WRITE)) {
+    fprintf (stderr, "no HBM buffer\n");
+    return 1;
+  }
+  for (gsize i = 0; i < size; i++)
+    m.data[i] = (guint8) (i * 7 + (i >> 9));
+  gst_buffer_unmap (b, &m);
+  GstMemory *src = gst_buffer_peek_memory (b, 0);
+  GstBuffer *c = gst_buffer_copy_deep (b);
+  GstMemory *cm = c ? gst_buffer_peek_memory (c, 0) : NULL;
+  GstMapInfo sd, cd;
+  if (!cm || !gst_is_amd_hip_memory (cm)) {
+    fprintf (stderr, "the deep copy is not HIP memory\n");
+    bad = 1;
+  } else {
+    if (gst_memory_map (src, &sd, GST_MAP_READ | GST_MAP_AMDHIP) && gst_memory_map (cm, &cd, GST_MAP_READ | GST_MAP_AMDHIP)) {
+      if (sd.data == cd.data) {
+        fprintf (stderr, "the deep copy shares the source's allocation\n");
+        bad = 1;
+      }
+      gst_memory_unmap (cm, &cd);
+      gst_memory_unmap (src, &sd);
+    }
+    if (!gst_buffer_map (c, &m, GST_MAP_READ))
+      bad = 1;
+    else {
+      for (gsize i = 0; i < size && !bad; i++)
+        bad = m.data[i] != (guint8) (i * 7 + (i >> 9));
+      if (bad)
+        fprintf (stderr, "the deep copy holds other bytes\n");
+      gst_buffer_unmap (c, &m);
+    }
+  }
+  /* a shared window, then a copy of part of it */
+  GstMemory *win = gst_memory_share (src, 4096, 8192);
+  if (!win || !gst_is_amd_hip_memory (win) || win->parent != src) {
+    fprintf (stderr, "gst_memory_share did not make a sub-memory of the allocation\n");
+    bad = 1;
+  } else {
+    if (gst_memory_map (win, &m, GST_MAP_READ)) {
+      for (gsize i = 0; i < 8192 && !bad; i++)
+        bad = m.data[i] != (guint8) ((i + 4096) * 7 + ((i + 4096) >> 9));
+      if (bad)
+        fprintf (stderr, "the shared window shows other bytes\n");
+      gst_memory_unmap (win, &m);
+    } else
+      bad = 1;
+    GstMemory *part = gst_memory_copy (win, 100, 1000);
+    if (!part || !gst_memory_map (part, &m, GST_MAP_READ))
+      bad = 1;
+    else {
+      for (gsize i = 0; i < 1000 && !bad; i++)
+        bad = m.data[i] != (guint8) ((i + 4196) * 7 + ((i + 4196) >> 9));
+      if (bad || m.size != 1000)
+        fprintf (stderr, "the copy of a region of the window is wrong\n"), bad = 1;
+      gst_memory_unmap (part, &m);
+    }
+    if (part)
+      gst_memory_unref (part);
+    gst_buffer_unref (b);          /* the window keeps the allocation */
+    b = NULL;
+    if (gst_memory_map (win, &m, GST_MAP_READ)) {
+      bad |= m.data[5] != (guint8) ((5 + 4096) * 7 + ((5 + 4096) >> 9));
+      gst_memory_unmap (win, &m);
+    }
+    gst_memory_unref (win);
+  }
+  if (b)
+    gst_buffer_unref (b);
+  if (c)
+    gst_buffer_unref (c);
+  if (!bad)
+    printf ("ok\n");
+  return bad;
+}
+
 int
 main (int argc, char **argv)
 {
   gst_init (&argc, &argv);
+  if (argc >= 2 && strcmp (argv[1], "hip-memory") == 0)
+    return hip_memory ();
   if (argc >= 2 && strcmp (argv[1], "upload-meta") == 0)
     return upload_meta ();
+  if (argc >= 2 && strcmp (argv[1], "nav-meta") == 0)
+    return nav_meta ();
   if (argc < 2 || strcmp (argv[1], "mix-matrix") != 0) {
     fprintf (stderr, "usage: %s mix-matrix | upload-meta\n", argv[0]);
     return 2;

@@ -1220,3 +1220,23 @@ def test_videoconvertscale_refuses_alternate_and_mismatched_interlace_modes(gst_
                                                               "video/x-raw,format=BGRA,%s ! fakesink" % (caps_in, caps_out)).split(),
                            env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
         assert r.returncode != 0, r.stdout[-500:]
+
+
+def test_videoconvertscale_rescales_navigation_events_and_size_tagged_metas(gst_env):
+    """src_event and transform_meta of the element (gstvideoconvertscale.c:2008-2037, 773-829; plugins/tests/live_props.c nav-meta): a navigation event
+    travelling upstream through a scaling element names input pixels, a GstVideoCropMeta arrives on the output buffer scaled to the output size"""
+    env, tmp = gst_env
+    only_on_114(env, "plugins/tests/live_props drives the element through GstHarness (libgstcheck)")
+    exe = os.path.join(ROOT, "plugins", "tests", "live_props")
+    r = subprocess.run([exe, "nav-meta"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_hip_allocator_copies_in_hbm_and_shares_windows(gst_env):
+    """GstAllocator::mem_copy and ::mem_share of the HIP allocator (plugins/gstamdhipmemory.c; plugins/tests/live_props.c hip-memory): gst_buffer_copy_deep
+    of an HBM buffer gives another HBM allocation with the same bytes, gst_memory_share a window that keeps the allocation alive"""
+    env, tmp = gst_env
+    only_on_114(env, "plugins/tests/live_props links the 1.14 build of the plugin")
+    exe = os.path.join(ROOT, "plugins", "tests", "live_props")
+    r = subprocess.run([exe, "hip-memory"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

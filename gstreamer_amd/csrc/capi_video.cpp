@@ -1714,6 +1714,20 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
         c->pre_img_size = need;
       }
       const int ident[4] = {0, 1, 2, 3};
+      if (p.fast_pre && ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0 && ((uintptr_t) pl.p[1] % 4) == 0 && (pl.stride[1] % 4) == 0 &&
+          !tuning_on ("GSTAMD_NO_FAST_PRE")) {
+        /* NV12 / NV21: that image is the unscaled conversion into A, R, G, B bytes - the line-pair kernel (11 MB at 1080p: 13 us through the per-pixel
+           kernel, round 6) */
+        FastParams fp;
+        fp.width = in_w, fp.height = in_h;
+        fast_params_finish (fp, p.matrix.p, ident, p.front.u_plane);
+        fp.crow_lo = -(p.rect.in_y >> 1);
+        fp.crow_hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
+        const uint8_t *y = pl.p[0], *uv = pl.p[1];
+        uint8_t *img = c->pre_img;
+        if ((e = launch_convert_pair (fp, p.front.chroma_h, 1, &y, &uv, &img, pl.stride[0], pl.stride[1], in_w * 4, stream)) != hipSuccess)
+          return hip_fail (e, "k_convert_pair(source size)");
+      } else
       if ((e = launch_convert (p.front, pl, c->vpair_dev, pre, ident, c->pre_img, in_w * 4, stream, 0)) != hipSuccess)
         return hip_fail (e, "k_convert(source size)");
       FrontParams f4;

@@ -3397,7 +3397,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   }
   /* the line-pair kernel (video_fast.h): unscaled 4:2:0 semi-planar -> 4-byte RGB through the AYUV_ARGB
    * matrix, with ORC's 16-bit addw wrap provably out of reach: |mulhsw (s, p)| <= (32896 * |p| >> 16) + 1 */
-  bool matrix_no_wrap = false;
+  bool matrix_no_wrap = false, matrix_no_wrap_core = false;          /* _core: whatever the destination's byte order */
   if (plan->matrix.kind == MATRIX_AYUV_ARGB && post.alpha_kind == ALPHA_NONE) {
     long t[5];
     bool fits = true;
@@ -3408,6 +3408,7 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     }
     long worst = t[0] + std::max (std::max (t[1], t[2]), t[3] + t[4]);
     matrix_no_wrap = fits && worst < 32000;
+    matrix_no_wrap_core = matrix_no_wrap;
     /* ... and the kernels built on it are instantiated for the four byte orders with the colour bytes in sequence (BGRx, RGBx, xRGB, xBGR and
        their alpha forms - GSTAMD_FOR_LAYOUTS in video_kernels.hip); RBGA goes through the generic kernels */
     if (plan->fout->kind == UNPACK_PACKED4 && plan->fout->hi_depth == 0) {
@@ -3450,8 +3451,25 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
         plan->fast_post = false;
     }
   }
+  /* enlarging from NV12 / NV21: the colour stage's source-size image (A, R, G, B bytes: one of the line-pair kernel's byte orders) when the pairing the
+     scaler's requests produce is the closed form that kernel computes - lines (2 p - 1, 2 p) over chroma rows (p - 1, p), clamped */
+  plan->fast_pre = false;
+  if (!plan->passes.empty () && plan->matrix_before_scale && matrix_no_wrap_core && fr.kind == UNPACK_SEMI && fr.chroma_v2 == 1 && (in_w % 4) == 0 && in_h >= 2 &&
+      fr.hi_depth == 0 && (int) plan->vpair.size () >= 2 * in_h) {
+    const int lo = -(plan->rect.in_y >> 1), hi = ((plan->rect.in_maxh + 1) >> 1) - 1 - (plan->rect.in_y >> 1);
+    bool regular = true;
+    for (int y = 0; y < in_h && regular; y++) {
+      const int u = (y + 1) >> 1;
+      const int ra = std::min (std::max (u - 1, lo), hi), rb = std::min (std::max (u, lo), hi);
+      const int heavy = (y & 1) ? ra : rb, light = (y & 1) ? rb : ra;
+      const int e0 = plan->vpair[(size_t) 2 * y], ta = vpair_row (e0), tb = plan->vpair[(size_t) 2 * y + 1];
+      const int th = vpair_role (e0) == 0 ? ta : tb, tl = vpair_role (e0) == 0 ? tb : ta;
+      regular = th == heavy && tl == light;
+    }
+    plan->fast_pre = regular;
+  }
   if (plan->deep16 || plan->deep_out)
-    plan->fast_pair = plan->fast_420p = plan->fast_422 = plan->fast_422_ayuv = plan->fast_enc420 = plan->fast_post = false;
+    plan->fast_pair = plan->fast_420p = plan->fast_422 = plan->fast_422_ayuv = plan->fast_enc420 = plan->fast_post = plan->fast_pre = false;
   if (field)            /* the generic kernels (their chroma rows and weights come from the field's pair table); the per-line 4:2:2 kernels stay */
     plan->fast_pair = plan->fast_420p = plan->fast_enc420 = false;
   if (plan->pack.dither.on)             /* the dither stage lives in the pack kernel: the fused kernels that write planes / 3-byte pixels themselves have none */

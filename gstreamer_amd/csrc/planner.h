@@ -392,6 +392,8 @@ struct VideoPlan {
   bool fast_422_ayuv;         // unscaled packed 4:2:2 with neither matrix nor alpha stage: the same kernel leaving A, Y, U, V bytes (AYUV destinations, the image ahead of a planar pack)
   bool fast_422;              // unscaled packed 4:2:2 -> 4-byte RGB through the no-wrap AYUV_ARGB matrix: video_422_fast.h applies
   bool fast_post;             // scaled plans: the post stage may run fast_pixel (matrix provably wrap-free, alpha stays 0xff)
+  bool fast_pre = false;      // enlarging plans (the colour stage runs on the SOURCE's pixels, chain_convert ahead of chain_scale): the source-size A, R, G, B image
+                              // ahead of the scaler is the unscaled NV12 / NV21 -> ARGB conversion - the line-pair kernel of video_fast.h makes it
   bool deep_out;              // 10-bit destination: the composite of GammaPlan with pack16
   bool deep16;                // 10-bit source, unscaled, 8-bit 4-byte destination: k_convert16 (video_deep.h)
   Deep16Params deep;

@@ -6,6 +6,7 @@
 // them changes a result - every path they select is held to the same byte-exact tests.
 //
 //   name                     meaning (value)
+//   GSTAMD_NO_FAST_PRE       enlarging NV12 / NV21 plans make their source-size colour image with the per-pixel kernel instead of the line-pair kernel (set)
 //   GSTAMD_STORE_POLICY, GSTAMD_STORE_WT_BELOW
 //                            how k_convert_strip's pixels leave the CU (video_fast.h store16_policy: 0 streaming, 1 write-through sc0 sc1, 2 sc1, 3 sc0 sc1 nt,
 //                            4 plain; default: 1 for launches of fewer than GSTAMD_STORE_WT_BELOW = 9 frames, 3 for longer lists; profiles/r06/store_policy.md)

@@ -1638,7 +1638,10 @@ static bool launch_fast (const FastParams &fp, const FrameBatch &batch, int n, h
   /* shipped configuration (MI355X sweeps, profiles/r01_c2_variants.txt): strip kernel, 4-pixel columns, 3 line pairs per
    * lane with the next pair's loads in flight during the current pair's math, one wave per workgroup */
   const FastVariant &v = fast_variant ();
-  const int shape = v.set ? v.shape : 0, K = v.set && v.K > 0 ? v.K : 3;
+  /* (one frame of less than 6 M pixels per launch: two pairs per lane - half again as many waves to fill the chip with; 2560 x 1440: 8.1 -> 6.7 us,
+     scripts/strip_k_probe.py, round 6; at 4K and in lists three pairs stay) */
+  const int k_default = n == 1 && (long) fp.width * fp.height < 6000000L ? 2 : 3;
+  const int shape = v.set ? v.shape : 0, K = v.set && v.K > 0 ? v.K : k_default;
 #ifdef GSTAMD_TUNING       /* memory-only ablation (wrong pixels on purpose): profiling builds only, never in the product library */
   if (v.set && v.abl && CH == CHROMA_H_H2_CS)
     return shape == 1 ? launch_wide_variant<CHROMA_H_H2_CS, 1> (fp, batch, n, K, stream) :

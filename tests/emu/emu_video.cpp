@@ -2054,6 +2054,27 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
       /* enlarging from planes / packed 4:2:2: k_convert at the source's size into an A, c1, c2, c3 image, then k_bilinear4_rows from it */
       const int in_w = p.front.width, in_h = p.front.height;
       std::vector<uint32_t> img ((size_t) in_w * in_h);
+      if (p.fast_pre && vec_ok && ((uintptr_t) pl.p[0] % 4) == 0 && (pl.stride[0] % 4) == 0 && ((uintptr_t) pl.p[1] % 4) == 0 && (pl.stride[1] % 4) == 0 &&
+          !getenv ("GSTAMD_NO_FAST_PRE")) {
+        /* capi_video.cpp: the line-pair kernel (k_convert_strip, byte order A, R, G, B) makes the source-size image */
+        FastParams fp;
+        fp.width = in_w, fp.height = in_h;
+        const int ident[4] = {0, 1, 2, 3};
+        fast_params_finish (fp, p.matrix.p, ident, p.front.u_plane);
+        fp.crow_lo = -(p.rect.in_y >> 1);
+        fp.crow_hi = ((p.rect.in_maxh + 1) >> 1) - 1 - (p.rect.in_y >> 1);
+        fp.store_policy = 1;
+        const int pairs = fp.height / 2 + 1, K = 3;
+        uint8_t *im = (uint8_t *) img.data ();
+#define STRIP_PRE(CH) \
+        for (int p0 = 0; p0 < pairs; p0 += K) \
+          for (int x0 = 0; x0 + 4 <= fp.width; x0 += 4) \
+            fast_strip<CH, GSTAMD_LAYOUT (1, 2, 3), 0> (fp, pl, im, in_w * 4, x0, p0, p0 + K < pairs ? p0 + K : pairs);
+        if (p.front.chroma_h == CHROMA_H_H2_CS) { STRIP_PRE (CHROMA_H_H2_CS) }
+        else if (p.front.chroma_h == CHROMA_H_H2) { STRIP_PRE (CHROMA_H_H2) }
+        else { STRIP_PRE (CHROMA_H_NONE) }
+#undef STRIP_PRE
+      } else
       for (int y = 0; y < in_h; y++)
         for (int x = 0; x < in_w; x++)
           img[(size_t) y * in_w + x] = sf.at (x, y);

@@ -2977,8 +2977,6 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     }
   }
 
-  if (field && (plan->dither.on || planar_dither.on || (plan->fout->hi_depth && cfg.dither_method != GSTAMD_DITHER_NONE && plan->fin->format != plan->fout->format)))
-    return fail (GSTAMD_ERR_UNSUPPORTED, "a dither stage on interlaced frames (its pattern follows the frame's line numbers) is not implemented on the GPU path");
   const bool unpack_rgb = !plan->fin->yuv, pack_rgb = !plan->fout->yuv;
   /* gst_video_converter_init_from_config (:2380-2404): RGB formats force the RGB matrix */
   int in_matrix = unpack_rgb ? GSTAMD_COLOR_MATRIX_RGB : in->color_matrix;
@@ -3037,6 +3035,9 @@ static int plan_core (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     else if (plan->fin->kind == UNPACK_GRAY16 && plan->fin->hi_depth == 10)
       fp = nullptr;
   }
+  /* (no fastpath has a dither stage: the keeps_interlaced ones - convert_UYVY_v210, convert_I420_v210 ... - run as they are) */
+  if (field && !fp && (plan->dither.on || planar_dither.on || (plan->fout->hi_depth && cfg.dither_method != GSTAMD_DITHER_NONE && plan->fin->format != plan->fout->format)))
+    return fail (GSTAMD_ERR_UNSUPPORTED, "a dither stage on interlaced frames (its pattern follows the frame's line numbers) is not implemented on the GPU path");
   plan->gamma.on = false;
   if (cfg.gamma_mode == GSTAMD_GAMMA_MODE_REMAP) {
     /* video_converter_lookup_fastpath :8940-8944: "fastpaths don't do gamma" - they are only looked at for a same-size conversion

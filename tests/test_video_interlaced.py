@@ -168,6 +168,17 @@ def test_interlaced_chain_with_a_vertical_scaler_matches_the_reference_stage_by_
     assert r == "staged", r
 
 
+@pytest.mark.parametrize("pair", [("UYVY", "v210"), ("v210", "UYVY"), ("I420", "v210"), ("v210", "I420"), ("YUY2", "v210"), ("v210", "Y42B"), ("I422_10LE", "v210"),
+                                  ("v210", "I422_10LE"), ("v210", "I420_10LE"), ("I420_10LE", "v210"), ("P010_10LE", "BGRA"), ("I422_10LE", "RGBx"), ("v210", "BGRA"),
+                                  ("Y210", "ARGB"), ("I420_10LE", "AYUV")], ids=lambda p: "%s-%s" % p)
+def test_interlaced_v210_fastpaths_and_10_bit_sources_match_the_reference_on_host(native_lib, emu_lib, ref, pair):
+    """broadcast capture: the reference's own v210 fastpaths keep interlaced frames (GET_LINE_OFFSETS pairs lines l and l + 2 over one chroma row of their
+    field) and have no dither stage; 10-bit sources into 4-byte 8-bit formats run the 16-bit chain with video_chroma_up_vi2 on 16-bit lines"""
+    a, b = pair
+    for (w, h) in ((48, 16), (50, 24), (12, 8)):
+        assert check(lambda c, s: _emu_run(emu_lib, c, s), ref, (a, w, h, b, w, h, {}, None, None), 7 + w) == "ok"
+
+
 def test_interlaced_reference_chain_scaler_is_line_aliased(ref):
     """the evidence behind the note: the reference's chain and its own plane scaler (same gst_video_scaler_new object, same taps) disagree on LUMA for an
     interlaced enlargement - the chain's top-field rows come from source lines further down"""

@@ -4083,3 +4083,97 @@ int scaled_tile_rows_for (const VideoPlan &p)
 }
 
 }  // namespace gstamd
+
+// ------------------------------------------------------------------------------------------------
+// GstVideoTestSrc (gst/videotestsrc/videotestsrc.c): the colours its painters use and the per-frame values of video_testsrc.h - host side of
+// gstamd_video_test_pattern_* (video_testsrc.hip) and of the host emulator
+// ------------------------------------------------------------------------------------------------
+#include "video_testsrc.h"
+
+namespace gstamd {
+
+namespace {
+struct VtsColor { int Y, U, V, A, R, G, B; };
+/* vts_colors_bt709_ycbcr_100 / _75 and vts_colors_bt601_ycbcr_100 / _75 (videotestsrc.c:59-155): published colour-bar values (white, yellow, cyan, green,
+   magenta, red, blue, black, -I, +Q, super black, dark grey) */
+const VtsColor k709_100[12] = {{235, 128, 128, 255, 255, 255, 255}, {219, 16, 138, 255, 255, 255, 0}, {188, 154, 16, 255, 0, 255, 255}, {173, 42, 26, 255, 0, 255, 0},
+  {78, 214, 230, 255, 255, 0, 255}, {63, 102, 240, 255, 255, 0, 0}, {32, 240, 118, 255, 0, 0, 255}, {16, 128, 128, 255, 0, 0, 0}, {16, 198, 21, 255, 0, 0, 128},
+  {16, 235, 198, 255, 0, 128, 255}, {0, 128, 128, 255, 0, 0, 0}, {32, 128, 128, 255, 19, 19, 19}};
+const VtsColor k709_75[8] = {{180, 128, 128, 255, 191, 191, 191}, {168, 44, 136, 255, 191, 191, 0}, {145, 147, 44, 255, 0, 191, 191}, {133, 63, 52, 255, 0, 191, 0},
+  {63, 193, 204, 255, 191, 0, 191}, {51, 109, 212, 255, 191, 0, 0}, {28, 212, 120, 255, 0, 0, 191}, {16, 128, 128, 255, 0, 0, 0}};
+const VtsColor k601_100[12] = {{235, 128, 128, 255, 255, 255, 255}, {210, 16, 146, 255, 255, 255, 0}, {170, 166, 16, 255, 0, 255, 255}, {145, 54, 34, 255, 0, 255, 0},
+  {106, 202, 222, 255, 255, 0, 255}, {81, 90, 240, 255, 255, 0, 0}, {41, 240, 110, 255, 0, 0, 255}, {16, 128, 128, 255, 0, 0, 0}, {16, 198, 21, 255, 0, 0, 128},
+  {16, 235, 198, 255, 0, 128, 255}, {0, 128, 128, 255, 0, 0, 0}, {32, 128, 128, 255, 19, 19, 19}};
+const VtsColor k601_75[8] = {{180, 128, 128, 255, 191, 191, 191}, {162, 44, 142, 255, 191, 191, 0}, {131, 156, 44, 255, 0, 191, 191}, {112, 72, 58, 255, 0, 191, 0},
+  {84, 184, 198, 255, 191, 0, 191}, {65, 100, 212, 255, 191, 0, 0}, {35, 212, 114, 255, 0, 0, 191}, {16, 128, 128, 255, 0, 0, 0}};
+
+uint32_t painted (const VtsColor &c, bool rgb)
+{
+  return rgb ? (uint32_t) c.A | ((uint32_t) c.R << 8) | ((uint32_t) c.G << 16) | ((uint32_t) c.B << 24)
+      : (uint32_t) c.A | ((uint32_t) (c.Y & 0xff) << 8) | ((uint32_t) (c.U & 0xff) << 16) | ((uint32_t) (c.V & 0xff) << 24);
+}
+
+/* RGB_TO_Y_CCIR & co (videotestsrc.c:164-202): 10 fractional bits */
+int fix10 (double x) { return (int) (x * 1024 + 0.5); }
+VtsColor user_color (uint32_t argb, bool bt601)
+{
+  VtsColor c;
+  const int r = (argb >> 16) & 0xff, g = (argb >> 8) & 0xff, b = argb & 0xff;
+  c.A = (argb >> 24) & 0xff, c.R = r, c.G = g, c.B = b;
+  const double kr = bt601 ? 0.29900 : 0.212600, kg = bt601 ? 0.58700 : 0.715200, kb = bt601 ? 0.11400 : 0.072200;
+  const double ur = bt601 ? 0.16874 : 0.114572, ug = bt601 ? 0.33126 : 0.385427, vg = bt601 ? 0.41869 : 0.454153, vb = bt601 ? 0.08131 : 0.045847;
+  c.Y = (fix10 (kr * 219.0 / 255.0) * r + fix10 (kg * 219.0 / 255.0) * g + fix10 (kb * 219.0 / 255.0) * b + (512 + (16 << 10))) >> 10;
+  c.U = ((-fix10 (ur * 224.0 / 255.0) * r - fix10 (ug * 224.0 / 255.0) * g + fix10 (0.50000 * 224.0 / 255.0) * b + 512 - 1) >> 10) + 128;
+  c.V = ((fix10 (0.50000 * 224.0 / 255.0) * r - fix10 (vg * 224.0 / 255.0) * g - fix10 (vb * 224.0 / 255.0) * b + 512 - 1) >> 10) + 128;
+  return c;
+}
+}  // namespace
+
+void test_pattern_setup (TestPatternParams *p, const GstAmdVideoInfo *info, int pattern, uint32_t foreground_argb, uint32_t background_argb)
+{
+  memset ((void *) p, 0, sizeof (*p));
+  const FormatDesc *f = format_desc (info->format);
+  const bool rgb = f && !f->yuv;          /* GST_VIDEO_INFO_IS_RGB: GRAY frames are painted as AYUV */
+  const bool bt601 = info->color_matrix == GSTAMD_COLOR_MATRIX_BT601;
+  p->pattern = pattern;
+  p->w = info->width;
+  p->h = info->height;
+  for (int i = 0; i < 12; i++)
+    p->colors[i] = painted (bt601 ? k601_100[i] : k709_100[i], rgb);
+  for (int i = 0; i < 8; i++)
+    p->colors75[i] = painted (bt601 ? k601_75[i] : k709_75[i], rgb);
+  p->fg = painted (user_color (foreground_argb, bt601), rgb);
+  p->bg = painted (user_color (background_argb, bt601), rgb);
+}
+
+void test_pattern_frame (TestPatternParams *p, uint64_t n_frames)
+{
+  p->odd_frame = (int) (n_frames & 1);
+  p->rand_state = testsrc_lcg_skip (0u, (uint32_t) (n_frames * (uint64_t) testsrc_draws_per_frame (p->pattern, p->w, p->h)));
+  /* gst_video_test_src_ball with animation-mode = frames, motion = wavy (:1486-1513): libm on the host, as in the reference */
+  const int radius = 20;
+  const double rad = 2 * 3.1415926535897932384626433832795028841971693993751 * ((double) n_frames / 200);
+  p->ball_radius = radius;
+  p->ball_x = radius + (0.5 + 0.5 * sin (rad)) * (p->w - 2 * radius);
+  p->ball_y = radius + (0.5 + 0.5 * sin (rad * sqrt (2))) * (p->h - 2 * radius);
+}
+
+void test_pattern_conversion (const GstAmdVideoInfo *info, GstAmdVideoInfo *pi, GstAmdVideoConverterConfig *cfg)
+{
+  const FormatDesc *f = format_desc (info->format);
+  const bool rgb = f && !f->yuv;
+  video_info_set_format (pi, rgb ? GSTAMD_VIDEO_FORMAT_ARGB : GSTAMD_VIDEO_FORMAT_AYUV, info->width, info->height);
+  pi->color_range = info->color_range;
+  pi->color_matrix = rgb ? GSTAMD_COLOR_MATRIX_RGB : info->color_matrix;
+  pi->color_transfer = info->color_transfer;
+  pi->color_primaries = info->color_primaries;
+  pi->chroma_site = info->chroma_site;
+  converter_config_init (cfg);
+  cfg->internal_flags = 1;                          /* the generic chain: chroma downsampler + pack, what convert_hline_generic (:1626-1683) calls */
+  cfg->dither_method = GSTAMD_DITHER_NONE;          /* (TO_16 and the pack function: no dither stage) */
+  cfg->matrix_mode = GSTAMD_MATRIX_MODE_NONE;
+  cfg->chroma_mode = GSTAMD_CHROMA_MODE_FULL;
+  cfg->alpha_mode = GSTAMD_ALPHA_MODE_COPY;
+}
+
+}  // namespace gstamd

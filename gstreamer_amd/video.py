@@ -247,6 +247,46 @@ def _ptr(x):
     raise TypeError("expected device pointer or CUDA tensor")
 
 
+TEST_PATTERNS = {"smpte": 0, "snow": 1, "black": 2, "white": 3, "red": 4, "green": 5, "blue": 6, "checkers-1": 7, "checkers-2": 8, "checkers-4": 9,
+                 "checkers-8": 10, "circular": 11, "blink": 12, "smpte75": 13, "zone-plate": 14, "gamut": 15, "chroma-zone-plate": 16, "solid-color": 17,
+                 "ball": 18, "smpte100": 19, "bar": 20, "pinwheel": 21, "spokes": 22, "gradient": 23, "colors": 24, "smpte-rp-219": 25}
+
+
+class VideoTestPattern:
+    """gstamd_video_test_pattern_*: GstVideoTestSrc's frames painted in HBM (include/gstamd_video.h)"""
+
+    def __init__(self, info, pattern, foreground=0xffffffff, background=0xff000000):
+        L = lib()
+        L.gstamd_video_test_pattern_new.restype = C.c_void_p
+        L.gstamd_video_test_pattern_new.argtypes = [C.POINTER(VideoInfo), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]
+        L.gstamd_video_test_pattern_frame.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.gstamd_video_test_pattern_free.argtypes = [C.c_void_p]
+        L.gstamd_video_test_pattern_free.restype = None
+        L.gstamd_video_test_pattern_describe.argtypes = [C.c_void_p]
+        L.gstamd_video_test_pattern_describe.restype = C.c_char_p
+        status = C.c_int(0)
+        self._h = L.gstamd_video_test_pattern_new(C.byref(info), TEST_PATTERNS[pattern] if isinstance(pattern, str) else pattern, foreground, background, C.byref(status))
+        if not self._h:
+            raise GstAmdError(status.value, last_error())
+
+    def frame(self, n_frames, dest, stream=None):
+        _check(lib().gstamd_video_test_pattern_frame(self._h, n_frames, _ptr(dest), stream))
+
+    def describe(self):
+        return lib().gstamd_video_test_pattern_describe(self._h).decode()
+
+    def free(self):
+        if self._h:
+            lib().gstamd_video_test_pattern_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class VideoConverter:
     """gst_video_converter_new(in_info, out_info, config) -> .frame(src, dest)."""
 

@@ -301,6 +301,19 @@ int gstamd_video_converter_frame_planes (GstAmdVideoConverter *convert,
 int gstamd_video_converter_frames (GstAmdVideoConverter *convert, int n_frames, const void *const *src,
     void *const *dest, void *stream);
 
+/* ---- GstVideoTestSrc's frames, painted in HBM --------------------------------------------------------------------------------------------------------
+ * gst/videotestsrc/videotestsrc.c: the element's painters (gst_video_test_src_smpte :381 ... _colors :1869) fill a GstVideoFrame line by line on the CPU.
+ * _new takes the caps' info, the `pattern` value (GstVideoTestSrcPattern, gstvideotestsrc.h:84-112) and the foreground-color / background-color
+ * properties (0xAARRGGBB; the element's defaults 0xffffffff / 0xff000000); _frame paints frame number `n_frames` (the element's running count: blink, the
+ * ball's position and the random generator of snow / smpte follow it) into the HBM frame `dest`.  Byte for byte the reference's frame.  Built: smpte,
+ * snow, black, white, red, green, blue, checkers-1 / -2 / -4 / -8, blink, smpte75, smpte100, solid-color, bar, gradient, colors, ball (motion wavy,
+ * animation-mode frames, no horizontal-speed); the other patterns: GSTAMD_ERR_UNSUPPORTED. */
+typedef struct GstAmdVideoTestPattern GstAmdVideoTestPattern;
+GstAmdVideoTestPattern *gstamd_video_test_pattern_new (const GstAmdVideoInfo *info, int pattern, uint32_t foreground_argb, uint32_t background_argb, int *status);
+int gstamd_video_test_pattern_frame (GstAmdVideoTestPattern *pattern, uint64_t n_frames, void *dest, void *stream);
+const char *gstamd_video_test_pattern_describe (const GstAmdVideoTestPattern *pattern);
+void gstamd_video_test_pattern_free (GstAmdVideoTestPattern *pattern);
+
 /* How the last _frames call on this converter ran: the number of kernel launches that each served a whole list (or a
  * chunk of up to 32 / 16 frames of it) - 0 when the plan's kernels took the frames one by one.  What tests and the
  * element's statistics read; no reference counterpart (the reference converts buffer lists buffer by buffer,

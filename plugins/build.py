@@ -11,7 +11,7 @@ OUT = os.path.join(HERE, "libgstamdhipdsp.so")
 
 
 def build():
-    srcs = [os.path.join(HERE, f) for f in ("gstamdplugin.c", "gstamdhipmemory.c", "gstamdhipbufferpool.c", "gstamdvideoconvertscale.c", "gstamdaudioresample.c", "gstamdaudioconvert.c", "gstamdcompositor.c", "gstamdhiptransfer.c")]
+    srcs = [os.path.join(HERE, f) for f in ("gstamdplugin.c", "gstamdhipmemory.c", "gstamdhipbufferpool.c", "gstamdvideoconvertscale.c", "gstamdaudioresample.c", "gstamdaudioconvert.c", "gstamdcompositor.c", "gstamdhiptransfer.c", "gstamdvideotestsrc.c")]
     inc = ["-I%s/include/gstreamer-1.0" % CONDA, "-I%s/lib/gstreamer-1.0/include" % CONDA, "-I%s/include/glib-2.0" % CONDA,
            "-I%s/lib/glib-2.0/include" % CONDA]
     libdir = os.path.join(ROOT, "gstreamer_amd", "lib")
@@ -43,7 +43,7 @@ def build129():
     if not os.path.isdir(ref) or not os.path.exists(os.path.join(RT129, "lib", "libgstvideo-1.0.so.0")):
         return OUT129 if os.path.exists(OUT129) else None
     os.makedirs(os.path.dirname(OUT129), exist_ok=True)
-    srcs = [os.path.join(HERE, f) for f in ("gstamdplugin.c", "gstamdhipmemory.c", "gstamdhipbufferpool.c", "gstamdvideoconvertscale.c", "gstamdaudioresample.c", "gstamdaudioconvert.c", "gstamdcompositor.c", "gstamdhiptransfer.c")]
+    srcs = [os.path.join(HERE, f) for f in ("gstamdplugin.c", "gstamdhipmemory.c", "gstamdhipbufferpool.c", "gstamdvideoconvertscale.c", "gstamdaudioresample.c", "gstamdaudioconvert.c", "gstamdcompositor.c", "gstamdhiptransfer.c", "gstamdvideotestsrc.c")]
     inc = ["-DHAVE_CONFIG_H", "-I" + gen, "-I%s/gstreamer" % ref, "-I%s/gstreamer/libs" % ref, "-I%s/gst-plugins-base/gst-libs" % ref,
            "-I" + os.path.join(gen, "gst/video"), "-I" + os.path.join(gen, "gst/audio"),
            "-I%s/include/glib-2.0" % CONDA, "-I%s/lib/glib-2.0/include" % CONDA]

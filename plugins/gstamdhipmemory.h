@@ -112,5 +112,10 @@ G_END_DECLS
 struct GstAmdVideoConverterConfig;
 void gst_amd_converter_config_from_structure (const GstStructure * st, struct GstAmdVideoConverterConfig * cfg);
 void gst_amd_converter_config_register_types (void);
+/* GstVideoInfo -> the C ABI's info (format, size, pitches, colorimetry, chroma site; FALSE: a format the library does not know), and the format list of the
+ * elements' pad templates ("{ NV12, ... }") - gstamdvideoconvertscale.c, shared with the test source */
+struct GstAmdVideoInfo;
+gboolean gst_amd_video_info_fill (const GstVideoInfo * vi, struct GstAmdVideoInfo * ai);
+const gchar *gst_amd_video_formats_string (void);
 
 #endif

@@ -5,7 +5,8 @@
  * one rank step above the stock elements so that autopluggers prefer them when both plugins are visible.  A registry keeps ONE
  * feature per name: with this plugin scanned after gst-plugins-base (or in a GST_PLUGIN_PATH of its own) the names resolve to these
  * elements.  `amd`-prefixed aliases are always there, so both implementations can be addressed side by side in one registry;
- * GSTAMD_PLUGIN_REFERENCE_NAMES=0 registers the aliases only.  Plus `amdhipupload` / `amdhipdownload` for a pipeline's edges. */
+ * GSTAMD_PLUGIN_REFERENCE_NAMES=0 registers the aliases only.  Plus `amdhipupload` / `amdhipdownload` for a pipeline's edges and
+ * `amdhipvideotestsrc`, GstVideoTestSrc's frames painted in HBM. */
 #include <gst/gst.h>
 #include <string.h>
 
@@ -17,6 +18,7 @@ GType gst_amd_audio_convert_get_type (void);
 GType gst_amd_compositor_get_type (void);
 GType gst_amd_hip_upload_element_get_type (void);
 GType gst_amd_hip_download_element_get_type (void);
+GType gst_amd_video_test_src_get_type (void);
 
 /* A registry holds one feature per name, and GStreamer does not define what happens when two plugins claim the same one (1.14 ends up
  * with the details of one factory and the type of the other).  A reference name is therefore claimed only while no OTHER plugin of the
@@ -70,6 +72,8 @@ plugin_init (GstPlugin * plugin)
   ok &= gst_element_register (plugin, "amdcompositor", GST_RANK_NONE, gst_amd_compositor_get_type ());
   ok &= gst_element_register (plugin, "amdhipupload", GST_RANK_NONE, gst_amd_hip_upload_element_get_type ());
   ok &= gst_element_register (plugin, "amdhipdownload", GST_RANK_NONE, gst_amd_hip_download_element_get_type ());
+  /* (videotestsrc keeps its name: the stock source feeds system-memory pipelines and the tests' references) */
+  ok &= gst_element_register (plugin, "amdhipvideotestsrc", GST_RANK_NONE, gst_amd_video_test_src_get_type ());
   return ok;
 }
 

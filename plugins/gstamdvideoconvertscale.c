@@ -795,8 +795,15 @@ amd_vcs_fixate_caps (GstBaseTransform * trans, GstPadDirection direction, GstCap
   return othercaps;
 }
 
-static gboolean
-fill_amd_info (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
+const gchar *
+gst_amd_video_formats_string (void)
+{
+  return AMD_OUT_FORMATS;
+}
+
+#define fill_amd_info gst_amd_video_info_fill
+gboolean
+gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
 {
   guint i;
   static const struct { GstVideoFormat f; int a; } map[] = {

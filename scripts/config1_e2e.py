@@ -72,6 +72,24 @@ def main():
         steady = max((t - t1) - (t_src - t_src1), 1e-9)                   # the converter's share of the n - 1 frames after the first
         out[name] = {"wall_s": round(t, 3), "one_frame_wall_s": round(t1, 3), "frames_per_s_wall": round(n / t, 1),
                      "converter_s_steady": round(steady, 3), "frames_per_s_converter_steady": round((n - 1) / steady, 1)}
+    # round 6: the same conversion with the frames BORN in HBM (amdhipvideotestsrc) and left there (fakesink takes the HBM buffers): no PCIe on the path
+    hsrc = "amdhipvideotestsrc num-buffers=%d pattern=smpte ! video/x-raw(memory:AMDHIPMemory),format=NV12,width=1920,height=1080,framerate=300/1"
+    hsink = "video/x-raw(memory:AMDHIPMemory),format=BGRA ! fakesink sync=false"
+    nh = n * 10
+    try:
+        th_src1 = run(env, (hsrc % 1) + " ! fakesink sync=false")
+        th_src = run(env, (hsrc % nh) + " ! fakesink sync=false")
+        th1 = run(env, (hsrc % 1) + " ! amdvideoconvertscale ! " + hsink)
+        th = run(env, (hsrc % nh) + " ! amdvideoconvertscale ! " + hsink)
+        out["ours_hbm_source_and_sink"] = {"frames": nh, "wall_s": round(th, 3), "one_frame_wall_s": round(th1, 3), "source_only_wall_s": round(th_src, 3),
+                                           "source_only_one_frame_wall_s": round(th_src1, 3),
+                                           "frames_per_s_wall_after_startup": round((nh - 1) / max(th - th1, 1e-9), 1),
+                                           "source_only_frames_per_s_after_startup": round((nh - 1) / max(th_src - th_src1, 1e-9), 1),
+                                           "note": "amdhipvideotestsrc paints smpte into HBM pool frames (k_test_pattern + the library's packer), amdvideoconvertscale "
+                                                   "converts HBM -> HBM, fakesink drops the HBM buffers: host work per frame is GStreamer's (pad pushes, pool, "
+                                                   "tickets) and two or three kernel launches"}
+    except RuntimeError as e:
+        out["ours_hbm_source_and_sink"] = {"error": str(e)[-300:]}
     out["caveat"] = ("the source dominates every pipeline (videotestsrc: ~2.1 ms per frame into fresh buffers when nothing downstream offers a pool, "
                      "less when a converter does), so the wall rates are the source's and `converter_s_steady` - a difference of two such runs - "
                      "is only an order of magnitude; the element's own clock (scripts/config1_stats.py, GSTAMD_ELEMENT_STATS=1) says 0.29 ms per "

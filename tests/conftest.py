@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 # kernel arguments in HBM (a switch of the HIP runtime, read when it initialises): the launcher's decision - the product library does not
 # touch the environment (gstreamer_amd/csrc/tuning.cpp); inherited by the gst-launch / bench_element child processes of the plugin tests
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# torch brings its own HIP runtime: a process that loads the product library (linked against /opt/rocm's) BEFORE torch ends up with two runtimes and the
+# second one finds no device (/dev/kfd opens once per process).  The tests hand torch tensors to the library, so torch goes first in every test process.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
 
 
 def pytest_configure(config):

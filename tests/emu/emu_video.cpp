@@ -2223,3 +2223,30 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
       p.passes[1].horizontal ? pass_tile_geom (p.passes[1]) : TileGeom {0, 0}, pf);
   return GSTAMD_OK;
 }
+
+
+// gstamd_video_test_pattern_frame of video_testsrc.hip: k_test_pattern's body over the frame, then the conversion of the painted image
+#include "../../gstreamer_amd/csrc/video_testsrc.h"
+extern "C" int emu_video_test_pattern (const GstAmdVideoInfo *info, int pattern, uint32_t fg, uint32_t bg, uint64_t n_frames, uint8_t *dst, char *desc, int desc_len)
+{
+  if (!test_pattern_built (pattern))
+    return GSTAMD_ERR_UNSUPPORTED;
+  TestPatternParams p;
+  test_pattern_setup (&p, info, pattern, fg, bg);
+  test_pattern_frame (&p, n_frames);
+  GstAmdVideoInfo painted;
+  GstAmdVideoConverterConfig cfg;
+  test_pattern_conversion (info, &painted, &cfg);
+  const bool direct = painted.format == info->format;
+  std::vector<uint8_t> img ((size_t) painted.size);
+  uint8_t *base = direct ? dst + info->offset[0] : img.data ();
+  const int stride = direct ? info->stride[0] : painted.stride[0];
+  for (int y = 0; y < p.h; y++)
+    for (int x = 0; x < p.w; x++) {
+      const uint32_t v = test_pattern_px (p, x, y);
+      memcpy (base + (size_t) y * stride + (size_t) x * 4, &v, 4);
+    }
+  if (direct)
+    return GSTAMD_OK;
+  return emu_video_convert (&painted, info, &cfg, img.data (), dst, 1, desc, desc_len);
+}

@@ -1240,3 +1240,41 @@ def test_hip_allocator_copies_in_hbm_and_shares_windows(gst_env):
     exe = os.path.join(ROOT, "plugins", "tests", "live_props")
     r = subprocess.run([exe, "hip-memory"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("pattern,fmt", [("smpte", "NV12"), ("ball", "I420"), ("snow", "BGRA"), ("colors", "UYVY"), ("blink", "P010_10LE")])
+def test_amdhipvideotestsrc_paints_the_reference_sources_frames_in_hbm(gst_env, pattern, fmt):
+    """`amdhipvideotestsrc` (plugins/gstamdvideotestsrc.c): frames painted in HBM, downloaded, against the stock videotestsrc of the same runtime's own
+    version where that is the reference's (1.29) - on 1.14 the stock source is an older painter, compared on the patterns that did not change"""
+    env, tmp = gst_env
+    w, h, n = 320, 240, 4
+    fa, fb = tmp / ("vts_%s_ours.raw" % pattern), tmp / ("vts_%s_stock.raw" % pattern)
+    launch(env, "amdhipvideotestsrc num-buffers=%d pattern=%s ! video/x-raw(memory:AMDHIPMemory),format=%s,width=%d,height=%d,framerate=30/1 ! amdhipdownload ! filesink location=%s"
+           % (n, pattern, fmt, w, h, fa))
+    launch(env, "videotestsrc num-buffers=%d pattern=%s ! video/x-raw,format=%s,width=%d,height=%d,framerate=30/1 ! filesink location=%s" % (n, pattern, fmt, w, h, fb))
+    a, b = np.fromfile(fa, np.uint8), np.fromfile(fb, np.uint8)
+    assert a.size == b.size and a.size > 0
+    if env.get("GSTAMD_RUNTIME") == "1.29" or pattern in ("smpte", "colors", "blink"):
+        import cases
+        from oracle import ref
+        ri = ref.video_info(fmt, w, h)
+        for k in range(n):
+            fa_k, fb_k = a.reshape(n, -1)[k], b.reshape(n, -1)[k]
+            va = cases.visible_bytes(fmt, w, h, list(ri["stride"]), list(ri["offset"]), fa_k)
+            vb = cases.visible_bytes(fmt, w, h, list(ri["stride"]), list(ri["offset"]), fb_k)
+            assert (va == vb).all(), (pattern, fmt, k, int((va != vb).sum()))
+
+
+def test_amdhipvideotestsrc_feeds_the_converter_without_leaving_hbm(gst_env, ref):
+    """BASELINE config 1's shape with nothing on the host: amdhipvideotestsrc ! NV12 1080p ! videoconvertscale ! BGRA in HBM; the last step downloads for the check"""
+    env, tmp = gst_env
+    w, h, n = 1920, 1080, 3
+    fa, fb = tmp / "c1_hbm.bgra", tmp / "c1_src.nv12"
+    launch(env, "amdhipvideotestsrc num-buffers=%d pattern=ball ! video/x-raw(memory:AMDHIPMemory),format=NV12,width=%d,height=%d,framerate=30/1,colorimetry=bt709,chroma-site=mpeg2 "
+                "! tee name=t t. ! queue ! amdhipdownload ! filesink location=%s t. ! queue ! videoconvertscale ! video/x-raw(memory:AMDHIPMemory),format=BGRA ! amdhipdownload "
+                "! filesink location=%s" % (n, w, h, fb, fa))
+    src = np.fromfile(fb, np.uint8).reshape(n, -1)
+    out = np.fromfile(fa, np.uint8).reshape(n, -1)
+    rc = ref.VideoConverter("NV12", w, h, "BGRA", w, h, in_colorimetry="bt709", in_chroma_site="mpeg2")
+    for i in range(n):
+        assert (rc.frame(src[i]) == out[i]).all(), i

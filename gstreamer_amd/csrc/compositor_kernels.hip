@@ -846,6 +846,8 @@ static int try_walk (int format, int ashift, int background, const GstAmdComposi
 {
   if (tuning_on ("GSTAMD_NO_AGG_WALK"))
     return 0;
+  if ((unsigned long long) dstride * (unsigned long long) dh >= 0x7fffffffull)           /* the canvas is addressed through a buffer resource */
+    return 0;
   WalkParams p;
   memset ((void *) &p, 0, sizeof (p));
   p.ashift = ashift;
@@ -941,7 +943,11 @@ static int try_walk (int format, int ashift, int background, const GstAmdComposi
     p.fill_tiles_y = (dh + 15) / 16;
   }
   int walk_grid = p.n_blocks;
-  if (tuning_int ("GSTAMD_WALK_XCD", 0) > 0) {          /* measured: no difference on C4-A (47.7 us either way) - off */
+  /* Workgroups go round the eight XCDs; handing each XCD a contiguous run of strips lets neighbours meet in ONE L2: the 128-byte lines two strips straddle
+     and part of the vertical halo are fetched once.  C4-A, round 6 (profiles/r06/walk_variants.txt): L2 -> fabric reads 198 -> 149 MB per frame (1.49 ->
+     1.12 x the pads' bytes), the time unchanged (45.6 / 45.8 us: the walk is not bound by those bytes) - on, because the bytes it leaves on the fabric are
+     another stream's */
+  if (tuning_int ("GSTAMD_WALK_XCD", 1) > 0) {
     p.xcd_span = (p.n_blocks + 7) / 8;
     walk_grid = 8 * p.xcd_span;
   }

@@ -189,6 +189,12 @@ __device__ __forceinline__ void walk_wave (const WalkParams &p, const WalkPad &w
   uint32_t vt[4];
   walk_entry4 (k_vt, r0, vt);
   // the canvas: the lane's pixel of row r0, one row further per output row; the checker's column phase
+  /* the lane's pixel leaves through a buffer store that is ISSUED by every lane (lanes without a pixel aim past the canvas and are dropped by the range
+     check): a store under `if (store)` is a branch when no lane stores, and after such a join the compiler no longer knows how many vector-memory
+     operations are in flight - it waits for vmcnt(0) at the next row's unpack, i.e. for this row's store to reach memory */
+  const colplane_t canvas = col_plane (dst, 0, (uint32_t) dstride * (uint32_t) dh);
+  const uint32_t out_lane = store ? 4u * (uint32_t) cx : 0xfffffff0u;
+  uint32_t out_row = (uint32_t) (k_ypos + r0) * (uint32_t) dstride;
   uint8_t *outp = dst + (size_t) (k_ypos + r0) * dstride + 4 * (ptrdiff_t) cx;
   const uint32_t chk_x = ((uint32_t) cx >> 3) & 1u;
   const int wl = lane <= 60 ? lane : 60;
@@ -196,6 +202,10 @@ __device__ __forceinline__ void walk_wave (const WalkParams &p, const WalkPad &w
   typedef __attribute__ ((address_space (3))) u32x4 *l4_t;
   const l4_t lds_mine = (l4_t) (lds + 4 * lane), lds_win = (l4_t) (lds + 4 * wl);
 
+  /* the loop is entered with the vector-memory queue in the shape its back edge leaves it in (two prefetches, then a store): a store no lane takes part
+     in, so that the wait counts of the first of every four rows are the exact ones too */
+  if (FAST && !PLAIN)
+    __builtin_amdgcn_raw_buffer_store_b32 (0u, canvas, (int) 0xfffffff0u, 0, 2);
   for (int rb = r0; rb < r1; rb += 4) {
 #pragma unroll
     for (int ph = 0; ph < 4; ph++) {
@@ -253,7 +263,10 @@ __device__ __forceinline__ void walk_wave (const WalkParams &p, const WalkPad &w
         d = !k_yuv ? (ASH == 0 ? (0xffu | (val * 0x01010100u)) : ((val * 0x00010101u) | 0xff000000u))
             : (ASH == 0 ? (0x808000ffu | (val << 8)) : (0xff008080u | (val << 16)));
       } else {
-        d = k_bg == 1 ? k_bgw : (store ? *out : 0u);
+        /* a constant word (black, white, transparent).  No load of the canvas in this loop, ever: on gfx9 one vmcnt counts everything, so a load on ANY
+           path to the blend makes the compiler wait for vmcnt(0) there - for the next row's two prefetches too, and every row pays the memory latency
+           the prefetch was meant to hide (round 6: C4-A 47.4 -> see DESIGN 12.7) */
+        d = k_bgw;
       }
       if (FAST && (!PLAIN || !crossing)) {
         Px2 acc = px2_unpack (d);
@@ -280,8 +293,11 @@ __device__ __forceinline__ void walk_wave (const WalkParams &p, const WalkPad &w
         if (wp.n_below >= p.n_plain)
           d = apply_pad (d, s, wp.s_alpha, wp.mode, ASH, p.overlay);
       }
-      if (store)
+      if (FAST && !PLAIN)
+        __builtin_amdgcn_raw_buffer_store_b32 (d, canvas, (int) out_lane, (int) __builtin_amdgcn_readfirstlane (out_row), 2 /* nt */);
+      else if (store)
         __builtin_nontemporal_store (d, out);
+      out_row += (uint32_t) dstride;
     }
   }
 }

@@ -737,6 +737,7 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE) - refusing to report a %d-GPU number"
                          % (args.gpus, world, args.gpus))
     cpu_mode = args.backend == "gloo"
+    shared_gpu = False
     if cpu_mode:
         if args.config != "stub":
             raise SystemExit("--backend gloo is for the stub workload (tests) only: the HIP path has no CPU fallback")
@@ -746,13 +747,16 @@ def main():
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
         if torch.cuda.device_count() < world and world > 1 and os.environ.get("GSTAMD_BENCH_SHARE_GPU") != "1":
             raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
+        # dry run of the N-rank job on fewer devices (GSTAMD_BENCH_SHARE_GPU=1): ranks share devices, which RCCL refuses ("Duplicate GPU detected") - the
+        # barrier and the two reductions of the line (never the data path) go over gloo on host tensors, and the line says so
+        shared_gpu = world > 1 and torch.cuda.device_count() < world
         local_dev = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_dev)
         dev = torch.device("cuda", local_dev)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if cpu_mode:
+        if cpu_mode or shared_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -796,11 +800,12 @@ def main():
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1) if not cpu_mode else t_rank * 1e3
 
-    wall_max, total_units = reduce_job(wall, steps * wl.units_per_step, dev, distributed)
+    ctl_dev = torch.device("cpu") if shared_gpu else dev
+    wall_max, total_units = reduce_job(wall, steps * wl.units_per_step, ctl_dev, distributed)
     launches = steps * wl.launches_per_step
     per_launch_us = ev_ms * 1e3 / launches
     achieved = wl.alg_bytes_per_launch / (per_launch_us * 1e-6) / 1e9
-    per_rank = gather_ranks([steps * wl.units_per_step / t_rank, achieved], dev, distributed, world)
+    per_rank = gather_ranks([steps * wl.units_per_step / t_rank, achieved], ctl_dev, distributed, world)
 
     if rank == 0:
         assert total_units == steps * wl.units_per_step * world
@@ -825,6 +830,9 @@ def main():
                          "algorithmic_bytes_per_unit": wl.alg_bytes, "avg_launch_us": round(per_launch_us, 3)},
             "per_rank": [{"rank": i, "value": round(v[0], 1), "hbm_gbs": round(v[1], 1)} for i, v in enumerate(per_rank)],
         }
+        if shared_gpu:
+            line["dry_run"] = ("%d ranks on %d device(s) (GSTAMD_BENCH_SHARE_GPU=1): the ranks' streams share a GPU, control-plane collectives over gloo - "
+                               "a launcher check, NOT a %d-GPU number" % (world, torch.cuda.device_count(), world))
         if hasattr(wl, "flops_per_step"):
             line["roofline"]["gflops"] = round(wl.flops_per_step * steps / (ev_ms * 1e-3) / 1e9, 1)
         if world == 1 and args.config == "c2" and not args.no_secondary and not cpu_mode and not args.size and not args.batch:

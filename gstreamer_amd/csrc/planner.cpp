@@ -82,6 +82,10 @@ static const FormatDesc g_formats[] = {
   /* unpack_rgb10a2_le / unpack_bgr10a2_le (video-format.c:6210-6330; format table :8384-8388): Y410's word with R, G, B fields, unpack format ARGB64 */
   {GSTAMD_VIDEO_FORMAT_RGB10A2_LE, "RGB10A2_LE", false, true, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 0, 10, 20}, 7},
   {GSTAMD_VIDEO_FORMAT_BGR10A2_LE, "BGR10A2_LE", false, true, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 20, 10, 0}, 7},
+  /* BGR10x2_LE / RGB10x2_LE (format table :8504-8507): PACK_BGR10A2_LE / PACK_RGB10A2_LE again - the two top bits are read as alpha and written from it -
+     under three declared components: no alpha flag, depth[3] = 0 (format_alpha_bits: no alpha quantiser in chain_dither) */
+  {GSTAMD_VIDEO_FORMAT_BGR10x2_LE, "BGR10x2_LE", false, false, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 20, 10, 0}, 7},
+  {GSTAMD_VIDEO_FORMAT_RGB10x2_LE, "RGB10x2_LE", false, false, 1, UNPACK_Y410, 0, 0, 0, 0, {0, 0, 10, 20}, 7},
   {GSTAMD_VIDEO_FORMAT_v210, "v210", true, false, 1, UNPACK_V210, 1, 0, 0, 0, {0, 0, 0, 0}, 8},          /* video-format.c:558-757 */
   // luma only (video-format.c:1207-1229)
   {GSTAMD_VIDEO_FORMAT_GRAY8, "GRAY8", true, false, 1, UNPACK_GRAY, 0, 0, 0, 0, {0, 0, 0, 0}},
@@ -2181,7 +2185,8 @@ static void setup_dither16 (const GstAmdVideoConverterConfig &cfg, const FormatD
   /* the planar formats have no alpha component (depth 0: quantiser 0); ARGB64 / AYUV64 carry 16 bits of it like the other three - their own
      quantiser is 1, so a stage only exists for dither-quantization > 1, run as a pass over the finished frame (k_dither16_image) */
   d->shift[0] = fo->hi_depth == 3 || fo->kind == UNPACK_PACKED64 || fo->kind == UNPACK_PLANAR_A ? shift : 0;
-  if (fo->kind == UNPACK_Y410 && fo->hi_depth != 27) {          /* 2 bits of alpha: quantiser 1 << 14 (chain_dither :2060-2075 per component depth) */
+  if (fo->kind == UNPACK_Y410 && fo->hi_depth != 27 && fo->format != GSTAMD_VIDEO_FORMAT_BGR10x2_LE && fo->format != GSTAMD_VIDEO_FORMAT_RGB10x2_LE) {
+    /* 2 bits of alpha: quantiser 1 << 14 (chain_dither :2060-2075 per component depth; the x2 formats declare no fourth component: depth 0) */
     unsigned qa = 1u << 14;
     if (cfg.dither_quantization > qa)
       qa = cfg.dither_quantization;

@@ -21,7 +21,7 @@ FORMATS = {"I420": 2, "YV12": 3, "AYUV": 6, "RGBx": 7, "BGRx": 8, "xRGB": 9, "xB
            "YUY2": 4, "UYVY": 5, "RGB": 15, "BGR": 16, "YVYU": 19, "NV16": 51, "NV24": 52, "NV61": 60, "VYUY": 64,
            "GBR": 48, "I420_10LE": 43, "P010_10LE": 62, "ARGB64": 39, "AYUV64": 40, "v308": 28, "IYU2": 63, "VUYA": 84, "I422_10LE": 45, "Y444_10LE": 47,
            "I420_12LE": 73, "I422_12LE": 75, "Y444_12LE": 77, "Y444_16LE": 88, "P016_LE": 90, "P012_LE": 92, "GRAY8": 25, "v210": 21, "Y210": 82, "Y410": 83, "Y212_LE": 94,
-           "BGR10A2_LE": 85, "RGB10A2_LE": 86, "GRAY16_BE": 26, "GRAY16_LE": 27, "ARGB64_LE": 102, "ARGB64_BE": 103,
+           "BGR10A2_LE": 85, "RGB10A2_LE": 86, "BGR10x2_LE": 140, "RGB10x2_LE": 141, "GRAY16_BE": 26, "GRAY16_LE": 27, "ARGB64_LE": 102, "ARGB64_BE": 103,
            "RGBA64_LE": 104, "RGBA64_BE": 105, "BGRA64_LE": 106, "BGRA64_BE": 107, "ABGR64_LE": 108, "ABGR64_BE": 109,
            "RGB16": 29, "BGR16": 30, "RGB15": 31, "BGR15": 32, "A420": 34,
            "GBR_10LE": 50, "GBRA": 65, "GBR_12LE": 69, "Y412_LE": 96, "RGBP": 99, "BGRP": 100, "A422": 117, "A444": 118, "GBR_16LE": 131, "RBGA": 133,

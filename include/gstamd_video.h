@@ -92,6 +92,8 @@ enum {
   GSTAMD_VIDEO_FORMAT_Y410 = 83,      /* packed 4:4:4 in one little-endian 32-bit word: U 10, Y 10, V 10, A 2 (from the low bits) */
   GSTAMD_VIDEO_FORMAT_BGR10A2_LE = 85,  /* one little-endian 32-bit word per pixel: B 10, G 10, R 10, A 2 (from the low bits) */
   GSTAMD_VIDEO_FORMAT_RGB10A2_LE = 86,  /* the same with R 10, G 10, B 10, A 2 */
+  GSTAMD_VIDEO_FORMAT_BGR10x2_LE = 140, /* BGR10A2_LE's word declared without an alpha component (video-format.c:8504: the same pack / unpack functions) */
+  GSTAMD_VIDEO_FORMAT_RGB10x2_LE = 141, /* RGB10A2_LE's word, likewise */
   GSTAMD_VIDEO_FORMAT_Y212_LE = 94,
   GSTAMD_VIDEO_FORMAT_A420_10LE = 55,   /* A420 / A422 / A444 with 10, 12 (A444_12LE = 119, A422_12LE = 121, A420_12LE = 123) or 16 bits (125, 127, 129) in LE words */
   GSTAMD_VIDEO_FORMAT_A422_10LE = 57,

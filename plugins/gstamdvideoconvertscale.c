@@ -38,9 +38,14 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
  * kernel for make set_caps fail (not-negotiated) */
 #define AMD_OUT_FORMATS AMD_IN_FORMATS
 /* (RGBP / BGRP 1.20, RBGA / A422 / A444 / GBR_16LE / Y216_LE / Y416_LE later: taken together where the headers are the reference's own) */
+#if GST_CHECK_VERSION (1, 28, 0)
+#define AMD_128_FORMATS ", BGR10x2_LE, RGB10x2_LE"
+#else
+#define AMD_128_FORMATS ""
+#endif
 #if GST_CHECK_VERSION (1, 26, 0)
 #define AMD_NEWEST_FORMATS ", RGBP, BGRP, RBGA, A422, A444, GBR_16LE, Y216_LE, Y412_LE, Y416_LE, A420_12LE, A422_12LE, A444_12LE, A420_16LE, A422_16LE, A444_16LE, " \
-    "GRAY10_LE16, I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE, AV12"
+    "GRAY10_LE16, I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE, AV12" AMD_128_FORMATS
 #else
 #define AMD_NEWEST_FORMATS ""
 #endif
@@ -882,6 +887,9 @@ gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_P012_LE, GSTAMD_VIDEO_FORMAT_P012_LE}, {GST_VIDEO_FORMAT_P016_LE, GSTAMD_VIDEO_FORMAT_P016_LE},
     {GST_VIDEO_FORMAT_Y444_16LE, GSTAMD_VIDEO_FORMAT_Y444_16LE}, {GST_VIDEO_FORMAT_Y212_LE, GSTAMD_VIDEO_FORMAT_Y212_LE},
     {GST_VIDEO_FORMAT_RGB10A2_LE, GSTAMD_VIDEO_FORMAT_RGB10A2_LE},
+#endif
+#if GST_CHECK_VERSION (1, 28, 0)
+    {GST_VIDEO_FORMAT_BGR10x2_LE, GSTAMD_VIDEO_FORMAT_BGR10x2_LE}, {GST_VIDEO_FORMAT_RGB10x2_LE, GSTAMD_VIDEO_FORMAT_RGB10x2_LE},
 #endif
 #if GST_CHECK_VERSION (1, 20, 0)
     {GST_VIDEO_FORMAT_ARGB64_LE, GSTAMD_VIDEO_FORMAT_ARGB64_LE}, {GST_VIDEO_FORMAT_ARGB64_BE, GSTAMD_VIDEO_FORMAT_ARGB64_BE},

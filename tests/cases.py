@@ -1374,6 +1374,25 @@ VIDEO_CASES += [c for f, col in (("v216", "bt709>sRGB"), ("r210", "sRGB>bt709"),
     ("r5m_bgra_%s_sierra_q128" % f.lower(), "BGRA", 36, 19, f, 36, 19, dict(dither_method="sierra-lite", dither_quantization=128), None, None, "random"),
     ("r5m_%s_bgra_gamma_remap" % f.lower(), f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), col, None, "random"))]
 
+# round 6: BGR10x2_LE / RGB10x2_LE - the 10A2 words declared with three components (no alpha flag, no alpha quantiser; the two top bits still travel)
+VIDEO_CASES += [c for f, g in (("BGR10x2_LE", "BGR10A2_LE"), ("RGB10x2_LE", "RGB10A2_LE")) for c in (
+    ("r6x_%s_bgra_37x7" % f.lower(), f, 37, 7, "BGRA", 37, 7, {}, None, None, "random"),
+    ("r6x_bgra_%s_41x7" % f.lower(), "BGRA", 41, 7, f, 41, 7, {}, None, None, "random"),
+    ("r6x_%s_nv12" % f.lower(), f, 40, 6, "NV12", 40, 6, {}, None, None, "random"),
+    ("r6x_%s_to_%s" % (f.lower(), g.lower()), f, 30, 20, g, 30, 20, {}, None, None, "random"),
+    ("r6x_%s_to_%s" % (g.lower(), f.lower()), g, 30, 20, f, 30, 20, {}, None, None, "random"),
+    ("r6x_argb64_%s_alpha_set" % f.lower(), "ARGB64", 33, 9, f, 33, 9, dict(alpha_mode="set", alpha_value=0.4), None, None, "random"),
+    ("r6x_%s_argb64_alpha_mult" % f.lower(), f, 33, 9, "ARGB64", 33, 9, dict(alpha_mode="mult", alpha_value=0.6), None, None, "random"),
+    ("r6x_nv12_%s_up_bilinear" % f.lower(), "NV12", 64, 36, f, 100, 50, LIN, None, None, "random"),
+    ("r6x_%s_i420_10le_down_lanczos" % f.lower(), f, 64, 36, "I420_10LE", 32, 20, LAN, None, None, "random"),
+    ("r6x_%s_self_down_bilinear" % f.lower(), f, 64, 36, f, 32, 20, LIN, None, None, "random"),
+    ("r6x_argb64_%s_dest_border" % f.lower(), "ARGB64", 30, 20, f, 50, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+    ("r6x_%s_self_crop_dest_border" % f.lower(), f, 48, 30, f, 60, 40, dict(src_x=4, src_y=2, src_width=30, src_height=20, dest_x=8, dest_y=10, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+    ("r6x_bgra_%s_sierra_q128" % f.lower(), "BGRA", 36, 19, f, 36, 19, dict(dither_method="sierra-lite", dither_quantization=128), None, None, "random"),
+    ("r6x_argb64_%s_bayer" % f.lower(), "ARGB64", 36, 19, f, 36, 19, dict(dither_method="bayer"), None, None, "random"),
+    ("r6x_argb64_%s_floyd" % f.lower(), "ARGB64", 36, 19, f, 36, 19, dict(dither_method="floyd-steinberg"), None, None, "random"),
+    ("r6x_%s_bgra_gamma_remap" % f.lower(), f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"))]
+
 # the reference's own v210 fastpaths between v210 and the 8-bit 4:2:0 / 4:2:2 formats (video_v210_fast.h): samples shifted, not widened; group tails
 # (widths 6 k + 1 .. 5), the odd last line of a 4:2:0 frame, one-pixel frames
 VIDEO_CASES += [("v210fast_%s_%s_%dx%d" % (a.lower(), b.lower(), w, h), a, w, h, b, w, h, {}, None, None, "random")

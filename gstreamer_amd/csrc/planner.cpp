@@ -55,6 +55,7 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_NV12, "NV12", true, false, 2, UNPACK_SEMI, 1, 1, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV21, "NV21", true, false, 2, UNPACK_SEMI, 1, 1, 0, 1, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_Y41B, "Y41B", true, false, 3, UNPACK_PLANAR_H4, 2, 0, 1, 2, {0, 0, 0, 0}},          /* unpack_Y41B / pack_Y41B video-format.c:923-1006 */
+  {GSTAMD_VIDEO_FORMAT_IYU1, "IYU1", true, false, 1, UNPACK_PACKED411, 2, 0, 0, 0, {0, 0, 0, 0}},          /* unpack_IYU1 / pack_IYU1 video-format.c:2368-2470 */
   {GSTAMD_VIDEO_FORMAT_AV12, "AV12", true, true, 3, UNPACK_SEMI_A, 1, 1, 1, 0, {0, 0, 0, 0}},          /* unpack_AV12 / pack_AV12 video-format.c: NV12 + an alpha plane */
   {GSTAMD_VIDEO_FORMAT_NV16, "NV16", true, false, 2, UNPACK_SEMI, 1, 0, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV61, "NV61", true, false, 2, UNPACK_SEMI, 1, 0, 0, 1, {0, 0, 0, 0}},
@@ -290,6 +291,10 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->offset[1] = (uint64_t) info->stride[0] * h;
       info->offset[2] = info->offset[1] * 2;
       info->size = (uint64_t) info->stride[0] * h * 3;
+      break;
+    case GSTAMD_VIDEO_FORMAT_IYU1:              /* video-info.c:965-970 */
+      info->stride[0] = round_up (round_up (width, 4) + round_up (width, 4) / 2, 4);
+      info->size = (uint64_t) info->stride[0] * height;
       break;
     case GSTAMD_VIDEO_FORMAT_Y41B:              /* video-info.c:1010-1019 */
       info->stride[0] = round_up (width, 4);
@@ -2155,6 +2160,8 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
     return (uint64_t) ((w + 1) / 2) * 8 * h;
   if (f->kind == UNPACK_V210)
     return (uint64_t) ((w + 5) / 6) * 16 * h;
+  if (f->kind == UNPACK_PACKED411)
+    return (uint64_t) ((w + 3) / 4) * 6 * h;
   const uint64_t cw = ((uint64_t) w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) h + (1 << f->h_sub) - 1) >> f->h_sub;
   const uint64_t n = (uint64_t) w * h + 2 * cw * ch + (GSTAMD_KIND_ALPHA_PLANE (f->kind) >= 0 ? (uint64_t) w * h : 0);
   return f->hi_depth ? 2 * n : n;
@@ -3674,6 +3681,19 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
      source is src_width pixels from the line's FIRST pixel on, whatever src-x says (do_unpack_lines :2966 passes in_x, the unpacker drops it) */
   if (fi && fi->kind == UNPACK_V210)
     rc.in_x = 0;
+  /* IYU1: whole frames.  unpack_IYU1 advances by x * 4 BYTES for a horizontal offset ("FIXME", video-format.c:2382) - a crop starts inside another group's
+     bytes; rectangles and borders inside its six-byte groups are not built either */
+  if (fi && fo && ((fi->kind == UNPACK_PACKED411 && (rc.in_x || rc.in_y || ein.width != rc.in_maxw || ein.height != rc.in_maxh)) ||
+          (fo->kind == UNPACK_PACKED411 && (rc.out_x || rc.out_y || rc.fill || eout.width != rc.out_maxw || eout.height != rc.out_maxh)))) {
+    if (error)
+      *error = "source crops and destination rectangles on IYU1 frames (six-byte groups of four pixels; the reference's unpacker misplaces a horizontal offset) are not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  if (is_field && fi && fo && (fi->kind == UNPACK_PACKED411 || fo->kind == UNPACK_PACKED411)) {
+    if (error)
+      *error = "interlaced IYU1 frames are not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
   /* unpack_RGBA64_LE and its seven siblings advance a guint16 pointer by x * 8 (video-format.c:2483, 2532 ...): 16 bytes per pixel of a horizontal
      crop offset - the picture starts at pixel 2 x (reproduced), and runs into the next row when that is too far right (refused) */
   if (fi && fi->kind == UNPACK_PACKED64 && !fi->yuv && rc.in_x != 0) {         /* (unpack_Y412_LE / _Y416_LE step x * 4: no quirk) */

@@ -32,6 +32,8 @@ enum UnpackKind : int {
   UNPACK_PLANAR_A = 12, // I420's planes plus a full-size alpha plane (A420: plane 3); generic per-pixel kernels only (kind_has_planes is false for it)
   UNPACK_SEMI_A = 13,   // NV12's planes plus a full-size alpha plane (AV12: plane 2); generic per-pixel kernels only
   UNPACK_PLANAR_H4 = 14, // Y, U, V planes with one chroma sample per FOUR pixels of a line (Y41B); generic per-pixel kernels only (kind_has_planes is false)
+  UNPACK_PACKED411 = 15, // one plane, groups of four pixels in six bytes U Y0 Y1 V Y2 Y3 (IYU1; unpack format AYUV, 8-bit chain, w_sub 2 like Y41B); generic per-pixel
+                        // kernels only; whole frames only (unpack_IYU1 steps a horizontal offset by x * 4 BYTES, "FIXME" video-format.c:2382: crops are refused)
   UNPACK_RGB16 = 11,    // one plane, a little-endian 16-bit word per pixel with 5-6-5 or 5-5-5 bit fields (RGB16, BGR16, RGB15, BGR15; unpack format ARGB,
                         // 8-bit chain): FormatDesc::pos = {bits of G, first bit of R, of G, of B}
 };
@@ -414,6 +416,8 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
     return (size_t) y * stride + (size_t) x * 3;
   if (f->kind == UNPACK_PACKED422)
     return (size_t) y * stride + (size_t) x * 2;
+  if (f->kind == UNPACK_PACKED411)        /* whole groups (x is 0: the planner refuses rectangles on these frames) */
+    return (size_t) y * stride + (size_t) (x >> 2) * 6;
   if (f->kind == UNPACK_P422_16 || f->kind == UNPACK_Y410)          /* 8 bytes per pair of pixels / 4 bytes per pixel */
     return (size_t) y * stride + (size_t) x * 4;
   if (f->kind == UNPACK_PACKED64)

@@ -78,8 +78,13 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
     for (int i = 0; i < 4 && x0 + i < w; i++)
       q[4 * (i >> 1) + pk.pos[1] + 2 * (i & 1)] = (uint8_t) pack_dither (pk.dither, 1, (int) ((src.at (x0 + i, y0) >> 8) & 0xff), x0 + i, y0);
   }
+  if (pk.kind == UNPACK_PACKED411) {       // pack_IYU1 (video-format.c:2438-2470): the lumas of the group's pixels that exist at bytes 1, 2, 4, 5
+    uint8_t *q = (d.p[0] + dd) + (size_t) y0 * d.stride[0] + 6 * (size_t) (x0 >> 2);
+    for (int i = 0; i < 4 && x0 + i < w; i++)
+      q[1 + i + (i >> 1)] = (uint8_t) pack_dither (pk.dither, 1, (int) ((src.at (x0 + i, y0) >> 8) & 0xff), x0 + i, y0);
+  }
   // ---- luma of every line of the block
-  for (int r = 0; r < nlines && pk.kind != UNPACK_PACKED422; r++) {
+  for (int r = 0; r < nlines && pk.kind != UNPACK_PACKED422 && pk.kind != UNPACK_PACKED411; r++) {
     const int y = y0 + r;
     if (y >= h)
       break;
@@ -119,6 +124,12 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
         c = ((at (x - 3) + 2u * (at (x - 2) + at (x + 2)) + 3u * (at (x - 1) + at (x + 1)) + 4u * at (x) + at (x + 3) + 0x00080008u) >> 4) & 0x00ff00ffu;
       else
         c = ((at (x - 3) + 2u * at (x - 2) + 3u * at (x - 1) + 10u * at (x) + 0x00080008u) >> 4) & 0x00ff00ffu;
+    }
+    if (pk.kind == UNPACK_PACKED411) {      // pack_IYU1: U and V of the group's first pixel at bytes 0 and 3
+      uint8_t *q = (d.p[0] + dd) + (size_t) y0 * d.stride[0] + 6 * (size_t) k;
+      q[0] = (uint8_t) pack_dither (pk.dither, 2, (int) (c & 0xff), x, y0);
+      q[3] = (uint8_t) pack_dither (pk.dither, 3, (int) ((c >> 16) & 0xff), x, y0);
+      return;
     }
     (d.p[pk.u_plane] + dd)[(size_t) yb * d.stride[pk.u_plane] + k] = (uint8_t) pack_dither (pk.dither, 2, (int) (c & 0xff), x, y0);
     (d.p[pk.v_plane] + dd)[(size_t) yb * d.stride[pk.v_plane] + k] = (uint8_t) pack_dither (pk.dither, 3, (int) ((c >> 16) & 0xff), x, y0);

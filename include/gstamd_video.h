@@ -73,6 +73,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_NV16 = 51,
   GSTAMD_VIDEO_FORMAT_NV24 = 52,
   GSTAMD_VIDEO_FORMAT_A420 = 34,        /* I420 with a fourth, full-size plane of alpha */
+  GSTAMD_VIDEO_FORMAT_IYU1 = 38,        /* packed 4:1:1: six bytes U Y0 Y1 V Y2 Y3 per group of four pixels */
   GSTAMD_VIDEO_FORMAT_v216 = 22,        /* packed 4:2:2, little-endian 16-bit words U Y0 V Y1 */
   GSTAMD_VIDEO_FORMAT_r210 = 41,        /* one big-endian 32-bit word per pixel: x 2, R 10, G 10, B 10 */
   GSTAMD_VIDEO_FORMAT_GRAY10_LE16 = 138,/* one plane of luma, 10 bits in the low bits of little-endian words */

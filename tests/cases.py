@@ -81,6 +81,8 @@ def visible_planes(fmt, w, h):
         return [(4 * up2(w), h)]         # whole macropixels; visible_bytes blanks the unused luma slot of an odd last pixel
     if fmt in ("RGB", "BGR", "v308", "IYU2"):
         return [(3 * w, h)]
+    if fmt == "IYU1":
+        return [(6 * ((w + 3) // 4), h)]  # whole groups U Y0 Y1 V Y2 Y3; visible_bytes blanks the luma slots of pixels past the width
     # 16-bit samples: the same shapes with two bytes a sample (found late in round 4: without these rows a frame with pitch padding was compared
     # on its first plane only)
     if fmt in ("I420_10LE", "I420_12LE"):
@@ -113,6 +115,10 @@ def visible_bytes(fmt, w, h, strides, offsets, buf):
         if fmt in ("YUY2", "UYVY", "YVYU", "VYUY") and w % 2:
             plane = plane.copy()
             plane[:, 2 * (w - 1) + (2 if fmt in ("YUY2", "YVYU") else 3)] = 0      # second luma slot of the last macropixel
+        if fmt == "IYU1" and w % 4:
+            plane = plane.copy()
+            for j in range(w % 4, 4):                                               # pack_IYU1 writes the lumas of the pixels that exist
+                plane[:, 6 * (w // 4) + 1 + j + (j >> 1)] = 0
         out.append(plane.reshape(-1))
     return np.concatenate(out)
 
@@ -1393,6 +1399,39 @@ VIDEO_CASES += [c for f, g in (("BGR10x2_LE", "BGR10A2_LE"), ("RGB10x2_LE", "RGB
     ("r6x_argb64_%s_floyd" % f.lower(), "ARGB64", 36, 19, f, 36, 19, dict(dither_method="floyd-steinberg"), None, None, "random"),
     ("r6x_%s_bgra_gamma_remap" % f.lower(), f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"))]
 
+# round 6: IYU1 (packed 4:1:1, six bytes U Y0 Y1 V Y2 Y3 per four pixels): Y41B's chain on one plane; whole frames
+VIDEO_CASES += [
+    ("r6i_iyu1_bgra_32x6", "IYU1", 32, 6, "BGRA", 32, 6, {}, None, None, "random"),
+    ("r6i_iyu1_bgra_37x7", "IYU1", 37, 7, "BGRA", 37, 7, {}, None, None, "random"),
+    ("r6i_iyu1_bgra_38x5_cosited", "IYU1", 38, 5, "BGRA", 38, 5, {}, None, "cosited", "random"),
+    ("r6i_iyu1_ayuv_39x4", "IYU1", 39, 4, "AYUV", 39, 4, {}, None, None, "random"),
+    ("r6i_iyu1_1x1", "IYU1", 1, 1, "BGRA", 1, 1, {}, None, None, "random"),
+    ("r6i_iyu1_3x2_i420", "IYU1", 3, 2, "I420", 3, 2, {}, None, None, "random"),
+    ("r6i_bgra_iyu1_41x7", "BGRA", 41, 7, "IYU1", 41, 7, {}, None, None, "random"),
+    ("r6i_bgra_iyu1_42x7_cosited", "BGRA", 42, 7, "IYU1", 42, 7, {}, None, "cosited", "random"),
+    ("r6i_bgra_iyu1_43x3", "BGRA", 43, 3, "IYU1", 43, 3, {}, None, None, "random"),
+    ("r6i_ayuv_iyu1_40x6", "AYUV", 40, 6, "IYU1", 40, 6, {}, None, None, "random"),
+    ("r6i_iyu1_nv12", "IYU1", 40, 6, "NV12", 40, 6, {}, None, None, "random"),
+    ("r6i_nv12_iyu1", "NV12", 40, 6, "IYU1", 40, 6, {}, None, None, "random"),
+    ("r6i_iyu1_y41b", "IYU1", 44, 6, "Y41B", 44, 6, {}, None, None, "random"),
+    ("r6i_y41b_iyu1_45", "Y41B", 45, 6, "IYU1", 45, 6, {}, None, None, "random"),
+    ("r6i_iyu1_yuy2", "IYU1", 46, 5, "YUY2", 46, 5, {}, None, None, "random"),
+    ("r6i_uyvy_iyu1", "UYVY", 46, 5, "IYU1", 46, 5, {}, None, None, "random"),
+    ("r6i_iyu1_self", "IYU1", 47, 5, "IYU1", 47, 5, {}, None, None, "random"),
+    ("r6i_nv12_iyu1_up_bilinear", "NV12", 64, 36, "IYU1", 100, 50, LIN, None, None, "random"),
+    ("r6i_iyu1_bgra_down_lanczos", "IYU1", 64, 36, "BGRA", 32, 20, LAN, None, None, "random"),
+    ("r6i_iyu1_i420_10le_down_lanczos", "IYU1", 64, 36, "I420_10LE", 32, 20, LAN, None, None, "random"),
+    ("r6i_p010_iyu1_down_bilinear", "P010_10LE", 64, 36, "IYU1", 30, 20, LIN, None, None, "random"),
+    ("r6i_iyu1_self_down_bilinear", "IYU1", 64, 36, "IYU1", 32, 20, LIN, None, None, "random"),
+    ("r6i_iyu1_self_up_cubic", "IYU1", 33, 17, "IYU1", 50, 31, dict(resampler_method="cubic"), None, None, "random"),
+    ("r6i_bgra_iyu1_bayer_q8", "BGRA", 36, 19, "IYU1", 36, 19, dict(dither_method="bayer", dither_quantization=8), None, None, "random"),
+    ("r6i_bgra_iyu1_sierra_q16", "BGRA", 36, 19, "IYU1", 36, 19, dict(dither_method="sierra-lite", dither_quantization=16), None, None, "random"),
+    ("r6i_iyu1_bgra_gamma_remap", "IYU1", 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"),
+    ("r6i_iyu1_bgra_alpha_set", "IYU1", 40, 8, "BGRA", 40, 8, dict(alpha_mode="set", alpha_value=0.3), None, None, "random"),
+    ("r6i_iyu1_gray8", "IYU1", 40, 8, "GRAY8", 40, 8, {}, None, None, "random"),
+    ("r6i_iyu1_bgra_1920x4", "IYU1", 1920, 4, "BGRA", 1920, 4, {}, None, None, "random"),
+    ("r6i_bgra_iyu1_1918x4", "BGRA", 1918, 4, "IYU1", 1918, 4, {}, None, None, "random")]
+
 # the reference's own v210 fastpaths between v210 and the 8-bit 4:2:0 / 4:2:2 formats (video_v210_fast.h): samples shifted, not widened; group tails
 # (widths 6 k + 1 .. 5), the odd last line of a 4:2:0 frame, one-pixel frames
 VIDEO_CASES += [("v210fast_%s_%s_%dx%d" % (a.lower(), b.lower(), w, h), a, w, h, b, w, h, {}, None, None, "random")
@@ -1431,6 +1470,9 @@ VIDEO_REFUSED = [
     # the reference's 64-bit unpackers step x * 8 on a guint16 pointer (video-format.c:2483 ...): a horizontal source crop starts at pixel 2 x
     ("RGBA64_LE", 48, 30, "BGRA", 30, 20, dict(src_x=10, src_y=3, src_width=30, src_height=20)),         # ... and past the row's end from x = 10 on
     ("ARGB64_BE", 48, 30, "ARGB64", 30, 20, dict(src_x=12, src_width=30, src_height=20)),
+    # IYU1: whole frames (unpack_IYU1 steps a horizontal offset by x * 4 bytes inside six-byte groups; rectangles and borders in such frames are not built)
+    ("IYU1", 48, 30, "BGRA", 32, 20, dict(src_x=8, src_y=3, src_width=32, src_height=20)),
+    ("BGRA", 32, 20, "IYU1", 48, 30, dict(dest_x=8, dest_y=4, dest_width=32, dest_height=20)),
 ]
 
 # Conversions for which the REFERENCE's own output is undefined - it reads lines it has not converted, converts a repeated line once per

@@ -65,7 +65,7 @@ def test_staged_reference_equals_the_one_step_reference(emu_lib, ref, seed):
         if not eq:
             bad.append((case, text, why))
     assert not bad, bad[:5]
-    assert same >= 120, same
+    assert same >= 100, same          # (a floor on how many draws the check covered; it moves with the format pool the draws come from)
 
 
 def _seed_list(spec):

@@ -56,6 +56,13 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_NV21, "NV21", true, false, 2, UNPACK_SEMI, 1, 1, 0, 1, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_Y41B, "Y41B", true, false, 3, UNPACK_PLANAR_H4, 2, 0, 1, 2, {0, 0, 0, 0}},          /* unpack_Y41B / pack_Y41B video-format.c:923-1006 */
   {GSTAMD_VIDEO_FORMAT_IYU1, "IYU1", true, false, 1, UNPACK_PACKED411, 2, 0, 0, 0, {0, 0, 0, 0}},          /* unpack_IYU1 / pack_IYU1 video-format.c:2368-2470 */
+  /* unpack / pack_GRAY10_LE32, _NV12_10LE32, _NV16_10LE32 (video-format.c:5490-5868): three 10-bit samples per little-endian word */
+  {GSTAMD_VIDEO_FORMAT_GRAY10_LE32, "GRAY10_LE32", true, false, 1, UNPACK_GRAY_LE32, 0, 0, 0, 0, {0, 0, 0, 0}, 13},
+  {GSTAMD_VIDEO_FORMAT_NV12_10LE32, "NV12_10LE32", true, false, 2, UNPACK_SEMI_LE32, 1, 1, 1, 0, {0, 0, 0, 0}, 13},
+  {GSTAMD_VIDEO_FORMAT_NV16_10LE32, "NV16_10LE32", true, false, 2, UNPACK_SEMI_LE32, 1, 0, 1, 0, {0, 0, 0, 0}, 13},
+  /* unpack / pack_NV12_10LE40, _NV16_10LE40 (video-format.c:5868-6200): sample n at bit 10 n of the row's little-endian byte stream */
+  {GSTAMD_VIDEO_FORMAT_NV12_10LE40, "NV12_10LE40", true, false, 2, UNPACK_SEMI_LE40, 1, 1, 1, 0, {0, 0, 0, 0}, 14},
+  {GSTAMD_VIDEO_FORMAT_NV16_10LE40, "NV16_10LE40", true, false, 2, UNPACK_SEMI_LE40, 1, 0, 1, 0, {0, 0, 0, 0}, 14},
   {GSTAMD_VIDEO_FORMAT_AV12, "AV12", true, true, 3, UNPACK_SEMI_A, 1, 1, 1, 0, {0, 0, 0, 0}},          /* unpack_AV12 / pack_AV12 video-format.c: NV12 + an alpha plane */
   {GSTAMD_VIDEO_FORMAT_NV16, "NV16", true, false, 2, UNPACK_SEMI, 1, 0, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV61, "NV61", true, false, 2, UNPACK_SEMI, 1, 0, 0, 1, {0, 0, 0, 0}},
@@ -292,6 +299,30 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->offset[2] = info->offset[1] * 2;
       info->size = (uint64_t) info->stride[0] * h * 3;
       break;
+    case GSTAMD_VIDEO_FORMAT_GRAY10_LE32:       /* video-info.c:1327-1348 */
+      info->stride[0] = (width + 2) / 3 * 4;
+      info->size = (uint64_t) info->stride[0] * round_up (height, 2);
+      break;
+    case GSTAMD_VIDEO_FORMAT_NV12_10LE32:
+      info->stride[0] = info->stride[1] = (width + 2) / 3 * 4;
+      info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
+      info->size = info->offset[1] + (uint64_t) info->stride[0] * (round_up (height, 2) / 2);
+      break;
+    case GSTAMD_VIDEO_FORMAT_NV16_10LE32:
+      info->stride[0] = info->stride[1] = (width + 2) / 3 * 4;
+      info->offset[1] = (uint64_t) info->stride[0] * height;
+      info->size = (uint64_t) info->stride[0] * height * 2;
+      break;
+    case GSTAMD_VIDEO_FORMAT_NV12_10LE40:       /* video-info.c:1349-1365 */
+      info->stride[0] = info->stride[1] = ((width * 5 >> 2) + 4) / 5 * 5;
+      info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
+      info->size = info->offset[1] + (uint64_t) info->stride[0] * (round_up (height, 2) / 2);
+      break;
+    case GSTAMD_VIDEO_FORMAT_NV16_10LE40:
+      info->stride[0] = info->stride[1] = ((width * 5 >> 2) + 4) / 5 * 5;
+      info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
+      info->size = info->offset[1] * 2;
+      break;
     case GSTAMD_VIDEO_FORMAT_IYU1:              /* video-info.c:965-970 */
       info->stride[0] = round_up (round_up (width, 4) + round_up (width, 4) / 2, 4);
       info->size = (uint64_t) info->stride[0] * height;
@@ -445,7 +476,7 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->size = w * 4 * h;
       break;
   }
-  if (f->kind == UNPACK_GRAY || f->kind == UNPACK_GRAY16) {         /* set_default_colorimetry (video-info.c:175-176): DEFAULT_GRAY = 0 .. 255, bt601, unknown, unknown */
+  if (f->kind == UNPACK_GRAY || f->kind == UNPACK_GRAY16 || f->kind == UNPACK_GRAY_LE32) {         /* set_default_colorimetry (video-info.c:175-176): DEFAULT_GRAY = 0 .. 255, bt601, unknown, unknown */
     info->color_range = GSTAMD_COLOR_RANGE_0_255;
     info->color_matrix = GSTAMD_COLOR_MATRIX_BT601;
     info->chroma_site = GSTAMD_CHROMA_SITE_UNKNOWN;
@@ -2162,6 +2193,12 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
     return (uint64_t) ((w + 5) / 6) * 16 * h;
   if (f->kind == UNPACK_PACKED411)
     return (uint64_t) ((w + 3) / 4) * 6 * h;
+  if (f->kind == UNPACK_GRAY_LE32)
+    return (uint64_t) ((w + 2) / 3) * 4 * h;
+  if (f->kind == UNPACK_SEMI_LE40)
+    return (uint64_t) ((10 * (uint64_t) w + 7) / 8) * h + (uint64_t) ((20 * (((uint64_t) w + 1) / 2) + 7) / 8) * ((h + (1 << f->h_sub) - 1) >> f->h_sub);
+  if (f->kind == UNPACK_SEMI_LE32)
+    return (uint64_t) ((w + 2) / 3) * 4 * (h + ((h + (1 << f->h_sub) - 1) >> f->h_sub));
   const uint64_t cw = ((uint64_t) w + (1 << f->w_sub) - 1) >> f->w_sub, ch = ((uint64_t) h + (1 << f->h_sub) - 1) >> f->h_sub;
   const uint64_t n = (uint64_t) w * h + 2 * cw * ch + (GSTAMD_KIND_ALPHA_PLANE (f->kind) >= 0 ? (uint64_t) w * h : 0);
   return f->hi_depth ? 2 * n : n;
@@ -2218,7 +2255,8 @@ static int plan_gamma (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out, Vi
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
   const bool in16 = fi->hi_depth != 0, out16 = fo->hi_depth != 0;
-  if (out16 && !kind_has_planes (fo->kind) && fo->kind != UNPACK_PLANAR_A && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && !GSTAMD_KIND_PX16 (fo->kind) && fo->kind != UNPACK_V210)
+  if (out16 && !kind_has_planes (fo->kind) && fo->kind != UNPACK_PLANAR_A && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && !GSTAMD_KIND_PX16 (fo->kind) && fo->kind != UNPACK_V210 &&
+      !GSTAMD_KIND_LE32 (fo->kind))
     return fail (GSTAMD_ERR_UNSUPPORTED, "10-bit destination layout not implemented on the GPU path");
   /* a 10 / 12 / 16-bit planar SOURCE: the 16-bit front (unpack + chroma upsampler, k_front16) of the conversion into an AYUV64 frame of
    * the same size - planned like any other conversion, its front / pair table taken over */
@@ -2716,7 +2754,8 @@ static int finalize_deep_out (const GstAmdVideoInfo *in, const GstAmdVideoInfo *
   const GstAmdVideoConverterConfig &cfg = plan->config;
   const FormatDesc *fi = plan->fin, *fo = plan->fout;
   GammaPlan &g = plan->gamma;
-  if (!kind_has_planes (fo->kind) && fo->kind != UNPACK_PLANAR_A && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && !GSTAMD_KIND_PX16 (fo->kind) && fo->kind != UNPACK_V210) {
+  if (!kind_has_planes (fo->kind) && fo->kind != UNPACK_PLANAR_A && fo->hi_depth != 3 && fo->kind != UNPACK_P422_16 && !GSTAMD_KIND_PX16 (fo->kind) && fo->kind != UNPACK_V210 &&
+      !GSTAMD_KIND_LE32 (fo->kind)) {
     if (error)
       *error = "10-bit destination layout not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
@@ -3645,7 +3684,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     rc.border[1] = (uint8_t) r;
     rc.border[2] = (uint8_t) g;
     rc.border[3] = (uint8_t) b;
-    if (fo->yuv && fo->kind != UNPACK_GRAY && fo->kind != UNPACK_GRAY16) {          /* GST_VIDEO_INFO_IS_YUV: a GRAY8 frame keeps the ARGB bytes, pack_GRAY8 then stores R */
+    if (fo->yuv && fo->kind != UNPACK_GRAY && fo->kind != UNPACK_GRAY16 && fo->kind != UNPACK_GRAY_LE32) {          /* GST_VIDEO_INFO_IS_YUV: a GRAY8 frame keeps the ARGB bytes, pack_GRAY8 then stores R */
       /* identity -> compute_matrix_to_YUV (force) -> rint; then 16 / 128 / 128 are added whatever the range */
       M44 dm;
       m_identity (dm);
@@ -3692,6 +3731,24 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   if (is_field && fi && fo && (fi->kind == UNPACK_PACKED411 || fo->kind == UNPACK_PACKED411)) {
     if (error)
       *error = "interlaced IYU1 frames are not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  /* the 10LE32 formats: whole frames (unpack_NV12_10LE32 & co skip the pixels left of x but keep writing from the line's first slot on, video-format.c:5620,
+     5646-5655); a source whose width is 6 n + 3 makes the unpacker read the chroma word AFTER its row for the last pixel's V - past the plane in the last row */
+  if (fi && fo && ((GSTAMD_KIND_LE32 (fi->kind) && (rc.in_x || rc.in_y || ein.width != rc.in_maxw || ein.height != rc.in_maxh)) ||
+          (GSTAMD_KIND_LE32 (fo->kind) && (rc.out_x || rc.out_y || rc.fill || eout.width != rc.out_maxw || eout.height != rc.out_maxh)))) {
+    if (error)
+      *error = "source crops and destination rectangles on frames with three 10-bit samples per 32-bit word (GRAY10_LE32, NV12_10LE32, NV16_10LE32) are not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  if (fi && fi->kind == UNPACK_SEMI_LE32 && (rc.in_maxw % 6) == 3) {
+    if (error)
+      *error = "NV12_10LE32 / NV16_10LE32 sources of width 6 n + 3: the reference's unpacker reads the word after the chroma row for the last pixel (past the plane in the last row); not reproduced";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  if (is_field && fi && fo && (GSTAMD_KIND_LE32 (fi->kind) || GSTAMD_KIND_LE32 (fo->kind))) {
+    if (error)
+      *error = "interlaced frames with three 10-bit samples per 32-bit word are not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
   }
   /* unpack_RGBA64_LE and its seven siblings advance a guint16 pointer by x * 8 (video-format.c:2483, 2532 ...): 16 bytes per pixel of a horizontal

@@ -36,6 +36,24 @@ GSTAMD_HD uint32_t y410_word (int hi_depth, uint32_t w)
   return hi_depth == 27 ? (w >> 24) | ((w >> 8) & 0xff00u) | ((w << 8) & 0xff0000u) | (w << 24) : w;
 }
 
+// sample n of a row that holds three 10-bit samples per little-endian 32-bit word (unpack_GRAY10_LE32 / _NV12_10LE32, video-format.c:5490-5660), widened
+// like every 10-bit sample: (v << 6) | (v >> 4)
+GSTAMD_HD int le32_sample (const uint8_t *row, int n)
+{
+  const uint32_t w = ((const uint32_t *) row)[n / 3];
+  const int t = (int) ((w >> (10 * (n % 3))) & 0x3ffu) << 6;
+  return t | (t >> 10);
+}
+
+// sample n of a row that is a little-endian stream of 10-bit samples (unpack_NV12_10LE40 video-format.c:6023-6098: four samples in five bytes), widened
+GSTAMD_HD int le40_sample (const uint8_t *row, int n)
+{
+  const int bit = 10 * n;
+  const uint32_t v = (uint32_t) row[bit >> 3] | ((uint32_t) row[(bit >> 3) + 1] << 8);
+  const int t = (int) ((v >> (bit & 7)) & 0x3ffu) << 6;
+  return t | (t >> 10);
+}
+
 // one 10-bit field of a Y410 word (unpack_Y410 video-format.c:863-896): (field << 6) | (field >> 4)
 GSTAMD_HD int y410_field (uint32_t w, int shift)
 {
@@ -58,8 +76,16 @@ GSTAMD_HD UV deep_load_uv (const FrontParams &f, const Planes &pl, int crow, int
     const uint16_t *p = (const uint16_t *) (pl.p[0] + (ptrdiff_t) crow * pl.stride[0]) + 4 * k;
     r.u = px16_load (f.hi_depth, p[f.pos[2]]);
     r.v = px16_load (f.hi_depth, p[f.pos[3]]);
-  } else if (f.kind == UNPACK_GRAY16) {
+  } else if (f.kind == UNPACK_GRAY16 || f.kind == UNPACK_GRAY_LE32) {
     r.u = r.v = 0x8000;
+  } else if (f.kind == UNPACK_SEMI_LE32) { // the UV plane's samples run U0 V0 U1 V1 ...: pair k at samples 2 k, 2 k + 1
+    const uint8_t *row = pl.p[1] + (ptrdiff_t) crow * pl.stride[1];
+    r.u = le32_sample (row, 2 * k);
+    r.v = le32_sample (row, 2 * k + 1);
+  } else if (f.kind == UNPACK_SEMI_LE40) {
+    const uint8_t *row = pl.p[1] + (ptrdiff_t) crow * pl.stride[1];
+    r.u = le40_sample (row, 2 * k);
+    r.v = le40_sample (row, 2 * k + 1);
   } else if (f.kind == UNPACK_V210) {     // unpack_v210 (video-format.c:560-649): chroma pair k of the line, pair k % 3 of group k / 3
     const uint32_t *g = (const uint32_t *) (pl.p[0] + (ptrdiff_t) crow * pl.stride[0]) + 4 * (k / 3);
     const int j = k % 3;
@@ -124,6 +150,10 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
   } else if (f.kind == UNPACK_GRAY16) {
     const int raw = ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x];
     c1 = f.hi_depth == 9 || f.hi_depth == 10 ? px16_word (f.hi_depth, raw) : deep_widen (f.hi_depth, raw);         /* GRAY16_LE / _BE, GRAY10_LE16 */
+  } else if (f.kind == UNPACK_SEMI_LE40) {
+    c1 = le40_sample (pl.p[0] + (ptrdiff_t) y * pl.stride[0], x);
+  } else if (GSTAMD_KIND_LE32 (f.kind)) {
+    c1 = le32_sample (pl.p[0] + (ptrdiff_t) y * pl.stride[0], x);
   } else if (f.kind == UNPACK_V210) {   // luma j of the group: words 0 1 1 2 3 3 at bit 10 0 20 10 0 20
     const uint32_t *g = (const uint32_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]) + 4 * (x / 6);
     const int j = x % 6;
@@ -814,12 +844,157 @@ GSTAMD_HD void pack16_down_h_px (const PackPlanarParams &pk, uint8_t *img, int s
   ra[x].y = (uint32_t) u | ((uint32_t) v << 16);
 }
 
+// GRAY10_LE32 / NV12_10LE32 / NV16_10LE32 destinations (pack_GRAY10_LE32 / _NV12_10LE32 / _NV16_10LE32, video-format.c:5539-5868): a lane per SIX pixels
+// (two luma words, the chroma pairs 3 u .. 3 u + 2 = the two UV words U V U | V U V) of the lines (yb << h_sub) ..  The stages are pack16_body's.  Which
+// words the reference writes at a line's end: the first UV word of a group whenever the group has a pixel, the second when it has four or more (with three
+// the pixel's V stays in the packer's local - that word is not written); missing samples are zero bits.
+GSTAMD_HD void pack16_le32_body (const PackPlanarParams &pk, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride, const DstPlanes16 &d, int unit, int yb)
+{
+  const int w = pk.width, h = pk.height, x0 = 6 * unit, y0 = yb << pk.h_sub;
+  if (x0 >= w || y0 >= h)
+    return;
+  const int nlines = 1 << pk.h_sub;
+  const uint2 *ra = (const uint2 *) (src + (size_t) y0 * sstride);
+  const uint2 *rb = (const uint2 *) (src + (size_t) (y0 + 1 < h ? y0 + 1 : h - 1) * sstride);
+  for (int r = 0; r < nlines; r++) {
+    const int y = y0 + r;
+    if (y >= h)
+      break;
+    const uint2 *pr = r ? rb : ra;
+    uint32_t *dy = (uint32_t *) (d.p[0] + (size_t) y * d.stride[0]) + 2 * unit;
+    for (int wd = 0; wd < 2 && x0 + 3 * wd < w; wd++) {
+      uint32_t Y = 0;
+      for (int c = 0; c < 3 && x0 + 3 * wd + c < w; c++)
+        Y |= ((uint32_t) dither16_comp (dt, 1, (int) (pr[x0 + 3 * wd + c].x >> 16), x0 + 3 * wd + c, y) >> 6) << (10 * c);
+      dy[wd] = Y;
+    }
+  }
+  if (pk.kind == UNPACK_GRAY_LE32)
+    return;
+  auto cu = [&](int i) {
+    i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
+    int u = (int) (ra[i].y & 0xffffu);
+    return pk.down_v ? (u + (int) (rb[i].y & 0xffffu) + 1) >> 1 : u;
+  };
+  auto cv = [&](int i) {
+    i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
+    int v = (int) (ra[i].y >> 16);
+    return pk.down_v ? (v + (int) (rb[i].y >> 16) + 1) >> 1 : v;
+  };
+  uint32_t s[6] = {0, 0, 0, 0, 0, 0};           // U0 V0 U1 V1 U2 V2 of the group, ten bits each
+  for (int j = 0; j < 3; j++) {
+    const int x = x0 + 2 * j;
+    if (x >= w)
+      break;
+    int u = cu (x), v = cv (x);
+    if (pk.down_h == 1) {
+      if (x + 1 < w) {
+        u = (cu (x) + cu (x + 1) + 1) >> 1;
+        v = (cv (x) + cv (x + 1) + 1) >> 1;
+      }
+    } else if (pk.down_h == 2 && w >= 2) {
+      if (x == 0) {
+        u = (3 * cu (x) + cu (x + 1) + 2) >> 2;
+        v = (3 * cv (x) + cv (x + 1) + 2) >> 2;
+      } else if (x < w - 2) {
+        u = (cu (x - 1) + 2 * cu (x) + cu (x + 1) + 2) >> 2;
+        v = (cv (x - 1) + 2 * cv (x) + cv (x + 1) + 2) >> 2;
+      } else {
+        u = (cu (x - 1) + 3 * cu (x) + 2) >> 2;
+        v = (cv (x - 1) + 3 * cv (x) + 2) >> 2;
+      }
+    }
+    s[2 * j] = (uint32_t) dither16_comp (dt, 2, u, x, y0) >> 6;
+    s[2 * j + 1] = (uint32_t) dither16_comp (dt, 3, v, x, y0) >> 6;
+  }
+  uint32_t *duv = (uint32_t *) (d.p[1] + (size_t) yb * d.stride[1]) + 2 * unit;
+  duv[0] = s[0] | (s[1] << 10) | (s[2] << 20);
+  if (w - x0 >= 4)
+    duv[1] = s[3] | (s[4] << 10) | (s[5] << 20);
+}
+
+// NV12_10LE40 / NV16_10LE40 destinations (pack_NV12_10LE40 / _NV16_10LE40, video-format.c:5946-6200): the four-pixel block is five bytes of the luma row and
+// (two chroma pairs = four samples) five bytes of the UV row; a line's last block holds what its pixels need, zero bits above them (m samples: the
+// bytes their 10 m bits reach into)
+GSTAMD_HD void pack16_le40_body (const PackPlanarParams &pk, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride, const DstPlanes16 &d, int x0, int yb)
+{
+  const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
+  if (x0 >= w || y0 >= h)
+    return;
+  const int nlines = 1 << pk.h_sub;
+  const uint2 *ra = (const uint2 *) (src + (size_t) y0 * sstride);
+  const uint2 *rb = (const uint2 *) (src + (size_t) (y0 + 1 < h ? y0 + 1 : h - 1) * sstride);
+  auto put = [](uint8_t *q, unsigned long long bits, int n_samples) {
+    const int nb = (10 * n_samples + 7) >> 3;
+    for (int i = 0; i < nb; i++)
+      q[i] = (uint8_t) (bits >> (8 * i));
+  };
+  for (int r = 0; r < nlines; r++) {
+    const int y = y0 + r;
+    if (y >= h)
+      break;
+    const uint2 *pr = r ? rb : ra;
+    unsigned long long bits = 0;
+    int m = 0;
+    for (; m < 4 && x0 + m < w; m++)
+      bits |= (unsigned long long) ((uint32_t) dither16_comp (dt, 1, (int) (pr[x0 + m].x >> 16), x0 + m, y) >> 6) << (10 * m);
+    put (d.p[0] + (size_t) y * d.stride[0] + 5 * (size_t) (x0 >> 2), bits, m);
+  }
+  auto cu = [&](int i) {
+    i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
+    int u = (int) (ra[i].y & 0xffffu);
+    return pk.down_v ? (u + (int) (rb[i].y & 0xffffu) + 1) >> 1 : u;
+  };
+  auto cv = [&](int i) {
+    i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
+    int v = (int) (ra[i].y >> 16);
+    return pk.down_v ? (v + (int) (rb[i].y >> 16) + 1) >> 1 : v;
+  };
+  unsigned long long bits = 0;
+  int ns = 0;
+  for (int j = 0; j < 2; j++) {
+    const int x = x0 + 2 * j;
+    if (x >= w)
+      break;
+    int u = cu (x), v = cv (x);
+    if (pk.down_h == 1) {
+      if (x + 1 < w) {
+        u = (cu (x) + cu (x + 1) + 1) >> 1;
+        v = (cv (x) + cv (x + 1) + 1) >> 1;
+      }
+    } else if (pk.down_h == 2 && w >= 2) {
+      if (x == 0) {
+        u = (3 * cu (x) + cu (x + 1) + 2) >> 2;
+        v = (3 * cv (x) + cv (x + 1) + 2) >> 2;
+      } else if (x < w - 2) {
+        u = (cu (x - 1) + 2 * cu (x) + cu (x + 1) + 2) >> 2;
+        v = (cv (x - 1) + 2 * cv (x) + cv (x + 1) + 2) >> 2;
+      } else {
+        u = (cu (x - 1) + 3 * cu (x) + 2) >> 2;
+        v = (cv (x - 1) + 3 * cv (x) + 2) >> 2;
+      }
+    }
+    bits |= (unsigned long long) ((uint32_t) dither16_comp (dt, 2, u, x, y0) >> 6) << (10 * ns);
+    bits |= (unsigned long long) ((uint32_t) dither16_comp (dt, 3, v, x, y0) >> 6) << (10 * ns + 10);
+    ns += 2;
+  }
+  put (d.p[1] + (size_t) yb * d.stride[1] + 5 * (size_t) (x0 >> 2), bits, ns);
+}
+
 // per-lane block as pack_planar_body: pixels x0 .. x0+3 of the lines (yb << h_sub) ..; planar and semi-planar kinds
 GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride,
     const DstPlanes16 &d, int x0, int yb)
 {
   const int w = pk.width, h = pk.height;
   const int y0 = yb << pk.h_sub;
+  if (pk.kind == UNPACK_SEMI_LE40) {
+    pack16_le40_body (pk, dt, src, sstride, d, x0, yb);
+    return;
+  }
+  if (GSTAMD_KIND_LE32 (pk.kind)) {          /* this grid's lane x0 / 4 is group x0 / 4 of those formats (more lanes than groups) */
+    pack16_le32_body (pk, dt, src, sstride, d, x0 >> 2, yb);
+    return;
+  }
   if (x0 >= w || y0 >= h)
     return;
   const int nlines = 1 << pk.h_sub;

@@ -74,6 +74,11 @@ enum {
   GSTAMD_VIDEO_FORMAT_NV24 = 52,
   GSTAMD_VIDEO_FORMAT_A420 = 34,        /* I420 with a fourth, full-size plane of alpha */
   GSTAMD_VIDEO_FORMAT_IYU1 = 38,        /* packed 4:1:1: six bytes U Y0 Y1 V Y2 Y3 per group of four pixels */
+  GSTAMD_VIDEO_FORMAT_GRAY10_LE32 = 78, /* one plane of luma, three 10-bit samples per little-endian 32-bit word (2 bits of padding on top) */
+  GSTAMD_VIDEO_FORMAT_NV12_10LE32 = 79, /* NV12 with both planes packed that way (the UV plane: U V U | V U V) */
+  GSTAMD_VIDEO_FORMAT_NV16_10LE32 = 80, /* NV16 likewise */
+  GSTAMD_VIDEO_FORMAT_NV12_10LE40 = 81, /* NV12 with fully packed 10-bit samples: a little-endian bit stream, four samples in five bytes */
+  GSTAMD_VIDEO_FORMAT_NV16_10LE40 = 139,/* NV16 likewise */
   GSTAMD_VIDEO_FORMAT_v216 = 22,        /* packed 4:2:2, little-endian 16-bit words U Y0 V Y1 */
   GSTAMD_VIDEO_FORMAT_r210 = 41,        /* one big-endian 32-bit word per pixel: x 2, R 10, G 10, B 10 */
   GSTAMD_VIDEO_FORMAT_GRAY10_LE16 = 138,/* one plane of luma, 10 bits in the low bits of little-endian words */

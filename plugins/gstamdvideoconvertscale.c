@@ -39,7 +39,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #define AMD_OUT_FORMATS AMD_IN_FORMATS
 /* (RGBP / BGRP 1.20, RBGA / A422 / A444 / GBR_16LE / Y216_LE / Y416_LE later: taken together where the headers are the reference's own) */
 #if GST_CHECK_VERSION (1, 28, 0)
-#define AMD_128_FORMATS ", BGR10x2_LE, RGB10x2_LE"
+#define AMD_128_FORMATS ", BGR10x2_LE, RGB10x2_LE, NV16_10LE40"
 #else
 #define AMD_128_FORMATS ""
 #endif
@@ -50,15 +50,15 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #define AMD_NEWEST_FORMATS ""
 #endif
 #if GST_CHECK_VERSION (1, 20, 0)
-#define AMD_NEWER_FORMATS ", VUYA, Y210, Y410, BGR10A2_LE, P012_LE, P016_LE, Y444_16LE, Y212_LE, RGB10A2_LE, ARGB64_LE, ARGB64_BE, RGBA64_LE, RGBA64_BE, BGRA64_LE, BGRA64_BE, ABGR64_LE, ABGR64_BE"
+#define AMD_NEWER_FORMATS ", NV12_10LE40, VUYA, Y210, Y410, BGR10A2_LE, P012_LE, P016_LE, Y444_16LE, Y212_LE, RGB10A2_LE, ARGB64_LE, ARGB64_BE, RGBA64_LE, RGBA64_BE, BGRA64_LE, BGRA64_BE, ABGR64_LE, ABGR64_BE"
 #elif GST_CHECK_VERSION (1, 18, 0)
-#define AMD_NEWER_FORMATS ", VUYA, Y210, Y410, BGR10A2_LE, P012_LE, P016_LE, Y444_16LE, Y212_LE, RGB10A2_LE"
+#define AMD_NEWER_FORMATS ", NV12_10LE40, VUYA, Y210, Y410, BGR10A2_LE, P012_LE, P016_LE, Y444_16LE, Y212_LE, RGB10A2_LE"
 #elif GST_CHECK_VERSION (1, 16, 0)
-#define AMD_NEWER_FORMATS ", VUYA, Y210, Y410, BGR10A2_LE"
+#define AMD_NEWER_FORMATS ", NV12_10LE40, VUYA, Y210, Y410, BGR10A2_LE"
 #else
 #define AMD_NEWER_FORMATS ""
 #endif
-#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y41B, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, IYU1, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210, v216, r210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y41B, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, IYU1, GRAY10_LE32, NV12_10LE32, NV16_10LE32, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210, v216, r210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
 
 /* progressive, interleaved and mixed content (caps without the field are progressive by definition).  An interleaved frame - every frame of
  * interlace-mode=interleaved, the buffers flagged GST_VIDEO_BUFFER_FLAG_INTERLACED of interlace-mode=mixed, which is what gst_video_frame_map makes
@@ -828,6 +828,8 @@ gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_P010_10LE, GSTAMD_VIDEO_FORMAT_P010_10LE}, {GST_VIDEO_FORMAT_I420_10LE, GSTAMD_VIDEO_FORMAT_I420_10LE},
     {GST_VIDEO_FORMAT_ARGB64, GSTAMD_VIDEO_FORMAT_ARGB64}, {GST_VIDEO_FORMAT_AYUV64, GSTAMD_VIDEO_FORMAT_AYUV64},
     {GST_VIDEO_FORMAT_v308, GSTAMD_VIDEO_FORMAT_v308}, {GST_VIDEO_FORMAT_IYU2, GSTAMD_VIDEO_FORMAT_IYU2}, {GST_VIDEO_FORMAT_IYU1, GSTAMD_VIDEO_FORMAT_IYU1},
+    {GST_VIDEO_FORMAT_GRAY10_LE32, GSTAMD_VIDEO_FORMAT_GRAY10_LE32}, {GST_VIDEO_FORMAT_NV12_10LE32, GSTAMD_VIDEO_FORMAT_NV12_10LE32},
+    {GST_VIDEO_FORMAT_NV16_10LE32, GSTAMD_VIDEO_FORMAT_NV16_10LE32},
     {GST_VIDEO_FORMAT_GRAY8, GSTAMD_VIDEO_FORMAT_GRAY8}, {GST_VIDEO_FORMAT_GBR, GSTAMD_VIDEO_FORMAT_GBR}, {GST_VIDEO_FORMAT_v210, GSTAMD_VIDEO_FORMAT_v210},
     {GST_VIDEO_FORMAT_I422_10LE, GSTAMD_VIDEO_FORMAT_I422_10LE}, {GST_VIDEO_FORMAT_Y444_10LE, GSTAMD_VIDEO_FORMAT_Y444_10LE},
     {GST_VIDEO_FORMAT_I420_12LE, GSTAMD_VIDEO_FORMAT_I420_12LE}, {GST_VIDEO_FORMAT_I422_12LE, GSTAMD_VIDEO_FORMAT_I422_12LE},
@@ -881,7 +883,7 @@ gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
      * against have them (plugins/build.py also type-checks every element against the reference's own 1.29 headers) */
 #if GST_CHECK_VERSION (1, 16, 0)
     {GST_VIDEO_FORMAT_VUYA, GSTAMD_VIDEO_FORMAT_VUYA}, {GST_VIDEO_FORMAT_Y210, GSTAMD_VIDEO_FORMAT_Y210}, {GST_VIDEO_FORMAT_Y410, GSTAMD_VIDEO_FORMAT_Y410},
-    {GST_VIDEO_FORMAT_BGR10A2_LE, GSTAMD_VIDEO_FORMAT_BGR10A2_LE},
+    {GST_VIDEO_FORMAT_BGR10A2_LE, GSTAMD_VIDEO_FORMAT_BGR10A2_LE}, {GST_VIDEO_FORMAT_NV12_10LE40, GSTAMD_VIDEO_FORMAT_NV12_10LE40},
 #endif
 #if GST_CHECK_VERSION (1, 18, 0)
     {GST_VIDEO_FORMAT_P012_LE, GSTAMD_VIDEO_FORMAT_P012_LE}, {GST_VIDEO_FORMAT_P016_LE, GSTAMD_VIDEO_FORMAT_P016_LE},
@@ -890,6 +892,7 @@ gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
 #endif
 #if GST_CHECK_VERSION (1, 28, 0)
     {GST_VIDEO_FORMAT_BGR10x2_LE, GSTAMD_VIDEO_FORMAT_BGR10x2_LE}, {GST_VIDEO_FORMAT_RGB10x2_LE, GSTAMD_VIDEO_FORMAT_RGB10x2_LE},
+    {GST_VIDEO_FORMAT_NV16_10LE40, GSTAMD_VIDEO_FORMAT_NV16_10LE40},
 #endif
 #if GST_CHECK_VERSION (1, 20, 0)
     {GST_VIDEO_FORMAT_ARGB64_LE, GSTAMD_VIDEO_FORMAT_ARGB64_LE}, {GST_VIDEO_FORMAT_ARGB64_BE, GSTAMD_VIDEO_FORMAT_ARGB64_BE},

@@ -81,6 +81,14 @@ def visible_planes(fmt, w, h):
         return [(4 * up2(w), h)]         # whole macropixels; visible_bytes blanks the unused luma slot of an odd last pixel
     if fmt in ("RGB", "BGR", "v308", "IYU2"):
         return [(3 * w, h)]
+    if fmt == "GRAY10_LE32":
+        return [((w + 2) // 3 * 4, h)]
+    if fmt == "NV12_10LE32":
+        return [((w + 2) // 3 * 4, h), ((w + 2) // 3 * 4, up2(h))]      # visible_bytes blanks the chroma word a width of 6 n + 3 leaves unwritten
+    if fmt == "NV16_10LE32":
+        return [((w + 2) // 3 * 4, h), ((w + 2) // 3 * 4, h)]
+    if fmt in ("NV12_10LE40", "NV16_10LE40"):
+        return [((10 * w + 7) // 8, h), ((20 * ((w + 1) // 2) + 7) // 8, up2(h) if fmt == "NV12_10LE40" else h)]
     if fmt == "IYU1":
         return [(6 * ((w + 3) // 4), h)]  # whole groups U Y0 Y1 V Y2 Y3; visible_bytes blanks the luma slots of pixels past the width
     # 16-bit samples: the same shapes with two bytes a sample (found late in round 4: without these rows a frame with pitch padding was compared
@@ -115,6 +123,9 @@ def visible_bytes(fmt, w, h, strides, offsets, buf):
         if fmt in ("YUY2", "UYVY", "YVYU", "VYUY") and w % 2:
             plane = plane.copy()
             plane[:, 2 * (w - 1) + (2 if fmt in ("YUY2", "YVYU") else 3)] = 0      # second luma slot of the last macropixel
+        if fmt in ("NV12_10LE32", "NV16_10LE32") and i == 1 and w % 6 == 3:
+            plane = plane.copy()
+            plane[:, 4 * (2 * (w // 6) + 1):] = 0                                   # pack_NV12_10LE32: the last pixel's V never leaves the packer's local
         if fmt == "IYU1" and w % 4:
             plane = plane.copy()
             for j in range(w % 4, 4):                                               # pack_IYU1 writes the lumas of the pixels that exist
@@ -1399,6 +1410,33 @@ VIDEO_CASES += [c for f, g in (("BGR10x2_LE", "BGR10A2_LE"), ("RGB10x2_LE", "RGB
     ("r6x_argb64_%s_floyd" % f.lower(), "ARGB64", 36, 19, f, 36, 19, dict(dither_method="floyd-steinberg"), None, None, "random"),
     ("r6x_%s_bgra_gamma_remap" % f.lower(), f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"))]
 
+# round 6: GRAY10_LE32 / NV12_10LE32 / NV16_10LE32 (three 10-bit samples per little-endian 32-bit word) and NV12_10LE40 / NV16_10LE40 (a little-endian stream of
+# 10-bit samples); whole frames; every width modulo 6 and modulo 4 as a destination
+VIDEO_CASES += [c for f in ("GRAY10_LE32", "NV12_10LE32", "NV16_10LE32", "NV12_10LE40", "NV16_10LE40") for c in (
+    ("r6w_%s_bgra_36x6" % f.lower(), f, 36, 6, "BGRA", 36, 6, {}, None, None, "random"),
+    ("r6w_%s_bgra_37x7" % f.lower(), f, 37, 7, "BGRA", 37, 7, {}, None, None, "random"),
+    ("r6w_%s_ayuv64_38x5" % f.lower(), f, 38, 5, "AYUV64", 38, 5, {}, None, None, "random"),
+    ("r6w_%s_p010_40x6" % f.lower(), f, 40, 6, "P010_10LE", 40, 6, {}, None, None, "random"),
+    ("r6w_%s_nv12_41x6_cosited" % f.lower(), f, 41, 6, "NV12", 41, 6, {}, None, "cosited", "random"),
+    ("r6w_%s_1x1" % f.lower(), f, 1, 1, "BGRA", 1, 1, {}, None, None, "random"),
+    ("r6w_bgra_%s_36x6" % f.lower(), "BGRA", 36, 6, f, 36, 6, {}, None, None, "random"),
+    ("r6w_bgra_%s_37x7" % f.lower(), "BGRA", 37, 7, f, 37, 7, {}, None, None, "random"),
+    ("r6w_bgra_%s_38x5" % f.lower(), "BGRA", 38, 5, f, 38, 5, {}, None, None, "random"),
+    ("r6w_bgra_%s_39x4" % f.lower(), "BGRA", 39, 4, f, 39, 4, {}, None, None, "random"),
+    ("r6w_bgra_%s_40x3_cosited" % f.lower(), "BGRA", 40, 3, f, 40, 3, {}, None, "cosited", "random"),
+    ("r6w_bgra_%s_41x2" % f.lower(), "BGRA", 41, 2, f, 41, 2, {}, None, None, "random"),
+    ("r6w_p010_%s_42x6" % f.lower(), "P010_10LE", 42, 6, f, 42, 6, {}, None, None, "random"),
+    ("r6w_i420_10le_%s_43x7" % f.lower(), "I420_10LE", 43, 7, f, 43, 7, {}, None, None, "random"),
+    ("r6w_%s_self_44x6" % f.lower(), f, 44, 6, f, 44, 6, {}, None, None, "random"),
+    ("r6w_nv12_%s_up_bilinear" % f.lower(), "NV12", 64, 36, f, 100, 50, LIN, None, None, "random"),
+    ("r6w_%s_i420_10le_down_lanczos" % f.lower(), f, 64, 36, "I420_10LE", 32, 20, LAN, None, None, "random"),
+    ("r6w_%s_self_down_bilinear" % f.lower(), f, 64, 36, f, 32, 20, LIN, None, None, "random"),
+    ("r6w_bgra_%s_sierra_q128" % f.lower(), "BGRA", 36, 19, f, 36, 19, dict(dither_method="sierra-lite", dither_quantization=128), None, None, "random"),
+    ("r6w_argb64_%s_bayer" % f.lower(), "ARGB64", 36, 19, f, 36, 19, dict(dither_method="bayer"), None, None, "random"),
+    ("r6w_%s_bgra_gamma_remap" % f.lower(), f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"),
+    ("r6w_%s_bgra_1920x4" % f.lower(), f, 1920, 4, "BGRA", 1920, 4, {}, None, None, "random"),
+    ("r6w_nv12_%s_1918x4" % f.lower(), "NV12", 1918, 4, f, 1918, 4, {}, None, None, "random"))]
+
 # round 6: IYU1 (packed 4:1:1, six bytes U Y0 Y1 V Y2 Y3 per four pixels): Y41B's chain on one plane; whole frames
 VIDEO_CASES += [
     ("r6i_iyu1_bgra_32x6", "IYU1", 32, 6, "BGRA", 32, 6, {}, None, None, "random"),
@@ -1470,6 +1508,14 @@ VIDEO_REFUSED = [
     # the reference's 64-bit unpackers step x * 8 on a guint16 pointer (video-format.c:2483 ...): a horizontal source crop starts at pixel 2 x
     ("RGBA64_LE", 48, 30, "BGRA", 30, 20, dict(src_x=10, src_y=3, src_width=30, src_height=20)),         # ... and past the row's end from x = 10 on
     ("ARGB64_BE", 48, 30, "ARGB64", 30, 20, dict(src_x=12, src_width=30, src_height=20)),
+    # the 10LE32 formats: whole frames; sources of width 6 n + 3 (the reference's unpacker reads the chroma word after the row)
+    ("NV12_10LE32", 48, 30, "BGRA", 30, 20, dict(src_x=6, src_y=2, src_width=30, src_height=20)),
+    ("BGRA", 30, 20, "NV16_10LE32", 48, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20)),
+    ("GRAY10_LE32", 48, 30, "GRAY8", 30, 20, dict(src_x=6, src_y=2, src_width=30, src_height=20)),
+    ("NV12_10LE32", 39, 6, "BGRA", 39, 6, {}),
+    ("NV12_10LE40", 48, 30, "BGRA", 30, 20, dict(src_x=6, src_y=2, src_width=30, src_height=20)),
+    ("BGRA", 30, 20, "NV16_10LE40", 48, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20)),
+    ("NV16_10LE32", 45, 6, "NV16_10LE32", 45, 6, {}),
     # IYU1: whole frames (unpack_IYU1 steps a horizontal offset by x * 4 bytes inside six-byte groups; rectangles and borders in such frames are not built)
     ("IYU1", 48, 30, "BGRA", 32, 20, dict(src_x=8, src_y=3, src_width=32, src_height=20)),
     ("BGRA", 32, 20, "IYU1", 48, 30, dict(dest_x=8, dest_y=4, dest_width=32, dest_height=20)),

@@ -176,7 +176,7 @@ def test_share_of_unchecked_and_refused_draws_stays_bounded(emu_lib, ref, seed, 
         if verdict == "bad":
             bad.append((case, text))
     assert count["bad"] == 0, (count, bad[:5])
-    assert count["defined-unchecked"] <= 0.03 * 1500, count
-    assert count["defined-staged"] + count["defined-masked"] >= 4 * count["defined-unchecked"], count
-    assert count["refused"] <= 0.05 * 1500, count
+    assert count["defined-unchecked"] <= 0.035 * 1500, count
+    assert count["defined-staged"] + count["defined-masked"] >= 3 * count["defined-unchecked"], count          # (floors on 1500 draws; they move with the format pool)
+    assert count["refused"] <= 0.07 * 1500, count          # (round 6: the whole-frame-only formats - IYU1, the 10LE32 / 10LE40 families - refuse every drawn crop / rectangle)
     assert count["ok"] >= 0.78 * 1500, count

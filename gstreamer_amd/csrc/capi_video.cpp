@@ -1619,8 +1619,16 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
     return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_convert422_ayuv");
   }
   if (p.deep16) {
-    if (((uintptr_t) dst % 4) != 0 || (dstride % 4) != 0 || ((uintptr_t) pl.p[0] % 2) != 0 || (pl.stride[0] % 2) != 0 || ((uintptr_t) pl.p[1] % 2) != 0 ||
-        (pl.stride[1] % 2) != 0 || (p.front.kind == UNPACK_PLANAR && (((uintptr_t) pl.p[2] % 2) != 0 || (pl.stride[2] % 2) != 0)))
+    /* (the byte-stream kinds - NV12_10LE40 & co, UYVP - are read byte by byte: rows of five-byte groups have no alignment; the three-samples-per-word
+       kinds are read as 32-bit words) */
+    const bool bytes_in = p.front.kind == UNPACK_SEMI_LE40 || p.front.kind == UNPACK_P422_UYVP;
+    const bool words_in = p.front.kind == UNPACK_SEMI_LE32 || p.front.kind == UNPACK_GRAY_LE32;
+    if (words_in && (((uintptr_t) pl.p[0] % 4) != 0 || (pl.stride[0] % 4) != 0 || (p.front.kind == UNPACK_SEMI_LE32 && (((uintptr_t) pl.p[1] % 4) != 0 || (pl.stride[1] % 4) != 0))))
+      return set_error (GSTAMD_ERR_UNSUPPORTED, "frames with three 10-bit samples per 32-bit word need 4-byte aligned planes and pitches");
+    if (((uintptr_t) dst % 4) != 0 || (dstride % 4) != 0)
+      return set_error (GSTAMD_ERR_UNSUPPORTED, "10-bit frames need 2-byte aligned planes and pitches, the destination 4-byte aligned ones");
+    if (!bytes_in && (((uintptr_t) pl.p[0] % 2) != 0 || (pl.stride[0] % 2) != 0 || ((uintptr_t) pl.p[1] % 2) != 0 ||
+        (pl.stride[1] % 2) != 0 || (p.front.kind == UNPACK_PLANAR && (((uintptr_t) pl.p[2] % 2) != 0 || (pl.stride[2] % 2) != 0))))
       return set_error (GSTAMD_ERR_UNSUPPORTED, "10-bit frames need 2-byte aligned planes and pitches, the destination 4-byte aligned ones");
     if (p.passes.empty ()) {
       e = launch_convert16 (p.front, pl, c->vpair_dev, p.deep, p.post, dst, dstride, stream);

@@ -63,6 +63,7 @@ static const FormatDesc g_formats[] = {
   /* unpack / pack_NV12_10LE40, _NV16_10LE40 (video-format.c:5868-6200): sample n at bit 10 n of the row's little-endian byte stream */
   {GSTAMD_VIDEO_FORMAT_NV12_10LE40, "NV12_10LE40", true, false, 2, UNPACK_SEMI_LE40, 1, 1, 1, 0, {0, 0, 0, 0}, 14},
   {GSTAMD_VIDEO_FORMAT_NV16_10LE40, "NV16_10LE40", true, false, 2, UNPACK_SEMI_LE40, 1, 0, 1, 0, {0, 0, 0, 0}, 14},
+  {GSTAMD_VIDEO_FORMAT_UYVP, "UYVP", true, false, 1, UNPACK_P422_UYVP, 1, 0, 0, 0, {0, 0, 0, 0}, 15},          /* unpack_UYVP / pack_UYVP video-format.c:2042-2118 */
   {GSTAMD_VIDEO_FORMAT_AV12, "AV12", true, true, 3, UNPACK_SEMI_A, 1, 1, 1, 0, {0, 0, 0, 0}},          /* unpack_AV12 / pack_AV12 video-format.c: NV12 + an alpha plane */
   {GSTAMD_VIDEO_FORMAT_NV16, "NV16", true, false, 2, UNPACK_SEMI, 1, 0, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV61, "NV61", true, false, 2, UNPACK_SEMI, 1, 0, 0, 1, {0, 0, 0, 0}},
@@ -322,6 +323,10 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->stride[0] = info->stride[1] = ((width * 5 >> 2) + 4) / 5 * 5;
       info->offset[1] = (uint64_t) info->stride[0] * round_up (height, 2);
       info->size = info->offset[1] * 2;
+      break;
+    case GSTAMD_VIDEO_FORMAT_UYVP:              /* video-info.c:953-957 */
+      info->stride[0] = round_up (round_up (width, 2) * 5 / 2, 4);
+      info->size = (uint64_t) info->stride[0] * height;
       break;
     case GSTAMD_VIDEO_FORMAT_IYU1:              /* video-info.c:965-970 */
       info->stride[0] = round_up (round_up (width, 4) + round_up (width, 4) / 2, 4);
@@ -2195,6 +2200,8 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
     return (uint64_t) ((w + 3) / 4) * 6 * h;
   if (f->kind == UNPACK_GRAY_LE32)
     return (uint64_t) ((w + 2) / 3) * 4 * h;
+  if (f->kind == UNPACK_P422_UYVP)
+    return (uint64_t) ((w + 1) / 2) * 5 * h;
   if (f->kind == UNPACK_SEMI_LE40)
     return (uint64_t) ((10 * (uint64_t) w + 7) / 8) * h + (uint64_t) ((20 * (((uint64_t) w + 1) / 2) + 7) / 8) * ((h + (1 << f->h_sub) - 1) >> f->h_sub);
   if (f->kind == UNPACK_SEMI_LE32)

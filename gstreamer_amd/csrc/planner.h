@@ -39,6 +39,8 @@ enum UnpackKind : int {
   UNPACK_GRAY_LE32 = 17, // the luma plane of those alone (GRAY10_LE32; U = V = 0x8000)
   UNPACK_SEMI_LE40 = 18, // NV12 / NV16 whose planes are little-endian streams of 10-bit samples, four in five bytes (NV12_10LE40, NV16_10LE40; hi_depth code 14; the UV
                         // plane's samples run U0 V0 U1 V1 ...); 16-bit chain, a lane per pixel in, the packer's four-pixel block = five bytes out; whole frames only
+  UNPACK_P422_UYVP = 19, // one plane, macropixels of four 10-bit samples U Y0 V Y1 as a big-endian bit stream in five bytes (UYVP; hi_depth code 15): Y210's chain and
+                        // Y210's rules (an odd line's last macropixel repeats its luma), a lane per macropixel out; whole frames only
   UNPACK_RGB16 = 11,    // one plane, a little-endian 16-bit word per pixel with 5-6-5 or 5-5-5 bit fields (RGB16, BGR16, RGB15, BGR15; unpack format ARGB,
                         // 8-bit chain): FormatDesc::pos = {bits of G, first bit of R, of G, of B}
 };
@@ -46,7 +48,7 @@ enum UnpackKind : int {
 // the full-size alpha plane of a kind that has one (A420 & co: 3, AV12: 2), else -1; interleaved U / V samples in plane 1
 #define GSTAMD_KIND_ALPHA_PLANE(k) ((k) == UNPACK_PLANAR_A ? 3 : ((k) == UNPACK_SEMI_A ? 2 : -1))
 #define GSTAMD_KIND_SEMI(k) ((k) == UNPACK_SEMI || (k) == UNPACK_SEMI_A)
-#define GSTAMD_KIND_LE32(k) ((k) == UNPACK_SEMI_LE32 || (k) == UNPACK_GRAY_LE32 || (k) == UNPACK_SEMI_LE40)          /* (the sample-stream kinds: three per word, four per five bytes) */
+#define GSTAMD_KIND_LE32(k) ((k) == UNPACK_SEMI_LE32 || (k) == UNPACK_GRAY_LE32 || (k) == UNPACK_SEMI_LE40 || (k) == UNPACK_P422_UYVP)          /* (the sample-stream kinds: three per word, four per five bytes) */
 #define GSTAMD_KIND_PX16(k) ((k) == UNPACK_Y410 || (k) == UNPACK_PACKED64 || (k) == UNPACK_GRAY16)
 
 struct FormatDesc {
@@ -119,7 +121,7 @@ GSTAMD_VP int hi_depth_le (int hi) { return hi >= 20 ? hi - 20 : hi; }
 GSTAMD_VP int bswap16i (int v) { return ((v >> 8) | (v << 8)) & 0xffff; }
 GSTAMD_VP int hi_depth_bits_le (int hi);
 GSTAMD_VP int hi_depth_bits (int hi) { return hi_depth_bits_le (hi_depth_le (hi)); }
-GSTAMD_VP int hi_depth_bits_le (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 || hi == 13 || hi == 14 ? 10 : (hi == 4 || hi == 5 || hi == 11 || hi == 12 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 ? 16 : 8)); }
+GSTAMD_VP int hi_depth_bits_le (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 || hi == 13 || hi == 14 || hi == 15 ? 10 : (hi == 4 || hi == 5 || hi == 11 || hi == 12 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 ? 16 : 8)); }
 // video_orc_unpack_RGB16 & co (video-orc.orc: mulhsw by 0x4200 / 0x2080 / 0x0210 = field * 8.25 or * 4.0625, floored): the field's bits replicated
 GSTAMD_VP int rgb16_field (int word, int shift, int bits) { const int f = (word >> shift) & ((1 << bits) - 1); return bits == 6 ? (f << 2) | (f >> 4) : (f << 3) | (f >> 2); }
 // video_orc_pack_RGB16_le & co: the top bits of every component at its field
@@ -432,6 +434,8 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
     return (size_t) y * stride + (size_t) x * 2;
   if (f->kind == UNPACK_V210)            /* rows only: a horizontal offset inside the 6-pixel groups is refused by the planner */
     return (size_t) y * stride;
+  if (f->kind == UNPACK_P422_UYVP)
+    return (size_t) y * stride + (size_t) (x >> 1) * 5;
   if (GSTAMD_KIND_LE32 (f->kind))          /* whole frames only (the planner refuses rectangles) */
     return (size_t) (plane == 0 ? y : y >> f->h_sub) * stride;
   const size_t bps = f->hi_depth ? 2 : 1;          /* planes of 10 / 12 / 16-bit formats hold 16-bit samples */

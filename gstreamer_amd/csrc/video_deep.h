@@ -54,6 +54,14 @@ GSTAMD_HD int le40_sample (const uint8_t *row, int n)
   return t | (t >> 10);
 }
 
+// field idx (0 U, 1 Y0, 2 V, 3 Y1) of a UYVP macropixel - 40 bits, big endian, ten per sample (unpack_UYVP video-format.c:2044-2085) -, widened
+GSTAMD_HD int uyvp_field (const uint8_t *m, int idx)
+{
+  const unsigned long long bits = ((unsigned long long) m[0] << 32) | ((unsigned long long) m[1] << 24) | ((unsigned long long) m[2] << 16) | ((unsigned long long) m[3] << 8) | m[4];
+  const int t = (int) ((bits >> (30 - 10 * idx)) & 0x3ffu) << 6;
+  return t | (t >> 10);
+}
+
 // one 10-bit field of a Y410 word (unpack_Y410 video-format.c:863-896): (field << 6) | (field >> 4)
 GSTAMD_HD int y410_field (uint32_t w, int shift)
 {
@@ -82,6 +90,10 @@ GSTAMD_HD UV deep_load_uv (const FrontParams &f, const Planes &pl, int crow, int
     const uint8_t *row = pl.p[1] + (ptrdiff_t) crow * pl.stride[1];
     r.u = le32_sample (row, 2 * k);
     r.v = le32_sample (row, 2 * k + 1);
+  } else if (f.kind == UNPACK_P422_UYVP) {
+    const uint8_t *m = pl.p[0] + (ptrdiff_t) crow * pl.stride[0] + 5 * (ptrdiff_t) k;
+    r.u = uyvp_field (m, 0);
+    r.v = uyvp_field (m, 2);
   } else if (f.kind == UNPACK_SEMI_LE40) {
     const uint8_t *row = pl.p[1] + (ptrdiff_t) crow * pl.stride[1];
     r.u = le40_sample (row, 2 * k);
@@ -150,6 +162,8 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
   } else if (f.kind == UNPACK_GRAY16) {
     const int raw = ((const uint16_t *) (pl.p[0] + (ptrdiff_t) y * pl.stride[0]))[x];
     c1 = f.hi_depth == 9 || f.hi_depth == 10 ? px16_word (f.hi_depth, raw) : deep_widen (f.hi_depth, raw);         /* GRAY16_LE / _BE, GRAY10_LE16 */
+  } else if (f.kind == UNPACK_P422_UYVP) {
+    c1 = uyvp_field (pl.p[0] + (ptrdiff_t) y * pl.stride[0] + 5 * (ptrdiff_t) (x >> 1), 1 + 2 * (x & 1));
   } else if (f.kind == UNPACK_SEMI_LE40) {
     c1 = le40_sample (pl.p[0] + (ptrdiff_t) y * pl.stride[0], x);
   } else if (GSTAMD_KIND_LE32 (f.kind)) {
@@ -1135,7 +1149,7 @@ GSTAMD_VP int pack16_units (const PackPlanarParams &pk)
 {
   if (pk.kind == UNPACK_V210)
     return ((pk.frame_on ? pk.frame_w : pk.width) + 5) / 6;          /* groups of the frame line */
-  return pk.kind == UNPACK_P422_16 ? (pk.width + 1) / 2 : pk.width;
+  return pk.kind == UNPACK_P422_16 || pk.kind == UNPACK_P422_UYVP ? (pk.width + 1) / 2 : pk.width;
 }
 // rows of k_pack16_packed's grid (PackPlanarParams::frame_on 2: the frame's)
 GSTAMD_VP int pack16_rows (const PackPlanarParams &pk) { return pk.kind == UNPACK_V210 && pk.frame_on == 2 ? pk.frame_h : pk.height; }
@@ -1232,6 +1246,18 @@ GSTAMD_HD void pack16_packed_body (const PackPlanarParams &pk, int hi_depth, con
   const int x = 2 * unit;
   int u, v;
   pack16_chroma_h (pk, row, w, x, &u, &v);
+  if (pk.kind == UNPACK_P422_UYVP) {       /* pack_UYVP (video-format.c:2087-2118): the samples' top ten bits, U Y0 V Y1, big endian; an odd line's last Y1 = its Y0 */
+    const uint32_t Y0 = (uint32_t) dither16_comp (dt, 1, (int) (row[x].x >> 16), x, y) >> 6;
+    const uint32_t Y1 = x + 1 < w ? (uint32_t) dither16_comp (dt, 1, (int) (row[x + 1].x >> 16), x + 1, y) >> 6 : Y0;
+    const uint32_t U = (uint32_t) dither16_comp (dt, 2, u, x, y) >> 6, V = (uint32_t) dither16_comp (dt, 3, v, x, y) >> 6;
+    uint8_t *m = dst + (size_t) y * dstride + 5 * (size_t) unit;
+    m[0] = (uint8_t) (U >> 2);
+    m[1] = (uint8_t) (((U & 3u) << 6) | (Y0 >> 4));
+    m[2] = (uint8_t) (((Y0 & 0xfu) << 4) | (V >> 6));
+    m[3] = (uint8_t) (((V & 0x3fu) << 2) | (Y1 >> 8));
+    m[4] = (uint8_t) (Y1 & 0xffu);
+    return;
+  }
   const uint16_t y0 = pack16_sample (hi_depth, dither16_comp (dt, 1, (int) (row[x].x >> 16), x, y));
   const uint16_t y1 = x + 1 < w ? pack16_sample (hi_depth, dither16_comp (dt, 1, (int) (row[x + 1].x >> 16), x + 1, y)) : y0;
   uint16_t *d = (uint16_t *) (dst + (size_t) y * dstride) + 4 * unit;

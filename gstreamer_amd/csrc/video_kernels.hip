@@ -402,7 +402,7 @@ hipError_t launch_pack16 (const PackPlanarParams &pk, int hi_depth, const Dither
     const int strides[3], hipStream_t stream)
 {
   video_frame_list_touch (planes[0]);
-  if (pk.kind == UNPACK_P422_16 || GSTAMD_KIND_PX16 (pk.kind) || pk.kind == UNPACK_V210) {          /* Y210, Y212_LE, Y410: a lane per macropixel / pixel */
+  if (pk.kind == UNPACK_P422_16 || pk.kind == UNPACK_P422_UYVP || GSTAMD_KIND_PX16 (pk.kind) || pk.kind == UNPACK_V210) {          /* Y210, Y212_LE, Y410: a lane per macropixel / pixel */
     hipLaunchKernelGGL (k_pack16_packed, dim3 ((pack16_units (pk) + 255) / 256, pack16_rows (pk)), dim3 (256), 0, stream, pk, hi_depth, dt, src, sstride, planes[0], strides[0]);
     return hipGetLastError ();
   }

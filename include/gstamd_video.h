@@ -79,6 +79,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_NV16_10LE32 = 80, /* NV16 likewise */
   GSTAMD_VIDEO_FORMAT_NV12_10LE40 = 81, /* NV12 with fully packed 10-bit samples: a little-endian bit stream, four samples in five bytes */
   GSTAMD_VIDEO_FORMAT_NV16_10LE40 = 139,/* NV16 likewise */
+  GSTAMD_VIDEO_FORMAT_UYVP = 33,        /* packed 4:2:2, 10 bits: U Y0 V Y1 as a big-endian bit stream, five bytes per two pixels */
   GSTAMD_VIDEO_FORMAT_v216 = 22,        /* packed 4:2:2, little-endian 16-bit words U Y0 V Y1 */
   GSTAMD_VIDEO_FORMAT_r210 = 41,        /* one big-endian 32-bit word per pixel: x 2, R 10, G 10, B 10 */
   GSTAMD_VIDEO_FORMAT_GRAY10_LE16 = 138,/* one plane of luma, 10 bits in the low bits of little-endian words */

@@ -58,7 +58,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #else
 #define AMD_NEWER_FORMATS ""
 #endif
-#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y41B, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, IYU1, GRAY10_LE32, NV12_10LE32, NV16_10LE32, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210, v216, r210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y41B, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, IYU1, GRAY10_LE32, NV12_10LE32, NV16_10LE32, UYVP, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210, v216, r210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
 
 /* progressive, interleaved and mixed content (caps without the field are progressive by definition).  An interleaved frame - every frame of
  * interlace-mode=interleaved, the buffers flagged GST_VIDEO_BUFFER_FLAG_INTERLACED of interlace-mode=mixed, which is what gst_video_frame_map makes
@@ -829,7 +829,7 @@ gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_ARGB64, GSTAMD_VIDEO_FORMAT_ARGB64}, {GST_VIDEO_FORMAT_AYUV64, GSTAMD_VIDEO_FORMAT_AYUV64},
     {GST_VIDEO_FORMAT_v308, GSTAMD_VIDEO_FORMAT_v308}, {GST_VIDEO_FORMAT_IYU2, GSTAMD_VIDEO_FORMAT_IYU2}, {GST_VIDEO_FORMAT_IYU1, GSTAMD_VIDEO_FORMAT_IYU1},
     {GST_VIDEO_FORMAT_GRAY10_LE32, GSTAMD_VIDEO_FORMAT_GRAY10_LE32}, {GST_VIDEO_FORMAT_NV12_10LE32, GSTAMD_VIDEO_FORMAT_NV12_10LE32},
-    {GST_VIDEO_FORMAT_NV16_10LE32, GSTAMD_VIDEO_FORMAT_NV16_10LE32},
+    {GST_VIDEO_FORMAT_NV16_10LE32, GSTAMD_VIDEO_FORMAT_NV16_10LE32}, {GST_VIDEO_FORMAT_UYVP, GSTAMD_VIDEO_FORMAT_UYVP},
     {GST_VIDEO_FORMAT_GRAY8, GSTAMD_VIDEO_FORMAT_GRAY8}, {GST_VIDEO_FORMAT_GBR, GSTAMD_VIDEO_FORMAT_GBR}, {GST_VIDEO_FORMAT_v210, GSTAMD_VIDEO_FORMAT_v210},
     {GST_VIDEO_FORMAT_I422_10LE, GSTAMD_VIDEO_FORMAT_I422_10LE}, {GST_VIDEO_FORMAT_Y444_10LE, GSTAMD_VIDEO_FORMAT_Y444_10LE},
     {GST_VIDEO_FORMAT_I420_12LE, GSTAMD_VIDEO_FORMAT_I420_12LE}, {GST_VIDEO_FORMAT_I422_12LE, GSTAMD_VIDEO_FORMAT_I422_12LE},

@@ -89,6 +89,8 @@ def visible_planes(fmt, w, h):
         return [((w + 2) // 3 * 4, h), ((w + 2) // 3 * 4, h)]
     if fmt in ("NV12_10LE40", "NV16_10LE40"):
         return [((10 * w + 7) // 8, h), ((20 * ((w + 1) // 2) + 7) // 8, up2(h) if fmt == "NV12_10LE40" else h)]
+    if fmt == "UYVP":
+        return [(5 * ((w + 1) // 2), h)]
     if fmt == "IYU1":
         return [(6 * ((w + 3) // 4), h)]  # whole groups U Y0 Y1 V Y2 Y3; visible_bytes blanks the luma slots of pixels past the width
     # 16-bit samples: the same shapes with two bytes a sample (found late in round 4: without these rows a frame with pitch padding was compared
@@ -1412,7 +1414,7 @@ VIDEO_CASES += [c for f, g in (("BGR10x2_LE", "BGR10A2_LE"), ("RGB10x2_LE", "RGB
 
 # round 6: GRAY10_LE32 / NV12_10LE32 / NV16_10LE32 (three 10-bit samples per little-endian 32-bit word) and NV12_10LE40 / NV16_10LE40 (a little-endian stream of
 # 10-bit samples); whole frames; every width modulo 6 and modulo 4 as a destination
-VIDEO_CASES += [c for f in ("GRAY10_LE32", "NV12_10LE32", "NV16_10LE32", "NV12_10LE40", "NV16_10LE40") for c in (
+VIDEO_CASES += [c for f in ("GRAY10_LE32", "NV12_10LE32", "NV16_10LE32", "NV12_10LE40", "NV16_10LE40", "UYVP") for c in (
     ("r6w_%s_bgra_36x6" % f.lower(), f, 36, 6, "BGRA", 36, 6, {}, None, None, "random"),
     ("r6w_%s_bgra_37x7" % f.lower(), f, 37, 7, "BGRA", 37, 7, {}, None, None, "random"),
     ("r6w_%s_ayuv64_38x5" % f.lower(), f, 38, 5, "AYUV64", 38, 5, {}, None, None, "random"),
@@ -1513,6 +1515,8 @@ VIDEO_REFUSED = [
     ("BGRA", 30, 20, "NV16_10LE32", 48, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20)),
     ("GRAY10_LE32", 48, 30, "GRAY8", 30, 20, dict(src_x=6, src_y=2, src_width=30, src_height=20)),
     ("NV12_10LE32", 39, 6, "BGRA", 39, 6, {}),
+    ("UYVP", 48, 30, "BGRA", 30, 20, dict(src_x=6, src_y=2, src_width=30, src_height=20)),
+    ("BGRA", 30, 20, "UYVP", 48, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20)),
     ("NV12_10LE40", 48, 30, "BGRA", 30, 20, dict(src_x=6, src_y=2, src_width=30, src_height=20)),
     ("BGRA", 30, 20, "NV16_10LE40", 48, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20)),
     ("NV16_10LE32", 45, 6, "NV16_10LE32", 45, 6, {}),

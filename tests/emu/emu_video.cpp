@@ -1197,7 +1197,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         pk16 = pack_select_only (pk16);
         memset (&dt16, 0, sizeof (dt16));
       }
-      if (g.pack.kind == UNPACK_P422_16 || GSTAMD_KIND_PX16 (g.pack.kind) || g.pack.kind == UNPACK_V210) {          /* k_pack16_packed */
+      if (g.pack.kind == UNPACK_P422_16 || g.pack.kind == UNPACK_P422_UYVP || GSTAMD_KIND_PX16 (g.pack.kind) || g.pack.kind == UNPACK_V210) {          /* k_pack16_packed */
         for (int y = 0; y < pack16_rows (g.pack); y++)
           for (int un = 0; un < (pack16_units (g.pack) + 255) / 256 * 256; un++)
             pack16_packed_body (pk16, g.pack_hi_depth, dt16, cur.p, cur.stride, d.p[0], d.stride[0], un, y);

@@ -133,7 +133,8 @@ GstAmdAudioConverter *gstamd_audio_converter_new (int flags, const GstAmdAudioIn
   }
   if (c->plan.ns) {
     const size_t hb = sizeof (int32_t) * 8 * GSTAMD_AUDIO_MAX_CHANNELS;
-    if (hipMalloc ((void **) &c->hist, hb) != hipSuccess || hipMemset (c->hist, 0, hb) != hipSuccess) {
+    /* (a null-stream memset returns before it has run and is not ordered against a non-blocking stream: wait for it - audio_kernels.hip ensure_hist) */
+    if (hipMalloc ((void **) &c->hist, hb) != hipSuccess || hipMemset (c->hist, 0, hb) != hipSuccess || hipDeviceSynchronize () != hipSuccess) {
       gstamd_audio_converter_free (c);
       return fail (GSTAMD_ERR_HIP, "error history");
     }
@@ -170,8 +171,11 @@ void gstamd_audio_converter_reset (GstAmdAudioConverter *c)
      history and touches neither the random state nor last_random */
   if (c && c->resampler)
     gstamd_audio_resampler_reset (c->resampler);
-  if (c && c->hist)
+  if (c && c->hist) {
+    (void) hipDeviceSynchronize ();
     (void) hipMemset (c->hist, 0, sizeof (int32_t) * 8 * GSTAMD_AUDIO_MAX_CHANNELS);
+    (void) hipDeviceSynchronize ();
+  }
 }
 
 size_t gstamd_audio_converter_get_out_frames (GstAmdAudioConverter *c, size_t in_frames)

@@ -171,6 +171,13 @@ static int ensure_hist (GstAmdAudioResampler *r, int which, size_t frames)
   size_t cap = frames + frames / 2 + 256;
   void *n = nullptr;
   const size_t fbytes = (size_t) r->plan.bps * r->plan.channels;
+  /* A (re)allocation is rare and synchronous, on BOTH sides.  hipMemset and a device-to-device hipMemcpy run on the null stream and return before they
+     have executed; the caller's stream is usually a non-blocking one, which the null stream does not order against: without the two synchronisations the
+     memset of a fresh history buffer could land AFTER the first kernel had written the next call's history into it (round 6, found by
+     plugins/tests/live_props audio-list: the SECOND buffer of a stream came out as if its history were silence, about one run in ten), and the copy out
+     of the old buffer could read it before the kernels still writing it were done. */
+  if (hipDeviceSynchronize () != hipSuccess)
+    return audio_hip_fail (__func__);
   if (hipMalloc (&n, cap * fbytes) != hipSuccess)
     return audio_hip_fail (__func__);
   if (hipMemset (n, 0, cap * fbytes) != hipSuccess)
@@ -179,8 +186,11 @@ static int ensure_hist (GstAmdAudioResampler *r, int which, size_t frames)
     /* keep the valid frames (only matters for the current buffer) */
     if (hipMemcpy (n, r->hist[which], r->hist_cap[which] * fbytes, hipMemcpyDeviceToDevice) != hipSuccess)
       return audio_hip_fail (__func__);
-    (void) hipFree (r->hist[which]);
   }
+  if (hipDeviceSynchronize () != hipSuccess)
+    return audio_hip_fail (__func__);
+  if (r->hist[which])
+    (void) hipFree (r->hist[which]);
   r->hist[which] = n;
   r->hist_cap[which] = cap;
   return GSTAMD_OK;
@@ -392,7 +402,10 @@ void gstamd_audio_resampler_reset (GstAmdAudioResampler *r)
   audio_state_reset (r->plan, &r->st);
   if (r->device_ready) {
     const size_t fbytes = (size_t) r->plan.bps * r->plan.channels;
+    /* (null-stream memset: ordered against the streams the resampler has been used on by synchronising around it, see ensure_hist) */
+    (void) hipDeviceSynchronize ();
     (void) hipMemset (r->hist[r->cur], 0, (size_t) (r->plan.n_taps / 2) * fbytes);
+    (void) hipDeviceSynchronize ();
   }
 }
 

@@ -37,12 +37,16 @@ typedef struct {
   gint r_method;                                         /* the method s->r was made with */
   gpointer d_in, d_out;
   gsize d_in_size, d_out_size;
+  gpointer h_in, h_out;                                  /* page-locked staging of the list path: one upload and one download per list */
+  gsize h_in_size, h_out_size;
   gpointer stream;             /* this instance's HIP stream */
   gint device_id;              /* device-id property: -1 = the process's current device */
   guint64 samples_in, samples_out;
   guint64 in_offset0, out_offset0;
   gboolean need_discont;
   GstClockTime t0;
+  GstPadChainFunction base_chain;      /* GstBaseTransform's chain function (the sink pad's, before chain_list was installed) */
+  guint64 n_list_calls, n_list_buffers; /* buffer lists resampled in one call / the buffers they held (GSTAMD_ELEMENT_STATS) */
 } GstAmdAudioResample;
 typedef struct { GstBaseTransformClass parent_class; } GstAmdAudioResampleClass;
 
@@ -233,6 +237,17 @@ ar_staging (gpointer * p, gsize * have, gsize need)
   return *p != NULL;
 }
 
+static gboolean
+ar_host_staging (gpointer * p, gsize * have, gsize need)
+{
+  if (*have >= need && *p)
+    return TRUE;
+  gstamd_host_free (*p);
+  *p = gstamd_host_alloc (need + 4096);
+  *have = *p ? need + 4096 : 0;
+  return *p != NULL;
+}
+
 /* resample in_frames from host memory (NULL = silence) into a host buffer; returns frames produced or -1.
  * in_planes: NULL, or one pointer per channel (a non-interleaved buffer whose GstAudioMeta places the planes; they are gathered
  * back to back in the device staging buffer, which is the layout the resampler was created for) */
@@ -381,6 +396,147 @@ amd_ar_transform (GstBaseTransform * t, GstBuffer * inbuf, GstBuffer * outbuf)
   return n > 0 ? GST_FLOW_OK : GST_BASE_TRANSFORM_FLOW_DROPPED;
 }
 
+/* amd_ar_check_discont for a buffer that would arrive after `samples_in` frames of the stream */
+static gboolean
+amd_ar_discont_at (GstAmdAudioResample * s, GstBuffer * buf, guint64 samples_in)
+{
+  guint64 offset, delta;
+  if (GST_BUFFER_IS_DISCONT (buf))
+    return TRUE;
+  if (!(GST_BUFFER_PTS_IS_VALID (buf) && GST_CLOCK_TIME_IS_VALID (s->t0)) || GST_BUFFER_PTS (buf) < s->t0)
+    return FALSE;
+  offset = gst_util_uint64_scale_int_round (GST_BUFFER_PTS (buf) - s->t0, GST_AUDIO_INFO_RATE (&s->in), GST_SECOND);
+  delta = offset > samples_in ? offset - samples_in : samples_in - offset;
+  return delta > (guint64) (GST_AUDIO_INFO_RATE (&s->in) >> 5);
+}
+
+/* A GstBufferList on the sink pad (the core would feed it to chain () buffer by buffer, gstpad.c gst_pad_chain_list_default; the reference's element
+ * has no list path, gstaudioresample.c).  Consecutive buffers of one stream are ONE stretch of samples: the run is uploaded back to back, resampled by
+ * one gstamd_audio_resampler_resample call (one launch instead of one per buffer - at 1024 frames a buffer the launch is the cost), downloaded, and cut
+ * where buffer by buffer calls would have cut it: the number of frames n input frames produce from a given state does not depend on how they are
+ * chunked (gst_audio_resampler_get_out_frames, audio-resampler.c:1640-1668: a function of the running phase), so output k holds
+ * out (in_0 + .. + in_k) - out (in_0 + .. + in_k-1) frames - sample for sample and timestamp for timestamp what the per-buffer path gives
+ * (plugins/tests/live_props.c audio-list).  Interleaved streams; a DISCONT or a timestamp jump ends the run and takes the regular path. */
+#define AMD_AR_LIST_CHUNK 64
+static GstFlowReturn
+amd_ar_chain_list (GstPad * pad, GstObject * parent, GstBufferList * list)
+{
+  GstAmdAudioResample *s = AMD_AR (parent);
+  GstBaseTransform *trans = GST_BASE_TRANSFORM (parent);
+  const guint n = gst_buffer_list_length (list);
+  GstFlowReturn ret = GST_FLOW_OK;
+  guint i = 0;
+
+  while (ret == GST_FLOW_OK && i < n) {
+    const gsize bpf = s->r ? GST_AUDIO_INFO_BPF (&s->in) : 0;
+    gboolean batch = s->r && bpf && !s->need_discont && s->samples_in > 0 && !gst_base_transform_is_passthrough (trans) &&
+        !gst_pad_needs_reconfigure (GST_BASE_TRANSFORM_SRC_PAD (trans)) && GST_AUDIO_INFO_LAYOUT (&s->in) == GST_AUDIO_LAYOUT_INTERLEAVED;
+    gsize in_frames[AMD_AR_LIST_CHUNK], out_cum[AMD_AR_LIST_CHUNK + 1];
+    guint cnt = 0, k;
+    guint64 sin = s->samples_in;
+    gsize total_in = 0;
+
+    for (k = i; batch && k < n && cnt < AMD_AR_LIST_CHUNK; k++) {
+      GstBuffer *b = gst_buffer_list_get (list, k);
+      const gsize sz = gst_buffer_get_size (b);
+      if (sz == 0 || sz % bpf || amd_ar_discont_at (s, b, sin))
+        break;
+      in_frames[cnt++] = sz / bpf;
+      total_in += sz / bpf;
+      sin += sz / bpf;
+    }
+    if (cnt < 2) {               /* nothing to gain (or the stream starts / restarts here): the regular path, which also settles negotiation */
+      ret = s->base_chain (pad, parent, gst_buffer_ref (gst_buffer_list_get (list, i)));
+      i++;
+      continue;
+    }
+    {
+      GstBufferList *out_list = gst_buffer_list_new_sized (cnt);
+      GstBuffer *outs[AMD_AR_LIST_CHUNK];
+      GstMapInfo imaps[AMD_AR_LIST_CHUNK], omaps[AMD_AR_LIST_CHUNK];
+      const gsize obpf = GST_AUDIO_INFO_BPF (&s->out);
+      gsize acc = 0, off = 0, total_out;
+      guint mapped_in = 0, mapped_out = 0;
+      gboolean ok = TRUE;
+
+      out_cum[0] = 0;
+      for (k = 0; k < cnt; k++) {
+        acc += in_frames[k];
+        out_cum[k + 1] = gstamd_audio_resampler_get_out_frames (s->r, acc);
+      }
+      total_out = out_cum[cnt];
+      gst_amd_hip_select_device (s->device_id);
+      if (!s->stream && !(s->stream = gstamd_stream_new ()))
+        ok = FALSE;
+      ok = ok && ar_staging (&s->d_in, &s->d_in_size, total_in * bpf) && ar_staging (&s->d_out, &s->d_out_size, total_out * obpf + 64) &&
+          ar_host_staging (&s->h_in, &s->h_in_size, total_in * bpf) && ar_host_staging (&s->h_out, &s->h_out_size, total_out * obpf + 64);
+      /* the run gathered in page-locked memory (a few KB a buffer: a memcpy), ONE upload, one launch, ONE download, then cut into the output buffers -
+         three asynchronous calls and one synchronisation per list, whatever its length (a copy call per buffer costs more than the kernel) */
+      for (k = 0; ok && k < cnt; k++) {
+        if (!gst_buffer_map (gst_buffer_list_get (list, i + k), &imaps[k], GST_MAP_READ)) {
+          ok = FALSE;
+          break;
+        }
+        mapped_in++;
+        memcpy ((guint8 *) s->h_in + off, imaps[k].data, in_frames[k] * bpf);
+        off += in_frames[k] * bpf;
+      }
+      for (k = 0; k < mapped_in; k++)
+        gst_buffer_unmap (gst_buffer_list_get (list, i + k), &imaps[k]);
+      mapped_in = 0;
+      ok = ok && gstamd_device_upload_async (s->d_in, s->h_in, total_in * bpf, s->stream) == GSTAMD_OK;
+      ok = ok && gstamd_audio_resampler_resample (s->r, s->d_in, total_in, s->d_out, total_out, s->stream) == GSTAMD_OK;
+      if (ok && total_out)
+        ok = gstamd_device_download_async (s->h_out, s->d_out, total_out * obpf, s->stream) == GSTAMD_OK;
+      if (s->stream && gstamd_stream_synchronize (s->stream) != GSTAMD_OK)
+        ok = FALSE;
+      for (k = 0; k < cnt; k++)
+        outs[k] = NULL;
+      for (k = 0; ok && k < cnt; k++) {
+        const gsize of = out_cum[k + 1] - out_cum[k];
+        if (of == 0)
+          continue;             /* (an input buffer too short to complete an output frame: GST_BASE_TRANSFORM_FLOW_DROPPED on the regular path) */
+        outs[k] = gst_buffer_new_and_alloc (of * obpf);
+        if (!gst_buffer_map (outs[k], &omaps[k], GST_MAP_WRITE)) {
+          ok = FALSE;
+          break;
+        }
+        memcpy (omaps[k].data, (guint8 *) s->h_out + out_cum[k] * obpf, of * obpf);
+        gst_buffer_unmap (outs[k], &omaps[k]);
+      }
+      (void) mapped_out;
+      if (!ok) {
+        for (k = 0; k < cnt; k++)
+          if (outs[k])
+            gst_buffer_unref (outs[k]);
+        gst_buffer_list_unref (out_list);
+        GST_ELEMENT_ERROR (s, LIBRARY, FAILED, ("HIP resampling of a buffer list failed"), ("%s", gstamd_last_error ()));
+        ret = GST_FLOW_ERROR;
+        break;
+      }
+      for (k = 0; k < cnt; k++) {
+        s->samples_in += in_frames[k];
+        if (!outs[k])
+          continue;
+        amd_ar_finish_layout (s, outs[k], out_cum[k + 1] - out_cum[k]);
+        amd_ar_stamp (s, outs[k], out_cum[k + 1] - out_cum[k]);
+        gst_buffer_list_add (out_list, outs[k]);
+      }
+      s->n_list_calls++;
+      s->n_list_buffers += cnt;
+      if (g_getenv ("GSTAMD_ELEMENT_STATS"))
+        g_printerr ("amdaudioresample: %u buffers of a list (%" G_GSIZE_FORMAT " frames) in one resample call\n", cnt, total_in);
+      if (gst_buffer_list_length (out_list) > 0)
+        ret = gst_pad_push_list (GST_BASE_TRANSFORM_SRC_PAD (trans), out_list);
+      else
+        gst_buffer_list_unref (out_list);
+      i += cnt;
+    }
+  }
+  gst_buffer_list_unref (list);
+  return ret;
+}
+
 /* drain: feed max-latency frames of silence, push what comes out */
 static void
 amd_ar_drain (GstAmdAudioResample * s)
@@ -429,6 +585,8 @@ static gboolean
 amd_ar_stop (GstBaseTransform * t)
 {
   GstAmdAudioResample *s = AMD_AR (t);
+  if (g_getenv ("GSTAMD_ELEMENT_STATS") && s->n_list_calls)
+    g_printerr ("amdaudioresample: %" G_GUINT64_FORMAT " buffers of lists in %" G_GUINT64_FORMAT " resample calls\n", s->n_list_buffers, s->n_list_calls);
   if (s->r)
     gstamd_audio_resampler_free (s->r);
   s->r = NULL;
@@ -442,6 +600,10 @@ amd_ar_stop (GstBaseTransform * t)
   gstamd_device_free (s->d_out);
   s->d_in = s->d_out = NULL;
   s->d_in_size = s->d_out_size = 0;
+  gstamd_host_free (s->h_in);
+  gstamd_host_free (s->h_out);
+  s->h_in = s->h_out = NULL;
+  s->h_in_size = s->h_out_size = 0;
   return TRUE;
 }
 
@@ -513,6 +675,8 @@ gst_amd_ar_init (GstAmdAudioResample * s)
   s->device_id = -1;
   s->need_discont = TRUE;
   s->in_offset0 = s->out_offset0 = GST_BUFFER_OFFSET_NONE;
+  s->base_chain = GST_PAD_CHAINFUNC (GST_BASE_TRANSFORM_SINK_PAD (s));
+  gst_pad_set_chain_list_function (GST_BASE_TRANSFORM_SINK_PAD (s), GST_DEBUG_FUNCPTR (amd_ar_chain_list));
 }
 
 GType

@@ -11,11 +11,14 @@
  *   live_props nav-meta        videoconvertscale while scaling: navigation events travelling upstream get input coordinates, size-tagged metas
  *                              (GstVideoCropMeta) are scaled onto the output buffer.
  *   live_props hip-memory      the HIP allocator's mem_copy (device to device) and mem_share (windows into one allocation).
+ *   live_props audio-list      audioresample fed a GstBufferList: the run of buffers is resampled in one call and cut where buffer by buffer calls
+ *                              cut it - same buffers, bytes, timestamps and offsets as the same stream pushed one buffer at a time.
  * prints "ok" and exits 0 when every output buffer is what the options in force at that buffer say. */
 #include <gst/check/gstharness.h>
 #include <gst/gst.h>
 #include <gst/video/video.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../gstamdhipmemory.h"
 
@@ -263,10 +266,172 @@ hip_memory (void)
   return bad;
 }
 
+/* buffer k of the test stream: `frames` frames of F32 stereo at 48 kHz, stamped like a live source would stamp them */
+static GstBuffer *
+audio_buffer (guint64 first_frame, int frames)
+{
+  GstBuffer *b = gst_buffer_new_allocate (NULL, frames * 2 * sizeof (float), NULL);
+  GstMapInfo m;
+  gst_buffer_map (b, &m, GST_MAP_WRITE);
+  float *f = (float *) m.data;
+  for (int i = 0; i < frames; i++) {
+    const guint64 t = first_frame + i;
+    f[2 * i] = (float) ((t * 2654435761u) % 20011u) / 10005.5f - 1.0f;
+    f[2 * i + 1] = (float) ((t * 40503u + 977u) % 30011u) / 15005.5f - 1.0f;
+  }
+  gst_buffer_unmap (b, &m);
+  GST_BUFFER_PTS (b) = gst_util_uint64_scale_int_round (first_frame, GST_SECOND, 48000);
+  GST_BUFFER_DURATION (b) = gst_util_uint64_scale_int_round (first_frame + frames, GST_SECOND, 48000) - GST_BUFFER_PTS (b);
+  GST_BUFFER_OFFSET (b) = first_frame;
+  GST_BUFFER_OFFSET_END (b) = first_frame + frames;
+  return b;
+}
+
+static int
+audio_list (void)
+{
+  static const int sizes[] = {1024, 1024, 1024, 1, 1024, 333, 1024, 1024, 2, 1024, 1024, 4096, 1024};
+  const int n = (int) G_N_ELEMENTS (sizes);
+  const char *in_caps = "audio/x-raw,format=F32LE,rate=48000,channels=2,layout=interleaved,channel-mask=(bitmask)0x3";
+  const char *out_caps = "audio/x-raw,format=F32LE,rate=44100,channels=2,layout=interleaved,channel-mask=(bitmask)0x3";
+  GstHarness *ha = gst_harness_new ("amdaudioresample"), *hb = gst_harness_new ("amdaudioresample"), *hc = gst_harness_new ("amdaudioresample");
+  int bad = 0;
+  if (!ha || !hb || !hc) {
+    fprintf (stderr, "no audioresample element (GST_PLUGIN_PATH?)\n");
+    return 1;
+  }
+  gst_harness_set_caps_str (ha, in_caps, out_caps);
+  gst_harness_set_caps_str (hb, in_caps, out_caps);
+  gst_harness_set_caps_str (hc, in_caps, out_caps);
+  /* C: one buffer at a time as well (a second element: what differs between A and C is not the list path's) */
+  {
+    guint64 p2 = 0;
+    for (int k = 0; k < n; k++) {
+      if (gst_harness_push (hc, audio_buffer (p2, sizes[k])) != GST_FLOW_OK)
+        bad |= 32;
+      p2 += sizes[k];
+    }
+  }
+  /* A: one buffer at a time.  B: the first buffer alone (it starts the stream), the others as two lists */
+  guint64 pos = 0;
+  for (int k = 0; k < n; k++) {
+    if (gst_harness_push (ha, audio_buffer (pos, sizes[k])) != GST_FLOW_OK)
+      bad |= 1;
+    pos += sizes[k];
+  }
+  pos = 0;
+  if (gst_harness_push (hb, audio_buffer (pos, sizes[0])) != GST_FLOW_OK)
+    bad |= 2;
+  pos += sizes[0];
+  for (int part = 0; part < 2; part++) {
+    const int k0 = part == 0 ? 1 : 7, k1 = part == 0 ? 7 : n;
+    GstBufferList *list = gst_buffer_list_new ();
+    for (int k = k0; k < k1; k++) {
+      gst_buffer_list_add (list, audio_buffer (pos, sizes[k]));
+      pos += sizes[k];
+    }
+    if (gst_pad_push_list (hb->srcpad, list) != GST_FLOW_OK)
+      bad |= 4;
+  }
+  const guint na = gst_harness_buffers_in_queue (ha), nb = gst_harness_buffers_in_queue (hb);
+  if (na != nb || na == 0) {
+    fprintf (stderr, "audio-list: %u buffers one by one, %u through lists\n", na, nb);
+    bad |= 8;
+  }
+  for (guint k = 0; k < na && k < nb; k++) {
+    GstBuffer *a = gst_harness_pull (ha), *b = gst_harness_pull (hb), *c = gst_harness_try_pull (hc);
+    GstMapInfo ma, mb;
+    gst_buffer_map (a, &ma, GST_MAP_READ);
+    gst_buffer_map (b, &mb, GST_MAP_READ);
+    if (c) {
+      GstMapInfo mc;
+      gst_buffer_map (c, &mc, GST_MAP_READ);
+      if (ma.size != mc.size || memcmp (ma.data, mc.data, ma.size) != 0) {
+        fprintf (stderr, "audio-list: output %u of two per-buffer runs differs\n", k);
+        bad |= 64;
+      }
+      gst_buffer_unmap (c, &mc);
+      gst_buffer_unref (c);
+    }
+    if (ma.size != mb.size || memcmp (ma.data, mb.data, ma.size) != 0 || GST_BUFFER_PTS (a) != GST_BUFFER_PTS (b) || GST_BUFFER_DURATION (a) != GST_BUFFER_DURATION (b) ||
+        GST_BUFFER_OFFSET (a) != GST_BUFFER_OFFSET (b) || GST_BUFFER_OFFSET_END (a) != GST_BUFFER_OFFSET_END (b)) {
+      fprintf (stderr, "audio-list: output %u differs (sizes %zu / %zu, pts %" GST_TIME_FORMAT " / %" GST_TIME_FORMAT ")\n", k, ma.size, mb.size,
+          GST_TIME_ARGS (GST_BUFFER_PTS (a)), GST_TIME_ARGS (GST_BUFFER_PTS (b)));
+      bad |= 16;
+    }
+    gst_buffer_unmap (a, &ma);
+    gst_buffer_unmap (b, &mb);
+    gst_buffer_unref (a);
+    gst_buffer_unref (b);
+  }
+  gst_harness_teardown (ha);
+  gst_harness_teardown (hb);
+  gst_harness_teardown (hc);
+  if (!bad)
+    printf ("ok (%u buffers)\n", na);
+  return bad;
+}
+
+/* live_props audio-list-bench [buffers per list]: wall time per 1024-frame buffer through amdaudioresample (system memory in and out: upload, kernel,
+ * download, synchronise), one buffer at a time against lists */
+static int
+audio_list_bench (int per_list)
+{
+  const char *in_caps = "audio/x-raw,format=F32LE,rate=48000,channels=2,layout=interleaved,channel-mask=(bitmask)0x3";
+  const char *out_caps = "audio/x-raw,format=F32LE,rate=44100,channels=2,layout=interleaved,channel-mask=(bitmask)0x3";
+  const int total = 2048;
+  for (int mode = 0; mode < 2; mode++) {
+    GstHarness *h = gst_harness_new ("amdaudioresample");
+    if (!h)
+      return 1;
+    gst_harness_set_caps_str (h, in_caps, out_caps);
+    guint64 pos = 0;
+    for (int k = 0; k < 64; k++, pos += 1024)             /* warm up: stream start, staging buffers, clocks */
+      gst_harness_push (h, audio_buffer (pos, 1024));
+    while (gst_harness_buffers_in_queue (h))
+      gst_buffer_unref (gst_harness_pull (h));
+    /* the input made ahead of the clock */
+    GPtrArray *items = g_ptr_array_new ();
+    for (int k = 0; k < total; k += mode ? per_list : 1) {
+      if (!mode) {
+        g_ptr_array_add (items, audio_buffer (pos, 1024));
+        pos += 1024;
+      } else {
+        GstBufferList *l = gst_buffer_list_new ();
+        for (int j = 0; j < per_list; j++, pos += 1024)
+          gst_buffer_list_add (l, audio_buffer (pos, 1024));
+        g_ptr_array_add (items, l);
+      }
+    }
+    const gint64 t0 = g_get_monotonic_time ();
+    for (guint k = 0; k < items->len; k++) {
+      if (!mode)
+        gst_harness_push (h, (GstBuffer *) g_ptr_array_index (items, k));
+      else
+        gst_pad_push_list (h->srcpad, (GstBufferList *) g_ptr_array_index (items, k));
+    }
+    const gint64 t1 = g_get_monotonic_time ();
+    const guint got = gst_harness_buffers_in_queue (h);
+    printf ("{\"case\": \"%s\", \"buffers\": %d, \"frames_per_buffer\": 1024, \"outputs\": %u, \"us_per_buffer\": %.2f}\n",
+        mode ? "buffer lists" : "one buffer at a time", total, got, (double) (t1 - t0) / total);
+    if (mode)
+      printf ("{\"buffers_per_list\": %d}\n", per_list);
+    while (gst_harness_buffers_in_queue (h))
+      gst_buffer_unref (gst_harness_pull (h));
+    g_ptr_array_free (items, TRUE);
+    gst_harness_teardown (h);
+  }
+  return 0;
+}
+
 int
 main (int argc, char **argv)
 {
   gst_init (&argc, &argv);
+  if (argc >= 2 && strcmp (argv[1], "audio-list-bench") == 0)
+    return audio_list_bench (argc >= 3 ? atoi (argv[2]) : 8);
+  if (argc >= 2 && strcmp (argv[1], "audio-list") == 0)
+    return audio_list ();
   if (argc >= 2 && strcmp (argv[1], "hip-memory") == 0)
     return hip_memory ();
   if (argc >= 2 && strcmp (argv[1], "upload-meta") == 0)

@@ -1232,6 +1232,18 @@ def test_videoconvertscale_rescales_navigation_events_and_size_tagged_metas(gst_
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_audioresample_resamples_a_buffer_list_in_one_call_with_the_per_buffer_results(gst_env):
+    """a GstBufferList on audioresample's sink pad (plugins/gstamdaudioresample.c amd_ar_chain_list; plugins/tests/live_props.c audio-list): the run of buffers
+    goes through ONE resample call; the output buffers - count, bytes, timestamps, offsets - are those of the same stream pushed buffer by buffer (which
+    test_audioresample_element_matches_reference pins to the reference)"""
+    env, tmp = gst_env
+    only_on_114(env, "plugins/tests/live_props drives the element through GstHarness (libgstcheck)")
+    exe = os.path.join(ROOT, "plugins", "tests", "live_props")
+    r = subprocess.run([exe, "audio-list"], env=dict(env, GSTAMD_ELEMENT_STATS="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    assert r.stderr.count("buffers of a list") == 2 and "6 buffers of a list" in r.stderr, r.stderr[-2000:]
+
+
 def test_hip_allocator_copies_in_hbm_and_shares_windows(gst_env):
     """GstAllocator::mem_copy and ::mem_share of the HIP allocator (plugins/gstamdhipmemory.c; plugins/tests/live_props.c hip-memory): gst_buffer_copy_deep
     of an HBM buffer gives another HBM allocation with the same bytes, gst_memory_share a window that keeps the allocation alive"""

@@ -168,6 +168,9 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_ARGB64_LE, "ARGB64_LE", false, true, 1, UNPACK_PACKED4, 0, 0, 0, 0, {0, 1, 2, 3}, 3},
   {GSTAMD_VIDEO_FORMAT_ARGB64_BE, "ARGB64_BE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {0, 1, 2, 3}, 10},
   {GSTAMD_VIDEO_FORMAT_RGBA64_LE, "RGBA64_LE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 0, 1, 2}, 9},
+  /* unpack / pack_RGBA_F16LE / _F16BE (video-format.c:2828-2918): RGBA64's words as IEEE half floats (hi_depth codes 16 / 36: px16_load / px16_store) */
+  {GSTAMD_VIDEO_FORMAT_RGBA_F16LE, "RGBA_F16LE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 0, 1, 2}, 16},
+  {GSTAMD_VIDEO_FORMAT_RGBA_F16BE, "RGBA_F16BE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 0, 1, 2}, 36},
   {GSTAMD_VIDEO_FORMAT_RGBA64_BE, "RGBA64_BE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 0, 1, 2}, 10},
   {GSTAMD_VIDEO_FORMAT_BGRA64_LE, "BGRA64_LE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 2, 1, 0}, 9},
   {GSTAMD_VIDEO_FORMAT_BGRA64_BE, "BGRA64_BE", false, true, 1, UNPACK_PACKED64, 0, 0, 0, 0, {3, 2, 1, 0}, 10},
@@ -465,6 +468,8 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
     case GSTAMD_VIDEO_FORMAT_Y416_LE:
     case GSTAMD_VIDEO_FORMAT_ARGB64_LE:
     case GSTAMD_VIDEO_FORMAT_ARGB64_BE:
+    case GSTAMD_VIDEO_FORMAT_RGBA_F16LE:
+    case GSTAMD_VIDEO_FORMAT_RGBA_F16BE:
     case GSTAMD_VIDEO_FORMAT_RGBA64_LE:
     case GSTAMD_VIDEO_FORMAT_RGBA64_BE:
     case GSTAMD_VIDEO_FORMAT_BGRA64_LE:
@@ -495,7 +500,8 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
     info->color_transfer = height > 576 ? GSTAMD_TRANSFER_BT709 : GSTAMD_TRANSFER_BT601;
     info->color_primaries = height > 576 ? GSTAMD_PRIMARIES_BT709 : GSTAMD_PRIMARIES_SMPTE170M;
   } else {
-    info->color_range = GSTAMD_COLOR_RANGE_0_255;
+    /* (float formats: DEFAULT_RGB_FLOAT, video-info.c:153-180 - range 0_1, which gst_video_color_range_offsets treats like 0_255, video-color.c:215) */
+    info->color_range = f->hi_depth == 16 || f->hi_depth == 36 ? GSTAMD_COLOR_RANGE_0_1 : GSTAMD_COLOR_RANGE_0_255;
     info->color_matrix = GSTAMD_COLOR_MATRIX_RGB;
     info->chroma_site = GSTAMD_CHROMA_SITE_UNKNOWN;
     info->color_transfer = GSTAMD_TRANSFER_SRGB;         /* sRGB row (:75) */
@@ -3760,7 +3766,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   }
   /* unpack_RGBA64_LE and its seven siblings advance a guint16 pointer by x * 8 (video-format.c:2483, 2532 ...): 16 bytes per pixel of a horizontal
      crop offset - the picture starts at pixel 2 x (reproduced), and runs into the next row when that is too far right (refused) */
-  if (fi && fi->kind == UNPACK_PACKED64 && !fi->yuv && rc.in_x != 0) {         /* (unpack_Y412_LE / _Y416_LE step x * 4: no quirk) */
+  if (fi && fi->kind == UNPACK_PACKED64 && !fi->yuv && rc.in_x != 0 && fi->hi_depth != 16 && fi->hi_depth != 36) {         /* (unpack_Y412_LE / _Y416_LE step x * 4, unpack_RGBA_F16LE x * 8 BYTES: no quirk) */
     if (2 * rc.in_x + ein.width > rc.in_maxw) {
       if (error)
         *error = "the reference's 64-bit unpackers misplace a horizontal source crop (x * 8 on a 16-bit pointer) and read past the row here; not reproduced";

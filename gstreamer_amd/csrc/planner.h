@@ -121,7 +121,7 @@ GSTAMD_VP int hi_depth_le (int hi) { return hi >= 20 ? hi - 20 : hi; }
 GSTAMD_VP int bswap16i (int v) { return ((v >> 8) | (v << 8)) & 0xffff; }
 GSTAMD_VP int hi_depth_bits_le (int hi);
 GSTAMD_VP int hi_depth_bits (int hi) { return hi_depth_bits_le (hi_depth_le (hi)); }
-GSTAMD_VP int hi_depth_bits_le (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 || hi == 13 || hi == 14 || hi == 15 ? 10 : (hi == 4 || hi == 5 || hi == 11 || hi == 12 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 ? 16 : 8)); }
+GSTAMD_VP int hi_depth_bits_le (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 || hi == 13 || hi == 14 || hi == 15 ? 10 : (hi == 4 || hi == 5 || hi == 11 || hi == 12 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 || hi == 16 ? 16 : 8)); }
 // video_orc_unpack_RGB16 & co (video-orc.orc: mulhsw by 0x4200 / 0x2080 / 0x0210 = field * 8.25 or * 4.0625, floored): the field's bits replicated
 GSTAMD_VP int rgb16_field (int word, int shift, int bits) { const int f = (word >> shift) & ((1 << bits) - 1); return bits == 6 ? (f << 2) | (f >> 4) : (f << 3) | (f >> 2); }
 // video_orc_pack_RGB16_le & co: the top bits of every component at its field
@@ -130,8 +130,85 @@ GSTAMD_VP int rgb16_pack (const int *pos, int r, int g, int b) { return ((r >> 3
 GSTAMD_VP int px16_word (int hi, int v) { return hi == 10 ? ((v >> 8) | (v << 8)) & 0xffff : v; }
 // hi_depth code 11 (Y412_LE): 12 bits in the high bits of a little-endian word - read: masked and widened (v | v >> 12), stored: masked
 // (code 12: the same big endian, Y412_BE)
-GSTAMD_VP int px16_load (int hi, int v) { if (hi == 12) v = bswap16i (v); return hi == 11 || hi == 12 ? (v & 0xfff0) | ((v & 0xfff0) >> 12) : px16_word (hi, v); }
-GSTAMD_VP int px16_store (int hi, int v) { return hi == 11 ? v & 0xfff0 : hi == 12 ? bswap16i (v & 0xfff0) : px16_word (hi, v); }
+// RGBA_F16LE / _BE (hi_depth codes 16 / 36): unpack_RGBA_F16LE (video-format.c:2830-2851) = float_to_u16 (gst_half_to_float (word)), pack = gst_float_to_half
+// (value * (1.0f / 65535.0f)); the two conversions restated from gstvideoutilsprivate.h:36-118 (binary16 <-> binary32 on the bit patterns, round to nearest
+// even, subnormals both ways), float_to_u16 from video-format.c:2818-2826 (NaN and negatives 0, >= 1 65535, else v * 65535.0f + 0.5f truncated)
+GSTAMD_VP float half_bits_to_float (int h)
+{
+  const uint32_t sign = ((uint32_t) h & 0x8000u) << 16;
+  uint32_t exponent = ((uint32_t) h >> 10) & 0x1fu, mantissa = (uint32_t) h & 0x3ffu, bits;
+  if (exponent == 0) {
+    if (mantissa == 0) {
+      bits = sign;
+    } else {
+      exponent = 127 - 15 + 1;
+      while ((mantissa & 0x400u) == 0) {
+        mantissa <<= 1;
+        exponent--;
+      }
+      mantissa &= 0x3ffu;
+      bits = sign | (exponent << 23) | (mantissa << 13);
+    }
+  } else if (exponent == 31) {
+    bits = sign | 0x7f800000u | (mantissa << 13);
+  } else {
+    bits = sign | ((exponent - 15 + 127) << 23) | (mantissa << 13);
+  }
+  float f;
+  __builtin_memcpy (&f, &bits, 4);
+  return f;
+}
+GSTAMD_VP int float_to_half_bits (float f)
+{
+  uint32_t bits;
+  __builtin_memcpy (&bits, &f, 4);
+  const uint32_t sign = (bits >> 16) & 0x8000u;
+  const int exponent = (int) ((bits >> 23) & 0xffu) - 127 + 15;
+  uint32_t mantissa = bits & 0x7fffffu;
+  if (((bits >> 23) & 0xffu) == 0xffu) {
+    if (mantissa == 0)
+      return (int) (sign | 0x7c00u);
+    mantissa >>= 13;
+    return (int) (sign | 0x7c00u | mantissa | (mantissa == 0 ? 1u : 0u));
+  }
+  if (exponent >= 31)
+    return (int) (sign | 0x7c00u);
+  if (exponent <= 0) {
+    if (exponent < -10)
+      return (int) sign;
+    mantissa |= 0x800000u;
+    const uint32_t shift = (uint32_t) (14 - exponent);
+    uint32_t h = mantissa >> shift;
+    const uint32_t rest = mantissa & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rest > halfway || (rest == halfway && (h & 1u)))
+      h++;
+    return (int) ((sign | h) & 0xffffu);
+  }
+  uint32_t h = ((uint32_t) exponent << 10) | (mantissa >> 13);
+  const uint32_t rest = mantissa & 0x1fffu;
+  if (rest > 0x1000u || (rest == 0x1000u && (h & 1u)))
+    h++;
+  return (int) ((sign | h) & 0xffffu);
+}
+GSTAMD_VP int half_word_to_u16 (int h)
+{
+  const float v = half_bits_to_float (h);
+  if (!(v > 0.0f))
+    return 0;
+  if (v >= 1.0f)
+    return 65535;
+  const float m = v * 65535.0f;          /* (two roundings, as the reference compiles it: no fused multiply-add - the library is built with -ffp-contract=off) */
+  return (int) (uint16_t) (m + 0.5f);
+}
+GSTAMD_VP int u16_to_half_word (int v) { return float_to_half_bits ((float) v * (1.0f / 65535.0f)); }
+GSTAMD_VP int px16_load (int hi, int v) {
+  if (hi == 16 || hi == 36)
+    return half_word_to_u16 (hi == 36 ? bswap16i (v) : v); if (hi == 12) v = bswap16i (v); return hi == 11 || hi == 12 ? (v & 0xfff0) | ((v & 0xfff0) >> 12) : px16_word (hi, v); }
+GSTAMD_VP int px16_store (int hi, int v) {
+  if (hi == 16)
+    return u16_to_half_word (v);
+  if (hi == 36)
+    return bswap16i (u16_to_half_word (v)); return hi == 11 ? v & 0xfff0 : hi == 12 ? bswap16i (v & 0xfff0) : px16_word (hi, v); }
 GSTAMD_VP bool hi_depth_words (int hi) { hi = hi_depth_le (hi); return hi == 1 || hi == 2 || (hi >= 4 && hi <= 6); }
 const FormatDesc *format_desc (int format);
 
@@ -467,7 +544,7 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
   *hi = 0;
   auto s16 = [&](int c) -> uint32_t {
     const uint32_t v = (uint32_t) border[c] * 257u;
-    if (f->hi_depth == 3 || f->hi_depth == 6 || f->hi_depth == 9 || f->hi_depth == 10 || f->hi_depth == 11 || f->hi_depth == 12)
+    if (f->hi_depth == 3 || f->hi_depth == 6 || f->hi_depth == 9 || f->hi_depth == 10 || f->hi_depth == 11 || f->hi_depth == 12 || f->hi_depth == 16 || f->hi_depth == 36)
       return (uint32_t) px16_store (f->hi_depth, (int) v);
     const int le = hi_depth_le (f->hi_depth), drop = 16 - hi_depth_bits (f->hi_depth);
     const uint32_t w = le == 6 ? v : (le == 1 || le == 4 ? v >> drop : v & ~((1u << drop) - 1u));

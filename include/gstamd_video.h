@@ -80,6 +80,8 @@ enum {
   GSTAMD_VIDEO_FORMAT_NV12_10LE40 = 81, /* NV12 with fully packed 10-bit samples: a little-endian bit stream, four samples in five bytes */
   GSTAMD_VIDEO_FORMAT_NV16_10LE40 = 139,/* NV16 likewise */
   GSTAMD_VIDEO_FORMAT_UYVP = 33,        /* packed 4:2:2, 10 bits: U Y0 V Y1 as a big-endian bit stream, five bytes per two pixels */
+  GSTAMD_VIDEO_FORMAT_RGBA_F16LE = 143, /* four IEEE half floats per pixel, R G B A, little endian (0.0 .. 1.0 = the 16-bit chain's 0 .. 65535) */
+  GSTAMD_VIDEO_FORMAT_RGBA_F16BE = 144, /* the same big endian */
   GSTAMD_VIDEO_FORMAT_v216 = 22,        /* packed 4:2:2, little-endian 16-bit words U Y0 V Y1 */
   GSTAMD_VIDEO_FORMAT_r210 = 41,        /* one big-endian 32-bit word per pixel: x 2, R 10, G 10, B 10 */
   GSTAMD_VIDEO_FORMAT_GRAY10_LE16 = 138,/* one plane of luma, 10 bits in the low bits of little-endian words */
@@ -167,7 +169,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_VYUY = 64
 };
 
-enum { GSTAMD_COLOR_RANGE_UNKNOWN = 0, GSTAMD_COLOR_RANGE_0_255 = 1, GSTAMD_COLOR_RANGE_16_235 = 2 };
+enum { GSTAMD_COLOR_RANGE_UNKNOWN = 0, GSTAMD_COLOR_RANGE_0_255 = 1, GSTAMD_COLOR_RANGE_16_235 = 2, GSTAMD_COLOR_RANGE_0_1 = 3 /* the float formats': full-range code values */ };
 enum {
   GSTAMD_COLOR_MATRIX_UNKNOWN = 0, GSTAMD_COLOR_MATRIX_RGB = 1, GSTAMD_COLOR_MATRIX_FCC = 2,
   GSTAMD_COLOR_MATRIX_BT709 = 3, GSTAMD_COLOR_MATRIX_BT601 = 4, GSTAMD_COLOR_MATRIX_SMPTE240M = 5,

@@ -38,7 +38,9 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
  * kernel for make set_caps fail (not-negotiated) */
 #define AMD_OUT_FORMATS AMD_IN_FORMATS
 /* (RGBP / BGRP 1.20, RBGA / A422 / A444 / GBR_16LE / Y216_LE / Y416_LE later: taken together where the headers are the reference's own) */
-#if GST_CHECK_VERSION (1, 28, 0)
+#if GST_CHECK_VERSION (1, 29, 0)
+#define AMD_128_FORMATS ", BGR10x2_LE, RGB10x2_LE, NV16_10LE40, RGBA_F16LE, RGBA_F16BE"
+#elif GST_CHECK_VERSION (1, 28, 0)
 #define AMD_128_FORMATS ", BGR10x2_LE, RGB10x2_LE, NV16_10LE40"
 #else
 #define AMD_128_FORMATS ""
@@ -893,6 +895,9 @@ gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
 #if GST_CHECK_VERSION (1, 28, 0)
     {GST_VIDEO_FORMAT_BGR10x2_LE, GSTAMD_VIDEO_FORMAT_BGR10x2_LE}, {GST_VIDEO_FORMAT_RGB10x2_LE, GSTAMD_VIDEO_FORMAT_RGB10x2_LE},
     {GST_VIDEO_FORMAT_NV16_10LE40, GSTAMD_VIDEO_FORMAT_NV16_10LE40},
+#endif
+#if GST_CHECK_VERSION (1, 29, 0)
+    {GST_VIDEO_FORMAT_RGBA_F16LE, GSTAMD_VIDEO_FORMAT_RGBA_F16LE}, {GST_VIDEO_FORMAT_RGBA_F16BE, GSTAMD_VIDEO_FORMAT_RGBA_F16BE},
 #endif
 #if GST_CHECK_VERSION (1, 20, 0)
     {GST_VIDEO_FORMAT_ARGB64_LE, GSTAMD_VIDEO_FORMAT_ARGB64_LE}, {GST_VIDEO_FORMAT_ARGB64_BE, GSTAMD_VIDEO_FORMAT_ARGB64_BE},

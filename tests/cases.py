@@ -105,7 +105,7 @@ def visible_planes(fmt, w, h):
         return [(2 * w, h), (4 * up2(w), up2(h))]
     if fmt in ("Y210", "Y212_LE", "Y216_LE", "v216"):
         return [(8 * up2(w), h)]
-    if fmt in ("ARGB64", "AYUV64", "Y412_LE", "Y416_LE") or fmt.endswith(("64_LE", "64_BE")):
+    if fmt in ("ARGB64", "AYUV64", "Y412_LE", "Y416_LE", "RGBA_F16LE", "RGBA_F16BE") or fmt.endswith(("64_LE", "64_BE")):
         return [(8 * w, h)]
     if fmt in ("GRAY16_LE", "GRAY16_BE", "RGB16", "BGR16", "RGB15", "BGR15", "GRAY10_LE16"):
         return [(2 * w, h)]
@@ -1439,6 +1439,25 @@ VIDEO_CASES += [c for f in ("GRAY10_LE32", "NV12_10LE32", "NV16_10LE32", "NV12_1
     ("r6w_%s_bgra_1920x4" % f.lower(), f, 1920, 4, "BGRA", 1920, 4, {}, None, None, "random"),
     ("r6w_nv12_%s_1918x4" % f.lower(), "NV12", 1918, 4, f, 1918, 4, {}, None, None, "random"))]
 
+# round 6: RGBA_F16LE / _BE (half floats; random bytes as a source cover NaN, infinities, negatives, subnormals and values above one)
+VIDEO_CASES += [c for f in ("RGBA_F16LE", "RGBA_F16BE") for c in (
+    ("r6h_%s_bgra_37x7" % f.lower(), f, 37, 7, "BGRA", 37, 7, {}, None, None, "random"),
+    ("r6h_%s_argb64_64x9" % f.lower(), f, 64, 9, "ARGB64", 64, 9, {}, None, None, "random"),
+    ("r6h_argb64_%s_64x9" % f.lower(), "ARGB64", 64, 9, f, 64, 9, {}, None, None, "random"),
+    ("r6h_bgra_%s_41x7" % f.lower(), "BGRA", 41, 7, f, 41, 7, {}, None, None, "random"),
+    ("r6h_rgba64_le_%s_33x5" % f.lower(), "RGBA64_LE", 33, 5, f, 33, 5, {}, None, None, "random"),
+    ("r6h_%s_rgba64_be_33x5" % f.lower(), f, 33, 5, "RGBA64_BE", 33, 5, {}, None, None, "random"),
+    ("r6h_%s_nv12" % f.lower(), f, 40, 6, "NV12", 40, 6, {}, None, None, "random"),
+    ("r6h_p010_%s" % f.lower(), "P010_10LE", 40, 6, f, 40, 6, {}, None, None, "random"),
+    ("r6h_nv12_%s_up_bilinear" % f.lower(), "NV12", 64, 36, f, 100, 50, LIN, None, None, "random"),
+    ("r6h_%s_i420_10le_down_lanczos" % f.lower(), f, 64, 36, "I420_10LE", 32, 20, LAN, None, None, "random"),
+    ("r6h_%s_self_down_bilinear" % f.lower(), f, 64, 36, f, 32, 20, LIN, None, None, "random"),
+    ("r6h_%s_self_copy" % f.lower(), f, 30, 20, f, 30, 20, {}, None, None, "random"),
+    ("r6h_argb64_%s_dest_border" % f.lower(), "ARGB64", 30, 20, f, 50, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20, border_argb=0xc0ff8040), None, None, "random"),
+    ("r6h_%s_self_crop_dest_border" % f.lower(), f, 48, 30, f, 60, 40, dict(src_x=4, src_y=2, src_width=30, src_height=20, dest_x=8, dest_y=10, dest_width=30, dest_height=20, border_argb=0x40e0a060), None, None, "random"),
+    ("r6h_bgra_%s_alpha_set" % f.lower(), "BGRA", 36, 19, f, 36, 19, dict(alpha_mode="set", alpha_value=0.4), None, None, "random"),
+    ("r6h_%s_bgra_gamma_remap" % f.lower(), f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"))]
+
 # round 6: IYU1 (packed 4:1:1, six bytes U Y0 Y1 V Y2 Y3 per four pixels): Y41B's chain on one plane; whole frames
 VIDEO_CASES += [
     ("r6i_iyu1_bgra_32x6", "IYU1", 32, 6, "BGRA", 32, 6, {}, None, None, "random"),
@@ -1624,7 +1643,7 @@ def default_layout(fmt, w, h):
         return [r4(3 * w)], [0]
     if fmt in ("GRAY16_LE", "GRAY16_BE", "RGB16", "BGR16", "RGB15", "BGR15"):
         return [r4(2 * w)], [0]
-    if fmt in ("ARGB64", "AYUV64", "Y412_LE", "Y416_LE") or fmt.endswith(("64_LE", "64_BE")):
+    if fmt in ("ARGB64", "AYUV64", "Y412_LE", "Y416_LE", "RGBA_F16LE", "RGBA_F16BE") or fmt.endswith(("64_LE", "64_BE")):
         return [8 * w], [0]
     return [4 * w], [0]
 

@@ -129,6 +129,18 @@ def _steps(ref, case, front=False):
     ifmt, w, h, ofmt, OW, OH, cfg, col, site = case
     pi, po = ref.format_props(ifmt), ref.format_props(ofmt)
     in_col = col or ref.video_info(ifmt, w, h)["colorimetry"]
+    if ifmt.startswith("RGBA_F"):
+        # gst_video_info_from_caps forces the 0_1 range on float formats (video-info.c:580-586): the stages behind the unpack step must see the range the
+        # one-step conversion works with (0_1 = full-range code values; on an integer format the same rule turns it into 0_255)
+        from gstreamer_amd import video as V
+        if in_col in V.COLORIMETRY:
+            rng, mtx, trc, prim = V.COLORIMETRY[in_col]
+            parts = [V.COLOR_RANGE[rng], V.COLOR_MATRIX[mtx], V.TRANSFER[trc], V.PRIMARIES[prim]]
+        else:
+            parts = [int(v) for v in in_col.split(":")]
+        if parts[0] != 0:
+            parts[0] = 3
+        in_col = ":".join(str(v) for v in parts)
     out_col = ref.video_info(ofmt, OW, OH)["colorimetry"]
     sx, sy = cfg.get("src_x", 0), cfg.get("src_y", 0)
     iw, ih = cfg.get("src_width", w - sx), cfg.get("src_height", h - sy)

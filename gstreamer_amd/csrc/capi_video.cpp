@@ -279,7 +279,7 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[4], co
   const int w = p.out_info.width, h = p.out_info.height;
   auto up = [](int v, int sub) { return -((-v) >> sub); };
   hipError_t e = hipSuccess;
-  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : f->kind == UNPACK_SEMI_LE32 || f->kind == UNPACK_SEMI_LE40 ? 2 : f->kind == UNPACK_SEMI_A || f->kind == UNPACK_PLANAR_H4 ? 3 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
+  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : f->kind == UNPACK_SEMI_LE32 || f->kind == UNPACK_SEMI_LE40 || f->kind == UNPACK_SEMI_TILED ? 2 : f->kind == UNPACK_SEMI_A || f->kind == UNPACK_PLANAR_H4 ? 3 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
   for (int i = 0; i < n_planes && e == hipSuccess; i++) {
     int es;
     uint32_t lo, hi;

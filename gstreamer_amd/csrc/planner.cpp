@@ -64,6 +64,12 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_NV12_10LE40, "NV12_10LE40", true, false, 2, UNPACK_SEMI_LE40, 1, 1, 1, 0, {0, 0, 0, 0}, 14},
   {GSTAMD_VIDEO_FORMAT_NV16_10LE40, "NV16_10LE40", true, false, 2, UNPACK_SEMI_LE40, 1, 0, 1, 0, {0, 0, 0, 0}, 14},
   {GSTAMD_VIDEO_FORMAT_UYVP, "UYVP", true, false, 1, UNPACK_P422_UYVP, 1, 0, 0, 0, {0, 0, 0, 0}, 15},          /* unpack_UYVP / pack_UYVP video-format.c:2042-2118 */
+  /* the tiled NV12 family (format table video-format.c:8316-8442, TILE_64x32 / _4x4 / _32x32 / _16x32s / _8x128 :8127-8131): pos = {mode, ws, hs, sub-tiles} */
+  {GSTAMD_VIDEO_FORMAT_NV12_64Z32, "NV12_64Z32", true, false, 2, UNPACK_SEMI_TILED, 1, 1, 1, 0, {1, 6, 5, 0}},
+  {GSTAMD_VIDEO_FORMAT_NV12_4L4, "NV12_4L4", true, false, 2, UNPACK_SEMI_TILED, 1, 1, 1, 0, {0, 2, 2, 0}},
+  {GSTAMD_VIDEO_FORMAT_NV12_32L32, "NV12_32L32", true, false, 2, UNPACK_SEMI_TILED, 1, 1, 1, 0, {0, 5, 5, 0}},
+  {GSTAMD_VIDEO_FORMAT_NV12_16L32S, "NV12_16L32S", true, false, 2, UNPACK_SEMI_TILED, 1, 1, 1, 0, {0, 4, 5, 1}},
+  {GSTAMD_VIDEO_FORMAT_NV12_8L128, "NV12_8L128", true, false, 2, UNPACK_SEMI_TILED, 1, 1, 1, 0, {0, 3, 7, 0}},
   {GSTAMD_VIDEO_FORMAT_AV12, "AV12", true, true, 3, UNPACK_SEMI_A, 1, 1, 1, 0, {0, 0, 0, 0}},          /* unpack_AV12 / pack_AV12 video-format.c: NV12 + an alpha plane */
   {GSTAMD_VIDEO_FORMAT_NV16, "NV16", true, false, 2, UNPACK_SEMI, 1, 0, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV61, "NV61", true, false, 2, UNPACK_SEMI, 1, 0, 0, 1, {0, 0, 0, 0}},
@@ -331,6 +337,33 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->stride[0] = round_up (round_up (width, 2) * 5 / 2, 4);
       info->size = (uint64_t) info->stride[0] * height;
       break;
+    case GSTAMD_VIDEO_FORMAT_NV12_64Z32: {      /* video-info.c:1204-1215 */
+      const int w128 = round_up (width, 128), h32 = round_up (height, 32), h64 = round_up (height, 64);
+      info->stride[0] = ((h32 / 32) << 16) | (w128 / 64);
+      info->stride[1] = ((h64 / 64) << 16) | (w128 / 64);
+      info->offset[1] = (uint64_t) w128 * h32;
+      info->size = info->offset[1] + (uint64_t) w128 * (h64 / 2);
+      break;
+    }
+    case GSTAMD_VIDEO_FORMAT_NV12_4L4:
+    case GSTAMD_VIDEO_FORMAT_NV12_32L32:
+    case GSTAMD_VIDEO_FORMAT_NV12_8L128: {      /* video-info.c:1216-1233, 1366-1388 */
+      const int ts = format == GSTAMD_VIDEO_FORMAT_NV12_4L4 ? 4 : (format == GSTAMD_VIDEO_FORMAT_NV12_32L32 ? 32 : 8);
+      const int th = format == GSTAMD_VIDEO_FORMAT_NV12_8L128 ? 128 : ts;
+      const int nx = round_up (width, ts) / ts, ny = round_up (height, th) / th, nuv = round_up (ny, 2) / 2;
+      info->stride[0] = (ny << 16) | nx;
+      info->stride[1] = (nuv << 16) | nx;
+      info->offset[1] = (uint64_t) nx * ny * (ts * th);
+      info->size = info->offset[1] + (uint64_t) nx * nuv * (ts * th);
+      break;
+    }
+    case GSTAMD_VIDEO_FORMAT_NV12_16L32S: {     /* video-info.c:1234-1255 */
+      const int nx = round_up (width, 16) / 16, ny = round_up (height, 32) / 32;
+      info->stride[0] = info->stride[1] = (ny << 16) | nx;
+      info->offset[1] = (uint64_t) nx * ny * 512;
+      info->size = info->offset[1] + (uint64_t) nx * ny * 256;
+      break;
+    }
     case GSTAMD_VIDEO_FORMAT_IYU1:              /* video-info.c:965-970 */
       info->stride[0] = round_up (round_up (width, 4) + round_up (width, 4) / 2, 4);
       info->size = (uint64_t) info->stride[0] * height;
@@ -2206,6 +2239,8 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
     return (uint64_t) ((w + 3) / 4) * 6 * h;
   if (f->kind == UNPACK_GRAY_LE32)
     return (uint64_t) ((w + 2) / 3) * 4 * h;
+  if (f->kind == UNPACK_SEMI_TILED)
+    return (uint64_t) w * h + 2 * (((uint64_t) w + 1) / 2) * (((uint64_t) h + 1) / 2);
   if (f->kind == UNPACK_P422_UYVP)
     return (uint64_t) ((w + 1) / 2) * 5 * h;
   if (f->kind == UNPACK_SEMI_LE40)
@@ -3744,6 +3779,13 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
   if (is_field && fi && fo && (fi->kind == UNPACK_PACKED411 || fo->kind == UNPACK_PACKED411)) {
     if (error)
       *error = "interlaced IYU1 frames are not implemented on the GPU path";
+    return GSTAMD_ERR_UNSUPPORTED;
+  }
+  if (fi && fo && ((fi->kind == UNPACK_SEMI_TILED && (rc.in_x || rc.in_y || ein.width != rc.in_maxw || ein.height != rc.in_maxh)) ||
+          (fo->kind == UNPACK_SEMI_TILED && (rc.out_x || rc.out_y || rc.fill || eout.width != rc.out_maxw || eout.height != rc.out_maxh)) ||
+          (is_field && (fi->kind == UNPACK_SEMI_TILED || fo->kind == UNPACK_SEMI_TILED)))) {
+    if (error)
+      *error = "source crops, destination rectangles and interlaced frames on tiled NV12 frames are not implemented on the GPU path";
     return GSTAMD_ERR_UNSUPPORTED;
   }
   /* the 10LE32 formats: whole frames (unpack_NV12_10LE32 & co skip the pixels left of x but keep writing from the line's first slot on, video-format.c:5620,

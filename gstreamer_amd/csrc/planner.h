@@ -41,6 +41,9 @@ enum UnpackKind : int {
                         // plane's samples run U0 V0 U1 V1 ...); 16-bit chain, a lane per pixel in, the packer's four-pixel block = five bytes out; whole frames only
   UNPACK_P422_UYVP = 19, // one plane, macropixels of four 10-bit samples U Y0 V Y1 as a big-endian bit stream in five bytes (UYVP; hi_depth code 15): Y210's chain and
                         // Y210's rules (an odd line's last macropixel repeats its luma), a lane per macropixel out; whole frames only
+  UNPACK_SEMI_TILED = 20, // NV12 stored in tiles (NV12_64Z32, NV12_4L4, NV12_32L32, NV12_16L32S, NV12_8L128; unpack_TILED / pack_TILED video-format.c:5083-5183 hand each
+                        // tile to unpack_NV12 / pack_NV12): FormatDesc::pos = {tile mode (0 linear, 1 ZFLIPZ_2X2), log2 tile width, log2 tile height, sub-tiled UV plane};
+                        // stride[] of such a frame is GST_VIDEO_TILE_MAKE_STRIDE (x tiles, y tiles).  8-bit chain, generic per-pixel kernels, whole frames only
   UNPACK_RGB16 = 11,    // one plane, a little-endian 16-bit word per pixel with 5-6-5 or 5-5-5 bit fields (RGB16, BGR16, RGB15, BGR15; unpack format ARGB,
                         // 8-bit chain): FormatDesc::pos = {bits of G, first bit of R, of G, of B}
 };
@@ -122,6 +125,40 @@ GSTAMD_VP int bswap16i (int v) { return ((v >> 8) | (v << 8)) & 0xffff; }
 GSTAMD_VP int hi_depth_bits_le (int hi);
 GSTAMD_VP int hi_depth_bits (int hi) { return hi_depth_bits_le (hi_depth_le (hi)); }
 GSTAMD_VP int hi_depth_bits_le (int hi) { return hi == 1 || hi == 2 || hi == 7 || hi == 8 || hi == 13 || hi == 14 || hi == 15 ? 10 : (hi == 4 || hi == 5 || hi == 11 || hi == 12 ? 12 : (hi == 3 || hi == 6 || hi == 9 || hi == 10 || hi == 16 ? 16 : 8)); }
+// ---- tiled NV12 (UNPACK_SEMI_TILED): byte offsets inside the two planes
+// gst_video_tile_get_index (video-tile.c:48-118)
+GSTAMD_VP int tile_index (int mode, int x, int y, int x_tiles, int y_tiles)
+{
+  if (mode == 0)
+    return y * x_tiles + x;
+  int off = (y & ~1) * x_tiles + x;
+  if (y & 1)
+    off += 2 + (x & ~3);
+  else if ((y_tiles & 1) == 0 || y != y_tiles - 1)
+    off += (x + 2) & ~3;
+  return off;
+}
+// luma sample (x, y): tile (x >> ws, y >> hs) of get_tile_NV12 (:5054-5081), then unpack_NV12's addressing inside the tile (tile stride = tile width)
+GSTAMD_VP size_t tiled_luma_offset (const int *tp, int stride, int x, int y)
+{
+  const int ws = tp[1], hs = tp[2], tw = 1 << ws, th = 1 << hs;
+  const int idx = tile_index (tp[0], x >> ws, y >> hs, stride & 0xffff, stride >> 16);
+  return (size_t) idx * (size_t) (tw * th) + (size_t) ((y & (th - 1)) * tw + (x & (tw - 1)));
+}
+// the U byte of chroma pair k of chroma row crow (V follows it): the UV tile under luma tile row ty - its own tile for sub-tiled formats, else the tile
+// of row ty / 2, odd rows in its second half -, row (y in tile) >> 1, byte (x in tile) & ~1 (unpack_NV12 :1597-1630 on the tile)
+GSTAMD_VP size_t tiled_uv_offset (const int *tp, int stride, int k, int crow)
+{
+  const int ws = tp[1], hs = tp[2], tw = 1 << ws, th = 1 << hs, sub = tp[3];
+  const int x = 2 * k, y = 2 * crow, ty = y >> hs;
+  const int size1 = sub ? tw * (th >> 1) : tw * th;
+  const int idx = tile_index (tp[0], x >> ws, sub ? ty : ty >> 1, stride & 0xffff, stride >> 16);
+  size_t base = (size_t) idx * (size_t) size1;
+  if (!sub && (ty & 1))
+    base += (size_t) (size1 >> 1);
+  return base + (size_t) (((y & (th - 1)) >> 1) * tw + (x & (tw - 1)));
+}
+
 // video_orc_unpack_RGB16 & co (video-orc.orc: mulhsw by 0x4200 / 0x2080 / 0x0210 = field * 8.25 or * 4.0625, floored): the field's bits replicated
 GSTAMD_VP int rgb16_field (int word, int shift, int bits) { const int f = (word >> shift) & ((1 << bits) - 1); return bits == 6 ? (f << 2) | (f >> 4) : (f << 3) | (f >> 2); }
 // video_orc_pack_RGB16_le & co: the top bits of every component at its field
@@ -511,6 +548,8 @@ inline size_t plane_origin (const FormatDesc *f, int plane, int x, int y, int st
     return (size_t) y * stride + (size_t) x * 2;
   if (f->kind == UNPACK_V210)            /* rows only: a horizontal offset inside the 6-pixel groups is refused by the planner */
     return (size_t) y * stride;
+  if (f->kind == UNPACK_SEMI_TILED)          /* whole frames only: the frame's first byte */
+    return 0;
   if (f->kind == UNPACK_P422_UYVP)
     return (size_t) y * stride + (size_t) (x >> 1) * 5;
   if (GSTAMD_KIND_LE32 (f->kind))          /* whole frames only (the planner refuses rectangles) */

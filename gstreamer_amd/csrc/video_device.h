@@ -129,6 +129,10 @@ GSTAMD_HD UV load_uv (const FrontParams &f, const Planes &pl, int crow, int k)
     const bool swap = k == f.swap_k;
     r.u = (int) ((m >> (8 * f.pos[swap ? 3 : 2])) & 0xffu);
     r.v = (int) ((m >> (8 * f.pos[swap ? 2 : 3])) & 0xffu);
+  } else if (f.kind == UNPACK_SEMI_TILED) {  // tiled NV12: the pair's bytes inside its UV tile (planner.h tiled_uv_offset)
+    const uint8_t *p = pl.p[1] + tiled_uv_offset (f.pos, pl.stride[1], k, crow);
+    r.u = p[0];
+    r.v = p[1];
   } else if (f.kind == UNPACK_PACKED411) {   // group k of the line: U Y0 Y1 V Y2 Y3 (unpack_IYU1 video-format.c:2370-2436)
     const uint8_t *p = pl.p[0] + (ptrdiff_t) crow * pl.stride[0] + 6 * k;
     r.u = p[0];
@@ -221,6 +225,7 @@ GSTAMD_HD uint32_t fetch_front (const FrontParams &f, const Planes &pl, const in
     return 0x808000ffu | ((uint32_t) pl.p[0][(size_t) y * pl.stride[0] + x] << 8);
   const int yl = y < f.luma_last ? y : f.luma_last;          /* a no-op for the picture's own lines; the line past it clamps like do_unpack_lines */
   const int Y = f.kind == UNPACK_PACKED422 ? (int) ((load_macropixel (pl.p[0] + (ptrdiff_t) yl * pl.stride[0] + 4 * (x >> 1)) >> (8 * (f.pos[1] + 2 * (x & 1)))) & 0xffu)
+      : f.kind == UNPACK_SEMI_TILED ? pl.p[0][tiled_luma_offset (f.pos, pl.stride[0], x, yl)]
       : f.kind == UNPACK_PACKED411 ? pl.p[0][(size_t) yl * pl.stride[0] + 6 * (size_t) (x >> 2) + 1 + (x & 3) + ((x & 3) >> 1)]          /* bytes 1, 2, 4, 5 of the group */
       : pl.p[0][(size_t) yl * pl.stride[0] + x];
   UV c;

@@ -83,8 +83,14 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
     for (int i = 0; i < 4 && x0 + i < w; i++)
       q[1 + i + (i >> 1)] = (uint8_t) pack_dither (pk.dither, 1, (int) ((src.at (x0 + i, y0) >> 8) & 0xff), x0 + i, y0);
   }
+  if (pk.kind == UNPACK_SEMI_TILED) {      // pack_TILED -> pack_NV12 on each tile (video-format.c:5135-5183): the block's bytes at their tile addresses (blocks never straddle tiles: widths >= 4)
+    for (int r = 0; r < nlines && y0 + r < h; r++)
+      for (int i = 0; i < 4 && x0 + i < w; i++)
+        (d.p[0] + dd)[tiled_luma_offset (pk.pos, d.stride[0], x0 + i, y0 + r)] =
+            (uint8_t) pack_dither (pk.dither, 1, (int) ((src.at (x0 + i, y0 + r) >> 8) & 0xff), x0 + i, y0 + r);
+  }
   // ---- luma of every line of the block
-  for (int r = 0; r < nlines && pk.kind != UNPACK_PACKED422 && pk.kind != UNPACK_PACKED411; r++) {
+  for (int r = 0; r < nlines && pk.kind != UNPACK_PACKED422 && pk.kind != UNPACK_PACKED411 && pk.kind != UNPACK_SEMI_TILED; r++) {
     const int y = y0 + r;
     if (y >= h)
       break;
@@ -166,6 +172,10 @@ GSTAMD_HD void pack_planar_body (const PackPlanarParams &pk, const SRC &src, con
       uint8_t *q = (d.p[0] + dd) + (size_t) y0 * d.stride[0] + 4 * (size_t) k;
       q[pk.pos[2]] = cu;
       q[pk.pos[3]] = cv;
+    } else if (pk.kind == UNPACK_SEMI_TILED) {
+      uint8_t *duv = (d.p[1] + dd) + tiled_uv_offset (pk.pos, d.stride[1], k, yb);
+      duv[0] = cu;
+      duv[1] = cv;
     } else if (GSTAMD_KIND_SEMI (pk.kind)) {
       uint8_t *duv = (d.p[1] + dd) + (size_t) yb * d.stride[1] + 2 * k;
       duv[0] = pk.u_plane ? cu : cv;

@@ -82,6 +82,11 @@ enum {
   GSTAMD_VIDEO_FORMAT_UYVP = 33,        /* packed 4:2:2, 10 bits: U Y0 V Y1 as a big-endian bit stream, five bytes per two pixels */
   GSTAMD_VIDEO_FORMAT_RGBA_F16LE = 143, /* four IEEE half floats per pixel, R G B A, little endian (0.0 .. 1.0 = the 16-bit chain's 0 .. 65535) */
   GSTAMD_VIDEO_FORMAT_RGBA_F16BE = 144, /* the same big endian */
+  GSTAMD_VIDEO_FORMAT_NV12_64Z32 = 53,  /* NV12 in 64 x 32 tiles, zigzag order (GST_VIDEO_TILE_MODE_ZFLIPZ_2X2); stride[] holds the tile counts (y tiles << 16 | x tiles) */
+  GSTAMD_VIDEO_FORMAT_NV12_4L4 = 97,    /* NV12 in 4 x 4 tiles, linear order */
+  GSTAMD_VIDEO_FORMAT_NV12_32L32 = 98,  /* 32 x 32 */
+  GSTAMD_VIDEO_FORMAT_NV12_16L32S = 110,/* 16 x 32, the UV plane in 16 x 16 sub-tiles */
+  GSTAMD_VIDEO_FORMAT_NV12_8L128 = 111, /* 8 x 128 */
   GSTAMD_VIDEO_FORMAT_v216 = 22,        /* packed 4:2:2, little-endian 16-bit words U Y0 V Y1 */
   GSTAMD_VIDEO_FORMAT_r210 = 41,        /* one big-endian 32-bit word per pixel: x 2, R 10, G 10, B 10 */
   GSTAMD_VIDEO_FORMAT_GRAY10_LE16 = 138,/* one plane of luma, 10 bits in the low bits of little-endian words */

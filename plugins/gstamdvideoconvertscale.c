@@ -47,12 +47,12 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #endif
 #if GST_CHECK_VERSION (1, 26, 0)
 #define AMD_NEWEST_FORMATS ", RGBP, BGRP, RBGA, A422, A444, GBR_16LE, Y216_LE, Y412_LE, Y416_LE, A420_12LE, A422_12LE, A444_12LE, A420_16LE, A422_16LE, A444_16LE, " \
-    "GRAY10_LE16, I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE, AV12" AMD_128_FORMATS
+    "GRAY10_LE16, I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE, AV12, NV12_16L32S, NV12_8L128" AMD_128_FORMATS
 #else
 #define AMD_NEWEST_FORMATS ""
 #endif
 #if GST_CHECK_VERSION (1, 20, 0)
-#define AMD_NEWER_FORMATS ", NV12_10LE40, VUYA, Y210, Y410, BGR10A2_LE, P012_LE, P016_LE, Y444_16LE, Y212_LE, RGB10A2_LE, ARGB64_LE, ARGB64_BE, RGBA64_LE, RGBA64_BE, BGRA64_LE, BGRA64_BE, ABGR64_LE, ABGR64_BE"
+#define AMD_NEWER_FORMATS ", NV12_4L4, NV12_32L32, NV12_10LE40, VUYA, Y210, Y410, BGR10A2_LE, P012_LE, P016_LE, Y444_16LE, Y212_LE, RGB10A2_LE, ARGB64_LE, ARGB64_BE, RGBA64_LE, RGBA64_BE, BGRA64_LE, BGRA64_BE, ABGR64_LE, ABGR64_BE"
 #elif GST_CHECK_VERSION (1, 18, 0)
 #define AMD_NEWER_FORMATS ", NV12_10LE40, VUYA, Y210, Y410, BGR10A2_LE, P012_LE, P016_LE, Y444_16LE, Y212_LE, RGB10A2_LE"
 #elif GST_CHECK_VERSION (1, 16, 0)
@@ -60,7 +60,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #else
 #define AMD_NEWER_FORMATS ""
 #endif
-#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y41B, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, IYU1, GRAY10_LE32, NV12_10LE32, NV16_10LE32, UYVP, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210, v216, r210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
+#define AMD_IN_FORMATS "{ NV12, NV21, NV16, NV61, NV24, I420, YV12, Y41B, Y42B, Y444, YUY2, UYVY, YVYU, VYUY, AYUV, RGB, BGR, RGBx, BGRx, xRGB, xBGR, RGBA, BGRA, ARGB, ABGR, P010_10LE, I420_10LE, I422_10LE, Y444_10LE, I420_12LE, I422_12LE, Y444_12LE, ARGB64, AYUV64, v308, IYU2, IYU1, GRAY10_LE32, NV12_10LE32, NV16_10LE32, UYVP, NV12_64Z32, GRAY8, GRAY16_LE, GRAY16_BE, RGB16, BGR16, RGB15, BGR15, A420, A420_10LE, A422_10LE, A444_10LE, GBR, GBRA, GBR_10LE, GBR_12LE, GBRA_10LE, GBRA_12LE, v210, v216, r210" AMD_NEWER_FORMATS AMD_NEWEST_FORMATS " }"
 
 /* progressive, interleaved and mixed content (caps without the field are progressive by definition).  An interleaved frame - every frame of
  * interlace-mode=interleaved, the buffers flagged GST_VIDEO_BUFFER_FLAG_INTERLACED of interlace-mode=mixed, which is what gst_video_frame_map makes
@@ -832,6 +832,7 @@ gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_v308, GSTAMD_VIDEO_FORMAT_v308}, {GST_VIDEO_FORMAT_IYU2, GSTAMD_VIDEO_FORMAT_IYU2}, {GST_VIDEO_FORMAT_IYU1, GSTAMD_VIDEO_FORMAT_IYU1},
     {GST_VIDEO_FORMAT_GRAY10_LE32, GSTAMD_VIDEO_FORMAT_GRAY10_LE32}, {GST_VIDEO_FORMAT_NV12_10LE32, GSTAMD_VIDEO_FORMAT_NV12_10LE32},
     {GST_VIDEO_FORMAT_NV16_10LE32, GSTAMD_VIDEO_FORMAT_NV16_10LE32}, {GST_VIDEO_FORMAT_UYVP, GSTAMD_VIDEO_FORMAT_UYVP},
+    {GST_VIDEO_FORMAT_NV12_64Z32, GSTAMD_VIDEO_FORMAT_NV12_64Z32},
     {GST_VIDEO_FORMAT_GRAY8, GSTAMD_VIDEO_FORMAT_GRAY8}, {GST_VIDEO_FORMAT_GBR, GSTAMD_VIDEO_FORMAT_GBR}, {GST_VIDEO_FORMAT_v210, GSTAMD_VIDEO_FORMAT_v210},
     {GST_VIDEO_FORMAT_I422_10LE, GSTAMD_VIDEO_FORMAT_I422_10LE}, {GST_VIDEO_FORMAT_Y444_10LE, GSTAMD_VIDEO_FORMAT_Y444_10LE},
     {GST_VIDEO_FORMAT_I420_12LE, GSTAMD_VIDEO_FORMAT_I420_12LE}, {GST_VIDEO_FORMAT_I422_12LE, GSTAMD_VIDEO_FORMAT_I422_12LE},
@@ -892,6 +893,9 @@ gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_Y444_16LE, GSTAMD_VIDEO_FORMAT_Y444_16LE}, {GST_VIDEO_FORMAT_Y212_LE, GSTAMD_VIDEO_FORMAT_Y212_LE},
     {GST_VIDEO_FORMAT_RGB10A2_LE, GSTAMD_VIDEO_FORMAT_RGB10A2_LE},
 #endif
+#if GST_CHECK_VERSION (1, 26, 0)
+    {GST_VIDEO_FORMAT_NV12_16L32S, GSTAMD_VIDEO_FORMAT_NV12_16L32S}, {GST_VIDEO_FORMAT_NV12_8L128, GSTAMD_VIDEO_FORMAT_NV12_8L128},
+#endif
 #if GST_CHECK_VERSION (1, 28, 0)
     {GST_VIDEO_FORMAT_BGR10x2_LE, GSTAMD_VIDEO_FORMAT_BGR10x2_LE}, {GST_VIDEO_FORMAT_RGB10x2_LE, GSTAMD_VIDEO_FORMAT_RGB10x2_LE},
     {GST_VIDEO_FORMAT_NV16_10LE40, GSTAMD_VIDEO_FORMAT_NV16_10LE40},
@@ -900,6 +904,7 @@ gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
     {GST_VIDEO_FORMAT_RGBA_F16LE, GSTAMD_VIDEO_FORMAT_RGBA_F16LE}, {GST_VIDEO_FORMAT_RGBA_F16BE, GSTAMD_VIDEO_FORMAT_RGBA_F16BE},
 #endif
 #if GST_CHECK_VERSION (1, 20, 0)
+    {GST_VIDEO_FORMAT_NV12_4L4, GSTAMD_VIDEO_FORMAT_NV12_4L4}, {GST_VIDEO_FORMAT_NV12_32L32, GSTAMD_VIDEO_FORMAT_NV12_32L32},
     {GST_VIDEO_FORMAT_ARGB64_LE, GSTAMD_VIDEO_FORMAT_ARGB64_LE}, {GST_VIDEO_FORMAT_ARGB64_BE, GSTAMD_VIDEO_FORMAT_ARGB64_BE},
     {GST_VIDEO_FORMAT_RGBA64_LE, GSTAMD_VIDEO_FORMAT_RGBA64_LE}, {GST_VIDEO_FORMAT_RGBA64_BE, GSTAMD_VIDEO_FORMAT_RGBA64_BE},
     {GST_VIDEO_FORMAT_BGRA64_LE, GSTAMD_VIDEO_FORMAT_BGRA64_LE}, {GST_VIDEO_FORMAT_BGRA64_BE, GSTAMD_VIDEO_FORMAT_BGRA64_BE},

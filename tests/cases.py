@@ -116,8 +116,42 @@ def visible_planes(fmt, w, h):
     return [(4 * w, h)]
 
 
+TILED = {"NV12_64Z32": (1, 6, 5, 0), "NV12_4L4": (0, 2, 2, 0), "NV12_32L32": (0, 5, 5, 0), "NV12_16L32S": (0, 4, 5, 1), "NV12_8L128": (0, 3, 7, 0)}
+
+
+def _tile_index(mode, x, y, x_tiles, y_tiles):
+    """gst_video_tile_get_index (video-tile.c:48-118) on numpy arrays"""
+    if mode == 0:
+        return y * x_tiles + x
+    off = (y & ~1) * x_tiles + x
+    odd = (y & 1) == 1
+    even_rule = ~odd & (((y_tiles & 1) == 0) | (y != y_tiles - 1))
+    return off + np.where(odd, 2 + (x & ~3), 0) + np.where(even_rule, (x + 2) & ~3, 0)
+
+
+def tiled_visible_bytes(fmt, w, h, strides, offsets, buf):
+    """the bytes of the picture's samples of a tiled NV12 frame (get_tile_NV12 + unpack_NV12's addressing, video-format.c:5054-5133), luma then U, V pairs"""
+    mode, ws, hs, sub = TILED[fmt]
+    tw, th = 1 << ws, 1 << hs
+    buf = np.asarray(buf)
+    y, x = np.mgrid[0:h, 0:w]
+    s0 = int(strides[0])
+    luma = int(offsets[0]) + _tile_index(mode, x >> ws, y >> hs, s0 & 0xffff, s0 >> 16) * (tw * th) + (y & (th - 1)) * tw + (x & (tw - 1))
+    cr, k = np.mgrid[0:(h + 1) // 2, 0:(w + 1) // 2]
+    xx, yy = 2 * k, 2 * cr
+    ty = yy >> hs
+    s1 = int(strides[1])
+    size1 = tw * (th >> 1) if sub else tw * th
+    idx = _tile_index(mode, xx >> ws, ty if sub else ty >> 1, s1 & 0xffff, s1 >> 16)
+    base = int(offsets[1]) + idx * size1 + (0 if sub else np.where(ty & 1, size1 >> 1, 0))
+    uv = base + ((yy & (th - 1)) >> 1) * tw + (xx & (tw - 1))
+    return np.concatenate([buf[luma.reshape(-1)], buf[uv.reshape(-1)], buf[uv.reshape(-1) + 1]])
+
+
 def visible_bytes(fmt, w, h, strides, offsets, buf):
     """Concatenation of the visible bytes of every plane of `buf`."""
+    if fmt in TILED:
+        return tiled_visible_bytes(fmt, w, h, strides, offsets, buf)
     out = []
     for i, (rb, rows) in enumerate(visible_planes(fmt, w, h)):
         st, off = int(strides[i]), int(offsets[i])
@@ -1458,6 +1492,27 @@ VIDEO_CASES += [c for f in ("RGBA_F16LE", "RGBA_F16BE") for c in (
     ("r6h_bgra_%s_alpha_set" % f.lower(), "BGRA", 36, 19, f, 36, 19, dict(alpha_mode="set", alpha_value=0.4), None, None, "random"),
     ("r6h_%s_bgra_gamma_remap" % f.lower(), f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "sRGB>bt709", None, "random"))]
 
+# round 6: tiled NV12 (64 x 32 zigzag, 4 x 4, 32 x 32, 16 x 32 with sub-tiled UV, 8 x 128): whole frames; sizes that end inside tiles, odd widths and heights,
+# several tile rows (the zigzag's odd-row and last-row rules)
+VIDEO_CASES += [c for f, (aw, ah) in (("NV12_64Z32", (200, 100)), ("NV12_4L4", (37, 23)), ("NV12_32L32", (100, 70)), ("NV12_16L32S", (70, 100)), ("NV12_8L128", (37, 300))) for c in (
+    ("r6t_%s_bgra" % f.lower(), f, aw, ah, "BGRA", aw, ah, {}, None, None, "random"),
+    ("r6t_%s_bgra_odd_cosited" % f.lower(), f, aw - 1, ah - 1, "BGRA", aw - 1, ah - 1, {}, None, "cosited", "random"),
+    ("r6t_%s_nv12" % f.lower(), f, aw, ah, "NV12", aw, ah, {}, None, None, "random"),
+    ("r6t_%s_i420_8x2" % f.lower(), f, 8, 2, "I420", 8, 2, {}, None, None, "random"),
+    ("r6t_%s_1x1" % f.lower(), f, 1, 1, "BGRA", 1, 1, {}, None, None, "random"),
+    ("r6t_bgra_%s" % f.lower(), "BGRA", aw, ah, f, aw, ah, {}, None, None, "random"),
+    ("r6t_bgra_%s_odd" % f.lower(), "BGRA", aw - 1, ah - 1, f, aw - 1, ah - 1, {}, None, None, "random"),
+    ("r6t_nv12_%s" % f.lower(), "NV12", aw, ah, f, aw, ah, {}, None, None, "random"),
+    ("r6t_i420_%s_wide" % f.lower(), "I420", 4 * aw + 2, 9, f, 4 * aw + 2, 9, {}, None, None, "random"),
+    ("r6t_%s_self" % f.lower(), f, aw, ah, f, aw, ah, {}, None, None, "random"),
+    ("r6t_%s_p010" % f.lower(), f, aw, ah, "P010_10LE", aw, ah, {}, None, None, "random"),
+    ("r6t_p010_%s" % f.lower(), "P010_10LE", aw, ah, f, aw, ah, {}, None, None, "random"),
+    ("r6t_%s_bgra_down_lanczos" % f.lower(), f, aw, ah, "BGRA", aw // 2 + 1 if ah < 200 else 13, ah // 2 + 3 if ah < 200 else 201, LAN, None, None, "random"),          # (horizontal pass first: the other order is a reference-undefined class)
+    ("r6t_nv12_%s_up_bilinear" % f.lower(), "NV12", 64, 36, f, 100, 50, LIN, None, None, "random"),
+    ("r6t_%s_self_down_bilinear" % f.lower(), f, aw, ah, f, aw // 2, ah // 2, LIN, None, None, "random"),
+    ("r6t_bgra_%s_bayer_q8" % f.lower(), "BGRA", aw, ah, f, aw, ah, dict(dither_method="bayer", dither_quantization=8), None, None, "random"),
+    ("r6t_%s_bgra_gamma_remap" % f.lower(), f, 40, 8, "BGRA", 40, 8, dict(gamma_mode="remap"), "bt709>sRGB", None, "random"))]
+
 # round 6: IYU1 (packed 4:1:1, six bytes U Y0 Y1 V Y2 Y3 per four pixels): Y41B's chain on one plane; whole frames
 VIDEO_CASES += [
     ("r6i_iyu1_bgra_32x6", "IYU1", 32, 6, "BGRA", 32, 6, {}, None, None, "random"),
@@ -1539,6 +1594,8 @@ VIDEO_REFUSED = [
     ("NV12_10LE40", 48, 30, "BGRA", 30, 20, dict(src_x=6, src_y=2, src_width=30, src_height=20)),
     ("BGRA", 30, 20, "NV16_10LE40", 48, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20)),
     ("NV16_10LE32", 45, 6, "NV16_10LE32", 45, 6, {}),
+    ("NV12_4L4", 48, 30, "BGRA", 30, 20, dict(src_x=6, src_y=2, src_width=30, src_height=20)),          # tiled NV12: whole frames
+    ("BGRA", 30, 20, "NV12_64Z32", 48, 30, dict(dest_x=6, dest_y=4, dest_width=30, dest_height=20)),
     # IYU1: whole frames (unpack_IYU1 steps a horizontal offset by x * 4 bytes inside six-byte groups; rectangles and borders in such frames are not built)
     ("IYU1", 48, 30, "BGRA", 32, 20, dict(src_x=8, src_y=3, src_width=32, src_height=20)),
     ("BGRA", 32, 20, "IYU1", 48, 30, dict(dest_x=8, dest_y=4, dest_width=32, dest_height=20)),

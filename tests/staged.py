@@ -316,6 +316,11 @@ def masked_check(ref, case, src, got, divergence):
         return False, True, ""          # error diffusion carries the undefined pixels' share to every pixel after them; seven probes do not show all of it
     iw, ih, ow, oh = _sizes(case)
     first, passes = chain_passes(iw, ih, ow, oh)
+    if ref.format_props(ifmt)["h_sub"] and ih != oh and cfg.get("chroma_mode", "full") in ("full", "upsample-only"):
+        # stageable ()'s "4:2:0 source under a vertical scaler": the reference's unpack ring is a line short there and whole source lines come out aliased
+        # (round 6, device seed 81273: I420_10LE 4 x 4 -> GRAY10_LE16 4 x 32 nearest - rows 16 .. 23 of the reference repeat source line 1), first
+        # hand-outs included; no region of such a frame is the reference's word
+        return False, True, ""
     notes = [d for d in divergence.split(". ") if d.strip()]
     only = lambda text: all(n.strip().startswith(text) for n in notes)
     po = ref.format_props(ofmt)

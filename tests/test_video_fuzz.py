@@ -178,5 +178,5 @@ def test_share_of_unchecked_and_refused_draws_stays_bounded(emu_lib, ref, seed, 
     assert count["bad"] == 0, (count, bad[:5])
     assert count["defined-unchecked"] <= 0.035 * 1500, count
     assert count["defined-staged"] + count["defined-masked"] >= 3 * count["defined-unchecked"], count          # (floors on 1500 draws; they move with the format pool)
-    assert count["refused"] <= 0.07 * 1500, count          # (round 6: the whole-frame-only formats - IYU1, the 10LE32 / 10LE40 families - refuse every drawn crop / rectangle)
+    assert count["refused"] <= 0.10 * 1500, count          # (round 6: the whole-frame-only formats - IYU1, the 10LE32 / 10LE40 families - and tiled NV12 - refuse every drawn crop / rectangle: 16 of the 134 formats of the pool)
     assert count["ok"] >= 0.78 * 1500, count

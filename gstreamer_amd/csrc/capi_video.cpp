@@ -279,7 +279,7 @@ static hipError_t fill_borders (const VideoPlan &p, uint8_t *const planes[4], co
   const int w = p.out_info.width, h = p.out_info.height;
   auto up = [](int v, int sub) { return -((-v) >> sub); };
   hipError_t e = hipSuccess;
-  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : f->kind == UNPACK_SEMI_LE32 || f->kind == UNPACK_SEMI_LE40 || f->kind == UNPACK_SEMI_TILED ? 2 : f->kind == UNPACK_SEMI_A || f->kind == UNPACK_PLANAR_H4 ? 3 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
+  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : f->kind == UNPACK_SEMI_LE32 || f->kind == UNPACK_SEMI_LE40 || f->kind == UNPACK_SEMI_TILED || f->kind == UNPACK_SEMI_LE40_TILED ? 2 : f->kind == UNPACK_SEMI_A || f->kind == UNPACK_PLANAR_H4 ? 3 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
   for (int i = 0; i < n_planes && e == hipSuccess; i++) {
     int es;
     uint32_t lo, hi;
@@ -1621,7 +1621,7 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
   if (p.deep16) {
     /* (the byte-stream kinds - NV12_10LE40 & co, UYVP - are read byte by byte: rows of five-byte groups have no alignment; the three-samples-per-word
        kinds are read as 32-bit words) */
-    const bool bytes_in = p.front.kind == UNPACK_SEMI_LE40 || p.front.kind == UNPACK_P422_UYVP;
+    const bool bytes_in = p.front.kind == UNPACK_SEMI_LE40 || p.front.kind == UNPACK_P422_UYVP || p.front.kind == UNPACK_SEMI_LE40_TILED;
     const bool words_in = p.front.kind == UNPACK_SEMI_LE32 || p.front.kind == UNPACK_GRAY_LE32;
     if (words_in && (((uintptr_t) pl.p[0] % 4) != 0 || (pl.stride[0] % 4) != 0 || (p.front.kind == UNPACK_SEMI_LE32 && (((uintptr_t) pl.p[1] % 4) != 0 || (pl.stride[1] % 4) != 0))))
       return set_error (GSTAMD_ERR_UNSUPPORTED, "frames with three 10-bit samples per 32-bit word need 4-byte aligned planes and pitches");

@@ -70,6 +70,7 @@ static const FormatDesc g_formats[] = {
   {GSTAMD_VIDEO_FORMAT_NV12_32L32, "NV12_32L32", true, false, 2, UNPACK_SEMI_TILED, 1, 1, 1, 0, {0, 5, 5, 0}},
   {GSTAMD_VIDEO_FORMAT_NV12_16L32S, "NV12_16L32S", true, false, 2, UNPACK_SEMI_TILED, 1, 1, 1, 0, {0, 4, 5, 1}},
   {GSTAMD_VIDEO_FORMAT_NV12_8L128, "NV12_8L128", true, false, 2, UNPACK_SEMI_TILED, 1, 1, 1, 0, {0, 3, 7, 0}},
+  {GSTAMD_VIDEO_FORMAT_NV12_10LE40_4L4, "NV12_10LE40_4L4", true, false, 2, UNPACK_SEMI_LE40_TILED, 1, 1, 1, 0, {0, 2, 2, 0}, 14},          /* :8446, unpack_TILED on unpack_NV12_10LE40 */
   {GSTAMD_VIDEO_FORMAT_AV12, "AV12", true, true, 3, UNPACK_SEMI_A, 1, 1, 1, 0, {0, 0, 0, 0}},          /* unpack_AV12 / pack_AV12 video-format.c: NV12 + an alpha plane */
   {GSTAMD_VIDEO_FORMAT_NV16, "NV16", true, false, 2, UNPACK_SEMI, 1, 0, 1, 0, {0, 0, 0, 0}},
   {GSTAMD_VIDEO_FORMAT_NV61, "NV61", true, false, 2, UNPACK_SEMI, 1, 0, 0, 1, {0, 0, 0, 0}},
@@ -355,6 +356,14 @@ int video_info_set_format (GstAmdVideoInfo *info, int format, int width, int hei
       info->stride[1] = (nuv << 16) | nx;
       info->offset[1] = (uint64_t) nx * ny * (ts * th);
       info->size = info->offset[1] + (uint64_t) nx * nuv * (ts * th);
+      break;
+    }
+    case GSTAMD_VIDEO_FORMAT_NV12_10LE40_4L4: { /* video-info.c:1216-1233 with 20-byte tiles */
+      const int nx = round_up (width, 4) / 4, ny = round_up (height, 4) / 4, nuv = round_up (ny, 2) / 2;
+      info->stride[0] = (ny << 16) | nx;
+      info->stride[1] = (nuv << 16) | nx;
+      info->offset[1] = (uint64_t) nx * ny * 20;
+      info->size = info->offset[1] + (uint64_t) nx * nuv * 20;
       break;
     }
     case GSTAMD_VIDEO_FORMAT_NV12_16L32S: {     /* video-info.c:1234-1255 */
@@ -2243,6 +2252,8 @@ static uint64_t picture_bytes (const FormatDesc *f, int w, int h)
     return (uint64_t) w * h + 2 * (((uint64_t) w + 1) / 2) * (((uint64_t) h + 1) / 2);
   if (f->kind == UNPACK_P422_UYVP)
     return (uint64_t) ((w + 1) / 2) * 5 * h;
+  if (f->kind == UNPACK_SEMI_LE40_TILED)
+    return (uint64_t) ((w + 3) / 4) * 5 * h + (uint64_t) ((w + 3) / 4) * 5 * ((h + 1) / 2);
   if (f->kind == UNPACK_SEMI_LE40)
     return (uint64_t) ((10 * (uint64_t) w + 7) / 8) * h + (uint64_t) ((20 * (((uint64_t) w + 1) / 2) + 7) / 8) * ((h + (1 << f->h_sub) - 1) >> f->h_sub);
   if (f->kind == UNPACK_SEMI_LE32)

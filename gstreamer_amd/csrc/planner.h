@@ -44,6 +44,8 @@ enum UnpackKind : int {
   UNPACK_SEMI_TILED = 20, // NV12 stored in tiles (NV12_64Z32, NV12_4L4, NV12_32L32, NV12_16L32S, NV12_8L128; unpack_TILED / pack_TILED video-format.c:5083-5183 hand each
                         // tile to unpack_NV12 / pack_NV12): FormatDesc::pos = {tile mode (0 linear, 1 ZFLIPZ_2X2), log2 tile width, log2 tile height, sub-tiled UV plane};
                         // stride[] of such a frame is GST_VIDEO_TILE_MAKE_STRIDE (x tiles, y tiles).  8-bit chain, generic per-pixel kernels, whole frames only
+  UNPACK_SEMI_LE40_TILED = 21, // NV12_10LE40_4L4: UNPACK_SEMI_LE40's sample stream restarting in every row of a 4 x 4 tile (five bytes; TILE_10bit_4x4, video-format.c:8134), tiles
+                        // addressed like UNPACK_SEMI_TILED's (pos = {mode, ws, hs, sub-tiles})
   UNPACK_RGB16 = 11,    // one plane, a little-endian 16-bit word per pixel with 5-6-5 or 5-5-5 bit fields (RGB16, BGR16, RGB15, BGR15; unpack format ARGB,
                         // 8-bit chain): FormatDesc::pos = {bits of G, first bit of R, of G, of B}
 };
@@ -51,7 +53,7 @@ enum UnpackKind : int {
 // the full-size alpha plane of a kind that has one (A420 & co: 3, AV12: 2), else -1; interleaved U / V samples in plane 1
 #define GSTAMD_KIND_ALPHA_PLANE(k) ((k) == UNPACK_PLANAR_A ? 3 : ((k) == UNPACK_SEMI_A ? 2 : -1))
 #define GSTAMD_KIND_SEMI(k) ((k) == UNPACK_SEMI || (k) == UNPACK_SEMI_A)
-#define GSTAMD_KIND_LE32(k) ((k) == UNPACK_SEMI_LE32 || (k) == UNPACK_GRAY_LE32 || (k) == UNPACK_SEMI_LE40 || (k) == UNPACK_P422_UYVP)          /* (the sample-stream kinds: three per word, four per five bytes) */
+#define GSTAMD_KIND_LE32(k) ((k) == UNPACK_SEMI_LE32 || (k) == UNPACK_GRAY_LE32 || (k) == UNPACK_SEMI_LE40 || (k) == UNPACK_P422_UYVP || (k) == UNPACK_SEMI_LE40_TILED)          /* (the sample-stream kinds: three per word, four per five bytes) */
 #define GSTAMD_KIND_PX16(k) ((k) == UNPACK_Y410 || (k) == UNPACK_PACKED64 || (k) == UNPACK_GRAY16)
 
 struct FormatDesc {
@@ -147,6 +149,24 @@ GSTAMD_VP size_t tiled_luma_offset (const int *tp, int stride, int x, int y)
 }
 // the U byte of chroma pair k of chroma row crow (V follows it): the UV tile under luma tile row ty - its own tile for sub-tiled formats, else the tile
 // of row ty / 2, odd rows in its second half -, row (y in tile) >> 1, byte (x in tile) & ~1 (unpack_NV12 :1597-1630 on the tile)
+// the same two for tiles whose rows are `rowb` bytes of a packed sample stream (NV12_10LE40_4L4: 5): the first byte of the tile row that holds the sample
+GSTAMD_VP size_t tiled_luma_row (const int *tp, int stride, int rowb, int x, int y)
+{
+  const int ws = tp[1], hs = tp[2], th = 1 << hs;
+  const int idx = tile_index (tp[0], x >> ws, y >> hs, stride & 0xffff, stride >> 16);
+  return (size_t) idx * (size_t) (rowb * th) + (size_t) ((y & (th - 1)) * rowb);
+}
+GSTAMD_VP size_t tiled_uv_row (const int *tp, int stride, int rowb, int k, int crow)
+{
+  const int ws = tp[1], hs = tp[2], th = 1 << hs, sub = tp[3];
+  const int x = 2 * k, y = 2 * crow, ty = y >> hs;
+  const int size1 = sub ? rowb * (th >> 1) : rowb * th;
+  const int idx = tile_index (tp[0], x >> ws, sub ? ty : ty >> 1, stride & 0xffff, stride >> 16);
+  size_t base = (size_t) idx * (size_t) size1;
+  if (!sub && (ty & 1))
+    base += (size_t) (size1 >> 1);
+  return base + (size_t) (((y & (th - 1)) >> 1) * rowb);
+}
 GSTAMD_VP size_t tiled_uv_offset (const int *tp, int stride, int k, int crow)
 {
   const int ws = tp[1], hs = tp[2], tw = 1 << ws, th = 1 << hs, sub = tp[3];

@@ -94,6 +94,11 @@ GSTAMD_HD UV deep_load_uv (const FrontParams &f, const Planes &pl, int crow, int
     const uint8_t *m = pl.p[0] + (ptrdiff_t) crow * pl.stride[0] + 5 * (ptrdiff_t) k;
     r.u = uyvp_field (m, 0);
     r.v = uyvp_field (m, 2);
+  } else if (f.kind == UNPACK_SEMI_LE40_TILED) {      // the pair's two samples in its UV tile row (4 x 4 tiles: two pairs a row)
+    const uint8_t *row = pl.p[1] + tiled_uv_row (f.pos, pl.stride[1], 5, k, crow);
+    const int j = ((2 * k) & ((1 << f.pos[1]) - 1)) >> 1;
+    r.u = le40_sample (row, 2 * j);
+    r.v = le40_sample (row, 2 * j + 1);
   } else if (f.kind == UNPACK_SEMI_LE40) {
     const uint8_t *row = pl.p[1] + (ptrdiff_t) crow * pl.stride[1];
     r.u = le40_sample (row, 2 * k);
@@ -164,6 +169,8 @@ GSTAMD_HD uint2 deep_front_px (const FrontParams &f, const Planes &pl, const int
     c1 = f.hi_depth == 9 || f.hi_depth == 10 ? px16_word (f.hi_depth, raw) : deep_widen (f.hi_depth, raw);         /* GRAY16_LE / _BE, GRAY10_LE16 */
   } else if (f.kind == UNPACK_P422_UYVP) {
     c1 = uyvp_field (pl.p[0] + (ptrdiff_t) y * pl.stride[0] + 5 * (ptrdiff_t) (x >> 1), 1 + 2 * (x & 1));
+  } else if (f.kind == UNPACK_SEMI_LE40_TILED) {
+    c1 = le40_sample (pl.p[0] + tiled_luma_row (f.pos, pl.stride[0], 5, x, y), x & ((1 << f.pos[1]) - 1));
   } else if (f.kind == UNPACK_SEMI_LE40) {
     c1 = le40_sample (pl.p[0] + (ptrdiff_t) y * pl.stride[0], x);
   } else if (GSTAMD_KIND_LE32 (f.kind)) {
@@ -952,7 +959,7 @@ GSTAMD_HD void pack16_le40_body (const PackPlanarParams &pk, const DitherParams 
     int m = 0;
     for (; m < 4 && x0 + m < w; m++)
       bits |= (unsigned long long) ((uint32_t) dither16_comp (dt, 1, (int) (pr[x0 + m].x >> 16), x0 + m, y) >> 6) << (10 * m);
-    put (d.p[0] + (size_t) y * d.stride[0] + 5 * (size_t) (x0 >> 2), bits, m);
+    put (pk.kind == UNPACK_SEMI_LE40_TILED ? d.p[0] + tiled_luma_row (pk.pos, d.stride[0], 5, x0, y) : d.p[0] + (size_t) y * d.stride[0] + 5 * (size_t) (x0 >> 2), bits, m);
   }
   auto cu = [&](int i) {
     i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
@@ -992,7 +999,7 @@ GSTAMD_HD void pack16_le40_body (const PackPlanarParams &pk, const DitherParams 
     bits |= (unsigned long long) ((uint32_t) dither16_comp (dt, 3, v, x, y0) >> 6) << (10 * ns + 10);
     ns += 2;
   }
-  put (d.p[1] + (size_t) yb * d.stride[1] + 5 * (size_t) (x0 >> 2), bits, ns);
+  put (pk.kind == UNPACK_SEMI_LE40_TILED ? d.p[1] + tiled_uv_row (pk.pos, d.stride[1], 5, x0 >> 1, yb) : d.p[1] + (size_t) yb * d.stride[1] + 5 * (size_t) (x0 >> 2), bits, ns);
 }
 
 // per-lane block as pack_planar_body: pixels x0 .. x0+3 of the lines (yb << h_sub) ..; planar and semi-planar kinds
@@ -1001,7 +1008,7 @@ GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const Dith
 {
   const int w = pk.width, h = pk.height;
   const int y0 = yb << pk.h_sub;
-  if (pk.kind == UNPACK_SEMI_LE40) {
+  if (pk.kind == UNPACK_SEMI_LE40 || pk.kind == UNPACK_SEMI_LE40_TILED) {
     pack16_le40_body (pk, dt, src, sstride, d, x0, yb);
     return;
   }

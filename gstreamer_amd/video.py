@@ -27,7 +27,7 @@ FORMATS = {"I420": 2, "YV12": 3, "AYUV": 6, "RGBx": 7, "BGRx": 8, "xRGB": 9, "xB
            "GBR_10LE": 50, "GBRA": 65, "GBR_12LE": 69, "Y412_LE": 96, "RGBP": 99, "BGRP": 100, "A422": 117, "A444": 118, "GBR_16LE": 131, "RBGA": 133,
            "Y216_LE": 134, "Y416_LE": 136,
            "A420_10LE": 55, "A422_10LE": 57, "A444_10LE": 59, "GBRA_10LE": 67, "GBRA_12LE": 71, "A444_12LE": 119, "A422_12LE": 121, "A420_12LE": 123,
-           "A444_16LE": 125, "A422_16LE": 127, "A420_16LE": 129, "v216": 22, "NV12_64Z32": 53, "NV12_4L4": 97, "NV12_32L32": 98, "NV12_16L32S": 110, "NV12_8L128": 111, "RGBA_F16LE": 143, "RGBA_F16BE": 144, "UYVP": 33, "NV12_10LE40": 81, "NV16_10LE40": 139, "GRAY10_LE32": 78, "NV12_10LE32": 79, "NV16_10LE32": 80, "IYU1": 38, "r210": 41, "GRAY10_LE16": 138, "AV12": 101, "Y41B": 17,
+           "A444_16LE": 125, "A422_16LE": 127, "A420_16LE": 129, "v216": 22, "NV12_10LE40_4L4": 113, "NV12_64Z32": 53, "NV12_4L4": 97, "NV12_32L32": 98, "NV12_16L32S": 110, "NV12_8L128": 111, "RGBA_F16LE": 143, "RGBA_F16BE": 144, "UYVP": 33, "NV12_10LE40": 81, "NV16_10LE40": 139, "GRAY10_LE32": 78, "NV12_10LE32": 79, "NV16_10LE32": 80, "IYU1": 38, "r210": 41, "GRAY10_LE16": 138, "AV12": 101, "Y41B": 17,
            "I420_10BE": 42, "I422_10BE": 44, "Y444_10BE": 46, "GBR_10BE": 49, "A420_10BE": 54, "A422_10BE": 56, "A444_10BE": 58, "P010_10BE": 61, "GBRA_10BE": 66, "GBR_12BE": 68, "GBRA_12BE": 70, "I420_12BE": 72, "I422_12BE": 74, "Y444_12BE": 76, "Y444_16BE": 87, "P016_BE": 89, "P012_BE": 91, "Y212_BE": 93, "Y412_BE": 95, "A444_12BE": 120, "A422_12BE": 122, "A420_12BE": 124, "A444_16BE": 126, "A422_16BE": 128, "A420_16BE": 130, "GBR_16BE": 132, "Y216_BE": 135, "Y416_BE": 137}
 COLOR_RANGE = {"unknown": 0, "0-255": 1, "16-235": 2, "0-1": 3}
 COLOR_MATRIX = {"unknown": 0, "rgb": 1, "fcc": 2, "bt709": 3, "bt601": 4, "smpte240m": 5, "bt2020": 6}

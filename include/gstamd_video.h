@@ -87,6 +87,7 @@ enum {
   GSTAMD_VIDEO_FORMAT_NV12_32L32 = 98,  /* 32 x 32 */
   GSTAMD_VIDEO_FORMAT_NV12_16L32S = 110,/* 16 x 32, the UV plane in 16 x 16 sub-tiles */
   GSTAMD_VIDEO_FORMAT_NV12_8L128 = 111, /* 8 x 128 */
+  GSTAMD_VIDEO_FORMAT_NV12_10LE40_4L4 = 113, /* NV12_10LE40's bit stream in 4 x 4 tiles (five bytes a tile row), linear order */
   GSTAMD_VIDEO_FORMAT_v216 = 22,        /* packed 4:2:2, little-endian 16-bit words U Y0 V Y1 */
   GSTAMD_VIDEO_FORMAT_r210 = 41,        /* one big-endian 32-bit word per pixel: x 2, R 10, G 10, B 10 */
   GSTAMD_VIDEO_FORMAT_GRAY10_LE16 = 138,/* one plane of luma, 10 bits in the low bits of little-endian words */

@@ -47,7 +47,7 @@ GST_DEBUG_CATEGORY_STATIC (CAT_PERFORMANCE);
 #endif
 #if GST_CHECK_VERSION (1, 26, 0)
 #define AMD_NEWEST_FORMATS ", RGBP, BGRP, RBGA, A422, A444, GBR_16LE, Y216_LE, Y412_LE, Y416_LE, A420_12LE, A422_12LE, A444_12LE, A420_16LE, A422_16LE, A444_16LE, " \
-    "GRAY10_LE16, I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE, AV12, NV12_16L32S, NV12_8L128" AMD_128_FORMATS
+    "GRAY10_LE16, I420_10BE, I422_10BE, Y444_10BE, I420_12BE, I422_12BE, Y444_12BE, Y444_16BE, P010_10BE, P012_BE, P016_BE, GBR_10BE, GBR_12BE, GBR_16BE, GBRA_10BE, GBRA_12BE, A420_10BE, A422_10BE, A444_10BE, A420_12BE, A422_12BE, A444_12BE, A420_16BE, A422_16BE, A444_16BE, Y212_BE, Y216_BE, Y412_BE, Y416_BE, AV12, NV12_16L32S, NV12_8L128, NV12_10LE40_4L4" AMD_128_FORMATS
 #else
 #define AMD_NEWEST_FORMATS ""
 #endif
@@ -895,6 +895,7 @@ gst_amd_video_info_fill (const GstVideoInfo * vi, GstAmdVideoInfo * ai)
 #endif
 #if GST_CHECK_VERSION (1, 26, 0)
     {GST_VIDEO_FORMAT_NV12_16L32S, GSTAMD_VIDEO_FORMAT_NV12_16L32S}, {GST_VIDEO_FORMAT_NV12_8L128, GSTAMD_VIDEO_FORMAT_NV12_8L128},
+    {GST_VIDEO_FORMAT_NV12_10LE40_4L4, GSTAMD_VIDEO_FORMAT_NV12_10LE40_4L4},
 #endif
 #if GST_CHECK_VERSION (1, 28, 0)
     {GST_VIDEO_FORMAT_BGR10x2_LE, GSTAMD_VIDEO_FORMAT_BGR10x2_LE}, {GST_VIDEO_FORMAT_RGB10x2_LE, GSTAMD_VIDEO_FORMAT_RGB10x2_LE},

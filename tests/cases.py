@@ -148,8 +148,31 @@ def tiled_visible_bytes(fmt, w, h, strides, offsets, buf):
     return np.concatenate([buf[luma.reshape(-1)], buf[uv.reshape(-1)], buf[uv.reshape(-1) + 1]])
 
 
+def tiled40_visible_bytes(w, h, strides, offsets, buf):
+    """NV12_10LE40_4L4: the bytes the samples of the picture reach in every tile row (five bytes for four samples; fewer at the right edge)"""
+    buf = np.asarray(buf)
+    idx = []
+    nx0, nx1 = int(strides[0]) & 0xffff, int(strides[1]) & 0xffff
+    for y in range(h):
+        for tx in range((w + 3) // 4):
+            m = min(4, w - 4 * tx)
+            base = int(offsets[0]) + ((y >> 2) * nx0 + tx) * 20 + (y & 3) * 5
+            idx += list(range(base, base + (10 * m + 7) // 8))
+    pairs = (w + 1) // 2
+    for cr in range((h + 1) // 2):
+        y = 2 * cr
+        ty = y >> 2
+        for tx in range((w + 3) // 4):
+            ns = 2 * min(2, pairs - 2 * tx)
+            base = int(offsets[1]) + ((ty >> 1) * nx1 + tx) * 20 + (10 if ty & 1 else 0) + ((y & 3) >> 1) * 5
+            idx += list(range(base, base + (10 * ns + 7) // 8))
+    return buf[np.array(idx, dtype=np.int64)]
+
+
 def visible_bytes(fmt, w, h, strides, offsets, buf):
     """Concatenation of the visible bytes of every plane of `buf`."""
+    if fmt == "NV12_10LE40_4L4":
+        return tiled40_visible_bytes(w, h, strides, offsets, buf)
     if fmt in TILED:
         return tiled_visible_bytes(fmt, w, h, strides, offsets, buf)
     out = []
@@ -1494,7 +1517,7 @@ VIDEO_CASES += [c for f in ("RGBA_F16LE", "RGBA_F16BE") for c in (
 
 # round 6: tiled NV12 (64 x 32 zigzag, 4 x 4, 32 x 32, 16 x 32 with sub-tiled UV, 8 x 128): whole frames; sizes that end inside tiles, odd widths and heights,
 # several tile rows (the zigzag's odd-row and last-row rules)
-VIDEO_CASES += [c for f, (aw, ah) in (("NV12_64Z32", (200, 100)), ("NV12_4L4", (37, 23)), ("NV12_32L32", (100, 70)), ("NV12_16L32S", (70, 100)), ("NV12_8L128", (37, 300))) for c in (
+VIDEO_CASES += [c for f, (aw, ah) in (("NV12_64Z32", (200, 100)), ("NV12_4L4", (37, 23)), ("NV12_32L32", (100, 70)), ("NV12_16L32S", (70, 100)), ("NV12_8L128", (37, 300)), ("NV12_10LE40_4L4", (38, 22))) for c in (
     ("r6t_%s_bgra" % f.lower(), f, aw, ah, "BGRA", aw, ah, {}, None, None, "random"),
     ("r6t_%s_bgra_odd_cosited" % f.lower(), f, aw - 1, ah - 1, "BGRA", aw - 1, ah - 1, {}, None, "cosited", "random"),
     ("r6t_%s_nv12" % f.lower(), f, aw, ah, "NV12", aw, ah, {}, None, None, "random"),

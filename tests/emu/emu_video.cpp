@@ -831,7 +831,7 @@ static void emu_fill_borders (const VideoPlan &p, const GstAmdVideoInfo *out, ui
 {
   const FormatDesc *f = p.fout;
   auto up = [](int v, int sub) { return -((-v) >> sub); };
-  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : f->kind == UNPACK_SEMI_LE32 || f->kind == UNPACK_SEMI_LE40 || f->kind == UNPACK_SEMI_TILED ? 2 : f->kind == UNPACK_SEMI_A || f->kind == UNPACK_PLANAR_H4 ? 3 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
+  const int n_planes = f->kind == UNPACK_PLANAR_A ? 4 : f->kind == UNPACK_SEMI_LE32 || f->kind == UNPACK_SEMI_LE40 || f->kind == UNPACK_SEMI_TILED || f->kind == UNPACK_SEMI_LE40_TILED ? 2 : f->kind == UNPACK_SEMI_A || f->kind == UNPACK_PLANAR_H4 ? 3 : kind_has_planes (f->kind) ? (f->kind == UNPACK_SEMI ? 2 : 3) : 1;
   for (int i = 0; i < n_planes; i++) {
     int es;
     uint32_t lo, hi;

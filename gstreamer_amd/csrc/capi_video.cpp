@@ -21,6 +21,7 @@
 #include "video_scale420_fused.h"
 #include "video_scale_col.h"
 #include "video_dither_ed.h"
+#include "video_deep_pack.h"
 
 using namespace gstamd;
 
@@ -100,6 +101,8 @@ struct GstAmdVideoConverter {
   bool post_lut_done = false;
   int list_launches = 0;                /* launches of the last _frames call that each served a whole (chunk of the) list; 0: frame by frame */
   bool hook_on = false;                 /* this converter is the direct conversion of a fused gamma plan: k_convert_gamma with `hook` */
+  const DeepPackParams *deep_hook = nullptr;         /* this converter is the sub-conversion (narrowed image -> planes) of a shrinking 10-bit plan whose pixels
+                                                      * come straight from the 10-bit source: k_deep_scale_pack (video_deep_pack.h) instead of reading an image */
   GammaDev hook;
   uint16_t *gamma_dec_dev = nullptr;
   uint16_t *gamma_dec16_dev = nullptr, *gamma_enc16_dev = nullptr;          /* the 65536-entry tables of a remap with 16-bit ends */
@@ -121,6 +124,7 @@ struct GstAmdVideoConverter {
 };
 
 namespace gstamd {
+hipError_t launch_deep_scale_pack (const PackPlanarParams &pk, const DeepPackParams &dp, uint8_t *const planes[3], const int strides[3], hipStream_t stream);
 size_t fused420_lds_bytes (int ring, int nwaves, int sched);
 int fused420_blocks_per_cu (int nwaves, size_t lds, int sched);
 hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
@@ -701,6 +705,12 @@ static int convert_to_packed (GstAmdVideoConverter *c, const Planes &pl, uint8_t
 static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const dest_planes[GSTAMD_VIDEO_MAX_PLANES],
     const int32_t dest_stride[GSTAMD_VIDEO_MAX_PLANES], hipStream_t stream);
 
+// does this composite plan go through k_deep_scale_pack (video_deep_pack.h)?  *dp: everything but the pointers
+static bool deep_pack_usable (const GstAmdVideoConverter *c, DeepPackParams *dp)
+{
+  return c->sub_out && !c->hook_on && !tuning_on ("GSTAMD_NO_DEEP_SCALE_PACK") && deep_scale_pack_plan_ok (c->plan, c->sub_out->plan, dp);
+}
+
 // gamma-mode = remap (GammaPlan, video_gamma.h): in -> 8-bit unpack-format image -> [decode | scalers on ARGB64 | primaries, alpha |
 // encode] -> 8-bit unpack-format image -> out.  The images live in HBM (correctness and coverage first).
 static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[GSTAMD_VIDEO_MAX_PLANES], const int32_t src_stride[GSTAMD_VIDEO_MAX_PLANES],
@@ -816,6 +826,29 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       if (!pl.p[i])
         return set_error (GSTAMD_ERR_INVALID, "NULL source plane");
       pl.p[i] += plane_origin (p.fin, i, p.rect.in_x, p.rect.in_y, pl.stride[i]);          /* the source crop (the vpair table knows the frame's rows) */
+    }
+    DeepPackParams dsp;
+    bool dsp_ok = c->sub_out && deep_pack_usable (c, &dsp);
+    for (int i = 0; dsp_ok && i < p.in_info.n_planes && i < 3; i++)           /* the block form's loads: source rows on 16 bytes ... */
+      dsp_ok = ((uintptr_t) pl.p[i] % 16) == 0 && (pl.stride[i] % 16) == 0;
+    for (int i = 0; dsp_ok && i < p.out_info.n_planes && i < 3; i++) {          /* ... its stores: the rectangle's plane rows on 4 */
+      const VideoPlan &sp = c->sub_out->plan;
+      const int ds = dest_stride ? dest_stride[i] : sp.out_info.stride[i];
+      dsp_ok = dest_planes[i] && ((uintptr_t) ((const uint8_t *) dest_planes[i] + plane_origin (sp.fout, i, sp.rect.out_x, sp.rect.out_y, ds)) % 4) == 0 && (ds % 4) == 0;
+    }
+    if (dsp_ok) {
+      /* front, both passes, narrowing and the sub-conversion's pack in one kernel (video_deep_pack.h): the sub-conversion does what it does around its
+         pack (destination rectangle, borders) and takes the pixels from the hook instead of the narrowed image */
+      dsp.pl = pl;
+      dsp.vpair = c->vpair_dev;
+      dsp.sh.offset = c->pass_dev[0].offset, dsp.sh.taps = c->pass_dev[0].taps;
+      dsp.sv.offset = c->pass_dev[1].offset, dsp.sv.taps = c->pass_dev[1].taps;
+      const void *hb[GSTAMD_VIDEO_MAX_PLANES] = {c->gamma_mid_b, nullptr, nullptr, nullptr};
+      const int32_t hbs[GSTAMD_VIDEO_MAX_PLANES] = {out_w * 4, 0, 0, 0};
+      c->sub_out->deep_hook = &dsp;
+      r = frame_planes_plan_order (c->sub_out, hb, hbs, dest_planes, dest_stride, stream);
+      c->sub_out->deep_hook = nullptr;
+      return r;
     }
     if (n >= 1 && p.passes[0].horizontal && !dec16 && (mid_done || g.shrink) && front_hscale16_usable (p.front)) {
       /* nothing between the front and a first, horizontal pass: the front runs inside it (k_front_hscale16), no full-size AYUV64 image */
@@ -1213,6 +1246,10 @@ static int convert_rect (GstAmdVideoConverter *c, const Planes &pl, void *const 
       strides[i] = dest_stride ? dest_stride[i] : p.out_info.stride[i];
       if (!planes[i])
         return set_error (GSTAMD_ERR_INVALID, "NULL destination plane");
+    }
+    if (c->deep_hook) {
+      hipError_t he = launch_deep_scale_pack (p.pack, *c->deep_hook, planes, strides, stream);
+      return he == hipSuccess ? GSTAMD_OK : hip_fail (he, "k_deep_scale_pack");
     }
     if (p.fout->kind == UNPACK_PACKED3 && fast_pair_usable (p, pl, planes[0], strides[0], 4)) {
       /* NV12 / NV21 -> RGB / BGR, same size: the line-pair kernel stores the 3-byte pixels itself (12 bytes per lane and line) */
@@ -1939,7 +1976,9 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
   }
   Enc16Params ep16_list;
   const bool enc16_list = p.gamma.on && enc16_params (p, &ep16_list) && !tuning_on ("GSTAMD_NO_ENCODE16");         /* k_encode16: one kernel, takes lists */
-  if (p.gamma.on && !p.gamma.planes_fast && !enc16_list)
+  DeepPackParams dsp_list;
+  const bool deep_pack_list = p.gamma.on && deep_pack_usable (c, &dsp_list) && !c->sub_out->plan.rect.fill;        /* k_deep_scale_pack: one kernel, takes lists */
+  if (p.gamma.on && !p.gamma.planes_fast && !enc16_list && !deep_pack_list)
     return frames_one_by_one (c, n_frames, src, dest, stream_);
   /* one launch for the whole list when the line-pair kernel applies to every frame */
   bool all_fast = true;
@@ -2037,7 +2076,7 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
   /* plans that convert a frame in ONE launch of a kernel that takes frame lists (video_kernels.hip: the list is the grid's third
      dimension): frame `base` is converted with the list of up to 32 frames behind it armed; the launcher says whether it took the list */
   int base = 0;
-  if (!p.rect.fill && !p.dither.on && (!p.gamma.on || p.gamma.planes_fast || enc16_list)) {
+  if (!p.rect.fill && !p.dither.on && (!p.gamma.on || p.gamma.planes_fast || enc16_list || deep_pack_list)) {
     /* a plan that scales into the pack image and packs from it with list-taking kernels (k_plane_quad + k_encode420 / k_convert_pack: raw4_pack) gets
        one image per frame of the list - up to 1 GiB of them - so that both launches take the list */
     if (c->raw4_pack && c->pk_img && !c->hook_on) {

@@ -19,6 +19,15 @@
 
 namespace gstamd {
 
+// frame lists of the single-kernel plans (video_kernels.hip "frame lists"): workgroup z of a list launch adds s[z] to every source pointer and d[z] to
+// every destination pointer
+#define GSTAMD_MAX_BATCH 32
+struct FrameDeltas {
+  long long s[GSTAMD_MAX_BATCH], d[GSTAMD_MAX_BATCH];
+};
+#define GSTAMD_FRAME_Z const long long fls_ = fl.s[blockIdx.z], fld_ = fl.d[blockIdx.z]
+const FrameDeltas &video_frame_list_for (const void *sp, const void *dp, int *nz);
+
 hipError_t launch_convert (const FrontParams &f, const Planes &pl, const int *vpair_dev, const ColorParams &color,
     const int pack_pos[4], uint8_t *dst, int dstride, hipStream_t stream, int extra_rows = 0);
 

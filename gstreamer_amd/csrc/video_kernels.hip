@@ -40,10 +40,7 @@ namespace gstamd {
 // launchers through a thread-local context: a launcher uses it only when ITS source and destination pointers lie inside frame 0 of
 // the list (a kernel that reads or writes a scratch image must not be rebased), and says so; the caller converts the remaining
 // frames one by one when nobody did.
-#define GSTAMD_MAX_BATCH 32
-struct FrameDeltas {
-  long long s[GSTAMD_MAX_BATCH], d[GSTAMD_MAX_BATCH];
-};
+// (GSTAMD_MAX_BATCH, FrameDeltas: video_kernels.h)
 namespace {
 struct FrameListCtx {
   bool armed = false;
@@ -129,7 +126,9 @@ static const FrameDeltas &frame_list_for (const void *sp, const void *dp, int *n
     c.mixed = true;             /* a kernel that writes frame 0's picture or scratch image and cannot be rebased: the list is not served by launches alone */
   return none;
 }
-#define GSTAMD_FRAME_Z const long long fls_ = fl.s[blockIdx.z], fld_ = fl.d[blockIdx.z]
+// (GSTAMD_FRAME_Z: video_kernels.h)
+// the same for launchers of other compilation units (video_deep_pack.hip)
+const FrameDeltas &video_frame_list_for (const void *sp, const void *dp, int *nz) { return frame_list_for (sp, dp, nz); }
 
 template <int CH>
 __global__ __launch_bounds__ (256) void k_convert (FrontParams f, Planes pl, const int *__restrict__ vpair, ColorParams color,

@@ -26,6 +26,7 @@
 #include "../../gstreamer_amd/csrc/video_planes.h"
 #include "../../gstreamer_amd/csrc/video_encode_fast.h"
 #include "../../gstreamer_amd/csrc/video_deep.h"
+#include "../../gstreamer_amd/csrc/video_deep_pack.h"
 #include "../../gstreamer_amd/csrc/video_gamma.h"
 #include "../../gstreamer_amd/csrc/video_dither.h"
 #include "../../gstreamer_amd/csrc/video_dither_ed.h"
@@ -779,6 +780,10 @@ static int g_fast420p_runs = 0;
 extern "C" int emu_fast420p_runs (void) { return g_fast420p_runs; }
 extern "C" int emu_fast422_runs (void) { return g_fast422_runs; }
 static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, const Planes &pl, uint8_t *d0, int dstride, int vec_ok, bool rgb24);
+static const DeepPackParams *g_deep_hook = nullptr;    /* set while the sub-conversion of a shrinking 10-bit plan runs with the source itself as its pixels (k_deep_scale_pack) */
+int g_emu_deep_pack_runs = 0, g_emu_deep_pack_wide = 0;
+extern "C" int emu_deep_pack_runs (void) { return g_emu_deep_pack_runs; }
+extern "C" int emu_deep_pack_wide (void) { return g_emu_deep_pack_wide; }
 static const GammaDev *g_gamma_hook = nullptr;          /* set while the direct conversion of a fused gamma plan runs (k_convert_gamma) */
 static int g_gamma_fused_runs = 0;
 extern "C" int emu_gamma_fused_runs (void) { return g_gamma_fused_runs; }
@@ -1077,6 +1082,28 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         pl.p[i] = src + in->offset[i] + plane_origin (p.fin, i, p.rect.in_x, p.rect.in_y, in->stride[i]);
         pl.stride[i] = in->stride[i];
       }
+      {
+        /* convert_gamma's k_deep_scale_pack branch: the sub-conversion with the 10-bit source as its pixels */
+        VideoPlan subp;
+        std::string serr;
+        DeepPackParams dsp;
+        plan_set_border_override (p.rect.border);
+        const int sr = plan_video_converter (&g.mid_out, &g.sub_out_info, &g.cfg_out, &subp, &serr);
+        plan_set_border_override (nullptr);
+        if (sr == GSTAMD_OK && !g_gamma_hook && getenv ("GSTAMD_NO_DEEP_SCALE_PACK") == nullptr && deep_scale_pack_plan_ok (p, subp, &dsp)) {
+          dsp.pl = pl;
+          dsp.vpair = p.vpair.data ();
+          dsp.sh.offset = p.passes[0].offset.data (), dsp.sh.taps = p.passes[0].taps.data ();
+          dsp.sv.offset = p.passes[1].offset.data (), dsp.sv.taps = p.passes[1].taps.data ();
+          mid_b.assign ((size_t) out_w * out_h * 4, 0);
+          g_deep_hook = &dsp;
+          plan_set_border_override (p.rect.border);
+          r = emu_video_convert (&g.mid_out, &g.sub_out_info, &g.cfg_out, mid_b.data (), dst, vec_ok, nullptr, 0);
+          plan_set_border_override (nullptr);
+          g_deep_hook = nullptr;
+          return r;
+        }
+      }
       a.resize ((size_t) in_w * in_h * 8);
       for (int y = 0; y < in_h; y++)
         for (int x0 = 0; x0 < (in_w / 4 + 256) / 256 * 1024; x0 += 4)
@@ -1329,6 +1356,30 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         run (pp.passes[1].horizontal, sd[1], ts, dp, pp.ow, pp.oh);
       }
     }
+    return GSTAMD_OK;
+  }
+  if (p.out_planar && g_deep_hook) {       /* k_deep_scale_pack over its grid (launch_deep_scale_pack) */
+    DeepPackParams dp = *g_deep_hook;
+    DstPlanes d;
+    memset (&d, 0, sizeof (d));
+    for (int i = 0; i < out->n_planes && i < 3; i++) {
+      d.p[i] = dst + out->offset[i];
+      d.stride[i] = out->stride[i];
+    }
+    const int variant = deep_front4_variant (dp.f);
+    const bool semi = variant >= 3;
+    dp.vec = vec_ok && ((uintptr_t) dp.pl.p[0] % 16) == 0 && (dp.pl.stride[0] % 16) == 0 && ((uintptr_t) dp.pl.p[1] % 16) == 0 && (dp.pl.stride[1] % 16) == 0 &&
+        (semi || (((uintptr_t) dp.pl.p[2] % 16) == 0 && (dp.pl.stride[2] % 16) == 0));
+    int wide = !p.pack.dither.on && (p.pack.kind == UNPACK_PLANAR || p.pack.kind == UNPACK_SEMI) && !getenv ("GSTAMD_DEEP_PACK_NARROW");
+    for (int i = 0; wide && i < (p.pack.kind == UNPACK_SEMI ? 2 : 3); i++)
+      wide = ((uintptr_t) d.p[i] % 4) == 0 && (d.stride[i] % 4) == 0;
+    const int lanes = (p.pack.width + 3) / 4, rows = (p.pack.height + (1 << p.pack.h_sub) - 1) >> p.pack.h_sub;
+    g_emu_deep_pack_runs++;
+    if (wide && dp.hx2 && dp.vec)
+      g_emu_deep_pack_wide++;
+    for (int yb = 0; yb < rows; yb++)
+      for (int l = 0; l < (lanes + 63) / 64 * 64; l++)
+        deep_scale_pack_any (variant, p.pack, dp, d, wide, 4 * l, yb);
     return GSTAMD_OK;
   }
   if (p.out_planar && p.fout->kind == UNPACK_PACKED3 && p.passes.empty () && !p.deep16 && !p.pack.dither.on && p.matrix.kind == MATRIX_NONE &&

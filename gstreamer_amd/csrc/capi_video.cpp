@@ -125,6 +125,7 @@ struct GstAmdVideoConverter {
 
 namespace gstamd {
 hipError_t launch_deep_scale_pack (const PackPlanarParams &pk, const DeepPackParams &dp, uint8_t *const planes[3], const int strides[3], hipStream_t stream);
+bool deep_scale_pack_usable (const PackPlanarParams &pk, const DeepPackParams &dp, uint8_t *const planes[3], const int strides[3]);
 size_t fused420_lds_bytes (int ring, int nwaves, int sched);
 int fused420_blocks_per_cu (int nwaves, size_t lds, int sched);
 hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
@@ -829,12 +830,17 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
     }
     DeepPackParams dsp;
     bool dsp_ok = c->sub_out && deep_pack_usable (c, &dsp);
-    for (int i = 0; dsp_ok && i < p.in_info.n_planes && i < 3; i++)           /* the block form's loads: source rows on 16 bytes ... */
-      dsp_ok = ((uintptr_t) pl.p[i] % 16) == 0 && (pl.stride[i] % 16) == 0;
-    for (int i = 0; dsp_ok && i < p.out_info.n_planes && i < 3; i++) {          /* ... its stores: the rectangle's plane rows on 4 */
+    if (dsp_ok) {               /* the frames' side of the question: the kernel's 16-byte loads and 4-byte stores */
       const VideoPlan &sp = c->sub_out->plan;
-      const int ds = dest_stride ? dest_stride[i] : sp.out_info.stride[i];
-      dsp_ok = dest_planes[i] && ((uintptr_t) ((const uint8_t *) dest_planes[i] + plane_origin (sp.fout, i, sp.rect.out_x, sp.rect.out_y, ds)) % 4) == 0 && (ds % 4) == 0;
+      uint8_t *rp[3] = {nullptr, nullptr, nullptr};
+      int rs[3] = {0, 0, 0};
+      for (int i = 0; i < sp.out_info.n_planes && i < 3; i++) {
+        rs[i] = dest_stride ? dest_stride[i] : sp.out_info.stride[i];
+        dsp_ok = dsp_ok && dest_planes[i];
+        rp[i] = dest_planes[i] ? (uint8_t *) dest_planes[i] + plane_origin (sp.fout, i, sp.rect.out_x, sp.rect.out_y, rs[i]) : nullptr;
+      }
+      dsp.pl = pl;
+      dsp_ok = dsp_ok && deep_scale_pack_usable (sp.pack, dsp, rp, rs);
     }
     if (dsp_ok) {
       /* front, both passes, narrowing and the sub-conversion's pack in one kernel (video_deep_pack.h): the sub-conversion does what it does around its

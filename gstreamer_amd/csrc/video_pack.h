@@ -304,8 +304,9 @@ struct ImgRows {
   }
 };
 
+// (store false: the lane takes part in the row source's calls - a source may trade values between the lanes of a wave - and writes nothing)
 template <class ROWS>
-GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const ROWS &rows, const DstPlanes &d, int x0, int yb, long long dd = 0)
+GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const ROWS &rows, const DstPlanes &d, int x0, int yb, long long dd = 0, bool store = true)
 {
   const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub;
   if (x0 + 4 > w || y0 >= h || (pk.tail_swap && x0 + 4 == w && (w & 1)))
@@ -322,6 +323,8 @@ GSTAMD_HD bool pack_planar_block4 (const PackPlanarParams &pk, const ROWS &rows,
   uint4 b = a;
   if (pk.h_sub || pk.down_v)
     b = rows.row4n (x0, yb1, edges && pk.down_v, xm, xp, fm, fp);
+  if (!store)
+    return true;
   // luma
   *(uint32_t *) ((d.p[0] + dd) + (size_t) y0 * d.stride[0] + x0) = ((a.x >> 8) & 0xffu) | (a.y & 0xff00u) | ((a.z << 8) & 0xff0000u) | ((a.w << 16) & 0xff000000u);
   if (pk.h_sub && y0 + 1 < h)

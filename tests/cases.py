@@ -1876,3 +1876,31 @@ def audio_update_stream(case, do_update, do_resample, max_latency):
 
 def audio_update_has_options(item):
     return any(k in item for k in ("quality", "filter_mode", "filter_interpolation"))
+
+# round 6: k_deep_scale_pack (video_deep_pack.h) - a 10 / 12 / 16-bit planar or semi-planar source that halves (2-tap both ways) into an 8-bit planar /
+# semi-planar destination: one kernel.  Destinations above 576 lines take the cosited downsampler by default (chroma traded between lanes; 63 / 64 / 125
+# blocks a line: the last workgroup stores one, two, the first of the third one block), input sites, 4:2:2 and 4:4:4 ends, crop + rectangle + border.
+BIL2 = LIN
+VIDEO_CASES += [
+    ("dsp_p010_nv12_512x1160_cosited_down", "P010_10LE", 512, 1160, "NV12", 256, 580, BIL2, None, None, "random"),
+    ("dsp_p010_nv12_504x1160_63_blocks", "P010_10LE", 504, 1160, "NV12", 252, 580, BIL2, None, None, "random"),
+    ("dsp_i42010_i420_1000x1156_125_blocks", "I420_10LE", 1000, 1156, "I420", 500, 578, BIL2, None, "jpeg", "random"),
+    ("dsp_p010_nv21_128x64", "P010_10LE", 128, 64, "NV21", 64, 32, BIL2, None, None, "random"),
+    ("dsp_p010_yv12_16x8_smallest", "P010_10LE", 16, 8, "YV12", 8, 4, BIL2, None, None, "random"),
+    ("dsp_p010_nv12_site_cosited", "P010_10LE", 128, 66, "NV12", 64, 33, BIL2, None, "cosited", "random"),
+    ("dsp_p010_i420_site_jpeg", "P010_10LE", 136, 64, "I420", 68, 32, BIL2, None, "jpeg", "random"),
+    ("dsp_i42012_nv12", "I420_12LE", 128, 64, "NV12", 64, 32, BIL2, None, None, "random"),
+    ("dsp_p012_i420", "P012_LE", 128, 64, "I420", 64, 32, BIL2, None, "mpeg2", "random"),
+    ("dsp_p016_nv12", "P016_LE", 128, 64, "NV12", 64, 32, BIL2, None, None, "random"),
+    ("dsp_i42210_y42b", "I422_10LE", 128, 64, "Y42B", 64, 32, BIL2, None, None, "random"),
+    ("dsp_i42210_nv12", "I422_10LE", 128, 64, "NV12", 64, 32, BIL2, None, "jpeg", "random"),
+    ("dsp_p010_nv16", "P010_10LE", 128, 64, "NV16", 64, 32, BIL2, None, None, "random"),
+    ("dsp_p010_y444", "P010_10LE", 128, 64, "Y444", 64, 32, BIL2, None, None, "random"),
+    ("dsp_p010_nv12_crop_rect_border", "P010_10LE", 256, 128, "NV12", 96, 48, dict(BIL2, src_x=64, src_y=32, src_width=128, src_height=64, dest_x=16, dest_y=8, dest_width=64, dest_height=32, border_argb=0xff204060), None, None, "random"),
+    ("dsp_p010_nv12_hd_crop_rect", "P010_10LE", 640, 1300, "NV12", 300, 620, dict(BIL2, src_x=16, src_y=20, src_width=512, src_height=1160, dest_x=20, dest_y=10, dest_width=256, dest_height=580, border_argb=0xff80c020), None, None, "random"),
+    # shapes the kernel leaves to the composite's launches: 4-tap, a width that is no multiple of four, another ratio, a dither stage
+    ("dsp_not_p010_nv12_linear4", "P010_10LE", 128, 64, "NV12", 64, 32, dict(resampler_method="linear"), None, None, "random"),
+    ("dsp_not_p010_nv12_ow_62", "P010_10LE", 124, 64, "NV12", 62, 32, BIL2, None, None, "random"),
+    ("dsp_not_p010_nv12_third", "P010_10LE", 192, 96, "NV12", 64, 32, BIL2, None, None, "random"),
+    ("dsp_not_p010_nv12_dither", "P010_10LE", 128, 64, "NV12", 64, 32, dict(BIL2, dither_method="bayer", dither_quantization=4), None, None, "random"),
+]

@@ -1367,19 +1367,12 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       d.stride[i] = out->stride[i];
     }
     const int variant = deep_front4_variant (dp.f);
-    const bool semi = variant >= 3;
-    dp.vec = vec_ok && ((uintptr_t) dp.pl.p[0] % 16) == 0 && (dp.pl.stride[0] % 16) == 0 && ((uintptr_t) dp.pl.p[1] % 16) == 0 && (dp.pl.stride[1] % 16) == 0 &&
-        (semi || (((uintptr_t) dp.pl.p[2] % 16) == 0 && (dp.pl.stride[2] % 16) == 0));
-    int wide = !p.pack.dither.on && (p.pack.kind == UNPACK_PLANAR || p.pack.kind == UNPACK_SEMI) && !getenv ("GSTAMD_DEEP_PACK_NARROW");
-    for (int i = 0; wide && i < (p.pack.kind == UNPACK_SEMI ? 2 : 3); i++)
-      wide = ((uintptr_t) d.p[i] % 4) == 0 && (d.stride[i] % 4) == 0;
-    const int lanes = (p.pack.width + 3) / 4, rows = (p.pack.height + (1 << p.pack.h_sub) - 1) >> p.pack.h_sub;
+    const int nblk = p.pack.width / 4, rows = (p.pack.height + (1 << p.pack.h_sub) - 1) >> p.pack.h_sub;
     g_emu_deep_pack_runs++;
-    if (wide && dp.hx2 && dp.vec)
-      g_emu_deep_pack_wide++;
+    g_emu_deep_pack_wide++;
     for (int yb = 0; yb < rows; yb++)
-      for (int l = 0; l < (lanes + 63) / 64 * 64; l++)
-        deep_scale_pack_any (variant, p.pack, dp, d, wide, 4 * l, yb);
+      for (int l = 0; l < nblk; l++)          /* (the device's lanes 0 and 63 of a workgroup repeat a neighbour's block and store nothing) */
+        deep_scale_pack_any (variant, p.pack, dp, d, 4 * l, yb);
     return GSTAMD_OK;
   }
   if (p.out_planar && p.fout->kind == UNPACK_PACKED3 && p.passes.empty () && !p.deep16 && !p.pack.dither.on && p.matrix.kind == MATRIX_NONE &&

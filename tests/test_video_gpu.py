@@ -166,6 +166,32 @@ def test_hip_matches_reference_bytewise_c5_full_size(native_lib, gpu, ref):
     assert (out == exp).all(), int((out != exp).sum())
 
 
+@pytest.mark.parametrize("shape", [("P010_10LE", 3840, 2160, "NV12"), ("I420_10LE", 3840, 2160, "I420"), ("P010_10LE", 1280, 2400, "NV21"), ("P010_10LE", 2016, 1208, "NV12")],
+                         ids=lambda s: "%s_%dx%d_%s" % s)
+def test_hip_deep_scale_pack_matches_reference_bytewise(native_lib, gpu, ref, shape):
+    """k_deep_scale_pack (video_deep_pack.h): a 10-bit source that halves into an 8-bit planar / semi-planar destination - the decoder-to-encoder
+    shape of an HDR transcode at its own size (8 workgroups a line; the cosited downsampler's chroma traded between lanes and, at the workgroups'
+    seams, made twice), memcmp'd against the reference; one launch (the converter says so for a frame list)"""
+    import torch
+    ifmt, w, h, ofmt = shape
+    ow, oh = w // 2, h // 2
+    src = cases.frame_bytes(ref.video_info(ifmt, w, h)["size"], "random", w + h)
+    exp = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, cases.LIN)).frame(src)
+    out = gpu_convert(gpu, ifmt, w, h, ofmt, ow, oh, cases.LIN, None, None, src)
+    assert out.size == exp.size and (out == exp).all(), int((out != exp).sum())
+    ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)
+    conv = V.VideoConverter(ii, oi, V.converter_config(**cases.LIN))
+    srcs = [torch.from_numpy(np.roll(src, i * 4099)).to(gpu) for i in range(3)]
+    outs = [torch.zeros(int(oi.size), dtype=torch.uint8, device=gpu) for _ in range(3)]
+    conv.frames(srcs, outs)
+    torch.cuda.synchronize()
+    assert conv.list_launches() == 1
+    assert (outs[0].cpu().numpy() == exp).all()
+    rc = ref.VideoConverter(ifmt, w, h, ofmt, ow, oh, config=cases.ref_config_string(ref, cases.LIN))
+    assert (outs[2].cpu().numpy() == rc.frame(np.roll(src, 2 * 4099))).all()
+    conv.free()
+
+
 def test_hip_frame_list_32x4k_matches_reference(native_lib, gpu, ref):
     """The launch bench.py times - 32 frames of 3840x2160 NV12 -> BGRA in ONE gstamd_video_converter_frames call, 32 distinct
     output buffers - against 32 reference frames (sha256 per frame)."""

@@ -659,3 +659,38 @@ def test_deep_plane_copies_without_border_fill_on_host(native_lib, emu_lib, ref,
     assert ok, text
     stride = V.video_info(ofmt, ow, oh).stride[0]
     assert not dst[:cfg["dest_y"] * stride].any()
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("dsp_")])
+def test_deep_scale_pack_body_is_the_one_that_runs(native_lib, emu_lib, name, monkeypatch):
+    """the dsp_* cases (a 10-bit planar / semi-planar source that halves into an 8-bit planar / semi-planar destination) go through
+    k_deep_scale_pack's lane function (video_deep_pack.h: front, both u16 passes, narrowing and pack per block) - the dsp_not_* ones (other filters,
+    ratios, widths, a dither stage) do not - and through the composite's four launches with GSTAMD_NO_DEEP_SCALE_PACK, with the reference's bytes
+    either way"""
+    _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
+    src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
+    emu_lib.emu_deep_pack_runs.restype = C.c_int
+    before = emu_lib.emu_deep_pack_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_deep_pack_runs() - before == (0 if name.startswith("dsp_not_") else 1)
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+    monkeypatch.setenv("GSTAMD_NO_DEEP_SCALE_PACK", "1")
+    before = emu_lib.emu_deep_pack_runs()
+    dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
+    assert emu_lib.emu_deep_pack_runs() == before
+    assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
+
+
+def test_packed_chroma_identities_of_deep_scale_pack():
+    """video_deep_pack.h runs the u16 chroma upsamplers on {c1 | c2 << 16} pairs through (a | b) - ((a ^ b) >> 1), (a & b) + ((a ^ b) >> 1) and
+    (3 a + b + 2) >> 2 = avg_ceil (a, avg_floor (a, b)): checked here on the edge values and a random sample of 16-bit pairs"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    a = np.concatenate([np.array([0, 0, 1, 65535, 65535, 65534, 1, 2, 3, 32768], np.int64), rng.integers(0, 65536, 200000)])
+    b = np.concatenate([np.array([0, 65535, 0, 65535, 0, 65535, 2, 1, 65535, 32767], np.int64), rng.integers(0, 65536, 200000)])
+    avgc = (a | b) - ((a ^ b) >> 1)
+    avgf = (a & b) + ((a ^ b) >> 1)
+    assert (avgc == (a + b + 1) >> 1).all() and (avgf == (a + b) >> 1).all()
+    f31 = (a | avgf) - ((a ^ avgf) >> 1)
+    assert (f31 == (3 * a + b + 2) >> 2).all()
+    assert (f31 == (6 * a + 2 * b + 4) >> 3).all()

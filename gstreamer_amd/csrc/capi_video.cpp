@@ -126,6 +126,8 @@ struct GstAmdVideoConverter {
 namespace gstamd {
 hipError_t launch_deep_scale_pack (const PackPlanarParams &pk, const DeepPackParams &dp, uint8_t *const planes[3], const int strides[3], hipStream_t stream);
 bool deep_scale_pack_usable (const PackPlanarParams &pk, const DeepPackParams &dp, uint8_t *const planes[3], const int strides[3]);
+hipError_t launch_deep_scale4 (const DeepPackParams &dp, const Deep16Params &dd, const PostParams &post, uint8_t *dst, int dstride, hipStream_t stream);
+bool deep_scale4_usable (const DeepPackParams &dp, const uint8_t *dst, int dstride);
 size_t fused420_lds_bytes (int ring, int nwaves, int sched);
 int fused420_blocks_per_cu (int nwaves, size_t lds, int sched);
 hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
@@ -1527,6 +1529,18 @@ static int convert_deep_scaled (GstAmdVideoConverter *c, const Planes &pl, uint8
   const int in_w = p.front.width, in_h = p.front.height, out_w = p.out_info.width, out_h = p.out_info.height;
   const size_t n = p.passes.size ();
   const size_t bpp = p.matrix_before_scale ? 4 : 8;
+  DeepPackParams ds4;
+  if (!c->hook_on && !tuning_on ("GSTAMD_NO_DEEP_SCALE_PACK") && deep_scale4_plan_ok (p, &ds4)) {
+    /* a picture that halves (2-tap both ways): front, both passes, convert stage and pack in one kernel, no 16-bit image (video_deep_pack.h) */
+    ds4.pl = pl;
+    ds4.vpair = c->vpair_dev;
+    ds4.sh.offset = c->pass_dev[0].offset, ds4.sh.taps = c->pass_dev[0].taps;
+    ds4.sv.offset = c->pass_dev[1].offset, ds4.sv.taps = c->pass_dev[1].taps;
+    if (deep_scale4_usable (ds4, dst, dstride)) {
+      const hipError_t fe = launch_deep_scale4 (ds4, p.deep, p.post, dst, dstride, stream);
+      return fe == hipSuccess ? GSTAMD_OK : hip_fail (fe, "k_deep_scale4");
+    }
+  }
   const int mid_w = p.passes[0].horizontal ? p.passes[0].out_size : in_w, mid_h = p.passes[0].horizontal ? in_h : p.passes[0].out_size;
   const size_t need_a = (size_t) in_w * in_h * bpp, need_b = n == 2 ? (size_t) mid_w * mid_h * bpp : 0;
   hipError_t e;

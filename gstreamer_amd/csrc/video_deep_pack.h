@@ -81,7 +81,7 @@ GSTAMD_HD int deep_v2tap (int s1, int s2, uint32_t p1)
 
 // a source line after the horizontal pass at the block's four positions: luma, and the two chroma components
 struct DeepHLine {
-  int y[4], c1[4], c2[4];
+  int y[4], c1[4], c2[4], al[4];        // (al: the alpha of AYUV64 lines, 0xffff through the pass - read by the 4-byte destinations only)
 };
 
 // The packer's row source (video_pack.h pack_planar_block4's ROWS): pixels x0 .. x0 + 3 of line y of the scaled, narrowed picture from the source planes.
@@ -153,40 +153,48 @@ struct DeepScaledSrc {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       o->y[i] = deep_h2tap_pk (pk_widen (wd, lw[i]), tw[i]);
+      o->al[i] = deep_h2tap_pk (0xffffffffu, tw[i]);
       const uint32_t e = pk_f31 (first[2 * i], second[2 * i]), g = pk_f31 (first[2 * i + 1], second[2 * i + 1]);        /* even and odd source pixel */
       o->c1[i] = deep_h2tap_pk ((e & 0xffffu) | (g << 16), tw[i]);
       o->c2[i] = deep_h2tap_pk ((e >> 16) | (g & 0xffff0000u), tw[i]);
     }
   }
 
-  // the block's pixels of destination line y: two source lines, whose four chroma rows are three in a picture that halves (rows y - 1, y | y, y + 1: the
-  // second line's first row is the first line's second - it goes through the horizontal upsampler once; the keys are wave-uniform)
-  GSTAMD_HD uint4 core4 (int x0, int y) const
+  // destination line y at the block's positions: its two source lines after the horizontal pass, the vertical pass's parameter.  The lines' four chroma
+  // rows are three in a picture that halves (rows y - 1, y | y, y + 1: the second line's first row is the first line's second - it goes through the
+  // horizontal upsampler once; the keys are wave-uniform)
+  GSTAMD_HD uint32_t lines2 (int x0, int y, DeepHLine *a, DeepHLine *b) const
   {
     const int off = (int) d.sv.offset[y];
-    const uint32_t p1 = (uint32_t) (uint16_t) d.sv.taps[2 * (size_t) y + 1];
     const int h = d.f.height;
     const int La = off < 0 ? 0 : (off > h - 1 ? h - 1 : off), Lb = off + 1 > h - 1 ? h - 1 : off + 1;          /* deep_img_at's clamp */
     const FrontRow fa = deep_front_row (d.f, d.vpair, La), fb = deep_front_row (d.f, d.vpair, Lb);
     const PkWiden wd = pk_widen_params (d.f.hi_depth);
+    uint32_t c0[8], c1[8];
+    crow8 (wd, fa.cw, fa.ra, x0, c0);
+    crow8 (wd, fa.cw, fa.rb, x0, c1);
+    if (fa.wa == 6)
+      hline4 (wd, c0, c1, x0, La, a);
+    else
+      hline4 (wd, c1, c0, x0, La, a);
+    if (fb.ra != fa.rb)
+      crow8 (wd, fb.cw, fb.ra, x0, c1);
+    crow8 (wd, fb.cw, fb.rb, x0, c0);
+    if (fb.wa == 6)
+      hline4 (wd, c1, c0, x0, Lb, b);
+    else
+      hline4 (wd, c0, c1, x0, Lb, b);
+    return (uint32_t) (uint16_t) d.sv.taps[2 * (size_t) y + 1];
+  }
+
+  GSTAMD_HD bool c1_is_u () const { return SEMI ? d.f.u_plane != 0 : d.f.u_plane == 1; }
+
+  // the block's pixels of destination line y, narrowed (video_orc_convert_u16_to_u8): A Y U V bytes
+  GSTAMD_HD uint4 core4 (int x0, int y) const
+  {
     DeepHLine a, b;
-    {
-      uint32_t c0[8], c1[8];
-      crow8 (wd, fa.cw, fa.ra, x0, c0);
-      crow8 (wd, fa.cw, fa.rb, x0, c1);
-      if (fa.wa == 6)
-        hline4 (wd, c0, c1, x0, La, &a);
-      else
-        hline4 (wd, c1, c0, x0, La, &a);
-      if (fb.ra != fa.rb)
-        crow8 (wd, fb.cw, fb.ra, x0, c1);
-      crow8 (wd, fb.cw, fb.rb, x0, c0);
-      if (fb.wa == 6)
-        hline4 (wd, c1, c0, x0, Lb, &b);
-      else
-        hline4 (wd, c0, c1, x0, Lb, &b);
-    }
-    const bool usw = SEMI ? d.f.u_plane != 0 : d.f.u_plane == 1;          /* c1 is U */
+    const uint32_t p1 = lines2 (x0, y, &a, &b);
+    const bool usw = c1_is_u ();
     uint32_t px[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -196,6 +204,20 @@ struct DeepScaledSrc {
     uint4 r;
     r.x = px[0], r.y = px[1], r.z = px[2], r.w = px[3];
     return r;
+  }
+
+  // the same as AYUV64 pixels {A | Y << 16, U | V << 16}: what the convert stage of a 4-byte destination takes (deep_finish_store4)
+  GSTAMD_HD void core4_16 (int x0, int y, uint2 *px) const
+  {
+    DeepHLine a, b;
+    const uint32_t p1 = lines2 (x0, y, &a, &b);
+    const bool usw = c1_is_u ();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t v1 = (uint32_t) deep_v2tap (a.c1[i], b.c1[i], p1), v2 = (uint32_t) deep_v2tap (a.c2[i], b.c2[i], p1);
+      px[i].x = (uint32_t) deep_v2tap (a.al[i], b.al[i], p1) | ((uint32_t) deep_v2tap (a.y[i], b.y[i], p1) << 16);
+      px[i].y = (usw ? v1 : v2) | ((usw ? v2 : v1) << 16);
+    }
   }
 
   GSTAMD_HD uint4 row4n (int x0, int y, bool edges, int, int, uint32_t &em, uint32_t &ep) const
@@ -223,6 +245,32 @@ GSTAMD_HD void deep_scale_pack_lane (const PackPlanarParams &pk, const DeepPackP
   (void) pack_planar_block4 (pk, src, dst, x0, yb, dd, store);
 }
 
+// one lane of k_deep_scale4: pixels x0 .. x0 + 3 of line y of a 4-byte destination - the same chain up to the vertical pass, then the convert stage on
+// 16-bit values (video_converter_matrix16), narrowing, alpha and pack (deep_finish_store4: what k_scale16_final does after its pass)
+template <int SEMI, int CH>
+GSTAMD_HD void deep_scale4_lane (const DeepPackParams &dp, const Deep16Params &dd, const PostParams &post, uint8_t *dst, int dstride, int x0, int y)
+{
+  if (x0 + 4 > dp.out_w || y >= dp.out_h)
+    return;
+  DeepScaledSrc<SEMI, CH> src;
+  src.d = dp;
+  uint2 px[4];
+  src.core4_16 (x0, y, px);
+  deep_finish_store4 (dd, post, px, (uint32_t *) (dst + (size_t) y * dstride + 4 * (size_t) x0));
+}
+
+GSTAMD_HD void deep_scale4_any (int variant, const DeepPackParams &dp, const Deep16Params &dd, const PostParams &post, uint8_t *dst, int dstride, int x0, int y)
+{
+  switch (variant) {
+    case 0: deep_scale4_lane<0, CHROMA_H_NONE> (dp, dd, post, dst, dstride, x0, y); break;
+    case 1: deep_scale4_lane<0, CHROMA_H_H2> (dp, dd, post, dst, dstride, x0, y); break;
+    case 2: deep_scale4_lane<0, CHROMA_H_H2_CS> (dp, dd, post, dst, dstride, x0, y); break;
+    case 3: deep_scale4_lane<1, CHROMA_H_NONE> (dp, dd, post, dst, dstride, x0, y); break;
+    case 4: deep_scale4_lane<1, CHROMA_H_H2> (dp, dd, post, dst, dstride, x0, y); break;
+    default: deep_scale4_lane<1, CHROMA_H_H2_CS> (dp, dd, post, dst, dstride, x0, y); break;
+  }
+}
+
 GSTAMD_HD void deep_scale_pack_any (int variant, const PackPlanarParams &pk, const DeepPackParams &dp, const DstPlanes &dst, int x0, int yb)
 {
   switch (variant) {
@@ -233,6 +281,39 @@ GSTAMD_HD void deep_scale_pack_any (int variant, const PackPlanarParams &pk, con
     case 4: deep_scale_pack_lane<1, CHROMA_H_H2> (pk, dp, dst, x0, yb); break;
     default: deep_scale_pack_lane<1, CHROMA_H_H2_CS> (pk, dp, dst, x0, yb); break;
   }
+}
+
+// host: two passes, horizontal first, both 2-tap, the horizontal one reading source pixels 2 x, 2 x + 1 for output x with taps 0 .. 4096 (pk_udot2), a front
+// the lanes know (planes with horizontally subsampled chroma, frame weights 3 : 1)
+inline bool deep_passes_halve (const VideoPlan &p)
+{
+  if (p.passes.size () != 2 || !p.passes[0].horizontal || p.passes[1].horizontal || deep_front4_variant (p.front) < 0 || p.front.chroma_v2 == 2)
+    return false;
+  const int ow = p.passes[0].out_size;
+  bool hx2 = p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && p.front.width >= 2 * ow && ow >= 8;
+  for (int x = 0; hx2 && x < ow; x++)
+    hx2 = (int) p.passes[0].offset[x] == 2 * x && p.passes[0].taps[2 * (size_t) x] >= 0 && p.passes[0].taps[2 * (size_t) x + 1] >= 0 &&
+        (int) p.passes[0].taps[2 * (size_t) x] + (int) p.passes[0].taps[2 * (size_t) x + 1] <= 8192;
+  return hx2;
+}
+
+// host: is `p` (a 10-bit source into a 4-byte 8-bit destination that shrinks: VideoPlan::deep16 with the scalers ahead of the convert stage) one
+// k_deep_scale4 serves?  Fills everything of `dp` but the pointers.
+inline bool deep_scale4_plan_ok (const VideoPlan &p, DeepPackParams *dp)
+{
+  if (!p.deep16 || p.gamma.on || p.matrix_before_scale || p.interlaced || p.field || p.out_planar || p.plane_mode || p.fout->kind != UNPACK_PACKED4 ||
+      p.fout->hi_depth != 0 || !deep_passes_halve (p))
+    return false;
+  const int ow = p.passes[0].out_size, oh = p.passes[1].out_size;
+  if (ow != p.out_info.width || oh != p.out_info.height || (ow % 4) != 0)
+    return false;
+  memset ((void *) dp, 0, sizeof (*dp));
+  dp->f = p.front;
+  dp->out_w = ow, dp->out_h = oh;
+  dp->sh.kind = p.passes[0].kind, dp->sh.n_taps = p.passes[0].n_taps, dp->sh.inc = p.passes[0].inc;
+  dp->sv.kind = p.passes[1].kind, dp->sv.n_taps = p.passes[1].n_taps, dp->sv.inc = p.passes[1].inc;
+  dp->hx2 = 1;
+  return true;
 }
 
 // host: is `p` (a composite plan with a 10-bit source, GammaPlan::src16) with the sub-conversion `sub` (8-bit unpack-format image -> destination) one
@@ -263,10 +344,7 @@ inline bool deep_scale_pack_plan_ok (const VideoPlan &p, const VideoPlan &sub, D
   dp->out_w = ow, dp->out_h = oh;
   dp->sh.kind = p.passes[0].kind, dp->sh.n_taps = p.passes[0].n_taps, dp->sh.inc = p.passes[0].inc;
   dp->sv.kind = p.passes[1].kind, dp->sv.n_taps = p.passes[1].n_taps, dp->sv.inc = p.passes[1].inc;
-  bool hx2 = p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && p.front.width >= 2 * ow && ow >= 8;
-  for (int x = 0; hx2 && x < ow; x++)
-    hx2 = (int) p.passes[0].offset[x] == 2 * x && p.passes[0].taps[2 * (size_t) x] >= 0 && p.passes[0].taps[2 * (size_t) x + 1] >= 0 &&
-        (int) p.passes[0].taps[2 * (size_t) x] + (int) p.passes[0].taps[2 * (size_t) x + 1] <= 8192;
+  const bool hx2 = deep_passes_halve (p);
   dp->hx2 = hx2;
   /* whole blocks only (a per-pixel form of the same chain was tried as the path of every other shape: as a whole frame's path it loses to the
      multi-launch composite - P010 4K -> NV12 1080p 4-tap 547 us against 85) */

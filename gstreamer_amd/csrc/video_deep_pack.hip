@@ -67,4 +67,43 @@ hipError_t launch_deep_scale_pack (const PackPlanarParams &pk, const DeepPackPar
   return hipGetLastError ();
 }
 
+// ---- k_deep_scale4: the same chain into a 4-byte 8-bit destination (P010 -> BGRA at half the size): a lane = four pixels of a line, one 16-byte store
+template <int SEMI, int CH>
+__global__ __launch_bounds__ (64) void k_deep_scale4 (DeepPackParams dp, Deep16Params dd, PostParams post, uint8_t *__restrict__ dst, int dstride, FrameDeltas fl)
+{
+  GSTAMD_FRAME_Z;
+  dp.pl.p[0] += fls_, dp.pl.p[1] += fls_;
+  if (!SEMI)
+    dp.pl.p[2] += fls_;
+  deep_scale4_lane<SEMI, CH> (dp, dd, post, dst + fld_, dstride, (int) (blockIdx.x * 64 + threadIdx.x) * 4, (int) blockIdx.y);
+}
+
+bool deep_scale4_usable (const DeepPackParams &dp, const uint8_t *dst, int dstride)
+{
+  const int variant = deep_front4_variant (dp.f);
+  bool ok = dp.hx2 && variant >= 0 && (dp.out_w % 4) == 0 && ((uintptr_t) dst % 4) == 0 && (dstride % 4) == 0;
+  for (int i = 0; ok && i < (variant >= 3 ? 2 : 3); i++)
+    ok = ((uintptr_t) dp.pl.p[i] % 16) == 0 && (dp.pl.stride[i] % 16) == 0;
+  return ok;
+}
+
+hipError_t launch_deep_scale4 (const DeepPackParams &dp, const Deep16Params &dd, const PostParams &post, uint8_t *dst, int dstride, hipStream_t stream)
+{
+  if (!deep_scale4_usable (dp, dst, dstride))
+    return hipErrorNotSupported;
+  int nz;
+  const FrameDeltas &fl = video_frame_list_for (dp.pl.p[0], dst, &nz);
+  const dim3 grid ((dp.out_w / 4 + 63) / 64, dp.out_h, nz);
+  switch (deep_front4_variant (dp.f)) {
+    case 0: hipLaunchKernelGGL ((k_deep_scale4<0, CHROMA_H_NONE>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 1: hipLaunchKernelGGL ((k_deep_scale4<0, CHROMA_H_H2>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 2: hipLaunchKernelGGL ((k_deep_scale4<0, CHROMA_H_H2_CS>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 3: hipLaunchKernelGGL ((k_deep_scale4<1, CHROMA_H_NONE>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 4: hipLaunchKernelGGL ((k_deep_scale4<1, CHROMA_H_H2>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 5: hipLaunchKernelGGL ((k_deep_scale4<1, CHROMA_H_H2_CS>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    default: return hipErrorNotSupported;
+  }
+  return hipGetLastError ();
+}
+
 }  // namespace gstamd

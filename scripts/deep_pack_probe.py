@@ -18,7 +18,8 @@ BIL, LIN, CUB = dict(resampler_method="linear", max_taps=2), dict(resampler_meth
 CASES = [("P010_10LE", 3840, 2160, "NV12", 1920, 1080, BIL), ("P010_10LE", 3840, 2160, "I420", 1920, 1080, BIL), ("I420_10LE", 3840, 2160, "NV12", 1920, 1080, BIL),
          ("P010_10LE", 3840, 2160, "NV12", 1280, 720, BIL), ("P010_10LE", 3840, 2160, "NV12", 1920, 1080, LIN), ("P010_10LE", 3840, 2160, "NV12", 1920, 1080, CUB),
          ("P010_10LE", 1920, 1080, "NV12", 960, 540, BIL), ("P010_10LE", 2560, 1440, "NV12", 1920, 1080, BIL), ("P010_10LE", 3840, 2160, "YUY2", 1920, 1080, BIL),
-         ("P010_10LE", 7680, 4320, "NV12", 3840, 2160, BIL)]
+         ("P010_10LE", 7680, 4320, "NV12", 3840, 2160, BIL), ("P010_10LE", 3840, 2160, "BGRA", 1920, 1080, BIL), ("I420_10LE", 3840, 2160, "RGBA", 1920, 1080, BIL),
+         ("P010_10LE", 7680, 4320, "BGRA", 3840, 2160, BIL)]
 if len(sys.argv) > 1:
     CASES = [CASES[int(a)] for a in sys.argv[1:]]
 dev = torch.device("cuda:0")

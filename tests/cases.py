@@ -1904,3 +1904,18 @@ VIDEO_CASES += [
     ("dsp_not_p010_nv12_third", "P010_10LE", 192, 96, "NV12", 64, 32, BIL2, None, None, "random"),
     ("dsp_not_p010_nv12_dither", "P010_10LE", 128, 64, "NV12", 64, 32, dict(BIL2, dither_method="bayer", dither_quantization=4), None, None, "random"),
 ]
+
+# ... and k_deep_scale4: the same chain into a 4-byte 8-bit destination (the convert stage on 16-bit values after the vertical pass)
+VIDEO_CASES += [
+    ("dsp4_p010_bgra_512x1160", "P010_10LE", 512, 1160, "BGRA", 256, 580, BIL2, None, None, "random"),
+    ("dsp4_i42010_rgba_site_jpeg", "I420_10LE", 128, 66, "RGBA", 64, 33, BIL2, None, "jpeg", "random"),
+    ("dsp4_p010_argb_alpha_set", "P010_10LE", 136, 64, "ARGB", 68, 32, dict(BIL2, alpha_mode="set", alpha_value=0.5), None, "cosited", "random"),
+    ("dsp4_p010_bgrx_bt2020", "P010_10LE", 128, 64, "BGRx", 64, 32, BIL2, "bt2020", None, "random"),
+    ("dsp4_i42012_xrgb", "I420_12LE", 128, 64, "xRGB", 64, 32, BIL2, None, None, "random"),
+    ("dsp4_p016_ayuv_same_matrix", "P016_LE", 128, 64, "AYUV", 64, 32, BIL2, None, None, "random"),
+    ("dsp4_i42210_vuya", "I422_10LE", 128, 64, "VUYA", 64, 32, BIL2, None, None, "random"),
+    ("dsp4_p010_bgra_crop_rect_border", "P010_10LE", 256, 128, "BGRA", 96, 48, dict(BIL2, src_x=64, src_y=32, src_width=128, src_height=64, dest_x=16, dest_y=8, dest_width=64, dest_height=32, border_argb=0xff204060), None, None, "random"),
+    ("dsp4_p010_bgra_dither", "P010_10LE", 128, 64, "BGRA", 64, 32, dict(BIL2, dither_method="bayer", dither_quantization=4), None, None, "random"),
+    ("dsp4_not_p010_bgra_ow_62", "P010_10LE", 124, 64, "BGRA", 62, 32, BIL2, None, None, "random"),
+    ("dsp4_not_p010_bgra_cubic", "P010_10LE", 128, 64, "BGRA", 64, 32, dict(resampler_method="cubic"), None, None, "random"),
+]

@@ -1745,6 +1745,19 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
         convert16_lane4 (p.front, pl, vpair, p.deep, p.post, d0, dstride, x0, y);
     return GSTAMD_OK;
   }
+  DeepPackParams ds4;
+  if (p.deep16 && !p.matrix_before_scale && !g_gamma_hook && getenv ("GSTAMD_NO_DEEP_SCALE_PACK") == nullptr && deep_scale4_plan_ok (p, &ds4) && ((uintptr_t) d0 % 4) == 0 &&
+      (dstride % 4) == 0) {         /* k_deep_scale4 over its grid */
+    ds4.pl = pl;
+    ds4.vpair = vpair;
+    ds4.sh.offset = p.passes[0].offset.data (), ds4.sh.taps = p.passes[0].taps.data ();
+    ds4.sv.offset = p.passes[1].offset.data (), ds4.sv.taps = p.passes[1].taps.data ();
+    g_emu_deep_pack_runs++;
+    for (int y = 0; y < ds4.out_h; y++)
+      for (int l = 0; l < (ds4.out_w / 4 + 63) / 64 * 64; l++)
+        deep_scale4_any (deep_front4_variant (p.front), ds4, p.deep, p.post, d0, dstride, 4 * l, y);
+    return GSTAMD_OK;
+  }
   if (p.deep16 && !p.matrix_before_scale) {        /* convert_deep_scaled: k_front16, k_scale16 ..., k_scale16_final */
     const int in_w = p.front.width, in_h = p.front.height;
     std::vector<uint8_t> a ((size_t) in_w * in_h * 8), b;

@@ -661,18 +661,18 @@ def test_deep_plane_copies_without_border_fill_on_host(native_lib, emu_lib, ref,
     assert not dst[:cfg["dest_y"] * stride].any()
 
 
-@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("dsp_")])
+@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("dsp_") or c[0].startswith("dsp4_")])
 def test_deep_scale_pack_body_is_the_one_that_runs(native_lib, emu_lib, name, monkeypatch):
     """the dsp_* cases (a 10-bit planar / semi-planar source that halves into an 8-bit planar / semi-planar destination) go through
-    k_deep_scale_pack's lane function (video_deep_pack.h: front, both u16 passes, narrowing and pack per block) - the dsp_not_* ones (other filters,
-    ratios, widths, a dither stage) do not - and through the composite's four launches with GSTAMD_NO_DEEP_SCALE_PACK, with the reference's bytes
-    either way"""
+    k_deep_scale_pack's lane function (video_deep_pack.h: front, both u16 passes, narrowing and pack per block), the dsp4_* ones (a 4-byte
+    destination) through k_deep_scale4's - the *_not_* ones (other filters, ratios, widths, a dither stage ahead of a planar pack) do not - and through
+    the multi-launch forms with GSTAMD_NO_DEEP_SCALE_PACK, with the reference's bytes either way"""
     _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
     emu_lib.emu_deep_pack_runs.restype = C.c_int
     before = emu_lib.emu_deep_pack_runs()
     dst = _emu_convert(emu_lib, ifmt, w, h, ofmt, ow, oh, cfg, col, site, src)
-    assert emu_lib.emu_deep_pack_runs() - before == (0 if name.startswith("dsp_not_") else 1)
+    assert emu_lib.emu_deep_pack_runs() - before == (0 if "_not_" in name else 1)
     assert cases.video_digest(name, dst) == GOLDEN[name]["sha256"]
     monkeypatch.setenv("GSTAMD_NO_DEEP_SCALE_PACK", "1")
     before = emu_lib.emu_deep_pack_runs()

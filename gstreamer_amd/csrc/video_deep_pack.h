@@ -35,8 +35,36 @@ struct DeepPackParams {
 //   (3 a + b + 2) >> 2 = ((a + ((a + b) >> 1)) + 1) >> 1  video_chroma_up_h2_u16, video_chroma_up_v2_u16 (deep_front1_t's (6 a + 2 b + 4) >> 3)
 // (the last one: with s = a + b even both sides are (2 a + s + 2) >> 2; with s odd the right side is (2 a + s + 1) >> 2 and 2 a + s + 2 is odd, so
 // the floor does not move).  No half ever carries into the other: each intermediate is at most max (a, b).
-GSTAMD_HD uint32_t pk_avgc (uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7fff7fffu); }
-GSTAMD_HD uint32_t pk_avgf (uint32_t a, uint32_t b) { return (a & b) + (((a ^ b) >> 1) & 0x7fff7fffu); }
+GSTAMD_HD uint32_t pk_half (uint32_t v)          // both halves >> 1 (v_pk_lshrrev_b16: no mask to apply)
+{
+#ifdef __HIPCC__
+  typedef unsigned short u2 __attribute__ ((ext_vector_type (2)));
+  u2 t = __builtin_bit_cast (u2, v);
+  t >>= 1;
+  return __builtin_bit_cast (uint32_t, t);
+#else
+  return (v >> 1) & 0x7fff7fffu;
+#endif
+}
+GSTAMD_HD uint32_t pk_avgc (uint32_t a, uint32_t b) { return (a | b) - pk_half (a ^ b); }
+GSTAMD_HD uint32_t pk_avgf (uint32_t a, uint32_t b) { return (a & b) + pk_half (a ^ b); }
+// {lo (a) | lo (b) << 16} and {hi (a) | hi (b) << 16}: one v_perm_b32 each
+GSTAMD_HD uint32_t pk_lo2 (uint32_t a, uint32_t b)
+{
+#ifdef __HIPCC__
+  return __builtin_amdgcn_perm (b, a, 0x05040100u);
+#else
+  return (a & 0xffffu) | (b << 16);
+#endif
+}
+GSTAMD_HD uint32_t pk_hi2 (uint32_t a, uint32_t b)
+{
+#ifdef __HIPCC__
+  return __builtin_amdgcn_perm (b, a, 0x07060302u);
+#else
+  return (a >> 16) | (b & 0xffff0000u);
+#endif
+}
 GSTAMD_HD uint32_t pk_f31 (uint32_t a, uint32_t b) { return pk_avgc (a, pk_avgf (a, b)); }
 
 // deep_widen_w on both halves of a word
@@ -72,11 +100,19 @@ GSTAMD_HD int deep_h2tap_pk (uint32_t pair, uint32_t taps)
   const uint32_t v = pk_udot2 (pair, taps, 4096u) >> 12;
   return (int) (v > 65535u ? 65535u : v);
 }
-// video_scale_v_2tap_u16: l1 + (((l2 - l1) * p1 + 4096) >> 12), p1 read as an unsigned 16-bit parameter (deep_scale_px).  mul24s: the difference has 17
-// bits, p1 16 - the low 32 bits of the 24-bit product are the 32-bit product's, and v_mul_i32_i24 runs at full rate where v_mul_lo_u32 takes four passes
-GSTAMD_HD int deep_v2tap (int s1, int s2, uint32_t p1)
+// video_scale_v_2tap_u16: l1 + (((l2 - l1) * p1 + 4096) >> 12), clamped to 16 bits (deep_scale_px) = (l1 (4096 - p1) + l2 p1 + 4096) >> 12 for
+// p1 = 0 .. 4096 (l1 is an integer: it moves inside the floor; nothing wraps, the sum stays below 2^29): one dot product on {l1 | l2 << 16} with
+// {4096 - p1 | p1 << 16}.  The sum before its shift; deep_v16: the 16-bit value, deep_v8: its high byte (min (x >> 12, 65535) >> 8 = min (x >> 20, 255))
+GSTAMD_HD uint32_t deep_v2tap_sum (int s1, int s2, uint32_t vt) { return pk_udot2 ((uint32_t) s1 | ((uint32_t) s2 << 16), vt, 4096u); }
+GSTAMD_HD uint32_t deep_v16 (int s1, int s2, uint32_t vt)
 {
-  return clampi (s1 + ((int) ((uint32_t) mul24s (s2 - s1, (int) p1) + 4096u) >> 12), 0, 65535);
+  const uint32_t v = deep_v2tap_sum (s1, s2, vt) >> 12;
+  return v > 65535u ? 65535u : v;
+}
+GSTAMD_HD uint32_t deep_v8 (int s1, int s2, uint32_t vt)
+{
+  const uint32_t v = deep_v2tap_sum (s1, s2, vt) >> 20;
+  return v > 255u ? 255u : v;
 }
 
 // a source line after the horizontal pass at the block's four positions: luma, and the two chroma components
@@ -155,8 +191,8 @@ struct DeepScaledSrc {
       o->y[i] = deep_h2tap_pk (pk_widen (wd, lw[i]), tw[i]);
       o->al[i] = deep_h2tap_pk (0xffffffffu, tw[i]);
       const uint32_t e = pk_f31 (first[2 * i], second[2 * i]), g = pk_f31 (first[2 * i + 1], second[2 * i + 1]);        /* even and odd source pixel */
-      o->c1[i] = deep_h2tap_pk ((e & 0xffffu) | (g << 16), tw[i]);
-      o->c2[i] = deep_h2tap_pk ((e >> 16) | (g & 0xffff0000u), tw[i]);
+      o->c1[i] = deep_h2tap_pk (pk_lo2 (e, g), tw[i]);
+      o->c2[i] = deep_h2tap_pk (pk_hi2 (e, g), tw[i]);
     }
   }
 
@@ -184,7 +220,8 @@ struct DeepScaledSrc {
       hline4 (wd, c1, c0, x0, Lb, b);
     else
       hline4 (wd, c0, c1, x0, Lb, b);
-    return (uint32_t) (uint16_t) d.sv.taps[2 * (size_t) y + 1];
+    const uint32_t p1 = (uint32_t) (uint16_t) d.sv.taps[2 * (size_t) y + 1];
+    return (4096u - p1) | (p1 << 16);
   }
 
   GSTAMD_HD bool c1_is_u () const { return SEMI ? d.f.u_plane != 0 : d.f.u_plane == 1; }
@@ -193,13 +230,13 @@ struct DeepScaledSrc {
   GSTAMD_HD uint4 core4 (int x0, int y) const
   {
     DeepHLine a, b;
-    const uint32_t p1 = lines2 (x0, y, &a, &b);
+    const uint32_t vt = lines2 (x0, y, &a, &b);
     const bool usw = c1_is_u ();
     uint32_t px[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const uint32_t v1 = (uint32_t) (deep_v2tap (a.c1[i], b.c1[i], p1) >> 8), v2 = (uint32_t) (deep_v2tap (a.c2[i], b.c2[i], p1) >> 8);
-      px[i] = 0xffu | ((uint32_t) (deep_v2tap (a.y[i], b.y[i], p1) >> 8) << 8) | ((usw ? v1 : v2) << 16) | ((usw ? v2 : v1) << 24);
+      const uint32_t v1 = deep_v8 (a.c1[i], b.c1[i], vt), v2 = deep_v8 (a.c2[i], b.c2[i], vt);
+      px[i] = 0xffu | (deep_v8 (a.y[i], b.y[i], vt) << 8) | ((usw ? v1 : v2) << 16) | ((usw ? v2 : v1) << 24);
     }
     uint4 r;
     r.x = px[0], r.y = px[1], r.z = px[2], r.w = px[3];
@@ -210,12 +247,12 @@ struct DeepScaledSrc {
   GSTAMD_HD void core4_16 (int x0, int y, uint2 *px) const
   {
     DeepHLine a, b;
-    const uint32_t p1 = lines2 (x0, y, &a, &b);
+    const uint32_t vt = lines2 (x0, y, &a, &b);
     const bool usw = c1_is_u ();
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const uint32_t v1 = (uint32_t) deep_v2tap (a.c1[i], b.c1[i], p1), v2 = (uint32_t) deep_v2tap (a.c2[i], b.c2[i], p1);
-      px[i].x = (uint32_t) deep_v2tap (a.al[i], b.al[i], p1) | ((uint32_t) deep_v2tap (a.y[i], b.y[i], p1) << 16);
+      const uint32_t v1 = deep_v16 (a.c1[i], b.c1[i], vt), v2 = deep_v16 (a.c2[i], b.c2[i], vt);
+      px[i].x = deep_v16 (a.al[i], b.al[i], vt) | (deep_v16 (a.y[i], b.y[i], vt) << 16);
       px[i].y = (usw ? v1 : v2) | ((usw ? v2 : v1) << 16);
     }
   }
@@ -283,7 +320,7 @@ GSTAMD_HD void deep_scale_pack_any (int variant, const PackPlanarParams &pk, con
   }
 }
 
-// host: two passes, horizontal first, both 2-tap, the horizontal one reading source pixels 2 x, 2 x + 1 for output x with taps 0 .. 4096 (pk_udot2), a front
+// host: two passes, horizontal first, both 2-tap, the horizontal one reading source pixels 2 x, 2 x + 1 for output x, taps 0 .. 4096 (pk_udot2), a front
 // the lanes know (planes with horizontally subsampled chroma, frame weights 3 : 1)
 inline bool deep_passes_halve (const VideoPlan &p)
 {
@@ -294,6 +331,8 @@ inline bool deep_passes_halve (const VideoPlan &p)
   for (int x = 0; hx2 && x < ow; x++)
     hx2 = (int) p.passes[0].offset[x] == 2 * x && p.passes[0].taps[2 * (size_t) x] >= 0 && p.passes[0].taps[2 * (size_t) x + 1] >= 0 &&
         (int) p.passes[0].taps[2 * (size_t) x] + (int) p.passes[0].taps[2 * (size_t) x + 1] <= 8192;
+  for (int y = 0; hx2 && y < p.passes[1].out_size; y++)          /* deep_v2tap_sum: the vertical parameter is a weight of 0 .. 4096 */
+    hx2 = p.passes[1].taps[2 * (size_t) y + 1] >= 0 && p.passes[1].taps[2 * (size_t) y + 1] <= 4096;
   return hx2;
 }
 

@@ -58,12 +58,21 @@ VIDEO_CONFIGS = {
                    "4K frames/s (videoconvertscale BGRA->P010_10LE) per GPU; % HBM roofline", "k_encode16 (widen, matrix16, chroma down, ordered dither, pack in one kernel)"),
     "f8swizzle": ("BGRA", 3840, 2160, "RGBA", 3840, 2160, {}, 8, 8,
                   "4K frames/s (videoconvert BGRA->RGBA) per GPU; % HBM roofline", "k_swizzle4"),
+    # the scaled pairs of real pipelines - a 10-bit decoder's frames at half the size into an encoder's / a display's format
+    "f6p010nv12": ("P010_10LE", 3840, 2160, "NV12", 1920, 1080, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
+                   "4K->1080p frames/s (videoconvertscale P010_10LE->NV12, bilinear) per GPU; % HBM roofline",
+                   "k_deep_scale_pack<semi-planar, CHROMA_H_H2_CS> (16-bit front, both u16 passes, narrowing, chroma downsampler and pack in one kernel)"),
+    "f6p010bgra": ("P010_10LE", 3840, 2160, "BGRA", 1920, 1080, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
+                   "4K->1080p frames/s (videoconvertscale P010_10LE->BGRA, bilinear) per GPU; % HBM roofline",
+                   "k_deep_scale4<semi-planar, CHROMA_H_H2_CS> (16-bit front, both u16 passes, matrix16, narrowing and pack in one kernel)"),
 }
 CONFIG_TEXT = {
     "f8scale": "SURVEY 8(f): 3840x2160 NV12 -> 1920x1080 NV12, bilinear (the elements' default method: linear, max-taps 2), plane by plane (convert_scale_planes)",
     "f8pack": "SURVEY 8(f): 3840x2160 YUY2 -> I420 (unpack, chroma downsample, planar pack)",
     "f8swizzle": "SURVEY 8(f): 3840x2160 BGRA -> RGBA (a byte permutation)",
     "f5encode16": "SURVEY 8(f)2 / VERDICT r03 item 5: 3840x2160 BGRA -> P010_10LE (widen, matrix16, cosited chroma down, ordered dither, pack)",
+    "f6p010nv12": "VERDICT r05 item 4: 3840x2160 P010_10LE -> 1920x1080 NV12, bilinear (the elements' default method) - an HDR decoder's frames into an encoder's format",
+    "f6p010bgra": "VERDICT r05 item 4: 3840x2160 P010_10LE -> 1920x1080 BGRA, bilinear (the elements' default method) - an HDR decoder's frames for display",
     "c2": "C2: 3840x2160 NV12 (bt709 limited, chroma-site mpeg2) -> BGRA, fused unpack + chroma upsample + matrix + pack",
     "c1": "C1 size on the GPU: 1920x1080 NV12 -> BGRA (the reference's CPU-runnable case)",
     "c3": "C3: 7680x4320 I420 -> 1920x1080 RGBA, Lanczos (16 x 16 taps), horizontal then vertical like chain_scale",
@@ -710,7 +719,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4opaque | c4audio | c4audiomany | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f5encode16 | f8scale | f8pack | f8swizzle")
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4opaque | c4audio | c4audiomany | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f5encode16 | f8scale | f8pack | f8swizzle | f6p010nv12 | f6p010bgra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="c2: skip the batch-1 / element numbers reported beside the headline")
     ap.add_argument("--preheat-ms", type=float, default=60.0,

@@ -125,9 +125,14 @@ struct DeepHLine {
 // neighbours) is what the neighbouring LANES made: the wave trades them (ds_bpermute), and the kernel lays the blocks over the lanes so that every block
 // that stores has both neighbours in its wave (k_deep_scale_pack: 62 storing lanes between two that only compute).  On the host (tests/emu) the
 // neighbour blocks are evaluated in place.
-template <int SEMI, int CH>
+// SH: bit 0 - semi-planar source (0: three planes); bit 1 - the stored words hold their bits on top (P010 / P012 / P016: widening is `v | v >> bits`, no shift and
+// mask ahead of it - two instructions a word less, and a lane widens 44 words)
+template <int SH, int CH>
 struct DeepScaledSrc {
+  static constexpr int SEMI = SH & 1, TOP = SH >> 1;
   DeepPackParams d;
+
+  GSTAMD_HD uint32_t widen (const PkWiden &w, uint32_t v) const { return TOP ? (v | ((v >> w.bits) & w.m2)) : pk_widen (w, v); }
 
   GSTAMD_HD bool ok4 (int, int y) const { return y < d.out_h; }
 
@@ -160,7 +165,7 @@ struct DeepScaledSrc {
     }
 #pragma unroll
     for (int i = 0; i < 6; i++)
-      s[i] = pk_widen (wd, s[i]);
+      s[i] = widen (wd, s[i]);
     const int w = d.f.width;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -188,7 +193,7 @@ struct DeepScaledSrc {
     const uint32_t lw[4] = {q.x, q.y, q.z, q.w}, tw[4] = {tq.x, tq.y, tq.z, tq.w};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      o->y[i] = deep_h2tap_pk (pk_widen (wd, lw[i]), tw[i]);
+      o->y[i] = deep_h2tap_pk (widen (wd, lw[i]), tw[i]);
       o->al[i] = deep_h2tap_pk (0xffffffffu, tw[i]);
       const uint32_t e = pk_f31 (first[2 * i], second[2 * i]), g = pk_f31 (first[2 * i + 1], second[2 * i + 1]);        /* even and odd source pixel */
       o->c1[i] = deep_h2tap_pk (pk_lo2 (e, g), tw[i]);
@@ -296,6 +301,13 @@ GSTAMD_HD void deep_scale4_lane (const DeepPackParams &dp, const Deep16Params &d
   deep_finish_store4 (dd, post, px, (uint32_t *) (dst + (size_t) y * dstride + 4 * (size_t) x0));
 }
 
+// the instantiation of a front: deep_front4_variant's number (+ 6 when the stored words hold their bits on top)
+GSTAMD_VP int deep_pack_variant (const FrontParams &f)
+{
+  const int v = deep_front4_variant (f);
+  return v < 0 ? v : v + (f.hi_depth == 1 || f.hi_depth == 4 ? 0 : 6);          /* (deep_widen_params: those two keep their bits at the bottom) */
+}
+
 GSTAMD_HD void deep_scale4_any (int variant, const DeepPackParams &dp, const Deep16Params &dd, const PostParams &post, uint8_t *dst, int dstride, int x0, int y)
 {
   switch (variant) {
@@ -304,7 +316,13 @@ GSTAMD_HD void deep_scale4_any (int variant, const DeepPackParams &dp, const Dee
     case 2: deep_scale4_lane<0, CHROMA_H_H2_CS> (dp, dd, post, dst, dstride, x0, y); break;
     case 3: deep_scale4_lane<1, CHROMA_H_NONE> (dp, dd, post, dst, dstride, x0, y); break;
     case 4: deep_scale4_lane<1, CHROMA_H_H2> (dp, dd, post, dst, dstride, x0, y); break;
-    default: deep_scale4_lane<1, CHROMA_H_H2_CS> (dp, dd, post, dst, dstride, x0, y); break;
+    case 5: deep_scale4_lane<1, CHROMA_H_H2_CS> (dp, dd, post, dst, dstride, x0, y); break;
+    case 6: deep_scale4_lane<2, CHROMA_H_NONE> (dp, dd, post, dst, dstride, x0, y); break;
+    case 7: deep_scale4_lane<2, CHROMA_H_H2> (dp, dd, post, dst, dstride, x0, y); break;
+    case 8: deep_scale4_lane<2, CHROMA_H_H2_CS> (dp, dd, post, dst, dstride, x0, y); break;
+    case 9: deep_scale4_lane<3, CHROMA_H_NONE> (dp, dd, post, dst, dstride, x0, y); break;
+    case 10: deep_scale4_lane<3, CHROMA_H_H2> (dp, dd, post, dst, dstride, x0, y); break;
+    default: deep_scale4_lane<3, CHROMA_H_H2_CS> (dp, dd, post, dst, dstride, x0, y); break;
   }
 }
 
@@ -316,7 +334,13 @@ GSTAMD_HD void deep_scale_pack_any (int variant, const PackPlanarParams &pk, con
     case 2: deep_scale_pack_lane<0, CHROMA_H_H2_CS> (pk, dp, dst, x0, yb); break;
     case 3: deep_scale_pack_lane<1, CHROMA_H_NONE> (pk, dp, dst, x0, yb); break;
     case 4: deep_scale_pack_lane<1, CHROMA_H_H2> (pk, dp, dst, x0, yb); break;
-    default: deep_scale_pack_lane<1, CHROMA_H_H2_CS> (pk, dp, dst, x0, yb); break;
+    case 5: deep_scale_pack_lane<1, CHROMA_H_H2_CS> (pk, dp, dst, x0, yb); break;
+    case 6: deep_scale_pack_lane<2, CHROMA_H_NONE> (pk, dp, dst, x0, yb); break;
+    case 7: deep_scale_pack_lane<2, CHROMA_H_H2> (pk, dp, dst, x0, yb); break;
+    case 8: deep_scale_pack_lane<2, CHROMA_H_H2_CS> (pk, dp, dst, x0, yb); break;
+    case 9: deep_scale_pack_lane<3, CHROMA_H_NONE> (pk, dp, dst, x0, yb); break;
+    case 10: deep_scale_pack_lane<3, CHROMA_H_H2> (pk, dp, dst, x0, yb); break;
+    default: deep_scale_pack_lane<3, CHROMA_H_H2_CS> (pk, dp, dst, x0, yb); break;
   }
 }
 

@@ -21,7 +21,7 @@ __global__ __launch_bounds__ (64) void k_deep_scale_pack (PackPlanarParams pk, D
 {
   GSTAMD_FRAME_Z;
   dp.pl.p[0] += fls_, dp.pl.p[1] += fls_;
-  if (!SEMI)
+  if (!(SEMI & 1))
     dp.pl.p[2] += fls_;
   const int lane = (int) threadIdx.x, blk = (int) blockIdx.x * 62 + lane - 1;
   const bool store = lane >= 1 && lane <= 62 && blk < nblk;
@@ -50,7 +50,7 @@ hipError_t launch_deep_scale_pack (const PackPlanarParams &pk, const DeepPackPar
     d.p[i] = planes[i];
     d.stride[i] = strides[i];
   }
-  const int variant = deep_front4_variant (dp.f);
+  const int variant = deep_pack_variant (dp.f);
   const int nblk = pk.width / 4, rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
   int nz;
   const FrameDeltas &fl = video_frame_list_for (dp.pl.p[0], planes[0], &nz);
@@ -62,6 +62,12 @@ hipError_t launch_deep_scale_pack (const PackPlanarParams &pk, const DeepPackPar
     case 3: hipLaunchKernelGGL ((k_deep_scale_pack<1, CHROMA_H_NONE>), grid, dim3 (64), 0, stream, pk, dp, d, nblk, fl); break;
     case 4: hipLaunchKernelGGL ((k_deep_scale_pack<1, CHROMA_H_H2>), grid, dim3 (64), 0, stream, pk, dp, d, nblk, fl); break;
     case 5: hipLaunchKernelGGL ((k_deep_scale_pack<1, CHROMA_H_H2_CS>), grid, dim3 (64), 0, stream, pk, dp, d, nblk, fl); break;
+    case 6: hipLaunchKernelGGL ((k_deep_scale_pack<2, CHROMA_H_NONE>), grid, dim3 (64), 0, stream, pk, dp, d, nblk, fl); break;
+    case 7: hipLaunchKernelGGL ((k_deep_scale_pack<2, CHROMA_H_H2>), grid, dim3 (64), 0, stream, pk, dp, d, nblk, fl); break;
+    case 8: hipLaunchKernelGGL ((k_deep_scale_pack<2, CHROMA_H_H2_CS>), grid, dim3 (64), 0, stream, pk, dp, d, nblk, fl); break;
+    case 9: hipLaunchKernelGGL ((k_deep_scale_pack<3, CHROMA_H_NONE>), grid, dim3 (64), 0, stream, pk, dp, d, nblk, fl); break;
+    case 10: hipLaunchKernelGGL ((k_deep_scale_pack<3, CHROMA_H_H2>), grid, dim3 (64), 0, stream, pk, dp, d, nblk, fl); break;
+    case 11: hipLaunchKernelGGL ((k_deep_scale_pack<3, CHROMA_H_H2_CS>), grid, dim3 (64), 0, stream, pk, dp, d, nblk, fl); break;
     default: return hipErrorNotSupported;
   }
   return hipGetLastError ();
@@ -73,7 +79,7 @@ __global__ __launch_bounds__ (64) void k_deep_scale4 (DeepPackParams dp, Deep16P
 {
   GSTAMD_FRAME_Z;
   dp.pl.p[0] += fls_, dp.pl.p[1] += fls_;
-  if (!SEMI)
+  if (!(SEMI & 1))
     dp.pl.p[2] += fls_;
   deep_scale4_lane<SEMI, CH> (dp, dd, post, dst + fld_, dstride, (int) (blockIdx.x * 64 + threadIdx.x) * 4, (int) blockIdx.y);
 }
@@ -94,13 +100,19 @@ hipError_t launch_deep_scale4 (const DeepPackParams &dp, const Deep16Params &dd,
   int nz;
   const FrameDeltas &fl = video_frame_list_for (dp.pl.p[0], dst, &nz);
   const dim3 grid ((dp.out_w / 4 + 63) / 64, dp.out_h, nz);
-  switch (deep_front4_variant (dp.f)) {
+  switch (deep_pack_variant (dp.f)) {
     case 0: hipLaunchKernelGGL ((k_deep_scale4<0, CHROMA_H_NONE>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
     case 1: hipLaunchKernelGGL ((k_deep_scale4<0, CHROMA_H_H2>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
     case 2: hipLaunchKernelGGL ((k_deep_scale4<0, CHROMA_H_H2_CS>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
     case 3: hipLaunchKernelGGL ((k_deep_scale4<1, CHROMA_H_NONE>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
     case 4: hipLaunchKernelGGL ((k_deep_scale4<1, CHROMA_H_H2>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
     case 5: hipLaunchKernelGGL ((k_deep_scale4<1, CHROMA_H_H2_CS>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 6: hipLaunchKernelGGL ((k_deep_scale4<2, CHROMA_H_NONE>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 7: hipLaunchKernelGGL ((k_deep_scale4<2, CHROMA_H_H2>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 8: hipLaunchKernelGGL ((k_deep_scale4<2, CHROMA_H_H2_CS>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 9: hipLaunchKernelGGL ((k_deep_scale4<3, CHROMA_H_NONE>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 10: hipLaunchKernelGGL ((k_deep_scale4<3, CHROMA_H_H2>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
+    case 11: hipLaunchKernelGGL ((k_deep_scale4<3, CHROMA_H_H2_CS>), grid, dim3 (64), 0, stream, dp, dd, post, dst, dstride, fl); break;
     default: return hipErrorNotSupported;
   }
   return hipGetLastError ();

@@ -1366,7 +1366,7 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
       d.p[i] = dst + out->offset[i];
       d.stride[i] = out->stride[i];
     }
-    const int variant = deep_front4_variant (dp.f);
+    const int variant = deep_pack_variant (dp.f);
     const int nblk = p.pack.width / 4, rows = (p.pack.height + (1 << p.pack.h_sub) - 1) >> p.pack.h_sub;
     g_emu_deep_pack_runs++;
     g_emu_deep_pack_wide++;
@@ -1755,7 +1755,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     g_emu_deep_pack_runs++;
     for (int y = 0; y < ds4.out_h; y++)
       for (int l = 0; l < (ds4.out_w / 4 + 63) / 64 * 64; l++)
-        deep_scale4_any (deep_front4_variant (p.front), ds4, p.deep, p.post, d0, dstride, 4 * l, y);
+        deep_scale4_any (deep_pack_variant (p.front), ds4, p.deep, p.post, d0, dstride, 4 * l, y);
     return GSTAMD_OK;
   }
   if (p.deep16 && !p.matrix_before_scale) {        /* convert_deep_scaled: k_front16, k_scale16 ..., k_scale16_final */

@@ -184,6 +184,24 @@ struct DeepScaledSrc {
     }
   }
 
+  // crow8 through the two rows the call before kept (the keys are wave-uniform: a branch, not a select)
+  mutable uint32_t ka[8], kb[8];
+  mutable int keep_x0 = -1, keep_a = -1, keep_b = -1;
+  GSTAMD_HD void crow_get (const PkWiden &wd, int cw, int crow, int x0, uint32_t *o) const
+  {
+    if (x0 == keep_x0 && crow == keep_a) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        o[i] = ka[i];
+    } else if (x0 == keep_x0 && crow == keep_b) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        o[i] = kb[i];
+    } else {
+      crow8 (wd, cw, crow, x0, o);
+    }
+  }
+
   // source line L at the block's positions: luma through the horizontal pass; the line's two upsampled chroma rows blended by its weights (`first` has
   // the weight 3 of 3 : 1), then the pass (deep_front1_t + front_hscale16_lane, value for value)
   GSTAMD_HD void hline4 (const PkWiden &wd, const uint32_t *first, const uint32_t *second, int x0, int L, DeepHLine *o) const
@@ -212,19 +230,24 @@ struct DeepScaledSrc {
     const FrontRow fa = deep_front_row (d.f, d.vpair, La), fb = deep_front_row (d.f, d.vpair, Lb);
     const PkWiden wd = pk_widen_params (d.f.hi_depth);
     uint32_t c0[8], c1[8];
-    crow8 (wd, fa.cw, fa.ra, x0, c0);
-    crow8 (wd, fa.cw, fa.rb, x0, c1);
+    crow_get (wd, fa.cw, fa.ra, x0, c0);
+    crow_get (wd, fa.cw, fa.rb, x0, c1);
     if (fa.wa == 6)
       hline4 (wd, c0, c1, x0, La, a);
     else
       hline4 (wd, c1, c0, x0, La, a);
     if (fb.ra != fa.rb)
-      crow8 (wd, fb.cw, fb.ra, x0, c1);
-    crow8 (wd, fb.cw, fb.rb, x0, c0);
+      crow_get (wd, fb.cw, fb.ra, x0, c1);
+    crow_get (wd, fb.cw, fb.rb, x0, c0);
     if (fb.wa == 6)
       hline4 (wd, c1, c0, x0, Lb, b);
     else
       hline4 (wd, c0, c1, x0, Lb, b);
+    /* the second line's rows are the next destination line's first rows in a picture that halves (lines 4 j + 1 and 4 j + 2 share their pair): kept */
+    keep_x0 = x0, keep_a = fb.ra, keep_b = fb.rb;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      ka[i] = c1[i], kb[i] = c0[i];
     const uint32_t p1 = (uint32_t) (uint16_t) d.sv.taps[2 * (size_t) y + 1];
     return (4096u - p1) | (p1 << 16);
   }

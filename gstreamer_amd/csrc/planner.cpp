@@ -3998,7 +3998,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * anything else; the reference's vertical chroma upsampler pairs lines in the order the nearest vertical scaler asks for them
    * (it skips / repeats lines), which the pair-table simulation of the direct plans follows and the composite does not */
   /* (a 10 / 12 / 16-bit 4:2:0 source under gamma-mode = remap goes the same way: its 16-bit front is planned as an unscaled conversion, plan_gamma) */
-  if (chain && pl.gamma.on && (!pl.gamma.src16 || remap) && !pl.gamma.src64 && fi->h_sub == 1 && (kind_has_planes (fi->kind) || GSTAMD_KIND_ALPHA_PLANE (fi->kind) >= 0)) {
+  if (chain && pl.gamma.on && (!pl.gamma.src16 || remap) && !pl.gamma.src64 && fi->h_sub == 1 && (kind_has_planes (fi->kind) || GSTAMD_KIND_ALPHA_PLANE (fi->kind) >= 0 || kind_is_tiled (fi->kind))) {
     for (const ScalePass &sp : pl.passes)
       if (!sp.horizontal && sp.kind == SCALE_NEAREST) {
         if (error)
@@ -4117,7 +4117,7 @@ int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
    * rectangle keeps what it wrote there */
   /* (the device fuzz's seed 5484 widened it: the same with one output row, and with the 16-bit unpack formats as destinations - the pair's other line
    * still lands in a frame row, or in front of the frame when the rectangle starts at row 0, and the picture's own row differs) */
-  const bool one_line_420 = pl.front.chroma_v2 || (pl.gamma.on && fi->h_sub == 1 && (kind_has_planes (fi->kind) || GSTAMD_KIND_ALPHA_PLANE (fi->kind) >= 0) && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE &&
+  const bool one_line_420 = pl.front.chroma_v2 || (pl.gamma.on && fi->h_sub == 1 && (kind_has_planes (fi->kind) || GSTAMD_KIND_ALPHA_PLANE (fi->kind) >= 0 || kind_is_tiled (fi->kind)) && cfg.chroma_mode != GSTAMD_CHROMA_MODE_NONE &&
       cfg.chroma_mode != GSTAMD_CHROMA_MODE_DOWNSAMPLE_ONLY);
   /* ... and every chain whose unpacker works in the destination's rows (no scaler that makes new lines in between) does it to the row above a rectangle
    * that starts below row 0: a crop copied unscaled into a rectangle of an ARGB frame keeps picture-derived pixels in that border row */

@@ -663,6 +663,7 @@ inline void border_plane_value (const FormatDesc *f, const uint8_t border[4], in
 // vpair table entry 0: chroma row of the pair's first line (signed 30 bits: with a source crop the row above the crop
 // origin is -1) | role << 30; entry 1: row of the second line
 GSTAMD_VP bool kind_has_planes (int kind) { return kind == UNPACK_PLANAR || kind == UNPACK_SEMI; }
+GSTAMD_VP bool kind_is_tiled (int kind) { return kind == UNPACK_SEMI_TILED || kind == UNPACK_SEMI_LE40_TILED; }          /* NV12 in tiles: 4:2:0 like NV12, generic per-pixel kernels */
 GSTAMD_VP int vpair_row (int e0) { return (int) ((uint32_t) e0 << 2) >> 2; }
 GSTAMD_VP int vpair_role (int e0) { return (e0 >> 30) & 1; }
 GSTAMD_VP int vpair_pack (int row, int role) { return (int) (((uint32_t) row & 0x3fffffffu) | ((uint32_t) role << 30)); }

@@ -1591,6 +1591,9 @@ VISIBLE_ONLY = {"uyvy_yv12_33x17_fastpath", "uyvy_y444_33x18_fastpath", "uyvy_yu
 
 # conversions the reference runs through code this library has no kernel for -> must be REFUSED ("not built", never approximated)
 VIDEO_REFUSED = [
+    # nearest vertical scaling of a 4:2:0 source through the 16-bit part of the chain: NV12 in tiles like NV12 (found by the device fuzz once the tiled formats were in its pool)
+    ("NV12_4L4", 23, 18, "AYUV64", 89, 14, dict(resampler_method="nearest")),
+    ("NV12_16L32S", 6, 8, "ABGR64_BE", 85, 5, dict(resampler_method="nearest")),
     # error diffusion below the frame's first line: the reference's error line is never cleared there, frames depend on each other
     ("NV12", 64, 64, "BGRA", 64, 70, dict(dither_quantization=4, dither_method="floyd-steinberg", dest_x=0, dest_y=3, dest_width=64, dest_height=64)),
     ("NV12", 64, 64, "P010_10LE", 64, 70, dict(dither_method="sierra-lite", dest_x=0, dest_y=3, dest_width=64, dest_height=64)),   # the same on 16-bit lines

@@ -689,6 +689,19 @@ GSTAMD_VP VPairW vpair_get (const int *vpair, int y, int mode)
 
 // Returns GSTAMD_OK and fills `plan`, or an error code (GSTAMD_ERR_UNSUPPORTED for conversions the
 // reference would run through a path this library has no kernel for yet).
+// a scaled plan without a colour stage between the scaler and the pack: the chain's lines stay A Y U V from the unpacker to the packer (no matrix, no alpha
+// operation, unpack order = pack order) - the bilinear 4:2:0 kernels serve it with the layout that stores A Y U V (video_fast.h GSTAMD_LAYOUT_AYUV)
+inline bool bilinear420_ayuv_plan (const VideoPlan &p)
+{
+  if (p.passes.empty () || p.matrix_before_scale || p.matrix.kind != MATRIX_NONE || p.post.alpha_kind != ALPHA_NONE || p.front.hi_depth != 0 || p.gamma.on || p.deep16 ||
+      p.plane_mode || p.interlaced || p.field)
+    return false;
+  for (int i = 0; i < 4; i++)
+    if (p.post.pack_pos[i] != i)
+      return false;
+  return true;
+}
+
 int plan_video_converter (const GstAmdVideoInfo *in, const GstAmdVideoInfo *out,
     const GstAmdVideoConverterConfig *config, VideoPlan *plan, std::string *error);
 

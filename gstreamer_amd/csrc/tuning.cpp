@@ -20,7 +20,7 @@ Knob g_knobs[] = {
   {"GSTAMD_NO_FAST_PRE", false, -1, "", false}, {"GSTAMD_STORE_POLICY", false, -1, "", false}, {"GSTAMD_STORE_WT_BELOW", false, -1, "", false},
   {"GSTAMD_NO_FUSED420", false, -1, "", false}, {"GSTAMD_NO_COL", false, -1, "", false}, {"GSTAMD_COL_OPL", false, -1, "", false}, {"GSTAMD_COL_SHARE", false, -1, "", false},
   {"GSTAMD_COL_WAVES", false, -1, "", false}, {"GSTAMD_COL_CHUNKS", false, -1, "", false}, {"GSTAMD_COL_SOLO", false, -1, "", false}, {"GSTAMD_COL_NO_REGWIN", false, -1, "", false}, {"GSTAMD_COL_DEBUG", false, -1, "", false}, {"GSTAMD_LIST_DEBUG", false, -1, "", false}, {"GSTAMD_DEEP_DEBUG", false, -1, "", false}, {"GSTAMD_NO_DEEP_PLANES16", false, -1, "", false}, {"GSTAMD_NO_ENCODE16", false, -1, "", false}, {"GSTAMD_ENCODE16_NARROW", false, -1, "", false}, {"GSTAMD_ENCODE16_WIDE", false, -1, "", false}, {"GSTAMD_NO_PLANE_QUAD", false, -1, "", false}, {"GSTAMD_PLANE_QUAD_ROWS", false, -1, "", false}, {"GSTAMD_PLANE_QUAD_MODE", false, -1, "", false}, {"GSTAMD_PLANE_QUAD_NT", false, -1, "", false}, {"GSTAMD_PLANE_QUAD_ONLY", false, -1, "", false}, {"GSTAMD_PLANE_QUAD_NO_DSTEP", false, -1, "", false}, {"GSTAMD_NO_H420_REG", false, -1, "", false}, {"GSTAMD_H420_ROWS", false, -1, "", false},
-  {"GSTAMD_VSCALE_ROWS", false, -1, "", false}, {"GSTAMD_NO_FAST420P", false, -1, "", false}, {"GSTAMD_NO_FAST422", false, -1, "", false}, {"GSTAMD_NO_CONVERT_PACK", false, -1, "", false}, {"GSTAMD_NO_CONVERT_PACK_WIDE", false, -1, "", false}, {"GSTAMD_NO_CONVERT_PACK_422UP", false, -1, "", false}, {"GSTAMD_NO_PLANE_FRAME", false, -1, "", false}, {"GSTAMD_NO_RELAYOUT", false, -1, "", false}, {"GSTAMD_NO_SWIZZLE34", false, -1, "", false}, {"GSTAMD_NO_GAMMA_COMP", false, -1, "", false}, {"GSTAMD_NO_BILINEAR4", false, -1, "", false}, {"GSTAMD_NO_BILINEAR4_UP", false, -1, "", false}, {"GSTAMD_BIL4_UP_ROWS", false, -1, "", false}, {"GSTAMD_NO_CONVERT16_FAST", false, -1, "", false}, {"GSTAMD_NO_DEEP_SCALE_PACK", false, -1, "", false}, {"GSTAMD_DEEP_PACK_NARROW", false, -1, "", false},
+  {"GSTAMD_VSCALE_ROWS", false, -1, "", false}, {"GSTAMD_NO_FAST420P", false, -1, "", false}, {"GSTAMD_NO_FAST422", false, -1, "", false}, {"GSTAMD_NO_CONVERT_PACK", false, -1, "", false}, {"GSTAMD_NO_CONVERT_PACK_WIDE", false, -1, "", false}, {"GSTAMD_NO_CONVERT_PACK_422UP", false, -1, "", false}, {"GSTAMD_NO_PLANE_FRAME", false, -1, "", false}, {"GSTAMD_NO_RELAYOUT", false, -1, "", false}, {"GSTAMD_NO_SWIZZLE34", false, -1, "", false}, {"GSTAMD_NO_GAMMA_COMP", false, -1, "", false}, {"GSTAMD_NO_BILINEAR4", false, -1, "", false}, {"GSTAMD_NO_BILINEAR4_UP", false, -1, "", false}, {"GSTAMD_BIL4_UP_ROWS", false, -1, "", false}, {"GSTAMD_NO_CONVERT16_FAST", false, -1, "", false}, {"GSTAMD_NO_DEEP_SCALE_PACK", false, -1, "", false}, {"GSTAMD_NO_BILINEAR_AYUV", false, -1, "", false}, {"GSTAMD_DEEP_PACK_NARROW", false, -1, "", false},
   {"GSTAMD_NO_BILINEAR420", false, -1, "", false}, {"GSTAMD_NO_BILINEAR_ROWS", false, -1, "", false}, {"GSTAMD_NO_BILINEAR_HALF", false, -1, "", false}, {"GSTAMD_BIL_HALF_ROWS", false, -1, "", false}, {"GSTAMD_BIL_HALF_STORE", false, -1, "", false}, {"GSTAMD_BIL_HALF_SMALL", false, -1, "", false}, {"GSTAMD_BIL_TILE", false, -1, "", false},
   {"GSTAMD_BIL_TABLE", false, -1, "", false}, {"GSTAMD_BIL_ROWS", false, -1, "", false}, {"GSTAMD_BIL_ROWS_TILE", false, -1, "", false},
   {"GSTAMD_BIL_SLOTS", false, -1, "", false}, {"GSTAMD_BIL_WG", false, -1, "", false}, {"GSTAMD_BIL_VERBOSE", false, -1, "", false},

@@ -161,7 +161,8 @@ hipError_t launch_bilinear420_half (const BilParams &bp, int chroma_h, int n, co
     else \
       hipLaunchKernelGGL ((k_bilinear420_half<CHROMA_H_NONE, GSTAMD_LAYOUT (pr, pg, pb)>), grid, block, (size_t) wg * 2048, stream, rp, fb, dstride, tiles, blocks_per_frame); \
     break;
-    switch (GSTAMD_LAYOUT (bp.fp.pack_pos[1], bp.fp.pack_pos[2], bp.fp.pack_pos[3])) {
+    switch (bp.fp.ayuv ? GSTAMD_LAYOUT_AYUV : GSTAMD_LAYOUT (bp.fp.pack_pos[1], bp.fp.pack_pos[2], bp.fp.pack_pos[3])) {
+      W (0, 0, 4)      /* GSTAMD_LAYOUT_AYUV: no colour stage (FastParams::ayuv) */
       W (2, 1, 0)      /* BGRA, BGRx */
       W (0, 1, 2)      /* RGBA, RGBx */
       W (1, 2, 3)      /* ARGB, xRGB */

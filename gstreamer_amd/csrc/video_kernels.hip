@@ -1537,7 +1537,7 @@ __global__ __launch_bounds__ (64) void k_convert_strip_xcd (FastParams fp, Frame
 // destination byte order -> layout template argument (the four orders of the eight 4-byte RGB formats)
 static int fast_layout (const FastParams &fp)
 {
-  return GSTAMD_LAYOUT (fp.pack_pos[1], fp.pack_pos[2], fp.pack_pos[3]);
+  return fp.ayuv ? GSTAMD_LAYOUT_AYUV : GSTAMD_LAYOUT (fp.pack_pos[1], fp.pack_pos[2], fp.pack_pos[3]);
 }
 
 #define GSTAMD_FOR_LAYOUTS(W) \
@@ -2122,6 +2122,7 @@ static hipError_t launch_bilinear420_rows (const BilParams &bp, int chroma_h, in
     break;
     switch (fast_layout (bp.fp)) {
       GSTAMD_FOR_LAYOUTS (W)
+      W (0, 0, 4)      /* GSTAMD_LAYOUT_AYUV: no colour stage */
       default:
         return hipErrorInvalidValue;
     }
@@ -2172,6 +2173,7 @@ hipError_t launch_bilinear420 (const BilParams &bp, int chroma_h, const Planes &
     return hipGetLastError ();
   switch (fast_layout (bp.fp)) {
     GSTAMD_FOR_LAYOUTS (W)
+    W (0, 0, 4)      /* GSTAMD_LAYOUT_AYUV: no colour stage */
   }
 #undef W
   return hipErrorInvalidValue;

@@ -1922,3 +1922,21 @@ VIDEO_CASES += [
     ("dsp4_not_p010_bgra_ow_62", "P010_10LE", 124, 64, "BGRA", 62, 32, BIL2, None, None, "random"),
     ("dsp4_not_p010_bgra_cubic", "P010_10LE", 128, 64, "BGRA", 64, 32, dict(resampler_method="cubic"), None, None, "random"),
 ]
+
+# round 6: the bilinear 4:2:0 kernels (k_bilinear420 / _rows / _half) with the layout that stores A Y U V (FastParams::ayuv): scaled YUV -> YUV conversions
+# of one colorimetry - the pack image of a planar / semi-planar destination, an AYUV frame - which took the generic wave-tile scaler before
+VIDEO_CASES += [
+    ("bay_nv12_i420_512x256_half", "NV12", 512, 256, "I420", 256, 128, LIN, None, None, "random"),
+    ("bay_i420_nv12_512x256_half", "I420", 512, 256, "NV12", 256, 128, LIN, None, "jpeg", "random"),
+    ("bay_nv12_i420_1080p_720p_rows", "NV12", 1920, 1080, "I420", 1280, 720, LIN, None, None, "random"),
+    ("bay_i420_nv12_hd_half_cosited_down", "I420", 640, 1280, "NV12", 320, 640, LIN, None, None, "random"),
+    ("bay_nv21_yv12_160x96_plain", "NV21", 160, 96, "YV12", 96, 64, LIN, None, None, "random"),
+    ("bay_nv21_yv12_odd", "NV21", 162, 98, "YV12", 95, 63, LIN, None, "cosited", "random"),
+    ("bay_not_yv12_nv21_odd_planar_width", "YV12", 162, 98, "NV21", 95, 63, LIN, None, "cosited", "random"),          # (three-plane sources: widths of 16 n)
+    ("bay_nv12_y42b", "NV12", 256, 128, "Y42B", 128, 64, LIN, None, None, "random"),
+    ("bay_nv12_ayuv", "NV12", 256, 128, "AYUV", 128, 64, LIN, None, None, "random"),
+    ("bay_nv12_yuy2", "NV12", 256, 128, "YUY2", 128, 64, LIN, None, None, "random"),
+    ("bay_nv12_i420_crop_rect_border", "NV12", 256, 128, "I420", 96, 48, dict(LIN, src_x=64, src_y=32, src_width=128, src_height=64, dest_x=16, dest_y=8, dest_width=64, dest_height=32, border_argb=0xff204060), None, None, "random"),
+    ("bay_nv12_i420_dither", "NV12", 256, 128, "I420", 128, 64, dict(LIN, dither_method="bayer", dither_quantization=4), None, None, "random"),
+    ("bay_not_nv12_i420_matrix", "NV12", 1280, 720, "I420", 640, 360, LIN, None, None, "random"),          # (HD -> SD: a colour matrix in between)
+]

@@ -784,6 +784,8 @@ static const DeepPackParams *g_deep_hook = nullptr;    /* set while the sub-conv
 int g_emu_deep_pack_runs = 0, g_emu_deep_pack_wide = 0;
 extern "C" int emu_deep_pack_runs (void) { return g_emu_deep_pack_runs; }
 extern "C" int emu_deep_pack_wide (void) { return g_emu_deep_pack_wide; }
+int g_bil_ayuv_runs = 0;
+extern "C" int emu_bil_ayuv_runs (void) { return g_bil_ayuv_runs; }
 static const GammaDev *g_gamma_hook = nullptr;          /* set while the direct conversion of a fused gamma plan runs (k_convert_gamma) */
 static int g_gamma_fused_runs = 0;
 extern "C" int emu_gamma_fused_runs (void) { return g_gamma_fused_runs; }
@@ -1939,14 +1941,18 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
     const int bil_tw = vec_ok >= 400 ? vec_ok - 400 : bil_pick_tile (p.out_info.width, p.passes[0].inc, &bil_yl);     /* 400 + w: tiles of w outputs */
     if (vec_ok >= 400)
       bil_yl = bil_ylen (p.out_info.width, p.passes[0].inc, bil_tw);
+    const bool bil_ayuv = bilinear420_ayuv_plan (p) && getenv ("GSTAMD_NO_BILINEAR_AYUV") == nullptr;          /* bilinear420_params of capi_video.cpp */
     const bool bil_planar = p.front.kind == UNPACK_PLANAR;
     const bool bil_planar_ok = bil_planar && ((uintptr_t) pl.p[0] % 16) == 0 && pl.stride[0] % 16 == 0 && ((uintptr_t) pl.p[1] % 8) == 0 &&
         ((uintptr_t) pl.p[2] % 8) == 0 && pl.stride[1] % 8 == 0 && pl.stride[2] % 8 == 0 && (p.front.width % 16) == 0;
     if (h_first && p.passes[0].kind == SCALE_2TAP && p.passes[1].kind == SCALE_2TAP && (p.front.kind == UNPACK_SEMI || bil_planar_ok) && p.front.w_sub == 1 &&
-        p.front.h_sub == 1 && !p.matrix_before_scale && p.fast_post && p.front.chroma_v2 != 2 && bil_tw > 0 && bil_yl > 0 && vec_ok != 300) {
+        p.front.h_sub == 1 && !p.matrix_before_scale && (p.fast_post || bil_ayuv) && (!p.out_planar || bil_ayuv) && p.front.chroma_v2 != 2 && bil_tw > 0 && bil_yl > 0 && vec_ok != 300) {
       /* k_bilinear420 (video_bilinear_fast.h); vec_ok == 300 selects the generic tile kernel below instead */
       BilParams bp;
       bp.fp = pf.fp;
+      bp.fp.ayuv = bil_ayuv ? 1 : 0;
+      if (bil_ayuv)
+        g_bil_ayuv_runs++;
       bp.out_w = p.out_info.width;
       bp.out_h = p.out_info.height;
       bp.inc = p.passes[0].inc;
@@ -1960,11 +1966,11 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
       bp.u_plane = p.front.u_plane;
       bp.v_plane = p.front.v_plane;
       g_bil_runs++;
-      const int lay = GSTAMD_LAYOUT (bp.fp.pack_pos[1], bp.fp.pack_pos[2], bp.fp.pack_pos[3]);
+      const int lay = bp.fp.ayuv ? GSTAMD_LAYOUT_AYUV : GSTAMD_LAYOUT (bp.fp.pack_pos[1], bp.fp.pack_pos[2], bp.fp.pack_pos[3]);
       std::vector<uint32_t> lds_w (bil_lds_words (bp.ylen));
       const BilLds lds = bil_lds (lds_w.data (), bp.ylen);
 #define BIL_L(CH, pr, pg, pb) if (lay == GSTAMD_LAYOUT (pr, pg, pb)) bil_emit<CH, GSTAMD_LAYOUT (pr, pg, pb)> (bp, d0, dstride, t0, t1, y, r0, lane, &lds);
-#define BIL(CH) { BIL_L (CH, 2, 1, 0) BIL_L (CH, 0, 1, 2) BIL_L (CH, 1, 2, 3) BIL_L (CH, 3, 2, 1) }
+#define BIL(CH) { BIL_L (CH, 2, 1, 0) BIL_L (CH, 0, 1, 2) BIL_L (CH, 1, 2, 3) BIL_L (CH, 3, 2, 1) BIL_L (CH, 0, 0, 4) }
       bp.regular_pairs = 0;
       bp.rows = 0;
       {
@@ -2019,7 +2025,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
               store16_stream (d + 16 * half, a, b, e, f);
           };
 #define BILH_L(CH, pr, pg, pb) if (lay == GSTAMD_LAYOUT (pr, pg, pb)) bilh_strip<CH, GSTAMD_LAYOUT (pr, pg, pb)> (hp, pl, d0, dstride, x0, y0, y1, p1_of, put);
-#define BILH(CH) { BILH_L (CH, 2, 1, 0) BILH_L (CH, 0, 1, 2) BILH_L (CH, 1, 2, 3) BILH_L (CH, 3, 2, 1) }
+#define BILH(CH) { BILH_L (CH, 2, 1, 0) BILH_L (CH, 0, 1, 2) BILH_L (CH, 1, 2, 3) BILH_L (CH, 3, 2, 1) BILH_L (CH, 0, 0, 4) }
           for (int g = 0; g < hp.strips; g++) {
             const int y0 = (int) ((unsigned) g * (unsigned) hp.out_h / (unsigned) hp.strips);
             const int y1 = (int) ((unsigned) (g + 1) * (unsigned) hp.out_h / (unsigned) hp.strips);
@@ -2046,7 +2052,7 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
           if (phase == 0) layout_init<GSTAMD_LAYOUT (pr, pg, pb)> (q[lane]); \
           else if (bp.rows_tile_w > 256) bilr_emit_row<GSTAMD_LAYOUT (pr, pg, pb), 3> (bp, lc[lane], lds.data (), d0, dstride, y, (int) bp.vtaps[(size_t) y * 2 + 1], q[lane][0]); \
           else bilr_emit_row<GSTAMD_LAYOUT (pr, pg, pb), 2> (bp, lc[lane], lds.data (), d0, dstride, y, (int) bp.vtaps[(size_t) y * 2 + 1], q[lane][0]); }
-#define BILR_EMIT() { BILR_L (0, 2, 1, 0) BILR_L (0, 0, 1, 2) BILR_L (0, 1, 2, 3) BILR_L (0, 3, 2, 1) }
+#define BILR_EMIT() { BILR_L (0, 2, 1, 0) BILR_L (0, 0, 1, 2) BILR_L (0, 1, 2, 3) BILR_L (0, 3, 2, 1) BILR_L (0, 0, 0, 4) }
         /* EMU_BIL_ROWS < 0: the balanced strips of the launcher for a device with -EMU_BIL_ROWS wave slots */
         bp.strips = bilr_strips (bp.out_h, bp.rows, (bp.out_w + bp.rows_tile_w - 1) / bp.rows_tile_w, bp.rows < 0 ? -bp.rows : 0);
         for (int g = 0; g < bp.strips; g++)

@@ -128,6 +128,9 @@ hipError_t launch_deep_scale_pack (const PackPlanarParams &pk, const DeepPackPar
 bool deep_scale_pack_usable (const PackPlanarParams &pk, const DeepPackParams &dp, uint8_t *const planes[3], const int strides[3]);
 hipError_t launch_deep_scale4 (const DeepPackParams &dp, const Deep16Params &dd, const PostParams &post, uint8_t *dst, int dstride, hipStream_t stream);
 bool deep_scale4_usable (const DeepPackParams &dp, const uint8_t *dst, int dstride);
+hipError_t launch_deep_scale_pack16 (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const DeepPackParams &dp, uint8_t *const planes[3],
+    const int strides[3], hipStream_t stream);
+bool deep_scale_pack16_usable (const PackPlanarParams &pk, const DeepPackParams &dp, uint8_t *const planes[3], const int strides[3]);
 size_t fused420_lds_bytes (int ring, int nwaves, int sched);
 int fused420_blocks_per_cu (int nwaves, size_t lds, int sched);
 hipError_t launch_scale420_fused (const Fused420Params &p, int chroma_h, int nw, int nwaves, uint8_t *dst, int dstride, const ColorParams &post,
@@ -831,6 +834,29 @@ static int convert_gamma (GstAmdVideoConverter *c, const void *const src_planes[
       pl.p[i] += plane_origin (p.fin, i, p.rect.in_x, p.rect.in_y, pl.stride[i]);          /* the source crop (the vpair table knows the frame's rows) */
     }
     DeepPackParams dsp;
+    if (!c->hook_on && !tuning_on ("GSTAMD_NO_DEEP_SCALE_PACK") && deep_scale_pack16_plan_ok (p, &dsp)) {
+      /* ... into a 10 / 12 / 16-bit planar destination: front, both passes, 16-bit chroma downsamplers, dither and pack in one kernel (k_deep_scale_pack16);
+         borders and the rectangle's origin as the tail of this function has them */
+      uint8_t *bp4[4] = {nullptr, nullptr, nullptr, nullptr}, *rp[3] = {nullptr, nullptr, nullptr};
+      int bs4[4] = {0, 0, 0, 0}, rs[3] = {0, 0, 0};
+      bool all = true;
+      for (int i = 0; i < p.out_info.n_planes && i < 3; i++) {
+        bp4[i] = (uint8_t *) dest_planes[i];
+        bs4[i] = rs[i] = dest_stride ? dest_stride[i] : p.out_info.stride[i];
+        all = all && bp4[i];
+        rp[i] = bp4[i] ? bp4[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, bs4[i]) : nullptr;
+      }
+      dsp.pl = pl;
+      dsp.vpair = c->vpair_dev;
+      dsp.sh.offset = c->pass_dev[0].offset, dsp.sh.taps = c->pass_dev[0].taps;
+      dsp.sv.offset = c->pass_dev[1].offset, dsp.sv.taps = c->pass_dev[1].taps;
+      if (all && deep_scale_pack16_usable (g.pack, dsp, rp, rs)) {
+        if (p.rect.fill && (e = fill_borders (p, bp4, bs4, stream)) != hipSuccess)
+          return hip_fail (e, "k_fill_border");
+        e = launch_deep_scale_pack16 (g.pack, g.pack_hi_depth, g.dither16, dsp, rp, rs, stream);
+        return e == hipSuccess ? GSTAMD_OK : hip_fail (e, "k_deep_scale_pack16");
+      }
+    }
     bool dsp_ok = c->sub_out && deep_pack_usable (c, &dsp);
     if (dsp_ok) {               /* the frames' side of the question: the kernel's 16-byte loads and 4-byte stores */
       const VideoPlan &sp = c->sub_out->plan;
@@ -2001,7 +2027,8 @@ int gstamd_video_converter_frames (GstAmdVideoConverter *c, int n_frames, const 
   Enc16Params ep16_list;
   const bool enc16_list = p.gamma.on && enc16_params (p, &ep16_list) && !tuning_on ("GSTAMD_NO_ENCODE16");         /* k_encode16: one kernel, takes lists */
   DeepPackParams dsp_list;
-  const bool deep_pack_list = p.gamma.on && deep_pack_usable (c, &dsp_list) && !c->sub_out->plan.rect.fill;        /* k_deep_scale_pack: one kernel, takes lists */
+  const bool deep_pack_list = p.gamma.on && !c->hook_on && !tuning_on ("GSTAMD_NO_DEEP_SCALE_PACK") &&
+      ((deep_pack_usable (c, &dsp_list) && !c->sub_out->plan.rect.fill) || deep_scale_pack16_plan_ok (p, &dsp_list));        /* k_deep_scale_pack / _pack16: one kernel, takes lists */
   if (p.gamma.on && !p.gamma.planes_fast && !enc16_list && !deep_pack_list)
     return frames_one_by_one (c, n_frames, src, dest, stream_);
   /* one launch for the whole list when the line-pair kernel applies to every frame */

@@ -1002,6 +1002,11 @@ GSTAMD_HD void pack16_le40_body (const PackPlanarParams &pk, const DitherParams 
   put (pk.kind == UNPACK_SEMI_LE40_TILED ? d.p[1] + tiled_uv_row (pk.pos, d.stride[1], 5, x0 >> 1, yb) : d.p[1] + (size_t) yb * d.stride[1] + 5 * (size_t) (x0 >> 2), bits, ns);
 }
 
+// pack16_body from the block's pixels at hand: pa / pb = pixels x0 - 1 .. x0 + 4 (clamped into the row) of the block's two lines (planar / semi-planar kinds;
+// k_deep_scale_pack16 hands over what its lanes made, video_deep_pack.h)
+GSTAMD_HD void pack16_block (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint2 *pa, const uint2 *pb, bool whole, const DstPlanes16 &d,
+    int x0, int yb);
+
 // per-lane block as pack_planar_body: pixels x0 .. x0+3 of the lines (yb << h_sub) ..; planar and semi-planar kinds
 GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint8_t *__restrict__ src, int sstride,
     const DstPlanes16 &d, int x0, int yb)
@@ -1038,26 +1043,42 @@ GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const Dith
       pa[i] = ra[x], pb[i] = rb[x];
     }
   }
-  for (int r = 0; r < nlines; r++) {
+  pack16_block (pk, hi_depth, dt, pa, pb, whole, d, x0, yb);
+}
+
+GSTAMD_HD void pack16_block (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const uint2 *pa, const uint2 *pb, bool whole, const DstPlanes16 &d,
+    int x0, int yb)
+{
+  const int w = pk.width, h = pk.height;
+  const int y0 = yb << pk.h_sub;
+  const int nlines = 1 << pk.h_sub;
+  /* (every loop with constant bounds and every array with constant indices: run-time bounds / a pointer chosen between the two lines put pa, pb and the
+     planes into scratch memory - 112 bytes a lane in k_deep_scale_pack16) */
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
     const int y = y0 + r;
-    if (y >= h)
+    if (r >= nlines || y >= h)
       break;
-    const uint2 *pr = r ? pb : pa;
     uint16_t *dy = (uint16_t *) (d.p[0] + (size_t) y * d.stride[0]) + x0;
     uint16_t o[4] = {0, 0, 0, 0};
-    for (int i = 0; i < 4 && x0 + i < w; i++)
-      o[i] = pack16_sample (hi_depth, dither16_comp (dt, 1, (int) (pr[i + 1].x >> 16), x0 + i, y));
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (x0 + i < w)
+        o[i] = pack16_sample (hi_depth, dither16_comp (dt, 1, (int) ((r ? pb[i + 1].x : pa[i + 1].x) >> 16), x0 + i, y));
     if (whole && (((uintptr_t) dy) & 7) == 0) {
       uint2 st;
       st.x = (uint32_t) o[0] | ((uint32_t) o[1] << 16);
       st.y = (uint32_t) o[2] | ((uint32_t) o[3] << 16);
       *(uint2 *) dy = st;
     } else {
-      for (int i = 0; i < 4 && x0 + i < w; i++)
-        dy[i] = o[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (x0 + i < w)
+          dy[i] = o[i];
     }
   }
   int cu[6], cv[6];                                     // U, V of pixels x0-1 .. x0+4
+#pragma unroll
   for (int i = 0; i < 6; i++) {
     int u = (int) (pa[i].y & 0xffffu), v = (int) (pa[i].y >> 16);
     if (pk.down_v) {
@@ -1068,10 +1089,11 @@ GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const Dith
     cv[i] = v;
   }
   const int step = 1 << pk.w_sub;
-  for (int i = 0; i < 4; i += step) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
     const int x = x0 + i;
-    if (x >= w)
-      break;
+    if ((i & (step - 1)) != 0 || x >= w)
+      continue;
     int u = cu[i + 1], v = cv[i + 1];
     if (pk.w_sub == 1) {
       if (pk.down_h == 1) {
@@ -1104,8 +1126,9 @@ GSTAMD_HD void pack16_body (const PackPlanarParams &pk, int hi_depth, const Dith
         duv[1] = c1;
       }
     } else {
-      ((uint16_t *) (d.p[pk.u_plane] + (size_t) yb * d.stride[pk.u_plane]))[k] = pu;
-      ((uint16_t *) (d.p[pk.v_plane] + (size_t) yb * d.stride[pk.v_plane]))[k] = pv;
+      const bool u1 = pk.u_plane == 1;
+      ((uint16_t *) ((u1 ? d.p[1] : d.p[2]) + (size_t) yb * (u1 ? d.stride[1] : d.stride[2])))[k] = pu;
+      ((uint16_t *) ((u1 ? d.p[2] : d.p[1]) + (size_t) yb * (u1 ? d.stride[2] : d.stride[1])))[k] = pv;
     }
   }
 }

@@ -14,6 +14,7 @@
 #pragma once
 #include "video_deep.h"
 #include "video_pack.h"
+#include "video_dither_ed.h"
 
 namespace gstamd {
 
@@ -310,6 +311,77 @@ GSTAMD_HD void deep_scale_pack_lane (const PackPlanarParams &pk, const DeepPackP
   (void) pack_planar_block4 (pk, src, dst, x0, yb, dd, store);
 }
 
+// one lane of k_deep_scale_pack16: the block at (x0, yb << h_sub) of a 10 / 12 / 16-bit planar or semi-planar destination - the chain stays on 16-bit values to
+// the end: chroma downsamplers on u16, ordered dither, pack (pack16_block: what k_pack16 does after reading the block from an image).  The neighbours the
+// cosited downsampler reads are traded between lanes like k_deep_scale_pack's.
+template <int SH, int CH>
+GSTAMD_HD void deep_scale_pack16_lane (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const DeepPackParams &dp, const DstPlanes16 &d, int x0, int yb,
+    bool store = true)
+{
+  DeepScaledSrc<SH, CH> src;
+  src.d = dp;
+  const int w = pk.width, h = pk.height, y0 = yb << pk.h_sub, y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+  uint2 pa[6], pb[6];
+  src.core4_16 (x0, y0, pa + 1);
+  const bool two = pk.h_sub || pk.down_v;
+  if (two) {
+    src.core4_16 (x0, y1, pb + 1);
+  } else {
+#pragma unroll
+    for (int i = 1; i < 5; i++)
+      pb[i] = pa[i];
+  }
+  pa[0] = pa[1], pa[5] = pa[4], pb[0] = pb[1], pb[5] = pb[4];         /* pack16_body's clamps at the picture's edges */
+  if (pk.w_sub == 1 && pk.down_h == 2) {
+#ifdef __HIPCC__
+    uint2 l, r, lb, rb;
+    l.x = (uint32_t) __shfl_up ((int) pa[4].x, 1), l.y = (uint32_t) __shfl_up ((int) pa[4].y, 1);
+    r.x = (uint32_t) __shfl_down ((int) pa[1].x, 1), r.y = (uint32_t) __shfl_down ((int) pa[1].y, 1);
+    lb.x = (uint32_t) __shfl_up ((int) pb[4].x, 1), lb.y = (uint32_t) __shfl_up ((int) pb[4].y, 1);
+    rb.x = (uint32_t) __shfl_down ((int) pb[1].x, 1), rb.y = (uint32_t) __shfl_down ((int) pb[1].y, 1);
+    if (x0 > 0)
+      pa[0] = l, pb[0] = lb;
+    if (x0 + 4 < w)
+      pa[5] = r, pb[5] = rb;
+#else
+    uint2 t[4];
+    if (x0 > 0) {
+      src.core4_16 (x0 - 4, y0, t), pa[0] = t[3];
+      if (two)
+        src.core4_16 (x0 - 4, y1, t);
+      pb[0] = t[3];
+    }
+    if (x0 + 4 < w) {
+      src.core4_16 (x0 + 4, y0, t), pa[5] = t[0];
+      if (two)
+        src.core4_16 (x0 + 4, y1, t);
+      pb[5] = t[0];
+    }
+#endif
+  }
+  if (store)
+    pack16_block (pk, hi_depth, dt, pa, pb, true, d, x0, yb);
+}
+
+GSTAMD_HD void deep_scale_pack16_any (int variant, const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const DeepPackParams &dp, const DstPlanes16 &d,
+    int x0, int yb)
+{
+  switch (variant) {
+    case 0: deep_scale_pack16_lane<0, CHROMA_H_NONE> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    case 1: deep_scale_pack16_lane<0, CHROMA_H_H2> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    case 2: deep_scale_pack16_lane<0, CHROMA_H_H2_CS> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    case 3: deep_scale_pack16_lane<1, CHROMA_H_NONE> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    case 4: deep_scale_pack16_lane<1, CHROMA_H_H2> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    case 5: deep_scale_pack16_lane<1, CHROMA_H_H2_CS> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    case 6: deep_scale_pack16_lane<2, CHROMA_H_NONE> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    case 7: deep_scale_pack16_lane<2, CHROMA_H_H2> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    case 8: deep_scale_pack16_lane<2, CHROMA_H_H2_CS> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    case 9: deep_scale_pack16_lane<3, CHROMA_H_NONE> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    case 10: deep_scale_pack16_lane<3, CHROMA_H_H2> (pk, hi_depth, dt, dp, d, x0, yb); break;
+    default: deep_scale_pack16_lane<3, CHROMA_H_H2_CS> (pk, hi_depth, dt, dp, d, x0, yb); break;
+  }
+}
+
 // one lane of k_deep_scale4: pixels x0 .. x0 + 3 of line y of a 4-byte destination - the same chain up to the vertical pass, then the convert stage on
 // 16-bit values (video_converter_matrix16), narrowing, alpha and pack (deep_finish_store4: what k_scale16_final does after its pass)
 template <int SEMI, int CH>
@@ -392,6 +464,27 @@ inline bool deep_scale4_plan_ok (const VideoPlan &p, DeepPackParams *dp)
     return false;
   const int ow = p.passes[0].out_size, oh = p.passes[1].out_size;
   if (ow != p.out_info.width || oh != p.out_info.height || (ow % 4) != 0)
+    return false;
+  memset ((void *) dp, 0, sizeof (*dp));
+  dp->f = p.front;
+  dp->out_w = ow, dp->out_h = oh;
+  dp->sh.kind = p.passes[0].kind, dp->sh.n_taps = p.passes[0].n_taps, dp->sh.inc = p.passes[0].inc;
+  dp->sv.kind = p.passes[1].kind, dp->sv.n_taps = p.passes[1].n_taps, dp->sv.inc = p.passes[1].inc;
+  dp->hx2 = 1;
+  return true;
+}
+
+// host: is `p` (a composite plan with a 10-bit source AND a 10 / 12 / 16-bit planar or semi-planar destination: GammaPlan::src16 + pack16) one k_deep_scale_pack16
+// serves?  Fills everything of `dp` but the pointers.
+inline bool deep_scale_pack16_plan_ok (const VideoPlan &p, DeepPackParams *dp)
+{
+  const GammaPlan &g = p.gamma;
+  if (!g.on || !g.src16 || !g.pack16 || g.store64 || g.planes_fast || g.fused || !g.shrink || !g.dec16.empty () || !g.enc16.empty () || g.prim.has_matrix ||
+      g.alpha_kind != ALPHA_NONE || p.interlaced || p.field || !deep_passes_halve (p) || dither_is_diffusion (g.dither16) ||
+      (g.pack.kind != UNPACK_PLANAR && g.pack.kind != UNPACK_SEMI) || g.pack.frame_on || g.pack.tail_swap)
+    return false;
+  const int ow = p.passes[0].out_size, oh = p.passes[1].out_size;
+  if (g.pack.width != ow || g.pack.height != oh || (ow % 4) != 0)
     return false;
   memset ((void *) dp, 0, sizeof (*dp));
   dp->f = p.front;

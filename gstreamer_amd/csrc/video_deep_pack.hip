@@ -73,6 +73,58 @@ hipError_t launch_deep_scale_pack (const PackPlanarParams &pk, const DeepPackPar
   return hipGetLastError ();
 }
 
+// ---- k_deep_scale_pack16: the same chain into a 10 / 12 / 16-bit planar or semi-planar destination (P010 -> P010 / I420_10LE at half the size); k_deep_scale_pack's
+// lane layout (62 storing lanes a workgroup)
+template <int SEMI, int CH>
+__global__ __launch_bounds__ (64) void k_deep_scale_pack16 (PackPlanarParams pk, int hi_depth, DitherParams dt, DeepPackParams dp, DstPlanes16 d, int nblk, FrameDeltas fl)
+{
+  GSTAMD_FRAME_Z;
+  dp.pl.p[0] += fls_, dp.pl.p[1] += fls_;
+  if (!(SEMI & 1))
+    dp.pl.p[2] += fls_;
+  d.p[0] += fld_, d.p[1] += fld_, d.p[2] += fld_;
+  const int lane = (int) threadIdx.x, blk = (int) blockIdx.x * 62 + lane - 1;
+  const bool store = lane >= 1 && lane <= 62 && blk < nblk;
+  const int bc = blk < 0 ? 0 : (blk > nblk - 1 ? nblk - 1 : blk);
+  deep_scale_pack16_lane<SEMI, CH> (pk, hi_depth, dt, dp, d, 4 * bc, (int) blockIdx.y, store);
+}
+
+bool deep_scale_pack16_usable (const PackPlanarParams &pk, const DeepPackParams &dp, uint8_t *const planes[3], const int strides[3])
+{
+  const int variant = deep_front4_variant (dp.f);
+  bool ok = dp.hx2 && variant >= 0 && (pk.width % 4) == 0 && (pk.kind == UNPACK_PLANAR || pk.kind == UNPACK_SEMI);
+  for (int i = 0; ok && i < (variant >= 3 ? 2 : 3); i++)
+    ok = ((uintptr_t) dp.pl.p[i] % 16) == 0 && (dp.pl.stride[i] % 16) == 0;
+  for (int i = 0; ok && i < (pk.kind == UNPACK_SEMI ? 2 : 3); i++)
+    ok = planes[i] != nullptr && ((uintptr_t) planes[i] % 2) == 0 && (strides[i] % 2) == 0;
+  return ok;
+}
+
+hipError_t launch_deep_scale_pack16 (const PackPlanarParams &pk, int hi_depth, const DitherParams &dt, const DeepPackParams &dp, uint8_t *const planes[3],
+    const int strides[3], hipStream_t stream)
+{
+  if (!deep_scale_pack16_usable (pk, dp, planes, strides))
+    return hipErrorNotSupported;
+  DstPlanes16 d;
+  for (int i = 0; i < 3; i++) {
+    d.p[i] = planes[i];
+    d.stride[i] = strides[i];
+  }
+  const int variant = deep_pack_variant (dp.f);
+  const int nblk = pk.width / 4, rows = (pk.height + (1 << pk.h_sub) - 1) >> pk.h_sub;
+  int nz;
+  const FrameDeltas &fl = video_frame_list_for (dp.pl.p[0], planes[0], &nz);
+  const dim3 grid ((nblk + 61) / 62, rows, nz);
+  switch (variant) {
+#define P16(v, sh, ch) case v: hipLaunchKernelGGL ((k_deep_scale_pack16<sh, ch>), grid, dim3 (64), 0, stream, pk, hi_depth, dt, dp, d, nblk, fl); break;
+    P16 (0, 0, CHROMA_H_NONE) P16 (1, 0, CHROMA_H_H2) P16 (2, 0, CHROMA_H_H2_CS) P16 (3, 1, CHROMA_H_NONE) P16 (4, 1, CHROMA_H_H2) P16 (5, 1, CHROMA_H_H2_CS)
+    P16 (6, 2, CHROMA_H_NONE) P16 (7, 2, CHROMA_H_H2) P16 (8, 2, CHROMA_H_H2_CS) P16 (9, 3, CHROMA_H_NONE) P16 (10, 3, CHROMA_H_H2) P16 (11, 3, CHROMA_H_H2_CS)
+#undef P16
+    default: return hipErrorNotSupported;
+  }
+  return hipGetLastError ();
+}
+
 // ---- k_deep_scale4: the same chain into a 4-byte 8-bit destination (P010 -> BGRA at half the size): a lane = four pixels of a line, one 16-byte store
 template <int SEMI, int CH>
 __global__ __launch_bounds__ (64) void k_deep_scale4 (DeepPackParams dp, Deep16Params dd, PostParams post, uint8_t *__restrict__ dst, int dstride, FrameDeltas fl)

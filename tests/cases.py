@@ -1940,3 +1940,19 @@ VIDEO_CASES += [
     ("bay_nv12_i420_dither", "NV12", 256, 128, "I420", 128, 64, dict(LIN, dither_method="bayer", dither_quantization=4), None, None, "random"),
     ("bay_not_nv12_i420_matrix", "NV12", 1280, 720, "I420", 640, 360, LIN, None, None, "random"),          # (HD -> SD: a colour matrix in between)
 ]
+
+# ... and k_deep_scale_pack16: into a 10 / 12 / 16-bit planar or semi-planar destination (the chain stays on 16-bit values: u16 downsamplers, ordered dither, pack)
+VIDEO_CASES += [
+    ("dsp16_p010_p010_512x1160", "P010_10LE", 512, 1160, "P010_10LE", 256, 580, BIL2, None, None, "random"),
+    ("dsp16_p010_i42010_504x1160_63_blocks", "P010_10LE", 504, 1160, "I420_10LE", 252, 580, BIL2, None, "cosited", "random"),
+    ("dsp16_i42010_p010_site_jpeg", "I420_10LE", 128, 66, "P010_10LE", 64, 33, BIL2, None, "jpeg", "random"),
+    ("dsp16_i42012_p012", "I420_12LE", 128, 64, "P012_LE", 64, 32, BIL2, None, None, "random"),
+    ("dsp16_p010_p016", "P010_10LE", 136, 64, "P016_LE", 68, 32, BIL2, None, None, "random"),
+    ("dsp16_p010_i42210", "P010_10LE", 128, 64, "I422_10LE", 64, 32, BIL2, None, None, "random"),
+    ("dsp16_i42210_y44410", "I422_10LE", 128, 64, "Y444_10LE", 64, 32, BIL2, None, None, "random"),
+    ("dsp16_p010_i42010be", "P010_10LE", 128, 64, "I420_10BE", 64, 32, BIL2, None, None, "random"),
+    ("dsp16_p016_p010_bayer", "P016_LE", 128, 64, "P010_10LE", 64, 32, dict(BIL2, dither_method="bayer", dither_quantization=4), None, None, "random"),
+    ("dsp16_p010_p010_crop_rect_border", "P010_10LE", 256, 128, "P010_10LE", 96, 48, dict(BIL2, src_x=64, src_y=32, src_width=128, src_height=64, dest_x=16, dest_y=8, dest_width=64, dest_height=32, border_argb=0xff204060), None, None, "random"),
+    ("dsp16_not_p010_p010_floyd", "P010_10LE", 128, 64, "P010_10LE", 64, 32, dict(BIL2, dither_method="floyd-steinberg"), None, None, "random"),
+    ("dsp16_not_p010_y210", "P010_10LE", 128, 64, "Y210", 64, 32, BIL2, None, None, "random"),
+]

@@ -1084,6 +1084,27 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         pl.p[i] = src + in->offset[i] + plane_origin (p.fin, i, p.rect.in_x, p.rect.in_y, in->stride[i]);
         pl.stride[i] = in->stride[i];
       }
+      DeepPackParams ds16;
+      if (!g_gamma_hook && getenv ("GSTAMD_NO_DEEP_SCALE_PACK") == nullptr && deep_scale_pack16_plan_ok (p, &ds16)) {       /* k_deep_scale_pack16 over its grid */
+        ds16.pl = pl;
+        ds16.vpair = p.vpair.data ();
+        ds16.sh.offset = p.passes[0].offset.data (), ds16.sh.taps = p.passes[0].taps.data ();
+        ds16.sv.offset = p.passes[1].offset.data (), ds16.sv.taps = p.passes[1].taps.data ();
+        DstPlanes16 d16;
+        memset (&d16, 0, sizeof (d16));
+        for (int i = 0; i < out->n_planes && i < 3; i++) {
+          d16.p[i] = dst + out->offset[i] + plane_origin (p.fout, i, p.rect.out_x, p.rect.out_y, out->stride[i]);
+          d16.stride[i] = out->stride[i];
+        }
+        if (p.rect.fill)
+          emu_fill_borders (p, out, dst);
+        g_emu_deep_pack_runs++;
+        const int rows16 = (g.pack.height + (1 << g.pack.h_sub) - 1) >> g.pack.h_sub;
+        for (int yb = 0; yb < rows16; yb++)
+          for (int l = 0; l < g.pack.width / 4; l++)
+            deep_scale_pack16_any (deep_pack_variant (p.front), g.pack, g.pack_hi_depth, g.dither16, ds16, d16, 4 * l, yb);
+        return GSTAMD_OK;
+      }
       {
         /* convert_gamma's k_deep_scale_pack branch: the sub-conversion with the 10-bit source as its pixels */
         VideoPlan subp;

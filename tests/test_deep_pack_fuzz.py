@@ -15,7 +15,8 @@ import cases  # noqa: E402
 from gstreamer_amd import video as V  # noqa: E402
 
 SRC = ["P010_10LE", "I420_10LE", "I420_12LE", "P012_LE", "P016_LE", "I422_10LE", "I422_12LE"]
-DST = ["NV12", "NV21", "I420", "YV12", "Y42B", "NV16", "NV61", "Y444", "NV24", "BGRA", "RGBA", "ARGB", "xBGR", "AYUV", "VUYA"]
+DST = ["NV12", "NV21", "I420", "YV12", "Y42B", "NV16", "NV61", "Y444", "NV24", "BGRA", "RGBA", "ARGB", "xBGR", "AYUV", "VUYA",
+       "P010_10LE", "I420_10LE", "P016_LE", "I422_12LE", "I420_12BE", "Y444_10LE"]
 
 
 def draw(rnd):

@@ -167,7 +167,7 @@ def test_hip_matches_reference_bytewise_c5_full_size(native_lib, gpu, ref):
 
 
 @pytest.mark.parametrize("shape", [("P010_10LE", 3840, 2160, "NV12"), ("I420_10LE", 3840, 2160, "I420"), ("P010_10LE", 1280, 2400, "NV21"), ("P010_10LE", 2016, 1208, "NV12"),
-                                   ("P010_10LE", 3840, 2160, "BGRA"), ("I420_10LE", 2016, 1208, "RGBA")],
+                                   ("P010_10LE", 3840, 2160, "BGRA"), ("I420_10LE", 2016, 1208, "RGBA"), ("P010_10LE", 3840, 2160, "P010_10LE"), ("P010_10LE", 2016, 1208, "I420_10LE")],
                          ids=lambda s: "%s_%dx%d_%s" % s)
 def test_hip_deep_scale_pack_matches_reference_bytewise(native_lib, gpu, ref, shape):
     """k_deep_scale_pack (video_deep_pack.h): a 10-bit source that halves into an 8-bit planar / semi-planar destination - the decoder-to-encoder

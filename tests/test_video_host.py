@@ -661,11 +661,11 @@ def test_deep_plane_copies_without_border_fill_on_host(native_lib, emu_lib, ref,
     assert not dst[:cfg["dest_y"] * stride].any()
 
 
-@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("dsp_") or c[0].startswith("dsp4_")])
+@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("dsp_") or c[0].startswith("dsp4_") or c[0].startswith("dsp16_")])
 def test_deep_scale_pack_body_is_the_one_that_runs(native_lib, emu_lib, name, monkeypatch):
     """the dsp_* cases (a 10-bit planar / semi-planar source that halves into an 8-bit planar / semi-planar destination) go through
     k_deep_scale_pack's lane function (video_deep_pack.h: front, both u16 passes, narrowing and pack per block), the dsp4_* ones (a 4-byte
-    destination) through k_deep_scale4's - the *_not_* ones (other filters, ratios, widths, a dither stage ahead of a planar pack) do not - and through
+    destination) through k_deep_scale4's, the dsp16_* ones (a 10 / 12 / 16-bit planar destination) through k_deep_scale_pack16's - the *_not_* ones (other filters, ratios, widths, a dither stage ahead of a planar pack) do not - and through
     the multi-launch forms with GSTAMD_NO_DEEP_SCALE_PACK, with the reference's bytes either way"""
     _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)

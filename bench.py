@@ -62,6 +62,12 @@ VIDEO_CONFIGS = {
     "f6p010nv12": ("P010_10LE", 3840, 2160, "NV12", 1920, 1080, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
                    "4K->1080p frames/s (videoconvertscale P010_10LE->NV12, bilinear) per GPU; % HBM roofline",
                    "k_deep_scale_pack<semi-planar, CHROMA_H_H2_CS> (16-bit front, both u16 passes, narrowing, chroma downsampler and pack in one kernel)"),
+    "f6p010p010": ("P010_10LE", 3840, 2160, "P010_10LE", 1920, 1080, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
+                   "4K->1080p frames/s (videoconvertscale P010_10LE->P010_10LE, bilinear) per GPU; % HBM roofline",
+                   "k_deep_scale_pack16<semi-planar, CHROMA_H_H2_CS> (16-bit front, both u16 passes, u16 chroma downsamplers, ordered dither and pack in one kernel)"),
+    "f6nv12i420": ("NV12", 3840, 2160, "I420", 1920, 1080, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
+                   "4K->1080p frames/s (videoconvertscale NV12->I420, bilinear) per GPU; % HBM roofline",
+                   "k_bilinear420_half<.., GSTAMD_LAYOUT_AYUV> into the pack image + k_pack_planar (two launches per list)"),
     "f6p010bgra": ("P010_10LE", 3840, 2160, "BGRA", 1920, 1080, {"resampler_method": "linear", "max_taps": 2}, 8, 8,
                    "4K->1080p frames/s (videoconvertscale P010_10LE->BGRA, bilinear) per GPU; % HBM roofline",
                    "k_deep_scale4<semi-planar, CHROMA_H_H2_CS> (16-bit front, both u16 passes, matrix16, narrowing and pack in one kernel)"),
@@ -72,6 +78,8 @@ CONFIG_TEXT = {
     "f8swizzle": "SURVEY 8(f): 3840x2160 BGRA -> RGBA (a byte permutation)",
     "f5encode16": "SURVEY 8(f)2 / VERDICT r03 item 5: 3840x2160 BGRA -> P010_10LE (widen, matrix16, cosited chroma down, ordered dither, pack)",
     "f6p010nv12": "VERDICT r05 item 4: 3840x2160 P010_10LE -> 1920x1080 NV12, bilinear (the elements' default method) - an HDR decoder's frames into an encoder's format",
+    "f6p010p010": "VERDICT r05 item 4: 3840x2160 P010_10LE -> 1920x1080 P010_10LE, bilinear - an HDR transcode that keeps ten bits",
+    "f6nv12i420": "VERDICT r05 item 4: 3840x2160 NV12 -> 1920x1080 I420, bilinear - a decoder's frames into a software encoder's format",
     "f6p010bgra": "VERDICT r05 item 4: 3840x2160 P010_10LE -> 1920x1080 BGRA, bilinear (the elements' default method) - an HDR decoder's frames for display",
     "c2": "C2: 3840x2160 NV12 (bt709 limited, chroma-site mpeg2) -> BGRA, fused unpack + chroma upsample + matrix + pack",
     "c1": "C1 size on the GPU: 1920x1080 NV12 -> BGRA (the reference's CPU-runnable case)",
@@ -719,7 +727,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4opaque | c4audio | c4audiomany | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f5encode16 | f8scale | f8pack | f8swizzle | f6p010nv12 | f6p010bgra")
+    ap.add_argument("--config", default="c2", help="c2 (headline) | c1 | c3 | c4 | c4opaque | c4audio | c4audiomany | c5 | c4a | f2gamma | f2p010out | f2p010in | f4audioconv | f5encode16 | f8scale | f8pack | f8swizzle | f6p010nv12 | f6p010bgra | f6p010p010 | f6nv12i420")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="c2: skip the batch-1 / element numbers reported beside the headline")
     ap.add_argument("--preheat-ms", type=float, default=60.0,

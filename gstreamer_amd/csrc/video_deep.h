@@ -1466,7 +1466,11 @@ GSTAMD_HD void deep_planes_body (const DeepPlanesParams &d, const DeepPlanesPtrs
 // A lane loads 32 / 16 bytes and stores 16 / 32; two samples per register in the packed 16-bit instructions.
 GSTAMD_VP bool deep_planes16_ok (const DeepPlanesParams &d)
 {
-  if (d.in_kind != d.out_kind || (d.in_kind != UNPACK_PLANAR && d.in_kind != UNPACK_SEMI) || (d.in_hi != 0) == (d.out_hi != 0) || d.w_sub > 1)
+  if ((d.in_kind != UNPACK_PLANAR && d.in_kind != UNPACK_SEMI) || (d.out_kind != UNPACK_PLANAR && d.out_kind != UNPACK_SEMI) || (d.in_hi != 0) == (d.out_hi != 0) || d.w_sub > 1)
+    return false;
+  /* the other plane layout on the way down to 8 bits (P010 -> I420 / YV12, I420_10LE -> NV12 / NV21: a decoder's frames for an 8-bit encoder): the chroma rows
+     are taken apart / put together with byte permutations (deep_planes16_body "mixed") */
+  if (d.in_kind != d.out_kind && (d.in_hi == 0 || d.w_sub != 1))
     return false;
   const int deep = d.in_hi ? d.in_hi : d.out_hi;
   if (deep != 1 && deep != 2 && deep != 4 && deep != 5 && deep != 6)
@@ -1474,7 +1478,7 @@ GSTAMD_VP bool deep_planes16_ok (const DeepPlanesParams &d)
   const int cw = (d.width + (1 << d.w_sub) - 1) >> d.w_sub;
   if ((d.width % 16) != 0 || ((d.in_kind == UNPACK_SEMI ? 2 * cw : cw) % 16) != 0)
     return false;
-  if (d.in_kind == UNPACK_SEMI && (d.in_u != d.out_u || d.w_sub != 1))
+  if (d.in_kind == UNPACK_SEMI && d.out_kind == UNPACK_SEMI && (d.in_u != d.out_u || d.w_sub != 1))
     return false;
   if (d.out_hi && d.dither.on && (d.dither.shift[1] != d.dither.shift[2] || d.dither.shift[1] != d.dither.shift[3] || d.dither.shift[1] > 8 || d.dither.shift[1] < 0))
     return false;
@@ -1495,7 +1499,22 @@ GSTAMD_HD uint32_t pk_adds16 (uint32_t a, uint32_t b)            // v_pk_add_u16
 GSTAMD_VP int deep_planes16_rows (const DeepPlanesParams &d)
 {
   const int ch = (d.height + (1 << d.h_sub) - 1) >> d.h_sub;
-  return d.height + (d.in_kind == UNPACK_SEMI ? ch : 2 * ch);
+  return d.height + (d.in_kind == UNPACK_SEMI || d.out_kind == UNPACK_SEMI ? ch : 2 * ch);          /* (mixed layouts: a lane of a chroma row serves both planes) */
+}
+
+// sixteen stored words of a deep plane row -> their sixteen bytes (the high byte of the widened value)
+GSTAMD_HD uint4 deep_narrow16 (int in_hi, const uint4 &a, const uint4 &b)
+{
+  uint4 o;
+  if (in_hi == 1 || in_hi == 4) {           /* the value in the low bits: (word >> (bits - 8)) & 0xff */
+    const int sh = hi_depth_bits (in_hi) - 8;
+    o.x = bperm (a.y >> sh, a.x >> sh, 0x06040200u), o.y = bperm (a.w >> sh, a.z >> sh, 0x06040200u);
+    o.z = bperm (b.y >> sh, b.x >> sh, 0x06040200u), o.w = bperm (b.w >> sh, b.z >> sh, 0x06040200u);
+  } else {
+    o.x = bperm (a.y, a.x, 0x07050301u), o.y = bperm (a.w, a.z, 0x07050301u);
+    o.z = bperm (b.y, b.x, 0x07050301u), o.w = bperm (b.w, b.z, 0x07050301u);
+  }
+  return o;
 }
 
 // lane: samples 16 * lane .. + 15 of plane row `row` (luma rows, then the chroma rows: of the interleaved plane, or of U and then of V)
@@ -1504,6 +1523,36 @@ GSTAMD_HD void deep_planes16_body (const DeepPlanesParams &d, const DeepPlanesPt
 {
   const int ch = (d.height + (1 << d.h_sub) - 1) >> d.h_sub, cw = (d.width + (1 << d.w_sub) - 1) >> d.w_sub;
   int ip = 0, op = 0, r = row, n = d.width, mode = 0, y = row;
+  if (!TO_HI && row >= d.height && d.in_kind != d.out_kind) {
+    /* mixed layouts, a chroma row: the lane's eight chroma positions - sixteen interleaved words of a semi-planar row, or eight words of each plane */
+    r = row - d.height;
+    const int s0 = 16 * lane;
+    if (r >= ch || s0 >= 2 * cw)
+      return;
+    if (d.in_kind == UNPACK_SEMI) {
+      const uint8_t *src = pp.in[1] + ds + (size_t) r * pp.in_stride[1];
+      const uint4 o = deep_narrow16 (d.in_hi, *(const uint4 *) (src + 2 * (size_t) s0), *(const uint4 *) (src + 2 * (size_t) s0 + 16));
+      uint2 first, second;          /* the pairs' first and second samples */
+      first.x = bperm (o.y, o.x, 0x06040200u), first.y = bperm (o.w, o.z, 0x06040200u);
+      second.x = bperm (o.y, o.x, 0x07050301u), second.y = bperm (o.w, o.z, 0x07050301u);
+      const bool u1 = d.out_u == 1;
+      uint8_t *du = (u1 ? pp.out[1] : pp.out[2]) + dd + (size_t) r * (u1 ? pp.out_stride[1] : pp.out_stride[2]) + s0 / 2;
+      uint8_t *dv = (u1 ? pp.out[2] : pp.out[1]) + dd + (size_t) r * (u1 ? pp.out_stride[2] : pp.out_stride[1]) + s0 / 2;
+      *(uint2 *) du = d.in_u ? first : second;          /* (semi-planar: in_u is the U-first flag) */
+      *(uint2 *) dv = d.in_u ? second : first;
+    } else {
+      const bool u1 = d.in_u == 1;
+      const uint8_t *su = (u1 ? pp.in[1] : pp.in[2]) + ds + (size_t) r * (u1 ? pp.in_stride[1] : pp.in_stride[2]) + s0;
+      const uint8_t *sv = (u1 ? pp.in[2] : pp.in[1]) + ds + (size_t) r * (u1 ? pp.in_stride[2] : pp.in_stride[1]) + s0;
+      const uint4 z = gstamd_make_uint4 (0, 0, 0, 0);
+      const uint4 nu = deep_narrow16 (d.in_hi, *(const uint4 *) su, z), nv = deep_narrow16 (d.in_hi, *(const uint4 *) sv, z);          /* eight bytes each: .x .y */
+      const uint32_t fx = d.out_u ? nu.x : nv.x, fy = d.out_u ? nu.y : nv.y, gx = d.out_u ? nv.x : nu.x, gy = d.out_u ? nv.y : nu.y;
+      uint4 o;
+      o.x = bperm (gx, fx, 0x05010400u), o.y = bperm (gx, fx, 0x07030602u), o.z = bperm (gy, fy, 0x05010400u), o.w = bperm (gy, fy, 0x07030602u);
+      *(uint4 *) (pp.out[1] + dd + (size_t) r * pp.out_stride[1] + s0) = o;
+    }
+    return;
+  }
   if (row >= d.height) {
     r = row - d.height;
     if (d.in_kind == UNPACK_SEMI) {
@@ -1524,17 +1573,7 @@ GSTAMD_HD void deep_planes16_body (const DeepPlanesParams &d, const DeepPlanesPt
   const uint8_t *src = pp.in[ip] + ds + (size_t) r * pp.in_stride[ip];
   uint8_t *dst = pp.out[op] + dd + (size_t) r * pp.out_stride[op];
   if (!TO_HI) {
-    const uint4 a = *(const uint4 *) (src + 2 * (size_t) s0), b = *(const uint4 *) (src + 2 * (size_t) s0 + 16);
-    uint4 o;
-    if (d.in_hi == 1 || d.in_hi == 4) {           /* the value in the low bits: (word >> (bits - 8)) & 0xff */
-      const int sh = hi_depth_bits (d.in_hi) - 8;
-      o.x = bperm (a.y >> sh, a.x >> sh, 0x06040200u), o.y = bperm (a.w >> sh, a.z >> sh, 0x06040200u);
-      o.z = bperm (b.y >> sh, b.x >> sh, 0x06040200u), o.w = bperm (b.w >> sh, b.z >> sh, 0x06040200u);
-    } else {
-      o.x = bperm (a.y, a.x, 0x07050301u), o.y = bperm (a.w, a.z, 0x07050301u);
-      o.z = bperm (b.y, b.x, 0x07050301u), o.w = bperm (b.w, b.z, 0x07050301u);
-    }
-    *(uint4 *) (dst + s0) = o;
+    *(uint4 *) (dst + s0) = deep_narrow16 (d.in_hi, *(const uint4 *) (src + 2 * (size_t) s0), *(const uint4 *) (src + 2 * (size_t) s0 + 16));
     return;
   }
   /* the row's sixteen dither values, as the eight pairs the lane's sample pairs meet */

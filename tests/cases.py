@@ -1956,3 +1956,15 @@ VIDEO_CASES += [
     ("dsp16_not_p010_p010_floyd", "P010_10LE", 128, 64, "P010_10LE", 64, 32, dict(BIL2, dither_method="floyd-steinberg"), None, None, "random"),
     ("dsp16_not_p010_y210", "P010_10LE", 128, 64, "Y210", 64, 32, BIL2, None, None, "random"),
 ]
+
+# round 6: k_deep_planes16 with the OTHER plane layout on the way down to 8 bits (a decoder's P010 for an 8-bit I420 encoder): chroma rows taken apart / put
+# together with byte permutations
+VIDEO_CASES += [
+    ("planes16_mixed_p010_i420", "P010_10LE", 160, 34, "I420", 160, 34, {}, None, None, "random"),
+    ("planes16_mixed_p016_yv12", "P016_LE", 64, 32, "YV12", 64, 32, {}, None, None, "random"),
+    ("planes16_mixed_i42010_nv12", "I420_10LE", 160, 34, "NV12", 160, 34, {}, None, None, "random"),
+    ("planes16_mixed_i42012_nv21", "I420_12LE", 64, 32, "NV21", 64, 32, {}, None, None, "random"),
+    ("planes16_mixed_i42210_nv16", "I422_10LE", 96, 20, "NV16", 96, 20, {}, None, None, "random"),
+    ("planes16_mixed_p010_i420_1080p", "P010_10LE", 1920, 1080, "I420", 1920, 1080, {}, None, None, "random"),
+    ("planes16_mixed_p010_i420_row_not_16", "P010_10LE", 48, 18, "I420", 40, 18, dict(src_width=40), None, None, "random"),
+]

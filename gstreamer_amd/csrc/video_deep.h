@@ -1466,8 +1466,22 @@ GSTAMD_HD void deep_planes_body (const DeepPlanesParams &d, const DeepPlanesPtrs
 // A lane loads 32 / 16 bytes and stores 16 / 32; two samples per register in the packed 16-bit instructions.
 GSTAMD_VP bool deep_planes16_ok (const DeepPlanesParams &d)
 {
-  if ((d.in_kind != UNPACK_PLANAR && d.in_kind != UNPACK_SEMI) || (d.out_kind != UNPACK_PLANAR && d.out_kind != UNPACK_SEMI) || (d.in_hi != 0) == (d.out_hi != 0) || d.w_sub > 1)
+  if ((d.in_kind != UNPACK_PLANAR && d.in_kind != UNPACK_SEMI) || (d.out_kind != UNPACK_PLANAR && d.out_kind != UNPACK_SEMI) || (d.in_hi == 0 && d.out_hi == 0) || d.w_sub > 1)
     return false;
+  const auto le_deep = [](int hi) { return hi == 1 || hi == 2 || hi == 4 || hi == 5 || hi == 6; };
+  if (d.in_hi && d.out_hi) {            /* deep -> deep (P010 -> I420_10LE: a 10-bit decoder's frames for a 10-bit three-plane encoder; deep_planes16_dd_body) */
+    if (!le_deep (d.in_hi) || !le_deep (d.out_hi))
+      return false;
+    const int cwd = (d.width + (1 << d.w_sub) - 1) >> d.w_sub;
+    const bool mixed = d.in_kind != d.out_kind;
+    if ((d.width % 16) != 0 || (mixed && d.w_sub != 1) || (((mixed || d.in_kind == UNPACK_SEMI) ? 2 * cwd : cwd) % 16) != 0)
+      return false;
+    if (!mixed && d.in_kind == UNPACK_SEMI && (d.in_u != d.out_u || d.w_sub != 1))
+      return false;
+    if (d.dither.on && (d.dither.shift[1] != d.dither.shift[2] || d.dither.shift[1] != d.dither.shift[3] || d.dither.shift[1] > 8 || d.dither.shift[1] < 0))
+      return false;
+    return true;
+  }
   /* the other plane layout on the way down to 8 bits (P010 -> I420 / YV12, I420_10LE -> NV12 / NV21: a decoder's frames for an 8-bit encoder): the chroma rows
      are taken apart / put together with byte permutations (deep_planes16_body "mixed") */
   if (d.in_kind != d.out_kind && (d.in_hi == 0 || d.w_sub != 1))
@@ -1517,10 +1531,149 @@ GSTAMD_HD uint4 deep_narrow16 (int in_hi, const uint4 &a, const uint4 &b)
   return o;
 }
 
+// the sixteen dither values of row y as the eight pairs a lane's sample pairs meet: mode 0 - sample j at column j; 1 - U and V of chroma position k (samples
+// 2 k, 2 k + 1) at column 2 k; 2 - chroma sample j at column 2 j (mod 16)
+struct DeepPairs8 { uint32_t v[8]; };
+GSTAMD_HD DeepPairs8 deep_dither_pairs16 (const DeepPlanesParams &d, int mode, int y)
+{
+  DeepPairs8 r;
+  uint32_t *e = r.v;
+  const int sh = d.dither.on ? d.dither.shift[1] : 0;
+  if (d.dither.on && sh > 0) {
+    const uint2 lo = dither_bayer_row8 (0, y), hi = dither_bayer_row8 (8, y);
+    uint32_t eb[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      eb[i] = (eb[i] >> (8 - sh)) & ((0xffu >> (8 - sh)) * 0x01010101u);
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+      if (mode == 0)
+        e[p] = bperm (0u, eb[p / 2], (p & 1) ? 0x0c030c02u : 0x0c010c00u);
+      else if (mode == 1)
+        e[p] = bperm (0u, eb[p / 2], (p & 1) ? 0x0c020c02u : 0x0c000c00u);
+      else
+        e[p] = bperm (0u, eb[p & 3], 0x0c020c00u);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+      e[p] = 0;
+  }
+  return r;
+}
+
+// what deep_planes16_dd_body does to a pair of stored words: widen, dither, mask, pack
+struct DeepFin {
+  int wsh, wbits, drop, low;
+  uint32_t m1, m2, keep, lowm;
+};
+GSTAMD_HD uint32_t deep_fin (const DeepFin &f, uint32_t v, uint32_t e)
+{
+  const uint32_t t = (v << f.wsh) & f.m1;
+  uint32_t q = pk_adds16 (t | ((t >> f.wbits) & f.m2), e) & f.keep;
+  if (f.low)
+    q = (q >> f.drop) & f.lowm;
+  return q;
+}
+
+// deep -> deep, sixteen samples a lane: widen the stored words to 16 bits (deep_widen on both halves of a word), ordered dither of the destination's depth
+// (saturating add, mask), the packer's mask or shift - gst_video_dither_line on 16-bit lines between unpack_P010_10LE & co and pack_I420_10LE & co.  The
+// other plane layout (P010 -> I420_10LE, I420_10LE -> P010): a lane of a chroma row works on the interleaved pairs / on eight words of each plane and
+// sorts the halves with byte permutations.
+GSTAMD_HD void deep_planes16_dd_body (const DeepPlanesParams &d, const DeepPlanesPtrs &pp, int lane, int row, long long ds, long long dd)
+{
+  const int ch = (d.height + (1 << d.h_sub) - 1) >> d.h_sub, cw = (d.width + (1 << d.w_sub) - 1) >> d.w_sub;
+  /* (the planes as scalars before anything chooses between them: a choice between two members of the argument struct is a choice between two ADDRESSES to
+     the compiler, and the struct moves to scratch memory for it) */
+  const uint8_t *const in0 = pp.in[0], *const in1 = pp.in[1], *const in2 = pp.in[2];
+  uint8_t *const out0 = pp.out[0], *const out1 = pp.out[1], *const out2 = pp.out[2];
+  const int is0 = pp.in_stride[0], is1 = pp.in_stride[1], is2 = pp.in_stride[2], os0 = pp.out_stride[0], os1 = pp.out_stride[1], os2 = pp.out_stride[2];
+  const Widen wdn = deep_widen_params (d.in_hi);
+  const int sh = d.dither.on ? d.dither.shift[1] : 0;
+  DeepFin F;
+  F.wsh = wdn.sh, F.wbits = wdn.bits;
+  F.m1 = ((0xffffu << wdn.sh) & 0xffffu) * 0x10001u, F.m2 = (0xffffu >> wdn.bits) * 0x10001u;
+  F.drop = d.out_hi == 6 ? 0 : 16 - hi_depth_bits (d.out_hi);
+  F.low = d.out_hi == 1 || d.out_hi == 4;
+  F.keep = ((0xffffu & ~((1u << sh) - 1u)) * 0x00010001u) & (F.low ? 0xffffffffu : (0xffffu & ~((1u << F.drop) - 1u)) * 0x00010001u);
+  F.lowm = (0xffffu >> F.drop) * 0x00010001u;
+#define fin(v, e) deep_fin (F, (v), (e))
+  const int s0 = 16 * lane;
+  if (row < d.height || d.in_kind == d.out_kind) {
+    int r = row, n = d.width, mode = 0, y = row;
+    const uint8_t *sb = in0;          /* (two-way choices only, made where the row's kind is known: a chain of three became a table in scratch memory) */
+    uint8_t *db = out0;
+    int sst = is0, dst_ = os0;
+    if (row >= d.height) {
+      r = row - d.height;
+      if (d.in_kind == UNPACK_SEMI) {
+        sb = in1, db = out1, sst = is1, dst_ = os1, n = 2 * cw, mode = 1;
+      } else {
+        const int second = r >= ch ? 1 : 0;
+        r -= second * ch;
+        const bool i1 = (second ? d.in_v : d.in_u) == 1, o1 = (second ? d.out_v : d.out_u) == 1;
+        sb = i1 ? in1 : in2, sst = i1 ? is1 : is2;
+        db = o1 ? out1 : out2, dst_ = o1 ? os1 : os2;
+        n = cw, mode = d.w_sub ? 2 : 0;
+      }
+      if (r >= ch)
+        return;
+      y = r << d.h_sub;
+    }
+    if (s0 >= n)
+      return;
+    const uint8_t *src = sb + ds + (size_t) r * sst;
+    uint8_t *dst = db + dd + (size_t) r * dst_;
+    const DeepPairs8 E = deep_dither_pairs16 (d, mode, y);
+    const uint4 a = *(const uint4 *) (src + 2 * (size_t) s0), b = *(const uint4 *) (src + 2 * (size_t) s0 + 16);
+    uint4 *dq = (uint4 *) (dst + 2 * (size_t) s0);
+    dq[0] = gstamd_make_uint4 (fin (a.x, E.v[0]), fin (a.y, E.v[1]), fin (a.z, E.v[2]), fin (a.w, E.v[3]));
+    dq[1] = gstamd_make_uint4 (fin (b.x, E.v[4]), fin (b.y, E.v[5]), fin (b.z, E.v[6]), fin (b.w, E.v[7]));
+    return;
+  }
+  /* mixed layouts, a chroma row: the lane's eight chroma positions */
+  const int r = row - d.height;
+  if (r >= ch || s0 >= 2 * cw)
+    return;
+  const int y = r << d.h_sub;
+  if (d.in_kind == UNPACK_SEMI) {
+    const DeepPairs8 E = deep_dither_pairs16 (d, 1, y);
+    const uint8_t *src = in1 + ds + (size_t) r * is1 + 2 * (size_t) s0;
+    const uint4 a = *(const uint4 *) src, b = *(const uint4 *) (src + 16);
+    const uint32_t q0 = fin (a.x, E.v[0]), q1 = fin (a.y, E.v[1]), q2 = fin (a.z, E.v[2]), q3 = fin (a.w, E.v[3]), q4 = fin (b.x, E.v[4]), q5 = fin (b.y, E.v[5]),
+        q6 = fin (b.z, E.v[6]), q7 = fin (b.w, E.v[7]);
+    const uint4 first = gstamd_make_uint4 (bperm (q1, q0, 0x05040100u), bperm (q3, q2, 0x05040100u), bperm (q5, q4, 0x05040100u), bperm (q7, q6, 0x05040100u));
+    const uint4 second = gstamd_make_uint4 (bperm (q1, q0, 0x07060302u), bperm (q3, q2, 0x07060302u), bperm (q5, q4, 0x07060302u), bperm (q7, q6, 0x07060302u));
+    const bool u1 = d.out_u == 1;
+    uint8_t *du = (u1 ? out1 : out2) + dd + (size_t) r * (u1 ? os1 : os2) + s0;
+    uint8_t *dv = (u1 ? out2 : out1) + dd + (size_t) r * (u1 ? os2 : os1) + s0;
+    *(uint4 *) (d.in_u ? du : dv) = first;          /* (semi-planar: in_u is the U-first flag; the choice between the POINTERS - between the values it is a table in scratch) */
+    *(uint4 *) (d.in_u ? dv : du) = second;
+  } else {
+    const DeepPairs8 E = deep_dither_pairs16 (d, 2, y);
+    const bool u1 = d.in_u == 1;
+    const uint8_t *su = (u1 ? in1 : in2) + ds + (size_t) r * (u1 ? is1 : is2) + s0;
+    const uint8_t *sv = (u1 ? in2 : in1) + ds + (size_t) r * (u1 ? is2 : is1) + s0;
+    const uint4 a = *(const uint4 *) su, b = *(const uint4 *) sv;
+    const bool uf = d.out_u != 0;          /* (semi-planar: out_u is the U-first flag) */
+    const uint32_t f0 = fin (uf ? a.x : b.x, E.v[0]), f1 = fin (uf ? a.y : b.y, E.v[1]), f2 = fin (uf ? a.z : b.z, E.v[2]), f3 = fin (uf ? a.w : b.w, E.v[3]);
+    const uint32_t g0 = fin (uf ? b.x : a.x, E.v[0]), g1 = fin (uf ? b.y : a.y, E.v[1]), g2 = fin (uf ? b.z : a.z, E.v[2]), g3 = fin (uf ? b.w : a.w, E.v[3]);
+    uint4 *dq = (uint4 *) (out1 + dd + (size_t) r * os1 + 2 * (size_t) s0);
+    dq[0] = gstamd_make_uint4 (bperm (g0, f0, 0x05040100u), bperm (g0, f0, 0x07060302u), bperm (g1, f1, 0x05040100u), bperm (g1, f1, 0x07060302u));
+    dq[1] = gstamd_make_uint4 (bperm (g2, f2, 0x05040100u), bperm (g2, f2, 0x07060302u), bperm (g3, f3, 0x05040100u), bperm (g3, f3, 0x07060302u));
+  }
+#undef fin
+}
+
 // lane: samples 16 * lane .. + 15 of plane row `row` (luma rows, then the chroma rows: of the interleaved plane, or of U and then of V)
+// TO_HI: 0 deep -> 8 bits, 1 8 bits -> deep, 2 deep -> deep (deep_planes16_dd_body)
 template <int TO_HI>
 GSTAMD_HD void deep_planes16_body (const DeepPlanesParams &d, const DeepPlanesPtrs &pp, int lane, int row, long long ds = 0, long long dd = 0)
 {
+  if (TO_HI == 2) {
+    deep_planes16_dd_body (d, pp, lane, row, ds, dd);
+    return;
+  }
   const int ch = (d.height + (1 << d.h_sub) - 1) >> d.h_sub, cw = (d.width + (1 << d.w_sub) - 1) >> d.w_sub;
   int ip = 0, op = 0, r = row, n = d.width, mode = 0, y = row;
   if (!TO_HI && row >= d.height && d.in_kind != d.out_kind) {
@@ -1531,19 +1684,23 @@ GSTAMD_HD void deep_planes16_body (const DeepPlanesParams &d, const DeepPlanesPt
       return;
     if (d.in_kind == UNPACK_SEMI) {
       const uint8_t *src = pp.in[1] + ds + (size_t) r * pp.in_stride[1];
+      uint8_t *const out1 = pp.out[1], *const out2 = pp.out[2];         /* (scalars before the choice: deep_planes16_dd_body) */
+      const int os1 = pp.out_stride[1], os2 = pp.out_stride[2];
       const uint4 o = deep_narrow16 (d.in_hi, *(const uint4 *) (src + 2 * (size_t) s0), *(const uint4 *) (src + 2 * (size_t) s0 + 16));
       uint2 first, second;          /* the pairs' first and second samples */
       first.x = bperm (o.y, o.x, 0x06040200u), first.y = bperm (o.w, o.z, 0x06040200u);
       second.x = bperm (o.y, o.x, 0x07050301u), second.y = bperm (o.w, o.z, 0x07050301u);
       const bool u1 = d.out_u == 1;
-      uint8_t *du = (u1 ? pp.out[1] : pp.out[2]) + dd + (size_t) r * (u1 ? pp.out_stride[1] : pp.out_stride[2]) + s0 / 2;
-      uint8_t *dv = (u1 ? pp.out[2] : pp.out[1]) + dd + (size_t) r * (u1 ? pp.out_stride[2] : pp.out_stride[1]) + s0 / 2;
+      uint8_t *du = (u1 ? out1 : out2) + dd + (size_t) r * (u1 ? os1 : os2) + s0 / 2;
+      uint8_t *dv = (u1 ? out2 : out1) + dd + (size_t) r * (u1 ? os2 : os1) + s0 / 2;
       *(uint2 *) du = d.in_u ? first : second;          /* (semi-planar: in_u is the U-first flag) */
       *(uint2 *) dv = d.in_u ? second : first;
     } else {
       const bool u1 = d.in_u == 1;
-      const uint8_t *su = (u1 ? pp.in[1] : pp.in[2]) + ds + (size_t) r * (u1 ? pp.in_stride[1] : pp.in_stride[2]) + s0;
-      const uint8_t *sv = (u1 ? pp.in[2] : pp.in[1]) + ds + (size_t) r * (u1 ? pp.in_stride[2] : pp.in_stride[1]) + s0;
+      const uint8_t *const in1 = pp.in[1], *const in2 = pp.in[2];
+      const int is1 = pp.in_stride[1], is2 = pp.in_stride[2];
+      const uint8_t *su = (u1 ? in1 : in2) + ds + (size_t) r * (u1 ? is1 : is2) + s0;
+      const uint8_t *sv = (u1 ? in2 : in1) + ds + (size_t) r * (u1 ? is2 : is1) + s0;
       const uint4 z = gstamd_make_uint4 (0, 0, 0, 0);
       const uint4 nu = deep_narrow16 (d.in_hi, *(const uint4 *) su, z), nv = deep_narrow16 (d.in_hi, *(const uint4 *) sv, z);          /* eight bytes each: .x .y */
       const uint32_t fx = d.out_u ? nu.x : nv.x, fy = d.out_u ? nu.y : nv.y, gx = d.out_u ? nv.x : nu.x, gy = d.out_u ? nv.y : nu.y;

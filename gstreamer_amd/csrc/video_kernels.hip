@@ -374,7 +374,9 @@ hipError_t launch_deep_planes (const DeepPlanesParams &d, const DeepPlanesPtrs &
   const FrameDeltas &fl = frame_list_for (pp.in[0], pp.out[0], &nz);
   if (pp.vec && deep_planes16_ok (d) && !tuning_on ("GSTAMD_NO_DEEP_PLANES16")) {
     const dim3 grid16 ((d.width / 16 + 63) / 64, deep_planes16_rows (d), nz);
-    if (d.out_hi)
+    if (d.in_hi && d.out_hi)
+      hipLaunchKernelGGL (k_deep_planes16<2>, grid16, dim3 (64), 0, stream, d, pp, fl);
+    else if (d.out_hi)
       hipLaunchKernelGGL (k_deep_planes16<1>, grid16, dim3 (64), 0, stream, d, pp, fl);
     else
       hipLaunchKernelGGL (k_deep_planes16<0>, grid16, dim3 (64), 0, stream, d, pp, fl);

@@ -12,6 +12,10 @@ LAN, CUB, L4 = dict(resampler_method="lanczos"), dict(resampler_method="cubic"),
 if len(sys.argv) > 1 and sys.argv[1] == "ntap":
     CASES = [("NV12", 3840, 2160, "I420", 1920, 1080, LAN), ("NV12", 3840, 2160, "I420", 1920, 1080, CUB), ("NV12", 3840, 2160, "I420", 1920, 1080, L4), ("NV12", 1920, 1080, "I420", 1280, 720, LAN),
              ("NV12", 3840, 2160, "BGRA", 1920, 1080, LAN), ("NV12", 3840, 2160, "NV12", 1920, 1080, LAN), ("I420", 3840, 2160, "NV12", 1280, 720, CUB), ("NV12", 1920, 1080, "I420", 3840, 2160, BIL)]
+if len(sys.argv) > 1 and sys.argv[1] == "deep":
+    CASES = [("P010_10LE", 3840, 2160, "I420_10LE", 3840, 2160, {}), ("I420_10LE", 3840, 2160, "P010_10LE", 3840, 2160, {}), ("NV12", 3840, 2160, "I420_10LE", 3840, 2160, {}),
+             ("NV12", 3840, 2160, "P010_10LE", 3840, 2160, {}), ("I420", 3840, 2160, "P010_10LE", 3840, 2160, {}), ("P010_10LE", 3840, 2160, "P016_LE", 3840, 2160, {}),
+             ("P010_10LE", 3840, 2160, "NV12", 3840, 2160, {}), ("I420_10LE", 3840, 2160, "I420", 3840, 2160, {}), ("P010_10LE", 1920, 1080, "I420_10LE", 1920, 1080, {})]
 dev = torch.device("cuda:0")
 for ifmt, w, h, ofmt, ow, oh, cfg in CASES:
     ii, oi = V.video_info(ifmt, w, h), V.video_info(ofmt, ow, oh)

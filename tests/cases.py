@@ -1968,3 +1968,17 @@ VIDEO_CASES += [
     ("planes16_mixed_p010_i420_1080p", "P010_10LE", 1920, 1080, "I420", 1920, 1080, {}, None, None, "random"),
     ("planes16_mixed_p010_i420_row_not_16", "P010_10LE", 48, 18, "I420", 40, 18, dict(src_width=40), None, None, "random"),
 ]
+
+# round 6: k_deep_planes16 deep -> deep (deep_planes16_dd_body): widen, ordered dither of the destination's depth, pack - also across plane layouts
+VIDEO_CASES += [
+    ("planes16_dd_p010_i42010", "P010_10LE", 160, 34, "I420_10LE", 160, 34, {}, None, None, "random"),
+    ("planes16_dd_i42010_p010", "I420_10LE", 160, 34, "P010_10LE", 160, 34, {}, None, "jpeg", "random"),
+    ("planes16_dd_p016_p010", "P016_LE", 64, 32, "P010_10LE", 64, 32, {}, None, None, "random"),
+    ("planes16_dd_p010_p016", "P010_10LE", 64, 32, "P016_LE", 64, 32, {}, None, None, "random"),
+    ("planes16_dd_i42012_p012", "I420_12LE", 64, 32, "P012_LE", 64, 32, {}, None, None, "random"),
+    ("planes16_dd_p012_i42010", "P012_LE", 96, 20, "I420_10LE", 96, 20, {}, None, None, "random"),
+    ("planes16_dd_i42210_i42212", "I422_10LE", 64, 20, "I422_12LE", 64, 20, {}, None, None, "random"),
+    ("planes16_dd_p016_i42010_bayer_q4", "P016_LE", 64, 32, "I420_10LE", 64, 32, dict(dither_method="bayer", dither_quantization=4), None, None, "random"),
+    ("planes16_dd_p010_i42010_1080p", "P010_10LE", 1920, 1080, "I420_10LE", 1920, 1080, {}, None, None, "random"),
+    ("planes16_dd_i42010_i42012_row_not_16", "I420_10LE", 48, 18, "I420_12LE", 48, 18, {}, None, None, "random"),
+]

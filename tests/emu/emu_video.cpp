@@ -969,7 +969,9 @@ extern "C" int emu_video_convert (const GstAmdVideoInfo *in, const GstAmdVideoIn
         g_emu_deep16_runs++;
         for (int row = 0; row < deep_planes16_rows (g.planes); row++)
           for (int lx = 0; lx < (g.planes.width / 16 + 63) / 64 * 64; lx++) {
-            if (g.planes.out_hi)
+            if (g.planes.in_hi && g.planes.out_hi)
+              deep_planes16_body<2> (g.planes, pp, lx, row);
+            else if (g.planes.out_hi)
               deep_planes16_body<1> (g.planes, pp, lx, row);
             else
               deep_planes16_body<0> (g.planes, pp, lx, row);

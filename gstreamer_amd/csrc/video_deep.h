@@ -1484,13 +1484,13 @@ GSTAMD_VP bool deep_planes16_ok (const DeepPlanesParams &d)
   }
   /* the other plane layout on the way down to 8 bits (P010 -> I420 / YV12, I420_10LE -> NV12 / NV21: a decoder's frames for an 8-bit encoder): the chroma rows
      are taken apart / put together with byte permutations (deep_planes16_body "mixed") */
-  if (d.in_kind != d.out_kind && (d.in_hi == 0 || d.w_sub != 1))
+  if (d.in_kind != d.out_kind && d.w_sub != 1)
     return false;
   const int deep = d.in_hi ? d.in_hi : d.out_hi;
   if (deep != 1 && deep != 2 && deep != 4 && deep != 5 && deep != 6)
     return false;
   const int cw = (d.width + (1 << d.w_sub) - 1) >> d.w_sub;
-  if ((d.width % 16) != 0 || ((d.in_kind == UNPACK_SEMI ? 2 * cw : cw) % 16) != 0)
+  if ((d.width % 16) != 0 || ((d.in_kind == UNPACK_SEMI || d.out_kind == UNPACK_SEMI ? 2 * cw : cw) % 16) != 0)
     return false;
   if (d.in_kind == UNPACK_SEMI && d.out_kind == UNPACK_SEMI && (d.in_u != d.out_u || d.w_sub != 1))
     return false;
@@ -1708,6 +1708,51 @@ GSTAMD_HD void deep_planes16_body (const DeepPlanesParams &d, const DeepPlanesPt
       o.x = bperm (gx, fx, 0x05010400u), o.y = bperm (gx, fx, 0x07030602u), o.z = bperm (gy, fy, 0x05010400u), o.w = bperm (gy, fy, 0x07030602u);
       *(uint4 *) (pp.out[1] + dd + (size_t) r * pp.out_stride[1] + s0) = o;
     }
+    return;
+  }
+  if (TO_HI == 1 && row >= d.height && d.in_kind != d.out_kind) {
+    /* 8 bits -> deep across plane layouts (NV12 -> I420_10LE, I420 -> P010): a chroma row, the lane's eight chroma positions */
+    r = row - d.height;
+    const int s0 = 16 * lane;
+    if (r >= ch || s0 >= 2 * cw)
+      return;
+    const int sh = d.dither.on ? d.dither.shift[1] : 0;
+    DeepFin F;
+    F.wsh = 0, F.wbits = 0, F.m1 = 0xffffffffu, F.m2 = 0;
+    F.drop = d.out_hi == 6 ? 0 : 16 - hi_depth_bits (d.out_hi);
+    F.low = d.out_hi == 1 || d.out_hi == 4;
+    F.keep = ((0xffffu & ~((1u << sh) - 1u)) * 0x00010001u) & (F.low ? 0xffffffffu : (0xffffu & ~((1u << F.drop) - 1u)) * 0x00010001u);
+    F.lowm = (0xffffu >> F.drop) * 0x00010001u;
+    const uint8_t *const in1 = pp.in[1], *const in2 = pp.in[2];
+    uint8_t *const out1 = pp.out[1], *const out2 = pp.out[2];
+    const int is1 = pp.in_stride[1], is2 = pp.in_stride[2], os1 = pp.out_stride[1], os2 = pp.out_stride[2];
+#define B2(w, hi) bperm (0u, (w), (hi) ? 0x03030202u : 0x01010000u)          /* two bytes * 257 */
+    if (d.in_kind == UNPACK_SEMI) {
+      const DeepPairs8 E = deep_dither_pairs16 (d, 1, r << d.h_sub);
+      const uint4 w = *(const uint4 *) (in1 + ds + (size_t) r * is1 + s0);
+      const uint32_t q0 = deep_fin (F, B2 (w.x, 0), E.v[0]), q1 = deep_fin (F, B2 (w.x, 1), E.v[1]), q2 = deep_fin (F, B2 (w.y, 0), E.v[2]), q3 = deep_fin (F, B2 (w.y, 1), E.v[3]),
+          q4 = deep_fin (F, B2 (w.z, 0), E.v[4]), q5 = deep_fin (F, B2 (w.z, 1), E.v[5]), q6 = deep_fin (F, B2 (w.w, 0), E.v[6]), q7 = deep_fin (F, B2 (w.w, 1), E.v[7]);
+      const uint4 first = gstamd_make_uint4 (bperm (q1, q0, 0x05040100u), bperm (q3, q2, 0x05040100u), bperm (q5, q4, 0x05040100u), bperm (q7, q6, 0x05040100u));
+      const uint4 second = gstamd_make_uint4 (bperm (q1, q0, 0x07060302u), bperm (q3, q2, 0x07060302u), bperm (q5, q4, 0x07060302u), bperm (q7, q6, 0x07060302u));
+      const bool u1 = d.out_u == 1;
+      uint8_t *du = (u1 ? out1 : out2) + dd + (size_t) r * (u1 ? os1 : os2) + s0;
+      uint8_t *dv = (u1 ? out2 : out1) + dd + (size_t) r * (u1 ? os2 : os1) + s0;
+      *(uint4 *) (d.in_u ? du : dv) = first;
+      *(uint4 *) (d.in_u ? dv : du) = second;
+    } else {
+      const DeepPairs8 E = deep_dither_pairs16 (d, 2, r << d.h_sub);
+      const bool u1 = d.in_u == 1;
+      const uint2 a = *(const uint2 *) ((u1 ? in1 : in2) + ds + (size_t) r * (u1 ? is1 : is2) + s0 / 2);
+      const uint2 b = *(const uint2 *) ((u1 ? in2 : in1) + ds + (size_t) r * (u1 ? is2 : is1) + s0 / 2);
+      const bool uf = d.out_u != 0;
+      const uint32_t fx = uf ? a.x : b.x, fy = uf ? a.y : b.y, gx = uf ? b.x : a.x, gy = uf ? b.y : a.y;
+      const uint32_t f0 = deep_fin (F, B2 (fx, 0), E.v[0]), f1 = deep_fin (F, B2 (fx, 1), E.v[1]), f2 = deep_fin (F, B2 (fy, 0), E.v[2]), f3 = deep_fin (F, B2 (fy, 1), E.v[3]);
+      const uint32_t g0 = deep_fin (F, B2 (gx, 0), E.v[0]), g1 = deep_fin (F, B2 (gx, 1), E.v[1]), g2 = deep_fin (F, B2 (gy, 0), E.v[2]), g3 = deep_fin (F, B2 (gy, 1), E.v[3]);
+      uint4 *dq = (uint4 *) (out1 + dd + (size_t) r * os1 + 2 * (size_t) s0);
+      dq[0] = gstamd_make_uint4 (bperm (g0, f0, 0x05040100u), bperm (g0, f0, 0x07060302u), bperm (g1, f1, 0x05040100u), bperm (g1, f1, 0x07060302u));
+      dq[1] = gstamd_make_uint4 (bperm (g2, f2, 0x05040100u), bperm (g2, f2, 0x07060302u), bperm (g3, f3, 0x05040100u), bperm (g3, f3, 0x07060302u));
+    }
+#undef B2
     return;
   }
   if (row >= d.height) {

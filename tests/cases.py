@@ -1982,3 +1982,14 @@ VIDEO_CASES += [
     ("planes16_dd_p010_i42010_1080p", "P010_10LE", 1920, 1080, "I420_10LE", 1920, 1080, {}, None, None, "random"),
     ("planes16_dd_i42010_i42012_row_not_16", "I420_10LE", 48, 18, "I420_12LE", 48, 18, {}, None, None, "random"),
 ]
+
+# ... and 8 bits -> deep across plane layouts (NV12 -> I420_10LE: a decoder's 8-bit frames for a 10-bit three-plane encoder)
+VIDEO_CASES += [
+    ("planes16_mixed_up_nv12_i42010", "NV12", 160, 34, "I420_10LE", 160, 34, {}, None, None, "random"),
+    ("planes16_mixed_up_i420_p010", "I420", 160, 34, "P010_10LE", 160, 34, {}, None, "jpeg", "random"),
+    ("planes16_mixed_up_nv21_i42012", "NV21", 64, 32, "I420_12LE", 64, 32, {}, None, None, "random"),
+    ("planes16_mixed_up_yv12_p016", "YV12", 64, 32, "P016_LE", 64, 32, {}, None, None, "random"),
+    ("planes16_mixed_up_nv16_i42210", "NV16", 96, 20, "I422_10LE", 96, 20, {}, None, None, "random"),
+    ("planes16_mixed_up_i420_p010_bayer_q4", "I420", 64, 32, "P010_10LE", 64, 32, dict(dither_method="bayer", dither_quantization=4), None, None, "random"),
+    ("planes16_mixed_up_nv12_i42010_1080p", "NV12", 1920, 1080, "I420_10LE", 1920, 1080, {}, None, None, "random"),
+]

@@ -706,7 +706,53 @@ def secondary_c2(wl, sync):
         except Exception as e:      # a report, never a reason to fail the bench
             rows.append({"case": label, "error": repr(e)[:200]})
     out["element"] = rows
+    try:
+        out["round6_pairs"] = secondary_pairs(sync)
+    except Exception as e:      # a report, never a reason to fail the bench
+        out["round6_pairs"] = {"error": repr(e)[:200]}
     return out
+
+
+def secondary_pairs(sync):
+    """The transcoding pairs round 6 gave kernels of their own (k_deep_scale_pack / _scale4 / _pack16, the A Y U V layout of the bilinear
+    4:2:0 kernels, k_deep_planes16 across layouts and deep -> deep), so that the driver's own run records them: microseconds per 4K source frame with one
+    frame per call and in lists of 8 (HIP events), fraction of the 8 TB/s peak on the plan's algorithmic bytes.  Not part of `value`."""
+    import torch
+    from gstreamer_amd import video as V
+    bil = {"resampler_method": "linear", "max_taps": 2}
+    pairs = [("P010_10LE", "NV12", 1920, 1080, bil), ("P010_10LE", "BGRA", 1920, 1080, bil), ("P010_10LE", "P010_10LE", 1920, 1080, bil), ("NV12", "I420", 1920, 1080, bil),
+             ("P010_10LE", "I420", 3840, 2160, {}), ("P010_10LE", "I420_10LE", 3840, 2160, {}), ("NV12", "I420_10LE", 3840, 2160, {})]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = torch.cuda.current_stream().cuda_stream
+    rows = []
+    for ifmt, ofmt, ow, oh, cfg in pairs:
+        ii, oi = V.video_info(ifmt, 3840, 2160), V.video_info(ofmt, ow, oh)
+        conv = V.VideoConverter(ii, oi, V.converter_config(**cfg))
+        src = torch.randint(0, 255, (8, int(ii.size)), dtype=torch.uint8, device=dev)
+        dst = torch.zeros((8, int(oi.size)), dtype=torch.uint8, device=dev)
+        srcs, dsts = [src[i] for i in range(8)], [dst[i] for i in range(8)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for i in range(8):
+            conv.frame(srcs[i], dsts[i], st)
+        conv.frames(srcs, dsts, st)
+        sync()
+        ev[0].record()
+        for i in range(80):
+            conv.frame(srcs[i % 8], dsts[i % 8], st)
+        ev[1].record()
+        ev[2].record()
+        for i in range(20):
+            conv.frames(srcs, dsts, st)
+        ev[3].record()
+        sync()
+        one, lst = ev[0].elapsed_time(ev[1]) * 1e3 / 80, ev[2].elapsed_time(ev[3]) * 1e3 / 160
+        alg = conv.algorithmic_bytes()
+        rows.append({"pair": "%s 3840x2160 -> %s %dx%d%s" % (ifmt, ofmt, ow, oh, " bilinear" if cfg else ""), "plan": conv.describe()[:90],
+                     "us_per_frame_single": round(one, 2), "frac_single": round(alg / (one * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
+                     "us_per_frame_lists_of_8": round(lst, 2), "frac_lists": round(alg / (lst * 1e-6) / 1e9 / HBM_PEAK_GBS, 3), "list_launches": conv.list_launches()})
+        conv.free()
+        del src, dst, srcs, dsts
+    return rows
 
 
 def spawn_ranks(args):

@@ -15,6 +15,7 @@
 #include "video_deep.h"
 #include "video_pack.h"
 #include "video_dither_ed.h"
+#include "video_gamma.h"
 
 namespace gstamd {
 
@@ -25,6 +26,8 @@ struct DeepPackParams {
   ScaleDev sh, sv;      // horizontal pass (runs first), vertical pass
   int out_w, out_h;     // size after both passes
   int hx2;              // both passes 2-tap, sh.offset[x] == 2 x for every x, taps 0 .. 4096, f.width >= 2 out_w
+  Deep16Params mx;      // the convert stage on the scaled 16-bit pixels (video_converter_matrix16: other colorimetry on the two sides - a bt2020 decoder's frames
+                        // for a bt709 encoder), ahead of the narrowing / the 16-bit pack; has_matrix 0: none.  (k_deep_scale4's is its own argument.)
 };
 
 // one component through the horizontal 2-tap (video_orc_resample_h_2tap_u16) and the vertical one (video_scale_v_2tap_u16): deep_scale_px's lines
@@ -258,6 +261,17 @@ struct DeepScaledSrc {
   // the block's pixels of destination line y, narrowed (video_orc_convert_u16_to_u8): A Y U V bytes
   GSTAMD_HD uint4 core4 (int x0, int y) const
   {
+    if (d.mx.has_matrix) {              /* (wave-uniform) the 16-bit pixels through the convert stage, then the high bytes */
+      uint2 p16[4];
+      core4_16 (x0, y, p16);
+      uint4 r;
+      uint32_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        o[i] = 0xffu | ((p16[i].x >> 24) << 8) | (((p16[i].y >> 8) & 0xffu) << 16) | ((p16[i].y >> 24) << 24);
+      r.x = o[0], r.y = o[1], r.z = o[2], r.w = o[3];
+      return r;
+    }
     DeepHLine a, b;
     const uint32_t vt = lines2 (x0, y, &a, &b);
     const bool usw = c1_is_u ();
@@ -283,6 +297,7 @@ struct DeepScaledSrc {
       const uint32_t v1 = deep_v16 (a.c1[i], b.c1[i], vt), v2 = deep_v16 (a.c2[i], b.c2[i], vt);
       px[i].x = deep_v16 (a.al[i], b.al[i], vt) | (deep_v16 (a.y[i], b.y[i], vt) << 16);
       px[i].y = (usw ? v1 : v2) | ((usw ? v2 : v1) << 16);
+      px[i] = gamma_matrix16 (d.mx, px[i]);         /* (has_matrix 0: as it is) */
     }
   }
 
@@ -479,7 +494,7 @@ inline bool deep_scale4_plan_ok (const VideoPlan &p, DeepPackParams *dp)
 inline bool deep_scale_pack16_plan_ok (const VideoPlan &p, DeepPackParams *dp)
 {
   const GammaPlan &g = p.gamma;
-  if (!g.on || !g.src16 || !g.pack16 || g.store64 || g.planes_fast || g.fused || !g.shrink || !g.dec16.empty () || !g.enc16.empty () || g.prim.has_matrix ||
+  if (!g.on || !g.src16 || !g.pack16 || g.store64 || g.planes_fast || g.fused || !g.shrink || !g.dec16.empty () || !g.enc16.empty () ||
       g.alpha_kind != ALPHA_NONE || p.interlaced || p.field || !deep_passes_halve (p) || dither_is_diffusion (g.dither16) ||
       (g.pack.kind != UNPACK_PLANAR && g.pack.kind != UNPACK_SEMI) || g.pack.frame_on || g.pack.tail_swap)
     return false;
@@ -492,6 +507,7 @@ inline bool deep_scale_pack16_plan_ok (const VideoPlan &p, DeepPackParams *dp)
   dp->sh.kind = p.passes[0].kind, dp->sh.n_taps = p.passes[0].n_taps, dp->sh.inc = p.passes[0].inc;
   dp->sv.kind = p.passes[1].kind, dp->sv.n_taps = p.passes[1].n_taps, dp->sv.inc = p.passes[1].inc;
   dp->hx2 = 1;
+  dp->mx = g.prim;
   return true;
 }
 
@@ -500,7 +516,7 @@ inline bool deep_scale_pack16_plan_ok (const VideoPlan &p, DeepPackParams *dp)
 inline bool deep_scale_pack_plan_ok (const VideoPlan &p, const VideoPlan &sub, DeepPackParams *dp)
 {
   const GammaPlan &g = p.gamma;
-  if (!g.on || !g.src16 || g.planes_fast || g.fused || g.pack16 || g.store64 || !g.shrink || !g.dec16.empty () || !g.enc16.empty () || g.prim.has_matrix ||
+  if (!g.on || !g.src16 || g.planes_fast || g.fused || g.pack16 || g.store64 || !g.shrink || !g.dec16.empty () || !g.enc16.empty () ||
       g.alpha_kind != ALPHA_NONE || g.to_yuv.kind != MATRIX_NONE || p.interlaced || p.field)
     return false;
   if (p.passes.size () != 2 || !p.passes[0].horizontal || p.passes[1].horizontal || deep_front4_variant (p.front) < 0)
@@ -525,6 +541,7 @@ inline bool deep_scale_pack_plan_ok (const VideoPlan &p, const VideoPlan &sub, D
   dp->sv.kind = p.passes[1].kind, dp->sv.n_taps = p.passes[1].n_taps, dp->sv.inc = p.passes[1].inc;
   const bool hx2 = deep_passes_halve (p);
   dp->hx2 = hx2;
+  dp->mx = g.prim;
   /* whole blocks only (a per-pixel form of the same chain was tried as the path of every other shape: as a whole frame's path it loses to the
      multi-launch composite - P010 4K -> NV12 1080p 4-tap 547 us against 85) */
   return hx2 && (ow % 4) == 0 && (sub.pack.kind == UNPACK_PLANAR || sub.pack.kind == UNPACK_SEMI) && !sub.pack.tail_swap;

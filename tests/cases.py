@@ -1993,3 +1993,13 @@ VIDEO_CASES += [
     ("planes16_mixed_up_i420_p010_bayer_q4", "I420", 64, 32, "P010_10LE", 64, 32, dict(dither_method="bayer", dither_quantization=4), None, None, "random"),
     ("planes16_mixed_up_nv12_i42010_1080p", "NV12", 1920, 1080, "I420_10LE", 1920, 1080, {}, None, None, "random"),
 ]
+
+# ... with the convert stage on 16-bit values between the scalers and the narrowing / the 16-bit pack (other colorimetry on the two sides: a bt2020 decoder's
+# frames for a bt709 encoder - what caps without a colorimetry field mean at 2160 -> 1080 lines on newer GStreamer versions)
+VIDEO_CASES += [
+    ("dspm_p010_nv12_bt2020_bt709", "P010_10LE", 512, 1160, "NV12", 256, 580, BIL2, "bt2020>bt709", None, "random"),
+    ("dspm_i42010_i420_bt709_bt601", "I420_10LE", 128, 64, "I420", 64, 32, BIL2, "bt709>bt601", "jpeg", "random"),
+    ("dspm_p010_p010_bt2020_bt709", "P010_10LE", 504, 1160, "P010_10LE", 252, 580, BIL2, "bt2020>bt709", None, "random"),
+    ("dspm_p010_i42010_bt601_bt2020", "P010_10LE", 128, 64, "I420_10LE", 64, 32, BIL2, "bt601>bt2020", None, "random"),
+    ("dspm_p016_y42b_bt2020_bt709", "P016_LE", 128, 64, "Y42B", 64, 32, BIL2, "bt2020>bt709", None, "random"),
+]

@@ -661,7 +661,7 @@ def test_deep_plane_copies_without_border_fill_on_host(native_lib, emu_lib, ref,
     assert not dst[:cfg["dest_y"] * stride].any()
 
 
-@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("dsp_") or c[0].startswith("dsp4_") or c[0].startswith("dsp16_")])
+@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("dsp_") or c[0].startswith("dsp4_") or c[0].startswith("dsp16_") or c[0].startswith("dspm_")])
 def test_deep_scale_pack_body_is_the_one_that_runs(native_lib, emu_lib, name, monkeypatch):
     """the dsp_* cases (a 10-bit planar / semi-planar source that halves into an 8-bit planar / semi-planar destination) go through
     k_deep_scale_pack's lane function (video_deep_pack.h: front, both u16 passes, narrowing and pack per block), the dsp4_* ones (a 4-byte

@@ -1497,7 +1497,8 @@ static bool bilinear420_params (GstAmdVideoConverter *c, BilParams *out)
   if (bp.tile_w <= 0 || bp.ylen <= 0)
     return false;
   bp.fp = make_fast_params (p);
-  bp.fp.ayuv = ayuv ? 1 : 0;
+  bp.fp.ayuv = ayuv ? (p.matrix.kind == MATRIX_NONE ? 1 : 2) : 0;
+  bp.fp.m8 = p.matrix;
   bp.out_w = out_w;
   bp.out_h = out_h;
   bp.inc = p.passes[0].inc;

@@ -693,7 +693,8 @@ GSTAMD_VP VPairW vpair_get (const int *vpair, int y, int mode)
 // operation, unpack order = pack order) - the bilinear 4:2:0 kernels serve it with the layout that stores A Y U V (video_fast.h GSTAMD_LAYOUT_AYUV)
 inline bool bilinear420_ayuv_plan (const VideoPlan &p)
 {
-  if (p.passes.empty () || p.matrix_before_scale || p.matrix.kind != MATRIX_NONE || p.post.alpha_kind != ALPHA_NONE || p.front.hi_depth != 0 || p.gamma.on || p.deep16 ||
+  /* (or with the 8-bit convert stage of two YUV colorimetries behind the scaler: FastParams::m8) */
+  if (p.passes.empty () || p.matrix_before_scale || (p.matrix.kind != MATRIX_NONE && p.matrix.kind != MATRIX_8 && p.matrix.kind != MATRIX_TABLE) || p.post.alpha_kind != ALPHA_NONE || p.front.hi_depth != 0 || p.gamma.on || p.deep16 ||
       p.plane_mode || p.interlaced || p.field)
     return false;
   for (int i = 0; i < 4; i++)

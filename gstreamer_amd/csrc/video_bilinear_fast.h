@@ -291,7 +291,7 @@ template <int L>
 GSTAMD_HD uint32_t fast_pixel1_l (const FastParams &fp, uint32_t y8, uint32_t uv, uint32_t (&q)[2])
 {
   if (L & GSTAMD_LAYOUT_AYUV)
-    return 0xffu | ((y8 & 0xffu) << 8) | ((uv & 0xffu) << 16) | ((uv & 0x00ff0000u) << 8);
+    return GSTAMD_AYUV_OUT (fp, 0xffu | ((y8 & 0xffu) << 8) | ((uv & 0xffu) << 16) | ((uv & 0x00ff0000u) << 8));
   constexpr int PR = L & 3, PG = (L >> 2) & 3, PB = (L >> 4) & 3;
   const uint32_t ys = (y8 ^ 0x80u) * 0x0101u;                         // word 0 = splatbw (y - 128)
   const uint32_t cx = uv ^ 0x00800080u, cs = bperm (cx, cx, 0x02020000u);      // words [t(U) | t(V)]

@@ -88,7 +88,7 @@ template <int L>
 GSTAMD_HD uint32_t bilh_pixel (const FastParams &fp, uint32_t ys, uint32_t cs, uint32_t (&q)[2])
 {
   if (L & GSTAMD_LAYOUT_AYUV)
-    return GSTAMD_AYUV_X80 (ys, cs);
+    return GSTAMD_AYUV_OUT (fp, GSTAMD_AYUV_X80 (ys, cs));
   constexpr int PR = L & 3, PG = (L >> 2) & 3, PB = (L >> 4) & 3;
   const int wy = mul_word<0> (ys, fp.pc[0]) + 0x00800000;
   const int pgu = mul_word<0> (cs, fp.pc[3]), prv = mul_word<1> (cs, fp.pc[1]);

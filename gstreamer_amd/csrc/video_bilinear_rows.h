@@ -307,7 +307,7 @@ template <int L>
 GSTAMD_HD uint32_t fast_pixel1_x80 (const FastParams &fp, uint32_t ys, uint32_t cx, uint32_t (&q)[2])
 {
   if (L & GSTAMD_LAYOUT_AYUV)
-    return GSTAMD_AYUV_X80 (ys, cx);
+    return GSTAMD_AYUV_OUT (fp, GSTAMD_AYUV_X80 (ys, cx));
   constexpr int PR = L & 3, PG = (L >> 2) & 3, PB = (L >> 4) & 3;
   const uint32_t cs = bperm (cx, cx, 0x02020000u);                     // words [t(U) | t(V)]
   const int wy = mul_word<0> (ys, fp.pc[0]) + 0x00800000;

@@ -33,7 +33,8 @@ struct FastParams {
   int px_bytes;         // 4; 3: RGB / BGR destination - the pixel is formed as RGBx / BGRx and its three colour bytes are stored
   const uint8_t *lut;   // NULL, or a 256-byte table in device memory every colour byte of the finished pixel goes through (GammaPlan::lut_direct:
   int lut_keep;         // decode table . encode table); lut_keep: the destination byte that is alpha / filler and stays
-  int ayuv;             // 1: no colour stage - the pixel is A (0xff) Y U V as it comes out of the scaler (the pack image of a planar destination, an AYUV
+  MatrixParams m8;      // ayuv == 2: the 8-bit convert stage behind the scaler (video_converter_matrix8 / _table between two YUV colorimetries: apply_matrix)
+  int ayuv;             // 2: as 1, then m8.  1: no colour stage - the pixel is A (0xff) Y U V as it comes out of the scaler (the pack image of a planar destination, an AYUV
                         // destination): the layout argument GSTAMD_LAYOUT_AYUV of the bilinear 4:2:0 kernels
   int store_policy;     // how the finished pixels leave the CU (store16_policy): 0 streaming (nt: the line stays in the XCD's L2 until evicted or flushed
                         // at the end of the kernel), 1 write-through (sc0 sc1: nothing of the frame is dirty in L2 when the kernel ends)
@@ -73,6 +74,7 @@ inline void fast_params_finish (FastParams &fp, const int p[5], const int pack_p
     fp.pack_pos[i] = pack_pos[i];
   fp.px_bytes = 4;
   fp.ayuv = 0;
+  fp.m8.kind = MATRIX_NONE;
   fp.store_policy = 0;
   fp.lut = nullptr;
   fp.lut_keep = 0;
@@ -344,6 +346,8 @@ GSTAMD_HD void blend_rows_hi (uint32_t a, uint32_t b, uint32_t &x0, uint32_t &x1
 #define GSTAMD_LAYOUT_AYUV GSTAMD_LAYOUT (0, 0, 4)      /* 64: not a byte order of R, G, B - the pixel leaves as A Y U V (FastParams::ayuv) */
 // the A Y U V word from operands that are XOR 0x80: byte 0 of ys = Y ^ 0x80, bytes 0 and 2 of c = U ^ 0x80, V ^ 0x80
 #define GSTAMD_AYUV_X80(ys, c) ((bperm ((c), (ys), 0x0604000cu) ^ 0x80808000u) | 0xffu)
+// ... through the convert stage of a plan that has one (wave-uniform)
+#define GSTAMD_AYUV_OUT(fp, px) ((fp).ayuv == 2 ? apply_matrix ((fp).m8, (px)) : (px))
 
 template <int L>
 GSTAMD_HD void layout_init (uint32_t (&q)[4][2])

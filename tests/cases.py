@@ -1938,7 +1938,7 @@ VIDEO_CASES += [
     ("bay_nv12_yuy2", "NV12", 256, 128, "YUY2", 128, 64, LIN, None, None, "random"),
     ("bay_nv12_i420_crop_rect_border", "NV12", 256, 128, "I420", 96, 48, dict(LIN, src_x=64, src_y=32, src_width=128, src_height=64, dest_x=16, dest_y=8, dest_width=64, dest_height=32, border_argb=0xff204060), None, None, "random"),
     ("bay_nv12_i420_dither", "NV12", 256, 128, "I420", 128, 64, dict(LIN, dither_method="bayer", dither_quantization=4), None, None, "random"),
-    ("bay_not_nv12_i420_matrix", "NV12", 1280, 720, "I420", 640, 360, LIN, None, None, "random"),          # (HD -> SD: a colour matrix in between)
+    ("bay_nv12_i420_hd_sd_matrix", "NV12", 1280, 720, "I420", 640, 360, LIN, None, None, "random"),          # (HD -> SD: a colour matrix behind the scaler - FastParams::m8)
 ]
 
 # ... and k_deep_scale_pack16: into a 10 / 12 / 16-bit planar or semi-planar destination (the chain stays on 16-bit values: u16 downsamplers, ordered dither, pack)
@@ -2002,4 +2002,13 @@ VIDEO_CASES += [
     ("dspm_p010_p010_bt2020_bt709", "P010_10LE", 504, 1160, "P010_10LE", 252, 580, BIL2, "bt2020>bt709", None, "random"),
     ("dspm_p010_i42010_bt601_bt2020", "P010_10LE", 128, 64, "I420_10LE", 64, 32, BIL2, "bt601>bt2020", None, "random"),
     ("dspm_p016_y42b_bt2020_bt709", "P016_LE", 128, 64, "Y42B", 64, 32, BIL2, "bt2020>bt709", None, "random"),
+]
+
+# ... with the 8-bit convert stage of two YUV colorimetries behind the scaler (FastParams::m8: what caps without a colorimetry field mean across 2160 / 1080 / 576 lines)
+VIDEO_CASES += [
+    ("baym_nv12_i420_bt2020_bt709_half", "NV12", 512, 256, "I420", 256, 128, LIN, "bt2020>bt709", None, "random"),
+    ("baym_i420_nv12_hd_sd_default", "I420", 1280, 720, "NV12", 640, 360, LIN, None, None, "random"),
+    ("baym_nv12_i420_1080p_720p_rows_bt2020", "NV12", 1920, 1080, "I420", 1280, 720, LIN, "bt2020>bt709", None, "random"),
+    ("baym_nv21_y42b_bt601_bt709", "NV21", 160, 96, "Y42B", 96, 64, LIN, "bt601>bt709", "jpeg", "random"),
+    ("baym_nv12_ayuv_bt709_bt601", "NV12", 256, 128, "AYUV", 128, 64, LIN, "bt709>bt601", None, "random"),
 ]

@@ -1973,7 +1973,8 @@ static int emu_convert_packed (const VideoPlan &p, const GstAmdVideoInfo *in, co
       /* k_bilinear420 (video_bilinear_fast.h); vec_ok == 300 selects the generic tile kernel below instead */
       BilParams bp;
       bp.fp = pf.fp;
-      bp.fp.ayuv = bil_ayuv ? 1 : 0;
+      bp.fp.ayuv = bil_ayuv ? (p.matrix.kind == MATRIX_NONE ? 1 : 2) : 0;
+      bp.fp.m8 = p.matrix;
       if (bil_ayuv)
         g_bil_ayuv_runs++;
       bp.out_w = p.out_info.width;

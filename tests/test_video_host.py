@@ -696,10 +696,10 @@ def test_packed_chroma_identities_of_deep_scale_pack():
     assert (f31 == (6 * a + 2 * b + 4) >> 3).all()
 
 
-@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if c[0].startswith("bay_") and c[2] * c[3] <= 1280 * 720])
+@pytest.mark.parametrize("name", [c[0] for c in cases.VIDEO_CASES if (c[0].startswith("bay_") or c[0].startswith("baym_")) and c[2] * c[3] <= 1280 * 720])
 def test_bilinear420_ayuv_layout_is_the_path_taken(native_lib, emu_lib, name, monkeypatch):
     """the bay_* cases (a scaled 8-bit 4:2:0 -> YUV conversion without a colour stage) go through the bilinear 4:2:0 kernels with the layout that
-    stores A Y U V - bay_not_* (a matrix between the colorimetries) does not - and through the generic scalers with GSTAMD_NO_BILINEAR_AYUV, with
+    stores A Y U V, the baym_* ones with the 8-bit convert stage behind it - bay_not_* (three-plane sources of other widths) does not - and through the generic scalers with GSTAMD_NO_BILINEAR_AYUV, with
     the reference's bytes either way"""
     _, ifmt, w, h, ofmt, ow, oh, cfg, col, site, pattern = [c for c in cases.VIDEO_CASES if c[0] == name][0]
     src = cases.frame_bytes(V.video_info(ifmt, w, h).size, pattern, cases.case_seed(name), w)
